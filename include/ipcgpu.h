@@ -1,0 +1,163 @@
+/* ipcgpu.h -- C ABI of the MI355X-native IPC Newton hot path (libipcgpu.so).
+ *
+ * The reference has no FFI: its hot path sits behind three C++ class interfaces
+ * (SURVEY.md 8b).  A maintainer drops this library in by adding three thin adapter
+ * subclasses (shown in INTEGRATION.md) that forward to the entry points below:
+ *
+ *   LinSysSolver<VectorXi,VectorXd>   src/LinSysSolver/LinSysSolver.hpp:31-467
+ *   Energy<3> / NeoHookeanEnergy<3>   src/Energy/Energy.hpp:27-138
+ *   Optimizer<3>                      src/TimeStepper/Optimizer.hpp:28-283
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every function returns an int status:
+ *       IPCGPU_OK 0, IPCGPU_NOT_PD 1 (factorize: matrix not positive definite,
+ *       the reference's `factorize() == false`, CHOLMODSolver.cpp:130-137),
+ *       negative = error (message via ipcgpu_last_error()).  No exceptions cross
+ *       the boundary.  One opaque context per Optimizer; a context is not thread-safe.
+ *   - layouts are the reference's: V is column-major nV x 3 (Eigen::MatrixXd,
+ *     Mesh.hpp:61), F is column-major nT x 4 int32 (Mesh.hpp:64), nodal vectors
+ *     are xyzxyz... of length 3 nV (Optimizer.hpp:91-92), the matrix is the
+ *     symmetric-UPPER CSR with 3x3 node blocks of LinSysSolver.hpp:46-150, 0-based.
+ *   - host pointers unless the name ends in _dev.  Device state (positions, CSR
+ *     values, factor) stays resident in HBM between calls.
+ *   - all arithmetic is fp64, all indices int32, like the reference.
+ */
+#ifndef IPCGPU_H
+#define IPCGPU_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IPCGPU_OK 0
+#define IPCGPU_NOT_PD 1
+#define IPCGPU_ERR_ARG -1
+#define IPCGPU_ERR_HIP -2
+#define IPCGPU_ERR_STATE -3
+#define IPCGPU_ERR_UNSUPPORTED -4
+
+typedef struct ipcgpu_ctx ipcgpu_ctx;
+
+/* DirichletBCType, src/Mesh.hpp:41-45 */
+enum { IPCGPU_NOT_DBC = 0, IPCGPU_DBC_ZERO = 1, IPCGPU_DBC_NONZERO = 2 };
+
+/* linear-solver back ends selectable per context (the reference selects CHOLMOD / EIGEN /
+ * AMGCL through LinSysSolver::create, LinSysSolver.cpp:10-28) */
+enum { IPCGPU_SOLVER_MULTIFRONTAL = 0, IPCGPU_SOLVER_ROCSOLVER_CSRRF = 1 };
+
+const char* ipcgpu_last_error(void);
+int ipcgpu_version(void);
+
+/* ---- context ------------------------------------------------------------------------ */
+int ipcgpu_ctx_create(int device_id, ipcgpu_ctx** out);
+int ipcgpu_ctx_destroy(ipcgpu_ctx*);
+int ipcgpu_ctx_set_solver(ipcgpu_ctx*, int solver_type);
+/* element sharding for multi-GPU runs: this context assembles only the tets
+ * [tet_begin, tet_end) of the mesh order given to set_mesh; partial results are summed by the
+ * caller's all-reduce (bench.py / torch.distributed over RCCL).  Default: all tets. */
+int ipcgpu_ctx_set_shard(ipcgpu_ctx*, int rank, int world_size);
+
+/* ---- mesh = the Mesh<3> data contract ----------------------------------------------- */
+/* Replaces Mesh::computeFeatures + computeMassMatrix + setLameParam
+ * (src/Mesh.cpp:414-527, 246-266, 399-401, 660-671): restTriInv, triArea, lumped mass,
+ * vNeighbor and the Lame parameters are derived here from the rest shape. */
+int ipcgpu_set_mesh(ipcgpu_ctx*, int nV, int nT, const double* V_rest_colmajor,
+    const int* F_colmajor, double youngs_modulus, double poisson_ratio, double density);
+/* vertexDBCType (Mesh.hpp:131-144) */
+int ipcgpu_set_dbc(ipcgpu_ctx*, int n, const int* vert_ids, int dbc_type);
+int ipcgpu_clear_dbc(ipcgpu_ctx*);
+/* Mesh::V (current positions) */
+int ipcgpu_set_positions(ipcgpu_ctx*, const double* V_colmajor);
+int ipcgpu_get_positions(ipcgpu_ctx*, double* V_colmajor);
+/* Optimizer::xTilta (Optimizer.cpp:1236-1257) */
+int ipcgpu_set_xtilde(ipcgpu_ctx*, const double* xTilta_colmajor);
+/* read back derived per-element / per-node data (any pointer may be NULL) */
+int ipcgpu_get_features(ipcgpu_ctx*, double* restTriInv_9nT, double* triArea_nT, double* mass_nV,
+    double* mu_nT, double* lambda_nT);
+/* Mesh::checkInversion (Mesh.cpp:715-764): *ok = 1 when no element has det < 0 */
+int ipcgpu_check_inversion(ipcgpu_ctx*, int* ok);
+
+/* ---- Energy<3> plugin (NeoHookeanEnergy) -------------------------------------------- */
+/* Energy::computeEnergyVal (Energy.hpp:42, Energy.cpp:195-242): E = coef * sum_t vol_t psi(F_t) */
+int ipcgpu_elastic_energy(ipcgpu_ctx*, double coef, double* energy);
+/* Energy::getEnergyValPerElemBySVD (Energy.hpp:66) */
+int ipcgpu_elastic_energy_per_elem(ipcgpu_ctx*, double* perElem_nT);
+/* Energy::computeGradient (Energy.hpp:47, Energy.cpp:245-289) */
+int ipcgpu_elastic_gradient(ipcgpu_ctx*, double coef, int projectDBC, double* grad_3nV);
+/* Energy::computeHessian (Energy.hpp:53, Energy.cpp:292-331) into the context's CSR values:
+ * a += elastic Hessian (projectSPD, vInd sign convention of Energy.cpp:402-407) */
+int ipcgpu_elastic_hessian_add(ipcgpu_ctx*, double coef, int projectDBC);
+/* Energy::filterStepSize (Energy.hpp:129, Energy.cpp:565-581), slackness 0.2, tol 1e-6 */
+int ipcgpu_filter_step_size(ipcgpu_ctx*, const double* searchDir_3nV, double* stepSize_inout);
+
+/* ---- LinSysSolver plugin ------------------------------------------------------------ */
+/* LinSysSolver::set_pattern(vNeighbor, fixedVert) (LinSysSolver.hpp:46-150).  extra_pairs adds
+ * contact connectivity on top of the mesh's vNeighbor (augmentConnectivity,
+ * SelfCollisionHandler.cpp:330-415); pass n_extra = 0 for the mesh pattern. */
+int ipcgpu_linsys_set_pattern(ipcgpu_ctx*, int n_extra, const int* extra_pairs_2n);
+/* LinSysSolver::set_pattern on a caller-provided 0-based symmetric-upper CSR (get_ia/get_ja) */
+int ipcgpu_linsys_set_pattern_csr(ipcgpu_ctx*, int n_rows, const int* ia, const int* ja);
+int ipcgpu_linsys_get_dims(ipcgpu_ctx*, int* n_rows, int* nnz); /* getNumRows / getNumNonzeros */
+int ipcgpu_linsys_get_pattern(ipcgpu_ctx*, int* ia, int* ja); /* get_ia / get_ja */
+int ipcgpu_linsys_set_zero(ipcgpu_ctx*); /* setZero, :348 */
+int ipcgpu_linsys_get_values(ipcgpu_ctx*, double* a); /* get_a, :465 */
+int ipcgpu_linsys_set_values(ipcgpu_ctx*, const double* a);
+int ipcgpu_linsys_add_coeff(ipcgpu_ctx*, int row, int col, double v); /* addCoeff :402 (row>col ignored) */
+int ipcgpu_linsys_set_coeff(ipcgpu_ctx*, int row, int col, double v); /* setCoeff :331 */
+int ipcgpu_linsys_multiply(ipcgpu_ctx*, const double* x, double* Ax); /* multiply :238 */
+int ipcgpu_linsys_analyze_pattern(ipcgpu_ctx*); /* analyze_pattern, CHOLMODSolver.cpp:123-128 */
+int ipcgpu_linsys_factorize(ipcgpu_ctx*); /* factorize, :130-137; returns IPCGPU_NOT_PD */
+int ipcgpu_linsys_solve(ipcgpu_ctx*, const double* rhs, double* result); /* solve, :139-154 */
+int ipcgpu_linsys_precondition_diag(ipcgpu_ctx*, const double* in, double* out); /* :411-420 */
+/* factor statistics: nnz(L), factorisation flops, number of supernodes / levels */
+int ipcgpu_linsys_stats(ipcgpu_ctx*, double* stats4);
+
+/* ---- Optimizer<3> building blocks --------------------------------------------------- */
+/* setZero + elastic Hessian + mass / DBC diagonal: computePrecondMtr without contact
+ * (Optimizer.cpp:3549-3668).  Fused with the gradient when grad_3nV != NULL
+ * (computeGradient, Optimizer.cpp:3409-3450: elasticity + m (x - xTilta)). */
+int ipcgpu_assemble_newton(ipcgpu_ctx*, double dtSq, int projectDBC, double* grad_3nV /*nullable*/);
+/* computeEnergyVal (Optimizer.cpp:3199-3239): dtSq * elastic + 1/2 m |x - xTilta|^2 */
+int ipcgpu_incremental_potential(ipcgpu_ctx*, double dtSq, double* energy);
+/* computeGradient alone */
+int ipcgpu_gradient(ipcgpu_ctx*, double dtSq, int projectDBC, double* grad_3nV);
+
+/* ---- Optimizer<3>: the time stepper itself, state resident on the GPU --------------- */
+/* Optimizer ctor + setTime (Optimizer.cpp:97-115, 418-430).  Uses the mesh of this context. */
+int ipcgpu_opt_init(ipcgpu_ctx*, double dt, int withGravity);
+int ipcgpu_opt_set_rel_tol(ipcgpu_ctx*, double relTol); /* setRelGL2Tol, Optimizer.cpp:390-396 */
+/* `script twist` (AnimScripter.cpp:555-572, 1674-1684): two handle sets rotating about x */
+int ipcgpu_opt_set_twist(ipcgpu_ctx*, int nLeft, const int* left, int nRight, const int* right, double angVel);
+int ipcgpu_opt_precompute(ipcgpu_ctx*); /* precompute, Optimizer.cpp:457-507 */
+int ipcgpu_opt_begin_timestep(ipcgpu_ctx*); /* solve(): stepAnimScript + fullyImplicit_IP head */
+/* one pass of the solveSub_IP loop (Optimizer.cpp:1829-2204) == one "Newton iteration" of the
+ * metric; *converged = 1 when the convergence test fired before any work was done */
+int ipcgpu_opt_newton_iter(ipcgpu_ctx*, int* converged);
+int ipcgpu_opt_end_timestep(ipcgpu_ctx*); /* BE velocity + xTilta update, Optimizer.cpp:570-580 */
+int ipcgpu_opt_solve_timestep(ipcgpu_ctx*, int maxIter, int* nIter); /* Optimizer::solve(1) */
+/* state readers (any pointer may be NULL); scalars8 = {lastEnergyVal, lastStepSize, targetGRes,
+ * innerIterAmt, timestep, alphaFeasible, 0, 0} */
+int ipcgpu_opt_get_state(ipcgpu_ctx*, double* V_colmajor, double* searchDir_3nV, double* gradient_3nV, double* scalars8);
+/* timer_step buckets in seconds (src/main.cpp:1326-1340): 0 matrixComputation .. 14 computeConstraintSets */
+int ipcgpu_opt_get_timers(ipcgpu_ctx*, double* t16);
+/* multi-GPU: the caller-supplied reduction hook used by the optimizer for sharded assembly.
+ * fn(user, buf_dev, count, op) must all-reduce `count` doubles in device memory in place
+ * (op 0 = sum, 1 = min).  bench.py binds it to torch.distributed (RCCL). */
+typedef int (*ipcgpu_allreduce_fn)(void* user, void* buf_dev, long long count, int op);
+int ipcgpu_opt_set_allreduce(ipcgpu_ctx*, ipcgpu_allreduce_fn fn, void* user);
+
+/* ---- measurement -------------------------------------------------------------------- */
+/* Launch the fused element-assembly kernel `reps` times on the context stream and return the
+ * average duration per launch measured with HIP events on that stream, plus the algorithmic
+ * bytes of one launch (112 nT + 84 nV + 8 nnz). */
+int ipcgpu_bench_assembly(ipcgpu_ctx*, double dtSq, int reps, double* avg_ms, double* algorithmic_bytes);
+/* same for one numeric factorisation + solve */
+int ipcgpu_bench_factor_solve(ipcgpu_ctx*, int reps, double* factor_ms, double* solve_ms);
+/* device streaming copy bandwidth (GB/s) measured here, the "STREAM" figure quoted beside the
+ * nominal 8 TB/s */
+int ipcgpu_bench_stream(ipcgpu_ctx*, long long bytes, int reps, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

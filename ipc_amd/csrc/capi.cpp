@@ -1,0 +1,703 @@
+// extern "C" boundary of libipcgpu.so (include/ipcgpu.h).  No exception leaves this file.
+#include "../../include/ipcgpu.h"
+#include "hip_ipc.h"
+#include <cstring>
+#include <mutex>
+
+using namespace ipcgpu;
+
+namespace {
+thread_local std::string g_err;
+
+template <class Fn>
+int guarded(Fn&& fn)
+{
+    try {
+        return fn();
+    }
+    catch (const ArgError& e) {
+        g_err = e.what();
+        return IPCGPU_ERR_ARG;
+    }
+    catch (const StateError& e) {
+        g_err = e.what();
+        return IPCGPU_ERR_STATE;
+    }
+    catch (const HipError& e) {
+        g_err = e.what();
+        return IPCGPU_ERR_HIP;
+    }
+    catch (const std::exception& e) {
+        g_err = e.what();
+        return IPCGPU_ERR_HIP;
+    }
+    catch (...) {
+        g_err = "unknown error";
+        return IPCGPU_ERR_HIP;
+    }
+}
+
+void need(bool cond, const char* what)
+{
+    if (!cond) throw StateError(what);
+}
+void needArg(bool cond, const char* what)
+{
+    if (!cond) throw ArgError(what);
+}
+HipMesh& M(ipcgpu_ctx* c)
+{
+    needArg(c != nullptr, "null context");
+    need(c->mesh && c->mesh->nV > 0, "no mesh: call ipcgpu_set_mesh first");
+    return *c->mesh;
+}
+HipLinSysSolver& L(ipcgpu_ctx* c)
+{
+    needArg(c != nullptr, "null context");
+    return *c->lin;
+}
+HipOptimizer& O(ipcgpu_ctx* c)
+{
+    M(c);
+    return *c->opt;
+}
+void bind(ipcgpu_ctx* c) { HIP_CHECK(hipSetDevice(c->device)); }
+
+// column-major nV x 3 (host) <-> xyz interleaved (device)
+void uploadColMajor(ipcgpu_ctx* c, const double* Vcm, DevBuf<double>& dst)
+{
+    const int nV = c->mesh->nV;
+    std::vector<double> aos(3 * (size_t)nV);
+    for (int v = 0; v < nV; ++v)
+        for (int k = 0; k < 3; ++k) aos[3 * (size_t)v + k] = Vcm[v + (size_t)nV * k];
+    dst.upload(aos, c->stream);
+    HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+void downloadColMajor(ipcgpu_ctx* c, const DevBuf<double>& src, double* Vcm)
+{
+    const int nV = c->mesh->nV;
+    std::vector<double> aos(3 * (size_t)nV);
+    src.download(aos.data(), aos.size(), c->stream);
+    for (int v = 0; v < nV; ++v)
+        for (int k = 0; k < 3; ++k) Vcm[v + (size_t)nV * k] = aos[3 * (size_t)v + k];
+}
+} // namespace
+
+extern "C" {
+
+const char* ipcgpu_last_error(void) { return g_err.c_str(); }
+int ipcgpu_version(void) { return 100; }
+
+int ipcgpu_ctx_create(int device_id, ipcgpu_ctx** out)
+{
+    return guarded([&] {
+        needArg(out != nullptr, "null out pointer");
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0) throw HipError("no HIP device visible (this library has no CPU fallback)");
+        needArg(device_id >= 0 && device_id < count, "device id out of range");
+        HIP_CHECK(hipSetDevice(device_id));
+        auto* c = new ipcgpu_ctx;
+        c->device = device_id;
+        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->mesh.reset(new HipMesh);
+        c->lin.reset(new HipLinSysSolver(c->stream));
+        c->opt.reset(new HipOptimizer(*c->mesh, *c->lin, c->stream));
+        *out = c;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_ctx_destroy(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        if (!c) return IPCGPU_OK;
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        c->opt.reset();
+        c->lin.reset();
+        c->mesh.reset();
+        (void)hipStreamDestroy(c->stream);
+        delete c;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_ctx_set_solver(ipcgpu_ctx* c, int type)
+{
+    return guarded([&] {
+        needArg(c && (type == IPCGPU_SOLVER_MULTIFRONTAL || type == IPCGPU_SOLVER_ROCSOLVER_CSRRF), "unknown solver type"); // LinSysSolver.cpp:24-26
+        c->lin->solverType = type;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_ctx_set_shard(ipcgpu_ctx* c, int rank, int world)
+{
+    return guarded([&] {
+        needArg(c && world >= 1 && rank >= 0 && rank < world, "bad shard");
+        c->rank = rank;
+        c->worldSize = world;
+        c->opt->rank = rank;
+        c->opt->worldSize = world;
+        if (c->mesh->nT) {
+            c->opt->tetBegin = (int)((long long)c->mesh->nT * rank / world);
+            c->opt->tetEnd = (int)((long long)c->mesh->nT * (rank + 1) / world);
+        }
+        return IPCGPU_OK;
+    });
+}
+
+int ipcgpu_set_mesh(ipcgpu_ctx* c, int nV, int nT, const double* Vr, const int* F, double YM, double PR, double rho)
+{
+    return guarded([&] {
+        needArg(c && Vr && (F || nT == 0), "null argument");
+        bind(c);
+        c->mesh->computeFeatures(nV, nT, Vr, F, YM, PR, rho, c->stream);
+        c->opt->tetBegin = (int)((long long)nT * c->rank / c->worldSize);
+        c->opt->tetEnd = (int)((long long)nT * (c->rank + 1) / c->worldSize);
+        c->opt->initialised = false;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_set_dbc(ipcgpu_ctx* c, int n, const int* ids, int type)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        needArg(type >= 0 && type <= 2, "bad DirichletBCType");
+        for (int i = 0; i < n; ++i) {
+            needArg(ids[i] >= 0 && ids[i] < m.nV, "vertex id out of range");
+            m.dbcType[ids[i]] = type;
+        }
+        m.uploadDBC(c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_clear_dbc(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        std::fill(m.dbcType.begin(), m.dbcType.end(), 0);
+        m.uploadDBC(c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_set_positions(ipcgpu_ctx* c, const double* V)
+{
+    return guarded([&] {
+        M(c);
+        bind(c);
+        needArg(V != nullptr, "null V");
+        uploadColMajor(c, V, c->mesh->d_x);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_get_positions(ipcgpu_ctx* c, double* V)
+{
+    return guarded([&] {
+        M(c);
+        bind(c);
+        needArg(V != nullptr, "null V");
+        downloadColMajor(c, c->mesh->d_x, V);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_set_xtilde(ipcgpu_ctx* c, const double* V)
+{
+    return guarded([&] {
+        M(c);
+        bind(c);
+        needArg(V != nullptr, "null xTilta");
+        uploadColMajor(c, V, c->mesh->d_xTilde);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_get_features(ipcgpu_ctx* c, double* A, double* vol, double* mass, double* mu, double* lam)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        if (A)
+            for (int t = 0; t < m.nT; ++t)
+                for (int k = 0; k < 9; ++k) A[9 * (size_t)t + k] = m.restTriInv[(size_t)k * m.nT + t];
+        if (vol) std::memcpy(vol, m.triArea.data(), sizeof(double) * m.nT);
+        if (mass) std::memcpy(mass, m.mass.data(), sizeof(double) * m.nV);
+        if (mu) std::memcpy(mu, m.mu.data(), sizeof(double) * m.nT);
+        if (lam) std::memcpy(lam, m.lam.data(), sizeof(double) * m.nT);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_check_inversion(ipcgpu_ctx* c, int* ok)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        *ok = o.checkInversion() ? 1 : 0;
+        return IPCGPU_OK;
+    });
+}
+
+// ---- Energy ------------------------------------------------------------------------------------------
+int ipcgpu_elastic_energy(ipcgpu_ctx* c, double coef, double* E)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        launch_energy(o.view(), coef, false, o.rank == 0, o.d_partial.p, (int)o.d_partial.n, o.d_scalar.p, c->stream);
+        o.reduceSum(o.d_scalar.p, 1);
+        *E = o.readScalar(o.d_scalar.p);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_elastic_energy_per_elem(ipcgpu_ctx* c, double* out)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        DevBuf<double> tmp;
+        tmp.alloc(c->mesh->nT);
+        launch_energy_per_elem(o.view(), tmp.p, c->stream);
+        tmp.download(out, c->mesh->nT, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_elastic_gradient(ipcgpu_ctx* c, double coef, int projectDBC, double* g)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        o.d_gradient.zero(c->stream);
+        launch_assemble(o.view(), coef, projectDBC, o.d_gradient.p, nullptr, c->stream);
+        o.reduceSum(o.d_gradient.p, 3LL * c->mesh->nV);
+        o.d_gradient.download(g, 3 * (size_t)c->mesh->nV, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_elastic_hessian_add(ipcgpu_ctx* c, double coef, int projectDBC)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        need(!c->lin->rowBase.empty(), "call ipcgpu_linsys_set_pattern first");
+        launch_assemble(o.view(), coef, projectDBC, nullptr, c->lin->d_a.p, c->stream);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_filter_step_size(ipcgpu_ctx* c, const double* p, double* step)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        DevBuf<double> dp;
+        dp.upload(p, 3 * (size_t)c->mesh->nV, c->stream);
+        *step = o.filterStepSize(dp.p, *step);
+        return IPCGPU_OK;
+    });
+}
+
+// ---- LinSysSolver ------------------------------------------------------------------------------------
+int ipcgpu_linsys_set_pattern(ipcgpu_ctx* c, int nExtra, const int* pairs)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        c->lin->set_pattern(m, nExtra, pairs);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_set_pattern_csr(ipcgpu_ctx* c, int n, const int* ia, const int* ja)
+{
+    return guarded([&] {
+        needArg(c && ia && ja, "null argument");
+        bind(c);
+        c->lin->set_pattern_csr(n, ia, ja);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_get_dims(ipcgpu_ctx* c, int* n, int* nnz)
+{
+    return guarded([&] {
+        if (n) *n = L(c).getNumRows();
+        if (nnz) *nnz = L(c).getNumNonzeros();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_get_pattern(ipcgpu_ctx* c, int* ia, int* ja)
+{
+    return guarded([&] {
+        HipLinSysSolver& l = L(c);
+        if (ia) std::memcpy(ia, l.ia.data(), sizeof(int) * l.ia.size());
+        if (ja) std::memcpy(ja, l.ja.data(), sizeof(int) * l.ja.size());
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_set_zero(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        bind(c);
+        L(c).setZero();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_get_values(ipcgpu_ctx* c, double* a)
+{
+    return guarded([&] {
+        bind(c);
+        L(c).d_a.download(a, L(c).ja.size(), c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_set_values(ipcgpu_ctx* c, const double* a)
+{
+    return guarded([&] {
+        bind(c);
+        HipLinSysSolver& l = L(c);
+        need(l.numRows > 0, "no pattern");
+        HIP_CHECK(hipMemcpyAsync(l.d_a.p, a, sizeof(double) * l.ja.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return IPCGPU_OK;
+    });
+}
+static int coeff(ipcgpu_ctx* c, int row, int col, double v, bool add)
+{
+    return guarded([&] {
+        bind(c);
+        HipLinSysSolver& l = L(c);
+        if (row > col) return IPCGPU_OK; // LinSysSolver.hpp:331-339, 402-410: lower-triangle writes are ignored
+        const int k = l.findEntry(row, col);
+        needArg(k >= 0, "entry not in the sparsity pattern");
+        double cur = 0.0;
+        if (add) {
+            HIP_CHECK(hipMemcpyAsync(&cur, l.d_a.p + k, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipStreamSynchronize(c->stream));
+        }
+        cur = add ? cur + v : v;
+        HIP_CHECK(hipMemcpyAsync(l.d_a.p + k, &cur, sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_add_coeff(ipcgpu_ctx* c, int row, int col, double v) { return coeff(c, row, col, v, true); }
+int ipcgpu_linsys_set_coeff(ipcgpu_ctx* c, int row, int col, double v) { return coeff(c, row, col, v, false); }
+int ipcgpu_linsys_multiply(ipcgpu_ctx* c, const double* x, double* y)
+{
+    return guarded([&] {
+        bind(c);
+        HipLinSysSolver& l = L(c);
+        need(l.numRows > 0, "no pattern");
+        DevBuf<double> dx, dy;
+        dx.upload(x, l.numRows, c->stream);
+        dy.alloc(l.numRows);
+        l.multiply(dx.p, dy.p);
+        dy.download(y, l.numRows, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_analyze_pattern(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        bind(c);
+        L(c).analyze_pattern(c->mesh->nV ? c->mesh.get() : nullptr);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_factorize(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        bind(c);
+        return L(c).factorize() ? IPCGPU_OK : IPCGPU_NOT_PD;
+    });
+}
+int ipcgpu_linsys_solve(ipcgpu_ctx* c, const double* rhs, double* x)
+{
+    return guarded([&] {
+        bind(c);
+        HipLinSysSolver& l = L(c);
+        DevBuf<double> db, dx;
+        db.upload(rhs, l.numRows, c->stream);
+        dx.alloc(l.numRows);
+        l.solve(db.p, dx.p);
+        dx.download(x, l.numRows, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_precondition_diag(ipcgpu_ctx* c, const double* in, double* out)
+{
+    return guarded([&] {
+        bind(c);
+        HipLinSysSolver& l = L(c);
+        DevBuf<double> di, dout;
+        di.upload(in, l.numRows, c->stream);
+        dout.alloc(l.numRows);
+        l.precondition_diag(di.p, dout.p);
+        dout.download(out, l.numRows, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_stats(ipcgpu_ctx* c, double* st)
+{
+    return guarded([&] {
+        const MfSymbolic& s = L(c).symbolic();
+        st[0] = (double)s.nnzL;
+        st[1] = s.flops;
+        st[2] = s.ns;
+        st[3] = (double)s.levelPtr.size() - 1;
+        return IPCGPU_OK;
+    });
+}
+
+// ---- Optimizer building blocks ----------------------------------------------------------------------
+int ipcgpu_assemble_newton(ipcgpu_ctx* c, double dtSq, int projectDBC, double* grad)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        const double keep = o.dtSq;
+        o.dtSq = dtSq;
+        o.computePrecondMtr(projectDBC != 0, grad != nullptr);
+        o.dtSq = keep;
+        if (grad) o.d_gradient.download(grad, 3 * (size_t)c->mesh->nV, c->stream);
+        else HIP_CHECK(hipStreamSynchronize(c->stream));
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_incremental_potential(ipcgpu_ctx* c, double dtSq, double* E)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        const double keep = o.dtSq;
+        o.dtSq = dtSq;
+        *E = o.computeEnergyVal();
+        o.dtSq = keep;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_gradient(ipcgpu_ctx* c, double dtSq, int projectDBC, double* grad)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        const double keep = o.dtSq;
+        o.dtSq = dtSq;
+        o.computeGradient(projectDBC != 0);
+        o.dtSq = keep;
+        o.d_gradient.download(grad, 3 * (size_t)c->mesh->nV, c->stream);
+        return IPCGPU_OK;
+    });
+}
+
+// ---- Optimizer --------------------------------------------------------------------------------------
+int ipcgpu_opt_init(ipcgpu_ctx* c, double dt, int withGravity)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        needArg(dt > 0, "dt must be positive");
+        o.rank = c->rank;
+        o.worldSize = c->worldSize;
+        o.init(dt, withGravity != 0);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_rel_tol(ipcgpu_ctx* c, double tol)
+{
+    return guarded([&] {
+        needArg(tol > 0, "relTol must be positive"); // Optimizer.cpp:392
+        O(c).setRelGL2Tol(tol);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_twist(ipcgpu_ctx* c, int nL, const int* l, int nR, const int* r, double angVel)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        for (int i = 0; i < nL; ++i) needArg(l[i] >= 0 && l[i] < c->mesh->nV, "handle id out of range");
+        for (int i = 0; i < nR; ++i) needArg(r[i] >= 0 && r[i] < c->mesh->nV, "handle id out of range");
+        o.setTwist(nL, l, nR, r, angVel);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_precompute(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        bind(c);
+        O(c).precompute();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_begin_timestep(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        bind(c);
+        O(c).beginTimestep();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_newton_iter(ipcgpu_ctx* c, int* converged)
+{
+    return guarded([&] {
+        bind(c);
+        const bool cv = O(c).newtonIter();
+        if (converged) *converged = cv ? 1 : 0;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_end_timestep(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        bind(c);
+        O(c).endTimestep();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_solve_timestep(ipcgpu_ctx* c, int maxIter, int* nIter)
+{
+    return guarded([&] {
+        bind(c);
+        const int n = O(c).solveTimestep(maxIter);
+        if (nIter) *nIter = n;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_get_state(ipcgpu_ctx* c, double* V, double* p, double* g, double* sc)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        const size_t n3 = 3 * (size_t)c->mesh->nV;
+        if (V) downloadColMajor(c, c->mesh->d_x, V);
+        if (p) o.d_searchDir.download(p, n3, c->stream);
+        if (g) o.d_gradient.download(g, n3, c->stream);
+        if (sc) {
+            sc[0] = o.lastEnergyVal;
+            sc[1] = o.lastStepSize;
+            sc[2] = o.targetGRes;
+            sc[3] = o.innerIterAmt;
+            sc[4] = o.globalIterNum;
+            sc[5] = o.lastAlphaFeasible;
+            sc[6] = sc[7] = 0.0;
+        }
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_get_timers(ipcgpu_ctx* c, double* t)
+{
+    return guarded([&] {
+        std::memcpy(t, O(c).timers, sizeof(double) * 16);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_allreduce(ipcgpu_ctx* c, ipcgpu_allreduce_fn fn, void* user)
+{
+    return guarded([&] {
+        needArg(c != nullptr, "null context");
+        c->opt->allreduce = fn;
+        c->opt->allreduceUser = user;
+        return IPCGPU_OK;
+    });
+}
+
+// ---- measurement ------------------------------------------------------------------------------------
+int ipcgpu_bench_assembly(ipcgpu_ctx* c, double dtSq, int reps, double* avg_ms, double* bytes)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised && !c->lin->rowBase.empty(), "needs opt_init + a pattern");
+        needArg(reps > 0, "reps must be positive");
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        const ElemView v = o.view();
+        double total = 0.0;
+        for (int r = 0; r < reps; ++r) {
+            // the scatter target must be re-initialised between launches; only the element kernel is timed
+            c->lin->setZero();
+            launch_node_init(v, 1, true, c->lin->d_a.p, o.d_gradient.p, c->stream);
+            HIP_CHECK(hipEventRecord(e0, c->stream));
+            launch_assemble(v, dtSq, 1, o.d_gradient.p, c->lin->d_a.p, c->stream);
+            HIP_CHECK(hipEventRecord(e1, c->stream));
+            HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            total += ms;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *avg_ms = total / reps;
+        const double nT = o.tetEnd - o.tetBegin;
+        // B_asm = 112 nT + 84 nV + 8 nnz
+        *bytes = 112.0 * nT + 84.0 * c->mesh->nV + 8.0 * (double)c->lin->ja.size();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_bench_factor_solve(ipcgpu_ctx* c, int reps, double* fms, double* sms)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(c->lin->analyzed(), "needs analyze_pattern");
+        hipEvent_t e0, e1, e2;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipEventCreate(&e2));
+        double tf = 0, ts = 0;
+        for (int r = 0; r < reps; ++r) {
+            HIP_CHECK(hipEventRecord(e0, c->stream));
+            c->lin->factorize();
+            HIP_CHECK(hipEventRecord(e1, c->stream));
+            c->lin->solve(o.d_gradient.p, o.d_minusG.p);
+            HIP_CHECK(hipEventRecord(e2, c->stream));
+            HIP_CHECK(hipEventSynchronize(e2));
+            float a = 0, b = 0;
+            HIP_CHECK(hipEventElapsedTime(&a, e0, e1));
+            HIP_CHECK(hipEventElapsedTime(&b, e1, e2));
+            tf += a;
+            ts += b;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipEventDestroy(e2);
+        *fms = tf / reps;
+        *sms = ts / reps;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_bench_stream(ipcgpu_ctx* c, long long bytes, int reps, double* gbps)
+{
+    return guarded([&] {
+        needArg(c && bytes > 0 && reps > 0, "bad argument");
+        bind(c);
+        DevBuf<double> a, b;
+        a.alloc((size_t)bytes / 8);
+        b.alloc((size_t)bytes / 8);
+        a.zero(c->stream);
+        hipEvent_t e0, e1;
+        HIP_CHECK(hipEventCreate(&e0));
+        HIP_CHECK(hipEventCreate(&e1));
+        HIP_CHECK(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipEventRecord(e0, c->stream));
+        for (int r = 0; r < reps; ++r) HIP_CHECK(hipMemcpyAsync(b.p, a.p, bytes, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipEventRecord(e1, c->stream));
+        HIP_CHECK(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *gbps = 2.0 * (double)bytes * reps / (ms * 1e-3) / 1e9; // read + write
+        return IPCGPU_OK;
+    });
+}
+}

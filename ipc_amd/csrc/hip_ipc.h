@@ -1,0 +1,138 @@
+// Host-side mirror of the three reference interfaces on the hot path, with their state resident in HBM:
+//   HipMesh          <- Mesh<3>                       (src/Mesh.hpp:58-171)
+//   HipLinSysSolver  <- LinSysSolver<VectorXi,VectorXd> (src/LinSysSolver/LinSysSolver.hpp:31-467)
+//   HipNeoHookean    <- Energy<3>/NeoHookeanEnergy<3>  (src/Energy/Energy.hpp:27-138)
+//   HipOptimizer     <- Optimizer<3>                   (src/TimeStepper/Optimizer.hpp:28-283)
+// Method names and argument meaning follow the reference so that the adapters in INTEGRATION.md are
+// one-line forwards.  Everything here is reached through the C ABI of include/ipcgpu.h.
+#pragma once
+#include "common.h"
+#include "mf_numeric.h"
+#include "mf_symbolic.h"
+#include "nh_kernels.h"
+#include <map>
+#include <memory>
+
+struct ipcgpu_ctx; // opaque C handle
+typedef int (*ipcgpu_allreduce_fn_t)(void* user, void* buf_dev, long long count, int op);
+
+namespace ipcgpu {
+
+class HipMesh {
+public:
+    int nV = 0, nT = 0;
+    std::vector<double> V_rest; // column-major nV x 3
+    std::vector<int> F; // column-major nT x 4
+    std::vector<double> restTriInv; // SoA [9][nT]
+    std::vector<double> triArea, mass, mu, lam;
+    std::vector<int> dbcType;
+    std::vector<int> nbPtr, nb; // vNeighbor as sorted CSR adjacency (Mesh.cpp:470-493)
+    double avgEdgeLen = 0, bboxDiag2 = 0, bboxLo[3] = { 0, 0, 0 }, bboxHi[3] = { 0, 0, 0 };
+    // device
+    DevBuf<double> d_x, d_xTilde, d_mass, d_A, d_vol, d_mu, d_lam;
+    DevBuf<int> d_dbc;
+    DevBuf<int4> d_tet;
+
+    // Mesh::computeFeatures + computeMassMatrix + setLameParam (Mesh.cpp:414-527, 246-266, 399-401, 660-671)
+    void computeFeatures(int nV, int nT, const double* Vrest, const int* F, double YM, double PR, double density, hipStream_t s);
+    void uploadDBC(hipStream_t s);
+    bool isDBCVertex(int v) const { return dbcType[v] != 0; }
+    bool isProjectDBCVertex(int v, bool projectDBC) const { return dbcType[v] == 1 || (dbcType[v] == 2 && projectDBC); }
+};
+
+class HipLinSysSolver {
+public:
+    explicit HipLinSysSolver(hipStream_t s);
+    ~HipLinSysSolver();
+    int numRows = 0;
+    std::vector<int> ia, ja; // 0-based symmetric-upper CSR (host copy, get_ia / get_ja)
+    DevBuf<int> d_ia, d_ja;
+    DevBuf<double> d_a;
+    // per-node row geometry + per-tet edge slots used by the element kernels
+    std::vector<int> rowBase, rowLen;
+    DevBuf<int> d_rowBase, d_rowLen, d_edgeP0;
+    int solverType = 0;
+    hipStream_t stream;
+
+    // set_pattern(vNeighbor, fixedVert) (LinSysSolver.hpp:46-150); extra = contact connectivity
+    void set_pattern(const HipMesh& mesh, int nExtra, const int* extraPairs);
+    void set_pattern_csr(int nRows, const int* ia, const int* ja);
+    void buildElementMap(const HipMesh& mesh); // tet edge -> CSR slot
+    void setZero();
+    int findEntry(int row, int col) const;
+    void analyze_pattern(const HipMesh* meshForCoords);
+    bool factorize();
+    void solve(const double* rhs_dev, double* x_dev);
+    void multiply(const double* x_dev, double* y_dev);
+    void precondition_diag(const double* in_dev, double* out_dev);
+    int getNumRows() const { return numRows; }
+    int getNumNonzeros() const { return (int)ja.size(); }
+    const MfSymbolic& symbolic() const { return sym_; }
+    bool analyzed() const { return analyzed_; }
+
+private:
+    MfSymbolic sym_;
+    MfNumeric num_;
+    bool analyzed_ = false;
+    std::unique_ptr<struct RocsolverCsrrf> rs_;
+    friend struct RocsolverCsrrf;
+};
+
+class HipOptimizer {
+public:
+    HipOptimizer(HipMesh& mesh, HipLinSysSolver& lin, hipStream_t s);
+    void init(double dt, bool withGravity);
+    void setRelGL2Tol(double relTol);
+    void setTwist(int nL, const int* left, int nR, const int* right, double angVel);
+    void precompute();
+    void beginTimestep();
+    bool newtonIter(); // true = converged before doing work
+    void endTimestep();
+    int solveTimestep(int maxIter);
+
+    // building blocks (virtuals of Optimizer.hpp:229-283)
+    double computeEnergyVal();
+    void computeGradient(bool projectDBC);
+    void computePrecondMtr(bool projectDBC, bool withGradient);
+    void computeSearchDir(bool projectDBC);
+    void lineSearch(double& stepSize);
+    void stepForward(const double* x0_dev, double alpha);
+    double filterStepSize(const double* p_dev, double stepSize);
+    bool checkInversion();
+    ElemView view() const;
+
+    HipMesh& mesh;
+    HipLinSysSolver& lin;
+    hipStream_t stream;
+    double dt = 0.025, dtSq = 0, gravity[3] = { 0, 0, 0 };
+    double relGL2Tol = 1e-8, targetGRes = 0;
+    DevBuf<double> d_vel, d_xPrev, d_searchDir, d_gradient, d_minusG, d_x0, d_partial, d_scalar;
+    DevBuf<int> d_flag, d_handleIds;
+    DevBuf<double> d_handleAng;
+    int nHandles = 0;
+    double rotCenter[3] = { 0, 0, 0 };
+    PinnedBuf<double> h_scalar;
+    PinnedBuf<int> h_flag;
+    int innerIterAmt = 0, globalIterNum = 0, k = 0;
+    double lastEnergyVal = 0, lastStepSize = 0, lastAlphaFeasible = 0;
+    double timers[16] = { 0 };
+    bool initialised = false;
+    int rank = 0, worldSize = 1;
+    int tetBegin = 0, tetEnd = 0;
+    ipcgpu_allreduce_fn_t allreduce = nullptr;
+    void* allreduceUser = nullptr;
+    void reduceSum(double* dev, long long n);
+    void reduceMin(double* dev, long long n);
+    double readScalar(const double* dev);
+};
+
+} // namespace ipcgpu
+
+struct ipcgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::unique_ptr<ipcgpu::HipMesh> mesh;
+    std::unique_ptr<ipcgpu::HipLinSysSolver> lin;
+    std::unique_ptr<ipcgpu::HipOptimizer> opt;
+    int rank = 0, worldSize = 1;
+};

@@ -1,0 +1,117 @@
+// HipMesh: the Mesh<3> data contract of the hot path, derived on the host once per mesh and uploaded.
+#include "hip_ipc.h"
+#include <algorithm>
+#include <cmath>
+
+namespace ipcgpu {
+
+namespace {
+inline double det3(const double X[9])
+{
+    return X[0] * (X[4] * X[8] - X[7] * X[5]) - X[3] * (X[1] * X[8] - X[7] * X[2]) + X[6] * (X[1] * X[5] - X[4] * X[2]);
+}
+// inverse of a column-major 3x3 through the adjugate
+inline void inv3(const double X[9], double R[9])
+{
+    const double d = det3(X);
+    R[0] = (X[4] * X[8] - X[7] * X[5]) / d;
+    R[1] = (X[7] * X[2] - X[1] * X[8]) / d;
+    R[2] = (X[1] * X[5] - X[4] * X[2]) / d;
+    R[3] = (X[6] * X[5] - X[3] * X[8]) / d;
+    R[4] = (X[0] * X[8] - X[6] * X[2]) / d;
+    R[5] = (X[3] * X[2] - X[0] * X[5]) / d;
+    R[6] = (X[3] * X[7] - X[6] * X[4]) / d;
+    R[7] = (X[6] * X[1] - X[0] * X[7]) / d;
+    R[8] = (X[0] * X[4] - X[3] * X[1]) / d;
+}
+} // namespace
+
+void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc, double YM, double PR, double density,
+    hipStream_t s)
+{
+    if (nV_ <= 0 || nT_ < 0) throw ArgError("set_mesh: bad sizes");
+    nV = nV_;
+    nT = nT_;
+    V_rest.assign(Vr, Vr + 3 * (size_t)nV);
+    F.assign(Fc, Fc + 4 * (size_t)nT);
+    for (size_t i = 0; i < F.size(); ++i)
+        if (F[i] < 0 || F[i] >= nV) throw ArgError("set_mesh: tetrahedron index out of range");
+    dbcType.assign(nV, 0);
+    restTriInv.assign(9 * (size_t)nT, 0.0);
+    triArea.assign(nT, 0.0);
+    mass.assign(nV, 0.0);
+    std::vector<std::pair<int, int>> edges;
+    edges.reserve(12 * (size_t)nT);
+    double edgeSum = 0.0;
+    auto X = [&](int v, int c) { return Vr[v + (size_t)nV * c]; };
+    for (int t = 0; t < nT; ++t) {
+        const int v[4] = { Fc[t], Fc[t + (size_t)nT], Fc[t + 2 * (size_t)nT], Fc[t + 3 * (size_t)nT] };
+        double X0[9], A[9];
+        for (int k = 0; k < 3; ++k)
+            for (int i = 0; i < 3; ++i) X0[i + 3 * k] = X(v[k + 1], i) - X(v[0], i);
+        inv3(X0, A); // restTriInv = X0^-1 (Mesh.cpp:449)
+        for (int k = 0; k < 9; ++k) restTriInv[(size_t)k * nT + t] = A[k];
+        const double d = det3(X0);
+        triArea[t] = d / 3 / 2; // Mesh.cpp:455
+        const double vol = std::fabs(d) / 6.0; // Mesh.cpp:255-266
+        for (int k = 0; k < 4; ++k) mass[v[k]] += vol / 4.0;
+        for (int a = 0; a < 4; ++a)
+            for (int b = a + 1; b < 4; ++b) {
+                edges.emplace_back(v[a], v[b]);
+                edges.emplace_back(v[b], v[a]);
+                double l2 = 0;
+                for (int i = 0; i < 3; ++i) {
+                    const double dd = X(v[a], i) - X(v[b], i);
+                    l2 += dd * dd;
+                }
+                edgeSum += std::sqrt(l2);
+            }
+    }
+    avgEdgeLen = nT ? edgeSum / (6.0 * nT) : 0.0;
+    for (int v = 0; v < nV; ++v) mass[v] *= density; // Mesh.cpp:399
+    mu.assign(nT, YM / 2.0 / (1.0 + PR)); // Mesh.cpp:663-664
+    lam.assign(nT, YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR));
+    // vNeighbor (Mesh.cpp:470-479); surface triangles of a tet mesh only repeat tet edges
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    nbPtr.assign(nV + 1, 0);
+    for (auto& e : edges) nbPtr[e.first + 1]++;
+    for (int v = 0; v < nV; ++v) nbPtr[v + 1] += nbPtr[v];
+    nb.resize(edges.size());
+    for (size_t i = 0; i < edges.size(); ++i) nb[i] = edges[i].second;
+    bboxDiag2 = 0;
+    for (int c = 0; c < 3; ++c) {
+        double lo = 1e300, hi = -1e300;
+        for (int v = 0; v < nV; ++v) {
+            lo = std::min(lo, X(v, c));
+            hi = std::max(hi, X(v, c));
+        }
+        bboxLo[c] = lo;
+        bboxHi[c] = hi;
+        bboxDiag2 += (hi - lo) * (hi - lo);
+    }
+    // upload
+    std::vector<double> aos(3 * (size_t)nV);
+    for (int v = 0; v < nV; ++v)
+        for (int c = 0; c < 3; ++c) aos[3 * (size_t)v + c] = X(v, c);
+    d_x.upload(aos, s);
+    d_xTilde.upload(aos, s);
+    d_mass.upload(mass, s);
+    d_A.upload(restTriInv, s);
+    d_vol.upload(triArea, s);
+    d_mu.upload(mu, s);
+    d_lam.upload(lam, s);
+    std::vector<int4> tets(nT);
+    for (int t = 0; t < nT; ++t) tets[t] = make_int4(Fc[t], Fc[t + (size_t)nT], Fc[t + 2 * (size_t)nT], Fc[t + 3 * (size_t)nT]);
+    d_tet.upload(tets.data(), tets.size(), s);
+    uploadDBC(s);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void HipMesh::uploadDBC(hipStream_t s)
+{
+    d_dbc.upload(dbcType, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+} // namespace ipcgpu

@@ -1,0 +1,340 @@
+// HipOptimizer: the Newton time stepper of Optimizer<3> with all state in HBM.
+//   solve()            Optimizer.cpp:510-602        beginTimestep / newtonIter* / endTimestep
+//   fullyImplicit_IP() Optimizer.cpp:1518-1819      (contact-free branch: one solveSub_IP per time step)
+//   solveSub_IP()      Optimizer.cpp:1822-2213      newtonIter()
+//   computeSearchDir() Optimizer.cpp:2324-2355
+//   lineSearch()       Optimizer.cpp:2662-2916      (armijoParam = 0 at the IP call site :2059)
+//   computeEnergyVal / computeGradient / computePrecondMtr   Optimizer.cpp:3199-3239, 3409-3450, 3549-3668
+// Per Newton iteration only a handful of scalars cross PCIe (energies, step bound, |p|_inf, not-PD flag).
+#include "hip_ipc.h"
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace ipcgpu {
+
+namespace {
+struct Tic {
+    double& acc;
+    hipStream_t s;
+    std::chrono::high_resolution_clock::time_point t0;
+    Tic(double& a, hipStream_t st) : acc(a), s(st), t0(std::chrono::high_resolution_clock::now()) {}
+    ~Tic()
+    {
+        (void)hipStreamSynchronize(s);
+        acc += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    }
+};
+} // namespace
+
+HipOptimizer::HipOptimizer(HipMesh& m, HipLinSysSolver& l, hipStream_t s) : mesh(m), lin(l), stream(s) {}
+
+ElemView HipOptimizer::view() const
+{
+    ElemView v;
+    v.nV = mesh.nV;
+    v.nT = mesh.nT;
+    v.tetBegin = tetBegin;
+    v.tetEnd = tetEnd;
+    v.x = mesh.d_x.p;
+    v.xTilde = mesh.d_xTilde.p;
+    v.mass = mesh.d_mass.p;
+    v.dbc = mesh.d_dbc.p;
+    v.tet = mesh.d_tet.p;
+    v.A = mesh.d_A.p;
+    v.vol = mesh.d_vol.p;
+    v.mu = mesh.d_mu.p;
+    v.lam = mesh.d_lam.p;
+    v.rowBase = lin.d_rowBase.p;
+    v.rowLen = lin.d_rowLen.p;
+    v.edgeP0 = lin.d_edgeP0.p;
+    return v;
+}
+
+void HipOptimizer::init(double dt_, bool withGravity)
+{
+    dt = dt_;
+    dtSq = dt * dt;
+    gravity[0] = gravity[2] = 0.0;
+    gravity[1] = withGravity ? -9.80665 : 0.0; // Optimizer.cpp:112-115
+    const size_t n3 = 3 * (size_t)mesh.nV;
+    d_vel.alloc(n3);
+    d_vel.zero(stream);
+    d_xPrev.alloc(n3);
+    d_searchDir.alloc(n3);
+    d_searchDir.zero(stream);
+    d_gradient.alloc(n3);
+    d_gradient.zero(stream);
+    d_minusG.alloc(n3);
+    d_x0.alloc(n3);
+    d_partial.alloc((size_t)std::max(mesh.nT, mesh.nV) / 256 + 2);
+    d_scalar.alloc(8);
+    d_flag.alloc(1);
+    h_scalar.alloc(8);
+    h_flag.alloc(1);
+    HIP_CHECK(hipMemcpyAsync(d_xPrev.p, mesh.d_x.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    HIP_CHECK(hipMemcpyAsync(mesh.d_xTilde.p, mesh.d_x.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+    for (int c = 0; c < 3; ++c) rotCenter[c] = 0.5 * (mesh.bboxLo[c] + mesh.bboxHi[c]);
+    // element shard of this rank (contiguous blocks of the caller's tet order)
+    tetBegin = (int)((long long)mesh.nT * rank / worldSize);
+    tetEnd = (int)((long long)mesh.nT * (rank + 1) / worldSize);
+    setRelGL2Tol(1.0e-2); // main.cpp:159 -> Optimizer.hpp:148 default
+    innerIterAmt = globalIterNum = k = 0;
+    std::memset(timers, 0, sizeof(timers));
+    initialised = true;
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void HipOptimizer::setRelGL2Tol(double relTol)
+{
+    relGL2Tol = relTol * relTol;
+    targetGRes = std::sqrt(relGL2Tol * mesh.bboxDiag2 * dtSq); // Optimizer.cpp:2941-2945
+}
+
+void HipOptimizer::setTwist(int nL, const int* left, int nR, const int* right, double angVel)
+{
+    // AnimScripter.cpp:555-572: handle set bI rotates with (-1)^bI * -0.4 pi about x through the rest bbox centre
+    std::vector<int> ids;
+    std::vector<double> ang;
+    for (int i = 0; i < nL; ++i) {
+        mesh.dbcType[left[i]] = 2;
+        ids.push_back(left[i]);
+        ang.push_back(-angVel * dt);
+    }
+    for (int i = 0; i < nR; ++i) {
+        mesh.dbcType[right[i]] = 2;
+        ids.push_back(right[i]);
+        ang.push_back(angVel * dt);
+    }
+    nHandles = (int)ids.size();
+    if (nHandles) {
+        d_handleIds.upload(ids, stream);
+        d_handleAng.upload(ang, stream);
+    }
+    mesh.uploadDBC(stream);
+}
+
+void HipOptimizer::reduceSum(double* dev, long long n)
+{
+    if (worldSize > 1) {
+        if (!allreduce) throw StateError("sharded context without an all-reduce hook");
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (allreduce(allreduceUser, dev, n, 0) != 0) throw HipError("all-reduce hook failed");
+    }
+}
+void HipOptimizer::reduceMin(double* dev, long long n)
+{
+    if (worldSize > 1) {
+        if (!allreduce) throw StateError("sharded context without an all-reduce hook");
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (allreduce(allreduceUser, dev, n, 1) != 0) throw HipError("all-reduce hook failed");
+    }
+}
+double HipOptimizer::readScalar(const double* dev)
+{
+    HIP_CHECK(hipMemcpyAsync(h_scalar.p, dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return h_scalar.p[0];
+}
+
+double HipOptimizer::computeEnergyVal()
+{
+    launch_energy(view(), dtSq, true, rank == 0, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
+    reduceSum(d_scalar.p, 1);
+    return readScalar(d_scalar.p);
+}
+
+void HipOptimizer::computeGradient(bool projectDBC)
+{
+    launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
+    launch_assemble(view(), dtSq, projectDBC, d_gradient.p, nullptr, stream);
+    reduceSum(d_gradient.p, 3LL * mesh.nV);
+}
+
+void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
+{
+    if (lin.rowBase.empty()) throw StateError("computePrecondMtr needs a pattern built by set_pattern");
+    lin.setZero(); // Optimizer.cpp:3616
+    launch_node_init(view(), projectDBC, rank == 0, lin.d_a.p, withGradient ? d_gradient.p : nullptr, stream);
+    launch_assemble(view(), dtSq, projectDBC, withGradient ? d_gradient.p : nullptr, lin.d_a.p, stream);
+    if (worldSize > 1) {
+        reduceSum(lin.d_a.p, (long long)lin.ja.size());
+        if (withGradient) reduceSum(d_gradient.p, 3LL * mesh.nV);
+    }
+}
+
+bool HipOptimizer::checkInversion()
+{
+    d_flag.zero(stream);
+    launch_check_inversion(view(), d_flag.p, stream);
+    HIP_CHECK(hipMemcpyAsync(h_flag.p, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    int f = h_flag.p[0];
+    if (worldSize > 1) {
+        h_scalar.p[1] = (double)f;
+        HIP_CHECK(hipMemcpyAsync(d_scalar.p + 1, h_scalar.p + 1, sizeof(double), hipMemcpyHostToDevice, stream));
+        reduceSum(d_scalar.p + 1, 1);
+        f = readScalar(d_scalar.p + 1) != 0.0;
+    }
+    return f == 0;
+}
+
+double HipOptimizer::filterStepSize(const double* p_dev, double stepSize)
+{
+    // Energy.cpp:565-581: min over elements of the root, applied only when 0 < min < stepSize
+    launch_fill(d_scalar.p + 2, 1, 1e20, stream);
+    launch_inversion_step(view(), p_dev, 0.2, d_scalar.p + 2, stream);
+    reduceMin(d_scalar.p + 2, 1);
+    const double t = readScalar(d_scalar.p + 2);
+    if (t > 0.0 && t < stepSize) stepSize = t;
+    return stepSize;
+}
+
+void HipOptimizer::stepForward(const double* x0_dev, double alpha)
+{
+    launch_step_forward(3 * mesh.nV, x0_dev, d_searchDir.p, alpha, mesh.d_x.p, stream);
+}
+
+void HipOptimizer::computeSearchDir(bool projectDBC)
+{
+    (void)projectDBC;
+    bool ok;
+    {
+        Tic t(timers[3], stream);
+        ok = lin.factorize();
+    }
+    Tic t(timers[4], stream);
+    launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
+    if (!ok) lin.precondition_diag(d_minusG.p, d_searchDir.p); // Optimizer.cpp:2331-2348
+    else lin.solve(d_minusG.p, d_searchDir.p);
+}
+
+void HipOptimizer::lineSearch(double& stepSize)
+{
+    {
+        Tic t(timers[9], stream);
+        lastEnergyVal = computeEnergyVal(); // Optimizer.cpp:2681
+    }
+    const size_t bytes = 3 * (size_t)mesh.nV * sizeof(double);
+    {
+        Tic t(timers[5], stream);
+        HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, bytes, hipMemcpyDeviceToDevice, stream));
+        stepForward(d_x0.p, stepSize);
+        while (!checkInversion()) { // Optimizer.cpp:2710-2717
+            stepSize /= 2.0;
+            if (stepSize == 0.0) break;
+            stepForward(d_x0.p, stepSize);
+        }
+    }
+    double testingE;
+    {
+        Tic t(timers[9], stream);
+        testingE = computeEnergyVal();
+    }
+    while (testingE > lastEnergyVal && stepSize > 0.0) { // Optimizer.cpp:2761-2797
+        stepSize /= 2.0;
+        if (stepSize == 0.0) break;
+        {
+            Tic t(timers[5], stream);
+            stepForward(d_x0.p, stepSize);
+        }
+        Tic t(timers[9], stream);
+        testingE = computeEnergyVal();
+    }
+    lastEnergyVal = testingE;
+}
+
+void HipOptimizer::precompute()
+{
+    // Optimizer.cpp:457-507
+    if (!initialised) throw StateError("opt_precompute before opt_init");
+    {
+        Tic t(timers[1], stream);
+        lin.set_pattern(mesh, 0, nullptr);
+    }
+    {
+        Tic t(timers[0], stream);
+        computePrecondMtr(true, false);
+    }
+    {
+        Tic t(timers[2], stream);
+        lin.analyze_pattern(&mesh);
+    }
+    lastEnergyVal = computeEnergyVal();
+}
+
+void HipOptimizer::beginTimestep()
+{
+    if (!initialised) throw StateError("opt_begin_timestep before opt_init");
+    if (!lin.analyzed()) throw StateError("opt_begin_timestep before opt_precompute");
+    Tic t(timers[11], stream);
+    if (!checkInversion()) throw StateError("element inversion before scripted motion (Optimizer.cpp:517-522)");
+    d_searchDir.zero(stream);
+    if (nHandles) {
+        // stepAnimScript, AST_TWIST (AnimScripter.cpp:1674-1684, 2140-2215)
+        launch_twist_dir(nHandles, d_handleIds.p, d_handleAng.p, rotCenter[1], rotCenter[2], mesh.d_x.p, d_searchDir.p, stream);
+        double stepSize = filterStepSize(d_searchDir.p, 1.0);
+        HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, 3 * (size_t)mesh.nV * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        stepForward(d_x0.p, stepSize);
+        while (!checkInversion()) {
+            stepSize /= 2.0;
+            stepForward(d_x0.p, stepSize);
+        }
+        if (stepSize < 1.0) throw StateError("scripted Dirichlet motion was cut short; the augmented-Lagrangian DBC path (AnimScripter.cpp:2303-2345) is a SURVEY 8f 'next' row");
+        d_searchDir.zero(stream); // initX(0), Optimizer.cpp:930-934
+    }
+    lastEnergyVal = computeEnergyVal(); // Optimizer.cpp:1609
+    k = 0;
+}
+
+bool HipOptimizer::newtonIter()
+{
+    // convergence test (Optimizer.cpp:1869-1879) looks at the search direction of the previous pass
+    launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+    launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+    const double distToOpt_PN = readScalar(d_scalar.p + 3);
+    if (k && distToOpt_PN < targetGRes) {
+        Tic t(timers[12], stream);
+        computeGradient(true); // the reference leaves the gradient of the converged state behind (:1861)
+        return true;
+    }
+    innerIterAmt++;
+    {
+        // gradient (:1861) and Hessian (:2327) come out of one fused element pass
+        Tic t(timers[0], stream);
+        computePrecondMtr(true, true);
+    }
+    computeSearchDir(true);
+    double alpha = 1.0;
+    {
+        Tic t(timers[13], stream);
+        alpha = filterStepSize(d_searchDir.p, alpha); // Optimizer.cpp:1887
+    }
+    lastAlphaFeasible = alpha;
+    lineSearch(alpha);
+    lastStepSize = alpha;
+    ++k;
+    return false;
+}
+
+void HipOptimizer::endTimestep()
+{
+    Tic t(timers[11], stream);
+    launch_be_update(mesh.nV, mesh.d_dbc.p, mesh.d_x.p, d_xPrev.p, d_vel.p, mesh.d_xTilde.p, dt, gravity[0], gravity[1], gravity[2],
+        stream);
+    globalIterNum++;
+}
+
+int HipOptimizer::solveTimestep(int maxIter)
+{
+    beginTimestep();
+    int it = 0;
+    while (it < maxIter) {
+        if (newtonIter()) break;
+        ++it;
+    }
+    endTimestep();
+    return it;
+}
+
+} // namespace ipcgpu

@@ -1,0 +1,44 @@
+// Host-side symbolic analysis for the GPU multifrontal Cholesky: fill-reducing nested-dissection
+// ordering of the node graph (3x3 block structure of LinSysSolver.hpp:46-150), assembly tree,
+// front index lists and the maps the numeric kernels consume.  This is the work the reference
+// delegates to cholmod_analyze (CHOLMODSolver.cpp:123-128); rocSOLVER's csrrf path needs the same
+// information handed to it (ordering + pattern of L), so it is produced here once per pattern.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace ipcgpu {
+
+struct MfSymbolic {
+    int n = 0; // scalar rows (3 * nn)
+    int nn = 0; // nodes
+    std::vector<int> newOf, oldOf; // node permutation: newOf[old] = new position
+    int ns = 0; // fronts (supernodes)
+    std::vector<int> firstNode; // ns+1, in new numbering; front s owns nodes [firstNode[s], firstNode[s+1])
+    std::vector<int> idxPtr; // ns+1 into idx
+    std::vector<int> idx; // per front: own nodes followed by the below-struct nodes (new numbering), ascending
+    std::vector<int> parent, level;
+    std::vector<int> childPtr, child; // children lists (ascending front id)
+    std::vector<int> invPtr; // per front (as a child): offset into inv; length = #index nodes of its parent
+    std::vector<int> inv; // parent-local node -> position in this child's struct list, or -1
+    std::vector<int64_t> frontOff; // ns+1, offsets (in doubles) of the N x N column-major fronts
+    std::vector<int64_t> wOff; // ns+1, offsets of the per-front solve work vectors (length N)
+    std::vector<int> levelPtr, levelFronts; // fronts grouped by level (leaves = level 0)
+    std::vector<int64_t> aDst; // per CSR entry of the user matrix: destination offset in the front buffer
+    int64_t nnzL = 0;
+    double flops = 0;
+    int maxN = 0;
+
+    int N(int s) const { return 3 * (idxPtr[s + 1] - idxPtr[s]); }
+    int nc(int s) const { return 3 * (firstNode[s + 1] - firstNode[s]); }
+};
+
+// ia/ja: 0-based symmetric-upper CSR (scalar).  coords: optional nn x 3 row-major node coordinates used for
+// geometric bisection (rest positions); when null the bisection direction is a BFS level structure.
+void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int leafSize, MfSymbolic& out);
+
+// scalar CSR pattern of L (lower triangle incl. diagonal, rows sorted) in the permuted ordering plus the
+// scalar permutation pivQ (new -> old) -- what rocsolver_dcsrrf_analysis expects as T and pivQ.
+void mf_L_pattern_csr(const MfSymbolic& sym, std::vector<int>& ptrT, std::vector<int>& indT, std::vector<int>& pivQ);
+
+} // namespace ipcgpu

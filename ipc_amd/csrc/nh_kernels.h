@@ -1,0 +1,61 @@
+// Launchers of the per-tetrahedron neo-Hookean kernels and the nodal helper kernels (gfx950).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ipcgpu {
+
+// Device view of the mesh / CSR map handed to the element kernels.  All pointers are HBM.
+struct ElemView {
+    int nV, nT;
+    int tetBegin, tetEnd; // element shard of this rank
+    const double* x; // positions, xyz interleaved (24 B per node: one gather touches one or two lines)
+    const double* xTilde; // same layout
+    const double* mass; // nV
+    const int* dbc; // nV, DirichletBCType
+    const int4* tet; // nT vertex ids
+    const double* A; // restTriInv, SoA: A[k * nT + t], k = i + 3 j (column-major entry k of tet t)
+    const double* vol; // triArea (rest volume)
+    const double* mu;
+    const double* lam;
+    // CSR map (valid after set_pattern)
+    const int* rowBase; // nV: ia[3 v]
+    const int* rowLen; // nV: ia[3 v + 1] - ia[3 v]
+    const int* edgeP0; // SoA [6][nT]: first CSR slot of the 3x3 block of local edge e in row 3*min(va,vb)
+};
+
+// a[] / grad[] initialisation: mass or identity on the diagonal, inertia term of the gradient.
+// (computePrecondMtr mass/DBC part, Optimizer.cpp:3638-3668; computeGradient inertia, :3438-3450)
+void launch_node_init(const ElemView& v, int projectDBC, bool ownerRank, double* a, double* grad, hipStream_t s);
+
+// fused elastic gradient (+ optional projected Hessian into CSR) -- the Newton assembly kernel
+void launch_assemble(const ElemView& v, double coef, int projectDBC, double* grad /*nullable*/,
+    double* a /*nullable*/, hipStream_t s);
+const char* assemble_kernel_name();
+
+// energy: partial[0..nBlocks) then reduced into *out (device) deterministically.
+// E = coef * sum vol psi + (withInertia ? sum 1/2 m |x - xTilde|^2 : 0)
+void launch_energy(const ElemView& v, double coef, bool withInertia, bool ownerRank, double* partial, int partialCap,
+    double* out, hipStream_t s);
+void launch_energy_per_elem(const ElemView& v, double* perElem, hipStream_t s);
+
+// inversion: flag[0] |= any det < 0 ; step bound: per-shard min written to *outMin (must be preset to +inf bits)
+void launch_check_inversion(const ElemView& v, int* flag, hipStream_t s);
+void launch_inversion_step(const ElemView& v, const double* p, double slackness, double* outMin, hipStream_t s);
+
+// nodal vector helpers
+void launch_step_forward(int n3, const double* x0, const double* p, double alpha, double* x, hipStream_t s);
+void launch_max_abs(int n, const double* v, double* out /*preset 0*/, hipStream_t s);
+void launch_fill(double* p, size_t n, double v, hipStream_t s);
+void launch_negate(int n, const double* in, double* out, hipStream_t s);
+void launch_colmajor_to_aos(int nV, const double* src, double* dst, hipStream_t s);
+void launch_aos_to_colmajor(int nV, const double* src, double* dst, hipStream_t s);
+// symmetric-upper CSR times vector and diagonal preconditioner (LinSysSolver.hpp:238-253, 411-420)
+void launch_csr_symv(int nRows, const int* ia, const int* ja, const double* a, const double* x, double* y, hipStream_t s);
+void launch_precond_diag(int nRows, const int* ia, const double* a, const double* in, double* out, hipStream_t s);
+// BE update (Optimizer.cpp:570-580, 1236-1257): vel = (x - xPrev)/dt ; xPrev = x ; xTilde = xPrev + dt vel + dt^2 g (DBC: xPrev)
+void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* xTilde, double dt,
+    double gx, double gy, double gz, hipStream_t s);
+// twist handles: rotate listed vertices about the x axis through c by their angle (AnimScripter.cpp:1674-1684)
+void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s);
+
+} // namespace ipcgpu

@@ -1,0 +1,347 @@
+"""ctypes binding of include/ipcgpu.h.
+
+Method names follow the reference interfaces the C ABI replaces
+(LinSysSolver.hpp:31-467, Energy.hpp:27-138, Optimizer.hpp:28-283) so that the
+parity tests read like tests of the reference classes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libipcgpu.so")
+_HEADER = os.path.join(_HERE, "..", "include", "ipcgpu.h")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+IPCGPU_OK = 0
+IPCGPU_NOT_PD = 1
+SOLVER_MULTIFRONTAL = 0
+SOLVER_ROCSOLVER_CSRRF = 1
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int)
+
+
+class IpcGpuError(RuntimeError):
+    pass
+
+
+class NotPositiveDefinite(IpcGpuError):
+    pass
+
+
+def lib_path() -> str:
+    return _LIB_PATH
+
+
+def declared_symbols():
+    """Every function declared in include/ipcgpu.h (used by the CPU-side export test)."""
+    txt = open(_HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ipcgpu_[a-z0-9_]+)\s*\(", txt)) - {"ipcgpu_allreduce_fn"})
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libipcgpu.so.  Raises when it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise IpcGpuError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.ipcgpu_last_error.restype = C.c_char_p
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_ip) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class Context:
+    """One `ipcgpu_ctx` == one Optimizer with its Mesh, Energy and LinSysSolver on one GPU."""
+
+    def __init__(self, device: int = 0, solver: int = SOLVER_MULTIFRONTAL):
+        self._L = load_library()
+        h = C.c_void_p()
+        self._chk(self._L.ipcgpu_ctx_create(C.c_int(device), C.byref(h)))
+        self.h = h
+        self.nV = self.nT = 0
+        self._cb = None
+        if solver != SOLVER_MULTIFRONTAL:
+            self.set_solver(solver)
+
+    def _chk(self, rc, allow_not_pd=False):
+        if rc == IPCGPU_OK:
+            return rc
+        if rc == IPCGPU_NOT_PD and allow_not_pd:
+            return rc
+        msg = self._L.ipcgpu_last_error().decode(errors="replace")
+        if rc == IPCGPU_NOT_PD:
+            raise NotPositiveDefinite(msg or "matrix not positive definite")
+        raise IpcGpuError(f"ipcgpu error {rc}: {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.ipcgpu_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- context
+    def set_solver(self, solver):
+        self._chk(self._L.ipcgpu_ctx_set_solver(self.h, C.c_int(solver)))
+
+    def set_shard(self, rank, world):
+        self._chk(self._L.ipcgpu_ctx_set_shard(self.h, C.c_int(rank), C.c_int(world)))
+
+    def set_allreduce(self, pyfunc):
+        """pyfunc(dev_ptr:int, count:int, op:int) -> int (0 ok)."""
+        def tramp(user, buf, count, op):
+            try:
+                return int(pyfunc(int(buf), int(count), int(op)))
+            except Exception as e:  # noqa: BLE001
+                print("allreduce hook failed:", e, flush=True)
+                return 1
+        self._cb = ALLREDUCE_FN(tramp)
+        self._chk(self._L.ipcgpu_opt_set_allreduce(self.h, self._cb, None))
+
+    # ---- Mesh
+    def set_mesh(self, V, F, YM=2e4, PR=0.4, density=1000.0):
+        V = np.asfortranarray(V, dtype=np.float64)
+        F = np.asfortranarray(F, dtype=np.int32)
+        self.nV, self.nT = V.shape[0], F.shape[0]
+        self._chk(self._L.ipcgpu_set_mesh(self.h, C.c_int(self.nV), C.c_int(self.nT), _dp(V), _ip(F),
+                                          C.c_double(YM), C.c_double(PR), C.c_double(density)))
+
+    def set_dbc(self, ids, typ):
+        ids = _i32(ids)
+        self._chk(self._L.ipcgpu_set_dbc(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(typ)))
+
+    def clear_dbc(self):
+        self._chk(self._L.ipcgpu_clear_dbc(self.h))
+
+    def set_positions(self, V):
+        V = np.asfortranarray(V, dtype=np.float64)
+        assert V.shape == (self.nV, 3)
+        self._chk(self._L.ipcgpu_set_positions(self.h, _dp(V)))
+
+    def get_positions(self):
+        V = np.zeros((self.nV, 3), order="F")
+        self._chk(self._L.ipcgpu_get_positions(self.h, _dp(V)))
+        return V
+
+    def set_xtilde(self, V):
+        V = np.asfortranarray(V, dtype=np.float64)
+        self._chk(self._L.ipcgpu_set_xtilde(self.h, _dp(V)))
+
+    def features(self):
+        A = np.zeros((self.nT, 9))
+        vol = np.zeros(self.nT)
+        mass = np.zeros(self.nV)
+        mu = np.zeros(self.nT)
+        lam = np.zeros(self.nT)
+        self._chk(self._L.ipcgpu_get_features(self.h, _dp(A), _dp(vol), _dp(mass), _dp(mu), _dp(lam)))
+        return dict(restTriInv=A, triArea=vol, mass=mass, mu=mu, lam=lam)
+
+    def check_inversion(self):
+        ok = C.c_int()
+        self._chk(self._L.ipcgpu_check_inversion(self.h, C.byref(ok)))
+        return bool(ok.value)
+
+    # ---- Energy
+    def elastic_energy(self, coef=1.0):
+        E = C.c_double()
+        self._chk(self._L.ipcgpu_elastic_energy(self.h, C.c_double(coef), C.byref(E)))
+        return E.value
+
+    def elastic_energy_per_elem(self):
+        out = np.zeros(self.nT)
+        self._chk(self._L.ipcgpu_elastic_energy_per_elem(self.h, _dp(out)))
+        return out
+
+    def elastic_gradient(self, coef=1.0, projectDBC=True):
+        g = np.zeros(3 * self.nV)
+        self._chk(self._L.ipcgpu_elastic_gradient(self.h, C.c_double(coef), C.c_int(int(projectDBC)), _dp(g)))
+        return g
+
+    def elastic_hessian_add(self, coef=1.0, projectDBC=True):
+        self._chk(self._L.ipcgpu_elastic_hessian_add(self.h, C.c_double(coef), C.c_int(int(projectDBC))))
+
+    def filter_step_size(self, p, step=1.0):
+        p = _f64(p)
+        s = C.c_double(step)
+        self._chk(self._L.ipcgpu_filter_step_size(self.h, _dp(p), C.byref(s)))
+        return s.value
+
+    # ---- LinSysSolver
+    def set_pattern(self, extra_pairs=None):
+        if extra_pairs is None or len(extra_pairs) == 0:
+            self._chk(self._L.ipcgpu_linsys_set_pattern(self.h, C.c_int(0), None))
+        else:
+            e = _i32(extra_pairs)
+            self._chk(self._L.ipcgpu_linsys_set_pattern(self.h, C.c_int(e.shape[0]), _ip(e)))
+
+    def set_pattern_csr(self, ia, ja):
+        ia, ja = _i32(ia), _i32(ja)
+        self._chk(self._L.ipcgpu_linsys_set_pattern_csr(self.h, C.c_int(len(ia) - 1), _ip(ia), _ip(ja)))
+
+    def get_dims(self):
+        n, nnz = C.c_int(), C.c_int()
+        self._chk(self._L.ipcgpu_linsys_get_dims(self.h, C.byref(n), C.byref(nnz)))
+        return n.value, nnz.value
+
+    def get_pattern(self):
+        n, nnz = self.get_dims()
+        ia = np.zeros(n + 1, dtype=np.int32)
+        ja = np.zeros(nnz, dtype=np.int32)
+        self._chk(self._L.ipcgpu_linsys_get_pattern(self.h, _ip(ia), _ip(ja)))
+        return ia, ja
+
+    def set_zero(self):
+        self._chk(self._L.ipcgpu_linsys_set_zero(self.h))
+
+    def get_a(self):
+        _, nnz = self.get_dims()
+        a = np.zeros(nnz)
+        self._chk(self._L.ipcgpu_linsys_get_values(self.h, _dp(a)))
+        return a
+
+    def set_a(self, a):
+        a = _f64(a)
+        self._chk(self._L.ipcgpu_linsys_set_values(self.h, _dp(a)))
+
+    def add_coeff(self, r, c, v):
+        self._chk(self._L.ipcgpu_linsys_add_coeff(self.h, C.c_int(r), C.c_int(c), C.c_double(v)))
+
+    def set_coeff(self, r, c, v):
+        self._chk(self._L.ipcgpu_linsys_set_coeff(self.h, C.c_int(r), C.c_int(c), C.c_double(v)))
+
+    def multiply(self, x):
+        x = _f64(x)
+        y = np.zeros_like(x)
+        self._chk(self._L.ipcgpu_linsys_multiply(self.h, _dp(x), _dp(y)))
+        return y
+
+    def analyze_pattern(self):
+        self._chk(self._L.ipcgpu_linsys_analyze_pattern(self.h))
+
+    def factorize(self):
+        """Returns True when the matrix is positive definite (LinSysSolver::factorize)."""
+        return self._chk(self._L.ipcgpu_linsys_factorize(self.h), allow_not_pd=True) == IPCGPU_OK
+
+    def solve(self, rhs):
+        rhs = _f64(rhs)
+        x = np.zeros_like(rhs)
+        self._chk(self._L.ipcgpu_linsys_solve(self.h, _dp(rhs), _dp(x)))
+        return x
+
+    def precondition_diag(self, v):
+        v = _f64(v)
+        out = np.zeros_like(v)
+        self._chk(self._L.ipcgpu_linsys_precondition_diag(self.h, _dp(v), _dp(out)))
+        return out
+
+    def linsys_stats(self):
+        st = np.zeros(4)
+        self._chk(self._L.ipcgpu_linsys_stats(self.h, _dp(st)))
+        return dict(nnzL=st[0], flops=st[1], fronts=int(st[2]), levels=int(st[3]))
+
+    # ---- Optimizer building blocks
+    def assemble_newton(self, dtSq, projectDBC=True, with_gradient=True):
+        g = np.zeros(3 * self.nV) if with_gradient else None
+        self._chk(self._L.ipcgpu_assemble_newton(self.h, C.c_double(dtSq), C.c_int(int(projectDBC)), _dp(g)))
+        return g
+
+    def incremental_potential(self, dtSq):
+        E = C.c_double()
+        self._chk(self._L.ipcgpu_incremental_potential(self.h, C.c_double(dtSq), C.byref(E)))
+        return E.value
+
+    def gradient(self, dtSq, projectDBC=True):
+        g = np.zeros(3 * self.nV)
+        self._chk(self._L.ipcgpu_gradient(self.h, C.c_double(dtSq), C.c_int(int(projectDBC)), _dp(g)))
+        return g
+
+    # ---- Optimizer
+    def opt_init(self, dt=0.04, gravity=False):
+        self._chk(self._L.ipcgpu_opt_init(self.h, C.c_double(dt), C.c_int(int(gravity))))
+
+    def set_rel_tol(self, tol):
+        self._chk(self._L.ipcgpu_opt_set_rel_tol(self.h, C.c_double(tol)))
+
+    def set_twist(self, left, right, ang_vel=0.4 * np.pi):
+        left, right = _i32(left), _i32(right)
+        self._chk(self._L.ipcgpu_opt_set_twist(self.h, C.c_int(len(left)), _ip(left), C.c_int(len(right)),
+                                               _ip(right), C.c_double(ang_vel)))
+
+    def precompute(self):
+        self._chk(self._L.ipcgpu_opt_precompute(self.h))
+
+    def begin_timestep(self):
+        self._chk(self._L.ipcgpu_opt_begin_timestep(self.h))
+
+    def newton_iter(self):
+        cv = C.c_int()
+        self._chk(self._L.ipcgpu_opt_newton_iter(self.h, C.byref(cv)))
+        return bool(cv.value)
+
+    def end_timestep(self):
+        self._chk(self._L.ipcgpu_opt_end_timestep(self.h))
+
+    def solve_timestep(self, max_iter=100):
+        n = C.c_int()
+        self._chk(self._L.ipcgpu_opt_solve_timestep(self.h, C.c_int(max_iter), C.byref(n)))
+        return n.value
+
+    def state(self):
+        V = np.zeros((self.nV, 3), order="F")
+        p = np.zeros(3 * self.nV)
+        g = np.zeros(3 * self.nV)
+        sc = np.zeros(8)
+        self._chk(self._L.ipcgpu_opt_get_state(self.h, _dp(V), _dp(p), _dp(g), _dp(sc)))
+        return dict(V=V, searchDir=p, gradient=g, E=sc[0], stepSize=sc[1], targetGRes=sc[2],
+                    innerIterAmt=int(sc[3]), timestep=int(sc[4]), alphaFeasible=sc[5])
+
+    def timers(self):
+        t = np.zeros(16)
+        self._chk(self._L.ipcgpu_opt_get_timers(self.h, _dp(t)))
+        return t
+
+    # ---- measurement
+    def bench_assembly(self, dtSq, reps=20):
+        ms, by = C.c_double(), C.c_double()
+        self._chk(self._L.ipcgpu_bench_assembly(self.h, C.c_double(dtSq), C.c_int(reps), C.byref(ms), C.byref(by)))
+        return ms.value, by.value
+
+    def bench_factor_solve(self, reps=3):
+        f, s = C.c_double(), C.c_double()
+        self._chk(self._L.ipcgpu_bench_factor_solve(self.h, C.c_int(reps), C.byref(f), C.byref(s)))
+        return f.value, s.value
+
+    def bench_stream(self, nbytes=1 << 30, reps=10):
+        g = C.c_double()
+        self._chk(self._L.ipcgpu_bench_stream(self.h, C.c_longlong(nbytes), C.c_int(reps), C.byref(g)))
+        return g.value

@@ -1,0 +1,284 @@
+"""ctypes binding of the CPU oracle (oracle/_build/liborc.so).
+
+ORACLE -- TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg; never by ipc_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liborc.so")
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+
+
+def build(force: bool = False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".cpp", ".h"))]
+    if (not force and os.path.exists(_LIB)
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs)):
+        return _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _LIB
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_ip) if a is not None else None
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        # on the GPU box only the prebuilt .so is expected; build when sources are newer / missing
+        if not os.path.exists(_LIB):
+            build()
+        _lib = C.CDLL(_LIB)
+        L = _lib
+        L.orc_mesh_create.restype = C.c_void_p
+        L.orc_mesh_create.argtypes = [C.c_int, C.c_int, c_dp, c_ip, C.c_double, C.c_double, C.c_double]
+        L.orc_opt_create.restype = C.c_void_p
+        L.orc_opt_create.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int]
+        L.orc_chol_create.restype = C.c_void_p
+        L.orc_chol_create.argtypes = [C.c_int, c_ip, c_ip, C.c_int]
+        L.orc_chol_nnzL.restype = C.c_longlong
+        L.orc_chol_flops.restype = C.c_double
+        L.orc_mesh_avg_edge_len.restype = C.c_double
+        L.orc_mesh_bbox_diag2.restype = C.c_double
+        L.orc_filter_step_size.restype = C.c_double
+        L.orc_pattern_ia.restype = c_ip
+        L.orc_pattern_ja.restype = c_ip
+        for name in ("orc_mesh_destroy", "orc_mesh_set_surface", "orc_mesh_set_dbc", "orc_mesh_clear_dbc",
+                     "orc_mesh_set_V", "orc_mesh_get_V", "orc_mesh_get_features", "orc_mesh_avg_edge_len",
+                     "orc_mesh_bbox_diag2", "orc_mesh_check_inversion", "orc_elastic_energy",
+                     "orc_elastic_gradient", "orc_elastic_hessian_elem", "orc_pattern_build",
+                     "orc_pattern_add_edges", "orc_pattern_rows", "orc_pattern_ia", "orc_pattern_ja",
+                     "orc_assemble_hessian", "orc_csr_symv", "orc_inversion_step", "orc_filter_step_size",
+                     "orc_chol_destroy", "orc_chol_nnzL", "orc_chol_flops", "orc_chol_factorize",
+                     "orc_chol_solve", "orc_opt_destroy", "orc_opt_set_twist", "orc_opt_set_rel_tol",
+                     "orc_opt_precompute", "orc_opt_newton_iter", "orc_opt_begin_timestep",
+                     "orc_opt_end_timestep", "orc_opt_solve_timestep", "orc_opt_get", "orc_opt_timers"):
+            getattr(L, name).argtypes = None
+    return _lib
+
+
+def svd3(F):
+    F = np.asfortranarray(F, dtype=np.float64)
+    U = np.zeros((3, 3), order="F")
+    V = np.zeros((3, 3), order="F")
+    S = np.zeros(3)
+    lib().orc_svd3(_dp(F), _dp(U), _dp(S), _dp(V))
+    return U, S, V
+
+
+def make_pd(A):
+    A = np.asfortranarray(A, dtype=np.float64).copy(order="F")
+    lib().orc_make_pd(C.c_int(A.shape[0]), _dp(A))
+    return A
+
+
+def nh_energy_sigma(s, mu, lam):
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    E = C.c_double()
+    lib().orc_nh_energy_sigma(_dp(s), C.c_double(mu), C.c_double(lam), C.byref(E))
+    return E.value
+
+
+def nh_P(F, mu, lam):
+    F = np.asfortranarray(F, dtype=np.float64)
+    P = np.zeros((3, 3), order="F")
+    lib().orc_nh_P(_dp(F), C.c_double(mu), C.c_double(lam), _dp(P))
+    return P
+
+
+def nh_dPdF(F, mu, lam, w=1.0, projectSPD=False):
+    F = np.asfortranarray(F, dtype=np.float64)
+    out = np.zeros((9, 9), order="F")
+    lib().orc_nh_dPdF(_dp(F), C.c_double(mu), C.c_double(lam), C.c_double(w), C.c_int(int(projectSPD)), _dp(out))
+    return out
+
+
+class Mesh:
+    def __init__(self, V, F, YM=2e4, PR=0.4, density=1000.0):
+        self.nV, self.nT = V.shape[0], F.shape[0]
+        self._Vr = np.asfortranarray(V, dtype=np.float64)
+        self._F = np.asfortranarray(F, dtype=np.int32)
+        self.h = C.c_void_p(lib().orc_mesh_create(self.nV, self.nT, _dp(self._Vr), _ip(self._F),
+                                                  YM, PR, density))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_mesh_destroy(self.h)
+            self.h = None
+
+    def set_surface(self, SF):
+        SF = np.asfortranarray(SF, dtype=np.int32)
+        lib().orc_mesh_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF))
+
+    def set_dbc(self, ids, typ):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lib().orc_mesh_set_dbc(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(typ))
+
+    def clear_dbc(self):
+        lib().orc_mesh_clear_dbc(self.h)
+
+    def set_V(self, V):
+        V = np.asfortranarray(V, dtype=np.float64)
+        lib().orc_mesh_set_V(self.h, _dp(V))
+
+    def get_V(self):
+        V = np.zeros((self.nV, 3), order="F")
+        lib().orc_mesh_get_V(self.h, _dp(V))
+        return V
+
+    def features(self):
+        A = np.zeros((self.nT, 9))
+        vol = np.zeros(self.nT)
+        mass = np.zeros(self.nV)
+        mu = np.zeros(self.nT)
+        lam = np.zeros(self.nT)
+        lib().orc_mesh_get_features(self.h, _dp(A), _dp(vol), _dp(mass), _dp(mu), _dp(lam))
+        return dict(restTriInv=A, triArea=vol, mass=mass, mu=mu, lam=lam,
+                    avgEdgeLen=lib().orc_mesh_avg_edge_len(self.h),
+                    bboxDiag2=lib().orc_mesh_bbox_diag2(self.h))
+
+    def check_inversion(self):
+        return bool(lib().orc_mesh_check_inversion(self.h))
+
+    def elastic_energy(self, coef=1.0, per_elem=False):
+        E = C.c_double()
+        pe = np.zeros(self.nT) if per_elem else None
+        lib().orc_elastic_energy(self.h, C.c_double(coef), C.byref(E), _dp(pe))
+        return (E.value, pe) if per_elem else E.value
+
+    def elastic_gradient(self, coef=1.0, projectDBC=True):
+        g = np.zeros(3 * self.nV)
+        lib().orc_elastic_gradient(self.h, C.c_double(coef), C.c_int(int(projectDBC)), _dp(g))
+        return g
+
+    def elastic_hessian_elem(self, e, coef=1.0, projectSPD=True):
+        H = np.zeros((12, 12), order="F")
+        lib().orc_elastic_hessian_elem(self.h, C.c_int(e), C.c_double(coef), C.c_int(int(projectSPD)), _dp(H))
+        return H
+
+    def pattern(self, extra_edges=None):
+        if extra_edges is not None and len(extra_edges):
+            ee = np.ascontiguousarray(extra_edges, dtype=np.int32)
+            lib().orc_pattern_add_edges(self.h, C.c_int(ee.shape[0]), _ip(ee))
+        nnz = lib().orc_pattern_build(self.h)
+        n = lib().orc_pattern_rows(self.h)
+        ia = np.ctypeslib.as_array(lib().orc_pattern_ia(self.h), shape=(n + 1,)).copy()
+        ja = np.ctypeslib.as_array(lib().orc_pattern_ja(self.h), shape=(nnz,)).copy()
+        return ia, ja
+
+    def assemble_hessian(self, nnz, coef=1.0, projectDBC=True):
+        a = np.zeros(nnz)
+        lib().orc_assemble_hessian(self.h, C.c_double(coef), C.c_int(int(projectDBC)), _dp(a))
+        return a
+
+    def symv(self, a, x):
+        y = np.zeros_like(x)
+        lib().orc_csr_symv(self.h, _dp(a), _dp(x), _dp(y))
+        return y
+
+    def inversion_step(self, p, slackness=0.2):
+        out = np.zeros(self.nT)
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        lib().orc_inversion_step(self.h, _dp(p), C.c_double(slackness), _dp(out))
+        return out
+
+    def filter_step_size(self, p, step=1.0):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        return lib().orc_filter_step_size(self.h, _dp(p), C.c_double(step))
+
+
+class Chol:
+    def __init__(self, ia, ja, nthreads=0):
+        self.n = len(ia) - 1
+        self._ia = np.ascontiguousarray(ia, dtype=np.int32)
+        self._ja = np.ascontiguousarray(ja, dtype=np.int32)
+        self.h = C.c_void_p(lib().orc_chol_create(self.n, _ip(self._ia), _ip(self._ja), nthreads or os.cpu_count()))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_chol_destroy(self.h)
+            self.h = None
+
+    @property
+    def nnzL(self):
+        return lib().orc_chol_nnzL(self.h)
+
+    @property
+    def flops(self):
+        return lib().orc_chol_flops(self.h)
+
+    def factorize(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        return bool(lib().orc_chol_factorize(self.h, _dp(a)))
+
+    def solve(self, rhs):
+        rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+        x = np.zeros_like(rhs)
+        lib().orc_chol_solve(self.h, _dp(rhs), _dp(x))
+        return x
+
+
+class Optimizer:
+    def __init__(self, mesh: Mesh, dt=0.04, gravity=False, nthreads=0):
+        self.mesh = mesh
+        self.h = C.c_void_p(lib().orc_opt_create(mesh.h, dt, int(gravity), nthreads or os.cpu_count()))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_opt_destroy(self.h)
+            self.h = None
+
+    def set_twist(self, left, right, ang_vel=0.4 * np.pi):
+        left = np.ascontiguousarray(left, dtype=np.int32)
+        right = np.ascontiguousarray(right, dtype=np.int32)
+        lib().orc_opt_set_twist(self.h, C.c_int(len(left)), _ip(left), C.c_int(len(right)), _ip(right),
+                                C.c_double(ang_vel))
+
+    def set_rel_tol(self, tol):
+        lib().orc_opt_set_rel_tol(self.h, C.c_double(tol))
+
+    def precompute(self):
+        lib().orc_opt_precompute(self.h)
+
+    def begin_timestep(self):
+        lib().orc_opt_begin_timestep(self.h)
+
+    def newton_iter(self):
+        return int(lib().orc_opt_newton_iter(self.h))
+
+    def end_timestep(self):
+        lib().orc_opt_end_timestep(self.h)
+
+    def solve_timestep(self, max_iter=100):
+        return int(lib().orc_opt_solve_timestep(self.h, C.c_int(max_iter)))
+
+    def state(self):
+        nV = self.mesh.nV
+        V = np.zeros((nV, 3), order="F")
+        p = np.zeros(3 * nV)
+        g = np.zeros(3 * nV)
+        sc = np.zeros(8)
+        lib().orc_opt_get(self.h, _dp(V), _dp(p), _dp(g), _dp(sc))
+        return dict(V=V, searchDir=p, gradient=g, E=sc[0], stepSize=sc[1], targetGRes=sc[2],
+                    innerIterAmt=int(sc[3]), timestep=int(sc[4]), alphaFeasible=sc[5])
+
+    def timers(self):
+        t = np.zeros(16)
+        lib().orc_opt_timers(self.h, _dp(t))
+        return t

@@ -1,0 +1,98 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY.
+//
+// CPU restatement of the reference's Newton time-step hot path,
+// used as the parity checker by tests/, __graft_entry__.smoke() and the cpu_baseline
+// leg of bench.py.  The product (ipc_amd/, libipcgpu.so) never includes, links or
+// calls anything in this directory.
+//
+// Parity status: the reference cannot be built in this image (Eigen,
+// TBB, SuiteSparse, libigl, CCD-Wrapper are all fetched at configure time), so this
+// restatement is pinned against the few known answers the reference holds --
+// psi(I)=0 (NeoHookeanEnergy.cpp:156-170), the 30x30 diagonal solve x=0.1
+// (Diagnostic.cpp:367-392), the 12 CTCD hit/no-hit cases
+// (tests/Collisions/CollisionConstraintTests.cpp:18-35,83-99) -- and against its
+// finite-difference recipes (Energy.cpp:584-893).  CCD times of impact and the sparse
+// Cholesky are "parity unpinned" (third-party, un-vendored): they are checked by
+// contract (residuals, conservativeness), not against CTCD / CHOLMOD output.
+//
+// Layouts follow the reference: V is column-major nV x 3 (x[nV] y[nV] z[nV]), F is
+// column-major nT x 4 int32, nodal vectors (gradient, searchDir) are xyzxyz... of
+// length 3 nV, 3x3 matrices are column-major.
+#pragma once
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orc_mesh orc_mesh;
+typedef struct orc_opt orc_opt;
+
+// ---- small math (for unit tests)
+void orc_svd3(const double* F9, double* U9, double* S3, double* V9);
+void orc_make_pd(int n, double* A);
+void orc_nh_energy_sigma(const double* s3, double mu, double lam, double* E);
+void orc_nh_dPdF(const double* F9, double mu, double lam, double w, int projectSPD, double* dPdF81);
+void orc_nh_P(const double* F9, double mu, double lam, double* P9);
+
+// ---- mesh = Mesh<3> data contract (Mesh.cpp:414-527, 246-266, 399-401, 660-671)
+orc_mesh* orc_mesh_create(int nV, int nT, const double* Vrest_colmajor, const int* F_colmajor,
+    double YM, double PR, double density);
+void orc_mesh_destroy(orc_mesh*);
+void orc_mesh_set_surface(orc_mesh*, int nSF, const int* SF_colmajor); // adds SF edges to vNeighbor, builds SVI/SFEdges
+void orc_mesh_set_dbc(orc_mesh*, int n, const int* vids, int type); // type: 1 ZERO, 2 NONZERO (Mesh.hpp:41-45)
+void orc_mesh_clear_dbc(orc_mesh*);
+void orc_mesh_set_V(orc_mesh*, const double* V_colmajor);
+void orc_mesh_get_V(const orc_mesh*, double* V_colmajor);
+void orc_mesh_get_features(const orc_mesh*, double* restTriInv9nT, double* triArea, double* mass, double* mu, double* lam);
+double orc_mesh_avg_edge_len(const orc_mesh*);
+double orc_mesh_bbox_diag2(const orc_mesh*);
+int orc_mesh_check_inversion(const orc_mesh*); // 1 = no inverted element (Mesh.cpp:715-764)
+
+// ---- elasticity (Energy.cpp:195-562, NeoHookeanEnergy.cpp:55-153)
+void orc_elastic_energy(const orc_mesh*, double coef, double* E, double* perElem /*nT or NULL*/);
+void orc_elastic_gradient(const orc_mesh*, double coef, int projectDBC, double* g3nV);
+void orc_elastic_hessian_elem(const orc_mesh*, int e, double coef, int projectSPD, double* H144_colmajor);
+
+// ---- CSR pattern + assembly (LinSysSolver.hpp:46-150, IglUtils.hpp:39-116, Optimizer.cpp:3549-3668)
+// pattern of the symmetric-upper CSR, 0-based; returns nnz. Pointers stay valid until the next build.
+int orc_pattern_build(orc_mesh*); // from mesh vNeighbor (+ extra connectivity set by orc_pattern_add_edges)
+void orc_pattern_add_edges(orc_mesh*, int n, const int* pairs2n); // augmentConnectivity stand-in
+int orc_pattern_rows(const orc_mesh*);
+const int* orc_pattern_ia(const orc_mesh*);
+const int* orc_pattern_ja(const orc_mesh*);
+// setZero + elastic Hessian + mass / DBC diagonal == computePrecondMtr without contact
+void orc_assemble_hessian(const orc_mesh*, double coef, int projectDBC, double* a_nnz);
+// y = A x with the symmetric-upper CSR (LinSysSolver.hpp:238-253)
+void orc_csr_symv(const orc_mesh*, const double* a, const double* x, double* y);
+
+// ---- step bounds
+void orc_inversion_step(const orc_mesh*, const double* p3nV, double slackness, double* perElem /*nT*/);
+double orc_filter_step_size(const orc_mesh*, const double* p3nV, double stepSize); // Energy.cpp:565-581
+
+// ---- sparse Cholesky on the symmetric-upper CSR (stand-in for CHOLMODSolver.cpp:123-154)
+typedef struct orc_chol orc_chol;
+orc_chol* orc_chol_create(int n, const int* ia, const int* ja, int nthreads);
+void orc_chol_destroy(orc_chol*);
+long long orc_chol_nnzL(const orc_chol*);
+double orc_chol_flops(const orc_chol*);
+int orc_chol_factorize(orc_chol*, const double* a); // 1 ok, 0 not positive definite
+void orc_chol_solve(const orc_chol*, const double* rhs, double* x);
+
+// ---- optimizer (Optimizer.cpp:457-627, 1518-1819, 1822-2213, 2324-2355, 2662-2945, 3199-3720), no contact yet
+orc_opt* orc_opt_create(orc_mesh*, double dt, int withGravity, int nthreads);
+void orc_opt_destroy(orc_opt*);
+void orc_opt_set_twist(orc_opt*, int nL, const int* left, int nR, const int* right, double angVel); // AnimScripter.cpp:555-572
+void orc_opt_set_rel_tol(orc_opt*, double relTol); // Optimizer.cpp:390-396
+void orc_opt_precompute(orc_opt*);
+// one pass of the solveSub_IP loop body; returns 1 if the time step converged before doing work
+int orc_opt_newton_iter(orc_opt*);
+void orc_opt_begin_timestep(orc_opt*); // stepAnimScript + initX(0) + energy, Optimizer.cpp:510-560,1518-1613
+void orc_opt_end_timestep(orc_opt*); // BE velocity / xTilta update, Optimizer.cpp:570-580
+int orc_opt_solve_timestep(orc_opt*, int maxIter); // returns # Newton iterations
+// state readers
+void orc_opt_get(const orc_opt*, double* V_colmajor, double* searchDir, double* gradient, double* scalars8);
+// scalars8 = {lastEnergyVal, lastStepSize, targetGRes, innerIterAmt, timestep, lastAlphaFeasible, 0, 0}
+void orc_opt_timers(const orc_opt*, double* t16); // timer_step buckets (main.cpp:1326-1340)
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,400 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_api.h).
+//
+// Sparse Cholesky for the symmetric-upper CSR of LinSysSolver.hpp:46-150: the role the reference
+// gives to SuiteSparse CHOLMOD (CHOLMODSolver.cpp:123-154: cholmod_analyze / cholmod_factorize /
+// cholmod_solve, factorize() == false iff not positive definite).  CHOLMOD is a system package that
+// is not in /root/reference ("parity unpinned"), so this is the published algorithm
+// class it implements -- a supernodal/multifrontal LL^T after a fill-reducing nested-dissection
+// ordering -- restated from scratch: graph nested dissection by BFS level structures, supernodes =
+// dissection tree nodes, dense partial factorisations of frontal matrices, OpenMP over independent
+// fronts.  Checked by residual |A x - b| and against dense Cholesky in tests/.
+#include "orc_api.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <queue>
+#include <vector>
+#include <omp.h>
+
+namespace {
+
+struct Chol {
+    int n = 0, nn = 0, nthreads = 1;
+    std::vector<int> ia, ja; // user pattern (scalar, upper)
+    std::vector<int> nadjp, nadj; // node graph (symmetric, no self loops)
+    std::vector<int> newOf, oldOf; // node permutation: newOf[old] = new
+    int ns = 0;
+    std::vector<int> snFirst; // ns+1, first node (new numbering) of each supernode
+    std::vector<std::vector<int>> snStruct; // below-row nodes (new numbering), ascending
+    std::vector<int> snParent, snLevel, snOfNode;
+    std::vector<std::vector<int>> snChildren, levels;
+    std::vector<std::vector<std::pair<int, long long>>> snAEntries; // (a index, offset in front)
+    std::vector<std::vector<int>> relind; // child -> local node index in parent's front
+    std::vector<std::vector<double>> panel; // N x nc column-major
+    long long nnzL = 0;
+    double flops = 0;
+};
+
+void buildNodeGraph(Chol& c)
+{
+    c.nn = c.n / 3;
+    std::vector<std::vector<int>> adj(c.nn);
+    for (int r = 0; r < c.n; ++r)
+        for (int k = c.ia[r]; k < c.ia[r + 1]; ++k) {
+            int u = r / 3, w = c.ja[k] / 3;
+            if (u != w) {
+                adj[u].push_back(w);
+                adj[w].push_back(u);
+            }
+        }
+    c.nadjp.assign(c.nn + 1, 0);
+    for (int u = 0; u < c.nn; ++u) {
+        std::sort(adj[u].begin(), adj[u].end());
+        adj[u].erase(std::unique(adj[u].begin(), adj[u].end()), adj[u].end());
+        c.nadjp[u + 1] = c.nadjp[u] + (int)adj[u].size();
+    }
+    c.nadj.resize(c.nadjp[c.nn]);
+    for (int u = 0; u < c.nn; ++u) std::copy(adj[u].begin(), adj[u].end(), c.nadj.begin() + c.nadjp[u]);
+}
+
+// nested dissection; emits supernodes (lists of old node ids) in elimination order
+struct ND {
+    const Chol& c;
+    std::vector<int> mark, dist; // mark[v] == tag -> in current subset
+    int tag = 0;
+    std::vector<std::vector<int>> out;
+    int leaf;
+    ND(const Chol& c_, int leaf_) : c(c_), mark(c_.nn, -1), dist(c_.nn, 0), leaf(leaf_) {}
+
+    // BFS inside subset from `start`; returns visit order; dist[] filled; unreachable nodes are appended by restarting
+    void bfsAll(const std::vector<int>& S, int start, std::vector<int>& order, int t)
+    {
+        order.clear();
+        std::vector<int>& seen = seenBuf;
+        if ((int)seen.size() < c.nn) seen.assign(c.nn, -1);
+        ++seenTag;
+        auto run = [&](int s, int d0) {
+            size_t head = order.size();
+            order.push_back(s);
+            seen[s] = seenTag;
+            dist[s] = d0;
+            while (head < order.size()) {
+                int u = order[head++];
+                for (int k = c.nadjp[u]; k < c.nadjp[u + 1]; ++k) {
+                    int w = c.nadj[k];
+                    if (mark[w] == t && seen[w] != seenTag) {
+                        seen[w] = seenTag;
+                        dist[w] = dist[u] + 1;
+                        order.push_back(w);
+                    }
+                }
+            }
+        };
+        run(start, 0);
+        for (int v : S)
+            if (seen[v] != seenTag) run(v, dist[order.back()] + 1);
+    }
+    std::vector<int> seenBuf;
+    int seenTag = 0;
+
+    void rec(std::vector<int>& S)
+    {
+        if ((int)S.size() <= leaf) {
+            if (!S.empty()) out.push_back(S);
+            return;
+        }
+        int t = ++tag;
+        for (int v : S) mark[v] = t;
+        std::vector<int> order;
+        bfsAll(S, S[0], order, t);
+        bfsAll(S, order.back(), order, t); // pseudo-peripheral start
+        // choose the level boundary closest to the median
+        int half = (int)S.size() / 2;
+        int cutLevel = dist[order[half]];
+        // count nodes with dist < cutLevel and dist <= cutLevel, pick nearer to half
+        int below = 0, upto = 0;
+        for (int v : order) {
+            if (dist[v] < cutLevel) ++below;
+            if (dist[v] <= cutLevel) ++upto;
+        }
+        int L = (half - below <= upto - half && below > 0) ? cutLevel : cutLevel + 1; // left = dist < L
+        std::vector<int> left, right, sep;
+        for (int v : order) (dist[v] < L ? left : right).push_back(v);
+        if (left.empty() || right.empty()) { // cannot split (e.g. clique): emit as one supernode
+            out.push_back(S);
+            return;
+        }
+        // separator = left nodes adjacent to a right node
+        std::vector<int> left2;
+        for (int v : left) {
+            bool adjR = false;
+            for (int k = c.nadjp[v]; k < c.nadjp[v + 1] && !adjR; ++k) {
+                int w = c.nadj[k];
+                if (mark[w] == t && dist[w] >= L) adjR = true;
+            }
+            (adjR ? sep : left2).push_back(v);
+        }
+        // release marks before recursing (children re-mark)
+        rec(left2);
+        rec(right);
+        if (!sep.empty()) out.push_back(sep);
+    }
+};
+
+void analyze(Chol& c)
+{
+    buildNodeGraph(c);
+    ND nd(c, 12);
+    std::vector<int> all(c.nn);
+    std::iota(all.begin(), all.end(), 0);
+    nd.rec(all);
+    c.ns = (int)nd.out.size();
+    c.newOf.assign(c.nn, -1);
+    c.oldOf.assign(c.nn, -1);
+    c.snFirst.assign(c.ns + 1, 0);
+    c.snOfNode.assign(c.nn, 0);
+    int next = 0;
+    for (int s = 0; s < c.ns; ++s) {
+        c.snFirst[s] = next;
+        std::sort(nd.out[s].begin(), nd.out[s].end());
+        for (int v : nd.out[s]) {
+            c.newOf[v] = next;
+            c.oldOf[next] = v;
+            c.snOfNode[next] = s;
+            ++next;
+        }
+    }
+    c.snFirst[c.ns] = next;
+    // symbolic: struct(s) = (adj(s) U children structs) restricted to nodes >= end(s)
+    c.snStruct.assign(c.ns, {});
+    c.snParent.assign(c.ns, -1);
+    c.snChildren.assign(c.ns, {});
+    c.snLevel.assign(c.ns, 0);
+    for (int s = 0; s < c.ns; ++s) {
+        int l = c.snFirst[s + 1];
+        std::vector<int> st;
+        for (int v = c.snFirst[s]; v < l; ++v) {
+            int o = c.oldOf[v];
+            for (int k = c.nadjp[o]; k < c.nadjp[o + 1]; ++k) {
+                int w = c.newOf[c.nadj[k]];
+                if (w >= l) st.push_back(w);
+            }
+        }
+        for (int ch : c.snChildren[s])
+            for (int w : c.snStruct[ch])
+                if (w >= l) st.push_back(w);
+        std::sort(st.begin(), st.end());
+        st.erase(std::unique(st.begin(), st.end()), st.end());
+        c.snStruct[s] = st;
+        if (!st.empty()) {
+            int p = c.snOfNode[st[0]];
+            c.snParent[s] = p;
+            c.snChildren[p].push_back(s);
+        }
+    }
+    int maxLevel = 0;
+    for (int s = 0; s < c.ns; ++s) {
+        int lv = 0;
+        for (int ch : c.snChildren[s]) lv = std::max(lv, c.snLevel[ch] + 1);
+        c.snLevel[s] = lv;
+        maxLevel = std::max(maxLevel, lv);
+    }
+    c.levels.assign(maxLevel + 1, {});
+    for (int s = 0; s < c.ns; ++s) c.levels[c.snLevel[s]].push_back(s);
+    // relative indices child -> parent front
+    c.relind.assign(c.ns, {});
+    for (int s = 0; s < c.ns; ++s) {
+        int p = c.snParent[s];
+        if (p < 0) continue;
+        int pf = c.snFirst[p], pl = c.snFirst[p + 1];
+        const auto& ps = c.snStruct[p];
+        auto& r = c.relind[s];
+        r.resize(c.snStruct[s].size());
+        for (size_t i = 0; i < r.size(); ++i) {
+            int w = c.snStruct[s][i];
+            if (w < pl) r[i] = w - pf;
+            else r[i] = (pl - pf) + int(std::lower_bound(ps.begin(), ps.end(), w) - ps.begin());
+        }
+    }
+    // map A entries to fronts
+    c.snAEntries.assign(c.ns, {});
+    c.nnzL = 0;
+    c.flops = 0;
+    for (int s = 0; s < c.ns; ++s) {
+        long long nc = 3LL * (c.snFirst[s + 1] - c.snFirst[s]), nb = 3LL * c.snStruct[s].size();
+        c.nnzL += nc * (nc + 1) / 2 + nc * nb;
+        for (long long j = 0; j < nc; ++j) {
+            double m = (double)(nc - j - 1) + nb;
+            c.flops += m * m + 2 * m + 1; // column-j outer product
+        }
+    }
+    for (int r = 0; r < c.n; ++r)
+        for (int k = c.ia[r]; k < c.ia[r + 1]; ++k) {
+            int col = c.ja[k];
+            int pr = 3 * c.newOf[r / 3] + r % 3, pc = 3 * c.newOf[col / 3] + col % 3;
+            int i = std::max(pr, pc), j = std::min(pr, pc);
+            int s = c.snOfNode[j / 3];
+            int f = c.snFirst[s], l = c.snFirst[s + 1];
+            long long nc = 3LL * (l - f), N = nc + 3LL * c.snStruct[s].size();
+            long long lr;
+            if (i / 3 < l) lr = i - 3 * f;
+            else {
+                const auto& st = c.snStruct[s];
+                auto it = std::lower_bound(st.begin(), st.end(), i / 3);
+                lr = nc + 3 * (it - st.begin()) + i % 3;
+            }
+            long long lc = j - 3 * f;
+            c.snAEntries[s].push_back({ k, lr + N * lc });
+        }
+    c.panel.assign(c.ns, {});
+}
+
+// dense partial Cholesky of the leading nc columns of the N x N lower front (column-major, ld N).
+// returns false when a non-positive pivot shows up.
+bool partialChol(double* A, int N, int nc, bool par)
+{
+    const int NB = 32;
+    for (int kb = 0; kb < nc; kb += NB) {
+        int w = std::min(NB, nc - kb);
+        for (int j = kb; j < kb + w; ++j) {
+            double* cj = A + (size_t)N * j;
+            for (int k = kb; k < j; ++k) {
+                const double* ck = A + (size_t)N * k;
+                double l = ck[j];
+                for (int i = j; i < N; ++i) cj[i] -= l * ck[i];
+            }
+            double d = cj[j];
+            if (!(d > 0.0)) return false;
+            d = std::sqrt(d);
+            double inv = 1.0 / d;
+            cj[j] = d;
+            for (int i = j + 1; i < N; ++i) cj[i] *= inv;
+        }
+        int j0 = kb + w;
+#pragma omp parallel for schedule(dynamic, 8) if (par && (N - j0) > 64)
+        for (int j = j0; j < N; ++j) {
+            double* cj = A + (size_t)N * j;
+            int k = kb;
+            for (; k + 3 < kb + w; k += 4) {
+                const double *c0 = A + (size_t)N * k, *c1 = c0 + N, *c2 = c1 + N, *c3 = c2 + N;
+                double l0 = c0[j], l1 = c1[j], l2 = c2[j], l3 = c3[j];
+                for (int i = j; i < N; ++i) cj[i] -= l0 * c0[i] + l1 * c1[i] + l2 * c2[i] + l3 * c3[i];
+            }
+            for (; k < kb + w; ++k) {
+                const double* ck = A + (size_t)N * k;
+                double l = ck[j];
+                for (int i = j; i < N; ++i) cj[i] -= l * ck[i];
+            }
+        }
+    }
+    return true;
+}
+
+} // namespace
+
+struct orc_chol {
+    Chol c;
+};
+
+extern "C" {
+
+orc_chol* orc_chol_create(int n, const int* ia, const int* ja, int nthreads)
+{
+    orc_chol* h = new orc_chol;
+    h->c.n = n;
+    h->c.nthreads = nthreads > 0 ? nthreads : 1;
+    h->c.ia.assign(ia, ia + n + 1);
+    h->c.ja.assign(ja, ja + ia[n]);
+    analyze(h->c);
+    return h;
+}
+void orc_chol_destroy(orc_chol* h) { delete h; }
+long long orc_chol_nnzL(const orc_chol* h) { return h->c.nnzL; }
+double orc_chol_flops(const orc_chol* h) { return h->c.flops; }
+
+int orc_chol_factorize(orc_chol* h, const double* a)
+{
+    Chol& c = h->c;
+    omp_set_num_threads(c.nthreads);
+    std::vector<std::vector<double>> upd(c.ns);
+    bool ok = true;
+    auto doFront = [&](int s, bool par) {
+        int f = c.snFirst[s], l = c.snFirst[s + 1];
+        int nc = 3 * (l - f), nb = 3 * (int)c.snStruct[s].size(), N = nc + nb;
+        std::vector<double> Fm((size_t)N * N, 0.0);
+        for (const auto& e : c.snAEntries[s]) Fm[e.second] += a[e.first];
+        for (int ch : c.snChildren[s]) {
+            const auto& r = c.relind[ch];
+            int cb = 3 * (int)r.size();
+            const double* U = upd[ch].data();
+            for (int j = 0; j < cb; ++j) {
+                int gj = 3 * r[j / 3] + j % 3;
+                for (int i = j; i < cb; ++i) {
+                    int gi = 3 * r[i / 3] + i % 3;
+                    Fm[gi + (size_t)N * gj] += U[i + (size_t)cb * j];
+                }
+            }
+            std::vector<double>().swap(upd[ch]);
+        }
+        if (!partialChol(Fm.data(), N, nc, par)) {
+#pragma omp atomic write
+            ok = false;
+            return;
+        }
+        c.panel[s].assign(Fm.begin(), Fm.begin() + (size_t)N * nc);
+        if (nb) {
+            upd[s].resize((size_t)nb * nb);
+            for (int j = 0; j < nb; ++j)
+                std::memcpy(&upd[s][(size_t)nb * j + j], &Fm[(size_t)N * (nc + j) + nc + j], sizeof(double) * (nb - j));
+        }
+    };
+    for (const auto& lv : c.levels) {
+        if (!ok) break;
+        if ((int)lv.size() >= 2 * c.nthreads) {
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int i = 0; i < (int)lv.size(); ++i) doFront(lv[i], false);
+        }
+        else {
+            for (int s : lv) doFront(s, true);
+        }
+    }
+    return ok ? 1 : 0;
+}
+
+void orc_chol_solve(const orc_chol* h, const double* rhs, double* x)
+{
+    const Chol& c = h->c;
+    std::vector<double> y(c.n);
+    for (int v = 0; v < c.nn; ++v)
+        for (int d = 0; d < 3; ++d) y[3 * c.newOf[v] + d] = rhs[3 * v + d];
+    // forward
+    for (int s = 0; s < c.ns; ++s) {
+        int f = c.snFirst[s], l = c.snFirst[s + 1];
+        int nc = 3 * (l - f), nb = 3 * (int)c.snStruct[s].size(), N = nc + nb;
+        const double* P = c.panel[s].data();
+        double* ys = &y[3 * f];
+        for (int j = 0; j < nc; ++j) {
+            ys[j] /= P[j + (size_t)N * j];
+            double t = ys[j];
+            for (int i = j + 1; i < nc; ++i) ys[i] -= t * P[i + (size_t)N * j];
+            for (int i = 0; i < nb; ++i) y[3 * c.snStruct[s][i / 3] + i % 3] -= t * P[nc + i + (size_t)N * j];
+        }
+    }
+    // backward
+    for (int s = c.ns - 1; s >= 0; --s) {
+        int f = c.snFirst[s], l = c.snFirst[s + 1];
+        int nc = 3 * (l - f), nb = 3 * (int)c.snStruct[s].size(), N = nc + nb;
+        const double* P = c.panel[s].data();
+        double* ys = &y[3 * f];
+        for (int j = nc - 1; j >= 0; --j) {
+            double t = ys[j];
+            for (int i = j + 1; i < nc; ++i) t -= P[i + (size_t)N * j] * ys[i];
+            for (int i = 0; i < nb; ++i) t -= P[nc + i + (size_t)N * j] * y[3 * c.snStruct[s][i / 3] + i % 3];
+            ys[j] = t / P[j + (size_t)N * j];
+        }
+    }
+    for (int v = 0; v < c.nn; ++v)
+        for (int d = 0; d < 3; ++d) x[3 * v + d] = y[3 * c.newOf[v] + d];
+}
+}

@@ -1,0 +1,56 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_api.h).
+#pragma once
+#include "orc_math.h"
+#include <set>
+#include <utility>
+#include <vector>
+
+namespace orc {
+
+// Restatement of the parts of Mesh<3> the hot path reads (Mesh.hpp:58-171).
+struct Mesh {
+    int nV, nT;
+    double density;
+    std::vector<double> V_rest, V; // column-major nV x 3
+    std::vector<int> F; // column-major nT x 4
+    std::vector<int> dbcType; // DirichletBCType: 0 NOT_DBC, 1 ZERO, 2 NONZERO (Mesh.hpp:41-45)
+    std::vector<M3> restTriInv;
+    std::vector<double> triArea, mass, mu, lam;
+    std::vector<std::set<std::pair<int, int>>> vFLoc;
+    std::vector<std::set<int>> vNeighbor;
+    std::vector<std::pair<int, int>> extraEdges; // contact connectivity (SelfCollisionHandler.cpp:330-415)
+    double avgEdgeLen, bboxDiag2, bboxLo[3], bboxHi[3];
+    // surface
+    int nSF = 0;
+    std::vector<int> SF; // column-major nSF x 3
+    std::vector<int> SVI;
+    std::vector<std::pair<int, int>> SFEdges;
+    // symmetric-upper CSR, 0-based (LinSysSolver.hpp:46-150)
+    std::vector<int> ia, ja;
+
+    Mesh(int nV, int nT, const double* Vrest, const int* F, double YM, double PR, double density);
+    int Fi(int t, int k) const { return F[t + nT * k]; }
+    double Vx(int v, int c) const { return V[v + nV * c]; }
+    bool isDBC(int v) const { return dbcType[v] != 0; }
+    bool isProjectDBC(int v, bool projectDBC) const { return dbcType[v] == 1 || (dbcType[v] == 2 && projectDBC); } // Mesh.hpp:135-144
+    void setSurface(int nSF, const int* SF);
+    bool checkInversion() const;
+    M3 defGrad(int t) const;
+    void buildPattern();
+    int findEntry(int row, int col) const;
+};
+
+double elasticEnergy(const Mesh& m, double coef, double* perElem);
+void elasticGradient(const Mesh& m, double coef, bool projectDBC, double* grad);
+void elemHessian(const Mesh& m, int t, double coef, bool projectSPD, double H[144]);
+void assembleHessian(const Mesh& m, double coef, bool projectDBC, double* a);
+void inversionStep(const Mesh& m, const double* p, double slackness, double* out);
+double filterStepSize(const Mesh& m, const double* p, double stepSize); // Energy.cpp:565-581
+
+} // namespace orc
+
+struct orc_mesh {
+    orc::Mesh m;
+    orc_mesh(int nV, int nT, const double* V, const int* F, double YM, double PR, double rho)
+        : m(nV, nT, V, F, YM, PR, rho) {}
+};

@@ -1,0 +1,46 @@
+"""CPU-side checks of the C-ABI library: it loads and exports every symbol include/ipcgpu.h declares.
+No compute call is made here (there is no GPU in the build container)."""
+import ctypes
+import os
+
+import pytest
+
+import ipc_amd
+from ipc_amd import lib as L
+
+
+def test_library_built_and_loads():
+    assert os.path.exists(L.lib_path()), "libipcgpu.so missing: run __graft_entry__.build()"
+    ipc_amd.load_library()
+
+
+def test_every_declared_symbol_is_exported():
+    lib = ipc_amd.load_library()
+    names = L.declared_symbols()
+    assert len(names) >= 45
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_context_creation_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(L.IpcGpuError):
+        L.Context(0)
+
+
+def test_no_oracle_reference_in_product():
+    """The product must never import, include, link or execute anything under oracle/."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = re.compile(r"(import\s+oracle|from\s+oracle|#include\s*[\"<][^\">]*orc_|liborc|oracle/|orc_[a-z_]+\()")
+    for dirpath, _, files in os.walk(os.path.join(root, "ipc_amd")):
+        if "_obj" in dirpath or "__pycache__" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not pat.search(txt), (f, pat.search(txt).group(0))
+    deps = os.popen(f"ldd {L.lib_path()}").read()
+    assert "liborc" not in deps
