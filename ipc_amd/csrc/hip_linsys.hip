@@ -16,7 +16,7 @@ struct RocsolverCsrrf {
     rocblas_handle handle = nullptr;
     rocsolver_rfinfo info = nullptr;
     int n = 0, nnzA = 0, nnzT = 0;
-    DevBuf<int> ptrA, indA, ptrT, indT, pivQ, trans; // trans[k] = index into the upper-CSR values for lower-CSR slot k
+    DevBuf<int> ptrA, indA, ptrT, indT, pivQ, trans, flag; // trans[k] = index into the upper-CSR values for lower-CSR slot k
     DevBuf<double> valA, valT, B;
     bool analyzed = false;
     ~RocsolverCsrrf()
@@ -37,6 +37,16 @@ __global__ void k_set_diag_one(int n, const int* __restrict__ ptrT, const int* _
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n) {
         for (int k = ptrT[r]; k < ptrT[r + 1]; ++k) valT[k] = (indT[k] == r) ? 1.0 : 0.0;
+    }
+}
+// csric0 does not report a non-positive pivot through the status: the diagonal of L (last entry of each
+// lower-CSR row) turns NaN / non-positive instead
+__global__ void k_check_diag(int n, const int* __restrict__ ptrT, const double* __restrict__ valT, int* __restrict__ flag)
+{
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) {
+        const double d = valT[ptrT[r + 1] - 1];
+        if (!(d > 0.0) || !(d < 1e300)) atomicOr(flag, 1);
     }
 }
 } // namespace
@@ -190,6 +200,7 @@ void HipLinSysSolver::analyze_pattern(const HipMesh* mesh)
         R.valT.alloc(iT.size());
         R.B.alloc(numRows);
         R.B.zero(stream);
+        R.flag.alloc(1);
         // the analysis wants a numerically valid pair (M, T): use M = I-pattern values, T = identity factor
         hipLaunchKernelGGL(k_set_diag_one, dim3((numRows + 255) / 256), dim3(256), 0, stream, numRows, R.ptrT.p, R.indT.p, R.valT.p);
         hipLaunchKernelGGL(k_set_diag_one, dim3((numRows + 255) / 256), dim3(256), 0, stream, numRows, R.ptrA.p, R.indA.p, R.valA.p);
@@ -211,9 +222,16 @@ bool HipLinSysSolver::factorize()
     hipLaunchKernelGGL(k_gather, dim3((R.nnzA + 255) / 256), dim3(256), 0, stream, R.nnzA, R.trans.p, d_a.p, R.valA.p);
     rocblas_status st = rocsolver_dcsrrf_refactchol(R.handle, R.n, R.nnzA, R.ptrA.p, R.indA.p, R.valA.p, R.nnzT, R.ptrT.p, R.indT.p,
         R.valT.p, R.pivQ.p, R.info);
+    if (st != rocblas_status_success) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        return false;
+    }
+    R.flag.zero(stream);
+    hipLaunchKernelGGL(k_check_diag, dim3((R.n + 255) / 256), dim3(256), 0, stream, R.n, R.ptrT.p, R.valT.p, R.flag.p);
+    int f = 0;
+    HIP_CHECK(hipMemcpyAsync(&f, R.flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    if (st == rocblas_status_success) return true;
-    return false; // singular / non-positive pivot reported by csric0
+    return f == 0;
 }
 
 void HipLinSysSolver::solve(const double* rhs_dev, double* x_dev)

@@ -351,12 +351,16 @@ int orc_chol_factorize(orc_chol* h, const double* a)
     };
     for (const auto& lv : c.levels) {
         if (!ok) break;
-        if ((int)lv.size() >= 2 * c.nthreads) {
+        // many fronts: one thread per front; few fronts: threads share the Schur update of each big front
+        if ((int)lv.size() >= std::max(2, c.nthreads / 2)) {
 #pragma omp parallel for schedule(dynamic, 1)
             for (int i = 0; i < (int)lv.size(); ++i) doFront(lv[i], false);
         }
         else {
-            for (int s : lv) doFront(s, true);
+            for (int s : lv) {
+                int N = 3 * (c.snFirst[s + 1] - c.snFirst[s]) + 3 * (int)c.snStruct[s].size();
+                doFront(s, N > 192);
+            }
         }
     }
     return ok ? 1 : 0;
