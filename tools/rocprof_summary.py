@@ -8,7 +8,7 @@ def short(name, n=110):
     name = name.replace("ipcgpu::(anonymous namespace)::", "").replace("void ", "")
     if name.startswith("Cijk_"):
         name = "rocBLAS/Tensile dgemm " + name[:40]
-    return name[:n]
+    return name.split("(")[0][:n]
 
 
 def main():
@@ -23,7 +23,8 @@ def main():
         a[2] += pct
     lines = ["| kernel | calls | total ms | avg us | % |", "|---|---:|---:|---:|---:|"]
     for k, (calls, tot, pct) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-        lines.append(f"| `{k}` | {calls} | {tot / 1e6:.3f} | {tot / calls / 1e3:.2f} | {pct:.2f} |")
+        # the `top_kernels` view reports microseconds
+        lines.append(f"| `{k}` | {calls} | {tot / 1e3:.3f} | {tot / calls:.2f} | {pct:.2f} |")
     out = "\n".join(lines)
     if len(sys.argv) > 2:
         open(sys.argv[2], "w").write(out + "\n")
