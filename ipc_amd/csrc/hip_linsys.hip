@@ -39,14 +39,19 @@ __global__ void k_set_diag_one(int n, const int* __restrict__ ptrT, const int* _
         for (int k = ptrT[r]; k < ptrT[r + 1]; ++k) valT[k] = (indT[k] == r) ? 1.0 : 0.0;
     }
 }
-// csric0 does not report a non-positive pivot through the status: the diagonal of L (last entry of each
-// lower-CSR row) turns NaN / non-positive instead
-__global__ void k_check_diag(int n, const int* __restrict__ ptrT, const double* __restrict__ valT, int* __restrict__ flag)
+// rocSPARSE's csric0 (behind csrrf_refactchol) does not surface a non-positive pivot: it returns success with a
+// finite factor.  A genuine Cholesky factor satisfies (L L^T)_rr = A_rr row by row; a pivot whose sign was lost
+// breaks that identity, so the check is one pass over T.
+__global__ void k_check_diag(int n, const int* __restrict__ ptrT, const double* __restrict__ valT, const int* __restrict__ pivQ,
+    const int* __restrict__ ia, const double* __restrict__ a, int* __restrict__ flag)
 {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n) {
+        double s2 = 0.0;
+        for (int k = ptrT[r]; k < ptrT[r + 1]; ++k) s2 += valT[k] * valT[k];
+        const double arr = a[ia[pivQ[r]]]; // the diagonal leads every upper-CSR row
         const double d = valT[ptrT[r + 1] - 1];
-        if (!(d > 0.0) || !(d < 1e300)) atomicOr(flag, 1);
+        if (!(d > 0.0) || !(fabs(s2 - arr) <= 1e-8 * fabs(arr) + 1e-300)) atomicOr(flag, 1);
     }
 }
 } // namespace
@@ -227,7 +232,8 @@ bool HipLinSysSolver::factorize()
         return false;
     }
     R.flag.zero(stream);
-    hipLaunchKernelGGL(k_check_diag, dim3((R.n + 255) / 256), dim3(256), 0, stream, R.n, R.ptrT.p, R.valT.p, R.flag.p);
+    hipLaunchKernelGGL(k_check_diag, dim3((R.n + 255) / 256), dim3(256), 0, stream, R.n, R.ptrT.p, R.valT.p, R.pivQ.p, d_ia.p, d_a.p,
+        R.flag.p);
     int f = 0;
     HIP_CHECK(hipMemcpyAsync(&f, R.flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));

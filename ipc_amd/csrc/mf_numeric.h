@@ -3,14 +3,12 @@
 #pragma once
 #include "common.h"
 #include "mf_symbolic.h"
-#include <rocblas/rocblas.h>
 
 namespace ipcgpu {
 
 class MfNumeric {
 public:
     MfNumeric() = default;
-    ~MfNumeric();
     MfNumeric(const MfNumeric&) = delete;
     MfNumeric& operator=(const MfNumeric&) = delete;
 
@@ -23,22 +21,29 @@ public:
     size_t front_bytes() const { return fronts_.n * sizeof(double); }
 
 private:
+    struct Range {
+        int off = 0, cnt = 0;
+    };
+    struct LevelPlan {
+        Range small; // into smallList_
+        size_t smallLds = 0, solveLds = 0;
+        Range ea; // extend-add descriptors
+        Range bigFronts; // into bigList_
+        std::vector<Range> trsm, syrk; // per 32-column step: descriptor ranges
+        std::vector<Range> fwd, bwd; // per step: solve descriptors
+        Range fwdGather, bwdInit; // descriptors for the big-front solve prologues
+    };
     const MfSymbolic* sym_ = nullptr;
     hipStream_t stream_ = nullptr;
-    rocblas_handle blas_ = nullptr;
     int ns_ = 0, nLevels_ = 0;
-    DevBuf<double> fronts_, w_, yperm_;
-    DevBuf<int> idx_, idxPtr_, firstNode_, childPtr_, child_, invPtr_, inv_, newOf_, levelFronts_, flag_, info_;
+    std::vector<LevelPlan> plan_;
+    DevBuf<double> fronts_, w_, yperm_, xsol_;
+    DevBuf<int> idx_, idxPtr_, firstNode_, childPtr_, child_, invPtr_, inv_, newOf_, flag_;
     DevBuf<long long> frontOff_, wOff_, aDst_;
-    // extend-add work descriptors per level: (front, chunk)
     DevBuf<int2> eaDesc_;
-    std::vector<int> eaLevelPtr_;
-    // per level: fronts handled by the single-workgroup kernel and those sent to rocBLAS / rocSOLVER
-    std::vector<std::vector<int>> smallFronts_, bigFronts_;
     DevBuf<int> smallList_;
-    std::vector<int> smallLevelPtr_;
+    DevBuf<int4> desc_; // all big-front step descriptors
     PinnedBuf<int> hflag_;
-    size_t ldsBytes_ = 0;
 };
 
 } // namespace ipcgpu

@@ -13,7 +13,9 @@
 // the sigma-space A block (3x3, PSD-clamped) and the three 2x2 B blocks (makePD2d-clamped)
 // -- the same numbers, ~2.5 kflop instead of ~7 kflop per element.
 #include "nh_kernels.h"
+#include <algorithm>
 #include <cfloat>
+#include <cstdlib>
 
 namespace ipcgpu {
 
@@ -268,7 +270,9 @@ __device__ __forceinline__ bool projected_dbc(int type, int projectDBC)
 // ------------------------------------------------------------------------------------------------
 // Newton assembly: gradient (+ Hessian) of dt^2 * elastic energy, scattered to the nodal gradient
 // and the symmetric-upper CSR.  v1 scatter: hardware fp64 atomics (global_atomic_add_f64).
-template <bool HESS>
+// SCATTER: 0 = hardware atomics (the shipped path); 1 = plain racy stores, 2 = one store per element -- both only
+// to split the kernel time into arithmetic and scatter when profiling (IPCGPU_ASM_PROBE), never for results.
+template <bool HESS, int SCATTER = 0>
 __global__ __launch_bounds__(BLOCK) void k_assemble(ElemView v, double coef, int projectDBC, double* __restrict__ grad,
     double* __restrict__ a)
 {
@@ -405,6 +409,33 @@ __global__ __launch_bounds__(BLOCK) void k_assemble(ElemView v, double coef, int
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) H[i][r] = UT[i][0] * U[r] + UT[i][1] * U[r + 3] + UT[i][2] * U[r + 6];
+            if (SCATTER == 2) {
+                double sum = 0.0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) sum += H[i][r];
+                if (sum == 1.2345e300) a[t] = sum;
+                continue;
+            }
+            if (SCATTER == 1) {
+                if (diag) {
+                    const int base = rb[ka], Lr = rl[ka];
+                    a[base + 0] = H[0][0]; a[base + 1] = H[0][1]; a[base + 2] = H[0][2];
+                    a[base + Lr + 0] = H[1][1]; a[base + Lr + 1] = H[1][2]; a[base + 2 * Lr - 1] = H[2][2];
+                }
+                else {
+                    const bool aFirst = vid[ka] < vid[kc];
+                    const int Lr = aFirst ? rl[ka] : rl[kc];
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) {
+                        const int rowOff = (r == 0) ? 0 : (r == 1 ? (Lr - 1) : (2 * Lr - 3));
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) a[p0 + rowOff + c] = aFirst ? H[r][c] : H[c][r];
+                    }
+                }
+                continue;
+            }
             if (diag) {
                 const int base = rb[ka], Lr = rl[ka];
                 atomicAdd(&a[base + 0], H[0][0]);
@@ -747,8 +778,11 @@ void launch_assemble(const ElemView& v, double coef, int projectDBC, double* gra
 {
     const int n = v.tetEnd - v.tetBegin;
     if (n <= 0) return;
-    if (a) hipLaunchKernelGGL(k_assemble<true>, dim3(nblk(n)), dim3(BLOCK), 0, s, v, coef, projectDBC, grad, a);
-    else hipLaunchKernelGGL(k_assemble<false>, dim3(nblk(n)), dim3(BLOCK), 0, s, v, coef, projectDBC, grad, a);
+    static const int probe = std::getenv("IPCGPU_ASM_PROBE") ? std::atoi(std::getenv("IPCGPU_ASM_PROBE")) : 0;
+    if (a && probe == 1) hipLaunchKernelGGL((k_assemble<true, 1>), dim3(nblk(n)), dim3(BLOCK), 0, s, v, coef, projectDBC, grad, a);
+    else if (a && probe == 2) hipLaunchKernelGGL((k_assemble<true, 2>), dim3(nblk(n)), dim3(BLOCK), 0, s, v, coef, projectDBC, grad, a);
+    else if (a) hipLaunchKernelGGL((k_assemble<true, 0>), dim3(nblk(n)), dim3(BLOCK), 0, s, v, coef, projectDBC, grad, a);
+    else hipLaunchKernelGGL((k_assemble<false, 0>), dim3(nblk(n)), dim3(BLOCK), 0, s, v, coef, projectDBC, grad, a);
 }
 const char* assemble_kernel_name() { return "k_assemble"; }
 

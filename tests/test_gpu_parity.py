@@ -183,35 +183,64 @@ def test_diagnostic_known_answer_through_c_abi(gpu_lib):
     c.close()
 
 
-def test_newton_iterates_track_the_oracle(orc, gpu_lib):
-    V, F = scene.make_bar(12, 2, 2, size=(5.0, 0.5, 1.0))
-    left, right = scene.border_verts(V, 0.01)
+def _pair_optimizers(orc, gpu_lib, V, F, Vstart, left, right, tol=None):
     m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_V(Vstart)
     o = orc.Optimizer(m, dt=0.025, gravity=False, nthreads=4)
     o.set_twist(left, right)
-    o.precompute()
     c = gpu_lib.Context(0)
     c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vstart)
     c.opt_init(0.025, False)
     c.set_twist(left, right)
+    if tol is not None:
+        o.set_rel_tol(tol)
+        c.set_rel_tol(tol)
+    o.precompute()
     c.precompute()
-    for step in range(3):
+    return m, o, c
+
+
+def test_newton_iterates_track_the_oracle(orc, gpu_lib):
+    """Iterate-by-iterate parity from a generic (jittered, pre-twisted) state.  A generic state matters: the
+    reference's makePD2d (IglUtils.hpp:138-177) is discontinuous where psi_i + psi_j changes sign, i.e. exactly
+    at rest, so from a rest start the projected Hessian -- in the reference as well -- depends on round-off."""
+    V, F = scene.make_bar(12, 2, 2, size=(5.0, 0.5, 1.0))
+    left, right = scene.border_verts(V, 0.01)
+    Vs = scene.twist_state(scene.jitter(V, F, rel=2e-2), 0.15)
+    m, o, c = _pair_optimizers(orc, gpu_lib, V, F, Vs, left, right)
+    for step in range(2):
         o.begin_timestep()
         c.begin_timestep()
         for it in range(40):
             co, cg = o.newton_iter(), c.newton_iter()
             assert bool(co) == cg, (step, it)
             so, sg = o.state(), c.state()
-            assert relerr(sg["gradient"], so["gradient"]) < 1e-8
+            assert relerr(sg["gradient"], so["gradient"]) < 1e-7
             if co:
                 break
             assert abs(sg["E"] - so["E"]) <= 1e-9 * abs(so["E"])
             assert abs(sg["stepSize"] - so["stepSize"]) <= 1e-9 * so["stepSize"]
-            assert relerr(sg["searchDir"], so["searchDir"]) < 1e-7
+            assert relerr(sg["searchDir"], so["searchDir"]) < 1e-6
             assert relerr(sg["V"], so["V"]) < 1e-9
         o.end_timestep()
         c.end_timestep()
     assert o.state()["innerIterAmt"] == c.state()["innerIterAmt"]
+    c.close()
+
+
+def test_converged_time_steps_from_rest(orc, gpu_lib):
+    """From the rest state both implementations must reach the same minimiser of every incremental potential
+    (tight Newton tolerance), whatever path the round-off-sensitive projection sends them on."""
+    V, F = scene.make_bar(12, 2, 2, size=(5.0, 0.5, 1.0))
+    left, right = scene.border_verts(V, 0.01)
+    m, o, c = _pair_optimizers(orc, gpu_lib, V, F, V, left, right, tol=1e-7)
+    for step in range(3):
+        no, ng = o.solve_timestep(60), c.solve_timestep(60)
+        assert no < 60 and ng < 60
+        so, sg = o.state(), c.state()
+        assert relerr(sg["V"], so["V"]) < 1e-7
+        assert abs(sg["E"] - so["E"]) <= 1e-8 * abs(so["E"])
     c.close()
 
 
