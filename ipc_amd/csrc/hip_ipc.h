@@ -10,6 +10,7 @@
 #include "mf_numeric.h"
 #include "mf_symbolic.h"
 #include "nh_kernels.h"
+#include "patch_assembly.h"
 #include <map>
 #include <memory>
 
@@ -52,6 +53,7 @@ public:
     std::vector<int> rowBase, rowLen;
     DevBuf<int> d_rowBase, d_rowLen, d_edgeP0;
     int solverType = 0;
+    int patternVersion = 0; // bumped by every set_pattern*: consumers (patch plan) rebuild lazily
     hipStream_t stream;
 
     // set_pattern(vNeighbor, fixedVert) (LinSysSolver.hpp:46-150); extra = contact connectivity
@@ -124,6 +126,10 @@ public:
     void reduceSum(double* dev, long long n);
     void reduceMin(double* dev, long long n);
     double readScalar(const double* dev);
+    PatchPlan patch; // atomic-free assembly plan for the current pattern
+    int patchVersion = -1;
+    void ensurePatchPlan();
+    void patchShard(int& pb, int& pe) const;
 };
 
 } // namespace ipcgpu

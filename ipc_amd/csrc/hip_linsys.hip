@@ -117,6 +117,7 @@ void HipLinSysSolver::set_pattern(const HipMesh& mesh, int nExtra, const int* ex
     d_edgeP0.upload(edgeP0, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
     analyzed_ = false;
+    ++patternVersion;
 }
 
 void HipLinSysSolver::set_pattern_csr(int nRows, const int* ia_, const int* ja_)
@@ -138,6 +139,7 @@ void HipLinSysSolver::set_pattern_csr(int nRows, const int* ia_, const int* ja_)
     rowLen.clear();
     HIP_CHECK(hipStreamSynchronize(stream));
     analyzed_ = false;
+    ++patternVersion;
 }
 
 void HipLinSysSolver::setZero() { d_a.zero(stream); }

@@ -144,19 +144,48 @@ double HipOptimizer::computeEnergyVal()
     return readScalar(d_scalar.p);
 }
 
+void HipOptimizer::ensurePatchPlan()
+{
+    if (patchVersion == lin.patternVersion && patch.valid) return;
+    patch.build(mesh, lin, stream);
+    patchVersion = lin.patternVersion;
+}
+void HipOptimizer::patchShard(int& pb, int& pe) const
+{
+    pb = (int)((long long)patch.nPatches * rank / worldSize);
+    pe = (int)((long long)patch.nPatches * (rank + 1) / worldSize);
+}
+
 void HipOptimizer::computeGradient(bool projectDBC)
 {
-    launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
-    launch_assemble(view(), dtSq, projectDBC, d_gradient.p, nullptr, stream);
+    if (lin.rowBase.empty()) { // no pattern yet: tet-parallel atomic path
+        launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
+        launch_assemble(view(), dtSq, projectDBC, d_gradient.p, nullptr, stream);
+        reduceSum(d_gradient.p, 3LL * mesh.nV);
+        return;
+    }
+    ensurePatchPlan();
+    int pb, pe;
+    patchShard(pb, pe);
+    if (worldSize > 1) d_gradient.zero(stream);
+    launch_assemble_patches(view(), patch, pb, pe, dtSq, projectDBC, d_gradient.p, nullptr, stream);
     reduceSum(d_gradient.p, 3LL * mesh.nV);
 }
 
 void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
 {
     if (lin.rowBase.empty()) throw StateError("computePrecondMtr needs a pattern built by set_pattern");
-    lin.setZero(); // Optimizer.cpp:3616
-    launch_node_init(view(), projectDBC, rank == 0, lin.d_a.p, withGradient ? d_gradient.p : nullptr, stream);
-    launch_assemble(view(), dtSq, projectDBC, withGradient ? d_gradient.p : nullptr, lin.d_a.p, stream);
+    // setZero (Optimizer.cpp:3616), elastic Hessian (:3619-3623) and the mass / DBC diagonal (:3638-3668) are one
+    // pass: every owned CSR row is written exactly once by the patch that owns its node
+    ensurePatchPlan();
+    int pb, pe;
+    patchShard(pb, pe);
+    if (worldSize > 1) {
+        lin.setZero();
+        if (withGradient) d_gradient.zero(stream);
+    }
+    launch_assemble_patches(view(), patch, pb, pe, dtSq, projectDBC, withGradient ? d_gradient.p : nullptr,
+        lin.d_a.p, stream);
     if (worldSize > 1) {
         reduceSum(lin.d_a.p, (long long)lin.ja.size());
         if (withGradient) reduceSum(d_gradient.p, 3LL * mesh.nV);
