@@ -282,3 +282,13 @@ class Optimizer:
         t = np.zeros(16)
         lib().orc_opt_timers(self.h, _dp(t))
         return t
+
+
+def assemble_shard(mesh: "Mesh", nnz, coef, projectDBC, t0, t1, owner, xTilde):
+    """Elasticity of the tets [t0, t1) (+ nodal terms when owner) -- one rank's share of a sharded assembly."""
+    xt = np.asfortranarray(xTilde, dtype=np.float64)
+    a = np.zeros(nnz)
+    g = np.zeros(3 * mesh.nV)
+    lib().orc_assemble_shard(mesh.h, C.c_double(coef), C.c_int(int(projectDBC)), C.c_int(t0), C.c_int(t1),
+                             C.c_int(int(owner)), _dp(xt), _dp(a), _dp(g))
+    return a, g

@@ -610,3 +610,42 @@ void orc_csr_symv(const orc_mesh* h, const double* a, const double* x, double* y
 void orc_inversion_step(const orc_mesh* h, const double* p, double slackness, double* out) { inversionStep(h->m, p, slackness, out); }
 double orc_filter_step_size(const orc_mesh* h, const double* p, double stepSize) { return filterStepSize(h->m, p, stepSize); }
 }
+
+// ---- element-sharded assembly (what each rank of a multi-GPU run computes; the ranks' results are summed by an
+// all-reduce).  Elasticity of the tets [t0, t1) only; the nodal terms (mass / DBC identity on the diagonal, inertia
+// part of the gradient, Optimizer.cpp:3438-3450, 3638-3668) are contributed by the rank with owner != 0.
+extern "C" void orc_assemble_shard(const orc_mesh* h, double coef, int projectDBC, int t0, int t1, int owner,
+    const double* xTilde_colmajor, double* a, double* grad)
+{
+    const Mesh& m = h->m;
+    const size_t nnz = m.ja.size();
+    for (size_t i = 0; i < nnz; ++i) a[i] = 0;
+    for (int i = 0; i < 3 * m.nV; ++i) grad[i] = 0;
+    for (int t = t0; t < t1; ++t) {
+        double H[144], g[12];
+        int vInd[4];
+        elemHessian(m, t, coef, true, H);
+        elemGradient(m, t, coef, g);
+        for (int k = 0; k < 4; ++k) {
+            int v = m.Fi(t, k);
+            vInd[k] = m.isProjectDBC(v, projectDBC != 0) ? (-v - 1) : v;
+            if (!(projectDBC && m.dbcType[v] != 0))
+                for (int c = 0; c < 3; ++c) grad[3 * v + c] += g[3 * k + c];
+        }
+        for (int k = 0; k < 4; ++k)
+            if (vInd[k] >= 0) addBlockToMatrix(m, a, H, vInd, k); // identity rows come from the owner below
+    }
+    if (owner) {
+        for (int v = 0; v < m.nV; ++v) {
+            const bool proj = m.isProjectDBC(v, projectDBC != 0);
+            for (int c = 0; c < 3; ++c) {
+                int k = m.findEntry(3 * v + c, 3 * v + c);
+                if (proj) a[k] = 1.0;
+                else {
+                    a[k] += m.mass[v];
+                    grad[3 * v + c] += m.mass[v] * (m.V[v + m.nV * c] - xTilde_colmajor[v + m.nV * c]);
+                }
+            }
+        }
+    }
+}
