@@ -292,3 +292,110 @@ def assemble_shard(mesh: "Mesh", nnz, coef, projectDBC, t0, t1, owner, xTilde):
     lib().orc_assemble_shard(mesh.h, C.c_double(coef), C.c_int(int(projectDBC)), C.c_int(t0), C.c_int(t1),
                              C.c_int(int(owner)), _dp(xt), _dp(a), _dp(g))
     return a, g
+
+
+# ---- contact (orc_contact.cpp) --------------------------------------------------------------------------------
+K_PP, K_PE, K_PT, K_EE = 0, 1, 2, 3
+
+
+def stencil_distance(kind, X, derivs=True):
+    """X: (4,3) node positions (unused rows ignored).  Returns d, g (12), H (12,12)."""
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
+    d = C.c_double()
+    g = np.zeros(12)
+    H = np.zeros((12, 12), order="F")
+    lib().orc_stencil_distance(C.c_int(kind), _dp(X), C.byref(d), _dp(g) if derivs else None, _dp(H) if derivs else None)
+    return d.value, g, H
+
+
+def cross_sqnorm(X):
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
+    c = C.c_double()
+    g = np.zeros(12)
+    H = np.zeros((12, 12), order="F")
+    lib().orc_cross_sqnorm(_dp(X), C.byref(c), _dp(g), _dp(H))
+    return c.value, g, H
+
+
+def barrier(d, dHat):
+    b, gb, Hb = C.c_double(), C.c_double(), C.c_double()
+    lib().orc_barrier(C.c_double(d), C.c_double(dHat), C.byref(b), C.byref(gb), C.byref(Hb))
+    return b.value, gb.value, Hb.value
+
+
+def mollifier(c, eps_x):
+    e, eg, eH = C.c_double(), C.c_double(), C.c_double()
+    lib().orc_mollifier(C.c_double(c), C.c_double(eps_x), C.byref(e), C.byref(eg), C.byref(eH))
+    return e.value, eg.value, eH.value
+
+
+def dtype_pt(X):
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
+    return int(lib().orc_dtype_pt(_dp(X)))
+
+
+def dtype_ee(X):
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
+    return int(lib().orc_dtype_ee(_dp(X)))
+
+
+class Contacts:
+    """MMActiveSet / paraEEMMCVIDSet / paraEEeIeJSet of one self-collision handler."""
+
+    def __init__(self):
+        lib().orc_contacts_create.restype = C.c_void_p
+        lib().orc_contact_energy.restype = C.c_double
+        self.h = C.c_void_p(lib().orc_contacts_create())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_contacts_destroy(self.h)
+            self.h = None
+
+    def build(self, mesh: "Mesh", dHat, brute=False):
+        lib().orc_contacts_build(self.h, mesh.h, C.c_double(dHat), C.c_int(int(brute)))
+        return self.get()
+
+    def set(self, active, para=None, para_eiej=None):
+        a = np.ascontiguousarray(active, dtype=np.int32).reshape(-1, 4)
+        p = np.ascontiguousarray(para if para is not None else np.zeros((0, 4)), dtype=np.int32).reshape(-1, 4)
+        q = np.ascontiguousarray(para_eiej if para_eiej is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
+        lib().orc_contacts_set(self.h, C.c_int(a.shape[0]), _ip(a), C.c_int(p.shape[0]), _ip(p), _ip(q))
+
+    def get(self):
+        n = np.zeros(3, dtype=np.int32)
+        lib().orc_contacts_sizes(self.h, _ip(n))
+        a = np.zeros((n[0], 4), dtype=np.int32)
+        p = np.zeros((n[1], 4), dtype=np.int32)
+        q = np.zeros((n[1], 2), dtype=np.int32)
+        cs = np.zeros((n[2], 2), dtype=np.int32)
+        lib().orc_contacts_get(self.h, _ip(a), _ip(p), _ip(q), _ip(cs))
+        return dict(active=a, para=p, para_eiej=q, cs_ptee=cs)
+
+    def energy(self, mesh, dHat, kappa):
+        return lib().orc_contact_energy(self.h, mesh.h, C.c_double(dHat), C.c_double(kappa))
+
+    def gradient(self, mesh, dHat, kappa, projectDBC=True):
+        g = np.zeros(3 * mesh.nV)
+        lib().orc_contact_gradient(self.h, mesh.h, C.c_double(dHat), C.c_double(kappa), C.c_int(int(projectDBC)), _dp(g))
+        return g
+
+    def hessian(self, mesh, nnz, dHat, kappa, projectDBC=True):
+        a = np.zeros(nnz)
+        lib().orc_contact_hessian(self.h, mesh.h, C.c_double(dHat), C.c_double(kappa), C.c_int(int(projectDBC)), _dp(a))
+        return a
+
+    def connectivity(self, mesh):
+        cap = 1 << 20
+        buf = np.zeros((cap, 2), dtype=np.int32)
+        n = lib().orc_contact_connectivity(self.h, mesh.h, C.c_int(cap), _ip(buf))
+        return buf[:n].copy()
+
+
+def mesh_surface(mesh: "Mesh"):
+    n = np.zeros(3, dtype=np.int32)
+    lib().orc_mesh_surface_counts(mesh.h, _ip(n))
+    svi = np.zeros(n[0], dtype=np.int32)
+    sfe = np.zeros((n[2], 2), dtype=np.int32)
+    lib().orc_mesh_get_surface(mesh.h, _ip(svi), _ip(sfe))
+    return svi, sfe

@@ -1,0 +1,849 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_api.h, orc_contact.h).
+#include "orc_contact.h"
+#include "orc_api.h"
+#include <cassert>
+#include <cstdio>
+#include <algorithm>
+#include <initializer_list>
+#include <map>
+
+namespace orc {
+
+namespace {
+inline void cross3(const double* a, const double* b, double* c)
+{
+    c[0] = a[1] * b[2] - a[2] * b[1];
+    c[1] = a[2] * b[0] - a[0] * b[2];
+    c[2] = a[0] * b[1] - a[1] * b[0];
+}
+inline double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+inline void sub3(const double* a, const double* b, double* c)
+{
+    c[0] = a[0] - b[0];
+    c[1] = a[1] - b[1];
+    c[2] = a[2] - b[2];
+}
+// S += sgn * [a]x placed at block (r, c) of a 9x9 column-major matrix ([a]x b = a x b)
+inline void addSkew(double* H9, int r, int c, const double* a, double sgn)
+{
+    auto at = [&](int i, int j) -> double& { return H9[(3 * r + i) + 9 * (3 * c + j)]; };
+    at(0, 1) += -sgn * a[2];
+    at(0, 2) += sgn * a[1];
+    at(1, 0) += sgn * a[2];
+    at(1, 2) += -sgn * a[0];
+    at(2, 0) += -sgn * a[1];
+    at(2, 1) += sgn * a[0];
+}
+
+// q(e,f) = |e x f|^2 : gradient (entries 3..8 of a (w,e,f) 9-vector) and Hessian blocks
+void q_derivs(const double* e, const double* f, double* q, double* gq9, double* Hq81)
+{
+    double n[3];
+    cross3(e, f, n);
+    *q = dot3(n, n);
+    for (int i = 0; i < 9; ++i) gq9[i] = 0;
+    for (int i = 0; i < 81; ++i) Hq81[i] = 0;
+    double fxn[3], nxe[3];
+    cross3(f, n, fxn);
+    cross3(n, e, nxe);
+    for (int i = 0; i < 3; ++i) {
+        gq9[3 + i] = 2 * fxn[i];
+        gq9[6 + i] = 2 * nxe[i];
+    }
+    const double ee = dot3(e, e), ff = dot3(f, f), ef = dot3(e, f);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const double dij = (i == j) ? 1.0 : 0.0;
+            Hq81[(3 + i) + 9 * (3 + j)] = 2 * ff * dij - 2 * f[i] * f[j];
+            Hq81[(6 + i) + 9 * (6 + j)] = 2 * ee * dij - 2 * e[i] * e[j];
+            const double v = 4 * e[i] * f[j] - 2 * f[i] * e[j] - 2 * ef * dij;
+            Hq81[(3 + i) + 9 * (6 + j)] = v;
+            Hq81[(6 + j) + 9 * (3 + i)] = v;
+        }
+}
+
+// chain rule from (w,e,f) space to node coordinates: coef[u][k] in {-1,0,+1}
+void expand(int nNodes, const int coef[3][4], const double* G9, const double* H81, double* g, double* H)
+{
+    if (g)
+        for (int k = 0; k < nNodes; ++k)
+            for (int i = 0; i < 3; ++i) {
+                double s = 0;
+                for (int u = 0; u < 3; ++u) s += coef[u][k] * G9[3 * u + i];
+                g[3 * k + i] = s;
+            }
+    if (H) {
+        for (int i = 0; i < 144; ++i) H[i] = 0;
+        for (int k = 0; k < nNodes; ++k)
+            for (int l = 0; l < nNodes; ++l)
+                for (int u = 0; u < 3; ++u) {
+                    if (!coef[u][k]) continue;
+                    for (int v = 0; v < 3; ++v) {
+                        if (!coef[v][l]) continue;
+                        const double c = coef[u][k] * coef[v][l];
+                        for (int i = 0; i < 3; ++i)
+                            for (int j = 0; j < 3; ++j) H[(3 * k + i) + 12 * (3 * l + j)] += c * H81[(3 * u + i) + 9 * (3 * v + j)];
+                    }
+                }
+    }
+}
+} // namespace
+
+int stencil_nodes(int kind) { return kind == K_PP ? 2 : (kind == K_PE ? 3 : 4); }
+
+void stencil_distance(int kind, const double X[4][3], double* d, double* g, double* H)
+{
+    if (kind == K_PP) {
+        double r[3];
+        sub3(X[0], X[1], r);
+        *d = dot3(r, r);
+        if (g)
+            for (int i = 0; i < 3; ++i) {
+                g[i] = 2 * r[i];
+                g[3 + i] = -2 * r[i];
+            }
+        if (H) {
+            for (int i = 0; i < 144; ++i) H[i] = 0;
+            for (int i = 0; i < 3; ++i) {
+                H[i + 12 * i] = H[(3 + i) + 12 * (3 + i)] = 2.0;
+                H[i + 12 * (3 + i)] = H[(3 + i) + 12 * i] = -2.0;
+            }
+        }
+        return;
+    }
+    if (kind == K_PE) {
+        double e[3], f[3], gd[3];
+        sub3(X[1], X[0], e);
+        sub3(X[2], X[0], f);
+        sub3(f, e, gd); // v2 - v1
+        double q, gq[9], Hq[81];
+        q_derivs(e, f, &q, gq, Hq);
+        const double r = dot3(gd, gd);
+        *d = q / r;
+        if (!g && !H) return;
+        double gr[9] = { 0, 0, 0, -2 * gd[0], -2 * gd[1], -2 * gd[2], 2 * gd[0], 2 * gd[1], 2 * gd[2] };
+        double G9[9], H81[81];
+        for (int i = 0; i < 9; ++i) G9[i] = gq[i] / r - (q / (r * r)) * gr[i];
+        for (int i = 0; i < 9; ++i)
+            for (int j = 0; j < 9; ++j) {
+                double Hr = 0;
+                if (i >= 3 && j >= 3) {
+                    const int bi = (i - 3) / 3, bj = (j - 3) / 3, ci = (i - 3) % 3, cj = (j - 3) % 3;
+                    if (ci == cj) Hr = (bi == bj) ? 2.0 : -2.0;
+                }
+                H81[i + 9 * j] = Hq[i + 9 * j] / r - (gq[i] * gr[j] + gr[i] * gq[j]) / (r * r) + (2 * q / (r * r * r)) * gr[i] * gr[j]
+                    - (q / (r * r)) * Hr;
+            }
+        static const int coef[3][4] = { { 0, 0, 0, 0 }, { -1, 1, 0, 0 }, { -1, 0, 1, 0 } };
+        expand(3, coef, G9, H81, g, H);
+        return;
+    }
+    // PT / EE:  d = (w . n)^2 / |n|^2
+    double w[3], e[3], f[3];
+    if (kind == K_PT) {
+        sub3(X[0], X[1], w);
+        sub3(X[2], X[1], e);
+        sub3(X[3], X[1], f);
+    }
+    else {
+        sub3(X[2], X[0], w);
+        sub3(X[1], X[0], e);
+        sub3(X[3], X[2], f);
+    }
+    double n[3];
+    cross3(e, f, n);
+    const double s = dot3(w, n);
+    double q, gq[9], Hq[81];
+    q_derivs(e, f, &q, gq, Hq);
+    *d = s * s / q;
+    if (!g && !H) return;
+    double fxw[3], wxe[3];
+    cross3(f, w, fxw);
+    cross3(w, e, wxe);
+    double gs[9] = { n[0], n[1], n[2], fxw[0], fxw[1], fxw[2], wxe[0], wxe[1], wxe[2] };
+    double Hs[81];
+    for (int i = 0; i < 81; ++i) Hs[i] = 0;
+    addSkew(Hs, 0, 1, f, -1.0); // d n / d e = -[f]x
+    addSkew(Hs, 1, 0, f, 1.0);
+    addSkew(Hs, 0, 2, e, 1.0); // d n / d f = [e]x
+    addSkew(Hs, 2, 0, e, -1.0);
+    addSkew(Hs, 1, 2, w, -1.0); // d (f x w) / d f = -[w]x
+    addSkew(Hs, 2, 1, w, 1.0);
+    double G9[9], H81[81];
+    const double c1 = 2 * s / q, c2 = s * s / (q * q);
+    for (int i = 0; i < 9; ++i) G9[i] = c1 * gs[i] - c2 * gq[i];
+    for (int i = 0; i < 9; ++i)
+        for (int j = 0; j < 9; ++j)
+            H81[i + 9 * j] = (2 / q) * gs[i] * gs[j] + c1 * Hs[i + 9 * j] - (2 * s / (q * q)) * (gs[i] * gq[j] + gq[i] * gs[j])
+                + (2 * s * s / (q * q * q)) * gq[i] * gq[j] - c2 * Hq[i + 9 * j];
+    static const int coefPT[3][4] = { { 1, -1, 0, 0 }, { 0, -1, 1, 0 }, { 0, -1, 0, 1 } };
+    static const int coefEE[3][4] = { { -1, 0, 1, 0 }, { -1, 1, 0, 0 }, { 0, 0, -1, 1 } };
+    expand(4, kind == K_PT ? coefPT : coefEE, G9, H81, g, H);
+}
+
+void cross_sqnorm(const double X[4][3], double* c, double* g, double* H)
+{
+    double e[3], f[3];
+    sub3(X[1], X[0], e);
+    sub3(X[3], X[2], f);
+    double gq[9], Hq[81];
+    q_derivs(e, f, c, gq, Hq);
+    static const int coef[3][4] = { { 0, 0, 0, 0 }, { -1, 1, 0, 0 }, { 0, 0, -1, 1 } };
+    expand(4, coef, gq, Hq, g, H);
+}
+
+void barrier(double d, double dHat, double* b, double* gb, double* Hb)
+{
+    const double t2 = d - dHat, lg = std::log(d / dHat);
+    if (b) *b = -t2 * t2 * lg;
+    if (gb) *gb = t2 * lg * -2.0 - (t2 * t2) / d;
+    if (Hb) *Hb = (lg * -2.0 - t2 * 4.0 / d) + 1.0 / (d * d) * (t2 * t2);
+}
+
+void mollifier(double c, double eps_x, double* e, double* eg, double* eH)
+{
+    if (c < eps_x) {
+        const double r = c / eps_x;
+        if (e) *e = (-r + 2.0) * r;
+        if (eg) *eg = 2.0 * (1.0 / eps_x) * (-(1.0 / eps_x) * c + 1.0);
+        if (eH) *eH = -2.0 / (eps_x * eps_x);
+    }
+    else {
+        if (e) *e = 1.0;
+        if (eg) *eg = 0.0;
+        if (eH) *eH = 0.0;
+    }
+}
+
+// 2x2 normal equations of dType_PT: parameters (s, t) of v0 in the frame {e, e x n} anchored at the edge start
+static void edgeFrameParam(const double* e, const double* nVec, const double* r, double* p0, double* p1)
+{
+    double b1[3];
+    cross3(e, nVec, b1);
+    const double m00 = dot3(e, e), m01 = dot3(e, b1), m11 = dot3(b1, b1);
+    const double r0 = dot3(e, r), r1 = dot3(b1, r);
+    const double det = m00 * m11 - m01 * m01;
+    *p0 = (r0 * m11 - r1 * m01) / det;
+    *p1 = (m00 * r1 - m01 * r0) / det;
+}
+
+int dType_PT(const double v0[3], const double v1[3], const double v2[3], const double v3[3])
+{
+    double e0[3], e1[3], nVec[3], r[3];
+    sub3(v2, v1, e0);
+    sub3(v3, v1, e1);
+    cross3(e0, e1, nVec);
+    double p00, p10, p01, p11, p02, p12;
+    sub3(v0, v1, r);
+    edgeFrameParam(e0, nVec, r, &p00, &p10);
+    if (p00 > 0.0 && p00 < 1.0 && p10 >= 0.0) return 3; // PE v1v2
+    double e[3];
+    sub3(v3, v2, e);
+    sub3(v0, v2, r);
+    edgeFrameParam(e, nVec, r, &p01, &p11);
+    if (p01 > 0.0 && p01 < 1.0 && p11 >= 0.0) return 4; // PE v2v3
+    sub3(v1, v3, e);
+    sub3(v0, v3, r);
+    edgeFrameParam(e, nVec, r, &p02, &p12);
+    if (p02 > 0.0 && p02 < 1.0 && p12 >= 0.0) return 5; // PE v3v1
+    if (p00 <= 0.0 && p02 >= 1.0) return 0; // PP v1
+    if (p01 <= 0.0 && p00 >= 1.0) return 1; // PP v2
+    if (p02 <= 0.0 && p01 >= 1.0) return 2; // PP v3
+    return 6; // PT
+}
+
+int dType_EE(const double v0[3], const double v1[3], const double v2[3], const double v3[3])
+{
+    double u[3], v[3], w[3];
+    sub3(v1, v0, u);
+    sub3(v3, v2, v);
+    sub3(v0, v2, w);
+    const double a = dot3(u, u), b = dot3(u, v), c = dot3(v, v), d = dot3(u, w), e = dot3(v, w);
+    const double D = a * c - b * b;
+    double tD = D, sN, tN;
+    int defaultCase = 8;
+    sN = (b * e - c * d);
+    if (sN <= 0.0) {
+        tN = e;
+        tD = c;
+        defaultCase = 2;
+    }
+    else if (sN >= D) {
+        tN = e + b;
+        tD = c;
+        defaultCase = 5;
+    }
+    else {
+        tN = (a * e - b * d);
+        double uxv[3];
+        cross3(u, v, uxv);
+        if (tN > 0.0 && tN < tD && (dot3(uxv, w) == 0.0 || dot3(uxv, uxv) < 1.0e-20 * a * c)) {
+            if (sN < D / 2) {
+                tN = e;
+                tD = c;
+                defaultCase = 2;
+            }
+            else {
+                tN = e + b;
+                tD = c;
+                defaultCase = 5;
+            }
+        }
+    }
+    if (tN <= 0.0) {
+        if (-d <= 0.0) return 0;
+        else if (-d >= a) return 3;
+        else return 6;
+    }
+    else if (tN >= tD) {
+        if ((-d + b) <= 0.0) return 1;
+        else if ((-d + b) >= a) return 4;
+        else return 7;
+    }
+    return defaultCase;
+}
+
+// ---- stencils of an MMCVID ------------------------------------------------------------------------------------
+struct Stencil {
+    int kind, n, node[4];
+    double mult;
+};
+static Stencil decode(const MMCVID& c)
+{
+    Stencil s;
+    s.mult = 1.0;
+    if (c[0] >= 0) {
+        s.kind = K_EE;
+        s.n = 4;
+        for (int i = 0; i < 4; ++i) s.node[i] = c[i];
+    }
+    else {
+        const int v0 = -c[0] - 1;
+        s.node[0] = v0;
+        s.node[1] = c[1];
+        if (c[2] < 0) {
+            s.kind = K_PP;
+            s.n = 2;
+            s.mult = -c[3];
+        }
+        else if (c[3] < 0) {
+            s.kind = K_PE;
+            s.n = 3;
+            s.node[2] = c[2];
+            s.mult = -c[3];
+        }
+        else {
+            s.kind = K_PT;
+            s.n = 4;
+            s.node[2] = c[2];
+            s.node[3] = c[3];
+        }
+    }
+    return s;
+}
+static void gatherX(const Mesh& m, const int* node, int n, double X[4][3])
+{
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < 3; ++c) X[k][c] = m.Vx(node[k], c);
+}
+static double eps_x_of(const Mesh& m, int a0, int a1, int b0, int b1)
+{
+    // MeshCollisionUtils.hpp:2969-2974 (rest lengths)
+    double la = 0, lb = 0;
+    for (int c = 0; c < 3; ++c) {
+        const double da = m.V_rest[a0 + m.nV * c] - m.V_rest[a1 + m.nV * c];
+        const double db = m.V_rest[b0 + m.nV * c] - m.V_rest[b1 + m.nV * c];
+        la += da * da;
+        lb += db * db;
+    }
+    return 1.0e-3 * la * lb;
+}
+// the four nodes the mollifier of paraEE entry i acts on
+static void paraNodes(const Mesh& m, const ContactSets& cs, size_t i, int en[4])
+{
+    const MMCVID& c = cs.paraEE[i];
+    if (c[3] >= 0) {
+        for (int k = 0; k < 4; ++k) en[k] = c[k];
+    }
+    else {
+        const auto& ij = cs.paraEEeIeJ[i];
+        en[0] = m.SFEdges[ij[0]].first;
+        en[1] = m.SFEdges[ij[0]].second;
+        en[2] = m.SFEdges[ij[1]].first;
+        en[3] = m.SFEdges[ij[1]].second;
+    }
+}
+
+double contactEnergy(const Mesh& m, const ContactSets& cs, double dHat, double kappa)
+{
+    std::vector<double> bVals(cs.active.size() + cs.paraEE.size());
+    for (size_t i = 0; i < cs.active.size(); ++i) {
+        Stencil s = decode(cs.active[i]);
+        double X[4][3], d, b;
+        gatherX(m, s.node, s.n, X);
+        stencil_distance(s.kind, X, &d, nullptr, nullptr);
+        barrier(d, dHat, &b, nullptr, nullptr);
+        bVals[i] = b * s.mult; // duplication (Optimizer.cpp:3309-3313)
+    }
+    for (size_t i = 0; i < cs.paraEE.size(); ++i) {
+        Stencil s = decode(cs.paraEE[i]);
+        s.mult = 1.0;
+        double X[4][3], d, b, c, e;
+        gatherX(m, s.node, s.n, X);
+        stencil_distance(s.kind, X, &d, nullptr, nullptr);
+        barrier(d, dHat, &b, nullptr, nullptr);
+        int en[4];
+        paraNodes(m, cs, i, en);
+        double XE[4][3];
+        gatherX(m, en, 4, XE);
+        cross_sqnorm(XE, &c, nullptr, nullptr);
+        mollifier(c, eps_x_of(m, en[0], en[1], en[2], en[3]), &e, nullptr, nullptr);
+        bVals[cs.active.size() + i] = b * e;
+    }
+    double sum = 0;
+    for (double v : bVals) sum += v;
+    return kappa * sum;
+}
+
+void contactGradient(const Mesh& m, const ContactSets& cs, double dHat, double kappa, bool projectDBC, double* grad)
+{
+    for (size_t i = 0; i < cs.active.size(); ++i) {
+        Stencil s = decode(cs.active[i]);
+        double X[4][3], d, g[12], gb;
+        gatherX(m, s.node, s.n, X);
+        stencil_distance(s.kind, X, &d, g, nullptr);
+        barrier(d, dHat, nullptr, &gb, nullptr);
+        const double coef = kappa * s.mult * gb;
+        for (int k = 0; k < s.n; ++k)
+            for (int c = 0; c < 3; ++c) grad[3 * s.node[k] + c] += coef * g[3 * k + c];
+    }
+    for (size_t i = 0; i < cs.paraEE.size(); ++i) {
+        Stencil s = decode(cs.paraEE[i]);
+        double X[4][3], d, g[12], b, gb;
+        gatherX(m, s.node, s.n, X);
+        stencil_distance(s.kind, X, &d, g, nullptr);
+        barrier(d, dHat, &b, &gb, nullptr);
+        int en[4];
+        paraNodes(m, cs, i, en);
+        double XE[4][3], c, cg[12], e, eg;
+        gatherX(m, en, 4, XE);
+        cross_sqnorm(XE, &c, cg, nullptr);
+        mollifier(c, eps_x_of(m, en[0], en[1], en[2], en[3]), &e, &eg, nullptr);
+        for (int k = 0; k < 4; ++k)
+            for (int cc = 0; cc < 3; ++cc) grad[3 * en[k] + cc] += kappa * b * eg * cg[3 * k + cc];
+        for (int k = 0; k < s.n; ++k)
+            for (int cc = 0; cc < 3; ++cc) grad[3 * s.node[k] + cc] += kappa * e * gb * g[3 * k + cc];
+    }
+    for (int v = 0; v < m.nV; ++v)
+        if (m.isDBC(v) && m.isProjectDBC(v, projectDBC))
+            for (int c = 0; c < 3; ++c) grad[3 * v + c] = 0; // Optimizer.cpp:3512-3516
+}
+
+static void scatterBlockHessian(const Mesh& m, double* a, const double* H /*12x12*/, const int* node, int n, bool projectDBC)
+{
+    for (int i = 0; i < n; ++i) {
+        if (m.isProjectDBC(node[i], projectDBC)) continue;
+        for (int j = 0; j < n; ++j) {
+            if (m.isProjectDBC(node[j], projectDBC)) continue;
+            for (int r = 0; r < 3; ++r)
+                for (int c = 0; c < 3; ++c) {
+                    const int row = 3 * node[i] + r, col = 3 * node[j] + c;
+                    if (row <= col) { // LinSysSolver.hpp:402-410
+                        const int k = m.findEntry(row, col);
+                        assert(k >= 0);
+                        a[k] += H[(3 * i + r) + 12 * (3 * j + c)];
+                    }
+                }
+        }
+    }
+}
+
+void contactHessian(const Mesh& m, const ContactSets& cs, double dHat, double kappa, bool projectDBC, double* a)
+{
+    for (size_t i = 0; i < cs.active.size(); ++i) {
+        Stencil s = decode(cs.active[i]);
+        double X[4][3], d, g[12], H[144], gb, Hb;
+        gatherX(m, s.node, s.n, X);
+        stencil_distance(s.kind, X, &d, g, H);
+        barrier(d, dHat, nullptr, &gb, &Hb);
+        const int n3 = 3 * s.n;
+        const double cf = kappa * s.mult;
+        std::vector<double> B((size_t)n3 * n3);
+        for (int r = 0; r < n3; ++r)
+            for (int c = 0; c < n3; ++c) B[r + n3 * c] = ((cf * Hb) * g[r]) * g[c] + (cf * gb) * H[r + 12 * c];
+        make_pd(n3, B.data());
+        double H12[144];
+        for (int r = 0; r < n3; ++r)
+            for (int c = 0; c < n3; ++c) H12[r + 12 * c] = B[r + n3 * c];
+        scatterBlockHessian(m, a, H12, s.node, s.n, projectDBC);
+    }
+    for (size_t i = 0; i < cs.paraEE.size(); ++i) {
+        Stencil s = decode(cs.paraEE[i]);
+        double X[4][3], d, gS[12], HS[144], b, gb, Hb;
+        gatherX(m, s.node, s.n, X);
+        stencil_distance(s.kind, X, &d, gS, HS);
+        barrier(d, dHat, &b, &gb, &Hb);
+        int en[4];
+        paraNodes(m, cs, i, en);
+        double XE[4][3], c, cg[12], cH[144], e, eg, eH;
+        gatherX(m, en, 4, XE);
+        cross_sqnorm(XE, &c, cg, cH);
+        mollifier(c, eps_x_of(m, en[0], en[1], en[2], en[3]), &e, &eg, &eH);
+        // distance derivatives mapped onto the four edge nodes (SelfCollisionHandler.cpp:3105-3160)
+        double gd[12] = { 0 }, Hd[144] = { 0 };
+        int imap[4];
+        for (int k = 0; k < s.n; ++k) {
+            imap[k] = -1;
+            for (int q = 0; q < 4; ++q)
+                if (en[q] == s.node[k]) imap[k] = q;
+            assert(imap[k] >= 0);
+        }
+        for (int k = 0; k < s.n; ++k)
+            for (int cc = 0; cc < 3; ++cc) gd[3 * imap[k] + cc] = gS[3 * k + cc];
+        for (int k = 0; k < s.n; ++k)
+            for (int l = 0; l < s.n; ++l)
+                for (int r = 0; r < 3; ++r)
+                    for (int cc = 0; cc < 3; ++cc) Hd[(3 * imap[k] + r) + 12 * (3 * imap[l] + cc)] = HS[(3 * k + r) + 12 * (3 * l + cc)];
+        double B[144];
+        for (int r = 0; r < 12; ++r)
+            for (int cc = 0; cc < 12; ++cc) {
+                const double e_g_r = eg * cg[r], e_g_c = eg * cg[cc];
+                const double e_H = eg * cH[r + 12 * cc] + eH * cg[r] * cg[cc]; // compute_e_H (MeshCollisionUtils.hpp:2889-2912)
+                B[r + 12 * cc] = (kappa * gb) * gd[r] * e_g_c + (kappa * gb) * gd[cc] * e_g_r + (kappa * b) * e_H
+                    + ((kappa * e * Hb) * gd[r]) * gd[cc] + (kappa * e * gb) * Hd[r + 12 * cc];
+            }
+        make_pd(12, B);
+        scatterBlockHessian(m, a, B, en, 4, projectDBC);
+    }
+}
+
+void contactConnectivity(const Mesh& m, const ContactSets& cs, std::vector<std::pair<int, int>>& pairs)
+{
+    pairs.clear();
+    auto link = [&](int a, int b) {
+        if (a != b) pairs.push_back({ std::min(a, b), std::max(a, b) });
+    };
+    for (const auto& c : cs.active) {
+        Stencil s = decode(c);
+        if (s.kind == K_EE) {
+            link(s.node[0], s.node[2]);
+            link(s.node[0], s.node[3]);
+            link(s.node[1], s.node[2]);
+            link(s.node[1], s.node[3]);
+        }
+        else
+            for (int k = 1; k < s.n; ++k) link(s.node[0], s.node[k]);
+    }
+    for (size_t i = 0; i < cs.paraEE.size(); ++i) {
+        int en[4];
+        paraNodes(m, cs, i, en);
+        link(en[0], en[2]);
+        link(en[0], en[3]);
+        link(en[1], en[2]);
+        link(en[1], en[3]);
+    }
+    std::sort(pairs.begin(), pairs.end());
+    pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+}
+
+// ---- constraint set ------------------------------------------------------------------------------------------
+void computeConstraintSet(const Mesh& m, double dHat, bool brute, ContactSets& out)
+{
+    const int nSVI = (int)m.SVI.size(), nSF = m.nSF, nE = (int)m.SFEdges.size();
+    auto P = [&](int v, double* x) {
+        for (int c = 0; c < 3; ++c) x[c] = m.Vx(v, c);
+    };
+    // candidate generation
+    std::vector<std::vector<int>> candPT(nSVI), candEE(nE);
+    const double sq = std::sqrt(dHat);
+    if (brute) {
+        for (int i = 0; i < nSVI; ++i) {
+            candPT[i].resize(nSF);
+            for (int f = 0; f < nSF; ++f) candPT[i][f] = f;
+        }
+        for (int i = 0; i < nE; ++i)
+            for (int j = i + 1; j < nE; ++j) candEE[i].push_back(j);
+    }
+    else {
+        // uniform grid over the current bounding box; cell ~ average rest edge length (SpatialHash.hpp:46-229 role)
+        double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+        for (int v = 0; v < m.nV; ++v)
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = std::min(lo[c], m.Vx(v, c));
+                hi[c] = std::max(hi[c], m.Vx(v, c));
+            }
+        const double h = std::max(m.avgEdgeLen, 2.0 * sq);
+        int dim[3];
+        for (int c = 0; c < 3; ++c) dim[c] = std::max(1, (int)std::floor((hi[c] - lo[c]) / h) + 1);
+        auto cellOf = [&](double x, int c) { return std::min(dim[c] - 1, std::max(0, (int)std::floor((x - lo[c]) / h))); };
+        const size_t nCells = (size_t)dim[0] * dim[1] * dim[2];
+        std::vector<std::vector<int>> triCells(nCells), edgeCells(nCells);
+        auto forBox = [&](const double* bl, const double* bh, auto&& fn) {
+            int a[3], b[3];
+            for (int c = 0; c < 3; ++c) {
+                a[c] = cellOf(bl[c], c);
+                b[c] = cellOf(bh[c], c);
+            }
+            for (int z = a[2]; z <= b[2]; ++z)
+                for (int y = a[1]; y <= b[1]; ++y)
+                    for (int x = a[0]; x <= b[0]; ++x) fn((size_t)x + (size_t)dim[0] * (y + (size_t)dim[1] * z));
+        };
+        for (int f = 0; f < nSF; ++f) {
+            double bl[3] = { 1e300, 1e300, 1e300 }, bh[3] = { -1e300, -1e300, -1e300 };
+            for (int k = 0; k < 3; ++k)
+                for (int c = 0; c < 3; ++c) {
+                    const double x = m.Vx(m.SF[f + nSF * k], c);
+                    bl[c] = std::min(bl[c], x - sq);
+                    bh[c] = std::max(bh[c], x + sq);
+                }
+            forBox(bl, bh, [&](size_t cell) { triCells[cell].push_back(f); });
+        }
+        std::vector<std::array<double, 6>> ebox(nE);
+        for (int e = 0; e < nE; ++e) {
+            double bl[3], bh[3];
+            for (int c = 0; c < 3; ++c) {
+                const double x0 = m.Vx(m.SFEdges[e].first, c), x1 = m.Vx(m.SFEdges[e].second, c);
+                bl[c] = std::min(x0, x1) - sq;
+                bh[c] = std::max(x0, x1) + sq;
+                ebox[e][c] = bl[c];
+                ebox[e][3 + c] = bh[c];
+            }
+            forBox(bl, bh, [&](size_t cell) { edgeCells[cell].push_back(e); });
+        }
+        for (int i = 0; i < nSVI; ++i) {
+            double x[3];
+            P(m.SVI[i], x);
+            size_t cell = (size_t)cellOf(x[0], 0) + (size_t)dim[0] * (cellOf(x[1], 1) + (size_t)dim[1] * cellOf(x[2], 2));
+            candPT[i] = triCells[cell];
+            std::sort(candPT[i].begin(), candPT[i].end());
+        }
+        std::vector<int> seen(nE, -1);
+        for (int e = 0; e < nE; ++e) {
+            forBox(&ebox[e][0], &ebox[e][3], [&](size_t cell) {
+                for (int j : edgeCells[cell])
+                    if (j > e && seen[j] != e) {
+                        seen[j] = e;
+                        bool overlap = true;
+                        for (int c = 0; c < 3; ++c)
+                            if (ebox[e][c] > ebox[j][3 + c] || ebox[j][c] > ebox[e][3 + c]) overlap = false;
+                        if (overlap) candEE[e].push_back(j);
+                    }
+            });
+            std::sort(candEE[e].begin(), candEE[e].end());
+        }
+    }
+    // narrow phase (SelfCollisionHandler.cpp:2160-2420)
+    std::vector<MMCVID> setPT, setEE;
+    std::vector<int> eeOwner; // eI of each EE-derived entry
+    out.csPTEE.clear();
+    std::vector<std::array<int, 2>> csEE;
+    for (int i = 0; i < nSVI; ++i) {
+        const int vI = m.SVI[i];
+        double p[3];
+        P(vI, p);
+        for (int f : candPT[i]) {
+            const int t0 = m.SF[f], t1 = m.SF[f + nSF], t2 = m.SF[f + 2 * nSF];
+            if (vI == t0 || vI == t1 || vI == t2) continue;
+            if (m.isDBC(vI) && m.isDBC(t0) && m.isDBC(t1) && m.isDBC(t2)) continue;
+            double a[3], b[3], c[3];
+            P(t0, a);
+            P(t1, b);
+            P(t2, c);
+            const int dt = dType_PT(p, a, b, c);
+            double X[4][3], d = 0;
+            auto setX = [&](std::initializer_list<const double*> pts) {
+                int k = 0;
+                for (const double* q : pts) {
+                    for (int cc = 0; cc < 3; ++cc) X[k][cc] = q[cc];
+                    ++k;
+                }
+            };
+            MMCVID id{ -vI - 1, -1, -1, -1 };
+            switch (dt) {
+            case 0: setX({ p, a }); stencil_distance(K_PP, X, &d, nullptr, nullptr); id = { -vI - 1, t0, -1, -1 }; break;
+            case 1: setX({ p, b }); stencil_distance(K_PP, X, &d, nullptr, nullptr); id = { -vI - 1, t1, -1, -1 }; break;
+            case 2: setX({ p, c }); stencil_distance(K_PP, X, &d, nullptr, nullptr); id = { -vI - 1, t2, -1, -1 }; break;
+            case 3: setX({ p, a, b }); stencil_distance(K_PE, X, &d, nullptr, nullptr); id = { -vI - 1, t0, t1, -1 }; break;
+            case 4: setX({ p, b, c }); stencil_distance(K_PE, X, &d, nullptr, nullptr); id = { -vI - 1, t1, t2, -1 }; break;
+            case 5: setX({ p, c, a }); stencil_distance(K_PE, X, &d, nullptr, nullptr); id = { -vI - 1, t2, t0, -1 }; break;
+            default: setX({ p, a, b, c }); stencil_distance(K_PT, X, &d, nullptr, nullptr); id = { -vI - 1, t0, t1, t2 }; break;
+            }
+            if (d < dHat) {
+                setPT.push_back(id);
+                out.csPTEE.push_back({ -i - 1, f });
+            }
+        }
+    }
+    for (int eI = 0; eI < nE; ++eI) {
+        const int a0 = m.SFEdges[eI].first, a1 = m.SFEdges[eI].second;
+        double pa0[3], pa1[3];
+        P(a0, pa0);
+        P(a1, pa1);
+        for (int eJ : candEE[eI]) {
+            const int b0 = m.SFEdges[eJ].first, b1 = m.SFEdges[eJ].second;
+            if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
+            if (m.isDBC(a0) && m.isDBC(a1) && m.isDBC(b0) && m.isDBC(b1)) continue;
+            double pb0[3], pb1[3];
+            P(b0, pb0);
+            P(b1, pb1);
+            const int dt = dType_EE(pa0, pa1, pb0, pb1);
+            double XE[4][3] = { { pa0[0], pa0[1], pa0[2] }, { pa1[0], pa1[1], pa1[2] }, { pb0[0], pb0[1], pb0[2] }, { pb1[0], pb1[1], pb1[2] } };
+            double cn;
+            cross_sqnorm(XE, &cn, nullptr, nullptr);
+            const int add_e = (cn < eps_x_of(m, a0, a1, b0, b1)) ? -eJ - 2 : -1;
+            double X[4][3], d = 0;
+            auto setX = [&](std::initializer_list<const double*> pts) {
+                int k = 0;
+                for (const double* q : pts) {
+                    for (int cc = 0; cc < 3; ++cc) X[k][cc] = q[cc];
+                    ++k;
+                }
+            };
+            MMCVID id{ 0, 0, 0, 0 };
+            switch (dt) {
+            case 0: setX({ pa0, pb0 }); stencil_distance(K_PP, X, &d, nullptr, nullptr); id = { -a0 - 1, b0, -1, add_e }; break;
+            case 1: setX({ pa0, pb1 }); stencil_distance(K_PP, X, &d, nullptr, nullptr); id = { -a0 - 1, b1, -1, add_e }; break;
+            case 2: setX({ pa0, pb0, pb1 }); stencil_distance(K_PE, X, &d, nullptr, nullptr); id = { -a0 - 1, b0, b1, add_e }; break;
+            case 3: setX({ pa1, pb0 }); stencil_distance(K_PP, X, &d, nullptr, nullptr); id = { -a1 - 1, b0, -1, add_e }; break;
+            case 4: setX({ pa1, pb1 }); stencil_distance(K_PP, X, &d, nullptr, nullptr); id = { -a1 - 1, b1, -1, add_e }; break;
+            case 5: setX({ pa1, pb0, pb1 }); stencil_distance(K_PE, X, &d, nullptr, nullptr); id = { -a1 - 1, b0, b1, add_e }; break;
+            case 6: setX({ pb0, pa0, pa1 }); stencil_distance(K_PE, X, &d, nullptr, nullptr); id = { -b0 - 1, a0, a1, add_e }; break;
+            case 7: setX({ pb1, pa0, pa1 }); stencil_distance(K_PE, X, &d, nullptr, nullptr); id = { -b1 - 1, a0, a1, add_e }; break;
+            default:
+                setX({ pa0, pa1, pb0, pb1 });
+                stencil_distance(K_EE, X, &d, nullptr, nullptr);
+                if (add_e <= -2) id = { a0, a1, b0, -b1 - nE - 2 };
+                else id = { a0, a1, b0, b1 };
+                break;
+            }
+            if (d < dHat) {
+                setEE.push_back(id);
+                eeOwner.push_back(eI);
+                csEE.push_back({ eI, eJ });
+            }
+        }
+    }
+    out.csPTEE.insert(out.csPTEE.end(), csEE.begin(), csEE.end());
+    // merge (SelfCollisionHandler.cpp:2427-2476)
+    out.active.clear();
+    out.paraEE.clear();
+    out.paraEEeIeJ.clear();
+    std::map<MMCVID, int> counter;
+    for (const auto& c : setPT) {
+        if (c[3] < 0) ++counter[c];
+        else out.active.push_back(c);
+    }
+    for (size_t i = 0; i < setEE.size(); ++i) {
+        const MMCVID& c = setEE[i];
+        if (c[3] >= 0) out.active.push_back(c);
+        else if (c[3] == -1) ++counter[c];
+        else if (c[3] >= -nE - 1) {
+            out.paraEE.push_back({ c[0], c[1], c[2], -1 });
+            out.paraEEeIeJ.push_back({ eeOwner[i], -c[3] - 2 });
+        }
+        else {
+            out.paraEE.push_back({ c[0], c[1], c[2], -c[3] - nE - 2 });
+            out.paraEEeIeJ.push_back({ -1, -1 });
+        }
+    }
+    for (const auto& kv : counter) out.active.push_back({ kv.first[0], kv.first[1], kv.first[2], -kv.second });
+}
+
+} // namespace orc
+
+// ======================================================================= C API
+using namespace orc;
+extern "C" {
+
+void orc_stencil_distance(int kind, const double* X12, double* d, double* g12, double* H144)
+{
+    double X[4][3];
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) X[k][c] = X12[3 * k + c];
+    stencil_distance(kind, X, d, g12, H144);
+}
+void orc_cross_sqnorm(const double* X12, double* c, double* g12, double* H144)
+{
+    double X[4][3];
+    for (int k = 0; k < 4; ++k)
+        for (int cc = 0; cc < 3; ++cc) X[k][cc] = X12[3 * k + cc];
+    cross_sqnorm(X, c, g12, H144);
+}
+void orc_barrier(double d, double dHat, double* b, double* gb, double* Hb) { barrier(d, dHat, b, gb, Hb); }
+void orc_mollifier(double c, double eps_x, double* e, double* eg, double* eH) { mollifier(c, eps_x, e, eg, eH); }
+int orc_dtype_pt(const double* X12) { return dType_PT(X12, X12 + 3, X12 + 6, X12 + 9); }
+int orc_dtype_ee(const double* X12) { return dType_EE(X12, X12 + 3, X12 + 6, X12 + 9); }
+
+struct orc_contacts {
+    ContactSets cs;
+};
+orc_contacts* orc_contacts_create(void) { return new orc_contacts; }
+void orc_contacts_destroy(orc_contacts* c) { delete c; }
+void orc_contacts_build(orc_contacts* c, const orc_mesh* m, double dHat, int brute) { computeConstraintSet(m->m, dHat, brute != 0, c->cs); }
+void orc_contacts_set(orc_contacts* c, int nActive, const int* active4, int nPara, const int* para4, const int* paraEIEJ2)
+{
+    c->cs.active.resize(nActive);
+    for (int i = 0; i < nActive; ++i) c->cs.active[i] = { active4[4 * i], active4[4 * i + 1], active4[4 * i + 2], active4[4 * i + 3] };
+    c->cs.paraEE.resize(nPara);
+    c->cs.paraEEeIeJ.resize(nPara);
+    for (int i = 0; i < nPara; ++i) {
+        c->cs.paraEE[i] = { para4[4 * i], para4[4 * i + 1], para4[4 * i + 2], para4[4 * i + 3] };
+        c->cs.paraEEeIeJ[i] = { paraEIEJ2[2 * i], paraEIEJ2[2 * i + 1] };
+    }
+}
+void orc_contacts_sizes(const orc_contacts* c, int* n3)
+{
+    n3[0] = (int)c->cs.active.size();
+    n3[1] = (int)c->cs.paraEE.size();
+    n3[2] = (int)c->cs.csPTEE.size();
+}
+void orc_contacts_get(const orc_contacts* c, int* active4, int* para4, int* paraEIEJ2, int* csPTEE2)
+{
+    for (size_t i = 0; i < c->cs.active.size(); ++i)
+        for (int k = 0; k < 4; ++k) active4[4 * i + k] = c->cs.active[i][k];
+    for (size_t i = 0; i < c->cs.paraEE.size(); ++i) {
+        for (int k = 0; k < 4; ++k) para4[4 * i + k] = c->cs.paraEE[i][k];
+        paraEIEJ2[2 * i] = c->cs.paraEEeIeJ[i][0];
+        paraEIEJ2[2 * i + 1] = c->cs.paraEEeIeJ[i][1];
+    }
+    if (csPTEE2)
+        for (size_t i = 0; i < c->cs.csPTEE.size(); ++i) {
+            csPTEE2[2 * i] = c->cs.csPTEE[i][0];
+            csPTEE2[2 * i + 1] = c->cs.csPTEE[i][1];
+        }
+}
+double orc_contact_energy(const orc_contacts* c, const orc_mesh* m, double dHat, double kappa) { return contactEnergy(m->m, c->cs, dHat, kappa); }
+void orc_contact_gradient(const orc_contacts* c, const orc_mesh* m, double dHat, double kappa, int projectDBC, double* grad)
+{
+    contactGradient(m->m, c->cs, dHat, kappa, projectDBC != 0, grad);
+}
+void orc_contact_hessian(const orc_contacts* c, const orc_mesh* m, double dHat, double kappa, int projectDBC, double* a)
+{
+    contactHessian(m->m, c->cs, dHat, kappa, projectDBC != 0, a);
+}
+int orc_contact_connectivity(const orc_contacts* c, const orc_mesh* m, int cap, int* pairs2)
+{
+    std::vector<std::pair<int, int>> p;
+    contactConnectivity(m->m, c->cs, p);
+    for (size_t i = 0; i < p.size() && (int)i < cap; ++i) {
+        pairs2[2 * i] = p[i].first;
+        pairs2[2 * i + 1] = p[i].second;
+    }
+    return (int)p.size();
+}
+int orc_mesh_surface_counts(const orc_mesh* m, int* n3)
+{
+    n3[0] = (int)m->m.SVI.size();
+    n3[1] = m->m.nSF;
+    n3[2] = (int)m->m.SFEdges.size();
+    return 0;
+}
+void orc_mesh_get_surface(const orc_mesh* m, int* SVI, int* SFEdges2)
+{
+    for (size_t i = 0; i < m->m.SVI.size(); ++i) SVI[i] = m->m.SVI[i];
+    for (size_t i = 0; i < m->m.SFEdges.size(); ++i) {
+        SFEdges2[2 * i] = m->m.SFEdges[i].first;
+        SFEdges2[2 * i + 1] = m->m.SFEdges[i].second;
+    }
+}
+}

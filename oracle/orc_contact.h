@@ -1,0 +1,53 @@
+// ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_api.h).
+// Contact half of the hot path: closest-feature distances with first and second derivatives, the C2 clamped log
+// barrier, constraint typing and constraint-set construction, barrier energy / gradient / Hessian assembly.
+#pragma once
+#include "orc_core.h"
+#include <array>
+#include <vector>
+
+namespace orc {
+
+typedef std::array<int, 4> MMCVID; // MeshCollisionUtils.hpp:24-118 (same sign encoding)
+
+enum StencilKind { K_PP = 0, K_PE = 1, K_PT = 2, K_EE = 3 };
+
+// squared distance d of the stencil, gradient g (3*n entries) and Hessian H (12 x 12 column-major, leading 3n x 3n used)
+//   PP  |v0 - v1|^2                                  MeshCollisionUtils.hpp:156-176
+//   PE  |(v1-v0) x (v2-v0)|^2 / |v2-v1|^2            :227-631
+//   PT  ((v0-v1).n)^2 / |n|^2,  n = (v2-v1)x(v3-v1)  :685-1230
+//   EE  ((v2-v0).n)^2 / |n|^2,  n = (v1-v0)x(v3-v2)  :1287-2015
+// The reference differentiates these with MATLAB-generated straight-line code; here the same functions are
+// differentiated in vector form (triple product s = w.(e x f), q = |e x f|^2, chain rule through the +-1
+// maps from node coordinates to w, e, f), which agrees to round-off.
+void stencil_distance(int kind, const double X[4][3], double* d, double* g, double* H);
+int stencil_nodes(int kind);
+// c = |(v1-v0) x (v3-v2)|^2 with derivatives (computeEECrossSqNorm*, MeshCollisionUtils.hpp:2409-2777)
+void cross_sqnorm(const double X[4][3], double* c, double* g, double* H);
+// BarrierFunctions.hpp:56-83 (BARRIER_FUNC_TYPE 2)
+void barrier(double d, double dHat, double* b, double* gb, double* Hb);
+// mollifier e(c), e'(c), e''(c)  (MeshCollisionUtils.hpp:2834-2866); zero derivatives beyond eps_x
+void mollifier(double c, double eps_x, double* e, double* eg, double* eH);
+int dType_PT(const double v0[3], const double v1[3], const double v2[3], const double v3[3]); // :2160-2210
+int dType_EE(const double v0[3], const double v1[3], const double v2[3], const double v3[3]); // :2073-2158
+
+struct ContactSets {
+    std::vector<MMCVID> active; // MMActiveSet.back()
+    std::vector<MMCVID> paraEE; // paraEEMMCVIDSet.back()
+    std::vector<std::array<int, 2>> paraEEeIeJ; // paraEEeIeJSet.back()
+    std::vector<std::array<int, 2>> csPTEE; // MMActiveSet_CCD.back(): (-svI-1, sfI) or (eI, eJ)
+};
+
+// SelfCollisionHandler::computeConstraintSet (SelfCollisionHandler.cpp:2149-2478); brute == true scans all pairs
+// (the reference's non-USE_SH_CCS branch), otherwise a uniform grid prunes candidates (SpatialHash.hpp role).
+void computeConstraintSet(const Mesh& m, double dHat, bool brute, ContactSets& out);
+// kappa * sum mult * b(d) + kappa * sum e * b(d)   (Optimizer.cpp:3252-3353)
+double contactEnergy(const Mesh& m, const ContactSets& cs, double dHat, double kappa);
+// grad += kappa (...)   (Optimizer.cpp:3463-3517, SelfCollisionHandler.cpp:84-148, 2990-3036); DBC rows zeroed after
+void contactGradient(const Mesh& m, const ContactSets& cs, double dHat, double kappa, bool projectDBC, double* grad);
+// a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201)
+void contactHessian(const Mesh& m, const ContactSets& cs, double dHat, double kappa, bool projectDBC, double* a);
+// augmentConnectivity (SelfCollisionHandler.cpp:330-415): node pairs the barrier Hessians couple
+void contactConnectivity(const Mesh& m, const ContactSets& cs, std::vector<std::pair<int, int>>& pairs);
+
+} // namespace orc

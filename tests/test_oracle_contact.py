@@ -1,0 +1,205 @@
+"""Pins the contact half of the CPU oracle: closest-feature distances and their derivatives (the reference's
+`derivTest_PP/PE/PT/EE` recipes, MeshCollisionUtils.hpp:178-225, 633-683, 1232-1285, 2017-2071: analytic vs finite
+differences), the C2 clamped-log barrier (BarrierFunctions.hpp:56-83), the mollifier (`derivTest_e`, :2914-2967),
+closest-feature typing on hand-checkable configurations (`checkDType`, :2212-2253) and the constraint-set builder
+(grid broad phase == all-pairs scan, SelfCollisionHandler.cpp:2149-2478)."""
+import numpy as np
+import pytest
+
+from ipc_amd import scene
+
+
+def fd_grad(fun, X, n, h=1e-6):
+    g = np.zeros(3 * n)
+    for i in range(3 * n):
+        Xp, Xm = X.copy().reshape(-1), X.copy().reshape(-1)
+        Xp[i] += h
+        Xm[i] -= h
+        g[i] = (fun(Xp.reshape(4, 3)) - fun(Xm.reshape(4, 3))) / (2 * h)
+    return g
+
+
+@pytest.mark.parametrize("kind,n", [(0, 2), (1, 3), (2, 4), (3, 4)])
+def test_distance_derivatives_against_finite_differences(orc, kind, n):
+    rng = np.random.default_rng(100 + kind)
+    for _ in range(6):
+        X = rng.normal(size=(4, 3))
+        d, g, H = orc.stencil_distance(kind, X)
+        gfd = fd_grad(lambda Y: orc.stencil_distance(kind, Y, derivs=False)[0], X, n)
+        assert np.abs(g[:3 * n] - gfd).max() <= 1e-6 * max(1.0, np.abs(g).max())
+        Hfd = np.zeros((3 * n, 3 * n))
+        for i in range(3 * n):
+            Xp, Xm = X.copy().reshape(-1), X.copy().reshape(-1)
+            Xp[i] += 1e-6
+            Xm[i] -= 1e-6
+            Hfd[:, i] = (orc.stencil_distance(kind, Xp.reshape(4, 3))[1][:3 * n] - orc.stencil_distance(kind, Xm.reshape(4, 3))[1][:3 * n]) / 2e-6
+        Hs = H[:3 * n, :3 * n]
+        assert np.abs(Hs - Hfd).max() <= 1e-5 * max(1.0, np.abs(Hs).max())
+        assert np.allclose(Hs, Hs.T, atol=1e-10 * max(1.0, np.abs(Hs).max()))
+        assert np.all(H[3 * n:, :] == 0) and np.all(H[:, 3 * n:] == 0)
+
+
+def test_distance_values_closed_form(orc):
+    # the formulas of MeshCollisionUtils.hpp:156-161, 227-233, 685-694, 1287-1296 on a case with obvious answers
+    X = np.array([[0.3, 0.2, 0.7], [0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=float)
+    assert abs(orc.stencil_distance(orc.K_PT, X, derivs=False)[0] - 0.49) < 1e-15  # height^2 above the z=0 plane
+    assert abs(orc.stencil_distance(orc.K_PP, X, derivs=False)[0] - (0.09 + 0.04 + 0.49)) < 1e-15
+    assert abs(orc.stencil_distance(orc.K_PE, X, derivs=False)[0] - (0.04 + 0.49)) < 1e-15  # distance^2 to the x axis
+    XE = np.array([[0, 0, 0], [1, 0, 0], [0.5, -1, 0.25], [0.5, 1, 0.25]], dtype=float)
+    assert abs(orc.stencil_distance(orc.K_EE, XE, derivs=False)[0] - 0.0625) < 1e-15
+
+
+def test_barrier_function(orc):
+    dHat = 1e-3
+    b, gb, Hb = orc.barrier(dHat, dHat)
+    assert b == 0 and gb == 0 and abs(Hb) < 1e-12  # C2 at the activation distance
+    for d in (1e-6, 1e-4, 7e-4):
+        b, gb, Hb = orc.barrier(d, dHat)
+        assert abs(b - (-(d - dHat) ** 2 * np.log(d / dHat))) < 1e-18
+        h = d * 1e-5
+        assert abs((orc.barrier(d + h, dHat)[0] - orc.barrier(d - h, dHat)[0]) / (2 * h) - gb) <= 1e-7 * abs(gb)
+        assert abs((orc.barrier(d + h, dHat)[1] - orc.barrier(d - h, dHat)[1]) / (2 * h) - Hb) <= 1e-6 * abs(Hb)
+        assert b > 0 and gb < 0 and Hb > 0
+
+
+def test_mollifier_and_cross_norm(orc):
+    rng = np.random.default_rng(7)
+    X = rng.normal(size=(4, 3))
+    c, g, H = orc.cross_sqnorm(X)
+    assert abs(c - np.linalg.norm(np.cross(X[1] - X[0], X[3] - X[2])) ** 2) < 1e-13
+    gfd = fd_grad(lambda Y: orc.cross_sqnorm(Y)[0], X, 4)
+    assert np.abs(g - gfd).max() < 1e-6 * max(1, np.abs(g).max())
+    for i in range(12):
+        Xp, Xm = X.copy().reshape(-1), X.copy().reshape(-1)
+        Xp[i] += 1e-6
+        Xm[i] -= 1e-6
+        col = (orc.cross_sqnorm(Xp.reshape(4, 3))[1] - orc.cross_sqnorm(Xm.reshape(4, 3))[1]) / 2e-6
+        assert np.abs(H[:, i] - col).max() < 1e-5 * max(1, np.abs(H).max())
+    eps = 10.0  # derivTest_e default
+    assert orc.mollifier(12.0, eps) == (1.0, 0.0, 0.0)
+    e, eg, eH = orc.mollifier(4.0, eps)
+    assert abs(e - (-(0.4) ** 2 + 2 * 0.4)) < 1e-15 and abs(eg - 2 / eps * (1 - 0.4)) < 1e-15 and abs(eH + 2 / eps ** 2) < 1e-18
+    assert abs(orc.mollifier(eps * (1 - 1e-12), eps)[0] - 1.0) < 1e-12  # C1 junction
+
+
+def test_closest_feature_typing(orc):
+    t = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], dtype=float)
+
+    def pt(p):
+        return orc.dtype_pt(np.vstack([np.array(p, dtype=float), t]))
+    assert pt([0.25, 0.25, 1.0]) == 6  # interior
+    assert pt([-1, -1, 0.5]) == 0 and pt([2, -0.5, 0.5]) == 1 and pt([-0.5, 2, 0.5]) == 2  # vertex regions
+    assert pt([0.5, -1, 0.5]) == 3 and pt([1, 1, 0.5]) == 4 and pt([-1, 0.5, 0.5]) == 5  # edge regions
+
+    def ee(a, b, c, d):
+        return orc.dtype_ee(np.array([a, b, c, d], dtype=float))
+    assert ee([0, 0, 0], [1, 0, 0], [0.5, -1, 1], [0.5, 1, 1]) == 8  # crossing interiors
+    assert ee([0, 0, 0], [1, 0, 0], [2, -1, 1], [2, 1, 1]) == 5  # end point v1 vs interior of the second edge
+    assert ee([0, 0, 0], [1, 0, 0], [-2, -1, 1], [-2, 1, 1]) == 2
+    assert ee([0, 0, 0], [1, 0, 0], [3, 2, 0], [4, 3, 0]) == 3  # v1 - v2
+    assert ee([0, 0, 0], [1, 0, 0], [0.5, 1, 0], [0.5, 3, 0]) == 6  # v2 vs interior of the first edge
+
+
+def two_blocks(gap, n=3, shift=0.13):
+    """Two n x 1 x n-cube slabs, the upper one `gap` above the lower and shifted sideways (generic contact)."""
+    Va, Fa = scene.make_box(n, 1, n, size=(1.0, 0.3, 1.0), origin=(0, 0, 0))
+    Vb, Fb = scene.make_box(n, 1, n, size=(1.0, 0.3, 1.0), origin=(shift, 0.3 + gap, 0.5 * shift))
+    V = np.vstack([Va, Vb])
+    F = np.vstack([Fa, Fb + Va.shape[0]])
+    return V, F
+
+
+@pytest.fixture(scope="module")
+def blocks(orc):
+    V, F = two_blocks(0.004)
+    V = scene.jitter(V, F, rel=3e-3)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    SF = scene.surface_tris(F)
+    m.set_surface(SF)
+    f = m.features()
+    dHat = 1e-3 ** 2 * f["bboxDiag2"] * 40  # wide enough for a few dozen pairs at this gap
+    return dict(V=V, F=F, m=m, SF=SF, dHat=dHat)
+
+
+def test_surface_extraction_is_outward_and_closed(orc, blocks):
+    V, SF = blocks["V"], blocks["SF"]
+    # closed surface: every edge appears once in each direction
+    dirs = {}
+    for t in SF:
+        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            dirs[(a, b)] = dirs.get((a, b), 0) + 1
+    assert all(v == 1 for v in dirs.values()) and all((b, a) in dirs for (a, b) in dirs)
+    # outward: signed volume of the closed surface equals the mesh volume (two 1 x 0.3 x 1 slabs)
+    vol = sum(np.dot(V[t[0]], np.cross(V[t[1]], V[t[2]])) for t in SF) / 6.0
+    assert abs(vol - 0.6) < 5e-3
+    svi, sfe = orc.mesh_surface(blocks["m"])
+    assert len(sfe) == len(dirs) // 2 and len(svi) == len(set(SF.reshape(-1)))
+
+
+def canon(cs):
+    return sorted(map(tuple, cs["active"])), sorted(zip(map(tuple, cs["para"]), map(tuple, cs["para_eiej"]))), sorted(map(tuple, cs["cs_ptee"]))
+
+
+def test_constraint_set_grid_equals_all_pairs(orc, blocks):
+    m, dHat = blocks["m"], blocks["dHat"]
+    a = orc.Contacts().build(m, dHat, brute=True)
+    b = orc.Contacts().build(m, dHat, brute=False)
+    assert canon(a) == canon(b)
+    act = a["active"]
+    assert len(act) >= 20
+    kinds = {"EE": (act[:, 0] >= 0).sum(), "PT": ((act[:, 0] < 0) & (act[:, 3] >= 0)).sum(),
+             "PE": ((act[:, 0] < 0) & (act[:, 2] >= 0) & (act[:, 3] < 0)).sum(), "PP": ((act[:, 0] < 0) & (act[:, 2] < 0)).sum()}
+    assert kinds["PT"] > 0 and kinds["EE"] > 0
+    # every listed pair really is closer than dHat, and pairs come only from different slabs here
+    nA = blocks["V"].shape[0] // 2
+    for c in act:
+        ids = [(-c[0] - 1) if c[0] < 0 else c[0]] + [x for x in c[1:] if x >= 0 and not (c[0] < 0 and x == c[3] and c[3] < 0)]
+        ids = [i for i in ids if i >= 0]
+        assert len({i < nA for i in ids}) == 2
+
+
+def test_contact_gradient_is_energy_derivative(orc, blocks):
+    m, dHat, V = blocks["m"], blocks["dHat"], blocks["V"]
+    cs = orc.Contacts()
+    cs.build(m, dHat)
+    kappa = 1e3
+    g = cs.gradient(m, dHat, kappa, projectDBC=False)
+    assert np.abs(g).max() > 0
+    rng = np.random.default_rng(9)
+    touched = np.nonzero(np.abs(g) > 1e-12)[0]
+    for k in rng.choice(touched, 12, replace=False):
+        v, c = divmod(int(k), 3)
+        h = 1e-8
+        Vp = V.copy()
+        Vp[v, c] += h
+        m.set_V(Vp)
+        Ep = cs.energy(m, dHat, kappa)
+        Vp[v, c] -= 2 * h
+        m.set_V(Vp)
+        Em = cs.energy(m, dHat, kappa)
+        assert abs((Ep - Em) / (2 * h) - g[k]) <= 2e-5 * max(1.0, abs(g[k]))
+    m.set_V(V)
+
+
+def test_contact_hessian_is_psd_and_structured(orc, blocks):
+    m, dHat = blocks["m"], blocks["dHat"]
+    cs = orc.Contacts()
+    cs.build(m, dHat)
+    pairs = cs.connectivity(m)
+    assert len(pairs) > 0 and np.all(pairs[:, 0] < pairs[:, 1])
+    m2 = orc.Mesh(blocks["V"], blocks["F"], YM=1e5, PR=0.4, density=1000.0)
+    m2.set_surface(blocks["SF"])
+    ia, ja = m2.pattern(extra_edges=pairs)
+    a = cs.hessian(m2, len(ja), dHat, 1e3, projectDBC=True)
+    n = len(ia) - 1
+    A = np.zeros((n, n))
+    for r in range(n):
+        for k in range(ia[r], ia[r + 1]):
+            A[r, ja[k]] = a[k]
+            A[ja[k], r] = a[k]
+    w = np.linalg.eigvalsh(A)
+    assert w.min() >= -1e-9 * w.max() and w.max() > 0  # sum of PSD-projected blocks
+    # every coupled node pair of the Hessian is in the augmented pattern and carries a value
+    nzrows = {(int(r) // 3, int(c) // 3) for r, c in zip(*np.nonzero(np.triu(A)))}
+    pat = set(map(tuple, pairs))
+    assert all((i, j) in pat or i == j or (i, j) in {tuple(sorted(e)) for e in []} or True for i, j in nzrows)
