@@ -122,6 +122,31 @@ int ipcgpu_incremental_potential(ipcgpu_ctx*, double dtSq, double* energy);
 /* computeGradient alone */
 int ipcgpu_gradient(ipcgpu_ctx*, double dtSq, int projectDBC, double* grad_3nV);
 
+/* ---- SelfCollisionHandler<3> (barrier contact) ------------------------------------- */
+/* Mesh::SF (column-major nSF x 3 surface triangles, outward).  SVI and SFEdges are derived exactly as
+ * Mesh::computeFeatures / computeBoundaryVert do (src/Mesh.cpp:495-515, 890-930), so edge and vertex indices
+ * agree with the reference's. */
+int ipcgpu_set_surface(ipcgpu_ctx*, int nSF, const int* SF_colmajor);
+int ipcgpu_get_surface(ipcgpu_ctx*, int* counts3 /*nSVI,nSF,nSFEdges*/, int* SVI /*nullable*/, int* SFEdges_2n /*nullable*/);
+/* SelfCollisionHandler::computeConstraintSet (SelfCollisionHandler.cpp:2149-2478) at the current positions:
+ * MMActiveSet (PP / PE duplicates merged, multiplicity in slot 3), paraEEMMCVIDSet + paraEEeIeJSet, and the
+ * candidate list for the partial CCD.  counts3 = {nActive, nParaEE, nCandidates}. */
+int ipcgpu_contact_build(ipcgpu_ctx*, double dHat, int* counts3);
+int ipcgpu_contact_get(ipcgpu_ctx*, int* active_4n, int* paraEE_4n, int* paraEEeIeJ_2n, int* csPTEE_2n /*nullable*/);
+/* hand an active set in (adapters that keep the reference's own constraint-set code; tests) */
+int ipcgpu_contact_set(ipcgpu_ctx*, int nActive, const int* active_4n, int nParaEE, const int* paraEE_4n, const int* paraEEeIeJ_2n);
+/* kappa * (sum mult b(d) + sum e(c) b(d))  -- the barrier part of computeEnergyVal (Optimizer.cpp:3252-3353) */
+int ipcgpu_contact_energy(ipcgpu_ctx*, double dHat, double kappa, double* energy);
+/* grad += kappa J^T b'  (leftMultiplyConstraintJacobianT + augmentParaEEGradient, SelfCollisionHandler.cpp:84-148,
+ * 2990-3036), then rows of projected Dirichlet nodes zeroed (Optimizer.cpp:3512-3516) */
+int ipcgpu_contact_gradient_add(ipcgpu_ctx*, double dHat, double kappa, int projectDBC, double* grad_3nV_inout);
+/* a += PSD-projected barrier Hessians (augmentIPHessian + augmentParaEEHessian, SelfCollisionHandler.cpp:418-561,
+ * 3039-3201).  The pattern must already contain the contact connectivity (ipcgpu_contact_connectivity ->
+ * ipcgpu_linsys_set_pattern); otherwise IPCGPU_ERR_STATE. */
+int ipcgpu_contact_hessian_add(ipcgpu_ctx*, double dHat, double kappa, int projectDBC);
+/* augmentConnectivity (SelfCollisionHandler.cpp:330-415): node pairs (a < b) coupled by the barrier Hessians */
+int ipcgpu_contact_connectivity(ipcgpu_ctx*, int capacity, int* pairs_2n, int* nPairs);
+
 /* ---- Optimizer<3>: the time stepper itself, state resident on the GPU --------------- */
 /* Optimizer ctor + setTime (Optimizer.cpp:97-115, 418-430).  Uses the mesh of this context. */
 int ipcgpu_opt_init(ipcgpu_ctx*, double dt, int withGravity);

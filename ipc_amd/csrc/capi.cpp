@@ -113,6 +113,7 @@ int ipcgpu_ctx_destroy(ipcgpu_ctx* c)
         if (!c) return IPCGPU_OK;
         (void)hipSetDevice(c->device);
         (void)hipStreamSynchronize(c->stream);
+        c->contact.reset();
         c->opt.reset();
         c->lin.reset();
         c->mesh.reset();
@@ -447,6 +448,135 @@ int ipcgpu_linsys_stats(ipcgpu_ctx* c, double* st)
         st[1] = s.flops;
         st[2] = s.ns;
         st[3] = (double)s.levelPtr.size() - 1;
+        return IPCGPU_OK;
+    });
+}
+
+// ---- SelfCollisionHandler ----------------------------------------------------------------------------
+static HipContact& CT(ipcgpu_ctx* c)
+{
+    M(c);
+    if (!c->contact) c->contact.reset(new HipContact(c->stream));
+    return *c->contact;
+}
+int ipcgpu_set_surface(ipcgpu_ctx* c, int nSF, const int* SF)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        needArg(nSF >= 0 && (SF || nSF == 0), "bad surface");
+        CT(c).setSurface(m, nSF, SF);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_get_surface(ipcgpu_ctx* c, int* counts, int* SVI, int* SFE)
+{
+    return guarded([&] {
+        HipContact& k = CT(c);
+        if (counts) {
+            counts[0] = k.nSVI;
+            counts[1] = k.nSF;
+            counts[2] = k.nSFE;
+        }
+        if (SVI) std::memcpy(SVI, k.SVI.data(), sizeof(int) * k.SVI.size());
+        if (SFE)
+            for (size_t i = 0; i < k.SFEdges.size(); ++i) {
+                SFE[2 * i] = k.SFEdges[i].first;
+                SFE[2 * i + 1] = k.SFEdges[i].second;
+            }
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_build(ipcgpu_ctx* c, double dHat, int* counts)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        needArg(dHat > 0, "dHat must be positive");
+        HipContact& k = CT(c);
+        k.buildConstraintSet(m, m.d_x.p, m.d_dbc.p, dHat);
+        if (counts) {
+            counts[0] = (int)k.active.size();
+            counts[1] = (int)k.para.size();
+            counts[2] = (int)k.csPTEE.size();
+        }
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_get(ipcgpu_ctx* c, int* a4, int* p4, int* pe2, int* cs2)
+{
+    return guarded([&] {
+        HipContact& k = CT(c);
+        for (size_t i = 0; a4 && i < k.active.size(); ++i)
+            for (int j = 0; j < 4; ++j) a4[4 * i + j] = k.active[i][j];
+        for (size_t i = 0; i < k.para.size(); ++i) {
+            for (int j = 0; p4 && j < 4; ++j) p4[4 * i + j] = k.para[i][j];
+            if (pe2) {
+                pe2[2 * i] = k.paraEIEJ[i][0];
+                pe2[2 * i + 1] = k.paraEIEJ[i][1];
+            }
+        }
+        for (size_t i = 0; cs2 && i < k.csPTEE.size(); ++i) {
+            cs2[2 * i] = k.csPTEE[i][0];
+            cs2[2 * i + 1] = k.csPTEE[i][1];
+        }
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_set(ipcgpu_ctx* c, int nA, const int* a4, int nP, const int* p4, const int* pe2)
+{
+    return guarded([&] {
+        bind(c);
+        HipContact& k = CT(c);
+        need(k.surfaceSet, "call ipcgpu_set_surface first");
+        needArg(nA >= 0 && nP >= 0 && (a4 || !nA) && ((p4 && pe2) || !nP), "bad constraint set");
+        k.setSets(nA, a4, nP, p4, pe2);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_energy(ipcgpu_ctx* c, double dHat, double kappa, double* E)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        *E = CT(c).energy(c->mesh->d_x.p, dHat, kappa, o.d_partial, o.d_scalar.p + 4);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_gradient_add(ipcgpu_ctx* c, double dHat, double kappa, int projectDBC, double* g)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        const size_t n3 = 3 * (size_t)c->mesh->nV;
+        HIP_CHECK(hipMemcpyAsync(o.d_gradient.p, g, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CT(c).gradientAdd(c->mesh->d_x.p, c->mesh->d_dbc.p, c->mesh->nV, dHat, kappa, projectDBC, o.d_gradient.p);
+        o.d_gradient.download(g, n3, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_hessian_add(ipcgpu_ctx* c, double dHat, double kappa, int projectDBC)
+{
+    return guarded([&] {
+        M(c);
+        bind(c);
+        need(c->lin->numRows == 3 * c->mesh->nV, "call ipcgpu_linsys_set_pattern first");
+        CT(c).hessianAdd(c->mesh->d_x.p, c->mesh->d_dbc.p, *c->lin, dHat, kappa, projectDBC, c->lin->d_a.p);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_connectivity(ipcgpu_ctx* c, int cap, int* pairs, int* n)
+{
+    return guarded([&] {
+        std::vector<std::pair<int, int>> p;
+        CT(c).connectivity(p);
+        if (n) *n = (int)p.size();
+        for (size_t i = 0; pairs && i < p.size() && (int)i < cap; ++i) {
+            pairs[2 * i] = p[i].first;
+            pairs[2 * i + 1] = p[i].second;
+        }
         return IPCGPU_OK;
     });
 }

@@ -1,0 +1,55 @@
+// HipContact: the self-collision handler of the hot path (SelfCollisionHandler<3> statics,
+// src/CollisionObject/SelfCollisionHandler.hpp:21-250) with its state in HBM.
+//   computeConstraintSet      SelfCollisionHandler.cpp:2149-2478  -> buildConstraintSet (grid broad phase + typing on the GPU,
+//                                                                   duplicate merge on the host like the reference's std::map)
+//   evaluateConstraints + b   :38-81, Optimizer.cpp:3252-3353     -> energy
+//   leftMultiplyConstraintJacobianT / augmentParaEEGradient  :84-148, 2990-3036   -> gradientAdd
+//   augmentIPHessian / augmentParaEEHessian   :418-561, 3039-3201 -> hessianAdd
+//   augmentConnectivity       :330-415                            -> connectivity
+//   largestFeasibleStepSize[_CCD]  :564-686, 982-1366             -> ccdStepBound (conservative additive CCD)
+#pragma once
+#include "common.h"
+#include <array>
+#include <utility>
+#include <vector>
+
+namespace ipcgpu {
+
+class HipMesh;
+class HipLinSysSolver;
+
+class HipContact {
+public:
+    explicit HipContact(hipStream_t s) : stream(s) {}
+    hipStream_t stream;
+    // surface (Mesh::SF, SVI, SFEdges; Mesh.cpp:495-515, 890-930)
+    int nSF = 0, nSVI = 0, nSFE = 0;
+    std::vector<int> SF; // column-major nSF x 3
+    std::vector<int> SVI;
+    std::vector<std::pair<int, int>> SFEdges;
+    DevBuf<int> d_SF, d_SVI, d_SFE; // d_SF: int[3 nSF] (t0 t1 t2 per triangle), d_SFE: int[2 nSFE]
+    DevBuf<double> d_xRest; // rest positions xyz-interleaved (eps_x needs rest edge lengths)
+    // sets
+    std::vector<std::array<int, 4>> active, para;
+    std::vector<std::array<int, 2>> paraEIEJ, csPTEE;
+    DevBuf<int> d_active, d_para, d_paraEIEJ;
+    bool surfaceSet = false;
+
+    void setSurface(const HipMesh& mesh, int nSF, const int* SF_colmajor);
+    void setSets(int nA, const int* a4, int nP, const int* p4, const int* pe2);
+    void uploadSets();
+    // returns #active
+    int buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat);
+    double energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
+    void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev);
+    void hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
+        double* a_dev);
+    void connectivity(std::vector<std::pair<int, int>>& pairs) const;
+
+private:
+    DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
+    DevBuf<double> bboxPartial_;
+    DevBuf<char> scanTmp_;
+};
+
+} // namespace ipcgpu

@@ -1,0 +1,778 @@
+// Contact kernels + HipContact host logic (gfx950).  Compiled with -ffp-contract=off (exact-comparison typing).
+#include "hip_contact.h"
+#include "contact_device.h"
+#include "hip_ipc.h"
+#include <hipcub/hipcub.hpp>
+#include <algorithm>
+#include <cmath>
+#include <map>
+#include <set>
+
+namespace ipcgpu {
+
+namespace {
+
+using namespace cdev;
+constexpr int BLOCK = 256;
+
+struct ContactView {
+    int nA, nP;
+    const int* active; // int4 per entry
+    const int* para;
+    const int* paraEIEJ; // int2 per entry
+    const int* SFE; // int2 per surface edge
+    const double* x;
+    const double* xRest;
+};
+
+struct Stencil {
+    int kind, n, node[4];
+    double mult;
+};
+__device__ __forceinline__ Stencil decode(const int* c)
+{
+    Stencil s;
+    s.mult = 1.0;
+    s.node[2] = s.node[3] = 0;
+    if (c[0] >= 0) {
+        s.kind = K_EE;
+        s.n = 4;
+        for (int i = 0; i < 4; ++i) s.node[i] = c[i];
+    }
+    else {
+        s.node[0] = -c[0] - 1;
+        s.node[1] = c[1];
+        if (c[2] < 0) {
+            s.kind = K_PP;
+            s.n = 2;
+            s.mult = -c[3];
+        }
+        else if (c[3] < 0) {
+            s.kind = K_PE;
+            s.n = 3;
+            s.node[2] = c[2];
+            s.mult = -c[3];
+        }
+        else {
+            s.kind = K_PT;
+            s.n = 4;
+            s.node[2] = c[2];
+            s.node[3] = c[3];
+        }
+    }
+    return s;
+}
+__device__ __forceinline__ void gatherX(const double* x, const int* node, int n, double (*X)[3])
+{
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) X[k][c] = (k < n) ? x[3 * (size_t)node[k] + c] : 0.0;
+}
+__device__ __forceinline__ double eps_x_of(const double* xr, int a0, int a1, int b0, int b1)
+{
+    double la = 0.0, lb = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const double da = xr[3 * (size_t)a0 + c] - xr[3 * (size_t)a1 + c];
+        const double db = xr[3 * (size_t)b0 + c] - xr[3 * (size_t)b1 + c];
+        la += da * da;
+        lb += db * db;
+    }
+    return 1.0e-3 * la * lb; // MeshCollisionUtils.hpp:2969-2974
+}
+__device__ __forceinline__ void paraNodes(const ContactView& cv, int i, int* en)
+{
+    const int* c = cv.para + 4 * (size_t)i;
+    if (c[3] >= 0) {
+        for (int k = 0; k < 4; ++k) en[k] = c[k];
+    }
+    else {
+        const int eI = cv.paraEIEJ[2 * (size_t)i], eJ = cv.paraEIEJ[2 * (size_t)i + 1];
+        en[0] = cv.SFE[2 * (size_t)eI];
+        en[1] = cv.SFE[2 * (size_t)eI + 1];
+        en[2] = cv.SFE[2 * (size_t)eJ];
+        en[3] = cv.SFE[2 * (size_t)eJ + 1];
+    }
+}
+__device__ __forceinline__ double dist_only(int kind, const double (*X)[3])
+{
+    switch (kind) {
+    case K_PP: return d_PP(X[0], X[1]);
+    case K_PE: return d_PE(X[0], X[1], X[2]);
+    case K_PT: return d_PT(X[0], X[1], X[2], X[3]);
+    default: return d_EE(X[0], X[1], X[2], X[3]);
+    }
+}
+__device__ __forceinline__ bool projected_dbc(int type, int projectDBC) { return type == 1 || (type == 2 && projectDBC); }
+
+__device__ __forceinline__ double block_sum(double x, double* sm)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) sm[wv] = x;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int i = 0; i < BLOCK / 64; ++i) r += sm[i];
+    return r;
+}
+
+// sum mult b(d) + sum e b(d)   (Optimizer.cpp:3252-3353), fixed-order reduction
+__global__ __launch_bounds__(BLOCK) void k_contact_energy(ContactView cv, double dHat, double* __restrict__ partial)
+{
+    __shared__ double sm[BLOCK / 64];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double val = 0.0;
+    if (i < cv.nA) {
+        const Stencil s = decode(cv.active + 4 * (size_t)i);
+        double X[4][3], b, gb, Hb;
+        gatherX(cv.x, s.node, s.n, X);
+        barrier(dist_only(s.kind, X), dHat, &b, &gb, &Hb);
+        val = b * s.mult;
+    }
+    else if (i < cv.nA + cv.nP) {
+        const int j = i - cv.nA;
+        Stencil s = decode(cv.para + 4 * (size_t)j);
+        double X[4][3], b, gb, Hb, e, eg, eH;
+        gatherX(cv.x, s.node, s.n, X);
+        barrier(dist_only(s.kind, X), dHat, &b, &gb, &Hb);
+        int en[4];
+        paraNodes(cv, j, en);
+        double XE[4][3];
+        gatherX(cv.x, en, 4, XE);
+        mollifier(cross_sqnorm(XE[0], XE[1], XE[2], XE[3]), eps_x_of(cv.xRest, en[0], en[1], en[2], en[3]), &e, &eg, &eH);
+        val = b * e;
+    }
+    const double r = block_sum(val, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(BLOCK) void k_reduce_scaled(const double* __restrict__ partial, int n, double scale, double* __restrict__ out)
+{
+    __shared__ double sm[BLOCK / 64];
+    double x = 0.0;
+    for (int i = threadIdx.x; i < n; i += BLOCK) x += partial[i];
+    const double r = block_sum(x, sm);
+    if (threadIdx.x == 0) out[0] = scale * r;
+}
+
+// grad += kappa (mult b' grad d)  resp.  kappa (b e' grad c + e b' grad d)   (SelfCollisionHandler.cpp:84-148, 2990-3036)
+__global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, double dHat, double kappa, double* __restrict__ grad)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < cv.nA) {
+        const Stencil s = decode(cv.active + 4 * (size_t)i);
+        double X[4][3], g[12], b, gb, Hb;
+        gatherX(cv.x, s.node, s.n, X);
+        const double d = stencil_distance(s.kind, X, g, nullptr);
+        barrier(d, dHat, &b, &gb, &Hb);
+        const double coef = kappa * s.mult * gb;
+        for (int k = 0; k < s.n; ++k)
+            for (int c = 0; c < 3; ++c) atomicAdd(&grad[3 * (size_t)s.node[k] + c], coef * g[3 * k + c]);
+    }
+    else if (i < cv.nA + cv.nP) {
+        const int j = i - cv.nA;
+        const Stencil s = decode(cv.para + 4 * (size_t)j);
+        double X[4][3], g[12], b, gb, Hb;
+        gatherX(cv.x, s.node, s.n, X);
+        const double d = stencil_distance(s.kind, X, g, nullptr);
+        barrier(d, dHat, &b, &gb, &Hb);
+        int en[4];
+        paraNodes(cv, j, en);
+        double XE[4][3], cg[12], e, eg, eH;
+        gatherX(cv.x, en, 4, XE);
+        const double c = cross_sqnorm_derivs(XE, cg, nullptr);
+        mollifier(c, eps_x_of(cv.xRest, en[0], en[1], en[2], en[3]), &e, &eg, &eH);
+        for (int k = 0; k < 4; ++k)
+            for (int cc = 0; cc < 3; ++cc) atomicAdd(&grad[3 * (size_t)en[k] + cc], kappa * b * eg * cg[3 * k + cc]);
+        for (int k = 0; k < s.n; ++k)
+            for (int cc = 0; cc < 3; ++cc) atomicAdd(&grad[3 * (size_t)s.node[k] + cc], kappa * e * gb * g[3 * k + cc]);
+    }
+}
+__global__ void k_zero_projected(int nV, const int* __restrict__ dbc, int projectDBC, double* __restrict__ grad)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV && projected_dbc(dbc[v], projectDBC)) grad[3 * (size_t)v] = grad[3 * (size_t)v + 1] = grad[3 * (size_t)v + 2] = 0.0; // Optimizer.cpp:3512-3516
+}
+
+struct CsrView {
+    const int* ia;
+    const int* ja;
+};
+// position of column 3*cn in row 3*rn of the upper CSR (cn > rn), -1 if absent
+__device__ __forceinline__ int find_block(const CsrView& m, int rn, int cn)
+{
+    int lo = m.ia[3 * rn] + 3, hi = m.ia[3 * rn + 1]; // neighbour blocks start behind the 3 diagonal-block entries
+    const int target = 3 * cn;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        const int c = m.ja[mid];
+        if (c < target) lo = mid + 1;
+        else hi = mid;
+    }
+    return (lo < m.ia[3 * rn + 1] && m.ja[lo] == target) ? lo : -1;
+}
+// scatter the node-block Hessian H (12x12, ld 12) of `n` nodes into the symmetric-upper CSR, skipping projected nodes
+__device__ inline void scatter_blocks(const CsrView& m, double* a, const double* H, const int* node, int n, const int* dbc, int projectDBC,
+    int* err)
+{
+    for (int i = 0; i < n; ++i) {
+        if (projected_dbc(dbc[node[i]], projectDBC)) continue;
+        for (int j = 0; j < n; ++j) {
+            if (projected_dbc(dbc[node[j]], projectDBC)) continue;
+            const int vi = node[i], vj = node[j];
+            if (vi > vj) continue; // lower-triangle writes are ignored (LinSysSolver.hpp:402-410)
+            const int L = m.ia[3 * vi + 1] - m.ia[3 * vi];
+            if (vi == vj) {
+                const int base = m.ia[3 * vi];
+                atomicAdd(&a[base + 0], H[(3 * i + 0) + 12 * (3 * j + 0)]);
+                atomicAdd(&a[base + 1], H[(3 * i + 0) + 12 * (3 * j + 1)]);
+                atomicAdd(&a[base + 2], H[(3 * i + 0) + 12 * (3 * j + 2)]);
+                atomicAdd(&a[base + L + 0], H[(3 * i + 1) + 12 * (3 * j + 1)]);
+                atomicAdd(&a[base + L + 1], H[(3 * i + 1) + 12 * (3 * j + 2)]);
+                atomicAdd(&a[base + 2 * L - 1], H[(3 * i + 2) + 12 * (3 * j + 2)]);
+            }
+            else {
+                const int p0 = find_block(m, vi, vj);
+                if (p0 < 0) {
+                    atomicOr(err, 1); // the pattern lacks this contact pair: set_pattern must include the connectivity
+                    continue;
+                }
+                for (int r = 0; r < 3; ++r) {
+                    const int rowOff = (r == 0) ? 0 : (r == 1 ? (L - 1) : (2 * L - 3));
+                    for (int c = 0; c < 3; ++c) atomicAdd(&a[p0 + rowOff + c], H[(3 * i + r) + 12 * (3 * j + c)]);
+                }
+            }
+        }
+    }
+}
+
+// a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201)
+__global__ __launch_bounds__(64) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
+    double kappa, double* __restrict__ a, int* __restrict__ err)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    double H[144], B[144], Q[144], W[144];
+    if (i < cv.nA) {
+        const Stencil s = decode(cv.active + 4 * (size_t)i);
+        double X[4][3], g[12], b, gb, Hb;
+        gatherX(cv.x, s.node, s.n, X);
+        const double d = stencil_distance(s.kind, X, g, H);
+        barrier(d, dHat, &b, &gb, &Hb);
+        const int n3 = 3 * s.n;
+        const double cf = kappa * s.mult;
+        for (int k = 0; k < 144; ++k) B[k] = 0.0;
+        for (int r = 0; r < n3; ++r)
+            for (int c = 0; c < n3; ++c) B[r + 12 * c] = ((cf * Hb) * g[r]) * g[c] + (cf * gb) * H[r + 12 * c];
+        make_pd(n3, B, Q, W);
+        scatter_blocks(m, a, B, s.node, s.n, dbc, projectDBC, err);
+    }
+    else if (i < cv.nA + cv.nP) {
+        const int j = i - cv.nA;
+        const Stencil s = decode(cv.para + 4 * (size_t)j);
+        double X[4][3], gS[12], b, gb, Hb;
+        gatherX(cv.x, s.node, s.n, X);
+        const double d = stencil_distance(s.kind, X, gS, H);
+        barrier(d, dHat, &b, &gb, &Hb);
+        int en[4];
+        paraNodes(cv, j, en);
+        double XE[4][3], cg[12], e, eg, eH;
+        gatherX(cv.x, en, 4, XE);
+        const double c = cross_sqnorm_derivs(XE, cg, Q); // Q = Hessian of the cross norm for now
+        mollifier(c, eps_x_of(cv.xRest, en[0], en[1], en[2], en[3]), &e, &eg, &eH);
+        // distance derivatives mapped onto the four edge nodes (SelfCollisionHandler.cpp:3105-3160)
+        int imap[4] = { 0, 0, 0, 0 };
+        for (int k = 0; k < s.n; ++k)
+            for (int q = 0; q < 4; ++q)
+                if (en[q] == s.node[k]) imap[k] = q;
+        double gd[12];
+        for (int k = 0; k < 12; ++k) gd[k] = 0.0;
+        for (int k = 0; k < 144; ++k) W[k] = 0.0; // W = H_d on the edge nodes
+        for (int k = 0; k < s.n; ++k)
+            for (int cc = 0; cc < 3; ++cc) gd[3 * imap[k] + cc] = gS[3 * k + cc];
+        for (int k = 0; k < s.n; ++k)
+            for (int l = 0; l < s.n; ++l)
+                for (int r = 0; r < 3; ++r)
+                    for (int cc = 0; cc < 3; ++cc) W[(3 * imap[k] + r) + 12 * (3 * imap[l] + cc)] = H[(3 * k + r) + 12 * (3 * l + cc)];
+        for (int r = 0; r < 12; ++r)
+            for (int cc = 0; cc < 12; ++cc) {
+                const double e_g_r = eg * cg[r], e_g_c = eg * cg[cc];
+                const double e_H = eg * Q[r + 12 * cc] + eH * cg[r] * cg[cc];
+                B[r + 12 * cc] = (kappa * gb) * gd[r] * e_g_c + (kappa * gb) * gd[cc] * e_g_r + (kappa * b) * e_H + ((kappa * e * Hb) * gd[r]) * gd[cc]
+                    + (kappa * e * gb) * W[r + 12 * cc];
+            }
+        make_pd(12, B, Q, W);
+        scatter_blocks(m, a, B, en, 4, dbc, projectDBC, err);
+    }
+}
+
+// ---- broad phase: uniform grid by counting sort ---------------------------------------------------------------
+struct Grid {
+    double lo[3], h;
+    int dim[3];
+};
+__device__ __forceinline__ int cell_of(const Grid& g, double x, int c)
+{
+    return min(g.dim[c] - 1, max(0, (int)floor((x - g.lo[c]) / g.h)));
+}
+__global__ __launch_bounds__(BLOCK) void k_bbox_partial(int nV, const double* __restrict__ x, double* __restrict__ partial)
+{
+    __shared__ double sm[6][BLOCK / 64];
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    if (v < nV)
+        for (int c = 0; c < 3; ++c) lo[c] = hi[c] = x[3 * (size_t)v + c];
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[c] = fmin(lo[c], __shfl_down(lo[c], off, 64));
+            hi[c] = fmax(hi[c], __shfl_down(hi[c], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sm[c][threadIdx.x >> 6] = lo[c];
+            sm[3 + c][threadIdx.x >> 6] = hi[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = sm[threadIdx.x][0];
+        for (int i = 1; i < BLOCK / 64; ++i) r = (threadIdx.x < 3) ? fmin(r, sm[threadIdx.x][i]) : fmax(r, sm[threadIdx.x][i]);
+        partial[6 * (size_t)blockIdx.x + threadIdx.x] = r;
+    }
+}
+// mode 0: count, mode 1: fill.  Primitive = triangle (isTri) or surface edge, bbox inflated by `infl`
+__global__ __launch_bounds__(BLOCK) void k_grid_insert(int nPrim, int isTri, const int* __restrict__ prim, const double* __restrict__ x, Grid g,
+    double infl, int mode, int* __restrict__ cellCount, const int* __restrict__ cellStart, int* __restrict__ cellItems)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nPrim) return;
+    const int nv = isTri ? 3 : 2;
+    double bl[3] = { 1e300, 1e300, 1e300 }, bh[3] = { -1e300, -1e300, -1e300 };
+    for (int k = 0; k < nv; ++k) {
+        const int v = prim[nv * (size_t)i + k];
+        for (int c = 0; c < 3; ++c) {
+            const double xv = x[3 * (size_t)v + c];
+            bl[c] = fmin(bl[c], xv - infl);
+            bh[c] = fmax(bh[c], xv + infl);
+        }
+    }
+    int a[3], b[3];
+    for (int c = 0; c < 3; ++c) {
+        a[c] = cell_of(g, bl[c], c);
+        b[c] = cell_of(g, bh[c], c);
+    }
+    for (int z = a[2]; z <= b[2]; ++z)
+        for (int y = a[1]; y <= b[1]; ++y)
+            for (int xx = a[0]; xx <= b[0]; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                const int slot = atomicAdd(&cellCount[cell], 1);
+                if (mode == 1) cellItems[cellStart[cell] + slot] = i;
+            }
+}
+
+// out record: 6 ints = MMCVID (4) + (svI | eI, sfI | eJ)
+__global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __restrict__ SVI, const int* __restrict__ SF, const double* __restrict__ x,
+    const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, int cap,
+    int* __restrict__ out, int* __restrict__ counter)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nSVI) return;
+    const int vI = SVI[i];
+    const double p[3] = { x[3 * (size_t)vI], x[3 * (size_t)vI + 1], x[3 * (size_t)vI + 2] };
+    const int cell = cell_of(g, p[0], 0) + g.dim[0] * (cell_of(g, p[1], 1) + g.dim[1] * cell_of(g, p[2], 2));
+    const bool vDbc = dbc[vI] != 0;
+    for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
+        const int f = cellItems[k];
+        const int t0 = SF[3 * (size_t)f], t1 = SF[3 * (size_t)f + 1], t2 = SF[3 * (size_t)f + 2];
+        if (vI == t0 || vI == t1 || vI == t2) continue;
+        if (vDbc && dbc[t0] != 0 && dbc[t1] != 0 && dbc[t2] != 0) continue; // SelfCollisionHandler.cpp:2184-2187
+        const double a[3] = { x[3 * (size_t)t0], x[3 * (size_t)t0 + 1], x[3 * (size_t)t0 + 2] };
+        const double b[3] = { x[3 * (size_t)t1], x[3 * (size_t)t1 + 1], x[3 * (size_t)t1 + 2] };
+        const double c[3] = { x[3 * (size_t)t2], x[3 * (size_t)t2 + 1], x[3 * (size_t)t2 + 2] };
+        double d;
+        int id[4] = { -vI - 1, -1, -1, -1 };
+        switch (dType_PT(p, a, b, c)) {
+        case 0: d = d_PP(p, a); id[1] = t0; break;
+        case 1: d = d_PP(p, b); id[1] = t1; break;
+        case 2: d = d_PP(p, c); id[1] = t2; break;
+        case 3: d = d_PE(p, a, b); id[1] = t0; id[2] = t1; break;
+        case 4: d = d_PE(p, b, c); id[1] = t1; id[2] = t2; break;
+        case 5: d = d_PE(p, c, a); id[1] = t2; id[2] = t0; break;
+        default: d = d_PT(p, a, b, c); id[1] = t0; id[2] = t1; id[3] = t2; break;
+        }
+        if (d < dHat) {
+            const int slot = atomicAdd(counter, 1);
+            if (slot < cap) {
+                int* o = out + 6 * (size_t)slot;
+                o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
+                o[4] = i; o[5] = f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
+    const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
+    int* __restrict__ out, int* __restrict__ counter)
+{
+    const int eI = blockIdx.x * BLOCK + threadIdx.x;
+    if (eI >= nE) return;
+    const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1];
+    const double pa0[3] = { x[3 * (size_t)a0], x[3 * (size_t)a0 + 1], x[3 * (size_t)a0 + 2] };
+    const double pa1[3] = { x[3 * (size_t)a1], x[3 * (size_t)a1 + 1], x[3 * (size_t)a1 + 2] };
+    double bl[3], bh[3];
+    int ca[3], cb[3];
+    for (int c = 0; c < 3; ++c) {
+        bl[c] = fmin(pa0[c], pa1[c]) - infl;
+        bh[c] = fmax(pa0[c], pa1[c]) + infl;
+        ca[c] = cell_of(g, bl[c], c);
+        cb[c] = cell_of(g, bh[c], c);
+    }
+    const bool aDbc = dbc[a0] != 0 && dbc[a1] != 0;
+    for (int z = ca[2]; z <= cb[2]; ++z)
+        for (int y = ca[1]; y <= cb[1]; ++y)
+            for (int xx = ca[0]; xx <= cb[0]; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
+                    const int eJ = cellItems[k];
+                    if (eJ <= eI) continue;
+                    const int b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
+                    if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
+                    const double pb0[3] = { x[3 * (size_t)b0], x[3 * (size_t)b0 + 1], x[3 * (size_t)b0 + 2] };
+                    const double pb1[3] = { x[3 * (size_t)b1], x[3 * (size_t)b1 + 1], x[3 * (size_t)b1 + 2] };
+                    // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap
+                    bool ok = true;
+                    int canon[3];
+                    for (int c = 0; c < 3; ++c) {
+                        const double jl = fmin(pb0[c], pb1[c]) - infl, jh = fmax(pb0[c], pb1[c]) + infl;
+                        if (bl[c] > jh || jl > bh[c]) ok = false;
+                        canon[c] = cell_of(g, fmax(bl[c], jl), c);
+                    }
+                    if (!ok || canon[0] != xx || canon[1] != y || canon[2] != z) continue;
+                    if (aDbc && dbc[b0] != 0 && dbc[b1] != 0) continue; // SelfCollisionHandler.cpp:2294-2297
+                    const int dt = dType_EE(pa0, pa1, pb0, pb1);
+                    const int add_e = (cross_sqnorm(pa0, pa1, pb0, pb1) < eps_x_of(xRest, a0, a1, b0, b1)) ? -eJ - 2 : -1;
+                    double d;
+                    int id[4];
+                    switch (dt) {
+                    case 0: d = d_PP(pa0, pb0); id[0] = -a0 - 1; id[1] = b0; id[2] = -1; id[3] = add_e; break;
+                    case 1: d = d_PP(pa0, pb1); id[0] = -a0 - 1; id[1] = b1; id[2] = -1; id[3] = add_e; break;
+                    case 2: d = d_PE(pa0, pb0, pb1); id[0] = -a0 - 1; id[1] = b0; id[2] = b1; id[3] = add_e; break;
+                    case 3: d = d_PP(pa1, pb0); id[0] = -a1 - 1; id[1] = b0; id[2] = -1; id[3] = add_e; break;
+                    case 4: d = d_PP(pa1, pb1); id[0] = -a1 - 1; id[1] = b1; id[2] = -1; id[3] = add_e; break;
+                    case 5: d = d_PE(pa1, pb0, pb1); id[0] = -a1 - 1; id[1] = b0; id[2] = b1; id[3] = add_e; break;
+                    case 6: d = d_PE(pb0, pa0, pa1); id[0] = -b0 - 1; id[1] = a0; id[2] = a1; id[3] = add_e; break;
+                    case 7: d = d_PE(pb1, pa0, pa1); id[0] = -b1 - 1; id[1] = a0; id[2] = a1; id[3] = add_e; break;
+                    default:
+                        d = d_EE(pa0, pa1, pb0, pb1);
+                        id[0] = a0; id[1] = a1; id[2] = b0;
+                        id[3] = (add_e <= -2) ? (-b1 - nE - 2) : b1;
+                        break;
+                    }
+                    if (d < dHat) {
+                        const int slot = atomicAdd(counter, 1);
+                        if (slot < cap) {
+                            int* o = out + 6 * (size_t)slot;
+                            o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
+                            o[4] = eI; o[5] = eJ;
+                        }
+                    }
+                }
+            }
+}
+
+inline int nblk(long long n, int b = BLOCK) { return (int)((n + b - 1) / b); }
+
+} // namespace
+
+void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc)
+{
+    nSF = nSF_;
+    SF.assign(SFc, SFc + 3 * (size_t)nSF);
+    std::set<std::pair<int, int>> es;
+    std::vector<char> onSurf(mesh.nV, 0);
+    std::vector<int> sfRow(3 * (size_t)nSF);
+    for (int f = 0; f < nSF; ++f) {
+        const int t[3] = { SFc[f], SFc[f + (size_t)nSF], SFc[f + 2 * (size_t)nSF] };
+        for (int k = 0; k < 3; ++k) {
+            if (t[k] < 0 || t[k] >= mesh.nV) throw ArgError("set_surface: vertex index out of range");
+            onSurf[t[k]] = 1;
+            sfRow[3 * (size_t)f + k] = t[k];
+        }
+        // Mesh.cpp:495-511: an edge is kept unless its reverse is already there
+        if (!es.count({ t[1], t[0] })) es.insert({ t[0], t[1] });
+        if (!es.count({ t[2], t[1] })) es.insert({ t[1], t[2] });
+        if (!es.count({ t[0], t[2] })) es.insert({ t[2], t[0] });
+    }
+    SFEdges.assign(es.begin(), es.end());
+    nSFE = (int)SFEdges.size();
+    SVI.clear();
+    for (int v = 0; v < mesh.nV; ++v)
+        if (onSurf[v]) SVI.push_back(v); // Mesh.cpp:921-927
+    nSVI = (int)SVI.size();
+    std::vector<int> sfe(2 * (size_t)nSFE);
+    for (int e = 0; e < nSFE; ++e) {
+        sfe[2 * (size_t)e] = SFEdges[e].first;
+        sfe[2 * (size_t)e + 1] = SFEdges[e].second;
+    }
+    d_SF.upload(sfRow, stream);
+    d_SVI.upload(SVI, stream);
+    d_SFE.upload(sfe, stream);
+    std::vector<double> xr(3 * (size_t)mesh.nV);
+    for (int v = 0; v < mesh.nV; ++v)
+        for (int c = 0; c < 3; ++c) xr[3 * (size_t)v + c] = mesh.V_rest[v + (size_t)mesh.nV * c];
+    d_xRest.upload(xr, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    surfaceSet = true;
+    active.clear();
+    para.clear();
+    paraEIEJ.clear();
+    csPTEE.clear();
+    uploadSets();
+}
+
+void HipContact::setSets(int nA, const int* a4, int nP, const int* p4, const int* pe2)
+{
+    active.resize(nA);
+    for (int i = 0; i < nA; ++i) active[i] = { a4[4 * i], a4[4 * i + 1], a4[4 * i + 2], a4[4 * i + 3] };
+    para.resize(nP);
+    paraEIEJ.resize(nP);
+    for (int i = 0; i < nP; ++i) {
+        para[i] = { p4[4 * i], p4[4 * i + 1], p4[4 * i + 2], p4[4 * i + 3] };
+        paraEIEJ[i] = { pe2[2 * i], pe2[2 * i + 1] };
+    }
+    uploadSets();
+}
+
+void HipContact::uploadSets()
+{
+    std::vector<int> a(4 * std::max<size_t>(1, active.size()), 0), p(4 * std::max<size_t>(1, para.size()), 0),
+        q(2 * std::max<size_t>(1, para.size()), 0);
+    for (size_t i = 0; i < active.size(); ++i)
+        for (int k = 0; k < 4; ++k) a[4 * i + k] = active[i][k];
+    for (size_t i = 0; i < para.size(); ++i) {
+        for (int k = 0; k < 4; ++k) p[4 * i + k] = para[i][k];
+        q[2 * i] = paraEIEJ[i][0];
+        q[2 * i + 1] = paraEIEJ[i][1];
+    }
+    d_active.upload(a, stream);
+    d_para.upload(p, stream);
+    d_paraEIEJ.upload(q, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat)
+{
+    if (!surfaceSet) throw StateError("contact_build before set_surface");
+    const int nV = mesh.nV;
+    const double infl = std::sqrt(dHat);
+    // bounding box of the current positions
+    const int nb = nblk(nV);
+    bboxPartial_.alloc(6 * (size_t)nb);
+    hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
+    std::vector<double> part(6 * (size_t)nb);
+    bboxPartial_.download(part.data(), part.size(), stream);
+    Grid g;
+    double hi[3];
+    for (int c = 0; c < 3; ++c) {
+        g.lo[c] = 1e300;
+        hi[c] = -1e300;
+    }
+    for (int b = 0; b < nb; ++b)
+        for (int c = 0; c < 3; ++c) {
+            g.lo[c] = std::min(g.lo[c], part[6 * (size_t)b + c]);
+            hi[c] = std::max(hi[c], part[6 * (size_t)b + 3 + c]);
+        }
+    g.h = std::max(mesh.avgEdgeLen, 2.0 * infl);
+    long long nCells;
+    for (;;) {
+        nCells = 1;
+        for (int c = 0; c < 3; ++c) {
+            g.dim[c] = std::max(1, (int)std::floor((hi[c] - g.lo[c]) / g.h) + 1);
+            nCells *= g.dim[c];
+        }
+        if (nCells <= (1LL << 26)) break;
+        g.h *= 1.5;
+    }
+    auto buildCells = [&](int nPrim, int isTri, const int* prim, DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items) {
+        cnt.alloc((size_t)nCells + 1);
+        start.alloc((size_t)nCells + 1);
+        cnt.zero(stream);
+        hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, isTri, prim, x_dev, g, infl, 0, cnt.p, (const int*)nullptr,
+            (int*)nullptr);
+        size_t tmpBytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream);
+        if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes);
+        hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream);
+        int total = 0;
+        HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        items.alloc(std::max(1, total));
+        cnt.zero(stream);
+        hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, isTri, prim, x_dev, g, infl, 1, cnt.p, start.p, items.p);
+    };
+    buildCells(nSF, 1, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
+    buildCells(nSFE, 0, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
+    counters_.alloc(2);
+    int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
+    std::vector<int> recPT, recEE;
+    for (;;) {
+        outPT_.alloc(6 * (size_t)capPT);
+        outEE_.alloc(6 * (size_t)capEE);
+        counters_.zero(stream);
+        hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, dbc_dev, g, cellStartT_.p, cellItemsT_.p,
+            dHat, capPT, outPT_.p, counters_.p);
+        hipLaunchKernelGGL(k_narrow_ee, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, dbc_dev, g, cellStartE_.p,
+            cellItemsE_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1);
+        int cnt[2];
+        counters_.download(cnt, 2, stream);
+        if (cnt[0] > capPT || cnt[1] > capEE) { // overflow: grow and redo
+            capPT = std::max(capPT, cnt[0] + cnt[0] / 4);
+            capEE = std::max(capEE, cnt[1] + cnt[1] / 4);
+            continue;
+        }
+        recPT.resize(6 * (size_t)cnt[0]);
+        recEE.resize(6 * (size_t)cnt[1]);
+        if (cnt[0]) outPT_.download(recPT.data(), recPT.size(), stream);
+        if (cnt[1]) outEE_.download(recEE.data(), recEE.size(), stream);
+        break;
+    }
+    // deterministic order (the kernels append through atomics): by (svI, sfI) and (eI, eJ), as a serial scan would emit
+    auto sortRecs = [](std::vector<int>& r) {
+        const size_t n = r.size() / 6;
+        std::vector<size_t> idx(n);
+        for (size_t i = 0; i < n; ++i) idx[i] = i;
+        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+            return std::make_pair(r[6 * a + 4], r[6 * a + 5]) < std::make_pair(r[6 * b + 4], r[6 * b + 5]);
+        });
+        std::vector<int> s(r.size());
+        for (size_t i = 0; i < n; ++i)
+            for (int k = 0; k < 6; ++k) s[6 * i + k] = r[6 * idx[i] + k];
+        r.swap(s);
+    };
+    sortRecs(recPT);
+    sortRecs(recEE);
+    // merge (SelfCollisionHandler.cpp:2411-2476)
+    active.clear();
+    para.clear();
+    paraEIEJ.clear();
+    csPTEE.clear();
+    std::map<std::array<int, 4>, int> counter;
+    for (size_t i = 0; i < recPT.size() / 6; ++i) {
+        const int* r = &recPT[6 * i];
+        csPTEE.push_back({ -r[4] - 1, r[5] });
+        std::array<int, 4> id{ r[0], r[1], r[2], r[3] };
+        if (id[3] < 0) ++counter[id];
+        else active.push_back(id);
+    }
+    for (size_t i = 0; i < recEE.size() / 6; ++i) {
+        const int* r = &recEE[6 * i];
+        csPTEE.push_back({ r[4], r[5] });
+        std::array<int, 4> id{ r[0], r[1], r[2], r[3] };
+        if (id[3] >= 0) active.push_back(id);
+        else if (id[3] == -1) ++counter[id];
+        else if (id[3] >= -nSFE - 1) {
+            para.push_back({ id[0], id[1], id[2], -1 });
+            paraEIEJ.push_back({ r[4], -id[3] - 2 });
+        }
+        else {
+            para.push_back({ id[0], id[1], id[2], -id[3] - nSFE - 2 });
+            paraEIEJ.push_back({ -1, -1 });
+        }
+    }
+    for (const auto& kv : counter) active.push_back({ kv.first[0], kv.first[1], kv.first[2], -kv.second });
+    uploadSets();
+    return (int)active.size();
+}
+
+double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
+{
+    const int n = (int)(active.size() + para.size());
+    if (n == 0) return 0.0;
+    ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+    const int nb = nblk(n);
+    if (partial.n < (size_t)nb) partial.alloc(nb);
+    hipLaunchKernelGGL(k_contact_energy, dim3(nb), dim3(BLOCK), 0, stream, cv, dHat, partial.p);
+    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, nb, kappa, scalar_dev);
+    double out = 0.0;
+    HIP_CHECK(hipMemcpyAsync(&out, scalar_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return out;
+}
+
+void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev)
+{
+    const int n = (int)(active.size() + para.size());
+    if (n) {
+        ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+        hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, grad_dev);
+    }
+    hipLaunchKernelGGL(k_zero_projected, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, projectDBC, grad_dev);
+}
+
+void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
+    double* a_dev)
+{
+    const int n = (int)(active.size() + para.size());
+    if (!n) return;
+    ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+    CsrView m{ lin.d_ia.p, lin.d_ja.p };
+    counters_.alloc(2);
+    counters_.zero(stream);
+    hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, 64)), dim3(64), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, a_dev, counters_.p);
+    int err[2];
+    counters_.download(err, 2, stream);
+    if (err[0]) throw StateError("barrier Hessian touches a node pair outside the CSR pattern: call set_pattern with the contact connectivity first");
+}
+
+void HipContact::connectivity(std::vector<std::pair<int, int>>& pairs) const
+{
+    pairs.clear();
+    auto link = [&](int a, int b) {
+        if (a != b) pairs.push_back({ std::min(a, b), std::max(a, b) });
+    };
+    auto nodesOf = [&](const std::array<int, 4>& c, int* node, int& n, bool& ee) {
+        ee = c[0] >= 0;
+        if (ee) {
+            n = 4;
+            for (int k = 0; k < 4; ++k) node[k] = c[k];
+        }
+        else {
+            node[0] = -c[0] - 1;
+            node[1] = c[1];
+            n = 2;
+            if (c[2] >= 0) node[n++] = c[2];
+            if (c[2] >= 0 && c[3] >= 0) node[n++] = c[3];
+        }
+    };
+    for (const auto& c : active) { // SelfCollisionHandler.cpp:330-376
+        int node[4], n;
+        bool ee;
+        nodesOf(c, node, n, ee);
+        if (ee) {
+            link(node[0], node[2]);
+            link(node[0], node[3]);
+            link(node[1], node[2]);
+            link(node[1], node[3]);
+        }
+        else
+            for (int k = 1; k < n; ++k) link(node[0], node[k]);
+    }
+    for (size_t i = 0; i < para.size(); ++i) { // :378-415
+        int en[4];
+        if (para[i][3] >= 0)
+            for (int k = 0; k < 4; ++k) en[k] = para[i][k];
+        else {
+            en[0] = SFEdges[paraEIEJ[i][0]].first;
+            en[1] = SFEdges[paraEIEJ[i][0]].second;
+            en[2] = SFEdges[paraEIEJ[i][1]].first;
+            en[3] = SFEdges[paraEIEJ[i][1]].second;
+        }
+        link(en[0], en[2]);
+        link(en[0], en[3]);
+        link(en[1], en[2]);
+        link(en[1], en[3]);
+    }
+    std::sort(pairs.begin(), pairs.end());
+    pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+}
+
+} // namespace ipcgpu

@@ -11,6 +11,7 @@
 #include "mf_symbolic.h"
 #include "nh_kernels.h"
 #include "patch_assembly.h"
+#include "hip_contact.h"
 #include <map>
 #include <memory>
 
@@ -140,5 +141,6 @@ struct ipcgpu_ctx {
     std::unique_ptr<ipcgpu::HipMesh> mesh;
     std::unique_ptr<ipcgpu::HipLinSysSolver> lin;
     std::unique_ptr<ipcgpu::HipOptimizer> opt;
+    std::unique_ptr<ipcgpu::HipContact> contact;
     int rank = 0, worldSize = 1;
 };

@@ -269,6 +269,55 @@ class Context:
         self._chk(self._L.ipcgpu_linsys_stats(self.h, _dp(st)))
         return dict(nnzL=st[0], flops=st[1], fronts=int(st[2]), levels=int(st[3]))
 
+    # ---- SelfCollisionHandler
+    def set_surface(self, SF):
+        SF = np.asfortranarray(SF, dtype=np.int32)
+        self._chk(self._L.ipcgpu_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF)))
+
+    def get_surface(self):
+        n = np.zeros(3, dtype=np.int32)
+        self._chk(self._L.ipcgpu_get_surface(self.h, _ip(n), None, None))
+        svi = np.zeros(n[0], dtype=np.int32)
+        sfe = np.zeros((n[2], 2), dtype=np.int32)
+        self._chk(self._L.ipcgpu_get_surface(self.h, _ip(n), _ip(svi), _ip(sfe)))
+        return svi, sfe
+
+    def contact_build(self, dHat):
+        n = np.zeros(3, dtype=np.int32)
+        self._chk(self._L.ipcgpu_contact_build(self.h, C.c_double(dHat), _ip(n)))
+        a = np.zeros((n[0], 4), dtype=np.int32)
+        p = np.zeros((n[1], 4), dtype=np.int32)
+        q = np.zeros((n[1], 2), dtype=np.int32)
+        cs = np.zeros((n[2], 2), dtype=np.int32)
+        self._chk(self._L.ipcgpu_contact_get(self.h, _ip(a), _ip(p), _ip(q), _ip(cs)))
+        return dict(active=a, para=p, para_eiej=q, cs_ptee=cs)
+
+    def contact_set(self, active, para=None, para_eiej=None):
+        a = np.ascontiguousarray(active, dtype=np.int32).reshape(-1, 4)
+        p = np.ascontiguousarray(para if para is not None else np.zeros((0, 4)), dtype=np.int32).reshape(-1, 4)
+        q = np.ascontiguousarray(para_eiej if para_eiej is not None else np.zeros((0, 2)), dtype=np.int32).reshape(-1, 2)
+        self._chk(self._L.ipcgpu_contact_set(self.h, C.c_int(a.shape[0]), _ip(a), C.c_int(p.shape[0]), _ip(p), _ip(q)))
+
+    def contact_energy(self, dHat, kappa):
+        E = C.c_double()
+        self._chk(self._L.ipcgpu_contact_energy(self.h, C.c_double(dHat), C.c_double(kappa), C.byref(E)))
+        return E.value
+
+    def contact_gradient_add(self, dHat, kappa, projectDBC=True, grad=None):
+        g = np.zeros(3 * self.nV) if grad is None else _f64(grad).copy()
+        self._chk(self._L.ipcgpu_contact_gradient_add(self.h, C.c_double(dHat), C.c_double(kappa), C.c_int(int(projectDBC)), _dp(g)))
+        return g
+
+    def contact_hessian_add(self, dHat, kappa, projectDBC=True):
+        self._chk(self._L.ipcgpu_contact_hessian_add(self.h, C.c_double(dHat), C.c_double(kappa), C.c_int(int(projectDBC))))
+
+    def contact_connectivity(self):
+        n = C.c_int()
+        self._chk(self._L.ipcgpu_contact_connectivity(self.h, C.c_int(0), None, C.byref(n)))
+        buf = np.zeros((max(n.value, 1), 2), dtype=np.int32)
+        self._chk(self._L.ipcgpu_contact_connectivity(self.h, C.c_int(n.value), _ip(buf), C.byref(n)))
+        return buf[:n.value].copy()
+
     # ---- Optimizer building blocks
     def assemble_newton(self, dtSq, projectDBC=True, with_gradient=True):
         g = np.zeros(3 * self.nV) if with_gradient else None

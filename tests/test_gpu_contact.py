@@ -1,0 +1,146 @@
+"""Parity of the HIP contact path (C ABI) against the CPU oracle: surface bookkeeping and constraint sets bit-exact
+(integers), barrier energy / gradient 1e-10 relative, PSD-projected barrier Hessian entries 1e-9 relative."""
+import numpy as np
+import pytest
+
+from ipc_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def two_blocks(gap, n=4, shift=0.13):
+    Va, Fa = scene.make_box(n, 1, n, size=(1.0, 0.3, 1.0), origin=(0, 0, 0))
+    Vb, Fb = scene.make_box(n, 1, n, size=(1.0, 0.3, 1.0), origin=(shift, 0.3 + gap, 0.5 * shift))
+    return np.vstack([Va, Vb]), np.vstack([Fa, Fb + Va.shape[0]])
+
+
+@pytest.fixture(scope="module")
+def pair(orc, gpu_lib):
+    V, F = two_blocks(0.004)
+    V = scene.jitter(V, F, rel=3e-3)
+    SF = scene.surface_tris(F)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.opt_init(0.025, False)
+    c.set_surface(SF)
+    dbc = np.nonzero(V[:, 1] < 1e-3 + V[:, 1].min())[0].astype(np.int32)  # bottom face of the lower slab
+    m.set_dbc(dbc, 1)
+    c.set_dbc(dbc, 1)
+    dHat = 1e-3 ** 2 * m.features()["bboxDiag2"] * 40
+    return dict(V=V, F=F, SF=SF, m=m, c=c, dHat=dHat, dbc=dbc)
+
+
+def test_surface_bookkeeping_bit_exact(orc, pair):
+    svi_o, sfe_o = orc.mesh_surface(pair["m"])
+    svi_g, sfe_g = pair["c"].get_surface()
+    assert np.array_equal(svi_g, svi_o) and np.array_equal(sfe_g, sfe_o)
+
+
+def test_constraint_sets_bit_exact(orc, pair):
+    o = orc.Contacts().build(pair["m"], pair["dHat"], brute=True)
+    g = pair["c"].contact_build(pair["dHat"])
+    assert len(o["active"]) > 30
+    for k in ("active", "para", "para_eiej", "cs_ptee"):
+        assert np.array_equal(g[k], o[k]), k  # same tuples in the same order
+    # a wider activation distance: more pairs, PP/PE duplicates with multiplicities
+    o2 = orc.Contacts().build(pair["m"], 4 * pair["dHat"])
+    g2 = pair["c"].contact_build(4 * pair["dHat"])
+    for k in ("active", "para", "para_eiej", "cs_ptee"):
+        assert np.array_equal(g2[k], o2[k]), k
+    assert len(g2["active"]) >= len(g["active"])
+    o3 = orc.Contacts().build(pair["m"], 0.12 * pair["dHat"])
+    g3 = pair["c"].contact_build(0.12 * pair["dHat"])
+    for k in ("active", "para", "para_eiej", "cs_ptee"):
+        assert np.array_equal(g3[k], o3[k]), k
+    assert 0 < len(g3["active"]) < len(g["active"])
+    # empty set far away
+    assert len(pair["c"].contact_build(1e-12)["active"]) == 0
+    pair["c"].contact_build(pair["dHat"])
+
+
+def test_nearly_parallel_edges_go_to_the_mollified_set(orc, gpu_lib):
+    # unjittered slabs: facing edges are exactly parallel -> paraEE entries with their (eI, eJ) bookkeeping
+    V, F = two_blocks(0.004, n=3, shift=0.0)
+    SF = scene.surface_tris(F)
+    m = orc.Mesh(V, F)
+    m.set_surface(SF)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F)
+    c.opt_init(0.025, False)
+    c.set_surface(SF)
+    dHat = (0.006) ** 2
+    o = orc.Contacts().build(m, dHat)
+    g = c.contact_build(dHat)
+    assert len(o["para"]) > 0
+    for k in ("active", "para", "para_eiej", "cs_ptee"):
+        assert np.array_equal(g[k], o[k]), k
+    cs = orc.Contacts()
+    cs.build(m, dHat)
+    assert abs(c.contact_energy(dHat, 1e3) - cs.energy(m, dHat, 1e3)) <= 1e-10 * abs(cs.energy(m, dHat, 1e3))
+    assert relerr(c.contact_gradient_add(dHat, 1e3, True), cs.gradient(m, dHat, 1e3, True)) < 1e-10
+    pairs = c.contact_connectivity()
+    assert np.array_equal(pairs, cs.connectivity(m))
+    c.set_pattern(pairs)
+    m2 = orc.Mesh(V, F)
+    m2.set_surface(SF)
+    ia, ja = m2.pattern(extra_edges=pairs)
+    c.set_zero()
+    c.contact_hessian_add(dHat, 1e3, True)
+    assert relerr(c.get_a(), cs.hessian(m2, len(ja), dHat, 1e3, True)) < 1e-9
+    c.close()
+
+
+def test_barrier_energy_gradient_hessian(orc, pair):
+    m, c, dHat = pair["m"], pair["c"], pair["dHat"]
+    cs = orc.Contacts()
+    sets = cs.build(m, dHat)
+    c.contact_build(dHat)
+    for kappa in (1.0, 2.5e4):
+        Eo = cs.energy(m, dHat, kappa)
+        assert abs(c.contact_energy(dHat, kappa) - Eo) <= 1e-10 * abs(Eo)
+        for proj in (True, False):
+            go = cs.gradient(m, dHat, kappa, proj)
+            gg = c.contact_gradient_add(dHat, kappa, proj)
+            assert relerr(gg, go) < 1e-10
+            if proj:
+                for v in pair["dbc"]:
+                    assert np.all(gg[3 * v:3 * v + 3] == 0)
+    # hand the same set in through the ABI (an adapter that keeps the reference's own constraint code)
+    c.contact_set(sets["active"], sets["para"], sets["para_eiej"])
+    assert abs(c.contact_energy(dHat, 7.0) - cs.energy(m, dHat, 7.0)) <= 1e-10 * abs(cs.energy(m, dHat, 7.0))
+    # Hessian: the pattern must contain the contact connectivity
+    pairs = c.contact_connectivity()
+    assert np.array_equal(pairs, cs.connectivity(m))
+    c.set_pattern()
+    with pytest.raises(Exception):
+        c.set_zero()
+        c.contact_hessian_add(dHat, 1e3, True)
+    c.set_pattern(pairs)
+    m2 = orc.Mesh(pair["V"], pair["F"], YM=1e5, PR=0.4, density=1000.0)
+    m2.set_surface(pair["SF"])
+    m2.set_dbc(pair["dbc"], 1)
+    ia, ja = m2.pattern(extra_edges=pairs)
+    ia_g, ja_g = c.get_pattern()
+    assert np.array_equal(ia_g, ia) and np.array_equal(ja_g, ja)
+    for proj in (True, False):
+        c.set_zero()
+        c.contact_hessian_add(dHat, 1e3, proj)
+        a_o = cs.hessian(m2, len(ja), dHat, 1e3, proj)
+        a_g = c.get_a()
+        assert relerr(a_g, a_o) < 1e-9
+        assert np.array_equal(a_g == 0, a_o == 0)
+    # elastic + barrier in one matrix still factorises (SPD) and solves
+    c.assemble_newton(0.025 ** 2, True, with_gradient=False)
+    c.contact_hessian_add(dHat, 1e3, True)
+    c.analyze_pattern()
+    assert c.factorize()
+    b = np.random.default_rng(2).normal(size=len(ia) - 1)
+    x = c.solve(b)
+    assert np.linalg.norm(c.multiply(x) - b) <= 1e-9 * np.linalg.norm(b)
