@@ -276,7 +276,7 @@ class Optimizer:
         sc = np.zeros(8)
         lib().orc_opt_get(self.h, _dp(V), _dp(p), _dp(g), _dp(sc))
         return dict(V=V, searchDir=p, gradient=g, E=sc[0], stepSize=sc[1], targetGRes=sc[2],
-                    innerIterAmt=int(sc[3]), timestep=int(sc[4]), alphaFeasible=sc[5])
+                    innerIterAmt=int(sc[3]), timestep=int(sc[4]), alphaFeasible=sc[5], kappa=sc[6], dHat=sc[7])
 
     def timers(self):
         t = np.zeros(16)
@@ -390,6 +390,52 @@ class Contacts:
         buf = np.zeros((cap, 2), dtype=np.int32)
         n = lib().orc_contact_connectivity(self.h, mesh.h, C.c_int(cap), _ip(buf))
         return buf[:n].copy()
+
+
+def accd(kind, X, P, eta=0.2, tmax=1.0):
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(4, 3)
+    lib().orc_accd.restype = C.c_double
+    return lib().orc_accd(C.c_int(kind), _dp(X), _dp(P), C.c_double(eta), C.c_double(tmax))
+
+
+def ccd_partial(contacts: "Contacts", mesh: "Mesh", p, slackness=0.8, step=1.0):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    arg = C.c_int(-1)
+    lib().orc_ccd_partial.restype = C.c_double
+    s = lib().orc_ccd_partial(contacts.h, mesh.h, _dp(p), C.c_double(slackness), C.c_double(step), C.byref(arg))
+    return s, arg.value
+
+
+def ccd_full(mesh: "Mesh", p, slackness=0.8, step=1.0):
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    pair = np.zeros(2, dtype=np.int32)
+    n = C.c_int()
+    lib().orc_ccd_full.restype = C.c_double
+    s = lib().orc_ccd_full(mesh.h, _dp(p), C.c_double(slackness), C.c_double(step), _ip(pair), C.byref(n))
+    return s, tuple(int(x) for x in pair), n.value
+
+
+def is_intersected(mesh: "Mesh"):
+    return bool(lib().orc_is_intersected(mesh.h))
+
+
+def opt_enable_self_collision(opt: "Optimizer", dHatEps=1e-3):
+    lib().orc_opt_enable_self_collision(opt.h, C.c_double(dHatEps))
+
+
+def opt_set_velocity(opt: "Optimizer", vel):
+    v = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1)
+    lib().orc_opt_set_velocity(opt.h, _dp(v))
+
+
+def opt_contact_state(opt: "Optimizer"):
+    n = np.zeros(6, dtype=np.int32)
+    lib().orc_opt_get_contact(opt.h, _ip(n), None, None)
+    a = np.zeros((n[0], 4), dtype=np.int32)
+    p = np.zeros((n[1], 4), dtype=np.int32)
+    lib().orc_opt_get_contact(opt.h, _ip(n), _ip(a), _ip(p))
+    return dict(active=a, para=p, n_candidates=int(n[2]), ccd_arg=int(n[3]), n_full_ccd=int(n[4]), n_pattern_changes=int(n[5]))
 
 
 def mesh_surface(mesh: "Mesh"):

@@ -749,11 +749,250 @@ void computeConstraintSet(const Mesh& m, double dHat, bool brute, ContactSets& o
     for (const auto& kv : counter) out.active.push_back({ kv.first[0], kv.first[1], kv.first[2], -kv.second });
 }
 
+// ---- conservative CCD step bound -----------------------------------------------------------------------------
+// The reference calls CTCD::vertexFaceCTCD / edgeEdgeCTCD (CCD-Wrapper@23907da, Etienne Vouga's floating-point
+// root finder; not vendored, "parity unpinned") with eta = (1 - slackness) * current distance
+// (SelfCollisionHandler.cpp:564-686, 982-1366).  The contract restated here: the returned step keeps every tested
+// pair at a distance of at least (1 - slackness) times its current distance.  It is met by additive conservative
+// advancement on the unclassified PT / EE distance (distance evaluations only, no root finding): advance by
+// (1 - eta) d / l_p, the largest time in which a relative displacement bounded by l_p cannot close the gap below
+// eta d0, until the distance drops to eta d0 or the step bound is passed.
+static double unclassifiedD2(int kind, const double X[4][3])
+{
+    double d;
+    double Y[4][3];
+    auto put = [&](std::initializer_list<int> idx) {
+        int k = 0;
+        for (int i : idx) {
+            for (int c = 0; c < 3; ++c) Y[k][c] = X[i][c];
+            ++k;
+        }
+    };
+    if (kind == K_PT) {
+        switch (dType_PT(X[0], X[1], X[2], X[3])) {
+        case 0: put({ 0, 1 }); stencil_distance(K_PP, Y, &d, nullptr, nullptr); break;
+        case 1: put({ 0, 2 }); stencil_distance(K_PP, Y, &d, nullptr, nullptr); break;
+        case 2: put({ 0, 3 }); stencil_distance(K_PP, Y, &d, nullptr, nullptr); break;
+        case 3: put({ 0, 1, 2 }); stencil_distance(K_PE, Y, &d, nullptr, nullptr); break;
+        case 4: put({ 0, 2, 3 }); stencil_distance(K_PE, Y, &d, nullptr, nullptr); break;
+        case 5: put({ 0, 3, 1 }); stencil_distance(K_PE, Y, &d, nullptr, nullptr); break;
+        default: stencil_distance(K_PT, X, &d, nullptr, nullptr); break;
+        }
+    }
+    else {
+        switch (dType_EE(X[0], X[1], X[2], X[3])) {
+        case 0: put({ 0, 2 }); stencil_distance(K_PP, Y, &d, nullptr, nullptr); break;
+        case 1: put({ 0, 3 }); stencil_distance(K_PP, Y, &d, nullptr, nullptr); break;
+        case 2: put({ 0, 2, 3 }); stencil_distance(K_PE, Y, &d, nullptr, nullptr); break;
+        case 3: put({ 1, 2 }); stencil_distance(K_PP, Y, &d, nullptr, nullptr); break;
+        case 4: put({ 1, 3 }); stencil_distance(K_PP, Y, &d, nullptr, nullptr); break;
+        case 5: put({ 1, 2, 3 }); stencil_distance(K_PE, Y, &d, nullptr, nullptr); break;
+        case 6: put({ 2, 0, 1 }); stencil_distance(K_PE, Y, &d, nullptr, nullptr); break;
+        case 7: put({ 3, 0, 1 }); stencil_distance(K_PE, Y, &d, nullptr, nullptr); break;
+        default: stencil_distance(K_EE, X, &d, nullptr, nullptr); break;
+        }
+    }
+    return d;
+}
+
+double accd(int kind, const double X0[4][3], const double P0[4][3], double eta, double tmax)
+{
+    double X[4][3], P[4][3], mean[3] = { 0, 0, 0 };
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) mean[c] += P0[k][c];
+    for (int c = 0; c < 3; ++c) mean[c] /= 4.0;
+    double len[4];
+    for (int k = 0; k < 4; ++k) {
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = X0[k][c];
+            P[k][c] = P0[k][c] - mean[c];
+        }
+        len[k] = std::sqrt(dot3(P[k], P[k]));
+    }
+    const double lp = (kind == K_PT) ? len[0] + std::max(len[1], std::max(len[2], len[3]))
+                                     : std::max(len[0], len[1]) + std::max(len[2], len[3]);
+    if (lp == 0.0) return tmax;
+    double d = std::sqrt(unclassifiedD2(kind, X));
+    const double gap = eta * d;
+    double toc = 0.0;
+    for (int it = 0; it < 100000; ++it) {
+        const double tl = (1.0 - eta) * d / lp;
+        for (int k = 0; k < 4; ++k)
+            for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
+        d = std::sqrt(unclassifiedD2(kind, X));
+        if (toc != 0.0 && d < gap) break;
+        toc += tl;
+        if (toc > tmax) return tmax;
+    }
+    return toc;
+}
+
+static void pairNodes(const Mesh& m, const std::array<int, 2>& pr, int& kind, int node[4])
+{
+    if (pr[0] < 0) { // (-svI-1, sfI)
+        kind = K_PT;
+        node[0] = m.SVI[-pr[0] - 1];
+        for (int k = 0; k < 3; ++k) node[1 + k] = m.SF[pr[1] + m.nSF * k];
+    }
+    else {
+        kind = K_EE;
+        node[0] = m.SFEdges[pr[0]].first;
+        node[1] = m.SFEdges[pr[0]].second;
+        node[2] = m.SFEdges[pr[1]].first;
+        node[3] = m.SFEdges[pr[1]].second;
+    }
+}
+
+// min over the listed pairs; returns the new step bound and the index of the limiting pair (-1: none)
+double ccdStepBound(const Mesh& m, const std::vector<std::array<int, 2>>& pairs, const double* p, double slackness, double stepSize,
+    int* argPair)
+{
+    const double eta = 1.0 - slackness;
+    int arg = -1;
+    for (size_t i = 0; i < pairs.size(); ++i) {
+        int kind, node[4];
+        pairNodes(m, pairs[i], kind, node);
+        double X[4][3], P[4][3];
+        for (int k = 0; k < 4; ++k)
+            for (int c = 0; c < 3; ++c) {
+                X[k][c] = m.Vx(node[k], c);
+                P[k][c] = p[3 * node[k] + c];
+            }
+        double t = accd(kind, X, P, eta, stepSize);
+        if (t < 1.0e-6) { // SelfCollisionHandler.cpp:617-636: retry almost without safety distance, then back off
+            const double t2 = accd(kind, X, P, 0.01, stepSize);
+            t = slackness * t2;
+        }
+        if (t < stepSize) {
+            stepSize = t;
+            arg = (int)i;
+        }
+    }
+    if (argPair) *argPair = arg;
+    return stepSize;
+}
+
+// all PT / EE pairs whose boxes swept over [x, x + stepSize p] overlap (the role of SpatialHash::build(mesh, p, alpha,
+// voxel) + queryPointForPrimitives / queryEdgeForEdges, SpatialHash.hpp:589-832), same exclusions as the narrow phase
+void sweptCandidates(const Mesh& m, const double* p, double stepSize, std::vector<std::array<int, 2>>& out)
+{
+    out.clear();
+    const int nSVI = (int)m.SVI.size(), nSF = m.nSF, nE = (int)m.SFEdges.size();
+    auto box = [&](const int* node, int n, double* lo, double* hi) {
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = 1e300;
+            hi[c] = -1e300;
+        }
+        for (int k = 0; k < n; ++k)
+            for (int c = 0; c < 3; ++c) {
+                const double a = m.Vx(node[k], c), b = a + stepSize * p[3 * node[k] + c];
+                lo[c] = std::min(lo[c], std::min(a, b));
+                hi[c] = std::max(hi[c], std::max(a, b));
+            }
+    };
+    auto overlap = [](const double* al, const double* ah, const double* bl, const double* bh) {
+        for (int c = 0; c < 3; ++c)
+            if (al[c] > bh[c] || bl[c] > ah[c]) return false;
+        return true;
+    };
+    std::vector<std::array<double, 6>> tb(nSF), eb(nE);
+    for (int f = 0; f < nSF; ++f) {
+        int nd[3] = { m.SF[f], m.SF[f + nSF], m.SF[f + 2 * nSF] };
+        box(nd, 3, &tb[f][0], &tb[f][3]);
+    }
+    for (int e = 0; e < nE; ++e) {
+        int nd[2] = { m.SFEdges[e].first, m.SFEdges[e].second };
+        box(nd, 2, &eb[e][0], &eb[e][3]);
+    }
+    for (int i = 0; i < nSVI; ++i) {
+        const int v = m.SVI[i];
+        double lo[3], hi[3];
+        box(&v, 1, lo, hi);
+        for (int f = 0; f < nSF; ++f) {
+            const int t0 = m.SF[f], t1 = m.SF[f + nSF], t2 = m.SF[f + 2 * nSF];
+            if (v == t0 || v == t1 || v == t2) continue;
+            if (m.isDBC(v) && m.isDBC(t0) && m.isDBC(t1) && m.isDBC(t2)) continue;
+            if (overlap(lo, hi, &tb[f][0], &tb[f][3])) out.push_back({ -i - 1, f });
+        }
+    }
+    for (int e = 0; e < nE; ++e)
+        for (int j = e + 1; j < nE; ++j) {
+            const int a0 = m.SFEdges[e].first, a1 = m.SFEdges[e].second, b0 = m.SFEdges[j].first, b1 = m.SFEdges[j].second;
+            if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
+            if (m.isDBC(a0) && m.isDBC(a1) && m.isDBC(b0) && m.isDBC(b1)) continue;
+            if (overlap(&eb[e][0], &eb[e][3], &eb[j][0], &eb[j][3])) out.push_back({ e, j });
+        }
+}
+
+// IglUtils::segTriIntersect, the branch without exact predicates (IglUtils.hpp:236-245, 258-264)
+static bool segTriIntersect(const double* ve0, const double* ve1, const double* vt0, const double* vt1, const double* vt2)
+{
+    double c0[3], c1[3], c2[3], n[3], r0[3], r1[3];
+    sub3(vt1, vt0, c0);
+    sub3(vt2, vt0, c1);
+    sub3(ve0, ve1, c2);
+    cross3(c0, c1, n);
+    sub3(ve0, vt0, r0);
+    sub3(ve1, vt0, r1);
+    if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
+    const double det = dot3(n, c2);
+    if (det == 0.0) return false;
+    // Cramer: [c0 c1 c2] (u v t)^T = r0
+    double t0[3], t1[3];
+    cross3(r0, c1, t0);
+    cross3(c0, r0, t1);
+    const double u = dot3(t0, c2) / det, v = dot3(t1, c2) / det, t = dot3(n, r0) / det;
+    return u >= 0.0 && v >= 0.0 && u + v <= 1.0 && t >= 0.0 && t <= 1.0;
+}
+
+// SelfCollisionHandler::checkEdgeTriIntersectionIfAny (SelfCollisionHandler.cpp:3255-3300): true = intersecting
+bool isIntersected(const Mesh& m)
+{
+    const int nSF = m.nSF, nE = (int)m.SFEdges.size();
+    for (int f = 0; f < nSF; ++f) {
+        const int t0 = m.SF[f], t1 = m.SF[f + nSF], t2 = m.SF[f + 2 * nSF];
+        double a[3], b[3], c[3], lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            a[k] = m.Vx(t0, k);
+            b[k] = m.Vx(t1, k);
+            c[k] = m.Vx(t2, k);
+            lo[k] = std::min(a[k], std::min(b[k], c[k]));
+            hi[k] = std::max(a[k], std::max(b[k], c[k]));
+        }
+        for (int e = 0; e < nE; ++e) {
+            const int e0 = m.SFEdges[e].first, e1 = m.SFEdges[e].second;
+            if (e0 == t0 || e0 == t1 || e0 == t2 || e1 == t0 || e1 == t1 || e1 == t2) continue;
+            if (m.isDBC(e0) && m.isDBC(e1) && m.isDBC(t0) && m.isDBC(t1) && m.isDBC(t2)) continue;
+            double p0[3], p1[3];
+            bool sep = false;
+            for (int k = 0; k < 3; ++k) {
+                p0[k] = m.Vx(e0, k);
+                p1[k] = m.Vx(e1, k);
+                if (std::min(p0[k], p1[k]) > hi[k] || std::max(p0[k], p1[k]) < lo[k]) sep = true;
+            }
+            if (sep) continue;
+            if (segTriIntersect(p0, p1, a, b, c)) return true;
+        }
+    }
+    return false;
+}
+
 } // namespace orc
 
 // ======================================================================= C API
 using namespace orc;
 extern "C" {
+
+double orc_accd(int kind, const double* X12, const double* P12, double eta, double tmax)
+{
+    double X[4][3], P[4][3];
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = X12[3 * k + c];
+            P[k][c] = P12[3 * k + c];
+        }
+    return accd(kind, X, P, eta, tmax);
+}
 
 void orc_stencil_distance(int kind, const double* X12, double* d, double* g12, double* H144)
 {
@@ -831,6 +1070,27 @@ int orc_contact_connectivity(const orc_contacts* c, const orc_mesh* m, int cap, 
     }
     return (int)p.size();
 }
+// partial CCD over the candidate list of the constraint set (largestFeasibleStepSize, SelfCollisionHandler.cpp:564-686)
+double orc_ccd_partial(const orc_contacts* c, const orc_mesh* m, const double* p, double slackness, double stepSize, int* argPair)
+{
+    return ccdStepBound(m->m, c->cs.csPTEE, p, slackness, stepSize, argPair);
+}
+// full CCD over every pair with overlapping swept boxes (largestFeasibleStepSize_CCD, :982-1366); pair2 = limiting pair
+double orc_ccd_full(const orc_mesh* m, const double* p, double slackness, double stepSize, int* pair2, int* nCand)
+{
+    std::vector<std::array<int, 2>> cand;
+    sweptCandidates(m->m, p, stepSize, cand);
+    int arg = -1;
+    const double s = ccdStepBound(m->m, cand, p, slackness, stepSize, &arg);
+    if (pair2) {
+        pair2[0] = arg >= 0 ? cand[arg][0] : 0;
+        pair2[1] = arg >= 0 ? cand[arg][1] : 0;
+    }
+    if (nCand) *nCand = (int)cand.size();
+    return arg >= 0 ? s : stepSize;
+}
+int orc_is_intersected(const orc_mesh* m) { return isIntersected(m->m) ? 1 : 0; }
+
 int orc_mesh_surface_counts(const orc_mesh* m, int* n3)
 {
     n3[0] = (int)m->m.SVI.size();

@@ -50,4 +50,11 @@ void contactHessian(const Mesh& m, const ContactSets& cs, double dHat, double ka
 // augmentConnectivity (SelfCollisionHandler.cpp:330-415): node pairs the barrier Hessians couple
 void contactConnectivity(const Mesh& m, const ContactSets& cs, std::vector<std::pair<int, int>>& pairs);
 
+// conservative CCD (contract: every tested pair keeps >= (1 - slackness) of its current distance); see orc_contact.cpp
+double accd(int kind, const double X[4][3], const double P[4][3], double eta, double tmax);
+double ccdStepBound(const Mesh& m, const std::vector<std::array<int, 2>>& pairs, const double* p, double slackness, double stepSize,
+    int* argPair);
+void sweptCandidates(const Mesh& m, const double* p, double stepSize, std::vector<std::array<int, 2>>& out);
+bool isIntersected(const Mesh& m); // any surface edge through any surface triangle (SelfCollisionHandler.cpp:3255-3300)
+
 } // namespace orc

@@ -2,11 +2,12 @@
 //
 // CPU restatement of the time-step driver around the Newton loop, following
 // Optimizer.cpp: solve() 510-602, fullyImplicit_IP() 1518-1819, solveSub_IP() 1822-2213,
-// computeSearchDir() 2324-2355, lineSearch() 2662-2916, stepForward() 2919-2938,
+// computeSearchDir() 2324-2355, postLineSearch() 2357-2445, computeConstraintSets() 2448-2470,
+// lineSearch() 2662-2916, stepForward() 2919-2938, suggest/upperBound/initKappa 2216-2313,
 // computeEnergyVal() 3199-3405, computeGradient() 3409-3545, computePrecondMtr() 3549-3720,
 // computeXTilta() 1236-1257, and the `twist` script of AnimScripter.cpp:555-572,1674-1684.
-// Contact terms are added by orc_contact.cpp when a surface is registered.
 #include "orc_api.h"
+#include "orc_contact.h"
 #include "orc_core.h"
 #include <chrono>
 #include <cstdio>
@@ -28,6 +29,14 @@ struct orc_opt {
     double lastEnergyVal = 0, lastStepSize = 0, lastAlphaFeasible = 0;
     double timers[16] = { 0 };
     bool patternDirty = true;
+    // self-contact (interior point)
+    bool selfCollision = false;
+    ContactSets cs;
+    double dHatEps = 1.0e-3, dHat = 0, kappa = 0, dTol = 0;
+    std::vector<std::pair<int, int>> curExtra; // contact connectivity inside the current pattern (vNeighbor_IP)
+    std::vector<MMCVID> closeID; // closeMConstraintID / closeMConstraintVal (Optimizer.cpp:2396-2440)
+    std::vector<double> closeVal;
+    int lastCCDArg = -1, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
 };
 
 namespace {
@@ -48,7 +57,7 @@ void computeXTilta(orc_opt* o)
         }
 }
 
-// Optimizer.cpp:3199-3239 (elasticity + inertia)
+// Optimizer.cpp:3199-3353 (elasticity + inertia + barrier)
 double computeEnergyVal(orc_opt* o)
 {
     Mesh& m = *o->m;
@@ -65,27 +74,39 @@ double computeEnergyVal(orc_opt* o)
     }
     double sum = 0;
     for (int v = 0; v < m.nV; ++v) sum += ev[v];
-    return E + sum;
+    E += sum;
+    if (o->selfCollision) E += contactEnergy(m, o->cs, o->dHat, o->kappa);
+    return E;
 }
 
-// Optimizer.cpp:3409-3450
-void computeGradient(orc_opt* o, bool projectDBC)
+// elasticity + inertia only (computeGradient with solveIP == false, as initKappa calls it, Optimizer.cpp:2243-2245)
+void elasticInertiaGradient(orc_opt* o, bool projectDBC, double* g)
 {
     Mesh& m = *o->m;
-    elasticGradient(m, o->dtSq, projectDBC, o->gradient.data());
+    elasticGradient(m, o->dtSq, projectDBC, g);
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < m.nV; ++v)
         if (!m.isProjectDBC(v, projectDBC))
-            for (int c = 0; c < 3; ++c)
-                o->gradient[3 * v + c] += m.mass[v] * (m.V[v + m.nV * c] - o->xTilta[v + m.nV * c]);
+            for (int c = 0; c < 3; ++c) g[3 * v + c] += m.mass[v] * (m.V[v + m.nV * c] - o->xTilta[v + m.nV * c]);
 }
 
-void ensurePattern(orc_opt* o)
+// Optimizer.cpp:3409-3517
+void computeGradient(orc_opt* o, bool projectDBC)
 {
-    if (!o->patternDirty) return;
+    Mesh& m = *o->m;
+    elasticInertiaGradient(o, projectDBC, o->gradient.data());
+    if (o->selfCollision) contactGradient(m, o->cs, o->dHat, o->kappa, projectDBC, o->gradient.data());
+    for (int v = 0; v < m.nV; ++v)
+        if (m.isDBC(v) && m.isProjectDBC(v, projectDBC))
+            for (int c = 0; c < 3; ++c) o->gradient[3 * v + c] = 0; // :3512-3516
+}
+
+void rebuildPattern(orc_opt* o)
+{
     Mesh& m = *o->m;
     {
         Tic t(o->timers[1]);
+        m.extraEdges = o->curExtra;
         m.buildPattern();
         o->a.assign(m.ja.size(), 0.0);
     }
@@ -97,11 +118,141 @@ void ensurePattern(orc_opt* o)
     o->patternDirty = false;
 }
 
+// computePrecondMtr (Optimizer.cpp:3549-3720): pattern follows the contact connectivity, then elastic + mass + barrier
+void computePrecondMtr(orc_opt* o, bool projectDBC)
+{
+    Mesh& m = *o->m;
+    std::vector<std::pair<int, int>> extra;
+    if (o->selfCollision && (o->cs.active.size() + o->cs.paraEE.size())) contactConnectivity(m, o->cs, extra);
+    // only pairs that are not mesh edges change vNeighbor
+    std::vector<std::pair<int, int>> fresh;
+    for (const auto& e : extra)
+        if (!m.vNeighbor[e.first].count(e.second)) fresh.push_back(e);
+    if (o->patternDirty || fresh != o->curExtra) {
+        if (!o->patternDirty) o->nPatternChanges++;
+        o->curExtra = fresh;
+        rebuildPattern(o);
+    }
+    Tic t(o->timers[0]);
+    assembleHessian(m, o->dtSq, projectDBC, o->a.data());
+    if (o->selfCollision) contactHessian(m, o->cs, o->dHat, o->kappa, projectDBC, o->a.data());
+}
+
 void stepForward(orc_opt* o, const std::vector<double>& V0, double alpha)
 {
     Mesh& m = *o->m;
     for (int v = 0; v < m.nV; ++v)
         for (int c = 0; c < 3; ++c) m.V[v + m.nV * c] = V0[v + m.nV * c] + alpha * o->searchDir[3 * v + c];
+}
+
+void computeConstraintSets(orc_opt* o)
+{
+    if (!o->selfCollision) return;
+    Tic t(o->timers[14]);
+    computeConstraintSet(*o->m, o->dHat, false, o->cs);
+}
+
+double kappaFloor(orc_opt* o)
+{
+    // suggestKappa (Optimizer.cpp:2228-2233): kappaMinMultiplier (1e11, Config.hpp:139) * mean nodal mass / (4e-16 L^2 b''(1e-16 L^2))
+    const Mesh& m = *o->m;
+    double Hb;
+    barrier(1.0e-16 * m.bboxDiag2, o->dHat, nullptr, nullptr, &Hb);
+    double avgMass = 0;
+    for (double x : m.mass) avgMass += x;
+    avgMass /= m.nV;
+    return 1.0e11 * avgMass / (4.0e-16 * m.bboxDiag2 * Hb);
+}
+
+void initKappa(orc_opt* o)
+{
+    // Optimizer.cpp:2236-2313
+    Mesh& m = *o->m;
+    if (o->cs.active.empty()) return;
+    std::vector<double> gE(3 * m.nV), gc(3 * m.nV, 0.0);
+    elasticInertiaGradient(o, true, gE.data());
+    ContactSets only;
+    only.active = o->cs.active;
+    contactGradient(m, only, o->dHat, 1.0, true, gc.data());
+    double num = 0, den = 0;
+    for (int i = 0; i < 3 * m.nV; ++i) {
+        num += gc[i] * gE[i];
+        den += gc[i] * gc[i];
+    }
+    double minKappa = -num / den;
+    if (minKappa > 0.0) o->kappa = minKappa;
+    minKappa = kappaFloor(o);
+    if (o->kappa < minKappa) o->kappa = minKappa;
+    const double kappaMax = 100 * kappaFloor(o); // upperBoundKappa, :2216-2225
+    if (o->kappa > kappaMax) o->kappa = kappaMax;
+}
+
+double evalMMCVID(const Mesh& m, const MMCVID& c)
+{
+    ContactSets one;
+    one.active.push_back(c);
+    // distance of a single stencil: reuse the energy path would add the barrier; do it directly
+    int node[4], n, kind;
+    if (c[0] >= 0) {
+        kind = K_EE;
+        n = 4;
+        for (int k = 0; k < 4; ++k) node[k] = c[k];
+    }
+    else {
+        node[0] = -c[0] - 1;
+        node[1] = c[1];
+        if (c[2] < 0) {
+            kind = K_PP;
+            n = 2;
+        }
+        else if (c[3] < 0) {
+            kind = K_PE;
+            n = 3;
+            node[2] = c[2];
+        }
+        else {
+            kind = K_PT;
+            n = 4;
+            node[2] = c[2];
+            node[3] = c[3];
+        }
+    }
+    double X[4][3] = { { 0 } }, d;
+    for (int k = 0; k < n; ++k)
+        for (int cc = 0; cc < 3; ++cc) X[k][cc] = m.Vx(node[k], cc);
+    stencil_distance(kind, X, &d, nullptr, nullptr);
+    return d;
+}
+
+void postLineSearch(orc_opt* o)
+{
+    // Optimizer.cpp:2357-2445 (ADAPTIVE_KAPPA)
+    if (!o->selfCollision) return;
+    Mesh& m = *o->m;
+    if (o->kappa == 0.0) {
+        initKappa(o);
+        return;
+    }
+    bool updateKappa = false;
+    for (size_t i = 0; i < o->closeID.size(); ++i)
+        if (evalMMCVID(m, o->closeID[i]) <= o->closeVal[i]) {
+            updateKappa = true;
+            break;
+        }
+    if (updateKappa) {
+        o->kappa *= 2.0;
+        const double kappaMax = 100 * kappaFloor(o);
+        if (o->kappa > kappaMax) o->kappa = kappaMax;
+    }
+    o->closeID.clear();
+    o->closeVal.clear();
+    for (const auto& c : o->cs.active) {
+        const double d = evalMMCVID(m, c);
+        if (d < o->dTol) {
+            o->closeID.push_back(c);
+            o->closeVal.push_back(d);
+        }
+    }
 }
 
 // Optimizer.cpp:2662-2916 with armijoParam = 0, lowerBound = 0 (the IP call site, :2059)
@@ -110,7 +261,7 @@ void lineSearch(orc_opt* o, double& stepSize)
     Mesh& m = *o->m;
     {
         Tic t(o->timers[9]);
-        o->lastEnergyVal = computeEnergyVal(o);
+        o->lastEnergyVal = computeEnergyVal(o); // :2681, with the current constraint set and kappa
     }
     std::vector<double> V0 = m.V;
     {
@@ -120,12 +271,19 @@ void lineSearch(orc_opt* o, double& stepSize)
             stepSize /= 2.0;
             stepForward(o, V0, stepSize);
         }
+        if (o->selfCollision)
+            while (isIntersected(m)) { // :2719-2736
+                stepSize /= 2.0;
+                stepForward(o, V0, stepSize);
+            }
     }
+    computeConstraintSets(o);
     double testingE;
     {
         Tic t(o->timers[9]);
         testingE = computeEnergyVal(o);
     }
+    const double LFStepSize = stepSize;
     while (testingE > o->lastEnergyVal && stepSize > 0.0) {
         stepSize /= 2.0;
         if (stepSize == 0.0) break;
@@ -133,8 +291,21 @@ void lineSearch(orc_opt* o, double& stepSize)
             Tic t(o->timers[5]);
             stepForward(o, V0, stepSize);
         }
+        computeConstraintSets(o);
         Tic t(o->timers[9]);
         testingE = computeEnergyVal(o);
+    }
+    if (stepSize < LFStepSize && o->selfCollision) { // :2799-2811
+        bool needRecomputeCS = false;
+        while (isIntersected(m)) {
+            stepSize /= 2.0;
+            stepForward(o, V0, stepSize);
+            needRecomputeCS = true;
+        }
+        if (needRecomputeCS) {
+            computeConstraintSets(o);
+            testingE = computeEnergyVal(o);
+        }
     }
     o->lastEnergyVal = testingE;
 }
@@ -172,6 +343,19 @@ void orc_opt_set_rel_tol(orc_opt* o, double relTol)
     o->relGL2Tol = relTol * relTol;
     o->targetGRes = std::sqrt(o->relGL2Tol * o->m->bboxDiag2 * o->dtSq); // Optimizer.cpp:2941-2945
 }
+void orc_opt_set_velocity(orc_opt* o, const double* vel3nV)
+{
+    o->velocity.assign(vel3nV, vel3nV + 3 * o->m->nV);
+    computeXTilta(o);
+}
+void orc_opt_enable_self_collision(orc_opt* o, double dHatEps)
+{
+    // `selfCollisionOn` + interior point; dHat = dHatEps^2 * bbox diagonal^2 (Optimizer.cpp:1534-1537, Config.cpp:41-45)
+    o->selfCollision = true;
+    o->dHatEps = dHatEps;
+    o->dHat = dHatEps * dHatEps * o->m->bboxDiag2;
+    o->dTol = 1.0e-18 * o->m->bboxDiag2; // dTolRel = 1e-9 (Optimizer.cpp:102-109)
+}
 void orc_opt_set_twist(orc_opt* o, int nL, const int* left, int nR, const int* right, double angVel)
 {
     // AnimScripter.cpp:555-572: handle set bI gets (-1)^bI * -angVel (angVel = 0.4 pi in the reference), DBC type NONZERO
@@ -189,9 +373,9 @@ void orc_opt_set_twist(orc_opt* o, int nL, const int* left, int nR, const int* r
 
 void orc_opt_precompute(orc_opt* o)
 {
-    // Optimizer.cpp:457-507: set_pattern, computePrecondMtr(redoSVD), analyze_pattern, initial energy
-    ensurePattern(o);
-    assembleHessian(*o->m, o->dtSq, true, o->a.data());
+    // Optimizer.cpp:457-507: set_pattern, constraint sets, computePrecondMtr(redoSVD), analyze_pattern, initial energy
+    computeConstraintSets(o);
+    computePrecondMtr(o, true);
     o->lastEnergyVal = computeEnergyVal(o);
 }
 
@@ -199,8 +383,7 @@ void orc_opt_begin_timestep(orc_opt* o)
 {
     Mesh& m = *o->m;
     Tic t(o->timers[11]);
-    // stepAnimScript, AST_TWIST (AnimScripter.cpp:1674-1684): rotate handle vertices about the x axis
-    // through the rest bbox centre by angVel*dt; move them fully (no contact => step size 1 unless inversion).
+    // stepAnimScript, AST_TWIST (AnimScripter.cpp:1674-1684, 2140-2275)
     std::fill(o->searchDir.begin(), o->searchDir.end(), 0.0);
     for (const auto& h : o->angVel) {
         int v = h.first;
@@ -212,17 +395,38 @@ void orc_opt_begin_timestep(orc_opt* o)
     }
     if (!o->angVel.empty()) {
         double stepSize = filterStepSize(m, o->searchDir.data(), 1.0);
+        if (o->selfCollision) { // :2158-2171: CCD of the scripted motion with slackness 0.5
+            std::vector<std::array<int, 2>> cand;
+            sweptCandidates(m, o->searchDir.data(), stepSize, cand);
+            stepSize = ccdStepBound(m, cand, o->searchDir.data(), 0.5, stepSize, nullptr);
+        }
         std::vector<double> V0 = m.V;
         stepForward(o, V0, stepSize);
         while (!m.checkInversion()) {
             stepSize /= 2.0;
             stepForward(o, V0, stepSize);
         }
-        if (stepSize < 1.0) std::fprintf(stderr, "[oracle] scripted DBC motion only completed %g (penalty path not restated)\n", stepSize);
+        if (o->selfCollision)
+            while (isIntersected(m)) {
+                stepSize /= 2.0;
+                stepForward(o, V0, stepSize);
+            }
+        if (stepSize < 1.0) {
+            o->dbcIncomplete++;
+            std::fprintf(stderr, "[oracle] scripted DBC motion only completed %g (penalty path not restated)\n", stepSize);
+        }
     }
-    // fullyImplicit_IP head (1518-1613): initX(0) -> searchDir = 0; initial energy with redoSVD
+    // fullyImplicit_IP head (1518-1613): initX(0) -> searchDir = 0; dHat; constraint sets; kappa; initial energy
     std::fill(o->searchDir.begin(), o->searchDir.end(), 0.0);
-    ensurePattern(o);
+    if (o->selfCollision) {
+        o->dHat = o->dHatEps * o->dHatEps * m.bboxDiag2;
+        computeConstraintSets(o);
+        o->kappa = kappaFloor(o); // kappa = 0 -> suggestKappa (:1540-1547)
+        initKappa(o); // ADAPTIVE_KAPPA (:1548-1550)
+        o->closeID.clear(); // initSubProb_IP (:2316-2322)
+        o->closeVal.clear();
+    }
+    if (o->patternDirty) computePrecondMtr(o, true);
     o->lastEnergyVal = computeEnergyVal(o);
     o->k = 0;
 }
@@ -240,10 +444,7 @@ int orc_opt_newton_iter(orc_opt* o)
     if (o->k && distToOpt_PN < o->targetGRes) return 1;
     o->innerIterAmt++;
     // computeSearchDir (2324-2355)
-    {
-        Tic t(o->timers[0]);
-        assembleHessian(m, o->dtSq, true, o->a.data());
-    }
+    computePrecondMtr(o, true);
     int ok;
     {
         Tic t(o->timers[3]);
@@ -259,14 +460,35 @@ int orc_opt_newton_iter(orc_opt* o)
         }
         else orc_chol_solve(o->chol, minusG.data(), o->searchDir.data());
     }
+    // step-size pipeline (1884-2040)
     double alpha = 1.0;
     {
         Tic t(o->timers[13]);
         alpha = filterStepSize(m, o->searchDir.data(), alpha);
+        if (o->selfCollision) {
+            const double slackness_m = 0.8;
+            alpha = ccdStepBound(m, o->cs.csPTEE, o->searchDir.data(), slackness_m, alpha, &o->lastCCDArg); // partial CCD (:1923-1928)
+            double pMax = 0; // CFL bound (:1947-1953)
+            for (int v : m.SVI) {
+                double s = 0;
+                for (int c = 0; c < 3; ++c) s += o->searchDir[3 * v + c] * o->searchDir[3 * v + c];
+                pMax = std::max(pMax, std::sqrt(s));
+            }
+            const double alpha_CFL = std::sqrt(o->dHat) / (pMax * 2.0);
+            if ((!o->k && alpha > alpha_CFL) || alpha > 2.0 * alpha_CFL) {
+                std::vector<std::array<int, 2>> cand; // full CCD (:1961-2021)
+                sweptCandidates(m, o->searchDir.data(), alpha, cand);
+                alpha = ccdStepBound(m, cand, o->searchDir.data(), slackness_m, alpha, &o->lastCCDArg);
+                o->nFullCCD++;
+                if (alpha < alpha_CFL) alpha = alpha_CFL;
+            }
+            else alpha = std::min(alpha, alpha_CFL);
+        }
     }
     o->lastAlphaFeasible = alpha;
     lineSearch(o, alpha);
     o->lastStepSize = alpha;
+    postLineSearch(o);
     o->k++;
     return 0;
 }
@@ -308,8 +530,25 @@ void orc_opt_get(const orc_opt* o, double* V, double* searchDir, double* gradien
         sc[3] = o->innerIterAmt;
         sc[4] = o->globalIterNum;
         sc[5] = o->lastAlphaFeasible;
-        sc[6] = sc[7] = 0;
+        sc[6] = o->kappa;
+        sc[7] = o->dHat;
     }
+}
+// contact-side state: counts6 = {nActive, nParaEE, nCandidates, lastCCDArg, nFullCCD, nPatternChanges}
+void orc_opt_get_contact(const orc_opt* o, int* counts6, int* active4, int* para4)
+{
+    counts6[0] = (int)o->cs.active.size();
+    counts6[1] = (int)o->cs.paraEE.size();
+    counts6[2] = (int)o->cs.csPTEE.size();
+    counts6[3] = o->lastCCDArg;
+    counts6[4] = o->nFullCCD;
+    counts6[5] = o->nPatternChanges;
+    if (active4)
+        for (size_t i = 0; i < o->cs.active.size(); ++i)
+            for (int k = 0; k < 4; ++k) active4[4 * i + k] = o->cs.active[i][k];
+    if (para4)
+        for (size_t i = 0; i < o->cs.paraEE.size(); ++i)
+            for (int k = 0; k < 4; ++k) para4[4 * i + k] = o->cs.paraEE[i][k];
 }
 void orc_opt_timers(const orc_opt* o, double* t16) { std::memcpy(t16, o->timers, sizeof(o->timers)); }
 }

@@ -203,3 +203,108 @@ def test_contact_hessian_is_psd_and_structured(orc, blocks):
     nzrows = {(int(r) // 3, int(c) // 3) for r, c in zip(*np.nonzero(np.triu(A)))}
     pat = set(map(tuple, pairs))
     assert all((i, j) in pat or i == j or (i, j) in {tuple(sorted(e)) for e in []} or True for i, j in nzrows)
+
+
+# ---- CCD, intersection check, contact-aware Newton -------------------------------------------------------------
+def test_ccd_reproduces_the_reference_ctcd_hit_table(orc):
+    """tests/Collisions/CollisionConstraintTests.cpp:18-35, 83-99: the only CCD facts the reference pins
+    (hit / no hit at eta = 0).  PT: point (0,1,-0.5) over triangle (-1,0,1),(1,0,1),(0,0,-1), y-displacements
+    u in {-1.1, 0, 1.1}^2 -> hit iff u_tri - u_point >= 1.  EE: edges (-1,-1,0)-(1,-1,0) and (0,1,-1)-(0,1,1)."""
+    for u0 in (-1.1, 0.0, 1.1):
+        for u1 in (-1.1, 0.0, 1.1):
+            X = np.array([[0, 1, -0.5], [-1, 0, 1], [1, 0, 1], [0, 0, -1]], dtype=float)
+            P = np.zeros((4, 3))
+            P[0, 1] = u0
+            P[1:, 1] = u1
+            t = orc.accd(orc.K_PT, X, P, eta=1e-3, tmax=1.0)
+            assert (t < 1.0) == (u1 - u0 >= 1.0), (u0, u1, t)
+            if t < 1.0:  # time of impact of a point approaching a plane at constant speed
+                assert abs(t - (1 - 1e-3) / (u1 - u0)) < 2e-3
+            XE = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, -1], [0, 1, 1]], dtype=float)
+            PE = np.zeros((4, 3))
+            PE[:2, 1] = u0
+            PE[2:, 1] = u1
+            t = orc.accd(orc.K_EE, XE, PE, eta=1e-3, tmax=1.0)
+            assert (t < 1.0) == (u0 - u1 >= 2.0 - 1e-9 or u0 - u1 >= 1.0 and False) or True
+            # the two edges are 2 apart in y; they meet iff the first moves up by >= 2 relative to the second
+            assert (t < 1.0) == (u0 - u1 >= 2.0), (u0, u1, t)
+
+
+def test_ccd_is_conservative(orc, blocks):
+    m, V, dHat = blocks["m"], blocks["V"], blocks["dHat"]
+    nA = V.shape[0] // 2
+    p = np.zeros_like(V)
+    p[nA:, 1] = -0.05  # push the upper slab through the lower one
+    p[nA:, 0] = 0.01
+    cs = orc.Contacts()
+    cs.build(m, dHat)
+    a_part, arg = orc.ccd_partial(cs, m, p.reshape(-1), 0.8, 1.0)
+    a_full, pair, ncand = orc.ccd_full(m, p.reshape(-1), 0.8, 1.0)
+    assert 0 < a_full <= a_part < 1 and ncand > 0 and arg >= 0
+    d0 = {tuple(c): None for c in cs.get()["cs_ptee"]}
+    # distances before / after the bounded step: every candidate keeps >= 20 % of its distance (slackness 0.8)
+    import itertools
+    svi, sfe = orc.mesh_surface(m)
+    SF = blocks["SF"]
+
+    def dist(Vc, pr):
+        if pr[0] < 0:
+            X = np.vstack([Vc[svi[-pr[0] - 1]], Vc[SF[pr[1]]]])
+            k = orc.dtype_pt(X)
+            sel = {0: (orc.K_PP, [0, 1]), 1: (orc.K_PP, [0, 2]), 2: (orc.K_PP, [0, 3]), 3: (orc.K_PE, [0, 1, 2]),
+                   4: (orc.K_PE, [0, 2, 3]), 5: (orc.K_PE, [0, 3, 1]), 6: (orc.K_PT, [0, 1, 2, 3])}[k]
+        else:
+            X = np.vstack([Vc[sfe[pr[0]]], Vc[sfe[pr[1]]]])
+            k = orc.dtype_ee(X)
+            sel = {0: (orc.K_PP, [0, 2]), 1: (orc.K_PP, [0, 3]), 2: (orc.K_PE, [0, 2, 3]), 3: (orc.K_PP, [1, 2]), 4: (orc.K_PP, [1, 3]),
+                   5: (orc.K_PE, [1, 2, 3]), 6: (orc.K_PE, [2, 0, 1]), 7: (orc.K_PE, [3, 0, 1]), 8: (orc.K_EE, [0, 1, 2, 3])}[k]
+        Y = np.zeros((4, 3))
+        Y[:len(sel[1])] = X[sel[1]]
+        return np.sqrt(orc.stencil_distance(sel[0], Y, derivs=False)[0])
+    V1 = V + a_full * p
+    for pr in cs.get()["cs_ptee"]:
+        assert dist(V1, pr) >= 0.2 * dist(V, pr) * (1 - 1e-9)
+    m.set_V(V1)
+    assert not orc.is_intersected(m)
+    m.set_V(V + 1.0 * p)  # the unbounded step tunnels
+    assert orc.is_intersected(m)
+    m.set_V(V)
+    assert not orc.is_intersected(m)
+
+
+def test_contact_newton_drop_converges_without_intersection(orc):
+    V, F = two_blocks(0.02, n=2)
+    SF = scene.surface_tris(F)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    nA = V.shape[0] // 2
+    bottom = np.nonzero(V[:nA, 1] < 1e-9)[0].astype(np.int32)
+    m.set_dbc(bottom, 1)
+    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=4)
+    orc.opt_enable_self_collision(o, 1e-2)
+    vel = np.zeros_like(V)
+    vel[nA:, 1] = -1.5  # the upper slab falls onto the fixed lower one
+    orc.opt_set_velocity(o, vel)
+    o.precompute()
+    seen_contact = 0
+    for step in range(6):
+        o.begin_timestep()
+        E_prev = o.state()["E"]
+        for it in range(60):
+            if o.newton_iter():
+                break
+            s = o.state()
+            assert s["E"] <= E_prev * (1 + 1e-12) + 1e-14
+            E_prev = s["E"]
+            assert s["stepSize"] > 0
+        else:
+            pytest.fail("contact Newton did not converge")
+        o.end_timestep()
+        assert m.check_inversion() and not orc.is_intersected(m)
+        cst = orc.opt_contact_state(o)
+        seen_contact = max(seen_contact, len(cst["active"]))
+    assert seen_contact > 0 and orc.opt_contact_state(o)["n_pattern_changes"] >= 1
+    assert o.state()["kappa"] > 0
+    # the slabs did not pass through each other (the overhang may droop, so compare the overlapping footprint's centre)
+    Vn = o.state()["V"]
+    assert Vn[nA:, 1].mean() > Vn[:nA, 1].mean() + 0.2
