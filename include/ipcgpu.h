@@ -146,6 +146,14 @@ int ipcgpu_contact_gradient_add(ipcgpu_ctx*, double dHat, double kappa, int proj
 int ipcgpu_contact_hessian_add(ipcgpu_ctx*, double dHat, double kappa, int projectDBC);
 /* augmentConnectivity (SelfCollisionHandler.cpp:330-415): node pairs (a < b) coupled by the barrier Hessians */
 int ipcgpu_contact_connectivity(ipcgpu_ctx*, int capacity, int* pairs_2n, int* nPairs);
+/* Conservative CCD step bounds (the role of SelfCollisionHandler::largestFeasibleStepSize, :564-686, on the candidate
+ * list of the last contact_build, and of largestFeasibleStepSize_CCD, :982-1366, on every pair whose swept boxes
+ * overlap).  Contract (CTCD itself is un-vendored): the returned step keeps every tested pair at
+ * >= (1 - slackness) of its current distance.  pair2 = limiting pair, (-svI-1, sfI) or (eI, eJ); (0,0) if none. */
+int ipcgpu_ccd_partial(ipcgpu_ctx*, const double* searchDir_3nV, double slackness, double* stepSize_inout, int* pair2);
+int ipcgpu_ccd_full(ipcgpu_ctx*, const double* searchDir_3nV, double slackness, double* stepSize_inout, int* pair2, int* nCandidates);
+/* isIntersected / checkEdgeTriIntersectionIfAny (Optimizer.cpp:2626-2659, SelfCollisionHandler.cpp:3255-3300) */
+int ipcgpu_is_intersected(ipcgpu_ctx*, int* flag);
 
 /* ---- Optimizer<3>: the time stepper itself, state resident on the GPU --------------- */
 /* Optimizer ctor + setTime (Optimizer.cpp:97-115, 418-430).  Uses the mesh of this context. */

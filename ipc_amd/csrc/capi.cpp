@@ -581,6 +581,40 @@ int ipcgpu_contact_connectivity(ipcgpu_ctx* c, int cap, int* pairs, int* n)
     });
 }
 
+int ipcgpu_ccd_partial(ipcgpu_ctx* c, const double* p, double slackness, double* step, int* pair2)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(p && step && slackness > 0 && slackness < 1, "bad ccd argument");
+        HIP_CHECK(hipMemcpyAsync(o.d_searchDir.p, p, 3 * (size_t)c->mesh->nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        *step = CT(c).ccdPartial(c->mesh->d_x.p, o.d_searchDir.p, slackness, *step, pair2);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_ccd_full(ipcgpu_ctx* c, const double* p, double slackness, double* step, int* pair2, int* nCand)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(p && step && slackness > 0 && slackness < 1, "bad ccd argument");
+        HIP_CHECK(hipMemcpyAsync(o.d_searchDir.p, p, 3 * (size_t)c->mesh->nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        *step = CT(c).ccdFull(*c->mesh, c->mesh->d_x.p, o.d_searchDir.p, c->mesh->d_dbc.p, slackness, *step, pair2, nCand);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_is_intersected(ipcgpu_ctx* c, int* flag)
+{
+    return guarded([&] {
+        M(c);
+        bind(c);
+        *flag = CT(c).isIntersected(*c->mesh, c->mesh->d_x.p, c->mesh->d_dbc.p) ? 1 : 0;
+        return IPCGPU_OK;
+    });
+}
+
 // ---- Optimizer building blocks ----------------------------------------------------------------------
 int ipcgpu_assemble_newton(ipcgpu_ctx* c, double dtSq, int projectDBC, double* grad)
 {

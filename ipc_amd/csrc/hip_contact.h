@@ -45,8 +45,26 @@ public:
     void hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
         double* a_dev);
     void connectivity(std::vector<std::pair<int, int>>& pairs) const;
+    // conservative CCD step bounds; pair2 receives the limiting pair ((-svI-1, sfI) or (eI, eJ)); returns the new bound
+    double ccdPartial(const double* x_dev, const double* p_dev, double slackness, double stepSize, int* pair2);
+    double ccdFull(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double stepSize, int* pair2,
+        int* nCand);
+    bool isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev);
+    void evalStencils(const std::vector<std::array<int, 4>>& ids, const double* x_dev, std::vector<double>& d2);
+    double maxSurfaceSpeed(const double* p_dev); // max_{v in SVI} |p_v|  (CFL bound, Optimizer.cpp:1947-1953)
 
 private:
+    struct GridHost {
+        double lo[3], h;
+        int dim[3];
+        long long nCells;
+    };
+    GridHost makeGrid(const HipMesh& mesh, const double* x_dev, const double* p_dev, double alpha, double minCell);
+    void buildCells(const GridHost& g, int nPrim, int nv, const int* prim_dev, const double* x_dev, const double* p_dev, double alpha, double infl,
+        DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items);
+    DevBuf<int> d_cand_, d_ids_;
+    DevBuf<double> d_vals_;
+    DevBuf<unsigned long long> ccdOut_;
     DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
     DevBuf<double> bboxPartial_;
     DevBuf<char> scanTmp_;

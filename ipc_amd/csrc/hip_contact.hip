@@ -5,6 +5,7 @@
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <set>
 
@@ -479,6 +480,296 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
             }
 }
 
+// ---- conservative CCD (additive advancement on the unclassified distance; contract in DESIGN.md) ---------------
+__device__ inline double accd(int kind, const double (*X0)[3], const double (*P0)[3], double eta, double tmax)
+{
+    double X[4][3], P[4][3], mean[3] = { 0.0, 0.0, 0.0 }, len[4];
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) mean[c] += P0[k][c];
+    for (int c = 0; c < 3; ++c) mean[c] /= 4.0;
+    for (int k = 0; k < 4; ++k) {
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = X0[k][c];
+            P[k][c] = P0[k][c] - mean[c];
+        }
+        len[k] = sqrt(dot3(P[k], P[k]));
+    }
+    const double lp = (kind == K_PT) ? len[0] + fmax(len[1], fmax(len[2], len[3])) : fmax(len[0], len[1]) + fmax(len[2], len[3]);
+    if (lp == 0.0) return tmax;
+    double d = sqrt(kind == K_PT ? dist2_PT(X[0], X[1], X[2], X[3]) : dist2_EE(X[0], X[1], X[2], X[3]));
+    const double gap = eta * d;
+    double toc = 0.0;
+    for (int it = 0; it < 100000; ++it) {
+        const double tl = (1.0 - eta) * d / lp;
+        for (int k = 0; k < 4; ++k)
+            for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
+        d = sqrt(kind == K_PT ? dist2_PT(X[0], X[1], X[2], X[3]) : dist2_EE(X[0], X[1], X[2], X[3]));
+        if (toc != 0.0 && d < gap) break;
+        toc += tl;
+        if (toc > tmax) return tmax;
+    }
+    return toc;
+}
+// time bound of one pair with the retry rule of SelfCollisionHandler.cpp:617-636
+__device__ inline double pair_toc(int kind, const int* node, const double* x, const double* p, double slackness, double tmax)
+{
+    double X[4][3], P[4][3];
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = x[3 * (size_t)node[k] + c];
+            P[k][c] = p[3 * (size_t)node[k] + c];
+        }
+    double t = accd(kind, X, P, 1.0 - slackness, tmax);
+    if (t < 1.0e-6) t = slackness * accd(kind, X, P, 0.01, tmax);
+    return t;
+}
+// order key of a pair inside the serial enumeration (PT by (svI, sfI), then EE by (eI, eJ)): ties resolve to the first
+__device__ __forceinline__ unsigned long long pair_key(int kind, int i, int j)
+{
+    return ((unsigned long long)(kind == K_PT ? 0 : 1) << 62) | ((unsigned long long)(unsigned)i << 31) | (unsigned long long)(unsigned)j;
+}
+struct CcdOut {
+    unsigned long long* minBits; // bit pattern of the smallest time (positive doubles order like integers)
+    unsigned long long* argKey; // smallest order key among the pairs that attain it
+};
+__device__ __forceinline__ void ccd_record_min(double t, double tmax, CcdOut o)
+{
+    if (t < tmax) atomicMin(o.minBits, (unsigned long long)__double_as_longlong(t));
+}
+__device__ __forceinline__ void ccd_record_arg(double t, unsigned long long key, CcdOut o)
+{
+    if ((unsigned long long)__double_as_longlong(t) == *o.minBits) atomicMin(o.argKey, key);
+}
+
+// pass 0: minimum time; pass 1: first pair attaining it
+__global__ __launch_bounds__(BLOCK) void k_ccd_list(int nPairs, const int* __restrict__ pairs, const int* __restrict__ SVI, const int* __restrict__ SF,
+    const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ p, double slackness, double tmax, int pass, CcdOut o)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nPairs) return;
+    const int a = pairs[2 * (size_t)i], b = pairs[2 * (size_t)i + 1];
+    int node[4], kind, ki, kj;
+    if (a < 0) {
+        kind = K_PT;
+        ki = -a - 1;
+        kj = b;
+        node[0] = SVI[ki];
+        node[1] = SF[3 * (size_t)b];
+        node[2] = SF[3 * (size_t)b + 1];
+        node[3] = SF[3 * (size_t)b + 2];
+    }
+    else {
+        kind = K_EE;
+        ki = a;
+        kj = b;
+        node[0] = SFE[2 * (size_t)a];
+        node[1] = SFE[2 * (size_t)a + 1];
+        node[2] = SFE[2 * (size_t)b];
+        node[3] = SFE[2 * (size_t)b + 1];
+    }
+    const double t = pair_toc(kind, node, x, p, slackness, tmax);
+    if (pass == 0) ccd_record_min(t, tmax, o);
+    else ccd_record_arg(t, pair_key(kind, ki, kj), o);
+}
+
+// swept boxes over [x, x + alpha p]
+__global__ __launch_bounds__(BLOCK) void k_grid_insert_swept(int nPrim, int nv, const int* __restrict__ prim, const double* __restrict__ x,
+    const double* __restrict__ p, double alpha, Grid g, int mode, int* __restrict__ cellCount, const int* __restrict__ cellStart,
+    int* __restrict__ cellItems)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nPrim) return;
+    double bl[3] = { 1e300, 1e300, 1e300 }, bh[3] = { -1e300, -1e300, -1e300 };
+    for (int k = 0; k < nv; ++k) {
+        const int v = prim[nv * (size_t)i + k];
+        for (int c = 0; c < 3; ++c) {
+            const double a = x[3 * (size_t)v + c], b = a + alpha * p[3 * (size_t)v + c];
+            bl[c] = fmin(bl[c], fmin(a, b));
+            bh[c] = fmax(bh[c], fmax(a, b));
+        }
+    }
+    int a[3], b[3];
+    for (int c = 0; c < 3; ++c) {
+        a[c] = cell_of(g, bl[c], c);
+        b[c] = cell_of(g, bh[c], c);
+    }
+    for (int z = a[2]; z <= b[2]; ++z)
+        for (int y = a[1]; y <= b[1]; ++y)
+            for (int xx = a[0]; xx <= b[0]; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                const int slot = atomicAdd(&cellCount[cell], 1);
+                if (mode == 1) cellItems[cellStart[cell] + slot] = i;
+            }
+}
+__device__ __forceinline__ void swept_box(const int* node, int n, const double* x, const double* p, double alpha, double* lo, double* hi)
+{
+    for (int c = 0; c < 3; ++c) {
+        lo[c] = 1e300;
+        hi[c] = -1e300;
+    }
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < 3; ++c) {
+            const double a = x[3 * (size_t)node[k] + c], b = a + alpha * p[3 * (size_t)node[k] + c];
+            lo[c] = fmin(lo[c], fmin(a, b));
+            hi[c] = fmax(hi[c], fmax(a, b));
+        }
+}
+// full CCD: every (surface vertex, triangle) and (edge, edge) pair with overlapping swept boxes (SelfCollisionHandler.cpp:982-1366)
+__global__ __launch_bounds__(BLOCK) void k_ccd_full_pt(int nSVI, const int* __restrict__ SVI, const int* __restrict__ SF, const double* __restrict__ x,
+    const double* __restrict__ p, const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems,
+    double alpha, double slackness, int pass, CcdOut o, int* __restrict__ nCand)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nSVI) return;
+    const int vI = SVI[i];
+    double lo[3], hi[3];
+    swept_box(&vI, 1, x, p, alpha, lo, hi);
+    int ca[3], cb[3];
+    for (int c = 0; c < 3; ++c) {
+        ca[c] = cell_of(g, lo[c], c);
+        cb[c] = cell_of(g, hi[c], c);
+    }
+    const bool vDbc = dbc[vI] != 0;
+    for (int z = ca[2]; z <= cb[2]; ++z)
+        for (int y = ca[1]; y <= cb[1]; ++y)
+            for (int xx = ca[0]; xx <= cb[0]; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
+                    const int f = cellItems[k];
+                    int node[4] = { vI, SF[3 * (size_t)f], SF[3 * (size_t)f + 1], SF[3 * (size_t)f + 2] };
+                    if (vI == node[1] || vI == node[2] || vI == node[3]) continue;
+                    if (vDbc && dbc[node[1]] != 0 && dbc[node[2]] != 0 && dbc[node[3]] != 0) continue;
+                    double tl[3], th[3];
+                    swept_box(node + 1, 3, x, p, alpha, tl, th);
+                    bool ok = true;
+                    int canon[3];
+                    for (int c = 0; c < 3; ++c) {
+                        if (lo[c] > th[c] || tl[c] > hi[c]) ok = false;
+                        canon[c] = cell_of(g, fmax(lo[c], tl[c]), c);
+                    }
+                    if (!ok || canon[0] != xx || canon[1] != y || canon[2] != z) continue;
+                    if (pass == 0) atomicAdd(nCand, 1);
+                    const double t = pair_toc(K_PT, node, x, p, slackness, alpha);
+                    if (pass == 0) ccd_record_min(t, alpha, o);
+                    else ccd_record_arg(t, pair_key(K_PT, i, f), o);
+                }
+            }
+}
+__global__ __launch_bounds__(BLOCK) void k_ccd_full_ee(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ p,
+    const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double alpha, double slackness,
+    int pass, CcdOut o, int* __restrict__ nCand)
+{
+    const int eI = blockIdx.x * BLOCK + threadIdx.x;
+    if (eI >= nE) return;
+    int node[4] = { SFE[2 * (size_t)eI], SFE[2 * (size_t)eI + 1], 0, 0 };
+    double lo[3], hi[3];
+    swept_box(node, 2, x, p, alpha, lo, hi);
+    int ca[3], cb[3];
+    for (int c = 0; c < 3; ++c) {
+        ca[c] = cell_of(g, lo[c], c);
+        cb[c] = cell_of(g, hi[c], c);
+    }
+    const bool aDbc = dbc[node[0]] != 0 && dbc[node[1]] != 0;
+    for (int z = ca[2]; z <= cb[2]; ++z)
+        for (int y = ca[1]; y <= cb[1]; ++y)
+            for (int xx = ca[0]; xx <= cb[0]; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
+                    const int eJ = cellItems[k];
+                    if (eJ <= eI) continue;
+                    node[2] = SFE[2 * (size_t)eJ];
+                    node[3] = SFE[2 * (size_t)eJ + 1];
+                    if (node[0] == node[2] || node[0] == node[3] || node[1] == node[2] || node[1] == node[3]) continue;
+                    if (aDbc && dbc[node[2]] != 0 && dbc[node[3]] != 0) continue;
+                    double jl[3], jh[3];
+                    swept_box(node + 2, 2, x, p, alpha, jl, jh);
+                    bool ok = true;
+                    int canon[3];
+                    for (int c = 0; c < 3; ++c) {
+                        if (lo[c] > jh[c] || jl[c] > hi[c]) ok = false;
+                        canon[c] = cell_of(g, fmax(lo[c], jl[c]), c);
+                    }
+                    if (!ok || canon[0] != xx || canon[1] != y || canon[2] != z) continue;
+                    if (pass == 0) atomicAdd(nCand, 1);
+                    const double t = pair_toc(K_EE, node, x, p, slackness, alpha);
+                    if (pass == 0) ccd_record_min(t, alpha, o);
+                    else ccd_record_arg(t, pair_key(K_EE, eI, eJ), o);
+                }
+            }
+}
+
+// IglUtils::segTriIntersect without exact predicates (IglUtils.hpp:236-245, 258-264)
+__device__ inline bool seg_tri_intersect(const double* ve0, const double* ve1, const double* vt0, const double* vt1, const double* vt2)
+{
+    double c0[3], c1[3], c2[3], n[3], r0[3], r1[3], t0[3], t1[3];
+    sub3(vt1, vt0, c0);
+    sub3(vt2, vt0, c1);
+    sub3(ve0, ve1, c2);
+    cross3(c0, c1, n);
+    sub3(ve0, vt0, r0);
+    sub3(ve1, vt0, r1);
+    if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
+    const double det = dot3(n, c2);
+    if (det == 0.0) return false;
+    cross3(r0, c1, t0);
+    cross3(c0, r0, t1);
+    const double u = dot3(t0, c2) / det, v = dot3(t1, c2) / det, t = dot3(n, r0) / det;
+    return u >= 0.0 && v >= 0.0 && u + v <= 1.0 && t >= 0.0 && t <= 1.0;
+}
+// checkEdgeTriIntersectionIfAny (SelfCollisionHandler.cpp:3255-3300): one lane per surface triangle, edges from the grid
+__global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restrict__ SF, const int* __restrict__ SFE, const double* __restrict__ x,
+    const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, int* __restrict__ flag)
+{
+    const int f = blockIdx.x * BLOCK + threadIdx.x;
+    if (f >= nSF) return;
+    const int t0 = SF[3 * (size_t)f], t1 = SF[3 * (size_t)f + 1], t2 = SF[3 * (size_t)f + 2];
+    double a[3], b[3], c[3], lo[3], hi[3];
+    int ca[3], cb[3];
+    for (int k = 0; k < 3; ++k) {
+        a[k] = x[3 * (size_t)t0 + k];
+        b[k] = x[3 * (size_t)t1 + k];
+        c[k] = x[3 * (size_t)t2 + k];
+        lo[k] = fmin(a[k], fmin(b[k], c[k]));
+        hi[k] = fmax(a[k], fmax(b[k], c[k]));
+        ca[k] = cell_of(g, lo[k], k);
+        cb[k] = cell_of(g, hi[k], k);
+    }
+    const bool tDbc = dbc[t0] != 0 && dbc[t1] != 0 && dbc[t2] != 0;
+    for (int z = ca[2]; z <= cb[2]; ++z)
+        for (int y = ca[1]; y <= cb[1]; ++y)
+            for (int xx = ca[0]; xx <= cb[0]; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
+                    const int e = cellItems[k];
+                    const int e0 = SFE[2 * (size_t)e], e1 = SFE[2 * (size_t)e + 1];
+                    if (e0 == t0 || e0 == t1 || e0 == t2 || e1 == t0 || e1 == t1 || e1 == t2) continue;
+                    if (tDbc && dbc[e0] != 0 && dbc[e1] != 0) continue;
+                    double p0[3], p1[3];
+                    bool sep = false;
+                    for (int q = 0; q < 3; ++q) {
+                        p0[q] = x[3 * (size_t)e0 + q];
+                        p1[q] = x[3 * (size_t)e1 + q];
+                        if (fmin(p0[q], p1[q]) > hi[q] || fmax(p0[q], p1[q]) < lo[q]) sep = true;
+                    }
+                    if (sep) continue;
+                    if (seg_tri_intersect(p0, p1, a, b, c)) {
+                        atomicOr(flag, 1);
+                        return;
+                    }
+                }
+            }
+}
+// squared distances of a list of MMCVID stencils (closeMConstraint bookkeeping, Optimizer.cpp:2365-2440)
+__global__ __launch_bounds__(BLOCK) void k_eval_stencils(int n, const int* __restrict__ ids, const double* __restrict__ x, double* __restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Stencil s = decode(ids + 4 * (size_t)i);
+    double X[4][3];
+    gatherX(x, s.node, s.n, X);
+    out[i] = dist_only(s.kind, X);
+}
+
 inline int nblk(long long n, int b = BLOCK) { return (int)((n + b - 1) / b); }
 
 } // namespace
@@ -773,6 +1064,227 @@ void HipContact::connectivity(std::vector<std::pair<int, int>>& pairs) const
     }
     std::sort(pairs.begin(), pairs.end());
     pairs.erase(std::unique(pairs.begin(), pairs.end()), pairs.end());
+}
+
+namespace {
+__global__ void k_max_speed(int n, const int* __restrict__ ids, const double* __restrict__ p, unsigned long long* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double s = 0.0;
+    if (i < n) {
+        const int v = ids ? ids[i] : i;
+        s = sqrt(p[3 * (size_t)v] * p[3 * (size_t)v] + p[3 * (size_t)v + 1] * p[3 * (size_t)v + 1] + p[3 * (size_t)v + 2] * p[3 * (size_t)v + 2]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s = fmax(s, __shfl_down(s, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(s));
+}
+} // namespace
+
+double HipContact::maxSurfaceSpeed(const double* p_dev)
+{
+    ccdOut_.alloc(4);
+    ccdOut_.zero(stream);
+    if (nSVI) hipLaunchKernelGGL(k_max_speed, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, p_dev, ccdOut_.p);
+    unsigned long long bits = 0;
+    HIP_CHECK(hipMemcpyAsync(&bits, ccdOut_.p, sizeof(bits), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    double v;
+    std::memcpy(&v, &bits, sizeof(v));
+    return v;
+}
+
+HipContact::GridHost HipContact::makeGrid(const HipMesh& mesh, const double* x_dev, const double* p_dev, double alpha, double minCell)
+{
+    const int nV = mesh.nV;
+    const int nb = nblk(nV);
+    bboxPartial_.alloc(6 * (size_t)nb);
+    hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
+    std::vector<double> part(6 * (size_t)nb);
+    bboxPartial_.download(part.data(), part.size(), stream);
+    GridHost g;
+    double hi[3];
+    for (int c = 0; c < 3; ++c) {
+        g.lo[c] = 1e300;
+        hi[c] = -1e300;
+    }
+    for (int b = 0; b < nb; ++b)
+        for (int c = 0; c < 3; ++c) {
+            g.lo[c] = std::min(g.lo[c], part[6 * (size_t)b + c]);
+            hi[c] = std::max(hi[c], part[6 * (size_t)b + 3 + c]);
+        }
+    double reach = 0.0;
+    if (p_dev) { // swept boxes reach at most alpha * max |p| beyond the current bounding box
+        ccdOut_.alloc(4);
+        ccdOut_.zero(stream);
+        hipLaunchKernelGGL(k_max_speed, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, (const int*)nullptr, p_dev, ccdOut_.p);
+        unsigned long long bits = 0;
+        HIP_CHECK(hipMemcpyAsync(&bits, ccdOut_.p, sizeof(bits), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        double pm;
+        std::memcpy(&pm, &bits, sizeof(pm));
+        reach = alpha * pm;
+    }
+    for (int c = 0; c < 3; ++c) {
+        g.lo[c] -= reach;
+        hi[c] += reach;
+    }
+    g.h = std::max(minCell, reach);
+    for (;;) {
+        g.nCells = 1;
+        for (int c = 0; c < 3; ++c) {
+            g.dim[c] = std::max(1, (int)std::floor((hi[c] - g.lo[c]) / g.h) + 1);
+            g.nCells *= g.dim[c];
+        }
+        if (g.nCells <= (1LL << 26)) break;
+        g.h *= 1.5;
+    }
+    return g;
+}
+
+void HipContact::buildCells(const GridHost& gh, int nPrim, int nv, const int* prim, const double* x_dev, const double* p_dev, double alpha, double infl,
+    DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items)
+{
+    Grid g;
+    for (int c = 0; c < 3; ++c) {
+        g.lo[c] = gh.lo[c];
+        g.dim[c] = gh.dim[c];
+    }
+    g.h = gh.h;
+    const long long nCells = gh.nCells;
+    cnt.alloc((size_t)nCells + 1);
+    start.alloc((size_t)nCells + 1);
+    auto insert = [&](int mode) {
+        cnt.zero(stream);
+        if (p_dev)
+            hipLaunchKernelGGL(k_grid_insert_swept, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv, prim, x_dev, p_dev, alpha, g, mode, cnt.p,
+                start.p, items.p);
+        else
+            hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv == 3 ? 1 : 0, prim, x_dev, g, infl, mode, cnt.p, start.p,
+                items.p);
+    };
+    insert(0);
+    size_t tmpBytes = 0;
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream));
+    if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes);
+    HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream));
+    int total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    items.alloc(std::max(1, total));
+    insert(1);
+}
+
+static void decodeCcdOut(const unsigned long long* h, double stepSize, double* outStep, int* pair2)
+{
+    double t;
+    std::memcpy(&t, &h[0], sizeof(t));
+    if (h[1] == ~0ull || !(t < stepSize)) { // no pair limits the step
+        *outStep = stepSize;
+        if (pair2) pair2[0] = pair2[1] = 0;
+        return;
+    }
+    *outStep = t;
+    if (pair2) {
+        const int isEE = (int)(h[1] >> 62), i = (int)((h[1] >> 31) & 0x7FFFFFFF), j = (int)(h[1] & 0x7FFFFFFF);
+        pair2[0] = isEE ? i : -i - 1;
+        pair2[1] = j;
+    }
+}
+
+double HipContact::ccdPartial(const double* x_dev, const double* p_dev, double slackness, double stepSize, int* pair2)
+{
+    const int n = (int)csPTEE.size();
+    if (pair2) pair2[0] = pair2[1] = 0;
+    if (!n) return stepSize;
+    std::vector<int> flat(2 * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        flat[2 * (size_t)i] = csPTEE[i][0];
+        flat[2 * (size_t)i + 1] = csPTEE[i][1];
+    }
+    d_cand_.upload(flat, stream);
+    ccdOut_.alloc(4);
+    const unsigned long long init[2] = { ~0ull, ~0ull };
+    HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
+    for (int pass = 0; pass < 2; ++pass)
+        hipLaunchKernelGGL(k_ccd_list, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_cand_.p, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, slackness, stepSize, pass,
+            o);
+    unsigned long long h[2];
+    HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    double out;
+    decodeCcdOut(h, stepSize, &out, pair2);
+    return out;
+}
+
+double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double stepSize,
+    int* pair2, int* nCand)
+{
+    if (!surfaceSet) throw StateError("ccd before set_surface");
+    const GridHost gh = makeGrid(mesh, x_dev, p_dev, stepSize, mesh.avgEdgeLen);
+    buildCells(gh, nSF, 3, d_SF.p, x_dev, p_dev, stepSize, 0.0, cellCountT_, cellStartT_, cellItemsT_);
+    buildCells(gh, nSFE, 2, d_SFE.p, x_dev, p_dev, stepSize, 0.0, cellCountE_, cellStartE_, cellItemsE_);
+    Grid g;
+    for (int c = 0; c < 3; ++c) {
+        g.lo[c] = gh.lo[c];
+        g.dim[c] = gh.dim[c];
+    }
+    g.h = gh.h;
+    ccdOut_.alloc(4);
+    const unsigned long long init[2] = { ~0ull, ~0ull };
+    HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    counters_.alloc(2);
+    counters_.zero(stream);
+    CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_ccd_full_pt, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, p_dev, dbc_dev, g, cellStartT_.p,
+            cellItemsT_.p, stepSize, slackness, pass, o, counters_.p);
+        hipLaunchKernelGGL(k_ccd_full_ee, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, p_dev, dbc_dev, g, cellStartE_.p, cellItemsE_.p,
+            stepSize, slackness, pass, o, counters_.p);
+    }
+    unsigned long long h[2];
+    int cnt[2];
+    HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+    counters_.download(cnt, 2, stream);
+    if (nCand) *nCand = cnt[0];
+    double out;
+    decodeCcdOut(h, stepSize, &out, pair2);
+    return out;
+}
+
+bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev)
+{
+    if (!surfaceSet) throw StateError("is_intersected before set_surface");
+    const GridHost gh = makeGrid(mesh, x_dev, nullptr, 0.0, mesh.avgEdgeLen);
+    buildCells(gh, nSFE, 2, d_SFE.p, x_dev, nullptr, 0.0, 0.0, cellCountE_, cellStartE_, cellItemsE_);
+    Grid g;
+    for (int c = 0; c < 3; ++c) {
+        g.lo[c] = gh.lo[c];
+        g.dim[c] = gh.dim[c];
+    }
+    g.h = gh.h;
+    counters_.alloc(2);
+    counters_.zero(stream);
+    hipLaunchKernelGGL(k_intersect, dim3(nblk(nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, dbc_dev, g, cellStartE_.p, cellItemsE_.p,
+        counters_.p);
+    int f[2];
+    counters_.download(f, 2, stream);
+    return f[0] != 0;
+}
+
+void HipContact::evalStencils(const std::vector<std::array<int, 4>>& ids, const double* x_dev, std::vector<double>& d2)
+{
+    const int n = (int)ids.size();
+    d2.assign(n, 0.0);
+    if (!n) return;
+    std::vector<int> flat(4 * (size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 4; ++k) flat[4 * (size_t)i + k] = ids[i][k];
+    d_ids_.upload(flat, stream);
+    d_vals_.alloc(n);
+    hipLaunchKernelGGL(k_eval_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_ids_.p, x_dev, d_vals_.p);
+    d_vals_.download(d2.data(), n, stream);
 }
 
 } // namespace ipcgpu

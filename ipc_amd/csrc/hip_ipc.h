@@ -131,6 +131,22 @@ public:
     int patchVersion = -1;
     void ensurePatchPlan();
     void patchShard(int& pb, int& pe) const;
+    // self-contact, interior point (fullyImplicit_IP with isSelfCollision, Optimizer.cpp:1518-1819)
+    HipContact* contact = nullptr;
+    bool selfCollision = false;
+    double dHatEps = 1.0e-3, dHat = 0, kappa = 0, dTol = 0;
+    std::vector<std::pair<int, int>> curExtra; // contact connectivity inside the current pattern (vNeighbor_IP)
+    std::vector<std::array<int, 4>> closeID; // closeMConstraintID / Val (Optimizer.cpp:2396-2440)
+    std::vector<double> closeVal;
+    int lastCCDPair[2] = { 0, 0 }, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
+    void enableSelfCollision(HipContact* c, double dHatEps);
+    void setVelocity(const double* vel3nV);
+    void computeConstraintSets();
+    double kappaFloor() const;
+    void initKappa();
+    void postLineSearch();
+    bool isIntersected();
+    void computeXTilta();
 };
 
 } // namespace ipcgpu

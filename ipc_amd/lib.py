@@ -318,6 +318,26 @@ class Context:
         self._chk(self._L.ipcgpu_contact_connectivity(self.h, C.c_int(n.value), _ip(buf), C.byref(n)))
         return buf[:n.value].copy()
 
+    def ccd_partial(self, p, slackness=0.8, step=1.0):
+        p = _f64(p)
+        s = C.c_double(step)
+        pair = np.zeros(2, dtype=np.int32)
+        self._chk(self._L.ipcgpu_ccd_partial(self.h, _dp(p), C.c_double(slackness), C.byref(s), _ip(pair)))
+        return s.value, (int(pair[0]), int(pair[1]))
+
+    def ccd_full(self, p, slackness=0.8, step=1.0):
+        p = _f64(p)
+        s = C.c_double(step)
+        pair = np.zeros(2, dtype=np.int32)
+        n = C.c_int()
+        self._chk(self._L.ipcgpu_ccd_full(self.h, _dp(p), C.c_double(slackness), C.byref(s), _ip(pair), C.byref(n)))
+        return s.value, (int(pair[0]), int(pair[1])), n.value
+
+    def is_intersected(self):
+        f = C.c_int()
+        self._chk(self._L.ipcgpu_is_intersected(self.h, C.byref(f)))
+        return bool(f.value)
+
     # ---- Optimizer building blocks
     def assemble_newton(self, dtSq, projectDBC=True, with_gradient=True):
         g = np.zeros(3 * self.nV) if with_gradient else None

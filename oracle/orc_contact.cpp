@@ -848,6 +848,7 @@ double ccdStepBound(const Mesh& m, const std::vector<std::array<int, 2>>& pairs,
     int* argPair)
 {
     const double eta = 1.0 - slackness;
+    const double tmax = stepSize; // every pair is tested against the incoming bound (order-independent result)
     int arg = -1;
     for (size_t i = 0; i < pairs.size(); ++i) {
         int kind, node[4];
@@ -858,9 +859,9 @@ double ccdStepBound(const Mesh& m, const std::vector<std::array<int, 2>>& pairs,
                 X[k][c] = m.Vx(node[k], c);
                 P[k][c] = p[3 * node[k] + c];
             }
-        double t = accd(kind, X, P, eta, stepSize);
+        double t = accd(kind, X, P, eta, tmax);
         if (t < 1.0e-6) { // SelfCollisionHandler.cpp:617-636: retry almost without safety distance, then back off
-            const double t2 = accd(kind, X, P, 0.01, stepSize);
+            const double t2 = accd(kind, X, P, 0.01, tmax);
             t = slackness * t2;
         }
         if (t < stepSize) {

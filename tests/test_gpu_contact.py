@@ -97,6 +97,41 @@ def test_nearly_parallel_edges_go_to_the_mollified_set(orc, gpu_lib):
     c.close()
 
 
+def test_ccd_step_bounds_and_intersection_check(orc, pair):
+    """'Bit-exact CCD index': the limiting pair is the same tuple, the bound agrees to round-off."""
+    m, c, dHat, V = pair["m"], pair["c"], pair["dHat"], pair["V"]
+    nA = V.shape[0] // 2
+    cs = orc.Contacts()
+    cs.build(m, dHat)
+    cand = cs.get()["cs_ptee"]
+    c.contact_build(dHat)
+    rng = np.random.default_rng(21)
+    for trial in range(4):
+        p = 0.002 * rng.normal(size=V.shape)
+        p[nA:, 1] -= 0.02 * (trial + 1)  # upper slab pushed into the lower one
+        so, arg = orc.ccd_partial(cs, m, p.reshape(-1), 0.8, 1.0)
+        sg, pg = c.ccd_partial(p.reshape(-1), 0.8, 1.0)
+        assert abs(sg - so) <= 1e-12 * so and so < 1.0
+        assert pg == tuple(int(x) for x in cand[arg])
+        fo, pfo, no = orc.ccd_full(m, p.reshape(-1), 0.8, 1.0)
+        fg, pfg, ng = c.ccd_full(p.reshape(-1), 0.8, 1.0)
+        assert abs(fg - fo) <= 1e-12 * fo and pfg == pfo and ng == no
+        assert fo <= so
+        # stepping by the bound keeps the mesh intersection-free, the full step does not
+        c.set_positions(V + fg * p)
+        assert not c.is_intersected()
+        c.set_positions(V + p)
+        m.set_V(V + p)
+        assert c.is_intersected() == orc.is_intersected(m)
+        c.set_positions(V)
+        m.set_V(V)
+    # separating motion: no pair limits the step
+    p = np.zeros_like(V)
+    p[nA:, 1] = 0.05
+    assert c.ccd_full(p.reshape(-1), 0.8, 0.7)[0] == 0.7 and c.ccd_partial(p.reshape(-1), 0.8, 0.7)[0] == 0.7
+    assert not c.is_intersected()
+
+
 def test_barrier_energy_gradient_hessian(orc, pair):
     m, c, dHat = pair["m"], pair["c"], pair["dHat"]
     cs = orc.Contacts()
