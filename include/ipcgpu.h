@@ -161,6 +161,16 @@ int ipcgpu_opt_init(ipcgpu_ctx*, double dt, int withGravity);
 int ipcgpu_opt_set_rel_tol(ipcgpu_ctx*, double relTol); /* setRelGL2Tol, Optimizer.cpp:390-396 */
 /* `script twist` (AnimScripter.cpp:555-572, 1674-1684): two handle sets rotating about x */
 int ipcgpu_opt_set_twist(ipcgpu_ctx*, int nLeft, const int* left, int nRight, const int* right, double angVel);
+/* `selfCollisionOn` with the interior-point solver (Config.cpp:41-45, Optimizer.cpp:1534-1550): needs ipcgpu_set_surface;
+ * dHat = dHatEps^2 * bboxDiag^2 (`dHat` keyword, default 1e-3).  From then on the stepper builds constraint sets, adds the
+ * barrier terms, adapts kappa and bounds every step by CCD exactly as fullyImplicit_IP / solveSub_IP do. */
+int ipcgpu_opt_enable_self_collision(ipcgpu_ctx*, double dHatEps);
+/* overwrite Optimizer::velocity (xyz-interleaved) and recompute xTilta (computeXTilta, Optimizer.cpp:1236-1257): the
+ * `initVel` script keyword (Config.cpp:247-262) */
+int ipcgpu_opt_set_velocity(ipcgpu_ctx*, const double* vel_3nV);
+/* counts6 = {#active, #paraEE, #CCD candidates, 0, #full CCD passes, #pattern changes}; pair2 = limiting CCD pair of the
+ * last iteration ((-svI-1, sfI) or (eI, eJ), (0,0) if none) */
+int ipcgpu_opt_get_contact_state(ipcgpu_ctx*, int* counts6, int* pair2);
 int ipcgpu_opt_precompute(ipcgpu_ctx*); /* precompute, Optimizer.cpp:457-507 */
 int ipcgpu_opt_begin_timestep(ipcgpu_ctx*); /* solve(): stepAnimScript + fullyImplicit_IP head */
 /* one pass of the solveSub_IP loop (Optimizer.cpp:1829-2204) == one "Newton iteration" of the
@@ -169,7 +179,7 @@ int ipcgpu_opt_newton_iter(ipcgpu_ctx*, int* converged);
 int ipcgpu_opt_end_timestep(ipcgpu_ctx*); /* BE velocity + xTilta update, Optimizer.cpp:570-580 */
 int ipcgpu_opt_solve_timestep(ipcgpu_ctx*, int maxIter, int* nIter); /* Optimizer::solve(1) */
 /* state readers (any pointer may be NULL); scalars8 = {lastEnergyVal, lastStepSize, targetGRes,
- * innerIterAmt, timestep, alphaFeasible, 0, 0} */
+ * innerIterAmt, timestep, alphaFeasible, kappa, dHat} */
 int ipcgpu_opt_get_state(ipcgpu_ctx*, double* V_colmajor, double* searchDir_3nV, double* gradient_3nV, double* scalars8);
 /* timer_step buckets in seconds (src/main.cpp:1326-1340): 0 matrixComputation .. 14 computeConstraintSets */
 int ipcgpu_opt_get_timers(ipcgpu_ctx*, double* t16);

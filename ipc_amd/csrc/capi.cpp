@@ -155,6 +155,9 @@ int ipcgpu_set_mesh(ipcgpu_ctx* c, int nV, int nT, const double* Vr, const int* 
         c->opt->tetBegin = (int)((long long)nT * c->rank / c->worldSize);
         c->opt->tetEnd = (int)((long long)nT * (c->rank + 1) / c->worldSize);
         c->opt->initialised = false;
+        c->opt->selfCollision = false; // surface + contact state belong to the previous mesh
+        c->opt->contact = nullptr;
+        c->contact.reset();
         return IPCGPU_OK;
     });
 }
@@ -692,6 +695,48 @@ int ipcgpu_opt_set_twist(ipcgpu_ctx* c, int nL, const int* l, int nR, const int*
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_enable_self_collision(ipcgpu_ctx* c, double dHatEps)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(dHatEps > 0, "dHatEps must be positive");
+        o.enableSelfCollision(&CT(c), dHatEps);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_velocity(ipcgpu_ctx* c, const double* vel)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(vel != nullptr, "null velocity");
+        o.setVelocity(vel);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_get_contact_state(ipcgpu_ctx* c, int* counts6, int* pair2)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        need(o.selfCollision, "self collision is not enabled");
+        if (counts6) {
+            counts6[0] = (int)o.contact->active.size();
+            counts6[1] = (int)o.contact->para.size();
+            counts6[2] = (int)o.contact->csPTEE.size();
+            counts6[3] = 0;
+            counts6[4] = o.nFullCCD;
+            counts6[5] = o.nPatternChanges;
+        }
+        if (pair2) {
+            pair2[0] = o.lastCCDPair[0];
+            pair2[1] = o.lastCCDPair[1];
+        }
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_precompute(ipcgpu_ctx* c)
 {
     return guarded([&] {
@@ -751,7 +796,8 @@ int ipcgpu_opt_get_state(ipcgpu_ctx* c, double* V, double* p, double* g, double*
             sc[3] = o.innerIterAmt;
             sc[4] = o.globalIterNum;
             sc[5] = o.lastAlphaFeasible;
-            sc[6] = sc[7] = 0.0;
+            sc[6] = o.kappa;
+            sc[7] = o.dHat;
         }
         return IPCGPU_OK;
     });

@@ -141,7 +141,127 @@ double HipOptimizer::computeEnergyVal()
 {
     launch_energy(view(), dtSq, true, rank == 0, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
     reduceSum(d_scalar.p, 1);
-    return readScalar(d_scalar.p);
+    double E = readScalar(d_scalar.p);
+    // barrier term over the current constraint set (Optimizer.cpp:3252-3353); replicated on every rank
+    if (selfCollision) E += contact->energy(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4);
+    return E;
+}
+
+// ---- self-contact ----------------------------------------------------------------------------------------------
+void HipOptimizer::enableSelfCollision(HipContact* c, double eps)
+{
+    // `selfCollisionOn` + interior point; dHat = dHatEps^2 * bbox diagonal^2 (Optimizer.cpp:1534-1537, Config.cpp:41-45)
+    if (!c || !c->surfaceSet) throw StateError("opt_enable_self_collision before set_surface");
+    contact = c;
+    selfCollision = true;
+    dHatEps = eps;
+    dHat = eps * eps * mesh.bboxDiag2;
+    dTol = 1.0e-18 * mesh.bboxDiag2; // dTolRel = 1e-9 (Optimizer.cpp:102-109)
+}
+
+void HipOptimizer::computeXTilta()
+{
+    // Optimizer.cpp:1236-1257 on the host: only used when the caller overrides the velocity
+    const size_t n3 = 3 * (size_t)mesh.nV;
+    std::vector<double> xp(n3), vel(n3), xt(n3);
+    d_xPrev.download(xp.data(), n3, stream);
+    d_vel.download(vel.data(), n3, stream);
+    for (int v = 0; v < mesh.nV; ++v)
+        for (int c = 0; c < 3; ++c) {
+            const size_t i = 3 * (size_t)v + c;
+            xt[i] = mesh.isDBCVertex(v) ? xp[i] : xp[i] + (vel[i] * dt + dtSq * gravity[c]);
+        }
+    mesh.d_xTilde.upload(xt, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void HipOptimizer::setVelocity(const double* vel3nV)
+{
+    HIP_CHECK(hipMemcpyAsync(d_vel.p, vel3nV, 3 * (size_t)mesh.nV * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    computeXTilta();
+}
+
+void HipOptimizer::computeConstraintSets()
+{
+    if (!selfCollision) return;
+    Tic t(timers[14], stream);
+    contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, dHat); // Optimizer.cpp:2448-2470
+}
+
+bool HipOptimizer::isIntersected() { return contact->isIntersected(mesh, mesh.d_x.p, mesh.d_dbc.p); }
+
+double HipOptimizer::kappaFloor() const
+{
+    // suggestKappa (Optimizer.cpp:2228-2233): kappaMinMultiplier (1e11, Config.hpp:139) * mean nodal mass / (4e-16 L^2 b''(1e-16 L^2))
+    const double d = 1.0e-16 * mesh.bboxDiag2, t2 = d - dHat, lg = std::log(d / dHat);
+    const double Hb = (lg * -2.0 - t2 * 4.0 / d) + 1.0 / (d * d) * (t2 * t2); // BarrierFunctions.hpp:76-83
+    double avgMass = 0;
+    for (double x : mesh.mass) avgMass += x;
+    avgMass /= mesh.nV;
+    return 1.0e11 * avgMass / (4.0e-16 * mesh.bboxDiag2 * Hb);
+}
+
+void HipOptimizer::initKappa()
+{
+    // Optimizer.cpp:2236-2313: balance the barrier gradient of the active set against elasticity + inertia.  Once per time
+    // step, so the two gradients are dotted on the host in index order
+    if (contact->active.empty()) return;
+    const size_t n3 = 3 * (size_t)mesh.nV;
+    std::vector<double> gE(n3), gc(n3);
+    const bool keepSC = selfCollision;
+    selfCollision = false;
+    computeGradient(true);
+    selfCollision = keepSC;
+    d_gradient.download(gE.data(), n3, stream);
+    std::vector<std::array<int, 4>> keepPara;
+    keepPara.swap(contact->para); // initKappa looks at the activeSet only
+    d_minusG.zero(stream);
+    contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, 1.0, 1, d_minusG.p);
+    keepPara.swap(contact->para);
+    d_minusG.download(gc.data(), n3, stream);
+    double num = 0, den = 0;
+    for (size_t i = 0; i < n3; ++i) {
+        num += gc[i] * gE[i];
+        den += gc[i] * gc[i];
+    }
+    double minKappa = -num / den;
+    if (minKappa > 0.0) kappa = minKappa;
+    minKappa = kappaFloor();
+    if (kappa < minKappa) kappa = minKappa;
+    const double kappaMax = 100 * kappaFloor(); // upperBoundKappa, :2216-2225
+    if (kappa > kappaMax) kappa = kappaMax;
+}
+
+void HipOptimizer::postLineSearch()
+{
+    // Optimizer.cpp:2357-2445 (ADAPTIVE_KAPPA)
+    if (!selfCollision) return;
+    if (kappa == 0.0) {
+        initKappa();
+        return;
+    }
+    std::vector<double> d;
+    contact->evalStencils(closeID, mesh.d_x.p, d);
+    bool updateKappa = false;
+    for (size_t i = 0; i < closeID.size(); ++i)
+        if (d[i] <= closeVal[i]) {
+            updateKappa = true;
+            break;
+        }
+    if (updateKappa) {
+        kappa *= 2.0;
+        const double kappaMax = 100 * kappaFloor();
+        if (kappa > kappaMax) kappa = kappaMax;
+    }
+    closeID.clear();
+    closeVal.clear();
+    contact->evalStencils(contact->active, mesh.d_x.p, d);
+    for (size_t i = 0; i < contact->active.size(); ++i)
+        if (d[i] < dTol) {
+            closeID.push_back(contact->active[i]);
+            closeVal.push_back(d[i]);
+        }
 }
 
 void HipOptimizer::ensurePatchPlan()
@@ -162,6 +282,7 @@ void HipOptimizer::computeGradient(bool projectDBC)
         launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
         launch_assemble(view(), dtSq, projectDBC, d_gradient.p, nullptr, stream);
         reduceSum(d_gradient.p, 3LL * mesh.nV);
+        if (selfCollision) contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa, projectDBC, d_gradient.p);
         return;
     }
     ensurePatchPlan();
@@ -170,11 +291,42 @@ void HipOptimizer::computeGradient(bool projectDBC)
     if (worldSize > 1) d_gradient.zero(stream);
     launch_assemble_patches(view(), patch, pb, pe, dtSq, projectDBC, d_gradient.p, nullptr, stream);
     reduceSum(d_gradient.p, 3LL * mesh.nV);
+    // barrier forces, then the projected rows are cleared again (Optimizer.cpp:3452-3516)
+    if (selfCollision) contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa, projectDBC, d_gradient.p);
 }
 
 void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
 {
     if (lin.rowBase.empty()) throw StateError("computePrecondMtr needs a pattern built by set_pattern");
+    if (selfCollision) {
+        // the pattern follows the contact connectivity (augmentConnectivity into vNeighbor_IP, Optimizer.cpp:3560-3612);
+        // only pairs that are not mesh edges change it
+        std::vector<std::pair<int, int>> extra, fresh;
+        if (contact->active.size() + contact->para.size()) contact->connectivity(extra);
+        for (const auto& e : extra) {
+            const int* b = mesh.nb.data() + mesh.nbPtr[e.first];
+            const int* en = mesh.nb.data() + mesh.nbPtr[e.first + 1];
+            if (!std::binary_search(b, en, e.second)) fresh.push_back(e);
+        }
+        std::sort(fresh.begin(), fresh.end());
+        fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+        if (fresh != curExtra) {
+            curExtra = fresh;
+            nPatternChanges++;
+            std::vector<int> flat;
+            flat.reserve(2 * fresh.size());
+            for (const auto& e : fresh) {
+                flat.push_back(e.first);
+                flat.push_back(e.second);
+            }
+            {
+                Tic t(timers[1], stream);
+                lin.set_pattern(mesh, (int)fresh.size(), flat.data());
+            }
+            Tic t(timers[2], stream);
+            lin.analyze_pattern(&mesh);
+        }
+    }
     // setZero (Optimizer.cpp:3616), elastic Hessian (:3619-3623) and the mass / DBC diagonal (:3638-3668) are one
     // pass: every owned CSR row is written exactly once by the patch that owns its node
     ensurePatchPlan();
@@ -189,6 +341,10 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
     if (worldSize > 1) {
         reduceSum(lin.d_a.p, (long long)lin.ja.size());
         if (withGradient) reduceSum(d_gradient.p, 3LL * mesh.nV);
+    }
+    if (selfCollision) { // barrier blocks, PSD-projected per stencil (Optimizer.cpp:3625-3636)
+        if (withGradient) contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa, projectDBC, d_gradient.p);
+        contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
     }
 }
 
@@ -254,12 +410,19 @@ void HipOptimizer::lineSearch(double& stepSize)
             if (stepSize == 0.0) break;
             stepForward(d_x0.p, stepSize);
         }
+        if (selfCollision)
+            while (isIntersected()) { // Optimizer.cpp:2719-2736
+                stepSize /= 2.0;
+                stepForward(d_x0.p, stepSize);
+            }
     }
+    computeConstraintSets();
     double testingE;
     {
         Tic t(timers[9], stream);
         testingE = computeEnergyVal();
     }
+    const double LFStepSize = stepSize;
     while (testingE > lastEnergyVal && stepSize > 0.0) { // Optimizer.cpp:2761-2797
         stepSize /= 2.0;
         if (stepSize == 0.0) break;
@@ -267,8 +430,21 @@ void HipOptimizer::lineSearch(double& stepSize)
             Tic t(timers[5], stream);
             stepForward(d_x0.p, stepSize);
         }
+        computeConstraintSets();
         Tic t(timers[9], stream);
         testingE = computeEnergyVal();
+    }
+    if (stepSize < LFStepSize && selfCollision) { // Optimizer.cpp:2799-2811
+        bool needRecomputeCS = false;
+        while (isIntersected()) {
+            stepSize /= 2.0;
+            stepForward(d_x0.p, stepSize);
+            needRecomputeCS = true;
+        }
+        if (needRecomputeCS) {
+            computeConstraintSets();
+            testingE = computeEnergyVal();
+        }
     }
     lastEnergyVal = testingE;
 }
@@ -280,12 +456,14 @@ void HipOptimizer::precompute()
     {
         Tic t(timers[1], stream);
         lin.set_pattern(mesh, 0, nullptr);
+        curExtra.clear();
     }
+    computeConstraintSets();
     {
         Tic t(timers[0], stream);
-        computePrecondMtr(true, false);
+        computePrecondMtr(true, false); // re-patterns + analyses when contact pairs are already active
     }
-    {
+    if (!lin.analyzed()) {
         Tic t(timers[2], stream);
         lin.analyze_pattern(&mesh);
     }
@@ -303,14 +481,33 @@ void HipOptimizer::beginTimestep()
         // stepAnimScript, AST_TWIST (AnimScripter.cpp:1674-1684, 2140-2215)
         launch_twist_dir(nHandles, d_handleIds.p, d_handleAng.p, rotCenter[1], rotCenter[2], mesh.d_x.p, d_searchDir.p, stream);
         double stepSize = filterStepSize(d_searchDir.p, 1.0);
+        if (selfCollision) // CCD of the scripted motion with slackness 0.5 (AnimScripter.cpp:2158-2171)
+            stepSize = contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, 0.5, stepSize, nullptr, nullptr);
         HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, 3 * (size_t)mesh.nV * sizeof(double), hipMemcpyDeviceToDevice, stream));
         stepForward(d_x0.p, stepSize);
         while (!checkInversion()) {
             stepSize /= 2.0;
             stepForward(d_x0.p, stepSize);
         }
-        if (stepSize < 1.0) throw StateError("scripted Dirichlet motion was cut short; the augmented-Lagrangian DBC path (AnimScripter.cpp:2303-2345) is a SURVEY 8f 'next' row");
+        if (selfCollision)
+            while (isIntersected()) {
+                stepSize /= 2.0;
+                stepForward(d_x0.p, stepSize);
+            }
+        if (stepSize < 1.0) {
+            dbcIncomplete++;
+            throw StateError("scripted Dirichlet motion was cut short; the augmented-Lagrangian DBC path (AnimScripter.cpp:2303-2345) is a SURVEY 8f 'next' row");
+        }
         d_searchDir.zero(stream); // initX(0), Optimizer.cpp:930-934
+    }
+    if (selfCollision) {
+        // fullyImplicit_IP head (Optimizer.cpp:1534-1550, 2316-2322): dHat, constraint sets, kappa, empty close-pair list
+        dHat = dHatEps * dHatEps * mesh.bboxDiag2;
+        computeConstraintSets();
+        kappa = kappaFloor();
+        initKappa();
+        closeID.clear();
+        closeVal.clear();
     }
     lastEnergyVal = computeEnergyVal(); // Optimizer.cpp:1609
     k = 0;
@@ -338,10 +535,25 @@ bool HipOptimizer::newtonIter()
     {
         Tic t(timers[13], stream);
         alpha = filterStepSize(d_searchDir.p, alpha); // Optimizer.cpp:1887
+        if (selfCollision) {
+            // step-size pipeline of Optimizer.cpp:1884-2040: partial CCD over the candidates of the current
+            // constraint set, CFL bound, full CCD only when the step leaves the CFL ball
+            const double slackness_m = 0.8;
+            alpha = contact->ccdPartial(mesh.d_x.p, d_searchDir.p, slackness_m, alpha, lastCCDPair);
+            const double pMax = contact->maxSurfaceSpeed(d_searchDir.p);
+            const double alpha_CFL = std::sqrt(dHat) / (pMax * 2.0);
+            if ((!k && alpha > alpha_CFL) || alpha > 2.0 * alpha_CFL) {
+                alpha = contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, slackness_m, alpha, lastCCDPair, nullptr);
+                nFullCCD++;
+                if (alpha < alpha_CFL) alpha = alpha_CFL;
+            }
+            else alpha = std::min(alpha, alpha_CFL);
+        }
     }
     lastAlphaFeasible = alpha;
     lineSearch(alpha);
     lastStepSize = alpha;
+    postLineSearch();
     ++k;
     return false;
 }

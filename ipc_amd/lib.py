@@ -392,7 +392,22 @@ class Context:
         sc = np.zeros(8)
         self._chk(self._L.ipcgpu_opt_get_state(self.h, _dp(V), _dp(p), _dp(g), _dp(sc)))
         return dict(V=V, searchDir=p, gradient=g, E=sc[0], stepSize=sc[1], targetGRes=sc[2],
-                    innerIterAmt=int(sc[3]), timestep=int(sc[4]), alphaFeasible=sc[5])
+                    innerIterAmt=int(sc[3]), timestep=int(sc[4]), alphaFeasible=sc[5], kappa=sc[6], dHat=sc[7])
+
+    def enable_self_collision(self, dHatEps=1e-3):
+        self._chk(self._L.ipcgpu_opt_enable_self_collision(self.h, C.c_double(dHatEps)))
+
+    def set_velocity(self, vel):
+        vel = _f64(np.asarray(vel).reshape(-1))
+        assert vel.size == 3 * self.nV
+        self._chk(self._L.ipcgpu_opt_set_velocity(self.h, _dp(vel)))
+
+    def contact_state(self):
+        cnt = np.zeros(6, dtype=np.int32)
+        pr = np.zeros(2, dtype=np.int32)
+        self._chk(self._L.ipcgpu_opt_get_contact_state(self.h, _ip(cnt), _ip(pr)))
+        return dict(nActive=int(cnt[0]), nPara=int(cnt[1]), nCand=int(cnt[2]), nFullCCD=int(cnt[4]),
+                    nPatternChanges=int(cnt[5]), ccdPair=(int(pr[0]), int(pr[1])))
 
     def timers(self):
         t = np.zeros(16)

@@ -132,6 +132,77 @@ def test_ccd_step_bounds_and_intersection_check(orc, pair):
     assert not c.is_intersected()
 
 
+def drop_scene(orc, gpu_lib, n=2, gap=0.03, dHatEps=1e-2, dt=0.01, speed=-1.5, jitter=1e-2):
+    """Two slabs, the upper one falling on the clamped lower one.  The start state is a jittered (pre-strained) copy of the
+    rest shape: exactly at rest the reference's makePD2d is discontinuous (see test_gpu_parity), which would make an
+    iterate-by-iterate comparison depend on round-off."""
+    V, F = two_blocks(gap, n=n)
+    Vstart = scene.jitter(V, F, rel=jitter) if jitter else V
+    SF = scene.surface_tris(F)
+    nA = V.shape[0] // 2
+    bottom = np.nonzero(V[:nA, 1] < V[:nA, 1].min() + 0.02)[0].astype(np.int32)
+    vel = np.zeros_like(V)
+    vel[nA:, 1] = speed
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_dbc(bottom, 1)
+    m.set_V(Vstart)
+    o = orc.Optimizer(m, dt=dt, gravity=True, nthreads=4)
+    orc.opt_enable_self_collision(o, dHatEps)
+    orc.opt_set_velocity(o, vel)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_dbc(bottom, 1)
+    c.set_positions(Vstart)
+    c.opt_init(dt, True)
+    c.set_surface(SF)
+    c.enable_self_collision(dHatEps)
+    c.set_velocity(vel)
+    return m, o, c, nA
+
+
+@pytest.mark.parametrize("n,speed,dt", [(2, -1.5, 0.01), (3, -6.0, 0.02)])
+def test_contact_newton_iterates_track_the_oracle(orc, gpu_lib, n, speed, dt):
+    """The whole contact-aware stepper (constraint sets per trial, barrier terms, adaptive kappa, partial / CFL / full CCD,
+    intersection-checked line search, pattern growth + re-analysis) iterate by iterate against the oracle."""
+    m, o, c, nA = drop_scene(orc, gpu_lib, n=n, speed=speed, dt=dt)
+    o.precompute()
+    c.precompute()
+    seen, worst = 0, 0.0
+    for step in range(6):
+        o.begin_timestep()
+        c.begin_timestep()
+        so, sg = o.state(), c.state()
+        assert sg["dHat"] == so["dHat"]
+        assert abs(sg["kappa"] - so["kappa"]) <= 1e-9 * so["kappa"]
+        assert abs(sg["E"] - so["E"]) <= 1e-9 * abs(so["E"])
+        for it in range(60):
+            co, cg = o.newton_iter(), c.newton_iter()
+            assert co == cg, (step, it)
+            if co:
+                break
+            so, sg = o.state(), c.state()
+            cst_o, cst_g = orc.opt_contact_state(o), c.contact_state()
+            assert cst_g["nActive"] == len(cst_o["active"]) and cst_g["nPara"] == len(cst_o["para"]), (step, it)
+            assert abs(sg["alphaFeasible"] - so["alphaFeasible"]) <= 1e-8 * so["alphaFeasible"], (step, it)
+            assert sg["stepSize"] == pytest.approx(so["stepSize"], rel=1e-8), (step, it)
+            assert abs(sg["kappa"] - so["kappa"]) <= 1e-8 * so["kappa"], (step, it)
+            assert abs(sg["E"] - so["E"]) <= 1e-8 * abs(so["E"]), (step, it)
+            worst = max(worst, relerr(sg["V"], so["V"]))
+            seen = max(seen, cst_g["nActive"])
+        else:
+            pytest.fail("contact Newton did not converge")
+        o.end_timestep()
+        c.end_timestep()
+        assert c.check_inversion() and not c.is_intersected()
+    assert seen > 0 and c.contact_state()["nPatternChanges"] >= 1
+    assert c.contact_state()["nFullCCD"] == orc.opt_contact_state(o)["n_full_ccd"]
+    assert worst < 1e-8
+    Vn = c.state()["V"]
+    assert Vn[nA:, 1].mean() > Vn[:nA, 1].mean() + 0.2
+    c.close()
+
+
 def test_barrier_energy_gradient_hessian(orc, pair):
     m, c, dHat = pair["m"], pair["c"], pair["dHat"]
     cs = orc.Contacts()
