@@ -165,10 +165,22 @@ int ipcgpu_opt_set_twist(ipcgpu_ctx*, int nLeft, const int* left, int nRight, co
  * dHat = dHatEps^2 * bboxDiag^2 (`dHat` keyword, default 1e-3).  From then on the stepper builds constraint sets, adds the
  * barrier terms, adapts kappa and bounds every step by CCD exactly as fullyImplicit_IP / solveSub_IP do. */
 int ipcgpu_opt_enable_self_collision(ipcgpu_ctx*, double dHatEps);
+/* analytic half-space obstacle (`ground` / `halfSpace` keywords, Config.cpp:306-345; HalfSpace.cpp:41-85): points with
+ * normal.(x - origin) > 0 are free.  Needs ipcgpu_set_surface.  Returns its index in *id.  The stepper then builds its
+ * vertex constraint set (CollisionObject.h:323-351), adds barrier energy / gradient / diagonal Hessian blocks
+ * (HalfSpace.cpp:106-214) and bounds each step by the ray test with slackness 0.9 (HalfSpace.cpp:242-269). */
+int ipcgpu_opt_add_half_space(ipcgpu_ctx*, const double* origin3, const double* normal3, double dHatEps, int* id);
+/* the same pieces one by one (adapter for a HalfSpace<3> subclass).  verts = activeSet[coI], ascending surface order. */
+int ipcgpu_halfspace_build(ipcgpu_ctx*, int id, double dHat, int cap, int* verts, int* n);
+int ipcgpu_halfspace_set(ipcgpu_ctx*, int id, int n, const int* verts);
+int ipcgpu_halfspace_energy(ipcgpu_ctx*, int id, double dHat, double kappa, double* E);
+int ipcgpu_halfspace_gradient_add(ipcgpu_ctx*, int id, double dHat, double kappa, double* grad_3nV_inout);
+int ipcgpu_halfspace_hessian_add(ipcgpu_ctx*, int id, double dHat, double kappa, int projectDBC);
+int ipcgpu_halfspace_step_bound(ipcgpu_ctx*, int id, const double* searchDir_3nV, double slackness, double* stepSize_inout);
 /* overwrite Optimizer::velocity (xyz-interleaved) and recompute xTilta (computeXTilta, Optimizer.cpp:1236-1257): the
  * `initVel` script keyword (Config.cpp:247-262) */
 int ipcgpu_opt_set_velocity(ipcgpu_ctx*, const double* vel_3nV);
-/* counts6 = {#active, #paraEE, #CCD candidates, 0, #full CCD passes, #pattern changes}; pair2 = limiting CCD pair of the
+/* counts6 = {#active, #paraEE, #CCD candidates, #half-space constraints, #full CCD passes, #pattern changes}; pair2 = limiting CCD pair of the
  * last iteration ((-svI-1, sfI) or (eI, eJ), (0,0) if none) */
 int ipcgpu_opt_get_contact_state(ipcgpu_ctx*, int* counts6, int* pair2);
 int ipcgpu_opt_precompute(ipcgpu_ctx*); /* precompute, Optimizer.cpp:457-507 */

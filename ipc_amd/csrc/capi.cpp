@@ -157,6 +157,7 @@ int ipcgpu_set_mesh(ipcgpu_ctx* c, int nV, int nT, const double* Vr, const int* 
         c->opt->initialised = false;
         c->opt->selfCollision = false; // surface + contact state belong to the previous mesh
         c->opt->contact = nullptr;
+        c->opt->planes.clear();
         c->contact.reset();
         return IPCGPU_OK;
     });
@@ -706,6 +707,91 @@ int ipcgpu_opt_enable_self_collision(ipcgpu_ctx* c, double dHatEps)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_add_half_space(ipcgpu_ctx* c, const double* origin, const double* normal, double dHatEps, int* id)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(origin && normal && dHatEps > 0, "bad half-space argument");
+        const int k = o.addHalfSpace(&CT(c), origin, normal, dHatEps);
+        if (id) *id = k;
+        return IPCGPU_OK;
+    });
+}
+static HipHalfSpace& HS(ipcgpu_ctx* c, int id)
+{
+    HipOptimizer& o = O(c);
+    needArg(id >= 0 && id < (int)o.planes.size(), "half-space index out of range");
+    return *o.planes[id];
+}
+int ipcgpu_halfspace_build(ipcgpu_ctx* c, int id, double dHat, int cap, int* verts, int* n)
+{
+    return guarded([&] {
+        HipHalfSpace& h = HS(c, id);
+        bind(c);
+        const int cnt = h.build(CT(c).nSVI, CT(c).d_SVI.p, c->mesh->d_x.p, c->mesh->d_dbc.p, dHat);
+        if (n) *n = cnt;
+        needArg(!verts || cap >= cnt, "verts buffer too small");
+        if (verts) std::memcpy(verts, h.set.data(), sizeof(int) * cnt);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_halfspace_set(ipcgpu_ctx* c, int id, int n, const int* verts)
+{
+    return guarded([&] {
+        HipHalfSpace& h = HS(c, id);
+        bind(c);
+        for (int i = 0; i < n; ++i) needArg(verts[i] >= 0 && verts[i] < c->mesh->nV, "vertex id out of range");
+        h.setSet(n, verts);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_halfspace_energy(ipcgpu_ctx* c, int id, double dHat, double kappa, double* E)
+{
+    return guarded([&] {
+        HipHalfSpace& h = HS(c, id);
+        bind(c);
+        *E = h.energy(c->mesh->d_x.p, dHat, kappa);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_halfspace_gradient_add(ipcgpu_ctx* c, int id, double dHat, double kappa, double* g)
+{
+    return guarded([&] {
+        HipHalfSpace& h = HS(c, id);
+        HipOptimizer& o = O(c);
+        bind(c);
+        const size_t n3 = 3 * (size_t)c->mesh->nV;
+        HIP_CHECK(hipMemcpyAsync(o.d_gradient.p, g, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        h.gradientAdd(c->mesh->d_x.p, dHat, kappa, o.d_gradient.p);
+        o.d_gradient.download(g, n3, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_halfspace_hessian_add(ipcgpu_ctx* c, int id, double dHat, double kappa, int projectDBC)
+{
+    return guarded([&] {
+        HipHalfSpace& h = HS(c, id);
+        bind(c);
+        need(c->lin->numRows == 3 * c->mesh->nV, "call ipcgpu_linsys_set_pattern first");
+        h.hessianAdd(c->mesh->d_x.p, c->mesh->d_dbc.p, c->lin->d_rowBase.p, c->lin->d_rowLen.p, dHat, kappa, projectDBC, c->lin->d_a.p);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_halfspace_step_bound(ipcgpu_ctx* c, int id, const double* p, double slackness, double* step)
+{
+    return guarded([&] {
+        HipHalfSpace& h = HS(c, id);
+        HipOptimizer& o = O(c);
+        bind(c);
+        needArg(p && step && slackness > 0 && slackness <= 1, "bad step-bound argument");
+        HIP_CHECK(hipMemcpyAsync(o.d_searchDir.p, p, 3 * (size_t)c->mesh->nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        *step = h.stepBound(CT(c).nSVI, CT(c).d_SVI.p, c->mesh->d_x.p, c->mesh->d_dbc.p, o.d_searchDir.p, slackness, *step);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_velocity(ipcgpu_ctx* c, const double* vel)
 {
     return guarded([&] {
@@ -721,12 +807,13 @@ int ipcgpu_opt_get_contact_state(ipcgpu_ctx* c, int* counts6, int* pair2)
 {
     return guarded([&] {
         HipOptimizer& o = O(c);
-        need(o.selfCollision, "self collision is not enabled");
+        need(o.ipOn(), "neither self collision nor a half-space is enabled");
         if (counts6) {
-            counts6[0] = (int)o.contact->active.size();
-            counts6[1] = (int)o.contact->para.size();
-            counts6[2] = (int)o.contact->csPTEE.size();
+            counts6[0] = o.selfCollision ? (int)o.contact->active.size() : 0;
+            counts6[1] = o.selfCollision ? (int)o.contact->para.size() : 0;
+            counts6[2] = o.selfCollision ? (int)o.contact->csPTEE.size() : 0;
             counts6[3] = 0;
+            for (const auto& h : o.planes) counts6[3] += (int)h->set.size();
             counts6[4] = o.nFullCCD;
             counts6[5] = o.nPatternChanges;
         }

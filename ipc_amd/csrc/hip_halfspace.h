@@ -1,0 +1,40 @@
+// HipHalfSpace: analytic half-space obstacle of the hot path with its vertex constraint set in HBM.
+//   HalfSpace::init                              src/CollisionObject/HalfSpace.cpp:41-85
+//   CollisionObject::computeConstraintSet        src/CollisionObject/CollisionObject.h:323-351   -> build
+//   evaluateConstraint + barrier energy          HalfSpace.cpp:106-111, Optimizer.cpp:3254-3267  -> energy
+//   leftMultiplyConstraintJacobianT              HalfSpace.cpp:121-143                           -> gradientAdd
+//   augmentIPHessian                             HalfSpace.cpp:169-214                           -> hessianAdd
+//   largestFeasibleStepSize                      HalfSpace.cpp:242-269                           -> stepBound
+//   CollisionObject::isIntersected               CollisionObject.h:386-401                       -> intersected
+#pragma once
+#include "common.h"
+#include <vector>
+
+namespace ipcgpu {
+
+class HipHalfSpace {
+public:
+    HipHalfSpace(hipStream_t s, const double* origin3, const double* normal3);
+    hipStream_t stream;
+    double n[3], D;
+    std::vector<int> set; // activeSet[coI]: vertex ids, ascending surface-vertex order
+    DevBuf<int> d_set;
+
+    int build(int nSVI, const int* svi_dev, const double* x_dev, const int* dbc_dev, double dHat);
+    void setSet(int n, const int* verts);
+    double energy(const double* x_dev, double dHat, double kappa);
+    void gradientAdd(const double* x_dev, double dHat, double kappa, double* grad_dev);
+    void hessianAdd(const double* x_dev, const int* dbc_dev, const int* rowBase_dev, const int* rowLen_dev, double dHat, double kappa, int projectDBC,
+        double* a_dev);
+    double stepBound(int nSVI, const int* svi_dev, const double* x_dev, const int* dbc_dev, const double* p_dev, double slackness, double stepSize);
+    bool intersected(int nV, const double* x_dev, const int* dbc_dev);
+    void evalDist2(const std::vector<int>& verts, const double* x_dev, std::vector<double>& d2);
+
+private:
+    DevBuf<int> flags_, count_, ids_;
+    DevBuf<char> tmp_;
+    DevBuf<double> partial_, vals_;
+    DevBuf<unsigned long long> minOut_;
+};
+
+} // namespace ipcgpu

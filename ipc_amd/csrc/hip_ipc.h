@@ -12,6 +12,7 @@
 #include "nh_kernels.h"
 #include "patch_assembly.h"
 #include "hip_contact.h"
+#include "hip_halfspace.h"
 #include <map>
 #include <memory>
 
@@ -139,6 +140,16 @@ public:
     std::vector<std::array<int, 4>> closeID; // closeMConstraintID / Val (Optimizer.cpp:2396-2440)
     std::vector<double> closeVal;
     int lastCCDPair[2] = { 0, 0 }, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
+    // analytic half-space obstacles (animConfig.collisionObjects) and their close-constraint list (Optimizer.cpp:2364-2374)
+    std::vector<std::unique_ptr<HipHalfSpace>> planes;
+    std::vector<std::pair<int, int>> closeHS;
+    std::vector<double> closeHSVal;
+    bool ipOn() const { return selfCollision || !planes.empty(); }
+    size_t nConstraints() const;
+    int addHalfSpace(HipContact* c, const double* origin3, const double* normal3, double dHatEps);
+    bool anyIntersection();
+    void elasticInertiaGradient(bool projectDBC);
+    void barrierGradientAdd(bool projectDBC, double kappa, bool activeOnly, double* grad_dev);
     void enableSelfCollision(HipContact* c, double dHatEps);
     void setVelocity(const double* vel3nV);
     void computeConstraintSets();

@@ -142,9 +142,37 @@ double HipOptimizer::computeEnergyVal()
     launch_energy(view(), dtSq, true, rank == 0, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
     reduceSum(d_scalar.p, 1);
     double E = readScalar(d_scalar.p);
-    // barrier term over the current constraint set (Optimizer.cpp:3252-3353); replicated on every rank
+    // barrier terms over the current constraint sets (Optimizer.cpp:3252-3353); replicated on every rank
+    for (auto& h : planes) E += h->energy(mesh.d_x.p, dHat, kappa);
     if (selfCollision) E += contact->energy(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4);
     return E;
+}
+
+size_t HipOptimizer::nConstraints() const
+{
+    size_t n = selfCollision ? contact->active.size() : 0;
+    for (const auto& h : planes) n += h->set.size();
+    return n;
+}
+
+int HipOptimizer::addHalfSpace(HipContact* c, const double* origin3, const double* normal3, double eps)
+{
+    // `ground` / `halfSpace` script keywords (Config.cpp:306-345) -> animConfig.collisionObjects; friction is a SURVEY 8f row
+    if (!c || !c->surfaceSet) throw StateError("opt_add_half_space before set_surface");
+    contact = c;
+    planes.emplace_back(new HipHalfSpace(stream, origin3, normal3));
+    dHatEps = eps;
+    dHat = eps * eps * mesh.bboxDiag2;
+    dTol = 1.0e-18 * mesh.bboxDiag2;
+    return (int)planes.size() - 1;
+}
+
+bool HipOptimizer::anyIntersection()
+{
+    // isIntersected (Optimizer.cpp:2626-2659): analytic objects first, then the mesh against itself
+    for (auto& h : planes)
+        if (h->intersected(mesh.nV, mesh.d_x.p, mesh.d_dbc.p)) return true;
+    return selfCollision && isIntersected();
 }
 
 // ---- self-contact ----------------------------------------------------------------------------------------------
@@ -184,9 +212,10 @@ void HipOptimizer::setVelocity(const double* vel3nV)
 
 void HipOptimizer::computeConstraintSets()
 {
-    if (!selfCollision) return;
+    if (!ipOn()) return;
     Tic t(timers[14], stream);
-    contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, dHat); // Optimizer.cpp:2448-2470
+    for (auto& h : planes) h->build(contact->nSVI, contact->d_SVI.p, mesh.d_x.p, mesh.d_dbc.p, dHat); // Optimizer.cpp:2460-2462
+    if (selfCollision) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, dHat); // Optimizer.cpp:2448-2470
 }
 
 bool HipOptimizer::isIntersected() { return contact->isIntersected(mesh, mesh.d_x.p, mesh.d_dbc.p); }
@@ -206,19 +235,13 @@ void HipOptimizer::initKappa()
 {
     // Optimizer.cpp:2236-2313: balance the barrier gradient of the active set against elasticity + inertia.  Once per time
     // step, so the two gradients are dotted on the host in index order
-    if (contact->active.empty()) return;
+    if (!nConstraints()) return;
     const size_t n3 = 3 * (size_t)mesh.nV;
     std::vector<double> gE(n3), gc(n3);
-    const bool keepSC = selfCollision;
-    selfCollision = false;
-    computeGradient(true);
-    selfCollision = keepSC;
+    elasticInertiaGradient(true); // computeGradient with solveIP == false (:2243-2245)
     d_gradient.download(gE.data(), n3, stream);
-    std::vector<std::array<int, 4>> keepPara;
-    keepPara.swap(contact->para); // initKappa looks at the activeSet only
     d_minusG.zero(stream);
-    contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, 1.0, 1, d_minusG.p);
-    keepPara.swap(contact->para);
+    barrierGradientAdd(true, 1.0, true, d_minusG.p); // also clears the DBC rows (:2275-2277)
     d_minusG.download(gc.data(), n3, stream);
     double num = 0, den = 0;
     for (size_t i = 0; i < n3; ++i) {
@@ -236,19 +259,33 @@ void HipOptimizer::initKappa()
 void HipOptimizer::postLineSearch()
 {
     // Optimizer.cpp:2357-2445 (ADAPTIVE_KAPPA)
-    if (!selfCollision) return;
+    if (!ipOn()) return;
     if (kappa == 0.0) {
         initKappa();
         return;
     }
     std::vector<double> d;
-    contact->evalStencils(closeID, mesh.d_x.p, d);
     bool updateKappa = false;
-    for (size_t i = 0; i < closeID.size(); ++i)
-        if (d[i] <= closeVal[i]) {
-            updateKappa = true;
-            break;
-        }
+    for (size_t pi = 0; pi < planes.size() && !updateKappa; ++pi) {
+        std::vector<int> verts;
+        std::vector<double> was;
+        for (size_t i = 0; i < closeHS.size(); ++i)
+            if (closeHS[i].first == (int)pi) {
+                verts.push_back(closeHS[i].second);
+                was.push_back(closeHSVal[i]);
+            }
+        planes[pi]->evalDist2(verts, mesh.d_x.p, d);
+        for (size_t i = 0; i < verts.size(); ++i)
+            if (d[i] <= was[i]) updateKappa = true;
+    }
+    if (!updateKappa && selfCollision) {
+        contact->evalStencils(closeID, mesh.d_x.p, d);
+        for (size_t i = 0; i < closeID.size(); ++i)
+            if (d[i] <= closeVal[i]) {
+                updateKappa = true;
+                break;
+            }
+    }
     if (updateKappa) {
         kappa *= 2.0;
         const double kappaMax = 100 * kappaFloor();
@@ -256,6 +293,17 @@ void HipOptimizer::postLineSearch()
     }
     closeID.clear();
     closeVal.clear();
+    closeHS.clear();
+    closeHSVal.clear();
+    for (size_t pi = 0; pi < planes.size(); ++pi) {
+        planes[pi]->evalDist2(planes[pi]->set, mesh.d_x.p, d);
+        for (size_t i = 0; i < planes[pi]->set.size(); ++i)
+            if (d[i] < dTol) {
+                closeHS.push_back({ (int)pi, planes[pi]->set[i] });
+                closeHSVal.push_back(d[i]);
+            }
+    }
+    if (!selfCollision) return;
     contact->evalStencils(contact->active, mesh.d_x.p, d);
     for (size_t i = 0; i < contact->active.size(); ++i)
         if (d[i] < dTol) {
@@ -276,13 +324,26 @@ void HipOptimizer::patchShard(int& pb, int& pe) const
     pe = (int)((long long)patch.nPatches * (rank + 1) / worldSize);
 }
 
-void HipOptimizer::computeGradient(bool projectDBC)
+void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activeOnly, double* grad_dev)
+{
+    // barrier forces of the half-spaces and of the mesh against itself; the projected rows are cleared again at the end
+    // (Optimizer.cpp:3452-3516).  activeOnly: initKappa leaves the mollified parallel-edge set out (:2262-2270)
+    for (auto& h : planes) h->gradientAdd(mesh.d_x.p, dHat, kappa_, grad_dev);
+    if (!contact) return;
+    std::vector<std::array<int, 4>> keepPara, keepActive;
+    if (activeOnly || !selfCollision) keepPara.swap(contact->para);
+    if (!selfCollision) keepActive.swap(contact->active);
+    contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, projectDBC, grad_dev);
+    if (activeOnly || !selfCollision) keepPara.swap(contact->para);
+    if (!selfCollision) keepActive.swap(contact->active);
+}
+
+void HipOptimizer::elasticInertiaGradient(bool projectDBC)
 {
     if (lin.rowBase.empty()) { // no pattern yet: tet-parallel atomic path
         launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
         launch_assemble(view(), dtSq, projectDBC, d_gradient.p, nullptr, stream);
         reduceSum(d_gradient.p, 3LL * mesh.nV);
-        if (selfCollision) contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa, projectDBC, d_gradient.p);
         return;
     }
     ensurePatchPlan();
@@ -291,8 +352,12 @@ void HipOptimizer::computeGradient(bool projectDBC)
     if (worldSize > 1) d_gradient.zero(stream);
     launch_assemble_patches(view(), patch, pb, pe, dtSq, projectDBC, d_gradient.p, nullptr, stream);
     reduceSum(d_gradient.p, 3LL * mesh.nV);
-    // barrier forces, then the projected rows are cleared again (Optimizer.cpp:3452-3516)
-    if (selfCollision) contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa, projectDBC, d_gradient.p);
+}
+
+void HipOptimizer::computeGradient(bool projectDBC)
+{
+    elasticInertiaGradient(projectDBC);
+    if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p);
 }
 
 void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
@@ -342,9 +407,11 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         reduceSum(lin.d_a.p, (long long)lin.ja.size());
         if (withGradient) reduceSum(d_gradient.p, 3LL * mesh.nV);
     }
-    if (selfCollision) { // barrier blocks, PSD-projected per stencil (Optimizer.cpp:3625-3636)
-        if (withGradient) contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa, projectDBC, d_gradient.p);
-        contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
+    if (ipOn()) { // barrier blocks, PSD-projected per stencil (Optimizer.cpp:3625-3636, 3670-3676)
+        if (withGradient) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p);
+        for (auto& h : planes)
+            h->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin.d_rowBase.p, lin.d_rowLen.p, dHat, kappa, projectDBC, lin.d_a.p);
+        if (selfCollision) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
     }
 }
 
@@ -410,8 +477,8 @@ void HipOptimizer::lineSearch(double& stepSize)
             if (stepSize == 0.0) break;
             stepForward(d_x0.p, stepSize);
         }
-        if (selfCollision)
-            while (isIntersected()) { // Optimizer.cpp:2719-2736
+        if (ipOn())
+            while (anyIntersection()) { // Optimizer.cpp:2719-2736
                 stepSize /= 2.0;
                 stepForward(d_x0.p, stepSize);
             }
@@ -434,17 +501,14 @@ void HipOptimizer::lineSearch(double& stepSize)
         Tic t(timers[9], stream);
         testingE = computeEnergyVal();
     }
-    if (stepSize < LFStepSize && selfCollision) { // Optimizer.cpp:2799-2811
+    if (stepSize < LFStepSize && ipOn()) { // Optimizer.cpp:2799-2811
         bool needRecomputeCS = false;
-        while (isIntersected()) {
+        while (anyIntersection()) {
             stepSize /= 2.0;
             stepForward(d_x0.p, stepSize);
             needRecomputeCS = true;
         }
-        if (needRecomputeCS) {
-            computeConstraintSets();
-            testingE = computeEnergyVal();
-        }
+        if (needRecomputeCS) computeConstraintSets(); // lastEnergyVal keeps the pre-halving value, as in the reference
     }
     lastEnergyVal = testingE;
 }
@@ -489,8 +553,8 @@ void HipOptimizer::beginTimestep()
             stepSize /= 2.0;
             stepForward(d_x0.p, stepSize);
         }
-        if (selfCollision)
-            while (isIntersected()) {
+        if (ipOn())
+            while (anyIntersection()) {
                 stepSize /= 2.0;
                 stepForward(d_x0.p, stepSize);
             }
@@ -500,12 +564,14 @@ void HipOptimizer::beginTimestep()
         }
         d_searchDir.zero(stream); // initX(0), Optimizer.cpp:930-934
     }
-    if (selfCollision) {
+    if (ipOn()) {
         // fullyImplicit_IP head (Optimizer.cpp:1534-1550, 2316-2322): dHat, constraint sets, kappa, empty close-pair list
         dHat = dHatEps * dHatEps * mesh.bboxDiag2;
         computeConstraintSets();
         kappa = kappaFloor();
         initKappa();
+        closeHS.clear();
+        closeHSVal.clear();
         closeID.clear();
         closeVal.clear();
     }
@@ -535,6 +601,8 @@ bool HipOptimizer::newtonIter()
     {
         Tic t(timers[13], stream);
         alpha = filterStepSize(d_searchDir.p, alpha); // Optimizer.cpp:1887
+        for (auto& h : planes) // slackness_a = 0.9 (:1886-1890)
+            alpha = h->stepBound(contact->nSVI, contact->d_SVI.p, mesh.d_x.p, mesh.d_dbc.p, d_searchDir.p, 0.9, alpha);
         if (selfCollision) {
             // step-size pipeline of Optimizer.cpp:1884-2040: partial CCD over the candidates of the current
             // constraint set, CFL bound, full CCD only when the step leaves the CFL ball

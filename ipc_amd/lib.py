@@ -397,6 +397,42 @@ class Context:
     def enable_self_collision(self, dHatEps=1e-3):
         self._chk(self._L.ipcgpu_opt_enable_self_collision(self.h, C.c_double(dHatEps)))
 
+    def add_half_space(self, origin, normal, dHatEps=1e-3):
+        o, n = _f64(np.asarray(origin)), _f64(np.asarray(normal))
+        idx = C.c_int()
+        self._chk(self._L.ipcgpu_opt_add_half_space(self.h, _dp(o), _dp(n), C.c_double(dHatEps), C.byref(idx)))
+        return idx.value
+
+    def halfspace_build(self, idx, dHat):
+        verts = np.zeros(self.nV, dtype=np.int32)
+        n = C.c_int()
+        self._chk(self._L.ipcgpu_halfspace_build(self.h, C.c_int(idx), C.c_double(dHat), C.c_int(self.nV), _ip(verts), C.byref(n)))
+        return verts[:n.value].copy()
+
+    def halfspace_set(self, idx, verts):
+        verts = _i32(verts)
+        self._chk(self._L.ipcgpu_halfspace_set(self.h, C.c_int(idx), C.c_int(len(verts)), _ip(verts)))
+
+    def halfspace_energy(self, idx, dHat, kappa):
+        E = C.c_double()
+        self._chk(self._L.ipcgpu_halfspace_energy(self.h, C.c_int(idx), C.c_double(dHat), C.c_double(kappa), C.byref(E)))
+        return E.value
+
+    def halfspace_gradient_add(self, idx, dHat, kappa, grad=None):
+        g = np.zeros(3 * self.nV) if grad is None else _f64(grad).copy()
+        self._chk(self._L.ipcgpu_halfspace_gradient_add(self.h, C.c_int(idx), C.c_double(dHat), C.c_double(kappa), _dp(g)))
+        return g
+
+    def halfspace_hessian_add(self, idx, dHat, kappa, projectDBC=True):
+        self._chk(self._L.ipcgpu_halfspace_hessian_add(self.h, C.c_int(idx), C.c_double(dHat), C.c_double(kappa),
+                                                       C.c_int(int(projectDBC))))
+
+    def halfspace_step_bound(self, idx, p, slackness=0.9, step=1.0):
+        p = _f64(np.asarray(p).reshape(-1))
+        s = C.c_double(step)
+        self._chk(self._L.ipcgpu_halfspace_step_bound(self.h, C.c_int(idx), _dp(p), C.c_double(slackness), C.byref(s)))
+        return s.value
+
     def set_velocity(self, vel):
         vel = _f64(np.asarray(vel).reshape(-1))
         assert vel.size == 3 * self.nV
@@ -406,7 +442,7 @@ class Context:
         cnt = np.zeros(6, dtype=np.int32)
         pr = np.zeros(2, dtype=np.int32)
         self._chk(self._L.ipcgpu_opt_get_contact_state(self.h, _ip(cnt), _ip(pr)))
-        return dict(nActive=int(cnt[0]), nPara=int(cnt[1]), nCand=int(cnt[2]), nFullCCD=int(cnt[4]),
+        return dict(nActive=int(cnt[0]), nPara=int(cnt[1]), nCand=int(cnt[2]), nHalfSpace=int(cnt[3]), nFullCCD=int(cnt[4]),
                     nPatternChanges=int(cnt[5]), ccdPair=(int(pr[0]), int(pr[1])))
 
     def timers(self):

@@ -429,6 +429,60 @@ def opt_set_velocity(opt: "Optimizer", vel):
     lib().orc_opt_set_velocity(opt.h, _dp(v))
 
 
+class HalfSpace:
+    """Analytic half-space obstacle (HalfSpace.cpp) with its vertex constraint set."""
+
+    def __init__(self, origin, normal):
+        L = lib()
+        L.orc_halfspace_create.restype = C.c_void_p
+        L.orc_halfspace_energy.restype = C.c_double
+        L.orc_halfspace_step_bound.restype = C.c_double
+        o = np.ascontiguousarray(origin, dtype=np.float64)
+        n = np.ascontiguousarray(normal, dtype=np.float64)
+        self.h = C.c_void_p(L.orc_halfspace_create(_dp(o), _dp(n)))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_halfspace_destroy(self.h)
+            self.h = None
+
+    def build(self, mesh, dHat):
+        n = lib().orc_halfspace_build(self.h, mesh.h, C.c_double(dHat))
+        v = np.zeros(n, dtype=np.int32)
+        lib().orc_halfspace_get(self.h, _ip(v))
+        return v
+
+    def energy(self, mesh, dHat, kappa):
+        return lib().orc_halfspace_energy(self.h, mesh.h, C.c_double(dHat), C.c_double(kappa))
+
+    def gradient(self, mesh, dHat, kappa):
+        g = np.zeros(3 * mesh.nV)
+        lib().orc_halfspace_gradient(self.h, mesh.h, C.c_double(dHat), C.c_double(kappa), _dp(g))
+        return g
+
+    def hessian(self, mesh, nnz, dHat, kappa, projectDBC=True):
+        a = np.zeros(nnz)
+        lib().orc_halfspace_hessian(self.h, mesh.h, C.c_double(dHat), C.c_double(kappa), C.c_int(int(projectDBC)), _dp(a))
+        return a
+
+    def step_bound(self, mesh, p, slackness=0.9, step=1.0):
+        p = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
+        return lib().orc_halfspace_step_bound(self.h, mesh.h, _dp(p), C.c_double(slackness), C.c_double(step))
+
+
+def opt_add_half_space(opt: "Optimizer", origin, normal, dHatEps=1e-3):
+    o = np.ascontiguousarray(origin, dtype=np.float64)
+    n = np.ascontiguousarray(normal, dtype=np.float64)
+    return lib().orc_opt_add_half_space(opt.h, _dp(o), _dp(n), C.c_double(dHatEps))
+
+
+def opt_half_space_set(opt: "Optimizer", idx=0):
+    n = lib().orc_opt_get_half_space_set(opt.h, C.c_int(idx), None)
+    v = np.zeros(n, dtype=np.int32)
+    lib().orc_opt_get_half_space_set(opt.h, C.c_int(idx), _ip(v))
+    return v
+
+
 def opt_contact_state(opt: "Optimizer"):
     n = np.zeros(6, dtype=np.int32)
     lib().orc_opt_get_contact(opt.h, _ip(n), None, None)

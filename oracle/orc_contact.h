@@ -57,4 +57,17 @@ double ccdStepBound(const Mesh& m, const std::vector<std::array<int, 2>>& pairs,
 void sweptCandidates(const Mesh& m, const double* p, double stepSize, std::vector<std::array<int, 2>>& out);
 bool isIntersected(const Mesh& m); // any surface edge through any surface triangle (SelfCollisionHandler.cpp:3255-3300)
 
+// ---- analytic half-space obstacle (HalfSpace.cpp:41-85): points x with n.x + D > 0 are outside, constraint d = (n.x + D)^2
+struct HalfSpace {
+    double n[3], D;
+    void init(const double origin[3], const double normal[3]);
+    double dist(const Mesh& m, int v) const { return n[0] * m.Vx(v, 0) + n[1] * m.Vx(v, 1) + n[2] * m.Vx(v, 2) + D; }
+};
+void hsConstraintSet(const Mesh& m, const HalfSpace& h, double dHat, std::vector<int>& set); // CollisionObject.h:323-351
+double hsEnergy(const Mesh& m, const HalfSpace& h, const std::vector<int>& set, double dHat, double kappa); // Optimizer.cpp:3254-3267
+void hsGradient(const Mesh& m, const HalfSpace& h, const std::vector<int>& set, double dHat, double kappa, double* grad); // HalfSpace.cpp:121-143
+void hsHessian(const Mesh& m, const HalfSpace& h, const std::vector<int>& set, double dHat, double kappa, bool projectDBC, double* a); // :169-214
+double hsStepBound(const Mesh& m, const HalfSpace& h, const double* p, double slackness, double stepSize); // :242-269
+bool hsIntersected(const Mesh& m, const HalfSpace& h); // CollisionObject.h:386-401 (fires only on d == 0: d is a square)
+
 } // namespace orc

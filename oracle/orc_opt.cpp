@@ -37,6 +37,18 @@ struct orc_opt {
     std::vector<MMCVID> closeID; // closeMConstraintID / closeMConstraintVal (Optimizer.cpp:2396-2440)
     std::vector<double> closeVal;
     int lastCCDArg = -1, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
+    // analytic half-space obstacles (animConfig.collisionObjects) with their active sets (activeSet[coI])
+    std::vector<HalfSpace> planes;
+    std::vector<std::vector<int>> hsSet;
+    std::vector<std::pair<int, int>> closeHS; // closeConstraintID / Val (Optimizer.cpp:2364-2374, 2403-2415)
+    std::vector<double> closeHSVal;
+    bool ipOn() const { return selfCollision || !planes.empty(); }
+    size_t nConstraints() const
+    {
+        size_t n = selfCollision ? cs.active.size() : 0;
+        for (const auto& s : hsSet) n += s.size();
+        return n;
+    }
 };
 
 namespace {
@@ -75,6 +87,7 @@ double computeEnergyVal(orc_opt* o)
     double sum = 0;
     for (int v = 0; v < m.nV; ++v) sum += ev[v];
     E += sum;
+    for (size_t i = 0; i < o->planes.size(); ++i) E += hsEnergy(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa);
     if (o->selfCollision) E += contactEnergy(m, o->cs, o->dHat, o->kappa);
     return E;
 }
@@ -95,6 +108,7 @@ void computeGradient(orc_opt* o, bool projectDBC)
 {
     Mesh& m = *o->m;
     elasticInertiaGradient(o, projectDBC, o->gradient.data());
+    for (size_t i = 0; i < o->planes.size(); ++i) hsGradient(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa, o->gradient.data());
     if (o->selfCollision) contactGradient(m, o->cs, o->dHat, o->kappa, projectDBC, o->gradient.data());
     for (int v = 0; v < m.nV; ++v)
         if (m.isDBC(v) && m.isProjectDBC(v, projectDBC))
@@ -135,6 +149,7 @@ void computePrecondMtr(orc_opt* o, bool projectDBC)
     }
     Tic t(o->timers[0]);
     assembleHessian(m, o->dtSq, projectDBC, o->a.data());
+    for (size_t i = 0; i < o->planes.size(); ++i) hsHessian(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa, projectDBC, o->a.data());
     if (o->selfCollision) contactHessian(m, o->cs, o->dHat, o->kappa, projectDBC, o->a.data());
 }
 
@@ -147,9 +162,18 @@ void stepForward(orc_opt* o, const std::vector<double>& V0, double alpha)
 
 void computeConstraintSets(orc_opt* o)
 {
-    if (!o->selfCollision) return;
+    if (!o->ipOn()) return;
     Tic t(o->timers[14]);
-    computeConstraintSet(*o->m, o->dHat, false, o->cs);
+    for (size_t i = 0; i < o->planes.size(); ++i) hsConstraintSet(*o->m, o->planes[i], o->dHat, o->hsSet[i]); // Optimizer.cpp:2460-2462
+    if (o->selfCollision) computeConstraintSet(*o->m, o->dHat, false, o->cs);
+}
+
+bool anyIntersection(orc_opt* o)
+{
+    // isIntersected (Optimizer.cpp:2626-2659): analytic objects first, then the mesh against itself
+    for (const auto& h : o->planes)
+        if (hsIntersected(*o->m, h)) return true;
+    return o->selfCollision && isIntersected(*o->m);
 }
 
 double kappaFloor(orc_opt* o)
@@ -168,12 +192,17 @@ void initKappa(orc_opt* o)
 {
     // Optimizer.cpp:2236-2313
     Mesh& m = *o->m;
-    if (o->cs.active.empty()) return;
+    if (!o->nConstraints()) return;
     std::vector<double> gE(3 * m.nV), gc(3 * m.nV, 0.0);
     elasticInertiaGradient(o, true, gE.data());
-    ContactSets only;
-    only.active = o->cs.active;
-    contactGradient(m, only, o->dHat, 1.0, true, gc.data());
+    for (size_t i = 0; i < o->planes.size(); ++i) hsGradient(m, o->planes[i], o->hsSet[i], o->dHat, 1.0, gc.data());
+    if (o->selfCollision) {
+        ContactSets only;
+        only.active = o->cs.active;
+        contactGradient(m, only, o->dHat, 1.0, true, gc.data());
+    }
+    for (int v = 0; v < m.nV; ++v)
+        if (m.isDBC(v)) gc[3 * v] = gc[3 * v + 1] = gc[3 * v + 2] = 0.0; // :2275-2277
     double num = 0, den = 0;
     for (int i = 0; i < 3 * m.nV; ++i) {
         num += gc[i] * gE[i];
@@ -227,14 +256,18 @@ double evalMMCVID(const Mesh& m, const MMCVID& c)
 void postLineSearch(orc_opt* o)
 {
     // Optimizer.cpp:2357-2445 (ADAPTIVE_KAPPA)
-    if (!o->selfCollision) return;
+    if (!o->ipOn()) return;
     Mesh& m = *o->m;
     if (o->kappa == 0.0) {
         initKappa(o);
         return;
     }
     bool updateKappa = false;
-    for (size_t i = 0; i < o->closeID.size(); ++i)
+    for (size_t i = 0; i < o->closeHS.size() && !updateKappa; ++i) {
+        const double dist = o->planes[o->closeHS[i].first].dist(m, o->closeHS[i].second);
+        if (dist * dist <= o->closeHSVal[i]) updateKappa = true;
+    }
+    for (size_t i = 0; i < o->closeID.size() && !updateKappa; ++i)
         if (evalMMCVID(m, o->closeID[i]) <= o->closeVal[i]) {
             updateKappa = true;
             break;
@@ -246,13 +279,24 @@ void postLineSearch(orc_opt* o)
     }
     o->closeID.clear();
     o->closeVal.clear();
-    for (const auto& c : o->cs.active) {
-        const double d = evalMMCVID(m, c);
-        if (d < o->dTol) {
-            o->closeID.push_back(c);
-            o->closeVal.push_back(d);
+    o->closeHS.clear();
+    o->closeHSVal.clear();
+    for (size_t i = 0; i < o->planes.size(); ++i)
+        for (int v : o->hsSet[i]) {
+            const double dist = o->planes[i].dist(m, v);
+            if (dist * dist < o->dTol) {
+                o->closeHS.push_back({ (int)i, v });
+                o->closeHSVal.push_back(dist * dist);
+            }
         }
-    }
+    if (o->selfCollision)
+        for (const auto& c : o->cs.active) {
+            const double d = evalMMCVID(m, c);
+            if (d < o->dTol) {
+                o->closeID.push_back(c);
+                o->closeVal.push_back(d);
+            }
+        }
 }
 
 // Optimizer.cpp:2662-2916 with armijoParam = 0, lowerBound = 0 (the IP call site, :2059)
@@ -271,8 +315,8 @@ void lineSearch(orc_opt* o, double& stepSize)
             stepSize /= 2.0;
             stepForward(o, V0, stepSize);
         }
-        if (o->selfCollision)
-            while (isIntersected(m)) { // :2719-2736
+        if (o->ipOn())
+            while (anyIntersection(o)) { // :2719-2736
                 stepSize /= 2.0;
                 stepForward(o, V0, stepSize);
             }
@@ -295,17 +339,14 @@ void lineSearch(orc_opt* o, double& stepSize)
         Tic t(o->timers[9]);
         testingE = computeEnergyVal(o);
     }
-    if (stepSize < LFStepSize && o->selfCollision) { // :2799-2811
+    if (stepSize < LFStepSize && o->ipOn()) { // :2799-2811
         bool needRecomputeCS = false;
-        while (isIntersected(m)) {
+        while (anyIntersection(o)) {
             stepSize /= 2.0;
             stepForward(o, V0, stepSize);
             needRecomputeCS = true;
         }
-        if (needRecomputeCS) {
-            computeConstraintSets(o);
-            testingE = computeEnergyVal(o);
-        }
+        if (needRecomputeCS) computeConstraintSets(o); // lastEnergyVal keeps the pre-halving value, as in the reference
     }
     o->lastEnergyVal = testingE;
 }
@@ -355,6 +396,24 @@ void orc_opt_enable_self_collision(orc_opt* o, double dHatEps)
     o->dHatEps = dHatEps;
     o->dHat = dHatEps * dHatEps * o->m->bboxDiag2;
     o->dTol = 1.0e-18 * o->m->bboxDiag2; // dTolRel = 1e-9 (Optimizer.cpp:102-109)
+}
+int orc_opt_add_half_space(orc_opt* o, const double* origin3, const double* normal3, double dHatEps)
+{
+    // `ground` / `halfSpace` script keywords (Config.cpp:306-345) -> animConfig.collisionObjects; friction is a 8f row
+    HalfSpace h;
+    h.init(origin3, normal3);
+    o->planes.push_back(h);
+    o->hsSet.emplace_back();
+    o->dHatEps = dHatEps;
+    o->dHat = dHatEps * dHatEps * o->m->bboxDiag2;
+    o->dTol = 1.0e-18 * o->m->bboxDiag2;
+    return (int)o->planes.size() - 1;
+}
+int orc_opt_get_half_space_set(const orc_opt* o, int id, int* verts)
+{
+    if (verts)
+        for (size_t i = 0; i < o->hsSet[id].size(); ++i) verts[i] = o->hsSet[id][i];
+    return (int)o->hsSet[id].size();
 }
 void orc_opt_set_twist(orc_opt* o, int nL, const int* left, int nR, const int* right, double angVel)
 {
@@ -406,8 +465,8 @@ void orc_opt_begin_timestep(orc_opt* o)
             stepSize /= 2.0;
             stepForward(o, V0, stepSize);
         }
-        if (o->selfCollision)
-            while (isIntersected(m)) {
+        if (o->ipOn())
+            while (anyIntersection(o)) {
                 stepSize /= 2.0;
                 stepForward(o, V0, stepSize);
             }
@@ -418,13 +477,15 @@ void orc_opt_begin_timestep(orc_opt* o)
     }
     // fullyImplicit_IP head (1518-1613): initX(0) -> searchDir = 0; dHat; constraint sets; kappa; initial energy
     std::fill(o->searchDir.begin(), o->searchDir.end(), 0.0);
-    if (o->selfCollision) {
+    if (o->ipOn()) {
         o->dHat = o->dHatEps * o->dHatEps * m.bboxDiag2;
         computeConstraintSets(o);
         o->kappa = kappaFloor(o); // kappa = 0 -> suggestKappa (:1540-1547)
         initKappa(o); // ADAPTIVE_KAPPA (:1548-1550)
         o->closeID.clear(); // initSubProb_IP (:2316-2322)
         o->closeVal.clear();
+        o->closeHS.clear();
+        o->closeHSVal.clear();
     }
     if (o->patternDirty) computePrecondMtr(o, true);
     o->lastEnergyVal = computeEnergyVal(o);
@@ -465,6 +526,7 @@ int orc_opt_newton_iter(orc_opt* o)
     {
         Tic t(o->timers[13]);
         alpha = filterStepSize(m, o->searchDir.data(), alpha);
+        for (const auto& h : o->planes) alpha = hsStepBound(m, h, o->searchDir.data(), 0.9, alpha); // slackness_a (:1886-1890)
         if (o->selfCollision) {
             const double slackness_m = 0.8;
             alpha = ccdStepBound(m, o->cs.csPTEE, o->searchDir.data(), slackness_m, alpha, &o->lastCCDArg); // partial CCD (:1923-1928)

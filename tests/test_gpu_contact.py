@@ -250,3 +250,112 @@ def test_barrier_energy_gradient_hessian(orc, pair):
     b = np.random.default_rng(2).normal(size=len(ia) - 1)
     x = c.solve(b)
     assert np.linalg.norm(c.multiply(x) - b) <= 1e-9 * np.linalg.norm(b)
+
+
+# ---- analytic half-space -------------------------------------------------------------------------
+def tilted_block(n=2, lift=0.004):
+    V, F = scene.make_box(n, n, n, size=(0.5, 0.5, 0.5), origin=(0, 0, 0))
+    nrm = np.array([0.1, 1.0, -0.05])
+    nrm /= np.linalg.norm(nrm)
+    Vs = scene.jitter(V, F, rel=1e-2)
+    origin = nrm * ((Vs @ nrm).min() - lift)
+    return V, Vs, F, origin, nrm
+
+
+def test_half_space_pieces(orc, gpu_lib):
+    V, Vs, F, origin, nrm = tilted_block(n=3)
+    SF = scene.surface_tris(F)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_V(Vs)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.01, True)
+    c.set_surface(SF)
+    idx = c.add_half_space(origin, 2.5 * nrm, 1e-2)
+    hs = orc.HalfSpace(origin, 2.5 * nrm)
+    dist = Vs @ nrm - origin @ nrm
+    dHat = (np.sort(dist)[9] * 1.0001) ** 2
+    vo, vg = hs.build(m, dHat), c.halfspace_build(idx, dHat)
+    assert len(vo) >= 9 and np.array_equal(vg, vo)  # integer output: bit-exact, same order
+    some = vo[:3]
+    m.set_dbc(some, 1)
+    c.set_dbc(some, 1)
+    assert np.array_equal(c.halfspace_build(idx, dHat), hs.build(m, dHat))
+    m.clear_dbc()
+    c.clear_dbc()
+    hs.build(m, dHat)
+    c.halfspace_build(idx, dHat)
+    kappa = 4.2e3
+    Eo = hs.energy(m, dHat, kappa)
+    assert abs(c.halfspace_energy(idx, dHat, kappa) - Eo) <= 1e-12 * abs(Eo)
+    assert relerr(c.halfspace_gradient_add(idx, dHat, kappa), hs.gradient(m, dHat, kappa)) < 1e-12
+    c.set_pattern()
+    ia, ja = m.pattern()
+    c.set_zero()
+    c.halfspace_hessian_add(idx, dHat, kappa, True)
+    a_o = hs.hessian(m, len(ja), dHat, kappa, True)
+    assert relerr(c.get_a(), a_o) < 1e-12 and np.count_nonzero(a_o) > 0
+    rng = np.random.default_rng(4)
+    for trial in range(3):
+        p = 0.05 * rng.normal(size=V.shape)
+        p[:, 1] -= 0.02 * trial
+        so, sg = hs.step_bound(m, p.reshape(-1), 0.9, 1.0), c.halfspace_step_bound(idx, p.reshape(-1), 0.9, 1.0)
+        assert abs(sg - so) <= 1e-14 * abs(so)
+    # a set handed in through the ABI
+    c.halfspace_set(idx, vo[::2])
+    hs2 = orc.HalfSpace(origin, nrm)
+    big = hs2.build(m, 1e9)
+    assert len(big) == len(np.unique(SF))
+    c.close()
+
+
+def test_half_space_newton_iterates_track_the_oracle(orc, gpu_lib):
+    """A block dropped on a tilted plane: half-space constraint set, barrier terms, kappa adaptation and the ray step bound
+    inside the stepper, iterate by iterate."""
+    V, Vs, F, origin, nrm = tilted_block(n=2, lift=0.03)
+    SF = scene.surface_tris(F)
+    vel = np.zeros_like(V)
+    vel[:, 1] = -2.0
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=2)
+    orc.opt_add_half_space(o, origin, nrm, 1e-2)
+    orc.opt_set_velocity(o, vel)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.01, True)
+    c.set_surface(SF)
+    c.add_half_space(origin, nrm, 1e-2)
+    c.set_velocity(vel)
+    o.precompute()
+    c.precompute()
+    touched, limited = 0, 0
+    for step in range(8):
+        o.begin_timestep()
+        c.begin_timestep()
+        assert abs(c.state()["kappa"] - o.state()["kappa"]) <= 1e-9 * o.state()["kappa"]
+        for it in range(60):
+            co, cg = o.newton_iter(), c.newton_iter()
+            assert co == cg, (step, it)
+            if co:
+                break
+            so, sg = o.state(), c.state()
+            assert c.contact_state()["nHalfSpace"] == len(orc.opt_half_space_set(o)), (step, it)
+            assert abs(sg["alphaFeasible"] - so["alphaFeasible"]) <= 1e-9 * so["alphaFeasible"], (step, it)
+            assert abs(sg["stepSize"] - so["stepSize"]) <= 1e-9 * so["stepSize"], (step, it)
+            assert abs(sg["kappa"] - so["kappa"]) <= 1e-9 * so["kappa"], (step, it)
+            assert abs(sg["E"] - so["E"]) <= 1e-9 * abs(so["E"]), (step, it)
+            assert relerr(sg["V"], so["V"]) < 1e-9, (step, it)
+            limited += so["alphaFeasible"] < 1.0
+        else:
+            pytest.fail("Newton did not converge")
+        o.end_timestep()
+        c.end_timestep()
+        touched = max(touched, c.contact_state()["nHalfSpace"])
+        assert ((c.state()["V"] - origin) @ nrm).min() > 0
+    assert touched > 0 and limited > 0
+    c.close()

@@ -308,3 +308,101 @@ def test_contact_newton_drop_converges_without_intersection(orc):
     # the slabs did not pass through each other (the overhang may droop, so compare the overlapping footprint's centre)
     Vn = o.state()["V"]
     assert Vn[nA:, 1].mean() > Vn[:nA, 1].mean() + 0.2
+
+
+# ---- analytic half-space -------------------------------------------------------------------------
+def tilted_block(n=2, lift=0.004):
+    V, F = scene.make_box(n, n, n, size=(0.5, 0.5, 0.5), origin=(0, 0, 0))
+    V = scene.jitter(V, F, rel=1e-2)
+    nrm = np.array([0.1, 1.0, -0.05])
+    nrm /= np.linalg.norm(nrm)
+    origin = nrm * ((V @ nrm).min() - lift)  # tilted plane, its closest vertex `lift` above it
+    return V, F, origin, nrm
+
+
+def test_half_space_constraint_set_energy_gradient_hessian(orc):
+    V, F, origin, nrm = tilted_block()
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(scene.surface_tris(F))
+    dist = V @ nrm - origin @ nrm
+    dHat = (np.sort(dist)[6] * 1.0001) ** 2
+    hs = orc.HalfSpace(origin, 3.0 * nrm)  # the normal is normalised on entry (HalfSpace.cpp:49)
+    verts = hs.build(m, dHat)
+    assert np.array_equal(verts, np.nonzero(dist ** 2 < dHat)[0]) and 0 < len(verts) < V.shape[0]
+    # DBC vertices never enter the set (CollisionObject.h:333)
+    m.set_dbc(verts[:2], 1)
+    assert np.array_equal(hs.build(m, dHat), verts[2:])
+    m.clear_dbc()
+    hs.build(m, dHat)
+    kappa = 3e3
+    b = -(dist[verts] ** 2 - dHat) ** 2 * np.log(dist[verts] ** 2 / dHat)
+    assert abs(hs.energy(m, dHat, kappa) - kappa * b.sum()) <= 1e-13 * kappa * b.sum()
+    g = hs.gradient(m, dHat, kappa)
+
+    def E_at(Vx):
+        m.set_V(Vx)
+        e = hs.energy(m, dHat, kappa)
+        m.set_V(V)
+        return e
+
+    h = 1e-7
+    for v in verts[:3]:
+        for c in range(3):
+            Vp, Vm = V.copy(), V.copy()
+            Vp[v, c] += h
+            Vm[v, c] -= h
+            fd = (E_at(Vp) - E_at(Vm)) / (2 * h)
+            assert abs(fd - g[3 * v + c]) <= 1e-5 * max(abs(g).max(), 1e-30)
+    ia, ja = m.pattern()
+    a = hs.hessian(m, len(ja), dHat, kappa)
+    for v in verts:
+        d = dist[v] ** 2
+        lg, t2 = np.log(d / dHat), d - dHat
+        gb = t2 * lg * -2.0 - t2 * t2 / d
+        Hb = (lg * -2.0 - t2 * 4.0 / d) + t2 * t2 / (d * d)
+        param = 4 * Hb * d + 2 * gb
+        blk = np.zeros((3, 3))
+        for r in range(3):
+            for c in range(r, 3):
+                row = 3 * v + r
+                k = ia[row] + np.searchsorted(ja[ia[row]:ia[row + 1]], 3 * v + c)
+                blk[r, c] = a[k]
+        want = np.triu(kappa * max(param, 0.0) * np.outer(nrm, nrm))
+        assert np.allclose(blk, want, rtol=1e-12, atol=1e-12 * abs(want).max())
+    assert np.count_nonzero(a) <= 6 * len(verts)
+    # ray step bound: the closest approaching vertex keeps (1 - slackness) of its distance
+    p = np.zeros_like(V)
+    p[:, 1] = -1.0
+    s = hs.step_bound(m, p.reshape(-1), 0.9, 1.0)
+    want = (0.9 * dist / (-(p @ nrm))).min()
+    assert abs(s - want) <= 1e-14 * abs(want) and 0 < s < 1.0
+    assert hs.step_bound(m, -p.reshape(-1), 0.9, 0.7) == 0.7  # moving away: untouched
+
+
+def test_block_dropped_on_a_half_space_comes_to_rest_above_it(orc):
+    V, F, origin, nrm = tilted_block(lift=0.05)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(scene.surface_tris(F))
+    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=2)
+    orc.opt_add_half_space(o, origin, nrm, 1e-2)
+    vel = np.zeros_like(V)
+    vel[:, 1] = -2.0
+    orc.opt_set_velocity(o, vel)
+    o.precompute()
+    touched = 0
+    for step in range(8):
+        o.begin_timestep()
+        E_prev = o.state()["E"]
+        for it in range(60):
+            if o.newton_iter():
+                break
+            s = o.state()
+            assert s["E"] <= E_prev * (1 + 1e-12) + 1e-14 and s["stepSize"] > 0
+            E_prev = s["E"]
+        else:
+            pytest.fail("Newton did not converge")
+        o.end_timestep()
+        Vn = o.state()["V"]
+        assert ((Vn - origin) @ nrm).min() > 0  # never through the plane
+        touched = max(touched, len(orc.opt_half_space_set(o)))
+    assert touched > 0 and o.state()["kappa"] > 0
