@@ -26,22 +26,23 @@ private:
     };
     struct LevelPlan {
         Range small; // into smallList_
-        size_t smallLds = 0, solveLds = 0;
+        size_t smallLds = 0, solveLds = 0, triLds = 0;
         Range ea; // extend-add descriptors
         Range bigFronts; // into bigList_
-        std::vector<Range> trsm, syrk; // per 32-column step: descriptor ranges
-        std::vector<Range> fwd, bwd; // per step: solve descriptors
-        Range fwdGather, bwdInit; // descriptors for the big-front solve prologues
+        std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1
+        Range fwdRect, bwdInit; // descriptors of the row-/column-parallel halves of the big-front solves
     };
     const MfSymbolic* sym_ = nullptr;
     hipStream_t stream_ = nullptr;
     int ns_ = 0, nLevels_ = 0;
+    long long nDiagBlocks_ = 0;
     std::vector<LevelPlan> plan_;
     DevBuf<double> fronts_, w_, yperm_, xsol_;
+    DevBuf<double> dinv_; // explicit inverses of the 32x32 diagonal blocks of L, 1024 doubles each
     DevBuf<int> idx_, idxPtr_, firstNode_, childPtr_, child_, invPtr_, inv_, newOf_, flag_;
-    DevBuf<long long> frontOff_, wOff_, aDst_;
+    DevBuf<long long> frontOff_, wOff_, aDst_, dinvOff_;
     DevBuf<int2> eaDesc_;
-    DevBuf<int> smallList_;
+    DevBuf<int> smallList_, bigList_;
     DevBuf<int4> desc_; // all big-front step descriptors
     PinnedBuf<int> hflag_;
 };

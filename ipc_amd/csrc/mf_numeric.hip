@@ -3,20 +3,24 @@
 // Data layout in HBM: every front is a full N x N column-major square (ld = N) inside one buffer; the leading
 // nc columns become the factor panel [L11; L21], the trailing (N-nc)^2 block is the update matrix that the
 // parent gathers.  All fronts stay resident (sized for 288 GB of HBM3E: ~0.5 GB for a 45 K-node sheet), so
-// there is no stack management and a child update is read in place.
+// there is no stack management and a child update is read in place.  Next to the fronts lives `dinv`: the explicit
+// inverse of every 32 x 32 diagonal block of L (column-major, 8 KB each).  The triangular solves and the panel TRSMs
+// multiply by these inverses instead of substituting, which turns 32-long dependent chains (one global load, one
+// division per link) into independent FMAs.
 //
 // Scheduling: the assembly tree is processed level by level; inside a level fronts are independent.
 //   extend-add   gather formulation (each parent entry sums its children through inverse index maps):
 //                race-free and bit-reproducible, no atomics
-//   small fronts one 256-thread workgroup per front: 32-column panels staged in LDS, wave-level shuffle
-//                Cholesky of the 32x32 pivot block, per-row TRSM, 4x4 register tiles for the Schur update
-//   big fronts   level-batched 32-column steps, two launches per step for ALL big fronts of the level:
-//                  k_big_trsm  every workgroup re-factors the 32x32 pivot block in registers (cheaper than a
-//                              launch boundary) and solves its 256 rows of the panel
-//                  k_big_syrk  64x64 tiles of the trailing matrix, panels staged in LDS, 4x4 register tiles;
-//                              the first tile of a front also publishes the factored pivot block
-//   solve        per-level forward / backward substitution: one workgroup per small front (vectors in LDS);
-//                big fronts again in level-batched 32-column steps with all workgroups sharing the row updates
+//   small fronts one 256-thread workgroup per front: 32-column panels staged in LDS, wave-level Cholesky of the
+//                32 x 32 pivot block (cross-lane traffic through v_readlane, the pivot index is a compile-time
+//                constant), inverse of the pivot block, TRSM as a product with it, 4x4 register tiles for the update
+//   big fronts   level-batched 32-column steps, ONE launch per step with look-ahead: while 64x64 tiles apply panel j
+//                to the trailing matrix (role A), other workgroups (role B) apply panel j to their rows of panel
+//                j+1, factor its pivot block (redundantly per workgroup, cheaper than a launch boundary) and solve
+//                their rows.  The factored pivot block itself is never written: only its inverse is needed later.
+//   solve        small fronts: one workgroup per front, vectors in LDS.  Big fronts: the nc x nc triangle is swept
+//                by one 512-thread workgroup per front (its only sequential part), the (N-nc) x nc rectangle is a
+//                row-parallel matrix-vector product in a second launch.
 // No vendor BLAS is involved: rocSOLVER's potrf / rocBLAS' trsm+syrk cost ~150 tiny launches per front.
 #include "mf_numeric.h"
 #include <algorithm>
@@ -27,7 +31,10 @@ namespace ipcgpu {
 namespace {
 
 constexpr int NB = 32;
+constexpr int LDP = NB + 1; // padded leading dimension of 32x32 blocks in LDS
 constexpr int WG = 256;
+constexpr int WGB = WG + 64; // big-front step: four row waves + one pivot wave
+constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
 constexpr int TS = 64; // trailing-update tile
 
@@ -40,6 +47,7 @@ struct TreeView {
     const int* invPtr;
     const int* inv;
     const int* idx;
+    const long long* dinvOff; // per front: first 32x32 inverse block (in blocks)
 };
 
 __device__ __forceinline__ int frontN(const TreeView& tv, int s) { return 3 * (tv.idxPtr[s + 1] - tv.idxPtr[s]); }
@@ -81,77 +89,171 @@ __global__ __launch_bounds__(WG) void k_extend_add(const int2* __restrict__ desc
     }
 }
 
-// Cholesky of a (<=) 32x32 pivot block by one wave: lane r owns row r in registers, cross-lane reads by shuffle.
-// blk is k-major in LDS: blk[k * ld + r] = A(r, k).  Columns / rows >= w are ignored.  Returns true on a bad pivot.
-__device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lane)
+// value of `v` in lane `lane` (uniform, here always a compile-time constant after unrolling): two v_readlane_b32
+__device__ __forceinline__ double bcast_lane(double v, int lane)
+{
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// reciprocal square root to full double precision: v_rsq_f64 seed + two Newton steps (the IEEE sqrt / divide expansions are
+// ~10x longer dependent chains, and this sits on the critical path of every pivot)
+__device__ __forceinline__ double rsqrt_nr(double d)
+{
+    double r = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    e = fma(-d * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    return r;
+}
+
+// Cholesky of a (<=) 32x32 pivot block by one wave: lane r owns row r in registers, cross-lane traffic through v_readlane.
+// blk is k-major in LDS: blk[k * ld + r] = A(r, k).  Columns / rows >= w are ignored.  rdiag[k] receives 1 / L(k, k)
+// (0 for k >= w).  Returns true on a bad pivot.
+__device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lane, double* rdiag)
 {
     bool bad = false;
     double row[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) row[k] = (lane < w && k <= lane && k < w) ? blk[k * ld + lane] : 0.0;
+    for (int k = 0; k < NB; ++k) row[k] = (lane < w && k <= lane && k < w) ? blk[k * ld + (lane & (NB - 1))] : 0.0;
+    double myRd = 0.0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        if (j < w) {
-            double djj = __shfl(row[j], j, 64);
+        if (j < w) { // uniform
+            double djj = bcast_lane(row[j], j);
             if (!(djj > 0.0)) {
                 bad = true;
                 djj = 1.0;
             }
-            const double dd = sqrt(djj);
-            const double invd = 1.0 / dd;
-            if (lane == j) row[j] = dd;
-            else if (lane > j) row[j] *= invd;
+            const double invd = rsqrt_nr(djj);
+            if (lane == j) myRd = invd;
+            row[j] *= invd; // lane j: d / sqrt(d); lanes above j hold the unused upper triangle
 #pragma unroll
             for (int jj = j + 1; jj < NB; ++jj) {
-                const double ljj = __shfl(row[j], jj, 64);
-                if (lane >= jj) row[jj] -= row[j] * ljj;
+                const double ljj = bcast_lane(row[j], jj);
+                row[jj] -= row[j] * ljj;
             }
         }
     }
 #pragma unroll
     for (int k = 0; k < NB; ++k)
         if (lane < w && k <= lane && k < w) blk[k * ld + lane] = row[k];
+    if (lane < NB) rdiag[lane] = myRd;
     return bad;
+}
+
+// Inverse of a lower-triangular 32x32 block held k-major in LDS (blk[k * ld + r] = L(r, k)).  Lane c (< 32) produces column c
+// of X = L^-1 by forward substitution, keeping it in LDS (row-major: out[r * LDI + c] = X(r, c), so a lane's own column is
+// bank-conflict free); L(r, k) is the same address for every lane (LDS broadcast).
+constexpr int LDI = NB + 2;
+__device__ __forceinline__ void wave_trinv32(const double* blk, int ld, int lane, double* out)
+{
+    if (lane >= NB) return;
+    double* col = out + lane;
+    for (int r = 0; r < NB; ++r) {
+        double acc0 = (r == lane) ? 1.0 : 0.0, acc1 = 0.0;
+        int k = 0;
+        for (; k + 1 < r; k += 2) {
+            acc0 -= blk[k * ld + r] * col[k * LDI];
+            acc1 -= blk[(k + 1) * ld + r] * col[(k + 1) * LDI];
+        }
+        if (k < r) acc0 -= blk[k * ld + r] * col[k * LDI];
+        col[r * LDI] = (acc0 + acc1) / blk[r * ld + r];
+    }
+}
+
+// x <- x L^-T for one row held in registers (right-looking substitution: after x[k] is final it is swept out of the columns
+// behind it, so the FMAs of one k are independent).  L(c, k) = blk[k * ld + c], 1 / L(k, k) = rdiag[k]; both LDS broadcasts.
+// RW rows per thread share every LDS read: the broadcasts (one 64-lane return per FMA otherwise) are what bounds this step.
+template <int RW>
+__device__ __forceinline__ void row_trsm32(double (&x)[RW][NB], const double* blk, int ld, const double* rdiag)
+{
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const double rd = rdiag[k];
+#pragma unroll
+        for (int h = 0; h < RW; ++h) x[h][k] *= rd;
+        // The addresses of column k are made to depend on the finished x[k]: with compile-time LDS addresses the scheduler
+        // otherwise issues all 496 reads up front and spills ~1000 registers.
+        // (x[RW-1][NB-1] is the last value the previous column touches, so the reads also wait for that column's sweep.)
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[0][k])), "v"(__double2loint(x[RW - 1][NB - 1])));
+        const double* lk = blk + k * ld + z;
+#pragma unroll
+        for (int c = k + 1; c < NB; ++c) {
+            const double l = lk[c];
+#pragma unroll
+            for (int h = 0; h < RW; ++h) x[h][c] -= x[h][k] * l;
+        }
+    }
+}
+
+// the factored pivot block goes to its `dinv` slot (k-major, identity-padded); k_invert_blocks turns it into L11^-1 at the end
+__device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int w, double* slot, int tid, int nthreads)
+{
+    for (int e = tid; e < NB * NB; e += nthreads) {
+        const int k = e >> 5, r = e & 31;
+        slot[e] = (k < w && r < w) ? (r >= k ? blk[k * ld + r] : 0.0) : (r == k ? 1.0 : 0.0);
+    }
+}
+
+// One wave per 32x32 block: L11 (k-major) -> L11^-1 (column-major), in place.
+__global__ __launch_bounds__(64) void k_invert_blocks(double* __restrict__ dinv)
+{
+    __shared__ double Ls[NB * LDP];
+    __shared__ double Xs[NB * LDI];
+    double* blk = dinv + (long long)blockIdx.x * (NB * NB);
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += 64) Ls[(e >> 5) * LDP + (e & 31)] = blk[e];
+    __syncthreads();
+    wave_trinv32(Ls, LDP, tid, Xs);
+    __syncthreads();
+    for (int e = tid; e < NB * NB; e += 64) blk[e] = Xs[(e & 31) * LDI + (e >> 5)]; // blk[c * 32 + r] = X(r, c)
 }
 
 // One workgroup factors the leading nc columns of one small front and forms its Schur complement in place.
 __global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ list, TreeView tv, double* __restrict__ fronts,
-    int* __restrict__ flag)
+    double* __restrict__ dinv, int* __restrict__ flag)
 {
     extern __shared__ double P[]; // NB panel columns, k-major: P[k * m + r]
+    __shared__ double rdiag[NB];
     const int s = list[blockIdx.x];
     const int N = frontN(tv, s);
     const int nc = frontNc(tv, s);
     double* F = fronts + tv.frontOff[s];
+    double* dblk = dinv + tv.dinvOff[s] * (NB * NB);
     const int tid = threadIdx.x;
     bool bad = false;
 
-    for (int kb = 0; kb < nc; kb += NB) {
+    for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
         const int w = min(NB, nc - kb);
         const int m = N - kb;
-        for (int e = tid; e < w * m; e += WG) {
+        for (int e = tid; e < NB * m; e += WG) {
             const int k = e / m, r = e - k * m;
-            P[e] = (r >= k) ? F[(kb + r) + (long long)N * (kb + k)] : 0.0;
+            P[e] = (k < w && r >= k) ? F[(kb + r) + (long long)N * (kb + k)] : 0.0;
         }
         __syncthreads();
-        if (tid < 64) bad |= wave_potrf32(P, m, w, tid);
+        if (tid < 64) bad |= wave_potrf32(P, m, w, tid, rdiag);
         __syncthreads();
+        store_pivot_block(P, m, w, dblk, tid, WG);
         // rows below the pivot block: X L11^T = A21, one row per thread
-        for (int r = w + tid; r < m; r += WG) {
-            double x[NB];
+        for (int r = w + tid; tid < WG / 2 && r < m; r += WG) { // two rows per thread on half of the waves
+            const int r1 = r + WG / 2;
+            const bool two = r1 < m;
+            double x[2][NB];
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
-                if (k < w) {
-                    double acc = P[k * m + r];
-#pragma unroll
-                    for (int q = 0; q < k; ++q) acc -= x[q] * P[q * m + k];
-                    x[k] = acc / P[k * m + k];
-                }
-                else x[k] = 0.0;
+                x[0][k] = P[k * m + r];
+                x[1][k] = two ? P[k * m + r1] : 0.0;
             }
+            row_trsm32<2>(x, P, m, rdiag);
 #pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (k < w) P[k * m + r] = x[k];
+            for (int k = 0; k < NB; ++k) {
+                P[k * m + r] = x[0][k];
+                if (two) P[k * m + r1] = x[1][k];
+            }
         }
         __syncthreads();
         for (int e = tid; e < w * m; e += WG) {
@@ -176,8 +278,8 @@ __global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ lis
                     double av[4], bv[4];
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
-                        av[ii] = pk[i0 + ii];
-                        bv[ii] = pk[j0 + ii];
+                        av[ii] = (i0 + ii < m) ? pk[i0 + ii] : 0.0;
+                        bv[ii] = (j0 + ii < m) ? pk[j0 + ii] : 0.0;
                     }
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii)
@@ -201,113 +303,118 @@ __global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ lis
     if (bad) atomicOr(flag, 1);
 }
 
-// ---- big fronts: level-batched 32-column steps ---------------------------------------------------------
-// desc = (front, kb, first row offset behind the pivot block, unused)
-__global__ __launch_bounds__(WG) void k_big_trsm(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
-    int* __restrict__ flag)
+// ---- big fronts: level-batched 32-column steps, one launch per step ------------------------------------
+// desc = (front, kb of the panel being applied or -1, a, b); 320 threads: four row waves + one pivot wave
+//   b >= 0 : role A, trailing tile (ti, tj) = (a, b) of the matrix behind panel kb and panel kb+32
+//   b == -2: role B, rows [kb1 + a, kb1 + a + 256) of the next panel (kb1 = kb + 32, or 0 when kb == -1)
+__global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
+    double* __restrict__ dinv, int* __restrict__ flag)
 {
-    __shared__ double L11[NB * NB];
+    __shared__ double sm[2 * NB * TS];
     const int4 d = desc[blockIdx.x];
-    const int s = d.x, kb = d.y;
+    const int s = d.x;
     const int N = frontN(tv, s), nc = frontNc(tv, s);
-    const int w = min(NB, nc - kb);
     double* F = fronts + tv.frontOff[s];
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += WG) {
-        const int k = e / NB, r = e - k * NB;
-        L11[e] = (k < w && r < w && r >= k) ? F[(kb + r) + (long long)N * (kb + k)] : 0.0;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        if (wave_potrf32(L11, NB, w, tid)) atomicOr(flag, 1);
-    }
-    __syncthreads();
-    const int r = kb + w + d.z + tid;
-    if (r < N) {
-        double x[NB];
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            if (k < w) {
-                double acc = F[r + (long long)N * (kb + k)];
-#pragma unroll
-                for (int q = 0; q < k; ++q) acc -= x[q] * L11[q * NB + k];
-                x[k] = acc / L11[k * NB + k];
-            }
-            else x[k] = 0.0;
-        }
-#pragma unroll
-        for (int k = 0; k < NB; ++k)
-            if (k < w) F[r + (long long)N * (kb + k)] = x[k];
-    }
-}
-
-// desc = (front, kb, ti, tj); ti < 0: no tile, publish the pivot block only; desc.w bit 30 of ti... kept simple:
-// the workgroup with (ti == tj == 0) or (ti < 0) also factors and writes the pivot block L11 to HBM.
-__global__ __launch_bounds__(WG) void k_big_syrk(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
-{
-    __shared__ double As[NB][TS];
-    __shared__ double Bs[NB][TS];
-    const int4 d = desc[blockIdx.x];
-    const int s = d.x, kb = d.y, ti = d.z, tj = d.w;
-    const int N = frontN(tv, s), nc = frontNc(tv, s);
-    const int w = min(NB, nc - kb);
-    double* F = fronts + tv.frontOff[s];
-    const int tid = threadIdx.x;
-    if (ti < 0 || (ti == 0 && tj == 0)) {
-        // publish L11 (k_big_trsm only kept it in LDS); nobody else reads or writes this block in this launch
-        double* blk = &As[0][0]; // NB*NB doubles fit (NB * TS)
-        for (int e = tid; e < NB * NB; e += WG) {
-            const int k = e / NB, r = e - k * NB;
-            blk[e] = (k < w && r < w && r >= k) ? F[(kb + r) + (long long)N * (kb + k)] : 0.0;
+    const int kb = d.y;
+    const int w = (kb >= 0) ? min(NB, nc - kb) : 0;
+    const int kb1 = (kb >= 0) ? kb + w : 0;
+    const int w1 = (kb1 < nc) ? min(NB, nc - kb1) : 0;
+    if (d.w >= 0) {
+        // ---- role A: F[i0.., j0..] -= P_kb[i0..] P_kb[j0..]^T behind the next panel
+        double(*As)[TS] = reinterpret_cast<double(*)[TS]>(sm);
+        double(*Bs)[TS] = reinterpret_cast<double(*)[TS]>(sm + NB * TS);
+        const int M0 = kb1 + w1;
+        const int i0 = M0 + TS * d.z, j0 = M0 + TS * d.w;
+        for (int e = tid; e < NB * TS; e += WGB) {
+            const int k = e / TS, i = e - k * TS;
+            const bool kin = k < w;
+            As[k][i] = (kin && i0 + i < N) ? F[(i0 + i) + (long long)N * (kb + k)] : 0.0;
+            Bs[k][i] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kb + k)] : 0.0;
         }
         __syncthreads();
-        if (tid < 64) (void)wave_potrf32(blk, NB, w, tid);
-        __syncthreads();
-        for (int e = tid; e < NB * NB; e += WG) {
-            const int k = e / NB, r = e - k * NB;
-            if (k < w && r < w && r >= k) F[(kb + r) + (long long)N * (kb + k)] = blk[e];
-        }
-        __syncthreads();
-        if (ti < 0) return;
-    }
-    const int M0 = kb + w;
-    const int i0 = M0 + TS * ti, j0 = M0 + TS * tj;
-    for (int e = tid; e < NB * TS; e += WG) {
-        const int k = e / TS, i = e - k * TS;
-        const bool kin = k < w;
-        As[k][i] = (kin && i0 + i < N) ? F[(i0 + i) + (long long)N * (kb + k)] : 0.0;
-        Bs[k][i] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kb + k)] : 0.0;
-    }
-    __syncthreads();
-    const int ty = tid & 15, tx = tid >> 4;
-    double acc[4][4];
-#pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-#pragma unroll 8
-    for (int k = 0; k < NB; ++k) {
-        double av[4], bv[4];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            av[ii] = As[k][4 * ty + ii];
-            bv[ii] = Bs[k][4 * tx + ii];
-        }
+        if (tid >= WG) return;
+        const int ty = tid & 15, tx = tid >> 4;
+        double acc[4][4];
 #pragma unroll
         for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                av[ii] = As[k][4 * ty + ii];
+                bv[ii] = Bs[k][4 * tx + ii];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int col = j0 + 4 * tx + jj;
+            if (col >= N) continue;
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int row = i0 + 4 * ty + ii;
+                if (row < N && row >= col) F[row + (long long)N * col] -= acc[ii][jj];
+            }
+        }
+        return;
     }
+    // ---- role B: bring panel kb1 up to date with panel kb, factor its pivot block, solve this workgroup's rows.
+    // The factored pivot block is never written back into the front (other workgroups of this launch still read the raw
+    // one); it goes to the dinv slot and is inverted at the end of the factorisation.
+    double* Lp = sm; // Lp[k * LDP + q]  = F(kb1 + q, kb + k): panel-kb rows of the pivot block
+    double* A11 = sm + NB * LDP; // A11[c * LDP + q] = pivot block, k-major
+    double* rdiag = sm + 2 * NB * LDP;
+    for (int e = tid; e < NB * NB; e += WGB) {
+        const int k = e >> 5, q = e & 31;
+        Lp[k * LDP + q] = (k < w && q < w1) ? F[(kb1 + q) + (long long)N * (kb + k)] : 0.0;
+        A11[k * LDP + q] = (k < w1 && q < w1 && q >= k) ? F[(kb1 + q) + (long long)N * (kb1 + k)] : 0.0;
+    }
+    __syncthreads();
+    if (w > 0)
+        for (int e = tid; e < NB * NB; e += WGB) {
+            const int c = e >> 5, q = e & 31;
+            if (q >= c) {
+                double acc = 0.0;
+#pragma unroll 8
+                for (int k = 0; k < NB; ++k) acc += Lp[k * LDP + q] * Lp[k * LDP + c];
+                A11[c * LDP + q] -= acc;
+            }
+        }
+    __syncthreads();
+    const int R = kb1 + d.z + tid;
+    const bool rowThread = tid < WG && R >= kb1 + w1 && R < N;
+    double x[1][NB];
+    if (tid >= WG) {
+        // pivot wave: Cholesky of the 32x32 block while the row waves fetch and update their rows
+        if (wave_potrf32(A11, LDP, w1, tid - WG, rdiag)) atomicOr(flag, 1);
+    }
+    else if (rowThread) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int col = j0 + 4 * tx + jj;
-        if (col >= N) continue;
+        for (int c = 0; c < NB; ++c) x[0][c] = (c < w1) ? F[R + (long long)N * (kb1 + c)] : 0.0;
+#pragma unroll 2
+        for (int k = 0; k < w; ++k) {
+            const double ak = F[R + (long long)N * (kb + k)];
+            const double* lpk = Lp + k * LDP;
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int row = i0 + 4 * ty + ii;
-            if (row < N && row >= col) F[row + (long long)N * col] -= acc[ii][jj];
+            for (int c = 0; c < NB; ++c) x[0][c] -= ak * lpk[c];
         }
     }
+    __syncthreads();
+    if (rowThread) {
+        row_trsm32<1>(x, A11, LDP, rdiag);
+        double* out = F + R + (long long)N * kb1;
+#pragma unroll
+        for (int c = 0; c < NB; ++c)
+            if (c < w1) out[(long long)N * c] = x[0][c];
+    }
+    if (d.z == 0) store_pivot_block(A11, LDP, w1, dinv + (tv.dinvOff[s] + kb1 / NB) * (NB * NB), tid, WGB);
 }
 
 // ---- triangular solves ------------------------------------------------------------------------------------
@@ -342,8 +449,64 @@ __device__ __forceinline__ double gather_w(const TreeView& tv, const long long* 
     return val;
 }
 
+// forward sweep over the nc x nc triangle of one front held in LDS (w1[0..nc)): y_b = Inv_b w_b, then the rows below
+template <int NT>
+__device__ __forceinline__ void fwd_triangle(const double* __restrict__ L, int N, int nc, int rowEnd, const double* __restrict__ dblk,
+    double* w1, int tid)
+{
+    for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
+        const int wd = min(NB, nc - kb);
+        double y = 0.0;
+        if (tid < NB) {
+#pragma unroll 8
+            for (int c = 0; c < NB; ++c) y += dblk[c * NB + tid] * ((c < wd) ? w1[kb + c] : 0.0);
+        }
+        __syncthreads();
+        if (tid < wd) w1[kb + tid] = y;
+        __syncthreads();
+        for (int i = kb + wd + tid; i < rowEnd; i += NT) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < wd; ++k) acc += L[i + (long long)N * (kb + k)] * w1[kb + k];
+            w1[i] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
+// backward sweep: t[0..nc) holds y - L21^T x2 on entry, x1 on exit.  x_b = Inv_b^T t_b, then the columns to the left
+template <int NT>
+__device__ __forceinline__ void bwd_triangle(const double* __restrict__ L, int N, int nc, const double* __restrict__ dblk0, double* t,
+    double* invs /* NB * LDP */, int tid)
+{
+    const int nblk = (nc + NB - 1) / NB;
+    for (int b = nblk - 1; b >= 0; --b) {
+        const int kb = b * NB;
+        const int wd = min(NB, nc - kb);
+        const double* dblk = dblk0 + (long long)b * (NB * NB);
+        for (int e = tid; e < NB * NB; e += NT) invs[(e >> 5) * LDP + (e & 31)] = dblk[e];
+        __syncthreads();
+        double x = 0.0;
+        if (tid < NB) {
+#pragma unroll 8
+            for (int r = 0; r < NB; ++r) x += invs[tid * LDP + r] * ((r < wd) ? t[kb + r] : 0.0);
+        }
+        __syncthreads();
+        if (tid < wd) t[kb + tid] = x;
+        __syncthreads();
+        for (int c = tid; c < kb; c += NT) {
+            const double* Lc = L + (long long)N * c + kb;
+            double acc = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < wd; ++k) acc += Lc[k] * t[kb + k];
+            t[c] -= acc;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, TreeView tv, const long long* __restrict__ wOff,
-    const double* __restrict__ fronts, double* __restrict__ wbuf, double* __restrict__ yperm)
+    const double* __restrict__ fronts, const double* __restrict__ dinv, double* __restrict__ wbuf, double* __restrict__ yperm)
 {
     extern __shared__ double w[];
     const int s = list[blockIdx.x];
@@ -353,26 +516,7 @@ __global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, 
     const int col0 = 3 * tv.firstNode[s];
     for (int I = tid; I < N; I += WG) w[I] = gather_w(tv, wOff, wbuf, yperm, s, nc, I);
     __syncthreads();
-    for (int kb = 0; kb < nc; kb += NB) {
-        const int wd = min(NB, nc - kb);
-        if (tid < 64) {
-            double y = (tid < wd) ? w[kb + tid] : 0.0;
-            for (int j = 0; j < wd; ++j) {
-                const double Ljj = L[(kb + j) + (long long)N * (kb + j)];
-                const double yj = __shfl(y, j, 64) / Ljj;
-                if (tid == j) y = yj;
-                else if (tid > j && tid < wd) y -= L[(kb + tid) + (long long)N * (kb + j)] * yj;
-            }
-            if (tid < wd) w[kb + tid] = y;
-        }
-        __syncthreads();
-        for (int i = kb + wd + tid; i < N; i += WG) {
-            double acc = 0.0;
-            for (int k = 0; k < wd; ++k) acc += L[i + (long long)N * (kb + k)] * w[kb + k];
-            w[i] -= acc;
-        }
-        __syncthreads();
-    }
+    fwd_triangle<WG>(L, N, nc, N, dinv + tv.dinvOff[s] * (NB * NB), w, tid);
     double* wo = wbuf + wOff[s];
     for (int I = tid; I < N; I += WG) {
         wo[I] = w[I]; // rows >= nc carry (children contributions - L21 y) up to the parent
@@ -380,54 +524,54 @@ __global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, 
     }
 }
 
-// big fronts, forward: prologue (gather) then one launch per 32-column step.
-// desc = (front, first row of this chunk, 0, 0)
-__global__ __launch_bounds__(WG) void k_big_fwd_gather(const int4* __restrict__ desc, TreeView tv, const long long* __restrict__ wOff,
-    double* __restrict__ wbuf, const double* __restrict__ yperm)
+// big fronts, forward: one workgroup sweeps the triangle ...
+__global__ __launch_bounds__(WGT) void k_big_fwd_tri(const int* __restrict__ list, TreeView tv, const long long* __restrict__ wOff,
+    const double* __restrict__ fronts, const double* __restrict__ dinv, const double* __restrict__ wbuf, double* __restrict__ yperm)
 {
+    extern __shared__ double w[];
+    const int s = list[blockIdx.x];
+    const int N = frontN(tv, s), nc = frontNc(tv, s);
+    const double* L = fronts + tv.frontOff[s];
+    const int tid = threadIdx.x;
+    const int col0 = 3 * tv.firstNode[s];
+    for (int I = tid; I < nc; I += WGT) w[I] = gather_w(tv, wOff, wbuf, yperm, s, nc, I);
+    __syncthreads();
+    fwd_triangle<WGT>(L, N, nc, nc, dinv + tv.dinvOff[s] * (NB * NB), w, tid);
+    for (int I = tid; I < nc; I += WGT) yperm[col0 + I] = w[I];
+}
+// ... then the rectangle below it: w2[r] = (children) - sum_c L(r, c) y_c.  desc = (front, first row behind nc, 0, 0);
+// 64 rows per workgroup, the four waves split the columns
+__global__ __launch_bounds__(WG) void k_big_fwd_rect(const int4* __restrict__ desc, TreeView tv, const long long* __restrict__ wOff,
+    const double* __restrict__ fronts, double* __restrict__ wbuf, const double* __restrict__ yperm)
+{
+    __shared__ double part[WG];
     const int4 d = desc[blockIdx.x];
     const int s = d.x;
     const int N = frontN(tv, s), nc = frontNc(tv, s);
-    const int I = d.y + threadIdx.x;
-    if (I < N) wbuf[wOff[s] + I] = gather_w(tv, wOff, wbuf, yperm, s, nc, I);
-}
-// desc = (front, kb, row offset behind the pivot block, 0).  Every workgroup solves the 32x32 pivot system itself
-// (the unsolved w_j stays untouched in wbuf, so there is no race); the chunk with offset 0 publishes y_j.
-__global__ __launch_bounds__(WG) void k_big_fwd_step(const int4* __restrict__ desc, TreeView tv, const long long* __restrict__ wOff,
-    const double* __restrict__ fronts, double* __restrict__ wbuf, double* __restrict__ yperm)
-{
-    __shared__ double ys[NB];
-    const int4 d = desc[blockIdx.x];
-    const int s = d.x, kb = d.y;
-    const int N = frontN(tv, s), nc = frontNc(tv, s);
-    const int wd = min(NB, nc - kb);
     const double* L = fronts + tv.frontOff[s];
-    double* wv = wbuf + wOff[s];
-    const int tid = threadIdx.x;
-    if (tid < 64) {
-        double y = (tid < wd) ? wv[kb + tid] : 0.0;
-        for (int j = 0; j < wd; ++j) {
-            const double Ljj = L[(kb + j) + (long long)N * (kb + j)];
-            const double yj = __shfl(y, j, 64) / Ljj;
-            if (tid == j) y = yj;
-            else if (tid > j && tid < wd) y -= L[(kb + tid) + (long long)N * (kb + j)] * yj;
-        }
-        if (tid < NB) ys[tid] = (tid < wd) ? y : 0.0;
-        if (d.z == 0 && tid < wd) yperm[3 * tv.firstNode[s] + kb + tid] = y;
-    }
-    __syncthreads();
-    const int r = kb + wd + d.z + tid;
+    const double* y = yperm + 3 * tv.firstNode[s];
+    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const int r = nc + d.y + lane;
+    double acc = 0.0;
     if (r < N) {
-        double acc = 0.0;
-        for (int k = 0; k < wd; ++k) acc += L[r + (long long)N * (kb + k)] * ys[k];
-        wv[r] -= acc;
+        const int per = (nc + 3) >> 2;
+        const int c0 = cg * per, c1 = min(nc, c0 + per);
+#pragma unroll 4
+        for (int c = c0; c < c1; ++c) acc += L[r + (long long)N * c] * y[c];
+    }
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (cg == 0 && r < N) {
+        const double tot = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+        wbuf[wOff[s] + r] = gather_w(tv, wOff, wbuf, yperm, s, nc, r) - tot;
     }
 }
 
 __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, TreeView tv, const double* __restrict__ fronts,
-    const double* __restrict__ yperm, double* __restrict__ xsol)
+    const double* __restrict__ dinv, const double* __restrict__ yperm, double* __restrict__ xsol)
 {
     extern __shared__ double x[];
+    __shared__ double invs[NB * LDP];
     const int s = list[blockIdx.x];
     const int N = frontN(tv, s), nc = frontNc(tv, s);
     const double* L = fronts + tv.frontOff[s];
@@ -439,31 +583,17 @@ __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, 
         x[I] = (I < nc) ? yperm[col0 + I] : xsol[3 * idx[In] + (I - 3 * In)];
     }
     __syncthreads();
-    const int nblk = (nc + NB - 1) / NB;
-    for (int b = nblk - 1; b >= 0; --b) {
-        const int kb = b * NB;
-        const int wd = min(NB, nc - kb);
-        for (int j = wave; j < wd; j += WG / 64) {
-            double acc = 0.0;
-            const double* Lj = L + (long long)N * (kb + j);
-            for (int i = kb + wd + lane; i < N; i += 64) acc += Lj[i] * x[i];
+    // t = y1 - L21^T x2: one wave per column, lanes stride the rows
+    for (int c = wave; c < nc; c += WG / 64) {
+        double acc = 0.0;
+        const double* Lc = L + (long long)N * c;
+        for (int i = nc + lane; i < N; i += 64) acc += Lc[i] * x[i];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-            if (lane == 0) x[kb + j] -= acc;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            double t = (tid < wd) ? x[kb + tid] : 0.0;
-            for (int j = wd - 1; j >= 0; --j) {
-                const double Ljj = L[(kb + j) + (long long)N * (kb + j)];
-                const double xj = __shfl(t, j, 64) / Ljj;
-                if (tid == j) t = xj;
-                else if (tid < j) t -= L[(kb + j) + (long long)N * (kb + tid)] * xj;
-            }
-            if (tid < wd) x[kb + tid] = t;
-        }
-        __syncthreads();
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) x[c] -= acc;
     }
+    __syncthreads();
+    bwd_triangle<WG>(L, N, nc, dinv + tv.dinvOff[s] * (NB * NB), x, invs, tid);
     for (int I = tid; I < nc; I += WG) xsol[col0 + I] = x[I];
 }
 
@@ -491,38 +621,21 @@ __global__ __launch_bounds__(WG) void k_big_bwd_init(const int4* __restrict__ de
         if (lane == 0) yperm[col0 + c] -= acc;
     }
 }
-// desc = (front, kb, first column of this chunk, 0), steps run from the last block to the first.  Every workgroup
-// solves L_jj^T x_j = t_j itself (t_j is read from yperm, x_j goes to xsol: no race), then updates its columns c < kb.
-__global__ __launch_bounds__(WG) void k_big_bwd_step(const int4* __restrict__ desc, TreeView tv, const double* __restrict__ fronts,
-    double* __restrict__ yperm, double* __restrict__ xsol)
+// ... then one workgroup sweeps the transposed triangle
+__global__ __launch_bounds__(WGT) void k_big_bwd_tri(const int* __restrict__ list, TreeView tv, const double* __restrict__ fronts,
+    const double* __restrict__ dinv, const double* __restrict__ yperm, double* __restrict__ xsol)
 {
-    __shared__ double xs[NB];
-    const int4 d = desc[blockIdx.x];
-    const int s = d.x, kb = d.y;
+    extern __shared__ double t[];
+    __shared__ double invs[NB * LDP];
+    const int s = list[blockIdx.x];
     const int N = frontN(tv, s), nc = frontNc(tv, s);
-    const int wd = min(NB, nc - kb);
     const double* L = fronts + tv.frontOff[s];
-    const int col0 = 3 * tv.firstNode[s];
     const int tid = threadIdx.x;
-    if (tid < 64) {
-        double t = (tid < wd) ? yperm[col0 + kb + tid] : 0.0;
-        for (int j = wd - 1; j >= 0; --j) {
-            const double Ljj = L[(kb + j) + (long long)N * (kb + j)];
-            const double xj = __shfl(t, j, 64) / Ljj;
-            if (tid == j) t = xj;
-            else if (tid < j) t -= L[(kb + j) + (long long)N * (kb + tid)] * xj;
-        }
-        if (tid < NB) xs[tid] = (tid < wd) ? t : 0.0;
-        if (d.z == 0 && tid < wd) xsol[col0 + kb + tid] = t;
-    }
+    const int col0 = 3 * tv.firstNode[s];
+    for (int I = tid; I < nc; I += WGT) t[I] = yperm[col0 + I];
     __syncthreads();
-    const int c = d.z + tid;
-    if (c < kb) {
-        const double* Lc = L + (long long)N * c + kb;
-        double acc = 0.0;
-        for (int k = 0; k < wd; ++k) acc += Lc[k] * xs[k];
-        yperm[col0 + c] -= acc;
-    }
+    bwd_triangle<WGT>(L, N, nc, dinv + tv.dinvOff[s] * (NB * NB), t, invs, tid);
+    for (int I = tid; I < nc; I += WGT) xsol[col0 + I] = t[I];
 }
 
 } // namespace
@@ -552,6 +665,11 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         wOff_.upload(u, stream);
         std::vector<long long> d(sym.aDst.begin(), sym.aDst.end());
         aDst_.upload(d, stream);
+        std::vector<long long> di(ns_ + 1, 0);
+        for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
+        dinvOff_.upload(di, stream);
+        nDiagBlocks_ = di[ns_];
+        dinv_.alloc((size_t)di[ns_] * NB * NB);
     }
     flag_.alloc(1);
     hflag_.alloc(4);
@@ -559,10 +677,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     int bigN = 192; // fronts wider than this go through the level-batched multi-workgroup kernels
     if (const char* e = std::getenv("IPCGPU_MF_BIGN")) bigN = std::max(NB + 1, std::min(448, std::atoi(e)));
     plan_.assign(nLevels_, LevelPlan());
-    std::vector<int> smallList;
+    std::vector<int> smallList, bigList;
     std::vector<int2> ea;
     std::vector<int4> desc;
-    size_t maxSmallLds = 0, maxSolveLds = 0;
+    size_t maxSmallLds = 0, maxSolveLds = 0, maxTriLds = 0;
     for (int l = 0; l < nLevels_; ++l) {
         LevelPlan& P = plan_[l];
         std::vector<int> small, big;
@@ -572,15 +690,22 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         }
         // heaviest first so the tail of the level is made of short jobs
         std::sort(small.begin(), small.end(), [&](int a, int b) { return sym.N(a) > sym.N(b); });
+        std::sort(big.begin(), big.end(), [&](int a, int b) { return sym.nc(a) > sym.nc(b); });
         P.small.off = (int)smallList.size();
         P.small.cnt = (int)small.size();
-        int maxN = 0;
+        int maxN = 0, maxNc = 0;
         for (int s : small) maxN = std::max(maxN, sym.N(s));
+        for (int s : big) maxNc = std::max(maxNc, sym.nc(s));
         smallList.insert(smallList.end(), small.begin(), small.end());
+        P.bigFronts.off = (int)bigList.size();
+        P.bigFronts.cnt = (int)big.size();
+        bigList.insert(bigList.end(), big.begin(), big.end());
         P.smallLds = (size_t)(NB * maxN + 8) * sizeof(double);
         P.solveLds = (size_t)std::max(maxN, 1) * sizeof(double);
+        P.triLds = (size_t)std::max(maxNc, 1) * sizeof(double);
         maxSmallLds = std::max(maxSmallLds, P.smallLds);
         maxSolveLds = std::max(maxSolveLds, P.solveLds);
+        maxTriLds = std::max(maxTriLds, P.triLds);
         // extend-add descriptors (fronts with children only)
         P.ea.off = (int)ea.size();
         for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
@@ -591,50 +716,35 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             for (int c = 0; c < chunks; ++c) ea.push_back(make_int2(s, c));
         }
         P.ea.cnt = (int)ea.size() - P.ea.off;
-        // big-front step descriptors
+        // big-front step descriptors: launch 0 factors panel 0, launch j + 1 applies panel j and factors panel j + 1
         int steps = 0;
         for (int s : big) steps = std::max(steps, (sym.nc(s) + NB - 1) / NB);
-        P.trsm.assign(steps, Range());
-        P.syrk.assign(steps, Range());
-        P.fwd.assign(steps, Range());
-        P.bwd.assign(steps, Range());
-        for (int j = 0; j < steps; ++j) {
-            const int kb = j * NB;
-            P.trsm[j].off = (int)desc.size();
+        P.step.assign(big.empty() ? 0 : steps + 1, Range());
+        for (int j = -1; j < steps && !big.empty(); ++j) {
+            Range& R = P.step[j + 1];
+            R.off = (int)desc.size();
             for (int s : big) {
-                if (kb >= sym.nc(s)) continue;
-                const int w = std::min(NB, sym.nc(s) - kb), rows = sym.N(s) - kb - w;
-                for (int r0 = 0; r0 < rows; r0 += WG) desc.push_back(make_int4(s, kb, r0, 0));
+                const int N = sym.N(s), nc = sym.nc(s);
+                const int kb = j * NB;
+                if (j >= 0 && kb >= nc) continue;
+                const int w = (j >= 0) ? std::min(NB, nc - kb) : 0;
+                const int kb1 = (j >= 0) ? kb + w : 0;
+                const int w1 = (kb1 < nc) ? std::min(NB, nc - kb1) : 0;
+                if (w1 > 0)
+                    for (int r0 = 0; r0 < N - kb1; r0 += WG) desc.push_back(make_int4(s, j >= 0 ? kb : -1, r0, -2));
+                if (j >= 0) {
+                    const int M = N - (kb1 + w1);
+                    const int nt = (M + TS - 1) / TS;
+                    for (int ti = 0; ti < nt; ++ti)
+                        for (int tj = 0; tj <= ti; ++tj) desc.push_back(make_int4(s, kb, ti, tj));
+                }
             }
-            P.trsm[j].cnt = (int)desc.size() - P.trsm[j].off;
-            P.syrk[j].off = (int)desc.size();
-            for (int s : big) {
-                if (kb >= sym.nc(s)) continue;
-                const int w = std::min(NB, sym.nc(s) - kb), M = sym.N(s) - kb - w;
-                const int nt = (M + TS - 1) / TS;
-                if (nt == 0) desc.push_back(make_int4(s, kb, -1, -1));
-                for (int ti = 0; ti < nt; ++ti)
-                    for (int tj = 0; tj <= ti; ++tj) desc.push_back(make_int4(s, kb, ti, tj));
-            }
-            P.syrk[j].cnt = (int)desc.size() - P.syrk[j].off;
-            P.fwd[j].off = (int)desc.size();
-            for (int s : big) {
-                if (kb >= sym.nc(s)) continue;
-                const int w = std::min(NB, sym.nc(s) - kb), rows = sym.N(s) - kb - w;
-                for (int r0 = 0; r0 == 0 || r0 < rows; r0 += WG) desc.push_back(make_int4(s, kb, r0, 0));
-            }
-            P.fwd[j].cnt = (int)desc.size() - P.fwd[j].off;
-            P.bwd[j].off = (int)desc.size();
-            for (int s : big) {
-                if (kb >= sym.nc(s)) continue;
-                for (int c0 = 0; c0 == 0 || c0 < kb; c0 += WG) desc.push_back(make_int4(s, kb, c0, 0));
-            }
-            P.bwd[j].cnt = (int)desc.size() - P.bwd[j].off;
+            R.cnt = (int)desc.size() - R.off;
         }
-        P.fwdGather.off = (int)desc.size();
+        P.fwdRect.off = (int)desc.size();
         for (int s : big)
-            for (int r0 = 0; r0 < sym.N(s); r0 += WG) desc.push_back(make_int4(s, r0, 0, 0));
-        P.fwdGather.cnt = (int)desc.size() - P.fwdGather.off;
+            for (int r0 = 0; r0 < sym.N(s) - sym.nc(s); r0 += 64) desc.push_back(make_int4(s, r0, 0, 0));
+        P.fwdRect.cnt = (int)desc.size() - P.fwdRect.off;
         P.bwdInit.off = (int)desc.size();
         for (int s : big)
             if (sym.N(s) > sym.nc(s))
@@ -643,15 +753,22 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     }
     if (smallList.empty()) smallList.push_back(0);
     smallList_.upload(smallList, stream);
+    if (bigList.empty()) bigList.push_back(0);
+    bigList_.upload(bigList, stream);
     if (ea.empty()) ea.push_back(make_int2(0, 0));
     eaDesc_.upload(ea.data(), ea.size(), stream);
     if (desc.empty()) desc.push_back(make_int4(0, 0, 0, 0));
     desc_.upload(desc.data(), desc.size(), stream);
-    if (maxSmallLds > 64 * 1024)
+    if (maxSmallLds > 48 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void*)k_factor_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
-    if (maxSolveLds > 64 * 1024) {
+    if (maxSolveLds > 48 * 1024) {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
+    }
+    if (maxTriLds > 48 * 1024) {
+        if (maxTriLds > 150 * 1024) throw StateError("a separator front is too wide for the single-workgroup triangular sweep");
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_big_fwd_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxTriLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_big_bwd_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxTriLds));
     }
     HIP_CHECK(hipStreamSynchronize(stream));
 }
@@ -660,7 +777,7 @@ bool MfNumeric::factorize(const double* a_dev)
 {
     if (!sym_) throw StateError("factorize before analyze_pattern");
     const MfSymbolic& sym = *sym_;
-    TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p };
+    TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     fronts_.zero(stream_);
     flag_.zero(stream_);
     const int nnz = (int)sym.aDst.size();
@@ -670,13 +787,12 @@ bool MfNumeric::factorize(const double* a_dev)
         if (P.ea.cnt) hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, tv, fronts_.p);
         if (P.small.cnt)
             hipLaunchKernelGGL(k_factor_front, dim3(P.small.cnt), dim3(WG), P.smallLds, stream_, smallList_.p + P.small.off, tv, fronts_.p,
-                flag_.p);
-        for (size_t j = 0; j < P.trsm.size(); ++j) {
-            if (P.trsm[j].cnt)
-                hipLaunchKernelGGL(k_big_trsm, dim3(P.trsm[j].cnt), dim3(WG), 0, stream_, desc_.p + P.trsm[j].off, tv, fronts_.p, flag_.p);
-            if (P.syrk[j].cnt) hipLaunchKernelGGL(k_big_syrk, dim3(P.syrk[j].cnt), dim3(WG), 0, stream_, desc_.p + P.syrk[j].off, tv, fronts_.p);
-        }
+                dinv_.p, flag_.p);
+        for (const Range& R : P.step)
+            if (R.cnt) hipLaunchKernelGGL(k_big_step, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p);
     }
+    // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)
+    hipLaunchKernelGGL(k_invert_blocks, dim3((unsigned)nDiagBlocks_), dim3(64), 0, stream_, dinv_.p);
     HIP_CHECK(hipMemcpyAsync(hflag_.p, flag_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
     HIP_CHECK(hipStreamSynchronize(stream_));
     return hflag_.p[0] == 0;
@@ -686,33 +802,31 @@ void MfNumeric::solve(const double* rhs_dev, double* x_dev)
 {
     if (!sym_) throw StateError("solve before analyze_pattern");
     const MfSymbolic& sym = *sym_;
-    TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p };
+    TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     const int n3 = sym.n;
     hipLaunchKernelGGL(k_permute_rhs, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, rhs_dev, yperm_.p);
     for (int l = 0; l < nLevels_; ++l) {
         const LevelPlan& P = plan_[l];
         if (P.small.cnt)
             hipLaunchKernelGGL(k_fwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, wOff_.p,
-                fronts_.p, w_.p, yperm_.p);
-        if (P.fwdGather.cnt)
-            hipLaunchKernelGGL(k_big_fwd_gather, dim3(P.fwdGather.cnt), dim3(WG), 0, stream_, desc_.p + P.fwdGather.off, tv, wOff_.p, w_.p,
+                fronts_.p, dinv_.p, w_.p, yperm_.p);
+        if (P.bigFronts.cnt)
+            hipLaunchKernelGGL(k_big_fwd_tri, dim3(P.bigFronts.cnt), dim3(WGT), P.triLds, stream_, bigList_.p + P.bigFronts.off, tv, wOff_.p,
+                fronts_.p, dinv_.p, w_.p, yperm_.p);
+        if (P.fwdRect.cnt)
+            hipLaunchKernelGGL(k_big_fwd_rect, dim3(P.fwdRect.cnt), dim3(WG), 0, stream_, desc_.p + P.fwdRect.off, tv, wOff_.p, fronts_.p, w_.p,
                 yperm_.p);
-        for (size_t j = 0; j < P.fwd.size(); ++j)
-            if (P.fwd[j].cnt)
-                hipLaunchKernelGGL(k_big_fwd_step, dim3(P.fwd[j].cnt), dim3(WG), 0, stream_, desc_.p + P.fwd[j].off, tv, wOff_.p, fronts_.p,
-                    w_.p, yperm_.p);
     }
     for (int l = nLevels_ - 1; l >= 0; --l) {
         const LevelPlan& P = plan_[l];
         if (P.bwdInit.cnt)
             hipLaunchKernelGGL(k_big_bwd_init, dim3(P.bwdInit.cnt), dim3(WG), 0, stream_, desc_.p + P.bwdInit.off, tv, fronts_.p, yperm_.p,
                 xsol_.p);
-        for (int j = (int)P.bwd.size() - 1; j >= 0; --j)
-            if (P.bwd[j].cnt)
-                hipLaunchKernelGGL(k_big_bwd_step, dim3(P.bwd[j].cnt), dim3(WG), 0, stream_, desc_.p + P.bwd[j].off, tv, fronts_.p, yperm_.p,
-                    xsol_.p);
+        if (P.bigFronts.cnt)
+            hipLaunchKernelGGL(k_big_bwd_tri, dim3(P.bigFronts.cnt), dim3(WGT), P.triLds, stream_, bigList_.p + P.bigFronts.off, tv, fronts_.p,
+                dinv_.p, yperm_.p, xsol_.p);
         if (P.small.cnt)
-            hipLaunchKernelGGL(k_bwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p,
+            hipLaunchKernelGGL(k_bwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
                 yperm_.p, xsol_.p);
     }
     hipLaunchKernelGGL(k_unpermute_x, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, xsol_.p, x_dev);

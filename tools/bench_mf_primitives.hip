@@ -1,0 +1,81 @@
+// Micro-timing of the building blocks of the multifrontal step kernel (cycles via s_memtime), to see which link of the
+// per-step critical chain costs what.  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast -I ipc_amd/csrc tools/bench_mf_primitives.hip -o /tmp/bmf && /tmp/bmf
+#include "../ipc_amd/csrc/mf_numeric.hip"
+#include <cstdio>
+#include <vector>
+
+using namespace ipcgpu;
+
+__global__ __launch_bounds__(WGB) void k_probe(double* A, long long* out, double* sink)
+{
+    __shared__ double blk[NB * LDP];
+    __shared__ double rd[NB];
+    __shared__ double Xs[NB * LDI];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < NB * NB; e += WGB) blk[(e >> 5) * LDP + (e & 31)] = A[e];
+    __syncthreads();
+    long long t0 = __builtin_readcyclecounter();
+    if (tid >= WG) (void)wave_potrf32(blk, LDP, NB, tid - WG, rd);
+    __syncthreads();
+    long long t1 = __builtin_readcyclecounter();
+    double x2[2][NB];
+    double (&x)[NB] = x2[0];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        x2[0][c] = A[(tid & 31) + 32 * c] + tid;
+        x2[1][c] = x2[0][c] + 1.0;
+    }
+    long long t2 = __builtin_readcyclecounter();
+    if (tid < WG / 2) row_trsm32<2>(x2, blk, LDP, rd);
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) s += x2[0][c] + x2[1][c];
+    sink[blockIdx.x * WGB + tid] = s;
+    __syncthreads();
+    long long t3 = __builtin_readcyclecounter();
+    if (tid < 64) wave_trinv32(blk, LDP, tid, Xs);
+    __syncthreads();
+    long long t4 = __builtin_readcyclecounter();
+    // 32 x 32 x 32 rank update of one row, as in role B
+#pragma unroll 2
+    for (int k = 0; k < NB; ++k) {
+        const double ak = A[(tid & 31) * 32 + k];
+        const double* lpk = blk + k * LDP;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) x[c] -= ak * lpk[c];
+    }
+    s = 0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) s += x[c];
+    sink[blockIdx.x * WGB + tid] += s + Xs[tid & 31];
+    __syncthreads();
+    long long t5 = __builtin_readcyclecounter();
+    if (tid == 0 && blockIdx.x == 0) {
+        out[0] = t1 - t0;
+        out[1] = t3 - t2;
+        out[2] = t4 - t3;
+        out[3] = t5 - t4;
+    }
+}
+
+int main()
+{
+    std::vector<double> A(1024, 0.0);
+    for (int k = 0; k < 32; ++k)
+        for (int r = k; r < 32; ++r) A[k * 32 + r] = (r == k) ? 40.0 + k : 1.0 / (1 + r + k);
+    double *dA, *dS;
+    long long* dO;
+    hipMalloc(&dA, 8192);
+    hipMalloc(&dS, 8 * WGB * 64);
+    hipMalloc(&dO, 64);
+    hipMemcpy(dA, A.data(), 8192, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(k_probe, dim3(rep == 2 ? 64 : 1), dim3(WGB), 0, 0, dA, dO, dS);
+        long long o[4];
+        hipMemcpy(o, dO, 32, hipMemcpyDeviceToHost);
+        std::printf("grid %2d: potrf32 %lld  row_trsm32<2>(2 waves) %lld  trinv32 %lld  row_update32 %lld  (cycles of the 100 MHz counter x ~24 = core clocks)\n",
+            rep == 2 ? 64 : 1, o[0], o[1], o[2], o[3]);
+    }
+    return 0;
+}
