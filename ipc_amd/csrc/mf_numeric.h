@@ -30,6 +30,7 @@ private:
         Range ea; // extend-add descriptors
         Range bigFronts; // into bigList_
         std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1
+        Range schur; // one-pass Schur complement tiles of the big fronts
         Range fwdRect, bwdInit; // descriptors of the row-/column-parallel halves of the big-front solves
     };
     const MfSymbolic* sym_ = nullptr;

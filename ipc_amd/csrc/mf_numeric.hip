@@ -37,6 +37,7 @@ constexpr int WGB = WG + 64; // big-front step: four row waves + one pivot wave
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
 constexpr int TS = 64; // trailing-update tile
+typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct TreeView {
     const long long* frontOff;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     const int kb1 = (kb >= 0) ? kb + w : 0;
     const int w1 = (kb1 < nc) ? min(NB, nc - kb1) : 0;
     if (d.w >= 0) {
-        // ---- role A: F[i0.., j0..] -= P_kb[i0..] P_kb[j0..]^T behind the next panel
+        // ---- role A: F[i0.., j0..] -= P_kb[i0..] P_kb[j0..]^T behind the next panel, own columns (< nc) only
         double(*As)[TS] = reinterpret_cast<double(*)[TS]>(sm);
         double(*Bs)[TS] = reinterpret_cast<double(*)[TS]>(sm + NB * TS);
         const int M0 = kb1 + w1;
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             const int col = j0 + 4 * tx + jj;
-            if (col >= N) continue;
+            if (col >= nc) continue; // columns >= nc form the Schur complement: one pass at the end (k_big_schur)
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int row = i0 + 4 * ty + ii;
@@ -395,15 +396,51 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         // pivot wave: Cholesky of the 32x32 block while the row waves fetch and update their rows
         if (wave_potrf32(A11, LDP, w1, tid - WG, rdiag)) atomicOr(flag, 1);
     }
-    else if (rowThread) {
+    else {
+        // row waves: X(64 x 32) = raw - P_kb(64 x 32) Lp^T on the matrix cores.  v_mfma_f64_16x16x4_f64: A[l&15][l>>4],
+        // B[l>>4][l&15], D col = l&15, row = (l>>4) + 4 reg.  One LDS read feeds 1024 FMAs instead of one.
+        const int wv = tid >> 6, l = tid & 63;
+        const int Rw = kb1 + d.z + 64 * wv; // first row of this wave
+        if (w > 0 && Rw < N) { // wave-uniform; a panel that has a successor is always full (w == NB)
+            f64x4 acc[4][2];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) x[0][c] = (c < w1) ? F[R + (long long)N * (kb1 + c)] : 0.0;
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+            const int ar = l & 15, ak = l >> 4;
+            const double* Fr[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) Fr[mt] = F + min(Rw + 16 * mt + ar, N - 1) + (long long)N * (kb + ak);
 #pragma unroll 2
-        for (int k = 0; k < w; ++k) {
-            const double ak = F[R + (long long)N * (kb + k)];
-            const double* lpk = Lp + k * LDP;
+            for (int ks = 0; ks < NB / 4; ++ks) {
+                const double b0 = Lp[(4 * ks + ak) * LDP + ar], b1 = Lp[(4 * ks + ak) * LDP + 16 + ar];
 #pragma unroll
-            for (int c = 0; c < NB; ++c) x[0][c] -= ak * lpk[c];
+                for (int mt = 0; mt < 4; ++mt) {
+                    const double a = Fr[mt][(long long)N * (4 * ks)];
+                    acc[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[mt][1], 0, 0, 0);
+                }
+            }
+            // the update goes straight into the front (rows below the pivot block only: the raw pivot block is still being
+            // read by the other workgroups); the wave then re-reads its rows one per lane
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = Rw + 16 * mt + ak + 4 * r;
+                    if (row >= kb1 + w1 && row < N) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int col = 16 * nt + ar;
+                            if (col < w1) F[row + (long long)N * (kb1 + col)] -= acc[mt][nt][r];
+                        }
+                    }
+                }
+            __threadfence_block(); // the rows of a wave are produced by that wave
+        }
+        if (rowThread) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) x[0][c] = (c < w1) ? F[R + (long long)N * (kb1 + c)] : 0.0;
         }
     }
     __syncthreads();
@@ -415,6 +452,61 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
             if (c < w1) out[(long long)N * c] = x[0][c];
     }
     if (d.z == 0) store_pivot_block(A11, LDP, w1, dinv + (tv.dinvOff[s] + kb1 / NB) * (NB * NB), tid, WGB);
+}
+
+// Schur complement of a big front in one pass: S(i, j) -= sum_{c < nc} L(i, c) L(j, c) for i, j >= nc.  Doing this per
+// 32-column step (right-looking) re-reads and re-writes the whole update matrix every step, which made the middle levels
+// of the tree HBM-bound; here every tile is read-modify-written once.  desc = (front, ti, tj, 0), 64 x 64 tiles, ti >= tj.
+__global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
+{
+    __shared__ double As[NB][TS];
+    __shared__ double Bs[NB][TS];
+    const int4 d = desc[blockIdx.x];
+    const int s = d.x;
+    const int N = frontN(tv, s), nc = frontNc(tv, s);
+    double* F = fronts + tv.frontOff[s];
+    const int tid = threadIdx.x;
+    const int i0 = nc + TS * d.y, j0 = nc + TS * d.z;
+    const int ty = tid & 15, tx = tid >> 4;
+    double acc[4][4];
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
+    for (int kc = 0; kc < nc; kc += NB) {
+        const int w = min(NB, nc - kc);
+        __syncthreads();
+        for (int e = tid; e < NB * TS; e += WG) {
+            const int k = e / TS, i = e - k * TS;
+            const bool kin = k < w;
+            As[k][i] = (kin && i0 + i < N) ? F[(i0 + i) + (long long)N * (kc + k)] : 0.0;
+            Bs[k][i] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kc + k)] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < NB; ++k) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                av[ii] = As[k][4 * ty + ii];
+                bv[ii] = Bs[k][4 * tx + ii];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+        }
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int col = j0 + 4 * tx + jj;
+        if (col >= N) continue;
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii) {
+            const int row = i0 + 4 * ty + ii;
+            if (row < N && row >= col) F[row + (long long)N * col] -= acc[ii][jj];
+        }
+    }
 }
 
 // ---- triangular solves ------------------------------------------------------------------------------------
@@ -674,7 +766,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     flag_.alloc(1);
     hflag_.alloc(4);
 
-    int bigN = 192; // fronts wider than this go through the level-batched multi-workgroup kernels
+    int bigN = 96; // fronts wider than this go through the level-batched multi-workgroup kernels
     if (const char* e = std::getenv("IPCGPU_MF_BIGN")) bigN = std::max(NB + 1, std::min(448, std::atoi(e)));
     plan_.assign(nLevels_, LevelPlan());
     std::vector<int> smallList, bigList;
@@ -733,14 +825,22 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 if (w1 > 0)
                     for (int r0 = 0; r0 < N - kb1; r0 += WG) desc.push_back(make_int4(s, j >= 0 ? kb : -1, r0, -2));
                 if (j >= 0) {
-                    const int M = N - (kb1 + w1);
-                    const int nt = (M + TS - 1) / TS;
-                    for (int ti = 0; ti < nt; ++ti)
-                        for (int tj = 0; tj <= ti; ++tj) desc.push_back(make_int4(s, kb, ti, tj));
+                    // trailing tiles inside the front's own columns; the Schur complement (columns >= nc) waits for k_big_schur
+                    const int M0 = kb1 + w1;
+                    const int ntr = (N - M0 + TS - 1) / TS, ntc = (nc - M0 + TS - 1) / TS;
+                    for (int ti = 0; ti < ntr; ++ti)
+                        for (int tj = 0; tj <= ti && tj < ntc; ++tj) desc.push_back(make_int4(s, kb, ti, tj));
                 }
             }
             R.cnt = (int)desc.size() - R.off;
         }
+        P.schur.off = (int)desc.size();
+        for (int s : big) {
+            const int nt = (sym.N(s) - sym.nc(s) + TS - 1) / TS;
+            for (int ti = 0; ti < nt; ++ti)
+                for (int tj = 0; tj <= ti; ++tj) desc.push_back(make_int4(s, ti, tj, 0));
+        }
+        P.schur.cnt = (int)desc.size() - P.schur.off;
         P.fwdRect.off = (int)desc.size();
         for (int s : big)
             for (int r0 = 0; r0 < sym.N(s) - sym.nc(s); r0 += 64) desc.push_back(make_int4(s, r0, 0, 0));
@@ -790,6 +890,7 @@ bool MfNumeric::factorize(const double* a_dev)
                 dinv_.p, flag_.p);
         for (const Range& R : P.step)
             if (R.cnt) hipLaunchKernelGGL(k_big_step, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p);
+        if (P.schur.cnt) hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, tv, fronts_.p);
     }
     // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)
     hipLaunchKernelGGL(k_invert_blocks, dim3((unsigned)nDiagBlocks_), dim3(64), 0, stream_, dinv_.p);
