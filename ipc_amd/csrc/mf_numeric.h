@@ -42,7 +42,7 @@ private:
     DevBuf<double> dinv_; // explicit inverses of the 32x32 diagonal blocks of L, 1024 doubles each
     DevBuf<int> idx_, idxPtr_, firstNode_, childPtr_, child_, invPtr_, inv_, newOf_, flag_;
     DevBuf<long long> frontOff_, wOff_, aDst_, dinvOff_;
-    DevBuf<int2> eaDesc_;
+    DevBuf<int4> eaDesc_;
     DevBuf<int> smallList_, bigList_;
     DevBuf<int4> desc_; // all big-front step descriptors
     PinnedBuf<int> hflag_;

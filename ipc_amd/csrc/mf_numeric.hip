@@ -60,33 +60,53 @@ __global__ void k_scatter_a(int nnz, const double* __restrict__ a, const long lo
     if (k < nnz) fronts[dst[k]] = a[k];
 }
 
-__global__ __launch_bounds__(WG) void k_extend_add(const int2* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
+// desc = (parent front, ti, tj, 0): one 64 x 64 tile (ti >= tj) of the parent.  Per child the parent-row / parent-column ->
+// child-index maps of the tile are built once in LDS (128 lookups instead of two per entry); lanes run along rows, which
+// are (mostly) consecutive in the child as well, the four waves split the 64 columns.
+__global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
 {
-    const int2 d = desc[blockIdx.x];
+    __shared__ int rmap[TS], cmap[TS];
+    const int4 d = desc[blockIdx.x];
     const int s = d.x;
     const int N = frontN(tv, s);
-    const long long total = (long long)N * N;
     double* F = fronts + tv.frontOff[s];
-    const int c0 = tv.childPtr[s], c1 = tv.childPtr[s + 1];
-    long long e = (long long)d.y * (WG * EA_ITEMS) + threadIdx.x;
-#pragma unroll 1
-    for (int it = 0; it < EA_ITEMS; ++it, e += WG) {
-        if (e >= total) break;
-        const int J = (int)(e / N), I = (int)(e - (long long)J * N);
-        if (I < J) continue;
-        const int In = I / 3, Id = I - 3 * In, Jn = J / 3, Jd = J - 3 * Jn;
-        double sum = 0.0;
-        for (int ci = c0; ci < c1; ++ci) {
-            const int c = tv.child[ci];
-            const int* inv = tv.inv + tv.invPtr[c];
-            const int ic = inv[In], jc = inv[Jn];
-            if (ic >= 0 && jc >= 0) {
-                const int Nc = frontN(tv, c);
-                const int ncc = frontNc(tv, c);
-                sum += fronts[tv.frontOff[c] + (ncc + 3 * ic + Id) + (long long)Nc * (ncc + 3 * jc + Jd)];
+    const int i0 = TS * d.y, j0 = TS * d.z;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double sum[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum[q] = 0.0;
+    for (int ci = tv.childPtr[s]; ci < tv.childPtr[s + 1]; ++ci) {
+        const int c = tv.child[ci];
+        const int* inv = tv.inv + tv.invPtr[c];
+        const int Nc = frontN(tv, c), ncc = frontNc(tv, c);
+        const double* Fc = fronts + tv.frontOff[c];
+        __syncthreads();
+        if (tid < 2 * TS) {
+            const int I = (tid < TS ? i0 : j0 - TS) + tid;
+            int m = -1;
+            if (I < N) {
+                const int ic = inv[I / 3];
+                if (ic >= 0) m = ncc + 3 * ic + (I - 3 * (I / 3));
+            }
+            (tid < TS ? rmap : cmap - TS)[tid] = m;
+        }
+        __syncthreads();
+        const int r = rmap[lane];
+        if (r >= 0) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int cc = cmap[16 * wv + q];
+                if (cc >= 0 && r >= cc) sum[q] += Fc[r + (long long)Nc * cc];
             }
         }
-        F[I + (long long)N * J] += sum;
+    }
+    const int I = i0 + lane;
+    if (I < N) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int J = j0 + 16 * wv + q;
+            if (J <= I && sum[q] != 0.0) F[I + (long long)N * J] += sum[q];
+        }
     }
 }
 
@@ -171,23 +191,34 @@ __device__ __forceinline__ void wave_trinv32(const double* blk, int ld, int lane
 template <int RW>
 __device__ __forceinline__ void row_trsm32(double (&x)[RW][NB], const double* blk, int ld, const double* rdiag)
 {
+    // Software pipeline: the LDS reads of column k + 1 are issued at the top of step k and consumed one step later.  Their
+    // addresses are made to depend on x[0][k] (final once step k - 1 has swept it): with compile-time LDS addresses the
+    // scheduler otherwise issues all 496 reads up front and spills ~1000 registers, and without the look-ahead every step
+    // would wait out one LDS round trip.
+    double lc[NB], ln[NB];
+    double rdc = rdiag[0], rdn = 0.0;
+#pragma unroll
+    for (int c = 1; c < NB; ++c) lc[c] = blk[c];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        const double rd = rdiag[k];
+        if (k + 1 < NB) {
+            int z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[0][k])));
+            const double* lk = blk + (k + 1) * ld + z;
+            rdn = rdiag[k + 1 + z];
 #pragma unroll
-        for (int h = 0; h < RW; ++h) x[h][k] *= rd;
-        // The addresses of column k are made to depend on the finished x[k]: with compile-time LDS addresses the scheduler
-        // otherwise issues all 496 reads up front and spills ~1000 registers.
-        // (x[RW-1][NB-1] is the last value the previous column touches, so the reads also wait for that column's sweep.)
-        int z;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[0][k])), "v"(__double2loint(x[RW - 1][NB - 1])));
-        const double* lk = blk + k * ld + z;
+            for (int c = k + 2; c < NB; ++c) ln[c] = lk[c];
+        }
+#pragma unroll
+        for (int h = 0; h < RW; ++h) x[h][k] *= rdc;
 #pragma unroll
         for (int c = k + 1; c < NB; ++c) {
-            const double l = lk[c];
 #pragma unroll
-            for (int h = 0; h < RW; ++h) x[h][c] -= x[h][k] * l;
+            for (int h = 0; h < RW; ++h) x[h][c] -= x[h][k] * lc[c];
         }
+#pragma unroll
+        for (int c = k + 2; c < NB; ++c) lc[c] = ln[c];
+        rdc = rdn;
     }
 }
 
@@ -240,21 +271,13 @@ __global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ lis
         __syncthreads();
         store_pivot_block(P, m, w, dblk, tid, WG);
         // rows below the pivot block: X L11^T = A21, one row per thread
-        for (int r = w + tid; tid < WG / 2 && r < m; r += WG) { // two rows per thread on half of the waves
-            const int r1 = r + WG / 2;
-            const bool two = r1 < m;
-            double x[2][NB];
+        for (int r = w + tid; r < m; r += WG) {
+            double x[1][NB];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                x[0][k] = P[k * m + r];
-                x[1][k] = two ? P[k * m + r1] : 0.0;
-            }
-            row_trsm32<2>(x, P, m, rdiag);
+            for (int k = 0; k < NB; ++k) x[0][k] = P[k * m + r];
+            row_trsm32<1>(x, P, m, rdiag);
 #pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                P[k * m + r] = x[0][k];
-                if (two) P[k * m + r1] = x[1][k];
-            }
+            for (int k = 0; k < NB; ++k) P[k * m + r] = x[0][k];
         }
         __syncthreads();
         for (int e = tid; e < w * m; e += WG) {
@@ -473,16 +496,30 @@ __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc,
     for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-    for (int kc = 0; kc < nc; kc += NB) {
+    // register double buffer: the chunk after the one being multiplied is already in flight
+    constexpr int PER = NB * TS / WG;
+    double ra[PER], rb[PER];
+    auto fetch = [&](int kc) {
         const int w = min(NB, nc - kc);
-        __syncthreads();
-        for (int e = tid; e < NB * TS; e += WG) {
-            const int k = e / TS, i = e - k * TS;
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int e = tid + WG * t, k = e / TS, i = e - k * TS;
             const bool kin = k < w;
-            As[k][i] = (kin && i0 + i < N) ? F[(i0 + i) + (long long)N * (kc + k)] : 0.0;
-            Bs[k][i] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kc + k)] : 0.0;
+            ra[t] = (kin && i0 + i < N) ? F[(i0 + i) + (long long)N * (kc + k)] : 0.0;
+            rb[t] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kc + k)] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int kc = 0; kc < nc; kc += NB) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+            const int e = tid + WG * t, k = e / TS, i = e - k * TS;
+            As[k][i] = ra[t];
+            Bs[k][i] = rb[t];
         }
         __syncthreads();
+        if (kc + NB < nc) fetch(kc + NB);
 #pragma unroll 8
         for (int k = 0; k < NB; ++k) {
             double av[4], bv[4];
@@ -542,21 +579,59 @@ __device__ __forceinline__ double gather_w(const TreeView& tv, const long long* 
 }
 
 // forward sweep over the nc x nc triangle of one front held in LDS (w1[0..nc)): y_b = Inv_b w_b, then the rows below
+// Both sweeps are software-pipelined: the inverse block and the L entries of a thread's first row / column for step b + 1
+// are requested before the barriers of step b, so their HBM / L2 latency overlaps the (short) compute of the step.
 template <int NT>
 __device__ __forceinline__ void fwd_triangle(const double* __restrict__ L, int N, int nc, int rowEnd, const double* __restrict__ dblk,
     double* w1, int tid)
 {
+    double dn[NB], ln[NB]; // prefetched: column `tid`-th row of the next inverse block; L(i, kb..kb+31) of this thread's first row
+    auto fetch = [&](int kb, const double* blk) {
+        const int wd = min(NB, nc - kb);
+        if (tid < NB) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) dn[c] = blk[c * NB + tid];
+        }
+        const int i = kb + wd + tid;
+        if (i < rowEnd) {
+#pragma unroll
+            for (int k = 0; k < NB; ++k) ln[k] = (k < wd) ? L[i + (long long)N * (kb + k)] : 0.0;
+        }
+    };
+    if (nc > 0) fetch(0, dblk);
     for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
         const int wd = min(NB, nc - kb);
         double y = 0.0;
-        if (tid < NB) {
-#pragma unroll 8
-            for (int c = 0; c < NB; ++c) y += dblk[c * NB + tid] * ((c < wd) ? w1[kb + c] : 0.0);
+        if (tid < NB) { // four partial sums: a single accumulator is a 32-long dependent chain
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+            for (int c = 0; c < NB; c += 4) {
+                p0 += dn[c] * ((c < wd) ? w1[kb + c] : 0.0);
+                p1 += dn[c + 1] * ((c + 1 < wd) ? w1[kb + c + 1] : 0.0);
+                p2 += dn[c + 2] * ((c + 2 < wd) ? w1[kb + c + 2] : 0.0);
+                p3 += dn[c + 3] * ((c + 3 < wd) ? w1[kb + c + 3] : 0.0);
+            }
+            y = (p0 + p1) + (p2 + p3);
         }
         __syncthreads();
         if (tid < wd) w1[kb + tid] = y;
         __syncthreads();
-        for (int i = kb + wd + tid; i < rowEnd; i += NT) {
+        const int i0 = kb + wd + tid;
+        double acc0 = 0.0;
+        if (i0 < rowEnd) {
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+            for (int k = 0; k < NB; k += 4) {
+                p0 += ln[k] * ((k < wd) ? w1[kb + k] : 0.0);
+                p1 += ln[k + 1] * ((k + 1 < wd) ? w1[kb + k + 1] : 0.0);
+                p2 += ln[k + 2] * ((k + 2 < wd) ? w1[kb + k + 2] : 0.0);
+                p3 += ln[k + 3] * ((k + 3 < wd) ? w1[kb + k + 3] : 0.0);
+            }
+            acc0 = (p0 + p1) + (p2 + p3);
+        }
+        if (kb + NB < nc) fetch(kb + NB, dblk + NB * NB); // in flight across the barrier below and the next block solve
+        if (i0 < rowEnd) w1[i0] -= acc0;
+        for (int i = i0 + NT; i < rowEnd; i += NT) {
             double acc = 0.0;
 #pragma unroll 8
             for (int k = 0; k < wd; ++k) acc += L[i + (long long)N * (kb + k)] * w1[kb + k];
@@ -580,18 +655,29 @@ __device__ __forceinline__ void bwd_triangle(const double* __restrict__ L, int N
         __syncthreads();
         double x = 0.0;
         if (tid < NB) {
-#pragma unroll 8
-            for (int r = 0; r < NB; ++r) x += invs[tid * LDP + r] * ((r < wd) ? t[kb + r] : 0.0);
+            double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+            for (int r = 0; r < NB; r += 4) {
+                p0 += invs[tid * LDP + r] * ((r < wd) ? t[kb + r] : 0.0);
+                p1 += invs[tid * LDP + r + 1] * ((r + 1 < wd) ? t[kb + r + 1] : 0.0);
+                p2 += invs[tid * LDP + r + 2] * ((r + 2 < wd) ? t[kb + r + 2] : 0.0);
+                p3 += invs[tid * LDP + r + 3] * ((r + 3 < wd) ? t[kb + r + 3] : 0.0);
+            }
+            x = (p0 + p1) + (p2 + p3);
         }
         __syncthreads();
         if (tid < wd) t[kb + tid] = x;
         __syncthreads();
         for (int c = tid; c < kb; c += NT) {
             const double* Lc = L + (long long)N * c + kb;
-            double acc = 0.0;
+            double p0 = 0.0, p1 = 0.0;
 #pragma unroll 8
-            for (int k = 0; k < wd; ++k) acc += Lc[k] * t[kb + k];
-            t[c] -= acc;
+            for (int k = 0; k + 1 < wd; k += 2) {
+                p0 += Lc[k] * t[kb + k];
+                p1 += Lc[k + 1] * t[kb + k + 1];
+            }
+            if (wd & 1) p0 += Lc[wd - 1] * t[kb + wd - 1];
+            t[c] -= p0 + p1;
         }
         __syncthreads();
     }
@@ -770,7 +856,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_BIGN")) bigN = std::max(NB + 1, std::min(448, std::atoi(e)));
     plan_.assign(nLevels_, LevelPlan());
     std::vector<int> smallList, bigList;
-    std::vector<int2> ea;
+    std::vector<int4> ea;
     std::vector<int4> desc;
     size_t maxSmallLds = 0, maxSolveLds = 0, maxTriLds = 0;
     for (int l = 0; l < nLevels_; ++l) {
@@ -798,14 +884,14 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         maxSmallLds = std::max(maxSmallLds, P.smallLds);
         maxSolveLds = std::max(maxSolveLds, P.solveLds);
         maxTriLds = std::max(maxTriLds, P.triLds);
-        // extend-add descriptors (fronts with children only)
+        // extend-add descriptors (fronts with children only): lower-triangular 64 x 64 tiles of the parent
         P.ea.off = (int)ea.size();
         for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
             const int s = sym.levelFronts[i];
             if (sym.childPtr[s + 1] == sym.childPtr[s]) continue;
-            const long long total = (long long)sym.N(s) * sym.N(s);
-            const int chunks = (int)((total + WG * EA_ITEMS - 1) / (WG * EA_ITEMS));
-            for (int c = 0; c < chunks; ++c) ea.push_back(make_int2(s, c));
+            const int nt = (sym.N(s) + TS - 1) / TS;
+            for (int ti = 0; ti < nt; ++ti)
+                for (int tj = 0; tj <= ti; ++tj) ea.push_back(make_int4(s, ti, tj, 0));
         }
         P.ea.cnt = (int)ea.size() - P.ea.off;
         // big-front step descriptors: launch 0 factors panel 0, launch j + 1 applies panel j and factors panel j + 1
@@ -855,7 +941,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     smallList_.upload(smallList, stream);
     if (bigList.empty()) bigList.push_back(0);
     bigList_.upload(bigList, stream);
-    if (ea.empty()) ea.push_back(make_int2(0, 0));
+    if (ea.empty()) ea.push_back(make_int4(0, 0, 0, 0));
     eaDesc_.upload(ea.data(), ea.size(), stream);
     if (desc.empty()) desc.push_back(make_int4(0, 0, 0, 0));
     desc_.upload(desc.data(), desc.size(), stream);

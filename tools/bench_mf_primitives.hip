@@ -27,7 +27,10 @@ __global__ __launch_bounds__(WGB) void k_probe(double* A, long long* out, double
         x2[1][c] = x2[0][c] + 1.0;
     }
     long long t2 = __builtin_readcyclecounter();
-    if (tid < WG / 2) row_trsm32<2>(x2, blk, LDP, rd);
+    {
+        double(&x1)[1][NB] = reinterpret_cast<double(&)[1][NB]>(x2[0]);
+        if (tid < WG) row_trsm32<1>(x1, blk, LDP, rd);
+    }
     double s = 0;
 #pragma unroll
     for (int c = 0; c < NB; ++c) s += x2[0][c] + x2[1][c];
@@ -74,7 +77,7 @@ int main()
         hipLaunchKernelGGL(k_probe, dim3(rep == 2 ? 64 : 1), dim3(WGB), 0, 0, dA, dO, dS);
         long long o[4];
         hipMemcpy(o, dO, 32, hipMemcpyDeviceToHost);
-        std::printf("grid %2d: potrf32 %lld  row_trsm32<2>(2 waves) %lld  trinv32 %lld  row_update32 %lld  (cycles of the 100 MHz counter x ~24 = core clocks)\n",
+        std::printf("grid %2d: potrf32 %lld  row_trsm32<1>(4 waves) %lld  trinv32 %lld  row_update32 %lld  (cycles of the 100 MHz counter x ~24 = core clocks)\n",
             rep == 2 ? 64 : 1, o[0], o[1], o[2], o[3]);
     }
     return 0;
