@@ -42,6 +42,15 @@ class DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
 
+def pmc_traffic(size):
+    """HBM bytes per launch of the assembly kernel as measured with the PMC counters (same workload), or None."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_assembly_traffic.json")
+    if size != 150 or not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return float(json.load(f)["traffic_bytes"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -168,7 +177,9 @@ def main():
             "roofline": {
                 "kernel": "k_assemble_patch<true> (fused NH gradient + PSD-projected Hessian + mass/DBC diagonal -> symmetric-upper CSR, atomic-free)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": pmc_traffic(args.size),
+                "traffic_source": "profiles/r01_pmc_assembly_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
+                                  "calibrated in-run on a 1 GiB device copy (tools/pmc_traffic.py); bytes per launch",
                 "algorithmic_bytes": bytes_asm, "avg_launch_ms": ms_asm,
                 "measured_stream_copy_GBs": stream_gbs,
             },
