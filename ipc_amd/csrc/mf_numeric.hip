@@ -33,7 +33,8 @@ namespace {
 constexpr int NB = 32;
 constexpr int LDP = NB + 1; // padded leading dimension of 32x32 blocks in LDS
 constexpr int WG = 256;
-constexpr int WGB = WG + 64; // big-front step: four row waves + one pivot wave
+constexpr int WGB = WG; // big-front step: three row waves + one pivot wave, one per SIMD
+constexpr int ROWS_B = WGB - 64; // panel rows per role-B workgroup
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
 constexpr int TS = 64; // trailing-update tile
@@ -328,9 +329,9 @@ __global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ lis
 }
 
 // ---- big fronts: level-batched 32-column steps, one launch per step ------------------------------------
-// desc = (front, kb of the panel being applied or -1, a, b); 320 threads: four row waves + one pivot wave
+// desc = (front, kb of the panel being applied or -1, a, b); 256 threads: three row waves + one pivot wave
 //   b >= 0 : role A, trailing tile (ti, tj) = (a, b) of the matrix behind panel kb and panel kb+32
-//   b == -2: role B, rows [kb1 + a, kb1 + a + 256) of the next panel (kb1 = kb + 32, or 0 when kb == -1)
+//   b == -2: role B, rows [kb1 + a, kb1 + a + 192) of the next panel (kb1 = kb + 32, or 0 when kb == -1)
 __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
     double* __restrict__ dinv, int* __restrict__ flag)
 {
@@ -357,7 +358,6 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
             Bs[k][i] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kb + k)] : 0.0;
         }
         __syncthreads();
-        if (tid >= WG) return;
         const int ty = tid & 15, tx = tid >> 4;
         double acc[4][4];
 #pragma unroll
@@ -413,57 +413,50 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         }
     __syncthreads();
     const int R = kb1 + d.z + tid;
-    const bool rowThread = tid < WG && R >= kb1 + w1 && R < N;
+    const bool rowThread = tid < ROWS_B && R >= kb1 + w1 && R < N;
     double x[1][NB];
-    if (tid >= WG) {
-        // pivot wave: Cholesky of the 32x32 block while the row waves fetch and update their rows
-        if (wave_potrf32(A11, LDP, w1, tid - WG, rdiag)) atomicOr(flag, 1);
+    if (tid >= ROWS_B) {
+        // pivot wave (alone on its SIMD): Cholesky of the 32x32 block while the row waves fetch and update their rows
+        if (wave_potrf32(A11, LDP, w1, tid - ROWS_B, rdiag)) atomicOr(flag, 1);
     }
     else {
         // row waves: X(64 x 32) = raw - P_kb(64 x 32) Lp^T on the matrix cores.  v_mfma_f64_16x16x4_f64: A[l&15][l>>4],
         // B[l>>4][l&15], D col = l&15, row = (l>>4) + 4 reg.  One LDS read feeds 1024 FMAs instead of one.
         const int wv = tid >> 6, l = tid & 63;
         const int Rw = kb1 + d.z + 64 * wv; // first row of this wave
-        if (w > 0 && Rw < N) { // wave-uniform; a panel that has a successor is always full (w == NB)
-            f64x4 acc[4][2];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
-            const int ar = l & 15, ak = l >> 4;
-            const double* Fr[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) Fr[mt] = F + min(Rw + 16 * mt + ar, N - 1) + (long long)N * (kb + ak);
-#pragma unroll 2
-            for (int ks = 0; ks < NB / 4; ++ks) {
-                const double b0 = Lp[(4 * ks + ak) * LDP + ar], b1 = Lp[(4 * ks + ak) * LDP + 16 + ar];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const double a = Fr[mt][(long long)N * (4 * ks)];
-                    acc[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[mt][1], 0, 0, 0);
-                }
-            }
-            // the update goes straight into the front (rows below the pivot block only: the raw pivot block is still being
-            // read by the other workgroups); the wave then re-reads its rows one per lane
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int row = Rw + 16 * mt + ak + 4 * r;
-                    if (row >= kb1 + w1 && row < N) {
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) {
-                            const int col = 16 * nt + ar;
-                            if (col < w1) F[row + (long long)N * (kb1 + col)] -= acc[mt][nt][r];
-                        }
-                    }
-                }
-            __threadfence_block(); // the rows of a wave are produced by that wave
-        }
         if (rowThread) {
 #pragma unroll
             for (int c = 0; c < NB; ++c) x[0][c] = (c < w1) ? F[R + (long long)N * (kb1 + c)] : 0.0;
+        }
+        if (w > 0 && Rw < N) { // wave-uniform; a panel that has a successor is always full (w == NB)
+            const int ar = l & 15, ak = l >> 4;
+            double* T = sm + 2 * NB * LDP + NB + wv * (16 * LDP); // 16 x 32 staging tile of this wave
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                f64x4 acc0 = { 0.0, 0.0, 0.0, 0.0 }, acc1 = { 0.0, 0.0, 0.0, 0.0 };
+                const double* Fr = F + min(Rw + 16 * mt + ar, N - 1) + (long long)N * (kb + ak);
+#pragma unroll
+                for (int ks = 0; ks < NB / 4; ++ks) {
+                    const double a = Fr[(long long)N * (4 * ks)];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lp[(4 * ks + ak) * LDP + ar], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lp[(4 * ks + ak) * LDP + 16 + ar], acc1, 0, 0, 0);
+                }
+                // 16 rows of the update through LDS: written in the D layout, read back one row per lane by the 16 lanes
+                // that own those rows (same wave: LDS operations of a wave execute in order)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    T[(ak + 4 * r) * LDP + ar] = acc0[r];
+                    T[(ak + 4 * r) * LDP + 16 + ar] = acc1[r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if ((l >> 4) == mt) {
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) x[0][c] -= T[(l & 15) * LDP + c];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            }
         }
     }
     __syncthreads();
@@ -909,7 +902,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 const int kb1 = (j >= 0) ? kb + w : 0;
                 const int w1 = (kb1 < nc) ? std::min(NB, nc - kb1) : 0;
                 if (w1 > 0)
-                    for (int r0 = 0; r0 < N - kb1; r0 += WG) desc.push_back(make_int4(s, j >= 0 ? kb : -1, r0, -2));
+                    for (int r0 = 0; r0 < N - kb1; r0 += ROWS_B) desc.push_back(make_int4(s, j >= 0 ? kb : -1, r0, -2));
                 if (j >= 0) {
                     // trailing tiles inside the front's own columns; the Schur complement (columns >= nc) waits for k_big_schur
                     const int M0 = kb1 + w1;
