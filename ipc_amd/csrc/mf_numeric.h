@@ -9,6 +9,7 @@ namespace ipcgpu {
 class MfNumeric {
 public:
     MfNumeric() = default;
+    ~MfNumeric();
     MfNumeric(const MfNumeric&) = delete;
     MfNumeric& operator=(const MfNumeric&) = delete;
 
@@ -21,12 +22,19 @@ public:
     size_t front_bytes() const { return fronts_.n * sizeof(double); }
 
 private:
+    void enqueueFactor(const double* a_dev);
+    void enqueueSolve(const double* rhs_dev, double* x_dev);
+    void dropGraphs();
+    hipGraphExec_t graphF_ = nullptr, graphS_ = nullptr;
+    const double *graphA_ = nullptr, *graphRhs_ = nullptr;
+    double* graphX_ = nullptr;
+    bool useGraph_ = false; // IPCGPU_MF_GRAPH=1: measured neutral at mat150 (the level loop is GPU-chain-bound, not dispatch-bound)
     struct Range {
         int off = 0, cnt = 0;
     };
     struct LevelPlan {
         Range small; // into smallList_
-        size_t smallLds = 0, solveLds = 0, triLds = 0;
+        size_t smallLds = 0, solveLds = 0, triLds = 0, bwdLds = 0;
         Range ea; // extend-add descriptors
         Range bigFronts; // into bigList_
         std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1

@@ -166,24 +166,31 @@ __device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lan
     return bad;
 }
 
-// Inverse of a lower-triangular 32x32 block held k-major in LDS (blk[k * ld + r] = L(r, k)).  Lane c (< 32) produces column c
-// of X = L^-1 by forward substitution, keeping it in LDS (row-major: out[r * LDI + c] = X(r, c), so a lane's own column is
-// bank-conflict free); L(r, k) is the same address for every lane (LDS broadcast).
+// Inverse of a lower-triangular 32x32 block.  rows[r * ld + k] = L(r, k) for k < r and 1 / L(r, r) on the diagonal (LDS,
+// row-major so that a row is contiguous).  Lane c (< 32) produces column c of X = L^-1 by forward substitution with the
+// column in registers: X(r, c) = (delta_rc - sum_{k < r} L(r, k) X(k, c)) / L(r, r); L(r, k) is an LDS broadcast.  The reads
+// of row r are tied to X(r - 2, c) (see row_trsm32 for why) so that they run one row ahead of their use.
 constexpr int LDI = NB + 2;
-__device__ __forceinline__ void wave_trinv32(const double* blk, int ld, int lane, double* out)
+__device__ __forceinline__ void wave_trinv32(const double* rows, int ld, int lane, double* out)
 {
     if (lane >= NB) return;
-    double* col = out + lane;
+    double x[NB];
+#pragma unroll
     for (int r = 0; r < NB; ++r) {
+        int z = 0;
+        if (r >= 2) asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[r - 2])));
+        const double* lr = rows + r * ld + z;
         double acc0 = (r == lane) ? 1.0 : 0.0, acc1 = 0.0;
-        int k = 0;
-        for (; k + 1 < r; k += 2) {
-            acc0 -= blk[k * ld + r] * col[k * LDI];
-            acc1 -= blk[(k + 1) * ld + r] * col[(k + 1) * LDI];
+#pragma unroll
+        for (int k = 0; k + 1 < r; k += 2) {
+            acc0 -= lr[k] * x[k];
+            acc1 -= lr[k + 1] * x[k + 1];
         }
-        if (k < r) acc0 -= blk[k * ld + r] * col[k * LDI];
-        col[r * LDI] = (acc0 + acc1) / blk[r * ld + r];
+        if (r & 1) acc0 -= lr[r - 1] * x[r - 1];
+        x[r] = (acc0 + acc1) * lr[r];
     }
+#pragma unroll
+    for (int r = 0; r < NB; ++r) out[r * LDI + lane] = x[r];
 }
 
 // x <- x L^-T for one row held in registers (right-looking substitution: after x[k] is final it is swept out of the columns
@@ -223,12 +230,13 @@ __device__ __forceinline__ void row_trsm32(double (&x)[RW][NB], const double* bl
     }
 }
 
-// the factored pivot block goes to its `dinv` slot (k-major, identity-padded); k_invert_blocks turns it into L11^-1 at the end
-__device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int w, double* slot, int tid, int nthreads)
+// the factored pivot block goes to its `dinv` slot (k-major, identity-padded, 1 / L(k, k) on the diagonal); k_invert_blocks
+// turns it into L11^-1 at the end
+__device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int w, const double* rdiag, double* slot, int tid, int nthreads)
 {
     for (int e = tid; e < NB * NB; e += nthreads) {
         const int k = e >> 5, r = e & 31;
-        slot[e] = (k < w && r < w) ? (r >= k ? blk[k * ld + r] : 0.0) : (r == k ? 1.0 : 0.0);
+        slot[e] = (k < w && r < w) ? (r > k ? blk[k * ld + r] : (r == k ? rdiag[k] : 0.0)) : (r == k ? 1.0 : 0.0);
     }
 }
 
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(64) void k_invert_blocks(double* __restrict__ dinv)
     __shared__ double Xs[NB * LDI];
     double* blk = dinv + (long long)blockIdx.x * (NB * NB);
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 64) Ls[(e >> 5) * LDP + (e & 31)] = blk[e];
+    for (int e = tid; e < NB * NB; e += 64) Ls[(e & 31) * LDP + (e >> 5)] = blk[e]; // transposed: row-major
     __syncthreads();
     wave_trinv32(Ls, LDP, tid, Xs);
     __syncthreads();
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ lis
         __syncthreads();
         if (tid < 64) bad |= wave_potrf32(P, m, w, tid, rdiag);
         __syncthreads();
-        store_pivot_block(P, m, w, dblk, tid, WG);
+        store_pivot_block(P, m, w, rdiag, dblk, tid, WG);
         // rows below the pivot block: X L11^T = A21, one row per thread
         for (int r = w + tid; r < m; r += WG) {
             double x[1][NB];
@@ -467,7 +475,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         for (int c = 0; c < NB; ++c)
             if (c < w1) out[(long long)N * c] = x[0][c];
     }
-    if (d.z == 0) store_pivot_block(A11, LDP, w1, dinv + (tv.dinvOff[s] + kb1 / NB) * (NB * NB), tid, WGB);
+    if (d.z == 0) store_pivot_block(A11, LDP, w1, rdiag, dinv + (tv.dinvOff[s] + kb1 / NB) * (NB * NB), tid, WGB);
 }
 
 // Schur complement of a big front in one pass: S(i, j) -= sum_{c < nc} L(i, c) L(j, c) for i, j >= nc.  Doing this per
@@ -773,6 +781,7 @@ __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, 
 __global__ __launch_bounds__(WG) void k_big_bwd_init(const int4* __restrict__ desc, TreeView tv, const double* __restrict__ fronts,
     double* __restrict__ yperm, const double* __restrict__ xsol)
 {
+    extern __shared__ double x2[]; // x of the ancestors in this front's row order, gathered once per workgroup
     const int4 d = desc[blockIdx.x];
     const int s = d.x;
     const int N = frontN(tv, s), nc = frontNc(tv, s);
@@ -780,13 +789,22 @@ __global__ __launch_bounds__(WG) void k_big_bwd_init(const int4* __restrict__ de
     const int* idx = tv.idx + tv.idxPtr[s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col0 = 3 * tv.firstNode[s];
+    for (int r = nc + threadIdx.x; r < N; r += WG) {
+        const int rn = r / 3;
+        x2[r - nc] = xsol[3 * idx[rn] + (r - 3 * rn)];
+    }
+    __syncthreads();
     for (int c = d.y + wave; c < min(nc, d.y + 16); c += WG / 64) {
-        double acc = 0.0;
-        const double* Lc = L + (long long)N * c;
-        for (int r = nc + lane; r < N; r += 64) {
-            const int rn = r / 3;
-            acc += Lc[r] * xsol[3 * idx[rn] + (r - 3 * rn)];
+        double acc0 = 0.0, acc1 = 0.0;
+        const double* Lc = L + (long long)N * c + nc;
+        const int m = N - nc;
+        int r = lane;
+        for (; r + 64 < m; r += 128) {
+            acc0 += Lc[r] * x2[r];
+            acc1 += Lc[r + 64] * x2[r + 64];
         }
+        if (r < m) acc0 += Lc[r] * x2[r];
+        double acc = acc0 + acc1;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
         if (lane == 0) yperm[col0 + c] -= acc;
@@ -815,6 +833,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
 {
     sym_ = &sym;
     stream_ = stream;
+    dropGraphs();
+    if (const char* e = std::getenv("IPCGPU_MF_GRAPH")) useGraph_ = std::atoi(e) != 0;
     ns_ = sym.ns;
     nLevels_ = (int)sym.levelPtr.size() - 1;
     fronts_.alloc((size_t)sym.frontOff[ns_]);
@@ -851,7 +871,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     std::vector<int> smallList, bigList;
     std::vector<int4> ea;
     std::vector<int4> desc;
-    size_t maxSmallLds = 0, maxSolveLds = 0, maxTriLds = 0;
+    size_t maxSmallLds = 0, maxSolveLds = 0, maxTriLds = 0, maxBwdLds = 0;
     for (int l = 0; l < nLevels_; ++l) {
         LevelPlan& P = plan_[l];
         std::vector<int> small, big;
@@ -874,6 +894,12 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         P.smallLds = (size_t)(NB * maxN + 8) * sizeof(double);
         P.solveLds = (size_t)std::max(maxN, 1) * sizeof(double);
         P.triLds = (size_t)std::max(maxNc, 1) * sizeof(double);
+        {
+            int maxBelow = 1;
+            for (int s : big) maxBelow = std::max(maxBelow, sym.N(s) - sym.nc(s));
+            P.bwdLds = (size_t)maxBelow * sizeof(double);
+            maxBwdLds = std::max(maxBwdLds, P.bwdLds);
+        }
         maxSmallLds = std::max(maxSmallLds, P.smallLds);
         maxSolveLds = std::max(maxSolveLds, P.solveLds);
         maxTriLds = std::max(maxTriLds, P.triLds);
@@ -944,6 +970,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
     }
+    if (maxBwdLds > 48 * 1024)
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_big_bwd_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxBwdLds));
     if (maxTriLds > 48 * 1024) {
         if (maxTriLds > 150 * 1024) throw StateError("a separator front is too wide for the single-workgroup triangular sweep");
         HIP_CHECK(hipFuncSetAttribute((const void*)k_big_fwd_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxTriLds));
@@ -952,9 +980,50 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
+MfNumeric::~MfNumeric() { dropGraphs(); }
+
+void MfNumeric::dropGraphs()
+{
+    if (graphF_) (void)hipGraphExecDestroy(graphF_);
+    if (graphS_) (void)hipGraphExecDestroy(graphS_);
+    graphF_ = graphS_ = nullptr;
+}
+
+// The launch sequences are static for a given analysis (same descriptors, same buffers), so they are captured once into
+// hipGraphs and replayed: ~130 (factor) / ~90 (solve) launches per call otherwise each pay the host-side dispatch path.
+template <class Enqueue>
+static void replay(hipStream_t stream, hipGraphExec_t& exec, bool& valid, Enqueue&& enqueue)
+{
+    if (!valid) {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        exec = nullptr;
+        hipGraph_t g = nullptr;
+        HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        enqueue();
+        HIP_CHECK(hipStreamEndCapture(stream, &g));
+        HIP_CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        valid = true;
+    }
+    HIP_CHECK(hipGraphLaunch(exec, stream));
+}
+
 bool MfNumeric::factorize(const double* a_dev)
 {
     if (!sym_) throw StateError("factorize before analyze_pattern");
+    if (useGraph_) {
+        bool valid = graphF_ && graphA_ == a_dev;
+        replay(stream_, graphF_, valid, [&] { enqueueFactor(a_dev); });
+        graphA_ = a_dev;
+    }
+    else enqueueFactor(a_dev);
+    HIP_CHECK(hipMemcpyAsync(hflag_.p, flag_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return hflag_.p[0] == 0;
+}
+
+void MfNumeric::enqueueFactor(const double* a_dev)
+{
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     fronts_.zero(stream_);
@@ -973,14 +1042,22 @@ bool MfNumeric::factorize(const double* a_dev)
     }
     // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)
     hipLaunchKernelGGL(k_invert_blocks, dim3((unsigned)nDiagBlocks_), dim3(64), 0, stream_, dinv_.p);
-    HIP_CHECK(hipMemcpyAsync(hflag_.p, flag_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
-    HIP_CHECK(hipStreamSynchronize(stream_));
-    return hflag_.p[0] == 0;
 }
 
 void MfNumeric::solve(const double* rhs_dev, double* x_dev)
 {
     if (!sym_) throw StateError("solve before analyze_pattern");
+    if (useGraph_) {
+        bool valid = graphS_ && graphRhs_ == rhs_dev && graphX_ == x_dev;
+        replay(stream_, graphS_, valid, [&] { enqueueSolve(rhs_dev, x_dev); });
+        graphRhs_ = rhs_dev;
+        graphX_ = x_dev;
+    }
+    else enqueueSolve(rhs_dev, x_dev);
+}
+
+void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
+{
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     const int n3 = sym.n;
@@ -1000,7 +1077,7 @@ void MfNumeric::solve(const double* rhs_dev, double* x_dev)
     for (int l = nLevels_ - 1; l >= 0; --l) {
         const LevelPlan& P = plan_[l];
         if (P.bwdInit.cnt)
-            hipLaunchKernelGGL(k_big_bwd_init, dim3(P.bwdInit.cnt), dim3(WG), 0, stream_, desc_.p + P.bwdInit.off, tv, fronts_.p, yperm_.p,
+            hipLaunchKernelGGL(k_big_bwd_init, dim3(P.bwdInit.cnt), dim3(WG), P.bwdLds, stream_, desc_.p + P.bwdInit.off, tv, fronts_.p, yperm_.p,
                 xsol_.p);
         if (P.bigFronts.cnt)
             hipLaunchKernelGGL(k_big_bwd_tri, dim3(P.bigFronts.cnt), dim3(WGT), P.triLds, stream_, bigList_.p + P.bigFronts.off, tv, fronts_.p,
