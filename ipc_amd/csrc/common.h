@@ -69,6 +69,7 @@ struct DevBuf {
 template <class T>
 struct PinnedBuf {
     T* p = nullptr;
+    T* dev = nullptr; // the same memory as seen by kernels: small results are written here directly instead of being copied
     size_t n = 0;
     ~PinnedBuf()
     {
@@ -77,7 +78,8 @@ struct PinnedBuf {
     void alloc(size_t count)
     {
         if (p) (void)hipHostFree(p);
-        HIP_CHECK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocDefault));
+        HIP_CHECK(hipHostMalloc((void**)&p, count * sizeof(T), hipHostMallocMapped | hipHostMallocPortable));
+        HIP_CHECK(hipHostGetDevicePointer((void**)&dev, p, 0));
         n = count;
     }
 };

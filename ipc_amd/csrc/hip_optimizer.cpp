@@ -132,7 +132,7 @@ void HipOptimizer::reduceMin(double* dev, long long n)
 }
 double HipOptimizer::readScalar(const double* dev)
 {
-    HIP_CHECK(hipMemcpyAsync(h_scalar.p, dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+    launch_publish(dev, h_scalar.dev, 2, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
     return h_scalar.p[0];
 }
@@ -419,7 +419,7 @@ bool HipOptimizer::checkInversion()
 {
     d_flag.zero(stream);
     launch_check_inversion(view(), d_flag.p, stream);
-    HIP_CHECK(hipMemcpyAsync(h_flag.p, d_flag.p, sizeof(int), hipMemcpyDeviceToHost, stream));
+    launch_publish(d_flag.p, h_flag.dev, 1, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
     int f = h_flag.p[0];
     if (worldSize > 1) {

@@ -55,6 +55,8 @@ struct TreeView {
 __device__ __forceinline__ int frontN(const TreeView& tv, int s) { return 3 * (tv.idxPtr[s + 1] - tv.idxPtr[s]); }
 __device__ __forceinline__ int frontNc(const TreeView& tv, int s) { return 3 * (tv.firstNode[s + 1] - tv.firstNode[s]); }
 
+__global__ void k_publish_flag(const int* __restrict__ flag, int* __restrict__ mapped) { mapped[0] = flag[0]; }
+
 __global__ void k_scatter_a(int nnz, const double* __restrict__ a, const long long* __restrict__ dst, double* __restrict__ fronts)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1017,7 +1019,7 @@ bool MfNumeric::factorize(const double* a_dev)
         graphA_ = a_dev;
     }
     else enqueueFactor(a_dev);
-    HIP_CHECK(hipMemcpyAsync(hflag_.p, flag_.p, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, stream_, flag_.p, hflag_.dev); // mapped pinned memory: no blit
     HIP_CHECK(hipStreamSynchronize(stream_));
     return hflag_.p[0] == 0;
 }

@@ -47,6 +47,8 @@ void launch_step_forward(int n3, const double* x0, const double* p, double alpha
 void launch_max_abs(int n, const double* v, double* out /*preset 0*/, hipStream_t s);
 void launch_fill(double* p, size_t n, double v, hipStream_t s);
 void launch_negate(int n, const double* in, double* out, hipStream_t s);
+// copies nWords 4-byte words from device memory into mapped pinned host memory (a ~24 us blit per scalar read-back otherwise)
+void launch_publish(const void* src_dev, void* dst_mapped, int nWords, hipStream_t s);
 void launch_colmajor_to_aos(int nV, const double* src, double* dst, hipStream_t s);
 void launch_aos_to_colmajor(int nV, const double* src, double* dst, hipStream_t s);
 // symmetric-upper CSR times vector and diagonal preconditioner (LinSysSolver.hpp:238-253, 411-420)

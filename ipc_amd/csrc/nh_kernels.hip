@@ -463,4 +463,14 @@ void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, doub
     if (nH) hipLaunchKernelGGL(k_twist_dir, dim3(nblk(nH)), dim3(BLOCK), 0, s, nH, ids, ang, cy, cz, x, p);
 }
 
+__global__ void k_publish(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n)
+{
+    const int i = threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+void launch_publish(const void* src_dev, void* dst_mapped, int nWords, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, (const unsigned*)src_dev, (unsigned*)dst_mapped, nWords);
+}
+
 } // namespace ipcgpu
