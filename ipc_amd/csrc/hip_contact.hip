@@ -247,11 +247,15 @@ __device__ inline void scatter_blocks(const CsrView& m, double* a, const double*
 }
 
 // a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201)
-__global__ __launch_bounds__(64) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
+// HESS_T stencils per workgroup: the two 12x12 matrices the Jacobi sweeps iterate on sit in LDS (2 x 144 x 8 B per stencil)
+constexpr int HESS_T = 32;
+__global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
     double kappa, double* __restrict__ a, int* __restrict__ err)
 {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    double H[144], B[144], Q[144], W[144];
+    __shared__ double jac[2 * 144 * HESS_T];
+    const int i = blockIdx.x * HESS_T + threadIdx.x;
+    const Strided Qs{ jac + threadIdx.x, HESS_T }, Ws{ jac + 144 * HESS_T + threadIdx.x, HESS_T };
+    double H[144], B[144];
     if (i < cv.nA) {
         const Stencil s = decode(cv.active + 4 * (size_t)i);
         double X[4][3], g[12], b, gb, Hb;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(64) void k_contact_hessian(ContactView cv, CsrView 
         for (int k = 0; k < 144; ++k) B[k] = 0.0;
         for (int r = 0; r < n3; ++r)
             for (int c = 0; c < n3; ++c) B[r + 12 * c] = ((cf * Hb) * g[r]) * g[c] + (cf * gb) * H[r + 12 * c];
-        make_pd(n3, B, Q, W);
+        atomicAdd(err + 1, make_pd(n3, B, Qs, Ws)); // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it)
         scatter_blocks(m, a, B, s.node, s.n, dbc, projectDBC, err);
     }
     else if (i < cv.nA + cv.nP) {
@@ -276,8 +280,9 @@ __global__ __launch_bounds__(64) void k_contact_hessian(ContactView cv, CsrView 
         int en[4];
         paraNodes(cv, j, en);
         double XE[4][3], cg[12], e, eg, eH;
+        double Q[144], W[144]; // Hessian of the cross norm, H_d on the edge nodes (used once each; the mollified set is small)
         gatherX(cv.x, en, 4, XE);
-        const double c = cross_sqnorm_derivs(XE, cg, Q); // Q = Hessian of the cross norm for now
+        const double c = cross_sqnorm_derivs(XE, cg, Q);
         mollifier(c, eps_x_of(cv.xRest, en[0], en[1], en[2], en[3]), &e, &eg, &eH);
         // distance derivatives mapped onto the four edge nodes (SelfCollisionHandler.cpp:3105-3160)
         int imap[4] = { 0, 0, 0, 0 };
@@ -300,7 +305,7 @@ __global__ __launch_bounds__(64) void k_contact_hessian(ContactView cv, CsrView 
                 B[r + 12 * cc] = (kappa * gb) * gd[r] * e_g_c + (kappa * gb) * gd[cc] * e_g_r + (kappa * b) * e_H + ((kappa * e * Hb) * gd[r]) * gd[cc]
                     + (kappa * e * gb) * W[r + 12 * cc];
             }
-        make_pd(12, B, Q, W);
+        make_pd(12, B, Qs, Ws);
         scatter_blocks(m, a, B, en, 4, dbc, projectDBC, err);
     }
 }
@@ -1008,9 +1013,10 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(2);
     counters_.zero(stream);
-    hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, 64)), dim3(64), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, a_dev, counters_.p);
+    hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, a_dev, counters_.p);
     int err[2];
     counters_.download(err, 2, stream);
+    if (std::getenv("IPCGPU_DEBUG")) std::fprintf(stderr, "[ipcgpu] barrier Hessian: %d stencils, %.2f Jacobi sweeps on average\n", n, (double)err[1] / n);
     if (err[0]) throw StateError("barrier Hessian touches a node pair outside the CSR pattern: call set_pattern with the contact connectivity first");
 }
 

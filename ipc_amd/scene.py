@@ -65,6 +65,20 @@ def make_mat(n: int, thickness_ratio: float = 0.013):
     return V, F
 
 
+def make_mat_stack(n: int, layers: int = 2, gap: float = 1.0e-3, thickness_ratio: float = 0.013, shift: float = 0.37):
+    """`layers` matN sheets stacked along y with `gap` between them, each shifted sideways by a fraction of the grid
+    spacing ("stack of k mats with gaps < sqrt(dHat) for a large active set").
+    Returns V, F and the node count of one sheet."""
+    Vs, Fs = [], []
+    h = 1.0 / (n - 1)
+    for k in range(layers):
+        V, F = make_mat(n, thickness_ratio)
+        V = V + np.array([shift * h * k, k * (thickness_ratio + gap), 0.61 * shift * h * k])
+        Fs.append(F + sum(v.shape[0] for v in Vs))
+        Vs.append(V)
+    return np.vstack(Vs), np.vstack(Fs).astype(np.int32), Vs[0].shape[0]
+
+
 def make_bar(ncx=20, ncy=2, ncz=2, size=(10.0, 0.5, 1.0)):
     """Hello-world bar of SURVEY.md 8(d) config 1 (480 tets by default)."""
     return make_box(ncx, ncy, ncz, size=size, origin=(-size[0] / 2, -size[1] / 2, -size[2] / 2))

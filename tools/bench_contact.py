@@ -1,0 +1,62 @@
+"""Contact half of the hot path on hardware: a stack of mats, the upper ones falling on the clamped lowest one, self-collision on.
+Reports the per-iteration split by the reference's timer buckets and the constraint-set sizes; run under
+`rocprofv3 --kernel-trace --stats` for the per-kernel table committed as profiles/r01_contact_kernel_stats.md.
+usage: python tools/bench_contact.py [--n 60] [--layers 2] [--steps 3] [--max-iter 12]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ipc_amd import lib, scene  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=60)
+ap.add_argument("--layers", type=int, default=2)
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--max-iter", type=int, default=12)
+ap.add_argument("--gap", type=float, default=1.2e-3)
+args = ap.parse_args()
+
+V, F, nA = scene.make_mat_stack(args.n, args.layers, gap=args.gap)
+Vs = scene.jitter(V, F, rel=2e-3)
+SF = scene.surface_tris(F)
+c = lib.Context(0)
+c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+c.set_positions(Vs)
+c.opt_init(0.01, True)
+c.set_surface(SF)
+low = np.arange(nA)
+border = low[(np.abs(V[:nA, 0]) > 0.49) | (np.abs(V[:nA, 2]) > 0.49)].astype(np.int32)
+c.set_dbc(border, 1)
+c.enable_self_collision(1e-3)
+vel = np.zeros_like(V)
+vel[nA:, 1] = -0.05
+c.set_velocity(vel)
+t0 = time.time()
+c.precompute()
+t_pre = time.time() - t0
+tm0 = c.timers()
+iters, counts = 0, []
+t0 = time.time()
+for step in range(args.steps):
+    c.begin_timestep()
+    for it in range(args.max_iter):
+        if c.newton_iter():
+            break
+        iters += 1
+    c.end_timestep()
+    counts.append(c.contact_state())
+wall = time.time() - t0
+tm = c.timers() - tm0
+names = {0: "assembly+barrier_hessian", 1: "set_pattern", 2: "symbolic_analysis", 3: "factor", 4: "solve", 5: "linesearch_moves+intersection",
+         9: "energy_evals", 13: "step_bounds(inversion+CCD+CFL)", 14: "constraint_sets", 11: "timestep"}
+split = {v: 1e3 * tm[k] / max(iters, 1) for k, v in names.items()}
+print(json.dumps({
+    "scene": f"{args.layers} x mat{args.n} stack, gap {args.gap}, dHat 1e-3, self-collision on", "n_nodes": int(V.shape[0]), "n_tets": int(F.shape[0]),
+    "n_surface_tris": int(SF.shape[0]), "newton_iterations": iters, "iters_per_s": iters / wall, "ms_per_iter_wall": 1e3 * wall / max(iters, 1),
+    "precompute_s": t_pre, "split_ms_per_iter": split, "contact_state_per_step": counts, "intersected_at_end": bool(c.is_intersected()),
+}))
