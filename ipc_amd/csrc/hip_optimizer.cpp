@@ -7,7 +7,9 @@
 //   computeEnergyVal / computeGradient / computePrecondMtr   Optimizer.cpp:3199-3239, 3409-3450, 3549-3668
 // Per Newton iteration only a handful of scalars cross PCIe (energies, step bound, |p|_inf, not-PD flag).
 #include "hip_ipc.h"
+#include <algorithm>
 #include <chrono>
+#include <iterator>
 #include <cmath>
 #include <cstring>
 
@@ -375,18 +377,25 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         }
         std::sort(fresh.begin(), fresh.end());
         fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
-        if (fresh != curExtra) {
-            curExtra = fresh;
+        // The reference rebuilds pattern + symbolic analysis whenever the contact graph changes (:3570-3592).  Here the pattern
+        // only ever GROWS inside the stepper: pairs that left the constraint set keep their (zero) slots, so a new analysis is
+        // needed only when a pair shows up that no earlier iteration had.  Same matrix, fewer host-side analyses; the
+        // union is dropped again once it has grown far beyond the live set.
+        if (!std::includes(curExtra.begin(), curExtra.end(), fresh.begin(), fresh.end())) {
+            std::vector<std::pair<int, int>> merged;
+            std::set_union(curExtra.begin(), curExtra.end(), fresh.begin(), fresh.end(), std::back_inserter(merged));
+            if (merged.size() > 3 * fresh.size() + 4096) merged = fresh;
+            curExtra.swap(merged);
             nPatternChanges++;
             std::vector<int> flat;
-            flat.reserve(2 * fresh.size());
-            for (const auto& e : fresh) {
+            flat.reserve(2 * curExtra.size());
+            for (const auto& e : curExtra) {
                 flat.push_back(e.first);
                 flat.push_back(e.second);
             }
             {
                 Tic t(timers[1], stream);
-                lin.set_pattern(mesh, (int)fresh.size(), flat.data());
+                lin.set_pattern(mesh, (int)curExtra.size(), flat.data());
             }
             Tic t(timers[2], stream);
             lin.analyze_pattern(&mesh);
