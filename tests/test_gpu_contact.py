@@ -359,3 +359,54 @@ def test_half_space_newton_iterates_track_the_oracle(orc, gpu_lib):
         assert ((c.state()["V"] - origin) @ nrm).min() > 0
     assert touched > 0 and limited > 0
     c.close()
+
+
+def test_mat_stack_sets_and_iterates_at_moderate_size(orc, gpu_lib):
+    """SURVEY 8(d) config 5 in small: two mat sheets closer than sqrt(dHat) -- thousands of active pairs, a broad-phase grid
+    with many primitives per cell, duplicate PP / PE merges -- sets bit-exact, then the stepper iterate by iterate."""
+    V, F, nA = scene.make_mat_stack(14, 2, gap=1.2e-3)
+    Vs = scene.jitter(V, F, rel=2e-3)
+    SF = scene.surface_tris(F)
+    border = np.nonzero((np.abs(V[:nA, 0]) > 0.49) | (np.abs(V[:nA, 2]) > 0.49))[0].astype(np.int32)
+    vel = np.zeros_like(V)
+    vel[nA:, 1] = -0.05
+    m = orc.Mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_dbc(border, 1)
+    m.set_V(Vs)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+    c.set_dbc(border, 1)
+    c.set_positions(Vs)
+    c.opt_init(0.01, True)
+    c.set_surface(SF)
+    dHat = 1e-6 * m.features()["bboxDiag2"]
+    o_sets = orc.Contacts().build(m, dHat)
+    g_sets = c.contact_build(dHat)
+    assert len(o_sets["active"]) > 1000
+    for k in ("active", "para", "para_eiej", "cs_ptee"):
+        assert np.array_equal(g_sets[k], o_sets[k]), k
+    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=4)
+    orc.opt_enable_self_collision(o, 1e-3)
+    orc.opt_set_velocity(o, vel)
+    c.enable_self_collision(1e-3)
+    c.set_velocity(vel)
+    o.precompute()
+    c.precompute()
+    for step in range(2):
+        o.begin_timestep()
+        c.begin_timestep()
+        for it in range(30):
+            co, cg = o.newton_iter(), c.newton_iter()
+            assert co == cg, (step, it)
+            if co:
+                break
+            so, sg = o.state(), c.state()
+            assert c.contact_state()["nActive"] == len(orc.opt_contact_state(o)["active"]), (step, it)
+            assert abs(sg["stepSize"] - so["stepSize"]) <= 1e-8 * so["stepSize"], (step, it)
+            assert abs(sg["E"] - so["E"]) <= 1e-8 * abs(so["E"]), (step, it)
+            assert relerr(sg["V"], so["V"]) < 1e-8, (step, it)
+        o.end_timestep()
+        c.end_timestep()
+    assert not c.is_intersected()
+    c.close()
