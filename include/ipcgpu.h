@@ -66,6 +66,9 @@ int ipcgpu_set_mesh(ipcgpu_ctx*, int nV, int nT, const double* V_rest_colmajor,
 /* vertexDBCType (Mesh.hpp:131-144) */
 int ipcgpu_set_dbc(ipcgpu_ctx*, int n, const int* vert_ids, int dbc_type);
 int ipcgpu_clear_dbc(ipcgpu_ctx*);
+/* one `componentMaterial` entry of Mesh::setLameParam (Mesh.cpp:661-671; `shapes ... material rho E nu` in the scene script):
+ * nodes [nodeBegin, nodeEnd) get density rho, tets [tetBegin, tetEnd) get (YM, PR).  Call after ipcgpu_set_mesh. */
+int ipcgpu_set_component_material(ipcgpu_ctx*, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR);
 /* Mesh::V (current positions) */
 int ipcgpu_set_positions(ipcgpu_ctx*, const double* V_colmajor);
 int ipcgpu_get_positions(ipcgpu_ctx*, double* V_colmajor);

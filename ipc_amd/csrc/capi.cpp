@@ -162,6 +162,17 @@ int ipcgpu_set_mesh(ipcgpu_ctx* c, int nV, int nT, const double* Vr, const int* 
         return IPCGPU_OK;
     });
 }
+int ipcgpu_set_component_material(ipcgpu_ctx* c, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        needArg(0 <= nodeBegin && nodeBegin <= nodeEnd && nodeEnd <= m.nV && 0 <= tetBegin && tetBegin <= tetEnd && tetEnd <= m.nT, "range out of bounds");
+        needArg(rho > 0 && YM > 0 && PR > -1.0 && PR < 0.5, "bad material");
+        m.setComponentMaterial(nodeBegin, nodeEnd, tetBegin, tetEnd, rho, YM, PR, c->stream);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_set_dbc(ipcgpu_ctx* c, int n, const int* ids, int type)
 {
     return guarded([&] {

@@ -39,6 +39,8 @@ public:
     // Mesh::computeFeatures + computeMassMatrix + setLameParam (Mesh.cpp:414-527, 246-266, 399-401, 660-671)
     void computeFeatures(int nV, int nT, const double* Vrest, const int* F, double YM, double PR, double density, hipStream_t s);
     void uploadDBC(hipStream_t s);
+    double density = 0; // global density handed to computeFeatures (component overrides rescale the nodal mass by rho / density)
+    void setComponentMaterial(int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR, hipStream_t s);
     bool isDBCVertex(int v) const { return dbcType[v] != 0; }
     bool isProjectDBCVertex(int v, bool projectDBC) const { return dbcType[v] == 1 || (dbcType[v] == 2 && projectDBC); }
 };

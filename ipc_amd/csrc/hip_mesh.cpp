@@ -69,6 +69,7 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
     }
     avgEdgeLen = nT ? edgeSum / (6.0 * nT) : 0.0;
     for (int v = 0; v < nV; ++v) mass[v] *= density; // Mesh.cpp:399
+    this->density = density;
     mu.assign(nT, YM / 2.0 / (1.0 + PR)); // Mesh.cpp:663-664
     lam.assign(nT, YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR));
     // vNeighbor (Mesh.cpp:470-479); surface triangles of a tet mesh only repeat tet edges
@@ -111,6 +112,20 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
 void HipMesh::uploadDBC(hipStream_t s)
 {
     d_dbc.upload(dbcType, s);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void HipMesh::setComponentMaterial(int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR, hipStream_t s)
+{
+    // Mesh::setLameParam, componentMaterial branch (Mesh.cpp:665-671)
+    for (int v = nodeBegin; v < nodeEnd; ++v) mass[v] *= rho / density;
+    for (int t = tetBegin; t < tetEnd; ++t) {
+        mu[t] = YM / 2.0 / (1.0 + PR);
+        lam[t] = YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR);
+    }
+    d_mass.upload(mass, s);
+    d_mu.upload(mu, s);
+    d_lam.upload(lam, s);
     HIP_CHECK(hipStreamSynchronize(s));
 }
 

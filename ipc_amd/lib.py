@@ -140,6 +140,10 @@ class Context:
         ids = _i32(ids)
         self._chk(self._L.ipcgpu_set_dbc(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(typ)))
 
+    def set_component_material(self, node_range, tet_range, density, YM, PR):
+        self._chk(self._L.ipcgpu_set_component_material(self.h, C.c_int(node_range[0]), C.c_int(node_range[1]), C.c_int(tet_range[0]),
+                                                        C.c_int(tet_range[1]), C.c_double(density), C.c_double(YM), C.c_double(PR)))
+
     def clear_dbc(self):
         self._chk(self._L.ipcgpu_clear_dbc(self.h))
 

@@ -130,6 +130,10 @@ class Mesh:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         lib().orc_mesh_set_dbc(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(typ))
 
+    def set_component_material(self, node_range, tet_range, density, YM, PR):
+        lib().orc_mesh_set_component_material(self.h, C.c_int(node_range[0]), C.c_int(node_range[1]), C.c_int(tet_range[0]), C.c_int(tet_range[1]),
+                                              C.c_double(density), C.c_double(YM), C.c_double(PR))
+
     def clear_dbc(self):
         lib().orc_mesh_clear_dbc(self.h)
 

@@ -562,6 +562,16 @@ void orc_mesh_set_dbc(orc_mesh* h, int n, const int* vids, int type)
 {
     for (int i = 0; i < n; ++i) h->m.dbcType[vids[i]] = type;
 }
+void orc_mesh_set_component_material(orc_mesh* h, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR)
+{
+    // Mesh::setLameParam with a componentMaterial entry (Mesh.cpp:661-671): nodal mass rescaled, Lame parameters of the element range
+    Mesh& m = h->m;
+    for (int v = nodeBegin; v < nodeEnd; ++v) m.mass[v] *= rho / m.density;
+    for (int t = tetBegin; t < tetEnd; ++t) {
+        m.mu[t] = YM / 2.0 / (1.0 + PR);
+        m.lam[t] = YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR);
+    }
+}
 void orc_mesh_clear_dbc(orc_mesh* h) { std::fill(h->m.dbcType.begin(), h->m.dbcType.end(), 0); }
 void orc_mesh_set_V(orc_mesh* h, const double* V) { h->m.V.assign(V, V + 3 * h->m.nV); }
 void orc_mesh_get_V(const orc_mesh* h, double* V) { std::memcpy(V, h->m.V.data(), sizeof(double) * 3 * h->m.nV); }
