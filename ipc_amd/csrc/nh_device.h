@@ -40,6 +40,33 @@ __device__ __forceinline__ void load_A(const ElemView& v, int t, double A[9])
     for (int k = 0; k < 9; ++k) A[k] = v.A[(size_t)k * v.nT + t];
 }
 
+// Reciprocal / reciprocal square root / square root from the hardware seeds (v_rcp_f64, v_rsq_f64) plus two Newton
+// steps: ~10 dependent instructions instead of the ~35 of the IEEE-exact expansions.  Used only inside the Jacobi
+// iterations (SVD, 3x3 eigen-solve), whose fixed point does not depend on the last bit of an individual rotation.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-x, r, 1.0);
+    return fma(r, e, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double r = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * r, r, 1.0);
+    r = fma(0.5 * r, e, r);
+    e = fma(-x * r, r, 1.0);
+    return fma(0.5 * r, e, r);
+}
+__device__ __forceinline__ double fast_sqrt(double x)
+{
+    if (!(x > 0.0)) return 0.0;
+    const double r = fast_rsqrt(x);
+    const double s = x * r;
+    return fma(fma(-s, s, x), 0.5 * r, s);
+}
+
 // One-sided Jacobi SVD  F = U diag(s) V^T with the output convention of the reference's SVD
 // (ImplicitQRSVD.h:681-850): U, V rotations, |s0|>=|s1|>=|s2|, only s2 may be negative.
 __device__ inline void svd3(const double Fin[9], double U[9], double s[3], double V[9])
@@ -60,11 +87,11 @@ __device__ inline void svd3(const double Fin[9], double U[9], double s[3], doubl
             double al = G[3 * p] * G[3 * p] + G[3 * p + 1] * G[3 * p + 1] + G[3 * p + 2] * G[3 * p + 2];
             double be = G[3 * q] * G[3 * q] + G[3 * q + 1] * G[3 * q + 1] + G[3 * q + 2] * G[3 * q + 2];
             double ga = G[3 * p] * G[3 * q] + G[3 * p + 1] * G[3 * q + 1] + G[3 * p + 2] * G[3 * q + 2];
-            if (ga != 0.0 && fabs(ga) > 1e-16 * sqrt(al * be)) {
+            if (ga != 0.0 && ga * ga > 1e-32 * (al * be)) {
                 rotated = true;
-                double zeta = (be - al) / (2.0 * ga);
-                double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                double c = rsqrt(1.0 + t * t), sn = c * t;
+                const double zeta = (be - al) * (0.5 * fast_rcp(ga));
+                const double t = copysign(fast_rcp(fabs(zeta) + fast_sqrt(1.0 + zeta * zeta)), zeta);
+                const double c = fast_rsqrt(1.0 + t * t), sn = c * t;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     double gp = G[3 * p + i], gq = G[3 * q + i];
@@ -79,7 +106,7 @@ __device__ inline void svd3(const double Fin[9], double U[9], double s[3], doubl
         if (!rotated) break;
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) s[j] = sqrt(G[3 * j] * G[3 * j] + G[3 * j + 1] * G[3 * j + 1] + G[3 * j + 2] * G[3 * j + 2]);
+    for (int j = 0; j < 3; ++j) s[j] = fast_sqrt(G[3 * j] * G[3 * j] + G[3 * j + 1] * G[3 * j + 1] + G[3 * j + 2] * G[3 * j + 2]);
     // sort columns by descending singular value (3-element network)
     auto cswap = [&](int a, int b) {
         if (s[a] < s[b]) {
@@ -98,7 +125,7 @@ __device__ inline void svd3(const double Fin[9], double U[9], double s[3], doubl
     cswap(0, 1);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        double inv = (s[j] > 0.0) ? 1.0 / s[j] : 0.0;
+        double inv = (s[j] > 0.0) ? fast_rcp(s[j]) : 0.0;
 #pragma unroll
         for (int i = 0; i < 3; ++i) U[3 * j + i] = G[3 * j + i] * inv;
     }
@@ -141,9 +168,9 @@ __device__ inline void make_pd3(double S[6])
             const int q = (pq == 0) ? 1 : 2;
             double apq = A[p + 3 * q];
             if (apq == 0.0) continue;
-            double theta = (A[q + 3 * q] - A[p + 3 * p]) / (2.0 * apq);
-            double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            double c = rsqrt(t * t + 1.0), sn = t * c;
+            const double theta = (A[q + 3 * q] - A[p + 3 * p]) * (0.5 * fast_rcp(apq));
+            const double t = copysign(fast_rcp(fabs(theta) + fast_sqrt(theta * theta + 1.0)), theta);
+            const double c = fast_rsqrt(t * t + 1.0), sn = t * c;
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 double akp = A[k + 3 * p], akq = A[k + 3 * q];
