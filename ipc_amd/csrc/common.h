@@ -48,12 +48,26 @@ struct DevBuf {
         if (count) HIP_CHECK(hipMalloc((void**)&p, count * sizeof(T)));
         n = count;
     }
+    // grow-only variant for buffers whose size changes from call to call (hipMalloc / hipFree cost ~100 us each)
+    void ensure(size_t count)
+    {
+        if (count > n || !p) alloc(count + count / 2 + 16);
+    }
+    void zeroN(size_t count, hipStream_t s)
+    {
+        if (count) HIP_CHECK(hipMemsetAsync(p, 0, count * sizeof(T), s));
+    }
     void upload(const T* h, size_t count, hipStream_t s)
     {
         alloc(count);
         if (count) HIP_CHECK(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
     }
     void upload(const std::vector<T>& h, hipStream_t s) { upload(h.data(), h.size(), s); }
+    void uploadGrow(const std::vector<T>& h, hipStream_t s) // capacity only grows; n stays the capacity
+    {
+        ensure(h.size());
+        if (!h.empty()) HIP_CHECK(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    }
     void download(T* h, size_t count, hipStream_t s) const
     {
         if (count) HIP_CHECK(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s));

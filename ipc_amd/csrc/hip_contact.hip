@@ -849,9 +849,9 @@ void HipContact::uploadSets()
         q[2 * i] = paraEIEJ[i][0];
         q[2 * i + 1] = paraEIEJ[i][1];
     }
-    d_active.upload(a, stream);
-    d_para.upload(p, stream);
-    d_paraEIEJ.upload(q, stream);
+    d_active.uploadGrow(a, stream);
+    d_para.uploadGrow(p, stream);
+    d_paraEIEJ.uploadGrow(q, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
@@ -862,7 +862,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     const double infl = std::sqrt(dHat);
     // bounding box of the current positions
     const int nb = nblk(nV);
-    bboxPartial_.alloc(6 * (size_t)nb);
+    bboxPartial_.ensure(6 * (size_t)nb);
     hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
     std::vector<double> part(6 * (size_t)nb);
     bboxPartial_.download(part.data(), part.size(), stream);
@@ -889,9 +889,9 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         g.h *= 1.5;
     }
     auto buildCells = [&](int nPrim, int isTri, const int* prim, DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items) {
-        cnt.alloc((size_t)nCells + 1);
-        start.alloc((size_t)nCells + 1);
-        cnt.zero(stream);
+        cnt.ensure((size_t)nCells + 1);
+        start.ensure((size_t)nCells + 1);
+        cnt.zeroN((size_t)nCells + 1, stream);
         hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, isTri, prim, x_dev, g, infl, 0, cnt.p, (const int*)nullptr,
             (int*)nullptr);
         size_t tmpBytes = 0;
@@ -901,8 +901,8 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         int total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        items.alloc(std::max(1, total));
-        cnt.zero(stream);
+        items.ensure(std::max(1, total));
+        cnt.zeroN((size_t)nCells + 1, stream);
         hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, isTri, prim, x_dev, g, infl, 1, cnt.p, start.p, items.p);
     };
     buildCells(nSF, 1, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
@@ -1104,7 +1104,7 @@ HipContact::GridHost HipContact::makeGrid(const HipMesh& mesh, const double* x_d
 {
     const int nV = mesh.nV;
     const int nb = nblk(nV);
-    bboxPartial_.alloc(6 * (size_t)nb);
+    bboxPartial_.ensure(6 * (size_t)nb);
     hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
     std::vector<double> part(6 * (size_t)nb);
     bboxPartial_.download(part.data(), part.size(), stream);
@@ -1158,10 +1158,10 @@ void HipContact::buildCells(const GridHost& gh, int nPrim, int nv, const int* pr
     }
     g.h = gh.h;
     const long long nCells = gh.nCells;
-    cnt.alloc((size_t)nCells + 1);
-    start.alloc((size_t)nCells + 1);
+    cnt.ensure((size_t)nCells + 1);
+    start.ensure((size_t)nCells + 1);
     auto insert = [&](int mode) {
-        cnt.zero(stream);
+        cnt.zeroN((size_t)nCells + 1, stream);
         if (p_dev)
             hipLaunchKernelGGL(k_grid_insert_swept, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv, prim, x_dev, p_dev, alpha, g, mode, cnt.p,
                 start.p, items.p);
@@ -1177,7 +1177,7 @@ void HipContact::buildCells(const GridHost& gh, int nPrim, int nv, const int* pr
     int total = 0;
     HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    items.alloc(std::max(1, total));
+    items.ensure(std::max(1, total));
     insert(1);
 }
 
@@ -1208,7 +1208,7 @@ double HipContact::ccdPartial(const double* x_dev, const double* p_dev, double s
         flat[2 * (size_t)i] = csPTEE[i][0];
         flat[2 * (size_t)i + 1] = csPTEE[i][1];
     }
-    d_cand_.upload(flat, stream);
+    d_cand_.uploadGrow(flat, stream);
     ccdOut_.alloc(4);
     const unsigned long long init[2] = { ~0ull, ~0ull };
     HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
@@ -1287,8 +1287,8 @@ void HipContact::evalStencils(const std::vector<std::array<int, 4>>& ids, const 
     std::vector<int> flat(4 * (size_t)n);
     for (int i = 0; i < n; ++i)
         for (int k = 0; k < 4; ++k) flat[4 * (size_t)i + k] = ids[i][k];
-    d_ids_.upload(flat, stream);
-    d_vals_.alloc(n);
+    d_ids_.uploadGrow(flat, stream);
+    d_vals_.ensure(n);
     hipLaunchKernelGGL(k_eval_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_ids_.p, x_dev, d_vals_.p);
     d_vals_.download(d2.data(), n, stream);
 }
