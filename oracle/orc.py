@@ -487,6 +487,66 @@ def opt_half_space_set(opt: "Optimizer", idx=0):
     return v
 
 
+class Friction:
+    """Lagged friction data of one active set (FrictionUtils.hpp / SelfCollisionHandler.cpp:2481-2988)."""
+
+    def __init__(self):
+        L = lib()
+        L.orc_friction_create.restype = C.c_void_p
+        L.orc_friction_energy.restype = C.c_double
+        self.h = C.c_void_p(L.orc_friction_create())
+        self.n = 0
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_friction_destroy(self.h)
+            self.h = None
+
+    def update(self, mesh, active, dHat, kappa):
+        a = np.ascontiguousarray(active, dtype=np.int32).reshape(-1, 4)
+        self.n = a.shape[0]
+        lib().orc_friction_update(self.h, mesh.h, C.c_int(self.n), _ip(a), C.c_double(dHat), C.c_double(kappa))
+        lam, co, ba = np.zeros(self.n), np.zeros((self.n, 2)), np.zeros((self.n, 6))
+        lib().orc_friction_get(self.h, _dp(lam), _dp(co), _dp(ba))
+        return dict(lam=lam, coord=co, basis=ba)
+
+    def energy(self, mesh, Vt, eps2, coef):
+        Vt = np.asfortranarray(Vt, dtype=np.float64)
+        return lib().orc_friction_energy(self.h, mesh.h, _dp(Vt), C.c_double(eps2), C.c_double(coef))
+
+    def gradient(self, mesh, Vt, eps2, coef):
+        Vt = np.asfortranarray(Vt, dtype=np.float64)
+        g = np.zeros(3 * mesh.nV)
+        lib().orc_friction_gradient(self.h, mesh.h, _dp(Vt), C.c_double(eps2), C.c_double(coef), _dp(g))
+        return g
+
+    def hessian(self, mesh, Vt, nnz, eps2, coef, projectDBC=True):
+        Vt = np.asfortranarray(Vt, dtype=np.float64)
+        a = np.zeros(nnz)
+        lib().orc_friction_hessian(self.h, mesh.h, _dp(Vt), C.c_double(eps2), C.c_double(coef), C.c_int(int(projectDBC)), _dp(a))
+        return a
+
+
+def opt_set_friction(opt: "Optimizer", self_fric=0.0, fric_iter_amt=1, eps_v=1e-3):
+    lib().orc_opt_set_friction(opt.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v))
+
+
+def opt_set_half_space_friction(opt: "Optimizer", idx, mu):
+    lib().orc_opt_set_half_space_friction(opt.h, C.c_int(idx), C.c_double(mu))
+
+
+def opt_next_subproblem(opt: "Optimizer"):
+    return bool(lib().orc_opt_next_subproblem(opt.h))
+
+
+def opt_friction_state(opt: "Optimizer"):
+    sc = np.zeros(4)
+    lib().orc_opt_get_friction(opt.h, _dp(sc), None)
+    lam = np.zeros(int(sc[1]))
+    lib().orc_opt_get_friction(opt.h, _dp(sc), _dp(lam))
+    return dict(fricDHat=sc[0], n_lagged=int(sc[1]), fric_iter=int(sc[2]), n_half_space_lagged=int(sc[3]), lam=lam)
+
+
 def opt_contact_state(opt: "Optimizer"):
     n = np.zeros(6, dtype=np.int32)
     lib().orc_opt_get_contact(opt.h, _ip(n), None, None)

@@ -71,3 +71,27 @@ double hsStepBound(const Mesh& m, const HalfSpace& h, const double* p, double sl
 bool hsIntersected(const Mesh& m, const HalfSpace& h); // CollisionObject.h:386-401 (fires only on d == 0: d is a square)
 
 } // namespace orc
+
+namespace orc {
+// ---- lagged friction: FrictionUtils.hpp:24-347, SelfCollisionHandler.cpp:2481-2988, HalfSpace.cpp:272-381
+struct FrictionLag {
+    std::vector<MMCVID> set; // MMActiveSet_lastH
+    std::vector<double> lambda; // MMLambda_lastH: -kappa b'(d) 2 sqrt(d), times the PP / PE multiplicity
+    std::vector<std::array<double, 2>> coord; // MMDistCoord: closest-point parameters
+    std::vector<std::array<double, 6>> basis; // MMTanBasis: 3 x 2, column-major
+};
+// Optimizer.cpp:1578-1598: multipliers + computeDistCoordAndTanBasis at the current positions
+void frictionLagUpdate(const Mesh& m, const std::vector<MMCVID>& active, double dHat, double kappa, FrictionLag& lag);
+double frictionEnergy(const Mesh& m, const double* Vt_colmajor, const FrictionLag& lag, double eps2, double coef);
+void frictionGradient(const Mesh& m, const double* Vt_colmajor, const FrictionLag& lag, double eps2, double coef, double* grad);
+void frictionHessian(const Mesh& m, const double* Vt_colmajor, const FrictionLag& lag, double eps2, double coef, bool projectDBC, double* a);
+void frictionConnectivity(const FrictionLag& lag, std::vector<std::pair<int, int>>& pairs); // augmentConnectivity on the lagged set
+// half-space (C0 clamping, HalfSpace.cpp:272-381); lambda per vertex of `set`
+void hsFrictionLagUpdate(const Mesh& m, const HalfSpace& h, const std::vector<int>& set, double dHat, double kappa, std::vector<double>& lambda);
+double hsFrictionEnergy(const Mesh& m, const double* Vt, const HalfSpace& h, const std::vector<int>& set, const std::vector<double>& lambda,
+    double mu, double eps2);
+void hsFrictionGradient(const Mesh& m, const double* Vt, const HalfSpace& h, const std::vector<int>& set, const std::vector<double>& lambda,
+    double mu, double eps2, double* grad);
+void hsFrictionHessian(const Mesh& m, const double* Vt, const HalfSpace& h, const std::vector<int>& set, const std::vector<double>& lambda,
+    double mu, double eps2, bool projectDBC, double* a);
+} // namespace orc

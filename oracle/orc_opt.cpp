@@ -42,6 +42,20 @@ struct orc_opt {
     std::vector<std::vector<int>> hsSet;
     std::vector<std::pair<int, int>> closeHS; // closeConstraintID / Val (Optimizer.cpp:2364-2374, 2403-2415)
     std::vector<double> closeHSVal;
+    // lagged friction: Optimizer.cpp:286-304, 1525-1600, 1615-1790
+    double selfFric = 0.0, epsV = 1.0e-3, fricDHat0 = 0, fricDHat = -1.0;
+    int fricIterAmt = 1, fricIterI = 0;
+    std::vector<double> hsFric; // per half-space friction coefficient
+    FrictionLag lag;
+    std::vector<std::vector<int>> hsLagSet;
+    std::vector<std::vector<double>> hsLambda;
+    bool solveFric() const
+    {
+        if (selfCollision && selfFric > 0.0) return true;
+        for (double mu : hsFric)
+            if (mu > 0.0) return true;
+        return false;
+    }
     bool ipOn() const { return selfCollision || !planes.empty(); }
     size_t nConstraints() const
     {
@@ -89,6 +103,13 @@ double computeEnergyVal(orc_opt* o)
     E += sum;
     for (size_t i = 0; i < o->planes.size(); ++i) E += hsEnergy(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa);
     if (o->selfCollision) E += contactEnergy(m, o->cs, o->dHat, o->kappa);
+    if (o->fricDHat > 0.0) { // Optimizer.cpp:3357-3377
+        for (size_t i = 0; i < o->planes.size(); ++i)
+            if (o->hsFric[i] > 0.0 && !o->hsLagSet[i].empty())
+                E += hsFrictionEnergy(m, o->V_prev.data(), o->planes[i], o->hsLagSet[i], o->hsLambda[i], o->hsFric[i], o->fricDHat);
+        if (o->selfCollision && o->selfFric > 0.0 && !o->lag.set.empty())
+            E += frictionEnergy(m, o->V_prev.data(), o->lag, o->fricDHat, o->selfFric);
+    }
     return E;
 }
 
@@ -110,6 +131,13 @@ void computeGradient(orc_opt* o, bool projectDBC)
     elasticInertiaGradient(o, projectDBC, o->gradient.data());
     for (size_t i = 0; i < o->planes.size(); ++i) hsGradient(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa, o->gradient.data());
     if (o->selfCollision) contactGradient(m, o->cs, o->dHat, o->kappa, projectDBC, o->gradient.data());
+    if (o->fricDHat > 0.0) { // Optimizer.cpp:3474-3478, 3504-3506
+        for (size_t i = 0; i < o->planes.size(); ++i)
+            if (o->hsFric[i] > 0.0 && !o->hsLagSet[i].empty())
+                hsFrictionGradient(m, o->V_prev.data(), o->planes[i], o->hsLagSet[i], o->hsLambda[i], o->hsFric[i], o->fricDHat, o->gradient.data());
+        if (o->selfCollision && o->selfFric > 0.0 && !o->lag.set.empty())
+            frictionGradient(m, o->V_prev.data(), o->lag, o->fricDHat, o->selfFric, o->gradient.data());
+    }
     for (int v = 0; v < m.nV; ++v)
         if (m.isDBC(v) && m.isProjectDBC(v, projectDBC))
             for (int c = 0; c < 3; ++c) o->gradient[3 * v + c] = 0; // :3512-3516
@@ -138,6 +166,7 @@ void computePrecondMtr(orc_opt* o, bool projectDBC)
     Mesh& m = *o->m;
     std::vector<std::pair<int, int>> extra;
     if (o->selfCollision && (o->cs.active.size() + o->cs.paraEE.size())) contactConnectivity(m, o->cs, extra);
+    if (o->selfCollision && o->fricDHat > 0.0 && o->selfFric > 0.0) frictionConnectivity(o->lag, extra); // :3565-3566
     // only pairs that are not mesh edges change vNeighbor
     std::vector<std::pair<int, int>> fresh;
     for (const auto& e : extra)
@@ -151,6 +180,13 @@ void computePrecondMtr(orc_opt* o, bool projectDBC)
     assembleHessian(m, o->dtSq, projectDBC, o->a.data());
     for (size_t i = 0; i < o->planes.size(); ++i) hsHessian(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa, projectDBC, o->a.data());
     if (o->selfCollision) contactHessian(m, o->cs, o->dHat, o->kappa, projectDBC, o->a.data());
+    if (o->fricDHat > 0.0) { // Optimizer.cpp:3677-3702
+        for (size_t i = 0; i < o->planes.size(); ++i)
+            if (o->hsFric[i] > 0.0 && !o->hsLagSet[i].empty())
+                hsFrictionHessian(m, o->V_prev.data(), o->planes[i], o->hsLagSet[i], o->hsLambda[i], o->hsFric[i], o->fricDHat, projectDBC, o->a.data());
+        if (o->selfCollision && o->selfFric > 0.0 && !o->lag.set.empty())
+            frictionHessian(m, o->V_prev.data(), o->lag, o->fricDHat, o->selfFric, projectDBC, o->a.data());
+    }
 }
 
 void stepForward(orc_opt* o, const std::vector<double>& V0, double alpha)
@@ -166,6 +202,19 @@ void computeConstraintSets(orc_opt* o)
     Tic t(o->timers[14]);
     for (size_t i = 0; i < o->planes.size(); ++i) hsConstraintSet(*o->m, o->planes[i], o->dHat, o->hsSet[i]); // Optimizer.cpp:2460-2462
     if (o->selfCollision) computeConstraintSet(*o->m, o->dHat, false, o->cs);
+}
+
+// multipliers, closest points and tangent bases of the current constraint sets (Optimizer.cpp:1553-1600 / 1620-1675)
+void updateFrictionLag(orc_opt* o)
+{
+    if (!o->solveFric()) return;
+    Mesh& m = *o->m;
+    for (size_t i = 0; i < o->planes.size(); ++i)
+        if (o->hsFric[i] > 0.0) {
+            hsFrictionLagUpdate(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa, o->hsLambda[i]);
+            o->hsLagSet[i] = o->hsSet[i];
+        }
+    if (o->selfCollision && o->selfFric > 0.0) frictionLagUpdate(m, o->cs.active, o->dHat, o->kappa, o->lag);
 }
 
 bool anyIntersection(orc_opt* o)
@@ -404,6 +453,9 @@ int orc_opt_add_half_space(orc_opt* o, const double* origin3, const double* norm
     h.init(origin3, normal3);
     o->planes.push_back(h);
     o->hsSet.emplace_back();
+    o->hsFric.push_back(0.0);
+    o->hsLagSet.emplace_back();
+    o->hsLambda.emplace_back();
     o->dHatEps = dHatEps;
     o->dHat = dHatEps * dHatEps * o->m->bboxDiag2;
     o->dTol = 1.0e-18 * o->m->bboxDiag2;
@@ -486,6 +538,13 @@ void orc_opt_begin_timestep(orc_opt* o)
         o->closeVal.clear();
         o->closeHS.clear();
         o->closeHSVal.clear();
+        // friction: lagged sets reset, eps_v^2 h^2 (Optimizer.cpp:1525-1533, 286-304), then lagged at x^n (:1553-1600)
+        o->lag = FrictionLag();
+        for (auto& s : o->hsLagSet) s.clear();
+        o->fricDHat0 = o->epsV * o->epsV * o->dtSq * m.bboxDiag2;
+        o->fricDHat = o->solveFric() ? o->fricDHat0 : -1.0;
+        o->fricIterI = 0;
+        updateFrictionLag(o);
     }
     if (o->patternDirty) computePrecondMtr(o, true);
     o->lastEnergyVal = computeEnergyVal(o);
@@ -567,13 +626,71 @@ void orc_opt_end_timestep(orc_opt* o)
     o->globalIterNum++;
 }
 
+// After a sub-problem has converged: the tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS,
+// HOMOTOPY_VAR 1, dHat already at its target).  Returns 1 when another solveSub_IP pass has to run (friction lagging).
+int orc_opt_next_subproblem(orc_opt* o)
+{
+    if (!o->ipOn() || !o->solveFric()) return 0;
+    Mesh& m = *o->m;
+    o->fricIterI++;
+    updateFrictionLag(o);
+    if (!o->nConstraints()) return 0; // "no collision in this time step"
+    bool updateFricDHat = true;
+    if (o->fricDHat <= o->fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45,547-548)
+        // tangent-space convergence test: one Newton direction with the refreshed lag (:1717-1731)
+        computeGradient(o, true);
+        computePrecondMtr(o, true);
+        const int ok = orc_chol_factorize(o->chol, o->a.data());
+        std::vector<double> minusG(o->gradient.size());
+        for (size_t i = 0; i < minusG.size(); ++i) minusG[i] = -o->gradient[i];
+        if (!ok)
+            for (int r = 0; r < 3 * m.nV; ++r) o->searchDir[r] = minusG[r] / o->a[m.ia[r]];
+        else orc_chol_solve(o->chol, minusG.data(), o->searchDir.data());
+        double pMax = 0;
+        for (double v : o->searchDir) pMax = std::max(pMax, std::fabs(v));
+        if (pMax < o->targetGRes) updateFricDHat = false;
+        if (o->fricIterAmt > 0 && o->fricIterI >= o->fricIterAmt) updateFricDHat = false;
+    }
+    if (!updateFricDHat) return 0;
+    if (o->fricDHat > 0.0) o->fricDHat = std::max(0.5 * o->fricDHat, o->fricDHat0); // :1776-1781
+    o->closeID.clear(); // initSubProb_IP
+    o->closeVal.clear();
+    o->closeHS.clear();
+    o->closeHSVal.clear();
+    o->k = 0;
+    return 1;
+}
+
+void orc_opt_set_friction(orc_opt* o, double selfFric, int fricIterAmt, double epsV)
+{
+    // `selfFric mu`, `fricIterAmt n`, `tuning ... eps_v` (Config.cpp:482-488, 550-551, 45)
+    o->selfFric = selfFric;
+    o->fricIterAmt = fricIterAmt;
+    o->epsV = epsV;
+}
+void orc_opt_set_half_space_friction(orc_opt* o, int id, double mu) { o->hsFric[id] = mu; }
+void orc_opt_get_friction(const orc_opt* o, double* scalars4, double* lambda)
+{
+    scalars4[0] = o->fricDHat;
+    scalars4[1] = (double)o->lag.set.size();
+    scalars4[2] = (double)o->fricIterI;
+    size_t nh = 0;
+    for (const auto& s : o->hsLagSet) nh += s.size();
+    scalars4[3] = (double)nh;
+    if (lambda)
+        for (size_t i = 0; i < o->lag.lambda.size(); ++i) lambda[i] = o->lag.lambda[i];
+}
+
 int orc_opt_solve_timestep(orc_opt* o, int maxIter)
 {
     orc_opt_begin_timestep(o);
     int it = 0;
-    while (it < maxIter) {
-        if (orc_opt_newton_iter(o)) break;
-        ++it;
+    for (;;) {
+        while (it < maxIter) {
+            if (orc_opt_newton_iter(o)) break;
+            ++it;
+        }
+        if (it >= maxIter || !orc_opt_next_subproblem(o)) break;
     }
     orc_opt_end_timestep(o);
     return it;

@@ -406,3 +406,90 @@ def test_block_dropped_on_a_half_space_comes_to_rest_above_it(orc):
         assert ((Vn - origin) @ nrm).min() > 0  # never through the plane
         touched = max(touched, len(orc.opt_half_space_set(o)))
     assert touched > 0 and o.state()["kappa"] > 0
+
+
+# ---- lagged friction --------------------------------------------------------------------------------
+def test_friction_terms_are_consistent_derivatives(orc, blocks):
+    m, V = blocks["m"], blocks["V"]
+    cs = orc.Contacts()
+    sets = cs.build(m, 4 * blocks["dHat"])  # all four stencil kinds show up at this activation distance
+    # the slabs only produce PT and EE stencils: derive a PE and a PP tuple from two of the PT ones so that all four kinds run
+    act = [tuple(a) for a in sets["active"]]
+    pts = [a for a in act if a[0] < 0 and a[3] >= 0]
+    assert pts and any(a[0] >= 0 for a in act)
+    act.append((pts[0][0], pts[0][1], pts[0][2], -1))
+    act.append((pts[-1][0], pts[-1][1], -1, -2))  # multiplicity 2
+    fr = orc.Friction()
+    lag = fr.update(m, np.array(act, dtype=np.int32), 1.0, 2.0e3)  # dHat = 1: every stencil inside the barrier's support
+    assert np.all(lag["lam"] > 0)
+    B = lag["basis"].reshape(-1, 2, 3)
+    assert np.allclose(np.einsum("nij,nkj->nik", B, B), np.eye(2)[None], atol=1e-12)  # orthonormal tangent bases
+    # multiplier of the first constraint by hand: -kappa b'(d) 2 sqrt(d) (Optimizer.cpp:1586-1587)
+    rng = np.random.default_rng(5)
+    Vt = V.copy()
+    U = 2e-4 * rng.normal(size=V.shape)  # sliding of very different sizes: both sides of eps
+    U[::3] *= 30.0
+    eps2, mu = (1.5e-3) ** 2, 0.37
+    Vn = V + U
+    m.set_V(Vn)
+    E0 = fr.energy(m, Vt, eps2, mu)
+    g = fr.gradient(m, Vt, eps2, mu)
+    extra = cs.connectivity(m).tolist() + [(min(-act[-2][0] - 1, act[-2][k]), max(-act[-2][0] - 1, act[-2][k])) for k in (1, 2)] \
+        + [(min(-act[-1][0] - 1, act[-1][1]), max(-act[-1][0] - 1, act[-1][1]))]
+    ia, ja = m.pattern(extra_edges=np.array(extra, dtype=np.int32))
+    a = fr.hessian(m, Vt, len(ja), eps2, mu, False)
+    assert E0 > 0 and np.abs(g).max() > 0
+    touched = np.unique(np.abs(np.nonzero(g)[0]))
+    h = 1e-7
+    for i in rng.choice(touched, size=8, replace=False):
+        v, c = divmod(int(i), 3)
+        Vp, Vm = Vn.copy(), Vn.copy()
+        Vp[v, c] += h
+        Vm[v, c] -= h
+        m.set_V(Vp)
+        Ep, gp = fr.energy(m, Vt, eps2, mu), fr.gradient(m, Vt, eps2, mu)
+        m.set_V(Vm)
+        Em, gm = fr.energy(m, Vt, eps2, mu), fr.gradient(m, Vt, eps2, mu)
+        assert abs((Ep - Em) / (2 * h) - g[i]) <= 2e-5 * np.abs(g).max()
+        # column i of the (symmetric-upper) Hessian against the finite difference of the gradient
+        e = np.zeros(3 * m.nV)
+        e[i] = 1.0
+        Hi = m.symv(a, e)
+        fd = (gp - gm) / (2 * h)
+        assert np.abs(Hi - fd).max() <= 5e-4 * max(np.abs(fd).max(), 1e-30)
+    m.set_V(V)
+
+
+def test_block_sliding_on_rough_ground_decelerates_by_mu_g(orc):
+    V, F = scene.make_box(2, 2, 2, size=(0.4, 0.4, 0.4), origin=(0, 0, 0))
+    Vs = scene.jitter(V, F, rel=5e-3)
+    m = orc.Mesh(V, F, YM=1e6, PR=0.3, density=1000.0)
+    m.set_surface(scene.surface_tris(F))
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.005, gravity=True, nthreads=2)
+    idx = orc.opt_add_half_space(o, [0, -0.004, 0], [0, 1, 0], 5e-3)
+    mu = 0.5
+    orc.opt_set_half_space_friction(o, idx, mu)
+    orc.opt_set_friction(o, 0.0, 1, 1e-3)
+    vel = np.zeros_like(V)
+    vel[:, 0] = 1.0
+    orc.opt_set_velocity(o, vel)
+    o.precompute()
+    xs = []
+    for step in range(36):
+        o.begin_timestep()
+        for rounds in range(5):
+            for it in range(80):
+                if o.newton_iter():
+                    break
+            else:
+                pytest.fail("Newton did not converge")
+            if not orc.opt_next_subproblem(o):
+                break
+        o.end_timestep()
+        xs.append(o.state()["V"][:, 0].mean())
+    assert orc.opt_friction_state(o)["n_half_space_lagged"] > 0
+    xs = np.array(xs)
+    vx = np.diff(xs) / 0.005
+    acc = np.polyfit(np.arange(len(vx))[12:] * 0.005, vx[12:], 1)[0]  # after the block has settled on the plane
+    assert vx[-1] < vx[12] and abs(acc + mu * 9.80665) < 0.25 * mu * 9.80665
