@@ -180,6 +180,25 @@ int ipcgpu_halfspace_energy(ipcgpu_ctx*, int id, double dHat, double kappa, doub
 int ipcgpu_halfspace_gradient_add(ipcgpu_ctx*, int id, double dHat, double kappa, double* grad_3nV_inout);
 int ipcgpu_halfspace_hessian_add(ipcgpu_ctx*, int id, double dHat, double kappa, int projectDBC);
 int ipcgpu_halfspace_step_bound(ipcgpu_ctx*, int id, const double* searchDir_3nV, double slackness, double* stepSize_inout);
+/* ---- lagged smoothed Coulomb friction (FrictionUtils.hpp, SelfCollisionHandler.cpp:2481-2988, HalfSpace.cpp:272-381)
+ * `selfFric mu` / `fricIterAmt n` / eps_v = tuning[4] (Config.cpp:482-488, 550-551, 45).  Self friction needs self collision. */
+int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, double epsV);
+int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx*, int id, double mu); /* CollisionObject::friction of half-space `id` */
+/* After ipcgpu_opt_newton_iter reported convergence: the tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790) --
+ * refresh the lagged multipliers / tangent bases, test tangent-space convergence.  *more = 1: another solveSub_IP pass has
+ * started (keep calling newton_iter); 0: the time step is done.  Without friction it returns 0 and changes nothing. */
+int ipcgpu_opt_next_subproblem(ipcgpu_ctx*, int* more);
+/* scalars4 = {fricDHat (eps_v^2 h^2, < 0: off), #lagged self-contact constraints, friction iteration, #lagged half-space
+ * vertices}; lambda (nullable) receives MMLambda_lastH */
+int ipcgpu_opt_get_friction_state(ipcgpu_ctx*, double* scalars4, double* lambda);
+/* building blocks over the lagged self-contact set.  friction_update lags the CURRENT constraint set (ipcgpu_contact_build /
+ * _set) at the current positions: multipliers (Optimizer.cpp:1586-1591), computeDistCoordAndTanBasis (:2481-2527).
+ * Vt_colmajor = positions at the beginning of the time step (result.V_prev). */
+int ipcgpu_friction_update(ipcgpu_ctx*, double dHat, double kappa, int* nLagged);
+int ipcgpu_friction_get(ipcgpu_ctx*, double* lambda_n, double* coord_2n, double* basis_6n);
+int ipcgpu_friction_energy(ipcgpu_ctx*, const double* Vt_colmajor, double eps2, double coef, double* energy);
+int ipcgpu_friction_gradient_add(ipcgpu_ctx*, const double* Vt_colmajor, double eps2, double coef, double* grad_3nV_inout);
+int ipcgpu_friction_hessian_add(ipcgpu_ctx*, const double* Vt_colmajor, double eps2, double coef, int projectDBC);
 /* overwrite Optimizer::velocity (xyz-interleaved) and recompute xTilta (computeXTilta, Optimizer.cpp:1236-1257): the
  * `initVel` script keyword (Config.cpp:247-262) */
 int ipcgpu_opt_set_velocity(ipcgpu_ctx*, const double* vel_3nV);

@@ -803,6 +803,113 @@ int ipcgpu_halfspace_step_bound(ipcgpu_ctx* c, int id, const double* p, double s
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_friction(ipcgpu_ctx* c, double selfFric, int fricIterAmt, double epsV)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        needArg(selfFric >= 0.0 && epsV > 0.0, "bad friction parameters");
+        o.selfFric = selfFric;
+        o.fricIterAmt = fricIterAmt;
+        o.epsV = epsV;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx* c, int id, double mu)
+{
+    return guarded([&] {
+        needArg(mu >= 0.0, "negative friction coefficient");
+        HS(c, id).friction = mu;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_next_subproblem(ipcgpu_ctx* c, int* more)
+{
+    return guarded([&] {
+        bind(c);
+        const bool m = O(c).nextSubproblem();
+        if (more) *more = m ? 1 : 0;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_get_friction_state(ipcgpu_ctx* c, double* sc, double* lambda)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        const size_t n = (o.contact && o.selfCollision) ? o.contact->fricSet.size() : 0;
+        if (sc) {
+            sc[0] = o.fricDHat;
+            sc[1] = (double)n;
+            sc[2] = (double)o.fricIterI;
+            size_t nh = 0;
+            for (const auto& h : o.planes) nh += h->lagSet.size();
+            sc[3] = (double)nh;
+        }
+        if (lambda && n) o.contact->d_fricLambda.download(lambda, n, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_friction_update(ipcgpu_ctx* c, double dHat, double kappa, int* nLagged)
+{
+    return guarded([&] {
+        M(c);
+        bind(c);
+        CT(c).frictionLagUpdate(c->mesh->d_x.p, dHat, kappa);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (nLagged) *nLagged = (int)CT(c).fricSet.size();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_friction_get(ipcgpu_ctx* c, double* lambda, double* coord, double* basis)
+{
+    return guarded([&] {
+        M(c);
+        bind(c);
+        needArg(lambda && coord && basis, "null output");
+        CT(c).frictionGet(lambda, coord, basis);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_friction_energy(ipcgpu_ctx* c, const double* Vt, double eps2, double coef, double* E)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(Vt && E && eps2 > 0, "bad argument");
+        uploadColMajor(c, Vt, o.d_x0);
+        *E = CT(c).frictionEnergy(c->mesh->d_x.p, o.d_x0.p, eps2, coef, o.d_partial, o.d_scalar.p + 4);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_friction_gradient_add(ipcgpu_ctx* c, const double* Vt, double eps2, double coef, double* g)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(Vt && g && eps2 > 0, "bad argument");
+        const size_t n3 = 3 * (size_t)c->mesh->nV;
+        uploadColMajor(c, Vt, o.d_x0);
+        HIP_CHECK(hipMemcpyAsync(o.d_gradient.p, g, n3 * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        CT(c).frictionGradientAdd(c->mesh->d_x.p, o.d_x0.p, eps2, coef, o.d_gradient.p);
+        o.d_gradient.download(g, n3, c->stream);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_friction_hessian_add(ipcgpu_ctx* c, const double* Vt, double eps2, double coef, int projectDBC)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        need(c->lin->numRows == 3 * c->mesh->nV, "call ipcgpu_linsys_set_pattern first");
+        needArg(Vt && eps2 > 0, "bad argument");
+        uploadColMajor(c, Vt, o.d_x0);
+        CT(c).frictionHessianAdd(c->mesh->d_x.p, o.d_x0.p, c->mesh->d_dbc.p, *c->lin, eps2, coef, projectDBC, c->lin->d_a.p);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_velocity(ipcgpu_ctx* c, const double* vel)
 {
     return guarded([&] {

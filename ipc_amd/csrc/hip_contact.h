@@ -52,6 +52,18 @@ public:
     bool isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev);
     void evalStencils(const std::vector<std::array<int, 4>>& ids, const double* x_dev, std::vector<double>& d2);
     double maxSurfaceSpeed(const double* p_dev); // max_{v in SVI} |p_v|  (CFL bound, Optimizer.cpp:1947-1953)
+    // lagged friction of the self-contact set: MMActiveSet_lastH, MMLambda_lastH, MMDistCoord, MMTanBasis
+    std::vector<std::array<int, 4>> fricSet;
+    DevBuf<int> d_fricSet;
+    DevBuf<double> d_fricLambda, d_fricCoord, d_fricBasis;
+    void frictionLagClear();
+    void frictionLagUpdate(const double* x_dev, double dHat, double kappa); // lags the current `active` set (Optimizer.cpp:1578-1598)
+    void frictionGet(double* lambda, double* coord2, double* basis6);
+    double frictionEnergy(const double* x_dev, const double* xt_dev, double eps2, double coef, DevBuf<double>& partial, double* scalar_dev);
+    void frictionGradientAdd(const double* x_dev, const double* xt_dev, double eps2, double coef, double* grad_dev);
+    void frictionHessianAdd(const double* x_dev, const double* xt_dev, const int* dbc_dev, const HipLinSysSolver& lin, double eps2, double coef,
+        int projectDBC, double* a_dev);
+    void frictionConnectivity(std::vector<std::pair<int, int>>& pairs) const; // appends
 
 private:
     struct GridHost {

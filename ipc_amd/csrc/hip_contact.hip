@@ -310,6 +310,221 @@ __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrV
     }
 }
 
+// ---- lagged friction (FrictionUtils.hpp:24-347, SelfCollisionHandler.cpp:2481-2988) --------------
+// All four stencil kinds share one form: node weights wt_k and the 3 x 2 tangent basis B give T^T = [wt_k B^T]_k and the
+// tangential sliding u = B^T sum_k wt_k (x_k - x_k^t).  One lane per lagged constraint.
+struct FrictionView {
+    int n;
+    const int* set; // int4 MMCVID tuples (MMActiveSet_lastH)
+    const double* lambda; // MMLambda_lastH
+    const double* coord; // 2 per constraint (MMDistCoord)
+    const double* basis; // 6 per constraint (MMTanBasis, column-major 3 x 2)
+};
+__device__ __forceinline__ void fr_weights(int kind, const double* co, double* wt)
+{
+    if (kind == K_PT) {
+        wt[0] = 1.0;
+        wt[1] = -1.0 + co[0] + co[1];
+        wt[2] = -co[0];
+        wt[3] = -co[1];
+    }
+    else if (kind == K_EE) {
+        wt[0] = 1.0 - co[0];
+        wt[1] = co[0];
+        wt[2] = co[1] - 1.0;
+        wt[3] = -co[1];
+    }
+    else if (kind == K_PE) {
+        wt[0] = 1.0;
+        wt[1] = co[0] - 1.0;
+        wt[2] = -co[0];
+        wt[3] = 0.0;
+    }
+    else {
+        wt[0] = 1.0;
+        wt[1] = -1.0;
+        wt[2] = wt[3] = 0.0;
+    }
+}
+__device__ __forceinline__ void fr_slide(const double* __restrict__ x, const double* __restrict__ xt, const Stencil& s, const double* wt,
+    const double* B, double* u)
+{
+    double r[3] = { 0.0, 0.0, 0.0 };
+    for (int k = 0; k < s.n; ++k)
+        for (int c = 0; c < 3; ++c) r[c] += wt[k] * (x[3 * (size_t)s.node[k] + c] - xt[3 * (size_t)s.node[k] + c]);
+    u[0] = B[0] * r[0] + B[1] * r[1] + B[2] * r[2];
+    u[1] = B[3] * r[0] + B[4] * r[1] + B[5] * r[2];
+}
+__device__ __forceinline__ void fr_solve2(double a, double b, double d, double r0, double r1, double* xo)
+{
+    const double l10 = b / a, d1 = d - l10 * b;
+    const double y1 = r1 - l10 * r0;
+    xo[1] = y1 / d1;
+    xo[0] = r0 / a - l10 * xo[1];
+}
+__device__ __forceinline__ void fr_normalize(double* a)
+{
+    const double l = sqrt(dot3(a, a));
+    for (int i = 0; i < 3; ++i) a[i] /= l;
+}
+// multipliers, closest-point parameters and tangent bases at the current positions (Optimizer.cpp:1578-1598)
+__global__ __launch_bounds__(BLOCK) void k_friction_lag(int n, const int* __restrict__ set, const double* __restrict__ x, double dHat, double kappa,
+    double* __restrict__ lambda, double* __restrict__ coord, double* __restrict__ basis)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Stencil s = decode(set + 4 * (size_t)i);
+    double X[4][3], b, gb, Hb;
+    gatherX(x, s.node, s.n, X);
+    const double d = dist_only(s.kind, X);
+    barrier(d, dHat, &b, &gb, &Hb);
+    double lam = gb * (-kappa * 2.0 * sqrt(d));
+    if (set[4 * (size_t)i + 3] < -1) lam *= -set[4 * (size_t)i + 3];
+    lambda[i] = lam;
+    double co[2] = { 0.0, 0.0 }, t0[3], t1[3], tmp[3];
+    if (s.kind == K_EE) {
+        double e20[3], e01[3], e23[3];
+        sub3(X[0], X[2], e20);
+        sub3(X[1], X[0], e01);
+        sub3(X[3], X[2], e23);
+        fr_solve2(dot3(e01, e01), -dot3(e23, e01), dot3(e23, e23), -dot3(e20, e01), dot3(e20, e23), co);
+        for (int c = 0; c < 3; ++c) t0[c] = e01[c];
+        cross3(e01, e23, tmp);
+        cross3(tmp, e01, t1);
+    }
+    else if (s.kind == K_PT) {
+        double e1[3], e2[3], w[3];
+        sub3(X[2], X[1], e1);
+        sub3(X[3], X[1], e2);
+        sub3(X[0], X[1], w);
+        fr_solve2(dot3(e1, e1), dot3(e1, e2), dot3(e2, e2), dot3(e1, w), dot3(e2, w), co);
+        for (int c = 0; c < 3; ++c) t0[c] = e1[c];
+        cross3(e1, e2, tmp);
+        cross3(tmp, e1, t1);
+    }
+    else if (s.kind == K_PE) {
+        double e12[3], w[3];
+        sub3(X[2], X[1], e12);
+        sub3(X[0], X[1], w);
+        co[0] = dot3(w, e12) / dot3(e12, e12);
+        for (int c = 0; c < 3; ++c) t0[c] = e12[c];
+        cross3(e12, w, t1);
+    }
+    else {
+        double v01[3], xC[3], yC[3];
+        sub3(X[1], X[0], v01);
+        const double ex[3] = { 1.0, 0.0, 0.0 }, ey[3] = { 0.0, 1.0, 0.0 };
+        cross3(ex, v01, xC);
+        cross3(ey, v01, yC);
+        const bool px = dot3(xC, xC) > dot3(yC, yC);
+        for (int c = 0; c < 3; ++c) t0[c] = px ? xC[c] : yC[c];
+        cross3(v01, t0, t1);
+    }
+    fr_normalize(t0);
+    fr_normalize(t1);
+    coord[2 * (size_t)i] = co[0];
+    coord[2 * (size_t)i + 1] = co[1];
+    for (int c = 0; c < 3; ++c) {
+        basis[6 * (size_t)i + c] = t0[c];
+        basis[6 * (size_t)i + 3 + c] = t1[c];
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_friction_energy(FrictionView fv, const double* __restrict__ x, const double* __restrict__ xt, double eps2,
+    double* __restrict__ partial)
+{
+    __shared__ double sm[BLOCK / 64];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double val = 0.0;
+    if (i < fv.n) {
+        const Stencil s = decode(fv.set + 4 * (size_t)i);
+        double wt[4], u[2];
+        fr_weights(s.kind, fv.coord + 2 * (size_t)i, wt);
+        fr_slide(x, xt, s, wt, fv.basis + 6 * (size_t)i, u);
+        const double x2 = u[0] * u[0] + u[1] * u[1], eps = sqrt(eps2);
+        val = fv.lambda[i] * ((x2 > eps2) ? sqrt(x2) : (x2 * (-sqrt(x2) / 3.0 + eps) / (eps * eps) + eps / 3.0)); // f0_SF_C1
+    }
+    const double r = block_sum(val, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(BLOCK) void k_friction_gradient(FrictionView fv, const double* __restrict__ x, const double* __restrict__ xt, double eps2,
+    double coef, double* __restrict__ grad)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= fv.n) return;
+    const Stencil s = decode(fv.set + 4 * (size_t)i);
+    const double* B = fv.basis + 6 * (size_t)i;
+    double wt[4], u[2];
+    fr_weights(s.kind, fv.coord + 2 * (size_t)i, wt);
+    fr_slide(x, xt, s, wt, B, u);
+    const double x2 = u[0] * u[0] + u[1] * u[1], eps = sqrt(eps2);
+    const double sc = (x2 > eps2) ? 1.0 / sqrt(x2) : (-sqrt(x2) + 2.0 * eps) / (eps * eps); // f1 / |u|
+    double t3[3];
+    for (int c = 0; c < 3; ++c) t3[c] = B[c] * (u[0] * sc) + B[3 + c] * (u[1] * sc);
+    for (int k = 0; k < s.n; ++k)
+        for (int c = 0; c < 3; ++c) atomicAdd(&grad[3 * (size_t)s.node[k] + c], coef * fv.lambda[i] * wt[k] * t3[c]);
+}
+// H = T^T (aI I + bU u u^T) T.  With orthonormal B, T T^T is a multiple of the identity, so the eigenvalues of H are those of
+// the 2 x 2 core: aI and aI + bU |u|^2, both >= 0 in either regime (sliding: lambda/|u| and 0; sticking: lambda f1/|u| and
+// lambda f2).  The reference's makePD (SelfCollisionHandler.cpp:2783, 2802 ...) is therefore the identity up to round-off
+// and no eigen-solve is needed here; the oracle keeps it and the two agree to 1e-9.
+__global__ __launch_bounds__(BLOCK) void k_friction_hessian(FrictionView fv, CsrView m, const double* __restrict__ x, const double* __restrict__ xt,
+    const int* __restrict__ dbc, int projectDBC, double eps2, double coef, double* __restrict__ a, int* __restrict__ err)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= fv.n) return;
+    const Stencil s = decode(fv.set + 4 * (size_t)i);
+    const double* B = fv.basis + 6 * (size_t)i;
+    double wt[4], u[2];
+    fr_weights(s.kind, fv.coord + 2 * (size_t)i, wt);
+    fr_slide(x, xt, s, wt, B, u);
+    const double x2 = u[0] * u[0] + u[1] * u[1], xn = sqrt(x2), eps = sqrt(eps2);
+    const double cl = coef * fv.lambda[i];
+    double aI, bU;
+    if (x2 > eps2) {
+        aI = cl / xn;
+        bU = -cl / (x2 * xn);
+    }
+    else {
+        const double f1d = (-xn + 2.0 * eps) / (eps * eps), f2 = 2.0 * (eps - xn) / (eps * eps);
+        aI = cl * f1d;
+        bU = (f2 != f1d && x2 != 0.0) ? cl * (f2 - f1d) / x2 : 0.0;
+    }
+    double bu[3], BBt[9];
+    for (int c = 0; c < 3; ++c) bu[c] = B[c] * u[0] + B[3 + c] * u[1];
+    for (int r = 0; r < 3; ++r)
+        for (int c = 0; c < 3; ++c) BBt[r + 3 * c] = aI * (B[r] * B[c] + B[3 + r] * B[3 + c]) + bU * bu[r] * bu[c];
+    for (int k = 0; k < s.n; ++k) {
+        const int vi = s.node[k];
+        if (projected_dbc(dbc[vi], projectDBC)) continue;
+        for (int l = 0; l < s.n; ++l) {
+            const int vj = s.node[l];
+            if (projected_dbc(dbc[vj], projectDBC) || vi > vj) continue;
+            const double w = wt[k] * wt[l];
+            const int L = m.ia[3 * vi + 1] - m.ia[3 * vi];
+            if (vi == vj) {
+                const int base = m.ia[3 * vi];
+                atomicAdd(&a[base + 0], w * BBt[0]);
+                atomicAdd(&a[base + 1], w * BBt[3]);
+                atomicAdd(&a[base + 2], w * BBt[6]);
+                atomicAdd(&a[base + L + 0], w * BBt[4]);
+                atomicAdd(&a[base + L + 1], w * BBt[7]);
+                atomicAdd(&a[base + 2 * L - 1], w * BBt[8]);
+            }
+            else {
+                const int p0 = find_block(m, vi, vj);
+                if (p0 < 0) {
+                    atomicOr(err, 1);
+                    continue;
+                }
+                for (int r = 0; r < 3; ++r) {
+                    const int rowOff = (r == 0) ? 0 : (r == 1 ? (L - 1) : (2 * L - 3));
+                    for (int c = 0; c < 3; ++c) atomicAdd(&a[p0 + rowOff + c], w * BBt[r + 3 * c]);
+                }
+            }
+        }
+    }
+}
+
 // ---- broad phase: uniform grid by counting sort ---------------------------------------------------------------
 struct Grid {
     double lo[3], h;
@@ -1018,6 +1233,92 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     counters_.download(err, 2, stream);
     if (std::getenv("IPCGPU_DEBUG")) std::fprintf(stderr, "[ipcgpu] barrier Hessian: %d stencils, %.2f Jacobi sweeps on average\n", n, (double)err[1] / n);
     if (err[0]) throw StateError("barrier Hessian touches a node pair outside the CSR pattern: call set_pattern with the contact connectivity first");
+}
+
+// ---- lagged friction: host side -------------------------------------------------------------------------------------
+void HipContact::frictionLagClear() { fricSet.clear(); }
+
+void HipContact::frictionLagUpdate(const double* x_dev, double dHat, double kappa)
+{
+    fricSet = active; // MMActiveSet_lastH = MMActiveSet (Optimizer.cpp:1596-1598); d_active holds the same tuples
+    const int n = (int)fricSet.size();
+    if (!n) return;
+    d_fricSet.ensure(4 * (size_t)n);
+    HIP_CHECK(hipMemcpyAsync(d_fricSet.p, d_active.p, 4 * (size_t)n * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    d_fricLambda.ensure(n);
+    d_fricCoord.ensure(2 * (size_t)n);
+    d_fricBasis.ensure(6 * (size_t)n);
+    hipLaunchKernelGGL(k_friction_lag, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_fricSet.p, x_dev, dHat, kappa, d_fricLambda.p, d_fricCoord.p,
+        d_fricBasis.p);
+}
+
+void HipContact::frictionGet(double* lambda, double* coord2, double* basis6)
+{
+    const size_t n = fricSet.size();
+    if (!n) return;
+    d_fricLambda.download(lambda, n, stream);
+    d_fricCoord.download(coord2, 2 * n, stream);
+    d_fricBasis.download(basis6, 6 * n, stream);
+}
+
+double HipContact::frictionEnergy(const double* x_dev, const double* xt_dev, double eps2, double coef, DevBuf<double>& partial, double* scalar_dev)
+{
+    const int n = (int)fricSet.size();
+    if (!n) return 0.0;
+    FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
+    const int nb = nblk(n);
+    if (partial.n < (size_t)nb) partial.alloc(nb);
+    hipLaunchKernelGGL(k_friction_energy, dim3(nb), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, partial.p);
+    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, nb, coef, scalar_dev);
+    double out = 0.0;
+    HIP_CHECK(hipMemcpyAsync(&out, scalar_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    return out;
+}
+
+void HipContact::frictionGradientAdd(const double* x_dev, const double* xt_dev, double eps2, double coef, double* grad_dev)
+{
+    const int n = (int)fricSet.size();
+    if (!n) return;
+    FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
+    hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, grad_dev);
+}
+
+void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, const int* dbc_dev, const HipLinSysSolver& lin, double eps2, double coef,
+    int projectDBC, double* a_dev)
+{
+    const int n = (int)fricSet.size();
+    if (!n) return;
+    FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
+    CsrView m{ lin.d_ia.p, lin.d_ja.p };
+    counters_.alloc(2);
+    counters_.zero(stream);
+    hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef, a_dev,
+        counters_.p);
+    int err[2];
+    counters_.download(err, 2, stream);
+    if (err[0]) throw StateError("friction Hessian touches a node pair outside the CSR pattern: the pattern must contain the lagged set's connectivity");
+}
+
+void HipContact::frictionConnectivity(std::vector<std::pair<int, int>>& pairs) const
+{
+    auto link = [&](int a, int b) {
+        if (a != b) pairs.push_back({ std::min(a, b), std::max(a, b) });
+    };
+    for (const auto& c : fricSet) { // SelfCollisionHandler.cpp:330-376 on MMActiveSet_lastH (Optimizer.cpp:3565-3566)
+        if (c[0] >= 0) {
+            link(c[0], c[2]);
+            link(c[0], c[3]);
+            link(c[1], c[2]);
+            link(c[1], c[3]);
+        }
+        else {
+            const int v0 = -c[0] - 1;
+            link(v0, c[1]);
+            if (c[2] >= 0) link(v0, c[2]);
+            if (c[2] >= 0 && c[3] >= 0) link(v0, c[3]);
+        }
+    }
 }
 
 void HipContact::connectivity(std::vector<std::pair<int, int>>& pairs) const

@@ -29,6 +29,17 @@ public:
     double stepBound(int nSVI, const int* svi_dev, const double* x_dev, const int* dbc_dev, const double* p_dev, double slackness, double stepSize);
     bool intersected(int nV, const double* x_dev, const int* dbc_dev);
     void evalDist2(const std::vector<int>& verts, const double* x_dev, std::vector<double>& d2);
+    // lagged friction (HalfSpace.cpp:272-381, C0 clamping): activeSet_lastH / lambda_lastH of this plane
+    double friction = 0.0; // Base::friction
+    std::vector<int> lagSet;
+    DevBuf<int> d_lagSet;
+    DevBuf<double> d_lagLambda;
+    void lagClear() { lagSet.clear(); }
+    void lagUpdate(const double* x_dev, double dHat, double kappa); // Optimizer.cpp:1560-1573 on the current `set`
+    double frictionEnergy(const double* x_dev, const double* xt_dev, double eps2);
+    void frictionGradientAdd(const double* x_dev, const double* xt_dev, double eps2, double* grad_dev);
+    void frictionHessianAdd(const double* x_dev, const double* xt_dev, const int* dbc_dev, const int* rowBase_dev, const int* rowLen_dev, double eps2,
+        int projectDBC, double* a_dev);
 
 private:
     DevBuf<int> flags_, count_, ids_;

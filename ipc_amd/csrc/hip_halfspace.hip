@@ -147,6 +147,84 @@ __global__ void k_hs_dist2(int n, const int* __restrict__ verts, const double* _
     const double dist = plane_dist(h, x, verts[i]);
     out[i] = dist * dist;
 }
+
+// ---- lagged friction (HalfSpace.cpp:272-381) ------------------------------------------------------------------------
+__global__ void k_hs_lag(int n, const int* __restrict__ set, const double* __restrict__ x, Plane h, double dHat, double kappa, double* __restrict__ lambda)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double dist = plane_dist(h, x, set[i]), d = dist * dist;
+    double b, gb, Hb;
+    cdev::barrier(d, dHat, &b, &gb, &Hb);
+    lambda[i] = gb * (-kappa * 2.0 * sqrt(d)); // Optimizer.cpp:1563-1566
+}
+__device__ __forceinline__ void hs_proj(const Plane& h, const double* __restrict__ x, const double* __restrict__ xt, int v, double* vp)
+{
+    const double vd[3] = { x[3 * (size_t)v] - xt[3 * (size_t)v], x[3 * (size_t)v + 1] - xt[3 * (size_t)v + 1], x[3 * (size_t)v + 2] - xt[3 * (size_t)v + 2] };
+    const double dn = vd[0] * h.n0 + vd[1] * h.n1 + vd[2] * h.n2;
+    vp[0] = vd[0] - dn * h.n0;
+    vp[1] = vd[1] - dn * h.n1;
+    vp[2] = vd[2] - dn * h.n2;
+}
+__global__ __launch_bounds__(BLOCK) void k_hs_fric_energy(int n, const int* __restrict__ set, const double* __restrict__ lambda, const double* __restrict__ x,
+    const double* __restrict__ xt, Plane h, double mu, double eps2, double* __restrict__ partial)
+{
+    __shared__ double sm[BLOCK / 64];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double val = 0.0;
+    if (i < n) {
+        double vp[3];
+        hs_proj(h, x, xt, set[i], vp);
+        const double m2 = vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2], eps = sqrt(eps2);
+        val = (m2 > eps2) ? mu * lambda[i] * (sqrt(m2) - eps * 0.5) : mu * lambda[i] * m2 / eps * 0.5;
+    }
+    const double r = block_sum(val, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+__global__ void k_hs_fric_gradient(int n, const int* __restrict__ set, const double* __restrict__ lambda, const double* __restrict__ x,
+    const double* __restrict__ xt, Plane h, double mu, double eps2, double* __restrict__ grad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = set[i];
+    double vp[3];
+    hs_proj(h, x, xt, v, vp);
+    const double m2 = vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2];
+    const double sc = (m2 > eps2) ? mu * lambda[i] / sqrt(m2) : mu * lambda[i] / sqrt(eps2);
+    for (int c = 0; c < 3; ++c) grad[3 * (size_t)v + c] += sc * vp[c];
+}
+// sliding: ml/|v| (P - vhat vhat^T) with P = I - n n^T has eigenvalues {ml/|v|, 0, 0}: the reference's makePD (HalfSpace.cpp:356)
+// is the identity up to round-off; sticking: ml/eps P ("already SPD", :360)
+__global__ void k_hs_fric_hessian(int n, const int* __restrict__ set, const double* __restrict__ lambda, const double* __restrict__ x,
+    const double* __restrict__ xt, const int* __restrict__ dbc, const int* __restrict__ rowBase, const int* __restrict__ rowLen, Plane h, double mu,
+    double eps2, int projectDBC, double* __restrict__ a)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int v = set[i];
+    if (projectDBC && dbc[v] != 0) return;
+    const double ml = mu * lambda[i];
+    double vp[3];
+    hs_proj(h, x, xt, v, vp);
+    const double m2 = vp[0] * vp[0] + vp[1] * vp[1] + vp[2] * vp[2];
+    const double nn[3] = { h.n0, h.n1, h.n2 };
+    double H[3][3];
+    if (m2 > eps2) {
+        const double mag = sqrt(m2);
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) H[r][c] = vp[r] * (-ml / m2 / mag) * vp[c] + ((r == c ? 1.0 : 0.0) - nn[r] * nn[c]) * (ml / mag);
+    }
+    else
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c) H[r][c] = ((r == c ? 1.0 : 0.0) - nn[r] * nn[c]) * (ml / sqrt(eps2));
+    const int p0 = rowBase[v], L = rowLen[v];
+    a[p0] += H[0][0];
+    a[p0 + 1] += H[0][1];
+    a[p0 + 2] += H[0][2];
+    a[p0 + L] += H[1][1];
+    a[p0 + L + 1] += H[1][2];
+    a[p0 + 2 * L - 1] += H[2][2];
+}
 } // namespace
 
 HipHalfSpace::HipHalfSpace(hipStream_t s, const double* origin, const double* normal) : stream(s)
@@ -252,6 +330,50 @@ void HipHalfSpace::evalDist2(const std::vector<int>& verts, const double* x_dev,
     if (vals_.n < (size_t)cnt) vals_.alloc(cnt);
     hipLaunchKernelGGL(k_hs_dist2, dim3(nblk(cnt)), dim3(BLOCK), 0, stream, cnt, ids_.p, x_dev, h, vals_.p);
     vals_.download(d2.data(), cnt, stream);
+}
+
+void HipHalfSpace::lagUpdate(const double* x_dev, double dHat, double kappa)
+{
+    lagSet = set;
+    const int cnt = (int)lagSet.size();
+    if (!cnt) return;
+    const Plane h{ n[0], n[1], n[2], D };
+    d_lagSet.ensure(cnt);
+    d_lagLambda.ensure(cnt);
+    HIP_CHECK(hipMemcpyAsync(d_lagSet.p, d_set.p, cnt * sizeof(int), hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(k_hs_lag, dim3(nblk(cnt)), dim3(BLOCK), 0, stream, cnt, d_lagSet.p, x_dev, h, dHat, kappa, d_lagLambda.p);
+}
+
+double HipHalfSpace::frictionEnergy(const double* x_dev, const double* xt_dev, double eps2)
+{
+    const int cnt = (int)lagSet.size();
+    if (!cnt) return 0.0;
+    const Plane h{ n[0], n[1], n[2], D };
+    const int nb = nblk(cnt);
+    if (partial_.n < (size_t)nb + 1) partial_.alloc(nb + 1);
+    hipLaunchKernelGGL(k_hs_fric_energy, dim3(nb), dim3(BLOCK), 0, stream, cnt, d_lagSet.p, d_lagLambda.p, x_dev, xt_dev, h, friction, eps2, partial_.p + 1);
+    hipLaunchKernelGGL(k_hs_reduce, dim3(1), dim3(BLOCK), 0, stream, partial_.p + 1, nb, 1.0, partial_.p);
+    double out = 0.0;
+    partial_.download(&out, 1, stream);
+    return out;
+}
+
+void HipHalfSpace::frictionGradientAdd(const double* x_dev, const double* xt_dev, double eps2, double* grad_dev)
+{
+    const int cnt = (int)lagSet.size();
+    if (!cnt) return;
+    const Plane h{ n[0], n[1], n[2], D };
+    hipLaunchKernelGGL(k_hs_fric_gradient, dim3(nblk(cnt)), dim3(BLOCK), 0, stream, cnt, d_lagSet.p, d_lagLambda.p, x_dev, xt_dev, h, friction, eps2, grad_dev);
+}
+
+void HipHalfSpace::frictionHessianAdd(const double* x_dev, const double* xt_dev, const int* dbc_dev, const int* rowBase_dev, const int* rowLen_dev,
+    double eps2, int projectDBC, double* a_dev)
+{
+    const int cnt = (int)lagSet.size();
+    if (!cnt) return;
+    const Plane h{ n[0], n[1], n[2], D };
+    hipLaunchKernelGGL(k_hs_fric_hessian, dim3(nblk(cnt)), dim3(BLOCK), 0, stream, cnt, d_lagSet.p, d_lagLambda.p, x_dev, xt_dev, dbc_dev, rowBase_dev,
+        rowLen_dev, h, friction, eps2, projectDBC, a_dev);
 }
 
 } // namespace ipcgpu

@@ -146,6 +146,13 @@ public:
     std::vector<std::unique_ptr<HipHalfSpace>> planes;
     std::vector<std::pair<int, int>> closeHS;
     std::vector<double> closeHSVal;
+    // lagged friction: Optimizer.cpp:286-304, 1525-1600, 1615-1790; the lagged sets live in HipContact /
+    // HipHalfSpace, x^t is d_xPrev
+    double selfFric = 0.0, epsV = 1.0e-3, fricDHat0 = 0, fricDHat = -1.0;
+    int fricIterAmt = 1, fricIterI = 0;
+    bool solveFric() const;
+    void updateFrictionLag();
+    bool nextSubproblem(); // tail of the fullyImplicit_IP loop body after a converged solveSub_IP; true = run another one
     bool ipOn() const { return selfCollision || !planes.empty(); }
     size_t nConstraints() const;
     int addHalfSpace(HipContact* c, const double* origin3, const double* normal3, double dHatEps);

@@ -147,7 +147,57 @@ double HipOptimizer::computeEnergyVal()
     // barrier terms over the current constraint sets (Optimizer.cpp:3252-3353); replicated on every rank
     for (auto& h : planes) E += h->energy(mesh.d_x.p, dHat, kappa);
     if (selfCollision) E += contact->energy(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4);
+    if (fricDHat > 0.0) { // lagged friction (Optimizer.cpp:3357-3377)
+        for (auto& h : planes)
+            if (h->friction > 0.0) E += h->frictionEnergy(mesh.d_x.p, d_xPrev.p, fricDHat);
+        if (selfCollision && selfFric > 0.0) E += contact->frictionEnergy(mesh.d_x.p, d_xPrev.p, fricDHat, selfFric, d_partial, d_scalar.p + 4);
+    }
     return E;
+}
+
+// ---- lagged friction ---------------------------------------------------------------------------------------------
+bool HipOptimizer::solveFric() const
+{
+    if (selfCollision && selfFric > 0.0) return true;
+    for (const auto& h : planes)
+        if (h->friction > 0.0) return true;
+    return false;
+}
+
+void HipOptimizer::updateFrictionLag()
+{
+    // multipliers, closest points and tangent bases of the current constraint sets (Optimizer.cpp:1553-1600 / 1620-1675)
+    if (!solveFric()) return;
+    for (auto& h : planes)
+        if (h->friction > 0.0) h->lagUpdate(mesh.d_x.p, dHat, kappa);
+    if (selfCollision && selfFric > 0.0) contact->frictionLagUpdate(mesh.d_x.p, dHat, kappa);
+}
+
+bool HipOptimizer::nextSubproblem()
+{
+    // Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS, HOMOTOPY_VAR 1 and dHat already at its target
+    if (!ipOn() || !solveFric()) return false;
+    fricIterI++;
+    updateFrictionLag();
+    if (!nConstraints()) return false; // "no collision in this time step"
+    bool updateFricDHat = true;
+    if (fricDHat <= fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45, 547-548)
+        // tangent-space convergence test: one Newton direction with the refreshed lag (:1717-1731)
+        computePrecondMtr(true, true);
+        computeSearchDir(true);
+        launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+        launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+        if (readScalar(d_scalar.p + 3) < targetGRes) updateFricDHat = false;
+        if (fricIterAmt > 0 && fricIterI >= fricIterAmt) updateFricDHat = false;
+    }
+    if (!updateFricDHat) return false;
+    if (fricDHat > 0.0) fricDHat = std::max(0.5 * fricDHat, fricDHat0); // :1776-1781
+    closeID.clear(); // initSubProb_IP
+    closeVal.clear();
+    closeHS.clear();
+    closeHSVal.clear();
+    k = 0;
+    return true;
 }
 
 size_t HipOptimizer::nConstraints() const
@@ -331,6 +381,11 @@ void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activ
     // barrier forces of the half-spaces and of the mesh against itself; the projected rows are cleared again at the end
     // (Optimizer.cpp:3452-3516).  activeOnly: initKappa leaves the mollified parallel-edge set out (:2262-2270)
     for (auto& h : planes) h->gradientAdd(mesh.d_x.p, dHat, kappa_, grad_dev);
+    if (!activeOnly && fricDHat > 0.0) { // Optimizer.cpp:3474-3478, 3504-3506
+        for (auto& h : planes)
+            if (h->friction > 0.0) h->frictionGradientAdd(mesh.d_x.p, d_xPrev.p, fricDHat, grad_dev);
+        if (selfCollision && selfFric > 0.0) contact->frictionGradientAdd(mesh.d_x.p, d_xPrev.p, fricDHat, selfFric, grad_dev);
+    }
     if (!contact) return;
     std::vector<std::array<int, 4>> keepPara, keepActive;
     if (activeOnly || !selfCollision) keepPara.swap(contact->para);
@@ -370,6 +425,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         // only pairs that are not mesh edges change it
         std::vector<std::pair<int, int>> extra, fresh;
         if (contact->active.size() + contact->para.size()) contact->connectivity(extra);
+        if (fricDHat > 0.0 && selfFric > 0.0) contact->frictionConnectivity(extra); // lagged set (:3565-3566)
         for (const auto& e : extra) {
             const int* b = mesh.nb.data() + mesh.nbPtr[e.first];
             const int* en = mesh.nb.data() + mesh.nbPtr[e.first + 1];
@@ -421,6 +477,13 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         for (auto& h : planes)
             h->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin.d_rowBase.p, lin.d_rowLen.p, dHat, kappa, projectDBC, lin.d_a.p);
         if (selfCollision) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
+        if (fricDHat > 0.0) { // Optimizer.cpp:3677-3702
+            for (auto& h : planes)
+                if (h->friction > 0.0)
+                    h->frictionHessianAdd(mesh.d_x.p, d_xPrev.p, mesh.d_dbc.p, lin.d_rowBase.p, lin.d_rowLen.p, fricDHat, projectDBC, lin.d_a.p);
+            if (selfCollision && selfFric > 0.0)
+                contact->frictionHessianAdd(mesh.d_x.p, d_xPrev.p, mesh.d_dbc.p, lin, fricDHat, selfFric, projectDBC, lin.d_a.p);
+        }
     }
 }
 
@@ -583,6 +646,13 @@ void HipOptimizer::beginTimestep()
         closeHSVal.clear();
         closeID.clear();
         closeVal.clear();
+        // friction: lagged sets reset, eps_v^2 h^2 (Optimizer.cpp:1525-1533, 286-304), then lagged at x^n (:1553-1600)
+        if (contact) contact->frictionLagClear();
+        for (auto& h : planes) h->lagClear();
+        fricDHat0 = epsV * epsV * dtSq * mesh.bboxDiag2;
+        fricDHat = solveFric() ? fricDHat0 : -1.0;
+        fricIterI = 0;
+        updateFrictionLag();
     }
     lastEnergyVal = computeEnergyVal(); // Optimizer.cpp:1609
     k = 0;
@@ -647,9 +717,12 @@ int HipOptimizer::solveTimestep(int maxIter)
 {
     beginTimestep();
     int it = 0;
-    while (it < maxIter) {
-        if (newtonIter()) break;
-        ++it;
+    for (;;) {
+        while (it < maxIter) {
+            if (newtonIter()) break;
+            ++it;
+        }
+        if (it >= maxIter || !nextSubproblem()) break; // friction lagging iterations (fricIterAmt)
     }
     endTimestep();
     return it;

@@ -437,6 +437,49 @@ class Context:
         self._chk(self._L.ipcgpu_halfspace_step_bound(self.h, C.c_int(idx), _dp(p), C.c_double(slackness), C.byref(s)))
         return s.value
 
+    def set_friction(self, self_fric=0.0, fric_iter_amt=1, eps_v=1e-3):
+        self._chk(self._L.ipcgpu_opt_set_friction(self.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v)))
+
+    def set_half_space_friction(self, idx, mu):
+        self._chk(self._L.ipcgpu_opt_set_half_space_friction(self.h, C.c_int(idx), C.c_double(mu)))
+
+    def next_subproblem(self):
+        more = C.c_int()
+        self._chk(self._L.ipcgpu_opt_next_subproblem(self.h, C.byref(more)))
+        return bool(more.value)
+
+    def friction_state(self):
+        sc = np.zeros(4)
+        self._chk(self._L.ipcgpu_opt_get_friction_state(self.h, _dp(sc), None))
+        lam = np.zeros(int(sc[1]))
+        if lam.size:
+            self._chk(self._L.ipcgpu_opt_get_friction_state(self.h, _dp(sc), _dp(lam)))
+        return dict(fricDHat=sc[0], n_lagged=int(sc[1]), fric_iter=int(sc[2]), n_half_space_lagged=int(sc[3]), lam=lam)
+
+    def friction_update(self, dHat, kappa):
+        n = C.c_int()
+        self._chk(self._L.ipcgpu_friction_update(self.h, C.c_double(dHat), C.c_double(kappa), C.byref(n)))
+        lam, co, ba = np.zeros(n.value), np.zeros((n.value, 2)), np.zeros((n.value, 6))
+        if n.value:
+            self._chk(self._L.ipcgpu_friction_get(self.h, _dp(lam), _dp(co), _dp(ba)))
+        return dict(lam=lam, coord=co, basis=ba)
+
+    def friction_energy(self, Vt, eps2, coef):
+        Vt = np.asfortranarray(Vt, dtype=np.float64)
+        E = C.c_double()
+        self._chk(self._L.ipcgpu_friction_energy(self.h, _dp(Vt), C.c_double(eps2), C.c_double(coef), C.byref(E)))
+        return E.value
+
+    def friction_gradient_add(self, Vt, eps2, coef, grad=None):
+        Vt = np.asfortranarray(Vt, dtype=np.float64)
+        g = np.zeros(3 * self.nV) if grad is None else _f64(grad).copy()
+        self._chk(self._L.ipcgpu_friction_gradient_add(self.h, _dp(Vt), C.c_double(eps2), C.c_double(coef), _dp(g)))
+        return g
+
+    def friction_hessian_add(self, Vt, eps2, coef, projectDBC=True):
+        Vt = np.asfortranarray(Vt, dtype=np.float64)
+        self._chk(self._L.ipcgpu_friction_hessian_add(self.h, _dp(Vt), C.c_double(eps2), C.c_double(coef), C.c_int(int(projectDBC))))
+
     def set_velocity(self, vel):
         vel = _f64(np.asarray(vel).reshape(-1))
         assert vel.size == 3 * self.nV
