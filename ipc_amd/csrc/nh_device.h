@@ -87,7 +87,7 @@ __device__ inline void svd3(const double Fin[9], double U[9], double s[3], doubl
             double al = G[3 * p] * G[3 * p] + G[3 * p + 1] * G[3 * p + 1] + G[3 * p + 2] * G[3 * p + 2];
             double be = G[3 * q] * G[3 * q] + G[3 * q + 1] * G[3 * q + 1] + G[3 * q + 2] * G[3 * q + 2];
             double ga = G[3 * p] * G[3 * q] + G[3 * p + 1] * G[3 * q + 1] + G[3 * p + 2] * G[3 * q + 2];
-            if (ga != 0.0 && ga * ga > 1e-32 * (al * be)) {
+            if (ga != 0.0 && ga * ga > 1e-30 * (al * be)) { // below ~1e-15 relative the "rotation" is rounding noise: 1e-32 made 2 % of the lanes (hence most waves) run all 30 sweeps
                 rotated = true;
                 const double zeta = (be - al) * (0.5 * fast_rcp(ga));
                 const double t = copysign(fast_rcp(fabs(zeta) + fast_sqrt(1.0 + zeta * zeta)), zeta);
@@ -161,7 +161,7 @@ __device__ inline void make_pd3(double S[6])
     for (int sweep = 0; sweep < 50; ++sweep) {
         double off = A[1] * A[1] + A[2] * A[2] + A[5] * A[5];
         double dg = A[0] * A[0] + A[4] * A[4] + A[8] * A[8];
-        if (off <= 1e-32 * dg || off == 0.0) break;
+        if (off <= 1e-30 * dg || off == 0.0) break;
 #pragma unroll
         for (int pq = 0; pq < 3; ++pq) {
             const int p = (pq == 2) ? 1 : 0;
@@ -212,7 +212,9 @@ __device__ __forceinline__ void make_pd2d(double& m00, double& m01, double& m11)
     const double b2 = b * b;
     const double D = a * d - b2;
     const double T_div_2 = (a + d) / 2.0;
-    const double sqrtTT4D = sqrt(T_div_2 * T_div_2 - D);
+    const double disc = T_div_2 * T_div_2 - D;
+    if (!(disc >= 0.0)) return; // the reference's sqrt gives NaN here and every comparison below is then false
+    const double sqrtTT4D = fast_sqrt(disc);
     const double L2 = T_div_2 - sqrtTT4D;
     if (L2 < 0.0) {
         const double L1 = T_div_2 + sqrtTT4D;
@@ -246,12 +248,13 @@ __device__ __forceinline__ void shape_grads(const double A[9], double b[4][3])
 }
 
 // First Piola-Kirchhoff stress times w (NeoHookeanEnergy.cpp:138-153): P = mu (F - F^-T) + lam ln J F^-T
-__device__ __forceinline__ void piola(const double F[9], double mu, double lam, double w, double P[9])
+// Returns ln J so that the sigma-space derivatives of the same element do not evaluate a second logarithm.
+__device__ __forceinline__ double piola(const double F[9], double mu, double lam, double w, double P[9])
 {
     if (mu == 0.0 && lam == 0.0) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) P[i] = 0.0;
-        return;
+        return 0.0;
     }
     double C[9]; // cofactor (IglUtils.hpp:448-458), column-major
     C[0] = F[4] * F[8] - F[7] * F[5];
@@ -264,13 +267,15 @@ __device__ __forceinline__ void piola(const double F[9], double mu, double lam, 
     C[5] = F[6] * F[1] - F[0] * F[7];
     C[8] = F[0] * F[4] - F[3] * F[1];
     const double J = F[0] * C[0] + F[3] * C[3] + F[6] * C[6];
-    const double invJ = 1.0 / J;
-    const double k = lam * log(J);
+    const double invJ = fast_rcp(J);
+    const double lnJ = log(J);
+    const double k = lam * lnJ;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         double fit = C[i] * invJ;
         P[i] = w * (mu * (F[i] - fit) + k * fit);
     }
+    return lnJ;
 }
 
 __device__ __forceinline__ bool projected_dbc(int type, int projectDBC)
@@ -314,9 +319,10 @@ __device__ __forceinline__ void element_generators(const ElemView& v, int t, dou
     shape_grads(A, b);
 #pragma unroll
     for (int k = 0; k < 4; ++k) g.dtype[k] = v.dbc[g.vid[k]];
+    double lnJ = 0.0;
     if (wantGrad) {
         double P[9];
-        piola(F, mu, lam, w, P);
+        lnJ = piola(F, mu, lam, w, P);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (projectDBC && g.dtype[k] != 0) continue; // Energy.cpp:284-288
@@ -329,11 +335,11 @@ __device__ __forceinline__ void element_generators(const ElemView& v, int t, dou
     double s[3], V[9];
     svd3(F, g.U, s, V);
     // sigma-space derivatives (NeoHookeanEnergy.cpp:71-136)
-    const double L = log(s[0] * s[1] * s[2]);
+    const double L = wantGrad ? lnJ : log(s[0] * s[1] * s[2]); // det F = s0 s1 s2 (U, V rotations)
     double dE[3], inv[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        inv[i] = 1.0 / s[i];
+        inv[i] = fast_rcp(s[i]);
         dE[i] = mu * (s[i] - inv[i]) + lam * inv[i] * L;
     }
     double A3[6];
@@ -357,7 +363,7 @@ __device__ __forceinline__ void element_generators(const ElemView& v, int t, dou
         double rc = dE[k] + dE[kp];
         const double ss = s[k] + s[kp];
         const double eps = 1.0e-6;
-        rc /= (ss < eps) ? (2.0 * eps) : (2.0 * ss);
+        rc *= fast_rcp((ss < eps) ? (2.0 * eps) : (2.0 * ss));
         B00[k] = B11[k] = BL[k] + rc;
         B01[k] = BL[k] - rc;
         make_pd2d(B00[k], B01[k], B11[k]);

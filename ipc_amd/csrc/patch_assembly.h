@@ -3,11 +3,11 @@
 // L2 atomics cap a tet-parallel scatter at ~30 G fp64 adds/s (90 adds per element, 8x the time of the
 // arithmetic) and same-address LDS atomics are no better.  Here every workgroup owns a spatially compact patch
 // of nodes, i.e. complete block rows of the symmetric-upper CSR (LinSysSolver.hpp:46-150):
-//   phase 1  one lane per element touching the patch: F, P, SVD, clamped sigma-space matrices -> 33 doubles of
+//   phase 1  one lane per element touching the patch: F, P, SVD, clamped sigma-space matrices -> 36 doubles of
 //            "generators" per element staged in LDS (halo elements are re-evaluated by the neighbouring patch)
 //   phase 2  one lane per (owned destination block, <= 8 contributions): rebuilds each contributing 3x3 block
 //            H_ac = U T_ac U^T from the staged generators, sums in registers, combines the chunks of a block by a
-//            wave-level segmented reduction (shuffles), adds the lumped mass / Dirichlet identity
+//            segmented reduction inside a 16-lane row (DPP row shifts), adds the lumped mass / Dirichlet identity
 //            (Optimizer.cpp:3638-3668) and stores the block once.  Deterministic: fixed summation order.
 //   gradient nodal forces accumulate in LDS (12 adds per element), inertia term added at the flush (:3438-3450)
 // No memset, no second kernel, no global atomics: every CSR value and gradient entry is written exactly once.
@@ -29,12 +29,11 @@ struct PatchView {
     const int* tets;
     const uint16_t* gradSlot; // SoA [4][totalTets]: local index of the owned node or 0xFFFF
     long long totalTets;
-    const int* itemPtr; // nPatches+1: work items of phase 2 (padded so that a block never straddles a wave)
-    const int* itemP0; // CSR index of the block's first entry (row 0), -1 = padding
-    const uint32_t* itemMeta; // rowLen (16) | segLen (4) | segPos (4) | isDiag (1)
-    const int* itemRow; // row node of the block
-    const int* itemCPtr; // contribution range [itemCPtr[i], itemCPtr[i+1])
-    const uint32_t* contrib; // tetLocal (16) | ka (2) | kc (2) | transpose (1)
+    const int* itemPtr; // nPatches+1: work items of phase 2 (padded so that a block never straddles a 16-lane row)
+    const int4* itemHdr; // x: CSR index of the block's first entry (row 0), -1 = padding; y: rowLen (16) | segLen (4) | segPos (4) |
+                         // isDiag (1) | contributions of this chunk (7); z: row node of the block; w: first contribution
+    const uint4* itemC4; // the chunk's first four contribution words (one 16-byte read instead of a pointer chase)
+    const uint32_t* contrib; // tetLocal (16) | ka (2) | kc (2)
 };
 
 struct PatchPlan {
@@ -42,8 +41,10 @@ struct PatchPlan {
     long long totalTets = 0, totalItems = 0, totalContribs = 0;
     int maxTets = 0, maxNodes = 0;
     double haloFactor = 0; // patch-tet instances / elements
-    DevBuf<int> nodePtr, nodes, tetPtr, tets, itemPtr, itemP0, itemRow, itemCPtr;
-    DevBuf<uint32_t> itemMeta, contrib;
+    DevBuf<int> nodePtr, nodes, tetPtr, tets, itemPtr;
+    DevBuf<int4> itemHdr;
+    DevBuf<uint4> itemC4;
+    DevBuf<uint32_t> contrib;
     DevBuf<uint16_t> gradSlot;
     bool valid = false;
 

@@ -11,19 +11,30 @@ namespace ipcgpu {
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int NF = 33; // staged doubles per element: U 9, beta_1..3 9, Ad 6, Bd 6, Bo 3
+constexpr int NF = 38; // staged doubles per element (one 304-byte record: 76 dwords = 12 mod 64, so records spread over the LDS banks):
+                        // U 9, Ad 6, Bd 6, Bo 3, beta_0..3 12, projection mask (int), pad
 constexpr int CHUNK = 4; // contributions per phase-2 lane
-constexpr int MAXSEG = 8; // chunks per block (wave-level segmented reduction over 1, 2, 4 lanes)
+constexpr int MAXSEG = 8; // chunks per block (segmented reduction over 1, 2, 4 lanes of a 16-lane row)
 using namespace dev;
+
+// lane i <- lane i + N inside its 16-lane row (v_mov_b32 row_shl:N), zero shifted in
+template <int N>
+__device__ __forceinline__ double row_shl(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + N, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + N, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
 
 template <bool HESS>
 __global__ __launch_bounds__(BLOCK) void k_assemble_patch(ElemView v, PatchView pv, int patchBegin, int tcap, int ncap, double coef,
     int projectDBC, double* __restrict__ grad, double* __restrict__ a, int probe)
 {
-    extern __shared__ double lds[];
-    double* stage = lds; // [NF][tcap]
+    extern __shared__ __align__(16) double lds[];
+    double* stage = lds; // [tcap][NF]: phase 2 reads a record with 128-bit LDS loads, the two beta rows by dynamic offset
     double* gacc = lds + (size_t)NF * tcap; // [3 * ncap]
-    int* pm = reinterpret_cast<int*>(gacc + 3 * ncap); // [tcap] projection mask (bit k: node k projected, bit 4: active)
+    // record slot 36 (as int): projection mask (bit k: node k projected, bit 4: active)
     const int p = patchBegin + blockIdx.x;
     const int n0 = pv.nodePtr[p], nOwned = pv.nodePtr[p + 1] - n0;
     const int t0 = pv.tetPtr[p], nTets = pv.tetPtr[p + 1] - t0;
@@ -49,96 +60,109 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_patch(ElemView v, PatchView 
 #pragma unroll
             for (int k = 0; k < 4; ++k)
                 if (projected_dbc(g.dtype[k], projectDBC)) mask |= (1 << k);
-            pm[tl] = mask;
+            double* e = stage + (size_t)tl * NF;
+            *reinterpret_cast<int*>(e + 36) = mask;
             if (g.active) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) stage[(size_t)i * tcap + tl] = g.U[i];
+                for (int i = 0; i < 9; ++i) e[i] = g.U[i];
 #pragma unroll
-                for (int k = 1; k < 4; ++k)
+                for (int i = 0; i < 6; ++i) e[9 + i] = g.Ad[i];
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) stage[(size_t)(9 + 3 * (k - 1) + q) * tcap + tl] = g.beta[k][q];
+                for (int i = 0; i < 6; ++i) e[15 + i] = g.Bd[i];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) stage[(size_t)(18 + i) * tcap + tl] = g.Ad[i];
+                for (int i = 0; i < 3; ++i) e[21 + i] = g.Bo[i];
 #pragma unroll
-                for (int i = 0; i < 6; ++i) stage[(size_t)(24 + i) * tcap + tl] = g.Bd[i];
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                for (int i = 0; i < 3; ++i) stage[(size_t)(30 + i) * tcap + tl] = g.Bo[i];
+                    for (int q = 0; q < 3; ++q) e[24 + 3 * k + q] = g.beta[k][q];
             }
         }
     }
     __syncthreads();
     // ---- phase 2: one lane per (destination block, <= CHUNK contributions)
     if (HESS && a && probe != 1) {
+        // Every global read of a pass is issued before the pass's arithmetic (and the next pass's reads before this
+        // pass's): a dependent item -> range -> contribution -> LDS chain costs four memory latencies per pass, which two
+        // waves per SIMD cannot hide.
         const int i0 = pv.itemPtr[p], i1 = pv.itemPtr[p + 1];
+        const int4 hdrPad = make_int4(-1, 1 << 16, 0, 0); // padding: segLen 1, segPos 0, no contributions
+        const uint4 c4Pad = make_uint4(0, 0, 0, 0);
+        int4 hdr = hdrPad;
+        uint4 c4 = c4Pad;
+        if (i0 + tid < i1) {
+            hdr = pv.itemHdr[i0 + tid];
+            c4 = pv.itemC4[i0 + tid];
+        }
         for (int base = i0; base < i1; base += BLOCK) {
-            const int it = base + tid;
-            const int p0 = (it < i1) ? pv.itemP0[it] : -1;
+            int4 hdrN = hdrPad;
+            uint4 c4N = c4Pad;
+            if (base + BLOCK + tid < i1) {
+                hdrN = pv.itemHdr[base + BLOCK + tid];
+                c4N = pv.itemC4[base + BLOCK + tid];
+            }
+            const int p0 = hdr.x, rowNode = hdr.z;
+            const uint32_t meta = (uint32_t)hdr.y;
+            const int nC = (int)(meta >> 25);
+            int rowDbc = 0;
+            double rowMass = 0.0;
+            if (p0 >= 0 && ((meta >> 20) & 15) == 0) {
+                rowDbc = v.dbc[rowNode];
+                rowMass = v.mass[rowNode];
+            }
             double S[3][3];
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) S[i][r] = 0.0;
-            uint32_t meta = 1u << 16; // segLen 1, segPos 0
-            int rowNode = 0;
-            if (p0 >= 0) {
-                meta = pv.itemMeta[it];
-                rowNode = pv.itemRow[it];
-                const int c0 = pv.itemCPtr[it], c1 = pv.itemCPtr[it + 1];
-                for (int c = c0; c < c1; ++c) {
-                    const uint32_t cw = pv.contrib[c];
-                    const int tl = cw & 0xFFFF, ka = (cw >> 16) & 3, kc = (cw >> 18) & 3;
-                    const int mask = pm[tl];
-                    if (!(mask & 16) || (mask & ((1 << ka) | (1 << kc)))) continue; // IglUtils.hpp:45-53: projected rows / columns dropped
-                    double U[9], ba[3], bc[3], Ad[6], Bd[6], Bo[3];
+            auto accumulate = [&](uint32_t cw) {
+                const int tl = cw & 0xFFFF, ka = (cw >> 16) & 3, kc = (cw >> 18) & 3;
+                const double* e = stage + (size_t)tl * NF;
+                const int mask = *reinterpret_cast<const int*>(e + 36);
+                if (!(mask & 16) || (mask & ((1 << ka) | (1 << kc)))) return; // IglUtils.hpp:45-53: projected rows / columns dropped
+                const double2* e2 = reinterpret_cast<const double2*>(e);
+                double rec[24];
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) U[i] = stage[(size_t)i * tcap + tl];
-                    double b1[3], b2[3], b3[3];
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        b1[q] = stage[(size_t)(9 + q) * tcap + tl];
-                        b2[q] = stage[(size_t)(12 + q) * tcap + tl];
-                        b3[q] = stage[(size_t)(15 + q) * tcap + tl];
-                    }
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const double b0 = -b1[q] - b2[q] - b3[q];
-                        ba[q] = ka == 0 ? b0 : (ka == 1 ? b1[q] : (ka == 2 ? b2[q] : b3[q]));
-                        bc[q] = kc == 0 ? b0 : (kc == 1 ? b1[q] : (kc == 2 ? b2[q] : b3[q]));
-                    }
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) {
-                        Ad[i] = stage[(size_t)(18 + i) * tcap + tl];
-                        Bd[i] = stage[(size_t)(24 + i) * tcap + tl];
-                    }
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) Bo[i] = stage[(size_t)(30 + i) * tcap + tl];
-                    double H[3][3];
-                    pair_block(U, ba, bc, Ad, Bd, Bo, H);
-#pragma unroll
-                    for (int i = 0; i < 3; ++i)
-#pragma unroll
-                        for (int r = 0; r < 3; ++r) S[i][r] += H[i][r];
+                for (int i = 0; i < 12; ++i) {
+                    const double2 t = e2[i];
+                    rec[2 * i] = t.x;
+                    rec[2 * i + 1] = t.y;
                 }
-            }
-            // wave-level segmented reduction over the (<= 4) chunks of a block, which sit in adjacent lanes
+                const double *U = rec, *Ad = rec + 9, *Bd = rec + 15, *Bo = rec + 21;
+                const double *pa = e + 24 + 3 * ka, *pc = e + 24 + 3 * kc;
+                const double ba[3] = { pa[0], pa[1], pa[2] }, bc[3] = { pc[0], pc[1], pc[2] };
+                double H[3][3];
+                pair_block(U, ba, bc, Ad, Bd, Bo, H);
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) S[i][r] += H[i][r];
+            };
+            if (nC > 0) accumulate(c4.x);
+            if (nC > 1) accumulate(c4.y);
+            if (nC > 2) accumulate(c4.z);
+            if (nC > 3) accumulate(c4.w);
+            for (int c = 4; c < nC; ++c) accumulate(pv.contrib[hdr.w + c]); // blocks with more than 4 * MAXSEG contributions
+            // segmented reduction over the (<= MAXSEG) chunks of a block, which sit in adjacent lanes of one 16-lane row:
+            // DPP row shifts (lanes shifted in from outside the row read 0 and are masked out anyway)
             const int segLen = (meta >> 16) & 15, segPos = (meta >> 20) & 15;
+            const bool m1 = segPos + 1 < segLen, m2 = segPos + 2 < segLen, m4 = segPos + 4 < segLen;
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
-                    double t1 = __shfl_down(S[i][r], 1, 64);
-                    if (segPos + 1 < segLen) S[i][r] += t1;
-                    double t2 = __shfl_down(S[i][r], 2, 64);
-                    if (segPos + 2 < segLen) S[i][r] += t2;
-                    double t4 = __shfl_down(S[i][r], 4, 64);
-                    if (segPos + 4 < segLen) S[i][r] += t4;
+                    const double t1 = row_shl<1>(S[i][r]);
+                    S[i][r] += m1 ? t1 : 0.0;
+                    const double t2 = row_shl<2>(S[i][r]);
+                    S[i][r] += m2 ? t2 : 0.0;
+                    const double t4 = row_shl<4>(S[i][r]);
+                    S[i][r] += m4 ? t4 : 0.0;
                 }
             if (p0 >= 0 && segPos == 0) {
                 const int L = meta & 0xFFFF;
                 const bool isDiag = (meta >> 24) & 1;
-                const bool proj = projected_dbc(v.dbc[rowNode], projectDBC);
+                const bool proj = projected_dbc(rowDbc, projectDBC);
                 if (isDiag) {
-                    const double m = v.mass[rowNode];
+                    const double m = rowMass;
                     if (proj) { // Optimizer.cpp:3654-3663
                         S[0][0] = S[1][1] = S[2][2] = 1.0;
                         S[0][1] = S[0][2] = S[1][2] = 0.0;
@@ -164,6 +188,8 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_patch(ElemView v, PatchView 
                     }
                 }
             }
+            hdr = hdrN;
+            c4 = c4N;
         }
     }
     // ---- gradient flush: elastic forces + m (x - xTilde)  (Optimizer.cpp:3438-3450)
@@ -291,10 +317,10 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
             const int n = (int)cl.size();
             const int chunk = std::max(CHUNK, (n + MAXSEG - 1) / MAXSEG);
             const int segLen = std::max(1, (n + chunk - 1) / chunk);
-            // a block's chunks must stay inside one wave
-            const int posInWave = ((int)hP0.size() - itemStart) % 64;
-            if (posInWave + segLen > 64)
-                for (int pad = posInWave; pad < 64; ++pad) pushItem(-1, 0, 1, 0, false, 0, nullptr, nullptr);
+            // a block's chunks must stay inside one 16-lane DPP row
+            const int posInRow = ((int)hP0.size() - itemStart) % 16;
+            if (posInRow + segLen > 16)
+                for (int pad = posInRow; pad < 16; ++pad) pushItem(-1, 0, 1, 0, false, 0, nullptr, nullptr);
             for (int sgi = 0; sgi < segLen; ++sgi) {
                 const int b = sgi * chunk, e = std::min(n, b + chunk);
                 pushItem(p0, L, segLen, sgi, isDiag, row, cl.data() + b, cl.data() + e);
@@ -329,16 +355,24 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
     totalItems = (long long)hP0.size();
     totalContribs = (long long)hContrib.size();
     if (hContrib.empty()) hContrib.push_back(0);
+    std::vector<int4> hHdr(hP0.size());
+    std::vector<uint4> hC4(hP0.size());
+    for (size_t i = 0; i < hP0.size(); ++i) {
+        const int c0 = hCPtr[i], n = hCPtr[i + 1] - c0;
+        if (n > 127) throw StateError("more than 127 element contributions in one chunk of a CSR block");
+        hHdr[i] = make_int4(hP0[i], (int)(hMeta[i] | ((uint32_t)n << 25)), hRow[i], c0);
+        uint32_t w[4] = { 0, 0, 0, 0 };
+        for (int k = 0; k < 4 && k < n; ++k) w[k] = hContrib[c0 + k];
+        hC4[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
     nodePtr.upload(hNodePtr, s);
     nodes.upload(hNodes, s);
     tetPtr.upload(hTetPtr, s);
     tets.upload(hTets, s);
     gradSlot.upload(hGrad, s);
     itemPtr.upload(hItemPtr, s);
-    itemP0.upload(hP0, s);
-    itemMeta.upload(hMeta, s);
-    itemRow.upload(hRow, s);
-    itemCPtr.upload(hCPtr, s);
+    itemHdr.upload(hHdr, s);
+    itemC4.upload(hC4, s);
     contrib.upload(hContrib, s);
     HIP_CHECK(hipStreamSynchronize(s));
     valid = true;
@@ -355,10 +389,8 @@ PatchView PatchPlan::view() const
     pv.gradSlot = gradSlot.p;
     pv.totalTets = totalTets;
     pv.itemPtr = itemPtr.p;
-    pv.itemP0 = itemP0.p;
-    pv.itemMeta = itemMeta.p;
-    pv.itemRow = itemRow.p;
-    pv.itemCPtr = itemCPtr.p;
+    pv.itemHdr = itemHdr.p;
+    pv.itemC4 = itemC4.p;
     pv.contrib = contrib.p;
     return pv;
 }
@@ -366,7 +398,7 @@ PatchView PatchPlan::view() const
 size_t PatchPlan::ldsBytes() const
 {
     const size_t tcap = (size_t)((maxTets + 63) / 64 * 64);
-    return sizeof(double) * (NF * tcap + 3 * (size_t)maxNodes) + sizeof(int) * tcap;
+    return sizeof(double) * (NF * tcap + 3 * (size_t)maxNodes);
 }
 
 void launch_assemble_patches(const ElemView& v, const PatchPlan& plan, int patchBegin, int patchEnd, double coef, int projectDBC,
