@@ -69,6 +69,10 @@ int ipcgpu_clear_dbc(ipcgpu_ctx*);
 /* one `componentMaterial` entry of Mesh::setLameParam (Mesh.cpp:661-671; `shapes ... material rho E nu` in the scene script):
  * nodes [nodeBegin, nodeEnd) get density rho, tets [tetBegin, tetEnd) get (YM, PR).  Call after ipcgpu_set_mesh. */
 int ipcgpu_set_component_material(ipcgpu_ctx*, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR);
+/* Config `energy NH|FCR` (src/Config.cpp:23-24,107-111; selects NeoHookeanEnergy or FixedCoRotEnergy in main.cpp): 0 = NH,
+ * 1 = FCR (src/Energy/Physics_Elasticity/FixedCoRotEnergy.cpp:62-153).  FCR has no element-inversion safeguard
+ * (Energy<dim>(false)): inversion checks and the injective step filter are skipped as in Optimizer.cpp:252,517,545,2710. */
+int ipcgpu_set_energy_type(ipcgpu_ctx*, int energy_type);
 /* Mesh::V (current positions) */
 int ipcgpu_set_positions(ipcgpu_ctx*, const double* V_colmajor);
 int ipcgpu_get_positions(ipcgpu_ctx*, double* V_colmajor);

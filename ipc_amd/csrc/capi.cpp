@@ -173,6 +173,15 @@ int ipcgpu_set_component_material(ipcgpu_ctx* c, int nodeBegin, int nodeEnd, int
         return IPCGPU_OK;
     });
 }
+int ipcgpu_set_energy_type(ipcgpu_ctx* c, int energyType)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        needArg(energyType == 0 || energyType == 1, "energy type: 0 = NH, 1 = FCR");
+        m.energyType = energyType;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_set_dbc(ipcgpu_ctx* c, int n, const int* ids, int type)
 {
     return guarded([&] {

@@ -39,6 +39,7 @@ public:
     // Mesh::computeFeatures + computeMassMatrix + setLameParam (Mesh.cpp:414-527, 246-266, 399-401, 660-671)
     void computeFeatures(int nV, int nT, const double* Vrest, const int* F, double YM, double PR, double density, hipStream_t s);
     void uploadDBC(hipStream_t s);
+    int energyType = 0; // Config `energy NH|FCR` (Config.cpp:23-24): 0 neo-Hookean, 1 fixed corotated
     double density = 0; // global density handed to computeFeatures (component overrides rescale the nodal mass by rho / density)
     void setComponentMaterial(int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR, hipStream_t s);
     bool isDBCVertex(int v) const { return dbcType[v] != 0; }

@@ -38,6 +38,7 @@ ElemView HipOptimizer::view() const
     v.nT = mesh.nT;
     v.tetBegin = tetBegin;
     v.tetEnd = tetEnd;
+    v.energyType = mesh.energyType;
     v.x = mesh.d_x.p;
     v.xTilde = mesh.d_xTilde.p;
     v.mass = mesh.d_mass.p;
@@ -489,6 +490,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
 
 bool HipOptimizer::checkInversion()
 {
+    if (mesh.energyType == 1) return true; // Optimizer.cpp:252,517,545,2710: only under getNeedElemInvSafeGuard()
     d_flag.zero(stream);
     launch_check_inversion(view(), d_flag.p, stream);
     launch_publish(d_flag.p, h_flag.dev, 1, stream);
@@ -506,6 +508,7 @@ bool HipOptimizer::checkInversion()
 double HipOptimizer::filterStepSize(const double* p_dev, double stepSize)
 {
     // Energy.cpp:565-581: min over elements of the root, applied only when 0 < min < stepSize
+    if (mesh.energyType == 1) return stepSize; // :567 needElemInvSafeGuard
     launch_fill(d_scalar.p + 2, 1, 1e20, stream);
     launch_inversion_step(view(), p_dev, 0.2, d_scalar.p + 2, stream);
     reduceMin(d_scalar.p + 2, 1);

@@ -34,7 +34,9 @@ constexpr int NB = 32;
 constexpr int LDP = NB + 1; // padded leading dimension of 32x32 blocks in LDS
 constexpr int WG = 256;
 constexpr int WGB = WG; // big-front step: three row waves + one pivot wave, one per SIMD
-constexpr int ROWS_B = WGB - 64; // panel rows per role-B workgroup
+constexpr int ROW_WAVES_B = 3; // row waves per role-B workgroup (1 was measured slower: 3x the workgroups, each repeating the pivot work)
+constexpr int ROWS_B = 64 * ROW_WAVES_B; // panel rows per role-B workgroup
+constexpr int PIVOT_T0 = WGB - 64; // first thread of the pivot wave
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
 constexpr int TS = 64; // trailing-update tile
@@ -159,6 +161,64 @@ __device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lan
                 const double ljj = bcast_lane(row[j], jj);
                 row[jj] -= row[j] * ljj;
             }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (lane < w && k <= lane && k < w) blk[k * ld + lane] = row[k];
+    if (lane < NB) rdiag[lane] = myRd;
+    return bad;
+}
+
+// Same factorisation with the cross-lane traffic split by urgency.  Column j is needed (a) by the next two pivots, through
+// L(j+1, j) and L(j+2, j): two v_readlane pairs on the critical chain; (b) by the columns further right: those multipliers
+// go through a 32-double LDS line (one ds_write per column, 128-bit broadcast reads) and are consumed one column later, so
+// their LDS round trip and their FMAs sit in the shadow of the next pivot's rsqrt chain instead of in front of it.
+// colbuf: 32 doubles of LDS, 16-byte aligned, private to this wave.
+__device__ __forceinline__ bool wave_potrf32p(double* blk, int ld, int w, int lane, double* rdiag, double* colbuf)
+{
+    bool bad = false;
+    double row[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) row[k] = (lane < w && k <= lane && k < w) ? blk[k * ld + (lane & (NB - 1))] : 0.0;
+    double myRd = 0.0;
+    double pend[NB]; // multipliers L(jj, j - 1), jj >= j + 2, read from LDS during column j - 1
+    double prevCol = 0.0; // this lane's L(r, j - 1)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < w) { // uniform
+            double djj = bcast_lane(row[j], j);
+            if (!(djj > 0.0)) {
+                bad = true;
+                djj = 1.0;
+            }
+            const double invd = rsqrt_nr(djj);
+            if (lane == j) myRd = invd;
+            row[j] *= invd;
+            if (j + 3 < NB && lane < NB) colbuf[lane] = row[j];
+            if (j + 1 < NB) row[j + 1] -= row[j] * bcast_lane(row[j], j + 1);
+            if (j + 2 < NB) row[j + 2] -= row[j] * bcast_lane(row[j], j + 2);
+        }
+        // deferred part of column j - 1
+        if (j >= 1 && j - 1 < w) {
+#pragma unroll
+            for (int jj = j + 2; jj < NB; ++jj) row[jj] -= prevCol * pend[jj];
+        }
+        if (j < w && j + 3 < NB) {
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            int jj = j + 3;
+            if (jj & 1) {
+                pend[jj] = colbuf[jj];
+                ++jj;
+            }
+#pragma unroll
+            for (; jj + 1 < NB; jj += 2) {
+                const double2 t = *reinterpret_cast<const double2*>(colbuf + jj);
+                pend[jj] = t.x;
+                pend[jj + 1] = t.y;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            prevCol = row[j];
         }
     }
 #pragma unroll
@@ -425,11 +485,11 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     const int R = kb1 + d.z + tid;
     const bool rowThread = tid < ROWS_B && R >= kb1 + w1 && R < N;
     double x[1][NB];
-    if (tid >= ROWS_B) {
+    if (tid >= PIVOT_T0) {
         // pivot wave (alone on its SIMD): Cholesky of the 32x32 block while the row waves fetch and update their rows
-        if (wave_potrf32(A11, LDP, w1, tid - ROWS_B, rdiag)) atomicOr(flag, 1);
+        if (wave_potrf32(A11, LDP, w1, tid - PIVOT_T0, rdiag)) atomicOr(flag, 1);
     }
-    else {
+    else if (tid < ROWS_B) {
         // row waves: X(64 x 32) = raw - P_kb(64 x 32) Lp^T on the matrix cores.  v_mfma_f64_16x16x4_f64: A[l&15][l>>4],
         // B[l>>4][l&15], D col = l&15, row = (l>>4) + 4 reg.  One LDS read feeds 1024 FMAs instead of one.
         const int wv = tid >> 6, l = tid & 63;
@@ -482,70 +542,74 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 
 // Schur complement of a big front in one pass: S(i, j) -= sum_{c < nc} L(i, c) L(j, c) for i, j >= nc.  Doing this per
 // 32-column step (right-looking) re-reads and re-writes the whole update matrix every step, which made the middle levels
-// of the tree HBM-bound; here every tile is read-modify-written once.  desc = (front, ti, tj, 0), 64 x 64 tiles, ti >= tj.
+// of the tree HBM-bound; here every tile is read-modify-written once.  desc = (front, ti, tj, 0), 32 x 32 tiles, ti >= tj.
+// One workgroup per 32 x 32 tile of S, four waves that split the nc columns of L between them (chunk c goes to wave c mod 4)
+// and combine through LDS in a fixed order at the end.  Upper levels of the tree have a handful of fronts: with 64 x 64
+// tiles and a serial loop over all of nc, a level was a few dozen workgroups each waiting out nc / 32 dependent
+// load -> multiply rounds.  The MFMA operands come straight from the front (a lane's A / B entry is one double of L; 16
+// lanes read 16 consecutive rows), so the loop has no LDS staging and no barrier.  The product is formed transposed,
+// D(j, i): the 16 lanes of an accumulator row hold 16 consecutive rows i of one column j, which makes the read-modify-write
+// of the column-major front 128-byte contiguous.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15],
+// D column = l & 15, row = (l >> 4) + 4 reg.
+constexpr int TQ = 32; // Schur tile
 __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
 {
-    __shared__ double As[NB][TS];
-    __shared__ double Bs[NB][TS];
+    __shared__ double red[4][4][256]; // [wave][16 x 16 tile][D layout: 64 lanes x 4]
     const int4 d = desc[blockIdx.x];
     const int s = d.x;
     const int N = frontN(tv, s), nc = frontNc(tv, s);
     double* F = fronts + tv.frontOff[s];
     const int tid = threadIdx.x;
-    const int i0 = nc + TS * d.y, j0 = nc + TS * d.z;
-    const int ty = tid & 15, tx = tid >> 4;
-    double acc[4][4];
+    const int i0 = nc + TQ * d.y, j0 = nc + TQ * d.z;
+    const int wv = tid >> 6, l = tid & 63;
+    const int ar = l & 15, ak = l >> 4;
+    f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i
 #pragma unroll
-    for (int ii = 0; ii < 4; ++ii)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-    // register double buffer: the chunk after the one being multiplied is already in flight
-    constexpr int PER = NB * TS / WG;
-    double ra[PER], rb[PER];
-    auto fetch = [&](int kc) {
-        const int w = min(NB, nc - kc);
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+    // rows past the end of the front are clamped: their products land in entries that are never written
+    const double* pa0 = F + min(i0 + ar, N - 1);
+    const double* pa1 = F + min(i0 + 16 + ar, N - 1);
+    const double* pb0 = F + min(j0 + ar, N - 1);
+    const double* pb1 = F + min(j0 + 16 + ar, N - 1);
+    const int nch = (nc + NB - 1) / NB;
+    for (int ch = wv; ch < nch; ch += 4) {
+        const int kc = NB * ch;
+        double a0[NB / 4], a1[NB / 4], b0[NB / 4], b1[NB / 4];
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int e = tid + WG * t, k = e / TS, i = e - k * TS;
-            const bool kin = k < w;
-            ra[t] = (kin && i0 + i < N) ? F[(i0 + i) + (long long)N * (kc + k)] : 0.0;
-            rb[t] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kc + k)] : 0.0;
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int k = kc + 4 * ks + ak;
+            const bool in = k < nc;
+            const long long off = (long long)N * min(k, nc - 1);
+            a0[ks] = in ? pa0[off] : 0.0;
+            a1[ks] = in ? pa1[off] : 0.0;
+            b0[ks] = in ? pb0[off] : 0.0;
+            b1[ks] = in ? pb1[off] : 0.0;
         }
-    };
-    fetch(0);
-    for (int kc = 0; kc < nc; kc += NB) {
-        __syncthreads();
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-            const int e = tid + WG * t, k = e / TS, i = e - k * TS;
-            As[k][i] = ra[t];
-            Bs[k][i] = rb[t];
-        }
-        __syncthreads();
-        if (kc + NB < nc) fetch(kc + NB);
-#pragma unroll 8
-        for (int k = 0; k < NB; ++k) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                av[ii] = As[k][4 * ty + ii];
-                bv[ii] = Bs[k][4 * tx + ii];
-            }
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[ks], a0[ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[ks], a1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[ks], a0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[ks], a1[ks], acc[1][1], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int col = j0 + 4 * tx + jj;
-        if (col >= N) continue;
+    for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-        for (int ii = 0; ii < 4; ++ii) {
-            const int row = i0 + 4 * ty + ii;
-            if (row < N && row >= col) F[row + (long long)N * col] -= acc[ii][jj];
-        }
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wv][2 * nj + mi][64 * r + l] = acc[nj][mi][r];
+    __syncthreads();
+    // wave q finishes 16 x 16 tile q = 2 nj + mi
+    const int nj = wv >> 1, mi = wv & 1;
+    const int row = i0 + 16 * mi + ar;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = j0 + 16 * nj + ak + 4 * r;
+        const double v = ((red[0][wv][64 * r + l] + red[1][wv][64 * r + l]) + red[2][wv][64 * r + l]) + red[3][wv][64 * r + l];
+        if (col < N && row < N && row >= col) F[row + (long long)N * col] -= v;
     }
 }
 
@@ -943,7 +1007,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         }
         P.schur.off = (int)desc.size();
         for (int s : big) {
-            const int nt = (sym.N(s) - sym.nc(s) + TS - 1) / TS;
+            const int nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
             for (int ti = 0; ti < nt; ++ti)
                 for (int tj = 0; tj <= ti; ++tj) desc.push_back(make_int4(s, ti, tj, 0));
         }

@@ -278,6 +278,37 @@ __device__ __forceinline__ double piola(const double F[9], double mu, double lam
     return lnJ;
 }
 
+// Fixed corotated (FixedCoRotEnergy.cpp:62-153) in sigma space
+__device__ __forceinline__ double fcr_psi(const double s[3], double mu, double lam)
+{
+    const double d0 = s[0] - 1.0, d1 = s[1] - 1.0, d2 = s[2] - 1.0;
+    const double pm1 = s[0] * s[1] * s[2] - 1.0;
+    return mu * (d0 * d0 + d1 * d1 + d2 * d2) + lam / 2.0 * pm1 * pm1; // :62-70
+}
+// P w = w (2 mu (F - U V^T) + lam (prod sigma - 1) cof F)  (:145-153)
+__device__ __forceinline__ void fcr_piola(const double F[9], const double U[9], const double s[3], const double V[9], double mu, double lam,
+    double w, double P[9])
+{
+    double C[9]; // cofactor (IglUtils.hpp:448-458), column-major
+    C[0] = F[4] * F[8] - F[7] * F[5];
+    C[3] = F[7] * F[2] - F[1] * F[8];
+    C[6] = F[1] * F[5] - F[4] * F[2];
+    C[1] = F[6] * F[5] - F[3] * F[8];
+    C[4] = F[0] * F[8] - F[6] * F[2];
+    C[7] = F[3] * F[2] - F[0] * F[5];
+    C[2] = F[3] * F[7] - F[6] * F[4];
+    C[5] = F[6] * F[1] - F[0] * F[7];
+    C[8] = F[0] * F[4] - F[3] * F[1];
+    const double k = lam * (s[0] * s[1] * s[2] - 1.0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double R = U[i] * V[j] + U[i + 3] * V[j + 3] + U[i + 6] * V[j + 6];
+            P[i + 3 * j] = w * (mu * 2.0 * (F[i + 3 * j] - R) + k * C[i + 3 * j]);
+        }
+}
+
 __device__ __forceinline__ bool projected_dbc(int type, int projectDBC)
 {
     return type == 1 || (type == 2 && projectDBC); // Mesh.hpp:135-144
@@ -319,42 +350,71 @@ __device__ __forceinline__ void element_generators(const ElemView& v, int t, dou
     shape_grads(A, b);
 #pragma unroll
     for (int k = 0; k < 4; ++k) g.dtype[k] = v.dbc[g.vid[k]];
-    double lnJ = 0.0;
-    if (wantGrad) {
-        double P[9];
-        lnJ = piola(F, mu, lam, w, P);
+    const bool fcr = v.energyType == 1;
+    const bool stiff = !(mu == 0.0 && lam == 0.0);
+    g.active = wantHess && stiff;
+    auto emitForces = [&](const double P[9]) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (projectDBC && g.dtype[k] != 0) continue; // Energy.cpp:284-288
 #pragma unroll
             for (int i = 0; i < 3; ++i) gradFn(k, i, P[i] * b[k][0] + P[i + 3] * b[k][1] + P[i + 6] * b[k][2]);
         }
+    };
+    double lnJ = 0.0;
+    const bool fcrStress = fcr && stiff && wantGrad; // FCR needs R = U V^T for the stress: SVD first
+    if (wantGrad && !fcrStress) {
+        double P[9];
+        lnJ = piola(F, mu, lam, w, P);
+        emitForces(P);
     }
-    g.active = wantHess && !(mu == 0.0 && lam == 0.0);
-    if (!g.active) return;
     double s[3], V[9];
-    svd3(F, g.U, s, V);
-    // sigma-space derivatives (NeoHookeanEnergy.cpp:71-136)
-    const double L = wantGrad ? lnJ : log(s[0] * s[1] * s[2]); // det F = s0 s1 s2 (U, V rotations)
-    double dE[3], inv[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        inv[i] = fast_rcp(s[i]);
-        dE[i] = mu * (s[i] - inv[i]) + lam * inv[i] * L;
+    if (g.active || fcrStress) svd3(F, g.U, s, V);
+    if (fcrStress) {
+        double P[9];
+        fcr_piola(F, g.U, s, V, mu, lam, w, P);
+        emitForces(P);
     }
-    double A3[6];
+    if (!g.active) return;
+    double dE[3], inv[3], A3[6], BL[3];
+    if (fcr) { // FixedCoRotEnergy.cpp:72-144
+        const double prod = s[0] * s[1] * s[2];
+        const double noI[3] = { s[1] * s[2], s[2] * s[0], s[0] * s[1] };
+        const double kl = lam * (prod - 1.0), twoMu = mu * 2.0;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const double inv2 = inv[i] * inv[i];
-        A3[i] = mu * (1.0 + inv2) - lam * inv2 * (L - 1.0);
+        for (int i = 0; i < 3; ++i) {
+            dE[i] = twoMu * (s[i] - 1.0) + noI[i] * kl;
+            A3[i] = twoMu + lam * noI[i] * noI[i];
+        }
+        A3[3] = lam * (s[2] * (prod - 1.0) + noI[0] * noI[1]);
+        A3[4] = lam * (s[0] * (prod - 1.0) + noI[2] * noI[1]);
+        A3[5] = lam * (s[1] * (prod - 1.0) + noI[0] * noI[2]);
+        const double hl = lam / 2.0;
+        BL[0] = mu - hl * s[2] * (prod - 1.0);
+        BL[1] = mu - hl * s[0] * (prod - 1.0);
+        BL[2] = mu - hl * s[1] * (prod - 1.0);
     }
-    A3[3] = lam * inv[0] * inv[1];
-    A3[4] = lam * inv[1] * inv[2];
-    A3[5] = lam * inv[2] * inv[0];
+    else { // sigma-space derivatives (NeoHookeanEnergy.cpp:71-136)
+        const double L = wantGrad ? lnJ : log(s[0] * s[1] * s[2]); // det F = s0 s1 s2 (U, V rotations)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            inv[i] = fast_rcp(s[i]);
+            dE[i] = mu * (s[i] - inv[i]) + lam * inv[i] * L;
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double inv2 = inv[i] * inv[i];
+            A3[i] = mu * (1.0 + inv2) - lam * inv2 * (L - 1.0);
+        }
+        A3[3] = lam * inv[0] * inv[1];
+        A3[4] = lam * inv[1] * inv[2];
+        A3[5] = lam * inv[2] * inv[0];
+        const double middle = mu - lam * L;
+        BL[0] = (mu + middle * inv[0] * inv[1]) / 2.0;
+        BL[1] = (mu + middle * inv[1] * inv[2]) / 2.0;
+        BL[2] = (mu + middle * inv[2] * inv[0]) / 2.0;
+    }
     make_pd3(A3); // Energy.cpp:459-465
-    const double middle = mu - lam * L;
-    const double BL[3] = { (mu + middle * inv[0] * inv[1]) / 2.0, (mu + middle * inv[1] * inv[2]) / 2.0,
-        (mu + middle * inv[2] * inv[0]) / 2.0 };
     // 2x2 blocks (Energy.cpp:467-491): k -> (i, j) = (k, (k+1)%3)
     double B00[3], B01[3], B11[3];
 #pragma unroll

@@ -8,6 +8,7 @@ namespace ipcgpu {
 struct ElemView {
     int nV, nT;
     int tetBegin, tetEnd; // element shard of this rank
+    int energyType; // Config `energy`: 0 NH (neo-Hookean, element-inversion safeguard on), 1 FCR (fixed corotated) (Config.cpp:23-24)
     const double* x; // positions, xyz interleaved (24 B per node: one gather touches one or two lines)
     const double* xTilde; // same layout
     const double* mass; // nV

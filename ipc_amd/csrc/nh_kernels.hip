@@ -124,6 +124,16 @@ __device__ __forceinline__ double nh_psi(const double F[9], double mu, double la
     return mu / 2.0 * (I1 - 3.0) - (mu - lam / 2.0 * lJ) * lJ; // NeoHookeanEnergy.cpp:64-68 with sum sigma^2 = |F|^2, prod sigma = det F
 }
 
+// strain energy density of the configured material
+__device__ __forceinline__ double elem_psi(const ElemView& v, const double F[9], double mu, double lam)
+{
+    if (v.energyType != 1) return nh_psi(F, mu, lam);
+    if (mu == 0.0 && lam == 0.0) return 0.0;
+    double U[9], s[3], V[9];
+    svd3(F, U, s, V); // Energy.cpp:195-242 (computeEnergyValBySVD)
+    return fcr_psi(s, mu, lam);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_energy(ElemView v, double coef, int withInertia, int owner, double* __restrict__ partial)
 {
     __shared__ double sm[BLOCK / 64];
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void k_energy(ElemView v, double coef, int w
         double A[9], F[9];
         load_A(v, t, A);
         deformation_gradient(ld3(v.x, tv.x), ld3(v.x, tv.y), ld3(v.x, tv.z), ld3(v.x, tv.w), A, F);
-        e = coef * v.vol[t] * nh_psi(F, v.mu[t], v.lam[t]);
+        e = coef * v.vol[t] * elem_psi(v, F, v.mu[t], v.lam[t]);
     }
     if (withInertia && owner && gid < v.nV) {
         double d2 = 0.0;
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(BLOCK) void k_energy_per_elem(ElemView v, double* _
     double A[9], F[9];
     load_A(v, t, A);
     deformation_gradient(ld3(v.x, tv.x), ld3(v.x, tv.y), ld3(v.x, tv.z), ld3(v.x, tv.w), A, F);
-    out[t] = v.vol[t] * nh_psi(F, v.mu[t], v.lam[t]);
+    out[t] = v.vol[t] * elem_psi(v, F, v.mu[t], v.lam[t]);
 }
 
 __global__ __launch_bounds__(BLOCK) void k_check_inversion(ElemView v, int* flag)

@@ -144,6 +144,10 @@ class Context:
         self._chk(self._L.ipcgpu_set_component_material(self.h, C.c_int(node_range[0]), C.c_int(node_range[1]), C.c_int(tet_range[0]),
                                                         C.c_int(tet_range[1]), C.c_double(density), C.c_double(YM), C.c_double(PR)))
 
+    def set_energy_type(self, name):
+        """Scene-script `energy NH|FCR`."""
+        self._chk(self._L.ipcgpu_set_energy_type(self.h, C.c_int({"NH": 0, "FCR": 1}[name])))
+
     def clear_dbc(self):
         self._chk(self._L.ipcgpu_clear_dbc(self.h))
 

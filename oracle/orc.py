@@ -137,6 +137,10 @@ class Mesh:
     def clear_dbc(self):
         lib().orc_mesh_clear_dbc(self.h)
 
+    def set_energy_type(self, name):
+        """Config `energy NH|FCR` (Config.cpp:23-24, 107-111)."""
+        lib().orc_mesh_set_energy_type(self.h, C.c_int({"NH": 0, "FCR": 1}[name]))
+
     def set_V(self, V):
         V = np.asfortranarray(V, dtype=np.float64)
         lib().orc_mesh_set_V(self.h, _dp(V))

@@ -76,15 +76,71 @@ static M3 nh_P(const M3& F, const double s[3], double u, double lam)
     return P;
 }
 
+// ---------------------------------------------------------------- fixed corotated in sigma space
+// FixedCoRotEnergy.cpp:62-70
+static double fcr_E(const double s[3], double u, double lam)
+{
+    const double d0 = s[0] - 1.0, d1 = s[1] - 1.0, d2 = s[2] - 1.0;
+    const double sigmam12Sum = d0 * d0 + d1 * d1 + d2 * d2;
+    const double sigmaProdm1 = s[0] * s[1] * s[2] - 1.0;
+    return u * sigmam12Sum + lam / 2.0 * sigmaProdm1 * sigmaProdm1;
+}
+// FixedCoRotEnergy.cpp:72-95
+static void fcr_dE(const double s[3], double u, double lam, double dE[3])
+{
+    const double sigmaProdm1lambda = lam * (s[0] * s[1] * s[2] - 1.0);
+    const double noI[3] = { s[1] * s[2], s[2] * s[0], s[0] * s[1] };
+    const double _2u = u * 2;
+    for (int i = 0; i < 3; ++i) dE[i] = _2u * (s[i] - 1.0) + noI[i] * sigmaProdm1lambda;
+}
+// FixedCoRotEnergy.cpp:96-128
+static void fcr_d2E(const double s[3], double u, double lam, double d2[9])
+{
+    const double sigmaProd = s[0] * s[1] * s[2];
+    const double noI[3] = { s[1] * s[2], s[2] * s[0], s[0] * s[1] };
+    const double _2u = u * 2;
+    for (int i = 0; i < 3; ++i) d2[i + 3 * i] = _2u + lam * noI[i] * noI[i];
+    d2[0 + 3 * 1] = d2[1 + 3 * 0] = lam * (s[2] * (sigmaProd - 1.0) + noI[0] * noI[1]);
+    d2[0 + 3 * 2] = d2[2 + 3 * 0] = lam * (s[1] * (sigmaProd - 1.0) + noI[0] * noI[2]);
+    d2[2 + 3 * 1] = d2[1 + 3 * 2] = lam * (s[0] * (sigmaProd - 1.0) + noI[2] * noI[1]);
+}
+// FixedCoRotEnergy.cpp:129-144
+static void fcr_BLeft(const double s[3], double u, double lam, double B[3])
+{
+    const double sigmaProd = s[0] * s[1] * s[2];
+    const double halfLambda = lam / 2.0;
+    B[0] = u - halfLambda * s[2] * (sigmaProd - 1);
+    B[1] = u - halfLambda * s[0] * (sigmaProd - 1);
+    B[2] = u - halfLambda * s[1] * (sigmaProd - 1);
+}
+// FixedCoRotEnergy.cpp:145-153: P = 2u (F - U V^T) + lam (prod sigma - 1) cof F
+static M3 fcr_P(const M3& F, const M3& U, const double s[3], const M3& V, double u, double lam)
+{
+    M3 R; // U V^T
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R(i, j) = U(i, 0) * V(j, 0) + U(i, 1) * V(j, 1) + U(i, 2) * V(j, 2);
+    M3 C = cofactor(F);
+    const double k = lam * (s[0] * s[1] * s[2] - 1);
+    M3 P;
+    for (int i = 0; i < 9; ++i) P.m[i] = u * 2 * (F.m[i] - R.m[i]) + k * C.m[i];
+    return P;
+}
+
+// dispatch on Config energyType ("energy NH" / "energy FCR", Config.cpp:23-24,107-111)
+static double sig_E(int type, const double s[3], double u, double lam) { return type == 1 ? fcr_E(s, u, lam) : nh_E(s, u, lam); }
+static void sig_dE(int type, const double s[3], double u, double lam, double dE[3]) { type == 1 ? fcr_dE(s, u, lam, dE) : nh_dE(s, u, lam, dE); }
+static void sig_d2E(int type, const double s[3], double u, double lam, double d2[9]) { type == 1 ? fcr_d2E(s, u, lam, d2) : nh_d2E(s, u, lam, d2); }
+static void sig_BLeft(int type, const double s[3], double u, double lam, double B[3]) { type == 1 ? fcr_BLeft(s, u, lam, B) : nh_BLeft(s, u, lam, B); }
+
 // Energy.cpp:448-562. dPdF is 9x9 column-major with row-major vec index 3*i+j for F(i,j).
 static void nh_dPdF(const M3& U, const double s[3], const M3& V, double u, double lam,
-    double w, bool projectSPD, double dPdF[81])
+    double w, bool projectSPD, double dPdF[81], int type = 0)
 {
     double dE[3], d2[9], BL[3];
-    nh_dE(s, u, lam, dE);
-    nh_d2E(s, u, lam, d2);
+    sig_dE(type, s, u, lam, dE);
+    sig_d2E(type, s, u, lam, d2);
     if (projectSPD) make_pd(3, d2);
-    nh_BLeft(s, u, lam, BL);
+    sig_BLeft(type, s, u, lam, BL);
     double B[3][4];
     for (int cI = 0; cI < 3; ++cI) {
         int cP = (cI + 1) % 3;
@@ -253,7 +309,7 @@ double elasticEnergy(const Mesh& m, double coef, double* perElem)
         M3 F = m.defGrad(t), U, V;
         double s[3];
         svd3(F, U, s, V);
-        e[t] = nh_E(s, m.mu[t], m.lam[t]) * m.triArea[t];
+        e[t] = sig_E(m.energyType, s, m.mu[t], m.lam[t]) * m.triArea[t];
     }
     double sum = 0;
     for (int t = 0; t < m.nT; ++t) sum += e[t]; // Eigen .sum() of the per-element vector (Energy.cpp:241)
@@ -267,7 +323,7 @@ static void elemGradient(const Mesh& m, int t, double coef, double g[12])
     M3 F = m.defGrad(t), U, V;
     double s[3];
     svd3(F, U, s, V);
-    M3 P = nh_P(F, s, m.mu[t], m.lam[t]);
+    M3 P = m.energyType == 1 ? fcr_P(F, U, s, V, m.mu[t], m.lam[t]) : nh_P(F, s, m.mu[t], m.lam[t]);
     const double w = coef * m.triArea[t];
     for (int i = 0; i < 9; ++i) P.m[i] *= w;
     const M3& A = m.restTriInv[t];
@@ -306,7 +362,7 @@ void elemHessian(const Mesh& m, int t, double coef, bool projectSPD, double H[14
     svd3(F, U, s, V);
     const double w = coef * m.triArea[t];
     double dPdF[81];
-    nh_dPdF(U, s, V, m.mu[t], m.lam[t], w, projectSPD, dPdF);
+    nh_dPdF(U, s, V, m.mu[t], m.lam[t], w, projectSPD, dPdF, m.energyType);
     const M3& A = m.restTriInv[t];
     double dPdF_T[81], wdPdx[12 * 9], wdPdx_T[9 * 12];
     for (int i = 0; i < 9; ++i)
@@ -509,6 +565,7 @@ void inversionStep(const Mesh& m, const double* p, double slackness, double* out
 // Energy.cpp:565-581
 double filterStepSize(const Mesh& m, const double* p, double stepSize)
 {
+    if (m.energyType == 1) return stepSize; // Energy.cpp:567: only energies that need the element-inversion safeguard
     std::vector<double> out(m.nT);
     inversionStep(m, p, 0.2, out.data());
     double mn = 1e300;
@@ -572,6 +629,7 @@ void orc_mesh_set_component_material(orc_mesh* h, int nodeBegin, int nodeEnd, in
         m.lam[t] = YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR);
     }
 }
+void orc_mesh_set_energy_type(orc_mesh* h, int type) { h->m.energyType = type; }
 void orc_mesh_clear_dbc(orc_mesh* h) { std::fill(h->m.dbcType.begin(), h->m.dbcType.end(), 0); }
 void orc_mesh_set_V(orc_mesh* h, const double* V) { h->m.V.assign(V, V + 3 * h->m.nV); }
 void orc_mesh_get_V(const orc_mesh* h, double* V) { std::memcpy(V, h->m.V.data(), sizeof(double) * 3 * h->m.nV); }

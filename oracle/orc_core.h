@@ -11,6 +11,7 @@ namespace orc {
 struct Mesh {
     int nV, nT;
     double density;
+    int energyType = 0; // Config energyType: 0 "NH" (needs the element-inversion safeguard), 1 "FCR" (Config.cpp:23-24)
     std::vector<double> V_rest, V; // column-major nV x 3
     std::vector<int> F; // column-major nT x 4
     std::vector<int> dbcType; // DirichletBCType: 0 NOT_DBC, 1 ZERO, 2 NONZERO (Mesh.hpp:41-45)
@@ -35,6 +36,7 @@ struct Mesh {
     bool isProjectDBC(int v, bool projectDBC) const { return dbcType[v] == 1 || (dbcType[v] == 2 && projectDBC); } // Mesh.hpp:135-144
     void setSurface(int nSF, const int* SF);
     bool checkInversion() const;
+    bool inversionFree() const { return energyType == 1 || checkInversion(); } // Optimizer.cpp:252,517,545,2710: getNeedElemInvSafeGuard()
     M3 defGrad(int t) const;
     void buildPattern();
     int findEntry(int row, int col) const;

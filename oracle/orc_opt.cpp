@@ -360,7 +360,7 @@ void lineSearch(orc_opt* o, double& stepSize)
     {
         Tic t(o->timers[5]);
         stepForward(o, V0, stepSize);
-        while (!m.checkInversion()) {
+        while (!m.inversionFree()) {
             stepSize /= 2.0;
             stepForward(o, V0, stepSize);
         }
@@ -513,7 +513,7 @@ void orc_opt_begin_timestep(orc_opt* o)
         }
         std::vector<double> V0 = m.V;
         stepForward(o, V0, stepSize);
-        while (!m.checkInversion()) {
+        while (!m.inversionFree()) {
             stepSize /= 2.0;
             stepForward(o, V0, stepSize);
         }
