@@ -206,6 +206,20 @@ int ipcgpu_friction_hessian_add(ipcgpu_ctx*, const double* Vt_colmajor, double e
 /* overwrite Optimizer::velocity (xyz-interleaved) and recompute xTilta (computeXTilta, Optimizer.cpp:1236-1257): the
  * `initVel` script keyword (Config.cpp:247-262) */
 int ipcgpu_opt_set_velocity(ipcgpu_ctx*, const double* vel_3nV);
+/* Config `timeIntegration BE | NM beta gamma` (src/Config.cpp:112-118, defaults beta = 0.25, gamma = 0.5 src/Config.hpp:96):
+ * type 0 = backward Euler, 1 = Newmark.  Newmark scales the elastic terms by dt^2 beta (Optimizer.cpp:3216-3224, 3427-3434,
+ * 3627-3631), predicts xTilta with the stored acceleration (:1259-1277) and updates velocity / acceleration at the end of the
+ * time step (:582-590).  Call after ipcgpu_opt_init, before ipcgpu_opt_precompute; the acceleration starts at zero (:177). */
+int ipcgpu_opt_set_time_integration(ipcgpu_ctx*, int type, double beta, double gamma);
+/* Optimizer::velocity (xyz-interleaved), acceleration and dx_Elastic = V - xTilta of the last finished time step
+ * (Optimizer.cpp:574-586); any pointer may be null */
+int ipcgpu_opt_get_kinematics(ipcgpu_ctx*, double* vel_3nV, double* acc_3nV, double* dx_elastic_3nV);
+/* Optimizer::saveStatus (Optimizer.cpp:2964-3011) and the `restart <status file>` branch of the Optimizer constructor
+ * (Optimizer.cpp:179-248, Config.cpp:513-516): the reference's text checkpoint (timestep / position / velocity / acceleration /
+ * dx_Elastic), written with 20 significant digits so that doubles round-trip; files are interchangeable with the reference's.
+ * Load after ipcgpu_opt_init (and ipcgpu_opt_set_time_integration), before ipcgpu_opt_precompute. */
+int ipcgpu_opt_save_status(ipcgpu_ctx*, const char* path);
+int ipcgpu_opt_load_status(ipcgpu_ctx*, const char* path);
 /* counts6 = {#active, #paraEE, #CCD candidates, #half-space constraints, #full CCD passes, #pattern changes}; pair2 = limiting CCD pair of the
  * last iteration ((-svI-1, sfI) or (eI, eJ), (0,0) if none) */
 int ipcgpu_opt_get_contact_state(ipcgpu_ctx*, int* counts6, int* pair2);

@@ -930,6 +930,50 @@ int ipcgpu_opt_set_velocity(ipcgpu_ctx* c, const double* vel)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_time_integration(ipcgpu_ctx* c, int type, double beta, double gamma)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(type == 0 || type == 1, "time integration: 0 = BE, 1 = NM");
+        needArg(type == 0 || (beta > 0.0 && gamma >= 0.0), "Newmark needs beta > 0, gamma >= 0");
+        o.setTimeIntegration(type, beta, gamma);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_get_kinematics(ipcgpu_ctx* c, double* vel, double* acc, double* dx)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        o.getKinematics(vel, acc, dx);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_save_status(ipcgpu_ctx* c, const char* path)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(path != nullptr && path[0] != 0, "empty path");
+        o.saveStatus(path);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_load_status(ipcgpu_ctx* c, const char* path)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(path != nullptr && path[0] != 0, "empty path");
+        o.loadStatus(path);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_get_contact_state(ipcgpu_ctx* c, int* counts6, int* pair2)
 {
     return guarded([&] {

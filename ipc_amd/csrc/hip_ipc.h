@@ -15,6 +15,7 @@
 #include "hip_halfspace.h"
 #include <map>
 #include <memory>
+#include <string>
 
 struct ipcgpu_ctx; // opaque C handle
 typedef int (*ipcgpu_allreduce_fn_t)(void* user, void* buf_dev, long long count, int op);
@@ -113,6 +114,15 @@ public:
     hipStream_t stream;
     double dt = 0.025, dtSq = 0, gravity[3] = { 0, 0, 0 };
     double relGL2Tol = 1e-8, targetGRes = 0;
+    // Config `timeIntegration BE | NM beta gamma` (Config.hpp:96, Config.cpp:112-118): 0 backward Euler, 1 Newmark
+    int timeIntegration = 0;
+    double betaNM = 0.25, gammaNM = 0.5;
+    DevBuf<double> d_acc, d_dxElastic; // acceleration, dx_Elastic = x - xTilta of the finished step (Optimizer.cpp:176-177, 574-586)
+    double elasticCoef() const { return timeIntegration == 1 ? dtSq * betaNM : dtSq; } // Optimizer.cpp:3205-3224, 3416-3434, 3618-3632
+    void setTimeIntegration(int type, double beta, double gamma);
+    void getKinematics(double* vel, double* acc, double* dxElastic);
+    void saveStatus(const std::string& path); // Optimizer::saveStatus, Optimizer.cpp:2964-3011
+    void loadStatus(const std::string& path); // restart, Optimizer.cpp:179-248
     DevBuf<double> d_vel, d_xPrev, d_searchDir, d_gradient, d_minusG, d_x0, d_partial, d_scalar;
     DevBuf<int> d_flag, d_handleIds;
     DevBuf<double> d_handleAng;

@@ -7,6 +7,10 @@
 //   computeEnergyVal / computeGradient / computePrecondMtr   Optimizer.cpp:3199-3239, 3409-3450, 3549-3668
 // Per Newton iteration only a handful of scalars cross PCIe (energies, step bound, |p|_inf, not-PD flag).
 #include "hip_ipc.h"
+#include <fstream>
+#include <iomanip>
+#include <limits>
+#include <sstream>
 #include <algorithm>
 #include <chrono>
 #include <iterator>
@@ -63,6 +67,10 @@ void HipOptimizer::init(double dt_, bool withGravity)
     const size_t n3 = 3 * (size_t)mesh.nV;
     d_vel.alloc(n3);
     d_vel.zero(stream);
+    d_acc.alloc(n3); // Optimizer.cpp:176-177
+    d_acc.zero(stream);
+    d_dxElastic.alloc(n3);
+    d_dxElastic.zero(stream);
     d_xPrev.alloc(n3);
     d_searchDir.alloc(n3);
     d_searchDir.zero(stream);
@@ -86,6 +94,7 @@ void HipOptimizer::init(double dt_, bool withGravity)
     std::memset(timers, 0, sizeof(timers));
     initialised = true;
     HIP_CHECK(hipStreamSynchronize(stream));
+    computeXTilta(); // Optimizer.cpp:247-248: the first time step already sees gravity
 }
 
 void HipOptimizer::setRelGL2Tol(double relTol)
@@ -115,6 +124,7 @@ void HipOptimizer::setTwist(int nL, const int* left, int nR, const int* right, d
         d_handleAng.upload(ang, stream);
     }
     mesh.uploadDBC(stream);
+    if (initialised) computeXTilta(); // the handles are Dirichlet nodes now: xTilta = V_prev there (Optimizer.cpp:1244-1246)
 }
 
 void HipOptimizer::reduceSum(double* dev, long long n)
@@ -142,7 +152,7 @@ double HipOptimizer::readScalar(const double* dev)
 
 double HipOptimizer::computeEnergyVal()
 {
-    launch_energy(view(), dtSq, true, rank == 0, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
+    launch_energy(view(), elasticCoef(), true, rank == 0, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
     reduceSum(d_scalar.p, 1);
     double E = readScalar(d_scalar.p);
     // barrier terms over the current constraint sets (Optimizer.cpp:3252-3353); replicated on every rank
@@ -244,16 +254,105 @@ void HipOptimizer::computeXTilta()
 {
     // Optimizer.cpp:1236-1257 on the host: only used when the caller overrides the velocity
     const size_t n3 = 3 * (size_t)mesh.nV;
-    std::vector<double> xp(n3), vel(n3), xt(n3);
+    std::vector<double> xp(n3), vel(n3), xt(n3), acc(n3, 0.0);
     d_xPrev.download(xp.data(), n3, stream);
     d_vel.download(vel.data(), n3, stream);
+    d_acc.download(acc.data(), n3, stream);
     for (int v = 0; v < mesh.nV; ++v)
         for (int c = 0; c < 3; ++c) {
             const size_t i = 3 * (size_t)v + c;
-            xt[i] = mesh.isDBCVertex(v) ? xp[i] : xp[i] + (vel[i] * dt + dtSq * gravity[c]);
+            if (mesh.isDBCVertex(v)) xt[i] = xp[i];
+            else if (timeIntegration == 1) xt[i] = xp[i] + (vel[i] * dt + betaNM * (dtSq * gravity[c]) + (0.5 - betaNM) * (dtSq * acc[i])); // :1259-1277
+            else xt[i] = xp[i] + (vel[i] * dt + dtSq * gravity[c]);
         }
     mesh.d_xTilde.upload(xt, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+void HipOptimizer::setTimeIntegration(int type, double beta, double gamma)
+{
+    timeIntegration = type;
+    betaNM = beta;
+    gammaNM = gamma;
+    computeXTilta();
+}
+
+void HipOptimizer::getKinematics(double* vel, double* acc, double* dxElastic)
+{
+    const size_t n3 = 3 * (size_t)mesh.nV;
+    if (vel) d_vel.download(vel, n3, stream);
+    if (acc) d_acc.download(acc, n3, stream);
+    if (dxElastic) d_dxElastic.download(dxElastic, n3, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+// Optimizer::saveStatus (Optimizer.cpp:2964-3011): the reference's text checkpoint, readable by either implementation
+void HipOptimizer::saveStatus(const std::string& path)
+{
+    const size_t n3 = 3 * (size_t)mesh.nV;
+    std::vector<double> x(n3), vel(n3), acc(n3), dx(n3);
+    mesh.d_x.download(x.data(), n3, stream);
+    getKinematics(vel.data(), acc.data(), dx.data());
+    std::ofstream out(path, std::ios::out);
+    if (!out.is_open()) throw StateError("unable to create status file " + path);
+    out << std::setprecision(std::numeric_limits<long double>::digits10 + 2);
+    out << "timestep " << globalIterNum << "\n\n";
+    auto rows = [&](const char* name, const std::vector<double>& a) {
+        out << name << " " << mesh.nV << " 3\n";
+        for (int v = 0; v < mesh.nV; ++v) out << a[3 * (size_t)v] << " " << a[3 * (size_t)v + 1] << " " << a[3 * (size_t)v + 2] << "\n";
+    };
+    rows("position", x);
+    out << "\n";
+    out << "velocity " << n3 << "\n";
+    for (size_t i = 0; i < n3; ++i) out << vel[i] << "\n";
+    out << "\n";
+    rows("acceleration", acc);
+    out << "\n";
+    rows("dx_Elastic", dx);
+    if (!out.good()) throw StateError("write error on status file " + path);
+}
+
+// restart branch of the Optimizer constructor (Optimizer.cpp:179-248): same token grammar, then V_prev = V and computeXTilta
+void HipOptimizer::loadStatus(const std::string& path)
+{
+    std::ifstream in(path);
+    if (!in.is_open()) throw StateError("unable to open status file " + path);
+    const size_t n3 = 3 * (size_t)mesh.nV;
+    std::vector<double> x(n3), vel(n3, 0.0), acc(n3, 0.0), dx(n3, 0.0);
+    mesh.d_x.download(x.data(), n3, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    auto readRows = [&](std::stringstream& ss, std::vector<double>& dst, bool zeroFirst) {
+        int rowsIn = 0, dimIn = 0;
+        ss >> rowsIn >> dimIn;
+        if (rowsIn < 0 || rowsIn > mesh.nV || dimIn != 3) throw StateError("status file does not match the mesh");
+        if (zeroFirst) std::fill(dst.begin(), dst.end(), 0.0);
+        for (int v = 0; v < rowsIn; ++v) in >> dst[3 * (size_t)v] >> dst[3 * (size_t)v + 1] >> dst[3 * (size_t)v + 2];
+    };
+    std::string line;
+    while (std::getline(in, line)) {
+        std::stringstream ss(line);
+        std::string token;
+        ss >> token;
+        if (token == "timestep") ss >> globalIterNum;
+        else if (token == "position") readRows(ss, x, false);
+        else if (token == "velocity") {
+            long long n = 0;
+            ss >> n;
+            if (n < 0 || n > (long long)n3) throw StateError("status file does not match the mesh");
+            std::fill(vel.begin(), vel.end(), 0.0);
+            for (long long i = 0; i < n; ++i) in >> vel[i];
+        }
+        else if (token == "acceleration") readRows(ss, acc, true);
+        else if (token == "dx_Elastic") readRows(ss, dx, true);
+    }
+    if (in.bad()) throw StateError("read error on status file " + path);
+    mesh.d_x.upload(x, stream);
+    d_xPrev.upload(x, stream);
+    d_vel.upload(vel, stream);
+    d_acc.upload(acc, stream);
+    d_dxElastic.upload(dx, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    computeXTilta();
 }
 
 void HipOptimizer::setVelocity(const double* vel3nV)
@@ -400,7 +499,7 @@ void HipOptimizer::elasticInertiaGradient(bool projectDBC)
 {
     if (lin.rowBase.empty()) { // no pattern yet: tet-parallel atomic path
         launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
-        launch_assemble(view(), dtSq, projectDBC, d_gradient.p, nullptr, stream);
+        launch_assemble(view(), elasticCoef(), projectDBC, d_gradient.p, nullptr, stream);
         reduceSum(d_gradient.p, 3LL * mesh.nV);
         return;
     }
@@ -408,7 +507,7 @@ void HipOptimizer::elasticInertiaGradient(bool projectDBC)
     int pb, pe;
     patchShard(pb, pe);
     if (worldSize > 1) d_gradient.zero(stream);
-    launch_assemble_patches(view(), patch, pb, pe, dtSq, projectDBC, d_gradient.p, nullptr, stream);
+    launch_assemble_patches(view(), patch, pb, pe, elasticCoef(), projectDBC, d_gradient.p, nullptr, stream);
     reduceSum(d_gradient.p, 3LL * mesh.nV);
 }
 
@@ -467,7 +566,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         lin.setZero();
         if (withGradient) d_gradient.zero(stream);
     }
-    launch_assemble_patches(view(), patch, pb, pe, dtSq, projectDBC, withGradient ? d_gradient.p : nullptr,
+    launch_assemble_patches(view(), patch, pb, pe, elasticCoef(), projectDBC, withGradient ? d_gradient.p : nullptr,
         lin.d_a.p, stream);
     if (worldSize > 1) {
         reduceSum(lin.d_a.p, (long long)lin.ja.size());
@@ -711,8 +810,12 @@ bool HipOptimizer::newtonIter()
 void HipOptimizer::endTimestep()
 {
     Tic t(timers[11], stream);
-    launch_be_update(mesh.nV, mesh.d_dbc.p, mesh.d_x.p, d_xPrev.p, d_vel.p, mesh.d_xTilde.p, dt, gravity[0], gravity[1], gravity[2],
-        stream);
+    if (timeIntegration == 1)
+        launch_nm_update(mesh.nV, mesh.d_dbc.p, mesh.d_x.p, d_xPrev.p, d_vel.p, d_acc.p, d_dxElastic.p, mesh.d_xTilde.p, dt, betaNM, gammaNM,
+            gravity[0], gravity[1], gravity[2], stream);
+    else
+        launch_be_update(mesh.nV, mesh.d_dbc.p, mesh.d_x.p, d_xPrev.p, d_vel.p, d_acc.p, d_dxElastic.p, mesh.d_xTilde.p, dt, gravity[0],
+            gravity[1], gravity[2], stream);
     globalIterNum++;
 }
 

@@ -55,9 +55,13 @@ void launch_aos_to_colmajor(int nV, const double* src, double* dst, hipStream_t 
 // symmetric-upper CSR times vector and diagonal preconditioner (LinSysSolver.hpp:238-253, 411-420)
 void launch_csr_symv(int nRows, const int* ia, const int* ja, const double* a, const double* x, double* y, hipStream_t s);
 void launch_precond_diag(int nRows, const int* ia, const double* a, const double* in, double* out, hipStream_t s);
-// BE update (Optimizer.cpp:570-580, 1236-1257): vel = (x - xPrev)/dt ; xPrev = x ; xTilde = xPrev + dt vel + dt^2 g (DBC: xPrev)
-void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* xTilde, double dt,
-    double gx, double gy, double gz, hipStream_t s);
+// BE update (Optimizer.cpp:570-580, 1236-1257): dxElastic = x - xTilde; acc = (vel_new - vel) / dt; vel = (x - xPrev) / dt;
+// xPrev = x; xTilde = xPrev + dt vel + dt^2 g (DBC: xPrev)
+void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* acc, double* dxElastic, double* xTilde,
+    double dt, double gx, double gy, double gz, hipStream_t s);
+// Newmark update (Optimizer.cpp:582-590, 1259-1277)
+void launch_nm_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* acc, double* dxElastic, double* xTilde,
+    double dt, double beta, double gamma, double gx, double gy, double gz, hipStream_t s);
 // twist handles: rotate listed vertices about the x axis through c by their angle (AnimScripter.cpp:1674-1684)
 void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s);
 

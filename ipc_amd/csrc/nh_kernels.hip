@@ -361,8 +361,32 @@ __global__ void k_precond_diag(int nRows, const int* __restrict__ ia, const doub
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < nRows) out[r] = in[r] / a[ia[r]]; // the diagonal is the first entry of every upper-CSR row
 }
+// Newmark update (Optimizer.cpp:582-590, 1259-1277): vel += dt (1 - gamma) acc; acc = (x - xTilde) / (dt^2 beta) + g;
+// vel += dt gamma acc; xPrev = x; xTilde = xPrev + dt vel + beta dt^2 g + (1/2 - beta) dt^2 acc (DBC: xPrev)
+__global__ void k_nm_update(int nV, const int* __restrict__ dbc, const double* __restrict__ x, double* __restrict__ xPrev,
+    double* __restrict__ vel, double* __restrict__ acc, double* __restrict__ dxElastic, double* __restrict__ xTilde, double dt, double beta,
+    double gamma, double gx, double gy, double gz)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * nV) return;
+    const int v = i / 3, c = i - 3 * v;
+    const double g = c == 0 ? gx : (c == 1 ? gy : gz);
+    const double dtSq = dt * dt;
+    double vl = vel[i] + dt * (1 - gamma) * acc[i];
+    const double dx = x[i] - xTilde[i];
+    dxElastic[i] = dx; // Optimizer.cpp:583
+    double a = dx / (dtSq * beta);
+    a += g;
+    vl += dt * gamma * a;
+    vel[i] = vl;
+    acc[i] = a;
+    const double xp = x[i];
+    xPrev[i] = xp;
+    xTilde[i] = dbc[v] != 0 ? xp : xp + (vl * dt + beta * (dtSq * g) + (0.5 - beta) * (dtSq * a));
+}
 __global__ void k_be_update(int nV, const int* __restrict__ dbc, const double* __restrict__ x, double* __restrict__ xPrev,
-    double* __restrict__ vel, double* __restrict__ xTilde, double dt, double gx, double gy, double gz)
+    double* __restrict__ vel, double* __restrict__ acc, double* __restrict__ dxElastic, double* __restrict__ xTilde, double dt, double gx,
+    double gy, double gz)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * nV) return;
@@ -370,6 +394,8 @@ __global__ void k_be_update(int nV, const int* __restrict__ dbc, const double* _
     const double g = (c == 0) ? gx : (c == 1 ? gy : gz);
     const double xi = x[i];
     const double vi = (xi - xPrev[i]) / dt;
+    dxElastic[i] = xi - xTilde[i]; // Optimizer.cpp:574
+    acc[i] = (vi - vel[i]) / dt; // :577
     vel[i] = vi;
     xPrev[i] = xi;
     xTilde[i] = (dbc[v] != 0) ? xi : (xi + (vi * dt + dt * dt * g));
@@ -463,10 +489,18 @@ void launch_precond_diag(int nRows, const int* ia, const double* a, const double
 {
     if (nRows) hipLaunchKernelGGL(k_precond_diag, dim3(nblk(nRows)), dim3(BLOCK), 0, s, nRows, ia, a, in, out);
 }
-void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* xTilde, double dt, double gx,
-    double gy, double gz, hipStream_t s)
+void launch_nm_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* acc, double* dxElastic, double* xTilde,
+    double dt, double beta, double gamma, double gx, double gy, double gz, hipStream_t s)
 {
-    if (nV) hipLaunchKernelGGL(k_be_update, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, x, xPrev, vel, xTilde, dt, gx, gy, gz);
+    hipLaunchKernelGGL(k_nm_update, dim3((3 * nV + 255) / 256), dim3(256), 0, s, nV, dbc, x, xPrev, vel, acc, dxElastic, xTilde, dt, beta, gamma,
+        gx, gy, gz);
+}
+void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* acc, double* dxElastic, double* xTilde,
+    double dt, double gx, double gy, double gz, hipStream_t s)
+{
+    if (nV)
+        hipLaunchKernelGGL(k_be_update, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, x, xPrev, vel, acc, dxElastic, xTilde, dt, gx, gy,
+            gz);
 }
 void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s)
 {

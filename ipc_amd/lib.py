@@ -484,6 +484,21 @@ class Context:
         Vt = np.asfortranarray(Vt, dtype=np.float64)
         self._chk(self._L.ipcgpu_friction_hessian_add(self.h, _dp(Vt), C.c_double(eps2), C.c_double(coef), C.c_int(int(projectDBC))))
 
+    def set_time_integration(self, name, beta=0.25, gamma=0.5):
+        """Scene-script `timeIntegration BE | NM beta gamma`."""
+        self._chk(self._L.ipcgpu_opt_set_time_integration(self.h, C.c_int({"BE": 0, "NM": 1}[name]), C.c_double(beta), C.c_double(gamma)))
+
+    def kinematics(self):
+        vel, acc, dx = np.zeros(3 * self.nV), np.zeros(3 * self.nV), np.zeros(3 * self.nV)
+        self._chk(self._L.ipcgpu_opt_get_kinematics(self.h, _dp(vel), _dp(acc), _dp(dx)))
+        return dict(velocity=vel, acceleration=acc, dx_Elastic=dx)
+
+    def save_status(self, path):
+        self._chk(self._L.ipcgpu_opt_save_status(self.h, str(path).encode()))
+
+    def load_status(self, path):
+        self._chk(self._L.ipcgpu_opt_load_status(self.h, str(path).encode()))
+
     def set_velocity(self, vel):
         vel = _f64(np.asarray(vel).reshape(-1))
         assert vel.size == 3 * self.nV

@@ -432,6 +432,62 @@ def opt_enable_self_collision(opt: "Optimizer", dHatEps=1e-3):
     lib().orc_opt_enable_self_collision(opt.h, C.c_double(dHatEps))
 
 
+def opt_kinematics(opt: "Optimizer"):
+    n3 = 3 * opt.mesh.nV
+    vel, acc, dx = np.zeros(n3), np.zeros(n3), np.zeros(n3)
+    lib().orc_opt_get_kinematics(opt.h, _dp(vel), _dp(acc), _dp(dx))
+    return dict(velocity=vel, acceleration=acc, dx_Elastic=dx)
+
+
+def opt_save_status(opt: "Optimizer", path):
+    """Optimizer::saveStatus (Optimizer.cpp:2964-3011): the reference's text checkpoint."""
+    st, k = opt.state(), opt_kinematics(opt)
+    nV = opt.mesh.nV
+    f = lambda x: format(float(x), ".20g")  # setprecision(digits10 of long double + 2)
+    with open(path, "w") as out:
+        out.write(f"timestep {st['timestep']}\n\n")
+        out.write(f"position {nV} 3\n")
+        for r in st["V"]:
+            out.write(" ".join(f(x) for x in r) + "\n")
+        out.write(f"\nvelocity {3 * nV}\n")
+        for x in k["velocity"]:
+            out.write(f(x) + "\n")
+        for name in ("acceleration", "dx_Elastic"):
+            out.write(f"\n{name} {nV} 3\n")
+            for r in k[name].reshape(nV, 3):
+                out.write(" ".join(f(x) for x in r) + "\n")
+
+
+def opt_load_status(opt: "Optimizer", path):
+    """`restart` branch of the Optimizer constructor (Optimizer.cpp:179-248): token grammar of the status file."""
+    nV = opt.mesh.nV
+    toks = open(path).read().split()
+    V = opt.state()["V"].copy()
+    vel, acc, dx = np.zeros(3 * nV), np.zeros((nV, 3)), np.zeros((nV, 3))
+    timestep, i = 0, 0
+    while i < len(toks):
+        t = toks[i]
+        if t == "timestep":
+            timestep = int(toks[i + 1]); i += 2
+        elif t == "velocity":
+            n = int(toks[i + 1]); vel[:n] = [float(x) for x in toks[i + 2:i + 2 + n]]; i += 2 + n
+        elif t in ("position", "acceleration", "dx_Elastic"):
+            rows, dim = int(toks[i + 1]), int(toks[i + 2])
+            assert rows <= nV and dim == 3
+            vals = np.array([float(x) for x in toks[i + 3:i + 3 + rows * dim]]).reshape(rows, dim)
+            {"position": V, "acceleration": acc, "dx_Elastic": dx}[t][:rows] = vals
+            i += 3 + rows * dim
+        else:
+            i += 1
+    opt.mesh.set_V(V)
+    lib().orc_opt_restart(opt.h, C.c_int(timestep), _dp(vel), _dp(np.ascontiguousarray(acc).reshape(-1)), _dp(np.ascontiguousarray(dx).reshape(-1)))
+
+
+def opt_set_time_integration(opt: "Optimizer", name, beta=0.25, gamma=0.5):
+    """Config `timeIntegration BE | NM beta gamma` (defaults Config.hpp:96)."""
+    lib().orc_opt_set_time_integration(opt.h, C.c_int({"BE": 0, "NM": 1}[name]), C.c_double(beta), C.c_double(gamma))
+
+
 def opt_set_velocity(opt: "Optimizer", vel):
     v = np.ascontiguousarray(vel, dtype=np.float64).reshape(-1)
     lib().orc_opt_set_velocity(opt.h, _dp(v))

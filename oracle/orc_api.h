@@ -89,7 +89,10 @@ void orc_opt_precompute(orc_opt*);
 // one pass of the solveSub_IP loop body; returns 1 if the time step converged before doing work
 int orc_opt_newton_iter(orc_opt*);
 void orc_opt_begin_timestep(orc_opt*); // stepAnimScript + initX(0) + energy, Optimizer.cpp:510-560,1518-1613
-void orc_opt_end_timestep(orc_opt*); // BE velocity / xTilta update, Optimizer.cpp:570-580
+void orc_opt_end_timestep(orc_opt*); // BE / NM velocity, acceleration and xTilta update, Optimizer.cpp:570-590
+void orc_opt_get_kinematics(const orc_opt*, double* vel_3nV, double* acc_3nV, double* dx_3nV);
+void orc_opt_restart(orc_opt*, int timestep, const double* vel, const double* acc, const double* dx); // Optimizer.cpp:179-248
+void orc_opt_set_time_integration(orc_opt*, int type /*0 BE, 1 NM*/, double beta, double gamma); // Config.cpp:112-118
 int orc_opt_solve_timestep(orc_opt*, int maxIter); // returns # Newton iterations
 // state readers
 void orc_opt_get(const orc_opt*, double* V_colmajor, double* searchDir, double* gradient, double* scalars8);

@@ -19,6 +19,11 @@ using namespace orc;
 struct orc_opt {
     Mesh* m;
     double dt, dtSq, gravity[3] = { 0, 0, 0 };
+    // time integration (Config timeIntegration BE | NM beta gamma, Config.hpp:96, Config.cpp:112-118)
+    int tit = 0;
+    double betaNM = 0.25, gammaNM = 0.5;
+    std::vector<double> acceleration, dxElastic; // 3 v + c
+    double elCoef() const { return tit == 1 ? dtSq * betaNM : dtSq; } // Optimizer.cpp:3205-3224, 3416-3434, 3618-3632
     int nthreads;
     double relGL2Tol = 1.0e-8, targetGRes = 0;
     std::vector<double> velocity, xTilta, V_prev, searchDir, gradient, a;
@@ -79,6 +84,9 @@ void computeXTilta(orc_opt* o)
     for (int v = 0; v < m.nV; ++v)
         for (int c = 0; c < 3; ++c) {
             if (m.isDBC(v)) o->xTilta[v + m.nV * c] = o->V_prev[v + m.nV * c];
+            else if (o->tit == 1) // Optimizer.cpp:1259-1277
+                o->xTilta[v + m.nV * c] = o->V_prev[v + m.nV * c]
+                    + (o->velocity[3 * v + c] * o->dt + o->betaNM * (o->dtSq * o->gravity[c]) + (0.5 - o->betaNM) * (o->dtSq * o->acceleration[3 * v + c]));
             else o->xTilta[v + m.nV * c] = o->V_prev[v + m.nV * c] + (o->velocity[3 * v + c] * o->dt + o->dtSq * o->gravity[c]);
         }
 }
@@ -87,7 +95,7 @@ void computeXTilta(orc_opt* o)
 double computeEnergyVal(orc_opt* o)
 {
     Mesh& m = *o->m;
-    double E = elasticEnergy(m, o->dtSq, nullptr);
+    double E = elasticEnergy(m, o->elCoef(), nullptr);
     std::vector<double> ev(m.nV);
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < m.nV; ++v) {
@@ -117,7 +125,7 @@ double computeEnergyVal(orc_opt* o)
 void elasticInertiaGradient(orc_opt* o, bool projectDBC, double* g)
 {
     Mesh& m = *o->m;
-    elasticGradient(m, o->dtSq, projectDBC, g);
+    elasticGradient(m, o->elCoef(), projectDBC, g);
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < m.nV; ++v)
         if (!m.isProjectDBC(v, projectDBC))
@@ -177,7 +185,7 @@ void computePrecondMtr(orc_opt* o, bool projectDBC)
         rebuildPattern(o);
     }
     Tic t(o->timers[0]);
-    assembleHessian(m, o->dtSq, projectDBC, o->a.data());
+    assembleHessian(m, o->elCoef(), projectDBC, o->a.data());
     for (size_t i = 0; i < o->planes.size(); ++i) hsHessian(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa, projectDBC, o->a.data());
     if (o->selfCollision) contactHessian(m, o->cs, o->dHat, o->kappa, projectDBC, o->a.data());
     if (o->fricDHat > 0.0) { // Optimizer.cpp:3677-3702
@@ -614,13 +622,64 @@ int orc_opt_newton_iter(orc_opt* o)
     return 0;
 }
 
+// Config `timeIntegration NM beta gamma` (Config.cpp:112-118); call before precompute
+void orc_opt_set_time_integration(orc_opt* o, int type, double beta, double gamma)
+{
+    o->tit = type;
+    o->betaNM = beta;
+    o->gammaNM = gamma;
+    o->acceleration.assign(3 * (size_t)o->m->nV, 0.0); // Optimizer.cpp:177
+    computeXTilta(o);
+}
+
+void orc_opt_get_kinematics(const orc_opt* o, double* vel, double* acc, double* dx)
+{
+    const size_t n3 = 3 * (size_t)o->m->nV;
+    for (size_t i = 0; i < n3; ++i) {
+        if (vel) vel[i] = o->velocity[i];
+        if (acc) acc[i] = i < o->acceleration.size() ? o->acceleration[i] : 0.0;
+        if (dx) dx[i] = i < o->dxElastic.size() ? o->dxElastic[i] : 0.0;
+    }
+}
+// restart branch of the Optimizer constructor (Optimizer.cpp:179-248) after the status file has been parsed: positions are
+// already in the mesh
+void orc_opt_restart(orc_opt* o, int timestep, const double* vel, const double* acc, const double* dx)
+{
+    const size_t n3 = 3 * (size_t)o->m->nV;
+    o->globalIterNum = timestep;
+    o->velocity.assign(vel, vel + n3);
+    o->acceleration.assign(acc, acc + n3);
+    o->dxElastic.assign(dx, dx + n3);
+    o->V_prev = o->m->V;
+    computeXTilta(o);
+}
+
 void orc_opt_end_timestep(orc_opt* o)
 {
     Mesh& m = *o->m;
     Tic t(o->timers[11]);
-    // TIT_BE (570-580)
+    if (o->acceleration.empty()) o->acceleration.assign(3 * (size_t)m.nV, 0.0);
+    o->dxElastic.resize(3 * (size_t)m.nV);
     for (int v = 0; v < m.nV; ++v)
-        for (int c = 0; c < 3; ++c) o->velocity[3 * v + c] = (m.V[v + m.nV * c] - o->V_prev[v + m.nV * c]) / o->dt;
+        for (int c = 0; c < 3; ++c) o->dxElastic[3 * v + c] = m.V[v + m.nV * c] - o->xTilta[v + m.nV * c]; // :574, :583
+    if (o->tit == 1) { // TIT_NM (582-590)
+        for (int v = 0; v < m.nV; ++v)
+            for (int c = 0; c < 3; ++c) {
+                double& vel = o->velocity[3 * v + c];
+                double& acc = o->acceleration[3 * v + c];
+                vel = vel + o->dt * (1 - o->gammaNM) * acc;
+                acc = (m.V[v + m.nV * c] - o->xTilta[v + m.nV * c]) / (o->dtSq * o->betaNM);
+                acc += o->gravity[c];
+                vel += o->dt * o->gammaNM * acc;
+            }
+    }
+    else // TIT_BE (570-580)
+        for (int v = 0; v < m.nV; ++v)
+            for (int c = 0; c < 3; ++c) {
+                const double vNew = (m.V[v + m.nV * c] - o->V_prev[v + m.nV * c]) / o->dt;
+                o->acceleration[3 * v + c] = (vNew - o->velocity[3 * v + c]) / o->dt; // :577
+                o->velocity[3 * v + c] = vNew;
+            }
     o->V_prev = m.V;
     computeXTilta(o);
     o->globalIterNum++;

@@ -1,0 +1,151 @@
+"""Either side of the Newton loop: Newmark time integration (Optimizer.cpp:582-590, 1259-1277,
+3216-3224) and the `status<N>` text checkpoint (Optimizer.cpp:179-248, 2964-3011)."""
+import numpy as np
+import pytest
+
+from ipc_amd import scene
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def _free_block(orc, integ, nthreads=2):
+    V, F = scene.make_box(4, 2, 2, size=(2.0, 0.5, 0.5))
+    m = orc.Mesh(V, F, YM=2e5, PR=0.3, density=1000.0)
+    o = orc.Optimizer(m, dt=0.004, gravity=False, nthreads=nthreads)
+    if integ == "NM":
+        orc.opt_set_time_integration(o, "NM")
+    vel = np.zeros_like(V)
+    vel[:, 0] = 1.5 * (V[:, 0] - V[:, 0].mean())  # stretching mode
+    orc.opt_set_velocity(o, vel)
+    o.set_rel_tol(1e-6)
+    o.precompute()
+    return V, F, m, o, vel
+
+
+def _mech_energy(orc, m, o):
+    k = orc.opt_kinematics(o)
+    mass = m.features()["mass"]
+    return m.elastic_energy(1.0) + 0.5 * (np.repeat(mass, 3) * k["velocity"] ** 2).sum()
+
+
+def test_newmark_keeps_the_energy_backward_euler_loses(orc):
+    """Trapezoidal Newmark (beta = 1/4, gamma = 1/2) is energy preserving up to the nonlinearity; BE damps."""
+    res = {}
+    for integ in ("BE", "NM"):
+        V, F, m, o, vel = _free_block(orc, integ)
+        E0 = _mech_energy(orc, m, o)
+        for _ in range(60):
+            assert o.solve_timestep(60) < 60
+        res[integ] = _mech_energy(orc, m, o) / E0
+    assert 0.97 < res["NM"] < 1.03
+    assert res["BE"] < 0.8
+
+
+def test_status_round_trip_in_the_oracle(orc, tmp_path):
+    for integ in ("BE", "NM"):
+        V, F, m, o, vel = _free_block(orc, integ)
+        for _ in range(3):
+            o.solve_timestep(60)
+        path = tmp_path / f"status3_{integ}"
+        orc.opt_save_status(o, path)
+        txt = open(path).read().split()
+        assert txt[:2] == ["timestep", "3"] and "position" in txt and "velocity" in txt and "acceleration" in txt and "dx_Elastic" in txt
+        for _ in range(2):
+            o.solve_timestep(60)
+        ref = o.state()["V"]
+        m2 = orc.Mesh(V, F, YM=2e5, PR=0.3, density=1000.0)
+        o2 = orc.Optimizer(m2, dt=0.004, gravity=False, nthreads=2)
+        if integ == "NM":
+            orc.opt_set_time_integration(o2, "NM")
+        o2.set_rel_tol(1e-6)
+        orc.opt_load_status(o2, path)
+        o2.precompute()
+        assert o2.state()["timestep"] == 3
+        for _ in range(2):
+            o2.solve_timestep(60)
+        assert relerr(o2.state()["V"], ref) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------ GPU
+def _gpu_pair(orc, gpu_lib, integ):
+    V, F = scene.make_bar(10, 2, 2, size=(4.0, 0.5, 1.0))
+    left, right = scene.border_verts(V, 0.01)
+    Vs = scene.twist_state(scene.jitter(V, F, rel=2e-2), 0.1)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.02, gravity=True, nthreads=4)
+    o.set_twist(left, right)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.02, True)
+    c.set_twist(left, right)
+    if integ == "NM":
+        orc.opt_set_time_integration(o, "NM", 0.3, 0.6)
+        c.set_time_integration("NM", 0.3, 0.6)
+    return V, F, Vs, left, right, m, o, c
+
+
+def _step_both(o, c, steps, tol=1e-9):
+    for step in range(steps):
+        o.begin_timestep()
+        c.begin_timestep()
+        for it in range(60):
+            co, cg = o.newton_iter(), c.newton_iter()
+            assert bool(co) == cg, (step, it)
+            if co:
+                break
+            so, sg = o.state(), c.state()
+            assert abs(sg["E"] - so["E"]) <= tol * abs(so["E"]), (step, it)
+            assert relerr(sg["V"], so["V"]) < tol, (step, it)
+        else:
+            pytest.fail("Newton did not converge")
+        o.end_timestep()
+        c.end_timestep()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integ", ["BE", "NM"])
+def test_time_integration_tracks_the_oracle(orc, gpu_lib, integ):
+    V, F, Vs, left, right, m, o, c = _gpu_pair(orc, gpu_lib, integ)
+    o.precompute()
+    c.precompute()
+    _step_both(o, c, 4)
+    ko, kg = orc.opt_kinematics(o), c.kinematics()
+    for k in ("velocity", "acceleration", "dx_Elastic"):
+        assert relerr(kg[k], ko[k]) < 1e-7, k  # differences of positions that agree to 1e-9, divided by dt (dt^2)
+    c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("integ", ["BE", "NM"])
+def test_status_checkpoint_is_interchangeable(orc, gpu_lib, tmp_path, integ):
+    V, F, Vs, left, right, m, o, c = _gpu_pair(orc, gpu_lib, integ)
+    o.precompute()
+    c.precompute()
+    _step_both(o, c, 2)
+    pg, po = tmp_path / "status_gpu", tmp_path / "status_orc"
+    c.save_status(pg)
+    orc.opt_save_status(o, po)
+    # same grammar, same numbers
+    tg, to = open(pg).read().split(), open(po).read().split()
+    assert len(tg) == len(to)
+    assert [t for t in tg if t[0].isalpha() and not t.startswith(("inf", "nan"))] == [t for t in to if t[0].isalpha() and not t.startswith(("inf", "nan"))]
+    assert tg[:2] == ["timestep", "2"]
+    # the uninterrupted pair goes on for two steps
+    _step_both(o, c, 2)
+    ref = c.state()["V"]
+    # a fresh GPU context restarts from the ORACLE's file, a fresh oracle from the GPU's file
+    V, F, Vs, left, right, m2, o2, c2 = _gpu_pair(orc, gpu_lib, integ)
+    c2.load_status(po)
+    orc.opt_load_status(o2, pg)
+    assert c2.state()["timestep"] == 2 and o2.state()["timestep"] == 2
+    o2.precompute()
+    c2.precompute()
+    _step_both(o2, c2, 2, tol=1e-8)
+    assert relerr(c2.state()["V"], ref) < 1e-8
+    c.close()
+    c2.close()
