@@ -57,6 +57,18 @@ int ipcgpu_ctx_set_solver(ipcgpu_ctx*, int solver_type);
  * caller's all-reduce (bench.py / torch.distributed over RCCL).  Default: all tets. */
 int ipcgpu_ctx_set_shard(ipcgpu_ctx*, int rank, int world_size);
 
+/* ---- tet-mesh files (host only, no GPU) ------------------------------------------------ */
+/* IglUtils::readTetMesh (src/Utils/IglUtils.cpp:451-584): Gmsh MSH 4.1 / 2.2 ASCII (the MshIO path) and the reference's own
+ * "msh 4.0" dialect with its optional $Surface section; nodes in file order, elements by tag - 1.  The surface is taken from
+ * $Surface when the dialect carries it, otherwise found as in IglUtils::findSurfaceTris (:203-233) in (tet, local face) order
+ * (the reference's order is that of a std::unordered_map).  Column-major outputs like the rest of this header. */
+typedef struct ipcgpu_tetmesh ipcgpu_tetmesh;
+int ipcgpu_read_tet_mesh(const char* path, ipcgpu_tetmesh** mesh, int* nV, int* nT, int* nSF);
+int ipcgpu_tet_mesh_get(const ipcgpu_tetmesh*, double* V_colmajor, int* T_colmajor, int* SF_colmajor);
+void ipcgpu_tet_mesh_free(ipcgpu_tetmesh*);
+/* IglUtils::saveTetMesh (src/Utils/IglUtils.cpp:300-361): MSH 4.1 ASCII + $Surface */
+int ipcgpu_save_tet_mesh(const char* path, int nV, int nT, const double* V_colmajor, const int* T_colmajor);
+
 /* ---- mesh = the Mesh<3> data contract ----------------------------------------------- */
 /* Replaces Mesh::computeFeatures + computeMassMatrix + setLameParam
  * (src/Mesh.cpp:414-527, 246-266, 399-401, 660-671): restTriInv, triArea, lumped mass,

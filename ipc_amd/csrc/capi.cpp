@@ -1,6 +1,7 @@
 // extern "C" boundary of libipcgpu.so (include/ipcgpu.h).  No exception leaves this file.
 #include "../../include/ipcgpu.h"
 #include "hip_ipc.h"
+#include "msh_io.h"
 #include <cstring>
 #include <mutex>
 
@@ -170,6 +171,59 @@ int ipcgpu_set_component_material(ipcgpu_ctx* c, int nodeBegin, int nodeEnd, int
         needArg(0 <= nodeBegin && nodeBegin <= nodeEnd && nodeEnd <= m.nV && 0 <= tetBegin && tetBegin <= tetEnd && tetEnd <= m.nT, "range out of bounds");
         needArg(rho > 0 && YM > 0 && PR > -1.0 && PR < 0.5, "bad material");
         m.setComponentMaterial(nodeBegin, nodeEnd, tetBegin, tetEnd, rho, YM, PR, c->stream);
+        return IPCGPU_OK;
+    });
+}
+struct ipcgpu_tetmesh {
+    ipcgpu::TetMeshFile m;
+};
+int ipcgpu_read_tet_mesh(const char* path, ipcgpu_tetmesh** mesh, int* nV, int* nT, int* nSF)
+{
+    return guarded([&] {
+        needArg(path && mesh && nV && nT && nSF, "null argument");
+        std::unique_ptr<ipcgpu_tetmesh> h(new ipcgpu_tetmesh);
+        readTetMesh(path, h->m, true);
+        *nV = (int)(h->m.V.size() / 3);
+        *nT = (int)(h->m.T.size() / 4);
+        *nSF = (int)(h->m.SF.size() / 3);
+        *mesh = h.release();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_tet_mesh_get(const ipcgpu_tetmesh* h, double* V, int* T, int* SF)
+{
+    return guarded([&] {
+        needArg(h != nullptr, "null mesh");
+        const size_t nV = h->m.V.size() / 3, nT = h->m.T.size() / 4, nSF = h->m.SF.size() / 3;
+        if (V)
+            for (size_t v = 0; v < nV; ++v)
+                for (int c = 0; c < 3; ++c) V[v + nV * c] = h->m.V[3 * v + c];
+        if (T)
+            for (size_t t = 0; t < nT; ++t)
+                for (int k = 0; k < 4; ++k) T[t + nT * k] = h->m.T[4 * t + k];
+        if (SF)
+            for (size_t t = 0; t < nSF; ++t)
+                for (int k = 0; k < 3; ++k) SF[t + nSF * k] = h->m.SF[3 * t + k];
+        return IPCGPU_OK;
+    });
+}
+void ipcgpu_tet_mesh_free(ipcgpu_tetmesh* h) { delete h; }
+int ipcgpu_save_tet_mesh(const char* path, int nV, int nT, const double* V, const int* T)
+{
+    return guarded([&] {
+        needArg(path && V && T && nV >= 4 && nT >= 1, "bad argument");
+        std::vector<double> v(3 * (size_t)nV);
+        std::vector<int> t(4 * (size_t)nT), sf;
+        for (int i = 0; i < nV; ++i)
+            for (int c = 0; c < 3; ++c) v[3 * (size_t)i + c] = V[i + (size_t)nV * c];
+        for (int i = 0; i < nT; ++i)
+            for (int k = 0; k < 4; ++k) {
+                const int n = T[i + (size_t)nT * k];
+                needArg(n >= 0 && n < nV, "element refers to a node that does not exist");
+                t[4 * (size_t)i + k] = n;
+            }
+        findSurfaceTris(nT, t.data(), sf);
+        saveTetMesh(path, nV, nT, v.data(), t.data(), sf);
         return IPCGPU_OK;
     });
 }

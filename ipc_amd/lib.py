@@ -57,6 +57,9 @@ def load_library():
             raise IpcGpuError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = C.CDLL(_LIB_PATH)
         _lib.ipcgpu_last_error.restype = C.c_char_p
+        _lib.ipcgpu_tet_mesh_free.restype = None
+        _lib.ipcgpu_tet_mesh_free.argtypes = [C.c_void_p]
+        _lib.ipcgpu_tet_mesh_get.argtypes = [C.c_void_p, c_dp, c_ip, c_ip]
     return _lib
 
 
@@ -74,6 +77,36 @@ def _f64(a):
 
 def _i32(a):
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def read_tet_mesh(path):
+    """IglUtils::readTetMesh through the C ABI: (V, T, SF) of a .msh file (MSH 4.1 / 2.2 ASCII or the reference's msh-4.0 dialect)."""
+    L = load_library()
+    h = C.c_void_p()
+    nV, nT, nSF = C.c_int(), C.c_int(), C.c_int()
+    rc = L.ipcgpu_read_tet_mesh(str(path).encode(), C.byref(h), C.byref(nV), C.byref(nT), C.byref(nSF))
+    if rc != 0:
+        raise RuntimeError(f"ipcgpu_read_tet_mesh failed ({rc}): {L.ipcgpu_last_error().decode()}")
+    try:
+        V = np.zeros((nV.value, 3), order="F")
+        T = np.zeros((nT.value, 4), dtype=np.int32, order="F")
+        SF = np.zeros((nSF.value, 3), dtype=np.int32, order="F")
+        rc = L.ipcgpu_tet_mesh_get(h, _dp(V), _ip(T), _ip(SF))
+        if rc != 0:
+            raise RuntimeError(f"ipcgpu_tet_mesh_get failed ({rc})")
+    finally:
+        L.ipcgpu_tet_mesh_free(h)
+    return V, T, SF
+
+
+def save_tet_mesh(path, V, T):
+    """IglUtils::saveTetMesh through the C ABI (MSH 4.1 ASCII + $Surface)."""
+    L = load_library()
+    V = np.asfortranarray(V, dtype=np.float64)
+    T = np.asfortranarray(T, dtype=np.int32)
+    rc = L.ipcgpu_save_tet_mesh(str(path).encode(), C.c_int(V.shape[0]), C.c_int(T.shape[0]), _dp(V), _ip(T))
+    if rc != 0:
+        raise RuntimeError(f"ipcgpu_save_tet_mesh failed ({rc}): {L.ipcgpu_last_error().decode()}")
 
 
 class Context:
