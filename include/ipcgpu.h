@@ -223,6 +223,14 @@ int ipcgpu_opt_set_velocity(ipcgpu_ctx*, const double* vel_3nV);
  * 3627-3631), predicts xTilta with the stored acceleration (:1259-1277) and updates velocity / acceleration at the end of the
  * time step (:582-590).  Call after ipcgpu_opt_init, before ipcgpu_opt_precompute; the acceleration starts at zero (:177). */
 int ipcgpu_opt_set_time_integration(ipcgpu_ctx*, int type, double beta, double gamma);
+/* One Mesh::DirichletBCs entry (src/Mesh.hpp:23-39; `DBC bboxMin bboxMax linVel angVel [t0 t1]` on a shape line,
+ * src/Config.cpp:246-263, vertices picked by IglUtils::Init_Dirichlet) or the scripted linear / angular velocity of a whole
+ * component (`linearVelocity` / `angularVelocity`, componentLVels / componentAVels -- how kinematic mesh obstacles move):
+ * while t0 <= stepStartTime < t1 the vertices are Dirichlet nodes (ZERO if both velocities vanish, else NONZERO,
+ * AnimScripter.cpp:58-110) and every time step moves them by R (x - c) + c + linVel dt - x with R = Rx Ry Rz of ang_vel dt and
+ * c the centre of their current bounding box (AnimScripter.cpp:1413-1462).  ang_vel in rad/s (the script gives deg/s).
+ * Call after ipcgpu_opt_init and after the static ipcgpu_set_dbc / ipcgpu_opt_set_twist calls. */
+int ipcgpu_opt_add_dirichlet(ipcgpu_ctx*, int n, const int* vert_ids, const double* lin_vel3, const double* ang_vel3, double t0, double t1);
 /* Optimizer::velocity (xyz-interleaved), acceleration and dx_Elastic = V - xTilta of the last finished time step
  * (Optimizer.cpp:574-586); any pointer may be null */
 int ipcgpu_opt_get_kinematics(ipcgpu_ctx*, double* vel_3nV, double* acc_3nV, double* dx_elastic_3nV);

@@ -996,6 +996,18 @@ int ipcgpu_opt_set_time_integration(ipcgpu_ctx* c, int type, double beta, double
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_add_dirichlet(ipcgpu_ctx* c, int n, const int* ids, const double* lin3, const double* ang3, double t0, double t1)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(n > 0 && ids && lin3 && ang3, "empty Dirichlet group");
+        for (int i = 0; i < n; ++i) needArg(ids[i] >= 0 && ids[i] < c->mesh->nV, "vertex id out of range");
+        o.addDirichletBC(n, ids, lin3, ang3, t0, t1);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_get_kinematics(ipcgpu_ctx* c, double* vel, double* acc, double* dx)
 {
     return guarded([&] {

@@ -127,6 +127,20 @@ public:
     DevBuf<int> d_flag, d_handleIds;
     DevBuf<double> d_handleAng;
     int nHandles = 0;
+    // Mesh::DirichletBCs (Mesh.hpp:23-39) and scripted component velocities (AnimScripter.cpp:1413-1435)
+    struct DbcGroup {
+        std::vector<int> ids;
+        DevBuf<int> d_ids;
+        DevBuf<double> d_pos;
+        double lin[3], ang[3], t0, t1;
+        bool isZero() const { return lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
+    };
+    std::vector<std::unique_ptr<DbcGroup>> dbcGroups;
+    std::vector<int> baseDbcType;
+    double stepStartTime = 0, stepEndTime = 0; // AnimScripter.cpp:1406-1407
+    void addDirichletBC(int n, const int* ids, const double* lin3, const double* angRad3, double t0, double t1);
+    void setDBCVertices(); // AnimScripter::setDBCVertices, AnimScripter.cpp:58-110
+    bool dbcGroupMotion(); // adds the active groups' motion to d_searchDir; true if any
     double rotCenter[3] = { 0, 0, 0 };
     PinnedBuf<double> h_scalar;
     PinnedBuf<int> h_flag;

@@ -127,6 +127,77 @@ void HipOptimizer::setTwist(int nL, const int* left, int nR, const int* right, d
     if (initialised) computeXTilta(); // the handles are Dirichlet nodes now: xTilta = V_prev there (Optimizer.cpp:1244-1246)
 }
 
+void HipOptimizer::addDirichletBC(int n, const int* ids, const double* lin3, const double* angRad3, double t0, double t1)
+{
+    std::unique_ptr<DbcGroup> g(new DbcGroup);
+    g->ids.assign(ids, ids + n);
+    for (int c = 0; c < 3; ++c) {
+        g->lin[c] = lin3[c];
+        g->ang[c] = angRad3[c];
+    }
+    g->t0 = t0;
+    g->t1 = t1;
+    g->d_ids.upload(g->ids, stream);
+    g->d_pos.alloc(3 * (size_t)n);
+    if (baseDbcType.empty()) baseDbcType = mesh.dbcType;
+    dbcGroups.push_back(std::move(g));
+    setDBCVertices(); // initAnimScript (AnimScripter.cpp:122-124)
+    if (initialised) computeXTilta();
+}
+
+void HipOptimizer::setDBCVertices()
+{
+    if (dbcGroups.empty()) return;
+    if (baseDbcType.empty()) baseDbcType = mesh.dbcType;
+    std::vector<int> t = baseDbcType;
+    for (const auto& g : dbcGroups) {
+        if (stepStartTime < g->t0 || stepStartTime >= g->t1) continue;
+        const int type = g->isZero() ? 1 : 2;
+        for (int v : g->ids) t[v] = std::max(t[v], type); // NONZERO overrides ZERO
+    }
+    if (t != mesh.dbcType) {
+        mesh.dbcType = t;
+        mesh.uploadDBC(stream);
+    }
+}
+
+bool HipOptimizer::dbcGroupMotion()
+{
+    bool any = false;
+    std::vector<double> pos;
+    for (const auto& g : dbcGroups) {
+        if (stepStartTime < g->t0 || stepStartTime >= g->t1 || g->ids.empty()) continue;
+        const int n = (int)g->ids.size();
+        // centre of the group's current bounding box (AnimScripter.cpp:1450-1455): a few KB to the host, once per time step
+        launch_gather3(n, g->d_ids.p, mesh.d_x.p, g->d_pos.p, stream);
+        pos.resize(3 * (size_t)n);
+        g->d_pos.download(pos.data(), pos.size(), stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        DbcMotion m;
+        double lo[3] = { pos[0], pos[1], pos[2] }, hi[3] = { pos[0], pos[1], pos[2] };
+        for (int i = 0; i < n; ++i)
+            for (int c = 0; c < 3; ++c) {
+                lo[c] = std::min(lo[c], pos[3 * (size_t)i + c]);
+                hi[c] = std::max(hi[c], pos[3 * (size_t)i + c]);
+            }
+        for (int c = 0; c < 3; ++c) {
+            m.c[c] = (lo[c] + hi[c]) / 2;
+            m.linDt[c] = g->lin[c] * dt;
+        }
+        const double ax = g->ang[0] * dt, ay = g->ang[1] * dt, az = g->ang[2] * dt;
+        const double cx = std::cos(ax), sx = std::sin(ax), cy = std::cos(ay), sy = std::sin(ay), cz = std::cos(az), sz = std::sin(az);
+        const double Rx[9] = { 1, 0, 0, 0, cx, -sx, 0, sx, cx }, Ry[9] = { cy, 0, sy, 0, 1, 0, -sy, 0, cy }, Rz[9] = { cz, -sz, 0, sz, cz, 0, 0, 0, 1 };
+        double T[9];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) T[3 * i + j] = Rx[3 * i] * Ry[j] + Rx[3 * i + 1] * Ry[3 + j] + Rx[3 * i + 2] * Ry[6 + j];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) m.R[3 * i + j] = T[3 * i] * Rz[j] + T[3 * i + 1] * Rz[3 + j] + T[3 * i + 2] * Rz[6 + j];
+        launch_dbc_motion(n, g->d_ids.p, m, mesh.d_x.p, d_searchDir.p, stream);
+        any = true;
+    }
+    return any;
+}
+
 void HipOptimizer::reduceSum(double* dev, long long n)
 {
     if (worldSize > 1) {
@@ -715,9 +786,13 @@ void HipOptimizer::beginTimestep()
     Tic t(timers[11], stream);
     if (!checkInversion()) throw StateError("element inversion before scripted motion (Optimizer.cpp:517-522)");
     d_searchDir.zero(stream);
-    if (nHandles) {
-        // stepAnimScript, AST_TWIST (AnimScripter.cpp:1674-1684, 2140-2215)
-        launch_twist_dir(nHandles, d_handleIds.p, d_handleAng.p, rotCenter[1], rotCenter[2], mesh.d_x.p, d_searchDir.p, stream);
+    stepStartTime = stepEndTime; // AnimScripter.cpp:1406-1407
+    stepEndTime += dt;
+    setDBCVertices();
+    // stepAnimScript, AST_TWIST (AnimScripter.cpp:1674-1684, 2140-2215)
+    if (nHandles) launch_twist_dir(nHandles, d_handleIds.p, d_handleAng.p, rotCenter[1], rotCenter[2], mesh.d_x.p, d_searchDir.p, stream);
+    const bool groupMotion = dbcGroupMotion(); // AST_NULL: Dirichlet groups / scripted components (:1413-1462)
+    if (nHandles || groupMotion) {
         double stepSize = filterStepSize(d_searchDir.p, 1.0);
         if (selfCollision) // CCD of the scripted motion with slackness 0.5 (AnimScripter.cpp:2158-2171)
             stepSize = contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, 0.5, stepSize, nullptr, nullptr);

@@ -62,6 +62,14 @@ void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, do
 // Newmark update (Optimizer.cpp:582-590, 1259-1277)
 void launch_nm_update(int nV, const int* dbc, const double* x, double* xPrev, double* vel, double* acc, double* dxElastic, double* xTilde,
     double dt, double beta, double gamma, double gx, double gy, double gz, hipStream_t s);
+// scripted Dirichlet groups (Mesh::DirichletBCs / scripted component velocities, AnimScripter.cpp:1413-1462)
+struct DbcMotion {
+    double R[9]; // row-major Rx Ry Rz of angVel dt
+    double c[3]; // centre of the group's current bounding box
+    double linDt[3];
+};
+void launch_gather3(int n, const int* ids, const double* x, double* out, hipStream_t s);
+void launch_dbc_motion(int n, const int* ids, const DbcMotion& m, const double* x, double* p, hipStream_t s);
 // twist handles: rotate listed vertices about the x axis through c by their angle (AnimScripter.cpp:1674-1684)
 void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s);
 

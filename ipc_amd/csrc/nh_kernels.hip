@@ -413,6 +413,25 @@ __global__ void k_twist_dir(int nH, const int* __restrict__ ids, const double* _
     p[3 * (size_t)v + 2] = (sn * y + cs * z + cz) - x[3 * (size_t)v + 2];
 }
 
+// positions of a vertex list, packed (for the bounding box of a Dirichlet group)
+__global__ void k_gather3(int n, const int* __restrict__ ids, const double* __restrict__ x, double* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int k = i / 3, c = i - 3 * k;
+    out[i] = x[3 * (size_t)ids[k] + c];
+}
+// scripted Dirichlet motion (AnimScripter.cpp:1440-1462): p += R (x - c) + c + linVel dt - x
+__global__ void k_dbc_motion(int n, const int* __restrict__ ids, DbcMotion m, const double* __restrict__ x, double* __restrict__ p)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t v = (size_t)ids[i];
+    const double d0 = x[3 * v] - m.c[0], d1 = x[3 * v + 1] - m.c[1], d2 = x[3 * v + 2] - m.c[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[3 * v + c] += (m.R[3 * c] * d0 + m.R[3 * c + 1] * d1 + m.R[3 * c + 2] * d2) + m.c[c] + m.linDt[c] - x[3 * v + c];
+}
+
 inline int nblk(long long n, int b = BLOCK) { return (int)((n + b - 1) / b); }
 
 } // namespace
@@ -505,6 +524,15 @@ void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, do
 void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s)
 {
     if (nH) hipLaunchKernelGGL(k_twist_dir, dim3(nblk(nH)), dim3(BLOCK), 0, s, nH, ids, ang, cy, cz, x, p);
+}
+
+void launch_gather3(int n, const int* ids, const double* x, double* out, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_gather3, dim3(nblk(3LL * n)), dim3(BLOCK), 0, s, n, ids, x, out);
+}
+void launch_dbc_motion(int n, const int* ids, const DbcMotion& m, const double* x, double* p, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_dbc_motion, dim3(nblk(n)), dim3(BLOCK), 0, s, n, ids, m, x, p);
 }
 
 __global__ void k_publish(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n)

@@ -521,6 +521,13 @@ class Context:
         """Scene-script `timeIntegration BE | NM beta gamma`."""
         self._chk(self._L.ipcgpu_opt_set_time_integration(self.h, C.c_int({"BE": 0, "NM": 1}[name]), C.c_double(beta), C.c_double(gamma)))
 
+    def add_dirichlet(self, ids, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), t0=0.0, t1=float("inf")):
+        """One `DBC bboxMin bboxMax linVel angVel [t0 t1]` entry of a shape line (degrees per second, as in the script)."""
+        ids = _i32(ids)
+        lin = _f64(np.asarray(lin_vel, dtype=np.float64))
+        ang = _f64(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
+        self._chk(self._L.ipcgpu_opt_add_dirichlet(self.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1)))
+
     def kinematics(self):
         vel, acc, dx = np.zeros(3 * self.nV), np.zeros(3 * self.nV), np.zeros(3 * self.nV)
         self._chk(self._L.ipcgpu_opt_get_kinematics(self.h, _dp(vel), _dp(acc), _dp(dx)))

@@ -145,3 +145,14 @@ def surface_edges(SF):
             if (int(b), int(a)) not in s:
                 s.add((int(a), int(b)))
     return np.array(sorted(s), dtype=np.int32).reshape(-1, 2)
+
+
+def select_dirichlet(V, SF, rel_min, rel_max):
+    """IglUtils::Init_Dirichlet (IglUtils.cpp:691-718): surface nodes inside the box given relative to the shape's bounding box."""
+    lo, hi = V.min(0), V.max(0)
+    rmin = (hi - lo) * np.asarray(rel_min, dtype=float) + lo
+    rmax = (hi - lo) * np.asarray(rel_max, dtype=float) + lo
+    on_boundary = np.zeros(V.shape[0], dtype=bool)
+    on_boundary[np.asarray(SF).reshape(-1)] = True
+    sel = on_boundary & (V >= rmin).all(1) & (V <= rmax).all(1)
+    return np.nonzero(sel)[0].astype(np.int32)

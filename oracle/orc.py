@@ -432,6 +432,14 @@ def opt_enable_self_collision(opt: "Optimizer", dHatEps=1e-3):
     lib().orc_opt_enable_self_collision(opt.h, C.c_double(dHatEps))
 
 
+def opt_add_dirichlet(opt: "Optimizer", ids, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), t0=0.0, t1=float("inf")):
+    """One `DBC bboxMin bboxMax linVel angVel [t0 t1]` entry of a shape line (Config.cpp:246-263; degrees per second in the script)."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    lin = np.ascontiguousarray(lin_vel, dtype=np.float64)
+    ang = np.ascontiguousarray(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
+    lib().orc_opt_add_dirichlet(opt.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1))
+
+
 def opt_kinematics(opt: "Optimizer"):
     n3 = 3 * opt.mesh.nV
     vel, acc, dx = np.zeros(n3), np.zeros(n3), np.zeros(n3)

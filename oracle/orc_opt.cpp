@@ -28,6 +28,16 @@ struct orc_opt {
     double relGL2Tol = 1.0e-8, targetGRes = 0;
     std::vector<double> velocity, xTilta, V_prev, searchDir, gradient, a;
     std::map<int, double> angVel; // twist handles
+    // Mesh::DirichletBCs (Mesh.hpp:23-39): `DBC bboxMin bboxMax linVel angVel [t0 t1]` of a shape line (Config.cpp:246-263), and
+    // the scripted linear / angular velocity of whole components (componentLVels / componentAVels, AnimScripter.cpp:1413-1435)
+    struct DBCGroup {
+        std::vector<int> ids;
+        double lin[3], ang[3], t0, t1;
+        bool isZero() const { return lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
+    };
+    std::vector<DBCGroup> dbcGroups;
+    std::vector<int> baseDbcType; // types that do not come from a group (set_dbc, twist handles)
+    double stepStartTime = 0, stepEndTime = 0; // AnimScripter.cpp:1406-1407
     double rotCenter[3];
     orc_chol* chol = nullptr;
     int innerIterAmt = 0, globalIterNum = 0, k = 0;
@@ -490,6 +500,67 @@ void orc_opt_set_twist(orc_opt* o, int nL, const int* left, int nR, const int* r
     computeXTilta(o);
 }
 
+// AnimScripter::setDBCVertices (AnimScripter.cpp:58-110): types of the groups that are active at stepStartTime on top of the
+// static ones; NONZERO overrides ZERO
+static void setDBCVertices(orc_opt* o)
+{
+    Mesh& m = *o->m;
+    if (o->dbcGroups.empty()) return;
+    if (o->baseDbcType.empty()) o->baseDbcType = m.dbcType;
+    std::vector<int> t = o->baseDbcType;
+    for (const auto& g : o->dbcGroups) {
+        if (o->stepStartTime < g.t0 || o->stepStartTime >= g.t1) continue;
+        const int type = g.isZero() ? 1 : 2;
+        for (int v : g.ids) t[v] = std::max(t[v], type);
+    }
+    m.dbcType = t;
+}
+
+// searchDir += R (x - c) + c + linVel dt - x, R = Rx Ry Rz of angVel dt, c = centre of the group's current bounding box
+// (AnimScripter.cpp:1440-1462)
+static void dbcGroupMotion(orc_opt* o, const orc_opt::DBCGroup& g)
+{
+    Mesh& m = *o->m;
+    const double ax = g.ang[0] * o->dt, ay = g.ang[1] * o->dt, az = g.ang[2] * o->dt;
+    const double cx = std::cos(ax), sx = std::sin(ax), cy = std::cos(ay), sy = std::sin(ay), cz = std::cos(az), sz = std::sin(az);
+    const double Rx[9] = { 1, 0, 0, 0, cx, -sx, 0, sx, cx }, Ry[9] = { cy, 0, sy, 0, 1, 0, -sy, 0, cy }, Rz[9] = { cz, -sz, 0, sz, cz, 0, 0, 0, 1 };
+    double T[9], R[9]; // row-major
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) T[3 * i + j] = Rx[3 * i] * Ry[j] + Rx[3 * i + 1] * Ry[3 + j] + Rx[3 * i + 2] * Ry[6 + j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = T[3 * i] * Rz[j] + T[3 * i + 1] * Rz[3 + j] + T[3 * i + 2] * Rz[6 + j];
+    double lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) lo[c] = hi[c] = m.V[g.ids[0] + m.nV * c];
+    for (int v : g.ids)
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = std::min(lo[c], m.V[v + m.nV * c]);
+            hi[c] = std::max(hi[c], m.V[v + m.nV * c]);
+        }
+    double ctr[3];
+    for (int c = 0; c < 3; ++c) ctr[c] = (lo[c] + hi[c]) / 2;
+    for (int v : g.ids) {
+        const double d[3] = { m.V[v] - ctr[0], m.V[v + m.nV] - ctr[1], m.V[v + 2 * m.nV] - ctr[2] };
+        for (int c = 0; c < 3; ++c)
+            o->searchDir[3 * v + c] += (R[3 * c] * d[0] + R[3 * c + 1] * d[1] + R[3 * c + 2] * d[2]) + ctr[c] + g.lin[c] * o->dt - m.V[v + m.nV * c];
+    }
+}
+
+void orc_opt_add_dirichlet(orc_opt* o, int n, const int* ids, const double* lin3, const double* angRad3, double t0, double t1)
+{
+    orc_opt::DBCGroup g;
+    g.ids.assign(ids, ids + n);
+    for (int c = 0; c < 3; ++c) {
+        g.lin[c] = lin3[c];
+        g.ang[c] = angRad3[c];
+    }
+    g.t0 = t0;
+    g.t1 = t1;
+    if (o->baseDbcType.empty()) o->baseDbcType = o->m->dbcType;
+    o->dbcGroups.push_back(g);
+    setDBCVertices(o); // initAnimScript (AnimScripter.cpp:122-124)
+    computeXTilta(o);
+}
+
 void orc_opt_precompute(orc_opt* o)
 {
     // Optimizer.cpp:457-507: set_pattern, constraint sets, computePrecondMtr(redoSVD), analyze_pattern, initial energy
@@ -512,7 +583,16 @@ void orc_opt_begin_timestep(orc_opt* o)
         o->searchDir[3 * v + 1] = ny - m.V[v + m.nV];
         o->searchDir[3 * v + 2] = nz - m.V[v + 2 * m.nV];
     }
-    if (!o->angVel.empty()) {
+    o->stepStartTime = o->stepEndTime; // AnimScripter.cpp:1406-1407
+    o->stepEndTime += o->dt;
+    setDBCVertices(o);
+    bool scripted = !o->angVel.empty();
+    for (const auto& g : o->dbcGroups)
+        if (o->stepStartTime >= g.t0 && o->stepStartTime < g.t1 && !g.ids.empty()) {
+            dbcGroupMotion(o, g);
+            scripted = true;
+        }
+    if (scripted) {
         double stepSize = filterStepSize(m, o->searchDir.data(), 1.0);
         if (o->selfCollision) { // :2158-2171: CCD of the scripted motion with slackness 0.5
             std::vector<std::array<int, 2>> cand;

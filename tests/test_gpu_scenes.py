@@ -119,3 +119,49 @@ def test_config4_two_rods_twisted_together(orc, gpu_lib):
     seen = run_side_by_side(orc, o, c, steps=8)
     assert seen["active"] > 50 and seen["para"] > 0
     c.close()
+
+
+# ------------------------------------------------------------------------------------------------ config 0
+def _config0():
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "config0_bar2523.npz"))
+    return {k: g[k] for k in g.files}
+
+
+def test_config0_hello_world_on_the_reference_mesh(orc, gpu_lib):
+    """BASELINE configs[0]: input/otherExamples/barTwist_noCollisions.txt on the reference's own bar-2523.msh (886 nodes,
+    2 523 tets, E = 1e9): left end fixed, right end turning 270 deg/s as a `DBC` group.  The mesh arrays and the expected
+    positions are the committed fixture of tools/make_golden_config0.py; the live oracle runs beside it as well."""
+    g = _config0()
+    V, T = g["V"], g["T"]
+    assert V.shape == (886, 3) and T.shape == (2523, 4)
+    m = orc.Mesh(V, T, YM=1e9, PR=0.4, density=1000.0)
+    o = orc.Optimizer(m, dt=0.025, gravity=True, nthreads=4)
+    orc.opt_add_dirichlet(o, g["left"])
+    orc.opt_add_dirichlet(o, g["right"], ang_vel_deg=(270, 0, 0))
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, T, YM=1e9, PR=0.4, density=1000.0)
+    c.opt_init(0.025, True)
+    c.add_dirichlet(g["left"])
+    c.add_dirichlet(g["right"], ang_vel_deg=(270, 0, 0))
+    # from an exact rest start single iterates are round-off dependent (makePD2d, see tools/make_golden_config0.py): compare
+    # the converged time steps at the fixture's tight tolerance
+    o.set_rel_tol(float(g["rel_tol"]))
+    c.set_rel_tol(float(g["rel_tol"]))
+    o.precompute()
+    c.precompute()
+    for step in range(len(g["iters"])):
+        no, ng = o.solve_timestep(100), c.solve_timestep(100)
+        assert no < 100 and ng < 100
+        so, sg = o.state(), c.state()
+        assert relerr(sg["V"], so["V"]) < 1e-6 and relerr(sg["V"], g["positions"][step]) < 1e-6
+        assert abs(sg["E"] - g["energy"][step]) <= 1e-6 * abs(g["energy"][step])
+    # the right end has really turned: 3 steps of 270 deg/s * 0.025 s
+    th = np.deg2rad(270 * 0.025 * len(g["iters"]))
+    ctr = 0.5 * (V[g["right"]].min(0) + V[g["right"]].max(0))
+    y0, z0 = (V[g["right"], 1] - ctr[1]), (V[g["right"], 2] - ctr[2])
+    Vn = c.state()["V"]
+    assert np.allclose(Vn[g["right"], 1] - ctr[1], np.cos(th) * y0 - np.sin(th) * z0, atol=1e-9)
+    assert np.allclose(Vn[g["right"], 2] - ctr[2], np.sin(th) * y0 + np.cos(th) * z0, atol=1e-9)
+    assert np.allclose(Vn[g["left"]], V[g["left"]], rtol=0, atol=1e-14)
+    c.close()

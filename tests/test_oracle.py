@@ -297,3 +297,33 @@ def test_newton_twist_bar_converges_and_decreases_energy(orc):
         y, z = V[v, 1] - c[1], V[v, 2] - c[2]
         assert abs(Vn[v, 1] - (c[1] + np.cos(ang) * y - np.sin(ang) * z)) < 1e-12
         assert abs(Vn[v, 2] - (c[2] + np.sin(ang) * y + np.cos(ang) * z)) < 1e-12
+
+
+def test_config0_golden_fixture_is_what_the_oracle_computes(orc):
+    """tests/golden/config0_bar2523.npz (tools/make_golden_config0.py): the reference's hello-world scene on its own mesh."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "config0_bar2523.npz"))
+    m = orc.Mesh(g["V"], g["T"], YM=1e9, PR=0.4, density=1000.0)
+    o = orc.Optimizer(m, dt=0.025, gravity=True, nthreads=4)
+    orc.opt_add_dirichlet(o, g["left"])
+    orc.opt_add_dirichlet(o, g["right"], ang_vel_deg=(270, 0, 0))
+    o.set_rel_tol(float(g["rel_tol"]))
+    o.precompute()
+    for step in range(2):
+        assert o.solve_timestep(100) == g["iters"][step]
+        assert np.abs(o.state()["V"] - g["positions"][step]).max() <= 1e-10 * np.abs(g["positions"][step]).max()
+    # Dirichlet groups with a time range: outside of it the nodes are free again (AnimScripter.cpp:98-107)
+    V, F = scene.make_box(3, 1, 1, size=(3.0, 1.0, 1.0))
+    SF = scene.surface_tris(F)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.3, density=1000.0)
+    o = orc.Optimizer(m, dt=0.02, gravity=True, nthreads=2)
+    sel = scene.select_dirichlet(V, SF, (0, 0, 0), (0.01, 1, 1))
+    orc.opt_add_dirichlet(o, sel, lin_vel=(0.0, 0.5, 0.0), t0=0.0, t1=0.03)
+    o.precompute()
+    o.solve_timestep(60)
+    assert np.allclose(o.state()["V"][sel, 1], V[sel, 1] + 0.5 * 0.02)
+    o.solve_timestep(60)
+    y2 = o.state()["V"][sel, 1].copy()
+    assert np.allclose(y2, V[sel, 1] + 2 * 0.5 * 0.02)
+    o.solve_timestep(60)  # stepStartTime = 0.04 >= t1: released, gravity takes over
+    assert (o.state()["V"][sel, 1] < y2 + 0.5 * 0.02 - 1e-6).all()

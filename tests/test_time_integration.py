@@ -149,3 +149,33 @@ def test_status_checkpoint_is_interchangeable(orc, gpu_lib, tmp_path, integ):
     assert relerr(c2.state()["V"], ref) < 1e-8
     c.close()
     c2.close()
+
+
+@pytest.mark.gpu
+def test_dirichlet_groups_track_the_oracle(orc, gpu_lib):
+    """`DBC` entries of a shape line (Mesh::DirichletBCs, AnimScripter.cpp:58-110, 1440-1462): a fixed group, a group with linear
+    and angular velocity that is released after two steps, iterate by iterate from a pre-strained state."""
+    V, F = scene.make_bar(10, 2, 2, size=(4.0, 0.5, 1.0))
+    SF = scene.surface_tris(F)
+    Vs = scene.jitter(V, F, rel=2e-2)
+    left = scene.select_dirichlet(V, SF, (0, 0, 0), (0.01, 1, 1))
+    right = scene.select_dirichlet(V, SF, (0.99, 0, 0), (1, 1, 1))
+    assert len(left) and len(right)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.02, gravity=True, nthreads=4)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.02, True)
+    for x in (o, c):
+        add = (lambda *a, **k: orc.opt_add_dirichlet(o, *a, **k)) if x is o else c.add_dirichlet
+        add(left)
+        add(right, lin_vel=(0.3, 0.0, -0.1), ang_vel_deg=(120, 20, -35), t0=0.0, t1=0.03)
+    o.precompute()
+    c.precompute()
+    _step_both(o, c, 4)
+    Vn = c.state()["V"]
+    assert np.abs(Vn[left] - Vs[left]).max() < 1e-14  # ZERO type: (x - c) + c - x, round-off only (as in the reference)
+    assert np.abs(Vn[right] - Vs[right]).max() > 5e-3
+    c.close()
