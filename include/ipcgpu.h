@@ -231,6 +231,11 @@ int ipcgpu_opt_set_time_integration(ipcgpu_ctx*, int type, double beta, double g
  * c the centre of their current bounding box (AnimScripter.cpp:1413-1462).  ang_vel in rad/s (the script gives deg/s).
  * Call after ipcgpu_opt_init and after the static ipcgpu_set_dbc / ipcgpu_opt_set_twist calls. */
 int ipcgpu_opt_add_dirichlet(ipcgpu_ctx*, int n, const int* vert_ids, const double* lin_vel3, const double* ang_vel3, double t0, double t1);
+/* State of the augmented-Lagrangian Dirichlet fallback (Optimizer.cpp:1826-1828, 2168-2203; AnimScripter.cpp:2280-2350): when
+ * the scripted motion of a time step is cut short (element inversion, CCD, intersection), the NONZERO Dirichlet nodes are
+ * released and pulled to their targets by a penalty rho_DBC / 2 m |x - target|^2 with multipliers until the completed step
+ * size exceeds 1 - 1e-3.  out4 = {completed step size, rho_DBC, m_projectDBC, number of target positions}. */
+int ipcgpu_opt_get_dbc_state(ipcgpu_ctx*, double* out4);
 /* Optimizer::velocity (xyz-interleaved), acceleration and dx_Elastic = V - xTilta of the last finished time step
  * (Optimizer.cpp:574-586); any pointer may be null */
 int ipcgpu_opt_get_kinematics(ipcgpu_ctx*, double* vel_3nV, double* acc_3nV, double* dx_elastic_3nV);

@@ -1008,6 +1008,16 @@ int ipcgpu_opt_add_dirichlet(ipcgpu_ctx* c, int n, const int* ids, const double*
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_get_dbc_state(ipcgpu_ctx* c, double* out4)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(out4 != nullptr, "null output");
+        o.getDbcState(out4);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_get_kinematics(ipcgpu_ctx* c, double* vel, double* acc, double* dx)
 {
     return guarded([&] {

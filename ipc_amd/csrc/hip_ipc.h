@@ -101,6 +101,7 @@ public:
     // building blocks (virtuals of Optimizer.hpp:229-283)
     double computeEnergyVal();
     void computeGradient(bool projectDBC);
+    void penaltyGradientAdd(bool projectDBC);
     void computePrecondMtr(bool projectDBC, bool withGradient);
     void computeSearchDir(bool projectDBC);
     void lineSearch(double& stepSize);
@@ -121,6 +122,7 @@ public:
     double elasticCoef() const { return timeIntegration == 1 ? dtSq * betaNM : dtSq; } // Optimizer.cpp:3205-3224, 3416-3434, 3618-3632
     void setTimeIntegration(int type, double beta, double gamma);
     void getKinematics(double* vel, double* acc, double* dxElastic);
+    void getDbcState(double* out4) const;
     void saveStatus(const std::string& path); // Optimizer::saveStatus, Optimizer.cpp:2964-3011
     void loadStatus(const std::string& path); // restart, Optimizer.cpp:179-248
     DevBuf<double> d_vel, d_xPrev, d_searchDir, d_gradient, d_minusG, d_x0, d_partial, d_scalar;
@@ -138,6 +140,17 @@ public:
     std::vector<std::unique_ptr<DbcGroup>> dbcGroups;
     std::vector<int> baseDbcType;
     double stepStartTime = 0, stepEndTime = 0; // AnimScripter.cpp:1406-1407
+    // augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2150-2157, 2280-2350; Optimizer.cpp:1826-1828, 2168-2203)
+    std::vector<int> tpIds; // targetPos keys = the Dirichlet nodes, ascending
+    DevBuf<int> d_tpIds;
+    DevBuf<double> d_tpPos, d_tpLam;
+    double dist2Tol = 0, completedStep = 1.0, lastMove = 1.0, rhoDBC = 0.0, CN_MBC = 0.0;
+    bool projDBC = true; // m_projectDBC
+    MdbcView mdbc() const { return MdbcView{ (int)tpIds.size(), d_tpIds.p, d_tpPos.p, d_tpLam.p, mesh.d_mass.p }; }
+    void buildTargetPositions(); // after the scripted search direction is known, before it is applied
+    void initSubProblem(); // head of solveSub_IP (Optimizer.cpp:1826-1828)
+    double computeCompletedStepSize(); // AnimScripter.cpp:2286-2300
+    void dirichletPenaltyUpdate(); // Optimizer.cpp:2168-2203
     void addDirichletBC(int n, const int* ids, const double* lin3, const double* angRad3, double t0, double t1);
     void setDBCVertices(); // AnimScripter::setDBCVertices, AnimScripter.cpp:58-110
     bool dbcGroupMotion(); // adds the active groups' motion to d_searchDir; true if any

@@ -101,6 +101,7 @@ void HipOptimizer::setRelGL2Tol(double relTol)
 {
     relGL2Tol = relTol * relTol;
     targetGRes = std::sqrt(relGL2Tol * mesh.bboxDiag2 * dtSq); // Optimizer.cpp:2941-2945
+    CN_MBC = std::sqrt(1.0e-4 * mesh.bboxDiag2 * dtSq); // Optimizer.cpp:268
 }
 
 void HipOptimizer::setTwist(int nL, const int* left, int nR, const int* right, double angVel)
@@ -234,6 +235,10 @@ double HipOptimizer::computeEnergyVal()
             if (h->friction > 0.0) E += h->frictionEnergy(mesh.d_x.p, d_xPrev.p, fricDHat);
         if (selfCollision && selfFric > 0.0) E += contact->frictionEnergy(mesh.d_x.p, d_xPrev.p, fricDHat, selfFric, d_partial, d_scalar.p + 4);
     }
+    if (rhoDBC && !tpIds.empty()) { // augmentMDBCEnergy (Optimizer.cpp:3402-3404)
+        launch_mdbc_reduce(mdbc(), mesh.d_x.p, rhoDBC, 0, d_scalar.p + 5, stream);
+        E += readScalar(d_scalar.p + 5);
+    }
     return E;
 }
 
@@ -274,6 +279,7 @@ bool HipOptimizer::nextSubproblem()
     }
     if (!updateFricDHat) return false;
     if (fricDHat > 0.0) fricDHat = std::max(0.5 * fricDHat, fricDHat0); // :1776-1781
+    initSubProblem(); // the next solveSub_IP starts with m_projectDBC = true, rho_DBC = 0 (Optimizer.cpp:1826-1828)
     closeID.clear(); // initSubProb_IP
     closeVal.clear();
     closeHS.clear();
@@ -346,6 +352,14 @@ void HipOptimizer::setTimeIntegration(int type, double beta, double gamma)
     betaNM = beta;
     gammaNM = gamma;
     computeXTilta();
+}
+
+void HipOptimizer::getDbcState(double* out4) const
+{
+    out4[0] = completedStep;
+    out4[1] = rhoDBC;
+    out4[2] = projDBC ? 1.0 : 0.0;
+    out4[3] = (double)tpIds.size();
 }
 
 void HipOptimizer::getKinematics(double* vel, double* acc, double* dxElastic)
@@ -586,6 +600,16 @@ void HipOptimizer::computeGradient(bool projectDBC)
 {
     elasticInertiaGradient(projectDBC);
     if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p);
+    penaltyGradientAdd(projectDBC);
+}
+
+// tail of Optimizer::computeGradient when the Dirichlet rows are not all projected: rows of the nodes that still are get
+// cleared (Optimizer.cpp:3512-3516; with projectDBC the element pass never wrote them), then augmentMDBCGradient (:3542-3544)
+void HipOptimizer::penaltyGradientAdd(bool projectDBC)
+{
+    if (projectDBC) return;
+    launch_clear_projected(mesh.nV, mesh.d_dbc.p, 0, d_gradient.p, stream);
+    if (rhoDBC && !tpIds.empty()) launch_mdbc_gradient(mdbc(), mesh.d_x.p, rhoDBC, d_gradient.p, stream);
 }
 
 void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
@@ -656,6 +680,8 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
                 contact->frictionHessianAdd(mesh.d_x.p, d_xPrev.p, mesh.d_dbc.p, lin, fricDHat, selfFric, projectDBC, lin.d_a.p);
         }
     }
+    if (withGradient) penaltyGradientAdd(projectDBC);
+    if (!projectDBC && rhoDBC && !tpIds.empty()) launch_mdbc_hessian(mdbc(), lin.d_ia.p, rhoDBC, lin.d_a.p, stream); // :3711-3713
 }
 
 bool HipOptimizer::checkInversion()
@@ -792,6 +818,8 @@ void HipOptimizer::beginTimestep()
     // stepAnimScript, AST_TWIST (AnimScripter.cpp:1674-1684, 2140-2215)
     if (nHandles) launch_twist_dir(nHandles, d_handleIds.p, d_handleAng.p, rotCenter[1], rotCenter[2], mesh.d_x.p, d_searchDir.p, stream);
     const bool groupMotion = dbcGroupMotion(); // AST_NULL: Dirichlet groups / scripted components (:1413-1462)
+    buildTargetPositions();
+    completedStep = 1.0;
     if (nHandles || groupMotion) {
         double stepSize = filterStepSize(d_searchDir.p, 1.0);
         if (selfCollision) // CCD of the scripted motion with slackness 0.5 (AnimScripter.cpp:2158-2171)
@@ -807,10 +835,8 @@ void HipOptimizer::beginTimestep()
                 stepSize /= 2.0;
                 stepForward(d_x0.p, stepSize);
             }
-        if (stepSize < 1.0) {
-            dbcIncomplete++;
-            throw StateError("scripted Dirichlet motion was cut short; the augmented-Lagrangian DBC path (AnimScripter.cpp:2303-2345) is a SURVEY 8f 'next' row");
-        }
+        if (stepSize < 1.0) dbcIncomplete++; // the penalty solve of newtonIter() takes the nodes the rest of the way
+        completedStep = stepSize; // AnimScripter::getCompletedStepSize
         d_searchDir.zero(stream); // initX(0), Optimizer.cpp:930-934
     }
     if (ipOn()) {
@@ -831,8 +857,77 @@ void HipOptimizer::beginTimestep()
         fricIterI = 0;
         updateFrictionLag();
     }
+    initSubProblem();
     lastEnergyVal = computeEnergyVal(); // Optimizer.cpp:1609
     k = 0;
+}
+
+void HipOptimizer::initSubProblem()
+{
+    projDBC = true;
+    rhoDBC = 0.0;
+    lastMove = completedStep;
+}
+
+// targetPos / dist2Tol of stepAnimScript (AnimScripter.cpp:2150-2157).  Every scripted node is a Dirichlet node here (twist
+// handles, Dirichlet groups, scripted components), so the keys are the Dirichlet nodes.  Per time step, a few KB.
+void HipOptimizer::buildTargetPositions()
+{
+    tpIds.clear();
+    for (int v = 0; v < mesh.nV; ++v)
+        if (mesh.dbcType[v] != 0) tpIds.push_back(v);
+    dist2Tol = 0.0;
+    if (tpIds.empty()) return;
+    const int n = (int)tpIds.size();
+    d_tpIds.uploadGrow(tpIds, stream);
+    d_tpPos.ensure(3 * (size_t)n);
+    d_tpLam.ensure(3 * (size_t)n);
+    d_tpLam.zeroN(3 * (size_t)n, stream);
+    std::vector<double> x(3 * (size_t)n), p(3 * (size_t)n);
+    launch_gather3(n, d_tpIds.p, mesh.d_x.p, d_tpPos.p, stream);
+    HIP_CHECK(hipMemcpyAsync(x.data(), d_tpPos.p, x.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    launch_gather3(n, d_tpIds.p, d_searchDir.p, d_tpPos.p, stream);
+    HIP_CHECK(hipMemcpyAsync(p.data(), d_tpPos.p, p.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    double sq = 0.0;
+    for (size_t i = 0; i < p.size(); ++i) {
+        sq += p[i] * p[i];
+        x[i] += p[i];
+    }
+    dist2Tol = sq * 1.0e-6;
+    HIP_CHECK(hipMemcpyAsync(d_tpPos.p, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+
+double HipOptimizer::computeCompletedStepSize()
+{
+    if (dist2Tol == 0.0 || tpIds.empty()) return completedStep = 1.0;
+    launch_mdbc_reduce(mdbc(), mesh.d_x.p, 0.0, 1, d_scalar.p + 5, stream);
+    const double sqNorm = readScalar(d_scalar.p + 5);
+    return completedStep = 1.0 - std::sqrt(sqNorm / (dist2Tol * 1.0e6));
+}
+
+// after postLineSearch (Optimizer.cpp:2168-2203)
+void HipOptimizer::dirichletPenaltyUpdate()
+{
+    if (projDBC) {
+        if (completedStep < 1.0 - 1.0e-3) { // setup penalty solve
+            projDBC = false;
+            rhoDBC = 1.0e6;
+        }
+        return;
+    }
+    const double completed = computeCompletedStepSize();
+    if (completed > 1.0 - 1.0e-3) projDBC = true; // penalty solve finished
+    else if (completed < lastMove && rhoDBC < 1.0e8) rhoDBC *= 2.0;
+    else {
+        launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+        launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+        if (readScalar(d_scalar.p + 3) < CN_MBC) { // safeToPull
+            if (completed < 0.99 && rhoDBC < 1.0e8) rhoDBC *= 2.0;
+            else launch_mdbc_lambda(mdbc(), mesh.d_x.p, rhoDBC, stream); // updateLambda (AnimScripter.cpp:2339-2346)
+        }
+    }
 }
 
 bool HipOptimizer::newtonIter()
@@ -841,18 +936,18 @@ bool HipOptimizer::newtonIter()
     launch_fill(d_scalar.p + 3, 1, 0.0, stream);
     launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
     const double distToOpt_PN = readScalar(d_scalar.p + 3);
-    if (k && distToOpt_PN < targetGRes) {
+    if (k && distToOpt_PN < targetGRes && completedStep > 1.0 - 1.0e-3) { // :1874-1879
         Tic t(timers[12], stream);
-        computeGradient(true); // the reference leaves the gradient of the converged state behind (:1861)
+        computeGradient(projDBC); // the reference leaves the gradient of the converged state behind (:1861)
         return true;
     }
     innerIterAmt++;
     {
         // gradient (:1861) and Hessian (:2327) come out of one fused element pass
         Tic t(timers[0], stream);
-        computePrecondMtr(true, true);
+        computePrecondMtr(projDBC, true);
     }
-    computeSearchDir(true);
+    computeSearchDir(projDBC);
     double alpha = 1.0;
     {
         Tic t(timers[13], stream);
@@ -878,6 +973,7 @@ bool HipOptimizer::newtonIter()
     lineSearch(alpha);
     lastStepSize = alpha;
     postLineSearch();
+    dirichletPenaltyUpdate();
     ++k;
     return false;
 }

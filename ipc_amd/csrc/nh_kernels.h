@@ -70,6 +70,19 @@ struct DbcMotion {
 };
 void launch_gather3(int n, const int* ids, const double* x, double* out, hipStream_t s);
 void launch_dbc_motion(int n, const int* ids, const DbcMotion& m, const double* x, double* p, hipStream_t s);
+// augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2303-2346; Optimizer.cpp:3402-3404, 3542-3544, 3711-3713)
+struct MdbcView {
+    int n; // target positions
+    const int* ids;
+    const double* pos; // 3 n
+    double* lam; // 3 n
+    const double* mass; // nV
+};
+void launch_clear_projected(int nV, const int* dbc, int projectDBC, double* g, hipStream_t s);
+void launch_mdbc_reduce(const MdbcView& m, const double* x, double rho, int mode /*0 energy, 1 |x - target|^2*/, double* out, hipStream_t s);
+void launch_mdbc_gradient(const MdbcView& m, const double* x, double rho, double* g, hipStream_t s);
+void launch_mdbc_hessian(const MdbcView& m, const int* ia, double rho, double* a, hipStream_t s);
+void launch_mdbc_lambda(const MdbcView& m, const double* x, double rho, hipStream_t s);
 // twist handles: rotate listed vertices about the x axis through c by their angle (AnimScripter.cpp:1674-1684)
 void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s);
 

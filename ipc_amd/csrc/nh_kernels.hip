@@ -432,6 +432,64 @@ __global__ void k_dbc_motion(int n, const int* __restrict__ ids, DbcMotion m, co
     for (int c = 0; c < 3; ++c) p[3 * v + c] += (m.R[3 * c] * d0 + m.R[3 * c + 1] * d1 + m.R[3 * c + 2] * d2) + m.c[c] + m.linDt[c] - x[3 * v + c];
 }
 
+// ---- augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2303-2346): nodes `ids` with target positions `pos` and
+// multipliers `lam` (3 per node)
+__global__ void k_clear_projected(int nV, const int* __restrict__ dbc, int projectDBC, double* __restrict__ g)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * nV && projected_dbc(dbc[i / 3], projectDBC)) g[i] = 0.0; // Optimizer.cpp:3512-3516
+}
+// one workgroup, fixed-order reduction: mode 0  sum -sqrt(m) lam . d + rho / 2 m |d|^2 ; mode 1  sum |d|^2   (d = x - target)
+__global__ __launch_bounds__(BLOCK) void k_mdbc_reduce(int n, const int* __restrict__ ids, const double* __restrict__ pos,
+    const double* __restrict__ lam, const double* __restrict__ mass, const double* __restrict__ x, double rho, int mode, double* __restrict__ out)
+{
+    __shared__ double sm[BLOCK / 64];
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < n; t += BLOCK) {
+        const size_t v = (size_t)ids[t];
+        double dot = 0.0, sq = 0.0;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const double d = x[3 * v + c] - pos[3 * (size_t)t + c];
+            dot += lam[3 * (size_t)t + c] * d;
+            sq += d * d;
+        }
+        acc += mode == 0 ? (rho / 2.0 * mass[v] * sq - sqrt(mass[v]) * dot) : sq;
+    }
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) out[0] = r;
+}
+__global__ void k_mdbc_gradient(int n, const int* __restrict__ ids, const double* __restrict__ pos, const double* __restrict__ lam,
+    const double* __restrict__ mass, const double* __restrict__ x, double rho, double* __restrict__ g)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int t = i / 3, c = i - 3 * t;
+    const size_t v = (size_t)ids[t];
+    double gi = g[3 * v + c];
+    gi -= sqrt(mass[v]) * lam[i];
+    gi += rho * mass[v] * (x[3 * v + c] - pos[i]);
+    g[3 * v + c] = gi;
+}
+__global__ void k_mdbc_hessian(int n, const int* __restrict__ ids, const double* __restrict__ mass, const int* __restrict__ ia, double rho,
+    double* __restrict__ a)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int t = i / 3, c = i - 3 * t;
+    const int v = ids[t];
+    a[ia[3 * v + c]] += rho * mass[v]; // the diagonal leads every upper-CSR row
+}
+__global__ void k_mdbc_lambda(int n, const int* __restrict__ ids, const double* __restrict__ pos, double* __restrict__ lam,
+    const double* __restrict__ mass, const double* __restrict__ x, double rho)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int t = i / 3, c = i - 3 * t;
+    const size_t v = (size_t)ids[t];
+    lam[i] -= rho * sqrt(mass[v]) * (x[3 * v + c] - pos[i]);
+}
+
 inline int nblk(long long n, int b = BLOCK) { return (int)((n + b - 1) / b); }
 
 } // namespace
@@ -526,6 +584,26 @@ void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, doub
     if (nH) hipLaunchKernelGGL(k_twist_dir, dim3(nblk(nH)), dim3(BLOCK), 0, s, nH, ids, ang, cy, cz, x, p);
 }
 
+void launch_clear_projected(int nV, const int* dbc, int projectDBC, double* g, hipStream_t s)
+{
+    if (nV) hipLaunchKernelGGL(k_clear_projected, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, projectDBC, g);
+}
+void launch_mdbc_reduce(const MdbcView& m, const double* x, double rho, int mode, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mdbc_reduce, dim3(1), dim3(BLOCK), 0, s, m.n, m.ids, m.pos, m.lam, m.mass, x, rho, mode, out);
+}
+void launch_mdbc_gradient(const MdbcView& m, const double* x, double rho, double* g, hipStream_t s)
+{
+    if (m.n) hipLaunchKernelGGL(k_mdbc_gradient, dim3(nblk(3LL * m.n)), dim3(BLOCK), 0, s, m.n, m.ids, m.pos, m.lam, m.mass, x, rho, g);
+}
+void launch_mdbc_hessian(const MdbcView& m, const int* ia, double rho, double* a, hipStream_t s)
+{
+    if (m.n) hipLaunchKernelGGL(k_mdbc_hessian, dim3(nblk(3LL * m.n)), dim3(BLOCK), 0, s, m.n, m.ids, m.mass, ia, rho, a);
+}
+void launch_mdbc_lambda(const MdbcView& m, const double* x, double rho, hipStream_t s)
+{
+    if (m.n) hipLaunchKernelGGL(k_mdbc_lambda, dim3(nblk(3LL * m.n)), dim3(BLOCK), 0, s, m.n, m.ids, m.pos, m.lam, m.mass, x, rho);
+}
 void launch_gather3(int n, const int* ids, const double* x, double* out, hipStream_t s)
 {
     if (n) hipLaunchKernelGGL(k_gather3, dim3(nblk(3LL * n)), dim3(BLOCK), 0, s, n, ids, x, out);

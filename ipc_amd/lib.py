@@ -528,6 +528,11 @@ class Context:
         ang = _f64(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
         self._chk(self._L.ipcgpu_opt_add_dirichlet(self.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1)))
 
+    def dbc_state(self):
+        out = np.zeros(4)
+        self._chk(self._L.ipcgpu_opt_get_dbc_state(self.h, _dp(out)))
+        return dict(completed=out[0], rho=out[1], projectDBC=bool(out[2]), n_targets=int(out[3]))
+
     def kinematics(self):
         vel, acc, dx = np.zeros(3 * self.nV), np.zeros(3 * self.nV), np.zeros(3 * self.nV)
         self._chk(self._L.ipcgpu_opt_get_kinematics(self.h, _dp(vel), _dp(acc), _dp(dx)))

@@ -440,6 +440,12 @@ def opt_add_dirichlet(opt: "Optimizer", ids, lin_vel=(0, 0, 0), ang_vel_deg=(0, 
     lib().orc_opt_add_dirichlet(opt.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1))
 
 
+def opt_dbc_state(opt: "Optimizer"):
+    out = np.zeros(4)
+    lib().orc_opt_get_dbc_state(opt.h, _dp(out))
+    return dict(completed=out[0], rho=out[1], projectDBC=bool(out[2]), n_targets=int(out[3]))
+
+
 def opt_kinematics(opt: "Optimizer"):
     n3 = 3 * opt.mesh.nV
     vel, acc, dx = np.zeros(n3), np.zeros(n3), np.zeros(n3)

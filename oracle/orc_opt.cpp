@@ -38,6 +38,11 @@ struct orc_opt {
     std::vector<DBCGroup> dbcGroups;
     std::vector<int> baseDbcType; // types that do not come from a group (set_dbc, twist handles)
     double stepStartTime = 0, stepEndTime = 0; // AnimScripter.cpp:1406-1407
+    // augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2150-2157, 2280-2350; Optimizer.cpp:1826-1828, 2168-2203)
+    std::vector<int> tpIds; // targetPos keys, ascending (std::map order)
+    std::vector<double> tpPos, tpLam; // 3 per key
+    double dist2Tol = 0, completedStep = 1.0, lastMove = 1.0, rhoDBC = 0.0, CN_MBC = 0.0;
+    bool projDBC = true; // m_projectDBC
     double rotCenter[3];
     orc_chol* chol = nullptr;
     int innerIterAmt = 0, globalIterNum = 0, k = 0;
@@ -128,6 +133,19 @@ double computeEnergyVal(orc_opt* o)
         if (o->selfCollision && o->selfFric > 0.0 && !o->lag.set.empty())
             E += frictionEnergy(m, o->V_prev.data(), o->lag, o->fricDHat, o->selfFric);
     }
+    if (o->rhoDBC) { // augmentMDBCEnergy (AnimScripter.cpp:2303-2311; Optimizer.cpp:3402-3404)
+        for (size_t t = 0; t < o->tpIds.size(); ++t) {
+            const int v = o->tpIds[t];
+            double dot = 0, sq = 0;
+            for (int c = 0; c < 3; ++c) {
+                const double d = m.V[v + m.nV * c] - o->tpPos[3 * t + c];
+                dot += o->tpLam[3 * t + c] * d;
+                sq += d * d;
+            }
+            E -= std::sqrt(m.mass[v]) * dot;
+            E += o->rhoDBC / 2.0 * m.mass[v] * sq;
+        }
+    }
     return E;
 }
 
@@ -159,6 +177,14 @@ void computeGradient(orc_opt* o, bool projectDBC)
     for (int v = 0; v < m.nV; ++v)
         if (m.isDBC(v) && m.isProjectDBC(v, projectDBC))
             for (int c = 0; c < 3; ++c) o->gradient[3 * v + c] = 0; // :3512-3516
+    if (!projectDBC && o->rhoDBC) // augmentMDBCGradient (AnimScripter.cpp:2313-2321; Optimizer.cpp:3542-3544)
+        for (size_t t = 0; t < o->tpIds.size(); ++t) {
+            const int v = o->tpIds[t];
+            for (int c = 0; c < 3; ++c) {
+                o->gradient[3 * v + c] -= std::sqrt(m.mass[v]) * o->tpLam[3 * t + c];
+                o->gradient[3 * v + c] += o->rhoDBC * m.mass[v] * (m.V[v + m.nV * c] - o->tpPos[3 * t + c]);
+            }
+        }
 }
 
 void rebuildPattern(orc_opt* o)
@@ -205,6 +231,9 @@ void computePrecondMtr(orc_opt* o, bool projectDBC)
         if (o->selfCollision && o->selfFric > 0.0 && !o->lag.set.empty())
             frictionHessian(m, o->V_prev.data(), o->lag, o->fricDHat, o->selfFric, projectDBC, o->a.data());
     }
+    if (!projectDBC && o->rhoDBC) // augmentMDBCHessian (AnimScripter.cpp:2323-2337; Optimizer.cpp:3711-3713)
+        for (int v : o->tpIds)
+            for (int c = 0; c < 3; ++c) o->a[m.ia[3 * v + c]] += o->rhoDBC * m.mass[v]; // the diagonal leads every upper-CSR row
 }
 
 void stepForward(orc_opt* o, const std::vector<double>& V0, double alpha)
@@ -429,6 +458,7 @@ orc_opt* orc_opt_create(orc_mesh* mh, double dt, int withGravity, int nthreads)
     o->dt = dt;
     o->dtSq = dt * dt;
     if (withGravity) o->gravity[1] = -9.80665; // Optimizer.cpp:112-115
+    o->CN_MBC = std::sqrt(1.0e-4 * m.bboxDiag2 * o->dtSq); // Optimizer.cpp:268
     o->nthreads = nthreads > 0 ? nthreads : omp_get_max_threads();
     omp_set_num_threads(o->nthreads);
     o->velocity.assign(3 * m.nV, 0.0);
@@ -569,6 +599,28 @@ void orc_opt_precompute(orc_opt* o)
     o->lastEnergyVal = computeEnergyVal(o);
 }
 
+// head of solveSub_IP (Optimizer.cpp:1826-1828)
+static void initSubProblem(orc_opt* o)
+{
+    o->projDBC = true;
+    o->rhoDBC = 0.0;
+    o->lastMove = o->completedStep;
+}
+
+// AnimScripter::computeCompletedStepSize (AnimScripter.cpp:2286-2300)
+static double computeCompletedStepSize(orc_opt* o)
+{
+    const Mesh& m = *o->m;
+    if (o->dist2Tol == 0.0) return o->completedStep = 1.0;
+    double sqNorm = 0.0;
+    for (size_t t = 0; t < o->tpIds.size(); ++t)
+        for (int c = 0; c < 3; ++c) {
+            const double d = m.V[o->tpIds[t] + m.nV * c] - o->tpPos[3 * t + c];
+            sqNorm += d * d;
+        }
+    return o->completedStep = 1.0 - std::sqrt(sqNorm / (o->dist2Tol * 1.0e6));
+}
+
 void orc_opt_begin_timestep(orc_opt* o)
 {
     Mesh& m = *o->m;
@@ -592,6 +644,21 @@ void orc_opt_begin_timestep(orc_opt* o)
             dbcGroupMotion(o, g);
             scripted = true;
         }
+    // targetPos / dist2Tol (AnimScripter.cpp:2150-2157)
+    o->tpIds.clear();
+    o->tpPos.clear();
+    double sq = 0;
+    for (int v = 0; v < m.nV; ++v) {
+        const double* p = &o->searchDir[3 * v];
+        sq += p[0] * p[0] + p[1] * p[1] + p[2] * p[2];
+        if (m.isDBC(v) || p[0] != 0 || p[1] != 0 || p[2] != 0) {
+            o->tpIds.push_back(v);
+            for (int c = 0; c < 3; ++c) o->tpPos.push_back(m.V[v + m.nV * c] + p[c]);
+        }
+    }
+    o->tpLam.assign(o->tpPos.size(), 0.0);
+    o->dist2Tol = sq * 1.0e-6;
+    o->completedStep = 1.0;
     if (scripted) {
         double stepSize = filterStepSize(m, o->searchDir.data(), 1.0);
         if (o->selfCollision) { // :2158-2171: CCD of the scripted motion with slackness 0.5
@@ -610,10 +677,8 @@ void orc_opt_begin_timestep(orc_opt* o)
                 stepSize /= 2.0;
                 stepForward(o, V0, stepSize);
             }
-        if (stepSize < 1.0) {
-            o->dbcIncomplete++;
-            std::fprintf(stderr, "[oracle] scripted DBC motion only completed %g (penalty path not restated)\n", stepSize);
-        }
+        if (stepSize < 1.0) o->dbcIncomplete++;
+        o->completedStep = stepSize; // AnimScripter::getCompletedStepSize
     }
     // fullyImplicit_IP head (1518-1613): initX(0) -> searchDir = 0; dHat; constraint sets; kappa; initial energy
     std::fill(o->searchDir.begin(), o->searchDir.end(), 0.0);
@@ -634,6 +699,7 @@ void orc_opt_begin_timestep(orc_opt* o)
         o->fricIterI = 0;
         updateFrictionLag(o);
     }
+    initSubProblem(o);
     if (o->patternDirty) computePrecondMtr(o, true);
     o->lastEnergyVal = computeEnergyVal(o);
     o->k = 0;
@@ -644,15 +710,15 @@ int orc_opt_newton_iter(orc_opt* o)
     Mesh& m = *o->m;
     {
         Tic t(o->timers[12]);
-        computeGradient(o, true);
+        computeGradient(o, o->projDBC);
     }
     // convergence test (1869-1879): uses the search direction of the previous pass
     double distToOpt_PN = 0;
     for (double v : o->searchDir) distToOpt_PN = std::max(distToOpt_PN, std::fabs(v));
-    if (o->k && distToOpt_PN < o->targetGRes) return 1;
+    if (o->k && distToOpt_PN < o->targetGRes && o->completedStep > 1.0 - 1.0e-3) return 1;
     o->innerIterAmt++;
     // computeSearchDir (2324-2355)
-    computePrecondMtr(o, true);
+    computePrecondMtr(o, o->projDBC);
     int ok;
     {
         Tic t(o->timers[3]);
@@ -698,6 +764,29 @@ int orc_opt_newton_iter(orc_opt* o)
     lineSearch(o, alpha);
     o->lastStepSize = alpha;
     postLineSearch(o);
+    // Dirichlet nodes that could not reach their scripted targets: augmented-Lagrangian pull (Optimizer.cpp:2168-2203)
+    if (o->projDBC) {
+        if (o->completedStep < 1.0 - 1.0e-3) {
+            o->projDBC = false;
+            o->rhoDBC = 1.0e6;
+        }
+    }
+    else {
+        const double completed = computeCompletedStepSize(o);
+        if (completed > 1.0 - 1.0e-3) o->projDBC = true;
+        else if (completed < o->lastMove && o->rhoDBC < 1.0e8) o->rhoDBC *= 2.0;
+        else {
+            double pInf = 0;
+            for (double v : o->searchDir) pInf = std::max(pInf, std::fabs(v));
+            if (pInf < o->CN_MBC) { // safeToPull
+                if (completed < 0.99 && o->rhoDBC < 1.0e8) o->rhoDBC *= 2.0;
+                else // updateLambda (AnimScripter.cpp:2339-2346)
+                    for (size_t t = 0; t < o->tpIds.size(); ++t)
+                        for (int c = 0; c < 3; ++c)
+                            o->tpLam[3 * t + c] -= o->rhoDBC * std::sqrt(m.mass[o->tpIds[t]]) * (m.V[o->tpIds[t] + m.nV * c] - o->tpPos[3 * t + c]);
+            }
+        }
+    }
     o->k++;
     return 0;
 }
@@ -712,6 +801,14 @@ void orc_opt_set_time_integration(orc_opt* o, int type, double beta, double gamm
     computeXTilta(o);
 }
 
+// {completed step size of the scripted motion, rho_DBC, m_projectDBC, number of target positions}
+void orc_opt_get_dbc_state(const orc_opt* o, double* out4)
+{
+    out4[0] = o->completedStep;
+    out4[1] = o->rhoDBC;
+    out4[2] = o->projDBC ? 1.0 : 0.0;
+    out4[3] = (double)o->tpIds.size();
+}
 void orc_opt_get_kinematics(const orc_opt* o, double* vel, double* acc, double* dx)
 {
     const size_t n3 = 3 * (size_t)o->m->nV;
@@ -797,6 +894,7 @@ int orc_opt_next_subproblem(orc_opt* o)
     o->closeHS.clear();
     o->closeHSVal.clear();
     o->k = 0;
+    initSubProblem(o); // the next solveSub_IP starts with m_projectDBC = true, rho_DBC = 0 (Optimizer.cpp:1826-1828)
     return 1;
 }
 

@@ -179,3 +179,95 @@ def test_dirichlet_groups_track_the_oracle(orc, gpu_lib):
     assert np.abs(Vn[left] - Vs[left]).max() < 1e-14  # ZERO type: (x - c) + c - x, round-off only (as in the reference)
     assert np.abs(Vn[right] - Vs[right]).max() > 5e-3
     c.close()
+
+
+# ------------------------------------------------------------------------------------------------ AL Dirichlet fallback
+def _press_scene():
+    """A kinematic block (every node in a `DBC` group moving down 1 m/s) 2 mm above an elastic slab with self-contact on: CCD
+    cuts the scripted motion to a few percent, the augmented-Lagrangian penalty has to take the block the rest of the way."""
+    Va, Fa = scene.make_box(3, 1, 3, size=(1.0, 0.3, 1.0), origin=(0, 0, 0))
+    Vb, Fb = scene.make_box(1, 1, 1, size=(0.3, 0.3, 0.3), origin=(0.33, 0.3 + 0.002, 0.36))
+    V = np.vstack([Va, Vb])
+    F = np.vstack([Fa, Fb + Va.shape[0]]).astype(np.int32)
+    Vs = scene.jitter(V, F, rel=3e-3)
+    Vs[Va.shape[0]:] = V[Va.shape[0]:]
+    ids = np.arange(Va.shape[0], V.shape[0], dtype=np.int32)
+    bottom = np.nonzero(V[:Va.shape[0], 1] < 1e-9)[0].astype(np.int32)
+    return V, F, Vs, scene.surface_tris(F), ids, bottom
+
+
+def test_augmented_lagrangian_dirichlet_fallback_in_the_oracle(orc):
+    V, F, Vs, SF, ids, bottom = _press_scene()
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.01, gravity=False, nthreads=4)
+    orc.opt_enable_self_collision(o, 1e-3)
+    orc.opt_add_dirichlet(o, ids, lin_vel=(0.0, -1.0, 0.0))
+    orc.opt_add_dirichlet(o, bottom)
+    o.precompute()
+    for step in range(2):
+        o.begin_timestep()
+        d0 = orc.opt_dbc_state(o)
+        assert d0["completed"] < 0.5 and d0["projectDBC"] and d0["rho"] == 0 and d0["n_targets"] == len(ids) + len(bottom)
+        released = False
+        for it in range(100):
+            if o.newton_iter():
+                break
+            d = orc.opt_dbc_state(o)
+            released |= (not d["projectDBC"]) and d["rho"] >= 1e6
+        else:
+            pytest.fail("no convergence")
+        assert released and orc.opt_dbc_state(o)["completed"] > 1 - 1e-3
+        o.end_timestep()
+        assert np.abs(o.state()["V"][ids] - (V[ids] + [0, -0.01 * (step + 1), 0])).max() < 1e-5  # the scripted targets
+    nA = len(V) - len(ids)
+    under = np.nonzero((V[:nA, 1] > 0.3 - 1e-9) & (np.abs(V[:nA, 0] - 0.48) < 0.16) & (np.abs(V[:nA, 2] - 0.51) < 0.16))[0]
+    assert len(under) and (o.state()["V"][under, 1] < V[ids, 1].min() - 0.02).all()  # the slab has been pressed down, no penetration
+
+
+@pytest.mark.gpu
+def test_augmented_lagrangian_dirichlet_fallback_tracks_the_oracle(orc, gpu_lib):
+    V, F, Vs, SF, ids, bottom = _press_scene()
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.01, gravity=False, nthreads=4)
+    orc.opt_enable_self_collision(o, 1e-3)
+    orc.opt_add_dirichlet(o, ids, lin_vel=(0.0, -1.0, 0.0))
+    orc.opt_add_dirichlet(o, bottom)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.01, False)
+    c.set_surface(SF)
+    c.enable_self_collision(1e-3)
+    c.add_dirichlet(ids, lin_vel=(0.0, -1.0, 0.0))
+    c.add_dirichlet(bottom)
+    o.precompute()
+    c.precompute()
+    released = 0
+    for step in range(3):
+        o.begin_timestep()
+        c.begin_timestep()
+        do, dg = orc.opt_dbc_state(o), c.dbc_state()
+        assert dg["n_targets"] == do["n_targets"] and abs(dg["completed"] - do["completed"]) < 1e-9
+        for it in range(100):
+            co, cg = o.newton_iter(), c.newton_iter()
+            assert bool(co) == cg, (step, it)
+            if co:
+                break
+            so, sg = o.state(), c.state()
+            do, dg = orc.opt_dbc_state(o), c.dbc_state()
+            assert dg["projectDBC"] == do["projectDBC"] and dg["rho"] == do["rho"], (step, it)
+            assert abs(dg["completed"] - do["completed"]) < 1e-7, (step, it)
+            assert abs(sg["E"] - so["E"]) <= 1e-8 * max(abs(so["E"]), 1e-6), (step, it)
+            assert relerr(sg["V"], so["V"]) < 1e-8, (step, it)
+            released += not dg["projectDBC"]
+        else:
+            pytest.fail("no convergence")
+        o.end_timestep()
+        c.end_timestep()
+    assert released >= 3
+    assert np.abs(c.state()["V"][ids] - (V[ids] + [0, -0.03, 0])).max() < 1e-5
+    c.close()
