@@ -246,6 +246,29 @@ __device__ inline void scatter_blocks(const CsrView& m, double* a, const double*
     }
 }
 
+// does the CSR pattern hold a block for every node pair the barrier Hessian of the current sets will write?  (flag |= 1 if not)
+__global__ void k_pattern_check(ContactView cv, CsrView m, int* __restrict__ flag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int node[4], n = 0;
+    if (i < cv.nA) {
+        const Stencil s = decode(cv.active + 4 * (size_t)i);
+        n = s.n;
+        for (int k = 0; k < 4; ++k) node[k] = s.node[k];
+    }
+    else if (i < cv.nA + cv.nP) {
+        paraNodes(cv, i - cv.nA, node);
+        n = 4;
+    }
+    bool miss = false;
+    for (int a = 0; a < n; ++a)
+        for (int b = a + 1; b < n; ++b) {
+            const int lo = min(node[a], node[b]), hi = max(node[a], node[b]);
+            if (lo != hi && find_block(m, lo, hi) < 0) miss = true;
+        }
+    if (miss) atomicOr(flag, 1);
+}
+
 // a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201)
 // HESS_T stencils per workgroup: the two 12x12 matrices the Jacobi sweeps iterate on sit in LDS (2 x 144 x 8 B per stencil)
 constexpr int HESS_T = 32;
@@ -1235,6 +1258,20 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     if (err[0]) throw StateError("barrier Hessian touches a node pair outside the CSR pattern: call set_pattern with the contact connectivity first");
 }
 
+bool HipContact::patternCovers(const HipLinSysSolver& lin)
+{
+    const int n = (int)(active.size() + para.size());
+    if (!n) return true;
+    ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, nullptr, d_xRest.p };
+    CsrView m{ lin.d_ia.p, lin.d_ja.p };
+    counters_.alloc(2);
+    counters_.zero(stream);
+    hipLaunchKernelGGL(k_pattern_check, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, m, counters_.p);
+    int miss = 0;
+    counters_.download(&miss, 1, stream);
+    return miss == 0;
+}
+
 // ---- lagged friction: host side -------------------------------------------------------------------------------------
 void HipContact::frictionLagClear() { fricSet.clear(); }
 
@@ -1317,6 +1354,29 @@ void HipContact::frictionConnectivity(std::vector<std::pair<int, int>>& pairs) c
             link(v0, c[1]);
             if (c[2] >= 0) link(v0, c[2]);
             if (c[2] >= 0 && c[3] >= 0) link(v0, c[3]);
+        }
+    }
+}
+
+// Every node pair a candidate primitive pair can ever couple, whatever its closest-feature type: vertex x the three triangle
+// nodes, the 2 x 2 end points of an edge pair.  A superset of connectivity() for the same set; used for the look-ahead pattern
+// (a stencil that slides from point-point to point-triangle needs no new matrix blocks then).
+void HipContact::candidateConnectivity(std::vector<std::pair<int, int>>& pairs) const
+{
+    auto link = [&](int a, int b) {
+        if (a != b) pairs.push_back({ std::min(a, b), std::max(a, b) });
+    };
+    for (const auto& c : csPTEE) {
+        if (c[0] < 0) {
+            const int v = SVI[-c[0] - 1];
+            for (int k = 0; k < 3; ++k) link(v, SF[c[1] + (size_t)nSF * k]);
+        }
+        else {
+            const auto &ea = SFEdges[c[0]], &eb = SFEdges[c[1]];
+            link(ea.first, eb.first);
+            link(ea.first, eb.second);
+            link(ea.second, eb.first);
+            link(ea.second, eb.second);
         }
     }
 }

@@ -322,6 +322,7 @@ void HipOptimizer::enableSelfCollision(HipContact* c, double eps)
     if (!c || !c->surfaceSet) throw StateError("opt_enable_self_collision before set_surface");
     contact = c;
     selfCollision = true;
+    if (const char* e = std::getenv("IPCGPU_PATTERN_PAD")) patternPad = std::atof(e); // < 1: exact pattern, 1: full stencils of the current candidates, > 1: also look ahead in distance
     dHatEps = eps;
     dHat = eps * eps * mesh.bboxDiag2;
     dTol = 1.0e-18 * mesh.bboxDiag2; // dTolRel = 1e-9 (Optimizer.cpp:102-109)
@@ -615,7 +616,11 @@ void HipOptimizer::penaltyGradientAdd(bool projectDBC)
 void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
 {
     if (lin.rowBase.empty()) throw StateError("computePrecondMtr needs a pattern built by set_pattern");
-    if (selfCollision) {
+    // The common case by far: the pattern already holds every block the current sets need (it only grows, and it is built with
+    // look-ahead).  One small kernel answers that; the host-side connectivity (hundreds of thousands of pairs to build, filter
+    // and sort) runs only when a pair is missing.  Lagged friction keeps its own set: always the host path there.
+    const bool frictionPairs = fricDHat > 0.0 && selfFric > 0.0;
+    if (selfCollision && (frictionPairs || !contact->patternCovers(lin))) {
         // the pattern follows the contact connectivity (augmentConnectivity into vNeighbor_IP, Optimizer.cpp:3560-3612);
         // only pairs that are not mesh edges change it
         std::vector<std::pair<int, int>> extra, fresh;
@@ -633,9 +638,27 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         // needed only when a pair shows up that no earlier iteration had.  Same matrix, fewer host-side analyses; the
         // union is dropped again once it has grown far beyond the live set.
         if (!std::includes(curExtra.begin(), curExtra.end(), fresh.begin(), fresh.end())) {
+            // Look-ahead: contact spreads, so the next iterations bring pairs that are a little farther apart now.  The new
+            // pattern is built from the constraint set at a larger distance (patternPad * dHat, squared distances): its
+            // blocks hold explicit zeros until the pairs become active, and pattern + symbolic analysis (tens of ms on the
+            // host) are needed far less often.  Costs two extra constraint-set builds per analysis.
+            std::vector<std::pair<int, int>> padded = fresh;
+            if (patternPad >= 1.0) {
+                std::vector<std::pair<int, int>> ahead;
+                if (patternPad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, patternPad * dHat);
+                contact->candidateConnectivity(ahead); // full stencils: closest-feature changes need no new blocks
+                if (patternPad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, dHat); // back to the real sets
+                for (const auto& e : ahead) {
+                    const int* b = mesh.nb.data() + mesh.nbPtr[e.first];
+                    const int* en = mesh.nb.data() + mesh.nbPtr[e.first + 1];
+                    if (!std::binary_search(b, en, e.second)) padded.push_back(e);
+                }
+                std::sort(padded.begin(), padded.end());
+                padded.erase(std::unique(padded.begin(), padded.end()), padded.end());
+            }
             std::vector<std::pair<int, int>> merged;
-            std::set_union(curExtra.begin(), curExtra.end(), fresh.begin(), fresh.end(), std::back_inserter(merged));
-            if (merged.size() > 3 * fresh.size() + 4096) merged = fresh;
+            std::set_union(curExtra.begin(), curExtra.end(), padded.begin(), padded.end(), std::back_inserter(merged));
+            if (merged.size() > 3 * padded.size() + 4096) merged = padded;
             curExtra.swap(merged);
             nPatternChanges++;
             std::vector<int> flat;

@@ -2,7 +2,9 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 namespace ipcgpu {
 
@@ -13,28 +15,46 @@ struct Graph {
     std::vector<int> ptr, adj;
 };
 
+// Patterns built by LinSysSolver::set_pattern are block structured: the three scalar rows of a node list the same neighbour
+// blocks (row 3u + d is row 3u minus its first d entries).  Then row 3u alone gives the node graph, already sorted: the
+// neighbours below u arrive in ascending order from the earlier rows, the ones above u from its own row.
+bool block_structured(int n, const int* ia, const int* ja)
+{
+    for (int r = 0; r < n; r += 3) {
+        const int L = ia[r + 1] - ia[r];
+        if (L % 3 != 0 || ia[r + 2] - ia[r + 1] != L - 1 || ia[r + 3] - ia[r + 2] != L - 2) return false;
+        for (int k = ia[r]; k < ia[r + 1]; k += 3)
+            if (ja[k] % 3 != 0 || ja[k + 1] != ja[k] + 1 || ja[k + 2] != ja[k] + 2) return false;
+    }
+    return true;
+}
+
 Graph node_graph(int n, const int* ia, const int* ja)
 {
     Graph g;
     g.nn = n / 3;
-    std::vector<int> deg(g.nn, 0);
-    // entries come in 3x3 blocks; count every (u,w) block once per scalar entry and dedupe below
+    if (block_structured(n, ia, ja)) {
+        g.ptr.assign(g.nn + 1, 0);
+        for (int u = 0; u < g.nn; ++u)
+            for (int k = ia[3 * u] + 3; k < ia[3 * u + 1]; k += 3) { // first block = the diagonal
+                g.ptr[u + 1]++;
+                g.ptr[ja[k] / 3 + 1]++;
+            }
+        for (int u = 0; u < g.nn; ++u) g.ptr[u + 1] += g.ptr[u];
+        g.adj.resize(g.ptr[g.nn]);
+        std::vector<int> pos(g.ptr.begin(), g.ptr.end() - 1);
+        for (int u = 0; u < g.nn; ++u)
+            for (int k = ia[3 * u] + 3; k < ia[3 * u + 1]; k += 3) {
+                const int w = ja[k] / 3;
+                g.adj[pos[u]++] = w;
+                g.adj[pos[w]++] = u;
+            }
+        return g;
+    }
+    // general scalar CSR (set_pattern_csr): every (u, w) block that holds at least one entry
     std::vector<std::pair<int, int>> edges;
     edges.reserve((size_t)ia[n] / 4);
-    for (int r = 0; r < n; r += 3) { // the first row of a block row lists every neighbour block
-        int u = r / 3, last = -1;
-        for (int k = ia[r]; k < ia[r + 1]; ++k) {
-            int w = ja[k] / 3;
-            if (w != u && w != last) {
-                edges.emplace_back(u, w);
-                last = w;
-            }
-        }
-    }
-    // rows 3u+1, 3u+2 carry the same neighbour blocks for patterns built by set_pattern; for a general CSR
-    // handed in through set_pattern_csr scan them too
     for (int r = 0; r < n; ++r) {
-        if (r % 3 == 0) continue;
         int u = r / 3, last = -1;
         for (int k = ia[r]; k < ia[r + 1]; ++k) {
             int w = ja[k] / 3;
@@ -140,29 +160,48 @@ private:
         const int t = ++tag_;
         for (int v : S) mark_[v] = t;
         compute_keys(S, t);
-        // median cut on the key; ties (same BFS level / same coordinate plane) stay on one side
+        // median cut on the key; ties (same BFS level / same coordinate plane) stay on one side.  left = { key < kcut }.
+        // The result depends on S only as a set, so the geometric case avoids the full sort: median by selection (O(n)), one
+        // counting pass for the tie range, one classification pass.  (BFS keys depend on the traversal start, i.e. on the
+        // order of S: that case keeps the sorted order.)
         std::vector<int> sorted = S;
-        std::sort(sorted.begin(), sorted.end(), [&](int a, int b) { return key_[a] < key_[b] || (key_[a] == key_[b] && a < b); });
+        size_t lo, hi;
+        double kmid;
         const size_t half = sorted.size() / 2;
-        const double kmid = key_[sorted[half]];
-        size_t lo = half, hi = half;
-        while (lo > 0 && key_[sorted[lo - 1]] == kmid) --lo;
-        while (hi < sorted.size() && key_[sorted[hi]] == kmid) ++hi;
-        size_t cut = (half - lo <= hi - half && lo > 0) ? lo : hi; // left = sorted[0..cut)
+        if (xyz_) {
+            std::vector<double> ks(S.size());
+            for (size_t i = 0; i < S.size(); ++i) ks[i] = key_[S[i]];
+            std::nth_element(ks.begin(), ks.begin() + half, ks.end());
+            kmid = ks[half];
+            lo = hi = 0;
+            for (int v : S) {
+                lo += key_[v] < kmid;
+                hi += key_[v] <= kmid;
+            }
+        }
+        else {
+            std::sort(sorted.begin(), sorted.end(), [&](int a, int b) { return key_[a] < key_[b] || (key_[a] == key_[b] && a < b); });
+            kmid = key_[sorted[half]];
+            lo = hi = half;
+            while (lo > 0 && key_[sorted[lo - 1]] == kmid) --lo;
+            while (hi < sorted.size() && key_[sorted[hi]] == kmid) ++hi;
+        }
+        const bool cutBelow = (half - lo <= hi - half && lo > 0); // left = keys < kmid, else keys <= kmid
+        const size_t cut = cutBelow ? lo : hi;
         if (cut == 0 || cut >= sorted.size()) { // cannot be split on this key
             groups_.push_back(S);
             return;
         }
-        const double kcut = key_[sorted[cut]]; // left: key < kcut
+        auto isLeftOf = [&](int v) { return cutBelow ? key_[v] < kmid : key_[v] <= kmid; };
         // vertex separator: the smaller of the two one-sided boundaries
         std::vector<int> bl, br;
         for (size_t i = 0; i < sorted.size(); ++i) {
             int v = sorted[i];
-            bool isLeft = i < cut;
+            const bool isLeft = isLeftOf(v);
             bool touches = false;
             for (int k = g_.ptr[v]; k < g_.ptr[v + 1] && !touches; ++k) {
                 int w = g_.adj[k];
-                if (mark_[w] == t && ((key_[w] < kcut) != isLeft)) touches = true;
+                if (mark_[w] == t && (isLeftOf(w) != isLeft)) touches = true;
             }
             if (touches) (isLeft ? bl : br).push_back(v);
         }
@@ -175,7 +214,7 @@ private:
         for (size_t i = 0; i < sorted.size(); ++i) {
             int v = sorted[i];
             if (mark_[v] == sepTag) continue;
-            (i < cut ? left : right).push_back(v);
+            (isLeftOf(v) ? left : right).push_back(v);
         }
         std::vector<int> sepCopy = sep;
         split(left);
@@ -189,7 +228,11 @@ private:
 void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int leafSize, MfSymbolic& o)
 {
     if (n % 3 != 0) throw std::invalid_argument("mf_analyze: row count must be a multiple of 3 (3x3 node blocks)");
-    o = MfSymbolic();
+    // every vector below is re-assigned in full: keep the capacity of a previous analysis (tens of MB that would otherwise be
+    // unmapped and page-faulted back in on every pattern change)
+    o.nnzL = 0;
+    o.flops = 0;
+    o.maxN = 0;
     o.n = n;
     Graph g = node_graph(n, ia, ja);
     o.nn = g.nn;
@@ -217,6 +260,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     // symbolic factorisation on the front level: struct(s) = (adj(s) U struct(children)) \ {nodes < end(s)}
     std::vector<std::vector<int>> st(o.ns), kids(o.ns);
     o.parent.assign(o.ns, -1);
+    std::vector<int> stamp(o.nn, -1); // the children's structures overlap almost completely: dedupe before sorting
     for (int s = 0; s < o.ns; ++s) {
         const int end = o.firstNode[s + 1];
         std::vector<int>& r = st[s];
@@ -224,14 +268,19 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
             const int ov = o.oldOf[v];
             for (int k = g.ptr[ov]; k < g.ptr[ov + 1]; ++k) {
                 const int w = o.newOf[g.adj[k]];
-                if (w >= end) r.push_back(w);
+                if (w >= end && stamp[w] != s) {
+                    stamp[w] = s;
+                    r.push_back(w);
+                }
             }
         }
         for (int c : kids[s])
             for (int w : st[c])
-                if (w >= end) r.push_back(w);
+                if (w >= end && stamp[w] != s) {
+                    stamp[w] = s;
+                    r.push_back(w);
+                }
         std::sort(r.begin(), r.end());
-        r.erase(std::unique(r.begin(), r.end()), r.end());
         if (!r.empty()) {
             o.parent[s] = frontOfNode[r[0]];
             kids[o.parent[s]].push_back(s);
@@ -304,25 +353,78 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     }
     // user-matrix entry -> front slot (lower triangle of the permuted matrix)
     o.aDst.resize(ia[n]);
-    for (int r = 0; r < n; ++r)
-        for (int k = ia[r]; k < ia[r + 1]; ++k) {
-            const int c = ja[k];
-            const int pr = 3 * o.newOf[r / 3] + r % 3, pc = 3 * o.newOf[c / 3] + c % 3;
-            const int i = std::max(pr, pc), j = std::min(pr, pc);
-            const int s = frontOfNode[j / 3];
-            const int f = o.firstNode[s], l = o.firstNode[s + 1];
-            const int64_t N = o.N(s);
-            int64_t lr;
-            if (i / 3 < l) lr = i - 3 * f;
-            else {
-                const int* b = o.idx.data() + o.idxPtr[s] + (l - f);
-                const int* e = o.idx.data() + o.idxPtr[s + 1];
-                const int* it = std::lower_bound(b, e, i / 3);
-                if (it == e || *it != i / 3) throw std::logic_error("mf_analyze: matrix entry outside the symbolic structure");
-                lr = 3 * (int64_t)((l - f) + (it - b)) + i % 3;
-            }
-            o.aDst[k] = o.frontOff[s] + lr + N * (int64_t)(j - 3 * f);
+    auto slot = [&](int r, int c) -> int64_t {
+        const int pr = 3 * o.newOf[r / 3] + r % 3, pc = 3 * o.newOf[c / 3] + c % 3;
+        const int i = std::max(pr, pc), j = std::min(pr, pc);
+        const int s = frontOfNode[j / 3];
+        const int f = o.firstNode[s], l = o.firstNode[s + 1];
+        const int64_t N = o.N(s);
+        int64_t lr;
+        if (i / 3 < l) lr = i - 3 * f;
+        else {
+            const int* b = o.idx.data() + o.idxPtr[s] + (l - f);
+            const int* e = o.idx.data() + o.idxPtr[s + 1];
+            const int* it = std::lower_bound(b, e, i / 3);
+            if (it == e || *it != i / 3) throw std::logic_error("mf_analyze: matrix entry outside the symbolic structure");
+            lr = 3 * (int64_t)((l - f) + (it - b)) + i % 3;
         }
+        return o.frontOff[s] + lr + N * (int64_t)(j - 3 * f);
+    };
+    if (block_structured(n, ia, ja)) {
+        // one lookup per 3 x 3 node block instead of one per scalar entry: inside a block the destination moves by 1 per
+        // row of the front and by N per column.  Node ranges are independent: a few host threads.
+        auto fillRange = [&](int u0, int u1) {
+        for (int u = u0; u < u1; ++u) {
+            const int base = ia[3 * u], L = ia[3 * u + 1] - base;
+            const int row1 = ia[3 * u + 1], row2 = ia[3 * u + 2];
+            // diagonal block: upper entries (a, b), a <= b, of node u -> lower entries (b, a) of its front
+            {
+                const int pu = o.newOf[u], s = frontOfNode[pu];
+                const int64_t N = o.N(s), d0 = o.frontOff[s] + 3 * (int64_t)(pu - o.firstNode[s]) * (N + 1);
+                o.aDst[base] = d0;
+                o.aDst[base + 1] = d0 + 1;
+                o.aDst[base + 2] = d0 + 2;
+                o.aDst[row1] = d0 + N + 1;
+                o.aDst[row1 + 1] = d0 + N + 2;
+                o.aDst[row2] = d0 + 2 * N + 2;
+            }
+            for (int q = 3; q < L; q += 3) {
+                const int w = ja[base + q] / 3;
+                const int pu = o.newOf[u], pw = o.newOf[w];
+                const int64_t d0 = slot(3 * u, 3 * w); // entry (row 0 of u, column 0 of w)
+                const int s = frontOfNode[std::min(pu, pw)];
+                const int64_t N = o.N(s);
+                // scalar (a of u, b of w): if u is the row node of the front (pu > pw) the row index follows a, the column b
+                const int64_t da = pu > pw ? 1 : N, db = pu > pw ? N : 1;
+                for (int b = 0; b < 3; ++b) {
+                    o.aDst[base + q + b] = d0 + db * b;
+                    o.aDst[row1 + q - 1 + b] = d0 + da + db * b;
+                    o.aDst[row2 + q - 2 + b] = d0 + 2 * da + db * b;
+                }
+            }
+        }
+        };
+        const int nThreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+        std::vector<std::thread> pool;
+        std::exception_ptr err;
+        std::mutex errLock;
+        for (int t = 0; t < nThreads; ++t)
+            pool.emplace_back([&, t] {
+                try {
+                    fillRange((int)((int64_t)o.nn * t / nThreads), (int)((int64_t)o.nn * (t + 1) / nThreads));
+                }
+                catch (...) {
+                    std::lock_guard<std::mutex> g(errLock);
+                    err = std::current_exception();
+                }
+            });
+        for (auto& th : pool) th.join();
+        if (err) std::rethrow_exception(err);
+    }
+    else {
+        for (int r = 0; r < n; ++r)
+            for (int k = ia[r]; k < ia[r + 1]; ++k) o.aDst[k] = slot(r, ja[k]);
+    }
 }
 
 void mf_L_pattern_csr(const MfSymbolic& sym, std::vector<int>& ptrT, std::vector<int>& indT, std::vector<int>& pivQ)
