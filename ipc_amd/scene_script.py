@@ -1,0 +1,302 @@
+"""The reference's scene-script grammar (src/Config.cpp:97-620) mapped onto the C ABI.
+
+This is tooling, not product: a maintainer who links libipcgpu.so into IPC keeps IPC's own Config class; this module lets
+the tests and tools/run_scene.py drive the library (or the CPU oracle, through the same `Backend` protocol) from the very
+scene files the reference ships, so both start from identical inputs.  Only keywords whose feature exists here are accepted;
+anything else raises `UnsupportedKeyword` instead of being ignored silently.
+
+    cfg = SceneConfig.parse(open(path).read(), base_dir)       # grammar only
+    scene = assemble(cfg, read_mesh)                          # shapes -> one mesh (main.cpp:880-1198)
+    apply(scene, backend)                                     # C-ABI calls, in the order INTEGRATION.md gives
+"""
+from dataclasses import dataclass, field
+import math
+import os
+
+import numpy as np
+
+from . import scene as _scene
+
+
+class UnsupportedKeyword(ValueError):
+    pass
+
+
+VIEWER_KEYWORDS = {"view", "zoom", "cameraTracking", "playBackSpeed", "appendStr", "disableCout", "size", "section"}
+
+
+def _rot(deg):
+    """Rx Ry Rz of Euler angles in degrees (Config.cpp:222-226)."""
+    x, y, z = (math.radians(a) for a in deg)
+    cx, sx, cy, sy, cz, sz = math.cos(x), math.sin(x), math.cos(y), math.sin(y), math.cos(z), math.sin(z)
+    Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    Ry = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]])
+    Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]])
+    return Rx @ Ry @ Rz
+
+
+@dataclass
+class Shape:
+    path: str
+    translate: np.ndarray
+    rotate_deg: np.ndarray
+    scale: np.ndarray
+    material: tuple = None  # (rho, E, nu)
+    lin_vel: tuple = None  # scripted (kinematic component)
+    ang_vel_deg: tuple = None
+    init_vel: tuple = None  # (linear, angular deg/s)
+    dbc: list = field(default_factory=list)  # (rel_min, rel_max, lin_vel, ang_vel_deg, t0, t1)
+
+
+@dataclass
+class SceneConfig:
+    energy: str = "NH"
+    time_integration: str = "BE"
+    beta: float = 0.25
+    gamma: float = 0.5
+    duration: float = 5.0
+    dt: float = 0.025
+    rho: float = 1000.0
+    YM: float = 1e5
+    PR: float = 0.4
+    gravity: bool = True
+    self_collision: bool = True  # Config.hpp:99
+    self_fric: float = 0.0
+    dHat_eps: float = 1e-3  # tuning[1]
+    eps_v: float = 1e-3  # tuning[4]
+    fric_iter_amt: int = 1
+    tol: float = 1e-2
+    script: str = "null"
+    restart: str = None
+    half_spaces: list = field(default_factory=list)  # (origin, normal, friction)
+    shapes: list = field(default_factory=list)
+
+    @staticmethod
+    def parse(text, base_dir="."):
+        cfg = SceneConfig()
+        lines = text.splitlines()
+        i = 0
+
+        def resolve(p):
+            return p if os.path.isabs(p) else os.path.normpath(os.path.join(base_dir, p))
+
+        while i < len(lines):
+            tok = lines[i].split()
+            i += 1
+            if not tok or tok[0].startswith("#"):
+                continue
+            k, a = tok[0], tok[1:]
+            if k == "energy":
+                if a[0] not in ("NH", "FCR"):
+                    raise UnsupportedKeyword(f"energy {a[0]}")
+                cfg.energy = a[0]
+            elif k == "timeIntegration":
+                cfg.time_integration = a[0]
+                if a[0] == "NM" and len(a) >= 3:
+                    cfg.beta, cfg.gamma = float(a[1]), float(a[2])
+                elif a[0] not in ("BE", "NM"):
+                    raise UnsupportedKeyword(f"timeIntegration {a[0]}")
+            elif k == "time":
+                cfg.duration, cfg.dt = float(a[0]), float(a[1])
+            elif k == "density":
+                cfg.rho = float(a[0])
+            elif k == "stiffness":
+                cfg.YM, cfg.PR = float(a[0]), float(a[1])
+            elif k == "turnOffGravity":
+                cfg.gravity = False
+            elif k == "script":
+                if a[0] not in ("null", "twist", "fall", "fallNoShift"):
+                    raise UnsupportedKeyword(f"script {a[0]}")
+                cfg.script = a[0]
+            elif k == "warmStart":  # initX option; 0 (searchDir = 0, Optimizer.cpp:930-934) is the one restated
+                if int(a[0]) != 0:
+                    raise UnsupportedKeyword(f"warmStart {a[0]}")
+            elif k == "constraintSolver":
+                if a[0] not in ("IP", "interiorPoint"):
+                    raise UnsupportedKeyword(f"constraintSolver {a[0]}")
+            elif k == "timeStepper":
+                if a[0] != "Newton":
+                    raise UnsupportedKeyword(f"timeStepper {a[0]}")
+            elif k == "shape":  # single shape, identity transform (Config.cpp:188-203)
+                if a[0] != "input":
+                    raise UnsupportedKeyword(f"shape {a[0]}")
+                cfg.shapes.append(Shape(resolve(a[1]), np.zeros(3), np.zeros(3), np.ones(3)))
+            elif k == "shapes":
+                if a[0] != "input":
+                    raise UnsupportedKeyword(f"shapes {a[0]}")
+                n = int(a[1])
+                got = 0
+                while got < n:
+                    st = lines[i].split()
+                    i += 1
+                    if not st or st[0].startswith("#"):
+                        continue
+                    cfg.shapes.append(_parse_shape(st, resolve))
+                    got += 1
+            elif k == "ground":  # friction, height (Config.cpp:425-430)
+                cfg.half_spaces.append((np.array([0.0, float(a[1]), 0.0]), np.array([0.0, 1.0, 0.0]), float(a[0])))
+            elif k == "halfSpace":  # origin, normal, stiffness (unused), friction (Config.cpp:431-447)
+                v = [float(x) for x in a]
+                n = np.array(v[3:6])
+                cfg.half_spaces.append((np.array(v[0:3]), n / np.linalg.norm(n), v[7] if len(v) > 7 else 0.0))
+            elif k == "selfCollisionOn":
+                cfg.self_collision = True
+            elif k == "selfCollisionOff":
+                cfg.self_collision = False
+            elif k == "selfFric":
+                cfg.self_fric = float(a[0])
+            elif k == "dHat":
+                cfg.dHat_eps = float(a[0])
+            elif k == "epsv":
+                cfg.eps_v = float(a[0])
+            elif k == "fricIterAmt":
+                cfg.fric_iter_amt = int(a[0])
+            elif k == "tol":
+                vals = []
+                while len(vals) < int(a[0]):
+                    vals += [float(x) for x in lines[i].split()]
+                    i += 1
+                if vals:
+                    cfg.tol = vals[0]
+            elif k == "tuning":  # Config.cpp:41-45, 533-541: [kappa (0 = automatic), dHat, dHat target, dTol, eps_v, eps_v target]
+                vals = []
+                while len(vals) < int(a[0]):
+                    vals += [float(x) for x in lines[i].split()]
+                    i += 1
+                if len(vals) > 0 and vals[0] != 0:
+                    raise UnsupportedKeyword("tuning with a fixed kappa")
+                if len(vals) > 1:
+                    cfg.dHat_eps = vals[1]
+                if len(vals) > 2 and vals[2] != vals[1]:
+                    raise UnsupportedKeyword("tuning with a dHat homotopy")
+                if len(vals) > 4:
+                    cfg.eps_v = vals[4]
+            elif k == "restart":
+                cfg.restart = resolve(a[0])
+            elif k in VIEWER_KEYWORDS:
+                pass  # viewer / logging only
+            else:
+                raise UnsupportedKeyword(k)
+        return cfg
+
+
+def _parse_shape(st, resolve):
+    sh = Shape(resolve(st[0]), np.array([float(x) for x in st[1:4]]), np.array([float(x) for x in st[4:7]]), np.array([float(x) for x in st[7:10]]))
+    j = 10
+    while j < len(st):
+        e = st[j]
+        j += 1
+        if e == "material":
+            sh.material = tuple(float(x) for x in st[j:j + 3])
+            j += 3
+        elif e == "linearVelocity":
+            sh.lin_vel = tuple(float(x) for x in st[j:j + 3])
+            j += 3
+        elif e == "angularVelocity":
+            sh.ang_vel_deg = tuple(float(x) for x in st[j:j + 3])
+            j += 3
+        elif e == "initVel":
+            v = [float(x) for x in st[j:j + 6]]
+            sh.init_vel = (tuple(v[:3]), tuple(v[3:]))
+            j += 6
+        elif e == "DBC":
+            v = [float(x) for x in st[j:j + 12]]
+            j += 12
+            t0, t1 = 0.0, float("inf")
+            try:  # optional start / stop time (Config.cpp:251-254)
+                t0 = float(st[j])
+                j += 1
+                t1 = float(st[j])
+                j += 1
+            except (IndexError, ValueError):
+                pass
+            sh.dbc.append((v[0:3], v[3:6], v[6:9], v[9:12], t0, t1))
+        else:
+            raise UnsupportedKeyword(f"shape keyword {e}")
+    return sh
+
+
+@dataclass
+class AssembledScene:
+    cfg: SceneConfig
+    V: np.ndarray
+    T: np.ndarray
+    SF: np.ndarray
+    node_ranges: list
+    tet_ranges: list
+    dirichlet: list  # (ids, lin_vel, ang_vel_deg, t0, t1)
+    velocity: np.ndarray
+
+
+def assemble(cfg, read_mesh):
+    """main.cpp:880-1198: transform every shape (R (p * scale) + translate), concatenate, select Dirichlet nodes per shape."""
+    Vs, Ts, SFs, nr, tr, dirichlet = [], [], [], [0], [0], []
+    for sh in cfg.shapes:
+        V, T, SF = read_mesh(sh.path)
+        V = (V * sh.scale) @ _rot(sh.rotate_deg).T + sh.translate
+        off = nr[-1]
+        for rel_min, rel_max, lin, ang, t0, t1 in sh.dbc:  # IglUtils::Init_Dirichlet on the shape's own box
+            ids = _scene.select_dirichlet(V, SF, rel_min, rel_max)
+            if len(ids):
+                dirichlet.append((ids + off, lin, ang, t0, t1))
+        if sh.lin_vel is not None or sh.ang_vel_deg is not None:  # scripted component: every node moves (AnimScripter.cpp:1413-1435)
+            ids = np.arange(V.shape[0], dtype=np.int32) + off
+            dirichlet.append((ids, sh.lin_vel or (0, 0, 0), sh.ang_vel_deg or (0, 0, 0), 0.0, float("inf")))
+        Vs.append(V)
+        Ts.append(T + off)
+        SFs.append(SF + off)
+        nr.append(off + V.shape[0])
+        tr.append(tr[-1] + T.shape[0])
+    V, T, SF = np.vstack(Vs), np.vstack(Ts).astype(np.int32), np.vstack(SFs).astype(np.int32)
+    if cfg.script in ("fall", "fallNoShift"):  # AnimScripter.cpp:779-788: lifted by half the bounding-box diagonal, no Dirichlet nodes
+        if cfg.script == "fall":
+            V[:, 1] += 0.5 * np.linalg.norm(V.max(0) - V.min(0))
+        dirichlet = []
+    vel = np.zeros_like(V)
+    fixed = np.zeros(V.shape[0], dtype=bool)
+    for ids, *_ in dirichlet:
+        fixed[ids] = True
+    for s, sh in enumerate(cfg.shapes):  # AnimScripter::initVelocity (AnimScripter.cpp:1319-1333)
+        if sh.init_vel is None:
+            continue
+        a, b = nr[s], nr[s + 1]
+        ctr = 0.5 * (V[a:b].max(0) + V[a:b].min(0))
+        w = np.radians(np.array(sh.init_vel[1]))
+        v = np.array(sh.init_vel[0]) + np.cross(w, V[a:b] - ctr)
+        v[fixed[a:b]] = 0.0
+        vel[a:b] = v
+    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel)
+
+
+def apply(sc, be):
+    """Drive a backend (the ctypes `Context` of ipc_amd/lib.py, or an adapter over the oracle with the same method names)."""
+    cfg = sc.cfg
+    be.set_mesh(sc.V, sc.T, YM=cfg.YM, PR=cfg.PR, density=cfg.rho)
+    be.set_energy_type(cfg.energy)
+    for s, sh in enumerate(cfg.shapes):
+        if sh.material is not None and all(np.isfinite(sh.material)):
+            be.set_component_material((sc.node_ranges[s], sc.node_ranges[s + 1]), (sc.tet_ranges[s], sc.tet_ranges[s + 1]), *sh.material)
+    be.opt_init(cfg.dt, cfg.gravity)
+    if cfg.time_integration == "NM":
+        be.set_time_integration("NM", cfg.beta, cfg.gamma)
+    be.set_surface(sc.SF)
+    if cfg.self_collision:
+        be.enable_self_collision(cfg.dHat_eps)
+    for origin, normal, mu in cfg.half_spaces:
+        idx = be.add_half_space(origin, normal, cfg.dHat_eps)
+        if mu > 0:
+            be.set_half_space_friction(idx, mu)
+    if cfg.self_fric > 0 or any(mu > 0 for *_, mu in cfg.half_spaces):
+        be.set_friction(cfg.self_fric, cfg.fric_iter_amt, cfg.eps_v)
+    for ids, lin, ang, t0, t1 in sc.dirichlet:
+        be.add_dirichlet(ids, lin_vel=lin, ang_vel_deg=ang, t0=t0, t1=t1)
+    if cfg.script == "twist":
+        left, right = _scene.border_verts(sc.V, 0.01)
+        be.set_twist(left, right)
+    if np.any(sc.velocity):
+        be.set_velocity(sc.velocity)
+    be.set_rel_tol(cfg.tol)
+    if cfg.restart:
+        be.load_status(cfg.restart)
+    be.precompute()
+    return be

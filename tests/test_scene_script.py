@@ -1,0 +1,184 @@
+"""Scene scripts (src/Config.cpp:97-620) driving the C ABI: grammar, shape assembly, and the tutorial
+scene run on the GPU beside the oracle through the same calls."""
+import os
+
+import numpy as np
+import pytest
+
+from ipc_amd import lib as gl
+from ipc_amd import scene, scene_script as ss
+
+REF_INPUT = "/root/reference/input"
+
+TUTORIAL = """
+shapes input 2
+cube.msh 0 3 0  0 0 0  1 1 1
+cube.msh 0 1 0  0 0 0  1 1 1
+
+selfFric 0.1
+
+ground 0.1 0
+"""  # input/tutorialExamples/2cubesFall.txt with a local mesh path
+
+HELLO = """
+energy NH
+density 1000
+stiffness 1e9 0.4
+
+shapes input 1
+bar.msh 0 0 0  0 0 0  1 1 1 DBC 0 0 0  0.01 1 1  0 0 0  0 0 0  DBC 0.99 0 0  1 1 1  0 0 0  270 0 0
+
+selfCollisionOff
+"""  # input/otherExamples/barTwist_noCollisions.txt
+
+
+def test_grammar():
+    c = ss.SceneConfig.parse(TUTORIAL, "/x")
+    assert c.energy == "NH" and c.dt == 0.025 and c.YM == 1e5 and c.self_collision and c.self_fric == 0.1
+    assert len(c.shapes) == 2 and c.shapes[0].path == "/x/cube.msh" and np.allclose(c.shapes[0].translate, [0, 3, 0])
+    (o, n, mu), = c.half_spaces
+    assert np.allclose(o, [0, 0, 0]) and np.allclose(n, [0, 1, 0]) and mu == 0.1
+    c = ss.SceneConfig.parse(HELLO)
+    assert c.YM == 1e9 and not c.self_collision and len(c.shapes[0].dbc) == 2
+    assert c.shapes[0].dbc[1][3] == [270.0, 0.0, 0.0] and c.shapes[0].dbc[1][0] == [0.99, 0.0, 0.0]
+    c = ss.SceneConfig.parse("energy FCR\ntimeIntegration NM 0.3 0.6\ntime 2 0.01\nturnOffGravity\ntol 1\n1e-4\ndHat 2e-3\nepsv 1e-4\nfricIterAmt 3\n"
+                             "halfSpace 0 -1 0  0 2 0  1 0.5\nshapes input 1\n# comment\nm.msh 1 2 3  0 0 90  2 2 2 material 2000 1e8 0.3 initVel 1 0 0  0 0 90 "
+                             "linearVelocity 0 -1 0\nview orthographic\n")
+    assert (c.energy, c.time_integration, c.beta, c.gamma, c.dt, c.gravity, c.tol, c.dHat_eps, c.eps_v, c.fric_iter_amt) == ("FCR", "NM", 0.3, 0.6, 0.01, False, 1e-4, 2e-3, 1e-4, 3)
+    assert np.allclose(c.half_spaces[0][1], [0, 1, 0]) and c.half_spaces[0][2] == 0.5
+    sh = c.shapes[0]
+    assert sh.material == (2000.0, 1e8, 0.3) and sh.init_vel == ((1.0, 0.0, 0.0), (0.0, 0.0, 90.0)) and sh.lin_vel == (0.0, -1.0, 0.0)
+    for bad in ("meshCO plane.obj 0 0 0 1 1 0.1\n", "script DCOVerschoorRoller\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 NBC 0 0 0 1 1 1 0 1 0\n"):
+        with pytest.raises(ss.UnsupportedKeyword):
+            ss.SceneConfig.parse(bad)
+
+
+def test_assemble_transforms_and_selects_like_main_cpp():
+    V0, F0 = scene.make_box(2, 1, 1, size=(2.0, 1.0, 1.0), origin=(0, 0, 0))
+    SF0 = scene.surface_tris(F0)
+    c = ss.SceneConfig.parse("shapes input 2\na.msh 0 0 0  0 0 0  1 1 1 DBC 0 0 0  0.01 1 1  0 0 0  0 0 0\n"
+                             "a.msh 5 0 0  0 0 90  2 1 1 initVel 0 1 0  0 0 0 angularVelocity 0 0 0\n")
+    sc = ss.assemble(c, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    n = V0.shape[0]
+    assert sc.V.shape[0] == 2 * n and sc.T.max() == 2 * n - 1 and sc.node_ranges == [0, n, 2 * n] and sc.tet_ranges == [0, len(F0), 2 * len(F0)]
+    # R (p * scale) + t with Rz(90): (x, y, z) -> (-y, 2x, z) + (5, 0, 0)
+    assert np.allclose(sc.V[n:], np.c_[-V0[:, 1] + 5, 2 * V0[:, 0], V0[:, 2]])
+    ids0 = sc.dirichlet[0][0]
+    assert np.array_equal(ids0, np.nonzero(V0[:, 0] < 0.02)[0])
+    assert np.array_equal(sc.dirichlet[1][0], np.arange(n, 2 * n))  # scripted component: all of its nodes
+    assert not sc.velocity.any()  # initVel is not applied to Dirichlet nodes (AnimScripter.cpp:1327)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INPUT), reason="the reference's scene files are only present in the build container")
+def test_reference_scene_files_parse():
+    ok, unsupported = [], {}
+    for root, _, files in os.walk(REF_INPUT):
+        for f in files:
+            if not f.endswith(".txt"):
+                continue
+            p = os.path.join(root, f)
+            try:
+                c = ss.SceneConfig.parse(open(p, errors="replace").read(), "/root/reference")
+                if c.shapes:
+                    ok.append(os.path.relpath(p, REF_INPUT))
+            except ss.UnsupportedKeyword as e:
+                unsupported[str(e).split()[0]] = unsupported.get(str(e).split()[0], 0) + 1
+            except (ValueError, IndexError):
+                unsupported["malformed"] = unsupported.get("malformed", 0) + 1
+    print(len(ok), "scene files map onto the C ABI;", unsupported)
+    for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
+        assert need in ok, need
+    assert len(ok) >= 45  # the rest needs meshCO obstacles or scripted handle motions (script DCOFix, dragright, ...) that are not restated
+
+
+class OracleBackend:
+    """The same method names as ipc_amd.lib.Context over the CPU oracle, so that one `apply()` drives both."""
+
+    def __init__(self, orc, nthreads=4):
+        self.orc, self.nthreads, self.m, self.o = orc, nthreads, None, None
+        self._pending = []
+
+    def set_mesh(self, V, T, YM, PR, density):
+        self.m = self.orc.Mesh(V, T, YM=YM, PR=PR, density=density)
+
+    def set_energy_type(self, name):
+        self.m.set_energy_type(name)
+
+    def set_component_material(self, *a):
+        self.m.set_component_material(*a)
+
+    def set_surface(self, SF):
+        self.m.set_surface(SF)
+
+    def opt_init(self, dt, gravity):
+        self.o = self.orc.Optimizer(self.m, dt=dt, gravity=gravity, nthreads=self.nthreads)
+
+    def set_time_integration(self, *a):
+        self.orc.opt_set_time_integration(self.o, *a)
+
+    def enable_self_collision(self, e):
+        self.orc.opt_enable_self_collision(self.o, e)
+
+    def add_half_space(self, o, n, e):
+        return self.orc.opt_add_half_space(self.o, o, n, e)
+
+    def set_half_space_friction(self, i, mu):
+        self.orc.opt_set_half_space_friction(self.o, i, mu)
+
+    def set_friction(self, mu, n, eps):
+        self.orc.opt_set_friction(self.o, mu, n, eps)
+
+    def add_dirichlet(self, ids, **k):
+        self.orc.opt_add_dirichlet(self.o, ids, **k)
+
+    def set_twist(self, l, r):
+        self.o.set_twist(l, r)
+
+    def set_velocity(self, v):
+        self.orc.opt_set_velocity(self.o, v)
+
+    def set_rel_tol(self, t):
+        self.o.set_rel_tol(t)
+
+    def load_status(self, p):
+        self.orc.opt_load_status(self.o, p)
+
+    def precompute(self):
+        self.o.precompute()
+
+
+@pytest.mark.gpu
+def test_tutorial_scene_runs_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
+    """input/tutorialExamples/2cubesFall.txt: two cubes, self-contact with friction, rough ground.  The cubes start exactly at
+    rest, so single iterates are round-off dependent (makePD2d); the converged steps are compared at a tight tolerance."""
+    V, F = scene.make_box(1, 1, 1, size=(1.0, 1.0, 1.0), origin=(-0.5, -0.5, -0.5))
+    gl.save_tet_mesh(tmp_path / "cube.msh", V, F)
+    text = TUTORIAL.replace("0 3 0", "0 1.6 0").replace("0 1 0", "0 0.52 0") + "tol 1\n1e-6\n"  # closer to the ground: contact within a few steps
+    cfg = ss.SceneConfig.parse(text, str(tmp_path))
+    sc = ss.assemble(cfg, gl.read_tet_mesh)
+    assert sc.V.shape == (16, 3) and sc.T.shape == (12, 4)
+    ob = ss.apply(sc, OracleBackend(orc))
+    c = ss.apply(sc, gpu_lib.Context(0))
+    touched = 0
+    for step in range(10):
+        no = 0
+        ob.o.begin_timestep()
+        c.begin_timestep()
+        for sub in range(4):
+            for it in range(200):
+                co, cg = ob.o.newton_iter(), c.newton_iter()
+                if co and cg:
+                    break
+            else:
+                pytest.fail("no convergence")
+            mo, mg = orc.opt_next_subproblem(ob.o), c.next_subproblem()
+            assert mo == mg
+            if not mo:
+                break
+        ob.o.end_timestep()
+        c.end_timestep()
+        so, sg = ob.o.state(), c.state()
+        assert np.abs(sg["V"] - so["V"]).max() < 1e-6, step
+        touched += c.contact_state()["nHalfSpace"] > 0
+    assert touched >= 3 and c.state()["V"][:, 1].min() > 0.0  # the lower cube has reached the ground and stays above it
+    c.close()
