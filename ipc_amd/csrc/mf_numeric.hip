@@ -170,64 +170,6 @@ __device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lan
     return bad;
 }
 
-// Same factorisation with the cross-lane traffic split by urgency.  Column j is needed (a) by the next two pivots, through
-// L(j+1, j) and L(j+2, j): two v_readlane pairs on the critical chain; (b) by the columns further right: those multipliers
-// go through a 32-double LDS line (one ds_write per column, 128-bit broadcast reads) and are consumed one column later, so
-// their LDS round trip and their FMAs sit in the shadow of the next pivot's rsqrt chain instead of in front of it.
-// colbuf: 32 doubles of LDS, 16-byte aligned, private to this wave.
-__device__ __forceinline__ bool wave_potrf32p(double* blk, int ld, int w, int lane, double* rdiag, double* colbuf)
-{
-    bool bad = false;
-    double row[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) row[k] = (lane < w && k <= lane && k < w) ? blk[k * ld + (lane & (NB - 1))] : 0.0;
-    double myRd = 0.0;
-    double pend[NB]; // multipliers L(jj, j - 1), jj >= j + 2, read from LDS during column j - 1
-    double prevCol = 0.0; // this lane's L(r, j - 1)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j < w) { // uniform
-            double djj = bcast_lane(row[j], j);
-            if (!(djj > 0.0)) {
-                bad = true;
-                djj = 1.0;
-            }
-            const double invd = rsqrt_nr(djj);
-            if (lane == j) myRd = invd;
-            row[j] *= invd;
-            if (j + 3 < NB && lane < NB) colbuf[lane] = row[j];
-            if (j + 1 < NB) row[j + 1] -= row[j] * bcast_lane(row[j], j + 1);
-            if (j + 2 < NB) row[j + 2] -= row[j] * bcast_lane(row[j], j + 2);
-        }
-        // deferred part of column j - 1
-        if (j >= 1 && j - 1 < w) {
-#pragma unroll
-            for (int jj = j + 2; jj < NB; ++jj) row[jj] -= prevCol * pend[jj];
-        }
-        if (j < w && j + 3 < NB) {
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            int jj = j + 3;
-            if (jj & 1) {
-                pend[jj] = colbuf[jj];
-                ++jj;
-            }
-#pragma unroll
-            for (; jj + 1 < NB; jj += 2) {
-                const double2 t = *reinterpret_cast<const double2*>(colbuf + jj);
-                pend[jj] = t.x;
-                pend[jj + 1] = t.y;
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-            prevCol = row[j];
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-        if (lane < w && k <= lane && k < w) blk[k * ld + lane] = row[k];
-    if (lane < NB) rdiag[lane] = myRd;
-    return bad;
-}
-
 // Inverse of a lower-triangular 32x32 block.  rows[r * ld + k] = L(r, k) for k < r and 1 / L(r, r) on the diagonal (LDS,
 // row-major so that a row is contiguous).  Lane c (< 32) produces column c of X = L^-1 by forward substitution with the
 // column in registers: X(r, c) = (delta_rc - sum_{k < r} L(r, k) X(k, c)) / L(r, r); L(r, k) is an LDS broadcast.  The reads
