@@ -28,19 +28,20 @@ __device__ __forceinline__ bool wave_potrf32c(double* blk, int ld, int w, int la
             if (lane == j) myRd = invd;
             row[j] *= invd;
             double invdNext = 1.0;
+            auto nextPivot = [&]() {
+                if (j + 1 < w) {
+                    double dn = bcast_lane(row[j + 1], j + 1);
+                    if (!(dn > 0.0)) {
+                        bad = true;
+                        dn = 1.0;
+                    }
+                    invdNext = rsqrt_nr(dn);
+                }
+            };
 #pragma unroll
             for (int j0 = j + 1, b = 0; j0 < NB; j0 += BATCH, ++b) {
                 double m[BATCH];
-                if (b == 1 || (b == 0 && j + 1 + BATCH >= NB)) { // the next pivot: independent of the batches that follow
-                    if (j + 1 < w) {
-                        double dn = bcast_lane(row[j + 1], j + 1);
-                        if (!(dn > 0.0)) {
-                            bad = true;
-                            dn = 1.0;
-                        }
-                        invdNext = rsqrt_nr(dn);
-                    }
-                }
+                if (b == 1) nextPivot(); // column j + 1 is final after batch 0: its rsqrt chain runs under the later batches
 #pragma unroll
                 for (int q = 0; q < BATCH; ++q)
                     if (j0 + q < NB) m[q] = bcast_lane(row[j], j0 + q);
@@ -50,6 +51,7 @@ __device__ __forceinline__ bool wave_potrf32c(double* blk, int ld, int w, int la
                     if (j0 + q < NB) row[j0 + q] -= row[j] * m[q];
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (j + 1 + BATCH >= NB) nextPivot(); // single batch: after it
             invd = invdNext;
         }
     }
@@ -112,10 +114,10 @@ __global__ __launch_bounds__(WGB) void k_probe(double* A, long long* out, double
     for (int e = tid; e < NB * NB; e += WGB) blk[(e >> 5) * LDP + (e & 31)] = blk2[(e >> 5) * LDP + (e & 31)] = blk3[(e >> 5) * LDP + (e & 31)] = A[e];
     __syncthreads();
     long long u0 = __builtin_readcyclecounter();
-    if (tid >= ROWS_B) (void)wave_potrf32b<8>(blk2, LDP, NB, tid - ROWS_B, rd2);
+    if (tid >= ROWS_B) (void)wave_potrf32c<8>(blk2, LDP, NB, tid - ROWS_B, rd2);
     __syncthreads();
     long long u1 = __builtin_readcyclecounter();
-    if (tid >= ROWS_B) (void)wave_potrf32c<8>(blk3, LDP, NB, tid - ROWS_B, rd2);
+    if (tid >= ROWS_B) (void)wave_potrf32c<16>(blk3, LDP, NB, tid - ROWS_B, rd2);
     __syncthreads();
     long long u2 = __builtin_readcyclecounter();
     long long t0 = __builtin_readcyclecounter();
@@ -188,7 +190,7 @@ int main()
         double md;
         hipMemcpy(o, dO, 48, hipMemcpyDeviceToHost);
         hipMemcpy(&md, dS, 8, hipMemcpyDeviceToHost);
-        std::printf("batched broadcasts: b<8> -> %lld, c<8> (early next pivot) -> %lld ticks, max |dL| %.2e\n", o[4], o[5], md);
+        std::printf("early next pivot: c<8> -> %lld, c<16> -> %lld ticks, max |dL| %.2e\n", o[4], o[5], md);
         std::printf("grid %2d: potrf32 %lld  row_trsm32<1>(4 waves) %lld  trinv32 %lld  row_update32 %lld  (s_memtime ticks)\n",
             rep == 2 ? 64 : 1, o[0], o[1], o[2], o[3]);
     }
