@@ -424,16 +424,24 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         A11[k * LDP + q] = (k < w1 && q < w1 && q >= k) ? F[(kb1 + q) + (long long)N * (kb1 + k)] : 0.0;
     }
     __syncthreads();
-    if (w > 0)
-        for (int e = tid; e < NB * NB; e += WGB) {
-            const int c = e >> 5, q = e & 31;
-            if (q >= c) {
-                double acc = 0.0;
-#pragma unroll 8
-                for (int k = 0; k < NB; ++k) acc += Lp[k * LDP + q] * Lp[k * LDP + c];
-                A11[c * LDP + q] -= acc;
-            }
+    if (w > 0 && tid < 192) {
+        // A11 -= Lp^T Lp (lower triangle) on the matrix cores: waves 0..2 take the 16 x 16 tiles (0,0), (1,0), (1,1).  As scalar
+        // FMAs this was 256 LDS reads per thread -- ~4 k cycles of LDS return traffic on the critical chain of every step.
+        const int wv = tid >> 6, l = tid & 63;
+        const int ti = wv >= 1, tj = wv == 2; // row tile (q), column tile (c)
+        const int ar = l & 15, ak = l >> 4;
+        f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[(4 * ks + ak) * LDP + 16 * ti + ar], Lp[(4 * ks + ak) * LDP + 16 * tj + ar], acc, 0, 0, 0);
+        // D: column = l & 15 -> c, row = (l >> 4) + 4 r -> q
+        const int c = 16 * tj + ar;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 16 * ti + ak + 4 * r;
+            if (q >= c) A11[c * LDP + q] -= acc[r];
         }
+    }
     __syncthreads();
     const int R = kb1 + d.z + tid;
     const bool rowThread = tid < ROWS_B && R >= kb1 + w1 && R < N;
