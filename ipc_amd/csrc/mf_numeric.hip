@@ -39,6 +39,7 @@ constexpr int ROWS_B = 64 * ROW_WAVES_B; // panel rows per role-B workgroup
 constexpr int PIVOT_T0 = WGB - 64; // first thread of the pivot wave
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
+constexpr int EA_KC = 4; // children whose index maps are staged together in the extend-add kernel
 constexpr int TS = 64; // trailing-update tile
 constexpr int PIVOT_BATCH = 16; // broadcasts issued ahead of their FMAs in the pivot-block Cholesky (2 SGPRs each)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -71,7 +72,9 @@ __global__ void k_scatter_a(int nnz, const double* __restrict__ a, const long lo
 // are (mostly) consecutive in the child as well, the four waves split the 64 columns.
 __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
 {
-    __shared__ int rmap[TS], cmap[TS];
+    // the index maps of up to EA_KC children are staged together: one barrier pair and one round of gathers per batch instead
+    // of per child (the kernel spends 93 % of its wave cycles parked on these dependent round trips, SQ_WAIT_ANY)
+    __shared__ int rmap[EA_KC][TS], cmap[EA_KC][TS];
     const int4 d = desc[blockIdx.x];
     const int s = d.x;
     const int N = frontN(tv, s);
@@ -81,28 +84,38 @@ __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc
     double sum[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) sum[q] = 0.0;
-    for (int ci = tv.childPtr[s]; ci < tv.childPtr[s + 1]; ++ci) {
-        const int c = tv.child[ci];
-        const int* inv = tv.inv + tv.invPtr[c];
-        const int Nc = frontN(tv, c), ncc = frontNc(tv, c);
-        const double* Fc = fronts + tv.frontOff[c];
+    const int cEnd = tv.childPtr[s + 1];
+    for (int ci0 = tv.childPtr[s]; ci0 < cEnd; ci0 += EA_KC) {
+        const int nk = min(EA_KC, cEnd - ci0);
         __syncthreads();
-        if (tid < 2 * TS) {
-            const int I = (tid < TS ? i0 : j0 - TS) + tid;
+        for (int e = tid; e < nk * 2 * TS; e += WG) {
+            const int k = e / (2 * TS), t = e - k * (2 * TS);
+            const int c = tv.child[ci0 + k];
+            const int* inv = tv.inv + tv.invPtr[c];
+            const int ncc = frontNc(tv, c);
+            const int I = (t < TS ? i0 : j0 - TS) + t;
             int m = -1;
             if (I < N) {
                 const int ic = inv[I / 3];
                 if (ic >= 0) m = ncc + 3 * ic + (I - 3 * (I / 3));
             }
-            (tid < TS ? rmap : cmap - TS)[tid] = m;
+            (t < TS ? rmap[k] : cmap[k] - TS)[t] = m;
         }
         __syncthreads();
-        const int r = rmap[lane];
-        if (r >= 0) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int cc = cmap[16 * wv + q];
-                if (cc >= 0 && r >= cc) sum[q] += Fc[r + (long long)Nc * cc];
+        for (int k = 0; k < EA_KC; ++k) {
+            if (k < nk) {
+                const int c = tv.child[ci0 + k];
+                const int Nc = frontN(tv, c);
+                const double* __restrict__ Fc = fronts + tv.frontOff[c];
+                const int r = rmap[k][lane];
+                if (r >= 0) {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int cc = cmap[k][16 * wv + q];
+                        if (cc >= 0 && r >= cc) sum[q] += Fc[r + (long long)Nc * cc];
+                    }
+                }
             }
         }
     }
