@@ -1,0 +1,84 @@
+"""Edge cases of the C ABI on the GPU: smallest meshes, empty sets, argument errors that must come back as status codes with a
+message (no exception crosses the boundary, nothing falls back to the CPU)."""
+import numpy as np
+import pytest
+
+from ipc_amd import scene
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+def test_single_tetrahedron_steps_like_the_oracle(orc, gpu_lib):
+    V = np.array([[0, 0, 0], [1.0, 0, 0], [0, 1.1, 0], [0.1, 0.2, 0.9]])
+    F = np.array([[0, 1, 2, 3]], dtype=np.int32)
+    X = V + 0.05 * np.random.default_rng(0).normal(size=V.shape)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_V(X)
+    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=1)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(X)
+    c.opt_init(0.01, True)
+    o.precompute()
+    c.precompute()
+    for _ in range(3):
+        assert o.solve_timestep(50) == c.solve_timestep(50)
+        assert relerr(c.state()["V"], o.state()["V"]) < 1e-9
+    c.close()
+
+
+def test_contact_machinery_with_nothing_in_contact(orc, gpu_lib):
+    """Two blocks far apart: empty constraint sets, unit CCD bound, no pattern change, and the stepper still matches."""
+    Va, Fa = scene.make_box(2, 1, 1, size=(1.0, 0.5, 0.5), origin=(0, 0, 0))
+    Vb, Fb = scene.make_box(1, 1, 1, size=(0.5, 0.5, 0.5), origin=(0, 3.0, 0))
+    V = np.vstack([Va, Vb])
+    F = np.vstack([Fa, Fb + Va.shape[0]]).astype(np.int32)
+    Vs = scene.jitter(V, F, rel=1e-2)
+    SF = scene.surface_tris(F)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.01, gravity=False, nthreads=2)
+    orc.opt_enable_self_collision(o, 1e-3)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.01, False)
+    c.set_surface(SF)
+    c.enable_self_collision(1e-3)
+    o.precompute()
+    c.precompute()
+    for _ in range(2):
+        assert o.solve_timestep(50) == c.solve_timestep(50)
+        cs = c.contact_state()
+        assert cs["nActive"] == 0 and cs["nPara"] == 0 and cs["nPatternChanges"] == 0
+        assert relerr(c.state()["V"], o.state()["V"]) < 1e-9
+    assert not c.is_intersected()
+    c.close()
+
+
+def test_errors_come_back_as_status_codes(gpu_lib, tmp_path):
+    V, F = scene.make_box(1, 1, 1)
+    c = gpu_lib.Context(0)
+    with pytest.raises(gpu_lib.IpcGpuError):
+        c.opt_init(0.01, False)  # no mesh yet
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    with pytest.raises(gpu_lib.IpcGpuError):
+        c._chk(c._L.ipcgpu_set_energy_type(c.h, 7))  # neither NH nor FCR
+    c.opt_init(0.01, False)
+    with pytest.raises(gpu_lib.IpcGpuError):
+        c.add_dirichlet(np.array([V.shape[0] + 3], dtype=np.int32))  # vertex id out of range
+    with pytest.raises(gpu_lib.IpcGpuError):
+        c.load_status(tmp_path / "nope")
+    bad = tmp_path / "status_bad"
+    open(bad, "w").write("timestep 1\n\nposition 999 3\n0 0 0\n")
+    with pytest.raises(gpu_lib.IpcGpuError):
+        c.load_status(bad)  # more rows than the mesh has
+    with pytest.raises(gpu_lib.IpcGpuError):
+        c.begin_timestep()  # before precompute
+    c.close()
