@@ -1172,14 +1172,15 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     // deterministic order (the kernels append through atomics): by (svI, sfI) and (eI, eJ), as a serial scan would emit
     auto sortRecs = [](std::vector<int>& r) {
         const size_t n = r.size() / 6;
-        std::vector<size_t> idx(n);
-        for (size_t i = 0; i < n; ++i) idx[i] = i;
-        std::sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
-            return std::make_pair(r[6 * a + 4], r[6 * a + 5]) < std::make_pair(r[6 * b + 4], r[6 * b + 5]);
-        });
+        // the pair of primitive indices (both >= 0) packed into one 64-bit key next to the record's position: a flat,
+        // cache-friendly sort instead of an indirect comparison through the 24-byte records
+        std::vector<std::pair<unsigned long long, unsigned>> key(n);
+        for (size_t i = 0; i < n; ++i)
+            key[i] = { ((unsigned long long)(unsigned)r[6 * i + 4] << 32) | (unsigned)r[6 * i + 5], (unsigned)i };
+        std::sort(key.begin(), key.end());
         std::vector<int> s(r.size());
         for (size_t i = 0; i < n; ++i)
-            for (int k = 0; k < 6; ++k) s[6 * i + k] = r[6 * idx[i] + k];
+            for (int k = 0; k < 6; ++k) s[6 * i + k] = r[6 * (size_t)key[i].second + k];
         r.swap(s);
     };
     sortRecs(recPT);
