@@ -231,6 +231,10 @@ int ipcgpu_opt_set_time_integration(ipcgpu_ctx*, int type, double beta, double g
  * c the centre of their current bounding box (AnimScripter.cpp:1413-1462).  ang_vel in rad/s (the script gives deg/s).
  * Call after ipcgpu_opt_init and after the static ipcgpu_set_dbc / ipcgpu_opt_set_twist calls. */
 int ipcgpu_opt_add_dirichlet(ipcgpu_ctx*, int n, const int* vert_ids, const double* lin_vel3, const double* ang_vel3, double t0, double t1);
+/* One Mesh::NeumannBCs entry (src/Mesh.hpp:47-56; `NBC bboxMin bboxMax force [t0 t1]` on a shape line, src/Config.cpp:264-280):
+ * while t0 <= stepStartTime < t1 every listed vertex that is not a Dirichlet node feels the acceleration `accel3` -- the
+ * incremental potential gets -dt^2 m_v accel . x_v, the gradient -dt^2 m_v accel (Optimizer.cpp:3241-3250, 3452-3461). */
+int ipcgpu_opt_add_neumann(ipcgpu_ctx*, int n, const int* vert_ids, const double* accel3, double t0, double t1);
 /* State of the augmented-Lagrangian Dirichlet fallback (Optimizer.cpp:1826-1828, 2168-2203; AnimScripter.cpp:2280-2350): when
  * the scripted motion of a time step is cut short (element inversion, CCD, intersection), the NONZERO Dirichlet nodes are
  * released and pulled to their targets by a penalty rho_DBC / 2 m |x - target|^2 with multipliers until the completed step

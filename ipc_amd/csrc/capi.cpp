@@ -1008,6 +1008,18 @@ int ipcgpu_opt_add_dirichlet(ipcgpu_ctx* c, int n, const int* ids, const double*
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_add_neumann(ipcgpu_ctx* c, int n, const int* ids, const double* accel3, double t0, double t1)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(n > 0 && ids && accel3, "empty Neumann group");
+        for (int i = 0; i < n; ++i) needArg(ids[i] >= 0 && ids[i] < c->mesh->nV, "vertex id out of range");
+        o.addNeumannBC(n, ids, accel3, t0, t1);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_get_dbc_state(ipcgpu_ctx* c, double* out4)
 {
     return guarded([&] {

@@ -138,6 +138,16 @@ public:
         bool isZero() const { return lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
     };
     std::vector<std::unique_ptr<DbcGroup>> dbcGroups;
+    // Mesh::NeumannBCs (Mesh.hpp:47-56): a mass-weighted acceleration on a vertex set while t0 <= stepStartTime < t1
+    struct NbcGroup {
+        int n = 0;
+        DevBuf<int> d_ids;
+        double a[3], t0, t1;
+    };
+    std::vector<std::unique_ptr<NbcGroup>> nbcGroups;
+    void addNeumannBC(int n, const int* ids, const double* accel3, double t0, double t1);
+    void neumannGradientAdd(double* grad_dev); // Optimizer.cpp:3452-3461
+    double neumannEnergy(); // :3241-3250
     std::vector<int> baseDbcType;
     double stepStartTime = 0, stepEndTime = 0; // AnimScripter.cpp:1406-1407
     // augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2150-2157, 2280-2350; Optimizer.cpp:1826-1828, 2168-2203)

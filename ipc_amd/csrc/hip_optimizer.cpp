@@ -128,6 +128,39 @@ void HipOptimizer::setTwist(int nL, const int* left, int nR, const int* right, d
     if (initialised) computeXTilta(); // the handles are Dirichlet nodes now: xTilta = V_prev there (Optimizer.cpp:1244-1246)
 }
 
+void HipOptimizer::addNeumannBC(int n, const int* ids, const double* accel3, double t0, double t1)
+{
+    std::unique_ptr<NbcGroup> g(new NbcGroup);
+    g->n = n;
+    g->d_ids.upload(ids, (size_t)n, stream);
+    for (int c = 0; c < 3; ++c) g->a[c] = accel3[c];
+    g->t0 = t0;
+    g->t1 = t1;
+    HIP_CHECK(hipStreamSynchronize(stream));
+    nbcGroups.push_back(std::move(g));
+}
+
+void HipOptimizer::neumannGradientAdd(double* grad_dev)
+{
+    for (const auto& g : nbcGroups) {
+        if (stepStartTime < g->t0 || stepStartTime >= g->t1) continue;
+        const double c[3] = { dtSq * g->a[0], dtSq * g->a[1], dtSq * g->a[2] };
+        launch_nbc_gradient(g->n, g->d_ids.p, mesh.d_dbc.p, mesh.d_mass.p, c, grad_dev, stream);
+    }
+}
+
+double HipOptimizer::neumannEnergy()
+{
+    double E = 0.0;
+    for (const auto& g : nbcGroups) {
+        if (stepStartTime < g->t0 || stepStartTime >= g->t1) continue;
+        const double c[3] = { dtSq * g->a[0], dtSq * g->a[1], dtSq * g->a[2] };
+        launch_nbc_energy(g->n, g->d_ids.p, mesh.d_dbc.p, mesh.d_mass.p, mesh.d_x.p, c, d_scalar.p + 5, stream);
+        E -= readScalar(d_scalar.p + 5);
+    }
+    return E;
+}
+
 void HipOptimizer::addDirichletBC(int n, const int* ids, const double* lin3, const double* angRad3, double t0, double t1)
 {
     std::unique_ptr<DbcGroup> g(new DbcGroup);
@@ -227,6 +260,7 @@ double HipOptimizer::computeEnergyVal()
     launch_energy(view(), elasticCoef(), true, rank == 0, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
     reduceSum(d_scalar.p, 1);
     double E = readScalar(d_scalar.p);
+    if (!nbcGroups.empty()) E += neumannEnergy();
     // barrier terms over the current constraint sets (Optimizer.cpp:3252-3353); replicated on every rank
     for (auto& h : planes) E += h->energy(mesh.d_x.p, dHat, kappa);
     if (selfCollision) E += contact->energy(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4);
@@ -587,6 +621,7 @@ void HipOptimizer::elasticInertiaGradient(bool projectDBC)
         launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
         launch_assemble(view(), elasticCoef(), projectDBC, d_gradient.p, nullptr, stream);
         reduceSum(d_gradient.p, 3LL * mesh.nV);
+        neumannGradientAdd(d_gradient.p);
         return;
     }
     ensurePatchPlan();
@@ -595,6 +630,7 @@ void HipOptimizer::elasticInertiaGradient(bool projectDBC)
     if (worldSize > 1) d_gradient.zero(stream);
     launch_assemble_patches(view(), patch, pb, pe, elasticCoef(), projectDBC, d_gradient.p, nullptr, stream);
     reduceSum(d_gradient.p, 3LL * mesh.nV);
+    neumannGradientAdd(d_gradient.p);
 }
 
 void HipOptimizer::computeGradient(bool projectDBC)
@@ -690,6 +726,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         reduceSum(lin.d_a.p, (long long)lin.ja.size());
         if (withGradient) reduceSum(d_gradient.p, 3LL * mesh.nV);
     }
+    if (withGradient) neumannGradientAdd(d_gradient.p);
     if (ipOn()) { // barrier blocks, PSD-projected per stencil (Optimizer.cpp:3625-3636, 3670-3676)
         if (withGradient) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p);
         for (auto& h : planes)

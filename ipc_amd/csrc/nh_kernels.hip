@@ -432,6 +432,32 @@ __global__ void k_dbc_motion(int n, const int* __restrict__ ids, DbcMotion m, co
     for (int c = 0; c < 3; ++c) p[3 * v + c] += (m.R[3 * c] * d0 + m.R[3 * c + 1] * d1 + m.R[3 * c + 2] * d2) + m.c[c] + m.linDt[c] - x[3 * v + c];
 }
 
+// ---- Neumann boundary conditions (Optimizer.cpp:3241-3250, 3452-3461): nodes `ids`, acceleration a, coefficient dt^2
+// gradient: g_v -= dt^2 m_v a ; energy (one workgroup, fixed order): sum dt^2 m_v a . x_v   (non-Dirichlet nodes only)
+__global__ void k_nbc_gradient(int n, const int* __restrict__ ids, const int* __restrict__ dbc, const double* __restrict__ mass, double cx, double cy,
+    double cz, double* __restrict__ g)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t v = (size_t)ids[i];
+    if (dbc[v] != 0) return;
+    g[3 * v] -= mass[v] * cx;
+    g[3 * v + 1] -= mass[v] * cy;
+    g[3 * v + 2] -= mass[v] * cz;
+}
+__global__ __launch_bounds__(BLOCK) void k_nbc_energy(int n, const int* __restrict__ ids, const int* __restrict__ dbc, const double* __restrict__ mass,
+    const double* __restrict__ x, double cx, double cy, double cz, double* __restrict__ out)
+{
+    __shared__ double sm[BLOCK / 64];
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < n; t += BLOCK) {
+        const size_t v = (size_t)ids[t];
+        if (dbc[v] == 0) acc += mass[v] * (x[3 * v] * cx + x[3 * v + 1] * cy + x[3 * v + 2] * cz);
+    }
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) out[0] = r;
+}
+
 // ---- augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2303-2346): nodes `ids` with target positions `pos` and
 // multipliers `lam` (3 per node)
 __global__ void k_clear_projected(int nV, const int* __restrict__ dbc, int projectDBC, double* __restrict__ g)
@@ -584,6 +610,14 @@ void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, doub
     if (nH) hipLaunchKernelGGL(k_twist_dir, dim3(nblk(nH)), dim3(BLOCK), 0, s, nH, ids, ang, cy, cz, x, p);
 }
 
+void launch_nbc_gradient(int n, const int* ids, const int* dbc, const double* mass, const double* dtSqA3, double* g, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_nbc_gradient, dim3(nblk(n)), dim3(BLOCK), 0, s, n, ids, dbc, mass, dtSqA3[0], dtSqA3[1], dtSqA3[2], g);
+}
+void launch_nbc_energy(int n, const int* ids, const int* dbc, const double* mass, const double* x, const double* dtSqA3, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_nbc_energy, dim3(1), dim3(BLOCK), 0, s, n, ids, dbc, mass, x, dtSqA3[0], dtSqA3[1], dtSqA3[2], out);
+}
 void launch_clear_projected(int nV, const int* dbc, int projectDBC, double* g, hipStream_t s)
 {
     if (nV) hipLaunchKernelGGL(k_clear_projected, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, projectDBC, g);

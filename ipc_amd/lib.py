@@ -528,6 +528,12 @@ class Context:
         ang = _f64(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
         self._chk(self._L.ipcgpu_opt_add_dirichlet(self.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1)))
 
+    def add_neumann(self, ids, accel, t0=0.0, t1=float("inf")):
+        """One `NBC bboxMin bboxMax force [t0 t1]` entry of a shape line."""
+        ids = _i32(ids)
+        a = _f64(np.asarray(accel, dtype=np.float64))
+        self._chk(self._L.ipcgpu_opt_add_neumann(self.h, C.c_int(len(ids)), _ip(ids), _dp(a), C.c_double(t0), C.c_double(t1)))
+
     def dbc_state(self):
         out = np.zeros(4)
         self._chk(self._L.ipcgpu_opt_get_dbc_state(self.h, _dp(out)))

@@ -46,6 +46,7 @@ class Shape:
     ang_vel_deg: tuple = None
     init_vel: tuple = None  # (linear, angular deg/s)
     dbc: list = field(default_factory=list)  # (rel_min, rel_max, lin_vel, ang_vel_deg, t0, t1)
+    nbc: list = field(default_factory=list)  # (rel_min, rel_max, acceleration, t0, t1)
 
 
 @dataclass
@@ -211,6 +212,18 @@ def _parse_shape(st, resolve):
             except (IndexError, ValueError):
                 pass
             sh.dbc.append((v[0:3], v[3:6], v[6:9], v[9:12], t0, t1))
+        elif e == "NBC":
+            v = [float(x) for x in st[j:j + 9]]
+            j += 9
+            t0, t1 = 0.0, float("inf")
+            try:  # optional start / stop time (Config.cpp:269-272)
+                t0 = float(st[j])
+                j += 1
+                t1 = float(st[j])
+                j += 1
+            except (IndexError, ValueError):
+                pass
+            sh.nbc.append((v[0:3], v[3:6], v[6:9], t0, t1))
         else:
             raise UnsupportedKeyword(f"shape keyword {e}")
     return sh
@@ -226,11 +239,12 @@ class AssembledScene:
     tet_ranges: list
     dirichlet: list  # (ids, lin_vel, ang_vel_deg, t0, t1)
     velocity: np.ndarray
+    neumann: list = field(default_factory=list)  # (ids, acceleration, t0, t1)
 
 
 def assemble(cfg, read_mesh):
     """main.cpp:880-1198: transform every shape (R (p * scale) + translate), concatenate, select Dirichlet nodes per shape."""
-    Vs, Ts, SFs, nr, tr, dirichlet = [], [], [], [0], [0], []
+    Vs, Ts, SFs, nr, tr, dirichlet, neumann = [], [], [], [0], [0], [], []
     for sh in cfg.shapes:
         V, T, SF = read_mesh(sh.path)
         V = (V * sh.scale) @ _rot(sh.rotate_deg).T + sh.translate
@@ -239,6 +253,10 @@ def assemble(cfg, read_mesh):
             ids = _scene.select_dirichlet(V, SF, rel_min, rel_max)
             if len(ids):
                 dirichlet.append((ids + off, lin, ang, t0, t1))
+        for rel_min, rel_max, acc, t0, t1 in sh.nbc:  # same vertex selection (main.cpp:1057-1068)
+            ids = _scene.select_dirichlet(V, SF, rel_min, rel_max)
+            if len(ids):
+                neumann.append((ids + off, acc, t0, t1))
         if sh.lin_vel is not None or sh.ang_vel_deg is not None:  # scripted component: every node moves (AnimScripter.cpp:1413-1435)
             ids = np.arange(V.shape[0], dtype=np.int32) + off
             dirichlet.append((ids, sh.lin_vel or (0, 0, 0), sh.ang_vel_deg or (0, 0, 0), 0.0, float("inf")))
@@ -265,7 +283,7 @@ def assemble(cfg, read_mesh):
         v = np.array(sh.init_vel[0]) + np.cross(w, V[a:b] - ctr)
         v[fixed[a:b]] = 0.0
         vel[a:b] = v
-    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel)
+    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann)
 
 
 def apply(sc, be):
@@ -290,6 +308,8 @@ def apply(sc, be):
         be.set_friction(cfg.self_fric, cfg.fric_iter_amt, cfg.eps_v)
     for ids, lin, ang, t0, t1 in sc.dirichlet:
         be.add_dirichlet(ids, lin_vel=lin, ang_vel_deg=ang, t0=t0, t1=t1)
+    for ids, acc, t0, t1 in sc.neumann:
+        be.add_neumann(ids, acc, t0=t0, t1=t1)
     if cfg.script == "twist":
         left, right = _scene.border_verts(sc.V, 0.01)
         be.set_twist(left, right)

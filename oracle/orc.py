@@ -440,6 +440,13 @@ def opt_add_dirichlet(opt: "Optimizer", ids, lin_vel=(0, 0, 0), ang_vel_deg=(0, 
     lib().orc_opt_add_dirichlet(opt.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1))
 
 
+def opt_add_neumann(opt: "Optimizer", ids, accel, t0=0.0, t1=float("inf")):
+    """One `NBC bboxMin bboxMax force [t0 t1]` entry of a shape line (Config.cpp:264-280)."""
+    ids = np.ascontiguousarray(ids, dtype=np.int32)
+    a = np.ascontiguousarray(accel, dtype=np.float64)
+    lib().orc_opt_add_neumann(opt.h, C.c_int(len(ids)), _ip(ids), _dp(a), C.c_double(t0), C.c_double(t1))
+
+
 def opt_dbc_state(opt: "Optimizer"):
     out = np.zeros(4)
     lib().orc_opt_get_dbc_state(opt.h, _dp(out))

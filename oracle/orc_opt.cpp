@@ -36,6 +36,13 @@ struct orc_opt {
         bool isZero() const { return lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
     };
     std::vector<DBCGroup> dbcGroups;
+    // Mesh::NeumannBCs (Mesh.hpp:47-56): `NBC bboxMin bboxMax force [t0 t1]` of a shape line (Config.cpp:264-280); `force` is an
+    // acceleration: the terms carry the nodal mass (Optimizer.cpp:3241-3250, 3452-3461)
+    struct NBCGroup {
+        std::vector<int> ids;
+        double a[3], t0, t1;
+    };
+    std::vector<NBCGroup> nbcGroups;
     std::vector<int> baseDbcType; // types that do not come from a group (set_dbc, twist handles)
     double stepStartTime = 0, stepEndTime = 0; // AnimScripter.cpp:1406-1407
     // augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2150-2157, 2280-2350; Optimizer.cpp:1826-1828, 2168-2203)
@@ -124,6 +131,11 @@ double computeEnergyVal(orc_opt* o)
     double sum = 0;
     for (int v = 0; v < m.nV; ++v) sum += ev[v];
     E += sum;
+    for (const auto& g : o->nbcGroups) { // Optimizer.cpp:3241-3250
+        if (o->stepStartTime < g.t0 || o->stepStartTime >= g.t1) continue;
+        for (int v : g.ids)
+            if (!m.isDBC(v)) E -= o->dtSq * m.mass[v] * (m.V[v] * g.a[0] + m.V[v + m.nV] * g.a[1] + m.V[v + 2 * m.nV] * g.a[2]);
+    }
     for (size_t i = 0; i < o->planes.size(); ++i) E += hsEnergy(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa);
     if (o->selfCollision) E += contactEnergy(m, o->cs, o->dHat, o->kappa);
     if (o->fricDHat > 0.0) { // Optimizer.cpp:3357-3377
@@ -158,6 +170,12 @@ void elasticInertiaGradient(orc_opt* o, bool projectDBC, double* g)
     for (int v = 0; v < m.nV; ++v)
         if (!m.isProjectDBC(v, projectDBC))
             for (int c = 0; c < 3; ++c) g[3 * v + c] += m.mass[v] * (m.V[v + m.nV * c] - o->xTilta[v + m.nV * c]);
+    for (const auto& nb : o->nbcGroups) { // Neumann terms, Optimizer.cpp:3452-3461
+        if (o->stepStartTime < nb.t0 || o->stepStartTime >= nb.t1) continue;
+        for (int v : nb.ids)
+            if (!m.isDBC(v))
+                for (int c = 0; c < 3; ++c) g[3 * v + c] -= o->dtSq * m.mass[v] * nb.a[c];
+    }
 }
 
 // Optimizer.cpp:3409-3517
@@ -573,6 +591,16 @@ static void dbcGroupMotion(orc_opt* o, const orc_opt::DBCGroup& g)
         for (int c = 0; c < 3; ++c)
             o->searchDir[3 * v + c] += (R[3 * c] * d[0] + R[3 * c + 1] * d[1] + R[3 * c + 2] * d[2]) + ctr[c] + g.lin[c] * o->dt - m.V[v + m.nV * c];
     }
+}
+
+void orc_opt_add_neumann(orc_opt* o, int n, const int* ids, const double* accel3, double t0, double t1)
+{
+    orc_opt::NBCGroup g;
+    g.ids.assign(ids, ids + n);
+    for (int c = 0; c < 3; ++c) g.a[c] = accel3[c];
+    g.t0 = t0;
+    g.t1 = t1;
+    o->nbcGroups.push_back(g);
 }
 
 void orc_opt_add_dirichlet(orc_opt* o, int n, const int* ids, const double* lin3, const double* angRad3, double t0, double t1)

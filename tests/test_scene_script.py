@@ -48,7 +48,9 @@ def test_grammar():
     assert np.allclose(c.half_spaces[0][1], [0, 1, 0]) and c.half_spaces[0][2] == 0.5
     sh = c.shapes[0]
     assert sh.material == (2000.0, 1e8, 0.3) and sh.init_vel == ((1.0, 0.0, 0.0), (0.0, 0.0, 90.0)) and sh.lin_vel == (0.0, -1.0, 0.0)
-    for bad in ("meshCO plane.obj 0 0 0 1 1 0.1\n", "script DCOVerschoorRoller\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 NBC 0 0 0 1 1 1 0 1 0\n"):
+    c = ss.SceneConfig.parse("shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 NBC 0.9 0 0 1 1 1 0 -5 0 0.1 0.3\n")
+    assert c.shapes[0].nbc == [([0.9, 0.0, 0.0], [1.0, 1.0, 1.0], [0.0, -5.0, 0.0], 0.1, 0.3)]
+    for bad in ("meshCO plane.obj 0 0 0 1 1 0.1\n", "script DCOVerschoorRoller\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 meshSeq dir\n"):
         with pytest.raises(ss.UnsupportedKeyword):
             ss.SceneConfig.parse(bad)
 
@@ -130,6 +132,9 @@ class OracleBackend:
 
     def add_dirichlet(self, ids, **k):
         self.orc.opt_add_dirichlet(self.o, ids, **k)
+
+    def add_neumann(self, ids, acc, **k):
+        self.orc.opt_add_neumann(self.o, ids, acc, **k)
 
     def set_twist(self, l, r):
         self.o.set_twist(l, r)

@@ -271,3 +271,52 @@ def test_augmented_lagrangian_dirichlet_fallback_tracks_the_oracle(orc, gpu_lib)
     assert released >= 3
     assert np.abs(c.state()["V"][ids] - (V[ids] + [0, -0.03, 0])).max() < 1e-5
     c.close()
+
+
+# ------------------------------------------------------------------------------------------------ Neumann BCs
+def test_neumann_on_every_node_is_gravity(orc):
+    """-dt^2 m a . x on all nodes is the gravity term of x_tilde expanded: a free block under `NBC ... 0 -9.80665 0` follows the
+    same trajectory as under gravity (Optimizer.cpp:3241-3250 vs. 1236-1257)."""
+    V, F = scene.make_box(2, 1, 1, size=(1.0, 0.5, 0.5))
+    Vs = scene.jitter(V, F, rel=1e-2)
+    runs = []
+    for mode in ("gravity", "nbc"):
+        m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+        m.set_V(Vs)
+        o = orc.Optimizer(m, dt=0.01, gravity=(mode == "gravity"), nthreads=2)
+        if mode == "nbc":
+            orc.opt_add_neumann(o, np.arange(V.shape[0]), (0.0, -9.80665, 0.0))
+        o.set_rel_tol(1e-6)
+        o.precompute()
+        for _ in range(5):
+            assert o.solve_timestep(60) < 60
+        runs.append(o.state()["V"].copy())
+    assert relerr(runs[1], runs[0]) < 1e-9
+    assert runs[0][:, 1].mean() < Vs[:, 1].mean() - 1e-3  # it fell
+
+
+@pytest.mark.gpu
+def test_neumann_groups_track_the_oracle(orc, gpu_lib):
+    """A bar clamped at one end (ZERO Dirichlet group), its other end pulled by a Neumann group for two steps, then released."""
+    V, F = scene.make_bar(8, 2, 2, size=(4.0, 0.5, 1.0))
+    SF = scene.surface_tris(F)
+    Vs = scene.jitter(V, F, rel=2e-2)
+    left = scene.select_dirichlet(V, SF, (0, 0, 0), (0.01, 1, 1))
+    right = scene.select_dirichlet(V, SF, (0.9, 0, 0), (1, 1, 1))
+    pull = np.concatenate([right, left[:2]])  # Dirichlet nodes inside a Neumann group are skipped
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.02, gravity=True, nthreads=4)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.02, True)
+    orc.opt_add_dirichlet(o, left)
+    c.add_dirichlet(left)
+    orc.opt_add_neumann(o, pull, (30.0, 10.0, -5.0), t0=0.0, t1=0.03)
+    c.add_neumann(pull, (30.0, 10.0, -5.0), t0=0.0, t1=0.03)
+    o.precompute()
+    c.precompute()
+    _step_both(o, c, 4)
+    assert (c.state()["V"][right, 0] > Vs[right, 0] + 1e-3).all()
+    c.close()
