@@ -42,6 +42,9 @@ class DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
 
+SHARD_MIN_TETS = 4_000_000  # ~1.8 ms of assembly on one GPU: where splitting it starts to beat an all-reduce of gradient + CSR values
+
+
 def pmc_traffic(size):
     """HBM bytes per launch of the assembly kernel as measured with the PMC counters (same workload), or None."""
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_assembly_traffic.json")
@@ -60,6 +63,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--solver", type=int, default=0, help="0 = GPU multifrontal, 1 = rocSOLVER csrrf")
+    ap.add_argument("--shard", choices=["auto", "on", "off"], default="auto",
+                    help="N > 1: shard the element assembly over the ranks (all-reduce of gradient + CSR values per iteration); "
+                         "auto = only when the mesh is big enough for that to pay (see DESIGN.md section 6)")
     args = ap.parse_args()
 
     import torch
@@ -83,7 +89,11 @@ def main():
 
     V, F, left, right = build_scene(args.size)
     ctx = ipc_amd.Context(local_rank, solver=args.solver)
-    if distributed:
+    # The fused assembly of mat150 takes 0.06 ms; an all-reduce of its 18 MB of CSR values over xGMI costs more than that, and
+    # the factorisation (94 % of an iteration) is replicated either way.  Sharding is therefore switched on only for meshes
+    # whose assembly outweighs the exchange; below that every rank runs the whole iteration (no data-path collective).
+    sharded = distributed and (args.shard == "on" or (args.shard == "auto" and F.shape[0] >= SHARD_MIN_TETS))
+    if sharded:
         ctx.set_shard(rank, world)
 
         def hook(ptr, count, op):
@@ -170,7 +180,10 @@ def main():
                             "self-contact off, BE dt=0.04, E=2e4 nu=0.4 rho=1000 (BASELINE configs[1])",
                 "n_nodes": int(V.shape[0]), "n_tets": int(F.shape[0]), "n_dofs": int(n_rows), "nnz_upper_csr": int(nnz),
                 "linear_solver": "gpu-multifrontal-llt" if args.solver == 0 else "rocsolver-csrrf",
-                "parallelism": "single GPU" if world == 1 else f"{world} GPUs: element-sharded assembly + RCCL all-reduce, replicated factorisation",
+                "parallelism": "single GPU" if world == 1 else (
+                    f"{world} GPUs: element-sharded assembly + RCCL all-reduce, replicated factorisation" if sharded else
+                    f"{world} GPUs: replicated (assembly sharding off below {SHARD_MIN_TETS} tets: the all-reduce would cost more than "
+                    f"the {1e3 * (timers[0] + timers[1] + timers[12]) / K:.2f} ms it splits; the direct solver does not shard)"),
                 "time_steps_completed": state["steps_done"],
             },
             "split_ms_per_iter": split,
