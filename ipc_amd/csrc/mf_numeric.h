@@ -49,7 +49,11 @@ private:
     DevBuf<double> fronts_, w_, yperm_, xsol_;
     DevBuf<double> dinv_; // explicit inverses of the 32x32 diagonal blocks of L, 1024 doubles each
     DevBuf<int> idx_, idxPtr_, firstNode_, childPtr_, child_, invPtr_, inv_, newOf_, flag_;
-    DevBuf<long long> frontOff_, wOff_, aDst_, dinvOff_;
+    DevBuf<long long> frontOff_, wOff_, dinvOff_;
+    DevBuf<int> aPtr_, aSrc_, aLoc_; // entries of A per fused front: CSR source index, offset inside the LDS panel
+    DevBuf<int> bigASrc_; // entries of A of the other fronts, grouped by level: source index ...
+    DevBuf<long long> bigADst_; // ... and destination in the front buffer
+    std::vector<int> bigAOff_; // level -> first entry
     DevBuf<int4> eaDesc_;
     DevBuf<int> smallList_, bigList_;
     DevBuf<int4> desc_; // all big-front step descriptors

@@ -61,10 +61,13 @@ __device__ __forceinline__ int frontNc(const TreeView& tv, int s) { return 3 * (
 
 __global__ void k_publish_flag(const int* __restrict__ flag, int* __restrict__ mapped) { mapped[0] = flag[0]; }
 
-__global__ void k_scatter_a(int nnz, const double* __restrict__ a, const long long* __restrict__ dst, double* __restrict__ fronts)
+// A entries of the fronts that go through the multi-workgroup path: F[dst] += a[src] after the extend-add of their level has
+// WRITTEN every lower-triangle entry (no memset of the front buffer: each entry that is ever read is written first)
+__global__ void k_scatter_big(int cnt, const int* __restrict__ src, const long long* __restrict__ dst, const double* __restrict__ a,
+    double* __restrict__ fronts)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < nnz) fronts[dst[k]] = a[k];
+    if (k < cnt) fronts[dst[k]] += a[src[k]];
 }
 
 // desc = (parent front, ti, tj, 0): one 64 x 64 tile (ti >= tj) of the parent.  Per child the parent-row / parent-column ->
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int J = j0 + 16 * wv + q;
-            if (J <= I && sum[q] != 0.0) F[I + (long long)N * J] += sum[q];
+            if (J <= I) F[I + (long long)N * J] = sum[q]; // write, not accumulate: the fronts are never zero-filled
         }
     }
 }
@@ -157,7 +160,13 @@ __device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lan
     bool bad = false;
     double row[NB];
 #pragma unroll
-    for (int k = 0; k < NB; ++k) row[k] = (lane < w && k <= lane && k < w) ? blk[k * ld + (lane & (NB - 1))] : 0.0;
+    for (int k = 0; k < NB; ++k) {
+        row[k] = 0.0;
+        if (k < w) { // uniform: columns >= w may lie outside the caller's LDS block, no address is formed for them
+            const double v = blk[k * ld + (lane & (NB - 1))];
+            row[k] = (lane < w && k <= lane) ? v : 0.0;
+        }
+    }
     double myRd = 0.0;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -225,36 +234,54 @@ __device__ __forceinline__ void wave_trinv32(const double* rows, int ld, int lan
 // behind it, so the FMAs of one k are independent).  L(c, k) = blk[k * ld + c], 1 / L(k, k) = rdiag[k]; both LDS broadcasts.
 // RW rows per thread share every LDS read: the broadcasts (one 64-lane return per FMA otherwise) are what bounds this step.
 template <int RW>
-__device__ __forceinline__ void row_trsm32(double (&x)[RW][NB], const double* blk, int ld, const double* rdiag)
+__device__ __forceinline__ void row_trsm32(double (&x)[RW][NB], const double* blk, int ld, const double* rdiag, int w = NB)
 {
     // Software pipeline: the LDS reads of column k + 1 are issued at the top of step k and consumed one step later.  Their
     // addresses are made to depend on x[0][k] (final once step k - 1 has swept it): with compile-time LDS addresses the
     // scheduler otherwise issues all 496 reads up front and spills ~1000 registers, and without the look-ahead every step
-    // would wait out one LDS round trip.
+    // would wait out one LDS round trip.  Columns >= w (uniform) are never touched: they may lie outside the caller's block.
     double lc[NB], ln[NB];
     double rdc = rdiag[0], rdn = 0.0;
 #pragma unroll
     for (int c = 1; c < NB; ++c) lc[c] = blk[c];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
-        if (k + 1 < NB) {
-            int z;
-            asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[0][k])));
-            const double* lk = blk + (k + 1) * ld + z;
-            rdn = rdiag[k + 1 + z];
+        if (k < w) {
+            if (k + 1 < w) {
+                int z;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[0][k])));
+                const double* lk = blk + (k + 1) * ld + z;
+                rdn = rdiag[k + 1 + z];
 #pragma unroll
-            for (int c = k + 2; c < NB; ++c) ln[c] = lk[c];
+                for (int c = k + 2; c < NB; ++c) ln[c] = lk[c];
+            }
+#pragma unroll
+            for (int h = 0; h < RW; ++h) x[h][k] *= rdc;
+#pragma unroll
+            for (int c = k + 1; c < NB; ++c) {
+#pragma unroll
+                for (int h = 0; h < RW; ++h) x[h][c] -= x[h][k] * lc[c];
+            }
+#pragma unroll
+            for (int c = k + 2; c < NB; ++c) lc[c] = ln[c];
+            rdc = rdn;
         }
+    }
+}
+
+// Same solve for the fused single-workgroup kernel, where several waves per SIMD hide the LDS latency: no prefetch arrays
+// (the pipelined version holds 3 x 32 doubles per thread, which alone caps the occupancy at one or two waves per SIMD).
+__device__ __forceinline__ void row_trsm32_lean(double (&x)[NB], const double* blk, int ld, const double* rdiag, int w)
+{
 #pragma unroll
-        for (int h = 0; h < RW; ++h) x[h][k] *= rdc;
+    for (int k = 0; k < NB; ++k) {
+        if (k < w) { // uniform
+            x[k] *= rdiag[k];
+            const double* lk = blk + k * ld;
 #pragma unroll
-        for (int c = k + 1; c < NB; ++c) {
-#pragma unroll
-            for (int h = 0; h < RW; ++h) x[h][c] -= x[h][k] * lc[c];
+            for (int c = k + 1; c < NB; ++c)
+                if (c < w) x[c] -= x[k] * lk[c];
         }
-#pragma unroll
-        for (int c = k + 2; c < NB; ++c) lc[c] = ln[c];
-        rdc = rdn;
     }
 }
 
@@ -264,7 +291,12 @@ __device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int
 {
     for (int e = tid; e < NB * NB; e += nthreads) {
         const int k = e >> 5, r = e & 31;
-        slot[e] = (k < w && r < w) ? (r > k ? blk[k * ld + r] : (r == k ? rdiag[k] : 0.0)) : (r == k ? 1.0 : 0.0);
+        double v = (r == k) ? 1.0 : 0.0;
+        if (k < w && r < w) {
+            if (r > k) v = blk[k * ld + r];
+            else v = (r == k) ? rdiag[k] : 0.0;
+        }
+        slot[e] = v;
     }
 }
 
@@ -282,65 +314,107 @@ __global__ __launch_bounds__(64) void k_invert_blocks(double* __restrict__ dinv)
     for (int e = tid; e < NB * NB; e += 64) blk[e] = Xs[(e & 31) * LDI + (e >> 5)]; // blk[c * 32 + r] = X(r, c)
 }
 
-// One workgroup factors the leading nc columns of one small front and forms its Schur complement in place.
-__global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ list, TreeView tv, double* __restrict__ fronts,
+// Fused path of the fronts whose nc own columns fit into LDS (every front of the lower tree levels): ONE workgroup assembles
+// the front (children's update matrices gathered through their inverse index maps + the entries of A), factors the nc columns
+// in LDS and writes the factor panel and the Schur complement -- each exactly once.  The front never exists in HBM in its
+// assembled form: no zero-fill, no extend-add pass, no read-modify-write of the update matrix.  (Before: memset + scatter +
+// extend-add + factor kernels, three to four passes over every front of the lower levels, which cost more than the top of
+// the tree.)
+//   P[k * N + r] = column k (< nc) of the front, rows 0..N (k-major: a wave reads 64 consecutive rows)
+//   cm[q * N + I] = scalar index of parent-local row I inside child q's front, or -1
+constexpr int FUSED_MAX_KIDS = 8;
+__global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ list, TreeView tv, const int* __restrict__ aPtr,
+    const int* __restrict__ aSrc, const int* __restrict__ aLoc, const double* __restrict__ a, double* __restrict__ fronts,
     double* __restrict__ dinv, int* __restrict__ flag)
 {
-    extern __shared__ double P[]; // NB panel columns, k-major: P[k * m + r]
+    extern __shared__ double P[];
     __shared__ double rdiag[NB];
+    __shared__ const double* cF[FUSED_MAX_KIDS];
+    __shared__ int cN[FUSED_MAX_KIDS];
     const int s = list[blockIdx.x];
     const int N = frontN(tv, s);
     const int nc = frontNc(tv, s);
     double* F = fronts + tv.frontOff[s];
     double* dblk = dinv + tv.dinvOff[s] * (NB * NB);
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int cp0 = tv.childPtr[s];
+    const int nk = tv.childPtr[s + 1] - cp0;
+    int* cm = reinterpret_cast<int*>(P + (size_t)nc * N);
     bool bad = false;
 
+    // ---- index maps of the children
+    if (tid < nk) {
+        const int c = tv.child[cp0 + tid];
+        cF[tid] = fronts + tv.frontOff[c];
+        cN[tid] = frontN(tv, c);
+    }
+    for (int q = 0; q < nk; ++q) {
+        const int c = tv.child[cp0 + q];
+        const int* inv = tv.inv + tv.invPtr[c];
+        const int ncc = frontNc(tv, c);
+        for (int I = tid; I < N; I += WG) {
+            const int In = I / 3;
+            const int ic = inv[In];
+            cm[q * N + I] = ic >= 0 ? ncc + 3 * ic + (I - 3 * In) : -1;
+        }
+    }
+    __syncthreads();
+    // ---- own columns: children sums (lower triangle), zeros above the diagonal
+    for (int J = wv; J < nc; J += WG / 64) {
+        for (int I = lane; I < N; I += 64) {
+            double v = 0.0;
+            if (I >= J) {
+                for (int q = 0; q < nk; ++q) {
+                    const int r = cm[q * N + I], cc = cm[q * N + J];
+                    if (r >= 0 && cc >= 0) v += cF[q][r + (long long)cN[q] * cc];
+                }
+            }
+            P[J * N + I] = v;
+        }
+    }
+    __syncthreads();
+    // ---- entries of A (every destination is distinct)
+    for (int e = aPtr[s] + tid; e < aPtr[s + 1]; e += WG) P[aLoc[e]] += a[aSrc[e]];
+    __syncthreads();
+
+    // ---- factor the nc columns, 32 at a time, right-looking inside LDS
     for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
         const int w = min(NB, nc - kb);
-        const int m = N - kb;
-        for (int e = tid; e < NB * m; e += WG) {
-            const int k = e / m, r = e - k * m;
-            P[e] = (k < w && r >= k) ? F[(kb + r) + (long long)N * (kb + k)] : 0.0;
-        }
+        double* Pk = P + (size_t)kb * N + kb; // Pk[k * N + q] = F(kb + q, kb + k)
+        if (tid < 64) bad |= wave_potrf32(Pk, N, w, tid, rdiag);
         __syncthreads();
-        if (tid < 64) bad |= wave_potrf32(P, m, w, tid, rdiag);
-        __syncthreads();
-        store_pivot_block(P, m, w, rdiag, dblk, tid, WG);
+        store_pivot_block(Pk, N, w, rdiag, dblk, tid, WG);
         // rows below the pivot block: X L11^T = A21, one row per thread
-        for (int r = w + tid; r < m; r += WG) {
-            double x[1][NB];
+        for (int r = kb + w + tid; r < N; r += WG) {
+            double x[NB];
 #pragma unroll
-            for (int k = 0; k < NB; ++k) x[0][k] = P[k * m + r];
-            row_trsm32<1>(x, P, m, rdiag);
+            for (int k = 0; k < NB; ++k) x[k] = (k < w) ? P[(kb + k) * N + r] : 0.0;
+            row_trsm32_lean(x, Pk, N, rdiag, w);
 #pragma unroll
-            for (int k = 0; k < NB; ++k) P[k * m + r] = x[0][k];
+            for (int k = 0; k < NB; ++k)
+                if (k < w) P[(kb + k) * N + r] = x[k];
         }
         __syncthreads();
-        for (int e = tid; e < w * m; e += WG) {
-            const int k = e / m, r = e - k * m;
-            if (r >= k) F[(kb + r) + (long long)N * (kb + k)] = P[e];
-        }
-        // Schur update of everything to the right: 4x4 register tiles, operands from LDS
-        const int mt = m - w;
-        const int ntile = (mt + 3) >> 2;
-        const int ty = tid & 15, tx = tid >> 4;
-        for (int tc = tx; tc < ntile; tc += 16) {
-            for (int tr = ty; tr < ntile; tr += 16) {
+        // the own columns to the right of this panel (rows >= column): 4 x 4 register tiles, operands and result in LDS
+        const int c0 = kb + w;
+        if (c0 < nc) {
+            const int ntc = (nc - c0 + 3) >> 2, ntr = (N - c0 + 3) >> 2;
+            for (int t = tid; t < ntc * ntr; t += WG) {
+                const int tc = t / ntr, tr = t - tc * ntr;
                 if (tr < tc) continue;
-                const int i0 = w + 4 * tr, j0 = w + 4 * tc;
+                const int i0 = c0 + 4 * tr, j0 = c0 + 4 * tc;
                 double acc[4][4];
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
                 for (int k = 0; k < w; ++k) {
-                    const double* pk = P + k * m;
+                    const double* pk = P + (size_t)(kb + k) * N;
                     double av[4], bv[4];
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
-                        av[ii] = (i0 + ii < m) ? pk[i0 + ii] : 0.0;
-                        bv[ii] = (j0 + ii < m) ? pk[j0 + ii] : 0.0;
+                        av[ii] = (i0 + ii < N) ? pk[i0 + ii] : 0.0;
+                        bv[ii] = (j0 + ii < nc) ? pk[j0 + ii] : 0.0;
                     }
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii)
@@ -350,16 +424,76 @@ __global__ __launch_bounds__(WG) void k_factor_front(const int* __restrict__ lis
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int j = j0 + jj;
-                    if (j >= m) continue;
+                    if (j >= nc) continue;
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
                         const int i = i0 + ii;
-                        if (i < m && i >= j) F[(kb + i) + (long long)N * (kb + j)] -= acc[ii][jj];
+                        if (i < N && i >= j) P[(size_t)j * N + i] -= acc[ii][jj];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- the factor panel goes to HBM once (the solves read it)
+    for (int J = wv; J < nc; J += WG / 64)
+        for (int I = J + lane; I < N; I += 64) F[I + (long long)N * J] = P[J * N + I];
+    // ---- Schur complement: S = (children) - L21 L21^T, written once.  16 x 16 thread grid of 4 x 4 tiles: a thread column owns
+    // four consecutive rows, so that the 16 threads ty = 0..15 store 512 contiguous bytes per column.
+    {
+        const int mt = N - nc;
+        const int ntile = (mt + 3) >> 2;
+        const int ty = tid & 15, tx = tid >> 4;
+        for (int tc = tx; tc < ntile; tc += 16) {
+            for (int tr = ty; tr < ntile; tr += 16) {
+                if (tr < tc) continue;
+                const int i0 = nc + 4 * tr, j0 = nc + 4 * tc;
+                double acc[4][4];
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
+                for (int k = 0; k < nc; ++k) {
+                    const double* pk = P + (size_t)k * N;
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        av[ii] = (i0 + ii < N) ? pk[i0 + ii] : 0.0;
+                        bv[ii] = (j0 + ii < N) ? pk[j0 + ii] : 0.0;
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+                }
+                for (int q = 0; q < nk; ++q) {
+                    const double* Fc = cF[q];
+                    const long long Nc = cN[q];
+                    const int* m = cm + q * N;
+                    int rr[4], cc[4];
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        rr[ii] = (i0 + ii < N) ? m[i0 + ii] : -1;
+                        cc[ii] = (j0 + ii < N) ? m[j0 + ii] : -1;
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                        for (int ii = 0; ii < 4; ++ii)
+                            if (rr[ii] >= 0 && cc[jj] >= 0 && rr[ii] >= cc[jj]) acc[ii][jj] -= Fc[rr[ii] + Nc * cc[jj]];
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = j0 + jj;
+                    if (j >= N) continue;
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        const int i = i0 + ii;
+                        if (i < N && i >= j) F[i + (long long)N * j] = -acc[ii][jj];
                     }
                 }
             }
         }
-        __syncthreads();
     }
     if (bad) atomicOr(flag, 1);
 }
@@ -878,6 +1012,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     ns_ = sym.ns;
     nLevels_ = (int)sym.levelPtr.size() - 1;
     fronts_.alloc((size_t)sym.frontOff[ns_]);
+    fronts_.zero(stream); // once per analysis: the numeric phase writes every entry it reads, this only keeps never-read padding finite
     w_.alloc((size_t)sym.wOff[ns_]);
     yperm_.alloc((size_t)sym.n);
     xsol_.alloc((size_t)sym.n);
@@ -894,8 +1029,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         frontOff_.upload(t, stream);
         std::vector<long long> u(sym.wOff.begin(), sym.wOff.end());
         wOff_.upload(u, stream);
-        std::vector<long long> d(sym.aDst.begin(), sym.aDst.end());
-        aDst_.upload(d, stream);
         std::vector<long long> di(ns_ + 1, 0);
         for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
         dinvOff_.upload(di, stream);
@@ -905,8 +1038,55 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     flag_.alloc(1);
     hflag_.alloc(4);
 
-    int bigN = 96; // fronts wider than this go through the level-batched multi-workgroup kernels
-    if (const char* e = std::getenv("IPCGPU_MF_BIGN")) bigN = std::max(NB + 1, std::min(448, std::atoi(e)));
+    // A front whose nc own columns (plus the index maps of its children) fit into LDS takes the fused single-workgroup path;
+    // the others go through the level-batched multi-workgroup kernels.
+    size_t fusedLds = 112 * 1024;
+    if (const char* e = std::getenv("IPCGPU_MF_FUSED_KB")) fusedLds = (size_t)std::max(8, std::min(150, std::atoi(e))) * 1024;
+    auto ldsOf = [&](int s) {
+        const size_t kids = (size_t)(sym.childPtr[s + 1] - sym.childPtr[s]);
+        return ((size_t)sym.nc(s) * sym.N(s) + 64) * sizeof(double) + kids * sym.N(s) * sizeof(int);
+    };
+    auto isFused = [&](int s) { return sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds; };
+    // entries of A grouped by owning front: (source index, offset inside the LDS panel) for the fused fronts,
+    // (source index, offset in the front buffer) per level for the others
+    {
+        const size_t nnz = sym.aDst.size();
+        std::vector<int> aPtr(ns_ + 1, 0);
+        std::vector<char> fused(ns_);
+        for (int s = 0; s < ns_; ++s) fused[s] = isFused(s);
+        for (size_t k = 0; k < nnz; ++k)
+            if (fused[sym.aFront[k]]) aPtr[sym.aFront[k] + 1]++;
+        for (int s = 0; s < ns_; ++s) aPtr[s + 1] += aPtr[s];
+        std::vector<int> aSrc(std::max<size_t>(aPtr[ns_], 1)), aLoc(std::max<size_t>(aPtr[ns_], 1));
+        std::vector<int> pos(aPtr.begin(), aPtr.end() - 1);
+        std::vector<int> bigCnt(nLevels_ + 1, 0);
+        for (size_t k = 0; k < nnz; ++k) {
+            const int s = sym.aFront[k];
+            if (fused[s]) {
+                const int64_t off = sym.aDst[k] - sym.frontOff[s]; // row + N * column, column < nc
+                aSrc[pos[s]] = (int)k;
+                aLoc[pos[s]++] = (int)off;
+            }
+            else bigCnt[sym.level[s] + 1]++;
+        }
+        for (int l = 0; l < nLevels_; ++l) bigCnt[l + 1] += bigCnt[l];
+        bigAOff_.assign(bigCnt.begin(), bigCnt.end());
+        std::vector<int> bSrc(std::max(bigCnt[nLevels_], 1));
+        std::vector<long long> bDst(std::max(bigCnt[nLevels_], 1));
+        std::vector<int> bpos(bigCnt.begin(), bigCnt.end() - 1);
+        for (size_t k = 0; k < nnz; ++k) {
+            const int s = sym.aFront[k];
+            if (fused[s]) continue;
+            const int q = bpos[sym.level[s]]++;
+            bSrc[q] = (int)k;
+            bDst[q] = sym.aDst[k];
+        }
+        aPtr_.upload(aPtr, stream);
+        aSrc_.upload(aSrc, stream);
+        aLoc_.upload(aLoc, stream);
+        bigASrc_.upload(bSrc, stream);
+        bigADst_.upload(bDst, stream);
+    }
     plan_.assign(nLevels_, LevelPlan());
     std::vector<int> smallList, bigList;
     std::vector<int4> ea;
@@ -917,7 +1097,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<int> small, big;
         for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
             const int s = sym.levelFronts[i];
-            (sym.N(s) <= bigN ? small : big).push_back(s);
+            (isFused(s) ? small : big).push_back(s);
         }
         // heaviest first so the tail of the level is made of short jobs
         std::sort(small.begin(), small.end(), [&](int a, int b) { return sym.N(a) > sym.N(b); });
@@ -931,7 +1111,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         P.bigFronts.off = (int)bigList.size();
         P.bigFronts.cnt = (int)big.size();
         bigList.insert(bigList.end(), big.begin(), big.end());
-        P.smallLds = (size_t)(NB * maxN + 8) * sizeof(double);
+        P.smallLds = 0;
+        for (int s : small) P.smallLds = std::max(P.smallLds, ldsOf(s));
         P.solveLds = (size_t)std::max(maxN, 1) * sizeof(double);
         P.triLds = (size_t)std::max(maxNc, 1) * sizeof(double);
         {
@@ -945,9 +1126,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         maxTriLds = std::max(maxTriLds, P.triLds);
         // extend-add descriptors (fronts with children only): lower-triangular 64 x 64 tiles of the parent
         P.ea.off = (int)ea.size();
-        for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
-            const int s = sym.levelFronts[i];
-            if (sym.childPtr[s + 1] == sym.childPtr[s]) continue;
+        for (int s : big) { // every lower-triangle tile is written (children sums or zeros): the fronts are never zero-filled
             const int nt = (sym.N(s) + TS - 1) / TS;
             for (int ti = 0; ti < nt; ++ti)
                 for (int tj = 0; tj <= ti; ++tj) ea.push_back(make_int4(s, ti, tj, 0));
@@ -1005,7 +1184,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (desc.empty()) desc.push_back(make_int4(0, 0, 0, 0));
     desc_.upload(desc.data(), desc.size(), stream);
     if (maxSmallLds > 48 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_factor_front, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
     if (maxSolveLds > 48 * 1024) {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
@@ -1066,16 +1245,19 @@ void MfNumeric::enqueueFactor(const double* a_dev)
 {
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
-    fronts_.zero(stream_);
     flag_.zero(stream_);
-    const int nnz = (int)sym.aDst.size();
-    hipLaunchKernelGGL(k_scatter_a, dim3((nnz + 255) / 256), dim3(256), 0, stream_, nnz, a_dev, aDst_.p, fronts_.p);
     for (int l = 0; l < nLevels_; ++l) {
         const LevelPlan& P = plan_[l];
-        if (P.ea.cnt) hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, tv, fronts_.p);
         if (P.small.cnt)
-            hipLaunchKernelGGL(k_factor_front, dim3(P.small.cnt), dim3(WG), P.smallLds, stream_, smallList_.p + P.small.off, tv, fronts_.p,
-                dinv_.p, flag_.p);
+            hipLaunchKernelGGL(k_front_fused, dim3(P.small.cnt), dim3(WG), P.smallLds, stream_, smallList_.p + P.small.off, tv, aPtr_.p,
+                aSrc_.p, aLoc_.p, a_dev, fronts_.p, dinv_.p, flag_.p);
+        if (P.ea.cnt) {
+            hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, tv, fronts_.p);
+            const int na = bigAOff_[l + 1] - bigAOff_[l];
+            if (na)
+                hipLaunchKernelGGL(k_scatter_big, dim3((na + 255) / 256), dim3(256), 0, stream_, na, bigASrc_.p + bigAOff_[l],
+                    bigADst_.p + bigAOff_[l], a_dev, fronts_.p);
+        }
         for (const Range& R : P.step)
             if (R.cnt) hipLaunchKernelGGL(k_big_step, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p);
         if (P.schur.cnt) hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, tv, fronts_.p);

@@ -353,10 +353,12 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     }
     // user-matrix entry -> front slot (lower triangle of the permuted matrix)
     o.aDst.resize(ia[n]);
-    auto slot = [&](int r, int c) -> int64_t {
+    o.aFront.resize(ia[n]);
+    auto slot = [&](int r, int c, int* owner = nullptr) -> int64_t {
         const int pr = 3 * o.newOf[r / 3] + r % 3, pc = 3 * o.newOf[c / 3] + c % 3;
         const int i = std::max(pr, pc), j = std::min(pr, pc);
         const int s = frontOfNode[j / 3];
+        if (owner) *owner = s;
         const int f = o.firstNode[s], l = o.firstNode[s + 1];
         const int64_t N = o.N(s);
         int64_t lr;
@@ -387,6 +389,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
                 o.aDst[row1] = d0 + N + 1;
                 o.aDst[row1 + 1] = d0 + N + 2;
                 o.aDst[row2] = d0 + 2 * N + 2;
+                o.aFront[base] = o.aFront[base + 1] = o.aFront[base + 2] = o.aFront[row1] = o.aFront[row1 + 1] = o.aFront[row2] = s;
             }
             for (int q = 3; q < L; q += 3) {
                 const int w = ja[base + q] / 3;
@@ -400,6 +403,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
                     o.aDst[base + q + b] = d0 + db * b;
                     o.aDst[row1 + q - 1 + b] = d0 + da + db * b;
                     o.aDst[row2 + q - 2 + b] = d0 + 2 * da + db * b;
+                    o.aFront[base + q + b] = o.aFront[row1 + q - 1 + b] = o.aFront[row2 + q - 2 + b] = s;
                 }
             }
         }
@@ -423,7 +427,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     }
     else {
         for (int r = 0; r < n; ++r)
-            for (int k = ia[r]; k < ia[r + 1]; ++k) o.aDst[k] = slot(r, ja[k]);
+            for (int k = ia[r]; k < ia[r + 1]; ++k) o.aDst[k] = slot(r, ja[k], &o.aFront[k]);
     }
 }
 

@@ -25,6 +25,7 @@ struct MfSymbolic {
     std::vector<int64_t> wOff; // ns+1, offsets of the per-front solve work vectors (length N)
     std::vector<int> levelPtr, levelFronts; // fronts grouped by level (leaves = level 0)
     std::vector<int64_t> aDst; // per CSR entry of the user matrix: destination offset in the front buffer
+    std::vector<int> aFront; // per CSR entry: the front that owns it (the front of its column in the permuted lower triangle)
     int64_t nnzL = 0;
     double flops = 0;
     int maxN = 0;
