@@ -31,7 +31,21 @@ def _needs(obj, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+    """variant / extra_flags: experiment builds (tools/): objects under _obj_<variant>, library libipcgpu_<variant>.so,
+    selected at load time with IPCGPU_LIB_VARIANT=<variant>.  The product build is the default (no variant)."""
+    global OBJ, LIB
+    obj0, lib0 = OBJ, LIB
+    if variant:
+        OBJ = os.path.join(HERE, "_obj_" + variant)
+        LIB = os.path.join(HERE, f"libipcgpu_{variant}.so")
+    try:
+        return _build(force, verbose, list(extra_flags))
+    finally:
+        OBJ, LIB = obj0, lib0
+
+
+def _build(force, verbose, extra):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "ipcgpu.h"))
@@ -46,7 +60,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             # FMA contraction: on for the fp64 throughput kernels (parity there is a 1e-10 tolerance), off for
             # files that hold exact-comparison predicates (contact typing) and for host code
             contract = "fast" if src in FMA_OK else "off"
-            cmd = [HIPCC] + FLAGS + [f"-ffp-contract={contract}"] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
+            cmd = [HIPCC] + FLAGS + extra + [f"-ffp-contract={contract}"] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
             jobs.append(cmd)
 
     def run(cmd):

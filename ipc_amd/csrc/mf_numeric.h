@@ -35,22 +35,48 @@ private:
     struct LevelPlan {
         Range small; // into smallList_
         size_t smallLds = 0, solveLds = 0, triLds = 0, bwdLds = 0;
+        int smallThreads = 256; // workgroup size of the fused kernel on this level
         Range ea; // extend-add descriptors
         Range bigFronts; // into bigList_
         std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1
         Range schur; // one-pass Schur complement tiles of the big fronts
         Range fwdRect, bwdInit; // descriptors of the row-/column-parallel halves of the big-front solves
+        Range bigTri; // into triList_: big fronts whose triangle is swept by one workgroup (no explicit inverse)
+        Range xinvFwd, xinvBwd; // into xinvDesc_: row / column blocks of the fronts with an explicit inverse
     };
     const MfSymbolic* sym_ = nullptr;
     hipStream_t stream_ = nullptr;
     int ns_ = 0, nLevels_ = 0;
     long long nDiagBlocks_ = 0;
     std::vector<LevelPlan> plan_;
-    DevBuf<double> fronts_, w_, yperm_, xsol_;
+    DevBuf<double> fronts_, w_, yperm_, bperm_, xsol_;
+    // explicit inverses X = L11^-1 of the widest fronts (and the scratch T of their recursive doubling)
+    DevBuf<double> xinvX_, xinvT_;
+    DevBuf<long long> xinvOff_;
+    DevBuf<int4> xinvDesc_;
+    DevBuf<int> triList_;
+    struct XinvLevel {
+        Range blocks; // into invBlockList_: diagonal blocks of the level's inverse fronts
+        Range init; // into xinvDesc_
+        std::vector<std::pair<Range, Range>> rounds; // per doubling: the two GEMM launches (descriptor pairs)
+    };
+    std::vector<XinvLevel> xinvLevel_;
+    Range plainBlocks_; // diagonal blocks of all other fronts (inverted at the end of the factorisation)
+    DevBuf<int> invBlockList_;
+    hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
+    hipEvent_t evSide_ = nullptr;
+    std::vector<hipEvent_t> evLevel_, evInvDone_;
+    bool sidePending_ = false; // the last factorisation left work on the side stream that nothing has waited for yet
+    void enqueueInverses(int level, hipStream_t st);
+    size_t xinvLds_ = 8;
     DevBuf<double> dinv_; // explicit inverses of the 32x32 diagonal blocks of L, 1024 doubles each
     DevBuf<int> idx_, idxPtr_, firstNode_, childPtr_, child_, invPtr_, inv_, newOf_, flag_;
     DevBuf<long long> frontOff_, wOff_, dinvOff_;
-    DevBuf<int> aPtr_, aSrc_, aLoc_; // entries of A per fused front: CSR source index, offset inside the LDS panel
+    DevBuf<int> aSrc_, aLoc_; // entries of A per fused front: CSR source index, offset inside the LDS panel
+    DevBuf<double> aPerm_; // values of A gathered into fused-front order at the start of every factorisation
+    int nFusedA_ = 0;
+    std::vector<int> aPtrHost_; // front -> first entry (goes into the packed descriptors)
+    DevBuf<int> fdesc_; // packed descriptors of the fused fronts (64 ints each, launch order)
     DevBuf<int> bigASrc_; // entries of A of the other fronts, grouped by level: source index ...
     DevBuf<long long> bigADst_; // ... and destination in the front buffer
     std::vector<int> bigAOff_; // level -> first entry

@@ -24,7 +24,9 @@
 // No vendor BLAS is involved: rocSOLVER's potrf / rocBLAS' trsm+syrk cost ~150 tiny launches per front.
 #include "mf_numeric.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 namespace ipcgpu {
 
@@ -60,6 +62,13 @@ __device__ __forceinline__ int frontN(const TreeView& tv, int s) { return 3 * (t
 __device__ __forceinline__ int frontNc(const TreeView& tv, int s) { return 3 * (tv.firstNode[s + 1] - tv.firstNode[s]); }
 
 __global__ void k_publish_flag(const int* __restrict__ flag, int* __restrict__ mapped) { mapped[0] = flag[0]; }
+
+// values of A in fused-front order: the fused kernel then reads its entries contiguously instead of chasing a[aSrc[e]]
+__global__ void k_gather_a(int cnt, const int* __restrict__ src, const double* __restrict__ a, double* __restrict__ aP)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < cnt) aP[k] = a[src[k]];
+}
 
 // A entries of the fronts that go through the multi-workgroup path: F[dst] += a[src] after the extend-add of their level has
 // WRITTEN every lower-triangle entry (no memset of the front buffer: each entry that is ever read is written first)
@@ -279,8 +288,7 @@ __device__ __forceinline__ void row_trsm32_lean(double (&x)[NB], const double* b
             x[k] *= rdiag[k];
             const double* lk = blk + k * ld;
 #pragma unroll
-            for (int c = k + 1; c < NB; ++c)
-                if (c < w) x[c] -= x[k] * lk[c];
+            for (int c = k + 1; c < NB; ++c) x[c] -= x[k] * lk[c]; // c >= w: reads stay inside the caller's block, results unused
         }
     }
 }
@@ -301,11 +309,11 @@ __device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int
 }
 
 // One wave per 32x32 block: L11 (k-major) -> L11^-1 (column-major), in place.
-__global__ __launch_bounds__(64) void k_invert_blocks(double* __restrict__ dinv)
+__global__ __launch_bounds__(64) void k_invert_blocks(const int* __restrict__ blockList, double* __restrict__ dinv)
 {
     __shared__ double Ls[NB * LDP];
     __shared__ double Xs[NB * LDI];
-    double* blk = dinv + (long long)blockIdx.x * (NB * NB);
+    double* blk = dinv + (long long)blockList[blockIdx.x] * (NB * NB);
     const int tid = threadIdx.x;
     for (int e = tid; e < NB * NB; e += 64) Ls[(e & 31) * LDP + (e >> 5)] = blk[e]; // transposed: row-major
     __syncthreads();
@@ -322,60 +330,90 @@ __global__ __launch_bounds__(64) void k_invert_blocks(double* __restrict__ dinv)
 // the tree.)
 //   P[k * N + r] = column k (< nc) of the front, rows 0..N (k-major: a wave reads 64 consecutive rows)
 //   cm[q * N + I] = scalar index of parent-local row I inside child q's front, or -1
+#ifdef MF_PHASE_TIMERS
+// debug build: shader-clock cycles per phase of the fused kernel, summed over workgroups (wave 0, lane 0)
+__device__ unsigned long long mf_phase_acc[16];
+#define MF_PHASE(i)                                                                       \
+    do {                                                                                  \
+        if (threadIdx.x == 0) {                                                           \
+            const long long t_ = clock64();                                               \
+            atomicAdd(&mf_phase_acc[i], (unsigned long long)(t_ - tphase_));              \
+            tphase_ = t_;                                                                 \
+        }                                                                                 \
+    } while (0)
+#else
+#define MF_PHASE(i)
+#endif
 constexpr int FUSED_MAX_KIDS = 8;
-__global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ list, TreeView tv, const int* __restrict__ aPtr,
-    const int* __restrict__ aSrc, const int* __restrict__ aLoc, const double* __restrict__ a, double* __restrict__ fronts,
+// Host-packed descriptor of a fused front, 64 ints: everything the kernel would otherwise chase through five rounds of
+// dependent loads (front list -> index pointers -> child list -> child pointers -> inverse maps) arrives in one.
+//   [0,1] front offset  [2] N  [3] nc  [4,5] first dinv block  [6] aBeg  [7] aEnd  [8] #children
+//   child q at 16 + 6 q: [0,1] front offset  [2] N  [3] nc  [4] offset of its inverse map
+constexpr int FD_STRIDE = 64;
+template <int NT>
+__global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ fdesc, const int* __restrict__ invMap,
+    const int* __restrict__ aLoc, const double* __restrict__ aP, double* __restrict__ fronts,
     double* __restrict__ dinv, int* __restrict__ flag)
 {
     extern __shared__ double P[];
     __shared__ double rdiag[NB];
-    __shared__ const double* cF[FUSED_MAX_KIDS];
-    __shared__ int cN[FUSED_MAX_KIDS];
-    const int s = list[blockIdx.x];
-    const int N = frontN(tv, s);
-    const int nc = frontNc(tv, s);
-    double* F = fronts + tv.frontOff[s];
-    double* dblk = dinv + tv.dinvOff[s] * (NB * NB);
+    __shared__ __attribute__((aligned(16))) int fd[FD_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int cp0 = tv.childPtr[s];
-    const int nk = tv.childPtr[s + 1] - cp0;
+#ifdef MF_PHASE_TIMERS
+    long long tphase_ = clock64();
+#endif
+    if (tid < FD_STRIDE) fd[tid] = fdesc[(size_t)blockIdx.x * FD_STRIDE + tid];
+    __syncthreads();
+    MF_PHASE(0);
+    const int N = fd[2], nc = fd[3], nk = fd[8];
+    double* F = fronts + *reinterpret_cast<const long long*>(fd);
+    double* dblk = dinv + *reinterpret_cast<const long long*>(fd + 4) * (NB * NB);
+    const int aBeg = fd[6], aEnd = fd[7];
     int* cm = reinterpret_cast<int*>(P + (size_t)nc * N);
     bool bad = false;
-
     // ---- index maps of the children
-    if (tid < nk) {
-        const int c = tv.child[cp0 + tid];
-        cF[tid] = fronts + tv.frontOff[c];
-        cN[tid] = frontN(tv, c);
-    }
     for (int q = 0; q < nk; ++q) {
-        const int c = tv.child[cp0 + q];
-        const int* inv = tv.inv + tv.invPtr[c];
-        const int ncc = frontNc(tv, c);
-        for (int I = tid; I < N; I += WG) {
+        const int* inv = invMap + fd[16 + 6 * q + 4];
+        const int ncc = fd[16 + 6 * q + 3];
+        for (int I = tid; I < N; I += NT) {
             const int In = I / 3;
             const int ic = inv[In];
             cm[q * N + I] = ic >= 0 ? ncc + 3 * ic + (I - 3 * In) : -1;
         }
     }
     __syncthreads();
-    // ---- own columns: children sums (lower triangle), zeros above the diagonal
-    for (int J = wv; J < nc; J += WG / 64) {
-        for (int I = lane; I < N; I += 64) {
-            double v = 0.0;
-            if (I >= J) {
-                for (int q = 0; q < nk; ++q) {
-                    const int r = cm[q * N + I], cc = cm[q * N + J];
-                    if (r >= 0 && cc >= 0) v += cF[q][r + (long long)cN[q] * cc];
+    MF_PHASE(1);
+    // ---- own columns: children sums (lower triangle), zeros above the diagonal.  The loads are unconditional (clamped
+    // address, value selected afterwards) so that all of them are in flight together.
+    for (int J = wv; J < nc; J += NT / 64) {
+        for (int I0 = 0; I0 < N; I0 += 4 * 64) {
+            double v[4] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int q = 0; q < nk; ++q) {
+                const double* Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * q);
+                const long long Nc = fd[16 + 6 * q + 2];
+                const int cc = cm[q * N + J];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int I = I0 + 64 * u + lane;
+                    const int r = (I < N) ? cm[q * N + I] : -1;
+                    const bool ok = r >= 0 && cc >= 0 && I >= J;
+                    const double x = Fc[ok ? r + Nc * cc : 0];
+                    v[u] += ok ? x : 0.0;
                 }
             }
-            P[J * N + I] = v;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int I = I0 + 64 * u + lane;
+                if (I < N) P[J * N + I] = v[u];
+            }
         }
     }
     __syncthreads();
+    MF_PHASE(2);
     // ---- entries of A (every destination is distinct)
-    for (int e = aPtr[s] + tid; e < aPtr[s + 1]; e += WG) P[aLoc[e]] += a[aSrc[e]];
+    for (int e = aBeg + tid; e < aEnd; e += NT) P[aLoc[e]] += aP[e]; // aP: the values of A gathered into front order (k_gather_a)
     __syncthreads();
+    MF_PHASE(3);
 
     // ---- factor the nc columns, 32 at a time, right-looking inside LDS
     for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
@@ -383,9 +421,10 @@ __global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ l
         double* Pk = P + (size_t)kb * N + kb; // Pk[k * N + q] = F(kb + q, kb + k)
         if (tid < 64) bad |= wave_potrf32(Pk, N, w, tid, rdiag);
         __syncthreads();
-        store_pivot_block(Pk, N, w, rdiag, dblk, tid, WG);
+        MF_PHASE(4);
+        store_pivot_block(Pk, N, w, rdiag, dblk, tid, NT);
         // rows below the pivot block: X L11^T = A21, one row per thread
-        for (int r = kb + w + tid; r < N; r += WG) {
+        for (int r = kb + w + tid; r < N; r += NT) {
             double x[NB];
 #pragma unroll
             for (int k = 0; k < NB; ++k) x[k] = (k < w) ? P[(kb + k) * N + r] : 0.0;
@@ -395,11 +434,12 @@ __global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ l
                 if (k < w) P[(kb + k) * N + r] = x[k];
         }
         __syncthreads();
+        MF_PHASE(5);
         // the own columns to the right of this panel (rows >= column): 4 x 4 register tiles, operands and result in LDS
         const int c0 = kb + w;
         if (c0 < nc) {
             const int ntc = (nc - c0 + 3) >> 2, ntr = (N - c0 + 3) >> 2;
-            for (int t = tid; t < ntc * ntr; t += WG) {
+            for (int t = tid; t < ntc * ntr; t += NT) {
                 const int tc = t / ntr, tr = t - tc * ntr;
                 if (tr < tc) continue;
                 const int i0 = c0 + 4 * tr, j0 = c0 + 4 * tc;
@@ -413,8 +453,8 @@ __global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ l
                     double av[4], bv[4];
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii) {
-                        av[ii] = (i0 + ii < N) ? pk[i0 + ii] : 0.0;
-                        bv[ii] = (j0 + ii < nc) ? pk[j0 + ii] : 0.0;
+                        av[ii] = pk[min(i0 + ii, N - 1)];
+                        bv[ii] = pk[min(j0 + ii, N - 1)];
                     }
 #pragma unroll
                     for (int ii = 0; ii < 4; ++ii)
@@ -433,18 +473,20 @@ __global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ l
                 }
             }
             __syncthreads();
+            MF_PHASE(6);
         }
     }
     // ---- the factor panel goes to HBM once (the solves read it)
-    for (int J = wv; J < nc; J += WG / 64)
+    for (int J = wv; J < nc; J += NT / 64)
         for (int I = J + lane; I < N; I += 64) F[I + (long long)N * J] = P[J * N + I];
+    MF_PHASE(7);
     // ---- Schur complement: S = (children) - L21 L21^T, written once.  16 x 16 thread grid of 4 x 4 tiles: a thread column owns
     // four consecutive rows, so that the 16 threads ty = 0..15 store 512 contiguous bytes per column.
     {
         const int mt = N - nc;
         const int ntile = (mt + 3) >> 2;
         const int ty = tid & 15, tx = tid >> 4;
-        for (int tc = tx; tc < ntile; tc += 16) {
+        for (int tc = tx; tc < ntile; tc += NT / 16) {
             for (int tr = ty; tr < ntile; tr += 16) {
                 if (tr < tc) continue;
                 const int i0 = nc + 4 * tr, j0 = nc + 4 * tc;
@@ -453,22 +495,10 @@ __global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ l
                 for (int ii = 0; ii < 4; ++ii)
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-                for (int k = 0; k < nc; ++k) {
-                    const double* pk = P + (size_t)k * N;
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        av[ii] = (i0 + ii < N) ? pk[i0 + ii] : 0.0;
-                        bv[ii] = (j0 + ii < N) ? pk[j0 + ii] : 0.0;
-                    }
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
-                }
+                // children first: their loads are in flight while the panel product runs
                 for (int q = 0; q < nk; ++q) {
-                    const double* Fc = cF[q];
-                    const long long Nc = cN[q];
+                    const double* Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * q);
+                    const long long Nc = fd[16 + 6 * q + 2];
                     const int* m = cm + q * N;
                     int rr[4], cc[4];
 #pragma unroll
@@ -479,8 +509,25 @@ __global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ l
 #pragma unroll
                     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                        for (int ii = 0; ii < 4; ++ii)
-                            if (rr[ii] >= 0 && cc[jj] >= 0 && rr[ii] >= cc[jj]) acc[ii][jj] -= Fc[rr[ii] + Nc * cc[jj]];
+                        for (int ii = 0; ii < 4; ++ii) {
+                            const bool ok = rr[ii] >= 0 && cc[jj] >= 0 && rr[ii] >= cc[jj];
+                            const double x = Fc[ok ? rr[ii] + Nc * cc[jj] : 0];
+                            acc[ii][jj] -= ok ? x : 0.0;
+                        }
+                }
+#pragma unroll 4
+                for (int k = 0; k < nc; ++k) {
+                    const double* pk = P + (size_t)k * N;
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii) {
+                        av[ii] = pk[min(i0 + ii, N - 1)];
+                        bv[ii] = pk[min(j0 + ii, N - 1)];
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
                 }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -495,6 +542,7 @@ __global__ __launch_bounds__(WG, 4) void k_front_fused(const int* __restrict__ l
             }
         }
     }
+    MF_PHASE(8);
     if (bad) atomicOr(flag, 1);
 }
 
@@ -741,9 +789,9 @@ __global__ void k_unpermute_x(int nn, const int* __restrict__ newOf, const doubl
 
 // w[I] of a front: own right-hand side rows plus what the children pushed up
 __device__ __forceinline__ double gather_w(const TreeView& tv, const long long* __restrict__ wOff, const double* __restrict__ wbuf,
-    const double* __restrict__ yperm, int s, int nc, int I)
+    const double* __restrict__ bperm, int s, int nc, int I)
 {
-    double val = (I < nc) ? yperm[3 * tv.firstNode[s] + I] : 0.0;
+    double val = (I < nc) ? bperm[3 * tv.firstNode[s] + I] : 0.0;
     const int In = I / 3, Id = I - 3 * In;
     for (int ci = tv.childPtr[s]; ci < tv.childPtr[s + 1]; ++ci) {
         const int c = tv.child[ci];
@@ -859,7 +907,8 @@ __device__ __forceinline__ void bwd_triangle(const double* __restrict__ L, int N
 }
 
 __global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, TreeView tv, const long long* __restrict__ wOff,
-    const double* __restrict__ fronts, const double* __restrict__ dinv, double* __restrict__ wbuf, double* __restrict__ yperm)
+    const double* __restrict__ fronts, const double* __restrict__ dinv, double* __restrict__ wbuf, const double* __restrict__ bperm,
+    double* __restrict__ yperm)
 {
     extern __shared__ double w[];
     const int s = list[blockIdx.x];
@@ -867,7 +916,7 @@ __global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, 
     const double* L = fronts + tv.frontOff[s];
     const int tid = threadIdx.x;
     const int col0 = 3 * tv.firstNode[s];
-    for (int I = tid; I < N; I += WG) w[I] = gather_w(tv, wOff, wbuf, yperm, s, nc, I);
+    for (int I = tid; I < N; I += WG) w[I] = gather_w(tv, wOff, wbuf, bperm, s, nc, I);
     __syncthreads();
     fwd_triangle<WG>(L, N, nc, N, dinv + tv.dinvOff[s] * (NB * NB), w, tid);
     double* wo = wbuf + wOff[s];
@@ -879,7 +928,8 @@ __global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, 
 
 // big fronts, forward: one workgroup sweeps the triangle ...
 __global__ __launch_bounds__(WGT) void k_big_fwd_tri(const int* __restrict__ list, TreeView tv, const long long* __restrict__ wOff,
-    const double* __restrict__ fronts, const double* __restrict__ dinv, const double* __restrict__ wbuf, double* __restrict__ yperm)
+    const double* __restrict__ fronts, const double* __restrict__ dinv, const double* __restrict__ wbuf, const double* __restrict__ bperm,
+    double* __restrict__ yperm)
 {
     extern __shared__ double w[];
     const int s = list[blockIdx.x];
@@ -887,7 +937,7 @@ __global__ __launch_bounds__(WGT) void k_big_fwd_tri(const int* __restrict__ lis
     const double* L = fronts + tv.frontOff[s];
     const int tid = threadIdx.x;
     const int col0 = 3 * tv.firstNode[s];
-    for (int I = tid; I < nc; I += WGT) w[I] = gather_w(tv, wOff, wbuf, yperm, s, nc, I);
+    for (int I = tid; I < nc; I += WGT) w[I] = gather_w(tv, wOff, wbuf, bperm, s, nc, I);
     __syncthreads();
     fwd_triangle<WGT>(L, N, nc, nc, dinv + tv.dinvOff[s] * (NB * NB), w, tid);
     for (int I = tid; I < nc; I += WGT) yperm[col0 + I] = w[I];
@@ -1001,10 +1051,198 @@ __global__ __launch_bounds__(WGT) void k_big_bwd_tri(const int* __restrict__ lis
     for (int I = tid; I < nc; I += WGT) xsol[col0 + I] = t[I];
 }
 
+// ---- explicit inverses of the factor triangles of the widest fronts ----------------------------------------------------
+// The nc x nc triangle of a top-level front is swept by ONE workgroup in the blocked substitution above: 3.2 MB through a
+// single CU for the root of a 45 K-node sheet, ~140 us per direction, and the top five levels make up half of the solve.
+// For fronts with nc >= XINV_MIN_NC the factorisation therefore also forms X = L11^-1 (recursive doubling on the 32 x 32
+// block inverses: X21 = -X22 (L21 X11), two batched GEMM launches per doubling), and the sweeps become two matrix-vector
+// products spread over many workgroups.  Extra work: ~nc^3 / 3 flops per front, 4 % of the factorisation.
+// X is column-major with leading dimension nc; only its lower triangle is ever read.
+struct XinvView {
+    const long long* xOff; // per front: offset of X (and of the scratch T) in their buffers, -1 when the front has none
+    double* X;
+    double* T;
+};
+
+// one workgroup per diagonal block: the 32 x 32 inverse goes from its dinv slot into X.  desc = (front, block, 0, 0)
+__global__ __launch_bounds__(256) void k_xinv_init(const int4* __restrict__ desc, TreeView tv, XinvView xv, const double* __restrict__ dinv)
+{
+    const int4 d = desc[blockIdx.x];
+    const int s = d.x, b = d.y;
+    const int nc = frontNc(tv, s);
+    const double* blk = dinv + (tv.dinvOff[s] + b) * (NB * NB); // blk[c * 32 + r] = X(r, c), identity-padded
+    double* X = xv.X + xv.xOff[s];
+    for (int e = threadIdx.x; e < NB * NB; e += 256) {
+        const int c = e >> 5, r = e & 31;
+        const int R = NB * b + r, C = NB * b + c;
+        if (R < nc && C < nc) X[R + (long long)nc * C] = blk[e];
+    }
+}
+
+// One workgroup per 32 x 32 output tile; its four waves split the k range (batch b of 16 goes to wave b mod 4, partial sums
+// combined through LDS in a fixed order) and keep the next batch of operands in flight while the matrix cores work on the
+// current one.  Operands come straight from HBM / L2 in the MFMA layout (the matrices are a few MB).  The product is formed
+// transposed, D(c, r), so that the 16 lanes of an accumulator row store 16 consecutive rows r of one column.
+// d0 = (front, r0, c0, mode), d1 = (rEnd, cEnd, kBeg, kEnd)
+//   mode 1: T(r, c)  =   sum_k L(r, k) X(k, c),  k >= c     (X11 lower triangular)
+//   mode 2: X(r, c)  = - sum_k X(r, k) T(k, c),  k <= r     (X22 lower triangular)
+__global__ __launch_bounds__(256) void k_xinv_gemm(const int4* __restrict__ desc, TreeView tv, XinvView xv, const double* __restrict__ fronts)
+{
+    __shared__ double red[4][4][256]; // [wave][16 x 16 tile][D layout: 64 lanes x 4]
+    const int4 d0 = desc[2 * blockIdx.x], d1 = desc[2 * blockIdx.x + 1];
+    const int s = d0.x, r0 = d0.y, c0 = d0.z, mode = d0.w;
+    const int rEnd = d1.x, cEnd = d1.y, kEnd = d1.w;
+    const int N = frontN(tv, s), nc = frontNc(tv, s);
+    const double* F = fronts + tv.frontOff[s];
+    double* X = xv.X + xv.xOff[s];
+    double* T = xv.T + xv.xOff[s];
+    const int wv = threadIdx.x >> 6, l = threadIdx.x & 63, lo = l & 15, hi = l >> 4;
+    f64x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+    const int cc[2] = { c0 + lo, c0 + 16 + lo };
+    const int rr[2] = { r0 + lo, r0 + 16 + lo };
+    const int rrc[2] = { min(rr[0], nc - 1), min(rr[1], nc - 1) };
+    const int ccc[2] = { min(cc[0], nc - 1), min(cc[1], nc - 1) };
+    // first k that can contribute: the triangular operand is zero before it
+    const int kBeg = (mode == 1) ? max(d1.z, c0) : d1.z;
+    const int kStop = (mode == 2) ? min(kEnd, r0 + 32) : kEnd;
+    // the two operand matrices of this mode: Bop(k, c) -> MFMA A operand, Aop(r, k) -> MFMA B operand
+    const double* Bm = (mode == 1) ? X : T;
+    const double* Am = (mode == 1) ? F : X;
+    const long long ldA = (mode == 1) ? N : nc;
+    auto fetch = [&](int k0, double (&va)[2][4], double (&vb)[2][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = k0 + 4 * ks + hi;
+            const bool kin = k < kStop;
+            const int kc = min(k, nc - 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double xb = Bm[kc + (long long)nc * ccc[q]];
+                const double xa = Am[rrc[q] + ldA * kc];
+                const bool tri = (mode == 1) ? (k >= cc[q]) : (k <= rr[q]);
+                va[q][ks] = (kin && cc[q] < cEnd && (mode == 2 || tri)) ? xb : 0.0;
+                vb[q][ks] = (kin && rr[q] < rEnd && (mode == 1 || tri)) ? xa : 0.0;
+            }
+        }
+    };
+    double va[2][4], vb[2][4], na[2][4], nb[2][4];
+    int k0 = kBeg + 16 * wv;
+    if (k0 < kStop) fetch(k0, va, vb);
+    for (; k0 < kStop; k0 += 64) {
+        const bool more = k0 + 64 < kStop;
+        if (more) fetch(k0 + 64, na, nb);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a][ks], vb[b][ks], acc[a][b], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    va[q][ks] = na[q][ks];
+                    vb[q][ks] = nb[q][ks];
+                }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wv][2 * a + b][64 * i + l] = acc[a][b][i];
+    __syncthreads();
+    // wave q finishes 16 x 16 tile q = 2 a + b
+    const int a = wv >> 1, b = wv & 1;
+    double* out = (mode == 1) ? T : X;
+    const double sgn = (mode == 1) ? 1.0 : -1.0;
+    const int r = r0 + 16 * b + lo;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + 16 * a + hi + 4 * i;
+        const double v = ((red[0][wv][64 * i + l] + red[1][wv][64 * i + l]) + red[2][wv][64 * i + l]) + red[3][wv][64 * i + l];
+        if (r < rEnd && c < cEnd) out[r + (long long)nc * c] = sgn * v;
+    }
+}
+
+// forward: y1 = X w1.  desc = (front, first row, 0, 0): 64 rows per workgroup, the four waves split the columns.
+__global__ __launch_bounds__(WG) void k_xinv_fwd(const int4* __restrict__ desc, TreeView tv, XinvView xv, const long long* __restrict__ wOff,
+    const double* __restrict__ wbuf, const double* __restrict__ bperm, double* __restrict__ yperm)
+{
+    extern __shared__ double w1[];
+    __shared__ double part[WG];
+    const int4 d = desc[blockIdx.x];
+    const int s = d.x, r0 = d.y;
+    const int nc = frontNc(tv, s);
+    const double* X = xv.X + xv.xOff[s];
+    const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
+    const int cols = min(nc, r0 + 64); // X(r, c) = 0 for c > r
+    for (int I = tid; I < cols; I += WG) w1[I] = gather_w(tv, wOff, wbuf, bperm, s, nc, I);
+    __syncthreads();
+    const int r = r0 + lane;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (r < nc) {
+        const int per = ((cols + 3) >> 2), cb = cg * per, ce = min(min(cols, cb + per), r + 1);
+        const double* Xr = X + r;
+        int c = cb;
+        for (; c + 7 < ce; c += 8) { // eight loads in flight per lane
+            double x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = Xr[(long long)nc * (c + u)];
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0 += x[u] * w1[c + u];
+                acc1 += x[u + 1] * w1[c + u + 1];
+            }
+        }
+        for (; c < ce; ++c) acc0 += Xr[(long long)nc * c] * w1[c];
+    }
+    part[tid] = acc0 + acc1;
+    __syncthreads();
+    if (cg == 0 && r < nc) yperm[3 * tv.firstNode[s] + r] = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+}
+
+// backward: x1 = X^T t with t = y1 - L21^T x2 (left in yperm by k_big_bwd_init).  desc = (front, first column, 0, 0):
+// one wave per column (contiguous reads), 16 columns per workgroup.
+__global__ __launch_bounds__(WG) void k_xinv_bwd(const int4* __restrict__ desc, TreeView tv, XinvView xv, const double* __restrict__ yperm,
+    double* __restrict__ xsol)
+{
+    extern __shared__ double tt[];
+    const int4 d = desc[blockIdx.x];
+    const int s = d.x, c0 = d.y;
+    const int nc = frontNc(tv, s);
+    const double* X = xv.X + xv.xOff[s];
+    const int col0 = 3 * tv.firstNode[s];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = c0 + threadIdx.x; r < nc; r += WG) tt[r - c0] = yperm[col0 + r];
+    __syncthreads();
+    for (int c = c0 + wave; c < min(nc, c0 + 16); c += WG / 64) {
+        const double* Xc = X + (long long)nc * c;
+        double acc0 = 0.0, acc1 = 0.0;
+        int r = c + lane;
+        for (; r + 64 < nc; r += 128) {
+            acc0 += Xc[r] * tt[r - c0];
+            acc1 += Xc[r + 64] * tt[r + 64 - c0];
+        }
+        if (r < nc) acc0 += Xc[r] * tt[r - c0];
+        double acc = acc0 + acc1;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+        if (lane == 0) xsol[col0 + c] = acc;
+    }
+}
+
 } // namespace
 
 void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
 {
+    if (side_) HIP_CHECK(hipStreamSynchronize(side_)); // buffers are about to be replaced
     sym_ = &sym;
     stream_ = stream;
     dropGraphs();
@@ -1015,6 +1253,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     fronts_.zero(stream); // once per analysis: the numeric phase writes every entry it reads, this only keeps never-read padding finite
     w_.alloc((size_t)sym.wOff[ns_]);
     yperm_.alloc((size_t)sym.n);
+    bperm_.alloc((size_t)sym.n);
     xsol_.alloc((size_t)sym.n);
     idx_.upload(sym.idx, stream);
     idxPtr_.upload(sym.idxPtr, stream);
@@ -1037,15 +1276,30 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     }
     flag_.alloc(1);
     hflag_.alloc(4);
+    if (!side_ && !std::getenv("IPCGPU_MF_NO_SIDE_STREAM")) {
+        HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
+    }
+    while ((int)evLevel_.size() < nLevels_) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        evLevel_.push_back(e);
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        evInvDone_.push_back(e);
+    }
+    sidePending_ = false;
 
     // A front whose nc own columns (plus the index maps of its children) fit into LDS takes the fused single-workgroup path;
     // the others go through the level-batched multi-workgroup kernels.
-    size_t fusedLds = 112 * 1024;
+    size_t fusedLds = 64 * 1024;
     if (const char* e = std::getenv("IPCGPU_MF_FUSED_KB")) fusedLds = (size_t)std::max(8, std::min(150, std::atoi(e))) * 1024;
     auto ldsOf = [&](int s) {
         const size_t kids = (size_t)(sym.childPtr[s + 1] - sym.childPtr[s]);
         return ((size_t)sym.nc(s) * sym.N(s) + 64) * sizeof(double) + kids * sym.N(s) * sizeof(int);
     };
+    int ntSmallN = 0, ntBigN = 200;
+    if (const char* e = std::getenv("IPCGPU_MF_NT128_N")) ntSmallN = std::atoi(e);
+    if (const char* e = std::getenv("IPCGPU_MF_NT512_N")) ntBigN = std::atoi(e);
     auto isFused = [&](int s) { return sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds; };
     // entries of A grouped by owning front: (source index, offset inside the LDS panel) for the fused fronts,
     // (source index, offset in the front buffer) per level for the others
@@ -1081,7 +1335,9 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             bSrc[q] = (int)k;
             bDst[q] = sym.aDst[k];
         }
-        aPtr_.upload(aPtr, stream);
+        aPtrHost_ = aPtr;
+        nFusedA_ = aPtr[ns_];
+        aPerm_.alloc(std::max<size_t>(aPtr[ns_], 1));
         aSrc_.upload(aSrc, stream);
         aLoc_.upload(aLoc, stream);
         bigASrc_.upload(bSrc, stream);
@@ -1113,6 +1369,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         bigList.insert(bigList.end(), big.begin(), big.end());
         P.smallLds = 0;
         for (int s : small) P.smallLds = std::max(P.smallLds, ldsOf(s));
+        // narrow fronts: two waves per workgroup, twice as many workgroups per CU (every phase of the kernel is latency-bound)
+        P.smallThreads = (maxN <= ntSmallN) ? 128 : (maxN >= ntBigN ? 512 : 256); // wide fronts: one workgroup per CU anyway (LDS)
         P.solveLds = (size_t)std::max(maxN, 1) * sizeof(double);
         P.triLds = (size_t)std::max(maxNc, 1) * sizeof(double);
         {
@@ -1175,6 +1433,151 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 for (int c0 = 0; c0 < sym.nc(s); c0 += 16) desc.push_back(make_int4(s, c0, 0, 0));
         P.bwdInit.cnt = (int)desc.size() - P.bwdInit.off;
     }
+    {
+        // packed descriptors of the fused fronts, in launch order
+        std::vector<int> fd((std::max<size_t>(smallList.size(), 1)) * FD_STRIDE, 0);
+        std::vector<long long> di(ns_ + 1, 0);
+        for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
+        for (size_t i = 0; i < smallList.size(); ++i) {
+            const int s = smallList[i];
+            int* d = fd.data() + i * FD_STRIDE;
+            const long long off = sym.frontOff[s];
+            std::memcpy(d, &off, 8);
+            d[2] = sym.N(s);
+            d[3] = sym.nc(s);
+            std::memcpy(d + 4, &di[s], 8);
+            d[6] = aPtrHost_[s];
+            d[7] = aPtrHost_[s + 1];
+            const int nk = sym.childPtr[s + 1] - sym.childPtr[s];
+            d[8] = nk;
+            for (int q = 0; q < nk; ++q) {
+                const int c = sym.child[sym.childPtr[s] + q];
+                int* k = d + 16 + 6 * q;
+                const long long coff = sym.frontOff[c];
+                std::memcpy(k, &coff, 8);
+                k[2] = sym.N(c);
+                k[3] = sym.nc(c);
+                k[4] = sym.invPtr[c];
+            }
+        }
+        fdesc_.upload(fd, stream);
+    }
+    {
+        // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
+        int xinvMin = 192;
+        if (const char* e = std::getenv("IPCGPU_MF_XINV_NC")) xinvMin = std::atoi(e) > 0 ? std::max(64, std::atoi(e)) : (1 << 30);
+        std::vector<long long> xOff(ns_, -1);
+        long long xTot = 0;
+        std::vector<int4> xd; // all descriptors of the inverse machinery
+        std::vector<int> invFronts;
+        size_t maxInvNc = 0;
+        for (int l = 0; l < nLevels_; ++l)
+            for (int i = plan_[l].bigFronts.off; i < plan_[l].bigFronts.off + plan_[l].bigFronts.cnt; ++i) {
+                const int s = bigList[i];
+                if (sym.nc(s) < xinvMin) continue;
+                xOff[s] = xTot;
+                xTot += (long long)sym.nc(s) * sym.nc(s);
+                invFronts.push_back(s);
+                maxInvNc = std::max<size_t>(maxInvNc, sym.nc(s));
+            }
+        // per level (the inverses of a level are formed on a side stream while the levels above factorise): the diagonal
+        // blocks to invert, the copies into X and the doubling rounds
+        std::vector<int> blockList;
+        std::vector<long long> di(ns_ + 1, 0);
+        for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
+        for (int s = 0; s < ns_; ++s)
+            if (xOff[s] < 0)
+                for (long long b = di[s]; b < di[s + 1]; ++b) blockList.push_back((int)b);
+        plainBlocks_.off = 0;
+        plainBlocks_.cnt = (int)blockList.size();
+        xinvLevel_.assign(nLevels_, XinvLevel());
+        for (int l = 0; l < nLevels_; ++l) {
+            XinvLevel& XL = xinvLevel_[l];
+            std::vector<int> lf;
+            for (int s : invFronts)
+                if (sym.level[s] == l) lf.push_back(s);
+            XL.blocks.off = (int)blockList.size();
+            XL.init.off = (int)xd.size();
+            for (int s : lf)
+                for (int b = 0; b < (sym.nc(s) + NB - 1) / NB; ++b) {
+                    blockList.push_back((int)(di[s] + b));
+                    xd.push_back(make_int4(s, b, 0, 0));
+                }
+            XL.blocks.cnt = (int)blockList.size() - XL.blocks.off;
+            XL.init.cnt = (int)xd.size() - XL.init.off;
+            if ((xd.size() & 1) != 0) xd.push_back(make_int4(0, 0, 0, 0)); // GEMM descriptors are pairs: keep them pair-aligned
+            int lvlMax = 0;
+            for (int s : lf) lvlMax = std::max(lvlMax, sym.nc(s));
+            for (int sz = NB; sz < lvlMax; sz *= 2) {
+                // pairs (A, C) of this doubling: A = [2 p sz, 2 p sz + sz), C = [2 p sz + sz, min(2 p sz + 2 sz, nc))
+                Range g1, g2;
+                for (int mode = 1; mode <= 2; ++mode) {
+                    Range& g = (mode == 1) ? g1 : g2;
+                    g.off = (int)xd.size() / 2;
+                    for (int s : lf) {
+                        const int nc = sym.nc(s);
+                        for (int a0 = 0; a0 + sz < nc; a0 += 2 * sz) {
+                            const int c0 = a0 + sz, cEnd = std::min(a0 + 2 * sz, nc);
+                            for (int r = c0; r < cEnd; r += 32)
+                                for (int c = a0; c < a0 + sz; c += 32) {
+                                    xd.push_back(make_int4(s, r, c, mode));
+                                    // mode 1 sums over the columns of A, mode 2 over the rows of C
+                                    xd.push_back(mode == 1 ? make_int4(cEnd, a0 + sz, a0, a0 + sz) : make_int4(cEnd, a0 + sz, c0, cEnd));
+                                }
+                        }
+                    }
+                    g.cnt = (int)xd.size() / 2 - g.off;
+                }
+                XL.rounds.push_back({ g1, g2 });
+            }
+        }
+        if (blockList.empty()) blockList.push_back(0);
+        invBlockList_.upload(blockList, stream);
+        // solve: per level the fronts swept by one workgroup (no inverse) and the row / column blocks of the others
+        std::vector<int> triList;
+        for (int l = 0; l < nLevels_; ++l) {
+            LevelPlan& P = plan_[l];
+            P.bigTri.off = (int)triList.size();
+            size_t triMax = 1;
+            std::vector<int4> fw, bw;
+            for (int i = P.bigFronts.off; i < P.bigFronts.off + P.bigFronts.cnt; ++i) {
+                const int s = bigList[i];
+                if (xOff[s] < 0) {
+                    triList.push_back(s);
+                    triMax = std::max<size_t>(triMax, sym.nc(s));
+                    continue;
+                }
+                for (int r0 = 0; r0 < sym.nc(s); r0 += 64) fw.push_back(make_int4(s, r0, 0, 0));
+                for (int c0 = 0; c0 < sym.nc(s); c0 += 16) bw.push_back(make_int4(s, c0, 0, 0));
+            }
+            P.bigTri.cnt = (int)triList.size() - P.bigTri.off;
+            P.triLds = triMax * sizeof(double);
+            if ((xd.size() & 1) != 0) xd.push_back(make_int4(0, 0, 0, 0));
+            P.xinvFwd.off = (int)xd.size();
+            xd.insert(xd.end(), fw.begin(), fw.end());
+            P.xinvFwd.cnt = (int)fw.size();
+            P.xinvBwd.off = (int)xd.size();
+            xd.insert(xd.end(), bw.begin(), bw.end());
+            P.xinvBwd.cnt = (int)bw.size();
+        }
+        maxTriLds = 0;
+        for (int l = 0; l < nLevels_; ++l) maxTriLds = std::max(maxTriLds, plan_[l].triLds);
+        xinvLds_ = std::max<size_t>(maxInvNc, 1) * sizeof(double);
+        if (xinvLds_ > 48 * 1024) {
+            if (xinvLds_ > 150 * 1024) throw StateError("a separator front is too wide for the inverse-based triangular solve");
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_xinv_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xinvLds_));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_xinv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xinvLds_));
+        }
+        if (triList.empty()) triList.push_back(0);
+        triList_.upload(triList, stream);
+        if (xd.empty()) xd.push_back(make_int4(0, 0, 0, 0));
+        xinvDesc_.upload(xd.data(), xd.size(), stream);
+        xinvOff_.upload(xOff.empty() ? std::vector<long long>{ -1 } : xOff, stream);
+        xinvX_.alloc((size_t)std::max<long long>(xTot, 1));
+        xinvT_.alloc((size_t)std::max<long long>(xTot, 1));
+        xinvX_.zero(stream);
+        xinvT_.zero(stream);
+    }
     if (smallList.empty()) smallList.push_back(0);
     smallList_.upload(smallList, stream);
     if (bigList.empty()) bigList.push_back(0);
@@ -1184,7 +1587,11 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (desc.empty()) desc.push_back(make_int4(0, 0, 0, 0));
     desc_.upload(desc.data(), desc.size(), stream);
     if (maxSmallLds > 48 * 1024)
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
+    {
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
+    }
     if (maxSolveLds > 48 * 1024) {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
@@ -1199,7 +1606,15 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     HIP_CHECK(hipStreamSynchronize(stream));
 }
 
-MfNumeric::~MfNumeric() { dropGraphs(); }
+MfNumeric::~MfNumeric()
+{
+    dropGraphs();
+    if (side_) (void)hipStreamSynchronize(side_);
+    for (hipEvent_t e : evLevel_) (void)hipEventDestroy(e);
+    for (hipEvent_t e : evInvDone_) (void)hipEventDestroy(e);
+    if (evSide_) (void)hipEventDestroy(evSide_);
+    if (side_) (void)hipStreamDestroy(side_);
+}
 
 void MfNumeric::dropGraphs()
 {
@@ -1245,12 +1660,37 @@ void MfNumeric::enqueueFactor(const double* a_dev)
 {
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
+    if (sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evSide_, 0)); // the side stream still reads the previous factor
     flag_.zero(stream_);
+    bool sideUsed = false;
+    if (nFusedA_) hipLaunchKernelGGL(k_gather_a, dim3((nFusedA_ + 255) / 256), dim3(256), 0, stream_, nFusedA_, aSrc_.p, a_dev, aPerm_.p);
     for (int l = 0; l < nLevels_; ++l) {
         const LevelPlan& P = plan_[l];
         if (P.small.cnt)
-            hipLaunchKernelGGL(k_front_fused, dim3(P.small.cnt), dim3(WG), P.smallLds, stream_, smallList_.p + P.small.off, tv, aPtr_.p,
-                aSrc_.p, aLoc_.p, a_dev, fronts_.p, dinv_.p, flag_.p);
+        {
+            const int* fd = fdesc_.p + (size_t)P.small.off * FD_STRIDE;
+            if (P.smallThreads == 128)
+                hipLaunchKernelGGL(k_front_fused<128>, dim3(P.small.cnt), dim3(128), P.smallLds, stream_, fd, inv_.p, aLoc_.p, aPerm_.p, fronts_.p,
+                    dinv_.p, flag_.p);
+            else if (P.smallThreads == 512)
+                hipLaunchKernelGGL(k_front_fused<512>, dim3(P.small.cnt), dim3(512), P.smallLds, stream_, fd, inv_.p, aLoc_.p, aPerm_.p, fronts_.p,
+                    dinv_.p, flag_.p);
+            else
+                hipLaunchKernelGGL(k_front_fused<256>, dim3(P.small.cnt), dim3(256), P.smallLds, stream_, fd, inv_.p, aLoc_.p, aPerm_.p, fronts_.p,
+                    dinv_.p, flag_.p);
+        }
+#ifdef MF_PHASE_TIMERS
+        if (P.small.cnt && std::getenv("IPCGPU_MF_PHASES")) {
+            HIP_CHECK(hipStreamSynchronize(stream_));
+            unsigned long long h[16];
+            HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(mf_phase_acc), sizeof(h)));
+            fprintf(stderr, "fused level %d (%d fronts): cycles per front by phase:", l, P.small.cnt);
+            for (int i = 0; i < 9; ++i) fprintf(stderr, " %.0f", (double)h[i] / P.small.cnt);
+            fprintf(stderr, "\n");
+            unsigned long long z[16] = { 0 };
+            HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mf_phase_acc), z, sizeof(z)));
+        }
+#endif
         if (P.ea.cnt) {
             hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, tv, fronts_.p);
             const int na = bigAOff_[l + 1] - bigAOff_[l];
@@ -1261,9 +1701,42 @@ void MfNumeric::enqueueFactor(const double* a_dev)
         for (const Range& R : P.step)
             if (R.cnt) hipLaunchKernelGGL(k_big_step, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p);
         if (P.schur.cnt) hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, tv, fronts_.p);
+        if (xinvLevel_[l].blocks.cnt) {
+            // the factor panels and pivot blocks of this level are final: form the triangle inverses of its fronts beside the
+            // latency-bound chain of the levels above (during graph capture everything stays on the one stream)
+            if (side_ && !useGraph_) {
+                HIP_CHECK(hipEventRecord(evLevel_[l], stream_));
+                HIP_CHECK(hipStreamWaitEvent(side_, evLevel_[l], 0));
+                enqueueInverses(l, side_);
+                HIP_CHECK(hipEventRecord(evInvDone_[l], side_));
+                sideUsed = true;
+            }
+            else enqueueInverses(l, stream_);
+        }
     }
     // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)
-    hipLaunchKernelGGL(k_invert_blocks, dim3((unsigned)nDiagBlocks_), dim3(64), 0, stream_, dinv_.p);
+    // the dinv slots hold the factored diagonal blocks: invert them (independent, one wave each); those of the fronts with an
+    // explicit inverse were already taken care of on the side stream
+    if (plainBlocks_.cnt)
+        hipLaunchKernelGGL(k_invert_blocks, dim3(plainBlocks_.cnt), dim3(64), 0, stream_, invBlockList_.p + plainBlocks_.off, dinv_.p);
+    // The inverses are first needed when the forward solve reaches their level (the root's: at its very end), so the main
+    // stream does not wait here: enqueueSolve waits per level, the next factorisation waits before it touches the fronts.
+    if (sideUsed) HIP_CHECK(hipEventRecord(evSide_, side_));
+    sidePending_ = sideUsed;
+}
+
+// X = L11^-1 of the fronts of one level (see k_xinv_*), enqueued on `st`
+void MfNumeric::enqueueInverses(int l, hipStream_t st)
+{
+    const XinvLevel& XL = xinvLevel_[l];
+    TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
+    XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
+    hipLaunchKernelGGL(k_invert_blocks, dim3(XL.blocks.cnt), dim3(64), 0, st, invBlockList_.p + XL.blocks.off, dinv_.p);
+    hipLaunchKernelGGL(k_xinv_init, dim3(XL.init.cnt), dim3(256), 0, st, xinvDesc_.p + XL.init.off, tv, xv, dinv_.p);
+    for (const auto& R : XL.rounds) {
+        if (R.first.cnt) hipLaunchKernelGGL(k_xinv_gemm, dim3(R.first.cnt), dim3(256), 0, st, xinvDesc_.p + 2 * (size_t)R.first.off, tv, xv, fronts_.p);
+        if (R.second.cnt) hipLaunchKernelGGL(k_xinv_gemm, dim3(R.second.cnt), dim3(256), 0, st, xinvDesc_.p + 2 * (size_t)R.second.off, tv, xv, fronts_.p);
+    }
 }
 
 void MfNumeric::solve(const double* rhs_dev, double* x_dev)
@@ -1282,16 +1755,23 @@ void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
 {
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
+    XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
     const int n3 = sym.n;
-    hipLaunchKernelGGL(k_permute_rhs, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, rhs_dev, yperm_.p);
+    // the permuted right-hand side stays in its own buffer: the forward kernels of a level write y into yperm while other
+    // workgroups of the same launch still gather right-hand-side entries
+    hipLaunchKernelGGL(k_permute_rhs, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, rhs_dev, bperm_.p);
     for (int l = 0; l < nLevels_; ++l) {
         const LevelPlan& P = plan_[l];
         if (P.small.cnt)
             hipLaunchKernelGGL(k_fwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, wOff_.p,
-                fronts_.p, dinv_.p, w_.p, yperm_.p);
-        if (P.bigFronts.cnt)
-            hipLaunchKernelGGL(k_big_fwd_tri, dim3(P.bigFronts.cnt), dim3(WGT), P.triLds, stream_, bigList_.p + P.bigFronts.off, tv, wOff_.p,
-                fronts_.p, dinv_.p, w_.p, yperm_.p);
+                fronts_.p, dinv_.p, w_.p, bperm_.p, yperm_.p);
+        if (P.bigTri.cnt)
+            hipLaunchKernelGGL(k_big_fwd_tri, dim3(P.bigTri.cnt), dim3(WGT), P.triLds, stream_, triList_.p + P.bigTri.off, tv, wOff_.p,
+                fronts_.p, dinv_.p, w_.p, bperm_.p, yperm_.p);
+        if (P.xinvFwd.cnt && sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evInvDone_[l], 0));
+        if (P.xinvFwd.cnt)
+            hipLaunchKernelGGL(k_xinv_fwd, dim3(P.xinvFwd.cnt), dim3(WG), xinvLds_, stream_, xinvDesc_.p + P.xinvFwd.off, tv, xv, wOff_.p, w_.p,
+                bperm_.p, yperm_.p);
         if (P.fwdRect.cnt)
             hipLaunchKernelGGL(k_big_fwd_rect, dim3(P.fwdRect.cnt), dim3(WG), 0, stream_, desc_.p + P.fwdRect.off, tv, wOff_.p, fronts_.p, w_.p,
                 yperm_.p);
@@ -1301,9 +1781,12 @@ void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
         if (P.bwdInit.cnt)
             hipLaunchKernelGGL(k_big_bwd_init, dim3(P.bwdInit.cnt), dim3(WG), P.bwdLds, stream_, desc_.p + P.bwdInit.off, tv, fronts_.p, yperm_.p,
                 xsol_.p);
-        if (P.bigFronts.cnt)
-            hipLaunchKernelGGL(k_big_bwd_tri, dim3(P.bigFronts.cnt), dim3(WGT), P.triLds, stream_, bigList_.p + P.bigFronts.off, tv, fronts_.p,
+        if (P.bigTri.cnt)
+            hipLaunchKernelGGL(k_big_bwd_tri, dim3(P.bigTri.cnt), dim3(WGT), P.triLds, stream_, triList_.p + P.bigTri.off, tv, fronts_.p,
                 dinv_.p, yperm_.p, xsol_.p);
+        if (P.xinvBwd.cnt)
+            hipLaunchKernelGGL(k_xinv_bwd, dim3(P.xinvBwd.cnt), dim3(WG), xinvLds_, stream_, xinvDesc_.p + P.xinvBwd.off, tv, xv, yperm_.p,
+                xsol_.p);
         if (P.small.cnt)
             hipLaunchKernelGGL(k_bwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
                 yperm_.p, xsol_.p);

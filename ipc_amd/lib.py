@@ -13,7 +13,8 @@ import re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libipcgpu.so")
+# IPCGPU_LIB_VARIANT selects an experiment build made by tools/ (ipc_amd/build.py variant=...); unset = the product library
+_LIB_PATH = os.path.join(_HERE, "libipcgpu_%s.so" % os.environ["IPCGPU_LIB_VARIANT"] if os.environ.get("IPCGPU_LIB_VARIANT") else "libipcgpu.so")
 _HEADER = os.path.join(_HERE, "..", "include", "ipcgpu.h")
 
 c_dp = C.POINTER(C.c_double)
