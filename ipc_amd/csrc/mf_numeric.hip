@@ -293,6 +293,96 @@ __device__ __forceinline__ void row_trsm32_lean(double (&x)[NB], const double* b
     }
 }
 
+// X = L^-1 of a factored 32 x 32 pivot block by one wave, recursive doubling on the matrix cores.
+//   blk[k * ld + r] = L(r, k) for r > k (LDS, k-major), rdiag[k] = 1 / L(k, k); rows / columns >= w count as identity
+//   Xs[c * LDX + r] = X(r, c), all 32 x 32 entries written (zeros above the diagonal)
+// 1. the four 8 x 8 diagonal blocks by substitution: lane 8 b + c computes column c of block b (8-long chain)
+// 2. 16 x 16: X21 = -X22 (L21 X11) for both halves at once, the two 8 x 8 problems packed block-diagonally into one
+//    16 x 16 x 16 product (v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15], D row = (l >> 4) + 4 reg, col = l & 15)
+// 3. 32 x 32: the same with full 16 x 16 blocks.
+// The first product of a pair leaves T in the accumulator layout, which is exactly the B-operand layout of the second
+// (register i holds row (l >> 4) + 4 i): no LDS round trip between them.  ~1.5 k cycles against ~6 k for the substitution
+// of wave_trinv32, and it runs inside the step that factored the block, so the panel rows can be solved by a product.
+constexpr int LDX = NB + 1;
+__device__ __forceinline__ void wave_trinv32_fast(const double* blk, int ld, const double* rdiag, int w, int lane, double* Xs)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+    for (int e = lane; e < NB * LDX; e += 64) Xs[e] = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < NB) {
+        const int b8 = lane & ~7, c = lane & 7;
+        double Lr[8][8], rd[8], x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            rd[r] = (b8 + r < w) ? rdiag[b8 + r] : 1.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) Lr[r][k] = blk[(b8 + k) * ld + b8 + r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            double acc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < r; ++k) acc -= Lr[r][k] * x[k];
+            x[r] = acc * rd[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) Xs[lane * LDX + b8 + r] = x[r];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        // 16 x 16 level, halves h = 0 (blocks 0, 1) and h = 1 (blocks 2, 3) packed: rows / columns 0..7 <-> h = 0, 8..15 <-> h = 1
+        f64x4 t = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + hi;
+            // A[m = lo][kk]: L21 of the half of row m;  B[kk][n = lo]: X11 of the half of row kk
+            const bool ha = lo >= 8, hk = kk >= 8;
+            const double av = blk[(ha ? kk + 8 : kk) * ld + (ha ? lo + 16 : lo + 8)]; // h=0: L(8+m, kk); h=1: L(24+m-8, 16+kk-8)
+            const double bv = Xs[(hk ? lo + 8 : lo) * LDX + (hk ? kk + 8 : kk)]; // h=0: X(kk, n); h=1: X(16+kk-8, 16+n-8)
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64((ha == hk) ? av : 0.0, (hk == (lo >= 8)) ? bv : 0.0, t, 0, 0, 0);
+        }
+        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + hi;
+            const bool ha = lo >= 8, hk = kk >= 8;
+            const double av = Xs[(ha ? kk + 16 : kk + 8) * LDX + (ha ? lo + 16 : lo + 8)]; // h=0: X(8+m, 8+kk); h=1: X(24+m-8, 24+kk-8)
+            u = __builtin_amdgcn_mfma_f64_16x16x4f64((ha == hk) ? av : 0.0, t[ks], u, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = hi + 4 * i; // row of the packed result, column lo
+            if ((m >= 8) == (lo >= 8)) {
+                const int row = (m >= 8) ? m + 16 : m + 8, col = (lo >= 8) ? lo + 8 : lo;
+                Xs[col * LDX + row] = -u[i];
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    {
+        // 32 x 32 level: X[16:32, 0:16] = -X22 (L21 X11)
+        f64x4 t = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + hi;
+            t = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[kk * ld + 16 + lo], Xs[lo * LDX + kk], t, 0, 0, 0); // L(16+m, kk), X(kk, n)
+        }
+        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kk = 4 * ks + hi;
+            u = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 + kk) * LDX + 16 + lo], t[ks], u, 0, 0, 0); // X(16+m, 16+kk)
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Xs[lo * LDX + 16 + hi + 4 * i] = -u[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // the factored pivot block goes to its `dinv` slot (k-major, identity-padded, 1 / L(k, k) on the diagonal); k_invert_blocks
 // turns it into L11^-1 at the end
 __device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int w, const double* rdiag, double* slot, int tid, int nthreads)
@@ -419,7 +509,11 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
     for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
         const int w = min(NB, nc - kb);
         double* Pk = P + (size_t)kb * N + kb; // Pk[k * N + q] = F(kb + q, kb + k)
-        if (tid < 64) bad |= wave_potrf32(Pk, N, w, tid, rdiag);
+        if (tid < 64) {
+            __builtin_amdgcn_s_setprio(3);
+            bad |= wave_potrf32(Pk, N, w, tid, rdiag);
+            __builtin_amdgcn_s_setprio(0);
+        }
         __syncthreads();
         MF_PHASE(4);
         store_pivot_block(Pk, N, w, rdiag, dblk, tid, NT);
@@ -607,6 +701,19 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         }
         return;
     }
+#ifdef MF_PHASE_TIMERS
+    long long tphase_ = clock64();
+#define MF_STEP_PHASE(i)                                                                                          \
+    do {                                                                                                          \
+        if (d.z == 0 && (threadIdx.x == PIVOT_T0)) {                                                              \
+            const long long t_ = clock64();                                                                       \
+            atomicAdd(&mf_phase_acc[i], (unsigned long long)(t_ - tphase_));                                      \
+            tphase_ = t_;                                                                                         \
+        }                                                                                                         \
+    } while (0)
+#else
+#define MF_STEP_PHASE(i)
+#endif
     // ---- role B: bring panel kb1 up to date with panel kb, factor its pivot block, solve this workgroup's rows.
     // The factored pivot block is never written back into the front (other workgroups of this launch still read the raw
     // one); it goes to the dinv slot and is inverted at the end of the factorisation.
@@ -619,6 +726,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         A11[k * LDP + q] = (k < w1 && q < w1 && q >= k) ? F[(kb1 + q) + (long long)N * (kb1 + k)] : 0.0;
     }
     __syncthreads();
+    MF_STEP_PHASE(10);
     if (w > 0 && tid < 192) {
         // A11 -= Lp^T Lp (lower triangle) on the matrix cores: waves 0..2 take the 16 x 16 tiles (0,0), (1,0), (1,1).  As scalar
         // FMAs this was 256 LDS reads per thread -- ~4 k cycles of LDS return traffic on the critical chain of every step.
@@ -638,62 +746,90 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         }
     }
     __syncthreads();
-    const int R = kb1 + d.z + tid;
-    const bool rowThread = tid < ROWS_B && R >= kb1 + w1 && R < N;
-    double x[1][NB];
+    MF_STEP_PHASE(11);
+    double* Xs = sm + 2 * NB * LDP + NB; // Xs[c * LDX + r] = X(r, c), X = L11^-1 (written by the pivot wave)
+    const int wv = tid >> 6, l = tid & 63, lo = l & 15, hi = l >> 4;
+    const int Rw = kb1 + d.z + 64 * wv; // first row of this wave
+    const bool rowWave = tid < ROWS_B && Rw < N;
+    // Everything the rows need is a product: X_rows = (raw - P_kb Lp^T) L11^-T.  It is formed transposed, tile by tile of 16 rows:
+    //   D1^T(k, m) = raw(m, k) - sum_j Lp(k, j) P(m, j)      A = -Lp (LDS), B = rows of panel kb straight from the front
+    //   X^T(n, m)  = sum_k Linv(n, k) D1^T(k, m)              A = Linv (LDS), B = D1^T as it sits in the accumulators
+    // (accumulator register i holds row (l >> 4) + 4 i, which is the B-operand row of k-step i), and the result lands as 16
+    // consecutive rows m per column n: 128-byte stores.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15],
+    // D row = (l >> 4) + 4 reg, col = l & 15.
+    f64x4 d1t[4][2];
     if (tid >= PIVOT_T0) {
-        // pivot wave (alone on its SIMD): Cholesky of the 32x32 block while the row waves fetch and update their rows
+        // pivot wave (alone on its SIMD): Cholesky of the 32 x 32 block and its inverse while the row waves fetch and update
+        // (the pivot chain is what every other wave of the step ends up waiting for: it gets issue priority on its SIMD)
+        __builtin_amdgcn_s_setprio(3);
         if (wave_potrf32(A11, LDP, w1, tid - PIVOT_T0, rdiag)) atomicOr(flag, 1);
+        MF_STEP_PHASE(12);
+        wave_trinv32_fast(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
+        __builtin_amdgcn_s_setprio(0);
     }
-    else if (tid < ROWS_B) {
-        // row waves: X(64 x 32) = raw - P_kb(64 x 32) Lp^T on the matrix cores.  v_mfma_f64_16x16x4_f64: A[l&15][l>>4],
-        // B[l>>4][l&15], D col = l&15, row = (l>>4) + 4 reg.  One LDS read feeds 1024 FMAs instead of one.
-        const int wv = tid >> 6, l = tid & 63;
-        const int Rw = kb1 + d.z + 64 * wv; // first row of this wave
-        if (rowThread) {
+    else if (rowWave) {
 #pragma unroll
-            for (int c = 0; c < NB; ++c) x[0][c] = (c < w1) ? F[R + (long long)N * (kb1 + c)] : 0.0;
-        }
-        if (w > 0 && Rw < N) { // wave-uniform; a panel that has a successor is always full (w == NB)
-            const int ar = l & 15, ak = l >> 4;
-            double* T = sm + 2 * NB * LDP + NB + wv * (16 * LDP); // 16 x 32 staging tile of this wave
+        for (int mt = 0; mt < 4; ++mt) {
+            const double* Fr = F + min(Rw + 16 * mt + lo, N - 1);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                f64x4 acc0 = { 0.0, 0.0, 0.0, 0.0 }, acc1 = { 0.0, 0.0, 0.0, 0.0 };
-                const double* Fr = F + min(Rw + 16 * mt + ar, N - 1) + (long long)N * (kb + ak);
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = 16 * kt + hi + 4 * i;
+                    const double v = Fr[(long long)N * (kb1 + min(k, max(w1, 1) - 1))];
+                    d1t[mt][kt][i] = (k < w1) ? v : 0.0;
+                }
+            if (w > 0) { // wave-uniform; a panel that has a successor is always full (w == NB)
+                double pv[NB / 4];
+#pragma unroll
+                for (int ks = 0; ks < NB / 4; ++ks) pv[ks] = Fr[(long long)N * (kb + 4 * ks + hi)];
 #pragma unroll
                 for (int ks = 0; ks < NB / 4; ++ks) {
-                    const double a = Fr[(long long)N * (4 * ks)];
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lp[(4 * ks + ak) * LDP + ar], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Lp[(4 * ks + ak) * LDP + 16 + ar], acc1, 0, 0, 0);
+                    d1t[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LDP + lo], pv[ks], d1t[mt][0], 0, 0, 0);
+                    d1t[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LDP + 16 + lo], pv[ks], d1t[mt][1], 0, 0, 0);
                 }
-                // 16 rows of the update through LDS: written in the D layout, read back one row per lane by the 16 lanes
-                // that own those rows (same wave: LDS operations of a wave execute in order)
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    T[(ak + 4 * r) * LDP + ar] = acc0[r];
-                    T[(ak + 4 * r) * LDP + 16 + ar] = acc1[r];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if ((l >> 4) == mt) {
-#pragma unroll
-                    for (int c = 0; c < NB; ++c) x[0][c] -= T[(l & 15) * LDP + c];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
             }
         }
     }
     __syncthreads();
-    if (rowThread) {
-        row_trsm32<1>(x, A11, LDP, rdiag);
-        double* out = F + R + (long long)N * kb1;
+    MF_STEP_PHASE(13);
+    if (tid < ROWS_B && rowWave) {
 #pragma unroll
-        for (int c = 0; c < NB; ++c)
-            if (c < w1) out[(long long)N * c] = x[0][c];
+        for (int mt = 0; mt < 4; ++mt) {
+            f64x4 x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + hi;
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[k * LDX + lo], d1t[mt][0][ks], x0, 0, 0, 0); // Linv(n, k), n < 16: k < 16 only
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[k * LDX + 16 + lo], d1t[mt][0][ks], x1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 16 + 4 * ks + hi;
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[k * LDX + 16 + lo], d1t[mt][1][ks], x1, 0, 0, 0);
+            }
+            const int row = Rw + 16 * mt + lo;
+            if (row >= kb1 + w1 && row < N) {
+                double* out = F + row + (long long)N * kb1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n0 = hi + 4 * i, n1 = 16 + hi + 4 * i;
+                    if (n0 < w1) out[(long long)N * n0] = x0[i];
+                    if (n1 < w1) out[(long long)N * n1] = x1[i];
+                }
+            }
+        }
     }
-    if (d.z == 0) store_pivot_block(A11, LDP, w1, rdiag, dinv + (tv.dinvOff[s] + kb1 / NB) * (NB * NB), tid, WGB);
+    if (d.z == 0) {
+        // the inverse of the pivot block goes straight to its dinv slot (column-major, identity-padded): the solves multiply by it
+        double* slot = dinv + (tv.dinvOff[s] + kb1 / NB) * (NB * NB);
+        for (int e = tid; e < NB * NB; e += WGB) slot[e] = Xs[(e >> 5) * LDX + (e & 31)];
+    }
+#ifdef MF_PHASE_TIMERS
+    __syncthreads();
+    MF_STEP_PHASE(14);
+    if (d.z == 0 && threadIdx.x == PIVOT_T0) atomicAdd(&mf_phase_acc[15], 1ull);
+#endif
 }
 
 // Schur complement of a big front in one pass: S(i, j) -= sum_{c < nc} L(i, c) L(j, c) for i, j >= nc.  Doing this per
@@ -1486,7 +1622,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<long long> di(ns_ + 1, 0);
         for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
         for (int s = 0; s < ns_; ++s)
-            if (xOff[s] < 0)
+            if (isFused(s)) // the multi-workgroup path leaves finished inverses in the dinv slots (wave_trinv32_fast)
                 for (long long b = di[s]; b < di[s + 1]; ++b) blockList.push_back((int)b);
         plainBlocks_.off = 0;
         plainBlocks_.cnt = (int)blockList.size();
@@ -1715,6 +1851,18 @@ void MfNumeric::enqueueFactor(const double* a_dev)
         }
     }
     // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)
+#ifdef MF_PHASE_TIMERS
+    if (std::getenv("IPCGPU_MF_PHASES")) {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        unsigned long long h[16];
+        HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(mf_phase_acc), sizeof(h)));
+        const double n = (double)std::max<unsigned long long>(h[15], 1);
+        fprintf(stderr, "big step, pivot wave of the first workgroup of every front (%llu samples): cycles load %.0f update %.0f potrf %.0f wait-rows %.0f trsm+store %.0f\n",
+            h[15], h[10] / n, h[11] / n, h[12] / n, h[13] / n, h[14] / n);
+        unsigned long long z[16] = { 0 };
+        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mf_phase_acc), z, sizeof(z)));
+    }
+#endif
     // the dinv slots hold the factored diagonal blocks: invert them (independent, one wave each); those of the fronts with an
     // explicit inverse were already taken care of on the side stream
     if (plainBlocks_.cnt)
@@ -1731,7 +1879,6 @@ void MfNumeric::enqueueInverses(int l, hipStream_t st)
     const XinvLevel& XL = xinvLevel_[l];
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
-    hipLaunchKernelGGL(k_invert_blocks, dim3(XL.blocks.cnt), dim3(64), 0, st, invBlockList_.p + XL.blocks.off, dinv_.p);
     hipLaunchKernelGGL(k_xinv_init, dim3(XL.init.cnt), dim3(256), 0, st, xinvDesc_.p + XL.init.off, tv, xv, dinv_.p);
     for (const auto& R : XL.rounds) {
         if (R.first.cnt) hipLaunchKernelGGL(k_xinv_gemm, dim3(R.first.cnt), dim3(256), 0, st, xinvDesc_.p + 2 * (size_t)R.first.off, tv, xv, fronts_.p);
