@@ -76,6 +76,7 @@ private:
     DevBuf<double> aPerm_; // values of A gathered into fused-front order at the start of every factorisation
     int nFusedA_ = 0;
     std::vector<int> aPtrHost_; // front -> first entry (goes into the packed descriptors)
+    DevBuf<int> bigFd_; // packed records of the other fronts (k_extend_add)
     DevBuf<int> fdesc_; // packed descriptors of the fused fronts (64 ints each, launch order)
     DevBuf<int> bigASrc_; // entries of A of the other fronts, grouped by level: source index ...
     DevBuf<long long> bigADst_; // ... and destination in the front buffer

@@ -41,8 +41,10 @@ constexpr int ROWS_B = 64 * ROW_WAVES_B; // panel rows per role-B workgroup
 constexpr int PIVOT_T0 = WGB - 64; // first thread of the pivot wave
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
-constexpr int EA_KC = 4; // children whose index maps are staged together in the extend-add kernel
+
 constexpr int TS = 64; // trailing-update tile
+constexpr int FD_STRIDE_EA = 64; // packed front descriptors (same layout as the fused kernel's, see k_front_fused)
+constexpr int FUSED_MAX_KIDS_EA = 8;
 constexpr int PIVOT_BATCH = 16; // broadcasts issued ahead of their FMAs in the pivot-block Cholesky (2 SGPRs each)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
@@ -79,32 +81,37 @@ __global__ void k_scatter_big(int cnt, const int* __restrict__ src, const long l
     if (k < cnt) fronts[dst[k]] += a[src[k]];
 }
 
-// desc = (parent front, ti, tj, 0): one 64 x 64 tile (ti >= tj) of the parent.  Per child the parent-row / parent-column ->
-// child-index maps of the tile are built once in LDS (128 lookups instead of two per entry); lanes run along rows, which
-// are (mostly) consecutive in the child as well, the four waves split the 64 columns.
-__global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
+// desc = (record, ti, tj, 0): one 64 x 64 tile (ti >= tj) of a parent front.  `record` indexes a packed 64-int descriptor
+// (layout of the fused kernel: [0,1] front offset [2] N [8] #children in this record [9] next record or -1; child q at
+// 16 + 6 q: [0,1] front offset [2] N [3] nc [4] inverse-map offset) so that front, child list, child geometry and map
+// offsets arrive in one load instead of five dependent ones.  Per child the parent-row / parent-column -> child-index maps of
+// the tile are built once in LDS; lanes run along rows, which are (mostly) consecutive in the child as well, the four waves
+// split the 64 columns.  The gathers are unconditional (clamped address, value selected afterwards): all in flight together.
+__global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc, const int* __restrict__ bigFd,
+    const int* __restrict__ invMap, double* __restrict__ fronts)
 {
-    // the index maps of up to EA_KC children are staged together: one barrier pair and one round of gathers per batch instead
-    // of per child (the kernel spends 93 % of its wave cycles parked on these dependent round trips, SQ_WAIT_ANY)
-    __shared__ int rmap[EA_KC][TS], cmap[EA_KC][TS];
+    __shared__ __attribute__((aligned(16))) int fd[FD_STRIDE_EA];
+    __shared__ int rmap[FUSED_MAX_KIDS_EA][TS], cmap[FUSED_MAX_KIDS_EA][TS];
     const int4 d = desc[blockIdx.x];
-    const int s = d.x;
-    const int N = frontN(tv, s);
-    double* F = fronts + tv.frontOff[s];
     const int i0 = TS * d.y, j0 = TS * d.z;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double sum[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) sum[q] = 0.0;
-    const int cEnd = tv.childPtr[s + 1];
-    for (int ci0 = tv.childPtr[s]; ci0 < cEnd; ci0 += EA_KC) {
-        const int nk = min(EA_KC, cEnd - ci0);
+    int N = 0;
+    double* F = nullptr;
+    for (int rec = d.x; rec >= 0;) {
         __syncthreads();
+        if (tid < FD_STRIDE_EA) fd[tid] = bigFd[(size_t)rec * FD_STRIDE_EA + tid];
+        __syncthreads();
+        N = fd[2];
+        F = fronts + *reinterpret_cast<const long long*>(fd);
+        const int nk = fd[8];
+        rec = fd[9];
         for (int e = tid; e < nk * 2 * TS; e += WG) {
             const int k = e / (2 * TS), t = e - k * (2 * TS);
-            const int c = tv.child[ci0 + k];
-            const int* inv = tv.inv + tv.invPtr[c];
-            const int ncc = frontNc(tv, c);
+            const int* inv = invMap + fd[16 + 6 * k + 4];
+            const int ncc = fd[16 + 6 * k + 3];
             const int I = (t < TS ? i0 : j0 - TS) + t;
             int m = -1;
             if (I < N) {
@@ -114,21 +121,20 @@ __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc
             (t < TS ? rmap[k] : cmap[k] - TS)[t] = m;
         }
         __syncthreads();
+        for (int k = 0; k < nk; ++k) {
+            const double* __restrict__ Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * k);
+            const long long Nc = fd[16 + 6 * k + 2];
+            const int r = rmap[k][lane];
+            double x[16];
+            bool ok[16];
 #pragma unroll
-        for (int k = 0; k < EA_KC; ++k) {
-            if (k < nk) {
-                const int c = tv.child[ci0 + k];
-                const int Nc = frontN(tv, c);
-                const double* __restrict__ Fc = fronts + tv.frontOff[c];
-                const int r = rmap[k][lane];
-                if (r >= 0) {
-#pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int cc = cmap[k][16 * wv + q];
-                        if (cc >= 0 && r >= cc) sum[q] += Fc[r + (long long)Nc * cc];
-                    }
-                }
+            for (int q = 0; q < 16; ++q) {
+                const int cc = cmap[k][16 * wv + q];
+                ok[q] = r >= 0 && cc >= 0 && r >= cc;
+                x[q] = Fc[ok[q] ? r + Nc * cc : 0];
             }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum[q] += ok[q] ? x[q] : 0.0;
         }
     }
     const int I = i0 + lane;
@@ -434,12 +440,12 @@ __device__ unsigned long long mf_phase_acc[16];
 #else
 #define MF_PHASE(i)
 #endif
-constexpr int FUSED_MAX_KIDS = 8;
+constexpr int FUSED_MAX_KIDS = FUSED_MAX_KIDS_EA;
 // Host-packed descriptor of a fused front, 64 ints: everything the kernel would otherwise chase through five rounds of
 // dependent loads (front list -> index pointers -> child list -> child pointers -> inverse maps) arrives in one.
 //   [0,1] front offset  [2] N  [3] nc  [4,5] first dinv block  [6] aBeg  [7] aEnd  [8] #children
 //   child q at 16 + 6 q: [0,1] front offset  [2] N  [3] nc  [4] offset of its inverse map
-constexpr int FD_STRIDE = 64;
+constexpr int FD_STRIDE = FD_STRIDE_EA;
 template <int NT>
 __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ fdesc, const int* __restrict__ invMap,
     const int* __restrict__ aLoc, const double* __restrict__ aP, double* __restrict__ fronts,
@@ -1482,6 +1488,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     plan_.assign(nLevels_, LevelPlan());
     std::vector<int> smallList, bigList;
     std::vector<int4> ea;
+    std::vector<int> bigFd; // packed records of the fronts of the multi-workgroup path (k_extend_add)
     std::vector<int4> desc;
     size_t maxSmallLds = 0, maxSolveLds = 0, maxTriLds = 0, maxBwdLds = 0;
     for (int l = 0; l < nLevels_; ++l) {
@@ -1518,12 +1525,35 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         maxSmallLds = std::max(maxSmallLds, P.smallLds);
         maxSolveLds = std::max(maxSolveLds, P.solveLds);
         maxTriLds = std::max(maxTriLds, P.triLds);
-        // extend-add descriptors (fronts with children only): lower-triangular 64 x 64 tiles of the parent
+        // extend-add descriptors: lower-triangular 64 x 64 tiles of the parent, each pointing at the parent's packed record
         P.ea.off = (int)ea.size();
         for (int s : big) { // every lower-triangle tile is written (children sums or zeros): the fronts are never zero-filled
+            const int first = (int)(bigFd.size() / FD_STRIDE);
+            const int nkAll = sym.childPtr[s + 1] - sym.childPtr[s];
+            for (int k0 = 0; k0 == 0 || k0 < nkAll; k0 += FUSED_MAX_KIDS) {
+                const size_t base = bigFd.size();
+                bigFd.resize(base + FD_STRIDE, 0);
+                int* d = bigFd.data() + base;
+                const long long off = sym.frontOff[s];
+                std::memcpy(d, &off, 8);
+                d[2] = sym.N(s);
+                d[3] = sym.nc(s);
+                const int nk = std::min(FUSED_MAX_KIDS, nkAll - k0);
+                d[8] = std::max(nk, 0);
+                d[9] = (k0 + FUSED_MAX_KIDS < nkAll) ? (int)(base / FD_STRIDE) + 1 : -1;
+                for (int q = 0; q < nk; ++q) {
+                    const int c = sym.child[sym.childPtr[s] + k0 + q];
+                    int* k = d + 16 + 6 * q;
+                    const long long coff = sym.frontOff[c];
+                    std::memcpy(k, &coff, 8);
+                    k[2] = sym.N(c);
+                    k[3] = sym.nc(c);
+                    k[4] = sym.invPtr[c];
+                }
+            }
             const int nt = (sym.N(s) + TS - 1) / TS;
             for (int ti = 0; ti < nt; ++ti)
-                for (int tj = 0; tj <= ti; ++tj) ea.push_back(make_int4(s, ti, tj, 0));
+                for (int tj = 0; tj <= ti; ++tj) ea.push_back(make_int4(first, ti, tj, 0));
         }
         P.ea.cnt = (int)ea.size() - P.ea.off;
         // big-front step descriptors: launch 0 factors panel 0, launch j + 1 applies panel j and factors panel j + 1
@@ -1720,6 +1750,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     bigList_.upload(bigList, stream);
     if (ea.empty()) ea.push_back(make_int4(0, 0, 0, 0));
     eaDesc_.upload(ea.data(), ea.size(), stream);
+    if (bigFd.empty()) bigFd.resize(FD_STRIDE, 0);
+    bigFd_.upload(bigFd, stream);
     if (desc.empty()) desc.push_back(make_int4(0, 0, 0, 0));
     desc_.upload(desc.data(), desc.size(), stream);
     if (maxSmallLds > 48 * 1024)
@@ -1828,7 +1860,7 @@ void MfNumeric::enqueueFactor(const double* a_dev)
         }
 #endif
         if (P.ea.cnt) {
-            hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, tv, fronts_.p);
+            hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, bigFd_.p, inv_.p, fronts_.p);
             const int na = bigAOff_[l + 1] - bigAOff_[l];
             if (na)
                 hipLaunchKernelGGL(k_scatter_big, dim3((na + 255) / 256), dim3(256), 0, stream_, na, bigASrc_.p + bigAOff_[l],
