@@ -93,6 +93,15 @@ int ipcgpu_set_xtilde(ipcgpu_ctx*, const double* xTilta_colmajor);
 /* read back derived per-element / per-node data (any pointer may be NULL) */
 int ipcgpu_get_features(ipcgpu_ctx*, double* restTriInv_9nT, double* triArea_nT, double* mass_nV,
     double* mu_nT, double* lambda_nT);
+/* nV = nT = 0 until ipcgpu_set_mesh was called */
+int ipcgpu_get_mesh_dims(ipcgpu_ctx*, int* nV, int* nT);
+/* Hand over the arrays Mesh<3> already holds instead of having them re-derived from (V_rest, F, E, nu, rho): restTriInv
+   (Mesh.hpp:163, one 3x3 per tet, column-major inside the 9), triArea (:151), the diagonal of massMatrix (:148, lumped),
+   u / lambda (:150, per tet).  Any pointer may be NULL (that array keeps what ipcgpu_set_mesh computed).  Call after
+   ipcgpu_set_mesh; lets per-element state the reference modified after construction (component materials, rescaled
+   masses) reach the device unchanged. */
+int ipcgpu_set_mesh_features(ipcgpu_ctx*, const double* restTriInv_9nT, const double* triArea_nT, const double* mass_nV,
+    const double* mu_nT, const double* lambda_nT);
 /* Mesh::checkInversion (Mesh.cpp:715-764): *ok = 1 when no element has det < 0 */
 int ipcgpu_check_inversion(ipcgpu_ctx*, int* ok);
 
@@ -121,6 +130,10 @@ int ipcgpu_linsys_get_pattern(ipcgpu_ctx*, int* ia, int* ja); /* get_ia / get_ja
 int ipcgpu_linsys_set_zero(ipcgpu_ctx*); /* setZero, :348 */
 int ipcgpu_linsys_get_values(ipcgpu_ctx*, double* a); /* get_a, :465 */
 int ipcgpu_linsys_set_values(ipcgpu_ctx*, const double* a);
+/* Batched form of the per-entry calls below for an adapter that keeps LinSysSolver's host-side addCoeff / setCoeff calls
+   (LinSysSolver.hpp:331-348, 402-410) but owns the values in HBM: for every entry k of the CSR
+   a[k] = (isSet && isSet[k]) ? setVal[k] + delta[k] : a[k] + delta[k].  isSet / setVal may be NULL (pure accumulate). */
+int ipcgpu_linsys_apply_host_updates(ipcgpu_ctx*, const double* delta_nnz, const unsigned char* isSet_nnz, const double* setVal_nnz);
 int ipcgpu_linsys_add_coeff(ipcgpu_ctx*, int row, int col, double v); /* addCoeff :402 (row>col ignored) */
 int ipcgpu_linsys_set_coeff(ipcgpu_ctx*, int row, int col, double v); /* setCoeff :331 */
 int ipcgpu_linsys_multiply(ipcgpu_ctx*, const double* x, double* Ax); /* multiply :238 */

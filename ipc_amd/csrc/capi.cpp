@@ -304,6 +304,46 @@ int ipcgpu_get_features(ipcgpu_ctx* c, double* A, double* vol, double* mass, dou
         return IPCGPU_OK;
     });
 }
+int ipcgpu_get_mesh_dims(ipcgpu_ctx* c, int* nV, int* nT)
+{
+    return guarded([&] {
+        need(c != nullptr, "null context");
+        if (nV) *nV = c->mesh ? c->mesh->nV : 0;
+        if (nT) *nT = c->mesh ? c->mesh->nT : 0;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_set_mesh_features(ipcgpu_ctx* c, const double* A, const double* vol, const double* mass, const double* mu, const double* lam)
+{
+    return guarded([&] {
+        bind(c);
+        HipMesh& m = M(c);
+        need(m.nV > 0 && m.nT > 0, "call ipcgpu_set_mesh first");
+        if (A) {
+            for (int t = 0; t < m.nT; ++t)
+                for (int k = 0; k < 9; ++k) m.restTriInv[(size_t)k * m.nT + t] = A[9 * (size_t)t + k];
+            m.d_A.upload(m.restTriInv, c->stream);
+        }
+        if (vol) {
+            m.triArea.assign(vol, vol + m.nT);
+            m.d_vol.upload(m.triArea, c->stream);
+        }
+        if (mass) {
+            m.mass.assign(mass, mass + m.nV);
+            m.d_mass.upload(m.mass, c->stream);
+        }
+        if (mu) {
+            m.mu.assign(mu, mu + m.nT);
+            m.d_mu.upload(m.mu, c->stream);
+        }
+        if (lam) {
+            m.lam.assign(lam, lam + m.nT);
+            m.d_lam.upload(m.lam, c->stream);
+        }
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_check_inversion(ipcgpu_ctx* c, int* ok)
 {
     return guarded([&] {
@@ -438,6 +478,26 @@ int ipcgpu_linsys_set_values(ipcgpu_ctx* c, const double* a)
         HipLinSysSolver& l = L(c);
         need(l.numRows > 0, "no pattern");
         HIP_CHECK(hipMemcpyAsync(l.d_a.p, a, sizeof(double) * l.ja.size(), hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_apply_host_updates(ipcgpu_ctx* c, const double* delta, const unsigned char* isSet, const double* setVal)
+{
+    return guarded([&] {
+        bind(c);
+        HipLinSysSolver& l = L(c);
+        need(l.numRows > 0, "no pattern");
+        need(delta != nullptr, "delta must not be NULL");
+        need((isSet == nullptr) == (setVal == nullptr), "isSet and setVal go together");
+        const size_t nnz = l.ja.size();
+        l.hostDelta.upload(delta, nnz, c->stream);
+        if (isSet) {
+            l.hostSetMask.upload(isSet, nnz, c->stream);
+            l.hostSetVal.upload(setVal, nnz, c->stream);
+        }
+        launch_apply_host_updates((long long)nnz, l.hostDelta.p, isSet ? l.hostSetMask.p : nullptr, isSet ? l.hostSetVal.p : nullptr, l.d_a.p,
+            c->stream);
         HIP_CHECK(hipStreamSynchronize(c->stream));
         return IPCGPU_OK;
     });

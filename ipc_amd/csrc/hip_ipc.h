@@ -55,6 +55,8 @@ public:
     std::vector<int> ia, ja; // 0-based symmetric-upper CSR (host copy, get_ia / get_ja)
     DevBuf<int> d_ia, d_ja;
     DevBuf<double> d_a;
+    DevBuf<double> hostDelta, hostSetVal; // staging of ipcgpu_linsys_apply_host_updates
+    DevBuf<unsigned char> hostSetMask;
     // per-node row geometry + per-tet edge slots used by the element kernels
     std::vector<int> rowBase, rowLen;
     DevBuf<int> d_rowBase, d_rowLen, d_edgeP0;

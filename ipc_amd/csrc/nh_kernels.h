@@ -54,6 +54,8 @@ void launch_colmajor_to_aos(int nV, const double* src, double* dst, hipStream_t 
 void launch_aos_to_colmajor(int nV, const double* src, double* dst, hipStream_t s);
 // symmetric-upper CSR times vector and diagonal preconditioner (LinSysSolver.hpp:238-253, 411-420)
 void launch_csr_symv(int nRows, const int* ia, const int* ja, const double* a, const double* x, double* y, hipStream_t s);
+// a[k] = mask && mask[k] ? setVal[k] + delta[k] : a[k] + delta[k]  (host-side addCoeff / setCoeff of an adapter, flushed in one pass)
+void launch_apply_host_updates(long long nnz, const double* delta, const unsigned char* mask, const double* setVal, double* a, hipStream_t s);
 void launch_precond_diag(int nRows, const int* ia, const double* a, const double* in, double* out, hipStream_t s);
 // BE update (Optimizer.cpp:570-580, 1236-1257): dxElastic = x - xTilde; acc = (vel_new - vel) / dt; vel = (x - xPrev) / dt;
 // xPrev = x; xTilde = xPrev + dt vel + dt^2 g (DBC: xPrev)

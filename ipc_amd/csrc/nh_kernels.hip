@@ -588,6 +588,16 @@ void launch_csr_symv(int nRows, const int* ia, const int* ja, const double* a, c
     hipLaunchKernelGGL(k_csr_symv_zero, dim3(nblk(nRows)), dim3(BLOCK), 0, s, nRows, y);
     hipLaunchKernelGGL(k_csr_symv, dim3(nblk(nRows)), dim3(BLOCK), 0, s, nRows, ia, ja, a, x, y);
 }
+__global__ void k_apply_host_updates(long long nnz, const double* __restrict__ delta, const unsigned char* __restrict__ mask,
+    const double* __restrict__ setVal, double* __restrict__ a)
+{
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nnz) a[k] = (mask && mask[k]) ? setVal[k] + delta[k] : a[k] + delta[k];
+}
+void launch_apply_host_updates(long long nnz, const double* delta, const unsigned char* mask, const double* setVal, double* a, hipStream_t s)
+{
+    if (nnz) hipLaunchKernelGGL(k_apply_host_updates, dim3(nblk(nnz)), dim3(BLOCK), 0, s, nnz, delta, mask, setVal, a);
+}
 void launch_precond_diag(int nRows, const int* ia, const double* a, const double* in, double* out, hipStream_t s)
 {
     if (nRows) hipLaunchKernelGGL(k_precond_diag, dim3(nblk(nRows)), dim3(BLOCK), 0, s, nRows, ia, a, in, out);
