@@ -634,9 +634,9 @@ int ipcgpu_contact_build(ipcgpu_ctx* c, double dHat, int* counts)
         HipContact& k = CT(c);
         k.buildConstraintSet(m, m.d_x.p, m.d_dbc.p, dHat);
         if (counts) {
-            counts[0] = (int)k.active.size();
-            counts[1] = (int)k.para.size();
-            counts[2] = (int)k.csPTEE.size();
+            counts[0] = k.nActive();
+            counts[1] = k.nPara();
+            counts[2] = k.nCand();
         }
         return IPCGPU_OK;
     });
@@ -644,7 +644,9 @@ int ipcgpu_contact_build(ipcgpu_ctx* c, double dHat, int* counts)
 int ipcgpu_contact_get(ipcgpu_ctx* c, int* a4, int* p4, int* pe2, int* cs2)
 {
     return guarded([&] {
+        bind(c);
         HipContact& k = CT(c);
+        k.syncHost();
         for (size_t i = 0; a4 && i < k.active.size(); ++i)
             for (int j = 0; j < 4; ++j) a4[4 * i + j] = k.active[i][j];
         for (size_t i = 0; i < k.para.size(); ++i) {
@@ -1128,9 +1130,9 @@ int ipcgpu_opt_get_contact_state(ipcgpu_ctx* c, int* counts6, int* pair2)
         HipOptimizer& o = O(c);
         need(o.ipOn(), "neither self collision nor a half-space is enabled");
         if (counts6) {
-            counts6[0] = o.selfCollision ? (int)o.contact->active.size() : 0;
-            counts6[1] = o.selfCollision ? (int)o.contact->para.size() : 0;
-            counts6[2] = o.selfCollision ? (int)o.contact->csPTEE.size() : 0;
+            counts6[0] = o.selfCollision ? o.contact->nActive() : 0;
+            counts6[1] = o.selfCollision ? o.contact->nPara() : 0;
+            counts6[2] = o.selfCollision ? o.contact->nCand() : 0;
             counts6[3] = 0;
             for (const auto& h : o.planes) counts6[3] += (int)h->set.size();
             counts6[4] = o.nFullCCD;

@@ -30,9 +30,15 @@ public:
     DevBuf<int> d_SF, d_SVI, d_SFE; // d_SF: int[3 nSF] (t0 t1 t2 per triangle), d_SFE: int[2 nSFE]
     DevBuf<double> d_xRest; // rest positions xyz-interleaved (eps_x needs rest edge lengths)
     // sets
+    // The sets live in HBM (d_active ... d_csPTEE with the counts below); the host vectors are mirrors that syncHost() fills
+    // when somebody needs the tuples on the host (tests, the connectivity of a pattern change, friction lagging).
     std::vector<std::array<int, 4>> active, para;
     std::vector<std::array<int, 2>> paraEIEJ, csPTEE;
-    DevBuf<int> d_active, d_para, d_paraEIEJ;
+    DevBuf<int> d_active, d_para, d_paraEIEJ, d_csPTEE;
+    int nActive() const { return nActive_; }
+    int nPara() const { return nPara_; }
+    int nCand() const { return nCand_; }
+    void syncHost() const;
     bool surfaceSet = false;
 
     void setSurface(const HipMesh& mesh, int nSF, const int* SF_colmajor);
@@ -41,7 +47,9 @@ public:
     // returns #active
     int buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat);
     double energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
-    void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev);
+    // useActive / usePara: initKappa leaves the mollified set out (Optimizer.cpp:2262-2270)
+    void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev, bool useActive = true,
+        bool usePara = true);
     void hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
         double* a_dev);
     void connectivity(std::vector<std::pair<int, int>>& pairs) const;
@@ -53,6 +61,7 @@ public:
         int* nCand);
     bool isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev);
     void evalStencils(const std::vector<std::array<int, 4>>& ids, const double* x_dev, std::vector<double>& d2);
+    void closeStencils(const double* x_dev, double dTol, std::vector<std::array<int, 4>>& ids, std::vector<double>& d2);
     double maxSurfaceSpeed(const double* p_dev); // max_{v in SVI} |p_v|  (CFL bound, Optimizer.cpp:1947-1953)
     // lagged friction of the self-contact set: MMActiveSet_lastH, MMLambda_lastH, MMDistCoord, MMTanBasis
     std::vector<std::array<int, 4>> fricSet;
@@ -81,6 +90,13 @@ private:
     DevBuf<unsigned long long> ccdOut_;
     DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
     DevBuf<double> bboxPartial_;
+    // on-device assembly of the sets (buildConstraintSet)
+    int nActive_ = 0, nPara_ = 0, nCand_ = 0;
+    mutable bool hostStale_ = false;
+    DevBuf<unsigned long long> sortKeyIn_, sortKeyOut_, flags_, flagPos_, dupHi_, dupHiOut_;
+    DevBuf<unsigned> dupLo_, dupLoOut_;
+    DevBuf<int> sortValIn_, permPT_, permEE_, dupTuple_, dupIdx_, dupIdx2_, head_, headPos_, closeIdx_;
+    DevBuf<double> closeVal_;
     DevBuf<char> scanTmp_;
 };
 

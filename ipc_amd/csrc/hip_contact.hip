@@ -1013,6 +1013,122 @@ __global__ __launch_bounds__(BLOCK) void k_eval_stencils(int n, const int* __res
     out[i] = dist_only(s.kind, X);
 }
 
+// ---- constraint-set assembly on the device (SelfCollisionHandler.cpp:2411-2476) ----------------------------------------------
+// The narrow phase appends candidate records through an atomic counter, in no particular order.  The reference emits them in
+// primitive order (vertex by vertex, edge by edge) and merges the point-point / point-edge duplicates in a std::map keyed by
+// the 4-tuple.  Same result here without the host: radix sort by the primitive pair, classification + stable compaction by a
+// prefix sum, a second radix sort of the duplicate candidates by tuple (signed lexicographic = the map's order), run lengths.
+__global__ void k_rec_keys(int n, const int* __restrict__ rec, int shift, unsigned long long* __restrict__ key, int* __restrict__ val)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    key[i] = ((unsigned long long)(unsigned)rec[6 * (size_t)i + 4] << shift) | (unsigned)rec[6 * (size_t)i + 5];
+    val[i] = i;
+}
+// category of a record: 0 direct active, 1 duplicate candidate (PP / PE), 2 mollified parallel edge pair.  Packed counters for
+// one 64-bit prefix sum: bits 0..20 direct, 21..41 duplicate, 42..62 parallel.
+__device__ __forceinline__ int rec_category(const int* r, bool isEE)
+{
+    if (!isEE) return r[3] < 0 ? 1 : 0;
+    return r[3] >= 0 ? 0 : (r[3] == -1 ? 1 : 2);
+}
+__global__ void k_classify(int nPT, int nEE, const int* __restrict__ recPT, const int* __restrict__ permPT, const int* __restrict__ recEE,
+    const int* __restrict__ permEE, int* __restrict__ csPTEE, unsigned long long* __restrict__ flags)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nPT + nEE) return;
+    const bool isEE = j >= nPT;
+    const int* r = isEE ? recEE + 6 * (size_t)permEE[j - nPT] : recPT + 6 * (size_t)permPT[j];
+    csPTEE[2 * (size_t)j] = isEE ? r[4] : -r[4] - 1;
+    csPTEE[2 * (size_t)j + 1] = r[5];
+    flags[j] = 1ull << (21 * rec_category(r, isEE));
+}
+__device__ __forceinline__ unsigned bias(int v) { return (unsigned)v ^ 0x80000000u; } // signed order -> unsigned order
+__global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict__ recPT, const int* __restrict__ permPT,
+    const int* __restrict__ recEE, const int* __restrict__ permEE, const unsigned long long* __restrict__ pos, int* __restrict__ active,
+    int* __restrict__ dupTuple, unsigned long long* __restrict__ dupHi, unsigned* __restrict__ dupLo, int* __restrict__ dupIdx,
+    int* __restrict__ para, int* __restrict__ paraEIEJ)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nPT + nEE) return;
+    const bool isEE = j >= nPT;
+    const int* r = isEE ? recEE + 6 * (size_t)permEE[j - nPT] : recPT + 6 * (size_t)permPT[j];
+    const unsigned long long p = pos[j];
+    const int cat = rec_category(r, isEE);
+    const int q = (int)((p >> (21 * cat)) & 0x1fffff);
+    if (cat == 0) {
+        for (int k = 0; k < 4; ++k) active[4 * (size_t)q + k] = r[k];
+    }
+    else if (cat == 1) {
+        for (int k = 0; k < 4; ++k) dupTuple[4 * (size_t)q + k] = r[k];
+        dupHi[q] = ((unsigned long long)bias(r[0]) << 32) | bias(r[1]);
+        dupLo[q] = bias(r[2]); // r[3] == -1 for every duplicate candidate
+        dupIdx[q] = q;
+    }
+    else {
+        int* o = para + 4 * (size_t)q;
+        o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
+        if (r[3] >= -nSFE - 1) {
+            o[3] = -1;
+            paraEIEJ[2 * (size_t)q] = r[4];
+            paraEIEJ[2 * (size_t)q + 1] = -r[3] - 2;
+        }
+        else {
+            o[3] = -r[3] - nSFE - 2;
+            paraEIEJ[2 * (size_t)q] = -1;
+            paraEIEJ[2 * (size_t)q + 1] = -1;
+        }
+    }
+}
+__global__ void k_gather_u64(int n, const int* __restrict__ idx, const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+// sorted duplicate candidates -> run heads
+__global__ void k_dup_heads(int n, const int* __restrict__ order, const int* __restrict__ tuple, int* __restrict__ head)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool h = i == 0;
+    if (!h) {
+        const int* a = tuple + 4 * (size_t)order[i];
+        const int* b = tuple + 4 * (size_t)order[i - 1];
+        h = a[0] != b[0] || a[1] != b[1] || a[2] != b[2];
+    }
+    head[i] = h ? 1 : 0;
+}
+// one thread per sorted duplicate: the head of a run writes (tuple, -multiplicity) behind the direct entries
+__global__ void k_dup_emit(int n, int nDirect, const int* __restrict__ order, const int* __restrict__ tuple, const int* __restrict__ head,
+    const int* __restrict__ headPos, int* __restrict__ active)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !head[i]) return;
+    int len = 1;
+    while (i + len < n && !head[i + len]) ++len; // runs are short (a vertex pair is seen from a handful of triangles)
+    const int* a = tuple + 4 * (size_t)order[i];
+    int* o = active + 4 * (size_t)(nDirect + headPos[i]);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = -len;
+}
+// stencils of the active set closer than dTol (closeMConstraint bookkeeping, Optimizer.cpp:2365-2440): index + distance
+__global__ void k_close_stencils(int n, const int* __restrict__ ids, const double* __restrict__ x, double dTol, int cap, int* __restrict__ outIdx,
+    double* __restrict__ outVal, int* __restrict__ counter)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Stencil s = decode(ids + 4 * (size_t)i);
+    double X[4][3];
+    gatherX(x, s.node, s.n, X);
+    const double d = dist_only(s.kind, X);
+    if (d < dTol) {
+        const int slot = atomicAdd(counter, 1);
+        if (slot < cap) {
+            outIdx[slot] = i;
+            outVal[slot] = d;
+        }
+    }
+}
+
 inline int nblk(long long n, int b = BLOCK) { return (int)((n + b - 1) / b); }
 
 } // namespace
@@ -1057,6 +1173,8 @@ void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc)
     HIP_CHECK(hipStreamSynchronize(stream));
     surfaceSet = true;
     active.clear();
+    nActive_ = nPara_ = nCand_ = 0;
+    hostStale_ = false;
     para.clear();
     paraEIEJ.clear();
     csPTEE.clear();
@@ -1091,6 +1209,9 @@ void HipContact::uploadSets()
     d_para.uploadGrow(p, stream);
     d_paraEIEJ.uploadGrow(q, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
+    nActive_ = (int)active.size();
+    nPara_ = (int)para.size();
+    hostStale_ = false; // the host vectors are the source here
 }
 
 int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat)
@@ -1147,7 +1268,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     buildCells(nSFE, 0, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
     counters_.alloc(2);
     int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
-    std::vector<int> recPT, recEE;
+    int nPT = 0, nEE = 0;
     for (;;) {
         outPT_.alloc(6 * (size_t)capPT);
         outEE_.alloc(6 * (size_t)capEE);
@@ -1163,66 +1284,126 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
             capEE = std::max(capEE, cnt[1] + cnt[1] / 4);
             continue;
         }
-        recPT.resize(6 * (size_t)cnt[0]);
-        recEE.resize(6 * (size_t)cnt[1]);
-        if (cnt[0]) outPT_.download(recPT.data(), recPT.size(), stream);
-        if (cnt[1]) outEE_.download(recEE.data(), recEE.size(), stream);
+        nPT = cnt[0];
+        nEE = cnt[1];
         break;
     }
-    // deterministic order (the kernels append through atomics): by (svI, sfI) and (eI, eJ), as a serial scan would emit
-    auto sortRecs = [](std::vector<int>& r) {
-        const size_t n = r.size() / 6;
-        // the pair of primitive indices (both >= 0) packed into one 64-bit key next to the record's position: a flat,
-        // cache-friendly sort instead of an indirect comparison through the 24-byte records
-        std::vector<std::pair<unsigned long long, unsigned>> key(n);
-        for (size_t i = 0; i < n; ++i)
-            key[i] = { ((unsigned long long)(unsigned)r[6 * i + 4] << 32) | (unsigned)r[6 * i + 5], (unsigned)i };
-        std::sort(key.begin(), key.end());
-        std::vector<int> s(r.size());
-        for (size_t i = 0; i < n; ++i)
-            for (int k = 0; k < 6; ++k) s[6 * i + k] = r[6 * (size_t)key[i].second + k];
-        r.swap(s);
+    // ---- sets assembled on the device (kernels above); two scalar read-backs: the category totals, the number of merged tuples
+    const int n = nPT + nEE;
+    nCand_ = n;
+    hostStale_ = true;
+    d_csPTEE.ensure(2 * (size_t)std::max(n, 1));
+    if (n == 0) {
+        nActive_ = nPara_ = 0;
+        return 0;
+    }
+    auto tmp = [&](size_t bytes) {
+        if (scanTmp_.n < bytes) scanTmp_.alloc(bytes + bytes / 4);
+        return (void*)scanTmp_.p;
     };
-    sortRecs(recPT);
-    sortRecs(recEE);
-    // merge (SelfCollisionHandler.cpp:2411-2476)
-    active.clear();
-    para.clear();
-    paraEIEJ.clear();
-    csPTEE.clear();
-    std::map<std::array<int, 4>, int> counter;
-    for (size_t i = 0; i < recPT.size() / 6; ++i) {
-        const int* r = &recPT[6 * i];
-        csPTEE.push_back({ -r[4] - 1, r[5] });
-        std::array<int, 4> id{ r[0], r[1], r[2], r[3] };
-        if (id[3] < 0) ++counter[id];
-        else active.push_back(id);
+    auto bitsFor = [](long long v) {
+        int b = 1;
+        while ((1LL << b) <= v) ++b;
+        return b;
+    };
+    sortKeyIn_.ensure((size_t)n);
+    sortKeyOut_.ensure((size_t)n);
+    sortValIn_.ensure((size_t)n);
+    permPT_.ensure((size_t)std::max(nPT, 1));
+    permEE_.ensure((size_t)std::max(nEE, 1));
+    auto sortRecs = [&](int cnt_, const int* rec, int nFirst, int nSecond, int* perm) {
+        if (!cnt_) return;
+        const int shift = bitsFor(nSecond), endBit = shift + bitsFor(nFirst);
+        hipLaunchKernelGGL(k_rec_keys, dim3(nblk(cnt_)), dim3(BLOCK), 0, stream, cnt_, rec, shift, sortKeyIn_.p, sortValIn_.p);
+        size_t bytes = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, perm, cnt_, 0, endBit, stream);
+        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, perm, cnt_, 0, endBit, stream);
+    };
+    sortRecs(nPT, outPT_.p, nSVI, nSF, permPT_.p); // by (svI, sfI) ...
+    sortRecs(nEE, outEE_.p, nSFE, nSFE, permEE_.p); // ... and (eI, eJ): the order a serial scan emits
+    flags_.ensure((size_t)n + 1);
+    flagPos_.ensure((size_t)n + 1);
+    hipLaunchKernelGGL(k_classify, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, outPT_.p, permPT_.p, outEE_.p, permEE_.p, d_csPTEE.p, flags_.p);
+    HIP_CHECK(hipMemsetAsync(flags_.p + n, 0, sizeof(unsigned long long), stream));
+    {
+        size_t bytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags_.p, flagPos_.p, n + 1, stream);
+        hipcub::DeviceScan::ExclusiveSum(tmp(bytes), bytes, flags_.p, flagPos_.p, n + 1, stream);
     }
-    for (size_t i = 0; i < recEE.size() / 6; ++i) {
-        const int* r = &recEE[6 * i];
-        csPTEE.push_back({ r[4], r[5] });
-        std::array<int, 4> id{ r[0], r[1], r[2], r[3] };
-        if (id[3] >= 0) active.push_back(id);
-        else if (id[3] == -1) ++counter[id];
-        else if (id[3] >= -nSFE - 1) {
-            para.push_back({ id[0], id[1], id[2], -1 });
-            paraEIEJ.push_back({ r[4], -id[3] - 2 });
-        }
-        else {
-            para.push_back({ id[0], id[1], id[2], -id[3] - nSFE - 2 });
-            paraEIEJ.push_back({ -1, -1 });
-        }
+    unsigned long long totals = 0;
+    HIP_CHECK(hipMemcpyAsync(&totals, flagPos_.p + n, sizeof(totals), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const int nDirect = (int)(totals & 0x1fffff), nDup = (int)((totals >> 21) & 0x1fffff), nPar = (int)((totals >> 42) & 0x1fffff);
+    if (n >= (1 << 21)) throw StateError("constraint-set build: more than 2 M candidate pairs in one set");
+    d_active.ensure(4 * (size_t)std::max(nDirect + nDup, 1));
+    d_para.ensure(4 * (size_t)std::max(nPar, 1));
+    d_paraEIEJ.ensure(2 * (size_t)std::max(nPar, 1));
+    dupTuple_.ensure(4 * (size_t)std::max(nDup, 1));
+    dupHi_.ensure((size_t)std::max(nDup, 1));
+    dupHiOut_.ensure((size_t)std::max(nDup, 1));
+    dupLo_.ensure((size_t)std::max(nDup, 1));
+    dupLoOut_.ensure((size_t)std::max(nDup, 1));
+    dupIdx_.ensure((size_t)std::max(nDup, 1));
+    dupIdx2_.ensure((size_t)std::max(nDup, 1));
+    hipLaunchKernelGGL(k_scatter_sets, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSFE, outPT_.p, permPT_.p, outEE_.p, permEE_.p, flagPos_.p,
+        d_active.p, dupTuple_.p, dupHi_.p, dupLo_.p, dupIdx_.p, d_para.p, d_paraEIEJ.p);
+    int nUnique = 0;
+    if (nDup) {
+        // lexicographic order of (id0, id1, id2): stable sort by the last component, then by the first two.  The second sort
+        // gathers its 64-bit keys through the order of the first.
+        size_t bytes = 0;
+        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupLo_.p, dupLoOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 32, stream);
+        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupLo_.p, dupLoOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 32, stream);
+        hipLaunchKernelGGL(k_gather_u64, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, dupIdx2_.p, dupHi_.p, dupHiOut_.p);
+        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupHiOut_.p, dupHi_.p, dupIdx2_.p, dupIdx_.p, nDup, 0, 64, stream);
+        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupHiOut_.p, dupHi_.p, dupIdx2_.p, dupIdx_.p, nDup, 0, 64, stream);
+        // dupIdx_ = order of the duplicates; run heads, their ranks, one tuple per run
+        head_.ensure((size_t)nDup + 1);
+        headPos_.ensure((size_t)nDup + 1);
+        hipLaunchKernelGGL(k_dup_heads, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, dupIdx_.p, dupTuple_.p, head_.p);
+        HIP_CHECK(hipMemsetAsync(head_.p + nDup, 0, sizeof(int), stream));
+        hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, head_.p, headPos_.p, nDup + 1, stream);
+        hipcub::DeviceScan::ExclusiveSum(tmp(bytes), bytes, head_.p, headPos_.p, nDup + 1, stream);
+        hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, nDirect, dupIdx_.p, dupTuple_.p, head_.p, headPos_.p, d_active.p);
+        HIP_CHECK(hipMemcpyAsync(&nUnique, headPos_.p + nDup, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
     }
-    for (const auto& kv : counter) active.push_back({ kv.first[0], kv.first[1], kv.first[2], -kv.second });
-    uploadSets();
-    return (int)active.size();
+    nActive_ = nDirect + nUnique;
+    nPara_ = nPar;
+    return nActive_;
+}
+
+// host mirrors of the sets (tests, connectivity on a pattern change, friction lagging): fetched when somebody asks
+void HipContact::syncHost() const
+{
+    if (!hostStale_) return;
+    HipContact* self = const_cast<HipContact*>(this);
+    std::vector<int> a(4 * (size_t)nActive_), p(4 * (size_t)nPara_), q(2 * (size_t)nPara_), c(2 * (size_t)nCand_);
+    if (nActive_) d_active.download(a.data(), a.size(), stream);
+    if (nPara_) {
+        d_para.download(p.data(), p.size(), stream);
+        d_paraEIEJ.download(q.data(), q.size(), stream);
+    }
+    if (nCand_) d_csPTEE.download(c.data(), c.size(), stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    self->active.resize(nActive_);
+    for (int i = 0; i < nActive_; ++i) self->active[i] = { a[4 * (size_t)i], a[4 * (size_t)i + 1], a[4 * (size_t)i + 2], a[4 * (size_t)i + 3] };
+    self->para.resize(nPara_);
+    self->paraEIEJ.resize(nPara_);
+    for (int i = 0; i < nPara_; ++i) {
+        self->para[i] = { p[4 * (size_t)i], p[4 * (size_t)i + 1], p[4 * (size_t)i + 2], p[4 * (size_t)i + 3] };
+        self->paraEIEJ[i] = { q[2 * (size_t)i], q[2 * (size_t)i + 1] };
+    }
+    self->csPTEE.resize(nCand_);
+    for (int i = 0; i < nCand_; ++i) self->csPTEE[i] = { c[2 * (size_t)i], c[2 * (size_t)i + 1] };
+    self->hostStale_ = false;
 }
 
 double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
 {
-    const int n = (int)(active.size() + para.size());
+    const int n = nActive_ + nPara_;
     if (n == 0) return 0.0;
-    ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+    ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
     const int nb = nblk(n);
     if (partial.n < (size_t)nb) partial.alloc(nb);
     hipLaunchKernelGGL(k_contact_energy, dim3(nb), dim3(BLOCK), 0, stream, cv, dHat, partial.p);
@@ -1233,11 +1414,13 @@ double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf
     return out;
 }
 
-void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev)
+void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev,
+    bool useActive, bool usePara)
 {
-    const int n = (int)(active.size() + para.size());
+    const int nA = useActive ? nActive_ : 0, nP = usePara ? nPara_ : 0;
+    const int n = nA + nP;
     if (n) {
-        ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+        ContactView cv{ nA, nP, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
         hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, grad_dev);
     }
     hipLaunchKernelGGL(k_zero_projected, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, projectDBC, grad_dev);
@@ -1246,9 +1429,9 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
 void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
     double* a_dev)
 {
-    const int n = (int)(active.size() + para.size());
+    const int n = nActive_ + nPara_;
     if (!n) return;
-    ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+    ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(2);
     counters_.zero(stream);
@@ -1261,9 +1444,9 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
 
 bool HipContact::patternCovers(const HipLinSysSolver& lin)
 {
-    const int n = (int)(active.size() + para.size());
+    const int n = nActive_ + nPara_;
     if (!n) return true;
-    ContactView cv{ (int)active.size(), (int)para.size(), d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, nullptr, d_xRest.p };
+    ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, nullptr, d_xRest.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(2);
     counters_.zero(stream);
@@ -1278,6 +1461,7 @@ void HipContact::frictionLagClear() { fricSet.clear(); }
 
 void HipContact::frictionLagUpdate(const double* x_dev, double dHat, double kappa)
 {
+    syncHost();
     fricSet = active; // MMActiveSet_lastH = MMActiveSet (Optimizer.cpp:1596-1598); d_active holds the same tuples
     const int n = (int)fricSet.size();
     if (!n) return;
@@ -1364,6 +1548,7 @@ void HipContact::frictionConnectivity(std::vector<std::pair<int, int>>& pairs) c
 // (a stencil that slides from point-point to point-triangle needs no new matrix blocks then).
 void HipContact::candidateConnectivity(std::vector<std::pair<int, int>>& pairs) const
 {
+    syncHost();
     auto link = [&](int a, int b) {
         if (a != b) pairs.push_back({ std::min(a, b), std::max(a, b) });
     };
@@ -1384,6 +1569,7 @@ void HipContact::candidateConnectivity(std::vector<std::pair<int, int>>& pairs) 
 
 void HipContact::connectivity(std::vector<std::pair<int, int>>& pairs) const
 {
+    syncHost();
     pairs.clear();
     auto link = [&](int a, int b) {
         if (a != b) pairs.push_back({ std::min(a, b), std::max(a, b) });
@@ -1562,21 +1748,15 @@ static void decodeCcdOut(const unsigned long long* h, double stepSize, double* o
 
 double HipContact::ccdPartial(const double* x_dev, const double* p_dev, double slackness, double stepSize, int* pair2)
 {
-    const int n = (int)csPTEE.size();
+    const int n = nCand_;
     if (pair2) pair2[0] = pair2[1] = 0;
     if (!n) return stepSize;
-    std::vector<int> flat(2 * (size_t)n);
-    for (int i = 0; i < n; ++i) {
-        flat[2 * (size_t)i] = csPTEE[i][0];
-        flat[2 * (size_t)i + 1] = csPTEE[i][1];
-    }
-    d_cand_.uploadGrow(flat, stream);
     ccdOut_.alloc(4);
     const unsigned long long init[2] = { ~0ull, ~0ull };
     HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
     CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
     for (int pass = 0; pass < 2; ++pass)
-        hipLaunchKernelGGL(k_ccd_list, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_cand_.p, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, slackness, stepSize, pass,
+        hipLaunchKernelGGL(k_ccd_list, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_csPTEE.p, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, slackness, stepSize, pass,
             o);
     unsigned long long h[2];
     HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -1639,6 +1819,47 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
     int f[2];
     counters_.download(f, 2, stream);
     return f[0] != 0;
+}
+
+// stencils of the current active set closer than dTol, in set order, with their squared distances: evaluated and
+// filtered on the device, only the (few) hits come back
+void HipContact::closeStencils(const double* x_dev, double dTol, std::vector<std::array<int, 4>>& ids, std::vector<double>& d2)
+{
+    ids.clear();
+    d2.clear();
+    const int n = nActive_;
+    if (!n) return;
+    int cap = std::max<int>(1024, (int)closeIdx_.n);
+    for (;;) {
+        closeIdx_.ensure((size_t)cap);
+        closeVal_.ensure((size_t)cap);
+        counters_.alloc(2);
+        counters_.zero(stream);
+        hipLaunchKernelGGL(k_close_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_active.p, x_dev, dTol, cap, closeIdx_.p, closeVal_.p, counters_.p);
+        int cnt = 0;
+        counters_.download(&cnt, 1, stream);
+        if (cnt > cap) {
+            cap = cnt + cnt / 4;
+            continue;
+        }
+        if (!cnt) return;
+        std::vector<int> idx(cnt);
+        std::vector<double> val(cnt);
+        closeIdx_.download(idx.data(), cnt, stream);
+        closeVal_.download(val.data(), cnt, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        std::vector<int> order(cnt);
+        for (int i = 0; i < cnt; ++i) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return idx[a] < idx[b]; }); // set order (the kernel appends atomically)
+        std::vector<int> tup(4 * (size_t)cnt);
+        // the tuples of the hits: gather from the device set
+        syncHost();
+        for (int k : order) {
+            ids.push_back(active[idx[k]]);
+            d2.push_back(val[k]);
+        }
+        return;
+    }
 }
 
 void HipContact::evalStencils(const std::vector<std::array<int, 4>>& ids, const double* x_dev, std::vector<double>& d2)

@@ -324,7 +324,7 @@ bool HipOptimizer::nextSubproblem()
 
 size_t HipOptimizer::nConstraints() const
 {
-    size_t n = selfCollision ? contact->active.size() : 0;
+    size_t n = selfCollision ? (size_t)contact->nActive() : 0;
     for (const auto& h : planes) n += h->set.size();
     return n;
 }
@@ -333,6 +333,9 @@ int HipOptimizer::addHalfSpace(HipContact* c, const double* origin3, const doubl
 {
     // `ground` / `halfSpace` script keywords (Config.cpp:306-345) -> animConfig.collisionObjects; friction is a SURVEY 8f row
     if (!c || !c->surfaceSet) throw StateError("opt_add_half_space before set_surface");
+    // one dHat for the whole interior-point problem, as in the reference (a single `dHat` script keyword, Config.cpp:41-45):
+    // a second object registered with another value would silently change the first one's activation distance
+    if ((selfCollision || !planes.empty()) && eps != dHatEps) throw ArgError("all collision objects of a context share one dHat (Config.cpp:41-45): got a different dHatEps");
     contact = c;
     planes.emplace_back(new HipHalfSpace(stream, origin3, normal3));
     dHatEps = eps;
@@ -354,6 +357,7 @@ void HipOptimizer::enableSelfCollision(HipContact* c, double eps)
 {
     // `selfCollisionOn` + interior point; dHat = dHatEps^2 * bbox diagonal^2 (Optimizer.cpp:1534-1537, Config.cpp:41-45)
     if (!c || !c->surfaceSet) throw StateError("opt_enable_self_collision before set_surface");
+    if (!planes.empty() && eps != dHatEps) throw ArgError("all collision objects of a context share one dHat (Config.cpp:41-45): got a different dHatEps");
     contact = c;
     selfCollision = true;
     if (const char* e = std::getenv("IPCGPU_PATTERN_PAD")) patternPad = std::atof(e); // < 1: exact pattern, 1: full stencils of the current candidates, > 1: also look ahead in distance
@@ -445,8 +449,12 @@ void HipOptimizer::loadStatus(const std::string& path)
         int rowsIn = 0, dimIn = 0;
         ss >> rowsIn >> dimIn;
         if (rowsIn < 0 || rowsIn > mesh.nV || dimIn != 3) throw StateError("status file does not match the mesh");
+        if (ss.fail()) throw StateError("malformed section header in status file " + path);
         if (zeroFirst) std::fill(dst.begin(), dst.end(), 0.0);
         for (int v = 0; v < rowsIn; ++v) in >> dst[3 * (size_t)v] >> dst[3 * (size_t)v + 1] >> dst[3 * (size_t)v + 2];
+        // a truncated or malformed section leaves failbit set: a restart from a corrupt checkpoint must not go on with
+        // partly read (or stale) arrays
+        if (in.fail()) throw StateError("truncated or malformed section in status file " + path);
     };
     std::string line;
     while (std::getline(in, line)) {
@@ -461,6 +469,7 @@ void HipOptimizer::loadStatus(const std::string& path)
             if (n < 0 || n > (long long)n3) throw StateError("status file does not match the mesh");
             std::fill(vel.begin(), vel.end(), 0.0);
             for (long long i = 0; i < n; ++i) in >> vel[i];
+            if (in.fail()) throw StateError("truncated or malformed velocity section in status file " + path);
         }
         else if (token == "acceleration") readRows(ss, acc, true);
         else if (token == "dx_Elastic") readRows(ss, dx, true);
@@ -576,12 +585,7 @@ void HipOptimizer::postLineSearch()
             }
     }
     if (!selfCollision) return;
-    contact->evalStencils(contact->active, mesh.d_x.p, d);
-    for (size_t i = 0; i < contact->active.size(); ++i)
-        if (d[i] < dTol) {
-            closeID.push_back(contact->active[i]);
-            closeVal.push_back(d[i]);
-        }
+    contact->closeStencils(mesh.d_x.p, dTol, closeID, closeVal);
 }
 
 void HipOptimizer::ensurePatchPlan()
@@ -607,12 +611,7 @@ void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activ
         if (selfCollision && selfFric > 0.0) contact->frictionGradientAdd(mesh.d_x.p, d_xPrev.p, fricDHat, selfFric, grad_dev);
     }
     if (!contact) return;
-    std::vector<std::array<int, 4>> keepPara, keepActive;
-    if (activeOnly || !selfCollision) keepPara.swap(contact->para);
-    if (!selfCollision) keepActive.swap(contact->active);
-    contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, projectDBC, grad_dev);
-    if (activeOnly || !selfCollision) keepPara.swap(contact->para);
-    if (!selfCollision) keepActive.swap(contact->active);
+    contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, projectDBC, grad_dev, selfCollision, selfCollision && !activeOnly);
 }
 
 void HipOptimizer::elasticInertiaGradient(bool projectDBC)
@@ -660,7 +659,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         // the pattern follows the contact connectivity (augmentConnectivity into vNeighbor_IP, Optimizer.cpp:3560-3612);
         // only pairs that are not mesh edges change it
         std::vector<std::pair<int, int>> extra, fresh;
-        if (contact->active.size() + contact->para.size()) contact->connectivity(extra);
+        if (contact->nActive() + contact->nPara()) contact->connectivity(extra);
         if (fricDHat > 0.0 && selfFric > 0.0) contact->frictionConnectivity(extra); // lagged set (:3565-3566)
         for (const auto& e : extra) {
             const int* b = mesh.nb.data() + mesh.nbPtr[e.first];

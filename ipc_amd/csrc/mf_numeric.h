@@ -85,6 +85,7 @@ private:
     DevBuf<int> smallList_, bigList_;
     DevBuf<int4> desc_; // all big-front step descriptors
     PinnedBuf<int> hflag_;
+    PinnedBuf<int> hSrc_, hLoc_, hBigSrc_, hBigDst_; // pinned staging of the A-entry lists (grow-only)
 };
 
 } // namespace ipcgpu

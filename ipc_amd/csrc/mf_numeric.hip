@@ -24,9 +24,11 @@
 // No vendor BLAS is involved: rocSOLVER's potrf / rocBLAS' trsm+syrk cost ~150 tiny launches per front.
 #include "mf_numeric.h"
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace ipcgpu {
 
@@ -1385,14 +1387,23 @@ __global__ __launch_bounds__(WG) void k_xinv_bwd(const int4* __restrict__ desc, 
 void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
 {
     if (side_) HIP_CHECK(hipStreamSynchronize(side_)); // buffers are about to be replaced
+    const bool timeIt = std::getenv("IPCGPU_MF_SETUP_TIMES") != nullptr;
+    auto tSetup = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timeIt) return;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "mf setup %-28s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tSetup).count());
+        tSetup = now;
+    };
     sym_ = &sym;
     stream_ = stream;
     dropGraphs();
     if (const char* e = std::getenv("IPCGPU_MF_GRAPH")) useGraph_ = std::atoi(e) != 0;
     ns_ = sym.ns;
     nLevels_ = (int)sym.levelPtr.size() - 1;
-    fronts_.alloc((size_t)sym.frontOff[ns_]);
-    fronts_.zero(stream); // once per analysis: the numeric phase writes every entry it reads, this only keeps never-read padding finite
+    fronts_.ensure((size_t)sym.frontOff[ns_]);
+    fronts_.zeroN((size_t)sym.frontOff[ns_], stream); // once per analysis: the numeric phase writes every entry it reads, this only keeps never-read padding finite
     w_.alloc((size_t)sym.wOff[ns_]);
     yperm_.alloc((size_t)sym.n);
     bperm_.alloc((size_t)sym.n);
@@ -1416,6 +1427,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         nDiagBlocks_ = di[ns_];
         dinv_.alloc((size_t)di[ns_] * NB * NB);
     }
+    lap("buffers + tree uploads");
     flag_.alloc(1);
     hflag_.alloc(4);
     if (!side_ && !std::getenv("IPCGPU_MF_NO_SIDE_STREAM")) {
@@ -1444,47 +1456,98 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_NT512_N")) ntBigN = std::atoi(e);
     auto isFused = [&](int s) { return sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds; };
     // entries of A grouped by owning front: (source index, offset inside the LDS panel) for the fused fronts,
-    // (source index, offset in the front buffer) per level for the others
+    // (source index, offset in the front buffer) per level for the others.  A parallel counting sort on a few host threads,
+    // written straight into pinned staging buffers (grow-only, like the device buffers they are copied to): this runs on
+    // every pattern change of a contact scene.
     {
         const size_t nnz = sym.aDst.size();
-        std::vector<int> aPtr(ns_ + 1, 0);
         std::vector<char> fused(ns_);
         for (int s = 0; s < ns_; ++s) fused[s] = isFused(s);
-        for (size_t k = 0; k < nnz; ++k)
-            if (fused[sym.aFront[k]]) aPtr[sym.aFront[k] + 1]++;
-        for (int s = 0; s < ns_; ++s) aPtr[s + 1] += aPtr[s];
-        std::vector<int> aSrc(std::max<size_t>(aPtr[ns_], 1)), aLoc(std::max<size_t>(aPtr[ns_], 1));
-        std::vector<int> pos(aPtr.begin(), aPtr.end() - 1);
+        // bucket of an entry: fused front s -> s, other front of level l -> ns_ + l
+        const int nBuckets = ns_ + nLevels_;
+        const int nThreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+        std::vector<std::vector<int>> cnt(nThreads, std::vector<int>(nBuckets, 0));
+        auto range = [&](int t) { return std::make_pair(nnz * t / nThreads, nnz * (t + 1) / nThreads); };
+        auto bucketOf = [&](size_t k) {
+            const int s = sym.aFront[k];
+            return fused[s] ? s : ns_ + sym.level[s];
+        };
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nThreads; ++t)
+                pool.emplace_back([&, t] {
+                    const auto r = range(t);
+                    int* c = cnt[t].data();
+                    for (size_t k = r.first; k < r.second; ++k) c[bucketOf(k)]++;
+                });
+            for (auto& th : pool) th.join();
+        }
+        // bucket starts: fused buckets share one index space (aSrc / aLoc), the level buckets another (bigASrc / bigADst)
+        std::vector<int> aPtr(ns_ + 1, 0);
         std::vector<int> bigCnt(nLevels_ + 1, 0);
-        for (size_t k = 0; k < nnz; ++k) {
-            const int s = sym.aFront[k];
-            if (fused[s]) {
-                const int64_t off = sym.aDst[k] - sym.frontOff[s]; // row + N * column, column < nc
-                aSrc[pos[s]] = (int)k;
-                aLoc[pos[s]++] = (int)off;
+        for (int bkt = 0; bkt < nBuckets; ++bkt) {
+            int tot = 0;
+            for (int t = 0; t < nThreads; ++t) {
+                const int c = cnt[t][bkt];
+                cnt[t][bkt] = tot; // offset of thread t inside the bucket
+                tot += c;
             }
-            else bigCnt[sym.level[s] + 1]++;
+            if (bkt < ns_) aPtr[bkt + 1] = aPtr[bkt] + tot;
+            else bigCnt[bkt - ns_ + 1] = bigCnt[bkt - ns_] + tot;
         }
-        for (int l = 0; l < nLevels_; ++l) bigCnt[l + 1] += bigCnt[l];
+        const size_t nFused = (size_t)aPtr[ns_], nBig = (size_t)bigCnt[nLevels_];
+        auto growPinned = [](PinnedBuf<int>& b, size_t n) {
+            if (b.n < n || !b.p) b.alloc(n + n / 4 + 16);
+        };
+        growPinned(hSrc_, nFused + 1);
+        growPinned(hLoc_, nFused + 1);
+        growPinned(hBigSrc_, nBig + 1);
+        growPinned(hBigDst_, 2 * (nBig + 1)); // 64-bit destinations
+        int* aSrc = hSrc_.p;
+        int* aLoc = hLoc_.p;
+        int* bSrc = hBigSrc_.p;
+        long long* bDst = reinterpret_cast<long long*>(hBigDst_.p);
+        {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nThreads; ++t)
+                pool.emplace_back([&, t] {
+                    const auto r = range(t);
+                    int* off = cnt[t].data();
+                    for (size_t k = r.first; k < r.second; ++k) {
+                        const int s = sym.aFront[k];
+                        if (fused[s]) {
+                            const int q = aPtr[s] + off[s]++;
+                            aSrc[q] = (int)k;
+                            aLoc[q] = (int)(sym.aDst[k] - sym.frontOff[s]); // row + N * column, column < nc
+                        }
+                        else {
+                            const int l = sym.level[s];
+                            const int q = bigCnt[l] + off[ns_ + l]++;
+                            bSrc[q] = (int)k;
+                            bDst[q] = sym.aDst[k];
+                        }
+                    }
+                });
+            for (auto& th : pool) th.join();
+        }
         bigAOff_.assign(bigCnt.begin(), bigCnt.end());
-        std::vector<int> bSrc(std::max(bigCnt[nLevels_], 1));
-        std::vector<long long> bDst(std::max(bigCnt[nLevels_], 1));
-        std::vector<int> bpos(bigCnt.begin(), bigCnt.end() - 1);
-        for (size_t k = 0; k < nnz; ++k) {
-            const int s = sym.aFront[k];
-            if (fused[s]) continue;
-            const int q = bpos[sym.level[s]]++;
-            bSrc[q] = (int)k;
-            bDst[q] = sym.aDst[k];
-        }
         aPtrHost_ = aPtr;
-        nFusedA_ = aPtr[ns_];
-        aPerm_.alloc(std::max<size_t>(aPtr[ns_], 1));
-        aSrc_.upload(aSrc, stream);
-        aLoc_.upload(aLoc, stream);
-        bigASrc_.upload(bSrc, stream);
-        bigADst_.upload(bDst, stream);
+        nFusedA_ = (int)nFused;
+        aPerm_.ensure(std::max<size_t>(nFused, 1));
+        aSrc_.ensure(nFused + 1);
+        aLoc_.ensure(nFused + 1);
+        bigASrc_.ensure(nBig + 1);
+        bigADst_.ensure(nBig + 1);
+        if (nFused) {
+            HIP_CHECK(hipMemcpyAsync(aSrc_.p, aSrc, nFused * sizeof(int), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(aLoc_.p, aLoc, nFused * sizeof(int), hipMemcpyHostToDevice, stream));
+        }
+        if (nBig) {
+            HIP_CHECK(hipMemcpyAsync(bigASrc_.p, bSrc, nBig * sizeof(int), hipMemcpyHostToDevice, stream));
+            HIP_CHECK(hipMemcpyAsync(bigADst_.p, bDst, nBig * sizeof(long long), hipMemcpyHostToDevice, stream));
+        }
     }
+    lap("A-entry lists");
     plan_.assign(nLevels_, LevelPlan());
     std::vector<int> smallList, bigList;
     std::vector<int4> ea;
@@ -1599,6 +1662,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 for (int c0 = 0; c0 < sym.nc(s); c0 += 16) desc.push_back(make_int4(s, c0, 0, 0));
         P.bwdInit.cnt = (int)desc.size() - P.bwdInit.off;
     }
+    lap("level plans");
     {
         // packed descriptors of the fused fronts, in launch order
         std::vector<int> fd((std::max<size_t>(smallList.size(), 1)) * FD_STRIDE, 0);
@@ -1626,8 +1690,9 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 k[4] = sym.invPtr[c];
             }
         }
-        fdesc_.upload(fd, stream);
+        fdesc_.uploadGrow(fd, stream);
     }
+    lap("fused descriptors");
     {
         // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
         int xinvMin = 192;
@@ -1744,6 +1809,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         xinvX_.zero(stream);
         xinvT_.zero(stream);
     }
+    lap("inverse plan + buffers");
     if (smallList.empty()) smallList.push_back(0);
     smallList_.upload(smallList, stream);
     if (bigList.empty()) bigList.push_back(0);
@@ -1751,7 +1817,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (ea.empty()) ea.push_back(make_int4(0, 0, 0, 0));
     eaDesc_.upload(ea.data(), ea.size(), stream);
     if (bigFd.empty()) bigFd.resize(FD_STRIDE, 0);
-    bigFd_.upload(bigFd, stream);
+    bigFd_.uploadGrow(bigFd, stream);
     if (desc.empty()) desc.push_back(make_int4(0, 0, 0, 0));
     desc_.upload(desc.data(), desc.size(), stream);
     if (maxSmallLds > 48 * 1024)
@@ -1772,6 +1838,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipFuncSetAttribute((const void*)k_big_bwd_tri, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxTriLds));
     }
     HIP_CHECK(hipStreamSynchronize(stream));
+    lap("uploads + attributes");
 }
 
 MfNumeric::~MfNumeric()

@@ -243,13 +243,14 @@ class AssembledScene:
 
 
 def assemble(cfg, read_mesh):
-    """main.cpp:880-1198: transform every shape (R (p * scale) + translate), concatenate, select Dirichlet nodes per shape."""
+    """main.cpp:880-1198: select Dirichlet / Neumann nodes per shape on the mesh as read, transform the shape (R (p * scale) + translate), concatenate."""
     Vs, Ts, SFs, nr, tr, dirichlet, neumann = [], [], [], [0], [0], [], []
     for sh in cfg.shapes:
         V, T, SF = read_mesh(sh.path)
-        V = (V * sh.scale) @ _rot(sh.rotate_deg).T + sh.translate
         off = nr[-1]
-        for rel_min, rel_max, lin, ang, t0, t1 in sh.dbc:  # IglUtils::Init_Dirichlet on the shape's own box
+        # Dirichlet / Neumann nodes are picked on the mesh AS READ (IglUtils::Init_Dirichlet on newV, main.cpp:1045-1068); the
+        # shape is scaled / rotated / translated only afterwards (main.cpp:1073-1077), so the relative box follows the shape
+        for rel_min, rel_max, lin, ang, t0, t1 in sh.dbc:
             ids = _scene.select_dirichlet(V, SF, rel_min, rel_max)
             if len(ids):
                 dirichlet.append((ids + off, lin, ang, t0, t1))
@@ -257,6 +258,7 @@ def assemble(cfg, read_mesh):
             ids = _scene.select_dirichlet(V, SF, rel_min, rel_max)
             if len(ids):
                 neumann.append((ids + off, acc, t0, t1))
+        V = (V * sh.scale) @ _rot(sh.rotate_deg).T + sh.translate
         if sh.lin_vel is not None or sh.ang_vel_deg is not None:  # scripted component: every node moves (AnimScripter.cpp:1413-1435)
             ids = np.arange(V.shape[0], dtype=np.int32) + off
             dirichlet.append((ids, sh.lin_vel or (0, 0, 0), sh.ang_vel_deg or (0, 0, 0), 0.0, float("inf")))

@@ -71,6 +71,26 @@ def test_assemble_transforms_and_selects_like_main_cpp():
     assert not sc.velocity.any()  # initVel is not applied to Dirichlet nodes (AnimScripter.cpp:1327)
 
 
+def test_dirichlet_and_neumann_boxes_follow_the_shape_through_its_transform():
+    """main.cpp:1045-1068 picks the nodes on the mesh as read and transforms the shape afterwards (:1073-1077): a shape rotated
+    by 90 degrees about z (and mirrored by a negative scale) keeps the same node ids in its Dirichlet / Neumann sets."""
+    V0, F0 = scene.make_box(4, 1, 1, size=(4.0, 1.0, 1.0), origin=(0, 0, 0))
+    SF0 = scene.surface_tris(F0)
+    want_dbc = np.nonzero(V0[:, 0] < 0.05)[0]  # the x = 0 face of the untransformed bar
+    want_nbc = np.nonzero(V0[:, 0] > 3.95)[0]
+    for rot, scl in (("0 0 90", "1 1 1"), ("0 0 90", "-1 2 1"), ("0 90 0", "1 1 1"), ("0 0 0", "1 1 1")):
+        c = ss.SceneConfig.parse(f"shapes input 1\na.msh 1 2 3  {rot}  {scl} DBC 0 0 0  0.01 1 1  0 0 0  0 0 0 NBC 0.99 0 0  1 1 1  0 -3 0\n")
+        sc = ss.assemble(c, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+        assert np.array_equal(np.sort(sc.dirichlet[0][0]), want_dbc), (rot, scl)
+        assert np.array_equal(np.sort(sc.neumann[0][0]), want_nbc), (rot, scl)
+    # with the 90-degree rotation the selected face is NOT the low-x face of the transformed shape (what a selection after the
+    # transform would have picked): it is a y-extreme face
+    c = ss.SceneConfig.parse("shapes input 1\na.msh 0 0 0  0 0 90  1 1 1 DBC 0 0 0  0.01 1 1  0 0 0  0 0 0\n")
+    sc = ss.assemble(c, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    sel = sc.V[sc.dirichlet[0][0]]
+    assert np.ptp(sel[:, 1]) < 1e-12 and np.ptp(sel[:, 0]) > 0.5
+
+
 @pytest.mark.skipif(not os.path.isdir(REF_INPUT), reason="the reference's scene files are only present in the build container")
 def test_reference_scene_files_parse():
     ok, unsupported = [], {}
