@@ -75,15 +75,38 @@ __device__ __forceinline__ double cross_sqnorm(const double* v0, const double* v
     return dot3(n, n);
 }
 
+// 2 x 2 normal equations of dType_PT, solved the way the reference solves them: Eigen's pivoted LDL^T
+// ((basis * basis.transpose()).ldlt().solve(...), MeshCollisionUtils.hpp:2174, 2182, 2190) restated step by step -- largest
+// diagonal entry first (first maximum wins a tie), L10 = m01 / D0, D1 = m' - L10 (D0 L10), then P, L^-1, D^-1 (entries of D not
+// above 1 / DBL_MAX give 0), L^-T, P^T.  Cramer's rule gives the same parameters up to rounding, but the classification
+// compares them with 0 and 1 exactly, so the rounding is part of the contract.
 __device__ __forceinline__ void edge_frame_param(const double* e, const double* nVec, const double* r, double* p0, double* p1)
 {
     double b1[3];
     cross3(e, nVec, b1);
     const double m00 = dot3(e, e), m01 = dot3(e, b1), m11 = dot3(b1, b1);
     const double r0 = dot3(e, r), r1 = dot3(b1, r);
-    const double det = m00 * m11 - m01 * m01;
-    *p0 = (r0 * m11 - r1 * m01) / det;
-    *p1 = (m00 * r1 - m01 * r0) / det;
+    double d0 = m00, d1 = m11;
+    const bool swapped = fabs(m11) > fabs(m00);
+    if (swapped) {
+        d0 = m11;
+        d1 = m00;
+    }
+    double x0 = swapped ? r1 : r0, x1 = swapped ? r0 : r1;
+    if (!(fabs(d0) > 0.0)) { // the whole matrix is zero: Eigen leaves L = I, D = 0 and solve() returns zeros
+        *p0 = 0.0;
+        *p1 = 0.0;
+        return;
+    }
+    const double l10 = m01 / d0;
+    d1 -= l10 * (d0 * l10);
+    x1 -= l10 * x0;
+    const double tol = 1.0 / 1.7976931348623157e308;
+    x0 = (fabs(d0) > tol) ? x0 / d0 : 0.0;
+    x1 = (fabs(d1) > tol) ? x1 / d1 : 0.0;
+    x0 -= l10 * x1;
+    *p0 = swapped ? x1 : x0;
+    *p1 = swapped ? x0 : x1;
 }
 
 __device__ inline int dType_PT(const double* v0, const double* v1, const double* v2, const double* v3)

@@ -407,6 +407,14 @@ def accd(kind, X, P, eta=0.2, tmax=1.0):
     return lib().orc_accd(C.c_int(kind), _dp(X), _dp(P), C.c_double(eta), C.c_double(tmax))
 
 
+def ccd_exact(kind, X, P, tmax=1.0):
+    """First time in [0, tmax] at which the point touches the triangle / the edges cross (eta = 0, cubic coplanarity roots), inf if none."""
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
+    P = np.ascontiguousarray(P, dtype=np.float64).reshape(4, 3)
+    lib().orc_ccd_exact.restype = C.c_double
+    return lib().orc_ccd_exact(C.c_int(kind), _dp(X), _dp(P), C.c_double(tmax))
+
+
 def ccd_partial(contacts: "Contacts", mesh: "Mesh", p, slackness=0.8, step=1.0):
     p = np.ascontiguousarray(p, dtype=np.float64)
     arg = C.c_int(-1)

@@ -2,6 +2,8 @@
 #include "orc_contact.h"
 #include "orc_api.h"
 #include <cassert>
+#include <cmath>
+#include <limits>
 #include <cstdio>
 #include <algorithm>
 #include <initializer_list>
@@ -215,16 +217,39 @@ void mollifier(double c, double eps_x, double* e, double* eg, double* eH)
     }
 }
 
-// 2x2 normal equations of dType_PT: parameters (s, t) of v0 in the frame {e, e x n} anchored at the edge start
+// 2 x 2 normal equations of dType_PT, solved the way the reference solves them: Eigen's pivoted LDL^T
+// ((basis * basis.transpose()).ldlt().solve(...), MeshCollisionUtils.hpp:2174, 2182, 2190) restated step by step -- largest
+// diagonal entry first (first maximum wins a tie), L10 = m01 / D0, D1 = m' - L10 (D0 L10), then P, L^-1, D^-1 (entries of D not
+// above 1 / DBL_MAX give 0), L^-T, P^T.  Cramer's rule gives the same parameters up to rounding, but the classification
+// compares them with 0 and 1 exactly, so the rounding is part of the contract.
+// parameters (s, t) of v0 in the frame {e, e x n} anchored at the edge start
 static void edgeFrameParam(const double* e, const double* nVec, const double* r, double* p0, double* p1)
 {
     double b1[3];
     cross3(e, nVec, b1);
     const double m00 = dot3(e, e), m01 = dot3(e, b1), m11 = dot3(b1, b1);
     const double r0 = dot3(e, r), r1 = dot3(b1, r);
-    const double det = m00 * m11 - m01 * m01;
-    *p0 = (r0 * m11 - r1 * m01) / det;
-    *p1 = (m00 * r1 - m01 * r0) / det;
+    double d0 = m00, d1 = m11;
+    const bool swapped = fabs(m11) > fabs(m00);
+    if (swapped) {
+        d0 = m11;
+        d1 = m00;
+    }
+    double x0 = swapped ? r1 : r0, x1 = swapped ? r0 : r1;
+    if (!(fabs(d0) > 0.0)) { // the whole matrix is zero: Eigen leaves L = I, D = 0 and solve() returns zeros
+        *p0 = 0.0;
+        *p1 = 0.0;
+        return;
+    }
+    const double l10 = m01 / d0;
+    d1 -= l10 * (d0 * l10);
+    x1 -= l10 * x0;
+    const double tol = 1.0 / 1.7976931348623157e308;
+    x0 = (fabs(d0) > tol) ? x0 / d0 : 0.0;
+    x1 = (fabs(d1) > tol) ? x1 / d1 : 0.0;
+    x0 -= l10 * x1;
+    *p0 = swapped ? x1 : x0;
+    *p1 = swapped ? x0 : x1;
 }
 
 int dType_PT(const double v0[3], const double v1[3], const double v2[3], const double v3[3])
@@ -827,6 +852,135 @@ double accd(int kind, const double X0[4][3], const double P0[4][3], double eta, 
     return toc;
 }
 
+// ---- exact time of first contact (eta = 0), the cross-check of the conservative bound above ----------------------------------
+// The geometric core of CTCD::vertexFaceCTCD / edgeEdgeCTCD (Vouga's CTCD as used through CCD-Wrapper, un-vendored): with linear
+// trajectories the four points are coplanar at the roots of a cubic in t, and a collision happens at the first root in
+// [0, tmax] at which the point lies inside the triangle / the two segments cross.  (CTCD thickens this by eta with a sextic
+// "distance to plane <= eta" polynomial and Jenkins-Traub; only its eta = 0 booleans are pinned by the reference's tests.)
+// Roots are bracketed between the critical points of the cubic and bisected: no closed-form cancellation.  Used by the tests
+// only: accd() may never return more than this, and on analytically solvable motions both agree.
+static double cubicAt(const double c[4], double t) { return ((c[3] * t + c[2]) * t + c[1]) * t + c[0]; }
+static int cubicRoots01(const double c[4], double tmax, double roots[3])
+{
+    // monotone pieces of [0, tmax]
+    double brk[4];
+    int nb = 0;
+    brk[nb++] = 0.0;
+    const double a = 3.0 * c[3], b = 2.0 * c[2], cc = c[1];
+    if (std::fabs(a) > 0.0) {
+        const double disc = b * b - 4.0 * a * cc;
+        if (disc > 0.0) {
+            const double q = -0.5 * (b + (b >= 0 ? 1.0 : -1.0) * std::sqrt(disc));
+            double r1 = q / a, r2 = (q != 0.0) ? cc / q : r1;
+            if (r1 > r2) std::swap(r1, r2);
+            if (r1 > 0.0 && r1 < tmax) brk[nb++] = r1;
+            if (r2 > 0.0 && r2 < tmax && r2 != r1) brk[nb++] = r2;
+        }
+    }
+    else if (std::fabs(b) > 0.0) {
+        const double r = -cc / b;
+        if (r > 0.0 && r < tmax) brk[nb++] = r;
+    }
+    brk[nb++] = tmax;
+    int n = 0;
+    for (int i = 0; i + 1 < nb; ++i) {
+        double lo = brk[i], hi = brk[i + 1];
+        double flo = cubicAt(c, lo), fhi = cubicAt(c, hi);
+        if (flo == 0.0) {
+            if (n == 0 || roots[n - 1] != lo) roots[n++] = lo;
+            continue;
+        }
+        if ((flo < 0.0) == (fhi < 0.0) && fhi != 0.0) continue;
+        for (int it = 0; it < 200 && hi - lo > 0.0; ++it) {
+            const double mid = 0.5 * (lo + hi);
+            if (mid == lo || mid == hi) break;
+            const double fm = cubicAt(c, mid);
+            if ((fm < 0.0) == (flo < 0.0) && fm != 0.0) {
+                lo = mid;
+                flo = fm;
+            }
+            else hi = mid;
+        }
+        roots[n++] = hi;
+        if (n == 3) break;
+    }
+    return n;
+}
+// coefficients of det[a(t), b(t), c(t)] with a(t) = a0 + t a1 etc.
+static void tripleCubic(const double a0[3], const double a1[3], const double b0[3], const double b1[3], const double c0[3], const double c1[3], double c[4])
+{
+    double b0c0[3], b0c1[3], b1c0[3], b1c1[3];
+    cross3(b0, c0, b0c0);
+    cross3(b0, c1, b0c1);
+    cross3(b1, c0, b1c0);
+    cross3(b1, c1, b1c1);
+    double m1[3], m1b[3];
+    for (int k = 0; k < 3; ++k) {
+        m1[k] = b0c1[k] + b1c0[k];
+        m1b[k] = b1c1[k];
+    }
+    c[0] = dot3(a0, b0c0);
+    c[1] = dot3(a1, b0c0) + dot3(a0, m1);
+    c[2] = dot3(a1, m1) + dot3(a0, m1b);
+    c[3] = dot3(a1, m1b);
+}
+double ccdExact(int kind, const double X[4][3], const double P[4][3], double tmax)
+{
+    double a0[3], a1[3], b0[3], b1[3], c0[3], c1[3];
+    if (kind == K_PT) { // (p - t0) . ((t1 - t0) x (t2 - t0))
+        sub3(X[0], X[1], a0);
+        sub3(P[0], P[1], a1);
+        sub3(X[2], X[1], b0);
+        sub3(P[2], P[1], b1);
+        sub3(X[3], X[1], c0);
+        sub3(P[3], P[1], c1);
+    }
+    else { // (c - a) . ((b - a) x (d - c))
+        sub3(X[2], X[0], a0);
+        sub3(P[2], P[0], a1);
+        sub3(X[1], X[0], b0);
+        sub3(P[1], P[0], b1);
+        sub3(X[3], X[2], c0);
+        sub3(P[3], P[2], c1);
+    }
+    double c[4], roots[3];
+    tripleCubic(a0, a1, b0, b1, c0, c1, c);
+    const int n = cubicRoots01(c, tmax, roots);
+    for (int i = 0; i < n; ++i) {
+        const double t = roots[i];
+        double Y[4][3];
+        for (int k = 0; k < 4; ++k)
+            for (int d = 0; d < 3; ++d) Y[k][d] = X[k][d] + t * P[k][d];
+        // coplanar at t: contact iff the point lies inside the triangle / the segments cross.  Plain geometric tests with a
+        // relative tolerance (the reference's closest-feature typing re-routes exactly coplanar edge pairs to an end-point
+        // case, MeshCollisionUtils.hpp:2129-2141, which is not what "touching" means here)
+        const double tol = 1e-9;
+        if (kind == K_PT) {
+            double e1[3], e2[3], r[3];
+            sub3(Y[2], Y[1], e1);
+            sub3(Y[3], Y[1], e2);
+            sub3(Y[0], Y[1], r);
+            const double m00 = dot3(e1, e1), m01 = dot3(e1, e2), m11 = dot3(e2, e2), r0 = dot3(e1, r), r1 = dot3(e2, r);
+            const double det = m00 * m11 - m01 * m01;
+            if (!(det > 0.0)) continue; // degenerate triangle
+            const double u = (r0 * m11 - r1 * m01) / det, v = (m00 * r1 - m01 * r0) / det;
+            if (u >= -tol && v >= -tol && u + v <= 1.0 + tol) return t;
+        }
+        else {
+            double u[3], v[3], w[3];
+            sub3(Y[1], Y[0], u);
+            sub3(Y[3], Y[2], v);
+            sub3(Y[0], Y[2], w);
+            const double a = dot3(u, u), b = dot3(u, v), c2 = dot3(v, v), d = dot3(u, w), e = dot3(v, w);
+            const double D = a * c2 - b * b;
+            if (!(D > 1e-20 * a * c2)) continue; // parallel edges: no single crossing point
+            const double sc = (b * e - c2 * d) / D, tc = (a * e - b * d) / D;
+            if (sc >= -tol && sc <= 1.0 + tol && tc >= -tol && tc <= 1.0 + tol) return t;
+        }
+    }
+    return std::numeric_limits<double>::infinity();
+}
+
 static void pairNodes(const Mesh& m, const std::array<int, 2>& pr, int& kind, int node[4])
 {
     if (pr[0] < 0) { // (-svI-1, sfI)
@@ -984,6 +1138,16 @@ bool isIntersected(const Mesh& m)
 using namespace orc;
 extern "C" {
 
+double orc_ccd_exact(int kind, const double* X12, const double* P12, double tmax)
+{
+    double X[4][3], P[4][3];
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = X12[3 * k + c];
+            P[k][c] = P12[3 * k + c];
+        }
+    return ccdExact(kind, X, P, tmax);
+}
 double orc_accd(int kind, const double* X12, const double* P12, double eta, double tmax)
 {
     double X[4][3], P[4][3];

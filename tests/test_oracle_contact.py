@@ -230,6 +230,58 @@ def test_ccd_reproduces_the_reference_ctcd_hit_table(orc):
             assert (t < 1.0) == (u0 - u1 >= 2.0), (u0, u1, t)
 
 
+def test_exact_time_of_impact_and_the_conservative_bound(orc):
+    """The eta = 0 core of CTCD (first coplanarity root of the cubic at which the features touch) restated in the oracle as the
+    cross-check of the contract-based bound: analytically solvable times of impact, the reference's hit table, and
+    accd <= exact on random motions (the additive bound never steps past a contact; with eta -> 0 it converges to it)."""
+    # a vertex dropping on a triangle at constant speed: t = h / v; the triangle may move too
+    tri = np.array([[-1, 0, 1], [1, 0, 1], [0, 0, -1]], dtype=float)
+    for h, vp, vt in ((0.5, 2.0, 0.0), (0.25, 0.3, -0.2), (1.0, 0.4, 0.7)):
+        X = np.vstack([[0.1, h, 0.2], tri])
+        P = np.zeros((4, 3))
+        P[0, 1] = -vp
+        P[1:, 1] = vt
+        t = orc.ccd_exact(orc.K_PT, X, P)
+        want = h / (vp + vt)
+        assert (abs(t - want) < 1e-14) if want <= 1 else np.isinf(t), (h, vp, vt, t)
+    # two perpendicular edges closing along y, plus a sideways drift that makes them miss
+    XE = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, -1], [0, 1, 1]], dtype=float)
+    PE = np.zeros((4, 3))
+    PE[:2, 1] = 3.0
+    PE[2:, 1] = -1.0
+    assert abs(orc.ccd_exact(orc.K_EE, XE, PE) - 0.5) < 1e-14
+    PE[2:, 0] = 5.0  # the second edge leaves sideways before they are level
+    assert np.isinf(orc.ccd_exact(orc.K_EE, XE, PE))
+    # the reference's hit table (CollisionConstraintTests.cpp:18-35, 83-99) with the exact test
+    for u0 in (-1.1, 0.0, 1.1):
+        for u1 in (-1.1, 0.0, 1.1):
+            X = np.array([[0, 1, -0.5], [-1, 0, 1], [1, 0, 1], [0, 0, -1]], dtype=float)
+            P = np.zeros((4, 3))
+            P[0, 1] = u0
+            P[1:, 1] = u1
+            assert np.isfinite(orc.ccd_exact(orc.K_PT, X, P)) == (u1 - u0 >= 1.0)
+            PE2 = np.zeros((4, 3))
+            PE2[:2, 1] = u0
+            PE2[2:, 1] = u1
+            XE2 = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, -1], [0, 1, 1]], dtype=float)
+            assert np.isfinite(orc.ccd_exact(orc.K_EE, XE2, PE2)) == (u0 - u1 >= 2.0)
+    # random motions: the conservative bound never passes the exact time of impact, and tightens towards it with eta
+    rng = np.random.default_rng(77)
+    hits = 0
+    for trial in range(400):
+        kind = orc.K_PT if trial % 2 == 0 else orc.K_EE
+        X = rng.normal(size=(4, 3))
+        P = 1.5 * rng.normal(size=(4, 3))
+        te = orc.ccd_exact(kind, X, P)
+        ta = orc.accd(kind, X, P, eta=0.2, tmax=1.0)
+        assert ta <= min(te, 1.0) + 1e-12, (trial, ta, te)
+        if np.isfinite(te):
+            hits += 1
+            tight = orc.accd(kind, X, P, eta=1e-4, tmax=1.0)
+            assert ta <= tight + 1e-12 and te - tight < 2e-3 * max(1.0, te), (trial, tight, te)
+    assert hits > 20
+
+
 def test_ccd_is_conservative(orc, blocks):
     m, V, dHat = blocks["m"], blocks["V"], blocks["dHat"]
     nA = V.shape[0] // 2
