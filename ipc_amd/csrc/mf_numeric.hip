@@ -36,6 +36,7 @@ namespace {
 
 constexpr int NB = 32;
 constexpr int LDP = NB + 1; // padded leading dimension of 32x32 blocks in LDS
+constexpr int LDX = NB + 1; // same for the inverse of a pivot block
 constexpr int WG = 256;
 constexpr int WGB = WG; // big-front step: three row waves + one pivot wave, one per SIMD
 constexpr int ROW_WAVES_B = 3; // row waves per role-B workgroup (1 was measured slower: 3x the workgroups, each repeating the pivot work)
@@ -301,6 +302,132 @@ __device__ __forceinline__ void row_trsm32_lean(double (&x)[NB], const double* b
     }
 }
 
+// Cholesky of a (<=) 32 x 32 pivot block by one wave, blocked by 8 with the off-diagonal work on the matrix cores.
+//   blk[k * LDP + r] = A(r, k), r >= k (LDS, k-major, full 32 x LDP block; entries with an index >= w are ZERO on entry)
+//   on exit: L in the lower triangle, rdiag[k] = 1 / L(k, k) (0 for k >= w), and -- so that wave_trinv32_fast can skip its
+//   substitution step -- the inverses of the four 8 x 8 diagonal blocks of L in Xs (identity-padded; Xs must be zero elsewhere)
+// Per 8-column panel: the 8 x 8 diagonal block is factored and inverted in registers by 8 lanes (lane = row, v_readlane
+// broadcasts: the only serial part, ~1/4 of what the 32-wide scalar loop serialises), the rows below are L21 = A21 X^T and the
+// trailing block is A22 -= L21 L21^T, both as v_mfma_f64_16x16x4_f64 products formed transposed (A[l & 15][l >> 4],
+// B[l >> 4][l & 15], D row = (l >> 4) + 4 reg, col = l & 15) with operands read from / written to the LDS block.
+// wave_potrf32 performs sum_j (31 - j) broadcast-multiply-add triplets on one wave's VALU, this version 4 x 28 of them.
+__device__ __forceinline__ bool wave_potrf32_blocked(double* blk, int w, int lane, double* rdiag, double* Xs)
+{
+    constexpr int ld = LDP;
+    const int lo = lane & 15, hi = lane >> 4;
+    bool bad = false;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int j0 = 8 * b;
+        if (j0 >= w) { // uniform: nothing left, identity padding of the inverse
+            if (lane < 8) {
+                rdiag[j0 + lane] = 0.0;
+                Xs[(j0 + lane) * LDX + j0 + lane] = 1.0;
+            }
+            continue;
+        }
+        // ---- (i) 8 x 8 diagonal block, lane r < 8 holds row j0 + r (rows / columns >= w: identity)
+        double a[8], x[8], myRd = 0.0;
+        const int r = lane & 7;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const double v = blk[(j0 + c) * ld + j0 + r];
+            a[c] = (c <= r) ? ((j0 + r < w && j0 + c < w) ? v : (c == r ? 1.0 : 0.0)) : 0.0;
+        }
+        double rd[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            double djj = bcast_lane(a[j], j);
+            if (!(djj > 0.0)) {
+                bad = true;
+                djj = 1.0;
+            }
+            const double invd = rsqrt_nr(djj);
+            rd[j] = invd;
+            if (r == j) myRd = invd;
+            a[j] *= invd;
+            double m[8];
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) m[c] = bcast_lane(a[j], c);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = j + 1; c < 8; ++c) a[c] -= a[j] * m[c];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- (ii) its inverse: lane c < 8 computes column c, L(q, k) broadcast from lane q
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            double acc = (q == r) ? 1.0 : 0.0;
+            double m[8];
+#pragma unroll
+            for (int k = 0; k < q; ++k) m[k] = bcast_lane(a[k], q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < q; ++k) acc -= m[k] * x[k];
+            x[q] = acc * rd[q];
+        }
+        if (lane < 8) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c <= r && j0 + r < w && j0 + c < w) blk[(j0 + c) * ld + j0 + r] = a[c];
+            rdiag[j0 + r] = (j0 + r < w) ? myRd : 0.0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) Xs[(j0 + r) * LDX + j0 + q] = x[q]; // X(j0 + q, j0 + r): column r of the inverse
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (b == 3 || j0 + 8 >= w) continue; // uniform: no rows below
+        // ---- (iii) rows below: L(R, j0 + c) = sum_k A(R, j0 + k) X(j0 + c, j0 + k), transposed product D(c, R)
+        f64x4 p0 = { 0.0, 0.0, 0.0, 0.0 }, p1 = { 0.0, 0.0, 0.0, 0.0 };
+        const int R0 = j0 + 8 + lo, R1 = j0 + 24 + lo;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kk = 4 * ks + hi;
+            const double xa = (lo < 8) ? Xs[(j0 + kk) * LDX + j0 + lo] : 0.0; // A[c = lo][kk] = X(j0 + c, j0 + kk)
+            const double b0 = (R0 < NB) ? blk[(j0 + kk) * ld + R0] : 0.0; // B[kk][R] = A(R, j0 + kk)
+            const double b1 = (R1 < NB) ? blk[(j0 + kk) * ld + min(R1, NB - 1)] : 0.0;
+            p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b0, p0, 0, 0, 0);
+            if (b == 0) p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b1, p1, 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { // rows c = hi + 4 i < 8 of the product
+            const int c = hi + 4 * i;
+            if (R0 < NB) blk[(j0 + c) * ld + R0] = p0[i];
+            if (b == 0 && R1 < NB) blk[(j0 + c) * ld + R1] = p1[i];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- (iv) trailing block: A(R, C) -= sum_k L(R, j0 + k) L(C, j0 + k) for R >= C >= j0 + 8, transposed product D(C, R)
+        //      16 x 16 tiles (tc, tr) of the remaining 24 / 16 / 8 rows: (0, 0) always, (0, 1) and (1, 1) for the first panel
+        f64x4 t00 = { 0.0, 0.0, 0.0, 0.0 }, t01 = { 0.0, 0.0, 0.0, 0.0 }, t11 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int kk = 4 * ks + hi;
+            const double l0 = (R0 < NB) ? blk[(j0 + kk) * ld + R0] : 0.0; // rows j0 + 8 + lo
+            const double l1 = (R1 < NB) ? blk[(j0 + kk) * ld + min(R1, NB - 1)] : 0.0; // rows j0 + 24 + lo
+            t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, l0, t00, 0, 0, 0);
+            if (b == 0) {
+                t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, l1, t01, 0, 0, 0);
+                t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, l1, t11, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int C0 = j0 + 8 + hi + 4 * i, C1 = j0 + 24 + hi + 4 * i; // D row -> column index C of the block
+            if (R0 < NB && C0 < NB && R0 >= C0) blk[C0 * ld + R0] -= t00[i];
+            if (b == 0) {
+                if (R1 < NB && C0 < NB) blk[C0 * ld + R1] -= t01[i]; // R1 >= 24 > C0
+                if (R1 < NB && C1 < NB && R1 >= C1) blk[C1 * ld + R1] -= t11[i];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return bad;
+}
+
 // X = L^-1 of a factored 32 x 32 pivot block by one wave, recursive doubling on the matrix cores.
 //   blk[k * ld + r] = L(r, k) for r > k (LDS, k-major), rdiag[k] = 1 / L(k, k); rows / columns >= w count as identity
 //   Xs[c * LDX + r] = X(r, c), all 32 x 32 entries written (zeros above the diagonal)
@@ -311,14 +438,16 @@ __device__ __forceinline__ void row_trsm32_lean(double (&x)[NB], const double* b
 // The first product of a pair leaves T in the accumulator layout, which is exactly the B-operand layout of the second
 // (register i holds row (l >> 4) + 4 i): no LDS round trip between them.  ~1.5 k cycles against ~6 k for the substitution
 // of wave_trinv32, and it runs inside the step that factored the block, so the panel rows can be solved by a product.
-constexpr int LDX = NB + 1;
+template <bool HAVE_DIAG8 = false>
 __device__ __forceinline__ void wave_trinv32_fast(const double* blk, int ld, const double* rdiag, int w, int lane, double* Xs)
 {
     const int lo = lane & 15, hi = lane >> 4;
-    for (int e = lane; e < NB * LDX; e += 64) Xs[e] = 0.0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane < NB) {
+    if (!HAVE_DIAG8) {
+        for (int e = lane; e < NB * LDX; e += 64) Xs[e] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!HAVE_DIAG8 && lane < NB) {
         const int b8 = lane & ~7, c = lane & 7;
         double Lr[8][8], rd[8], x[8];
 #pragma unroll
@@ -770,9 +899,18 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         // pivot wave (alone on its SIMD): Cholesky of the 32 x 32 block and its inverse while the row waves fetch and update
         // (the pivot chain is what every other wave of the step ends up waiting for: it gets issue priority on its SIMD)
         __builtin_amdgcn_s_setprio(3);
+#ifdef MF_POTRF_SCALAR
         if (wave_potrf32(A11, LDP, w1, tid - PIVOT_T0, rdiag)) atomicOr(flag, 1);
         MF_STEP_PHASE(12);
-        wave_trinv32_fast(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
+        wave_trinv32_fast<false>(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
+#else
+        for (int e = tid - PIVOT_T0; e < NB * LDX; e += 64) Xs[e] = 0.0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (wave_potrf32_blocked(A11, w1, tid - PIVOT_T0, rdiag, Xs)) atomicOr(flag, 1);
+        MF_STEP_PHASE(12);
+        wave_trinv32_fast<true>(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
+#endif
         __builtin_amdgcn_s_setprio(0);
     }
     else if (rowWave) {
