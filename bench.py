@@ -198,6 +198,20 @@ def main():
                 "algorithmic_bytes": bytes_asm, "avg_launch_ms": ms_asm,
                 "measured_stream_copy_GBs": stream_gbs,
             },
+            # the step is dominated by the sparse Cholesky, not by the HBM-bound assembly kernel above: its two kernel groups with
+            # their own bounds.  Factorisation: flops of the symbolic analysis / HIP-event time of the whole launch sequence, against
+            # the fp64 matrix-core rate (the guide lists no fp64 peak; 78.6 TFLOP/s = 256 CUs x 4 SIMDs x 32 MAC/cycle x 2.4 GHz is the
+            # vendor figure).  Triangular solves: every entry of L is read once per sweep (2 x 8 nnz(L) bytes) against HBM.
+            "roofline_solver": [
+                {"kernel": "multifrontal factorisation (k_front_fused, k_big_step, k_big_schur, k_extend_add, k_xinv_gemm)",
+                 "bound": "mfma", "achieved": st["flops"] / 1e12 / (f_ms * 1e-3), "peak": 78.6, "unit": "TFLOP/s",
+                 "frac": st["flops"] / 1e12 / (f_ms * 1e-3) / 78.6, "traffic": None,
+                 "note": "latency-bound: ~90 dependent 32-column pivot steps on the critical path of the assembly tree"},
+                {"kernel": "triangular solves (k_fwd_level, k_bwd_level, k_big_fwd_rect, k_big_bwd_init, k_xinv_fwd, k_xinv_bwd)",
+                 "bound": "hbm", "achieved": 2 * 8 * st["nnzL"] / 1e9 / (s_ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": 2 * 8 * st["nnzL"] / 1e9 / (s_ms * 1e-3) / HBM_PEAK_GBS, "traffic": None,
+                 "note": "launch-bound: two to four dependent launches per level of the assembly tree, 15 levels, both directions"},
+            ],
             "solver": {"nnzL": st["nnzL"], "factor_gflop": st["flops"] / 1e9, "fronts": st["fronts"], "levels": st["levels"],
                        "factor_ms": f_ms, "solve_ms": s_ms, "factor_gflops_per_s": st["flops"] / 1e9 / (f_ms * 1e-3),
                        "precompute_s": t_pre},

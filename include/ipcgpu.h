@@ -160,6 +160,13 @@ int ipcgpu_gradient(ipcgpu_ctx*, double dtSq, int projectDBC, double* grad_3nV);
  * agree with the reference's. */
 int ipcgpu_set_surface(ipcgpu_ctx*, int nSF, const int* SF_colmajor);
 int ipcgpu_get_surface(ipcgpu_ctx*, int* counts3 /*nSVI,nSF,nSFEdges*/, int* SVI /*nullable*/, int* SFEdges_2n /*nullable*/);
+/* Kinematic mesh obstacles (MeshCO, src/CollisionObject/MeshCO.cpp:37-80; `meshCO` script keyword, Config.cpp:448-474): the
+   obstacle rides along as a surface-only component of the mesh handed to ipcgpu_set_mesh -- extra nodes that belong to no
+   tetrahedron (no mass, Dirichlet: ipcgpu_set_dbc), its triangles in the surface of ipcgpu_set_surface.  This call marks those
+   nodes.  obstacle_only != 0: the contact sets, CCD and intersection checks keep only primitive pairs that involve an obstacle
+   (a scene with `meshCO` but `selfCollisionOff`: Optimizer.cpp:2448-2470 asks only the collision objects).  Bounding box and
+   mean nodal mass (dHat, kappa) are taken over element nodes, so the obstacle does not change them.  Call after set_surface. */
+int ipcgpu_set_obstacle_nodes(ipcgpu_ctx*, int n, const int* vert_ids, int obstacle_only);
 /* SelfCollisionHandler::computeConstraintSet (SelfCollisionHandler.cpp:2149-2478) at the current positions:
  * MMActiveSet (PP / PE duplicates merged, multiplicity in slot 3), paraEEMMCVIDSet + paraEEeIeJSet, and the
  * candidate list for the partial CCD.  counts3 = {nActive, nParaEE, nCandidates}. */
@@ -236,6 +243,12 @@ int ipcgpu_opt_set_velocity(ipcgpu_ctx*, const double* vel_3nV);
  * 3627-3631), predicts xTilta with the stored acceleration (:1259-1277) and updates velocity / acceleration at the end of the
  * time step (:582-590).  Call after ipcgpu_opt_init, before ipcgpu_opt_precompute; the acceleration starts at zero (:177). */
 int ipcgpu_opt_set_time_integration(ipcgpu_ctx*, int type, double beta, double gamma);
+/* Config `warmStart n` -> Optimizer::initX(n) (Optimizer.cpp:925-1215): first iterate of every time step.  0 = the last
+   configuration (default), 1 explicit Euler, 2 xHat, 3 symplectic Euler, 4 uniformly accelerated motion; the step is cut by the
+   inversion filter, the half-space bounds and a full CCD pass, then halved while the mesh is inverted or intersecting.
+   *last_step (nullable) receives the fraction of the predicted displacement the last begin_timestep could take. */
+int ipcgpu_opt_set_warm_start(ipcgpu_ctx*, int option);
+int ipcgpu_opt_get_warm_step(ipcgpu_ctx*, double* last_step);
 /* One Mesh::DirichletBCs entry (src/Mesh.hpp:23-39; `DBC bboxMin bboxMax linVel angVel [t0 t1]` on a shape line,
  * src/Config.cpp:246-263, vertices picked by IglUtils::Init_Dirichlet) or the scripted linear / angular velocity of a whole
  * component (`linearVelocity` / `angularVelocity`, componentLVels / componentAVels -- how kinematic mesh obstacles move):

@@ -641,6 +641,17 @@ int ipcgpu_contact_build(ipcgpu_ctx* c, double dHat, int* counts)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_set_obstacle_nodes(ipcgpu_ctx* c, int n, const int* ids, int only)
+{
+    return guarded([&] {
+        bind(c);
+        HipContact& k = CT(c);
+        need(k.surfaceSet, "call ipcgpu_set_surface first");
+        needArg(n >= 0 && (ids || !n), "bad obstacle node list");
+        k.setObstacle(M(c).nV, n, ids, only != 0);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_contact_get(ipcgpu_ctx* c, int* a4, int* p4, int* pe2, int* cs2)
 {
     return guarded([&] {
@@ -1043,6 +1054,22 @@ int ipcgpu_opt_set_velocity(ipcgpu_ctx* c, const double* vel)
         need(o.initialised, "call ipcgpu_opt_init first");
         needArg(vel != nullptr, "null velocity");
         o.setVelocity(vel);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_warm_start(ipcgpu_ctx* c, int option)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        needArg(option >= 0 && option <= 4, "warmStart option must be 0..4 (5, the Jacobi guess, is not restated)");
+        o.warmStart = option;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_get_warm_step(ipcgpu_ctx* c, double* out)
+{
+    return guarded([&] {
+        if (out) *out = O(c).warmStepSize;
         return IPCGPU_OK;
     });
 }

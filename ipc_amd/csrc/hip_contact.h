@@ -42,6 +42,12 @@ public:
     bool surfaceSet = false;
 
     void setSurface(const HipMesh& mesh, int nSF, const int* SF_colmajor);
+    // kinematic obstacle nodes (the reference's MeshCO riding along as a surface-only component, MeshCO.cpp) and, for scenes with
+    // `selfCollisionOff`, the filter that keeps only primitive pairs involving an obstacle
+    void setObstacle(int nV, int n, const int* ids, bool obstacleOnly);
+    bool hasObstacle = false, obstacleOnly = false;
+    DevBuf<int> d_obst, d_pairFlags;
+    const int* pairFlags(int nV, const int* dbc_dev);
     void setSets(int nA, const int* a4, int nP, const int* p4, const int* pe2);
     void uploadSets();
     // returns #active

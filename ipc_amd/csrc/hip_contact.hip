@@ -557,6 +557,16 @@ __device__ __forceinline__ int cell_of(const Grid& g, double x, int c)
 {
     return min(g.dim[c] - 1, max(0, (int)floor((x - g.lo[c]) / g.h)));
 }
+// Pair flags of a node as the broad / narrow phase kernels read them: bit 0 Dirichlet node, bit 1 node of a kinematic
+// obstacle (the reference's MeshCO riding along as a surface-only component), bit 2 "only pairs that involve an obstacle"
+// (a scene with `meshCO` and `selfCollisionOff`; set on every node so that either operand tells).
+__device__ __forceinline__ bool pair_filtered(int fa, int fb) { return (fa & 4) && !((fa | fb) & 2); }
+__global__ void k_pair_flags(int nV, const int* __restrict__ dbc, const int* __restrict__ obst, int obstacleOnly, int* __restrict__ flags)
+{
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v < nV) flags[v] = (dbc[v] != 0 ? 1 : 0) | ((obst && obst[v]) ? 2 : 0) | (obstacleOnly ? 4 : 0);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_bbox_partial(int nV, const double* __restrict__ x, double* __restrict__ partial)
 {
     __shared__ double sm[6][BLOCK / 64];
@@ -622,12 +632,13 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __rest
     const int vI = SVI[i];
     const double p[3] = { x[3 * (size_t)vI], x[3 * (size_t)vI + 1], x[3 * (size_t)vI + 2] };
     const int cell = cell_of(g, p[0], 0) + g.dim[0] * (cell_of(g, p[1], 1) + g.dim[1] * cell_of(g, p[2], 2));
-    const bool vDbc = dbc[vI] != 0;
+    const bool vDbc = (dbc[vI] & 1) != 0; // dbc: pair flags (bit 0 Dirichlet, bit 1 obstacle node, bit 2 obstacle-only filter on)
     for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
         const int f = cellItems[k];
         const int t0 = SF[3 * (size_t)f], t1 = SF[3 * (size_t)f + 1], t2 = SF[3 * (size_t)f + 2];
         if (vI == t0 || vI == t1 || vI == t2) continue;
-        if (vDbc && dbc[t0] != 0 && dbc[t1] != 0 && dbc[t2] != 0) continue; // SelfCollisionHandler.cpp:2184-2187
+        if (vDbc && (dbc[t0] & 1) && (dbc[t1] & 1) && (dbc[t2] & 1)) continue; // SelfCollisionHandler.cpp:2184-2187
+        if (pair_filtered(dbc[vI], dbc[t0])) continue;
         const double a[3] = { x[3 * (size_t)t0], x[3 * (size_t)t0 + 1], x[3 * (size_t)t0 + 2] };
         const double b[3] = { x[3 * (size_t)t1], x[3 * (size_t)t1 + 1], x[3 * (size_t)t1 + 2] };
         const double c[3] = { x[3 * (size_t)t2], x[3 * (size_t)t2 + 1], x[3 * (size_t)t2 + 2] };
@@ -670,7 +681,7 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
         ca[c] = cell_of(g, bl[c], c);
         cb[c] = cell_of(g, bh[c], c);
     }
-    const bool aDbc = dbc[a0] != 0 && dbc[a1] != 0;
+    const bool aDbc = (dbc[a0] & 1) && (dbc[a1] & 1);
     for (int z = ca[2]; z <= cb[2]; ++z)
         for (int y = ca[1]; y <= cb[1]; ++y)
             for (int xx = ca[0]; xx <= cb[0]; ++xx) {
@@ -691,7 +702,8 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
                         canon[c] = cell_of(g, fmax(bl[c], jl), c);
                     }
                     if (!ok || canon[0] != xx || canon[1] != y || canon[2] != z) continue;
-                    if (aDbc && dbc[b0] != 0 && dbc[b1] != 0) continue; // SelfCollisionHandler.cpp:2294-2297
+                    if (aDbc && (dbc[b0] & 1) && (dbc[b1] & 1)) continue; // SelfCollisionHandler.cpp:2294-2297
+                    if (pair_filtered(dbc[a0], dbc[b0])) continue;
                     const int dt = dType_EE(pa0, pa1, pb0, pb1);
                     const int add_e = (cross_sqnorm(pa0, pa1, pb0, pb1) < eps_x_of(xRest, a0, a1, b0, b1)) ? -eJ - 2 : -1;
                     double d;
@@ -872,7 +884,7 @@ __global__ __launch_bounds__(BLOCK) void k_ccd_full_pt(int nSVI, const int* __re
         ca[c] = cell_of(g, lo[c], c);
         cb[c] = cell_of(g, hi[c], c);
     }
-    const bool vDbc = dbc[vI] != 0;
+    const bool vDbc = (dbc[vI] & 1) != 0;
     for (int z = ca[2]; z <= cb[2]; ++z)
         for (int y = ca[1]; y <= cb[1]; ++y)
             for (int xx = ca[0]; xx <= cb[0]; ++xx) {
@@ -881,7 +893,8 @@ __global__ __launch_bounds__(BLOCK) void k_ccd_full_pt(int nSVI, const int* __re
                     const int f = cellItems[k];
                     int node[4] = { vI, SF[3 * (size_t)f], SF[3 * (size_t)f + 1], SF[3 * (size_t)f + 2] };
                     if (vI == node[1] || vI == node[2] || vI == node[3]) continue;
-                    if (vDbc && dbc[node[1]] != 0 && dbc[node[2]] != 0 && dbc[node[3]] != 0) continue;
+                    if (vDbc && (dbc[node[1]] & 1) && (dbc[node[2]] & 1) && (dbc[node[3]] & 1)) continue;
+                    if (pair_filtered(dbc[vI], dbc[node[1]])) continue;
                     double tl[3], th[3];
                     swept_box(node + 1, 3, x, p, alpha, tl, th);
                     bool ok = true;
@@ -912,7 +925,7 @@ __global__ __launch_bounds__(BLOCK) void k_ccd_full_ee(int nE, const int* __rest
         ca[c] = cell_of(g, lo[c], c);
         cb[c] = cell_of(g, hi[c], c);
     }
-    const bool aDbc = dbc[node[0]] != 0 && dbc[node[1]] != 0;
+    const bool aDbc = (dbc[node[0]] & 1) && (dbc[node[1]] & 1);
     for (int z = ca[2]; z <= cb[2]; ++z)
         for (int y = ca[1]; y <= cb[1]; ++y)
             for (int xx = ca[0]; xx <= cb[0]; ++xx) {
@@ -923,7 +936,8 @@ __global__ __launch_bounds__(BLOCK) void k_ccd_full_ee(int nE, const int* __rest
                     node[2] = SFE[2 * (size_t)eJ];
                     node[3] = SFE[2 * (size_t)eJ + 1];
                     if (node[0] == node[2] || node[0] == node[3] || node[1] == node[2] || node[1] == node[3]) continue;
-                    if (aDbc && dbc[node[2]] != 0 && dbc[node[3]] != 0) continue;
+                    if (aDbc && (dbc[node[2]] & 1) && (dbc[node[3]] & 1)) continue;
+                    if (pair_filtered(dbc[node[0]], dbc[node[2]])) continue;
                     double jl[3], jh[3];
                     swept_box(node + 2, 2, x, p, alpha, jl, jh);
                     bool ok = true;
@@ -977,7 +991,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
         ca[k] = cell_of(g, lo[k], k);
         cb[k] = cell_of(g, hi[k], k);
     }
-    const bool tDbc = dbc[t0] != 0 && dbc[t1] != 0 && dbc[t2] != 0;
+    const bool tDbc = (dbc[t0] & 1) && (dbc[t1] & 1) && (dbc[t2] & 1);
     for (int z = ca[2]; z <= cb[2]; ++z)
         for (int y = ca[1]; y <= cb[1]; ++y)
             for (int xx = ca[0]; xx <= cb[0]; ++xx) {
@@ -986,7 +1000,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
                     const int e = cellItems[k];
                     const int e0 = SFE[2 * (size_t)e], e1 = SFE[2 * (size_t)e + 1];
                     if (e0 == t0 || e0 == t1 || e0 == t2 || e1 == t0 || e1 == t1 || e1 == t2) continue;
-                    if (tDbc && dbc[e0] != 0 && dbc[e1] != 0) continue;
+                    if (tDbc && (dbc[e0] & 1) && (dbc[e1] & 1)) continue;
+                    if (pair_filtered(dbc[e0], dbc[t0])) continue;
                     double p0[3], p1[3];
                     bool sep = false;
                     for (int q = 0; q < 3; ++q) {
@@ -1181,6 +1196,27 @@ void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc)
     uploadSets();
 }
 
+// obstacle nodes (MeshCO as a surface-only component) and the "only pairs with an obstacle" filter
+void HipContact::setObstacle(int nV, int n, const int* ids, bool only)
+{
+    std::vector<int> f((size_t)std::max(nV, 1), 0);
+    for (int i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= nV) throw ArgError("set_obstacle_nodes: node id out of range");
+        f[ids[i]] = 1;
+    }
+    d_obst.upload(f, stream);
+    hasObstacle = n > 0;
+    obstacleOnly = only;
+    HIP_CHECK(hipStreamSynchronize(stream));
+}
+const int* HipContact::pairFlags(int nV, const int* dbc_dev)
+{
+    d_pairFlags.ensure((size_t)std::max(nV, 1));
+    hipLaunchKernelGGL(k_pair_flags, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, hasObstacle ? d_obst.p : (const int*)nullptr, obstacleOnly ? 1 : 0,
+        d_pairFlags.p);
+    return d_pairFlags.p;
+}
+
 void HipContact::setSets(int nA, const int* a4, int nP, const int* p4, const int* pe2)
 {
     active.resize(nA);
@@ -1218,6 +1254,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
 {
     if (!surfaceSet) throw StateError("contact_build before set_surface");
     const int nV = mesh.nV;
+    const int* pf = pairFlags(nV, dbc_dev);
     const double infl = std::sqrt(dHat);
     // bounding box of the current positions
     const int nb = nblk(nV);
@@ -1273,9 +1310,9 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         outPT_.alloc(6 * (size_t)capPT);
         outEE_.alloc(6 * (size_t)capEE);
         counters_.zero(stream);
-        hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, dbc_dev, g, cellStartT_.p, cellItemsT_.p,
+        hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, pf, g, cellStartT_.p, cellItemsT_.p,
             dHat, capPT, outPT_.p, counters_.p);
-        hipLaunchKernelGGL(k_narrow_ee, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, dbc_dev, g, cellStartE_.p,
+        hipLaunchKernelGGL(k_narrow_ee, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, cellStartE_.p,
             cellItemsE_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1);
         int cnt[2];
         counters_.download(cnt, 2, stream);
@@ -1770,6 +1807,7 @@ double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const doubl
     int* pair2, int* nCand)
 {
     if (!surfaceSet) throw StateError("ccd before set_surface");
+    const int* pf = pairFlags(mesh.nV, dbc_dev);
     const GridHost gh = makeGrid(mesh, x_dev, p_dev, stepSize, mesh.avgEdgeLen);
     buildCells(gh, nSF, 3, d_SF.p, x_dev, p_dev, stepSize, 0.0, cellCountT_, cellStartT_, cellItemsT_);
     buildCells(gh, nSFE, 2, d_SFE.p, x_dev, p_dev, stepSize, 0.0, cellCountE_, cellStartE_, cellItemsE_);
@@ -1786,9 +1824,9 @@ double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const doubl
     counters_.zero(stream);
     CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
     for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(k_ccd_full_pt, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, p_dev, dbc_dev, g, cellStartT_.p,
+        hipLaunchKernelGGL(k_ccd_full_pt, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, p_dev, pf, g, cellStartT_.p,
             cellItemsT_.p, stepSize, slackness, pass, o, counters_.p);
-        hipLaunchKernelGGL(k_ccd_full_ee, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, p_dev, dbc_dev, g, cellStartE_.p, cellItemsE_.p,
+        hipLaunchKernelGGL(k_ccd_full_ee, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, p_dev, pf, g, cellStartE_.p, cellItemsE_.p,
             stepSize, slackness, pass, o, counters_.p);
     }
     unsigned long long h[2];
@@ -1804,6 +1842,7 @@ double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const doubl
 bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev)
 {
     if (!surfaceSet) throw StateError("is_intersected before set_surface");
+    const int* pf = pairFlags(mesh.nV, dbc_dev);
     const GridHost gh = makeGrid(mesh, x_dev, nullptr, 0.0, mesh.avgEdgeLen);
     buildCells(gh, nSFE, 2, d_SFE.p, x_dev, nullptr, 0.0, 0.0, cellCountE_, cellStartE_, cellItemsE_);
     Grid g;
@@ -1814,7 +1853,7 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
     g.h = gh.h;
     counters_.alloc(2);
     counters_.zero(stream);
-    hipLaunchKernelGGL(k_intersect, dim3(nblk(nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, dbc_dev, g, cellStartE_.p, cellItemsE_.p,
+    hipLaunchKernelGGL(k_intersect, dim3(nblk(nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p, cellItemsE_.p,
         counters_.p);
     int f[2];
     counters_.download(f, 2, stream);

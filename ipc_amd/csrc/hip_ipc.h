@@ -25,6 +25,7 @@ namespace ipcgpu {
 class HipMesh {
 public:
     int nV = 0, nT = 0;
+    int nElemNodes = 0; // nodes referenced by at least one element (mean nodal mass, bounding box)
     std::vector<double> V_rest; // column-major nV x 3
     std::vector<int> F; // column-major nT x 4
     std::vector<double> restTriInv; // SoA [9][nT]
@@ -119,6 +120,8 @@ public:
     double relGL2Tol = 1e-8, targetGRes = 0;
     // Config `timeIntegration BE | NM beta gamma` (Config.hpp:96, Config.cpp:112-118): 0 backward Euler, 1 Newmark
     int timeIntegration = 0;
+    int warmStart = 0; // Config `warmStart`: initX option 0..4 (Optimizer.cpp:925-1080)
+    double warmStepSize = 0.0; // step the last warm start could take
     double betaNM = 0.25, gammaNM = 0.5;
     DevBuf<double> d_acc, d_dxElastic; // acceleration, dx_Elastic = x - xTilta of the finished step (Optimizer.cpp:176-177, 574-586)
     double elasticCoef() const { return timeIntegration == 1 ? dtSq * betaNM : dtSq; } // Optimizer.cpp:3205-3224, 3416-3434, 3618-3632

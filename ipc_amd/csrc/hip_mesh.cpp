@@ -80,10 +80,18 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
     for (int v = 0; v < nV; ++v) nbPtr[v + 1] += nbPtr[v];
     nb.resize(edges.size());
     for (size_t i = 0; i < edges.size(); ++i) nb[i] = edges[i].second;
+    // bounding box of the simulated material (Mesh::matSpaceBBoxSize2): nodes of elements only -- a kinematic obstacle riding
+    // along as a surface-only component must not change dHat = dHatEps^2 * diagonal^2
+    std::vector<char> inElem(nV, 0);
+    for (int t = 0; t < nT; ++t)
+        for (int k = 0; k < 4; ++k) inElem[F[t + (size_t)nT * k]] = 1;
+    nElemNodes = 0;
+    for (int v = 0; v < nV; ++v) nElemNodes += inElem[v];
     bboxDiag2 = 0;
     for (int c = 0; c < 3; ++c) {
         double lo = 1e300, hi = -1e300;
         for (int v = 0; v < nV; ++v) {
+            if (nT && !inElem[v]) continue;
             lo = std::min(lo, X(v, c));
             hi = std::max(hi, X(v, c));
         }

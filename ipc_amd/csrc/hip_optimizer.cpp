@@ -508,7 +508,7 @@ double HipOptimizer::kappaFloor() const
     const double Hb = (lg * -2.0 - t2 * 4.0 / d) + 1.0 / (d * d) * (t2 * t2); // BarrierFunctions.hpp:76-83
     double avgMass = 0;
     for (double x : mesh.mass) avgMass += x;
-    avgMass /= mesh.nV;
+    avgMass /= std::max(mesh.nElemNodes, 1); // mean over the simulated nodes (obstacle nodes carry no mass and do not count)
     return 1.0e11 * avgMass / (4.0e-16 * mesh.bboxDiag2 * Hb);
 }
 
@@ -897,6 +897,31 @@ void HipOptimizer::beginTimestep()
         if (stepSize < 1.0) dbcIncomplete++; // the penalty solve of newtonIter() takes the nodes the rest of the way
         completedStep = stepSize; // AnimScripter::getCompletedStepSize
         d_searchDir.zero(stream); // initX(0), Optimizer.cpp:930-934
+    }
+    if (warmStart >= 1 && warmStart <= 4) {
+        // initX options 1-4 (Optimizer.cpp:936-1080): explicit Euler / xHat / symplectic Euler / uniformly accelerated motion as the
+        // first iterate, then the feasibility filters of a Newton step with "always full CCD" (:1117-1215)
+        static const double CG[2][5] = { { 0, 0, 1, 1, 1 }, { 0, 0, 0.5, 0.5, 0.5 } }, CE[2][5] = { { 0, 0, 0, 1, 0.5 }, { 0, 0, 0, 2, 1 } };
+        const double cg = CG[timeIntegration][warmStart], ce = CE[timeIntegration][warmStart];
+        const double g3[3] = { cg * (dtSq * gravity[0]), cg * (dtSq * gravity[1]), cg * (dtSq * gravity[2]) };
+        launch_warm_dir(mesh.nV, mesh.d_dbc.p, d_vel.p, d_dxElastic.p, dt, g3, ce, d_searchDir.p, stream);
+        double stepSize = filterStepSize(d_searchDir.p, 1.0);
+        if (ipOn()) {
+            for (auto& h : planes) stepSize = h->stepBound(contact->nSVI, contact->d_SVI.p, mesh.d_x.p, mesh.d_dbc.p, d_searchDir.p, 0.9, stepSize);
+            if (selfCollision) stepSize = contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, 0.8, stepSize, nullptr, nullptr);
+        }
+        HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, 3 * (size_t)mesh.nV * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        stepForward(d_x0.p, stepSize);
+        while (!checkInversion()) {
+            stepSize /= 2.0;
+            stepForward(d_x0.p, stepSize);
+        }
+        if (ipOn())
+            while (anyIntersection()) {
+                stepSize /= 2.0;
+                stepForward(d_x0.p, stepSize);
+            }
+        warmStepSize = stepSize;
     }
     if (ipOn()) {
         // fullyImplicit_IP head (Optimizer.cpp:1534-1550, 2316-2322): dHat, constraint sets, kappa, empty close-pair list

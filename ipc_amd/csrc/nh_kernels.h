@@ -89,6 +89,9 @@ void launch_mdbc_gradient(const MdbcView& m, const double* x, double rho, double
 void launch_mdbc_hessian(const MdbcView& m, const int* ia, double rho, double* a, hipStream_t s);
 void launch_mdbc_lambda(const MdbcView& m, const double* x, double rho, hipStream_t s);
 // twist handles: rotate listed vertices about the x axis through c by their angle (AnimScripter.cpp:1674-1684)
+// p = dbc ? 0 : dt vel + cgDtSqG + ce dx  (initX options 1-4, Optimizer.cpp:936-1080)
+void launch_warm_dir(int nV, const int* dbc, const double* vel, const double* dx, double dt, const double* cgDtSqG3, double ce, double* p,
+    hipStream_t s);
 void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s);
 
 } // namespace ipcgpu

@@ -413,6 +413,17 @@ __global__ void k_twist_dir(int nH, const int* __restrict__ ids, const double* _
     p[3 * (size_t)v + 2] = (sn * y + cs * z + cz) - x[3 * (size_t)v + 2];
 }
 
+// first iterate of a time step, initX options 1-4 (Optimizer.cpp:936-1080): p = dt v + cg dt^2 g + ce dx_Elastic on the free nodes
+__global__ void k_warm_dir(int nV, const int* __restrict__ dbc, const double* __restrict__ vel, const double* __restrict__ dx, double dt,
+    double gx, double gy, double gz, double ce, double* __restrict__ p)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * nV) return;
+    const int v = i / 3, c = i - 3 * v;
+    const double g = c == 0 ? gx : (c == 1 ? gy : gz);
+    p[i] = (dbc[v] != 0) ? 0.0 : dt * vel[i] + g + ce * dx[i];
+}
+
 // positions of a vertex list, packed (for the bounding box of a Dirichlet group)
 __global__ void k_gather3(int n, const int* __restrict__ ids, const double* __restrict__ x, double* __restrict__ out)
 {
@@ -614,6 +625,11 @@ void launch_be_update(int nV, const int* dbc, const double* x, double* xPrev, do
     if (nV)
         hipLaunchKernelGGL(k_be_update, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, x, xPrev, vel, acc, dxElastic, xTilde, dt, gx, gy,
             gz);
+}
+void launch_warm_dir(int nV, const int* dbc, const double* vel, const double* dx, double dt, const double* cgDtSqG3, double ce, double* p,
+    hipStream_t s)
+{
+    if (nV) hipLaunchKernelGGL(k_warm_dir, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, vel, dx, dt, cgDtSqG3[0], cgDtSqG3[1], cgDtSqG3[2], ce, p);
 }
 void launch_twist_dir(int nH, const int* ids, const double* ang, double cy, double cz, const double* x, double* p, hipStream_t s)
 {

@@ -316,6 +316,10 @@ class Context:
         SF = np.asfortranarray(SF, dtype=np.int32)
         self._chk(self._L.ipcgpu_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF)))
 
+    def set_obstacle(self, ids, obstacle_only=False):
+        ids = _i32(ids)
+        self._chk(_lib.ipcgpu_set_obstacle_nodes(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(int(obstacle_only))))
+
     def get_surface(self):
         n = np.zeros(3, dtype=np.int32)
         self._chk(self._L.ipcgpu_get_surface(self.h, _ip(n), None, None))
@@ -521,6 +525,14 @@ class Context:
     def set_time_integration(self, name, beta=0.25, gamma=0.5):
         """Scene-script `timeIntegration BE | NM beta gamma`."""
         self._chk(self._L.ipcgpu_opt_set_time_integration(self.h, C.c_int({"BE": 0, "NM": 1}[name]), C.c_double(beta), C.c_double(gamma)))
+
+    def set_warm_start(self, option):
+        self._chk(_lib.ipcgpu_opt_set_warm_start(self.h, C.c_int(int(option))))
+
+    def warm_step(self):
+        v = C.c_double()
+        self._chk(_lib.ipcgpu_opt_get_warm_step(self.h, C.byref(v)))
+        return v.value
 
     def add_dirichlet(self, ids, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), t0=0.0, t1=float("inf")):
         """One `DBC bboxMin bboxMax linVel angVel [t0 t1]` entry of a shape line (degrees per second, as in the script)."""

@@ -68,8 +68,10 @@ class SceneConfig:
     fric_iter_amt: int = 1
     tol: float = 1e-2
     script: str = "null"
+    warm_start: int = 0  # initX option
     restart: str = None
     half_spaces: list = field(default_factory=list)  # (origin, normal, friction)
+    mesh_cos: list = field(default_factory=list)  # (obj path, origin, scale, friction, rotate_deg) -- kinematic mesh obstacles (MeshCO)
     shapes: list = field(default_factory=list)
 
     @staticmethod
@@ -109,9 +111,10 @@ class SceneConfig:
                 if a[0] not in ("null", "twist", "fall", "fallNoShift"):
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
-            elif k == "warmStart":  # initX option; 0 (searchDir = 0, Optimizer.cpp:930-934) is the one restated
-                if int(a[0]) != 0:
+            elif k == "warmStart":  # initX option (Optimizer.cpp:925-1080); 5 (Jacobi guess) is not restated
+                if int(a[0]) not in (0, 1, 2, 3, 4):
                     raise UnsupportedKeyword(f"warmStart {a[0]}")
+                cfg.warm_start = int(a[0])
             elif k == "constraintSolver":
                 if a[0] not in ("IP", "interiorPoint"):
                     raise UnsupportedKeyword(f"constraintSolver {a[0]}")
@@ -140,6 +143,12 @@ class SceneConfig:
                 v = [float(x) for x in a]
                 n = np.array(v[3:6])
                 cfg.half_spaces.append((np.array(v[0:3]), n / np.linalg.norm(n), v[7] if len(v) > 7 else 0.0))
+            elif k == "meshCO":  # path, origin, scale, stiffness (unused), friction [rotate x y z] (Config.cpp:448-474)
+                v = [float(x) for x in a[1:7]]
+                rot = np.zeros(3)
+                if len(a) > 10 and a[7] == "rotate":
+                    rot = np.array([float(x) for x in a[8:11]])
+                cfg.mesh_cos.append((resolve(a[0]), np.array(v[0:3]), v[3], v[5], rot))
             elif k == "selfCollisionOn":
                 cfg.self_collision = True
             elif k == "selfCollisionOff":
@@ -172,6 +181,14 @@ class SceneConfig:
                     raise UnsupportedKeyword("tuning with a dHat homotopy")
                 if len(vals) > 4:
                     cfg.eps_v = vals[4]
+            elif k == "section":  # Config.cpp:572-605: settings for one constraint solver; other solvers' sections are skipped
+                names = ["interiorPoint" if x == "IP" else x for x in a]
+                if "end" not in names and "interiorPoint" not in names:
+                    while i < len(lines):
+                        t2 = lines[i].split()
+                        i += 1
+                        if len(t2) >= 2 and t2[0] == "section" and t2[1] == "end":
+                            break
             elif k == "restart":
                 cfg.restart = resolve(a[0])
             elif k in VIEWER_KEYWORDS:
@@ -229,6 +246,27 @@ def _parse_shape(st, resolve):
     return sh
 
 
+def read_obj(path):
+    """Triangle mesh of a Wavefront .obj (igl::readOBJ as MeshCO uses it, MeshCO.cpp:49): `v x y z` and `f a b c` lines, 1-based
+    indices, `a/b/c` index groups reduced to the vertex index, negative (relative) indices, polygons fan-triangulated."""
+    V, F = [], []
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                V.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = []
+                for g in t[1:]:
+                    k = int(g.split("/")[0])
+                    idx.append(k - 1 if k > 0 else len(V) + k)
+                for q in range(1, len(idx) - 1):
+                    F.append([idx[0], idx[q], idx[q + 1]])
+    return np.array(V, dtype=np.float64).reshape(-1, 3), np.array(F, dtype=np.int32).reshape(-1, 3)
+
+
 @dataclass
 class AssembledScene:
     cfg: SceneConfig
@@ -240,6 +278,7 @@ class AssembledScene:
     dirichlet: list  # (ids, lin_vel, ang_vel_deg, t0, t1)
     velocity: np.ndarray
     neumann: list = field(default_factory=list)  # (ids, acceleration, t0, t1)
+    obstacle_nodes: np.ndarray = None  # nodes of the kinematic mesh obstacles (surface-only components, no tetrahedra)
 
 
 def assemble(cfg, read_mesh):
@@ -267,10 +306,25 @@ def assemble(cfg, read_mesh):
         SFs.append(SF + off)
         nr.append(off + V.shape[0])
         tr.append(tr[-1] + T.shape[0])
+    # kinematic mesh obstacles (MeshCO::MeshCO, MeshCO.cpp:37-58): centred on the vertex mean, rotated, scaled so that the largest
+    # bounding-box extent equals `scale`, moved to `origin`.  They ride along as surface-only components: nodes of no tetrahedron.
+    obstacle = []
+    for path, origin, scale, _mu, rot in cfg.mesh_cos:
+        Vo, Fo = read_obj(path)
+        Vo = Vo - Vo.mean(0)
+        Vo = Vo @ _rot(rot).T
+        Vo = Vo * (scale / (Vo.max(0) - Vo.min(0)).max()) + origin
+        off = nr[-1]
+        obstacle.append(np.arange(off, off + Vo.shape[0], dtype=np.int32))
+        Vs.append(Vo)
+        SFs.append(Fo + off)
+        nr.append(off + Vo.shape[0])
+        tr.append(tr[-1])
     V, T, SF = np.vstack(Vs), np.vstack(Ts).astype(np.int32), np.vstack(SFs).astype(np.int32)
+    nSim = nr[len(cfg.shapes)]  # the simulated mesh: everything before the obstacle components
     if cfg.script in ("fall", "fallNoShift"):  # AnimScripter.cpp:779-788: lifted by half the bounding-box diagonal, no Dirichlet nodes
-        if cfg.script == "fall":
-            V[:, 1] += 0.5 * np.linalg.norm(V.max(0) - V.min(0))
+        if cfg.script == "fall":  # Mesh<3> only: the obstacles are not part of it in the reference
+            V[:nSim, 1] += 0.5 * np.linalg.norm(V[:nSim].max(0) - V[:nSim].min(0))
         dirichlet = []
     vel = np.zeros_like(V)
     fixed = np.zeros(V.shape[0], dtype=bool)
@@ -285,7 +339,8 @@ def assemble(cfg, read_mesh):
         v = np.array(sh.init_vel[0]) + np.cross(w, V[a:b] - ctr)
         v[fixed[a:b]] = 0.0
         vel[a:b] = v
-    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann)
+    obst = np.concatenate(obstacle) if obstacle else None
+    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst)
 
 
 def apply(sc, be):
@@ -300,14 +355,25 @@ def apply(sc, be):
     if cfg.time_integration == "NM":
         be.set_time_integration("NM", cfg.beta, cfg.gamma)
     be.set_surface(sc.SF)
-    if cfg.self_collision:
+    self_fric = cfg.self_fric
+    if sc.obstacle_nodes is not None:
+        # static obstacle: all of its nodes are ZERO Dirichlet nodes; without `selfCollisionOn` only pairs that involve the
+        # obstacle collide.  One friction coefficient per contact set: the obstacles' (MeshCO::friction) when nothing else is in
+        # contact with itself, otherwise it has to agree with selfFric.
+        be.set_dbc(sc.obstacle_nodes, 1)
+        be.set_obstacle(sc.obstacle_nodes, obstacle_only=not cfg.self_collision)
+        mus = {mu for _p, _o, _s, mu, _r in cfg.mesh_cos}
+        if len(mus) > 1 or (cfg.self_collision and mus != {cfg.self_fric}):
+            raise UnsupportedKeyword("meshCO friction that differs from selfFric (one friction coefficient per contact set)")
+        self_fric = mus.pop()
+    if cfg.self_collision or sc.obstacle_nodes is not None:
         be.enable_self_collision(cfg.dHat_eps)
     for origin, normal, mu in cfg.half_spaces:
         idx = be.add_half_space(origin, normal, cfg.dHat_eps)
         if mu > 0:
             be.set_half_space_friction(idx, mu)
-    if cfg.self_fric > 0 or any(mu > 0 for *_, mu in cfg.half_spaces):
-        be.set_friction(cfg.self_fric, cfg.fric_iter_amt, cfg.eps_v)
+    if self_fric > 0 or any(mu > 0 for *_, mu in cfg.half_spaces):
+        be.set_friction(self_fric, cfg.fric_iter_amt, cfg.eps_v)
     for ids, lin, ang, t0, t1 in sc.dirichlet:
         be.add_dirichlet(ids, lin_vel=lin, ang_vel_deg=ang, t0=t0, t1=t1)
     for ids, acc, t0, t1 in sc.neumann:
@@ -317,6 +383,8 @@ def apply(sc, be):
         be.set_twist(left, right)
     if np.any(sc.velocity):
         be.set_velocity(sc.velocity)
+    if cfg.warm_start:
+        be.set_warm_start(cfg.warm_start)
     be.set_rel_tol(cfg.tol)
     if cfg.restart:
         be.load_status(cfg.restart)

@@ -130,6 +130,10 @@ class Mesh:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         lib().orc_mesh_set_dbc(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(typ))
 
+    def set_obstacle(self, ids, obstacle_only=False):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        lib().orc_mesh_set_obstacle(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(int(obstacle_only)))
+
     def set_component_material(self, node_range, tet_range, density, YM, PR):
         lib().orc_mesh_set_component_material(self.h, C.c_int(node_range[0]), C.c_int(node_range[1]), C.c_int(tet_range[0]), C.c_int(tet_range[1]),
                                               C.c_double(density), C.c_double(YM), C.c_double(PR))
@@ -515,6 +519,15 @@ def opt_load_status(opt: "Optimizer", path):
 def opt_set_time_integration(opt: "Optimizer", name, beta=0.25, gamma=0.5):
     """Config `timeIntegration BE | NM beta gamma` (defaults Config.hpp:96)."""
     lib().orc_opt_set_time_integration(opt.h, C.c_int({"BE": 0, "NM": 1}[name]), C.c_double(beta), C.c_double(gamma))
+
+
+def opt_set_warm_start(opt: "Optimizer", option):
+    lib().orc_opt_set_warm_start(opt.h, C.c_int(int(option)))
+
+
+def opt_warm_step(opt: "Optimizer"):
+    lib().orc_opt_warm_step.restype = C.c_double
+    return lib().orc_opt_warm_step(opt.h)
 
 
 def opt_set_velocity(opt: "Optimizer", vel):

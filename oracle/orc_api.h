@@ -39,6 +39,7 @@ orc_mesh* orc_mesh_create(int nV, int nT, const double* Vrest_colmajor, const in
 void orc_mesh_destroy(orc_mesh*);
 void orc_mesh_set_surface(orc_mesh*, int nSF, const int* SF_colmajor); // adds SF edges to vNeighbor, builds SVI/SFEdges
 void orc_mesh_set_dbc(orc_mesh*, int n, const int* vids, int type); // type: 1 ZERO, 2 NONZERO (Mesh.hpp:41-45)
+void orc_mesh_set_obstacle(orc_mesh*, int n, const int* vids, int obstacleOnly);
 void orc_mesh_clear_dbc(orc_mesh*);
 void orc_mesh_set_energy_type(orc_mesh*, int type); // 0 NH, 1 FCR (Config.cpp:23-24)
 // componentMaterial entry of Mesh::setLameParam (Mesh.cpp:661-671): node range gets density rho, tet range gets (YM, PR)
@@ -101,6 +102,8 @@ int orc_opt_solve_timestep(orc_opt*, int maxIter); // returns # Newton iteration
 // state readers
 void orc_opt_get(const orc_opt*, double* V_colmajor, double* searchDir, double* gradient, double* scalars8);
 // scalars8 = {lastEnergyVal, lastStepSize, targetGRes, innerIterAmt, timestep, lastAlphaFeasible, 0, 0}
+void orc_opt_set_warm_start(orc_opt*, int option); // Config warmStart: initX option 0..4 (Optimizer.cpp:925-1080)
+double orc_opt_warm_step(const orc_opt*);
 void orc_opt_timers(const orc_opt*, double* t16); // timer_step buckets (main.cpp:1326-1340)
 
 #ifdef __cplusplus

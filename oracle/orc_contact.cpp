@@ -670,6 +670,7 @@ void computeConstraintSet(const Mesh& m, double dHat, bool brute, ContactSets& o
             const int t0 = m.SF[f], t1 = m.SF[f + nSF], t2 = m.SF[f + 2 * nSF];
             if (vI == t0 || vI == t1 || vI == t2) continue;
             if (m.isDBC(vI) && m.isDBC(t0) && m.isDBC(t1) && m.isDBC(t2)) continue;
+            if (!m.pairAllowed(vI, t0)) continue;
             double a[3], b[3], c[3];
             P(t0, a);
             P(t1, b);
@@ -708,6 +709,7 @@ void computeConstraintSet(const Mesh& m, double dHat, bool brute, ContactSets& o
             const int b0 = m.SFEdges[eJ].first, b1 = m.SFEdges[eJ].second;
             if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
             if (m.isDBC(a0) && m.isDBC(a1) && m.isDBC(b0) && m.isDBC(b1)) continue;
+            if (!m.pairAllowed(a0, b0)) continue;
             double pb0[3], pb1[3];
             P(b0, pb0);
             P(b1, pb1);
@@ -1067,6 +1069,7 @@ void sweptCandidates(const Mesh& m, const double* p, double stepSize, std::vecto
             const int t0 = m.SF[f], t1 = m.SF[f + nSF], t2 = m.SF[f + 2 * nSF];
             if (v == t0 || v == t1 || v == t2) continue;
             if (m.isDBC(v) && m.isDBC(t0) && m.isDBC(t1) && m.isDBC(t2)) continue;
+            if (!m.pairAllowed(v, t0)) continue;
             if (overlap(lo, hi, &tb[f][0], &tb[f][3])) out.push_back({ -i - 1, f });
         }
     }
@@ -1075,6 +1078,7 @@ void sweptCandidates(const Mesh& m, const double* p, double stepSize, std::vecto
             const int a0 = m.SFEdges[e].first, a1 = m.SFEdges[e].second, b0 = m.SFEdges[j].first, b1 = m.SFEdges[j].second;
             if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
             if (m.isDBC(a0) && m.isDBC(a1) && m.isDBC(b0) && m.isDBC(b1)) continue;
+            if (!m.pairAllowed(a0, b0)) continue;
             if (overlap(&eb[e][0], &eb[e][3], &eb[j][0], &eb[j][3])) out.push_back({ e, j });
         }
 }
@@ -1118,6 +1122,7 @@ bool isIntersected(const Mesh& m)
             const int e0 = m.SFEdges[e].first, e1 = m.SFEdges[e].second;
             if (e0 == t0 || e0 == t1 || e0 == t2 || e1 == t0 || e1 == t1 || e1 == t2) continue;
             if (m.isDBC(e0) && m.isDBC(e1) && m.isDBC(t0) && m.isDBC(t1) && m.isDBC(t2)) continue;
+            if (!m.pairAllowed(e0, t0)) continue;
             double p0[3], p1[3];
             bool sep = false;
             for (int k = 0; k < 3; ++k) {

@@ -242,9 +242,17 @@ Mesh::Mesh(int nV_, int nT_, const double* Vr, const int* Fc, double YM, double 
     // Mesh.cpp:663-664
     mu.assign(nT, YM / 2.0 / (1.0 + PR));
     lam.assign(nT, YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR));
+    // bounding box of the simulated material (Mesh::matSpaceBBoxSize2, Mesh.cpp): nodes of elements only, so that a kinematic
+    // obstacle riding along as a surface-only component does not change dHat = dHatEps^2 * diagonal^2
+    std::vector<char> inElem(nV, 0);
+    for (int t = 0; t < nT; ++t)
+        for (int k = 0; k < 4; ++k) inElem[Fi(t, k)] = 1;
+    nElemNodes = 0;
+    for (int v = 0; v < nV; ++v) nElemNodes += inElem[v];
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     for (int v = 0; v < nV; ++v)
         for (int i = 0; i < 3; ++i) {
+            if (nT && !inElem[v]) continue;
             lo[i] = std::min(lo[i], Vr[v + nV * i]);
             hi[i] = std::max(hi[i], Vr[v + nV * i]);
         }
@@ -618,6 +626,14 @@ void orc_mesh_set_surface(orc_mesh* h, int nSF, const int* SF) { h->m.setSurface
 void orc_mesh_set_dbc(orc_mesh* h, int n, const int* vids, int type)
 {
     for (int i = 0; i < n; ++i) h->m.dbcType[vids[i]] = type;
+}
+// kinematic obstacle nodes (MeshCO riding along as a surface-only component); obstacleOnly: contact only with obstacles
+void orc_mesh_set_obstacle(orc_mesh* h, int n, const int* vids, int obstacleOnly)
+{
+    Mesh& m = h->m;
+    m.obstacle.assign(m.nV, 0);
+    for (int i = 0; i < n; ++i) m.obstacle[vids[i]] = 1;
+    m.obstacleOnly = obstacleOnly != 0;
 }
 void orc_mesh_set_component_material(orc_mesh* h, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR)
 {

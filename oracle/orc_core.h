@@ -15,6 +15,14 @@ struct Mesh {
     std::vector<double> V_rest, V; // column-major nV x 3
     std::vector<int> F; // column-major nT x 4
     std::vector<int> dbcType; // DirichletBCType: 0 NOT_DBC, 1 ZERO, 2 NONZERO (Mesh.hpp:41-45)
+    // Kinematic obstacle meshes (the reference's MeshCO, src/CollisionObject/MeshCO.cpp: a triangle mesh outside the simulated
+    // mesh that only collides) ride along as surface-only components: nodes that belong to no tetrahedron (zero mass, Dirichlet),
+    // their triangles in SF.  obstacle[v] marks them; with obstacleOnly the contact sets keep only primitive pairs that involve an
+    // obstacle (a scene with `meshCO` but `selfCollisionOff`: Optimizer.cpp:2448-2470 then only asks the collision objects).
+    std::vector<char> obstacle;
+    bool obstacleOnly = false;
+    bool pairAllowed(int a, int b) const { return !obstacleOnly || (!obstacle.empty() && (obstacle[a] || obstacle[b])); }
+    int nElemNodes = 0; // nodes referenced by at least one element (mean nodal mass and bounding box are taken over these)
     std::vector<M3> restTriInv;
     std::vector<double> triArea, mass, mu, lam;
     std::vector<std::set<std::pair<int, int>>> vFLoc;

@@ -21,6 +21,8 @@ struct orc_opt {
     double dt, dtSq, gravity[3] = { 0, 0, 0 };
     // time integration (Config timeIntegration BE | NM beta gamma, Config.hpp:96, Config.cpp:112-118)
     int tit = 0;
+    int warmStart = 0; // Config `warmStart` (initX option, Optimizer.cpp:925-1080)
+    double warmStepSize = 0.0;
     double betaNM = 0.25, gammaNM = 0.5;
     std::vector<double> acceleration, dxElastic; // 3 v + c
     double elCoef() const { return tit == 1 ? dtSq * betaNM : dtSq; } // Optimizer.cpp:3205-3224, 3416-3434, 3618-3632
@@ -298,7 +300,7 @@ double kappaFloor(orc_opt* o)
     barrier(1.0e-16 * m.bboxDiag2, o->dHat, nullptr, nullptr, &Hb);
     double avgMass = 0;
     for (double x : m.mass) avgMass += x;
-    avgMass /= m.nV;
+    avgMass /= std::max(m.nElemNodes, 1); // mean over the simulated nodes (obstacle nodes carry no mass and do not count)
     return 1.0e11 * avgMass / (4.0e-16 * m.bboxDiag2 * Hb);
 }
 
@@ -708,8 +710,40 @@ void orc_opt_begin_timestep(orc_opt* o)
         if (stepSize < 1.0) o->dbcIncomplete++;
         o->completedStep = stepSize; // AnimScripter::getCompletedStepSize
     }
-    // fullyImplicit_IP head (1518-1613): initX(0) -> searchDir = 0; dHat; constraint sets; kappa; initial energy
+    // fullyImplicit_IP head (1518-1613): initX(warmStart); dHat; constraint sets; kappa; initial energy
     std::fill(o->searchDir.begin(), o->searchDir.end(), 0.0);
+    if (o->warmStart >= 1 && o->warmStart <= 4) {
+        // initX options 1-4 (Optimizer.cpp:936-1080): explicit Euler / xHat / symplectic Euler / uniformly accelerated motion as the
+        // first iterate, then the same feasibility filters as a Newton step with "always full CCD" (:1117-1215)
+        static const double CG[2][5] = { { 0, 0, 1, 1, 1 }, { 0, 0, 0.5, 0.5, 0.5 } }, CE[2][5] = { { 0, 0, 0, 1, 0.5 }, { 0, 0, 0, 2, 1 } };
+        const double cg = CG[o->tit][o->warmStart], ce = CE[o->tit][o->warmStart];
+        for (int v = 0; v < m.nV; ++v)
+            for (int c = 0; c < 3; ++c)
+                o->searchDir[3 * v + c] = m.isDBC(v) ? 0.0
+                                                     : o->dt * o->velocity[3 * v + c] + cg * (o->dtSq * o->gravity[c])
+                        + ce * (o->dxElastic.empty() ? 0.0 : o->dxElastic[3 * v + c]);
+        double stepSize = filterStepSize(m, o->searchDir.data(), 1.0);
+        if (o->ipOn()) {
+            for (const auto& h : o->planes) stepSize = hsStepBound(m, h, o->searchDir.data(), 0.9, stepSize);
+            if (o->selfCollision) {
+                std::vector<std::array<int, 2>> cand;
+                sweptCandidates(m, o->searchDir.data(), stepSize, cand);
+                stepSize = ccdStepBound(m, cand, o->searchDir.data(), 0.8, stepSize, nullptr);
+            }
+        }
+        std::vector<double> V0 = m.V;
+        stepForward(o, V0, stepSize);
+        while (!m.inversionFree()) {
+            stepSize /= 2.0;
+            stepForward(o, V0, stepSize);
+        }
+        if (o->ipOn())
+            while (anyIntersection(o)) {
+                stepSize /= 2.0;
+                stepForward(o, V0, stepSize);
+            }
+        o->warmStepSize = stepSize;
+    }
     if (o->ipOn()) {
         o->dHat = o->dHatEps * o->dHatEps * m.bboxDiag2;
         computeConstraintSets(o);
@@ -994,5 +1028,11 @@ void orc_opt_get_contact(const orc_opt* o, int* counts6, int* active4, int* para
         for (size_t i = 0; i < o->cs.paraEE.size(); ++i)
             for (int k = 0; k < 4; ++k) para4[4 * i + k] = o->cs.paraEE[i][k];
 }
+void orc_opt_set_warm_start(orc_opt* o, int option)
+{
+    if (option < 0 || option > 4) return;
+    o->warmStart = option;
+}
+double orc_opt_warm_step(const orc_opt* o) { return o->warmStepSize; }
 void orc_opt_timers(const orc_opt* o, double* t16) { std::memcpy(t16, o->timers, sizeof(o->timers)); }
 }

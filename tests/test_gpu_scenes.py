@@ -165,3 +165,64 @@ def test_config0_hello_world_on_the_reference_mesh(orc, gpu_lib):
     assert np.allclose(Vn[g["right"], 2] - ctr[2], np.sin(th) * y0 + np.cos(th) * z0, atol=1e-9)
     assert np.allclose(Vn[g["left"]], V[g["left"]], rtol=0, atol=1e-14)
     c.close()
+
+
+@pytest.mark.parametrize("option,tit", [(1, "BE"), (2, "BE"), (3, "BE"), (4, "NM")])
+def test_warm_start_options_track_the_oracle(orc, gpu_lib, option, tit):
+    """Config `warmStart n` -> Optimizer::initX(n) (Optimizer.cpp:925-1215): the predicted first iterate, cut by the inversion
+    filter, the half-space bound and a full CCD pass.  A block thrown at the ground and at a second block: the admitted fraction
+    of the prediction and every Newton iterate after it agree with the oracle."""
+    Va, Fa = scene.make_box(2, 1, 2, size=(0.6, 0.2, 0.6), origin=(-0.3, 0.02, -0.3))
+    Vb, Fb = scene.make_box(1, 1, 1, size=(0.2, 0.2, 0.2), origin=(-0.07, 0.26, -0.11))
+    V = np.vstack([Va, Vb])
+    F = np.vstack([Fa, Fb + Va.shape[0]]).astype(np.int32)
+    Vs = scene.jitter(V, F, rel=1e-2)
+    SF = scene.surface_tris(F)
+    vel = np.zeros_like(V)
+    vel[:, 1] = -1.5
+    vel[Va.shape[0]:, 1] = -4.0  # the small block catches up with the slab
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF)
+    m.set_V(Vs)
+    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=2)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.01, True)
+    c.set_surface(SF)
+    if tit == "NM":
+        orc.opt_set_time_integration(o, "NM")
+        c.set_time_integration("NM")
+    orc.opt_enable_self_collision(o, 1e-2)
+    c.enable_self_collision(1e-2)
+    orc.opt_add_half_space(o, [0, 0, 0], [0, 1, 0], 1e-2)
+    c.add_half_space([0, 0, 0], [0, 1, 0], 1e-2)
+    orc.opt_set_velocity(o, vel)
+    c.set_velocity(vel)
+    orc.opt_set_warm_start(o, option)
+    c.set_warm_start(option)
+    o.precompute()
+    c.precompute()
+    cut = 0
+    for step in range(5):
+        o.begin_timestep()
+        c.begin_timestep()
+        wo, wg = orc.opt_warm_step(o), c.warm_step()
+        assert abs(wg - wo) <= 1e-9 * wo and 0 < wo <= 1.0, (step, wo, wg)
+        cut += wo < 1.0
+        assert relerr(c.state()["V"], o.state()["V"]) < 1e-10, step  # the first iterate itself
+        for it in range(60):
+            co, cg = o.newton_iter(), c.newton_iter()
+            assert co == cg, (step, it)
+            if co:
+                break
+            so, sg = o.state(), c.state()
+            assert abs(sg["stepSize"] - so["stepSize"]) <= 1e-8 * so["stepSize"], (step, it)
+            assert abs(sg["E"] - so["E"]) <= 1e-8 * abs(so["E"]), (step, it)
+            assert relerr(sg["V"], so["V"]) < 1e-8, (step, it)
+        else:
+            pytest.fail("Newton did not converge")
+        o.end_timestep()
+        c.end_timestep()
+    assert cut > 0  # the prediction was cut by a step bound at least once (ground / CCD)
+    c.close()

@@ -50,7 +50,10 @@ def test_grammar():
     assert sh.material == (2000.0, 1e8, 0.3) and sh.init_vel == ((1.0, 0.0, 0.0), (0.0, 0.0, 90.0)) and sh.lin_vel == (0.0, -1.0, 0.0)
     c = ss.SceneConfig.parse("shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 NBC 0.9 0 0 1 1 1 0 -5 0 0.1 0.3\n")
     assert c.shapes[0].nbc == [([0.9, 0.0, 0.0], [1.0, 1.0, 1.0], [0.0, -5.0, 0.0], 0.1, 0.3)]
-    for bad in ("meshCO plane.obj 0 0 0 1 1 0.1\n", "script DCOVerschoorRoller\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 meshSeq dir\n"):
+    c = ss.SceneConfig.parse("meshCO input/triMeshes/plane.obj 0.5 0 0.5  10  50  1.0 rotate 0 0 30\n", "/r")
+    (path, origin, scale, mu, rot), = c.mesh_cos
+    assert path == "/r/input/triMeshes/plane.obj" and np.allclose(origin, [0.5, 0, 0.5]) and scale == 10 and mu == 1.0 and np.allclose(rot, [0, 0, 30])
+    for bad in ("script DCOVerschoorRoller\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 meshSeq dir\n"):
         with pytest.raises(ss.UnsupportedKeyword):
             ss.SceneConfig.parse(bad)
 
@@ -110,7 +113,7 @@ def test_reference_scene_files_parse():
     print(len(ok), "scene files map onto the C ABI;", unsupported)
     for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
         assert need in ok, need
-    assert len(ok) >= 45  # the rest needs meshCO obstacles or scripted handle motions (script DCOFix, dragright, ...) that are not restated
+    assert len(ok) >= 85  # the rest needs scripted handle / obstacle motions (script DCOFix, dragright, ...) that are not restated
 
 
 class OracleBackend:
@@ -134,6 +137,15 @@ class OracleBackend:
 
     def opt_init(self, dt, gravity):
         self.o = self.orc.Optimizer(self.m, dt=dt, gravity=gravity, nthreads=self.nthreads)
+
+    def set_dbc(self, ids, typ):
+        self.m.set_dbc(ids, typ)
+
+    def set_warm_start(self, option):
+        self.orc.opt_set_warm_start(self.o, option)
+
+    def set_obstacle(self, ids, obstacle_only=False):
+        self.m.set_obstacle(ids, obstacle_only)
 
     def set_time_integration(self, *a):
         self.orc.opt_set_time_integration(self.o, *a)
@@ -170,6 +182,58 @@ class OracleBackend:
 
     def precompute(self):
         self.o.precompute()
+
+
+PLANE_OBJ = "v -1 0 -1\nv 1 0 -1\nv 1 0 1\nv -1 0 1\nv 0 0 0\nf 1 5 2\nf 2 5 3\nf 3/1/1 5/2/2 4/3/3\nf -2 -1 1\n"
+
+
+def test_mesh_obstacles_ride_along_as_surface_only_components(tmp_path):
+    """`meshCO` (Config.cpp:448-474, MeshCO.cpp:37-58): centred, rotated, scaled to the given largest extent, moved to the origin;
+    appended behind the simulated mesh without tetrahedra, its triangles in the surface, `fall` lifting the simulated mesh only."""
+    (tmp_path / "plane.obj").write_text(PLANE_OBJ)
+    Vo, Fo = ss.read_obj(tmp_path / "plane.obj")
+    assert Vo.shape == (5, 3) and np.array_equal(Fo, [[0, 4, 1], [1, 4, 2], [2, 4, 3], [3, 4, 0]])
+    V0, F0 = scene.make_box(1, 1, 1, size=(1.0, 1.0, 1.0), origin=(-0.5, 0.5, -0.5))
+    SF0 = scene.surface_tris(F0)
+    c = ss.SceneConfig.parse(f"shapes input 1\ncube.msh 0 0 0  0 0 0  1 1 1\nmeshCO {tmp_path}/plane.obj 0.25 -0.5 0  6  50  0.0 rotate 0 90 0\nscript fall\nselfCollisionOff\n")
+    sc = ss.assemble(c, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    n = V0.shape[0]
+    assert sc.V.shape[0] == n + 5 and sc.T.shape[0] == F0.shape[0] and np.array_equal(sc.obstacle_nodes, np.arange(n, n + 5))
+    P = sc.V[n:]
+    assert np.allclose(P.mean(0), [0.25 - 0.0, -0.5, 0.0], atol=1e-12)  # vertex mean at the origin given on the line
+    assert abs((P.max(0) - P.min(0)).max() - 6.0) < 1e-12 and np.ptp(P[:, 1]) < 1e-12  # largest extent = scale; still a y = const plane
+    assert sc.SF.shape[0] == SF0.shape[0] + 4 and sc.SF[-4:].min() >= n
+    lift = 0.5 * np.linalg.norm(V0.max(0) - V0.min(0))
+    assert np.allclose(sc.V[:n, 1], V0[:, 1] + lift)  # only the simulated cube is lifted
+
+
+@pytest.mark.gpu
+def test_cube_dropped_on_a_mesh_obstacle_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
+    """A `meshCO` scene end to end (selfCollisionOff: only pairs with the obstacle collide): constraint sets bit-exact while the cube
+    lands, converged steps equal, the cube comes to rest on the plane."""
+    (tmp_path / "plane.obj").write_text(PLANE_OBJ)
+    V, F = scene.make_box(2, 2, 2, size=(0.5, 0.5, 0.5), origin=(-0.25, -0.25, -0.25))
+    gl.save_tet_mesh(tmp_path / "cube.msh", scene.jitter(V, F, rel=1e-2), F)
+    text = (f"shapes input 1\ncube.msh 0 0.262 0  0 0 0  1 1 1\nmeshCO {tmp_path}/plane.obj 0.1 0 0.05  3  50  0.0 rotate 0 0 0\n"
+            "selfCollisionOff\ntime 1 0.01\ntol 1\n1e-6\n")
+    cfg = ss.SceneConfig.parse(text, str(tmp_path))
+    sc = ss.assemble(cfg, gl.read_tet_mesh)
+    ob = ss.apply(sc, OracleBackend(orc))
+    gb = ss.apply(sc, gpu_lib.Context(0))
+    assert gb.features()["bboxDiag2"] == pytest.approx(0.75, rel=1e-2)  # the cube's box, not the 3 x 3 obstacle
+    seen = 0
+    for step in range(14):
+        no, ng = ob.o.solve_timestep(60), gb.solve_timestep(60)
+        assert no < 60 and ng < 60
+        so, sg = ob.o.state(), gb.state()
+        cs_o, cs_g = orc.opt_contact_state(ob.o), gb.contact_state()
+        assert cs_g["nActive"] == len(cs_o["active"]), step
+        seen = max(seen, cs_g["nActive"])
+        assert np.abs(sg["V"] - so["V"]).max() < 1e-6 * np.abs(so["V"]).max(), step
+    n = V.shape[0]
+    assert seen > 0 and sg["V"][:n, 1].min() > 0.0  # resting above the plane y = 0
+    assert np.array_equal(sg["V"][n:], sc.V[n:])  # the obstacle did not move
+    gb.close()
 
 
 @pytest.mark.gpu
