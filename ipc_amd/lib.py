@@ -318,7 +318,7 @@ class Context:
 
     def set_obstacle(self, ids, obstacle_only=False):
         ids = _i32(ids)
-        self._chk(_lib.ipcgpu_set_obstacle_nodes(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(int(obstacle_only))))
+        self._chk(self._L.ipcgpu_set_obstacle_nodes(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(int(obstacle_only))))
 
     def get_surface(self):
         n = np.zeros(3, dtype=np.int32)
@@ -527,11 +527,11 @@ class Context:
         self._chk(self._L.ipcgpu_opt_set_time_integration(self.h, C.c_int({"BE": 0, "NM": 1}[name]), C.c_double(beta), C.c_double(gamma)))
 
     def set_warm_start(self, option):
-        self._chk(_lib.ipcgpu_opt_set_warm_start(self.h, C.c_int(int(option))))
+        self._chk(self._L.ipcgpu_opt_set_warm_start(self.h, C.c_int(int(option))))
 
     def warm_step(self):
         v = C.c_double()
-        self._chk(_lib.ipcgpu_opt_get_warm_step(self.h, C.byref(v)))
+        self._chk(self._L.ipcgpu_opt_get_warm_step(self.h, C.byref(v)))
         return v.value
 
     def add_dirichlet(self, ids, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), t0=0.0, t1=float("inf")):

@@ -220,12 +220,13 @@ def test_cube_dropped_on_a_mesh_obstacle_gpu_beside_the_oracle(orc, gpu_lib, tmp
     sc = ss.assemble(cfg, gl.read_tet_mesh)
     ob = ss.apply(sc, OracleBackend(orc))
     gb = ss.apply(sc, gpu_lib.Context(0))
-    assert gb.features()["bboxDiag2"] == pytest.approx(0.75, rel=1e-2)  # the cube's box, not the 3 x 3 obstacle
     seen = 0
     for step in range(14):
         no, ng = ob.o.solve_timestep(60), gb.solve_timestep(60)
         assert no < 60 and ng < 60
         so, sg = ob.o.state(), gb.state()
+        # dHat = dHatEps^2 * (diagonal of the cube's box)^2: the 3 x 3 obstacle does not count
+        assert sg["dHat"] == so["dHat"] and sg["dHat"] == pytest.approx(1e-6 * 0.75, rel=5e-2)
         cs_o, cs_g = orc.opt_contact_state(ob.o), gb.contact_state()
         assert cs_g["nActive"] == len(cs_o["active"]), step
         seen = max(seen, cs_g["nActive"])
