@@ -10,8 +10,8 @@ One "step" = one pass of the solveSub_IP loop (Optimizer.cpp:1829-2204) = one Ne
 time-step boundaries (scripted DBC motion, BE velocity update) included as they occur.
 
   python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by torch.distributed.run, one rank per GPU, element-sharded assembly with RCCL
-all-reduce of the shared gradient / Hessian values; the factorisation is replicated.)
+(N > 1: launched by torch.distributed.run, one rank per GPU: subtree-sharded direct solver over RCCL,
+element assembly sharded as well from 4 M tets)
 """
 import argparse
 import json
@@ -63,6 +63,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--solver", type=int, default=0, help="0 = GPU multifrontal, 1 = rocSOLVER csrrf")
+    ap.add_argument("--solver-shard", choices=["on", "off"], default="on",
+                    help="N > 1: subtree-sharded factorisation and solves (ipcgpu_linsys_set_shard); off = every rank repeats the whole solve")
+    ap.add_argument("--single-device-test", action="store_true",
+                    help="plumbing check on a one-GPU box: all ranks on cuda:0, collectives over gloo through a host bounce (numbers are meaningless)")
     ap.add_argument("--shard", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: shard the element assembly over the ranks (all-reduce of gradient + CSR values per iteration); "
                          "auto = only when the mesh is big enough for that to pay (see DESIGN.md section 6)")
@@ -80,10 +84,12 @@ def main():
     distributed = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.single_device_test:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.single_device_test else "nccl", rank=rank, world_size=world)
 
     import ipc_amd
 
@@ -93,15 +99,25 @@ def main():
     # the factorisation (94 % of an iteration) is replicated either way.  Sharding is therefore switched on only for meshes
     # whose assembly outweighs the exchange; below that every rank runs the whole iteration (no data-path collective).
     sharded = distributed and (args.shard == "on" or (args.shard == "auto" and F.shape[0] >= SHARD_MIN_TETS))
-    if sharded:
-        ctx.set_shard(rank, world)
-
+    solver_sharded = distributed and args.solver_shard == "on"
+    if distributed:
         def hook(ptr, count, op):
             t = torch.as_tensor(DevPtr(ptr, count), device=f"cuda:{local_rank}")
-            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
+            if args.single_device_test:  # gloo works on host tensors
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
             torch.cuda.synchronize()
             return 0
+        if sharded:
+            ctx.set_shard(rank, world)  # element assembly split over the ranks, gradient / CSR values all-reduced
         ctx.set_allreduce(hook)
+        if solver_sharded:
+            # the direct solver is what an iteration consists of: the assembly tree is cut below its top separators, every rank
+            # factorises / solves its own subtrees, the fronts above the cut are repeated
+            ctx.set_solver_shard(rank, world)
     ctx.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
     ctx.opt_init(dt=0.04, gravity=False)
     ctx.set_twist(left, right, 0.4 * np.pi)
@@ -145,6 +161,8 @@ def main():
         elapsed = float(tt.item())
     timers = ctx.timers() - t_before
 
+    # collective when the solver is sharded: every rank takes part
+    f_ms, s_ms = ctx.bench_factor_solve(3)
     out = None
     if rank == 0:
         K = args.steps
@@ -160,7 +178,6 @@ def main():
         ms_asm, bytes_asm = ctx.bench_assembly(0.04 ** 2, reps=20)
         ach = bytes_asm / (ms_asm * 1e-3) / 1e9
         stream_gbs = ctx.bench_stream(1 << 30, 10)
-        f_ms, s_ms = ctx.bench_factor_solve(3)
         st = ctx.linsys_stats()
         out = {
             "metric": "newton_iterations_per_sec",
@@ -173,7 +190,7 @@ def main():
             "higher_is_better": True,
             # the metric's workload is fixed (strong scaling) -- but below SHARD_MIN_TETS every rank runs the whole iteration and
             # nothing is divided: say so instead of letting N replicas read as an N-GPU strong-scaling point
-            "scaling": "strong" if (world == 1 or sharded) else "none (replicated: every rank runs the whole iteration)",
+            "scaling": "strong" if (world == 1 or sharded or solver_sharded) else "none (replicated: every rank runs the whole iteration)",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -183,9 +200,12 @@ def main():
                 "n_nodes": int(V.shape[0]), "n_tets": int(F.shape[0]), "n_dofs": int(n_rows), "nnz_upper_csr": int(nnz),
                 "linear_solver": "gpu-multifrontal-llt" if args.solver == 0 else "rocsolver-csrrf",
                 "parallelism": "single GPU" if world == 1 else (
-                    f"{world} GPUs: element-sharded assembly + RCCL all-reduce, replicated factorisation" if sharded else
-                    f"{world} GPUs: replicated (assembly sharding off below {SHARD_MIN_TETS} tets: the all-reduce would cost more than "
-                    f"the {1e3 * (timers[0] + timers[1] + timers[12]) / K:.2f} ms it splits; the direct solver does not shard)"),
+                    f"{world} GPUs: " + ("element-sharded assembly (RCCL all-reduce of gradient + CSR values)" if sharded else
+                                         f"assembly repeated on every rank (sharding it is switched on from {SHARD_MIN_TETS} tets: below, the "
+                                         "all-reduce of the CSR values costs more than the assembly)")
+                    + "; " + (f"subtree-sharded multifrontal factorisation and solves: {100 * ctx.solver_shard_stats()['shared_flop_fraction']:.0f} % of the "
+                              "factorisation flops lie above the cut and are repeated, update matrices / vectors of the subtree roots and the "
+                              "solution cross ranks by all-reduce" if solver_sharded else "factorisation and solves repeated on every rank")),
                 "time_steps_completed": state["steps_done"],
             },
             "split_ms_per_iter": split,

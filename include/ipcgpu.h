@@ -141,6 +141,14 @@ int ipcgpu_linsys_analyze_pattern(ipcgpu_ctx*); /* analyze_pattern, CHOLMODSolve
 int ipcgpu_linsys_factorize(ipcgpu_ctx*); /* factorize, :130-137; returns IPCGPU_NOT_PD */
 int ipcgpu_linsys_solve(ipcgpu_ctx*, const double* rhs, double* result); /* solve, :139-154 */
 int ipcgpu_linsys_precondition_diag(ipcgpu_ctx*, const double* in, double* out); /* :411-420 */
+/* Multi-GPU direct solver (one process per GPU): the assembly tree is cut below its top separators; rank r factorises and solves
+   the subtrees it owns, every rank repeats the fronts above the cut, and the update matrices / vectors of the subtree roots and
+   the final solution cross ranks through the all-reduce hook of ipcgpu_opt_set_allreduce (set the hook first).  The matrix
+   values must be present on every rank (replicated assembly, or ipcgpu_ctx_set_shard with its all-reduce of the values).
+   Takes effect at the next analyze_pattern.  ipcgpu_linsys_shard_stats (after analyze_pattern): out2[0] = world size,
+   out2[1] = the share of the factorisation flops that lies above the cut and is repeated by every rank. */
+int ipcgpu_linsys_set_shard(ipcgpu_ctx*, int rank, int world_size);
+int ipcgpu_linsys_shard_stats(ipcgpu_ctx*, double* out2);
 /* factor statistics: nnz(L), factorisation flops, number of supernodes / levels */
 int ipcgpu_linsys_stats(ipcgpu_ctx*, double* stats4);
 

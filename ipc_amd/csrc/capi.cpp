@@ -578,6 +578,23 @@ int ipcgpu_linsys_precondition_diag(ipcgpu_ctx* c, const double* in, double* out
         return IPCGPU_OK;
     });
 }
+int ipcgpu_linsys_set_shard(ipcgpu_ctx* c, int rank, int world)
+{
+    return guarded([&] {
+        needArg(c && world >= 1 && rank >= 0 && rank < world, "bad shard");
+        need(world == 1 || c->opt->allreduce != nullptr, "set the all-reduce hook first (ipcgpu_opt_set_allreduce)");
+        c->lin->setShard(rank, world, c->opt->allreduce, c->opt->allreduceUser);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_shard_stats(ipcgpu_ctx* c, double* out2)
+{
+    return guarded([&] {
+        out2[0] = L(c).solverWorld();
+        out2[1] = L(c).sharedFlopFraction();
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_linsys_stats(ipcgpu_ctx* c, double* st)
 {
     return guarded([&] {

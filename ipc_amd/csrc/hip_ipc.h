@@ -79,6 +79,14 @@ public:
     int getNumRows() const { return numRows; }
     int getNumNonzeros() const { return (int)ja.size(); }
     const MfSymbolic& symbolic() const { return sym_; }
+    // subtree-sharded factorisation / solves over `world` ranks (MfNumeric::setShard); takes effect at the next analyze_pattern
+    void setShard(int rank, int world, ipcgpu_allreduce_fn_t fn, void* user)
+    {
+        num_.setShard(rank, world, fn, user);
+        analyzed_ = false;
+    }
+    int solverWorld() const { return num_.world(); }
+    double sharedFlopFraction() const { return num_.sharedFlopFraction(); }
     bool analyzed() const { return analyzed_; }
 
 private:

@@ -14,6 +14,19 @@ public:
     MfNumeric& operator=(const MfNumeric&) = delete;
 
     void setup(const MfSymbolic& sym, hipStream_t stream); // uploads maps, allocates fronts
+    // Multi-GPU (one process per GPU): the assembly tree is cut below its top separators, every rank factorises and solves the
+    // subtrees it owns and all ranks repeat the fronts above the cut; the update matrices / update vectors of the subtree roots
+    // and the final solution cross ranks through `allreduce` (sum, in place, on a device buffer).  Call before setup().
+    typedef int (*AllreduceFn)(void* user, void* buf_dev, long long count, int op);
+    void setShard(int rank, int world, AllreduceFn fn, void* user)
+    {
+        rank_ = rank;
+        world_ = world;
+        allreduce_ = fn;
+        allreduceUser_ = user;
+    }
+    int world() const { return world_; }
+    double sharedFlopFraction() const { return sharedFlops_; } // share of the factorisation flops every rank repeats
     // a_dev: CSR values (device).  Returns false when a non-positive pivot was met.
     bool factorize(const double* a_dev);
     // rhs_dev / x_dev: device vectors in the user's ordering
@@ -44,6 +57,23 @@ private:
         Range bigTri; // into triList_: big fronts whose triangle is swept by one workgroup (no explicit inverse)
         Range xinvFwd, xinvBwd; // into xinvDesc_: row / column blocks of the fronts with an explicit inverse
     };
+    int rank_ = 0, world_ = 1;
+    AllreduceFn allreduce_ = nullptr;
+    void* allreduceUser_ = nullptr;
+    double sharedFlops_ = 0.0;
+    bool flagShared_ = false; // the update exchanges carry the pivot flag
+    std::vector<int> owner_; // per front: owning rank, -1 = above the cut (repeated by every rank)
+    struct Xchg {
+        Range pack; // into xchgDesc_: (front, staging offset lo, hi, 0) of the subtree roots of this level
+        long long count = 0; // doubles exchanged after the level's factorisation (update matrices)
+        long long countW = 0; // ... and after its forward sweep (update vectors)
+    };
+    std::vector<Xchg> xchg_;
+    DevBuf<int4> xchgDesc_;
+    DevBuf<double> xchgBuf_;
+    DevBuf<int> nodeOwner_; // per permuted node: owning rank or -1
+    DevBuf<int> ownerDev_; // owner_ on the device
+    void allreduceSum(double* dev, long long count);
     const MfSymbolic* sym_ = nullptr;
     hipStream_t stream_ = nullptr;
     int ns_ = 0, nLevels_ = 0;

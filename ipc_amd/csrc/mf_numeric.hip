@@ -1333,6 +1333,52 @@ __global__ __launch_bounds__(WGT) void k_big_bwd_tri(const int* __restrict__ lis
     for (int I = tid; I < nc; I += WGT) xsol[col0 + I] = t[I];
 }
 
+// ---- subtree-sharded factorisation: what crosses ranks -----------------------------------------------------------------------
+// desc = (front, staging offset lo, hi, mode).  The update block of a subtree root (lower triangle, (N - nc)^2 doubles in the
+// staging buffer, zeros above the diagonal) is packed by its owner, summed over the ranks (everybody else holds zeros), and
+// unpacked into the same front on every rank: the fronts above the cut then find their children's contributions in place.
+__global__ __launch_bounds__(256) void k_xchg_update(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts, double* __restrict__ buf,
+    int unpack, int rank, const int* __restrict__ owner)
+{
+    const int4 d = desc[blockIdx.y];
+    const int s = d.x;
+    if (!unpack && owner[s] != rank) return;
+    const int N = frontN(tv, s), nc = frontNc(tv, s), m = N - nc;
+    double* F = fronts + tv.frontOff[s];
+    double* B = buf + (((long long)(unsigned)d.z << 32) | (unsigned)d.y);
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)m * m; e += (long long)gridDim.x * 256) {
+        const int j = (int)(e / m), i = (int)(e - (long long)j * m);
+        if (i < j) continue;
+        if (unpack) F[(nc + i) + (long long)N * (nc + j)] = B[e];
+        else B[e] = F[(nc + i) + (long long)N * (nc + j)];
+    }
+}
+// the same for the update vectors of the forward sweep (rows >= nc of the front's work vector)
+__global__ __launch_bounds__(256) void k_xchg_w(const int4* __restrict__ desc, TreeView tv, const long long* __restrict__ wOff, double* __restrict__ wbuf,
+    double* __restrict__ buf, int unpack, int rank, const int* __restrict__ owner)
+{
+    const int4 d = desc[blockIdx.y];
+    const int s = d.x;
+    if (!unpack && owner[s] != rank) return;
+    const int N = frontN(tv, s), nc = frontNc(tv, s), m = N - nc;
+    double* w = wbuf + wOff[s] + nc;
+    double* B = buf + d.w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+        if (unpack) w[i] = B[i];
+        else B[i] = w[i];
+    }
+}
+// the solution: every rank keeps the entries of the nodes it owns (rank 0 also the ones above the cut), zeros elsewhere; the sum is x
+__global__ void k_mask_xsol(int nn, const int* __restrict__ nodeOwner, int rank, double* __restrict__ xsol)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * nn) return;
+    const int o = nodeOwner[i / 3];
+    if (!(o == rank || (o < 0 && rank == 0))) xsol[i] = 0.0;
+}
+__global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ buf) { buf[0] = flag[0] ? 1.0 : 0.0; }
+__global__ void k_double_to_flag(const double* __restrict__ buf, int* __restrict__ flag) { flag[0] = (flag[0] || buf[0] > 0.0) ? 1 : 0; }
+
 // ---- explicit inverses of the factor triangles of the widest fronts ----------------------------------------------------
 // The nc x nc triangle of a top-level front is swept by ONE workgroup in the blocked substitution above: 3.2 MB through a
 // single CU for the root of a 45 K-node sheet, ~140 us per direction, and the top five levels make up half of the solve.
@@ -1593,6 +1639,85 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_NT128_N")) ntSmallN = std::atoi(e);
     if (const char* e = std::getenv("IPCGPU_MF_NT512_N")) ntBigN = std::atoi(e);
     auto isFused = [&](int s) { return sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds; };
+    // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
+    owner_.assign(ns_, rank_);
+    sharedFlops_ = 0.0;
+    if (world_ > 1) {
+        std::vector<double> own(ns_, 0.0), cost(ns_, 0.0);
+        for (int s = 0; s < ns_; ++s) {
+            const double N = sym.N(s), nc = sym.nc(s);
+            for (int j = 0; j < (int)nc; ++j) own[s] += (N - j - 1) * (N - j - 1);
+            cost[s] += own[s];
+            if (sym.parent[s] >= 0) cost[sym.parent[s]] += cost[s]; // children precede their parent in the elimination order
+        }
+        std::vector<int> frontier;
+        for (int s = 0; s < ns_; ++s)
+            if (sym.parent[s] < 0) frontier.push_back(s);
+        std::vector<char> shared(ns_, 0);
+        while ((int)frontier.size() < world_) { // open the most expensive subtree that still has children
+            int best = -1;
+            for (size_t i = 0; i < frontier.size(); ++i) {
+                const int f = frontier[i];
+                if (sym.childPtr[f + 1] > sym.childPtr[f] && (best < 0 || cost[f] > cost[frontier[best]])) best = (int)i;
+            }
+            if (best < 0) break;
+            const int f = frontier[best];
+            frontier.erase(frontier.begin() + best);
+            shared[f] = 1;
+            for (int q = sym.childPtr[f]; q < sym.childPtr[f + 1]; ++q) frontier.push_back(sym.child[q]);
+        }
+        std::sort(frontier.begin(), frontier.end(), [&](int a, int b) { return cost[a] > cost[b] || (cost[a] == cost[b] && a < b); });
+        std::vector<double> load(world_, 0.0);
+        std::vector<int> rootOwner(ns_, -1);
+        for (int f : frontier) {
+            const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+            load[r] += cost[f];
+            rootOwner[f] = r;
+        }
+        // fronts in descending order: a front inherits its parent's owner unless it is a subtree root or above the cut
+        double tot = 0.0, sh = 0.0;
+        for (int s = ns_ - 1; s >= 0; --s) {
+            if (shared[s]) owner_[s] = -1;
+            else if (rootOwner[s] >= 0) owner_[s] = rootOwner[s];
+            else owner_[s] = owner_[sym.parent[s]];
+            tot += own[s];
+            if (shared[s]) sh += own[s];
+        }
+        sharedFlops_ = tot > 0 ? sh / tot : 0.0;
+        // exchange lists: subtree roots whose parent is above the cut, by level
+        xchg_.assign(nLevels_, Xchg());
+        std::vector<int4> xd;
+        long long maxCount = 1;
+        for (int l = 0; l < nLevels_; ++l) {
+            Xchg& X = xchg_[l];
+            X.pack.off = (int)xd.size();
+            long long off = 0;
+            int offW = 0;
+            for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
+                const int s = sym.levelFronts[i];
+                if (owner_[s] < 0 || sym.parent[s] < 0 || owner_[sym.parent[s]] >= 0) continue;
+                const long long m = sym.N(s) - sym.nc(s);
+                xd.push_back(make_int4(s, (int)(unsigned)(off & 0xffffffffLL), (int)(off >> 32), offW));
+                off += m * m;
+                offW += (int)m;
+            }
+            X.pack.cnt = (int)xd.size() - X.pack.off;
+            X.count = off;
+            X.countW = offW;
+            maxCount = std::max(maxCount, off);
+        }
+        if (xd.empty()) xd.push_back(make_int4(0, 0, 0, 0));
+        xchgDesc_.upload(xd.data(), xd.size(), stream);
+        xchgBuf_.ensure((size_t)maxCount + 1);
+        flagShared_ = false;
+        for (const Xchg& X : xchg_) flagShared_ |= X.pack.cnt > 0;
+        std::vector<int> no(std::max(sym.nn, 1), -1);
+        for (int s = 0; s < ns_; ++s)
+            for (int v = sym.firstNode[s]; v < sym.firstNode[s + 1]; ++v) no[v] = owner_[s];
+        nodeOwner_.upload(no, stream);
+        ownerDev_.upload(owner_, stream);
+    }
+    auto mine = [&](int s) { return world_ == 1 || owner_[s] < 0 || owner_[s] == rank_; };
     // entries of A grouped by owning front: (source index, offset inside the LDS panel) for the fused fronts,
     // (source index, offset in the front buffer) per level for the others.  A parallel counting sort on a few host threads,
     // written straight into pinned staging buffers (grow-only, like the device buffers they are copied to): this runs on
@@ -1602,12 +1727,14 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<char> fused(ns_);
         for (int s = 0; s < ns_; ++s) fused[s] = isFused(s);
         // bucket of an entry: fused front s -> s, other front of level l -> ns_ + l
-        const int nBuckets = ns_ + nLevels_;
+        const int nBuckets = ns_ + nLevels_ + 1;
         const int nThreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
         std::vector<std::vector<int>> cnt(nThreads, std::vector<int>(nBuckets, 0));
         auto range = [&](int t) { return std::make_pair(nnz * t / nThreads, nnz * (t + 1) / nThreads); };
+        const int skipBucket = ns_ + nLevels_; // entries of fronts another rank owns
         auto bucketOf = [&](size_t k) {
             const int s = sym.aFront[k];
+            if (!mine(s)) return skipBucket;
             return fused[s] ? s : ns_ + sym.level[s];
         };
         {
@@ -1631,7 +1758,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 tot += c;
             }
             if (bkt < ns_) aPtr[bkt + 1] = aPtr[bkt] + tot;
-            else bigCnt[bkt - ns_ + 1] = bigCnt[bkt - ns_] + tot;
+            else if (bkt < ns_ + nLevels_) bigCnt[bkt - ns_ + 1] = bigCnt[bkt - ns_] + tot;
         }
         const size_t nFused = (size_t)aPtr[ns_], nBig = (size_t)bigCnt[nLevels_];
         auto growPinned = [](PinnedBuf<int>& b, size_t n) {
@@ -1653,6 +1780,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                     int* off = cnt[t].data();
                     for (size_t k = r.first; k < r.second; ++k) {
                         const int s = sym.aFront[k];
+                        if (!mine(s)) continue;
                         if (fused[s]) {
                             const int q = aPtr[s] + off[s]++;
                             aSrc[q] = (int)k;
@@ -1697,6 +1825,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<int> small, big;
         for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
             const int s = sym.levelFronts[i];
+            if (!mine(s)) continue; // factorised and solved by the rank that owns its subtree
             (isFused(s) ? small : big).push_back(s);
         }
         // heaviest first so the tail of the level is made of short jobs
@@ -1855,7 +1984,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<long long> di(ns_ + 1, 0);
         for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
         for (int s = 0; s < ns_; ++s)
-            if (isFused(s)) // the multi-workgroup path leaves finished inverses in the dinv slots (wave_trinv32_fast)
+            if (isFused(s) && mine(s)) // the multi-workgroup path leaves finished inverses in the dinv slots (wave_trinv32_fast)
                 for (long long b = di[s]; b < di[s + 1]; ++b) blockList.push_back((int)b);
         plainBlocks_.off = 0;
         plainBlocks_.cnt = (int)blockList.size();
@@ -1979,6 +2108,14 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     lap("uploads + attributes");
 }
 
+void MfNumeric::allreduceSum(double* dev, long long count)
+{
+    if (world_ <= 1 || count <= 0) return;
+    if (!allreduce_) throw StateError("sharded solver without an all-reduce hook (ipcgpu_opt_set_allreduce)");
+    HIP_CHECK(hipStreamSynchronize(stream_)); // the hook works on the caller's stream: ours has to be drained first
+    if (allreduce_(allreduceUser_, dev, count, 0) != 0) throw HipError("all-reduce hook failed");
+}
+
 MfNumeric::~MfNumeric()
 {
     dropGraphs();
@@ -2018,12 +2155,17 @@ static void replay(hipStream_t stream, hipGraphExec_t& exec, bool& valid, Enqueu
 bool MfNumeric::factorize(const double* a_dev)
 {
     if (!sym_) throw StateError("factorize before analyze_pattern");
-    if (useGraph_) {
+    if (useGraph_ && world_ == 1) {
         bool valid = graphF_ && graphA_ == a_dev;
         replay(stream_, graphF_, valid, [&] { enqueueFactor(a_dev); });
         graphA_ = a_dev;
     }
     else enqueueFactor(a_dev);
+    if (world_ > 1 && !flagShared_) { // no exchange carried the flag (a tree that was not cut): a bad pivot met by any rank fails all
+        hipLaunchKernelGGL(k_flag_to_double, dim3(1), dim3(1), 0, stream_, flag_.p, xchgBuf_.p);
+        allreduceSum(xchgBuf_.p, 1);
+        hipLaunchKernelGGL(k_double_to_flag, dim3(1), dim3(1), 0, stream_, xchgBuf_.p, flag_.p);
+    }
     hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, stream_, flag_.p, hflag_.dev); // mapped pinned memory: no blit
     HIP_CHECK(hipStreamSynchronize(stream_));
     return hflag_.p[0] == 0;
@@ -2074,6 +2216,20 @@ void MfNumeric::enqueueFactor(const double* a_dev)
         for (const Range& R : P.step)
             if (R.cnt) hipLaunchKernelGGL(k_big_step, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p);
         if (P.schur.cnt) hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, tv, fronts_.p);
+        if (world_ > 1 && xchg_[l].pack.cnt) {
+            // the update matrices of the subtree roots of this level: packed by their owners, summed, unpacked everywhere
+            // (the pivot flag of this rank rides along in one extra double: a bad pivot inside a subtree reaches every rank
+            // with the exchange that follows it, the fronts above the cut are repeated and seen by all anyway)
+            const Xchg& X = xchg_[l];
+            xchgBuf_.zeroN((size_t)X.count + 1, stream_);
+            hipLaunchKernelGGL(k_xchg_update, dim3(64, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, fronts_.p, xchgBuf_.p, 0, rank_,
+                ownerDev_.p);
+            hipLaunchKernelGGL(k_flag_to_double, dim3(1), dim3(1), 0, stream_, flag_.p, xchgBuf_.p + X.count);
+            allreduceSum(xchgBuf_.p, X.count + 1);
+            hipLaunchKernelGGL(k_xchg_update, dim3(64, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, fronts_.p, xchgBuf_.p, 1, rank_,
+                ownerDev_.p);
+            hipLaunchKernelGGL(k_double_to_flag, dim3(1), dim3(1), 0, stream_, xchgBuf_.p + X.count, flag_.p);
+        }
         if (xinvLevel_[l].blocks.cnt) {
             // the factor panels and pivot blocks of this level are final: form the triangle inverses of its fronts beside the
             // latency-bound chain of the levels above (during graph capture everything stays on the one stream)
@@ -2126,7 +2282,7 @@ void MfNumeric::enqueueInverses(int l, hipStream_t st)
 void MfNumeric::solve(const double* rhs_dev, double* x_dev)
 {
     if (!sym_) throw StateError("solve before analyze_pattern");
-    if (useGraph_) {
+    if (useGraph_ && world_ == 1) {
         bool valid = graphS_ && graphRhs_ == rhs_dev && graphX_ == x_dev;
         replay(stream_, graphS_, valid, [&] { enqueueSolve(rhs_dev, x_dev); });
         graphRhs_ = rhs_dev;
@@ -2159,6 +2315,15 @@ void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
         if (P.fwdRect.cnt)
             hipLaunchKernelGGL(k_big_fwd_rect, dim3(P.fwdRect.cnt), dim3(WG), 0, stream_, desc_.p + P.fwdRect.off, tv, wOff_.p, fronts_.p, w_.p,
                 yperm_.p);
+        if (world_ > 1 && xchg_[l].pack.cnt) { // update vectors of the subtree roots of this level -> every rank
+            const Xchg& X = xchg_[l];
+            xchgBuf_.zeroN((size_t)X.countW, stream_);
+            hipLaunchKernelGGL(k_xchg_w, dim3(4, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, wOff_.p, w_.p, xchgBuf_.p, 0, rank_,
+                ownerDev_.p);
+            allreduceSum(xchgBuf_.p, X.countW);
+            hipLaunchKernelGGL(k_xchg_w, dim3(4, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, wOff_.p, w_.p, xchgBuf_.p, 1, rank_,
+                ownerDev_.p);
+        }
     }
     for (int l = nLevels_ - 1; l >= 0; --l) {
         const LevelPlan& P = plan_[l];
@@ -2174,6 +2339,10 @@ void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
         if (P.small.cnt)
             hipLaunchKernelGGL(k_bwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
                 yperm_.p, xsol_.p);
+    }
+    if (world_ > 1) { // every rank holds the solution of its own subtrees (and of the fronts above the cut): sum of the masked parts
+        hipLaunchKernelGGL(k_mask_xsol, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, nodeOwner_.p, rank_, xsol_.p);
+        allreduceSum(xsol_.p, n3);
     }
     hipLaunchKernelGGL(k_unpermute_x, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, xsol_.p, x_dev);
 }

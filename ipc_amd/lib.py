@@ -151,6 +151,15 @@ class Context:
     def set_shard(self, rank, world):
         self._chk(self._L.ipcgpu_ctx_set_shard(self.h, C.c_int(rank), C.c_int(world)))
 
+    def set_solver_shard(self, rank, world):
+        """subtree-sharded factorisation / solves (ipcgpu_linsys_set_shard); call after set_allreduce"""
+        self._chk(self._L.ipcgpu_linsys_set_shard(self.h, C.c_int(rank), C.c_int(world)))
+
+    def solver_shard_stats(self):
+        o = np.zeros(2)
+        self._chk(self._L.ipcgpu_linsys_shard_stats(self.h, _dp(o)))
+        return dict(world=int(o[0]), shared_flop_fraction=float(o[1]))
+
     def set_allreduce(self, pyfunc):
         """pyfunc(dev_ptr:int, count:int, op:int) -> int (0 ok)."""
         def tramp(user, buf, count, op):

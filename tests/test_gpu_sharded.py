@@ -28,12 +28,9 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
-V, F = scene.make_bar(12, 2, 2, size=(5.0, 0.5, 1.0))
-left, right = scene.border_verts(V, 0.01)
-Vs = scene.twist_state(scene.jitter(V, F, rel=2e-2), 0.15)
+mode = os.environ.get("MODE", "assembly")
 c = ipc_amd.Context(0)
 if world > 1:
-    c.set_shard(rank, world)
     def hook(ptr, count, op):
         t = torch.as_tensor(DevPtr(ptr, count), device="cuda:0")
         h = t.cpu()
@@ -41,18 +38,69 @@ if world > 1:
         t.copy_(h)
         torch.cuda.synchronize()
         return 0
+    if mode == "assembly":
+        c.set_shard(rank, world)  # patches sharded, gradient / CSR values / scalars all-reduced
     c.set_allreduce(hook)
-c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
-c.set_positions(Vs)
-c.opt_init(0.025, False)
-c.set_twist(left, right)
-c.precompute()
+    if mode != "assembly":
+        c.set_solver_shard(rank, world)  # subtree-sharded factorisation and solves, everything else replicated
+extra = {}
+if mode in ("assembly", "solver"):
+    n = 12 if mode == "assembly" else 40
+    V, F = scene.make_bar(12, 2, 2, size=(5.0, 0.5, 1.0)) if mode == "assembly" else scene.make_mat(n)
+    left, right = scene.border_verts(V, 0.01)
+    Vs = scene.twist_state(scene.jitter(V, F, rel=2e-2), 0.15)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.025, False)
+    c.set_twist(left, right)
+    c.precompute()
+    if mode == "solver":  # the solver alone first: residual of one solve, not-PD agreed on by all ranks
+        rows, nnz = c.get_dims()
+        c.assemble_newton(0.025 ** 2, True, with_gradient=False)
+        c.analyze_pattern()
+        assert c.factorize()
+        b = np.random.default_rng(5).normal(size=rows)
+        x = c.solve(b)
+        extra["res"] = np.linalg.norm(c.multiply(x) - b) / np.linalg.norm(b)
+        extra["x"] = x
+        extra["shared"] = c.solver_shard_stats()["shared_flop_fraction"]
+        a = c.get_a()
+        ia, ja = c.get_pattern()
+        k = ia[3 * (rows // 6)]
+        c.set_coeff(3 * (rows // 6), 3 * (rows // 6), -abs(a[k]))
+        extra["notpd"] = not c.factorize()
+        c.set_coeff(3 * (rows // 6), 3 * (rows // 6), a[k])
+    steps, cap = 2, 40
+else:  # contact: two slabs, the upper one dropped on the clamped lower one (pattern changes -> re-analysis with a new cut)
+    def two_blocks(gap, n=3, shift=0.13):
+        Va, Fa = scene.make_box(n, 1, n, size=(1.0, 0.3, 1.0), origin=(0, 0, 0))
+        Vb, Fb = scene.make_box(n, 1, n, size=(1.0, 0.3, 1.0), origin=(shift, 0.3 + gap, 0.5 * shift))
+        return np.vstack([Va, Vb]), np.vstack([Fa, Fb + Va.shape[0]])
+    V, F = two_blocks(0.03)
+    Vs = scene.jitter(V, F, rel=1e-2)
+    SF = scene.surface_tris(F)
+    nA = V.shape[0] // 2
+    bottom = np.nonzero(V[:nA, 1] < V[:nA, 1].min() + 0.02)[0].astype(np.int32)
+    vel = np.zeros_like(V)
+    vel[nA:, 1] = -6.0
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_dbc(bottom, 1)
+    c.set_positions(Vs)
+    c.opt_init(0.02, True)
+    c.set_surface(SF)
+    c.enable_self_collision(1e-2)
+    c.set_velocity(vel)
+    c.precompute()
+    steps, cap = 4, 60
 iters = []
-for step in range(2):
-    iters.append(c.solve_timestep(40))
+for step in range(steps):
+    iters.append(c.solve_timestep(cap))
 s = c.state()
+if mode == "contact":
+    extra["nActive"] = c.contact_state()["nActive"]
+    extra["nPatternChanges"] = c.contact_state()["nPatternChanges"]
 if rank == 0:
-    np.savez(os.environ["OUT"], V=s["V"], E=s["E"], g=s["gradient"], iters=np.array(iters))
+    np.savez(os.environ["OUT"], V=s["V"], E=s["E"], g=s["gradient"], iters=np.array(iters), **extra)
 c.close()
 if world > 1:
     dist.barrier()
@@ -60,12 +108,12 @@ if world > 1:
 '''
 
 
-def run(world, out):
+def run(world, out, mode="assembly"):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(WORKER)
         script = f.name
-    env = dict(os.environ, IPC_REPO=repo, OUT=out, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
+    env = dict(os.environ, IPC_REPO=repo, OUT=out, MODE=mode, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533")
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r))
@@ -86,3 +134,36 @@ def test_two_ranks_reproduce_the_single_rank_trajectory():
         scale = np.abs(a["V"]).max()
         assert np.abs(a["V"] - b["V"]).max() <= 1e-11 * scale
         assert abs(a["E"] - b["E"]) <= 1e-11 * abs(a["E"])
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_subtree_sharded_solver_reproduces_the_single_rank_run(world):
+    """ipcgpu_linsys_set_shard: the assembly tree cut below its top separators, every rank factorising and solving its own subtrees
+    (update matrices / vectors of the subtree roots and the final solution crossing ranks through the hook).  The per-front
+    arithmetic is the single-rank one, so the solution and the whole Newton trajectory agree to round-off."""
+    with tempfile.TemporaryDirectory() as d:
+        one, many = os.path.join(d, "one.npz"), os.path.join(d, "many.npz")
+        run(1, one, "solver")
+        run(world, many, "solver")
+        a, b = np.load(one), np.load(many)
+        assert a["res"] < 1e-11 and b["res"] < 1e-11
+        assert np.abs(a["x"] - b["x"]).max() <= 1e-12 * np.abs(a["x"]).max()
+        assert bool(a["notpd"]) and bool(b["notpd"])
+        assert 0.0 < float(b["shared"]) < 0.7 and float(a["shared"]) == 0.0  # a real cut: part of the tree, not all of it, is repeated
+        assert np.array_equal(a["iters"], b["iters"])
+        assert np.abs(a["V"] - b["V"]).max() <= 1e-11 * np.abs(a["V"]).max()
+        assert abs(a["E"] - b["E"]) <= 1e-11 * abs(a["E"])
+
+
+def test_two_ranks_with_contact_reproduce_the_single_rank_trajectory():
+    """The same with self-contact: constraint sets, barrier terms and CCD replicated, the solver sharded, the pattern (and with it
+    the cut of the assembly tree) changing while the slabs come into contact."""
+    with tempfile.TemporaryDirectory() as d:
+        one, two = os.path.join(d, "one.npz"), os.path.join(d, "two.npz")
+        run(1, one, "contact")
+        run(2, two, "contact")
+        a, b = np.load(one), np.load(two)
+        assert int(a["nActive"]) > 0 and int(a["nActive"]) == int(b["nActive"])
+        assert int(a["nPatternChanges"]) >= 1
+        assert np.array_equal(a["iters"], b["iters"])
+        assert np.abs(a["V"] - b["V"]).max() <= 1e-10 * np.abs(a["V"]).max()
