@@ -102,6 +102,7 @@ private:
     DevBuf<double> dinv_; // explicit inverses of the 32x32 diagonal blocks of L, 1024 doubles each
     DevBuf<int> idx_, idxPtr_, firstNode_, childPtr_, child_, invPtr_, inv_, newOf_, flag_;
     DevBuf<long long> frontOff_, wOff_, dinvOff_;
+    std::vector<long long> hDinvOff_; // host copy: the step records carry a front's first inverse block
     DevBuf<int> aSrc_, aLoc_; // entries of A per fused front: CSR source index, offset inside the LDS panel
     DevBuf<double> aPerm_; // values of A gathered into fused-front order at the start of every factorisation
     int nFusedA_ = 0;

@@ -40,7 +40,11 @@ constexpr int LDX = NB + 1; // same for the inverse of a pivot block
 constexpr int WG = 256;
 constexpr int WGB = WG; // big-front step: three row waves + one pivot wave, one per SIMD
 constexpr int ROW_WAVES_B = 3; // row waves per role-B workgroup (1 was measured slower: 3x the workgroups, each repeating the pivot work)
-constexpr int ROWS_B = 64 * ROW_WAVES_B; // panel rows per role-B workgroup
+#ifndef MF_ROWS_MT
+#define MF_ROWS_MT 2
+#endif
+constexpr int MT_B = MF_ROWS_MT; // 16-row tiles per row wave of a role-B workgroup
+constexpr int ROWS_B = 16 * MT_B * ROW_WAVES_B; // panel rows per role-B workgroup
 constexpr int PIVOT_T0 = WGB - 64; // first thread of the pivot wave
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
@@ -520,6 +524,147 @@ __device__ __forceinline__ void wave_trinv32_fast(const double* blk, int ld, con
     __builtin_amdgcn_wave_barrier();
 }
 
+// reciprocal to full double precision: v_rcp_f64 seed + two Newton steps
+__device__ __forceinline__ double rcp_nr(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    return r;
+}
+
+// X = L11^-1 of a (<=) 32 x 32 SPD pivot block A11 = L11 L11^T by one wave, in the accumulator registers of the matrix
+// cores: symmetric Gauss-Jordan, one rank-1 update per pivot as ONE v_mfma_f64_16x16x4_f64 per 16 x 16 tile.
+//   blk[k * LDP + r] = A(r, k), r >= k (LDS, k-major; entries with an index >= w are zero on entry and count as identity)
+//   Xs[c * LDX + r] = X(r, c), all 32 x 32 entries written (zeros above the diagonal); returns true on a pivot <= 0
+// The block lives as tiles T00, T01, T11 (upper triangle: the row of a pivot is its column) in the D layout
+// (row = (l >> 4) + 4 reg, col = l & 15).  Row k of a tile sits in register k >> 2 of the 16 lanes with l >> 4 == (k & 3),
+// indexed by l & 15 -- which is exactly an operand of k-slice (k & 3): A[i = l & 15][kk = l >> 4], B[kk = l >> 4][j = l & 15].
+// So with every other k-slice masked to zero, D[i][j] += m_i a_j needs no data movement at all: the pivot row scaled by
+// -1 / d is the A operand (multipliers, rows <= k masked), the pivot row itself the B operand.  The same eliminations
+// applied to W = I give the inverse of the unit-lower factor; X = D^-1/2 W.  On the dependent chain of a pivot: two
+// v_readlane (d), v_rcp_f64 + two Newton steps, one multiply, one MFMA -- no square root, no lane-to-lane broadcast of
+// multipliers, no LDS.  (Entries left of a pivot are dead: they only ever feed other dead entries, so neither they nor
+// the B operands need masking.)  On this chip an fp64 MFMA occupies the SIMD for 64 cycles and does NOT overlap with the
+// wave's own VALU work (measured: pivot time = MFMAs x 64 + ~240 cycles of chain, whatever the order) -- the matrix and
+// vector fp64 rates of MI355X are the same units -- so what counts is the number of MFMAs and the length of the chain.
+// Blocked 16 + 16 so that the pipe (64 cycles per fp64 MFMA here) does not become the bound:
+//   pivots 0..15 update T00, T01 = U01 and W00 only (three MFMAs each; the W00 update of pivot k is issued in the middle of
+//   the reciprocal chain of pivot k + 1, where the pipe would idle); then, as K = 16 products whose operands are the accumulator
+//   registers as they stand (register i of a tile is row (l >> 4) + 4 i = the operand of k-step i, either side):
+//       T11 -= U01^T D0^-1 U01,   W10 = -(D0^-1 U01)^T W00;
+//   pivots 16..31 update T11 and W11 (two MFMAs each); finally X10 = X11 W10 (X11 transposed through LDS, where it goes anyway).
+// 92 MFMAs, against 16.5 k + 3.1 k cycles for the lane-per-row Cholesky + recursive-doubling inverse this replaces.
+__device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int w, int lane, double* Xs)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+    f64x4 T00, T01, T11, W00, W11, s0, s1, n0;
+    f64x4 W10 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = hi + 4 * r; // tile row; the LDS block holds the lower triangle: A(row, col) = blk[min * LDP + max]
+        const double a00 = blk[min(q, lo) * LDP + max(q, lo)];
+        const double a01 = blk[q * LDP + 16 + lo];
+        const double a11 = blk[(16 + min(q, lo)) * LDP + 16 + max(q, lo)];
+        const bool dg = q == lo;
+        T00[r] = (dg && q >= w) ? 1.0 : a00;
+        T01[r] = a01;
+        T11[r] = (dg && 16 + q >= w) ? 1.0 : a11;
+        W00[r] = dg ? 1.0 : 0.0;
+        W11[r] = dg ? 1.0 : 0.0;
+        s0[r] = 1.0;
+        s1[r] = 1.0;
+        n0[r] = 0.0;
+    }
+    bool bad = false;
+    double pm = 0.0, pw = 0.0; // the W update of the previous pivot, issued inside this pivot's reciprocal chain
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int h = k & 3, r = k >> 2;
+        const bool sel = hi == h, selgt = sel && lo > k;
+        const double row0 = T00[r];
+        const double dk = bcast_lane(row0, 16 * h + k);
+        bad |= !(dk > 0.0); // not on the chain: a bad pivot leaves garbage behind, and the flag says so
+        double ri = __builtin_amdgcn_rcp(dk);
+        double e = fma(-dk, ri, 1.0);
+        ri = fma(ri, e, ri);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k > 0) W00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W00, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        e = fma(-dk, ri, 1.0);
+        ri = fma(ri, e, ri);
+        const double nri = -ri;
+        const double m0 = selgt ? row0 * nri : 0.0; // the B operands go in unmasked: their other k-slices meet zeros of m0
+        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, row0, T00, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, T01[r], T01, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pw = W00[r]; // row k of W00 is final once pivot k - 1 has been applied
+        pm = m0;
+        s0[r] = sel ? dk : s0[r]; // pivots collected per D-layout row; their rsqrt is taken once, vectorised, at the end
+        n0[r] = sel ? nri : n0[r];
+    }
+    W00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W00, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const double a = T01[ks] * n0[ks]; // -(D0^-1 U01)(row (l >> 4) + 4 ks, col l & 15): A operand [i = col][kk = row]
+        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T01[ks], T11, 0, 0, 0);
+        W10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W00[ks], W10, 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    pm = 0.0;
+    pw = 0.0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int h = k & 3, r = k >> 2;
+        const bool sel = hi == h, selgt = sel && lo > k;
+        const double row1 = T11[r];
+        const double dk = bcast_lane(row1, 16 * h + k);
+        bad |= !(dk > 0.0);
+        double ri = __builtin_amdgcn_rcp(dk);
+        double e = fma(-dk, ri, 1.0);
+        ri = fma(ri, e, ri);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k > 0) W11 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W11, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        e = fma(-dk, ri, 1.0);
+        ri = fma(ri, e, ri);
+        const double nri = -ri;
+        const double m1 = selgt ? row1 * nri : 0.0;
+        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, row1, T11, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        pw = W11[r];
+        pm = m1;
+        s1[r] = sel ? dk : s1[r];
+    }
+    W11 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W11, 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = hi + 4 * r;
+        const double r0 = rsqrt_nr(s0[r]);
+        s1[r] = rsqrt_nr(s1[r]);
+        Xs[lo * LDX + q] = W00[r] * r0;
+        Xs[(16 + lo) * LDX + 16 + q] = W11[r] * s1[r];
+        Xs[(16 + lo) * LDX + q] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // X10 = X11 W10: A[i = l & 15][kk] = X(16 + i, 16 + kk) read back transposed, B = W10 as it sits in the accumulators
+    f64x4 X10 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 + 4 * ks + hi) * LDX + 16 + lo], W10[ks], X10, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[lo * LDX + 16 + hi + 4 * r] = X10[r];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return bad;
+}
+
 // the factored pivot block goes to its `dinv` slot (k-major, identity-padded, 1 / L(k, k) on the diagonal); k_invert_blocks
 // turns it into L11^-1 at the end
 __device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int w, const double* rdiag, double* slot, int tid, int nthreads)
@@ -778,17 +923,19 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
 }
 
 // ---- big fronts: level-batched 32-column steps, one launch per step ------------------------------------
-// desc = (front, kb of the panel being applied or -1, a, b); 256 threads: three row waves + one pivot wave
+// desc = (first dinv block of the front, kb of the panel being applied or -1, a, b) + (N, nc, front offset); 256 threads: three row waves + one pivot wave
 //   b >= 0 : role A, trailing tile (ti, tj) = (a, b) of the matrix behind panel kb and panel kb+32
 //   b == -2: role B, rows [kb1 + a, kb1 + a + 192) of the next panel (kb1 = kb + 32, or 0 when kb == -1)
 __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
     double* __restrict__ dinv, int* __restrict__ flag)
 {
     __shared__ double sm[2 * NB * TS];
-    const int4 d = desc[blockIdx.x];
-    const int s = d.x;
-    const int N = frontN(tv, s), nc = frontNc(tv, s);
-    double* F = fronts + tv.frontOff[s];
+    // two records per workgroup, both addressed by blockIdx alone: (first dinv block, kb, a, b) and (N, nc, front offset) -- the front's
+    // dimensions used to be two more dependent loads (tree arrays indexed by the front) at the head of every step
+    const int4 d = desc[2 * blockIdx.x];
+    const int4 d2 = desc[2 * blockIdx.x + 1];
+    const int N = d2.x, nc = d2.y;
+    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
     const int tid = threadIdx.x;
     const int kb = d.y;
     const int w = (kb >= 0) ? min(NB, nc - kb) : 0;
@@ -800,11 +947,32 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         double(*Bs)[TS] = reinterpret_cast<double(*)[TS]>(sm + NB * TS);
         const int M0 = kb1 + w1;
         const int i0 = M0 + TS * d.z, j0 = M0 + TS * d.w;
-        for (int e = tid; e < NB * TS; e += WGB) {
+        // All 16 panel loads and the 16 old values of this thread's 4 x 4 sub-tile are issued before anything waits on them.
+        // Written as loops of conditional loads / read-modify-writes, the compiler emitted load -> wait -> store chains: 32
+        // dependent memory round trips per workgroup, which made the trailing tiles as long as the pivot chain of role B.
+        constexpr int NLD = NB * TS / WGB;
+        double va[NLD], vb[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + WGB * it;
+            const int k = e / TS, i = e - k * TS;
+            const long long colOff = (long long)N * (kb + min(k, w - 1)); // role A only exists behind a panel: w >= 1
+            va[it] = F[min(i0 + i, N - 1) + colOff];
+            vb[it] = F[min(j0 + i, N - 1) + colOff];
+        }
+        double old[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                old[ii][jj] = F[min(i0 + 4 * (tid & 15) + ii, N - 1) + (long long)N * min(j0 + 4 * (tid >> 4) + jj, N - 1)];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + WGB * it;
             const int k = e / TS, i = e - k * TS;
             const bool kin = k < w;
-            As[k][i] = (kin && i0 + i < N) ? F[(i0 + i) + (long long)N * (kb + k)] : 0.0;
-            Bs[k][i] = (kin && j0 + i < N) ? F[(j0 + i) + (long long)N * (kb + k)] : 0.0;
+            As[k][i] = (kin && i0 + i < N) ? va[it] : 0.0;
+            Bs[k][i] = (kin && j0 + i < N) ? vb[it] : 0.0;
         }
         __syncthreads();
         const int ty = tid & 15, tx = tid >> 4;
@@ -833,7 +1001,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 #pragma unroll
             for (int ii = 0; ii < 4; ++ii) {
                 const int row = i0 + 4 * ty + ii;
-                if (row < N && row >= col) F[row + (long long)N * col] -= acc[ii][jj];
+                if (row < N && row >= col) F[row + (long long)N * col] = old[ii][jj] - acc[ii][jj];
             }
         }
         return;
@@ -857,10 +1025,25 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     double* Lp = sm; // Lp[k * LDP + q]  = F(kb1 + q, kb + k): panel-kb rows of the pivot block
     double* A11 = sm + NB * LDP; // A11[c * LDP + q] = pivot block, k-major
     double* rdiag = sm + 2 * NB * LDP;
-    for (int e = tid; e < NB * NB; e += WGB) {
-        const int k = e >> 5, q = e & 31;
-        Lp[k * LDP + q] = (k < w && q < w1) ? F[(kb1 + q) + (long long)N * (kb + k)] : 0.0;
-        A11[k * LDP + q] = (k < w1 && q < w1 && q >= k) ? F[(kb1 + q) + (long long)N * (kb1 + k)] : 0.0;
+    {
+        // eight unconditional (clamped) loads in flight at once, selected afterwards: see role A
+        constexpr int NLB = NB * NB / WGB;
+        double vl[NLB], vd[NLB];
+#pragma unroll
+        for (int it = 0; it < NLB; ++it) {
+            const int e = tid + WGB * it;
+            const int k = e >> 5, q = e & 31;
+            const double* Fq = F + min(kb1 + q, N - 1);
+            vl[it] = Fq[(long long)N * (max(kb, 0) + min(k, max(w, 1) - 1))];
+            vd[it] = Fq[(long long)N * (kb1 + min(k, w1 - 1))]; // role B only exists for a non-empty panel: w1 >= 1
+        }
+#pragma unroll
+        for (int it = 0; it < NLB; ++it) {
+            const int e = tid + WGB * it;
+            const int k = e >> 5, q = e & 31;
+            Lp[k * LDP + q] = (k < w && q < w1) ? vl[it] : 0.0;
+            A11[k * LDP + q] = (k < w1 && q < w1 && q >= k) ? vd[it] : 0.0;
+        }
     }
     __syncthreads();
     MF_STEP_PHASE(10);
@@ -886,15 +1069,15 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     MF_STEP_PHASE(11);
     double* Xs = sm + 2 * NB * LDP + NB; // Xs[c * LDX + r] = X(r, c), X = L11^-1 (written by the pivot wave)
     const int wv = tid >> 6, l = tid & 63, lo = l & 15, hi = l >> 4;
-    const int Rw = kb1 + d.z + 64 * wv; // first row of this wave
-    const bool rowWave = tid < ROWS_B && Rw < N;
+    const int Rw = kb1 + d.z + 16 * MT_B * wv; // first row of this wave
+    const bool rowWave = tid < 64 * ROW_WAVES_B && Rw < N;
     // Everything the rows need is a product: X_rows = (raw - P_kb Lp^T) L11^-T.  It is formed transposed, tile by tile of 16 rows:
     //   D1^T(k, m) = raw(m, k) - sum_j Lp(k, j) P(m, j)      A = -Lp (LDS), B = rows of panel kb straight from the front
     //   X^T(n, m)  = sum_k Linv(n, k) D1^T(k, m)              A = Linv (LDS), B = D1^T as it sits in the accumulators
     // (accumulator register i holds row (l >> 4) + 4 i, which is the B-operand row of k-step i), and the result lands as 16
     // consecutive rows m per column n: 128-byte stores.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15],
     // D row = (l >> 4) + 4 reg, col = l & 15.
-    f64x4 d1t[4][2];
+    f64x4 d1t[MT_B][2];
     if (tid >= PIVOT_T0) {
         // pivot wave (alone on its SIMD): Cholesky of the 32 x 32 block and its inverse while the row waves fetch and update
         // (the pivot chain is what every other wave of the step ends up waiting for: it gets issue priority on its SIMD)
@@ -903,19 +1086,25 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         if (wave_potrf32(A11, LDP, w1, tid - PIVOT_T0, rdiag)) atomicOr(flag, 1);
         MF_STEP_PHASE(12);
         wave_trinv32_fast<false>(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
-#else
+#elif defined(MF_POTRF_BLOCKED8)
         for (int e = tid - PIVOT_T0; e < NB * LDX; e += 64) Xs[e] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (wave_potrf32_blocked(A11, w1, tid - PIVOT_T0, rdiag, Xs)) atomicOr(flag, 1);
         MF_STEP_PHASE(12);
         wave_trinv32_fast<true>(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
+#else
+        if (wave_potrf_inv32_mfma(A11, w1, tid - PIVOT_T0, Xs)) atomicOr(flag, 1);
+        MF_STEP_PHASE(12);
 #endif
         __builtin_amdgcn_s_setprio(0);
     }
     else if (rowWave) {
+        // every load of the wave (raw rows of the panel and its rows of panel kb, all 16-row tiles) is issued first: tile by
+        // tile the compiler waited out two memory round trips per tile, and the row waves ended up as late as the pivot wave
+        double pv[MT_B][NB / 4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT_B; ++mt) {
             const double* Fr = F + min(Rw + 16 * mt + lo, N - 1);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
@@ -925,23 +1114,25 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
                     const double v = Fr[(long long)N * (kb1 + min(k, max(w1, 1) - 1))];
                     d1t[mt][kt][i] = (k < w1) ? v : 0.0;
                 }
-            if (w > 0) { // wave-uniform; a panel that has a successor is always full (w == NB)
-                double pv[NB / 4];
 #pragma unroll
-                for (int ks = 0; ks < NB / 4; ++ks) pv[ks] = Fr[(long long)N * (kb + 4 * ks + hi)];
+            for (int ks = 0; ks < NB / 4; ++ks) pv[mt][ks] = Fr[(long long)N * min(max(kb, 0) + 4 * ks + hi, N - 1)]; // unused when w == 0
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (w > 0) { // wave-uniform; a panel that has a successor is always full (w == NB)
+#pragma unroll
+            for (int mt = 0; mt < MT_B; ++mt)
 #pragma unroll
                 for (int ks = 0; ks < NB / 4; ++ks) {
-                    d1t[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LDP + lo], pv[ks], d1t[mt][0], 0, 0, 0);
-                    d1t[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LDP + 16 + lo], pv[ks], d1t[mt][1], 0, 0, 0);
+                    d1t[mt][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LDP + lo], pv[mt][ks], d1t[mt][0], 0, 0, 0);
+                    d1t[mt][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LDP + 16 + lo], pv[mt][ks], d1t[mt][1], 0, 0, 0);
                 }
-            }
         }
     }
     __syncthreads();
     MF_STEP_PHASE(13);
-    if (tid < ROWS_B && rowWave) {
+    if (rowWave) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT_B; ++mt) {
             f64x4 x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -968,7 +1159,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     }
     if (d.z == 0) {
         // the inverse of the pivot block goes straight to its dinv slot (column-major, identity-padded): the solves multiply by it
-        double* slot = dinv + (tv.dinvOff[s] + kb1 / NB) * (NB * NB);
+        double* slot = dinv + ((long long)d.x + kb1 / NB) * (NB * NB);
         for (int e = tid; e < NB * NB; e += WGB) slot[e] = Xs[(e >> 5) * LDX + (e & 31)];
     }
 #ifdef MF_PHASE_TIMERS
@@ -993,14 +1184,23 @@ constexpr int TQ = 32; // Schur tile
 __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
 {
     __shared__ double red[4][4][256]; // [wave][16 x 16 tile][D layout: 64 lanes x 4]
-    const int4 d = desc[blockIdx.x];
-    const int s = d.x;
-    const int N = frontN(tv, s), nc = frontNc(tv, s);
-    double* F = fronts + tv.frontOff[s];
+    // two records per workgroup (see k_big_step): (front, ti, tj, 0) and (N, nc, front offset)
+    const int4 d = desc[2 * blockIdx.x];
+    const int4 d2 = desc[2 * blockIdx.x + 1];
+    const int N = d2.x, nc = d2.y;
+    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
     const int tid = threadIdx.x;
     const int i0 = nc + TQ * d.y, j0 = nc + TQ * d.z;
     const int wv = tid >> 6, l = tid & 63;
     const int ar = l & 15, ak = l >> 4;
+    // the entries this wave will update at the end (16 x 16 tile wv of the 32 x 32 tile) are requested now: as a
+    // read-modify-write at the end they were four dependent memory round trips behind the reduction
+    double old[4];
+    {
+        const int row = min(i0 + 16 * (wv & 1) + ar, N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) old[r] = F[row + (long long)N * min(j0 + 16 * (wv >> 1) + ak + 4 * r, N - 1)];
+    }
     f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1011,27 +1211,46 @@ __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc,
     const double* pa1 = F + min(i0 + 16 + ar, N - 1);
     const double* pb0 = F + min(j0 + ar, N - 1);
     const double* pb1 = F + min(j0 + 16 + ar, N - 1);
-    const int nch = (nc + NB - 1) / NB;
-    for (int ch = wv; ch < nch; ch += 4) {
-        const int kc = NB * ch;
-        double a0[NB / 4], a1[NB / 4], b0[NB / 4], b1[NB / 4];
+    // The nc columns go to the four waves in chunks of CW.  The loads of a wave's next chunk are issued before the products
+    // of the current one and only touched after them (the compiler neither pipelines the loop nor keeps that order by itself:
+    // hence the scheduling fences).  Loads are unconditional with a clamped column; past nc only the A operands need zeroing.
+    constexpr int CW = 16, CS = CW / 4;
+    const int nch = (nc + CW - 1) / CW;
+    double a0[CS], a1[CS], b0[CS], b1[CS], na0[CS], na1[CS], nb0[CS], nb1[CS];
+    auto fetch = [&](int ch, double* x0, double* x1, double* y0, double* y1) {
 #pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            const int k = kc + 4 * ks + ak;
-            const bool in = k < nc;
-            const long long off = (long long)N * min(k, nc - 1);
-            a0[ks] = in ? pa0[off] : 0.0;
-            a1[ks] = in ? pa1[off] : 0.0;
-            b0[ks] = in ? pb0[off] : 0.0;
-            b1[ks] = in ? pb1[off] : 0.0;
+        for (int ks = 0; ks < CS; ++ks) {
+            const long long off = (long long)N * min(CW * ch + 4 * ks + ak, nc - 1);
+            x0[ks] = pa0[off];
+            x1[ks] = pa1[off];
+            y0[ks] = pb0[off];
+            y1[ks] = pb1[off];
         }
+    };
+    auto mult = [&](int ch, const double* x0, const double* x1, const double* y0, const double* y1) {
 #pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[ks], a0[ks], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0[ks], a1[ks], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[ks], a0[ks], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1[ks], a1[ks], acc[1][1], 0, 0, 0);
+        for (int ks = 0; ks < CS; ++ks) {
+            const bool in = CW * ch + 4 * ks + ak < nc;
+            const double m0 = in ? y0[ks] : 0.0, m1 = in ? y1[ks] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x0[ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x1[ks], acc[1][1], 0, 0, 0);
         }
+    };
+    // two register sets, ping-pong (a copy from a "next" set would wait for its loads at the end of every iteration)
+    // the fetches are unconditional (past the end they re-read the clamped last column): behind a branch, the compiler's wait
+    // counters have to assume the loads were not issued and the products end up waiting for the newest load
+    fetch(wv, a0, a1, b0, b1);
+    for (int ch = wv; ch < nch; ch += 8) {
+        fetch(ch + 4, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(ch, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(ch + 8, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 4 < nch) mult(ch + 4, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int nj = 0; nj < 2; ++nj)
@@ -1047,7 +1266,7 @@ __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc,
     for (int r = 0; r < 4; ++r) {
         const int col = j0 + 16 * nj + ak + 4 * r;
         const double v = ((red[0][wv][64 * r + l] + red[1][wv][64 * r + l]) + red[2][wv][64 * r + l]) + red[3][wv][64 * r + l];
-        if (col < N && row < N && row >= col) F[row + (long long)N * col] -= v;
+        if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[r] - v;
     }
 }
 
@@ -1069,16 +1288,33 @@ __global__ void k_unpermute_x(int nn, const int* __restrict__ newOf, const doubl
     }
 }
 
-// w[I] of a front: own right-hand side rows plus what the children pushed up
+// w[I] of a front: own right-hand side rows plus what the children pushed up.  Four children at a time, level by level of
+// the index chain (child -> its map and offsets -> map entry -> value): as a plain loop over the children every child paid
+// its own four dependent memory round trips.  The sum runs over the children in order, as before.
 __device__ __forceinline__ double gather_w(const TreeView& tv, const long long* __restrict__ wOff, const double* __restrict__ wbuf,
     const double* __restrict__ bperm, int s, int nc, int I)
 {
+    const int cb = tv.childPtr[s], ce = tv.childPtr[s + 1];
     double val = (I < nc) ? bperm[3 * tv.firstNode[s] + I] : 0.0;
     const int In = I / 3, Id = I - 3 * In;
-    for (int ci = tv.childPtr[s]; ci < tv.childPtr[s + 1]; ++ci) {
-        const int c = tv.child[ci];
-        const int ic = tv.inv[tv.invPtr[c] + In];
-        if (ic >= 0) val += wbuf[wOff[c] + frontNc(tv, c) + 3 * ic + Id];
+    for (int c0 = cb; c0 < ce; c0 += 4) {
+        int ip[4];
+        long long base[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int c = tv.child[min(c0 + q, ce - 1)];
+            ip[q] = tv.invPtr[c];
+            base[q] = wOff[c] + frontNc(tv, c) + Id;
+        }
+        int ic[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ic[q] = tv.inv[ip[q] + In];
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = wbuf[base[q] + 3 * max(ic[q], 0)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (c0 + q < ce && ic[q] >= 0) val += v[q];
     }
     return val;
 }
@@ -1237,18 +1473,36 @@ __global__ __launch_bounds__(WG) void k_big_fwd_rect(const int4* __restrict__ de
     const double* y = yperm + 3 * tv.firstNode[s];
     const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
     const int r = nc + d.y + lane;
-    double acc = 0.0;
-    if (r < N) {
+    // what the children pushed up for this row: requested first, its index chain resolves while the products run
+    const double up = (cg == 0 && r < N) ? gather_w(tv, wOff, wbuf, yperm, s, nc, r) : 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    {
+        // 16 loads of the row in flight at a time (rows past the end are clamped and dropped): four per round trip was
+        // nc / 16 dependent round trips per thread
+        const double* Lr = L + min(r, N - 1);
         const int per = (nc + 3) >> 2;
         const int c0 = cg * per, c1 = min(nc, c0 + per);
+        int c = c0;
+        for (; c + 16 <= c1; c += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = Lr[(long long)N * (c + u)];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                a0 += v[u] * y[c + u];
+                a1 += v[u + 1] * y[c + u + 1];
+                a2 += v[u + 2] * y[c + u + 2];
+                a3 += v[u + 3] * y[c + u + 3];
+            }
+        }
 #pragma unroll 4
-        for (int c = c0; c < c1; ++c) acc += L[r + (long long)N * c] * y[c];
+        for (; c < c1; ++c) a0 += Lr[(long long)N * c] * y[c];
     }
-    part[threadIdx.x] = acc;
+    part[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (cg == 0 && r < N) {
         const double tot = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
-        wbuf[wOff[s] + r] = gather_w(tv, wOff, wbuf, yperm, s, nc, r) - tot;
+        wbuf[wOff[s] + r] = up - tot;
     }
 }
 
@@ -1268,14 +1522,33 @@ __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, 
         x[I] = (I < nc) ? yperm[col0 + I] : xsol[3 * idx[In] + (I - 3 * In)];
     }
     __syncthreads();
-    // t = y1 - L21^T x2: one wave per column, lanes stride the rows
-    for (int c = wave; c < nc; c += WG / 64) {
-        double acc = 0.0;
-        const double* Lc = L + (long long)N * c;
-        for (int i = nc + lane; i < N; i += 64) acc += Lc[i] * x[i];
+    // t = y1 - L21^T x2: a wave takes four columns at a time, lanes stride the rows (two 64-row strips per round: eight loads
+    // in flight; one column and one strip at a time this loop was nc / 4 x (N - nc) / 64 dependent round trips per wave)
+    {
+        const int m = N - nc;
+        for (int c0 = wave; c0 < nc; c0 += 16) {
+            double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int i0 = 0; i0 < m; i0 += 128) {
+                const int ia = i0 + lane, ib = i0 + 64 + lane;
+                const double xa = (ia < m) ? x[nc + min(ia, m - 1)] : 0.0, xb = (ib < m) ? x[nc + min(ib, m - 1)] : 0.0;
+                double va[4], vb[4];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) x[c] -= acc;
+                for (int q = 0; q < 4; ++q) {
+                    const double* Lc = L + (long long)N * min(c0 + 4 * q, nc - 1) + nc;
+                    va[q] = Lc[min(ia, m - 1)];
+                    vb[q] = Lc[min(ib, m - 1)];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += va[q] * xa + vb[q] * xb;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                double t = acc[q];
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+                if (lane == 0 && c0 + 4 * q < nc) x[c0 + 4 * q] -= t;
+            }
+        }
     }
     __syncthreads();
     bwd_triangle<WG>(L, N, nc, dinv + tv.dinvOff[s] * (NB * NB), x, invs, tid);
@@ -1295,26 +1568,52 @@ __global__ __launch_bounds__(WG) void k_big_bwd_init(const int4* __restrict__ de
     const int* idx = tv.idx + tv.idxPtr[s];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col0 = 3 * tv.firstNode[s];
-    for (int r = nc + threadIdx.x; r < N; r += WG) {
-        const int rn = r / 3;
-        x2[r - nc] = xsol[3 * idx[rn] + (r - 3 * rn)];
+    // the four columns of a wave go together, two 64-row strips each per round: eight loads in flight instead of two, and the
+    // old value of y is requested up front rather than behind the reduction
+    const int m = N - nc;
+    int cq[4];
+    double yold[4], acc[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        cq[q] = d.y + wave + 4 * q;
+        yold[q] = yperm[col0 + min(cq[q], nc - 1)];
+    }
+    for (int r0 = nc; r0 < N; r0 += 4 * WG) { // x of the ancestors: four index loads, then four value loads, per round
+        int rq[4], id[4];
+        double xv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            rq[q] = min(r0 + q * WG + (int)threadIdx.x, N - 1);
+            id[q] = idx[rq[q] / 3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) xv[q] = xsol[3 * id[q] + rq[q] % 3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (r0 + q * WG + (int)threadIdx.x < N) x2[rq[q] - nc] = xv[q];
     }
     __syncthreads();
-    for (int c = d.y + wave; c < min(nc, d.y + 16); c += WG / 64) {
-        double acc0 = 0.0, acc1 = 0.0;
-        const double* Lc = L + (long long)N * c + nc;
-        const int m = N - nc;
-        int r = lane;
-        for (; r + 64 < m; r += 128) {
-            acc0 += Lc[r] * x2[r];
-            acc1 += Lc[r + 64] * x2[r + 64];
-        }
-        if (r < m) acc0 += Lc[r] * x2[r];
-        double acc = acc0 + acc1;
+    for (int r0 = 0; r0 < m; r0 += 128) {
+        const int ra = r0 + lane, rb = r0 + 64 + lane;
+        const double xa = (ra < m) ? x2[min(ra, m - 1)] : 0.0, xb = (rb < m) ? x2[min(rb, m - 1)] : 0.0;
+        double va[4], vb[4];
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) yperm[col0 + c] -= acc;
+        for (int q = 0; q < 4; ++q) {
+            const double* Lc = L + (long long)N * min(cq[q], nc - 1) + nc;
+            va[q] = Lc[min(ra, m - 1)];
+            vb[q] = Lc[min(rb, m - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += va[q] * xa + vb[q] * xb;
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double t = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0 && cq[q] < min(nc, d.y + 16)) yperm[col0 + cq[q]] = yold[q] - t;
+    }
+
 }
 // ... then one workgroup sweeps the transposed triangle
 __global__ __launch_bounds__(WGT) void k_big_bwd_tri(const int* __restrict__ list, TreeView tv, const double* __restrict__ fronts,
@@ -1519,12 +1818,22 @@ __global__ __launch_bounds__(WG) void k_xinv_fwd(const int4* __restrict__ desc, 
         const int per = ((cols + 3) >> 2), cb = cg * per, ce = min(min(cols, cb + per), r + 1);
         const double* Xr = X + r;
         int c = cb;
-        for (; c + 7 < ce; c += 8) { // eight loads in flight per lane
-            double x[8];
+        for (; c + 15 < ce; c += 16) { // sixteen loads in flight per lane
+            double x[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) x[u] = Xr[(long long)nc * (c + u)];
+            for (int u = 0; u < 16; ++u) x[u] = Xr[(long long)nc * (c + u)];
 #pragma unroll
-            for (int u = 0; u < 8; u += 2) {
+            for (int u = 0; u < 16; u += 2) {
+                acc0 += x[u] * w1[c + u];
+                acc1 += x[u + 1] * w1[c + u + 1];
+            }
+        }
+        for (; c + 3 < ce; c += 4) {
+            double x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = Xr[(long long)nc * (c + u)];
+#pragma unroll
+            for (int u = 0; u < 4; u += 2) {
                 acc0 += x[u] * w1[c + u];
                 acc1 += x[u + 1] * w1[c + u + 1];
             }
@@ -1550,19 +1859,31 @@ __global__ __launch_bounds__(WG) void k_xinv_bwd(const int4* __restrict__ desc, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = c0 + threadIdx.x; r < nc; r += WG) tt[r - c0] = yperm[col0 + r];
     __syncthreads();
-    for (int c = c0 + wave; c < min(nc, c0 + 16); c += WG / 64) {
-        const double* Xc = X + (long long)nc * c;
-        double acc0 = 0.0, acc1 = 0.0;
-        int r = c + lane;
-        for (; r + 64 < nc; r += 128) {
-            acc0 += Xc[r] * tt[r - c0];
-            acc1 += Xc[r + 64] * tt[r + 64 - c0];
-        }
-        if (r < nc) acc0 += Xc[r] * tt[r - c0];
-        double acc = acc0 + acc1;
+    // the four columns of a wave together, two 64-row strips per round (rows above a column's diagonal are zeros of X and are
+    // masked): eight loads in flight instead of two
+    int cq[4];
+    double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-        if (lane == 0) xsol[col0 + c] = acc;
+    for (int q = 0; q < 4; ++q) cq[q] = c0 + wave + 4 * q;
+    for (int r0 = c0 + wave; r0 < nc; r0 += 128) {
+        const int ra = r0 + lane, rb = r0 + 64 + lane;
+        const double ta = (ra < nc) ? tt[min(ra, nc - 1) - c0] : 0.0, tb = (rb < nc) ? tt[min(rb, nc - 1) - c0] : 0.0;
+        double va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const double* Xc = X + (long long)nc * min(cq[q], nc - 1);
+            va[q] = Xc[min(ra, nc - 1)];
+            vb[q] = Xc[min(rb, nc - 1)];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += ((ra >= cq[q]) ? va[q] * ta : 0.0) + ((rb >= cq[q]) ? vb[q] * tb : 0.0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double t = acc[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+        if (lane == 0 && cq[q] < min(nc, c0 + 16)) xsol[col0 + cq[q]] = t;
     }
 }
 
@@ -1608,6 +1929,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<long long> di(ns_ + 1, 0);
         for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
         dinvOff_.upload(di, stream);
+        hDinvOff_ = di;
         nDiagBlocks_ = di[ns_];
         dinv_.alloc((size_t)di[ns_] * NB * NB);
     }
@@ -1900,25 +2222,38 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 const int w = (j >= 0) ? std::min(NB, nc - kb) : 0;
                 const int kb1 = (j >= 0) ? kb + w : 0;
                 const int w1 = (kb1 < nc) ? std::min(NB, nc - kb1) : 0;
+                const long long foff = sym.frontOff[s];
+                const int4 rec2 = make_int4(N, nc, (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
                 if (w1 > 0)
-                    for (int r0 = 0; r0 < N - kb1; r0 += ROWS_B) desc.push_back(make_int4(s, j >= 0 ? kb : -1, r0, -2));
+                    for (int r0 = 0; r0 < N - kb1; r0 += ROWS_B) {
+                        desc.push_back(make_int4((int)hDinvOff_[s], j >= 0 ? kb : -1, r0, -2));
+                        desc.push_back(rec2);
+                    }
                 if (j >= 0) {
                     // trailing tiles inside the front's own columns; the Schur complement (columns >= nc) waits for k_big_schur
                     const int M0 = kb1 + w1;
                     const int ntr = (N - M0 + TS - 1) / TS, ntc = (nc - M0 + TS - 1) / TS;
                     for (int ti = 0; ti < ntr; ++ti)
-                        for (int tj = 0; tj <= ti && tj < ntc; ++tj) desc.push_back(make_int4(s, kb, ti, tj));
+                        for (int tj = 0; tj <= ti && tj < ntc; ++tj) {
+                            desc.push_back(make_int4((int)hDinvOff_[s], kb, ti, tj));
+                            desc.push_back(rec2);
+                        }
                 }
             }
-            R.cnt = (int)desc.size() - R.off;
+            R.cnt = ((int)desc.size() - R.off) / 2; // workgroups: two records each
         }
         P.schur.off = (int)desc.size();
         for (int s : big) {
             const int nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
+            const long long foff = sym.frontOff[s];
+            const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
             for (int ti = 0; ti < nt; ++ti)
-                for (int tj = 0; tj <= ti; ++tj) desc.push_back(make_int4(s, ti, tj, 0));
+                for (int tj = 0; tj <= ti; ++tj) {
+                    desc.push_back(make_int4(s, ti, tj, 0));
+                    desc.push_back(rec2);
+                }
         }
-        P.schur.cnt = (int)desc.size() - P.schur.off;
+        P.schur.cnt = ((int)desc.size() - P.schur.off) / 2; // workgroups: two records each
         P.fwdRect.off = (int)desc.size();
         for (int s : big)
             for (int r0 = 0; r0 < sym.N(s) - sym.nc(s); r0 += 64) desc.push_back(make_int4(s, r0, 0, 0));
