@@ -537,7 +537,7 @@ __device__ __forceinline__ double rcp_nr(double d)
 
 // X = L11^-1 of a (<=) 32 x 32 SPD pivot block A11 = L11 L11^T by one wave, in the accumulator registers of the matrix
 // cores: symmetric Gauss-Jordan, one rank-1 update per pivot as ONE v_mfma_f64_16x16x4_f64 per 16 x 16 tile.
-//   blk[k * LDP + r] = A(r, k), r >= k (LDS, k-major; entries with an index >= w are zero on entry and count as identity)
+//   blk[k * ld + r] = A(r, k), r >= k (LDS, k-major; rows / columns >= w count as identity and are not read)
 //   Xs[c * LDX + r] = X(r, c), all 32 x 32 entries written (zeros above the diagonal); returns true on a pivot <= 0
 // The block lives as tiles T00, T01, T11 (upper triangle: the row of a pivot is its column) in the D layout
 // (row = (l >> 4) + 4 reg, col = l & 15).  Row k of a tile sits in register k >> 2 of the 16 lanes with l >> 4 == (k & 3),
@@ -557,21 +557,25 @@ __device__ __forceinline__ double rcp_nr(double d)
 //       T11 -= U01^T D0^-1 U01,   W10 = -(D0^-1 U01)^T W00;
 //   pivots 16..31 update T11 and W11 (two MFMAs each); finally X10 = X11 W10 (X11 transposed through LDS, where it goes anyway).
 // 92 MFMAs, against 16.5 k + 3.1 k cycles for the lane-per-row Cholesky + recursive-doubling inverse this replaces.
-__device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int w, int lane, double* Xs)
+__device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld, int w, int lane, double* Xs)
 {
     const int lo = lane & 15, hi = lane >> 4;
     f64x4 T00, T01, T11, W00, W11, s0, s1, n0;
     f64x4 W10 = { 0.0, 0.0, 0.0, 0.0 };
+    const int wm = w - 1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const int q = hi + 4 * r; // tile row; the LDS block holds the lower triangle: A(row, col) = blk[min * LDP + max]
-        const double a00 = blk[min(q, lo) * LDP + max(q, lo)];
-        const double a01 = blk[q * LDP + 16 + lo];
-        const double a11 = blk[(16 + min(q, lo)) * LDP + 16 + max(q, lo)];
+        // tile row q; the block holds the lower triangle: A(row, col) = blk[min * ld + max].  Nothing with an index >= w is
+        // touched (clamped address, identity selected): the caller's block may end there.
+        const int q = hi + 4 * r;
+        const int mn = min(q, lo), mx = max(q, lo);
+        const double a00 = blk[min(mn, wm) * ld + min(mx, wm)];
+        const double a01 = blk[min(q, wm) * ld + min(16 + lo, wm)];
+        const double a11 = blk[min(16 + mn, wm) * ld + min(16 + mx, wm)];
         const bool dg = q == lo;
-        T00[r] = (dg && q >= w) ? 1.0 : a00;
-        T01[r] = a01;
-        T11[r] = (dg && 16 + q >= w) ? 1.0 : a11;
+        T00[r] = (mx < w) ? a00 : (dg ? 1.0 : 0.0);
+        T01[r] = (16 + lo < w) ? a01 : 0.0; // q < 16 + lo: inside iff the column is
+        T11[r] = (16 + mx < w) ? a11 : (dg ? 1.0 : 0.0);
         W00[r] = dg ? 1.0 : 0.0;
         W11[r] = dg ? 1.0 : 0.0;
         s0[r] = 1.0;
@@ -608,6 +612,7 @@ __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int w, 
     }
     W00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W00, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    if (w > 16) { // wave-uniform: a block of at most 16 columns is finished (rows 16..31 are identity)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
         const double a = T01[ks] * n0[ks]; // -(D0^-1 U01)(row (l >> 4) + 4 ks, col l & 15): A operand [i = col][kk = row]
@@ -642,6 +647,7 @@ __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int w, 
     }
     W11 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W11, 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int q = hi + 4 * r;
@@ -655,9 +661,11 @@ __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int w, 
     __builtin_amdgcn_wave_barrier();
     // X10 = X11 W10: A[i = l & 15][kk] = X(16 + i, 16 + kk) read back transposed, B = W10 as it sits in the accumulators
     f64x4 X10 = { 0.0, 0.0, 0.0, 0.0 };
+    if (w > 16) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-        X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 + 4 * ks + hi) * LDX + 16 + lo], W10[ks], X10, 0, 0, 0);
+        for (int ks = 0; ks < 4; ++ks)
+            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 + 4 * ks + hi) * LDX + 16 + lo], W10[ks], X10, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) Xs[lo * LDX + 16 + hi + 4 * r] = X10[r];
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -729,6 +737,7 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
 {
     extern __shared__ double P[];
     __shared__ double rdiag[NB];
+    __shared__ double Xs[NB * LDX]; // inverse of the current pivot block
     __shared__ __attribute__((aligned(16))) int fd[FD_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 #ifdef MF_PHASE_TIMERS
@@ -757,33 +766,61 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
     MF_PHASE(1);
     // ---- own columns: children sums (lower triangle), zeros above the diagonal.  The loads are unconditional (clamped
     // address, value selected afterwards) so that all of them are in flight together.
-    for (int J = wv; J < nc; J += NT / 64) {
+    // Two columns per wave and round, the children two at a time: 16 loads in flight (one column and one child per round was a
+    // dependent memory round trip per child, column and strip -- the longest phase of a small front).
+    for (int J0 = 2 * wv; J0 < nc; J0 += 2 * (NT / 64)) {
+        const int Ja = J0, Jb = min(J0 + 1, nc - 1);
         for (int I0 = 0; I0 < N; I0 += 4 * 64) {
-            double v[4] = { 0.0, 0.0, 0.0, 0.0 };
+            double va[4] = { 0.0, 0.0, 0.0, 0.0 }, vb[4] = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll 2
             for (int q = 0; q < nk; ++q) {
                 const double* Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * q);
                 const long long Nc = fd[16 + 6 * q + 2];
-                const int cc = cm[q * N + J];
+                const int cca = cm[q * N + Ja], ccb = cm[q * N + Jb];
+                double xa[4], xb[4];
+                bool oka[4], okb[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int I = I0 + 64 * u + lane;
                     const int r = (I < N) ? cm[q * N + I] : -1;
-                    const bool ok = r >= 0 && cc >= 0 && I >= J;
-                    const double x = Fc[ok ? r + Nc * cc : 0];
-                    v[u] += ok ? x : 0.0;
+                    oka[u] = r >= 0 && cca >= 0 && I >= Ja;
+                    okb[u] = r >= 0 && ccb >= 0 && I >= Jb;
+                    xa[u] = Fc[oka[u] ? r + Nc * cca : 0];
+                    xb[u] = Fc[okb[u] ? r + Nc * ccb : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    va[u] += oka[u] ? xa[u] : 0.0;
+                    vb[u] += okb[u] ? xb[u] : 0.0;
                 }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int I = I0 + 64 * u + lane;
-                if (I < N) P[J * N + I] = v[u];
+                if (I < N) {
+                    P[Ja * N + I] = va[u];
+                    if (J0 + 1 < nc) P[Jb * N + I] = vb[u];
+                }
             }
         }
     }
     __syncthreads();
     MF_PHASE(2);
     // ---- entries of A (every destination is distinct)
-    for (int e = aBeg + tid; e < aEnd; e += NT) P[aLoc[e]] += aP[e]; // aP: the values of A gathered into front order (k_gather_a)
+    // aP: the values of A gathered into front order (k_gather_a); four (location, value) pairs requested per round
+    for (int e0 = aBeg; e0 < aEnd; e0 += 4 * NT) {
+        int loc[4];
+        double av[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = min(e0 + u * NT + tid, aEnd - 1);
+            loc[u] = aLoc[e];
+            av[u] = aP[e];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u * NT + tid < aEnd) P[loc[u]] += av[u];
+    }
     __syncthreads();
     MF_PHASE(3);
 
@@ -791,6 +828,7 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
     for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
         const int w = min(NB, nc - kb);
         double* Pk = P + (size_t)kb * N + kb; // Pk[k * N + q] = F(kb + q, kb + k)
+#ifdef MF_FUSED_SCALAR_PIVOT
         if (tid < 64) {
             __builtin_amdgcn_s_setprio(3);
             bad |= wave_potrf32(Pk, N, w, tid, rdiag);
@@ -809,6 +847,52 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
             for (int k = 0; k < NB; ++k)
                 if (k < w) P[(kb + k) * N + r] = x[k];
         }
+#else
+        // pivot block: X = L11^-1 straight from the Gauss-Jordan sweep in the matrix-core accumulators (see
+        // wave_potrf_inv32_mfma); L11 itself is needed nowhere -- the rows below are a product with X, the solves multiply by X
+        if (tid < 64) {
+            __builtin_amdgcn_s_setprio(3);
+            bad |= wave_potrf_inv32_mfma(Pk, N, w, tid, Xs);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();
+        MF_PHASE(4);
+        for (int e = tid; e < NB * NB; e += NT) dblk[e] = Xs[(e >> 5) * LDX + (e & 31)]; // column-major, identity-padded
+        // rows below the pivot block: L21 = A21 L11^-T, formed transposed per 16-row tile on the matrix cores, in place in LDS:
+        //   D(n, m) = sum_k X(n, k) A21(m, k)     A[i = l & 15][kk = l >> 4] = X(n, k) (LDS), B[kk][j] = P[(kb + k) N + row m]
+        // (a lane's B entries are 16 consecutive rows of one column of P: conflict-free; X is lower triangular, so the first 16
+        // result rows need k < 16 only).  One row per thread by substitution (row_trsm32_lean) was 8 us per panel.
+        {
+            const int lo = lane & 15, hi = lane >> 4;
+            const int R0 = kb + w, ntile = (N - R0 + 15) >> 4;
+            for (int t = wv; t < ntile; t += NT / 64) {
+                const int row = min(R0 + 16 * t + lo, N - 1);
+                double bv[8];
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const int k = 4 * ks + hi;
+                    const double v = P[(kb + min(k, w - 1)) * N + row];
+                    bv[ks] = (k < w) ? v : 0.0;
+                }
+                f64x4 x0 = { 0.0, 0.0, 0.0, 0.0 }, x1 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(4 * ks + hi) * LDX + lo], bv[ks], x0, 0, 0, 0);
+                if (w > 16) {
+#pragma unroll
+                    for (int ks = 0; ks < 8; ++ks)
+                        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(4 * ks + hi) * LDX + 16 + lo], bv[ks], x1, 0, 0, 0);
+                }
+                if (R0 + 16 * t + lo < N) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n0 = hi + 4 * i, n1 = 16 + hi + 4 * i;
+                        if (n0 < w) P[(kb + n0) * N + row] = x0[i];
+                        if (n1 < w) P[(kb + n1) * N + row] = x1[i];
+                    }
+                }
+            }
+        }
+#endif
         __syncthreads();
         MF_PHASE(5);
         // the own columns to the right of this panel (rows >= column): 4 x 4 register tiles, operands and result in LDS
@@ -1010,7 +1094,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     long long tphase_ = clock64();
 #define MF_STEP_PHASE(i)                                                                                          \
     do {                                                                                                          \
-        if (d.z == 0 && (threadIdx.x == PIVOT_T0)) {                                                              \
+        if (d.z == 0 && (threadIdx.x == 64 * ((3 + (int)blockIdx.x) & 3))) {                                           \
             const long long t_ = clock64();                                                                       \
             atomicAdd(&mf_phase_acc[i], (unsigned long long)(t_ - tphase_));                                      \
             tphase_ = t_;                                                                                         \
@@ -1068,9 +1152,16 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     __syncthreads();
     MF_STEP_PHASE(11);
     double* Xs = sm + 2 * NB * LDP + NB; // Xs[c * LDX + r] = X(r, c), X = L11^-1 (written by the pivot wave)
-    const int wv = tid >> 6, l = tid & 63, lo = l & 15, hi = l >> 4;
+    // The wave that takes the pivot block rotates with the workgroup index: with the same wave of every workgroup doing it,
+    // the pivot chains of all workgroups resident on a CU shared one SIMD while the other three idled behind them.
+#ifdef MF_NO_PIVOT_ROT
+    const int wv = tid >> 6;
+#else
+    const int wv = ((tid >> 6) - (int)blockIdx.x) & 3; // 0..2: row waves, 3: pivot wave
+#endif
+    const int l = tid & 63, lo = l & 15, hi = l >> 4;
     const int Rw = kb1 + d.z + 16 * MT_B * wv; // first row of this wave
-    const bool rowWave = tid < 64 * ROW_WAVES_B && Rw < N;
+    const bool rowWave = wv < ROW_WAVES_B && Rw < N;
     // Everything the rows need is a product: X_rows = (raw - P_kb Lp^T) L11^-T.  It is formed transposed, tile by tile of 16 rows:
     //   D1^T(k, m) = raw(m, k) - sum_j Lp(k, j) P(m, j)      A = -Lp (LDS), B = rows of panel kb straight from the front
     //   X^T(n, m)  = sum_k Linv(n, k) D1^T(k, m)              A = Linv (LDS), B = D1^T as it sits in the accumulators
@@ -1078,23 +1169,23 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     // consecutive rows m per column n: 128-byte stores.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15],
     // D row = (l >> 4) + 4 reg, col = l & 15.
     f64x4 d1t[MT_B][2];
-    if (tid >= PIVOT_T0) {
+    if (wv == 3) {
         // pivot wave (alone on its SIMD): Cholesky of the 32 x 32 block and its inverse while the row waves fetch and update
         // (the pivot chain is what every other wave of the step ends up waiting for: it gets issue priority on its SIMD)
         __builtin_amdgcn_s_setprio(3);
 #ifdef MF_POTRF_SCALAR
-        if (wave_potrf32(A11, LDP, w1, tid - PIVOT_T0, rdiag)) atomicOr(flag, 1);
+        if (wave_potrf32(A11, LDP, w1, l, rdiag)) atomicOr(flag, 1);
         MF_STEP_PHASE(12);
-        wave_trinv32_fast<false>(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
+        wave_trinv32_fast<false>(A11, LDP, rdiag, w1, l, Xs);
 #elif defined(MF_POTRF_BLOCKED8)
-        for (int e = tid - PIVOT_T0; e < NB * LDX; e += 64) Xs[e] = 0.0;
+        for (int e = l; e < NB * LDX; e += 64) Xs[e] = 0.0;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (wave_potrf32_blocked(A11, w1, tid - PIVOT_T0, rdiag, Xs)) atomicOr(flag, 1);
+        if (wave_potrf32_blocked(A11, w1, l, rdiag, Xs)) atomicOr(flag, 1);
         MF_STEP_PHASE(12);
-        wave_trinv32_fast<true>(A11, LDP, rdiag, w1, tid - PIVOT_T0, Xs);
+        wave_trinv32_fast<true>(A11, LDP, rdiag, w1, l, Xs);
 #else
-        if (wave_potrf_inv32_mfma(A11, w1, tid - PIVOT_T0, Xs)) atomicOr(flag, 1);
+        if (wave_potrf_inv32_mfma(A11, LDP, w1, l, Xs)) atomicOr(flag, 1);
         MF_STEP_PHASE(12);
 #endif
         __builtin_amdgcn_s_setprio(0);
@@ -1165,7 +1256,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 #ifdef MF_PHASE_TIMERS
     __syncthreads();
     MF_STEP_PHASE(14);
-    if (d.z == 0 && threadIdx.x == PIVOT_T0) atomicAdd(&mf_phase_acc[15], 1ull);
+    if (d.z == 0 && threadIdx.x == 64 * ((3 + (int)blockIdx.x) & 3)) atomicAdd(&mf_phase_acc[15], 1ull);
 #endif
 }
 
@@ -2318,9 +2409,12 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<int> blockList;
         std::vector<long long> di(ns_ + 1, 0);
         for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
+#ifdef MF_FUSED_SCALAR_PIVOT
         for (int s = 0; s < ns_; ++s)
-            if (isFused(s) && mine(s)) // the multi-workgroup path leaves finished inverses in the dinv slots (wave_trinv32_fast)
+            if (isFused(s) && mine(s)) // the multi-workgroup path leaves finished inverses in the dinv slots
                 for (long long b = di[s]; b < di[s + 1]; ++b) blockList.push_back((int)b);
+#endif
+        // (both front kernels now leave finished inverses in the dinv slots: nothing is left for k_invert_blocks)
         plainBlocks_.off = 0;
         plainBlocks_.cnt = (int)blockList.size();
         xinvLevel_.assign(nLevels_, XinvLevel());
