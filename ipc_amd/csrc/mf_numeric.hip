@@ -50,6 +50,7 @@ constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
 
 constexpr int TS = 64; // trailing-update tile
+constexpr int MV_ROWS = 32; // rows per workgroup of the forward matrix-vector kernels (k_big_fwd_rect, k_xinv_fwd): 32 rows x 8 column groups
 constexpr int FD_STRIDE_EA = 64; // packed front descriptors (same layout as the fused kernel's, see k_front_fused)
 constexpr int FUSED_MAX_KIDS_EA = 8;
 constexpr int PIVOT_BATCH = 16; // broadcasts issued ahead of their FMAs in the pivot-block Cholesky (2 SGPRs each)
@@ -1552,7 +1553,7 @@ __global__ __launch_bounds__(WGT) void k_big_fwd_tri(const int* __restrict__ lis
     for (int I = tid; I < nc; I += WGT) yperm[col0 + I] = w[I];
 }
 // ... then the rectangle below it: w2[r] = (children) - sum_c L(r, c) y_c.  desc = (front, first row behind nc, 0, 0);
-// 64 rows per workgroup, the four waves split the columns
+// 32 rows per workgroup, eight column groups
 __global__ __launch_bounds__(WG) void k_big_fwd_rect(const int4* __restrict__ desc, TreeView tv, const long long* __restrict__ wOff,
     const double* __restrict__ fronts, double* __restrict__ wbuf, const double* __restrict__ yperm)
 {
@@ -1562,16 +1563,17 @@ __global__ __launch_bounds__(WG) void k_big_fwd_rect(const int4* __restrict__ de
     const int N = frontN(tv, s), nc = frontNc(tv, s);
     const double* L = fronts + tv.frontOff[s];
     const double* y = yperm + 3 * tv.firstNode[s];
-    const int lane = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    // 32 rows x 8 column groups per workgroup (64 x 4 before): the products of a row are a chain of dependent load rounds, 16
+    // loads each, and a top-level front has few rows -- more, shorter chains on more CUs
+    const int lane = threadIdx.x & (MV_ROWS - 1), cg = threadIdx.x / MV_ROWS;
+    constexpr int NCG = WG / MV_ROWS;
     const int r = nc + d.y + lane;
     // what the children pushed up for this row: requested first, its index chain resolves while the products run
     const double up = (cg == 0 && r < N) ? gather_w(tv, wOff, wbuf, yperm, s, nc, r) : 0.0;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     {
-        // 16 loads of the row in flight at a time (rows past the end are clamped and dropped): four per round trip was
-        // nc / 16 dependent round trips per thread
-        const double* Lr = L + min(r, N - 1);
-        const int per = (nc + 3) >> 2;
+        const double* Lr = L + min(r, N - 1); // rows past the end are clamped and dropped
+        const int per = (nc + NCG - 1) / NCG;
         const int c0 = cg * per, c1 = min(nc, c0 + per);
         int c = c0;
         for (; c + 16 <= c1; c += 16) {
@@ -1586,13 +1588,23 @@ __global__ __launch_bounds__(WG) void k_big_fwd_rect(const int4* __restrict__ de
                 a3 += v[u + 3] * y[c + u + 3];
             }
         }
-#pragma unroll 4
+        for (; c + 4 <= c1; c += 4) {
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = Lr[(long long)N * (c + u)];
+            a0 += v[0] * y[c];
+            a1 += v[1] * y[c + 1];
+            a2 += v[2] * y[c + 2];
+            a3 += v[3] * y[c + 3];
+        }
         for (; c < c1; ++c) a0 += Lr[(long long)N * c] * y[c];
     }
     part[threadIdx.x] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (cg == 0 && r < N) {
-        const double tot = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+        double tot = 0.0;
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) tot += part[g * MV_ROWS + lane];
         wbuf[wOff[s] + r] = up - tot;
     }
 }
@@ -1831,43 +1843,50 @@ __global__ __launch_bounds__(256) void k_xinv_gemm(const int4* __restrict__ desc
     const double* Bm = (mode == 1) ? X : T;
     const double* Am = (mode == 1) ? F : X;
     const long long ldA = (mode == 1) ? N : nc;
-    auto fetch = [&](int k0, double (&va)[2][4], double (&vb)[2][4]) {
+    // Two operand sets, ping-pong: the loads of the next batch are issued (unconditionally, clamped) before the products of the
+    // current one, and masked only when they are used -- selecting at load time, copying a "next" set or fetching behind a
+    // branch each make the compiler wait for the newest load before the products (see k_big_schur).
+    auto fetch = [&](int k0, double (&ra)[2][4], double (&rb)[2][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = min(k0 + 4 * ks + hi, nc - 1);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ra[q][ks] = Bm[kc + (long long)nc * ccc[q]];
+                rb[q][ks] = Am[rrc[q] + ldA * kc];
+            }
+        }
+    };
+    auto mult = [&](int k0, const double (&ra)[2][4], const double (&rb)[2][4]) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int k = k0 + 4 * ks + hi;
             const bool kin = k < kStop;
-            const int kc = min(k, nc - 1);
+            double ma[2], mb[2];
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const double xb = Bm[kc + (long long)nc * ccc[q]];
-                const double xa = Am[rrc[q] + ldA * kc];
                 const bool tri = (mode == 1) ? (k >= cc[q]) : (k <= rr[q]);
-                va[q][ks] = (kin && cc[q] < cEnd && (mode == 2 || tri)) ? xb : 0.0;
-                vb[q][ks] = (kin && rr[q] < rEnd && (mode == 1 || tri)) ? xa : 0.0;
+                ma[q] = (kin && cc[q] < cEnd && (mode == 2 || tri)) ? ra[q][ks] : 0.0;
+                mb[q] = (kin && rr[q] < rEnd && (mode == 1 || tri)) ? rb[q][ks] : 0.0;
             }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[a], mb[b], acc[a][b], 0, 0, 0);
         }
     };
     double va[2][4], vb[2][4], na[2][4], nb[2][4];
     int k0 = kBeg + 16 * wv;
-    if (k0 < kStop) fetch(k0, va, vb);
-    for (; k0 < kStop; k0 += 64) {
-        const bool more = k0 + 64 < kStop;
-        if (more) fetch(k0 + 64, na, nb);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(va[a][ks], vb[b][ks], acc[a][b], 0, 0, 0);
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    va[q][ks] = na[q][ks];
-                    vb[q][ks] = nb[q][ks];
-                }
-        }
+    fetch(k0, va, vb);
+    for (; k0 < kStop; k0 += 128) {
+        fetch(k0 + 64, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(k0, va, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(k0 + 128, va, vb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 64 < kStop) mult(k0 + 64, na, nb);
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1889,7 +1908,7 @@ __global__ __launch_bounds__(256) void k_xinv_gemm(const int4* __restrict__ desc
     }
 }
 
-// forward: y1 = X w1.  desc = (front, first row, 0, 0): 64 rows per workgroup, the four waves split the columns.
+// forward: y1 = X w1.  desc = (front, first row, 0, 0): 32 rows per workgroup, eight column groups.
 __global__ __launch_bounds__(WG) void k_xinv_fwd(const int4* __restrict__ desc, TreeView tv, XinvView xv, const long long* __restrict__ wOff,
     const double* __restrict__ wbuf, const double* __restrict__ bperm, double* __restrict__ yperm)
 {
@@ -1899,14 +1918,15 @@ __global__ __launch_bounds__(WG) void k_xinv_fwd(const int4* __restrict__ desc, 
     const int s = d.x, r0 = d.y;
     const int nc = frontNc(tv, s);
     const double* X = xv.X + xv.xOff[s];
-    const int tid = threadIdx.x, lane = tid & 63, cg = tid >> 6;
-    const int cols = min(nc, r0 + 64); // X(r, c) = 0 for c > r
+    const int tid = threadIdx.x, lane = tid & (MV_ROWS - 1), cg = tid / MV_ROWS; // 32 rows x 8 column groups (see k_big_fwd_rect)
+    constexpr int NCG = WG / MV_ROWS;
+    const int cols = min(nc, r0 + MV_ROWS); // X(r, c) = 0 for c > r
     for (int I = tid; I < cols; I += WG) w1[I] = gather_w(tv, wOff, wbuf, bperm, s, nc, I);
     __syncthreads();
     const int r = r0 + lane;
     double acc0 = 0.0, acc1 = 0.0;
     if (r < nc) {
-        const int per = ((cols + 3) >> 2), cb = cg * per, ce = min(min(cols, cb + per), r + 1);
+        const int per = (cols + NCG - 1) / NCG, cb = cg * per, ce = min(min(cols, cb + per), r + 1);
         const double* Xr = X + r;
         int c = cb;
         for (; c + 15 < ce; c += 16) { // sixteen loads in flight per lane
@@ -1933,7 +1953,12 @@ __global__ __launch_bounds__(WG) void k_xinv_fwd(const int4* __restrict__ desc, 
     }
     part[tid] = acc0 + acc1;
     __syncthreads();
-    if (cg == 0 && r < nc) yperm[3 * tv.firstNode[s] + r] = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+    if (cg == 0 && r < nc) {
+        double tot = 0.0;
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) tot += part[g * MV_ROWS + lane];
+        yperm[3 * tv.firstNode[s] + r] = tot;
+    }
 }
 
 // backward: x1 = X^T t with t = y1 - L21^T x2 (left in yperm by k_big_bwd_init).  desc = (front, first column, 0, 0):
@@ -2347,7 +2372,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         P.schur.cnt = ((int)desc.size() - P.schur.off) / 2; // workgroups: two records each
         P.fwdRect.off = (int)desc.size();
         for (int s : big)
-            for (int r0 = 0; r0 < sym.N(s) - sym.nc(s); r0 += 64) desc.push_back(make_int4(s, r0, 0, 0));
+            for (int r0 = 0; r0 < sym.N(s) - sym.nc(s); r0 += MV_ROWS) desc.push_back(make_int4(s, r0, 0, 0));
         P.fwdRect.cnt = (int)desc.size() - P.fwdRect.off;
         P.bwdInit.off = (int)desc.size();
         for (int s : big)
@@ -2474,7 +2499,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                     triMax = std::max<size_t>(triMax, sym.nc(s));
                     continue;
                 }
-                for (int r0 = 0; r0 < sym.nc(s); r0 += 64) fw.push_back(make_int4(s, r0, 0, 0));
+                for (int r0 = 0; r0 < sym.nc(s); r0 += MV_ROWS) fw.push_back(make_int4(s, r0, 0, 0));
                 for (int c0 = 0; c0 < sym.nc(s); c0 += 16) bw.push_back(make_int4(s, c0, 0, 0));
             }
             P.bigTri.cnt = (int)triList.size() - P.bigTri.off;
