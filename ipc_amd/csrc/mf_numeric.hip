@@ -558,7 +558,7 @@ __device__ __forceinline__ double rcp_nr(double d)
 //       T11 -= U01^T D0^-1 U01,   W10 = -(D0^-1 U01)^T W00;
 //   pivots 16..31 update T11 and W11 (two MFMAs each); finally X10 = X11 W10 (X11 transposed through LDS, where it goes anyway).
 // 92 MFMAs, against 16.5 k + 3.1 k cycles for the lane-per-row Cholesky + recursive-doubling inverse this replaces.
-__device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld, int w, int lane, double* Xs)
+__device__ __forceinline__ bool wave_potrf_inv32_mfma_single(const double* blk, int ld, int w, int lane, double* Xs)
 {
     const int lo = lane & 15, hi = lane >> 4;
     f64x4 T00, T01, T11, W00, W11, s0, s1, n0;
@@ -656,6 +656,122 @@ __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld,
         s1[r] = rsqrt_nr(s1[r]);
         Xs[lo * LDX + q] = W00[r] * r0;
         Xs[(16 + lo) * LDX + 16 + q] = W11[r] * s1[r];
+        Xs[(16 + lo) * LDX + q] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // X10 = X11 W10: A[i = l & 15][kk] = X(16 + i, 16 + kk) read back transposed, B = W10 as it sits in the accumulators
+    f64x4 X10 = { 0.0, 0.0, 0.0, 0.0 };
+    if (w > 16) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 + 4 * ks + hi) * LDX + 16 + lo], W10[ks], X10, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xs[lo * LDX + 16 + hi + 4 * r] = X10[r];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return bad;
+}
+
+// The same with 2 x 2 block pivots -- the version in use.  Rows k, k + 1 (k even) of a tile sit in the SAME accumulator
+// register, in lane groups l >> 4 == (k & 3) and (k & 3) + 1: one MFMA applies the rank-2 update of a pivot pair (two
+// k-slices instead of one), so a block costs half the MFMAs and half the dependent chains of the single-pivot sweep above
+// (on this chip an fp64 MFMA occupies the SIMD for 64 cycles and does not overlap with the wave's own VALU work, so those
+// two counts ARE the time).  With P = [a b; b c] the pivot block and P^-1 = [ca -cb; -cb cc], the multipliers of row i are
+//     m_i^(k) = -(ca A(k, i) - cb A(k + 1, i)),    m_i^(k+1) = -(cc A(k + 1, i) - cb A(k, i)):
+// "own row times own coefficient minus partner row times cb", the partner row being 16 lanes away (one ds_bpermute pair,
+// issued before the reciprocal chain needs it).  The block-LDL^T factors come out as W = (unit block lower)^-1 and the pivot
+// blocks; X = C^-1 W with C the 2 x 2 Cholesky factors of the pivot blocks is the (unique) inverse of the Cholesky factor:
+//     X_k = W_k / l11,   X_k+1 = (W_k+1 - (l21 / l11) W_k) / l22,   l11 = sqrt(a), l21 = b / l11, l22 = sqrt(det / a).
+// Blocked 16 + 16 as above: T11 -= U01^T D0^-1 U01 and W10 = -(D0^-1 U01)^T W00 with D0 the block diagonal of pivot blocks.
+__device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16, 64); }
+
+__device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld, int w, int lane, double* Xs)
+{
+    const int lo = lane & 15, hi = lane >> 4;
+    f64x4 T00, T01, T11, W00, W11;
+    f64x4 W10 = { 0.0, 0.0, 0.0, 0.0 };
+    f64x4 aV0, bV0, dV0, alV0, cbV0, aV1, bV1, dV1; // per D-layout row: pivot block entries a, b, det and the coefficients of P^-1
+    const int wm = w - 1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = hi + 4 * r;
+        const int mn = min(q, lo), mx = max(q, lo);
+        const double a00 = blk[min(mn, wm) * ld + min(mx, wm)];
+        const double a01 = blk[min(q, wm) * ld + min(16 + lo, wm)];
+        const double a11 = blk[min(16 + mn, wm) * ld + min(16 + mx, wm)];
+        const bool dg = q == lo;
+        T00[r] = (mx < w) ? a00 : (dg ? 1.0 : 0.0);
+        T01[r] = (16 + lo < w) ? a01 : 0.0;
+        T11[r] = (16 + mx < w) ? a11 : (dg ? 1.0 : 0.0);
+        W00[r] = dg ? 1.0 : 0.0;
+        W11[r] = dg ? 1.0 : 0.0;
+        aV0[r] = aV1[r] = dV0[r] = dV1[r] = 1.0;
+        bV0[r] = bV1[r] = alV0[r] = cbV0[r] = 0.0;
+    }
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        const int h = k & 3, r = k >> 2;
+        const bool selh = hi == h, both = (hi >> 1) == (h >> 1), live = both && lo > k + 1;
+        const double row = T00[r];
+        const double partner = lane_xor16(row);
+        const double a = bcast_lane(row, 16 * h + k), b = bcast_lane(row, 16 * h + k + 1), c = bcast_lane(row, 16 * (h + 1) + k + 1);
+        const double det = fma(a, c, -(b * b));
+        bad |= !(a > 0.0) || !(det > 0.0); // not on the chain: a bad pivot leaves garbage behind, and the flag says so
+        const double rdet = rcp_nr(det);
+        const double ca = c * rdet, cb = b * rdet, cc = a * rdet;
+        const double alpha = selh ? ca : cc;
+        const double m = live ? fma(-alpha, row, cb * partner) : 0.0; // the B operands go in unmasked: their other k-slices meet zeros of m
+        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m, row, T00, 0, 0, 0);
+        T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(m, T01[r], T01, 0, 0, 0);
+        W00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m, W00[r], W00, 0, 0, 0);
+        aV0[r] = both ? a : aV0[r];
+        bV0[r] = both ? b : bV0[r];
+        dV0[r] = both ? det : dV0[r];
+        alV0[r] = both ? alpha : alV0[r];
+        cbV0[r] = both ? cb : cbV0[r];
+    }
+    if (w > 16) { // wave-uniform: a block of at most 16 columns is finished (rows 16..31 are identity)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const double t = T01[ks];
+            const double a = fma(-alV0[ks], t, cbV0[ks] * lane_xor16(t)); // -(D0^-1 U01)(row (l >> 4) + 4 ks, col l & 15): A operand [i = col][kk = row]
+            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, t, T11, 0, 0, 0);
+            W10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W00[ks], W10, 0, 0, 0);
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k += 2) {
+            const int h = k & 3, r = k >> 2;
+            const bool selh = hi == h, both = (hi >> 1) == (h >> 1), live = both && lo > k + 1;
+            const double row = T11[r];
+            const double partner = lane_xor16(row);
+            const double a = bcast_lane(row, 16 * h + k), b = bcast_lane(row, 16 * h + k + 1), c = bcast_lane(row, 16 * (h + 1) + k + 1);
+            const double det = fma(a, c, -(b * b));
+            bad |= !(a > 0.0) || !(det > 0.0);
+            const double rdet = rcp_nr(det);
+            const double ca = c * rdet, cb = b * rdet, cc = a * rdet;
+            const double alpha = selh ? ca : cc;
+            const double m = live ? fma(-alpha, row, cb * partner) : 0.0;
+            T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m, row, T11, 0, 0, 0);
+            W11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m, W11[r], W11, 0, 0, 0);
+            aV1[r] = both ? a : aV1[r];
+            bV1[r] = both ? b : bV1[r];
+            dV1[r] = both ? det : dV1[r];
+        }
+    }
+    const bool even = (hi & 1) == 0; // rows k (even) of the pairs
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int q = hi + 4 * r;
+        const double ia0 = rsqrt_nr(aV0[r]), iv0 = ia0 * ia0, il0 = rsqrt_nr(dV0[r] * iv0);
+        const double ia1 = rsqrt_nr(aV1[r]), iv1 = ia1 * ia1, il1 = rsqrt_nr(dV1[r] * iv1);
+        const double p0 = even ? ia0 : il0, q0 = even ? 0.0 : -bV0[r] * iv0 * il0;
+        const double p1 = even ? ia1 : il1, q1 = even ? 0.0 : -bV1[r] * iv1 * il1;
+        const double w0 = W00[r], w1 = W11[r];
+        Xs[lo * LDX + q] = fma(q0, lane_xor16(w0), p0 * w0);
+        Xs[(16 + lo) * LDX + 16 + q] = fma(q1, lane_xor16(w1), p1 * w1);
         Xs[(16 + lo) * LDX + q] = 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -853,7 +969,11 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
         // wave_potrf_inv32_mfma); L11 itself is needed nowhere -- the rows below are a product with X, the solves multiply by X
         if (tid < 64) {
             __builtin_amdgcn_s_setprio(3);
+#ifdef MF_GJ_SINGLE
+            bad |= wave_potrf_inv32_mfma_single(Pk, N, w, tid, Xs);
+#else
             bad |= wave_potrf_inv32_mfma(Pk, N, w, tid, Xs);
+#endif
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
@@ -1186,7 +1306,11 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
         MF_STEP_PHASE(12);
         wave_trinv32_fast<true>(A11, LDP, rdiag, w1, l, Xs);
 #else
+#ifdef MF_GJ_SINGLE
+        if (wave_potrf_inv32_mfma_single(A11, LDP, w1, l, Xs)) atomicOr(flag, 1);
+#else
         if (wave_potrf_inv32_mfma(A11, LDP, w1, l, Xs)) atomicOr(flag, 1);
+#endif
         MF_STEP_PHASE(12);
 #endif
         __builtin_amdgcn_s_setprio(0);
