@@ -265,6 +265,11 @@ int ipcgpu_opt_get_warm_step(ipcgpu_ctx*, double* last_step);
  * c the centre of their current bounding box (AnimScripter.cpp:1413-1462).  ang_vel in rad/s (the script gives deg/s).
  * Call after ipcgpu_opt_init and after the static ipcgpu_set_dbc / ipcgpu_opt_set_twist calls. */
 int ipcgpu_opt_add_dirichlet(ipcgpu_ctx*, int n, const int* vert_ids, const double* lin_vel3, const double* ang_vel3, double t0, double t1);
+/* Ends group `group` (0-based, in the order of the ipcgpu_opt_add_dirichlet calls) at time t_end: from the time step that starts at
+ * t_end on its vertices are free again.  This is what the state-dependent scripts do with mesh.resetDBCVertices() inside
+ * AnimScripter::stepAnimScript -- e.g. `script dragright` lets go of the handle once the body has been pulled past the
+ * obstacles (AnimScripter.cpp:1619-1632); the condition is the caller's. */
+int ipcgpu_opt_end_dirichlet(ipcgpu_ctx*, int group, double t_end);
 /* One Mesh::NeumannBCs entry (src/Mesh.hpp:47-56; `NBC bboxMin bboxMax force [t0 t1]` on a shape line, src/Config.cpp:264-280):
  * while t0 <= stepStartTime < t1 every listed vertex that is not a Dirichlet node feels the acceleration `accel3` -- the
  * incremental potential gets -dt^2 m_v accel . x_v, the gradient -dt^2 m_v accel (Optimizer.cpp:3241-3250, 3452-3461). */

@@ -1114,6 +1114,16 @@ int ipcgpu_opt_add_dirichlet(ipcgpu_ctx* c, int n, const int* ids, const double*
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_end_dirichlet(ipcgpu_ctx* c, int group, double t_end)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        needArg(group >= 0 && group < (int)o.dbcGroups.size(), "no such Dirichlet group");
+        o.dbcGroups[group]->t1 = std::min(o.dbcGroups[group]->t1, t_end);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_add_neumann(ipcgpu_ctx* c, int n, const int* ids, const double* accel3, double t0, double t1)
 {
     return guarded([&] {

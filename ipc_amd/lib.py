@@ -550,6 +550,10 @@ class Context:
         ang = _f64(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
         self._chk(self._L.ipcgpu_opt_add_dirichlet(self.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1)))
 
+    def end_dirichlet(self, group, t_end):
+        """Free the vertices of Dirichlet group `group` from the time step starting at t_end on (scripts that let go of a handle)."""
+        self._chk(self._L.ipcgpu_opt_end_dirichlet(self.h, C.c_int(group), C.c_double(t_end)))
+
     def add_neumann(self, ids, accel, t0=0.0, t1=float("inf")):
         """One `NBC bboxMin bboxMax force [t0 t1]` entry of a shape line."""
         ids = _i32(ids)

@@ -108,7 +108,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift"):
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright"):
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
             elif k == "warmStart":  # initX option (Optimizer.cpp:925-1080); 5 (Jacobi guess) is not restated
@@ -135,7 +135,24 @@ class SceneConfig:
                     i += 1
                     if not st or st[0].startswith("#"):
                         continue
-                    cfg.shapes.append(_parse_shape(st, resolve))
+                    # a `\` token continues the shape on the next line; a `#` token drops the rest of the line up to a
+                    # `\` (Config.cpp:290-305)
+                    toks = []
+                    while True:
+                        cont = False
+                        for j, t in enumerate(st):
+                            if t == "\\":
+                                cont = True
+                                break
+                            if t.startswith("#"):
+                                cont = "\\" in st[j + 1:]
+                                break
+                            toks.append(t)
+                        if not cont or i >= len(lines):
+                            break
+                        st = lines[i].split()
+                        i += 1
+                    cfg.shapes.append(_parse_shape(toks, resolve))
                     got += 1
             elif k == "ground":  # friction, height (Config.cpp:425-430)
                 cfg.half_spaces.append((np.array([0.0, float(a[1]), 0.0]), np.array([0.0, 1.0, 0.0]), float(a[0])))
@@ -189,6 +206,9 @@ class SceneConfig:
                         i += 1
                         if len(t2) >= 2 and t2[0] == "section" and t2[1] == "end":
                             break
+            elif k in ("CCDMethod", "ccdMethod"):  # Config.cpp:564-568: only the default method is rebuilt here
+                if a[0] != "FloatingPointRootFinder":
+                    raise UnsupportedKeyword(f"CCDMethod {a[0]}")
             elif k == "restart":
                 cfg.restart = resolve(a[0])
             elif k in VIEWER_KEYWORDS:
@@ -279,6 +299,19 @@ class AssembledScene:
     velocity: np.ndarray
     neumann: list = field(default_factory=list)  # (ids, acceleration, t0, t1)
     obstacle_nodes: np.ndarray = None  # nodes of the kinematic mesh obstacles (surface-only components, no tetrahedra)
+    release: dict = None  # state-dependent end of a scripted handle (`script dragright`)
+
+    def before_step(self, be, t):
+        """What AnimScripter::stepAnimScript decides from the state before a time step (call with the step's start time)."""
+        r = self.release
+        if r is None or r["done"]:
+            return False
+        x = np.asarray(be.state()["V"]).reshape(-1, 3)
+        if x[: r["nSim"], 0].min() > r["x_limit"]:
+            be.end_dirichlet(r["group"], t)
+            r["done"] = True
+            return True
+        return False
 
 
 def assemble(cfg, read_mesh):
@@ -326,6 +359,16 @@ def assemble(cfg, read_mesh):
         if cfg.script == "fall":  # Mesh<3> only: the obstacles are not part of it in the reference
             V[:nSim, 1] += 0.5 * np.linalg.norm(V[:nSim].max(0) - V[:nSim].min(0))
         dirichlet = []
+    release = None
+    if cfg.script == "dragright":
+        # AnimScripter.cpp:809-826: lifted like `fall`, the nodes within 4 % of the right end of the body become a NONZERO handle
+        # pulled at 0.5 in +x; stepAnimScript lets go once the whole body is right of every mesh obstacle (:1619-1632)
+        V[:nSim, 1] += 0.5 * np.linalg.norm(V[:nSim].max(0) - V[:nSim].min(0))
+        lo, hi = V[:nSim].min(0), V[:nSim].max(0)
+        ids = np.nonzero(V[:nSim, 0] > hi[0] - 0.04 * (hi[0] - lo[0]))[0].astype(np.int32)
+        dirichlet = [(ids, (0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
+        limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
+        release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}
     vel = np.zeros_like(V)
     fixed = np.zeros(V.shape[0], dtype=bool)
     for ids, *_ in dirichlet:
@@ -340,7 +383,7 @@ def assemble(cfg, read_mesh):
         v[fixed[a:b]] = 0.0
         vel[a:b] = v
     obst = np.concatenate(obstacle) if obstacle else None
-    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst)
+    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release)
 
 
 def apply(sc, be):

@@ -452,6 +452,11 @@ def opt_add_dirichlet(opt: "Optimizer", ids, lin_vel=(0, 0, 0), ang_vel_deg=(0, 
     lib().orc_opt_add_dirichlet(opt.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1))
 
 
+def opt_end_dirichlet(opt: "Optimizer", group, t_end):
+    """The handle of a state-dependent script is released: group `group` ends at t_end (AnimScripter.cpp:1619-1632)."""
+    lib().orc_opt_end_dirichlet(opt.h, C.c_int(group), C.c_double(t_end))
+
+
 def opt_add_neumann(opt: "Optimizer", ids, accel, t0=0.0, t1=float("inf")):
     """One `NBC bboxMin bboxMax force [t0 t1]` entry of a shape line (Config.cpp:264-280)."""
     ids = np.ascontiguousarray(ids, dtype=np.int32)

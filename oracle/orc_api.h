@@ -93,6 +93,7 @@ void orc_opt_begin_timestep(orc_opt*); // stepAnimScript + initX(0) + energy, Op
 void orc_opt_end_timestep(orc_opt*); // BE / NM velocity, acceleration and xTilta update, Optimizer.cpp:570-590
 // Mesh::DirichletBCs entry / scripted component velocity (Mesh.hpp:23-39, AnimScripter.cpp:58-110, 1413-1462); angular velocity in rad/s
 void orc_opt_add_dirichlet(orc_opt*, int n, const int* ids, const double* lin3, const double* ang3, double t0, double t1);
+void orc_opt_end_dirichlet(orc_opt*, int group, double t_end); /* mesh.resetDBCVertices() of a state-dependent script (AnimScripter.cpp:1619-1632) */
 void orc_opt_add_neumann(orc_opt*, int n, const int* ids, const double* accel3, double t0, double t1); // Mesh::NeumannBCs, Optimizer.cpp:3241-3250, 3452-3461
 void orc_opt_get_dbc_state(const orc_opt*, double* out4); // completed step, rho_DBC, m_projectDBC, #targets (Optimizer.cpp:2168-2203)
 void orc_opt_get_kinematics(const orc_opt*, double* vel_3nV, double* acc_3nV, double* dx_3nV);

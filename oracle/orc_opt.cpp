@@ -605,6 +605,10 @@ void orc_opt_add_neumann(orc_opt* o, int n, const int* ids, const double* accel3
     o->nbcGroups.push_back(g);
 }
 
+void orc_opt_end_dirichlet(orc_opt* o, int group, double t_end)
+{
+    if (group >= 0 && group < (int)o->dbcGroups.size()) o->dbcGroups[group].t1 = std::min(o->dbcGroups[group].t1, t_end);
+}
 void orc_opt_add_dirichlet(orc_opt* o, int n, const int* ids, const double* lin3, const double* angRad3, double t0, double t1)
 {
     orc_opt::DBCGroup g;

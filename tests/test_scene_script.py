@@ -113,7 +113,7 @@ def test_reference_scene_files_parse():
     print(len(ok), "scene files map onto the C ABI;", unsupported)
     for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
         assert need in ok, need
-    assert len(ok) >= 85  # the rest needs scripted handle / obstacle motions (script DCOFix, dragright, ...) that are not restated
+    assert len(ok) >= 97  # the rest needs codimensional shapes (script DCOFix ...), other scripted motions, other solvers or damping
 
 
 class OracleBackend:
@@ -167,6 +167,15 @@ class OracleBackend:
 
     def add_neumann(self, ids, acc, **k):
         self.orc.opt_add_neumann(self.o, ids, acc, **k)
+
+    def end_dirichlet(self, group, t_end):
+        self.orc.opt_end_dirichlet(self.o, group, t_end)
+
+    def state(self):
+        return self.o.state()
+
+    def solve_timestep(self, cap):
+        return self.o.solve_timestep(cap)
 
     def set_twist(self, l, r):
         self.o.set_twist(l, r)
@@ -272,3 +281,79 @@ def test_tutorial_scene_runs_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path
         touched += c.contact_state()["nHalfSpace"] > 0
     assert touched >= 3 and c.state()["V"][:, 1].min() > 0.0  # the lower cube has reached the ground and stays above it
     c.close()
+
+
+def test_shape_lines_continue_over_backslashes():
+    """tutorialExamples/BC/2cubesFall_DBC_timeRange.txt: a shape whose DBC entries sit on continuation lines (Config.cpp:290-305)."""
+    text = ("shapes input 2\na.msh 0 3 0  0 0 0  1 1 1\n"
+            "a.msh 0 1 0  0 0 0  1 1 1 \\\n    DBC -0.1 -0.1 -0.1  0.1 1.1 0.1  -0.2 0.0 -0.2  0 0 0  0.0 2.5 \\\n"
+            "    DBC 0.9 -0.1 0.9  1.1 1.1 1.1  0.2 0 0.2  0 0 0  2.5   # from 2.5 s on \\\n    NBC 0 0 0 1 1 1  0 -1 0\nselfFric 0.1\n")
+    c = ss.SceneConfig.parse(text)
+    assert len(c.shapes) == 2 and not c.shapes[0].dbc and c.self_fric == 0.1
+    d = c.shapes[1].dbc
+    assert len(d) == 2 and d[0][4:] == (0.0, 2.5) and d[1][4] == 2.5 and d[1][5] == float("inf") and len(c.shapes[1].nbc) == 1
+
+
+def test_dragright_grabs_the_right_end_and_lets_go_behind_the_obstacles(orc, tmp_path):
+    """`script dragright` (AnimScripter.cpp:809-826, 1619-1632): body lifted like `fall`, the rightmost 4 % of the nodes pulled at
+    0.5 in +x as a NONZERO handle; once every node is right of the obstacles the handle is released and the body falls freely."""
+    (tmp_path / "plane.obj").write_text(PLANE_OBJ)
+    V0, F0 = scene.make_box(4, 1, 1, size=(1.0, 0.25, 0.25), origin=(0.0, 0.0, 0.0))
+    SF0 = scene.surface_tris(F0)
+    text = (f"script dragright\nshapes input 1\nbar.msh 0 0 0  0 0 0  1 1 1\nmeshCO {tmp_path}/plane.obj -0.75 -2 0  0.5  50  0.0\n"
+            "selfCollisionOff\ntime 1 0.02\ntol 1\n1e-6\n")
+    cfg = ss.SceneConfig.parse(text, str(tmp_path))
+    sc = ss.assemble(cfg, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    n = V0.shape[0]
+    lift = 0.5 * np.linalg.norm(V0.max(0) - V0.min(0))
+    assert np.allclose(sc.V[:n, 1], V0[:, 1] + lift)
+    (ids, lin, ang, t0, t1), = sc.dirichlet
+    assert np.array_equal(ids, np.nonzero(V0[:, 0] > 0.96)[0]) and lin == (0.5, 0.0, 0.0) and t1 == float("inf")
+    assert sc.release["x_limit"] == pytest.approx(-0.5) and sc.release["nSim"] == n  # obstacle: x in [-1, -0.5]
+    be = ss.apply(sc, OracleBackend(orc))
+    # the body starts at x in [0, 1], right of the obstacle: the very first stepAnimScript lets go
+    x0 = be.state()["V"][ids, 0].copy()
+    assert sc.before_step(be, 0.0) and not sc.before_step(be, 0.02)
+    assert be.solve_timestep(50) < 50
+    s1 = be.state()
+    # nobody pulls any more (a pulled handle would be 0.5 dt = 1e-2 further right); the body falls.  As in the reference the
+    # released nodes still carry the xTilde of a Dirichlet node for this one step (computeXTilta ran before stepAnimScript let go,
+    # Optimizer.cpp:524-530, 1247-1249), so they lag behind the free fall g dt^2 of the others
+    assert np.abs(s1["V"][ids, 0] - x0).max() < 2e-3
+    fall = sc.V[:n, 1] - s1["V"][:n, 1]
+    assert np.all(fall > 0) and fall.max() == pytest.approx(9.80665 * 0.02 ** 2, rel=2e-2) and fall[ids].max() < 0.5 * fall.max()
+    # with the obstacle to the right the handle keeps pulling: 0.5 * dt per step, exactly
+    sc2 = ss.assemble(ss.SceneConfig.parse(text.replace("-0.75 -2 0", "3 -2 0"), str(tmp_path)), lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    be2 = ss.apply(sc2, OracleBackend(orc))
+    for k in range(2):
+        assert not sc2.before_step(be2, 0.02 * k)
+        assert be2.solve_timestep(50) < 50
+    assert np.allclose(be2.state()["V"][ids, 0], x0 + 2 * 0.5 * 0.02, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_dragright_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
+    """The pulled handle and its state-dependent release through the C ABI (ipcgpu_opt_end_dirichlet): same decisions, same steps."""
+    (tmp_path / "plane.obj").write_text(PLANE_OBJ)
+    V0, F0 = scene.make_box(4, 1, 1, size=(1.0, 0.25, 0.25), origin=(0.0, 0.0, 0.0))
+    V0 = scene.jitter(V0, F0, rel=1e-2)
+    SF0 = scene.surface_tris(F0)
+    # the obstacle's right end is at x = 0.015
+    text = (f"script dragright\nshapes input 1\nbar.msh 0 0 0  0 0 0  1 1 1\nmeshCO {tmp_path}/plane.obj -0.235 -2 0  0.5  50  0.0\n"
+            "selfCollisionOff\ntime 1 0.02\ntol 1\n1e-6\n")
+    cfg = ss.SceneConfig.parse(text, str(tmp_path))
+    read = lambda p: (V0.copy(), F0.copy(), SF0.copy())
+    sco, scg = ss.assemble(cfg, read), ss.assemble(cfg, read)
+    assert sco.release["x_limit"] == pytest.approx(0.015)
+    ob, gb = ss.apply(sco, OracleBackend(orc)), ss.apply(scg, gpu_lib.Context(0))
+    released = []
+    for k in range(8):
+        ro, rg = sco.before_step(ob, 0.02 * k), scg.before_step(gb, 0.02 * k)
+        assert ro == rg
+        released.append(ro)
+        no, ng = ob.solve_timestep(60), gb.solve_timestep(60)
+        assert no < 60 and ng == no
+        so, sg = ob.state(), gb.state()
+        assert np.abs(sg["V"] - so["V"]).max() < 1e-8 * np.abs(so["V"]).max(), k
+    assert released == [False] * 5 + [True, False, False]  # the left end follows the pulled handle elastically: past x = 0.015 after five steps
+    gb.close()

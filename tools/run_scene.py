@@ -26,6 +26,7 @@ c = ss.apply(sc, lib.Context(0))
 steps = args.steps if args.steps is not None else int(round(cfg.duration / cfg.dt))
 for step in range(steps):
     t0 = time.time()
+    sc.before_step(c, step * cfg.dt)  # state-dependent script decisions (AnimScripter::stepAnimScript)
     it = c.solve_timestep(1000)
     st = c.state()
     cs = c.contact_state() if cfg.self_collision or cfg.half_spaces else {}
