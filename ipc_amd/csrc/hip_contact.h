@@ -61,6 +61,7 @@ public:
     void connectivity(std::vector<std::pair<int, int>>& pairs) const;
     bool patternCovers(const HipLinSysSolver& lin); // every node pair of the current sets has its block in lin's pattern (one small kernel)
     void candidateConnectivity(std::vector<std::pair<int, int>>& pairs) const; // appends; all node pairs of the candidate list
+    void candidateConnectivitySorted(std::vector<std::pair<int, int>>& pairs); // the same, sorted and unique, formed on the device
     // conservative CCD step bounds; pair2 receives the limiting pair ((-svI-1, sfI) or (eI, eJ)); returns the new bound
     double ccdPartial(const double* x_dev, const double* p_dev, double slackness, double stepSize, int* pair2);
     double ccdFull(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double stepSize, int* pair2,

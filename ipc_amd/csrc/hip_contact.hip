@@ -1583,6 +1583,66 @@ void HipContact::frictionConnectivity(std::vector<std::pair<int, int>>& pairs) c
 // Every node pair a candidate primitive pair can ever couple, whatever its closest-feature type: vertex x the three triangle
 // nodes, the 2 x 2 end points of an edge pair.  A superset of connectivity() for the same set; used for the look-ahead pattern
 // (a stencil that slides from point-point to point-triangle needs no new matrix blocks then).
+// node pairs of the candidate list as 64-bit keys (lo << 32 | hi), four per candidate (a point-triangle candidate has three: the
+// fourth slot, like a pair of equal nodes, is the all-ones sentinel that sorts last)
+__global__ void k_cand_pair_keys(int n, const int* __restrict__ cs, const int* __restrict__ SVI, const int* __restrict__ SF,
+    const int* __restrict__ SFE, unsigned long long* __restrict__ key)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int c0 = cs[2 * (size_t)i], c1 = cs[2 * (size_t)i + 1];
+    auto mk = [](int a, int b) { return a == b ? ~0ull : (((unsigned long long)(unsigned)min(a, b) << 32) | (unsigned)max(a, b)); };
+    unsigned long long* k = key + 4 * (size_t)i;
+    if (c0 < 0) {
+        const int v = SVI[-c0 - 1];
+        for (int q = 0; q < 3; ++q) k[q] = mk(v, SF[3 * (size_t)c1 + q]);
+        k[3] = ~0ull;
+    }
+    else {
+        const int a0 = SFE[2 * (size_t)c0], a1 = SFE[2 * (size_t)c0 + 1], b0 = SFE[2 * (size_t)c1], b1 = SFE[2 * (size_t)c1 + 1];
+        k[0] = mk(a0, b0);
+        k[1] = mk(a0, b1);
+        k[2] = mk(a1, b0);
+        k[3] = mk(a1, b1);
+    }
+}
+
+// The same pairs as candidateConnectivity, sorted and without duplicates, formed on the device: radix sort + unique of the keys
+// (a few hundred thousand pairs: 20 ms of std::sort on the host, per pattern change, twice).  Appends to `pairs`.
+void HipContact::candidateConnectivitySorted(std::vector<std::pair<int, int>>& pairs)
+{
+    const int n = nCand_;
+    if (n <= 0) return;
+    const size_t m = 4 * (size_t)n;
+    sortKeyIn_.ensure(m + 1);
+    sortKeyOut_.ensure(m + 1);
+    hipLaunchKernelGGL(k_cand_pair_keys, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_csPTEE.p, d_SVI.p, d_SF.p, d_SFE.p, sortKeyIn_.p);
+    auto tmp = [&](size_t bytes) {
+        if (scanTmp_.n < bytes) scanTmp_.alloc(bytes + bytes / 4);
+        return (void*)scanTmp_.p;
+    };
+    {
+        size_t bytes = 0;
+        hipcub::DeviceRadixSort::SortKeys(nullptr, bytes, sortKeyIn_.p, sortKeyOut_.p, (int)m, 0, 64, stream);
+        hipcub::DeviceRadixSort::SortKeys(tmp(bytes), bytes, sortKeyIn_.p, sortKeyOut_.p, (int)m, 0, 64, stream);
+    }
+    unsigned long long* d_cnt = sortKeyOut_.p + m; // one spare slot behind the keys
+    {
+        size_t bytes = 0;
+        hipcub::DeviceSelect::Unique(nullptr, bytes, sortKeyOut_.p, sortKeyIn_.p, reinterpret_cast<int*>(d_cnt), (int)m, stream);
+        hipcub::DeviceSelect::Unique(tmp(bytes), bytes, sortKeyOut_.p, sortKeyIn_.p, reinterpret_cast<int*>(d_cnt), (int)m, stream);
+    }
+    int cnt = 0;
+    HIP_CHECK(hipMemcpyAsync(&cnt, d_cnt, sizeof(int), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    std::vector<unsigned long long> keys((size_t)cnt);
+    if (cnt) HIP_CHECK(hipMemcpyAsync(keys.data(), sortKeyIn_.p, (size_t)cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    pairs.reserve(pairs.size() + keys.size());
+    for (unsigned long long k : keys)
+        if (k != ~0ull) pairs.push_back({ (int)(k >> 32), (int)(k & 0xffffffffull) });
+}
+
 void HipContact::candidateConnectivity(std::vector<std::pair<int, int>>& pairs) const
 {
     syncHost();

@@ -39,6 +39,7 @@ public:
     DevBuf<int4> d_tet;
 
     // Mesh::computeFeatures + computeMassMatrix + setLameParam (Mesh.cpp:414-527, 246-266, 399-401, 660-671)
+    unsigned featuresVersion = 0; // bumped by every computeFeatures: host-side caches of mesh topology key on it
     void computeFeatures(int nV, int nT, const double* Vrest, const int* F, double YM, double PR, double density, hipStream_t s);
     void uploadDBC(hipStream_t s);
     int energyType = 0; // Config `energy NH|FCR` (Config.cpp:23-24): 0 neo-Hookean, 1 fixed corotated

@@ -30,6 +30,7 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
     hipStream_t s)
 {
     if (nV_ <= 0 || nT_ < 0) throw ArgError("set_mesh: bad sizes");
+    ++featuresVersion;
     nV = nV_;
     nT = nT_;
     V_rest.assign(Vr, Vr + 3 * (size_t)nV);

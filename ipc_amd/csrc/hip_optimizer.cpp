@@ -655,7 +655,17 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
     // look-ahead).  One small kernel answers that; the host-side connectivity (hundreds of thousands of pairs to build, filter
     // and sort) runs only when a pair is missing.  Lagged friction keeps its own set: always the host path there.
     const bool frictionPairs = fricDHat > 0.0 && selfFric > 0.0;
+    static const bool timeIt = std::getenv("IPCGPU_PATTERN_TIMES") != nullptr; // stderr: where a pattern change spends its time
+    auto tLap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timeIt) return;
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "pattern change: %-34s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tLap).count());
+        tLap = now;
+    };
     if (selfCollision && (frictionPairs || !contact->patternCovers(lin))) {
+        lap("coverage check");
         // the pattern follows the contact connectivity (augmentConnectivity into vNeighbor_IP, Optimizer.cpp:3560-3612);
         // only pairs that are not mesh edges change it
         std::vector<std::pair<int, int>> extra, fresh;
@@ -668,6 +678,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         }
         std::sort(fresh.begin(), fresh.end());
         fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
+        lap("connectivity of the live sets");
         // The reference rebuilds pattern + symbolic analysis whenever the contact graph changes (:3570-3592).  Here the pattern
         // only ever GROWS inside the stepper: pairs that left the constraint set keep their (zero) slots, so a new analysis is
         // needed only when a pair shows up that no earlier iteration had.  Same matrix, fewer host-side analyses; the
@@ -681,16 +692,19 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
             if (patternPad >= 1.0) {
                 std::vector<std::pair<int, int>> ahead;
                 if (patternPad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, patternPad * dHat);
-                contact->candidateConnectivity(ahead); // full stencils: closest-feature changes need no new blocks
+                contact->candidateConnectivitySorted(ahead); // full stencils: closest-feature changes need no new blocks; sorted, unique
                 if (patternPad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, dHat); // back to the real sets
+                std::vector<std::pair<int, int>> aheadNew;
+                aheadNew.reserve(ahead.size());
                 for (const auto& e : ahead) {
                     const int* b = mesh.nb.data() + mesh.nbPtr[e.first];
                     const int* en = mesh.nb.data() + mesh.nbPtr[e.first + 1];
-                    if (!std::binary_search(b, en, e.second)) padded.push_back(e);
+                    if (!std::binary_search(b, en, e.second)) aheadNew.push_back(e);
                 }
-                std::sort(padded.begin(), padded.end());
-                padded.erase(std::unique(padded.begin(), padded.end()), padded.end());
+                padded.clear(); // fresh and aheadNew are both sorted and unique: their union is one linear merge
+                std::set_union(fresh.begin(), fresh.end(), aheadNew.begin(), aheadNew.end(), std::back_inserter(padded));
             }
+            lap("look-ahead sets + connectivity");
             std::vector<std::pair<int, int>> merged;
             std::set_union(curExtra.begin(), curExtra.end(), padded.begin(), padded.end(), std::back_inserter(merged));
             if (merged.size() > 3 * padded.size() + 4096) merged = padded;
@@ -702,17 +716,24 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
                 flat.push_back(e.first);
                 flat.push_back(e.second);
             }
+            lap("union + flatten");
             {
                 Tic t(timers[1], stream);
                 lin.set_pattern(mesh, (int)curExtra.size(), flat.data());
             }
-            Tic t(timers[2], stream);
-            lin.analyze_pattern(&mesh);
+            lap("set_pattern");
+            {
+                Tic t(timers[2], stream);
+                lin.analyze_pattern(&mesh);
+            }
+            lap("analyze_pattern");
         }
     }
     // setZero (Optimizer.cpp:3616), elastic Hessian (:3619-3623) and the mass / DBC diagonal (:3638-3668) are one
     // pass: every owned CSR row is written exactly once by the patch that owns its node
+    const bool planStale = !(patchVersion == lin.patternVersion && patch.valid);
     ensurePatchPlan();
+    if (planStale) lap("patch plan");
     int pb, pe;
     patchShard(pb, pe);
     if (worldSize > 1) {

@@ -1,5 +1,10 @@
 #include "mf_symbolic.h"
 #include <algorithm>
+#include <memory>
+#include <atomic>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 #include <cmath>
 #include <numeric>
 #include <mutex>
@@ -84,25 +89,36 @@ Graph node_graph(int n, const int* ia, const int* ja)
 // Nested dissection.  Produces groups of old node ids in elimination order (domains first, separators last).
 class Dissector {
 public:
-    Dissector(const Graph& g, const double* coords, int leaf) : g_(g), xyz_(coords), leaf_(leaf), mark_(g.nn, -1), key_(g.nn, 0.0), seen_(g.nn, -1) {}
+    Dissector(const Graph& g, const double* coords, int leaf)
+        : g_(g), xyz_(coords), leaf_(leaf), mark_(new std::atomic<int>[std::max(g.nn, 1)]), key_(g.nn, 0.0), seen_(g.nn, -1)
+    {
+        for (int i = 0; i < g.nn; ++i) mark_[i].store(-1, std::memory_order_relaxed);
+    }
 
     std::vector<std::vector<int>> run()
     {
         std::vector<int> all(g_.nn);
         std::iota(all.begin(), all.end(), 0);
-        split(all);
-        return std::move(groups_);
+        std::vector<std::vector<int>> groups;
+        split(all, groups, 0);
+        return groups;
     }
 
 private:
+    // The two halves of a cut are independent: the first levels of the recursion run them on separate threads.  A node belongs
+    // to exactly one active subproblem, so key_ / seen_ are only touched by their owner; mark_ is also READ for neighbours
+    // that may belong to another subproblem (where it holds that subproblem's tag, never ours) -- hence relaxed atomics; the tags
+    // come from atomic counters and are unique.
+    static constexpr int PAR_DEPTH = 3;
     const Graph& g_;
     const double* xyz_;
     int leaf_;
-    std::vector<int> mark_;
+    std::unique_ptr<std::atomic<int>[]> mark_;
     std::vector<double> key_;
     std::vector<int> seen_;
-    int tag_ = 0, seenTag_ = 0;
-    std::vector<std::vector<int>> groups_;
+    std::atomic<int> tag_{ 0 }, seenTag_{ 0 };
+    int markOf(int v) const { return mark_[v].load(std::memory_order_relaxed); }
+    void setMark(int v, int t) { mark_[v].store(t, std::memory_order_relaxed); }
 
     // key_[v] = coordinate along the longest bbox axis (geometric) or BFS depth from a pseudo-peripheral node
     void compute_keys(const std::vector<int>& S, int t)
@@ -128,18 +144,18 @@ private:
     void bfs(const std::vector<int>& S, int start, int t, std::vector<int>& order)
     {
         order.clear();
-        ++seenTag_;
+        const int st = ++seenTag_;
         auto run = [&](int s0, double d0) {
             size_t head = order.size();
             order.push_back(s0);
-            seen_[s0] = seenTag_;
+            seen_[s0] = st;
             key_[s0] = d0;
             while (head < order.size()) {
                 int u = order[head++];
                 for (int k = g_.ptr[u]; k < g_.ptr[u + 1]; ++k) {
                     int w = g_.adj[k];
-                    if (mark_[w] == t && seen_[w] != seenTag_) {
-                        seen_[w] = seenTag_;
+                    if (markOf(w) == t && seen_[w] != st) {
+                        seen_[w] = st;
                         key_[w] = key_[u] + 1.0;
                         order.push_back(w);
                     }
@@ -148,17 +164,17 @@ private:
         };
         run(start, 0.0);
         for (int v : S)
-            if (seen_[v] != seenTag_) run(v, key_[order.back()] + 1.0);
+            if (seen_[v] != st) run(v, key_[order.back()] + 1.0);
     }
 
-    void split(std::vector<int>& S)
+    void split(std::vector<int>& S, std::vector<std::vector<int>>& out, int depth)
     {
         if ((int)S.size() <= leaf_) {
-            if (!S.empty()) groups_.push_back(S);
+            if (!S.empty()) out.push_back(S);
             return;
         }
         const int t = ++tag_;
-        for (int v : S) mark_[v] = t;
+        for (int v : S) setMark(v, t);
         compute_keys(S, t);
         // median cut on the key; ties (same BFS level / same coordinate plane) stay on one side.  left = { key < kcut }.
         // The result depends on S only as a set, so the geometric case avoids the full sort: median by selection (O(n)), one
@@ -189,7 +205,7 @@ private:
         const bool cutBelow = (half - lo <= hi - half && lo > 0); // left = keys < kmid, else keys <= kmid
         const size_t cut = cutBelow ? lo : hi;
         if (cut == 0 || cut >= sorted.size()) { // cannot be split on this key
-            groups_.push_back(S);
+            out.push_back(S);
             return;
         }
         auto isLeftOf = [&](int v) { return cutBelow ? key_[v] < kmid : key_[v] <= kmid; };
@@ -201,7 +217,7 @@ private:
             bool touches = false;
             for (int k = g_.ptr[v]; k < g_.ptr[v + 1] && !touches; ++k) {
                 int w = g_.adj[k];
-                if (mark_[w] == t && (isLeftOf(w) != isLeft)) touches = true;
+                if (markOf(w) == t && (isLeftOf(w) != isLeft)) touches = true;
             }
             if (touches) (isLeft ? bl : br).push_back(v);
         }
@@ -209,17 +225,35 @@ private:
         const std::vector<int>& sep = useLeft ? bl : br;
         std::vector<char> inSep; // local flags through seen_ reuse would clash with bfs; use a tag on mark_
         const int sepTag = ++tag_;
-        for (int v : sep) mark_[v] = sepTag;
+        for (int v : sep) setMark(v, sepTag);
         std::vector<int> left, right;
         for (size_t i = 0; i < sorted.size(); ++i) {
             int v = sorted[i];
-            if (mark_[v] == sepTag) continue;
+            if (markOf(v) == sepTag) continue;
             (isLeftOf(v) ? left : right).push_back(v);
         }
         std::vector<int> sepCopy = sep;
-        split(left);
-        split(right);
-        if (!sepCopy.empty()) groups_.push_back(std::move(sepCopy));
+        if (depth < PAR_DEPTH && sorted.size() > 8192) {
+            std::vector<std::vector<int>> gr;
+            std::exception_ptr err;
+            std::thread th([&] {
+                try {
+                    split(right, gr, depth + 1);
+                }
+                catch (...) {
+                    err = std::current_exception();
+                }
+            });
+            split(left, out, depth + 1);
+            th.join();
+            if (err) std::rethrow_exception(err);
+            for (auto& grp : gr) out.push_back(std::move(grp));
+        }
+        else {
+            split(left, out, depth + 1);
+            split(right, out, depth + 1);
+        }
+        if (!sepCopy.empty()) out.push_back(std::move(sepCopy));
     }
 };
 
@@ -234,10 +268,20 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     o.flops = 0;
     o.maxN = 0;
     o.n = n;
+    static const bool timeIt = std::getenv("IPCGPU_MF_SETUP_TIMES") != nullptr;
+    auto tLap = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timeIt) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "mf analyze %-26s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tLap).count());
+        tLap = now;
+    };
     Graph g = node_graph(n, ia, ja);
+    lap("node graph");
     o.nn = g.nn;
     Dissector nd(g, coords, leafSize);
     std::vector<std::vector<int>> groups = nd.run();
+    lap("nested dissection");
     o.ns = (int)groups.size();
     o.newOf.assign(o.nn, -1);
     o.oldOf.assign(o.nn, -1);
@@ -286,6 +330,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
             kids[o.parent[s]].push_back(s);
         }
     }
+    lap("front structures");
     o.level.assign(o.ns, 0);
     int maxLevel = 0;
     for (int s = 0; s < o.ns; ++s) {
@@ -351,6 +396,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
         std::vector<int> pos(o.levelPtr.begin(), o.levelPtr.end() - 1);
         for (int s = 0; s < o.ns; ++s) o.levelFronts[pos[o.level[s]]++] = s;
     }
+    lap("index + inverse maps, levels");
     // user-matrix entry -> front slot (lower triangle of the permuted matrix)
     o.aDst.resize(ia[n]);
     o.aFront.resize(ia[n]);
@@ -429,6 +475,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
         for (int r = 0; r < n; ++r)
             for (int k = ia[r]; k < ia[r + 1]; ++k) o.aDst[k] = slot(r, ja[k], &o.aFront[k]);
     }
+    lap("entry destinations");
 }
 
 void mf_L_pattern_csr(const MfSymbolic& sym, std::vector<int>& ptrT, std::vector<int>& indT, std::vector<int>& pivQ)

@@ -12,6 +12,7 @@
 //   gradient nodal forces accumulate in LDS (12 adds per element), inertia term added at the flush (:3438-3450)
 // No memset, no second kernel, no global atomics: every CSR value and gradient entry is written exactly once.
 #pragma once
+#include <vector>
 #include "common.h"
 #include "nh_kernels.h"
 #include <cstdint>
@@ -47,6 +48,14 @@ struct PatchPlan {
     DevBuf<uint32_t> contrib;
     DevBuf<uint16_t> gradSlot;
     bool valid = false;
+    // The part of the plan that does not depend on the CSR pattern (node -> elements, Morton order, patches, gradient slots) is kept
+    // on the host: when contact changes the pattern only the work items (CSR positions) are rebuilt, by a few threads.
+    struct Topo {
+        const void* mesh = nullptr;
+        int nV = -1, nT = -1, tetCap = 0;
+        unsigned version = 0;
+        std::vector<int> vtPtr, vt, vtLoc, nodePtr, nodes, tetPtr, tets;
+    } topo;
 
     void build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream_t s);
     PatchView view() const;

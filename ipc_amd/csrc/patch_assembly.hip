@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 
 namespace ipcgpu {
 
@@ -226,63 +227,83 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
     if (lin.rowBase.empty() || nT == 0) return;
     int tetCap = BLOCK;
     if (const char* e = std::getenv("IPCGPU_PATCH_TETS")) tetCap = std::max(32, std::min(BLOCK, std::atoi(e)));
-    // node -> incident elements (with the local index of the node inside the element)
-    std::vector<int> vtPtr(nV + 1, 0), vt(4 * (size_t)nT), vtLoc(4 * (size_t)nT);
-    for (int t = 0; t < nT; ++t)
-        for (int k = 0; k < 4; ++k) vtPtr[mesh.F[t + (size_t)nT * k] + 1]++;
-    for (int v = 0; v < nV; ++v) vtPtr[v + 1] += vtPtr[v];
-    {
-        std::vector<int> pos(vtPtr.begin(), vtPtr.end() - 1);
+    std::vector<int> owner, localIdx; // filled with the patches (fresh topology only): who owns a node, and where in its patch
+    const bool freshTopo = !(topo.mesh == (const void*)&mesh && topo.version == mesh.featuresVersion && topo.nV == nV && topo.nT == nT && topo.tetCap == tetCap);
+    if (freshTopo) {
+        topo.mesh = &mesh;
+        topo.nV = nV;
+        topo.nT = nT;
+        topo.tetCap = tetCap;
+        topo.version = mesh.featuresVersion;
+        // node -> incident elements (with the local index of the node inside the element)
+        std::vector<int>&vtPtr = topo.vtPtr, &vt = topo.vt, &vtLoc = topo.vtLoc;
+        vtPtr.assign(nV + 1, 0);
+        vt.assign(4 * (size_t)nT, 0);
+        vtLoc.assign(4 * (size_t)nT, 0);
         for (int t = 0; t < nT; ++t)
-            for (int k = 0; k < 4; ++k) {
-                const int v = mesh.F[t + (size_t)nT * k];
-                vt[pos[v]] = t;
-                vtLoc[pos[v]] = k;
-                pos[v]++;
-            }
+            for (int k = 0; k < 4; ++k) vtPtr[mesh.F[t + (size_t)nT * k] + 1]++;
+        for (int v = 0; v < nV; ++v) vtPtr[v + 1] += vtPtr[v];
+        {
+            std::vector<int> pos(vtPtr.begin(), vtPtr.end() - 1);
+            for (int t = 0; t < nT; ++t)
+                for (int k = 0; k < 4; ++k) {
+                    const int v = mesh.F[t + (size_t)nT * k];
+                    vt[pos[v]] = t;
+                    vtLoc[pos[v]] = k;
+                    pos[v]++;
+                }
+        }
+        // Morton order of the rest positions (cubic cells so that thin directions collapse)
+        double ext = 0;
+        for (int c = 0; c < 3; ++c) ext = std::max(ext, mesh.bboxHi[c] - mesh.bboxLo[c]);
+        if (!(ext > 0)) ext = 1;
+        std::vector<std::pair<uint32_t, int>> keyed(nV);
+        for (int v = 0; v < nV; ++v) {
+            uint32_t q[3];
+            for (int c = 0; c < 3; ++c) q[c] = (uint32_t)std::min(1023.0, std::max(0.0, (mesh.V_rest[v + (size_t)nV * c] - mesh.bboxLo[c]) / ext * 1023.0));
+            keyed[v] = { morton3(q[0], q[1], q[2]), v };
+        }
+        std::sort(keyed.begin(), keyed.end());
+        // greedy patches: consecutive Morton nodes while the touched elements fit one phase-1 round
+        std::vector<int>&hNodePtr = topo.nodePtr, &hNodes = topo.nodes, &hTetPtr = topo.tetPtr, &hTets = topo.tets;
+        hNodePtr.assign(1, 0);
+        hTetPtr.assign(1, 0);
+        hNodes.clear();
+        hTets.clear();
+        std::vector<int> mark(nT, -1);
+        std::vector<int> curTets;
+        owner.assign(nV, -1);
+        localIdx.assign(nV, 0);
+        int pid = 0;
+        auto closePatch = [&]() {
+            std::sort(curTets.begin(), curTets.end());
+            hTets.insert(hTets.end(), curTets.begin(), curTets.end());
+            hTetPtr.push_back((int)hTets.size());
+            hNodePtr.push_back((int)hNodes.size());
+            curTets.clear();
+            ++pid;
+        };
+        for (int i = 0; i < nV; ++i) {
+            const int v = keyed[i].second;
+            int fresh = 0;
+            for (int k = vtPtr[v]; k < vtPtr[v + 1]; ++k)
+                if (mark[vt[k]] != pid) ++fresh;
+            if ((int)hNodes.size() > hNodePtr.back() && (int)curTets.size() + fresh > tetCap) closePatch();
+            for (int k = vtPtr[v]; k < vtPtr[v + 1]; ++k)
+                if (mark[vt[k]] != pid) {
+                    mark[vt[k]] = pid;
+                    curTets.push_back(vt[k]);
+                }
+            if ((int)curTets.size() > 65535) throw StateError("a single node touches more elements than the 16-bit element slot can hold");
+            owner[v] = pid;
+            localIdx[v] = (int)hNodes.size() - hNodePtr.back();
+            hNodes.push_back(v);
+        }
+        if ((int)hNodes.size() > hNodePtr.back()) closePatch();
     }
-    // Morton order of the rest positions (cubic cells so that thin directions collapse)
-    double ext = 0;
-    for (int c = 0; c < 3; ++c) ext = std::max(ext, mesh.bboxHi[c] - mesh.bboxLo[c]);
-    if (!(ext > 0)) ext = 1;
-    std::vector<std::pair<uint32_t, int>> keyed(nV);
-    for (int v = 0; v < nV; ++v) {
-        uint32_t q[3];
-        for (int c = 0; c < 3; ++c) q[c] = (uint32_t)std::min(1023.0, std::max(0.0, (mesh.V_rest[v + (size_t)nV * c] - mesh.bboxLo[c]) / ext * 1023.0));
-        keyed[v] = { morton3(q[0], q[1], q[2]), v };
-    }
-    std::sort(keyed.begin(), keyed.end());
-    // greedy patches: consecutive Morton nodes while the touched elements fit one phase-1 round
-    std::vector<int> hNodePtr{ 0 }, hNodes, hTetPtr{ 0 }, hTets;
-    std::vector<int> mark(nT, -1), owner(nV, -1), localIdx(nV, 0);
-    std::vector<int> curTets;
-    int pid = 0;
-    auto closePatch = [&]() {
-        std::sort(curTets.begin(), curTets.end());
-        hTets.insert(hTets.end(), curTets.begin(), curTets.end());
-        hTetPtr.push_back((int)hTets.size());
-        hNodePtr.push_back((int)hNodes.size());
-        curTets.clear();
-        ++pid;
-    };
-    for (int i = 0; i < nV; ++i) {
-        const int v = keyed[i].second;
-        int fresh = 0;
-        for (int k = vtPtr[v]; k < vtPtr[v + 1]; ++k)
-            if (mark[vt[k]] != pid) ++fresh;
-        if ((int)hNodes.size() > hNodePtr.back() && (int)curTets.size() + fresh > tetCap) closePatch();
-        for (int k = vtPtr[v]; k < vtPtr[v + 1]; ++k)
-            if (mark[vt[k]] != pid) {
-                mark[vt[k]] = pid;
-                curTets.push_back(vt[k]);
-            }
-        if ((int)curTets.size() > 65535) throw StateError("a single node touches more elements than the 16-bit element slot can hold");
-        owner[v] = pid;
-        localIdx[v] = (int)hNodes.size() - hNodePtr.back();
-        hNodes.push_back(v);
-    }
-    if ((int)hNodes.size() > hNodePtr.back()) closePatch();
-    nPatches = pid;
+    const std::vector<int>&vtPtr = topo.vtPtr, &vt = topo.vt, &vtLoc = topo.vtLoc;
+    const std::vector<int>&hNodePtr = topo.nodePtr, &hNodes = topo.nodes, &hTetPtr = topo.tetPtr, &hTets = topo.tets;
+    nPatches = (int)hNodePtr.size() - 1;
     totalTets = (long long)hTets.size();
     haloFactor = (double)totalTets / nT;
     maxTets = maxNodes = 0;
@@ -290,86 +311,120 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
         maxTets = std::max(maxTets, hTetPtr[p + 1] - hTetPtr[p]);
         maxNodes = std::max(maxNodes, hNodePtr[p + 1] - hNodePtr[p]);
     }
-    // gradient slots + phase-2 work items
-    std::vector<uint16_t> hGrad(4 * (size_t)totalTets, 0xFFFFu);
-    std::vector<int> hItemPtr{ 0 }, hP0, hRow, hCPtr;
-    std::vector<uint32_t> hMeta, hContrib;
-    std::vector<int> tetLocal(nT, -1);
-    auto pushItem = [&](int p0, int L, int segLen, int segPos, bool isDiag, int row, const uint32_t* cb, const uint32_t* ce) {
-        hP0.push_back(p0);
-        hMeta.push_back((uint32_t)L | ((uint32_t)segLen << 16) | ((uint32_t)segPos << 20) | ((uint32_t)(isDiag ? 1 : 0) << 24));
-        hRow.push_back(row);
-        hCPtr.push_back((int)hContrib.size());
-        hContrib.insert(hContrib.end(), cb, ce);
+    // gradient slots + phase-2 work items: per patch, independent of each other -- a few threads, each with its own output
+    std::vector<uint16_t> hGrad;
+    if (freshTopo) hGrad.assign(4 * (size_t)totalTets, 0xFFFFu);
+    struct Part {
+        std::vector<int> p0, row, cptr, itemEnd; // itemEnd[patch - first]: items of this part up to and including the patch
+        std::vector<uint32_t> meta, contrib;
     };
-    std::vector<uint32_t> cl;
-    for (int p = 0; p < nPatches; ++p) {
-        for (int inst = hTetPtr[p]; inst < hTetPtr[p + 1]; ++inst) {
-            const int t = hTets[inst];
-            tetLocal[t] = inst - hTetPtr[p];
-            for (int k = 0; k < 4; ++k) {
-                const int vv = mesh.F[t + (size_t)nT * k];
-                if (owner[vv] == p) hGrad[(size_t)k * totalTets + inst] = (uint16_t)localIdx[vv];
-            }
-        }
-        const int itemStart = (int)hP0.size();
-        auto addBlock = [&](int p0, int L, bool isDiag, int row) {
-            const int n = (int)cl.size();
-            const int chunk = std::max(CHUNK, (n + MAXSEG - 1) / MAXSEG);
-            const int segLen = std::max(1, (n + chunk - 1) / chunk);
-            // a block's chunks must stay inside one 16-lane DPP row
-            const int posInRow = ((int)hP0.size() - itemStart) % 16;
-            if (posInRow + segLen > 16)
-                for (int pad = posInRow; pad < 16; ++pad) pushItem(-1, 0, 1, 0, false, 0, nullptr, nullptr);
-            for (int sgi = 0; sgi < segLen; ++sgi) {
-                const int b = sgi * chunk, e = std::min(n, b + chunk);
-                pushItem(p0, L, segLen, sgi, isDiag, row, cl.data() + b, cl.data() + e);
-            }
+    const int nThreads = std::max(1, std::min(8, std::min((int)std::thread::hardware_concurrency(), nPatches / 64 + 1)));
+    std::vector<Part> parts(nThreads);
+    auto work = [&](int ti) {
+        Part& P = parts[ti];
+        const int pBeg = (int)((long long)nPatches * ti / nThreads), pEnd = (int)((long long)nPatches * (ti + 1) / nThreads);
+        std::vector<int> tetLocal(nT, -1);
+        std::vector<uint32_t> cl;
+        auto pushItem = [&](int p0, int L, int segLen, int segPos, bool isDiag, int row, const uint32_t* cb, const uint32_t* ce) {
+            P.p0.push_back(p0);
+            P.meta.push_back((uint32_t)L | ((uint32_t)segLen << 16) | ((uint32_t)segPos << 20) | ((uint32_t)(isDiag ? 1 : 0) << 24));
+            P.row.push_back(row);
+            P.cptr.push_back((int)P.contrib.size());
+            P.contrib.insert(P.contrib.end(), cb, ce);
         };
-        for (int j = hNodePtr[p]; j < hNodePtr[p + 1]; ++j) {
-            const int vv = hNodes[j];
-            const int L = lin.rowLen[vv], base = lin.rowBase[vv];
-            // diagonal block: every incident element
-            cl.clear();
-            for (int k = vtPtr[vv]; k < vtPtr[vv + 1]; ++k)
-                cl.push_back((uint32_t)tetLocal[vt[k]] | ((uint32_t)vtLoc[k] << 16) | ((uint32_t)vtLoc[k] << 18));
-            addBlock(base, L, true, vv);
-            // off-diagonal blocks (vv, n), n > vv ascending: elements containing both
-            const int nUp = (L - 3) / 3;
-            for (int r = 0; r < nUp; ++r) {
-                const int n = lin.ja[base + 3 + 3 * r] / 3;
-                cl.clear();
-                for (int k = vtPtr[vv]; k < vtPtr[vv + 1]; ++k) {
-                    const int t = vt[k];
-                    for (int kk = 0; kk < 4; ++kk)
-                        if (mesh.F[t + (size_t)nT * kk] == n)
-                            cl.push_back((uint32_t)tetLocal[t] | ((uint32_t)vtLoc[k] << 16) | ((uint32_t)kk << 18));
-                }
-                addBlock(base + 3 + 3 * r, L, false, vv);
+        for (int p = pBeg; p < pEnd; ++p) {
+            for (int inst = hTetPtr[p]; inst < hTetPtr[p + 1]; ++inst) {
+                const int t = hTets[inst];
+                tetLocal[t] = inst - hTetPtr[p];
+                if (freshTopo)
+                    for (int k = 0; k < 4; ++k) {
+                        const int vv = mesh.F[t + (size_t)nT * k];
+                        if (owner[vv] == p) hGrad[(size_t)k * totalTets + inst] = (uint16_t)localIdx[vv];
+                    }
             }
+            const int itemStart = (int)P.p0.size();
+            auto addBlock = [&](int p0, int L, bool isDiag, int row) {
+                const int n = (int)cl.size();
+                const int chunk = std::max(CHUNK, (n + MAXSEG - 1) / MAXSEG);
+                const int segLen = std::max(1, (n + chunk - 1) / chunk);
+                // a block's chunks must stay inside one 16-lane DPP row
+                const int posInRow = ((int)P.p0.size() - itemStart) % 16;
+                if (posInRow + segLen > 16)
+                    for (int pad = posInRow; pad < 16; ++pad) pushItem(-1, 0, 1, 0, false, 0, nullptr, nullptr);
+                for (int sgi = 0; sgi < segLen; ++sgi) {
+                    const int b = sgi * chunk, e = std::min(n, b + chunk);
+                    pushItem(p0, L, segLen, sgi, isDiag, row, cl.data() + b, cl.data() + e);
+                }
+            };
+            for (int j = hNodePtr[p]; j < hNodePtr[p + 1]; ++j) {
+                const int vv = hNodes[j];
+                const int L = lin.rowLen[vv], base = lin.rowBase[vv];
+                // diagonal block: every incident element
+                cl.clear();
+                for (int k = vtPtr[vv]; k < vtPtr[vv + 1]; ++k)
+                    cl.push_back((uint32_t)tetLocal[vt[k]] | ((uint32_t)vtLoc[k] << 16) | ((uint32_t)vtLoc[k] << 18));
+                addBlock(base, L, true, vv);
+                // off-diagonal blocks (vv, n), n > vv ascending: elements containing both
+                const int nUp = (L - 3) / 3;
+                for (int r = 0; r < nUp; ++r) {
+                    const int n = lin.ja[base + 3 + 3 * r] / 3;
+                    cl.clear();
+                    for (int k = vtPtr[vv]; k < vtPtr[vv + 1]; ++k) {
+                        const int t = vt[k];
+                        for (int kk = 0; kk < 4; ++kk)
+                            if (mesh.F[t + (size_t)nT * kk] == n)
+                                cl.push_back((uint32_t)tetLocal[t] | ((uint32_t)vtLoc[k] << 16) | ((uint32_t)kk << 18));
+                    }
+                    addBlock(base + 3 + 3 * r, L, false, vv);
+                }
+            }
+            P.itemEnd.push_back((int)P.p0.size());
+            for (int inst = hTetPtr[p]; inst < hTetPtr[p + 1]; ++inst) tetLocal[hTets[inst]] = -1;
         }
-        hItemPtr.push_back((int)hP0.size());
-        for (int inst = hTetPtr[p]; inst < hTetPtr[p + 1]; ++inst) tetLocal[hTets[inst]] = -1;
+    };
+    if (nThreads == 1) work(0);
+    else {
+        std::vector<std::thread> pool;
+        for (int ti = 0; ti < nThreads; ++ti) pool.emplace_back(work, ti);
+        for (auto& th : pool) th.join();
     }
-    hCPtr.push_back((int)hContrib.size());
-    totalItems = (long long)hP0.size();
-    totalContribs = (long long)hContrib.size();
+    // concatenate the parts (item and contribution offsets shift by what came before)
+    size_t nItems = 0, nContrib = 0;
+    for (const Part& P : parts) {
+        nItems += P.p0.size();
+        nContrib += P.contrib.size();
+    }
+    totalItems = (long long)nItems;
+    totalContribs = (long long)nContrib;
+    std::vector<int> hItemPtr{ 0 };
+    hItemPtr.reserve(nPatches + 1);
+    std::vector<uint32_t> hContrib;
+    hContrib.reserve(std::max<size_t>(nContrib, 1));
+    std::vector<int4> hHdr(nItems);
+    std::vector<uint4> hC4(nItems);
+    size_t itemBase = 0;
+    for (const Part& P : parts) {
+        const size_t cBase = hContrib.size();
+        for (size_t i = 0; i < P.p0.size(); ++i) {
+            const int c0 = P.cptr[i], n = (int)((i + 1 < P.p0.size() ? (size_t)P.cptr[i + 1] : P.contrib.size()) - (size_t)c0);
+            if (n > 127) throw StateError("more than 127 element contributions in one chunk of a CSR block");
+            hHdr[itemBase + i] = make_int4(P.p0[i], (int)(P.meta[i] | ((uint32_t)n << 25)), P.row[i], (int)(cBase + c0));
+            uint32_t w[4] = { 0, 0, 0, 0 };
+            for (int k = 0; k < 4 && k < n; ++k) w[k] = P.contrib[c0 + k];
+            hC4[itemBase + i] = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+        for (int e : P.itemEnd) hItemPtr.push_back((int)(itemBase + e));
+        hContrib.insert(hContrib.end(), P.contrib.begin(), P.contrib.end());
+        itemBase += P.p0.size();
+    }
     if (hContrib.empty()) hContrib.push_back(0);
-    std::vector<int4> hHdr(hP0.size());
-    std::vector<uint4> hC4(hP0.size());
-    for (size_t i = 0; i < hP0.size(); ++i) {
-        const int c0 = hCPtr[i], n = hCPtr[i + 1] - c0;
-        if (n > 127) throw StateError("more than 127 element contributions in one chunk of a CSR block");
-        hHdr[i] = make_int4(hP0[i], (int)(hMeta[i] | ((uint32_t)n << 25)), hRow[i], c0);
-        uint32_t w[4] = { 0, 0, 0, 0 };
-        for (int k = 0; k < 4 && k < n; ++k) w[k] = hContrib[c0 + k];
-        hC4[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    if (freshTopo) {
+        nodePtr.upload(hNodePtr, s);
+        nodes.upload(hNodes, s);
+        tetPtr.upload(hTetPtr, s);
+        tets.upload(hTets, s);
+        gradSlot.upload(hGrad, s);
     }
-    nodePtr.upload(hNodePtr, s);
-    nodes.upload(hNodes, s);
-    tetPtr.upload(hTetPtr, s);
-    tets.upload(hTets, s);
-    gradSlot.upload(hGrad, s);
     itemPtr.upload(hItemPtr, s);
     itemHdr.upload(hHdr, s);
     itemC4.upload(hC4, s);
