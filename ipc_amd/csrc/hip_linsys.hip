@@ -3,6 +3,7 @@
 #include "hip_ipc.h"
 #include <rocsolver/rocsolver.h>
 #include <algorithm>
+#include <thread>
 #include <cstdlib>
 
 namespace ipcgpu {
@@ -62,59 +63,105 @@ HipLinSysSolver::~HipLinSysSolver() = default;
 void HipLinSysSolver::set_pattern(const HipMesh& mesh, int nExtra, const int* extraPairs)
 {
     const int nV = mesh.nV;
-    // neighbours > v, ascending: mesh vNeighbor merged with the extra (contact) pairs
-    std::vector<std::vector<int>> up(nV);
+    // neighbours > v, ascending: mesh vNeighbor merged with the extra (contact) pairs.  Flat CSR-like storage (counting pass,
+    // fill pass, per-node sort + unique) and a few threads over node ranges: this runs on every change of the contact pattern.
+    for (int i = 0; i < nExtra; ++i) {
+        const int a = extraPairs[2 * i], b = extraPairs[2 * i + 1];
+        if (a < 0 || b < 0 || a >= nV || b >= nV) throw ArgError("set_pattern: extra pair out of range");
+    }
+    std::vector<int> upPtr(nV + 1, 0);
     for (int v = 0; v < nV; ++v)
         for (int k = mesh.nbPtr[v]; k < mesh.nbPtr[v + 1]; ++k)
-            if (mesh.nb[k] > v) up[v].push_back(mesh.nb[k]);
+            if (mesh.nb[k] > v) upPtr[v + 1]++;
     for (int i = 0; i < nExtra; ++i) {
-        int a = extraPairs[2 * i], b = extraPairs[2 * i + 1];
-        if (a < 0 || b < 0 || a >= nV || b >= nV) throw ArgError("set_pattern: extra pair out of range");
-        if (a == b) continue;
-        up[std::min(a, b)].push_back(std::max(a, b));
+        const int a = extraPairs[2 * i], b = extraPairs[2 * i + 1];
+        if (a != b) upPtr[std::min(a, b) + 1]++;
     }
+    for (int v = 0; v < nV; ++v) upPtr[v + 1] += upPtr[v];
+    std::vector<int> upRaw(upPtr[nV]), upCnt(nV, 0);
+    {
+        std::vector<int> pos(upPtr.begin(), upPtr.end() - 1);
+        for (int v = 0; v < nV; ++v)
+            for (int k = mesh.nbPtr[v]; k < mesh.nbPtr[v + 1]; ++k)
+                if (mesh.nb[k] > v) upRaw[pos[v]++] = mesh.nb[k];
+        for (int i = 0; i < nExtra; ++i) {
+            const int a = extraPairs[2 * i], b = extraPairs[2 * i + 1];
+            if (a != b) upRaw[pos[std::min(a, b)]++] = std::max(a, b);
+        }
+    }
+    const int nThreads = std::max(1, std::min(8, std::min((int)std::thread::hardware_concurrency(), nV / 4096 + 1)));
+    auto parallel = [&](auto&& body) {
+        if (nThreads == 1) {
+            body(0, nV);
+            return;
+        }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nThreads; ++t)
+            pool.emplace_back([&, t] { body((int)((long long)nV * t / nThreads), (int)((long long)nV * (t + 1) / nThreads)); });
+        for (auto& th : pool) th.join();
+    };
+    parallel([&](int v0, int v1) {
+        for (int v = v0; v < v1; ++v) {
+            int* b = upRaw.data() + upPtr[v];
+            int* e = upRaw.data() + upPtr[v + 1];
+            std::sort(b, e);
+            upCnt[v] = (int)(std::unique(b, e) - b);
+        }
+    });
     numRows = 3 * nV;
     ia.assign(numRows + 1, 0);
     rowBase.assign(nV, 0);
     rowLen.assign(nV, 0);
     for (int v = 0; v < nV; ++v) {
-        auto& u = up[v];
-        std::sort(u.begin(), u.end());
-        u.erase(std::unique(u.begin(), u.end()), u.end());
-        const int nnz = 3 + 3 * (int)u.size(); // LinSysSolver.hpp:63-111: row 3v has nnz, 3v+1 nnz-1, 3v+2 nnz-2 entries
+        const int nnz = 3 + 3 * upCnt[v]; // LinSysSolver.hpp:63-111: row 3v has nnz, 3v+1 nnz-1, 3v+2 nnz-2 entries
         ia[3 * v + 1] = ia[3 * v] + nnz;
         ia[3 * v + 2] = ia[3 * v + 1] + nnz - 1;
         ia[3 * v + 3] = ia[3 * v + 2] + nnz - 2;
         rowBase[v] = ia[3 * v];
         rowLen[v] = nnz;
     }
-    ja.assign(ia[numRows], 0);
-    for (int v = 0; v < nV; ++v) {
-        for (int r = 0; r < 3; ++r) {
-            int p = ia[3 * v + r];
-            for (int c = r; c < 3; ++c) ja[p++] = 3 * v + c;
-            for (int nbv : up[v])
-                for (int c = 0; c < 3; ++c) ja[p++] = 3 * nbv + c;
+    ja.resize(ia[numRows]);
+    parallel([&](int v0, int v1) {
+        for (int v = v0; v < v1; ++v) {
+            const int* u = upRaw.data() + upPtr[v];
+            for (int r = 0; r < 3; ++r) {
+                int p = ia[3 * v + r];
+                for (int c = r; c < 3; ++c) ja[p++] = 3 * v + c;
+                for (int q = 0; q < upCnt[v]; ++q)
+                    for (int c = 0; c < 3; ++c) ja[p++] = 3 * u[q] + c;
+            }
         }
-    }
-    d_ia.upload(ia, stream);
-    d_ja.upload(ja, stream);
-    d_a.alloc(ja.size());
-    d_a.zero(stream);
-    d_rowBase.upload(rowBase, stream);
-    d_rowLen.upload(rowLen, stream);
+    });
+    d_ia.uploadGrow(ia, stream);
+    d_ja.uploadGrow(ja, stream);
+    d_a.ensure(ja.size());
+    d_a.zeroN(ja.size(), stream);
+    d_rowBase.uploadGrow(rowBase, stream);
+    d_rowLen.uploadGrow(rowLen, stream);
     // tet edge -> first slot of its 3x3 block in row 3*min: ia[3 vmin] + 3 + 3 * rank(vmax among up[vmin])
     std::vector<int> edgeP0(6 * (size_t)mesh.nT);
     static const int ea[6] = { 0, 0, 0, 1, 1, 2 }, eb[6] = { 1, 2, 3, 2, 3, 3 };
-    for (int t = 0; t < mesh.nT; ++t)
-        for (int e = 0; e < 6; ++e) {
-            const int va = mesh.F[t + (size_t)mesh.nT * ea[e]], vb = mesh.F[t + (size_t)mesh.nT * eb[e]];
-            const int lo = std::min(va, vb), hi = std::max(va, vb);
-            const auto& u = up[lo];
-            const int rank = int(std::lower_bound(u.begin(), u.end(), hi) - u.begin());
-            edgeP0[(size_t)e * mesh.nT + t] = rowBase[lo] + 3 + 3 * rank;
+    {
+        const int nT = mesh.nT;
+        auto edges = [&](int t0, int t1) {
+            for (int t = t0; t < t1; ++t)
+                for (int e = 0; e < 6; ++e) {
+                    const int va = mesh.F[t + (size_t)nT * ea[e]], vb = mesh.F[t + (size_t)nT * eb[e]];
+                    const int lo = std::min(va, vb), hi = std::max(va, vb);
+                    const int* ub = upRaw.data() + upPtr[lo];
+                    const int rank = int(std::lower_bound(ub, ub + upCnt[lo], hi) - ub);
+                    edgeP0[(size_t)e * nT + t] = rowBase[lo] + 3 + 3 * rank;
+                }
+        };
+        if (nThreads == 1 || nT < 8192) edges(0, nT);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nThreads; ++t)
+                pool.emplace_back([&, t] { edges((int)((long long)nT * t / nThreads), (int)((long long)nT * (t + 1) / nThreads)); });
+            for (auto& th : pool) th.join();
         }
-    d_edgeP0.upload(edgeP0, stream);
+    }
+    d_edgeP0.uploadGrow(edgeP0, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
     analyzed_ = false;
     ++patternVersion;
@@ -142,7 +189,7 @@ void HipLinSysSolver::set_pattern_csr(int nRows, const int* ia_, const int* ja_)
     ++patternVersion;
 }
 
-void HipLinSysSolver::setZero() { d_a.zero(stream); }
+void HipLinSysSolver::setZero() { d_a.zeroN(ja.size(), stream); }
 
 int HipLinSysSolver::findEntry(int row, int col) const
 {

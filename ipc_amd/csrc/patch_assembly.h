@@ -57,6 +57,10 @@ struct PatchPlan {
         std::vector<int> vtPtr, vt, vtLoc, nodePtr, nodes, tetPtr, tets;
     } topo;
 
+    PinnedBuf<int4> hHdrPin; // pinned staging of the work items (grow-only): they are rebuilt and shipped on every pattern change
+    PinnedBuf<uint4> hC4Pin;
+    PinnedBuf<uint32_t> hContribPin;
+
     void build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream_t s);
     PatchView view() const;
     size_t ldsBytes() const;

@@ -4,6 +4,7 @@
 #include "nh_device.h"
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 #include <numeric>
 #include <thread>
 
@@ -398,13 +399,16 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
     totalContribs = (long long)nContrib;
     std::vector<int> hItemPtr{ 0 };
     hItemPtr.reserve(nPatches + 1);
-    std::vector<uint32_t> hContrib;
-    hContrib.reserve(std::max<size_t>(nContrib, 1));
-    std::vector<int4> hHdr(nItems);
-    std::vector<uint4> hC4(nItems);
-    size_t itemBase = 0;
+    if (hHdrPin.n < nItems) {
+        hHdrPin.alloc(nItems + nItems / 2 + 16);
+        hC4Pin.alloc(nItems + nItems / 2 + 16);
+    }
+    if (hContribPin.n < nContrib + 1) hContribPin.alloc(nContrib + nContrib / 2 + 16);
+    int4* hHdr = hHdrPin.p;
+    uint4* hC4 = hC4Pin.p;
+    uint32_t* hContrib = hContribPin.p;
+    size_t itemBase = 0, cBase = 0;
     for (const Part& P : parts) {
-        const size_t cBase = hContrib.size();
         for (size_t i = 0; i < P.p0.size(); ++i) {
             const int c0 = P.cptr[i], n = (int)((i + 1 < P.p0.size() ? (size_t)P.cptr[i + 1] : P.contrib.size()) - (size_t)c0);
             if (n > 127) throw StateError("more than 127 element contributions in one chunk of a CSR block");
@@ -414,10 +418,11 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
             hC4[itemBase + i] = make_uint4(w[0], w[1], w[2], w[3]);
         }
         for (int e : P.itemEnd) hItemPtr.push_back((int)(itemBase + e));
-        hContrib.insert(hContrib.end(), P.contrib.begin(), P.contrib.end());
+        if (!P.contrib.empty()) std::memcpy(hContrib + cBase, P.contrib.data(), P.contrib.size() * sizeof(uint32_t));
+        cBase += P.contrib.size();
         itemBase += P.p0.size();
     }
-    if (hContrib.empty()) hContrib.push_back(0);
+    if (nContrib == 0) hContrib[0] = 0;
     if (freshTopo) {
         nodePtr.upload(hNodePtr, s);
         nodes.upload(hNodes, s);
@@ -425,10 +430,15 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
         tets.upload(hTets, s);
         gradSlot.upload(hGrad, s);
     }
-    itemPtr.upload(hItemPtr, s);
-    itemHdr.upload(hHdr, s);
-    itemC4.upload(hC4, s);
-    contrib.upload(hContrib, s);
+    itemPtr.uploadGrow(hItemPtr, s);
+    itemHdr.ensure(nItems);
+    itemC4.ensure(nItems);
+    contrib.ensure(std::max<size_t>(nContrib, 1));
+    if (nItems) {
+        HIP_CHECK(hipMemcpyAsync(itemHdr.p, hHdr, nItems * sizeof(int4), hipMemcpyHostToDevice, s));
+        HIP_CHECK(hipMemcpyAsync(itemC4.p, hC4, nItems * sizeof(uint4), hipMemcpyHostToDevice, s));
+    }
+    HIP_CHECK(hipMemcpyAsync(contrib.p, hContrib, std::max<size_t>(nContrib, 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     HIP_CHECK(hipStreamSynchronize(s));
     valid = true;
 }
