@@ -175,6 +175,13 @@ int ipcgpu_get_surface(ipcgpu_ctx*, int* counts3 /*nSVI,nSF,nSFEdges*/, int* SVI
    (a scene with `meshCO` but `selfCollisionOff`: Optimizer.cpp:2448-2470 asks only the collision objects).  Bounding box and
    mean nodal mass (dHat, kappa) are taken over element nodes, so the obstacle does not change them.  Call after set_surface. */
 int ipcgpu_set_obstacle_nodes(ipcgpu_ctx*, int n, const int* vert_ids, int obstacle_only);
+/* Surface-only ("codimensional") components of the simulated mesh: nodes of no tetrahedron that nevertheless belong to Mesh<3> --
+ * the triangle meshes listed under `shapes` (componentCoDim 2; src/main.cpp, src/Mesh.cpp:310-345).  Unlike the nodes of a MeshCO
+ * (ipcgpu_set_obstacle_nodes), which the reference keeps outside the mesh, they count in the bounding box behind dHat and in the
+ * mean nodal mass behind kappa, and carry lumped masses: density x a third of the areas of the adjacent triangles.  The scripts
+ * fix or move them as Dirichlet nodes (`script DCOFix`: ipcgpu_set_dbc(ids, NONZERO)).  Call after ipcgpu_set_mesh, before
+ * ipcgpu_opt_init / ipcgpu_opt_enable_self_collision. */
+int ipcgpu_set_codim_nodes(ipcgpu_ctx*, int n, const int* node_ids, const double* node_mass);
 /* SelfCollisionHandler::computeConstraintSet (SelfCollisionHandler.cpp:2149-2478) at the current positions:
  * MMActiveSet (PP / PE duplicates merged, multiplicity in slot 3), paraEEMMCVIDSet + paraEEeIeJSet, and the
  * candidate list for the partial CCD.  counts3 = {nActive, nParaEE, nCandidates}. */

@@ -658,6 +658,17 @@ int ipcgpu_contact_build(ipcgpu_ctx* c, double dHat, int* counts)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_set_codim_nodes(ipcgpu_ctx* c, int n, const int* ids, const double* mass)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        needArg(n >= 0 && ((ids && mass) || !n), "bad codimensional node list");
+        need(!c->opt->initialised, "ipcgpu_set_codim_nodes must come before ipcgpu_opt_init (dHat and kappa derive from the mesh extent and mass)");
+        m.setCodimNodes(n, ids, mass, c->stream);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_set_obstacle_nodes(ipcgpu_ctx* c, int n, const int* ids, int only)
 {
     return guarded([&] {

@@ -41,6 +41,11 @@ public:
     // Mesh::computeFeatures + computeMassMatrix + setLameParam (Mesh.cpp:414-527, 246-266, 399-401, 660-671)
     unsigned featuresVersion = 0; // bumped by every computeFeatures: host-side caches of mesh topology key on it
     void computeFeatures(int nV, int nT, const double* Vrest, const int* F, double YM, double PR, double density, hipStream_t s);
+    // surface-only nodes that belong to the mesh (triangle meshes under `shapes`, componentCoDim 2): they count in the bounding box
+    // and the mean nodal mass and carry the given lumped masses (Mesh.cpp:310-345)
+    std::vector<char> inMesh; // per node: referenced by an element, or declared by setCodimNodes
+    void setCodimNodes(int n, const int* ids, const double* nodeMass, hipStream_t s);
+    void meshBBox(); // bounding box and node count over inMesh (Mesh::matSpaceBBoxSize2 and avgNodeMass take all of Mesh<3>)
     void uploadDBC(hipStream_t s);
     int energyType = 0; // Config `energy NH|FCR` (Config.cpp:23-24): 0 neo-Hookean, 1 fixed corotated
     double density = 0; // global density handed to computeFeatures (component overrides rescale the nodal mass by rho / density)

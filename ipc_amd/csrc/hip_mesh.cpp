@@ -82,24 +82,12 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
     nb.resize(edges.size());
     for (size_t i = 0; i < edges.size(); ++i) nb[i] = edges[i].second;
     // bounding box of the simulated material (Mesh::matSpaceBBoxSize2): nodes of elements only -- a kinematic obstacle riding
-    // along as a surface-only component must not change dHat = dHatEps^2 * diagonal^2
-    std::vector<char> inElem(nV, 0);
+    // along as a surface-only component must not change dHat = dHatEps^2 * diagonal^2.  (Surface-only components that DO belong
+    // to the mesh are declared afterwards: setCodimNodes.)
+    inMesh.assign(nV, 0);
     for (int t = 0; t < nT; ++t)
-        for (int k = 0; k < 4; ++k) inElem[F[t + (size_t)nT * k]] = 1;
-    nElemNodes = 0;
-    for (int v = 0; v < nV; ++v) nElemNodes += inElem[v];
-    bboxDiag2 = 0;
-    for (int c = 0; c < 3; ++c) {
-        double lo = 1e300, hi = -1e300;
-        for (int v = 0; v < nV; ++v) {
-            if (nT && !inElem[v]) continue;
-            lo = std::min(lo, X(v, c));
-            hi = std::max(hi, X(v, c));
-        }
-        bboxLo[c] = lo;
-        bboxHi[c] = hi;
-        bboxDiag2 += (hi - lo) * (hi - lo);
-    }
+        for (int k = 0; k < 4; ++k) inMesh[F[t + (size_t)nT * k]] = 1;
+    meshBBox();
     // upload
     std::vector<double> aos(3 * (size_t)nV);
     for (int v = 0; v < nV; ++v)
@@ -115,6 +103,39 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
     for (int t = 0; t < nT; ++t) tets[t] = make_int4(Fc[t], Fc[t + (size_t)nT], Fc[t + 2 * (size_t)nT], Fc[t + 3 * (size_t)nT]);
     d_tet.upload(tets.data(), tets.size(), s);
     uploadDBC(s);
+    HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void HipMesh::meshBBox()
+{
+    nElemNodes = 0;
+    for (int v = 0; v < nV; ++v) nElemNodes += inMesh[v];
+    bboxDiag2 = 0;
+    for (int c = 0; c < 3; ++c) {
+        double lo = 1e300, hi = -1e300;
+        for (int v = 0; v < nV; ++v) {
+            if (nElemNodes && !inMesh[v]) continue;
+            lo = std::min(lo, V_rest[v + (size_t)nV * c]);
+            hi = std::max(hi, V_rest[v + (size_t)nV * c]);
+        }
+        bboxLo[c] = lo;
+        bboxHi[c] = hi;
+        bboxDiag2 += (hi - lo) * (hi - lo);
+    }
+}
+
+void HipMesh::setCodimNodes(int n, const int* ids, const double* nodeMass, hipStream_t s)
+{
+    for (int i = 0; i < n; ++i) {
+        if (ids[i] < 0 || ids[i] >= nV) throw ArgError("set_codim_nodes: node id out of range");
+        if (!(nodeMass[i] >= 0.0)) throw ArgError("set_codim_nodes: negative mass");
+    }
+    for (int i = 0; i < n; ++i) {
+        inMesh[ids[i]] = 1;
+        mass[ids[i]] = nodeMass[i];
+    }
+    meshBBox();
+    d_mass.upload(mass, s);
     HIP_CHECK(hipStreamSynchronize(s));
 }
 

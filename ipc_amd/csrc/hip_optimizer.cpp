@@ -13,6 +13,7 @@
 #include <sstream>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <iterator>
 #include <cmath>
 #include <cstring>
@@ -723,10 +724,33 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
             }
             lap("set_pattern");
             {
-                Tic t(timers[2], stream);
-                lin.analyze_pattern(&mesh);
+                // the assembly plan of the new pattern is built on a second host thread while this one runs the symbolic analysis:
+                // both only read the pattern, and the GPU is idle either way
+                int dev = 0;
+                HIP_CHECK(hipGetDevice(&dev));
+                std::exception_ptr planErr;
+                std::thread planThread([&] {
+                    try {
+                        HIP_CHECK(hipSetDevice(dev));
+                        ensurePatchPlan();
+                    }
+                    catch (...) {
+                        planErr = std::current_exception();
+                    }
+                });
+                std::exception_ptr anaErr;
+                try {
+                    Tic t(timers[2], stream);
+                    lin.analyze_pattern(&mesh);
+                }
+                catch (...) {
+                    anaErr = std::current_exception();
+                }
+                planThread.join();
+                if (anaErr) std::rethrow_exception(anaErr);
+                if (planErr) std::rethrow_exception(planErr);
             }
-            lap("analyze_pattern");
+            lap("analyze_pattern + patch plan");
         }
     }
     // setZero (Optimizer.cpp:3616), elastic Hessian (:3619-3623) and the mass / DBC diagonal (:3638-3668) are one

@@ -325,6 +325,12 @@ class Context:
         SF = np.asfortranarray(SF, dtype=np.int32)
         self._chk(self._L.ipcgpu_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF)))
 
+    def set_codim_nodes(self, ids, mass):
+        """Surface-only nodes that belong to the mesh (triangle meshes under `shapes`): they count in bounding box and mean mass."""
+        ids = _i32(ids)
+        m = _f64(np.asarray(mass, dtype=np.float64))
+        self._chk(self._L.ipcgpu_set_codim_nodes(self.h, C.c_int(len(ids)), _ip(ids), _dp(m)))
+
     def set_obstacle(self, ids, obstacle_only=False):
         ids = _i32(ids)
         self._chk(self._L.ipcgpu_set_obstacle_nodes(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(int(obstacle_only))))

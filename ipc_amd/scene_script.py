@@ -108,7 +108,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright"):
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix"):
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
             elif k == "warmStart":  # initX option (Optimizer.cpp:925-1080); 5 (Jacobi guess) is not restated
@@ -154,6 +154,22 @@ class SceneConfig:
                         i += 1
                     cfg.shapes.append(_parse_shape(toks, resolve))
                     got += 1
+            elif k == "shapeMatrix":  # Config.cpp:319-378: one shape replicated on an nx x ny x nz grid
+                if a[0] != "input":
+                    raise UnsupportedKeyword(f"shapeMatrix {a[0]}")
+                cnt = [int(x) for x in a[1:4]]
+                pos = [float(x) for x in a[4:7]] + [0.0] * (3 - len(a[4:7]))
+                st = lines[i].split()
+                i += 1
+                if st[0].lower().endswith((".seg", ".pt")):
+                    raise UnsupportedKeyword("codimensional shape (.seg / .pt)")
+                step = np.array([float(x) for x in st[1:4]])
+                rot, scl = np.array([float(x) for x in st[4:7]]), np.array([float(x) for x in st[7:10]])
+                mat = tuple(float(x) for x in st[11:14]) if len(st) > 13 and st[10] == "material" else None
+                for xi in range(cnt[0]):
+                    for yi in range(cnt[1]):
+                        for zi in range(cnt[2]):
+                            cfg.shapes.append(Shape(resolve(st[0]), np.array(pos) + step * np.array([xi, yi, zi]), rot, scl, material=mat))
             elif k == "ground":  # friction, height (Config.cpp:425-430)
                 cfg.half_spaces.append((np.array([0.0, float(a[1]), 0.0]), np.array([0.0, 1.0, 0.0]), float(a[0])))
             elif k == "halfSpace":  # origin, normal, stiffness (unused), friction (Config.cpp:431-447)
@@ -219,6 +235,8 @@ class SceneConfig:
 
 
 def _parse_shape(st, resolve):
+    if st[0].lower().endswith((".seg", ".pt")):  # componentCoDim 1 / 0 (main.cpp:957-1030): segment and point clouds are not rebuilt
+        raise UnsupportedKeyword("codimensional shape (.seg / .pt)")
     sh = Shape(resolve(st[0]), np.array([float(x) for x in st[1:4]]), np.array([float(x) for x in st[4:7]]), np.array([float(x) for x in st[7:10]]))
     j = 10
     while j < len(st):
@@ -300,6 +318,9 @@ class AssembledScene:
     neumann: list = field(default_factory=list)  # (ids, acceleration, t0, t1)
     obstacle_nodes: np.ndarray = None  # nodes of the kinematic mesh obstacles (surface-only components, no tetrahedra)
     release: dict = None  # state-dependent end of a scripted handle (`script dragright`)
+    codim_nodes: np.ndarray = None  # surface-only nodes of the mesh itself (triangle meshes under `shapes`, componentCoDim 2) ...
+    codim_mass: np.ndarray = None  # ... and their lumped masses (density x a third of the adjacent triangle areas, Mesh.cpp:310-345)
+    codim_fixed: np.ndarray = None  # `script DCOFix`: those of them held as NONZERO Dirichlet nodes (AnimScripter.cpp:1222-1236)
 
     def before_step(self, be, t):
         """What AnimScripter::stepAnimScript decides from the state before a time step (call with the step's start time)."""
@@ -317,8 +338,16 @@ class AssembledScene:
 def assemble(cfg, read_mesh):
     """main.cpp:880-1198: select Dirichlet / Neumann nodes per shape on the mesh as read, transform the shape (R (p * scale) + translate), concatenate."""
     Vs, Ts, SFs, nr, tr, dirichlet, neumann = [], [], [], [0], [0], [], []
+    codim = []  # (node ids, triangles) of the surface-only components of the mesh
     for sh in cfg.shapes:
-        V, T, SF = read_mesh(sh.path)
+        is_codim = sh.path.lower().endswith(".obj")  # main.cpp:948-956: a triangle mesh under `shapes` is a kinematic surface
+        if is_codim:
+            V, SF = read_obj(sh.path)
+            T = np.zeros((0, 4), dtype=np.int32)
+        elif sh.path.lower().endswith((".seg", ".pt")):
+            raise UnsupportedKeyword("codimensional shape (.seg / .pt)")
+        else:
+            V, T, SF = read_mesh(sh.path)
         off = nr[-1]
         # Dirichlet / Neumann nodes are picked on the mesh AS READ (IglUtils::Init_Dirichlet on newV, main.cpp:1045-1068); the
         # shape is scaled / rotated / translated only afterwards (main.cpp:1073-1077), so the relative box follows the shape
@@ -334,6 +363,8 @@ def assemble(cfg, read_mesh):
         if sh.lin_vel is not None or sh.ang_vel_deg is not None:  # scripted component: every node moves (AnimScripter.cpp:1413-1435)
             ids = np.arange(V.shape[0], dtype=np.int32) + off
             dirichlet.append((ids, sh.lin_vel or (0, 0, 0), sh.ang_vel_deg or (0, 0, 0), 0.0, float("inf")))
+        if is_codim:
+            codim.append((np.arange(off, off + V.shape[0], dtype=np.int32), SF + off, sh.lin_vel is not None or sh.ang_vel_deg is not None))
         Vs.append(V)
         Ts.append(T + off)
         SFs.append(SF + off)
@@ -359,6 +390,22 @@ def assemble(cfg, read_mesh):
         if cfg.script == "fall":  # Mesh<3> only: the obstacles are not part of it in the reference
             V[:nSim, 1] += 0.5 * np.linalg.norm(V[:nSim].max(0) - V[:nSim].min(0))
         dirichlet = []
+    codim_nodes = codim_mass = codim_fixed = None
+    if codim:
+        codim_nodes = np.concatenate([ids for ids, _f, _m in codim])
+        m = np.zeros(V.shape[0])
+        for _ids, tri, _m in codim:  # barycentric lumping of the triangle areas times the density (Mesh.cpp:318-343, 399)
+            a = 0.5 * np.linalg.norm(np.cross(V[tri[:, 1]] - V[tri[:, 0]], V[tri[:, 2]] - V[tri[:, 0]]), axis=1)
+            for k in range(3):
+                np.add.at(m, tri[:, k], cfg.rho * a / 3.0)
+        codim_mass = m[codim_nodes]
+        if cfg.script == "DCOFix":  # AnimScripter.cpp:1222-1236: every codimensional component is held (NONZERO, no motion)
+            dirichlet = []
+            codim_fixed = codim_nodes
+        elif not all(moved for _i, _f, moved in codim):
+            raise UnsupportedKeyword("codimensional shape that no script fixes or moves")
+    elif cfg.script == "DCOFix":
+        dirichlet = []  # mesh.resetDBCVertices(); nothing to hold
     release = None
     if cfg.script == "dragright":
         # AnimScripter.cpp:809-826: lifted like `fall`, the nodes within 4 % of the right end of the body become a NONZERO handle
@@ -383,13 +430,15 @@ def assemble(cfg, read_mesh):
         v[fixed[a:b]] = 0.0
         vel[a:b] = v
     obst = np.concatenate(obstacle) if obstacle else None
-    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release)
+    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release, codim_nodes, codim_mass, codim_fixed)
 
 
 def apply(sc, be):
     """Drive a backend (the ctypes `Context` of ipc_amd/lib.py, or an adapter over the oracle with the same method names)."""
     cfg = sc.cfg
     be.set_mesh(sc.V, sc.T, YM=cfg.YM, PR=cfg.PR, density=cfg.rho)
+    if sc.codim_nodes is not None:
+        be.set_codim_nodes(sc.codim_nodes, sc.codim_mass)
     be.set_energy_type(cfg.energy)
     for s, sh in enumerate(cfg.shapes):
         if sh.material is not None and all(np.isfinite(sh.material)):
@@ -398,6 +447,8 @@ def apply(sc, be):
     if cfg.time_integration == "NM":
         be.set_time_integration("NM", cfg.beta, cfg.gamma)
     be.set_surface(sc.SF)
+    if sc.codim_fixed is not None:
+        be.set_dbc(sc.codim_fixed, 2)
     self_fric = cfg.self_fric
     if sc.obstacle_nodes is not None:
         # static obstacle: all of its nodes are ZERO Dirichlet nodes; without `selfCollisionOn` only pairs that involve the

@@ -130,6 +130,11 @@ class Mesh:
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         lib().orc_mesh_set_dbc(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(typ))
 
+    def set_codim_nodes(self, ids, mass):
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        m = np.ascontiguousarray(mass, dtype=np.float64)
+        lib().orc_mesh_set_codim_nodes(self.h, C.c_int(len(ids)), _ip(ids), _dp(m))
+
     def set_obstacle(self, ids, obstacle_only=False):
         ids = np.ascontiguousarray(ids, dtype=np.int32)
         lib().orc_mesh_set_obstacle(self.h, C.c_int(len(ids)), _ip(ids), C.c_int(int(obstacle_only)))

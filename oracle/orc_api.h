@@ -40,6 +40,7 @@ void orc_mesh_destroy(orc_mesh*);
 void orc_mesh_set_surface(orc_mesh*, int nSF, const int* SF_colmajor); // adds SF edges to vNeighbor, builds SVI/SFEdges
 void orc_mesh_set_dbc(orc_mesh*, int n, const int* vids, int type); // type: 1 ZERO, 2 NONZERO (Mesh.hpp:41-45)
 void orc_mesh_set_obstacle(orc_mesh*, int n, const int* vids, int obstacleOnly);
+void orc_mesh_set_codim_nodes(orc_mesh*, int n, const int* vids, const double* nodeMass); /* surface-only nodes of Mesh<3> (Mesh.cpp:310-345) */
 void orc_mesh_clear_dbc(orc_mesh*);
 void orc_mesh_set_energy_type(orc_mesh*, int type); // 0 NH, 1 FCR (Config.cpp:23-24)
 // componentMaterial entry of Mesh::setLameParam (Mesh.cpp:661-671): node range gets density rho, tet range gets (YM, PR)

@@ -244,17 +244,22 @@ Mesh::Mesh(int nV_, int nT_, const double* Vr, const int* Fc, double YM, double 
     lam.assign(nT, YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR));
     // bounding box of the simulated material (Mesh::matSpaceBBoxSize2, Mesh.cpp): nodes of elements only, so that a kinematic
     // obstacle riding along as a surface-only component does not change dHat = dHatEps^2 * diagonal^2
-    std::vector<char> inElem(nV, 0);
+    inMesh.assign(nV, 0);
     for (int t = 0; t < nT; ++t)
-        for (int k = 0; k < 4; ++k) inElem[Fi(t, k)] = 1;
+        for (int k = 0; k < 4; ++k) inMesh[Fi(t, k)] = 1;
+    meshBBox();
+}
+
+void Mesh::meshBBox()
+{
     nElemNodes = 0;
-    for (int v = 0; v < nV; ++v) nElemNodes += inElem[v];
+    for (int v = 0; v < nV; ++v) nElemNodes += inMesh[v];
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     for (int v = 0; v < nV; ++v)
         for (int i = 0; i < 3; ++i) {
-            if (nT && !inElem[v]) continue;
-            lo[i] = std::min(lo[i], Vr[v + nV * i]);
-            hi[i] = std::max(hi[i], Vr[v + nV * i]);
+            if (nElemNodes && !inMesh[v]) continue;
+            lo[i] = std::min(lo[i], V_rest[v + nV * i]);
+            hi[i] = std::max(hi[i], V_rest[v + nV * i]);
         }
     bboxDiag2 = 0;
     for (int i = 0; i < 3; ++i) {
@@ -634,6 +639,17 @@ void orc_mesh_set_obstacle(orc_mesh* h, int n, const int* vids, int obstacleOnly
     m.obstacle.assign(m.nV, 0);
     for (int i = 0; i < n; ++i) m.obstacle[vids[i]] = 1;
     m.obstacleOnly = obstacleOnly != 0;
+}
+void orc_mesh_set_codim_nodes(orc_mesh* h, int n, const int* vids, const double* nodeMass)
+{
+    // triangle meshes listed under `shapes` (componentCoDim 2): part of Mesh<3> for the bounding box and the mean mass, lumped
+    // masses = density x a third of the adjacent triangle areas (Mesh.cpp:310-345, 399)
+    Mesh& m = h->m;
+    for (int i = 0; i < n; ++i) {
+        m.inMesh[vids[i]] = 1;
+        m.mass[vids[i]] = nodeMass[i];
+    }
+    m.meshBBox();
 }
 void orc_mesh_set_component_material(orc_mesh* h, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR)
 {

@@ -113,7 +113,7 @@ def test_reference_scene_files_parse():
     print(len(ok), "scene files map onto the C ABI;", unsupported)
     for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
         assert need in ok, need
-    assert len(ok) >= 97  # the rest needs codimensional shapes (script DCOFix ...), other scripted motions, other solvers or damping
+    assert len(ok) >= 105  # the rest needs segment / point shapes, other scripted motions, other solvers or damping
 
 
 class OracleBackend:
@@ -146,6 +146,9 @@ class OracleBackend:
 
     def set_obstacle(self, ids, obstacle_only=False):
         self.m.set_obstacle(ids, obstacle_only)
+
+    def set_codim_nodes(self, ids, mass):
+        self.m.set_codim_nodes(ids, mass)
 
     def set_time_integration(self, *a):
         self.orc.opt_set_time_integration(self.o, *a)
@@ -356,4 +359,72 @@ def test_dragright_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
         so, sg = ob.state(), gb.state()
         assert np.abs(sg["V"] - so["V"]).max() < 1e-8 * np.abs(so["V"]).max(), k
     assert released == [False] * 5 + [True, False, False]  # the left end follows the pulled handle elastically: past x = 0.015 after five steps
+    gb.close()
+
+
+DCOFIX = ("script DCOFix\nshapes input 2\n{plane} 0 -0.01 0  0 0 0  3 1 3\ncube.msh 0 0.012 0  0 0 0  1 1 1\n"
+          "selfCollisionOn\ntime 1 0.01\ntol 1\n1e-6\n")
+
+
+def test_triangle_meshes_under_shapes_are_surface_only_components_of_the_mesh(tmp_path):
+    """`.obj` under `shapes` (main.cpp:948-956, Mesh.cpp:310-345): nodes of no tetrahedron that still belong to Mesh<3> -- lumped
+    masses from the triangle areas, inside the bounding box; `script DCOFix` holds them; `shapeMatrix` replicates a shape."""
+    (tmp_path / "plane.obj").write_text(PLANE_OBJ)
+    V0, F0 = scene.make_box(1, 1, 1, size=(0.5, 0.5, 0.5), origin=(-0.25, 0.0, -0.25))
+    SF0 = scene.surface_tris(F0)
+    cfg = ss.SceneConfig.parse(DCOFIX.format(plane=tmp_path / "plane.obj"), str(tmp_path))
+    sc = ss.assemble(cfg, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    assert np.array_equal(sc.codim_nodes, np.arange(5)) and np.array_equal(sc.codim_fixed, sc.codim_nodes) and sc.obstacle_nodes is None
+    assert sc.T.min() >= 5 and sc.SF.shape[0] == 4 + SF0.shape[0] and not sc.dirichlet
+    # the plane is 2 x 2 scaled by 3: area 36, four triangles of area 9; corner nodes touch two of them, the centre all four
+    assert np.allclose(sc.codim_mass, 1000.0 * np.array([6.0, 6.0, 6.0, 6.0, 12.0]))
+    m = ss.SceneConfig.parse("shapeMatrix input 2 1 3  1 2 3\na.obj 10 0 5  0 0 0  1 1 1\n")
+    assert len(m.shapes) == 6 and [tuple(x.translate) for x in m.shapes][:4] == [(1, 2, 3), (1, 2, 8), (1, 2, 13), (11, 2, 3)]
+    with pytest.raises(ss.UnsupportedKeyword):
+        ss.SceneConfig.parse("shapes input 1\nrope.seg 0 0 0  0 0 0  1 1 1\n")
+    with pytest.raises(ss.UnsupportedKeyword):  # nobody holds the surface: it would fall as a cloud of free particles
+        ss.assemble(ss.SceneConfig.parse(DCOFIX.format(plane=tmp_path / "plane.obj").replace("script DCOFix\n", ""), str(tmp_path)),
+                    lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+
+
+def test_cube_lands_on_a_fixed_surface_of_the_mesh_oracle(orc, tmp_path):
+    """DCOFix end to end on the oracle: the held surface takes part in self-collision, in the bounding box behind dHat and in the
+    mean mass behind kappa (unlike a meshCO, which stays outside the mesh)."""
+    (tmp_path / "plane.obj").write_text(PLANE_OBJ)
+    V0, F0 = scene.make_box(2, 2, 2, size=(0.5, 0.5, 0.5), origin=(-0.25, 0.0, -0.25))
+    SF0 = scene.surface_tris(F0)
+    cfg = ss.SceneConfig.parse(DCOFIX.format(plane=tmp_path / "plane.obj"), str(tmp_path))
+    sc = ss.assemble(cfg, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    be = ss.apply(sc, OracleBackend(orc))
+    diag2 = float(((sc.V.max(0) - sc.V.min(0)) ** 2).sum())  # the 6 x 6 plane dominates the box
+    assert be.state()["dHat"] == pytest.approx(1e-6 * diag2, rel=1e-12)
+    seen = 0
+    for k in range(12):
+        assert be.solve_timestep(80) < 80
+        seen = max(seen, len(orc.opt_contact_state(be.o)["active"]))
+    s = be.state()
+    assert seen > 0 and s["V"][5:, 1].min() > -0.01  # resting on the plane y = -0.01
+    assert np.array_equal(s["V"][:5], sc.V[:5])  # which did not move
+
+
+@pytest.mark.gpu
+def test_dcofix_scene_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
+    (tmp_path / "plane.obj").write_text(PLANE_OBJ)
+    V0, F0 = scene.make_box(2, 2, 2, size=(0.5, 0.5, 0.5), origin=(-0.25, 0.0, -0.25))
+    V0 = scene.jitter(V0, F0, rel=1e-2)
+    SF0 = scene.surface_tris(F0)
+    cfg = ss.SceneConfig.parse(DCOFIX.format(plane=tmp_path / "plane.obj"), str(tmp_path))
+    read = lambda p: (V0.copy(), F0.copy(), SF0.copy())
+    ob, gb = ss.apply(ss.assemble(cfg, read), OracleBackend(orc)), ss.apply(ss.assemble(cfg, read), gpu_lib.Context(0))
+    seen = 0
+    for k in range(12):
+        no, ng = ob.solve_timestep(80), gb.solve_timestep(80)
+        assert no < 80 and ng < 80
+        so, sg = ob.state(), gb.state()
+        assert sg["dHat"] == so["dHat"] and sg["kappa"] == pytest.approx(so["kappa"], rel=1e-9)
+        cs_o, cs_g = orc.opt_contact_state(ob.o), gb.contact_state()
+        assert cs_g["nActive"] == len(cs_o["active"]), k
+        seen = max(seen, cs_g["nActive"])
+        assert np.abs(sg["V"] - so["V"]).max() < 1e-6 * np.abs(so["V"]).max(), k
+    assert seen > 0
     gb.close()
