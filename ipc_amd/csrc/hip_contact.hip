@@ -270,14 +270,15 @@ __global__ void k_pattern_check(ContactView cv, CsrView m, int* __restrict__ fla
 }
 
 // a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201)
-// HESS_T stencils per workgroup: the two 12x12 matrices the Jacobi sweeps iterate on sit in LDS (2 x 144 x 8 B per stencil)
+// HESS_T stencils per workgroup: the two 9 x 9 matrices the Jacobi sweeps iterate on (the block reduced by the three rigid
+// translations, see make_pd_stencil) sit in LDS (2 x 81 x 8 B per stencil)
 constexpr int HESS_T = 32;
 __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
     double kappa, double* __restrict__ a, int* __restrict__ err)
 {
-    __shared__ double jac[2 * 144 * HESS_T];
+    __shared__ double jac[2 * 81 * HESS_T];
     const int i = blockIdx.x * HESS_T + threadIdx.x;
-    const Strided Qs{ jac + threadIdx.x, HESS_T }, Ws{ jac + 144 * HESS_T + threadIdx.x, HESS_T };
+    const Strided Qs{ jac + threadIdx.x, HESS_T }, Ws{ jac + 81 * HESS_T + threadIdx.x, HESS_T };
     double H[144], B[144];
     if (i < cv.nA) {
         const Stencil s = decode(cv.active + 4 * (size_t)i);
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrV
         for (int k = 0; k < 144; ++k) B[k] = 0.0;
         for (int r = 0; r < n3; ++r)
             for (int c = 0; c < n3; ++c) B[r + 12 * c] = ((cf * Hb) * g[r]) * g[c] + (cf * gb) * H[r + 12 * c];
-        atomicAdd(err + 1, make_pd(n3, B, Qs, Ws)); // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it)
+        atomicAdd(err + 1, make_pd_stencil(s.n, B, Qs, Ws)); // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it)
         scatter_blocks(m, a, B, s.node, s.n, dbc, projectDBC, err);
     }
     else if (i < cv.nA + cv.nP) {
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrV
                 B[r + 12 * cc] = (kappa * gb) * gd[r] * e_g_c + (kappa * gb) * gd[cc] * e_g_r + (kappa * b) * e_H + ((kappa * e * Hb) * gd[r]) * gd[cc]
                     + (kappa * e * gb) * W[r + 12 * cc];
             }
-        make_pd(12, B, Qs, Ws);
+        make_pd_stencil(4, B, Qs, Ws);
         scatter_blocks(m, a, B, en, 4, dbc, projectDBC, err);
     }
 }
