@@ -1153,6 +1153,14 @@ double orc_ccd_exact(int kind, const double* X12, const double* P12, double tmax
         }
     return ccdExact(kind, X, P, tmax);
 }
+// sqrt of the unclassified PT / EE distance accd() advances on (used by oracle/ref_plug.cpp)
+double orc_unclassified_distance(int kind, const double* X12)
+{
+    double X[4][3];
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) X[k][c] = X12[3 * k + c];
+    return std::sqrt(unclassifiedD2(kind, X));
+}
 double orc_accd(int kind, const double* X12, const double* P12, double eta, double tmax)
 {
     double X[4][3], P[4][3];

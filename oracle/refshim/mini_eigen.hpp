@@ -1,0 +1,2524 @@
+// ORACLE / TEST INFRASTRUCTURE -- a small dense-matrix library with Eigen's spelling.
+//
+// Why it exists: Eigen is not in this image, and every file of the reference on the Newton path is written
+// against it.  With this header first on the include path the reference's OWN sources (Energy.cpp,
+// NeoHookeanEnergy.cpp, ImplicitQRSVD.h, MeshCollisionUtils.hpp, FrictionUtils.hpp, LinSysSolver.hpp,
+// get_feasible_steps.cpp ...) compile where they lie under /root/reference into oracle/_ref/libipcref.so
+// (recipe: oracle/Makefile.ref), and the restatement under oracle/ is checked against them.
+//
+// What it is: eager (no expression templates) column-major matrices, fixed or dynamic, with the members those
+// files touch.  Everything is plain arithmetic in the obvious order: a product is a dot product per entry
+// summed left to right, reductions run in storage order.  Three pieces are algorithms rather than spelling and
+// are restated from Eigen's published behaviour: LDLT (pivoting on the largest |diagonal|, solve with
+// pseudo-inverse of D below 1/highest), SelfAdjointEigenSolver (cyclic Jacobi here; the eigen-decomposition of a
+// symmetric matrix is unique up to round-off where the reference uses it: clamping eigenvalues) and inverse /
+// determinant of 2x2 and 3x3 by cofactors.  Results that depend on them are compared with tolerances, never
+// bit-for-bit.
+//
+// Nothing under ipc_amd/ includes this file.
+#pragma once
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cmath>
+#include <complex>
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include <iostream>
+#include <limits>
+#include <map>
+#include <memory>
+#include <numeric>
+#include <set>
+#include <sstream>
+#include <string>
+#include <utility>
+#include <type_traits>
+#include <vector>
+
+#define EIGEN_MAKE_ALIGNED_OPERATOR_NEW
+#define EIGEN_DEVICE_FUNC
+#define EIGEN_STRONG_INLINE inline
+
+namespace Eigen {
+
+const int Dynamic = -1;
+typedef std::ptrdiff_t Index;
+enum { ColMajor = 0,
+    RowMajor = 1,
+    AutoAlign = 0,
+    DontAlign = 2 };
+enum { ComputeFullU = 0x04,
+    ComputeThinU = 0x08,
+    ComputeFullV = 0x10,
+    ComputeThinV = 0x20 };
+enum { Lower = 1,
+    Upper = 2 };
+enum NoChange_t { NoChange };
+enum ComputationInfo { Success = 0,
+    NumericalIssue = 1,
+    NoConvergence = 2,
+    InvalidInput = 3 };
+
+template <class S, int R, int C, int O = 0, int MR = R, int MC = C>
+class Matrix;
+template <class X, int BR, int BC>
+class Block;
+template <class S, int N, int MN = N>
+class DiagonalMatrix;
+template <class M>
+class LDLT;
+template <class P, int = 0, class = void>
+class Map;
+template <class M>
+class FullPivLU;
+template <class S, int R, int C, int O = 0, int MR = R, int MC = C>
+class Array;
+template <class X>
+class ArrayWrap;
+template <class D>
+class ArrayBase;
+
+namespace internal {
+template <class T>
+struct traits;
+template <class S, int R, int C, int O, int MR, int MC>
+struct traits<Matrix<S, R, C, O, MR, MC>> {
+    typedef S Scalar;
+    enum { Rows = R,
+        Cols = C,
+        Options = O };
+};
+template <class X, int BR, int BC>
+struct traits<Block<X, BR, BC>> {
+    typedef typename traits<typename std::remove_const<X>::type>::Scalar Scalar;
+    enum { Rows = BR,
+        Cols = BC };
+};
+template <class P, int A, class B>
+struct traits<Map<P, A, B>> : traits<P> {
+};
+template <class S, int N, int MN>
+struct traits<DiagonalMatrix<S, N, MN>> {
+    typedef S Scalar;
+    enum { Rows = N,
+        Cols = N };
+};
+template <class X>
+struct traits<const X> : traits<X> {
+};
+template <class S, int R, int C, int O, int MR, int MC>
+struct traits<Array<S, R, C, O, MR, MC>> {
+    typedef S Scalar;
+    enum { Rows = R,
+        Cols = C };
+};
+template <class X>
+struct traits<ArrayWrap<X>> : traits<typename std::remove_const<X>::type> {
+};
+constexpr int pick(int a, int b) { return a != Dynamic ? a : b; }
+} // namespace internal
+
+template <class S>
+struct NumTraits {
+    static S epsilon() { return std::numeric_limits<S>::epsilon(); }
+    static S highest() { return (std::numeric_limits<S>::max)(); }
+    static S lowest() { return std::numeric_limits<S>::lowest(); }
+    static S dummy_precision() { return S(1e-12); }
+};
+
+template <class S, class M>
+struct CommaInit;
+
+// ------------------------------------------------------------------------------------------------------------
+template <class Derived>
+class MatrixBase {
+public:
+    typedef typename internal::traits<Derived>::Scalar Scalar;
+    typedef Scalar RealScalar;
+    enum { RowsAtCompileTime = internal::traits<Derived>::Rows,
+        ColsAtCompileTime = internal::traits<Derived>::Cols,
+        SizeAtCompileTime = (RowsAtCompileTime == Dynamic || ColsAtCompileTime == Dynamic) ? Dynamic : RowsAtCompileTime * ColsAtCompileTime,
+        IsVectorAtCompileTime = (RowsAtCompileTime == 1 || ColsAtCompileTime == 1) ? 1 : 0 };
+    typedef Matrix<Scalar, RowsAtCompileTime, ColsAtCompileTime> PlainObject;
+    typedef Matrix<Scalar, ColsAtCompileTime, RowsAtCompileTime> TransposeReturn;
+    typedef Eigen::Index Index;
+    typedef Eigen::Index StorageIndex;
+
+    Derived& derived() { return *static_cast<Derived*>(this); }
+    const Derived& derived() const { return *static_cast<const Derived*>(this); }
+    Index rows() const { return derived().rows_(); }
+    Index cols() const { return derived().cols_(); }
+    Index size() const { return rows() * cols(); }
+
+    // element access
+    Scalar coeff(Index i, Index j) const { return derived().get(i, j); }
+    Scalar& coeffRef(Index i, Index j) { return derived().ref(i, j); }
+    Scalar operator()(Index i, Index j) const { return derived().get(i, j); }
+    Scalar& operator()(Index i, Index j) { return derived().ref(i, j); }
+    Scalar lin(Index k) const { return cols() == 1 ? derived().get(k, 0) : (rows() == 1 ? derived().get(0, k) : derived().get(k % rows(), k / rows())); }
+    Scalar& linRef(Index k) { return cols() == 1 ? derived().ref(k, 0) : (rows() == 1 ? derived().ref(0, k) : derived().ref(k % rows(), k / rows())); }
+    Scalar operator()(Index k) const { return lin(k); }
+    Scalar& operator()(Index k) { return linRef(k); }
+    Scalar operator[](Index k) const { return lin(k); }
+    Scalar& operator[](Index k) { return linRef(k); }
+    Scalar x() const { return lin(0); }
+    Scalar y() const { return lin(1); }
+    Scalar z() const { return lin(2); }
+    Scalar& x() { return linRef(0); }
+    Scalar& y() { return linRef(1); }
+    Scalar& z() { return linRef(2); }
+
+    PlainObject eval() const
+    {
+        PlainObject r;
+        r.resize(rows(), cols());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                r.ref(i, j) = coeff(i, j);
+        return r;
+    }
+    TransposeReturn transpose() const
+    {
+        TransposeReturn r;
+        r.resize(cols(), rows());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                r.ref(j, i) = coeff(i, j);
+        return r;
+    }
+    TransposeReturn adjoint() const { return transpose(); }
+    void transposeInPlace()
+    {
+        TransposeReturn t = transpose();
+        assignFrom(t);
+    }
+    Derived& noalias() { return derived(); }
+    // assignment through a base reference (ImplicitQRSVD.h writes `S = A` with S a MatrixBase<TS>&)
+    template <class O>
+    MatrixBase& operator=(const MatrixBase<O>& o)
+    {
+        derived() = o.derived();
+        return *this;
+    }
+    MatrixBase& operator=(const MatrixBase& o)
+    {
+        derived() = o.derived();
+        return *this;
+    }
+    MatrixBase() = default;
+    MatrixBase(const MatrixBase&) = default;
+
+    // assignment helpers ---------------------------------------------------------------------------------
+    template <class O>
+    void assignFrom(const MatrixBase<O>& o)
+    {
+        // o is always a materialised object or a view of another object; take a copy first when it may alias
+        typename MatrixBase<O>::PlainObject t = o.eval();
+        bool vecT = (t.rows() != rows() || t.cols() != cols()) && (t.rows() == cols() && t.cols() == rows()) && (t.rows() == 1 || t.cols() == 1);
+        if (vecT) {
+            for (Index k = 0; k < t.size(); ++k)
+                linRef(k) = t.lin(k);
+            return;
+        }
+        assert(t.rows() == rows() && t.cols() == cols());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                coeffRef(i, j) = t.get(i, j);
+    }
+    template <class O>
+    Derived& operator+=(const MatrixBase<O>& o)
+    {
+        typename MatrixBase<O>::PlainObject t = o.eval();
+        if (t.rows() == rows() && t.cols() == cols()) {
+            for (Index j = 0; j < cols(); ++j)
+                for (Index i = 0; i < rows(); ++i)
+                    coeffRef(i, j) += t.get(i, j);
+        }
+        else {
+            assert(t.size() == size());
+            for (Index k = 0; k < size(); ++k)
+                linRef(k) += t.lin(k);
+        }
+        return derived();
+    }
+    template <class O>
+    Derived& operator-=(const MatrixBase<O>& o)
+    {
+        typename MatrixBase<O>::PlainObject t = o.eval();
+        if (t.rows() == rows() && t.cols() == cols()) {
+            for (Index j = 0; j < cols(); ++j)
+                for (Index i = 0; i < rows(); ++i)
+                    coeffRef(i, j) -= t.get(i, j);
+        }
+        else {
+            assert(t.size() == size());
+            for (Index k = 0; k < size(); ++k)
+                linRef(k) -= t.lin(k);
+        }
+        return derived();
+    }
+    Derived& operator*=(Scalar s)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                coeffRef(i, j) *= s;
+        return derived();
+    }
+    Derived& operator/=(Scalar s)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                coeffRef(i, j) /= s;
+        return derived();
+    }
+    template <class O>
+    Derived& operator*=(const MatrixBase<O>& o)
+    {
+        PlainObject t = (*this) * o;
+        assignFrom(t);
+        return derived();
+    }
+
+    // setters -----------------------------------------------------------------------------------------------
+    Derived& setConstant(Scalar v)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                coeffRef(i, j) = v;
+        return derived();
+    }
+    Derived& fill(Scalar v) { return setConstant(v); }
+    Derived& setZero() { return setConstant(Scalar(0)); }
+    Derived& setOnes() { return setConstant(Scalar(1)); }
+    Derived& setIdentity()
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                coeffRef(i, j) = (i == j) ? Scalar(1) : Scalar(0);
+        return derived();
+    }
+    Derived& setRandom()
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                coeffRef(i, j) = Scalar(2.0 * std::rand() / RAND_MAX - 1.0);
+        return derived();
+    }
+    CommaInit<Scalar, Derived> operator<<(Scalar v);
+    template <class O>
+    CommaInit<Scalar, Derived> operator<<(const MatrixBase<O>& o);
+
+    // reductions ----------------------------------------------------------------------------------------------
+    Scalar sum() const
+    {
+        Scalar s = 0;
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                s += coeff(i, j);
+        return s;
+    }
+    Scalar prod() const
+    {
+        Scalar s = 1;
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                s *= coeff(i, j);
+        return s;
+    }
+    Scalar mean() const { return sum() / Scalar(size()); }
+    Scalar trace() const
+    {
+        Scalar s = 0;
+        for (Index i = 0; i < rows() && i < cols(); ++i)
+            s += coeff(i, i);
+        return s;
+    }
+    Scalar squaredNorm() const
+    {
+        Scalar s = 0;
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                s += coeff(i, j) * coeff(i, j);
+        return s;
+    }
+    Scalar norm() const { return std::sqrt(squaredNorm()); }
+    PlainObject normalized() const
+    {
+        PlainObject r = eval();
+        Scalar n = norm();
+        if (n > Scalar(0)) r /= n;
+        return r;
+    }
+    void normalize()
+    {
+        Scalar n = norm();
+        if (n > Scalar(0)) (*this) /= n;
+    }
+    Scalar minCoeff() const
+    {
+        Scalar m = coeff(0, 0);
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                m = coeff(i, j) < m ? coeff(i, j) : m;
+        return m;
+    }
+    Scalar maxCoeff() const
+    {
+        Scalar m = coeff(0, 0);
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                m = coeff(i, j) > m ? coeff(i, j) : m;
+        return m;
+    }
+    template <class I>
+    Scalar minCoeff(I* idx) const
+    {
+        Scalar m = lin(0);
+        *idx = 0;
+        for (Index k = 1; k < size(); ++k)
+            if (lin(k) < m) {
+                m = lin(k);
+                *idx = (I)k;
+            }
+        return m;
+    }
+    template <class I>
+    Scalar maxCoeff(I* idx) const
+    {
+        Scalar m = lin(0);
+        *idx = 0;
+        for (Index k = 1; k < size(); ++k)
+            if (lin(k) > m) {
+                m = lin(k);
+                *idx = (I)k;
+            }
+        return m;
+    }
+    bool isZero(Scalar prec = NumTraits<Scalar>::dummy_precision()) const
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                if (std::abs(coeff(i, j)) > prec) return false;
+        return true;
+    }
+    bool hasNaN() const
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                if (coeff(i, j) != coeff(i, j)) return true;
+        return false;
+    }
+    bool allFinite() const
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i)
+                if (!std::isfinite(coeff(i, j))) return false;
+        return true;
+    }
+    template <class O>
+    Scalar dot(const MatrixBase<O>& o) const
+    {
+        assert(size() == o.size());
+        Scalar s = 0;
+        for (Index k = 0; k < size(); ++k)
+            s += lin(k) * o.lin(k);
+        return s;
+    }
+    template <class O>
+    PlainObject cross(const MatrixBase<O>& o) const
+    {
+        PlainObject r;
+        r.resize(rows(), cols());
+        Scalar a0 = lin(0), a1 = lin(1), a2 = lin(2), b0 = o.lin(0), b1 = o.lin(1), b2 = o.lin(2);
+        r.linRef(0) = a1 * b2 - a2 * b1;
+        r.linRef(1) = a2 * b0 - a0 * b2;
+        r.linRef(2) = a0 * b1 - a1 * b0;
+        return r;
+    }
+    PlainObject unitOrthogonal() const
+    {
+        // Eigen's rule for 3-vectors (OrthoMethods.h): pick x,y unless they are negligible next to z
+        PlainObject r;
+        r.resize(rows(), cols());
+        Scalar X = lin(0), Y = lin(1), Z = lin(2);
+        if (!(std::abs(X) <= std::abs(Z) * NumTraits<Scalar>::dummy_precision()) || !(std::abs(Y) <= std::abs(Z) * NumTraits<Scalar>::dummy_precision())) {
+            Scalar inv = Scalar(1) / std::sqrt(X * X + Y * Y);
+            r.linRef(0) = -Y * inv;
+            r.linRef(1) = X * inv;
+            r.linRef(2) = 0;
+        }
+        else {
+            Scalar inv = Scalar(1) / std::sqrt(Y * Y + Z * Z);
+            r.linRef(0) = 0;
+            r.linRef(1) = -Z * inv;
+            r.linRef(2) = Y * inv;
+        }
+        return r;
+    }
+    Scalar determinant() const
+    {
+        assert(rows() == cols());
+        if (rows() == 1) return coeff(0, 0);
+        if (rows() == 2) return coeff(0, 0) * coeff(1, 1) - coeff(1, 0) * coeff(0, 1);
+        if (rows() == 3) {
+            // Eigen's bruteforce_det3_helper order
+            auto h = [&](int a, int b, int c) { return coeff(0, a) * (coeff(1, b) * coeff(2, c) - coeff(1, c) * coeff(2, b)); };
+            return h(0, 1, 2) - h(1, 0, 2) + h(2, 0, 1);
+        }
+        // general: Gaussian elimination with partial pivoting
+        PlainObject a = eval();
+        Index n = rows();
+        Scalar det = 1;
+        for (Index k = 0; k < n; ++k) {
+            Index p = k;
+            for (Index i = k + 1; i < n; ++i)
+                if (std::abs(a.get(i, k)) > std::abs(a.get(p, k))) p = i;
+            if (a.get(p, k) == Scalar(0)) return Scalar(0);
+            if (p != k) {
+                for (Index j = 0; j < n; ++j) std::swap(a.ref(k, j), a.ref(p, j));
+                det = -det;
+            }
+            det *= a.get(k, k);
+            for (Index i = k + 1; i < n; ++i) {
+                Scalar f = a.get(i, k) / a.get(k, k);
+                for (Index j = k; j < n; ++j) a.ref(i, j) -= f * a.get(k, j);
+            }
+        }
+        return det;
+    }
+    PlainObject inverse() const
+    {
+        assert(rows() == cols());
+        Index n = rows();
+        PlainObject r;
+        r.resize(n, n);
+        if (n == 2) {
+            Scalar invdet = Scalar(1) / determinant();
+            r.ref(0, 0) = coeff(1, 1) * invdet;
+            r.ref(1, 0) = -coeff(1, 0) * invdet;
+            r.ref(0, 1) = -coeff(0, 1) * invdet;
+            r.ref(1, 1) = coeff(0, 0) * invdet;
+            return r;
+        }
+        if (n == 3) {
+            auto cof = [&](int i, int j) {
+                int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+                return coeff(i1, j1) * coeff(i2, j2) - coeff(i1, j2) * coeff(i2, j1);
+            };
+            Scalar c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+            Scalar det = c00 * coeff(0, 0) + c10 * coeff(1, 0) + c20 * coeff(2, 0);
+            Scalar invdet = Scalar(1) / det;
+            for (int i = 0; i < 3; ++i)
+                for (int j = 0; j < 3; ++j)
+                    r.ref(j, i) = cof(i, j) * invdet;
+            return r;
+        }
+        // general: Gauss-Jordan with partial pivoting
+        PlainObject a = eval();
+        r.setIdentity();
+        for (Index k = 0; k < n; ++k) {
+            Index p = k;
+            for (Index i = k + 1; i < n; ++i)
+                if (std::abs(a.get(i, k)) > std::abs(a.get(p, k))) p = i;
+            if (p != k)
+                for (Index j = 0; j < n; ++j) {
+                    std::swap(a.ref(k, j), a.ref(p, j));
+                    std::swap(r.ref(k, j), r.ref(p, j));
+                }
+            Scalar d = a.get(k, k);
+            for (Index j = 0; j < n; ++j) {
+                a.ref(k, j) /= d;
+                r.ref(k, j) /= d;
+            }
+            for (Index i = 0; i < n; ++i)
+                if (i != k) {
+                    Scalar f = a.get(i, k);
+                    for (Index j = 0; j < n; ++j) {
+                        a.ref(i, j) -= f * a.get(k, j);
+                        r.ref(i, j) -= f * r.get(k, j);
+                    }
+                }
+        }
+        return r;
+    }
+    PlainObject cwiseAbs() const
+    {
+        PlainObject r = eval();
+        for (Index k = 0; k < size(); ++k) r.linRef(k) = std::abs(r.lin(k));
+        return r;
+    }
+    template <class O>
+    PlainObject cwiseMin(const MatrixBase<O>& o) const
+    {
+        PlainObject r = eval();
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) = o.coeff(i, j) < r.get(i, j) ? o.coeff(i, j) : r.get(i, j);
+        return r;
+    }
+    template <class O>
+    PlainObject cwiseMax(const MatrixBase<O>& o) const
+    {
+        PlainObject r = eval();
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) = r.get(i, j) < o.coeff(i, j) ? o.coeff(i, j) : r.get(i, j);
+        return r;
+    }
+    PlainObject cwiseMin(Scalar v) const
+    {
+        PlainObject r = eval();
+        for (Index k = 0; k < size(); ++k) r.linRef(k) = v < r.lin(k) ? v : r.lin(k);
+        return r;
+    }
+    PlainObject cwiseMax(Scalar v) const
+    {
+        PlainObject r = eval();
+        for (Index k = 0; k < size(); ++k) r.linRef(k) = r.lin(k) < v ? v : r.lin(k);
+        return r;
+    }
+    PlainObject cwiseInverse() const
+    {
+        PlainObject r = eval();
+        for (Index k = 0; k < size(); ++k) r.linRef(k) = Scalar(1) / r.lin(k);
+        return r;
+    }
+    PlainObject cwiseSqrt() const
+    {
+        PlainObject r = eval();
+        for (Index k = 0; k < size(); ++k) r.linRef(k) = std::sqrt(r.lin(k));
+        return r;
+    }
+    template <class O>
+    PlainObject cwiseProduct(const MatrixBase<O>& o) const
+    {
+        PlainObject r = eval();
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) *= o.coeff(i, j);
+        return r;
+    }
+    template <class O>
+    PlainObject cwiseQuotient(const MatrixBase<O>& o) const
+    {
+        PlainObject r = eval();
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) /= o.coeff(i, j);
+        return r;
+    }
+    DiagonalMatrix<Scalar, internal::pick(RowsAtCompileTime, ColsAtCompileTime) == 1 ? internal::pick(ColsAtCompileTime, RowsAtCompileTime) : internal::pick(RowsAtCompileTime, ColsAtCompileTime)> asDiagonal() const;
+    Matrix<Scalar, Dynamic, 1> diagonal() const;
+    LDLT<PlainObject> ldlt() const;
+    FullPivLU<PlainObject> fullPivLu() const;
+    FullPivLU<PlainObject> lu() const; // the partial-pivoting variant is only used by the SQP baselines
+
+    // coefficient-wise world (see ArrayBase below)
+    ArrayWrap<Derived> array() { return ArrayWrap<Derived>(derived()); }
+    ArrayWrap<const Derived> array() const { return ArrayWrap<const Derived>(derived()); }
+    struct ColwiseView {
+        const Derived* p;
+        Matrix<Scalar, 1, ColsAtCompileTime> squaredNorm() const
+        {
+            Matrix<Scalar, 1, ColsAtCompileTime> r;
+            r.resize(1, p->cols());
+            for (Index j = 0; j < p->cols(); ++j) r.ref(0, j) = p->col(j).squaredNorm();
+            return r;
+        }
+        Matrix<Scalar, 1, ColsAtCompileTime> norm() const
+        {
+            Matrix<Scalar, 1, ColsAtCompileTime> r;
+            r.resize(1, p->cols());
+            for (Index j = 0; j < p->cols(); ++j) r.ref(0, j) = p->col(j).norm();
+            return r;
+        }
+        Matrix<Scalar, 1, ColsAtCompileTime> sum() const
+        {
+            Matrix<Scalar, 1, ColsAtCompileTime> r;
+            r.resize(1, p->cols());
+            for (Index j = 0; j < p->cols(); ++j) r.ref(0, j) = p->col(j).sum();
+            return r;
+        }
+        Matrix<Scalar, 1, ColsAtCompileTime> mean() const
+        {
+            Matrix<Scalar, 1, ColsAtCompileTime> r;
+            r.resize(1, p->cols());
+            for (Index j = 0; j < p->cols(); ++j) r.ref(0, j) = p->col(j).mean();
+            return r;
+        }
+        Matrix<Scalar, 1, ColsAtCompileTime> minCoeff() const
+        {
+            Matrix<Scalar, 1, ColsAtCompileTime> r;
+            r.resize(1, p->cols());
+            for (Index j = 0; j < p->cols(); ++j) r.ref(0, j) = p->col(j).minCoeff();
+            return r;
+        }
+        Matrix<Scalar, 1, ColsAtCompileTime> maxCoeff() const
+        {
+            Matrix<Scalar, 1, ColsAtCompileTime> r;
+            r.resize(1, p->cols());
+            for (Index j = 0; j < p->cols(); ++j) r.ref(0, j) = p->col(j).maxCoeff();
+            return r;
+        }
+    };
+    ColwiseView colwise() const { return ColwiseView{ &derived() }; }
+    template <class Self>
+    struct RowwiseView {
+        Self* p;
+        template <class O>
+        void operator+=(const MatrixBase<O>& v)
+        {
+            for (Index j = 0; j < p->cols(); ++j)
+                for (Index i = 0; i < p->rows(); ++i) p->coeffRef(i, j) += v.lin(j);
+        }
+        template <class O>
+        void operator-=(const MatrixBase<O>& v)
+        {
+            for (Index j = 0; j < p->cols(); ++j)
+                for (Index i = 0; i < p->rows(); ++i) p->coeffRef(i, j) -= v.lin(j);
+        }
+        template <class O>
+        void operator=(const MatrixBase<O>& v)
+        {
+            for (Index j = 0; j < p->cols(); ++j)
+                for (Index i = 0; i < p->rows(); ++i) p->coeffRef(i, j) = v.lin(j);
+        }
+        template <class O>
+        PlainObject operator+(const MatrixBase<O>& v) const
+        {
+            PlainObject r = p->eval();
+            for (Index j = 0; j < r.cols(); ++j)
+                for (Index i = 0; i < r.rows(); ++i) r.ref(i, j) += v.lin(j);
+            return r;
+        }
+        template <class O>
+        PlainObject operator-(const MatrixBase<O>& v) const
+        {
+            PlainObject r = p->eval();
+            for (Index j = 0; j < r.cols(); ++j)
+                for (Index i = 0; i < r.rows(); ++i) r.ref(i, j) -= v.lin(j);
+            return r;
+        }
+        Matrix<Scalar, RowsAtCompileTime, 1> squaredNorm() const
+        {
+            Matrix<Scalar, RowsAtCompileTime, 1> r;
+            r.resize(p->rows(), 1);
+            for (Index i = 0; i < p->rows(); ++i) r.ref(i, 0) = p->row(i).squaredNorm();
+            return r;
+        }
+        Matrix<Scalar, RowsAtCompileTime, 1> norm() const
+        {
+            Matrix<Scalar, RowsAtCompileTime, 1> r;
+            r.resize(p->rows(), 1);
+            for (Index i = 0; i < p->rows(); ++i) r.ref(i, 0) = p->row(i).norm();
+            return r;
+        }
+        Matrix<Scalar, RowsAtCompileTime, 1> sum() const
+        {
+            Matrix<Scalar, RowsAtCompileTime, 1> r;
+            r.resize(p->rows(), 1);
+            for (Index i = 0; i < p->rows(); ++i) r.ref(i, 0) = p->row(i).sum();
+            return r;
+        }
+        Matrix<Scalar, RowsAtCompileTime, 1> mean() const
+        {
+            Matrix<Scalar, RowsAtCompileTime, 1> r;
+            r.resize(p->rows(), 1);
+            for (Index i = 0; i < p->rows(); ++i) r.ref(i, 0) = p->row(i).mean();
+            return r;
+        }
+    };
+    RowwiseView<Derived> rowwise() { return RowwiseView<Derived>{ &derived() }; }
+    RowwiseView<const Derived> rowwise() const { return RowwiseView<const Derived>{ &derived() }; }
+
+    // views ---------------------------------------------------------------------------------------------------
+    Block<Derived, 1, ColsAtCompileTime> row(Index i) { return Block<Derived, 1, ColsAtCompileTime>(derived(), i, 0, 1, cols()); }
+    Block<Derived, RowsAtCompileTime, 1> col(Index j) { return Block<Derived, RowsAtCompileTime, 1>(derived(), 0, j, rows(), 1); }
+    Block<const Derived, 1, ColsAtCompileTime> row(Index i) const { return Block<const Derived, 1, ColsAtCompileTime>(derived(), i, 0, 1, cols()); }
+    Block<const Derived, RowsAtCompileTime, 1> col(Index j) const { return Block<const Derived, RowsAtCompileTime, 1>(derived(), 0, j, rows(), 1); }
+    template <int BR, int BC>
+    Block<Derived, BR, BC> block(Index i, Index j) { return Block<Derived, BR, BC>(derived(), i, j, BR, BC); }
+    template <int BR, int BC>
+    Block<const Derived, BR, BC> block(Index i, Index j) const { return Block<const Derived, BR, BC>(derived(), i, j, BR, BC); }
+    Block<Derived, Dynamic, Dynamic> block(Index i, Index j, Index r, Index c) { return Block<Derived, Dynamic, Dynamic>(derived(), i, j, r, c); }
+    Block<const Derived, Dynamic, Dynamic> block(Index i, Index j, Index r, Index c) const { return Block<const Derived, Dynamic, Dynamic>(derived(), i, j, r, c); }
+    // vector segments: orientation follows the vector
+    template <int N>
+    Block<Derived, (ColsAtCompileTime == 1 ? N : 1), (ColsAtCompileTime == 1 ? 1 : N)> segment(Index s)
+    {
+        typedef Block<Derived, (ColsAtCompileTime == 1 ? N : 1), (ColsAtCompileTime == 1 ? 1 : N)> B;
+        return cols() == 1 ? B(derived(), s, 0, N, 1) : B(derived(), 0, s, 1, N);
+    }
+    template <int N>
+    Block<const Derived, (ColsAtCompileTime == 1 ? N : 1), (ColsAtCompileTime == 1 ? 1 : N)> segment(Index s) const
+    {
+        typedef Block<const Derived, (ColsAtCompileTime == 1 ? N : 1), (ColsAtCompileTime == 1 ? 1 : N)> B;
+        return cols() == 1 ? B(derived(), s, 0, N, 1) : B(derived(), 0, s, 1, N);
+    }
+    Block<Derived, (ColsAtCompileTime == 1 ? Dynamic : 1), (ColsAtCompileTime == 1 ? 1 : Dynamic)> segment(Index s, Index n)
+    {
+        typedef Block<Derived, (ColsAtCompileTime == 1 ? Dynamic : 1), (ColsAtCompileTime == 1 ? 1 : Dynamic)> B;
+        return cols() == 1 ? B(derived(), s, 0, n, 1) : B(derived(), 0, s, 1, n);
+    }
+    Block<const Derived, (ColsAtCompileTime == 1 ? Dynamic : 1), (ColsAtCompileTime == 1 ? 1 : Dynamic)> segment(Index s, Index n) const
+    {
+        typedef Block<const Derived, (ColsAtCompileTime == 1 ? Dynamic : 1), (ColsAtCompileTime == 1 ? 1 : Dynamic)> B;
+        return cols() == 1 ? B(derived(), s, 0, n, 1) : B(derived(), 0, s, 1, n);
+    }
+    template <int N>
+    auto head() { return this->template segment<N>(0); }
+    template <int N>
+    auto head() const { return this->template segment<N>(0); }
+    template <int N>
+    auto tail() { return this->template segment<N>(size() - N); }
+    template <int N>
+    auto tail() const { return this->template segment<N>(size() - N); }
+    auto head(Index n) { return segment(0, n); }
+    auto head(Index n) const { return segment(0, n); }
+    auto tail(Index n) { return segment(size() - n, n); }
+    auto tail(Index n) const { return segment(size() - n, n); }
+    auto topRows(Index n) { return block(0, 0, n, cols()); }
+    auto topRows(Index n) const { return block(0, 0, n, cols()); }
+    auto bottomRows(Index n) { return block(rows() - n, 0, n, cols()); }
+    auto bottomRows(Index n) const { return block(rows() - n, 0, n, cols()); }
+    auto leftCols(Index n) { return block(0, 0, rows(), n); }
+    auto leftCols(Index n) const { return block(0, 0, rows(), n); }
+    auto rightCols(Index n) { return block(0, cols() - n, rows(), n); }
+    auto rightCols(Index n) const { return block(0, cols() - n, rows(), n); }
+    template <int BR, int BC>
+    auto topLeftCorner() { return this->template block<BR, BC>(0, 0); }
+    template <int BR, int BC>
+    auto topLeftCorner() const { return this->template block<BR, BC>(0, 0); }
+
+    template <class O>
+    void swap(MatrixBase<O>& o)
+    {
+        PlainObject t = eval();
+        assignFrom(o);
+        o.assignFrom(t);
+    }
+    template <class O>
+    void swap(MatrixBase<O>&& o)
+    {
+        PlainObject t = eval();
+        assignFrom(o);
+        o.assignFrom(t);
+    }
+    template <class NewT>
+    Matrix<NewT, RowsAtCompileTime, ColsAtCompileTime> cast() const
+    {
+        Matrix<NewT, RowsAtCompileTime, ColsAtCompileTime> r;
+        r.resize(rows(), cols());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) = NewT(coeff(i, j));
+        return r;
+    }
+};
+template <class D>
+using DenseBase = MatrixBase<D>;
+template <class D>
+using EigenBase = MatrixBase<D>;
+
+// ------------------------------------------------------------------------------------------------------------
+namespace internal {
+template <class S, int N>
+struct Store {
+    S v[N > 0 ? N : 1];
+    Store()
+    {
+        for (int i = 0; i < N; ++i) v[i] = S();
+    }
+    void resize(size_t) {}
+    S* data() { return v; }
+    const S* data() const { return v; }
+};
+template <class S>
+struct Store<S, Dynamic> {
+    std::vector<S> v;
+    void resize(size_t n) { v.resize(n); }
+    S* data() { return v.data(); }
+    const S* data() const { return v.data(); }
+};
+} // namespace internal
+
+template <class S, int R, int C, int O, int MR, int MC>
+class Matrix : public MatrixBase<Matrix<S, R, C, O, MR, MC>> {
+    typedef MatrixBase<Matrix> Base;
+    internal::Store<S, (R == Dynamic || C == Dynamic) ? Dynamic : R * C> st_;
+    Index r_ = (R == Dynamic ? 0 : R), c_ = (C == Dynamic ? 0 : C);
+
+public:
+    typedef S Scalar;
+    Index rows_() const { return r_; }
+    Index cols_() const { return c_; }
+    S get(Index i, Index j) const
+    {
+        assert(i >= 0 && i < r_ && j >= 0 && j < c_);
+        return st_.data()[(O & RowMajor) ? (i * c_ + j) : (i + r_ * j)];
+    }
+    S& ref(Index i, Index j)
+    {
+        assert(i >= 0 && i < r_ && j >= 0 && j < c_);
+        return st_.data()[(O & RowMajor) ? (i * c_ + j) : (i + r_ * j)];
+    }
+    S* data() { return st_.data(); }
+    const S* data() const { return st_.data(); }
+
+    Matrix() {}
+    // sizes: Matrix(n) for vectors, Matrix(r, c)
+    template <class I, class = typename std::enable_if<std::is_integral<I>::value && (R == Dynamic || C == Dynamic)>::type>
+    explicit Matrix(I n)
+    {
+        if (C == 1) resize(n, 1);
+        else if (R == 1) resize(1, n);
+        else resize(n, n);
+    }
+    template <class I, class J, class = typename std::enable_if<std::is_integral<I>::value && std::is_integral<J>::value && (R == Dynamic || C == Dynamic)>::type>
+    Matrix(I r, J c) { resize(r, c); }
+    // coefficients of small fixed vectors
+    template <class A, class B, class = typename std::enable_if<std::is_arithmetic<A>::value && std::is_arithmetic<B>::value && R != Dynamic && C != Dynamic && R * C == 2>::type, class = void>
+    Matrix(A a, B b)
+    {
+        st_.data()[0] = S(a);
+        st_.data()[1] = S(b);
+    }
+    Matrix(S a, S b, S c)
+    {
+        static_assert(R != Dynamic && C != Dynamic && R * C == 3, "3-coefficient constructor");
+        st_.data()[0] = a;
+        st_.data()[1] = b;
+        st_.data()[2] = c;
+    }
+    Matrix(S a, S b, S c, S d)
+    {
+        static_assert(R != Dynamic && C != Dynamic && R * C == 4, "4-coefficient constructor");
+        st_.data()[0] = a;
+        st_.data()[1] = b;
+        st_.data()[2] = c;
+        st_.data()[3] = d;
+    }
+    Matrix(const Matrix& o)
+        : Base(), st_(o.st_), r_(o.r_), c_(o.c_) {}
+    Matrix& operator=(const Matrix& o)
+    {
+        // not defaulted: the base's copy assignment forwards to the derived one (assignment through base references)
+        st_ = o.st_;
+        r_ = o.r_;
+        c_ = o.c_;
+        return *this;
+    }
+    template <class Od>
+    Matrix(const MatrixBase<Od>& o) { *this = o; }
+    template <class Od>
+    Matrix& operator=(const MatrixBase<Od>& o)
+    {
+        Index orr = o.rows(), occ = o.cols();
+        // vector <- transposed vector
+        if ((R == 1 && C != 1 && occ == 1 && orr != 1) || (C == 1 && R != 1 && orr == 1 && occ != 1)) std::swap(orr, occ);
+        if (R == Dynamic || C == Dynamic) {
+            typename MatrixBase<Od>::PlainObject t = o.eval(); // o may be a view of *this
+            resize(orr, occ);
+            Base::assignFrom(t);
+        }
+        else
+            Base::assignFrom(o);
+        return *this;
+    }
+
+    template <class Od>
+    Matrix(const ArrayBase<Od>& o) { *this = o.matrix(); }
+    template <class Od>
+    Matrix& operator=(const ArrayBase<Od>& o) { return *this = o.matrix(); }
+
+    void resize(Index r, Index c)
+    {
+        assert((R == Dynamic || R == r) && (C == Dynamic || C == c));
+        if (r != r_ || c != c_) {
+            r_ = r;
+            c_ = c;
+            st_.resize((size_t)(r * c));
+        }
+    }
+    void resize(Index n)
+    {
+        if (C == 1) resize(n, 1);
+        else resize(1, n);
+    }
+    template <class Od>
+    void resizeLike(const MatrixBase<Od>& o) { resize(o.rows(), o.cols()); }
+    void conservativeResize(Index r, Index c)
+    {
+        Matrix t = *this;
+        Index orr = r_, occ = c_;
+        r_ = -1; // force
+        resize(r, c);
+        for (Index j = 0; j < c; ++j)
+            for (Index i = 0; i < r; ++i) ref(i, j) = (i < orr && j < occ) ? t.get(i, j) : S();
+    }
+    void conservativeResize(Index n)
+    {
+        if (C == 1) conservativeResize(n, 1);
+        else conservativeResize(1, n);
+    }
+    void conservativeResize(Index r, NoChange_t) { conservativeResize(r, c_); }
+    void conservativeResize(NoChange_t, Index c) { conservativeResize(r_, c); }
+    void resize(Index r, NoChange_t) { resize(r, c_); }
+    void resize(NoChange_t, Index c) { resize(r_, c); }
+    using Base::setZero;
+    using Base::setOnes;
+    using Base::setConstant;
+    using Base::setIdentity;
+    using Base::setRandom;
+    Matrix& setZero(Index n)
+    {
+        resize(n);
+        return Base::setZero();
+    }
+    Matrix& setZero(Index r, Index c)
+    {
+        resize(r, c);
+        return Base::setZero();
+    }
+    Matrix& setOnes(Index n)
+    {
+        resize(n);
+        return Base::setOnes();
+    }
+    Matrix& setConstant(Index n, S v)
+    {
+        resize(n);
+        return Base::setConstant(v);
+    }
+    Matrix& setConstant(Index r, Index c, S v)
+    {
+        resize(r, c);
+        return Base::setConstant(v);
+    }
+    Matrix& setIdentity(Index r, Index c)
+    {
+        resize(r, c);
+        return Base::setIdentity();
+    }
+    Matrix& setRandom(Index r, Index c)
+    {
+        resize(r, c);
+        return Base::setRandom();
+    }
+    static Matrix Zero()
+    {
+        Matrix m;
+        m.Base::setZero();
+        return m;
+    }
+    static Matrix Zero(Index n)
+    {
+        Matrix m;
+        m.setZero(n);
+        return m;
+    }
+    static Matrix Zero(Index r, Index c)
+    {
+        Matrix m;
+        m.setZero(r, c);
+        return m;
+    }
+    static Matrix Ones()
+    {
+        Matrix m;
+        m.Base::setOnes();
+        return m;
+    }
+    static Matrix Ones(Index n)
+    {
+        Matrix m;
+        m.setOnes(n);
+        return m;
+    }
+    static Matrix Ones(Index r, Index c)
+    {
+        Matrix m;
+        m.resize(r, c);
+        m.Base::setOnes();
+        return m;
+    }
+    static Matrix Constant(S v)
+    {
+        Matrix m;
+        m.Base::setConstant(v);
+        return m;
+    }
+    static Matrix Constant(Index n, S v)
+    {
+        Matrix m;
+        m.setConstant(n, v);
+        return m;
+    }
+    static Matrix Constant(Index r, Index c, S v)
+    {
+        Matrix m;
+        m.setConstant(r, c, v);
+        return m;
+    }
+    static Matrix Identity()
+    {
+        Matrix m;
+        m.Base::setIdentity();
+        return m;
+    }
+    static Matrix Identity(Index r, Index c)
+    {
+        Matrix m;
+        m.setIdentity(r, c);
+        return m;
+    }
+    static Matrix Random()
+    {
+        Matrix m;
+        m.Base::setRandom();
+        return m;
+    }
+    static Matrix Random(Index r, Index c)
+    {
+        Matrix m;
+        m.setRandom(r, c);
+        return m;
+    }
+    static Matrix Random(Index n)
+    {
+        Matrix m;
+        m.resize(n);
+        m.Base::setRandom();
+        return m;
+    }
+    static Eigen::Map<Matrix> Map(S* d, Index r, Index c) { return Eigen::Map<Matrix>(d, r, c); }
+    static Eigen::Map<Matrix> Map(const S* d, Index r, Index c) { return Eigen::Map<Matrix>(d, r, c); }
+    static Eigen::Map<Matrix> Map(S* d, Index n) { return Eigen::Map<Matrix>(d, n); }
+    static Eigen::Map<Matrix> Map(const S* d, Index n) { return Eigen::Map<Matrix>(d, n); }
+    static Matrix LinSpaced(Index n, S lo, S hi)
+    {
+        Matrix m;
+        m.resize(n);
+        for (Index k = 0; k < n; ++k) m.linRef(k) = (n == 1) ? hi : (std::is_integral<S>::value ? S(lo + k * (hi - lo) / (n - 1)) : S(lo + (hi - lo) * S(k) / S(n - 1)));
+        return m;
+    }
+    static Matrix UnitX()
+    {
+        Matrix m = Zero();
+        m.linRef(0) = 1;
+        return m;
+    }
+    static Matrix UnitY()
+    {
+        Matrix m = Zero();
+        m.linRef(1) = 1;
+        return m;
+    }
+    static Matrix UnitZ()
+    {
+        Matrix m = Zero();
+        m.linRef(2) = 1;
+        return m;
+    }
+};
+
+// a rectangular view of another object -----------------------------------------------------------------------
+template <class X, int BR, int BC>
+class Block : public MatrixBase<Block<X, BR, BC>> {
+    typedef MatrixBase<Block> Base;
+    X* x_;
+    Index i0_, j0_, r_, c_;
+
+public:
+    typedef typename internal::traits<Block>::Scalar Scalar;
+    Block(X& x, Index i0, Index j0, Index r, Index c)
+        : x_(&x), i0_(i0), j0_(j0), r_(r), c_(c)
+    {
+        assert(i0 >= 0 && j0 >= 0 && i0 + r <= x.rows() && j0 + c <= x.cols());
+    }
+    Block(const Block&) = default;
+    Index rows_() const { return r_; }
+    Index cols_() const { return c_; }
+    Scalar get(Index i, Index j) const { return x_->get(i0_ + i, j0_ + j); }
+    template <class XX = X>
+    typename std::enable_if<!std::is_const<XX>::value, Scalar&>::type ref(Index i, Index j) { return x_->ref(i0_ + i, j0_ + j); }
+    template <class XX = X>
+    typename std::enable_if<std::is_const<XX>::value, Scalar&>::type ref(Index, Index)
+    {
+        static Scalar dummy;
+        assert(!"write through a const view");
+        return dummy;
+    }
+    Block& operator=(const Block& o)
+    {
+        Base::assignFrom(o);
+        return *this;
+    }
+    template <class Od>
+    Block& operator=(const MatrixBase<Od>& o)
+    {
+        Base::assignFrom(o);
+        return *this;
+    }
+    template <class Od>
+    Block& operator=(const ArrayBase<Od>& o)
+    {
+        Base::assignFrom(o.matrix());
+        return *this;
+    }
+    void resize(Index r, Index c) { assert(r == r_ && c == c_); }
+};
+
+// a view of caller-owned memory with the layout of PlainType
+template <class P, int MapOpt, class Stride>
+class Map : public MatrixBase<Map<P, MapOpt, Stride>> {
+    typedef typename internal::traits<P>::Scalar S;
+    S* d_;
+    Index r_, c_;
+
+public:
+    typedef S Scalar;
+    Map(S* d, Index n)
+        : d_(d), r_(internal::traits<P>::Cols == 1 ? n : 1), c_(internal::traits<P>::Cols == 1 ? 1 : n) {}
+    Map(const S* d, Index n)
+        : Map(const_cast<S*>(d), n) {}
+    Map(S* d, Index r, Index c)
+        : d_(d), r_(r), c_(c) {}
+    Map(const S* d, Index r, Index c)
+        : d_(const_cast<S*>(d)), r_(r), c_(c) {}
+    explicit Map(S* d)
+        : d_(d), r_(internal::traits<P>::Rows), c_(internal::traits<P>::Cols) {}
+    Index rows_() const { return r_; }
+    Index cols_() const { return c_; }
+    S get(Index i, Index j) const { return d_[(internal::traits<P>::Options & RowMajor) ? (i * c_ + j) : (i + r_ * j)]; }
+    S& ref(Index i, Index j) { return d_[(internal::traits<P>::Options & RowMajor) ? (i * c_ + j) : (i + r_ * j)]; }
+    S* data() { return d_; }
+    template <class Od>
+    Map& operator=(const MatrixBase<Od>& o)
+    {
+        MatrixBase<Map>::assignFrom(o);
+        return *this;
+    }
+    Map& operator=(const Map& o)
+    {
+        MatrixBase<Map>::assignFrom(o);
+        return *this;
+    }
+    Map(const Map&) = default;
+};
+
+template <class S, int N, int MN>
+class DiagonalMatrix : public MatrixBase<DiagonalMatrix<S, N, MN>> {
+    Matrix<S, N, 1> d_;
+
+public:
+    typedef S Scalar;
+    DiagonalMatrix() {}
+    DiagonalMatrix(const DiagonalMatrix& o)
+        : MatrixBase<DiagonalMatrix>(), d_(o.d_) {}
+    DiagonalMatrix& operator=(const DiagonalMatrix& o)
+    {
+        d_ = o.d_;
+        return *this;
+    }
+    template <class O>
+    explicit DiagonalMatrix(const MatrixBase<O>& v)
+    {
+        d_.resize(v.size(), 1);
+        for (Index k = 0; k < v.size(); ++k) d_.ref(k, 0) = v.lin(k);
+    }
+    Index rows_() const { return d_.rows(); }
+    Index cols_() const { return d_.rows(); }
+    S get(Index i, Index j) const { return i == j ? d_.get(i, 0) : S(0); }
+    S& ref(Index i, Index j)
+    {
+        assert(i == j);
+        return d_.ref(i, 0);
+    }
+    Matrix<S, N, 1>& diagonal() { return d_; }
+    const Matrix<S, N, 1>& diagonal() const { return d_; }
+    void resize(Index r, Index) { d_.resize(r, 1); }
+};
+template <class D>
+DiagonalMatrix<typename MatrixBase<D>::Scalar, internal::pick(MatrixBase<D>::RowsAtCompileTime, MatrixBase<D>::ColsAtCompileTime) == 1 ? internal::pick(MatrixBase<D>::ColsAtCompileTime, MatrixBase<D>::RowsAtCompileTime) : internal::pick(MatrixBase<D>::RowsAtCompileTime, MatrixBase<D>::ColsAtCompileTime)> MatrixBase<D>::asDiagonal() const
+{
+    return DiagonalMatrix < Scalar, internal::pick(RowsAtCompileTime, ColsAtCompileTime) == 1 ? internal::pick(ColsAtCompileTime, RowsAtCompileTime) : internal::pick(RowsAtCompileTime, ColsAtCompileTime) > (*this);
+}
+template <class D>
+Matrix<typename MatrixBase<D>::Scalar, Dynamic, 1> MatrixBase<D>::diagonal() const
+{
+    Index n = std::min(rows(), cols());
+    Matrix<Scalar, Dynamic, 1> r(n);
+    for (Index i = 0; i < n; ++i) r.ref(i, 0) = coeff(i, i);
+    return r;
+}
+
+// comma initialiser: row-major fill, scalars and blocks ---------------------------------------------------
+template <class S, class M>
+struct CommaInit {
+    M& m;
+    Index row = 0, col = 0, curRows = 1;
+    CommaInit(M& mm)
+        : m(mm) {}
+    void put(S v)
+    {
+        if (col == m.cols()) {
+            row += curRows;
+            col = 0;
+            curRows = 1;
+        }
+        m.coeffRef(row, col) = v;
+        ++col;
+    }
+    template <class O>
+    void putBlock(const MatrixBase<O>& o)
+    {
+        // a vector fed into a vector of the other orientation is taken coefficient by coefficient
+        if ((m.rows() == 1 && o.cols() == 1 && o.rows() > 1) || (m.cols() == 1 && o.rows() == 1 && o.cols() > 1)) {
+            for (Index k = 0; k < o.size(); ++k) put(o.lin(k));
+            return;
+        }
+        if (col == m.cols()) {
+            row += curRows;
+            col = 0;
+        }
+        curRows = o.rows();
+        for (Index j = 0; j < o.cols(); ++j)
+            for (Index i = 0; i < o.rows(); ++i) m.coeffRef(row + i, col + j) = o.coeff(i, j);
+        col += o.cols();
+    }
+    CommaInit& operator,(S v)
+    {
+        put(v);
+        return *this;
+    }
+    template <class O>
+    CommaInit& operator,(const MatrixBase<O>& o)
+    {
+        putBlock(o);
+        return *this;
+    }
+    M& finished() { return m; }
+};
+template <class D>
+CommaInit<typename MatrixBase<D>::Scalar, D> MatrixBase<D>::operator<<(Scalar v)
+{
+    CommaInit<Scalar, D> c(derived());
+    c.put(v);
+    return c;
+}
+template <class D>
+template <class O>
+CommaInit<typename MatrixBase<D>::Scalar, D> MatrixBase<D>::operator<<(const MatrixBase<O>& o)
+{
+    CommaInit<Scalar, D> c(derived());
+    c.putBlock(o);
+    return c;
+}
+
+// arithmetic ------------------------------------------------------------------------------------------------------
+#define MINI_EIGEN_RES(A, B) Matrix<typename MatrixBase<A>::Scalar, internal::pick(MatrixBase<A>::RowsAtCompileTime, MatrixBase<B>::RowsAtCompileTime), internal::pick(MatrixBase<A>::ColsAtCompileTime, MatrixBase<B>::ColsAtCompileTime)>
+template <class A, class B>
+MINI_EIGEN_RES(A, B)
+operator+(const MatrixBase<A>& a, const MatrixBase<B>& b)
+{
+    assert(a.rows() == b.rows() && a.cols() == b.cols());
+    MINI_EIGEN_RES(A, B)
+    r;
+    r.resize(a.rows(), a.cols());
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = a.coeff(i, j) + b.coeff(i, j);
+    return r;
+}
+template <class A, class B>
+MINI_EIGEN_RES(A, B)
+operator-(const MatrixBase<A>& a, const MatrixBase<B>& b)
+{
+    assert(a.rows() == b.rows() && a.cols() == b.cols());
+    MINI_EIGEN_RES(A, B)
+    r;
+    r.resize(a.rows(), a.cols());
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = a.coeff(i, j) - b.coeff(i, j);
+    return r;
+}
+template <class A>
+typename MatrixBase<A>::PlainObject operator-(const MatrixBase<A>& a)
+{
+    typename MatrixBase<A>::PlainObject r;
+    r.resize(a.rows(), a.cols());
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = -a.coeff(i, j);
+    return r;
+}
+template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+typename MatrixBase<A>::PlainObject operator*(const MatrixBase<A>& a, T s)
+{
+    typename MatrixBase<A>::PlainObject r;
+    r.resize(a.rows(), a.cols());
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = a.coeff(i, j) * typename MatrixBase<A>::Scalar(s);
+    return r;
+}
+template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+typename MatrixBase<A>::PlainObject operator*(T s, const MatrixBase<A>& a)
+{
+    typename MatrixBase<A>::PlainObject r;
+    r.resize(a.rows(), a.cols());
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = typename MatrixBase<A>::Scalar(s) * a.coeff(i, j);
+    return r;
+}
+template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+typename MatrixBase<A>::PlainObject operator/(const MatrixBase<A>& a, T s)
+{
+    typename MatrixBase<A>::PlainObject r;
+    r.resize(a.rows(), a.cols());
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = a.coeff(i, j) / typename MatrixBase<A>::Scalar(s);
+    return r;
+}
+template <class A, class B>
+Matrix<typename MatrixBase<A>::Scalar, MatrixBase<A>::RowsAtCompileTime, MatrixBase<B>::ColsAtCompileTime>
+operator*(const MatrixBase<A>& a, const MatrixBase<B>& b)
+{
+    assert(a.cols() == b.rows());
+    Matrix<typename MatrixBase<A>::Scalar, MatrixBase<A>::RowsAtCompileTime, MatrixBase<B>::ColsAtCompileTime> r;
+    r.resize(a.rows(), b.cols());
+    for (Index j = 0; j < b.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i) {
+            typename MatrixBase<A>::Scalar s = 0;
+            for (Index k = 0; k < a.cols(); ++k) s += a.coeff(i, k) * b.coeff(k, j);
+            r.ref(i, j) = s;
+        }
+    return r;
+}
+template <class A, class B>
+bool operator==(const MatrixBase<A>& a, const MatrixBase<B>& b)
+{
+    if (a.rows() != b.rows() || a.cols() != b.cols()) return false;
+    for (Index j = 0; j < a.cols(); ++j)
+        for (Index i = 0; i < a.rows(); ++i)
+            if (a.coeff(i, j) != b.coeff(i, j)) return false;
+    return true;
+}
+template <class A, class B>
+bool operator!=(const MatrixBase<A>& a, const MatrixBase<B>& b) { return !(a == b); }
+
+template <class A>
+std::ostream& operator<<(std::ostream& os, const MatrixBase<A>& a)
+{
+    for (Index i = 0; i < a.rows(); ++i) {
+        for (Index j = 0; j < a.cols(); ++j) os << (j ? " " : "") << a.coeff(i, j);
+        if (i + 1 < a.rows()) os << "\n";
+    }
+    return os;
+}
+
+// coefficient-wise objects --------------------------------------------------------------------------------------------
+struct BoolArray {
+    std::vector<char> m;
+    Index r = 0, c = 0;
+    char at(Index i, Index j) const { return m[(size_t)(i + r * j)]; }
+    bool all() const
+    {
+        for (char x : m)
+            if (!x) return false;
+        return true;
+    }
+    bool any() const
+    {
+        for (char x : m)
+            if (x) return true;
+        return false;
+    }
+    Index count() const
+    {
+        Index n = 0;
+        for (char x : m) n += x ? 1 : 0;
+        return n;
+    }
+    template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+    Matrix<typename MatrixBase<A>::Scalar, Dynamic, Dynamic> select(const MatrixBase<A>& a, T b) const
+    {
+        Matrix<typename MatrixBase<A>::Scalar, Dynamic, Dynamic> o(r, c);
+        for (Index j = 0; j < c; ++j)
+            for (Index i = 0; i < r; ++i) o.ref(i, j) = at(i, j) ? a.coeff(i, j) : typename MatrixBase<A>::Scalar(b);
+        return o;
+    }
+    template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>
+    Matrix<typename MatrixBase<A>::Scalar, Dynamic, Dynamic> select(T a, const MatrixBase<A>& b) const
+    {
+        Matrix<typename MatrixBase<A>::Scalar, Dynamic, Dynamic> o(r, c);
+        for (Index j = 0; j < c; ++j)
+            for (Index i = 0; i < r; ++i) o.ref(i, j) = at(i, j) ? typename MatrixBase<A>::Scalar(a) : b.coeff(i, j);
+        return o;
+    }
+    template <class A, class B>
+    Matrix<typename MatrixBase<A>::Scalar, Dynamic, Dynamic> select(const MatrixBase<A>& a, const MatrixBase<B>& b) const
+    {
+        Matrix<typename MatrixBase<A>::Scalar, Dynamic, Dynamic> o(r, c);
+        for (Index j = 0; j < c; ++j)
+            for (Index i = 0; i < r; ++i) o.ref(i, j) = at(i, j) ? a.coeff(i, j) : b.coeff(i, j);
+        return o;
+    }
+};
+
+template <class Derived>
+class ArrayBase {
+public:
+    typedef typename internal::traits<Derived>::Scalar Scalar;
+    enum { RowsAtCompileTime = internal::traits<Derived>::Rows,
+        ColsAtCompileTime = internal::traits<Derived>::Cols };
+    typedef Array<Scalar, RowsAtCompileTime, ColsAtCompileTime> PlainArray;
+    typedef Matrix<Scalar, RowsAtCompileTime, ColsAtCompileTime> PlainMatrix;
+    Derived& derived() { return *static_cast<Derived*>(this); }
+    const Derived& derived() const { return *static_cast<const Derived*>(this); }
+    Index rows() const { return derived().rows_(); }
+    Index cols() const { return derived().cols_(); }
+    Index size() const { return rows() * cols(); }
+    Scalar coeff(Index i, Index j) const { return derived().get(i, j); }
+    Scalar& coeffRef(Index i, Index j) { return derived().ref(i, j); }
+    Scalar lin(Index k) const { return cols() == 1 ? coeff(k, 0) : (rows() == 1 ? coeff(0, k) : coeff(k % rows(), k / rows())); }
+    Scalar& linRef(Index k) { return cols() == 1 ? coeffRef(k, 0) : (rows() == 1 ? coeffRef(0, k) : coeffRef(k % rows(), k / rows())); }
+    Scalar operator()(Index i, Index j) const { return coeff(i, j); }
+    Scalar& operator()(Index i, Index j) { return coeffRef(i, j); }
+    Scalar operator()(Index k) const { return lin(k); }
+    Scalar& operator()(Index k) { return linRef(k); }
+    Scalar operator[](Index k) const { return lin(k); }
+    Scalar& operator[](Index k) { return linRef(k); }
+    PlainMatrix matrix() const
+    {
+        PlainMatrix r;
+        r.resize(rows(), cols());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) = coeff(i, j);
+        return r;
+    }
+    PlainArray eval() const { return PlainArray(*this); }
+    template <class F>
+    PlainArray map(F f) const
+    {
+        PlainArray r;
+        r.resize(rows(), cols());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) = f(coeff(i, j));
+        return r;
+    }
+    template <class O, class F>
+    PlainArray zip(const ArrayBase<O>& o, F f) const
+    {
+        assert(rows() == o.rows() && cols() == o.cols());
+        PlainArray r;
+        r.resize(rows(), cols());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) = f(coeff(i, j), o.coeff(i, j));
+        return r;
+    }
+    PlainArray ceil() const
+    {
+        return map([](Scalar x) { return Scalar(std::ceil(x)); });
+    }
+    PlainArray floor() const
+    {
+        return map([](Scalar x) { return Scalar(std::floor(x)); });
+    }
+    PlainArray abs() const
+    {
+        return map([](Scalar x) { return Scalar(std::abs(x)); });
+    }
+    PlainArray sqrt() const
+    {
+        return map([](Scalar x) { return Scalar(std::sqrt(x)); });
+    }
+    PlainArray square() const
+    {
+        return map([](Scalar x) { return x * x; });
+    }
+    PlainArray inverse() const
+    {
+        return map([](Scalar x) { return Scalar(1) / x; });
+    }
+    template <class T>
+    PlainArray pow(T p) const
+    {
+        return map([p](Scalar x) { return Scalar(std::pow(x, p)); });
+    }
+    template <class O>
+    PlainArray min(const ArrayBase<O>& o) const
+    {
+        return zip(o, [](Scalar a, Scalar b) { return b < a ? b : a; });
+    }
+    template <class O>
+    PlainArray max(const ArrayBase<O>& o) const
+    {
+        return zip(o, [](Scalar a, Scalar b) { return a < b ? b : a; });
+    }
+    PlainArray min(Scalar b) const
+    {
+        return map([b](Scalar a) { return b < a ? b : a; });
+    }
+    PlainArray max(Scalar b) const
+    {
+        return map([b](Scalar a) { return a < b ? b : a; });
+    }
+    template <class NewT>
+    Array<NewT, RowsAtCompileTime, ColsAtCompileTime> cast() const
+    {
+        Array<NewT, RowsAtCompileTime, ColsAtCompileTime> r;
+        r.resize(rows(), cols());
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) r.ref(i, j) = NewT(coeff(i, j));
+        return r;
+    }
+    BoolArray isFinite() const
+    {
+        BoolArray k;
+        k.r = rows();
+        k.c = cols();
+        k.m.resize((size_t)size());
+        for (Index j = 0; j < k.c; ++j)
+            for (Index i = 0; i < k.r; ++i) k.m[(size_t)(i + k.r * j)] = std::isfinite((double)coeff(i, j)) ? 1 : 0;
+        return k;
+    }
+    struct AColwise {
+        PlainArray a;
+        template <class O>
+        PlainArray operator/(const ArrayBase<O>& v) const
+        {
+            PlainArray r = a;
+            for (Index j = 0; j < r.cols(); ++j)
+                for (Index i = 0; i < r.rows(); ++i) r.ref(i, j) /= v.lin(i);
+            return r;
+        }
+        template <class O>
+        PlainArray operator*(const ArrayBase<O>& v) const
+        {
+            PlainArray r = a;
+            for (Index j = 0; j < r.cols(); ++j)
+                for (Index i = 0; i < r.rows(); ++i) r.ref(i, j) *= v.lin(i);
+            return r;
+        }
+    };
+    struct ARowwise {
+        PlainArray a;
+        Array<Scalar, RowsAtCompileTime, 1> sum() const
+        {
+            Array<Scalar, RowsAtCompileTime, 1> r;
+            r.resize(a.rows(), 1);
+            for (Index i = 0; i < a.rows(); ++i) {
+                Scalar s = 0;
+                for (Index j = 0; j < a.cols(); ++j) s += a.get(i, j);
+                r.ref(i, 0) = s;
+            }
+            return r;
+        }
+    };
+    AColwise colwise() const { return AColwise{ PlainArray(*this) }; }
+    ARowwise rowwise() const { return ARowwise{ PlainArray(*this) }; }
+    Scalar sum() const { return matrix().sum(); }
+    Scalar prod() const { return matrix().prod(); }
+    Scalar minCoeff() const { return matrix().minCoeff(); }
+    Scalar maxCoeff() const { return matrix().maxCoeff(); }
+    Scalar mean() const { return matrix().mean(); }
+    // in-place
+    template <class O>
+    Derived& operator+=(const ArrayBase<O>& o)
+    {
+        PlainArray t = zip(o, [](Scalar a, Scalar b) { return a + b; });
+        return assignA(t);
+    }
+    template <class O>
+    Derived& operator-=(const ArrayBase<O>& o)
+    {
+        PlainArray t = zip(o, [](Scalar a, Scalar b) { return a - b; });
+        return assignA(t);
+    }
+    template <class O>
+    Derived& operator*=(const ArrayBase<O>& o)
+    {
+        PlainArray t = zip(o, [](Scalar a, Scalar b) { return a * b; });
+        return assignA(t);
+    }
+    template <class O>
+    Derived& operator/=(const ArrayBase<O>& o)
+    {
+        PlainArray t = zip(o, [](Scalar a, Scalar b) { return a / b; });
+        return assignA(t);
+    }
+    Derived& operator+=(Scalar s)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) coeffRef(i, j) += s;
+        return derived();
+    }
+    Derived& operator-=(Scalar s)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) coeffRef(i, j) -= s;
+        return derived();
+    }
+    Derived& operator*=(Scalar s)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) coeffRef(i, j) *= s;
+        return derived();
+    }
+    Derived& operator/=(Scalar s)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) coeffRef(i, j) /= s;
+        return derived();
+    }
+    template <class O>
+    Derived& assignA(const ArrayBase<O>& o)
+    {
+        PlainArray t(o);
+        assert(t.size() == size());
+        if (t.rows() == rows() && t.cols() == cols()) {
+            for (Index j = 0; j < cols(); ++j)
+                for (Index i = 0; i < rows(); ++i) coeffRef(i, j) = t.get(i, j);
+        }
+        else
+            for (Index k = 0; k < size(); ++k) linRef(k) = t.lin(k);
+        return derived();
+    }
+    Derived& setConstant(Scalar v)
+    {
+        for (Index j = 0; j < cols(); ++j)
+            for (Index i = 0; i < rows(); ++i) coeffRef(i, j) = v;
+        return derived();
+    }
+    Derived& setZero() { return setConstant(Scalar(0)); }
+    Derived& setOnes() { return setConstant(Scalar(1)); }
+    Derived& fill(Scalar v) { return setConstant(v); }
+};
+
+template <class S, int R, int C, int O, int MR, int MC>
+class Array : public ArrayBase<Array<S, R, C, O, MR, MC>> {
+    Matrix<S, R, C> m_;
+
+public:
+    typedef S Scalar;
+    Index rows_() const { return m_.rows(); }
+    Index cols_() const { return m_.cols(); }
+    S get(Index i, Index j) const { return m_.get(i, j); }
+    S& ref(Index i, Index j) { return m_.ref(i, j); }
+    S* data() { return m_.data(); }
+    const S* data() const { return m_.data(); }
+    void resize(Index r, Index c) { m_.resize(r, c); }
+    void resize(Index n) { m_.resize(n); }
+    Array() {}
+    template <class I, class = typename std::enable_if<std::is_integral<I>::value && (R == Dynamic || C == Dynamic)>::type>
+    explicit Array(I n)
+        : m_(n) {}
+    template <class I, class J, class = typename std::enable_if<std::is_integral<I>::value && std::is_integral<J>::value && (R == Dynamic || C == Dynamic)>::type>
+    Array(I r, J c)
+        : m_(r, c) {}
+    Array(S a, S b, S c)
+        : m_(a, b, c) {}
+    Array(const Array&) = default;
+    Array& operator=(const Array&) = default;
+    template <class Od>
+    Array(const ArrayBase<Od>& o) { *this = o; }
+    template <class Od>
+    Array(const MatrixBase<Od>& o) { m_ = o; }
+    template <class Od>
+    Array& operator=(const ArrayBase<Od>& o)
+    {
+        Matrix<S, Dynamic, Dynamic> t(o.rows(), o.cols());
+        for (Index j = 0; j < o.cols(); ++j)
+            for (Index i = 0; i < o.rows(); ++i) t.ref(i, j) = o.coeff(i, j);
+        m_ = t;
+        return *this;
+    }
+    template <class Od>
+    Array& operator=(const MatrixBase<Od>& o)
+    {
+        m_ = o;
+        return *this;
+    }
+    Array& operator=(S v)
+    {
+        m_.setConstant(v);
+        return *this;
+    }
+    using ArrayBase<Array>::setZero;
+    using ArrayBase<Array>::setOnes;
+    using ArrayBase<Array>::setConstant;
+    Array& setZero(Index n)
+    {
+        m_.setZero(n);
+        return *this;
+    }
+    Array& setZero(Index r, Index c)
+    {
+        m_.setZero(r, c);
+        return *this;
+    }
+    Array& setOnes(Index n)
+    {
+        m_.setOnes(n);
+        return *this;
+    }
+    Array& setConstant(Index n, S v)
+    {
+        m_.setConstant(n, v);
+        return *this;
+    }
+    static Array Zero()
+    {
+        Array a;
+        a.m_.setZero();
+        return a;
+    }
+    static Array Zero(Index n)
+    {
+        Array a;
+        a.m_.setZero(n);
+        return a;
+    }
+    static Array Zero(Index r, Index c)
+    {
+        Array a;
+        a.m_.setZero(r, c);
+        return a;
+    }
+    static Array Ones()
+    {
+        Array a;
+        a.m_.setOnes();
+        return a;
+    }
+    static Array Constant(S v)
+    {
+        Array a;
+        a.m_.setConstant(v);
+        return a;
+    }
+    static Array Constant(Index n, S v)
+    {
+        Array a;
+        a.m_.setConstant(n, v);
+        return a;
+    }
+};
+
+template <class X>
+class ArrayWrap : public ArrayBase<ArrayWrap<X>> {
+    X* x_;
+
+public:
+    typedef typename internal::traits<ArrayWrap>::Scalar Scalar;
+    explicit ArrayWrap(X& x)
+        : x_(&x) {}
+    ArrayWrap(const ArrayWrap&) = default;
+    Index rows_() const { return x_->rows(); }
+    Index cols_() const { return x_->cols(); }
+    Scalar get(Index i, Index j) const { return x_->coeff(i, j); }
+    template <class XX = X>
+    typename std::enable_if<!std::is_const<XX>::value, Scalar&>::type ref(Index i, Index j) { return x_->coeffRef(i, j); }
+    template <class XX = X>
+    typename std::enable_if<std::is_const<XX>::value, Scalar&>::type ref(Index, Index)
+    {
+        static Scalar dummy;
+        assert(!"write through a const view");
+        return dummy;
+    }
+    template <class Od>
+    ArrayWrap& operator=(const ArrayBase<Od>& o)
+    {
+        this->assignA(o);
+        return *this;
+    }
+    ArrayWrap& operator=(const ArrayWrap& o)
+    {
+        this->assignA(o);
+        return *this;
+    }
+};
+
+#define MINI_EIGEN_ARES(A, B) Array<typename ArrayBase<A>::Scalar, internal::pick(ArrayBase<A>::RowsAtCompileTime, ArrayBase<B>::RowsAtCompileTime), internal::pick(ArrayBase<A>::ColsAtCompileTime, ArrayBase<B>::ColsAtCompileTime)>
+#define MINI_EIGEN_ABIN(op)                                                                                          \
+    template <class A, class B>                                                                                      \
+    MINI_EIGEN_ARES(A, B)                                                                                            \
+    operator op(const ArrayBase<A>& a, const ArrayBase<B>& b)                                                        \
+    {                                                                                                                \
+        assert(a.rows() == b.rows() && a.cols() == b.cols());                                                        \
+        MINI_EIGEN_ARES(A, B)                                                                                        \
+        r;                                                                                                           \
+        r.resize(a.rows(), a.cols());                                                                                \
+        for (Index j = 0; j < a.cols(); ++j)                                                                         \
+            for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = a.coeff(i, j) op b.coeff(i, j);                       \
+        return r;                                                                                                    \
+    }                                                                                                                \
+    template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>                 \
+    typename ArrayBase<A>::PlainArray operator op(const ArrayBase<A>& a, T s)                                        \
+    {                                                                                                                \
+        typename ArrayBase<A>::PlainArray r;                                                                         \
+        r.resize(a.rows(), a.cols());                                                                                \
+        for (Index j = 0; j < a.cols(); ++j)                                                                         \
+            for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = a.coeff(i, j) op typename ArrayBase<A>::Scalar(s);    \
+        return r;                                                                                                    \
+    }                                                                                                                \
+    template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>                 \
+    typename ArrayBase<A>::PlainArray operator op(T s, const ArrayBase<A>& a)                                        \
+    {                                                                                                                \
+        typename ArrayBase<A>::PlainArray r;                                                                         \
+        r.resize(a.rows(), a.cols());                                                                                \
+        for (Index j = 0; j < a.cols(); ++j)                                                                         \
+            for (Index i = 0; i < a.rows(); ++i) r.ref(i, j) = typename ArrayBase<A>::Scalar(s) op a.coeff(i, j);    \
+        return r;                                                                                                    \
+    }
+MINI_EIGEN_ABIN(+)
+MINI_EIGEN_ABIN(-)
+MINI_EIGEN_ABIN(*)
+MINI_EIGEN_ABIN(/)
+#undef MINI_EIGEN_ABIN
+template <class A>
+typename ArrayBase<A>::PlainArray operator-(const ArrayBase<A>& a)
+{
+    return a.map([](typename ArrayBase<A>::Scalar x) { return -x; });
+}
+#define MINI_EIGEN_ACMP(op)                                                                                         \
+    template <class A, class B>                                                                                     \
+    BoolArray operator op(const ArrayBase<A>& a, const ArrayBase<B>& b)                                             \
+    {                                                                                                               \
+        assert(a.rows() == b.rows() && a.cols() == b.cols());                                                       \
+        BoolArray k;                                                                                                \
+        k.r = a.rows();                                                                                             \
+        k.c = a.cols();                                                                                             \
+        k.m.resize((size_t)(k.r * k.c));                                                                            \
+        for (Index j = 0; j < k.c; ++j)                                                                             \
+            for (Index i = 0; i < k.r; ++i) k.m[(size_t)(i + k.r * j)] = (a.coeff(i, j) op b.coeff(i, j)) ? 1 : 0;  \
+        return k;                                                                                                   \
+    }                                                                                                               \
+    template <class A, class T, class = typename std::enable_if<std::is_arithmetic<T>::value>::type>                \
+    BoolArray operator op(const ArrayBase<A>& a, T s)                                                               \
+    {                                                                                                               \
+        BoolArray k;                                                                                                \
+        k.r = a.rows();                                                                                             \
+        k.c = a.cols();                                                                                             \
+        k.m.resize((size_t)(k.r * k.c));                                                                            \
+        for (Index j = 0; j < k.c; ++j)                                                                             \
+            for (Index i = 0; i < k.r; ++i) k.m[(size_t)(i + k.r * j)] = (a.coeff(i, j) op typename ArrayBase<A>::Scalar(s)) ? 1 : 0; \
+        return k;                                                                                                   \
+    }
+MINI_EIGEN_ACMP(<)
+MINI_EIGEN_ACMP(<=)
+MINI_EIGEN_ACMP(>)
+MINI_EIGEN_ACMP(>=)
+MINI_EIGEN_ACMP(==)
+MINI_EIGEN_ACMP(!=)
+#undef MINI_EIGEN_ACMP
+template <class A>
+std::ostream& operator<<(std::ostream& os, const ArrayBase<A>& a) { return os << a.matrix(); }
+
+typedef Array<double, 3, 1> Array3d;
+typedef Array<double, 2, 1> Array2d;
+typedef Array<int, 3, 1> Array3i;
+typedef Array<double, Dynamic, 1> ArrayXd;
+typedef Array<int, Dynamic, 1> ArrayXi;
+typedef Array<double, Dynamic, Dynamic> ArrayXXd;
+typedef Array<int, Dynamic, Dynamic> ArrayXXi;
+
+// typedefs ------------------------------------------------------------------------------------------------------
+#define MINI_EIGEN_TYPEDEFS(T, s)                      \
+    typedef Matrix<T, 2, 2> Matrix2##s;                \
+    typedef Matrix<T, 3, 3> Matrix3##s;                \
+    typedef Matrix<T, 4, 4> Matrix4##s;                \
+    typedef Matrix<T, Dynamic, Dynamic> MatrixX##s;    \
+    typedef Matrix<T, 2, 1> Vector2##s;                \
+    typedef Matrix<T, 3, 1> Vector3##s;                \
+    typedef Matrix<T, 4, 1> Vector4##s;                \
+    typedef Matrix<T, Dynamic, 1> VectorX##s;          \
+    typedef Matrix<T, 1, 2> RowVector2##s;             \
+    typedef Matrix<T, 1, 3> RowVector3##s;             \
+    typedef Matrix<T, 1, 4> RowVector4##s;             \
+    typedef Matrix<T, 1, Dynamic> RowVectorX##s;       \
+    typedef Matrix<T, 2, Dynamic> Matrix2X##s;         \
+    typedef Matrix<T, 3, Dynamic> Matrix3X##s;         \
+    typedef Matrix<T, Dynamic, 2> MatrixX2##s;         \
+    typedef Matrix<T, Dynamic, 3> MatrixX3##s;
+MINI_EIGEN_TYPEDEFS(double, d)
+MINI_EIGEN_TYPEDEFS(float, f)
+MINI_EIGEN_TYPEDEFS(int, i)
+
+// LDLT as Eigen does it (Cholesky/LDLT.h, ldlt_inplace<Lower>::unblocked + _solve_impl) -------------------------------
+template <class M>
+class LDLT {
+    typedef typename M::Scalar S;
+    M m_; // L below the diagonal, D on it
+    std::vector<Index> tr_; // transpositions
+    Index n_ = 0;
+
+public:
+    LDLT() {}
+    explicit LDLT(const M& a) { compute(a); }
+    LDLT& compute(const M& a)
+    {
+        m_ = a;
+        n_ = a.rows();
+        tr_.assign((size_t)n_, 0);
+        if (n_ <= 1) {
+            if (n_ == 1) tr_[0] = 0;
+            return *this;
+        }
+        for (Index k = 0; k < n_; ++k) {
+            // largest |diagonal| of the remaining block
+            Index p = k;
+            S big = std::abs(m_.get(k, k));
+            for (Index i = k + 1; i < n_; ++i)
+                if (std::abs(m_.get(i, i)) > big) {
+                    big = std::abs(m_.get(i, i));
+                    p = i;
+                }
+            tr_[(size_t)k] = p;
+            if (p != k) {
+                // symmetric swap of rows / columns k and p, lower triangle only
+                for (Index j = 0; j < k; ++j) std::swap(m_.ref(k, j), m_.ref(p, j));
+                for (Index i = p + 1; i < n_; ++i) std::swap(m_.ref(i, k), m_.ref(i, p));
+                std::swap(m_.ref(k, k), m_.ref(p, p));
+                for (Index i = k + 1; i < p; ++i) std::swap(m_.ref(i, k), m_.ref(p, i));
+            }
+            // A10 = row k left of the diagonal, A20 = rows below left of column k, A21 = column k below the diagonal
+            Index rs = n_ - k - 1;
+            if (k > 0) {
+                std::vector<S> temp((size_t)k);
+                for (Index j = 0; j < k; ++j) temp[(size_t)j] = m_.get(j, j) * m_.get(k, j);
+                S s = 0;
+                for (Index j = 0; j < k; ++j) s += m_.get(k, j) * temp[(size_t)j];
+                m_.ref(k, k) -= s;
+                for (Index i = 0; i < rs; ++i) {
+                    S t = 0;
+                    for (Index j = 0; j < k; ++j) t += m_.get(k + 1 + i, j) * temp[(size_t)j];
+                    m_.ref(k + 1 + i, k) -= t;
+                }
+            }
+            S piv = m_.get(k, k);
+            bool pivot_is_valid = (std::abs(piv) > S(0));
+            if (k == 0 && !pivot_is_valid) {
+                // the whole matrix is zero: identity transpositions for the rest
+                for (Index j = 0; j < n_; ++j) tr_[(size_t)j] = j;
+                break;
+            }
+            if (rs > 0 && pivot_is_valid)
+                for (Index i = 0; i < rs; ++i) m_.ref(k + 1 + i, k) /= piv;
+        }
+        return *this;
+    }
+    template <class B>
+    Matrix<S, MatrixBase<B>::RowsAtCompileTime, MatrixBase<B>::ColsAtCompileTime> solve(const MatrixBase<B>& b) const
+    {
+        Matrix<S, MatrixBase<B>::RowsAtCompileTime, MatrixBase<B>::ColsAtCompileTime> x = b.eval();
+        Index nc = x.cols();
+        // x = P b
+        for (Index k = 0; k < n_; ++k)
+            if (tr_[(size_t)k] != k)
+                for (Index c = 0; c < nc; ++c) std::swap(x.ref(k, c), x.ref(tr_[(size_t)k], c));
+        // L y = x (unit lower)
+        for (Index c = 0; c < nc; ++c)
+            for (Index i = 0; i < n_; ++i) {
+                S s = x.get(i, c);
+                for (Index j = 0; j < i; ++j) s -= m_.get(i, j) * x.get(j, c);
+                x.ref(i, c) = s;
+            }
+        // pseudo-inverse of D: entries with |d| <= 1 / highest give 0
+        const S tol = S(1) / NumTraits<S>::highest();
+        for (Index i = 0; i < n_; ++i) {
+            S d = m_.get(i, i);
+            for (Index c = 0; c < nc; ++c) {
+                if (std::abs(d) > tol) x.ref(i, c) /= d;
+                else x.ref(i, c) = S(0);
+            }
+        }
+        // L^T z = y
+        for (Index c = 0; c < nc; ++c)
+            for (Index i = n_ - 1; i >= 0; --i) {
+                S s = x.get(i, c);
+                for (Index j = i + 1; j < n_; ++j) s -= m_.get(j, i) * x.get(j, c);
+                x.ref(i, c) = s;
+            }
+        // x = P^T z
+        for (Index k = n_ - 1; k >= 0; --k)
+            if (tr_[(size_t)k] != k)
+                for (Index c = 0; c < nc; ++c) std::swap(x.ref(k, c), x.ref(tr_[(size_t)k], c));
+        return x;
+    }
+    ComputationInfo info() const { return Success; }
+};
+template <class D>
+LDLT<typename MatrixBase<D>::PlainObject> MatrixBase<D>::ldlt() const
+{
+    return LDLT<PlainObject>(eval());
+}
+
+// LU with complete pivoting as Eigen does it (LU/FullPivLU.h: computeInPlace + _solve_impl): at step k the entry of
+// largest magnitude of the remaining corner becomes the pivot; solve returns the solution with the free
+// variables of a rank-deficient system set to zero (rank by Eigen's default threshold eps * diagonal size).
+template <class M>
+class FullPivLU {
+    typedef typename M::Scalar S;
+    M lu_;
+    std::vector<Index> rowT_, colT_;
+    Index n_ = 0, nonzeroPivots_ = 0;
+    S maxPivot_ = 0;
+
+public:
+    FullPivLU() {}
+    explicit FullPivLU(const M& a) { compute(a); }
+    FullPivLU& compute(const M& a)
+    {
+        lu_ = a;
+        const Index rows = a.rows(), cols = a.cols(), size = std::min(rows, cols);
+        n_ = size;
+        rowT_.assign((size_t)size, 0);
+        colT_.assign((size_t)size, 0);
+        nonzeroPivots_ = size;
+        maxPivot_ = S(0);
+        for (Index k = 0; k < size; ++k) {
+            Index pr = k, pc = k;
+            S big = S(0);
+            // Eigen scans the corner column by column (visitor over a column-major block) and keeps the first maximum
+            for (Index j = k; j < cols; ++j)
+                for (Index i = k; i < rows; ++i)
+                    if (std::abs(lu_.get(i, j)) > big) {
+                        big = std::abs(lu_.get(i, j));
+                        pr = i;
+                        pc = j;
+                    }
+            if (big == S(0)) {
+                nonzeroPivots_ = k;
+                for (Index i = k; i < size; ++i) {
+                    rowT_[(size_t)i] = i;
+                    colT_[(size_t)i] = i;
+                }
+                break;
+            }
+            if (big > maxPivot_) maxPivot_ = big;
+            rowT_[(size_t)k] = pr;
+            colT_[(size_t)k] = pc;
+            if (pr != k)
+                for (Index j = 0; j < cols; ++j) std::swap(lu_.ref(k, j), lu_.ref(pr, j));
+            if (pc != k)
+                for (Index i = 0; i < rows; ++i) std::swap(lu_.ref(i, k), lu_.ref(i, pc));
+            if (k < rows - 1)
+                for (Index i = k + 1; i < rows; ++i) lu_.ref(i, k) /= lu_.get(k, k);
+            if (k < size - 1)
+                for (Index j = k + 1; j < cols; ++j)
+                    for (Index i = k + 1; i < rows; ++i) lu_.ref(i, j) -= lu_.get(i, k) * lu_.get(k, j);
+        }
+        return *this;
+    }
+    Index rank() const
+    {
+        S thr = NumTraits<S>::epsilon() * S(n_);
+        S premult = std::abs(maxPivot_) * thr;
+        Index r = 0;
+        for (Index i = 0; i < nonzeroPivots_; ++i) r += (std::abs(lu_.get(i, i)) > premult);
+        return r;
+    }
+    bool isInvertible() const { return rank() == n_; }
+    template <class B>
+    Matrix<S, M::ColsAtCompileTime, MatrixBase<B>::ColsAtCompileTime> solve(const MatrixBase<B>& b) const
+    {
+        const Index rows = lu_.rows(), cols = lu_.cols(), smalldim = std::min(rows, cols);
+        const Index nzp = rank();
+        Matrix<S, M::ColsAtCompileTime, MatrixBase<B>::ColsAtCompileTime> dst;
+        dst.resize(cols, b.cols());
+        if (nzp == 0) {
+            dst.setZero();
+            return dst;
+        }
+        Matrix<S, Dynamic, Dynamic> c = b.eval();
+        // c = P b
+        for (Index k = 0; k < smalldim; ++k)
+            if (rowT_[(size_t)k] != k)
+                for (Index j = 0; j < c.cols(); ++j) std::swap(c.ref(k, j), c.ref(rowT_[(size_t)k], j));
+        // unit lower solve on the top smalldim rows
+        for (Index j = 0; j < c.cols(); ++j)
+            for (Index i = 0; i < smalldim; ++i) {
+                S s = c.get(i, j);
+                for (Index k = 0; k < i; ++k) s -= lu_.get(i, k) * c.get(k, j);
+                c.ref(i, j) = s;
+            }
+        // upper solve on the leading nzp x nzp corner
+        for (Index j = 0; j < c.cols(); ++j)
+            for (Index i = nzp - 1; i >= 0; --i) {
+                S s = c.get(i, j);
+                for (Index k = i + 1; k < nzp; ++k) s -= lu_.get(i, k) * c.get(k, j);
+                c.ref(i, j) = s / lu_.get(i, i);
+            }
+        // dst = Q [c_top; 0]: undo the column transpositions in reverse
+        std::vector<Index> perm((size_t)cols);
+        for (Index i = 0; i < cols; ++i) perm[(size_t)i] = i;
+        for (Index k = smalldim - 1; k >= 0; --k) std::swap(perm[(size_t)k], perm[(size_t)colT_[(size_t)k]]);
+        // perm now maps position -> original column, composed as Eigen composes m_q
+        for (Index i = 0; i < cols; ++i)
+            for (Index j = 0; j < c.cols(); ++j) dst.ref(perm[(size_t)i], j) = (i < nzp) ? c.get(i, j) : S(0);
+        return dst;
+    }
+};
+template <class D>
+FullPivLU<typename MatrixBase<D>::PlainObject> MatrixBase<D>::fullPivLu() const
+{
+    return FullPivLU<PlainObject>(eval());
+}
+template <class D>
+FullPivLU<typename MatrixBase<D>::PlainObject> MatrixBase<D>::lu() const
+{
+    return FullPivLU<PlainObject>(eval());
+}
+
+// symmetric eigen-decomposition, cyclic Jacobi, eigenvalues ascending like Eigen's --------------------------------
+template <class M>
+class SelfAdjointEigenSolver {
+    typedef typename M::Scalar S;
+    M vec_;
+    Matrix<S, M::RowsAtCompileTime, 1> val_;
+
+public:
+    SelfAdjointEigenSolver() {}
+    template <class O>
+    explicit SelfAdjointEigenSolver(const MatrixBase<O>& a, int = 0) { compute(a); }
+    template <class O>
+    SelfAdjointEigenSolver& compute(const MatrixBase<O>& a_, int = 0)
+    {
+        M a = a_.eval();
+        Index n = a.rows();
+        // only the lower triangle is referenced, as in Eigen
+        for (Index j = 0; j < n; ++j)
+            for (Index i = 0; i < j; ++i) a.ref(i, j) = a.get(j, i);
+        vec_.resize(n, n);
+        vec_.setIdentity();
+        for (int sweep = 0; sweep < 100; ++sweep) {
+            S off = 0, dia = 0;
+            for (Index j = 0; j < n; ++j)
+                for (Index i = 0; i < n; ++i) (i == j ? dia : off) += a.get(i, j) * a.get(i, j);
+            if (off <= S(1e-32) * dia || off == S(0)) break;
+            for (Index p = 0; p < n - 1; ++p)
+                for (Index q = p + 1; q < n; ++q) {
+                    S apq = a.get(p, q);
+                    if (apq == S(0)) continue;
+                    S theta = (a.get(q, q) - a.get(p, p)) / (S(2) * apq);
+                    S t = (theta >= 0 ? S(1) : S(-1)) / (std::abs(theta) + std::sqrt(theta * theta + S(1)));
+                    S c = S(1) / std::sqrt(t * t + S(1)), s = t * c;
+                    for (Index k = 0; k < n; ++k) {
+                        S akp = a.get(k, p), akq = a.get(k, q);
+                        a.ref(k, p) = c * akp - s * akq;
+                        a.ref(k, q) = s * akp + c * akq;
+                    }
+                    for (Index k = 0; k < n; ++k) {
+                        S apk = a.get(p, k), aqk = a.get(q, k);
+                        a.ref(p, k) = c * apk - s * aqk;
+                        a.ref(q, k) = s * apk + c * aqk;
+                    }
+                    for (Index k = 0; k < n; ++k) {
+                        S vkp = vec_.get(k, p), vkq = vec_.get(k, q);
+                        vec_.ref(k, p) = c * vkp - s * vkq;
+                        vec_.ref(k, q) = s * vkp + c * vkq;
+                    }
+                }
+        }
+        val_.resize(n, 1);
+        std::vector<Index> ord((size_t)n);
+        for (Index i = 0; i < n; ++i) ord[(size_t)i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](Index x, Index y) { return a.get(x, x) < a.get(y, y); });
+        M v2 = vec_;
+        for (Index j = 0; j < n; ++j) {
+            val_.ref(j, 0) = a.get(ord[(size_t)j], ord[(size_t)j]);
+            for (Index i = 0; i < n; ++i) vec_.ref(i, j) = v2.get(i, ord[(size_t)j]);
+        }
+        return *this;
+    }
+    const Matrix<S, M::RowsAtCompileTime, 1>& eigenvalues() const { return val_; }
+    const M& eigenvectors() const { return vec_; }
+    ComputationInfo info() const { return Success; }
+};
+
+// The reference derives AutoFlipSVD from JacobiSVD but, built with USE_IQRSVD, only ever uses its typedefs.
+template <class M, int = 0>
+class JacobiSVD {
+public:
+    typedef Matrix<typename M::Scalar, M::RowsAtCompileTime, 1> SingularValuesType;
+    typedef M MatrixUType;
+    typedef M MatrixVType;
+
+protected:
+    M m_matrixU, m_matrixV;
+    SingularValuesType m_singularValues;
+
+public:
+    JacobiSVD() {}
+    JacobiSVD(const M& m, unsigned int o = 0) { compute(m, o); }
+    JacobiSVD& compute(const M&, unsigned int = 0)
+    {
+        std::cerr << "mini_eigen: JacobiSVD::compute is not provided (the reference is built with USE_IQRSVD)" << std::endl;
+        std::abort();
+        return *this;
+    }
+    const M& matrixU() const { return m_matrixU; }
+    const M& matrixV() const { return m_matrixV; }
+    const SingularValuesType& singularValues() const { return m_singularValues; }
+};
+
+template <class S>
+class AngleAxis;
+// unit quaternion as in Eigen/Geometry/Quaternion.h: from an angle-axis, product, toRotationMatrix
+template <class S>
+class Quaternion {
+    S w_, x_, y_, z_;
+
+public:
+    Quaternion()
+        : w_(1), x_(0), y_(0), z_(0) {}
+    Quaternion(S w, S x, S y, S z)
+        : w_(w), x_(x), y_(y), z_(z) {}
+    explicit Quaternion(const AngleAxis<S>& aa);
+    S w() const { return w_; }
+    S x() const { return x_; }
+    S y() const { return y_; }
+    S z() const { return z_; }
+    Quaternion operator*(const Quaternion& b) const
+    {
+        const Quaternion& a = *this;
+        return Quaternion(a.w_ * b.w_ - a.x_ * b.x_ - a.y_ * b.y_ - a.z_ * b.z_,
+            a.w_ * b.x_ + a.x_ * b.w_ + a.y_ * b.z_ - a.z_ * b.y_,
+            a.w_ * b.y_ + a.y_ * b.w_ + a.z_ * b.x_ - a.x_ * b.z_,
+            a.w_ * b.z_ + a.z_ * b.w_ + a.x_ * b.y_ - a.y_ * b.x_);
+    }
+    Quaternion operator*(const AngleAxis<S>& b) const { return *this * Quaternion(b); }
+    Matrix<S, 3, 3> toRotationMatrix() const
+    {
+        Matrix<S, 3, 3> res;
+        const S tx = S(2) * x_, ty = S(2) * y_, tz = S(2) * z_;
+        const S twx = tx * w_, twy = ty * w_, twz = tz * w_;
+        const S txx = tx * x_, txy = ty * x_, txz = tz * x_;
+        const S tyy = ty * y_, tyz = tz * y_, tzz = tz * z_;
+        res.ref(0, 0) = S(1) - (tyy + tzz);
+        res.ref(0, 1) = txy - twz;
+        res.ref(0, 2) = txz + twy;
+        res.ref(1, 0) = txy + twz;
+        res.ref(1, 1) = S(1) - (txx + tzz);
+        res.ref(1, 2) = tyz - twx;
+        res.ref(2, 0) = txz - twy;
+        res.ref(2, 1) = tyz + twx;
+        res.ref(2, 2) = S(1) - (txx + tyy);
+        return res;
+    }
+    Matrix<S, 3, 3> matrix() const { return toRotationMatrix(); }
+};
+typedef Quaternion<double> Quaterniond;
+// rotation about an axis; toRotationMatrix as in Eigen/Geometry/AngleAxis.h
+template <class S>
+class AngleAxis {
+    S a_;
+    Matrix<S, 3, 1> ax_;
+
+public:
+    AngleAxis()
+        : a_(0) {}
+    template <class O>
+    AngleAxis(S angle, const MatrixBase<O>& axis)
+        : a_(angle), ax_(axis) {}
+    S angle() const { return a_; }
+    const Matrix<S, 3, 1>& axis() const { return ax_; }
+    Matrix<S, 3, 3> toRotationMatrix() const
+    {
+        Matrix<S, 3, 3> res;
+        S sn = std::sin(a_), cs = std::cos(a_);
+        Matrix<S, 3, 1> sin_axis = sn * ax_;
+        Matrix<S, 3, 1> cos1_axis = (S(1) - cs) * ax_;
+        S tmp;
+        tmp = cos1_axis.x() * ax_.y();
+        res.ref(0, 1) = tmp - sin_axis.z();
+        res.ref(1, 0) = tmp + sin_axis.z();
+        tmp = cos1_axis.x() * ax_.z();
+        res.ref(0, 2) = tmp + sin_axis.y();
+        res.ref(2, 0) = tmp - sin_axis.y();
+        tmp = cos1_axis.y() * ax_.z();
+        res.ref(1, 2) = tmp - sin_axis.x();
+        res.ref(2, 1) = tmp + sin_axis.x();
+        res.ref(0, 0) = cos1_axis.x() * ax_.x() + cs;
+        res.ref(1, 1) = cos1_axis.y() * ax_.y() + cs;
+        res.ref(2, 2) = cos1_axis.z() * ax_.z() + cs;
+        return res;
+    }
+    Matrix<S, 3, 3> matrix() const { return toRotationMatrix(); }
+    operator Matrix<S, 3, 3>() const { return toRotationMatrix(); }
+    template <class O>
+    Matrix<S, 3, MatrixBase<O>::ColsAtCompileTime> operator*(const MatrixBase<O>& v) const { return toRotationMatrix() * v; }
+    Quaternion<S> operator*(const AngleAxis& o) const { return Quaternion<S>(*this) * Quaternion<S>(o); }
+    Quaternion<S> operator*(const Quaternion<S>& o) const { return Quaternion<S>(*this) * o; }
+};
+template <class S>
+Quaternion<S>::Quaternion(const AngleAxis<S>& aa)
+{
+    const S ha = S(0.5) * aa.angle();
+    w_ = std::cos(ha);
+    const S sn = std::sin(ha);
+    x_ = sn * aa.axis().x();
+    y_ = sn * aa.axis().y();
+    z_ = sn * aa.axis().z();
+}
+template <class A, class S>
+Matrix<S, MatrixBase<A>::RowsAtCompileTime, 3> operator*(const MatrixBase<A>& m, const AngleAxis<S>& r) { return m * r.toRotationMatrix(); }
+typedef AngleAxis<double> AngleAxisd;
+typedef AngleAxis<float> AngleAxisf;
+
+// storage-only stand-ins -------------------------------------------------------------------------------------------
+template <class S, class I = int>
+class Triplet {
+    I r_, c_;
+    S v_;
+
+public:
+    Triplet()
+        : r_(0), c_(0), v_(0) {}
+    Triplet(I r, I c, S v = S(0))
+        : r_(r), c_(c), v_(v) {}
+    I row() const { return r_; }
+    I col() const { return c_; }
+    S value() const { return v_; }
+};
+template <class S, int O = 0, class I = int>
+class SparseMatrix {
+    // The reference keeps a lumped (diagonal) mass matrix and a few debugging exports in this type; the stand-in is a
+    // coordinate map, ordered by column then row like Eigen's default storage, with the members those uses touch.
+    Index r_ = 0, c_ = 0;
+    std::map<std::pair<I, I>, S> m_; // key = (col, row)
+
+public:
+    typedef S Scalar;
+    SparseMatrix() {}
+    SparseMatrix(Index r, Index c)
+        : r_(r), c_(c) {}
+    void resize(Index r, Index c)
+    {
+        r_ = r;
+        c_ = c;
+        m_.clear();
+    }
+    void conservativeResize(Index r, Index c)
+    {
+        r_ = r;
+        c_ = c;
+    }
+    Index rows() const { return r_; }
+    Index cols() const { return c_; }
+    Index outerSize() const { return c_; }
+    void setZero() { m_.clear(); }
+    void reserve(Index) {}
+    void makeCompressed() {}
+    void setIdentity()
+    {
+        m_.clear();
+        for (Index i = 0; i < std::min(r_, c_); ++i) m_[{ (I)i, (I)i }] = S(1);
+    }
+    template <class It>
+    void setFromTriplets(It b, It e)
+    {
+        m_.clear();
+        for (; b != e; ++b) m_[{ (I)b->col(), (I)b->row() }] += b->value();
+    }
+    S coeff(Index i, Index j) const
+    {
+        auto f = m_.find({ (I)j, (I)i });
+        return f == m_.end() ? S(0) : f->second;
+    }
+    S& coeffRef(Index i, Index j) { return m_[{ (I)j, (I)i }]; }
+    S& insert(Index i, Index j) { return m_[{ (I)j, (I)i }]; }
+    Index nonZeros() const { return (Index)m_.size(); }
+    const std::map<std::pair<I, I>, S>& entriesByColRow() const { return m_; }
+    class InnerIterator {
+        typename std::map<std::pair<I, I>, S>::const_iterator it_, end_;
+        I k_;
+
+    public:
+        InnerIterator(const SparseMatrix& m, Index k)
+            : it_(m.m_.lower_bound({ (I)k, (I)0 })), end_(m.m_.end()), k_((I)k) {}
+        operator bool() const { return it_ != end_ && it_->first.first == k_; }
+        InnerIterator& operator++()
+        {
+            ++it_;
+            return *this;
+        }
+        Index row() const { return it_->first.second; }
+        Index col() const { return it_->first.first; }
+        Index index() const { return it_->first.second; }
+        S value() const { return it_->second; }
+    };
+    S norm() const
+    {
+        S s = 0;
+        for (const auto& e : m_) s += e.second * e.second;
+        return std::sqrt(s);
+    }
+    S squaredNorm() const { return norm() * norm(); }
+    Matrix<S, Dynamic, 1> diagonal() const
+    {
+        Matrix<S, Dynamic, 1> d = Matrix<S, Dynamic, 1>::Zero(std::min(r_, c_));
+        for (const auto& e : m_)
+            if (e.first.first == e.first.second) d.ref(e.first.first, 0) = e.second;
+        return d;
+    }
+    SparseMatrix& operator*=(S s)
+    {
+        for (auto& e : m_) e.second *= s;
+        return *this;
+    }
+    SparseMatrix operator*(S s) const
+    {
+        SparseMatrix r = *this;
+        r *= s;
+        return r;
+    }
+    SparseMatrix operator-(const SparseMatrix& o) const
+    {
+        SparseMatrix r = *this;
+        for (const auto& e : o.m_) r.m_[e.first] -= e.second;
+        return r;
+    }
+    SparseMatrix operator+(const SparseMatrix& o) const
+    {
+        SparseMatrix r = *this;
+        for (const auto& e : o.m_) r.m_[e.first] += e.second;
+        return r;
+    }
+    template <class D>
+    Matrix<S, Dynamic, MatrixBase<D>::ColsAtCompileTime> operator*(const MatrixBase<D>& x) const
+    {
+        Matrix<S, Dynamic, MatrixBase<D>::ColsAtCompileTime> y;
+        y.resize(r_, x.cols());
+        y.setZero();
+        for (const auto& e : m_)
+            for (Index c = 0; c < x.cols(); ++c) y.ref(e.first.second, c) += e.second * x.coeff(e.first.first, c);
+        return y;
+    }
+    SparseMatrix transpose() const
+    {
+        SparseMatrix r(c_, r_);
+        for (const auto& e : m_) r.m_[{ e.first.second, e.first.first }] = e.second;
+        return r;
+    }
+    // compressed-storage accessors exist so that LinSysSolver::set_pattern(SparseMatrix) / getCoeffMtr_lower parse; the
+    // Newton path never calls those overloads
+    I* innerIndexPtr() const { return nullptr; }
+    I* outerIndexPtr() const { return nullptr; }
+    S* valuePtr() const { return nullptr; }
+};
+
+template <class T>
+class aligned_allocator : public std::allocator<T> {
+public:
+    template <class U>
+    struct rebind {
+        typedef aligned_allocator<U> other;
+    };
+    aligned_allocator() {}
+    template <class U>
+    aligned_allocator(const aligned_allocator<U>&) {}
+};
+
+inline void initParallel() {}
+inline void setNbThreads(int) {}
+
+} // namespace Eigen
