@@ -1267,6 +1267,8 @@ double orc_ccd_full(const orc_mesh* m, const double* p, double slackness, double
     if (nCand) *nCand = (int)cand.size();
     return arg >= 0 ? s : stepSize;
 }
+// X15: segment end points, then the triangle
+int orc_seg_tri_intersect(const double* X15) { return segTriIntersect(X15, X15 + 3, X15 + 6, X15 + 9, X15 + 12) ? 1 : 0; }
 int orc_is_intersected(const orc_mesh* m) { return isIntersected(m->m) ? 1 : 0; }
 
 int orc_mesh_surface_counts(const orc_mesh* m, int* n3)

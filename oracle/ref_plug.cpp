@@ -19,6 +19,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 extern "C" {
@@ -52,6 +53,7 @@ bool advance(int kind, const double* X, const double* P, double d0, double eta, 
 {
     const double frac = (eta > 0.0 && d0 > 0.0) ? eta / d0 : 0.01;
     const double toc = orc_accd(kind, X, P, frac, 1.0);
+    if (std::getenv("IPCREF_LOG_CCD")) std::fprintf(stderr, "ccd kind %d d0 %g eta %g frac %g -> %g\n", kind, d0, eta, frac, toc);
     if (toc < 1.0) {
         t = toc;
         return true;
@@ -128,6 +130,7 @@ bool advanceSmall(int n, double X[3][3], const double P0[3][3], double eta, doub
         toc += tl;
         if (toc > 1.0) return false;
     }
+    if (std::getenv("IPCREF_LOG_CCD")) std::fprintf(stderr, "ccd small n %d eta %g frac %g lp %g -> %g\n", n, eta, frac, lp, toc);
     t = toc;
     return true;
 }

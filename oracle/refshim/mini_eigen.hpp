@@ -2147,11 +2147,11 @@ public:
                 for (Index k = i + 1; k < nzp; ++k) s -= lu_.get(i, k) * c.get(k, j);
                 c.ref(i, j) = s / lu_.get(i, i);
             }
-        // dst = Q [c_top; 0]: undo the column transpositions in reverse
+        // dst = Q [c_top; 0]
         std::vector<Index> perm((size_t)cols);
         for (Index i = 0; i < cols; ++i) perm[(size_t)i] = i;
-        for (Index k = smalldim - 1; k >= 0; --k) std::swap(perm[(size_t)k], perm[(size_t)colT_[(size_t)k]]);
-        // perm now maps position -> original column, composed as Eigen composes m_q
+        for (Index k = 0; k < smalldim; ++k) std::swap(perm[(size_t)k], perm[(size_t)colT_[(size_t)k]]);
+        // perm now maps position -> original column, composed as Eigen composes m_q (transpositions applied on the right, k ascending)
         for (Index i = 0; i < cols; ++i)
             for (Index j = 0; j < c.cols(); ++j) dst.ref(perm[(size_t)i], j) = (i < nzp) ? c.get(i, j) : S(0);
         return dst;

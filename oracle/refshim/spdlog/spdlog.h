@@ -1,6 +1,7 @@
 // ORACLE / TEST INFRASTRUCTURE: logging calls of the reference compile to nothing.
 #pragma once
 #include <cstdio>
+#include <cstdlib>
 #include <sstream>
 #include <string>
 // {fmt} comes with spdlog; the reference formats a few file names with it.  Enough of the grammar for those:
@@ -56,12 +57,25 @@ inline void print(const char*, const A&...) {}
 } // namespace fmt
 namespace spdlog {
 namespace level { enum level_enum { trace, debug, info, warn, err, critical, off }; }
-template <class... A> inline void trace(const A&...) {}
-template <class... A> inline void debug(const A&...) {}
-template <class... A> inline void info(const A&...) {}
-template <class... A> inline void warn(const A&...) {}
-template <class... A> inline void error(const A&...) {}
-template <class... A> inline void critical(const A&...) {}
+// messages are dropped unless IPCREF_LOG is set in the environment (debugging the stand-ins)
+inline bool refshim_log_on()
+{
+    static const bool on = std::getenv("IPCREF_LOG") != nullptr;
+    return on;
+}
+template <class... A>
+inline void refshim_log(const char* lvl, const char* f, const A&... a)
+{
+    if (refshim_log_on()) std::fprintf(stderr, "[%s] %s\n", lvl, fmt::format(f, a...).c_str());
+}
+template <class... A> inline void trace(const char* f, const A&... a) { refshim_log("trace", f, a...); }
+template <class... A> inline void debug(const char* f, const A&... a) { refshim_log("debug", f, a...); }
+template <class... A> inline void info(const char* f, const A&... a) { refshim_log("info", f, a...); }
+template <class... A> inline void warn(const char* f, const A&... a) { refshim_log("warn", f, a...); }
+template <class... A> inline void error(const char* f, const A&... a) { refshim_log("error", f, a...); }
+template <class... A> inline void critical(const char* f, const A&... a) { refshim_log("critical", f, a...); }
+template <class... A> inline void info(const std::string& f, const A&... a) { refshim_log("info", f.c_str(), a...); }
+template <class... A> inline void error(const std::string& f, const A&... a) { refshim_log("error", f.c_str(), a...); }
 inline void set_level(level::level_enum) {}
 inline level::level_enum get_level() { return level::off; }
 } // namespace spdlog

@@ -1,0 +1,277 @@
+"""The oracle pinned against the REFERENCE ITSELF.
+
+tests/golden/ref_functions.npz and ref_scene_*.npz hold what the reference's own sources return -- compiled from /root/reference
+into oracle/_ref/libipcref.so (oracle/Makefile.ref: Eigen replaced by the stand-in header oracle/refshim/mini_eigen.hpp, CTCD and
+the Cholesky plugged from the oracle, everything else the reference's code) and evaluated by tools/make_golden_ref.py on seeded
+inputs.  These tests recompute the same quantities with the CPU oracle.  They run wherever the repository is (no /root/reference
+needed); when libipcref.so is present they also check that the committed vectors are what the library returns today.
+
+Tolerances: integer outputs (closest-feature types, constraint tuples, CSR pattern, surface bookkeeping, intersection flags)
+bit-exact; floating-point values 1e-10 relative unless a line says why it is looser."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from oracle import orc, ref  # noqa: E402
+
+GOLD = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(GOLD, "ref_functions.npz"))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+NODES = (2, 3, 4, 4)
+
+
+def test_distances_gradients_hessians(G):
+    """d_PP / d_PE / d_PT / d_EE with g_* and H_* (MeshCollisionUtils.hpp:156-2004, MATLAB-generated straight-line code in the
+    reference, vector-form derivatives in the oracle)."""
+    for kind, name in enumerate(("PP", "PE", "PT", "EE")):
+        n = 3 * NODES[kind]
+        for i, X in enumerate(G["dist_X"]):
+            d, g, H = orc.stencil_distance(kind, X)
+            assert abs(d - G[f"dist_{name}_d"][i]) <= 1e-12 * abs(d), (name, i)
+            gs = np.abs(G[f"dist_{name}_g"][i]).max()
+            assert np.abs(g[:n] - G[f"dist_{name}_g"][i]).max() <= 1e-10 * gs, (name, i)
+            Hs = np.abs(G[f"dist_{name}_H"][i]).max()
+            # the reference's generated Hessians cancel large terms: 1e-8 of the largest entry
+            assert np.abs(H[:n, :n] - G[f"dist_{name}_H"][i]).max() <= 1e-8 * Hs, (name, i)
+
+
+def test_closest_feature_types_bit_exact(G):
+    """dType_PT / dType_EE (MeshCollisionUtils.hpp:2073-2210), including feet exactly on vertices and edges and parallel edges."""
+    pt = np.array([orc.dtype_pt(x) for x in G["cls_X"]])
+    ee = np.array([orc.dtype_ee(x) for x in G["cls_X"]])
+    assert np.array_equal(pt, G["cls_pt"])
+    assert np.array_equal(ee, G["cls_ee"])
+
+
+def test_barrier_and_mollifier(G):
+    for d, want in zip(G["bar_d"], G["bar_bgH"]):
+        assert rel(orc.barrier(d, float(G["bar_dHat"])), want) < 1e-13
+    for X, eps, c, cg, cH, e, eg, eH in zip(G["mol_X"], G["mol_eps"], G["mol_c"], G["mol_cg"], G["mol_cH"], G["mol_e"], G["mol_eg"], G["mol_eH"]):
+        oc, ocg, ocH = orc.cross_sqnorm(X)
+        assert abs(oc - c) <= 1e-12 * max(abs(c), 1e-300)
+        assert rel(ocg, cg) < 1e-10 and rel(ocH, cH) < 1e-10
+        # e(c) = q(c / eps_x) chained through the cross-product norm (compute_e / compute_e_g / compute_e_H)
+        m, mg, mH = orc.mollifier(oc, eps)
+        assert abs(m - e) <= 1e-12
+        if np.abs(eg).max() > 0:
+            assert rel(mg * ocg, eg) < 1e-10
+            assert rel(mH * np.outer(ocg, ocg) + mg * ocH, eH) < 1e-9
+
+
+def test_svd_convention_and_make_pd(G):
+    """AutoFlipSVD over ImplicitQRSVD.h (implicit-shift QR in the reference, Jacobi sweeps in the oracle): same singular values, same
+    sign convention (negative sign on the smallest), U S V^T = F, rotations; makePD: the clamped matrix is unique."""
+    for F, U, s, V in zip(G["svd_F"], G["svd_U"], G["svd_s"], G["svd_V"]):
+        Uo, so, Vo = orc.svd3(F)
+        scale = max(np.abs(s).max(), 1.0)
+        assert np.abs(so - s).max() <= 1e-12 * scale
+        assert np.abs(Uo @ np.diag(so) @ Vo.T - F).max() <= 1e-12 * scale
+        assert abs(np.linalg.det(Uo) - 1) < 1e-10 and abs(np.linalg.det(Vo) - 1) < 1e-10
+        assert abs(np.linalg.det(U) - 1) < 1e-10 and abs(np.linalg.det(V) - 1) < 1e-10  # the reference's convention itself
+    for n in (6, 9, 12):
+        for A, P in zip(G[f"pd{n}_A"], G[f"pd{n}_P"]):
+            assert rel(orc.make_pd(A), P) < 1e-10
+
+
+def test_mesh_features_and_elasticity(G):
+    """Mesh<3> features (Mesh.cpp:414-527, 246-266), NH and FCR energy / gradient / PSD-projected Hessian in the solver's CSR
+    (Energy.cpp:195-562, LinSysSolver.hpp:46-150) and the inversion filter, on the reference's bar-186 mesh, pre-strained."""
+    V, T, SF = G["bar_V"], G["bar_T"], G["bar_SF"]
+    m = orc.Mesh(V, T, YM=float(G["bar_YM"]), PR=float(G["bar_PR"]), density=float(G["bar_rho"]))
+    m.set_surface(SF)
+    f = m.features()
+    assert rel(f["restTriInv"].reshape(-1, 3, 3).transpose(0, 2, 1), G["bar_restTriInv"]) < 1e-12
+    assert rel(f["triArea"], G["bar_triArea"]) < 1e-13 and rel(f["mass"], G["bar_mass"]) < 1e-13
+    assert rel(f["mu"], G["bar_mu"]) < 1e-15 and rel(f["lam"], G["bar_lam"]) < 1e-15
+    assert abs(f["bboxDiag2"] - G["bar_bbox2"]) <= 1e-13 * G["bar_bbox2"]
+    SVI, SFE = orc.mesh_surface(m)
+    assert np.array_equal(SVI, G["bar_SVI"]) and np.array_equal(SFE, G["bar_SFEdges"])
+    m.set_V(G["bar_Vx"])
+    m.set_dbc(G["bar_dbc"], 1)
+    ia, ja = m.pattern()
+    for name in ("NH", "FCR"):
+        m.set_energy_type(name)
+        assert abs(m.elastic_energy(0.7) - G[f"bar_E_{name}"]) <= 1e-12 * abs(G[f"bar_E_{name}"])
+        assert rel(m.elastic_gradient(0.7), G[f"bar_g_{name}"]) < 1e-11
+        assert np.array_equal(ia, G[f"bar_ia_{name}"]) and np.array_equal(ja, G[f"bar_ja_{name}"])
+        # the oracle's Newton assembly = elasticity + lumped mass on free diagonals, unit diagonal on Dirichlet rows: remove the mass
+        a = m.assemble_hessian(len(ja), 0.7)
+        free = np.ones(V.shape[0], bool)
+        free[G["bar_dbc"]] = False
+        diag = ia[:-1]
+        a_el = a.copy()
+        a_el[diag] -= np.repeat(np.where(free, f["mass"], 0.0), 3)
+        want = G[f"bar_a_{name}"]
+        assert np.array_equal(a_el == 0, want == 0) or np.abs(a_el[(a_el == 0) != (want == 0)]).max() < 1e-9 * np.abs(want).max()
+        assert rel(a_el, want) < 1e-10, name
+    m.set_energy_type("NH")
+    for p, want in zip(G["bar_p"], G["bar_filter"]):
+        assert abs(m.filter_step_size(p, 1.0) - want) <= 1e-10 * want
+
+
+@pytest.fixture(scope="module")
+def contact(G):
+    m = orc.Mesh(G["con_V"], G["con_T"], YM=2e4, PR=0.4, density=1000.0)
+    m.set_surface(G["con_SF"])
+    return m
+
+
+def test_constraint_sets_bit_exact_against_the_reference(G, contact):
+    """SelfCollisionHandler::computeConstraintSet through the reference's SpatialHash (SelfCollisionHandler.cpp:2149-2478):
+    the same MMCVID tuples -- as sets; the reference's order is the iteration order of its hash, the oracle's is canonical."""
+    cs = orc.Contacts()
+    got = cs.build(contact, float(G["con_dHat"]))
+
+    def canon(a):
+        return sorted(map(tuple, np.asarray(a).tolist()))
+
+    assert canon(got["active"]) == canon(G["con_active"])
+    assert canon(np.hstack([got["para"], got["para_eiej"]])) == canon(np.hstack([G["con_para"], G["con_eiej"]]))
+    assert canon(got["cs_ptee"]) == canon(G["con_csPTEE"])
+    kinds = got["active"]
+    assert ((kinds[:, 0] < 0) & (kinds[:, 2] < 0)).any() and (kinds[:, 3] < -1).any() and len(got["para"]) > 0  # PP, duplicates, mollified pairs present
+
+
+def test_barrier_terms_against_the_reference(G, contact):
+    """kappa * (sum b(d) with multiplicities + mollified pairs), its gradient and PSD-projected Hessian (evaluateConstraints,
+    leftMultiplyConstraintJacobianT, augmentIPHessian, augmentParaEE*, Optimizer.cpp:3262-3349)."""
+    dHat, kappa = float(G["con_dHat"]), float(G["con_kappa"])
+    cs = orc.Contacts()
+    cs.set(G["con_active"], G["con_para"], G["con_eiej"])  # the reference's own sets, in its order
+    assert abs(cs.energy(contact, dHat, kappa) - G["con_E"]) <= 1e-11 * abs(G["con_E"])
+    assert rel(cs.gradient(contact, dHat, kappa), G["con_g"]) < 1e-10
+    pairs = cs.connectivity(contact)
+    ia, ja = contact.pattern(pairs)
+    assert np.array_equal(ia, G["con_ia"]) and np.array_equal(ja, G["con_ja"])  # augmentConnectivity + set_pattern
+    a = cs.hessian(contact, len(ja), dHat, kappa)
+    assert rel(a, G["con_a"]) < 1e-8  # makePD on 6/9/12 blocks: two different symmetric eigen-solvers
+
+
+def test_step_bounds_and_intersection_against_the_reference(G, contact):
+    """largestFeasibleStepSize (candidate list) and largestFeasibleStepSize_CCD (full sweep through the reference's spatial hash,
+    SelfCollisionHandler.cpp:564-686, 982-1366) with the per-pair query plugged from the oracle; checkEdgeTriIntersectionIfAny."""
+    cs = orc.Contacts()
+    cs.build(contact, float(G["con_dHat"]))
+    for p, part, full in zip(G["con_p"], G["con_ccd_partial"], G["con_ccd_full"]):
+        assert abs(orc.ccd_partial(cs, contact, p, 0.8, 1.0)[0] - part) <= 1e-9 * part
+        assert abs(orc.ccd_full(contact, p, 0.8, 1.0)[0] - full) <= 1e-9 * full
+    assert orc.is_intersected(contact) == bool(G["con_intersected"][0]) and not orc.is_intersected(contact)
+    contact.set_V(G["con_Vi"])
+    assert orc.is_intersected(contact) == bool(G["con_intersected_i"][0]) and orc.is_intersected(contact)
+    contact.set_V(G["con_V"])
+
+
+def test_segment_triangle_intersection_flags(G):
+    """IglUtils::segTriIntersect, the branch of the default build (IglUtils.hpp:236-264)."""
+    import ctypes as C
+    L = orc.lib()
+    if not hasattr(L, "orc_seg_tri_intersect"):
+        pytest.skip("oracle built without orc_seg_tri_intersect")
+    hit = np.array([L.orc_seg_tri_intersect(np.ascontiguousarray(x).ctypes.data_as(C.c_void_p)) for x in G["seg_X"]], np.int8)
+    assert np.array_equal(hit, G["seg_hit"])
+
+
+def test_half_space_against_the_reference(G):
+    """HalfSpace<3> (HalfSpace.cpp:41-269, CollisionObject.h:323-401): active vertices, barrier terms, ray step bound."""
+    contact = orc.Mesh(G["con_V"], G["con_T"], YM=2e4, PR=0.4, density=1000.0)
+    contact.set_surface(G["con_SF"])
+    dHat, kappa = float(G["con_dHat"]), float(G["con_kappa"])
+    hs = orc.HalfSpace(G["hs_o"], G["hs_n"])
+    act = hs.build(contact, dHat)
+    assert np.array_equal(np.sort(act), np.sort(G["hs_active"])) and len(act) > 0
+    assert abs(hs.energy(contact, dHat, kappa) - G["hs_E"]) <= 1e-12 * abs(G["hs_E"])
+    assert rel(hs.gradient(contact, dHat, kappa), G["hs_g"]) < 1e-12
+    ia, ja = contact.pattern()
+    assert rel(hs.hessian(contact, len(ja), dHat, kappa), G["hs_a"]) < 1e-12
+    for p, want in zip(G["con_p"], G["hs_step"]):
+        assert abs(hs.step_bound(contact, p, 0.9, 1.0) - want) <= 1e-12 * want
+
+
+# ---- whole scenes through the reference's main.cpp / Optimizer.cpp ------------------------------------------------------------------
+def load_scene(name):
+    S = np.load(os.path.join(GOLD, f"ref_scene_{name}.npz"))
+    meshes = {str(k): (S[f"mesh{i}_V"], S[f"mesh{i}_T"], S[f"mesh{i}_SF"]) for i, k in enumerate(S["mesh_keys"])}
+    return S, meshes
+
+
+def run_scene(S, meshes, backend, steps):
+    from ipc_amd import scene_script as ss
+    cfg = ss.SceneConfig.parse(str(S["script"]), "/root/reference")
+    sc = ss.assemble(cfg, lambda p: tuple(a.copy() for a in meshes[os.path.relpath(p, "/root/reference")]))
+    be = ss.apply(sc, backend)
+    pos, its = [], []
+    for s in range(steps):
+        sc.before_step(be, s * cfg.dt)
+        its.append(be.solve_timestep(10000))
+        pos.append(be.state()["V"].copy())
+    return np.array(pos), np.array(its)
+
+
+def oracle_backend():
+    from test_scene_script import OracleBackend
+    return OracleBackend(orc, nthreads=4)
+
+
+def test_scene_bar_twist_against_the_reference():
+    """BASELINE configs[0] (barTwist_noCollisions.txt on bar-2523.msh) run by the reference itself: the same Newton iteration
+    count in every step; positions agree to the Newton tolerance of the script (1e-2 of the characteristic residual: observed 1e-6
+    of the bar's length -- the scene starts exactly at rest, where IglUtils::makePD2d is discontinuous and round-off decides)."""
+    S, meshes = load_scene("bar_twist")
+    pos, its = run_scene(S, meshes, oracle_backend(), 3)
+    assert np.array_equal(its, S["iters"][:3])
+    for s in range(3):
+        assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-5 * np.abs(S["positions"][s]).max()
+
+
+def test_scene_bar_twist_minimisers_against_the_reference():
+    """The same scene with `tol 1e-6`: both solve every incremental potential to its minimiser, which does not depend on the
+    rest-state round-off."""
+    S, meshes = load_scene("bar_twist_tight")
+    pos, its = run_scene(S, meshes, oracle_backend(), 2)
+    assert np.array_equal(its[1:], S["iters"][1:2])  # from step 2 on the start is generic
+    for s in range(2):
+        assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-7 * np.abs(S["positions"][s]).max()
+
+
+def test_scene_two_cubes_fall_against_the_reference():
+    """The tutorial scene 2cubesFall.txt (two cubes, ground with friction, self-contact with friction) run by the reference itself,
+    40 steps: free fall identical to round-off; the same Newton iteration counts through both impacts except the step of the first
+    touch-down, where the bottom cube is still exactly undeformed (F = I up to round-off, the makePD2d discontinuity)."""
+    S, meshes = load_scene("two_cubes_fall")
+    steps = int(S["steps"])
+    pos, its = run_scene(S, meshes, oracle_backend(), steps)
+    free = 17
+    for s in range(free):
+        assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-13
+    assert np.array_equal(its[:free], S["iters"][:free])
+    differ = np.nonzero(its != S["iters"])[0]
+    assert set(differ.tolist()) <= {free}, (its.tolist(), S["iters"].tolist())
+    assert its.sum() <= S["iters"].sum() + 2 and its.sum() >= S["iters"].sum() - 2
+    # after the impacts the two trajectories stay close (friction amplifies the touch-down difference slowly)
+    assert np.abs(pos[-1] - S["positions"][-1]).max() <= 5e-3 * np.abs(S["positions"][-1]).max()
+
+
+@pytest.mark.skipif(not (ref.available() and os.path.isdir("/root/reference")), reason="oracle/_ref/libipcref.so exists in the build container only")
+def test_committed_vectors_are_what_the_reference_library_returns(G):
+    for kind, name in enumerate(("PP", "PE", "PT", "EE")):
+        for i in (0, 17, 63):
+            d, g, H = ref.stencil_distance(kind, G["dist_X"][i])
+            assert d == G[f"dist_{name}_d"][i] and np.array_equal(g, G[f"dist_{name}_g"][i]) and np.array_equal(H, G[f"dist_{name}_H"][i])
+    m = ref.Mesh(G["con_V"], G["con_T"], G["con_SF"], 2e4, 0.4, 1000.0, node_ranges=G["con_nodeRanges"], sf_ranges=G["con_sfRanges"])
+    act, par, eiej, cs = m.constraint_set(float(G["con_dHat"]))
+    assert np.array_equal(act, G["con_active"]) and np.array_equal(par, G["con_para"]) and np.array_equal(cs, G["con_csPTEE"])
+    assert m.barrier_energy(float(G["con_dHat"]), float(G["con_kappa"])) == G["con_E"]

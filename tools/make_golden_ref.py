@@ -1,0 +1,206 @@
+"""TEST INFRASTRUCTURE -- golden vectors taken from the REFERENCE ITSELF.
+
+oracle/_ref/libipcref.so is the reference's own sources compiled from /root/reference (oracle/Makefile.ref).  This script
+evaluates them on seeded inputs and writes what they return to tests/golden/ref_functions.npz (single functions and
+mesh-level pieces of the Newton path) and tests/golden/ref_scene_<name>.npz (whole scene scripts run through the reference's
+main.cpp / Optimizer.cpp in offline mode: positions after every time step, Newton iterations per step).  The fixtures carry
+their inputs (meshes included), so tests/ can check the oracle on the CPU and the HIP library on the GPU box, where neither
+/root/reference nor libipcref.so exists.
+
+    make -C oracle -f Makefile.ref && python tools/make_golden_ref.py [functions] [scenes]
+
+Build container only."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+from ipc_amd import lib as gl  # noqa: E402  (the msh reader only; no GPU is touched)
+from ipc_amd import scene_script as ss  # noqa: E402
+from oracle import ref  # noqa: E402
+import ref_compare as rc  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REF_ROOT = "/root/reference"
+
+
+def stencil_inputs(rng, n):
+    """Generic stencils plus the configurations the classification has to get right: feet on vertices / edges, parallel edges."""
+    X = rng.standard_normal((n, 4, 3))
+    X[n // 2:] *= rng.uniform(1e-3, 1e2, size=(n - n // 2, 1, 1))
+    return X
+
+
+def functions():
+    rng = np.random.default_rng(20240925)
+    out = {}
+    # --- distances with gradient and Hessian (MeshCollisionUtils.hpp:156-2004) -------------------------------------------------
+    X = stencil_inputs(rng, 64)
+    for kind, name in enumerate(("PP", "PE", "PT", "EE")):
+        n = (2, 3, 4, 4)[kind]
+        d, g, H = np.zeros(len(X)), np.zeros((len(X), 3 * n)), np.zeros((len(X), 3 * n, 3 * n))
+        for i, x in enumerate(X):
+            d[i], g[i], H[i] = ref.stencil_distance(kind, x)
+        out[f"dist_{name}_d"], out[f"dist_{name}_g"], out[f"dist_{name}_H"] = d, g, H
+    out["dist_X"] = X
+    # --- closest-feature classification (MeshCollisionUtils.hpp:2073-2210) and the classified distances ---------------------
+    Xc = [rng.standard_normal((4, 3)) for _ in range(300)]
+    for _ in range(100):  # point over a vertex / an edge / the interior of a unit triangle, edges in special positions
+        t = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], float)
+        p = np.array([rng.choice([-0.5, 0.0, 0.25, 0.5, 1.0, 1.5]), rng.choice([-0.5, 0.0, 0.25, 0.5, 1.0, 1.5]), rng.choice([0.3, 1.0])])
+        Xc.append(np.vstack([p, t]))
+        e = np.array([[0, 0, 0], [1, 0, 0], [rng.choice([-1, 0, 0.5, 1, 2]), rng.choice([-1, 0.5, 1]), 0.7], [rng.choice([-1, 0, 0.5, 1, 2]), rng.choice([-1, 0.5, 1]), 0.7]], float)
+        Xc.append(e)
+    Xc = np.array(Xc)
+    out["cls_X"] = Xc
+    out["cls_pt"] = np.array([ref.dtype_pt(x) for x in Xc], np.int32)
+    out["cls_ee"] = np.array([ref.dtype_ee(x) for x in Xc], np.int32)
+    out["cls_dpt"] = np.array([ref.classified_distance(2, x) for x in Xc])
+    out["cls_dee"] = np.array([ref.classified_distance(3, x) for x in Xc])
+    # --- barrier (BarrierFunctions.hpp) and the edge-edge mollifier (MeshCollisionUtils.hpp:2409-2912) -------------------------
+    dHat = 1.3e-3
+    ds = dHat * np.concatenate([rng.uniform(1e-6, 1.0, 40), [0.5, 0.999999]])
+    out["bar_dHat"], out["bar_d"] = dHat, ds
+    out["bar_bgH"] = np.array([ref.barrier(d, dHat) for d in ds])
+    Xm = rng.standard_normal((48, 4, 3))
+    Xm[24:, 3] = Xm[24:, 2] + (Xm[24:, 1] - Xm[24:, 0]) * rng.uniform(0.5, 2.0, (24, 1)) + 1e-3 * rng.standard_normal((24, 3))  # nearly parallel
+    eps_x = rng.uniform(1e-3, 1.0, 48)
+    mo = [ref.ee_mollifier(x, e) for x, e in zip(Xm, eps_x)]
+    out["mol_X"], out["mol_eps"] = Xm, eps_x
+    for k, name in enumerate(("c", "cg", "cH", "e", "eg", "eH")):
+        out[f"mol_{name}"] = np.array([m[k] for m in mo])
+    # --- segment / triangle intersection (IglUtils.hpp:214-265, the branch the default build compiles) ----------------------
+    Xs = [rng.standard_normal((5, 3)) for _ in range(400)]
+    for _ in range(200):  # a segment through / beside / in the plane of the unit triangle
+        a = np.array([rng.uniform(-0.2, 1.2), rng.uniform(-0.2, 1.2), rng.choice([0.5, 1e-9, 0.0])])
+        b = np.array([rng.uniform(-0.2, 1.2), rng.uniform(-0.2, 1.2), rng.choice([-0.5, -1e-9, 0.0, 0.5])])
+        Xs.append(np.vstack([a, b, [0, 0, 0], [1, 0, 0], [0, 1, 0]]))
+    Xs = np.array(Xs)
+    out["seg_X"], out["seg_hit"] = Xs, np.array([ref.seg_tri_intersect(x) for x in Xs], np.int8)
+    # --- 3x3 SVD (AutoFlipSVD over ImplicitQRSVD.h:687-850) and makePD (IglUtils.hpp) -----------------------------------------
+    Fs = [np.eye(3) + 0.3 * rng.standard_normal((3, 3)) for _ in range(60)]
+    Fs += [np.diag([1.0, 1.0, 1.0]), np.diag([2.0, 1.0, 0.5]), -np.eye(3), np.diag([1.0, 1.0, -0.3]), np.zeros((3, 3)), np.outer([1, 2, 3], [0.5, -1, 2.0])]
+    Fs = np.array(Fs)
+    sv = [ref.svd3(F) for F in Fs]
+    out["svd_F"], out["svd_U"], out["svd_s"], out["svd_V"] = Fs, np.array([s[0] for s in sv]), np.array([s[1] for s in sv]), np.array([s[2] for s in sv])
+    for n in (6, 9, 12):
+        A = rng.standard_normal((12, n, n))
+        A = A + A.transpose(0, 2, 1)
+        out[f"pd{n}_A"], out[f"pd{n}_P"] = A, np.array([ref.make_pd(a) for a in A])
+
+    # --- mesh level: bar-186 of the reference, jittered and pre-strained ------------------------------------------------------------
+    V, T, SF = gl.read_tet_mesh(os.path.join(REF_ROOT, "input/tetMeshes/bar-186.msh"))
+    YM, PR, rho = 1e5, 0.4, 1000.0
+    Vx = V * [1.05, 0.97, 1.02] + 5e-3 * rng.standard_normal(V.shape)
+    m = ref.Mesh(V, T, SF, YM, PR, rho)
+    f = m.features()
+    SVI, SFE = m.surface()
+    out.update(bar_V=V, bar_T=T, bar_SF=SF, bar_Vx=Vx, bar_YM=YM, bar_PR=PR, bar_rho=rho, bar_restTriInv=f["restTriInv"], bar_triArea=f["triArea"], bar_mass=f["mass"],
+               bar_mu=f["mu"], bar_lam=f["lam"], bar_bbox2=f["bbox2"], bar_avgNodeMass=f["avgNodeMass"], bar_SVI=SVI, bar_SFEdges=SFE)
+    dbc = np.where(V[:, 0] < V[:, 0].min() + 1e-9)[0].astype(np.int32)
+    out["bar_dbc"] = dbc
+    m.set_positions(Vx)
+    m.set_dbc(dbc, 1)
+    for kind, name in ((0, "NH"), (1, "FCR")):
+        out[f"bar_E_{name}"] = m.elastic_energy(kind, 0.7)
+        out[f"bar_g_{name}"] = m.elastic_gradient(kind, 0.7)
+        ia, ja, a = m.elastic_hessian(kind, 0.7)
+        out[f"bar_ia_{name}"], out[f"bar_ja_{name}"], out[f"bar_a_{name}"] = ia, ja, a
+    ps = 0.3 * rng.standard_normal((6, 3 * V.shape[0]))
+    out["bar_p"], out["bar_filter"] = ps, np.array([m.filter_step_size(p, 1.0, 0) for p in ps])
+
+    # --- contact: three mat20x20 sheets of the reference -- a base, one standing on its rim above it (point-edge, point-triangle,
+    # edge-edge pairs, merged duplicates, nearly parallel edges), one hanging corner-down beside the base's corner (point-point) ------
+    Vm, Tm, SFm = gl.read_tet_mesh(os.path.join(REF_ROOT, "input/tetMeshes/mat20x20.msh"))
+    thick = Vm[:, 1].max() - Vm[:, 1].min()
+    gap = 2e-3
+
+    def rot(axis, th):
+        c, s_ = np.cos(th), np.sin(th)
+        R = np.eye(3)
+        i, j = [(1, 2), (2, 0), (0, 1)][axis]
+        R[i, i], R[i, j], R[j, i], R[j, j] = c, -s_, s_, c
+        return R
+
+    A = Vm @ rot(2, np.pi / 2).T + [0.3, 0.5 + thick * 0.5 + gap, 0.0513]
+    B = Vm @ (rot(0, 0.6) @ rot(2, -0.7)).T
+    k = B[:, 1].argmin()
+    B += [-0.5 - 8e-4 - B[k, 0], thick * 0.5 + 8e-4 - B[k, 1], -0.5 - 8e-4 - B[k, 2]]
+    nm, nf = len(Vm), len(SFm)
+    Vc = np.vstack([Vm, A, B])
+    Tc, SFc = np.vstack([Tm, Tm + nm, Tm + 2 * nm]), np.vstack([SFm, SFm + nm, SFm + 2 * nm])
+    mc = ref.Mesh(Vc, Tc, SFc, 2e4, 0.4, 1000.0, node_ranges=[0, nm, 2 * nm, 3 * nm], sf_ranges=[0, nf, 2 * nf, 3 * nf])
+    fc = mc.features()
+    dHat = (2.5e-3) ** 2
+    kappa = 1e4
+    act, par, eiej, cs = mc.constraint_set(dHat)
+    print("contact fixture:", len(act), "active,", len(par), "mollified,", len(cs), "PT/EE candidates")
+    out.update(con_V=Vc, con_T=Tc, con_SF=SFc, con_nodeRanges=np.array([0, nm, 2 * nm, 3 * nm], np.int32), con_sfRanges=np.array([0, nf, 2 * nf, 3 * nf], np.int32),
+               con_dHat=dHat, con_kappa=kappa, con_active=act, con_para=par, con_eiej=eiej, con_csPTEE=cs, con_bbox2=fc["bbox2"])
+    out["con_E"] = mc.barrier_energy(dHat, kappa)
+    out["con_g"] = mc.barrier_gradient(dHat, kappa)
+    out["con_ia"], out["con_ja"], out["con_a"] = mc.barrier_hessian(dHat, kappa)
+    pc = 1e-3 * rng.standard_normal((4, 3 * len(Vc)))
+    pc[:, 3 * nm + 1::3] -= 2e-3  # the two upper sheets move into the base
+    out["con_p"] = pc
+    out["con_ccd_partial"] = np.array([mc.partial_ccd(p, 0.8, 1.0) for p in pc])
+    out["con_ccd_full"] = np.array([mc.full_ccd(p, 0.8, 1.0) for p in pc])
+    out["con_intersected"] = np.array([mc.is_intersected()], np.int8)
+    Vi = Vc.copy()
+    Vi[nm:2 * nm, 1] -= gap + 0.3 * thick  # the standing sheet pushed through the base
+    mc.set_positions(Vi)
+    out["con_Vi"], out["con_intersected_i"] = Vi, np.array([mc.is_intersected()], np.int8)
+    mc.set_positions(Vc)
+    # half-space under the lower sheet
+    o, n = np.array([0.0, Vm[:, 1].min() - 1e-3, 0.0]), np.array([0.0, 1.0, 0.0])
+    hact, hE, hg, (hia, hja, ha) = mc.halfspace(o, n, dHat, kappa)
+    out.update(hs_o=o, hs_n=n, hs_active=hact, hs_E=hE, hs_g=hg, hs_a=ha, hs_step=np.array([mc.halfspace_step_bound(o, n, p, 0.9, 1.0) for p in pc]))
+    np.savez_compressed(os.path.join(GOLD, "ref_functions.npz"), **out)
+    print("wrote ref_functions.npz", os.path.getsize(os.path.join(GOLD, "ref_functions.npz")) >> 10, "KiB")
+
+
+# scene scripts run through the reference's own main(): (name, script text, steps)
+SCENES = [
+    ("bar_twist", open(os.path.join(REF_ROOT, "input/otherExamples/barTwist_noCollisions.txt")).read() if os.path.isdir(REF_ROOT) else "", 4),
+    ("bar_twist_tight", (open(os.path.join(REF_ROOT, "input/otherExamples/barTwist_noCollisions.txt")).read() if os.path.isdir(REF_ROOT) else "") + "\ntol 1\n1e-6\n", 3),
+    ("two_cubes_fall", open(os.path.join(REF_ROOT, "input/tutorialExamples/2cubesFall.txt")).read() if os.path.isdir(REF_ROOT) else "", 40),
+]
+
+
+def scenes(extra=()):
+    for name, text, steps in list(SCENES) + list(extra):
+        cfg = ss.SceneConfig.parse(text, REF_ROOT)
+        with tempfile.TemporaryDirectory(prefix="ipcref_") as tmp:
+            path = os.path.join(tmp, "scene.txt")
+            lines = [ln for ln in text.splitlines() if not ln.strip().startswith("time ")]
+            open(path, "w").write("\n".join(lines) + f"\ntime {steps * cfg.dt:.17g} {cfg.dt:.17g}\n")
+            rcode, log = rc.run_reference(path, os.path.join(tmp, "ref"))
+            assert rcode == 0, log[-2000:]
+            its = rc.read_iter_counts(os.path.join(tmp, "ref"), steps)
+            pos = np.array([rc.read_status_positions(os.path.join(tmp, "ref", f"status{s + 1}")) for s in range(steps)])
+        meshes = {}
+        for sh in cfg.shapes:
+            V, T, SF = gl.read_tet_mesh(sh.path)
+            key = os.path.relpath(sh.path, REF_ROOT)
+            meshes[key] = (V, T, SF)
+        keys = sorted(meshes)
+        out = dict(script=np.array(text), steps=steps, positions=pos, iters=its, mesh_keys=np.array(keys))
+        for i, k in enumerate(keys):
+            out[f"mesh{i}_V"], out[f"mesh{i}_T"], out[f"mesh{i}_SF"] = meshes[k]
+        fn = os.path.join(GOLD, f"ref_scene_{name}.npz")
+        np.savez_compressed(fn, **out)
+        print(f"wrote {os.path.basename(fn)}: {steps} steps, Newton iterations per step {its.tolist()}, {os.path.getsize(fn) >> 10} KiB")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["functions", "scenes"]
+    assert ref.available(), "build oracle/_ref first: make -C oracle -f Makefile.ref"
+    if "functions" in what:
+        functions()
+    if "scenes" in what:
+        scenes()
