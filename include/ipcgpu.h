@@ -206,6 +206,18 @@ int ipcgpu_contact_connectivity(ipcgpu_ctx*, int capacity, int* pairs_2n, int* n
  * >= (1 - slackness) of its current distance.  pair2 = limiting pair, (-svI-1, sfI) or (eI, eJ); (0,0) if none. */
 int ipcgpu_ccd_partial(ipcgpu_ctx*, const double* searchDir_3nV, double slackness, double* stepSize_inout, int* pair2);
 int ipcgpu_ccd_full(ipcgpu_ctx*, const double* searchDir_3nV, double slackness, double* stepSize_inout, int* pair2, int* nCandidates);
+/* The full sweep exactly as the reference runs it (largestFeasibleStepSize_CCD, SelfCollisionHandler.cpp:982-1366, over the swept
+ * SpatialHash::build, SpatialHash.hpp:589-832, whose step-size argument is a reference): (1) the hash caps the step so that the mean
+ * |component| of the search direction over the surface nodes, times the step, stays below its cell size avgEdgeLen / 3 -- returned in
+ * alphaCapped; (2) a surface vertex is swept against the surface vertices (svJ > svI), the edges and the triangles that share a cell
+ * with it, an edge against the edges (eJ > eI) that share a cell and whose swept boxes overlap; (3) each pair with the safety
+ * distance (1 - slackness) * its own current distance, asked again without it when it reports t < 1e-6.  The per-pair query is the
+ * conservative advancement of ipcgpu_ccd_full (CTCD is un-vendored).  arg3 = limiting pair (kind, i, j): 0 (svI, svJ), 1 (svI, eI),
+ * 2 (svI, sfI), 3 (eI, eJ); (-1,-1,-1) if none.  This is what the time stepper uses (ipcgpu_set_ccd_mode 1, the default);
+ * mode 0 keeps the swept-box sweep over point-triangle / edge-edge pairs of ipcgpu_ccd_full. */
+int ipcgpu_ccd_full_reference(ipcgpu_ctx*, const double* searchDir_3nV, double slackness, double* stepSize_inout, double* alphaCapped, int* arg3,
+    int* nCandidates);
+int ipcgpu_set_ccd_mode(ipcgpu_ctx*, int mode);
 /* isIntersected / checkEdgeTriIntersectionIfAny (Optimizer.cpp:2626-2659, SelfCollisionHandler.cpp:3255-3300) */
 int ipcgpu_is_intersected(ipcgpu_ctx*, int* flag);
 

@@ -784,6 +784,26 @@ int ipcgpu_ccd_full(ipcgpu_ctx* c, const double* p, double slackness, double* st
         return IPCGPU_OK;
     });
 }
+int ipcgpu_ccd_full_reference(ipcgpu_ctx* c, const double* p, double slackness, double* step, double* alphaCapped, int* arg3, int* nCand)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        need(o.initialised, "call ipcgpu_opt_init first");
+        needArg(p && step && slackness > 0 && slackness < 1, "bad ccd argument");
+        HIP_CHECK(hipMemcpyAsync(o.d_searchDir.p, p, 3 * (size_t)c->mesh->nV * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        *step = CT(c).ccdFullReference(*c->mesh, c->mesh->d_x.p, o.d_searchDir.p, c->mesh->d_dbc.p, slackness, *step, alphaCapped, arg3, nCand);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_set_ccd_mode(ipcgpu_ctx* c, int mode)
+{
+    return guarded([&] {
+        needArg(mode == 0 || mode == 1, "ccd mode is 0 (swept boxes, PT / EE pairs) or 1 (the reference's sweep)");
+        CT(c).ccdMode = mode;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_is_intersected(ipcgpu_ctx* c, int* flag)
 {
     return guarded([&] {

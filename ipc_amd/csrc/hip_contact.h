@@ -8,6 +8,7 @@
 //   augmentConnectivity       :330-415                            -> connectivity
 //   largestFeasibleStepSize[_CCD]  :564-686, 982-1366             -> ccdStepBound (conservative additive CCD)
 #pragma once
+#include <cstdlib>
 #include "common.h"
 #include <array>
 #include <utility>
@@ -20,7 +21,10 @@ class HipLinSysSolver;
 
 class HipContact {
 public:
-    explicit HipContact(hipStream_t s) : stream(s) {}
+    explicit HipContact(hipStream_t s) : stream(s)
+    {
+        if (const char* e = std::getenv("IPCGPU_CCD_MODE")) ccdMode = std::atoi(e) != 0 ? 1 : 0;
+    }
     hipStream_t stream;
     // surface (Mesh::SF, SVI, SFEdges; Mesh.cpp:495-515, 890-930)
     int nSF = 0, nSVI = 0, nSFE = 0;
@@ -66,6 +70,12 @@ public:
     double ccdPartial(const double* x_dev, const double* p_dev, double slackness, double stepSize, int* pair2);
     double ccdFull(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double stepSize, int* pair2,
         int* nCand);
+    // the full sweep as the reference runs it (SelfCollisionHandler.cpp:982-1366 over SpatialHash.hpp:589-832): the hash first caps the step
+    // (alphaCapped), a surface vertex is swept against vertices / edges / triangles that share a cell with it, an edge against edges;
+    // arg3 = (kind, i, j) of the limiting pair: K_PP (svI, svJ), K_PE (svI, eI), K_PT (svI, sfI), K_EE (eI, eJ)
+    double ccdFullReference(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double stepSize,
+        double* alphaCapped, int* arg3, int* nCand);
+    int ccdMode = 1; // 1: ccdFullReference in the time stepper; 0: the swept-box sweep of PT / EE pairs (ccdFull)
     bool isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev);
     void evalStencils(const std::vector<std::array<int, 4>>& ids, const double* x_dev, std::vector<double>& d2);
     void closeStencils(const double* x_dev, double dTol, std::vector<std::array<int, 4>>& ids, std::vector<double>& d2);
@@ -96,6 +106,7 @@ private:
     DevBuf<double> d_vals_;
     DevBuf<unsigned long long> ccdOut_;
     DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
+    DevBuf<int> d_v2sv, refVbox_, cellCountV_, cellStartV_, cellItemsV_; // reference-mode sweep: node -> surface index, index boxes, vertex cells
     DevBuf<double> bboxPartial_;
     // on-device assembly of the sets (buildConstraintSet)
     int nActive_ = 0, nPara_ = 0, nCand_ = 0;

@@ -776,7 +776,10 @@ __device__ inline double pair_toc(int kind, const int* node, const double* x, co
             P[k][c] = p[3 * (size_t)node[k] + c];
         }
     double t = accd(kind, X, P, 1.0 - slackness, tmax);
-    if (t < 1.0e-6) t = slackness * accd(kind, X, P, 0.01, tmax);
+    if (t < tmax && t < 1.0e-6) { // asked again almost without safety distance over CTCD's own window [0, 1]: no hit drops the pair
+        const double t2 = accd(kind, X, P, 0.01, 1.0);
+        t = t2 < 1.0 ? slackness * t2 : tmax;
+    }
     return t;
 }
 // order key of a pair inside the serial enumeration (PT by (svI, sfI), then EE by (eI, eJ)): ties resolve to the first
@@ -952,6 +955,307 @@ __global__ __launch_bounds__(BLOCK) void k_ccd_full_ee(int nE, const int* __rest
                     const double t = pair_toc(K_EE, node, x, p, slackness, alpha);
                     if (pass == 0) ccd_record_min(t, alpha, o);
                     else ccd_record_arg(t, pair_key(K_EE, eI, eJ), o);
+                }
+            }
+}
+
+// ---- full CCD as the reference sweeps it (SelfCollisionHandler.cpp:982-1366 over SpatialHash.hpp:589-832) ------------------------
+// The step is capped by the hash first, candidates are the primitives
+// whose index boxes in the reference's voxel grid (cell = avgEdgeLen / 3, corner = min over the nodes now and the surface nodes at
+// alpha) intersect, a surface vertex is swept against vertices (svJ > svI), edges and triangles, an edge against edges (eJ > eI)
+// whose boxes swept over the bound left by the vertex sweeps overlap.  The search grid is the reference's grid coarsened by an
+// integer factor m (search cell = reference index / m) so that its size stays bounded; acceptance is decided on the reference
+// indices, so m does not change the result.
+struct RefGrid {
+    double lb[3], oneDiv;
+    int m, dim[3];
+};
+__device__ __forceinline__ int ref_index(const RefGrid& g, double x, int c) { return (int)floor(__dmul_rn(__dsub_rn(x, g.lb[c]), g.oneDiv)); }
+__device__ __forceinline__ double swept_pos(double x, double alpha, double p) { return __dadd_rn(x, __dmul_rn(alpha, p)); }
+
+__global__ __launch_bounds__(BLOCK) void k_ref_abs_sum(int n, const int* __restrict__ SVI, const double* __restrict__ p, double* __restrict__ partial)
+{
+    __shared__ double sm[BLOCK];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double s = 0.0;
+    if (i < n) {
+        const size_t v = (size_t)SVI[i];
+        s = fabs(p[3 * v]) + fabs(p[3 * v + 1]) + fabs(p[3 * v + 2]);
+    }
+    sm[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = BLOCK / 2; off > 0; off >>= 1) { // fixed tree: the same bits on every run
+        if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+}
+// bounding box of the surface nodes at x + alpha p, one partial per block (6 doubles: lo, hi)
+__global__ __launch_bounds__(BLOCK) void k_ref_bbox_swept(int n, const int* __restrict__ SVI, const double* __restrict__ x, const double* __restrict__ p,
+    double alpha, double* __restrict__ partial)
+{
+    __shared__ double sm[6][BLOCK / 64];
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    if (i < n) {
+        const size_t v = (size_t)SVI[i];
+        for (int c = 0; c < 3; ++c) lo[c] = hi[c] = swept_pos(x[3 * v + c], alpha, p[3 * v + c]);
+    }
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[c] = fmin(lo[c], __shfl_down(lo[c], off, 64));
+            hi[c] = fmax(hi[c], __shfl_down(hi[c], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sm[c][threadIdx.x >> 6] = lo[c];
+            sm[3 + c][threadIdx.x >> 6] = hi[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = sm[threadIdx.x][0];
+        for (int k = 1; k < BLOCK / 64; ++k) r = (threadIdx.x < 3) ? fmin(r, sm[threadIdx.x][k]) : fmax(r, sm[threadIdx.x][k]);
+        partial[6 * (size_t)blockIdx.x + threadIdx.x] = r;
+    }
+}
+// index box of every surface vertex: [min(now, then), max(now, then)] per axis (svMinVAI / svMaxVAI, SpatialHash.hpp:640-660)
+__global__ __launch_bounds__(BLOCK) void k_ref_vbox(int n, const int* __restrict__ SVI, const double* __restrict__ x, const double* __restrict__ p, double alpha,
+    RefGrid g, int* __restrict__ vbox)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const size_t v = (size_t)SVI[i];
+    for (int c = 0; c < 3; ++c) {
+        const int a = ref_index(g, x[3 * v + c], c), b = ref_index(g, swept_pos(x[3 * v + c], alpha, p[3 * v + c]), c);
+        vbox[6 * (size_t)i + c] = min(a, b);
+        vbox[6 * (size_t)i + 3 + c] = max(a, b);
+    }
+}
+__device__ __forceinline__ void ref_box(const int* node, int n, const int* __restrict__ v2sv, const int* __restrict__ vbox, int* b)
+{
+    for (int c = 0; c < 3; ++c) {
+        b[c] = 0x7fffffff;
+        b[3 + c] = -0x7fffffff;
+    }
+    for (int k = 0; k < n; ++k) {
+        const int* vb = vbox + 6 * (size_t)v2sv[node[k]];
+        for (int c = 0; c < 3; ++c) {
+            b[c] = min(b[c], vb[c]);
+            b[3 + c] = max(b[3 + c], vb[3 + c]);
+        }
+    }
+}
+__device__ __forceinline__ bool ref_share(const int* a, const int* b)
+{
+    return !(a[0] > b[3] || b[0] > a[3] || a[1] > b[4] || b[1] > a[4] || a[2] > b[5] || b[2] > a[5]);
+}
+// the one search cell in which a pair of intersecting boxes is processed
+__device__ __forceinline__ bool ref_canon(const RefGrid& g, const int* a, const int* b, int cx, int cy, int cz)
+{
+    return max(a[0], b[0]) / g.m == cx && max(a[1], b[1]) / g.m == cy && max(a[2], b[2]) / g.m == cz;
+}
+// nv nodes per primitive (1: surface vertices given by SVI, 2: edges, 3: triangles); mode 0 counts, mode 1 fills
+__global__ __launch_bounds__(BLOCK) void k_ref_insert(int nPrim, int nv, const int* __restrict__ prim, const int* __restrict__ v2sv, const int* __restrict__ vbox,
+    RefGrid g, int mode, int* __restrict__ cellCount, const int* __restrict__ cellStart, int* __restrict__ cellItems)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nPrim) return;
+    int node[3] = { 0, 0, 0 }, b[6];
+    for (int k = 0; k < nv; ++k) node[k] = prim[nv * (size_t)i + k];
+    ref_box(node, nv, v2sv, vbox, b);
+    for (int z = b[2] / g.m; z <= b[5] / g.m; ++z)
+        for (int y = b[1] / g.m; y <= b[4] / g.m; ++y)
+            for (int xx = b[0] / g.m; xx <= b[3] / g.m; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                const int slot = atomicAdd(&cellCount[cell], 1);
+                if (mode == 1) cellItems[cellStart[cell] + slot] = i;
+            }
+}
+// point-point (n = 2) / point-segment (n = 3) advancement: the scheme of accd() on the point-point / point-segment distance
+__device__ inline double dist_ps(const double* p, const double* a, const double* b)
+{
+    double ab[3], ap[3], abab = 0.0, apab = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        ab[c] = b[c] - a[c];
+        ap[c] = p[c] - a[c];
+        abab += ab[c] * ab[c];
+        apab += ap[c] * ab[c];
+    }
+    double s = abab > 0.0 ? apab / abab : 0.0;
+    s = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+    double d2 = 0.0;
+    for (int c = 0; c < 3; ++c) {
+        const double r = ap[c] - s * ab[c];
+        d2 += r * r;
+    }
+    return sqrt(d2);
+}
+__device__ inline double accd_small(int n, const double (*X0)[3], const double (*P0)[3], double eta, double tmax)
+{
+    double X[3][3], P[3][3], mean[3] = { 0.0, 0.0, 0.0 }, len[3] = { 0.0, 0.0, 0.0 };
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < 3; ++c) mean[c] += P0[k][c];
+    for (int c = 0; c < 3; ++c) mean[c] /= (double)n;
+    for (int k = 0; k < n; ++k) {
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = X0[k][c];
+            P[k][c] = P0[k][c] - mean[c];
+        }
+        len[k] = sqrt(dot3(P[k], P[k]));
+    }
+    const double lp = n == 2 ? len[0] + len[1] : len[0] + fmax(len[1], len[2]);
+    if (lp == 0.0) return tmax;
+    const int kb = n == 2 ? 1 : 2;
+    double d = dist_ps(X[0], X[1], X[kb]);
+    const double gap = eta * d;
+    double toc = 0.0;
+    for (int it = 0; it < 100000; ++it) {
+        const double tl = (1.0 - eta) * d / lp;
+        for (int k = 0; k < n; ++k)
+            for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
+        d = dist_ps(X[0], X[1], X[kb]);
+        if (toc != 0.0 && d < gap) break;
+        toc += tl;
+        if (toc > tmax) return tmax;
+    }
+    return toc;
+}
+// one pair of the reference sweep with its retry rule; kind K_PP / K_PE / K_PT / K_EE
+__device__ inline double ref_pair_bound(int kind, const int* node, const double* x, const double* p, double slackness, double tmax)
+{
+    if (kind == K_PT || kind == K_EE) return pair_toc(kind, node, x, p, slackness, tmax);
+    const int n = kind == K_PP ? 2 : 3;
+    double X[3][3], P[3][3];
+    for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < 3; ++c) {
+            const int kk = k < n ? k : n - 1;
+            X[k][c] = x[3 * (size_t)node[kk] + c];
+            P[k][c] = p[3 * (size_t)node[kk] + c];
+        }
+    double t = accd_small(n, X, P, 1.0 - slackness, tmax);
+    if (t < tmax && t < 1.0e-6) {
+        const double t2 = accd_small(n, X, P, 0.01, 1.0);
+        t = t2 < 1.0 ? slackness * t2 : tmax;
+    }
+    return t;
+}
+// order of the serial enumeration: per surface vertex its vertices, edges, triangles; then the edge pairs
+__device__ __forceinline__ unsigned long long ref_key(int isEE, int i, int rank, int j)
+{
+    return ((unsigned long long)isEE << 63) | ((unsigned long long)(unsigned)i << 33) | ((unsigned long long)rank << 31) | (unsigned long long)(unsigned)j;
+}
+struct RefLists {
+    const int *startV, *itemsV, *startE, *itemsE, *startT, *itemsT;
+};
+__global__ __launch_bounds__(BLOCK) void k_ref_sweep_vertex(int nSVI, const int* __restrict__ SVI, const int* __restrict__ SF, const int* __restrict__ SFE,
+    const double* __restrict__ x, const double* __restrict__ p, const int* __restrict__ pf, const int* __restrict__ v2sv, const int* __restrict__ vbox,
+    RefGrid g, RefLists L, double alpha, double slackness, int pass, CcdOut o, int* __restrict__ nCand)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= nSVI) return;
+    const int vI = SVI[i];
+    const int* bi = vbox + 6 * (size_t)i;
+    const bool vDbc = (pf[vI] & 1) != 0;
+    for (int z = bi[2] / g.m; z <= bi[5] / g.m; ++z)
+        for (int y = bi[1] / g.m; y <= bi[4] / g.m; ++y)
+            for (int xx = bi[0] / g.m; xx <= bi[3] / g.m; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                // vertices svJ > svI
+                for (int k = L.startV[cell]; k < L.startV[cell + 1]; ++k) {
+                    const int j = L.itemsV[k];
+                    if (j <= i) continue;
+                    const int* bj = vbox + 6 * (size_t)j;
+                    if (!ref_share(bi, bj) || !ref_canon(g, bi, bj, xx, y, z)) continue;
+                    const int vJ = SVI[j];
+                    if (vDbc && (pf[vJ] & 1)) continue;
+                    if (pair_filtered(pf[vI], pf[vJ])) continue;
+                    const int node[4] = { vI, vJ, vJ, vJ };
+                    if (pass == 0) atomicAdd(nCand, 1);
+                    const double t = ref_pair_bound(K_PP, node, x, p, slackness, alpha);
+                    if (pass == 0) ccd_record_min(t, alpha, o);
+                    else ccd_record_arg(t, ref_key(0, i, 0, j), o);
+                }
+                // edges that do not contain the vertex
+                for (int k = L.startE[cell]; k < L.startE[cell + 1]; ++k) {
+                    const int e = L.itemsE[k];
+                    const int node[4] = { vI, SFE[2 * (size_t)e], SFE[2 * (size_t)e + 1], SFE[2 * (size_t)e + 1] };
+                    if (node[1] == vI || node[2] == vI) continue;
+                    int be[6];
+                    ref_box(node + 1, 2, v2sv, vbox, be);
+                    if (!ref_share(bi, be) || !ref_canon(g, bi, be, xx, y, z)) continue;
+                    if (vDbc && (pf[node[1]] & 1) && (pf[node[2]] & 1)) continue;
+                    if (pair_filtered(pf[vI], pf[node[1]])) continue;
+                    if (pass == 0) atomicAdd(nCand, 1);
+                    const double t = ref_pair_bound(K_PE, node, x, p, slackness, alpha);
+                    if (pass == 0) ccd_record_min(t, alpha, o);
+                    else ccd_record_arg(t, ref_key(0, i, 1, e), o);
+                }
+                // triangles that do not contain the vertex
+                for (int k = L.startT[cell]; k < L.startT[cell + 1]; ++k) {
+                    const int f = L.itemsT[k];
+                    const int node[4] = { vI, SF[3 * (size_t)f], SF[3 * (size_t)f + 1], SF[3 * (size_t)f + 2] };
+                    if (vI == node[1] || vI == node[2] || vI == node[3]) continue;
+                    int bt[6];
+                    ref_box(node + 1, 3, v2sv, vbox, bt);
+                    if (!ref_share(bi, bt) || !ref_canon(g, bi, bt, xx, y, z)) continue;
+                    if (vDbc && (pf[node[1]] & 1) && (pf[node[2]] & 1) && (pf[node[3]] & 1)) continue;
+                    if (pair_filtered(pf[vI], pf[node[1]])) continue;
+                    if (pass == 0) atomicAdd(nCand, 1);
+                    const double t = ref_pair_bound(K_PT, node, x, p, slackness, alpha);
+                    if (pass == 0) ccd_record_min(t, alpha, o);
+                    else ccd_record_arg(t, ref_key(0, i, 2, f), o);
+                }
+            }
+}
+// edge pairs eJ > eI that share a cell and whose boxes swept over alphaEE (the bound the vertex sweeps left) overlap
+__global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ p,
+    const int* __restrict__ pf, const int* __restrict__ v2sv, const int* __restrict__ vbox, RefGrid g, const int* __restrict__ startE,
+    const int* __restrict__ itemsE, double alpha, const unsigned long long* __restrict__ alphaEEBits, double slackness, int pass, CcdOut o,
+    int* __restrict__ nCand)
+{
+    const int eI = blockIdx.x * BLOCK + threadIdx.x;
+    if (eI >= nE) return;
+    double alphaEE = alpha;
+    if (*alphaEEBits != ~0ull) alphaEE = fmin(alpha, __longlong_as_double((long long)*alphaEEBits));
+    int node[4] = { SFE[2 * (size_t)eI], SFE[2 * (size_t)eI + 1], 0, 0 };
+    int bi[6];
+    ref_box(node, 2, v2sv, vbox, bi);
+    double lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) {
+        const double a0 = x[3 * (size_t)node[0] + c], a1 = x[3 * (size_t)node[1] + c];
+        const double b0 = swept_pos(a0, alphaEE, p[3 * (size_t)node[0] + c]), b1 = swept_pos(a1, alphaEE, p[3 * (size_t)node[1] + c]);
+        lo[c] = fmin(fmin(a0, b0), fmin(a1, b1));
+        hi[c] = fmax(fmax(a0, b0), fmax(a1, b1));
+    }
+    const bool aDbc = (pf[node[0]] & 1) && (pf[node[1]] & 1);
+    for (int z = bi[2] / g.m; z <= bi[5] / g.m; ++z)
+        for (int y = bi[1] / g.m; y <= bi[4] / g.m; ++y)
+            for (int xx = bi[0] / g.m; xx <= bi[3] / g.m; ++xx) {
+                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
+                for (int k = startE[cell]; k < startE[cell + 1]; ++k) {
+                    const int eJ = itemsE[k];
+                    if (eJ <= eI) continue;
+                    node[2] = SFE[2 * (size_t)eJ];
+                    node[3] = SFE[2 * (size_t)eJ + 1];
+                    int bj[6];
+                    ref_box(node + 2, 2, v2sv, vbox, bj);
+                    if (!ref_share(bi, bj) || !ref_canon(g, bi, bj, xx, y, z)) continue;
+                    bool apart = false;
+                    for (int c = 0; c < 3; ++c) {
+                        const double a0 = x[3 * (size_t)node[2] + c], a1 = x[3 * (size_t)node[3] + c];
+                        const double b0 = swept_pos(a0, alphaEE, p[3 * (size_t)node[2] + c]), b1 = swept_pos(a1, alphaEE, p[3 * (size_t)node[3] + c]);
+                        const double jl = fmin(fmin(a0, b0), fmin(a1, b1)), jh = fmax(fmax(a0, b0), fmax(a1, b1));
+                        if (jl - hi[c] > 0.0 || lo[c] - jh > 0.0) apart = true;
+                    }
+                    if (apart) continue;
+                    if (node[0] == node[2] || node[0] == node[3] || node[1] == node[2] || node[1] == node[3]) continue;
+                    if (aDbc && (pf[node[2]] & 1) && (pf[node[3]] & 1)) continue;
+                    if (pair_filtered(pf[node[0]], pf[node[2]])) continue;
+                    if (pass == 0) atomicAdd(nCand, 1);
+                    const double t = ref_pair_bound(K_EE, node, x, p, slackness, alpha);
+                    if (pass == 0) ccd_record_min(t, alpha, o);
+                    else ccd_record_arg(t, ref_key(1, eI, 0, eJ), o);
                 }
             }
 }
@@ -1179,6 +1483,9 @@ void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc)
         sfe[2 * (size_t)e] = SFEdges[e].first;
         sfe[2 * (size_t)e + 1] = SFEdges[e].second;
     }
+    std::vector<int> v2sv((size_t)mesh.nV, -1);
+    for (int i = 0; i < nSVI; ++i) v2sv[(size_t)SVI[i]] = i;
+    d_v2sv.upload(v2sv, stream);
     d_SF.upload(sfRow, stream);
     d_SVI.upload(SVI, stream);
     d_SFE.upload(sfe, stream);
@@ -1898,6 +2205,125 @@ double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const doubl
     double out;
     decodeCcdOut(h, stepSize, &out, pair2);
     return out;
+}
+
+double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double alpha,
+    double* alphaCapped, int* arg3, int* nCand)
+{
+    if (!surfaceSet) throw StateError("ccd before set_surface");
+    if (arg3) arg3[0] = arg3[1] = arg3[2] = -1;
+    if (nCand) *nCand = 0;
+    if (alphaCapped) *alphaCapped = alpha;
+    if (!nSVI) return alpha;
+    const int* pf = pairFlags(mesh.nV, dbc_dev);
+    // the cap (SpatialHash.hpp:603-618): mean |component| of p over the surface nodes against the cell size
+    const int nbS = nblk(nSVI);
+    bboxPartial_.ensure(6 * (size_t)std::max(nbS, nblk(mesh.nV)));
+    hipLaunchKernelGGL(k_ref_abs_sum, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, p_dev, bboxPartial_.p);
+    std::vector<double> part(6 * (size_t)std::max(nbS, nblk(mesh.nV)));
+    bboxPartial_.download(part.data(), (size_t)nbS, stream);
+    double pSize = 0.0;
+    for (int b = 0; b < nbS; ++b) pSize += part[(size_t)b];
+    pSize /= (double)nSVI * 3;
+    const double voxelSize = mesh.avgEdgeLen / 3.0;
+    const double spanSize = alpha * pSize / voxelSize;
+    if (spanSize > 1) alpha /= spanSize;
+    if (alphaCapped) *alphaCapped = alpha;
+    // corner and extent: all nodes now, the surface nodes at alpha (:620-634)
+    double lb[3] = { 1e300, 1e300, 1e300 }, rt[3] = { -1e300, -1e300, -1e300 };
+    const int nbV = nblk(mesh.nV);
+    hipLaunchKernelGGL(k_bbox_partial, dim3(nbV), dim3(BLOCK), 0, stream, mesh.nV, x_dev, bboxPartial_.p);
+    bboxPartial_.download(part.data(), 6 * (size_t)nbV, stream);
+    for (int b = 0; b < nbV; ++b)
+        for (int c = 0; c < 3; ++c) {
+            lb[c] = std::min(lb[c], part[6 * (size_t)b + c]);
+            rt[c] = std::max(rt[c], part[6 * (size_t)b + 3 + c]);
+        }
+    hipLaunchKernelGGL(k_ref_bbox_swept, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, x_dev, p_dev, alpha, bboxPartial_.p);
+    bboxPartial_.download(part.data(), 6 * (size_t)nbS, stream);
+    for (int b = 0; b < nbS; ++b)
+        for (int c = 0; c < 3; ++c) {
+            lb[c] = std::min(lb[c], part[6 * (size_t)b + c]);
+            rt[c] = std::max(rt[c], part[6 * (size_t)b + 3 + c]);
+        }
+    RefGrid g;
+    g.oneDiv = 1.0 / voxelSize;
+    {
+        int minCount = 1 << 30;
+        double maxRange = 0.0;
+        for (int c = 0; c < 3; ++c) {
+            minCount = std::min(minCount, (int)std::ceil((rt[c] - lb[c]) * g.oneDiv));
+            maxRange = std::max(maxRange, rt[c] - lb[c]);
+        }
+        if (minCount <= 0) g.oneDiv = 1.0 / (maxRange * 1.01);
+    }
+    int nRef[3];
+    for (int c = 0; c < 3; ++c) {
+        g.lb[c] = lb[c];
+        nRef[c] = std::max(1, (int)std::floor((rt[c] - lb[c]) * g.oneDiv) + 1);
+    }
+    long long nCells;
+    for (g.m = 1;; ++g.m) {
+        nCells = 1;
+        for (int c = 0; c < 3; ++c) {
+            g.dim[c] = (nRef[c] + g.m - 1) / g.m;
+            nCells *= g.dim[c];
+        }
+        if (nCells <= (1LL << 23)) break;
+    }
+    refVbox_.ensure(6 * (size_t)nSVI);
+    hipLaunchKernelGGL(k_ref_vbox, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, x_dev, p_dev, alpha, g, refVbox_.p);
+    auto build = [&](int nPrim, int nv, const int* prim, DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items) {
+        cnt.ensure((size_t)nCells + 1);
+        start.ensure((size_t)nCells + 1);
+        cnt.zeroN((size_t)nCells + 1, stream);
+        hipLaunchKernelGGL(k_ref_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv, prim, d_v2sv.p, refVbox_.p, g, 0, cnt.p, (const int*)nullptr,
+            (int*)nullptr);
+        size_t tmpBytes = 0;
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream));
+        if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream));
+        int total = 0;
+        HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        items.ensure((size_t)std::max(1, total));
+        cnt.zeroN((size_t)nCells + 1, stream);
+        hipLaunchKernelGGL(k_ref_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv, prim, d_v2sv.p, refVbox_.p, g, 1, cnt.p, start.p, items.p);
+    };
+    build(nSVI, 1, d_SVI.p, cellCountV_, cellStartV_, cellItemsV_);
+    build(nSFE, 2, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
+    build(nSF, 3, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
+    ccdOut_.alloc(4);
+    const unsigned long long init[3] = { ~0ull, ~0ull, ~0ull };
+    HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
+    counters_.alloc(2);
+    counters_.zero(stream);
+    CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
+    const RefLists L{ cellStartV_.p, cellItemsV_.p, cellStartE_.p, cellItemsE_.p, cellStartT_.p, cellItemsT_.p };
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(k_ref_sweep_vertex, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, pf, d_v2sv.p, refVbox_.p, g, L,
+            alpha, slackness, pass, o, counters_.p);
+        // the bound the vertex sweeps left is what the edge pairs' boxes are swept over (SelfCollisionHandler.cpp:1189, 1219)
+        if (pass == 0) HIP_CHECK(hipMemcpyAsync(ccdOut_.p + 2, ccdOut_.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
+        if (nSFE)
+            hipLaunchKernelGGL(k_ref_sweep_edge, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, p_dev, pf, d_v2sv.p, refVbox_.p, g,
+                cellStartE_.p, cellItemsE_.p, alpha, ccdOut_.p + 2, slackness, pass, o, counters_.p);
+    }
+    unsigned long long h[2];
+    int cnt[2];
+    HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+    counters_.download(cnt, 2, stream);
+    if (nCand) *nCand = cnt[0];
+    double t;
+    std::memcpy(&t, &h[0], sizeof(t));
+    if (h[1] == ~0ull || !(t < alpha)) return alpha;
+    if (arg3) {
+        const int isEE = (int)(h[1] >> 63);
+        arg3[0] = isEE ? K_EE : (int)((h[1] >> 31) & 3); // rank 0 / 1 / 2 = K_PP / K_PE / K_PT
+        arg3[1] = (int)((h[1] >> 33) & 0x3FFFFFFF);
+        arg3[2] = (int)(h[1] & 0x7FFFFFFF);
+    }
+    return t;
 }
 
 bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev)

@@ -124,6 +124,7 @@ public:
     void lineSearch(double& stepSize);
     void stepForward(const double* x0_dev, double alpha);
     double filterStepSize(const double* p_dev, double stepSize);
+    double fullCcd(double slackness, double stepSize); // the full sweep of the search direction in the mode of the contact handler
     bool checkInversion();
     ElemView view() const;
 

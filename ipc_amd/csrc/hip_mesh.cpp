@@ -60,15 +60,20 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
             for (int b = a + 1; b < 4; ++b) {
                 edges.emplace_back(v[a], v[b]);
                 edges.emplace_back(v[b], v[a]);
-                double l2 = 0;
-                for (int i = 0; i < 3; ++i) {
-                    const double dd = X(v[a], i) - X(v[b], i);
-                    l2 += dd * dd;
-                }
-                edgeSum += std::sqrt(l2);
             }
+        for (int a = 0; a < 4; ++a) { // igl::avg_edge_length walks the columns cyclically: edges (0,1) (1,2) (2,3) (3,0)
+            const int b = (a + 1) % 4;
+            double l2 = 0;
+            for (int i = 0; i < 3; ++i) {
+                const double dd = X(v[a], i) - X(v[b], i);
+                l2 += dd * dd;
+            }
+            edgeSum += std::sqrt(l2);
+        }
     }
-    avgEdgeLen = nT ? edgeSum / (6.0 * nT) : 0.0;
+    // Mesh.cpp:460: the mean over four of the six edges of every tetrahedron (what libigl's avg_edge_length computes for a
+    // 4-column F); a third of it is the cell size of the reference's spatial hash, which caps the full-CCD step (SpatialHash.hpp:603-618)
+    avgEdgeLen = nT ? edgeSum / (4.0 * nT) : 0.0;
     for (int v = 0; v < nV; ++v) mass[v] *= density; // Mesh.cpp:399
     this->density = density;
     mu.assign(nT, YM / 2.0 / (1.0 + PR)); // Mesh.cpp:663-664

@@ -805,6 +805,18 @@ bool HipOptimizer::checkInversion()
     return f == 0;
 }
 
+double HipOptimizer::fullCcd(double slackness, double stepSize)
+{
+    if (contact->ccdMode == 1) {
+        int arg3[3];
+        const double a = contact->ccdFullReference(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, slackness, stepSize, nullptr, arg3, nullptr);
+        lastCCDPair[0] = arg3[1];
+        lastCCDPair[1] = arg3[2];
+        return a;
+    }
+    return contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, slackness, stepSize, lastCCDPair, nullptr);
+}
+
 double HipOptimizer::filterStepSize(const double* p_dev, double stepSize)
 {
     // Energy.cpp:565-581: min over elements of the root, applied only when 0 < min < stepSize
@@ -927,7 +939,7 @@ void HipOptimizer::beginTimestep()
     if (nHandles || groupMotion) {
         double stepSize = filterStepSize(d_searchDir.p, 1.0);
         if (selfCollision) // CCD of the scripted motion with slackness 0.5 (AnimScripter.cpp:2158-2171)
-            stepSize = contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, 0.5, stepSize, nullptr, nullptr);
+            stepSize = fullCcd(0.5, stepSize);
         HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, 3 * (size_t)mesh.nV * sizeof(double), hipMemcpyDeviceToDevice, stream));
         stepForward(d_x0.p, stepSize);
         while (!checkInversion()) {
@@ -953,7 +965,7 @@ void HipOptimizer::beginTimestep()
         double stepSize = filterStepSize(d_searchDir.p, 1.0);
         if (ipOn()) {
             for (auto& h : planes) stepSize = h->stepBound(contact->nSVI, contact->d_SVI.p, mesh.d_x.p, mesh.d_dbc.p, d_searchDir.p, 0.9, stepSize);
-            if (selfCollision) stepSize = contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, 0.8, stepSize, nullptr, nullptr);
+            if (selfCollision) stepSize = fullCcd(0.8, stepSize);
         }
         HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, 3 * (size_t)mesh.nV * sizeof(double), hipMemcpyDeviceToDevice, stream));
         stepForward(d_x0.p, stepSize);
@@ -1091,7 +1103,7 @@ bool HipOptimizer::newtonIter()
             const double pMax = contact->maxSurfaceSpeed(d_searchDir.p);
             const double alpha_CFL = std::sqrt(dHat) / (pMax * 2.0);
             if ((!k && alpha > alpha_CFL) || alpha > 2.0 * alpha_CFL) {
-                alpha = contact->ccdFull(mesh, mesh.d_x.p, d_searchDir.p, mesh.d_dbc.p, slackness_m, alpha, lastCCDPair, nullptr);
+                alpha = fullCcd(slackness_m, alpha);
                 nFullCCD++;
                 if (alpha < alpha_CFL) alpha = alpha_CFL;
             }

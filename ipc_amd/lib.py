@@ -394,6 +394,18 @@ class Context:
         self._chk(self._L.ipcgpu_ccd_full(self.h, _dp(p), C.c_double(slackness), C.byref(s), _ip(pair), C.byref(n)))
         return s.value, (int(pair[0]), int(pair[1])), n.value
 
+    def ccd_full_reference(self, p, slackness=0.8, step=1.0):
+        """The reference's full sweep: returns the bound, the step after the hash's cap, the limiting pair (kind, i, j), #pairs queried."""
+        p = _f64(p)
+        s, cap = C.c_double(step), C.c_double()
+        arg = np.zeros(3, dtype=np.int32)
+        n = C.c_int()
+        self._chk(self._L.ipcgpu_ccd_full_reference(self.h, _dp(p), C.c_double(slackness), C.byref(s), C.byref(cap), _ip(arg), C.byref(n)))
+        return s.value, cap.value, tuple(int(x) for x in arg), n.value
+
+    def set_ccd_mode(self, mode):
+        self._chk(self._L.ipcgpu_set_ccd_mode(self.h, C.c_int(mode)))
+
     def is_intersected(self):
         f = C.c_int()
         self._chk(self._L.ipcgpu_is_intersected(self.h, C.byref(f)))

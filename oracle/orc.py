@@ -441,6 +441,17 @@ def ccd_full(mesh: "Mesh", p, slackness=0.8, step=1.0):
     return s, tuple(int(x) for x in pair), n.value
 
 
+def ccd_full_reference(mesh: "Mesh", p, slackness=0.8, step=1.0):
+    """The reference's full sweep (cap of the step by the hash, shared-cell candidates, PP / PE / PT / EE pairs).  Returns the bound,
+    the step after the cap, the limiting pair (kind, i, j) and the number of pairs queried."""
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    arg = np.zeros(3, dtype=np.int32)
+    n, cap = C.c_int(), C.c_double()
+    lib().orc_ccd_full_reference.restype = C.c_double
+    s = lib().orc_ccd_full_reference(mesh.h, _dp(p), C.c_double(slackness), C.c_double(step), C.byref(cap), _ip(arg), C.byref(n))
+    return s, cap.value, tuple(int(x) for x in arg), n.value
+
+
 def is_intersected(mesh: "Mesh"):
     return bool(lib().orc_is_intersected(mesh.h))
 

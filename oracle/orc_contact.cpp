@@ -1016,9 +1016,9 @@ double ccdStepBound(const Mesh& m, const std::vector<std::array<int, 2>>& pairs,
                 P[k][c] = p[3 * node[k] + c];
             }
         double t = accd(kind, X, P, eta, tmax);
-        if (t < 1.0e-6) { // SelfCollisionHandler.cpp:617-636: retry almost without safety distance, then back off
-            const double t2 = accd(kind, X, P, 0.01, tmax);
-            t = slackness * t2;
+        if (t < tmax && t < 1.0e-6) { // SelfCollisionHandler.cpp:617-636: asked again almost without safety distance over [0, 1];
+            const double t2 = accd(kind, X, P, 0.01, 1.0); // no hit then: the pair does not constrain the step, a hit backs off
+            t = t2 < 1.0 ? slackness * t2 : tmax;
         }
         if (t < stepSize) {
             stepSize = t;
@@ -1081,6 +1081,247 @@ void sweptCandidates(const Mesh& m, const double* p, double stepSize, std::vecto
             if (!m.pairAllowed(a0, b0)) continue;
             if (overlap(&eb[e][0], &eb[e][3], &eb[j][0], &eb[j][3])) out.push_back({ e, j });
         }
+}
+
+// ---- the reference's full CCD sweep, restated (SelfCollisionHandler.cpp:982-1366 over SpatialHash.hpp:589-832) -----------------
+// What the per-pair query is stays "by contract" (accd above).  Everything around it follows the reference:
+//  * the spatial hash may first CAP the step: with pSize the mean |component| of p over the surface nodes and the cell size
+//    avgEdgeLen / 3, alpha is divided by alpha * pSize / cell when that exceeds 1 (SpatialHash.hpp:603-618; the argument is a
+//    reference to the Optimizer's alpha);
+//  * candidates are the primitives that share a cell with the swept point / edge: cell index floor((x - corner) / cell) per axis,
+//    corner = min over all nodes now and the surface nodes at alpha, the index box of a primitive = union over its nodes of
+//    [min(now, then), max(now, then)]; edge-edge pairs additionally need overlapping swept boxes (queryEdgeForEdgesWithBBoxCheck).
+//    No inflation by the safety distance: "long-distance pairs are dropped" (SelfCollisionHandler.cpp:1008);
+//  * a surface vertex is swept against the other surface VERTICES (svJ > svI) and the surface EDGES that do not contain it as well
+//    as the triangles (:1011-1100), each pair with eta = (1 - slackness) * its own current distance;
+//  * a pair that reports t < 1e-6 is asked again with eta = 0; no hit then drops the pair, a hit is scaled by the slackness.
+// point-point / point-segment advancement (the same scheme as accd)
+static double distPS(const double* p, const double* a, const double* b)
+{
+    double ab[3], ap[3], abab = 0, apab = 0;
+    for (int c = 0; c < 3; ++c) {
+        ab[c] = b[c] - a[c];
+        ap[c] = p[c] - a[c];
+        abab += ab[c] * ab[c];
+        apab += ap[c] * ab[c];
+    }
+    double s = abab > 0.0 ? apab / abab : 0.0;
+    s = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+    double d2 = 0;
+    for (int c = 0; c < 3; ++c) {
+        const double r = ap[c] - s * ab[c];
+        d2 += r * r;
+    }
+    return std::sqrt(d2);
+}
+// n = 2: point-point, n = 3: point-segment; eta as a fraction of the current distance; returns tmax when the gap is not reached
+double accdSmall(int n, const double X0[3][3], const double P0[3][3], double eta, double tmax)
+{
+    double X[3][3], P[3][3], mean[3] = { 0, 0, 0 }, len[3] = { 0, 0, 0 };
+    for (int k = 0; k < n; ++k)
+        for (int c = 0; c < 3; ++c) mean[c] += P0[k][c];
+    for (int c = 0; c < 3; ++c) mean[c] /= (double)n;
+    for (int k = 0; k < n; ++k) {
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = X0[k][c];
+            P[k][c] = P0[k][c] - mean[c];
+        }
+        len[k] = std::sqrt(dot3(P[k], P[k]));
+    }
+    const double lp = n == 2 ? len[0] + len[1] : len[0] + std::max(len[1], len[2]);
+    if (lp == 0.0) return tmax;
+    auto D = [&]() { return n == 2 ? distPS(X[0], X[1], X[1]) : distPS(X[0], X[1], X[2]); };
+    double d = D();
+    const double gap = eta * d;
+    double toc = 0.0;
+    for (int it = 0; it < 100000; ++it) {
+        const double tl = (1.0 - eta) * d / lp;
+        for (int k = 0; k < n; ++k)
+            for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
+        d = D();
+        if (toc != 0.0 && d < gap) break;
+        toc += tl;
+        if (toc > tmax) return tmax;
+    }
+    return toc;
+}
+// one pair with the retry rule; kind K_PP / K_PE / K_PT / K_EE; returns tmax for "no constraint from this pair"
+static double pairBound(int kind, const Mesh& m, const int* node, const double* p, double slackness, double tmax)
+{
+    const int n = stencil_nodes(kind);
+    double X[4][3], P[4][3];
+    for (int k = 0; k < 4; ++k)
+        for (int c = 0; c < 3; ++c) {
+            const int kk = k < n ? k : n - 1;
+            X[k][c] = m.Vx(node[kk], c);
+            P[k][c] = p[3 * node[kk] + c];
+        }
+    const double eta = 1.0 - slackness;
+    auto query = [&](double e, double tm) { return kind == K_PP || kind == K_PE ? accdSmall(n, X, P, e, tm) : accd(kind, X, P, e, tm); };
+    double t = query(eta, tmax);
+    if (t < tmax && t < 1.0e-6) {
+        // "eta = 0" of the reference's second call (the contract needs a positive fraction), over CTCD's own window [0, 1]
+        const double t2 = query(0.01, 1.0);
+        if (!(t2 < 1.0)) return tmax;
+        t = slackness * t2;
+    }
+    return t;
+}
+// returns the new step bound; alphaCapped receives the step after the hash's cap, arg the limiting pair as
+// (kind, i, j): PP (svI, svJ), PE (svI, eI), PT (svI, sfI), EE (eI, eJ); nCand the number of pairs queried
+double fullCcdReference(const Mesh& m, const double* p, double slackness, double alpha, double* alphaCapped, int arg[3], int* nCand)
+{
+    const int nSV = (int)m.SVI.size(), nE = (int)m.SFEdges.size(), nSF = m.nSF;
+    if (arg) arg[0] = arg[1] = arg[2] = -1;
+    if (nCand) *nCand = 0;
+    if (!nSV) {
+        if (alphaCapped) *alphaCapped = alpha;
+        return alpha;
+    }
+    // the cap (SpatialHash.hpp:603-618)
+    double pSize = 0;
+    for (int i = 0; i < nSV; ++i)
+        for (int c = 0; c < 3; ++c) pSize += std::abs(p[3 * m.SVI[i] + c]);
+    pSize /= (double)nSV * 3;
+    const double voxelSize = m.avgEdgeLen / 3.0;
+    const double spanSize = alpha * pSize / voxelSize;
+    if (spanSize > 1) alpha /= spanSize;
+    if (alphaCapped) *alphaCapped = alpha;
+    // the grid (:620-634)
+    double lb[3] = { 1e300, 1e300, 1e300 }, rt[3] = { -1e300, -1e300, -1e300 };
+    for (int v = 0; v < m.nV; ++v)
+        for (int c = 0; c < 3; ++c) {
+            lb[c] = std::min(lb[c], m.Vx(v, c));
+            rt[c] = std::max(rt[c], m.Vx(v, c));
+        }
+    std::vector<std::array<double, 3>> xt((size_t)nSV);
+    for (int i = 0; i < nSV; ++i)
+        for (int c = 0; c < 3; ++c) {
+            xt[i][c] = m.Vx(m.SVI[i], c) + alpha * p[3 * m.SVI[i] + c];
+            lb[c] = std::min(lb[c], xt[i][c]);
+            rt[c] = std::max(rt[c], xt[i][c]);
+        }
+    double oneDiv = 1.0 / voxelSize;
+    {
+        int minCount = 1 << 30;
+        double maxRange = 0;
+        for (int c = 0; c < 3; ++c) {
+            minCount = std::min(minCount, (int)std::ceil((rt[c] - lb[c]) * oneDiv));
+            maxRange = std::max(maxRange, rt[c] - lb[c]);
+        }
+        if (minCount <= 0) oneDiv = 1.0 / (maxRange * 1.01); // "cast overflow due to huge search direction" (:628-632)
+    }
+    auto cellOf = [&](double x, int c) { return (int)std::floor((x - lb[c]) * oneDiv); };
+    std::vector<int> vI2SVI((size_t)m.nV, -1);
+    std::vector<std::array<int, 6>> vb((size_t)nSV), eb((size_t)nE), tb((size_t)nSF); // index boxes: lo[3], hi[3]
+    for (int i = 0; i < nSV; ++i) {
+        vI2SVI[m.SVI[i]] = i;
+        for (int c = 0; c < 3; ++c) {
+            const int a = cellOf(m.Vx(m.SVI[i], c), c), b = cellOf(xt[i][c], c);
+            vb[i][c] = std::min(a, b);
+            vb[i][3 + c] = std::max(a, b);
+        }
+    }
+    auto unite = [&](std::array<int, 6>& o, const int* nodes, int n) {
+        for (int c = 0; c < 3; ++c) {
+            o[c] = 1 << 30;
+            o[3 + c] = -(1 << 30);
+        }
+        for (int k = 0; k < n; ++k) {
+            const auto& b = vb[vI2SVI[nodes[k]]];
+            for (int c = 0; c < 3; ++c) {
+                o[c] = std::min(o[c], b[c]);
+                o[3 + c] = std::max(o[3 + c], b[3 + c]);
+            }
+        }
+    };
+    for (int e = 0; e < nE; ++e) {
+        const int nd[2] = { m.SFEdges[e].first, m.SFEdges[e].second };
+        unite(eb[e], nd, 2);
+    }
+    for (int f = 0; f < nSF; ++f) {
+        const int nd[3] = { m.SF[f], m.SF[f + nSF], m.SF[f + 2 * nSF] };
+        unite(tb[f], nd, 3);
+    }
+    auto share = [](const std::array<int, 6>& a, const std::array<int, 6>& b) {
+        for (int c = 0; c < 3; ++c)
+            if (a[c] > b[3 + c] || b[c] > a[3 + c]) return false;
+        return true;
+    };
+    double best = alpha;
+    int cnt = 0;
+    auto take = [&](double t, int kind, int i, int j) {
+        ++cnt;
+        if (t < best) {
+            best = t;
+            if (arg) {
+                arg[0] = kind;
+                arg[1] = i;
+                arg[2] = j;
+            }
+        }
+    };
+    // point-point / point-edge / point-triangle (:995-1186); every pair is tested against the incoming alpha
+    for (int i = 0; i < nSV; ++i) {
+        const int vI = m.SVI[i];
+        for (int j = i + 1; j < nSV; ++j) {
+            if (!share(vb[i], vb[j])) continue;
+            const int vJ = m.SVI[j];
+            if (m.isDBC(vI) && m.isDBC(vJ)) continue;
+            if (!m.pairAllowed(vI, vJ)) continue;
+            const int nd[4] = { vI, vJ, vJ, vJ };
+            take(pairBound(K_PP, m, nd, p, slackness, alpha), K_PP, i, j);
+        }
+        for (int e = 0; e < nE; ++e) {
+            const int e0 = m.SFEdges[e].first, e1 = m.SFEdges[e].second;
+            if (e0 == vI || e1 == vI || !share(vb[i], eb[e])) continue;
+            if (m.isDBC(vI) && m.isDBC(e0) && m.isDBC(e1)) continue;
+            if (!m.pairAllowed(vI, e0)) continue;
+            const int nd[4] = { vI, e0, e1, e1 };
+            take(pairBound(K_PE, m, nd, p, slackness, alpha), K_PE, i, e);
+        }
+        for (int f = 0; f < nSF; ++f) {
+            const int t0 = m.SF[f], t1 = m.SF[f + nSF], t2 = m.SF[f + 2 * nSF];
+            if (vI == t0 || vI == t1 || vI == t2 || !share(vb[i], tb[f])) continue;
+            if (m.isDBC(vI) && m.isDBC(t0) && m.isDBC(t1) && m.isDBC(t2)) continue;
+            if (!m.pairAllowed(vI, t0)) continue;
+            const int nd[4] = { vI, t0, t1, t2 };
+            take(pairBound(K_PT, m, nd, p, slackness, alpha), K_PT, i, f);
+        }
+    }
+    // edge-edge (:1198-1340): shared cell and overlapping boxes swept over the bound the vertex sweeps left (the step size is
+    // lowered between the two loops, :1189, and queryEdgeForEdgesWithBBoxCheck receives the lowered value)
+    const double alphaEE = best;
+    std::vector<std::array<double, 6>> ebox((size_t)nE);
+    for (int e = 0; e < nE; ++e) {
+        const int nd[2] = { m.SFEdges[e].first, m.SFEdges[e].second };
+        for (int c = 0; c < 3; ++c) {
+            double lo = 1e300, hi = -1e300;
+            for (int k = 0; k < 2; ++k) {
+                const double a = m.Vx(nd[k], c), b = a + alphaEE * p[3 * nd[k] + c];
+                lo = std::min(lo, std::min(a, b));
+                hi = std::max(hi, std::max(a, b));
+            }
+            ebox[e][c] = lo;
+            ebox[e][3 + c] = hi;
+        }
+    }
+    for (int e = 0; e < nE; ++e)
+        for (int j = e + 1; j < nE; ++j) {
+            if (!share(eb[e], eb[j])) continue;
+            const int a0 = m.SFEdges[e].first, a1 = m.SFEdges[e].second, b0 = m.SFEdges[j].first, b1 = m.SFEdges[j].second;
+            bool apart = false;
+            for (int c = 0; c < 3; ++c)
+                if (ebox[j][c] - ebox[e][3 + c] > 0.0 || ebox[e][c] - ebox[j][3 + c] > 0.0) apart = true;
+            if (apart) continue;
+            if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
+            if (m.isDBC(a0) && m.isDBC(a1) && m.isDBC(b0) && m.isDBC(b1)) continue;
+            if (!m.pairAllowed(a0, b0)) continue;
+            const int nd[4] = { a0, a1, b0, b1 };
+            take(pairBound(K_EE, m, nd, p, slackness, alpha), K_EE, e, j);
+        }
+    if (nCand) *nCand = cnt;
+    return best;
 }
 
 // IglUtils::segTriIntersect, the branch without exact predicates (IglUtils.hpp:236-245, 258-264)
@@ -1266,6 +1507,20 @@ double orc_ccd_full(const orc_mesh* m, const double* p, double slackness, double
     }
     if (nCand) *nCand = (int)cand.size();
     return arg >= 0 ? s : stepSize;
+}
+double orc_ccd_full_reference(const orc_mesh* m, const double* p, double slackness, double stepSize, double* alphaCapped, int* arg3, int* nCand)
+{
+    return fullCcdReference(m->m, p, slackness, stepSize, alphaCapped, arg3, nCand);
+}
+double orc_accd_small(int n, const double* X9, const double* P9, double eta, double tmax)
+{
+    double X[3][3], P[3][3];
+    for (int k = 0; k < 3; ++k)
+        for (int c = 0; c < 3; ++c) {
+            X[k][c] = X9[3 * k + c];
+            P[k][c] = P9[3 * k + c];
+        }
+    return accdSmall(n, X, P, eta, tmax);
 }
 // X15: segment end points, then the triangle
 int orc_seg_tri_intersect(const double* X15) { return segTriIntersect(X15, X15 + 3, X15 + 6, X15 + 9, X15 + 12) ? 1 : 0; }

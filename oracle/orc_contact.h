@@ -52,6 +52,8 @@ void contactConnectivity(const Mesh& m, const ContactSets& cs, std::vector<std::
 
 // conservative CCD (contract: every tested pair keeps >= (1 - slackness) of its current distance); see orc_contact.cpp
 double accd(int kind, const double X[4][3], const double P[4][3], double eta, double tmax);
+double accdSmall(int n, const double X[3][3], const double P[3][3], double eta, double tmax);
+double fullCcdReference(const Mesh& m, const double* p, double slackness, double alpha, double* alphaCapped, int arg[3], int* nCand);
 double ccdStepBound(const Mesh& m, const std::vector<std::array<int, 2>>& pairs, const double* p, double slackness, double stepSize,
     int* argPair);
 void sweptCandidates(const Mesh& m, const double* p, double stepSize, std::vector<std::array<int, 2>>& out);

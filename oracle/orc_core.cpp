@@ -229,15 +229,21 @@ Mesh::Mesh(int nV_, int nT_, const double* Vr, const int* Fc, double YM, double 
             for (int b = a + 1; b < 4; ++b) {
                 vNeighbor[v[a]].insert(v[b]);
                 vNeighbor[v[b]].insert(v[a]);
-                double d2 = 0;
-                for (int i = 0; i < 3; ++i) {
-                    double d = Vr[v[a] + nV * i] - Vr[v[b] + nV * i];
-                    d2 += d * d;
-                }
-                edgeSum += std::sqrt(d2);
             }
+        for (int a = 0; a < 4; ++a) { // igl::avg_edge_length walks the columns cyclically: edges (0,1) (1,2) (2,3) (3,0)
+            const int b = (a + 1) % 4;
+            double d2 = 0;
+            for (int i = 0; i < 3; ++i) {
+                double d = Vr[v[a] + nV * i] - Vr[v[b] + nV * i];
+                d2 += d * d;
+            }
+            edgeSum += std::sqrt(d2);
+        }
     }
-    avgEdgeLen = nT ? edgeSum / (6.0 * nT) : 0; // igl::avg_edge_length: mean over the 6 edges of every tet
+    // Mesh.cpp:460 igl::avg_edge_length(V_rest, F): the mean of |V(F(i,j)) - V(F(i,(j+1)%4))| over all i, j -- four of the six
+    // edges of every tetrahedron.  The reference's spatial hash takes a third of it as its cell size, and the full CCD caps the
+    // step with it (SpatialHash.hpp:603-618), so the value itself matters.
+    avgEdgeLen = nT ? edgeSum / (4.0 * nT) : 0;
     for (int v = 0; v < nV; ++v) mass[v] *= density; // Mesh.cpp:399
     // Mesh.cpp:663-664
     mu.assign(nT, YM / 2.0 / (1.0 + PR));

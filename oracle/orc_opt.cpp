@@ -9,6 +9,7 @@
 #include "orc_api.h"
 #include "orc_contact.h"
 #include "orc_core.h"
+#include <cstdlib>
 #include <chrono>
 #include <cstdio>
 #include <map>
@@ -66,6 +67,7 @@ struct orc_opt {
     std::vector<MMCVID> closeID; // closeMConstraintID / closeMConstraintVal (Optimizer.cpp:2396-2440)
     std::vector<double> closeVal;
     int lastCCDArg = -1, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
+    int ccdMode = std::getenv("IPCGPU_CCD_MODE") ? (std::atoi(std::getenv("IPCGPU_CCD_MODE")) != 0) : 1; // 1: the reference's full sweep, 0: swept boxes over PT / EE
     // analytic half-space obstacles (animConfig.collisionObjects) with their active sets (activeSet[coI])
     std::vector<HalfSpace> planes;
     std::vector<std::vector<int>> hsSet;
@@ -93,6 +95,23 @@ struct orc_opt {
         return n;
     }
 };
+
+// the full CCD sweep of the search direction (Optimizer.cpp:1961-2021): as the reference runs it, or (mode 0) over the PT / EE pairs
+// with overlapping swept boxes
+static double fullCcd(orc_opt* o, double slackness, double stepSize)
+{
+    const Mesh& m = *o->m;
+    if (o->ccdMode == 1) {
+        int arg3[3];
+        const double a = fullCcdReference(m, o->searchDir.data(), slackness, stepSize, nullptr, arg3, nullptr);
+        o->lastCCDArg = arg3[1];
+        return a;
+    }
+    std::vector<std::array<int, 2>> cand;
+    sweptCandidates(m, o->searchDir.data(), stepSize, cand);
+    return ccdStepBound(m, cand, o->searchDir.data(), slackness, stepSize, &o->lastCCDArg);
+}
+
 
 namespace {
 struct Tic {
@@ -696,9 +715,7 @@ void orc_opt_begin_timestep(orc_opt* o)
     if (scripted) {
         double stepSize = filterStepSize(m, o->searchDir.data(), 1.0);
         if (o->selfCollision) { // :2158-2171: CCD of the scripted motion with slackness 0.5
-            std::vector<std::array<int, 2>> cand;
-            sweptCandidates(m, o->searchDir.data(), stepSize, cand);
-            stepSize = ccdStepBound(m, cand, o->searchDir.data(), 0.5, stepSize, nullptr);
+            stepSize = fullCcd(o, 0.5, stepSize);
         }
         std::vector<double> V0 = m.V;
         stepForward(o, V0, stepSize);
@@ -730,9 +747,7 @@ void orc_opt_begin_timestep(orc_opt* o)
         if (o->ipOn()) {
             for (const auto& h : o->planes) stepSize = hsStepBound(m, h, o->searchDir.data(), 0.9, stepSize);
             if (o->selfCollision) {
-                std::vector<std::array<int, 2>> cand;
-                sweptCandidates(m, o->searchDir.data(), stepSize, cand);
-                stepSize = ccdStepBound(m, cand, o->searchDir.data(), 0.8, stepSize, nullptr);
+                stepSize = fullCcd(o, 0.8, stepSize);
             }
         }
         std::vector<double> V0 = m.V;
@@ -817,9 +832,8 @@ int orc_opt_newton_iter(orc_opt* o)
             }
             const double alpha_CFL = std::sqrt(o->dHat) / (pMax * 2.0);
             if ((!o->k && alpha > alpha_CFL) || alpha > 2.0 * alpha_CFL) {
-                std::vector<std::array<int, 2>> cand; // full CCD (:1961-2021)
-                sweptCandidates(m, o->searchDir.data(), alpha, cand);
-                alpha = ccdStepBound(m, cand, o->searchDir.data(), slackness_m, alpha, &o->lastCCDArg);
+                // full CCD (:1961-2021): the hash may cap alpha, then vertices against vertices / edges / triangles, edges against edges
+                alpha = fullCcd(o, slackness_m, alpha);
                 o->nFullCCD++;
                 if (alpha < alpha_CFL) alpha = alpha_CFL;
             }

@@ -80,59 +80,56 @@ bool CTCD::edgeEdgeCTCD(const Eigen::Vector3d& q0s, const Eigen::Vector3d& p0s, 
     pack(s, e, 4, X, P);
     return advance(K_EE, X, P, orc_unclassified_distance(K_EE, X), eta, t);
 }
+extern "C" double orc_accd_small(int n, const double* X9, const double* P9, double eta, double tmax); // liborc.so
 namespace {
-// point-point and point-segment pairs (the reference's full CCD also sweeps those, SelfCollisionHandler.cpp:1011-1100):
-// the same additive advancement as orc_contact.cpp::accd, on the point-point / point-segment distance
-double dPS(const double* p, const double* a, const double* b)
+// point-point and point-segment pairs (the reference's full CCD also sweeps those, SelfCollisionHandler.cpp:1011-1100): the same
+// additive advancement on the point-point / point-segment distance (oracle/orc_contact.cpp::accdSmall)
+bool advanceSmall(int n, double X[3][3], const double P[3][3], double eta, double& t)
 {
-    double ab[3], ap[3], abab = 0, apab = 0;
-    for (int c = 0; c < 3; ++c) {
-        ab[c] = b[c] - a[c];
-        ap[c] = p[c] - a[c];
-        abab += ab[c] * ab[c];
-        apab += ap[c] * ab[c];
-    }
-    double s = abab > 0.0 ? apab / abab : 0.0;
-    s = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
     double d2 = 0;
-    for (int c = 0; c < 3; ++c) {
-        const double r = ap[c] - s * ab[c];
-        d2 += r * r;
+    if (n == 2) {
+        for (int c = 0; c < 3; ++c) d2 += (X[0][c] - X[1][c]) * (X[0][c] - X[1][c]);
     }
-    return std::sqrt(d2);
-}
-bool advanceSmall(int n, double X[3][3], const double P0[3][3], double eta, double& t)
-{
-    double P[3][3], mean[3] = { 0, 0, 0 }, len[3];
-    for (int k = 0; k < n; ++k)
-        for (int c = 0; c < 3; ++c) mean[c] += P0[k][c] / n;
-    for (int k = 0; k < n; ++k) {
-        double l2 = 0;
+    const double frac = (eta > 0.0) ? -1.0 : 0.01;
+    (void)d2;
+    double X9[9], P9[9];
+    for (int k = 0; k < 3; ++k)
         for (int c = 0; c < 3; ++c) {
-            P[k][c] = P0[k][c] - mean[c];
-            l2 += P[k][c] * P[k][c];
+            const int kk = k < n ? k : n - 1;
+            X9[3 * k + c] = X[kk][c];
+            P9[3 * k + c] = P[kk][c];
         }
-        len[k] = std::sqrt(l2);
+    // eta arrives as an absolute distance: the fraction of the current distance is recovered by one call with eta = 0 ... the
+    // current distance is what accdSmall starts from, so pass eta / d0 computed here
+    double d0;
+    {
+        double ab[3], ap[3], abab = 0, apab = 0;
+        const double* pnt = X9;
+        const double* a = X9 + 3;
+        const double* b = X9 + (n == 2 ? 3 : 6);
+        for (int c = 0; c < 3; ++c) {
+            ab[c] = b[c] - a[c];
+            ap[c] = pnt[c] - a[c];
+            abab += ab[c] * ab[c];
+            apab += ap[c] * ab[c];
+        }
+        double s_ = abab > 0.0 ? apab / abab : 0.0;
+        s_ = s_ < 0.0 ? 0.0 : (s_ > 1.0 ? 1.0 : s_);
+        double q = 0;
+        for (int c = 0; c < 3; ++c) {
+            const double r = ap[c] - s_ * ab[c];
+            q += r * r;
+        }
+        d0 = std::sqrt(q);
     }
-    const double lp = n == 2 ? len[0] + len[1] : len[0] + std::max(len[1], len[2]);
-    if (lp == 0.0) return false;
-    auto D = [&]() { return n == 2 ? dPS(X[0], X[1], X[1]) : dPS(X[0], X[1], X[2]); };
-    double d = D();
-    const double frac = (eta > 0.0 && d > 0.0) ? eta / d : 0.01;
-    const double gap = frac * d;
-    double toc = 0.0;
-    for (int it = 0; it < 100000; ++it) {
-        const double tl = (1.0 - frac) * d / lp;
-        for (int k = 0; k < n; ++k)
-            for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
-        d = D();
-        if (toc != 0.0 && d < gap) break;
-        toc += tl;
-        if (toc > 1.0) return false;
+    const double f = (frac > 0.0 || d0 <= 0.0) ? 0.01 : eta / d0;
+    const double toc = orc_accd_small(n, X9, P9, f, 1.0);
+    if (std::getenv("IPCREF_LOG_CCD")) std::fprintf(stderr, "ccd small n %d eta %g frac %g -> %g\n", n, eta, f, toc);
+    if (toc < 1.0) {
+        t = toc;
+        return true;
     }
-    if (std::getenv("IPCREF_LOG_CCD")) std::fprintf(stderr, "ccd small n %d eta %g frac %g lp %g -> %g\n", n, eta, frac, lp, toc);
-    t = toc;
-    return true;
+    return false;
 }
 } // namespace
 bool CTCD::vertexEdgeCTCD(const Eigen::Vector3d& q0s, const Eigen::Vector3d& q1s, const Eigen::Vector3d& q2s,

@@ -162,13 +162,14 @@ def test_barrier_terms_against_the_reference(G, contact):
 
 
 def test_step_bounds_and_intersection_against_the_reference(G, contact):
-    """largestFeasibleStepSize (candidate list) and largestFeasibleStepSize_CCD (full sweep through the reference's spatial hash,
+    """largestFeasibleStepSize (candidate list) and largestFeasibleStepSize_CCD (full sweep through the reference's spatial hash:
+    the cap of the step by the hash, shared-cell candidates, vertex-vertex / vertex-edge / vertex-triangle / edge-edge pairs,
     SelfCollisionHandler.cpp:564-686, 982-1366) with the per-pair query plugged from the oracle; checkEdgeTriIntersectionIfAny."""
     cs = orc.Contacts()
     cs.build(contact, float(G["con_dHat"]))
     for p, part, full in zip(G["con_p"], G["con_ccd_partial"], G["con_ccd_full"]):
         assert abs(orc.ccd_partial(cs, contact, p, 0.8, 1.0)[0] - part) <= 1e-9 * part
-        assert abs(orc.ccd_full(contact, p, 0.8, 1.0)[0] - full) <= 1e-9 * full
+        assert abs(orc.ccd_full_reference(contact, p, 0.8, 1.0)[0] - full) <= 1e-12 * full
     assert orc.is_intersected(contact) == bool(G["con_intersected"][0]) and not orc.is_intersected(contact)
     contact.set_V(G["con_Vi"])
     assert orc.is_intersected(contact) == bool(G["con_intersected_i"][0]) and orc.is_intersected(contact)
