@@ -778,7 +778,8 @@ void computeConstraintSet(const Mesh& m, double dHat, bool brute, ContactSets& o
 
 // ---- conservative CCD step bound -----------------------------------------------------------------------------
 // The reference calls CTCD::vertexFaceCTCD / edgeEdgeCTCD (CCD-Wrapper@23907da, Etienne Vouga's floating-point
-// root finder; not vendored, "parity unpinned") with eta = (1 - slackness) * current distance
+// root finder; not vendored: the per-pair time of impact stays "parity unpinned", SURVEY.md 8c -- everything around the per-pair
+// query is pinned against the reference-compiled call sites, tests/test_oracle_vs_reference.py) with eta = (1 - slackness) * current distance
 // (SelfCollisionHandler.cpp:564-686, 982-1366).  The contract restated here: the returned step keeps every tested
 // pair at a distance of at least (1 - slackness) times its current distance.  It is met by additive conservative
 // advancement on the unclassified PT / EE distance (distance evaluations only, no root finding): advance by

@@ -1,0 +1,200 @@
+"""The HIP library (through the C ABI) against the REFERENCE ITSELF.
+
+tests/golden/ref_functions.npz and ref_scene_*.npz hold what the reference's own sources return (oracle/_ref/libipcref.so, built
+from /root/reference by oracle/Makefile.ref; vectors made by tools/make_golden_ref.py).  Here the same inputs go through
+libipcgpu.so on the GPU.  Integer outputs bit-exact, floating point 1e-10 relative unless a line says why it is looser."""
+import os
+
+import numpy as np
+import pytest
+
+from test_oracle_vs_reference import GOLD, load_scene, rel, run_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    return np.load(os.path.join(GOLD, "ref_functions.npz"))
+
+
+def test_mesh_features_and_elasticity_against_the_reference(G, gpu_lib):
+    """Mesh<3> features, NH and FCR energy / gradient / PSD-projected Hessian in the solver's CSR, the inversion filter, on the
+    reference's bar-186 mesh (Mesh.cpp:414-527, Energy.cpp:195-562, LinSysSolver.hpp:46-150, get_feasible_steps.cpp)."""
+    V, T = G["bar_V"], G["bar_T"]
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, T, YM=float(G["bar_YM"]), PR=float(G["bar_PR"]), density=float(G["bar_rho"]))
+    c.opt_init(0.025, False)
+    c.set_surface(G["bar_SF"])
+    f = c.features()
+    assert rel(f["restTriInv"].reshape(-1, 3, 3).transpose(0, 2, 1), G["bar_restTriInv"]) < 1e-12
+    assert rel(f["triArea"], G["bar_triArea"]) < 1e-13 and rel(f["mass"], G["bar_mass"]) < 1e-13
+    assert rel(f["mu"], G["bar_mu"]) < 1e-15 and rel(f["lam"], G["bar_lam"]) < 1e-15
+    SVI, SFE = c.get_surface()
+    assert np.array_equal(SVI, G["bar_SVI"]) and np.array_equal(SFE, G["bar_SFEdges"])
+    c.set_positions(G["bar_Vx"])
+    c.set_dbc(G["bar_dbc"], 1)
+    c.set_pattern()
+    ia, ja = c.get_pattern()
+    for name in ("NH", "FCR"):
+        c.set_energy_type(name)
+        assert abs(c.elastic_energy(0.7) - G[f"bar_E_{name}"]) <= 1e-12 * abs(G[f"bar_E_{name}"])
+        assert rel(c.elastic_gradient(0.7), G[f"bar_g_{name}"]) < 1e-11
+        assert np.array_equal(ia, G[f"bar_ia_{name}"]) and np.array_equal(ja, G[f"bar_ja_{name}"])
+        c.set_zero()
+        c.elastic_hessian_add(0.7, True)
+        a = c.get_a()
+        want = G[f"bar_a_{name}"]
+        # rows / columns of Dirichlet nodes carry nothing but their diagonal (Energy.cpp:402-407); the diagonal itself is left out here
+        dof = np.repeat(np.isin(np.arange(V.shape[0]), G["bar_dbc"]), 3)
+        row = np.repeat(np.arange(len(ia) - 1), np.diff(ia))
+        keep = ~(dof[row] | dof[ja])
+        assert rel(a[keep], want[keep]) < 1e-10, name
+        off = ~keep & (row != ja)
+        assert np.all(want[off] == 0) and np.all(a[off] == 0)
+    c.set_energy_type("NH")
+    for p, want in zip(G["bar_p"], G["bar_filter"]):
+        assert abs(c.filter_step_size(p, 1.0) - want) <= 1e-9 * want
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def contact(G, gpu_lib):
+    c = gpu_lib.Context(0)
+    c.set_mesh(G["con_V"], G["con_T"], YM=2e4, PR=0.4, density=1000.0)
+    c.opt_init(0.025, False)
+    c.set_surface(G["con_SF"])
+    yield c
+    c.close()
+
+
+def canon(a):
+    return sorted(map(tuple, np.asarray(a).tolist()))
+
+
+def test_constraint_sets_against_the_reference(G, contact):
+    """SelfCollisionHandler::computeConstraintSet through the reference's SpatialHash: the same MMCVID tuples (PP, PE, PT, EE, merged
+    duplicates, mollified pairs) and the same PT / EE candidate list, as sets."""
+    got = contact.contact_build(float(G["con_dHat"]))
+    assert canon(got["active"]) == canon(G["con_active"])
+    assert canon(np.hstack([got["para"], got["para_eiej"]])) == canon(np.hstack([G["con_para"], G["con_eiej"]]))
+    assert canon(got["cs_ptee"]) == canon(G["con_csPTEE"])
+
+
+def test_barrier_terms_against_the_reference(G, contact):
+    dHat, kappa = float(G["con_dHat"]), float(G["con_kappa"])
+    contact.contact_set(G["con_active"], G["con_para"], G["con_eiej"])  # the reference's own sets, in its order
+    assert abs(contact.contact_energy(dHat, kappa) - G["con_E"]) <= 1e-10 * abs(G["con_E"])
+    assert rel(contact.contact_gradient_add(dHat, kappa, True), G["con_g"]) < 1e-10
+    contact.set_pattern(contact.contact_connectivity())
+    ia, ja = contact.get_pattern()
+    assert np.array_equal(ia, G["con_ia"]) and np.array_equal(ja, G["con_ja"])  # augmentConnectivity + set_pattern
+    contact.set_zero()
+    contact.contact_hessian_add(dHat, kappa, True)
+    assert rel(contact.get_a(), G["con_a"]) < 1e-8  # makePD on 6 / 9 / 12 blocks: different symmetric eigen-solvers
+    contact.set_pattern()
+
+
+def test_step_bounds_and_intersection_against_the_reference(G, contact, orc):
+    """largestFeasibleStepSize over the candidate list and largestFeasibleStepSize_CCD through the reference's swept spatial hash (cap
+    of the step, shared-cell candidates, vertex-vertex / vertex-edge / vertex-triangle / edge-edge pairs); same limiting pair and
+    the same number of queried pairs as the CPU restatement; checkEdgeTriIntersectionIfAny."""
+    contact.set_positions(G["con_V"])
+    contact.contact_build(float(G["con_dHat"]))
+    m = orc.Mesh(G["con_V"], G["con_T"], YM=2e4, PR=0.4, density=1000.0)
+    m.set_surface(G["con_SF"])
+    for p, part, full in zip(G["con_p"], G["con_ccd_partial"], G["con_ccd_full"]):
+        assert abs(contact.ccd_partial(p, 0.8, 1.0)[0] - part) <= 1e-9 * part
+        s, cap, arg, n = contact.ccd_full_reference(p, 0.8, 1.0)
+        assert abs(s - full) <= 1e-9 * full
+        so, capo, argo, no = orc.ccd_full_reference(m, p, 0.8, 1.0)
+        assert cap == 1.0 and capo == 1.0 and arg == argo and n == no
+        # a direction long enough for the hash to cap the step (SpatialHash.hpp:603-618)
+        s2, cap2, arg2, n2 = contact.ccd_full_reference(30.0 * p, 0.8, 1.0)
+        so2, capo2, argo2, no2 = orc.ccd_full_reference(m, 30.0 * p, 0.8, 1.0)
+        assert capo2 < 1.0 and abs(cap2 - capo2) <= 1e-12 * capo2 and abs(s2 - so2) <= 1e-9 * so2 and arg2 == argo2 and n2 == no2
+    assert contact.is_intersected() == bool(G["con_intersected"][0]) and not contact.is_intersected()
+    contact.set_positions(G["con_Vi"])
+    assert contact.is_intersected() == bool(G["con_intersected_i"][0]) and contact.is_intersected()
+    contact.set_positions(G["con_V"])
+
+
+def test_full_sweep_tracks_the_cpu_restatement_on_random_directions(G, contact, orc):
+    """Random directions (a vertex-edge pair limits one of them), then the exclusions of the sweep with the whole base sheet
+    Dirichlet (pairs of Dirichlet nodes only are skipped, SelfCollisionHandler.cpp:1017, 1058, 1103, 1231)."""
+    m = orc.Mesh(G["con_V"], G["con_T"], YM=2e4, PR=0.4, density=1000.0)
+    m.set_surface(G["con_SF"])
+    contact.set_positions(G["con_V"])
+    n = G["con_V"].shape[0]
+    rng = np.random.default_rng(5)
+    kinds = set()
+    for trial in range(16):
+        if trial == 12:
+            dbc = np.arange(0, n // 3, dtype=np.int32)
+            m.set_dbc(dbc, 1)
+            contact.set_dbc(dbc, 1)
+        p = G["con_p"][trial % 4] * rng.choice([0.3, 1.0, 3.0, 30.0]) + 1e-3 * rng.standard_normal(3 * n) * rng.choice([0, 1, 5])
+        so, capo, argo, no = orc.ccd_full_reference(m, p, 0.8, 1.0)
+        s, cap, arg, cnt = contact.ccd_full_reference(p, 0.8, 1.0)
+        assert abs(s - so) <= 1e-9 * so and abs(cap - capo) <= 1e-12 * capo and arg == argo and cnt == no, (trial, s, so, arg, argo, cnt, no)
+        kinds.add(arg[0])
+    assert {1, 2} <= kinds
+    contact.clear_dbc()
+
+
+def test_half_space_against_the_reference(G, contact):
+    dHat, kappa = float(G["con_dHat"]), float(G["con_kappa"])
+    contact.set_positions(G["con_V"])
+    idx = contact.add_half_space(G["hs_o"], G["hs_n"], 1e-3)
+    act = contact.halfspace_build(idx, dHat)
+    assert np.array_equal(np.sort(act), np.sort(G["hs_active"])) and len(act) > 0
+    assert abs(contact.halfspace_energy(idx, dHat, kappa) - G["hs_E"]) <= 1e-12 * abs(G["hs_E"])
+    assert rel(contact.halfspace_gradient_add(idx, dHat, kappa), G["hs_g"]) < 1e-12
+    contact.set_pattern()
+    contact.set_zero()
+    contact.halfspace_hessian_add(idx, dHat, kappa, True)
+    assert rel(contact.get_a(), G["hs_a"]) < 1e-12
+    for p, want in zip(G["con_p"], G["hs_step"]):
+        assert abs(contact.halfspace_step_bound(idx, p, 0.9, 1.0) - want) <= 1e-12 * want
+
+
+# ---- whole scenes: the reference's main.cpp / Optimizer.cpp against the HIP time stepper ---------------------------------------------
+def test_scene_bar_twist_against_the_reference(gpu_lib):
+    """BASELINE configs[0] run by the reference itself: the same Newton iteration count in every step, positions within the Newton
+    tolerance of the script (the scene starts exactly at rest: IglUtils::makePD2d is discontinuous there, round-off decides)."""
+    S, meshes = load_scene("bar_twist")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, 3)
+    assert np.array_equal(its, S["iters"][:3])
+    for s in range(3):
+        assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-5 * np.abs(S["positions"][s]).max()
+    c.close()
+
+
+def test_scene_bar_twist_minimisers_against_the_reference(gpu_lib):
+    S, meshes = load_scene("bar_twist_tight")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, 2)
+    assert np.array_equal(its[1:], S["iters"][1:2])
+    for s in range(2):
+        assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-7 * np.abs(S["positions"][s]).max()
+    c.close()
+
+
+def test_scene_two_cubes_fall_against_the_reference(gpu_lib):
+    """2cubesFall.txt (ground and self-contact with friction) run by the reference itself, 40 steps: free fall identical to
+    round-off, the same Newton iteration counts through both impacts except the step of the first touch-down (F = I up to
+    round-off in the bottom cube: the makePD2d discontinuity)."""
+    S, meshes = load_scene("two_cubes_fall")
+    steps = int(S["steps"])
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, steps)
+    free = 17
+    for s in range(free):
+        assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-12
+    assert np.array_equal(its[:free], S["iters"][:free])
+    differ = np.nonzero(its != S["iters"])[0]
+    assert len(differ) <= 4, (its.tolist(), S["iters"].tolist())
+    assert abs(int(its.sum()) - int(S["iters"].sum())) <= 6
+    assert np.abs(pos[-1] - S["positions"][-1]).max() <= 1e-2 * np.abs(S["positions"][-1]).max()
+    c.close()
