@@ -43,9 +43,9 @@ public:
     void computeFeatures(int nV, int nT, const double* Vrest, const int* F, double YM, double PR, double density, hipStream_t s);
     // surface-only nodes that belong to the mesh (triangle meshes under `shapes`, componentCoDim 2): they count in the bounding box
     // and the mean nodal mass and carry the given lumped masses (Mesh.cpp:310-345)
-    std::vector<char> inMesh; // per node: referenced by an element, or declared by setCodimNodes
+    std::vector<char> inMesh; // per node: referenced by an element (the components of codimension 3)
     void setCodimNodes(int n, const int* ids, const double* nodeMass, hipStream_t s);
-    void meshBBox(); // bounding box and node count over inMesh (Mesh::matSpaceBBoxSize2 and avgNodeMass take all of Mesh<3>)
+    void meshBBox(); // bounding box and node count over inMesh (Mesh::matSpaceBBoxSize2(dim) / avgNodeMass(dim): tetrahedral components only)
     void uploadDBC(hipStream_t s);
     int energyType = 0; // Config `energy NH|FCR` (Config.cpp:23-24): 0 neo-Hookean, 1 fixed corotated
     double density = 0; // global density handed to computeFeatures (component overrides rescale the nodal mass by rho / density)

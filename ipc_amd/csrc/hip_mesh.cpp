@@ -135,10 +135,10 @@ void HipMesh::setCodimNodes(int n, const int* ids, const double* nodeMass, hipSt
         if (ids[i] < 0 || ids[i] >= nV) throw ArgError("set_codim_nodes: node id out of range");
         if (!(nodeMass[i] >= 0.0)) throw ArgError("set_codim_nodes: negative mass");
     }
-    for (int i = 0; i < n; ++i) {
-        inMesh[ids[i]] = 1;
-        mass[ids[i]] = nodeMass[i];
-    }
+    // Nodes of Mesh<3> with their lumped area masses; the Optimizer's bounding box and mean mass (matSpaceBBoxSize2(dim),
+    // avgNodeMass(dim): Mesh.cpp:576-637, Optimizer.cpp:101, 2220, 2232) run over the components of codimension 3 only, so these
+    // nodes stay out of both.
+    for (int i = 0; i < n; ++i) mass[ids[i]] = nodeMass[i];
     meshBBox();
     d_mass.upload(mass, s);
     HIP_CHECK(hipStreamSynchronize(s));

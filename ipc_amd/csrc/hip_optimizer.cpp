@@ -507,9 +507,10 @@ double HipOptimizer::kappaFloor() const
     // suggestKappa (Optimizer.cpp:2228-2233): kappaMinMultiplier (1e11, Config.hpp:139) * mean nodal mass / (4e-16 L^2 b''(1e-16 L^2))
     const double d = 1.0e-16 * mesh.bboxDiag2, t2 = d - dHat, lg = std::log(d / dHat);
     const double Hb = (lg * -2.0 - t2 * 4.0 / d) + 1.0 / (d * d) * (t2 * t2); // BarrierFunctions.hpp:76-83
-    double avgMass = 0;
-    for (double x : mesh.mass) avgMass += x;
-    avgMass /= std::max(mesh.nElemNodes, 1); // mean over the simulated nodes (obstacle nodes carry no mass and do not count)
+    double avgMass = 0; // Mesh::avgNodeMass(dim): over the nodes of the tetrahedral components (Mesh.cpp:576-609)
+    for (int v = 0; v < mesh.nV; ++v)
+        if (!mesh.nElemNodes || mesh.inMesh[v]) avgMass += mesh.mass[v];
+    avgMass /= std::max(mesh.nElemNodes, 1);
     return 1.0e11 * avgMass / (4.0e-16 * mesh.bboxDiag2 * Hb);
 }
 

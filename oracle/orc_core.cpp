@@ -648,13 +648,13 @@ void orc_mesh_set_obstacle(orc_mesh* h, int n, const int* vids, int obstacleOnly
 }
 void orc_mesh_set_codim_nodes(orc_mesh* h, int n, const int* vids, const double* nodeMass)
 {
-    // triangle meshes listed under `shapes` (componentCoDim 2): part of Mesh<3> for the bounding box and the mean mass, lumped
-    // masses = density x a third of the adjacent triangle areas (Mesh.cpp:310-345, 399)
+    // triangle meshes listed under `shapes` (componentCoDim 2): nodes of Mesh<3> with lumped masses = density x a third of the
+    // adjacent triangle areas (Mesh.cpp:310-345, 399).  The Optimizer sizes dHat, eps_v, the Newton tolerance and kappa with
+    // matSpaceBBoxSize2(dim) and avgNodeMass(dim), which run over the components of codimension 3 only (Mesh.cpp:576-637,
+    // Optimizer.cpp:101, 2220, 2232) -- seen in a run of the reference-compiled code (2cubesFall_rotateCO_closedSurface.txt:
+    // dHat = 1e-6 x 3, the box of the one tetrahedral cube).  So these nodes stay out of the box and the mean.
     Mesh& m = h->m;
-    for (int i = 0; i < n; ++i) {
-        m.inMesh[vids[i]] = 1;
-        m.mass[vids[i]] = nodeMass[i];
-    }
+    for (int i = 0; i < n; ++i) m.mass[vids[i]] = nodeMass[i];
     m.meshBBox();
 }
 void orc_mesh_set_component_material(orc_mesh* h, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR)

@@ -23,7 +23,7 @@ struct Mesh {
     bool obstacleOnly = false;
     bool pairAllowed(int a, int b) const { return !obstacleOnly || (!obstacle.empty() && (obstacle[a] || obstacle[b])); }
     int nElemNodes = 0; // nodes referenced by at least one element (mean nodal mass and bounding box are taken over these)
-    std::vector<char> inMesh; // referenced by an element, or a declared surface-only node of the mesh (Mesh.cpp:310-345)
+    std::vector<char> inMesh; // referenced by an element: the components of codimension 3 that matSpaceBBoxSize2(dim) / avgNodeMass(dim) run over
     void meshBBox();
     std::vector<M3> restTriInv;
     std::vector<double> triArea, mass, mu, lam;

@@ -317,9 +317,10 @@ double kappaFloor(orc_opt* o)
     const Mesh& m = *o->m;
     double Hb;
     barrier(1.0e-16 * m.bboxDiag2, o->dHat, nullptr, nullptr, &Hb);
-    double avgMass = 0;
-    for (double x : m.mass) avgMass += x;
-    avgMass /= std::max(m.nElemNodes, 1); // mean over the simulated nodes (obstacle nodes carry no mass and do not count)
+    double avgMass = 0; // Mesh::avgNodeMass(dim): over the nodes of the tetrahedral components (Mesh.cpp:576-609)
+    for (int v = 0; v < m.nV; ++v)
+        if (!m.nElemNodes || m.inMesh[v]) avgMass += m.mass[v];
+    avgMass /= std::max(m.nElemNodes, 1);
     return 1.0e11 * avgMass / (4.0e-16 * m.bboxDiag2 * Hb);
 }
 

@@ -368,7 +368,7 @@ DCOFIX = ("script DCOFix\nshapes input 2\n{plane} 0 -0.01 0  0 0 0  3 1 3\ncube.
 
 def test_triangle_meshes_under_shapes_are_surface_only_components_of_the_mesh(tmp_path):
     """`.obj` under `shapes` (main.cpp:948-956, Mesh.cpp:310-345): nodes of no tetrahedron that still belong to Mesh<3> -- lumped
-    masses from the triangle areas, inside the bounding box; `script DCOFix` holds them; `shapeMatrix` replicates a shape."""
+    masses from the triangle areas; `script DCOFix` holds them; `shapeMatrix` replicates a shape."""
     (tmp_path / "plane.obj").write_text(PLANE_OBJ)
     V0, F0 = scene.make_box(1, 1, 1, size=(0.5, 0.5, 0.5), origin=(-0.25, 0.0, -0.25))
     SF0 = scene.surface_tris(F0)
@@ -388,15 +388,16 @@ def test_triangle_meshes_under_shapes_are_surface_only_components_of_the_mesh(tm
 
 
 def test_cube_lands_on_a_fixed_surface_of_the_mesh_oracle(orc, tmp_path):
-    """DCOFix end to end on the oracle: the held surface takes part in self-collision, in the bounding box behind dHat and in the
-    mean mass behind kappa (unlike a meshCO, which stays outside the mesh)."""
+    """DCOFix end to end on the oracle: the held surface takes part in self-collision; dHat and kappa are sized by the tetrahedral
+    components alone (Optimizer.cpp:101, 2220: matSpaceBBoxSize2(dim), avgNodeMass(dim) -- checked against a run of the
+    reference-compiled code, tools/ref_compare.py on 2cubesFall_rotateCO_closedSurface.txt)."""
     (tmp_path / "plane.obj").write_text(PLANE_OBJ)
     V0, F0 = scene.make_box(2, 2, 2, size=(0.5, 0.5, 0.5), origin=(-0.25, 0.0, -0.25))
     SF0 = scene.surface_tris(F0)
     cfg = ss.SceneConfig.parse(DCOFIX.format(plane=tmp_path / "plane.obj"), str(tmp_path))
     sc = ss.assemble(cfg, lambda p: (V0.copy(), F0.copy(), SF0.copy()))
     be = ss.apply(sc, OracleBackend(orc))
-    diag2 = float(((sc.V.max(0) - sc.V.min(0)) ** 2).sum())  # the 6 x 6 plane dominates the box
+    diag2 = float(((sc.V[5:].max(0) - sc.V[5:].min(0)) ** 2).sum())  # the cube alone, not the 6 x 6 plane
     assert be.state()["dHat"] == pytest.approx(1e-6 * diag2, rel=1e-12)
     seen = 0
     for k in range(12):
