@@ -22,7 +22,7 @@ class UnsupportedKeyword(ValueError):
     pass
 
 
-VIEWER_KEYWORDS = {"view", "zoom", "cameraTracking", "playBackSpeed", "appendStr", "disableCout", "size", "section"}
+VIEWER_KEYWORDS = {"view", "zoom", "cameraTracking", "playBackSpeed", "appendStr", "disableCout", "section"}
 
 
 def _rot(deg):
@@ -68,6 +68,7 @@ class SceneConfig:
     fric_iter_amt: int = 1
     tol: float = 1e-2
     script: str = "null"
+    size: float = -1.0  # > 0: the assembled model is scaled so that its largest extent is `size` and moved to the origin (main.cpp:1140-1145)
     warm_start: int = 0  # initX option
     restart: str = None
     half_spaces: list = field(default_factory=list)  # (origin, normal, friction)
@@ -227,6 +228,8 @@ class SceneConfig:
                     raise UnsupportedKeyword(f"CCDMethod {a[0]}")
             elif k == "restart":
                 cfg.restart = resolve(a[0])
+            elif k == "size":  # Config.cpp: `size s`; applied to the whole model after the shapes are assembled (main.cpp:1140-1145)
+                cfg.size = float(a[0])
             elif k in VIEWER_KEYWORDS:
                 pass  # viewer / logging only
             else:
@@ -386,6 +389,12 @@ def assemble(cfg, read_mesh):
         tr.append(tr[-1])
     V, T, SF = np.vstack(Vs), np.vstack(Ts).astype(np.int32), np.vstack(SFs).astype(np.int32)
     nSim = nr[len(cfg.shapes)]  # the simulated mesh: everything before the obstacle components
+    if cfg.size > 0 and nSim:
+        # main.cpp:1140-1145: the assembled model (all shapes, not the collision objects) is scaled so that its largest
+        # bounding-box extent equals `size`, then moved so that the box's lower corner sits at the origin
+        ext = (V[:nSim].max(0) - V[:nSim].min(0)).max()
+        V[:nSim] *= cfg.size / ext
+        V[:nSim] -= V[:nSim].min(0)
     if cfg.script in ("fall", "fallNoShift"):  # AnimScripter.cpp:779-788: lifted by half the bounding-box diagonal, no Dirichlet nodes
         if cfg.script == "fall":  # Mesh<3> only: the obstacles are not part of it in the reference
             V[:nSim, 1] += 0.5 * np.linalg.norm(V[:nSim].max(0) - V[:nSim].min(0))

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import GOLD, load_scene, rel, run_scene
+from test_oracle_vs_reference import GOLD, MORE_SCENES, check_scene, load_scene, rel, run_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -197,4 +197,16 @@ def test_scene_two_cubes_fall_against_the_reference(gpu_lib):
     assert len(differ) <= 4, (its.tolist(), S["iters"].tolist())
     assert abs(int(its.sum()) - int(S["iters"].sum())) <= 6
     assert np.abs(pos[-1] - S["positions"][-1]).max() <= 1e-2 * np.abs(S["positions"][-1]).max()
+    c.close()
+
+
+@pytest.mark.parametrize("name,exact,mism,tol", MORE_SCENES)
+def test_more_scenes_against_the_reference(name, exact, mism, tol, gpu_lib):
+    """Scripted angular velocity components (tetrahedral and codimension-2 surface), Dirichlet time ranges, FCR + `size` + `script fall` +
+    a kinematic mesh obstacle: the reference's own runs against the HIP time stepper (one more step may differ in its count than on
+    the CPU restatement: the touch-down round-off)."""
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    check_scene(S, pos, its, exact, mism + 1, 10 * tol)
     c.close()

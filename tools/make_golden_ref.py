@@ -164,16 +164,26 @@ def functions():
     print("wrote ref_functions.npz", os.path.getsize(os.path.join(GOLD, "ref_functions.npz")) >> 10, "KiB")
 
 
-# scene scripts run through the reference's own main(): (name, script text, steps)
+# scene scripts run through the reference's own main(): (name, path under the reference's input/, appended text, steps)
 SCENES = [
-    ("bar_twist", open(os.path.join(REF_ROOT, "input/otherExamples/barTwist_noCollisions.txt")).read() if os.path.isdir(REF_ROOT) else "", 4),
-    ("bar_twist_tight", (open(os.path.join(REF_ROOT, "input/otherExamples/barTwist_noCollisions.txt")).read() if os.path.isdir(REF_ROOT) else "") + "\ntol 1\n1e-6\n", 3),
-    ("two_cubes_fall", open(os.path.join(REF_ROOT, "input/tutorialExamples/2cubesFall.txt")).read() if os.path.isdir(REF_ROOT) else "", 40),
+    ("bar_twist", "otherExamples/barTwist_noCollisions.txt", "", 4),
+    ("bar_twist_tight", "otherExamples/barTwist_noCollisions.txt", "\ntol 1\n1e-6\n", 3),
+    ("two_cubes_fall", "tutorialExamples/2cubesFall.txt", "", 40),
+    # a cube falling on a rotating kinematic cube given as a tetrahedral mesh / as a closed triangle surface (codimension 2)
+    ("rotate_co", "tutorialExamples/MCO/2cubesFall_rotateCO.txt", "", 30),
+    ("rotate_co_surface", "tutorialExamples/MCO/2cubesFall_rotateCO_closedSurface.txt", "", 30),
+    # Dirichlet groups with time ranges
+    ("dbc_time_range", "tutorialExamples/BC/2cubesFall_DBC_timeRange.txt", "", 30),
+    # fixed-corotated energy, `size`, `script fall`, a kinematic mesh obstacle (meshCO plane.obj), self-collision
+    ("aligned_cubes", "paperExamples/supplementB/SQPBenchmark/12_alignedCubes.txt", "", 30),
 ]
 
 
-def scenes(extra=()):
-    for name, text, steps in list(SCENES) + list(extra):
+def scenes(only=()):
+    for name, rel, extra, steps in SCENES:
+        if only and name not in only:
+            continue
+        text = open(os.path.join(REF_ROOT, "input", rel)).read() + extra
         cfg = ss.SceneConfig.parse(text, REF_ROOT)
         with tempfile.TemporaryDirectory(prefix="ipcref_") as tmp:
             path = os.path.join(tmp, "scene.txt")
@@ -183,15 +193,20 @@ def scenes(extra=()):
             assert rcode == 0, log[-2000:]
             its = rc.read_iter_counts(os.path.join(tmp, "ref"), steps)
             pos = np.array([rc.read_status_positions(os.path.join(tmp, "ref", f"status{s + 1}")) for s in range(steps)])
-        meshes = {}
-        for sh in cfg.shapes:
-            V, T, SF = gl.read_tet_mesh(sh.path)
-            key = os.path.relpath(sh.path, REF_ROOT)
-            meshes[key] = (V, T, SF)
-        keys = sorted(meshes)
-        out = dict(script=np.array(text), steps=steps, positions=pos, iters=its, mesh_keys=np.array(keys))
-        for i, k in enumerate(keys):
-            out[f"mesh{i}_V"], out[f"mesh{i}_T"], out[f"mesh{i}_SF"] = meshes[k]
+        out = dict(script=np.array(text), steps=steps, positions=pos, iters=its)
+        keys = []
+        for pth in [sh.path for sh in cfg.shapes] + [mc[0] for mc in cfg.mesh_cos]:  # every mesh file the script names travels with the fixture
+            key = os.path.relpath(pth, REF_ROOT)
+            if key in keys:
+                continue
+            i = len(keys)
+            keys.append(key)
+            if pth.lower().endswith(".obj"):
+                out[f"mesh{i}_V"], out[f"mesh{i}_SF"] = ss.read_obj(pth)
+                out[f"mesh{i}_T"] = np.zeros((0, 4), np.int32)
+            else:
+                out[f"mesh{i}_V"], out[f"mesh{i}_T"], out[f"mesh{i}_SF"] = gl.read_tet_mesh(pth)
+        out["mesh_keys"] = np.array(keys)
         fn = os.path.join(GOLD, f"ref_scene_{name}.npz")
         np.savez_compressed(fn, **out)
         print(f"wrote {os.path.basename(fn)}: {steps} steps, Newton iterations per step {its.tolist()}, {os.path.getsize(fn) >> 10} KiB")
@@ -203,4 +218,4 @@ if __name__ == "__main__":
     if "functions" in what:
         functions()
     if "scenes" in what:
-        scenes()
+        scenes([w for w in what if w not in ("functions", "scenes")])

@@ -90,18 +90,34 @@ if __name__ == "__main__":
     if rc != 0:
         print(log[-3000:])
         sys.exit(1)
-    done = 0
-    while os.path.exists(os.path.join(out, "ref", f"info{done + 1}.txt")):
-        done += 1
-    if done < a.steps:
-        print(f"the reference stopped after {done} of {a.steps} steps; last lines of its log:")
-        print("".join(open(os.path.join(out, "ref", "log.txt")).readlines()[-6:]))
-        a.steps = done
-    its_r = read_iter_counts(os.path.join(out, "ref"), a.steps)
+    ref_dir = os.path.join(out, "ref")
+    cum_r = {}  # Newton iterations after step N, where the reference wrote info<N>.txt (at most 100 per simulated second, main.cpp:408-420)
+    have_pos = []
+    for sN in range(1, a.steps + 1):
+        f = os.path.join(ref_dir, f"info{sN}.txt")
+        if os.path.exists(f):
+            with open(f) as fh:
+                fh.readline()
+                cum_r[sN] = int(fh.readline().split()[1])
+        if os.path.exists(os.path.join(ref_dir, f"status{sN}")):
+            have_pos.append(sN)
+    last = max(list(cum_r) + have_pos + [0])
+    if last < a.steps:
+        print(f"the reference stopped after {last} of {a.steps} steps; last lines of its log:")
+        print("".join(open(os.path.join(ref_dir, "log.txt")).readlines()[-6:]))
+        a.steps = last
     pos_o, its_o = run_oracle(a.scene, a.steps)
-    for s in range(a.steps):
-        Pr = read_status_positions(os.path.join(out, "ref", f"status{s + 1}"))
-        scale = np.abs(Pr).max()
-        # kinematic mesh obstacles (`meshCO`) are separate objects in the reference and trailing surface-only nodes here
-        dev = np.abs(Pr - pos_o[s][:Pr.shape[0]]).max() / scale
-        print(f"step {s + 1}: Newton iterations reference {its_r[s]:3d}  oracle {its_o[s]:3d}   max |dx| / scale = {dev:.3e}")
+    cum_o = np.cumsum(its_o)
+    prev_r = prev_o = 0
+    for sN in range(1, a.steps + 1):
+        msg = f"step {sN}:"
+        if sN in cum_r:
+            msg += f" Newton iterations reference {cum_r[sN] - prev_r:3d}  oracle {int(cum_o[sN - 1]) - prev_o:3d}"
+            prev_r, prev_o = cum_r[sN], int(cum_o[sN - 1])
+        if sN in have_pos:
+            Pr = read_status_positions(os.path.join(ref_dir, f"status{sN}"))
+            # kinematic mesh obstacles (`meshCO`) are separate objects in the reference and trailing surface-only nodes here
+            dev = np.abs(Pr - pos_o[sN - 1][:Pr.shape[0]]).max() / np.abs(Pr).max()
+            msg += f"   max |dx| / scale = {dev:.3e}"
+        if sN in cum_r or sN in have_pos:
+            print(msg)
