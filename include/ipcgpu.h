@@ -246,6 +246,10 @@ int ipcgpu_halfspace_step_bound(ipcgpu_ctx*, int id, const double* searchDir_3nV
 /* ---- lagged smoothed Coulomb friction (FrictionUtils.hpp, SelfCollisionHandler.cpp:2481-2988, HalfSpace.cpp:272-381)
  * `selfFric mu` / `fricIterAmt n` / eps_v = tuning[4] (Config.cpp:482-488, 550-551, 45).  Self friction needs self collision. */
 int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, double epsV);
+/* MeshCO::friction (Config.cpp:459-474, MeshCO.cpp) beside Config::selfFric: a kinematic mesh obstacle carries its own friction
+ * coefficient for the pairs that involve it.  Pass the larger coefficient to ipcgpu_opt_set_friction and the ratios here: the lagged
+ * normal forces (MMLambda_lastH) of stencils without / with an obstacle node are multiplied by scaleSelf / scaleObstacle. */
+int ipcgpu_opt_set_friction_scales(ipcgpu_ctx*, double scaleSelf, double scaleObstacle);
 int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx*, int id, double mu); /* CollisionObject::friction of half-space `id` */
 /* After ipcgpu_opt_newton_iter reported convergence: the tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790) --
  * refresh the lagged multipliers / tangent bases, test tangent-space convergence.  *more = 1: another solveSub_IP pass has

@@ -998,6 +998,15 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx* c, double selfFric, int fricIterAmt, dou
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_friction_scales(ipcgpu_ctx* c, double scaleSelf, double scaleObstacle)
+{
+    return guarded([&] {
+        needArg(scaleSelf >= 0.0 && scaleObstacle >= 0.0, "friction scales must not be negative");
+        CT(c).fricScaleSelf = scaleSelf;
+        CT(c).fricScaleObst = scaleObstacle;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx* c, int id, double mu)
 {
     return guarded([&] {

@@ -84,6 +84,7 @@ public:
     std::vector<std::array<int, 4>> fricSet;
     DevBuf<int> d_fricSet;
     DevBuf<double> d_fricLambda, d_fricCoord, d_fricBasis;
+    double fricScaleSelf = 1.0, fricScaleObst = 1.0; // MeshCO::friction beside selfFric: factors on the lagged normal forces by stencil kind
     void frictionLagClear();
     void frictionLagUpdate(const double* x_dev, double dHat, double kappa); // lags the current `active` set (Optimizer.cpp:1578-1598)
     void frictionGet(double* lambda, double* coord2, double* basis6);

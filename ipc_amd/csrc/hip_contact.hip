@@ -392,8 +392,11 @@ __device__ __forceinline__ void fr_normalize(double* a)
     for (int i = 0; i < 3; ++i) a[i] /= l;
 }
 // multipliers, closest-point parameters and tangent bases at the current positions (Optimizer.cpp:1578-1598)
+// obst / scaleSelf / scaleObst: a kinematic mesh obstacle carries its own friction coefficient (MeshCO::friction); the caller passes the
+// larger coefficient to the friction terms and the lagged normal force of a stencil is scaled by the factor of its kind here
 __global__ __launch_bounds__(BLOCK) void k_friction_lag(int n, const int* __restrict__ set, const double* __restrict__ x, double dHat, double kappa,
-    double* __restrict__ lambda, double* __restrict__ coord, double* __restrict__ basis)
+    const int* __restrict__ obst, double scaleSelf, double scaleObst, double* __restrict__ lambda, double* __restrict__ coord,
+    double* __restrict__ basis)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -404,6 +407,11 @@ __global__ __launch_bounds__(BLOCK) void k_friction_lag(int n, const int* __rest
     barrier(d, dHat, &b, &gb, &Hb);
     double lam = gb * (-kappa * 2.0 * sqrt(d));
     if (set[4 * (size_t)i + 3] < -1) lam *= -set[4 * (size_t)i + 3];
+    if (obst) {
+        bool ob = false;
+        for (int k = 0; k < s.n; ++k) ob = ob || obst[s.node[k]] != 0;
+        lam *= ob ? scaleObst : scaleSelf;
+    }
     lambda[i] = lam;
     double co[2] = { 0.0, 0.0 }, t0[3], t1[3], tmp[3];
     if (s.kind == K_EE) {
@@ -1815,8 +1823,9 @@ void HipContact::frictionLagUpdate(const double* x_dev, double dHat, double kapp
     d_fricLambda.ensure(n);
     d_fricCoord.ensure(2 * (size_t)n);
     d_fricBasis.ensure(6 * (size_t)n);
-    hipLaunchKernelGGL(k_friction_lag, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_fricSet.p, x_dev, dHat, kappa, d_fricLambda.p, d_fricCoord.p,
-        d_fricBasis.p);
+    const bool scaled = hasObstacle && (fricScaleSelf != 1.0 || fricScaleObst != 1.0);
+    hipLaunchKernelGGL(k_friction_lag, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_fricSet.p, x_dev, dHat, kappa, scaled ? (const int*)d_obst.p : nullptr,
+        fricScaleSelf, fricScaleObst, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p);
 }
 
 void HipContact::frictionGet(double* lambda, double* coord2, double* basis6)

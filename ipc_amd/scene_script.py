@@ -459,16 +459,20 @@ def apply(sc, be):
     if sc.codim_fixed is not None:
         be.set_dbc(sc.codim_fixed, 2)
     self_fric = cfg.self_fric
+    fric_scales = None
     if sc.obstacle_nodes is not None:
         # static obstacle: all of its nodes are ZERO Dirichlet nodes; without `selfCollisionOn` only pairs that involve the
-        # obstacle collide.  One friction coefficient per contact set: the obstacles' (MeshCO::friction) when nothing else is in
-        # contact with itself, otherwise it has to agree with selfFric.
+        # obstacle collide.
         be.set_dbc(sc.obstacle_nodes, 1)
         be.set_obstacle(sc.obstacle_nodes, obstacle_only=not cfg.self_collision)
-        mus = {mu for _p, _o, _s, mu, _r in cfg.mesh_cos}
-        if len(mus) > 1 or (cfg.self_collision and mus != {cfg.self_fric}):
-            raise UnsupportedKeyword("meshCO friction that differs from selfFric (one friction coefficient per contact set)")
-        self_fric = mus.pop()
+        # MeshCO::friction is read (Config.cpp:459-474) and stored, but no friction term is ever evaluated for a mesh collision object:
+        # Optimizer::computeEnergyVal / computeGradient / computePrecondMtr add friction for the analytic objects and for the
+        # self-collision set only (Optimizer.cpp:3357-3376, 3473-3510, 3676-3705); the value merely switches the lagging loop on
+        # (:156-161).  Seen in a run of the reference-compiled code (cubeCliffCO.txt with and without the coefficient).  So pairs that
+        # involve an obstacle node carry no friction, the others selfFric.
+        self_fric = cfg.self_fric if cfg.self_collision else 0.0
+        if self_fric > 0:
+            fric_scales = (1.0, 0.0)
     if cfg.self_collision or sc.obstacle_nodes is not None:
         be.enable_self_collision(cfg.dHat_eps)
     for origin, normal, mu in cfg.half_spaces:
@@ -477,6 +481,8 @@ def apply(sc, be):
             be.set_half_space_friction(idx, mu)
     if self_fric > 0 or any(mu > 0 for *_, mu in cfg.half_spaces):
         be.set_friction(self_fric, cfg.fric_iter_amt, cfg.eps_v)
+        if sc.obstacle_nodes is not None and fric_scales is not None:
+            be.set_friction_scales(*fric_scales)
     for ids, lin, ang, t0, t1 in sc.dirichlet:
         be.add_dirichlet(ids, lin_vel=lin, ang_vel_deg=ang, t0=t0, t1=t1)
     for ids, acc, t0, t1 in sc.neumann:

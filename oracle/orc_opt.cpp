@@ -75,6 +75,9 @@ struct orc_opt {
     std::vector<double> closeHSVal;
     // lagged friction: Optimizer.cpp:286-304, 1525-1600, 1615-1790
     double selfFric = 0.0, epsV = 1.0e-3, fricDHat0 = 0, fricDHat = -1.0;
+    // a kinematic mesh obstacle carries its own friction coefficient (MeshCO::friction, Config.cpp:459-474): selfFric holds the larger of the
+    // two, the lagged normal forces of the stencils with / without an obstacle node are scaled by these factors (1 = the same coefficient)
+    double fricScaleSelf = 1.0, fricScaleObst = 1.0;
     int fricIterAmt = 1, fricIterI = 0;
     std::vector<double> hsFric; // per half-space friction coefficient
     FrictionLag lag;
@@ -300,7 +303,21 @@ void updateFrictionLag(orc_opt* o)
             hsFrictionLagUpdate(m, o->planes[i], o->hsSet[i], o->dHat, o->kappa, o->hsLambda[i]);
             o->hsLagSet[i] = o->hsSet[i];
         }
-    if (o->selfCollision && o->selfFric > 0.0) frictionLagUpdate(m, o->cs.active, o->dHat, o->kappa, o->lag);
+    if (o->selfCollision && o->selfFric > 0.0) {
+        frictionLagUpdate(m, o->cs.active, o->dHat, o->kappa, o->lag);
+        if ((o->fricScaleSelf != 1.0 || o->fricScaleObst != 1.0) && !m.obstacle.empty())
+            for (size_t i = 0; i < o->lag.set.size(); ++i) {
+                bool obst = false;
+                for (int k = 0; k < 4; ++k) {
+                    const int e = o->lag.set[i][k];
+                    const int v = e >= 0 ? e : -e - 1;
+                    // entry 0 is the point / first edge node (negative = -v-1 for point stencils); negative entries behind it are
+                    // "absent" markers or multiplicities, not nodes
+                    if (k == 0 || e >= 0) obst = obst || m.obstacle[v];
+                }
+                o->lag.lambda[i] *= obst ? o->fricScaleObst : o->fricScaleSelf;
+            }
+    }
 }
 
 bool anyIntersection(orc_opt* o)
@@ -979,6 +996,11 @@ int orc_opt_next_subproblem(orc_opt* o)
     return 1;
 }
 
+void orc_opt_set_friction_scales(orc_opt* o, double scaleSelf, double scaleObstacle)
+{
+    o->fricScaleSelf = scaleSelf;
+    o->fricScaleObst = scaleObstacle;
+}
 void orc_opt_set_friction(orc_opt* o, double selfFric, int fricIterAmt, double epsV)
 {
     // `selfFric mu`, `fricIterAmt n`, `tuning ... eps_v` (Config.cpp:482-488, 550-551, 45)
