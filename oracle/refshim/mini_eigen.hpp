@@ -70,6 +70,8 @@ template <class S, int N, int MN = N>
 class DiagonalMatrix;
 template <class M>
 class LDLT;
+template <class SM>
+class SparseDiag;
 template <class P, int = 0, class = void>
 class Map;
 template <class M>
@@ -99,6 +101,12 @@ struct traits<Block<X, BR, BC>> {
 };
 template <class P, int A, class B>
 struct traits<Map<P, A, B>> : traits<P> {
+};
+template <class SM>
+struct traits<SparseDiag<SM>> {
+    typedef typename SM::Scalar Scalar;
+    enum { Rows = Dynamic,
+        Cols = 1 };
 };
 template <class S, int N, int MN>
 struct traits<DiagonalMatrix<S, N, MN>> {
@@ -2379,6 +2387,33 @@ public:
     I col() const { return c_; }
     S value() const { return v_; }
 };
+// writable view of the diagonal of a SparseMatrix (`m.diagonal().segment(a, n) *= s`, Mesh.cpp:666-668)
+template <class SM>
+class SparseDiag : public MatrixBase<SparseDiag<SM>> {
+    SM* m_;
+
+public:
+    typedef typename SM::Scalar Scalar;
+    explicit SparseDiag(SM& m)
+        : m_(&m) {}
+    SparseDiag(const SparseDiag&) = default;
+    Index rows_() const { return std::min(m_->rows(), m_->cols()); }
+    Index cols_() const { return 1; }
+    Scalar get(Index i, Index) const { return m_->coeff(i, i); }
+    Scalar& ref(Index i, Index) { return m_->coeffRef(i, i); }
+    template <class Od>
+    SparseDiag& operator=(const MatrixBase<Od>& o)
+    {
+        MatrixBase<SparseDiag>::assignFrom(o);
+        return *this;
+    }
+    SparseDiag& operator=(const SparseDiag& o)
+    {
+        MatrixBase<SparseDiag>::assignFrom(o);
+        return *this;
+    }
+};
+
 template <class S, int O = 0, class I = int>
 class SparseMatrix {
     // The reference keeps a lumped (diagonal) mass matrix and a few debugging exports in this type; the stand-in is a
@@ -2453,6 +2488,7 @@ public:
         return std::sqrt(s);
     }
     S squaredNorm() const { return norm() * norm(); }
+    SparseDiag<SparseMatrix> diagonal() { return SparseDiag<SparseMatrix>(*this); }
     Matrix<S, Dynamic, 1> diagonal() const
     {
         Matrix<S, Dynamic, 1> d = Matrix<S, Dynamic, 1>::Zero(std::min(r_, c_));
