@@ -176,6 +176,9 @@ SCENES = [
     ("dbc_time_range", "tutorialExamples/BC/2cubesFall_DBC_timeRange.txt", "", 30),
     # fixed-corotated energy, `size`, `script fall`, a kinematic mesh obstacle (meshCO plane.obj), self-collision
     ("aligned_cubes", "paperExamples/supplementB/SQPBenchmark/12_alignedCubes.txt", "", 30),
+    # the same with friction between the cubes: the pairs that involve the mesh collision object carry none (its coefficient only
+    # switches the lagging loop on in the reference), the cube-cube pairs carry selfFric
+    ("aligned_cubes_fric", "paperExamples/supplementB/SQPBenchmark/12_alignedCubes.txt", "\nselfFric 0.3\n", 40),
 ]
 
 
