@@ -620,6 +620,7 @@ int ipcgpu_set_surface(ipcgpu_ctx* c, int nSF, const int* SF)
         HipMesh& m = M(c);
         bind(c);
         needArg(nSF >= 0 && (SF || nSF == 0), "bad surface");
+        m.addSurfaceEdges(nSF, SF);
         CT(c).setSurface(m, nSF, SF);
         return IPCGPU_OK;
     });

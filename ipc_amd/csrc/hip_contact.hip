@@ -744,7 +744,10 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
             }
 }
 
-// ---- conservative CCD (additive advancement on the unclassified distance; contract in DESIGN.md) ---------------
+// ---- conservative CCD (advancement on the unclassified distance until it meets the gap; contract in DESIGN.md) ---------------
+// Converged to ADVANCE_TOL * (initial distance): a bound that stops one step short of the gap jumps by up to a fifth of itself
+// when the iteration count changes, and the Newton path that leans on it would not be reproducible.
+#define ADVANCE_TOL 1.0e-8
 __device__ inline double accd(int kind, const double (*X0)[3], const double (*P0)[3], double eta, double tmax)
 {
     double X[4][3], P[4][3], mean[3] = { 0.0, 0.0, 0.0 }, len[4];
@@ -763,14 +766,17 @@ __device__ inline double accd(int kind, const double (*X0)[3], const double (*P0
     double d = sqrt(kind == K_PT ? dist2_PT(X[0], X[1], X[2], X[3]) : dist2_EE(X[0], X[1], X[2], X[3]));
     const double gap = eta * d;
     double toc = 0.0;
+    const double tol = ADVANCE_TOL * d;
     for (int it = 0; it < 100000; ++it) {
-        const double tl = (1.0 - eta) * d / lp;
+        // the distance cannot shrink faster than lp per unit of t: advancing by (d - gap) / lp never passes d = gap, and the
+        // iteration converges onto the first time the distance equals the gap -- what CTCD's thickened query returns
+        if (!(d - gap > tol)) break;
+        const double tl = (d - gap) / lp;
+        toc += tl;
+        if (toc > tmax) return tmax;
         for (int k = 0; k < 4; ++k)
             for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
         d = sqrt(kind == K_PT ? dist2_PT(X[0], X[1], X[2], X[3]) : dist2_EE(X[0], X[1], X[2], X[3]));
-        if (toc != 0.0 && d < gap) break;
-        toc += tl;
-        if (toc > tmax) return tmax;
     }
     return toc;
 }
@@ -1118,14 +1124,15 @@ __device__ inline double accd_small(int n, const double (*X0)[3], const double (
     double d = dist_ps(X[0], X[1], X[kb]);
     const double gap = eta * d;
     double toc = 0.0;
+    const double tol = ADVANCE_TOL * d;
     for (int it = 0; it < 100000; ++it) {
-        const double tl = (1.0 - eta) * d / lp;
+        if (!(d - gap > tol)) break;
+        const double tl = (d - gap) / lp;
+        toc += tl;
+        if (toc > tmax) return tmax;
         for (int k = 0; k < n; ++k)
             for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
         d = dist_ps(X[0], X[1], X[kb]);
-        if (toc != 0.0 && d < gap) break;
-        toc += tl;
-        if (toc > tmax) return tmax;
     }
     return toc;
 }

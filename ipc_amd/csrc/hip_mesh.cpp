@@ -78,7 +78,7 @@ void HipMesh::computeFeatures(int nV_, int nT_, const double* Vr, const int* Fc,
     this->density = density;
     mu.assign(nT, YM / 2.0 / (1.0 + PR)); // Mesh.cpp:663-664
     lam.assign(nT, YM * PR / (1.0 + PR) / (1.0 - 2.0 * PR));
-    // vNeighbor (Mesh.cpp:470-479); surface triangles of a tet mesh only repeat tet edges
+    // vNeighbor (Mesh.cpp:470-479); the surface triangles join in addSurfaceEdges
     std::sort(edges.begin(), edges.end());
     edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
     nbPtr.assign(nV + 1, 0);
@@ -142,6 +142,32 @@ void HipMesh::setCodimNodes(int n, const int* ids, const double* nodeMass, hipSt
     meshBBox();
     d_mass.upload(mass, s);
     HIP_CHECK(hipStreamSynchronize(s));
+}
+
+void HipMesh::addSurfaceEdges(int nSF, const int* SF)
+{
+    // Mesh.cpp:480-487: every surface triangle's edges enter vNeighbor too.  For a tet component they only repeat tet edges; for
+    // a surface-only component (shell, scripted collision surface) they are the only adjacency its nodes have, and the barrier
+    // blocks of a stencil whose nodes share such a triangle land on them once the nodes are free (penalty phase of a moving DBC).
+    std::vector<std::pair<int, int>> edges;
+    edges.reserve(nb.size() + 6 * (size_t)nSF);
+    for (int v = 0; v < nV; ++v)
+        for (int k = nbPtr[v]; k < nbPtr[v + 1]; ++k) edges.emplace_back(v, nb[k]);
+    for (int t = 0; t < nSF; ++t)
+        for (int a = 0; a < 3; ++a) {
+            const int i = SF[t + (size_t)nSF * a], j = SF[t + (size_t)nSF * ((a + 1) % 3)];
+            if (i < 0 || i >= nV || j < 0 || j >= nV) throw ArgError("set_surface: node id out of range");
+            edges.emplace_back(i, j);
+            edges.emplace_back(j, i);
+        }
+    std::sort(edges.begin(), edges.end());
+    edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
+    if (edges.size() == nb.size()) return;
+    nbPtr.assign(nV + 1, 0);
+    for (auto& e : edges) nbPtr[e.first + 1]++;
+    for (int v = 0; v < nV; ++v) nbPtr[v + 1] += nbPtr[v];
+    nb.resize(edges.size());
+    for (size_t i = 0; i < edges.size(); ++i) nb[i] = edges[i].second;
 }
 
 void HipMesh::uploadDBC(hipStream_t s)

@@ -905,6 +905,8 @@ void HipOptimizer::precompute()
 {
     // Optimizer.cpp:457-507
     if (!initialised) throw StateError("opt_precompute before opt_init");
+    // Optimizer.cpp:258-263: the reference ends its process on an intersecting start (every line search after it would halve forever)
+    if (anyIntersection()) throw StateError("intersection detected in initial configuration");
     {
         Tic t(timers[1], stream);
         lin.set_pattern(mesh, 0, nullptr);

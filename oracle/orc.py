@@ -271,7 +271,8 @@ class Optimizer:
         lib().orc_opt_set_rel_tol(self.h, C.c_double(tol))
 
     def precompute(self):
-        lib().orc_opt_precompute(self.h)
+        if lib().orc_opt_precompute(self.h) != 0:
+            raise RuntimeError("intersection detected in initial configuration")
 
     def begin_timestep(self):
         lib().orc_opt_begin_timestep(self.h)

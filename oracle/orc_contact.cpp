@@ -823,6 +823,10 @@ static double unclassifiedD2(int kind, const double X[4][3])
     return d;
 }
 
+// The advancement stops once the distance is within ADVANCE_TOL * (initial distance) of the gap.  (Stopping at the first iterate
+// below the gap instead -- one step short of it -- makes the result jump by up to a fifth of itself whenever the iteration count
+// changes, and a Newton path that leans on such a bound is not reproducible between two implementations.)
+static const double ADVANCE_TOL = 1.0e-8;
 double accd(int kind, const double X0[4][3], const double P0[4][3], double eta, double tmax)
 {
     double X[4][3], P[4][3], mean[3] = { 0, 0, 0 };
@@ -843,14 +847,17 @@ double accd(int kind, const double X0[4][3], const double P0[4][3], double eta, 
     double d = std::sqrt(unclassifiedD2(kind, X));
     const double gap = eta * d;
     double toc = 0.0;
+    const double tol = ADVANCE_TOL * d;
     for (int it = 0; it < 100000; ++it) {
-        const double tl = (1.0 - eta) * d / lp;
+        // the distance cannot shrink faster than lp per unit of t: advancing by (d - gap) / lp never passes d = gap, and the
+        // iteration converges onto the first time the distance equals the gap -- what CTCD's thickened query returns
+        if (!(d - gap > tol)) break;
+        const double tl = (d - gap) / lp;
+        toc += tl;
+        if (toc > tmax) return tmax;
         for (int k = 0; k < 4; ++k)
             for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
         d = std::sqrt(unclassifiedD2(kind, X));
-        if (toc != 0.0 && d < gap) break;
-        toc += tl;
-        if (toc > tmax) return tmax;
     }
     return toc;
 }
@@ -1135,14 +1142,15 @@ double accdSmall(int n, const double X0[3][3], const double P0[3][3], double eta
     double d = D();
     const double gap = eta * d;
     double toc = 0.0;
+    const double tol = ADVANCE_TOL * d;
     for (int it = 0; it < 100000; ++it) {
-        const double tl = (1.0 - eta) * d / lp;
+        if (!(d - gap > tol)) break;
+        const double tl = (d - gap) / lp;
+        toc += tl;
+        if (toc > tmax) return tmax;
         for (int k = 0; k < n; ++k)
             for (int c = 0; c < 3; ++c) X[k][c] += tl * P[k][c];
         d = D();
-        if (toc != 0.0 && d < gap) break;
-        toc += tl;
-        if (toc > tmax) return tmax;
     }
     return toc;
 }

@@ -662,12 +662,15 @@ void orc_opt_add_dirichlet(orc_opt* o, int n, const int* ids, const double* lin3
     computeXTilta(o);
 }
 
-void orc_opt_precompute(orc_opt* o)
+int orc_opt_precompute(orc_opt* o)
 {
+    // Optimizer.cpp:258-263: "intersection detected in initial configuration!" ends the reference's process
+    if (anyIntersection(o)) return -1;
     // Optimizer.cpp:457-507: set_pattern, constraint sets, computePrecondMtr(redoSVD), analyze_pattern, initial energy
     computeConstraintSets(o);
     computePrecondMtr(o, true);
     o->lastEnergyVal = computeEnergyVal(o);
+    return 0;
 }
 
 // head of solveSub_IP (Optimizer.cpp:1826-1828)

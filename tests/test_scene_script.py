@@ -255,17 +255,20 @@ def test_cube_dropped_on_a_mesh_obstacle_gpu_beside_the_oracle(orc, gpu_lib, tmp
 @pytest.mark.gpu
 def test_tutorial_scene_runs_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
     """input/tutorialExamples/2cubesFall.txt: two cubes, self-contact with friction, rough ground.  The cubes start exactly at
-    rest, so single iterates are round-off dependent (makePD2d); the converged steps are compared at a tight tolerance."""
+    rest, so single iterates are round-off dependent (makePD2d); the converged steps are compared at a tight tolerance.
+    The upper cube is offset and tilted: two exactly aligned cubes are a symmetric configuration whose landing is a bifurcation
+    (which corner gives way is decided by round-off and by the adaptive stiffness that follows: a 1e-9 perturbation of the
+    CPU restatement's own start moves its own step 7 by 5e-4), so only a generic contact can be compared step by step."""
     V, F = scene.make_box(1, 1, 1, size=(1.0, 1.0, 1.0), origin=(-0.5, -0.5, -0.5))
     gl.save_tet_mesh(tmp_path / "cube.msh", V, F)
-    text = TUTORIAL.replace("0 3 0", "0 1.6 0").replace("0 1 0", "0 0.52 0") + "tol 1\n1e-6\n"  # closer to the ground: contact within a few steps
+    text = TUTORIAL.replace("0 3 0  0 0 0", "0.13 1.66 0.07  4 10 7").replace("0 1 0", "0 0.52 0") + "tol 1\n1e-6\n"  # closer to the ground: contact within a few steps
     cfg = ss.SceneConfig.parse(text, str(tmp_path))
     sc = ss.assemble(cfg, gl.read_tet_mesh)
     assert sc.V.shape == (16, 3) and sc.T.shape == (12, 4)
     ob = ss.apply(sc, OracleBackend(orc))
     c = ss.apply(sc, gpu_lib.Context(0))
-    touched = 0
-    for step in range(10):
+    touched = pairs = 0
+    for step in range(14):
         no = 0
         ob.o.begin_timestep()
         c.begin_timestep()
@@ -285,7 +288,30 @@ def test_tutorial_scene_runs_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path
         so, sg = ob.o.state(), c.state()
         assert np.abs(sg["V"] - so["V"]).max() < 1e-6, step
         touched += c.contact_state()["nHalfSpace"] > 0
+        pairs += c.contact_state()["nActive"] > 0
+    assert pairs >= 3  # the cubes are in contact with each other
     assert touched >= 3 and c.state()["V"][:, 1].min() > 0.0  # the lower cube has reached the ground and stays above it
+    c.close()
+
+
+def _intersecting_start(tmp_path):
+    V, F = scene.make_box(1, 1, 1, size=(1.0, 1.0, 1.0), origin=(-0.5, -0.5, -0.5))
+    gl.save_tet_mesh(tmp_path / "cube.msh", V, F)
+    cfg = ss.SceneConfig.parse(TUTORIAL.replace("0 3 0  0 0 0", "0.13 1.45 0.07  4 10 7"), str(tmp_path))  # a corner of the upper cube inside the lower
+    return ss.assemble(cfg, gl.read_tet_mesh)
+
+
+def test_intersecting_start_is_refused(orc, tmp_path):
+    """Optimizer.cpp:258-263: "intersection detected in initial configuration!" ends the reference's process."""
+    with pytest.raises(RuntimeError, match="intersection detected in initial configuration"):
+        ss.apply(_intersecting_start(tmp_path), OracleBackend(orc))
+
+
+@pytest.mark.gpu
+def test_intersecting_start_is_refused_on_the_gpu(gpu_lib, tmp_path):
+    c = gpu_lib.Context(0)
+    with pytest.raises(gl.IpcGpuError, match="intersection detected in initial configuration"):
+        ss.apply(_intersecting_start(tmp_path), c)
     c.close()
 
 
