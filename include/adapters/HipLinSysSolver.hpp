@@ -17,6 +17,12 @@
 #include <stdexcept>
 #include <vector>
 
+// the enum value a maintainer adds to LinSysSolverType (LinSysSolver.hpp:25-29); overridable so that the header also compiles
+// against an unmodified tree
+#ifndef IPCGPU_LINSYSSOLVER_TYPE
+#define IPCGPU_LINSYSSOLVER_TYPE LinSysSolverType::HIP
+#endif
+
 namespace IPC {
 
 // Hand a block-structured symmetric-upper CSR (0-based; what LinSysSolver::set_pattern builds) to the context.  When the
@@ -86,7 +92,7 @@ public:
     HipLinSysSolver& operator=(const HipLinSysSolver&) = delete;
 
     ipcgpu_ctx* context() const { return ctx; }
-    LinSysSolverType type() const override { return LinSysSolverType::HIP; }
+    LinSysSolverType type() const override { return IPCGPU_LINSYSSOLVER_TYPE; }
 
     // host-side addCoeff / setCoeff since the last flush -> HBM (one pass over the values)
     void flush() const

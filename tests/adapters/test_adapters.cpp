@@ -1,5 +1,6 @@
 // TEST INFRASTRUCTURE -- compiles the adapters of include/adapters/ against the Eigen-free stand-ins of the reference's
-// interfaces (tests/mock_ipc/) and, on a GPU, runs them:
+// interfaces (tests/mock_ipc/) -- and, where /root/reference exists, against the reference's own headers and compiled sources
+// (tests/test_adapters.py::build_exe_ref) -- and, on a GPU, runs them:
 //   1. Diagnostic.cpp:367-392 through the adapter CLASS: 10 isolated nodes, diagonal 10, rhs 1  =>  x = 0.1
 //   2. composition on one shared context: HipElasticEnergy::computeHessian adds into the HipLinSysSolver it is handed
 //      (values stay in HBM), host-side addCoeff / setCoeff of the reference's Optimizer land on top, factorize + solve;
@@ -125,7 +126,7 @@ static int run_gpu()
         for (int t = 0; t < nT; ++t)
             for (int k = 0; k < 9; ++k) mesh.restTriInv[t].data()[k] = A[9 * (size_t)t + k];
         mesh.massMatrix.resize(nV, nV);
-        for (int v = 0; v < nV; ++v) mesh.massMatrix.diag(v) = mass[v];
+        for (int v = 0; v < nV; ++v) mesh.massMatrix.coeffRef(v, v) = mass[v];
         for (int t = nT / 2; t < nT; ++t) { // a stiffer second half, set on the Mesh<3> side only
             mesh.u[t] *= 3.0;
             mesh.lambda[t] *= 3.0;
@@ -208,7 +209,7 @@ static int run_gpu()
 int main(int argc, char** argv)
 {
     if (argc > 1 && !std::strcmp(argv[1], "compile-only")) {
-        std::printf("adapters compiled against the interface stand-ins\n");
+        std::printf("adapters compiled and linked\n");
         return 0;
     }
     const int f = run_gpu();

@@ -30,6 +30,41 @@ def build_exe():
     return EXE
 
 
+REF_SRC = "/root/reference/src"
+EXE_REF = os.path.join(BUILD, "test_adapters_ref")
+LIB_REF = os.path.join(ROOT, "oracle", "_ref", "libipcref.so")
+
+
+def build_exe_ref():
+    """The same translation unit against the reference's OWN LinSysSolver.hpp / Energy.hpp / Mesh.hpp (the dense-matrix stand-in of
+    oracle/refshim in place of Eigen), linked with the reference's compiled sources (oracle/_ref/libipcref.so: Mesh<3>,
+    Energy<3>, LinSysSolver::create).  Build container only; the executable travels to the GPU box like the other built files.
+    LinSysSolverType::HIP is the one enum value a maintainer adds: the unmodified tree is given CHOLMOD's in its place."""
+    from ipc_amd import build as b
+    b.build()
+    os.makedirs(BUILD, exist_ok=True)
+    src = os.path.join(ROOT, "tests", "adapters", "test_adapters.cpp")
+    deps = [src, LIB_REF, os.path.join(ROOT, "include", "ipcgpu.h")] + [os.path.join(ROOT, "include", "adapters", f) for f in os.listdir(os.path.join(ROOT, "include", "adapters"))]
+    if os.path.exists(EXE_REF) and all(os.path.getmtime(EXE_REF) >= os.path.getmtime(d) for d in deps):
+        return EXE_REF
+    inc = ["-I" + os.path.join(ROOT, "oracle", "refshim")] + ["-I" + os.path.join(REF_SRC, d) for d in
+           ("", "Utils", "CollisionObject", "Energy", "Energy/Physics_Elasticity", "LinSysSolver", "Utils/SVD", "TimeStepper")]
+    cmd = ["g++", "-std=c++17", "-O1", "-w", "-DDIM=3", "-DNDEBUG", "-DIPCGPU_LINSYSSOLVER_TYPE=LinSysSolverType::CHOLMOD"] + inc + [
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "adapters"), src, "-o", EXE_REF,
+           "-L" + os.path.join(ROOT, "ipc_amd"), "-lipcgpu", "-L" + os.path.dirname(LIB_REF), "-lipcref",
+           "-Wl,-rpath,$ORIGIN/../../../ipc_amd", "-Wl,-rpath,$ORIGIN/../../../oracle/_ref", "-Wl,-rpath,$ORIGIN/../../../oracle/_build", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return EXE_REF
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF_SRC) and os.path.exists(LIB_REF)), reason="the reference's headers exist in the build container only")
+def test_adapters_compile_and_link_against_the_reference_headers():
+    exe = build_exe_ref()
+    r = subprocess.run([exe, "compile-only"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
 def test_adapters_compile_and_link_against_the_interface_stand_ins():
     exe = build_exe()
     r = subprocess.run([exe, "compile-only"], capture_output=True, text=True)
@@ -51,5 +86,16 @@ def test_adapter_headers_use_only_the_public_c_abi():
 def test_adapters_run_on_the_gpu():
     exe = build_exe()
     r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "adapters ok" in r.stdout
+
+
+@pytest.mark.gpu
+def test_adapters_built_on_the_reference_headers_run_on_the_gpu():
+    """tests/adapters/_build/test_adapters_ref: HipLinSysSolver / HipElasticEnergy deriving from the reference's own LinSysSolver /
+    Energy<3>, on a Mesh<3> of the reference's own Mesh.cpp -- built where /root/reference exists (__graft_entry__.build)."""
+    if not (os.path.exists(EXE_REF) and os.path.exists(LIB_REF)):
+        pytest.skip("built in the container that holds /root/reference")
+    r = subprocess.run([EXE_REF], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "adapters ok" in r.stdout
