@@ -251,6 +251,11 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, doubl
  * normal forces (MMLambda_lastH) of stencils without / with an obstacle node are multiplied by scaleSelf / scaleObstacle. */
 int ipcgpu_opt_set_friction_scales(ipcgpu_ctx*, double scaleSelf, double scaleObstacle);
 int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx*, int id, double mu); /* CollisionObject::friction of half-space `id` */
+/* Lagged stiffness-proportional damping: `dampingStiff s` (Config.cpp:141-147; `dampingRatio r` is s = r * dt^3 * 3 / 4, :148-157,
+ * 614-616).  The damping matrix is the PSD-projected elastic Hessian at the end of the last time step times s / dt
+ * (Optimizer.cpp:593-595, 3723-3735); 1/2 dx^T D dx joins the energy (:3381-3400), D dx the gradient (:3519-3540), D the Hessian
+ * (:3707-3709).  Call before ipcgpu_opt_precompute; 0 switches it off. */
+int ipcgpu_opt_set_damping(ipcgpu_ctx*, double dampingStiff);
 /* After ipcgpu_opt_newton_iter reported convergence: the tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790) --
  * refresh the lagged multipliers / tangent bases, test tangent-space convergence.  *more = 1: another solveSub_IP pass has
  * started (keep calling newton_iter); 0: the time step is done.  Without friction it returns 0 and changes nothing. */

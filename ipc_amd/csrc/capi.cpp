@@ -999,6 +999,14 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx* c, double selfFric, int fricIterAmt, dou
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_damping(ipcgpu_ctx* c, double dampingStiff)
+{
+    return guarded([&] {
+        needArg(dampingStiff == dampingStiff, "damping stiffness is not a number");
+        O(c).setDamping(dampingStiff);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_friction_scales(ipcgpu_ctx* c, double scaleSelf, double scaleObstacle)
 {
     return guarded([&] {

@@ -121,6 +121,14 @@ public:
     void computeGradient(bool projectDBC);
     void penaltyGradientAdd(bool projectDBC);
     void computePrecondMtr(bool projectDBC, bool withGradient);
+    // lagged stiffness-proportional damping (Optimizer.cpp:3381-3400, 3519-3540, 3707-3709, 3723-3735; Config.cpp:141-157, 614-616):
+    // D = projected elastic Hessian at the state the last time step ended in, times dampingStiff / dt, on the solver's pattern
+    double dampingStiff = 0.0;
+    void setDamping(double stiff);
+    void computeDampingMtr(); // at the current positions (precompute, end of a time step)
+    void assembleDampingMtr(); // (re)builds the values at the remembered positions on the current pattern
+    double dampingEnergy();
+    void dampingGradientAdd(bool projectDBC, double* grad_dev);
     void computeSearchDir(bool projectDBC);
     void lineSearch(double& stepSize);
     void stepForward(const double* x0_dev, double alpha);
@@ -147,6 +155,8 @@ public:
     void saveStatus(const std::string& path); // Optimizer::saveStatus, Optimizer.cpp:2964-3011
     void loadStatus(const std::string& path); // restart, Optimizer.cpp:179-248
     DevBuf<double> d_vel, d_xPrev, d_searchDir, d_gradient, d_minusG, d_x0, d_partial, d_scalar;
+    DevBuf<double> d_damp, d_xDamp, d_zeroMass, d_dampDx, d_dampAdx;
+    unsigned long long dampPatternVersion = ~0ULL;
     DevBuf<int> d_flag, d_handleIds;
     DevBuf<double> d_handleAng;
     int nHandles = 0;

@@ -270,11 +270,71 @@ double HipOptimizer::computeEnergyVal()
             if (h->friction > 0.0) E += h->frictionEnergy(mesh.d_x.p, d_xPrev.p, fricDHat);
         if (selfCollision && selfFric > 0.0) E += contact->frictionEnergy(mesh.d_x.p, d_xPrev.p, fricDHat, selfFric, d_partial, d_scalar.p + 4);
     }
+    if (dampingStiff > 0.0) E += dampingEnergy();
     if (rhoDBC && !tpIds.empty()) { // augmentMDBCEnergy (Optimizer.cpp:3402-3404)
         launch_mdbc_reduce(mdbc(), mesh.d_x.p, rhoDBC, 0, d_scalar.p + 5, stream);
         E += readScalar(d_scalar.p + 5);
     }
     return E;
+}
+
+// ---- lagged damping ----------------------------------------------------------------------------------------------
+void HipOptimizer::setDamping(double stiff)
+{
+    dampingStiff = stiff > 0.0 ? stiff : 0.0; // Config.cpp:141-147
+}
+void HipOptimizer::computeDampingMtr()
+{
+    // computeDampingMtr (Optimizer.cpp:3723-3735) at the end of a time step (:593-595) and inside the first computePrecondMtr (:470,
+    // 3598-3612).  The positions are kept: when the pattern grows the values are rebuilt from them on the new pattern.
+    if (!(dampingStiff > 0.0)) return;
+    d_xDamp.ensure(3 * (size_t)mesh.nV);
+    HIP_CHECK(hipMemcpyAsync(d_xDamp.p, mesh.d_x.p, sizeof(double) * 3 * (size_t)mesh.nV, hipMemcpyDeviceToDevice, stream));
+    assembleDampingMtr();
+}
+void HipOptimizer::assembleDampingMtr()
+{
+    const size_t nnz = lin.ja.size();
+    d_damp.ensure(nnz);
+    if (d_zeroMass.n < (size_t)mesh.nV) {
+        d_zeroMass.alloc(mesh.nV);
+        d_zeroMass.zero(stream);
+    }
+    ensurePatchPlan();
+    int pb, pe;
+    patchShard(pb, pe);
+    ElemView v = view();
+    v.x = d_xDamp.p;
+    v.xTilde = d_xDamp.p;
+    v.mass = d_zeroMass.p; // the patch pass owns the diagonal: no mass here, and the identity of the projected rows is cleared below
+    if (worldSize > 1) HIP_CHECK(hipMemsetAsync(d_damp.p, 0, sizeof(double) * nnz, stream));
+    launch_assemble_patches(v, patch, pb, pe, dampingStiff / dt, 1, nullptr, d_damp.p, stream);
+    if (worldSize > 1) reduceSum(d_damp.p, (long long)nnz);
+    launch_damp_clear_diag(mesh.nV, mesh.d_dbc.p, lin.d_ia.p, d_damp.p, stream);
+    dampPatternVersion = lin.patternVersion;
+}
+double HipOptimizer::dampingEnergy()
+{
+    // Optimizer.cpp:3381-3400: 1/2 dx^T D dx with the displacement of the step, zero on every Dirichlet node
+    if (dampPatternVersion != lin.patternVersion) assembleDampingMtr();
+    const int n3 = 3 * mesh.nV;
+    d_dampDx.ensure(n3);
+    d_dampAdx.ensure(n3);
+    launch_damp_dx(mesh.nV, mesh.d_dbc.p, 0, 1, mesh.d_x.p, d_xPrev.p, d_dampDx.p, stream);
+    launch_csr_symv(n3, lin.d_ia.p, lin.d_ja.p, d_damp.p, d_dampDx.p, d_dampAdx.p, stream);
+    launch_dot_scaled(n3, d_dampDx.p, d_dampAdx.p, 0.5, d_scalar.p + 6, stream);
+    return readScalar(d_scalar.p + 6);
+}
+void HipOptimizer::dampingGradientAdd(bool projectDBC, double* grad_dev)
+{
+    // Optimizer.cpp:3519-3540: gradient += D dx, the displacement cleared on the projected Dirichlet nodes
+    if (dampPatternVersion != lin.patternVersion) assembleDampingMtr();
+    const int n3 = 3 * mesh.nV;
+    d_dampDx.ensure(n3);
+    d_dampAdx.ensure(n3);
+    launch_damp_dx(mesh.nV, mesh.d_dbc.p, 1, projectDBC ? 1 : 0, mesh.d_x.p, d_xPrev.p, d_dampDx.p, stream);
+    launch_csr_symv(n3, lin.d_ia.p, lin.d_ja.p, d_damp.p, d_dampDx.p, d_dampAdx.p, stream);
+    launch_axpy(n3, 1.0, d_dampAdx.p, grad_dev, stream);
 }
 
 // ---- lagged friction ---------------------------------------------------------------------------------------------
@@ -522,6 +582,7 @@ void HipOptimizer::initKappa()
     const size_t n3 = 3 * (size_t)mesh.nV;
     std::vector<double> gE(n3), gc(n3);
     elasticInertiaGradient(true); // computeGradient with solveIP == false (:2243-2245)
+    if (dampingStiff > 0.0) dampingGradientAdd(true, d_gradient.p); // still part of it (:3519-3540)
     d_gradient.download(gE.data(), n3, stream);
     d_minusG.zero(stream);
     barrierGradientAdd(true, 1.0, true, d_minusG.p); // also clears the DBC rows (:2275-2277)
@@ -645,6 +706,7 @@ void HipOptimizer::computeGradient(bool projectDBC)
 // cleared (Optimizer.cpp:3512-3516; with projectDBC the element pass never wrote them), then augmentMDBCGradient (:3542-3544)
 void HipOptimizer::penaltyGradientAdd(bool projectDBC)
 {
+    if (dampingStiff > 0.0) dampingGradientAdd(projectDBC, d_gradient.p); // Optimizer.cpp:3519-3540 (rows of D of Dirichlet nodes are empty)
     if (projectDBC) return;
     launch_clear_projected(mesh.nV, mesh.d_dbc.p, 0, d_gradient.p, stream);
     if (rhoDBC && !tpIds.empty()) launch_mdbc_gradient(mdbc(), mesh.d_x.p, rhoDBC, d_gradient.p, stream);
@@ -785,6 +847,10 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
                 contact->frictionHessianAdd(mesh.d_x.p, d_xPrev.p, mesh.d_dbc.p, lin, fricDHat, selfFric, projectDBC, lin.d_a.p);
         }
     }
+    if (dampingStiff > 0.0) { // addCoeff(dampingMtr, 1.0), Optimizer.cpp:3707-3709
+        if (dampPatternVersion != lin.patternVersion) assembleDampingMtr();
+        launch_axpy((long long)lin.ja.size(), 1.0, d_damp.p, lin.d_a.p, stream);
+    }
     if (withGradient) penaltyGradientAdd(projectDBC);
     if (!projectDBC && rhoDBC && !tpIds.empty()) launch_mdbc_hessian(mdbc(), lin.d_ia.p, rhoDBC, lin.d_a.p, stream); // :3711-3713
 }
@@ -913,6 +979,7 @@ void HipOptimizer::precompute()
         curExtra.clear();
     }
     computeConstraintSets();
+    computeDampingMtr(); // computePrecondMtr(..., updateDamping): Optimizer.cpp:470, 3598-3612
     {
         Tic t(timers[0], stream);
         computePrecondMtr(true, false); // re-patterns + analyses when contact pairs are already active
@@ -1131,6 +1198,7 @@ void HipOptimizer::endTimestep()
     else
         launch_be_update(mesh.nV, mesh.d_dbc.p, mesh.d_x.p, d_xPrev.p, d_vel.p, d_acc.p, d_dxElastic.p, mesh.d_xTilde.p, dt, gravity[0],
             gravity[1], gravity[2], stream);
+    computeDampingMtr(); // Optimizer.cpp:593-595
     globalIterNum++;
 }
 

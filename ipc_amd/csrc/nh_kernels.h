@@ -84,6 +84,12 @@ struct MdbcView {
     const double* mass; // nV
 };
 void launch_clear_projected(int nV, const int* dbc, int projectDBC, double* g, hipStream_t s);
+// lagged damping (Optimizer.cpp:3381-3400, 3519-3540, 3707-3709): displacement of the step (mode 0: rows of every Dirichlet node
+// cleared, 1: of the projected ones), the diagonal fix-up of the damping matrix, y += alpha x, out = scale * x . y (one workgroup)
+void launch_damp_dx(int nV, const int* dbc, int mode, int projectDBC, const double* x, const double* xPrev, double* dx, hipStream_t s);
+void launch_damp_clear_diag(int nV, const int* dbc, const int* ia, double* d, hipStream_t s);
+void launch_axpy(long long n, double alpha, const double* x, double* y, hipStream_t s);
+void launch_dot_scaled(int n, const double* x, const double* y, double scale, double* out, hipStream_t s);
 void launch_mdbc_reduce(const MdbcView& m, const double* x, double rho, int mode /*0 energy, 1 |x - target|^2*/, double* out, hipStream_t s);
 void launch_mdbc_gradient(const MdbcView& m, const double* x, double rho, double* g, hipStream_t s);
 void launch_mdbc_hessian(const MdbcView& m, const int* ia, double rho, double* a, hipStream_t s);

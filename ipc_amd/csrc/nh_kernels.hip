@@ -496,6 +496,37 @@ __global__ __launch_bounds__(BLOCK) void k_mdbc_reduce(int n, const int* __restr
     const double r = block_sum(acc, sm);
     if (threadIdx.x == 0) out[0] = r;
 }
+// ---- lagged stiffness-proportional damping (Optimizer.cpp:3381-3400, 3519-3540, 3707-3709, 3723-3735) -----------------------
+// displacement of the step with the rows of Dirichlet nodes cleared: mode 0 every Dirichlet node (energy), 1 the projected ones
+__global__ void k_damp_dx(int nV, const int* __restrict__ dbc, int mode, int projectDBC, const double* __restrict__ x, const double* __restrict__ xPrev,
+    double* __restrict__ dx)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * nV) return;
+    const int t = dbc[i / 3];
+    const bool zero = mode == 0 ? t != 0 : projected_dbc(t, projectDBC);
+    dx[i] = zero ? 0.0 : x[i] - xPrev[i];
+}
+// the patch pass writes identity / mass on the diagonal of the rows it owns; the damping matrix carries neither
+__global__ void k_damp_clear_diag(int nV, const int* __restrict__ dbc, const int* __restrict__ ia, double* __restrict__ d)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * nV && projected_dbc(dbc[i / 3], 1)) d[ia[i]] = 0.0; // the diagonal leads every upper-CSR row
+}
+__global__ void k_axpy(long long n, double alpha, const double* __restrict__ x, double* __restrict__ y)
+{
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += alpha * x[i];
+}
+// one workgroup, fixed-order reduction: out = scale * x . y
+__global__ __launch_bounds__(BLOCK) void k_dot_scaled(int n, const double* __restrict__ x, const double* __restrict__ y, double scale, double* __restrict__ out)
+{
+    __shared__ double sm[BLOCK / 64];
+    double acc = 0.0;
+    for (int t = threadIdx.x; t < n; t += BLOCK) acc += x[t] * y[t];
+    const double r = block_sum(acc, sm);
+    if (threadIdx.x == 0) out[0] = scale * r;
+}
 __global__ void k_mdbc_gradient(int n, const int* __restrict__ ids, const double* __restrict__ pos, const double* __restrict__ lam,
     const double* __restrict__ mass, const double* __restrict__ x, double rho, double* __restrict__ g)
 {
@@ -643,6 +674,22 @@ void launch_nbc_gradient(int n, const int* ids, const int* dbc, const double* ma
 void launch_nbc_energy(int n, const int* ids, const int* dbc, const double* mass, const double* x, const double* dtSqA3, double* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_nbc_energy, dim3(1), dim3(BLOCK), 0, s, n, ids, dbc, mass, x, dtSqA3[0], dtSqA3[1], dtSqA3[2], out);
+}
+void launch_damp_dx(int nV, const int* dbc, int mode, int projectDBC, const double* x, const double* xPrev, double* dx, hipStream_t s)
+{
+    if (nV) hipLaunchKernelGGL(k_damp_dx, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, mode, projectDBC, x, xPrev, dx);
+}
+void launch_damp_clear_diag(int nV, const int* dbc, const int* ia, double* d, hipStream_t s)
+{
+    if (nV) hipLaunchKernelGGL(k_damp_clear_diag, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, dbc, ia, d);
+}
+void launch_axpy(long long n, double alpha, const double* x, double* y, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_axpy, dim3(nblk(n)), dim3(BLOCK), 0, s, n, alpha, x, y);
+}
+void launch_dot_scaled(int n, const double* x, const double* y, double scale, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_dot_scaled, dim3(1), dim3(BLOCK), 0, s, n, x, y, scale, out);
 }
 void launch_clear_projected(int nV, const int* dbc, int projectDBC, double* g, hipStream_t s)
 {

@@ -509,6 +509,9 @@ class Context:
     def set_friction(self, self_fric=0.0, fric_iter_amt=1, eps_v=1e-3):
         self._chk(self._L.ipcgpu_opt_set_friction(self.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v)))
 
+    def set_damping(self, damping_stiff):
+        self._chk(self._L.ipcgpu_opt_set_damping(self.h, C.c_double(damping_stiff)))
+
     def set_friction_scales(self, scale_self=1.0, scale_obstacle=1.0):
         self._chk(self._L.ipcgpu_opt_set_friction_scales(self.h, C.c_double(scale_self), C.c_double(scale_obstacle)))
 

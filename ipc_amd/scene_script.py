@@ -66,6 +66,8 @@ class SceneConfig:
     dHat_eps: float = 1e-3  # tuning[1]
     eps_v: float = 1e-3  # tuning[4]
     fric_iter_amt: int = 1
+    damping_stiff: float = 0.0  # Config.cpp:141-147; `dampingRatio r` becomes r * dt^3 * 3 / 4 once the file is read (:614-616)
+    damping_ratio: float = 0.0
     tol: float = 1e-2
     script: str = "null"
     size: float = -1.0  # > 0: the assembled model is scaled so that its largest extent is `size` and moved to the origin (main.cpp:1140-1145)
@@ -230,10 +232,16 @@ class SceneConfig:
                 cfg.restart = resolve(a[0])
             elif k == "size":  # Config.cpp: `size s`; applied to the whole model after the shapes are assembled (main.cpp:1140-1145)
                 cfg.size = float(a[0])
+            elif k == "dampingStiff":  # Config.cpp:141-147
+                cfg.damping_stiff = max(float(a[0]), 0.0)
+            elif k == "dampingRatio":  # Config.cpp:148-157
+                cfg.damping_ratio = min(max(float(a[0]), 0.0), 1.0)
             elif k in VIEWER_KEYWORDS:
                 pass  # viewer / logging only
             else:
                 raise UnsupportedKeyword(k)
+        if cfg.damping_ratio > 0:  # Config.cpp:614-616
+            cfg.damping_stiff = cfg.damping_ratio * cfg.dt ** 3 * 3 / 4
         return cfg
 
 
@@ -483,6 +491,8 @@ def apply(sc, be):
         be.set_friction(self_fric, cfg.fric_iter_amt, cfg.eps_v)
         if sc.obstacle_nodes is not None and fric_scales is not None:
             be.set_friction_scales(*fric_scales)
+    if cfg.damping_stiff > 0:
+        be.set_damping(cfg.damping_stiff)
     for ids, lin, ang, t0, t1 in sc.dirichlet:
         be.add_dirichlet(ids, lin_vel=lin, ang_vel_deg=ang, t0=t0, t1=t1)
     for ids, acc, t0, t1 in sc.neumann:

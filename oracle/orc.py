@@ -270,6 +270,9 @@ class Optimizer:
     def set_rel_tol(self, tol):
         lib().orc_opt_set_rel_tol(self.h, C.c_double(tol))
 
+    def set_damping(self, damping_stiff):
+        lib().orc_opt_set_damping(self.h, C.c_double(damping_stiff))
+
     def precompute(self):
         if lib().orc_opt_precompute(self.h) != 0:
             raise RuntimeError("intersection detected in initial configuration")

@@ -90,6 +90,7 @@ void orc_opt_destroy(orc_opt*);
 void orc_opt_set_twist(orc_opt*, int nL, const int* left, int nR, const int* right, double angVel); // AnimScripter.cpp:555-572
 void orc_opt_set_friction_scales(orc_opt*, double scaleSelf, double scaleObstacle); // MeshCO::friction beside selfFric
 void orc_opt_set_rel_tol(orc_opt*, double relTol); // Optimizer.cpp:390-396
+void orc_opt_set_damping(orc_opt*, double dampingStiff); /* Config.cpp:141-147, 614-616; before precompute */
 int orc_opt_precompute(orc_opt*); /* -1: the initial configuration intersects (the reference exits, Optimizer.cpp:258-263) */
 // one pass of the solveSub_IP loop body; returns 1 if the time step converged before doing work
 int orc_opt_newton_iter(orc_opt*);

@@ -56,6 +56,7 @@ double elasticEnergy(const Mesh& m, double coef, double* perElem);
 void elasticGradient(const Mesh& m, double coef, bool projectDBC, double* grad);
 void elemHessian(const Mesh& m, int t, double coef, bool projectSPD, double H[144]);
 void assembleHessian(const Mesh& m, double coef, bool projectDBC, double* a);
+void addBlockToMatrix(const Mesh& m, double* a, const double* H12 /*12x12 col-major*/, const int vInd[4], int rowIndI);
 void inversionStep(const Mesh& m, const double* p, double slackness, double* out);
 double filterStepSize(const Mesh& m, const double* p, double stepSize); // Energy.cpp:565-581
 

@@ -30,6 +30,11 @@ struct orc_opt {
     int nthreads;
     double relGL2Tol = 1.0e-8, targetGRes = 0;
     std::vector<double> velocity, xTilta, V_prev, searchDir, gradient, a;
+    // lagged stiffness-proportional damping (Optimizer.cpp:3723-3735): the projected element Hessians at the state the last time
+    // step ended in, times dampingStiff / dt, rows and columns of Dirichlet nodes dropped
+    double dampingStiff = 0.0;
+    std::vector<double> dampH;
+    std::vector<int> dampInd;
     std::map<int, double> angVel; // twist handles
     // Mesh::DirichletBCs (Mesh.hpp:23-39): `DBC bboxMin bboxMax linVel angVel [t0 t1]` of a shape line (Config.cpp:246-263), and
     // the scripted linear / angular velocity of whole components (componentLVels / componentAVels, AnimScripter.cpp:1413-1435)
@@ -138,6 +143,50 @@ void computeXTilta(orc_opt* o)
 }
 
 // Optimizer.cpp:3199-3353 (elasticity + inertia + barrier)
+// computeDampingMtr (Optimizer.cpp:3723-3735): kept per element here (the reference keeps the same numbers summed into a second
+// LinSysSolver; the products below differ from its CSR product by the order of the additions only)
+void computeDampingMtr(orc_opt* o)
+{
+    if (!(o->dampingStiff > 0.0)) return;
+    const Mesh& m = *o->m;
+    o->dampH.assign(144 * (size_t)m.nT, 0.0);
+    o->dampInd.assign(4 * (size_t)m.nT, 0);
+#pragma omp parallel for schedule(static)
+    for (int t = 0; t < m.nT; ++t) {
+        elemHessian(m, t, o->dampingStiff / o->dt, true, &o->dampH[144 * (size_t)t]);
+        for (int k = 0; k < 4; ++k) {
+            const int v = m.Fi(t, k);
+            o->dampInd[4 * (size_t)t + k] = m.isProjectDBC(v, true) ? (-v - 1) : v; // projectDBC = true (Optimizer.hpp:273)
+        }
+    }
+}
+// y_e = D_e dx_e over the nodes that took part when D was built; dx = V - V_prev, zero where `skip` says so
+template <class Skip>
+static void dampingProduct(const orc_opt* o, Skip skip, double* y /* 3 nV, added to */, double* quad)
+{
+    const Mesh& m = *o->m;
+    double q = 0.0;
+    for (int t = 0; t < m.nT; ++t) {
+        const double* H = &o->dampH[144 * (size_t)t];
+        const int* ind = &o->dampInd[4 * (size_t)t];
+        double dx[12];
+        for (int k = 0; k < 4; ++k) {
+            const int v = m.Fi(t, k);
+            for (int c = 0; c < 3; ++c) dx[3 * k + c] = (ind[k] < 0 || skip(v)) ? 0.0 : m.V[v + m.nV * c] - o->V_prev[v + m.nV * c];
+        }
+        for (int k = 0; k < 4; ++k) {
+            if (ind[k] < 0) continue;
+            for (int i = 0; i < 3; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < 12; ++j) s += H[(3 * k + i) + 12 * j] * dx[j];
+                if (y) y[3 * ind[k] + i] += s;
+                q += dx[3 * k + i] * s;
+            }
+        }
+    }
+    if (quad) *quad = q;
+}
+
 double computeEnergyVal(orc_opt* o)
 {
     Mesh& m = *o->m;
@@ -168,6 +217,11 @@ double computeEnergyVal(orc_opt* o)
                 E += hsFrictionEnergy(m, o->V_prev.data(), o->planes[i], o->hsLagSet[i], o->hsLambda[i], o->hsFric[i], o->fricDHat);
         if (o->selfCollision && o->selfFric > 0.0 && !o->lag.set.empty())
             E += frictionEnergy(m, o->V_prev.data(), o->lag, o->fricDHat, o->selfFric);
+    }
+    if (o->dampingStiff > 0.0) { // Optimizer.cpp:3381-3400: displacement of the step, zero on every Dirichlet node
+        double q = 0.0;
+        dampingProduct(o, [&](int v) { return m.isDBC(v); }, nullptr, &q);
+        E += 0.5 * q;
     }
     if (o->rhoDBC) { // augmentMDBCEnergy (AnimScripter.cpp:2303-2311; Optimizer.cpp:3402-3404)
         for (size_t t = 0; t < o->tpIds.size(); ++t) {
@@ -219,6 +273,8 @@ void computeGradient(orc_opt* o, bool projectDBC)
     for (int v = 0; v < m.nV; ++v)
         if (m.isDBC(v) && m.isProjectDBC(v, projectDBC))
             for (int c = 0; c < 3; ++c) o->gradient[3 * v + c] = 0; // :3512-3516
+    if (o->dampingStiff > 0.0) // :3519-3540
+        dampingProduct(o, [&](int v) { return m.isDBC(v) && m.isProjectDBC(v, projectDBC); }, o->gradient.data(), nullptr);
     if (!projectDBC && o->rhoDBC) // augmentMDBCGradient (AnimScripter.cpp:2313-2321; Optimizer.cpp:3542-3544)
         for (size_t t = 0; t < o->tpIds.size(); ++t) {
             const int v = o->tpIds[t];
@@ -272,6 +328,17 @@ void computePrecondMtr(orc_opt* o, bool projectDBC)
                 hsFrictionHessian(m, o->V_prev.data(), o->planes[i], o->hsLagSet[i], o->hsLambda[i], o->hsFric[i], o->fricDHat, projectDBC, o->a.data());
         if (o->selfCollision && o->selfFric > 0.0 && !o->lag.set.empty())
             frictionHessian(m, o->V_prev.data(), o->lag, o->fricDHat, o->selfFric, projectDBC, o->a.data());
+    }
+    if (o->dampingStiff > 0.0) { // addCoeff(dampingMtr, 1.0), Optimizer.cpp:3707-3709
+        std::vector<int> ind(4);
+        for (int t = 0; t < m.nT; ++t) {
+            for (int k = 0; k < 4; ++k) {
+                const int v = m.Fi(t, k);
+                ind[k] = (o->dampInd[4 * (size_t)t + k] < 0 || m.isProjectDBC(v, projectDBC)) ? (-v - 1) : v;
+            }
+            for (int k = 0; k < 4; ++k)
+                if (ind[k] >= 0) addBlockToMatrix(m, o->a.data(), &o->dampH[144 * (size_t)t], ind.data(), k);
+        }
     }
     if (!projectDBC && o->rhoDBC) // augmentMDBCHessian (AnimScripter.cpp:2323-2337; Optimizer.cpp:3711-3713)
         for (int v : o->tpIds)
@@ -348,6 +415,8 @@ void initKappa(orc_opt* o)
     if (!o->nConstraints()) return;
     std::vector<double> gE(3 * m.nV), gc(3 * m.nV, 0.0);
     elasticInertiaGradient(o, true, gE.data());
+    if (o->dampingStiff > 0.0) // computeGradient with solveIP off still adds the damping force (Optimizer.cpp:3519-3540)
+        dampingProduct(o, [&](int v) { return o->m->isDBC(v); }, gE.data(), nullptr);
     for (size_t i = 0; i < o->planes.size(); ++i) hsGradient(m, o->planes[i], o->hsSet[i], o->dHat, 1.0, gc.data());
     if (o->selfCollision) {
         ContactSets only;
@@ -668,6 +737,7 @@ int orc_opt_precompute(orc_opt* o)
     if (anyIntersection(o)) return -1;
     // Optimizer.cpp:457-507: set_pattern, constraint sets, computePrecondMtr(redoSVD), analyze_pattern, initial energy
     computeConstraintSets(o);
+    computeDampingMtr(o); // computePrecondMtr(..., updateDamping = dampingStiff): Optimizer.cpp:470, 3598-3612
     computePrecondMtr(o, true);
     o->lastEnergyVal = computeEnergyVal(o);
     return 0;
@@ -960,6 +1030,7 @@ void orc_opt_end_timestep(orc_opt* o)
             }
     o->V_prev = m.V;
     computeXTilta(o);
+    computeDampingMtr(o); // Optimizer.cpp:593-595
     o->globalIterNum++;
 }
 
@@ -999,6 +1070,7 @@ int orc_opt_next_subproblem(orc_opt* o)
     return 1;
 }
 
+void orc_opt_set_damping(orc_opt* o, double dampingStiff) { o->dampingStiff = dampingStiff > 0.0 ? dampingStiff : 0.0; } // Config.cpp:141-147
 void orc_opt_set_friction_scales(orc_opt* o, double scaleSelf, double scaleObstacle)
 {
     o->fricScaleSelf = scaleSelf;

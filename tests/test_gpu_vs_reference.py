@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import GOLD, MORE_SCENES, check_scene, load_scene, rel, run_scene
+from test_oracle_vs_reference import GOLD, MORE_SCENES, check_damped_bar, check_scene, load_scene, rel, run_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -183,6 +183,16 @@ def test_scene_two_cubes_fall_against_the_reference(gpu_lib):
     assert len(differ) <= 8, (its.tolist(), S["iters"].tolist())
     assert abs(int(its.sum()) - int(S["iters"].sum())) <= 0.12 * int(S["iters"].sum()), (its.tolist(), S["iters"].tolist())
     assert np.abs(pos[-1] - S["positions"][-1]).max() <= 1e-2 * np.abs(S["positions"][-1]).max()
+    c.close()
+
+
+def test_damped_bar_twist_against_the_reference(gpu_lib):
+    """barTwist_noCollisions.txt + `dampingRatio 0.5` at `tol 1e-6` run by the reference itself: lagged stiffness-proportional damping in
+    energy, gradient and Hessian (ipcgpu_opt_set_damping).  The same criteria as for the CPU restatement."""
+    S, meshes = load_scene("bar_twist_damped")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, 6)
+    check_damped_bar(S, pos, its)
     c.close()
 
 

@@ -159,6 +159,9 @@ class OracleBackend:
     def add_half_space(self, o, n, e):
         return self.orc.opt_add_half_space(self.o, o, n, e)
 
+    def set_damping(self, stiff):
+        self.o.set_damping(stiff)
+
     def set_friction_scales(self, a, b):
         self.orc.opt_set_friction_scales(self.o, a, b)
 

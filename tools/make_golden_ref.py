@@ -179,6 +179,10 @@ SCENES = [
     # the same with friction between the cubes: the pairs that involve the mesh collision object carry none (its coefficient only
     # switches the lagging loop on in the reference), the cube-cube pairs carry selfFric
     ("aligned_cubes_fric", "paperExamples/supplementB/SQPBenchmark/12_alignedCubes.txt", "\nselfFric 0.3\n", 40),
+    # lagged stiffness-proportional damping (dampingRatio): the twisting bar solved to its minimisers, and the reference's own
+    # Newmark + damping tutorial scene
+    ("bar_twist_damped", "otherExamples/barTwist_noCollisions.txt", "\ndampingRatio 0.5\ntol 1\n1e-6\n", 6),
+    ("two_cubes_nm_damped", "tutorialExamples/advanced/2cubesFall_NM.txt", "\ntime 5 0.025\n", 30),  # every step written at this step size
 ]
 
 
