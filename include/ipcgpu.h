@@ -256,6 +256,14 @@ int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx*, int id, double mu); /* Colli
  * (Optimizer.cpp:593-595, 3723-3735); 1/2 dx^T D dx joins the energy (:3381-3400), D dx the gradient (:3519-3540), D the Hessian
  * (:3707-3709).  Call before ipcgpu_opt_precompute; 0 switches it off. */
 int ipcgpu_opt_set_damping(ipcgpu_ctx*, double dampingStiff);
+/* `tuning` entry 0 (Config.cpp:41-45, 533-541): the barrier stiffness every time step starts from, bounded from above by
+ * upperBoundKappa and still raised by initKappa / the adaptive updates (Optimizer.cpp:1540-1550, 2216-2225); 0 = suggestKappa. */
+int ipcgpu_opt_set_kappa(ipcgpu_ctx*, double kappa);
+/* `tuning` entry 2 (relative, like dHat): the dHat homotopy of fullyImplicit_IP.  Every time step starts at dHat; after a converged
+ * sub-problem whose largest active distance is not below the target, ipcgpu_opt_next_subproblem halves dHat (not below the
+ * target), rebuilds the constraint sets and re-initialises kappa (Optimizer.cpp:283-289, 1706-1713, 1763-1774).  <= 0: target =
+ * dHat, no homotopy (the default, and what `dHat x` / a 6-entry `tuning` with equal entries 1 and 2 mean). */
+int ipcgpu_opt_set_dhat_target(ipcgpu_ctx*, double dHatTargetEps);
 /* After ipcgpu_opt_newton_iter reported convergence: the tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790) --
  * refresh the lagged multipliers / tangent bases, test tangent-space convergence.  *more = 1: another solveSub_IP pass has
  * started (keep calling newton_iter); 0: the time step is done.  Without friction it returns 0 and changes nothing. */

@@ -999,6 +999,22 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx* c, double selfFric, int fricIterAmt, dou
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_kappa(ipcgpu_ctx* c, double kappa)
+{
+    return guarded([&] {
+        needArg(kappa >= 0.0, "negative barrier stiffness");
+        O(c).kappaConfig = kappa;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_dhat_target(ipcgpu_ctx* c, double dHatTargetEps)
+{
+    return guarded([&] {
+        needArg(dHatTargetEps == dHatTargetEps, "dHat target is not a number");
+        O(c).dHatTargetEps = dHatTargetEps;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_damping(ipcgpu_ctx* c, double dampingStiff)
 {
     return guarded([&] {

@@ -124,6 +124,8 @@ public:
     // lagged stiffness-proportional damping (Optimizer.cpp:3381-3400, 3519-3540, 3707-3709, 3723-3735; Config.cpp:141-157, 614-616):
     // D = projected elastic Hessian at the state the last time step ended in, times dampingStiff / dt, on the solver's pattern
     double dampingStiff = 0.0;
+    double dHatTargetEps = -1.0; // tuning[2] (Optimizer.cpp:283-289): every time step starts at dHat and halves it down to this; < 0: no homotopy
+    double kappaConfig = 0.0; // tuning[0] (Config.cpp:41-45): the barrier stiffness a time step starts from, 0 = suggestKappa
     void setDamping(double stiff);
     void computeDampingMtr(); // at the current positions (precompute, end of a time step)
     void assembleDampingMtr(); // (re)builds the values at the remembered positions on the current pattern

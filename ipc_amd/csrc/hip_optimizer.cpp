@@ -357,13 +357,38 @@ void HipOptimizer::updateFrictionLag()
 
 bool HipOptimizer::nextSubproblem()
 {
-    // Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS, HOMOTOPY_VAR 1 and dHat already at its target
-    if (!ipOn() || !solveFric()) return false;
+    // tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS, HOMOTOPY_VAR 1)
+    if (!ipOn()) return false;
+    const double dHatTarget = dHatTargetEps > 0.0 ? dHatTargetEps * dHatTargetEps * mesh.bboxDiag2 : dHat;
+    const bool fric = solveFric(), homotopy = dHat > dHatTarget;
+    if (!fric && !homotopy) return false; // every active distance is below dHat = dHatTarget: nothing left to update (:1706-1709, 1754-1757)
     fricIterI++;
-    updateFrictionLag();
+    if (fric) updateFrictionLag();
     if (!nConstraints()) return false; // "no collision in this time step"
-    bool updateFricDHat = true;
-    if (fricDHat <= fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45, 547-548)
+    bool updateDHat = true;
+    { // discrete complementarity slackness on the distances of the active sets (:1706-1713); once per sub-problem, on the host
+        double dMax = 0.0, dMin = 1.0e300;
+        std::vector<double> d;
+        for (auto& h : planes) {
+            h->evalDist2(h->set, mesh.d_x.p, d);
+            for (size_t i = 0; i < h->set.size(); ++i) {
+                dMax = std::max(dMax, d[i]);
+                dMin = std::min(dMin, d[i]);
+            }
+        }
+        if (selfCollision) {
+            std::vector<std::array<int, 4>> ids;
+            contact->closeStencils(mesh.d_x.p, 1.0e300, ids, d);
+            for (size_t i = 0; i < ids.size(); ++i) {
+                dMax = std::max(dMax, d[i]);
+                dMin = std::min(dMin, d[i]);
+            }
+        }
+        if (dMax < dHatTarget) updateDHat = false;
+        else if (dMin < dTol) return false; // "tiny distance fail-safe"
+    }
+    bool updateFricDHat = fric;
+    if (fric && fricDHat <= fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45, 547-548)
         // tangent-space convergence test: one Newton direction with the refreshed lag (:1717-1731)
         computePrecondMtr(true, true);
         computeSearchDir(true);
@@ -372,8 +397,13 @@ bool HipOptimizer::nextSubproblem()
         if (readScalar(d_scalar.p + 3) < targetGRes) updateFricDHat = false;
         if (fricIterAmt > 0 && fricIterI >= fricIterAmt) updateFricDHat = false;
     }
-    if (!updateFricDHat) return false;
-    if (fricDHat > 0.0) fricDHat = std::max(0.5 * fricDHat, fricDHat0); // :1776-1781
+    if (!updateDHat && !updateFricDHat) return false;
+    if (updateDHat) { // :1763-1774
+        dHat = std::max(0.5 * dHat, dHatTarget);
+        computeConstraintSets();
+        initKappa();
+    }
+    if (updateFricDHat && fricDHat > 0.0) fricDHat = std::max(0.5 * fricDHat, fricDHat0); // :1776-1781
     initSubProblem(); // the next solveSub_IP starts with m_projectDBC = true, rho_DBC = 0 (Optimizer.cpp:1826-1828)
     closeID.clear(); // initSubProb_IP
     closeVal.clear();
@@ -1054,7 +1084,8 @@ void HipOptimizer::beginTimestep()
         // fullyImplicit_IP head (Optimizer.cpp:1534-1550, 2316-2322): dHat, constraint sets, kappa, empty close-pair list
         dHat = dHatEps * dHatEps * mesh.bboxDiag2;
         computeConstraintSets();
-        kappa = kappaFloor();
+        // tuning[0] when the script gives one, bounded from above; 0 -> suggestKappa (Optimizer.cpp:1540-1547)
+        kappa = kappaConfig > 0.0 ? std::min(kappaConfig, 100 * kappaFloor()) : kappaFloor();
         initKappa();
         closeHS.clear();
         closeHSVal.clear();

@@ -509,6 +509,12 @@ class Context:
     def set_friction(self, self_fric=0.0, fric_iter_amt=1, eps_v=1e-3):
         self._chk(self._L.ipcgpu_opt_set_friction(self.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v)))
 
+    def set_kappa(self, kappa):
+        self._chk(self._L.ipcgpu_opt_set_kappa(self.h, C.c_double(kappa)))
+
+    def set_dhat_target(self, eps):
+        self._chk(self._L.ipcgpu_opt_set_dhat_target(self.h, C.c_double(eps)))
+
     def set_damping(self, damping_stiff):
         self._chk(self._L.ipcgpu_opt_set_damping(self.h, C.c_double(damping_stiff)))
 

@@ -66,6 +66,8 @@ class SceneConfig:
     dHat_eps: float = 1e-3  # tuning[1]
     eps_v: float = 1e-3  # tuning[4]
     fric_iter_amt: int = 1
+    kappa: float = 0.0  # tuning[0]; 0 = suggestKappa
+    dHat_target: float = -1.0  # tuning[2]; < 0: the same as dHat (no homotopy)
     damping_stiff: float = 0.0  # Config.cpp:141-147; `dampingRatio r` becomes r * dt^3 * 3 / 4 once the file is read (:614-616)
     damping_ratio: float = 0.0
     tol: float = 1e-2
@@ -191,8 +193,8 @@ class SceneConfig:
                 cfg.self_collision = False
             elif k == "selfFric":
                 cfg.self_fric = float(a[0])
-            elif k == "dHat":
-                cfg.dHat_eps = float(a[0])
+            elif k == "dHat":  # Config.cpp:542-545: entries 1 and 2 of `tuning`
+                cfg.dHat_eps = cfg.dHat_target = float(a[0])
             elif k == "epsv":
                 cfg.eps_v = float(a[0])
             elif k == "fricIterAmt":
@@ -209,12 +211,12 @@ class SceneConfig:
                 while len(vals) < int(a[0]):
                     vals += [float(x) for x in lines[i].split()]
                     i += 1
-                if len(vals) > 0 and vals[0] != 0:
-                    raise UnsupportedKeyword("tuning with a fixed kappa")
+                if len(vals) > 0:
+                    cfg.kappa = max(vals[0], 0.0)  # the start value of every time step (Optimizer.cpp:1540-1547)
                 if len(vals) > 1:
                     cfg.dHat_eps = vals[1]
-                if len(vals) > 2 and vals[2] != vals[1]:
-                    raise UnsupportedKeyword("tuning with a dHat homotopy")
+                if len(vals) > 1:  # Optimizer.cpp:283-289: without a third entry the target is 1e-3 (relative)
+                    cfg.dHat_target = vals[2] if len(vals) > 2 else 1e-3
                 if len(vals) > 4:
                     cfg.eps_v = vals[4]
             elif k == "section":  # Config.cpp:572-605: settings for one constraint solver; other solvers' sections are skipped
@@ -491,6 +493,10 @@ def apply(sc, be):
         be.set_friction(self_fric, cfg.fric_iter_amt, cfg.eps_v)
         if sc.obstacle_nodes is not None and fric_scales is not None:
             be.set_friction_scales(*fric_scales)
+    if cfg.kappa > 0:
+        be.set_kappa(cfg.kappa)
+    if 0 < cfg.dHat_target < cfg.dHat_eps:
+        be.set_dhat_target(cfg.dHat_target)
     if cfg.damping_stiff > 0:
         be.set_damping(cfg.damping_stiff)
     for ids, lin, ang, t0, t1 in sc.dirichlet:

@@ -270,6 +270,12 @@ class Optimizer:
     def set_rel_tol(self, tol):
         lib().orc_opt_set_rel_tol(self.h, C.c_double(tol))
 
+    def set_kappa(self, kappa):
+        lib().orc_opt_set_kappa(self.h, C.c_double(kappa))
+
+    def set_dhat_target(self, eps):
+        lib().orc_opt_set_dhat_target(self.h, C.c_double(eps))
+
     def set_damping(self, damping_stiff):
         lib().orc_opt_set_damping(self.h, C.c_double(damping_stiff))
 

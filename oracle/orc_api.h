@@ -90,6 +90,8 @@ void orc_opt_destroy(orc_opt*);
 void orc_opt_set_twist(orc_opt*, int nL, const int* left, int nR, const int* right, double angVel); // AnimScripter.cpp:555-572
 void orc_opt_set_friction_scales(orc_opt*, double scaleSelf, double scaleObstacle); // MeshCO::friction beside selfFric
 void orc_opt_set_rel_tol(orc_opt*, double relTol); // Optimizer.cpp:390-396
+void orc_opt_set_kappa(orc_opt*, double kappa); /* tuning[0]: start value of the barrier stiffness in every time step (Optimizer.cpp:1540-1547) */
+void orc_opt_set_dhat_target(orc_opt*, double dHatTargetEps); /* tuning[2]: the dHat homotopy of fullyImplicit_IP (Optimizer.cpp:283-289, 1706-1713, 1763-1774) */
 void orc_opt_set_damping(orc_opt*, double dampingStiff); /* Config.cpp:141-147, 614-616; before precompute */
 int orc_opt_precompute(orc_opt*); /* -1: the initial configuration intersects (the reference exits, Optimizer.cpp:258-263) */
 // one pass of the solveSub_IP loop body; returns 1 if the time step converged before doing work

@@ -33,6 +33,8 @@ struct orc_opt {
     // lagged stiffness-proportional damping (Optimizer.cpp:3723-3735): the projected element Hessians at the state the last time
     // step ended in, times dampingStiff / dt, rows and columns of Dirichlet nodes dropped
     double dampingStiff = 0.0;
+    double dHatTargetEps = -1.0; // tuning[2] (Optimizer.cpp:283-289): every time step starts at dHat and halves it down to this; < 0: no homotopy
+    double kappaConfig = 0.0; // tuning[0] (Config.cpp:41-45): the stiffness a time step starts from, 0 = suggestKappa
     std::vector<double> dampH;
     std::vector<int> dampInd;
     std::map<int, double> angVel; // twist handles
@@ -857,7 +859,8 @@ void orc_opt_begin_timestep(orc_opt* o)
     if (o->ipOn()) {
         o->dHat = o->dHatEps * o->dHatEps * m.bboxDiag2;
         computeConstraintSets(o);
-        o->kappa = kappaFloor(o); // kappa = 0 -> suggestKappa (:1540-1547)
+        // tuning[0] when the script gives one, bounded from above; 0 -> suggestKappa (Optimizer.cpp:1540-1547)
+        o->kappa = o->kappaConfig > 0.0 ? std::min(o->kappaConfig, 100 * kappaFloor(o)) : kappaFloor(o);
         initKappa(o); // ADAPTIVE_KAPPA (:1548-1550)
         o->closeID.clear(); // initSubProb_IP (:2316-2322)
         o->closeVal.clear();
@@ -1038,13 +1041,35 @@ void orc_opt_end_timestep(orc_opt* o)
 // HOMOTOPY_VAR 1, dHat already at its target).  Returns 1 when another solveSub_IP pass has to run (friction lagging).
 int orc_opt_next_subproblem(orc_opt* o)
 {
-    if (!o->ipOn() || !o->solveFric()) return 0;
+    // tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS, HOMOTOPY_VAR 1)
+    if (!o->ipOn()) return 0;
     Mesh& m = *o->m;
+    const double dHatTarget = o->dHatTargetEps > 0.0 ? o->dHatTargetEps * o->dHatTargetEps * m.bboxDiag2 : o->dHat;
+    const bool fric = o->solveFric(), homotopy = o->dHat > dHatTarget;
+    if (!fric && !homotopy) return 0; // every active distance is below dHat = dHatTarget: nothing left to update (:1706-1709, 1754-1757)
     o->fricIterI++;
-    updateFrictionLag(o);
+    if (fric) updateFrictionLag(o);
     if (!o->nConstraints()) return 0; // "no collision in this time step"
-    bool updateFricDHat = true;
-    if (o->fricDHat <= o->fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45,547-548)
+    bool updateDHat = true;
+    { // discrete complementarity slackness on the distances of the active sets (:1706-1713)
+        double dMax = 0.0, dMin = 1.0e300;
+        for (size_t i = 0; i < o->planes.size(); ++i)
+            for (int v : o->hsSet[i]) {
+                const double d = o->planes[i].dist(m, v);
+                dMax = std::max(dMax, d * d);
+                dMin = std::min(dMin, d * d);
+            }
+        if (o->selfCollision)
+            for (const auto& c : o->cs.active) {
+                const double d2 = evalMMCVID(m, c);
+                dMax = std::max(dMax, d2);
+                dMin = std::min(dMin, d2);
+            }
+        if (dMax < dHatTarget) updateDHat = false;
+        else if (dMin < o->dTol) return 0; // "tiny distance fail-safe"
+    }
+    bool updateFricDHat = fric;
+    if (fric && o->fricDHat <= o->fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45,547-548)
         // tangent-space convergence test: one Newton direction with the refreshed lag (:1717-1731)
         computeGradient(o, true);
         computePrecondMtr(o, true);
@@ -1059,8 +1084,13 @@ int orc_opt_next_subproblem(orc_opt* o)
         if (pMax < o->targetGRes) updateFricDHat = false;
         if (o->fricIterAmt > 0 && o->fricIterI >= o->fricIterAmt) updateFricDHat = false;
     }
-    if (!updateFricDHat) return 0;
-    if (o->fricDHat > 0.0) o->fricDHat = std::max(0.5 * o->fricDHat, o->fricDHat0); // :1776-1781
+    if (!updateDHat && !updateFricDHat) return 0;
+    if (updateDHat) { // :1763-1774
+        o->dHat = std::max(0.5 * o->dHat, dHatTarget);
+        computeConstraintSets(o);
+        initKappa(o);
+    }
+    if (updateFricDHat && o->fricDHat > 0.0) o->fricDHat = std::max(0.5 * o->fricDHat, o->fricDHat0); // :1776-1781
     o->closeID.clear(); // initSubProb_IP
     o->closeVal.clear();
     o->closeHS.clear();
@@ -1070,6 +1100,8 @@ int orc_opt_next_subproblem(orc_opt* o)
     return 1;
 }
 
+void orc_opt_set_dhat_target(orc_opt* o, double dHatTargetEps) { o->dHatTargetEps = dHatTargetEps; }
+void orc_opt_set_kappa(orc_opt* o, double kappa) { o->kappaConfig = kappa > 0.0 ? kappa : 0.0; }
 void orc_opt_set_damping(orc_opt* o, double dampingStiff) { o->dampingStiff = dampingStiff > 0.0 ? dampingStiff : 0.0; } // Config.cpp:141-147
 void orc_opt_set_friction_scales(orc_opt* o, double scaleSelf, double scaleObstacle)
 {

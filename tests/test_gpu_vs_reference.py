@@ -209,6 +209,7 @@ def test_more_scenes_against_the_reference(name, exact, mism, tol, gpu_lib):
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     ref_its = S["iters"][:len(its)]
     report = (its.tolist(), ref_its.tolist())
-    check_scene(S, pos, its, exact, len(its), 10 * tol)
+    # (1e-9 before the touch-down: the homotopy scene solves barrier problems at a dHat of half the scene from its first step on)
+    check_scene(S, pos, its, exact, len(its), 10 * tol, exact_tol=1e-9)
     assert abs(int(its.sum()) - int(ref_its.sum())) <= 0.25 * int(ref_its.sum()), report
     c.close()

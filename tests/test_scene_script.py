@@ -113,7 +113,7 @@ def test_reference_scene_files_parse():
     print(len(ok), "scene files map onto the C ABI;", unsupported)
     for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
         assert need in ok, need
-    assert len(ok) >= 105  # the rest needs segment / point shapes, other scripted motions, other solvers or damping
+    assert len(ok) >= 111  # the rest needs segment / point shapes, other scripted motions or other solvers
 
 
 class OracleBackend:
@@ -158,6 +158,12 @@ class OracleBackend:
 
     def add_half_space(self, o, n, e):
         return self.orc.opt_add_half_space(self.o, o, n, e)
+
+    def set_kappa(self, kappa):
+        self.o.set_kappa(kappa)
+
+    def set_dhat_target(self, eps):
+        self.o.set_dhat_target(eps)
 
     def set_damping(self, stiff):
         self.o.set_damping(stiff)

@@ -182,6 +182,9 @@ SCENES = [
     # lagged stiffness-proportional damping (dampingRatio): the twisting bar solved to its minimisers, and the reference's own
     # Newmark + damping tutorial scene
     ("bar_twist_damped", "otherExamples/barTwist_noCollisions.txt", "\ndampingRatio 0.5\ntol 1\n1e-6\n", 6),
+    # `tuning 2`: a start value for kappa and the dHat homotopy of fullyImplicit_IP (dHat 0.5 of the diagonal halved down to 1e-3 in
+    # every time step), FCR, `size`, `script fall`, a mesh collision object
+    ("cubes_dhat_homotopy", "paperExamples/supplementB/SQPBenchmark/11_cubes.txt", "", 20),
     ("two_cubes_nm_damped", "tutorialExamples/advanced/2cubesFall_NM.txt", "\ntime 5 0.025\n", 30),  # every step written at this step size
 ]
 
