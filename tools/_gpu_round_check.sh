@@ -1,6 +1,10 @@
+cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
-timeout 300 python -m pytest tests -m gpu -q -rf --tb=short --maxfail=15 -p no:cacheprovider > gpurun_out/r02f_gpu_tests.txt 2>&1
-echo "rc=$?" >> gpurun_out/r02f_gpu_tests.txt
-tail -8 gpurun_out/r02f_gpu_tests.txt
-timeout 60 python tools/_gpu_diag.py > gpurun_out/r02f_scene_counts.txt 2>&1
-tail -8 gpurun_out/r02f_scene_counts.txt | cut -c1-250
+tag=r02f
+export TMPDIR=/tmp
+rm -rf /tmp/prof_$tag
+( cd /tmp && timeout 70 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o run -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/${tag}_bench_line_under_rocprof.json 2> /dev/null )
+db=$(find /tmp/prof_$tag -name "*.db" | head -1)
+[ -n "$db" ] && python tools/rocprof_summary.py $db gpurun_out/${tag}_kernel_stats.md > /dev/null
+head -12 gpurun_out/${tag}_kernel_stats.md
+head -c 400 gpurun_out/${tag}_bench_line_under_rocprof.json
