@@ -66,6 +66,8 @@ class SceneConfig:
     dHat_eps: float = 1e-3  # tuning[1]
     eps_v: float = 1e-3  # tuning[4]
     fric_iter_amt: int = 1
+    rot_axis: tuple = (0.0, 0.0, 0.0)  # rotateModel ax ay az deg (Config.cpp:523-526)
+    rot_deg: float = 0.0
     kappa: float = 0.0  # tuning[0]; 0 = suggestKappa
     dHat_target: float = -1.0  # tuning[2]; < 0: the same as dHat (no homotopy)
     damping_stiff: float = 0.0  # Config.cpp:141-147; `dampingRatio r` becomes r * dt^3 * 3 / 4 once the file is read (:614-616)
@@ -234,6 +236,8 @@ class SceneConfig:
                 cfg.restart = resolve(a[0])
             elif k == "size":  # Config.cpp: `size s`; applied to the whole model after the shapes are assembled (main.cpp:1140-1145)
                 cfg.size = float(a[0])
+            elif k == "rotateModel":  # Config.cpp:523-526
+                cfg.rot_axis, cfg.rot_deg = tuple(float(x) for x in a[:3]), float(a[3])
             elif k == "dampingStiff":  # Config.cpp:141-147
                 cfg.damping_stiff = max(float(a[0]), 0.0)
             elif k == "dampingRatio":  # Config.cpp:148-157
@@ -334,6 +338,7 @@ class AssembledScene:
     codim_nodes: np.ndarray = None  # surface-only nodes of the mesh itself (triangle meshes under `shapes`, componentCoDim 2) ...
     codim_mass: np.ndarray = None  # ... and their lumped masses (density x a third of the adjacent triangle areas, Mesh.cpp:310-345)
     codim_fixed: np.ndarray = None  # `script DCOFix`: those of them held as NONZERO Dirichlet nodes (AnimScripter.cpp:1222-1236)
+    V0: np.ndarray = None  # start positions when they differ from the rest shape V (`rotateModel`, main.cpp:1115-1139)
 
     def before_step(self, be, t):
         """What AnimScripter::stepAnimScript decides from the state before a time step (call with the step's start time)."""
@@ -399,15 +404,35 @@ def assemble(cfg, read_mesh):
         tr.append(tr[-1])
     V, T, SF = np.vstack(Vs), np.vstack(Ts).astype(np.int32), np.vstack(SFs).astype(np.int32)
     nSim = nr[len(cfg.shapes)]  # the simulated mesh: everything before the obstacle components
+    V0 = None
+    if cfg.rot_deg != 0.0 and nSim:
+        # main.cpp:1115-1139: the START positions are the model turned about an axis (Eigen::AngleAxis::toRotationMatrix, the axis as
+        # given) through `center` = HALF THE EXTENT of the bounding box (not its middle); the rest shape stays as assembled
+        c, sn = math.cos(math.radians(cfg.rot_deg)), math.sin(math.radians(cfg.rot_deg))
+        ax = np.array(cfg.rot_axis, float)
+        R = (1 - c) * np.outer(ax, ax) + c * np.eye(3) + sn * np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        V0 = V.copy()
+        center = (V[:nSim].max(0) - V[:nSim].min(0)) / 2.0
+        V0[:nSim] = (V[:nSim] - center) @ R.T + center
     if cfg.size > 0 and nSim:
-        # main.cpp:1140-1145: the assembled model (all shapes, not the collision objects) is scaled so that its largest
-        # bounding-box extent equals `size`, then moved so that the box's lower corner sits at the origin
-        ext = (V[:nSim].max(0) - V[:nSim].min(0)).max()
+        # main.cpp:1140-1145: the assembled model (all shapes, not the collision objects) is scaled so that the largest
+        # bounding-box extent of its start positions equals `size`, then moved so that the box's lower corner sits at the origin
+        U = V if V0 is None else V0
+        ext = (U[:nSim].max(0) - U[:nSim].min(0)).max()
         V[:nSim] *= cfg.size / ext
-        V[:nSim] -= V[:nSim].min(0)
+        if V0 is not None:
+            V0[:nSim] *= cfg.size / ext
+        lo = (V if V0 is None else V0)[:nSim].min(0).copy()
+        V[:nSim] -= lo
+        if V0 is not None:
+            V0[:nSim] -= lo
     if cfg.script in ("fall", "fallNoShift"):  # AnimScripter.cpp:779-788: lifted by half the bounding-box diagonal, no Dirichlet nodes
         if cfg.script == "fall":  # Mesh<3> only: the obstacles are not part of it in the reference
-            V[:nSim, 1] += 0.5 * np.linalg.norm(V[:nSim].max(0) - V[:nSim].min(0))
+            U = V if V0 is None else V0
+            lift = 0.5 * np.linalg.norm(U[:nSim].max(0) - U[:nSim].min(0))
+            V[:nSim, 1] += lift
+            if V0 is not None:
+                V0[:nSim, 1] += lift
         dirichlet = []
     codim_nodes = codim_mass = codim_fixed = None
     if codim:
@@ -449,7 +474,7 @@ def assemble(cfg, read_mesh):
         v[fixed[a:b]] = 0.0
         vel[a:b] = v
     obst = np.concatenate(obstacle) if obstacle else None
-    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release, codim_nodes, codim_mass, codim_fixed)
+    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release, codim_nodes, codim_mass, codim_fixed, V0)
 
 
 def apply(sc, be):
@@ -462,6 +487,8 @@ def apply(sc, be):
     for s, sh in enumerate(cfg.shapes):
         if sh.material is not None and all(np.isfinite(sh.material)):
             be.set_component_material((sc.node_ranges[s], sc.node_ranges[s + 1]), (sc.tet_ranges[s], sc.tet_ranges[s + 1]), *sh.material)
+    if sc.V0 is not None:
+        be.set_positions(sc.V0)
     be.opt_init(cfg.dt, cfg.gravity)
     if cfg.time_integration == "NM":
         be.set_time_integration("NM", cfg.beta, cfg.gamma)

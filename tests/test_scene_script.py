@@ -129,6 +129,9 @@ class OracleBackend:
     def set_energy_type(self, name):
         self.m.set_energy_type(name)
 
+    def set_positions(self, V):
+        self.m.set_V(V)
+
     def set_component_material(self, *a):
         self.m.set_component_material(*a)
 

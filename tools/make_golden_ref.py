@@ -185,6 +185,8 @@ SCENES = [
     # `tuning 2`: a start value for kappa and the dHat homotopy of fullyImplicit_IP (dHat 0.5 of the diagonal halved down to 1e-3 in
     # every time step), FCR, `size`, `script fall`, a mesh collision object
     ("cubes_dhat_homotopy", "paperExamples/supplementB/SQPBenchmark/11_cubes.txt", "", 20),
+    # `rotateModel` (start positions turned against the rest shape), `tuning 2` homotopy, warm start 1, point-triangle impact
+    ("point_triangle_rotated", "paperExamples/supplementB/SQPBenchmark/04_pointTriangle.txt", "", 45),
     ("two_cubes_nm_damped", "tutorialExamples/advanced/2cubesFall_NM.txt", "\ntime 5 0.025\n", 30),  # every step written at this step size
 ]
 
