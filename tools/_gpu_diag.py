@@ -6,7 +6,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ipc_amd
 from test_oracle_vs_reference import load_scene, run_scene
 ipc_amd.load_library()
-for name in ("two_cubes_fall", "rotate_co", "rotate_co_surface", "dbc_time_range", "aligned_cubes", "aligned_cubes_fric", "bar_twist_damped", "two_cubes_nm_damped", "cubes_dhat_homotopy"):
+for name in ("two_cubes_fall", "rotate_co", "rotate_co_surface", "dbc_time_range", "aligned_cubes", "aligned_cubes_fric", "bar_twist_damped", "two_cubes_nm_damped", "cubes_dhat_homotopy", "point_triangle_rotated"):
     S, meshes = load_scene(name)
     c = ipc_amd.Context(0)
     try:
