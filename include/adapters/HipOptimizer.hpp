@@ -1,0 +1,443 @@
+// HipOptimizer -- the Optimizer<3> subclass a maintainer drops into src/TimeStepper/ to run the Newton time-step loop of
+// ipc-sim/IPC on an MI355X.  Optimizer<dim> is all-virtual (src/TimeStepper/Optimizer.hpp:131-283) and constructed at exactly
+// one site, src/main.cpp:1397; the one-line change there is `new IPC::HipOptimizer<DIM>(...)` with the same arguments.
+//
+// Two ways to run, chosen with the environment variable IPCGPU_OPTIMIZER_MODE (or the last constructor argument):
+//
+//   resident (default)   precompute() hands the state the base-class constructor assembled -- Mesh<3> with the arrays it already
+//       holds, Config, the Dirichlet / Neumann groups, half-spaces, mesh collision objects, start velocity -- to the library
+//       once; solve() then runs whole time steps on the device (ipcgpu_opt_solve_timestep: scripted Dirichlet motion,
+//       constraint sets, barrier + friction terms, assembly, Cholesky, CCD line search, velocity update) and mirrors positions,
+//       velocity, acceleration, dx_Elastic and the counters back into the base-class members, so that getResult(),
+//       getIterNum(), getInnerIterAmt() and saveStatus() (Optimizer.cpp:2964-3011) keep working unchanged.  Per iteration a
+//       handful of scalars cross PCIe.
+//   percall              the reference's own solve() / fullyImplicit_IP() / solveSub_IP() / lineSearch() control flow stays in
+//       charge; the elasticity term it evaluates is a HipElasticEnergy and the solver LinSysSolver::create hands it is a
+//       HipLinSysSolver on the same context (values in HBM).  Contact terms, CCD and the scripts run as the reference's host
+//       code.  This is the A/B configuration inside one binary, and it supports every script / collision object the reference has.
+//
+// Scripts (AnimScripter.hpp:22-95) that run resident: null (Dirichlet / Neumann groups, scripted component velocities), twist,
+// fall, fallNoShift, dragright, DCOFix.  Any other one falls back to percall with a note on stderr.
+// Needs: the reference's Optimizer.hpp, include/ipcgpu.h, -lipcgpu.
+#pragma once
+#include "Optimizer.hpp"
+#include "HalfSpace.hpp"
+#include "HipElasticEnergy.hpp"
+#include <ipcgpu.h>
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace IPC {
+
+enum HipOptimizerMode {
+    HIP_OPT_RESIDENT = 0,
+    HIP_OPT_PERCALL = 1,
+    HIP_OPT_FROM_ENV = -1
+};
+
+// LinSysSolver::create is a static factory without arguments (LinSysSolver.cpp:13-27): the optimizer adapter leaves its
+// context here right before the base-class constructor asks for `linSysSolver`; the `case LinSysSolverType::HIP:` a maintainer
+// adds to the factory is `return hipCreateLinSysSolver<vectorTypeI, vectorTypeS>();`.  The first solver created after an
+// optimizer adapter shares its context (the Hessian), every other one owns a private context (the damping matrix, Diagnostic.cpp).
+struct HipAdapterRegistry {
+    ipcgpu_ctx* pending = nullptr;
+};
+inline HipAdapterRegistry& hipAdapterRegistry()
+{
+    static HipAdapterRegistry r;
+    return r;
+}
+template <typename vectorTypeI, typename vectorTypeS>
+inline LinSysSolver<vectorTypeI, vectorTypeS>* hipCreateLinSysSolver()
+{
+    ipcgpu_ctx* shared = hipAdapterRegistry().pending;
+    hipAdapterRegistry().pending = nullptr;
+    return new HipLinSysSolver<vectorTypeI, vectorTypeS>(shared);
+}
+
+// HalfSpace<3>::normal is protected and has no getter (HalfSpace.hpp:21-22); a pointer to member named through a derived class
+// is the access the language allows without touching the reference (a maintainer adds `getNormal()` instead).
+struct HipHalfSpaceAccess : HalfSpace<3> {
+    static const Eigen::Matrix<double, 3, 1>& normalOf(const HalfSpace<3>& h) { return h.*(&HipHalfSpaceAccess::normal); }
+};
+
+// members that must exist before the Optimizer<3> base is constructed (it keeps a reference to the energy terms and asks
+// LinSysSolver::create for its solver inside its constructor)
+struct HipOptimizerParts {
+    ipcgpu_ctx* ctx = nullptr;
+    int mode = HIP_OPT_RESIDENT;
+    std::vector<Energy<3>*> terms;
+    std::unique_ptr<HipElasticEnergy> hipEnergy;
+
+    static void chk(int rc)
+    {
+        if (rc < 0) throw std::runtime_error(ipcgpu_last_error());
+    }
+    static bool residentScript(AnimScriptType t)
+    {
+        return t == AST_NULL || t == AST_TWIST || t == AST_FALL || t == AST_FALL_NOSHIFT || t == AST_DRAGRIGHT || t == AST_DCOFIX;
+    }
+    HipOptimizerParts(const std::vector<Energy<3>*>& given, const Config& cfg, int requested, int device)
+    {
+        mode = requested;
+        if (mode == HIP_OPT_FROM_ENV) {
+            const char* e = std::getenv("IPCGPU_OPTIMIZER_MODE");
+            mode = (e && std::strcmp(e, "percall") == 0) ? HIP_OPT_PERCALL : HIP_OPT_RESIDENT;
+        }
+        if (mode == HIP_OPT_RESIDENT) {
+            const char* why = nullptr;
+            if (!residentScript(cfg.animScriptType)) why = "this script is not built into the resident stepper";
+            else if (cfg.useAbsParameters) why = "absolute tuning parameters";
+            else if (cfg.isConstrained && cfg.constraintSolverType != CST_IP) why = "a constraint solver other than interiorPoint";
+            else if (!cfg.isConstrained && (cfg.collisionObjects.size() || cfg.meshCollisionObjects.size())) why = "unconstrained run with collision objects";
+            if (why) {
+                std::fprintf(stderr, "HipOptimizer: %s -> percall mode (elasticity + Cholesky on the device, the rest as the reference's host code)\n", why);
+                mode = HIP_OPT_PERCALL;
+            }
+        }
+        chk(ipcgpu_ctx_create(device, &ctx));
+        if (mode == HIP_OPT_PERCALL) {
+            hipEnergy.reset(new HipElasticEnergy(ctx, cfg.energyType == ET_FCR ? 1 : 0));
+            terms.assign(1, hipEnergy.get());
+            hipAdapterRegistry().pending = ctx;
+        }
+        else {
+            terms = given;
+            hipAdapterRegistry().pending = nullptr;
+        }
+    }
+    ~HipOptimizerParts()
+    {
+        hipEnergy.reset();
+        if (ctx) ipcgpu_ctx_destroy(ctx);
+    }
+    HipOptimizerParts(const HipOptimizerParts&) = delete;
+    HipOptimizerParts& operator=(const HipOptimizerParts&) = delete;
+};
+
+template <int dim>
+class HipOptimizer : private HipOptimizerParts, public Optimizer<dim> {
+    static_assert(dim == 3, "the device path is three-dimensional");
+    typedef Optimizer<dim> Base;
+    typedef HipOptimizerParts Parts;
+
+protected:
+    int nSim = 0, nObst = 0; // nodes of Mesh<3>; nodes of the mesh collision objects riding along behind them
+    bool uploaded = false, dragReleased = false;
+    int dragGroup = -1;
+    std::vector<unsigned char> dbcMirror_; // vertexDBCType as last handed to the device (percall)
+    std::vector<double> bufV_, bufA_, bufB_, bufC_;
+
+    using Parts::chk;
+
+public:
+    HipOptimizer(const Mesh<dim>& p_data0, const std::vector<Energy<dim>*>& p_energyTerms, const std::vector<double>& p_energyParams,
+        bool p_mute = false, const Eigen::MatrixXd& UV_bnds = Eigen::MatrixXd(), const Eigen::MatrixXi& E = Eigen::MatrixXi(),
+        const Eigen::VectorXi& bnd = Eigen::VectorXi(), const Config& p_animConfig = Config(), int p_mode = HIP_OPT_FROM_ENV, int device = 0)
+        : Parts(p_energyTerms, p_animConfig, p_mode, device), Base(p_data0, Parts::terms, p_energyParams, p_mute, UV_bnds, E, bnd, p_animConfig)
+    {
+        hipAdapterRegistry().pending = nullptr;
+        nSim = (int)Base::result.V.rows();
+        if (Parts::mode == HIP_OPT_PERCALL) {
+            // the energy adapter evaluates on the mesh of the shared context: Mesh<3> as the base-class constructor left it
+            hipUploadMesh(Parts::ctx, Base::result, Base::result.m_YM, Base::result.m_PR, Base::result.density);
+            mirrorDBC();
+        }
+    }
+
+    ipcgpu_ctx* context() const { return Parts::ctx; }
+    bool resident() const { return Parts::mode == HIP_OPT_RESIDENT; }
+
+    // ---- Optimizer API (Optimizer.hpp:131-161) --------------------------------------------------------------------------
+    void setRelGL2Tol(double p_relTol = 1.0e-2) override
+    {
+        Base::setRelGL2Tol(p_relTol);
+        if (resident() && uploaded) chk(ipcgpu_opt_set_rel_tol(Parts::ctx, p_relTol));
+    }
+
+    void precompute(void) override
+    {
+        if (!resident()) {
+            Base::precompute();
+            return;
+        }
+        uploadScene(); // after setTime (main.cpp:1398): dt is final
+        chk(ipcgpu_opt_set_rel_tol(Parts::ctx, std::sqrt(Base::relGL2Tol)));
+        chk(ipcgpu_opt_precompute(Parts::ctx));
+        double sc[8];
+        chk(ipcgpu_opt_get_state(Parts::ctx, nullptr, nullptr, nullptr, sc));
+        Base::lastEnergyVal = sc[0];
+    }
+
+    // Optimizer::solve (Optimizer.cpp:509-602): maxIter time steps; 1 = the animation is over, 0 otherwise
+    int solve(int maxIter = 100) override
+    {
+        if (!resident()) return Base::solve(maxIter);
+        for (int iterI = 0; iterI < maxIter; ++iterI) {
+            if (Base::globalIterNum >= Base::frameAmt) return 1;
+            if (Base::animConfig.animScriptType == AST_DRAGRIGHT) dragRightRule();
+            int n = 0;
+            chk(ipcgpu_opt_solve_timestep(Parts::ctx, 1 << 30, &n));
+            Base::innerIterAmt += n;
+            Base::globalIterNum++;
+            mirrorState();
+        }
+        return 0;
+    }
+
+    // ---- percall: the reference's control flow, device elasticity + solver ---------------------------------------------------
+    // the Dirichlet types change under stepAnimScript (time ranges, released handles): hand them over before the next evaluation
+    void computeEnergyVal(const Mesh<dim>& data, int redoSVD, double& energyVal) override
+    {
+        if (!resident()) mirrorDBC(&data);
+        Base::computeEnergyVal(data, redoSVD, energyVal);
+    }
+    void computeGradient(const Mesh<dim>& data, bool redoSVD, Eigen::VectorXd& gradient, bool projectDBC = true) override
+    {
+        if (!resident()) mirrorDBC(&data);
+        Base::computeGradient(data, redoSVD, gradient, projectDBC);
+    }
+    void computePrecondMtr(const Mesh<dim>& data, bool redoSVD, LinSysSolver<Eigen::VectorXi, Eigen::VectorXd>* p_linSysSolver,
+        bool updateDamping = false, bool projectDBC = true) override
+    {
+        if (!resident()) mirrorDBC(&data);
+        Base::computePrecondMtr(data, redoSVD, p_linSysSolver, updateDamping, projectDBC);
+    }
+
+protected:
+    void mirrorDBC(const Mesh<dim>* data = nullptr)
+    {
+        const Mesh<dim>& m = data ? *data : Base::result;
+        const size_t n = m.vertexDBCType.size();
+        bool same = dbcMirror_.size() == n;
+        for (size_t v = 0; same && v < n; ++v) same = dbcMirror_[v] == (unsigned char)m.vertexDBCType[v];
+        if (same) return;
+        dbcMirror_.resize(n);
+        std::vector<int> ids[3];
+        for (size_t v = 0; v < n; ++v) {
+            dbcMirror_[v] = (unsigned char)m.vertexDBCType[v];
+            ids[dbcMirror_[v]].push_back((int)v);
+        }
+        chk(ipcgpu_clear_dbc(Parts::ctx));
+        for (int type = 1; type <= 2; ++type)
+            if (!ids[type].empty()) chk(ipcgpu_set_dbc(Parts::ctx, (int)ids[type].size(), ids[type].data(), type));
+    }
+
+    // `script dragright` (AnimScripter.cpp:1619-1632): the handle is let go once the whole body is right of every mesh obstacle
+    void dragRightRule()
+    {
+        if (dragReleased || dragGroup < 0) return;
+        double rightMost = -1.0e300;
+        for (const auto& mco : Base::animConfig.meshCollisionObjects)
+            for (int i = 0; i < mco->V.rows(); ++i) rightMost = std::max(rightMost, mco->V(i, 0));
+        double left = 1.0e300;
+        for (int v = 0; v < nSim; ++v) left = std::min(left, Base::result.V(v, 0));
+        if (left > rightMost) {
+            chk(ipcgpu_opt_end_dirichlet(Parts::ctx, dragGroup, Base::globalIterNum * Base::dt));
+            dragReleased = true;
+        }
+    }
+
+    // device -> result.V / V_prev, velocity, acceleration, dx_Elastic (what saveStatus writes and main.cpp draws)
+    void mirrorState()
+    {
+        const size_t nAll = (size_t)(nSim + nObst);
+        bufV_.resize(3 * nAll);
+        bufA_.resize(3 * nAll);
+        bufB_.resize(3 * nAll);
+        bufC_.resize(3 * nAll);
+        double sc[8];
+        chk(ipcgpu_opt_get_state(Parts::ctx, bufV_.data(), nullptr, nullptr, sc));
+        chk(ipcgpu_opt_get_kinematics(Parts::ctx, bufA_.data(), bufB_.data(), bufC_.data()));
+        for (int v = 0; v < nSim; ++v)
+            for (int c = 0; c < 3; ++c) {
+                Base::result.V(v, c) = bufV_[(size_t)c * nAll + v];
+                Base::velocity[3 * v + c] = bufA_[3 * (size_t)v + c];
+                Base::acceleration(v, c) = bufB_[3 * (size_t)v + c];
+                Base::dx_Elastic(v, c) = bufC_[3 * (size_t)v + c];
+            }
+        Base::result.V_prev = Base::result.V;
+        Base::lastEnergyVal = sc[0];
+        Base::kappa = sc[6];
+        Base::dHat = sc[7];
+    }
+
+    // the scene as the base-class constructor assembled it -> one context (what ipc_amd/scene_script.py::apply does from a script)
+    void uploadScene()
+    {
+        ipcgpu_ctx* ctx = Parts::ctx;
+        const Config& cfg = Base::animConfig;
+        const Mesh<dim>& m = Base::result;
+        const int nT = (int)m.F.rows();
+        // mesh collision objects ride along as surface-only components behind the nodes of Mesh<3> (MeshCO.cpp:37-80)
+        nObst = 0;
+        int nSFObst = 0;
+        for (const auto& mco : cfg.meshCollisionObjects) {
+            nObst += (int)mco->V.rows();
+            nSFObst += (int)mco->F.rows();
+        }
+        const int nAll = nSim + nObst, nSF = (int)m.SF.rows(), nSFAll = nSF + nSFObst;
+        std::vector<double> Vrest(3 * (size_t)nAll), Vcur(3 * (size_t)nAll), mass((size_t)nAll, 0.0);
+        std::vector<int> SF(3 * (size_t)nSFAll), obst;
+        for (int v = 0; v < nSim; ++v)
+            for (int c = 0; c < 3; ++c) {
+                Vrest[(size_t)c * nAll + v] = m.V_rest(v, c);
+                Vcur[(size_t)c * nAll + v] = m.V(v, c);
+            }
+        for (int f = 0; f < nSF; ++f)
+            for (int c = 0; c < 3; ++c) SF[(size_t)c * nSFAll + f] = m.SF(f, c);
+        int vOff = nSim, fOff = nSF;
+        for (const auto& mco : cfg.meshCollisionObjects) {
+            for (int v = 0; v < mco->V.rows(); ++v) {
+                for (int c = 0; c < 3; ++c) Vrest[(size_t)c * nAll + vOff + v] = Vcur[(size_t)c * nAll + vOff + v] = mco->V(v, c);
+                obst.push_back(vOff + v);
+            }
+            for (int f = 0; f < mco->F.rows(); ++f)
+                for (int c = 0; c < 3; ++c) SF[(size_t)c * nSFAll + fOff + f] = mco->F(f, c) + vOff;
+            vOff += (int)mco->V.rows();
+            fOff += (int)mco->F.rows();
+        }
+        chk(ipcgpu_set_mesh(ctx, nAll, nT, Vrest.data(), m.F.data(), m.m_YM, m.m_PR, m.density));
+        // codimension-2 components (triangle meshes under `shapes`, main.cpp:948-956): nodes of no tetrahedron with lumped area masses
+        std::vector<int> codim;
+        std::vector<double> codimMass;
+        for (size_t compI = 0; compI < m.componentCoDim.size(); ++compI) {
+            if (m.componentCoDim[compI] == 3) continue;
+            if (m.componentCoDim[compI] != 2) throw std::runtime_error("HipOptimizer: segment / point components need percall mode");
+            for (int v = m.componentNodeRange[compI]; v < m.componentNodeRange[compI + 1]; ++v) {
+                codim.push_back(v);
+                codimMass.push_back(m.massMatrix.coeff(v, v));
+            }
+        }
+        if (!codim.empty()) chk(ipcgpu_set_codim_nodes(ctx, (int)codim.size(), codim.data(), codimMass.data()));
+        // the arrays Mesh<3> already holds (component materials and densities included, Mesh.cpp:660-671)
+        {
+            std::vector<double> A(9 * (size_t)nT);
+            for (int t = 0; t < nT; ++t)
+                for (int k = 0; k < 9; ++k) A[9 * (size_t)t + k] = m.restTriInv[t].data()[k];
+            for (int v = 0; v < nSim; ++v) mass[v] = m.massMatrix.coeff(v, v);
+            chk(ipcgpu_set_mesh_features(ctx, A.data(), m.triArea.data(), mass.data(), m.u.data(), m.lambda.data()));
+        }
+        chk(ipcgpu_set_energy_type(ctx, cfg.energyType == ET_FCR ? 1 : 0));
+        chk(ipcgpu_set_positions(ctx, Vcur.data()));
+        chk(ipcgpu_opt_init(ctx, Base::dt, cfg.withGravity ? 1 : 0));
+        if (cfg.timeIntegrationType == TIT_NM) chk(ipcgpu_opt_set_time_integration(ctx, 1, Base::beta_NM, Base::gamma_NM));
+        chk(ipcgpu_set_surface(ctx, nSFAll, SF.data()));
+        // static Dirichlet types: held surfaces; the obstacle
+        chk(ipcgpu_clear_dbc(ctx));
+        if (!codim.empty() && (cfg.animScriptType == AST_NULL || cfg.animScriptType == AST_DCOFIX))
+            chk(ipcgpu_set_dbc(ctx, (int)codim.size(), codim.data(), cfg.animScriptType == AST_DCOFIX ? IPCGPU_DBC_NONZERO : IPCGPU_DBC_ZERO));
+        const bool selfCollision = Base::solveIP && cfg.isSelfCollision;
+        if (!obst.empty()) {
+            chk(ipcgpu_set_dbc(ctx, (int)obst.size(), obst.data(), IPCGPU_DBC_ZERO));
+            chk(ipcgpu_set_obstacle_nodes(ctx, (int)obst.size(), obst.data(), selfCollision ? 0 : 1));
+        }
+        if (Base::solveIP && (selfCollision || !obst.empty())) chk(ipcgpu_opt_enable_self_collision(ctx, Base::dHatEps));
+        // analytic half-spaces (`ground`, `halfSpace`: Config.cpp:306-345)
+        bool planeFric = false;
+        if (Base::solveIP)
+            for (const auto& co : cfg.collisionObjects) {
+                const HalfSpace<3>* hs = dynamic_cast<const HalfSpace<3>*>(co.get());
+                if (!hs) throw std::runtime_error("HipOptimizer: an analytic collision object that is not a half-space");
+                const Eigen::Matrix<double, 3, 1>& nrm = HipHalfSpaceAccess::normalOf(*hs);
+                const double o[3] = { hs->origin[0], hs->origin[1], hs->origin[2] }, n[3] = { nrm[0], nrm[1], nrm[2] };
+                int id = -1;
+                chk(ipcgpu_opt_add_half_space(ctx, o, n, Base::dHatEps, &id));
+                if (hs->friction > 0.0) {
+                    chk(ipcgpu_opt_set_half_space_friction(ctx, id, hs->friction));
+                    planeFric = true;
+                }
+            }
+        // friction (Optimizer.cpp:146-166): mesh collision objects only switch the lagging loop on, their pairs carry none
+        // (:3357-3376, 3473-3510, 3676-3705 evaluate friction for the analytic objects and the self-collision set only)
+        const double epsV = cfg.tuning.size() > 4 ? cfg.tuning[4] : 1.0e-3;
+        const double selfFric = selfCollision ? cfg.selfFric : 0.0;
+        if (Base::solveFric) {
+            chk(ipcgpu_opt_set_friction(ctx, selfFric, cfg.fricIterAmt, epsV));
+            if (selfFric > 0.0 && !obst.empty()) chk(ipcgpu_opt_set_friction_scales(ctx, 1.0, 0.0));
+            if (!(selfFric > 0.0) && !planeFric) chk(ipcgpu_opt_force_friction_loop(ctx, 1));
+        }
+        if (cfg.tuning.size() > 0 && cfg.tuning[0] > 0.0) chk(ipcgpu_opt_set_kappa(ctx, cfg.tuning[0]));
+        {
+            const double target = cfg.tuning.size() > 2 ? cfg.tuning[2] : 1.0e-3; // Optimizer.cpp:283-289
+            if (target > 0.0 && target < Base::dHatEps) chk(ipcgpu_opt_set_dhat_target(ctx, target));
+        }
+        if (cfg.dampingStiff > 0.0) chk(ipcgpu_opt_set_damping(ctx, cfg.dampingStiff));
+        // scripted motion
+        const double zero3[3] = { 0, 0, 0 };
+        const double inf = std::numeric_limits<double>::infinity();
+        if (cfg.animScriptType == AST_NULL) {
+            // whole components with a scripted velocity (AnimScripter.cpp:1413-1435), then the Dirichlet groups (:1437-1462)
+            std::vector<std::array<double, 6>> comp(m.componentNodeRange.size());
+            std::vector<char> has(m.componentNodeRange.size(), 0);
+            for (const auto& lv : m.componentLVels) {
+                has[lv.first[0]] = 1;
+                for (int c = 0; c < 3; ++c) comp[lv.first[0]][c] = lv.second[c];
+            }
+            for (const auto& av : m.componentAVels) {
+                if (!has[av.first[0]]) comp[av.first[0]] = { 0, 0, 0, 0, 0, 0 };
+                has[av.first[0]] = 1;
+                for (int c = 0; c < 3; ++c) comp[av.first[0]][3 + c] = av.second[c];
+            }
+            for (size_t compI = 0; compI + 1 < m.componentNodeRange.size(); ++compI) {
+                if (!has[compI]) continue;
+                std::vector<int> ids;
+                for (int v = m.componentNodeRange[compI]; v < m.componentNodeRange[compI + 1]; ++v) ids.push_back(v);
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)ids.size(), ids.data(), comp[compI].data(), comp[compI].data() + 3, 0.0, inf));
+            }
+            for (const auto& dbc : m.DirichletBCs) {
+                const double lin[3] = { dbc.linearVelocity[0], dbc.linearVelocity[1], dbc.linearVelocity[2] };
+                const double ang[3] = { dbc.angularVelocity[0], dbc.angularVelocity[1], dbc.angularVelocity[2] };
+                const double t0 = std::max(dbc.timeRange[0], cfg.DBCTimeRange[0]), t1 = std::min(dbc.timeRange[1], cfg.DBCTimeRange[1]);
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)dbc.vertIds.size(), dbc.vertIds.data(), lin, ang, t0, t1));
+            }
+        }
+        else if (cfg.animScriptType == AST_TWIST) {
+            // AnimScripter.cpp:555-572: the two border vertex sets turn about x with -/+ 0.4 pi
+            if (m.borderVerts_primitive.size() != 2) throw std::runtime_error("HipOptimizer: script twist needs two border vertex sets");
+            const std::vector<int>&l = m.borderVerts_primitive[0], &r = m.borderVerts_primitive[1];
+            chk(ipcgpu_opt_set_twist(ctx, (int)l.size(), l.data(), (int)r.size(), r.data(), 0.4 * M_PI));
+        }
+        else if (cfg.animScriptType == AST_DRAGRIGHT) {
+            // AnimScripter.cpp:809-826: the NONZERO handle the constructor picked, pulled at 0.5 in +x until the rule lets go
+            std::vector<int> ids;
+            for (int v = 0; v < nSim; ++v)
+                if (m.vertexDBCType[v] == DirichletBCType::NONZERO) ids.push_back(v);
+            const double lin[3] = { 0.5, 0.0, 0.0 };
+            if (!ids.empty()) {
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)ids.size(), ids.data(), lin, zero3, 0.0, inf));
+                dragGroup = 0;
+            }
+        }
+        // Neumann groups (Optimizer.cpp:3241-3250; AnimScripter::isNBCActive)
+        for (const auto& nbc : m.NeumannBCs) {
+            const double f[3] = { nbc.force[0], nbc.force[1], nbc.force[2] };
+            const double t0 = std::max(nbc.timeRange[0], cfg.NBCTimeRange[0]), t1 = std::min(nbc.timeRange[1], cfg.NBCTimeRange[1]);
+            chk(ipcgpu_opt_add_neumann(ctx, (int)nbc.vertIds.size(), nbc.vertIds.data(), f, t0, t1));
+        }
+        // start velocity (AnimScripter::initVelocity ran in the base-class constructor)
+        {
+            bool any = false;
+            std::vector<double> vel(3 * (size_t)nAll, 0.0);
+            for (int i = 0; i < 3 * nSim; ++i) {
+                vel[i] = Base::velocity[i];
+                any = any || vel[i] != 0.0;
+            }
+            if (any) chk(ipcgpu_opt_set_velocity(ctx, vel.data()));
+        }
+        if (cfg.warmStart) chk(ipcgpu_opt_set_warm_start(ctx, cfg.warmStart));
+        if (cfg.restart) chk(ipcgpu_opt_load_status(ctx, cfg.statusPath.c_str()));
+        uploaded = true;
+    }
+};
+
+} // namespace IPC

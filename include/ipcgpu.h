@@ -177,8 +177,10 @@ int ipcgpu_get_surface(ipcgpu_ctx*, int* counts3 /*nSVI,nSF,nSFEdges*/, int* SVI
 int ipcgpu_set_obstacle_nodes(ipcgpu_ctx*, int n, const int* vert_ids, int obstacle_only);
 /* Surface-only ("codimensional") components of the simulated mesh: nodes of no tetrahedron that nevertheless belong to Mesh<3> --
  * the triangle meshes listed under `shapes` (componentCoDim 2; src/main.cpp, src/Mesh.cpp:310-345).  Unlike the nodes of a MeshCO
- * (ipcgpu_set_obstacle_nodes), which the reference keeps outside the mesh, they count in the bounding box behind dHat and in the
- * mean nodal mass behind kappa, and carry lumped masses: density x a third of the areas of the adjacent triangles.  The scripts
+ * (ipcgpu_set_obstacle_nodes), which the reference keeps outside the mesh, they carry lumped masses: density x a third of the areas
+ * of the adjacent triangles.  Like a MeshCO they stay OUT of the bounding box behind dHat / eps_v / the Newton tolerance and out of
+ * the mean nodal mass behind kappa: the Optimizer sizes those with matSpaceBBoxSize2(dim) / avgNodeMass(dim), i.e. over the
+ * tetrahedral components only (Mesh.cpp:576-637).  The scripts
  * fix or move them as Dirichlet nodes (`script DCOFix`: ipcgpu_set_dbc(ids, NONZERO)).  Call after ipcgpu_set_mesh, before
  * ipcgpu_opt_init / ipcgpu_opt_enable_self_collision. */
 int ipcgpu_set_codim_nodes(ipcgpu_ctx*, int n, const int* node_ids, const double* node_mass);
@@ -250,6 +252,10 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, doubl
  * coefficient for the pairs that involve it.  Pass the larger coefficient to ipcgpu_opt_set_friction and the ratios here: the lagged
  * normal forces (MMLambda_lastH) of stencils without / with an obstacle node are multiplied by scaleSelf / scaleObstacle. */
 int ipcgpu_opt_set_friction_scales(ipcgpu_ctx*, double scaleSelf, double scaleObstacle);
+/* Optimizer.cpp:146-166: solveFric is also true when a mesh collision object carries a friction coefficient, although no friction
+ * term is ever evaluated for its pairs (:3357-3376, 3473-3510, 3676-3705): the lagging loop with its tangent-space convergence solve
+ * then runs after every converged sub-problem.  on != 0 switches that loop on without any frictional pair. */
+int ipcgpu_opt_force_friction_loop(ipcgpu_ctx*, int on);
 int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx*, int id, double mu); /* CollisionObject::friction of half-space `id` */
 /* Lagged stiffness-proportional damping: `dampingStiff s` (Config.cpp:141-147; `dampingRatio r` is s = r * dt^3 * 3 / 4, :148-157,
  * 614-616).  The damping matrix is the PSD-projected elastic Hessian at the end of the last time step times s / dt

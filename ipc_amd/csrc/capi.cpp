@@ -1032,6 +1032,13 @@ int ipcgpu_opt_set_friction_scales(ipcgpu_ctx* c, double scaleSelf, double scale
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_force_friction_loop(ipcgpu_ctx* c, int on)
+{
+    return guarded([&] {
+        O(c).fricLoopForced = on != 0;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx* c, int id, double mu)
 {
     return guarded([&] {

@@ -987,22 +987,37 @@ struct RefGrid {
 __device__ __forceinline__ int ref_index(const RefGrid& g, double x, int c) { return (int)floor(__dmul_rn(__dsub_rn(x, g.lb[c]), g.oneDiv)); }
 __device__ __forceinline__ double swept_pos(double x, double alpha, double p) { return __dadd_rn(x, __dmul_rn(alpha, p)); }
 
-__global__ __launch_bounds__(BLOCK) void k_ref_abs_sum(int n, const int* __restrict__ SVI, const double* __restrict__ p, double* __restrict__ partial)
+// surface nodes of a mesh collision object (obst flag) are left out and counted out: SpatialHash.hpp:603-618 runs over mesh.SVI, and
+// Mesh<3> does not contain them in the reference.  partial[b] = sum, partial[gridDim.x + b] = number of nodes that counted.
+__global__ __launch_bounds__(BLOCK) void k_ref_abs_sum(int n, const int* __restrict__ SVI, const int* __restrict__ obst, const double* __restrict__ p,
+    double* __restrict__ partial)
 {
     __shared__ double sm[BLOCK];
+    __shared__ int cnt[BLOCK];
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     double s = 0.0;
+    int own = 0;
     if (i < n) {
         const size_t v = (size_t)SVI[i];
-        s = fabs(p[3 * v]) + fabs(p[3 * v + 1]) + fabs(p[3 * v + 2]);
+        if (!(obst && obst[v])) {
+            own = 1;
+            s = fabs(p[3 * v]) + fabs(p[3 * v + 1]) + fabs(p[3 * v + 2]);
+        }
     }
+    cnt[threadIdx.x] = own;
     sm[threadIdx.x] = s;
     __syncthreads();
     for (int off = BLOCK / 2; off > 0; off >>= 1) { // fixed tree: the same bits on every run
-        if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        if ((int)threadIdx.x < off) {
+            sm[threadIdx.x] += sm[threadIdx.x + off];
+            cnt[threadIdx.x] += cnt[threadIdx.x + off];
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = sm[0];
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = sm[0];
+        partial[gridDim.x + blockIdx.x] = (double)cnt[0];
+    }
 }
 // bounding box of the surface nodes at x + alpha p, one partial per block (6 doubles: lo, hi)
 __global__ __launch_bounds__(BLOCK) void k_ref_bbox_swept(int n, const int* __restrict__ SVI, const double* __restrict__ x, const double* __restrict__ p,
@@ -2235,12 +2250,16 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
     // the cap (SpatialHash.hpp:603-618): mean |component| of p over the surface nodes against the cell size
     const int nbS = nblk(nSVI);
     bboxPartial_.ensure(6 * (size_t)std::max(nbS, nblk(mesh.nV)));
-    hipLaunchKernelGGL(k_ref_abs_sum, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, p_dev, bboxPartial_.p);
+    hipLaunchKernelGGL(k_ref_abs_sum, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, hasObstacle ? (const int*)d_obst.p : (const int*)nullptr, p_dev,
+        bboxPartial_.p);
     std::vector<double> part(6 * (size_t)std::max(nbS, nblk(mesh.nV)));
-    bboxPartial_.download(part.data(), (size_t)nbS, stream);
-    double pSize = 0.0;
-    for (int b = 0; b < nbS; ++b) pSize += part[(size_t)b];
-    pSize /= (double)nSVI * 3;
+    bboxPartial_.download(part.data(), 2 * (size_t)nbS, stream);
+    double pSize = 0.0, nOwn = 0.0;
+    for (int b = 0; b < nbS; ++b) {
+        pSize += part[(size_t)b];
+        nOwn += part[(size_t)nbS + b];
+    }
+    pSize /= std::max(nOwn, 1.0) * 3;
     const double voxelSize = mesh.avgEdgeLen / 3.0;
     const double spanSize = alpha * pSize / voxelSize;
     if (spanSize > 1) alpha /= spanSize;

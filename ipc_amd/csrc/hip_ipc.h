@@ -232,6 +232,7 @@ public:
     // HipHalfSpace, x^t is d_xPrev
     double selfFric = 0.0, epsV = 1.0e-3, fricDHat0 = 0, fricDHat = -1.0;
     int fricIterAmt = 1, fricIterI = 0;
+    bool fricLoopForced = false; // a mesh collision object with a friction coefficient: the lagging loop runs, no pair carries friction (Optimizer.cpp:156-161)
     bool solveFric() const;
     void updateFrictionLag();
     bool nextSubproblem(); // tail of the fullyImplicit_IP loop body after a converged solveSub_IP; true = run another one

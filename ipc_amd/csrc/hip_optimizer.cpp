@@ -340,6 +340,7 @@ void HipOptimizer::dampingGradientAdd(bool projectDBC, double* grad_dev)
 // ---- lagged friction ---------------------------------------------------------------------------------------------
 bool HipOptimizer::solveFric() const
 {
+    if (fricLoopForced) return true;
     if (selfCollision && selfFric > 0.0) return true;
     for (const auto& h : planes)
         if (h->friction > 0.0) return true;

@@ -2739,7 +2739,8 @@ bool MfNumeric::factorize(const double* a_dev)
         graphA_ = a_dev;
     }
     else enqueueFactor(a_dev);
-    if (world_ > 1 && !flagShared_) { // no exchange carried the flag (a tree that was not cut): a bad pivot met by any rank fails all
+    if (world_ > 1) { // ALWAYS once more at the end: the exchanges only carry the flag of pivots met before them, and a tree of the
+        // forest that was not cut (several bodies, world > number of roots) lives on one rank alone -- one double
         hipLaunchKernelGGL(k_flag_to_double, dim3(1), dim3(1), 0, stream_, flag_.p, xchgBuf_.p);
         allreduceSum(xchgBuf_.p, 1);
         hipLaunchKernelGGL(k_double_to_flag, dim3(1), dim3(1), 0, stream_, xchgBuf_.p, flag_.p);

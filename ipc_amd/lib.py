@@ -326,7 +326,8 @@ class Context:
         self._chk(self._L.ipcgpu_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF)))
 
     def set_codim_nodes(self, ids, mass):
-        """Surface-only nodes that belong to the mesh (triangle meshes under `shapes`): they count in bounding box and mean mass."""
+        """Surface-only nodes that belong to the mesh (triangle meshes under `shapes`) with their lumped area masses; like a MeshCO they
+        stay out of the bounding box behind dHat and of the mean nodal mass behind kappa (matSpaceBBoxSize2(dim) / avgNodeMass(dim))."""
         ids = _i32(ids)
         m = _f64(np.asarray(mass, dtype=np.float64))
         self._chk(self._L.ipcgpu_set_codim_nodes(self.h, C.c_int(len(ids)), _ip(ids), _dp(m)))
@@ -520,6 +521,9 @@ class Context:
 
     def set_friction_scales(self, scale_self=1.0, scale_obstacle=1.0):
         self._chk(self._L.ipcgpu_opt_set_friction_scales(self.h, C.c_double(scale_self), C.c_double(scale_obstacle)))
+
+    def force_friction_loop(self, on=True):
+        self._chk(self._L.ipcgpu_opt_force_friction_loop(self.h, C.c_int(int(on))))
 
     def set_half_space_friction(self, idx, mu):
         self._chk(self._L.ipcgpu_opt_set_half_space_friction(self.h, C.c_int(idx), C.c_double(mu)))

@@ -213,14 +213,12 @@ class SceneConfig:
                 while len(vals) < int(a[0]):
                     vals += [float(x) for x in lines[i].split()]
                     i += 1
-                if len(vals) > 0:
-                    cfg.kappa = max(vals[0], 0.0)  # the start value of every time step (Optimizer.cpp:1540-1547)
-                if len(vals) > 1:
-                    cfg.dHat_eps = vals[1]
-                if len(vals) > 1:  # Optimizer.cpp:283-289: without a third entry the target is 1e-3 (relative)
-                    cfg.dHat_target = vals[2] if len(vals) > 2 else 1e-3
-                if len(vals) > 4:
-                    cfg.eps_v = vals[4]
+                # `tuning.resize(amt)` (Config.cpp:533-541) DROPS the entries the line does not give: whatever an earlier `dHat` / `epsv`
+                # keyword had set falls back to the Optimizer's defaults (Optimizer.cpp:276-304: 1e-3 each, kappa automatic)
+                cfg.kappa = max(vals[0], 0.0) if len(vals) > 0 else 0.0  # the start value of every time step (Optimizer.cpp:1540-1547)
+                cfg.dHat_eps = vals[1] if len(vals) > 1 else 1e-3
+                cfg.dHat_target = vals[2] if len(vals) > 2 else 1e-3  # Optimizer.cpp:283-289: without a third entry the target is 1e-3 (relative)
+                cfg.eps_v = vals[4] if len(vals) > 4 else 1e-3
             elif k == "section":  # Config.cpp:572-605: settings for one constraint solver; other solvers' sections are skipped
                 names = ["interiorPoint" if x == "IP" else x for x in a]
                 if "end" not in names and "interiorPoint" not in names:
@@ -516,10 +514,16 @@ def apply(sc, be):
         idx = be.add_half_space(origin, normal, cfg.dHat_eps)
         if mu > 0:
             be.set_half_space_friction(idx, mu)
-    if self_fric > 0 or any(mu > 0 for *_, mu in cfg.half_spaces):
+    plane_fric = any(mu > 0 for *_, mu in cfg.half_spaces)
+    # Optimizer.cpp:146-166: solveFric is true as soon as ANY collision object -- a mesh collision object included -- or selfFric carries a
+    # coefficient: the lagging loop with its tangent-space convergence solve then runs even when no pair carries friction
+    loop_only = any(mc[3] > 0 for mc in cfg.mesh_cos) and not (self_fric > 0 or plane_fric)
+    if self_fric > 0 or plane_fric or loop_only:
         be.set_friction(self_fric, cfg.fric_iter_amt, cfg.eps_v)
         if sc.obstacle_nodes is not None and fric_scales is not None:
             be.set_friction_scales(*fric_scales)
+        if loop_only:
+            be.force_friction_loop(True)
     if cfg.kappa > 0:
         be.set_kappa(cfg.kappa)
     if 0 < cfg.dHat_target < cfg.dHat_eps:

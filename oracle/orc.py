@@ -664,6 +664,10 @@ def opt_set_friction(opt: "Optimizer", self_fric=0.0, fric_iter_amt=1, eps_v=1e-
     lib().orc_opt_set_friction(opt.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v))
 
 
+def opt_force_friction_loop(opt: "Optimizer", on=True):
+    lib().orc_opt_force_friction_loop(opt.h, C.c_int(int(on)))
+
+
 def opt_set_friction_scales(opt: "Optimizer", scale_self=1.0, scale_obstacle=1.0):
     lib().orc_opt_set_friction_scales(opt.h, C.c_double(scale_self), C.c_double(scale_obstacle))
 

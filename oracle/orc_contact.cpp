@@ -1188,10 +1188,16 @@ double fullCcdReference(const Mesh& m, const double* p, double slackness, double
         return alpha;
     }
     // the cap (SpatialHash.hpp:603-618)
+    // over mesh.SVI only: the nodes of a mesh collision object are not part of Mesh<3> there (they ride along here with p = 0 and would
+    // dilute the mean); the same hash is reused for the MeshCO sweep (Optimizer.cpp:1135-1160)
     double pSize = 0;
-    for (int i = 0; i < nSV; ++i)
+    int nOwn = 0;
+    for (int i = 0; i < nSV; ++i) {
+        if (!m.obstacle.empty() && m.obstacle[m.SVI[i]]) continue;
+        ++nOwn;
         for (int c = 0; c < 3; ++c) pSize += std::abs(p[3 * m.SVI[i] + c]);
-    pSize /= (double)nSV * 3;
+    }
+    pSize /= (double)std::max(nOwn, 1) * 3;
     const double voxelSize = m.avgEdgeLen / 3.0;
     const double spanSize = alpha * pSize / voxelSize;
     if (spanSize > 1) alpha /= spanSize;

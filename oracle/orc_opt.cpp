@@ -90,8 +90,10 @@ struct orc_opt {
     FrictionLag lag;
     std::vector<std::vector<int>> hsLagSet;
     std::vector<std::vector<double>> hsLambda;
+    bool fricLoopForced = false; // a mesh collision object with a friction coefficient switches the lagging loop on (Optimizer.cpp:156-161)
     bool solveFric() const
     {
+        if (fricLoopForced) return true;
         if (selfCollision && selfFric > 0.0) return true;
         for (double mu : hsFric)
             if (mu > 0.0) return true;
@@ -1103,6 +1105,7 @@ int orc_opt_next_subproblem(orc_opt* o)
 void orc_opt_set_dhat_target(orc_opt* o, double dHatTargetEps) { o->dHatTargetEps = dHatTargetEps; }
 void orc_opt_set_kappa(orc_opt* o, double kappa) { o->kappaConfig = kappa > 0.0 ? kappa : 0.0; }
 void orc_opt_set_damping(orc_opt* o, double dampingStiff) { o->dampingStiff = dampingStiff > 0.0 ? dampingStiff : 0.0; } // Config.cpp:141-147
+void orc_opt_force_friction_loop(orc_opt* o, int on) { o->fricLoopForced = on != 0; }
 void orc_opt_set_friction_scales(orc_opt* o, double scaleSelf, double scaleObstacle)
 {
     o->fricScaleSelf = scaleSelf;

@@ -157,6 +157,7 @@ bool CTCD::vertexVertexCTCD(const Eigen::Vector3d& q1s, const Eigen::Vector3d& q
     return advanceSmall(2, X, P, eta, t);
 }
 
+#ifndef IPCREF_PLUG_CTCD_ONLY // tests/adapters/: the executable that runs the reference's main() on the HIP adapters brings its own factory and main
 namespace IPC {
 
 template <typename vectorTypeI, typename vectorTypeS>
@@ -202,3 +203,4 @@ template class LinSysSolver<Eigen::VectorXi, Eigen::VectorXd>;
 int ipc_reference_main(int argc, char* argv[]); // main.cpp compiled with -Dmain=ipc_reference_main
 
 extern "C" int ipcref_main(int argc, char** argv) { return ipc_reference_main(argc, argv); }
+#endif // IPCREF_PLUG_CTCD_ONLY

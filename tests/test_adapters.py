@@ -58,6 +58,54 @@ def build_exe_ref():
     return EXE_REF
 
 
+MAIN_HIP = os.path.join(BUILD, "ipc_main_hip")
+REF_OBJ = os.path.join(ROOT, "oracle", "_ref", "obj")
+
+
+def _ref_includes():
+    return ["-I" + os.path.join(ROOT, "oracle", "refshim")] + ["-I" + os.path.join(REF_SRC, d) for d in
+            ("", "Utils", "CollisionObject", "Energy", "Energy/Physics_Elasticity", "LinSysSolver", "Utils/SVD", "TimeStepper")]
+
+
+def build_main_hip():
+    """tests/adapters/_build/ipc_main_hip: the reference's OWN main.cpp (compiled where it lies, tests/adapters/main_hook.hpp
+    pre-included: the one `new Optimizer` of main.cpp:1397 becomes `new HipOptimizer`) + include/adapters/HipOptimizer.hpp +
+    the reference's other compiled sources (the objects oracle/Makefile.ref built) + the factory line of
+    tests/adapters/main_hip_plug.cpp.  Build container only; the executable travels to the GPU box."""
+    from ipc_amd import build as b
+    b.build()
+    os.makedirs(BUILD, exist_ok=True)
+    hook = os.path.join(ROOT, "tests", "adapters", "main_hook.hpp")
+    plug = os.path.join(ROOT, "tests", "adapters", "main_hip_plug.cpp")
+    ctcd = os.path.join(ROOT, "oracle", "ref_plug.cpp")
+    deps = [hook, plug, ctcd, LIB_REF, os.path.join(ROOT, "include", "ipcgpu.h"), os.path.join(REF_SRC, "main.cpp")]
+    deps += [os.path.join(ROOT, "include", "adapters", f) for f in os.listdir(os.path.join(ROOT, "include", "adapters"))]
+    if os.path.exists(MAIN_HIP) and all(os.path.getmtime(MAIN_HIP) >= os.path.getmtime(d) for d in deps):
+        return MAIN_HIP
+    # the flags of oracle/Makefile.ref (no FMA contraction: what the reference computes on a machine without FMA)
+    flags = ["-O2", "-std=c++17", "-ffp-contract=off", "-w", "-DDIM=3", "-DNDEBUG", "-DIPC_DEFAULT_LINSYSSOLVER=LinSysSolverType::CHOLMOD",
+             "-DIPC_WITH_CHOLMOD", "-DIPCGPU_LINSYSSOLVER_TYPE=LinSysSolverType::CHOLMOD"] + _ref_includes() + [
+             "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "adapters")]
+    objs = []
+    jobs = [(os.path.join(REF_SRC, "main.cpp"), "main_hip.o", ["-Dmain=ipc_reference_main", "-include", hook]),
+            (plug, "main_hip_plug.o", []), (ctcd, "ctcd_plug.o", ["-DIPCREF_PLUG_CTCD_ONLY"])]
+    procs = []
+    for src, name, extra in jobs:
+        o = os.path.join(BUILD, name)
+        objs.append(o)
+        procs.append(subprocess.Popen(["g++"] + flags + extra + ["-c", src, "-o", o], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for pr in procs:
+        out = pr.communicate()[0]
+        assert pr.returncode == 0, out[-6000:]
+    for dirpath, _d, files in os.walk(REF_OBJ):  # the reference's other translation units, as compiled for libipcref.so
+        objs += [os.path.join(dirpath, f) for f in files if f.endswith(".o") and f not in ("main.o", "ref_plug.o", "ref_api.o")]
+    cmd = ["g++", "-o", MAIN_HIP] + objs + ["-L" + os.path.join(ROOT, "ipc_amd"), "-lipcgpu", "-L" + os.path.join(ROOT, "oracle", "_build"), "-lorc",
+           "-lstdc++fs", "-Wl,-rpath,$ORIGIN/../../../ipc_amd", "-Wl,-rpath,$ORIGIN/../../../oracle/_build", "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-6000:]
+    return MAIN_HIP
+
+
 @pytest.mark.skipif(not (os.path.isdir(REF_SRC) and os.path.exists(LIB_REF)), reason="the reference's headers exist in the build container only")
 def test_adapters_compile_and_link_against_the_reference_headers():
     exe = build_exe_ref()
@@ -78,7 +126,8 @@ def test_adapter_headers_use_only_the_public_c_abi():
         for line in txt.splitlines():
             if line.startswith("#include"):
                 inc = line.split()[1].strip('<>"')
-                assert inc in ("LinSysSolver.hpp", "Energy.hpp", "HipLinSysSolver.hpp", "ipcgpu.h", "stdexcept", "vector"), (f, inc)
+                assert inc in ("LinSysSolver.hpp", "Energy.hpp", "Optimizer.hpp", "HalfSpace.hpp", "HipLinSysSolver.hpp", "HipElasticEnergy.hpp", "ipcgpu.h",
+                               "algorithm", "array", "cmath", "cstdio", "cstdlib", "cstring", "limits", "memory", "stdexcept", "string", "vector"), (f, inc)
         assert "oracle" not in txt and "hip/hip_runtime" not in txt
 
 

@@ -171,6 +171,9 @@ class OracleBackend:
     def set_damping(self, stiff):
         self.o.set_damping(stiff)
 
+    def force_friction_loop(self, on=True):
+        self.orc.opt_force_friction_loop(self.o, on)
+
     def set_friction_scales(self, a, b):
         self.orc.opt_set_friction_scales(self.o, a, b)
 
