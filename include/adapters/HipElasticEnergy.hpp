@@ -52,14 +52,21 @@ class HipElasticEnergy : public Energy<3> {
     {
         if (rc < 0) throw std::runtime_error(ipcgpu_last_error());
     }
-    void positions(const Mesh<3>& data) const { chk(ipcgpu_set_positions(ctx, data.V.data())); }
+    int energyType_;
+    mutable bool typeSet_ = false;
+    void positions(const Mesh<3>& data) const
+    {
+        if (!typeSet_) { // the type is a property of the mesh on the device: handed over once the mesh is there (hipUploadMesh)
+            chk(ipcgpu_set_energy_type(ctx, energyType_));
+            typeSet_ = true;
+        }
+        chk(ipcgpu_set_positions(ctx, data.V.data()));
+    }
 
 public:
     // energyType: 0 = neo-Hookean (needs the inversion safeguard), 1 = fixed corotated (Config.cpp:107-111)
-    HipElasticEnergy(ipcgpu_ctx* shared, int energyType = 0) : Energy<3>(energyType == 0), ctx(shared)
-    {
-        chk(ipcgpu_set_energy_type(ctx, energyType));
-    }
+    // may be constructed before the mesh is uploaded (the optimizer adapter creates it ahead of its base class)
+    HipElasticEnergy(ipcgpu_ctx* shared, int energyType = 0) : Energy<3>(energyType == 0), ctx(shared), energyType_(energyType) {}
 
     void computeEnergyVal(const Mesh<3>& data, int, std::vector<AutoFlipSVD<Eigen::Matrix<double, 3, 3>>>&,
         std::vector<Eigen::Matrix<double, 3, 3>>&, double coef, double& energyVal) const override

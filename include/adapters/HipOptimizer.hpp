@@ -150,6 +150,7 @@ public:
         if (Parts::mode == HIP_OPT_PERCALL) {
             // the energy adapter evaluates on the mesh of the shared context: Mesh<3> as the base-class constructor left it
             hipUploadMesh(Parts::ctx, Base::result, Base::result.m_YM, Base::result.m_PR, Base::result.density);
+            chk(ipcgpu_opt_init(Parts::ctx, Base::dt, p_animConfig.withGravity ? 1 : 0)); // work buffers of the element kernels; the time step itself stays the base class's
             mirrorDBC();
         }
     }
