@@ -84,7 +84,7 @@ struct HipOptimizerParts {
     }
     static bool residentScript(AnimScriptType t)
     {
-        return t == AST_NULL || t == AST_TWIST || t == AST_FALL || t == AST_FALL_NOSHIFT || t == AST_DRAGRIGHT || t == AST_DCOFIX;
+        return t == AST_NULL || t == AST_TWIST || t == AST_FALL || t == AST_FALL_NOSHIFT || t == AST_DRAGRIGHT || t == AST_DCOFIX || t == AST_STRETCHNPAUSE;
     }
     HipOptimizerParts(const std::vector<Energy<3>*>& given, const Config& cfg, int requested, int device)
     {
@@ -133,7 +133,8 @@ class HipOptimizer : private HipOptimizerParts, public Optimizer<dim> {
 protected:
     int nSim = 0, nObst = 0; // nodes of Mesh<3>; nodes of the mesh collision objects riding along behind them
     bool uploaded = false, dragReleased = false;
-    int dragGroup = -1;
+    int dragGroup = -1, pauseTurn = -1, pauseGroup[2] = { -1, -1 };
+    std::vector<int> pauseIds[2];
     std::vector<unsigned char> dbcMirror_; // vertexDBCType as last handed to the device (percall)
     std::vector<double> bufV_, bufA_, bufB_, bufC_;
 
@@ -186,6 +187,7 @@ public:
         for (int iterI = 0; iterI < maxIter; ++iterI) {
             if (Base::globalIterNum >= Base::frameAmt) return 1;
             if (Base::animConfig.animScriptType == AST_DRAGRIGHT) dragRightRule();
+            if (Base::animConfig.animScriptType == AST_STRETCHNPAUSE) stretchPauseRule();
             int n = 0;
             chk(ipcgpu_opt_solve_timestep(Parts::ctx, 1 << 30, &n));
             Base::innerIterAmt += n;
@@ -246,6 +248,21 @@ protected:
             chk(ipcgpu_opt_end_dirichlet(Parts::ctx, dragGroup, Base::globalIterNum * Base::dt));
             dragReleased = true;
         }
+    }
+
+    // `script stretchAndPause` (AnimScripter.cpp:1605-1616): the handles are pulled apart while the turning vertex has not passed
+    // x = -0.28; from then on every Dirichlet node is held (ZERO)
+    void stretchPauseRule()
+    {
+        if (dragReleased || pauseTurn < 0) return;
+        if (Base::result.V(pauseTurn, 0) >= -0.28) return;
+        const double t = Base::globalIterNum * Base::dt, zero3[3] = { 0, 0, 0 };
+        for (int g = 0; g < 2; ++g) {
+            if (pauseIds[g].empty()) continue;
+            chk(ipcgpu_opt_end_dirichlet(Parts::ctx, pauseGroup[g], t));
+            chk(ipcgpu_opt_add_dirichlet(Parts::ctx, (int)pauseIds[g].size(), pauseIds[g].data(), zero3, zero3, t, std::numeric_limits<double>::infinity()));
+        }
+        dragReleased = true;
     }
 
     // device -> result.V / V_prev, velocity, acceleration, dx_Elastic (what saveStatus writes and main.cpp draws)
@@ -417,6 +434,29 @@ protected:
             if (!ids.empty()) {
                 chk(ipcgpu_opt_add_dirichlet(ctx, (int)ids.size(), ids.data(), lin, zero3, 0.0, inf));
                 dragGroup = 0;
+            }
+        }
+        else if (cfg.animScriptType == AST_STRETCHNPAUSE) {
+            // AnimScripter.cpp:475-500: the nodes within 1 % of the left / right end (the NONZERO nodes the constructor picked) move at
+            // 1 in -x / +x; the turning vertex is the last left handle in index order
+            double lo = 1.0e300, hi = -1.0e300;
+            for (int v = 0; v < nSim; ++v) {
+                lo = std::min(lo, m.V(v, 0));
+                hi = std::max(hi, m.V(v, 0));
+            }
+            for (int v = 0; v < nSim; ++v) {
+                if (m.V(v, 0) < lo + (hi - lo) * 0.01) {
+                    pauseIds[0].push_back(v);
+                    pauseTurn = v;
+                }
+                else if (m.V(v, 0) > hi - (hi - lo) * 0.01) pauseIds[1].push_back(v);
+            }
+            int group = 0;
+            for (int g = 0; g < 2; ++g) {
+                if (pauseIds[g].empty()) continue;
+                const double lin[3] = { g == 0 ? -1.0 : 1.0, 0.0, 0.0 };
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)pauseIds[g].size(), pauseIds[g].data(), lin, zero3, 0.0, inf));
+                pauseGroup[g] = group++;
             }
         }
         // Neumann groups (Optimizer.cpp:3241-3250; AnimScripter::isNBCActive)

@@ -115,7 +115,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix"):
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "stretchAndPause"):
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
             elif k == "warmStart":  # initX option (Optimizer.cpp:925-1080); 5 (Jacobi guess) is not restated
@@ -344,6 +344,17 @@ class AssembledScene:
         if r is None or r["done"]:
             return False
         x = np.asarray(be.state()["V"]).reshape(-1, 3)
+        if r.get("kind") == "pause":
+            # `script stretchAndPause` (AnimScripter.cpp:1605-1616): the handles move while the turning vertex has not passed x = -0.28;
+            # from then on every Dirichlet node is held (vertexDBCType ZERO)
+            if x[r["turn"], 0] >= r["x_limit"]:
+                return False
+            for g in r["groups"]:
+                be.end_dirichlet(g, t)
+            for ids in r["ids"]:
+                be.add_dirichlet(ids, lin_vel=(0.0, 0.0, 0.0), ang_vel_deg=(0.0, 0.0, 0.0), t0=t, t1=float("inf"))
+            r["done"] = True
+            return True
         if x[: r["nSim"], 0].min() > r["x_limit"]:
             be.end_dirichlet(r["group"], t)
             r["done"] = True
@@ -458,6 +469,15 @@ def assemble(cfg, read_mesh):
         dirichlet = [(ids, (0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
         limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
         release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}
+    if cfg.script == "stretchAndPause":
+        # AnimScripter.cpp:475-500: the nodes within 1 % of the left / right end of the model are NONZERO handles pulled apart at 1 in
+        # -x / +x; the turning vertex is the LAST left handle in index order (`turningPointAdded` is never set), the limit x = -0.28
+        U = V if V0 is None else V0
+        lo, hi = U[:nSim].min(0), U[:nSim].max(0)
+        left = np.nonzero(U[:nSim, 0] < lo[0] + 0.01 * (hi[0] - lo[0]))[0].astype(np.int32)
+        right = np.nonzero((U[:nSim, 0] > hi[0] - 0.01 * (hi[0] - lo[0])) & ~(U[:nSim, 0] < lo[0] + 0.01 * (hi[0] - lo[0])))[0].astype(np.int32)
+        dirichlet = [(left, (-1.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf")), (right, (1.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
+        release = {"kind": "pause", "turn": int(left[-1]), "x_limit": -0.28, "groups": [0, 1], "ids": [left, right], "done": False}
     vel = np.zeros_like(V)
     fixed = np.zeros(V.shape[0], dtype=bool)
     for ids, *_ in dirichlet:

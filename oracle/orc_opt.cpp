@@ -939,6 +939,13 @@ int orc_opt_newton_iter(orc_opt* o)
     o->lastAlphaFeasible = alpha;
     lineSearch(o, alpha);
     o->lastStepSize = alpha;
+    if (std::getenv("ORC_TRACE")) { // debugging aid: one line per Newton iteration, comparable with the reference's spdlog lines (IPCREF_LOG)
+        double g2 = 0, pInf = 0;
+        for (double v : o->gradient) g2 += v * v;
+        for (double v : o->searchDir) pInf = std::max(pInf, std::fabs(v));
+        std::fprintf(stderr, "[orc] step %d k %d kappa %.10g dHat %.10g fricDHat %.10g #c %zu #para %zu ||g||^2 %.10g |p|inf %.10g alphaFeasible %.10g alpha %.10g E %.12g\n",
+            o->globalIterNum, o->k, o->kappa, o->dHat, o->fricDHat, o->cs.active.size(), o->cs.paraEE.size(), g2, pInf, o->lastAlphaFeasible, alpha, o->lastEnergyVal);
+    }
     postLineSearch(o);
     // Dirichlet nodes that could not reach their scripted targets: augmented-Lagrangian pull (Optimizer.cpp:2168-2203)
     if (o->projDBC) {

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import GOLD, MORE_SCENES, check_damped_bar, check_scene, load_scene, rel, run_scene
+from test_oracle_vs_reference import GOLD, MORE_SCENES, RESTART_SCENES, check_damped_bar, check_restart, check_scene, load_scene, rel, run_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -206,10 +206,22 @@ def test_more_scenes_against_the_reference(name, exact, mism, tol, gpu_lib):
     the resting steps of the friction variant), so the total work and the end positions are compared instead."""
     S, meshes = load_scene(name)
     c = gpu_lib.Context(0)
-    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    pos, its = run_scene(S, meshes, c, min(int(S["steps"]), 30))
     ref_its = S["iters"][:len(its)]
     report = (its.tolist(), ref_its.tolist())
     # (1e-9 before the touch-down: the homotopy scene solves barrier problems at a dHat of half the scene from its first step on)
     check_scene(S, pos, its, exact, len(its), 10 * tol, exact_tol=1e-9)
     assert abs(int(its.sum()) - int(ref_its.sum())) <= 0.25 * int(ref_its.sum()), report
+    c.close()
+
+
+@pytest.mark.parametrize("name,tol", RESTART_SCENES)
+def test_continuation_from_the_references_own_state(name, tol, tmp_path, gpu_lib):
+    """The HIP time stepper continued from the reference's own post-contact status file (ipcgpu_opt_load_status): the reference's Newton
+    iteration count in EVERY step, positions to round-off growth (the barrier scatter's summation order adds a few ulps per step)."""
+    S, meshes = load_scene(name)
+    if "restart_status" not in S.files:
+        pytest.skip("fixture without a continuation")
+    c = gpu_lib.Context(0)
+    check_restart(S, meshes, c, tmp_path, 10 * tol)
     c.close()

@@ -187,8 +187,16 @@ SCENES = [
     ("cubes_dhat_homotopy", "paperExamples/supplementB/SQPBenchmark/11_cubes.txt", "", 20),
     # `rotateModel` (start positions turned against the rest shape), `tuning 2` homotopy, warm start 1, point-triangle impact
     ("point_triangle_rotated", "paperExamples/supplementB/SQPBenchmark/04_pointTriangle.txt", "", 45),
-    ("two_cubes_nm_damped", "tutorialExamples/advanced/2cubesFall_NM.txt", "\ntime 5 0.025\n", 30),  # every step written at this step size
+    ("two_cubes_nm_damped", "tutorialExamples/advanced/2cubesFall_NM.txt", "\ntime 5 0.025\n", 36),  # every step written at this step size
 ]
+
+
+# Restart fixtures: the reference run is continued from ITS OWN status file at step R (`restart <file>`, Optimizer.cpp:179-248) for K more
+# steps, and that second run is what the fixture holds.  Both implementations then start from one and the same post-contact state --
+# deformed, moving, constraints active -- so every step can be held to round-off instead of "the same minimiser within the Newton
+# tolerance": the scenes above all touch down from exact rest (F = I), where IglUtils::makePD2d is decided by round-off.
+RESTARTS = {"two_cubes_fall": (30, 8), "aligned_cubes": (20, 8), "aligned_cubes_fric": (24, 10), "cubes_dhat_homotopy": (14, 4),
+            "two_cubes_nm_damped": (28, 8), "rotate_co": (20, 8)}
 
 
 def scenes(only=()):
@@ -205,7 +213,25 @@ def scenes(only=()):
             assert rcode == 0, log[-2000:]
             its = rc.read_iter_counts(os.path.join(tmp, "ref"), steps)
             pos = np.array([rc.read_status_positions(os.path.join(tmp, "ref", f"status{s + 1}")) for s in range(steps)])
-        out = dict(script=np.array(text), steps=steps, positions=pos, iters=its)
+            extra = {}
+            if name in RESTARTS:
+                R, K = RESTARTS[name]
+                status = open(os.path.join(tmp, "ref", f"status{R}")).read()
+                spath = os.path.join(tmp, "restart_status")
+                open(spath, "w").write(status)
+                path2 = os.path.join(tmp, "scene_restart.txt")
+                open(path2, "w").write("\n".join(lines) + f"\ntime {(R + K) * cfg.dt:.17g} {cfg.dt:.17g}\nrestart {spath}\n")
+                rcode, log = rc.run_reference(path2, os.path.join(tmp, "ref2"))
+                assert rcode == 0, log[-2000:]
+                cum = []
+                for sN in range(R + 1, R + K + 1):
+                    with open(os.path.join(tmp, "ref2", f"info{sN}.txt")) as fh:
+                        fh.readline()
+                        cum.append(int(fh.readline().split()[1]))
+                extra = dict(restart_step=R, restart_status=np.array(status), restart_iters=np.diff(np.array([0] + cum)),
+                             restart_positions=np.array([rc.read_status_positions(os.path.join(tmp, "ref2", f"status{sN}")) for sN in range(R + 1, R + K + 1)]))
+                print(f"  restart at step {R}: Newton iterations {extra['restart_iters'].tolist()}")
+        out = dict(script=np.array(text), steps=steps, positions=pos, iters=its, **extra)
         keys = []
         for pth in [sh.path for sh in cfg.shapes] + [mc[0] for mc in cfg.mesh_cos]:  # every mesh file the script names travels with the fixture
             key = os.path.relpath(pth, REF_ROOT)
