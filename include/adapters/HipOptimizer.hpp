@@ -84,7 +84,8 @@ struct HipOptimizerParts {
     }
     static bool residentScript(AnimScriptType t)
     {
-        return t == AST_NULL || t == AST_TWIST || t == AST_FALL || t == AST_FALL_NOSHIFT || t == AST_DRAGRIGHT || t == AST_DCOFIX || t == AST_STRETCHNPAUSE;
+        return t == AST_NULL || t == AST_TWIST || t == AST_FALL || t == AST_FALL_NOSHIFT || t == AST_DRAGRIGHT || t == AST_DCOFIX || t == AST_STRETCHNPAUSE
+            || t == AST_DCOSQUASH || t == AST_DCOSQUASH6 || t == AST_DCOROTCYLINDERS || t == AST_DCOVERSCHOORROLLER || t == AST_DCOSQUEEZEOUT;
     }
     HipOptimizerParts(const std::vector<Energy<3>*>& given, const Config& cfg, int requested, int device)
     {
@@ -135,6 +136,7 @@ protected:
     bool uploaded = false, dragReleased = false;
     int dragGroup = -1, pauseTurn = -1, pauseGroup[2] = { -1, -1 };
     std::vector<int> pauseIds[2];
+    std::vector<std::array<double, 3>> plateVel; // DCOSquash / DCOSquash6: current velocity of every plate
     std::vector<unsigned char> dbcMirror_; // vertexDBCType as last handed to the device (percall)
     std::vector<double> bufV_, bufA_, bufB_, bufC_;
 
@@ -188,6 +190,7 @@ public:
             if (Base::globalIterNum >= Base::frameAmt) return 1;
             if (Base::animConfig.animScriptType == AST_DRAGRIGHT) dragRightRule();
             if (Base::animConfig.animScriptType == AST_STRETCHNPAUSE) stretchPauseRule();
+            if (Base::animConfig.animScriptType == AST_DCOSQUASH || Base::animConfig.animScriptType == AST_DCOSQUASH6) squashRule();
             int n = 0;
             chk(ipcgpu_opt_solve_timestep(Parts::ctx, 1 << 30, &n));
             Base::innerIterAmt += n;
@@ -247,6 +250,22 @@ protected:
         if (left > rightMost) {
             chk(ipcgpu_opt_end_dirichlet(Parts::ctx, dragGroup, Base::globalIterNum * Base::dt));
             dragReleased = true;
+        }
+    }
+
+    // `script DCOSquash / DCOSquash6` (AnimScripter.cpp:2034-2074): while the first two plates are closer than 0.1 in x, every plate
+    // velocity changes sign -- once per time step, as written
+    void squashRule()
+    {
+        const Mesh<dim>& m = Base::result;
+        double co0right = -1.0e300, co1left = 1.0e300;
+        for (int v = m.componentNodeRange[0]; v < m.componentNodeRange[1]; ++v) co0right = std::max(co0right, m.V(v, 0));
+        for (int v = m.componentNodeRange[1]; v < m.componentNodeRange[2]; ++v) co1left = std::min(co1left, m.V(v, 0));
+        if (!(co1left - co0right < 0.1)) return;
+        const double zero3[3] = { 0, 0, 0 };
+        for (size_t g = 0; g < plateVel.size(); ++g) {
+            for (int c = 0; c < 3; ++c) plateVel[g][c] = -plateVel[g][c];
+            chk(ipcgpu_opt_set_dirichlet_motion(Parts::ctx, (int)g, plateVel[g].data(), zero3, nullptr, 1));
         }
     }
 
@@ -457,6 +476,45 @@ protected:
                 const double lin[3] = { g == 0 ? -1.0 : 1.0, 0.0, 0.0 };
                 chk(ipcgpu_opt_add_dirichlet(ctx, (int)pauseIds[g].size(), pauseIds[g].data(), lin, zero3, 0.0, inf));
                 pauseGroup[g] = group++;
+            }
+        }
+        else if (cfg.animScriptType == AST_DCOSQUASH || cfg.animScriptType == AST_DCOSQUASH6 || cfg.animScriptType == AST_DCOROTCYLINDERS
+            || cfg.animScriptType == AST_DCOVERSCHOORROLLER) {
+            // whole leading components moved by the script, all their nodes NONZERO (AnimScripter.cpp:1060-1221 set-up, :1961-2074 per step)
+            static const double S6[6][3] = { { 1, 0, 0 }, { -1, 0, 0 }, { 0, 1, 0 }, { 0, -1, 0 }, { 0, 0, 1 }, { 0, 0, -1 } };
+            static const double RC[4][3] = { { M_PI / 2, 0, 0 }, { -M_PI / 2, 0, 0 }, { 0, 0, -M_PI / 2 }, { 0, 0, M_PI / 2 } };
+            static const double VR[6][3] = { { 0, 0, -4 }, { 0, 0, -2 }, { 0, 0, 2 }, { 0, 0, 4 }, { 2, 0, 0 }, { -2, 0, 0 } };
+            const bool rot = cfg.animScriptType == AST_DCOROTCYLINDERS || cfg.animScriptType == AST_DCOVERSCHOORROLLER;
+            const int n = cfg.animScriptType == AST_DCOSQUASH ? 2 : (cfg.animScriptType == AST_DCOROTCYLINDERS ? 4 : 6);
+            if ((int)m.componentNodeRange.size() < n + 2) throw std::runtime_error("HipOptimizer: the script needs more components");
+            for (int compI = 0; compI < n; ++compI) {
+                std::vector<int> ids;
+                double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+                for (int v = m.componentNodeRange[compI]; v < m.componentNodeRange[compI + 1]; ++v) {
+                    ids.push_back(v);
+                    for (int c = 0; c < 3; ++c) {
+                        lo[c] = std::min(lo[c], m.V(v, c));
+                        hi[c] = std::max(hi[c], m.V(v, c));
+                    }
+                }
+                const double* lin = rot ? zero3 : S6[compI];
+                const double* ang = !rot ? zero3 : (cfg.animScriptType == AST_DCOROTCYLINDERS ? RC[compI] : VR[compI]);
+                const double ctr[3] = { 0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2]) }; // MCORotCenter: fixed at set-up
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)ids.size(), ids.data(), lin, ang, 0.0, inf));
+                chk(ipcgpu_opt_set_dirichlet_motion(ctx, compI, lin, ang, rot ? ctr : nullptr, 1));
+                if (!rot) plateVel.push_back({ lin[0], lin[1], lin[2] });
+            }
+        }
+        else if (cfg.animScriptType == AST_DCOSQUEEZEOUT) {
+            // every surface-only component is a held NONZERO node set (AnimScripter.cpp:1261-1280).  The rule that would move the first one
+            // down (:2102-2124) never fires as shipped: bottomMin starts at -infinity and is updated with std::min, the test compares with NaN
+            int group = 0;
+            for (size_t compI = 0; compI < m.componentCoDim.size(); ++compI) {
+                if (m.componentCoDim[compI] >= 3) continue;
+                std::vector<int> ids;
+                for (int v = m.componentNodeRange[compI]; v < m.componentNodeRange[compI + 1]; ++v) ids.push_back(v);
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)ids.size(), ids.data(), zero3, zero3, 0.0, inf));
+                chk(ipcgpu_opt_set_dirichlet_motion(ctx, group++, zero3, zero3, nullptr, 1));
             }
         }
         // Neumann groups (Optimizer.cpp:3241-3250; AnimScripter::isNBCActive)

@@ -312,6 +312,14 @@ int ipcgpu_opt_add_dirichlet(ipcgpu_ctx*, int n, const int* vert_ids, const doub
  * AnimScripter::stepAnimScript -- e.g. `script dragright` lets go of the handle once the body has been pulled past the
  * obstacles (AnimScripter.cpp:1619-1632); the condition is the caller's. */
 int ipcgpu_opt_end_dirichlet(ipcgpu_ctx*, int group, double t_end);
+/* The hard-coded scripted motions of AnimScripter::stepAnimScript that move whole components by a rule evaluated on the current state
+ * (`script DCOSquash / DCOSquash6 / DCOSqueezeOut / DCORotCylinders / DCOVerschoorRoller`, AnimScripter.cpp:1060-1300 set-up, :1961-2135
+ * per step): the caller evaluates the rule before a time step and hands the group's motion for that step over.  center3 != NULL: the
+ * rotation turns about this fixed point (MCORotCenter, the component's bounding-box centre at set-up) instead of the centre of the
+ * group's current bounding box; force_nonzero: the nodes are NONZERO Dirichlet nodes even while their velocity is zero, as those
+ * scripts type them (it decides whether they are released with the others when a scripted move is cut short, Optimizer.cpp:2168-2203). */
+int ipcgpu_opt_set_dirichlet_motion(ipcgpu_ctx*, int group, const double* lin_vel3, const double* ang_vel3, const double* center3 /*nullable*/,
+    int force_nonzero);
 /* One Mesh::NeumannBCs entry (src/Mesh.hpp:47-56; `NBC bboxMin bboxMax force [t0 t1]` on a shape line, src/Config.cpp:264-280):
  * while t0 <= stepStartTime < t1 every listed vertex that is not a Dirichlet node feels the acceleration `accel3` -- the
  * incremental potential gets -dt^2 m_v accel . x_v, the gradient -dt^2 m_v accel (Optimizer.cpp:3241-3250, 3452-3461). */

@@ -1196,6 +1196,25 @@ int ipcgpu_opt_end_dirichlet(ipcgpu_ctx* c, int group, double t_end)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_dirichlet_motion(ipcgpu_ctx* c, int group, const double* lin3, const double* ang3, const double* center3, int forceNonzero)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        needArg(group >= 0 && group < (int)o.dbcGroups.size(), "no such Dirichlet group");
+        needArg(lin3 && ang3, "null velocity");
+        auto& g = *o.dbcGroups[group];
+        for (int k = 0; k < 3; ++k) {
+            g.lin[k] = lin3[k];
+            g.ang[k] = ang3[k];
+            if (center3) g.center[k] = center3[k];
+        }
+        g.hasCenter = center3 != nullptr;
+        g.forceNonzero = forceNonzero != 0;
+        o.setDBCVertices();
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_add_neumann(ipcgpu_ctx* c, int n, const int* ids, const double* accel3, double t0, double t1)
 {
     return guarded([&] {

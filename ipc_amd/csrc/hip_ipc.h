@@ -168,7 +168,11 @@ public:
         DevBuf<int> d_ids;
         DevBuf<double> d_pos;
         double lin[3], ang[3], t0, t1;
-        bool isZero() const { return lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
+        // the hard-coded scripts of AnimScripter.cpp:1961-2135 (DCOSquash6, DCOSqueezeOut, DCORotCylinders, ...): every node of the group is a
+        // NONZERO Dirichlet node whatever its velocity currently is, and rotations turn about a centre fixed at set-up time
+        bool forceNonzero = false, hasCenter = false;
+        double center[3] = { 0, 0, 0 };
+        bool isZero() const { return !forceNonzero && lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
     };
     std::vector<std::unique_ptr<DbcGroup>> dbcGroups;
     // Mesh::NeumannBCs (Mesh.hpp:47-56): a mass-weighted acceleration on a vertex set while t0 <= stepStartTime < t1

@@ -216,7 +216,7 @@ bool HipOptimizer::dbcGroupMotion()
                 hi[c] = std::max(hi[c], pos[3 * (size_t)i + c]);
             }
         for (int c = 0; c < 3; ++c) {
-            m.c[c] = (lo[c] + hi[c]) / 2;
+            m.c[c] = g->hasCenter ? g->center[c] : (lo[c] + hi[c]) / 2;
             m.linDt[c] = g->lin[c] * dt;
         }
         const double ax = g->ang[0] * dt, ay = g->ang[1] * dt, az = g->ang[2] * dt;

@@ -584,6 +584,14 @@ class Context:
         ang = _f64(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
         self._chk(self._L.ipcgpu_opt_add_dirichlet(self.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1)))
 
+    def set_dirichlet_motion(self, group, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), center=None, force_nonzero=True):
+        """Motion of Dirichlet group `group` for the coming time steps (the rule-driven scripts of AnimScripter.cpp:1961-2135)."""
+        lin = _f64(np.asarray(lin_vel, dtype=np.float64))
+        ang = _f64(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
+        ctr = None if center is None else _f64(np.asarray(center, dtype=np.float64))
+        self._chk(self._L.ipcgpu_opt_set_dirichlet_motion(self.h, C.c_int(group), _dp(lin), _dp(ang), None if ctr is None else _dp(ctr),
+                                                          C.c_int(int(force_nonzero))))
+
     def end_dirichlet(self, group, t_end):
         """Free the vertices of Dirichlet group `group` from the time step starting at t_end on (scripts that let go of a handle)."""
         self._chk(self._L.ipcgpu_opt_end_dirichlet(self.h, C.c_int(group), C.c_double(t_end)))

@@ -74,6 +74,7 @@ class SceneConfig:
     damping_ratio: float = 0.0
     tol: float = 1e-2
     script: str = "null"
+    script_params: list = field(default_factory=list)
     size: float = -1.0  # > 0: the assembled model is scaled so that its largest extent is `size` and moved to the origin (main.cpp:1140-1145)
     warm_start: int = 0  # initX option
     restart: str = None
@@ -115,9 +116,11 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "stretchAndPause"):
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") and a[0] not in DCO_SCRIPTS:
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
+                if len(a) > 1 and int(a[1]) > 0:  # `script name n p1 .. pn` (Config.cpp:166-175): parameters of the script
+                    cfg.script_params = [float(x) for x in a[2:2 + int(a[1])]]
             elif k == "warmStart":  # initX option (Optimizer.cpp:925-1080); 5 (Jacobi guess) is not restated
                 if int(a[0]) not in (0, 1, 2, 3, 4):
                     raise UnsupportedKeyword(f"warmStart {a[0]}")
@@ -320,6 +323,19 @@ def read_obj(path):
     return np.array(V, dtype=np.float64).reshape(-1, 3), np.array(F, dtype=np.int32).reshape(-1, 3)
 
 
+# The hard-coded scripts of AnimScripter that move whole components (set-up AnimScripter.cpp:1060-1300, per step :1961-2135): how many
+# leading components they move and with what.  Linear velocities in units / s, angular velocities in rad / s about x, y, z.
+_S6 = [(1.0, 0, 0), (-1.0, 0, 0), (0, 1.0, 0), (0, -1.0, 0), (0, 0, 1.0), (0, 0, -1.0)]
+_HP = math.pi / 2.0
+DCO_SCRIPTS = {
+    "DCOSquash": {"n": 2, "lin": _S6[:2]},  # two plates closing along x, turning round when 0.1 apart (:1172-1191, 2034-2051)
+    "DCOSquash6": {"n": 6, "lin": _S6},  # six plates closing along x, y, z (the trash compactor; :1193-1221, 2053-2074)
+    "DCORotCylinders": {"n": 4, "ang": [(_HP, 0, 0), (-_HP, 0, 0), (0, 0, -_HP), (0, 0, _HP)]},  # :1060-1086, 1961-1975
+    "DCOVerschoorRoller": {"n": 6, "ang": [(0, 0, -4.0), (0, 0, -2.0), (0, 0, 2.0), (0, 0, 4.0), (2.0, 0, 0), (-2.0, 0, 0)]},  # :1088-1118, 1977-1991
+    "DCOSqueezeOut": {"n": 0},  # every surface-only component is held (the rule of :2102-2124 that would move the first one never fires, see assemble)
+}
+
+
 @dataclass
 class AssembledScene:
     cfg: SceneConfig
@@ -337,6 +353,7 @@ class AssembledScene:
     codim_mass: np.ndarray = None  # ... and their lumped masses (density x a third of the adjacent triangle areas, Mesh.cpp:310-345)
     codim_fixed: np.ndarray = None  # `script DCOFix`: those of them held as NONZERO Dirichlet nodes (AnimScripter.cpp:1222-1236)
     V0: np.ndarray = None  # start positions when they differ from the rest shape V (`rotateModel`, main.cpp:1115-1139)
+    motions: list = None  # rule-driven scripts: per Dirichlet group (lin, ang in degrees, fixed rotation centre or None), nodes NONZERO throughout
 
     def before_step(self, be, t):
         """What AnimScripter::stepAnimScript decides from the state before a time step (call with the step's start time)."""
@@ -344,6 +361,17 @@ class AssembledScene:
         if r is None or r["done"]:
             return False
         x = np.asarray(be.state()["V"]).reshape(-1, 3)
+        if r.get("kind") == "dco":
+            nr = self.node_ranges
+            if r["script"] in ("DCOSquash", "DCOSquash6"):
+                # AnimScripter.cpp:2034-2074: while the first two plates are closer than 0.1 in x, EVERY velocity changes sign -- once per
+                # time step, as written
+                if x[nr[1]:nr[2], 0].min() - x[nr[0]:nr[1], 0].max() < 0.1:
+                    r["lin"] = [tuple(-c for c in v) for v in r["lin"]]
+                    for g, v in enumerate(r["lin"]):
+                        be.set_dirichlet_motion(g, lin_vel=v, force_nonzero=True)
+                    return True
+            return False
         if r.get("kind") == "pause":
             # `script stretchAndPause` (AnimScripter.cpp:1605-1616): the handles move while the turning vertex has not passed x = -0.28;
             # from then on every Dirichlet node is held (vertexDBCType ZERO)
@@ -452,12 +480,12 @@ def assemble(cfg, read_mesh):
             for k in range(3):
                 np.add.at(m, tri[:, k], cfg.rho * a / 3.0)
         codim_mass = m[codim_nodes]
-        if cfg.script == "DCOFix":  # AnimScripter.cpp:1222-1236: every codimensional component is held (NONZERO, no motion)
+        if cfg.script in ("DCOFix", "DCOBallHitWall"):  # AnimScripter.cpp:1222-1236: every codimensional component is held (NONZERO, no motion)
             dirichlet = []
             codim_fixed = codim_nodes
-        elif not all(moved for _i, _f, moved in codim):
+        elif cfg.script not in DCO_SCRIPTS and not all(moved for _i, _f, moved in codim):
             raise UnsupportedKeyword("codimensional shape that no script fixes or moves")
-    elif cfg.script == "DCOFix":
+    elif cfg.script in ("DCOFix", "DCOBallHitWall"):
         dirichlet = []  # mesh.resetDBCVertices(); nothing to hold
     release = None
     if cfg.script == "dragright":
@@ -469,6 +497,38 @@ def assemble(cfg, read_mesh):
         dirichlet = [(ids, (0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
         limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
         release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}
+    motions = None  # per Dirichlet group: (lin, ang in degrees, fixed centre or None) with the nodes typed NONZERO throughout
+    if cfg.script in DCO_SCRIPTS:
+        spec = DCO_SCRIPTS[cfg.script]
+        U = V if V0 is None else V0
+        dirichlet, motions = [], []
+        codim_comp = {int(ids[0]): True for ids, _f, _m in codim}  # first node of every surface-only component
+        if cfg.script == "DCOSqueezeOut":
+            # Every surface-only component is a NONZERO Dirichlet node set (AnimScripter.cpp:1261-1280); the first one carries a velocity of
+            # 0.3 downwards that is applied while `topMax > bottomMin + (bottomMax - bottomMin) / 3.8 * 0.9` (:2102-2124).  As shipped that
+            # test is never true: bottomMin starts at -infinity and is updated with std::min, so it STAYS -infinity and the right-hand side
+            # is -inf + inf = NaN.  Seen in a run of the reference-compiled code (the plane does not move); restated as what it does.
+            comps = [c for c in range(len(cfg.shapes)) if nr[c] in codim_comp]  # mesh.componentCoDim[compI] < 3
+            for c in comps:
+                dirichlet.append((np.arange(nr[c], nr[c + 1], dtype=np.int32), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf")))
+                motions.append(((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), None))
+            release = None
+        else:
+            n = spec["n"]
+            if len(cfg.shapes) < n + 1:
+                raise UnsupportedKeyword(f"script {cfg.script} needs {n} scripted components and a body")
+            for c in range(n):
+                ids = np.arange(nr[c], nr[c + 1], dtype=np.int32)
+                lin = tuple(float(x) for x in spec["lin"][c]) if "lin" in spec else (0.0, 0.0, 0.0)
+                ang = tuple(math.degrees(x) for x in spec["ang"][c]) if "ang" in spec else (0.0, 0.0, 0.0)
+                ctr = tuple(0.5 * (U[ids].max(0) + U[ids].min(0))) if "ang" in spec else None  # MCORotCenter: fixed at set-up
+                dirichlet.append((ids, lin, ang, 0.0, float("inf")))
+                motions.append((lin, ang, ctr))
+            release = {"kind": "dco", "script": cfg.script, "done": False, "lin": [m[0] for m in motions]} if "lin" in spec else None
+            comps = list(range(n))
+        if any(nr[c] in codim_comp and c not in comps for c in range(len(cfg.shapes))):
+            raise UnsupportedKeyword("surface-only component that the script neither moves nor holds")
+        codim_fixed = None
     if cfg.script == "stretchAndPause":
         # AnimScripter.cpp:475-500: the nodes within 1 % of the left / right end of the model are NONZERO handles pulled apart at 1 in
         # -x / +x; the turning vertex is the LAST left handle in index order (`turningPointAdded` is never set), the limit x = -0.28
@@ -482,8 +542,13 @@ def assemble(cfg, read_mesh):
     fixed = np.zeros(V.shape[0], dtype=bool)
     for ids, *_ in dirichlet:
         fixed[ids] = True
-    for s, sh in enumerate(cfg.shapes):  # AnimScripter::initVelocity (AnimScripter.cpp:1319-1333)
-        if sh.init_vel is None:
+    if cfg.script == "DCOBallHitWall":  # AnimScripter.cpp:1376-1389: every node of a tetrahedral component starts at v_x (default 1000)
+        vx = cfg.script_params[0] if cfg.script_params and cfg.script_params[0] == cfg.script_params[0] else 1000.0
+        for s in range(len(cfg.shapes)):
+            if tr[s + 1] > tr[s]:
+                vel[nr[s]:nr[s + 1], 0] = vx
+    for s, sh in enumerate(cfg.shapes):  # AnimScripter::initVelocity (AnimScripter.cpp:1319-1333): `initVel` under `script null` only
+        if sh.init_vel is None or cfg.script != "null" or not tr[s + 1] > tr[s]:
             continue
         a, b = nr[s], nr[s + 1]
         ctr = 0.5 * (V[a:b].max(0) + V[a:b].min(0))
@@ -492,7 +557,9 @@ def assemble(cfg, read_mesh):
         v[fixed[a:b]] = 0.0
         vel[a:b] = v
     obst = np.concatenate(obstacle) if obstacle else None
-    return AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release, codim_nodes, codim_mass, codim_fixed, V0)
+    sc = AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release, codim_nodes, codim_mass, codim_fixed, V0)
+    sc.motions = motions
+    return sc
 
 
 def apply(sc, be):
@@ -550,8 +617,10 @@ def apply(sc, be):
         be.set_dhat_target(cfg.dHat_target)
     if cfg.damping_stiff > 0:
         be.set_damping(cfg.damping_stiff)
-    for ids, lin, ang, t0, t1 in sc.dirichlet:
+    for g, (ids, lin, ang, t0, t1) in enumerate(sc.dirichlet):
         be.add_dirichlet(ids, lin_vel=lin, ang_vel_deg=ang, t0=t0, t1=t1)
+        if sc.motions is not None:
+            be.set_dirichlet_motion(g, lin_vel=sc.motions[g][0], ang_vel_deg=sc.motions[g][1], center=sc.motions[g][2], force_nonzero=True)
     for ids, acc, t0, t1 in sc.neumann:
         be.add_neumann(ids, acc, t0=t0, t1=t1)
     if cfg.script == "twist":

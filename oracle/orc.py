@@ -483,6 +483,14 @@ def opt_end_dirichlet(opt: "Optimizer", group, t_end):
     lib().orc_opt_end_dirichlet(opt.h, C.c_int(group), C.c_double(t_end))
 
 
+def opt_set_dirichlet_motion(opt: "Optimizer", group, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), center=None, force_nonzero=True):
+    """Motion of Dirichlet group `group` for the coming time steps (the rule-driven scripts of AnimScripter.cpp:1961-2135)."""
+    lin = np.ascontiguousarray(lin_vel, dtype=np.float64)
+    ang = np.ascontiguousarray(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
+    ctr = None if center is None else np.ascontiguousarray(center, dtype=np.float64)
+    lib().orc_opt_set_dirichlet_motion(opt.h, C.c_int(group), _dp(lin), _dp(ang), None if ctr is None else _dp(ctr), C.c_int(int(force_nonzero)))
+
+
 def opt_add_neumann(opt: "Optimizer", ids, accel, t0=0.0, t1=float("inf")):
     """One `NBC bboxMin bboxMax force [t0 t1]` entry of a shape line (Config.cpp:264-280)."""
     ids = np.ascontiguousarray(ids, dtype=np.int32)

@@ -43,7 +43,9 @@ struct orc_opt {
     struct DBCGroup {
         std::vector<int> ids;
         double lin[3], ang[3], t0, t1;
-        bool isZero() const { return lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
+        bool forceNonzero = false, hasCenter = false; // the hard-coded DCO scripts (AnimScripter.cpp:1060-1300, 1961-2135)
+        double center[3] = { 0, 0, 0 };
+        bool isZero() const { return !forceNonzero && lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
     };
     std::vector<DBCGroup> dbcGroups;
     // Mesh::NeumannBCs (Mesh.hpp:47-56): `NBC bboxMin bboxMax force [t0 t1]` of a shape line (Config.cpp:264-280); `force` is an
@@ -697,7 +699,7 @@ static void dbcGroupMotion(orc_opt* o, const orc_opt::DBCGroup& g)
             hi[c] = std::max(hi[c], m.V[v + m.nV * c]);
         }
     double ctr[3];
-    for (int c = 0; c < 3; ++c) ctr[c] = (lo[c] + hi[c]) / 2;
+    for (int c = 0; c < 3; ++c) ctr[c] = g.hasCenter ? g.center[c] : (lo[c] + hi[c]) / 2;
     for (int v : g.ids) {
         const double d[3] = { m.V[v] - ctr[0], m.V[v + m.nV] - ctr[1], m.V[v + 2 * m.nV] - ctr[2] };
         for (int c = 0; c < 3; ++c)
@@ -705,6 +707,19 @@ static void dbcGroupMotion(orc_opt* o, const orc_opt::DBCGroup& g)
     }
 }
 
+void orc_opt_set_dirichlet_motion(orc_opt* o, int group, const double* lin3, const double* ang3, const double* center3, int forceNonzero)
+{
+    if (group < 0 || group >= (int)o->dbcGroups.size()) return;
+    orc_opt::DBCGroup& g = o->dbcGroups[group];
+    for (int c = 0; c < 3; ++c) {
+        g.lin[c] = lin3[c];
+        g.ang[c] = ang3[c];
+        if (center3) g.center[c] = center3[c];
+    }
+    g.hasCenter = center3 != nullptr;
+    g.forceNonzero = forceNonzero != 0;
+    setDBCVertices(o);
+}
 void orc_opt_add_neumann(orc_opt* o, int n, const int* ids, const double* accel3, double t0, double t1)
 {
     orc_opt::NBCGroup g;

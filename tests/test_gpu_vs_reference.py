@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import GOLD, MORE_SCENES, RESTART_SCENES, check_damped_bar, check_restart, check_scene, load_scene, rel, run_scene
+from test_oracle_vs_reference import (GOLD, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_damped_bar, check_plates, check_restart, check_scene, load_scene, rel,
+                                      run_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -224,4 +225,48 @@ def test_continuation_from_the_references_own_state(name, tol, tmp_path, gpu_lib
         pytest.skip("fixture without a continuation")
     c = gpu_lib.Context(0)
     check_restart(S, meshes, c, tmp_path, 10 * tol)
+    c.close()
+
+
+@pytest.mark.parametrize("name,tol", PLATE_SCENES)
+def test_scripted_plates_against_the_reference(name, tol, gpu_lib):
+    """`script DCOSquash6` on the HIP stepper (ipcgpu_opt_set_dirichlet_motion driven by the rule of AnimScripter.cpp:2053-2074)."""
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    check_plates(S, pos, its, tol)
+    c.close()
+
+
+@pytest.mark.parametrize("name,steps", [("mat100_twist", 3), ("rods_twist", 2)])
+def test_baseline_configs_on_the_references_own_meshes(name, steps, gpu_lib):
+    """BASELINE configs[1] and [3] as the reference ships them -- 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets) and
+    4_rodsTwist.txt (4 x rod300x33.msh, 202 044 tets, selfCollisionOn), `script twist` -- run by the reference itself: the same Newton
+    iteration count in every step, positions within the Newton tolerance of the script (both start exactly at rest, where makePD2d's
+    projection is decided by round-off; the CPU restatement's run beside the reference is in profiles/r03_ref_compare_*.txt)."""
+    path = os.path.join(GOLD, f"ref_scene_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, steps)
+    assert np.array_equal(its, S["iters"][:steps]), (its.tolist(), S["iters"].tolist())
+    for s in range(steps):
+        assert np.abs(pos[s] - S["positions"][s]).max() <= 2e-5 * np.abs(S["positions"][s]).max()
+    c.close()
+
+
+def test_sphere_on_mat_against_the_reference(gpu_lib):
+    """BASELINE configs[2] as the reference ships it, paperExamples/12_sphereOnMat.txt (a stiff ball dropped on a mat that `script
+    stretchAndPause` is pulling apart; half-space below, self-contact on), 36 steps run by the reference itself.  The ball lands at step
+    29 on a mat that is already strained and moving: no touch-down from exact rest, so the contact steps can be held to the same
+    criterion as the free ones -- EVERY Newton iteration count equal (4 ... 6, 8, 6, 12, 9, 15, 10, 16), positions to 1e-7 (the CPU
+    restatement beside the reference: profiles/r03_ref_compare_sphereOnMat_cpu.txt, 1e-8)."""
+    S, meshes = load_scene("sphere_on_mat")
+    steps = int(S["steps"])
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, steps)
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    dev = [float(np.abs(pos[s] - S["positions"][s]).max() / np.abs(S["positions"][s]).max()) for s in range(steps)]
+    assert max(dev[1:]) <= 1e-7 and dev[0] <= 1e-5, dev  # (step 1 starts from exact rest: the Newton tolerance holds it)
     c.close()

@@ -162,3 +162,14 @@ def test_reference_main_two_cubes_fall_percall(tmp_path):
         assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-12
     assert np.array_equal(its[:free], S["iters"][:free])
     assert abs(int(its.sum()) - int(S["iters"][:steps].sum())) <= 0.15 * int(S["iters"][:steps].sum()), (its.tolist(), S["iters"].tolist())
+
+
+@pytest.mark.gpu
+@needs_exe
+def test_reference_main_squash6_resident(tmp_path):
+    """`script DCOSquash6` (six closing plates, FCR) through the reference's main() with HipOptimizer resident: the adapter evaluates the
+    script's rule (AnimScripter.cpp:2053-2074) before every step and hands the plate motion to ipcgpu_opt_set_dirichlet_motion."""
+    from test_oracle_vs_reference import check_plates
+    S, meshes = load_scene("squash6_contact")
+    pos, its, _ = run_main_hip(S, meshes, tmp_path, int(S["steps"]))
+    check_plates(S, pos, its, 1e-6)

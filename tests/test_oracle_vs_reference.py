@@ -353,6 +353,28 @@ def test_more_scenes_against_the_reference(name, exact, mism, tol):
     check_scene(S, pos, its, exact, mism, tol)
 
 
+# `script DCOSquash6` (AnimScripter.cpp:1193-1221, 2053-2074; the script of BASELINE configs[4]'s 15_trashComp_shapes.txt) on one cube between
+# the six plates, run by the reference: (fixture, position tolerance)
+PLATE_SCENES = [("squash6_small", 1e-12), ("squash6_contact", 1e-6)]
+
+
+def check_plates(S, pos, its, tol):
+    """Every Newton count equal; the plates (rule-driven Dirichlet components: closing, turning round when the first two are 0.1 apart,
+    opening) to round-off, the squeezed cube within `tol` (it is caught from exact rest)."""
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    ref = S["positions"]
+    free = int(np.argmax(S["iters"] > 1)) if np.any(S["iters"] > 1) else len(its)  # steps before the plates touch anything
+    assert np.abs(pos[:free, :24] - ref[:free, :24]).max() <= 1e-13  # afterwards the plates' moves are bounded by CCD (1e-9)
+    assert np.abs(pos - ref).max() <= tol * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name,tol", PLATE_SCENES)
+def test_scripted_plates_against_the_reference(name, tol):
+    S, meshes = load_scene(name)
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    check_plates(S, pos, its, tol)
+
+
 @pytest.mark.parametrize("name,tol", RESTART_SCENES)
 def test_continuation_from_the_references_own_state(name, tol, tmp_path):
     """Every whole-scene fixture above touches down from exact rest, where makePD2d's projection is decided by round-off, so after the

@@ -53,7 +53,7 @@ def test_grammar():
     c = ss.SceneConfig.parse("meshCO input/triMeshes/plane.obj 0.5 0 0.5  10  50  1.0 rotate 0 0 30\n", "/r")
     (path, origin, scale, mu, rot), = c.mesh_cos
     assert path == "/r/input/triMeshes/plane.obj" and np.allclose(origin, [0.5, 0, 0.5]) and scale == 10 and mu == 1.0 and np.allclose(rot, [0, 0, 30])
-    for bad in ("script DCOVerschoorRoller\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 meshSeq dir\n"):
+    for bad in ("script DCOHammerWalnut\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 meshSeq dir\n"):
         with pytest.raises(ss.UnsupportedKeyword):
             ss.SceneConfig.parse(bad)
 
@@ -113,7 +113,7 @@ def test_reference_scene_files_parse():
     print(len(ok), "scene files map onto the C ABI;", unsupported)
     for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
         assert need in ok, need
-    assert len(ok) >= 111  # the rest needs segment / point shapes, other scripted motions or other solvers
+    assert len(ok) >= 122  # the rest needs segment / point shapes, other scripted motions or other solvers
 
 
 class OracleBackend:
@@ -191,6 +191,9 @@ class OracleBackend:
 
     def end_dirichlet(self, group, t_end):
         self.orc.opt_end_dirichlet(self.o, group, t_end)
+
+    def set_dirichlet_motion(self, group, **k):
+        self.orc.opt_set_dirichlet_motion(self.o, group, **k)
 
     def state(self):
         return self.o.state()

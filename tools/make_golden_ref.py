@@ -199,11 +199,52 @@ RESTARTS = {"two_cubes_fall": (30, 8), "aligned_cubes": (20, 8), "aligned_cubes_
             "two_cubes_nm_damped": (28, 8), "rotate_co": (20, 8)}
 
 
+# scene scripts written here (the reference's own input files do not exercise these scripts on a mesh small enough for a fixture)
+_SQUASH6 = """energy FCR
+warmStart 0
+time 2 0.025
+density 1000
+stiffness 10000 0.4
+script DCOSquash6
+turnOffGravity
+
+shapes input 7
+input/triMeshes/plane.obj -1 1.5 -1.5  0 0 -90  3 3 3
+input/triMeshes/plane.obj 1 1.5 -1.5  0 0 -90  3 3 3
+input/triMeshes/plane.obj -1.5 -1 -1.5  0 0 0  3 3 3
+input/triMeshes/plane.obj -1.5 1 -1.5  0 0 0  3 3 3
+input/triMeshes/plane.obj -1.5 1.5 -1  90 0 0  3 3 3
+input/triMeshes/plane.obj -1.5 1.5 1  90 0 0  3 3 3
+input/tetMeshes/cube.msh %s
+
+selfCollisionOn
+constraintSolver interiorPoint
+"""
+INLINE = {
+    # 15_trashComp_shapes.txt's six closing plates (`script DCOSquash6`, FCR, no gravity) around one cube: a tiny one that is never
+    # touched -- the plates close to 0.1, turn round (the sign flip of AnimScripter.cpp:2053-2074, once per step as written) and open --
+    # and one that fills the box and is squeezed from step 16 on
+    "inline:squash6_small": _SQUASH6 % "-0.025 -0.025 -0.025  0 0 0  0.05 0.05 0.05",
+    "inline:squash6_contact": _SQUASH6 % "-0.6 -0.6 -0.6  0 0 0  1.2 1.2 1.2",
+}
+SCENES += [
+    ("squash6_small", "inline:squash6_small", "", 44),
+    ("squash6_contact", "inline:squash6_contact", "", 24),
+    # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
+    ("mat100_twist", "paperExamples/21_scalability/mat100x100_twist.txt", "", 3),
+    # BASELINE configs[3]: 4_rodsTwist.txt (4 x rod300x33.msh = 202 044 tets, `script twist`, selfCollisionOn)
+    ("rods_twist", "paperExamples/4_rodsTwist.txt", "", 2),
+    # BASELINE configs[2]: 12_sphereOnMat.txt (sphere1K 6 851 tets, E = 1e8, on mat40x40 9 126 tets, E = 1e6; `script stretchAndPause`, half-space,
+    # selfCollisionOn): the mat is being stretched when the ball lands on it (step 29 on) -- contact in a generic, pre-strained state
+    ("sphere_on_mat", "paperExamples/12_sphereOnMat.txt", "", 36),
+]
+
+
 def scenes(only=()):
     for name, rel, extra, steps in SCENES:
         if only and name not in only:
             continue
-        text = open(os.path.join(REF_ROOT, "input", rel)).read() + extra
+        text = (INLINE[rel] if rel in INLINE else open(os.path.join(REF_ROOT, "input", rel)).read()) + extra
         cfg = ss.SceneConfig.parse(text, REF_ROOT)
         with tempfile.TemporaryDirectory(prefix="ipcref_") as tmp:
             path = os.path.join(tmp, "scene.txt")
