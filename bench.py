@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--size", type=int, default=150, help="mat N (N x N x 2 nodes); 150 = BASELINE config[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-contact", action="store_true", help="skip the contact sub-record (2 x mat100 stack with self-collision, N = 1 only)")
+    ap.add_argument("--large-size", type=int, default=433, help="N > 1: mat size of the second, >= 1 M-tet workload reported under 'large_workload' (0 = off)")
     ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--solver", type=int, default=0, help="0 = GPU multifrontal, 1 = rocSOLVER csrrf")
     ap.add_argument("--solver-shard", choices=["on", "off"], default="on",
@@ -113,7 +115,16 @@ def main():
             return 0
         if sharded:
             ctx.set_shard(rank, world)  # element assembly split over the ranks, gradient / CSR values all-reduced
-        ctx.set_allreduce(hook)
+        if args.single_device_test:
+            ctx.set_allreduce(hook)  # gloo through a host bounce: plumbing only
+        else:
+            # RCCL called from C on the context's own stream (include/ipcgpu_rccl.h): rank 0 draws the unique id, torch.distributed is
+            # only the bootstrap that carries its 128 bytes; no collective of the data path goes through Python after this
+            idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ipc_amd.Context.rccl_unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, 0)
+            ctx.rccl_attach(rank, world, bytes(idt.cpu().numpy().tobytes()))
         if solver_sharded:
             # the direct solver is what an iteration consists of: the assembly tree is cut below its top separators, every rank
             # factorises / solves its own subtrees, the fronts above the cut are repeated
@@ -239,11 +250,88 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, F, left, right, args.cpu_iters)
     ctx.close()
+    if rank == 0 and world == 1 and not args.no_contact:
+        # the contact half of the path, timed by the same process: two stacked mat100 sheets with self-collision on (barrier terms,
+        # constraint sets, CCD, pattern changes); BASELINE's metric is quoted on the contact-free matTwist above, this is a sub-record
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_contact
+        r = bench_contact.run(n=100, layers=2, steps=12, max_iter=12)
+        out["contact"] = {"workload": r["scene"] + f": {r['n_nodes']} nodes / {r['n_tets']} tets, {r['n_surface_tris']} surface triangles, dt 0.01, 12 time steps",
+                          "newton_iterations": r["newton_iterations"], "value": r["iters_per_s"], "unit": "iter/s", "ms_per_iter": r["ms_per_iter_wall"],
+                          "split_ms_per_iter": r["split_ms_per_iter"],
+                          "active_constraints_per_step": [c["nActive"] for c in r["contact_state_per_step"]],
+                          "pattern_changes": r["contact_state_per_step"][-1]["nPatternChanges"], "intersected_at_end": r["intersected_at_end"]}
+    if distributed and args.large_size and args.size != args.large_size:
+        # a second, >= 1 M-tet strong-scaling point for the curve (mat150's 2.9 ms iteration is mostly the dependent pivot chain of
+        # its top separators, which does not shard): same script, same measurement, fewer steps
+        big = large_workload(args, rank, local_rank, world, torch, dist, ipc_amd)
+        if rank == 0:
+            out["large_workload"] = big
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def large_workload(args, rank, local_rank, world, torch, dist, ipc_amd):
+    """bench.py --gpus N: the same twist scene at --large-size (mat433 = 1.12 M tets), sharded the same way, timed like the main line."""
+    V, F, left, right = build_scene(args.large_size)
+    ctx = ipc_amd.Context(local_rank, solver=args.solver)
+    sharded = args.shard == "on" or (args.shard == "auto" and F.shape[0] >= SHARD_MIN_TETS)
+    if sharded:
+        ctx.set_shard(rank, world)
+    if args.single_device_test:
+        def hook(ptr, count, op):
+            t = torch.as_tensor(DevPtr(ptr, count), device=f"cuda:{local_rank}")
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
+            t.copy_(h)
+            torch.cuda.synchronize()
+            return 0
+        ctx.set_allreduce(hook)
+    else:
+        idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
+        if rank == 0:
+            idt.copy_(torch.frombuffer(bytearray(ipc_amd.Context.rccl_unique_id()), dtype=torch.uint8))
+        dist.broadcast(idt, 0)
+        ctx.rccl_attach(rank, world, idt.cpu().numpy().tobytes())
+    if args.solver_shard == "on":
+        ctx.set_solver_shard(rank, world)
+    ctx.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+    ctx.opt_init(dt=0.04, gravity=False)
+    ctx.set_twist(left, right, 0.4 * np.pi)
+    ctx.precompute()
+    state = {"in": False}
+
+    def one():
+        while True:
+            if not state["in"]:
+                ctx.begin_timestep()
+                state["in"] = True
+            if ctx.newton_iter():
+                ctx.end_timestep()
+                state["in"] = False
+                continue
+            return
+    K, W = max(4, args.steps // 5), 2
+    for _ in range(W):
+        one()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        one()
+    dist.barrier()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=f"cuda:{local_rank}")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    rec = {"workload": f"matTwist mat{args.large_size}: {V.shape[0]} nodes / {F.shape[0]} tets", "steps": K, "warmup": W, "value": K / float(el.item()),
+           "unit": "iter/s", "ms_per_step": 1e3 * float(el.item()) / K, "element_assembly_sharded": bool(sharded),
+           "solver_sharded": args.solver_shard == "on",
+           "shared_flop_fraction": ctx.solver_shard_stats()["shared_flop_fraction"] if args.solver_shard == "on" else None}
+    ctx.close()
+    return rec
 
 
 def cpu_baseline(V, F, left, right, iters):

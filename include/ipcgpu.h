@@ -358,6 +358,13 @@ int ipcgpu_opt_get_timers(ipcgpu_ctx*, double* t16);
  * (op 0 = sum, 1 = min).  bench.py binds it to torch.distributed (RCCL). */
 typedef int (*ipcgpu_allreduce_fn)(void* user, void* buf_dev, long long count, int op);
 int ipcgpu_opt_set_allreduce(ipcgpu_ctx*, ipcgpu_allreduce_fn fn, void* user);
+/* Stream-ordered variant, and the one a C / C++ caller uses: fn enqueues the all-reduce on the HIP stream it is handed (the
+ * context's own) and returns -- `ncclAllReduce(buf, buf, count, ncclDouble, op ? ncclMin : ncclSum, comm, stream)` is the whole body.
+ * The library then never synchronises with the host around a collective.  include/adapters/ipcgpu_rccl.cpp is that hook on RCCL
+ * (libipcgpu_rccl.so: ipcgpu_rccl_unique_id / ipcgpu_rccl_attach); takes precedence over ipcgpu_opt_set_allreduce. */
+typedef int (*ipcgpu_allreduce_stream_fn)(void* user, void* buf_dev, long long count, int op, void* hip_stream);
+int ipcgpu_opt_set_allreduce_stream(ipcgpu_ctx*, ipcgpu_allreduce_stream_fn fn, void* user);
+int ipcgpu_ctx_get_stream(ipcgpu_ctx*, void** hip_stream);
 
 /* ---- measurement -------------------------------------------------------------------- */
 /* Launch the fused element-assembly kernel `reps` times on the context stream and return the

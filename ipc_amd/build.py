@@ -79,6 +79,13 @@ def _build(force, verbose, extra):
         link = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + [
             f"-L{ROCM}/lib", "-lrocblas", "-lrocsolver", f"-Wl,-rpath,{ROCM}/lib"]
         run(link)
+    # the caller-side RCCL binding (include/adapters/ipcgpu_rccl.cpp): its own small library, so that libipcgpu.so itself never links RCCL
+    rsrc = os.path.join(HERE, "..", "include", "adapters", "ipcgpu_rccl.cpp")
+    rlib = LIB.replace("libipcgpu", "libipcgpu_rccl", 1) if "libipcgpu_" not in os.path.basename(LIB) else LIB.replace(".so", "_rccl.so")
+    if force or _needs(rlib, [rsrc, os.path.join(HERE, "..", "include", "ipcgpu_rccl.h"), LIB]):
+        run([HIPCC, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", f"-I{ROCM}/include", f"-I{os.path.join(HERE, '..', 'include')}",
+             "-x", "hip", rsrc, "-o", rlib, f"-L{os.path.dirname(LIB)}", "-l" + os.path.basename(LIB)[3:-3], f"-L{ROCM}/lib", "-lrccl",
+             "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{ROCM}/lib"])
     return LIB
 
 

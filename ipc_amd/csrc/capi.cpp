@@ -63,6 +63,15 @@ HipOptimizer& O(ipcgpu_ctx* c)
     return *c->opt;
 }
 void bind(ipcgpu_ctx* c) { HIP_CHECK(hipSetDevice(c->device)); }
+// contact-pair lists shard with the elements (ipcgpu_ctx_set_shard): the handler is created lazily, so both places call this
+void applyContactShard(ipcgpu_ctx* c)
+{
+    if (!c->contact) return;
+    c->contact->shardRank = c->rank;
+    c->contact->shardWorld = c->worldSize;
+    HipOptimizer* o = c->opt.get();
+    c->contact->shardReduce = [o](double* d, long long n) { o->reduceSum(d, n); };
+}
 
 // column-major nV x 3 (host) <-> xyz interleaved (device)
 void uploadColMajor(ipcgpu_ctx* c, const double* Vcm, DevBuf<double>& dst)
@@ -139,6 +148,7 @@ int ipcgpu_ctx_set_shard(ipcgpu_ctx* c, int rank, int world)
         c->worldSize = world;
         c->opt->rank = rank;
         c->opt->worldSize = world;
+        applyContactShard(c);
         if (c->mesh->nT) {
             c->opt->tetBegin = (int)((long long)c->mesh->nT * rank / world);
             c->opt->tetEnd = (int)((long long)c->mesh->nT * (rank + 1) / world);
@@ -582,8 +592,8 @@ int ipcgpu_linsys_set_shard(ipcgpu_ctx* c, int rank, int world)
 {
     return guarded([&] {
         needArg(c && world >= 1 && rank >= 0 && rank < world, "bad shard");
-        need(world == 1 || c->opt->allreduce != nullptr, "set the all-reduce hook first (ipcgpu_opt_set_allreduce)");
-        c->lin->setShard(rank, world, c->opt->allreduce, c->opt->allreduceUser);
+        need(world == 1 || c->opt->allreduce != nullptr || c->opt->allreduceStream != nullptr, "set the all-reduce hook first (ipcgpu_opt_set_allreduce)");
+        c->lin->setShard(rank, world, c->opt->allreduce, c->opt->allreduceUser, c->opt->allreduceStream);
         return IPCGPU_OK;
     });
 }
@@ -611,7 +621,10 @@ int ipcgpu_linsys_stats(ipcgpu_ctx* c, double* st)
 static HipContact& CT(ipcgpu_ctx* c)
 {
     M(c);
-    if (!c->contact) c->contact.reset(new HipContact(c->stream));
+    if (!c->contact) {
+        c->contact.reset(new HipContact(c->stream));
+        applyContactShard(c);
+    }
     return *c->contact;
 }
 int ipcgpu_set_surface(ipcgpu_ctx* c, int nSF, const int* SF)
@@ -1368,6 +1381,24 @@ int ipcgpu_opt_set_allreduce(ipcgpu_ctx* c, ipcgpu_allreduce_fn fn, void* user)
         needArg(c != nullptr, "null context");
         c->opt->allreduce = fn;
         c->opt->allreduceUser = user;
+        return IPCGPU_OK;
+    });
+}
+
+int ipcgpu_opt_set_allreduce_stream(ipcgpu_ctx* c, ipcgpu_allreduce_stream_fn fn, void* user)
+{
+    return guarded([&] {
+        needArg(c != nullptr, "null context");
+        c->opt->allreduceStream = fn;
+        c->opt->allreduceUser = user;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_ctx_get_stream(ipcgpu_ctx* c, void** hipStream)
+{
+    return guarded([&] {
+        needArg(c != nullptr && hipStream != nullptr, "null argument");
+        *hipStream = (void*)c->stream;
         return IPCGPU_OK;
     });
 }

@@ -12,6 +12,7 @@
 #include "common.h"
 #include <array>
 #include <utility>
+#include <functional>
 #include <vector>
 
 namespace ipcgpu {
@@ -56,6 +57,17 @@ public:
     void uploadSets();
     // returns #active
     int buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat);
+    // Multi-GPU ("contact pairs assigned to ..."): the constraint SETS are the same on every rank (integer outputs every rank needs
+    // for the pattern), their EVALUATION is split -- rank r takes the stencils [n r / W, n (r + 1) / W) of the active and of the mollified
+    // list.  energy() then all-reduces its scalar through `shardReduce`; gradientAdd / hessianAdd add this rank's share into arrays the
+    // caller all-reduces (HipOptimizer::computePrecondMtr, barrierGradientAdd).
+    int shardRank = 0, shardWorld = 1;
+    std::function<void(double*, long long)> shardReduce;
+    void shardRange(int n, int& b, int& e) const
+    {
+        b = (int)((long long)n * shardRank / shardWorld);
+        e = (int)((long long)n * (shardRank + 1) / shardWorld);
+    }
     double energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
     // useActive / usePara: initKappa leaves the mollified set out (Optimizer.cpp:2262-2270)
     void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev, bool useActive = true,

@@ -1776,13 +1776,17 @@ void HipContact::syncHost() const
 
 double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
 {
-    const int n = nActive_ + nPara_;
-    if (n == 0) return 0.0;
-    ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
-    const int nb = nblk(n);
+    if (nActive_ + nPara_ == 0) return 0.0;
+    int aB, aE, pB, pE; // this rank's share of the two lists
+    shardRange(nActive_, aB, aE);
+    shardRange(nPara_, pB, pE);
+    const int n = (aE - aB) + (pE - pB);
+    ContactView cv{ aE - aB, pE - pB, d_active.p + 4 * (size_t)aB, d_para.p + 4 * (size_t)pB, d_paraEIEJ.p + 2 * (size_t)pB, d_SFE.p, x_dev, d_xRest.p };
+    const int nb = std::max(1, nblk(n));
     if (partial.n < (size_t)nb) partial.alloc(nb);
-    hipLaunchKernelGGL(k_contact_energy, dim3(nb), dim3(BLOCK), 0, stream, cv, dHat, partial.p);
-    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, nb, kappa, scalar_dev);
+    if (n) hipLaunchKernelGGL(k_contact_energy, dim3(nb), dim3(BLOCK), 0, stream, cv, dHat, partial.p);
+    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, n ? nb : 0, kappa, scalar_dev);
+    if (shardWorld > 1 && shardReduce) shardReduce(scalar_dev, 1);
     double out = 0.0;
     HIP_CHECK(hipMemcpyAsync(&out, scalar_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
@@ -1792,10 +1796,13 @@ double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf
 void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev,
     bool useActive, bool usePara)
 {
-    const int nA = useActive ? nActive_ : 0, nP = usePara ? nPara_ : 0;
+    int aB, aE, pB, pE;
+    shardRange(useActive ? nActive_ : 0, aB, aE);
+    shardRange(usePara ? nPara_ : 0, pB, pE);
+    const int nA = aE - aB, nP = pE - pB;
     const int n = nA + nP;
     if (n) {
-        ContactView cv{ nA, nP, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+        ContactView cv{ nA, nP, d_active.p + 4 * (size_t)aB, d_para.p + 4 * (size_t)pB, d_paraEIEJ.p + 2 * (size_t)pB, d_SFE.p, x_dev, d_xRest.p };
         hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, grad_dev);
     }
     hipLaunchKernelGGL(k_zero_projected, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, projectDBC, grad_dev);
@@ -1804,9 +1811,12 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
 void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
     double* a_dev)
 {
-    const int n = nActive_ + nPara_;
+    int aB, aE, pB, pE;
+    shardRange(nActive_, aB, aE);
+    shardRange(nPara_, pB, pE);
+    const int n = (aE - aB) + (pE - pB);
     if (!n) return;
-    ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p };
+    ContactView cv{ aE - aB, pE - pB, d_active.p + 4 * (size_t)aB, d_para.p + 4 * (size_t)pB, d_paraEIEJ.p + 2 * (size_t)pB, d_SFE.p, x_dev, d_xRest.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(2);
     counters_.zero(stream);

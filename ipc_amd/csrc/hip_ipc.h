@@ -19,6 +19,7 @@
 
 struct ipcgpu_ctx; // opaque C handle
 typedef int (*ipcgpu_allreduce_fn_t)(void* user, void* buf_dev, long long count, int op);
+typedef int (*ipcgpu_allreduce_stream_fn_t)(void* user, void* buf_dev, long long count, int op, void* hipStream);
 
 namespace ipcgpu {
 
@@ -87,9 +88,9 @@ public:
     int getNumNonzeros() const { return (int)ja.size(); }
     const MfSymbolic& symbolic() const { return sym_; }
     // subtree-sharded factorisation / solves over `world` ranks (MfNumeric::setShard); takes effect at the next analyze_pattern
-    void setShard(int rank, int world, ipcgpu_allreduce_fn_t fn, void* user)
+    void setShard(int rank, int world, ipcgpu_allreduce_fn_t fn, void* user, ipcgpu_allreduce_stream_fn_t sfn = nullptr)
     {
-        num_.setShard(rank, world, fn, user);
+        num_.setShard(rank, world, fn, user, sfn);
         analyzed_ = false;
     }
     int solverWorld() const { return num_.world(); }
@@ -211,6 +212,9 @@ public:
     int rank = 0, worldSize = 1;
     int tetBegin = 0, tetEnd = 0;
     ipcgpu_allreduce_fn_t allreduce = nullptr;
+    ipcgpu_allreduce_stream_fn_t allreduceStream = nullptr; // takes precedence: enqueued on `stream`, no host synchronisation
+    void hookReduce(double* dev, long long n, int op);
+    DevBuf<double> d_contactG; // this rank's share of the barrier forces before their all-reduce (contact-pair lists sharded)
     void* allreduceUser = nullptr;
     void reduceSum(double* dev, long long n);
     void reduceMin(double* dev, long long n);

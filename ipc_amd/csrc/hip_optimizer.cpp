@@ -235,19 +235,21 @@ bool HipOptimizer::dbcGroupMotion()
 
 void HipOptimizer::reduceSum(double* dev, long long n)
 {
-    if (worldSize > 1) {
-        if (!allreduce) throw StateError("sharded context without an all-reduce hook");
-        HIP_CHECK(hipStreamSynchronize(stream));
-        if (allreduce(allreduceUser, dev, n, 0) != 0) throw HipError("all-reduce hook failed");
-    }
+    if (worldSize > 1) hookReduce(dev, n, 0);
 }
 void HipOptimizer::reduceMin(double* dev, long long n)
 {
-    if (worldSize > 1) {
-        if (!allreduce) throw StateError("sharded context without an all-reduce hook");
-        HIP_CHECK(hipStreamSynchronize(stream));
-        if (allreduce(allreduceUser, dev, n, 1) != 0) throw HipError("all-reduce hook failed");
+    if (worldSize > 1) hookReduce(dev, n, 1);
+}
+void HipOptimizer::hookReduce(double* dev, long long n, int op)
+{
+    if (allreduceStream) { // RCCL from C, ordered on our stream
+        if (allreduceStream(allreduceUser, dev, n, op, (void*)stream) != 0) throw HipError("all-reduce hook failed");
+        return;
     }
+    if (!allreduce) throw StateError("sharded context without an all-reduce hook");
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (allreduce(allreduceUser, dev, n, op) != 0) throw HipError("all-reduce hook failed");
 }
 double HipOptimizer::readScalar(const double* dev)
 {
@@ -705,6 +707,18 @@ void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activ
         if (selfCollision && selfFric > 0.0) contact->frictionGradientAdd(mesh.d_x.p, d_xPrev.p, fricDHat, selfFric, grad_dev);
     }
     if (!contact) return;
+    if (worldSize > 1 && contact->shardWorld > 1) {
+        // the stencils of the two lists are split over the ranks (HipContact::shardRange): this rank's share into a zeroed scratch
+        // vector, one all-reduce of the 3 nV doubles, then on top of the caller's gradient
+        const size_t n3 = 3 * (size_t)mesh.nV;
+        d_contactG.ensure(n3);
+        d_contactG.zeroN(n3, stream);
+        contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, 0, d_contactG.p, selfCollision, selfCollision && !activeOnly);
+        reduceSum(d_contactG.p, (long long)n3);
+        launch_axpy((long long)n3, 1.0, d_contactG.p, grad_dev, stream);
+        launch_clear_projected(mesh.nV, mesh.d_dbc.p, projectDBC ? 1 : 0, grad_dev, stream);
+        return;
+    }
     contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, projectDBC, grad_dev, selfCollision, selfCollision && !activeOnly);
 }
 
@@ -860,6 +874,10 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
     }
     launch_assemble_patches(view(), patch, pb, pe, elasticCoef(), projectDBC, withGradient ? d_gradient.p : nullptr,
         lin.d_a.p, stream);
+    // contact-pair lists sharded like the elements: this rank's share of the barrier Hessian blocks goes into the same partial matrix,
+    // so that ONE all-reduce carries the elastic and the barrier rows
+    const bool contactSharded = worldSize > 1 && ipOn() && selfCollision && contact->shardWorld > 1;
+    if (contactSharded) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
     if (worldSize > 1) {
         reduceSum(lin.d_a.p, (long long)lin.ja.size());
         if (withGradient) reduceSum(d_gradient.p, 3LL * mesh.nV);
@@ -869,7 +887,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         if (withGradient) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p);
         for (auto& h : planes)
             h->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin.d_rowBase.p, lin.d_rowLen.p, dHat, kappa, projectDBC, lin.d_a.p);
-        if (selfCollision) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
+        if (selfCollision && !contactSharded) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
         if (fricDHat > 0.0) { // Optimizer.cpp:3677-3702
             for (auto& h : planes)
                 if (h->friction > 0.0)

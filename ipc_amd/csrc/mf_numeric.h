@@ -18,11 +18,14 @@ public:
     // subtrees it owns and all ranks repeat the fronts above the cut; the update matrices / update vectors of the subtree roots
     // and the final solution cross ranks through `allreduce` (sum, in place, on a device buffer).  Call before setup().
     typedef int (*AllreduceFn)(void* user, void* buf_dev, long long count, int op);
-    void setShard(int rank, int world, AllreduceFn fn, void* user)
+    // stream-ordered variant (ipcgpu_opt_set_allreduce_stream): enqueued on the solver's stream, no host synchronisation around it
+    typedef int (*AllreduceStreamFn)(void* user, void* buf_dev, long long count, int op, void* hipStream);
+    void setShard(int rank, int world, AllreduceFn fn, void* user, AllreduceStreamFn sfn = nullptr)
     {
         rank_ = rank;
         world_ = world;
         allreduce_ = fn;
+        allreduceStream_ = sfn;
         allreduceUser_ = user;
     }
     int world() const { return world_; }
@@ -59,6 +62,7 @@ private:
     };
     int rank_ = 0, world_ = 1;
     AllreduceFn allreduce_ = nullptr;
+    AllreduceStreamFn allreduceStream_ = nullptr;
     void* allreduceUser_ = nullptr;
     double sharedFlops_ = 0.0;
     bool flagShared_ = false; // the update exchanges carry the pivot flag

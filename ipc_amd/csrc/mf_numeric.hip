@@ -2689,6 +2689,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
 void MfNumeric::allreduceSum(double* dev, long long count)
 {
     if (world_ <= 1 || count <= 0) return;
+    if (allreduceStream_) { // stream-ordered (RCCL called from C on this stream): nothing to wait for on the host
+        if (allreduceStream_(allreduceUser_, dev, count, 0, (void*)stream_) != 0) throw HipError("all-reduce hook failed");
+        return;
+    }
     if (!allreduce_) throw StateError("sharded solver without an all-reduce hook (ipcgpu_opt_set_allreduce)");
     HIP_CHECK(hipStreamSynchronize(stream_)); // the hook works on the caller's stream: ours has to be drained first
     if (allreduce_(allreduceUser_, dev, count, 0) != 0) throw HipError("all-reduce hook failed");

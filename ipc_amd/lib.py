@@ -44,7 +44,31 @@ def declared_symbols():
     """Every function declared in include/ipcgpu.h (used by the CPU-side export test)."""
     txt = open(_HEADER).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(ipcgpu_[a-z0-9_]+)\s*\(", txt)) - {"ipcgpu_allreduce_fn"})
+    return sorted(set(re.findall(r"\b(ipcgpu_[a-z0-9_]+)\s*\(", txt)) - {"ipcgpu_allreduce_fn", "ipcgpu_allreduce_stream_fn"})
+
+
+_RCCL_PATH = os.path.join(os.path.dirname(_LIB_PATH), os.path.basename(_LIB_PATH).replace("libipcgpu", "libipcgpu_rccl", 1) if "libipcgpu_" not in os.path.basename(_LIB_PATH)
+                          else os.path.basename(_LIB_PATH).replace(".so", "_rccl.so"))
+_RCCL_HEADER = os.path.join(os.path.dirname(_HEADER), "ipcgpu_rccl.h")
+_rccl = None
+
+
+def rccl_declared_symbols():
+    """Every function include/ipcgpu_rccl.h declares (the caller-side RCCL binding, libipcgpu_rccl.so)."""
+    txt = re.sub(r"/\*.*?\*/", "", open(_RCCL_HEADER).read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ipcgpu_rccl_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load_rccl():
+    """dlopen libipcgpu_rccl.so (include/adapters/ipcgpu_rccl.cpp: RCCL bound to a context from C)."""
+    global _rccl
+    if _rccl is None:
+        load_library()
+        if not os.path.exists(_RCCL_PATH):
+            raise IpcGpuError(f"{_RCCL_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _rccl = C.CDLL(_RCCL_PATH)
+        _rccl.ipcgpu_rccl_last_error.restype = C.c_char_p
+    return _rccl
 
 
 _lib = None
@@ -135,6 +159,7 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            self.rccl_detach()
             self._L.ipcgpu_ctx_destroy(self.h)
             self.h = None
 
@@ -159,6 +184,33 @@ class Context:
         o = np.zeros(2)
         self._chk(self._L.ipcgpu_linsys_shard_stats(self.h, _dp(o)))
         return dict(world=int(o[0]), shared_flop_fraction=float(o[1]))
+
+    # ---- RCCL from C (include/ipcgpu_rccl.h): every exchange is then one ncclAllReduce on the context's own stream
+    @staticmethod
+    def rccl_unique_id():
+        R = load_rccl()
+        buf = C.create_string_buffer(128)
+        if R.ipcgpu_rccl_unique_id(buf) != 0:
+            raise IpcGpuError("ipcgpu_rccl_unique_id: " + R.ipcgpu_rccl_last_error().decode())
+        return buf.raw
+
+    def rccl_attach(self, rank, world, id128):
+        R = load_rccl()
+        if R.ipcgpu_rccl_attach(self.h, C.c_int(rank), C.c_int(world), C.c_char_p(bytes(id128))) != 0:
+            raise IpcGpuError("ipcgpu_rccl_attach: " + R.ipcgpu_rccl_last_error().decode())
+        self._rccl_attached = True
+
+    def rccl_detach(self):
+        if getattr(self, "_rccl_attached", False):
+            load_rccl().ipcgpu_rccl_detach(self.h)
+            self._rccl_attached = False
+
+    def rccl_selftest(self, rank, count=1024, op=0):
+        R = load_rccl()
+        out = C.c_double()
+        if R.ipcgpu_rccl_selftest(self.h, C.c_int(rank), C.c_longlong(count), C.c_int(op), C.byref(out)) != 0:
+            raise IpcGpuError("ipcgpu_rccl_selftest: " + R.ipcgpu_rccl_last_error().decode())
+        return out.value
 
     def set_allreduce(self, pyfunc):
         """pyfunc(dev_ptr:int, count:int, op:int) -> int (0 ok)."""

@@ -22,6 +22,15 @@ def test_every_declared_symbol_is_exported():
     assert not missing, missing
 
 
+def test_rccl_binding_exports_every_declared_symbol():
+    """libipcgpu_rccl.so (include/adapters/ipcgpu_rccl.cpp: RCCL bound to a context from C, include/ipcgpu_rccl.h) loads and exports what
+    its header declares; libipcgpu.so itself does not link RCCL."""
+    r = L.load_rccl()
+    names = L.rccl_declared_symbols()
+    assert len(names) >= 5 and not [n for n in names if not hasattr(r, n)]
+    assert "rccl" not in os.popen(f"ldd {L.lib_path()}").read()
+
+
 def test_context_creation_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

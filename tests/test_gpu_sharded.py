@@ -38,8 +38,8 @@ if world > 1:
         t.copy_(h)
         torch.cuda.synchronize()
         return 0
-    if mode == "assembly":
-        c.set_shard(rank, world)  # patches sharded, gradient / CSR values / scalars all-reduced
+    if mode in ("assembly", "contact_sharded"):
+        c.set_shard(rank, world)  # patches AND contact-pair lists sharded, gradient / CSR values / scalars all-reduced
     c.set_allreduce(hook)
     if mode != "assembly":
         c.set_solver_shard(rank, world)  # subtree-sharded factorisation and solves, everything else replicated
@@ -96,7 +96,7 @@ iters = []
 for step in range(steps):
     iters.append(c.solve_timestep(cap))
 s = c.state()
-if mode == "contact":
+if mode.startswith("contact"):
     extra["nActive"] = c.contact_state()["nActive"]
     extra["nPatternChanges"] = c.contact_state()["nPatternChanges"]
 if rank == 0:
@@ -167,3 +167,33 @@ def test_two_ranks_with_contact_reproduce_the_single_rank_trajectory():
         assert int(a["nPatternChanges"]) >= 1
         assert np.array_equal(a["iters"], b["iters"])
         assert np.abs(a["V"] - b["V"]).max() <= 1e-10 * np.abs(a["V"]).max()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_contact_pair_lists_sharded_reproduce_the_single_rank_trajectory(world):
+    """ipcgpu_ctx_set_shard with self-contact: the elements AND the contact-pair lists are split over the ranks -- rank r evaluates the
+    barrier energy / forces / Hessian blocks of its share of the active and of the mollified list, the blocks ride in the same all-reduce
+    as the elastic rows -- on top of the subtree-sharded solver.  Same sets, same Newton counts, positions to the round-off of a
+    different summation order."""
+    with tempfile.TemporaryDirectory() as d:
+        one, many = os.path.join(d, "one.npz"), os.path.join(d, "many.npz")
+        run(1, one, "contact_sharded")
+        run(world, many, "contact_sharded")
+        a, b = np.load(one), np.load(many)
+        assert int(a["nActive"]) > 0 and int(a["nActive"]) == int(b["nActive"])
+        assert np.array_equal(a["iters"], b["iters"])
+        assert np.abs(a["V"] - b["V"]).max() <= 1e-9 * np.abs(a["V"]).max()
+
+
+@pytest.mark.gpu
+def test_rccl_binding_from_c_on_one_rank(gpu_lib):
+    """include/adapters/ipcgpu_rccl.cpp: ncclCommInitRank on the context's device and the stream-ordered all-reduce hook, driven from C
+    (libipcgpu_rccl.so).  A one-GPU box can only form a communicator of one rank (RCCL refuses two ranks on one device); what is
+    checked is the binding itself -- unique id, attach, an all-reduce (sum and min) enqueued on the context's stream, detach."""
+    c = gpu_lib.Context(0)
+    uid = gpu_lib.Context.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    c.rccl_attach(0, 1, uid)
+    assert c.rccl_selftest(0, 4096, 0) == 1.0 and c.rccl_selftest(0, 4096, 1) == 1.0
+    c.rccl_detach()
+    c.close()

@@ -13,78 +13,88 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ipc_amd import lib, scene  # noqa: E402
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, default=60)
-ap.add_argument("--layers", type=int, default=2)
-ap.add_argument("--steps", type=int, default=3)
-ap.add_argument("--max-iter", type=int, default=12)
-ap.add_argument("--gap", type=float, default=1.2e-3)
-ap.add_argument("--cpu-iters", type=int, default=0, help="also time the CPU oracle on the first N Newton iterations of the same scene")
-args = ap.parse_args()
+def run(n=60, layers=2, steps=3, max_iter=12, gap=1.2e-3, cpu_iters=0):
+    """One run of the contact scene on cuda:0; returns the record (dict) that the command line prints."""
+    class A:
+        pass
+    args = A()
+    args.n, args.layers, args.steps, args.max_iter, args.gap, args.cpu_iters = n, layers, steps, max_iter, gap, cpu_iters
 
-V, F, nA = scene.make_mat_stack(args.n, args.layers, gap=args.gap)
-Vs = scene.jitter(V, F, rel=2e-3)
-SF = scene.surface_tris(F)
-c = lib.Context(0)
-c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
-c.set_positions(Vs)
-c.opt_init(0.01, True)
-c.set_surface(SF)
-low = np.arange(nA)
-border = low[(np.abs(V[:nA, 0]) > 0.49) | (np.abs(V[:nA, 2]) > 0.49)].astype(np.int32)
-c.set_dbc(border, 1)
-c.enable_self_collision(1e-3)
-vel = np.zeros_like(V)
-vel[nA:, 1] = -0.05
-c.set_velocity(vel)
-t0 = time.time()
-c.precompute()
-t_pre = time.time() - t0
-tm0 = c.timers()
-iters, counts = 0, []
-t0 = time.time()
-for step in range(args.steps):
-    c.begin_timestep()
-    for it in range(args.max_iter):
-        if c.newton_iter():
-            break
-        iters += 1
-    c.end_timestep()
-    counts.append(c.contact_state())
-wall = time.time() - t0
-tm = c.timers() - tm0
-names = {0: "assembly+barrier_hessian", 1: "set_pattern", 2: "symbolic_analysis", 3: "factor", 4: "solve", 5: "linesearch_moves+intersection",
-         9: "energy_evals", 13: "step_bounds(inversion+CCD+CFL)", 14: "constraint_sets", 11: "timestep"}
-split = {v: 1e3 * tm[k] / max(iters, 1) for k, v in names.items()}
-cpu = None
-if args.cpu_iters > 0:
-    from oracle import orc  # noqa: E402  (the checker, timed beside the GPU path as in bench.py's cpu_baseline)
-    nthreads = os.cpu_count() or 1
-    m = orc.Mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
-    m.set_surface(SF)
-    m.set_V(Vs)
-    m.set_dbc(border, 1)
-    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=nthreads)
-    orc.opt_enable_self_collision(o, 1e-3)
-    orc.opt_set_velocity(o, vel)
-    o.precompute()
-    n_cpu, t0 = 0, time.time()
+    V, F, nA = scene.make_mat_stack(args.n, args.layers, gap=args.gap)
+    Vs = scene.jitter(V, F, rel=2e-3)
+    SF = scene.surface_tris(F)
+    c = lib.Context(0)
+    c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+    c.set_positions(Vs)
+    c.opt_init(0.01, True)
+    c.set_surface(SF)
+    low = np.arange(nA)
+    border = low[(np.abs(V[:nA, 0]) > 0.49) | (np.abs(V[:nA, 2]) > 0.49)].astype(np.int32)
+    c.set_dbc(border, 1)
+    c.enable_self_collision(1e-3)
+    vel = np.zeros_like(V)
+    vel[nA:, 1] = -0.05
+    c.set_velocity(vel)
+    t0 = time.time()
+    c.precompute()
+    t_pre = time.time() - t0
+    tm0 = c.timers()
+    iters, counts = 0, []
+    t0 = time.time()
     for step in range(args.steps):
-        o.begin_timestep()
+        c.begin_timestep()
         for it in range(args.max_iter):
-            if o.newton_iter():
+            if c.newton_iter():
                 break
-            n_cpu += 1
+            iters += 1
+        c.end_timestep()
+        counts.append(c.contact_state())
+    wall = time.time() - t0
+    tm = c.timers() - tm0
+    names = {0: "assembly+barrier_hessian", 1: "set_pattern", 2: "symbolic_analysis", 3: "factor", 4: "solve", 5: "linesearch_moves+intersection",
+             9: "energy_evals", 13: "step_bounds(inversion+CCD+CFL)", 14: "constraint_sets", 11: "timestep"}
+    split = {v: 1e3 * tm[k] / max(iters, 1) for k, v in names.items()}
+    cpu = None
+    if args.cpu_iters > 0:
+        from oracle import orc  # noqa: E402  (the checker, timed beside the GPU path as in bench.py's cpu_baseline)
+        nthreads = os.cpu_count() or 1
+        m = orc.Mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+        m.set_surface(SF)
+        m.set_V(Vs)
+        m.set_dbc(border, 1)
+        o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=nthreads)
+        orc.opt_enable_self_collision(o, 1e-3)
+        orc.opt_set_velocity(o, vel)
+        o.precompute()
+        n_cpu, t0 = 0, time.time()
+        for step in range(args.steps):
+            o.begin_timestep()
+            for it in range(args.max_iter):
+                if o.newton_iter():
+                    break
+                n_cpu += 1
+                if n_cpu >= args.cpu_iters:
+                    break
             if n_cpu >= args.cpu_iters:
                 break
-        if n_cpu >= args.cpu_iters:
-            break
-        o.end_timestep()
-    t_cpu = time.time() - t0
-    cpu = {"kind": "port", "cores": nthreads, "newton_iterations": n_cpu, "iters_per_s": n_cpu / t_cpu, "ms_per_iter_wall": 1e3 * t_cpu / max(n_cpu, 1)}
-print(json.dumps({
-    "cpu_baseline": cpu,
-    "scene": f"{args.layers} x mat{args.n} stack, gap {args.gap}, dHat 1e-3, self-collision on", "n_nodes": int(V.shape[0]), "n_tets": int(F.shape[0]),
-    "n_surface_tris": int(SF.shape[0]), "newton_iterations": iters, "iters_per_s": iters / wall, "ms_per_iter_wall": 1e3 * wall / max(iters, 1),
-    "precompute_s": t_pre, "split_ms_per_iter": split, "contact_state_per_step": counts, "intersected_at_end": bool(c.is_intersected()),
-}))
+            o.end_timestep()
+        t_cpu = time.time() - t0
+        cpu = {"kind": "port", "cores": nthreads, "newton_iterations": n_cpu, "iters_per_s": n_cpu / t_cpu, "ms_per_iter_wall": 1e3 * t_cpu / max(n_cpu, 1)}
+    return {
+        "cpu_baseline": cpu,
+        "scene": f"{args.layers} x mat{args.n} stack, gap {args.gap}, dHat 1e-3, self-collision on", "n_nodes": int(V.shape[0]), "n_tets": int(F.shape[0]),
+        "n_surface_tris": int(SF.shape[0]), "newton_iterations": iters, "iters_per_s": iters / wall, "ms_per_iter_wall": 1e3 * wall / max(iters, 1),
+        "precompute_s": t_pre, "split_ms_per_iter": split, "contact_state_per_step": counts, "intersected_at_end": bool(c.is_intersected()),
+    }
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=60)
+    ap.add_argument("--layers", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--max-iter", type=int, default=12)
+    ap.add_argument("--gap", type=float, default=1.2e-3)
+    ap.add_argument("--cpu-iters", type=int, default=0, help="also time the CPU oracle on the first N Newton iterations of the same scene")
+    args = ap.parse_args()
+    print(json.dumps(run(args.n, args.layers, args.steps, args.max_iter, args.gap, args.cpu_iters)))
