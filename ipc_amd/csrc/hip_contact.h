@@ -25,6 +25,7 @@ public:
     explicit HipContact(hipStream_t s) : stream(s)
     {
         if (const char* e = std::getenv("IPCGPU_CCD_MODE")) ccdMode = std::atoi(e) != 0 ? 1 : 0;
+        if (const char* e = std::getenv("IPCGPU_CONTACT_ATOMICS")) atomicScatter_ = std::atoi(e) != 0;
     }
     hipStream_t stream;
     // surface (Mesh::SF, SVI, SFEdges; Mesh.cpp:495-515, 890-930)
@@ -129,6 +130,16 @@ private:
     DevBuf<int> sortValIn_, permPT_, permEE_, dupTuple_, dupIdx_, dupIdx2_, head_, headPos_, closeIdx_;
     DevBuf<double> closeVal_;
     DevBuf<char> scanTmp_;
+    // deterministic scatter of the barrier / friction terms (hip_contact.hip "deterministic scatter"): per-stencil slots, keys, sort, run sums
+    bool atomicScatter_ = false; // IPCGPU_CONTACT_ATOMICS=1: the fp64-atomic path of rounds 1-2 (A/B timing)
+    DevBuf<double> detVals_;
+    DevBuf<unsigned> detKey_, detKeyOut_;
+    DevBuf<int> detIota_, detPerm_, detRow_;
+    int detIotaN_ = 0;
+    void detBegin(size_t nSlots, int valsPerSlot, bool withRow);
+    void detReduce3(size_t nSlots, int keyBits, double* grad_dev);
+    void detReduceBlocks(size_t nSlots, int keyBits, const int* ia_dev, double* a_dev);
+    void detSort(size_t nSlots, int keyBits);
 };
 
 } // namespace ipcgpu

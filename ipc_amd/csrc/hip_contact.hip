@@ -155,8 +155,99 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_scaled(const double* __restric
     if (threadIdx.x == 0) out[0] = scale * r;
 }
 
+// ---- deterministic scatter ------------------------------------------------------------------------------------------------------------
+// Barrier and friction terms add into nodes / CSR blocks that several stencils share.  Rounds 1-2 used hardware fp64 atomics: the last
+// bits of g and a[] then depend on the order the atomics retire.  Now every stencil writes its contributions into its OWN slots of a
+// scratch array together with a key (the node, or the CSR position of the 3x3 block); the keys are radix-sorted (stable: equal keys
+// stay in slot order, i.e. stencil order) and one lane per run sums it front to back and adds the sum to the destination -- a fixed
+// summation order, bit-reproducible.  contrib == nullptr keeps the atomic path (IPCGPU_CONTACT_ATOMICS=1, for A/B timing).
+constexpr unsigned KEY_NONE = 0xFFFFFFFFu;
+struct GradSink {
+    double* grad; // atomic path
+    double* contrib; // 3 doubles per slot
+    unsigned* key; // node per slot (prefilled with KEY_NONE)
+};
+__device__ __forceinline__ void sink_add3(const GradSink& k, size_t slot, int node, const double v[3])
+{
+    if (k.contrib) {
+        k.key[slot] = (unsigned)node;
+        k.contrib[3 * slot] = v[0];
+        k.contrib[3 * slot + 1] = v[1];
+        k.contrib[3 * slot + 2] = v[2];
+    }
+    else
+        for (int c = 0; c < 3; ++c) atomicAdd(&k.grad[3 * (size_t)node + c], v[c]);
+}
+struct BlockSink {
+    double* a; // atomic path
+    double* contrib; // 9 doubles per slot, entry (r, c) at r + 3 c
+    unsigned* key; // CSR index of the block's first entry (prefilled with KEY_NONE)
+    int* rowNode; // row node of the block (the reducer derives row length and diagonal / off-diagonal from it)
+};
+// one lane per sorted entry; the head of a run (first entry with its key) sums the run in order
+__global__ __launch_bounds__(BLOCK) void k_seg_sum3(int n, const unsigned* __restrict__ keys, const int* __restrict__ perm, const double* __restrict__ contrib,
+    double* __restrict__ grad)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n) return;
+    const unsigned key = keys[t];
+    if (key == KEY_NONE || (t > 0 && keys[t - 1] == key)) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int u = t; u < n && keys[u] == key; ++u) {
+        const double* q = contrib + 3 * (size_t)perm[u];
+        s0 += q[0];
+        s1 += q[1];
+        s2 += q[2];
+    }
+    double* g = grad + 3 * (size_t)key;
+    g[0] += s0;
+    g[1] += s1;
+    g[2] += s2;
+}
+__global__ __launch_bounds__(BLOCK) void k_seg_sum_blocks(int n, const unsigned* __restrict__ keys, const int* __restrict__ perm, const double* __restrict__ contrib,
+    const int* __restrict__ rowNode, const int* __restrict__ ia, double* __restrict__ a)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n) return;
+    const unsigned key = keys[t];
+    if (key == KEY_NONE || (t > 0 && keys[t - 1] == key)) return;
+    double S[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) S[k] = 0.0;
+    for (int u = t; u < n && keys[u] == key; ++u) {
+        const double* q = contrib + 9 * (size_t)perm[u];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) S[k] += q[k];
+    }
+    const int vi = rowNode[perm[t]], p0 = (int)key;
+    const int base = ia[3 * vi], L = ia[3 * vi + 1] - base;
+    if (p0 == base) { // the diagonal block: its upper triangle
+        a[p0 + 0] += S[0];
+        a[p0 + 1] += S[3];
+        a[p0 + 2] += S[6];
+        a[p0 + L + 0] += S[4];
+        a[p0 + L + 1] += S[7];
+        a[p0 + 2 * L - 1] += S[8];
+    }
+    else {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int rowOff = (r == 0) ? 0 : (r == 1 ? (L - 1) : (2 * L - 3));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) a[p0 + rowOff + c] += S[r + 3 * c];
+        }
+    }
+}
+__global__ void k_iota(int n, int* __restrict__ v)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = i;
+}
+
 // grad += kappa (mult b' grad d)  resp.  kappa (b e' grad c + e b' grad d)   (SelfCollisionHandler.cpp:84-148, 2990-3036)
-__global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, double dHat, double kappa, double* __restrict__ grad)
+// slots: 8 per stencil -- 0..3 the nodes of the distance stencil (active list) resp. the four edge nodes (mollified list), 4..7 the
+// nodes of the distance stencil of a mollified pair
+__global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, double dHat, double kappa, GradSink sink)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < cv.nA) {
@@ -166,8 +257,10 @@ __global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, doub
         const double d = stencil_distance(s.kind, X, g, nullptr);
         barrier(d, dHat, &b, &gb, &Hb);
         const double coef = kappa * s.mult * gb;
-        for (int k = 0; k < s.n; ++k)
-            for (int c = 0; c < 3; ++c) atomicAdd(&grad[3 * (size_t)s.node[k] + c], coef * g[3 * k + c]);
+        for (int k = 0; k < s.n; ++k) {
+            const double v[3] = { coef * g[3 * k], coef * g[3 * k + 1], coef * g[3 * k + 2] };
+            sink_add3(sink, 8 * (size_t)i + k, s.node[k], v);
+        }
     }
     else if (i < cv.nA + cv.nP) {
         const int j = i - cv.nA;
@@ -182,10 +275,14 @@ __global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, doub
         gatherX(cv.x, en, 4, XE);
         const double c = cross_sqnorm_derivs(XE, cg, nullptr);
         mollifier(c, eps_x_of(cv.xRest, en[0], en[1], en[2], en[3]), &e, &eg, &eH);
-        for (int k = 0; k < 4; ++k)
-            for (int cc = 0; cc < 3; ++cc) atomicAdd(&grad[3 * (size_t)en[k] + cc], kappa * b * eg * cg[3 * k + cc]);
-        for (int k = 0; k < s.n; ++k)
-            for (int cc = 0; cc < 3; ++cc) atomicAdd(&grad[3 * (size_t)s.node[k] + cc], kappa * e * gb * g[3 * k + cc]);
+        for (int k = 0; k < 4; ++k) {
+            const double v[3] = { kappa * b * eg * cg[3 * k], kappa * b * eg * cg[3 * k + 1], kappa * b * eg * cg[3 * k + 2] };
+            sink_add3(sink, 8 * (size_t)i + k, en[k], v);
+        }
+        for (int k = 0; k < s.n; ++k) {
+            const double v[3] = { kappa * e * gb * g[3 * k], kappa * e * gb * g[3 * k + 1], kappa * e * gb * g[3 * k + 2] };
+            sink_add3(sink, 8 * (size_t)i + 4 + k, s.node[k], v);
+        }
     }
 }
 __global__ void k_zero_projected(int nV, const int* __restrict__ dbc, int projectDBC, double* __restrict__ grad)
@@ -212,9 +309,36 @@ __device__ __forceinline__ int find_block(const CsrView& m, int rn, int cn)
     return (lo < m.ia[3 * rn + 1] && m.ja[lo] == target) ? lo : -1;
 }
 // scatter the node-block Hessian H (12x12, ld 12) of `n` nodes into the symmetric-upper CSR, skipping projected nodes
-__device__ inline void scatter_blocks(const CsrView& m, double* a, const double* H, const int* node, int n, const int* dbc, int projectDBC,
-    int* err)
+// slot0: first of the 16 slots (4 i + j) this stencil owns in the deterministic path
+__device__ inline void scatter_blocks(const CsrView& m, const BlockSink& sink, size_t slot0, const double* H, const int* node, int n, const int* dbc,
+    int projectDBC, int* err)
 {
+    double* a = sink.a;
+    if (sink.contrib) {
+        for (int i = 0; i < n; ++i) {
+            if (projected_dbc(dbc[node[i]], projectDBC)) continue;
+            for (int j = 0; j < n; ++j) {
+                const int vi = node[i], vj = node[j];
+                if (projected_dbc(dbc[vj], projectDBC) || vi > vj) continue;
+                if (vi == vj && j != i) continue; // (a stencil names a node once)
+                int p0 = m.ia[3 * vi];
+                if (vi != vj) {
+                    p0 = find_block(m, vi, vj);
+                    if (p0 < 0) {
+                        atomicOr(err, 1);
+                        continue;
+                    }
+                }
+                const size_t slot = slot0 + 4 * i + j;
+                sink.key[slot] = (unsigned)p0;
+                sink.rowNode[slot] = vi;
+                double* q = sink.contrib + 9 * slot;
+                for (int r = 0; r < 3; ++r)
+                    for (int c = 0; c < 3; ++c) q[r + 3 * c] = H[(3 * i + r) + 12 * (3 * j + c)];
+            }
+        }
+        return;
+    }
     for (int i = 0; i < n; ++i) {
         if (projected_dbc(dbc[node[i]], projectDBC)) continue;
         for (int j = 0; j < n; ++j) {
@@ -274,7 +398,7 @@ __global__ void k_pattern_check(ContactView cv, CsrView m, int* __restrict__ fla
 // translations, see make_pd_stencil) sit in LDS (2 x 81 x 8 B per stencil)
 constexpr int HESS_T = 32;
 __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
-    double kappa, double* __restrict__ a, int* __restrict__ err)
+    double kappa, BlockSink sink, int* __restrict__ err)
 {
     __shared__ double jac[2 * 81 * HESS_T];
     const int i = blockIdx.x * HESS_T + threadIdx.x;
@@ -292,7 +416,7 @@ __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrV
         for (int r = 0; r < n3; ++r)
             for (int c = 0; c < n3; ++c) B[r + 12 * c] = ((cf * Hb) * g[r]) * g[c] + (cf * gb) * H[r + 12 * c];
         atomicAdd(err + 1, make_pd_stencil(s.n, B, Qs, Ws)); // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it)
-        scatter_blocks(m, a, B, s.node, s.n, dbc, projectDBC, err);
+        scatter_blocks(m, sink, 16 * (size_t)i, B, s.node, s.n, dbc, projectDBC, err);
     }
     else if (i < cv.nA + cv.nP) {
         const int j = i - cv.nA;
@@ -330,7 +454,7 @@ __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrV
                     + (kappa * e * gb) * W[r + 12 * cc];
             }
         make_pd_stencil(4, B, Qs, Ws);
-        scatter_blocks(m, a, B, en, 4, dbc, projectDBC, err);
+        scatter_blocks(m, sink, 16 * (size_t)i, B, en, 4, dbc, projectDBC, err);
     }
 }
 
@@ -479,7 +603,7 @@ __global__ __launch_bounds__(BLOCK) void k_friction_energy(FrictionView fv, cons
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 __global__ __launch_bounds__(BLOCK) void k_friction_gradient(FrictionView fv, const double* __restrict__ x, const double* __restrict__ xt, double eps2,
-    double coef, double* __restrict__ grad)
+    double coef, GradSink sink)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= fv.n) return;
@@ -492,16 +616,19 @@ __global__ __launch_bounds__(BLOCK) void k_friction_gradient(FrictionView fv, co
     const double sc = (x2 > eps2) ? 1.0 / sqrt(x2) : (-sqrt(x2) + 2.0 * eps) / (eps * eps); // f1 / |u|
     double t3[3];
     for (int c = 0; c < 3; ++c) t3[c] = B[c] * (u[0] * sc) + B[3 + c] * (u[1] * sc);
-    for (int k = 0; k < s.n; ++k)
-        for (int c = 0; c < 3; ++c) atomicAdd(&grad[3 * (size_t)s.node[k] + c], coef * fv.lambda[i] * wt[k] * t3[c]);
+    for (int k = 0; k < s.n; ++k) {
+        const double v[3] = { coef * fv.lambda[i] * wt[k] * t3[0], coef * fv.lambda[i] * wt[k] * t3[1], coef * fv.lambda[i] * wt[k] * t3[2] };
+        sink_add3(sink, 8 * (size_t)i + k, s.node[k], v);
+    }
 }
 // H = T^T (aI I + bU u u^T) T.  With orthonormal B, T T^T is a multiple of the identity, so the eigenvalues of H are those of
 // the 2 x 2 core: aI and aI + bU |u|^2, both >= 0 in either regime (sliding: lambda/|u| and 0; sticking: lambda f1/|u| and
 // lambda f2).  The reference's makePD (SelfCollisionHandler.cpp:2783, 2802 ...) is therefore the identity up to round-off
 // and no eigen-solve is needed here; the oracle keeps it and the two agree to 1e-9.
 __global__ __launch_bounds__(BLOCK) void k_friction_hessian(FrictionView fv, CsrView m, const double* __restrict__ x, const double* __restrict__ xt,
-    const int* __restrict__ dbc, int projectDBC, double eps2, double coef, double* __restrict__ a, int* __restrict__ err)
+    const int* __restrict__ dbc, int projectDBC, double eps2, double coef, BlockSink sink, int* __restrict__ err)
 {
+    double* a = sink.a;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= fv.n) return;
     const Stencil s = decode(fv.set + 4 * (size_t)i);
@@ -533,6 +660,22 @@ __global__ __launch_bounds__(BLOCK) void k_friction_hessian(FrictionView fv, Csr
             if (projected_dbc(dbc[vj], projectDBC) || vi > vj) continue;
             const double w = wt[k] * wt[l];
             const int L = m.ia[3 * vi + 1] - m.ia[3 * vi];
+            if (sink.contrib) { // deterministic path: the weighted block into this stencil's slot (4 k + l)
+                if (vi == vj && l != k) continue;
+                int p0 = m.ia[3 * vi];
+                if (vi != vj) {
+                    p0 = find_block(m, vi, vj);
+                    if (p0 < 0) {
+                        atomicOr(err, 1);
+                        continue;
+                    }
+                }
+                const size_t slot = 16 * (size_t)i + 4 * k + l;
+                sink.key[slot] = (unsigned)p0;
+                sink.rowNode[slot] = vi;
+                for (int q = 0; q < 9; ++q) sink.contrib[9 * slot + q] = w * BBt[q];
+                continue;
+            }
             if (vi == vj) {
                 const int base = m.ia[3 * vi];
                 atomicAdd(&a[base + 0], w * BBt[0]);
@@ -1803,7 +1946,12 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
     const int n = nA + nP;
     if (n) {
         ContactView cv{ nA, nP, d_active.p + 4 * (size_t)aB, d_para.p + 4 * (size_t)pB, d_paraEIEJ.p + 2 * (size_t)pB, d_SFE.p, x_dev, d_xRest.p };
-        hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, grad_dev);
+        if (atomicScatter_) hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ grad_dev, nullptr, nullptr });
+        else {
+            detBegin(8 * (size_t)n, 3, false);
+            hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ nullptr, detVals_.p, detKey_.p });
+            detReduce3(8 * (size_t)n, 32, grad_dev);
+        }
     }
     hipLaunchKernelGGL(k_zero_projected, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, projectDBC, grad_dev);
 }
@@ -1820,7 +1968,15 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(2);
     counters_.zero(stream);
-    hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, a_dev, counters_.p);
+    if (atomicScatter_)
+        hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa,
+            BlockSink{ a_dev, nullptr, nullptr, nullptr }, counters_.p);
+    else {
+        detBegin(16 * (size_t)n, 9, true);
+        hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa,
+            BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p }, counters_.p);
+        detReduceBlocks(16 * (size_t)n, 32, lin.d_ia.p, a_dev);
+    }
     int err[2];
     counters_.download(err, 2, stream);
     if (std::getenv("IPCGPU_DEBUG")) std::fprintf(stderr, "[ipcgpu] barrier Hessian: %d stencils, %.2f Jacobi sweeps on average\n", n, (double)err[1] / n);
@@ -1884,12 +2040,53 @@ double HipContact::frictionEnergy(const double* x_dev, const double* xt_dev, dou
     return out;
 }
 
+// ---- deterministic scatter, host side: slots + keys for one launch, then sort and sum the runs -------------------------------------------
+void HipContact::detBegin(size_t nSlots, int valsPerSlot, bool withRow)
+{
+    detVals_.ensure(nSlots * (size_t)valsPerSlot);
+    detKey_.ensure(nSlots);
+    detKeyOut_.ensure(nSlots);
+    detPerm_.ensure(nSlots);
+    if (withRow) detRow_.ensure(nSlots);
+    if (detIota_.n < nSlots || (size_t)detIotaN_ < nSlots) {
+        detIota_.ensure(nSlots);
+        detIotaN_ = (int)detIota_.n;
+        hipLaunchKernelGGL(k_iota, dim3(nblk(detIotaN_)), dim3(BLOCK), 0, stream, detIotaN_, detIota_.p);
+    }
+    HIP_CHECK(hipMemsetAsync(detKey_.p, 0xFF, nSlots * sizeof(unsigned), stream)); // KEY_NONE: slots nobody writes sort to the end
+}
+void HipContact::detSort(size_t nSlots, int keyBits)
+{
+    // unused slots carry KEY_NONE = all ones: they must sort behind every real key, so the top bit takes part
+    (void)keyBits;
+    size_t bytes = 0;
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, 32, stream);
+    if (scanTmp_.n < bytes) scanTmp_.alloc(bytes + bytes / 4);
+    hipcub::DeviceRadixSort::SortPairs((void*)scanTmp_.p, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, 32, stream);
+}
+void HipContact::detReduce3(size_t nSlots, int keyBits, double* grad_dev)
+{
+    detSort(nSlots, keyBits);
+    hipLaunchKernelGGL(k_seg_sum3, dim3(nblk((int)nSlots)), dim3(BLOCK), 0, stream, (int)nSlots, detKeyOut_.p, detPerm_.p, detVals_.p, grad_dev);
+}
+void HipContact::detReduceBlocks(size_t nSlots, int keyBits, const int* ia_dev, double* a_dev)
+{
+    detSort(nSlots, keyBits);
+    hipLaunchKernelGGL(k_seg_sum_blocks, dim3(nblk((int)nSlots)), dim3(BLOCK), 0, stream, (int)nSlots, detKeyOut_.p, detPerm_.p, detVals_.p, detRow_.p, ia_dev,
+        a_dev);
+}
+
 void HipContact::frictionGradientAdd(const double* x_dev, const double* xt_dev, double eps2, double coef, double* grad_dev)
 {
     const int n = (int)fricSet.size();
     if (!n) return;
     FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
-    hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, grad_dev);
+    if (atomicScatter_) hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, GradSink{ grad_dev, nullptr, nullptr });
+    else {
+        detBegin(8 * (size_t)n, 3, false);
+        hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, GradSink{ nullptr, detVals_.p, detKey_.p });
+        detReduce3(8 * (size_t)n, 32, grad_dev);
+    }
 }
 
 void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, const int* dbc_dev, const HipLinSysSolver& lin, double eps2, double coef,
@@ -1901,8 +2098,15 @@ void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, c
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(2);
     counters_.zero(stream);
-    hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef, a_dev,
-        counters_.p);
+    if (atomicScatter_)
+        hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
+            BlockSink{ a_dev, nullptr, nullptr, nullptr }, counters_.p);
+    else {
+        detBegin(16 * (size_t)n, 9, true);
+        hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
+            BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p }, counters_.p);
+        detReduceBlocks(16 * (size_t)n, 32, lin.d_ia.p, a_dev);
+    }
     int err[2];
     counters_.download(err, 2, stream);
     if (err[0]) throw StateError("friction Hessian touches a node pair outside the CSR pattern: the pattern must contain the lagged set's connectivity");
