@@ -361,21 +361,22 @@ __device__ __forceinline__ void element_generators(const ElemView& v, int t, dou
             for (int i = 0; i < 3; ++i) gradFn(k, i, P[i] * b[k][0] + P[i + 3] * b[k][1] + P[i + 6] * b[k][2]);
         }
     };
-    double lnJ = 0.0;
-    const bool fcrStress = fcr && stiff && wantGrad; // FCR needs R = U V^T for the stress: SVD first
-    if (wantGrad && !fcrStress) {
-        double P[9];
-        lnJ = piola(F, mu, lam, w, P);
-        emitForces(P);
-    }
+    // The nodal forces are emitted LAST (end of this function): a kernel that accumulates them in a fixed order (patch_assembly.hip
+    // takes its waves one after the other) then holds the twelve values in registers for a few instructions only, not across the SVD.
+    const bool fcrStress = fcr && stiff && wantGrad; // FCR needs R = U V^T for the stress
     double s[3], V[9];
     if (g.active || fcrStress) svd3(F, g.U, s, V);
-    if (fcrStress) {
+    auto forces = [&]() {
+        if (!wantGrad) return;
         double P[9];
-        fcr_piola(F, g.U, s, V, mu, lam, w, P);
+        if (fcrStress) fcr_piola(F, g.U, s, V, mu, lam, w, P);
+        else piola(F, mu, lam, w, P);
         emitForces(P);
+    };
+    if (!g.active) {
+        forces();
+        return;
     }
-    if (!g.active) return;
     double dE[3], inv[3], A3[6], BL[3];
     if (fcr) { // FixedCoRotEnergy.cpp:72-144
         const double prod = s[0] * s[1] * s[2];
@@ -395,7 +396,7 @@ __device__ __forceinline__ void element_generators(const ElemView& v, int t, dou
         BL[2] = mu - hl * s[1] * (prod - 1.0);
     }
     else { // sigma-space derivatives (NeoHookeanEnergy.cpp:71-136)
-        const double L = wantGrad ? lnJ : log(s[0] * s[1] * s[2]); // det F = s0 s1 s2 (U, V rotations)
+        const double L = log(s[0] * s[1] * s[2]); // det F = s0 s1 s2 (U, V rotations)
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             inv[i] = fast_rcp(s[i]);
@@ -438,6 +439,7 @@ __device__ __forceinline__ void element_generators(const ElemView& v, int t, dou
     for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int q = 0; q < 3; ++q) g.beta[k][q] = V[3 * q] * b[k][0] + V[3 * q + 1] * b[k][1] + V[3 * q + 2] * b[k][2];
+    forces();
 }
 
 // H = U T U^T for the node pair with sigma-space shape vectors ba, bc

@@ -46,17 +46,19 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_patch(ElemView v, PatchView 
         __syncthreads();
     }
     // ---- phase 1: generators of every element touching the patch
-    for (int tl = tid; tl < nTets; tl += BLOCK) {
+    for (int base = 0; base < nTets; base += BLOCK) { // (uniform trip count: the loop body holds barriers)
+        const int tl = base + tid;
+        const bool act = tl < nTets;
+        uint16_t gs[4] = { 0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu };
+        double fb[12]; // forces of this lane's element on its four nodes
+#pragma unroll
+        for (int k = 0; k < 12; ++k) fb[k] = 0.0;
+        if (act) {
         const int inst = t0 + tl;
-        uint16_t gs[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) gs[k] = grad ? pv.gradSlot[(size_t)k * pv.totalTets + inst] : (uint16_t)0xFFFF;
         ElemGen g;
-        element_generators(v, pv.tets[inst], coef, projectDBC, grad != nullptr, HESS,
-            [&](int k, int i, double val) {
-                if (gs[k] != 0xFFFFu) atomicAdd(&gacc[3 * (int)gs[k] + i], val); // ds_add_f64, 12 per element
-            },
-            g);
+        element_generators(v, pv.tets[inst], coef, projectDBC, grad != nullptr, HESS, [&](int k, int i, double val) { fb[3 * k + i] = val; }, g);
         if (HESS) {
             int mask = g.active ? 16 : 0;
 #pragma unroll
@@ -77,6 +79,23 @@ __global__ __launch_bounds__(BLOCK) void k_assemble_patch(ElemView v, PatchView 
                 for (int k = 0; k < 4; ++k)
 #pragma unroll
                     for (int q = 0; q < 3; ++q) e[24 + 3 * k + q] = g.beta[k][q];
+            }
+        }
+        }
+        if (grad) {
+            // nodal forces into the LDS accumulators, ONE WAVE AT A TIME and in instruction order inside a wave: the order of the
+            // additions to a node is then a function of the plan alone, and the gradient comes out with the same bits on every run
+            // (ds_add_f64 across waves retires in scheduling order -- measured: last-bit noise run to run)
+            for (int w = 0; w < BLOCK / 64; ++w) {
+                if ((tid >> 6) == w && act) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (gs[k] != 0xFFFFu) {
+#pragma unroll
+                            for (int i = 0; i < 3; ++i) atomicAdd(&gacc[3 * (int)gs[k] + i], fb[3 * k + i]); // ds_add_f64, 12 per element
+                        }
+                }
+                __syncthreads();
             }
         }
     }
