@@ -1371,6 +1371,7 @@ int ipcgpu_opt_get_state(ipcgpu_ctx* c, double* V, double* p, double* g, double*
 int ipcgpu_opt_get_timers(ipcgpu_ctx* c, double* t)
 {
     return guarded([&] {
+        O(c).resolveEventTimers();
         std::memcpy(t, O(c).timers, sizeof(double) * 16);
         return IPCGPU_OK;
     });

@@ -214,6 +214,15 @@ public:
     ipcgpu_allreduce_fn_t allreduce = nullptr;
     ipcgpu_allreduce_stream_fn_t allreduceStream = nullptr; // takes precedence: enqueued on `stream`, no host synchronisation
     void hookReduce(double* dev, long long n, int op);
+    // Contact-free single-rank iterations (the matTwist bench): the scalars the host branches on come back in batches -- one read after the
+    // solve (|p|_inf for the next convergence test, the inversion step filter, E at the current iterate), one after the trial step (inversion
+    // flag + E at the trial point) -- instead of one host synchronisation per scalar; the assembly bucket is timed with HIP events.
+    bool fastPath() const;
+    bool cachedDistValid = false, cachedE0Valid = false;
+    double cachedDist = 0, cachedE0 = 0, cachedFilter = 0;
+    hipEvent_t evAsm0 = nullptr, evAsm1 = nullptr;
+    bool evAsmPending = false;
+    void resolveEventTimers();
     DevBuf<double> d_contactG; // this rank's share of the barrier forces before their all-reduce (contact-pair lists sharded)
     void* allreduceUser = nullptr;
     void reduceSum(double* dev, long long n);

@@ -962,15 +962,77 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
     launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
     if (!ok) lin.precondition_diag(d_minusG.p, d_searchDir.p); // Optimizer.cpp:2331-2348
     else lin.solve(d_minusG.p, d_searchDir.p);
+    if (fastPath()) {
+        // everything the host needs next, behind the solve on the same stream, read back with ONE synchronisation (the Tic's): |p|_inf
+        // (convergence test of the next pass, Optimizer.cpp:1869-1879), the inversion step filter (:1887) and E at the current iterate
+        // (line search entry, :2681)
+        launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+        launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+        launch_fill(d_scalar.p + 2, 1, 1e20, stream);
+        if (mesh.energyType != 1) launch_inversion_step(view(), d_searchDir.p, 0.2, d_scalar.p + 2, stream);
+        launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
+        launch_publish(d_scalar.p, h_scalar.dev, 8, stream); // 4 doubles = 8 words
+        HIP_CHECK(hipStreamSynchronize(stream));
+        cachedE0 = h_scalar.p[0];
+        cachedFilter = h_scalar.p[2];
+        cachedDist = h_scalar.p[3];
+        cachedDistValid = cachedE0Valid = true;
+    }
+}
+
+bool HipOptimizer::fastPath() const
+{
+    static const bool off = std::getenv("IPCGPU_NO_FASTPATH") != nullptr; // A/B: the one-scalar-per-synchronisation flow of rounds 1-2
+    return !off && worldSize == 1 && !ipOn() && nbcGroups.empty() && !(dampingStiff > 0.0) && !(rhoDBC && !tpIds.empty());
+}
+
+void HipOptimizer::resolveEventTimers()
+{
+    if (!evAsmPending) return;
+    HIP_CHECK(hipEventSynchronize(evAsm1));
+    float ms = 0.0f;
+    HIP_CHECK(hipEventElapsedTime(&ms, evAsm0, evAsm1));
+    timers[0] += 1.0e-3 * (double)ms;
+    evAsmPending = false;
 }
 
 void HipOptimizer::lineSearch(double& stepSize)
 {
+    const size_t bytes = 3 * (size_t)mesh.nV * sizeof(double);
+    if (cachedE0Valid && fastPath()) {
+        // E at the iterate came back with the solve; the trial step, its inversion flag and E at the trial point are enqueued together
+        // and read with one synchronisation.  Anything but "not inverted and E decreased" falls through to the general loop below.
+        cachedE0Valid = false;
+        lastEnergyVal = cachedE0; // Optimizer.cpp:2681
+        bool done = false;
+        double testingE = 0.0;
+        {
+            Tic t(timers[5], stream);
+            HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, bytes, hipMemcpyDeviceToDevice, stream));
+            stepForward(d_x0.p, stepSize);
+            int inverted = 0;
+            if (mesh.energyType != 1) {
+                d_flag.zero(stream);
+                launch_check_inversion(view(), d_flag.p, stream);
+                launch_publish(d_flag.p, h_flag.dev, 1, stream);
+            }
+            launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
+            launch_publish(d_scalar.p, h_scalar.dev, 2, stream);
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (mesh.energyType != 1) inverted = h_flag.p[0];
+            testingE = h_scalar.p[0];
+            done = !inverted && !(testingE > lastEnergyVal);
+        }
+        if (done) {
+            lastEnergyVal = testingE;
+            return;
+        }
+        HIP_CHECK(hipMemcpyAsync(mesh.d_x.p, d_x0.p, bytes, hipMemcpyDeviceToDevice, stream)); // back to the iterate: the general loop redoes the step
+    }
     {
         Tic t(timers[9], stream);
         lastEnergyVal = computeEnergyVal(); // Optimizer.cpp:2681
     }
-    const size_t bytes = 3 * (size_t)mesh.nV * sizeof(double);
     {
         Tic t(timers[5], stream);
         HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, bytes, hipMemcpyDeviceToDevice, stream));
@@ -1194,24 +1256,46 @@ void HipOptimizer::dirichletPenaltyUpdate()
 bool HipOptimizer::newtonIter()
 {
     // convergence test (Optimizer.cpp:1869-1879) looks at the search direction of the previous pass
-    launch_fill(d_scalar.p + 3, 1, 0.0, stream);
-    launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
-    const double distToOpt_PN = readScalar(d_scalar.p + 3);
+    double distToOpt_PN;
+    if (k && cachedDistValid && fastPath()) distToOpt_PN = cachedDist; // read back with the last solve
+    else {
+        launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+        launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+        distToOpt_PN = k ? readScalar(d_scalar.p + 3) : 0.0; // (the test needs k > 0)
+    }
+    cachedDistValid = false;
     if (k && distToOpt_PN < targetGRes && completedStep > 1.0 - 1.0e-3) { // :1874-1879
         Tic t(timers[12], stream);
         computeGradient(projDBC); // the reference leaves the gradient of the converged state behind (:1861)
         return true;
     }
     innerIterAmt++;
-    {
+    if (fastPath()) {
+        // the assembly is timed with events: no host synchronisation between it and the factorisation
+        resolveEventTimers();
+        if (!evAsm0) {
+            HIP_CHECK(hipEventCreate(&evAsm0));
+            HIP_CHECK(hipEventCreate(&evAsm1));
+        }
+        HIP_CHECK(hipEventRecord(evAsm0, stream));
+        computePrecondMtr(projDBC, true);
+        HIP_CHECK(hipEventRecord(evAsm1, stream));
+        evAsmPending = true;
+    }
+    else {
         // gradient (:1861) and Hessian (:2327) come out of one fused element pass
         Tic t(timers[0], stream);
         computePrecondMtr(projDBC, true);
     }
+    cachedE0Valid = false;
     computeSearchDir(projDBC);
     double alpha = 1.0;
     {
         Tic t(timers[13], stream);
+        if (cachedE0Valid) { // Optimizer.cpp:1887 with the value the solve's batch brought back
+            if (mesh.energyType != 1 && cachedFilter > 0.0 && cachedFilter < alpha) alpha = cachedFilter;
+        }
+        else
         alpha = filterStepSize(d_searchDir.p, alpha); // Optimizer.cpp:1887
         for (auto& h : planes) // slackness_a = 0.9 (:1886-1890)
             alpha = h->stepBound(contact->nSVI, contact->d_SVI.p, mesh.d_x.p, mesh.d_dbc.p, d_searchDir.p, 0.9, alpha);

@@ -426,6 +426,14 @@ def accd(kind, X, P, eta=0.2, tmax=1.0):
     return lib().orc_accd(C.c_int(kind), _dp(X), _dp(P), C.c_double(eta), C.c_double(tmax))
 
 
+def unclassified_d2(kind, X):
+    """Squared distance of the stencil as a whole (point-triangle / segment-segment as closed sets): what accd advances on."""
+    X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
+    lib().orc_unclassified_distance.restype = C.c_double
+    d = lib().orc_unclassified_distance(C.c_int(kind), _dp(X))
+    return d * d
+
+
 def ccd_exact(kind, X, P, tmax=1.0):
     """First time in [0, tmax] at which the point touches the triangle / the edges cross (eta = 0, cubic coplanarity roots), inf if none."""
     X = np.ascontiguousarray(X, dtype=np.float64).reshape(4, 3)
