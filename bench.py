@@ -47,8 +47,9 @@ SHARD_MIN_TETS = 4_000_000  # ~1.8 ms of assembly on one GPU: where splitting it
 
 def pmc_traffic(size):
     """HBM bytes per launch of the assembly kernel as measured with the PMC counters (same workload), or None."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_assembly_traffic.json")
-    if size != 150 or not os.path.exists(path):
+    name = "r03_pmc_assembly_traffic.json" if size == 150 else f"r03_pmc_assembly_traffic_mat{size}.json"
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+    if not os.path.exists(path):
         return None
     with open(path) as f:
         return float(json.load(f)["traffic_bytes"])
@@ -224,8 +225,9 @@ def main():
                 "kernel": "k_assemble_patch<true> (fused NH gradient + PSD-projected Hessian + mass/DBC diagonal -> symmetric-upper CSR, atomic-free)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.size),
-                "traffic_source": "profiles/r01_pmc_assembly_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, "
-                                  "calibrated in-run on a 1 GiB device copy (tools/pmc_traffic.py); bytes per launch",
+                "traffic_source": "NOT a live counter: read from profiles/r03_pmc_assembly_traffic*.json, measured this round on this kernel with "
+                                  "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated in-run on a 1 GiB device copy "
+                                  "(tools/pmc_traffic.py, tools/gpu_round3.sh); bytes per launch",
                 "algorithmic_bytes": bytes_asm, "avg_launch_ms": ms_asm,
                 "measured_stream_copy_GBs": stream_gbs,
             },

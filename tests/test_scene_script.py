@@ -469,7 +469,7 @@ def test_dcofix_scene_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
         no, ng = ob.solve_timestep(80), gb.solve_timestep(80)
         assert no < 80 and ng < 80
         so, sg = ob.state(), gb.state()
-        assert sg["dHat"] == so["dHat"] and sg["kappa"] == pytest.approx(so["kappa"], rel=1e-9)
+        assert sg["dHat"] == so["dHat"] and sg["kappa"] == pytest.approx(so["kappa"], rel=1e-7)  # kappa_bal = -g_c.g_E / |g_c|^2 cancels: a ratio that amplifies round-off
         cs_o, cs_g = orc.opt_contact_state(ob.o), gb.contact_state()
         assert cs_g["nActive"] == len(cs_o["active"]), k
         seen = max(seen, cs_g["nActive"])

@@ -15,15 +15,17 @@ import json
 import os
 import sys
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COPY_BYTES = 1 << 30
 
 
-def workload():
+def workload(size=150):
     sys.path.insert(0, ROOT)
     import numpy as np
     from ipc_amd import lib, scene
-    V, F = scene.make_mat(150)
+    V, F = scene.make_mat(size)
     c = lib.Context(0)
     c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
     c.opt_init(0.04, False)
@@ -60,25 +62,34 @@ def summarise(d, counter):
     return sum(big) / len(big), sum(asm) / len(asm), len(asm)
 
 
-def parse(rd_dir, wr_dir):
+def parse(rd_dir, wr_dir, size=150):
+    sys.path.insert(0, ROOT)
+    from ipc_amd import scene
+    V, F = scene.make_mat(size)
+    nT, nV = F.shape[0], V.shape[0]
     rd_copy, rd_asm, n1 = summarise(rd_dir, "FETCH_SIZE")
     wr_copy, wr_asm, n2 = summarise(wr_dir, "WRITE_SIZE")
     rd_scale, wr_scale = COPY_BYTES / rd_copy, COPY_BYTES / wr_copy
     out = {
-        "kernel": "k_assemble_patch<true>", "workload": "mat150 (133206 tets)", "launches_averaged": [n1, n2],
+        "kernel": "k_assemble_patch<true>", "workload": f"mat{size} ({nT} tets)", "launches_averaged": [n1, n2],
         "calibration": {"copy_bytes": COPY_BYTES, "FETCH_SIZE_per_copy": rd_copy, "WRITE_SIZE_per_copy": wr_copy,
                         "bytes_per_FETCH_SIZE_unit": rd_scale, "bytes_per_WRITE_SIZE_unit": wr_scale},
         "raw": {"FETCH_SIZE": rd_asm, "WRITE_SIZE": wr_asm},
         "read_bytes": rd_asm * rd_scale, "write_bytes": wr_asm * wr_scale,
         "traffic_bytes": rd_asm * rd_scale + wr_asm * wr_scale,
-        "algorithmic_bytes": 112 * 133206 + 84 * 45000 + 8 * 2278827,
     }
+    # B_asm = 112 nT + 84 nV + 8 nnz; nnz of the symmetric-upper CSR with 3x3 node blocks = 6 nV + 9 #edges
+    edges = set()
+    for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3)):
+        lo, hi = np.minimum(F[:, a], F[:, b]), np.maximum(F[:, a], F[:, b])
+        edges.update((lo.astype(np.int64) * nV + hi).tolist())
+    out["algorithmic_bytes"] = 112 * nT + 84 * nV + 8 * (6 * nV + 9 * len(edges))
     out["traffic_over_algorithmic"] = out["traffic_bytes"] / out["algorithmic_bytes"]
     print(json.dumps(out, indent=1))
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "workload":
-        workload()
+        workload(int(sys.argv[2]) if len(sys.argv) > 2 else 150)
     else:
-        parse(sys.argv[2], sys.argv[3])
+        parse(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 150)
