@@ -82,6 +82,7 @@ public:
     void analyze_pattern(const HipMesh* meshForCoords);
     bool factorize();
     void solve(const double* rhs_dev, double* x_dev);
+    bool factorizeSolve(const double* rhs_dev, double* x_dev); // factorize + solve, forward sweep overlapped with the factorisation
     void multiply(const double* x_dev, double* y_dev);
     void precondition_diag(const double* in_dev, double* out_dev);
     int getNumRows() const { return numRows; }

@@ -289,6 +289,16 @@ bool HipLinSysSolver::factorize()
     return f == 0;
 }
 
+// factorize() followed by solve(), with the forward sweep running beside the factorisation (MfNumeric::factorizeSolve)
+bool HipLinSysSolver::factorizeSolve(const double* rhs_dev, double* x_dev)
+{
+    if (!analyzed_) throw StateError("factorize before analyze_pattern");
+    if (solverType == 0) return num_.factorizeSolve(d_a.p, rhs_dev, x_dev);
+    const bool ok = factorize();
+    if (ok) solve(rhs_dev, x_dev);
+    return ok;
+}
+
 void HipLinSysSolver::solve(const double* rhs_dev, double* x_dev)
 {
     if (!analyzed_) throw StateError("solve before analyze_pattern");

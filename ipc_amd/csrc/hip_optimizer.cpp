@@ -954,14 +954,17 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
 {
     (void)projectDBC;
     bool ok;
+    static const bool twoCalls = std::getenv("IPCGPU_MF_NO_FWD_OVERLAP") != nullptr; // A/B: factorize(), then solve()
+    launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
     {
+        // the right-hand side is known before the factorisation starts: the forward sweep of each level runs beside the pivot chain of
+        // the levels above (MfNumeric::factorizeSolve); this bucket then holds factorisation + both sweeps
         Tic t(timers[3], stream);
-        ok = lin.factorize();
+        ok = twoCalls ? lin.factorize() : lin.factorizeSolve(d_minusG.p, d_searchDir.p);
     }
     Tic t(timers[4], stream);
-    launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
     if (!ok) lin.precondition_diag(d_minusG.p, d_searchDir.p); // Optimizer.cpp:2331-2348
-    else lin.solve(d_minusG.p, d_searchDir.p);
+    else if (twoCalls) lin.solve(d_minusG.p, d_searchDir.p);
     if (fastPath()) {
         // everything the host needs next, behind the solve on the same stream, read back with ONE synchronisation (the Tic's): |p|_inf
         // (convergence test of the next pass, Optimizer.cpp:1869-1879), the inversion step filter (:1887) and E at the current iterate

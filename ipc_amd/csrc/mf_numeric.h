@@ -34,11 +34,14 @@ public:
     bool factorize(const double* a_dev);
     // rhs_dev / x_dev: device vectors in the user's ordering
     void solve(const double* rhs_dev, double* x_dev);
+    // factorize(a) and solve(rhs) in one go, the forward sweep overlapped with the factorisation (single rank); returns false when a
+    // non-positive pivot was met (x is then meaningless)
+    bool factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev);
     bool ready() const { return ns_ > 0; }
     size_t front_bytes() const { return fronts_.n * sizeof(double); }
 
 private:
-    void enqueueFactor(const double* a_dev);
+    void enqueueFactor(const double* a_dev, bool overlapForward = false);
     void enqueueSolve(const double* rhs_dev, double* x_dev);
     void dropGraphs();
     hipGraphExec_t graphF_ = nullptr, graphS_ = nullptr;
@@ -98,6 +101,13 @@ private:
     Range plainBlocks_; // diagonal blocks of all other fronts (inverted at the end of the factorisation)
     DevBuf<int> invBlockList_;
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
+    // factorizeSolve(): the forward sweep of a level is enqueued on its own stream as soon as that level's factor kernels are, so that it
+    // runs beside the latency-bound pivot chain of the levels above instead of behind the whole factorisation
+    hipStream_t fwd_ = nullptr;
+    hipEvent_t evRhs_ = nullptr, evFwdDone_ = nullptr;
+    std::vector<hipEvent_t> evFactLevel_;
+    void enqueueForwardLevel(int l, hipStream_t st);
+    void enqueueBackward(double* x_dev);
     hipEvent_t evSide_ = nullptr;
     std::vector<hipEvent_t> evLevel_, evInvDone_;
     bool sidePending_ = false; // the last factorisation left work on the side stream that nothing has waited for yet

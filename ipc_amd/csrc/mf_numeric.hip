@@ -2180,6 +2180,16 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
+    if (!fwd_ && !std::getenv("IPCGPU_MF_NO_FWD_OVERLAP")) {
+        HIP_CHECK(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreateWithFlags(&evRhs_, hipEventDisableTiming));
+        HIP_CHECK(hipEventCreateWithFlags(&evFwdDone_, hipEventDisableTiming));
+    }
+    while ((int)evFactLevel_.size() < nLevels_) {
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        evFactLevel_.push_back(e);
+    }
     while ((int)evLevel_.size() < nLevels_) {
         hipEvent_t e;
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -2702,6 +2712,11 @@ MfNumeric::~MfNumeric()
 {
     dropGraphs();
     if (side_) (void)hipStreamSynchronize(side_);
+    if (fwd_) (void)hipStreamSynchronize(fwd_);
+    for (hipEvent_t e : evFactLevel_) (void)hipEventDestroy(e);
+    if (evRhs_) (void)hipEventDestroy(evRhs_);
+    if (evFwdDone_) (void)hipEventDestroy(evFwdDone_);
+    if (fwd_) (void)hipStreamDestroy(fwd_);
     for (hipEvent_t e : evLevel_) (void)hipEventDestroy(e);
     for (hipEvent_t e : evInvDone_) (void)hipEventDestroy(e);
     if (evSide_) (void)hipEventDestroy(evSide_);
@@ -2754,7 +2769,32 @@ bool MfNumeric::factorize(const double* a_dev)
     return hflag_.p[0] == 0;
 }
 
-void MfNumeric::enqueueFactor(const double* a_dev)
+bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev)
+{
+    if (!sym_) throw StateError("factorize before analyze_pattern");
+    if (world_ > 1 || !fwd_ || useGraph_) { // sharded / captured runs keep the two-call sequence
+        const bool ok = factorize(a_dev);
+        if (ok) solve(rhs_dev, x_dev);
+        return ok;
+    }
+    const MfSymbolic& sym = *sym_;
+    const int n3 = sym.n;
+    // the right-hand side is ready on the main stream now: permute it on the forward stream, then level by level behind the factorisation
+    HIP_CHECK(hipEventRecord(evRhs_, stream_));
+    HIP_CHECK(hipStreamWaitEvent(fwd_, evRhs_, 0));
+    hipLaunchKernelGGL(k_permute_rhs, dim3((n3 + 255) / 256), dim3(256), 0, fwd_, sym.nn, newOf_.p, rhs_dev, bperm_.p);
+    enqueueFactor(a_dev, true);
+    HIP_CHECK(hipEventRecord(evFwdDone_, fwd_));
+    hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, stream_, flag_.p, hflag_.dev);
+    // the backward sweep follows the root's forward result; enqueued before the flag is looked at (a failed pivot makes x meaningless,
+    // the caller falls back to the diagonal preconditioner as after factorize() == false)
+    HIP_CHECK(hipStreamWaitEvent(stream_, evFwdDone_, 0));
+    enqueueBackward(x_dev);
+    HIP_CHECK(hipStreamSynchronize(stream_));
+    return hflag_.p[0] == 0;
+}
+
+void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
 {
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
@@ -2825,6 +2865,14 @@ void MfNumeric::enqueueFactor(const double* a_dev)
             }
             else enqueueInverses(l, stream_);
         }
+        if (overlapForward) {
+            // everything the forward sweep of this level reads is final (factor panels, pivot-block inverses; the triangle inverses of the
+            // widest fronts follow on the side stream): hand the level to the forward stream, which runs beside the levels above
+            HIP_CHECK(hipEventRecord(evFactLevel_[l], stream_));
+            HIP_CHECK(hipStreamWaitEvent(fwd_, evFactLevel_[l], 0));
+            if (plan_[l].xinvFwd.cnt && sideUsed) HIP_CHECK(hipStreamWaitEvent(fwd_, evInvDone_[l], 0));
+            enqueueForwardLevel(l, fwd_);
+        }
     }
     // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)
 #ifdef MF_PHASE_TIMERS
@@ -2885,19 +2933,8 @@ void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
     hipLaunchKernelGGL(k_permute_rhs, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, rhs_dev, bperm_.p);
     for (int l = 0; l < nLevels_; ++l) {
         const LevelPlan& P = plan_[l];
-        if (P.small.cnt)
-            hipLaunchKernelGGL(k_fwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, wOff_.p,
-                fronts_.p, dinv_.p, w_.p, bperm_.p, yperm_.p);
-        if (P.bigTri.cnt)
-            hipLaunchKernelGGL(k_big_fwd_tri, dim3(P.bigTri.cnt), dim3(WGT), P.triLds, stream_, triList_.p + P.bigTri.off, tv, wOff_.p,
-                fronts_.p, dinv_.p, w_.p, bperm_.p, yperm_.p);
         if (P.xinvFwd.cnt && sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evInvDone_[l], 0));
-        if (P.xinvFwd.cnt)
-            hipLaunchKernelGGL(k_xinv_fwd, dim3(P.xinvFwd.cnt), dim3(WG), xinvLds_, stream_, xinvDesc_.p + P.xinvFwd.off, tv, xv, wOff_.p, w_.p,
-                bperm_.p, yperm_.p);
-        if (P.fwdRect.cnt)
-            hipLaunchKernelGGL(k_big_fwd_rect, dim3(P.fwdRect.cnt), dim3(WG), 0, stream_, desc_.p + P.fwdRect.off, tv, wOff_.p, fronts_.p, w_.p,
-                yperm_.p);
+        enqueueForwardLevel(l, stream_);
         if (world_ > 1 && xchg_[l].pack.cnt) { // update vectors of the subtree roots of this level -> every rank
             const Xchg& X = xchg_[l];
             xchgBuf_.zeroN((size_t)X.countW, stream_);
@@ -2908,6 +2945,32 @@ void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
                 ownerDev_.p);
         }
     }
+    enqueueBackward(x_dev);
+}
+
+void MfNumeric::enqueueForwardLevel(int l, hipStream_t st)
+{
+    TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
+    XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
+    const LevelPlan& P = plan_[l];
+    if (P.small.cnt)
+        hipLaunchKernelGGL(k_fwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, st, smallList_.p + P.small.off, tv, wOff_.p, fronts_.p, dinv_.p, w_.p,
+            bperm_.p, yperm_.p);
+    if (P.bigTri.cnt)
+        hipLaunchKernelGGL(k_big_fwd_tri, dim3(P.bigTri.cnt), dim3(WGT), P.triLds, st, triList_.p + P.bigTri.off, tv, wOff_.p, fronts_.p, dinv_.p, w_.p,
+            bperm_.p, yperm_.p);
+    if (P.xinvFwd.cnt)
+        hipLaunchKernelGGL(k_xinv_fwd, dim3(P.xinvFwd.cnt), dim3(WG), xinvLds_, st, xinvDesc_.p + P.xinvFwd.off, tv, xv, wOff_.p, w_.p, bperm_.p, yperm_.p);
+    if (P.fwdRect.cnt)
+        hipLaunchKernelGGL(k_big_fwd_rect, dim3(P.fwdRect.cnt), dim3(WG), 0, st, desc_.p + P.fwdRect.off, tv, wOff_.p, fronts_.p, w_.p, yperm_.p);
+}
+
+void MfNumeric::enqueueBackward(double* x_dev)
+{
+    const MfSymbolic& sym = *sym_;
+    TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
+    XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
+    const int n3 = sym.n;
     for (int l = nLevels_ - 1; l >= 0; --l) {
         const LevelPlan& P = plan_[l];
         if (P.bwdInit.cnt)
