@@ -118,7 +118,7 @@ private:
         DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items);
     DevBuf<int> d_cand_, d_ids_;
     DevBuf<double> d_vals_;
-    DevBuf<unsigned long long> ccdOut_;
+    DevBuf<unsigned long long> ccdOut_, ccdHits_;
     DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
     DevBuf<int> d_v2sv, refVbox_, cellCountV_, cellStartV_, cellItemsV_; // reference-mode sweep: node -> surface index, index boxes, vertex cells
     DevBuf<double> bboxPartial_;

@@ -1,6 +1,7 @@
 // Contact kernels + HipContact host logic (gfx950).  Compiled with -ffp-contract=off (exact-comparison typing).
 #include "hip_contact.h"
 #include "contact_device.h"
+#include "jacobi9_device.h"
 #include "hip_ipc.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
@@ -396,13 +397,20 @@ __global__ void k_pattern_check(ContactView cv, CsrView m, int* __restrict__ fla
 // a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201)
 // HESS_T stencils per workgroup: the two 9 x 9 matrices the Jacobi sweeps iterate on (the block reduced by the three rigid
 // translations, see make_pd_stencil) sit in LDS (2 x 81 x 8 B per stencil)
+// REG: the Jacobi iterates live in registers (jacobi9_device.h; one wave per workgroup, no LDS) -- the default.  The LDS version is kept
+// behind IPCGPU_HESS_LDS for A/B runs.
 constexpr int HESS_T = 32;
-__global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
-    double kappa, BlockSink sink, int* __restrict__ err)
+constexpr int HESS_R = 64;
+template <bool REG>
+__global__ __launch_bounds__(REG ? HESS_R : HESS_T) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
+    double kappa, BlockSink sink, int* __restrict__ err, int probe)
 {
-    __shared__ double jac[2 * 81 * HESS_T];
-    const int i = blockIdx.x * HESS_T + threadIdx.x;
-    const Strided Qs{ jac + threadIdx.x, HESS_T }, Ws{ jac + 81 * HESS_T + threadIdx.x, HESS_T };
+    // probe (IPCGPU_HESS_PROBE, timing runs only -- the result is then wrong): 1 skips the projection, 2 also the scatter
+    constexpr int T = REG ? HESS_R : HESS_T;
+    __shared__ double jac[REG ? 1 : 2 * 81 * HESS_T];
+    const int i = blockIdx.x * T + threadIdx.x;
+    const Strided Qs{ jac + (REG ? 0 : threadIdx.x), T }, Ws{ jac + (REG ? 0 : 81 * T + threadIdx.x), T };
+    int sweepsDone = 0; // summed over the wave below: one atomic per wave instead of one per stencil
     double H[144], B[144];
     if (i < cv.nA) {
         const Stencil s = decode(cv.active + 4 * (size_t)i);
@@ -415,8 +423,9 @@ __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrV
         for (int k = 0; k < 144; ++k) B[k] = 0.0;
         for (int r = 0; r < n3; ++r)
             for (int c = 0; c < n3; ++c) B[r + 12 * c] = ((cf * Hb) * g[r]) * g[c] + (cf * gb) * H[r + 12 * c];
-        atomicAdd(err + 1, make_pd_stencil(s.n, B, Qs, Ws)); // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it)
-        scatter_blocks(m, sink, 16 * (size_t)i, B, s.node, s.n, dbc, projectDBC, err);
+        if (probe < 1) sweepsDone = REG ? j9::make_pd_stencil_reg(s.n, B) : make_pd_stencil(s.n, B, Qs, Ws);
+        if (probe < 2) scatter_blocks(m, sink, 16 * (size_t)i, B, s.node, s.n, dbc, projectDBC, err);
+        else if (B[0] == 12345.678) err[0] = 1; // keeps the block alive
     }
     else if (i < cv.nA + cv.nP) {
         const int j = i - cv.nA;
@@ -453,9 +462,13 @@ __global__ __launch_bounds__(HESS_T) void k_contact_hessian(ContactView cv, CsrV
                 B[r + 12 * cc] = (kappa * gb) * gd[r] * e_g_c + (kappa * gb) * gd[cc] * e_g_r + (kappa * b) * e_H + ((kappa * e * Hb) * gd[r]) * gd[cc]
                     + (kappa * e * gb) * W[r + 12 * cc];
             }
-        make_pd_stencil(4, B, Qs, Ws);
+        if (REG) j9::make_pd_stencil_reg(4, B);
+        else make_pd_stencil(4, B, Qs, Ws);
         scatter_blocks(m, sink, 16 * (size_t)i, B, en, 4, dbc, projectDBC, err);
     }
+    // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it)
+    for (int o = 32; o; o >>= 1) sweepsDone += __shfl_xor(sweepsDone, o);
+    if ((threadIdx.x & 63) == 0 && sweepsDone) atomicAdd(err + 1, sweepsDone);
 }
 
 // ---- lagged friction (FrictionUtils.hpp:24-347, SelfCollisionHandler.cpp:2481-2988) --------------
@@ -744,7 +757,69 @@ __global__ __launch_bounds__(BLOCK) void k_bbox_partial(int nV, const double* __
         partial[6 * (size_t)blockIdx.x + threadIdx.x] = r;
     }
 }
-// mode 0: count, mode 1: fill.  Primitive = triangle (isTri) or surface edge, bbox inflated by `infl`
+// Candidate walks (narrow phase, CCD sweeps, intersection test).  A surface has ~1e5 primitives and a primitive ~1e2 candidates behind a chain
+// of dependent loads (cell range -> item -> its nodes -> their positions): one lane per primitive leaves the machine two waves per SIMD, each
+// lane serialising its chains.  What the walks cost in round 2 (k_narrow_ee 0.57 ms, k_ref_sweep_edge 0.83 ms, k_ref_sweep_vertex 0.56 ms for
+// 1.2e5 edges / 4e4 vertices) and what measurements on the contact benchmark said about it, in the order tried:
+//   * COOP lanes share a primitive and stride over the ITEMS of each cell (eight times the waves in flight): narrow phase and intersection
+//     test 2-3x faster, the sweeps unchanged.  Splitting the CELLS of a primitive's box over the lanes instead was 2.5x slower;
+//   * 32-byte records in cell order instead of indices (below): no gather chain before the box test -- by itself no change either;
+//   * what the sweeps were actually waiting for: a global counter bumped once per queried pair.  Same-address atomics retire at ~2.5 ns each
+//     whatever the number of lanes: 3e5 of them ARE the 0.8 ms.  Counters now live in registers and are added once per wave at the end
+//     (wave_count_add), found pairs are collected per workgroup in LDS (WgList), the limiting pair comes out of a hit list instead of a second
+//     run of the sweep: k_ref_sweep_edge 2 x 0.83 -> 0.44 ms, k_ref_sweep_vertex 2 x 0.56 -> 0.11 ms, k_narrow_ee 0.27 ms, k_narrow_pt 0.036 ms.
+//   Listing the candidates first and querying them one lane per pair in a second kernel (balanced queries) was tried as well: the list costs one
+//   same-address atomic per group of lanes that reach the append together -- in a divergent walk almost one per pair -- and ran 5x slower.
+constexpr int COOP = 8;
+constexpr int SWEEP_COOP = 8;
+// A slot of a device-side list for every lane that is active here: ONE atomic per wave (the lanes of a candidate walk reach this point a few
+// at a time; a counter bumped once per candidate by 3e5 lanes serialises in the L2 atomic unit).
+__device__ __forceinline__ int wave_slot(int* counter)
+{
+    const unsigned long long m = __ballot(1);
+    const int lane = (int)__lane_id();
+    int base = 0;
+    if (lane == __ffsll((long long)m) - 1) base = atomicAdd(counter, __popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+// What a cell list holds.  With bare primitive indices, every candidate of a walk costs a chain of gathers -- index -> its nodes -> their positions
+// (or node -> surface vertex -> voxel box): 3-5 scattered 32-64 B sectors per candidate, ~1e7 candidates per walk, and the walks sat at the L2's
+// gather rate whatever the number of lanes.  The lists therefore hold 32-byte RECORDS in cell order -- the primitive and the box the insertion
+// computed anyway -- so that a walk streams its candidates and touches a primitive's nodes only when the boxes overlap:
+//   uniform grid (narrow phase, intersection test):  (index, float lo[3], float hi[3], 0), the inflated box rounded OUTWARDS to float -- a
+//       conservative first test; the exact double test on the positions follows for the survivors, unchanged
+//   reference voxel grid (CCD sweeps):               (index, int lo[3], int hi[3], 0), the voxel box itself -- the test on it is the exact one
+constexpr int REC = 8; // ints per record
+__device__ __forceinline__ float f_down(double v)
+{
+    const float f = (float)v;
+    return ((double)f > v) ? nextafterf(f, -INFINITY) : f;
+}
+__device__ __forceinline__ float f_up(double v)
+{
+    const float f = (float)v;
+    return ((double)f < v) ? nextafterf(f, INFINITY) : f;
+}
+struct BoxRec {
+    int id;
+    float lo[3], hi[3];
+};
+__device__ __forceinline__ BoxRec load_box_rec(const int* __restrict__ recs, int k)
+{
+    const int4 r0 = reinterpret_cast<const int4*>(recs)[2 * (size_t)k], r1 = reinterpret_cast<const int4*>(recs)[2 * (size_t)k + 1];
+    return BoxRec{ r0.x, { __int_as_float(r0.y), __int_as_float(r0.z), __int_as_float(r0.w) }, { __int_as_float(r1.x), __int_as_float(r1.y), __int_as_float(r1.z) } };
+}
+struct VoxRec {
+    int id;
+    int b[6];
+};
+__device__ __forceinline__ VoxRec load_vox_rec(const int* __restrict__ recs, int k)
+{
+    const int4 r0 = reinterpret_cast<const int4*>(recs)[2 * (size_t)k], r1 = reinterpret_cast<const int4*>(recs)[2 * (size_t)k + 1];
+    return VoxRec{ r0.x, { r0.y, r0.z, r0.w, r1.x, r1.y, r1.z } };
+}
+// mode 0: count, mode 1: fill (records, see above).  Primitive = triangle (isTri) or surface edge, bbox inflated by `infl`
 __global__ __launch_bounds__(BLOCK) void k_grid_insert(int nPrim, int isTri, const int* __restrict__ prim, const double* __restrict__ x, Grid g,
     double infl, int mode, int* __restrict__ cellCount, const int* __restrict__ cellStart, int* __restrict__ cellItems)
 {
@@ -770,23 +845,68 @@ __global__ __launch_bounds__(BLOCK) void k_grid_insert(int nPrim, int isTri, con
             for (int xx = a[0]; xx <= b[0]; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
                 const int slot = atomicAdd(&cellCount[cell], 1);
-                if (mode == 1) cellItems[cellStart[cell] + slot] = i;
+                if (mode == 1) {
+                    int4* r = reinterpret_cast<int4*>(cellItems) + 2 * (size_t)(cellStart[cell] + slot);
+                    r[0] = make_int4(i, __float_as_int(f_down(bl[0])), __float_as_int(f_down(bl[1])), __float_as_int(f_down(bl[2])));
+                    r[1] = make_int4(__float_as_int(f_up(bh[0])), __float_as_int(f_up(bh[1])), __float_as_int(f_up(bh[2])), 0);
+                }
             }
 }
 
-// out record: 6 ints = MMCVID (4) + (svI | eI, sfI | eJ)
+// Output of the narrow phase: records of 6 ints = MMCVID (4) + (svI | eI, sfI | eJ), appended to a global list.  A workgroup collects its
+// records in LDS and reserves its range of the list with ONE atomic at the end (7.8e4 records through one global counter were 0.2 ms of
+// serialised same-address atomics); a workgroup that finds more than WG_RECS falls back to the global counter for the excess.
+constexpr int WG_RECS = 512;
+struct WgList {
+    int* count; // LDS
+    int* recs; // LDS, 6 * WG_RECS
+};
+__device__ __forceinline__ void wg_list_put(const WgList& w, const int* id, int i, int j, int cap, int* __restrict__ out, int* __restrict__ counter)
+{
+    int slot = atomicAdd(w.count, 1);
+    int* o;
+    if (slot < WG_RECS) o = w.recs + 6 * slot;
+    else {
+        slot = atomicAdd(counter, 1);
+        if (slot >= cap) return;
+        o = out + 6 * (size_t)slot;
+    }
+    o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
+    o[4] = i; o[5] = j;
+}
+__device__ __forceinline__ void wg_list_flush(const WgList& w, int* sBase, int cap, int* __restrict__ out, int* __restrict__ counter) // all threads
+{
+    __syncthreads();
+    const int n = min(*w.count, WG_RECS);
+    if (threadIdx.x == 0) *sBase = n ? atomicAdd(counter, n) : 0;
+    __syncthreads();
+    const int base = *sBase;
+    for (int e = threadIdx.x; e < 6 * n; e += BLOCK) {
+        const int slot = base + e / 6;
+        if (slot < cap) out[6 * (size_t)slot + e % 6] = w.recs[e];
+    }
+}
 __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __restrict__ SVI, const int* __restrict__ SF, const double* __restrict__ x,
     const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, int cap,
     int* __restrict__ out, int* __restrict__ counter)
 {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= nSVI) return;
+    __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
+    const WgList wl{ &sCount, sRecs };
+    if (threadIdx.x == 0) sCount = 0;
+    __syncthreads();
+    const int gi = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = gi / COOP < nSVI; // lanes past the end walk an empty range: every thread reaches the flush
+    const int i = valid ? gi / COOP : 0, sub = gi % COOP; // COOP lanes share a vertex and stride over the cell's triangles (see COOP)
     const int vI = SVI[i];
     const double p[3] = { x[3 * (size_t)vI], x[3 * (size_t)vI + 1], x[3 * (size_t)vI + 2] };
     const int cell = cell_of(g, p[0], 0) + g.dim[0] * (cell_of(g, p[1], 1) + g.dim[1] * cell_of(g, p[2], 2));
     const bool vDbc = (dbc[vI] & 1) != 0; // dbc: pair flags (bit 0 Dirichlet, bit 1 obstacle node, bit 2 obstacle-only filter on)
-    for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
-        const int f = cellItems[k];
+    const int kEnd = valid ? cellStart[cell + 1] : 0;
+    for (int k = cellStart[cell] + sub; k < kEnd; k += COOP) {
+        const BoxRec rec = load_box_rec(cellItems, k);
+        // a point closer than sqrt(dHat) to the triangle lies inside the triangle's box inflated by that much
+        if (p[0] < rec.lo[0] || p[0] > rec.hi[0] || p[1] < rec.lo[1] || p[1] > rec.hi[1] || p[2] < rec.lo[2] || p[2] > rec.hi[2]) continue;
+        const int f = rec.id;
         const int t0 = SF[3 * (size_t)f], t1 = SF[3 * (size_t)f + 1], t2 = SF[3 * (size_t)f + 2];
         if (vI == t0 || vI == t1 || vI == t2) continue;
         if (vDbc && (dbc[t0] & 1) && (dbc[t1] & 1) && (dbc[t2] & 1)) continue; // SelfCollisionHandler.cpp:2184-2187
@@ -805,23 +925,47 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __rest
         case 5: d = d_PE(p, c, a); id[1] = t2; id[2] = t0; break;
         default: d = d_PT(p, a, b, c); id[1] = t0; id[2] = t1; id[3] = t2; break;
         }
-        if (d < dHat) {
-            const int slot = atomicAdd(counter, 1);
-            if (slot < cap) {
-                int* o = out + 6 * (size_t)slot;
-                o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
-                o[4] = i; o[5] = f;
-            }
-        }
+        if (d < dHat) wg_list_put(wl, id, i, f, cap, out, counter);
     }
+    wg_list_flush(wl, &sBase, cap, out, counter);
 }
 
+// typing, distance and the MMCVID tuple of one edge pair that passed the box tests (SelfCollisionHandler.cpp:2270-2400)
+__device__ __forceinline__ void narrow_ee_pair(int eI, int eJ, int a0, int a1, int b0, int b1, const double* pa0, const double* pa1, const double* pb0,
+    const double* pb1, const double* __restrict__ xRest, int nE, double dHat, const WgList& wl, int cap, int* __restrict__ out, int* __restrict__ counter)
+{
+    const int dt = dType_EE(pa0, pa1, pb0, pb1);
+    const int add_e = (cross_sqnorm(pa0, pa1, pb0, pb1) < eps_x_of(xRest, a0, a1, b0, b1)) ? -eJ - 2 : -1;
+    double d;
+    int id[4];
+    switch (dt) {
+    case 0: d = d_PP(pa0, pb0); id[0] = -a0 - 1; id[1] = b0; id[2] = -1; id[3] = add_e; break;
+    case 1: d = d_PP(pa0, pb1); id[0] = -a0 - 1; id[1] = b1; id[2] = -1; id[3] = add_e; break;
+    case 2: d = d_PE(pa0, pb0, pb1); id[0] = -a0 - 1; id[1] = b0; id[2] = b1; id[3] = add_e; break;
+    case 3: d = d_PP(pa1, pb0); id[0] = -a1 - 1; id[1] = b0; id[2] = -1; id[3] = add_e; break;
+    case 4: d = d_PP(pa1, pb1); id[0] = -a1 - 1; id[1] = b1; id[2] = -1; id[3] = add_e; break;
+    case 5: d = d_PE(pa1, pb0, pb1); id[0] = -a1 - 1; id[1] = b0; id[2] = b1; id[3] = add_e; break;
+    case 6: d = d_PE(pb0, pa0, pa1); id[0] = -b0 - 1; id[1] = a0; id[2] = a1; id[3] = add_e; break;
+    case 7: d = d_PE(pb1, pa0, pa1); id[0] = -b1 - 1; id[1] = a0; id[2] = a1; id[3] = add_e; break;
+    default:
+        d = d_EE(pa0, pa1, pb0, pb1);
+        id[0] = a0; id[1] = a1; id[2] = b0;
+        id[3] = (add_e <= -2) ? (-b1 - nE - 2) : b1;
+        break;
+    }
+    if (d < dHat) wg_list_put(wl, id, eI, eJ, cap, out, counter);
+}
 __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
     const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
     int* __restrict__ out, int* __restrict__ counter)
 {
-    const int eI = blockIdx.x * BLOCK + threadIdx.x;
-    if (eI >= nE) return;
+    __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
+    const WgList wl{ &sCount, sRecs };
+    if (threadIdx.x == 0) sCount = 0;
+    __syncthreads();
+    const int gi = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = gi / COOP < nE; // see k_narrow_pt
+    const int eI = valid ? gi / COOP : 0, sub = gi % COOP;
     const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1];
     const double pa0[3] = { x[3 * (size_t)a0], x[3 * (size_t)a0 + 1], x[3 * (size_t)a0 + 2] };
     const double pa1[3] = { x[3 * (size_t)a1], x[3 * (size_t)a1 + 1], x[3 * (size_t)a1 + 2] };
@@ -834,13 +978,18 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
         cb[c] = cell_of(g, bh[c], c);
     }
     const bool aDbc = (dbc[a0] & 1) && (dbc[a1] & 1);
-    for (int z = ca[2]; z <= cb[2]; ++z)
+    const float blF[3] = { f_down(bl[0]), f_down(bl[1]), f_down(bl[2]) }, bhF[3] = { f_up(bh[0]), f_up(bh[1]), f_up(bh[2]) };
+    for (int z = ca[2], zEnd = valid ? cb[2] : -1; z <= zEnd; ++z)
         for (int y = ca[1]; y <= cb[1]; ++y)
             for (int xx = ca[0]; xx <= cb[0]; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
-                for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
-                    const int eJ = cellItems[k];
+                const int kEnd = cellStart[cell + 1];
+                for (int k = cellStart[cell] + sub; k < kEnd; k += COOP) {
+                    const BoxRec rec = load_box_rec(cellItems, k);
+                    const int eJ = rec.id;
                     if (eJ <= eI) continue;
+                    if (blF[0] > rec.hi[0] || rec.lo[0] > bhF[0] || blF[1] > rec.hi[1] || rec.lo[1] > bhF[1] || blF[2] > rec.hi[2] || rec.lo[2] > bhF[2])
+                        continue; // outward-rounded boxes apart: the exact ones below are too
                     const int b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
                     if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
                     const double pb0[3] = { x[3 * (size_t)b0], x[3 * (size_t)b0 + 1], x[3 * (size_t)b0 + 2] };
@@ -856,37 +1005,11 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
                     if (!ok || canon[0] != xx || canon[1] != y || canon[2] != z) continue;
                     if (aDbc && (dbc[b0] & 1) && (dbc[b1] & 1)) continue; // SelfCollisionHandler.cpp:2294-2297
                     if (pair_filtered(dbc[a0], dbc[b0])) continue;
-                    const int dt = dType_EE(pa0, pa1, pb0, pb1);
-                    const int add_e = (cross_sqnorm(pa0, pa1, pb0, pb1) < eps_x_of(xRest, a0, a1, b0, b1)) ? -eJ - 2 : -1;
-                    double d;
-                    int id[4];
-                    switch (dt) {
-                    case 0: d = d_PP(pa0, pb0); id[0] = -a0 - 1; id[1] = b0; id[2] = -1; id[3] = add_e; break;
-                    case 1: d = d_PP(pa0, pb1); id[0] = -a0 - 1; id[1] = b1; id[2] = -1; id[3] = add_e; break;
-                    case 2: d = d_PE(pa0, pb0, pb1); id[0] = -a0 - 1; id[1] = b0; id[2] = b1; id[3] = add_e; break;
-                    case 3: d = d_PP(pa1, pb0); id[0] = -a1 - 1; id[1] = b0; id[2] = -1; id[3] = add_e; break;
-                    case 4: d = d_PP(pa1, pb1); id[0] = -a1 - 1; id[1] = b1; id[2] = -1; id[3] = add_e; break;
-                    case 5: d = d_PE(pa1, pb0, pb1); id[0] = -a1 - 1; id[1] = b0; id[2] = b1; id[3] = add_e; break;
-                    case 6: d = d_PE(pb0, pa0, pa1); id[0] = -b0 - 1; id[1] = a0; id[2] = a1; id[3] = add_e; break;
-                    case 7: d = d_PE(pb1, pa0, pa1); id[0] = -b1 - 1; id[1] = a0; id[2] = a1; id[3] = add_e; break;
-                    default:
-                        d = d_EE(pa0, pa1, pb0, pb1);
-                        id[0] = a0; id[1] = a1; id[2] = b0;
-                        id[3] = (add_e <= -2) ? (-b1 - nE - 2) : b1;
-                        break;
-                    }
-                    if (d < dHat) {
-                        const int slot = atomicAdd(counter, 1);
-                        if (slot < cap) {
-                            int* o = out + 6 * (size_t)slot;
-                            o[0] = id[0]; o[1] = id[1]; o[2] = id[2]; o[3] = id[3];
-                            o[4] = eI; o[5] = eJ;
-                        }
-                    }
+                    narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
                 }
             }
+    wg_list_flush(wl, &sBase, cap, out, counter);
 }
-
 // ---- conservative CCD (advancement on the unclassified distance until it meets the gap; contract in DESIGN.md) ---------------
 // Converged to ADVANCE_TOL * (initial distance): a bound that stops one step short of the gap jumps by up to a fifth of itself
 // when the iteration count changes, and the Newton path that leans on it would not be reproducible.
@@ -947,6 +1070,11 @@ __device__ __forceinline__ unsigned long long pair_key(int kind, int i, int j)
 struct CcdOut {
     unsigned long long* minBits; // bit pattern of the smallest time (positive doubles order like integers)
     unsigned long long* argKey; // smallest order key among the pairs that attain it
+    // pairs that returned a time below the step (few: most candidates of a sweep do not meet inside it) as (time bits, order key): the pair
+    // that attains the minimum is then found by one small pass over this list instead of a second run of the whole sweep
+    unsigned long long* hits = nullptr;
+    int* hitCount = nullptr;
+    int hitCap = 0;
 };
 __device__ __forceinline__ void ccd_record_min(double t, double tmax, CcdOut o)
 {
@@ -955,6 +1083,27 @@ __device__ __forceinline__ void ccd_record_min(double t, double tmax, CcdOut o)
 __device__ __forceinline__ void ccd_record_arg(double t, unsigned long long key, CcdOut o)
 {
     if ((unsigned long long)__double_as_longlong(t) == *o.minBits) atomicMin(o.argKey, key);
+}
+// pass 0 of a sweep that keeps a hit list: the minimum, and the pair for the pass over the list
+__device__ __forceinline__ void ccd_record_hit(double t, double tmax, unsigned long long key, CcdOut o)
+{
+    if (!(t < tmax)) return;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(t);
+    atomicMin(o.minBits, bits);
+    if (o.hits) {
+        const int slot = atomicAdd(o.hitCount, 1);
+        if (slot < o.hitCap) {
+            o.hits[2 * (size_t)slot] = bits;
+            o.hits[2 * (size_t)slot + 1] = key;
+        }
+    }
+}
+__global__ __launch_bounds__(BLOCK) void k_ccd_hits_arg(CcdOut o)
+{
+    const int n = min(*o.hitCount, o.hitCap);
+    const unsigned long long best = *o.minBits;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
+        if (o.hits[2 * (size_t)i] == best) atomicMin(o.argKey, o.hits[2 * (size_t)i + 1]);
 }
 
 // pass 0: minimum time; pass 1: first pair attaining it
@@ -1241,7 +1390,11 @@ __global__ __launch_bounds__(BLOCK) void k_ref_insert(int nPrim, int nv, const i
             for (int xx = b[0] / g.m; xx <= b[3] / g.m; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
                 const int slot = atomicAdd(&cellCount[cell], 1);
-                if (mode == 1) cellItems[cellStart[cell] + slot] = i;
+                if (mode == 1) {
+                    int4* r = reinterpret_cast<int4*>(cellItems) + 2 * (size_t)(cellStart[cell] + slot);
+                    r[0] = make_int4(i, b[0], b[1], b[2]);
+                    r[1] = make_int4(b[3], b[4], b[5], 0);
+                }
             }
 }
 // point-point (n = 2) / point-segment (n = 3) advancement: the scheme of accd() on the point-point / point-segment distance
@@ -1321,65 +1474,77 @@ __device__ __forceinline__ unsigned long long ref_key(int isEE, int i, int rank,
 struct RefLists {
     const int *startV, *itemsV, *startE, *itemsE, *startT, *itemsT;
 };
+// one candidate pair of a sweep: its time bound, the minimum, the hit list (pass 0) or the first pair attaining the minimum (pass 1).  The
+// number of queried pairs is kept in a register and added up once per wave at the end of the kernel: bumped per candidate, a global counter
+// serialised 3e5 same-address atomics -- 0.8 ms of the sweep's 0.9, whatever the walk did.
+__device__ __forceinline__ void ref_pair(int kind, const int* node, unsigned long long key, const double* __restrict__ x, const double* __restrict__ p,
+    double slackness, double alpha, int pass, CcdOut o, int& nQueried)
+{
+    if (pass == 0) ++nQueried;
+    const double t = ref_pair_bound(kind, node, x, p, slackness, alpha);
+    if (pass == 0) ccd_record_hit(t, alpha, key, o);
+    else ccd_record_arg(t, key, o);
+}
+__device__ __forceinline__ void wave_count_add(int v, int* __restrict__ counter) // every lane of the wave must call it
+{
+#pragma unroll
+    for (int off = 32; off; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(counter, v);
+}
 __global__ __launch_bounds__(BLOCK) void k_ref_sweep_vertex(int nSVI, const int* __restrict__ SVI, const int* __restrict__ SF, const int* __restrict__ SFE,
     const double* __restrict__ x, const double* __restrict__ p, const int* __restrict__ pf, const int* __restrict__ v2sv, const int* __restrict__ vbox,
     RefGrid g, RefLists L, double alpha, double slackness, int pass, CcdOut o, int* __restrict__ nCand)
 {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= nSVI) return;
+    const int gi = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = gi / SWEEP_COOP < nSVI; // lanes past the end walk an empty range: every lane reaches the wave sum at the end
+    const int i = valid ? gi / SWEEP_COOP : 0, sub = gi % SWEEP_COOP; // SWEEP_COOP lanes share a vertex (see COOP)
     const int vI = SVI[i];
     const int* bi = vbox + 6 * (size_t)i;
     const bool vDbc = (pf[vI] & 1) != 0;
-    for (int z = bi[2] / g.m; z <= bi[5] / g.m; ++z)
+    int nQueried = 0;
+    for (int z = bi[2] / g.m, zEnd = valid ? bi[5] / g.m : -1; z <= zEnd; ++z)
         for (int y = bi[1] / g.m; y <= bi[4] / g.m; ++y)
             for (int xx = bi[0] / g.m; xx <= bi[3] / g.m; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
                 // vertices svJ > svI
-                for (int k = L.startV[cell]; k < L.startV[cell + 1]; ++k) {
-                    const int j = L.itemsV[k];
+                for (int k = L.startV[cell] + sub, kEnd = L.startV[cell + 1]; k < kEnd; k += SWEEP_COOP) {
+                    const VoxRec rec = load_vox_rec(L.itemsV, k);
+                    const int j = rec.id;
                     if (j <= i) continue;
-                    const int* bj = vbox + 6 * (size_t)j;
+                    const int* bj = rec.b;
                     if (!ref_share(bi, bj) || !ref_canon(g, bi, bj, xx, y, z)) continue;
                     const int vJ = SVI[j];
                     if (vDbc && (pf[vJ] & 1)) continue;
                     if (pair_filtered(pf[vI], pf[vJ])) continue;
                     const int node[4] = { vI, vJ, vJ, vJ };
-                    if (pass == 0) atomicAdd(nCand, 1);
-                    const double t = ref_pair_bound(K_PP, node, x, p, slackness, alpha);
-                    if (pass == 0) ccd_record_min(t, alpha, o);
-                    else ccd_record_arg(t, ref_key(0, i, 0, j), o);
+                    ref_pair(K_PP, node, ref_key(0, i, 0, j), x, p, slackness, alpha, pass, o, nQueried);
                 }
                 // edges that do not contain the vertex
-                for (int k = L.startE[cell]; k < L.startE[cell + 1]; ++k) {
-                    const int e = L.itemsE[k];
+                for (int k = L.startE[cell] + sub, kEnd = L.startE[cell + 1]; k < kEnd; k += SWEEP_COOP) {
+                    const VoxRec rec = load_vox_rec(L.itemsE, k);
+                    const int e = rec.id;
+                    const int* be = rec.b; // the edge's voxel box as the insertion computed it
+                    if (!ref_share(bi, be) || !ref_canon(g, bi, be, xx, y, z)) continue;
                     const int node[4] = { vI, SFE[2 * (size_t)e], SFE[2 * (size_t)e + 1], SFE[2 * (size_t)e + 1] };
                     if (node[1] == vI || node[2] == vI) continue;
-                    int be[6];
-                    ref_box(node + 1, 2, v2sv, vbox, be);
-                    if (!ref_share(bi, be) || !ref_canon(g, bi, be, xx, y, z)) continue;
                     if (vDbc && (pf[node[1]] & 1) && (pf[node[2]] & 1)) continue;
                     if (pair_filtered(pf[vI], pf[node[1]])) continue;
-                    if (pass == 0) atomicAdd(nCand, 1);
-                    const double t = ref_pair_bound(K_PE, node, x, p, slackness, alpha);
-                    if (pass == 0) ccd_record_min(t, alpha, o);
-                    else ccd_record_arg(t, ref_key(0, i, 1, e), o);
+                    ref_pair(K_PE, node, ref_key(0, i, 1, e), x, p, slackness, alpha, pass, o, nQueried);
                 }
                 // triangles that do not contain the vertex
-                for (int k = L.startT[cell]; k < L.startT[cell + 1]; ++k) {
-                    const int f = L.itemsT[k];
+                for (int k = L.startT[cell] + sub, kEnd = L.startT[cell + 1]; k < kEnd; k += SWEEP_COOP) {
+                    const VoxRec rec = load_vox_rec(L.itemsT, k);
+                    const int f = rec.id;
+                    const int* bt = rec.b;
+                    if (!ref_share(bi, bt) || !ref_canon(g, bi, bt, xx, y, z)) continue;
                     const int node[4] = { vI, SF[3 * (size_t)f], SF[3 * (size_t)f + 1], SF[3 * (size_t)f + 2] };
                     if (vI == node[1] || vI == node[2] || vI == node[3]) continue;
-                    int bt[6];
-                    ref_box(node + 1, 3, v2sv, vbox, bt);
-                    if (!ref_share(bi, bt) || !ref_canon(g, bi, bt, xx, y, z)) continue;
                     if (vDbc && (pf[node[1]] & 1) && (pf[node[2]] & 1) && (pf[node[3]] & 1)) continue;
                     if (pair_filtered(pf[vI], pf[node[1]])) continue;
-                    if (pass == 0) atomicAdd(nCand, 1);
-                    const double t = ref_pair_bound(K_PT, node, x, p, slackness, alpha);
-                    if (pass == 0) ccd_record_min(t, alpha, o);
-                    else ccd_record_arg(t, ref_key(0, i, 2, f), o);
+                    ref_pair(K_PT, node, ref_key(0, i, 2, f), x, p, slackness, alpha, pass, o, nQueried);
                 }
             }
+    wave_count_add(nQueried, nCand);
 }
 // edge pairs eJ > eI that share a cell and whose boxes swept over alphaEE (the bound the vertex sweeps left) overlap
 __global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ p,
@@ -1387,8 +1552,10 @@ __global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __r
     const int* __restrict__ itemsE, double alpha, const unsigned long long* __restrict__ alphaEEBits, double slackness, int pass, CcdOut o,
     int* __restrict__ nCand)
 {
-    const int eI = blockIdx.x * BLOCK + threadIdx.x;
-    if (eI >= nE) return;
+    const int gi = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = gi / SWEEP_COOP < nE; // see k_ref_sweep_vertex
+    const int eI = valid ? gi / SWEEP_COOP : 0, sub = gi % SWEEP_COOP;
+    int nQueried = 0;
     double alphaEE = alpha;
     if (*alphaEEBits != ~0ull) alphaEE = fmin(alpha, __longlong_as_double((long long)*alphaEEBits));
     int node[4] = { SFE[2 * (size_t)eI], SFE[2 * (size_t)eI + 1], 0, 0 };
@@ -1402,18 +1569,18 @@ __global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __r
         hi[c] = fmax(fmax(a0, b0), fmax(a1, b1));
     }
     const bool aDbc = (pf[node[0]] & 1) && (pf[node[1]] & 1);
-    for (int z = bi[2] / g.m; z <= bi[5] / g.m; ++z)
+    for (int z = bi[2] / g.m, zEnd = valid ? bi[5] / g.m : -1; z <= zEnd; ++z)
         for (int y = bi[1] / g.m; y <= bi[4] / g.m; ++y)
             for (int xx = bi[0] / g.m; xx <= bi[3] / g.m; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
-                for (int k = startE[cell]; k < startE[cell + 1]; ++k) {
-                    const int eJ = itemsE[k];
+                for (int k = startE[cell] + sub, kEnd = startE[cell + 1]; k < kEnd; k += SWEEP_COOP) {
+                    const VoxRec rec = load_vox_rec(itemsE, k);
+                    const int eJ = rec.id;
                     if (eJ <= eI) continue;
+                    const int* bj = rec.b;
+                    if (!ref_share(bi, bj) || !ref_canon(g, bi, bj, xx, y, z)) continue;
                     node[2] = SFE[2 * (size_t)eJ];
                     node[3] = SFE[2 * (size_t)eJ + 1];
-                    int bj[6];
-                    ref_box(node + 2, 2, v2sv, vbox, bj);
-                    if (!ref_share(bi, bj) || !ref_canon(g, bi, bj, xx, y, z)) continue;
                     bool apart = false;
                     for (int c = 0; c < 3; ++c) {
                         const double a0 = x[3 * (size_t)node[2] + c], a1 = x[3 * (size_t)node[3] + c];
@@ -1425,12 +1592,10 @@ __global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __r
                     if (node[0] == node[2] || node[0] == node[3] || node[1] == node[2] || node[1] == node[3]) continue;
                     if (aDbc && (pf[node[2]] & 1) && (pf[node[3]] & 1)) continue;
                     if (pair_filtered(pf[node[0]], pf[node[2]])) continue;
-                    if (pass == 0) atomicAdd(nCand, 1);
-                    const double t = ref_pair_bound(K_EE, node, x, p, slackness, alpha);
-                    if (pass == 0) ccd_record_min(t, alpha, o);
-                    else ccd_record_arg(t, ref_key(1, eI, 0, eJ), o);
+                    ref_pair(K_EE, node, ref_key(1, eI, 0, eJ), x, p, slackness, alpha, pass, o, nQueried);
                 }
             }
+    wave_count_add(nQueried, nCand);
 }
 
 // IglUtils::segTriIntersect without exact predicates (IglUtils.hpp:236-245, 258-264)
@@ -1455,7 +1620,8 @@ __device__ inline bool seg_tri_intersect(const double* ve0, const double* ve1, c
 __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restrict__ SF, const int* __restrict__ SFE, const double* __restrict__ x,
     const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, int* __restrict__ flag)
 {
-    const int f = blockIdx.x * BLOCK + threadIdx.x;
+    const int gi = blockIdx.x * BLOCK + threadIdx.x;
+    const int f = gi / COOP, sub = gi % COOP; // COOP lanes share a triangle and stride over the edges of each cell (see COOP)
     if (f >= nSF) return;
     const int t0 = SF[3 * (size_t)f], t1 = SF[3 * (size_t)f + 1], t2 = SF[3 * (size_t)f + 2];
     double a[3], b[3], c[3], lo[3], hi[3];
@@ -1470,12 +1636,16 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
         cb[k] = cell_of(g, hi[k], k);
     }
     const bool tDbc = (dbc[t0] & 1) && (dbc[t1] & 1) && (dbc[t2] & 1);
+    const float loF[3] = { f_down(lo[0]), f_down(lo[1]), f_down(lo[2]) }, hiF[3] = { f_up(hi[0]), f_up(hi[1]), f_up(hi[2]) };
     for (int z = ca[2]; z <= cb[2]; ++z)
         for (int y = ca[1]; y <= cb[1]; ++y)
             for (int xx = ca[0]; xx <= cb[0]; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
-                for (int k = cellStart[cell]; k < cellStart[cell + 1]; ++k) {
-                    const int e = cellItems[k];
+                for (int k = cellStart[cell] + sub, kEnd = cellStart[cell + 1]; k < kEnd; k += COOP) {
+                    const BoxRec rec = load_box_rec(cellItems, k);
+                    if (rec.lo[0] > hiF[0] || rec.hi[0] < loF[0] || rec.lo[1] > hiF[1] || rec.hi[1] < loF[1] || rec.lo[2] > hiF[2] || rec.hi[2] < loF[2])
+                        continue; // outward-rounded boxes apart: the exact test below would say the same
+                    const int e = rec.id;
                     const int e0 = SFE[2 * (size_t)e], e1 = SFE[2 * (size_t)e + 1];
                     if (e0 == t0 || e0 == t1 || e0 == t2 || e1 == t0 || e1 == t1 || e1 == t2) continue;
                     if (tDbc && (dbc[e0] & 1) && (dbc[e1] & 1)) continue;
@@ -1778,22 +1948,22 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         int total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        items.ensure(std::max(1, total));
+        items.ensure((size_t)REC * std::max(1, total));
         cnt.zeroN((size_t)nCells + 1, stream);
         hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, isTri, prim, x_dev, g, infl, 1, cnt.p, start.p, items.p);
     };
     buildCells(nSF, 1, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
     buildCells(nSFE, 0, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
-    counters_.alloc(2);
+    counters_.alloc(4);
     int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
     int nPT = 0, nEE = 0;
     for (;;) {
         outPT_.alloc(6 * (size_t)capPT);
         outEE_.alloc(6 * (size_t)capEE);
         counters_.zero(stream);
-        hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, pf, g, cellStartT_.p, cellItemsT_.p,
+        hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(COOP * nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, pf, g, cellStartT_.p, cellItemsT_.p,
             dHat, capPT, outPT_.p, counters_.p);
-        hipLaunchKernelGGL(k_narrow_ee, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, cellStartE_.p,
+        hipLaunchKernelGGL(k_narrow_ee, dim3(nblk(COOP * nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, cellStartE_.p,
             cellItemsE_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1);
         int cnt[2];
         counters_.download(cnt, 2, stream);
@@ -1966,15 +2136,20 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     if (!n) return;
     ContactView cv{ aE - aB, pE - pB, d_active.p + 4 * (size_t)aB, d_para.p + 4 * (size_t)pB, d_paraEIEJ.p + 2 * (size_t)pB, d_SFE.p, x_dev, d_xRest.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
-    counters_.alloc(2);
+    counters_.alloc(4);
     counters_.zero(stream);
-    if (atomicScatter_)
-        hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa,
-            BlockSink{ a_dev, nullptr, nullptr, nullptr }, counters_.p);
+    static const int probe = std::getenv("IPCGPU_HESS_PROBE") ? std::atoi(std::getenv("IPCGPU_HESS_PROBE")) : 0;
+    static const bool ldsJacobi = std::getenv("IPCGPU_HESS_LDS") != nullptr; // A/B: the Jacobi iterates in LDS (rounds 1-2)
+    auto launch = [&](const BlockSink& sink) {
+        if (ldsJacobi)
+            hipLaunchKernelGGL(k_contact_hessian<false>, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, sink, counters_.p, probe);
+        else
+            hipLaunchKernelGGL(k_contact_hessian<true>, dim3(nblk(n, HESS_R)), dim3(HESS_R), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, sink, counters_.p, probe);
+    };
+    if (atomicScatter_) launch(BlockSink{ a_dev, nullptr, nullptr, nullptr });
     else {
         detBegin(16 * (size_t)n, 9, true);
-        hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa,
-            BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p }, counters_.p);
+        launch(BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p });
         detReduceBlocks(16 * (size_t)n, 32, lin.d_ia.p, a_dev);
     }
     int err[2];
@@ -1989,7 +2164,7 @@ bool HipContact::patternCovers(const HipLinSysSolver& lin)
     if (!n) return true;
     ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, nullptr, d_xRest.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
-    counters_.alloc(2);
+    counters_.alloc(4);
     counters_.zero(stream);
     hipLaunchKernelGGL(k_pattern_check, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, m, counters_.p);
     int miss = 0;
@@ -2096,7 +2271,7 @@ void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, c
     if (!n) return;
     FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
-    counters_.alloc(2);
+    counters_.alloc(4);
     counters_.zero(stream);
     if (atomicScatter_)
         hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
@@ -2375,7 +2550,7 @@ void HipContact::buildCells(const GridHost& gh, int nPrim, int nv, const int* pr
     int total = 0;
     HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    items.ensure(std::max(1, total));
+    items.ensure((size_t)(p_dev ? 1 : REC) * std::max(1, total)); // k_grid_insert writes records, k_grid_insert_swept indices
     insert(1);
 }
 
@@ -2433,7 +2608,7 @@ double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const doubl
     ccdOut_.alloc(4);
     const unsigned long long init[2] = { ~0ull, ~0ull };
     HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    counters_.alloc(2);
+    counters_.alloc(4);
     counters_.zero(stream);
     CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
     for (int pass = 0; pass < 2; ++pass) {
@@ -2535,7 +2710,7 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
         int total = 0;
         HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        items.ensure((size_t)std::max(1, total));
+        items.ensure((size_t)REC * std::max(1, total));
         cnt.zeroN((size_t)nCells + 1, stream);
         hipLaunchKernelGGL(k_ref_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv, prim, d_v2sv.p, refVbox_.p, g, 1, cnt.p, start.p, items.p);
     };
@@ -2543,25 +2718,37 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
     build(nSFE, 2, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
     build(nSF, 3, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
     ccdOut_.alloc(4);
-    const unsigned long long init[3] = { ~0ull, ~0ull, ~0ull };
-    HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    counters_.alloc(2);
+    counters_.alloc(4);
+    // counters_: [0] queried pairs, [1] pairs that returned a time inside the step (the hit list)
+    constexpr int HIT_CAP = 1 << 20;
+    static const bool twoPass = std::getenv("IPCGPU_CCD_TWO_PASS") != nullptr; // A/B: find the limiting pair by a second run of the sweep (rounds 1-2)
+    if (!twoPass) ccdHits_.ensure(2 * (size_t)HIT_CAP);
+    const unsigned long long init3[3] = { ~0ull, ~0ull, ~0ull };
+    HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init3, sizeof(init3), hipMemcpyHostToDevice, stream));
     counters_.zero(stream);
-    CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
+    CcdOut o{ ccdOut_.p, ccdOut_.p + 1, twoPass ? nullptr : ccdHits_.p, counters_.p + 1, twoPass ? 0 : HIT_CAP };
     const RefLists L{ cellStartV_.p, cellItemsV_.p, cellStartE_.p, cellItemsE_.p, cellStartT_.p, cellItemsT_.p };
-    for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(k_ref_sweep_vertex, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, pf, d_v2sv.p, refVbox_.p, g, L,
-            alpha, slackness, pass, o, counters_.p);
+    auto sweep = [&](int pass) {
+        hipLaunchKernelGGL(k_ref_sweep_vertex, dim3(nblk(SWEEP_COOP * (long long)nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, pf,
+            d_v2sv.p, refVbox_.p, g, L, alpha, slackness, pass, o, counters_.p);
         // the bound the vertex sweeps left is what the edge pairs' boxes are swept over (SelfCollisionHandler.cpp:1189, 1219)
         if (pass == 0) HIP_CHECK(hipMemcpyAsync(ccdOut_.p + 2, ccdOut_.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
         if (nSFE)
-            hipLaunchKernelGGL(k_ref_sweep_edge, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, p_dev, pf, d_v2sv.p, refVbox_.p, g,
-                cellStartE_.p, cellItemsE_.p, alpha, ccdOut_.p + 2, slackness, pass, o, counters_.p);
-    }
+            hipLaunchKernelGGL(k_ref_sweep_edge, dim3(nblk(SWEEP_COOP * (long long)nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, p_dev, pf, d_v2sv.p,
+                refVbox_.p, g, cellStartE_.p, cellItemsE_.p, alpha, ccdOut_.p + 2, slackness, pass, o, counters_.p);
+    };
+    sweep(0);
+    if (twoPass) sweep(1);
+    else hipLaunchKernelGGL(k_ccd_hits_arg, dim3(64), dim3(BLOCK), 0, stream, o);
     unsigned long long h[2];
     int cnt[2];
     HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
     counters_.download(cnt, 2, stream);
+    if (!twoPass && cnt[1] > HIT_CAP) { // more hits than the list holds (never seen): the limiting pair by the second run after all
+        sweep(1);
+        HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+    }
     if (nCand) *nCand = cnt[0];
     double t;
     std::memcpy(&t, &h[0], sizeof(t));
@@ -2587,9 +2774,9 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
         g.dim[c] = gh.dim[c];
     }
     g.h = gh.h;
-    counters_.alloc(2);
+    counters_.alloc(4);
     counters_.zero(stream);
-    hipLaunchKernelGGL(k_intersect, dim3(nblk(nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p, cellItemsE_.p,
+    hipLaunchKernelGGL(k_intersect, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p, cellItemsE_.p,
         counters_.p);
     int f[2];
     counters_.download(f, 2, stream);
@@ -2608,7 +2795,7 @@ void HipContact::closeStencils(const double* x_dev, double dTol, std::vector<std
     for (;;) {
         closeIdx_.ensure((size_t)cap);
         closeVal_.ensure((size_t)cap);
-        counters_.alloc(2);
+        counters_.alloc(4);
         counters_.zero(stream);
         hipLaunchKernelGGL(k_close_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_active.p, x_dev, dTol, cap, closeIdx_.p, closeVal_.p, counters_.p);
         int cnt = 0;
