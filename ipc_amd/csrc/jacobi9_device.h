@@ -10,7 +10,7 @@
 // (252 VGPRs; gfx950 gives a wave 512), and a rotation is ~100 independent fp64 instructions.  Blocks of 2- and 3-node stencils are
 // embedded in the 9 x 9 frame: their zero rows make the extra rotations identities (apq == 0), skipped per wave when no lane needs them.
 //
-// The arithmetic of a rotation, the order of the rotations, the stopping rule (off-diagonal norm <= 1e-14 of the diagonal norm, per
+// The order of the rotations, the stopping rule (off-diagonal norm <= 1e-14 of the diagonal norm, per
 // stencil) and the reduction to the complement of the three rigid translations are those of make_pd_stencil (contact_device.h), so a
 // stencil's result does not depend on which other stencils share its wave.
 //
@@ -48,9 +48,30 @@ J9_HD void rotate(double (&W)[81], double (&V)[81], bool live)
     const bool rot = live && apq != 0.0;
     if (!J9_WAVE_ANY(rot)) return;
     const double app = W[us(P, P)], aqq = W[us(Q, Q)];
-    const double theta = (aqq - app) / (2.0 * (rot ? apq : 1.0));
-    const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    // tan of the rotation angle: t = sgn(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq), written without the quotient
+    // theta: t = sgn(a) b / (|a| + sqrt(a^2 + b^2)) with a = (aqq - app) / 2, b = apq.  One square root and one division instead of two of
+    // each (an IEEE fp64 division or square root is ~35 instructions here: they were half of a rotation).  On the device both come from the
+    // hardware estimates with Newton steps: t only steers the iteration (an error in it costs convergence speed, nothing else), while
+    // c = rsqrt(1 + t^2) is refined to full precision for the t actually used -- c^2 + s^2 = 1 is what keeps the rotation orthogonal.
+    const double a = 0.5 * (aqq - app), b = rot ? apq : 1.0;
+    const double h2 = a * a + b * b;
+#ifdef __HIPCC__
+    double rh = __builtin_amdgcn_rsq(h2);
+    rh = rh * (1.5 - 0.5 * h2 * rh * rh);
+    const double den = fabs(a) + h2 * rh;
+    double rd = __builtin_amdgcn_rcp(den);
+    rd = rd * (2.0 - den * rd);
+    rd = rd * (2.0 - den * rd);
+    const double tt = (a >= 0 ? b : -b) * rd;
+    const double u = tt * tt + 1.0;
+    double cc = __builtin_amdgcn_rsq(u);
+    cc = cc * (1.5 - 0.5 * u * cc * cc);
+    cc = cc * (1.5 - 0.5 * u * cc * cc);
+    cc = cc * (1.5 - 0.5 * u * cc * cc);
+#else
+    const double tt = (a >= 0 ? b : -b) / (fabs(a) + sqrt(h2));
     const double cc = 1.0 / sqrt(tt * tt + 1.0);
+#endif
     const double t = rot ? tt : 0.0, c = rot ? cc : 1.0, s = rot ? tt * cc : 0.0;
 #pragma unroll
     for (int k = 0; k < M; ++k) {

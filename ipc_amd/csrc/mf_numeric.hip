@@ -2334,7 +2334,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         }
         const size_t nFused = (size_t)aPtr[ns_], nBig = (size_t)bigCnt[nLevels_];
         auto growPinned = [](PinnedBuf<int>& b, size_t n) {
-            if (b.n < n || !b.p) b.alloc(n + n / 4 + 16);
+            if (b.n < n || !b.p) b.alloc(2 * n + 16); // pinned allocations cost ~5 ms each: room for the contact blocks a later pattern adds
         };
         growPinned(hSrc_, nFused + 1);
         growPinned(hLoc_, nFused + 1);

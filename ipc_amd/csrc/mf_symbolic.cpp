@@ -398,6 +398,11 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     }
     lap("index + inverse maps, levels");
     // user-matrix entry -> front slot (lower triangle of the permuted matrix)
+    // room for the blocks a later (contact) pattern adds: growing inside the capacity faults in only the new pages, a reallocation all of them
+    if (o.aDst.capacity() < (size_t)ia[n]) {
+        o.aDst.reserve((size_t)ia[n] + (size_t)ia[n] / 2);
+        o.aFront.reserve((size_t)ia[n] + (size_t)ia[n] / 2);
+    }
     o.aDst.resize(ia[n]);
     o.aFront.resize(ia[n]);
     auto slot = [&](int r, int c, int* owner = nullptr) -> int64_t {

@@ -293,7 +293,9 @@ __global__ __launch_bounds__(BLOCK) void k_inversion_step(ElemView v, const doub
     // all results are >= 0, so their bit patterns order like unsigned integers
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) res = fmin(res, __shfl_down(res, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMin(outMin, (unsigned long long)__double_as_longlong(res));
+    // the caller starts the minimum at 1e20 = "no element limits the step": waves without a root (almost all of them) have nothing to report,
+    // and the ones that do are few -- same-address atomics retire one at a time (~2.5 ns each; one per wave was 5 us of this kernel)
+    if ((threadIdx.x & 63) == 0 && res < 1e20) atomicMin(outMin, (unsigned long long)__double_as_longlong(res));
 }
 
 // ---- nodal helpers -----------------------------------------------------------------------------
@@ -302,13 +304,21 @@ __global__ void k_step_forward(int n, const double* __restrict__ x0, const doubl
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = x0[i] + alpha * p[i];
 }
-__global__ void k_max_abs(int n, const double* __restrict__ v, unsigned long long* __restrict__ out)
+// grid-stride, one atomic per workgroup (the launch caps the grid at 256 workgroups): per wave of a thread-per-entry launch they were 2 100
+// same-address atomics for 1.35e5 entries, most of the kernel's 23 us
+__global__ __launch_bounds__(BLOCK) void k_max_abs(int n, const double* __restrict__ v, unsigned long long* __restrict__ out)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    double m = (i < n) ? fabs(v[i]) : 0.0;
+    __shared__ double sm[BLOCK / 64];
+    double m = 0.0;
+    for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) m = fmax(m, fabs(v[i]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < BLOCK / 64; ++w) m = fmax(m, sm[w]);
+        atomicMax(out, (unsigned long long)__double_as_longlong(m));
+    }
 }
 __global__ void k_fill(double* p, size_t n, double v)
 {
@@ -606,7 +616,7 @@ void launch_step_forward(int n3, const double* x0, const double* p, double alpha
 }
 void launch_max_abs(int n, const double* v, double* out, hipStream_t s)
 {
-    if (n) hipLaunchKernelGGL(k_max_abs, dim3(nblk(n)), dim3(BLOCK), 0, s, n, v, (unsigned long long*)out);
+    if (n) hipLaunchKernelGGL(k_max_abs, dim3(std::min(nblk(n), 256)), dim3(BLOCK), 0, s, n, v, (unsigned long long*)out);
 }
 void launch_fill(double* p, size_t n, double v, hipStream_t s)
 {
