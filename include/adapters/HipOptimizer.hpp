@@ -344,12 +344,12 @@ protected:
             fOff += (int)mco->F.rows();
         }
         chk(ipcgpu_set_mesh(ctx, nAll, nT, Vrest.data(), m.F.data(), m.m_YM, m.m_PR, m.density));
-        // codimension-2 components (triangle meshes under `shapes`, main.cpp:948-956): nodes of no tetrahedron with lumped area masses
+        // components of codimension 2 / 1 / 0 (triangle meshes, `.seg` segments, `.pt` points under `shapes`, main.cpp:948-1005): nodes of no
+        // tetrahedron with the masses Mesh<3> gave them (Mesh.cpp:279-345, 405-411)
         std::vector<int> codim;
         std::vector<double> codimMass;
         for (size_t compI = 0; compI < m.componentCoDim.size(); ++compI) {
             if (m.componentCoDim[compI] == 3) continue;
-            if (m.componentCoDim[compI] != 2) throw std::runtime_error("HipOptimizer: segment / point components need percall mode");
             for (int v = m.componentNodeRange[compI]; v < m.componentNodeRange[compI + 1]; ++v) {
                 codim.push_back(v);
                 codimMass.push_back(m.massMatrix.coeff(v, v));
@@ -368,7 +368,15 @@ protected:
         chk(ipcgpu_set_positions(ctx, Vcur.data()));
         chk(ipcgpu_opt_init(ctx, Base::dt, cfg.withGravity ? 1 : 0));
         if (cfg.timeIntegrationType == TIT_NM) chk(ipcgpu_opt_set_time_integration(ctx, 1, Base::beta_NM, Base::gamma_NM));
-        chk(ipcgpu_set_surface(ctx, nSFAll, SF.data()));
+        {
+            // Mesh<3>::CE, the segments of `.seg` shapes; `.pt` points need nothing: nodes without a neighbour are found by the library
+            std::vector<int> ce(2 * (size_t)m.CE.rows());
+            for (int e = 0; e < (int)m.CE.rows(); ++e) {
+                ce[2 * (size_t)e] = m.CE(e, 0);
+                ce[2 * (size_t)e + 1] = m.CE(e, 1);
+            }
+            chk(ipcgpu_set_surface_codim(ctx, nSFAll, SF.data(), (int)m.CE.rows(), ce.empty() ? nullptr : ce.data()));
+        }
         // static Dirichlet types: held surfaces; the obstacle
         chk(ipcgpu_clear_dbc(ctx));
         if (!codim.empty() && (cfg.animScriptType == AST_NULL || cfg.animScriptType == AST_DCOFIX))

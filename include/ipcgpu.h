@@ -167,6 +167,12 @@ int ipcgpu_gradient(ipcgpu_ctx*, double dtSq, int projectDBC, double* grad_3nV);
  * Mesh::computeFeatures / computeBoundaryVert do (src/Mesh.cpp:495-515, 890-930), so edge and vertex indices
  * agree with the reference's. */
 int ipcgpu_set_surface(ipcgpu_ctx*, int nSF, const int* SF_colmajor);
+/* The same with the codimensional parts of Mesh<3> (`.seg` / `.pt` shapes, main.cpp:957-1005): CE = Mesh::CE, nCE node pairs.  The
+ * segments enter vNeighbor and -- behind the triangles' edges, in the order given -- SFEdges, their ends SVI (Mesh.cpp:490-493, 513-515,
+ * 912-915); a node that has no neighbour at all (no tetrahedron, triangle or segment: a `.pt` point) is a surface vertex as well
+ * (:916-920) and is tested against every tetrahedron by the intersection check (SelfCollisionHandler.cpp:3301-3338).  Their masses:
+ * ipcgpu_set_codim_nodes (segments: density * l^3 pi / 12 per end, Mesh.cpp:279-295; points: the mean nodal mass, :405-411). */
+int ipcgpu_set_surface_codim(ipcgpu_ctx*, int nSF, const int* SF_colmajor, int nCE, const int* CE_pairs);
 int ipcgpu_get_surface(ipcgpu_ctx*, int* counts3 /*nSVI,nSF,nSFEdges*/, int* SVI /*nullable*/, int* SFEdges_2n /*nullable*/);
 /* Kinematic mesh obstacles (MeshCO, src/CollisionObject/MeshCO.cpp:37-80; `meshCO` script keyword, Config.cpp:448-474): the
    obstacle rides along as a surface-only component of the mesh handed to ipcgpu_set_mesh -- extra nodes that belong to no

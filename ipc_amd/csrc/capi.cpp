@@ -638,6 +638,18 @@ int ipcgpu_set_surface(ipcgpu_ctx* c, int nSF, const int* SF)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_set_surface_codim(ipcgpu_ctx* c, int nSF, const int* SF, int nCE, const int* CE)
+{
+    return guarded([&] {
+        HipMesh& m = M(c);
+        bind(c);
+        needArg(nSF >= 0 && (SF || nSF == 0), "bad surface");
+        needArg(nCE >= 0 && (CE || nCE == 0), "bad codimensional segments");
+        m.addSurfaceEdges(nSF, SF, nCE, CE);
+        CT(c).setSurface(m, nSF, SF, nCE, CE);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_get_surface(ipcgpu_ctx* c, int* counts, int* SVI, int* SFE)
 {
     return guarded([&] {

@@ -47,7 +47,10 @@ public:
     void syncHost() const;
     bool surfaceSet = false;
 
-    void setSurface(const HipMesh& mesh, int nSF, const int* SF_colmajor);
+    // CE: codimensional segments (`.seg` shapes, Mesh::CE) as node pairs; nodes without any neighbour in the mesh are codimensional points
+    // (`.pt` shapes): both join SVI, the segments SFEdges (Mesh.cpp:490-515, 912-927)
+    void setSurface(const HipMesh& mesh, int nSF, const int* SF_colmajor, int nCE = 0, const int* CE_pairs = nullptr);
+    std::vector<int> codimPoints;
     // kinematic obstacle nodes (the reference's MeshCO riding along as a surface-only component, MeshCO.cpp) and, for scenes with
     // `selfCollisionOff`, the filter that keeps only primitive pairs involving an obstacle
     void setObstacle(int nV, int n, const int* ids, bool obstacleOnly);
@@ -119,6 +122,7 @@ private:
     DevBuf<int> d_cand_, d_ids_;
     DevBuf<double> d_vals_;
     DevBuf<unsigned long long> ccdOut_, ccdHits_;
+    DevBuf<int> d_codimPoints;
     DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
     DevBuf<int> d_v2sv, refVbox_, cellCountV_, cellStartV_, cellItemsV_; // reference-mode sweep: node -> surface index, index boxes, vertex cells
     DevBuf<double> bboxPartial_;

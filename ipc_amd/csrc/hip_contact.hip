@@ -1665,6 +1665,35 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
                 }
             }
 }
+// codimensional points against every tetrahedron (SelfCollisionHandler.cpp:3301-3338): inside the element's box, then behind its four faces
+// (IglUtils::pointInsideTetrahedron / pointBehindTri, IglUtils.hpp:266-311, the build without exact predicates).  One lane per (point, element).
+__device__ __forceinline__ bool point_behind_tri(const double* t0, const double* t1, const double* t2, const double* v)
+{
+    double e1[3], e2[3], r[3], n[3];
+    sub3(t1, t0, e1);
+    sub3(t2, t0, e2);
+    sub3(v, t0, r);
+    cross3(e1, e2, n);
+    return dot3(n, r) <= 0.0;
+}
+__global__ __launch_bounds__(BLOCK) void k_points_in_tets(int nPts, const int* __restrict__ pts, int nT, const int4* __restrict__ tet,
+    const double* __restrict__ x, int* __restrict__ flag)
+{
+    const long long gi = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (gi >= (long long)nPts * nT) return;
+    const int v = pts[gi / nT];
+    const int4 t = tet[gi % nT];
+    const int id[4] = { t.x, t.y, t.z, t.w };
+    double p[3], q[4][3];
+    for (int c = 0; c < 3; ++c) {
+        p[c] = x[3 * (size_t)v + c];
+        for (int k = 0; k < 4; ++k) q[k][c] = x[3 * (size_t)id[k] + c];
+        if (!(fmin(fmin(q[0][c], q[1][c]), fmin(q[2][c], q[3][c])) <= p[c] && fmax(fmax(q[0][c], q[1][c]), fmax(q[2][c], q[3][c])) >= p[c])) return;
+    }
+    if (point_behind_tri(q[0], q[2], q[1], p) && point_behind_tri(q[0], q[3], q[2], p) && point_behind_tri(q[0], q[1], q[3], p)
+        && point_behind_tri(q[1], q[2], q[3], p))
+        atomicOr(flag, 1);
+}
 // squared distances of a list of MMCVID stencils (closeMConstraint bookkeeping, Optimizer.cpp:2365-2440)
 __global__ __launch_bounds__(BLOCK) void k_eval_stencils(int n, const int* __restrict__ ids, const double* __restrict__ x, double* __restrict__ out)
 {
@@ -1796,7 +1825,7 @@ inline int nblk(long long n, int b = BLOCK) { return (int)((n + b - 1) / b); }
 
 } // namespace
 
-void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc)
+void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc, int nCE, const int* CE)
 {
     nSF = nSF_;
     SF.assign(SFc, SFc + 3 * (size_t)nSF);
@@ -1816,6 +1845,19 @@ void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc)
         if (!es.count({ t[0], t[2] })) es.insert({ t[2], t[0] });
     }
     SFEdges.assign(es.begin(), es.end());
+    for (int e = 0; e < nCE; ++e) { // Mesh.cpp:513-515, 912-915: behind the triangles' edges, in file order; the ends are surface vertices
+        const int a = CE[2 * (size_t)e], b = CE[2 * (size_t)e + 1];
+        if (a < 0 || a >= mesh.nV || b < 0 || b >= mesh.nV) throw ArgError("set_surface: vertex index of a codimensional segment out of range");
+        SFEdges.emplace_back(a, b);
+        onSurf[a] = onSurf[b] = 1;
+    }
+    codimPoints.clear();
+    for (int v = 0; v < mesh.nV; ++v) // Mesh.cpp:916-920: a node without any neighbour is on the surface (`.pt` shapes)
+        if (mesh.nbPtr[v + 1] == mesh.nbPtr[v]) {
+            onSurf[v] = 1;
+            codimPoints.push_back(v);
+        }
+    d_codimPoints.upload(codimPoints, stream);
     nSFE = (int)SFEdges.size();
     SVI.clear();
     for (int v = 0; v < mesh.nV; ++v)
@@ -2778,6 +2820,9 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
     counters_.zero(stream);
     hipLaunchKernelGGL(k_intersect, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p, cellItemsE_.p,
         counters_.p);
+    if (!codimPoints.empty() && mesh.nT)
+        hipLaunchKernelGGL(k_points_in_tets, dim3(nblk((long long)codimPoints.size() * mesh.nT)), dim3(BLOCK), 0, stream, (int)codimPoints.size(),
+            d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev, counters_.p);
     int f[2];
     counters_.download(f, 2, stream);
     return f[0] != 0;

@@ -45,7 +45,7 @@ public:
     // surface-only nodes that belong to the mesh (triangle meshes under `shapes`, componentCoDim 2): they count in the bounding box
     // and the mean nodal mass and carry the given lumped masses (Mesh.cpp:310-345)
     std::vector<char> inMesh; // per node: referenced by an element (the components of codimension 3)
-    void addSurfaceEdges(int nSF, const int* SF_colmajor);
+    void addSurfaceEdges(int nSF, const int* SF_colmajor, int nCE = 0, const int* CE_pairs = nullptr);
     void setCodimNodes(int n, const int* ids, const double* nodeMass, hipStream_t s);
     void meshBBox(); // bounding box and node count over inMesh (Mesh::matSpaceBBoxSize2(dim) / avgNodeMass(dim): tetrahedral components only)
     void uploadDBC(hipStream_t s);

@@ -144,7 +144,7 @@ void HipMesh::setCodimNodes(int n, const int* ids, const double* nodeMass, hipSt
     HIP_CHECK(hipStreamSynchronize(s));
 }
 
-void HipMesh::addSurfaceEdges(int nSF, const int* SF)
+void HipMesh::addSurfaceEdges(int nSF, const int* SF, int nCE, const int* CE)
 {
     // Mesh.cpp:480-487: every surface triangle's edges enter vNeighbor too.  For a tet component they only repeat tet edges; for
     // a surface-only component (shell, scripted collision surface) they are the only adjacency its nodes have, and the barrier
@@ -160,6 +160,12 @@ void HipMesh::addSurfaceEdges(int nSF, const int* SF)
             edges.emplace_back(i, j);
             edges.emplace_back(j, i);
         }
+    for (int e = 0; e < nCE; ++e) { // codimensional segments (`.seg` shapes, Mesh.cpp:490-493)
+        const int i = CE[2 * (size_t)e], j = CE[2 * (size_t)e + 1];
+        if (i < 0 || i >= nV || j < 0 || j >= nV || i == j) throw ArgError("set_surface: bad codimensional segment");
+        edges.emplace_back(i, j);
+        edges.emplace_back(j, i);
+    }
     std::sort(edges.begin(), edges.end());
     edges.erase(std::unique(edges.begin(), edges.end()), edges.end());
     if (edges.size() == nb.size()) return;

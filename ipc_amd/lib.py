@@ -373,9 +373,14 @@ class Context:
         return dict(nnzL=st[0], flops=st[1], fronts=int(st[2]), levels=int(st[3]))
 
     # ---- SelfCollisionHandler
-    def set_surface(self, SF):
-        SF = np.asfortranarray(SF, dtype=np.int32)
-        self._chk(self._L.ipcgpu_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF)))
+    def set_surface(self, SF, codim_edges=None):
+        """codim_edges: n x 2 node pairs of `.seg` shapes (Mesh::CE); nodes without any neighbour count as `.pt` points"""
+        SF = np.asfortranarray(np.asarray(SF, dtype=np.int32).reshape(-1, 3))
+        if codim_edges is None or len(codim_edges) == 0:
+            self._chk(self._L.ipcgpu_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF)))
+            return
+        CE = np.ascontiguousarray(codim_edges, dtype=np.int32).reshape(-1, 2)
+        self._chk(self._L.ipcgpu_set_surface_codim(self.h, C.c_int(SF.shape[0]), _ip(SF), C.c_int(CE.shape[0]), _ip(CE)))
 
     def set_codim_nodes(self, ids, mass):
         """Surface-only nodes that belong to the mesh (triangle meshes under `shapes`) with their lumped area masses; like a MeshCO they

@@ -171,8 +171,6 @@ class SceneConfig:
                 pos = [float(x) for x in a[4:7]] + [0.0] * (3 - len(a[4:7]))
                 st = lines[i].split()
                 i += 1
-                if st[0].lower().endswith((".seg", ".pt")):
-                    raise UnsupportedKeyword("codimensional shape (.seg / .pt)")
                 step = np.array([float(x) for x in st[1:4]])
                 rot, scl = np.array([float(x) for x in st[4:7]]), np.array([float(x) for x in st[7:10]])
                 mat = tuple(float(x) for x in st[11:14]) if len(st) > 13 and st[10] == "material" else None
@@ -253,8 +251,6 @@ class SceneConfig:
 
 
 def _parse_shape(st, resolve):
-    if st[0].lower().endswith((".seg", ".pt")):  # componentCoDim 1 / 0 (main.cpp:957-1030): segment and point clouds are not rebuilt
-        raise UnsupportedKeyword("codimensional shape (.seg / .pt)")
     sh = Shape(resolve(st[0]), np.array([float(x) for x in st[1:4]]), np.array([float(x) for x in st[4:7]]), np.array([float(x) for x in st[7:10]]))
     j = 10
     while j < len(st):
@@ -323,6 +319,38 @@ def read_obj(path):
     return np.array(V, dtype=np.float64).reshape(-1, 3), np.array(F, dtype=np.int32).reshape(-1, 3)
 
 
+def read_seg(path):
+    """Segment mesh of a `.seg` shape (main.cpp:957-990): IglUtils::readSEG (`v x y z` / `s a b`, 1-based; IglUtils.cpp:146-175) or, when that
+    file does not exist, the edges of the triangles of the `.obj` beside it -- each undirected edge once, with the direction it is first
+    seen in, in the order of a std::set of pairs."""
+    if os.path.exists(path):
+        V, E = [], []
+        with open(path) as f:
+            for line in f:
+                t = line.split()
+                if not t:
+                    continue
+                if t[0] == "v":
+                    V.append([float(x) for x in t[1:4]])
+                elif t[0] == "s":
+                    E.append([int(t[1]) - 1, int(t[2]) - 1])
+        return np.array(V, dtype=np.float64).reshape(-1, 3), np.array(E, dtype=np.int32).reshape(-1, 2)
+    V, F = read_obj(os.path.splitext(path)[0] + ".obj")
+    es = set()
+    for a, b, c in F.tolist():
+        for i, j in ((a, b), (b, c), (c, a)):
+            if (j, i) not in es:
+                es.add((i, j))
+    return V, np.array(sorted(es), dtype=np.int32).reshape(-1, 2)
+
+
+def read_pt(path):
+    """Point cloud of a `.pt` shape (main.cpp:991-1005): the vertices of the file read as an .obj, or of the `.obj` beside it"""
+    if os.path.exists(path):
+        return read_obj(path)[0]
+    return read_obj(os.path.splitext(path)[0] + ".obj")[0]
+
+
 # The hard-coded scripts of AnimScripter that move whole components (set-up AnimScripter.cpp:1060-1300, per step :1961-2135): how many
 # leading components they move and with what.  Linear velocities in units / s, angular velocities in rad / s about x, y, z.
 _S6 = [(1.0, 0, 0), (-1.0, 0, 0), (0, 1.0, 0), (0, -1.0, 0), (0, 0, 1.0), (0, 0, -1.0)]
@@ -353,6 +381,7 @@ class AssembledScene:
     codim_mass: np.ndarray = None  # ... and their lumped masses (density x a third of the adjacent triangle areas, Mesh.cpp:310-345)
     codim_fixed: np.ndarray = None  # `script DCOFix`: those of them held as NONZERO Dirichlet nodes (AnimScripter.cpp:1222-1236)
     V0: np.ndarray = None  # start positions when they differ from the rest shape V (`rotateModel`, main.cpp:1115-1139)
+    codim_edges: np.ndarray = None  # segments of the `.seg` shapes (Mesh::CE), global node pairs
     motions: list = None  # rule-driven scripts: per Dirichlet group (lin, ang in degrees, fixed rotation centre or None), nodes NONZERO throughout
 
     def before_step(self, be, t):
@@ -393,16 +422,24 @@ class AssembledScene:
 def assemble(cfg, read_mesh):
     """main.cpp:880-1198: select Dirichlet / Neumann nodes per shape on the mesh as read, transform the shape (R (p * scale) + translate), concatenate."""
     Vs, Ts, SFs, nr, tr, dirichlet, neumann = [], [], [], [0], [0], [], []
-    codim = []  # (node ids, triangles) of the surface-only components of the mesh
+    codim = []  # (node ids, triangles, moved by its own keywords, segments) of the components of the mesh without tetrahedra
+    CEs = []
     for sh in cfg.shapes:
-        is_codim = sh.path.lower().endswith(".obj")  # main.cpp:948-956: a triangle mesh under `shapes` is a kinematic surface
-        if is_codim:
+        ext = os.path.splitext(sh.path.lower())[1]
+        is_codim = ext in (".obj", ".seg", ".pt")  # main.cpp:948-1005: kinematic surface / segments / points (componentCoDim 2 / 1 / 0)
+        E = np.zeros((0, 2), dtype=np.int32)
+        if ext == ".obj":
             V, SF = read_obj(sh.path)
-            T = np.zeros((0, 4), dtype=np.int32)
-        elif sh.path.lower().endswith((".seg", ".pt")):
-            raise UnsupportedKeyword("codimensional shape (.seg / .pt)")
+        elif ext == ".seg":
+            V, E = read_seg(sh.path)
+            SF = np.zeros((0, 3), dtype=np.int32)
+        elif ext == ".pt":
+            V = read_pt(sh.path)
+            SF = np.zeros((0, 3), dtype=np.int32)
         else:
             V, T, SF = read_mesh(sh.path)
+        if is_codim:
+            T = np.zeros((0, 4), dtype=np.int32)
         off = nr[-1]
         # Dirichlet / Neumann nodes are picked on the mesh AS READ (IglUtils::Init_Dirichlet on newV, main.cpp:1045-1068); the
         # shape is scaled / rotated / translated only afterwards (main.cpp:1073-1077), so the relative box follows the shape
@@ -419,7 +456,8 @@ def assemble(cfg, read_mesh):
             ids = np.arange(V.shape[0], dtype=np.int32) + off
             dirichlet.append((ids, sh.lin_vel or (0, 0, 0), sh.ang_vel_deg or (0, 0, 0), 0.0, float("inf")))
         if is_codim:
-            codim.append((np.arange(off, off + V.shape[0], dtype=np.int32), SF + off, sh.lin_vel is not None or sh.ang_vel_deg is not None))
+            codim.append((np.arange(off, off + V.shape[0], dtype=np.int32), SF + off, sh.lin_vel is not None or sh.ang_vel_deg is not None, E + off))
+        CEs.append(E + off)
         Vs.append(V)
         Ts.append(T + off)
         SFs.append(SF + off)
@@ -472,18 +510,34 @@ def assemble(cfg, read_mesh):
                 V0[:nSim, 1] += lift
         dirichlet = []
     codim_nodes = codim_mass = codim_fixed = None
+    codim_edges = np.vstack(CEs).astype(np.int32) if CEs else np.zeros((0, 2), dtype=np.int32)
     if codim:
-        codim_nodes = np.concatenate([ids for ids, _f, _m in codim])
+        codim_nodes = np.concatenate([ids for ids, _f, _m, _e in codim])
         m = np.zeros(V.shape[0])
-        for _ids, tri, _m in codim:  # barycentric lumping of the triangle areas times the density (Mesh.cpp:318-343, 399)
-            a = 0.5 * np.linalg.norm(np.cross(V[tri[:, 1]] - V[tri[:, 0]], V[tri[:, 2]] - V[tri[:, 0]]), axis=1)
-            for k in range(3):
-                np.add.at(m, tri[:, k], cfg.rho * a / 3.0)
+        for ids, tri, _m, seg in codim:
+            if len(tri):  # barycentric lumping of the triangle areas times the density (Mesh.cpp:318-343, 399)
+                a = 0.5 * np.linalg.norm(np.cross(V[tri[:, 1]] - V[tri[:, 0]], V[tri[:, 2]] - V[tri[:, 0]]), axis=1)
+                for k in range(3):
+                    np.add.at(m, tri[:, k], cfg.rho * a / 3.0)
+            elif len(seg):  # both ends of a segment of length l get density * l^3 pi / 12 (Mesh.cpp:279-295, 399)
+                l = np.linalg.norm(V[seg[:, 0]] - V[seg[:, 1]], axis=1)
+                for k in range(2):
+                    np.add.at(m, seg[:, k], cfg.rho * l ** 3 * math.pi / 12.0)
+            else:
+                # a point carries the mean nodal mass of the tetrahedral components (avgNodeMass(dim), Mesh.cpp:403-411, 583-607): lumped
+                # masses = density * a quarter of the adjacent element volumes
+                tm = np.zeros(V.shape[0])
+                if T.shape[0]:
+                    vol = np.abs(np.einsum("ij,ij->i", np.cross(V[T[:, 1]] - V[T[:, 0]], V[T[:, 2]] - V[T[:, 0]]), V[T[:, 3]] - V[T[:, 0]])) / 6.0
+                    for k in range(4):
+                        np.add.at(tm, T[:, k], cfg.rho * vol / 4.0)
+                n_tet_nodes = sum(nr[c + 1] - nr[c] for c in range(len(cfg.shapes)) if tr[c + 1] > tr[c])
+                m[ids] = tm.sum() / n_tet_nodes if n_tet_nodes else 0.0
         codim_mass = m[codim_nodes]
         if cfg.script in ("DCOFix", "DCOBallHitWall"):  # AnimScripter.cpp:1222-1236: every codimensional component is held (NONZERO, no motion)
             dirichlet = []
             codim_fixed = codim_nodes
-        elif cfg.script not in DCO_SCRIPTS and not all(moved for _i, _f, moved in codim):
+        elif cfg.script not in DCO_SCRIPTS and not all(moved for _i, _f, moved, _e in codim):
             raise UnsupportedKeyword("codimensional shape that no script fixes or moves")
     elif cfg.script in ("DCOFix", "DCOBallHitWall"):
         dirichlet = []  # mesh.resetDBCVertices(); nothing to hold
@@ -502,7 +556,7 @@ def assemble(cfg, read_mesh):
         spec = DCO_SCRIPTS[cfg.script]
         U = V if V0 is None else V0
         dirichlet, motions = [], []
-        codim_comp = {int(ids[0]): True for ids, _f, _m in codim}  # first node of every surface-only component
+        codim_comp = {int(ids[0]): True for ids, _f, _m, _e in codim}  # first node of every component without tetrahedra
         if cfg.script == "DCOSqueezeOut":
             # Every surface-only component is a NONZERO Dirichlet node set (AnimScripter.cpp:1261-1280); the first one carries a velocity of
             # 0.3 downwards that is applied while `topMax > bottomMin + (bottomMax - bottomMin) / 3.8 * 0.9` (:2102-2124).  As shipped that
@@ -559,6 +613,7 @@ def assemble(cfg, read_mesh):
     obst = np.concatenate(obstacle) if obstacle else None
     sc = AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release, codim_nodes, codim_mass, codim_fixed, V0)
     sc.motions = motions
+    sc.codim_edges = codim_edges
     return sc
 
 
@@ -577,7 +632,10 @@ def apply(sc, be):
     be.opt_init(cfg.dt, cfg.gravity)
     if cfg.time_integration == "NM":
         be.set_time_integration("NM", cfg.beta, cfg.gamma)
-    be.set_surface(sc.SF)
+    if sc.codim_edges is not None and len(sc.codim_edges):
+        be.set_surface(sc.SF, sc.codim_edges)
+    else:
+        be.set_surface(sc.SF)
     if sc.codim_fixed is not None:
         be.set_dbc(sc.codim_fixed, 2)
     self_fric = cfg.self_fric

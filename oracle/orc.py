@@ -122,9 +122,14 @@ class Mesh:
             lib().orc_mesh_destroy(self.h)
             self.h = None
 
-    def set_surface(self, SF):
-        SF = np.asfortranarray(SF, dtype=np.int32)
-        lib().orc_mesh_set_surface(self.h, C.c_int(SF.shape[0]), _ip(SF))
+    def set_surface(self, SF, codim_edges=None):
+        """codim_edges: n x 2 node pairs of `.seg` shapes (Mesh::CE); nodes without any neighbour count as `.pt` points"""
+        SF = np.asfortranarray(np.asarray(SF, dtype=np.int32).reshape(-1, 3))
+        if codim_edges is None or len(codim_edges) == 0:
+            lib().orc_mesh_set_surface_codim(self.h, C.c_int(SF.shape[0]), _ip(SF), C.c_int(0), None)
+            return
+        CE = np.ascontiguousarray(codim_edges, dtype=np.int32).reshape(-1, 2)
+        lib().orc_mesh_set_surface_codim(self.h, C.c_int(SF.shape[0]), _ip(SF), C.c_int(CE.shape[0]), _ip(CE))
 
     def set_dbc(self, ids, typ):
         ids = np.ascontiguousarray(ids, dtype=np.int32)

@@ -1390,6 +1390,38 @@ bool isIntersected(const Mesh& m)
             if (segTriIntersect(p0, p1, a, b, c)) return true;
         }
     }
+    // codimensional points against every tetrahedron (SelfCollisionHandler.cpp:3301-3338): inside the element's box, then behind its
+    // four faces (IglUtils::pointInsideTetrahedron / pointBehindTri, IglUtils.hpp:266-311, the build without exact predicates)
+    auto behind = [](const double* t0, const double* t1, const double* t2, const double* v) {
+        double e1[3], e2[3], r[3], n[3];
+        for (int k = 0; k < 3; ++k) {
+            e1[k] = t1[k] - t0[k];
+            e2[k] = t2[k] - t0[k];
+            r[k] = v[k] - t0[k];
+        }
+        n[0] = e1[1] * e2[2] - e1[2] * e2[1];
+        n[1] = e1[2] * e2[0] - e1[0] * e2[2];
+        n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+        return n[0] * r[0] + n[1] * r[1] + n[2] * r[2] <= 0.0;
+    };
+    for (int v : m.codimPoints) {
+        const double p[3] = { m.Vx(v, 0), m.Vx(v, 1), m.Vx(v, 2) };
+        for (int t = 0; t < m.nT; ++t) {
+            double q[4][3];
+            bool in = true;
+            for (int c = 0; c < 3 && in; ++c) {
+                double lo = 1e300, hi = -1e300;
+                for (int k = 0; k < 4; ++k) {
+                    q[k][c] = m.Vx(m.Fi(t, k), c);
+                    lo = std::min(lo, q[k][c]);
+                    hi = std::max(hi, q[k][c]);
+                }
+                in = lo <= p[c] && hi >= p[c];
+            }
+            if (!in) continue;
+            if (behind(q[0], q[2], q[1], p) && behind(q[0], q[3], q[2], p) && behind(q[0], q[1], q[3], p) && behind(q[1], q[2], q[3], p)) return true;
+        }
+    }
     return false;
 }
 

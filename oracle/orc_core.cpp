@@ -275,7 +275,7 @@ void Mesh::meshBBox()
     }
 }
 
-void Mesh::setSurface(int n, const int* SFc)
+void Mesh::setSurface(int n, const int* SFc, int nCE, const int* CE)
 {
     nSF = n;
     SF.assign(SFc, SFc + 3 * n);
@@ -296,6 +296,23 @@ void Mesh::setSurface(int n, const int* SFc)
         if (!es.count({ t[0], t[2] })) es.insert({ t[2], t[0] });
     }
     SFEdges.assign(es.begin(), es.end());
+    // codimensional segments (`.seg` shapes): vNeighbor (Mesh.cpp:490-493), appended to SFEdges behind the triangles' edges in file order
+    // (:513-515), their ends on the surface (:912-915)
+    for (int e = 0; e < nCE; ++e) {
+        const int a = CE[2 * e], b = CE[2 * e + 1];
+        vNeighbor[a].insert(b);
+        vNeighbor[b].insert(a);
+        SFEdges.emplace_back(a, b);
+        svi.insert(a);
+        svi.insert(b);
+    }
+    // nodes without any neighbour (`.pt` shapes) are surface vertices too (:916-920)
+    codimPoints.clear();
+    for (int v = 0; v < nV; ++v)
+        if (vNeighbor[v].empty()) {
+            svi.insert(v);
+            codimPoints.push_back(v);
+        }
     SVI.assign(svi.begin(), svi.end());
 }
 
@@ -634,6 +651,7 @@ orc_mesh* orc_mesh_create(int nV, int nT, const double* V, const int* F, double 
 }
 void orc_mesh_destroy(orc_mesh* h) { delete h; }
 void orc_mesh_set_surface(orc_mesh* h, int nSF, const int* SF) { h->m.setSurface(nSF, SF); }
+void orc_mesh_set_surface_codim(orc_mesh* h, int nSF, const int* SF, int nCE, const int* CE) { h->m.setSurface(nSF, SF, nCE, CE); }
 void orc_mesh_set_dbc(orc_mesh* h, int n, const int* vids, int type)
 {
     for (int i = 0; i < n; ++i) h->m.dbcType[vids[i]] = type;

@@ -8,8 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import (GOLD, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_damped_bar, check_plates, check_restart, check_scene, load_scene, rel,
-                                      run_scene)
+from test_oracle_vs_reference import (CODIM_SCENES, GOLD, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_codim, check_damped_bar, check_plates, check_restart,
+                                      check_scene, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -235,6 +235,17 @@ def test_scripted_plates_against_the_reference(name, tol, gpu_lib):
     c = gpu_lib.Context(0)
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     check_plates(S, pos, its, tol)
+    c.close()
+
+
+@pytest.mark.parametrize("name,tol", CODIM_SCENES)
+def test_codimensional_segments_and_points_against_the_reference(name, tol, gpu_lib):
+    """`.seg` / `.pt` shapes on the HIP stepper (ipcgpu_set_surface_codim; the point-in-tetrahedron kernel of the intersection check): the
+    tutorial cube caught by the edges / corners of a turning triangle, all 44 Newton counts the reference's."""
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    check_codim(S, pos, its, 10 * tol)
     c.close()
 
 

@@ -24,10 +24,20 @@ def export_scene(S, meshes, out_dir, steps):
     from ipc_amd import scene_script as ss
     text = str(S["script"])
     cfg = ss.SceneConfig.parse(text, out_dir)
-    for key, (V, T, SF) in meshes.items():
+    for key, (V, T, SF, E) in meshes.items():
         path = os.path.join(out_dir, key)
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        if key.lower().endswith(".obj"):
+        if key.lower().endswith(".seg"):
+            with open(path, "w") as f:  # IglUtils::readSEG, IglUtils.cpp:146-175
+                for v in V:
+                    f.write("v %.17g %.17g %.17g\n" % tuple(v))
+                for e in E:
+                    f.write("s %d %d\n" % tuple(int(i) + 1 for i in e))
+        elif key.lower().endswith(".pt"):
+            with open(path, "w") as f:
+                for v in V:
+                    f.write("v %.17g %.17g %.17g\n" % tuple(v))
+        elif key.lower().endswith(".obj"):
             with open(path, "w") as f:
                 for v in V:
                     f.write("v %.17g %.17g %.17g\n" % tuple(v))
@@ -173,3 +183,15 @@ def test_reference_main_squash6_resident(tmp_path):
     S, meshes = load_scene("squash6_contact")
     pos, its, _ = run_main_hip(S, meshes, tmp_path, int(S["steps"]))
     check_plates(S, pos, its, 1e-6)
+
+
+@pytest.mark.gpu
+@needs_exe
+@pytest.mark.parametrize("name,tol", [("rotate_co_edges", 1e-6), ("rotate_co_points", 1e-5)])
+def test_reference_main_codimensional_shapes_resident(name, tol, tmp_path):
+    """`.seg` / `.pt` shapes read by the reference's own main() (readSEG / the vertices of an .obj, main.cpp:957-1005) and handed to the
+    library by HipOptimizer (Mesh<3>::CE through ipcgpu_set_surface_codim, masses through ipcgpu_set_mesh_features): all 44 Newton counts."""
+    from test_oracle_vs_reference import check_codim
+    S, meshes = load_scene(name)
+    pos, its, _ = run_main_hip(S, meshes, tmp_path, int(S["steps"]))
+    check_codim(S, pos, its, tol)

@@ -205,7 +205,8 @@ def test_half_space_against_the_reference(G):
 # ---- whole scenes through the reference's main.cpp / Optimizer.cpp ------------------------------------------------------------------
 def load_scene(name):
     S = np.load(os.path.join(GOLD, f"ref_scene_{name}.npz"))
-    meshes = {str(k): (S[f"mesh{i}_V"], S[f"mesh{i}_T"], S[f"mesh{i}_SF"]) for i, k in enumerate(S["mesh_keys"])}
+    meshes = {str(k): (S[f"mesh{i}_V"], S[f"mesh{i}_T"], S[f"mesh{i}_SF"], S[f"mesh{i}_E"] if f"mesh{i}_E" in S.files else np.zeros((0, 2), np.int32))
+              for i, k in enumerate(S["mesh_keys"])}
     return S, meshes
 
 
@@ -220,12 +221,14 @@ def run_scene(S, meshes, backend, steps, restart=None):
     def key(p):
         return os.path.relpath(str(p), "/root/reference")
 
-    read_obj = ss.read_obj
+    read_obj, read_seg, read_pt = ss.read_obj, ss.read_seg, ss.read_pt
     ss.read_obj = lambda p: (meshes[key(p)][0].copy(), meshes[key(p)][2].copy())
+    ss.read_seg = lambda p: (meshes[key(p)][0].copy(), meshes[key(p)][3].copy())
+    ss.read_pt = lambda p: meshes[key(p)][0].copy()
     try:
-        sc = ss.assemble(cfg, lambda p: tuple(a.copy() for a in meshes[key(p)]))
+        sc = ss.assemble(cfg, lambda p: tuple(a.copy() for a in meshes[key(p)][:3]))
     finally:
-        ss.read_obj = read_obj
+        ss.read_obj, ss.read_seg, ss.read_pt = read_obj, read_seg, read_pt
     be = ss.apply(sc, backend)
     pos, its = [], []
     for s in range(steps):
@@ -373,6 +376,29 @@ def test_scripted_plates_against_the_reference(name, tol):
     S, meshes = load_scene(name)
     pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
     check_plates(S, pos, its, tol)
+
+
+# codimensional shapes of Mesh<3> (main.cpp:957-1005, Mesh.cpp:279-309, 405-411, 490-515, 912-920): the tutorial cube falling on the three
+# EDGES (`.seg`, codimension 1) / the three CORNERS (`.pt`, codimension 0) of a triangle that turns about y at 90 degrees per second, run by
+# the reference: (fixture, position tolerance).  The cube is in free fall for 24 steps and is then caught, spun and dropped by the segments /
+# points alone -- edge-edge stencils against segments that belong to no triangle, point-triangle stencils with vertices that belong to
+# nothing, the point-in-tetrahedron test of the intersection check (SelfCollisionHandler.cpp:3301-3338).
+CODIM_SCENES = [("rotate_co_edges", 1e-7), ("rotate_co_points", 1e-6)]
+
+
+def check_codim(S, pos, its, tol):
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())  # all 44 Newton counts
+    ref = S["positions"]
+    free = int(np.argmax(S["iters"] > 2))
+    assert free >= 20 and np.abs(pos[:free] - ref[:free]).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(pos - ref).max() <= tol * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name,tol", CODIM_SCENES)
+def test_codimensional_segments_and_points_against_the_reference(name, tol):
+    S, meshes = load_scene(name)
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    check_codim(S, pos, its, tol)
 
 
 @pytest.mark.parametrize("name,tol", RESTART_SCENES)

@@ -113,7 +113,7 @@ def test_reference_scene_files_parse():
     print(len(ok), "scene files map onto the C ABI;", unsupported)
     for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
         assert need in ok, need
-    assert len(ok) >= 122  # the rest needs segment / point shapes, other scripted motions or other solvers
+    assert len(ok) >= 134  # the rest needs other scripted motions, mesh sequences, other CCD methods or other solvers
 
 
 class OracleBackend:
@@ -135,8 +135,8 @@ class OracleBackend:
     def set_component_material(self, *a):
         self.m.set_component_material(*a)
 
-    def set_surface(self, SF):
-        self.m.set_surface(SF)
+    def set_surface(self, SF, codim_edges=None):
+        self.m.set_surface(SF, codim_edges)
 
     def opt_init(self, dt, gravity):
         self.o = self.orc.Optimizer(self.m, dt=dt, gravity=gravity, nthreads=self.nthreads)
@@ -427,8 +427,22 @@ def test_triangle_meshes_under_shapes_are_surface_only_components_of_the_mesh(tm
     assert np.allclose(sc.codim_mass, 1000.0 * np.array([6.0, 6.0, 6.0, 6.0, 12.0]))
     m = ss.SceneConfig.parse("shapeMatrix input 2 1 3  1 2 3\na.obj 10 0 5  0 0 0  1 1 1\n")
     assert len(m.shapes) == 6 and [tuple(x.translate) for x in m.shapes][:4] == [(1, 2, 3), (1, 2, 8), (1, 2, 13), (11, 2, 3)]
-    with pytest.raises(ss.UnsupportedKeyword):
-        ss.SceneConfig.parse("shapes input 1\nrope.seg 0 0 0  0 0 0  1 1 1\n")
+    # `.seg` / `.pt` shapes (main.cpp:957-1005): segments from the file or from the triangles of the .obj beside it, points from its vertices;
+    # a segment end carries density * l^3 pi / 12, a point the mean nodal mass of the tetrahedral components (Mesh.cpp:279-295, 405-411)
+    (tmp_path / "rope.seg").write_text("v 0 0 0\nv 2 0 0\nv 2 1 0\ns 1 2\ns 2 3\n")
+    Vs, Es = ss.read_seg(str(tmp_path / "rope.seg"))
+    assert Vs.shape == (3, 3) and Es.tolist() == [[0, 1], [1, 2]]
+    Vt, Et = ss.read_seg(str(tmp_path / "plane.seg"))  # no such file: the edges of plane.obj, each once, in std::set order
+    assert Vt.shape == (5, 3) and len(Et) == 8 and Et.tolist() == sorted(Et.tolist()) and len({frozenset(e) for e in Et.tolist()}) == 8
+    assert ss.read_pt(str(tmp_path / "plane.pt")).shape == (5, 3)
+    txt = ("script null\nshapes input 3\nbox.msh 0 2 0  0 0 0  1 1 1\n" + str(tmp_path / "rope.seg") + " 0 0 0  0 0 0  1 1 1 linearVelocity 0 0 0\n"
+           + str(tmp_path / "plane.pt") + " 0 -1 0  0 0 0  1 1 1 angularVelocity 0 10 0\n")
+    sc2 = ss.assemble(ss.SceneConfig.parse(txt, str(tmp_path)), lambda p: (V0.copy(), F0.copy(), SF0.copy()))
+    nb = V0.shape[0]
+    assert sc2.codim_edges.tolist() == [[nb, nb + 1], [nb + 1, nb + 2]] and np.array_equal(sc2.codim_nodes, np.arange(nb, nb + 8))
+    assert np.allclose(sc2.codim_mass[:3], 1000.0 * np.pi / 12.0 * np.array([8.0, 8.0 + 1.0, 1.0]))
+    assert np.allclose(sc2.codim_mass[3:], 1000.0 * 0.125 / nb)  # the box of volume 1/8 over its nb nodes
+    assert len(sc2.dirichlet) == 2 and sc2.SF.shape[0] == SF0.shape[0]
     with pytest.raises(ss.UnsupportedKeyword):  # nobody holds the surface: it would fall as a cloud of free particles
         ss.assemble(ss.SceneConfig.parse(DCOFIX.format(plane=tmp_path / "plane.obj").replace("script DCOFix\n", ""), str(tmp_path)),
                     lambda p: (V0.copy(), F0.copy(), SF0.copy()))

@@ -172,6 +172,9 @@ SCENES = [
     # a cube falling on a rotating kinematic cube given as a tetrahedral mesh / as a closed triangle surface (codimension 2)
     ("rotate_co", "tutorialExamples/MCO/2cubesFall_rotateCO.txt", "", 30),
     ("rotate_co_surface", "tutorialExamples/MCO/2cubesFall_rotateCO_closedSurface.txt", "", 30),
+    # ... on the three EDGES of a rotating triangle (`.seg` shape, codimension 1) and on its three CORNERS (`.pt` shape, codimension 0)
+    ("rotate_co_edges", "tutorialExamples/MCO/2cubesFall_rotateCO_edges.txt", "", 44),
+    ("rotate_co_points", "tutorialExamples/MCO/2cubesFall_rotateCO_points.txt", "", 44),
     # Dirichlet groups with time ranges
     ("dbc_time_range", "tutorialExamples/BC/2cubesFall_DBC_timeRange.txt", "", 30),
     # fixed-corotated energy, `size`, `script fall`, a kinematic mesh obstacle (meshCO plane.obj), self-collision
@@ -283,6 +286,12 @@ def scenes(only=()):
             if pth.lower().endswith(".obj"):
                 out[f"mesh{i}_V"], out[f"mesh{i}_SF"] = ss.read_obj(pth)
                 out[f"mesh{i}_T"] = np.zeros((0, 4), np.int32)
+            elif pth.lower().endswith((".seg", ".pt")):
+                if pth.lower().endswith(".seg"):
+                    out[f"mesh{i}_V"], out[f"mesh{i}_E"] = ss.read_seg(pth)
+                else:
+                    out[f"mesh{i}_V"] = ss.read_pt(pth)
+                out[f"mesh{i}_T"], out[f"mesh{i}_SF"] = np.zeros((0, 4), np.int32), np.zeros((0, 3), np.int32)
             else:
                 out[f"mesh{i}_V"], out[f"mesh{i}_T"], out[f"mesh{i}_SF"] = gl.read_tet_mesh(pth)
         out["mesh_keys"] = np.array(keys)
