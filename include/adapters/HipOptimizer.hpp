@@ -98,6 +98,7 @@ struct HipOptimizerParts {
             const char* why = nullptr;
             if (!residentScript(cfg.animScriptType)) why = "this script is not built into the resident stepper";
             else if (cfg.useAbsParameters) why = "absolute tuning parameters";
+            else if (!cfg.inputShapeMeshSeqFolderPath.empty()) why = "a mesh sequence (ipcgpu_opt_set_dirichlet_targets is driven by the scene tooling only)";
             else if (cfg.isConstrained && cfg.constraintSolverType != CST_IP) why = "a constraint solver other than interiorPoint";
             else if (!cfg.isConstrained && (cfg.collisionObjects.size() || cfg.meshCollisionObjects.size())) why = "unconstrained run with collision objects";
             if (why) {

@@ -326,6 +326,12 @@ int ipcgpu_opt_end_dirichlet(ipcgpu_ctx*, int group, double t_end);
  * scripts type them (it decides whether they are released with the others when a scripted move is cut short, Optimizer.cpp:2168-2203). */
 int ipcgpu_opt_set_dirichlet_motion(ipcgpu_ctx*, int group, const double* lin_vel3, const double* ang_vel3, const double* center3 /*nullable*/,
     int force_nonzero);
+/* Mesh-sequence motion of a Dirichlet group (`meshSeq <folder>` behind a shape, Config.cpp:284-289; AnimScripter.cpp:1465-1532): before
+   every time step the reference reads <folder>/<step>.{msh,obj,seg,pt} and makes `file position - current position` the move of the
+   component's nodes, overriding its velocities; the move is then bounded by CCD and the intersection check like any scripted motion
+   (:2162-2250).  targets_3n = the file's positions (node order of the group, xyz interleaved), handed over before each step; NULL ends
+   the sequence.  The nodes keep the type their velocities give them (ZERO for a codimensional component that only follows a sequence). */
+int ipcgpu_opt_set_dirichlet_targets(ipcgpu_ctx*, int group, int n, const double* targets_3n);
 /* One Mesh::NeumannBCs entry (src/Mesh.hpp:47-56; `NBC bboxMin bboxMax force [t0 t1]` on a shape line, src/Config.cpp:264-280):
  * while t0 <= stepStartTime < t1 every listed vertex that is not a Dirichlet node feels the acceleration `accel3` -- the
  * incremental potential gets -dt^2 m_v accel . x_v, the gradient -dt^2 m_v accel (Optimizer.cpp:3241-3250, 3452-3461). */

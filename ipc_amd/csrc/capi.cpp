@@ -1240,6 +1240,24 @@ int ipcgpu_opt_set_dirichlet_motion(ipcgpu_ctx* c, int group, const double* lin3
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_dirichlet_targets(ipcgpu_ctx* c, int group, int n, const double* targets)
+{
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        bind(c);
+        needArg(group >= 0 && group < (int)o.dbcGroups.size(), "no such Dirichlet group");
+        auto& g = *o.dbcGroups[group];
+        if (!targets) {
+            g.hasTargets = false;
+            return IPCGPU_OK;
+        }
+        needArg(n == (int)g.ids.size(), "one target position per node of the group");
+        g.d_targets.upload(targets, 3 * (size_t)n, c->stream);
+        HIP_CHECK(hipStreamSynchronize(c->stream));
+        g.hasTargets = true;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_add_neumann(ipcgpu_ctx* c, int n, const int* ids, const double* accel3, double t0, double t1)
 {
     return guarded([&] {

@@ -174,6 +174,10 @@ public:
         // NONZERO Dirichlet node whatever its velocity currently is, and rotations turn about a centre fixed at set-up time
         bool forceNonzero = false, hasCenter = false;
         double center[3] = { 0, 0, 0 };
+        // mesh-sequence motion (`meshSeq <folder>`, AnimScripter.cpp:1465-1528): the positions the nodes are to reach in the next time step,
+        // handed over before every step; the velocities above are then ignored
+        bool hasTargets = false;
+        DevBuf<double> d_targets;
         bool isZero() const { return !forceNonzero && lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
     };
     std::vector<std::unique_ptr<DbcGroup>> dbcGroups;

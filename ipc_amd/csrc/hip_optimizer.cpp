@@ -201,7 +201,7 @@ bool HipOptimizer::dbcGroupMotion()
     bool any = false;
     std::vector<double> pos;
     for (const auto& g : dbcGroups) {
-        if (stepStartTime < g->t0 || stepStartTime >= g->t1 || g->ids.empty()) continue;
+        if (stepStartTime < g->t0 || stepStartTime >= g->t1 || g->ids.empty() || g->hasTargets) continue;
         const int n = (int)g->ids.size();
         // centre of the group's current bounding box (AnimScripter.cpp:1450-1455): a few KB to the host, once per time step
         launch_gather3(n, g->d_ids.p, mesh.d_x.p, g->d_pos.p, stream);
@@ -228,6 +228,11 @@ bool HipOptimizer::dbcGroupMotion()
         for (int i = 0; i < 3; ++i)
             for (int j = 0; j < 3; ++j) m.R[3 * i + j] = T[3 * i] * Rz[j] + T[3 * i + 1] * Rz[3 + j] + T[3 * i + 2] * Rz[6 + j];
         launch_dbc_motion(n, g->d_ids.p, m, mesh.d_x.p, d_searchDir.p, stream);
+        any = true;
+    }
+    for (const auto& g : dbcGroups) { // behind the velocities, as in AnimScripter.cpp:1465: the sequence SETS the move of its nodes
+        if (!g->hasTargets || stepStartTime < g->t0 || stepStartTime >= g->t1 || g->ids.empty()) continue;
+        launch_dbc_targets((int)g->ids.size(), g->d_ids.p, g->d_targets.p, mesh.d_x.p, d_searchDir.p, stream);
         any = true;
     }
     return any;

@@ -72,6 +72,7 @@ struct DbcMotion {
 };
 void launch_gather3(int n, const int* ids, const double* x, double* out, hipStream_t s);
 void launch_dbc_motion(int n, const int* ids, const DbcMotion& m, const double* x, double* p, hipStream_t s);
+void launch_dbc_targets(int n, const int* ids, const double* target_3n, const double* x, double* p, hipStream_t s);
 // Neumann boundary conditions (Mesh::NeumannBCs; Optimizer.cpp:3241-3250, 3452-3461): dtSqA3 = dt^2 * acceleration
 void launch_nbc_gradient(int n, const int* ids, const int* dbc, const double* mass, const double* dtSqA3, double* g, hipStream_t s);
 void launch_nbc_energy(int n, const int* ids, const int* dbc, const double* mass, const double* x, const double* dtSqA3, double* out, hipStream_t s);

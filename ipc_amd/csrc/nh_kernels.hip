@@ -453,6 +453,15 @@ __global__ void k_dbc_motion(int n, const int* __restrict__ ids, DbcMotion m, co
     for (int c = 0; c < 3; ++c) p[3 * v + c] += (m.R[3 * c] * d0 + m.R[3 * c + 1] * d1 + m.R[3 * c + 2] * d2) + m.c[c] + m.linDt[c] - x[3 * v + c];
 }
 
+// mesh-sequence Dirichlet motion (AnimScripter.cpp:1465-1528): p = target - x (set, not added: it overrides whatever the velocities asked for)
+__global__ void k_dbc_targets(int n, const int* __restrict__ ids, const double* __restrict__ target, const double* __restrict__ x, double* __restrict__ p)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const size_t v = (size_t)ids[i / 3];
+    p[3 * v + i % 3] = target[i] - x[3 * v + i % 3];
+}
+
 // ---- Neumann boundary conditions (Optimizer.cpp:3241-3250, 3452-3461): nodes `ids`, acceleration a, coefficient dt^2
 // gradient: g_v -= dt^2 m_v a ; energy (one workgroup, fixed order): sum dt^2 m_v a . x_v   (non-Dirichlet nodes only)
 __global__ void k_nbc_gradient(int n, const int* __restrict__ ids, const int* __restrict__ dbc, const double* __restrict__ mass, double cx, double cy,
@@ -728,6 +737,10 @@ void launch_gather3(int n, const int* ids, const double* x, double* out, hipStre
 void launch_dbc_motion(int n, const int* ids, const DbcMotion& m, const double* x, double* p, hipStream_t s)
 {
     if (n) hipLaunchKernelGGL(k_dbc_motion, dim3(nblk(n)), dim3(BLOCK), 0, s, n, ids, m, x, p);
+}
+void launch_dbc_targets(int n, const int* ids, const double* target, const double* x, double* p, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_dbc_targets, dim3(nblk(3LL * n)), dim3(BLOCK), 0, s, n, ids, target, x, p);
 }
 
 __global__ void k_publish(const unsigned* __restrict__ src, unsigned* __restrict__ dst, int n)

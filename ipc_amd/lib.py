@@ -641,6 +641,14 @@ class Context:
         ang = _f64(np.asarray(ang_vel_deg, dtype=np.float64) * np.pi / 180)
         self._chk(self._L.ipcgpu_opt_add_dirichlet(self.h, C.c_int(len(ids)), _ip(ids), _dp(lin), _dp(ang), C.c_double(t0), C.c_double(t1)))
 
+    def set_dirichlet_targets(self, group, targets):
+        """mesh-sequence motion: the positions the group's nodes are to reach in the next time step (None ends the sequence)"""
+        if targets is None:
+            self._chk(self._L.ipcgpu_opt_set_dirichlet_targets(self.h, C.c_int(group), C.c_int(0), None))
+            return
+        t = _f64(np.ascontiguousarray(np.asarray(targets, dtype=np.float64).reshape(-1, 3)))
+        self._chk(self._L.ipcgpu_opt_set_dirichlet_targets(self.h, C.c_int(group), C.c_int(t.shape[0]), _dp(t)))
+
     def set_dirichlet_motion(self, group, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), center=None, force_nonzero=True):
         """Motion of Dirichlet group `group` for the coming time steps (the rule-driven scripts of AnimScripter.cpp:1961-2135)."""
         lin = _f64(np.asarray(lin_vel, dtype=np.float64))

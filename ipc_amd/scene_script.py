@@ -45,6 +45,7 @@ class Shape:
     lin_vel: tuple = None  # scripted (kinematic component)
     ang_vel_deg: tuple = None
     init_vel: tuple = None  # (linear, angular deg/s)
+    mesh_seq: str = None  # `meshSeq <folder>`: the component follows the positions of <folder>/<step>.{msh,obj,seg,pt} (Config.cpp:284-289)
     dbc: list = field(default_factory=list)  # (rel_min, rel_max, lin_vel, ang_vel_deg, t0, t1)
     nbc: list = field(default_factory=list)  # (rel_min, rel_max, acceleration, t0, t1)
 
@@ -265,6 +266,9 @@ def _parse_shape(st, resolve):
         elif e == "angularVelocity":
             sh.ang_vel_deg = tuple(float(x) for x in st[j:j + 3])
             j += 3
+        elif e == "meshSeq":
+            sh.mesh_seq = resolve(st[j])
+            j += 1
         elif e == "initVel":
             v = [float(x) for x in st[j:j + 6]]
             sh.init_vel = (tuple(v[:3]), tuple(v[3:]))
@@ -351,6 +355,16 @@ def read_pt(path):
     return read_obj(os.path.splitext(path)[0] + ".obj")[0]
 
 
+def read_seq_file(folder, index, ext):
+    """positions of file `index` of a mesh sequence, by the kind of the component that follows it (AnimScripter.cpp:1468-1518)"""
+    base = os.path.join(folder, str(index))
+    if ext == ".obj":
+        return read_obj(base + ".obj")[0]
+    if ext == ".seg":
+        return read_seg(base + ".seg")[0]
+    return read_pt(base + ".pt")
+
+
 # The hard-coded scripts of AnimScripter that move whole components (set-up AnimScripter.cpp:1060-1300, per step :1961-2135): how many
 # leading components they move and with what.  Linear velocities in units / s, angular velocities in rad / s about x, y, z.
 _S6 = [(1.0, 0, 0), (-1.0, 0, 0), (0, 1.0, 0), (0, -1.0, 0), (0, 0, 1.0), (0, 0, -1.0)]
@@ -382,10 +396,19 @@ class AssembledScene:
     codim_fixed: np.ndarray = None  # `script DCOFix`: those of them held as NONZERO Dirichlet nodes (AnimScripter.cpp:1222-1236)
     V0: np.ndarray = None  # start positions when they differ from the rest shape V (`rotateModel`, main.cpp:1115-1139)
     codim_edges: np.ndarray = None  # segments of the `.seg` shapes (Mesh::CE), global node pairs
+    mesh_seqs: list = None  # `meshSeq` components: {ids, folder, ext, group}
+    mesh_i: int = 0  # AnimScripter::meshI: index of the next file of the sequences
+    read_seq: object = None  # (folder, index, ext) -> positions; None = the files themselves (tests hand in a fixture's)
     motions: list = None  # rule-driven scripts: per Dirichlet group (lin, ang in degrees, fixed rotation centre or None), nodes NONZERO throughout
 
     def before_step(self, be, t):
         """What AnimScripter::stepAnimScript decides from the state before a time step (call with the step's start time)."""
+        if self.mesh_seqs:
+            # AnimScripter.cpp:1465-1532: <folder>/<meshI>.{obj,seg,pt} read as main.cpp reads the shape itself (file positions as they are,
+            # NOT moved by the shape's translation / rotation / scale); meshI counts the time steps
+            for q in self.mesh_seqs:
+                be.set_dirichlet_targets(q["group"], (self.read_seq or read_seq_file)(q["folder"], self.mesh_i, q["ext"]))
+            self.mesh_i += 1
         r = self.release
         if r is None or r["done"]:
             return False
@@ -424,6 +447,7 @@ def assemble(cfg, read_mesh):
     Vs, Ts, SFs, nr, tr, dirichlet, neumann = [], [], [], [0], [0], [], []
     codim = []  # (node ids, triangles, moved by its own keywords, segments) of the components of the mesh without tetrahedra
     CEs = []
+    seqs = []  # mesh sequences: {ids, folder, ext}
     for sh in cfg.shapes:
         ext = os.path.splitext(sh.path.lower())[1]
         is_codim = ext in (".obj", ".seg", ".pt")  # main.cpp:948-1005: kinematic surface / segments / points (componentCoDim 2 / 1 / 0)
@@ -455,8 +479,19 @@ def assemble(cfg, read_mesh):
         if sh.lin_vel is not None or sh.ang_vel_deg is not None:  # scripted component: every node moves (AnimScripter.cpp:1413-1435)
             ids = np.arange(V.shape[0], dtype=np.int32) + off
             dirichlet.append((ids, sh.lin_vel or (0, 0, 0), sh.ang_vel_deg or (0, 0, 0), 0.0, float("inf")))
+        if sh.mesh_seq is not None:
+            # AnimScripter.cpp:1465-1528: every node of the component is moved to the positions of the next file of the sequence before each
+            # step.  The nodes carry the type their velocities give them: a codimensional component without velocities is held (ZERO, :62-70)
+            if cfg.script != "null":
+                raise UnsupportedKeyword("meshSeq under a script other than null")
+            if not is_codim:
+                raise UnsupportedKeyword("meshSeq on a tetrahedral component (its nodes are free: the sequence would only nudge them)")
+            ids = np.arange(V.shape[0], dtype=np.int32) + off
+            dirichlet.append((ids, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf")))
+            seqs.append({"ids": ids, "folder": sh.mesh_seq, "ext": ext})
         if is_codim:
-            codim.append((np.arange(off, off + V.shape[0], dtype=np.int32), SF + off, sh.lin_vel is not None or sh.ang_vel_deg is not None, E + off))
+            codim.append((np.arange(off, off + V.shape[0], dtype=np.int32), SF + off,
+                          sh.lin_vel is not None or sh.ang_vel_deg is not None or sh.mesh_seq is not None, E + off))
         CEs.append(E + off)
         Vs.append(V)
         Ts.append(T + off)
@@ -614,6 +649,9 @@ def assemble(cfg, read_mesh):
     sc = AssembledScene(cfg, V, T, SF, nr, tr, dirichlet, vel, neumann, obst, release, codim_nodes, codim_mass, codim_fixed, V0)
     sc.motions = motions
     sc.codim_edges = codim_edges
+    for q in seqs:  # the group a sequence drives = the entry of `dirichlet` that holds its nodes
+        q["group"] = next(g for g, d in enumerate(dirichlet) if d[0] is q["ids"])
+    sc.mesh_seqs = seqs
     return sc
 
 

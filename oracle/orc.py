@@ -496,6 +496,15 @@ def opt_end_dirichlet(opt: "Optimizer", group, t_end):
     lib().orc_opt_end_dirichlet(opt.h, C.c_int(group), C.c_double(t_end))
 
 
+def opt_set_dirichlet_targets(o, group, targets):
+    """mesh-sequence motion (AnimScripter.cpp:1465-1528): where the group's nodes are to be after the next time step; None ends it"""
+    if targets is None:
+        lib().orc_opt_set_dirichlet_targets(o.h, C.c_int(group), C.c_int(0), None)
+        return
+    t = np.ascontiguousarray(np.asarray(targets, dtype=np.float64).reshape(-1, 3))
+    lib().orc_opt_set_dirichlet_targets(o.h, C.c_int(group), C.c_int(t.shape[0]), _dp(t))
+
+
 def opt_set_dirichlet_motion(opt: "Optimizer", group, lin_vel=(0, 0, 0), ang_vel_deg=(0, 0, 0), center=None, force_nonzero=True):
     """Motion of Dirichlet group `group` for the coming time steps (the rule-driven scripts of AnimScripter.cpp:1961-2135)."""
     lin = np.ascontiguousarray(lin_vel, dtype=np.float64)

@@ -90,6 +90,7 @@ orc_opt* orc_opt_create(orc_mesh*, double dt, int withGravity, int nthreads);
 void orc_opt_destroy(orc_opt*);
 void orc_opt_set_twist(orc_opt*, int nL, const int* left, int nR, const int* right, double angVel); // AnimScripter.cpp:555-572
 void orc_opt_set_dirichlet_motion(orc_opt*, int group, const double* lin3, const double* angRad3, const double* center3 /*nullable*/, int forceNonzero);
+void orc_opt_set_dirichlet_targets(orc_opt*, int group, int n, const double* targets_3n); // mesh-sequence motion; NULL ends it
 void orc_opt_force_friction_loop(orc_opt*, int on); // Optimizer.cpp:156-161: a MeshCO friction coefficient only switches the lagging loop on
 void orc_opt_set_friction_scales(orc_opt*, double scaleSelf, double scaleObstacle); // MeshCO::friction beside selfFric
 void orc_opt_set_rel_tol(orc_opt*, double relTol); // Optimizer.cpp:390-396

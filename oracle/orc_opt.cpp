@@ -46,6 +46,7 @@ struct orc_opt {
         bool forceNonzero = false, hasCenter = false; // the hard-coded DCO scripts (AnimScripter.cpp:1060-1300, 1961-2135)
         double center[3] = { 0, 0, 0 };
         bool isZero() const { return !forceNonzero && lin[0] == 0 && lin[1] == 0 && lin[2] == 0 && ang[0] == 0 && ang[1] == 0 && ang[2] == 0; }
+        std::vector<double> targets; // mesh-sequence motion (AnimScripter.cpp:1465-1528): where the nodes are to be after the next step (3 per node)
     };
     std::vector<DBCGroup> dbcGroups;
     // Mesh::NeumannBCs (Mesh.hpp:47-56): `NBC bboxMin bboxMax force [t0 t1]` of a shape line (Config.cpp:264-280); `force` is an
@@ -720,6 +721,13 @@ void orc_opt_set_dirichlet_motion(orc_opt* o, int group, const double* lin3, con
     g.forceNonzero = forceNonzero != 0;
     setDBCVertices(o);
 }
+void orc_opt_set_dirichlet_targets(orc_opt* o, int group, int n, const double* targets)
+{
+    if (group < 0 || group >= (int)o->dbcGroups.size()) return;
+    orc_opt::DBCGroup& g = o->dbcGroups[group];
+    if (!targets || n != (int)g.ids.size()) g.targets.clear();
+    else g.targets.assign(targets, targets + 3 * (size_t)n);
+}
 void orc_opt_add_neumann(orc_opt* o, int n, const int* ids, const double* accel3, double t0, double t1)
 {
     orc_opt::NBCGroup g;
@@ -803,8 +811,14 @@ void orc_opt_begin_timestep(orc_opt* o)
     setDBCVertices(o);
     bool scripted = !o->angVel.empty();
     for (const auto& g : o->dbcGroups)
-        if (o->stepStartTime >= g.t0 && o->stepStartTime < g.t1 && !g.ids.empty()) {
+        if (o->stepStartTime >= g.t0 && o->stepStartTime < g.t1 && !g.ids.empty() && g.targets.empty()) {
             dbcGroupMotion(o, g);
+            scripted = true;
+        }
+    for (const auto& g : o->dbcGroups) // the sequence SETS the move of its nodes, behind the velocities (AnimScripter.cpp:1465-1528)
+        if (o->stepStartTime >= g.t0 && o->stepStartTime < g.t1 && !g.targets.empty()) {
+            for (size_t i = 0; i < g.ids.size(); ++i)
+                for (int c = 0; c < 3; ++c) o->searchDir[3 * g.ids[i] + c] = g.targets[3 * i + c] - m.V[g.ids[i] + m.nV * c];
             scripted = true;
         }
     // targetPos / dist2Tol (AnimScripter.cpp:2150-2157)

@@ -229,6 +229,8 @@ def run_scene(S, meshes, backend, steps, restart=None):
         sc = ss.assemble(cfg, lambda p: tuple(a.copy() for a in meshes[key(p)][:3]))
     finally:
         ss.read_obj, ss.read_seg, ss.read_pt = read_obj, read_seg, read_pt
+    if sc.mesh_seqs:  # the files of a mesh sequence come out of the fixture as well
+        sc.read_seq = lambda folder, i, ext: S["seq_" + key(folder)][i]
     be = ss.apply(sc, backend)
     pos, its = [], []
     for s in range(steps):
@@ -382,8 +384,9 @@ def test_scripted_plates_against_the_reference(name, tol):
 # EDGES (`.seg`, codimension 1) / the three CORNERS (`.pt`, codimension 0) of a triangle that turns about y at 90 degrees per second, run by
 # the reference: (fixture, position tolerance).  The cube is in free fall for 24 steps and is then caught, spun and dropped by the segments /
 # points alone -- edge-edge stencils against segments that belong to no triangle, point-triangle stencils with vertices that belong to
-# nothing, the point-in-tetrahedron test of the intersection check (SelfCollisionHandler.cpp:3301-3338).
-CODIM_SCENES = [("rotate_co_edges", 1e-7), ("rotate_co_points", 1e-6)]
+# nothing, the point-in-tetrahedron test of the intersection check (SelfCollisionHandler.cpp:3301-3338).  The third fixture drives the
+# segments by a mesh sequence (`meshSeq`, one file of positions per time step; AnimScripter.cpp:1465-1532) instead of a velocity.
+CODIM_SCENES = [("rotate_co_edges", 1e-7), ("rotate_co_points", 1e-6), ("rotate_co_mesh_seq", 1e-6)]
 
 
 def check_codim(S, pos, its, tol):

@@ -195,6 +195,9 @@ class OracleBackend:
     def set_dirichlet_motion(self, group, **k):
         self.orc.opt_set_dirichlet_motion(self.o, group, **k)
 
+    def set_dirichlet_targets(self, group, targets):
+        self.orc.opt_set_dirichlet_targets(self.o, group, targets)
+
     def state(self):
         return self.o.state()
 

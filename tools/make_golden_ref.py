@@ -175,6 +175,8 @@ SCENES = [
     # ... on the three EDGES of a rotating triangle (`.seg` shape, codimension 1) and on its three CORNERS (`.pt` shape, codimension 0)
     ("rotate_co_edges", "tutorialExamples/MCO/2cubesFall_rotateCO_edges.txt", "", 44),
     ("rotate_co_points", "tutorialExamples/MCO/2cubesFall_rotateCO_points.txt", "", 44),
+    # ... and on the segments of a triangle that follows a MESH SEQUENCE (`meshSeq input/segMeshes/sequence`: one .seg file per time step)
+    ("rotate_co_mesh_seq", "tutorialExamples/advanced/2cubesFall_rotateCO_meshSeq.txt", "", 25),  # (in step 26 the reference as compiled here runs into its iteration cap)
     # Dirichlet groups with time ranges
     ("dbc_time_range", "tutorialExamples/BC/2cubesFall_DBC_timeRange.txt", "", 30),
     # fixed-corotated energy, `size`, `script fall`, a kinematic mesh obstacle (meshCO plane.obj), self-collision
@@ -295,6 +297,10 @@ def scenes(only=()):
             else:
                 out[f"mesh{i}_V"], out[f"mesh{i}_T"], out[f"mesh{i}_SF"] = gl.read_tet_mesh(pth)
         out["mesh_keys"] = np.array(keys)
+        for sh in cfg.shapes:  # the files of a mesh sequence travel too: positions of file 0 .. steps - 1
+            if sh.mesh_seq is not None:
+                ext = os.path.splitext(sh.path.lower())[1]
+                out["seq_" + os.path.relpath(sh.mesh_seq, REF_ROOT)] = np.array([ss.read_seq_file(sh.mesh_seq, i, ext) for i in range(steps)])
         fn = os.path.join(GOLD, f"ref_scene_{name}.npz")
         np.savez_compressed(fn, **out)
         print(f"wrote {os.path.basename(fn)}: {steps} steps, Newton iterations per step {its.tolist()}, {os.path.getsize(fn) >> 10} KiB")
