@@ -117,7 +117,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") and a[0] not in DCO_SCRIPTS:
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") + HANDLE_SCRIPTS and a[0] not in DCO_SCRIPTS:
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
                 if len(a) > 1 and int(a[1]) > 0:  # `script name n p1 .. pn` (Config.cpp:166-175): parameters of the script
@@ -244,6 +244,8 @@ class SceneConfig:
                 cfg.damping_ratio = min(max(float(a[0]), 0.0), 1.0)
             elif k in VIEWER_KEYWORDS:
                 pass  # viewer / logging only
+            elif k in ("resolution", "inexactSolve"):
+                pass  # tokens Config::loadFromFile itself has no branch for (Config.cpp:97-617): the reference reads past them
             else:
                 raise UnsupportedKeyword(k)
         if cfg.damping_ratio > 0:  # Config.cpp:614-616
@@ -378,6 +380,10 @@ DCO_SCRIPTS = {
 }
 
 
+# scripts that pick their Dirichlet / Neumann nodes from the bounding box of the assembled mesh (set-up in AnimScripter::initAnimScript)
+HANDLE_SCRIPTS = ("fixLowerHalf", "pushRightMost1", "utopiaComparison", "DCOSegBedSquash", "hangLeft")
+
+
 @dataclass
 class AssembledScene:
     cfg: SceneConfig
@@ -423,6 +429,15 @@ class AssembledScene:
                     for g, v in enumerate(r["lin"]):
                         be.set_dirichlet_motion(g, lin_vel=v, force_nonzero=True)
                     return True
+            return False
+        if r.get("kind") == "segbed":  # AnimScripter.cpp:2080-2100: the upper parts move only while they are more than 0.1 above the lower ones
+            top_min = x[r["up"], 1].min()
+            bottom_max = x[r["down"], 1].max() if len(r["down"]) else -np.inf
+            moving = bool(top_min - bottom_max > 0.1)
+            if moving != r["moving"]:
+                r["moving"] = moving
+                be.set_dirichlet_motion(r["group"], lin_vel=(0.0, -1.0, 0.0) if moving else (0.0, 0.0, 0.0), force_nonzero=True)
+                return True
             return False
         if r.get("kind") == "pause":
             # `script stretchAndPause` (AnimScripter.cpp:1605-1616): the handles move while the turning vertex has not passed x = -0.28;
@@ -572,7 +587,7 @@ def assemble(cfg, read_mesh):
         if cfg.script in ("DCOFix", "DCOBallHitWall"):  # AnimScripter.cpp:1222-1236: every codimensional component is held (NONZERO, no motion)
             dirichlet = []
             codim_fixed = codim_nodes
-        elif cfg.script not in DCO_SCRIPTS and not all(moved for _i, _f, moved, _e in codim):
+        elif cfg.script not in DCO_SCRIPTS and cfg.script != "DCOSegBedSquash" and not all(moved for _i, _f, moved, _e in codim):
             raise UnsupportedKeyword("codimensional shape that no script fixes or moves")
     elif cfg.script in ("DCOFix", "DCOBallHitWall"):
         dirichlet = []  # mesh.resetDBCVertices(); nothing to hold
@@ -627,6 +642,45 @@ def assemble(cfg, read_mesh):
         right = np.nonzero((U[:nSim, 0] > hi[0] - 0.01 * (hi[0] - lo[0])) & ~(U[:nSim, 0] < lo[0] + 0.01 * (hi[0] - lo[0])))[0].astype(np.int32)
         dirichlet = [(left, (-1.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf")), (right, (1.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
         release = {"kind": "pause", "turn": int(left[-1]), "x_limit": -0.28, "groups": [0, 1], "ids": [left, right], "done": False}
+    if cfg.script in HANDLE_SCRIPTS:
+        U = V if V0 is None else V0
+        lo, hi = U[:nSim].min(0), U[:nSim].max(0)  # mesh.V.colwise().minCoeff() / maxCoeff(): every node of Mesh<3>
+        rng = hi - lo
+        still = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), None)
+        if cfg.script == "hangLeft":  # AnimScripter.cpp:191-204: the left border nodes (IglUtils::findBorderVerts, handleRatio 0.01) are held (ZERO)
+            left, _right = _scene.border_verts(U[:nSim], 0.01)
+            dirichlet = [(np.asarray(left, dtype=np.int32), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
+        elif cfg.script == "fixLowerHalf":  # AnimScripter.cpp:337-350: the lower half of the model is held (NONZERO, no motion)
+            ids = np.nonzero(U[:nSim, 1] < lo[1] + rng[1] * 0.5)[0].astype(np.int32)
+            dirichlet, motions = [(ids, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))], [still]
+        elif cfg.script == "pushRightMost1":  # :895-910, 1820-1826: the FIRST node within 1e-3 of the right end is pushed at 0.15 in -x
+            ids = np.nonzero(U[:nSim, 0] > hi[0] - 1.0e-3 * rng[0])[0][:1].astype(np.int32)
+            dirichlet, motions = [(ids, (-0.15, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))], [((-0.15, 0.0, 0.0), (0.0, 0.0, 0.0), None)]
+        elif cfg.script == "utopiaComparison":
+            # :1283-1302, 1641-1646: nodes within 1e-4 of the model's WIDTH (range[0], as written) of the top carry a Neumann acceleration of
+            # 1.5 downwards, those as close to the bottom are held
+            top = U[:nSim, 1] > hi[1] - rng[0] * 1e-4
+            bottom = ~top & (U[:nSim, 1] < lo[1] + rng[0] * 1e-4)
+            dirichlet, motions = [(np.nonzero(bottom)[0].astype(np.int32), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))], [still]
+            neumann = [(np.nonzero(top)[0].astype(np.int32), (0.0, -1.5, 0.0), 0.0, float("inf"))]
+        else:
+            # DCOSegBedSquash (:1239-1259, 2080-2100): every component without tetrahedra is a NONZERO Dirichlet set; those in the upper half of
+            # the component list (index >= (#components + 1) / 2) move down at 1 while the gap between the lowest node of the upper ones and the
+            # highest node of the lower ones exceeds 0.1 -- the two beds of `17_pinCushionBall.txt` closing on the ball
+            ncomp = len(cfg.shapes)
+            parts = [c for c in range(ncomp) if not tr[c + 1] > tr[c]]
+            if not parts:
+                raise UnsupportedKeyword("script DCOSegBedSquash without a component to move")
+            up = [c for c in parts if c >= (ncomp + 1) // 2]
+            down = [c for c in parts if c < (ncomp + 1) // 2]
+            cat = lambda cs: np.concatenate([np.arange(nr[c], nr[c + 1], dtype=np.int32) for c in cs]) if cs else np.zeros(0, np.int32)  # noqa: E731
+            dirichlet, motions = [], []
+            for ids, lin in ((cat(down), (0.0, 0.0, 0.0)), (cat(up), (0.0, -1.0, 0.0))):
+                if len(ids):
+                    dirichlet.append((ids, lin, (0.0, 0.0, 0.0), 0.0, float("inf")))
+                    motions.append((lin, (0.0, 0.0, 0.0), None))
+            release = {"kind": "segbed", "up": cat(up), "down": cat(down), "group": len(dirichlet) - 1, "moving": True, "done": False} if len(up) else None
+            codim_fixed = None
     vel = np.zeros_like(V)
     fixed = np.zeros(V.shape[0], dtype=bool)
     for ids, *_ in dirichlet:

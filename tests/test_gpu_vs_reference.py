@@ -8,8 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import (CODIM_SCENES, GOLD, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_codim, check_damped_bar, check_plates, check_restart,
-                                      check_scene, load_scene, rel, run_scene)
+from test_oracle_vs_reference import (CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_codim, check_damped_bar, check_plates,
+                                      check_restart, check_scene, check_seg_bed, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -247,6 +247,26 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol, gpu_
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     check_codim(S, pos, its, 10 * tol)
     c.close()
+
+
+@pytest.mark.parametrize("name", HANDLE_SCENES)
+def test_handle_scripts_against_the_reference(name, gpu_lib):
+    """fixLowerHalf / pushRightMost1 / utopiaComparison on the HIP stepper"""
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    assert np.array_equal(its, S["iters"])
+    assert np.abs(pos - S["positions"]).max() <= 1e-11 * np.abs(S["positions"]).max()
+
+
+def test_seg_bed_squash_against_the_reference(gpu_lib):
+    """`script DCOSegBedSquash`, the script of 17_pinCushionBall.txt, on the HIP stepper"""
+    S, meshes = load_scene("seg_bed_squash")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    check_seg_bed(S, pos, its)
 
 
 @pytest.mark.parametrize("name,steps", [("mat100_twist", 3), ("rods_twist", 2)])

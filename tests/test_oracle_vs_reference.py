@@ -404,6 +404,41 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol):
     check_codim(S, pos, its, tol)
 
 
+# scripts that pick their handles from the bounding box of the mesh (AnimScripter::initAnimScript), each on the tutorial cube, run by the
+# reference: fixLowerHalf (AnimScripter.cpp:337-350), pushRightMost1 (:895-910, 1820-1826), utopiaComparison (:1283-1302, 1641-1646)
+HANDLE_SCENES = ["fix_lower_half", "push_right_most", "utopia"]
+
+
+@pytest.mark.parametrize("name", HANDLE_SCENES)
+def test_handle_scripts_against_the_reference(name):
+    S, meshes = load_scene(name)
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    assert np.array_equal(its, S["iters"])
+    assert np.abs(pos - S["positions"]).max() <= 1e-13 * np.abs(S["positions"]).max()
+    assert np.abs(S["positions"][-1] - S["positions"][0]).max() > 1e-4  # something moves
+
+
+def check_seg_bed(S, pos, its):
+    """`script DCOSegBedSquash` (AnimScripter.cpp:1239-1259, 2080-2100): the beds of segments (the nodes behind the cube's eight) follow the
+    rule exactly -- the upper one comes down at 1 and stops 0.1 above the lower one; the cube between them has the reference's Newton counts
+    while it is picked up and pressed onto the lower bed (8 steps, up to 34 iterations each).  From the step in which the reference needs 301
+    iterations to squeeze the six-element cube the two runs are different paths to a strongly compressed state: bounded loosely."""
+    ref = S["positions"]
+    assert np.abs(pos[:, 8:] - ref[:, 8:]).max() <= 1e-7  # the beds (their moves are bounded by CCD once they touch the cube)
+    top = ref[:, 14:, 1].min(axis=1) - ref[:, 8:14, 1].max(axis=1)
+    assert top[0] > 0.25 and abs(top[-1] - 0.1) < 0.026 and np.all(np.diff(top) <= 1e-12)
+    assert np.array_equal(its[:8], S["iters"][:8]), (its.tolist(), S["iters"].tolist())
+    assert np.abs(pos[:8, :8] - ref[:8, :8]).max() <= 1e-4 * np.abs(ref).max()
+    assert abs(int(its.sum()) - int(S["iters"].sum())) <= 0.15 * int(S["iters"].sum())
+    assert np.abs(pos - ref).max() <= 5e-2 * np.abs(ref).max()
+
+
+def test_seg_bed_squash_against_the_reference():
+    S, meshes = load_scene("seg_bed_squash")
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    check_seg_bed(S, pos, its)
+
+
 @pytest.mark.parametrize("name,tol", RESTART_SCENES)
 def test_continuation_from_the_references_own_state(name, tol, tmp_path):
     """Every whole-scene fixture above touches down from exact rest, where makePD2d's projection is decided by round-off, so after the

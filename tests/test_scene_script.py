@@ -53,7 +53,9 @@ def test_grammar():
     c = ss.SceneConfig.parse("meshCO input/triMeshes/plane.obj 0.5 0 0.5  10  50  1.0 rotate 0 0 30\n", "/r")
     (path, origin, scale, mu, rot), = c.mesh_cos
     assert path == "/r/input/triMeshes/plane.obj" and np.allclose(origin, [0.5, 0, 0.5]) and scale == 10 and mu == 1.0 and np.allclose(rot, [0, 0, 30])
-    for bad in ("script DCOHammerWalnut\n", "constraintSolver QP\n", "shapes input 1\nm.msh 0 0 0 0 0 0 1 1 1 meshSeq dir\n"):
+    c = ss.SceneConfig.parse("shapes input 1\nm.seg 0 0 0 0 0 0 1 1 1 meshSeq dir\n", "/r")
+    assert c.shapes[0].mesh_seq == "/r/dir"
+    for bad in ("script DCOHammerWalnut\n", "constraintSolver QP\n", "CCDMethod TightInclusion\n"):
         with pytest.raises(ss.UnsupportedKeyword):
             ss.SceneConfig.parse(bad)
 
@@ -113,7 +115,7 @@ def test_reference_scene_files_parse():
     print(len(ok), "scene files map onto the C ABI;", unsupported)
     for need in ("tutorialExamples/2cubesFall.txt", "otherExamples/barTwist_noCollisions.txt", "paperExamples/4_rodsTwist.txt", "paperExamples/14_matTwist.txt"):
         assert need in ok, need
-    assert len(ok) >= 134  # the rest needs other scripted motions, mesh sequences, other CCD methods or other solvers
+    assert len(ok) >= 142  # the rest asks for another CCD method or another constraint solver
 
 
 class OracleBackend:

@@ -225,7 +225,45 @@ input/tetMeshes/cube.msh %s
 selfCollisionOn
 constraintSolver interiorPoint
 """
+_HANDLES = """energy NH
+warmStart 0
+time 1 0.025
+density 1000
+stiffness 1e5 0.4
+script %s
+%s
+shapes input 1
+input/tetMeshes/cube.msh 0 0 0  0 0 0  1 1 1
+"""
+_SEGBED = """energy NH
+warmStart 0
+time 1 0.025
+density 1000
+stiffness 1e5 0.4
+script DCOSegBedSquash
+turnOffGravity
+
+shapes input 1
+input/tetMeshes/cube.msh 0.07 0.09 0.07  0 0 0  0.14 0.14 0.14
+
+shapeMatrix input 1 1 3  -0.08 0 0.03
+input/segMeshes/edge.seg 1 1 0.04  0 0 0  0.3 0.3 0.3
+
+shapeMatrix input 1 1 3  -0.08 0.3 0.03
+input/segMeshes/edge.seg 1 1 0.04  0 0 0  0.3 0.3 0.3
+
+selfCollisionOn
+constraintSolver interiorPoint
+"""
 INLINE = {
+    # scripts that pick their handles from the bounding box of the mesh (AnimScripter::initAnimScript): the lower half of a cube held under
+    # gravity; one corner node pushed in -x; the bottom held and the top pressed down by a Neumann acceleration
+    "inline:fix_lower_half": _HANDLES % ("fixLowerHalf", ""),
+    "inline:push_right_most": _HANDLES % ("pushRightMost1", "turnOffGravity"),
+    "inline:utopia": _HANDLES % ("utopiaComparison", "turnOffGravity"),
+    # `script DCOSegBedSquash` (17_pinCushionBall.txt's script): a small cube between two beds of three segments each, the upper bed coming
+    # down at 1 until it is 0.1 above the lower one -- the cube is picked up, pressed onto the lower bed and squeezed by a quarter
+    "inline:seg_bed_squash": _SEGBED,
     # 15_trashComp_shapes.txt's six closing plates (`script DCOSquash6`, FCR, no gravity) around one cube: a tiny one that is never
     # touched -- the plates close to 0.1, turn round (the sign flip of AnimScripter.cpp:2053-2074, once per step as written) and open --
     # and one that fills the box and is squeezed from step 16 on
@@ -233,6 +271,10 @@ INLINE = {
     "inline:squash6_contact": _SQUASH6 % "-0.6 -0.6 -0.6  0 0 0  1.2 1.2 1.2",
 }
 SCENES += [
+    ("fix_lower_half", "inline:fix_lower_half", "", 6),
+    ("push_right_most", "inline:push_right_most", "", 6),
+    ("utopia", "inline:utopia", "", 6),
+    ("seg_bed_squash", "inline:seg_bed_squash", "", 16),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
