@@ -424,7 +424,8 @@ def check_seg_bed(S, pos, its):
     while it is picked up and pressed onto the lower bed (8 steps, up to 34 iterations each).  From the step in which the reference needs 301
     iterations to squeeze the six-element cube the two runs are different paths to a strongly compressed state: bounded loosely."""
     ref = S["positions"]
-    assert np.abs(pos[:, 8:] - ref[:, 8:]).max() <= 1e-7  # the beds (their moves are bounded by CCD once they touch the cube)
+    # the beds: their moves are bounded by CCD against the cube once they touch it, so they follow the cube's path after step 8
+    assert np.abs(pos[:8, 8:] - ref[:8, 8:]).max() <= 1e-7 and np.abs(pos[:, 8:] - ref[:, 8:]).max() <= 1e-3
     top = ref[:, 14:, 1].min(axis=1) - ref[:, 8:14, 1].max(axis=1)
     assert top[0] > 0.25 and abs(top[-1] - 0.1) < 0.026 and np.all(np.diff(top) <= 1e-12)
     assert np.array_equal(its[:8], S["iters"][:8]), (its.tolist(), S["iters"].tolist())
