@@ -59,11 +59,13 @@ private:
         Range bigFronts; // into bigList_
         std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1
         Range schur; // one-pass Schur complement tiles of the big fronts
+        bool schur64 = false; // ... as 64 x 64 tiles (k_big_schur64) instead of 32 x 32 with the columns split over the waves
         Range fwdRect, bwdInit; // descriptors of the row-/column-parallel halves of the big-front solves
         Range bigTri; // into triList_: big fronts whose triangle is swept by one workgroup (no explicit inverse)
         Range xinvFwd, xinvBwd; // into xinvDesc_: row / column blocks of the fronts with an explicit inverse
     };
     int rank_ = 0, world_ = 1;
+    long long schur64Min_ = 512;
     AllreduceFn allreduce_ = nullptr;
     AllreduceStreamFn allreduceStream_ = nullptr;
     void* allreduceUser_ = nullptr;

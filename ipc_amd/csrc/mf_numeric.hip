@@ -1486,6 +1486,90 @@ __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc,
     }
 }
 
+// The same update with 64 x 64 tiles, for levels of the tree that have thousands of tiles anyway: one wave per 32 x 32 quadrant running over
+// ALL nc columns, no split of the columns over the waves and so no reduction through LDS, no barrier; half the operand loads per flop of the
+// 32 x 32 version (a workgroup reads 128 rows of L for 4096 entries of S instead of 64 for 1024).  The fronts of those levels have nc of
+// 100-450: split four ways a wave ran two or three chunks between its prologue and the LDS reduction.  Upper levels keep the 32 x 32 kernel: they
+// have a handful of fronts and need the tiles for parallelism.  desc as above with 64 x 64 tile indices.
+constexpr int TQ64 = 64;
+__global__ __launch_bounds__(WG) void k_big_schur64(const int4* __restrict__ desc, double* __restrict__ fronts)
+{
+    const int4 d = desc[2 * blockIdx.x];
+    const int4 d2 = desc[2 * blockIdx.x + 1];
+    const int N = d2.x, nc = d2.y;
+    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63;
+    const int i0 = nc + TQ64 * d.y + 32 * (wv & 1), j0 = nc + TQ64 * d.z + 32 * (wv >> 1); // this wave's quadrant
+    if (i0 + 31 < j0 || i0 >= N || j0 >= N) return; // entirely above the diagonal (the upper right quadrant of a diagonal tile) or outside
+    const int ar = l & 15, ak = l >> 4;
+    double old[2][2][4];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = min(i0 + 16 * mi + ar, N - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[nj][mi][r] = F[row + (long long)N * min(j0 + 16 * nj + ak + 4 * r, N - 1)];
+        }
+    f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i (formed transposed, see k_big_schur)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+    const double* pa0 = F + min(i0 + ar, N - 1);
+    const double* pa1 = F + min(i0 + 16 + ar, N - 1);
+    const double* pb0 = F + min(j0 + ar, N - 1);
+    const double* pb1 = F + min(j0 + 16 + ar, N - 1);
+    constexpr int CW = 16, CS = CW / 4;
+    const int nch = (nc + CW - 1) / CW;
+    double a0[CS], a1[CS], b0[CS], b1[CS], na0[CS], na1[CS], nb0[CS], nb1[CS];
+    auto fetch = [&](int ch, double* x0, double* x1, double* y0, double* y1) {
+#pragma unroll
+        for (int ks = 0; ks < CS; ++ks) {
+            const long long off = (long long)N * min(CW * ch + 4 * ks + ak, nc - 1);
+            x0[ks] = pa0[off];
+            x1[ks] = pa1[off];
+            y0[ks] = pb0[off];
+            y1[ks] = pb1[off];
+        }
+    };
+    auto mult = [&](int ch, const double* x0, const double* x1, const double* y0, const double* y1) {
+#pragma unroll
+        for (int ks = 0; ks < CS; ++ks) {
+            const bool in = CW * ch + 4 * ks + ak < nc;
+            const double m0 = in ? y0[ks] : 0.0, m1 = in ? y1[ks] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x0[ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x1[ks], acc[1][1], 0, 0, 0);
+        }
+    };
+    // ping-pong register sets, unconditional fetches behind scheduling fences: see k_big_schur
+    fetch(0, a0, a1, b0, b1);
+    for (int ch = 0; ch < nch; ch += 2) {
+        fetch(ch + 1, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(ch, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(ch + 2, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < nch) mult(ch + 1, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = i0 + 16 * mi + ar;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = j0 + 16 * nj + ak + 4 * r;
+                if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[nj][mi][r] - acc[nj][mi][r];
+            }
+        }
+}
+
 // ---- triangular solves ------------------------------------------------------------------------------------
 __global__ void k_permute_rhs(int nn, const int* __restrict__ newOf, const double* __restrict__ b, double* __restrict__ bp)
 {
@@ -2202,6 +2286,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     // A front whose nc own columns (plus the index maps of its children) fit into LDS takes the fused single-workgroup path;
     // the others go through the level-batched multi-workgroup kernels.
     size_t fusedLds = 64 * 1024;
+    schur64Min_ = 512; // levels with at least this many 32 x 32 Schur tiles take the 64 x 64 kernel (k_big_schur64); IPCGPU_MF_SCHUR64_MIN=0 always, huge never
+    if (const char* e = std::getenv("IPCGPU_MF_SCHUR64_MIN")) schur64Min_ = std::atoll(e);
     if (const char* e = std::getenv("IPCGPU_MF_FUSED_KB")) fusedLds = (size_t)std::max(8, std::min(150, std::atoi(e))) * 1024;
     auto ldsOf = [&](int s) {
         const size_t kids = (size_t)(sym.childPtr[s + 1] - sym.childPtr[s]);
@@ -2493,8 +2579,17 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             R.cnt = ((int)desc.size() - R.off) / 2; // workgroups: two records each
         }
         P.schur.off = (int)desc.size();
+        {
+            long long tiles32 = 0;
+            for (int s : big) {
+                const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
+                tiles32 += nt * (nt + 1) / 2;
+            }
+            P.schur64 = tiles32 >= schur64Min_;
+        }
+        const int TQl = P.schur64 ? TQ64 : TQ;
         for (int s : big) {
-            const int nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
+            const int nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
             const long long foff = sym.frontOff[s];
             const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
             for (int ti = 0; ti < nt; ++ti)
@@ -2838,7 +2933,10 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
         }
         for (const Range& R : P.step)
             if (R.cnt) hipLaunchKernelGGL(k_big_step, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p);
-        if (P.schur.cnt) hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, tv, fronts_.p);
+        if (P.schur.cnt) {
+            if (P.schur64) hipLaunchKernelGGL(k_big_schur64, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
+            else hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, tv, fronts_.p);
+        }
         if (world_ > 1 && xchg_[l].pack.cnt) {
             // the update matrices of the subtree roots of this level: packed by their owners, summed, unpacked everywhere
             // (the pivot flag of this rank rides along in one extra double: a bad pivot inside a subtree reaches every rank
