@@ -440,3 +440,38 @@ def test_contact_assembly_is_bit_reproducible(gpu_lib):
     c.close()
     assert report["barrier gradient"] == 0.0 and report["barrier Hessian"] == 0.0 and report["elastic Hessian"] == 0.0, report
     assert report["elastic gradient"] == 0.0, report
+
+
+def test_codimensional_points_and_segments_bookkeeping_sets_and_intersection(orc, gpu_lib):
+    """ipcgpu_set_surface_codim (Mesh.cpp:490-515, 912-920): SVI / SFEdges equal to the oracle's with a segment and isolated points in the
+    mesh; the constraint sets they take part in; k_points_in_tets (SelfCollisionHandler.cpp:3301-3338) beside the oracle's loop."""
+    from test_oracle_contact import codim_point_mesh
+    Vall, F, SF, CE, n = codim_point_mesh()
+    m = orc.Mesh(Vall, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF, CE)
+    c = gpu_lib.Context(0)
+    c.set_mesh(Vall, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_surface(SF, CE)
+    svi_o, sfe_o = orc.mesh_surface(m)
+    svi_g, sfe_g = c.get_surface()
+    assert np.array_equal(svi_o, svi_g) and np.array_equal(np.asarray(sfe_o).reshape(-1, 2), sfe_g)
+    V2 = Vall.copy()
+    for pos, want in (([0.31, 0.47, 0.52], True), ([0.5, 1.3, 0.5], False), ([0.5, 0.999, 0.5], True), ([0.25, 0.25, 1e-9], True), ([0.5, 0.5, -1e-9], False)):
+        V2[n] = pos
+        m.set_V(V2)
+        c.set_positions(V2)
+        assert orc.is_intersected(m) == want and c.is_intersected() == want, pos
+    # a point hovering over the top face and the segment lowered next to an edge of the box: the same constraint tuples
+    V2[n] = [0.4, 1.0 + 2e-3, 0.6]
+    V2[n + 3] = [-0.2, 1.0 + 1e-3, 0.3]
+    V2[n + 4] = [1.2, 1.0 + 1e-3, 0.35]
+    m.set_V(V2)
+    c.set_positions(V2)
+    dHat = 1e-4
+    o = orc.Contacts().build(m, dHat)
+    g = c.contact_build(dHat)
+    assert len(o["active"]) > 0
+    for k in ("active", "para", "para_eiej", "cs_ptee"):
+        assert np.array_equal(g[k], o[k]), k
+    assert any(int(t[0]) == -n - 1 for t in np.asarray(o["active"]).reshape(-1, 4))  # the point is the vertex of a PT / PE / PP tuple
+    c.close()

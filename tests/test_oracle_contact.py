@@ -545,3 +545,32 @@ def test_block_sliding_on_rough_ground_decelerates_by_mu_g(orc):
     vx = np.diff(xs) / 0.005
     acc = np.polyfit(np.arange(len(vx))[12:] * 0.005, vx[12:], 1)[0]  # after the block has settled on the plane
     assert vx[-1] < vx[12] and abs(acc + mu * 9.80665) < 0.25 * mu * 9.80665
+
+
+def codim_point_mesh():
+    """a box of tetrahedra plus three nodes that belong to nothing (`.pt` points) and one segment (`.seg`)"""
+    from ipc_amd import scene
+    V, F = scene.make_box(2, 2, 2, size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0))
+    extra = np.array([[0.31, 0.47, 0.52], [1.7, 0.5, 0.5], [0.5, -0.4, 0.5], [2.0, 2.0, 2.0], [2.5, 2.0, 2.0]])
+    Vall = np.vstack([V, extra])
+    n = V.shape[0]
+    return Vall, F, scene.surface_tris(F), np.array([[n + 3, n + 4]], dtype=np.int32), n
+
+
+def test_codimensional_points_and_segments_in_the_surface_bookkeeping(orc):
+    """Mesh.cpp:490-515, 912-920: the segment is an SFEdge behind the triangles' edges, its ends and the isolated nodes are surface vertices;
+    SelfCollisionHandler.cpp:3301-3338: a point inside a tetrahedron is an intersection, one outside is not."""
+    Vall, F, SF, CE, n = codim_point_mesh()
+    m = orc.Mesh(Vall, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF, CE)
+    svi, sfe = orc.mesh_surface(m)
+    assert set(range(n, n + 5)) <= set(np.asarray(svi).tolist())
+    assert np.asarray(sfe).reshape(-1, 2)[-1].tolist() == [n + 3, n + 4]
+    assert orc.is_intersected(m)  # the first point sits inside the box
+    V2 = Vall.copy()
+    V2[n] = [0.5, 1.3, 0.5]
+    m.set_V(V2)
+    assert not orc.is_intersected(m)
+    V2[n + 2] = [0.5, 0.999, 0.5]  # just under the top face
+    m.set_V(V2)
+    assert orc.is_intersected(m)
