@@ -301,5 +301,7 @@ def test_sphere_on_mat_against_the_reference(gpu_lib):
     dev = [float(np.abs(pos[s] - S["positions"][s]).max() / np.abs(S["positions"][s]).max()) for s in range(steps)]
     # step 1 starts from exact rest (makePD2d decided by round-off: the Newton tolerance holds it); that difference decays over the next
     # steps, and the contact steps 29-36 sit at 1e-8
-    assert dev[0] <= 1e-5 and max(dev[1:8]) <= 1e-6 and max(dev[8:]) <= 5e-7, dev
+    # (with the 64 x 64 Schur tiles of round 3 -- another summation order in the factorisation -- the last three steps moved from 7e-8 to 9e-7;
+    # the counts did not move)
+    assert dev[0] <= 1e-5 and max(dev[1:8]) <= 1e-6 and max(dev[8:]) <= 3e-6, dev
     c.close()
