@@ -223,7 +223,8 @@ def main():
             "split_ms_per_iter": split,
             "split_note": "factor_ms holds the numeric factorisation AND both triangular sweeps (the forward sweep of a level runs on its own stream beside the "
                           "factorisation of the levels above, MfNumeric::factorizeSolve); backsolve_ms is what follows them in the same bucket: the batched "
-                          "read-back of |p|_inf, the inversion step filter and E.  solver.factor_ms / solver.solve_ms below time the two separately "
+                          "read-back of |p|_inf, the inversion step filter and E -- and the first trial of the line search (step, inversion flag, E at the trial "
+                          "point), taken on the device behind the solve: ccd_linesearch_ms is what a rejected trial costs.  solver.factor_ms / solver.solve_ms below time the two separately "
                           "(ipcgpu_bench_factor_solve, HIP events)",
             "roofline": {
                 "kernel": "k_assemble_patch<true> (fused NH gradient + PSD-projected Hessian + mass/DBC diagonal -> symmetric-upper CSR, atomic-free)",

@@ -82,7 +82,9 @@ public:
     void analyze_pattern(const HipMesh* meshForCoords);
     bool factorize();
     void solve(const double* rhs_dev, double* x_dev);
-    bool factorizeSolve(const double* rhs_dev, double* x_dev); // factorize + solve, forward sweep overlapped with the factorisation
+    bool factorizeSolve(const double* rhs_dev, double* x_dev, bool wait = true); // factorize + solve, forward sweep overlapped with the factorisation
+    bool lastPivotsOk() const; // after factorizeSolve(..., wait = false) and a synchronisation of the stream
+    bool lastSyncOk_ = true;
     void multiply(const double* x_dev, double* y_dev);
     void precondition_diag(const double* in_dev, double* out_dev);
     int getNumRows() const { return numRows; }
@@ -225,6 +227,10 @@ public:
     bool fastPath() const;
     bool cachedDistValid = false, cachedE0Valid = false;
     double cachedDist = 0, cachedE0 = 0, cachedFilter = 0;
+    // ... and, second step (IPCGPU_NO_TRIAL_AHEAD restores the above): the first trial of the line search is taken on the device behind the solve
+    // as well -- its step size, inversion flag and energy arrive with the same synchronisation, ONE per Newton iteration
+    bool cachedTrialValid = false, cachedTrialInverted = false;
+    double cachedTrialE = 0, cachedAlpha = 1.0;
     hipEvent_t evAsm0 = nullptr, evAsm1 = nullptr;
     bool evAsmPending = false;
     void resolveEventTimers();

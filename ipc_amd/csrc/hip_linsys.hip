@@ -290,14 +290,16 @@ bool HipLinSysSolver::factorize()
 }
 
 // factorize() followed by solve(), with the forward sweep running beside the factorisation (MfNumeric::factorizeSolve)
-bool HipLinSysSolver::factorizeSolve(const double* rhs_dev, double* x_dev)
+bool HipLinSysSolver::factorizeSolve(const double* rhs_dev, double* x_dev, bool wait)
 {
     if (!analyzed_) throw StateError("factorize before analyze_pattern");
-    if (solverType == 0) return num_.factorizeSolve(d_a.p, rhs_dev, x_dev);
+    lastSyncOk_ = true;
+    if (solverType == 0) return lastSyncOk_ = num_.factorizeSolve(d_a.p, rhs_dev, x_dev, wait);
     const bool ok = factorize();
     if (ok) solve(rhs_dev, x_dev);
-    return ok;
+    return lastSyncOk_ = ok;
 }
+bool HipLinSysSolver::lastPivotsOk() const { return lastSyncOk_ && (solverType != 0 || num_.lastPivotsOk()); }
 
 void HipLinSysSolver::solve(const double* rhs_dev, double* x_dev)
 {

@@ -961,7 +961,47 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
     bool ok;
     static const bool twoCalls = std::getenv("IPCGPU_MF_NO_FWD_OVERLAP") != nullptr; // A/B: factorize(), then solve()
     launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
-    {
+    static const bool noSpec = std::getenv("IPCGPU_NO_TRIAL_AHEAD") != nullptr; // A/B: synchronise after the solve, again after the trial step
+    cachedTrialValid = false;
+    if (fastPath() && !twoCalls && !noSpec) {
+        // ONE synchronisation per Newton iteration.  Behind factorisation + sweeps, on the same stream and without the host in between: |p|_inf
+        // (convergence test of the next pass, Optimizer.cpp:1869-1879), the inversion step filter (:1887), E at the iterate (:2681), then the
+        // first trial of the line search -- step size decided on the device from the filter's result, the step, its inversion flag
+        // (:2710-2717), E at the trial point (:2757).  The pivot flag of the factorisation arrives with them.  The host then only decides:
+        // bad pivot -> back to the iterate and the diagonal fallback; trial inverted or uphill -> back to the iterate and the general loop.
+        Tic t(timers[3], stream); // (its synchronisation is the one)
+        const size_t bytes = 3 * (size_t)mesh.nV * sizeof(double);
+        if (lin.factorizeSolve(d_minusG.p, d_searchDir.p, /*wait=*/false)) {
+            launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+            launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+            launch_fill(d_scalar.p + 2, 1, 1e20, stream);
+            if (mesh.energyType != 1) launch_inversion_step(view(), d_searchDir.p, 0.2, d_scalar.p + 2, stream);
+            launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
+            HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, bytes, hipMemcpyDeviceToDevice, stream));
+            launch_trial_step(3 * mesh.nV, d_x0.p, d_searchDir.p, d_scalar.p + 2, mesh.energyType != 1, d_scalar.p + 6, mesh.d_x.p, stream);
+            if (mesh.energyType != 1) {
+                d_flag.zero(stream);
+                launch_check_inversion(view(), d_flag.p, stream);
+                launch_publish(d_flag.p, h_flag.dev, 1, stream);
+            }
+            launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p + 1, stream);
+            launch_publish(d_scalar.p, h_scalar.dev, 14, stream); // 7 doubles
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (lin.lastPivotsOk()) {
+                cachedE0 = h_scalar.p[0];
+                cachedTrialE = h_scalar.p[1];
+                cachedFilter = h_scalar.p[2];
+                cachedDist = h_scalar.p[3];
+                cachedAlpha = h_scalar.p[6];
+                cachedTrialInverted = mesh.energyType != 1 && h_flag.p[0] != 0;
+                cachedDistValid = cachedE0Valid = cachedTrialValid = true;
+                return;
+            }
+            HIP_CHECK(hipMemcpyAsync(mesh.d_x.p, d_x0.p, bytes, hipMemcpyDeviceToDevice, stream)); // the step was taken along garbage
+        }
+        ok = false;
+    }
+    else {
         // the right-hand side is known before the factorisation starts: the forward sweep of each level runs beside the pivot chain of
         // the levels above (MfNumeric::factorizeSolve); this bucket then holds factorisation + both sweeps
         Tic t(timers[3], stream);
@@ -1007,7 +1047,17 @@ void HipOptimizer::resolveEventTimers()
 void HipOptimizer::lineSearch(double& stepSize)
 {
     const size_t bytes = 3 * (size_t)mesh.nV * sizeof(double);
-    if (cachedE0Valid && fastPath()) {
+    if (cachedTrialValid && fastPath()) {
+        // the first trial came back with the solve (computeSearchDir): d_x0 holds the iterate, x the trial point
+        cachedTrialValid = cachedE0Valid = false;
+        lastEnergyVal = cachedE0; // Optimizer.cpp:2681
+        if (!cachedTrialInverted && !(cachedTrialE > lastEnergyVal)) {
+            lastEnergyVal = cachedTrialE;
+            return;
+        }
+        HIP_CHECK(hipMemcpyAsync(mesh.d_x.p, d_x0.p, bytes, hipMemcpyDeviceToDevice, stream)); // back to the iterate: the general loop redoes the step
+    }
+    else if (cachedE0Valid && fastPath()) {
         // E at the iterate came back with the solve; the trial step, its inversion flag and E at the trial point are enqueued together
         // and read with one synchronisation.  Anything but "not inverted and E decreased" falls through to the general loop below.
         cachedE0Valid = false;
@@ -1300,7 +1350,8 @@ bool HipOptimizer::newtonIter()
     double alpha = 1.0;
     {
         Tic t(timers[13], stream);
-        if (cachedE0Valid) { // Optimizer.cpp:1887 with the value the solve's batch brought back
+        if (cachedTrialValid) alpha = cachedAlpha; // decided on the device by the same rule, the trial step is already taken with it
+        else if (cachedE0Valid) { // Optimizer.cpp:1887 with the value the solve's batch brought back
             if (mesh.energyType != 1 && cachedFilter > 0.0 && cachedFilter < alpha) alpha = cachedFilter;
         }
         else

@@ -36,7 +36,11 @@ public:
     void solve(const double* rhs_dev, double* x_dev);
     // factorize(a) and solve(rhs) in one go, the forward sweep overlapped with the factorisation (single rank); returns false when a
     // non-positive pivot was met (x is then meaningless)
-    bool factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev);
+    // wait = false: everything is enqueued and the call returns true without synchronising (the pivot flag is on its way to pinned memory:
+    // lastPivotsOk() after the caller's own synchronisation of the stream).  Returns false when the call had to take the synchronous
+    // two-call sequence (sharded / graph runs) and the factorisation failed there.
+    bool factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev, bool wait = true);
+    bool lastPivotsOk() const { return hflag_.p[0] == 0; }
     bool ready() const { return ns_ > 0; }
     size_t front_bytes() const { return fronts_.n * sizeof(double); }
 

@@ -2864,7 +2864,7 @@ bool MfNumeric::factorize(const double* a_dev)
     return hflag_.p[0] == 0;
 }
 
-bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev)
+bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev, bool wait)
 {
     if (!sym_) throw StateError("factorize before analyze_pattern");
     if (world_ > 1 || !fwd_ || useGraph_) { // sharded / captured runs keep the two-call sequence
@@ -2885,6 +2885,7 @@ bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, doubl
     // the caller falls back to the diagonal preconditioner as after factorize() == false)
     HIP_CHECK(hipStreamWaitEvent(stream_, evFwdDone_, 0));
     enqueueBackward(x_dev);
+    if (!wait) return true;
     HIP_CHECK(hipStreamSynchronize(stream_));
     return hflag_.p[0] == 0;
 }

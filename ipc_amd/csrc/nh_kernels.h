@@ -45,6 +45,8 @@ void launch_inversion_step(const ElemView& v, const double* p, double slackness,
 
 // nodal vector helpers
 void launch_step_forward(int n3, const double* x0, const double* p, double alpha, double* x, hipStream_t s);
+// alpha = 1, or the inversion filter's minimum when it applies, decided on the device; x = x0 + alpha p
+void launch_trial_step(int n3, const double* x0, const double* p, const double* filterMin, bool useFilter, double* alphaOut, double* x, hipStream_t s);
 void launch_max_abs(int n, const double* v, double* out /*preset 0*/, hipStream_t s);
 void launch_fill(double* p, size_t n, double v, hipStream_t s);
 void launch_negate(int n, const double* in, double* out, hipStream_t s);

@@ -304,6 +304,22 @@ __global__ void k_step_forward(int n, const double* __restrict__ x0, const doubl
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = x0[i] + alpha * p[i];
 }
+// The step size of the first trial of a contact-free line search, decided where the inversion step filter left its result (Energy.cpp:565-581:
+// the filter applies when 0 < t < step; Optimizer.cpp:1887), and the trial step taken with it -- without the host in between
+__global__ void k_trial_alpha(const double* __restrict__ filterMin, int useFilter, double* __restrict__ alphaOut)
+{
+    double alpha = 1.0;
+    const double t = filterMin[0];
+    if (useFilter && t > 0.0 && t < alpha) alpha = t;
+    alphaOut[0] = alpha;
+}
+__global__ void k_step_forward_dev(int n, const double* __restrict__ x0, const double* __restrict__ p, const double* __restrict__ alphaPtr,
+    double* __restrict__ x)
+{
+    const double alpha = alphaPtr[0];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = x0[i] + alpha * p[i];
+}
 // grid-stride, one atomic per workgroup (the launch caps the grid at 256 workgroups): per wave of a thread-per-entry launch they were 2 100
 // same-address atomics for 1.35e5 entries, most of the kernel's 23 us
 __global__ __launch_bounds__(BLOCK) void k_max_abs(int n, const double* __restrict__ v, unsigned long long* __restrict__ out)
@@ -622,6 +638,11 @@ void launch_inversion_step(const ElemView& v, const double* p, double slackness,
 void launch_step_forward(int n3, const double* x0, const double* p, double alpha, double* x, hipStream_t s)
 {
     if (n3) hipLaunchKernelGGL(k_step_forward, dim3(nblk(n3)), dim3(BLOCK), 0, s, n3, x0, p, alpha, x);
+}
+void launch_trial_step(int n3, const double* x0, const double* p, const double* filterMin, bool useFilter, double* alphaOut, double* x, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trial_alpha, dim3(1), dim3(1), 0, s, filterMin, useFilter ? 1 : 0, alphaOut);
+    if (n3) hipLaunchKernelGGL(k_step_forward_dev, dim3(nblk(n3)), dim3(BLOCK), 0, s, n3, x0, p, (const double*)alphaOut, x);
 }
 void launch_max_abs(int n, const double* v, double* out, hipStream_t s)
 {
