@@ -300,7 +300,8 @@ int ipcgpu_opt_set_velocity(ipcgpu_ctx*, const double* vel_3nV);
  * time step (:582-590).  Call after ipcgpu_opt_init, before ipcgpu_opt_precompute; the acceleration starts at zero (:177). */
 int ipcgpu_opt_set_time_integration(ipcgpu_ctx*, int type, double beta, double gamma);
 /* Config `warmStart n` -> Optimizer::initX(n) (Optimizer.cpp:925-1215): first iterate of every time step.  0 = the last
-   configuration (default), 1 explicit Euler, 2 xHat, 3 symplectic Euler, 4 uniformly accelerated motion; the step is cut by the
+   configuration (default), 1 explicit Euler, 2 xHat, 3 symplectic Euler, 4 uniformly accelerated motion, 5 the Jacobi guess -g_i / H_ii
+   (gradient with projected, matrix with unprojected Dirichlet rows, :1082-1110); the step is cut by the
    inversion filter, the half-space bounds and a full CCD pass, then halved while the mesh is inverted or intersecting.
    *last_step (nullable) receives the fraction of the predicted displacement the last begin_timestep could take. */
 int ipcgpu_opt_set_warm_start(ipcgpu_ctx*, int option);

@@ -1175,7 +1175,7 @@ int ipcgpu_opt_set_warm_start(ipcgpu_ctx* c, int option)
 {
     return guarded([&] {
         HipOptimizer& o = O(c);
-        needArg(option >= 0 && option <= 4, "warmStart option must be 0..4 (5, the Jacobi guess, is not restated)");
+        needArg(option >= 0 && option <= 5, "warmStart option must be 0..5");
         o.warmStart = option;
         return IPCGPU_OK;
     });

@@ -1194,13 +1194,24 @@ void HipOptimizer::beginTimestep()
         completedStep = stepSize; // AnimScripter::getCompletedStepSize
         d_searchDir.zero(stream); // initX(0), Optimizer.cpp:930-934
     }
-    if (warmStart >= 1 && warmStart <= 4) {
+    if (warmStart >= 1 && warmStart <= 5) {
         // initX options 1-4 (Optimizer.cpp:936-1080): explicit Euler / xHat / symplectic Euler / uniformly accelerated motion as the
         // first iterate, then the feasibility filters of a Newton step with "always full CCD" (:1117-1215)
+        if (warmStart == 5) {
+            // option 5 (:1082-1110), "Jacobi": -g_i / H_ii with the gradient of the projected and the matrix of the UNprojected Dirichlet rows,
+            // zero on every Dirichlet node; sets, kappa and dHat are whatever the previous time step left
+            computeGradient(true);
+            computePrecondMtr(false, false);
+            launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
+            lin.precondition_diag(d_minusG.p, d_searchDir.p);
+            launch_clear_projected(mesh.nV, mesh.d_dbc.p, 1, d_searchDir.p, stream); // isDBCVertex: ZERO and NONZERO alike
+        }
+        else {
         static const double CG[2][5] = { { 0, 0, 1, 1, 1 }, { 0, 0, 0.5, 0.5, 0.5 } }, CE[2][5] = { { 0, 0, 0, 1, 0.5 }, { 0, 0, 0, 2, 1 } };
         const double cg = CG[timeIntegration][warmStart], ce = CE[timeIntegration][warmStart];
         const double g3[3] = { cg * (dtSq * gravity[0]), cg * (dtSq * gravity[1]), cg * (dtSq * gravity[2]) };
         launch_warm_dir(mesh.nV, mesh.d_dbc.p, d_vel.p, d_dxElastic.p, dt, g3, ce, d_searchDir.p, stream);
+        }
         double stepSize = filterStepSize(d_searchDir.p, 1.0);
         if (ipOn()) {
             for (auto& h : planes) stepSize = h->stepBound(contact->nSVI, contact->d_SVI.p, mesh.d_x.p, mesh.d_dbc.p, d_searchDir.p, 0.9, stepSize);

@@ -122,8 +122,8 @@ class SceneConfig:
                 cfg.script = a[0]
                 if len(a) > 1 and int(a[1]) > 0:  # `script name n p1 .. pn` (Config.cpp:166-175): parameters of the script
                     cfg.script_params = [float(x) for x in a[2:2 + int(a[1])]]
-            elif k == "warmStart":  # initX option (Optimizer.cpp:925-1080); 5 (Jacobi guess) is not restated
-                if int(a[0]) not in (0, 1, 2, 3, 4):
+            elif k == "warmStart":  # initX option (Optimizer.cpp:925-1110)
+                if int(a[0]) not in (0, 1, 2, 3, 4, 5):
                     raise UnsupportedKeyword(f"warmStart {a[0]}")
                 cfg.warm_start = int(a[0])
             elif k == "constraintSolver":

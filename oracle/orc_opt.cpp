@@ -857,9 +857,18 @@ void orc_opt_begin_timestep(orc_opt* o)
     }
     // fullyImplicit_IP head (1518-1613): initX(warmStart); dHat; constraint sets; kappa; initial energy
     std::fill(o->searchDir.begin(), o->searchDir.end(), 0.0);
-    if (o->warmStart >= 1 && o->warmStart <= 4) {
+    if (o->warmStart >= 1 && o->warmStart <= 5) {
         // initX options 1-4 (Optimizer.cpp:936-1080): explicit Euler / xHat / symplectic Euler / uniformly accelerated motion as the
         // first iterate, then the same feasibility filters as a Newton step with "always full CCD" (:1117-1215)
+        if (o->warmStart == 5) {
+            // option 5 (:1082-1110), "Jacobi": -g_i / H_ii with the gradient of the projected and the matrix of the unprojected Dirichlet
+            // rows, zero on every Dirichlet node; sets, kappa and dHat are whatever the previous time step left
+            computeGradient(o, true);
+            computePrecondMtr(o, false);
+            for (int v = 0; v < m.nV; ++v)
+                for (int c = 0; c < 3; ++c) o->searchDir[3 * v + c] = m.isDBC(v) ? 0.0 : -o->gradient[3 * v + c] / o->a[m.ia[3 * v + c]];
+        }
+        else {
         static const double CG[2][5] = { { 0, 0, 1, 1, 1 }, { 0, 0, 0.5, 0.5, 0.5 } }, CE[2][5] = { { 0, 0, 0, 1, 0.5 }, { 0, 0, 0, 2, 1 } };
         const double cg = CG[o->tit][o->warmStart], ce = CE[o->tit][o->warmStart];
         for (int v = 0; v < m.nV; ++v)
@@ -867,6 +876,7 @@ void orc_opt_begin_timestep(orc_opt* o)
                 o->searchDir[3 * v + c] = m.isDBC(v) ? 0.0
                                                      : o->dt * o->velocity[3 * v + c] + cg * (o->dtSq * o->gravity[c])
                         + ce * (o->dxElastic.empty() ? 0.0 : o->dxElastic[3 * v + c]);
+        }
         double stepSize = filterStepSize(m, o->searchDir.data(), 1.0);
         if (o->ipOn()) {
             for (const auto& h : o->planes) stepSize = hsStepBound(m, h, o->searchDir.data(), 0.9, stepSize);
@@ -1217,7 +1227,7 @@ void orc_opt_get_contact(const orc_opt* o, int* counts6, int* active4, int* para
 }
 void orc_opt_set_warm_start(orc_opt* o, int option)
 {
-    if (option < 0 || option > 4) return;
+    if (option < 0 || option > 5) return;
     o->warmStart = option;
 }
 double orc_opt_warm_step(const orc_opt* o) { return o->warmStepSize; }

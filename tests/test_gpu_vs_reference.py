@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from test_oracle_vs_reference import (CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_codim, check_damped_bar, check_plates,
-                                      check_restart, check_scene, check_seg_bed, load_scene, rel, run_scene)
+                                      check_restart, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -247,6 +247,16 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol, gpu_
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     check_codim(S, pos, its, 10 * tol)
     c.close()
+
+
+@pytest.mark.parametrize("name", ["bar_twist_warm5", "two_cubes_warm5"])
+def test_warm_start_5_against_the_reference(name, gpu_lib):
+    """ipcgpu_opt_set_warm_start(5): the Jacobi guess on the HIP stepper, beside runs of the reference with `warmStart 5`"""
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    check_warm5(S, pos, its, name)
 
 
 @pytest.mark.parametrize("name", HANDLE_SCENES)

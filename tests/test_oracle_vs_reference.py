@@ -404,6 +404,26 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol):
     check_codim(S, pos, its, tol)
 
 
+def check_warm5(S, pos, its, name):
+    """`warmStart 5` (Optimizer::initX option 5, Optimizer.cpp:1082-1110): the Jacobi guess -g_i / H_ii as the first iterate of every step."""
+    ref = S["positions"]
+    if name == "bar_twist_warm5":
+        assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+        assert np.abs(pos - ref).max() <= 1e-6 * np.abs(ref).max()  # (starts exactly at rest: the Newton tolerance holds the first step)
+        return
+    free = 17  # the cubes in free fall, every step started from the Jacobi guess: identical to round-off
+    assert np.array_equal(its[:19], S["iters"][:19]), (its.tolist(), S["iters"].tolist())  # ... and through the first touch-down
+    assert np.abs(pos[:free] - ref[:free]).max() <= 1e-12 * np.abs(ref).max()
+    assert np.abs(pos[-1] - ref[len(pos) - 1]).max() <= 1e-2 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name", ["bar_twist_warm5", "two_cubes_warm5"])
+def test_warm_start_5_against_the_reference(name):
+    S, meshes = load_scene(name)
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    check_warm5(S, pos, its, name)
+
+
 # scripts that pick their handles from the bounding box of the mesh (AnimScripter::initAnimScript), each on the tutorial cube, run by the
 # reference: fixLowerHalf (AnimScripter.cpp:337-350), pushRightMost1 (:895-910, 1820-1826), utopiaComparison (:1283-1302, 1641-1646)
 HANDLE_SCENES = ["fix_lower_half", "push_right_most", "utopia"]

@@ -271,6 +271,9 @@ INLINE = {
     "inline:squash6_contact": _SQUASH6 % "-0.6 -0.6 -0.6  0 0 0  1.2 1.2 1.2",
 }
 SCENES += [
+    # `warmStart 5` (Optimizer::initX option 5, the Jacobi guess -g_i / H_ii): the twisting bar and the tutorial scene through its impacts
+    ("bar_twist_warm5", "otherExamples/barTwist_noCollisions.txt", "\nwarmStart 5\n", 4),
+    ("two_cubes_warm5", "tutorialExamples/2cubesFall.txt", "\nwarmStart 5\n", 24),
     ("fix_lower_half", "inline:fix_lower_half", "", 6),
     ("push_right_most", "inline:push_right_most", "", 6),
     ("utopia", "inline:utopia", "", 6),
