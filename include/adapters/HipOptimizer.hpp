@@ -377,6 +377,9 @@ protected:
                 ce[2 * (size_t)e + 1] = m.CE(e, 1);
             }
             chk(ipcgpu_set_surface_codim(ctx, nSFAll, SF.data(), (int)m.CE.rows(), ce.empty() ? nullptr : ce.data()));
+#ifdef USE_PREDICATES
+            chk(ipcgpu_set_exact_predicates(ctx, 1)); // this build of the reference tests plane sides with igl::predicates::orient3d
+#endif
         }
         // static Dirichlet types: held surfaces; the obstacle
         chk(ipcgpu_clear_dbc(ctx));

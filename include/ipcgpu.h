@@ -173,6 +173,11 @@ int ipcgpu_set_surface(ipcgpu_ctx*, int nSF, const int* SF_colmajor);
  * (:916-920) and is tested against every tetrahedron by the intersection check (SelfCollisionHandler.cpp:3301-3338).  Their masses:
  * ipcgpu_set_codim_nodes (segments: density * l^3 pi / 12 per end, Mesh.cpp:279-295; points: the mean nodal mass, :405-411). */
 int ipcgpu_set_surface_codim(ipcgpu_ctx*, int nSF, const int* SF_colmajor, int nCE, const int* CE_pairs);
+/* A build of the reference with USE_PREDICATES (CMakeLists.txt:137-140; not what the shipped CMake configures) decides the plane-side tests
+ * of IglUtils::segTriIntersect (IglUtils.hpp:222-233) and IglUtils::pointInsideTetrahedron (:280-294) with the exact orient3d of
+ * igl::predicates instead of floating-point products.  on != 0: the intersection checks do the same (orient3d_exact.h: Shewchuk's predicate
+ * restated -- floating-point filter, exact expansion arithmetic behind it).  Default off = the default build. */
+int ipcgpu_set_exact_predicates(ipcgpu_ctx*, int on);
 int ipcgpu_get_surface(ipcgpu_ctx*, int* counts3 /*nSVI,nSF,nSFEdges*/, int* SVI /*nullable*/, int* SFEdges_2n /*nullable*/);
 /* Kinematic mesh obstacles (MeshCO, src/CollisionObject/MeshCO.cpp:37-80; `meshCO` script keyword, Config.cpp:448-474): the
    obstacle rides along as a surface-only component of the mesh handed to ipcgpu_set_mesh -- extra nodes that belong to no

@@ -650,6 +650,13 @@ int ipcgpu_set_surface_codim(ipcgpu_ctx* c, int nSF, const int* SF, int nCE, con
         return IPCGPU_OK;
     });
 }
+int ipcgpu_set_exact_predicates(ipcgpu_ctx* c, int on)
+{
+    return guarded([&] {
+        CT(c).exactPredicates = on != 0;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_get_surface(ipcgpu_ctx* c, int* counts, int* SVI, int* SFE)
 {
     return guarded([&] {

@@ -51,6 +51,7 @@ public:
     // (`.pt` shapes): both join SVI, the segments SFEdges (Mesh.cpp:490-515, 912-927)
     void setSurface(const HipMesh& mesh, int nSF, const int* SF_colmajor, int nCE = 0, const int* CE_pairs = nullptr);
     std::vector<int> codimPoints;
+    bool exactPredicates = false; // the intersection checks as a USE_PREDICATES build of the reference makes them (IglUtils.hpp:222-233, 280-294)
     // kinematic obstacle nodes (the reference's MeshCO riding along as a surface-only component, MeshCO.cpp) and, for scenes with
     // `selfCollisionOff`, the filter that keeps only primitive pairs involving an obstacle
     void setObstacle(int nV, int n, const int* ids, bool obstacleOnly);

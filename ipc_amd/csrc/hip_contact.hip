@@ -2,6 +2,7 @@
 #include "hip_contact.h"
 #include "contact_device.h"
 #include "jacobi9_device.h"
+#include "orient3d_exact.h"
 #include "hip_ipc.h"
 #include <hipcub/hipcub.hpp>
 #include <algorithm>
@@ -1598,7 +1599,11 @@ __global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __r
     wave_count_add(nQueried, nCand);
 }
 
-// IglUtils::segTriIntersect without exact predicates (IglUtils.hpp:236-245, 258-264)
+// IglUtils::segTriIntersect (IglUtils.hpp:214-265).  exact == 0: the branch the default build compiles (:236-245); exact != 0: the branch of a
+// build with USE_PREDICATES (:222-233) -- the segment's ends strictly on opposite sides of the triangle's plane by the exact orientation
+// predicate (orient3d_exact.h: floating-point filter, expansion arithmetic behind it).  A template parameter, not an argument: the expansion
+// arithmetic would cost the default kernel three quarters of its occupancy (252 VGPRs and 2.7 KB of scratch per lane) without ever running
+template <bool exact>
 __device__ inline bool seg_tri_intersect(const double* ve0, const double* ve1, const double* vt0, const double* vt1, const double* vt2)
 {
     double c0[3], c1[3], c2[3], n[3], r0[3], r1[3], t0[3], t1[3];
@@ -1608,15 +1613,22 @@ __device__ inline bool seg_tri_intersect(const double* ve0, const double* ve1, c
     cross3(c0, c1, n);
     sub3(ve0, vt0, r0);
     sub3(ve1, vt0, r1);
-    if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
     const double det = dot3(n, c2);
-    if (det == 0.0) return false;
+    if constexpr (exact) {
+        const int o1 = o3::orient3d(vt0, vt1, vt2, ve0), o2 = o3::orient3d(vt0, vt1, vt2, ve1);
+        if (o1 == 0 || o2 == 0 || o1 == o2) return false;
+    }
+    else {
+        if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
+        if (det == 0.0) return false;
+    }
     cross3(r0, c1, t0);
     cross3(c0, r0, t1);
     const double u = dot3(t0, c2) / det, v = dot3(t1, c2) / det, t = dot3(n, r0) / det;
     return u >= 0.0 && v >= 0.0 && u + v <= 1.0 && t >= 0.0 && t <= 1.0;
 }
 // checkEdgeTriIntersectionIfAny (SelfCollisionHandler.cpp:3255-3300): one lane per surface triangle, edges from the grid
+template <bool exact>
 __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restrict__ SF, const int* __restrict__ SFE, const double* __restrict__ x,
     const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, int* __restrict__ flag)
 {
@@ -1658,7 +1670,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
                         if (fmin(p0[q], p1[q]) > hi[q] || fmax(p0[q], p1[q]) < lo[q]) sep = true;
                     }
                     if (sep) continue;
-                    if (seg_tri_intersect(p0, p1, a, b, c)) {
+                    if (seg_tri_intersect<exact>(p0, p1, a, b, c)) {
                         atomicOr(flag, 1);
                         return;
                     }
@@ -1676,6 +1688,7 @@ __device__ __forceinline__ bool point_behind_tri(const double* t0, const double*
     cross3(e1, e2, n);
     return dot3(n, r) <= 0.0;
 }
+template <bool exact>
 __global__ __launch_bounds__(BLOCK) void k_points_in_tets(int nPts, const int* __restrict__ pts, int nT, const int4* __restrict__ tet,
     const double* __restrict__ x, int* __restrict__ flag)
 {
@@ -1689,6 +1702,12 @@ __global__ __launch_bounds__(BLOCK) void k_points_in_tets(int nPts, const int* _
         p[c] = x[3 * (size_t)v + c];
         for (int k = 0; k < 4; ++k) q[k][c] = x[3 * (size_t)id[k] + c];
         if (!(fmin(fmin(q[0][c], q[1][c]), fmin(q[2][c], q[3][c])) <= p[c] && fmax(fmax(q[0][c], q[1][c]), fmax(q[2][c], q[3][c])) >= p[c])) return;
+    }
+    if constexpr (exact) { // IglUtils.hpp:280-294: orient3d(...) != NEGATIVE four times
+        if (o3::orient3d(q[0], q[2], q[1], p) >= 0 && o3::orient3d(q[0], q[3], q[2], p) >= 0 && o3::orient3d(q[0], q[1], q[3], p) >= 0
+            && o3::orient3d(q[1], q[2], q[3], p) >= 0)
+            atomicOr(flag, 1);
+        return;
     }
     if (point_behind_tri(q[0], q[2], q[1], p) && point_behind_tri(q[0], q[3], q[2], p) && point_behind_tri(q[0], q[1], q[3], p)
         && point_behind_tri(q[1], q[2], q[3], p))
@@ -2818,11 +2837,21 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
     g.h = gh.h;
     counters_.alloc(4);
     counters_.zero(stream);
-    hipLaunchKernelGGL(k_intersect, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p, cellItemsE_.p,
-        counters_.p);
-    if (!codimPoints.empty() && mesh.nT)
-        hipLaunchKernelGGL(k_points_in_tets, dim3(nblk((long long)codimPoints.size() * mesh.nT)), dim3(BLOCK), 0, stream, (int)codimPoints.size(),
-            d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev, counters_.p);
+    if (exactPredicates)
+        hipLaunchKernelGGL(k_intersect<true>, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p,
+            cellItemsE_.p, counters_.p);
+    else
+        hipLaunchKernelGGL(k_intersect<false>, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p,
+            cellItemsE_.p, counters_.p);
+    if (!codimPoints.empty() && mesh.nT) {
+        const dim3 grid(nblk((long long)codimPoints.size() * mesh.nT));
+        if (exactPredicates)
+            hipLaunchKernelGGL(k_points_in_tets<true>, grid, dim3(BLOCK), 0, stream, (int)codimPoints.size(), d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev,
+                counters_.p);
+        else
+            hipLaunchKernelGGL(k_points_in_tets<false>, grid, dim3(BLOCK), 0, stream, (int)codimPoints.size(), d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev,
+                counters_.p);
+    }
     int f[2];
     counters_.download(f, 2, stream);
     return f[0] != 0;

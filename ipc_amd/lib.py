@@ -382,6 +382,10 @@ class Context:
         CE = np.ascontiguousarray(codim_edges, dtype=np.int32).reshape(-1, 2)
         self._chk(self._L.ipcgpu_set_surface_codim(self.h, C.c_int(SF.shape[0]), _ip(SF), C.c_int(CE.shape[0]), _ip(CE)))
 
+    def set_exact_predicates(self, on=True):
+        """intersection checks as a USE_PREDICATES build of the reference makes them (exact orient3d)"""
+        self._chk(self._L.ipcgpu_set_exact_predicates(self.h, C.c_int(int(on))))
+
     def set_codim_nodes(self, ids, mass):
         """Surface-only nodes that belong to the mesh (triangle meshes under `shapes`) with their lumped area masses; like a MeshCO they
         stay out of the bounding box behind dHat and of the mean nodal mass behind kappa (matSpaceBBoxSize2(dim) / avgNodeMass(dim))."""

@@ -122,6 +122,9 @@ class Mesh:
             lib().orc_mesh_destroy(self.h)
             self.h = None
 
+    def set_exact_predicates(self, on=True):
+        lib().orc_mesh_set_exact_predicates(self.h, C.c_int(int(on)))
+
     def set_surface(self, SF, codim_edges=None):
         """codim_edges: n x 2 node pairs of `.seg` shapes (Mesh::CE); nodes without any neighbour count as `.pt` points"""
         SF = np.asfortranarray(np.asarray(SF, dtype=np.int32).reshape(-1, 3))

@@ -41,6 +41,8 @@ orc_mesh* orc_mesh_create(int nV, int nT, const double* Vrest_colmajor, const in
 void orc_mesh_destroy(orc_mesh*);
 void orc_mesh_set_surface(orc_mesh*, int nSF, const int* SF_colmajor); // adds SF edges to vNeighbor, builds SVI/SFEdges
 void orc_mesh_set_surface_codim(orc_mesh*, int nSF, const int* SF_colmajor, int nCE, const int* CE_pairs); // + `.seg` segments; isolated nodes = `.pt` points
+void orc_mesh_set_exact_predicates(orc_mesh*, int on); // intersection checks as a USE_PREDICATES build of the reference makes them
+int orc_seg_tri_intersect_exact(const double* X15);
 void orc_mesh_set_dbc(orc_mesh*, int n, const int* vids, int type); // type: 1 ZERO, 2 NONZERO (Mesh.hpp:41-45)
 void orc_mesh_set_obstacle(orc_mesh*, int n, const int* vids, int obstacleOnly);
 void orc_mesh_set_codim_nodes(orc_mesh*, int n, const int* vids, const double* nodeMass); /* surface-only nodes of Mesh<3> (Mesh.cpp:310-345) */

@@ -1,4 +1,5 @@
 // ORACLE -- TEST INFRASTRUCTURE ONLY (see orc_api.h, orc_contact.h).
+#include "../ipc_amd/csrc/orient3d_exact.h"
 #include "orc_contact.h"
 #include "orc_api.h"
 #include <cassert>
@@ -1339,8 +1340,11 @@ double fullCcdReference(const Mesh& m, const double* p, double slackness, double
     return best;
 }
 
-// IglUtils::segTriIntersect, the branch without exact predicates (IglUtils.hpp:236-245, 258-264)
-static bool segTriIntersect(const double* ve0, const double* ve1, const double* vt0, const double* vt1, const double* vt2)
+// IglUtils::segTriIntersect (IglUtils.hpp:214-265).  exact = false: the branch of the default build (:236-245); exact = true: the branch of a
+// build with USE_PREDICATES (:222-233) -- the two ends of the segment strictly on opposite sides of the triangle's plane, decided by the exact
+// orientation predicate (ipc_amd/csrc/orient3d_exact.h, shared with the product: a restatement of a published algorithm, pinned on rational
+// arithmetic in tests/test_orient3d.py)
+static bool segTriIntersect(const double* ve0, const double* ve1, const double* vt0, const double* vt1, const double* vt2, bool exact = false)
 {
     double c0[3], c1[3], c2[3], n[3], r0[3], r1[3];
     sub3(vt1, vt0, c0);
@@ -1349,9 +1353,15 @@ static bool segTriIntersect(const double* ve0, const double* ve1, const double* 
     cross3(c0, c1, n);
     sub3(ve0, vt0, r0);
     sub3(ve1, vt0, r1);
-    if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
     const double det = dot3(n, c2);
+    if (exact) {
+        const int o1 = ipcgpu::o3::orient3d(vt0, vt1, vt2, ve0), o2 = ipcgpu::o3::orient3d(vt0, vt1, vt2, ve1);
+        if (o1 == 0 || o2 == 0 || o1 == o2) return false;
+    }
+    else {
+    if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
     if (det == 0.0) return false;
+    }
     // Cramer: [c0 c1 c2] (u v t)^T = r0
     double t0[3], t1[3];
     cross3(r0, c1, t0);
@@ -1387,7 +1397,7 @@ bool isIntersected(const Mesh& m)
                 if (std::min(p0[k], p1[k]) > hi[k] || std::max(p0[k], p1[k]) < lo[k]) sep = true;
             }
             if (sep) continue;
-            if (segTriIntersect(p0, p1, a, b, c)) return true;
+            if (segTriIntersect(p0, p1, a, b, c, m.exactPredicates)) return true;
         }
     }
     // codimensional points against every tetrahedron (SelfCollisionHandler.cpp:3301-3338): inside the element's box, then behind its
@@ -1419,6 +1429,12 @@ bool isIntersected(const Mesh& m)
                 in = lo <= p[c] && hi >= p[c];
             }
             if (!in) continue;
+            if (m.exactPredicates) { // IglUtils.hpp:280-294: orient3d(...) != NEGATIVE four times
+                if (ipcgpu::o3::orient3d(q[0], q[2], q[1], p) >= 0 && ipcgpu::o3::orient3d(q[0], q[3], q[2], p) >= 0 && ipcgpu::o3::orient3d(q[0], q[1], q[3], p) >= 0
+                    && ipcgpu::o3::orient3d(q[1], q[2], q[3], p) >= 0)
+                    return true;
+                continue;
+            }
             if (behind(q[0], q[2], q[1], p) && behind(q[0], q[3], q[2], p) && behind(q[0], q[1], q[3], p) && behind(q[1], q[2], q[3], p)) return true;
         }
     }
@@ -1571,6 +1587,8 @@ double orc_accd_small(int n, const double* X9, const double* P9, double eta, dou
 }
 // X15: segment end points, then the triangle
 int orc_seg_tri_intersect(const double* X15) { return segTriIntersect(X15, X15 + 3, X15 + 6, X15 + 9, X15 + 12) ? 1 : 0; }
+int orc_seg_tri_intersect_exact(const double* X15) { return segTriIntersect(X15, X15 + 3, X15 + 6, X15 + 9, X15 + 12, true) ? 1 : 0; }
+void orc_mesh_set_exact_predicates(orc_mesh* m, int on) { m->m.exactPredicates = on != 0; }
 int orc_is_intersected(const orc_mesh* m) { return isIntersected(m->m) ? 1 : 0; }
 
 int orc_mesh_surface_counts(const orc_mesh* m, int* n3)

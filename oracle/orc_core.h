@@ -46,6 +46,7 @@ struct Mesh {
     bool isProjectDBC(int v, bool projectDBC) const { return dbcType[v] == 1 || (dbcType[v] == 2 && projectDBC); } // Mesh.hpp:135-144
     void setSurface(int nSF, const int* SF, int nCE = 0, const int* CE = nullptr); // CE: codimensional segments (node pairs); nodes without any neighbour are codimensional points
     std::vector<int> codimPoints; // nodes of no tetrahedron, triangle or segment (`.pt` shapes, Mesh.cpp:916-920)
+    bool exactPredicates = false; // the intersection checks of a USE_PREDICATES build (IglUtils.hpp:222-233, 280-294)
     bool checkInversion() const;
     bool inversionFree() const { return energyType == 1 || checkInversion(); } // Optimizer.cpp:252,517,545,2710: getNeedElemInvSafeGuard()
     M3 defGrad(int t) const;

@@ -475,3 +475,52 @@ def test_codimensional_points_and_segments_bookkeeping_sets_and_intersection(orc
         assert np.array_equal(g[k], o[k]), k
     assert any(int(t[0]) == -n - 1 for t in np.asarray(o["active"]).reshape(-1, 4))  # the point is the vertex of a PT / PE / PP tuple
     c.close()
+
+
+def test_intersection_checks_with_exact_predicates(orc, gpu_lib):
+    """ipcgpu_set_exact_predicates: the plane-side tests of the intersection checks as a USE_PREDICATES build of the reference makes them
+    (IglUtils.hpp:222-233, 280-294; orient3d_exact.h pinned on rational arithmetic in tests/test_orient3d.py).  A segment that ends exactly IN
+    the plane of a face touches it in the default build and does not in this one; a point exactly ON a face of a tetrahedron is inside in both."""
+    from test_oracle_contact import codim_point_mesh
+    Vall, F, SF, CE, n = codim_point_mesh()
+    m = orc.Mesh(Vall, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_surface(SF, CE)
+    c = gpu_lib.Context(0)
+    c.set_mesh(Vall, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_surface(SF, CE)
+    rng = np.random.default_rng(12)
+    V2 = Vall.copy()
+    V2[n] = [5.0, 5.0, 5.0]  # the points out of the way
+    cases = [([0.3, 1.0, 0.4], [0.35, 1.6, 0.45], True, False),  # one end exactly in the plane y = 1 of the top face
+             ([0.3, 0.9, 0.4], [0.35, 1.6, 0.45], True, True),  # through the top face
+             ([0.3, 1.0 + 1e-15, 0.4], [0.35, 1.6, 0.45], False, False)]  # a hair above it
+    for e0, e1, want_default, want_exact in cases:
+        V2[n + 3], V2[n + 4] = e0, e1
+        m.set_V(V2)
+        c.set_positions(V2)
+        for exact, want in ((False, want_default), (True, want_exact)):
+            m.set_exact_predicates(exact)
+            c.set_exact_predicates(exact)
+            assert orc.is_intersected(m) == want and c.is_intersected() == want, (e0, exact)
+    # random segments around the box, both modes: oracle and GPU agree
+    agree = 0
+    for trial in range(40):
+        V2[n + 3] = rng.uniform(-0.3, 1.3, size=3)
+        V2[n + 4] = rng.uniform(-0.3, 1.3, size=3)
+        m.set_V(V2)
+        c.set_positions(V2)
+        for exact in (False, True):
+            m.set_exact_predicates(exact)
+            c.set_exact_predicates(exact)
+            assert orc.is_intersected(m) == c.is_intersected()
+            agree += 1
+    # a point exactly on a face of the box (orient3d == 0 counts as inside, like `<= 0.0` of pointBehindTri)
+    V2[n + 3], V2[n + 4] = [2.0, 2.0, 2.0], [2.5, 2.0, 2.0]
+    V2[n] = [0.5, 0.25, 0.0]
+    m.set_V(V2)
+    c.set_positions(V2)
+    for exact in (False, True):
+        m.set_exact_predicates(exact)
+        c.set_exact_predicates(exact)
+        assert orc.is_intersected(m) and c.is_intersected()
+    c.close()
