@@ -10,7 +10,8 @@
 // expansions with zero elimination): its most significant component carries the sign.  No adaptive stages in between: the exact path is rare
 // (nearly coplanar configurations only) and correctness, not its speed, is what the intersection checks need.
 //
-// Compiles for the device and for the host (oracle/, tests/test_orient3d.py pins it on exact rational arithmetic).
+// Compiles for the device and for the host (tests/test_orient3d.py builds it with g++ and pins it on exact rational arithmetic; the CPU checker of
+// the test suite includes it too).
 #pragma once
 #include <cmath>
 #ifdef __HIPCC__
