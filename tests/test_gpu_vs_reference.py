@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import (CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_codim, check_damped_bar, check_plates,
+from test_oracle_vs_reference import (CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_chain, check_codim, check_damped_bar, check_plates,
                                       check_restart, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
@@ -247,6 +247,15 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol, gpu_
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     check_codim(S, pos, its, 10 * tol)
     c.close()
+
+
+def test_chain_against_the_reference(gpu_lib):
+    """BASELINE configs[4]: videoExamples/chain10.txt on the HIP stepper beside the reference's run, all 30 Newton counts"""
+    S, meshes = load_scene("chain10")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    check_chain(S, pos, its)
 
 
 @pytest.mark.parametrize("name", ["bar_twist_warm5", "two_cubes_warm5"])

@@ -404,6 +404,23 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol):
     check_codim(S, pos, its, tol)
 
 
+def check_chain(S, pos, its):
+    """BASELINE configs[4]'s chain, videoExamples/chain10.txt as shipped (ten interlocked tori dropping onto a fixed torus ring given as a mesh
+    collision object, `size -1`, `script fallNoShift`), 30 steps run by the reference: EVERY Newton count equal while link after link is caught;
+    positions within the Newton tolerance of the touch-downs from exact rest."""
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    ref = S["positions"]
+    n = min(pos.shape[1], ref.shape[1])
+    assert np.abs(pos[:2, :n] - ref[:2, :n]).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(pos[:, :n] - ref[:, :n]).max() <= 1e-4 * np.abs(ref).max()
+
+
+def test_chain_against_the_reference():
+    S, meshes = load_scene("chain10")
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    check_chain(S, pos, its)
+
+
 def check_warm5(S, pos, its, name):
     """`warmStart 5` (Optimizer::initX option 5, Optimizer.cpp:1082-1110): the Jacobi guess -g_i / H_ii as the first iterate of every step."""
     ref = S["positions"]

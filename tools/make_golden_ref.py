@@ -278,6 +278,12 @@ SCENES += [
     ("push_right_most", "inline:push_right_most", "", 6),
     ("utopia", "inline:utopia", "", 6),
     ("seg_bed_squash", "inline:seg_bed_squash", "", 16),
+    # BASELINE configs[4]: 15_trashComp_shapes.txt as shipped -- six closing plates (`script DCOSquash6`, FCR, `size 1`) around a ball, a mat and a
+    # bunny (46 K tets together) that touch the plates and each other from the first step on; 4 steps = 47 Newton iterations of the serial reference
+    ("trash_compactor", "paperExamples/15_trashComp_shapes.txt", "", 4),
+    # BASELINE configs[4], the other scene it names: videoExamples/chain10.txt as shipped -- ten interlocked tori (NH, E = 1e7) dropping onto a fixed
+    # torus (meshCO), `script fallNoShift`: link after link is caught by the one above it
+    ("chain10", "paperExamples/videoExamples/chain10.txt", "", 30),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
