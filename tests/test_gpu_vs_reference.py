@@ -249,6 +249,21 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol, gpu_
     c.close()
 
 
+def test_trash_compactor_against_the_reference(gpu_lib):
+    """BASELINE configs[4]: paperExamples/15_trashComp_shapes.txt as shipped -- six closing plates (`script DCOSquash6`, FCR, `size 1`) around a
+    ball, a mat and a bunny (46 K tets) that touch the plates and each other from the first step on -- four steps run by the reference itself
+    (47 Newton iterations of its serial build): every count equal, positions within the Newton tolerance of a start from exact rest (the CPU
+    restatement beside the reference: profiles/r03_ref_compare_trashCompactor_cpu.txt)."""
+    S, meshes = load_scene("trash_compactor")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    ref = S["positions"]
+    n = min(pos.shape[1], ref.shape[1])
+    assert np.abs(pos[:, :n] - ref[:, :n]).max() <= 5e-5 * np.abs(ref).max()
+
+
 def test_chain_against_the_reference(gpu_lib):
     """BASELINE configs[4]: videoExamples/chain10.txt on the HIP stepper beside the reference's run, all 30 Newton counts"""
     S, meshes = load_scene("chain10")
