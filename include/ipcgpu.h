@@ -259,6 +259,10 @@ int ipcgpu_halfspace_step_bound(ipcgpu_ctx*, int id, const double* searchDir_3nV
 /* ---- lagged smoothed Coulomb friction (FrictionUtils.hpp, SelfCollisionHandler.cpp:2481-2988, HalfSpace.cpp:272-381)
  * `selfFric mu` / `fricIterAmt n` / eps_v = tuning[4] (Config.cpp:482-488, 550-551, 45).  Self friction needs self collision. */
 int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, double epsV);
+/* eps_v homotopy: `tuning`'s sixth entry (Config.cpp:41-45, Optimizer.cpp:296-303).  The smoothing distance of the friction terms starts every
+   time step at eps_v (fifth entry) and is halved down -- or clamped up -- to eps_v_target between the friction-lag passes (:1776-1781); the
+   tangent-space convergence test runs only once it has arrived (:1717).  <= 0: the target is eps_v itself (what the `epsv` keyword sets). */
+int ipcgpu_opt_set_friction_target(ipcgpu_ctx*, double eps_v_target);
 /* MeshCO::friction (Config.cpp:459-474, MeshCO.cpp) beside Config::selfFric: a kinematic mesh obstacle carries its own friction
  * coefficient for the pairs that involve it.  Pass the larger coefficient to ipcgpu_opt_set_friction and the ratios here: the lagged
  * normal forces (MMLambda_lastH) of stencils without / with an obstacle node are multiplied by scaleSelf / scaleObstacle. */

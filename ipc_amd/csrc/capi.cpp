@@ -1031,6 +1031,13 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx* c, double selfFric, int fricIterAmt, dou
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_friction_target(ipcgpu_ctx* c, double epsVTarget)
+{
+    return guarded([&] {
+        O(c).epsVTarget = epsVTarget > 0.0 ? epsVTarget : -1.0;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_kappa(ipcgpu_ctx* c, double kappa)
 {
     return guarded([&] {

@@ -1622,9 +1622,90 @@ __device__ inline bool seg_tri_intersect(const double* ve0, const double* ve1, c
         if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
         if (det == 0.0) return false;
     }
-    cross3(r0, c1, t0);
-    cross3(c0, r0, t1);
-    const double u = dot3(t0, c2) / det, v = dot3(t1, c2) / det, t = dot3(n, r0) / det;
+    // (u, v, t) = coefMtr.fullPivLu().solve(ve0 - vt0), coefMtr = [c0 c1 c2] (IglUtils.hpp:258): Eigen's rank-revealing LU -- pivots below
+    // 3 eps |largest pivot| count as zero and the unknowns behind them come out as exactly 0.  Rounds 1-2 used Cramer's rule here: on the flat,
+    // obliquely placed sides of a mesh (edge and triangle coplanar up to round-off: det = 1e-20, not 0) it returned ratios of round-off, and
+    // one start in twenty was then called intersecting (12_matOnBoard.txt, 5_hitCardHouse.txt were refused); the truncated solve returns t = 0
+    // and the in-plane coordinates of the segment's end.  Registers only: rows / columns are swapped by selects, no indexed arrays.
+    (void)t0;
+    (void)t1;
+    double a00 = c0[0], a01 = c1[0], a02 = c2[0], a10 = c0[1], a11 = c1[1], a12 = c2[1], a20 = c0[2], a21 = c1[2], a22 = c2[2];
+    double b0 = r0[0], b1 = r0[1], b2 = r0[2];
+    int q0 = 0, q1 = 1, q2 = 2; // original column at positions 0, 1, 2
+    auto swp = [](double& x, double& y) {
+        const double tmp = x;
+        x = y;
+        y = tmp;
+    };
+    // ---- step 0: largest entry of the whole matrix, columns first (Eigen's visitor order: the first maximum wins)
+    int pr = 0, pc = 0;
+    double big = 0.0;
+    {
+        const double e[9] = { a00, a10, a20, a01, a11, a21, a02, a12, a22 }; // column-major scan
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            if (fabs(e[k]) > big) {
+                big = fabs(e[k]);
+                pr = k % 3;
+                pc = k / 3;
+            }
+    }
+    double u = 0.0, v = 0.0, t = 0.0;
+    if (big == 0.0) return u >= 0.0 && v >= 0.0 && u + v <= 1.0 && t >= 0.0 && t <= 1.0; // rank 0: the zero vector (as FullPivLU::solve)
+    double maxPivot = big;
+    if (pr == 1) { swp(a00, a10); swp(a01, a11); swp(a02, a12); swp(b0, b1); }
+    if (pr == 2) { swp(a00, a20); swp(a01, a21); swp(a02, a22); swp(b0, b2); }
+    if (pc == 1) { swp(a00, a01); swp(a10, a11); swp(a20, a21); const int tq = q0; q0 = q1; q1 = tq; }
+    if (pc == 2) { swp(a00, a02); swp(a10, a12); swp(a20, a22); const int tq = q0; q0 = q2; q2 = tq; }
+    a10 /= a00;
+    a20 /= a00;
+    a11 -= a10 * a01;
+    a21 -= a20 * a01;
+    a12 -= a10 * a02;
+    a22 -= a20 * a02;
+    // ---- step 1: largest entry of the trailing 2 x 2, columns first
+    int nonzero = 3;
+    pr = 1;
+    pc = 1;
+    big = 0.0;
+    if (fabs(a11) > big) { big = fabs(a11); pr = 1; pc = 1; }
+    if (fabs(a21) > big) { big = fabs(a21); pr = 2; pc = 1; }
+    if (fabs(a12) > big) { big = fabs(a12); pr = 1; pc = 2; }
+    if (fabs(a22) > big) { big = fabs(a22); pr = 2; pc = 2; }
+    if (big == 0.0) nonzero = 1;
+    else {
+        if (big > maxPivot) maxPivot = big;
+        if (pr == 2) { swp(a10, a20); swp(a11, a21); swp(a12, a22); swp(b1, b2); }
+        if (pc == 2) { swp(a01, a02); swp(a11, a12); swp(a21, a22); const int tq = q1; q1 = q2; q2 = tq; }
+        a21 /= a11;
+        a22 -= a21 * a12;
+        // ---- step 2
+        if (a22 == 0.0) nonzero = 2;
+        else if (fabs(a22) > maxPivot) maxPivot = fabs(a22);
+    }
+    const double thr = maxPivot * (2.220446049250313e-16 * 3.0);
+    int rank = 0;
+    rank += (nonzero > 0 && fabs(a00) > thr) ? 1 : 0;
+    rank += (nonzero > 1 && fabs(a11) > thr) ? 1 : 0;
+    rank += (nonzero > 2 && fabs(a22) > thr) ? 1 : 0;
+    // unit-lower solve on all three rows, upper solve on the leading rank x rank corner, zeros behind it
+    double y0 = b0, y1 = b1 - a10 * y0, y2 = b2 - a20 * y0 - a21 * y1;
+    double z0 = 0.0, z1 = 0.0, z2 = 0.0;
+    if (rank == 3) {
+        z2 = y2 / a22;
+        z1 = (y1 - a12 * z2) / a11;
+        z0 = ((y0 - a01 * z1) - a02 * z2) / a00;
+    }
+    else if (rank == 2) {
+        z1 = y1 / a11;
+        z0 = (y0 - a01 * z1) / a00;
+    }
+    else if (rank == 1) z0 = y0 / a00;
+    (void)y2;
+    // x[q_i] = z_i
+    u = (q0 == 0) ? z0 : ((q1 == 0) ? z1 : z2);
+    v = (q0 == 1) ? z0 : ((q1 == 1) ? z1 : z2);
+    t = (q0 == 2) ? z0 : ((q1 == 2) ? z1 : z2);
     return u >= 0.0 && v >= 0.0 && u + v <= 1.0 && t >= 0.0 && t <= 1.0;
 }
 // checkEdgeTriIntersectionIfAny (SelfCollisionHandler.cpp:3255-3300): one lane per surface triangle, edges from the grid

@@ -259,6 +259,9 @@ public:
     // lagged friction: Optimizer.cpp:286-304, 1525-1600, 1615-1790; the lagged sets live in HipContact /
     // HipHalfSpace, x^t is d_xPrev
     double selfFric = 0.0, epsV = 1.0e-3, fricDHat0 = 0, fricDHat = -1.0;
+    // eps_v homotopy (tuning[5], Optimizer.cpp:296-303, 1717, 1776-1781): fricDHat is halved down (or clamped UP) to this target between the
+    // friction-lag passes, the tangent-space convergence test runs only once it is there; < 0: the same as the start value (no homotopy)
+    double epsVTarget = -1.0, fricDHatTarget = 0;
     int fricIterAmt = 1, fricIterI = 0;
     bool fricLoopForced = false; // a mesh collision object with a friction coefficient: the lagging loop runs, no pair carries friction (Optimizer.cpp:156-161)
     bool solveFric() const;

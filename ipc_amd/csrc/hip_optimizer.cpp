@@ -396,7 +396,7 @@ bool HipOptimizer::nextSubproblem()
         else if (dMin < dTol) return false; // "tiny distance fail-safe"
     }
     bool updateFricDHat = fric;
-    if (fric && fricDHat <= fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45, 547-548)
+    if (fric && fricDHat <= fricDHatTarget) { // :1717 (the target equals the start value unless `tuning` gives a sixth entry)
         // tangent-space convergence test: one Newton direction with the refreshed lag (:1717-1731)
         computePrecondMtr(true, true);
         computeSearchDir(true);
@@ -411,7 +411,7 @@ bool HipOptimizer::nextSubproblem()
         computeConstraintSets();
         initKappa();
     }
-    if (updateFricDHat && fricDHat > 0.0) fricDHat = std::max(0.5 * fricDHat, fricDHat0); // :1776-1781
+    if (updateFricDHat && fricDHat > 0.0) fricDHat = std::max(0.5 * fricDHat, fricDHatTarget); // :1776-1781
     initSubProblem(); // the next solveSub_IP starts with m_projectDBC = true, rho_DBC = 0 (Optimizer.cpp:1826-1828)
     closeID.clear(); // initSubProb_IP
     closeVal.clear();
@@ -1245,6 +1245,7 @@ void HipOptimizer::beginTimestep()
         if (contact) contact->frictionLagClear();
         for (auto& h : planes) h->lagClear();
         fricDHat0 = epsV * epsV * dtSq * mesh.bboxDiag2;
+        fricDHatTarget = epsVTarget > 0.0 ? epsVTarget * epsVTarget * dtSq * mesh.bboxDiag2 : fricDHat0;
         fricDHat = solveFric() ? fricDHat0 : -1.0;
         fricIterI = 0;
         updateFrictionLag();

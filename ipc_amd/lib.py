@@ -568,6 +568,10 @@ class Context:
         self._chk(self._L.ipcgpu_halfspace_step_bound(self.h, C.c_int(idx), _dp(p), C.c_double(slackness), C.byref(s)))
         return s.value
 
+    def set_friction_target(self, eps_v_target):
+        """eps_v homotopy target (`tuning`'s sixth entry); <= 0: the same as eps_v"""
+        self._chk(self._L.ipcgpu_opt_set_friction_target(self.h, C.c_double(eps_v_target)))
+
     def set_friction(self, self_fric=0.0, fric_iter_amt=1, eps_v=1e-3):
         self._chk(self._L.ipcgpu_opt_set_friction(self.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v)))
 

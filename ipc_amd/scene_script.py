@@ -66,6 +66,7 @@ class SceneConfig:
     self_fric: float = 0.0
     dHat_eps: float = 1e-3  # tuning[1]
     eps_v: float = 1e-3  # tuning[4]
+    eps_v_target: float = -1.0  # tuning[5]; < 0: the same as eps_v (the `epsv` keyword sets both)
     fric_iter_amt: int = 1
     rot_axis: tuple = (0.0, 0.0, 0.0)  # rotateModel ax ay az deg (Config.cpp:523-526)
     rot_deg: float = 0.0
@@ -199,8 +200,9 @@ class SceneConfig:
                 cfg.self_fric = float(a[0])
             elif k == "dHat":  # Config.cpp:542-545: entries 1 and 2 of `tuning`
                 cfg.dHat_eps = cfg.dHat_target = float(a[0])
-            elif k == "epsv":
+            elif k == "epsv":  # Config.cpp:546-549: entries 4 and 5 of `tuning`
                 cfg.eps_v = float(a[0])
+                cfg.eps_v_target = -1.0
             elif k == "fricIterAmt":
                 cfg.fric_iter_amt = int(a[0])
             elif k == "tol":
@@ -221,6 +223,7 @@ class SceneConfig:
                 cfg.dHat_eps = vals[1] if len(vals) > 1 else 1e-3
                 cfg.dHat_target = vals[2] if len(vals) > 2 else 1e-3  # Optimizer.cpp:283-289: without a third entry the target is 1e-3 (relative)
                 cfg.eps_v = vals[4] if len(vals) > 4 else 1e-3
+                cfg.eps_v_target = vals[5] if len(vals) > 5 else 1e-3  # Optimizer.cpp:296-299: without a sixth entry the target is 1e-3
             elif k == "section":  # Config.cpp:572-605: settings for one constraint solver; other solvers' sections are skipped
                 names = ["interiorPoint" if x == "IP" else x for x in a]
                 if "end" not in names and "interiorPoint" not in names:
@@ -757,6 +760,8 @@ def apply(sc, be):
     loop_only = any(mc[3] > 0 for mc in cfg.mesh_cos) and not (self_fric > 0 or plane_fric)
     if self_fric > 0 or plane_fric or loop_only:
         be.set_friction(self_fric, cfg.fric_iter_amt, cfg.eps_v)
+        if cfg.eps_v_target > 0 and cfg.eps_v_target != cfg.eps_v:
+            be.set_friction_target(cfg.eps_v_target)
         if sc.obstacle_nodes is not None and fric_scales is not None:
             be.set_friction_scales(*fric_scales)
         if loop_only:

@@ -693,6 +693,10 @@ class Friction:
         return a
 
 
+def opt_set_friction_target(opt: "Optimizer", eps_v_target):
+    lib().orc_opt_set_friction_target(opt.h, C.c_double(eps_v_target))
+
+
 def opt_set_friction(opt: "Optimizer", self_fric=0.0, fric_iter_amt=1, eps_v=1e-3):
     lib().orc_opt_set_friction(opt.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v))
 

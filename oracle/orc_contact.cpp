@@ -1362,11 +1362,62 @@ static bool segTriIntersect(const double* ve0, const double* ve1, const double* 
     if (dot3(n, r0) * dot3(n, r1) > 0.0) return false;
     if (det == 0.0) return false;
     }
-    // Cramer: [c0 c1 c2] (u v t)^T = r0
-    double t0[3], t1[3];
-    cross3(r0, c1, t0);
-    cross3(c0, r0, t1);
-    const double u = dot3(t0, c2) / det, v = dot3(t1, c2) / det, t = dot3(n, r0) / det;
+    // (u, v, t) = coefMtr.fullPivLu().solve(ve0 - vt0) with coefMtr = [c0 c1 c2] (IglUtils.hpp:258): Eigen's rank-revealing LU -- pivots below
+    // 3 eps |largest pivot| count as zero and the unknowns behind them come out as exactly 0.  That is what keeps the test quiet on the flat,
+    // obliquely placed sides of a mesh, where edge and triangle are coplanar up to round-off (det is then 1e-20, not 0): Cramer's rule returned
+    // ratios of round-off there -- the check then called a clean start intersecting (12_matOnBoard.txt, 5_hitCardHouse.txt) -- while the
+    // truncated solve returns t = 0 and the in-plane coordinates of the segment's end.
+    double A[3][3] = { { c0[0], c1[0], c2[0] }, { c0[1], c1[1], c2[1] }, { c0[2], c1[2], c2[2] } }, b[3] = { r0[0], r0[1], r0[2] };
+    int colOf[3] = { 0, 1, 2 };
+    double maxPivot = 0.0;
+    int nonzero = 3;
+    for (int k = 0; k < 3; ++k) {
+        int pr = k, pc = k;
+        double big = 0.0;
+        for (int j = k; j < 3; ++j) // the corner column by column, the first maximum (Eigen's visitor order)
+            for (int i = k; i < 3; ++i)
+                if (std::fabs(A[i][j]) > big) {
+                    big = std::fabs(A[i][j]);
+                    pr = i;
+                    pc = j;
+                }
+        if (big == 0.0) {
+            nonzero = k;
+            break;
+        }
+        if (big > maxPivot) maxPivot = big;
+        if (pr != k) {
+            for (int j = 0; j < 3; ++j) std::swap(A[k][j], A[pr][j]);
+            std::swap(b[k], b[pr]);
+        }
+        if (pc != k) {
+            for (int i = 0; i < 3; ++i) std::swap(A[i][k], A[i][pc]);
+            std::swap(colOf[k], colOf[pc]);
+        }
+        for (int i = k + 1; i < 3; ++i) A[i][k] /= A[k][k];
+        for (int j = k + 1; j < 3; ++j)
+            for (int i = k + 1; i < 3; ++i) A[i][j] -= A[i][k] * A[k][j];
+    }
+    const double thr = maxPivot * (std::numeric_limits<double>::epsilon() * 3.0);
+    int rank = 0;
+    for (int i = 0; i < nonzero; ++i) rank += std::fabs(A[i][i]) > thr;
+    double uvt[3] = { 0.0, 0.0, 0.0 };
+    if (rank) {
+        // (the row swaps were applied to b as they happened; Eigen applies them first and then runs the same unit-lower solve)
+        double c[3];
+        for (int i = 0; i < 3; ++i) {
+            double sAcc = b[i];
+            for (int k = 0; k < i; ++k) sAcc -= A[i][k] * c[k];
+            c[i] = sAcc;
+        }
+        for (int i = rank - 1; i >= 0; --i) {
+            double sAcc = c[i];
+            for (int k = i + 1; k < rank; ++k) sAcc -= A[i][k] * c[k];
+            c[i] = sAcc / A[i][i];
+        }
+        for (int i = 0; i < rank; ++i) uvt[colOf[i]] = c[i];
+    }
+    const double u = uvt[0], v = uvt[1], t = uvt[2];
     return u >= 0.0 && v >= 0.0 && u + v <= 1.0 && t >= 0.0 && t <= 1.0;
 }
 

@@ -85,6 +85,7 @@ struct orc_opt {
     std::vector<double> closeHSVal;
     // lagged friction: Optimizer.cpp:286-304, 1525-1600, 1615-1790
     double selfFric = 0.0, epsV = 1.0e-3, fricDHat0 = 0, fricDHat = -1.0;
+    double epsVTarget = -1.0, fricDHatTarget = 0; // eps_v homotopy (tuning[5], Optimizer.cpp:296-303, 1717, 1776-1781); < 0: no homotopy
     // a kinematic mesh obstacle carries its own friction coefficient (MeshCO::friction, Config.cpp:459-474): selfFric holds the larger of the
     // two, the lagged normal forces of the stencils with / without an obstacle node are scaled by these factors (1 = the same coefficient)
     double fricScaleSelf = 1.0, fricScaleObst = 1.0;
@@ -911,6 +912,7 @@ void orc_opt_begin_timestep(orc_opt* o)
         o->lag = FrictionLag();
         for (auto& s : o->hsLagSet) s.clear();
         o->fricDHat0 = o->epsV * o->epsV * o->dtSq * m.bboxDiag2;
+        o->fricDHatTarget = o->epsVTarget > 0.0 ? o->epsVTarget * o->epsVTarget * o->dtSq * m.bboxDiag2 : o->fricDHat0;
         o->fricDHat = o->solveFric() ? o->fricDHat0 : -1.0;
         o->fricIterI = 0;
         updateFrictionLag(o);
@@ -1117,7 +1119,7 @@ int orc_opt_next_subproblem(orc_opt* o)
         else if (dMin < o->dTol) return 0; // "tiny distance fail-safe"
     }
     bool updateFricDHat = fric;
-    if (fric && o->fricDHat <= o->fricDHat0) { // fricDHatTarget == fricDHat0 (tuning[5] = tuning[4], Config.cpp:45,547-548)
+    if (fric && o->fricDHat <= o->fricDHatTarget) { // :1717 (the target equals the start value unless `tuning` gives a sixth entry)
         // tangent-space convergence test: one Newton direction with the refreshed lag (:1717-1731)
         computeGradient(o, true);
         computePrecondMtr(o, true);
@@ -1138,7 +1140,7 @@ int orc_opt_next_subproblem(orc_opt* o)
         computeConstraintSets(o);
         initKappa(o);
     }
-    if (updateFricDHat && o->fricDHat > 0.0) o->fricDHat = std::max(0.5 * o->fricDHat, o->fricDHat0); // :1776-1781
+    if (updateFricDHat && o->fricDHat > 0.0) o->fricDHat = std::max(0.5 * o->fricDHat, o->fricDHatTarget); // :1776-1781
     o->closeID.clear(); // initSubProb_IP
     o->closeVal.clear();
     o->closeHS.clear();
@@ -1225,6 +1227,7 @@ void orc_opt_get_contact(const orc_opt* o, int* counts6, int* active4, int* para
         for (size_t i = 0; i < o->cs.paraEE.size(); ++i)
             for (int k = 0; k < 4; ++k) para4[4 * i + k] = o->cs.paraEE[i][k];
 }
+void orc_opt_set_friction_target(orc_opt* o, double epsVTarget) { o->epsVTarget = epsVTarget > 0.0 ? epsVTarget : -1.0; }
 void orc_opt_set_warm_start(orc_opt* o, int option)
 {
     if (option < 0 || option > 5) return;

@@ -8,7 +8,8 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import (CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, check_chain, check_codim, check_damped_bar, check_plates,
+from test_oracle_vs_reference import (CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, SHIPPED_SCENES, check_chain, check_codim, check_damped_bar,
+                                      check_plates, check_shipped,
                                       check_restart, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
@@ -247,6 +248,17 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol, gpu_
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     check_codim(S, pos, its, 10 * tol)
     c.close()
+
+
+@pytest.mark.parametrize("name,mism,tol", SHIPPED_SCENES)
+def test_shipped_scenes_against_the_reference(name, mism, tol, gpu_lib):
+    """five more of the reference's shipped scenes on the HIP stepper beside the reference's runs (friction on a slope with and without the
+    eps_v homotopy, fixLowerHalf in a tight corner, two mats on a board)"""
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    check_shipped(S, pos, its, max(mism, 1), 10 * tol)
 
 
 def test_trash_compactor_against_the_reference(gpu_lib):

@@ -404,6 +404,31 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol):
     check_codim(S, pos, its, tol)
 
 
+# more of the reference's shipped scenes (tools/make_golden_ref.py): (fixture, Newton counts that may differ, position tolerance)
+SHIPPED_SCENES = [
+    ("slope_049", 0, 1e-6),  # a block on a slope just below the friction angle: half-space friction, FCR, tol 1e-4, fricIterAmt -1 -- all 16 counts
+    ("slope_05", 0, 1e-6),  # ... at the friction angle (it comes to rest: 1 iteration per step from step 6 on)
+    ("slope_epsv_homotopy", 1, 1e-6),  # + `tuning`'s sixth entry: eps_v 4e-3 halved down to 1e-3 between the friction-lag passes (one count +-1)
+    ("tight_fit_cube", 0, 1e-12),  # `script fixLowerHalf`, halfSpace, six tuning entries, E = 1e5 ... every count, positions to round-off
+    ("mat_on_board", 0, 5e-5),  # 12_matOnBoard.txt: two mats edge-on, flat sides oblique to the axes (segTriIntersect's rank-revealing solve)
+]
+
+
+def check_shipped(S, pos, its, mism, tol):
+    differ = np.nonzero(its != S["iters"][:len(its)])[0]
+    assert len(differ) <= mism and np.abs(its - S["iters"][:len(its)]).max() <= 1, (its.tolist(), S["iters"].tolist())
+    ref = S["positions"]
+    n = min(pos.shape[1], ref.shape[1])
+    assert np.abs(pos[:, :n] - ref[:len(pos), :n]).max() <= tol * np.abs(ref).max()
+
+
+@pytest.mark.parametrize("name,mism,tol", SHIPPED_SCENES)
+def test_shipped_scenes_against_the_reference(name, mism, tol):
+    S, meshes = load_scene(name)
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    check_shipped(S, pos, its, mism, tol)
+
+
 def check_chain(S, pos, its):
     """BASELINE configs[4]'s chain, videoExamples/chain10.txt as shipped (ten interlocked tori dropping onto a fixed torus ring given as a mesh
     collision object, `size -1`, `script fallNoShift`), 30 steps run by the reference: EVERY Newton count equal while link after link is caught;

@@ -185,6 +185,9 @@ class OracleBackend:
     def set_friction(self, mu, n, eps):
         self.orc.opt_set_friction(self.o, mu, n, eps)
 
+    def set_friction_target(self, eps):
+        self.orc.opt_set_friction_target(self.o, eps)
+
     def add_dirichlet(self, ids, **k):
         self.orc.opt_add_dirichlet(self.o, ids, **k)
 

@@ -284,6 +284,15 @@ SCENES += [
     # BASELINE configs[4], the other scene it names: videoExamples/chain10.txt as shipped -- ten interlocked tori (NH, E = 1e7) dropping onto a fixed
     # torus (meshCO), `script fallNoShift`: link after link is caught by the one above it
     ("chain10", "paperExamples/videoExamples/chain10.txt", "", 30),
+    # more of the reference's shipped scenes, small ones: a block on a slope just below / at the friction angle (half-space friction, FCR, tol
+    # 1e-4, fricIterAmt -1); the same with an eps_v homotopy (`tuning`'s sixth entry: 4e-3 halved down to 1e-3 between the friction-lag passes);
+    # a stiff cube held by its lower half in a tight corner (fixLowerHalf, halfSpace, tuning); two mats dropped edge-on onto a board and a
+    # half-space (flat sides oblique to the axes: the rank-revealing solve of segTriIntersect decides the intersection checks there)
+    ("slope_049", "otherExamples/friction/slopeTest_highSchoolPhysics_0.49.txt", "", 16),
+    ("slope_05", "otherExamples/friction/slopeTest_highSchoolPhysics_0.5.txt", "", 16),
+    ("slope_epsv_homotopy", "otherExamples/friction/slopeTest_highSchoolPhysics_0.5.txt", "\ntuning 6\n0\n1e-3\n1e-3\n1e-9\n4e-3\n1e-3\n", 16),
+    ("tight_fit_cube", "paperExamples/videoExamples/tightFitCube.txt", "", 6),
+    ("mat_on_board", "paperExamples/12_matOnBoard.txt", "", 4),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
