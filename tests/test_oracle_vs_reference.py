@@ -411,6 +411,10 @@ SHIPPED_SCENES = [
     ("slope_epsv_homotopy", 1, 1e-6),  # + `tuning`'s sixth entry: eps_v 4e-3 halved down to 1e-3 between the friction-lag passes (one count +-1)
     ("tight_fit_cube", 0, 1e-12),  # `script fixLowerHalf`, halfSpace, six tuning entries, E = 1e5 ... every count, positions to round-off
     ("mat_on_board", 0, 5e-5),  # 12_matOnBoard.txt: two mats edge-on, flat sides oblique to the axes (segTriIntersect's rank-revealing solve)
+    ("mat_on_segments", 0, 1e-13),  # coDimUnitTests/mat40x40_segPlaneDrop.txt: a mat on a bed of 210 held segments -- counts and positions to round-off
+    ("mat_on_points", 0, 1e-13),  # ... on 420 held points
+    ("nbc_time_range", 0, 1e-12),  # Neumann groups with time ranges through the first touch-down
+    ("attach", 0, 5e-3),  # 2cubesFall_attach.txt: every count through the impact (positions: a touch-down from exact rest)
 ]
 
 

@@ -293,6 +293,11 @@ SCENES += [
     ("slope_epsv_homotopy", "otherExamples/friction/slopeTest_highSchoolPhysics_0.5.txt", "\ntuning 6\n0\n1e-3\n1e-3\n1e-9\n4e-3\n1e-3\n", 16),
     ("tight_fit_cube", "paperExamples/videoExamples/tightFitCube.txt", "", 6),
     ("mat_on_board", "paperExamples/12_matOnBoard.txt", "", 4),
+    # a mat dropped on a bed of 210 segments / 420 points held by `script DCOFix` (coDimUnitTests); Neumann groups with time ranges; `attach`
+    ("mat_on_segments", "otherExamples/coDimUnitTests/mat40x40_segPlaneDrop.txt", "", 4),
+    ("mat_on_points", "otherExamples/coDimUnitTests/mat40x40_pointPlaneDrop.txt", "", 4),
+    ("nbc_time_range", "tutorialExamples/BC/2cubesFall_NBC_timeRange.txt", "", 22),
+    ("attach", "tutorialExamples/advanced/2cubesFall_attach.txt", "", 22),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
