@@ -598,9 +598,12 @@ def assemble(cfg, read_mesh):
     if cfg.script == "dragright":
         # AnimScripter.cpp:809-826: lifted like `fall`, the nodes within 4 % of the right end of the body become a NONZERO handle
         # pulled at 0.5 in +x; stepAnimScript lets go once the whole body is right of every mesh obstacle (:1619-1632)
-        V[:nSim, 1] += 0.5 * np.linalg.norm(V[:nSim].max(0) - V[:nSim].min(0))
-        lo, hi = V[:nSim].min(0), V[:nSim].max(0)
-        ids = np.nonzero(V[:nSim, 0] > hi[0] - 0.04 * (hi[0] - lo[0]))[0].astype(np.int32)
+        # (the script works on mesh.V, the START positions: with `rotateModel` those are not the rest shape -- 13_dolphinFunnel.txt; found by
+        # running that scene through the reference: lift and handle were taken from the rest shape before)
+        U = V if V0 is None else V0
+        U[:nSim, 1] += 0.5 * np.linalg.norm(U[:nSim].max(0) - U[:nSim].min(0))
+        lo, hi = U[:nSim].min(0), U[:nSim].max(0)
+        ids = np.nonzero(U[:nSim, 0] > hi[0] - 0.04 * (hi[0] - lo[0]))[0].astype(np.int32)
         dirichlet = [(ids, (0.5, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
         limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
         release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}

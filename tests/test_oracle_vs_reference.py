@@ -414,6 +414,7 @@ SHIPPED_SCENES = [
     ("mat_on_segments", 0, 1e-13),  # coDimUnitTests/mat40x40_segPlaneDrop.txt: a mat on a bed of 210 held segments -- counts and positions to round-off
     ("mat_on_points", 0, 1e-13),  # ... on 420 held points
     ("nbc_time_range", 0, 1e-12),  # Neumann groups with time ranges through the first touch-down
+    ("dolphin_funnel", 0, 1e-5),  # 13_dolphinFunnel.txt: `script dragright` + `rotateModel` + a funnel (meshCO), 8 111 nodes
     ("attach", 0, 5e-3),  # 2cubesFall_attach.txt: every count through the impact (positions: a touch-down from exact rest)
 ]
 

@@ -298,6 +298,9 @@ SCENES += [
     ("mat_on_points", "otherExamples/coDimUnitTests/mat40x40_pointPlaneDrop.txt", "", 4),
     ("nbc_time_range", "tutorialExamples/BC/2cubesFall_NBC_timeRange.txt", "", 22),
     ("attach", "tutorialExamples/advanced/2cubesFall_attach.txt", "", 22),
+    # 13_dolphinFunnel.txt as shipped: `script dragright` on a model that `rotateModel` turns at the start (lift and handle follow the START
+    # positions), a funnel as mesh collision object, no gravity
+    ("dolphin_funnel", "paperExamples/13_dolphinFunnel.txt", "", 3),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
