@@ -97,7 +97,6 @@ struct HipOptimizerParts {
         if (mode == HIP_OPT_RESIDENT) {
             const char* why = nullptr;
             if (!residentScript(cfg.animScriptType)) why = "this script is not built into the resident stepper";
-            else if (cfg.useAbsParameters) why = "absolute tuning parameters";
             else if (!cfg.inputShapeMeshSeqFolderPath.empty()) why = "a mesh sequence (ipcgpu_opt_set_dirichlet_targets is driven by the scene tooling only)";
             else if (cfg.isConstrained && cfg.constraintSolverType != CST_IP) why = "a constraint solver other than interiorPoint";
             else if (!cfg.isConstrained && (cfg.collisionObjects.size() || cfg.meshCollisionObjects.size())) why = "unconstrained run with collision objects";
@@ -412,9 +411,13 @@ protected:
         const double selfFric = selfCollision ? cfg.selfFric : 0.0;
         if (Base::solveFric) {
             chk(ipcgpu_opt_set_friction(ctx, selfFric, cfg.fricIterAmt, epsV));
+            const double epsVTarget = cfg.tuning.size() > 5 ? cfg.tuning[5] : 1.0e-3; // Optimizer.cpp:296-299
+            if (epsVTarget > 0.0 && epsVTarget != epsV) chk(ipcgpu_opt_set_friction_target(ctx, epsVTarget));
             if (selfFric > 0.0 && !obst.empty()) chk(ipcgpu_opt_set_friction_scales(ctx, 1.0, 0.0));
             if (!(selfFric > 0.0) && !planeFric) chk(ipcgpu_opt_force_friction_loop(ctx, 1));
         }
+        // useAbsParameters, tuning[3], kappaMinMultiplier (Config.cpp:553-558; Optimizer.cpp:102-109, 279-302, 2228-2233, 2941-2945)
+        chk(ipcgpu_opt_set_parameter_scaling(ctx, cfg.useAbsParameters ? 1 : 0, cfg.tuning.size() > 3 ? cfg.tuning[3] : 1.0e-9, cfg.kappaMinMultiplier));
         if (cfg.tuning.size() > 0 && cfg.tuning[0] > 0.0) chk(ipcgpu_opt_set_kappa(ctx, cfg.tuning[0]));
         {
             const double target = cfg.tuning.size() > 2 ? cfg.tuning[2] : 1.0e-3; // Optimizer.cpp:283-289

@@ -263,6 +263,15 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, doubl
    time step at eps_v (fifth entry) and is halved down -- or clamped up -- to eps_v_target between the friction-lag passes (:1776-1781); the
    tangent-space convergence test runs only once it has arrived (:1717).  <= 0: the target is eps_v itself (what the `epsv` keyword sets). */
 int ipcgpu_opt_set_friction_target(ipcgpu_ctx*, double eps_v_target);
+/* The three remaining knobs of the scene file behind the interior-point lengths (Config.cpp:553-558, Config.hpp:138-139):
+ *   useAbsParameters   dHat, its homotopy target, dTol, eps_v (and its target) and the Newton tolerance are ABSOLUTE lengths instead of fractions
+ *                      of the rest-shape bounding-box diagonal (Optimizer.cpp:107-109, 279-302, 1535-1537, 2941-2945); suggestKappa's
+ *                      distances and CN_MBC stay relative there too (:268, 2228-2233)
+ *   dTolRel            tuning[3] (1e-9): below dTol = dTolRel^2 (x diagonal^2) a converged distance ends the homotopy / the close-pair
+ *                      bookkeeping counts a stencil (:102-109, 1710, 1744, 2409-2434)
+ *   kappaMinMultiplier 1e11 (`kappaMinMultiplier` / `minBarrierStiffnessScale`): numerator of suggestKappa and, x 100, of upperBoundKappa
+ * Call it after the collision objects are registered or before -- the derived lengths are recomputed. */
+int ipcgpu_opt_set_parameter_scaling(ipcgpu_ctx*, int useAbsParameters, double dTolRel, double kappaMinMultiplier);
 /* MeshCO::friction (Config.cpp:459-474, MeshCO.cpp) beside Config::selfFric: a kinematic mesh obstacle carries its own friction
  * coefficient for the pairs that involve it.  Pass the larger coefficient to ipcgpu_opt_set_friction and the ratios here: the lagged
  * normal forces (MMLambda_lastH) of stencils without / with an obstacle node are multiplied by scaleSelf / scaleObstacle. */

@@ -1038,6 +1038,13 @@ int ipcgpu_opt_set_friction_target(ipcgpu_ctx* c, double epsVTarget)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_parameter_scaling(ipcgpu_ctx* c, int useAbsParameters, double dTolRel, double kappaMinMultiplier)
+{
+    return guarded([&] {
+        O(c).setParameterScaling(useAbsParameters != 0, dTolRel, kappaMinMultiplier);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_kappa(ipcgpu_ctx* c, double kappa)
 {
     return guarded([&] {

@@ -113,6 +113,7 @@ public:
     HipOptimizer(HipMesh& mesh, HipLinSysSolver& lin, hipStream_t s);
     void init(double dt, bool withGravity);
     void setRelGL2Tol(double relTol);
+    void setParameterScaling(bool absolute, double dTolRel, double kappaMinMultiplier); // useAbsParameters / tuning[3] / kappaMinMultiplier
     void setTwist(int nL, const int* left, int nR, const int* right, double angVel);
     void precompute();
     void beginTimestep();
@@ -247,6 +248,9 @@ public:
     HipContact* contact = nullptr;
     bool selfCollision = false;
     double dHatEps = 1.0e-3, dHat = 0, kappa = 0, dTol = 0;
+    bool absParameters = false; // useAbsParameters: lengths of `tuning` and the tolerance are absolute (Config.cpp:553-555)
+    double dTolRel = 1.0e-9, kappaMinMultiplier = 1.0e11; // tuning[3] (Optimizer.cpp:102-106), Config.hpp:139
+    double lenScale2() const { return absParameters ? 1.0 : mesh.bboxDiag2; }
     std::vector<std::pair<int, int>> curExtra; // contact connectivity inside the current pattern (vNeighbor_IP)
     std::vector<std::array<int, 4>> closeID; // closeMConstraintID / Val (Optimizer.cpp:2396-2440)
     std::vector<double> closeVal;

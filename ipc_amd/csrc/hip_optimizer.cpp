@@ -101,8 +101,24 @@ void HipOptimizer::init(double dt_, bool withGravity)
 void HipOptimizer::setRelGL2Tol(double relTol)
 {
     relGL2Tol = relTol * relTol;
-    targetGRes = std::sqrt(relGL2Tol * mesh.bboxDiag2 * dtSq); // Optimizer.cpp:2941-2945
+    targetGRes = std::sqrt(relGL2Tol * (absParameters ? 1.0 : mesh.bboxDiag2 * dtSq)); // Optimizer.cpp:2941-2945
     CN_MBC = std::sqrt(1.0e-4 * mesh.bboxDiag2 * dtSq); // Optimizer.cpp:268
+}
+
+void HipOptimizer::setParameterScaling(bool absolute, double dTolRel_, double kappaMinMultiplier_)
+{
+    // `useAbsParameters`, tuning[3], `kappaMinMultiplier` of the scene file (Config.cpp:553-558, Optimizer.cpp:102-109, 279-302, 1535-1537,
+    // 2228-2233, 2941-2945): dHat, its target, dTol, eps_v and the Newton tolerance are absolute lengths instead of fractions of the
+    // bounding-box diagonal; the distances of suggestKappa and CN_MBC stay relative there too
+    if (!(dTolRel_ > 0.0) || !(kappaMinMultiplier_ > 0.0)) throw ArgError("set_parameter_scaling: dTolRel and kappaMinMultiplier must be positive");
+    absParameters = absolute;
+    dTolRel = dTolRel_;
+    kappaMinMultiplier = kappaMinMultiplier_;
+    targetGRes = std::sqrt(relGL2Tol * (absParameters ? 1.0 : mesh.bboxDiag2 * dtSq));
+    if (ipOn()) {
+        dHat = dHatEps * dHatEps * lenScale2();
+        dTol = dTolRel * dTolRel * lenScale2();
+    }
 }
 
 void HipOptimizer::setTwist(int nL, const int* left, int nR, const int* right, double angVel)
@@ -367,7 +383,7 @@ bool HipOptimizer::nextSubproblem()
 {
     // tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS, HOMOTOPY_VAR 1)
     if (!ipOn()) return false;
-    const double dHatTarget = dHatTargetEps > 0.0 ? dHatTargetEps * dHatTargetEps * mesh.bboxDiag2 : dHat;
+    const double dHatTarget = dHatTargetEps > 0.0 ? dHatTargetEps * dHatTargetEps * lenScale2() : dHat;
     const bool fric = solveFric(), homotopy = dHat > dHatTarget;
     if (!fric && !homotopy) return false; // every active distance is below dHat = dHatTarget: nothing left to update (:1706-1709, 1754-1757)
     fricIterI++;
@@ -438,8 +454,8 @@ int HipOptimizer::addHalfSpace(HipContact* c, const double* origin3, const doubl
     contact = c;
     planes.emplace_back(new HipHalfSpace(stream, origin3, normal3));
     dHatEps = eps;
-    dHat = eps * eps * mesh.bboxDiag2;
-    dTol = 1.0e-18 * mesh.bboxDiag2;
+    dHat = eps * eps * lenScale2();
+    dTol = dTolRel * dTolRel * lenScale2();
     return (int)planes.size() - 1;
 }
 
@@ -461,8 +477,8 @@ void HipOptimizer::enableSelfCollision(HipContact* c, double eps)
     selfCollision = true;
     if (const char* e = std::getenv("IPCGPU_PATTERN_PAD")) patternPad = std::atof(e); // < 1: exact pattern, 1: full stencils of the current candidates, > 1: also look ahead in distance
     dHatEps = eps;
-    dHat = eps * eps * mesh.bboxDiag2;
-    dTol = 1.0e-18 * mesh.bboxDiag2; // dTolRel = 1e-9 (Optimizer.cpp:102-109)
+    dHat = eps * eps * lenScale2();
+    dTol = dTolRel * dTolRel * lenScale2(); // dTolRel = tuning[3], 1e-9 by default (Optimizer.cpp:102-109)
 }
 
 void HipOptimizer::computeXTilta()
@@ -609,7 +625,7 @@ double HipOptimizer::kappaFloor() const
     for (int v = 0; v < mesh.nV; ++v)
         if (!mesh.nElemNodes || mesh.inMesh[v]) avgMass += mesh.mass[v];
     avgMass /= std::max(mesh.nElemNodes, 1);
-    return 1.0e11 * avgMass / (4.0e-16 * mesh.bboxDiag2 * Hb);
+    return kappaMinMultiplier * avgMass / (4.0e-16 * mesh.bboxDiag2 * Hb);
 }
 
 void HipOptimizer::initKappa()
@@ -1232,7 +1248,7 @@ void HipOptimizer::beginTimestep()
     }
     if (ipOn()) {
         // fullyImplicit_IP head (Optimizer.cpp:1534-1550, 2316-2322): dHat, constraint sets, kappa, empty close-pair list
-        dHat = dHatEps * dHatEps * mesh.bboxDiag2;
+        dHat = dHatEps * dHatEps * lenScale2();
         computeConstraintSets();
         // tuning[0] when the script gives one, bounded from above; 0 -> suggestKappa (Optimizer.cpp:1540-1547)
         kappa = kappaConfig > 0.0 ? std::min(kappaConfig, 100 * kappaFloor()) : kappaFloor();
@@ -1244,8 +1260,8 @@ void HipOptimizer::beginTimestep()
         // friction: lagged sets reset, eps_v^2 h^2 (Optimizer.cpp:1525-1533, 286-304), then lagged at x^n (:1553-1600)
         if (contact) contact->frictionLagClear();
         for (auto& h : planes) h->lagClear();
-        fricDHat0 = epsV * epsV * dtSq * mesh.bboxDiag2;
-        fricDHatTarget = epsVTarget > 0.0 ? epsVTarget * epsVTarget * dtSq * mesh.bboxDiag2 : fricDHat0;
+        fricDHat0 = epsV * epsV * dtSq * lenScale2();
+        fricDHatTarget = epsVTarget > 0.0 ? epsVTarget * epsVTarget * dtSq * lenScale2() : fricDHat0;
         fricDHat = solveFric() ? fricDHat0 : -1.0;
         fricIterI = 0;
         updateFrictionLag();

@@ -572,6 +572,11 @@ class Context:
         """eps_v homotopy target (`tuning`'s sixth entry); <= 0: the same as eps_v"""
         self._chk(self._L.ipcgpu_opt_set_friction_target(self.h, C.c_double(eps_v_target)))
 
+    def set_parameter_scaling(self, use_abs_parameters=False, dtol_rel=1e-9, kappa_min_multiplier=1e11):
+        """`useAbsParameters`, tuning[3] and `kappaMinMultiplier` of the scene file (Config.cpp:553-558)"""
+        self._chk(self._L.ipcgpu_opt_set_parameter_scaling(self.h, C.c_int(int(use_abs_parameters)), C.c_double(dtol_rel),
+                                                           C.c_double(kappa_min_multiplier)))
+
     def set_friction(self, self_fric=0.0, fric_iter_amt=1, eps_v=1e-3):
         self._chk(self._L.ipcgpu_opt_set_friction(self.h, C.c_double(self_fric), C.c_int(fric_iter_amt), C.c_double(eps_v)))
 

@@ -67,6 +67,9 @@ class SceneConfig:
     dHat_eps: float = 1e-3  # tuning[1]
     eps_v: float = 1e-3  # tuning[4]
     eps_v_target: float = -1.0  # tuning[5]; < 0: the same as eps_v (the `epsv` keyword sets both)
+    dtol_rel: float = 1e-9  # tuning[3] (Optimizer.cpp:102-106)
+    use_abs_parameters: bool = False  # Config.cpp:553-555: the lengths of `tuning` and the tolerance are absolute
+    kappa_min_multiplier: float = 1e11  # Config.cpp:556-558, Config.hpp:139
     fric_iter_amt: int = 1
     rot_axis: tuple = (0.0, 0.0, 0.0)  # rotateModel ax ay az deg (Config.cpp:523-526)
     rot_deg: float = 0.0
@@ -222,8 +225,13 @@ class SceneConfig:
                 cfg.kappa = max(vals[0], 0.0) if len(vals) > 0 else 0.0  # the start value of every time step (Optimizer.cpp:1540-1547)
                 cfg.dHat_eps = vals[1] if len(vals) > 1 else 1e-3
                 cfg.dHat_target = vals[2] if len(vals) > 2 else 1e-3  # Optimizer.cpp:283-289: without a third entry the target is 1e-3 (relative)
+                cfg.dtol_rel = vals[3] if len(vals) > 3 else 1e-9
                 cfg.eps_v = vals[4] if len(vals) > 4 else 1e-3
                 cfg.eps_v_target = vals[5] if len(vals) > 5 else 1e-3  # Optimizer.cpp:296-299: without a sixth entry the target is 1e-3
+            elif k == "useAbsParameters":  # Config.cpp:553-555
+                cfg.use_abs_parameters = True
+            elif k in ("kappaMinMultiplier", "minBarrierStiffnessScale"):  # Config.cpp:556-558
+                cfg.kappa_min_multiplier = float(a[0])
             elif k == "section":  # Config.cpp:572-605: settings for one constraint solver; other solvers' sections are skipped
                 names = ["interiorPoint" if x == "IP" else x for x in a]
                 if "end" not in names and "interiorPoint" not in names:
@@ -769,6 +777,8 @@ def apply(sc, be):
             be.set_friction_scales(*fric_scales)
         if loop_only:
             be.force_friction_loop(True)
+    if cfg.use_abs_parameters or cfg.dtol_rel != 1e-9 or cfg.kappa_min_multiplier != 1e11:
+        be.set_parameter_scaling(cfg.use_abs_parameters, cfg.dtol_rel, cfg.kappa_min_multiplier)
     if cfg.kappa > 0:
         be.set_kappa(cfg.kappa)
     if 0 < cfg.dHat_target < cfg.dHat_eps:

@@ -693,6 +693,10 @@ class Friction:
         return a
 
 
+def opt_set_parameter_scaling(opt: "Optimizer", use_abs_parameters=False, dtol_rel=1e-9, kappa_min_multiplier=1e11):
+    lib().orc_opt_set_parameter_scaling(opt.h, C.c_int(int(use_abs_parameters)), C.c_double(dtol_rel), C.c_double(kappa_min_multiplier))
+
+
 def opt_set_friction_target(opt: "Optimizer", eps_v_target):
     lib().orc_opt_set_friction_target(opt.h, C.c_double(eps_v_target))
 

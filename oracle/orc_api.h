@@ -116,6 +116,7 @@ int orc_opt_solve_timestep(orc_opt*, int maxIter); // returns # Newton iteration
 // state readers
 void orc_opt_get(const orc_opt*, double* V_colmajor, double* searchDir, double* gradient, double* scalars8);
 // scalars8 = {lastEnergyVal, lastStepSize, targetGRes, innerIterAmt, timestep, lastAlphaFeasible, 0, 0}
+void orc_opt_set_parameter_scaling(orc_opt*, int useAbsParameters, double dTolRel, double kappaMinMultiplier); // Config.cpp:553-558
 void orc_opt_set_friction_target(orc_opt*, double eps_v_target); // eps_v homotopy (tuning[5]); <= 0: none
 void orc_opt_set_warm_start(orc_opt*, int option); // Config warmStart: initX option 0..4 (Optimizer.cpp:925-1080)
 double orc_opt_warm_step(const orc_opt*);

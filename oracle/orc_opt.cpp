@@ -29,6 +29,9 @@ struct orc_opt {
     double elCoef() const { return tit == 1 ? dtSq * betaNM : dtSq; } // Optimizer.cpp:3205-3224, 3416-3434, 3618-3632
     int nthreads;
     double relGL2Tol = 1.0e-8, targetGRes = 0;
+    bool absParameters = false; // useAbsParameters (Config.cpp:553-555)
+    double dTolRel = 1.0e-9, kappaMinMultiplier = 1.0e11; // tuning[3] (Optimizer.cpp:102-106), Config.hpp:139
+    double lenScale2() const { return absParameters ? 1.0 : m->bboxDiag2; }
     std::vector<double> velocity, xTilta, V_prev, searchDir, gradient, a;
     // lagged stiffness-proportional damping (Optimizer.cpp:3723-3735): the projected element Hessians at the state the last time
     // step ended in, times dampingStiff / dt, rows and columns of Dirichlet nodes dropped
@@ -413,7 +416,7 @@ double kappaFloor(orc_opt* o)
     for (int v = 0; v < m.nV; ++v)
         if (!m.nElemNodes || m.inMesh[v]) avgMass += m.mass[v];
     avgMass /= std::max(m.nElemNodes, 1);
-    return 1.0e11 * avgMass / (4.0e-16 * m.bboxDiag2 * Hb);
+    return o->kappaMinMultiplier * avgMass / (4.0e-16 * m.bboxDiag2 * Hb);
 }
 
 void initKappa(orc_opt* o)
@@ -613,7 +616,7 @@ void orc_opt_destroy(orc_opt* o)
 void orc_opt_set_rel_tol(orc_opt* o, double relTol)
 {
     o->relGL2Tol = relTol * relTol;
-    o->targetGRes = std::sqrt(o->relGL2Tol * o->m->bboxDiag2 * o->dtSq); // Optimizer.cpp:2941-2945
+    o->targetGRes = std::sqrt(o->relGL2Tol * (o->absParameters ? 1.0 : o->m->bboxDiag2 * o->dtSq)); // Optimizer.cpp:2941-2945
 }
 void orc_opt_set_velocity(orc_opt* o, const double* vel3nV)
 {
@@ -625,8 +628,8 @@ void orc_opt_enable_self_collision(orc_opt* o, double dHatEps)
     // `selfCollisionOn` + interior point; dHat = dHatEps^2 * bbox diagonal^2 (Optimizer.cpp:1534-1537, Config.cpp:41-45)
     o->selfCollision = true;
     o->dHatEps = dHatEps;
-    o->dHat = dHatEps * dHatEps * o->m->bboxDiag2;
-    o->dTol = 1.0e-18 * o->m->bboxDiag2; // dTolRel = 1e-9 (Optimizer.cpp:102-109)
+    o->dHat = dHatEps * dHatEps * o->lenScale2();
+    o->dTol = o->dTolRel * o->dTolRel * o->lenScale2(); // dTolRel = tuning[3], 1e-9 by default (Optimizer.cpp:102-109)
 }
 int orc_opt_add_half_space(orc_opt* o, const double* origin3, const double* normal3, double dHatEps)
 {
@@ -639,8 +642,8 @@ int orc_opt_add_half_space(orc_opt* o, const double* origin3, const double* norm
     o->hsLagSet.emplace_back();
     o->hsLambda.emplace_back();
     o->dHatEps = dHatEps;
-    o->dHat = dHatEps * dHatEps * o->m->bboxDiag2;
-    o->dTol = 1.0e-18 * o->m->bboxDiag2;
+    o->dHat = dHatEps * dHatEps * o->lenScale2();
+    o->dTol = o->dTolRel * o->dTolRel * o->lenScale2();
     return (int)o->planes.size() - 1;
 }
 int orc_opt_get_half_space_set(const orc_opt* o, int id, int* verts)
@@ -899,7 +902,7 @@ void orc_opt_begin_timestep(orc_opt* o)
         o->warmStepSize = stepSize;
     }
     if (o->ipOn()) {
-        o->dHat = o->dHatEps * o->dHatEps * m.bboxDiag2;
+        o->dHat = o->dHatEps * o->dHatEps * o->lenScale2();
         computeConstraintSets(o);
         // tuning[0] when the script gives one, bounded from above; 0 -> suggestKappa (Optimizer.cpp:1540-1547)
         o->kappa = o->kappaConfig > 0.0 ? std::min(o->kappaConfig, 100 * kappaFloor(o)) : kappaFloor(o);
@@ -911,8 +914,8 @@ void orc_opt_begin_timestep(orc_opt* o)
         // friction: lagged sets reset, eps_v^2 h^2 (Optimizer.cpp:1525-1533, 286-304), then lagged at x^n (:1553-1600)
         o->lag = FrictionLag();
         for (auto& s : o->hsLagSet) s.clear();
-        o->fricDHat0 = o->epsV * o->epsV * o->dtSq * m.bboxDiag2;
-        o->fricDHatTarget = o->epsVTarget > 0.0 ? o->epsVTarget * o->epsVTarget * o->dtSq * m.bboxDiag2 : o->fricDHat0;
+        o->fricDHat0 = o->epsV * o->epsV * o->dtSq * o->lenScale2();
+        o->fricDHatTarget = o->epsVTarget > 0.0 ? o->epsVTarget * o->epsVTarget * o->dtSq * o->lenScale2() : o->fricDHat0;
         o->fricDHat = o->solveFric() ? o->fricDHat0 : -1.0;
         o->fricIterI = 0;
         updateFrictionLag(o);
@@ -1094,7 +1097,7 @@ int orc_opt_next_subproblem(orc_opt* o)
     // tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS, HOMOTOPY_VAR 1)
     if (!o->ipOn()) return 0;
     Mesh& m = *o->m;
-    const double dHatTarget = o->dHatTargetEps > 0.0 ? o->dHatTargetEps * o->dHatTargetEps * m.bboxDiag2 : o->dHat;
+    const double dHatTarget = o->dHatTargetEps > 0.0 ? o->dHatTargetEps * o->dHatTargetEps * o->lenScale2() : o->dHat;
     const bool fric = o->solveFric(), homotopy = o->dHat > dHatTarget;
     if (!fric && !homotopy) return 0; // every active distance is below dHat = dHatTarget: nothing left to update (:1706-1709, 1754-1757)
     o->fricIterI++;
@@ -1226,6 +1229,18 @@ void orc_opt_get_contact(const orc_opt* o, int* counts6, int* active4, int* para
     if (para4)
         for (size_t i = 0; i < o->cs.paraEE.size(); ++i)
             for (int k = 0; k < 4; ++k) para4[4 * i + k] = o->cs.paraEE[i][k];
+}
+void orc_opt_set_parameter_scaling(orc_opt* o, int useAbs, double dTolRel, double kappaMinMultiplier)
+{
+    // useAbsParameters / tuning[3] / kappaMinMultiplier (Config.cpp:553-558; Optimizer.cpp:102-109, 279-302, 1535-1537, 2228-2233, 2941-2945)
+    o->absParameters = useAbs != 0;
+    o->dTolRel = dTolRel;
+    o->kappaMinMultiplier = kappaMinMultiplier;
+    o->targetGRes = std::sqrt(o->relGL2Tol * (o->absParameters ? 1.0 : o->m->bboxDiag2 * o->dtSq));
+    if (o->selfCollision || !o->planes.empty()) {
+        o->dHat = o->dHatEps * o->dHatEps * o->lenScale2();
+        o->dTol = dTolRel * dTolRel * o->lenScale2();
+    }
 }
 void orc_opt_set_friction_target(orc_opt* o, double epsVTarget) { o->epsVTarget = epsVTarget > 0.0 ? epsVTarget : -1.0; }
 void orc_opt_set_warm_start(orc_opt* o, int option)

@@ -328,6 +328,7 @@ MORE_SCENES = [
     ("aligned_cubes_fric", 12, 2, 1e-2),  # + selfFric: friction between the cubes, none with the mesh collision object
     ("cubes_dhat_homotopy", 13, 5, 5e-2),  # SQPBenchmark/11_cubes.txt: kappa start value + dHat homotopy (9 Newton iterations per free-fall step)
     ("point_triangle_rotated", 0, 2, 1e-4),  # SQPBenchmark/04_pointTriangle.txt: `rotateModel 1 0 0 -90`, homotopy, warmStart 1: all 45 counts equal, positions 1e-8 (the turned start differs in its last bits)
+    ("point_triangle_abs_parameters", 0, 2, 1e-4),  # the same scene with `useAbsParameters`, `kappaMinMultiplier 3e10` and a six-entry `tuning` (dHat 8e-2 -> 2e-3 as absolute lengths, dTol 1e-8): 30 steps through the impact
     ("two_cubes_nm_damped", 18, 6, 5e-2),  # tutorialExamples/advanced/2cubesFall_NM.txt: Newmark + dampingRatio; the counts differ after the touch-down
 ]
 

@@ -192,6 +192,9 @@ SCENES = [
     ("cubes_dhat_homotopy", "paperExamples/supplementB/SQPBenchmark/11_cubes.txt", "", 20),
     # `rotateModel` (start positions turned against the rest shape), `tuning 2` homotopy, warm start 1, point-triangle impact
     ("point_triangle_rotated", "paperExamples/supplementB/SQPBenchmark/04_pointTriangle.txt", "", 45),
+    # `useAbsParameters` (dHat, its target, dTol and the Newton tolerance as ABSOLUTE lengths), `kappaMinMultiplier`, a fourth `tuning` entry
+    ("point_triangle_abs_parameters", "paperExamples/supplementB/SQPBenchmark/04_pointTriangle.txt",
+     "\nuseAbsParameters\nkappaMinMultiplier 3e10\ntuning 6\n0\n8e-2\n2e-3\n1e-8\n1e-3\n1e-3\ntol 1\n2e-2\n", 45),
     ("two_cubes_nm_damped", "tutorialExamples/advanced/2cubesFall_NM.txt", "\ntime 5 0.025\n", 36),  # every step written at this step size
 ]
 
