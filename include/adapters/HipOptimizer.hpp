@@ -97,6 +97,7 @@ struct HipOptimizerParts {
         if (mode == HIP_OPT_RESIDENT) {
             const char* why = nullptr;
             if (!residentScript(cfg.animScriptType)) why = "this script is not built into the resident stepper";
+            else if (cfg.ccdMethod != ccd::CCDMethod::FLOATING_POINT_ROOT_FINDER) why = "a CCD back end other than the default (the library builds the step bound of FloatingPointRootFinder only)";
             else if (!cfg.inputShapeMeshSeqFolderPath.empty()) why = "a mesh sequence (ipcgpu_opt_set_dirichlet_targets is driven by the scene tooling only)";
             else if (cfg.isConstrained && cfg.constraintSolverType != CST_IP) why = "a constraint solver other than interiorPoint";
             else if (!cfg.isConstrained && (cfg.collisionObjects.size() || cfg.meshCollisionObjects.size())) why = "unconstrained run with collision objects";

@@ -195,3 +195,16 @@ def test_reference_main_codimensional_shapes_resident(name, tol, tmp_path):
     S, meshes = load_scene(name)
     pos, its, _ = run_main_hip(S, meshes, tmp_path, int(S["steps"]))
     check_codim(S, pos, its, tol)
+
+
+@pytest.mark.gpu
+@needs_exe
+def test_reference_main_absolute_parameters_resident(tmp_path):
+    """`useAbsParameters`, `kappaMinMultiplier` and a six-entry `tuning` read by the reference's Config and handed over by HipOptimizer
+    (ipcgpu_opt_set_parameter_scaling, ipcgpu_opt_set_dhat_target): the Newton counts of the reference's own run, through the impact."""
+    S, meshes = load_scene("point_triangle_abs_parameters")
+    steps = 30
+    pos, its, log = run_main_hip(S, meshes, tmp_path, steps)
+    assert "percall mode" not in log
+    assert np.array_equal(its, S["iters"][:steps]), (its.tolist(), S["iters"][:steps].tolist())
+    assert np.abs(pos[-1] - S["positions"][steps - 1]).max() <= 1e-6 * np.abs(S["positions"][steps - 1]).max()
