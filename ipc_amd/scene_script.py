@@ -67,6 +67,8 @@ class SceneConfig:
     dHat_eps: float = 1e-3  # tuning[1]
     eps_v: float = 1e-3  # tuning[4]
     eps_v_target: float = -1.0  # tuning[5]; < 0: the same as eps_v (the `epsv` keyword sets both)
+    dbc_time_range: tuple = (0.0, math.inf)  # `DBCTimeRange t0 t1` (Config.cpp:175-177): every Dirichlet group acts inside it only (AnimScripter.cpp:99, 1440)
+    nbc_time_range: tuple = (0.0, math.inf)  # `NBCTimeRange t0 t1` (Config.cpp:178-180; AnimScripter.cpp:2372-2375)
     dtol_rel: float = 1e-9  # tuning[3] (Optimizer.cpp:102-106)
     use_abs_parameters: bool = False  # Config.cpp:553-555: the lengths of `tuning` and the tolerance are absolute
     kappa_min_multiplier: float = 1e11  # Config.cpp:556-558, Config.hpp:139
@@ -228,6 +230,10 @@ class SceneConfig:
                 cfg.dtol_rel = vals[3] if len(vals) > 3 else 1e-9
                 cfg.eps_v = vals[4] if len(vals) > 4 else 1e-3
                 cfg.eps_v_target = vals[5] if len(vals) > 5 else 1e-3  # Optimizer.cpp:296-299: without a sixth entry the target is 1e-3
+            elif k == "DBCTimeRange":
+                cfg.dbc_time_range = (float(a[0]), float(a[1]))
+            elif k == "NBCTimeRange":
+                cfg.nbc_time_range = (float(a[0]), float(a[1]))
             elif k == "useAbsParameters":  # Config.cpp:553-555
                 cfg.use_abs_parameters = True
             elif k in ("kappaMinMultiplier", "minBarrierStiffnessScale"):  # Config.cpp:556-558
@@ -786,11 +792,12 @@ def apply(sc, be):
     if cfg.damping_stiff > 0:
         be.set_damping(cfg.damping_stiff)
     for g, (ids, lin, ang, t0, t1) in enumerate(sc.dirichlet):
+        t0, t1 = max(t0, cfg.dbc_time_range[0]), min(t1, cfg.dbc_time_range[1])  # a group acts where its own range and the scene's overlap
         be.add_dirichlet(ids, lin_vel=lin, ang_vel_deg=ang, t0=t0, t1=t1)
         if sc.motions is not None:
             be.set_dirichlet_motion(g, lin_vel=sc.motions[g][0], ang_vel_deg=sc.motions[g][1], center=sc.motions[g][2], force_nonzero=True)
     for ids, acc, t0, t1 in sc.neumann:
-        be.add_neumann(ids, acc, t0=t0, t1=t1)
+        be.add_neumann(ids, acc, t0=max(t0, cfg.nbc_time_range[0]), t1=min(t1, cfg.nbc_time_range[1]))
     if cfg.script == "twist":
         left, right = _scene.border_verts(sc.V, 0.01)
         be.set_twist(left, right)

@@ -55,6 +55,8 @@ def test_grammar():
     assert path == "/r/input/triMeshes/plane.obj" and np.allclose(origin, [0.5, 0, 0.5]) and scale == 10 and mu == 1.0 and np.allclose(rot, [0, 0, 30])
     c = ss.SceneConfig.parse("shapes input 1\nm.seg 0 0 0 0 0 0 1 1 1 meshSeq dir\n", "/r")
     assert c.shapes[0].mesh_seq == "/r/dir"
+    c = ss.SceneConfig.parse("DBCTimeRange 0.1 0.5\nNBCTimeRange 0.2 1\n")
+    assert c.dbc_time_range == (0.1, 0.5) and c.nbc_time_range == (0.2, 1.0)
     c = ss.SceneConfig.parse("useAbsParameters\nminBarrierStiffnessScale 2e10\ntuning 4\n0 1e-2 1e-3\n2e-10\n")
     assert c.use_abs_parameters and c.kappa_min_multiplier == 2e10 and (c.dHat_eps, c.dHat_target, c.dtol_rel, c.eps_v) == (1e-2, 1e-3, 2e-10, 1e-3)
     for bad in ("script DCOHammerWalnut\n", "constraintSolver QP\n", "CCDMethod TightInclusion\n"):

@@ -195,6 +195,9 @@ SCENES = [
     # `useAbsParameters` (dHat, its target, dTol and the Newton tolerance as ABSOLUTE lengths), `kappaMinMultiplier`, a fourth `tuning` entry
     ("point_triangle_abs_parameters", "paperExamples/supplementB/SQPBenchmark/04_pointTriangle.txt",
      "\nuseAbsParameters\nkappaMinMultiplier 3e10\ntuning 6\n0\n8e-2\n2e-3\n1e-8\n1e-3\n1e-3\ntol 1\n2e-2\n", 45),
+    # the scene-wide `DBCTimeRange` / `NBCTimeRange` (Config.cpp:175-180): groups act where their own range and the scene's overlap
+    ("dbc_global_time_range", "tutorialExamples/BC/2cubesFall_DBC_timeRange.txt", "\nDBCTimeRange 0.1 0.25\n", 14),
+    ("nbc_global_time_range", "tutorialExamples/BC/2cubesFall_NBC.txt", "\nNBCTimeRange 0.1 0.2\ntol 1\n1e-5\n", 14),
     ("two_cubes_nm_damped", "tutorialExamples/advanced/2cubesFall_NM.txt", "\ntime 5 0.025\n", 36),  # every step written at this step size
 ]
 
