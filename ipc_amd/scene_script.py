@@ -67,6 +67,7 @@ class SceneConfig:
     dHat_eps: float = 1e-3  # tuning[1]
     eps_v: float = 1e-3  # tuning[4]
     eps_v_target: float = -1.0  # tuning[5]; < 0: the same as eps_v (the `epsv` keyword sets both)
+    handle_ratio: float = 0.01  # `handleRatio r` (Config.cpp:528-531): the width, in bounding-box extents, of the border slabs the handle scripts take (main.cpp:1180)
     dbc_time_range: tuple = (0.0, math.inf)  # `DBCTimeRange t0 t1` (Config.cpp:175-177): every Dirichlet group acts inside it only (AnimScripter.cpp:99, 1440)
     nbc_time_range: tuple = (0.0, math.inf)  # `NBCTimeRange t0 t1` (Config.cpp:178-180; AnimScripter.cpp:2372-2375)
     dtol_rel: float = 1e-9  # tuning[3] (Optimizer.cpp:102-106)
@@ -230,6 +231,14 @@ class SceneConfig:
                 cfg.dtol_rel = vals[3] if len(vals) > 3 else 1e-9
                 cfg.eps_v = vals[4] if len(vals) > 4 else 1e-3
                 cfg.eps_v_target = vals[5] if len(vals) > 5 else 1e-3  # Optimizer.cpp:296-299: without a sixth entry the target is 1e-3
+            elif k == "handleRatio":
+                cfg.handle_ratio = float(a[0])
+                if not 0 < cfg.handle_ratio < 0.5:
+                    raise ValueError("handleRatio must lie in (0, 0.5) (Config.cpp:530)")
+            elif k in ("linearSolver", "linSysSolver"):
+                pass  # Config.cpp:120-124 picks CHOLMOD / AMGCL / Eigen inside the reference; the library brings its own factorisation
+            elif k in ("CCDTolerance", "ccdTolerance"):
+                pass  # Config.cpp:569-571: read by the TightInclusion back end only (Optimizer.cpp:1149, 1173); the default method takes none
             elif k == "DBCTimeRange":
                 cfg.dbc_time_range = (float(a[0]), float(a[1]))
             elif k == "NBCTimeRange":
@@ -668,7 +677,7 @@ def assemble(cfg, read_mesh):
         rng = hi - lo
         still = ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), None)
         if cfg.script == "hangLeft":  # AnimScripter.cpp:191-204: the left border nodes (IglUtils::findBorderVerts, handleRatio 0.01) are held (ZERO)
-            left, _right = _scene.border_verts(U[:nSim], 0.01)
+            left, _right = _scene.border_verts(U[:nSim], cfg.handle_ratio)
             dirichlet = [(np.asarray(left, dtype=np.int32), (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf"))]
         elif cfg.script == "fixLowerHalf":  # AnimScripter.cpp:337-350: the lower half of the model is held (NONZERO, no motion)
             ids = np.nonzero(U[:nSim, 1] < lo[1] + rng[1] * 0.5)[0].astype(np.int32)
@@ -799,7 +808,7 @@ def apply(sc, be):
     for ids, acc, t0, t1 in sc.neumann:
         be.add_neumann(ids, acc, t0=max(t0, cfg.nbc_time_range[0]), t1=min(t1, cfg.nbc_time_range[1]))
     if cfg.script == "twist":
-        left, right = _scene.border_verts(sc.V, 0.01)
+        left, right = _scene.border_verts(sc.V, cfg.handle_ratio)
         be.set_twist(left, right)
     if np.any(sc.velocity):
         be.set_velocity(sc.velocity)
