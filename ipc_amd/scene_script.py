@@ -124,7 +124,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") + HANDLE_SCRIPTS and a[0] not in DCO_SCRIPTS:
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS and a[0] not in DCO_SCRIPTS:
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
                 if len(a) > 1 and int(a[1]) > 0:  # `script name n p1 .. pn` (Config.cpp:166-175): parameters of the script
@@ -408,6 +408,12 @@ DCO_SCRIPTS = {
 
 # scripts that pick their Dirichlet / Neumann nodes from the bounding box of the assembled mesh (set-up in AnimScripter::initAnimScript)
 HANDLE_SCRIPTS = ("fixLowerHalf", "pushRightMost1", "utopiaComparison", "DCOSegBedSquash", "hangLeft")
+# nodes picked by a box rule of the start positions and HELD (ZERO: taken out of the system; NONZERO: a Dirichlet set that does not move), or moved
+# at a constant velocity (AnimScripter.cpp:153-189, 224-247, 284-297, 318-373, 459-473, 502-516, 790-807, 860-893; per step :1536-1551, 1597-1603,
+# 1817-1826); `drop`, `leftHitRight`, `XYRotate` only give start velocities (:853-858, 1336-1374)
+HOLD_SCRIPTS = ("hang", "hang2", "hangTopLeft", "stamp", "stampTopLeft", "stampBoth", "stand", "topbottomfix", "corner", "fixRightMost1")
+PULL_SCRIPTS = ("stretch", "squash", "dragdown", "curtain")
+INITVEL_SCRIPTS = ("drop", "leftHitRight", "XYRotate")
 
 
 @dataclass
@@ -578,13 +584,72 @@ def assemble(cfg, read_mesh):
         if V0 is not None:
             V0[:nSim] -= lo
     if cfg.script in ("fall", "fallNoShift"):  # AnimScripter.cpp:779-788: lifted by half the bounding-box diagonal, no Dirichlet nodes
-        if cfg.script == "fall":  # Mesh<3> only: the obstacles are not part of it in the reference
+        if cfg.script == "fall":  # Mesh<3> only: the obstacles are not part of it in the reference (dragdown lifts the same way, below)
             U = V if V0 is None else V0
             lift = 0.5 * np.linalg.norm(U[:nSim].max(0) - U[:nSim].min(0))
             V[:nSim, 1] += lift
             if V0 is not None:
                 V0[:nSim, 1] += lift
         dirichlet = []
+    if cfg.script in HOLD_SCRIPTS + PULL_SCRIPTS:
+        if cfg.script == "dragdown":  # AnimScripter.cpp:790-792: lifted like `fall`
+            U = V if V0 is None else V0
+            lift = 0.5 * np.linalg.norm(U[:nSim].max(0) - U[:nSim].min(0))
+            V[:nSim, 1] += lift
+            if V0 is not None:
+                V0[:nSim, 1] += lift
+        U = (V if V0 is None else V0)[:nSim]
+        lo, hi = U.min(0), U.max(0)  # mesh.V.colwise().minCoeff() / maxCoeff()
+        rng = hi - lo
+        left, right = _scene.border_verts(U, cfg.handle_ratio)  # mesh.borderVerts_primitive (main.cpp:1180)
+        ids32 = lambda m: np.nonzero(m)[0].astype(np.int32)  # noqa: E731
+        inf = float("inf")
+        zero3 = (0.0, 0.0, 0.0)
+        hold = None  # (node ids, ZERO?)
+        if cfg.script == "hang":  # the LAST node of either border set, ZERO
+            hold = (np.array([b[-1] for b in (left, right) if len(b)], dtype=np.int32), True)
+        elif cfg.script == "hang2":  # the top 1 %, ZERO
+            hold = (ids32(U[:, 1] > hi[1] - rng[1] * 0.01), True)
+        elif cfg.script == "hangTopLeft":  # the nodes of the left border set in the top 1 % and within 1 % of either z end, ZERO
+            L = np.asarray(left)
+            m = (U[L, 1] > hi[1] - rng[1] * 0.01) & ((U[L, 2] > hi[2] - rng[2] * 0.01) | (U[L, 2] < lo[2] + rng[2] * 0.01))
+            hold = (L[m].astype(np.int32), True)
+        elif cfg.script == "stamp":
+            hold = (np.asarray(left, dtype=np.int32), False)
+        elif cfg.script == "stampTopLeft":
+            L = np.asarray(left)
+            hold = (L[U[L, 1] > hi[1] - rng[1] * 0.01].astype(np.int32), False)
+        elif cfg.script == "stampBoth":
+            hold = (np.concatenate([left, right]).astype(np.int32), False)
+        elif cfg.script == "stand":  # the bottom 1 %
+            hold = (ids32(U[:, 1] < lo[1] + rng[1] * 0.01), False)
+        elif cfg.script == "topbottomfix":  # the bottom and the top 2 %
+            hold = (ids32((U[:, 1] < lo[1] + rng[1] * 0.02) | (U[:, 1] > hi[1] - rng[1] * 0.02)), False)
+        elif cfg.script == "corner":  # within 1 % of the x, y or z minimum
+            hold = (ids32((U[:, 0] < lo[0] + rng[0] * 0.01) | (U[:, 1] < lo[1] + rng[1] * 0.01) | (U[:, 2] < lo[2] + rng[2] * 0.01)), False)
+        elif cfg.script == "fixRightMost1":  # the FIRST node within 1e-3 of the right end
+            hold = (ids32(U[:, 0] > hi[0] - 1.0e-3 * rng[0])[:1], False)
+        if hold is not None:
+            hp_dirichlet = [(hold[0], zero3, zero3, 0.0, inf)] if len(hold[0]) else []
+            hp_motions = None if hold[1] or not hp_dirichlet else [(zero3, zero3, None)]
+        else:
+            groups = []
+            if cfg.script in ("stretch", "squash"):  # the border sets pulled apart at 0.1 / pushed together at 0.03 along x
+                v = -0.1 if cfg.script == "stretch" else 0.03
+                groups = [(np.asarray(left, dtype=np.int32), (v, 0.0, 0.0)), (np.asarray(right, dtype=np.int32), (-v, 0.0, 0.0))]
+            elif cfg.script == "dragdown":  # the middle of the bottom tenth pulled down at 1.5
+                m = (U[:, 1] < lo[1] + rng[1] * 0.1) & (U[:, 0] < lo[0] + rng[0] * 0.52) & (U[:, 0] > lo[0] + rng[0] * 0.42)
+                groups = [(ids32(m), (0.0, -1.5, 0.0))]
+            else:  # curtain: eight pins along the top edge, pin i drawn in +x at 0.04 (7 - i) / 7; a node takes the first pin that fits
+                taken = np.zeros(len(U), dtype=bool)
+                for pin in range(8):
+                    x0 = lo[0] + rng[0] / 7.0 * pin
+                    m = (U[:, 0] > x0 - rng[0] * 0.0025) & (U[:, 0] < x0 + rng[0] * 0.0025) & (U[:, 1] > hi[1] - rng[1] * 0.005) & ~taken
+                    taken |= m
+                    groups.append((ids32(m), (0.04 * (7.0 - pin) / 7.0, 0.0, 0.0)))
+            groups = [g for g in groups if len(g[0])]
+            hp_dirichlet = [(ids, lin, zero3, 0.0, inf) for ids, lin in groups]
+            hp_motions = [(lin, zero3, None) for _ids, lin in groups]
     codim_nodes = codim_mass = codim_fixed = None
     codim_edges = np.vstack(CEs).astype(np.int32) if CEs else np.zeros((0, 2), dtype=np.int32)
     if codim:
@@ -631,6 +696,8 @@ def assemble(cfg, read_mesh):
         limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
         release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}
     motions = None  # per Dirichlet group: (lin, ang in degrees, fixed centre or None) with the nodes typed NONZERO throughout
+    if cfg.script in HOLD_SCRIPTS + PULL_SCRIPTS:  # resetDBCVertices(): the scripts replace whatever the shapes' own DBC keywords selected
+        dirichlet, motions = hp_dirichlet, hp_motions
     if cfg.script in DCO_SCRIPTS:
         spec = DCO_SCRIPTS[cfg.script]
         U = V if V0 is None else V0
@@ -719,6 +786,18 @@ def assemble(cfg, read_mesh):
         for s in range(len(cfg.shapes)):
             if tr[s + 1] > tr[s]:
                 vel[nr[s]:nr[s + 1], 0] = vx
+    if cfg.script in INITVEL_SCRIPTS:  # AnimScripter::initVelocity (AnimScripter.cpp:1336-1374), over every node of Mesh<3>
+        U = (V if V0 is None else V0)[:nSim]
+        lo, hi = U.min(0), U.max(0)
+        rng = hi - lo
+        if cfg.script == "drop":
+            vel[:nSim, 1] = -1.0
+        elif cfg.script == "leftHitRight":
+            vel[:nSim][U[:, 0] < lo[0] + rng[0] / 2.0, 0] = 1.0
+        else:
+            bottom = U[:, 1] < lo[1] + rng[1] * 0.01
+            vel[:nSim][bottom, 0] = 1.0
+            vel[:nSim][~bottom & (U[:, 1] > hi[1] - rng[1] * 0.01), 0] = -1.0
     for s, sh in enumerate(cfg.shapes):  # AnimScripter::initVelocity (AnimScripter.cpp:1319-1333): `initVel` under `script null` only
         if sh.init_vel is None or cfg.script != "null" or not tr[s + 1] > tr[s]:
             continue

@@ -8,9 +8,9 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import (CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, SHIPPED_SCENES, check_chain, check_codim, check_damped_bar,
+from test_oracle_vs_reference import (BOXRULE_SCENES, CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, SHIPPED_SCENES, check_chain, check_codim, check_damped_bar,
                                       check_plates, check_shipped,
-                                      check_restart, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
+                                      check_boxrule, check_restart, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -304,6 +304,16 @@ def test_handle_scripts_against_the_reference(name, gpu_lib):
     c.close()
     assert np.array_equal(its, S["iters"])
     assert np.abs(pos - S["positions"]).max() <= 1e-11 * np.abs(S["positions"]).max()
+
+
+@pytest.mark.parametrize("name,tol", BOXRULE_SCENES)
+def test_box_rule_scripts_against_the_reference(name, tol, gpu_lib):
+    """hang2 / corner / squash / dragdown / leftHitRight on the HIP stepper"""
+    S, meshes = load_scene(name)
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    check_boxrule(S, pos, its, 3 * tol)
 
 
 def test_seg_bed_squash_against_the_reference(gpu_lib):

@@ -488,6 +488,25 @@ def test_handle_scripts_against_the_reference(name):
     assert np.abs(S["positions"][-1] - S["positions"][0]).max() > 1e-4  # something moves
 
 
+# box-rule scripts of AnimScripter::initAnimScript that hold nodes (hang2: ZERO, corner: NONZERO), move them at a constant velocity (squash;
+# dragdown -- a sheet pulled through the barrier of a ground plane, 10 to 24 Newton iterations per step) or only set start velocities
+# (leftHitRight), each on one of the reference's small meshes, run by the reference: (fixture, position tolerance -- the solves stop at 1e-4)
+BOXRULE_SCENES = [("script_hang2", 3e-6), ("script_corner", 1e-6), ("script_squash", 1e-6), ("script_dragdown", 3e-6), ("script_left_hit_right", 3e-6)]
+
+
+def check_boxrule(S, pos, its, tol):
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    assert np.abs(pos - S["positions"]).max() <= tol * np.abs(S["positions"]).max()
+    assert np.abs(S["positions"][-1] - S["positions"][0]).max() > 1e-3  # something moves
+
+
+@pytest.mark.parametrize("name,tol", BOXRULE_SCENES)
+def test_box_rule_scripts_against_the_reference(name, tol):
+    S, meshes = load_scene(name)
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    check_boxrule(S, pos, its, tol)
+
+
 def check_seg_bed(S, pos, its):
     """`script DCOSegBedSquash` (AnimScripter.cpp:1239-1259, 2080-2100): the beds of segments (the nodes behind the cube's eight) follow the
     rule exactly -- the upper one comes down at 1 and stops 0.1 above the lower one; the cube between them has the reference's Newton counts

@@ -55,6 +55,8 @@ def test_grammar():
     assert path == "/r/input/triMeshes/plane.obj" and np.allclose(origin, [0.5, 0, 0.5]) and scale == 10 and mu == 1.0 and np.allclose(rot, [0, 0, 30])
     c = ss.SceneConfig.parse("shapes input 1\nm.seg 0 0 0 0 0 0 1 1 1 meshSeq dir\n", "/r")
     assert c.shapes[0].mesh_seq == "/r/dir"
+    for name in ss.HOLD_SCRIPTS + ss.PULL_SCRIPTS + ss.INITVEL_SCRIPTS:
+        assert ss.SceneConfig.parse(f"script {name}\n").script == name
     c = ss.SceneConfig.parse("DBCTimeRange 0.1 0.5\nNBCTimeRange 0.2 1\n")
     assert c.dbc_time_range == (0.1, 0.5) and c.nbc_time_range == (0.2, 1.0)
     c = ss.SceneConfig.parse("useAbsParameters\nminBarrierStiffnessScale 2e10\ntuning 4\n0 1e-2 1e-3\n2e-10\n")

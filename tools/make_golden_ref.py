@@ -261,7 +261,29 @@ input/segMeshes/edge.seg 1 1 0.04  0 0 0  0.3 0.3 0.3
 selfCollisionOn
 constraintSolver interiorPoint
 """
+_BOXRULE = """energy NH
+time 1 0.02
+density 1000
+stiffness 1e5 0.4
+script %s
+shapes input 1
+%s
+selfCollisionOff
+tol 1
+1e-4
+%s
+"""
+_BAR, _MAT, _MAT_UPRIGHT = ("input/tetMeshes/bar-186.msh 0 0 0  0 0 0  1 1 1", "input/tetMeshes/mat20x20.msh 0 0 0  0 0 0  1 1 1",
+                            "input/tetMeshes/mat20x20.msh 0 0 0  0 0 90  1 1 1")
 INLINE = {
+    # more scripts that pick nodes by a box rule of the start positions: the top 1 % of an upright sheet held (ZERO); the x < 1 %, y < 1 % or z < 1 %
+    # nodes of a bar held (NONZERO); the two ends of a bar pushed together at 0.03; the middle of the bottom tenth of a lifted sheet dragged down
+    # at 1.5 through a ground plane's barrier; the left half of a bar starting at +1 in x
+    "inline:script_hang2": _BOXRULE % ("hang2", _MAT_UPRIGHT, ""),
+    "inline:script_corner": _BOXRULE % ("corner", _BAR, ""),
+    "inline:script_squash": _BOXRULE % ("squash", _BAR, ""),
+    "inline:script_dragdown": _BOXRULE % ("dragdown", _MAT, "ground 0.1 0"),
+    "inline:script_left_hit_right": _BOXRULE % ("leftHitRight", _BAR, "turnOffGravity"),
     # scripts that pick their handles from the bounding box of the mesh (AnimScripter::initAnimScript): the lower half of a cube held under
     # gravity; one corner node pushed in -x; the bottom held and the top pressed down by a Neumann acceleration
     "inline:fix_lower_half": _HANDLES % ("fixLowerHalf", ""),
@@ -307,6 +329,11 @@ SCENES += [
     # 13_dolphinFunnel.txt as shipped: `script dragright` on a model that `rotateModel` turns at the start (lift and handle follow the START
     # positions), a funnel as mesh collision object, no gravity
     ("dolphin_funnel", "paperExamples/13_dolphinFunnel.txt", "", 3),
+    ("script_hang2", "inline:script_hang2", "", 6),
+    ("script_corner", "inline:script_corner", "", 6),
+    ("script_squash", "inline:script_squash", "", 6),
+    ("script_dragdown", "inline:script_dragdown", "", 6),
+    ("script_left_hit_right", "inline:script_left_hit_right", "", 6),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
