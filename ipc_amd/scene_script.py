@@ -124,7 +124,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS and a[0] not in DCO_SCRIPTS:
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS + RULE_SCRIPTS and a[0] not in DCO_SCRIPTS:
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
                 if len(a) > 1 and int(a[1]) > 0:  # `script name n p1 .. pn` (Config.cpp:166-175): parameters of the script
@@ -414,6 +414,8 @@ HANDLE_SCRIPTS = ("fixLowerHalf", "pushRightMost1", "utopiaComparison", "DCOSegB
 HOLD_SCRIPTS = ("hang", "hang2", "hangTopLeft", "stamp", "stampTopLeft", "stampBoth", "stand", "topbottomfix", "corner", "fixRightMost1")
 PULL_SCRIPTS = ("stretch", "squash", "dragdown", "curtain")
 INITVEL_SCRIPTS = ("drop", "leftHitRight", "XYRotate")
+# handle sets that move, turn round or stop by a rule on one "turning" node (AnimScripter.cpp:375-457, 518-553, 574-631; per step :1554-1595, 1648-1729)
+RULE_SCRIPTS = ("push", "tear", "upndown", "undstamp", "stretchnsquash", "bend", "twistnstretch", "twistnsns", "twistnsns_old")
 
 
 @dataclass
@@ -471,6 +473,20 @@ class AssembledScene:
                 be.set_dirichlet_motion(r["group"], lin_vel=(0.0, -1.0, 0.0) if moving else (0.0, 0.0, 0.0), force_nonzero=True)
                 return True
             return False
+        if r.get("kind") == "turn":
+            # one node decides (velocityTurningPoints): outside its window the listed velocity components change sign -- every step it is found
+            # outside, as written (AnimScripter.cpp:1568-1595, 1648-1660, 1702-1729) -- or, `push`, the handles stop for good (:1554-1566)
+            c = x[r["turn"], r["axis"]]
+            if not (c <= r["lo"] or c >= r["hi"]):
+                return False
+            if r["stop"]:
+                r["lin"] = [(0.0, 0.0, 0.0) if g in r["groups"] else v for g, v in enumerate(r["lin"])]
+                r["done"] = True
+            else:
+                r["lin"] = [tuple(-c_ if k == r["comp"] else c_ for k, c_ in enumerate(v)) if g in r["groups"] else v for g, v in enumerate(r["lin"])]
+            for g in r["groups"]:
+                be.set_dirichlet_motion(g, lin_vel=r["lin"][g], ang_vel_deg=r["ang"][g], center=r["ctr"][g], force_nonzero=True)
+            return True
         if r.get("kind") == "pause":
             # `script stretchAndPause` (AnimScripter.cpp:1605-1616): the handles move while the turning vertex has not passed x = -0.28;
             # from then on every Dirichlet node is held (vertexDBCType ZERO)
@@ -650,6 +666,48 @@ def assemble(cfg, read_mesh):
             groups = [g for g in groups if len(g[0])]
             hp_dirichlet = [(ids, lin, zero3, 0.0, inf) for ids, lin in groups]
             hp_motions = [(lin, zero3, None) for _ids, lin in groups]
+    rule_release = None
+    if cfg.script in RULE_SCRIPTS:
+        U = (V if V0 is None else V0)[:nSim]
+        lo, hi = U.min(0), U.max(0)
+        rng = hi - lo
+        left, right = (np.asarray(b, dtype=np.int32) for b in _scene.border_verts(U, cfg.handle_ratio))
+        ids32 = lambda m: np.nonzero(m)[0].astype(np.int32)  # noqa: E731
+        zero3 = (0.0, 0.0, 0.0)
+        ctr_rest = tuple(0.5 * (V[:nSim].min(0) + V[:nSim].max(0)))  # mesh.bbox.colwise().mean(): the rest shape's box
+        groups = []  # (ids, lin, ang in degrees, centre)
+        turn = None  # (node, axis, lo, hi, component that changes sign, groups it applies to, stop instead)
+        if cfg.script in ("push", "tear"):  # bottom 1 % held; top 1 % pushed down at 1 until it is 0.5 lower / dragged in -x at 5, turning at 4 further left
+            bottom = U[:, 1] < lo[1] + rng[1] * 0.01
+            top = ids32(~bottom & (U[:, 1] > hi[1] - rng[1] * 0.01))
+            groups = [(ids32(bottom), zero3, zero3, None), (top, (0.0, -1.0, 0.0) if cfg.script == "push" else (-5.0, 0.0, 0.0), zero3, None)]
+            if len(top):
+                turn = (int(top[0]), 1, U[top[0], 1] - 0.5, np.inf, 1, [1], True) if cfg.script == "push" else (int(top[0]), 0, U[top[0], 0] - 4.0, np.inf, 0, [1], False)
+        elif cfg.script in ("upndown", "undstamp"):  # the border sets (undstamp: the left one) go up / down at 1.8, turning 0.6 above and below the start
+            sets = [left, right] if cfg.script == "upndown" else [left]
+            groups = [(b, (0.0, (-1.0) ** i * 1.8, 0.0), zero3, None) for i, b in enumerate(sets)]
+            turn = (int(left[0]), 1, U[left[0], 1] - 0.6, U[left[0], 1] + 0.6, 1, list(range(len(sets))), False)
+        elif cfg.script == "stretchnsquash":  # pulled apart at 0.9, turning when the first left node is 0.8 further out / 0.4 further in
+            groups = [(b, ((-1.0) ** i * -0.9, 0.0, 0.0), zero3, None) for i, b in enumerate((left, right))]
+            turn = (int(left[0]), 0, U[left[0], 0] - 0.8, U[left[0], 0] + 0.4, 0, [0, 1], False)
+        elif cfg.script == "bend":  # every border node but the last of its set turns about z through that last one at 0.05 pi (9 degrees) per unit time
+            for i, b in enumerate((left, right)):
+                groups.append((b[:-1], zero3, (0.0, 0.0, (-1.0) ** i * -9.0), tuple(U[b[-1]])))
+                groups.append((b[-1:], zero3, zero3, None))
+        else:  # twist about x through the rest box centre + a pull along x; twistnsns turns the pull round like stretchnsquash
+            w, v, out = {"twistnstretch": (18.0, 0.1, None), "twistnsns": (72.0, 1.2, 1.2), "twistnsns_old": (72.0, 0.9, 0.8)}[cfg.script]
+            groups = [(b, ((-1.0) ** i * -v, 0.0, 0.0), ((-1.0) ** i * -w, 0.0, 0.0), ctr_rest) for i, b in enumerate((left, right))]
+            if out is not None:
+                turn = (int(left[0]), 0, U[left[0], 0] - out, U[left[0], 0] + 0.4, 0, [0, 1], False)
+        keep = [k for k, g in enumerate(groups) if len(g[0])]
+        remap = {k: i for i, k in enumerate(keep)}
+        groups = [groups[k] for k in keep]
+        hp_dirichlet = [(ids, lin, ang, 0.0, float("inf")) for ids, lin, ang, _c in groups]
+        hp_motions = [(lin, ang, c) for _ids, lin, ang, c in groups]
+        if turn is not None:
+            rule_release = {"kind": "turn", "turn": turn[0], "axis": turn[1], "lo": float(turn[2]), "hi": float(turn[3]), "comp": turn[4],
+                            "groups": [remap[g] for g in turn[5] if g in remap], "stop": turn[6], "lin": [m[0] for m in hp_motions],
+                            "ang": [m[1] for m in hp_motions], "ctr": [m[2] for m in hp_motions], "done": False}
     codim_nodes = codim_mass = codim_fixed = None
     codim_edges = np.vstack(CEs).astype(np.int32) if CEs else np.zeros((0, 2), dtype=np.int32)
     if codim:
@@ -696,8 +754,10 @@ def assemble(cfg, read_mesh):
         limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
         release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}
     motions = None  # per Dirichlet group: (lin, ang in degrees, fixed centre or None) with the nodes typed NONZERO throughout
-    if cfg.script in HOLD_SCRIPTS + PULL_SCRIPTS:  # resetDBCVertices(): the scripts replace whatever the shapes' own DBC keywords selected
+    if cfg.script in HOLD_SCRIPTS + PULL_SCRIPTS + RULE_SCRIPTS:  # resetDBCVertices(): the scripts replace whatever the shapes' own DBC keywords selected
         dirichlet, motions = hp_dirichlet, hp_motions
+        if cfg.script in RULE_SCRIPTS:
+            release = rule_release
     if cfg.script in DCO_SCRIPTS:
         spec = DCO_SCRIPTS[cfg.script]
         U = V if V0 is None else V0

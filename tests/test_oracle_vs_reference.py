@@ -491,7 +491,10 @@ def test_handle_scripts_against_the_reference(name):
 # box-rule scripts of AnimScripter::initAnimScript that hold nodes (hang2: ZERO, corner: NONZERO), move them at a constant velocity (squash;
 # dragdown -- a sheet pulled through the barrier of a ground plane, 10 to 24 Newton iterations per step) or only set start velocities
 # (leftHitRight), each on one of the reference's small meshes, run by the reference: (fixture, position tolerance -- the solves stop at 1e-4)
-BOXRULE_SCENES = [("script_hang2", 3e-6), ("script_corner", 1e-6), ("script_squash", 1e-6), ("script_dragdown", 3e-6), ("script_left_hit_right", 3e-6)]
+BOXRULE_SCENES = [("script_hang2", 3e-6), ("script_corner", 1e-6), ("script_squash", 1e-6), ("script_dragdown", 3e-6), ("script_left_hit_right", 3e-6),
+                  # ... and handles that turn round by a rule on one node (before_step kind "turn"): upndown turns in step 8, twistnsns_old twists at
+                  # 0.4 pi while it pulls, twistnstretch at 0.1 pi, tear drags the top of a cube and turns 4 further left (every node scripted: exact)
+                  ("script_upndown", 3e-6), ("script_twistnsns_old", 5e-6), ("script_twistnstretch", 5e-6), ("script_tear", 1e-14)]
 
 
 def check_boxrule(S, pos, its, tol):

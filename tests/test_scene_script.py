@@ -55,7 +55,7 @@ def test_grammar():
     assert path == "/r/input/triMeshes/plane.obj" and np.allclose(origin, [0.5, 0, 0.5]) and scale == 10 and mu == 1.0 and np.allclose(rot, [0, 0, 30])
     c = ss.SceneConfig.parse("shapes input 1\nm.seg 0 0 0 0 0 0 1 1 1 meshSeq dir\n", "/r")
     assert c.shapes[0].mesh_seq == "/r/dir"
-    for name in ss.HOLD_SCRIPTS + ss.PULL_SCRIPTS + ss.INITVEL_SCRIPTS:
+    for name in ss.HOLD_SCRIPTS + ss.PULL_SCRIPTS + ss.INITVEL_SCRIPTS + ss.RULE_SCRIPTS:
         assert ss.SceneConfig.parse(f"script {name}\n").script == name
     c = ss.SceneConfig.parse("DBCTimeRange 0.1 0.5\nNBCTimeRange 0.2 1\n")
     assert c.dbc_time_range == (0.1, 0.5) and c.nbc_time_range == (0.2, 1.0)

@@ -284,6 +284,12 @@ INLINE = {
     "inline:script_squash": _BOXRULE % ("squash", _BAR, ""),
     "inline:script_dragdown": _BOXRULE % ("dragdown", _MAT, "ground 0.1 0"),
     "inline:script_left_hit_right": _BOXRULE % ("leftHitRight", _BAR, "turnOffGravity"),
+    # scripts whose handles turn round or stop by a rule on one node: the ends of a bar going up / down at 1.8 and turning 0.6 from the start (step 8);
+    # a twist at 0.4 pi with a pull at 0.9 that turns round; a twist at 0.1 pi with a steady pull; the top of a cube dragged at 5, turning 4 further left
+    "inline:script_upndown": (_BOXRULE % ("upndown", _BAR, "")).replace("time 1 0.02", "time 1 0.05"),
+    "inline:script_twistnsns_old": (_BOXRULE % ("twistnsns_old", _BAR, "")).replace("time 1 0.02", "time 1 0.05"),
+    "inline:script_twistnstretch": (_BOXRULE % ("twistnstretch", _BAR, "")).replace("time 1 0.02", "time 1 0.1"),
+    "inline:script_tear": (_BOXRULE % ("tear", "input/tetMeshes/cube.msh 0 0 0  0 0 0  1 1 1", "")).replace("time 1 0.02", "time 1 0.1"),
     # scripts that pick their handles from the bounding box of the mesh (AnimScripter::initAnimScript): the lower half of a cube held under
     # gravity; one corner node pushed in -x; the bottom held and the top pressed down by a Neumann acceleration
     "inline:fix_lower_half": _HANDLES % ("fixLowerHalf", ""),
@@ -334,6 +340,10 @@ SCENES += [
     ("script_squash", "inline:script_squash", "", 6),
     ("script_dragdown", "inline:script_dragdown", "", 6),
     ("script_left_hit_right", "inline:script_left_hit_right", "", 6),
+    ("script_upndown", "inline:script_upndown", "", 12),
+    ("script_twistnsns_old", "inline:script_twistnsns_old", "", 14),
+    ("script_twistnstretch", "inline:script_twistnstretch", "", 8),
+    ("script_tear", "inline:script_tear", "", 12),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
