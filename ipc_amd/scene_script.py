@@ -415,7 +415,11 @@ HOLD_SCRIPTS = ("hang", "hang2", "hangTopLeft", "stamp", "stampTopLeft", "stampB
 PULL_SCRIPTS = ("stretch", "squash", "dragdown", "curtain")
 INITVEL_SCRIPTS = ("drop", "leftHitRight", "XYRotate")
 # handle sets that move, turn round or stop by a rule on one "turning" node (AnimScripter.cpp:375-457, 518-553, 574-631; per step :1554-1595, 1648-1729)
-RULE_SCRIPTS = ("push", "tear", "upndown", "undstamp", "stretchnsquash", "bend", "twistnstretch", "twistnsns", "twistnsns_old")
+RULE_SCRIPTS = ("push", "tear", "upndown", "undstamp", "stretchnsquash", "bend", "twistnstretch", "twistnsns", "twistnsns_old",
+                # handle sets that are LET GO (the others stop) when the turning node has travelled far enough (:633-760, 827-851; per step :1731-1812)
+                "rubberBandPull", "fourLegPull", "headTailPull", "toggleTop",
+                # start positions changed and / or nodes held (:129-151, 206-222, 265-282, 299-316), Neumann pull on the top (:912-954)
+                "scaleF", "swing", "stampInv", "standInv", "NMFixBottomDragLeft", "NMFixBottomDragForward")
 
 
 @dataclass
@@ -486,6 +490,16 @@ class AssembledScene:
                 r["lin"] = [tuple(-c_ if k == r["comp"] else c_ for k, c_ in enumerate(v)) if g in r["groups"] else v for g, v in enumerate(r["lin"])]
             for g in r["groups"]:
                 be.set_dirichlet_motion(g, lin_vel=r["lin"][g], ang_vel_deg=r["ang"][g], center=r["ctr"][g], force_nonzero=True)
+            return True
+        if r.get("kind") == "let_go":
+            c = x[r["turn"], r["axis"]]
+            if not (c <= r["limit"] if r["below"] else c >= r["limit"]):
+                return False
+            for g in r["free"]:
+                be.end_dirichlet(g, t)
+            for g in r["stop"]:
+                be.set_dirichlet_motion(g, lin_vel=(0.0, 0.0, 0.0), force_nonzero=True)
+            r["done"] = True
             return True
         if r.get("kind") == "pause":
             # `script stretchAndPause` (AnimScripter.cpp:1605-1616): the handles move while the turning vertex has not passed x = -0.28;
@@ -677,6 +691,8 @@ def assemble(cfg, read_mesh):
         ctr_rest = tuple(0.5 * (V[:nSim].min(0) + V[:nSim].max(0)))  # mesh.bbox.colwise().mean(): the rest shape's box
         groups = []  # (ids, lin, ang in degrees, centre)
         turn = None  # (node, axis, lo, hi, component that changes sign, groups it applies to, stop instead)
+        let_go = None
+        rule_zero = False  # the held set is typed ZERO
         if cfg.script in ("push", "tear"):  # bottom 1 % held; top 1 % pushed down at 1 until it is 0.5 lower / dragged in -x at 5, turning at 4 further left
             bottom = U[:, 1] < lo[1] + rng[1] * 0.01
             top = ids32(~bottom & (U[:, 1] > hi[1] - rng[1] * 0.01))
@@ -694,6 +710,56 @@ def assemble(cfg, read_mesh):
             for i, b in enumerate((left, right)):
                 groups.append((b[:-1], zero3, (0.0, 0.0, (-1.0) ** i * -9.0), tuple(U[b[-1]])))
                 groups.append((b[-1:], zero3, zero3, None))
+        elif cfg.script in ("rubberBandPull", "fourLegPull", "headTailPull", "toggleTop"):
+            y0, y1, x0, x1, z0, z1 = lo[1], hi[1], lo[0], hi[0], lo[2], hi[2]
+            if cfg.script == "rubberBandPull":  # bottom / top 2 % drawn apart at 0.2, the waist pulled in -x at 2.5 and let go 5 further left
+                a = U[:, 1] < y0 + rng[1] * 0.02
+                b = ~a & (U[:, 1] > y1 - rng[1] * 0.02)
+                w = ~a & ~b & (U[:, 1] < y1 - rng[1] * 0.48) & (U[:, 1] > y0 + rng[1] * 0.48)
+                sets = [(a, (0.0, -0.2, 0.0), False), (b, (0.0, 0.2, 0.0), False), (w, (-2.5, 0.0, 0.0), True)]
+                lim = (2, 0, -5.0, True)  # (set whose first node decides, axis, offset of the limit, "<=")
+            elif cfg.script == "fourLegPull":
+                a = (U[:, 1] > y1 - rng[1] * 0.129) & (U[:, 0] < x0 + rng[0] * 0.16)
+                b = ~a & (U[:, 1] > y1 - rng[1] * 0.16) & (U[:, 0] > x1 - rng[0] * 0.16)
+                c = ~a & ~b & (U[:, 1] < y0 + rng[1] * 0.02) & (U[:, 0] > x1 - rng[0] * 0.25)
+                d = ~a & ~b & ~c & (U[:, 1] < y0 + rng[1] * 0.02) & (U[:, 0] < x0 + rng[0] * 0.25)
+                sets = [(a, zero3, False), (b, (2.5, 0.0, 0.0), True), (c, (2.5, -3.5, 0.0), True), (d, (0.0, -3.5, 0.0), True)]
+                lim = (3, 1, -5.0, True)
+            elif cfg.script == "headTailPull":
+                a = U[:, 2] < z0 + rng[2] * 0.02
+                b = ~a & (U[:, 2] > z1 - rng[2] * 0.02)
+                c = ~a & ~b & (U[:, 2] > z0 + rng[2] * 0.46) & (U[:, 2] < z0 + rng[2] * 0.54)
+                sets = [(a, (3.5, 0.0, 0.0), True), (b, (3.5, 0.0, 0.0), True), (c, zero3, False)]
+                lim = (0, 0, 4.5, False)
+            else:  # toggleTop: the top 2 % drawn in -x at 0.5 and let go 0.1 further left
+                sets = [(U[:, 1] > y1 - rng[1] * 0.02, (-0.5, 0.0, 0.0), True)]
+                lim = (0, 0, -0.1, True)
+            groups = [(ids32(m), lin, zero3, None) for m, lin, _f in sets]
+            first = groups[lim[0]][0]
+            if len(first):
+                let_go = {"kind": "let_go", "turn": int(first[0]), "axis": lim[1], "limit": float(U[first[0], lim[1]] + lim[2]), "below": lim[3],
+                          "free": [k for k, (_m, _l, f) in enumerate(sets) if f], "stop": [k for k, (_m, _l, f) in enumerate(sets) if not f], "done": False}
+        elif cfg.script in ("scaleF", "swing", "stampInv", "standInv", "NMFixBottomDragLeft", "NMFixBottomDragForward"):
+            W = V if V0 is None else V0  # the start positions themselves (the rest shape stays)
+            if cfg.script in ("scaleF", "stampInv", "standInv", "swing") and V0 is None:
+                V0 = V.copy()
+                W = V0
+            if cfg.script == "scaleF":  # every start position times 1.5 about the origin
+                W[:nSim] *= 1.5
+            elif cfg.script == "swing":  # lifted by 1.3 heights, the left 5 % held (ZERO)
+                W[:nSim, 1] += 1.3 * rng[1]
+                groups = [(ids32(U[:, 0] < lo[0] + rng[0] * 0.05), zero3, zero3, None)]
+                rule_zero = True
+            elif cfg.script in ("stampInv", "standInv"):  # the left / bottom 1 % held; the start turned inside out and squeezed to a tenth about it
+                ax = 0 if cfg.script == "stampInv" else 1
+                held = ids32(U[:, ax] < lo[ax] + rng[ax] * 0.01)
+                groups = [(held, zero3, zero3, None)]
+                off = 1.1 * U[held[0], ax]  # *mesh.DBCVertexIds.begin(): the smallest held index
+                W[:nSim, ax] = -0.1 * W[:nSim, ax] + off
+            else:  # the bottom 5 % held, the top 5 % pulled by a Neumann acceleration of 600 in -x / +x
+                bottom = U[:, 1] < lo[1] + rng[1] * 0.05
+                groups = [(ids32(bottom), zero3, zero3, None)]
+                neumann = [(ids32(~bottom & (U[:, 1] > hi[1] - rng[1] * 0.05)), (-600.0 if cfg.script == "NMFixBottomDragLeft" else 600.0, 0.0, 0.0), 0.0, float("inf"))]
         else:  # twist about x through the rest box centre + a pull along x; twistnsns turns the pull round like stretchnsquash
             w, v, out = {"twistnstretch": (18.0, 0.1, None), "twistnsns": (72.0, 1.2, 1.2), "twistnsns_old": (72.0, 0.9, 0.8)}[cfg.script]
             groups = [(b, ((-1.0) ** i * -v, 0.0, 0.0), ((-1.0) ** i * -w, 0.0, 0.0), ctr_rest) for i, b in enumerate((left, right))]
@@ -703,7 +769,11 @@ def assemble(cfg, read_mesh):
         remap = {k: i for i, k in enumerate(keep)}
         groups = [groups[k] for k in keep]
         hp_dirichlet = [(ids, lin, ang, 0.0, float("inf")) for ids, lin, ang, _c in groups]
-        hp_motions = [(lin, ang, c) for _ids, lin, ang, c in groups]
+        hp_motions = None if rule_zero or not groups else [(lin, ang, c) for _ids, lin, ang, c in groups]
+        if let_go is not None:
+            let_go["free"] = [remap[g] for g in let_go["free"] if g in remap]
+            let_go["stop"] = [remap[g] for g in let_go["stop"] if g in remap]
+            rule_release = let_go
         if turn is not None:
             rule_release = {"kind": "turn", "turn": turn[0], "axis": turn[1], "lo": float(turn[2]), "hi": float(turn[3]), "comp": turn[4],
                             "groups": [remap[g] for g in turn[5] if g in remap], "stop": turn[6], "lin": [m[0] for m in hp_motions],

@@ -289,6 +289,14 @@ INLINE = {
     "inline:script_upndown": (_BOXRULE % ("upndown", _BAR, "")).replace("time 1 0.02", "time 1 0.05"),
     "inline:script_twistnsns_old": (_BOXRULE % ("twistnsns_old", _BAR, "")).replace("time 1 0.02", "time 1 0.05"),
     "inline:script_twistnstretch": (_BOXRULE % ("twistnstretch", _BAR, "")).replace("time 1 0.02", "time 1 0.1"),
+    # the top of a bar drawn sideways and LET GO after 0.1 (step 5); two handle sets of an upright sheet dragged apart (12 to 37 Newton iterations per
+    # step); both ends of a sheet pulled along x with its middle strip held; start positions times 1.5 (scaleF); the start turned inside out and
+    # squeezed to a tenth about the held left end (stampInv, FCR: 548 Newton iterations in the first step)
+    "inline:script_toggle_top": (_BOXRULE % ("toggleTop", _BAR, "")).replace("time 1 0.02", "time 1 0.05"),
+    "inline:script_four_leg_pull": _BOXRULE % ("fourLegPull", _MAT_UPRIGHT, ""),
+    "inline:script_head_tail_pull": _BOXRULE % ("headTailPull", _MAT, ""),
+    "inline:script_scale_f": _BOXRULE % ("scaleF", _BAR, ""),
+    "inline:script_stamp_inv": (_BOXRULE % ("stampInv", _BAR, "")).replace("energy NH", "energy FCR"),
     "inline:script_tear": (_BOXRULE % ("tear", "input/tetMeshes/cube.msh 0 0 0  0 0 0  1 1 1", "")).replace("time 1 0.02", "time 1 0.1"),
     # scripts that pick their handles from the bounding box of the mesh (AnimScripter::initAnimScript): the lower half of a cube held under
     # gravity; one corner node pushed in -x; the bottom held and the top pressed down by a Neumann acceleration
@@ -344,6 +352,11 @@ SCENES += [
     ("script_twistnsns_old", "inline:script_twistnsns_old", "", 14),
     ("script_twistnstretch", "inline:script_twistnstretch", "", 8),
     ("script_tear", "inline:script_tear", "", 12),
+    ("script_toggle_top", "inline:script_toggle_top", "", 10),
+    ("script_four_leg_pull", "inline:script_four_leg_pull", "", 6),
+    ("script_head_tail_pull", "inline:script_head_tail_pull", "", 6),
+    ("script_scale_f", "inline:script_scale_f", "", 6),
+    ("script_stamp_inv", "inline:script_stamp_inv", "", 6),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
