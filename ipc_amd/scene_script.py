@@ -83,6 +83,7 @@ class SceneConfig:
     tol: float = 1e-2
     script: str = "null"
     script_params: list = field(default_factory=list)
+    script_seq_folder: str = None  # `script meshSeqFromFile <folder>`
     size: float = -1.0  # > 0: the assembled model is scaled so that its largest extent is `size` and moved to the origin (main.cpp:1140-1145)
     warm_start: int = 0  # initX option
     restart: str = None
@@ -124,9 +125,12 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS + RULE_SCRIPTS and a[0] not in DCO_SCRIPTS:
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause", "meshSeqFromFile") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS + RULE_SCRIPTS and a[0] not in DCO_SCRIPTS:
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
+                if a[0] == "meshSeqFromFile":  # Config.cpp:161-164: the folder of <n>.obj files follows the name
+                    cfg.script_seq_folder = resolve(a[1])
+                    a = a[:1] + a[2:]
                 if len(a) > 1 and int(a[1]) > 0:  # `script name n p1 .. pn` (Config.cpp:166-175): parameters of the script
                     cfg.script_params = [float(x) for x in a[2:2 + int(a[1])]]
             elif k == "warmStart":  # initX option (Optimizer.cpp:925-1110)
@@ -806,7 +810,7 @@ def assemble(cfg, read_mesh):
         if cfg.script in ("DCOFix", "DCOBallHitWall"):  # AnimScripter.cpp:1222-1236: every codimensional component is held (NONZERO, no motion)
             dirichlet = []
             codim_fixed = codim_nodes
-        elif cfg.script not in DCO_SCRIPTS and cfg.script != "DCOSegBedSquash" and not all(moved for _i, _f, moved, _e in codim):
+        elif cfg.script not in DCO_SCRIPTS and cfg.script not in ("DCOSegBedSquash", "meshSeqFromFile") and not all(moved for _i, _f, moved, _e in codim):
             raise UnsupportedKeyword("codimensional shape that no script fixes or moves")
     elif cfg.script in ("DCOFix", "DCOBallHitWall"):
         dirichlet = []  # mesh.resetDBCVertices(); nothing to hold
@@ -824,6 +828,16 @@ def assemble(cfg, read_mesh):
         limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
         release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}
     motions = None  # per Dirichlet group: (lin, ang in degrees, fixed centre or None) with the nodes typed NONZERO throughout
+    if cfg.script == "meshSeqFromFile":
+        # AnimScripter.cpp:1222-1236, 2126-2144: every component without tetrahedra is a NONZERO Dirichlet set; before each step the FIRST of them is
+        # moved onto the positions of <folder>/<meshI>.obj, meshI counted from 1
+        parts = [ids for ids, _f, _m, _e in codim]
+        if not parts:
+            raise UnsupportedKeyword("script meshSeqFromFile without a surface-only component to move")
+        dirichlet = [(ids, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), 0.0, float("inf")) for ids in parts]
+        motions = [((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), None)] * len(parts)
+        seqs = [{"ids": parts[0], "folder": cfg.script_seq_folder, "ext": ".obj"}]
+        codim_fixed = None
     if cfg.script in HOLD_SCRIPTS + PULL_SCRIPTS + RULE_SCRIPTS:  # resetDBCVertices(): the scripts replace whatever the shapes' own DBC keywords selected
         dirichlet, motions = hp_dirichlet, hp_motions
         if cfg.script in RULE_SCRIPTS:
@@ -944,6 +958,8 @@ def assemble(cfg, read_mesh):
     for q in seqs:  # the group a sequence drives = the entry of `dirichlet` that holds its nodes
         q["group"] = next(g for g, d in enumerate(dirichlet) if d[0] is q["ids"])
     sc.mesh_seqs = seqs
+    if cfg.script == "meshSeqFromFile":
+        sc.mesh_i = 1
     return sc
 
 

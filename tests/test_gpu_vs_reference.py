@@ -319,6 +319,16 @@ def test_box_rule_scripts_against_the_reference(name, tol, gpu_lib):
     check_boxrule(S, pos, its, max(3 * tol, 1e-7))
 
 
+def test_mesh_seq_from_file_against_the_reference(gpu_lib):
+    """`script meshSeqFromFile` on the HIP stepper (ipcgpu_opt_set_dirichlet_targets before every step)"""
+    S, meshes = load_scene("mesh_seq_from_file")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, int(S["steps"]))
+    c.close()
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    assert np.abs(pos - S["positions"]).max() <= 3e-5 * np.abs(S["positions"]).max()
+
+
 def test_seg_bed_squash_against_the_reference(gpu_lib):
     """`script DCOSegBedSquash`, the script of 17_pinCushionBall.txt, on the HIP stepper"""
     S, meshes = load_scene("seg_bed_squash")

@@ -516,6 +516,16 @@ def test_box_rule_scripts_against_the_reference(name, tol):
     check_boxrule(S, pos, its, tol)
 
 
+def test_mesh_seq_from_file_against_the_reference():
+    """`script meshSeqFromFile <folder>` (Config.cpp:161-164, AnimScripter.cpp:1222-1236, 2126-2144): the surface-only component is moved onto the
+    positions of <folder>/<n>.obj before step n (counted from 1); the cube lands on the turning, rising triangle in step 25."""
+    S, meshes = load_scene("mesh_seq_from_file")
+    pos, its = run_scene(S, meshes, oracle_backend(), int(S["steps"]))
+    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    assert int(S["iters"].max()) > 2 and np.abs(pos - S["positions"]).max() <= 1e-5 * np.abs(S["positions"]).max()
+    assert np.abs(pos[:24] - S["positions"][:24]).max() <= 1e-14 * np.abs(S["positions"]).max()
+
+
 def check_seg_bed(S, pos, its):
     """`script DCOSegBedSquash` (AnimScripter.cpp:1239-1259, 2080-2100): the beds of segments (the nodes behind the cube's eight) follow the
     rule exactly -- the upper one comes down at 1 and stops 0.1 above the lower one; the cube between them has the reference's Newton counts

@@ -275,7 +275,31 @@ tol 1
 """
 _BAR, _MAT, _MAT_UPRIGHT = ("input/tetMeshes/bar-186.msh 0 0 0  0 0 0  1 1 1", "input/tetMeshes/mat20x20.msh 0 0 0  0 0 0  1 1 1",
                             "input/tetMeshes/mat20x20.msh 0 0 0  0 0 90  1 1 1")
+_SEQ_FOLDER = "/tmp/ipc_amd_fixture_seq_from_file"  # written by write_obj_sequence() right before the reference runs
+
+
+def write_obj_sequence(folder, n):
+    """<folder>/1.obj .. n.obj: triangle.obj lifted to y = 1, turning about y through its centre by 4 degrees and rising by 0.004 per file"""
+    os.makedirs(folder, exist_ok=True)
+    Vt, Ft = ss.read_obj(os.path.join(REF_ROOT, "input/triMeshes/triangle.obj"))
+    W0 = Vt + np.array([0.0, 1.0, 0.0])
+    c = W0.mean(0)
+    for k in range(1, n + 1):
+        th = np.radians(4.0 * k)
+        R = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        W = (W0 - c) @ R.T + c + np.array([0.0, 0.004 * k, 0.0])
+        with open(os.path.join(folder, f"{k}.obj"), "w") as f:
+            for v in W:
+                f.write("v %.17g %.17g %.17g\n" % tuple(v))
+            for t in Ft:
+                f.write("f %d %d %d\n" % tuple(int(i) + 1 for i in t))
+
+
 INLINE = {
+    # `script meshSeqFromFile <folder>` (AnimScripter.cpp:2126-2144): the tutorial's cube falls on a triangle (surface-only component) that follows
+    # <folder>/<n>.obj, n = 1, 2, ...
+    "inline:mesh_seq_from_file": "shapes input 2\ninput/tetMeshes/cube.msh 0 3 0  0 0 0  1 1 1\ninput/triMeshes/triangle.obj 0 1 0  0 0 0  1 1 1\n"
+                                 "selfFric 0.1\nground 0.1 0\nscript meshSeqFromFile " + _SEQ_FOLDER + "\n",
     # more scripts that pick nodes by a box rule of the start positions: the top 1 % of an upright sheet held (ZERO); the x < 1 %, y < 1 % or z < 1 %
     # nodes of a bar held (NONZERO); the two ends of a bar pushed together at 0.03; the middle of the bottom tenth of a lifted sheet dragged down
     # at 1.5 through a ground plane's barrier; the left half of a bar starting at +1 in x
@@ -357,6 +381,7 @@ SCENES += [
     ("script_head_tail_pull", "inline:script_head_tail_pull", "", 6),
     ("script_scale_f", "inline:script_scale_f", "", 6),
     ("script_stamp_inv", "inline:script_stamp_inv", "", 6),
+    ("mesh_seq_from_file", "inline:mesh_seq_from_file", "", 30),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
@@ -375,6 +400,8 @@ def scenes(only=()):
             continue
         text = (INLINE[rel] if rel in INLINE else open(os.path.join(REF_ROOT, "input", rel)).read()) + extra
         cfg = ss.SceneConfig.parse(text, REF_ROOT)
+        if cfg.script_seq_folder:
+            write_obj_sequence(cfg.script_seq_folder, steps + 1)
         with tempfile.TemporaryDirectory(prefix="ipcref_") as tmp:
             path = os.path.join(tmp, "scene.txt")
             lines = [ln for ln in text.splitlines() if not ln.strip().startswith("time ")]
@@ -425,6 +452,9 @@ def scenes(only=()):
             if sh.mesh_seq is not None:
                 ext = os.path.splitext(sh.path.lower())[1]
                 out["seq_" + os.path.relpath(sh.mesh_seq, REF_ROOT)] = np.array([ss.read_seq_file(sh.mesh_seq, i, ext) for i in range(steps)])
+        if cfg.script_seq_folder:  # file n at index n (index 0 unused: the script counts from 1)
+            files = [ss.read_seq_file(cfg.script_seq_folder, i, ".obj") for i in range(1, steps + 1)]
+            out["seq_" + os.path.relpath(cfg.script_seq_folder, REF_ROOT)] = np.array([np.zeros_like(files[0])] + files)
         fn = os.path.join(GOLD, f"ref_scene_{name}.npz")
         np.savez_compressed(fn, **out)
         print(f"wrote {os.path.basename(fn)}: {steps} steps, Newton iterations per step {its.tolist()}, {os.path.getsize(fn) >> 10} KiB")
