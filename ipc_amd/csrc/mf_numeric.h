@@ -70,6 +70,7 @@ private:
     };
     int rank_ = 0, world_ = 1;
     long long schur64Min_ = 512;
+    int xinvSkipTop_ = 0; // fronts of the last n levels solve their triangles block by block instead of through an explicit inverse (IPCGPU_MF_XINV_SKIP_TOP)
     AllreduceFn allreduce_ = nullptr;
     AllreduceStreamFn allreduceStream_ = nullptr;
     void* allreduceUser_ = nullptr;

@@ -2644,6 +2644,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
         int xinvMin = 192;
         if (const char* e = std::getenv("IPCGPU_MF_XINV_NC")) xinvMin = std::atoi(e) > 0 ? std::max(64, std::atoi(e)) : (1 << 30);
+        if (const char* e = std::getenv("IPCGPU_MF_XINV_SKIP_TOP")) xinvSkipTop_ = std::max(0, std::atoi(e));
         std::vector<long long> xOff(ns_, -1);
         long long xTot = 0;
         std::vector<int4> xd; // all descriptors of the inverse machinery
@@ -2653,6 +2654,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             for (int i = plan_[l].bigFronts.off; i < plan_[l].bigFronts.off + plan_[l].bigFronts.cnt; ++i) {
                 const int s = bigList[i];
                 if (sym.nc(s) < xinvMin) continue;
+                if (l >= nLevels_ - xinvSkipTop_) continue; // A/B: the last levels' inverses finish after the factorisation (they are the tail of the step)
                 xOff[s] = xTot;
                 xTot += (long long)sym.nc(s) * sym.nc(s);
                 invFronts.push_back(s);
