@@ -255,6 +255,10 @@ int ipcgpu_halfspace_set(ipcgpu_ctx*, int id, int n, const int* verts);
 int ipcgpu_halfspace_energy(ipcgpu_ctx*, int id, double dHat, double kappa, double* E);
 int ipcgpu_halfspace_gradient_add(ipcgpu_ctx*, int id, double dHat, double kappa, double* grad_3nV_inout);
 int ipcgpu_halfspace_hessian_add(ipcgpu_ctx*, int id, double dHat, double kappa, int projectDBC);
+/* HalfSpace::move (HalfSpace.cpp:389-416), what the ACO* scripts of AnimScripter call before a time step (AnimScripter.cpp:1832-1890): the plane's
+ * origin moves along delta by the largest fraction <= 1 that keeps `slackness` of the distance of every surface node (Dirichlet nodes included);
+ * stepSizeLeft = 1 - that fraction. */
+int ipcgpu_halfspace_move(ipcgpu_ctx*, int id, const double* delta3, double slackness, double* stepSizeLeft);
 int ipcgpu_halfspace_step_bound(ipcgpu_ctx*, int id, const double* searchDir_3nV, double slackness, double* stepSize_inout);
 /* ---- lagged smoothed Coulomb friction (FrictionUtils.hpp, SelfCollisionHandler.cpp:2481-2988, HalfSpace.cpp:272-381)
  * `selfFric mu` / `fricIterAmt n` / eps_v = tuning[4] (Config.cpp:482-488, 550-551, 45).  Self friction needs self collision. */

@@ -1008,6 +1008,17 @@ int ipcgpu_halfspace_hessian_add(ipcgpu_ctx* c, int id, double dHat, double kapp
         return IPCGPU_OK;
     });
 }
+int ipcgpu_halfspace_move(ipcgpu_ctx* c, int id, const double* delta3, double slackness, double* stepSizeLeft)
+{
+    return guarded([&] {
+        HipHalfSpace& h = HS(c, id);
+        bind(c);
+        needArg(delta3 && slackness > 0.0 && slackness <= 1.0, "bad half-space move");
+        const double left = h.move(CT(c).nSVI, CT(c).d_SVI.p, c->mesh->d_x.p, delta3, slackness);
+        if (stepSizeLeft) *stepSizeLeft = left;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_halfspace_step_bound(ipcgpu_ctx* c, int id, const double* p, double slackness, double* step)
 {
     return guarded([&] {

@@ -16,7 +16,7 @@ class HipHalfSpace {
 public:
     HipHalfSpace(hipStream_t s, const double* origin3, const double* normal3);
     hipStream_t stream;
-    double n[3], D;
+    double n[3], D, origin[3];
     std::vector<int> set; // activeSet[coI]: vertex ids, ascending surface-vertex order
     DevBuf<int> d_set;
 
@@ -28,6 +28,9 @@ public:
         double* a_dev);
     double stepBound(int nSVI, const int* svi_dev, const double* x_dev, const int* dbc_dev, const double* p_dev, double slackness, double stepSize);
     bool intersected(int nV, const double* x_dev, const int* dbc_dev);
+    // HalfSpace::move (HalfSpace.cpp:389-416): the plane is displaced by the largest fraction <= 1 of delta that keeps `slackness` of every surface
+    // node's distance (Dirichlet nodes included); returns the fraction that is left
+    double move(int nSVI, const int* svi_dev, const double* x_dev, const double* delta3, double slackness);
     void evalDist2(const std::vector<int>& verts, const double* x_dev, std::vector<double>& d2);
     // lagged friction (HalfSpace.cpp:272-381, C0 clamping): activeSet_lastH / lambda_lastH of this plane
     double friction = 0.0; // Base::friction

@@ -132,6 +132,17 @@ __global__ void k_hs_step(int nSVI, const int* __restrict__ svi, const double* _
     if ((threadIdx.x & 63) == 0) atomicMin(out, ordered_bits(best));
 }
 
+// the plane moves by delta: every surface node (Dirichlet or not) bounds the fraction, coef = n . (-delta) is the same for all (HalfSpace.cpp:393-411)
+__global__ void k_hs_move(int nSVI, const int* __restrict__ svi, const double* __restrict__ x, Plane h, double coef, double slackness, unsigned long long* __restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    double best = 1.0;
+    if (i < nSVI) best = -plane_dist(h, x, svi[i]) / coef * slackness;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) best = fmin(best, __shfl_down(best, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMin(out, ordered_bits(best));
+}
+
 __global__ void k_hs_intersected(int nV, const double* __restrict__ x, const int* __restrict__ dbc, Plane h, int* __restrict__ flag)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -232,6 +243,7 @@ HipHalfSpace::HipHalfSpace(hipStream_t s, const double* origin, const double* no
     const double len = std::sqrt(normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2]);
     if (!(len > 0.0)) throw ArgError("half-space normal must be non-zero");
     for (int c = 0; c < 3; ++c) n[c] = normal[c] / len;
+    for (int c = 0; c < 3; ++c) this->origin[c] = origin[c];
     D = -(n[0] * origin[0] + n[1] * origin[1] + n[2] * origin[2]);
 }
 
@@ -307,6 +319,25 @@ double HipHalfSpace::stepBound(int nSVI, const int* svi_dev, const double* x_dev
     unsigned long long k = 0;
     minOut_.download(&k, 1, stream);
     return std::min(stepSize, from_ordered_bits(k));
+}
+
+double HipHalfSpace::move(int nSVI, const int* svi_dev, const double* x_dev, const double* delta, double slackness)
+{
+    const double coef = -(n[0] * delta[0] + n[1] * delta[1] + n[2] * delta[2]);
+    double stepSize = 1.0;
+    if (coef < 0.0 && nSVI) { // going towards the object
+        const Plane h{ n[0], n[1], n[2], D };
+        minOut_.alloc(1);
+        const unsigned long long init = ~0ull;
+        HIP_CHECK(hipMemcpyAsync(minOut_.p, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_hs_move, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, svi_dev, x_dev, h, coef, slackness, minOut_.p);
+        unsigned long long k = 0;
+        minOut_.download(&k, 1, stream);
+        stepSize = std::min(1.0, from_ordered_bits(k));
+    }
+    for (int c = 0; c < 3; ++c) origin[c] += stepSize * delta[c];
+    D = -(n[0] * origin[0] + n[1] * origin[1] + n[2] * origin[2]); // init(origin + stepSize * deltaX, normal, ...), HalfSpace.cpp:413
+    return 1.0 - stepSize;
 }
 
 bool HipHalfSpace::intersected(int nV, const double* x_dev, const int* dbc_dev)

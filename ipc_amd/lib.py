@@ -562,6 +562,13 @@ class Context:
         self._chk(self._L.ipcgpu_halfspace_hessian_add(self.h, C.c_int(idx), C.c_double(dHat), C.c_double(kappa),
                                                        C.c_int(int(projectDBC))))
 
+    def half_space_move(self, idx, delta, slackness=0.5):
+        """HalfSpace::move: displace plane `idx` by (the feasible fraction of) delta; returns the fraction left"""
+        d = _f64(np.asarray(delta, dtype=np.float64))
+        left = C.c_double()
+        self._chk(self._L.ipcgpu_halfspace_move(self.h, C.c_int(idx), _dp(d), C.c_double(slackness), C.byref(left)))
+        return left.value
+
     def halfspace_step_bound(self, idx, p, slackness=0.9, step=1.0):
         p = _f64(np.asarray(p).reshape(-1))
         s = C.c_double(step)

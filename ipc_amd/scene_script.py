@@ -125,7 +125,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause", "meshSeqFromFile") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS + RULE_SCRIPTS and a[0] not in DCO_SCRIPTS:
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause", "meshSeqFromFile", "ACOSquash", "ACOSquash6") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS + RULE_SCRIPTS and a[0] not in DCO_SCRIPTS:
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
                 if a[0] == "meshSeqFromFile":  # Config.cpp:161-164: the folder of <n>.obj files follows the name
@@ -495,6 +495,18 @@ class AssembledScene:
             for g in r["groups"]:
                 be.set_dirichlet_motion(g, lin_vel=r["lin"][g], ang_vel_deg=r["ang"][g], center=r["ctr"][g], force_nonzero=True)
             return True
+        if r.get("kind") == "aco":
+            # AnimScripter.cpp:1832-1871: the analytic planes close in at 1 along their axis, every velocity of a pair changing sign while the two
+            # are closer than 0.1 (ACOSquash) / 0.2 (ACOSquash6); each plane then moves by the fraction of v dt that HalfSpace::move admits
+            o, v = r["origins"], r["vel"]
+            for a, gap in r["pairs"]:
+                if o[a + 1][a // 2] - o[a][a // 2] < gap:
+                    v[a][a // 2] *= -1.0
+                    v[a + 1][a // 2] *= -1.0
+            for i in range(len(v)):
+                d = v[i] * self.cfg.dt
+                o[i] = o[i] + (1.0 - be.half_space_move(i, d, 0.5)) * d
+            return True
         if r.get("kind") == "let_go":
             c = x[r["turn"], r["axis"]]
             if not (c <= r["limit"] if r["below"] else c >= r["limit"]):
@@ -828,6 +840,14 @@ def assemble(cfg, read_mesh):
         limit = max((V[o, 0].max() for o in obstacle), default=-np.inf)
         release = {"group": 0, "x_limit": float(limit), "nSim": int(nSim), "done": False}
     motions = None  # per Dirichlet group: (lin, ang in degrees, fixed centre or None) with the nodes typed NONZERO throughout
+    if cfg.script in ("ACOSquash", "ACOSquash6"):  # AnimScripter.cpp:956-985: no Dirichlet nodes; planes 2 i / 2 i + 1 move at +1 / -1 along axis i
+        nP = 2 if cfg.script == "ACOSquash" else 6
+        if len(cfg.half_spaces) < nP:
+            raise UnsupportedKeyword(f"script {cfg.script} needs {nP} analytic planes (ground / halfSpace)")
+        dirichlet = []
+        vel_p = [np.eye(3)[i // 2] * (1.0 if i % 2 == 0 else -1.0) for i in range(nP)]
+        release = {"kind": "aco", "vel": vel_p, "origins": [np.array(h[0], dtype=np.float64) for h in cfg.half_spaces[:nP]],
+                   "pairs": [(a, 0.1 if nP == 2 else 0.2) for a in range(0, nP, 2)], "done": False}
     if cfg.script == "meshSeqFromFile":
         # AnimScripter.cpp:1222-1236, 2126-2144: every component without tetrahedra is a NONZERO Dirichlet set; before each step the FIRST of them is
         # moved onto the positions of <folder>/<meshI>.obj, meshI counted from 1

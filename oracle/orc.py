@@ -635,6 +635,13 @@ class HalfSpace:
         lib().orc_halfspace_hessian(self.h, mesh.h, C.c_double(dHat), C.c_double(kappa), C.c_int(int(projectDBC)), _dp(a))
         return a
 
+    def move(self, mesh, delta, slackness=0.5):
+        """HalfSpace::move (HalfSpace.cpp:389-416): (origin after the move, fraction of delta that is left)"""
+        lib().orc_halfspace_move.restype = C.c_double
+        d, out = np.ascontiguousarray(delta, dtype=np.float64), np.zeros(3)
+        left = lib().orc_halfspace_move(self.h, mesh.h, _dp(d), C.c_double(slackness), _dp(out))
+        return out, left
+
     def step_bound(self, mesh, p, slackness=0.9, step=1.0):
         p = np.ascontiguousarray(p, dtype=np.float64).reshape(-1)
         return lib().orc_halfspace_step_bound(self.h, mesh.h, _dp(p), C.c_double(slackness), C.c_double(step))
@@ -711,6 +718,12 @@ def opt_force_friction_loop(opt: "Optimizer", on=True):
 
 def opt_set_friction_scales(opt: "Optimizer", scale_self=1.0, scale_obstacle=1.0):
     lib().orc_opt_set_friction_scales(opt.h, C.c_double(scale_self), C.c_double(scale_obstacle))
+
+
+def opt_half_space_move(opt: "Optimizer", idx, delta, slackness=0.5):
+    lib().orc_opt_half_space_move.restype = C.c_double
+    d = np.ascontiguousarray(delta, dtype=np.float64)
+    return lib().orc_opt_half_space_move(opt.h, C.c_int(idx), _dp(d), C.c_double(slackness))
 
 
 def opt_set_half_space_friction(opt: "Optimizer", idx, mu):

@@ -61,7 +61,7 @@ bool isIntersected(const Mesh& m); // any surface edge through any surface trian
 
 // ---- analytic half-space obstacle (HalfSpace.cpp:41-85): points x with n.x + D > 0 are outside, constraint d = (n.x + D)^2
 struct HalfSpace {
-    double n[3], D;
+    double n[3], D, o[3];
     void init(const double origin[3], const double normal[3]);
     double dist(const Mesh& m, int v) const { return n[0] * m.Vx(v, 0) + n[1] * m.Vx(v, 1) + n[2] * m.Vx(v, 2) + D; }
 };
@@ -70,6 +70,7 @@ double hsEnergy(const Mesh& m, const HalfSpace& h, const std::vector<int>& set, 
 void hsGradient(const Mesh& m, const HalfSpace& h, const std::vector<int>& set, double dHat, double kappa, double* grad); // HalfSpace.cpp:121-143
 void hsHessian(const Mesh& m, const HalfSpace& h, const std::vector<int>& set, double dHat, double kappa, bool projectDBC, double* a); // :169-214
 double hsStepBound(const Mesh& m, const HalfSpace& h, const double* p, double slackness, double stepSize); // :242-269
+double hsMove(const Mesh& m, HalfSpace& h, const double delta[3], double slackness); // HalfSpace::move, :389-416; returns the fraction left
 bool hsIntersected(const Mesh& m, const HalfSpace& h); // CollisionObject.h:386-401 (fires only on d == 0: d is a square)
 
 } // namespace orc

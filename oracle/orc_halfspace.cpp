@@ -18,6 +18,7 @@ void HalfSpace::init(const double origin[3], const double normal[3])
 {
     const double len = std::sqrt(normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2]);
     for (int c = 0; c < 3; ++c) n[c] = normal[c] / len;
+    for (int c = 0; c < 3; ++c) o[c] = origin[c];
     D = -(n[0] * origin[0] + n[1] * origin[1] + n[2] * origin[2]);
 }
 
@@ -79,6 +80,19 @@ double hsStepBound(const Mesh& m, const HalfSpace& h, const double* p, double sl
     return std::min(stepSize, best);
 }
 
+double hsMove(const Mesh& m, HalfSpace& h, const double delta[3], double slackness)
+{
+    // HalfSpace.cpp:389-416: every surface node, Dirichlet or not, bounds the fraction of delta the plane may take
+    const double coef = -(h.n[0] * delta[0] + h.n[1] * delta[1] + h.n[2] * delta[2]);
+    double best = 1.0;
+    if (coef < 0.0)
+        for (int v : m.SVI) best = std::min(best, -h.dist(m, v) / coef * slackness);
+    const double stepSize = std::min(1.0, best);
+    const double origin[3] = { h.o[0] + stepSize * delta[0], h.o[1] + stepSize * delta[1], h.o[2] + stepSize * delta[2] };
+    h.init(origin, h.n);
+    return 1.0 - stepSize;
+}
+
 bool hsIntersected(const Mesh& m, const HalfSpace& h)
 {
     for (int v = 0; v < m.nV; ++v)
@@ -122,6 +136,12 @@ void orc_halfspace_gradient(const orc_halfspace* o, const orc_mesh* mh, double d
 void orc_halfspace_hessian(const orc_halfspace* o, const orc_mesh* mh, double dHat, double kappa, int projectDBC, double* a)
 {
     hsHessian(mh->m, o->h, o->set, dHat, kappa, projectDBC != 0, a);
+}
+double orc_halfspace_move(orc_halfspace* o, const orc_mesh* mh, const double* delta3, double slackness, double* originOut)
+{
+    const double left = hsMove(mh->m, o->h, delta3, slackness);
+    for (int c = 0; c < 3; ++c) originOut[c] = o->h.o[c];
+    return left;
 }
 double orc_halfspace_step_bound(const orc_halfspace* o, const orc_mesh* mh, const double* p, double slackness, double stepSize)
 {

@@ -1230,6 +1230,8 @@ void orc_opt_get_contact(const orc_opt* o, int* counts6, int* active4, int* para
         for (size_t i = 0; i < o->cs.paraEE.size(); ++i)
             for (int k = 0; k < 4; ++k) para4[4 * i + k] = o->cs.paraEE[i][k];
 }
+// HalfSpace::move (HalfSpace.cpp:389-416): returns the fraction of delta that is left
+double orc_opt_half_space_move(orc_opt* o, int id, const double* delta3, double slackness) { return hsMove(*o->m, o->planes.at(id), delta3, slackness); }
 void orc_opt_set_parameter_scaling(orc_opt* o, int useAbs, double dTolRel, double kappaMinMultiplier)
 {
     // useAbsParameters / tuning[3] / kappaMinMultiplier (Config.cpp:553-558; Optimizer.cpp:102-109, 279-302, 1535-1537, 2228-2233, 2941-2945)

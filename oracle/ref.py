@@ -55,6 +55,7 @@ def lib():
             "ipcref_is_intersected": (i, [p]),
             "ipcref_halfspace_eval": (i, [p, p, p, d, d, i, p, p, p, p, p, p, i]),
             "ipcref_halfspace_step_bound": (d, [p, p, p, p, d, d]),
+            "ipcref_halfspace_move": (d, [p, p, p, p, d, p]),
         }
         for name, (res, args) in sig.items():
             f = getattr(_lib, name)
@@ -193,6 +194,13 @@ class Mesh:
     def halfspace_step_bound(self, origin, normal, p, slackness=0.9, step=1.0):
         o, n, p = _d(origin), _d(normal), _d(p)
         return lib().ipcref_halfspace_step_bound(self.h, _p(o), _p(n), _p(p), slackness, step)
+
+
+def halfspace_move(mesh, origin, normal, delta, slackness=0.5):
+    """HalfSpace::move run by the reference: (origin after the move, fraction left)"""
+    o, n, d, out = _d(origin), _d(normal), _d(delta), np.zeros(3)
+    left = lib().ipcref_halfspace_move(mesh.h, _p(o), _p(n), _p(d), slackness, _p(out))
+    return out, left
 
 
 def stencil_distance(kind, X):

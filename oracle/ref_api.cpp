@@ -474,4 +474,16 @@ double ipcref_halfspace_step_bound(ipcref_mesh* h, const double* origin3, const 
     return stepSize;
 }
 
+// HalfSpace::move (HalfSpace.cpp:389-416): the origin after the move; returns the fraction that is left
+double ipcref_halfspace_move(ipcref_mesh* h, const double* origin3, const double* normal3, const double* delta3, double slackness, double* originOut)
+{
+    Eigen::Vector3d o(origin3[0], origin3[1], origin3[2]), n(normal3[0], normal3[1], normal3[2]), v0(0.0, 0.0, 0.0), d(delta3[0], delta3[1], delta3[2]);
+    HalfSpace<3> hs(o, n, v0, 0.0);
+    SpatialHash<3> sh;
+    double left = 0.0;
+    hs.move(d, *h->m, sh, slackness, left);
+    for (int c = 0; c < 3; ++c) originOut[c] = hs.origin[c];
+    return left;
+}
+
 } // extern "C"

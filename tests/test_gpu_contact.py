@@ -303,6 +303,16 @@ def test_half_space_pieces(orc, gpu_lib):
         p[:, 1] -= 0.02 * trial
         so, sg = hs.step_bound(m, p.reshape(-1), 0.9, 1.0), c.halfspace_step_bound(idx, p.reshape(-1), 0.9, 1.0)
         assert abs(sg - so) <= 1e-14 * abs(so)
+    # HalfSpace::move (ipcgpu_halfspace_move): towards the block the nearest surface node cuts the move short, away from it the whole move is taken;
+    # the plane the library then uses is the moved one (same active set, same energy as the moved oracle plane)
+    for delta in (0.5 * nrm, 0.003 * nrm + np.array([0.02, 0.0, -0.01]), -0.01 * nrm):
+        (o_new, left_o), left_g = hs.move(m, delta, 0.5), c.half_space_move(idx, delta, 0.5)
+        assert abs(left_g - left_o) <= 1e-14, (left_g, left_o)
+        vo2 = hs.build(m, dHat)
+        assert np.array_equal(c.halfspace_build(idx, dHat), vo2)
+        Eo2 = hs.energy(m, dHat, kappa)
+        assert abs(c.halfspace_energy(idx, dHat, kappa) - Eo2) <= 1e-11 * max(abs(Eo2), 1e-30)
+    assert left_o == 0.0
     # a set handed in through the ABI
     c.halfspace_set(idx, vo[::2])
     hs2 = orc.HalfSpace(origin, nrm)

@@ -200,6 +200,12 @@ def test_half_space_against_the_reference(G):
     assert rel(hs.hessian(contact, len(ja), dHat, kappa), G["hs_a"]) < 1e-12
     for p, want in zip(G["con_p"], G["hs_step"]):
         assert abs(hs.step_bound(contact, p, 0.9, 1.0) - want) <= 1e-12 * want
+    # HalfSpace::move (HalfSpace.cpp:389-416): towards the sheets the nearest surface node cuts the move short
+    assert G["hs_move_left"].max() > 0.5 and G["hs_move_left"].min() == 0.0
+    for d, want_o, want_left in zip(G["hs_move_delta"], G["hs_move_origin"], G["hs_move_left"]):
+        h2 = orc.HalfSpace(G["hs_o"], G["hs_n"])
+        o2, left = h2.move(contact, d, 0.5)
+        assert abs(left - want_left) <= 1e-14 and np.abs(o2 - want_o).max() <= 1e-15
 
 
 # ---- whole scenes through the reference's main.cpp / Optimizer.cpp ------------------------------------------------------------------

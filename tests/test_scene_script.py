@@ -185,6 +185,9 @@ class OracleBackend:
     def set_friction_scales(self, a, b):
         self.orc.opt_set_friction_scales(self.o, a, b)
 
+    def half_space_move(self, i, delta, slackness=0.5):
+        return self.orc.opt_half_space_move(self.o, i, delta, slackness)
+
     def set_half_space_friction(self, i, mu):
         self.orc.opt_set_half_space_friction(self.o, i, mu)
 
@@ -506,4 +509,62 @@ def test_dcofix_scene_on_the_gpu_beside_the_oracle(orc, gpu_lib, tmp_path):
         seen = max(seen, cs_g["nActive"])
         assert np.abs(sg["V"] - so["V"]).max() < 1e-6 * np.abs(so["V"]).max(), k
     assert seen > 0
+    gb.close()
+
+
+ACO6 = """energy NH
+time 1 0.025
+density 1000
+stiffness 1e5 0.4
+script ACOSquash6
+shapes input 1
+box.msh 0 0 0  0 0 0  1 1 1
+selfCollisionOff
+tol 1
+1e-4
+halfSpace -0.2 0.5 0.5  1 0 0  1000 0
+halfSpace 1.2 0.5 0.5  -1 0 0  1000 0
+halfSpace 0.5 -0.2 0.5  0 1 0  1000 0
+halfSpace 0.5 1.2 0.5  0 -1 0  1000 0
+halfSpace 0.5 0.5 -0.2  0 0 1  1000 0
+halfSpace 0.5 0.5 1.2  0 0 -1  1000 0
+"""
+
+
+def test_aco_squash_rules():
+    """ACOSquash6 (AnimScripter.cpp:966-985, 1848-1871): six planes closing at 1, each move cut short by HalfSpace::move's slackness; the tooling
+    keeps the origins it asked the backend to move to."""
+    cfg = ss.SceneConfig.parse(ACO6, "/x")
+    assert cfg.script == "ACOSquash6" and len(cfg.half_spaces) == 6
+    V0, F0 = scene.make_box(1, 1, 1)
+    read = lambda p: (V0.copy(), F0.copy(), scene.surface_tris(F0))
+    sc = ss.assemble(cfg, read)
+    assert sc.release["kind"] == "aco" and len(sc.release["vel"]) == 6 and sc.dirichlet == []
+    assert np.array_equal(sc.release["vel"][3], [0.0, -1.0, 0.0]) and sc.release["pairs"] == [(0, 0.2), (2, 0.2), (4, 0.2)]
+    with pytest.raises(ss.UnsupportedKeyword):
+        ss.assemble(ss.SceneConfig.parse(ACO6.replace("halfSpace 0.5 0.5 1.2  0 0 -1  1000 0\n", ""), "/x"), read)
+
+
+@pytest.mark.gpu
+def test_aco_squash6_on_the_gpu_beside_the_oracle(orc, gpu_lib):
+    """The planes of `script ACOSquash6` moved by ipcgpu_halfspace_move before every step: the unit cube is caught by the rising bottom plane and
+    boxed in; plane moves (fractions left), constraint sets and iterates next to the CPU restatement."""
+    V0, F0 = scene.make_box(2, 2, 2, size=(1.0, 1.0, 1.0), origin=(0.0, 0.0, 0.0))
+    V0 = scene.jitter(V0, F0, rel=1e-2)
+    SF0 = scene.surface_tris(F0)
+    cfg = ss.SceneConfig.parse(ACO6, "/x")
+    read = lambda p: (V0.copy(), F0.copy(), SF0.copy())
+    so_, sg_ = ss.assemble(cfg, read), ss.assemble(cfg, read)
+    ob, gb = ss.apply(so_, OracleBackend(orc)), ss.apply(sg_, gpu_lib.Context(0))
+    limited = False
+    for k in range(16):
+        so_.before_step(ob, k * cfg.dt)
+        sg_.before_step(gb, k * cfg.dt)
+        for a, b in zip(so_.release["origins"], sg_.release["origins"]):
+            assert np.abs(a - b).max() <= 1e-9
+        limited |= abs(so_.release["origins"][2][1] - (-0.2 + (k + 1) * cfg.dt)) > 1e-6  # the bottom plane no longer takes its whole step
+        no, ng = ob.solve_timestep(200), gb.solve_timestep(200)
+        assert no < 200 and ng == no, (k, no, ng)
+        assert np.abs(gb.state()["V"] - ob.state()["V"]).max() < 1e-7 * np.abs(ob.state()["V"]).max(), k
+    assert limited
     gb.close()

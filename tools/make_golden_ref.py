@@ -160,6 +160,10 @@ def functions():
     o, n = np.array([0.0, Vm[:, 1].min() - 1e-3, 0.0]), np.array([0.0, 1.0, 0.0])
     hact, hE, hg, (hia, hja, ha) = mc.halfspace(o, n, dHat, kappa)
     out.update(hs_o=o, hs_n=n, hs_active=hact, hs_E=hE, hs_g=hg, hs_a=ha, hs_step=np.array([mc.halfspace_step_bound(o, n, p, 0.9, 1.0) for p in pc]))
+    # HalfSpace::move: the plane displaced towards the sheets (limited by the nearest surface node), along them, and away
+    deltas = np.array([[0.0, 0.01, 0.0], [0.0, 2e-4, 0.0], [0.3, 0.004, -0.2], [0.0, -0.5, 0.1], [0.02, 0.0, 0.0]])
+    moved = [ref.halfspace_move(mc, o, n, d, 0.5) for d in deltas]
+    out.update(hs_move_delta=deltas, hs_move_origin=np.array([m_[0] for m_ in moved]), hs_move_left=np.array([m_[1] for m_ in moved]))
     np.savez_compressed(os.path.join(GOLD, "ref_functions.npz"), **out)
     print("wrote ref_functions.npz", os.path.getsize(os.path.join(GOLD, "ref_functions.npz")) >> 10, "KiB")
 
