@@ -125,7 +125,7 @@ class SceneConfig:
             elif k == "turnOffGravity":
                 cfg.gravity = False
             elif k == "script":
-                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause", "meshSeqFromFile", "ACOSquash", "ACOSquash6") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS + RULE_SCRIPTS and a[0] not in DCO_SCRIPTS:
+                if a[0] not in ("null", "twist", "fall", "fallNoShift", "dragright", "DCOFix", "DCOBallHitWall", "stretchAndPause", "meshSeqFromFile", "ACOSquash", "ACOSquash6", "DCOHammerWalnut", "DCOCut") + HANDLE_SCRIPTS + HOLD_SCRIPTS + PULL_SCRIPTS + INITVEL_SCRIPTS + RULE_SCRIPTS and a[0] not in DCO_SCRIPTS:
                     raise UnsupportedKeyword(f"script {a[0]}")
                 cfg.script = a[0]
                 if a[0] == "meshSeqFromFile":  # Config.cpp:161-164: the folder of <n>.obj files follows the name
@@ -507,6 +507,14 @@ class AssembledScene:
                 d = v[i] * self.cfg.dt
                 o[i] = o[i] + (1.0 - be.half_space_move(i, d, 0.5)) * d
             return True
+        if r.get("kind") == "while_above":  # AnimScripter.cpp:1996-2012, 2019-2030: the component moves in the steps that start with its lowest node above the mark
+            moving = bool(x[r["ids"], 1].min() > r["y"])
+            if moving != r["moving"]:
+                r["moving"] = moving
+                lin, ang, ctr = r["motion"] if moving else ((0.0, 0.0, 0.0), (0.0, 0.0, 0.0), None)
+                be.set_dirichlet_motion(0, lin_vel=lin, ang_vel_deg=ang, center=ctr, force_nonzero=True)
+                return True
+            return False
         if r.get("kind") == "let_go":
             c = x[r["turn"], r["axis"]]
             if not (c <= r["limit"] if r["below"] else c >= r["limit"]):
@@ -822,7 +830,7 @@ def assemble(cfg, read_mesh):
         if cfg.script in ("DCOFix", "DCOBallHitWall"):  # AnimScripter.cpp:1222-1236: every codimensional component is held (NONZERO, no motion)
             dirichlet = []
             codim_fixed = codim_nodes
-        elif cfg.script not in DCO_SCRIPTS and cfg.script not in ("DCOSegBedSquash", "meshSeqFromFile") and not all(moved for _i, _f, moved, _e in codim):
+        elif cfg.script not in DCO_SCRIPTS and cfg.script not in ("DCOSegBedSquash", "meshSeqFromFile", "DCOHammerWalnut", "DCOCut") and not all(moved for _i, _f, moved, _e in codim):
             raise UnsupportedKeyword("codimensional shape that no script fixes or moves")
     elif cfg.script in ("DCOFix", "DCOBallHitWall"):
         dirichlet = []  # mesh.resetDBCVertices(); nothing to hold
@@ -891,6 +899,25 @@ def assemble(cfg, read_mesh):
             release = {"kind": "dco", "script": cfg.script, "done": False, "lin": [m[0] for m in motions]} if "lin" in spec else None
             comps = list(range(n))
         if any(nr[c] in codim_comp and c not in comps for c in range(len(cfg.shapes))):
+            raise UnsupportedKeyword("surface-only component that the script neither moves nor holds")
+        codim_fixed = None
+    if cfg.script in ("DCOHammerWalnut", "DCOCut"):
+        # AnimScripter.cpp:1120-1170, 1993-2032: the SECOND component (whatever its kind) is a NONZERO set; while its lowest node is above 0.05 it
+        # turns about z at pi / 6 through (x max, y min, z middle) of its start box (the hammer), resp. above 0.001 it moves at (0, -1, -1) (the knife)
+        if len(cfg.shapes) < 2:
+            raise UnsupportedKeyword(f"script {cfg.script} needs a second component to move")
+        U = V if V0 is None else V0
+        ids = np.arange(nr[1], nr[2], dtype=np.int32)
+        lo, hi = U[ids].min(0), U[ids].max(0)
+        if cfg.script == "DCOHammerWalnut":
+            mot = ((0.0, 0.0, 0.0), (0.0, 0.0, 30.0), (float(hi[0]), float(lo[1]), float(0.5 * (hi[2] + lo[2]))))
+            y_stop = 0.05
+        else:
+            mot = ((0.0, -1.0, -1.0), (0.0, 0.0, 0.0), None)
+            y_stop = 0.001
+        dirichlet, motions = [(ids, mot[0], mot[1], 0.0, float("inf"))], [mot]
+        release = {"kind": "while_above", "ids": ids, "y": y_stop, "motion": mot, "moving": True, "done": False}
+        if any(c != 1 for c in range(len(cfg.shapes)) if not tr[c + 1] > tr[c]):
             raise UnsupportedKeyword("surface-only component that the script neither moves nor holds")
         codim_fixed = None
     if cfg.script == "stretchAndPause":

@@ -337,6 +337,7 @@ MORE_SCENES = [
     ("point_triangle_abs_parameters", 0, 2, 1e-4),  # the same scene with `useAbsParameters`, `kappaMinMultiplier 3e10` and a six-entry `tuning` (dHat 8e-2 -> 2e-3 as absolute lengths, dTol 1e-8): 30 steps through the impact
     ("dbc_global_time_range", 14, 0, 1e-9),  # 2cubesFall_DBC_timeRange.txt + `DBCTimeRange 0.1 0.25`: the groups hold / move their nodes inside the scene-wide range only
     ("nbc_global_time_range", 4, 1, 1e-10),  # 2cubesFall_NBC.txt + `NBCTimeRange 0.1 0.2`, tol 1e-5: the pull starts in step 5 and ends after step 8 on both sides; that first step deforms the cube from exact rest (4 iterations there, 3 here), every later count equal, positions 1e-12
+    ("script_dco_cut", 0, 4, 1e-4),  # `script DCOCut`: a triangle (second component) moving at (0, -1, -1) over a cube that rests on the ground from the start (a few counts differ there)
     ("two_cubes_nm_damped", 18, 6, 5e-2),  # tutorialExamples/advanced/2cubesFall_NM.txt: Newmark + dampingRatio; the counts differ after the touch-down
 ]
 

@@ -61,7 +61,7 @@ def test_grammar():
     assert c.dbc_time_range == (0.1, 0.5) and c.nbc_time_range == (0.2, 1.0)
     c = ss.SceneConfig.parse("useAbsParameters\nminBarrierStiffnessScale 2e10\ntuning 4\n0 1e-2 1e-3\n2e-10\n")
     assert c.use_abs_parameters and c.kappa_min_multiplier == 2e10 and (c.dHat_eps, c.dHat_target, c.dtol_rel, c.eps_v) == (1e-2, 1e-3, 2e-10, 1e-3)
-    for bad in ("script DCOHammerWalnut\n", "constraintSolver QP\n", "CCDMethod TightInclusion\n"):
+    for bad in ("script MCOSquash\n", "constraintSolver QP\n", "CCDMethod TightInclusion\n"):
         with pytest.raises(ss.UnsupportedKeyword):
             ss.SceneConfig.parse(bad)
 

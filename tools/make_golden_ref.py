@@ -325,6 +325,9 @@ INLINE = {
     "inline:script_head_tail_pull": _BOXRULE % ("headTailPull", _MAT, ""),
     "inline:script_scale_f": _BOXRULE % ("scaleF", _BAR, ""),
     "inline:script_stamp_inv": (_BOXRULE % ("stampInv", _BAR, "")).replace("energy NH", "energy FCR"),
+    # `script DCOCut`: the second component (a triangle as the knife) moves at (0, -1, -1) while its lowest node is above 0.001, over a cube on the ground
+    "inline:script_dco_cut": "energy NH\ntime 1 0.02\ndensity 1000\nstiffness 1e5 0.4\nscript DCOCut\nshapes input 2\ninput/tetMeshes/cube.msh 0 0.002 0  0 0 0  1 1 1\n"
+                             "input/triMeshes/triangle.obj 0.2 1.6 0.9  0 0 0  1 1 1\nselfCollisionOn\nground 0.1 0\ntol 1\n1e-4\n",
     "inline:script_tear": (_BOXRULE % ("tear", "input/tetMeshes/cube.msh 0 0 0  0 0 0  1 1 1", "")).replace("time 1 0.02", "time 1 0.1"),
     # scripts that pick their handles from the bounding box of the mesh (AnimScripter::initAnimScript): the lower half of a cube held under
     # gravity; one corner node pushed in -x; the bottom held and the top pressed down by a Neumann acceleration
@@ -386,6 +389,7 @@ SCENES += [
     ("script_scale_f", "inline:script_scale_f", "", 6),
     ("script_stamp_inv", "inline:script_stamp_inv", "", 6),
     ("mesh_seq_from_file", "inline:mesh_seq_from_file", "", 30),
+    ("script_dco_cut", "inline:script_dco_cut", "", 20),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
