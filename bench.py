@@ -256,6 +256,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(V, F, left, right, args.cpu_iters)
+            out["cpu_reference"] = cpu_reference(V, F)
     ctx.close()
     if rank == 0 and world == 1 and not args.no_contact:
         # the contact half of the path, timed by the same process: two stacked mat100 sheets with self-collision on (barrier terms,
@@ -366,6 +367,46 @@ def cpu_baseline(V, F, left, right, iters):
             "split_ms_per_iter": {"assembly_ms": 1e3 * (t[0] + t[1] + t[12]) / max(done, 1),
                                   "solve_ms": 1e3 * (t[2] + t[3] + t[4]) / max(done, 1),
                                   "ccd_linesearch_ms": 1e3 * (t[13] + t[14] + t[5] + t[9]) / max(done, 1)}}
+
+
+def cpu_reference(V, F):
+    """The reference's OWN code on the same scene, beside the port above: oracle/_ref/libipcref.so is ipc-sim/IPC's main.cpp / Optimizer.cpp /
+    Energy / Mesh compiled where they lie by oracle/Makefile.ref (built in the container that holds the reference; the .so travels with the
+    repository snapshot).  What it is NOT: the reference's production configuration -- this image has neither TBB nor CHOLMOD, so the build is
+    serial and its linear solver is this repository's CPU multifrontal Cholesky behind the reference's LinSysSolver interface.  One time step
+    of the bench scene (mat150, `script twist`, BE, dt 0.04, no gravity, self-collision off); the time is the reference's own `descent` timer."""
+    import re
+    import subprocess
+    import tempfile
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "oracle", "_ref", "libipcref.so")
+    if not os.path.exists(so):
+        return {"value": None, "kind": "reference", "note": "oracle/_ref/libipcref.so not present on this box"}
+    sys.path.insert(0, os.path.join(here, "tools"))
+    try:
+        import ref_compare as rc
+        from ipc_amd import lib as gl
+        with tempfile.TemporaryDirectory(prefix="ipcref_bench_") as tmp:
+            gl.save_tet_mesh(os.path.join(tmp, "mat.msh"), V, F)
+            with open(os.path.join(tmp, "scene.txt"), "w") as f:
+                f.write(f"energy NH\ntimeIntegration BE\ntime 0.04 0.04\ndensity 1000\nstiffness 2e4 0.4\nturnOffGravity\nscript twist\n"
+                        f"shapes input 1\n{tmp}/mat.msh 0 0 0  0 0 0  1 1 1\nselfCollisionOff\n")
+            t0 = time.perf_counter()
+            rcode, log = rc.run_reference(os.path.join(tmp, "scene.txt"), os.path.join(tmp, "out"), timeout=900, cwd=tmp)
+            wall = time.perf_counter() - t0
+            if rcode != 0:
+                return {"value": None, "kind": "reference", "note": "the reference run failed: " + log[-300:]}
+            its = int(rc.read_iter_counts(os.path.join(tmp, "out"), 1)[0])
+            info = open(os.path.join(tmp, "out", "info1.txt")).read()
+            m = re.search(r"([0-9.eE+-]+) s: descent", info)
+            descent = float(m.group(1)) if m else wall
+        return {"value": its / descent, "unit": "iter/s", "cores": 1, "kind": "reference",
+                "sample": f"time step 1 of the bench scene through the reference's own main() (libipcref.so): {its} Newton iterations in {descent:.1f} s "
+                          f"of its `descent` timer ({wall:.1f} s with set-up)",
+                "note": "serial build of the reference's sources (no TBB in this image); its LinSysSolver is this repository's CPU multifrontal Cholesky "
+                        "(no CHOLMOD in this image)"}
+    except Exception as e:  # noqa: BLE001  (a reported side figure must not take the bench line down)
+        return {"value": None, "kind": "reference", "note": f"not measured: {e!r}"[:300]}
 
 
 if __name__ == "__main__":
