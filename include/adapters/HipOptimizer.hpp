@@ -85,7 +85,18 @@ struct HipOptimizerParts {
     static bool residentScript(AnimScriptType t)
     {
         return t == AST_NULL || t == AST_TWIST || t == AST_FALL || t == AST_FALL_NOSHIFT || t == AST_DRAGRIGHT || t == AST_DCOFIX || t == AST_STRETCHNPAUSE
-            || t == AST_DCOSQUASH || t == AST_DCOSQUASH6 || t == AST_DCOROTCYLINDERS || t == AST_DCOVERSCHOORROLLER || t == AST_DCOSQUEEZEOUT;
+            || t == AST_DCOSQUASH || t == AST_DCOSQUASH6 || t == AST_DCOROTCYLINDERS || t == AST_DCOVERSCHOORROLLER || t == AST_DCOSQUEEZEOUT
+            || staticScript(t);
+    }
+    // scripts whose whole effect is decided in AnimScripter::initAnimScript / initVelocity (run by the base-class constructor): node sets that are
+    // held for good (ZERO or NONZERO without a velocity), changed start positions, a Neumann group, start velocities -- stepAnimScript does nothing
+    // for them (AnimScripter.cpp:1536-1551, 1814-1817, 1828-1830)
+    static bool staticScript(AnimScriptType t)
+    {
+        return t == AST_HANG || t == AST_HANG2 || t == AST_HANGTOPLEFT || t == AST_HANGLEFT || t == AST_SWING || t == AST_STAMP || t == AST_STAMPTOPLEFT
+            || t == AST_STAMPBOTH || t == AST_STAMPINV || t == AST_STAND || t == AST_STANDINV || t == AST_TOPBOTTOMFIX || t == AST_FIXLOWERHALF
+            || t == AST_CORNER || t == AST_SCALEF || t == AST_FIXRIGHTMOST1 || t == AST_LEFTHITRIGHT || t == AST_DROP || t == AST_XYROTATE
+            || t == AST_NMFIXBOTTOMDRAGLEFT || t == AST_NMFIXBOTTOMDRAGFORWARD;
     }
     HipOptimizerParts(const std::vector<Energy<3>*>& given, const Config& cfg, int requested, int device)
     {
@@ -519,6 +530,21 @@ protected:
                 chk(ipcgpu_opt_add_dirichlet(ctx, (int)ids.size(), ids.data(), lin, ang, 0.0, inf));
                 chk(ipcgpu_opt_set_dirichlet_motion(ctx, compI, lin, ang, rot ? ctr : nullptr, 1));
                 if (!rot) plateVel.push_back({ lin[0], lin[1], lin[2] });
+            }
+        }
+        else if (Parts::staticScript(cfg.animScriptType)) {
+            // the node sets the constructor picked: ZERO nodes leave the system, NONZERO ones form a Dirichlet group that never moves
+            std::vector<int> z, nz;
+            for (int v = 0; v < nSim; ++v)
+                if (m.isDBCVertex(v)) (m.vertexDBCType[v] == DirichletBCType::ZERO ? z : nz).push_back(v);
+            int group = 0;
+            if (!z.empty()) {
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)z.size(), z.data(), zero3, zero3, 0.0, inf));
+                ++group;
+            }
+            if (!nz.empty()) {
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)nz.size(), nz.data(), zero3, zero3, 0.0, inf));
+                chk(ipcgpu_opt_set_dirichlet_motion(ctx, group, zero3, zero3, nullptr, 1));
             }
         }
         else if (cfg.animScriptType == AST_DCOSQUEEZEOUT) {

@@ -208,3 +208,19 @@ def test_reference_main_absolute_parameters_resident(tmp_path):
     assert "percall mode" not in log
     assert np.array_equal(its, S["iters"][:steps]), (its.tolist(), S["iters"][:steps].tolist())
     assert np.abs(pos[-1] - S["positions"][steps - 1]).max() <= 1e-5 * np.abs(S["positions"][steps - 1]).max()  # (Newton tolerance 2e-2 absolute; observed 1.4e-6)
+
+
+@pytest.mark.gpu
+@needs_exe
+@pytest.mark.parametrize("name", ["script_hang2", "script_corner", "script_left_hit_right", "script_stamp_inv"])
+def test_reference_main_static_scripts_resident(name, tmp_path):
+    """Scripts whose effect is decided in the base-class constructor (held node sets ZERO / NONZERO, start velocities, changed start positions):
+    HipOptimizer hands the sets the reference's own AnimScripter picked to the library and stays in resident mode."""
+    from test_oracle_vs_reference import check_boxrule
+    S, meshes = load_scene(name)
+    pos, its, log = run_main_hip(S, meshes, tmp_path, int(S["steps"]))
+    assert "percall mode" not in log
+    if name == "script_stamp_inv":  # 548 Newton iterations out of an inside-out start (see test_gpu_vs_reference.py)
+        assert abs(int(its[0]) - int(S["iters"][0])) <= 30 and np.abs(pos[-1] - S["positions"][-1]).max() <= 1e-5 * np.abs(S["positions"]).max(), its.tolist()
+        return
+    check_boxrule(S, pos, its, 3e-5)
