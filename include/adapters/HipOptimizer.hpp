@@ -86,8 +86,10 @@ struct HipOptimizerParts {
     {
         return t == AST_NULL || t == AST_TWIST || t == AST_FALL || t == AST_FALL_NOSHIFT || t == AST_DRAGRIGHT || t == AST_DCOFIX || t == AST_STRETCHNPAUSE
             || t == AST_DCOSQUASH || t == AST_DCOSQUASH6 || t == AST_DCOROTCYLINDERS || t == AST_DCOVERSCHOORROLLER || t == AST_DCOSQUEEZEOUT
-            || staticScript(t);
+            || staticScript(t) || pulledScript(t);
     }
+    // handle sets that move at a constant velocity for good (AnimScripter.cpp:459-473, 502-516, 790-807, 860-878, 895-910; per step :1597-1603, 1820-1826)
+    static bool pulledScript(AnimScriptType t) { return t == AST_STRETCH || t == AST_SQUASH || t == AST_DRAGDOWN || t == AST_CURTAIN || t == AST_PUSHRIGHTMOST1; }
     // scripts whose whole effect is decided in AnimScripter::initAnimScript / initVelocity (run by the base-class constructor): node sets that are
     // held for good (ZERO or NONZERO without a velocity), changed start positions, a Neumann group, start velocities -- stepAnimScript does nothing
     // for them (AnimScripter.cpp:1536-1551, 1814-1817, 1828-1830)
@@ -545,6 +547,49 @@ protected:
             if (!nz.empty()) {
                 chk(ipcgpu_opt_add_dirichlet(ctx, (int)nz.size(), nz.data(), zero3, zero3, 0.0, inf));
                 chk(ipcgpu_opt_set_dirichlet_motion(ctx, group, zero3, zero3, nullptr, 1));
+            }
+        }
+        else if (Parts::pulledScript(cfg.animScriptType)) {
+            // the NONZERO sets the constructor picked, with the velocities initAnimScript gives them (they are private to AnimScripter: restated)
+            std::vector<std::pair<std::vector<int>, std::array<double, 3>>> groups;
+            if (cfg.animScriptType == AST_STRETCH || cfg.animScriptType == AST_SQUASH) {
+                if (m.borderVerts_primitive.size() != 2) throw std::runtime_error("HipOptimizer: the script needs two border vertex sets");
+                const double v = cfg.animScriptType == AST_STRETCH ? -0.1 : 0.03; // (-1)^bI * v along x
+                groups.push_back({ m.borderVerts_primitive[0], { v, 0.0, 0.0 } });
+                groups.push_back({ m.borderVerts_primitive[1], { -v, 0.0, 0.0 } });
+            }
+            else if (cfg.animScriptType == AST_CURTAIN) {
+                // eight pins along the top edge, pin i drawn in +x at 0.04 (7 - i) / 7; a node takes the first pin whose window holds it
+                double lo = 1.0e300, hi = -1.0e300;
+                for (int v = 0; v < nSim; ++v) {
+                    lo = std::min(lo, m.V(v, 0));
+                    hi = std::max(hi, m.V(v, 0));
+                }
+                groups.resize(8);
+                for (int pin = 0; pin < 8; ++pin) groups[pin].second = { 0.04 * (7.0 - pin) / 7.0, 0.0, 0.0 };
+                for (int v = 0; v < nSim; ++v) {
+                    if (m.vertexDBCType[v] != DirichletBCType::NONZERO) continue;
+                    for (int pin = 0; pin < 8; ++pin) {
+                        const double x0 = lo + (hi - lo) / 7.0 * pin;
+                        if (m.V(v, 0) > x0 - (hi - lo) * 0.0025 && m.V(v, 0) < x0 + (hi - lo) * 0.0025) {
+                            groups[pin].first.push_back(v);
+                            break;
+                        }
+                    }
+                }
+            }
+            else {
+                std::vector<int> ids;
+                for (int v = 0; v < nSim; ++v)
+                    if (m.vertexDBCType[v] == DirichletBCType::NONZERO) ids.push_back(v);
+                if (cfg.animScriptType == AST_DRAGDOWN) groups.push_back({ ids, { 0.0, -1.5, 0.0 } });
+                else groups.push_back({ ids, { -0.15, 0.0, 0.0 } });
+            }
+            int group = 0;
+            for (const auto& g : groups) {
+                if (g.first.empty()) continue;
+                chk(ipcgpu_opt_add_dirichlet(ctx, (int)g.first.size(), g.first.data(), g.second.data(), zero3, 0.0, inf));
+                chk(ipcgpu_opt_set_dirichlet_motion(ctx, group++, g.second.data(), zero3, nullptr, 1));
             }
         }
         else if (cfg.animScriptType == AST_DCOSQUEEZEOUT) {

@@ -212,10 +212,11 @@ def test_reference_main_absolute_parameters_resident(tmp_path):
 
 @pytest.mark.gpu
 @needs_exe
-@pytest.mark.parametrize("name", ["script_hang2", "script_corner", "script_left_hit_right", "script_stamp_inv"])
+@pytest.mark.parametrize("name", ["script_hang2", "script_corner", "script_left_hit_right", "script_stamp_inv", "script_squash", "script_dragdown"])
 def test_reference_main_static_scripts_resident(name, tmp_path):
-    """Scripts whose effect is decided in the base-class constructor (held node sets ZERO / NONZERO, start velocities, changed start positions):
-    HipOptimizer hands the sets the reference's own AnimScripter picked to the library and stays in resident mode."""
+    """Scripts whose effect is decided in the base-class constructor (held node sets ZERO / NONZERO, start velocities, changed start positions) and
+    sets pulled at a constant velocity (squash; dragdown through the barrier of a ground plane): HipOptimizer hands the sets the reference's own
+    AnimScripter picked to the library and stays in resident mode."""
     from test_oracle_vs_reference import check_boxrule
     S, meshes = load_scene(name)
     pos, its, log = run_main_hip(S, meshes, tmp_path, int(S["steps"]))
