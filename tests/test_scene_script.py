@@ -568,3 +568,57 @@ def test_aco_squash6_on_the_gpu_beside_the_oracle(orc, gpu_lib):
         assert np.abs(gb.state()["V"] - ob.state()["V"]).max() < 1e-7 * np.abs(ob.state()["V"]).max(), k
     assert limited
     gb.close()
+
+
+class _MockBackend:
+    """records what AssembledScene.before_step asks for; positions are set by the test"""
+
+    def __init__(self, V):
+        self.V, self.calls = np.array(V, dtype=np.float64), []
+
+    def state(self):
+        return {"V": self.V}
+
+    def set_dirichlet_motion(self, g, **k):
+        self.calls.append(("motion", g, tuple(k.get("lin_vel", (0, 0, 0))), tuple(k.get("ang_vel_deg", (0, 0, 0)))))
+
+    def end_dirichlet(self, g, t):
+        self.calls.append(("end", g, t))
+
+
+def _box_scene(script, n=(2, 2, 2), second=None):
+    V0, F0 = scene.make_box(*n)
+    shapes = "m.msh 0 0 0  0 0 0  1 1 1\n" + (second or "")
+    cfg = ss.SceneConfig.parse(f"script {script}\nshapes input {1 + (second is not None)}\n{shapes}", "/x")
+    return ss.assemble(cfg, lambda p: (V0.copy(), F0.copy(), scene.surface_tris(F0)))
+
+
+def test_before_step_rules_on_a_mock_backend():
+    """The state-dependent halves of the rule scripts (AnimScripter::stepAnimScript), driven by hand: `push` stops for good, `tear` changes sign in
+    EVERY step that finds the turning node beyond its mark, `toggleTop` lets its set go once, `DCOCut` pauses while the knife is below 0.001."""
+    sc = _box_scene("push")
+    be = _MockBackend(sc.V)
+    r = sc.release
+    assert r["kind"] == "turn" and r["stop"] and not sc.before_step(be, 0.0) and be.calls == []
+    be.V[r["turn"], 1] = r["lo"] - 1e-3
+    assert sc.before_step(be, 0.1) and be.calls[-1] == ("motion", 1, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0)) and r["done"]
+    assert not sc.before_step(be, 0.2)  # nothing more, whatever the node does
+    sc = _box_scene("tear")
+    be, r = _MockBackend(sc.V), sc.release
+    be.V[r["turn"], 0] = r["lo"] - 1e-3
+    assert sc.before_step(be, 0.0) and be.calls[-1][2] == (5.0, 0.0, 0.0)
+    assert sc.before_step(be, 0.1) and be.calls[-1][2] == (-5.0, 0.0, 0.0)  # still beyond the mark: the sign changes again
+    be.V[r["turn"], 0] = r["lo"] + 1.0
+    assert not sc.before_step(be, 0.2)
+    sc = _box_scene("toggleTop")
+    be, r = _MockBackend(sc.V), sc.release
+    assert r["kind"] == "let_go" and not sc.before_step(be, 0.0)
+    be.V[r["turn"], 0] = r["limit"] - 1e-6
+    assert sc.before_step(be, 0.3) and be.calls == [("end", 0, 0.3)] and not sc.before_step(be, 0.4)
+    sc = _box_scene("DCOCut", second="k.msh 0 2 0  0 0 0  1 1 1\n")
+    be, r = _MockBackend(sc.V), sc.release
+    assert r["kind"] == "while_above" and len(sc.dirichlet) == 1 and sc.motions[0][0] == (0.0, -1.0, -1.0) and not sc.before_step(be, 0.0)
+    be.V[r["ids"], 1] -= be.V[r["ids"], 1].min() - 5e-4  # the knife's lowest node below the mark
+    assert sc.before_step(be, 0.1) and be.calls[-1][:3] == ("motion", 0, (0.0, 0.0, 0.0))
+    be.V[r["ids"], 1] += 0.1
+    assert sc.before_step(be, 0.2) and be.calls[-1][:3] == ("motion", 0, (0.0, -1.0, -1.0))
