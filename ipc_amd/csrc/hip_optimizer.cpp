@@ -20,6 +20,12 @@
 
 namespace ipcgpu {
 
+// The reference's Optimizer constructor calls setTime(10.0, 0.025) (Optimizer.cpp:116) and derives eps_v^2 h^2 (fricDHat0 / fricDHatTarget, :290-303)
+// and CN_MBC (:268) from THAT step size; main.cpp:1398 sets the scene's dt afterwards and setTime (:421-429) recomputes neither.  So in the reference
+// these three carry h = 0.025 whatever `time` the scene file gives -- found on otherExamples/typical/sphere1K_DCORotCylinders.txt (dt 0.04, selfFric 0.5:
+// 47 Newton iterations in the step after the first contact, 20 with eps_v scaled by the scene's own dt; same counts once this is followed).
+static constexpr double kCtorDtSq = 0.025 * 0.025;
+
 namespace {
 struct Tic {
     double& acc;
@@ -102,7 +108,7 @@ void HipOptimizer::setRelGL2Tol(double relTol)
 {
     relGL2Tol = relTol * relTol;
     targetGRes = std::sqrt(relGL2Tol * (absParameters ? 1.0 : mesh.bboxDiag2 * dtSq)); // Optimizer.cpp:2941-2945
-    CN_MBC = std::sqrt(1.0e-4 * mesh.bboxDiag2 * dtSq); // Optimizer.cpp:268
+    CN_MBC = std::sqrt(1.0e-4 * mesh.bboxDiag2 * kCtorDtSq); // Optimizer.cpp:268 -- evaluated in the constructor, see kCtorDtSq
 }
 
 void HipOptimizer::setParameterScaling(bool absolute, double dTolRel_, double kappaMinMultiplier_)
@@ -1260,8 +1266,8 @@ void HipOptimizer::beginTimestep()
         // friction: lagged sets reset, eps_v^2 h^2 (Optimizer.cpp:1525-1533, 286-304), then lagged at x^n (:1553-1600)
         if (contact) contact->frictionLagClear();
         for (auto& h : planes) h->lagClear();
-        fricDHat0 = epsV * epsV * dtSq * lenScale2();
-        fricDHatTarget = epsVTarget > 0.0 ? epsVTarget * epsVTarget * dtSq * lenScale2() : fricDHat0;
+        fricDHat0 = epsV * epsV * kCtorDtSq * lenScale2(); // Optimizer.cpp:290-303: set once in the constructor, see kCtorDtSq
+        fricDHatTarget = epsVTarget > 0.0 ? epsVTarget * epsVTarget * kCtorDtSq * lenScale2() : fricDHat0;
         fricDHat = solveFric() ? fricDHat0 : -1.0;
         fricIterI = 0;
         updateFrictionLag();

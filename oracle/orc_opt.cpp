@@ -17,6 +17,10 @@
 
 using namespace orc;
 
+// The reference's Optimizer constructor calls setTime(10.0, 0.025) (Optimizer.cpp:116) and derives fricDHat0 / fricDHatTarget (:290-303) and CN_MBC (:268)
+// from that step size; the scene's dt arrives later (main.cpp:1398) through setTime (:421-429), which recomputes neither: they carry h = 0.025 always.
+static constexpr double kCtorDtSq = 0.025 * 0.025;
+
 struct orc_opt {
     Mesh* m;
     double dt, dtSq, gravity[3] = { 0, 0, 0 };
@@ -595,7 +599,7 @@ orc_opt* orc_opt_create(orc_mesh* mh, double dt, int withGravity, int nthreads)
     o->dt = dt;
     o->dtSq = dt * dt;
     if (withGravity) o->gravity[1] = -9.80665; // Optimizer.cpp:112-115
-    o->CN_MBC = std::sqrt(1.0e-4 * m.bboxDiag2 * o->dtSq); // Optimizer.cpp:268
+    o->CN_MBC = std::sqrt(1.0e-4 * m.bboxDiag2 * kCtorDtSq); // Optimizer.cpp:268 -- evaluated in the constructor, see kCtorDtSq
     o->nthreads = nthreads > 0 ? nthreads : omp_get_max_threads();
     omp_set_num_threads(o->nthreads);
     o->velocity.assign(3 * m.nV, 0.0);
@@ -914,8 +918,8 @@ void orc_opt_begin_timestep(orc_opt* o)
         // friction: lagged sets reset, eps_v^2 h^2 (Optimizer.cpp:1525-1533, 286-304), then lagged at x^n (:1553-1600)
         o->lag = FrictionLag();
         for (auto& s : o->hsLagSet) s.clear();
-        o->fricDHat0 = o->epsV * o->epsV * o->dtSq * o->lenScale2();
-        o->fricDHatTarget = o->epsVTarget > 0.0 ? o->epsVTarget * o->epsVTarget * o->dtSq * o->lenScale2() : o->fricDHat0;
+        o->fricDHat0 = o->epsV * o->epsV * kCtorDtSq * o->lenScale2(); // set once in the reference's constructor, see kCtorDtSq
+        o->fricDHatTarget = o->epsVTarget > 0.0 ? o->epsVTarget * o->epsVTarget * kCtorDtSq * o->lenScale2() : o->fricDHat0;
         o->fricDHat = o->solveFric() ? o->fricDHat0 : -1.0;
         o->fricIterI = 0;
         updateFrictionLag(o);

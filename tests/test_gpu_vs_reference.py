@@ -10,7 +10,7 @@ import pytest
 
 from test_oracle_vs_reference import (BOXRULE_SCENES, CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, SHIPPED_SCENES, check_chain, check_codim, check_damped_bar,
                                       check_plates, check_shipped,
-                                      check_boxrule, check_restart, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
+                                      check_boxrule, check_restart, check_rot_cylinders, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
 
@@ -317,6 +317,15 @@ def test_box_rule_scripts_against_the_reference(name, tol, gpu_lib):
         assert abs(int(its[0]) - int(S["iters"][0])) <= 30 and np.abs(pos[-1] - S["positions"][-1]).max() <= 1e-5 * np.abs(S["positions"]).max(), its.tolist()
         return
     check_boxrule(S, pos, its, max(3 * tol, 1e-7))
+
+
+def test_sphere_between_turning_cylinders_against_the_reference(gpu_lib):
+    """sphere1K_DCORotCylinders.txt (dt 0.04, friction 0.5, four turning surface-only cylinders) on the HIP stepper"""
+    S, meshes = load_scene("sphere_rot_cylinders")
+    c = gpu_lib.Context(0)
+    pos, its = run_scene(S, meshes, c, 5)
+    c.close()
+    check_rot_cylinders(S, pos, its)
 
 
 def test_mesh_seq_from_file_against_the_reference(gpu_lib):

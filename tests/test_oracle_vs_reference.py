@@ -523,6 +523,25 @@ def test_box_rule_scripts_against_the_reference(name, tol):
     check_boxrule(S, pos, its, tol)
 
 
+def check_rot_cylinders(S, pos, its):
+    """sphere1K_DCORotCylinders.txt as shipped (dt 0.04, selfFric 0.5): identical to round-off while the ball falls, the 19 iterations of the first
+    contact (step 4), and the step after it within the spread of a stiff stick-slip solve -- 43 iterations here, 47 in the reference, positions 4e-5.
+    With eps_v^2 h^2 scaled by the scene's dt instead of the 0.025 the reference's constructor leaves in it (Optimizer.cpp:116, 290-303) that step took
+    20 iterations and ended 2e-2 away: the scene that exposed it."""
+    ref = S["positions"]
+    n = pos.shape[1]
+    assert np.array_equal(its[:4], S["iters"][:4]), (its.tolist(), S["iters"].tolist())
+    assert np.abs(pos[:3] - ref[:3, :n]).max() <= 1e-13 * np.abs(ref).max()
+    assert np.abs(pos[3] - ref[3, :n]).max() <= 1e-4 * np.abs(ref).max() and np.abs(pos[4] - ref[4, :n]).max() <= 1e-3 * np.abs(ref).max()
+    assert abs(int(its[4]) - int(S["iters"][4])) <= 12, (its.tolist(), S["iters"].tolist())
+
+
+def test_sphere_between_turning_cylinders_against_the_reference():
+    S, meshes = load_scene("sphere_rot_cylinders")
+    pos, its = run_scene(S, meshes, oracle_backend(), 5)
+    check_rot_cylinders(S, pos, its)
+
+
 def test_mesh_seq_from_file_against_the_reference():
     """`script meshSeqFromFile <folder>` (Config.cpp:161-164, AnimScripter.cpp:1222-1236, 2126-2144): the surface-only component is moved onto the
     positions of <folder>/<n>.obj before step n (counted from 1); the cube lands on the turning, rising triangle in step 25."""

@@ -211,7 +211,7 @@ SCENES = [
 # deformed, moving, constraints active -- so every step can be held to round-off instead of "the same minimiser within the Newton
 # tolerance": the scenes above all touch down from exact rest (F = I), where IglUtils::makePD2d is decided by round-off.
 RESTARTS = {"two_cubes_fall": (30, 8), "aligned_cubes": (20, 8), "aligned_cubes_fric": (24, 10), "cubes_dhat_homotopy": (14, 4),
-            "two_cubes_nm_damped": (28, 8), "rotate_co": (20, 8)}
+            "two_cubes_nm_damped": (28, 8), "rotate_co": (20, 8), "sphere_rot_cylinders": (4, 4)}
 
 
 # scene scripts written here (the reference's own input files do not exercise these scripts on a mesh small enough for a fixture)
@@ -390,6 +390,9 @@ SCENES += [
     ("script_stamp_inv", "inline:script_stamp_inv", "", 6),
     ("mesh_seq_from_file", "inline:mesh_seq_from_file", "", 30),
     ("script_dco_cut", "inline:script_dco_cut", "", 20),
+    # otherExamples/typical/sphere1K_DCORotCylinders.txt as shipped: a ball dropped between four turning cylinders (surface-only components, `script
+    # DCORotCylinders`), selfFric 0.5; first contact in step 4 (19 Newton iterations), continued from the reference's own state after it
+    ("sphere_rot_cylinders", "otherExamples/typical/sphere1K_DCORotCylinders.txt", "", 8),
     ("squash6_small", "inline:squash6_small", "", 44),
     ("squash6_contact", "inline:squash6_contact", "", 24),
     # BASELINE configs[1] on the reference's own mesh: 21_scalability/mat100x100_twist.txt (mat100x100t40.msh, 58 806 tets, `script twist`)
