@@ -262,6 +262,9 @@ int ipcgpu_halfspace_move(ipcgpu_ctx*, int id, const double* delta3, double slac
 int ipcgpu_halfspace_step_bound(ipcgpu_ctx*, int id, const double* searchDir_3nV, double slackness, double* stepSize_inout);
 /* ---- lagged smoothed Coulomb friction (FrictionUtils.hpp, SelfCollisionHandler.cpp:2481-2988, HalfSpace.cpp:272-381)
  * `selfFric mu` / `fricIterAmt n` / eps_v = tuning[4] (Config.cpp:482-488, 550-551, 45).  Self friction needs self collision. */
+/* NOTE on eps_v: the smoothing distance the friction terms use is eps_v^2 * h^2 * (bounding-box diagonal)^2 with h = 0.025 -- the step size of the
+ * setTime(10.0, 0.025) inside the reference's Optimizer constructor (Optimizer.cpp:116, 290-303) -- NOT the dt of ipcgpu_opt_init: the reference sets
+ * the scene's dt afterwards (main.cpp:1398) without recomputing it, and this library follows the reference (CN_MBC of :268 likewise). */
 int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, double epsV);
 /* eps_v homotopy: `tuning`'s sixth entry (Config.cpp:41-45, Optimizer.cpp:296-303).  The smoothing distance of the friction terms starts every
    time step at eps_v (fifth entry) and is halved down -- or clamped up -- to eps_v_target between the friction-lag passes (:1776-1781); the
