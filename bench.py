@@ -369,12 +369,13 @@ def cpu_baseline(V, F, left, right, iters):
                                   "ccd_linesearch_ms": 1e3 * (t[13] + t[14] + t[5] + t[9]) / max(done, 1)}}
 
 
-def cpu_reference(V, F):
+def cpu_reference(V, F, steps=4):
     """The reference's OWN code on the same scene, beside the port above: oracle/_ref/libipcref.so is ipc-sim/IPC's main.cpp / Optimizer.cpp /
     Energy / Mesh compiled where they lie by oracle/Makefile.ref (built in the container that holds the reference; the .so travels with the
-    repository snapshot).  What it is NOT: the reference's production configuration -- this image has neither TBB nor CHOLMOD, so the build is
-    serial and its linear solver is this repository's CPU multifrontal Cholesky behind the reference's LinSysSolver interface.  One time step
-    of the bench scene (mat150, `script twist`, BE, dt 0.04, no gravity, self-collision off); the time is the reference's own `descent` timer."""
+    repository snapshot), run through its own main() on ALL host cores: its loops are the ones it hands to tbb::parallel_for, executed by the
+    std::thread pool of oracle/refshim/tbb/parallel_for.h (IPCREF_THREADS; this image has no oneTBB), and its LinSysSolver is this repository's
+    CPU multifrontal Cholesky on the same number of OpenMP threads (this image has no CHOLMOD).  The first `steps` time steps of the bench scene
+    (mat150, `script twist`, BE, dt 0.04, no gravity, self-collision off: >= 10 Newton iterations); the time is the reference's own `descent` timer."""
     import re
     import subprocess
     import tempfile
@@ -383,30 +384,38 @@ def cpu_reference(V, F):
     if not os.path.exists(so):
         return {"value": None, "kind": "reference", "note": "oracle/_ref/libipcref.so not present on this box"}
     sys.path.insert(0, os.path.join(here, "tools"))
+    cores = os.cpu_count() or 1
+    saved = os.environ.get("IPCREF_THREADS")
     try:
         import ref_compare as rc
         from ipc_amd import lib as gl
+        os.environ["IPCREF_THREADS"] = str(cores)
         with tempfile.TemporaryDirectory(prefix="ipcref_bench_") as tmp:
             gl.save_tet_mesh(os.path.join(tmp, "mat.msh"), V, F)
             with open(os.path.join(tmp, "scene.txt"), "w") as f:
-                f.write(f"energy NH\ntimeIntegration BE\ntime 0.04 0.04\ndensity 1000\nstiffness 2e4 0.4\nturnOffGravity\nscript twist\n"
+                f.write(f"energy NH\ntimeIntegration BE\ntime {0.04 * steps:.17g} 0.04\ndensity 1000\nstiffness 2e4 0.4\nturnOffGravity\nscript twist\n"
                         f"shapes input 1\n{tmp}/mat.msh 0 0 0  0 0 0  1 1 1\nselfCollisionOff\n")
             t0 = time.perf_counter()
             rcode, log = rc.run_reference(os.path.join(tmp, "scene.txt"), os.path.join(tmp, "out"), timeout=900, cwd=tmp)
             wall = time.perf_counter() - t0
             if rcode != 0:
                 return {"value": None, "kind": "reference", "note": "the reference run failed: " + log[-300:]}
-            its = int(rc.read_iter_counts(os.path.join(tmp, "out"), 1)[0])
-            info = open(os.path.join(tmp, "out", "info1.txt")).read()
+            its = int(rc.read_iter_counts(os.path.join(tmp, "out"), steps).sum())
+            info = open(os.path.join(tmp, "out", f"info{steps}.txt")).read()
             m = re.search(r"([0-9.eE+-]+) s: descent", info)
             descent = float(m.group(1)) if m else wall
-        return {"value": its / descent, "unit": "iter/s", "cores": 1, "kind": "reference",
-                "sample": f"time step 1 of the bench scene through the reference's own main() (libipcref.so): {its} Newton iterations in {descent:.1f} s "
+        return {"value": its / descent, "unit": "iter/s", "cores": cores, "kind": "reference",
+                "sample": f"time steps 1-{steps} of the bench scene through the reference's own main() (libipcref.so): {its} Newton iterations in {descent:.1f} s "
                           f"of its `descent` timer ({wall:.1f} s with set-up)",
-                "note": "serial build of the reference's sources (no TBB in this image); its LinSysSolver is this repository's CPU multifrontal Cholesky "
-                        "(no CHOLMOD in this image)"}
+                "note": f"the reference's sources on {cores} threads: its tbb::parallel_for loops on a std::thread pool (no oneTBB in this image), its LinSysSolver "
+                        "= this repository's CPU multifrontal Cholesky on the same threads (no CHOLMOD in this image); IPCREF_THREADS=1 is the serial build the fixtures come from"}
     except Exception as e:  # noqa: BLE001  (a reported side figure must not take the bench line down)
         return {"value": None, "kind": "reference", "note": f"not measured: {e!r}"[:300]}
+    finally:
+        if saved is None:
+            os.environ.pop("IPCREF_THREADS", None)
+        else:
+            os.environ["IPCREF_THREADS"] = saved
 
 
 if __name__ == "__main__":

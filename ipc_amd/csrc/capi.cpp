@@ -2,6 +2,7 @@
 #include "../../include/ipcgpu.h"
 #include "hip_ipc.h"
 #include "msh_io.h"
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -109,7 +110,14 @@ int ipcgpu_ctx_create(int device_id, ipcgpu_ctx** out)
         HIP_CHECK(hipSetDevice(device_id));
         auto* c = new ipcgpu_ctx;
         c->device = device_id;
-        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        {
+            // the context's stream carries the dependent chain of every Newton iteration (pivot steps of the top separators): highest priority, so that its
+            // workgroups are placed ahead of the bulk work the solver keeps on its own streams beside it (Schur passes, forward sweep)
+            int lo = 0, hi = 0;
+            HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            if (std::getenv("IPCGPU_NO_STREAM_PRIORITY")) hi = lo = 0;
+            HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+        }
         c->mesh.reset(new HipMesh);
         c->lin.reset(new HipLinSysSolver(c->stream));
         c->opt.reset(new HipOptimizer(*c->mesh, *c->lin, c->stream));

@@ -64,12 +64,16 @@ private:
         std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1
         Range schur; // one-pass Schur complement tiles of the big fronts
         bool schur64 = false; // ... as 64 x 64 tiles (k_big_schur64) instead of 32 x 32 with the columns split over the waves
+        // round 4: on the levels whose pivot chain is long the update rides on the chain's launches in passes of a few panels (role S of k_big_step);
+        // `schur` is then empty.  stepTop: the level's step launches carry roles C / S (k_big_step<true>)
+        bool stepTop = false;
         Range fwdRect, bwdInit; // descriptors of the row-/column-parallel halves of the big-front solves
         Range bigTri; // into triList_: big fronts whose triangle is swept by one workgroup (no explicit inverse)
         Range xinvFwd, xinvBwd; // into xinvDesc_: row / column blocks of the fronts with an explicit inverse
     };
     int rank_ = 0, world_ = 1;
     long long schur64Min_ = 512;
+    bool xinvBorder_ = true; // X = L11^-1 by bordering inside the step launches (IPCGPU_MF_XINV_BORDER=0: recursive doubling on the side stream)
     int xinvSkipTop_ = 0; // fronts of the last n levels solve their triangles block by block instead of through an explicit inverse (IPCGPU_MF_XINV_SKIP_TOP)
     AllreduceFn allreduce_ = nullptr;
     AllreduceStreamFn allreduceStream_ = nullptr;
@@ -108,6 +112,8 @@ private:
     Range plainBlocks_; // diagonal blocks of all other fronts (inverted at the end of the factorisation)
     DevBuf<int> invBlockList_;
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
+    bool fwdRootOnMain_ = true, fwdJoined_ = false; // the root's forward sweep on the main stream (IPCGPU_MF_FWD_ROOT_ON_MAIN=0: on the forward stream like the other levels)
+    int schurFold_ = 4, schurFoldMinSteps_ = 8; // IPCGPU_MF_SCHUR_FOLD: panels per folded pass (0 = one pass behind the chain); ..._MIN: levels with at least this many panels
     // factorizeSolve(): the forward sweep of a level is enqueued on its own stream as soon as that level's factor kernels are, so that it
     // runs beside the latency-bound pivot chain of the levels above instead of behind the whole factorisation
     hipStream_t fwd_ = nullptr;

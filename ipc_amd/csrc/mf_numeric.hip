@@ -1127,12 +1127,346 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
     if (bad) atomicOr(flag, 1);
 }
 
+// Schur complement of a big front in one pass: S(i, j) -= sum_{c < nc} L(i, c) L(j, c) for i, j >= nc.  Doing this per
+// 32-column step (right-looking) re-reads and re-writes the whole update matrix every step, which made the middle levels
+// of the tree HBM-bound; here every tile is read-modify-written once.  desc = (front, ti, tj, 0), 32 x 32 tiles, ti >= tj.
+// One workgroup per 32 x 32 tile of S, four waves that split the nc columns of L between them (chunk c goes to wave c mod 4)
+// and combine through LDS in a fixed order at the end.  Upper levels of the tree have a handful of fronts: with 64 x 64
+// tiles and a serial loop over all of nc, a level was a few dozen workgroups each waiting out nc / 32 dependent
+// load -> multiply rounds.  The MFMA operands come straight from the front (a lane's A / B entry is one double of L; 16
+// lanes read 16 consecutive rows), so the loop has no LDS staging and no barrier.  The product is formed transposed,
+// D(j, i): the 16 lanes of an accumulator row hold 16 consecutive rows i of one column j, which makes the read-modify-write
+// of the column-major front 128-byte contiguous.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15],
+// D column = l & 15, row = (l >> 4) + 4 reg.
+constexpr int TQ = 32; // Schur tile
+// [cLo, cHi): the columns of L of this pass (multiples of 32).  One pass over all columns behind the chain (k_big_schur) on most levels; on the top
+// levels, where the pivot chain is what the level takes, the update rides on the chain's own launches in passes of a few panels (role S of k_big_step,
+// round 4): only the last pass is left behind the chain.  red: 4096 doubles of LDS, [wave][16 x 16 tile][D layout: 64 lanes x 4].
+__device__ __forceinline__ void schur_tile32(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi,
+    double (*red)[4][256])
+{
+    const int nc = min(ncAll, cHi);
+    if (cLo >= nc) return; // a front with fewer panels than the widest of its level: nothing left for this pass
+    const int tid = threadIdx.x;
+    const int i0 = ncAll + TQ * ti, j0 = ncAll + TQ * tj; // the tile sits behind ALL own columns of the front; nc is the end of this pass
+    const int wv = tid >> 6, l = tid & 63;
+    const int ar = l & 15, ak = l >> 4;
+    // the entries this wave will update at the end (16 x 16 tile wv of the 32 x 32 tile) are requested now: as a
+    // read-modify-write at the end they were four dependent memory round trips behind the reduction
+    double old[4];
+    {
+        const int row = min(i0 + 16 * (wv & 1) + ar, N - 1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) old[r] = F[row + (long long)N * min(j0 + 16 * (wv >> 1) + ak + 4 * r, N - 1)];
+    }
+    f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+    // rows past the end of the front are clamped: their products land in entries that are never written
+    const double* pa0 = F + min(i0 + ar, N - 1);
+    const double* pa1 = F + min(i0 + 16 + ar, N - 1);
+    const double* pb0 = F + min(j0 + ar, N - 1);
+    const double* pb1 = F + min(j0 + 16 + ar, N - 1);
+    // The nc columns go to the four waves in chunks of CW.  The loads of a wave's next chunk are issued before the products
+    // of the current one and only touched after them (the compiler neither pipelines the loop nor keeps that order by itself:
+    // hence the scheduling fences).  Loads are unconditional with a clamped column; past nc only the A operands need zeroing.
+    constexpr int CW = 16, CS = CW / 4;
+    const int nch = (nc + CW - 1) / CW, ch0 = cLo / CW;
+    double a0[CS], a1[CS], b0[CS], b1[CS], na0[CS], na1[CS], nb0[CS], nb1[CS];
+    auto fetch = [&](int ch, double* x0, double* x1, double* y0, double* y1) {
+#pragma unroll
+        for (int ks = 0; ks < CS; ++ks) {
+            const long long off = (long long)N * min(CW * ch + 4 * ks + ak, nc - 1);
+            x0[ks] = pa0[off];
+            x1[ks] = pa1[off];
+            y0[ks] = pb0[off];
+            y1[ks] = pb1[off];
+        }
+    };
+    auto mult = [&](int ch, const double* x0, const double* x1, const double* y0, const double* y1) {
+#pragma unroll
+        for (int ks = 0; ks < CS; ++ks) {
+            const bool in = CW * ch + 4 * ks + ak < nc;
+            const double m0 = in ? y0[ks] : 0.0, m1 = in ? y1[ks] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x0[ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x1[ks], acc[1][1], 0, 0, 0);
+        }
+    };
+    // two register sets, ping-pong (a copy from a "next" set would wait for its loads at the end of every iteration)
+    // the fetches are unconditional (past the end they re-read the clamped last column): behind a branch, the compiler's wait
+    // counters have to assume the loads were not issued and the products end up waiting for the newest load
+    fetch(ch0 + wv, a0, a1, b0, b1);
+    for (int ch = ch0 + wv; ch < nch; ch += 8) {
+        fetch(ch + 4, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(ch, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(ch + 8, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 4 < nch) mult(ch + 4, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wv][2 * nj + mi][64 * r + l] = acc[nj][mi][r];
+    __syncthreads();
+    // wave q finishes 16 x 16 tile q = 2 nj + mi
+    const int nj = wv >> 1, mi = wv & 1;
+    const int row = i0 + 16 * mi + ar;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int col = j0 + 16 * nj + ak + 4 * r;
+        const double v = ((red[0][wv][64 * r + l] + red[1][wv][64 * r + l]) + red[2][wv][64 * r + l]) + red[3][wv][64 * r + l];
+        if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[r] - v;
+    }
+}
+__global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc, double* __restrict__ fronts)
+{
+    __shared__ double red[4][4][256];
+    // two records per workgroup (see k_big_step): (front, ti, tj, 0) and (N, nc, front offset)
+    const int4 d = desc[2 * blockIdx.x];
+    const int4 d2 = desc[2 * blockIdx.x + 1];
+    schur_tile32(d2.x, d2.y, fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z), d.y, d.z, 0, 1 << 30, red);
+}
+
+// The same update with 64 x 64 tiles, for levels of the tree that have thousands of tiles anyway: one wave per 32 x 32 quadrant running over
+// ALL nc columns, no split of the columns over the waves and so no reduction through LDS, no barrier; half the operand loads per flop of the
+// 32 x 32 version (a workgroup reads 128 rows of L for 4096 entries of S instead of 64 for 1024).  The fronts of those levels have nc of
+// 100-450: split four ways a wave ran two or three chunks between its prologue and the LDS reduction.  Upper levels keep the 32 x 32 kernel: they
+// have a handful of fronts and need the tiles for parallelism.  desc as above with 64 x 64 tile indices.
+constexpr int TQ64 = 64;
+__device__ __forceinline__ void schur_tile64(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi)
+{
+    const int nc = min(ncAll, cHi);
+    if (cLo >= nc) return;
+    const int tid = threadIdx.x;
+    const int wv = tid >> 6, l = tid & 63;
+    const int i0 = ncAll + TQ64 * ti + 32 * (wv & 1), j0 = ncAll + TQ64 * tj + 32 * (wv >> 1); // this wave's quadrant (behind ALL own columns; nc is the end of this pass)
+    if (i0 + 31 < j0 || i0 >= N || j0 >= N) return; // entirely above the diagonal (the upper right quadrant of a diagonal tile) or outside
+    const int ar = l & 15, ak = l >> 4;
+    double old[2][2][4];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = min(i0 + 16 * mi + ar, N - 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[nj][mi][r] = F[row + (long long)N * min(j0 + 16 * nj + ak + 4 * r, N - 1)];
+        }
+    f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i (formed transposed, see k_big_schur)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+    const double* pa0 = F + min(i0 + ar, N - 1);
+    const double* pa1 = F + min(i0 + 16 + ar, N - 1);
+    const double* pb0 = F + min(j0 + ar, N - 1);
+    const double* pb1 = F + min(j0 + 16 + ar, N - 1);
+    constexpr int CW = 16, CS = CW / 4;
+    const int nch = (nc + CW - 1) / CW;
+    double a0[CS], a1[CS], b0[CS], b1[CS], na0[CS], na1[CS], nb0[CS], nb1[CS];
+    auto fetch = [&](int ch, double* x0, double* x1, double* y0, double* y1) {
+#pragma unroll
+        for (int ks = 0; ks < CS; ++ks) {
+            const long long off = (long long)N * min(CW * ch + 4 * ks + ak, nc - 1);
+            x0[ks] = pa0[off];
+            x1[ks] = pa1[off];
+            y0[ks] = pb0[off];
+            y1[ks] = pb1[off];
+        }
+    };
+    auto mult = [&](int ch, const double* x0, const double* x1, const double* y0, const double* y1) {
+#pragma unroll
+        for (int ks = 0; ks < CS; ++ks) {
+            const bool in = CW * ch + 4 * ks + ak < nc;
+            const double m0 = in ? y0[ks] : 0.0, m1 = in ? y1[ks] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x0[ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x1[ks], acc[1][1], 0, 0, 0);
+        }
+    };
+    // ping-pong register sets, unconditional fetches behind scheduling fences: see k_big_schur
+    const int ch0 = cLo / CW;
+    fetch(ch0, a0, a1, b0, b1);
+    for (int ch = ch0; ch < nch; ch += 2) {
+        fetch(ch + 1, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(ch, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(ch + 2, a0, a1, b0, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ch + 1 < nch) mult(ch + 1, na0, na1, nb0, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int row = i0 + 16 * mi + ar;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = j0 + 16 * nj + ak + 4 * r;
+                if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[nj][mi][r] - acc[nj][mi][r];
+            }
+        }
+}
+__global__ __launch_bounds__(WG) void k_big_schur64(const int4* __restrict__ desc, double* __restrict__ fronts)
+{
+    const int4 d = desc[2 * blockIdx.x];
+    const int4 d2 = desc[2 * blockIdx.x + 1];
+    schur_tile64(d2.x, d2.y, fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z), d.y, d.z, 0, 1 << 30);
+}
+
+// ---- explicit inverses of the factor triangles of the widest fronts (see the k_xinv_* kernels further down for what they are used for)
+struct XinvView {
+    const long long* xOff; // per front: offset of X (and of the scratch T) in their buffers, -1 when the front has none
+    double* X;
+    double* T;
+};
+
+// Role C of the step kernel (round 4): X = L11^-1 grows BY BORDERING, one panel per step launch, beside the pivot chain that produces the panels.
+// Launch p + 1 holds, for every front with an explicit inverse, the rows R = [kb, kb + 32) of panel p (finished by launch p), one workgroup per
+// column tile C = [c0, c0 + CT) left of them:
+//     X(R, C) = -X_RR ( L(R, C..kb) X(C..kb, C) )            X(0:kb, 0:kb) was finished by the launches before, X_RR is the panel's dinv block
+// Both products are formed in ONE workgroup (the column tiles are independent), so the inverse is complete one launch after the last panel
+// instead of eleven dependent launches (recursive doubling on a side stream: the tail of every factorisation, 0.105 ms at mat150).
+//   stage 1: T(r, c) = sum_k L(kb + r, k) X(k, c0 + c) over k in [c0, kb): four waves split k in batches of 16, combine through LDS in a fixed order
+//   stage 2: X(kb + r, c0 + c) = -sum_k' Xd(r, k') T(k', c): one 16 x 16 quadrant per wave, T from LDS
+// A workgroup is as long as its k range (up to nc columns, on ONE CU): tiles far left of the panel are CT = 16 columns wide (half the products per
+// wave, twice the workgroups), and the operands are fetched two batches ahead of their products (one batch = 8 or 16 MFMAs = 0.2 - 0.4 us, less than
+// a strided L2 round trip).  d = (front, kb, c0, -3 [CT = 32] / -6 [CT = 16]); c0 == kb: the diagonal block itself (a copy of the dinv block).
+template <int CT>
+__device__ __forceinline__ void step_border(const int4 d, const int4 d2, const TreeView& tv, const XinvView& xv, const double* __restrict__ F,
+    const double* __restrict__ dinv, double* sm)
+{
+    constexpr int NA = CT / 16; // 16-column halves of the tile
+    const int s = d.x, kb = d.y, c0 = d.z;
+    const int N = d2.x, nc = d2.y;
+    const int w = min(NB, nc - kb);
+    double* X = xv.X + xv.xOff[s];
+    const double* blk = dinv + (tv.dinvOff[s] + kb / NB) * (NB * NB); // blk[c * 32 + r] = Xd(r, c), identity-padded
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, lo = l & 15, hi = l >> 4;
+    if (c0 == kb) {
+        for (int e = tid; e < NB * NB; e += WGB) {
+            const int c = e >> 5, r = e & 31;
+            if (r < w && c < w) X[(kb + r) + (long long)nc * (kb + c)] = blk[e];
+        }
+        return;
+    }
+    double(*red)[4][256] = reinterpret_cast<double(*)[4][256]>(sm); // [wave][16 x 16 tile][D layout: 64 lanes x 4]
+    f64x4 acc[NA][2];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+    const int cc[2] = { c0 + lo, c0 + 16 + lo }; // < kb: always inside
+    const int rr[2] = { kb + lo, kb + 16 + lo };
+    const int rrc[2] = { min(rr[0], nc - 1), min(rr[1], nc - 1) };
+    // the second stage's operand (the panel's own inverse block, lower triangular) is requested now
+    double xd[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) xd[ks] = blk[(4 * ks + hi) * NB + 16 * (wv & 1) + lo]; // Xd(r = 16 b + lo, k' = 4 ks + hi)
+    // three operand sets in rotation, unconditional clamped fetches, masks at use: see k_big_schur / k_xinv_gemm
+    auto fetch = [&](int k0, double(&ra)[NA][4], double(&rb)[2][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = min(k0 + 4 * ks + hi, nc - 1);
+#pragma unroll
+            for (int q = 0; q < NA; ++q) ra[q][ks] = X[kc + (long long)nc * cc[q]];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) rb[q][ks] = F[rrc[q] + (long long)N * kc];
+        }
+    };
+    auto mult = [&](int k0, const double(&ra)[NA][4], const double(&rb)[2][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = k0 + 4 * ks + hi;
+            const bool kin = k < kb;
+            double ma[NA], mb[2];
+#pragma unroll
+            for (int q = 0; q < NA; ++q) ma[q] = (kin && k >= cc[q]) ? ra[q][ks] : 0.0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) mb[q] = (kin && rr[q] < kb + w) ? rb[q][ks] : 0.0;
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma[a], mb[b], acc[a][b], 0, 0, 0);
+        }
+    };
+    double xa[NA][4], la[2][4], xb[NA][4], lb[2][4], xc[NA][4], lc[2][4];
+    int k0 = c0 + 16 * wv;
+    fetch(k0, xa, la);
+    fetch(k0 + 64, xb, lb);
+    for (; k0 < kb; k0 += 192) {
+        fetch(k0 + 128, xc, lc);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(k0, xa, la);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(k0 + 192, xa, la);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 64 < kb) mult(k0 + 64, xb, lb);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(k0 + 256, xb, lb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 128 < kb) mult(k0 + 128, xc, lc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[wv][2 * a + b][64 * i + l] = acc[a][b][i];
+    __syncthreads();
+    // wave q finishes the 16 x 16 tile q = 2 a + b of T: entry i of a lane is T(r = 16 b + lo, c = 16 a + hi + 4 i)
+    const int a = wv >> 1, b = wv & 1;
+    const bool mine = a < NA; // a 16-column tile has two quadrants: waves 2 and 3 only help with the sums over k
+    double t[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i] = ((red[0][wv & (2 * NA - 1)][64 * i + l] + red[1][wv & (2 * NA - 1)][64 * i + l]) + red[2][wv & (2 * NA - 1)][64 * i + l]) + red[3][wv & (2 * NA - 1)][64 * i + l];
+    __syncthreads();
+    double* Ts = sm; // Ts[k' * LDP + c] = T(k', c)
+    if (mine) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Ts[(16 * b + lo) * LDP + 16 * a + hi + 4 * i] = t[i];
+    }
+    __syncthreads();
+    if (!mine) return;
+    // stage 2, formed transposed like stage 1: D(c, r) = sum_k' T(k', c) Xd(r, k'), k' <= r
+    f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const int kp = 4 * ks + hi;
+        o = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[kp * LDP + 16 * a + lo], (kp <= 16 * b + lo) ? xd[ks] : 0.0, o, 0, 0, 0);
+    }
+    const int r = 16 * b + lo;
+    if (r < w) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) X[(kb + r) + (long long)nc * (c0 + 16 * a + hi + 4 * i)] = -o[i];
+    }
+}
+
 // ---- big fronts: level-batched 32-column steps, one launch per step ------------------------------------
 // desc = (first dinv block of the front, kb of the panel being applied or -1, a, b) + (N, nc, front offset); 256 threads: three row waves + one pivot wave
 //   b >= 0 : role A, trailing tile (ti, tj) = (a, b) of the matrix behind panel kb and panel kb+32
 //   b == -2: role B, rows [kb1 + a, kb1 + a + 192) of the next panel (kb1 = kb + 32, or 0 when kb == -1)
+// TOP = true (the levels of the top separators, where the chain of these launches IS the level) adds two roles that ride on the chain's launches
+// instead of following it as launches of their own:
+//   b == -6: role C, one 32 x 16 tile of the explicit inverse X = L11^-1 growing by bordering (step_border): d = (front, panel, first column, b)
+//   b == -4: role S, one 32 x 32 tile of the Schur complement updated with the panels [cLo, cHi) that are final by this launch (schur_tile32):
+//            d = (cLo, cHi, ti | tj << 16, b).  (64 x 64 tiles in here cost the whole kernel 198 registers and were slower anyway: short sums.)
+// (a separate instance: the extra roles would cost the trailing tiles of the middle levels registers they do not need)
+template <bool TOP>
 __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
-    double* __restrict__ dinv, int* __restrict__ flag)
+    double* __restrict__ dinv, int* __restrict__ flag, XinvView xv)
 {
     __shared__ double sm[2 * NB * TS];
     // two records per workgroup, both addressed by blockIdx alone: (first dinv block, kb, a, b) and (N, nc, front offset) -- the front's
@@ -1142,6 +1476,11 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     const int N = d2.x, nc = d2.y;
     double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
     const int tid = threadIdx.x;
+    if (TOP && d.w <= -3) {
+        if (d.w == -6) step_border<16>(d, d2, tv, xv, F, dinv, sm);
+        else if (d.w == -4) schur_tile32(N, nc, F, d.z & 0xffff, (d.z >> 16) & 0xffff, d.x, d.y, reinterpret_cast<double(*)[4][256]>(sm));
+        return;
+    }
     const int kb = d.y;
     const int w = (kb >= 0) ? min(NB, nc - kb) : 0;
     const int kb1 = (kb >= 0) ? kb + w : 0;
@@ -1383,191 +1722,6 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     MF_STEP_PHASE(14);
     if (d.z == 0 && threadIdx.x == 64 * ((3 + (int)blockIdx.x) & 3)) atomicAdd(&mf_phase_acc[15], 1ull);
 #endif
-}
-
-// Schur complement of a big front in one pass: S(i, j) -= sum_{c < nc} L(i, c) L(j, c) for i, j >= nc.  Doing this per
-// 32-column step (right-looking) re-reads and re-writes the whole update matrix every step, which made the middle levels
-// of the tree HBM-bound; here every tile is read-modify-written once.  desc = (front, ti, tj, 0), 32 x 32 tiles, ti >= tj.
-// One workgroup per 32 x 32 tile of S, four waves that split the nc columns of L between them (chunk c goes to wave c mod 4)
-// and combine through LDS in a fixed order at the end.  Upper levels of the tree have a handful of fronts: with 64 x 64
-// tiles and a serial loop over all of nc, a level was a few dozen workgroups each waiting out nc / 32 dependent
-// load -> multiply rounds.  The MFMA operands come straight from the front (a lane's A / B entry is one double of L; 16
-// lanes read 16 consecutive rows), so the loop has no LDS staging and no barrier.  The product is formed transposed,
-// D(j, i): the 16 lanes of an accumulator row hold 16 consecutive rows i of one column j, which makes the read-modify-write
-// of the column-major front 128-byte contiguous.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15],
-// D column = l & 15, row = (l >> 4) + 4 reg.
-constexpr int TQ = 32; // Schur tile
-__global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts)
-{
-    __shared__ double red[4][4][256]; // [wave][16 x 16 tile][D layout: 64 lanes x 4]
-    // two records per workgroup (see k_big_step): (front, ti, tj, 0) and (N, nc, front offset)
-    const int4 d = desc[2 * blockIdx.x];
-    const int4 d2 = desc[2 * blockIdx.x + 1];
-    const int N = d2.x, nc = d2.y;
-    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
-    const int tid = threadIdx.x;
-    const int i0 = nc + TQ * d.y, j0 = nc + TQ * d.z;
-    const int wv = tid >> 6, l = tid & 63;
-    const int ar = l & 15, ak = l >> 4;
-    // the entries this wave will update at the end (16 x 16 tile wv of the 32 x 32 tile) are requested now: as a
-    // read-modify-write at the end they were four dependent memory round trips behind the reduction
-    double old[4];
-    {
-        const int row = min(i0 + 16 * (wv & 1) + ar, N - 1);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) old[r] = F[row + (long long)N * min(j0 + 16 * (wv >> 1) + ak + 4 * r, N - 1)];
-    }
-    f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
-    // rows past the end of the front are clamped: their products land in entries that are never written
-    const double* pa0 = F + min(i0 + ar, N - 1);
-    const double* pa1 = F + min(i0 + 16 + ar, N - 1);
-    const double* pb0 = F + min(j0 + ar, N - 1);
-    const double* pb1 = F + min(j0 + 16 + ar, N - 1);
-    // The nc columns go to the four waves in chunks of CW.  The loads of a wave's next chunk are issued before the products
-    // of the current one and only touched after them (the compiler neither pipelines the loop nor keeps that order by itself:
-    // hence the scheduling fences).  Loads are unconditional with a clamped column; past nc only the A operands need zeroing.
-    constexpr int CW = 16, CS = CW / 4;
-    const int nch = (nc + CW - 1) / CW;
-    double a0[CS], a1[CS], b0[CS], b1[CS], na0[CS], na1[CS], nb0[CS], nb1[CS];
-    auto fetch = [&](int ch, double* x0, double* x1, double* y0, double* y1) {
-#pragma unroll
-        for (int ks = 0; ks < CS; ++ks) {
-            const long long off = (long long)N * min(CW * ch + 4 * ks + ak, nc - 1);
-            x0[ks] = pa0[off];
-            x1[ks] = pa1[off];
-            y0[ks] = pb0[off];
-            y1[ks] = pb1[off];
-        }
-    };
-    auto mult = [&](int ch, const double* x0, const double* x1, const double* y0, const double* y1) {
-#pragma unroll
-        for (int ks = 0; ks < CS; ++ks) {
-            const bool in = CW * ch + 4 * ks + ak < nc;
-            const double m0 = in ? y0[ks] : 0.0, m1 = in ? y1[ks] : 0.0;
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x0[ks], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x1[ks], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x0[ks], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x1[ks], acc[1][1], 0, 0, 0);
-        }
-    };
-    // two register sets, ping-pong (a copy from a "next" set would wait for its loads at the end of every iteration)
-    // the fetches are unconditional (past the end they re-read the clamped last column): behind a branch, the compiler's wait
-    // counters have to assume the loads were not issued and the products end up waiting for the newest load
-    fetch(wv, a0, a1, b0, b1);
-    for (int ch = wv; ch < nch; ch += 8) {
-        fetch(ch + 4, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(ch, a0, a1, b0, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(ch + 8, a0, a1, b0, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ch + 4 < nch) mult(ch + 4, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[wv][2 * nj + mi][64 * r + l] = acc[nj][mi][r];
-    __syncthreads();
-    // wave q finishes 16 x 16 tile q = 2 nj + mi
-    const int nj = wv >> 1, mi = wv & 1;
-    const int row = i0 + 16 * mi + ar;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int col = j0 + 16 * nj + ak + 4 * r;
-        const double v = ((red[0][wv][64 * r + l] + red[1][wv][64 * r + l]) + red[2][wv][64 * r + l]) + red[3][wv][64 * r + l];
-        if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[r] - v;
-    }
-}
-
-// The same update with 64 x 64 tiles, for levels of the tree that have thousands of tiles anyway: one wave per 32 x 32 quadrant running over
-// ALL nc columns, no split of the columns over the waves and so no reduction through LDS, no barrier; half the operand loads per flop of the
-// 32 x 32 version (a workgroup reads 128 rows of L for 4096 entries of S instead of 64 for 1024).  The fronts of those levels have nc of
-// 100-450: split four ways a wave ran two or three chunks between its prologue and the LDS reduction.  Upper levels keep the 32 x 32 kernel: they
-// have a handful of fronts and need the tiles for parallelism.  desc as above with 64 x 64 tile indices.
-constexpr int TQ64 = 64;
-__global__ __launch_bounds__(WG) void k_big_schur64(const int4* __restrict__ desc, double* __restrict__ fronts)
-{
-    const int4 d = desc[2 * blockIdx.x];
-    const int4 d2 = desc[2 * blockIdx.x + 1];
-    const int N = d2.x, nc = d2.y;
-    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
-    const int tid = threadIdx.x;
-    const int wv = tid >> 6, l = tid & 63;
-    const int i0 = nc + TQ64 * d.y + 32 * (wv & 1), j0 = nc + TQ64 * d.z + 32 * (wv >> 1); // this wave's quadrant
-    if (i0 + 31 < j0 || i0 >= N || j0 >= N) return; // entirely above the diagonal (the upper right quadrant of a diagonal tile) or outside
-    const int ar = l & 15, ak = l >> 4;
-    double old[2][2][4];
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int row = min(i0 + 16 * mi + ar, N - 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) old[nj][mi][r] = F[row + (long long)N * min(j0 + 16 * nj + ak + 4 * r, N - 1)];
-        }
-    f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i (formed transposed, see k_big_schur)
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
-    const double* pa0 = F + min(i0 + ar, N - 1);
-    const double* pa1 = F + min(i0 + 16 + ar, N - 1);
-    const double* pb0 = F + min(j0 + ar, N - 1);
-    const double* pb1 = F + min(j0 + 16 + ar, N - 1);
-    constexpr int CW = 16, CS = CW / 4;
-    const int nch = (nc + CW - 1) / CW;
-    double a0[CS], a1[CS], b0[CS], b1[CS], na0[CS], na1[CS], nb0[CS], nb1[CS];
-    auto fetch = [&](int ch, double* x0, double* x1, double* y0, double* y1) {
-#pragma unroll
-        for (int ks = 0; ks < CS; ++ks) {
-            const long long off = (long long)N * min(CW * ch + 4 * ks + ak, nc - 1);
-            x0[ks] = pa0[off];
-            x1[ks] = pa1[off];
-            y0[ks] = pb0[off];
-            y1[ks] = pb1[off];
-        }
-    };
-    auto mult = [&](int ch, const double* x0, const double* x1, const double* y0, const double* y1) {
-#pragma unroll
-        for (int ks = 0; ks < CS; ++ks) {
-            const bool in = CW * ch + 4 * ks + ak < nc;
-            const double m0 = in ? y0[ks] : 0.0, m1 = in ? y1[ks] : 0.0;
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x0[ks], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x1[ks], acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x0[ks], acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x1[ks], acc[1][1], 0, 0, 0);
-        }
-    };
-    // ping-pong register sets, unconditional fetches behind scheduling fences: see k_big_schur
-    fetch(0, a0, a1, b0, b1);
-    for (int ch = 0; ch < nch; ch += 2) {
-        fetch(ch + 1, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(ch, a0, a1, b0, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(ch + 2, a0, a1, b0, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (ch + 1 < nch) mult(ch + 1, na0, na1, nb0, nb1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int row = i0 + 16 * mi + ar;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int col = j0 + 16 * nj + ak + 4 * r;
-                if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[nj][mi][r] - acc[nj][mi][r];
-            }
-        }
 }
 
 // ---- triangular solves ------------------------------------------------------------------------------------
@@ -1996,11 +2150,6 @@ __global__ void k_double_to_flag(const double* __restrict__ buf, int* __restrict
 // block inverses: X21 = -X22 (L21 X11), two batched GEMM launches per doubling), and the sweeps become two matrix-vector
 // products spread over many workgroups.  Extra work: ~nc^3 / 3 flops per front, 4 % of the factorisation.
 // X is column-major with leading dimension nc; only its lower triangle is ever read.
-struct XinvView {
-    const long long* xOff; // per front: offset of X (and of the scratch T) in their buffers, -1 when the front has none
-    double* X;
-    double* T;
-};
 
 // one workgroup per diagonal block: the 32 x 32 inverse goes from its dinv slot into X.  desc = (front, block, 0, 0)
 __global__ __launch_bounds__(256) void k_xinv_init(const int4* __restrict__ desc, TreeView tv, XinvView xv, const double* __restrict__ dinv)
@@ -2264,6 +2413,9 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
+    if (const char* e = std::getenv("IPCGPU_MF_FWD_ROOT_ON_MAIN")) fwdRootOnMain_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD")) schurFold_ = std::max(0, std::atoi(e));
+    if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD_MIN")) schurFoldMinSteps_ = std::max(2, std::atoi(e));
     if (!fwd_ && !std::getenv("IPCGPU_MF_NO_FWD_OVERLAP")) {
         HIP_CHECK(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evRhs_, hipEventDisableTiming));
@@ -2297,6 +2449,13 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_NT128_N")) ntSmallN = std::atoi(e);
     if (const char* e = std::getenv("IPCGPU_MF_NT512_N")) ntBigN = std::atoi(e);
     auto isFused = [&](int s) { return sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds; };
+    // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
+    int xinvMin = 192;
+    if (const char* e = std::getenv("IPCGPU_MF_XINV_NC")) xinvMin = std::atoi(e) > 0 ? std::max(64, std::atoi(e)) : (1 << 30);
+    if (const char* e = std::getenv("IPCGPU_MF_XINV_SKIP_TOP")) xinvSkipTop_ = std::max(0, std::atoi(e));
+    xinvBorder_ = true; // the inverse grows by bordering inside the step launches (step_border); 0: recursive doubling on the side stream, as before round 4
+    if (const char* e = std::getenv("IPCGPU_MF_XINV_BORDER")) xinvBorder_ = std::atoi(e) != 0;
+    auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin && sym.level[s] < nLevels_ - xinvSkipTop_; };
     // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
     owner_.assign(ns_, rank_);
     sharedFlops_ = 0.0;
@@ -2548,6 +2707,20 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         int steps = 0;
         for (int s : big) steps = std::max(steps, (sym.nc(s) + NB - 1) / NB);
         P.step.assign(big.empty() ? 0 : steps + 1, Range());
+        {
+            long long tiles32 = 0;
+            for (int s : big) {
+                const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
+                tiles32 += nt * (nt + 1) / 2;
+            }
+            P.schur64 = tiles32 >= schur64Min_;
+        }
+        // Schur complement: one pass behind the chain (k_big_schur / k_big_schur64), or -- on the levels of the top separators, where the chain of step
+        // launches is what the level takes -- folded into those launches in passes of schurFold_ panels (role S): pass q = panels [e(q-1), e(q)) rides on
+        // launch e(q), the first one that finds them final; the last pass on the last launch (which otherwise only carries role C).
+        const bool foldSchur = schurFold_ > 0 && steps >= schurFoldMinSteps_;
+        if (foldSchur) P.stepTop = true;
+        const int nPass = foldSchur ? (steps + schurFold_ - 1) / schurFold_ : 0;
         for (int j = -1; j < steps && !big.empty(); ++j) {
             Range& R = P.step[j + 1];
             R.off = (int)desc.size();
@@ -2565,6 +2738,14 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                         desc.push_back(make_int4((int)hDinvOff_[s], j >= 0 ? kb : -1, r0, -2));
                         desc.push_back(rec2);
                     }
+                if (j >= 0 && xinvBorder_ && hasXinv(s)) { // role C: the rows of panel j of X = L11^-1, one workgroup per column tile up to the diagonal block
+                    P.stepTop = true;
+                    // 16-column tiles (32 wide ones made the late steps of the root 20 us long: one CU per tile, k up to nc); c0 == kb: the diagonal block, one copy
+                    for (int c0 = 0; c0 <= kb; c0 += 16) {
+                        desc.push_back(make_int4(s, kb, c0, -6));
+                        desc.push_back(rec2);
+                    }
+                }
                 if (j >= 0) {
                     // trailing tiles inside the front's own columns; the Schur complement (columns >= nc) waits for k_big_schur
                     const int M0 = kb1 + w1;
@@ -2576,27 +2757,39 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                         }
                 }
             }
+            if (foldSchur && j >= 0 && ((j + 1) % schurFold_ == 0 || j + 1 == steps)) { // role S: launch j + 1 finds the panels [.., j] final
+                const int q = (j + schurFold_) / schurFold_; // pass number, 1-based: panels [(q - 1) fold, min(q fold, steps))
+                const int cLo = NB * (q - 1) * schurFold_, cHi = (q == nPass) ? (1 << 30) : NB * q * schurFold_;
+                // folded passes are SHORT sums (schurFold_ panels): the 32 x 32 tiles split them over their four waves and are done in one memory round trip,
+                // a 64 x 64 tile walks them chunk by chunk (measured: +5.5 us per step launch that carried a pass of 64 x 64 tiles)
+                const int TQl = TQ;
+                for (int s : big) {
+                    if (cLo >= sym.nc(s)) continue;
+                    const int nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
+                    const long long foff = sym.frontOff[s];
+                    const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
+                    for (int ti = 0; ti < nt; ++ti)
+                        for (int tj = 0; tj <= ti; ++tj) {
+                            desc.push_back(make_int4(cLo, cHi, ti | (tj << 16), -4));
+                            desc.push_back(rec2);
+                        }
+                }
+            }
             R.cnt = ((int)desc.size() - R.off) / 2; // workgroups: two records each
         }
         P.schur.off = (int)desc.size();
-        {
-            long long tiles32 = 0;
+        if (!foldSchur) {
+            const int TQl = P.schur64 ? TQ64 : TQ;
             for (int s : big) {
-                const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
-                tiles32 += nt * (nt + 1) / 2;
+                const int nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
+                const long long foff = sym.frontOff[s];
+                const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
+                for (int ti = 0; ti < nt; ++ti)
+                    for (int tj = 0; tj <= ti; ++tj) {
+                        desc.push_back(make_int4(s, ti, tj, 0));
+                        desc.push_back(rec2);
+                    }
             }
-            P.schur64 = tiles32 >= schur64Min_;
-        }
-        const int TQl = P.schur64 ? TQ64 : TQ;
-        for (int s : big) {
-            const int nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
-            const long long foff = sym.frontOff[s];
-            const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
-            for (int ti = 0; ti < nt; ++ti)
-                for (int tj = 0; tj <= ti; ++tj) {
-                    desc.push_back(make_int4(s, ti, tj, 0));
-                    desc.push_back(rec2);
-                }
         }
         P.schur.cnt = ((int)desc.size() - P.schur.off) / 2; // workgroups: two records each
         P.fwdRect.off = (int)desc.size();
@@ -2641,10 +2834,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     }
     lap("fused descriptors");
     {
-        // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
-        int xinvMin = 192;
-        if (const char* e = std::getenv("IPCGPU_MF_XINV_NC")) xinvMin = std::atoi(e) > 0 ? std::max(64, std::atoi(e)) : (1 << 30);
-        if (const char* e = std::getenv("IPCGPU_MF_XINV_SKIP_TOP")) xinvSkipTop_ = std::max(0, std::atoi(e));
         std::vector<long long> xOff(ns_, -1);
         long long xTot = 0;
         std::vector<int4> xd; // all descriptors of the inverse machinery
@@ -2653,8 +2842,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         for (int l = 0; l < nLevels_; ++l)
             for (int i = plan_[l].bigFronts.off; i < plan_[l].bigFronts.off + plan_[l].bigFronts.cnt; ++i) {
                 const int s = bigList[i];
-                if (sym.nc(s) < xinvMin) continue;
-                if (l >= nLevels_ - xinvSkipTop_) continue; // A/B: the last levels' inverses finish after the factorisation (they are the tail of the step)
+                if (!hasXinv(s)) continue; // (IPCGPU_MF_XINV_SKIP_TOP, A/B: the fronts of the last levels sweep their triangles block by block)
                 xOff[s] = xTot;
                 xTot += (long long)sym.nc(s) * sym.nc(s);
                 invFronts.push_back(s);
@@ -2681,6 +2869,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 if (sym.level[s] == l) lf.push_back(s);
             XL.blocks.off = (int)blockList.size();
             XL.init.off = (int)xd.size();
+            if (xinvBorder_) lf.clear(); // nothing for the side stream: the step launches build the inverses (step_border)
             for (int s : lf)
                 for (int b = 0; b < (sym.nc(s) + NB - 1) / NB; ++b) {
                     blockList.push_back((int)(di[s] + b));
@@ -2880,12 +3069,13 @@ bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, doubl
     HIP_CHECK(hipEventRecord(evRhs_, stream_));
     HIP_CHECK(hipStreamWaitEvent(fwd_, evRhs_, 0));
     hipLaunchKernelGGL(k_permute_rhs, dim3((n3 + 255) / 256), dim3(256), 0, fwd_, sym.nn, newOf_.p, rhs_dev, bperm_.p);
+    fwdJoined_ = false;
     enqueueFactor(a_dev, true);
-    HIP_CHECK(hipEventRecord(evFwdDone_, fwd_));
+    if (!fwdJoined_) HIP_CHECK(hipEventRecord(evFwdDone_, fwd_));
     hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, stream_, flag_.p, hflag_.dev);
     // the backward sweep follows the root's forward result; enqueued before the flag is looked at (a failed pivot makes x meaningless,
     // the caller falls back to the diagonal preconditioner as after factorize() == false)
-    HIP_CHECK(hipStreamWaitEvent(stream_, evFwdDone_, 0));
+    if (!fwdJoined_) HIP_CHECK(hipStreamWaitEvent(stream_, evFwdDone_, 0));
     enqueueBackward(x_dev);
     if (!wait) return true;
     HIP_CHECK(hipStreamSynchronize(stream_));
@@ -2896,6 +3086,7 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
 {
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
+    XinvView xvF{ xinvOff_.p, xinvX_.p, xinvT_.p };
     if (sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evSide_, 0)); // the side stream still reads the previous factor
     flag_.zero(stream_);
     bool sideUsed = false;
@@ -2934,11 +3125,14 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
                 hipLaunchKernelGGL(k_scatter_big, dim3((na + 255) / 256), dim3(256), 0, stream_, na, bigASrc_.p + bigAOff_[l],
                     bigADst_.p + bigAOff_[l], a_dev, fronts_.p);
         }
-        for (const Range& R : P.step)
-            if (R.cnt) hipLaunchKernelGGL(k_big_step, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p);
+        for (const Range& R : P.step) {
+            if (!R.cnt) continue;
+            if (P.stepTop) hipLaunchKernelGGL(k_big_step<true>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
+            else hipLaunchKernelGGL(k_big_step<false>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
+        }
         if (P.schur.cnt) {
             if (P.schur64) hipLaunchKernelGGL(k_big_schur64, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
-            else hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, tv, fronts_.p);
+            else hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
         }
         if (world_ > 1 && xchg_[l].pack.cnt) {
             // the update matrices of the subtree roots of this level: packed by their owners, summed, unpacked everywhere
@@ -2969,10 +3163,21 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
         if (overlapForward) {
             // everything the forward sweep of this level reads is final (factor panels, pivot-block inverses; the triangle inverses of the
             // widest fronts follow on the side stream): hand the level to the forward stream, which runs beside the levels above
-            HIP_CHECK(hipEventRecord(evFactLevel_[l], stream_));
-            HIP_CHECK(hipStreamWaitEvent(fwd_, evFactLevel_[l], 0));
-            if (plan_[l].xinvFwd.cnt && sideUsed) HIP_CHECK(hipStreamWaitEvent(fwd_, evInvDone_[l], 0));
-            enqueueForwardLevel(l, fwd_);
+            if (l == nLevels_ - 1 && fwdRootOnMain_ && !sideUsed) {
+                // the last level (the root separator) has nothing to run beside: its forward sweep follows its factorisation on THIS stream, and the
+                // hand-over back from the forward stream happens here, where that stream has long been idle, instead of behind the whole factorisation
+                // (a cross-stream event wait costs the waiting stream ~20 us on this runtime: it used to sit between the forward and the backward sweep)
+                HIP_CHECK(hipEventRecord(evFwdDone_, fwd_));
+                HIP_CHECK(hipStreamWaitEvent(stream_, evFwdDone_, 0));
+                enqueueForwardLevel(l, stream_);
+                fwdJoined_ = true;
+            }
+            else {
+                HIP_CHECK(hipEventRecord(evFactLevel_[l], stream_));
+                HIP_CHECK(hipStreamWaitEvent(fwd_, evFactLevel_[l], 0));
+                if (plan_[l].xinvFwd.cnt && sideUsed) HIP_CHECK(hipStreamWaitEvent(fwd_, evInvDone_[l], 0));
+                enqueueForwardLevel(l, fwd_);
+            }
         }
     }
     // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)

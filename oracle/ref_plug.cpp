@@ -181,7 +181,9 @@ public:
         ja0_.resize((size_t)Base::ja.size());
         for (size_t k = 0; k < ja0_.size(); ++k) ja0_[k] = Base::ja[(Eigen::Index)k] - 1;
         if (h_) orc_chol_destroy(h_);
-        h_ = orc_chol_create(n, ia0_.data(), ja0_.data(), 1);
+        // IPCREF_THREADS (see refshim/tbb/parallel_for.h): the timed `cpu_reference` of bench.py runs the factorisation on the same number of threads
+        const char* e = std::getenv("IPCREF_THREADS");
+        h_ = orc_chol_create(n, ia0_.data(), ja0_.data(), e && std::atoi(e) > 1 ? std::atoi(e) : 1);
     }
     bool factorize(void) override { return orc_chol_factorize(h_, Base::a.data()) == 1; }
     void solve(Eigen::VectorXd& rhs, Eigen::VectorXd& result) override

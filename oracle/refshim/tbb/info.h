@@ -1,3 +1,4 @@
 // ORACLE / TEST INFRASTRUCTURE: see parallel_for.h
 #pragma once
-namespace tbb { namespace info { inline int default_concurrency() { return 1; } } }
+#include "parallel_for.h"
+namespace tbb { namespace info { inline int default_concurrency() { return detail_shim::env_threads(); } } }
