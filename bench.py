@@ -55,14 +55,24 @@ def pmc_traffic(size):
         return float(json.load(f)["traffic_bytes"])
 
 
+_T0 = time.time()
+
+
+def progress(msg):
+    """phase marks on stderr (the JSON line on stdout stays alone): what a run that is cut short was doing"""
+    print(f"[bench {time.time() - _T0:7.1f} s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--size", type=int, default=150, help="mat N (N x N x 2 nodes); 150 = BASELINE config[1]")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-contact", action="store_true", help="skip the contact sub-record (2 x mat100 stack with self-collision, N = 1 only)")
+    ap.add_argument("--no-contact", action="store_true", help="skip the contact sub-records (2 x mat100 stack with self-collision; BASELINE's contact "
+                    "configurations as shipped: 4_rodsTwist, 12_sphereOnMat; N = 1 only)")
+    ap.add_argument("--no-large", action="store_true", help="skip the 1.12 M-tet sub-record `roofline_large` (mat433, N = 1 only)")
     ap.add_argument("--large-size", type=int, default=433, help="N > 1: mat size of the second, >= 1 M-tet workload reported under 'large_workload' (0 = off)")
     ap.add_argument("--cpu-iters", type=int, default=40)
     ap.add_argument("--solver", type=int, default=0, help="0 = GPU multifrontal, 1 = rocSOLVER csrrf")
@@ -158,6 +168,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    progress(f"precompute done ({t_pre:.1f} s); {args.warmup} warm-up + {args.steps} timed Newton iterations")
     for _ in range(args.warmup):
         one_iteration()
     t_before = ctx.timers().copy()
@@ -173,6 +184,7 @@ def main():
         elapsed = float(tt.item())
     timers = ctx.timers() - t_before
 
+    progress(f"timed region done: {args.steps / elapsed:.1f} it/s")
     # collective when the solver is sharded: every rank takes part
     f_ms, s_ms = ctx.bench_factor_solve(3)
     out = None
@@ -255,7 +267,9 @@ def main():
                        "precompute_s": t_pre},
         }
         if world == 1 and not args.no_cpu_baseline:
+            progress("cpu_baseline (port, all host cores)")
             out["cpu_baseline"] = cpu_baseline(V, F, left, right, args.cpu_iters)
+            progress("cpu_reference (the reference's sources, all host cores)")
             out["cpu_reference"] = cpu_reference(V, F)
     ctx.close()
     if rank == 0 and world == 1 and not args.no_contact:
@@ -263,12 +277,33 @@ def main():
         # constraint sets, CCD, pattern changes); BASELINE's metric is quoted on the contact-free matTwist above, this is a sub-record
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import bench_contact
+        progress("contact sub-record (2 x mat100 stack)")
         r = bench_contact.run(n=100, layers=2, steps=12, max_iter=12)
         out["contact"] = {"workload": r["scene"] + f": {r['n_nodes']} nodes / {r['n_tets']} tets, {r['n_surface_tris']} surface triangles, dt 0.01, 12 time steps",
                           "newton_iterations": r["newton_iterations"], "value": r["iters_per_s"], "unit": "iter/s", "ms_per_iter": r["ms_per_iter_wall"],
                           "split_ms_per_iter": r["split_ms_per_iter"],
                           "active_constraints_per_step": [c["nActive"] for c in r["contact_state_per_step"]],
                           "pattern_changes": r["contact_state_per_step"][-1]["nPatternChanges"], "intersected_at_end": r["intersected_at_end"]}
+    if rank == 0 and world == 1 and not args.no_contact:
+        # BASELINE configs[3] and configs[2] AS SHIPPED, from the fixtures the reference's own main() produced (tests/golden/ref_scene_*.npz): timed, and the
+        # Newton iteration count of every step compared with the reference's in the same record (tools/bench_scene.py)
+        import bench_scene
+        for name, steps, first, what in (
+                ("rods_twist", 2, 1, "BASELINE configs[3]: input/paperExamples/4_rodsTwist.txt as shipped (4 x rod300x33.msh, self-contact on, script twist), time steps 1-2"),
+                ("sphere_on_mat", 36, 29, "BASELINE configs[2]: input/paperExamples/12_sphereOnMat.txt as shipped (stiff ball on a mat being stretched, half-space, self-contact on): "
+                                          "all 36 steps run, the contact steps 29-36 timed")):
+            try:
+                progress(f"{name} (fixture of the reference's own run)")
+                out[name] = bench_scene.run(name, steps, first, what)
+            except Exception as e:  # noqa: BLE001  (a sub-record must not take the bench line down)
+                out[name] = {"value": None, "note": f"not measured: {e!r}"[:300]}
+    if rank == 0 and world == 1 and not args.no_large and args.size != args.large_size and args.large_size:
+        # the same twist scene at 1.12 M tets (mat433) on ONE GPU: where the latency-bound steps amortise, the fractions are what the kernels do when fed
+        try:
+            progress(f"roofline_large (mat{args.large_size})")
+            out["roofline_large"] = large_single(args, ipc_amd)
+        except Exception as e:  # noqa: BLE001
+            out["roofline_large"] = {"value": None, "note": f"not measured: {e!r}"[:300]}
     if distributed and args.large_size and args.size != args.large_size:
         # a second, >= 1 M-tet strong-scaling point for the curve (mat150's 2.9 ms iteration is mostly the dependent pivot chain of
         # its top separators, which does not shard): same script, same measurement, fewer steps
@@ -279,7 +314,53 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        progress("done")
         print(json.dumps(out))
+
+
+def large_single(args, ipc_amd, steps=12, warmup=3):
+    """N = 1: the twist scene at --large-size (mat433 = 1.12 M tets): Newton iterations per second and the three roofline fractions at a size where the
+    kernels are fed (the assembly kernel live with HIP events, factorisation and sweeps through ipcgpu_bench_factor_solve)."""
+    V, F, left, right = build_scene(args.large_size)
+    ctx = ipc_amd.Context(0, solver=args.solver)
+    ctx.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+    ctx.opt_init(dt=0.04, gravity=False)
+    ctx.set_twist(left, right, 0.4 * np.pi)
+    t0 = time.time()
+    ctx.precompute()
+    t_pre = time.time() - t0
+    state = {"in": False}
+
+    def one():
+        while True:
+            if not state["in"]:
+                ctx.begin_timestep()
+                state["in"] = True
+            if ctx.newton_iter():
+                ctx.end_timestep()
+                state["in"] = False
+                continue
+            return
+    for _ in range(warmup):
+        one()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    el = time.perf_counter() - t0
+    f_ms, s_ms = ctx.bench_factor_solve(2)
+    ms_asm, bytes_asm = ctx.bench_assembly(0.04 ** 2, reps=10)
+    st = ctx.linsys_stats()
+    ctx.close()
+    ach = bytes_asm / (ms_asm * 1e-3) / 1e9
+    return {"workload": f"matTwist mat{args.large_size}: {V.shape[0]} nodes / {F.shape[0]} tets, one GPU", "value": steps / el, "unit": "iter/s", "ms_per_step": 1e3 * el / steps,
+            "steps": steps, "warmup": warmup, "precompute_s": t_pre,
+            "roofline": {"kernel": "k_assemble_patch<true>", "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "algorithmic_bytes": bytes_asm, "avg_launch_ms": ms_asm, "traffic": pmc_traffic(args.large_size)},
+            "roofline_solver": [
+                {"kernel": "multifrontal factorisation", "bound": "mfma", "achieved": st["flops"] / 1e12 / (f_ms * 1e-3), "peak": 78.6, "unit": "TFLOP/s",
+                 "frac": st["flops"] / 1e12 / (f_ms * 1e-3) / 78.6, "factor_ms": f_ms, "factor_gflop": st["flops"] / 1e9},
+                {"kernel": "triangular solves", "bound": "hbm", "achieved": 2 * 8 * st["nnzL"] / 1e9 / (s_ms * 1e-3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": 2 * 8 * st["nnzL"] / 1e9 / (s_ms * 1e-3) / HBM_PEAK_GBS, "solve_ms": s_ms}]}
 
 
 def large_workload(args, rank, local_rank, world, torch, dist, ipc_amd):
@@ -396,7 +477,7 @@ def cpu_reference(V, F, steps=4):
                 f.write(f"energy NH\ntimeIntegration BE\ntime {0.04 * steps:.17g} 0.04\ndensity 1000\nstiffness 2e4 0.4\nturnOffGravity\nscript twist\n"
                         f"shapes input 1\n{tmp}/mat.msh 0 0 0  0 0 0  1 1 1\nselfCollisionOff\n")
             t0 = time.perf_counter()
-            rcode, log = rc.run_reference(os.path.join(tmp, "scene.txt"), os.path.join(tmp, "out"), timeout=900, cwd=tmp)
+            rcode, log = rc.run_reference(os.path.join(tmp, "scene.txt"), os.path.join(tmp, "out"), timeout=240, cwd=tmp)
             wall = time.perf_counter() - t0
             if rcode != 0:
                 return {"value": None, "kind": "reference", "note": "the reference run failed: " + log[-300:]}

@@ -2416,6 +2416,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_FWD_ROOT_ON_MAIN")) fwdRootOnMain_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD")) schurFold_ = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD_MIN")) schurFoldMinSteps_ = std::max(2, std::atoi(e));
+    if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD_MB")) schurFoldBudget_ = (long long)std::max(0, std::atoi(e)) << 20;
     if (!fwd_ && !std::getenv("IPCGPU_MF_NO_FWD_OVERLAP")) {
         HIP_CHECK(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evRhs_, hipEventDisableTiming));
@@ -2455,7 +2456,11 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_XINV_SKIP_TOP")) xinvSkipTop_ = std::max(0, std::atoi(e));
     xinvBorder_ = true; // the inverse grows by bordering inside the step launches (step_border); 0: recursive doubling on the side stream, as before round 4
     if (const char* e = std::getenv("IPCGPU_MF_XINV_BORDER")) xinvBorder_ = std::atoi(e) != 0;
+    int borderMaxNc = 1024; // wider separators (a root of 2 600 columns at 1.12 M tets) keep the recursive doubling: a bordering workgroup is as long as the
+                            // front is wide, and at that width it stretches every step launch (measured at mat433: factorisation 20.0 -> 20.8 ms)
+    if (const char* e = std::getenv("IPCGPU_MF_BORDER_MAX_NC")) borderMaxNc = std::max(0, std::atoi(e));
     auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin && sym.level[s] < nLevels_ - xinvSkipTop_; };
+    auto hasBorder = [&](int s) { return xinvBorder_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; };
     // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
     owner_.assign(ns_, rank_);
     sharedFlops_ = 0.0;
@@ -2718,9 +2723,20 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         // Schur complement: one pass behind the chain (k_big_schur / k_big_schur64), or -- on the levels of the top separators, where the chain of step
         // launches is what the level takes -- folded into those launches in passes of schurFold_ panels (role S): pass q = panels [e(q-1), e(q)) rides on
         // launch e(q), the first one that finds them final; the last pass on the last launch (which otherwise only carries role C).
-        const bool foldSchur = schurFold_ > 0 && steps >= schurFoldMinSteps_;
+        // Every pass reads and writes the level's update matrices once more: worth it while they are small (the top of a 45 K-node sheet: 6 - 30 MB per
+        // level), a loss where they are not (at 1.12 M tets the two fronts below the root hold 54 MB: folded into 11 passes the factorisation went from
+        // 20.0 to 23.1 ms).  The passes of a level may move schurFoldBudget_ bytes in all.
+        long long sBytes = 0;
+        for (int s : big) sBytes += 4ll * (sym.N(s) - sym.nc(s)) * (sym.N(s) - sym.nc(s)); // lower triangle, doubles
+        int foldPanels = schurFold_;
+        if (schurFold_ > 0 && sBytes > 0) {
+            const long long maxPass = schurFoldBudget_ / sBytes;
+            if (maxPass < 2) foldPanels = 0;
+            else foldPanels = std::max<long long>(schurFold_, (steps + maxPass - 1) / maxPass);
+        }
+        const bool foldSchur = foldPanels > 0 && steps >= schurFoldMinSteps_ && steps > foldPanels;
         if (foldSchur) P.stepTop = true;
-        const int nPass = foldSchur ? (steps + schurFold_ - 1) / schurFold_ : 0;
+        const int nPass = foldSchur ? (steps + foldPanels - 1) / foldPanels : 0;
         for (int j = -1; j < steps && !big.empty(); ++j) {
             Range& R = P.step[j + 1];
             R.off = (int)desc.size();
@@ -2738,7 +2754,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                         desc.push_back(make_int4((int)hDinvOff_[s], j >= 0 ? kb : -1, r0, -2));
                         desc.push_back(rec2);
                     }
-                if (j >= 0 && xinvBorder_ && hasXinv(s)) { // role C: the rows of panel j of X = L11^-1, one workgroup per column tile up to the diagonal block
+                if (j >= 0 && hasBorder(s)) { // role C: the rows of panel j of X = L11^-1, one workgroup per column tile up to the diagonal block
                     P.stepTop = true;
                     // 16-column tiles (32 wide ones made the late steps of the root 20 us long: one CU per tile, k up to nc); c0 == kb: the diagonal block, one copy
                     for (int c0 = 0; c0 <= kb; c0 += 16) {
@@ -2757,9 +2773,9 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                         }
                 }
             }
-            if (foldSchur && j >= 0 && ((j + 1) % schurFold_ == 0 || j + 1 == steps)) { // role S: launch j + 1 finds the panels [.., j] final
-                const int q = (j + schurFold_) / schurFold_; // pass number, 1-based: panels [(q - 1) fold, min(q fold, steps))
-                const int cLo = NB * (q - 1) * schurFold_, cHi = (q == nPass) ? (1 << 30) : NB * q * schurFold_;
+            if (foldSchur && j >= 0 && ((j + 1) % foldPanels == 0 || j + 1 == steps)) { // role S: launch j + 1 finds the panels [.., j] final
+                const int q = (j + foldPanels) / foldPanels; // pass number, 1-based: panels [(q - 1) fold, min(q fold, steps))
+                const int cLo = NB * (q - 1) * foldPanels, cHi = (q == nPass) ? (1 << 30) : NB * q * foldPanels;
                 // folded passes are SHORT sums (schurFold_ panels): the 32 x 32 tiles split them over their four waves and are done in one memory round trip,
                 // a 64 x 64 tile walks them chunk by chunk (measured: +5.5 us per step launch that carried a pass of 64 x 64 tiles)
                 const int TQl = TQ;
@@ -2869,7 +2885,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 if (sym.level[s] == l) lf.push_back(s);
             XL.blocks.off = (int)blockList.size();
             XL.init.off = (int)xd.size();
-            if (xinvBorder_) lf.clear(); // nothing for the side stream: the step launches build the inverses (step_border)
+            lf.erase(std::remove_if(lf.begin(), lf.end(), [&](int s) { return hasBorder(s); }), lf.end()); // the step launches build those inverses (step_border)
             for (int s : lf)
                 for (int b = 0; b < (sym.nc(s) + NB - 1) / NB; ++b) {
                     blockList.push_back((int)(di[s] + b));

@@ -12,7 +12,7 @@ namespace ipcgpu {
 
 namespace {
 
-constexpr int BLOCK = 256;
+constexpr int BLOCK_MAX = 512; // workgroup sizes: 256 (patches of <= 256 elements, two workgroups per CU) or 512 (<= 512 elements, one per CU: less halo)
 constexpr int NF = 38; // staged doubles per element (one 304-byte record: 76 dwords = 12 mod 64, so records spread over the LDS banks):
                         // U 9, Ad 6, Bd 6, Bo 3, beta_0..3 12, projection mask (int), pad
 constexpr int CHUNK = 4; // contributions per phase-2 lane
@@ -29,8 +29,13 @@ __device__ __forceinline__ double row_shl(double x)
     return __hiloint2double(hi, lo);
 }
 
-template <bool HESS>
-__global__ __launch_bounds__(BLOCK) void k_assemble_patch(ElemView v, PatchView pv, int patchBegin, int tcap, int ncap, double coef,
+#ifdef IPCGPU_ASM_WAVES3 // experiment build (tools/): three waves per SIMD at the price of spills
+#define ASM_OCC __attribute__((amdgpu_waves_per_eu(3, 3)))
+#else
+#define ASM_OCC
+#endif
+template <bool HESS, int BLOCK>
+__global__ __launch_bounds__(BLOCK) ASM_OCC void k_assemble_patch(ElemView v, PatchView pv, int patchBegin, int tcap, int ncap, double coef,
     int projectDBC, double* __restrict__ grad, double* __restrict__ a, int probe)
 {
     extern __shared__ __align__(16) double lds[];
@@ -245,8 +250,11 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
     valid = false;
     const int nV = mesh.nV, nT = mesh.nT;
     if (lin.rowBase.empty() || nT == 0) return;
-    int tetCap = BLOCK;
-    if (const char* e = std::getenv("IPCGPU_PATCH_TETS")) tetCap = std::max(32, std::min(BLOCK, std::atoi(e)));
+    // elements per patch: 256 fills a 256-thread workgroup and has the least halo; a mesh that is only a round or two of resident workgroups (two per CU)
+    // does better with 224 (mat150: 45.9 us against 47.8 -- more, shorter workgroups in the second round; mat433: 0.361 ms against 0.307,
+    // profiles/r04_assembly_patch_size_ab.txt)
+    int tetCap = (nT < 300000) ? 224 : 256;
+    if (const char* e = std::getenv("IPCGPU_PATCH_TETS")) tetCap = std::max(32, std::min(BLOCK_MAX, std::atoi(e)));
     std::vector<int> owner, localIdx; // filled with the patches (fresh topology only): who owns a node, and where in its patch
     const bool freshTopo = !(topo.mesh == (const void*)&mesh && topo.version == mesh.featuresVersion && topo.nV == nV && topo.nT == nT && topo.tetCap == tetCap);
     if (freshTopo) {
@@ -492,20 +500,33 @@ void launch_assemble_patches(const ElemView& v, const PatchPlan& plan, int patch
     if (n <= 0) return;
     const size_t lds = plan.ldsBytes();
     const int tcap = (plan.maxTets + 63) / 64 * 64;
-    static size_t attrSet = 0;
-    if (lds > 64 * 1024 && lds > attrSet) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_assemble_patch<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_assemble_patch<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attrSet = lds;
+    const bool wide = plan.maxTets > 256; // patches of up to 512 elements: 512-thread workgroups
+    static size_t attrSet[2] = { 0, 0 };
+    if (lds > 64 * 1024 && lds > attrSet[wide]) {
+        if (wide) {
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_assemble_patch<true, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_assemble_patch<false, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        else {
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_assemble_patch<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            HIP_CHECK(hipFuncSetAttribute((const void*)k_assemble_patch<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        attrSet[wide] = lds;
     }
     const PatchView pv = plan.view();
     static const int probe = std::getenv("IPCGPU_ASM_PROBE") ? std::atoi(std::getenv("IPCGPU_ASM_PROBE")) : 0; // profiling only
-    if (a)
-        hipLaunchKernelGGL(k_assemble_patch<true>, dim3(n), dim3(BLOCK), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad,
-            a, probe);
-    else
-        hipLaunchKernelGGL(k_assemble_patch<false>, dim3(n), dim3(BLOCK), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad,
-            a, probe);
+    if (wide) {
+        if (a)
+            hipLaunchKernelGGL((k_assemble_patch<true, 512>), dim3(n), dim3(512), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+        else
+            hipLaunchKernelGGL((k_assemble_patch<false, 512>), dim3(n), dim3(512), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+    }
+    else {
+        if (a)
+            hipLaunchKernelGGL((k_assemble_patch<true, 256>), dim3(n), dim3(256), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+        else
+            hipLaunchKernelGGL((k_assemble_patch<false, 256>), dim3(n), dim3(256), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+    }
 }
 
 } // namespace ipcgpu

@@ -18,7 +18,7 @@ for rep in 1 2; do
     i=$((i + 1))
     if [ "$setting" = "-" ]; then env_s=""; else env_s="$setting"; fi
     if [ -n "$CHECK" ] && [ $rep = 1 ]; then ( env $env_s timeout 120 python tools/check_solver.py 2>&1 | tail -1 ) | sed "s/^/[$setting] /"; fi
-    env $env_s timeout 300 python bench.py --no-cpu-baseline $flags > $out/ab_${i}_$rep.json 2>> $out/err.log
+    env $env_s timeout 300 python bench.py --no-cpu-baseline --no-large --steps ${STEPS:-200} --warmup 10 $flags > $out/ab_${i}_$rep.json 2>> $out/err.log
   done
 done
 python - "$out" "$@" <<'PY'
