@@ -34,16 +34,30 @@ inline bool& inside()
     static thread_local bool f = false;
     return f;
 }
+// Workers wait for the next loop by SPINNING on a generation counter for a few tens of microseconds before they go to sleep on a condition variable
+// (the reference issues thousands of short loops per Newton iteration: waking 255 sleepers through a mutex for each of them took minutes on a
+// 256-core box), and a loop only takes as many threads as it has blocks of GRAIN iterations.
 class Pool {
+    static constexpr long long GRAIN = 64;
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable cvStart_, cvDone_;
+    std::condition_variable cv_;
+    std::atomic<unsigned long long> gen_{ 0 };
+    std::atomic<int> pending_{ 0 }, sleepers_{ 0 };
+    std::atomic<bool> stop_{ false };
     const std::function<void(long long, long long)>* body_ = nullptr;
     std::atomic<long long> next_{ 0 };
     long long end_ = 0, chunk_ = 1;
-    unsigned long long gen_ = 0;
-    int active_ = 0;
-    bool stop_ = false;
+    int participants_ = 1;
+    int spin_ = 0;
+    static void relax()
+    {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        std::this_thread::yield();
+#endif
+    }
     void drain()
     {
         for (;;) {
@@ -52,58 +66,79 @@ class Pool {
             (*body_)(b, b + chunk_ < end_ ? b + chunk_ : end_);
         }
     }
+    void work(int idx)
+    {
+        inside() = true;
+        unsigned long long seen = 0;
+        for (;;) {
+            bool got = false;
+            for (int i = 0; i < spin_; ++i) {
+                if (gen_.load(std::memory_order_acquire) != seen || stop_.load(std::memory_order_relaxed)) {
+                    got = true;
+                    break;
+                }
+                relax();
+            }
+            if (!got) {
+                std::unique_lock<std::mutex> lk(m_);
+                sleepers_.fetch_add(1);
+                cv_.wait(lk, [&] { return stop_.load() || gen_.load() != seen; });
+                sleepers_.fetch_sub(1);
+            }
+            if (stop_.load()) return;
+            seen = gen_.load(std::memory_order_acquire);
+            if (idx < participants_) { // a participant cannot miss a generation: run() does not return before all of them have checked out
+                drain();
+                pending_.fetch_sub(1, std::memory_order_acq_rel);
+            }
+        }
+    }
 
 public:
     explicit Pool(int n)
     {
-        for (int t = 1; t < n; ++t)
-            workers_.emplace_back([this] {
-                inside() = true;
-                unsigned long long seen = 0;
-                for (;;) {
-                    {
-                        std::unique_lock<std::mutex> lk(m_);
-                        cvStart_.wait(lk, [&] { return stop_ || gen_ != seen; });
-                        if (stop_) return;
-                        seen = gen_;
-                    }
-                    drain();
-                    {
-                        std::lock_guard<std::mutex> lk(m_);
-                        if (--active_ == 0) cvDone_.notify_one();
-                    }
-                }
-            });
+        const int hw = (int)std::thread::hardware_concurrency();
+        spin_ = (hw > 0 && n <= hw) ? 20000 : 0; // oversubscribed: straight to sleep
+        for (int t = 1; t < n; ++t) workers_.emplace_back([this, t] { work(t); });
     }
     ~Pool()
     {
+        stop_.store(true);
         {
             std::lock_guard<std::mutex> lk(m_);
-            stop_ = true;
         }
-        cvStart_.notify_all();
+        cv_.notify_all();
         for (auto& w : workers_) w.join();
     }
     int size() const { return (int)workers_.size() + 1; }
     void run(long long n, const std::function<void(long long, long long)>& body)
     {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            body_ = &body;
-            next_.store(0);
-            end_ = n;
-            const long long parts = 8LL * size();
-            chunk_ = (n + parts - 1) / parts;
-            if (chunk_ < 1) chunk_ = 1;
-            active_ = (int)workers_.size();
-            ++gen_;
+        const long long blocks = (n + GRAIN - 1) / GRAIN;
+        const int p = (int)(blocks < (long long)size() ? blocks : (long long)size());
+        if (p <= 1) {
+            inside() = true;
+            body(0, n);
+            inside() = false;
+            return;
         }
-        cvStart_.notify_all();
+        body_ = &body;
+        end_ = n;
+        chunk_ = (n + 8LL * p - 1) / (8LL * p);
+        if (chunk_ < 1) chunk_ = 1;
+        next_.store(0, std::memory_order_relaxed);
+        participants_ = p;
+        pending_.store(p - 1, std::memory_order_relaxed);
+        gen_.fetch_add(1, std::memory_order_seq_cst);
+        if (sleepers_.load() > 0) {
+            {
+                std::lock_guard<std::mutex> lk(m_);
+            }
+            cv_.notify_all();
+        }
         inside() = true;
         drain();
         inside() = false;
-        std::unique_lock<std::mutex> lk(m_);
-        cvDone_.wait(lk, [&] { return active_ == 0; });
+        while (pending_.load(std::memory_order_acquire) != 0) relax();
     }
 };
 inline Pool& pool()
