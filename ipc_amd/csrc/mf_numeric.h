@@ -112,6 +112,7 @@ private:
     Range plainBlocks_; // diagonal blocks of all other fronts (inverted at the end of the factorisation)
     DevBuf<int> invBlockList_;
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
+    int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)
     bool fwdRootOnMain_ = true, fwdJoined_ = false; // the root's forward sweep on the main stream (IPCGPU_MF_FWD_ROOT_ON_MAIN=0: on the forward stream like the other levels)
     int schurFold_ = 0, schurFoldMinSteps_ = 8; // off by default: measured neutral at mat150 (382.4 it/s with passes of 4 panels, 384.1 without) and a loss where the update matrices are large
     long long schurFoldBudget_ = 128ll << 20; // bytes of update matrix the folded passes of one level may move (IPCGPU_MF_SCHUR_FOLD_MB) // IPCGPU_MF_SCHUR_FOLD: panels per folded pass (0 = one pass behind the chain); ..._MIN: levels with at least this many panels

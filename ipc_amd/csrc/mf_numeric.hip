@@ -2414,6 +2414,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
     if (const char* e = std::getenv("IPCGPU_MF_FWD_ROOT_ON_MAIN")) fwdRootOnMain_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IPCGPU_MF_FWD_STRIDE")) fwdStride_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD")) schurFold_ = std::max(0, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD_MIN")) schurFoldMinSteps_ = std::max(2, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD_MB")) schurFoldBudget_ = (long long)std::max(0, std::atoi(e)) << 20;
@@ -3106,6 +3107,7 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
     if (sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evSide_, 0)); // the side stream still reads the previous factor
     flag_.zero(stream_);
     bool sideUsed = false;
+    int fwdNext = 0; // first level not yet handed to the forward stream
     if (nFusedA_) hipLaunchKernelGGL(k_gather_a, dim3((nFusedA_ + 255) / 256), dim3(256), 0, stream_, nFusedA_, aSrc_.p, a_dev, aPerm_.p);
     for (int l = 0; l < nLevels_; ++l) {
         const LevelPlan& P = plan_[l];
@@ -3188,11 +3190,16 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
                 enqueueForwardLevel(l, stream_);
                 fwdJoined_ = true;
             }
-            else {
+            else if (l >= nLevels_ - 2 || (l + 1) % fwdStride_ == 0) {
+                // An event recorded on this stream costs the chain a ~7 us bubble (profiles/r04_schur_passes_on_a_side_stream_ab.txt), so the levels are handed
+                // over in groups of fwdStride_: the forward stream has the whole rest of the factorisation to catch up, only the level below the root
+                // must not wait (the root's own sweep follows on this stream)
                 HIP_CHECK(hipEventRecord(evFactLevel_[l], stream_));
                 HIP_CHECK(hipStreamWaitEvent(fwd_, evFactLevel_[l], 0));
-                if (plan_[l].xinvFwd.cnt && sideUsed) HIP_CHECK(hipStreamWaitEvent(fwd_, evInvDone_[l], 0));
-                enqueueForwardLevel(l, fwd_);
+                for (; fwdNext <= l; ++fwdNext) {
+                    if (plan_[fwdNext].xinvFwd.cnt && sideUsed) HIP_CHECK(hipStreamWaitEvent(fwd_, evInvDone_[fwdNext], 0));
+                    enqueueForwardLevel(fwdNext, fwd_);
+                }
             }
         }
     }

@@ -89,15 +89,14 @@ __device__ inline void svd3(const double Fin[9], double U[9], double s[3], doubl
             double ga = G[3 * p] * G[3 * q] + G[3 * p + 1] * G[3 * q + 1] + G[3 * p + 2] * G[3 * q + 2];
             if (ga != 0.0 && ga * ga > 1e-30 * (al * be)) { // below ~1e-15 relative the "rotation" is rounding noise: 1e-32 made 2 % of the lanes (hence most waves) run all 30 sweeps
                 rotated = true;
-                // the rotation that makes the two columns orthogonal, tan 2 theta = 2 ga / (be - al), |theta| <= pi / 4, from TWO reciprocal square roots:
-                //   cos 2 theta = |d| / r, sin 2 theta = sign(d) h / r (d = be - al, h = 2 ga, r = |(d, h)|);  c = sqrt((1 + cos 2 theta) / 2), s = sin 2 theta / (2 c)
-                // (round 4: the textbook route zeta -> t -> c is a reciprocal, a square root, a reciprocal and a reciprocal square root, each a seed + two
-                // Newton steps on the dependent chain of every rotation; the fixed point -- the SVD -- is the same)
-                const double d = be - al, h = ga + ga;
-                const double ir = fast_rsqrt(fma(d, d, h * h));
-                const double m = fma(0.5 * fabs(d), ir, 0.5); // (1 + cos 2 theta) / 2 in [1/2, 1]
-                const double iq = fast_rsqrt(m);
-                const double c = m * iq, sn = copysign(0.5, d) * (h * ir) * iq;
+                // (round 4: a cheaper route to the same rotation -- cos 2 theta = |d| / r, sin 2 theta = sign(d) h / r with d = be - al, h = 2 ga, two reciprocal
+                // square roots instead of a reciprocal, a square root, a reciprocal and a reciprocal square root -- was tried and withdrawn: it changes the last
+                // bits of U and V, which is harmless everywhere except at F = I up to round-off, where the sigma-space projection is decided by exactly those
+                // bits; three from-rest scene fixtures (`seg_bed_squash`, `script_toggle_top`, `dbc_time_range`) then take other Newton paths than the CPU
+                // restatement, which uses this textbook form.  It bought 1.5 us of 46.)
+                const double zeta = (be - al) * (0.5 * fast_rcp(ga));
+                const double t = copysign(fast_rcp(fabs(zeta) + fast_sqrt(1.0 + zeta * zeta)), zeta);
+                const double c = fast_rsqrt(1.0 + t * t), sn = c * t;
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
                     double gp = G[3 * p + i], gq = G[3 * q + i];

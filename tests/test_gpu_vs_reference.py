@@ -14,6 +14,8 @@ from test_oracle_vs_reference import (BOXRULE_SCENES, CODIM_SCENES, GOLD, HANDLE
 
 pytestmark = pytest.mark.gpu
 
+GPU_MISMATCH_BUDGET = {"dbc_time_range": 5}  # see test_more_scenes_against_the_reference
+
 
 @pytest.fixture(scope="module")
 def G():
@@ -212,8 +214,12 @@ def test_more_scenes_against_the_reference(name, exact, mism, tol, gpu_lib):
     ref_its = S["iters"][:len(its)]
     report = (its.tolist(), ref_its.tolist())
     # (1e-9 before the touch-down: the homotopy scene solves barrier problems at a dHat of half the scene from its first step on)
-    check_scene(S, pos, its, exact, len(its), 10 * tol, exact_tol=1e-9)
-    assert abs(int(its.sum()) - int(ref_its.sum())) <= 0.25 * int(ref_its.sum()), report
+    # round 4: the CPU restatement's own budgets (count mismatches, end-position tolerance) -- no blanket "+25 % of the total work" any more.  ONE scene keeps
+    # a budget of its own: in `dbc_time_range` the cube touches down from exact rest (F = I up to round-off, where the sigma-space projection is decided by the
+    # last bits) and the HIP element kernels contract multiply-adds where the restatement does not: five steps of the touch-down (17-19, 21, 22) differ from the
+    # reference's count instead of the restatement's three, the end positions stay inside the same tolerance.
+    check_scene(S, pos, its, exact, GPU_MISMATCH_BUDGET.get(name, mism), tol, exact_tol=1e-9)
+    assert report is not None
     c.close()
 
 
@@ -225,7 +231,7 @@ def test_continuation_from_the_references_own_state(name, tol, tmp_path, gpu_lib
     if "restart_status" not in S.files:
         pytest.skip("fixture without a continuation")
     c = gpu_lib.Context(0)
-    check_restart(S, meshes, c, tmp_path, 10 * tol)
+    check_restart(S, meshes, c, tmp_path, tol)
     c.close()
 
 
@@ -246,7 +252,7 @@ def test_codimensional_segments_and_points_against_the_reference(name, tol, gpu_
     S, meshes = load_scene(name)
     c = gpu_lib.Context(0)
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
-    check_codim(S, pos, its, 10 * tol)
+    check_codim(S, pos, its, tol)
     c.close()
 
 
@@ -258,7 +264,7 @@ def test_shipped_scenes_against_the_reference(name, mism, tol, gpu_lib):
     c = gpu_lib.Context(0)
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     c.close()
-    check_shipped(S, pos, its, max(mism, 1), 10 * tol)
+    check_shipped(S, pos, its, mism, tol)
 
 
 def test_trash_compactor_against_the_reference(gpu_lib):
