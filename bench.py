@@ -42,7 +42,8 @@ class DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
 
-SHARD_MIN_TETS = 4_000_000  # ~1.8 ms of assembly on one GPU: where splitting it starts to beat an all-reduce of gradient + CSR values
+# (rounds 2-3 switched the sharded assembly on only from 4 M tets: its partial matrices were summed by an all-reduce of the CSR values.  Round 4: with the solver
+# sharded as well the assembly is owner-computes -- a rank assembles the rows its fronts read, no matrix value crosses ranks -- so every size shards.)
 
 
 def pmc_traffic(size):
@@ -108,11 +109,10 @@ def main():
 
     V, F, left, right = build_scene(args.size)
     ctx = ipc_amd.Context(local_rank, solver=args.solver)
-    # The fused assembly of mat150 takes 0.06 ms; an all-reduce of its 18 MB of CSR values over xGMI costs more than that, and
-    # the factorisation (94 % of an iteration) is replicated either way.  Sharding is therefore switched on only for meshes
-    # whose assembly outweighs the exchange; below that every rank runs the whole iteration (no data-path collective).
-    sharded = distributed and (args.shard == "on" or (args.shard == "auto" and F.shape[0] >= SHARD_MIN_TETS))
+    # Elements and contact-pair lists shard with the solver's subtrees (owner-computes rows, ipcgpu_opt_comm_stats): what crosses ranks per Newton iteration is
+    # the nodal gradient, scalars, and the solver's update matrices / vectors above its cut -- no CSR value.  --shard off / --solver-shard off are A/B switches.
     solver_sharded = distributed and args.solver_shard == "on"
+    sharded = distributed and (args.shard == "on" or (args.shard == "auto" and solver_sharded))
     if distributed:
         def hook(ptr, count, op):
             t = torch.as_tensor(DevPtr(ptr, count), device=f"cuda:{local_rank}")
@@ -171,6 +171,7 @@ def main():
     progress(f"precompute done ({t_pre:.1f} s); {args.warmup} warm-up + {args.steps} timed Newton iterations")
     for _ in range(args.warmup):
         one_iteration()
+    comm0 = ctx.comm_stats()
     t_before = ctx.timers().copy()
     barrier()
     t0 = time.perf_counter()
@@ -183,6 +184,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     timers = ctx.timers() - t_before
+    comm1 = ctx.comm_stats()
 
     progress(f"timed region done: {args.steps / elapsed:.1f} it/s")
     # collective when the solver is sharded: every rank takes part
@@ -212,7 +214,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True,
-            # the metric's workload is fixed (strong scaling) -- but below SHARD_MIN_TETS every rank runs the whole iteration and
+            # the metric's workload is fixed (strong scaling); with both shards switched off every rank runs the whole iteration and
             # nothing is divided: say so instead of letting N replicas read as an N-GPU strong-scaling point
             "scaling": "strong" if (world == 1 or sharded or solver_sharded) else "none (replicated: every rank runs the whole iteration)",
             "vs_baseline": None,
@@ -224,14 +226,22 @@ def main():
                 "n_nodes": int(V.shape[0]), "n_tets": int(F.shape[0]), "n_dofs": int(n_rows), "nnz_upper_csr": int(nnz),
                 "linear_solver": "gpu-multifrontal-llt" if args.solver == 0 else "rocsolver-csrrf",
                 "parallelism": "single GPU" if world == 1 else (
-                    f"{world} GPUs: " + ("element-sharded assembly (RCCL all-reduce of gradient + CSR values)" if sharded else
-                                         f"assembly repeated on every rank (sharding it is switched on from {SHARD_MIN_TETS} tets: below, the "
-                                         "all-reduce of the CSR values costs more than the assembly)")
+                    f"{world} GPUs: " + ("owner-computes assembly: a rank assembles the CSR rows of the nodes its subtrees eliminate + the separator rows above "
+                                         "the cut (elements and contact stencils on a cut evaluated by both sides), no matrix value crosses ranks; RCCL all-reduce "
+                                         "of the nodal gradient and of scalars" if sharded and solver_sharded else
+                                         ("element-sharded assembly, partial matrices summed by an all-reduce of the CSR values" if sharded else
+                                          "assembly repeated on every rank"))
                     + "; " + (f"subtree-sharded multifrontal factorisation and solves: {100 * ctx.solver_shard_stats()['shared_flop_fraction']:.0f} % of the "
                               "factorisation flops lie above the cut and are repeated, update matrices / vectors of the subtree roots and the "
                               "solution cross ranks by all-reduce" if solver_sharded else "factorisation and solves repeated on every rank")),
                 "time_steps_completed": state["steps_done"],
             },
+            "comm_per_iter": {"stepper_allreduce_bytes": (comm1["stepper_bytes"] - comm0["stepper_bytes"]) / K,
+                              "stepper_allreduce_calls": (comm1["stepper_calls"] - comm0["stepper_calls"]) / K,
+                              "solver_allreduce_bytes": (comm1["solver_bytes"] - comm0["solver_bytes"]) / K,
+                              "solver_allreduce_calls": (comm1["solver_calls"] - comm0["solver_calls"]) / K,
+                              "csr_value_bytes": 8 * int(nnz), "nodal_vector_bytes": 24 * int(V.shape[0]),
+                              "rows_assembled_on_rank0": comm1["rows_assembled_nodes"] / max(comm1["nodes"], 1)},
             "split_ms_per_iter": split,
             "split_note": "factor_ms holds the numeric factorisation AND both triangular sweeps (the forward sweep of a level runs on its own stream beside the "
                           "factorisation of the levels above, MfNumeric::factorizeSolve); backsolve_ms is what follows them in the same bucket: the batched "
@@ -367,7 +377,7 @@ def large_workload(args, rank, local_rank, world, torch, dist, ipc_amd):
     """bench.py --gpus N: the same twist scene at --large-size (mat433 = 1.12 M tets), sharded the same way, timed like the main line."""
     V, F, left, right = build_scene(args.large_size)
     ctx = ipc_amd.Context(local_rank, solver=args.solver)
-    sharded = args.shard == "on" or (args.shard == "auto" and F.shape[0] >= SHARD_MIN_TETS)
+    sharded = args.shard == "on" or (args.shard == "auto" and args.solver_shard == "on")
     if sharded:
         ctx.set_shard(rank, world)
     if args.single_device_test:

@@ -143,12 +143,21 @@ int ipcgpu_linsys_solve(ipcgpu_ctx*, const double* rhs, double* result); /* solv
 int ipcgpu_linsys_precondition_diag(ipcgpu_ctx*, const double* in, double* out); /* :411-420 */
 /* Multi-GPU direct solver (one process per GPU): the assembly tree is cut below its top separators; rank r factorises and solves
    the subtrees it owns, every rank repeats the fronts above the cut, and the update matrices / vectors of the subtree roots and
-   the final solution cross ranks through the all-reduce hook of ipcgpu_opt_set_allreduce (set the hook first).  The matrix
-   values must be present on every rank (replicated assembly, or ipcgpu_ctx_set_shard with its all-reduce of the values).
+   the final solution cross ranks through the all-reduce hook of ipcgpu_opt_set_allreduce (set the hook first).  A rank needs the matrix
+   values of its own fronts: replicated assembly, or ipcgpu_ctx_set_shard (owner-computes rows, see ipcgpu_opt_comm_stats below).
    Takes effect at the next analyze_pattern.  ipcgpu_linsys_shard_stats (after analyze_pattern): out2[0] = world size,
    out2[1] = the share of the factorisation flops that lies above the cut and is repeated by every rank. */
 int ipcgpu_linsys_set_shard(ipcgpu_ctx*, int rank, int world_size);
 int ipcgpu_linsys_shard_stats(ipcgpu_ctx*, double* out2);
+/* Owner-computes sharding (round 4; SURVEY.md 8e, the north star's "RCCL all-reduce of the shared-node gradient / Hessian rows"): a context that has BOTH
+   ipcgpu_ctx_set_shard and ipcgpu_linsys_set_shard (same world) assembles, per rank, exactly the CSR rows its fronts read -- the rows of the nodes its
+   subtrees eliminate plus the separator rows above the cut, which every rank repeats (elements and contact stencils on a cut are evaluated by both sides) --
+   so NO matrix value crosses ranks: the nodal gradient (one all-reduce, every node contributed by one rank), scalars, and the solver's update matrices /
+   vectors / solution do.  ipcgpu_opt_comm_stats: out6 = bytes and calls all-reduced by the time stepper, by the solver, then the number of nodes whose
+   rows this rank assembles and the number of nodes; ipcgpu_opt_complete_matrix: the rare consumer of the WHOLE matrix (ipcgpu_linsys_get_a / multiply on
+   such a context) sums the rows over the ranks first.  IPCGPU_NO_OWNER_COMPUTES=1 keeps the older all-reduce of the values. */
+int ipcgpu_opt_comm_stats(ipcgpu_ctx*, double* out6);
+int ipcgpu_opt_complete_matrix(ipcgpu_ctx*);
 /* factor statistics: nnz(L), factorisation flops, number of supernodes / levels */
 int ipcgpu_linsys_stats(ipcgpu_ctx*, double* stats4);
 

@@ -605,6 +605,28 @@ int ipcgpu_linsys_set_shard(ipcgpu_ctx* c, int rank, int world)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_comm_stats(ipcgpu_ctx* c, double* out6)
+{
+    return guarded([&] {
+        needArg(c && out6, "null argument");
+        HipOptimizer& o = O(c);
+        out6[0] = (double)o.commBytes;
+        out6[1] = (double)o.commCalls;
+        out6[2] = (double)L(c).exchangedBytes();
+        out6[3] = (double)L(c).exchangeCalls();
+        out6[4] = (double)(o.ownerMode() ? o.ownerNeededNodes : c->mesh->nV);
+        out6[5] = (double)c->mesh->nV;
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_complete_matrix(ipcgpu_ctx* c)
+{
+    return guarded([&] {
+        bind(c);
+        O(c).completeMatrix();
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_linsys_shard_stats(ipcgpu_ctx* c, double* out2)
 {
     return guarded([&] {

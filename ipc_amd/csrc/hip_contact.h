@@ -62,10 +62,10 @@ public:
     void uploadSets();
     // returns #active
     int buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat);
-    // Multi-GPU ("contact pairs assigned to ..."): the constraint SETS are the same on every rank (integer outputs every rank needs
-    // for the pattern), their EVALUATION is split -- rank r takes the stencils [n r / W, n (r + 1) / W) of the active and of the mollified
-    // list.  energy() then all-reduces its scalar through `shardReduce`; gradientAdd / hessianAdd add this rank's share into arrays the
-    // caller all-reduces (HipOptimizer::computePrecondMtr, barrierGradientAdd).
+    // Multi-GPU ("contact pairs assigned to the owner of ..."): the constraint SETS are the same on every rank (integer outputs every rank
+    // needs for the pattern), their EVALUATION is split.  energy(): rank r takes the stencils [n r / W, n (r + 1) / W) of the two lists and all-reduces its
+    // scalar through `shardReduce`.  gradientAdd / hessianAdd (round 4): the CALLER hands in a node mask -- a stencil is evaluated where one of its nodes owns
+    // rows (HipOptimizer's owner-computes plan); with a null mask they evaluate the whole lists, whatever the context's shard (the C entry points do).
     int shardRank = 0, shardWorld = 1;
     std::function<void(double*, long long)> shardReduce;
     void shardRange(int n, int& b, int& e) const
@@ -76,9 +76,9 @@ public:
     double energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
     // useActive / usePara: initKappa leaves the mollified set out (Optimizer.cpp:2262-2270)
     void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev, bool useActive = true,
-        bool usePara = true);
+        bool usePara = true, const unsigned char* need_dev = nullptr);
     void hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
-        double* a_dev);
+        double* a_dev, const unsigned char* need_dev = nullptr);
     void connectivity(std::vector<std::pair<int, int>>& pairs) const;
     bool patternCovers(const HipLinSysSolver& lin); // every node pair of the current sets has its block in lin's pattern (one small kernel)
     void candidateConnectivity(std::vector<std::pair<int, int>>& pairs) const; // appends; all node pairs of the candidate list

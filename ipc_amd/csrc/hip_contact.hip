@@ -26,6 +26,7 @@ struct ContactView {
     const int* SFE; // int2 per surface edge
     const double* x;
     const double* xRest;
+    const unsigned char* need = nullptr; // owner-computes sharding: per node, does this rank own rows that the node's stencils add to?  null = every stencil
 };
 
 struct Stencil {
@@ -249,11 +250,22 @@ __global__ void k_iota(int n, int* __restrict__ v)
 // grad += kappa (mult b' grad d)  resp.  kappa (b e' grad c + e b' grad d)   (SelfCollisionHandler.cpp:84-148, 2990-3036)
 // slots: 8 per stencil -- 0..3 the nodes of the distance stencil (active list) resp. the four edge nodes (mollified list), 4..7 the
 // nodes of the distance stencil of a mollified pair
+// owner-computes sharding: a stencil is evaluated by every rank that owns rows of one of its nodes (stencils on a cut are evaluated more than once,
+// like the elements on the rim of a patch); what it adds to the other nodes' rows is never read on this rank
+__device__ __forceinline__ bool stencil_skipped(const unsigned char* need, const int* node, int n)
+{
+    if (!need) return false;
+    for (int k = 0; k < n; ++k)
+        if (need[node[k]]) return false;
+    return true;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, double dHat, double kappa, GradSink sink)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < cv.nA) {
         const Stencil s = decode(cv.active + 4 * (size_t)i);
+        if (stencil_skipped(cv.need, s.node, s.n)) return;
         double X[4][3], g[12], b, gb, Hb;
         gatherX(cv.x, s.node, s.n, X);
         const double d = stencil_distance(s.kind, X, g, nullptr);
@@ -267,12 +279,13 @@ __global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, doub
     else if (i < cv.nA + cv.nP) {
         const int j = i - cv.nA;
         const Stencil s = decode(cv.para + 4 * (size_t)j);
+        int en[4];
+        paraNodes(cv, j, en);
+        if (stencil_skipped(cv.need, en, 4)) return; // the edge pair's four nodes contain the stencil's
         double X[4][3], g[12], b, gb, Hb;
         gatherX(cv.x, s.node, s.n, X);
         const double d = stencil_distance(s.kind, X, g, nullptr);
         barrier(d, dHat, &b, &gb, &Hb);
-        int en[4];
-        paraNodes(cv, j, en);
         double XE[4][3], cg[12], e, eg, eH;
         gatherX(cv.x, en, 4, XE);
         const double c = cross_sqnorm_derivs(XE, cg, nullptr);
@@ -413,7 +426,21 @@ __global__ __launch_bounds__(REG ? HESS_R : HESS_T) void k_contact_hessian(Conta
     const Strided Qs{ jac + (REG ? 0 : threadIdx.x), T }, Ws{ jac + (REG ? 0 : 81 * T + threadIdx.x), T };
     int sweepsDone = 0; // summed over the wave below: one atomic per wave instead of one per stencil
     double H[144], B[144];
-    if (i < cv.nA) {
+    bool skip = false; // owner-computes sharding: none of the stencil's nodes has rows on this rank (no early return: the wave sums sweepsDone below)
+    if (cv.need) {
+        if (i < cv.nA) {
+            const Stencil q = decode(cv.active + 4 * (size_t)i);
+            skip = stencil_skipped(cv.need, q.node, q.n);
+        }
+        else if (i < cv.nA + cv.nP) {
+            int en[4];
+            paraNodes(cv, i - cv.nA, en);
+            skip = stencil_skipped(cv.need, en, 4);
+        }
+    }
+    if (skip) {
+    }
+    else if (i < cv.nA) {
         const Stencil s = decode(cv.active + 4 * (size_t)i);
         double X[4][3], g[12], b, gb, Hb;
         gatherX(cv.x, s.node, s.n, X);
@@ -2249,15 +2276,14 @@ double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf
 }
 
 void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev,
-    bool useActive, bool usePara)
+    bool useActive, bool usePara, const unsigned char* need_dev)
 {
-    int aB, aE, pB, pE;
-    shardRange(useActive ? nActive_ : 0, aB, aE);
-    shardRange(usePara ? nPara_ : 0, pB, pE);
-    const int nA = aE - aB, nP = pE - pB;
+    // Always the WHOLE lists (round 4): which stencils a rank evaluates is decided by the caller's node mask (the optimizer's owner-computes plan), never by
+    // an index range hidden in here -- ipcgpu_contact_gradient_add on a sharded context used to return a rank's share without saying so.
+    const int nA = useActive ? nActive_ : 0, nP = usePara ? nPara_ : 0;
     const int n = nA + nP;
     if (n) {
-        ContactView cv{ nA, nP, d_active.p + 4 * (size_t)aB, d_para.p + 4 * (size_t)pB, d_paraEIEJ.p + 2 * (size_t)pB, d_SFE.p, x_dev, d_xRest.p };
+        ContactView cv{ nA, nP, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p, need_dev };
         if (atomicScatter_) hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ grad_dev, nullptr, nullptr });
         else {
             detBegin(8 * (size_t)n, 3, false);
@@ -2269,14 +2295,11 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
 }
 
 void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
-    double* a_dev)
+    double* a_dev, const unsigned char* need_dev)
 {
-    int aB, aE, pB, pE;
-    shardRange(nActive_, aB, aE);
-    shardRange(nPara_, pB, pE);
-    const int n = (aE - aB) + (pE - pB);
+    const int n = nActive_ + nPara_; // the whole lists; need_dev (or null) says which stencils this rank evaluates: see gradientAdd
     if (!n) return;
-    ContactView cv{ aE - aB, pE - pB, d_active.p + 4 * (size_t)aB, d_para.p + 4 * (size_t)pB, d_paraEIEJ.p + 2 * (size_t)pB, d_SFE.p, x_dev, d_xRest.p };
+    ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p, need_dev };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(4);
     counters_.zero(stream);

@@ -97,6 +97,10 @@ public:
         analyzed_ = false;
     }
     int solverWorld() const { return num_.world(); }
+    void nodeOwners(std::vector<int>& o) const { num_.nodeOwners(o); }
+    long long exchangedBytes() const { return num_.exchangedBytes(); }
+    long long exchangeCalls() const { return num_.exchangeCalls(); }
+    int analysisVersion = 0; // bumped by every analyze_pattern (the owner-computes plan of the assembly follows the solver's cut)
     double sharedFlopFraction() const { return num_.sharedFlopFraction(); }
     bool analyzed() const { return analyzed_; }
 
@@ -244,6 +248,22 @@ public:
     int patchVersion = -1;
     void ensurePatchPlan();
     void patchShard(int& pb, int& pe) const;
+    // Owner-computes sharding (round 4; SURVEY.md 8e as north_star states it): with the assembly AND the solver sharded, a rank assembles exactly the CSR rows
+    // its fronts read -- the rows of the nodes its subtrees eliminate plus the rows of the separator nodes above the cut, which every rank repeats -- by running
+    // the patches that hold such a node (elements and contact stencils on a cut are evaluated by both sides, like the halo of a patch).  NO matrix value crosses
+    // ranks; the gradient does (one all-reduce of 3 nV doubles in which every node is contributed by one designated rank), scalars, and what the solver
+    // exchanges above its cut (update matrices / vectors of the subtree roots, the solution).
+    bool ownerMode() const;
+    void ensureOwnerPlan();
+    int ownerPlanPatch = -1, ownerPlanAnalysis = -1;
+    int nOwnerPatches = 0;
+    DevBuf<int> d_ownerPatches; // the patches this rank runs
+    DevBuf<unsigned char> d_need, d_mine; // per node: rows needed on this rank / this rank is the node's designated contributor to all-reduced nodal vectors
+    long long ownerNeededNodes = 0;
+    bool matrixComplete = true; // false after an owner-mode assembly: a[] holds this rank's rows only
+    void maskAndReduceGradient(double* g);
+    void completeMatrix(); // sum of the designated rows over the ranks: for the consumers of the WHOLE matrix on a sharded context (diagonal fallback, get_a)
+    long long commBytes = 0, commCalls = 0; // all-reduced through the hook by the optimizer itself (the solver counts its own: HipLinSysSolver::exchangedBytes)
     // self-contact, interior point (fullyImplicit_IP with isSelfCollision, Optimizer.cpp:1518-1819)
     HipContact* contact = nullptr;
     bool selfCollision = false;
@@ -275,8 +295,8 @@ public:
     size_t nConstraints() const;
     int addHalfSpace(HipContact* c, const double* origin3, const double* normal3, double dHatEps);
     bool anyIntersection();
-    void elasticInertiaGradient(bool projectDBC);
-    void barrierGradientAdd(bool projectDBC, double kappa, bool activeOnly, double* grad_dev);
+    void elasticInertiaGradient(bool projectDBC, bool finish = true); // finish = false: owner-computes callers that exchange the sum themselves
+    void barrierGradientAdd(bool projectDBC, double kappa, bool activeOnly, double* grad_dev, int part = 0);
     void enableSelfCollision(HipContact* c, double dHatEps);
     void setVelocity(const double* vel3nV);
     void computeConstraintSets();

@@ -215,6 +215,7 @@ void HipLinSysSolver::analyze_pattern(const HipMesh* mesh)
     int leaf = 8;
     if (const char* e = std::getenv("IPCGPU_ND_LEAF")) leaf = std::max(1, std::atoi(e));
     mf_analyze(numRows, ia.data(), ja.data(), cptr, leaf, sym_);
+    ++analysisVersion;
     if (solverType == 0) {
         num_.setup(sym_, stream);
     }

@@ -270,6 +270,8 @@ void HipOptimizer::reduceMin(double* dev, long long n)
 }
 void HipOptimizer::hookReduce(double* dev, long long n, int op)
 {
+    commBytes += 8 * n;
+    commCalls++;
     if (allreduceStream) { // RCCL from C, ordered on our stream
         if (allreduceStream(allreduceUser, dev, n, op, (void*)stream) != 0) throw HipError("all-reduce hook failed");
         return;
@@ -717,16 +719,77 @@ void HipOptimizer::ensurePatchPlan()
     patch.build(mesh, lin, stream);
     patchVersion = lin.patternVersion;
 }
+bool HipOptimizer::ownerMode() const
+{
+    // both halves sharded, and nothing in play that reads the WHOLE matrix every iteration (the lagged damping matrix is a second value array on the pattern
+    // that enters energy and gradient through products with it: those runs keep the all-reduce of the values)
+    static const bool off = std::getenv("IPCGPU_NO_OWNER_COMPUTES") != nullptr; // A/B and tests of the older scheme
+    return !off && worldSize > 1 && lin.solverWorld() == worldSize && lin.solverType == 0 && lin.analyzed() && !(dampingStiff > 0.0); // (before the first analysis: the older scheme)
+}
+
+void HipOptimizer::ensureOwnerPlan()
+{
+    ensurePatchPlan();
+    if (ownerPlanPatch == patchVersion && ownerPlanAnalysis == lin.analysisVersion) return;
+    std::vector<int> owner;
+    lin.nodeOwners(owner); // rank of the subtree that eliminates the node, -1 above the cut
+    const int nV = mesh.nV;
+    std::vector<unsigned char> need(nV, 0), mine(nV, 0);
+    ownerNeededNodes = 0;
+    for (int v = 0; v < nV; ++v) {
+        const int o = (v < (int)owner.size()) ? owner[v] : -1;
+        need[v] = (o < 0 || o == rank) ? 1 : 0;
+        mine[v] = (o == rank || (o < 0 && rank == 0)) ? 1 : 0;
+        ownerNeededNodes += need[v];
+    }
+    std::vector<int> list;
+    const std::vector<int>&np = patch.topo.nodePtr, &nodes = patch.topo.nodes;
+    for (int p = 0; p + 1 < (int)np.size(); ++p) {
+        bool any = false;
+        for (int j = np[p]; j < np[p + 1] && !any; ++j) any = need[nodes[j]] != 0;
+        if (any) list.push_back(p);
+    }
+    nOwnerPatches = (int)list.size();
+    if (list.empty()) list.push_back(0);
+    d_ownerPatches.upload(list, stream);
+    d_need.upload(need, stream);
+    d_mine.upload(mine, stream);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    ownerPlanPatch = patchVersion;
+    ownerPlanAnalysis = lin.analysisVersion;
+}
+
+void HipOptimizer::maskAndReduceGradient(double* g)
+{
+    launch_keep_mine3(mesh.nV, d_mine.p, g, stream);
+    reduceSum(g, 3LL * mesh.nV);
+}
+
+void HipOptimizer::completeMatrix()
+{
+    if (matrixComplete || worldSize <= 1) return;
+    launch_keep_mine_rows(lin.numRows, d_mine.p, lin.d_ia.p, lin.d_a.p, stream);
+    reduceSum(lin.d_a.p, (long long)lin.ja.size());
+    matrixComplete = true;
+}
+
 void HipOptimizer::patchShard(int& pb, int& pe) const
 {
     pb = (int)((long long)patch.nPatches * rank / worldSize);
     pe = (int)((long long)patch.nPatches * (rank + 1) / worldSize);
 }
 
-void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activeOnly, double* grad_dev)
+void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activeOnly, double* grad_dev, int part)
 {
     // barrier forces of the half-spaces and of the mesh against itself; the projected rows are cleared again at the end
     // (Optimizer.cpp:3452-3516).  activeOnly: initKappa leaves the mollified parallel-edge set out (:2262-2270)
+    // part (owner-computes sharding): 0 = everything; 1 = only the self-contact stencils this rank evaluates, BEFORE the gradient exchange; 2 = the terms every
+    // rank evaluates alike (half-spaces, lagged friction), after it
+    if (part == 1) {
+        if (contact && selfCollision)
+            contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, 0, grad_dev, true, !activeOnly, d_need.p);
+        return;
+    }
     for (auto& h : planes) h->gradientAdd(mesh.d_x.p, dHat, kappa_, grad_dev);
     if (!activeOnly && fricDHat > 0.0) { // Optimizer.cpp:3474-3478, 3504-3506
         for (auto& h : planes)
@@ -734,14 +797,19 @@ void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activ
         if (selfCollision && selfFric > 0.0) contact->frictionGradientAdd(mesh.d_x.p, d_xPrev.p, fricDHat, selfFric, grad_dev);
     }
     if (!contact) return;
-    if (worldSize > 1 && contact->shardWorld > 1) {
-        // the stencils of the two lists are split over the ranks (HipContact::shardRange): this rank's share into a zeroed scratch
-        // vector, one all-reduce of the 3 nV doubles, then on top of the caller's gradient
+    if (part == 2) { // the stencils went in before the exchange: only the projected rows are left to clear
+        launch_clear_projected(mesh.nV, mesh.d_dbc.p, projectDBC ? 1 : 0, grad_dev, stream);
+        return;
+    }
+    if (ownerMode() && !lin.rowBase.empty()) {
+        // a caller outside computeGradient (initKappa's barrier-only gradient): this rank's stencils into a zeroed scratch vector, the designated entries
+        // exchanged, the sum on top of the caller's vector
+        ensureOwnerPlan();
         const size_t n3 = 3 * (size_t)mesh.nV;
         d_contactG.ensure(n3);
         d_contactG.zeroN(n3, stream);
-        contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, 0, d_contactG.p, selfCollision, selfCollision && !activeOnly);
-        reduceSum(d_contactG.p, (long long)n3);
+        contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, 0, d_contactG.p, selfCollision, selfCollision && !activeOnly, d_need.p);
+        maskAndReduceGradient(d_contactG.p);
         launch_axpy((long long)n3, 1.0, d_contactG.p, grad_dev, stream);
         launch_clear_projected(mesh.nV, mesh.d_dbc.p, projectDBC ? 1 : 0, grad_dev, stream);
         return;
@@ -749,7 +817,7 @@ void HipOptimizer::barrierGradientAdd(bool projectDBC, double kappa_, bool activ
     contact->gradientAdd(mesh.d_x.p, mesh.d_dbc.p, mesh.nV, dHat, kappa_, projectDBC, grad_dev, selfCollision, selfCollision && !activeOnly);
 }
 
-void HipOptimizer::elasticInertiaGradient(bool projectDBC)
+void HipOptimizer::elasticInertiaGradient(bool projectDBC, bool finish)
 {
     if (lin.rowBase.empty()) { // no pattern yet: tet-parallel atomic path
         launch_node_init(view(), projectDBC, rank == 0, nullptr, d_gradient.p, stream);
@@ -759,6 +827,16 @@ void HipOptimizer::elasticInertiaGradient(bool projectDBC)
         return;
     }
     ensurePatchPlan();
+    if (ownerMode()) { // this rank's patches only; the caller (computeGradient) adds its share of the barrier forces and exchanges the sum once
+        ensureOwnerPlan();
+        d_gradient.zero(stream);
+        launch_assemble_patches(view(), patch, 0, nOwnerPatches, elasticCoef(), projectDBC, d_gradient.p, nullptr, stream, d_ownerPatches.p);
+        if (finish) { // a caller that wants the elastic + inertia gradient by itself (initKappa)
+            maskAndReduceGradient(d_gradient.p);
+            neumannGradientAdd(d_gradient.p);
+        }
+        return;
+    }
     int pb, pe;
     patchShard(pb, pe);
     if (worldSize > 1) d_gradient.zero(stream);
@@ -769,7 +847,18 @@ void HipOptimizer::elasticInertiaGradient(bool projectDBC)
 
 void HipOptimizer::computeGradient(bool projectDBC)
 {
-    elasticInertiaGradient(projectDBC);
+    const bool owner = ownerMode() && !lin.rowBase.empty();
+    elasticInertiaGradient(projectDBC, !owner);
+    if (owner) {
+        // owner-computes: elastic + inertia forces of this rank's patches, its share of the self-contact stencils (those that touch a node it owns rows
+        // of), then ONE exchange in which every node is contributed by its designated rank; what is evaluated identically everywhere follows
+        if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p, 1);
+        maskAndReduceGradient(d_gradient.p);
+        neumannGradientAdd(d_gradient.p);
+        if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p, 2);
+        penaltyGradientAdd(projectDBC);
+        return;
+    }
     if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p);
     penaltyGradientAdd(projectDBC);
 }
@@ -893,6 +982,38 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
     const bool planStale = !(patchVersion == lin.patternVersion && patch.valid);
     ensurePatchPlan();
     if (planStale) lap("patch plan");
+    if (ownerMode()) {
+        // Owner-computes (round 4): this rank's patches write the complete CSR rows of the nodes it owns or shares, its share of the contact stencils adds
+        // their blocks to those rows -- and that is all its fronts ever read (an entry belongs to the front of whichever of its two nodes is eliminated
+        // first; the other node then sits in the same subtree or above the cut).  No matrix value crosses ranks.  The rows of other ranks' nodes stay zero.
+        ensureOwnerPlan();
+        lin.setZero();
+        if (withGradient) d_gradient.zero(stream);
+        launch_assemble_patches(view(), patch, 0, nOwnerPatches, elasticCoef(), projectDBC, withGradient ? d_gradient.p : nullptr, lin.d_a.p, stream,
+            d_ownerPatches.p);
+        matrixComplete = false;
+        if (ipOn() && selfCollision) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p, d_need.p);
+        if (withGradient) {
+            if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p, 1);
+            maskAndReduceGradient(d_gradient.p);
+            neumannGradientAdd(d_gradient.p);
+            if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p, 2);
+        }
+        if (ipOn()) { // evaluated alike on every rank (vertex-wise diagonal blocks / the lagged friction set): added to the rows each rank holds
+            for (auto& h : planes)
+                h->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin.d_rowBase.p, lin.d_rowLen.p, dHat, kappa, projectDBC, lin.d_a.p);
+            if (fricDHat > 0.0) {
+                for (auto& h : planes)
+                    if (h->friction > 0.0)
+                        h->frictionHessianAdd(mesh.d_x.p, d_xPrev.p, mesh.d_dbc.p, lin.d_rowBase.p, lin.d_rowLen.p, fricDHat, projectDBC, lin.d_a.p);
+                if (selfCollision && selfFric > 0.0)
+                    contact->frictionHessianAdd(mesh.d_x.p, d_xPrev.p, mesh.d_dbc.p, lin, fricDHat, selfFric, projectDBC, lin.d_a.p);
+            }
+        }
+        if (withGradient) penaltyGradientAdd(projectDBC);
+        if (!projectDBC && rhoDBC && !tpIds.empty()) launch_mdbc_hessian(mdbc(), lin.d_ia.p, rhoDBC, lin.d_a.p, stream);
+        return;
+    }
     int pb, pe;
     patchShard(pb, pe);
     if (worldSize > 1) {
@@ -901,10 +1022,10 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
     }
     launch_assemble_patches(view(), patch, pb, pe, elasticCoef(), projectDBC, withGradient ? d_gradient.p : nullptr,
         lin.d_a.p, stream);
-    // contact-pair lists sharded like the elements: this rank's share of the barrier Hessian blocks goes into the same partial matrix,
-    // so that ONE all-reduce carries the elastic and the barrier rows
-    const bool contactSharded = worldSize > 1 && ipOn() && selfCollision && contact->shardWorld > 1;
-    if (contactSharded) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
+    matrixComplete = true;
+    // (the older scheme, kept for contexts whose solver is not sharded: partial matrices summed by one all-reduce of the values; the contact stencils are
+    // then evaluated alike on every rank, after the exchange)
+    const bool contactSharded = false;
     if (worldSize > 1) {
         reduceSum(lin.d_a.p, (long long)lin.ja.size());
         if (withGradient) reduceSum(d_gradient.p, 3LL * mesh.nV);
@@ -1030,7 +1151,10 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
         ok = twoCalls ? lin.factorize() : lin.factorizeSolve(d_minusG.p, d_searchDir.p);
     }
     Tic t(timers[4], stream);
-    if (!ok) lin.precondition_diag(d_minusG.p, d_searchDir.p); // Optimizer.cpp:2331-2348
+    if (!ok) {
+        completeMatrix(); // (owner-computes sharding: the diagonal of the rows other ranks hold)
+        lin.precondition_diag(d_minusG.p, d_searchDir.p); // Optimizer.cpp:2331-2348
+    }
     else if (twoCalls) lin.solve(d_minusG.p, d_searchDir.p);
     if (fastPath()) {
         // everything the host needs next, behind the solve on the same stream, read back with ONE synchronisation (the Tic's): |p|_inf
@@ -1225,6 +1349,7 @@ void HipOptimizer::beginTimestep()
             computeGradient(true);
             computePrecondMtr(false, false);
             launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
+            completeMatrix();
             lin.precondition_diag(d_minusG.p, d_searchDir.p);
             launch_clear_projected(mesh.nV, mesh.d_dbc.p, 1, d_searchDir.p, stream); // isDBCVertex: ZERO and NONZERO alike
         }

@@ -29,6 +29,11 @@ public:
         allreduceUser_ = user;
     }
     int world() const { return world_; }
+    // per node of the CALLER's numbering: the rank whose subtree eliminates it, -1 above the cut (every rank repeats those fronts); all -1 on one rank.
+    // What the owner-computes sharding of the assembly needs: a rank assembles the CSR rows of the nodes it owns or shares.
+    void nodeOwners(std::vector<int>& ownerOfNode) const;
+    long long exchangedBytes() const { return commBytes_; } // all-reduced by the factorisations / solves so far (update matrices, update vectors, solutions, flags)
+    long long exchangeCalls() const { return commCalls_; }
     double sharedFlopFraction() const { return sharedFlops_; } // share of the factorisation flops every rank repeats
     // a_dev: CSR values (device).  Returns false when a non-positive pivot was met.
     bool factorize(const double* a_dev);
@@ -81,6 +86,7 @@ private:
     double sharedFlops_ = 0.0;
     bool flagShared_ = false; // the update exchanges carry the pivot flag
     std::vector<int> owner_; // per front: owning rank, -1 = above the cut (repeated by every rank)
+    long long commBytes_ = 0, commCalls_ = 0;
     struct Xchg {
         Range pack; // into xchgDesc_: (front, staging offset lo, hi, 0) of the subtree roots of this level
         long long count = 0; // doubles exchanged after the level's factorisation (update matrices)

@@ -2098,8 +2098,8 @@ __global__ __launch_bounds__(WGT) void k_big_bwd_tri(const int* __restrict__ lis
 }
 
 // ---- subtree-sharded factorisation: what crosses ranks -----------------------------------------------------------------------
-// desc = (front, staging offset lo, hi, mode).  The update block of a subtree root (lower triangle, (N - nc)^2 doubles in the
-// staging buffer, zeros above the diagonal) is packed by its owner, summed over the ranks (everybody else holds zeros), and
+// desc = (front, staging offset lo, hi, mode).  The update block of a subtree root (its lower triangle, packed: m (m + 1) / 2 doubles in the
+// staging buffer, m = N - nc) is packed by its owner, summed over the ranks (everybody else holds zeros), and
 // unpacked into the same front on every rank: the fronts above the cut then find their children's contributions in place.
 __global__ __launch_bounds__(256) void k_xchg_update(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts, double* __restrict__ buf,
     int unpack, int rank, const int* __restrict__ owner)
@@ -2113,8 +2113,9 @@ __global__ __launch_bounds__(256) void k_xchg_update(const int4* __restrict__ de
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)m * m; e += (long long)gridDim.x * 256) {
         const int j = (int)(e / m), i = (int)(e - (long long)j * m);
         if (i < j) continue;
-        if (unpack) F[(nc + i) + (long long)N * (nc + j)] = B[e];
-        else B[e] = F[(nc + i) + (long long)N * (nc + j)];
+        const long long t = (long long)j * m - (long long)j * (j - 1) / 2 + (i - j); // packed lower triangle, column by column (round 4: half the bytes on the wire)
+        if (unpack) F[(nc + i) + (long long)N * (nc + j)] = B[t];
+        else B[t] = F[(nc + i) + (long long)N * (nc + j)];
     }
 }
 // the same for the update vectors of the forward sweep (rows >= nc of the front's work vector)
@@ -2521,7 +2522,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 if (owner_[s] < 0 || sym.parent[s] < 0 || owner_[sym.parent[s]] >= 0) continue;
                 const long long m = sym.N(s) - sym.nc(s);
                 xd.push_back(make_int4(s, (int)(unsigned)(off & 0xffffffffLL), (int)(off >> 32), offW));
-                off += m * m;
+                off += m * (m + 1) / 2;
                 offW += (int)m;
             }
             X.pack.cnt = (int)xd.size() - X.pack.off;
@@ -2999,9 +3000,23 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     lap("uploads + attributes");
 }
 
+void MfNumeric::nodeOwners(std::vector<int>& ownerOfNode) const
+{
+    if (!sym_) throw StateError("nodeOwners before analyze_pattern");
+    const MfSymbolic& sym = *sym_;
+    ownerOfNode.assign(sym.nn, -1);
+    if (world_ <= 1) return;
+    std::vector<int> perm(sym.nn, -1); // owner per permuted node
+    for (int s = 0; s < ns_; ++s)
+        for (int v = sym.firstNode[s]; v < sym.firstNode[s + 1]; ++v) perm[v] = owner_[s];
+    for (int v = 0; v < sym.nn; ++v) ownerOfNode[v] = perm[sym.newOf[v]];
+}
+
 void MfNumeric::allreduceSum(double* dev, long long count)
 {
     if (world_ <= 1 || count <= 0) return;
+    commBytes_ += 8 * count;
+    commCalls_++;
     if (allreduceStream_) { // stream-ordered (RCCL called from C on this stream): nothing to wait for on the host
         if (allreduceStream_(allreduceUser_, dev, count, 0, (void*)stream_) != 0) throw HipError("all-reduce hook failed");
         return;

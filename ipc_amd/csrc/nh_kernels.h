@@ -87,6 +87,8 @@ struct MdbcView {
     const double* mass; // nV
 };
 void launch_clear_projected(int nV, const int* dbc, int projectDBC, double* g, hipStream_t s);
+void launch_keep_mine3(int nV, const unsigned char* mine, double* g, hipStream_t s); // owner-computes sharding: zero what other ranks contribute
+void launch_keep_mine_rows(int nRows, const unsigned char* mine, const int* ia, double* a, hipStream_t s);
 // lagged damping (Optimizer.cpp:3381-3400, 3519-3540, 3707-3709): displacement of the step (mode 0: rows of every Dirichlet node
 // cleared, 1: of the projected ones), the diagonal fix-up of the damping matrix, y += alpha x, out = scale * x . y (one workgroup)
 void launch_damp_dx(int nV, const int* dbc, int mode, int projectDBC, const double* x, const double* xPrev, double* dx, hipStream_t s);

@@ -511,6 +511,19 @@ __global__ void k_clear_projected(int nV, const int* __restrict__ dbc, int proje
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < 3 * nV && projected_dbc(dbc[i / 3], projectDBC)) g[i] = 0.0; // Optimizer.cpp:3512-3516
 }
+// owner-computes sharding: a nodal vector keeps the entries of the nodes this rank is the designated contributor of (the sum over the ranks is then the vector)
+__global__ void k_keep_mine3(int nV, const unsigned char* __restrict__ mine, double* __restrict__ g)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * nV && !mine[i / 3]) g[i] = 0.0;
+}
+// ... and the CSR values the rows of those nodes (ipcgpu_opt_complete_matrix: the rare consumers of the WHOLE matrix on a sharded context)
+__global__ void k_keep_mine_rows(int nRows, const unsigned char* __restrict__ mine, const int* __restrict__ ia, double* __restrict__ a)
+{
+    const int r = blockIdx.x;
+    if (r >= nRows || mine[r / 3]) return;
+    for (int k = ia[r] + threadIdx.x; k < ia[r + 1]; k += blockDim.x) a[k] = 0.0;
+}
 // one workgroup, fixed-order reduction: mode 0  sum -sqrt(m) lam . d + rho / 2 m |d|^2 ; mode 1  sum |d|^2   (d = x - target)
 __global__ __launch_bounds__(BLOCK) void k_mdbc_reduce(int n, const int* __restrict__ ids, const double* __restrict__ pos,
     const double* __restrict__ lam, const double* __restrict__ mass, const double* __restrict__ x, double rho, int mode, double* __restrict__ out)
@@ -730,6 +743,14 @@ void launch_axpy(long long n, double alpha, const double* x, double* y, hipStrea
 void launch_dot_scaled(int n, const double* x, const double* y, double scale, double* out, hipStream_t s)
 {
     hipLaunchKernelGGL(k_dot_scaled, dim3(1), dim3(BLOCK), 0, s, n, x, y, scale, out);
+}
+void launch_keep_mine3(int nV, const unsigned char* mine, double* g, hipStream_t s)
+{
+    if (nV) hipLaunchKernelGGL(k_keep_mine3, dim3(nblk(3LL * nV)), dim3(BLOCK), 0, s, nV, mine, g);
+}
+void launch_keep_mine_rows(int nRows, const unsigned char* mine, const int* ia, double* a, hipStream_t s)
+{
+    if (nRows) hipLaunchKernelGGL(k_keep_mine_rows, dim3(nRows), dim3(64), 0, s, nRows, mine, ia, a);
 }
 void launch_clear_projected(int nV, const int* dbc, int projectDBC, double* g, hipStream_t s)
 {

@@ -66,8 +66,9 @@ struct PatchPlan {
     size_t ldsBytes() const;
 };
 
-// grad / a may be null (Hessian-only or gradient-only).  patchBegin/End select this rank's shard of patches.
+// grad / a may be null (Hessian-only or gradient-only).  patchBegin/End select a contiguous range of patches; patchList (device, patchEnd - patchBegin
+// entries, patchBegin = 0) an arbitrary subset: the patches in which this rank owns CSR rows (owner-computes sharding, round 4).
 void launch_assemble_patches(const ElemView& v, const PatchPlan& plan, int patchBegin, int patchEnd, double coef, int projectDBC,
-    double* grad, double* a, hipStream_t s);
+    double* grad, double* a, hipStream_t s, const int* patchList = nullptr);
 
 } // namespace ipcgpu

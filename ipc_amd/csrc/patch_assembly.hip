@@ -36,13 +36,13 @@ __device__ __forceinline__ double row_shl(double x)
 #endif
 template <bool HESS, int BLOCK>
 __global__ __launch_bounds__(BLOCK) ASM_OCC void k_assemble_patch(ElemView v, PatchView pv, int patchBegin, int tcap, int ncap, double coef,
-    int projectDBC, double* __restrict__ grad, double* __restrict__ a, int probe)
+    int projectDBC, double* __restrict__ grad, double* __restrict__ a, int probe, const int* __restrict__ patchList)
 {
     extern __shared__ __align__(16) double lds[];
     double* stage = lds; // [tcap][NF]: phase 2 reads a record with 128-bit LDS loads, the two beta rows by dynamic offset
     double* gacc = lds + (size_t)NF * tcap; // [3 * ncap]
     // record slot 36 (as int): projection mask (bit k: node k projected, bit 4: active)
-    const int p = patchBegin + blockIdx.x;
+    const int p = patchList ? patchList[blockIdx.x] : patchBegin + blockIdx.x; // a list: the patches this rank owns rows in (owner-computes sharding)
     const int n0 = pv.nodePtr[p], nOwned = pv.nodePtr[p + 1] - n0;
     const int t0 = pv.tetPtr[p], nTets = pv.tetPtr[p + 1] - t0;
     const int tid = threadIdx.x;
@@ -494,9 +494,9 @@ size_t PatchPlan::ldsBytes() const
 }
 
 void launch_assemble_patches(const ElemView& v, const PatchPlan& plan, int patchBegin, int patchEnd, double coef, int projectDBC,
-    double* grad, double* a, hipStream_t s)
+    double* grad, double* a, hipStream_t s, const int* patchList)
 {
-    const int n = patchEnd - patchBegin;
+    const int n = patchEnd - patchBegin; // with a list: its length (patchBegin = 0)
     if (n <= 0) return;
     const size_t lds = plan.ldsBytes();
     const int tcap = (plan.maxTets + 63) / 64 * 64;
@@ -517,15 +517,15 @@ void launch_assemble_patches(const ElemView& v, const PatchPlan& plan, int patch
     static const int probe = std::getenv("IPCGPU_ASM_PROBE") ? std::atoi(std::getenv("IPCGPU_ASM_PROBE")) : 0; // profiling only
     if (wide) {
         if (a)
-            hipLaunchKernelGGL((k_assemble_patch<true, 512>), dim3(n), dim3(512), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+            hipLaunchKernelGGL((k_assemble_patch<true, 512>), dim3(n), dim3(512), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe, patchList);
         else
-            hipLaunchKernelGGL((k_assemble_patch<false, 512>), dim3(n), dim3(512), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+            hipLaunchKernelGGL((k_assemble_patch<false, 512>), dim3(n), dim3(512), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe, patchList);
     }
     else {
         if (a)
-            hipLaunchKernelGGL((k_assemble_patch<true, 256>), dim3(n), dim3(256), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+            hipLaunchKernelGGL((k_assemble_patch<true, 256>), dim3(n), dim3(256), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe, patchList);
         else
-            hipLaunchKernelGGL((k_assemble_patch<false, 256>), dim3(n), dim3(256), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe);
+            hipLaunchKernelGGL((k_assemble_patch<false, 256>), dim3(n), dim3(256), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe, patchList);
     }
 }
 

@@ -185,6 +185,15 @@ class Context:
         self._chk(self._L.ipcgpu_linsys_shard_stats(self.h, _dp(o)))
         return dict(world=int(o[0]), shared_flop_fraction=float(o[1]))
 
+    def comm_stats(self):
+        """what crossed ranks so far (bytes, calls) through the time stepper's and through the solver's all-reduces; nodes whose rows this rank assembles"""
+        o = np.zeros(6)
+        self._chk(self._L.ipcgpu_opt_comm_stats(self.h, _dp(o)))
+        return dict(stepper_bytes=int(o[0]), stepper_calls=int(o[1]), solver_bytes=int(o[2]), solver_calls=int(o[3]), rows_assembled_nodes=int(o[4]), nodes=int(o[5]))
+
+    def complete_matrix(self):
+        self._chk(self._L.ipcgpu_opt_complete_matrix(self.h))
+
     # ---- RCCL from C (include/ipcgpu_rccl.h): every exchange is then one ncclAllReduce on the context's own stream
     @staticmethod
     def rccl_unique_id():

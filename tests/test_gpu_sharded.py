@@ -38,13 +38,13 @@ if world > 1:
         t.copy_(h)
         torch.cuda.synchronize()
         return 0
-    if mode in ("assembly", "contact_sharded"):
-        c.set_shard(rank, world)  # patches AND contact-pair lists sharded, gradient / CSR values / scalars all-reduced
+    if mode in ("assembly", "contact_sharded", "owner", "capi_contact"):
+        c.set_shard(rank, world)  # the assembly sharded: with the solver sharded as well, owner-computes rows (no matrix value crosses ranks)
     c.set_allreduce(hook)
     if mode != "assembly":
-        c.set_solver_shard(rank, world)  # subtree-sharded factorisation and solves, everything else replicated
+        c.set_solver_shard(rank, world)  # subtree-sharded factorisation and solves
 extra = {}
-if mode in ("assembly", "solver"):
+if mode in ("assembly", "solver", "owner"):
     n = 12 if mode == "assembly" else 40
     V, F = scene.make_bar(12, 2, 2, size=(5.0, 0.5, 1.0)) if mode == "assembly" else scene.make_mat(n)
     left, right = scene.border_verts(V, 0.01)
@@ -92,6 +92,18 @@ else:  # contact: two slabs, the upper one dropped on the clamped lower one (pat
     c.set_velocity(vel)
     c.precompute()
     steps, cap = 4, 60
+    if mode == "capi_contact":
+        # the direct C entry points on a sharded context: the WHOLE barrier gradient / Hessian blocks, not a rank's share (ADVICE round 3)
+        for step in range(3):
+            c.solve_timestep(cap)
+        extra["nActive0"] = c.contact_state()["nActive"]
+        st0 = c.state()
+        dHat, kappa = st0["dHat"], st0["kappa"]
+        extra["cg"] = c.contact_gradient_add(dHat, kappa, True)
+        c.set_zero()
+        c.contact_hessian_add(dHat, kappa, True)
+        extra["ca"] = c.get_a()
+        steps = 0
 iters = []
 for step in range(steps):
     iters.append(c.solve_timestep(cap))
@@ -99,6 +111,9 @@ s = c.state()
 if mode.startswith("contact"):
     extra["nActive"] = c.contact_state()["nActive"]
     extra["nPatternChanges"] = c.contact_state()["nPatternChanges"]
+cm = c.comm_stats()
+rows, nnz = c.get_dims()
+extra.update(stepper_bytes=cm["stepper_bytes"], solver_bytes=cm["solver_bytes"], rows_nodes=cm["rows_assembled_nodes"], nodes=cm["nodes"], nnz=nnz)
 if rank == 0:
     np.savez(os.environ["OUT"], V=s["V"], E=s["E"], g=s["gradient"], iters=np.array(iters), **extra)
 c.close()
@@ -171,10 +186,10 @@ def test_two_ranks_with_contact_reproduce_the_single_rank_trajectory():
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_contact_pair_lists_sharded_reproduce_the_single_rank_trajectory(world):
-    """ipcgpu_ctx_set_shard with self-contact: the elements AND the contact-pair lists are split over the ranks -- rank r evaluates the
-    barrier energy / forces / Hessian blocks of its share of the active and of the mollified list, the blocks ride in the same all-reduce
-    as the elastic rows -- on top of the subtree-sharded solver.  Same sets, same Newton counts, positions to the round-off of a
-    different summation order."""
+    """ipcgpu_ctx_set_shard with self-contact on top of the subtree-sharded solver: the elements AND the contact-pair lists are split over the
+    ranks by row ownership -- a rank evaluates the stencils that touch a node whose rows it holds (stencils on a cut by both sides) and adds
+    their blocks to those rows; the barrier energy is split by index and summed as a scalar.  Same sets, same Newton counts, positions to
+    the round-off of a different summation order."""
     with tempfile.TemporaryDirectory() as d:
         one, many = os.path.join(d, "one.npz"), os.path.join(d, "many.npz")
         run(1, one, "contact_sharded")
@@ -183,6 +198,47 @@ def test_contact_pair_lists_sharded_reproduce_the_single_rank_trajectory(world):
         assert int(a["nActive"]) > 0 and int(a["nActive"]) == int(b["nActive"])
         assert np.array_equal(a["iters"], b["iters"])
         assert np.abs(a["V"] - b["V"]).max() <= 1e-9 * np.abs(a["V"]).max()
+        # owner-computes (round 4): the barrier blocks are added to the rows a rank holds, nothing of the matrix is exchanged -- per Newton iteration
+        # the time stepper moves nodal vectors and scalars only
+        its = int(b["iters"].sum())
+        assert float(b["stepper_bytes"]) / max(its, 1) <= 0.5 * 8 * float(b["nnz"]), (float(b["stepper_bytes"]) / its, 8 * float(b["nnz"]))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_owner_computes_rows_no_matrix_value_crosses_ranks(world):
+    """Round 4, SURVEY.md 8e as the north star states it: with the assembly and the solver sharded, a rank assembles exactly the CSR rows its
+    fronts read (its subtrees' nodes + the separator rows above the cut) and NO matrix value crosses ranks.  Same Newton counts and positions
+    as the single-rank run; what the time stepper all-reduces per Newton iteration is a few nodal vectors and scalars -- far less than one
+    copy of the CSR values, which the older scheme summed every iteration -- and every rank assembles only part of the rows."""
+    with tempfile.TemporaryDirectory() as d:
+        one, many = os.path.join(d, "one.npz"), os.path.join(d, "many.npz")
+        run(1, one, "owner")
+        run(world, many, "owner")
+        a, b = np.load(one), np.load(many)
+        assert np.array_equal(a["iters"], b["iters"])
+        assert np.abs(a["V"] - b["V"]).max() <= 1e-11 * np.abs(a["V"]).max()
+        assert abs(a["E"] - b["E"]) <= 1e-11 * abs(a["E"])
+        its = int(b["iters"].sum())
+        per_iter = float(b["stepper_bytes"]) / max(its, 1)
+        nodal = 3 * 8 * float(b["nodes"])
+        assert per_iter <= 6 * nodal + 4096, (per_iter, nodal)  # gradient (+ the line search's scalars): a handful of nodal vectors, never the matrix
+        assert per_iter <= 0.25 * 8 * float(b["nnz"]), (per_iter, 8 * float(b["nnz"]))
+        assert 0 < int(b["rows_nodes"]) < int(b["nodes"])  # rank 0 holds its subtrees' rows and the shared separator rows, not all of them
+        assert int(a["stepper_bytes"]) == 0 and int(a["solver_bytes"]) == 0
+
+
+def test_contact_entry_points_return_whole_sums_on_a_sharded_context():
+    """ipcgpu_contact_gradient_add / ipcgpu_contact_hessian_add called directly on a context that is sharded over two ranks return the whole
+    barrier gradient and all Hessian blocks -- which stencils a rank evaluates is the time stepper's owner-computes plan, never an index range
+    hidden in the handler (round 3 returned a rank's share there without saying so)."""
+    with tempfile.TemporaryDirectory() as d:
+        one, two = os.path.join(d, "one.npz"), os.path.join(d, "two.npz")
+        run(1, one, "capi_contact")
+        run(2, two, "capi_contact")
+        a, b = np.load(one), np.load(two)
+        assert int(a["nActive0"]) > 0 and int(a["nActive0"]) == int(b["nActive0"])
+        assert np.abs(a["cg"] - b["cg"]).max() <= 1e-9 * np.abs(a["cg"]).max()
+        assert np.abs(a["ca"] - b["ca"]).max() <= 1e-9 * np.abs(a["ca"]).max()
 
 
 @pytest.mark.gpu
