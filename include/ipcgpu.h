@@ -279,6 +279,10 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx*, double selfFric, int fricIterAmt, doubl
    time step at eps_v (fifth entry) and is halved down -- or clamped up -- to eps_v_target between the friction-lag passes (:1776-1781); the
    tangent-space convergence test runs only once it has arrived (:1717).  <= 0: the target is eps_v itself (what the `epsv` keyword sets). */
 int ipcgpu_opt_set_friction_target(ipcgpu_ctx*, double eps_v_target);
+/* The step size h inside eps_v^2 h^2 (fricDHat0 / fricDHatTarget) and CN_MBC.  In the reference these are evaluated in the Optimizer constructor right after its
+   setTime(10.0, 0.025) (Optimizer.cpp:116, 268, 290-303) and never again when main.cpp:1398 sets the scene's dt: they carry h = 0.025 whatever `time` says.  That
+   is the default here; pass the scene's dt for the paper's semantics.  Call before ipcgpu_opt_init / ipcgpu_opt_precompute. */
+int ipcgpu_opt_set_constructor_dt(ipcgpu_ctx*, double h);
 /* The three remaining knobs of the scene file behind the interior-point lengths (Config.cpp:553-558, Config.hpp:138-139):
  *   useAbsParameters   dHat, its homotopy target, dTol, eps_v (and its target) and the Newton tolerance are ABSOLUTE lengths instead of fractions
  *                      of the rest-shape bounding-box diagonal (Optimizer.cpp:107-109, 279-302, 1535-1537, 2941-2945); suggestKappa's

@@ -25,7 +25,9 @@ extern "C" {
 int ipcgpu_rccl_unique_id(void* id128);
 /* all ranks (collective): communicator on the context's device, all-reduce hook installed */
 int ipcgpu_rccl_attach(ipcgpu_ctx* ctx, int rank, int world, const void* id128);
-/* destroys the communicator and removes the hook */
+/* destroys the communicator and removes the hook (the context and its solver stop using it at once: a host hook set with
+ * ipcgpu_opt_set_allreduce before the attach is in charge again).  Call it BEFORE ipcgpu_ctx_destroy: the binding lives on the caller's side and the
+ * library does not know about it. */
 int ipcgpu_rccl_detach(ipcgpu_ctx* ctx);
 /* all-reduces `count` doubles of a scratch device buffer filled with (rank + 1) through the installed hook and returns element 0:
  * world * (world + 1) / 2 for op 0 (sum), 1 for op 1 (min).  A smoke test of the binding. */

@@ -601,7 +601,7 @@ int ipcgpu_linsys_set_shard(ipcgpu_ctx* c, int rank, int world)
     return guarded([&] {
         needArg(c && world >= 1 && rank >= 0 && rank < world, "bad shard");
         need(world == 1 || c->opt->allreduce != nullptr || c->opt->allreduceStream != nullptr, "set the all-reduce hook first (ipcgpu_opt_set_allreduce)");
-        c->lin->setShard(rank, world, c->opt->allreduce, c->opt->allreduceUser, c->opt->allreduceStream);
+        c->lin->setShard(rank, world, c->opt->allreduce, c->opt->allreduceUser, c->opt->allreduceStream, c->opt->allreduceStreamUser);
         return IPCGPU_OK;
     });
 }
@@ -1079,6 +1079,14 @@ int ipcgpu_opt_set_friction_target(ipcgpu_ctx* c, double epsVTarget)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_constructor_dt(ipcgpu_ctx* c, double h)
+{
+    return guarded([&] {
+        needArg(h > 0.0, "the step size must be positive");
+        O(c).ctorDt = h;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_set_parameter_scaling(ipcgpu_ctx* c, int useAbsParameters, double dTolRel, double kappaMinMultiplier)
 {
     return guarded([&] {
@@ -1474,6 +1482,8 @@ int ipcgpu_opt_set_allreduce(ipcgpu_ctx* c, ipcgpu_allreduce_fn fn, void* user)
         needArg(c != nullptr, "null context");
         c->opt->allreduce = fn;
         c->opt->allreduceUser = user;
+        // a solver that was sharded before keeps copies of the hooks: refresh them (no new analysis)
+        c->lin->setHooks(c->opt->allreduce, c->opt->allreduceUser, c->opt->allreduceStream, c->opt->allreduceStreamUser);
         return IPCGPU_OK;
     });
 }
@@ -1483,7 +1493,8 @@ int ipcgpu_opt_set_allreduce_stream(ipcgpu_ctx* c, ipcgpu_allreduce_stream_fn fn
     return guarded([&] {
         needArg(c != nullptr, "null context");
         c->opt->allreduceStream = fn;
-        c->opt->allreduceUser = user;
+        c->opt->allreduceStreamUser = user; // its own slot: a host hook set earlier keeps its user pointer; detaching (fn = NULL) leaves that hook in charge
+        c->lin->setHooks(c->opt->allreduce, c->opt->allreduceUser, c->opt->allreduceStream, c->opt->allreduceStreamUser);
         return IPCGPU_OK;
     });
 }

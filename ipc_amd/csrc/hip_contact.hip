@@ -1,4 +1,5 @@
 // Contact kernels + HipContact host logic (gfx950).  Compiled with -ffp-contract=off (exact-comparison typing).
+#include <climits>
 #include "hip_contact.h"
 #include "contact_device.h"
 #include "jacobi9_device.h"
@@ -17,6 +18,14 @@ namespace {
 
 using namespace cdev;
 constexpr int BLOCK = 256;
+
+// bit width of (largest real key + 1): see HipContact::detSort
+static int keyBitsFor(size_t nKeys)
+{
+    int b = 1;
+    while (b < 32 && ((size_t)1 << b) <= nKeys) ++b; // 2^b - 1 >= nKeys > every real key
+    return b;
+}
 
 struct ContactView {
     int nA, nP;
@@ -2288,7 +2297,7 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
         else {
             detBegin(8 * (size_t)n, 3, false);
             hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ nullptr, detVals_.p, detKey_.p });
-            detReduce3(8 * (size_t)n, 32, grad_dev);
+            detReduce3(8 * (size_t)n, keyBitsFor((size_t)nV), grad_dev);
         }
     }
     hipLaunchKernelGGL(k_zero_projected, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, projectDBC, grad_dev);
@@ -2315,7 +2324,7 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     else {
         detBegin(16 * (size_t)n, 9, true);
         launch(BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p });
-        detReduceBlocks(16 * (size_t)n, 32, lin.d_ia.p, a_dev);
+        detReduceBlocks(16 * (size_t)n, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
     }
     int err[2];
     counters_.download(err, 2, stream);
@@ -2397,12 +2406,15 @@ void HipContact::detBegin(size_t nSlots, int valsPerSlot, bool withRow)
 }
 void HipContact::detSort(size_t nSlots, int keyBits)
 {
-    // unused slots carry KEY_NONE = all ones: they must sort behind every real key, so the top bit takes part
-    (void)keyBits;
+    // Only the significant bits are sorted (round 4): keyBits = bit width of (largest real key + 1), so that no real key has all of them set; unused
+    // slots carry KEY_NONE = all ones and still sort behind every real key.  A node id has 16-19 bits, a CSR position 22-25: two or three digit passes of the
+    // radix sort instead of four.
+    if (nSlots > (size_t)INT_MAX) throw StateError("too many contact contributions for one scatter pass");
+    const int bits = std::max(1, std::min(32, keyBits));
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, 32, stream);
+    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, bits, stream);
     if (scanTmp_.n < bytes) scanTmp_.alloc(bytes + bytes / 4);
-    hipcub::DeviceRadixSort::SortPairs((void*)scanTmp_.p, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, 32, stream);
+    hipcub::DeviceRadixSort::SortPairs((void*)scanTmp_.p, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, bits, stream);
 }
 void HipContact::detReduce3(size_t nSlots, int keyBits, double* grad_dev)
 {
@@ -2445,7 +2457,7 @@ void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, c
         detBegin(16 * (size_t)n, 9, true);
         hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
             BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p }, counters_.p);
-        detReduceBlocks(16 * (size_t)n, 32, lin.d_ia.p, a_dev);
+        detReduceBlocks(16 * (size_t)n, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
     }
     int err[2];
     counters_.download(err, 2, stream);

@@ -91,11 +91,12 @@ public:
     int getNumNonzeros() const { return (int)ja.size(); }
     const MfSymbolic& symbolic() const { return sym_; }
     // subtree-sharded factorisation / solves over `world` ranks (MfNumeric::setShard); takes effect at the next analyze_pattern
-    void setShard(int rank, int world, ipcgpu_allreduce_fn_t fn, void* user, ipcgpu_allreduce_stream_fn_t sfn = nullptr)
+    void setShard(int rank, int world, ipcgpu_allreduce_fn_t fn, void* user, ipcgpu_allreduce_stream_fn_t sfn = nullptr, void* streamUser = nullptr)
     {
-        num_.setShard(rank, world, fn, user, sfn);
+        num_.setShard(rank, world, fn, user, sfn, streamUser);
         analyzed_ = false;
     }
+    void setHooks(ipcgpu_allreduce_fn_t fn, void* user, ipcgpu_allreduce_stream_fn_t sfn, void* streamUser) { num_.setHooks(fn, user, sfn, streamUser); }
     int solverWorld() const { return num_.world(); }
     void nodeOwners(std::vector<int>& o) const { num_.nodeOwners(o); }
     long long exchangedBytes() const { return num_.exchangedBytes(); }
@@ -133,6 +134,7 @@ public:
     // lagged stiffness-proportional damping (Optimizer.cpp:3381-3400, 3519-3540, 3707-3709, 3723-3735; Config.cpp:141-157, 614-616):
     // D = projected elastic Hessian at the state the last time step ended in, times dampingStiff / dt, on the solver's pattern
     double dampingStiff = 0.0;
+    double ctorDt = 0.025; // the step size inside eps_v^2 h^2 and CN_MBC: the reference's constructor leaves its setTime(10, 0.025) in them (hip_optimizer.cpp, top)
     double dHatTargetEps = -1.0; // tuning[2] (Optimizer.cpp:283-289): every time step starts at dHat and halves it down to this; < 0: no homotopy
     double kappaConfig = 0.0; // tuning[0] (Config.cpp:41-45): the barrier stiffness a time step starts from, 0 = suggestKappa
     void setDamping(double stiff);
@@ -241,6 +243,7 @@ public:
     void resolveEventTimers();
     DevBuf<double> d_contactG; // this rank's share of the barrier forces before their all-reduce (contact-pair lists sharded)
     void* allreduceUser = nullptr;
+    void* allreduceStreamUser = nullptr; // separate slots: the two hooks can be set in any order
     void reduceSum(double* dev, long long n);
     void reduceMin(double* dev, long long n);
     double readScalar(const double* dev);

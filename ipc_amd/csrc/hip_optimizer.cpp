@@ -24,7 +24,8 @@ namespace ipcgpu {
 // and CN_MBC (:268) from THAT step size; main.cpp:1398 sets the scene's dt afterwards and setTime (:421-429) recomputes neither.  So in the reference
 // these three carry h = 0.025 whatever `time` the scene file gives -- found on otherExamples/typical/sphere1K_DCORotCylinders.txt (dt 0.04, selfFric 0.5:
 // 47 Newton iterations in the step after the first contact, 20 with eps_v scaled by the scene's own dt; same counts once this is followed).
-static constexpr double kCtorDtSq = 0.025 * 0.025;
+// The value is an optimizer parameter since round 4 (HipOptimizer::ctorDt, ipcgpu_opt_set_constructor_dt): 0.025 = the reference's behaviour is the default,
+// the scene's own dt gives the paper's eps_v h.
 
 namespace {
 struct Tic {
@@ -108,7 +109,7 @@ void HipOptimizer::setRelGL2Tol(double relTol)
 {
     relGL2Tol = relTol * relTol;
     targetGRes = std::sqrt(relGL2Tol * (absParameters ? 1.0 : mesh.bboxDiag2 * dtSq)); // Optimizer.cpp:2941-2945
-    CN_MBC = std::sqrt(1.0e-4 * mesh.bboxDiag2 * kCtorDtSq); // Optimizer.cpp:268 -- evaluated in the constructor, see kCtorDtSq
+    CN_MBC = std::sqrt(1.0e-4 * mesh.bboxDiag2 * (ctorDt * ctorDt)); // Optimizer.cpp:268 -- evaluated in the constructor, see (ctorDt * ctorDt)
 }
 
 void HipOptimizer::setParameterScaling(bool absolute, double dTolRel_, double kappaMinMultiplier_)
@@ -273,7 +274,7 @@ void HipOptimizer::hookReduce(double* dev, long long n, int op)
     commBytes += 8 * n;
     commCalls++;
     if (allreduceStream) { // RCCL from C, ordered on our stream
-        if (allreduceStream(allreduceUser, dev, n, op, (void*)stream) != 0) throw HipError("all-reduce hook failed");
+        if (allreduceStream(allreduceStreamUser, dev, n, op, (void*)stream) != 0) throw HipError("all-reduce hook failed");
         return;
     }
     if (!allreduce) throw StateError("sharded context without an all-reduce hook");
@@ -1391,8 +1392,8 @@ void HipOptimizer::beginTimestep()
         // friction: lagged sets reset, eps_v^2 h^2 (Optimizer.cpp:1525-1533, 286-304), then lagged at x^n (:1553-1600)
         if (contact) contact->frictionLagClear();
         for (auto& h : planes) h->lagClear();
-        fricDHat0 = epsV * epsV * kCtorDtSq * lenScale2(); // Optimizer.cpp:290-303: set once in the constructor, see kCtorDtSq
-        fricDHatTarget = epsVTarget > 0.0 ? epsVTarget * epsVTarget * kCtorDtSq * lenScale2() : fricDHat0;
+        fricDHat0 = epsV * epsV * (ctorDt * ctorDt) * lenScale2(); // Optimizer.cpp:290-303: set once in the constructor, see (ctorDt * ctorDt)
+        fricDHatTarget = epsVTarget > 0.0 ? epsVTarget * epsVTarget * (ctorDt * ctorDt) * lenScale2() : fricDHat0;
         fricDHat = solveFric() ? fricDHat0 : -1.0;
         fricIterI = 0;
         updateFrictionLag();

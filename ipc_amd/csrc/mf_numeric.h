@@ -20,13 +20,19 @@ public:
     typedef int (*AllreduceFn)(void* user, void* buf_dev, long long count, int op);
     // stream-ordered variant (ipcgpu_opt_set_allreduce_stream): enqueued on the solver's stream, no host synchronisation around it
     typedef int (*AllreduceStreamFn)(void* user, void* buf_dev, long long count, int op, void* hipStream);
-    void setShard(int rank, int world, AllreduceFn fn, void* user, AllreduceStreamFn sfn = nullptr)
+    void setShard(int rank, int world, AllreduceFn fn, void* user, AllreduceStreamFn sfn = nullptr, void* streamUser = nullptr)
     {
         rank_ = rank;
         world_ = world;
+        setHooks(fn, user, sfn, streamUser);
+    }
+    // the hooks alone (the caller attached or detached a communicator after the solver was sharded): nothing to re-analyse
+    void setHooks(AllreduceFn fn, void* user, AllreduceStreamFn sfn, void* streamUser)
+    {
         allreduce_ = fn;
-        allreduceStream_ = sfn;
         allreduceUser_ = user;
+        allreduceStream_ = sfn;
+        allreduceStreamUser_ = streamUser;
     }
     int world() const { return world_; }
     // per node of the CALLER's numbering: the rank whose subtree eliminates it, -1 above the cut (every rank repeats those fronts); all -1 on one rank.
@@ -83,6 +89,7 @@ private:
     AllreduceFn allreduce_ = nullptr;
     AllreduceStreamFn allreduceStream_ = nullptr;
     void* allreduceUser_ = nullptr;
+    void* allreduceStreamUser_ = nullptr; // its own slot: attaching RCCL after a host hook must not replace that hook's user pointer
     double sharedFlops_ = 0.0;
     bool flagShared_ = false; // the update exchanges carry the pivot flag
     std::vector<int> owner_; // per front: owning rank, -1 = above the cut (repeated by every rank)

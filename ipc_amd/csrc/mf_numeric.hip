@@ -3018,7 +3018,7 @@ void MfNumeric::allreduceSum(double* dev, long long count)
     commBytes_ += 8 * count;
     commCalls_++;
     if (allreduceStream_) { // stream-ordered (RCCL called from C on this stream): nothing to wait for on the host
-        if (allreduceStream_(allreduceUser_, dev, count, 0, (void*)stream_) != 0) throw HipError("all-reduce hook failed");
+        if (allreduceStream_(allreduceStreamUser_, dev, count, 0, (void*)stream_) != 0) throw HipError("all-reduce hook failed");
         return;
     }
     if (!allreduce_) throw StateError("sharded solver without an all-reduce hook (ipcgpu_opt_set_allreduce)");

@@ -588,6 +588,10 @@ class Context:
         """eps_v homotopy target (`tuning`'s sixth entry); <= 0: the same as eps_v"""
         self._chk(self._L.ipcgpu_opt_set_friction_target(self.h, C.c_double(eps_v_target)))
 
+    def set_constructor_dt(self, h):
+        """the step size inside eps_v^2 h^2 and CN_MBC (0.025 in the reference whatever the scene's dt: Optimizer.cpp:116, 268, 290-303)"""
+        self._chk(self._L.ipcgpu_opt_set_constructor_dt(self.h, C.c_double(h)))
+
     def set_parameter_scaling(self, use_abs_parameters=False, dtol_rel=1e-9, kappa_min_multiplier=1e11):
         """`useAbsParameters`, tuning[3] and `kappaMinMultiplier` of the scene file (Config.cpp:553-558)"""
         self._chk(self._L.ipcgpu_opt_set_parameter_scaling(self.h, C.c_int(int(use_abs_parameters)), C.c_double(dtol_rel),
