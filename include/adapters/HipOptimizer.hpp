@@ -16,8 +16,11 @@
 //       HipLinSysSolver on the same context (values in HBM).  Contact terms, CCD and the scripts run as the reference's host
 //       code.  This is the A/B configuration inside one binary, and it supports every script / collision object the reference has.
 //
-// Scripts (AnimScripter.hpp:22-95) that run resident: null (Dirichlet / Neumann groups, scripted component velocities), twist,
-// fall, fallNoShift, dragright, DCOFix.  Any other one falls back to percall with a note on stderr.
+// Scripts (AnimScripter.hpp:22-95) that run resident are the ones residentScript() below accepts: null (Dirichlet / Neumann groups, scripted component
+// velocities), twist, fall, fallNoShift, dragright, DCOFix, stretchAndPause, DCOSquash, DCOSquash6, DCORotCylinders, DCOVerschoorRoller, DCOSqueezeOut, the
+// handle sets that are held for good (staticScript) and the ones pulled at a constant velocity (pulledScript).  Any other one falls back to percall with a note
+// on stderr.  Not reproduced in resident mode (side effects of Optimizer::solve, Optimizer.cpp:517-530): the pre-step inversion check that ends the process,
+// and saveBCNodes.
 // Needs: the reference's Optimizer.hpp, include/ipcgpu.h, -lipcgpu.
 #pragma once
 #include "Optimizer.hpp"

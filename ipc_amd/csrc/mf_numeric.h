@@ -51,7 +51,8 @@ public:
     // lastPivotsOk() after the caller's own synchronisation of the stream).  Returns false when the call had to take the synchronous
     // two-call sequence (sharded / graph runs) and the factorisation failed there.
     bool factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev, bool wait = true);
-    bool lastPivotsOk() const { return hflag_.p[0] == 0; }
+    bool lastPivotsOk() const { return pivotsOk(); }
+    bool pivotsOk() const; // false: a non-positive pivot; throws when a merged step launch timed out (flag bit 2)
     bool ready() const { return ns_ > 0; }
     size_t front_bytes() const { return fronts_.n * sizeof(double); }
 
@@ -125,6 +126,10 @@ private:
     Range plainBlocks_; // diagonal blocks of all other fronts (inverted at the end of the factorisation)
     DevBuf<int> invBlockList_;
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
+    // consecutive step launches of a level merged into one, later steps waiting on in-launch counters (k_big_step, StepGroup): IPCGPU_MF_STEP_MERGE = steps per
+    // launch (1 = one launch per step, as before round 4), IPCGPU_MF_STEP_MERGE_WGS = workgroups per launch at most
+    int stepMerge_ = 1, stepMergeWgs_ = 1536, stepProbe_ = 0; // OFF by default: measured slower than the launches it replaces (profiles/r04_merged_step_launches_ab.txt)
+    DevBuf<int> stepCtr_;
     int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)
     bool fwdRootOnMain_ = true, fwdJoined_ = false; // the root's forward sweep on the main stream (IPCGPU_MF_FWD_ROOT_ON_MAIN=0: on the forward stream like the other levels)
     int schurFold_ = 0, schurFoldMinSteps_ = 8; // off by default: measured neutral at mat150 (382.4 it/s with passes of 4 panels, 384.1 without) and a loss where the update matrices are large

@@ -1465,14 +1465,12 @@ __device__ __forceinline__ void step_border(const int4 d, const int4 d2, const T
 //            d = (cLo, cHi, ti | tj << 16, b).  (64 x 64 tiles in here cost the whole kernel 198 registers and were slower anyway: short sums.)
 // (a separate instance: the extra roles would cost the trailing tiles of the middle levels registers they do not need)
 template <bool TOP>
-__global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
-    double* __restrict__ dinv, int* __restrict__ flag, XinvView xv)
+__device__ __forceinline__ void step_work(const int wg, const int4 d, const int4 d2, const TreeView& tv, double* __restrict__ fronts,
+    double* __restrict__ dinv, int* __restrict__ flag, const XinvView& xv)
 {
     __shared__ double sm[2 * NB * TS];
-    // two records per workgroup, both addressed by blockIdx alone: (first dinv block, kb, a, b) and (N, nc, front offset) -- the front's
+    // two records per workgroup, both addressed by the workgroup index alone: (first dinv block, kb, a, b) and (N, nc, front offset) -- the front's
     // dimensions used to be two more dependent loads (tree arrays indexed by the front) at the head of every step
-    const int4 d = desc[2 * blockIdx.x];
-    const int4 d2 = desc[2 * blockIdx.x + 1];
     const int N = d2.x, nc = d2.y;
     double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
     const int tid = threadIdx.x;
@@ -1554,7 +1552,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     long long tphase_ = clock64();
 #define MF_STEP_PHASE(i)                                                                                          \
     do {                                                                                                          \
-        if (d.z == 0 && (threadIdx.x == 64 * ((3 + (int)blockIdx.x) & 3))) {                                           \
+        if (d.z == 0 && (threadIdx.x == 64 * ((3 + wg) & 3))) {                                                        \
             const long long t_ = clock64();                                                                       \
             atomicAdd(&mf_phase_acc[i], (unsigned long long)(t_ - tphase_));                                      \
             tphase_ = t_;                                                                                         \
@@ -1617,7 +1615,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 #ifdef MF_NO_PIVOT_ROT
     const int wv = tid >> 6;
 #else
-    const int wv = ((tid >> 6) - (int)blockIdx.x) & 3; // 0..2: row waves, 3: pivot wave
+    const int wv = ((tid >> 6) - wg) & 3; // 0..2: row waves, 3: pivot wave
 #endif
     const int l = tid & 63, lo = l & 15, hi = l >> 4;
     const int Rw = kb1 + d.z + 16 * MT_B * wv; // first row of this wave
@@ -1720,8 +1718,64 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 #ifdef MF_PHASE_TIMERS
     __syncthreads();
     MF_STEP_PHASE(14);
-    if (d.z == 0 && threadIdx.x == 64 * ((3 + (int)blockIdx.x) & 3)) atomicAdd(&mf_phase_acc[15], 1ull);
+    if (d.z == 0 && threadIdx.x == 64 * ((3 + wg) & 3)) atomicAdd(&mf_phase_acc[15], 1ull);
 #endif
+}
+
+// SEVERAL consecutive step launches as ONE launch (round 4).  A dependent launch costs 3.4 us on this runtime (profiles/r04_sync_primitives.txt), a step itself
+// 6: the workgroups of the steps [0, sg.n) are laid out step after step in one grid; a workgroup of step g > 0 waits -- one lane polling a counter in global
+// memory -- until every workgroup of step g - 1 has checked out, then runs exactly the code it would have run in its own launch.  Release / acquire at agent
+// scope on both sides (the L2s of the eight XCDs are not coherent with each other: the same write-back / invalidate a kernel boundary performs).
+// Why this cannot hang: workgroups are dispatched in the order of their index (per XCD as well: a later workgroup never gets a slot an earlier one is
+// waiting for), so whatever a workgroup waits for is already running or finished; spinning workgroups only hold their own slots.  And every poll loop gives
+// up after ~1 s (flag bit 2 -> MfNumeric throws instead of returning garbage).
+constexpr int STEP_GROUP_MAX = 16;
+struct StepGroup {
+    int n; // steps in this launch
+    int end[STEP_GROUP_MAX]; // end[g] = first workgroup behind step g
+    int* ctr; // ctr[g]: workgroups of step g that have finished (zeroed at the start of the factorisation)
+    int probe; // timing experiments only (IPCGPU_MF_STEP_PROBE): bit 0 no release fences, bit 1 no acquire fences, bit 2 fences by one wave only
+};
+template <bool TOP>
+__global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
+    double* __restrict__ dinv, int* __restrict__ flag, XinvView xv, StepGroup sg)
+{
+    const int wg = blockIdx.x;
+    const int4 d = desc[2 * wg]; // requested before the wait: the records do not depend on the step before
+    const int4 d2 = desc[2 * wg + 1];
+    int g = 0;
+#pragma unroll
+    for (int q = 0; q < STEP_GROUP_MAX - 1; ++q)
+        if (q + 1 < sg.n && wg >= sg.end[q]) g = q + 1;
+    if (g > 0) {
+        if (threadIdx.x == 0) {
+            const int need = sg.end[g - 1] - (g > 1 ? sg.end[g - 2] : 0);
+            // the workgroup that carries the pivot chain polls at once, the others can afford to be told a little later (and must not crowd the counter)
+            const bool chain = d.w == -2 && d.z == 0;
+            long long spins = 0;
+            // RELAXED polls (an acquire here would invalidate this XCD's L2 on every iteration, for everybody: measured 78 us per step); the one acquire
+            // that matters is the fence behind the loop
+            while (__hip_atomic_load(&sg.ctr[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+                ++spins;
+                if (spins > (chain ? 4000000LL : 400000LL) || ((spins & 1023) == 0 && (*(volatile int*)flag & 4))) { // ~1 s, or somebody else gave up
+                    atomicOr(flag, 4);
+                    break;
+                }
+                if (chain) __builtin_amdgcn_s_sleep(1);
+                else __builtin_amdgcn_s_sleep(8);
+            }
+            if ((sg.probe & 4) && !(sg.probe & 2)) __threadfence();
+        }
+        __syncthreads();
+        if (!(sg.probe & 6)) __threadfence(); // acquire for every lane: nothing this workgroup reads from now on may come from a stale line of its XCD's L2
+    }
+    step_work<TOP>(wg, d, d2, tv, fronts, dinv, flag, xv);
+    if (sg.n > 1 && g + 1 < sg.n) { // (the last step of a launch is followed by a kernel boundary)
+        if (!(sg.probe & 5)) __threadfence(); // release: this lane's stores written back before the counter moves
+        __syncthreads();
+        if ((sg.probe & 4) && !(sg.probe & 1) && threadIdx.x == 0) __threadfence();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&sg.ctr[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the fences above are the release)
+    }
 }
 
 // ---- triangular solves ------------------------------------------------------------------------------------
@@ -2414,6 +2468,9 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
+    if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE")) stepMerge_ = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE_WGS")) stepMergeWgs_ = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IPCGPU_MF_STEP_PROBE")) stepProbe_ = std::atoi(e);
     if (const char* e = std::getenv("IPCGPU_MF_FWD_ROOT_ON_MAIN")) fwdRootOnMain_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCGPU_MF_FWD_STRIDE")) fwdStride_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD")) schurFold_ = std::max(0, std::atoi(e));
@@ -2820,6 +2877,11 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 for (int c0 = 0; c0 < sym.nc(s); c0 += 16) desc.push_back(make_int4(s, c0, 0, 0));
         P.bwdInit.cnt = (int)desc.size() - P.bwdInit.off;
     }
+    {
+        size_t nStepLaunches = 0;
+        for (const LevelPlan& P : plan_) nStepLaunches += P.step.size();
+        stepCtr_.alloc(nStepLaunches + 1);
+    }
     lap("level plans");
     {
         // packed descriptors of the fused fronts, in launch order
@@ -3084,6 +3146,12 @@ bool MfNumeric::factorize(const double* a_dev)
     }
     hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, stream_, flag_.p, hflag_.dev); // mapped pinned memory: no blit
     HIP_CHECK(hipStreamSynchronize(stream_));
+    return pivotsOk();
+}
+
+bool MfNumeric::pivotsOk() const
+{
+    if (hflag_.p[0] & 4) throw HipError("multifrontal factorisation: a merged step launch gave up waiting for the step before it (IPCGPU_MF_STEP_MERGE=1 disables merging)");
     return hflag_.p[0] == 0;
 }
 
@@ -3111,7 +3179,7 @@ bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, doubl
     enqueueBackward(x_dev);
     if (!wait) return true;
     HIP_CHECK(hipStreamSynchronize(stream_));
-    return hflag_.p[0] == 0;
+    return pivotsOk();
 }
 
 void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
@@ -3121,6 +3189,8 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
     XinvView xvF{ xinvOff_.p, xinvX_.p, xinvT_.p };
     if (sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evSide_, 0)); // the side stream still reads the previous factor
     flag_.zero(stream_);
+    if (stepCtr_.n) stepCtr_.zero(stream_);
+    size_t ctrNext = 0; // next free counter of the merged step launches
     bool sideUsed = false;
     int fwdNext = 0; // first level not yet handed to the forward stream
     if (nFusedA_) hipLaunchKernelGGL(k_gather_a, dim3((nFusedA_ + 255) / 256), dim3(256), 0, stream_, nFusedA_, aSrc_.p, a_dev, aPerm_.p);
@@ -3158,10 +3228,31 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
                 hipLaunchKernelGGL(k_scatter_big, dim3((na + 255) / 256), dim3(256), 0, stream_, na, bigASrc_.p + bigAOff_[l],
                     bigADst_.p + bigAOff_[l], a_dev, fronts_.p);
         }
-        for (const Range& R : P.step) {
-            if (!R.cnt) continue;
-            if (P.stepTop) hipLaunchKernelGGL(k_big_step<true>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
-            else hipLaunchKernelGGL(k_big_step<false>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
+        // consecutive step launches merged into one (k_big_step, StepGroup): as many as stepMerge_ allows and as fit stepMergeWgs_ workgroups (later steps'
+        // workgroups wait in their slots: no point in parking thousands of them)
+        for (size_t i = 0; i < P.step.size();) {
+            if (!P.step[i].cnt) {
+                ++i;
+                continue;
+            }
+            StepGroup sg;
+            sg.n = 0;
+            sg.ctr = stepCtr_.p + ctrNext;
+            sg.probe = stepProbe_;
+            int total = 0;
+            size_t j = i;
+            for (; j < P.step.size() && sg.n < std::min(stepMerge_, STEP_GROUP_MAX); ++j) {
+                const Range& R = P.step[j];
+                if (!R.cnt) break; // (only ever the last one)
+                if (sg.n > 0 && (total + R.cnt > stepMergeWgs_ || R.off != P.step[i].off + 2 * total)) break; // the records of a launch are contiguous
+                total += R.cnt;
+                sg.end[sg.n++] = total;
+            }
+            for (int q = sg.n; q < STEP_GROUP_MAX; ++q) sg.end[q] = total;
+            ctrNext += sg.n;
+            if (P.stepTop) hipLaunchKernelGGL(k_big_step<true>, dim3(total), dim3(WGB), 0, stream_, desc_.p + P.step[i].off, tv, fronts_.p, dinv_.p, flag_.p, xvF, sg);
+            else hipLaunchKernelGGL(k_big_step<false>, dim3(total), dim3(WGB), 0, stream_, desc_.p + P.step[i].off, tv, fronts_.p, dinv_.p, flag_.p, xvF, sg);
+            i = j;
         }
         if (P.schur.cnt) {
             if (P.schur64) hipLaunchKernelGGL(k_big_schur64, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
