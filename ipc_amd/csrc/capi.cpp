@@ -285,6 +285,7 @@ int ipcgpu_set_positions(ipcgpu_ctx* c, const double* V)
         bind(c);
         needArg(V != nullptr, "null V");
         uploadColMajor(c, V, c->mesh->d_x);
+        if (c->opt) c->opt->specAsmValid = false; // (an assembly enqueued ahead for the old positions)
         return IPCGPU_OK;
     });
 }

@@ -238,7 +238,15 @@ public:
     // as well -- its step size, inversion flag and energy arrive with the same synchronisation, ONE per Newton iteration
     bool cachedTrialValid = false, cachedTrialInverted = false;
     double cachedTrialE = 0, cachedAlpha = 1.0;
-    hipEvent_t evAsm0 = nullptr, evAsm1 = nullptr;
+    // ... and, round 4: the NEXT iteration's fused assembly (gradient + Hessian at the trial point) is enqueued behind the trial kernels, before that one
+    // synchronisation -- into buffers of its own, swapped in when the trial is accepted and the next pass asks for exactly this assembly.  The host's
+    // read-back, its decisions and the way back through the caller's loop (45 us per iteration on the bench) then run beside a kernel instead of in front of it.
+    // Nothing is skipped and nothing observable moves: d_gradient and the solver's values keep describing the iterate the search direction came from
+    // until the swap; a rejected trial, a converged pass (one assembly per time step goes unused), a bad pivot or a time-step call drop the buffers' content.
+    DevBuf<double> d_aSpec, d_gradSpec;
+    bool specAsmValid = false, specAsmOn = true; // IPCGPU_NO_SPEC_ASSEMBLY=1
+    void speculativeAssembly();
+    hipEvent_t evAsm0 = nullptr, evAsm1 = nullptr, evTail = nullptr;
     bool evAsmPending = false;
     void resolveEventTimers();
     DevBuf<double> d_contactG; // this rank's share of the barrier forces before their all-reduce (contact-pair lists sharded)

@@ -32,10 +32,11 @@ struct Tic {
     double& acc;
     hipStream_t s;
     std::chrono::high_resolution_clock::time_point t0;
+    bool nosync = false; // the caller has synchronised what it timed by an event: the stream may carry work enqueued AHEAD (speculativeAssembly) that must not be waited for
     Tic(double& a, hipStream_t st) : acc(a), s(st), t0(std::chrono::high_resolution_clock::now()) {}
     ~Tic()
     {
-        (void)hipStreamSynchronize(s);
+        if (!nosync) (void)hipStreamSynchronize(s);
         acc += std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
     }
 };
@@ -563,6 +564,7 @@ void HipOptimizer::saveStatus(const std::string& path)
 // restart branch of the Optimizer constructor (Optimizer.cpp:179-248): same token grammar, then V_prev = V and computeXTilta
 void HipOptimizer::loadStatus(const std::string& path)
 {
+    specAsmValid = false;
     std::ifstream in(path);
     if (!in.is_open()) throw StateError("unable to open status file " + path);
     const size_t n3 = 3 * (size_t)mesh.nV;
@@ -1099,6 +1101,22 @@ void HipOptimizer::stepForward(const double* x0_dev, double alpha)
     launch_step_forward(3 * mesh.nV, x0_dev, d_searchDir.p, alpha, mesh.d_x.p, stream);
 }
 
+void HipOptimizer::speculativeAssembly()
+{
+    static const bool off = std::getenv("IPCGPU_NO_SPEC_ASSEMBLY") != nullptr;
+    specAsmValid = false;
+    if (off || !specAsmOn || !fastPath() || !projDBC || lin.rowBase.empty()) return;
+    ensurePatchPlan();
+    d_aSpec.alloc(lin.d_a.n); // same capacity as the solver's value array: the two are swapped
+    d_gradSpec.alloc(d_gradient.n);
+    resolveEventTimers(); // (this pass's own assembly: finished long ago)
+    HIP_CHECK(hipEventRecord(evAsm0, stream));
+    launch_assemble_patches(view(), patch, 0, patch.nPatches, elasticCoef(), 1, d_gradSpec.p, d_aSpec.p, stream); // what computePrecondMtr(true, true) launches on this path
+    HIP_CHECK(hipEventRecord(evAsm1, stream));
+    evAsmPending = true;
+    specAsmValid = true;
+}
+
 void HipOptimizer::computeSearchDir(bool projectDBC)
 {
     (void)projectDBC;
@@ -1116,21 +1134,21 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
         Tic t(timers[3], stream); // (its synchronisation is the one)
         const size_t bytes = 3 * (size_t)mesh.nV * sizeof(double);
         if (lin.factorizeSolve(d_minusG.p, d_searchDir.p, /*wait=*/false)) {
-            launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+            // ten launches (fifteen before round 4: the resets, the copy + step-size + step and the two read-backs are one launch each now)
+            launch_iter_reset(d_scalar.p, d_flag.p, stream);
             launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
-            launch_fill(d_scalar.p + 2, 1, 1e20, stream);
             if (mesh.energyType != 1) launch_inversion_step(view(), d_searchDir.p, 0.2, d_scalar.p + 2, stream);
             launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
-            HIP_CHECK(hipMemcpyAsync(d_x0.p, mesh.d_x.p, bytes, hipMemcpyDeviceToDevice, stream));
-            launch_trial_step(3 * mesh.nV, d_x0.p, d_searchDir.p, d_scalar.p + 2, mesh.energyType != 1, d_scalar.p + 6, mesh.d_x.p, stream);
-            if (mesh.energyType != 1) {
-                d_flag.zero(stream);
-                launch_check_inversion(view(), d_flag.p, stream);
-                launch_publish(d_flag.p, h_flag.dev, 1, stream);
-            }
+            launch_trial_step_fused(3 * mesh.nV, mesh.d_x.p, d_x0.p, d_searchDir.p, d_scalar.p + 2, mesh.energyType != 1, d_scalar.p + 6, stream);
+            if (mesh.energyType != 1) launch_check_inversion(view(), d_flag.p, stream);
             launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p + 1, stream);
-            launch_publish(d_scalar.p, h_scalar.dev, 14, stream); // 7 doubles
-            HIP_CHECK(hipStreamSynchronize(stream));
+            launch_publish2(d_flag.p, h_flag.dev, 1, d_scalar.p, h_scalar.dev, 14, stream); // the inversion flag + 7 doubles
+            // the ONE synchronisation waits for the read-back, not for the stream: behind it runs the next pass's assembly at the trial point, enqueued ahead
+            if (!evTail) HIP_CHECK(hipEventCreateWithFlags(&evTail, hipEventDisableTiming));
+            HIP_CHECK(hipEventRecord(evTail, stream));
+            speculativeAssembly();
+            HIP_CHECK(hipEventSynchronize(evTail));
+            t.nosync = specAsmValid;
             if (lin.lastPivotsOk()) {
                 cachedE0 = h_scalar.p[0];
                 cachedTrialE = h_scalar.p[1];
@@ -1142,6 +1160,8 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
                 return;
             }
             HIP_CHECK(hipMemcpyAsync(mesh.d_x.p, d_x0.p, bytes, hipMemcpyDeviceToDevice, stream)); // the step was taken along garbage
+            specAsmValid = false;
+            t.nosync = false;
         }
         ok = false;
     }
@@ -1203,6 +1223,7 @@ void HipOptimizer::lineSearch(double& stepSize)
             return;
         }
         HIP_CHECK(hipMemcpyAsync(mesh.d_x.p, d_x0.p, bytes, hipMemcpyDeviceToDevice, stream)); // back to the iterate: the general loop redoes the step
+        specAsmValid = false;
     }
     else if (cachedE0Valid && fastPath()) {
         // E at the iterate came back with the solve; the trial step, its inversion flag and E at the trial point are enqueued together
@@ -1285,6 +1306,7 @@ void HipOptimizer::lineSearch(double& stepSize)
 
 void HipOptimizer::precompute()
 {
+    specAsmValid = false;
     // Optimizer.cpp:457-507
     if (!initialised) throw StateError("opt_precompute before opt_init");
     // Optimizer.cpp:258-263: the reference ends its process on an intersecting start (every line search after it would halve forever)
@@ -1309,6 +1331,7 @@ void HipOptimizer::precompute()
 
 void HipOptimizer::beginTimestep()
 {
+    specAsmValid = false;
     if (!initialised) throw StateError("opt_begin_timestep before opt_init");
     if (!lin.analyzed()) throw StateError("opt_begin_timestep before opt_precompute");
     Tic t(timers[11], stream);
@@ -1483,6 +1506,7 @@ bool HipOptimizer::newtonIter()
     }
     cachedDistValid = false;
     if (k && distToOpt_PN < targetGRes && completedStep > 1.0 - 1.0e-3) { // :1874-1879
+        specAsmValid = false; // (the one assembly per time step that goes unused)
         Tic t(timers[12], stream);
         computeGradient(projDBC); // the reference leaves the gradient of the converged state behind (:1861)
         return true;
@@ -1490,15 +1514,24 @@ bool HipOptimizer::newtonIter()
     innerIterAmt++;
     if (fastPath()) {
         // the assembly is timed with events: no host synchronisation between it and the factorisation
-        resolveEventTimers();
         if (!evAsm0) {
             HIP_CHECK(hipEventCreate(&evAsm0));
             HIP_CHECK(hipEventCreate(&evAsm1));
         }
-        HIP_CHECK(hipEventRecord(evAsm0, stream));
-        computePrecondMtr(projDBC, true);
-        HIP_CHECK(hipEventRecord(evAsm1, stream));
-        evAsmPending = true;
+        if (specAsmValid && projDBC && d_aSpec.n == lin.d_a.n && d_gradSpec.n == d_gradient.n) {
+            // the assembly of exactly this state is already there (enqueued behind the last pass's trial, timed by its own events): swap it in
+            std::swap(lin.d_a.p, d_aSpec.p);
+            std::swap(d_gradient.p, d_gradSpec.p);
+            matrixComplete = true;
+        }
+        else {
+            resolveEventTimers();
+            HIP_CHECK(hipEventRecord(evAsm0, stream));
+            computePrecondMtr(projDBC, true);
+            HIP_CHECK(hipEventRecord(evAsm1, stream));
+            evAsmPending = true;
+        }
+        specAsmValid = false;
     }
     else {
         // gradient (:1861) and Hessian (:2327) come out of one fused element pass
@@ -1510,6 +1543,7 @@ bool HipOptimizer::newtonIter()
     double alpha = 1.0;
     {
         Tic t(timers[13], stream);
+        t.nosync = specAsmValid && cachedTrialValid; // nothing is enqueued in here on that path, and the stream carries the assembly enqueued ahead
         if (cachedTrialValid) alpha = cachedAlpha; // decided on the device by the same rule, the trial step is already taken with it
         else if (cachedE0Valid) { // Optimizer.cpp:1887 with the value the solve's batch brought back
             if (mesh.energyType != 1 && cachedFilter > 0.0 && cachedFilter < alpha) alpha = cachedFilter;
@@ -1544,6 +1578,7 @@ bool HipOptimizer::newtonIter()
 
 void HipOptimizer::endTimestep()
 {
+    specAsmValid = false;
     Tic t(timers[11], stream);
     if (timeIntegration == 1)
         launch_nm_update(mesh.nV, mesh.d_dbc.p, mesh.d_x.p, d_xPrev.p, d_vel.p, d_acc.p, d_dxElastic.p, mesh.d_xTilde.p, dt, betaNM, gammaNM,

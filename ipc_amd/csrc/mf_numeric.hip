@@ -74,9 +74,11 @@ __device__ __forceinline__ int frontNc(const TreeView& tv, int s) { return 3 * (
 __global__ void k_publish_flag(const int* __restrict__ flag, int* __restrict__ mapped) { mapped[0] = flag[0]; }
 
 // values of A in fused-front order: the fused kernel then reads its entries contiguously instead of chasing a[aSrc[e]]
-__global__ void k_gather_a(int cnt, const int* __restrict__ src, const double* __restrict__ a, double* __restrict__ aP)
+// (the first kernel of every factorisation: it also clears the pivot flag -- a memset of four bytes was a launch of its own on the critical path)
+__global__ void k_gather_a(int cnt, const int* __restrict__ src, const double* __restrict__ a, double* __restrict__ aP, int* __restrict__ flag)
 {
     int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) flag[0] = 0;
     if (k < cnt) aP[k] = a[src[k]];
 }
 
@@ -95,8 +97,9 @@ __global__ void k_scatter_big(int cnt, const int* __restrict__ src, const long l
 // offsets arrive in one load instead of five dependent ones.  Per child the parent-row / parent-column -> child-index maps of
 // the tile are built once in LDS; lanes run along rows, which are (mostly) consecutive in the child as well, the four waves
 // split the 64 columns.  The gathers are unconditional (clamped address, value selected afterwards): all in flight together.
+// ownOnly: the level's Schur kernel gathers the children for the update block itself (k_big_schur64_ea): only columns < nc are written here
 __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc, const int* __restrict__ bigFd,
-    const int* __restrict__ invMap, double* __restrict__ fronts)
+    const int* __restrict__ invMap, double* __restrict__ fronts, int ownOnly)
 {
     __shared__ __attribute__((aligned(16))) int fd[FD_STRIDE_EA];
     __shared__ int rmap[FUSED_MAX_KIDS_EA][TS], cmap[FUSED_MAX_KIDS_EA][TS];
@@ -106,13 +109,14 @@ __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc
     double sum[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) sum[q] = 0.0;
-    int N = 0;
+    int N = 0, ncOwn = 0;
     double* F = nullptr;
     for (int rec = d.x; rec >= 0;) {
         __syncthreads();
         if (tid < FD_STRIDE_EA) fd[tid] = bigFd[(size_t)rec * FD_STRIDE_EA + tid];
         __syncthreads();
         N = fd[2];
+        ncOwn = fd[3];
         F = fronts + *reinterpret_cast<const long long*>(fd);
         const int nk = fd[8];
         rec = fd[9];
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int J = j0 + 16 * wv + q;
-            if (J <= I) F[I + (long long)N * J] = sum[q]; // write, not accumulate: the fronts are never zero-filled
+            if (J <= I && (!ownOnly || J < ncOwn)) F[I + (long long)N * J] = sum[q]; // write, not accumulate: the fronts are never zero-filled
         }
     }
 }
@@ -1242,7 +1246,10 @@ __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc,
 // 100-450: split four ways a wave ran two or three chunks between its prologue and the LDS reduction.  Upper levels keep the 32 x 32 kernel: they
 // have a handful of fronts and need the tiles for parallelism.  desc as above with 64 x 64 tile indices.
 constexpr int TQ64 = 64;
-__device__ __forceinline__ void schur_tile64(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi)
+// LOAD_OLD = false: `old` arrives filled (the children's sums gathered by the caller: k_big_schur64_ea) and the tile is WRITTEN, not read-modify-written
+template <bool LOAD_OLD>
+__device__ __forceinline__ void schur_tile64_core(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi,
+    double (&old)[2][2][4])
 {
     const int nc = min(ncAll, cHi);
     if (cLo >= nc) return;
@@ -1251,15 +1258,16 @@ __device__ __forceinline__ void schur_tile64(const int N, const int ncAll, doubl
     const int i0 = ncAll + TQ64 * ti + 32 * (wv & 1), j0 = ncAll + TQ64 * tj + 32 * (wv >> 1); // this wave's quadrant (behind ALL own columns; nc is the end of this pass)
     if (i0 + 31 < j0 || i0 >= N || j0 >= N) return; // entirely above the diagonal (the upper right quadrant of a diagonal tile) or outside
     const int ar = l & 15, ak = l >> 4;
-    double old[2][2][4];
+    if (LOAD_OLD) {
 #pragma unroll
-    for (int nj = 0; nj < 2; ++nj)
+        for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int row = min(i0 + 16 * mi + ar, N - 1);
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = min(i0 + 16 * mi + ar, N - 1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) old[nj][mi][r] = F[row + (long long)N * min(j0 + 16 * nj + ak + 4 * r, N - 1)];
-        }
+                for (int r = 0; r < 4; ++r) old[nj][mi][r] = F[row + (long long)N * min(j0 + 16 * nj + ak + 4 * r, N - 1)];
+            }
+    }
     f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i (formed transposed, see k_big_schur)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1318,11 +1326,89 @@ __device__ __forceinline__ void schur_tile64(const int N, const int ncAll, doubl
             }
         }
 }
+__device__ __forceinline__ void schur_tile64(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi)
+{
+    double old[2][2][4];
+    schur_tile64_core<true>(N, ncAll, F, ti, tj, cLo, cHi, old);
+}
 __global__ __launch_bounds__(WG) void k_big_schur64(const int4* __restrict__ desc, double* __restrict__ fronts)
 {
     const int4 d = desc[2 * blockIdx.x];
     const int4 d2 = desc[2 * blockIdx.x + 1];
     schur_tile64(d2.x, d2.y, fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z), d.y, d.z, 0, 1 << 30);
+}
+
+// The same with the EXTEND-ADD of the update block fused in (round 4): S = (children) - L21 L21^T written once.  The extend-add kernel of such a level
+// only writes the front's own columns; the update block used to be written by it (children sums or zeros), read back and written again here: two passes
+// over the largest part of every middle-level front.  desc = (front, ti, tj, packed record of the front's children) + (N, nc, front offset); the
+// records, the child -> parent index maps and the order of the sums are those of k_extend_add.
+__global__ __launch_bounds__(WG) void k_big_schur64_ea(const int4* __restrict__ desc, const int* __restrict__ bigFd, const int* __restrict__ invMap,
+    double* __restrict__ fronts)
+{
+    __shared__ __attribute__((aligned(16))) int fd[FD_STRIDE_EA];
+    __shared__ int rmap[FUSED_MAX_KIDS_EA][TQ64], cmap[FUSED_MAX_KIDS_EA][TQ64];
+    const int4 d = desc[2 * blockIdx.x];
+    const int4 d2 = desc[2 * blockIdx.x + 1];
+    const int N = d2.x, nc = d2.y;
+    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, ar = l & 15, ak = l >> 4;
+    const int I0 = nc + TQ64 * d.y, J0 = nc + TQ64 * d.z;
+    const int qi = 32 * (wv & 1), qj = 32 * (wv >> 1);
+    const bool active = !(I0 + qi + 31 < J0 + qj || I0 + qi >= N || J0 + qj >= N);
+    double old[2][2][4];
+#pragma unroll
+    for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) old[nj][mi][r] = 0.0;
+    for (int rec = d.w; rec >= 0;) {
+        __syncthreads();
+        if (tid < FD_STRIDE_EA) fd[tid] = bigFd[(size_t)rec * FD_STRIDE_EA + tid];
+        __syncthreads();
+        const int nk = fd[8];
+        rec = fd[9];
+        for (int e = tid; e < nk * 2 * TQ64; e += WG) {
+            const int k = e / (2 * TQ64), t = e - k * (2 * TQ64);
+            const int* inv = invMap + fd[16 + 6 * k + 4];
+            const int ncc = fd[16 + 6 * k + 3];
+            const int I = (t < TQ64 ? I0 : J0 - TQ64) + t;
+            int m = -1;
+            if (I < N) {
+                const int ic = inv[I / 3];
+                if (ic >= 0) m = ncc + 3 * ic + (I - 3 * (I / 3));
+            }
+            (t < TQ64 ? rmap[k] : cmap[k] - TQ64)[t] = m;
+        }
+        __syncthreads();
+        if (active) {
+            for (int k = 0; k < nk; ++k) {
+                const double* __restrict__ Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * k);
+                const long long Nc = fd[16 + 6 * k + 2];
+                double x[2][2][4];
+                bool ok[2][2][4];
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi) {
+                        const int rr = rmap[k][qi + 16 * mi + ar];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int cc = cmap[k][qj + 16 * nj + ak + 4 * r];
+                            ok[nj][mi][r] = rr >= 0 && cc >= 0 && rr >= cc;
+                            x[nj][mi][r] = Fc[ok[nj][mi][r] ? rr + Nc * cc : 0];
+                        }
+                    }
+#pragma unroll
+                for (int nj = 0; nj < 2; ++nj)
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) old[nj][mi][r] += ok[nj][mi][r] ? x[nj][mi][r] : 0.0;
+            }
+        }
+    }
+    if (active) schur_tile64_core<false>(N, nc, F, d.y, d.z, 0, 1 << 30, old);
 }
 
 // ---- explicit inverses of the factor triangles of the widest fronts (see the k_xinv_* kernels further down for what they are used for)
@@ -2468,6 +2554,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
+    if (const char* e = std::getenv("IPCGPU_MF_FUSE_EA")) fuseEA_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE")) stepMerge_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE_WGS")) stepMergeWgs_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_STEP_PROBE")) stepProbe_ = std::atoi(e);
@@ -2699,6 +2786,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     std::vector<int> smallList, bigList;
     std::vector<int4> ea;
     std::vector<int> bigFd; // packed records of the fronts of the multi-workgroup path (k_extend_add)
+    std::vector<int> eaRecOf(ns_, -1); // front -> its first record
     std::vector<int4> desc;
     size_t maxSmallLds = 0, maxSolveLds = 0, maxTriLds = 0, maxBwdLds = 0;
     for (int l = 0; l < nLevels_; ++l) {
@@ -2738,8 +2826,21 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         maxTriLds = std::max(maxTriLds, P.triLds);
         // extend-add descriptors: lower-triangular 64 x 64 tiles of the parent, each pointing at the parent's packed record
         P.ea.off = (int)ea.size();
+        // the extend-add of the update block fused into the Schur kernel (k_big_schur64_ea) on the levels that take the 64 x 64 tiles in one pass behind
+        // the chain: decided here because it thins out the extend-add's tiles (needs the same tile count as the decision further down: recomputed there)
+        {
+            long long tiles32 = 0;
+            int stepsL = 0;
+            for (int s : big) {
+                const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
+                tiles32 += nt * (nt + 1) / 2;
+                stepsL = std::max(stepsL, (sym.nc(s) + NB - 1) / NB);
+            }
+            P.fuseEA = fuseEA_ && tiles32 >= schur64Min_ && !(schurFold_ > 0 && stepsL >= schurFoldMinSteps_);
+        }
         for (int s : big) { // every lower-triangle tile is written (children sums or zeros): the fronts are never zero-filled
             const int first = (int)(bigFd.size() / FD_STRIDE);
+            eaRecOf[s] = first;
             const int nkAll = sym.childPtr[s + 1] - sym.childPtr[s];
             for (int k0 = 0; k0 == 0 || k0 < nkAll; k0 += FUSED_MAX_KIDS) {
                 const size_t base = bigFd.size();
@@ -2764,7 +2865,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             }
             const int nt = (sym.N(s) + TS - 1) / TS;
             for (int ti = 0; ti < nt; ++ti)
-                for (int tj = 0; tj <= ti; ++tj) ea.push_back(make_int4(first, ti, tj, 0));
+                for (int tj = 0; tj <= ti; ++tj) {
+                    if (P.fuseEA && TS * tj >= sym.nc(s)) continue; // a tile of the update block alone: the Schur kernel's
+                    ea.push_back(make_int4(first, ti, tj, 0));
+                }
         }
         P.ea.cnt = (int)ea.size() - P.ea.off;
         // big-front step descriptors: launch 0 factors panel 0, launch j + 1 applies panel j and factors panel j + 1
@@ -2861,12 +2965,13 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
                 for (int ti = 0; ti < nt; ++ti)
                     for (int tj = 0; tj <= ti; ++tj) {
-                        desc.push_back(make_int4(s, ti, tj, 0));
+                        desc.push_back(make_int4(s, ti, tj, P.fuseEA ? eaRecOf[s] : 0));
                         desc.push_back(rec2);
                     }
             }
         }
         P.schur.cnt = ((int)desc.size() - P.schur.off) / 2; // workgroups: two records each
+        if (P.fuseEA && (!P.schur64 || foldSchur)) throw StateError("internal: fused extend-add planned for a level without the one-pass 64 x 64 Schur kernel");
         P.fwdRect.off = (int)desc.size();
         for (int s : big)
             for (int r0 = 0; r0 < sym.N(s) - sym.nc(s); r0 += MV_ROWS) desc.push_back(make_int4(s, r0, 0, 0));
@@ -3188,12 +3293,12 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     XinvView xvF{ xinvOff_.p, xinvX_.p, xinvT_.p };
     if (sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evSide_, 0)); // the side stream still reads the previous factor
-    flag_.zero(stream_);
-    if (stepCtr_.n) stepCtr_.zero(stream_);
+    if (stepMerge_ > 1 && stepCtr_.n) stepCtr_.zero(stream_);
     size_t ctrNext = 0; // next free counter of the merged step launches
     bool sideUsed = false;
     int fwdNext = 0; // first level not yet handed to the forward stream
-    if (nFusedA_) hipLaunchKernelGGL(k_gather_a, dim3((nFusedA_ + 255) / 256), dim3(256), 0, stream_, nFusedA_, aSrc_.p, a_dev, aPerm_.p);
+    if (nFusedA_) hipLaunchKernelGGL(k_gather_a, dim3((nFusedA_ + 255) / 256), dim3(256), 0, stream_, nFusedA_, aSrc_.p, a_dev, aPerm_.p, flag_.p);
+    else flag_.zero(stream_);
     for (int l = 0; l < nLevels_; ++l) {
         const LevelPlan& P = plan_[l];
         if (P.small.cnt)
@@ -3222,7 +3327,7 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
         }
 #endif
         if (P.ea.cnt) {
-            hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, bigFd_.p, inv_.p, fronts_.p);
+            hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, bigFd_.p, inv_.p, fronts_.p, P.fuseEA ? 1 : 0);
             const int na = bigAOff_[l + 1] - bigAOff_[l];
             if (na)
                 hipLaunchKernelGGL(k_scatter_big, dim3((na + 255) / 256), dim3(256), 0, stream_, na, bigASrc_.p + bigAOff_[l],
@@ -3255,7 +3360,8 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
             i = j;
         }
         if (P.schur.cnt) {
-            if (P.schur64) hipLaunchKernelGGL(k_big_schur64, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
+            if (P.fuseEA) hipLaunchKernelGGL(k_big_schur64_ea, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, bigFd_.p, inv_.p, fronts_.p);
+            else if (P.schur64) hipLaunchKernelGGL(k_big_schur64, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
             else hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
         }
         if (world_ > 1 && xchg_[l].pack.cnt) {

@@ -48,6 +48,10 @@ void launch_step_forward(int n3, const double* x0, const double* p, double alpha
 // alpha = 1, or the inversion filter's minimum when it applies, decided on the device; x = x0 + alpha p
 void launch_trial_step(int n3, const double* x0, const double* p, const double* filterMin, bool useFilter, double* alphaOut, double* x, hipStream_t s);
 void launch_max_abs(int n, const double* v, double* out /*preset 0*/, hipStream_t s);
+// round 4: the small launches of a contact-free iteration's tail, fused (x -> x0 + alpha + step; scalar resets; the two read-backs)
+void launch_trial_step_fused(int n3, double* x, double* x0, const double* p, const double* filterMin, bool useFilter, double* alphaOut, hipStream_t s);
+void launch_iter_reset(double* scalar, int* flag, hipStream_t s);
+void launch_publish2(const void* a, void* da, int na, const void* b, void* db, int nb, hipStream_t s);
 void launch_fill(double* p, size_t n, double v, hipStream_t s);
 void launch_negate(int n, const double* in, double* out, hipStream_t s);
 // copies nWords 4-byte words from device memory into mapped pinned host memory (a ~24 us blit per scalar read-back otherwise)

@@ -320,6 +320,36 @@ __global__ void k_step_forward_dev(int n, const double* __restrict__ x0, const d
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) x[i] = x0[i] + alpha * p[i];
 }
+// The three small launches in front of the trial -- copy x -> x0, decide alpha, take the step -- as one (round 4: a dependent launch costs 3.4 us whatever it does):
+// every lane applies k_trial_alpha's rule to the same scalar, lane 0 publishes the result
+__global__ void k_trial_step_fused(int n, double* __restrict__ x, double* __restrict__ x0, const double* __restrict__ p, const double* __restrict__ filterMin,
+    int useFilter, double* __restrict__ alphaOut)
+{
+    double alpha = 1.0;
+    const double t = filterMin[0];
+    if (useFilter && t > 0.0 && t < alpha) alpha = t;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) alphaOut[0] = alpha;
+    if (i < n) {
+        const double xi = x[i];
+        x0[i] = xi;
+        x[i] = xi + alpha * p[i];
+    }
+}
+// the scalars a contact-free Newton iteration accumulates into behind the solve, reset by one launch: |p|_inf = 0, the step filter's minimum = 1e20, inversion flag = 0
+__global__ void k_iter_reset(double* __restrict__ scalar, int* __restrict__ flag)
+{
+    scalar[3] = 0.0;
+    scalar[2] = 1e20;
+    flag[0] = 0;
+}
+// the inversion flag and the scalars to their mapped host buffers in one launch
+__global__ void k_publish2(const unsigned* __restrict__ a, unsigned* __restrict__ da, int na, const unsigned* __restrict__ b, unsigned* __restrict__ db, int nb)
+{
+    const int i = threadIdx.x;
+    if (i < na) da[i] = a[i];
+    if (i < nb) db[i] = b[i];
+}
 // grid-stride, one atomic per workgroup (the launch caps the grid at 256 workgroups): per wave of a thread-per-entry launch they were 2 100
 // same-address atomics for 1.35e5 entries, most of the kernel's 23 us
 __global__ __launch_bounds__(BLOCK) void k_max_abs(int n, const double* __restrict__ v, unsigned long long* __restrict__ out)
@@ -656,6 +686,15 @@ void launch_trial_step(int n3, const double* x0, const double* p, const double* 
 {
     hipLaunchKernelGGL(k_trial_alpha, dim3(1), dim3(1), 0, s, filterMin, useFilter ? 1 : 0, alphaOut);
     if (n3) hipLaunchKernelGGL(k_step_forward_dev, dim3(nblk(n3)), dim3(BLOCK), 0, s, n3, x0, p, (const double*)alphaOut, x);
+}
+void launch_trial_step_fused(int n3, double* x, double* x0, const double* p, const double* filterMin, bool useFilter, double* alphaOut, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trial_step_fused, dim3(std::max(nblk(n3), 1)), dim3(BLOCK), 0, s, n3, x, x0, p, filterMin, useFilter ? 1 : 0, alphaOut);
+}
+void launch_iter_reset(double* scalar, int* flag, hipStream_t s) { hipLaunchKernelGGL(k_iter_reset, dim3(1), dim3(1), 0, s, scalar, flag); }
+void launch_publish2(const void* a, void* da, int na, const void* b, void* db, int nb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_publish2, dim3(1), dim3(64), 0, s, (const unsigned*)a, (unsigned*)da, na, (const unsigned*)b, (unsigned*)db, nb);
 }
 void launch_max_abs(int n, const double* v, double* out, hipStream_t s)
 {
