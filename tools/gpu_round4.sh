@@ -9,7 +9,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 if [ -z "$SKIP_TESTS" ]; then
-  ( timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -8 ) > $out/gpu_tests.txt; cat $out/gpu_tests.txt
+  ( timeout 1500 python -m pytest tests -m gpu -q --tb=line -rf 2>&1 | grep -E "FAILED|passed|failed|assert" | cut -c1-400 | tail -12 ) > $out/gpu_tests.txt; cat $out/gpu_tests.txt
 fi
 timeout 400 python bench.py > $out/bench_line.json 2> $out/bench.err; grep bench $out/bench.err | tail -12
 rm -rf /tmp/prof_r04
@@ -21,7 +21,7 @@ rm -rf /tmp/profc_r04
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/profc_r04 -o run -- python $R/tools/bench_contact.py --n 100 --steps 12 > $R/$out/contact_bench_under_rocprof.json 2> /dev/null )
 db=$(find /tmp/profc_r04 -name "*.db" | head -1)
 [ -n "$db" ] && python tools/rocprof_summary.py $db $out/contact_kernel_stats.md > /dev/null
-for size in 150 433; do
+for size in ${PMC_SIZES-150 433}; do
   rm -rf $out/pmc_rd_$size $out/pmc_wr_$size
   ( cd /tmp && timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$out/pmc_rd_$size -- python $R/tools/pmc_traffic.py workload $size > /dev/null 2>&1 )
   ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$out/pmc_wr_$size -- python $R/tools/pmc_traffic.py workload $size > /dev/null 2>&1 )
