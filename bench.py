@@ -10,8 +10,8 @@ One "step" = one pass of the solveSub_IP loop (Optimizer.cpp:1829-2204) = one Ne
 time-step boundaries (scripted DBC motion, BE velocity update) included as they occur.
 
   python bench.py --gpus N --steps K --warmup W
-(N > 1: launched by torch.distributed.run, one rank per GPU: subtree-sharded direct solver over RCCL,
-element assembly sharded as well from 4 M tets)
+(N > 1: launched by torch.distributed.run, one rank per GPU over RCCL: the direct solver sharded by subtrees, elements and contact-pair lists by the
+CSR rows those subtrees read -- no matrix value crosses ranks; the line's `comm_per_iter` says what does.  See DESIGN.md section 6.)
 """
 import argparse
 import json
