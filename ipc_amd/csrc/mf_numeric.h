@@ -129,7 +129,7 @@ private:
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
     // consecutive step launches of a level merged into one, later steps waiting on in-launch counters (k_big_step, StepGroup): IPCGPU_MF_STEP_MERGE = steps per
     // launch (1 = one launch per step, as before round 4), IPCGPU_MF_STEP_MERGE_WGS = workgroups per launch at most
-    int stepMerge_ = 1, stepMergeWgs_ = 1536, stepProbe_ = 0; // OFF by default: measured slower than the launches it replaces (profiles/r04_merged_step_launches_ab.txt)
+    int stepMerge_ = 1, stepMergeWgs_ = 1536; // OFF by default: measured slower than the launches it replaces (profiles/r04_merged_step_launches_ab.txt)
     DevBuf<int> stepCtr_;
     bool fuseEA_ = true; // IPCGPU_MF_FUSE_EA=0: extend-add of the whole front, then a read-modify-write Schur pass (rounds 1-3)
     int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)

@@ -1820,7 +1820,6 @@ struct StepGroup {
     int n; // steps in this launch
     int end[STEP_GROUP_MAX]; // end[g] = first workgroup behind step g
     int* ctr; // ctr[g]: workgroups of step g that have finished (zeroed at the start of the factorisation)
-    int probe; // timing experiments only (IPCGPU_MF_STEP_PROBE): bit 0 no release fences, bit 1 no acquire fences, bit 2 fences by one wave only
 };
 template <bool TOP>
 __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
@@ -1850,16 +1849,14 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
                 if (chain) __builtin_amdgcn_s_sleep(1);
                 else __builtin_amdgcn_s_sleep(8);
             }
-            if ((sg.probe & 4) && !(sg.probe & 2)) __threadfence();
         }
         __syncthreads();
-        if (!(sg.probe & 6)) __threadfence(); // acquire for every lane: nothing this workgroup reads from now on may come from a stale line of its XCD's L2
+        __threadfence(); // acquire for every lane: nothing this workgroup reads from now on may come from a stale line of its XCD's L2
     }
     step_work<TOP>(wg, d, d2, tv, fronts, dinv, flag, xv);
     if (sg.n > 1 && g + 1 < sg.n) { // (the last step of a launch is followed by a kernel boundary)
-        if (!(sg.probe & 5)) __threadfence(); // release: this lane's stores written back before the counter moves
+        __threadfence(); // release: this lane's stores written back before the counter moves
         __syncthreads();
-        if ((sg.probe & 4) && !(sg.probe & 1) && threadIdx.x == 0) __threadfence();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(&sg.ctr[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the fences above are the release)
     }
 }
@@ -2557,7 +2554,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_FUSE_EA")) fuseEA_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE")) stepMerge_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE_WGS")) stepMergeWgs_ = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IPCGPU_MF_STEP_PROBE")) stepProbe_ = std::atoi(e);
     if (const char* e = std::getenv("IPCGPU_MF_FWD_ROOT_ON_MAIN")) fwdRootOnMain_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCGPU_MF_FWD_STRIDE")) fwdStride_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD")) schurFold_ = std::max(0, std::atoi(e));
@@ -3343,7 +3339,6 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
             StepGroup sg;
             sg.n = 0;
             sg.ctr = stepCtr_.p + ctrNext;
-            sg.probe = stepProbe_;
             int total = 0;
             size_t j = i;
             for (; j < P.step.size() && sg.n < std::min(stepMerge_, STEP_GROUP_MAX); ++j) {
