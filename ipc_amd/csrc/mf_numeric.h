@@ -131,6 +131,7 @@ private:
     // launch (1 = one launch per step, as before round 4), IPCGPU_MF_STEP_MERGE_WGS = workgroups per launch at most
     int stepMerge_ = 1, stepMergeWgs_ = 1536; // OFF by default: measured slower than the launches it replaces (profiles/r04_merged_step_launches_ab.txt)
     DevBuf<int> stepCtr_;
+    bool borderXT_ = true; // role C keeps X^T beside X for coalesced operand loads (IPCGPU_MF_BORDER_XT=0: reads the column-major X)
     bool fuseEA_ = true; // IPCGPU_MF_FUSE_EA=0: extend-add of the whole front, then a read-modify-write Schur pass (rounds 1-3)
     int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)
     bool fwdRootOnMain_ = true, fwdJoined_ = false; // the root's forward sweep on the main stream (IPCGPU_MF_FWD_ROOT_ON_MAIN=0: on the forward stream like the other levels)

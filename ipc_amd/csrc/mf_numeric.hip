@@ -1429,7 +1429,7 @@ struct XinvView {
 // A workgroup is as long as its k range (up to nc columns, on ONE CU): tiles far left of the panel are CT = 16 columns wide (half the products per
 // wave, twice the workgroups), and the operands are fetched two batches ahead of their products (one batch = 8 or 16 MFMAs = 0.2 - 0.4 us, less than
 // a strided L2 round trip).  d = (front, kb, c0, -3 [CT = 32] / -6 [CT = 16]); c0 == kb: the diagonal block itself (a copy of the dinv block).
-template <int CT>
+template <int CT, bool XT_ON>
 __device__ __forceinline__ void step_border(const int4 d, const int4 d2, const TreeView& tv, const XinvView& xv, const double* __restrict__ F,
     const double* __restrict__ dinv, double* sm)
 {
@@ -1438,12 +1438,18 @@ __device__ __forceinline__ void step_border(const int4 d, const int4 d2, const T
     const int N = d2.x, nc = d2.y;
     const int w = min(NB, nc - kb);
     double* X = xv.X + xv.xOff[s];
+    // X^T beside X (in the scratch buffer the recursive doubling would use): the first product reads X(k, c) for 16 columns c and 4 rows k per instruction --
+    // 16 cache lines from the column-major X, 4 from its transpose
+    double* XT = XT_ON ? xv.T + xv.xOff[s] : nullptr;
     const double* blk = dinv + (tv.dinvOff[s] + kb / NB) * (NB * NB); // blk[c * 32 + r] = Xd(r, c), identity-padded
     const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, lo = l & 15, hi = l >> 4;
     if (c0 == kb) {
         for (int e = tid; e < NB * NB; e += WGB) {
             const int c = e >> 5, r = e & 31;
-            if (r < w && c < w) X[(kb + r) + (long long)nc * (kb + c)] = blk[e];
+            if (r < w && c < w) {
+                X[(kb + r) + (long long)nc * (kb + c)] = blk[e];
+                if (XT_ON) XT[(kb + c) + (long long)nc * (kb + r)] = blk[e];
+            }
         }
         return;
     }
@@ -1466,7 +1472,7 @@ __device__ __forceinline__ void step_border(const int4 d, const int4 d2, const T
         for (int ks = 0; ks < 4; ++ks) {
             const int kc = min(k0 + 4 * ks + hi, nc - 1);
 #pragma unroll
-            for (int q = 0; q < NA; ++q) ra[q][ks] = X[kc + (long long)nc * cc[q]];
+            for (int q = 0; q < NA; ++q) ra[q][ks] = XT_ON ? XT[cc[q] + (long long)nc * kc] : X[kc + (long long)nc * cc[q]];
 #pragma unroll
             for (int q = 0; q < 2; ++q) rb[q][ks] = F[rrc[q] + (long long)N * kc];
         }
@@ -1536,7 +1542,11 @@ __device__ __forceinline__ void step_border(const int4 d, const int4 d2, const T
     const int r = 16 * b + lo;
     if (r < w) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) X[(kb + r) + (long long)nc * (c0 + 16 * a + hi + 4 * i)] = -o[i];
+        for (int i = 0; i < 4; ++i) {
+            const int c = c0 + 16 * a + hi + 4 * i;
+            X[(kb + r) + (long long)nc * c] = -o[i];
+            if (XT_ON) XT[c + (long long)nc * (kb + r)] = -o[i];
+        }
     }
 }
 
@@ -1561,7 +1571,8 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
     double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
     const int tid = threadIdx.x;
     if (TOP && d.w <= -3) {
-        if (d.w == -6) step_border<16>(d, d2, tv, xv, F, dinv, sm);
+        if (d.w == -6) step_border<16, true>(d, d2, tv, xv, F, dinv, sm);
+        else if (d.w == -7) step_border<16, false>(d, d2, tv, xv, F, dinv, sm); // A/B: operands from the column-major X (IPCGPU_MF_BORDER_XT=0)
         else if (d.w == -4) schur_tile32(N, nc, F, d.z & 0xffff, (d.z >> 16) & 0xffff, d.x, d.y, reinterpret_cast<double(*)[4][256]>(sm));
         return;
     }
@@ -2552,6 +2563,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
     if (const char* e = std::getenv("IPCGPU_MF_FUSE_EA")) fuseEA_ = std::atoi(e) != 0;
+    if (const char* e = std::getenv("IPCGPU_MF_BORDER_XT")) borderXT_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE")) stepMerge_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE_WGS")) stepMergeWgs_ = std::max(1, std::atoi(e));
     if (const char* e = std::getenv("IPCGPU_MF_FWD_ROOT_ON_MAIN")) fwdRootOnMain_ = std::atoi(e) != 0;
@@ -2917,7 +2929,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                     P.stepTop = true;
                     // 16-column tiles (32 wide ones made the late steps of the root 20 us long: one CU per tile, k up to nc); c0 == kb: the diagonal block, one copy
                     for (int c0 = 0; c0 <= kb; c0 += 16) {
-                        desc.push_back(make_int4(s, kb, c0, -6));
+                        desc.push_back(make_int4(s, kb, c0, borderXT_ ? -6 : -7));
                         desc.push_back(rec2);
                     }
                 }
