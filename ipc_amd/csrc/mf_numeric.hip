@@ -2704,7 +2704,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         for (int s = 0; s < ns_; ++s) fused[s] = isFused(s);
         // bucket of an entry: fused front s -> s, other front of level l -> ns_ + l
         const int nBuckets = ns_ + nLevels_ + 1;
-        const int nThreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+        const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
         std::vector<std::vector<int>> cnt(nThreads, std::vector<int>(nBuckets, 0));
         auto range = [&](int t) { return std::make_pair(nnz * t / nThreads, nnz * (t + 1) / nThreads); };
         const int skipBucket = ns_ + nLevels_; // entries of fronts another rank owns

@@ -39,21 +39,50 @@ Graph node_graph(int n, const int* ia, const int* ja)
     Graph g;
     g.nn = n / 3;
     if (block_structured(n, ia, ja)) {
-        g.ptr.assign(g.nn + 1, 0);
-        for (int u = 0; u < g.nn; ++u)
-            for (int k = ia[3 * u] + 3; k < ia[3 * u + 1]; k += 3) { // first block = the diagonal
-                g.ptr[u + 1]++;
-                g.ptr[ja[k] / 3 + 1]++;
+        // adj(u) = neighbours below u in ascending order (they come from the rows of those neighbours) followed by the ones above u (its own row).
+        // A counting sort over node ranges on a few threads: thread t counts, per target w, the rows of its range that list w; the offsets of
+        // the threads inside adj(w) follow in thread order, i.e. ascending u -- the same lists a single pass over the rows produces.
+        const int nn = g.nn;
+        const int nThreads = nn < 4096 ? 1 : std::max(1, std::min(4, (int)std::thread::hardware_concurrency())); // starting a thread costs what 1 000 nodes do
+        auto lo = [&](int t) { return (int)((int64_t)nn * t / nThreads); };
+        std::vector<std::vector<int>> below(nThreads, std::vector<int>(nn, 0)); // below[t][w]: rows u of range t with w in row u (u < w)
+        auto parallel = [&](auto&& body) {
+            if (nThreads == 1) {
+                body(0);
+                return;
             }
-        for (int u = 0; u < g.nn; ++u) g.ptr[u + 1] += g.ptr[u];
-        g.adj.resize(g.ptr[g.nn]);
-        std::vector<int> pos(g.ptr.begin(), g.ptr.end() - 1);
-        for (int u = 0; u < g.nn; ++u)
-            for (int k = ia[3 * u] + 3; k < ia[3 * u + 1]; k += 3) {
-                const int w = ja[k] / 3;
-                g.adj[pos[u]++] = w;
-                g.adj[pos[w]++] = u;
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nThreads; ++t) pool.emplace_back([&, t] { body(t); });
+            for (auto& th : pool) th.join();
+        };
+        parallel([&](int t) {
+            int* c = below[t].data();
+            for (int u = lo(t); u < lo(t + 1); ++u)
+                for (int k = ia[3 * u] + 3; k < ia[3 * u + 1]; k += 3) c[ja[k] / 3]++; // first block = the diagonal
+        });
+        g.ptr.assign(nn + 1, 0);
+        for (int w = 0; w < nn; ++w) {
+            int tot = 0;
+            for (int t = 0; t < nThreads; ++t) {
+                const int c = below[t][w];
+                below[t][w] = tot; // offset of thread t's rows inside the lower part of adj(w)
+                tot += c;
             }
+            g.ptr[w + 1] = g.ptr[w] + tot + (ia[3 * w + 1] - ia[3 * w]) / 3 - 1;
+        }
+        g.adj.resize(g.ptr[nn]);
+        parallel([&](int t) {
+            int* off = below[t].data();
+            for (int u = lo(t); u < lo(t + 1); ++u) {
+                // the upper part of adj(u) sits behind the lower part, whose length is what is left of the list
+                int* dst = g.adj.data() + g.ptr[u + 1] - ((ia[3 * u + 1] - ia[3 * u]) / 3 - 1);
+                for (int k = ia[3 * u] + 3; k < ia[3 * u + 1]; k += 3) {
+                    const int w = ja[k] / 3;
+                    g.adj[g.ptr[w] + off[w]++] = u;
+                    *dst++ = w;
+                }
+            }
+        });
         return g;
     }
     // general scalar CSR (set_pattern_csr): every (u, w) block that holds at least one entry
@@ -95,12 +124,16 @@ public:
         for (int i = 0; i < g.nn; ++i) mark_[i].store(-1, std::memory_order_relaxed);
     }
 
-    std::vector<std::vector<int>> run()
+    // taskOf[i]: groups of one subproblem that ran on a single thread share an id >= 0 and are contiguous; -1 for the separators above those
+    // subproblems.  Nothing outside such a subproblem except its ancestors' separators is adjacent to it, which is what lets the caller build
+    // the front structures of different subproblems on different threads.
+    std::vector<std::vector<int>> run(std::vector<int>& taskOf)
     {
         std::vector<int> all(g_.nn);
         std::iota(all.begin(), all.end(), 0);
         std::vector<std::vector<int>> groups;
-        split(all, groups, 0);
+        taskOf.clear();
+        split(all, groups, taskOf, 0, -1);
         return groups;
     }
 
@@ -116,7 +149,7 @@ private:
     std::unique_ptr<std::atomic<int>[]> mark_;
     std::vector<double> key_;
     std::vector<int> seen_;
-    std::atomic<int> tag_{ 0 }, seenTag_{ 0 };
+    std::atomic<int> tag_{ 0 }, seenTag_{ 0 }, task_{ 0 };
     int markOf(int v) const { return mark_[v].load(std::memory_order_relaxed); }
     void setMark(int v, int t) { mark_[v].store(t, std::memory_order_relaxed); }
 
@@ -167,10 +200,13 @@ private:
             if (seen_[v] != st) run(v, key_[order.back()] + 1.0);
     }
 
-    void split(std::vector<int>& S, std::vector<std::vector<int>>& out, int depth)
+    void split(std::vector<int>& S, std::vector<std::vector<int>>& out, std::vector<int>& outTask, int depth, int task)
     {
         if ((int)S.size() <= leaf_) {
-            if (!S.empty()) out.push_back(S);
+            if (!S.empty()) {
+                out.push_back(S);
+                outTask.push_back(task);
+            }
             return;
         }
         const int t = ++tag_;
@@ -206,6 +242,7 @@ private:
         const size_t cut = cutBelow ? lo : hi;
         if (cut == 0 || cut >= sorted.size()) { // cannot be split on this key
             out.push_back(S);
+            outTask.push_back(task);
             return;
         }
         auto isLeftOf = [&](int v) { return cutBelow ? key_[v] < kmid : key_[v] <= kmid; };
@@ -235,25 +272,31 @@ private:
         std::vector<int> sepCopy = sep;
         if (depth < PAR_DEPTH && sorted.size() > 8192) {
             std::vector<std::vector<int>> gr;
+            std::vector<int> grTask;
             std::exception_ptr err;
             std::thread th([&] {
                 try {
-                    split(right, gr, depth + 1);
+                    split(right, gr, grTask, depth + 1, -1);
                 }
                 catch (...) {
                     err = std::current_exception();
                 }
             });
-            split(left, out, depth + 1);
+            split(left, out, outTask, depth + 1, -1);
             th.join();
             if (err) std::rethrow_exception(err);
             for (auto& grp : gr) out.push_back(std::move(grp));
+            outTask.insert(outTask.end(), grTask.begin(), grTask.end());
         }
         else {
-            split(left, out, depth + 1);
-            split(right, out, depth + 1);
+            if (task < 0) task = task_++; // from here down one thread
+            split(left, out, outTask, depth + 1, task);
+            split(right, out, outTask, depth + 1, task);
         }
-        if (!sepCopy.empty()) out.push_back(std::move(sepCopy));
+        if (!sepCopy.empty()) {
+            out.push_back(std::move(sepCopy));
+            outTask.push_back(task);
+        }
     }
 };
 
@@ -280,7 +323,8 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     lap("node graph");
     o.nn = g.nn;
     Dissector nd(g, coords, leafSize);
-    std::vector<std::vector<int>> groups = nd.run();
+    std::vector<int> taskOf;
+    std::vector<std::vector<int>> groups = nd.run(taskOf);
     lap("nested dissection");
     o.ns = (int)groups.size();
     o.newOf.assign(o.nn, -1);
@@ -301,35 +345,90 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     o.firstNode[o.ns] = next;
     if (next != o.nn) throw std::logic_error("mf_analyze: ordering lost nodes");
 
-    // symbolic factorisation on the front level: struct(s) = (adj(s) U struct(children)) \ {nodes < end(s)}
+    // symbolic factorisation on the front level: struct(s) = (adj(s) U struct(children)) \ {nodes < end(s)}.
+    // The subproblems the dissection ran on one thread each (taskOf) are closed under "child of": a front in one of them has its structure
+    // inside the subproblem or in the separators above it, so its parent is never a front of another subproblem.  They are built on
+    // separate threads (own stamp array; children whose parent lies above the subproblem are handed over afterwards); the separators above
+    // follow in order.  Should a parent ever turn up inside another subproblem, everything is redone on one thread.
     std::vector<std::vector<int>> st(o.ns), kids(o.ns);
     o.parent.assign(o.ns, -1);
-    std::vector<int> stamp(o.nn, -1); // the children's structures overlap almost completely: dedupe before sorting
-    for (int s = 0; s < o.ns; ++s) {
-        const int end = o.firstNode[s + 1];
-        std::vector<int>& r = st[s];
-        for (int v = o.firstNode[s]; v < end; ++v) {
-            const int ov = o.oldOf[v];
-            for (int k = g.ptr[ov]; k < g.ptr[ov + 1]; ++k) {
-                const int w = o.newOf[g.adj[k]];
-                if (w >= end && stamp[w] != s) {
-                    stamp[w] = s;
-                    r.push_back(w);
+    auto buildRange = [&](int s0, int s1, bool all, std::vector<int>& stamp, std::vector<std::pair<int, int>>* handOver) {
+        // fronts [s0, s1) (all) or those of [s0, s1) with taskOf < 0
+        for (int s = s0; s < s1; ++s) {
+            if (!all && taskOf[s] >= 0) continue;
+            const int end = o.firstNode[s + 1];
+            std::vector<int>& r = st[s];
+            r.clear();
+            for (int v = o.firstNode[s]; v < end; ++v) {
+                const int ov = o.oldOf[v];
+                for (int k = g.ptr[ov]; k < g.ptr[ov + 1]; ++k) {
+                    const int w = o.newOf[g.adj[k]];
+                    if (w >= end && stamp[w] != s) {
+                        stamp[w] = s;
+                        r.push_back(w);
+                    }
                 }
             }
+            for (int c : kids[s])
+                for (int w : st[c])
+                    if (w >= end && stamp[w] != s) {
+                        stamp[w] = s;
+                        r.push_back(w);
+                    }
+            std::sort(r.begin(), r.end());
+            if (!r.empty()) {
+                const int p = frontOfNode[r[0]];
+                o.parent[s] = p;
+                if (handOver && p >= s1) handOver->emplace_back(p, s);
+                else kids[p].push_back(s);
+            }
         }
-        for (int c : kids[s])
-            for (int w : st[c])
-                if (w >= end && stamp[w] != s) {
-                    stamp[w] = s;
-                    r.push_back(w);
-                }
-        std::sort(r.begin(), r.end());
-        if (!r.empty()) {
-            o.parent[s] = frontOfNode[r[0]];
-            kids[o.parent[s]].push_back(s);
+    };
+    std::vector<std::pair<int, int>> ranges; // [first, end) of the single-thread subproblems
+    for (int s = 0; s < o.ns;) {
+        int e = s + 1;
+        if (taskOf[s] >= 0) {
+            while (e < o.ns && taskOf[e] == taskOf[s]) ++e;
+            ranges.emplace_back(s, e);
         }
+        s = e;
     }
+    bool closed = true;
+    if (ranges.size() > 1) {
+        std::vector<std::vector<std::pair<int, int>>> handOver(ranges.size());
+        std::vector<std::thread> pool;
+        std::exception_ptr err;
+        std::mutex errLock;
+        for (size_t t = 0; t < ranges.size(); ++t)
+            pool.emplace_back([&, t] {
+                try {
+                    std::vector<int> stamp(o.nn, -1);
+                    buildRange(ranges[t].first, ranges[t].second, true, stamp, &handOver[t]);
+                }
+                catch (...) {
+                    std::lock_guard<std::mutex> lk(errLock);
+                    err = std::current_exception();
+                }
+            });
+        for (auto& th : pool) th.join();
+        if (err) std::rethrow_exception(err);
+        for (auto& h : handOver)
+            for (auto& pc : h) {
+                if (taskOf[pc.first] >= 0) closed = false; // parent inside another subproblem: that front was built without this child
+                kids[pc.first].push_back(pc.second);
+            }
+    }
+    std::vector<int> stamp(o.nn, -1); // the children's structures overlap almost completely: dedupe before sorting
+    if (closed && ranges.size() > 1) {
+        buildRange(0, o.ns, false, stamp, nullptr);
+        for (auto& k : kids) std::sort(k.begin(), k.end()); // ascending, as a single pass over the fronts lists them
+    }
+    else {
+        for (auto& k : kids) k.clear();
+        o.parent.assign(o.ns, -1);
+        buildRange(0, o.ns, true, stamp, nullptr);
+    }
+    if (timeIt) fprintf(stderr, "mf analyze   (%d fronts, %zu single-thread subproblems, closed %d)\n", o.ns, ranges.size(), (int)closed);
     lap("front structures");
     o.level.assign(o.ns, 0);
     int maxLevel = 0;
@@ -459,7 +558,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
             }
         }
         };
-        const int nThreads = std::max(1, std::min(8, (int)std::thread::hardware_concurrency()));
+        const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
         std::vector<std::thread> pool;
         std::exception_ptr err;
         std::mutex errLock;
