@@ -64,6 +64,12 @@ HipOptimizer& O(ipcgpu_ctx* c)
     return *c->opt;
 }
 void bind(ipcgpu_ctx* c) { HIP_CHECK(hipSetDevice(c->device)); }
+// Every entry point that changes what the next assembly depends on (positions, constraints, material, time step, ...) calls this first: the stepper
+// may hold an assembly it enqueued ahead for the state it had (HipOptimizer::speculativeAssembly), and that one must not be swapped in afterwards.
+void specChanged(ipcgpu_ctx* c)
+{
+    if (c && c->opt) c->opt->specAsmValid = false;
+}
 // contact-pair lists shard with the elements (ipcgpu_ctx_set_shard): the handler is created lazily, so both places call this
 void applyContactShard(ipcgpu_ctx* c)
 {
@@ -183,6 +189,7 @@ int ipcgpu_set_mesh(ipcgpu_ctx* c, int nV, int nT, const double* Vr, const int* 
 }
 int ipcgpu_set_component_material(ipcgpu_ctx* c, int nodeBegin, int nodeEnd, int tetBegin, int tetEnd, double rho, double YM, double PR)
 {
+    specChanged(c);
     return guarded([&] {
         HipMesh& m = M(c);
         bind(c);
@@ -247,6 +254,7 @@ int ipcgpu_save_tet_mesh(const char* path, int nV, int nT, const double* V, cons
 }
 int ipcgpu_set_energy_type(ipcgpu_ctx* c, int energyType)
 {
+    specChanged(c);
     return guarded([&] {
         HipMesh& m = M(c);
         needArg(energyType == 0 || energyType == 1, "energy type: 0 = NH, 1 = FCR");
@@ -256,6 +264,7 @@ int ipcgpu_set_energy_type(ipcgpu_ctx* c, int energyType)
 }
 int ipcgpu_set_dbc(ipcgpu_ctx* c, int n, const int* ids, int type)
 {
+    specChanged(c);
     return guarded([&] {
         HipMesh& m = M(c);
         bind(c);
@@ -270,6 +279,7 @@ int ipcgpu_set_dbc(ipcgpu_ctx* c, int n, const int* ids, int type)
 }
 int ipcgpu_clear_dbc(ipcgpu_ctx* c)
 {
+    specChanged(c);
     return guarded([&] {
         HipMesh& m = M(c);
         bind(c);
@@ -280,12 +290,12 @@ int ipcgpu_clear_dbc(ipcgpu_ctx* c)
 }
 int ipcgpu_set_positions(ipcgpu_ctx* c, const double* V)
 {
+    specChanged(c);
     return guarded([&] {
         M(c);
         bind(c);
         needArg(V != nullptr, "null V");
         uploadColMajor(c, V, c->mesh->d_x);
-        if (c->opt) c->opt->specAsmValid = false; // (an assembly enqueued ahead for the old positions)
         return IPCGPU_OK;
     });
 }
@@ -301,6 +311,7 @@ int ipcgpu_get_positions(ipcgpu_ctx* c, double* V)
 }
 int ipcgpu_set_xtilde(ipcgpu_ctx* c, const double* V)
 {
+    specChanged(c);
     return guarded([&] {
         M(c);
         bind(c);
@@ -334,6 +345,7 @@ int ipcgpu_get_mesh_dims(ipcgpu_ctx* c, int* nV, int* nT)
 }
 int ipcgpu_set_mesh_features(ipcgpu_ctx* c, const double* A, const double* vol, const double* mass, const double* mu, const double* lam)
 {
+    specChanged(c);
     return guarded([&] {
         bind(c);
         HipMesh& m = M(c);
@@ -660,6 +672,7 @@ static HipContact& CT(ipcgpu_ctx* c)
 }
 int ipcgpu_set_surface(ipcgpu_ctx* c, int nSF, const int* SF)
 {
+    specChanged(c);
     return guarded([&] {
         HipMesh& m = M(c);
         bind(c);
@@ -671,6 +684,7 @@ int ipcgpu_set_surface(ipcgpu_ctx* c, int nSF, const int* SF)
 }
 int ipcgpu_set_surface_codim(ipcgpu_ctx* c, int nSF, const int* SF, int nCE, const int* CE)
 {
+    specChanged(c);
     return guarded([&] {
         HipMesh& m = M(c);
         bind(c);
@@ -683,6 +697,7 @@ int ipcgpu_set_surface_codim(ipcgpu_ctx* c, int nSF, const int* SF, int nCE, con
 }
 int ipcgpu_set_exact_predicates(ipcgpu_ctx* c, int on)
 {
+    specChanged(c);
     return guarded([&] {
         CT(c).exactPredicates = on != 0;
         return IPCGPU_OK;
@@ -724,6 +739,7 @@ int ipcgpu_contact_build(ipcgpu_ctx* c, double dHat, int* counts)
 }
 int ipcgpu_set_codim_nodes(ipcgpu_ctx* c, int n, const int* ids, const double* mass)
 {
+    specChanged(c);
     return guarded([&] {
         HipMesh& m = M(c);
         bind(c);
@@ -735,6 +751,7 @@ int ipcgpu_set_codim_nodes(ipcgpu_ctx* c, int n, const int* ids, const double* m
 }
 int ipcgpu_set_obstacle_nodes(ipcgpu_ctx* c, int n, const int* ids, int only)
 {
+    specChanged(c);
     return guarded([&] {
         bind(c);
         HipContact& k = CT(c);
@@ -862,6 +879,7 @@ int ipcgpu_ccd_full_reference(ipcgpu_ctx* c, const double* p, double slackness, 
 }
 int ipcgpu_set_ccd_mode(ipcgpu_ctx* c, int mode)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(mode == 0 || mode == 1, "ccd mode is 0 (swept boxes, PT / EE pairs) or 1 (the reference's sweep)");
         CT(c).ccdMode = mode;
@@ -937,6 +955,7 @@ int ipcgpu_opt_init(ipcgpu_ctx* c, double dt, int withGravity)
 }
 int ipcgpu_opt_set_rel_tol(ipcgpu_ctx* c, double tol)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(tol > 0, "relTol must be positive"); // Optimizer.cpp:392
         O(c).setRelGL2Tol(tol);
@@ -945,6 +964,7 @@ int ipcgpu_opt_set_rel_tol(ipcgpu_ctx* c, double tol)
 }
 int ipcgpu_opt_set_twist(ipcgpu_ctx* c, int nL, const int* l, int nR, const int* r, double angVel)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1064,6 +1084,7 @@ int ipcgpu_halfspace_step_bound(ipcgpu_ctx* c, int id, const double* p, double s
 }
 int ipcgpu_opt_set_friction(ipcgpu_ctx* c, double selfFric, int fricIterAmt, double epsV)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         needArg(selfFric >= 0.0 && epsV > 0.0, "bad friction parameters");
@@ -1075,6 +1096,7 @@ int ipcgpu_opt_set_friction(ipcgpu_ctx* c, double selfFric, int fricIterAmt, dou
 }
 int ipcgpu_opt_set_friction_target(ipcgpu_ctx* c, double epsVTarget)
 {
+    specChanged(c);
     return guarded([&] {
         O(c).epsVTarget = epsVTarget > 0.0 ? epsVTarget : -1.0;
         return IPCGPU_OK;
@@ -1082,6 +1104,7 @@ int ipcgpu_opt_set_friction_target(ipcgpu_ctx* c, double epsVTarget)
 }
 int ipcgpu_opt_set_constructor_dt(ipcgpu_ctx* c, double h)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(h > 0.0, "the step size must be positive");
         O(c).ctorDt = h;
@@ -1090,6 +1113,7 @@ int ipcgpu_opt_set_constructor_dt(ipcgpu_ctx* c, double h)
 }
 int ipcgpu_opt_set_parameter_scaling(ipcgpu_ctx* c, int useAbsParameters, double dTolRel, double kappaMinMultiplier)
 {
+    specChanged(c);
     return guarded([&] {
         O(c).setParameterScaling(useAbsParameters != 0, dTolRel, kappaMinMultiplier);
         return IPCGPU_OK;
@@ -1097,6 +1121,7 @@ int ipcgpu_opt_set_parameter_scaling(ipcgpu_ctx* c, int useAbsParameters, double
 }
 int ipcgpu_opt_set_kappa(ipcgpu_ctx* c, double kappa)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(kappa >= 0.0, "negative barrier stiffness");
         O(c).kappaConfig = kappa;
@@ -1105,6 +1130,7 @@ int ipcgpu_opt_set_kappa(ipcgpu_ctx* c, double kappa)
 }
 int ipcgpu_opt_set_dhat_target(ipcgpu_ctx* c, double dHatTargetEps)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(dHatTargetEps == dHatTargetEps, "dHat target is not a number");
         O(c).dHatTargetEps = dHatTargetEps;
@@ -1113,6 +1139,7 @@ int ipcgpu_opt_set_dhat_target(ipcgpu_ctx* c, double dHatTargetEps)
 }
 int ipcgpu_opt_set_damping(ipcgpu_ctx* c, double dampingStiff)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(dampingStiff == dampingStiff, "damping stiffness is not a number");
         O(c).setDamping(dampingStiff);
@@ -1121,6 +1148,7 @@ int ipcgpu_opt_set_damping(ipcgpu_ctx* c, double dampingStiff)
 }
 int ipcgpu_opt_set_friction_scales(ipcgpu_ctx* c, double scaleSelf, double scaleObstacle)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(scaleSelf >= 0.0 && scaleObstacle >= 0.0, "friction scales must not be negative");
         CT(c).fricScaleSelf = scaleSelf;
@@ -1137,6 +1165,7 @@ int ipcgpu_opt_force_friction_loop(ipcgpu_ctx* c, int on)
 }
 int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx* c, int id, double mu)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(mu >= 0.0, "negative friction coefficient");
         HS(c, id).friction = mu;
@@ -1233,6 +1262,7 @@ int ipcgpu_friction_hessian_add(ipcgpu_ctx* c, const double* Vt, double eps2, do
 }
 int ipcgpu_opt_set_velocity(ipcgpu_ctx* c, const double* vel)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1244,6 +1274,7 @@ int ipcgpu_opt_set_velocity(ipcgpu_ctx* c, const double* vel)
 }
 int ipcgpu_opt_set_warm_start(ipcgpu_ctx* c, int option)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         needArg(option >= 0 && option <= 5, "warmStart option must be 0..5");
@@ -1260,6 +1291,7 @@ int ipcgpu_opt_get_warm_step(ipcgpu_ctx* c, double* out)
 }
 int ipcgpu_opt_set_time_integration(ipcgpu_ctx* c, int type, double beta, double gamma)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1294,6 +1326,7 @@ int ipcgpu_opt_end_dirichlet(ipcgpu_ctx* c, int group, double t_end)
 }
 int ipcgpu_opt_set_dirichlet_motion(ipcgpu_ctx* c, int group, const double* lin3, const double* ang3, const double* center3, int forceNonzero)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1313,6 +1346,7 @@ int ipcgpu_opt_set_dirichlet_motion(ipcgpu_ctx* c, int group, const double* lin3
 }
 int ipcgpu_opt_set_dirichlet_targets(ipcgpu_ctx* c, int group, int n, const double* targets)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1374,6 +1408,7 @@ int ipcgpu_opt_save_status(ipcgpu_ctx* c, const char* path)
 }
 int ipcgpu_opt_load_status(ipcgpu_ctx* c, const char* path)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);

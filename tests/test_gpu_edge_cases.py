@@ -82,3 +82,36 @@ def test_errors_come_back_as_status_codes(gpu_lib, tmp_path):
     with pytest.raises(gpu_lib.IpcGpuError):
         c.begin_timestep()  # before precompute
     c.close()
+
+
+def test_a_setter_between_newton_iterations_discards_the_assembly_enqueued_ahead(orc, gpu_lib):
+    """On the contact-free path the stepper enqueues the next iteration's assembly behind an accepted trial (HipOptimizer::speculativeAssembly).
+    A caller that changes the constraints between two ipcgpu_opt_newton_iter calls must get an assembly of the NEW state: same iterates as the
+    oracle driven the same way (a stale assembly would project the Dirichlet rows of the old node set)."""
+    V, F = scene.make_mat(10)
+    X = scene.jitter(V, F, rel=5e-2)
+    left = np.where(V[:, 0] < -0.49)[0].astype(np.int32)
+    right = np.where(V[:, 0] > 0.49)[0].astype(np.int32)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_V(X)
+    m.set_dbc(left, 1)
+    o = orc.Optimizer(m, dt=0.01, gravity=True, nthreads=1)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.set_positions(X)
+    c.set_dbc(left, 1)
+    c.opt_init(0.01, True)
+    o.precompute()
+    c.precompute()
+    o.begin_timestep()
+    c.begin_timestep()
+    for _ in range(2):
+        assert bool(o.newton_iter()) == bool(c.newton_iter())
+    m.clear_dbc()
+    m.set_dbc(right, 1)
+    c.clear_dbc()
+    c.set_dbc(right, 1)
+    for _ in range(3):
+        assert bool(o.newton_iter()) == bool(c.newton_iter())
+        assert relerr(c.state()["V"], o.state()["V"]) < 1e-9
+    c.close()
