@@ -153,8 +153,41 @@ private:
     int markOf(int v) const { return mark_[v].load(std::memory_order_relaxed); }
     void setMark(int v, int t) { mark_[v].store(t, std::memory_order_relaxed); }
 
-    // key_[v] = coordinate along the longest bbox axis (geometric) or BFS depth from a pseudo-peripheral node
-    void compute_keys(const std::vector<int>& S, int t)
+    // Per axis, the smallest and largest coordinate among a node's neighbours (whole graph): a node whose neighbours all lie on its own side of the
+    // cut plane cannot be on the boundary of the cut, and that is nearly every node -- the adjacency scan of the separator search then only runs for
+    // the few next to the plane.  (A necessary condition only: the separators are the same sets as without it.)  Built on first use of an axis.
+    std::vector<double> nbMin_[3], nbMax_[3];
+    std::once_flag nbOnce_[3];
+    void ensureNeighbourRange(int ax)
+    {
+        std::call_once(nbOnce_[ax], [&] {
+            const int nn = g_.nn;
+            nbMin_[ax].resize(nn);
+            nbMax_[ax].resize(nn);
+            const int nThreads = nn < 16384 ? 1 : std::max(1, std::min(4, (int)std::thread::hardware_concurrency()));
+            auto range = [&](int t) {
+                for (int v = (int)((int64_t)nn * t / nThreads); v < (int)((int64_t)nn * (t + 1) / nThreads); ++v) {
+                    double mn = 1e300, mx = -1e300;
+                    for (int k = g_.ptr[v]; k < g_.ptr[v + 1]; ++k) {
+                        const double c = xyz_[3 * (size_t)g_.adj[k] + ax];
+                        mn = std::min(mn, c);
+                        mx = std::max(mx, c);
+                    }
+                    nbMin_[ax][v] = mn;
+                    nbMax_[ax][v] = mx;
+                }
+            };
+            if (nThreads == 1) range(0);
+            else {
+                std::vector<std::thread> pool;
+                for (int t = 0; t < nThreads; ++t) pool.emplace_back(range, t);
+                for (auto& th : pool) th.join();
+            }
+        });
+    }
+
+    // key_[v] = coordinate along the longest bbox axis (geometric) or BFS depth from a pseudo-peripheral node; returns the axis, -1 for BFS keys
+    int compute_keys(const std::vector<int>& S, int t)
     {
         if (xyz_) {
             double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
@@ -167,12 +200,13 @@ private:
             for (int c = 1; c < 3; ++c)
                 if (hi[c] - lo[c] > hi[ax] - lo[ax]) ax = c;
             for (int v : S) key_[v] = xyz_[3 * (size_t)v + ax];
-            return;
+            return ax;
         }
         std::vector<int> order;
         bfs(S, S[0], t, order);
         int far = order.back();
         bfs(S, far, t, order);
+        return -1;
     }
     void bfs(const std::vector<int>& S, int start, int t, std::vector<int>& order)
     {
@@ -211,7 +245,7 @@ private:
         }
         const int t = ++tag_;
         for (int v : S) setMark(v, t);
-        compute_keys(S, t);
+        const int ax = compute_keys(S, t);
         // median cut on the key; ties (same BFS level / same coordinate plane) stay on one side.  left = { key < kcut }.
         // The result depends on S only as a set, so the geometric case avoids the full sort: median by selection (O(n)), one
         // counting pass for the tie range, one classification pass.  (BFS keys depend on the traversal start, i.e. on the
@@ -246,11 +280,26 @@ private:
             return;
         }
         auto isLeftOf = [&](int v) { return cutBelow ? key_[v] < kmid : key_[v] <= kmid; };
+        // can v have a neighbour on the other side at all?  (geometric keys: from the coordinate range of its neighbours; BFS keys: neighbours are at
+        // most one level apart)
+        const double* nbMin = nullptr;
+        const double* nbMax = nullptr;
+        if (ax >= 0) {
+            ensureNeighbourRange(ax);
+            nbMin = nbMin_[ax].data();
+            nbMax = nbMax_[ax].data();
+        }
+        auto mayTouch = [&](int v, bool isLeft) {
+            if (ax < 0) return std::fabs(key_[v] - kmid) <= 1.0;
+            if (isLeft) return cutBelow ? nbMax[v] >= kmid : nbMax[v] > kmid;
+            return cutBelow ? nbMin[v] < kmid : nbMin[v] <= kmid;
+        };
         // vertex separator: the smaller of the two one-sided boundaries
         std::vector<int> bl, br;
         for (size_t i = 0; i < sorted.size(); ++i) {
             int v = sorted[i];
             const bool isLeft = isLeftOf(v);
+            if (!mayTouch(v, isLeft)) continue;
             bool touches = false;
             for (int k = g_.ptr[v]; k < g_.ptr[v + 1] && !touches; ++k) {
                 int w = g_.adj[k];
