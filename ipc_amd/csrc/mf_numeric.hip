@@ -2619,47 +2619,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     owner_.assign(ns_, rank_);
     sharedFlops_ = 0.0;
     if (world_ > 1) {
-        std::vector<double> own(ns_, 0.0), cost(ns_, 0.0);
-        for (int s = 0; s < ns_; ++s) {
-            const double N = sym.N(s), nc = sym.nc(s);
-            for (int j = 0; j < (int)nc; ++j) own[s] += (N - j - 1) * (N - j - 1);
-            cost[s] += own[s];
-            if (sym.parent[s] >= 0) cost[sym.parent[s]] += cost[s]; // children precede their parent in the elimination order
-        }
-        std::vector<int> frontier;
-        for (int s = 0; s < ns_; ++s)
-            if (sym.parent[s] < 0) frontier.push_back(s);
-        std::vector<char> shared(ns_, 0);
-        while ((int)frontier.size() < world_) { // open the most expensive subtree that still has children
-            int best = -1;
-            for (size_t i = 0; i < frontier.size(); ++i) {
-                const int f = frontier[i];
-                if (sym.childPtr[f + 1] > sym.childPtr[f] && (best < 0 || cost[f] > cost[frontier[best]])) best = (int)i;
-            }
-            if (best < 0) break;
-            const int f = frontier[best];
-            frontier.erase(frontier.begin() + best);
-            shared[f] = 1;
-            for (int q = sym.childPtr[f]; q < sym.childPtr[f + 1]; ++q) frontier.push_back(sym.child[q]);
-        }
-        std::sort(frontier.begin(), frontier.end(), [&](int a, int b) { return cost[a] > cost[b] || (cost[a] == cost[b] && a < b); });
-        std::vector<double> load(world_, 0.0);
-        std::vector<int> rootOwner(ns_, -1);
-        for (int f : frontier) {
-            const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
-            load[r] += cost[f];
-            rootOwner[f] = r;
-        }
-        // fronts in descending order: a front inherits its parent's owner unless it is a subtree root or above the cut
-        double tot = 0.0, sh = 0.0;
-        for (int s = ns_ - 1; s >= 0; --s) {
-            if (shared[s]) owner_[s] = -1;
-            else if (rootOwner[s] >= 0) owner_[s] = rootOwner[s];
-            else owner_[s] = owner_[sym.parent[s]];
-            tot += own[s];
-            if (shared[s]) sh += own[s];
-        }
-        sharedFlops_ = tot > 0 ? sh / tot : 0.0;
+        sharedFlops_ = mf_assign_owners(sym, world_, owner_); // host logic, shared with the CPU tests of the protocol (mf_symbolic.cpp)
         // exchange lists: subtree roots whose parent is above the cut, by level
         xchg_.assign(nLevels_, Xchg());
         std::vector<int4> xd;

@@ -631,6 +631,54 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     lap("entry destinations");
 }
 
+double mf_assign_owners(const MfSymbolic& sym, int world, std::vector<int>& owner)
+{
+    const int ns = sym.ns;
+    owner.assign(ns, 0);
+    if (world <= 1) return 0.0;
+    std::vector<double> own(ns, 0.0), cost(ns, 0.0);
+    for (int s = 0; s < ns; ++s) {
+        const double N = sym.N(s), nc = sym.nc(s);
+        for (int j = 0; j < (int)nc; ++j) own[s] += (N - j - 1) * (N - j - 1);
+        cost[s] += own[s];
+        if (sym.parent[s] >= 0) cost[sym.parent[s]] += cost[s]; // children precede their parent in the elimination order
+    }
+    std::vector<int> frontier;
+    for (int s = 0; s < ns; ++s)
+        if (sym.parent[s] < 0) frontier.push_back(s);
+    std::vector<char> shared(ns, 0);
+    while ((int)frontier.size() < world) { // open the most expensive subtree that still has children
+        int best = -1;
+        for (size_t i = 0; i < frontier.size(); ++i) {
+            const int f = frontier[i];
+            if (sym.childPtr[f + 1] > sym.childPtr[f] && (best < 0 || cost[f] > cost[frontier[best]])) best = (int)i;
+        }
+        if (best < 0) break;
+        const int f = frontier[best];
+        frontier.erase(frontier.begin() + best);
+        shared[f] = 1;
+        for (int q = sym.childPtr[f]; q < sym.childPtr[f + 1]; ++q) frontier.push_back(sym.child[q]);
+    }
+    std::sort(frontier.begin(), frontier.end(), [&](int a, int b) { return cost[a] > cost[b] || (cost[a] == cost[b] && a < b); });
+    std::vector<double> load(world, 0.0);
+    std::vector<int> rootOwner(ns, -1);
+    for (int f : frontier) {
+        const int r = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[r] += cost[f];
+        rootOwner[f] = r;
+    }
+    // fronts in descending order: a front inherits its parent's owner unless it is a subtree root or above the cut
+    double tot = 0.0, sh = 0.0;
+    for (int s = ns - 1; s >= 0; --s) {
+        if (shared[s]) owner[s] = -1;
+        else if (rootOwner[s] >= 0) owner[s] = rootOwner[s];
+        else owner[s] = owner[sym.parent[s]];
+        tot += own[s];
+        if (shared[s]) sh += own[s];
+    }
+    return tot > 0 ? sh / tot : 0.0;
+}
+
 void mf_L_pattern_csr(const MfSymbolic& sym, std::vector<int>& ptrT, std::vector<int>& indT, std::vector<int>& pivQ)
 {
     const int n = sym.n;

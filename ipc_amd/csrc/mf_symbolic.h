@@ -38,6 +38,12 @@ struct MfSymbolic {
 // geometric bisection (rest positions); when null the bisection direction is a BFS level structure.
 void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int leafSize, MfSymbolic& out);
 
+// Multi-GPU: cut the assembly tree below its top separators.  The most expensive subtree that still has children is opened until there are at least `world`
+// subtree roots; those go to the ranks greedily by factorisation cost (largest first, least-loaded rank), every front below a root inherits its rank,
+// the opened fronts above the cut are shared (owner -1: every rank factorises them redundantly from exchanged update matrices).  Returns the share of the
+// factorisation flops above the cut.  world <= 1: every front owned by rank 0.
+double mf_assign_owners(const MfSymbolic& sym, int world, std::vector<int>& owner);
+
 // scalar CSR pattern of L (lower triangle incl. diagonal, rows sorted) in the permuted ordering plus the
 // scalar permutation pivQ (new -> old) -- what rocsolver_dcsrrf_analysis expects as T and pivQ.
 void mf_L_pattern_csr(const MfSymbolic& sym, std::vector<int>& ptrT, std::vector<int>& indT, std::vector<int>& pivQ);

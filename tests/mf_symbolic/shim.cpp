@@ -33,3 +33,13 @@ extern "C" void shim_fetch(int* newOf, int* firstNode, int* parent, int* idxPtr,
     cp(aFront, g_sym.aFront);
     cp(frontOff, g_sym.frontOff);
 }
+// owner of every front (rank, -1 above the cut) and of every node (old numbering) for `world` ranks; returns the share of the flops above the cut
+extern "C" double shim_owners(int world, int* frontOwner, int* nodeOwner)
+{
+    std::vector<int> owner;
+    const double shared = mf_assign_owners(g_sym, world, owner);
+    std::copy(owner.begin(), owner.end(), frontOwner);
+    for (int s = 0; s < g_sym.ns; ++s)
+        for (int v = g_sym.firstNode[s]; v < g_sym.firstNode[s + 1]; ++v) nodeOwner[g_sym.oldOf[v]] = owner[s];
+    return shared;
+}

@@ -93,3 +93,106 @@ def test_patch_shards_partition_every_patch_once():
             for r in range(w):
                 cover += list(range(n * r // w, n * (r + 1) // w))
             assert cover == list(range(n))
+
+
+# ---- owner-computes (round 4): a rank assembles the complete CSR rows of the nodes its subtrees eliminate plus the separator rows above the cut; its fronts
+# read nothing else, so NO matrix value crosses ranks; the gradient is exchanged once, every node contributed by its designated rank.
+# (HipOptimizer::ensureOwnerPlan / computePrecondMtr, MfNumeric::setup.)  The analysis and the owner assignment are the product's own host code
+# (mf_symbolic.cpp through tests/mf_symbolic/shim.cpp); the CPU oracle's assembly stands in for a rank's kernels, masked to the rows that rank writes.
+def _shim_lib():
+    import ctypes as C
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, "mf_symbolic", "_build", "libmfsym.so")
+    srcs = [os.path.join(here, "mf_symbolic", "shim.cpp"), os.path.join(os.path.dirname(here), "ipc_amd", "csrc", "mf_symbolic.cpp")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+        os.makedirs(os.path.dirname(so), exist_ok=True)
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread"] + srcs + ["-o", so])
+    return C.CDLL(so)
+
+
+def _owner_plan(world, rank):
+    """what one rank knows: mesh, pattern, analysis, owners (all deterministic: every rank computes the same), its masks, its rows"""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import orc
+    from test_mf_symbolic import analyze
+    V, F, nA = scene.make_mat_stack(14, 2, gap=1.2e-3)
+    X = scene.jitter(V, F, rel=3e-2)
+    nn = V.shape[0]
+    low = np.arange(nA)[V[:nA, 1] > V[:nA, 1].mean()]
+    up = nA + np.arange(nn - nA)[V[nA:, 1] < V[nA:, 1].mean()]
+    k = min(len(low), len(up))
+    pairs = np.stack([low[:k], up[:k]], 1).astype(np.int32)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    m.set_dbc(np.where(V[:, 0] < -0.49)[0].astype(np.int32), 1)
+    m.set_V(X)
+    ia, ja = m.pattern(extra_edges=pairs)
+    ia, ja = np.ascontiguousarray(ia, np.int32), np.ascontiguousarray(ja, np.int32)
+    L = _shim_lib()
+    L.shim_owners.restype = C.c_double
+    o = analyze(L, ia, ja, np.ascontiguousarray(V, np.float64), 8)
+    frontOwner, nodeOwner = np.zeros(o["ns"], np.int32), np.zeros(nn, np.int32)
+    shared = L.shim_owners(C.c_int(world), frontOwner.ctypes.data_as(C.c_void_p), nodeOwner.ctypes.data_as(C.c_void_p))
+    need = (nodeOwner < 0) | (nodeOwner == rank)  # rows this rank assembles (HipOptimizer::ensureOwnerPlan)
+    mine = (nodeOwner == rank) | ((nodeOwner < 0) & (rank == 0))  # the rank that contributes a node to an exchange
+    a = m.assemble_hessian(len(ja), 0.01 ** 2, True)
+    g = m.elastic_gradient(0.01 ** 2, True)
+    rowNode = np.repeat(np.arange(nn), np.diff(ia)[0::3] + np.diff(ia)[1::3] + np.diff(ia)[2::3])
+    return dict(o=o, frontOwner=frontOwner, nodeOwner=nodeOwner, shared=shared, need=need, mine=mine, a=a, g=g, rowNode=rowNode, nn=nn, ja=ja)
+
+
+def _owner_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = _owner_plan(world, rank)
+    a, g, need, mine, rowNode = P["a"], P["g"], P["need"], P["mine"], P["rowNode"]
+    a_r = np.where(need[rowNode], a, 0.0)  # what this rank's assembly writes: complete rows of its nodes and of the shared separators, zeros elsewhere
+    g_r = np.where(np.repeat(need, 3), g.reshape(-1), 0.0)
+    # (1) everything the fronts this rank factorises read is already there, bit for bit -- nothing to exchange
+    fo = P["frontOwner"][P["o"]["aFront"]]
+    reads = (fo == rank) | (fo < 0)
+    complete = bool(np.array_equal(a_r[reads], a[reads]))
+    # (2) the gradient: every node contributed once, by its designated rank; ONE all-reduce of 3 nV doubles
+    tg = torch.from_numpy(np.where(np.repeat(mine, 3), g_r, 0.0))
+    wire = tg.numel() * 8
+    dist.all_reduce(tg, op=dist.ReduceOp.SUM)
+    designated = torch.from_numpy(mine.astype(np.float64))
+    dist.all_reduce(designated, op=dist.ReduceOp.SUM)
+    # (3) a consumer of the WHOLE matrix (HipOptimizer::completeMatrix): designated rows summed
+    ta = torch.from_numpy(np.where(mine[rowNode], a_r, 0.0))
+    dist.all_reduce(ta, op=dist.ReduceOp.SUM)
+    # (4) every entry is read by some rank's front
+    cover = torch.from_numpy(reads.astype(np.float64))
+    dist.all_reduce(cover, op=dist.ReduceOp.MAX)
+    res = dict(rank=rank, complete=complete, g_equal=bool(np.array_equal(tg.numpy(), g.reshape(-1))), once=bool((designated.numpy() == 1.0).all()),
+               a_equal=bool(np.array_equal(ta.numpy(), a)), covered=bool((cover.numpy() == 1.0).all()), wire=wire, nn=P["nn"],
+               rows=float(need.mean()), shared=float(P["shared"]), need_mine=bool((need | ~mine).all()))
+    out.put(res)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_owner_computes_protocol_on_gloo(world):
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_owner_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["complete"], f"rank {r['rank']}: a front of this rank reads a matrix entry the rank did not assemble"
+        assert r["g_equal"] and r["once"] and r["a_equal"] and r["covered"] and r["need_mine"]
+        assert r["wire"] == 3 * r["nn"] * 8  # the one exchange of the assembly: the gradient
+        assert 0.0 < r["shared"] < 0.9
+    # the ranks split the rows: each assembles its subtrees + the shared separators, far from everything at 4 ranks
+    assert sum(r["rows"] for r in res) < world * 0.95
+    assert max(r["rows"] for r in res) < (0.8 if world == 2 else 0.6)
