@@ -212,7 +212,10 @@ void HipLinSysSolver::analyze_pattern(const HipMesh* mesh)
             for (int c = 0; c < 3; ++c) coords[3 * (size_t)v + c] = mesh->V_rest[v + (size_t)mesh->nV * c];
         cptr = coords.data();
     }
-    int leaf = 8;
+    // leaf domains of at most 12 nodes (36 columns): one level less at the bottom of the tree than with 8 -- one launch less in the factorisation and in each sweep --
+    // and still a single-workgroup front in 64 KB of LDS.  Measured (profiles/r04_nd_leaf_size_ab.txt): mat150 5: 382, 6: 384, 8: 393, 10: 396, 12: 406, 14: 406, 16: 394,
+    // 20: 398 it/s; mat433 42.9 -> 43.7; contact bench 10.98 -> 10.78 ms per iteration.
+    int leaf = 12;
     if (const char* e = std::getenv("IPCGPU_ND_LEAF")) leaf = std::max(1, std::atoi(e));
     mf_analyze(numRows, ia.data(), ja.data(), cptr, leaf, sym_);
     ++analysisVersion;

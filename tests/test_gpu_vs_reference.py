@@ -26,9 +26,12 @@ GPU_MISMATCH_BUDGET = {
     "aligned_cubes_fric": 12,  # + friction: the resting steps take 2 iterations where the reference takes 1 (explained in round 3: from the reference's own status24 both take 1)
     "attach": 1,  # shipped scene `attach`: one count of the first contact step (restatement: none)
 }
-# ... and their end positions: the exactly aligned cubes sit in a symmetric configuration whose lateral drift is born from round-off; after 30 steps the HIP run
-# is 1.1 % of the scene's extent away from the reference's (restatement: inside 1 %)
-GPU_END_TOL = {"aligned_cubes": 2e-2, "aligned_cubes_fric": 2e-2}
+# ... and their end positions: the exactly aligned cubes sit in a symmetric configuration whose lateral drift is born from round-off at the impact of step 12 and
+# grows linearly from there.  Measured on the REFERENCE ITSELF (tools/masonry_perturb.py on 12_alignedCubes.txt, profiles/r04_aligned_cubes_reference_1ulp_perturbation.txt):
+# continued from its own status1 with ONE coordinate of one node moved by one ulp it ends 1.9e-2 of the scene's scale away from its own unperturbed run, with every
+# coordinate moved by a random +-1 ulp 1.7e-2 / 4.4e-3 / 2.6e-3 -- the end state of this scene is defined to about 2e-2, whoever computes it.  The HIP run ends 1.1e-2
+# (elimination order with leaf domains of 8 nodes) or 2.3e-2 (12 nodes, the default since round 4) from the reference's; the budget is 1.5 x the reference's own spread.
+GPU_END_TOL = {"aligned_cubes": 3e-2, "aligned_cubes_fric": 2e-2}
 GPU_RESTART_TOL = {"cubes_dhat_homotopy": 2e-7}  # the 30-39-iteration steps of the dHat homotopy: 1.16e-7 after four steps (restatement: 1e-7), every count equal
 
 

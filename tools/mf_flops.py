@@ -31,7 +31,7 @@ def main(n=150):
     Vr = np.ascontiguousarray(V, np.float64)
     out, chain = np.zeros(8), np.zeros(64, np.int32)
     L = lib()
-    nl = L.mf_flops_report(C.c_int(len(ia) - 1), ia.ctypes.data_as(C.c_void_p), ja.ctypes.data_as(C.c_void_p), Vr.ctypes.data_as(C.c_void_p), C.c_int(8), C.c_int(8),
+    nl = L.mf_flops_report(C.c_int(len(ia) - 1), ia.ctypes.data_as(C.c_void_p), ja.ctypes.data_as(C.c_void_p), Vr.ctypes.data_as(C.c_void_p), C.c_int(12), C.c_int(8),
                            out.ctypes.data_as(C.c_void_p), chain.ctypes.data_as(C.c_void_p), C.c_int(64))
     tot = out[1] + out[2] + out[3]
     print(f"mat{n}: {V.shape[0]} nodes, nnz(L) {int(out[6])}, total {out[0] / 1e9:.2f} GFLOP (classes sum {tot / 1e9:.2f})")
