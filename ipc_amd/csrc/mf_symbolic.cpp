@@ -9,6 +9,7 @@
 #include <numeric>
 #include <mutex>
 #include <stdexcept>
+#include <system_error>
 #include <thread>
 
 namespace ipcgpu {
@@ -19,6 +20,39 @@ struct Graph {
     int nn;
     std::vector<int> ptr, adj;
 };
+
+// body(0) ... body(n - 1) on n host threads (body(0) on the caller's).  A thread that cannot be started has its share run by the caller; the first exception
+// of any share is rethrown once every thread has been joined.
+template <class Body>
+void run_threads(int n, Body&& body)
+{
+    std::exception_ptr err;
+    std::mutex errLock;
+    auto guarded = [&](int t) {
+        try {
+            body(t);
+        }
+        catch (...) {
+            std::lock_guard<std::mutex> lk(errLock);
+            if (!err) err = std::current_exception();
+        }
+    };
+    std::vector<std::thread> pool;
+    pool.reserve(std::max(n - 1, 0));
+    std::vector<int> inlineShares;
+    for (int t = 1; t < n; ++t) {
+        try {
+            pool.emplace_back(guarded, t);
+        }
+        catch (const std::system_error&) {
+            inlineShares.push_back(t);
+        }
+    }
+    if (n > 0) guarded(0);
+    for (int t : inlineShares) guarded(t);
+    for (auto& th : pool) th.join();
+    if (err) std::rethrow_exception(err);
+}
 
 // Patterns built by LinSysSolver::set_pattern are block structured: the three scalar rows of a node list the same neighbour
 // blocks (row 3u + d is row 3u minus its first d entries).  Then row 3u alone gives the node graph, already sorted: the
@@ -46,15 +80,7 @@ Graph node_graph(int n, const int* ia, const int* ja)
         const int nThreads = nn < 4096 ? 1 : std::max(1, std::min(4, (int)std::thread::hardware_concurrency())); // starting a thread costs what 1 000 nodes do
         auto lo = [&](int t) { return (int)((int64_t)nn * t / nThreads); };
         std::vector<std::vector<int>> below(nThreads, std::vector<int>(nn, 0)); // below[t][w]: rows u of range t with w in row u (u < w)
-        auto parallel = [&](auto&& body) {
-            if (nThreads == 1) {
-                body(0);
-                return;
-            }
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nThreads; ++t) pool.emplace_back([&, t] { body(t); });
-            for (auto& th : pool) th.join();
-        };
+        auto parallel = [&](auto&& body) { run_threads(nThreads, body); };
         parallel([&](int t) {
             int* c = below[t].data();
             for (int u = lo(t); u < lo(t + 1); ++u)
@@ -177,12 +203,7 @@ private:
                     nbMax_[ax][v] = mx;
                 }
             };
-            if (nThreads == 1) range(0);
-            else {
-                std::vector<std::thread> pool;
-                for (int t = 0; t < nThreads; ++t) pool.emplace_back(range, t);
-                for (auto& th : pool) th.join();
-            }
+            run_threads(nThreads, range);
         });
     }
 
@@ -445,22 +466,10 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
     bool closed = true;
     if (ranges.size() > 1) {
         std::vector<std::vector<std::pair<int, int>>> handOver(ranges.size());
-        std::vector<std::thread> pool;
-        std::exception_ptr err;
-        std::mutex errLock;
-        for (size_t t = 0; t < ranges.size(); ++t)
-            pool.emplace_back([&, t] {
-                try {
-                    std::vector<int> stamp(o.nn, -1);
-                    buildRange(ranges[t].first, ranges[t].second, true, stamp, &handOver[t]);
-                }
-                catch (...) {
-                    std::lock_guard<std::mutex> lk(errLock);
-                    err = std::current_exception();
-                }
-            });
-        for (auto& th : pool) th.join();
-        if (err) std::rethrow_exception(err);
+        run_threads((int)ranges.size(), [&](int t) {
+            std::vector<int> stamp(o.nn, -1);
+            buildRange(ranges[t].first, ranges[t].second, true, stamp, &handOver[t]);
+        });
         for (auto& h : handOver)
             for (auto& pc : h) {
                 if (taskOf[pc.first] >= 0) closed = false; // parent inside another subproblem: that front was built without this child
@@ -608,21 +617,7 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
         }
         };
         const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-        std::vector<std::thread> pool;
-        std::exception_ptr err;
-        std::mutex errLock;
-        for (int t = 0; t < nThreads; ++t)
-            pool.emplace_back([&, t] {
-                try {
-                    fillRange((int)((int64_t)o.nn * t / nThreads), (int)((int64_t)o.nn * (t + 1) / nThreads));
-                }
-                catch (...) {
-                    std::lock_guard<std::mutex> g(errLock);
-                    err = std::current_exception();
-                }
-            });
-        for (auto& th : pool) th.join();
-        if (err) std::rethrow_exception(err);
+        run_threads(nThreads, [&](int t) { fillRange((int)((int64_t)o.nn * t / nThreads), (int)((int64_t)o.nn * (t + 1) / nThreads)); });
     }
     else {
         for (int r = 0; r < n; ++r)
