@@ -178,6 +178,7 @@ def _owner_worker(rank, world, port, out):
 @pytest.mark.timeout(300)
 @pytest.mark.parametrize("world", [2, 4])
 def test_owner_computes_protocol_on_gloo(world):
+    _shim_lib()  # built once here, not by the ranks side by side
     ctx = mp.get_context("spawn")
     out = ctx.Queue()
     port = _free_port()
