@@ -79,6 +79,7 @@ private:
         // round 4: on the levels whose pivot chain is long the update rides on the chain's launches in passes of a few panels (role S of k_big_step);
         // `schur` is then empty.  stepTop: the level's step launches carry roles C / S (k_big_step<true>)
         bool stepTop = false;
+        bool step2 = false; // the level's big fronts advance two panels per launch (k_big_step2, IPCGPU_MF_STEP2=1: written at the end of round 4, not yet run)
         bool fuseEA = false; // the level's Schur kernel gathers the children of the update block itself (k_big_schur64_ea); the extend-add only writes own columns
         Range fwdRect, bwdInit; // descriptors of the row-/column-parallel halves of the big-front solves
         Range bigTri; // into triList_: big fronts whose triangle is swept by one workgroup (no explicit inverse)
@@ -131,6 +132,7 @@ private:
     // launch (1 = one launch per step, as before round 4), IPCGPU_MF_STEP_MERGE_WGS = workgroups per launch at most
     int stepMerge_ = 1, stepMergeWgs_ = 1536; // OFF by default: measured slower than the launches it replaces (profiles/r04_merged_step_launches_ab.txt)
     DevBuf<int> stepCtr_;
+    bool step2_ = false; // IPCGPU_MF_STEP2
     bool borderXT_ = true; // role C keeps X^T beside X for coalesced operand loads (IPCGPU_MF_BORDER_XT=0: reads the column-major X)
     bool fuseEA_ = true; // IPCGPU_MF_FUSE_EA=0: extend-add of the whole front, then a read-modify-write Schur pass (rounds 1-3)
     int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)

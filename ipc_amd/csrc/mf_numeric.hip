@@ -1872,6 +1872,334 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
     }
 }
 
+// ---- big fronts: TWO 32-column panels per step launch (written at the end of round 4, after the GPU budget of the round was spent: compiles for gfx950,
+// NOT YET RUN -- off unless IPCGPU_MF_STEP2=1; DESIGN.md section 8, "what comes next").  A step launch of k_big_step is a kernel boundary (3.4 us) + a load
+// phase on data the previous launch wrote (~2 us) + the 32 x 32 pivot inverse (5.1 us) + row product and stores: 11.8 us per 32 columns, and the chain of
+// these launches is what a top level takes.  Here a launch advances by a PAIR Q = (Q1, Q2) of panels:
+//   role B' (b == -2): the pivot blocks of Q and the rows [Rb + a, Rb + a + 96) below them, Rb = kb1 + wq.  Every workgroup repeats the pivot work, as in
+//            k_big_step; nothing is exchanged between workgroups:
+//       S0  Lp(k, q) = F(kb1 + q, kb + k) (the rows of Q's 64 x 64 pivot block in the columns of the pair P before it) and the raw pivot block -> LDS
+//       S1  A11 -= Lp Lp^T on the three 16 x 16 tiles of Q1's pivot block                                   (row waves)
+//       S2  X1 = chol(A11)^-1                                                                               (pivot wave, 5 us)
+//           beside it: the other seven tiles of the 64 x 64 update; D(c, m) = raw(m, kb1 + c) - sum_k Lp(k, c) P(m, k) for the workgroup's rows m, c < 64
+//       S3  L21 = A21 X1^T (the rows of Q2's pivot block in Q1's columns: one 16 x 16 tile per wave, to LDS; workgroup 0 also writes it to the front);
+//           L(m, Q1) = D(., m)[0:32] X1^T -> front, kept in registers;  then A22 -= L21 L21^T
+//       S4  X2 = chol(A22)^-1                                                                               (pivot wave, 5 us)
+//           beside it: D(c, m)[32:64] -= sum_n L21(c, n) L(m, Q1)(n)
+//       S5  L(m, Q2) = D(., m)[32:64] X2^T -> front;  X1, X2 -> their dinv slots (workgroup 0)
+//   role A' (b >= 0): trailing tile (a, b) behind Q, F -= P_i P_j^T with all 64 columns of P, own columns (< nc) only.
+// desc = (first dinv block of the front, kb of P or -1, a, b) + (N, nc, front offset), as for k_big_step.  dinv slots, factor layout and everything
+// downstream (Schur complement, inverses, sweeps) are those of the 32-column steps.  The explicit inverses of fronts stepped this way grow by recursive
+// doubling behind the factorisation (no role C here yet).
+constexpr int LD2 = 2 * NB + 1; // padded leading dimension of the 64 x 64 blocks of role B'
+constexpr int MT2 = 2; // 16-row tiles per row wave
+constexpr int ROWS_B2 = 16 * MT2 * ROW_WAVES_B;
+constexpr int STEP2_LDS_B = (2 * (2 * NB) * LD2 + 2 * NB * LDX + NB * LDP) * (int)sizeof(double); // Lp, Aq, Xs1, Xs2, L21s
+constexpr int STEP2_LDS_A = 2 * (2 * NB) * TS * (int)sizeof(double); // As, Bs: 64 x TS each
+constexpr int STEP2_LDS = STEP2_LDS_B > STEP2_LDS_A ? STEP2_LDS_B : STEP2_LDS_A;
+
+__global__ __launch_bounds__(WGB) void k_big_step2(const int4* __restrict__ desc, double* __restrict__ fronts, double* __restrict__ dinv, int* __restrict__ flag)
+{
+    extern __shared__ double sm2[];
+    const int wg = blockIdx.x;
+    const int4 d = desc[2 * wg];
+    const int4 d2 = desc[2 * wg + 1];
+    const int N = d2.x, nc = d2.y;
+    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
+    const int tid = threadIdx.x;
+    constexpr int KW = 2 * NB; // columns of a pair
+    const int kb = d.y;
+    const int w = (kb >= 0) ? min(KW, nc - kb) : 0; // the pair P = [kb, kb + w) is final
+    const int kb1 = (kb >= 0) ? kb + w : 0;
+    const int wq = (kb1 < nc) ? min(KW, nc - kb1) : 0; // the pair Q = [kb1, kb1 + wq) is factored by this launch
+    const int w1 = min(NB, wq), w2 = wq - w1;
+    if (d.w >= 0) {
+        // ---- role A': F[i0.., j0..] -= P[i0..] P[j0..]^T behind Q, own columns (< nc) only (k_big_step's role A with 64 columns of P)
+        double(*As)[TS] = reinterpret_cast<double(*)[TS]>(sm2);
+        double(*Bs)[TS] = reinterpret_cast<double(*)[TS]>(sm2 + KW * TS);
+        const int M0 = kb1 + wq;
+        const int i0 = M0 + TS * d.z, j0 = M0 + TS * d.w;
+        constexpr int NLD = KW * TS / WGB;
+        double va[NLD], vb[NLD];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + WGB * it;
+            const int k = e / TS, i = e - k * TS;
+            const long long colOff = (long long)N * (kb + min(k, w - 1)); // role A' only exists behind a pair: w >= 1
+            va[it] = F[min(i0 + i, N - 1) + colOff];
+            vb[it] = F[min(j0 + i, N - 1) + colOff];
+        }
+        double old[4][4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+                old[ii][jj] = F[min(i0 + 4 * (tid & 15) + ii, N - 1) + (long long)N * min(j0 + 4 * (tid >> 4) + jj, N - 1)];
+#pragma unroll
+        for (int it = 0; it < NLD; ++it) {
+            const int e = tid + WGB * it;
+            const int k = e / TS, i = e - k * TS;
+            const bool kin = k < w;
+            As[k][i] = (kin && i0 + i < N) ? va[it] : 0.0;
+            Bs[k][i] = (kin && j0 + i < N) ? vb[it] : 0.0;
+        }
+        __syncthreads();
+        const int ty = tid & 15, tx = tid >> 4;
+        double acc[4][4];
+#pragma unroll
+        for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
+#pragma unroll 8
+        for (int k = 0; k < KW; ++k) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                av[ii] = As[k][4 * ty + ii];
+                bv[ii] = Bs[k][4 * tx + ii];
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int col = j0 + 4 * tx + jj;
+            if (col >= nc) continue; // columns >= nc form the Schur complement: one pass at the end (k_big_schur)
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+                const int row = i0 + 4 * ty + ii;
+                if (row < N && row >= col) F[row + (long long)N * col] = old[ii][jj] - acc[ii][jj];
+            }
+        }
+        return;
+    }
+    // ---- role B'
+    double* Lp = sm2; // Lp[k * LD2 + q] = F(kb1 + q, kb + k)
+    double* Aq = sm2 + KW * LD2; // Aq[c * LD2 + q] = pivot block of Q, entry (q, c), q >= c
+    double* Xs1 = sm2 + 2 * KW * LD2; // Xs[c * LDX + r] = X(r, c), X = chol(pivot block)^-1
+    double* Xs2 = Xs1 + NB * LDX;
+    double* L21s = Xs2 + NB * LDX; // L21s[c * LDP + q] = L(kb1 + 32 + q, kb1 + c)
+    const int wv = ((tid >> 6) - wg) & 3; // 0..2: row waves, 3: pivot wave (rotating with the workgroup: see k_big_step)
+    const int l = tid & 63, lo = l & 15, hi = l >> 4;
+    const int Rb = kb1 + wq; // first row below the pivot blocks of Q
+    const int Rw = Rb + d.z + 16 * MT2 * wv; // first row of this wave
+    const bool rowWave = wv < ROW_WAVES_B && Rw < N;
+    // the row waves' operands from the front are requested before anything else: D(c, m) starts as raw(m, kb1 + c); pv(m, k) = P(m, k)
+    f64x4 dt[MT2][4];
+    double pv[MT2][KW / 4];
+    if (rowWave) {
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+            const double* Fr = F + min(Rw + 16 * mt + lo, N - 1);
+#pragma unroll
+            for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = 16 * ct + hi + 4 * i;
+                    const double v = Fr[(long long)N * (kb1 + min(c, max(wq, 1) - 1))];
+                    dt[mt][ct][i] = (c < wq) ? v : 0.0;
+                }
+#pragma unroll
+            for (int ks = 0; ks < KW / 4; ++ks) pv[mt][ks] = Fr[(long long)N * min(max(kb, 0) + 4 * ks + hi, N - 1)]; // unused when w == 0
+        }
+    }
+    {
+        // S0: sixteen unconditional (clamped) loads per array in flight at once, selected afterwards
+        constexpr int NLB = KW * KW / WGB;
+        double vl[NLB], vd[NLB];
+#pragma unroll
+        for (int it = 0; it < NLB; ++it) {
+            const int e = tid + WGB * it;
+            const int k = e >> 6, q = e & 63;
+            const double* Fq = F + min(kb1 + q, N - 1);
+            vl[it] = Fq[(long long)N * (max(kb, 0) + min(k, max(w, 1) - 1))];
+            vd[it] = Fq[(long long)N * (kb1 + min(k, wq - 1))]; // role B' only exists for a non-empty pair: wq >= 1
+        }
+#pragma unroll
+        for (int it = 0; it < NLB; ++it) {
+            const int e = tid + WGB * it;
+            const int k = e >> 6, q = e & 63;
+            Lp[k * LD2 + q] = (k < w && q < wq) ? vl[it] : 0.0;
+            Aq[k * LD2 + q] = (k < wq && q < wq && q >= k) ? vd[it] : 0.0;
+        }
+    }
+    __syncthreads();
+    // one 16 x 16 tile (ti, tj), ti >= tj, of Aq -= Lp^T Lp, by one wave: A[i = q][kk], B[kk][j = c], D row = (l >> 4) + 4 r -> q, column = l & 15 -> c
+    auto pairUpdateTile = [&](int ti, int tj) {
+        f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < KW / 4; ++ks)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[(4 * ks + hi) * LD2 + 16 * ti + lo], Lp[(4 * ks + hi) * LD2 + 16 * tj + lo], acc, 0, 0, 0);
+        const int c = 16 * tj + lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = 16 * ti + hi + 4 * r;
+            if (q >= c) Aq[c * LD2 + q] -= acc[r];
+        }
+    };
+    if (w > 0 && wv < 3) pairUpdateTile(wv >= 1, wv == 2); // S1: (0,0), (1,0), (1,1) -- Q1's pivot block
+    __syncthreads();
+    f64x4 x0[MT2], x1[MT2]; // L(m, Q1)^T of the wave's tiles, as it leaves the matrix cores: register i = column n = (l >> 4) + 4 i (x0) / 16 + that (x1)
+    if (wv == 3) {
+        // S2, pivot wave (alone on its SIMD, issue priority: the chain every other wave of the step ends up waiting for)
+        __builtin_amdgcn_s_setprio(3);
+        if (wave_potrf_inv32_mfma(Aq, LD2, w1, l, Xs1)) atomicOr(flag, 1);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    else {
+        // S2, row waves: the rest of the 64 x 64 update (A21: (2,0) (2,1) (3,0) (3,1); A22: (2,2) (3,2) (3,3)), then their rows
+        if (w > 0 && w2 > 0) {
+            if (wv == 0) {
+                pairUpdateTile(2, 0);
+                pairUpdateTile(3, 1);
+                pairUpdateTile(3, 3);
+            }
+            else if (wv == 1) {
+                pairUpdateTile(2, 1);
+                pairUpdateTile(2, 2);
+            }
+            else {
+                pairUpdateTile(3, 0);
+                pairUpdateTile(3, 2);
+            }
+        }
+        if (rowWave && w > 0) { // wave-uniform; a pair that has a successor is always full (w == 64)
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < KW / 4; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < 4; ++ct)
+                        dt[mt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LD2 + 16 * ct + lo], pv[mt][ks], dt[mt][ct], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // S3: L21 = A21 X1^T, formed transposed, one 16 x 16 tile per wave: D(c, q) = sum_k X1(c, k) A21(q, k)
+    if (w2 > 0) {
+        const int tw = tid >> 6; // (the tile follows the hardware wave, not its role: all four waves take one)
+        const int tc = tw >> 1, tq = tw & 1;
+        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int k = 4 * ks + hi;
+            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + 16 * tc + lo], Aq[k * LD2 + NB + 16 * tq + lo], o, 0, 0, 0); // X1(c, k) is zero for k > c
+        }
+        const int q = 16 * tq + lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = 16 * tc + hi + 4 * i;
+            L21s[c * LDP + q] = o[i];
+            if (d.z == 0 && q < w2 && c < w1) F[(kb1 + NB + q) + (long long)N * (kb1 + c)] = o[i];
+        }
+    }
+    if (rowWave) {
+        // L(m, Q1) = D(., m)[0:32] X1^T: X^T(n, m) = sum_k X1(n, k) D(k, m), D as it sits in the accumulators (register i = row (l >> 4) + 4 i = k-step i)
+#pragma unroll
+        for (int mt = 0; mt < MT2; ++mt) {
+            f64x4 a0 = { 0.0, 0.0, 0.0, 0.0 }, a1 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 4 * ks + hi;
+                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + lo], dt[mt][0][ks], a0, 0, 0, 0); // X1(n, k), n < 16: k < 16 only
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + 16 + lo], dt[mt][0][ks], a1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int k = 16 + 4 * ks + hi;
+                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + 16 + lo], dt[mt][1][ks], a1, 0, 0, 0);
+            }
+            x0[mt] = a0;
+            x1[mt] = a1;
+            const int row = Rw + 16 * mt + lo;
+            if (row < N) {
+                double* out = F + row + (long long)N * kb1;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int n0 = hi + 4 * i, n1 = 16 + hi + 4 * i;
+                    if (n0 < w1) out[(long long)N * n0] = a0[i];
+                    if (n1 < w1) out[(long long)N * n1] = a1[i];
+                }
+            }
+        }
+    }
+    if (w2 > 0) { // (block-uniform)
+        __syncthreads();
+        // A22 -= L21 L21^T on the three tiles of Q2's pivot block: A[i = q][kk = n] = L21(q, n), B[kk = n][j = c] = L21(c, n)
+        if ((tid >> 6) < 3) {
+            const int tw = tid >> 6;
+            const int ti = tw >= 1, tj = tw == 2;
+            f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+            for (int ks = 0; ks < NB / 4; ++ks)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L21s[(4 * ks + hi) * LDP + 16 * ti + lo], L21s[(4 * ks + hi) * LDP + 16 * tj + lo], acc, 0, 0, 0);
+            const int c = 16 * tj + lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = 16 * ti + hi + 4 * r;
+                if (q >= c) Aq[(NB + c) * LD2 + NB + q] -= acc[r];
+            }
+        }
+        __syncthreads();
+        if (wv == 3) {
+            // S4, pivot wave
+            __builtin_amdgcn_s_setprio(3);
+            if (wave_potrf_inv32_mfma(Aq + NB * LD2 + NB, LD2, w2, l, Xs2)) atomicOr(flag, 1);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        else if (rowWave) {
+            // S4, row waves: D(c, m)[32:64] -= sum_n L21(c, n) L(m, Q1)(n): A[i = c][kk = n] = -L21s[n][c], B[kk = n][j = m] = x0 / x1 as they stand
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct) {
+                        dt[mt][2 + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-L21s[(4 * ks + hi) * LDP + 16 * ct + lo], x0[mt][ks], dt[mt][2 + ct], 0, 0, 0);
+                        dt[mt][2 + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-L21s[(16 + 4 * ks + hi) * LDP + 16 * ct + lo], x1[mt][ks], dt[mt][2 + ct], 0, 0, 0);
+                    }
+        }
+        __syncthreads();
+        if (rowWave) {
+            // S5: L(m, Q2) = D(., m)[32:64] X2^T
+#pragma unroll
+            for (int mt = 0; mt < MT2; ++mt) {
+                f64x4 a0 = { 0.0, 0.0, 0.0, 0.0 }, a1 = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = 4 * ks + hi;
+                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs2[k * LDX + lo], dt[mt][2][ks], a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs2[k * LDX + 16 + lo], dt[mt][2][ks], a1, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int k = 16 + 4 * ks + hi;
+                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs2[k * LDX + 16 + lo], dt[mt][3][ks], a1, 0, 0, 0);
+                }
+                const int row = Rw + 16 * mt + lo;
+                if (row < N) {
+                    double* out = F + row + (long long)N * (kb1 + NB);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int n0 = hi + 4 * i, n1 = 16 + hi + 4 * i;
+                        if (n0 < w2) out[(long long)N * n0] = a0[i];
+                        if (n1 < w2) out[(long long)N * n1] = a1[i];
+                    }
+                }
+            }
+        }
+    }
+    else __syncthreads(); // (Xs1 is read below by threads that did not write it)
+    if (d.z == 0) {
+        // the inverses of the pivot blocks go straight to their dinv slots (column-major, identity-padded): the solves multiply by them
+        double* slot = dinv + ((long long)d.x + kb1 / NB) * (NB * NB);
+        for (int e = tid; e < NB * NB; e += WGB) slot[e] = Xs1[(e >> 5) * LDX + (e & 31)];
+        if (w2 > 0)
+            for (int e = tid; e < NB * NB; e += WGB) slot[NB * NB + e] = Xs2[(e >> 5) * LDX + (e & 31)];
+    }
+}
+
 // ---- triangular solves ------------------------------------------------------------------------------------
 __global__ void k_permute_rhs(int nn, const int* __restrict__ newOf, const double* __restrict__ b, double* __restrict__ bp)
 {
@@ -2614,7 +2942,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                             // front is wide, and at that width it stretches every step launch (measured at mat433: factorisation 20.0 -> 20.8 ms)
     if (const char* e = std::getenv("IPCGPU_MF_BORDER_MAX_NC")) borderMaxNc = std::max(0, std::atoi(e));
     auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin && sym.level[s] < nLevels_ - xinvSkipTop_; };
-    auto hasBorder = [&](int s) { return xinvBorder_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; };
+    if (const char* e = std::getenv("IPCGPU_MF_STEP2")) step2_ = std::atoi(e) != 0; // two panels per step launch (k_big_step2): written, not yet run
+    auto hasBorder = [&](int s) { return xinvBorder_ && !step2_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; }; // (k_big_step2 has no role C yet)
     // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
     owner_.assign(ns_, rank_);
     sharedFlops_ = 0.0;
@@ -2842,6 +3171,44 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         // big-front step descriptors: launch 0 factors panel 0, launch j + 1 applies panel j and factors panel j + 1
         int steps = 0;
         for (int s : big) steps = std::max(steps, (sym.nc(s) + NB - 1) / NB);
+        P.step2 = step2_ && !big.empty();
+        if (P.step2) {
+            // ... or, two panels per launch (k_big_step2): launch 0 factors the pair 0, launch J + 1 applies pair J and factors pair J + 1
+            const int pairs = (steps + 1) / 2;
+            P.step.assign(pairs + 1, Range());
+            for (int J = -1; J < pairs; ++J) {
+                Range& R = P.step[J + 1];
+                R.off = (int)desc.size();
+                for (int s : big) {
+                    const int N = sym.N(s), nc = sym.nc(s);
+                    const int kb = J * 2 * NB;
+                    if (J >= 0 && kb >= nc) continue;
+                    const int w = (J >= 0) ? std::min(2 * NB, nc - kb) : 0;
+                    const int kb1 = (J >= 0) ? kb + w : 0;
+                    const int wq = (kb1 < nc) ? std::min(2 * NB, nc - kb1) : 0;
+                    const long long foff = sym.frontOff[s];
+                    const int4 rec2 = make_int4(N, nc, (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
+                    if (wq > 0) {
+                        const int Rb = kb1 + wq; // first row below the pair's pivot blocks; one workgroup even when there is none (the pivot work)
+                        for (int r0 = 0; r0 == 0 || r0 < N - Rb; r0 += ROWS_B2) {
+                            desc.push_back(make_int4((int)hDinvOff_[s], J >= 0 ? kb : -1, r0, -2));
+                            desc.push_back(rec2);
+                        }
+                    }
+                    if (J >= 0) {
+                        const int M0 = kb1 + wq;
+                        const int ntr = (N - M0 + TS - 1) / TS, ntc = (nc - M0 + TS - 1) / TS;
+                        for (int ti = 0; ti < ntr; ++ti)
+                            for (int tj = 0; tj <= ti && tj < ntc; ++tj) {
+                                desc.push_back(make_int4((int)hDinvOff_[s], kb, ti, tj));
+                                desc.push_back(rec2);
+                            }
+                    }
+                }
+                R.cnt = ((int)desc.size() - R.off) / 2;
+            }
+        }
+        else
         P.step.assign(big.empty() ? 0 : steps + 1, Range());
         {
             long long tiles32 = 0;
@@ -2865,10 +3232,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             if (maxPass < 2) foldPanels = 0;
             else foldPanels = std::max<long long>(schurFold_, (steps + maxPass - 1) / maxPass);
         }
-        const bool foldSchur = foldPanels > 0 && steps >= schurFoldMinSteps_ && steps > foldPanels;
+        const bool foldSchur = !P.step2 && foldPanels > 0 && steps >= schurFoldMinSteps_ && steps > foldPanels;
         if (foldSchur) P.stepTop = true;
         const int nPass = foldSchur ? (steps + foldPanels - 1) / foldPanels : 0;
-        for (int j = -1; j < steps && !big.empty(); ++j) {
+        for (int j = -1; j < steps && !big.empty() && !P.step2; ++j) {
             Range& R = P.step[j + 1];
             R.off = (int)desc.size();
             for (int s : big) {
@@ -3120,6 +3487,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
     }
+    if (step2_) HIP_CHECK(hipFuncSetAttribute((const void*)k_big_step2, hipFuncAttributeMaxDynamicSharedMemorySize, STEP2_LDS));
     if (maxSolveLds > 48 * 1024) {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
@@ -3305,6 +3673,11 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
         // workgroups wait in their slots: no point in parking thousands of them)
         for (size_t i = 0; i < P.step.size();) {
             if (!P.step[i].cnt) {
+                ++i;
+                continue;
+            }
+            if (P.step2) { // two panels per launch (IPCGPU_MF_STEP2=1)
+                hipLaunchKernelGGL(k_big_step2, dim3(P.step[i].cnt), dim3(WGB), STEP2_LDS, stream_, desc_.p + P.step[i].off, fronts_.p, dinv_.p, flag_.p);
                 ++i;
                 continue;
             }

@@ -1,0 +1,110 @@
+"""Host-only (numpy).  """Descriptor-level emulation of k_big_step2: the host loop of MfNumeric::setup (step2 branch) mirrored line by line, every workgroup emulated with the index
+arithmetic of the kernel (tiles, row chunks, masks, clamps), launches in order with a snapshot of the front per launch (no workgroup sees another's writes)."""
+import numpy as np
+NB, TS, ROWS_B2, MT2 = 32, 64, 96, 2
+rng = np.random.default_rng(1)
+def plan(N, nc):
+    steps = (nc + NB - 1) // NB
+    pairs = (steps + 1) // 2
+    launches = []
+    for J in range(-1, pairs):
+        descs = []
+        kb = J * 2 * NB
+        if J >= 0 and kb >= nc:
+            launches.append(descs); continue
+        w = min(2 * NB, nc - kb) if J >= 0 else 0
+        kb1 = kb + w if J >= 0 else 0
+        wq = min(2 * NB, nc - kb1) if kb1 < nc else 0
+        if wq > 0:
+            Rb = kb1 + wq
+            r0 = 0
+            while r0 == 0 or r0 < N - Rb:
+                descs.append((kb if J >= 0 else -1, r0, -2)); r0 += ROWS_B2
+        if J >= 0:
+            M0 = kb1 + wq
+            ntr = (N - M0 + TS - 1) // TS; ntc = (nc - M0 + TS - 1) // TS
+            for ti in range(ntr):
+                for tj in range(min(ti, ntc - 1) + 1):
+                    if tj < ntc: descs.append((kb, ti, tj))
+        launches.append(descs)
+    return launches
+def chol_inv(Ablk, wdt):
+    A = np.eye(32); A[:wdt, :wdt] = Ablk[:wdt, :wdt]
+    A = np.tril(A) + np.tril(A, -1).T
+    return np.linalg.inv(np.linalg.cholesky(A))
+def run(N, nc):
+    A0 = rng.normal(size=(N, N)); A0 = A0 @ A0.T + N * np.eye(N)
+    F = np.tril(A0).copy()
+    dinv = {}
+    for descs in plan(N, nc):
+        Fin = F.copy()
+        for (kb, a, b) in descs:
+            w = min(64, nc - kb) if kb >= 0 else 0
+            kb1 = kb + w if kb >= 0 else 0
+            wq = min(64, nc - kb1) if kb1 < nc else 0
+            w1 = min(32, wq); w2 = wq - w1
+            if b >= 0:   # role A'
+                M0 = kb1 + wq; i0 = M0 + TS * a; j0 = M0 + TS * b
+                for jj in range(TS):
+                    col = j0 + jj
+                    if col >= nc: continue
+                    for ii in range(TS):
+                        row = i0 + ii
+                        if row < N and row >= col:
+                            acc = sum(Fin[row, kb + k] * Fin[col, kb + k] for k in range(w))
+                            F[row, col] = Fin[row, col] - acc
+                continue
+            # role B'
+            Lp = np.zeros((64, 64)); Aq = np.zeros((64, 64))
+            for k in range(64):
+                for q in range(64):
+                    if k < w and q < wq: Lp[k, q] = Fin[min(kb1 + q, N - 1), max(kb, 0) + min(k, max(w, 1) - 1)]
+                    if k < wq and q < wq and q >= k: Aq[k, q] = Fin[min(kb1 + q, N - 1), kb1 + min(k, wq - 1)]
+            # Aq[c][q] -= sum_k Lp[k][q] Lp[k][c], lower tiles
+            if w > 0:
+                U = Lp.T @ Lp    # U[q][c]
+                for c in range(64):
+                    for q in range(c, 64):
+                        if (q < 32 and c < 32) or w2 > 0: Aq[c, q] -= U[q, c]
+            blk = lambda r0, c0: np.array([[Aq[c0 + c, r0 + q] if q >= c or r0 != c0 else Aq[c0 + c, r0 + q] for c in range(32)] for q in range(32)])
+            X1 = chol_inv(np.tril(blk(0, 0)), w1)
+            rows = [m for m in range(kb1 + wq + a, min(kb1 + wq + a + ROWS_B2, N))]
+            D = np.zeros((len(rows), 64))
+            for i, m in enumerate(rows):
+                for c in range(64):
+                    v = Fin[m, kb1 + min(c, max(wq, 1) - 1)] if c < wq else 0.0
+                    D[i, c] = v - sum(Lp[k, c] * Fin[m, max(kb, 0) + k] for k in range(64) if k < w) if w > 0 else v
+            LQ1 = D[:, :32] @ X1.T
+            for i, m in enumerate(rows):
+                for n in range(w1): F[m, kb1 + n] = LQ1[i, n]
+            if a == 0: dinv[kb1 // 32] = X1[:w1, :w1]
+            if w2 > 0:
+                A21 = np.array([[Aq[k, 32 + q] for k in range(32)] for q in range(32)])   # (q, k)
+                L21 = A21 @ X1.T
+                if a == 0:
+                    for q in range(w2):
+                        for c in range(w1): F[kb1 + 32 + q, kb1 + c] = L21[q, c]
+                A22 = np.array([[Aq[32 + c, 32 + q] for c in range(32)] for q in range(32)])
+                A22 = np.tril(A22) - np.tril(L21 @ L21.T)
+                X2 = chol_inv(A22, w2)
+                D2 = D[:, 32:] - LQ1 @ L21.T
+                LQ2 = D2 @ X2.T
+                for i, m in enumerate(rows):
+                    for n in range(w2): F[m, kb1 + 32 + n] = LQ2[i, n]
+                if a == 0: dinv[kb1 // 32 + 1] = X2[:w2, :w2]
+    # reference
+    Aw = A0.copy(); Lr = np.zeros((N, nc))
+    for k in range(nc):
+        Lr[k, k] = np.sqrt(Aw[k, k]); Lr[k+1:, k] = Aw[k+1:, k] / Lr[k, k]
+        Aw[k+1:, k+1:] -= np.outer(Lr[k+1:, k], Lr[k+1:, k])
+    err = 0.0
+    for p in range(0, nc, 32):
+        we = min(32, nc - p)
+        if p + we < N: err = max(err, np.abs(F[p + we:, p:p + we] - Lr[p + we:, p:p + we]).max())
+        err = max(err, np.abs(dinv[p // 32] - np.linalg.inv(Lr[p:p + we, p:p + we])).max())
+    # the Schur complement region must be untouched by the steps (k_big_schur's job)
+    untouched = np.array_equal(F[nc:, nc:], np.tril(A0)[nc:, nc:])
+    return err, untouched, sum(len(d) for d in plan(N, nc))
+for N, nc in [(64, 64), (100, 64), (160, 97), (130, 129), (200, 160), (96, 33), (70, 31), (260, 96), (230, 200)]:
+    e, u, nwg = run(N, nc)
+    print(N, nc, "err %.1e  Schur block untouched %s  workgroups %d" % (e, u, nwg))
