@@ -1,4 +1,4 @@
-"""Host-only (numpy).  """Tile-level emulation of the two-panels-per-launch step (roles A', B', C') on a dense front: checks the algebra and the launch invariants."""
+"""Host-only (numpy).  Tile-level emulation of the two-panels-per-launch step (roles A', B', C') on a dense front: checks the algebra and the launch invariants."""
 import numpy as np
 rng = np.random.default_rng(0)
 def spd(n):

@@ -1,4 +1,4 @@
-"""Host-only (numpy).  """Descriptor-level emulation of k_big_step2: the host loop of MfNumeric::setup (step2 branch) mirrored line by line, every workgroup emulated with the index
+"""Host-only (numpy).  Descriptor-level emulation of k_big_step2: the host loop of MfNumeric::setup (step2 branch) mirrored line by line, every workgroup emulated with the index
 arithmetic of the kernel (tiles, row chunks, masks, clamps), launches in order with a snapshot of the front per launch (no workgroup sees another's writes)."""
 import numpy as np
 NB, TS, ROWS_B2, MT2 = 32, 64, 96, 2
