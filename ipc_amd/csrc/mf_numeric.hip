@@ -1889,16 +1889,214 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 //       S5  L(m, Q2) = D(., m)[32:64] X2^T -> front;  X1, X2 -> their dinv slots (workgroup 0)
 //   role A' (b >= 0): trailing tile (a, b) behind Q, F -= P_i P_j^T with all 64 columns of P, own columns (< nc) only.
 // desc = (first dinv block of the front, kb of P or -1, a, b) + (N, nc, front offset), as for k_big_step.  dinv slots, factor layout and everything
-// downstream (Schur complement, inverses, sweeps) are those of the 32-column steps.  The explicit inverses of fronts stepped this way grow by recursive
-// doubling behind the factorisation (no role C here yet).
+// downstream (Schur complement, sweeps) are those of the 32-column steps.
+//   role C' (b == -6): the explicit inverse grows by bordering, 64 rows per launch (step2_border above).
+// Role C' of k_big_step2 (b == -6): the rows R = [kb, kb + w) of the pair P (finished by the launch before) of X = L11^-1, by bordering -- step_border for 64 rows.
+// One workgroup per 16-column tile C = [c0, c0 + 16) left of the pair, plus one for the pair's own 64 x 64 block (c0 == kb):
+//     T(r, c) = sum_{k in [c0, kb)} L(kb + r, k) X(k, c0 + c)                       stage 1: four waves split k, four 16-row tiles each, combined through LDS
+//     X(R1, C) = -X1 T1                                                              stage 2a (R1, R2: the two panels of the pair; X1, X2 their dinv blocks)
+//     X(R2, C) = -X2 (T2 + L(R2, R1) X(R1, C))                                       stage 2b, 2c: the second term from the workgroup's own tile
+//     own block: X(R1, R1) = X1, X(R2, R2) = X2, X(R2, R1) = -X2 L(R2, R1) X1
+// X is written column-major (ld nc) and transposed (xv.T), as by step_border<16, true>.  d = (front, kb, c0, -6).
+constexpr int LDT = 17;
+constexpr int STEP2_LDS_C = (4 * 4 * 256 + 2 * NB * LDT + NB * LDT + NB * LDT) * (int)sizeof(double); // red, Ts, XR1s, Us
+__device__ __forceinline__ void step2_border(const int4 d, const int4 d2, const TreeView& tv, const XinvView& xv, const double* __restrict__ F,
+    const double* __restrict__ dinv, double* sm)
+{
+    const int s = d.x, kb = d.y, c0 = d.z;
+    const int N = d2.x, nc = d2.y;
+    const int w = min(2 * NB, nc - kb);
+    const int wa = min(NB, w), wb = w - wa; // rows of R1, R2
+    double* X = xv.X + xv.xOff[s];
+    double* XT = xv.T + xv.xOff[s];
+    const double* blk1 = dinv + (tv.dinvOff[s] + kb / NB) * (NB * NB); // blk[c * 32 + r] = Xd(r, c), identity-padded
+    const double* blk2 = blk1 + NB * NB;
+    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, lo = l & 15, hi = l >> 4;
+    if (c0 == kb) {
+        // the pair's own block
+        double* Xa = sm; // Xa[c * LDX + r] = X1(r, c)
+        double* Xb = sm + NB * LDX;
+        double* Us = sm + 2 * NB * LDX; // Us[q * LDP + c] = (L21 X1)(q, c)
+        for (int e = tid; e < NB * NB; e += WGB) {
+            const int c = e >> 5, r = e & 31;
+            const double v1 = blk1[e], v2 = (wb > 0) ? blk2[e] : 0.0;
+            Xa[c * LDX + r] = v1;
+            Xb[c * LDX + r] = v2;
+            if (r < wa && c < wa) {
+                X[(kb + r) + (long long)nc * (kb + c)] = v1;
+                XT[(kb + c) + (long long)nc * (kb + r)] = v1;
+            }
+            if (r < wb && c < wb) {
+                X[(kb + NB + r) + (long long)nc * (kb + NB + c)] = v2;
+                XT[(kb + NB + c) + (long long)nc * (kb + NB + r)] = v2;
+            }
+        }
+        if (wb == 0) return; // (block-uniform)
+        // L21(q, n) = F(kb + 32 + q, kb + n), requested before the barrier
+        const int tc = wv >> 1, tq = wv & 1;
+        double l21[NB / 4];
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) l21[ks] = F[min(kb + NB + 16 * tq + lo, N - 1) + (long long)N * (kb + 4 * ks + hi)];
+        __syncthreads();
+        // U(q, c) = sum_n L21(q, n) X1(n, c), formed transposed: A[i = c][kk = n] = X1(n, c), B[kk = n][j = q] = L21(q, n); D register i = (c = 16 tc + hi + 4 i, q = 16 tq + lo)
+        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int n = 4 * ks + hi;
+            u = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[(16 * tc + lo) * LDX + n], (16 * tq + lo < wb) ? l21[ks] : 0.0, u, 0, 0, 0); // X1(n, c) is zero for n < c
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Us[(16 * tq + lo) * LDP + 16 * tc + hi + 4 * i] = u[i];
+        __syncthreads();
+        // X(R2, R1)(r2, c) = -sum_q X2(r2, q) U(q, c): A[i = c][kk = q] = U(q, c), B[kk = q][j = r2] = X2(r2, q); D register i = (c = 16 tc + hi + 4 i, r2 = 16 tq + lo)
+        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int q = 4 * ks + hi;
+            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[q * LDP + 16 * tc + lo], Xb[q * LDX + 16 * tq + lo], o, 0, 0, 0); // X2(r2, q) is zero for q > r2
+        }
+        const int r2 = 16 * tq + lo;
+        if (r2 < wb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = 16 * tc + hi + 4 * i;
+                X[(kb + NB + r2) + (long long)nc * (kb + c)] = -o[i];
+                XT[(kb + c) + (long long)nc * (kb + NB + r2)] = -o[i];
+            }
+        }
+        return;
+    }
+    double(*red)[4][256] = reinterpret_cast<double(*)[4][256]>(sm); // [wave][16-row tile b][D layout: 64 lanes x 4]
+    double* Ts = sm + 4 * 4 * 256; // Ts[k' * LDT + c] = T(k', c), k' < 64
+    double* XR1s = Ts + 2 * NB * LDT; // XR1s[r * LDT + c] = X(kb + r, c0 + c), r < 32
+    double* Us = XR1s + NB * LDT; // Us[k'' * LDT + c] = (T2 + L21 X(R1, C))(k'', c)
+    f64x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+    const int cc = c0 + lo; // < kb: always inside
+    int rr[4], rrc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        rr[b] = kb + 16 * b + lo;
+        rrc[b] = min(rr[b], N - 1);
+    }
+    const int bq = wv & 1; // the 16-row tile of R1 (waves 0, 1) / R2 (waves 2, 3) this wave finishes
+    // operands of the second stage, requested now: the dinv block of the wave's panel and (waves 2, 3) its rows of L(R2, R1)
+    const double* blkw = (wv < 2 || wb == 0) ? blk1 : blk2; // (the second slot need not exist when the pair is a single panel)
+    double xd[NB / 4], l21[NB / 4];
+#pragma unroll
+    for (int ks = 0; ks < NB / 4; ++ks) {
+        xd[ks] = blkw[(4 * ks + hi) * NB + 16 * bq + lo]; // Xd(r = 16 bq + lo, k' = 4 ks + hi)
+        l21[ks] = F[min(kb + NB + 16 * bq + lo, N - 1) + (long long)N * min(kb + 4 * ks + hi, N - 1)]; // L21(k'' = 16 bq + lo, r1 = 4 ks + hi); clamped, masked at use
+    }
+    // three operand sets in rotation, unconditional clamped fetches, masks at use (step_border)
+    auto fetch = [&](int k0, double(&ra)[4], double(&rb)[4][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int kc = min(k0 + 4 * ks + hi, nc - 1);
+            ra[ks] = XT[cc + (long long)nc * kc];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rb[q][ks] = F[rrc[q] + (long long)N * kc];
+        }
+    };
+    auto mult = [&](int k0, const double(&ra)[4], const double(&rb)[4][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int k = k0 + 4 * ks + hi;
+            const bool kin = k < kb;
+            const double ma = (kin && k >= cc) ? ra[ks] : 0.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, (kin && rr[b] < kb + w) ? rb[b][ks] : 0.0, acc[b], 0, 0, 0);
+        }
+    };
+    double xa[4], la[4][4], xb[4], lb[4][4], xc[4], lc[4][4];
+    int k0 = c0 + 16 * wv;
+    fetch(k0, xa, la);
+    fetch(k0 + 64, xb, lb);
+    for (; k0 < kb; k0 += 192) {
+        fetch(k0 + 128, xc, lc);
+        __builtin_amdgcn_sched_barrier(0);
+        mult(k0, xa, la);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(k0 + 192, xa, la);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 64 < kb) mult(k0 + 64, xb, lb);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(k0 + 256, xb, lb);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 128 < kb) mult(k0 + 128, xc, lc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) red[wv][b][64 * i + l] = acc[b][i];
+    __syncthreads();
+    // wave b finishes the 16-row tile b of T: entry i of a lane is T(r = 16 b + lo, c = hi + 4 i); the sums over the waves in a fixed order
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        Ts[(16 * wv + lo) * LDT + hi + 4 * i] = ((red[0][wv][64 * i + l] + red[1][wv][64 * i + l]) + red[2][wv][64 * i + l]) + red[3][wv][64 * i + l];
+    __syncthreads();
+    if (wv < 2) {
+        // stage 2a, formed transposed like stage 1: D(c, r) = sum_k' T1(k', c) X1(r, k'), k' <= r
+        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int kp = 4 * ks + hi;
+            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[kp * LDT + lo], (kp <= 16 * bq + lo) ? xd[ks] : 0.0, o, 0, 0, 0);
+        }
+        const int r = 16 * bq + lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = hi + 4 * i;
+            XR1s[r * LDT + c] = (r < wa) ? -o[i] : 0.0;
+            if (r < wa) {
+                X[(kb + r) + (long long)nc * (c0 + c)] = -o[i];
+                XT[(c0 + c) + (long long)nc * (kb + r)] = -o[i];
+            }
+        }
+    }
+    if (wb == 0) return; // (block-uniform)
+    __syncthreads();
+    if (wv >= 2) {
+        // stage 2b: U(k'', c) = T2(k'', c) + sum_r1 L21(k'', r1) X(R1, C)(r1, c): A[i = c][kk = r1] = XR1s, B[kk = r1][j = k''] = L21(k'', r1)
+        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) u = __builtin_amdgcn_mfma_f64_16x16x4f64(XR1s[(4 * ks + hi) * LDT + lo], (16 * bq + lo < wb) ? l21[ks] : 0.0, u, 0, 0, 0);
+        const int k2 = 16 * bq + lo;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Us[k2 * LDT + hi + 4 * i] = u[i] + Ts[(NB + k2) * LDT + hi + 4 * i];
+    }
+    __syncthreads();
+    if (wv >= 2) {
+        // stage 2c: D(c, r2) = sum_k'' U(k'', c) X2(r2, k''), k'' <= r2
+        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const int kp = 4 * ks + hi;
+            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kp * LDT + lo], (kp <= 16 * bq + lo) ? xd[ks] : 0.0, o, 0, 0, 0);
+        }
+        const int r2 = 16 * bq + lo;
+        if (r2 < wb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = hi + 4 * i;
+                X[(kb + NB + r2) + (long long)nc * (c0 + c)] = -o[i];
+                XT[(c0 + c) + (long long)nc * (kb + NB + r2)] = -o[i];
+            }
+        }
+    }
+}
+
 constexpr int LD2 = 2 * NB + 1; // padded leading dimension of the 64 x 64 blocks of role B'
 constexpr int MT2 = 2; // 16-row tiles per row wave
 constexpr int ROWS_B2 = 16 * MT2 * ROW_WAVES_B;
 constexpr int STEP2_LDS_B = (2 * (2 * NB) * LD2 + 2 * NB * LDX + NB * LDP) * (int)sizeof(double); // Lp, Aq, Xs1, Xs2, L21s
 constexpr int STEP2_LDS_A = 2 * (2 * NB) * TS * (int)sizeof(double); // As, Bs: 64 x TS each
-constexpr int STEP2_LDS = STEP2_LDS_B > STEP2_LDS_A ? STEP2_LDS_B : STEP2_LDS_A;
+constexpr int STEP2_LDS = (STEP2_LDS_B > STEP2_LDS_A ? STEP2_LDS_B : STEP2_LDS_A) > STEP2_LDS_C ? (STEP2_LDS_B > STEP2_LDS_A ? STEP2_LDS_B : STEP2_LDS_A) : STEP2_LDS_C;
 
-__global__ __launch_bounds__(WGB) void k_big_step2(const int4* __restrict__ desc, double* __restrict__ fronts, double* __restrict__ dinv, int* __restrict__ flag)
+__global__ __launch_bounds__(WGB) void k_big_step2(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts, double* __restrict__ dinv,
+    int* __restrict__ flag, XinvView xv)
 {
     extern __shared__ double sm2[];
     const int wg = blockIdx.x;
@@ -1907,6 +2105,10 @@ __global__ __launch_bounds__(WGB) void k_big_step2(const int4* __restrict__ desc
     const int N = d2.x, nc = d2.y;
     double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
     const int tid = threadIdx.x;
+    if (d.w == -6) { // role C': the rows of the pair before, of the explicit inverse
+        step2_border(d, d2, tv, xv, F, dinv, sm2);
+        return;
+    }
     constexpr int KW = 2 * NB; // columns of a pair
     const int kb = d.y;
     const int w = (kb >= 0) ? min(KW, nc - kb) : 0; // the pair P = [kb, kb + w) is final
@@ -2943,7 +3145,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     if (const char* e = std::getenv("IPCGPU_MF_BORDER_MAX_NC")) borderMaxNc = std::max(0, std::atoi(e));
     auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin && sym.level[s] < nLevels_ - xinvSkipTop_; };
     if (const char* e = std::getenv("IPCGPU_MF_STEP2")) step2_ = std::atoi(e) != 0; // two panels per step launch (k_big_step2): written, not yet run
-    auto hasBorder = [&](int s) { return xinvBorder_ && !step2_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; }; // (k_big_step2 has no role C yet)
+    auto hasBorder = [&](int s) { return xinvBorder_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; };
     // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
     owner_.assign(ns_, rank_);
     sharedFlops_ = 0.0;
@@ -3192,6 +3394,12 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                         const int Rb = kb1 + wq; // first row below the pair's pivot blocks; one workgroup even when there is none (the pivot work)
                         for (int r0 = 0; r0 == 0 || r0 < N - Rb; r0 += ROWS_B2) {
                             desc.push_back(make_int4((int)hDinvOff_[s], J >= 0 ? kb : -1, r0, -2));
+                            desc.push_back(rec2);
+                        }
+                    }
+                    if (J >= 0 && hasBorder(s)) { // role C': the rows of pair J of X = L11^-1: 16-column tiles left of the pair, one workgroup for its own block
+                        for (int c0 = 0; c0 <= kb; c0 += 16) {
+                            desc.push_back(make_int4(s, kb, c0, -6));
                             desc.push_back(rec2);
                         }
                     }
@@ -3677,7 +3885,7 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
                 continue;
             }
             if (P.step2) { // two panels per launch (IPCGPU_MF_STEP2=1)
-                hipLaunchKernelGGL(k_big_step2, dim3(P.step[i].cnt), dim3(WGB), STEP2_LDS, stream_, desc_.p + P.step[i].off, fronts_.p, dinv_.p, flag_.p);
+                hipLaunchKernelGGL(k_big_step2, dim3(P.step[i].cnt), dim3(WGB), STEP2_LDS, stream_, desc_.p + P.step[i].off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
                 ++i;
                 continue;
             }

@@ -21,6 +21,10 @@ def plan(N, nc):
             while r0 == 0 or r0 < N - Rb:
                 descs.append((kb if J >= 0 else -1, r0, -2)); r0 += ROWS_B2
         if J >= 0:
+            c0 = 0
+            while c0 <= kb:   # role C': 16-column tiles left of the pair, then its own block (c0 == kb)
+                descs.append((kb, c0, -6)); c0 += 16
+        if J >= 0:
             M0 = kb1 + wq
             ntr = (N - M0 + TS - 1) // TS; ntc = (nc - M0 + TS - 1) // TS
             for ti in range(ntr):
@@ -36,9 +40,47 @@ def run(N, nc):
     A0 = rng.normal(size=(N, N)); A0 = A0 @ A0.T + N * np.eye(N)
     F = np.tril(A0).copy()
     dinv = {}
+    X = np.zeros((nc, nc)); XT = np.zeros((nc, nc))
+    def slot(i):   # identity-padded 32 x 32 dinv block, as the kernel reads it
+        B = np.eye(32); d_ = dinvIn[i]; B[:d_.shape[0], :d_.shape[1]] = d_; return B
     for descs in plan(N, nc):
-        Fin = F.copy()
+        Fin = F.copy(); Xin = X.copy(); XTin = XT.copy(); dinvIn = dict(dinv)
         for (kb, a, b) in descs:
+            if b == -6:   # role C' (step2_border): rows of the pair [kb, kb + w) of X
+                c0 = a
+                w = min(64, nc - kb); wa = min(32, w); wb = w - wa
+                X1 = slot(kb // 32); X2 = slot(kb // 32 + 1) if wb > 0 else np.zeros((32, 32))
+                if c0 == kb:
+                    for c in range(32):
+                        for r in range(32):
+                            if r < wa and c < wa: X[kb + r, kb + c] = X1[r, c]; XT[kb + c, kb + r] = X1[r, c]
+                            if r < wb and c < wb: X[kb + 32 + r, kb + 32 + c] = X2[r, c]; XT[kb + 32 + c, kb + 32 + r] = X2[r, c]
+                    if wb > 0:
+                        L21 = np.array([[Fin[min(kb + 32 + q, N - 1), kb + n] if q < wb else 0.0 for n in range(32)] for q in range(32)])
+                        U = L21 @ np.tril(X1)
+                        X21 = -np.tril(X2) @ U
+                        for r2 in range(wb):
+                            for c in range(32): X[kb + 32 + r2, kb + c] = X21[r2, c]; XT[kb + c, kb + 32 + r2] = X21[r2, c]
+                    continue
+                T = np.zeros((64, 16))
+                for r in range(64):
+                    if kb + r >= kb + w: continue
+                    for c in range(16):
+                        cc = c0 + c
+                        T[r, c] = sum(Fin[min(kb + r, N - 1), k] * XTin[cc, k] for k in range(c0, kb) if k >= cc)
+                XR1 = np.zeros((32, 16))
+                for r in range(32):
+                    for c in range(16):
+                        v = -sum(T[kp, c] * X1[r, kp] for kp in range(32) if kp <= r)
+                        if r < wa: XR1[r, c] = v; X[kb + r, c0 + c] = v; XT[c0 + c, kb + r] = v
+                if wb > 0:
+                    L21 = np.array([[Fin[min(kb + 32 + q, N - 1), min(kb + n, N - 1)] if q < wb else 0.0 for n in range(32)] for q in range(32)])
+                    U = T[32:, :] + L21 @ XR1
+                    for r2 in range(wb):
+                        for c in range(16):
+                            v = -sum(U[kp, c] * X2[r2, kp] for kp in range(32) if kp <= r2)
+                            X[kb + 32 + r2, c0 + c] = v; XT[c0 + c, kb + 32 + r2] = v
+                continue
             w = min(64, nc - kb) if kb >= 0 else 0
             kb1 = kb + w if kb >= 0 else 0
             wq = min(64, nc - kb1) if kb1 < nc else 0
@@ -104,7 +146,9 @@ def run(N, nc):
         err = max(err, np.abs(dinv[p // 32] - np.linalg.inv(Lr[p:p + we, p:p + we])).max())
     # the Schur complement region must be untouched by the steps (k_big_schur's job)
     untouched = np.array_equal(F[nc:, nc:], np.tril(A0)[nc:, nc:])
-    return err, untouched, sum(len(d) for d in plan(N, nc))
+    Xref = np.linalg.inv(np.tril(Lr[:nc, :nc]))
+    errX = max(np.abs(np.tril(X) - Xref).max(), np.abs(np.triu(XT) - Xref.T).max()) / np.abs(Xref).max()
+    return err, errX, untouched, sum(len(d) for d in plan(N, nc))
 for N, nc in [(64, 64), (100, 64), (160, 97), (130, 129), (200, 160), (96, 33), (70, 31), (260, 96), (230, 200)]:
-    e, u, nwg = run(N, nc)
-    print(N, nc, "err %.1e  Schur block untouched %s  workgroups %d" % (e, u, nwg))
+    e, ex, u, nwg = run(N, nc)
+    print(N, nc, "L / dinv err %.1e  X and X^T err (rel) %.1e  Schur block untouched %s  workgroups %d" % (e, ex, u, nwg))
