@@ -1891,6 +1891,7 @@ __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc,
 // desc = (first dinv block of the front, kb of P or -1, a, b) + (N, nc, front offset), as for k_big_step.  dinv slots, factor layout and everything
 // downstream (Schur complement, sweeps) are those of the 32-column steps.
 //   role C' (b == -6): the explicit inverse grows by bordering, 64 rows per launch (step2_border above).
+//   role M  (b == -8): one workgroup per front moves L(P2 rows, P1 columns) of the pair before into place (role B' could not: see there).
 // Role C' of k_big_step2 (b == -6): the rows R = [kb, kb + w) of the pair P (finished by the launch before) of X = L11^-1, by bordering -- step_border for 64 rows.
 // One workgroup per 16-column tile C = [c0, c0 + 16) left of the pair, plus one for the pair's own 64 x 64 block (c0 == kb):
 //     T(r, c) = sum_{k in [c0, kb)} L(kb + r, k) X(k, c0 + c)                       stage 1: four waves split k, four 16-row tiles each, combined through LDS
@@ -1932,11 +1933,11 @@ __device__ __forceinline__ void step2_border(const int4 d, const int4 d2, const 
             }
         }
         if (wb == 0) return; // (block-uniform)
-        // L21(q, n) = F(kb + 32 + q, kb + n), requested before the barrier
+        // L21(q, n) = L(kb + 32 + q, kb + n), requested before the barrier
         const int tc = wv >> 1, tq = wv & 1;
         double l21[NB / 4];
 #pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) l21[ks] = F[min(kb + NB + 16 * tq + lo, N - 1) + (long long)N * (kb + 4 * ks + hi)];
+        for (int ks = 0; ks < NB / 4; ++ks) l21[ks] = F[(kb + 4 * ks + hi) + (long long)N * min(kb + NB + 16 * tq + lo, N - 1)]; // (transposed, above the diagonal: see role B')
         __syncthreads();
         // U(q, c) = sum_n L21(q, n) X1(n, c), formed transposed: A[i = c][kk = n] = X1(n, c), B[kk = n][j = q] = L21(q, n); D register i = (c = 16 tc + hi + 4 i, q = 16 tq + lo)
         f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
@@ -1987,7 +1988,7 @@ __device__ __forceinline__ void step2_border(const int4 d, const int4 d2, const 
 #pragma unroll
     for (int ks = 0; ks < NB / 4; ++ks) {
         xd[ks] = blkw[(4 * ks + hi) * NB + 16 * bq + lo]; // Xd(r = 16 bq + lo, k' = 4 ks + hi)
-        l21[ks] = F[min(kb + NB + 16 * bq + lo, N - 1) + (long long)N * min(kb + 4 * ks + hi, N - 1)]; // L21(k'' = 16 bq + lo, r1 = 4 ks + hi); clamped, masked at use
+        l21[ks] = F[(kb + 4 * ks + hi) + (long long)N * min(kb + NB + 16 * bq + lo, N - 1)]; // L21(k'' = 16 bq + lo, r1 = 4 ks + hi) from where role B' left it: transposed, above the diagonal (role M moves it in this same launch); clamped, masked at use
     }
     // three operand sets in rotation, unconditional clamped fetches, masks at use (step_border)
     auto fetch = [&](int k0, double(&ra)[4], double(&rb)[4][4]) {
@@ -2107,6 +2108,14 @@ __global__ __launch_bounds__(WGB) void k_big_step2(const int4* __restrict__ desc
     const int tid = threadIdx.x;
     if (d.w == -6) { // role C': the rows of the pair before, of the explicit inverse
         step2_border(d, d2, tv, xv, F, dinv, sm2);
+        return;
+    }
+    if (d.w == -8) { // role M: L(P2 rows, P1 columns) of the pair before, from where its launch left it (transposed, above the diagonal) into place
+        const int kbm = d.y, wbm = min(2 * NB, nc - kbm) - NB;
+        for (int e = tid; e < NB * NB; e += WGB) {
+            const int c = e >> 5, q = e & 31;
+            if (q < wbm) F[(kbm + NB + q) + (long long)N * (kbm + c)] = F[(kbm + c) + (long long)N * (kbm + NB + q)];
+        }
         return;
     }
     constexpr int KW = 2 * NB; // columns of a pair
@@ -2293,7 +2302,9 @@ __global__ __launch_bounds__(WGB) void k_big_step2(const int4* __restrict__ desc
         for (int i = 0; i < 4; ++i) {
             const int c = 16 * tc + hi + 4 * i;
             L21s[c * LDP + q] = o[i];
-            if (d.z == 0 && q < w2 && c < w1) F[(kb1 + NB + q) + (long long)N * (kb1 + c)] = o[i];
+            // (workgroup 0) kept for the front TRANSPOSED in the unused upper triangle of the pivot block: the other workgroups of this launch may still be
+            // loading the raw block; role M of the next launch moves it into place, and that launch's role C' reads it from here
+            if (d.z == 0 && q < w2 && c < w1) F[(kb1 + c) + (long long)N * (kb1 + NB + q)] = o[i];
         }
     }
     if (rowWave) {
@@ -3396,6 +3407,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                             desc.push_back(make_int4((int)hDinvOff_[s], J >= 0 ? kb : -1, r0, -2));
                             desc.push_back(rec2);
                         }
+                    }
+                    if (J >= 0 && w > NB) { // role M
+                        desc.push_back(make_int4((int)hDinvOff_[s], kb, 0, -8));
+                        desc.push_back(rec2);
                     }
                     if (J >= 0 && hasBorder(s)) { // role C': the rows of pair J of X = L11^-1: 16-column tiles left of the pair, one workgroup for its own block
                         for (int c0 = 0; c0 <= kb; c0 += 16) {

@@ -20,6 +20,8 @@ def plan(N, nc):
             r0 = 0
             while r0 == 0 or r0 < N - Rb:
                 descs.append((kb if J >= 0 else -1, r0, -2)); r0 += ROWS_B2
+        if J >= 0 and w > NB:
+            descs.append((kb, 0, -8))   # role M: the pair's L(P2 rows, P1 columns) from its stash above the diagonal into place
         if J >= 0:
             c0 = 0
             while c0 <= kb:   # role C': 16-column tiles left of the pair, then its own block (c0 == kb)
@@ -36,7 +38,8 @@ def chol_inv(Ablk, wdt):
     A = np.eye(32); A[:wdt, :wdt] = Ablk[:wdt, :wdt]
     A = np.tril(A) + np.tril(A, -1).T
     return np.linalg.inv(np.linalg.cholesky(A))
-def run(N, nc):
+def run(N, nc, mode="snapshot", seed=3):
+    rng = np.random.default_rng(seed)
     A0 = rng.normal(size=(N, N)); A0 = A0 @ A0.T + N * np.eye(N)
     F = np.tril(A0).copy()
     dinv = {}
@@ -44,8 +47,19 @@ def run(N, nc):
     def slot(i):   # identity-padded 32 x 32 dinv block, as the kernel reads it
         B = np.eye(32); d_ = dinvIn[i]; B[:d_.shape[0], :d_.shape[1]] = d_; return B
     for descs in plan(N, nc):
-        Fin = F.copy(); Xin = X.copy(); XTin = XT.copy(); dinvIn = dict(dinv)
-        for (kb, a, b) in descs:
+        # what a workgroup reads: the state before the launch ("snapshot": no other workgroup of the launch has written yet) or the live arrays with the
+        # workgroups run in listed / reversed order ("forward", "reverse": every earlier one has finished) -- a launch without dependencies between its
+        # workgroups gives the same result under all three
+        live = mode != "snapshot"
+        Fin = F if live else F.copy(); Xin = X if live else X.copy(); XTin = XT if live else XT.copy(); dinvIn = dinv if live else dict(dinv)
+        for (kb, a, b) in (descs[::-1] if mode == "reverse" else descs):
+            if b == -8:   # role M
+                wbm = min(64, nc - kb) - 32
+                vals = [[Fin[kb + c, kb + 32 + q] for c in range(32)] for q in range(32)]
+                for q in range(32):
+                    for c in range(32):
+                        if q < wbm: F[kb + 32 + q, kb + c] = vals[q][c]
+                continue
             if b == -6:   # role C' (step2_border): rows of the pair [kb, kb + w) of X
                 c0 = a
                 w = min(64, nc - kb); wa = min(32, w); wb = w - wa
@@ -56,7 +70,7 @@ def run(N, nc):
                             if r < wa and c < wa: X[kb + r, kb + c] = X1[r, c]; XT[kb + c, kb + r] = X1[r, c]
                             if r < wb and c < wb: X[kb + 32 + r, kb + 32 + c] = X2[r, c]; XT[kb + 32 + c, kb + 32 + r] = X2[r, c]
                     if wb > 0:
-                        L21 = np.array([[Fin[min(kb + 32 + q, N - 1), kb + n] if q < wb else 0.0 for n in range(32)] for q in range(32)])
+                        L21 = np.array([[Fin[kb + n, min(kb + 32 + q, N - 1)] if q < wb else 0.0 for n in range(32)] for q in range(32)])   # the stash, transposed
                         U = L21 @ np.tril(X1)
                         X21 = -np.tril(X2) @ U
                         for r2 in range(wb):
@@ -74,7 +88,7 @@ def run(N, nc):
                         v = -sum(T[kp, c] * X1[r, kp] for kp in range(32) if kp <= r)
                         if r < wa: XR1[r, c] = v; X[kb + r, c0 + c] = v; XT[c0 + c, kb + r] = v
                 if wb > 0:
-                    L21 = np.array([[Fin[min(kb + 32 + q, N - 1), min(kb + n, N - 1)] if q < wb else 0.0 for n in range(32)] for q in range(32)])
+                    L21 = np.array([[Fin[kb + n, min(kb + 32 + q, N - 1)] if q < wb else 0.0 for n in range(32)] for q in range(32)])   # the stash, transposed
                     U = T[32:, :] + L21 @ XR1
                     for r2 in range(wb):
                         for c in range(16):
@@ -125,7 +139,7 @@ def run(N, nc):
                 L21 = A21 @ X1.T
                 if a == 0:
                     for q in range(w2):
-                        for c in range(w1): F[kb1 + 32 + q, kb1 + c] = L21[q, c]
+                        for c in range(w1): F[kb1 + c, kb1 + 32 + q] = L21[q, c]   # stash: transposed, above the diagonal
                 A22 = np.array([[Aq[32 + c, 32 + q] for c in range(32)] for q in range(32)])
                 A22 = np.tril(A22) - np.tril(L21 @ L21.T)
                 X2 = chol_inv(A22, w2)
@@ -150,5 +164,7 @@ def run(N, nc):
     errX = max(np.abs(np.tril(X) - Xref).max(), np.abs(np.triu(XT) - Xref.T).max()) / np.abs(Xref).max()
     return err, errX, untouched, sum(len(d) for d in plan(N, nc))
 for N, nc in [(64, 64), (100, 64), (160, 97), (130, 129), (200, 160), (96, 33), (70, 31), (260, 96), (230, 200)]:
-    e, ex, u, nwg = run(N, nc)
-    print(N, nc, "L / dinv err %.1e  X and X^T err (rel) %.1e  Schur block untouched %s  workgroups %d" % (e, ex, u, nwg))
+    res = [run(N, nc, mode) for mode in ("snapshot", "forward", "reverse")]
+    e, ex, u, nwg = res[0]
+    print(N, nc, "L / dinv err %.1e  X and X^T err (rel) %.1e  Schur block untouched %s  workgroups %d   any order of the workgroups: %s"
+          % (e, ex, u, nwg, all(r[0] < 1e-12 and r[1] < 1e-12 and r[2] for r in res)))
