@@ -20,7 +20,7 @@ IPCGPU_MF_STEP2=1 IPCGPU_MF_XINV_BORDER=0 timeout 120 python tools/check_solver.
 ok $out/check_noborder.txt || { echo "STAGE 1a FAILED (roles A', B', M)"; exit 0; }
 IPCGPU_MF_STEP2=1 timeout 120 python tools/check_solver.py > $out/check_border.txt 2>&1; tail -1 $out/check_border.txt
 ok $out/check_border.txt || { echo "STAGE 1b FAILED (role C')"; exit 0; }
-IPCGPU_MF_STEP2=1 timeout 600 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q -x 2>&1 | grep -E "passed|failed|Error" | tail -3 | tee $out/tests.txt
+( IPCGPU_TEST_STEP2=1 timeout 300 python -m pytest tests/test_gpu_step2.py -m gpu -q -x; IPCGPU_MF_STEP2=1 timeout 600 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -m gpu -q -x ) 2>&1 | grep -E "passed|failed|Error" | tail -3 | tee $out/tests.txt
 grep -q failed $out/tests.txt && { echo "STAGE 2 FAILED"; exit 0; }
 CHECK=1 bash tools/gpu_ab.sh step2/ab "" "IPCGPU_MF_STEP2=0" "IPCGPU_MF_STEP2=1"
 STEPS=12 bash tools/gpu_ab.sh step2/ab433 "--no-contact --size 433" "IPCGPU_MF_STEP2=0" "IPCGPU_MF_STEP2=1"
