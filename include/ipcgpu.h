@@ -52,9 +52,14 @@ int ipcgpu_version(void);
 int ipcgpu_ctx_create(int device_id, ipcgpu_ctx** out);
 int ipcgpu_ctx_destroy(ipcgpu_ctx*);
 int ipcgpu_ctx_set_solver(ipcgpu_ctx*, int solver_type);
-/* element sharding for multi-GPU runs: this context assembles only the tets
- * [tet_begin, tet_end) of the mesh order given to set_mesh; partial results are summed by the
- * caller's all-reduce (bench.py / torch.distributed over RCCL).  Default: all tets. */
+/* Sharding of the assembly for multi-GPU runs, one context per rank.  Together with ipcgpu_linsys_set_shard (same world) this is
+ * OWNER-COMPUTES ROWS: the rank assembles exactly the CSR rows its fronts read (the rows of the nodes its subtrees eliminate plus the separator rows
+ * above the cut; elements and contact stencils on a cut are evaluated by both sides) and NO matrix value crosses ranks -- see ipcgpu_opt_comm_stats
+ * below.  Energies, step bounds and the CCD sweeps are split by index ranges (elements [nT rank / world, nT (rank + 1) / world) in the order given to
+ * set_mesh) and combined by scalar all-reduces through the hook of ipcgpu_opt_set_allreduce[_stream].  Without a sharded solver (and for runs with
+ * lagged damping) the element pass is split by that same element range and the partial gradient / matrix values are summed by the hook.
+ * A consumer of the WHOLE matrix on an owner-computes context (ipcgpu_linsys_get_values / multiply / precondition_diag) gets IPCGPU_ERR_STATE until
+ * ipcgpu_opt_complete_matrix has been called on every rank.  Default: rank 0 of 1. */
 int ipcgpu_ctx_set_shard(ipcgpu_ctx*, int rank, int world_size);
 
 /* ---- tet-mesh files (host only, no GPU) ------------------------------------------------ */

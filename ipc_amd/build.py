@@ -31,21 +31,22 @@ def _needs(obj, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> str:
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=(), fma: bool = True) -> str:
     """variant / extra_flags: experiment builds (tools/): objects under _obj_<variant>, library libipcgpu_<variant>.so,
-    selected at load time with IPCGPU_LIB_VARIANT=<variant>.  The product build is the default (no variant)."""
+    selected at load time with IPCGPU_LIB_VARIANT=<variant>.  The product build is the default (no variant).
+    fma=False compiles EVERY file with -ffp-contract=off (the parity study of tools/gpu_nofma_study.py)."""
     global OBJ, LIB
     obj0, lib0 = OBJ, LIB
     if variant:
         OBJ = os.path.join(HERE, "_obj_" + variant)
         LIB = os.path.join(HERE, f"libipcgpu_{variant}.so")
     try:
-        return _build(force, verbose, list(extra_flags))
+        return _build(force, verbose, list(extra_flags), fma)
     finally:
         OBJ, LIB = obj0, lib0
 
 
-def _build(force, verbose, extra):
+def _build(force, verbose, extra, fma=True):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "ipcgpu.h"))
@@ -59,7 +60,7 @@ def _build(force, verbose, extra):
         if force or _needs(o, [s] + headers):
             # FMA contraction: on for the fp64 throughput kernels (parity there is a 1e-10 tolerance), off for
             # files that hold exact-comparison predicates (contact typing) and for host code
-            contract = "fast" if src in FMA_OK else "off"
+            contract = "fast" if (fma and src in FMA_OK) else "off"
             cmd = [HIPCC] + FLAGS + extra + [f"-ffp-contract={contract}"] + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", s, "-o", o]
             jobs.append(cmd)
 
@@ -90,4 +91,7 @@ def _build(force, verbose, extra):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    if "--nofma" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, variant="nofma", fma=False))
+    else:
+        print(build(force="--force" in sys.argv, verbose=True))

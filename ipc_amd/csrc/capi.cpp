@@ -70,6 +70,14 @@ void specChanged(ipcgpu_ctx* c)
 {
     if (c && c->opt) c->opt->specAsmValid = false;
 }
+// After an owner-computes assembly on a sharded context (HipOptimizer::ownerMode) a[] holds this rank's rows only.  Entry points that consume the WHOLE
+// matrix refuse to work on such a partial one instead of returning a rank's share silently; ipcgpu_opt_complete_matrix (a collective: never called
+// implicitly) completes it.  ADVICE round 4.
+void needWholeMatrix(ipcgpu_ctx* c)
+{
+    need(!(c->opt && c->opt->ownerMode() && !c->opt->matrixComplete),
+        "the matrix holds this rank's rows only (owner-computes assembly): call ipcgpu_opt_complete_matrix on every rank first");
+}
 // contact-pair lists shard with the elements (ipcgpu_ctx_set_shard): the handler is created lazily, so both places call this
 void applyContactShard(ipcgpu_ctx* c)
 {
@@ -148,6 +156,7 @@ int ipcgpu_ctx_destroy(ipcgpu_ctx* c)
 }
 int ipcgpu_ctx_set_solver(ipcgpu_ctx* c, int type)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(c && (type == IPCGPU_SOLVER_MULTIFRONTAL || type == IPCGPU_SOLVER_ROCSOLVER_CSRRF), "unknown solver type"); // LinSysSolver.cpp:24-26
         c->lin->solverType = type;
@@ -156,6 +165,7 @@ int ipcgpu_ctx_set_solver(ipcgpu_ctx* c, int type)
 }
 int ipcgpu_ctx_set_shard(ipcgpu_ctx* c, int rank, int world)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(c && world >= 1 && rank >= 0 && rank < world, "bad shard");
         c->rank = rank;
@@ -491,6 +501,8 @@ int ipcgpu_linsys_set_zero(ipcgpu_ctx* c)
     return guarded([&] {
         bind(c);
         L(c).setZero();
+        if (c->opt) c->opt->matrixComplete = true; // whatever the caller adds from here on is whole on every rank (the handler's entry points return whole sums)
+        specChanged(c);
         return IPCGPU_OK;
     });
 }
@@ -498,6 +510,7 @@ int ipcgpu_linsys_get_values(ipcgpu_ctx* c, double* a)
 {
     return guarded([&] {
         bind(c);
+        needWholeMatrix(c);
         L(c).d_a.download(a, L(c).ja.size(), c->stream);
         return IPCGPU_OK;
     });
@@ -560,6 +573,7 @@ int ipcgpu_linsys_multiply(ipcgpu_ctx* c, const double* x, double* y)
         bind(c);
         HipLinSysSolver& l = L(c);
         need(l.numRows > 0, "no pattern");
+        needWholeMatrix(c);
         DevBuf<double> dx, dy;
         dx.upload(x, l.numRows, c->stream);
         dy.alloc(l.numRows);
@@ -601,6 +615,7 @@ int ipcgpu_linsys_precondition_diag(ipcgpu_ctx* c, const double* in, double* out
     return guarded([&] {
         bind(c);
         HipLinSysSolver& l = L(c);
+        needWholeMatrix(c);
         DevBuf<double> di, dout;
         di.upload(in, l.numRows, c->stream);
         dout.alloc(l.numRows);
@@ -611,6 +626,7 @@ int ipcgpu_linsys_precondition_diag(ipcgpu_ctx* c, const double* in, double* out
 }
 int ipcgpu_linsys_set_shard(ipcgpu_ctx* c, int rank, int world)
 {
+    specChanged(c);
     return guarded([&] {
         needArg(c && world >= 1 && rank >= 0 && rank < world, "bad shard");
         need(world == 1 || c->opt->allreduce != nullptr || c->opt->allreduceStream != nullptr, "set the all-reduce hook first (ipcgpu_opt_set_allreduce)");
@@ -943,6 +959,7 @@ int ipcgpu_gradient(ipcgpu_ctx* c, double dtSq, int projectDBC, double* grad)
 // ---- Optimizer --------------------------------------------------------------------------------------
 int ipcgpu_opt_init(ipcgpu_ctx* c, double dt, int withGravity)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -977,6 +994,7 @@ int ipcgpu_opt_set_twist(ipcgpu_ctx* c, int nL, const int* l, int nR, const int*
 }
 int ipcgpu_opt_enable_self_collision(ipcgpu_ctx* c, double dHatEps)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -988,6 +1006,7 @@ int ipcgpu_opt_enable_self_collision(ipcgpu_ctx* c, double dHatEps)
 }
 int ipcgpu_opt_add_half_space(ipcgpu_ctx* c, const double* origin, const double* normal, double dHatEps, int* id)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1174,6 +1193,7 @@ int ipcgpu_opt_set_half_space_friction(ipcgpu_ctx* c, int id, double mu)
 }
 int ipcgpu_opt_next_subproblem(ipcgpu_ctx* c, int* more)
 {
+    specChanged(c);
     return guarded([&] {
         bind(c);
         const bool m = O(c).nextSubproblem();
@@ -1304,6 +1324,7 @@ int ipcgpu_opt_set_time_integration(ipcgpu_ctx* c, int type, double beta, double
 }
 int ipcgpu_opt_add_dirichlet(ipcgpu_ctx* c, int n, const int* ids, const double* lin3, const double* ang3, double t0, double t1)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1316,6 +1337,7 @@ int ipcgpu_opt_add_dirichlet(ipcgpu_ctx* c, int n, const int* ids, const double*
 }
 int ipcgpu_opt_end_dirichlet(ipcgpu_ctx* c, int group, double t_end)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);
@@ -1365,6 +1387,7 @@ int ipcgpu_opt_set_dirichlet_targets(ipcgpu_ctx* c, int group, int n, const doub
 }
 int ipcgpu_opt_add_neumann(ipcgpu_ctx* c, int n, const int* ids, const double* accel3, double t0, double t1)
 {
+    specChanged(c);
     return guarded([&] {
         HipOptimizer& o = O(c);
         bind(c);

@@ -392,6 +392,7 @@ void HipOptimizer::updateFrictionLag()
 bool HipOptimizer::nextSubproblem()
 {
     // tail of the fullyImplicit_IP loop body (Optimizer.cpp:1617-1790 with USE_DISCRETE_CMS, HOMOTOPY_VAR 1)
+    specAsmValid = false; // friction lag / dHat / kappa change under an assembly enqueued ahead
     if (!ipOn()) return false;
     const double dHatTarget = dHatTargetEps > 0.0 ? dHatTargetEps * dHatTargetEps * lenScale2() : dHat;
     const bool fric = solveFric(), homotopy = dHat > dHatTarget;
@@ -1428,6 +1429,7 @@ void HipOptimizer::beginTimestep()
 
 void HipOptimizer::initSubProblem()
 {
+    specAsmValid = false;
     projDBC = true;
     rhoDBC = 0.0;
     lastMove = completedStep;
@@ -1535,6 +1537,7 @@ bool HipOptimizer::newtonIter()
     }
     else {
         // gradient (:1861) and Hessian (:2327) come out of one fused element pass
+        specAsmValid = false; // an assembly enqueued ahead by an earlier fast-path pass describes a state this branch has left behind
         Tic t(timers[0], stream);
         computePrecondMtr(projDBC, true);
     }

@@ -48,8 +48,11 @@ class Pool {
     const std::function<void(long long, long long)>* body_ = nullptr;
     std::atomic<long long> next_{ 0 };
     long long end_ = 0, chunk_ = 1;
-    int participants_ = 1;
     int spin_ = 0;
+    // gen_ holds (generation << 16) | participants: a worker decides whether it takes part in a loop from the SAME atomic value it remembers as
+    // `seen` (a separate plain `participants_` could be read after run() had already set up the next loop: a worker would then drain one generation
+    // twice and run() could return while a body on its stack was still being executed -- ADVICE round 4)
+    static constexpr unsigned long long PART_MASK = 0xffffull;
     static void relax()
     {
 #if defined(__x86_64__) || defined(__i386__)
@@ -87,7 +90,7 @@ class Pool {
             }
             if (stop_.load()) return;
             seen = gen_.load(std::memory_order_acquire);
-            if (idx < participants_) { // a participant cannot miss a generation: run() does not return before all of them have checked out
+            if (idx < (int)(seen & PART_MASK)) { // a participant cannot miss a generation: run() does not return before all of them have checked out
                 drain();
                 pending_.fetch_sub(1, std::memory_order_acq_rel);
             }
@@ -99,6 +102,7 @@ public:
     {
         const int hw = (int)std::thread::hardware_concurrency();
         spin_ = (hw > 0 && n <= hw) ? 20000 : 0; // oversubscribed: straight to sleep
+        if (n > (int)PART_MASK) n = (int)PART_MASK;
         for (int t = 1; t < n; ++t) workers_.emplace_back([this, t] { work(t); });
     }
     ~Pool()
@@ -114,7 +118,7 @@ public:
     void run(long long n, const std::function<void(long long, long long)>& body)
     {
         const long long blocks = (n + GRAIN - 1) / GRAIN;
-        const int p = (int)(blocks < (long long)size() ? blocks : (long long)size());
+        const int p = (int)(blocks < (long long)size() ? blocks : (long long)size()); // (size() <= PART_MASK: the constructor caps it)
         if (p <= 1) {
             inside() = true;
             body(0, n);
@@ -126,9 +130,8 @@ public:
         chunk_ = (n + 8LL * p - 1) / (8LL * p);
         if (chunk_ < 1) chunk_ = 1;
         next_.store(0, std::memory_order_relaxed);
-        participants_ = p;
         pending_.store(p - 1, std::memory_order_relaxed);
-        gen_.fetch_add(1, std::memory_order_seq_cst);
+        gen_.store((((gen_.load(std::memory_order_relaxed) >> 16) + 1) << 16) | (unsigned long long)p, std::memory_order_seq_cst); // (only run() writes gen_)
         if (sleepers_.load() > 0) {
             {
                 std::lock_guard<std::mutex> lk(m_);

@@ -8,30 +8,22 @@ import os
 import numpy as np
 import pytest
 
-from test_oracle_vs_reference import (BOXRULE_SCENES, CODIM_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, SHIPPED_SCENES, check_chain, check_codim, check_damped_bar,
-                                      check_plates, check_shipped,
+from test_oracle_vs_reference import (BOXRULE_SCENES, CODIM_SCENES, ENVELOPE_SCENES, GOLD, HANDLE_SCENES, MORE_SCENES, PLATE_SCENES, RESTART_SCENES, SHIPPED_SCENES, check_chain, check_codim,
+                                      check_damped_bar, check_envelope, check_plates, check_shipped,
                                       check_boxrule, check_restart, check_rot_cylinders, check_scene, check_seg_bed, check_warm5, load_scene, rel, run_scene)
 
 pytestmark = pytest.mark.gpu
 
-# Round 4: the HIP path is held to the CPU restatement's own budgets (tests/test_oracle_vs_reference.py) -- no blanket "one more mismatch", "10 x the tolerance" or
-# "+-25 % of the total work" any more.  FIVE scenes keep a budget of their own, each for the same stated reason: their contact begins from a state that round-off
-# decides -- F = I up to the last bits (the sigma-space projection of IglUtils::makePD2d is discontinuous there) or cubes stacked exactly corner
-# above corner (the closest-feature typing sits on its region boundaries, exact comparisons with 0.0) -- and the HIP element kernels contract multiply-adds where
-# the restatement (and the reference's -O2 build) does not, so the two take different, equally valid Newton paths there.  The same scenes CONTINUED from the
-# reference's own post-contact state give the reference's count in every step (test_continuation_from_the_references_own_state).
-GPU_MISMATCH_BUDGET = {
-    "dbc_time_range": 5,  # touch-down from exact rest: steps 17-19, 21, 22 (restatement: three steps)
-    "aligned_cubes": 6,  # exactly aligned cubes: six of the 30 counts differ after the impacts (restatement: three), end positions inside the same 1e-2
-    "aligned_cubes_fric": 12,  # + friction: the resting steps take 2 iterations where the reference takes 1 (explained in round 3: from the reference's own status24 both take 1)
-    "attach": 1,  # shipped scene `attach`: one count of the first contact step (restatement: none)
-}
-# ... and their end positions: the exactly aligned cubes sit in a symmetric configuration whose lateral drift is born from round-off at the impact of step 12 and
-# grows linearly from there.  Measured on the REFERENCE ITSELF (tools/masonry_perturb.py on 12_alignedCubes.txt, profiles/r04_aligned_cubes_reference_1ulp_perturbation.txt):
-# continued from its own status1 with ONE coordinate of one node moved by one ulp it ends 1.9e-2 of the scene's scale away from its own unperturbed run, with every
-# coordinate moved by a random +-1 ulp 1.7e-2 / 4.4e-3 / 2.6e-3 -- the end state of this scene is defined to about 2e-2, whoever computes it.  The HIP run ends 1.1e-2
-# (elimination order with leaf domains of 8 nodes) or 2.3e-2 (12 nodes, the default since round 4) from the reference's; the budget is 1.5 x the reference's own spread.
-GPU_END_TOL = {"aligned_cubes": 3e-2, "aligned_cubes_fric": 2e-2}
+# Round 5: NO GPU-only budgets any more.  Rounds 3-4 gave five scenes whose contact begins from exact rest budgets of their own (5 / 6 / 12 / 1 mismatching
+# Newton counts, an end tolerance that went from 2e-2 to 3e-2 when the elimination order changed) and blamed multiply-add contraction in the element kernels.
+# That explanation was tested and is WRONG: a library with -ffp-contract=off in every file differs from the reference in as many steps
+# (tools/gpu_nofma_study.py, profiles/r05_nofma_parity_study.txt).  What is right is the sensitivity: the REFERENCE ITSELF, continued from its own status1
+# with every coordinate moved by one ulp, changes up to 4 (dbc_time_range), 6 (aligned_cubes), 16 (aligned_cubes_fric), 2 (two_cubes_fall), 1 (attach) of its
+# Newton counts and ends up to 2.1e-2 of the scene's size away from its own unperturbed run (tools/make_golden_ensemble.py, tests/golden/ref_ensemble_*.npz).
+# These scenes are therefore held to the ENVELOPE of that ensemble (check_envelope, tests/test_oracle_vs_reference.py: exact before the first step in which
+# the reference disagrees with itself; inside the ensemble's count range +-1 and within twice its position spread from there on) -- a criterion fixed by the
+# reference and the scene, the same for the CPU restatement and for the HIP path, that cannot follow this repository's code.  The same scenes CONTINUED from
+# the reference's own post-contact state give the reference's count in every step (test_continuation_from_the_references_own_state).
 GPU_RESTART_TOL = {"cubes_dhat_homotopy": 2e-7}  # the 30-39-iteration steps of the dHat homotopy: 1.16e-7 after four steps (restatement: 1e-7), every count equal
 
 
@@ -191,20 +183,13 @@ def test_scene_bar_twist_minimisers_against_the_reference(gpu_lib):
 
 def test_scene_two_cubes_fall_against_the_reference(gpu_lib):
     """2cubesFall.txt (ground and self-contact with friction) run by the reference itself, 40 steps: free fall identical to
-    round-off, the same Newton iteration counts through both impacts except the step of the first touch-down (F = I up to
-    round-off in the bottom cube: the makePD2d discontinuity)."""
+    round-off; from the first touch-down on (where the reference's own counts move by 2 under a one-ulp perturbation: 6 -> 4 or 5 in step 18, 8 -> 7 ... 11
+    in step 26) inside the envelope of that ensemble (observed: 4 in step 18, every other count equal, end positions 4e-4)."""
     S, meshes = load_scene("two_cubes_fall")
     steps = int(S["steps"])
     c = gpu_lib.Context(0)
     pos, its = run_scene(S, meshes, c, steps)
-    free = 17
-    for s in range(free):
-        assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-12
-    assert np.array_equal(its[:free], S["iters"][:free])
-    differ = np.nonzero(its != S["iters"])[0]
-    assert len(differ) <= 8, (its.tolist(), S["iters"].tolist())
-    assert abs(int(its.sum()) - int(S["iters"].sum())) <= 0.12 * int(S["iters"].sum()), (its.tolist(), S["iters"].tolist())
-    assert np.abs(pos[-1] - S["positions"][-1]).max() <= 1e-2 * np.abs(S["positions"][-1]).max()
+    check_envelope("two_cubes_fall", S, pos, its)  # free fall to 1e-12 and every count; from the touch-down on inside the reference's own one-ulp ensemble
     c.close()
 
 
@@ -232,8 +217,10 @@ def test_more_scenes_against_the_reference(name, exact, mism, tol, gpu_lib):
     ref_its = S["iters"][:len(its)]
     report = (its.tolist(), ref_its.tolist())
     # (1e-9 before the touch-down: the homotopy scene solves barrier problems at a dHat of half the scene from its first step on)
-    # the CPU restatement's own budgets, except where GPU_MISMATCH_BUDGET (top of this file) states another one and why
-    check_scene(S, pos, its, exact, GPU_MISMATCH_BUDGET.get(name, mism), GPU_END_TOL.get(name, tol), exact_tol=1e-9)
+    if name in ENVELOPE_SCENES:  # the touch-downs from exact rest: the envelope of the reference's own one-ulp ensemble (top of this file)
+        check_envelope(name, S, pos, its, exact_tol=1e-9)
+    else:  # everything else: the CPU restatement's own budgets
+        check_scene(S, pos, its, exact, mism, tol, exact_tol=1e-9)
     assert report is not None
     c.close()
 
@@ -279,7 +266,10 @@ def test_shipped_scenes_against_the_reference(name, mism, tol, gpu_lib):
     c = gpu_lib.Context(0)
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     c.close()
-    check_shipped(S, pos, its, GPU_MISMATCH_BUDGET.get(name, mism), tol)
+    if name in ENVELOPE_SCENES:
+        check_envelope(name, S, pos, its, exact_tol=1e-9)
+    else:
+        check_shipped(S, pos, its, mism, tol)
 
 
 def test_trash_compactor_against_the_reference(gpu_lib):
@@ -334,9 +324,6 @@ def test_box_rule_scripts_against_the_reference(name, tol, gpu_lib):
     c = gpu_lib.Context(0)
     pos, its = run_scene(S, meshes, c, int(S["steps"]))
     c.close()
-    if name == "script_stamp_inv":  # 548 Newton iterations out of an inside-out start: the path is long enough for a different summation order to show
-        assert abs(int(its[0]) - int(S["iters"][0])) <= 30 and np.abs(pos[-1] - S["positions"][-1]).max() <= 1e-5 * np.abs(S["positions"]).max(), its.tolist()
-        return
     check_boxrule(S, pos, its, max(3 * tol, 1e-7))
 
 

@@ -38,6 +38,9 @@ def main(n=150):
     print(f"  fused fronts   {int(out[4]):6d}  {out[1] / 1e9:7.3f} GFLOP")
     print(f"  big fronts     {int(out[5]):6d}  steps {out[2] / 1e9:7.3f} GFLOP, Schur complements {out[3] / 1e9:7.3f} GFLOP")
     print("  dependent 32-column steps per level:", chain[:nl].tolist(), "sum", int(chain[:nl].sum()))
+    if "--levels" in sys.argv:
+        sys.stdout.flush()
+        L.mf_level_report(C.c_int(len(ia) - 1), ia.ctypes.data_as(C.c_void_p), ja.ctypes.data_as(C.c_void_p), Vr.ctypes.data_as(C.c_void_p), C.c_int(12), C.c_int(8))
 
 
 if __name__ == "__main__":
