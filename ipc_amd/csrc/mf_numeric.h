@@ -52,18 +52,13 @@ public:
     // two-call sequence (sharded / graph runs) and the factorisation failed there.
     bool factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev, bool wait = true);
     bool lastPivotsOk() const { return pivotsOk(); }
-    bool pivotsOk() const; // false: a non-positive pivot; throws when a merged step launch timed out (flag bit 2)
+    bool pivotsOk() const; // false: a non-positive pivot
     bool ready() const { return ns_ > 0; }
     size_t front_bytes() const { return fronts_.n * sizeof(double); }
 
 private:
     void enqueueFactor(const double* a_dev, bool overlapForward = false);
     void enqueueSolve(const double* rhs_dev, double* x_dev);
-    void dropGraphs();
-    hipGraphExec_t graphF_ = nullptr, graphS_ = nullptr;
-    const double *graphA_ = nullptr, *graphRhs_ = nullptr;
-    double* graphX_ = nullptr;
-    bool useGraph_ = false; // IPCGPU_MF_GRAPH=1: measured neutral at mat150 (the level loop is GPU-chain-bound, not dispatch-bound)
     struct Range {
         int off = 0, cnt = 0;
     };
@@ -76,10 +71,7 @@ private:
         std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1
         Range schur; // one-pass Schur complement tiles of the big fronts
         bool schur64 = false; // ... as 64 x 64 tiles (k_big_schur64) instead of 32 x 32 with the columns split over the waves
-        // round 4: on the levels whose pivot chain is long the update rides on the chain's launches in passes of a few panels (role S of k_big_step);
-        // `schur` is then empty.  stepTop: the level's step launches carry roles C / S (k_big_step<true>)
-        bool stepTop = false;
-        bool step2 = false; // the level's big fronts advance two panels per launch (k_big_step2, IPCGPU_MF_STEP2=1: written at the end of round 4, not yet run)
+        bool stepTop = false; // the level's step launches carry role C, the explicit inverse growing by bordering (k_big_step<true>)
         bool fuseEA = false; // the level's Schur kernel gathers the children of the update block itself (k_big_schur64_ea); the extend-add only writes own columns
         Range fwdRect, bwdInit; // descriptors of the row-/column-parallel halves of the big-front solves
         Range bigTri; // into triList_: big fronts whose triangle is swept by one workgroup (no explicit inverse)
@@ -88,7 +80,6 @@ private:
     int rank_ = 0, world_ = 1;
     long long schur64Min_ = 512;
     bool xinvBorder_ = true; // X = L11^-1 by bordering inside the step launches (IPCGPU_MF_XINV_BORDER=0: recursive doubling on the side stream)
-    int xinvSkipTop_ = 0; // fronts of the last n levels solve their triangles block by block instead of through an explicit inverse (IPCGPU_MF_XINV_SKIP_TOP)
     AllreduceFn allreduce_ = nullptr;
     AllreduceStreamFn allreduceStream_ = nullptr;
     void* allreduceUser_ = nullptr;
@@ -120,25 +111,14 @@ private:
     DevBuf<int4> xinvDesc_;
     DevBuf<int> triList_;
     struct XinvLevel {
-        Range blocks; // into invBlockList_: diagonal blocks of the level's inverse fronts
+        Range blocks; // diagonal blocks of the level's inverse fronts (cnt > 0: the level has inverses to form by recursive doubling)
         Range init; // into xinvDesc_
         std::vector<std::pair<Range, Range>> rounds; // per doubling: the two GEMM launches (descriptor pairs)
     };
     std::vector<XinvLevel> xinvLevel_;
-    Range plainBlocks_; // diagonal blocks of all other fronts (inverted at the end of the factorisation)
-    DevBuf<int> invBlockList_;
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
-    // consecutive step launches of a level merged into one, later steps waiting on in-launch counters (k_big_step, StepGroup): IPCGPU_MF_STEP_MERGE = steps per
-    // launch (1 = one launch per step, as before round 4), IPCGPU_MF_STEP_MERGE_WGS = workgroups per launch at most
-    int stepMerge_ = 1, stepMergeWgs_ = 1536; // OFF by default: measured slower than the launches it replaces (profiles/r04_merged_step_launches_ab.txt)
-    DevBuf<int> stepCtr_;
-    bool step2_ = false; // IPCGPU_MF_STEP2
-    bool borderXT_ = true; // role C keeps X^T beside X for coalesced operand loads (IPCGPU_MF_BORDER_XT=0: reads the column-major X)
-    bool fuseEA_ = true; // IPCGPU_MF_FUSE_EA=0: extend-add of the whole front, then a read-modify-write Schur pass (rounds 1-3)
     int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)
-    bool fwdRootOnMain_ = true, fwdJoined_ = false; // the root's forward sweep on the main stream (IPCGPU_MF_FWD_ROOT_ON_MAIN=0: on the forward stream like the other levels)
-    int schurFold_ = 0, schurFoldMinSteps_ = 8; // off by default: measured neutral at mat150 (382.4 it/s with passes of 4 panels, 384.1 without) and a loss where the update matrices are large
-    long long schurFoldBudget_ = 128ll << 20; // bytes of update matrix the folded passes of one level may move (IPCGPU_MF_SCHUR_FOLD_MB) // IPCGPU_MF_SCHUR_FOLD: panels per folded pass (0 = one pass behind the chain); ..._MIN: levels with at least this many panels
+    bool fwdJoined_ = false; // the root's forward sweep went onto the main stream (factorizeSolve)
     // factorizeSolve(): the forward sweep of a level is enqueued on its own stream as soon as that level's factor kernels are, so that it
     // runs beside the latency-bound pivot chain of the levels above instead of behind the whole factorisation
     hipStream_t fwd_ = nullptr;

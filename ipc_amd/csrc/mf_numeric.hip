@@ -45,15 +45,12 @@ constexpr int ROW_WAVES_B = 3; // row waves per role-B workgroup (1 was measured
 #endif
 constexpr int MT_B = MF_ROWS_MT; // 16-row tiles per row wave of a role-B workgroup
 constexpr int ROWS_B = 16 * MT_B * ROW_WAVES_B; // panel rows per role-B workgroup
-constexpr int PIVOT_T0 = WGB - 64; // first thread of the pivot wave
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
-constexpr int EA_ITEMS = 8; // entries per thread in the extend-add kernel
 
 constexpr int TS = 64; // trailing-update tile
 constexpr int MV_ROWS = 32; // rows per workgroup of the forward matrix-vector kernels (k_big_fwd_rect, k_xinv_fwd): 32 rows x 8 column groups
 constexpr int FD_STRIDE_EA = 64; // packed front descriptors (same layout as the fused kernel's, see k_front_fused)
 constexpr int FUSED_MAX_KIDS_EA = 8;
-constexpr int PIVOT_BATCH = 16; // broadcasts issued ahead of their FMAs in the pivot-block Cholesky (2 SGPRs each)
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 
 struct TreeView {
@@ -179,356 +176,6 @@ __device__ __forceinline__ double rsqrt_nr(double d)
     return r;
 }
 
-// Cholesky of a (<=) 32x32 pivot block by one wave: lane r owns row r in registers, cross-lane traffic through v_readlane.
-// blk is k-major in LDS: blk[k * ld + r] = A(r, k).  Columns / rows >= w are ignored.  rdiag[k] receives 1 / L(k, k)
-// (0 for k >= w).  Returns true on a bad pivot.
-__device__ __forceinline__ bool wave_potrf32(double* blk, int ld, int w, int lane, double* rdiag)
-{
-    bool bad = false;
-    double row[NB];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        row[k] = 0.0;
-        if (k < w) { // uniform: columns >= w may lie outside the caller's LDS block, no address is formed for them
-            const double v = blk[k * ld + (lane & (NB - 1))];
-            row[k] = (lane < w && k <= lane) ? v : 0.0;
-        }
-    }
-    double myRd = 0.0;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        if (j < w) { // uniform
-            double djj = bcast_lane(row[j], j);
-            if (!(djj > 0.0)) {
-                bad = true;
-                djj = 1.0;
-            }
-            const double invd = rsqrt_nr(djj);
-            if (lane == j) myRd = invd;
-            row[j] *= invd; // lane j: d / sqrt(d); lanes above j hold the unused upper triangle
-            // The multipliers of a column are broadcast in batches AHEAD of the FMAs that consume them.  Left to itself the
-            // scheduler emits readlane, readlane, fma triplets, and every fma then waits out the VALU -> SGPR -> VALU round
-            // trip of its own operand: 16.9 k cycles per block against 12.5 k with the batches (bit-identical results).
-#pragma unroll
-            for (int j0 = j + 1; j0 < NB; j0 += PIVOT_BATCH) {
-                double m[PIVOT_BATCH];
-#pragma unroll
-                for (int q = 0; q < PIVOT_BATCH; ++q)
-                    if (j0 + q < NB) m[q] = bcast_lane(row[j], j0 + q);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int q = 0; q < PIVOT_BATCH; ++q)
-                    if (j0 + q < NB) row[j0 + q] -= row[j] * m[q];
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < NB; ++k)
-        if (lane < w && k <= lane && k < w) blk[k * ld + lane] = row[k];
-    if (lane < NB) rdiag[lane] = myRd;
-    return bad;
-}
-
-// Inverse of a lower-triangular 32x32 block.  rows[r * ld + k] = L(r, k) for k < r and 1 / L(r, r) on the diagonal (LDS,
-// row-major so that a row is contiguous).  Lane c (< 32) produces column c of X = L^-1 by forward substitution with the
-// column in registers: X(r, c) = (delta_rc - sum_{k < r} L(r, k) X(k, c)) / L(r, r); L(r, k) is an LDS broadcast.  The reads
-// of row r are tied to X(r - 2, c) (see row_trsm32 for why) so that they run one row ahead of their use.
-constexpr int LDI = NB + 2;
-__device__ __forceinline__ void wave_trinv32(const double* rows, int ld, int lane, double* out)
-{
-    if (lane >= NB) return;
-    double x[NB];
-#pragma unroll
-    for (int r = 0; r < NB; ++r) {
-        int z = 0;
-        if (r >= 2) asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[r - 2])));
-        const double* lr = rows + r * ld + z;
-        double acc0 = (r == lane) ? 1.0 : 0.0, acc1 = 0.0;
-#pragma unroll
-        for (int k = 0; k + 1 < r; k += 2) {
-            acc0 -= lr[k] * x[k];
-            acc1 -= lr[k + 1] * x[k + 1];
-        }
-        if (r & 1) acc0 -= lr[r - 1] * x[r - 1];
-        x[r] = (acc0 + acc1) * lr[r];
-    }
-#pragma unroll
-    for (int r = 0; r < NB; ++r) out[r * LDI + lane] = x[r];
-}
-
-// x <- x L^-T for one row held in registers (right-looking substitution: after x[k] is final it is swept out of the columns
-// behind it, so the FMAs of one k are independent).  L(c, k) = blk[k * ld + c], 1 / L(k, k) = rdiag[k]; both LDS broadcasts.
-// RW rows per thread share every LDS read: the broadcasts (one 64-lane return per FMA otherwise) are what bounds this step.
-template <int RW>
-__device__ __forceinline__ void row_trsm32(double (&x)[RW][NB], const double* blk, int ld, const double* rdiag, int w = NB)
-{
-    // Software pipeline: the LDS reads of column k + 1 are issued at the top of step k and consumed one step later.  Their
-    // addresses are made to depend on x[0][k] (final once step k - 1 has swept it): with compile-time LDS addresses the
-    // scheduler otherwise issues all 496 reads up front and spills ~1000 registers, and without the look-ahead every step
-    // would wait out one LDS round trip.  Columns >= w (uniform) are never touched: they may lie outside the caller's block.
-    double lc[NB], ln[NB];
-    double rdc = rdiag[0], rdn = 0.0;
-#pragma unroll
-    for (int c = 1; c < NB; ++c) lc[c] = blk[c];
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        if (k < w) {
-            if (k + 1 < w) {
-                int z;
-                asm volatile("v_mov_b32 %0, 0" : "=v"(z) : "v"(__double2loint(x[0][k])));
-                const double* lk = blk + (k + 1) * ld + z;
-                rdn = rdiag[k + 1 + z];
-#pragma unroll
-                for (int c = k + 2; c < NB; ++c) ln[c] = lk[c];
-            }
-#pragma unroll
-            for (int h = 0; h < RW; ++h) x[h][k] *= rdc;
-#pragma unroll
-            for (int c = k + 1; c < NB; ++c) {
-#pragma unroll
-                for (int h = 0; h < RW; ++h) x[h][c] -= x[h][k] * lc[c];
-            }
-#pragma unroll
-            for (int c = k + 2; c < NB; ++c) lc[c] = ln[c];
-            rdc = rdn;
-        }
-    }
-}
-
-// Same solve for the fused single-workgroup kernel, where several waves per SIMD hide the LDS latency: no prefetch arrays
-// (the pipelined version holds 3 x 32 doubles per thread, which alone caps the occupancy at one or two waves per SIMD).
-__device__ __forceinline__ void row_trsm32_lean(double (&x)[NB], const double* blk, int ld, const double* rdiag, int w)
-{
-#pragma unroll
-    for (int k = 0; k < NB; ++k) {
-        if (k < w) { // uniform
-            x[k] *= rdiag[k];
-            const double* lk = blk + k * ld;
-#pragma unroll
-            for (int c = k + 1; c < NB; ++c) x[c] -= x[k] * lk[c]; // c >= w: reads stay inside the caller's block, results unused
-        }
-    }
-}
-
-// Cholesky of a (<=) 32 x 32 pivot block by one wave, blocked by 8 with the off-diagonal work on the matrix cores.
-//   blk[k * LDP + r] = A(r, k), r >= k (LDS, k-major, full 32 x LDP block; entries with an index >= w are ZERO on entry)
-//   on exit: L in the lower triangle, rdiag[k] = 1 / L(k, k) (0 for k >= w), and -- so that wave_trinv32_fast can skip its
-//   substitution step -- the inverses of the four 8 x 8 diagonal blocks of L in Xs (identity-padded; Xs must be zero elsewhere)
-// Per 8-column panel: the 8 x 8 diagonal block is factored and inverted in registers by 8 lanes (lane = row, v_readlane
-// broadcasts: the only serial part, ~1/4 of what the 32-wide scalar loop serialises), the rows below are L21 = A21 X^T and the
-// trailing block is A22 -= L21 L21^T, both as v_mfma_f64_16x16x4_f64 products formed transposed (A[l & 15][l >> 4],
-// B[l >> 4][l & 15], D row = (l >> 4) + 4 reg, col = l & 15) with operands read from / written to the LDS block.
-// wave_potrf32 performs sum_j (31 - j) broadcast-multiply-add triplets on one wave's VALU, this version 4 x 28 of them.
-__device__ __forceinline__ bool wave_potrf32_blocked(double* blk, int w, int lane, double* rdiag, double* Xs)
-{
-    constexpr int ld = LDP;
-    const int lo = lane & 15, hi = lane >> 4;
-    bool bad = false;
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        const int j0 = 8 * b;
-        if (j0 >= w) { // uniform: nothing left, identity padding of the inverse
-            if (lane < 8) {
-                rdiag[j0 + lane] = 0.0;
-                Xs[(j0 + lane) * LDX + j0 + lane] = 1.0;
-            }
-            continue;
-        }
-        // ---- (i) 8 x 8 diagonal block, lane r < 8 holds row j0 + r (rows / columns >= w: identity)
-        double a[8], x[8], myRd = 0.0;
-        const int r = lane & 7;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const double v = blk[(j0 + c) * ld + j0 + r];
-            a[c] = (c <= r) ? ((j0 + r < w && j0 + c < w) ? v : (c == r ? 1.0 : 0.0)) : 0.0;
-        }
-        double rd[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            double djj = bcast_lane(a[j], j);
-            if (!(djj > 0.0)) {
-                bad = true;
-                djj = 1.0;
-            }
-            const double invd = rsqrt_nr(djj);
-            rd[j] = invd;
-            if (r == j) myRd = invd;
-            a[j] *= invd;
-            double m[8];
-#pragma unroll
-            for (int c = j + 1; c < 8; ++c) m[c] = bcast_lane(a[j], c);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = j + 1; c < 8; ++c) a[c] -= a[j] * m[c];
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // ---- (ii) its inverse: lane c < 8 computes column c, L(q, k) broadcast from lane q
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            double acc = (q == r) ? 1.0 : 0.0;
-            double m[8];
-#pragma unroll
-            for (int k = 0; k < q; ++k) m[k] = bcast_lane(a[k], q);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int k = 0; k < q; ++k) acc -= m[k] * x[k];
-            x[q] = acc * rd[q];
-        }
-        if (lane < 8) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-                if (c <= r && j0 + r < w && j0 + c < w) blk[(j0 + c) * ld + j0 + r] = a[c];
-            rdiag[j0 + r] = (j0 + r < w) ? myRd : 0.0;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) Xs[(j0 + r) * LDX + j0 + q] = x[q]; // X(j0 + q, j0 + r): column r of the inverse
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (b == 3 || j0 + 8 >= w) continue; // uniform: no rows below
-        // ---- (iii) rows below: L(R, j0 + c) = sum_k A(R, j0 + k) X(j0 + c, j0 + k), transposed product D(c, R)
-        f64x4 p0 = { 0.0, 0.0, 0.0, 0.0 }, p1 = { 0.0, 0.0, 0.0, 0.0 };
-        const int R0 = j0 + 8 + lo, R1 = j0 + 24 + lo;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kk = 4 * ks + hi;
-            const double xa = (lo < 8) ? Xs[(j0 + kk) * LDX + j0 + lo] : 0.0; // A[c = lo][kk] = X(j0 + c, j0 + kk)
-            const double b0 = (R0 < NB) ? blk[(j0 + kk) * ld + R0] : 0.0; // B[kk][R] = A(R, j0 + kk)
-            const double b1 = (R1 < NB) ? blk[(j0 + kk) * ld + min(R1, NB - 1)] : 0.0;
-            p0 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b0, p0, 0, 0, 0);
-            if (b == 0) p1 = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, b1, p1, 0, 0, 0);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { // rows c = hi + 4 i < 8 of the product
-            const int c = hi + 4 * i;
-            if (R0 < NB) blk[(j0 + c) * ld + R0] = p0[i];
-            if (b == 0 && R1 < NB) blk[(j0 + c) * ld + R1] = p1[i];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- (iv) trailing block: A(R, C) -= sum_k L(R, j0 + k) L(C, j0 + k) for R >= C >= j0 + 8, transposed product D(C, R)
-        //      16 x 16 tiles (tc, tr) of the remaining 24 / 16 / 8 rows: (0, 0) always, (0, 1) and (1, 1) for the first panel
-        f64x4 t00 = { 0.0, 0.0, 0.0, 0.0 }, t01 = { 0.0, 0.0, 0.0, 0.0 }, t11 = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int kk = 4 * ks + hi;
-            const double l0 = (R0 < NB) ? blk[(j0 + kk) * ld + R0] : 0.0; // rows j0 + 8 + lo
-            const double l1 = (R1 < NB) ? blk[(j0 + kk) * ld + min(R1, NB - 1)] : 0.0; // rows j0 + 24 + lo
-            t00 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, l0, t00, 0, 0, 0);
-            if (b == 0) {
-                t01 = __builtin_amdgcn_mfma_f64_16x16x4f64(l0, l1, t01, 0, 0, 0);
-                t11 = __builtin_amdgcn_mfma_f64_16x16x4f64(l1, l1, t11, 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int C0 = j0 + 8 + hi + 4 * i, C1 = j0 + 24 + hi + 4 * i; // D row -> column index C of the block
-            if (R0 < NB && C0 < NB && R0 >= C0) blk[C0 * ld + R0] -= t00[i];
-            if (b == 0) {
-                if (R1 < NB && C0 < NB) blk[C0 * ld + R1] -= t01[i]; // R1 >= 24 > C0
-                if (R1 < NB && C1 < NB && R1 >= C1) blk[C1 * ld + R1] -= t11[i];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    return bad;
-}
-
-// X = L^-1 of a factored 32 x 32 pivot block by one wave, recursive doubling on the matrix cores.
-//   blk[k * ld + r] = L(r, k) for r > k (LDS, k-major), rdiag[k] = 1 / L(k, k); rows / columns >= w count as identity
-//   Xs[c * LDX + r] = X(r, c), all 32 x 32 entries written (zeros above the diagonal)
-// 1. the four 8 x 8 diagonal blocks by substitution: lane 8 b + c computes column c of block b (8-long chain)
-// 2. 16 x 16: X21 = -X22 (L21 X11) for both halves at once, the two 8 x 8 problems packed block-diagonally into one
-//    16 x 16 x 16 product (v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4], B[l >> 4][l & 15], D row = (l >> 4) + 4 reg, col = l & 15)
-// 3. 32 x 32: the same with full 16 x 16 blocks.
-// The first product of a pair leaves T in the accumulator layout, which is exactly the B-operand layout of the second
-// (register i holds row (l >> 4) + 4 i): no LDS round trip between them.  ~1.5 k cycles against ~6 k for the substitution
-// of wave_trinv32, and it runs inside the step that factored the block, so the panel rows can be solved by a product.
-template <bool HAVE_DIAG8 = false>
-__device__ __forceinline__ void wave_trinv32_fast(const double* blk, int ld, const double* rdiag, int w, int lane, double* Xs)
-{
-    const int lo = lane & 15, hi = lane >> 4;
-    if (!HAVE_DIAG8) {
-        for (int e = lane; e < NB * LDX; e += 64) Xs[e] = 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (!HAVE_DIAG8 && lane < NB) {
-        const int b8 = lane & ~7, c = lane & 7;
-        double Lr[8][8], rd[8], x[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            rd[r] = (b8 + r < w) ? rdiag[b8 + r] : 1.0;
-#pragma unroll
-            for (int k = 0; k < r; ++k) Lr[r][k] = blk[(b8 + k) * ld + b8 + r];
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            double acc = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < r; ++k) acc -= Lr[r][k] * x[k];
-            x[r] = acc * rd[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) Xs[lane * LDX + b8 + r] = x[r];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    {
-        // 16 x 16 level, halves h = 0 (blocks 0, 1) and h = 1 (blocks 2, 3) packed: rows / columns 0..7 <-> h = 0, 8..15 <-> h = 1
-        f64x4 t = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = 4 * ks + hi;
-            // A[m = lo][kk]: L21 of the half of row m;  B[kk][n = lo]: X11 of the half of row kk
-            const bool ha = lo >= 8, hk = kk >= 8;
-            const double av = blk[(ha ? kk + 8 : kk) * ld + (ha ? lo + 16 : lo + 8)]; // h=0: L(8+m, kk); h=1: L(24+m-8, 16+kk-8)
-            const double bv = Xs[(hk ? lo + 8 : lo) * LDX + (hk ? kk + 8 : kk)]; // h=0: X(kk, n); h=1: X(16+kk-8, 16+n-8)
-            t = __builtin_amdgcn_mfma_f64_16x16x4f64((ha == hk) ? av : 0.0, (hk == (lo >= 8)) ? bv : 0.0, t, 0, 0, 0);
-        }
-        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = 4 * ks + hi;
-            const bool ha = lo >= 8, hk = kk >= 8;
-            const double av = Xs[(ha ? kk + 16 : kk + 8) * LDX + (ha ? lo + 16 : lo + 8)]; // h=0: X(8+m, 8+kk); h=1: X(24+m-8, 24+kk-8)
-            u = __builtin_amdgcn_mfma_f64_16x16x4f64((ha == hk) ? av : 0.0, t[ks], u, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = hi + 4 * i; // row of the packed result, column lo
-            if ((m >= 8) == (lo >= 8)) {
-                const int row = (m >= 8) ? m + 16 : m + 8, col = (lo >= 8) ? lo + 8 : lo;
-                Xs[col * LDX + row] = -u[i];
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    {
-        // 32 x 32 level: X[16:32, 0:16] = -X22 (L21 X11)
-        f64x4 t = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = 4 * ks + hi;
-            t = __builtin_amdgcn_mfma_f64_16x16x4f64(blk[kk * ld + 16 + lo], Xs[lo * LDX + kk], t, 0, 0, 0); // L(16+m, kk), X(kk, n)
-        }
-        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kk = 4 * ks + hi;
-            u = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 + kk) * LDX + 16 + lo], t[ks], u, 0, 0, 0); // X(16+m, 16+kk)
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Xs[lo * LDX + 16 + hi + 4 * i] = -u[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
-
 // reciprocal to full double precision: v_rcp_f64 seed + two Newton steps
 __device__ __forceinline__ double rcp_nr(double d)
 {
@@ -562,122 +209,6 @@ __device__ __forceinline__ double rcp_nr(double d)
 //       T11 -= U01^T D0^-1 U01,   W10 = -(D0^-1 U01)^T W00;
 //   pivots 16..31 update T11 and W11 (two MFMAs each); finally X10 = X11 W10 (X11 transposed through LDS, where it goes anyway).
 // 92 MFMAs, against 16.5 k + 3.1 k cycles for the lane-per-row Cholesky + recursive-doubling inverse this replaces.
-__device__ __forceinline__ bool wave_potrf_inv32_mfma_single(const double* blk, int ld, int w, int lane, double* Xs)
-{
-    const int lo = lane & 15, hi = lane >> 4;
-    f64x4 T00, T01, T11, W00, W11, s0, s1, n0;
-    f64x4 W10 = { 0.0, 0.0, 0.0, 0.0 };
-    const int wm = w - 1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        // tile row q; the block holds the lower triangle: A(row, col) = blk[min * ld + max].  Nothing with an index >= w is
-        // touched (clamped address, identity selected): the caller's block may end there.
-        const int q = hi + 4 * r;
-        const int mn = min(q, lo), mx = max(q, lo);
-        const double a00 = blk[min(mn, wm) * ld + min(mx, wm)];
-        const double a01 = blk[min(q, wm) * ld + min(16 + lo, wm)];
-        const double a11 = blk[min(16 + mn, wm) * ld + min(16 + mx, wm)];
-        const bool dg = q == lo;
-        T00[r] = (mx < w) ? a00 : (dg ? 1.0 : 0.0);
-        T01[r] = (16 + lo < w) ? a01 : 0.0; // q < 16 + lo: inside iff the column is
-        T11[r] = (16 + mx < w) ? a11 : (dg ? 1.0 : 0.0);
-        W00[r] = dg ? 1.0 : 0.0;
-        W11[r] = dg ? 1.0 : 0.0;
-        s0[r] = 1.0;
-        s1[r] = 1.0;
-        n0[r] = 0.0;
-    }
-    bool bad = false;
-    double pm = 0.0, pw = 0.0; // the W update of the previous pivot, issued inside this pivot's reciprocal chain
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int h = k & 3, r = k >> 2;
-        const bool sel = hi == h, selgt = sel && lo > k;
-        const double row0 = T00[r];
-        const double dk = bcast_lane(row0, 16 * h + k);
-        bad |= !(dk > 0.0); // not on the chain: a bad pivot leaves garbage behind, and the flag says so
-        double ri = __builtin_amdgcn_rcp(dk);
-        double e = fma(-dk, ri, 1.0);
-        ri = fma(ri, e, ri);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k > 0) W00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W00, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        e = fma(-dk, ri, 1.0);
-        ri = fma(ri, e, ri);
-        const double nri = -ri;
-        const double m0 = selgt ? row0 * nri : 0.0; // the B operands go in unmasked: their other k-slices meet zeros of m0
-        T00 = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, row0, T00, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        T01 = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, T01[r], T01, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        pw = W00[r]; // row k of W00 is final once pivot k - 1 has been applied
-        pm = m0;
-        s0[r] = sel ? dk : s0[r]; // pivots collected per D-layout row; their rsqrt is taken once, vectorised, at the end
-        n0[r] = sel ? nri : n0[r];
-    }
-    W00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W00, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    if (w > 16) { // wave-uniform: a block of at most 16 columns is finished (rows 16..31 are identity)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const double a = T01[ks] * n0[ks]; // -(D0^-1 U01)(row (l >> 4) + 4 ks, col l & 15): A operand [i = col][kk = row]
-        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, T01[ks], T11, 0, 0, 0);
-        W10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, W00[ks], W10, 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    pm = 0.0;
-    pw = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int h = k & 3, r = k >> 2;
-        const bool sel = hi == h, selgt = sel && lo > k;
-        const double row1 = T11[r];
-        const double dk = bcast_lane(row1, 16 * h + k);
-        bad |= !(dk > 0.0);
-        double ri = __builtin_amdgcn_rcp(dk);
-        double e = fma(-dk, ri, 1.0);
-        ri = fma(ri, e, ri);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k > 0) W11 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W11, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        e = fma(-dk, ri, 1.0);
-        ri = fma(ri, e, ri);
-        const double nri = -ri;
-        const double m1 = selgt ? row1 * nri : 0.0;
-        T11 = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, row1, T11, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        pw = W11[r];
-        pm = m1;
-        s1[r] = sel ? dk : s1[r];
-    }
-    W11 = __builtin_amdgcn_mfma_f64_16x16x4f64(pm, pw, W11, 0, 0, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int q = hi + 4 * r;
-        const double r0 = rsqrt_nr(s0[r]);
-        s1[r] = rsqrt_nr(s1[r]);
-        Xs[lo * LDX + q] = W00[r] * r0;
-        Xs[(16 + lo) * LDX + 16 + q] = W11[r] * s1[r];
-        Xs[(16 + lo) * LDX + q] = 0.0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // X10 = X11 W10: A[i = l & 15][kk] = X(16 + i, 16 + kk) read back transposed, B = W10 as it sits in the accumulators
-    f64x4 X10 = { 0.0, 0.0, 0.0, 0.0 };
-    if (w > 16) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            X10 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs[(16 + 4 * ks + hi) * LDX + 16 + lo], W10[ks], X10, 0, 0, 0);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Xs[lo * LDX + 16 + hi + 4 * r] = X10[r];
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    return bad;
-}
-
 // The same with 2 x 2 block pivots -- the version in use.  Rows k, k + 1 (k even) of a tile sit in the SAME accumulator
 // register, in lane groups l >> 4 == (k & 3) and (k & 3) + 1: one MFMA applies the rank-2 update of a pivot pair (two
 // k-slices instead of one), so a block costs half the MFMAs and half the dependent chains of the single-pivot sweep above
@@ -794,35 +325,6 @@ __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld,
     return bad;
 }
 
-// the factored pivot block goes to its `dinv` slot (k-major, identity-padded, 1 / L(k, k) on the diagonal); k_invert_blocks
-// turns it into L11^-1 at the end
-__device__ __forceinline__ void store_pivot_block(const double* blk, int ld, int w, const double* rdiag, double* slot, int tid, int nthreads)
-{
-    for (int e = tid; e < NB * NB; e += nthreads) {
-        const int k = e >> 5, r = e & 31;
-        double v = (r == k) ? 1.0 : 0.0;
-        if (k < w && r < w) {
-            if (r > k) v = blk[k * ld + r];
-            else v = (r == k) ? rdiag[k] : 0.0;
-        }
-        slot[e] = v;
-    }
-}
-
-// One wave per 32x32 block: L11 (k-major) -> L11^-1 (column-major), in place.
-__global__ __launch_bounds__(64) void k_invert_blocks(const int* __restrict__ blockList, double* __restrict__ dinv)
-{
-    __shared__ double Ls[NB * LDP];
-    __shared__ double Xs[NB * LDI];
-    double* blk = dinv + (long long)blockList[blockIdx.x] * (NB * NB);
-    const int tid = threadIdx.x;
-    for (int e = tid; e < NB * NB; e += 64) Ls[(e & 31) * LDP + (e >> 5)] = blk[e]; // transposed: row-major
-    __syncthreads();
-    wave_trinv32(Ls, LDP, tid, Xs);
-    __syncthreads();
-    for (int e = tid; e < NB * NB; e += 64) blk[e] = Xs[(e & 31) * LDI + (e >> 5)]; // blk[c * 32 + r] = X(r, c)
-}
-
 // Fused path of the fronts whose nc own columns fit into LDS (every front of the lower tree levels): ONE workgroup assembles
 // the front (children's update matrices gathered through their inverse index maps + the entries of A), factors the nc columns
 // in LDS and writes the factor panel and the Schur complement -- each exactly once.  The front never exists in HBM in its
@@ -831,20 +333,6 @@ __global__ __launch_bounds__(64) void k_invert_blocks(const int* __restrict__ bl
 // the tree.)
 //   P[k * N + r] = column k (< nc) of the front, rows 0..N (k-major: a wave reads 64 consecutive rows)
 //   cm[q * N + I] = scalar index of parent-local row I inside child q's front, or -1
-#ifdef MF_PHASE_TIMERS
-// debug build: shader-clock cycles per phase of the fused kernel, summed over workgroups (wave 0, lane 0)
-__device__ unsigned long long mf_phase_acc[16];
-#define MF_PHASE(i)                                                                       \
-    do {                                                                                  \
-        if (threadIdx.x == 0) {                                                           \
-            const long long t_ = clock64();                                               \
-            atomicAdd(&mf_phase_acc[i], (unsigned long long)(t_ - tphase_));              \
-            tphase_ = t_;                                                                 \
-        }                                                                                 \
-    } while (0)
-#else
-#define MF_PHASE(i)
-#endif
 constexpr int FUSED_MAX_KIDS = FUSED_MAX_KIDS_EA;
 // Host-packed descriptor of a fused front, 64 ints: everything the kernel would otherwise chase through five rounds of
 // dependent loads (front list -> index pointers -> child list -> child pointers -> inverse maps) arrives in one.
@@ -857,16 +345,11 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
     double* __restrict__ dinv, int* __restrict__ flag)
 {
     extern __shared__ double P[];
-    __shared__ double rdiag[NB];
     __shared__ double Xs[NB * LDX]; // inverse of the current pivot block
     __shared__ __attribute__((aligned(16))) int fd[FD_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifdef MF_PHASE_TIMERS
-    long long tphase_ = clock64();
-#endif
     if (tid < FD_STRIDE) fd[tid] = fdesc[(size_t)blockIdx.x * FD_STRIDE + tid];
     __syncthreads();
-    MF_PHASE(0);
     const int N = fd[2], nc = fd[3], nk = fd[8];
     double* F = fronts + *reinterpret_cast<const long long*>(fd);
     double* dblk = dinv + *reinterpret_cast<const long long*>(fd + 4) * (NB * NB);
@@ -884,7 +367,6 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
         }
     }
     __syncthreads();
-    MF_PHASE(1);
     // ---- own columns: children sums (lower triangle), zeros above the diagonal.  The loads are unconditional (clamped
     // address, value selected afterwards) so that all of them are in flight together.
     // Two columns per wave and round, the children two at a time: 16 loads in flight (one column and one child per round was a
@@ -926,7 +408,6 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
         }
     }
     __syncthreads();
-    MF_PHASE(2);
     // ---- entries of A (every destination is distinct)
     // aP: the values of A gathered into front order (k_gather_a); four (location, value) pairs requested per round
     for (int e0 = aBeg; e0 < aEnd; e0 += 4 * NT) {
@@ -943,45 +424,19 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
             if (e0 + u * NT + tid < aEnd) P[loc[u]] += av[u];
     }
     __syncthreads();
-    MF_PHASE(3);
 
     // ---- factor the nc columns, 32 at a time, right-looking inside LDS
     for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
         const int w = min(NB, nc - kb);
         double* Pk = P + (size_t)kb * N + kb; // Pk[k * N + q] = F(kb + q, kb + k)
-#ifdef MF_FUSED_SCALAR_PIVOT
-        if (tid < 64) {
-            __builtin_amdgcn_s_setprio(3);
-            bad |= wave_potrf32(Pk, N, w, tid, rdiag);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        __syncthreads();
-        MF_PHASE(4);
-        store_pivot_block(Pk, N, w, rdiag, dblk, tid, NT);
-        // rows below the pivot block: X L11^T = A21, one row per thread
-        for (int r = kb + w + tid; r < N; r += NT) {
-            double x[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) x[k] = (k < w) ? P[(kb + k) * N + r] : 0.0;
-            row_trsm32_lean(x, Pk, N, rdiag, w);
-#pragma unroll
-            for (int k = 0; k < NB; ++k)
-                if (k < w) P[(kb + k) * N + r] = x[k];
-        }
-#else
         // pivot block: X = L11^-1 straight from the Gauss-Jordan sweep in the matrix-core accumulators (see
         // wave_potrf_inv32_mfma); L11 itself is needed nowhere -- the rows below are a product with X, the solves multiply by X
         if (tid < 64) {
             __builtin_amdgcn_s_setprio(3);
-#ifdef MF_GJ_SINGLE
-            bad |= wave_potrf_inv32_mfma_single(Pk, N, w, tid, Xs);
-#else
             bad |= wave_potrf_inv32_mfma(Pk, N, w, tid, Xs);
-#endif
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
-        MF_PHASE(4);
         for (int e = tid; e < NB * NB; e += NT) dblk[e] = Xs[(e >> 5) * LDX + (e & 31)]; // column-major, identity-padded
         // rows below the pivot block: L21 = A21 L11^-T, formed transposed per 16-row tile on the matrix cores, in place in LDS:
         //   D(n, m) = sum_k X(n, k) A21(m, k)     A[i = l & 15][kk = l >> 4] = X(n, k) (LDS), B[kk][j] = P[(kb + k) N + row m]
@@ -1017,9 +472,7 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
                 }
             }
         }
-#endif
         __syncthreads();
-        MF_PHASE(5);
         // the own columns to the right of this panel (rows >= column): 4 x 4 register tiles, operands and result in LDS
         const int c0 = kb + w;
         if (c0 < nc) {
@@ -1058,13 +511,11 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
                 }
             }
             __syncthreads();
-            MF_PHASE(6);
         }
     }
     // ---- the factor panel goes to HBM once (the solves read it)
     for (int J = wv; J < nc; J += NT / 64)
         for (int I = J + lane; I < N; I += 64) F[I + (long long)N * J] = P[J * N + I];
-    MF_PHASE(7);
     // ---- Schur complement: S = (children) - L21 L21^T, written once.  16 x 16 thread grid of 4 x 4 tiles: a thread column owns
     // four consecutive rows, so that the 16 threads ty = 0..15 store 512 contiguous bytes per column.
     {
@@ -1127,7 +578,6 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
             }
         }
     }
-    MF_PHASE(8);
     if (bad) atomicOr(flag, 1);
 }
 
@@ -1554,12 +1004,14 @@ __device__ __forceinline__ void step_border(const int4 d, const int4 d2, const T
 // desc = (first dinv block of the front, kb of the panel being applied or -1, a, b) + (N, nc, front offset); 256 threads: three row waves + one pivot wave
 //   b >= 0 : role A, trailing tile (ti, tj) = (a, b) of the matrix behind panel kb and panel kb+32
 //   b == -2: role B, rows [kb1 + a, kb1 + a + 192) of the next panel (kb1 = kb + 32, or 0 when kb == -1)
-// TOP = true (the levels of the top separators, where the chain of these launches IS the level) adds two roles that ride on the chain's launches
-// instead of following it as launches of their own:
+// TOP = true (the levels of the top separators, where the chain of these launches IS the level) adds a role that rides on the chain's launches
+// instead of following it as launches of its own:
 //   b == -6: role C, one 32 x 16 tile of the explicit inverse X = L11^-1 growing by bordering (step_border): d = (front, panel, first column, b)
-//   b == -4: role S, one 32 x 32 tile of the Schur complement updated with the panels [cLo, cHi) that are final by this launch (schur_tile32):
-//            d = (cLo, cHi, ti | tj << 16, b).  (64 x 64 tiles in here cost the whole kernel 198 registers and were slower anyway: short sums.)
-// (a separate instance: the extra roles would cost the trailing tiles of the middle levels registers they do not need)
+// (a separate instance: the extra role would cost the trailing tiles of the middle levels registers they do not need.  Tried in round 4 and removed
+// in round 5, numbers in profiles/: the Schur complement folded into these launches in passes -- role S, neutral at 45 K nodes, a loss at 375 K --,
+// several steps merged into one launch with in-launch counters -- 2-5 x slower: an agent-scope release / acquire is an L2 write-back / invalidate
+// and was paid per workgroup, profiles/r04_merged_step_launches_ab.txt -- and two panels per launch -- k_big_step2, brought up in round 5: correct and
+// 8 % slower, profiles/r05_step2_bringup.txt.)
 template <bool TOP>
 __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4 d2, const TreeView& tv, double* __restrict__ fronts,
     double* __restrict__ dinv, int* __restrict__ flag, const XinvView& xv)
@@ -1570,10 +1022,8 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
     const int N = d2.x, nc = d2.y;
     double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
     const int tid = threadIdx.x;
-    if (TOP && d.w <= -3) {
-        if (d.w == -6) step_border<16, true>(d, d2, tv, xv, F, dinv, sm);
-        else if (d.w == -7) step_border<16, false>(d, d2, tv, xv, F, dinv, sm); // A/B: operands from the column-major X (IPCGPU_MF_BORDER_XT=0)
-        else if (d.w == -4) schur_tile32(N, nc, F, d.z & 0xffff, (d.z >> 16) & 0xffff, d.x, d.y, reinterpret_cast<double(*)[4][256]>(sm));
+    if (TOP && d.w == -6) {
+        step_border<16, true>(d, d2, tv, xv, F, dinv, sm);
         return;
     }
     const int kb = d.y;
@@ -1645,25 +1095,11 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
         }
         return;
     }
-#ifdef MF_PHASE_TIMERS
-    long long tphase_ = clock64();
-#define MF_STEP_PHASE(i)                                                                                          \
-    do {                                                                                                          \
-        if (d.z == 0 && (threadIdx.x == 64 * ((3 + wg) & 3))) {                                                        \
-            const long long t_ = clock64();                                                                       \
-            atomicAdd(&mf_phase_acc[i], (unsigned long long)(t_ - tphase_));                                      \
-            tphase_ = t_;                                                                                         \
-        }                                                                                                         \
-    } while (0)
-#else
-#define MF_STEP_PHASE(i)
-#endif
     // ---- role B: bring panel kb1 up to date with panel kb, factor its pivot block, solve this workgroup's rows.
     // The factored pivot block is never written back into the front (other workgroups of this launch still read the raw
     // one); it goes to the dinv slot and is inverted at the end of the factorisation.
     double* Lp = sm; // Lp[k * LDP + q]  = F(kb1 + q, kb + k): panel-kb rows of the pivot block
     double* A11 = sm + NB * LDP; // A11[c * LDP + q] = pivot block, k-major
-    double* rdiag = sm + 2 * NB * LDP;
     {
         // eight unconditional (clamped) loads in flight at once, selected afterwards: see role A
         constexpr int NLB = NB * NB / WGB;
@@ -1685,7 +1121,6 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
         }
     }
     __syncthreads();
-    MF_STEP_PHASE(10);
     if (w > 0 && tid < 192) {
         // A11 -= Lp^T Lp (lower triangle) on the matrix cores: waves 0..2 take the 16 x 16 tiles (0,0), (1,0), (1,1).  As scalar
         // FMAs this was 256 LDS reads per thread -- ~4 k cycles of LDS return traffic on the critical chain of every step.
@@ -1705,15 +1140,10 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
         }
     }
     __syncthreads();
-    MF_STEP_PHASE(11);
     double* Xs = sm + 2 * NB * LDP + NB; // Xs[c * LDX + r] = X(r, c), X = L11^-1 (written by the pivot wave)
     // The wave that takes the pivot block rotates with the workgroup index: with the same wave of every workgroup doing it,
     // the pivot chains of all workgroups resident on a CU shared one SIMD while the other three idled behind them.
-#ifdef MF_NO_PIVOT_ROT
-    const int wv = tid >> 6;
-#else
     const int wv = ((tid >> 6) - wg) & 3; // 0..2: row waves, 3: pivot wave
-#endif
     const int l = tid & 63, lo = l & 15, hi = l >> 4;
     const int Rw = kb1 + d.z + 16 * MT_B * wv; // first row of this wave
     const bool rowWave = wv < ROW_WAVES_B && Rw < N;
@@ -1728,25 +1158,7 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
         // pivot wave (alone on its SIMD): Cholesky of the 32 x 32 block and its inverse while the row waves fetch and update
         // (the pivot chain is what every other wave of the step ends up waiting for: it gets issue priority on its SIMD)
         __builtin_amdgcn_s_setprio(3);
-#ifdef MF_POTRF_SCALAR
-        if (wave_potrf32(A11, LDP, w1, l, rdiag)) atomicOr(flag, 1);
-        MF_STEP_PHASE(12);
-        wave_trinv32_fast<false>(A11, LDP, rdiag, w1, l, Xs);
-#elif defined(MF_POTRF_BLOCKED8)
-        for (int e = l; e < NB * LDX; e += 64) Xs[e] = 0.0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        if (wave_potrf32_blocked(A11, w1, l, rdiag, Xs)) atomicOr(flag, 1);
-        MF_STEP_PHASE(12);
-        wave_trinv32_fast<true>(A11, LDP, rdiag, w1, l, Xs);
-#else
-#ifdef MF_GJ_SINGLE
-        if (wave_potrf_inv32_mfma_single(A11, LDP, w1, l, Xs)) atomicOr(flag, 1);
-#else
         if (wave_potrf_inv32_mfma(A11, LDP, w1, l, Xs)) atomicOr(flag, 1);
-#endif
-        MF_STEP_PHASE(12);
-#endif
         __builtin_amdgcn_s_setprio(0);
     }
     else if (rowWave) {
@@ -1779,7 +1191,6 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
         }
     }
     __syncthreads();
-    MF_STEP_PHASE(13);
     if (rowWave) {
 #pragma unroll
         for (int mt = 0; mt < MT_B; ++mt) {
@@ -1812,605 +1223,14 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
         double* slot = dinv + ((long long)d.x + kb1 / NB) * (NB * NB);
         for (int e = tid; e < NB * NB; e += WGB) slot[e] = Xs[(e >> 5) * LDX + (e & 31)];
     }
-#ifdef MF_PHASE_TIMERS
-    __syncthreads();
-    MF_STEP_PHASE(14);
-    if (d.z == 0 && threadIdx.x == 64 * ((3 + wg) & 3)) atomicAdd(&mf_phase_acc[15], 1ull);
-#endif
 }
 
-// SEVERAL consecutive step launches as ONE launch (round 4).  A dependent launch costs 3.4 us on this runtime (profiles/r04_sync_primitives.txt), a step itself
-// 6: the workgroups of the steps [0, sg.n) are laid out step after step in one grid; a workgroup of step g > 0 waits -- one lane polling a counter in global
-// memory -- until every workgroup of step g - 1 has checked out, then runs exactly the code it would have run in its own launch.  Release / acquire at agent
-// scope on both sides (the L2s of the eight XCDs are not coherent with each other: the same write-back / invalidate a kernel boundary performs).
-// Why this cannot hang: workgroups are dispatched in the order of their index (per XCD as well: a later workgroup never gets a slot an earlier one is
-// waiting for), so whatever a workgroup waits for is already running or finished; spinning workgroups only hold their own slots.  And every poll loop gives
-// up after ~1 s (flag bit 2 -> MfNumeric throws instead of returning garbage).
-constexpr int STEP_GROUP_MAX = 16;
-struct StepGroup {
-    int n; // steps in this launch
-    int end[STEP_GROUP_MAX]; // end[g] = first workgroup behind step g
-    int* ctr; // ctr[g]: workgroups of step g that have finished (zeroed at the start of the factorisation)
-};
 template <bool TOP>
 __global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
-    double* __restrict__ dinv, int* __restrict__ flag, XinvView xv, StepGroup sg)
+    double* __restrict__ dinv, int* __restrict__ flag, XinvView xv)
 {
     const int wg = blockIdx.x;
-    const int4 d = desc[2 * wg]; // requested before the wait: the records do not depend on the step before
-    const int4 d2 = desc[2 * wg + 1];
-    int g = 0;
-#pragma unroll
-    for (int q = 0; q < STEP_GROUP_MAX - 1; ++q)
-        if (q + 1 < sg.n && wg >= sg.end[q]) g = q + 1;
-    if (g > 0) {
-        if (threadIdx.x == 0) {
-            const int need = sg.end[g - 1] - (g > 1 ? sg.end[g - 2] : 0);
-            // the workgroup that carries the pivot chain polls at once, the others can afford to be told a little later (and must not crowd the counter)
-            const bool chain = d.w == -2 && d.z == 0;
-            long long spins = 0;
-            // RELAXED polls (an acquire here would invalidate this XCD's L2 on every iteration, for everybody: measured 78 us per step); the one acquire
-            // that matters is the fence behind the loop
-            while (__hip_atomic_load(&sg.ctr[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-                ++spins;
-                if (spins > (chain ? 4000000LL : 400000LL) || ((spins & 1023) == 0 && (*(volatile int*)flag & 4))) { // ~1 s, or somebody else gave up
-                    atomicOr(flag, 4);
-                    break;
-                }
-                if (chain) __builtin_amdgcn_s_sleep(1);
-                else __builtin_amdgcn_s_sleep(8);
-            }
-        }
-        __syncthreads();
-        __threadfence(); // acquire for every lane: nothing this workgroup reads from now on may come from a stale line of its XCD's L2
-    }
-    step_work<TOP>(wg, d, d2, tv, fronts, dinv, flag, xv);
-    if (sg.n > 1 && g + 1 < sg.n) { // (the last step of a launch is followed by a kernel boundary)
-        __threadfence(); // release: this lane's stores written back before the counter moves
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&sg.ctr[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (the fences above are the release)
-    }
-}
-
-// ---- big fronts: TWO 32-column panels per step launch (written at the end of round 4, after the GPU budget of the round was spent: compiles for gfx950,
-// NOT YET RUN -- off unless IPCGPU_MF_STEP2=1; DESIGN.md section 8, "what comes next").  A step launch of k_big_step is a kernel boundary (3.4 us) + a load
-// phase on data the previous launch wrote (~2 us) + the 32 x 32 pivot inverse (5.1 us) + row product and stores: 11.8 us per 32 columns, and the chain of
-// these launches is what a top level takes.  Here a launch advances by a PAIR Q = (Q1, Q2) of panels:
-//   role B' (b == -2): the pivot blocks of Q and the rows [Rb + a, Rb + a + 96) below them, Rb = kb1 + wq.  Every workgroup repeats the pivot work, as in
-//            k_big_step; nothing is exchanged between workgroups:
-//       S0  Lp(k, q) = F(kb1 + q, kb + k) (the rows of Q's 64 x 64 pivot block in the columns of the pair P before it) and the raw pivot block -> LDS
-//       S1  A11 -= Lp Lp^T on the three 16 x 16 tiles of Q1's pivot block                                   (row waves)
-//       S2  X1 = chol(A11)^-1                                                                               (pivot wave, 5 us)
-//           beside it: the other seven tiles of the 64 x 64 update; D(c, m) = raw(m, kb1 + c) - sum_k Lp(k, c) P(m, k) for the workgroup's rows m, c < 64
-//       S3  L21 = A21 X1^T (the rows of Q2's pivot block in Q1's columns: one 16 x 16 tile per wave, to LDS; workgroup 0 also writes it to the front);
-//           L(m, Q1) = D(., m)[0:32] X1^T -> front, kept in registers;  then A22 -= L21 L21^T
-//       S4  X2 = chol(A22)^-1                                                                               (pivot wave, 5 us)
-//           beside it: D(c, m)[32:64] -= sum_n L21(c, n) L(m, Q1)(n)
-//       S5  L(m, Q2) = D(., m)[32:64] X2^T -> front;  X1, X2 -> their dinv slots (workgroup 0)
-//   role A' (b >= 0): trailing tile (a, b) behind Q, F -= P_i P_j^T with all 64 columns of P, own columns (< nc) only.
-// desc = (first dinv block of the front, kb of P or -1, a, b) + (N, nc, front offset), as for k_big_step.  dinv slots, factor layout and everything
-// downstream (Schur complement, sweeps) are those of the 32-column steps.
-//   role C' (b == -6): the explicit inverse grows by bordering, 64 rows per launch (step2_border above).
-//   role M  (b == -8): one workgroup per front moves L(P2 rows, P1 columns) of the pair before into place (role B' could not: see there).
-// Role C' of k_big_step2 (b == -6): the rows R = [kb, kb + w) of the pair P (finished by the launch before) of X = L11^-1, by bordering -- step_border for 64 rows.
-// One workgroup per 16-column tile C = [c0, c0 + 16) left of the pair, plus one for the pair's own 64 x 64 block (c0 == kb):
-//     T(r, c) = sum_{k in [c0, kb)} L(kb + r, k) X(k, c0 + c)                       stage 1: four waves split k, four 16-row tiles each, combined through LDS
-//     X(R1, C) = -X1 T1                                                              stage 2a (R1, R2: the two panels of the pair; X1, X2 their dinv blocks)
-//     X(R2, C) = -X2 (T2 + L(R2, R1) X(R1, C))                                       stage 2b, 2c: the second term from the workgroup's own tile
-//     own block: X(R1, R1) = X1, X(R2, R2) = X2, X(R2, R1) = -X2 L(R2, R1) X1
-// X is written column-major (ld nc) and transposed (xv.T), as by step_border<16, true>.  d = (front, kb, c0, -6).
-constexpr int LDT = 17;
-constexpr int STEP2_LDS_C = (4 * 4 * 256 + 2 * NB * LDT + NB * LDT + NB * LDT) * (int)sizeof(double); // red, Ts, XR1s, Us
-__device__ __forceinline__ void step2_border(const int4 d, const int4 d2, const TreeView& tv, const XinvView& xv, const double* __restrict__ F,
-    const double* __restrict__ dinv, double* sm)
-{
-    const int s = d.x, kb = d.y, c0 = d.z;
-    const int N = d2.x, nc = d2.y;
-    const int w = min(2 * NB, nc - kb);
-    const int wa = min(NB, w), wb = w - wa; // rows of R1, R2
-    double* X = xv.X + xv.xOff[s];
-    double* XT = xv.T + xv.xOff[s];
-    const double* blk1 = dinv + (tv.dinvOff[s] + kb / NB) * (NB * NB); // blk[c * 32 + r] = Xd(r, c), identity-padded
-    const double* blk2 = blk1 + NB * NB;
-    const int tid = threadIdx.x, wv = tid >> 6, l = tid & 63, lo = l & 15, hi = l >> 4;
-    if (c0 == kb) {
-        // the pair's own block
-        double* Xa = sm; // Xa[c * LDX + r] = X1(r, c)
-        double* Xb = sm + NB * LDX;
-        double* Us = sm + 2 * NB * LDX; // Us[q * LDP + c] = (L21 X1)(q, c)
-        for (int e = tid; e < NB * NB; e += WGB) {
-            const int c = e >> 5, r = e & 31;
-            const double v1 = blk1[e], v2 = (wb > 0) ? blk2[e] : 0.0;
-            Xa[c * LDX + r] = v1;
-            Xb[c * LDX + r] = v2;
-            if (r < wa && c < wa) {
-                X[(kb + r) + (long long)nc * (kb + c)] = v1;
-                XT[(kb + c) + (long long)nc * (kb + r)] = v1;
-            }
-            if (r < wb && c < wb) {
-                X[(kb + NB + r) + (long long)nc * (kb + NB + c)] = v2;
-                XT[(kb + NB + c) + (long long)nc * (kb + NB + r)] = v2;
-            }
-        }
-        if (wb == 0) return; // (block-uniform)
-        // L21(q, n) = L(kb + 32 + q, kb + n), requested before the barrier
-        const int tc = wv >> 1, tq = wv & 1;
-        double l21[NB / 4];
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) l21[ks] = F[(kb + 4 * ks + hi) + (long long)N * min(kb + NB + 16 * tq + lo, N - 1)]; // (transposed, above the diagonal: see role B')
-        __syncthreads();
-        // U(q, c) = sum_n L21(q, n) X1(n, c), formed transposed: A[i = c][kk = n] = X1(n, c), B[kk = n][j = q] = L21(q, n); D register i = (c = 16 tc + hi + 4 i, q = 16 tq + lo)
-        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            const int n = 4 * ks + hi;
-            u = __builtin_amdgcn_mfma_f64_16x16x4f64(Xa[(16 * tc + lo) * LDX + n], (16 * tq + lo < wb) ? l21[ks] : 0.0, u, 0, 0, 0); // X1(n, c) is zero for n < c
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Us[(16 * tq + lo) * LDP + 16 * tc + hi + 4 * i] = u[i];
-        __syncthreads();
-        // X(R2, R1)(r2, c) = -sum_q X2(r2, q) U(q, c): A[i = c][kk = q] = U(q, c), B[kk = q][j = r2] = X2(r2, q); D register i = (c = 16 tc + hi + 4 i, r2 = 16 tq + lo)
-        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            const int q = 4 * ks + hi;
-            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[q * LDP + 16 * tc + lo], Xb[q * LDX + 16 * tq + lo], o, 0, 0, 0); // X2(r2, q) is zero for q > r2
-        }
-        const int r2 = 16 * tq + lo;
-        if (r2 < wb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = 16 * tc + hi + 4 * i;
-                X[(kb + NB + r2) + (long long)nc * (kb + c)] = -o[i];
-                XT[(kb + c) + (long long)nc * (kb + NB + r2)] = -o[i];
-            }
-        }
-        return;
-    }
-    double(*red)[4][256] = reinterpret_cast<double(*)[4][256]>(sm); // [wave][16-row tile b][D layout: 64 lanes x 4]
-    double* Ts = sm + 4 * 4 * 256; // Ts[k' * LDT + c] = T(k', c), k' < 64
-    double* XR1s = Ts + 2 * NB * LDT; // XR1s[r * LDT + c] = X(kb + r, c0 + c), r < 32
-    double* Us = XR1s + NB * LDT; // Us[k'' * LDT + c] = (T2 + L21 X(R1, C))(k'', c)
-    f64x4 acc[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
-    const int cc = c0 + lo; // < kb: always inside
-    int rr[4], rrc[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-        rr[b] = kb + 16 * b + lo;
-        rrc[b] = min(rr[b], N - 1);
-    }
-    const int bq = wv & 1; // the 16-row tile of R1 (waves 0, 1) / R2 (waves 2, 3) this wave finishes
-    // operands of the second stage, requested now: the dinv block of the wave's panel and (waves 2, 3) its rows of L(R2, R1)
-    const double* blkw = (wv < 2 || wb == 0) ? blk1 : blk2; // (the second slot need not exist when the pair is a single panel)
-    double xd[NB / 4], l21[NB / 4];
-#pragma unroll
-    for (int ks = 0; ks < NB / 4; ++ks) {
-        xd[ks] = blkw[(4 * ks + hi) * NB + 16 * bq + lo]; // Xd(r = 16 bq + lo, k' = 4 ks + hi)
-        l21[ks] = F[(kb + 4 * ks + hi) + (long long)N * min(kb + NB + 16 * bq + lo, N - 1)]; // L21(k'' = 16 bq + lo, r1 = 4 ks + hi) from where role B' left it: transposed, above the diagonal (role M moves it in this same launch); clamped, masked at use
-    }
-    // three operand sets in rotation, unconditional clamped fetches, masks at use (step_border)
-    auto fetch = [&](int k0, double(&ra)[4], double(&rb)[4][4]) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int kc = min(k0 + 4 * ks + hi, nc - 1);
-            ra[ks] = XT[cc + (long long)nc * kc];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) rb[q][ks] = F[rrc[q] + (long long)N * kc];
-        }
-    };
-    auto mult = [&](int k0, const double(&ra)[4], const double(&rb)[4][4]) {
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int k = k0 + 4 * ks + hi;
-            const bool kin = k < kb;
-            const double ma = (kin && k >= cc) ? ra[ks] : 0.0;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(ma, (kin && rr[b] < kb + w) ? rb[b][ks] : 0.0, acc[b], 0, 0, 0);
-        }
-    };
-    double xa[4], la[4][4], xb[4], lb[4][4], xc[4], lc[4][4];
-    int k0 = c0 + 16 * wv;
-    fetch(k0, xa, la);
-    fetch(k0 + 64, xb, lb);
-    for (; k0 < kb; k0 += 192) {
-        fetch(k0 + 128, xc, lc);
-        __builtin_amdgcn_sched_barrier(0);
-        mult(k0, xa, la);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(k0 + 192, xa, la);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k0 + 64 < kb) mult(k0 + 64, xb, lb);
-        __builtin_amdgcn_sched_barrier(0);
-        fetch(k0 + 256, xb, lb);
-        __builtin_amdgcn_sched_barrier(0);
-        if (k0 + 128 < kb) mult(k0 + 128, xc, lc);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) red[wv][b][64 * i + l] = acc[b][i];
-    __syncthreads();
-    // wave b finishes the 16-row tile b of T: entry i of a lane is T(r = 16 b + lo, c = hi + 4 i); the sums over the waves in a fixed order
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        Ts[(16 * wv + lo) * LDT + hi + 4 * i] = ((red[0][wv][64 * i + l] + red[1][wv][64 * i + l]) + red[2][wv][64 * i + l]) + red[3][wv][64 * i + l];
-    __syncthreads();
-    if (wv < 2) {
-        // stage 2a, formed transposed like stage 1: D(c, r) = sum_k' T1(k', c) X1(r, k'), k' <= r
-        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            const int kp = 4 * ks + hi;
-            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Ts[kp * LDT + lo], (kp <= 16 * bq + lo) ? xd[ks] : 0.0, o, 0, 0, 0);
-        }
-        const int r = 16 * bq + lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = hi + 4 * i;
-            XR1s[r * LDT + c] = (r < wa) ? -o[i] : 0.0;
-            if (r < wa) {
-                X[(kb + r) + (long long)nc * (c0 + c)] = -o[i];
-                XT[(c0 + c) + (long long)nc * (kb + r)] = -o[i];
-            }
-        }
-    }
-    if (wb == 0) return; // (block-uniform)
-    __syncthreads();
-    if (wv >= 2) {
-        // stage 2b: U(k'', c) = T2(k'', c) + sum_r1 L21(k'', r1) X(R1, C)(r1, c): A[i = c][kk = r1] = XR1s, B[kk = r1][j = k''] = L21(k'', r1)
-        f64x4 u = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) u = __builtin_amdgcn_mfma_f64_16x16x4f64(XR1s[(4 * ks + hi) * LDT + lo], (16 * bq + lo < wb) ? l21[ks] : 0.0, u, 0, 0, 0);
-        const int k2 = 16 * bq + lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Us[k2 * LDT + hi + 4 * i] = u[i] + Ts[(NB + k2) * LDT + hi + 4 * i];
-    }
-    __syncthreads();
-    if (wv >= 2) {
-        // stage 2c: D(c, r2) = sum_k'' U(k'', c) X2(r2, k''), k'' <= r2
-        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            const int kp = 4 * ks + hi;
-            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Us[kp * LDT + lo], (kp <= 16 * bq + lo) ? xd[ks] : 0.0, o, 0, 0, 0);
-        }
-        const int r2 = 16 * bq + lo;
-        if (r2 < wb) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = hi + 4 * i;
-                X[(kb + NB + r2) + (long long)nc * (c0 + c)] = -o[i];
-                XT[(c0 + c) + (long long)nc * (kb + NB + r2)] = -o[i];
-            }
-        }
-    }
-}
-
-constexpr int LD2 = 2 * NB + 1; // padded leading dimension of the 64 x 64 blocks of role B'
-constexpr int MT2 = 2; // 16-row tiles per row wave
-constexpr int ROWS_B2 = 16 * MT2 * ROW_WAVES_B;
-constexpr int STEP2_LDS_B = (2 * (2 * NB) * LD2 + 2 * NB * LDX + NB * LDP) * (int)sizeof(double); // Lp, Aq, Xs1, Xs2, L21s
-constexpr int STEP2_LDS_A = 2 * (2 * NB) * TS * (int)sizeof(double); // As, Bs: 64 x TS each
-constexpr int STEP2_LDS = (STEP2_LDS_B > STEP2_LDS_A ? STEP2_LDS_B : STEP2_LDS_A) > STEP2_LDS_C ? (STEP2_LDS_B > STEP2_LDS_A ? STEP2_LDS_B : STEP2_LDS_A) : STEP2_LDS_C;
-
-__global__ __launch_bounds__(WGB) void k_big_step2(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts, double* __restrict__ dinv,
-    int* __restrict__ flag, XinvView xv)
-{
-    extern __shared__ double sm2[];
-    const int wg = blockIdx.x;
-    const int4 d = desc[2 * wg];
-    const int4 d2 = desc[2 * wg + 1];
-    const int N = d2.x, nc = d2.y;
-    double* F = fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z);
-    const int tid = threadIdx.x;
-    if (d.w == -6) { // role C': the rows of the pair before, of the explicit inverse
-        step2_border(d, d2, tv, xv, F, dinv, sm2);
-        return;
-    }
-    if (d.w == -8) { // role M: L(P2 rows, P1 columns) of the pair before, from where its launch left it (transposed, above the diagonal) into place
-        const int kbm = d.y, wbm = min(2 * NB, nc - kbm) - NB;
-        for (int e = tid; e < NB * NB; e += WGB) {
-            const int c = e >> 5, q = e & 31;
-            if (q < wbm) F[(kbm + NB + q) + (long long)N * (kbm + c)] = F[(kbm + c) + (long long)N * (kbm + NB + q)];
-        }
-        return;
-    }
-    constexpr int KW = 2 * NB; // columns of a pair
-    const int kb = d.y;
-    const int w = (kb >= 0) ? min(KW, nc - kb) : 0; // the pair P = [kb, kb + w) is final
-    const int kb1 = (kb >= 0) ? kb + w : 0;
-    const int wq = (kb1 < nc) ? min(KW, nc - kb1) : 0; // the pair Q = [kb1, kb1 + wq) is factored by this launch
-    const int w1 = min(NB, wq), w2 = wq - w1;
-    if (d.w >= 0) {
-        // ---- role A': F[i0.., j0..] -= P[i0..] P[j0..]^T behind Q, own columns (< nc) only (k_big_step's role A with 64 columns of P)
-        double(*As)[TS] = reinterpret_cast<double(*)[TS]>(sm2);
-        double(*Bs)[TS] = reinterpret_cast<double(*)[TS]>(sm2 + KW * TS);
-        const int M0 = kb1 + wq;
-        const int i0 = M0 + TS * d.z, j0 = M0 + TS * d.w;
-        constexpr int NLD = KW * TS / WGB;
-        double va[NLD], vb[NLD];
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + WGB * it;
-            const int k = e / TS, i = e - k * TS;
-            const long long colOff = (long long)N * (kb + min(k, w - 1)); // role A' only exists behind a pair: w >= 1
-            va[it] = F[min(i0 + i, N - 1) + colOff];
-            vb[it] = F[min(j0 + i, N - 1) + colOff];
-        }
-        double old[4][4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-                old[ii][jj] = F[min(i0 + 4 * (tid & 15) + ii, N - 1) + (long long)N * min(j0 + 4 * (tid >> 4) + jj, N - 1)];
-#pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + WGB * it;
-            const int k = e / TS, i = e - k * TS;
-            const bool kin = k < w;
-            As[k][i] = (kin && i0 + i < N) ? va[it] : 0.0;
-            Bs[k][i] = (kin && j0 + i < N) ? vb[it] : 0.0;
-        }
-        __syncthreads();
-        const int ty = tid & 15, tx = tid >> 4;
-        double acc[4][4];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < KW; ++k) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                av[ii] = As[k][4 * ty + ii];
-                bv[ii] = Bs[k][4 * tx + ii];
-            }
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int col = j0 + 4 * tx + jj;
-            if (col >= nc) continue; // columns >= nc form the Schur complement: one pass at the end (k_big_schur)
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int row = i0 + 4 * ty + ii;
-                if (row < N && row >= col) F[row + (long long)N * col] = old[ii][jj] - acc[ii][jj];
-            }
-        }
-        return;
-    }
-    // ---- role B'
-    double* Lp = sm2; // Lp[k * LD2 + q] = F(kb1 + q, kb + k)
-    double* Aq = sm2 + KW * LD2; // Aq[c * LD2 + q] = pivot block of Q, entry (q, c), q >= c
-    double* Xs1 = sm2 + 2 * KW * LD2; // Xs[c * LDX + r] = X(r, c), X = chol(pivot block)^-1
-    double* Xs2 = Xs1 + NB * LDX;
-    double* L21s = Xs2 + NB * LDX; // L21s[c * LDP + q] = L(kb1 + 32 + q, kb1 + c)
-    const int wv = ((tid >> 6) - wg) & 3; // 0..2: row waves, 3: pivot wave (rotating with the workgroup: see k_big_step)
-    const int l = tid & 63, lo = l & 15, hi = l >> 4;
-    const int Rb = kb1 + wq; // first row below the pivot blocks of Q
-    const int Rw = Rb + d.z + 16 * MT2 * wv; // first row of this wave
-    const bool rowWave = wv < ROW_WAVES_B && Rw < N;
-    // the row waves' operands from the front are requested before anything else: D(c, m) starts as raw(m, kb1 + c); pv(m, k) = P(m, k)
-    f64x4 dt[MT2][4];
-    double pv[MT2][KW / 4];
-    if (rowWave) {
-#pragma unroll
-        for (int mt = 0; mt < MT2; ++mt) {
-            const double* Fr = F + min(Rw + 16 * mt + lo, N - 1);
-#pragma unroll
-            for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = 16 * ct + hi + 4 * i;
-                    const double v = Fr[(long long)N * (kb1 + min(c, max(wq, 1) - 1))];
-                    dt[mt][ct][i] = (c < wq) ? v : 0.0;
-                }
-#pragma unroll
-            for (int ks = 0; ks < KW / 4; ++ks) pv[mt][ks] = Fr[(long long)N * min(max(kb, 0) + 4 * ks + hi, N - 1)]; // unused when w == 0
-        }
-    }
-    {
-        // S0: sixteen unconditional (clamped) loads per array in flight at once, selected afterwards
-        constexpr int NLB = KW * KW / WGB;
-        double vl[NLB], vd[NLB];
-#pragma unroll
-        for (int it = 0; it < NLB; ++it) {
-            const int e = tid + WGB * it;
-            const int k = e >> 6, q = e & 63;
-            const double* Fq = F + min(kb1 + q, N - 1);
-            vl[it] = Fq[(long long)N * (max(kb, 0) + min(k, max(w, 1) - 1))];
-            vd[it] = Fq[(long long)N * (kb1 + min(k, wq - 1))]; // role B' only exists for a non-empty pair: wq >= 1
-        }
-#pragma unroll
-        for (int it = 0; it < NLB; ++it) {
-            const int e = tid + WGB * it;
-            const int k = e >> 6, q = e & 63;
-            Lp[k * LD2 + q] = (k < w && q < wq) ? vl[it] : 0.0;
-            Aq[k * LD2 + q] = (k < wq && q < wq && q >= k) ? vd[it] : 0.0;
-        }
-    }
-    __syncthreads();
-    // one 16 x 16 tile (ti, tj), ti >= tj, of Aq -= Lp^T Lp, by one wave: A[i = q][kk], B[kk][j = c], D row = (l >> 4) + 4 r -> q, column = l & 15 -> c
-    auto pairUpdateTile = [&](int ti, int tj) {
-        f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < KW / 4; ++ks)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lp[(4 * ks + hi) * LD2 + 16 * ti + lo], Lp[(4 * ks + hi) * LD2 + 16 * tj + lo], acc, 0, 0, 0);
-        const int c = 16 * tj + lo;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int q = 16 * ti + hi + 4 * r;
-            if (q >= c) Aq[c * LD2 + q] -= acc[r];
-        }
-    };
-    if (w > 0 && wv < 3) pairUpdateTile(wv >= 1, wv == 2); // S1: (0,0), (1,0), (1,1) -- Q1's pivot block
-    __syncthreads();
-    f64x4 x0[MT2], x1[MT2]; // L(m, Q1)^T of the wave's tiles, as it leaves the matrix cores: register i = column n = (l >> 4) + 4 i (x0) / 16 + that (x1)
-    if (wv == 3) {
-        // S2, pivot wave (alone on its SIMD, issue priority: the chain every other wave of the step ends up waiting for)
-        __builtin_amdgcn_s_setprio(3);
-        if (wave_potrf_inv32_mfma(Aq, LD2, w1, l, Xs1)) atomicOr(flag, 1);
-        __builtin_amdgcn_s_setprio(0);
-    }
-    else {
-        // S2, row waves: the rest of the 64 x 64 update (A21: (2,0) (2,1) (3,0) (3,1); A22: (2,2) (3,2) (3,3)), then their rows
-        if (w > 0 && w2 > 0) {
-            if (wv == 0) {
-                pairUpdateTile(2, 0);
-                pairUpdateTile(3, 1);
-                pairUpdateTile(3, 3);
-            }
-            else if (wv == 1) {
-                pairUpdateTile(2, 1);
-                pairUpdateTile(2, 2);
-            }
-            else {
-                pairUpdateTile(3, 0);
-                pairUpdateTile(3, 2);
-            }
-        }
-        if (rowWave && w > 0) { // wave-uniform; a pair that has a successor is always full (w == 64)
-#pragma unroll
-            for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < KW / 4; ++ks)
-#pragma unroll
-                    for (int ct = 0; ct < 4; ++ct)
-                        dt[mt][ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-Lp[(4 * ks + hi) * LD2 + 16 * ct + lo], pv[mt][ks], dt[mt][ct], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    // S3: L21 = A21 X1^T, formed transposed, one 16 x 16 tile per wave: D(c, q) = sum_k X1(c, k) A21(q, k)
-    if (w2 > 0) {
-        const int tw = tid >> 6; // (the tile follows the hardware wave, not its role: all four waves take one)
-        const int tc = tw >> 1, tq = tw & 1;
-        f64x4 o = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-        for (int ks = 0; ks < NB / 4; ++ks) {
-            const int k = 4 * ks + hi;
-            o = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + 16 * tc + lo], Aq[k * LD2 + NB + 16 * tq + lo], o, 0, 0, 0); // X1(c, k) is zero for k > c
-        }
-        const int q = 16 * tq + lo;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = 16 * tc + hi + 4 * i;
-            L21s[c * LDP + q] = o[i];
-            // (workgroup 0) kept for the front TRANSPOSED in the unused upper triangle of the pivot block: the other workgroups of this launch may still be
-            // loading the raw block; role M of the next launch moves it into place, and that launch's role C' reads it from here
-            if (d.z == 0 && q < w2 && c < w1) F[(kb1 + c) + (long long)N * (kb1 + NB + q)] = o[i];
-        }
-    }
-    if (rowWave) {
-        // L(m, Q1) = D(., m)[0:32] X1^T: X^T(n, m) = sum_k X1(n, k) D(k, m), D as it sits in the accumulators (register i = row (l >> 4) + 4 i = k-step i)
-#pragma unroll
-        for (int mt = 0; mt < MT2; ++mt) {
-            f64x4 a0 = { 0.0, 0.0, 0.0, 0.0 }, a1 = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int k = 4 * ks + hi;
-                a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + lo], dt[mt][0][ks], a0, 0, 0, 0); // X1(n, k), n < 16: k < 16 only
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + 16 + lo], dt[mt][0][ks], a1, 0, 0, 0);
-            }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int k = 16 + 4 * ks + hi;
-                a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs1[k * LDX + 16 + lo], dt[mt][1][ks], a1, 0, 0, 0);
-            }
-            x0[mt] = a0;
-            x1[mt] = a1;
-            const int row = Rw + 16 * mt + lo;
-            if (row < N) {
-                double* out = F + row + (long long)N * kb1;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int n0 = hi + 4 * i, n1 = 16 + hi + 4 * i;
-                    if (n0 < w1) out[(long long)N * n0] = a0[i];
-                    if (n1 < w1) out[(long long)N * n1] = a1[i];
-                }
-            }
-        }
-    }
-    if (w2 > 0) { // (block-uniform)
-        __syncthreads();
-        // A22 -= L21 L21^T on the three tiles of Q2's pivot block: A[i = q][kk = n] = L21(q, n), B[kk = n][j = c] = L21(c, n)
-        if ((tid >> 6) < 3) {
-            const int tw = tid >> 6;
-            const int ti = tw >= 1, tj = tw == 2;
-            f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-            for (int ks = 0; ks < NB / 4; ++ks)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L21s[(4 * ks + hi) * LDP + 16 * ti + lo], L21s[(4 * ks + hi) * LDP + 16 * tj + lo], acc, 0, 0, 0);
-            const int c = 16 * tj + lo;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = 16 * ti + hi + 4 * r;
-                if (q >= c) Aq[(NB + c) * LD2 + NB + q] -= acc[r];
-            }
-        }
-        __syncthreads();
-        if (wv == 3) {
-            // S4, pivot wave
-            __builtin_amdgcn_s_setprio(3);
-            if (wave_potrf_inv32_mfma(Aq + NB * LD2 + NB, LD2, w2, l, Xs2)) atomicOr(flag, 1);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        else if (rowWave) {
-            // S4, row waves: D(c, m)[32:64] -= sum_n L21(c, n) L(m, Q1)(n): A[i = c][kk = n] = -L21s[n][c], B[kk = n][j = m] = x0 / x1 as they stand
-#pragma unroll
-            for (int mt = 0; mt < MT2; ++mt)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct) {
-                        dt[mt][2 + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-L21s[(4 * ks + hi) * LDP + 16 * ct + lo], x0[mt][ks], dt[mt][2 + ct], 0, 0, 0);
-                        dt[mt][2 + ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(-L21s[(16 + 4 * ks + hi) * LDP + 16 * ct + lo], x1[mt][ks], dt[mt][2 + ct], 0, 0, 0);
-                    }
-        }
-        __syncthreads();
-        if (rowWave) {
-            // S5: L(m, Q2) = D(., m)[32:64] X2^T
-#pragma unroll
-            for (int mt = 0; mt < MT2; ++mt) {
-                f64x4 a0 = { 0.0, 0.0, 0.0, 0.0 }, a1 = { 0.0, 0.0, 0.0, 0.0 };
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int k = 4 * ks + hi;
-                    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs2[k * LDX + lo], dt[mt][2][ks], a0, 0, 0, 0);
-                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs2[k * LDX + 16 + lo], dt[mt][2][ks], a1, 0, 0, 0);
-                }
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const int k = 16 + 4 * ks + hi;
-                    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Xs2[k * LDX + 16 + lo], dt[mt][3][ks], a1, 0, 0, 0);
-                }
-                const int row = Rw + 16 * mt + lo;
-                if (row < N) {
-                    double* out = F + row + (long long)N * (kb1 + NB);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int n0 = hi + 4 * i, n1 = 16 + hi + 4 * i;
-                        if (n0 < w2) out[(long long)N * n0] = a0[i];
-                        if (n1 < w2) out[(long long)N * n1] = a1[i];
-                    }
-                }
-            }
-        }
-    }
-    else __syncthreads(); // (Xs1 is read below by threads that did not write it)
-    if (d.z == 0) {
-        // the inverses of the pivot blocks go straight to their dinv slots (column-major, identity-padded): the solves multiply by them
-        double* slot = dinv + ((long long)d.x + kb1 / NB) * (NB * NB);
-        for (int e = tid; e < NB * NB; e += WGB) slot[e] = Xs1[(e >> 5) * LDX + (e & 31)];
-        if (w2 > 0)
-            for (int e = tid; e < NB * NB; e += WGB) slot[NB * NB + e] = Xs2[(e >> 5) * LDX + (e & 31)];
-    }
+    step_work<TOP>(wg, desc[2 * wg], desc[2 * wg + 1], tv, fronts, dinv, flag, xv);
 }
 
 // ---- triangular solves ------------------------------------------------------------------------------------
@@ -3066,8 +1886,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     };
     sym_ = &sym;
     stream_ = stream;
-    dropGraphs();
-    if (const char* e = std::getenv("IPCGPU_MF_GRAPH")) useGraph_ = std::atoi(e) != 0;
     ns_ = sym.ns;
     nLevels_ = (int)sym.levelPtr.size() - 1;
     fronts_.ensure((size_t)sym.frontOff[ns_]);
@@ -3099,19 +1917,11 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     lap("buffers + tree uploads");
     flag_.alloc(1);
     hflag_.alloc(4);
-    if (!side_ && !std::getenv("IPCGPU_MF_NO_SIDE_STREAM")) {
+    if (!side_) {
         HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
-    if (const char* e = std::getenv("IPCGPU_MF_FUSE_EA")) fuseEA_ = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IPCGPU_MF_BORDER_XT")) borderXT_ = std::atoi(e) != 0;
-    if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE")) stepMerge_ = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IPCGPU_MF_STEP_MERGE_WGS")) stepMergeWgs_ = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IPCGPU_MF_FWD_ROOT_ON_MAIN")) fwdRootOnMain_ = std::atoi(e) != 0;
     if (const char* e = std::getenv("IPCGPU_MF_FWD_STRIDE")) fwdStride_ = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD")) schurFold_ = std::max(0, std::atoi(e));
-    if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD_MIN")) schurFoldMinSteps_ = std::max(2, std::atoi(e));
-    if (const char* e = std::getenv("IPCGPU_MF_SCHUR_FOLD_MB")) schurFoldBudget_ = (long long)std::max(0, std::atoi(e)) << 20;
     if (!fwd_ && !std::getenv("IPCGPU_MF_NO_FWD_OVERLAP")) {
         HIP_CHECK(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evRhs_, hipEventDisableTiming));
@@ -3148,14 +1958,12 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
     int xinvMin = 192;
     if (const char* e = std::getenv("IPCGPU_MF_XINV_NC")) xinvMin = std::atoi(e) > 0 ? std::max(64, std::atoi(e)) : (1 << 30);
-    if (const char* e = std::getenv("IPCGPU_MF_XINV_SKIP_TOP")) xinvSkipTop_ = std::max(0, std::atoi(e));
     xinvBorder_ = true; // the inverse grows by bordering inside the step launches (step_border); 0: recursive doubling on the side stream, as before round 4
     if (const char* e = std::getenv("IPCGPU_MF_XINV_BORDER")) xinvBorder_ = std::atoi(e) != 0;
     int borderMaxNc = 1024; // wider separators (a root of 2 600 columns at 1.12 M tets) keep the recursive doubling: a bordering workgroup is as long as the
                             // front is wide, and at that width it stretches every step launch (measured at mat433: factorisation 20.0 -> 20.8 ms)
     if (const char* e = std::getenv("IPCGPU_MF_BORDER_MAX_NC")) borderMaxNc = std::max(0, std::atoi(e));
-    auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin && sym.level[s] < nLevels_ - xinvSkipTop_; };
-    if (const char* e = std::getenv("IPCGPU_MF_STEP2")) step2_ = std::atoi(e) != 0; // two panels per step launch (k_big_step2): written, not yet run
+    auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin; };
     auto hasBorder = [&](int s) { return xinvBorder_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; };
     // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
     owner_.assign(ns_, rank_);
@@ -3336,17 +2144,15 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         maxTriLds = std::max(maxTriLds, P.triLds);
         // extend-add descriptors: lower-triangular 64 x 64 tiles of the parent, each pointing at the parent's packed record
         P.ea.off = (int)ea.size();
-        // the extend-add of the update block fused into the Schur kernel (k_big_schur64_ea) on the levels that take the 64 x 64 tiles in one pass behind
-        // the chain: decided here because it thins out the extend-add's tiles (needs the same tile count as the decision further down: recomputed there)
+        // the extend-add of the update block is fused into the Schur kernel (k_big_schur64_ea) on the levels that take the 64 x 64 tiles: decided here
+        // because it thins out the extend-add's tiles
         {
             long long tiles32 = 0;
-            int stepsL = 0;
             for (int s : big) {
                 const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
                 tiles32 += nt * (nt + 1) / 2;
-                stepsL = std::max(stepsL, (sym.nc(s) + NB - 1) / NB);
             }
-            P.fuseEA = fuseEA_ && tiles32 >= schur64Min_ && !(schurFold_ > 0 && stepsL >= schurFoldMinSteps_);
+            P.schur64 = P.fuseEA = tiles32 >= schur64Min_;
         }
         for (int s : big) { // every lower-triangle tile is written (children sums or zeros): the fronts are never zero-filled
             const int first = (int)(bigFd.size() / FD_STRIDE);
@@ -3384,81 +2190,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         // big-front step descriptors: launch 0 factors panel 0, launch j + 1 applies panel j and factors panel j + 1
         int steps = 0;
         for (int s : big) steps = std::max(steps, (sym.nc(s) + NB - 1) / NB);
-        P.step2 = step2_ && !big.empty();
-        if (P.step2) {
-            // ... or, two panels per launch (k_big_step2): launch 0 factors the pair 0, launch J + 1 applies pair J and factors pair J + 1
-            const int pairs = (steps + 1) / 2;
-            P.step.assign(pairs + 1, Range());
-            for (int J = -1; J < pairs; ++J) {
-                Range& R = P.step[J + 1];
-                R.off = (int)desc.size();
-                for (int s : big) {
-                    const int N = sym.N(s), nc = sym.nc(s);
-                    const int kb = J * 2 * NB;
-                    if (J >= 0 && kb >= nc) continue;
-                    const int w = (J >= 0) ? std::min(2 * NB, nc - kb) : 0;
-                    const int kb1 = (J >= 0) ? kb + w : 0;
-                    const int wq = (kb1 < nc) ? std::min(2 * NB, nc - kb1) : 0;
-                    const long long foff = sym.frontOff[s];
-                    const int4 rec2 = make_int4(N, nc, (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
-                    if (wq > 0) {
-                        const int Rb = kb1 + wq; // first row below the pair's pivot blocks; one workgroup even when there is none (the pivot work)
-                        for (int r0 = 0; r0 == 0 || r0 < N - Rb; r0 += ROWS_B2) {
-                            desc.push_back(make_int4((int)hDinvOff_[s], J >= 0 ? kb : -1, r0, -2));
-                            desc.push_back(rec2);
-                        }
-                    }
-                    if (J >= 0 && w > NB) { // role M
-                        desc.push_back(make_int4((int)hDinvOff_[s], kb, 0, -8));
-                        desc.push_back(rec2);
-                    }
-                    if (J >= 0 && hasBorder(s)) { // role C': the rows of pair J of X = L11^-1: 16-column tiles left of the pair, one workgroup for its own block
-                        for (int c0 = 0; c0 <= kb; c0 += 16) {
-                            desc.push_back(make_int4(s, kb, c0, -6));
-                            desc.push_back(rec2);
-                        }
-                    }
-                    if (J >= 0) {
-                        const int M0 = kb1 + wq;
-                        const int ntr = (N - M0 + TS - 1) / TS, ntc = (nc - M0 + TS - 1) / TS;
-                        for (int ti = 0; ti < ntr; ++ti)
-                            for (int tj = 0; tj <= ti && tj < ntc; ++tj) {
-                                desc.push_back(make_int4((int)hDinvOff_[s], kb, ti, tj));
-                                desc.push_back(rec2);
-                            }
-                    }
-                }
-                R.cnt = ((int)desc.size() - R.off) / 2;
-            }
-        }
-        else
         P.step.assign(big.empty() ? 0 : steps + 1, Range());
-        {
-            long long tiles32 = 0;
-            for (int s : big) {
-                const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
-                tiles32 += nt * (nt + 1) / 2;
-            }
-            P.schur64 = tiles32 >= schur64Min_;
-        }
-        // Schur complement: one pass behind the chain (k_big_schur / k_big_schur64), or -- on the levels of the top separators, where the chain of step
-        // launches is what the level takes -- folded into those launches in passes of schurFold_ panels (role S): pass q = panels [e(q-1), e(q)) rides on
-        // launch e(q), the first one that finds them final; the last pass on the last launch (which otherwise only carries role C).
-        // Every pass reads and writes the level's update matrices once more: worth it while they are small (the top of a 45 K-node sheet: 6 - 30 MB per
-        // level), a loss where they are not (at 1.12 M tets the two fronts below the root hold 54 MB: folded into 11 passes the factorisation went from
-        // 20.0 to 23.1 ms).  The passes of a level may move schurFoldBudget_ bytes in all.
-        long long sBytes = 0;
-        for (int s : big) sBytes += 4ll * (sym.N(s) - sym.nc(s)) * (sym.N(s) - sym.nc(s)); // lower triangle, doubles
-        int foldPanels = schurFold_;
-        if (schurFold_ > 0 && sBytes > 0) {
-            const long long maxPass = schurFoldBudget_ / sBytes;
-            if (maxPass < 2) foldPanels = 0;
-            else foldPanels = std::max<long long>(schurFold_, (steps + maxPass - 1) / maxPass);
-        }
-        const bool foldSchur = !P.step2 && foldPanels > 0 && steps >= schurFoldMinSteps_ && steps > foldPanels;
-        if (foldSchur) P.stepTop = true;
-        const int nPass = foldSchur ? (steps + foldPanels - 1) / foldPanels : 0;
-        for (int j = -1; j < steps && !big.empty() && !P.step2; ++j) {
+        for (int j = -1; j < steps && !big.empty(); ++j) {
             Range& R = P.step[j + 1];
             R.off = (int)desc.size();
             for (int s : big) {
@@ -3479,7 +2212,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                     P.stepTop = true;
                     // 16-column tiles (32 wide ones made the late steps of the root 20 us long: one CU per tile, k up to nc); c0 == kb: the diagonal block, one copy
                     for (int c0 = 0; c0 <= kb; c0 += 16) {
-                        desc.push_back(make_int4(s, kb, c0, borderXT_ ? -6 : -7));
+                        desc.push_back(make_int4(s, kb, c0, -6));
                         desc.push_back(rec2);
                     }
                 }
@@ -3494,28 +2227,11 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                         }
                 }
             }
-            if (foldSchur && j >= 0 && ((j + 1) % foldPanels == 0 || j + 1 == steps)) { // role S: launch j + 1 finds the panels [.., j] final
-                const int q = (j + foldPanels) / foldPanels; // pass number, 1-based: panels [(q - 1) fold, min(q fold, steps))
-                const int cLo = NB * (q - 1) * foldPanels, cHi = (q == nPass) ? (1 << 30) : NB * q * foldPanels;
-                // folded passes are SHORT sums (schurFold_ panels): the 32 x 32 tiles split them over their four waves and are done in one memory round trip,
-                // a 64 x 64 tile walks them chunk by chunk (measured: +5.5 us per step launch that carried a pass of 64 x 64 tiles)
-                const int TQl = TQ;
-                for (int s : big) {
-                    if (cLo >= sym.nc(s)) continue;
-                    const int nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
-                    const long long foff = sym.frontOff[s];
-                    const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
-                    for (int ti = 0; ti < nt; ++ti)
-                        for (int tj = 0; tj <= ti; ++tj) {
-                            desc.push_back(make_int4(cLo, cHi, ti | (tj << 16), -4));
-                            desc.push_back(rec2);
-                        }
-                }
-            }
             R.cnt = ((int)desc.size() - R.off) / 2; // workgroups: two records each
         }
+        // Schur complement: one pass behind the chain (k_big_schur / k_big_schur64 / k_big_schur64_ea)
         P.schur.off = (int)desc.size();
-        if (!foldSchur) {
+        {
             const int TQl = P.schur64 ? TQ64 : TQ;
             for (int s : big) {
                 const int nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
@@ -3529,7 +2245,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             }
         }
         P.schur.cnt = ((int)desc.size() - P.schur.off) / 2; // workgroups: two records each
-        if (P.fuseEA && (!P.schur64 || foldSchur)) throw StateError("internal: fused extend-add planned for a level without the one-pass 64 x 64 Schur kernel");
         P.fwdRect.off = (int)desc.size();
         for (int s : big)
             for (int r0 = 0; r0 < sym.N(s) - sym.nc(s); r0 += MV_ROWS) desc.push_back(make_int4(s, r0, 0, 0));
@@ -3539,11 +2254,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             if (sym.N(s) > sym.nc(s))
                 for (int c0 = 0; c0 < sym.nc(s); c0 += 16) desc.push_back(make_int4(s, c0, 0, 0));
         P.bwdInit.cnt = (int)desc.size() - P.bwdInit.off;
-    }
-    {
-        size_t nStepLaunches = 0;
-        for (const LevelPlan& P : plan_) nStepLaunches += P.step.size();
-        stepCtr_.alloc(nStepLaunches + 1);
     }
     lap("level plans");
     {
@@ -3585,7 +2295,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         for (int l = 0; l < nLevels_; ++l)
             for (int i = plan_[l].bigFronts.off; i < plan_[l].bigFronts.off + plan_[l].bigFronts.cnt; ++i) {
                 const int s = bigList[i];
-                if (!hasXinv(s)) continue; // (IPCGPU_MF_XINV_SKIP_TOP, A/B: the fronts of the last levels sweep their triangles block by block)
+                if (!hasXinv(s)) continue;
                 xOff[s] = xTot;
                 xTot += (long long)sym.nc(s) * sym.nc(s);
                 invFronts.push_back(s);
@@ -3596,14 +2306,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         std::vector<int> blockList;
         std::vector<long long> di(ns_ + 1, 0);
         for (int s = 0; s < ns_; ++s) di[s + 1] = di[s] + (sym.nc(s) + NB - 1) / NB;
-#ifdef MF_FUSED_SCALAR_PIVOT
-        for (int s = 0; s < ns_; ++s)
-            if (isFused(s) && mine(s)) // the multi-workgroup path leaves finished inverses in the dinv slots
-                for (long long b = di[s]; b < di[s + 1]; ++b) blockList.push_back((int)b);
-#endif
-        // (both front kernels now leave finished inverses in the dinv slots: nothing is left for k_invert_blocks)
-        plainBlocks_.off = 0;
-        plainBlocks_.cnt = (int)blockList.size();
         xinvLevel_.assign(nLevels_, XinvLevel());
         for (int l = 0; l < nLevels_; ++l) {
             XinvLevel& XL = xinvLevel_[l];
@@ -3646,8 +2348,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 XL.rounds.push_back({ g1, g2 });
             }
         }
-        if (blockList.empty()) blockList.push_back(0);
-        invBlockList_.upload(blockList, stream);
         // solve: per level the fronts swept by one workgroup (no inverse) and the row / column blocks of the others
         std::vector<int> triList;
         for (int l = 0; l < nLevels_; ++l) {
@@ -3710,7 +2410,6 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_front_fused<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSmallLds));
     }
-    if (step2_) HIP_CHECK(hipFuncSetAttribute((const void*)k_big_step2, hipFuncAttributeMaxDynamicSharedMemorySize, STEP2_LDS));
     if (maxSolveLds > 48 * 1024) {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
@@ -3754,7 +2453,6 @@ void MfNumeric::allreduceSum(double* dev, long long count)
 
 MfNumeric::~MfNumeric()
 {
-    dropGraphs();
     if (side_) (void)hipStreamSynchronize(side_);
     if (fwd_) (void)hipStreamSynchronize(fwd_);
     for (hipEvent_t e : evFactLevel_) (void)hipEventDestroy(e);
@@ -3767,41 +2465,10 @@ MfNumeric::~MfNumeric()
     if (side_) (void)hipStreamDestroy(side_);
 }
 
-void MfNumeric::dropGraphs()
-{
-    if (graphF_) (void)hipGraphExecDestroy(graphF_);
-    if (graphS_) (void)hipGraphExecDestroy(graphS_);
-    graphF_ = graphS_ = nullptr;
-}
-
-// The launch sequences are static for a given analysis (same descriptors, same buffers), so they are captured once into
-// hipGraphs and replayed: ~130 (factor) / ~90 (solve) launches per call otherwise each pay the host-side dispatch path.
-template <class Enqueue>
-static void replay(hipStream_t stream, hipGraphExec_t& exec, bool& valid, Enqueue&& enqueue)
-{
-    if (!valid) {
-        if (exec) (void)hipGraphExecDestroy(exec);
-        exec = nullptr;
-        hipGraph_t g = nullptr;
-        HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        enqueue();
-        HIP_CHECK(hipStreamEndCapture(stream, &g));
-        HIP_CHECK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(g);
-        valid = true;
-    }
-    HIP_CHECK(hipGraphLaunch(exec, stream));
-}
-
 bool MfNumeric::factorize(const double* a_dev)
 {
     if (!sym_) throw StateError("factorize before analyze_pattern");
-    if (useGraph_ && world_ == 1) {
-        bool valid = graphF_ && graphA_ == a_dev;
-        replay(stream_, graphF_, valid, [&] { enqueueFactor(a_dev); });
-        graphA_ = a_dev;
-    }
-    else enqueueFactor(a_dev);
+    enqueueFactor(a_dev);
     if (world_ > 1) { // ALWAYS once more at the end: the exchanges only carry the flag of pivots met before them, and a tree of the
         // forest that was not cut (several bodies, world > number of roots) lives on one rank alone -- one double
         hipLaunchKernelGGL(k_flag_to_double, dim3(1), dim3(1), 0, stream_, flag_.p, xchgBuf_.p);
@@ -3815,14 +2482,13 @@ bool MfNumeric::factorize(const double* a_dev)
 
 bool MfNumeric::pivotsOk() const
 {
-    if (hflag_.p[0] & 4) throw HipError("multifrontal factorisation: a merged step launch gave up waiting for the step before it (IPCGPU_MF_STEP_MERGE=1 disables merging)");
     return hflag_.p[0] == 0;
 }
 
 bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, double* x_dev, bool wait)
 {
     if (!sym_) throw StateError("factorize before analyze_pattern");
-    if (world_ > 1 || !fwd_ || useGraph_) { // sharded / captured runs keep the two-call sequence
+    if (world_ > 1 || !fwd_) { // sharded runs keep the two-call sequence
         const bool ok = factorize(a_dev);
         if (ok) solve(rhs_dev, x_dev);
         return ok;
@@ -3848,12 +2514,9 @@ bool MfNumeric::factorizeSolve(const double* a_dev, const double* rhs_dev, doubl
 
 void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
 {
-    const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     XinvView xvF{ xinvOff_.p, xinvX_.p, xinvT_.p };
     if (sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evSide_, 0)); // the side stream still reads the previous factor
-    if (stepMerge_ > 1 && stepCtr_.n) stepCtr_.zero(stream_);
-    size_t ctrNext = 0; // next free counter of the merged step launches
     bool sideUsed = false;
     int fwdNext = 0; // first level not yet handed to the forward stream
     if (nFusedA_) hipLaunchKernelGGL(k_gather_a, dim3((nFusedA_ + 255) / 256), dim3(256), 0, stream_, nFusedA_, aSrc_.p, a_dev, aPerm_.p, flag_.p);
@@ -3873,18 +2536,6 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
                 hipLaunchKernelGGL(k_front_fused<256>, dim3(P.small.cnt), dim3(256), P.smallLds, stream_, fd, inv_.p, aLoc_.p, aPerm_.p, fronts_.p,
                     dinv_.p, flag_.p);
         }
-#ifdef MF_PHASE_TIMERS
-        if (P.small.cnt && std::getenv("IPCGPU_MF_PHASES")) {
-            HIP_CHECK(hipStreamSynchronize(stream_));
-            unsigned long long h[16];
-            HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(mf_phase_acc), sizeof(h)));
-            fprintf(stderr, "fused level %d (%d fronts): cycles per front by phase:", l, P.small.cnt);
-            for (int i = 0; i < 9; ++i) fprintf(stderr, " %.0f", (double)h[i] / P.small.cnt);
-            fprintf(stderr, "\n");
-            unsigned long long z[16] = { 0 };
-            HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mf_phase_acc), z, sizeof(z)));
-        }
-#endif
         if (P.ea.cnt) {
             hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, bigFd_.p, inv_.p, fronts_.p, P.fuseEA ? 1 : 0);
             const int na = bigAOff_[l + 1] - bigAOff_[l];
@@ -3892,35 +2543,10 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
                 hipLaunchKernelGGL(k_scatter_big, dim3((na + 255) / 256), dim3(256), 0, stream_, na, bigASrc_.p + bigAOff_[l],
                     bigADst_.p + bigAOff_[l], a_dev, fronts_.p);
         }
-        // consecutive step launches merged into one (k_big_step, StepGroup): as many as stepMerge_ allows and as fit stepMergeWgs_ workgroups (later steps'
-        // workgroups wait in their slots: no point in parking thousands of them)
-        for (size_t i = 0; i < P.step.size();) {
-            if (!P.step[i].cnt) {
-                ++i;
-                continue;
-            }
-            if (P.step2) { // two panels per launch (IPCGPU_MF_STEP2=1)
-                hipLaunchKernelGGL(k_big_step2, dim3(P.step[i].cnt), dim3(WGB), STEP2_LDS, stream_, desc_.p + P.step[i].off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
-                ++i;
-                continue;
-            }
-            StepGroup sg;
-            sg.n = 0;
-            sg.ctr = stepCtr_.p + ctrNext;
-            int total = 0;
-            size_t j = i;
-            for (; j < P.step.size() && sg.n < std::min(stepMerge_, STEP_GROUP_MAX); ++j) {
-                const Range& R = P.step[j];
-                if (!R.cnt) break; // (only ever the last one)
-                if (sg.n > 0 && (total + R.cnt > stepMergeWgs_ || R.off != P.step[i].off + 2 * total)) break; // the records of a launch are contiguous
-                total += R.cnt;
-                sg.end[sg.n++] = total;
-            }
-            for (int q = sg.n; q < STEP_GROUP_MAX; ++q) sg.end[q] = total;
-            ctrNext += sg.n;
-            if (P.stepTop) hipLaunchKernelGGL(k_big_step<true>, dim3(total), dim3(WGB), 0, stream_, desc_.p + P.step[i].off, tv, fronts_.p, dinv_.p, flag_.p, xvF, sg);
-            else hipLaunchKernelGGL(k_big_step<false>, dim3(total), dim3(WGB), 0, stream_, desc_.p + P.step[i].off, tv, fronts_.p, dinv_.p, flag_.p, xvF, sg);
-            i = j;
+        for (const Range& R : P.step) { // one launch per 32-column step, each with look-ahead (k_big_step)
+            if (!R.cnt) continue;
+            if (P.stepTop) hipLaunchKernelGGL(k_big_step<true>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
+            else hipLaunchKernelGGL(k_big_step<false>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
         }
         if (P.schur.cnt) {
             if (P.fuseEA) hipLaunchKernelGGL(k_big_schur64_ea, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, bigFd_.p, inv_.p, fronts_.p);
@@ -3943,8 +2569,8 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
         }
         if (xinvLevel_[l].blocks.cnt) {
             // the factor panels and pivot blocks of this level are final: form the triangle inverses of its fronts beside the
-            // latency-bound chain of the levels above (during graph capture everything stays on the one stream)
-            if (side_ && !useGraph_) {
+            // latency-bound chain of the levels above
+            if (side_) {
                 HIP_CHECK(hipEventRecord(evLevel_[l], stream_));
                 HIP_CHECK(hipStreamWaitEvent(side_, evLevel_[l], 0));
                 enqueueInverses(l, side_);
@@ -3956,7 +2582,7 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
         if (overlapForward) {
             // everything the forward sweep of this level reads is final (factor panels, pivot-block inverses; the triangle inverses of the
             // widest fronts follow on the side stream): hand the level to the forward stream, which runs beside the levels above
-            if (l == nLevels_ - 1 && fwdRootOnMain_ && !sideUsed) {
+            if (l == nLevels_ - 1 && !sideUsed) {
                 // the last level (the root separator) has nothing to run beside: its forward sweep follows its factorisation on THIS stream, and the
                 // hand-over back from the forward stream happens here, where that stream has long been idle, instead of behind the whole factorisation
                 // (a cross-stream event wait costs the waiting stream ~20 us on this runtime: it used to sit between the forward and the backward sweep)
@@ -3978,23 +2604,6 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
             }
         }
     }
-    // the dinv slots hold the factored diagonal blocks: invert all of them at once (independent, one wave each)
-#ifdef MF_PHASE_TIMERS
-    if (std::getenv("IPCGPU_MF_PHASES")) {
-        HIP_CHECK(hipStreamSynchronize(stream_));
-        unsigned long long h[16];
-        HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(mf_phase_acc), sizeof(h)));
-        const double n = (double)std::max<unsigned long long>(h[15], 1);
-        fprintf(stderr, "big step, pivot wave of the first workgroup of every front (%llu samples): cycles load %.0f update %.0f potrf %.0f wait-rows %.0f trsm+store %.0f\n",
-            h[15], h[10] / n, h[11] / n, h[12] / n, h[13] / n, h[14] / n);
-        unsigned long long z[16] = { 0 };
-        HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(mf_phase_acc), z, sizeof(z)));
-    }
-#endif
-    // the dinv slots hold the factored diagonal blocks: invert them (independent, one wave each); those of the fronts with an
-    // explicit inverse were already taken care of on the side stream
-    if (plainBlocks_.cnt)
-        hipLaunchKernelGGL(k_invert_blocks, dim3(plainBlocks_.cnt), dim3(64), 0, stream_, invBlockList_.p + plainBlocks_.off, dinv_.p);
     // The inverses are first needed when the forward solve reaches their level (the root's: at its very end), so the main
     // stream does not wait here: enqueueSolve waits per level, the next factorisation waits before it touches the fronts.
     if (sideUsed) HIP_CHECK(hipEventRecord(evSide_, side_));
@@ -4017,20 +2626,13 @@ void MfNumeric::enqueueInverses(int l, hipStream_t st)
 void MfNumeric::solve(const double* rhs_dev, double* x_dev)
 {
     if (!sym_) throw StateError("solve before analyze_pattern");
-    if (useGraph_ && world_ == 1) {
-        bool valid = graphS_ && graphRhs_ == rhs_dev && graphX_ == x_dev;
-        replay(stream_, graphS_, valid, [&] { enqueueSolve(rhs_dev, x_dev); });
-        graphRhs_ = rhs_dev;
-        graphX_ = x_dev;
-    }
-    else enqueueSolve(rhs_dev, x_dev);
+    enqueueSolve(rhs_dev, x_dev);
 }
 
 void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
 {
     const MfSymbolic& sym = *sym_;
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
-    XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
     const int n3 = sym.n;
     // the permuted right-hand side stays in its own buffer: the forward kernels of a level write y into yperm while other
     // workgroups of the same launch still gather right-hand-side entries

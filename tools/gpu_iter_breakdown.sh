@@ -11,7 +11,7 @@ cd $R
 python tools/iter_breakdown.py $out/trace 12 10 | tee $out/iter_breakdown.txt
 IPCGPU_MF_NO_FWD_OVERLAP=1 timeout 600 python bench.py --no-cpu-baseline --no-contact > $out/bench_no_fwd_overlap.json 2>> $out/trace.log
 timeout 600 python bench.py --no-cpu-baseline --no-contact > $out/bench_default.json 2>> $out/trace.log
-IPCGPU_MF_GRAPH=0 timeout 600 python bench.py --no-cpu-baseline --no-contact > $out/bench_no_graph.json 2>> $out/trace.log
+timeout 600 python bench.py --no-cpu-baseline --no-contact > $out/bench_no_graph.json 2>> $out/trace.log
 python - <<PY
 import json
 for n in ("bench_under_trace", "bench_default", "bench_no_fwd_overlap", "bench_no_graph"):

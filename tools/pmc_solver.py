@@ -10,7 +10,7 @@ SIMDs, SQ_BUSY_CU_CYCLES quad-cycles summed over CUs.  The ratios below stay ins
   wait_any / wave_cycles          waves parked on s_waitcnt or a barrier (memory latency, the pivot chain's __syncthreads)
   wait_inst_any / wave_cycles     issue stalls (MFMA read-after-write, busy pipe)
   active_inst_any / wave_cycles   issuing
-The factorisation runs without graph replay here (IPCGPU_MF_GRAPH=0) so that every dispatch is attributed to its kernel."""
+Every dispatch is attributed to its kernel (the solver replays no graphs)."""
 import csv
 import glob
 import json
@@ -23,7 +23,6 @@ KERNELS = ["k_big_step", "k_big_schur64", "k_big_schur", "k_front_fused", "k_ext
 
 
 def workload(size=150):
-    os.environ["IPCGPU_MF_GRAPH"] = "0"
     sys.path.insert(0, ROOT)
     from ipc_amd import lib, scene
     V, F = scene.make_mat(size)
