@@ -91,7 +91,11 @@ def _build(force, verbose, extra, fma=True):
 
 
 if __name__ == "__main__":
+    # python ipc_amd/build.py [--force] [--nofma] [--variant NAME -DMACRO=VALUE ...]: experiment builds land in libipcgpu_NAME.so (IPCGPU_LIB_VARIANT=NAME)
     if "--nofma" in sys.argv:
         print(build(force="--force" in sys.argv, verbose=True, variant="nofma", fma=False))
+    elif "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        print(build(force="--force" in sys.argv, verbose=True, variant=sys.argv[i + 1], extra_flags=[a for a in sys.argv[i + 2:] if a.startswith("-D")]))
     else:
         print(build(force="--force" in sys.argv, verbose=True))

@@ -117,6 +117,7 @@ private:
     };
     std::vector<XinvLevel> xinvLevel_;
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
+    bool xcdOrder_ = true; // Schur tiles dealt to the XCDs front by front (IPCGPU_MF_XCD_ORDER=0: front after front over all XCDs, as before round 5)
     int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)
     bool fwdJoined_ = false; // the root's forward sweep went onto the main stream (factorizeSolve)
     // factorizeSolve(): the forward sweep of a level is enqueued on its own stream as soon as that level's factor kernels are, so that it

@@ -43,11 +43,19 @@ constexpr int ROW_WAVES_B = 3; // row waves per role-B workgroup (1 was measured
 #ifndef MF_ROWS_MT
 #define MF_ROWS_MT 2
 #endif
+#ifndef MF_SCHUR_OCC
+#define MF_SCHUR_OCC 1 // the same for k_big_schur / k_big_schur64 (the levels without the fused extend-add)
+#endif
+#ifndef MF_STEP_OCC
+#define MF_STEP_OCC 3 // waves per SIMD the step kernel is compiled for: 130 registers, no scratch (1 = no constraint: 180 registers, 2 waves; +0.7 % at 45 K nodes,
+                      // profiles/r05_solver_ab_xcd_occupancy.txt)
+#endif
 constexpr int MT_B = MF_ROWS_MT; // 16-row tiles per row wave of a role-B workgroup
 constexpr int ROWS_B = 16 * MT_B * ROW_WAVES_B; // panel rows per role-B workgroup
 constexpr int WGT = 512; // workgroup of the big-front triangular sweeps
 
 constexpr int TS = 64; // trailing-update tile
+constexpr int XCDS = 8; // accelerator complex dies of an MI355X: workgroup b of a launch is observed to run on XCD b % 8
 constexpr int MV_ROWS = 32; // rows per workgroup of the forward matrix-vector kernels (k_big_fwd_rect, k_xinv_fwd): 32 rows x 8 column groups
 constexpr int FD_STRIDE_EA = 64; // packed front descriptors (same layout as the fused kernel's, see k_front_fused)
 constexpr int FUSED_MAX_KIDS_EA = 8;
@@ -248,6 +256,8 @@ __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld,
     bool bad = false;
 #pragma unroll
     for (int k = 0; k < 16; k += 2) {
+        if (k >= w) break; // wave-uniform: the rows / columns >= w are identity -- their pivots are 1, their multipliers 0, the updates add zeros (a panel
+                           // of 4 columns, the last one of a 900-column separator or the second one of a 36-column leaf, takes 2 of the 16 pivot steps)
         const int h = k & 3, r = k >> 2;
         const bool selh = hi == h, both = (hi >> 1) == (h >> 1), live = both && lo > k + 1;
         const double row = T00[r];
@@ -278,6 +288,7 @@ __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld,
         }
 #pragma unroll
         for (int k = 0; k < 16; k += 2) {
+            if (16 + k >= w) break;
             const int h = k & 3, r = k >> 2;
             const bool selh = hi == h, both = (hi >> 1) == (h >> 1), live = both && lo > k + 1;
             const double row = T11[r];
@@ -681,7 +692,7 @@ __device__ __forceinline__ void schur_tile32(const int N, const int ncAll, doubl
         if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[r] - v;
     }
 }
-__global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc, double* __restrict__ fronts)
+__global__ __launch_bounds__(WG, MF_SCHUR_OCC) void k_big_schur(const int4* __restrict__ desc, double* __restrict__ fronts)
 {
     __shared__ double red[4][4][256];
     // two records per workgroup (see k_big_step): (front, ti, tj, 0) and (N, nc, front offset)
@@ -696,7 +707,9 @@ __global__ __launch_bounds__(WG) void k_big_schur(const int4* __restrict__ desc,
 // 100-450: split four ways a wave ran two or three chunks between its prologue and the LDS reduction.  Upper levels keep the 32 x 32 kernel: they
 // have a handful of fronts and need the tiles for parallelism.  desc as above with 64 x 64 tile indices.
 constexpr int TQ64 = 64;
-// LOAD_OLD = false: `old` arrives filled (the children's sums gathered by the caller: k_big_schur64_ea) and the tile is WRITTEN, not read-modify-written
+// LOAD_OLD = false: `old` arrives filled (the children's sums gathered by the caller: k_big_schur64_ea) and the tile is WRITTEN, not read-modify-written.
+// (Round 5: parking `old` in LDS over the product loop -- 32 registers less, a third wave per SIMD -- changed nothing, measured at 45 K and 375 K nodes:
+// the kernel is not occupancy-bound.  profiles/r05_solver_ab_xcd_occupancy.txt.)
 template <bool LOAD_OLD>
 __device__ __forceinline__ void schur_tile64_core(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi,
     double (&old)[2][2][4])
@@ -781,7 +794,7 @@ __device__ __forceinline__ void schur_tile64(const int N, const int ncAll, doubl
     double old[2][2][4];
     schur_tile64_core<true>(N, ncAll, F, ti, tj, cLo, cHi, old);
 }
-__global__ __launch_bounds__(WG) void k_big_schur64(const int4* __restrict__ desc, double* __restrict__ fronts)
+__global__ __launch_bounds__(WG, MF_SCHUR_OCC) void k_big_schur64(const int4* __restrict__ desc, double* __restrict__ fronts)
 {
     const int4 d = desc[2 * blockIdx.x];
     const int4 d2 = desc[2 * blockIdx.x + 1];
@@ -1226,7 +1239,7 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
 }
 
 template <bool TOP>
-__global__ __launch_bounds__(WGB) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
+__global__ __launch_bounds__(WGB, MF_STEP_OCC) void k_big_step(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts,
     double* __restrict__ dinv, int* __restrict__ flag, XinvView xv)
 {
     const int wg = blockIdx.x;
@@ -1922,6 +1935,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
     if (const char* e = std::getenv("IPCGPU_MF_FWD_STRIDE")) fwdStride_ = std::max(1, std::atoi(e));
+    if (const char* e = std::getenv("IPCGPU_MF_XCD_ORDER")) xcdOrder_ = std::atoi(e) != 0;
     if (!fwd_ && !std::getenv("IPCGPU_MF_NO_FWD_OVERLAP")) {
         HIP_CHECK(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evRhs_, hipEventDisableTiming));
@@ -1954,7 +1968,26 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     int ntSmallN = 0, ntBigN = 200;
     if (const char* e = std::getenv("IPCGPU_MF_NT128_N")) ntSmallN = std::atoi(e);
     if (const char* e = std::getenv("IPCGPU_MF_NT512_N")) ntBigN = std::atoi(e);
-    auto isFused = [&](int s) { return sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds; };
+    // ... unless its level has fronts of the second kind anyway and only a few of the first (round 5): the single-workgroup kernel of such a level is a launch of
+    // its own IN FRONT of the level's batched kernels -- 57 us for the 93 widest fused fronts of level 4 of a 45 K-node sheet, one workgroup each at the limit of
+    // what LDS holds -- while as members of the batched launches the same fronts cost next to nothing (those launches are latency-bound and far from full).
+    // IPCGPU_MF_MIXED_LEVELS=1: every front that fits goes the fused way, as before round 5.
+    std::vector<char> fusedFront(ns_, 0);
+    {
+        bool mixedOk = false;
+        if (const char* e = std::getenv("IPCGPU_MF_MIXED_LEVELS")) mixedOk = std::atoi(e) != 0;
+        std::vector<int> nFit(nLevels_, 0), nBigL(nLevels_, 0);
+        for (int s = 0; s < ns_; ++s) {
+            fusedFront[s] = sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds;
+            (fusedFront[s] ? nFit : nBigL)[sym.level[s]]++;
+        }
+        if (!mixedOk)
+            for (int s = 0; s < ns_; ++s) {
+                const int l = sym.level[s];
+                if (fusedFront[s] && nBigL[l] > 0 && nFit[l] <= std::max(64, nBigL[l])) fusedFront[s] = 0;
+            }
+    }
+    auto isFused = [&](int s) { return fusedFront[s] != 0; };
     // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
     int xinvMin = 192;
     if (const char* e = std::getenv("IPCGPU_MF_XINV_NC")) xinvMin = std::atoi(e) > 0 ? std::max(64, std::atoi(e)) : (1 << 30);
@@ -2229,18 +2262,65 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             }
             R.cnt = ((int)desc.size() - R.off) / 2; // workgroups: two records each
         }
-        // Schur complement: one pass behind the chain (k_big_schur / k_big_schur64 / k_big_schur64_ea)
+        // Schur complement: one pass behind the chain (k_big_schur / k_big_schur64 / k_big_schur64_ea).
+        // XCD-aware order (round 5): workgroup b of a launch runs on XCD b % 8 (observed, MI355X_MICROARCH.md; a speed assumption only -- any placement is
+        // correct) and every XCD has its own 4 MB L2.  In front-after-front order the tiles of one front land on all eight XCDs, so each L2 sees the factor
+        // panels L21 of ALL fronts of the level (25 MB on the 64-front level of a 45 K-node sheet) and every operand load is an L2 miss.  Here the tile rows of
+        // a front form groups of about total / 8 tiles, the groups are dealt to eight bins (largest first onto the least loaded bin) and slot b of the
+        // launch takes the next tile of bin b % 8: an XCD works through whole fronts and reads their panels from memory once.
         P.schur.off = (int)desc.size();
         {
             const int TQl = P.schur64 ? TQ64 : TQ;
+            struct Tile {
+                int4 a, b;
+            };
+            std::vector<std::vector<Tile>> groups;
+            long long total = 0;
+            for (int s : big) {
+                const long long nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
+                total += nt * (nt + 1) / 2;
+            }
+            const long long target = std::max<long long>(1, (total + XCDS - 1) / XCDS);
             for (int s : big) {
                 const int nt = (sym.N(s) - sym.nc(s) + TQl - 1) / TQl;
                 const long long foff = sym.frontOff[s];
                 const int4 rec2 = make_int4(sym.N(s), sym.nc(s), (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
-                for (int ti = 0; ti < nt; ++ti)
-                    for (int tj = 0; tj <= ti; ++tj) {
-                        desc.push_back(make_int4(s, ti, tj, P.fuseEA ? eaRecOf[s] : 0));
-                        desc.push_back(rec2);
+                groups.emplace_back();
+                for (int ti = 0; ti < nt; ++ti) {
+                    if (xcdOrder_ && (long long)groups.back().size() + ti + 1 > target && !groups.back().empty()) groups.emplace_back(); // next row range of a front too large for one bin
+                    for (int tj = 0; tj <= ti; ++tj) groups.back().push_back(Tile{ make_int4(s, ti, tj, P.fuseEA ? eaRecOf[s] : 0), rec2 });
+                }
+            }
+            if (!xcdOrder_) {
+                for (const auto& g : groups)
+                    for (const Tile& t : g) {
+                        desc.push_back(t.a);
+                        desc.push_back(t.b);
+                    }
+            }
+            else {
+                std::vector<int> order(groups.size());
+                for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+                std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return groups[a].size() > groups[b].size(); });
+                std::vector<std::vector<Tile>> bins(XCDS);
+                for (int g : order) {
+                    int best = 0;
+                    for (int x = 1; x < XCDS; ++x)
+                        if (bins[x].size() < bins[best].size()) best = x;
+                    bins[best].insert(bins[best].end(), groups[g].begin(), groups[g].end());
+                }
+                std::vector<size_t> head(XCDS, 0), tail(XCDS);
+                for (int x = 0; x < XCDS; ++x) tail[x] = bins[x].size();
+                for (long long left = total; left > 0;)
+                    for (int x = 0; x < XCDS && left > 0; ++x, --left) {
+                        int from = x;
+                        if (head[x] >= tail[x]) { // this bin has run dry: take from the END of the fullest one (its head keeps its order)
+                            for (int y = 0; y < XCDS; ++y)
+                                if (tail[y] - head[y] > tail[from] - head[from]) from = y;
+                        }
+                        const Tile& t = (from == x) ? bins[x][head[x]++] : bins[from][--tail[from]];
+                        desc.push_back(t.a);
+                        desc.push_back(t.b);
                     }
             }
         }
