@@ -42,6 +42,31 @@ class DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
 
+def gloo_exchange_hook(local_rank):
+    """--single-device-test only: the sharded solver's point-to-point group (ipcgpu_opt_set_exchange) over gloo through a host bounce -- plumbing, not a
+    data path (on real multi-GPU runs the RCCL binding enqueues ncclSend / ncclRecv on the context's stream, include/adapters/ipcgpu_rccl.cpp)."""
+    import torch
+    import torch.distributed as dist
+
+    def xhook(ops):
+        reqs, recvs = [], []
+        for ptr, count, peer, send in ops:
+            t = torch.as_tensor(DevPtr(ptr, count), device=f"cuda:{local_rank}")
+            if send:
+                reqs.append(dist.P2POp(dist.isend, t.cpu(), peer))
+            else:
+                h = torch.empty(count, dtype=torch.float64)
+                recvs.append((t, h))
+                reqs.append(dist.P2POp(dist.irecv, h, peer))
+        for r in dist.batch_isend_irecv(reqs):
+            r.wait()
+        for t, h in recvs:
+            t.copy_(h)
+        torch.cuda.synchronize()
+        return 0
+    return xhook
+
+
 # (rounds 2-3 switched the sharded assembly on only from 4 M tets: its partial matrices were summed by an all-reduce of the CSR values.  Round 4: with the solver
 # sharded as well the assembly is owner-computes -- a rank assembles the rows its fronts read, no matrix value crosses ranks -- so every size shards.)
 
@@ -133,6 +158,7 @@ def main():
             ctx.set_shard(rank, world)  # element assembly split over the ranks, gradient / CSR values all-reduced
         if args.single_device_test:
             ctx.set_allreduce(hook)  # gloo through a host bounce: plumbing only
+            ctx.set_exchange(gloo_exchange_hook(local_rank))
         else:
             # RCCL called from C on the context's own stream (include/ipcgpu_rccl.h): rank 0 draws the unique id, torch.distributed is
             # only the bootstrap that carries its 128 bytes; no collective of the data path goes through Python after this
@@ -143,7 +169,7 @@ def main():
             ctx.rccl_attach(rank, world, bytes(idt.cpu().numpy().tobytes()))
         if solver_sharded:
             # the direct solver is what an iteration consists of: the assembly tree is cut below its top separators, every rank
-            # factorises / solves its own subtrees, the fronts above the cut are repeated
+            # factorises / solves its own subtrees, a front above the cut is executed by ONE rank and fed point to point
             ctx.set_solver_shard(rank, world)
     ctx.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
     ctx.opt_init(dt=0.04, gravity=False)
@@ -177,6 +203,7 @@ def main():
     for _ in range(args.warmup):
         one_iteration()
     comm0 = ctx.comm_stats()
+    xs0 = ctx.solver_exchange_stats()
     t_before = ctx.timers().copy()
     barrier()
     t0 = time.perf_counter()
@@ -190,6 +217,7 @@ def main():
         elapsed = float(tt.item())
     timers = ctx.timers() - t_before
     comm1 = ctx.comm_stats()
+    xs1 = ctx.solver_exchange_stats()
 
     progress(f"timed region done: {args.steps / elapsed:.1f} it/s")
     # collective when the solver is sharded: every rank takes part
@@ -237,14 +265,17 @@ def main():
                                          ("element-sharded assembly, partial matrices summed by an all-reduce of the CSR values" if sharded else
                                           "assembly repeated on every rank"))
                     + "; " + (f"subtree-sharded multifrontal factorisation and solves: {100 * ctx.solver_shard_stats()['shared_flop_fraction']:.0f} % of the "
-                              "factorisation flops lie above the cut and are repeated, update matrices / vectors of the subtree roots and the "
-                              "solution cross ranks by all-reduce" if solver_sharded else "factorisation and solves repeated on every rank")),
+                              "factorisation flops lie above the cut (each front there executed by one rank, the ranks below it waiting for its result); update "
+                              "matrices / vectors of children on other ranks and the separators' solution entries go point to point (ncclSend / ncclRecv groups), "
+                              "the pivot flag and the solution vector by all-reduce" if solver_sharded else "factorisation and solves repeated on every rank")),
                 "time_steps_completed": state["steps_done"],
             },
             "comm_per_iter": {"stepper_allreduce_bytes": (comm1["stepper_bytes"] - comm0["stepper_bytes"]) / K,
                               "stepper_allreduce_calls": (comm1["stepper_calls"] - comm0["stepper_calls"]) / K,
-                              "solver_allreduce_bytes": (comm1["solver_bytes"] - comm0["solver_bytes"]) / K,
-                              "solver_allreduce_calls": (comm1["solver_calls"] - comm0["solver_calls"]) / K,
+                              "solver_bytes_rank0": (comm1["solver_bytes"] - comm0["solver_bytes"]) / K,  # sent + received point to point + all-reduced buffers, this rank
+                              "solver_p2p_sent_bytes_rank0": (xs1["sent_bytes"] - xs0["sent_bytes"]) / K,
+                              "solver_p2p_received_bytes_rank0": (xs1["received_bytes"] - xs0["received_bytes"]) / K,
+                              "solver_collective_calls": (comm1["solver_calls"] - comm0["solver_calls"]) / K,
                               "csr_value_bytes": 8 * int(nnz), "nodal_vector_bytes": 24 * int(V.shape[0]),
                               "rows_assembled_on_rank0": comm1["rows_assembled_nodes"] / max(comm1["nodes"], 1)},
             "split_ms_per_iter": split,
@@ -394,6 +425,7 @@ def large_workload(args, rank, local_rank, world, torch, dist, ipc_amd):
             torch.cuda.synchronize()
             return 0
         ctx.set_allreduce(hook)
+        ctx.set_exchange(gloo_exchange_hook(local_rank))
     else:
         idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
         if rank == 0:
@@ -421,6 +453,7 @@ def large_workload(args, rank, local_rank, world, torch, dist, ipc_amd):
     K, W = max(4, args.steps // 5), 2
     for _ in range(W):
         one()
+    xs0, cm0 = ctx.solver_exchange_stats(), ctx.comm_stats()
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -433,7 +466,13 @@ def large_workload(args, rank, local_rank, world, torch, dist, ipc_amd):
     rec = {"workload": f"matTwist mat{args.large_size}: {V.shape[0]} nodes / {F.shape[0]} tets", "steps": K, "warmup": W, "value": K / float(el.item()),
            "unit": "iter/s", "ms_per_step": 1e3 * float(el.item()) / K, "element_assembly_sharded": bool(sharded),
            "solver_sharded": args.solver_shard == "on",
+           # the share of the factorisation flops above the cut: executed once each (round 5), by one rank while the ranks below it wait -- the serial part
+           # of the strong-scaling model of DESIGN.md section 6.  This >= 1 M-tet workload is the one on which the subtrees dominate; on the headline
+           # size (45 K nodes) the dependent pivot chain of the top separators caps strong scaling near 1.5-2 x whatever the number of GPUs.
            "shared_flop_fraction": ctx.solver_shard_stats()["shared_flop_fraction"] if args.solver_shard == "on" else None}
+    xs1, cm1 = ctx.solver_exchange_stats(), ctx.comm_stats()
+    rec["comm_per_iter_rank0"] = {"solver_p2p_sent_bytes": (xs1["sent_bytes"] - xs0["sent_bytes"]) / K, "solver_p2p_received_bytes": (xs1["received_bytes"] - xs0["received_bytes"]) / K,
+                                  "solver_bytes": (cm1["solver_bytes"] - cm0["solver_bytes"]) / K, "stepper_allreduce_bytes": (cm1["stepper_bytes"] - cm0["stepper_bytes"]) / K}
     ctx.close()
     return rec
 

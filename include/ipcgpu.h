@@ -147,13 +147,16 @@ int ipcgpu_linsys_factorize(ipcgpu_ctx*); /* factorize, :130-137; returns IPCGPU
 int ipcgpu_linsys_solve(ipcgpu_ctx*, const double* rhs, double* result); /* solve, :139-154 */
 int ipcgpu_linsys_precondition_diag(ipcgpu_ctx*, const double* in, double* out); /* :411-420 */
 /* Multi-GPU direct solver (one process per GPU): the assembly tree is cut below its top separators; rank r factorises and solves
-   the subtrees it owns, every rank repeats the fronts above the cut, and the update matrices / vectors of the subtree roots and
-   the final solution cross ranks through the all-reduce hook of ipcgpu_opt_set_allreduce (set the hook first).  A rank needs the matrix
-   values of its own fronts: replicated assembly, or ipcgpu_ctx_set_shard (owner-computes rows, see ipcgpu_opt_comm_stats below).
-   Takes effect at the next analyze_pattern.  ipcgpu_linsys_shard_stats (after analyze_pattern): out2[0] = world size,
-   out2[1] = the share of the factorisation flops that lies above the cut and is repeated by every rank. */
+   the subtrees it owns; a front above the cut is executed by ONE rank (the one that holds its most expensive child), and the update
+   matrices / vectors of children on other ranks and the solution entries of ancestors travel point to point through the exchange hook
+   (ipcgpu_opt_set_exchange[_stream] below: set it first, together with an all-reduce hook for the pivot flag and the solution vector).
+   A rank needs the matrix values of the fronts it executes: replicated assembly, or ipcgpu_ctx_set_shard (owner-computes rows, see
+   ipcgpu_opt_comm_stats below).  Takes effect at the next analyze_pattern.  ipcgpu_linsys_shard_stats (after analyze_pattern):
+   out2[0] = world size, out2[1] = the share of the factorisation flops that lies above the cut (executed once each, on the chain of the cut's levels). */
 int ipcgpu_linsys_set_shard(ipcgpu_ctx*, int rank, int world_size);
 int ipcgpu_linsys_shard_stats(ipcgpu_ctx*, double* out2);
+/* out4 = bytes THIS rank sent, bytes it received point to point through the solver's exchange hook so far, number of collective / group calls, 0 */
+int ipcgpu_linsys_exchange_stats(ipcgpu_ctx*, double* out4);
 /* Owner-computes sharding (round 4; SURVEY.md 8e, the north star's "RCCL all-reduce of the shared-node gradient / Hessian rows"): a context that has BOTH
    ipcgpu_ctx_set_shard and ipcgpu_linsys_set_shard (same world) assembles, per rank, exactly the CSR rows its fronts read -- the rows of the nodes its
    subtrees eliminate plus the separator rows above the cut, which every rank repeats (elements and contact stencils on a cut are evaluated by both sides) --
@@ -420,6 +423,24 @@ int ipcgpu_opt_set_allreduce(ipcgpu_ctx*, ipcgpu_allreduce_fn fn, void* user);
  * (libipcgpu_rccl.so: ipcgpu_rccl_unique_id / ipcgpu_rccl_attach); takes precedence over ipcgpu_opt_set_allreduce. */
 typedef int (*ipcgpu_allreduce_stream_fn)(void* user, void* buf_dev, long long count, int op, void* hip_stream);
 int ipcgpu_opt_set_allreduce_stream(ipcgpu_ctx*, ipcgpu_allreduce_stream_fn fn, void* user);
+/* Point-to-point exchange of the sharded direct solver (round 5; ipcgpu_linsys_set_shard).  A front above the cut of the assembly tree is executed by
+ * ONE rank; the packed update matrix of a child that another rank computed (factorisation), its update vector (forward sweep) and the solution entries
+ * of an ancestor (backward sweep) go from the rank that has them to exactly the ranks that need them.  One call = ONE group of operations between which
+ * no order may be assumed (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd; torch.distributed.batch_isend_irecv): op i moves `count` doubles of the
+ * device buffer `buf_dev` to (send = 1) or from (send = 0) rank `peer`; several operations between one pair of ranks match in the order given.
+ * Host-ordered variant: the library drains its stream before the call and expects the data in place when it returns.  Stream variant: the hook
+ * enqueues on the stream it is handed (include/adapters/ipcgpu_rccl.cpp); takes precedence.  Set one of them before ipcgpu_linsys_set_shard with
+ * world_size > 1.  (The all-reduce hooks above stay in use for scalars, the nodal gradient, the pivot flag and the solution vector.) */
+typedef struct ipcgpu_p2p_op {
+    void* buf_dev;
+    long long count;
+    int peer;
+    int send;
+} ipcgpu_p2p_op;
+typedef int (*ipcgpu_exchange_fn)(void* user, int n_ops, const ipcgpu_p2p_op* ops);
+typedef int (*ipcgpu_exchange_stream_fn)(void* user, int n_ops, const ipcgpu_p2p_op* ops, void* hip_stream);
+int ipcgpu_opt_set_exchange(ipcgpu_ctx*, ipcgpu_exchange_fn fn, void* user);
+int ipcgpu_opt_set_exchange_stream(ipcgpu_ctx*, ipcgpu_exchange_stream_fn fn, void* user);
 int ipcgpu_ctx_get_stream(ipcgpu_ctx*, void** hip_stream);
 
 /* ---- measurement -------------------------------------------------------------------- */

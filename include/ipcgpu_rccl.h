@@ -7,11 +7,13 @@
  *     char id[IPCGPU_RCCL_ID_BYTES];
  *     if (rank == 0) ipcgpu_rccl_unique_id(id);
  *     bcast(id);                                    // the caller's bootstrap
- *     ipcgpu_rccl_attach(ctx, rank, world, id);     // ncclCommInitRank + ipcgpu_opt_set_allreduce_stream
+ *     ipcgpu_rccl_attach(ctx, rank, world, id);     // ncclCommInitRank + ipcgpu_opt_set_allreduce_stream + ipcgpu_opt_set_exchange_stream
  *     ipcgpu_linsys_set_shard(ctx, rank, world);    // and / or ipcgpu_ctx_set_shard
  *
- * From then on every exchange of the library (update matrices of the sharded Cholesky, shared-row gradient / Hessian values,
- * energies, step bounds) is one ncclAllReduce enqueued on the context's own HIP stream: no Python, no host synchronisation.
+ * From then on every exchange of the library is enqueued on the context's own HIP stream, no Python, no host synchronisation: the nodal gradient,
+ * energies, step bounds, the pivot flag and the solution vector as ncclAllReduce; the update matrices / vectors of the sharded Cholesky and the
+ * solution entries of the separators above the cut as ONE group of ncclSend / ncclRecv per level of the cut (round 5: point to point to the ranks
+ * that need them -- xGMI links every pair of GPUs of a node directly).
  * Source: include/adapters/ipcgpu_rccl.cpp (links -lrccl -lipcgpu), built by ipc_amd/build.py into ipc_amd/libipcgpu_rccl.so.
  */
 #ifndef IPCGPU_RCCL_H
@@ -32,6 +34,9 @@ int ipcgpu_rccl_detach(ipcgpu_ctx* ctx);
 /* all-reduces `count` doubles of a scratch device buffer filled with (rank + 1) through the installed hook and returns element 0:
  * world * (world + 1) / 2 for op 0 (sum), 1 for op 1 (min).  A smoke test of the binding. */
 int ipcgpu_rccl_selftest(ipcgpu_ctx* ctx, int rank, long long count, int op, double* result);
+/* ring shift of `count` doubles filled with (rank + 1) through the point-to-point hook (ncclSend / ncclRecv in one group): returns what arrived from
+ * rank - 1 (mod world), i.e. ((rank - 1 + world) % world) + 1. */
+int ipcgpu_rccl_selftest_p2p(ipcgpu_ctx* ctx, int rank, int world, long long count, double* result);
 const char* ipcgpu_rccl_last_error(void);
 #ifdef __cplusplus
 }

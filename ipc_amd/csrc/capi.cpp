@@ -630,6 +630,7 @@ int ipcgpu_linsys_set_shard(ipcgpu_ctx* c, int rank, int world)
     return guarded([&] {
         needArg(c && world >= 1 && rank >= 0 && rank < world, "bad shard");
         need(world == 1 || c->opt->allreduce != nullptr || c->opt->allreduceStream != nullptr, "set the all-reduce hook first (ipcgpu_opt_set_allreduce)");
+        need(world == 1 || c->lin->hasExchangeHook(), "set the exchange hook first (ipcgpu_opt_set_exchange / ipcgpu_opt_set_exchange_stream): the sharded solver sends point to point");
         c->lin->setShard(rank, world, c->opt->allreduce, c->opt->allreduceUser, c->opt->allreduceStream, c->opt->allreduceStreamUser);
         return IPCGPU_OK;
     });
@@ -653,6 +654,17 @@ int ipcgpu_opt_complete_matrix(ipcgpu_ctx* c)
     return guarded([&] {
         bind(c);
         O(c).completeMatrix();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_exchange_stats(ipcgpu_ctx* c, double* out4)
+{
+    return guarded([&] {
+        needArg(c && out4, "null argument");
+        out4[0] = (double)L(c).sentBytes();
+        out4[1] = (double)L(c).receivedBytes();
+        out4[2] = (double)L(c).exchangeCalls();
+        out4[3] = 0.0;
         return IPCGPU_OK;
     });
 }
@@ -1554,6 +1566,29 @@ int ipcgpu_opt_set_allreduce_stream(ipcgpu_ctx* c, ipcgpu_allreduce_stream_fn fn
         c->opt->allreduceStream = fn;
         c->opt->allreduceStreamUser = user; // its own slot: a host hook set earlier keeps its user pointer; detaching (fn = NULL) leaves that hook in charge
         c->lin->setHooks(c->opt->allreduce, c->opt->allreduceUser, c->opt->allreduceStream, c->opt->allreduceStreamUser);
+        return IPCGPU_OK;
+    });
+}
+static_assert(sizeof(ipcgpu_p2p_op) == sizeof(MfNumeric::P2POp), "ipcgpu_p2p_op and MfNumeric::P2POp must be one layout");
+int ipcgpu_opt_set_exchange(ipcgpu_ctx* c, ipcgpu_exchange_fn fn, void* user)
+{
+    return guarded([&] {
+        needArg(c != nullptr, "null context");
+        c->exchange = reinterpret_cast<void*>(fn);
+        c->exchangeUser = user;
+        c->lin->setExchangeHooks(reinterpret_cast<MfNumeric::ExchangeFn>(c->exchange), c->exchangeUser, reinterpret_cast<MfNumeric::ExchangeStreamFn>(c->exchangeStream),
+            c->exchangeStreamUser);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_opt_set_exchange_stream(ipcgpu_ctx* c, ipcgpu_exchange_stream_fn fn, void* user)
+{
+    return guarded([&] {
+        needArg(c != nullptr, "null context");
+        c->exchangeStream = reinterpret_cast<void*>(fn);
+        c->exchangeStreamUser = user;
+        c->lin->setExchangeHooks(reinterpret_cast<MfNumeric::ExchangeFn>(c->exchange), c->exchangeUser, reinterpret_cast<MfNumeric::ExchangeStreamFn>(c->exchangeStream),
+            c->exchangeStreamUser);
         return IPCGPU_OK;
     });
 }

@@ -97,10 +97,14 @@ public:
         analyzed_ = false;
     }
     void setHooks(ipcgpu_allreduce_fn_t fn, void* user, ipcgpu_allreduce_stream_fn_t sfn, void* streamUser) { num_.setHooks(fn, user, sfn, streamUser); }
+    void setExchangeHooks(MfNumeric::ExchangeFn fn, void* user, MfNumeric::ExchangeStreamFn sfn, void* streamUser) { num_.setExchangeHooks(fn, user, sfn, streamUser); }
+    bool hasExchangeHook() const { return num_.hasExchangeHook(); }
     int solverWorld() const { return num_.world(); }
     void nodeOwners(std::vector<int>& o) const { num_.nodeOwners(o); }
     long long exchangedBytes() const { return num_.exchangedBytes(); }
     long long exchangeCalls() const { return num_.exchangeCalls(); }
+    long long sentBytes() const { return num_.sentBytes(); }
+    long long receivedBytes() const { return num_.receivedBytes(); }
     int analysisVersion = 0; // bumped by every analyze_pattern (the owner-computes plan of the assembly follows the solver's cut)
     double sharedFlopFraction() const { return num_.sharedFlopFraction(); }
     bool analyzed() const { return analyzed_; }
@@ -328,4 +332,9 @@ struct ipcgpu_ctx {
     std::unique_ptr<ipcgpu::HipOptimizer> opt;
     std::unique_ptr<ipcgpu::HipContact> contact;
     int rank = 0, worldSize = 1;
+    // point-to-point exchange hooks of the sharded solver (ipcgpu_opt_set_exchange[_stream]); stored here as opaque pointers of the C ABI's types
+    void* exchange = nullptr;
+    void* exchangeUser = nullptr;
+    void* exchangeStream = nullptr;
+    void* exchangeStreamUser = nullptr;
 };

@@ -15,17 +15,37 @@ public:
 
     void setup(const MfSymbolic& sym, hipStream_t stream); // uploads maps, allocates fronts
     // Multi-GPU (one process per GPU): the assembly tree is cut below its top separators, every rank factorises and solves the
-    // subtrees it owns and all ranks repeat the fronts above the cut; the update matrices / update vectors of the subtree roots
-    // and the final solution cross ranks through `allreduce` (sum, in place, on a device buffer).  Call before setup().
+    // subtrees it owns.  Round 5: a front above the cut is executed by ONE rank (the executor of its most expensive child, mf_assign_executors) instead
+    // of being repeated by all of them, and what a parent on another rank needs -- the packed update matrix of a child in the factorisation, its update
+    // vector in the forward sweep, the solution entries of an ancestor in the backward sweep -- travels POINT TO POINT to exactly the ranks that
+    // need it (`exchange`: one group of sends / receives per level of the cut; ncclSend / ncclRecv between ncclGroupStart / End in the RCCL binding).
+    // Two all-reduces remain: the pivot flag (one double per factorisation) and the solution every rank ends up with (3 nV doubles per solve,
+    // every entry contributed by its executor).  Call before setup().
     typedef int (*AllreduceFn)(void* user, void* buf_dev, long long count, int op);
     // stream-ordered variant (ipcgpu_opt_set_allreduce_stream): enqueued on the solver's stream, no host synchronisation around it
     typedef int (*AllreduceStreamFn)(void* user, void* buf_dev, long long count, int op, void* hipStream);
+    struct P2POp { // == ipcgpu_p2p_op (include/ipcgpu.h)
+        void* buf_dev;
+        long long count;
+        int peer;
+        int send;
+    };
+    typedef int (*ExchangeFn)(void* user, int nOps, const P2POp* ops); // host-ordered: the solver drains its stream first
+    typedef int (*ExchangeStreamFn)(void* user, int nOps, const P2POp* ops, void* hipStream); // enqueued on the solver's stream
     void setShard(int rank, int world, AllreduceFn fn, void* user, AllreduceStreamFn sfn = nullptr, void* streamUser = nullptr)
     {
         rank_ = rank;
         world_ = world;
         setHooks(fn, user, sfn, streamUser);
     }
+    void setExchangeHooks(ExchangeFn fn, void* user, ExchangeStreamFn sfn, void* streamUser)
+    {
+        exchange_ = fn;
+        exchangeUser_ = user;
+        exchangeStream_ = sfn;
+        exchangeStreamUser_ = streamUser;
+    }
+    bool hasExchangeHook() const { return exchange_ || exchangeStream_; }
     // the hooks alone (the caller attached or detached a communicator after the solver was sharded): nothing to re-analyse
     void setHooks(AllreduceFn fn, void* user, AllreduceStreamFn sfn, void* streamUser)
     {
@@ -35,12 +55,15 @@ public:
         allreduceStreamUser_ = streamUser;
     }
     int world() const { return world_; }
-    // per node of the CALLER's numbering: the rank whose subtree eliminates it, -1 above the cut (every rank repeats those fronts); all -1 on one rank.
+    // per node of the CALLER's numbering: the rank whose subtree eliminates it, -1 above the cut (the rows of those nodes are assembled by every rank: a
+    // subtree's fronts read entries of the separator rows above them); all -1 on one rank.
     // What the owner-computes sharding of the assembly needs: a rank assembles the CSR rows of the nodes it owns or shares.
     void nodeOwners(std::vector<int>& ownerOfNode) const;
-    long long exchangedBytes() const { return commBytes_; } // all-reduced by the factorisations / solves so far (update matrices, update vectors, solutions, flags)
+    long long exchangedBytes() const { return commBytes_; } // bytes THIS rank sent + received point to point + the buffers it all-reduced, factorisations and solves so far
     long long exchangeCalls() const { return commCalls_; }
-    double sharedFlopFraction() const { return sharedFlops_; } // share of the factorisation flops every rank repeats
+    long long sentBytes() const { return sentBytes_; }
+    long long receivedBytes() const { return recvBytes_; }
+    double sharedFlopFraction() const { return sharedFlops_; } // share of the factorisation flops above the cut (executed once each since round 5, on the chain of the cut's levels)
     // a_dev: CSR values (device).  Returns false when a non-positive pivot was met.
     bool factorize(const double* a_dev);
     // rhs_dev / x_dev: device vectors in the user's ordering
@@ -85,20 +108,27 @@ private:
     void* allreduceUser_ = nullptr;
     void* allreduceStreamUser_ = nullptr; // its own slot: attaching RCCL after a host hook must not replace that hook's user pointer
     double sharedFlops_ = 0.0;
-    bool flagShared_ = false; // the update exchanges carry the pivot flag
-    std::vector<int> owner_; // per front: owning rank, -1 = above the cut (repeated by every rank)
-    long long commBytes_ = 0, commCalls_ = 0;
+    ExchangeFn exchange_ = nullptr;
+    ExchangeStreamFn exchangeStream_ = nullptr;
+    void* exchangeUser_ = nullptr;
+    void* exchangeStreamUser_ = nullptr;
+    std::vector<int> owner_; // per front: owning rank, -1 = above the cut
+    std::vector<int> exec_; // per front: the rank that factorises and solves it (== owner_ below the cut)
+    std::vector<unsigned long long> group_; // per front: ranks that execute a front of its subtree
+    long long commBytes_ = 0, commCalls_ = 0, sentBytes_ = 0, recvBytes_ = 0;
     struct Xchg {
-        Range pack; // into xchgDesc_: (front, staging offset lo, hi, 0) of the subtree roots of this level
+        Range pack; // into xchgDesc_: (front, staging offset lo, hi, offset of its update vector) of the fronts of this level this rank SENDS to their parent's rank
+        Range unpack; // ... and of the children (of this level) of fronts this rank executes that it RECEIVES
+        std::vector<P2POp> opsM, opsW, opsX; // the level's groups: update matrices (factorisation), update vectors (forward sweep), solution segments (backward sweep)
         long long count = 0; // doubles exchanged after the level's factorisation (update matrices)
         long long countW = 0; // ... and after its forward sweep (update vectors)
     };
     std::vector<Xchg> xchg_;
     DevBuf<int4> xchgDesc_;
     DevBuf<double> xchgBuf_;
-    DevBuf<int> nodeOwner_; // per permuted node: owning rank or -1
-    DevBuf<int> ownerDev_; // owner_ on the device
+    DevBuf<int> nodeExec_; // per permuted node: executing rank
     void allreduceSum(double* dev, long long count);
+    void exchange(const std::vector<P2POp>& ops);
     const MfSymbolic* sym_ = nullptr;
     hipStream_t stream_ = nullptr;
     int ns_ = 0, nLevels_ = 0;

@@ -1620,33 +1620,31 @@ __global__ __launch_bounds__(WGT) void k_big_bwd_tri(const int* __restrict__ lis
 }
 
 // ---- subtree-sharded factorisation: what crosses ranks -----------------------------------------------------------------------
-// desc = (front, staging offset lo, hi, mode).  The update block of a subtree root (its lower triangle, packed: m (m + 1) / 2 doubles in the
-// staging buffer, m = N - nc) is packed by its owner, summed over the ranks (everybody else holds zeros), and
-// unpacked into the same front on every rank: the fronts above the cut then find their children's contributions in place.
+// desc = (front, staging offset lo, hi, offset of the update vector).  The update block of a front whose parent is executed by another rank (its lower
+// triangle, packed: m (m + 1) / 2 doubles in the staging buffer, m = N - nc) is packed by the rank that computed it, sent to the parent's rank
+// (MfNumeric::exchange: point to point) and unpacked there into the same front: the parent's extend-add then finds its child's contribution in place.
 __global__ __launch_bounds__(256) void k_xchg_update(const int4* __restrict__ desc, TreeView tv, double* __restrict__ fronts, double* __restrict__ buf,
-    int unpack, int rank, const int* __restrict__ owner)
+    int unpack)
 {
     const int4 d = desc[blockIdx.y];
     const int s = d.x;
-    if (!unpack && owner[s] != rank) return;
     const int N = frontN(tv, s), nc = frontNc(tv, s), m = N - nc;
     double* F = fronts + tv.frontOff[s];
     double* B = buf + (((long long)(unsigned)d.z << 32) | (unsigned)d.y);
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < (long long)m * m; e += (long long)gridDim.x * 256) {
         const int j = (int)(e / m), i = (int)(e - (long long)j * m);
         if (i < j) continue;
-        const long long t = (long long)j * m - (long long)j * (j - 1) / 2 + (i - j); // packed lower triangle, column by column (round 4: half the bytes on the wire)
+        const long long t = (long long)j * m - (long long)j * (j - 1) / 2 + (i - j); // packed lower triangle, column by column
         if (unpack) F[(nc + i) + (long long)N * (nc + j)] = B[t];
         else B[t] = F[(nc + i) + (long long)N * (nc + j)];
     }
 }
 // the same for the update vectors of the forward sweep (rows >= nc of the front's work vector)
 __global__ __launch_bounds__(256) void k_xchg_w(const int4* __restrict__ desc, TreeView tv, const long long* __restrict__ wOff, double* __restrict__ wbuf,
-    double* __restrict__ buf, int unpack, int rank, const int* __restrict__ owner)
+    double* __restrict__ buf, int unpack)
 {
     const int4 d = desc[blockIdx.y];
     const int s = d.x;
-    if (!unpack && owner[s] != rank) return;
     const int N = frontN(tv, s), nc = frontNc(tv, s), m = N - nc;
     double* w = wbuf + wOff[s] + nc;
     double* B = buf + d.w;
@@ -1655,13 +1653,12 @@ __global__ __launch_bounds__(256) void k_xchg_w(const int4* __restrict__ desc, T
         else B[i] = w[i];
     }
 }
-// the solution: every rank keeps the entries of the nodes it owns (rank 0 also the ones above the cut), zeros elsewhere; the sum is x
-__global__ void k_mask_xsol(int nn, const int* __restrict__ nodeOwner, int rank, double* __restrict__ xsol)
+// the solution: every rank keeps the entries of the fronts it executed, zeros elsewhere; the sum over the ranks is x
+__global__ void k_mask_xsol(int nn, const int* __restrict__ nodeExec, int rank, double* __restrict__ xsol)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 3 * nn) return;
-    const int o = nodeOwner[i / 3];
-    if (!(o == rank || (o < 0 && rank == 0))) xsol[i] = 0.0;
+    if (nodeExec[i / 3] != rank) xsol[i] = 0.0;
 }
 __global__ void k_flag_to_double(const int* __restrict__ flag, double* __restrict__ buf) { buf[0] = flag[0] ? 1.0 : 0.0; }
 __global__ void k_double_to_flag(const double* __restrict__ buf, int* __restrict__ flag) { flag[0] = (flag[0] || buf[0] > 0.0) ? 1 : 0; }
@@ -2000,43 +1997,49 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     auto hasBorder = [&](int s) { return xinvBorder_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; };
     // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
     owner_.assign(ns_, rank_);
+    exec_.assign(ns_, rank_);
     sharedFlops_ = 0.0;
     if (world_ > 1) {
+        if (world_ > 64) throw StateError("the sharded solver supports at most 64 ranks");
         sharedFlops_ = mf_assign_owners(sym, world_, owner_); // host logic, shared with the CPU tests of the protocol (mf_symbolic.cpp)
-        // exchange lists: subtree roots whose parent is above the cut, by level
+        mf_assign_executors(sym, owner_, exec_, group_);
+        // exchange lists, by level (mf_exchange_plan: fronts whose parent another rank executes, solution segments of the fronts above the cut).  Every
+        // rank computes the same staging layout; it packs what it sends and unpacks what it receives.
+        std::vector<MfExchangeLevel> plan;
+        mf_exchange_plan(sym, owner_, exec_, group_, rank_, world_, plan);
         xchg_.assign(nLevels_, Xchg());
         std::vector<int4> xd;
         long long maxCount = 1;
+        for (const MfExchangeLevel& E : plan) maxCount = std::max(maxCount, E.count + E.countW);
+        xchgBuf_.ensure((size_t)maxCount + 1);
         for (int l = 0; l < nLevels_; ++l) {
             Xchg& X = xchg_[l];
-            X.pack.off = (int)xd.size();
-            long long off = 0;
-            int offW = 0;
-            for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
-                const int s = sym.levelFronts[i];
-                if (owner_[s] < 0 || sym.parent[s] < 0 || owner_[sym.parent[s]] >= 0) continue;
-                const long long m = sym.N(s) - sym.nc(s);
-                xd.push_back(make_int4(s, (int)(unsigned)(off & 0xffffffffLL), (int)(off >> 32), offW));
-                off += m * (m + 1) / 2;
-                offW += (int)m;
-            }
-            X.pack.cnt = (int)xd.size() - X.pack.off;
-            X.count = off;
-            X.countW = offW;
-            maxCount = std::max(maxCount, off);
+            const MfExchangeLevel& E = plan[l];
+            X.count = E.count;
+            X.countW = E.countW;
+            auto emit = [&](const std::vector<MfExchangeItem>& items, Range& R, int sendFlag) {
+                R.off = (int)xd.size();
+                for (const MfExchangeItem& it : items) {
+                    xd.push_back(make_int4(it.front, (int)(unsigned)(it.off & 0xffffffffLL), (int)(it.off >> 32), (int)(E.count + it.offW))); // vectors sit behind the matrices
+                    const long long m = sym.N(it.front) - sym.nc(it.front);
+                    X.opsM.push_back(P2POp{ xchgBuf_.p + it.off, m * (m + 1) / 2, it.peer, sendFlag });
+                    X.opsW.push_back(P2POp{ xchgBuf_.p + E.count + it.offW, m, it.peer, sendFlag });
+                }
+                R.cnt = (int)xd.size() - R.off;
+            };
+            emit(E.send, X.pack, 1);
+            emit(E.recv, X.unpack, 0);
+            for (const MfExchangeItem& it : E.xsSend) X.opsX.push_back(P2POp{ xsol_.p + 3 * (long long)sym.firstNode[it.front], (long long)sym.nc(it.front), it.peer, 1 });
+            for (const MfExchangeItem& it : E.xsRecv) X.opsX.push_back(P2POp{ xsol_.p + 3 * (long long)sym.firstNode[it.front], (long long)sym.nc(it.front), it.peer, 0 });
         }
         if (xd.empty()) xd.push_back(make_int4(0, 0, 0, 0));
         xchgDesc_.upload(xd.data(), xd.size(), stream);
-        xchgBuf_.ensure((size_t)maxCount + 1);
-        flagShared_ = false;
-        for (const Xchg& X : xchg_) flagShared_ |= X.pack.cnt > 0;
-        std::vector<int> no(std::max(sym.nn, 1), -1);
+        std::vector<int> ne(std::max(sym.nn, 1), 0);
         for (int s = 0; s < ns_; ++s)
-            for (int v = sym.firstNode[s]; v < sym.firstNode[s + 1]; ++v) no[v] = owner_[s];
-        nodeOwner_.upload(no, stream);
-        ownerDev_.upload(owner_, stream);
+            for (int v = sym.firstNode[s]; v < sym.firstNode[s + 1]; ++v) ne[v] = exec_[s];
+        nodeExec_.upload(ne, stream);
     }
-    auto mine = [&](int s) { return world_ == 1 || owner_[s] < 0 || owner_[s] == rank_; };
+    auto mine = [&](int s) { return world_ == 1 || exec_[s] == rank_; };
     // entries of A grouped by owning front: (source index, offset inside the LDS panel) for the fused fronts,
     // (source index, offset in the front buffer) per level for the others.  A parallel counting sort on a few host threads,
     // written straight into pinned staging buffers (grow-only, like the device buffers they are copied to): this runs on
@@ -2531,6 +2534,23 @@ void MfNumeric::allreduceSum(double* dev, long long count)
     if (allreduce_(allreduceUser_, dev, count, 0) != 0) throw HipError("all-reduce hook failed");
 }
 
+void MfNumeric::exchange(const std::vector<P2POp>& ops)
+{
+    if (world_ <= 1 || ops.empty()) return;
+    for (const P2POp& o : ops) {
+        (o.send ? sentBytes_ : recvBytes_) += 8 * o.count;
+        commBytes_ += 8 * o.count;
+    }
+    commCalls_++;
+    if (exchangeStream_) { // stream-ordered (ncclSend / ncclRecv in one group on this stream): nothing to wait for on the host
+        if (exchangeStream_(exchangeStreamUser_, (int)ops.size(), ops.data(), (void*)stream_) != 0) throw HipError("exchange hook failed");
+        return;
+    }
+    if (!exchange_) throw StateError("sharded solver without an exchange hook (ipcgpu_opt_set_exchange / ipcgpu_opt_set_exchange_stream)");
+    HIP_CHECK(hipStreamSynchronize(stream_)); // the hook works on the caller's stream: ours has to be drained first
+    if (exchange_(exchangeUser_, (int)ops.size(), ops.data()) != 0) throw HipError("exchange hook failed");
+}
+
 MfNumeric::~MfNumeric()
 {
     if (side_) (void)hipStreamSynchronize(side_);
@@ -2633,19 +2653,15 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
             else if (P.schur64) hipLaunchKernelGGL(k_big_schur64, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
             else hipLaunchKernelGGL(k_big_schur, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, fronts_.p);
         }
-        if (world_ > 1 && xchg_[l].pack.cnt) {
-            // the update matrices of the subtree roots of this level: packed by their owners, summed, unpacked everywhere
-            // (the pivot flag of this rank rides along in one extra double: a bad pivot inside a subtree reaches every rank
-            // with the exchange that follows it, the fronts above the cut are repeated and seen by all anyway)
+        if (world_ > 1 && !xchg_[l].opsM.empty()) {
+            // update matrices of this level whose parent another rank executes: packed by the rank that computed them, sent point to point, unpacked into
+            // the same front on the parent's rank (a bad pivot anywhere reaches everybody with the one-double all-reduce behind the factorisation)
             const Xchg& X = xchg_[l];
-            xchgBuf_.zeroN((size_t)X.count + 1, stream_);
-            hipLaunchKernelGGL(k_xchg_update, dim3(64, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, fronts_.p, xchgBuf_.p, 0, rank_,
-                ownerDev_.p);
-            hipLaunchKernelGGL(k_flag_to_double, dim3(1), dim3(1), 0, stream_, flag_.p, xchgBuf_.p + X.count);
-            allreduceSum(xchgBuf_.p, X.count + 1);
-            hipLaunchKernelGGL(k_xchg_update, dim3(64, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, fronts_.p, xchgBuf_.p, 1, rank_,
-                ownerDev_.p);
-            hipLaunchKernelGGL(k_double_to_flag, dim3(1), dim3(1), 0, stream_, xchgBuf_.p + X.count, flag_.p);
+            if (X.pack.cnt)
+                hipLaunchKernelGGL(k_xchg_update, dim3(64, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, fronts_.p, xchgBuf_.p, 0);
+            exchange(X.opsM);
+            if (X.unpack.cnt)
+                hipLaunchKernelGGL(k_xchg_update, dim3(64, X.unpack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.unpack.off, tv, fronts_.p, xchgBuf_.p, 1);
         }
         if (xinvLevel_[l].blocks.cnt) {
             // the factor panels and pivot blocks of this level are final: form the triangle inverses of its fronts beside the
@@ -2721,14 +2737,11 @@ void MfNumeric::enqueueSolve(const double* rhs_dev, double* x_dev)
         const LevelPlan& P = plan_[l];
         if (P.xinvFwd.cnt && sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evInvDone_[l], 0));
         enqueueForwardLevel(l, stream_);
-        if (world_ > 1 && xchg_[l].pack.cnt) { // update vectors of the subtree roots of this level -> every rank
+        if (world_ > 1 && !xchg_[l].opsW.empty()) { // update vectors of this level's fronts -> the rank that executes their parent
             const Xchg& X = xchg_[l];
-            xchgBuf_.zeroN((size_t)X.countW, stream_);
-            hipLaunchKernelGGL(k_xchg_w, dim3(4, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, wOff_.p, w_.p, xchgBuf_.p, 0, rank_,
-                ownerDev_.p);
-            allreduceSum(xchgBuf_.p, X.countW);
-            hipLaunchKernelGGL(k_xchg_w, dim3(4, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, wOff_.p, w_.p, xchgBuf_.p, 1, rank_,
-                ownerDev_.p);
+            if (X.pack.cnt) hipLaunchKernelGGL(k_xchg_w, dim3(4, X.pack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.pack.off, tv, wOff_.p, w_.p, xchgBuf_.p, 0);
+            exchange(X.opsW);
+            if (X.unpack.cnt) hipLaunchKernelGGL(k_xchg_w, dim3(4, X.unpack.cnt), dim3(256), 0, stream_, xchgDesc_.p + X.unpack.off, tv, wOff_.p, w_.p, xchgBuf_.p, 1);
         }
     }
     enqueueBackward(x_dev);
@@ -2771,9 +2784,10 @@ void MfNumeric::enqueueBackward(double* x_dev)
         if (P.small.cnt)
             hipLaunchKernelGGL(k_bwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
                 yperm_.p, xsol_.p);
+        if (world_ > 1) exchange(xchg_[l].opsX); // solution entries of this level's fronts above the cut -> the ranks that execute fronts below them
     }
-    if (world_ > 1) { // every rank holds the solution of its own subtrees (and of the fronts above the cut): sum of the masked parts
-        hipLaunchKernelGGL(k_mask_xsol, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, nodeOwner_.p, rank_, xsol_.p);
+    if (world_ > 1) { // every rank holds the solution of the fronts it executed (and of their ancestors): sum of the masked parts
+        hipLaunchKernelGGL(k_mask_xsol, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, nodeExec_.p, rank_, xsol_.p);
         allreduceSum(xsol_.p, n3);
     }
     hipLaunchKernelGGL(k_unpermute_x, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, xsol_.p, x_dev);

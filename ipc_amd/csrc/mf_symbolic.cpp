@@ -674,6 +674,65 @@ double mf_assign_owners(const MfSymbolic& sym, int world, std::vector<int>& owne
     return tot > 0 ? sh / tot : 0.0;
 }
 
+void mf_assign_executors(const MfSymbolic& sym, const std::vector<int>& owner, std::vector<int>& exec, std::vector<unsigned long long>& group)
+{
+    const int ns = sym.ns;
+    exec.assign(ns, 0);
+    group.assign(ns, 0ull);
+    std::vector<double> cost(ns, 0.0);
+    for (int s = 0; s < ns; ++s) { // children precede their parent in the elimination order
+        const double N = sym.N(s), nc = sym.nc(s);
+        for (int j = 0; j < (int)nc; ++j) cost[s] += (N - j - 1) * (N - j - 1);
+        if (owner[s] >= 0) exec[s] = owner[s];
+        else {
+            int best = -1;
+            for (int q = sym.childPtr[s]; q < sym.childPtr[s + 1]; ++q) {
+                const int c = sym.child[q];
+                if (best < 0 || cost[c] > cost[best]) best = c;
+            }
+            exec[s] = best >= 0 ? exec[best] : 0; // (a front above the cut always has children: only opened fronts are shared)
+        }
+        for (int q = sym.childPtr[s]; q < sym.childPtr[s + 1]; ++q) {
+            const int c = sym.child[q];
+            cost[s] += cost[c];
+            group[s] |= group[c];
+        }
+        group[s] |= 1ull << exec[s];
+    }
+}
+
+void mf_exchange_plan(const MfSymbolic& sym, const std::vector<int>& owner, const std::vector<int>& exec, const std::vector<unsigned long long>& group, int rank,
+    int world, std::vector<MfExchangeLevel>& plan)
+{
+    const int nLevels = (int)sym.levelPtr.size() - 1;
+    plan.assign(nLevels, MfExchangeLevel());
+    for (int l = 0; l < nLevels; ++l) {
+        MfExchangeLevel& X = plan[l];
+        long long off = 0;
+        int offW = 0;
+        for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
+            const int s = sym.levelFronts[i];
+            const int p = sym.parent[s];
+            if (p >= 0 && exec[p] != exec[s]) {
+                const long long m = sym.N(s) - sym.nc(s);
+                if (exec[s] == rank) X.send.push_back(MfExchangeItem{ s, off, offW, exec[p] });
+                if (exec[p] == rank) X.recv.push_back(MfExchangeItem{ s, off, offW, exec[s] });
+                off += m * (m + 1) / 2;
+                offW += (int)m;
+            }
+            if (owner[s] < 0) { // above the cut: its solution entries go to the ranks that execute fronts below it
+                if (exec[s] == rank) {
+                    for (int r = 0; r < world; ++r)
+                        if (r != rank && (group[s] >> r & 1ull)) X.xsSend.push_back(MfExchangeItem{ s, 0, 0, r });
+                }
+                else if (group[s] >> rank & 1ull) X.xsRecv.push_back(MfExchangeItem{ s, 0, 0, exec[s] });
+            }
+        }
+        X.count = off;
+        X.countW = offW;
+    }
+}
+
 void mf_L_pattern_csr(const MfSymbolic& sym, std::vector<int>& ptrT, std::vector<int>& indT, std::vector<int>& pivQ)
 {
     const int n = sym.n;

@@ -43,6 +43,30 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
 // the opened fronts above the cut are shared (owner -1: every rank factorises them redundantly from exchanged update matrices).  Returns the share of the
 // factorisation flops above the cut.  world <= 1: every front owned by rank 0.
 double mf_assign_owners(const MfSymbolic& sym, int world, std::vector<int>& owner);
+// Round 5: the fronts above the cut are no longer repeated by every rank -- each is EXECUTED by one rank, the executor of the child with the most expensive
+// subtree (ties: the first child), so the update matrix of that child never travels and the other children's go point to point to the one rank that
+// needs them.  exec[s] = owner[s] below the cut.  group[s] (bit r set: rank r executes a front of the subtree of s; world <= 64) tells who needs the
+// solution entries of s in the backward sweep.
+void mf_assign_executors(const MfSymbolic& sym, const std::vector<int>& owner, std::vector<int>& exec, std::vector<unsigned long long>& group);
+// What rank `rank` sends and receives, level by level (host logic of MfNumeric's exchanges, shared with the CPU tests of the protocol):
+//   send / recv: fronts of the level whose parent another rank executes -- `off` = offset of the packed update matrix (m (m + 1) / 2 doubles, m = N - nc)
+//                in the level's staging area, `offW` = offset of the update vector (m doubles) in the vector area behind it; every rank computes the
+//                same layout.  After the level's factorisation the matrices travel, after its forward sweep the vectors.
+//   xs:          after the level's backward sweep: the solution entries (nc doubles at 3 firstNode) of a front above the cut go from its executor
+//                to every other rank of its group.
+struct MfExchangeItem {
+    int front;
+    long long off;
+    int offW;
+    int peer;
+};
+struct MfExchangeLevel {
+    std::vector<MfExchangeItem> send, recv, xsSend, xsRecv;
+    long long count = 0; // doubles of the matrix area
+    int countW = 0; // doubles of the vector area
+};
+void mf_exchange_plan(const MfSymbolic& sym, const std::vector<int>& owner, const std::vector<int>& exec, const std::vector<unsigned long long>& group, int rank,
+    int world, std::vector<MfExchangeLevel>& plan);
 
 // scalar CSR pattern of L (lower triangle incl. diagonal, rows sorted) in the permuted ordering plus the
 // scalar permutation pivQ (new -> old) -- what rocsolver_dcsrrf_analysis expects as T and pivQ.

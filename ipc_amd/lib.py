@@ -28,6 +28,13 @@ SOLVER_ROCSOLVER_CSRRF = 1
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int)
 
 
+class P2POp(C.Structure):  # ipcgpu_p2p_op
+    _fields_ = [("buf_dev", C.c_void_p), ("count", C.c_longlong), ("peer", C.c_int), ("send", C.c_int)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(P2POp))
+
+
 class IpcGpuError(RuntimeError):
     pass
 
@@ -180,6 +187,24 @@ class Context:
         """subtree-sharded factorisation / solves (ipcgpu_linsys_set_shard); call after set_allreduce"""
         self._chk(self._L.ipcgpu_linsys_set_shard(self.h, C.c_int(rank), C.c_int(world)))
 
+    def set_exchange(self, pyfunc):
+        """the point-to-point hook of the sharded solver (ipcgpu_opt_set_exchange, host-ordered): pyfunc(ops) with ops = [(dev_ptr, count, peer, send), ...],
+        ONE group -- no order between the operations may be assumed; returns 0."""
+        def tramp(user, n, ops):
+            try:
+                return int(pyfunc([(int(ops[i].buf_dev), int(ops[i].count), int(ops[i].peer), int(ops[i].send)) for i in range(n)]))
+            except Exception as e:  # noqa: BLE001
+                print("exchange hook failed:", e, flush=True)
+                return 1
+        self._xcb = EXCHANGE_FN(tramp)
+        self._chk(self._L.ipcgpu_opt_set_exchange(self.h, self._xcb, None))
+
+    def solver_exchange_stats(self):
+        """bytes this rank sent / received point to point through the solver so far (ipcgpu_linsys_exchange_stats)"""
+        o = np.zeros(4)
+        self._chk(self._L.ipcgpu_linsys_exchange_stats(self.h, _dp(o)))
+        return dict(sent_bytes=int(o[0]), received_bytes=int(o[1]), calls=int(o[2]))
+
     def solver_shard_stats(self):
         o = np.zeros(2)
         self._chk(self._L.ipcgpu_linsys_shard_stats(self.h, _dp(o)))
@@ -213,6 +238,13 @@ class Context:
         if getattr(self, "_rccl_attached", False):
             load_rccl().ipcgpu_rccl_detach(self.h)
             self._rccl_attached = False
+
+    def rccl_selftest_p2p(self, rank, world, count=1024):
+        R = load_rccl()
+        out = C.c_double()
+        if R.ipcgpu_rccl_selftest_p2p(self.h, C.c_int(rank), C.c_int(world), C.c_longlong(count), C.byref(out)) != 0:
+            raise IpcGpuError("ipcgpu_rccl_selftest_p2p: " + R.ipcgpu_rccl_last_error().decode())
+        return out.value
 
     def rccl_selftest(self, rank, count=1024, op=0):
         R = load_rccl()

@@ -38,6 +38,24 @@ if world > 1:
         t.copy_(h)
         torch.cuda.synchronize()
         return 0
+    def xhook(ops):
+        # the solver's point-to-point group (ipcgpu_opt_set_exchange): sends / receives of device buffers, bounced through the host for gloo
+        reqs, recvs = [], []
+        for ptr, count, peer, send in ops:
+            t = torch.as_tensor(DevPtr(ptr, count), device="cuda:0")
+            if send:
+                reqs.append(dist.P2POp(dist.isend, t.cpu(), peer))
+            else:
+                h = torch.empty(count, dtype=torch.float64)
+                recvs.append((t, h))
+                reqs.append(dist.P2POp(dist.irecv, h, peer))
+        for r in dist.batch_isend_irecv(reqs):
+            r.wait()
+        for t, h in recvs:
+            t.copy_(h)
+        torch.cuda.synchronize()
+        return 0
+    c.set_exchange(xhook)
     if mode in ("assembly", "contact_sharded", "owner", "capi_contact"):
         c.set_shard(rank, world)  # the assembly sharded: with the solver sharded as well, owner-computes rows (no matrix value crosses ranks)
     c.set_allreduce(hook)
@@ -113,7 +131,13 @@ if mode.startswith("contact"):
     extra["nPatternChanges"] = c.contact_state()["nPatternChanges"]
 cm = c.comm_stats()
 rows, nnz = c.get_dims()
-extra.update(stepper_bytes=cm["stepper_bytes"], solver_bytes=cm["solver_bytes"], rows_nodes=cm["rows_assembled_nodes"], nodes=cm["nodes"], nnz=nnz)
+xs = c.solver_exchange_stats()
+extra.update(stepper_bytes=cm["stepper_bytes"], solver_bytes=cm["solver_bytes"], rows_nodes=cm["rows_assembled_nodes"], nodes=cm["nodes"], nnz=nnz,
+             solver_sent=xs["sent_bytes"], solver_received=xs["received_bytes"])
+if world > 1:  # what every rank moved through the solver, gathered on rank 0
+    allx = [None] * world
+    dist.all_gather_object(allx, (xs["sent_bytes"], xs["received_bytes"], cm["solver_bytes"]))
+    extra.update(solver_sent_all=np.array([a[0] for a in allx]), solver_received_all=np.array([a[1] for a in allx]), solver_bytes_all=np.array([a[2] for a in allx]))
 if rank == 0:
     np.savez(os.environ["OUT"], V=s["V"], E=s["E"], g=s["gradient"], iters=np.array(iters), **extra)
 c.close()
@@ -225,6 +249,12 @@ def test_owner_computes_rows_no_matrix_value_crosses_ranks(world):
         assert per_iter <= 0.25 * 8 * float(b["nnz"]), (per_iter, 8 * float(b["nnz"]))
         assert 0 < int(b["rows_nodes"]) < int(b["nodes"])  # rank 0 holds its subtrees' rows and the shared separator rows, not all of them
         assert int(a["stepper_bytes"]) == 0 and int(a["solver_bytes"]) == 0
+        # round 5: the solver sends point to point -- every byte sent is received exactly once, and what crosses per Newton iteration (update matrices of
+        # the children another rank computed, their update vectors, the separators' solution entries, + the all-reduced solution vector and pivot flag)
+        # stays below one copy of the CSR values on every rank
+        sent, recv = b["solver_sent_all"].astype(float), b["solver_received_all"].astype(float)
+        assert sent.sum() > 0 and sent.sum() == recv.sum(), (sent, recv)
+        assert (b["solver_bytes_all"].astype(float) / max(its, 1)).max() <= 8 * float(b["nnz"]), (b["solver_bytes_all"] / max(its, 1), 8 * float(b["nnz"]))
 
 
 def test_contact_entry_points_return_whole_sums_on_a_sharded_context():
@@ -251,5 +281,78 @@ def test_rccl_binding_from_c_on_one_rank(gpu_lib):
     assert len(uid) == 128 and any(uid)
     c.rccl_attach(0, 1, uid)
     assert c.rccl_selftest(0, 4096, 0) == 1.0 and c.rccl_selftest(0, 4096, 1) == 1.0
+    assert c.rccl_selftest_p2p(0, 1, 4096) == 1.0  # (world 1: the hook is installed, the shift is a copy)
     c.rccl_detach()
     c.close()
+
+
+RCCL_WORKER = r'''
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["IPC_REPO"])
+import ipc_amd
+from ipc_amd import scene
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dist.init_process_group("gloo", rank=rank, world_size=world)  # bootstrap only: carries the 128 bytes of the unique id
+c = ipc_amd.Context(rank)
+uid = [ipc_amd.Context.rccl_unique_id() if rank == 0 else None]
+dist.broadcast_object_list(uid, 0)
+c.rccl_attach(rank, world, uid[0])
+out = dict(sum=c.rccl_selftest(rank, 1 << 16, 0), min=c.rccl_selftest(rank, 1 << 16, 1), shift=c.rccl_selftest_p2p(rank, world, 1 << 16))
+c.set_shard(rank, world)
+c.set_solver_shard(rank, world)
+V, F = scene.make_mat(40)
+left, right = scene.border_verts(V, 0.01)
+c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+c.set_positions(scene.twist_state(scene.jitter(V, F, rel=2e-2), 0.15))
+c.opt_init(0.025, False)
+c.set_twist(left, right)
+c.precompute()
+iters = [c.solve_timestep(40) for _ in range(2)]
+s = c.state()
+xs, cm = c.solver_exchange_stats(), c.comm_stats()
+allx = [None] * world
+dist.all_gather_object(allx, (xs["sent_bytes"], xs["received_bytes"]))
+if rank == 0:
+    np.savez(os.environ["OUT"], V=s["V"], E=s["E"], iters=np.array(iters), sent=np.array([a[0] for a in allx]), received=np.array([a[1] for a in allx]),
+             shared=c.solver_shard_stats()["shared_flop_fraction"], **{k: np.array(v) for k, v in out.items()})
+c.rccl_detach()
+c.close()
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_rccl_over_two_or_more_gpus():
+    """The real thing, whenever the box has more than one GPU (skipped on a one-GPU box): one process per GPU, RCCL bound to the contexts from C
+    (ipcgpu_rccl_attach: all-reduce AND point-to-point hooks on the context's own stream), owner-computes assembly + the subtree-sharded solver whose
+    update matrices travel as ncclSend / ncclRecv groups over xGMI.  Same Newton counts and positions as the single-rank run on GPU 0."""
+    import torch
+    ngpu = torch.cuda.device_count()
+    if ngpu < 2:
+        pytest.skip("one GPU visible: RCCL refuses two ranks on one device (the multi-rank paths run over gloo on one device in the tests above)")
+    world = 4 if ngpu >= 4 else 2
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        one, many = os.path.join(d, "one.npz"), os.path.join(d, "many.npz")
+        run(1, one, "owner")  # the single-rank reference (gloo worker with world 1: no hooks)
+        with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+            f.write(RCCL_WORKER)
+            script = f.name
+        env = dict(os.environ, IPC_REPO=repo, OUT=many, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = [subprocess.Popen([sys.executable, script], env=dict(env, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                                  stderr=subprocess.STDOUT, text=True) for r in range(world)]
+        logs = [p.communicate(timeout=600)[0] for p in procs]
+        os.unlink(script)
+        for p, log in zip(procs, logs):
+            assert p.returncode == 0, log[-3000:]
+        a, b = np.load(one), np.load(many)
+        assert float(b["sum"]) == world * (world + 1) / 2 and float(b["min"]) == 1.0 and float(b["shift"]) == world  # rank 0 hears from rank world - 1
+        assert np.array_equal(a["iters"], b["iters"])
+        assert np.abs(a["V"] - b["V"]).max() <= 1e-11 * np.abs(a["V"]).max()
+        assert b["sent"].sum() == b["received"].sum() > 0

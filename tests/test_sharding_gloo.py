@@ -197,3 +197,198 @@ def test_owner_computes_protocol_on_gloo(world):
     # the ranks split the rows: each assembles its subtrees + the shared separators, far from everything at 4 ranks
     assert sum(r["rows"] for r in res) < world * 0.95
     assert max(r["rows"] for r in res) < (0.8 if world == 2 else 0.6)
+
+
+# ---- round 5: the sharded direct solver sends POINT TO POINT.  A front above the cut is executed by one rank (mf_assign_executors); the packed update matrix of
+# a child another rank computed, its update vector and the solution entries of the separators travel to exactly the ranks that need them
+# (mf_exchange_plan -> MfNumeric::exchange -> ncclSend / ncclRecv groups).  Here the product's own plan (mf_symbolic.cpp through the shim) drives a dense
+# multifrontal factorisation in numpy, one process per rank over gloo: every rank factorises and solves ONLY the fronts the plan gives it and moves ONLY what the
+# plan lists.  Anything the plan forgot would be missing (None / NaN) where a front needs it, and the solution would not be the direct one.
+def _p2p_worker(rank, world, port, out):
+    import ctypes as C
+    import sys
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import orc
+    from test_mf_symbolic import analyze
+    V, F = scene.make_mat(16)
+    m = orc.Mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    ia, ja = m.pattern()
+    ia, ja = np.ascontiguousarray(ia, np.int32), np.ascontiguousarray(ja, np.int32)
+    L = _shim_lib()
+    o = analyze(L, ia, ja, np.ascontiguousarray(V, np.float64), 8)
+    ns, nn = o["ns"], o["nn"]
+    n = 3 * nn
+    exec_, group, level = np.zeros(ns, np.int32), np.zeros(ns, np.uint64), np.zeros(ns, np.int32)
+    cap = 8 * ns + 64
+    rec = np.zeros(7 * cap, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    nrec = L.shim_exchange_plan(C.c_int(world), C.c_int(rank), p(exec_), p(group), p(level), p(rec), C.c_int(cap))
+    assert nrec >= 0
+    rec = rec[:7 * nrec].reshape(-1, 7)
+    # an SPD matrix on the pattern, the same on every rank; permuted to the elimination order
+    rng = np.random.default_rng(11)
+    row = np.repeat(np.arange(n), np.diff(ia))
+    val = rng.uniform(-1.0, 1.0, len(ja))
+    A = np.zeros((n, n))
+    A[row, ja] = val
+    A = A + A.T
+    A[np.arange(n), np.arange(n)] = np.abs(A).sum(1) + 1.0
+    b = rng.normal(size=n)
+    newS = (3 * o["newOf"][:, None] + np.arange(3)[None, :]).ravel()  # new scalar index of old scalar index
+    oldS = np.argsort(newS)
+    Ap, bp = A[np.ix_(oldS, oldS)], b[oldS]
+    first, parent = o["firstNode"], o["parent"]
+    fronts = []
+    for s in range(ns):
+        nodes = o["idx"][o["idxPtr"][s]:o["idxPtr"][s + 1]]
+        assert np.array_equal(nodes[:first[s + 1] - first[s]], np.arange(first[s], first[s + 1]))  # own nodes lead the front's index list
+        fronts.append((3 * nodes[:, None] + np.arange(3)[None, :]).ravel())
+    nc = 3 * np.diff(first)
+    kids = [o["child"][o["childPtr"][s]:o["childPtr"][s + 1]] for s in range(ns)]
+    nLevels = int(level.max()) + 1
+    mine = exec_ == rank
+    U, W, Lf = [None] * ns, [None] * ns, [None] * ns
+    moved = dict(sent=0, received=0)
+
+    def group_exchange(items):  # items: (tensor, peer, send)
+        if not items:
+            return
+        reqs = [dist.P2POp(dist.isend if snd else dist.irecv, t, peer) for t, peer, snd in items]
+        for r in dist.batch_isend_irecv(reqs):
+            r.wait()
+        for t, peer, snd in items:
+            moved["sent" if snd else "received"] += 8 * t.numel()
+
+    def recs(l, kind):
+        return rec[(rec[:, 0] == l) & (rec[:, 1] == kind)]
+
+    def tri(mm):
+        jj, ii = np.triu_indices(mm)  # column by column of the lower triangle
+        return ii, jj
+
+    # ---- factorisation, level by level
+    for l in range(nLevels):
+        for s in np.nonzero(mine & (level == l))[0]:
+            I, k = fronts[s], nc[s]
+            Fm = np.zeros((len(I), len(I)))
+            Fm[:, :k] = Ap[np.ix_(I, I[:k])]
+            Fm[:k, :] = Fm[:, :k].T
+            pos = {int(g): i for i, g in enumerate(I)}
+            for c in kids[s]:
+                Ic = fronts[c][nc[c]:]
+                loc = np.array([pos[int(g)] for g in Ic], dtype=np.int64)
+                assert U[c] is not None, f"rank {rank}: front {s} needs the update matrix of child {c}, which nobody sent"
+                Fm[np.ix_(loc, loc)] += U[c]
+            L11 = np.linalg.cholesky(Fm[:k, :k])
+            L21 = np.linalg.solve(L11, Fm[k:, :k].T).T
+            U[s] = Fm[k:, k:] - L21 @ L21.T
+            Lf[s] = (L11, L21)
+        items, unpack = [], []
+        off_seen = []
+        for r in recs(l, 0):
+            s, mm = int(r[2]), len(fronts[int(r[2])]) - nc[int(r[2])]
+            assert mine[s] and exec_[parent[s]] == r[6] != rank
+            ii, jj = tri(mm)
+            items.append((torch.from_numpy(np.ascontiguousarray(U[s][ii, jj])), int(r[6]), True))
+            off_seen.append(((int(r[4]) << 32) | (int(r[3]) & 0xffffffff), mm * (mm + 1) // 2))
+        for r in recs(l, 1):
+            s, mm = int(r[2]), len(fronts[int(r[2])]) - nc[int(r[2])]
+            assert exec_[parent[s]] == rank and exec_[s] == r[6] != rank
+            t = torch.empty(mm * (mm + 1) // 2, dtype=torch.float64)
+            items.append((t, int(r[6]), False))
+            unpack.append((s, mm, t))
+            off_seen.append(((int(r[4]) << 32) | (int(r[3]) & 0xffffffff), mm * (mm + 1) // 2))
+        off_seen.sort()
+        for (o0, c0), (o1, _) in zip(off_seen, off_seen[1:]):
+            assert o0 + c0 <= o1, "staging regions of one level overlap"
+        group_exchange(items)
+        for s, mm, t in unpack:
+            ii, jj = tri(mm)
+            Um = np.zeros((mm, mm))
+            Um[ii, jj] = t.numpy()
+            U[s] = Um + np.tril(Um, -1).T
+    # ---- forward sweep
+    y = np.full(n, np.nan)
+    for l in range(nLevels):
+        for s in np.nonzero(mine & (level == l))[0]:
+            I, k = fronts[s], nc[s]
+            w = np.zeros(len(I))
+            w[:k] = bp[I[:k]]
+            pos = {int(g): i for i, g in enumerate(I)}
+            for c in kids[s]:
+                assert W[c] is not None, f"rank {rank}: front {s} needs the update vector of child {c}"
+                loc = np.array([pos[int(g)] for g in fronts[c][nc[c]:]], dtype=np.int64)
+                np.add.at(w, loc, W[c])
+            L11, L21 = Lf[s]
+            ys = np.linalg.solve(L11, w[:k])
+            y[I[:k]] = ys
+            W[s] = w[k:] - L21 @ ys
+        items, unpack = [], []
+        for r in recs(l, 0):
+            items.append((torch.from_numpy(np.ascontiguousarray(W[int(r[2])])), int(r[6]), True))
+        for r in recs(l, 1):
+            s = int(r[2])
+            t = torch.empty(len(fronts[s]) - nc[s], dtype=torch.float64)
+            items.append((t, int(r[6]), False))
+            unpack.append((s, t))
+        group_exchange(items)
+        for s, t in unpack:
+            W[s] = t.numpy()
+    # ---- backward sweep
+    x = np.full(n, np.nan)
+    for l in range(nLevels - 1, -1, -1):
+        for s in np.nonzero(mine & (level == l))[0]:
+            I, k = fronts[s], nc[s]
+            L11, L21 = Lf[s]
+            x[I[:k]] = np.linalg.solve(L11.T, y[I[:k]] - L21.T @ x[I[k:]])
+        items, unpack = [], []
+        for r in recs(l, 2):
+            s = int(r[2])
+            items.append((torch.from_numpy(np.ascontiguousarray(x[fronts[s][:nc[s]]])), int(r[6]), True))
+        for r in recs(l, 3):
+            s = int(r[2])
+            t = torch.empty(nc[s], dtype=torch.float64)
+            items.append((t, int(r[6]), False))
+            unpack.append((s, t))
+        group_exchange(items)
+        for s, t in unpack:
+            x[fronts[s][:nc[s]]] = t.numpy()
+    # ---- the solution every rank ends up with: each entry contributed by its executor (one all-reduce, as in MfNumeric::enqueueBackward)
+    nodeExec = np.repeat(exec_, np.diff(first))
+    own = np.repeat(nodeExec == rank, 3)
+    assert not np.isnan(x[own]).any(), f"rank {rank}: a solution entry of its own fronts was never computed"
+    tx = torch.from_numpy(np.where(own, x, 0.0))
+    dist.all_reduce(tx, op=dist.ReduceOp.SUM)
+    xref = np.linalg.solve(Ap, bp)
+    tot = torch.tensor([float(moved["sent"]), float(moved["received"])], dtype=torch.float64)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    out.put(dict(rank=rank, err=float(np.abs(tx.numpy() - xref).max() / np.abs(xref).max()), sent=moved["sent"], received=moved["received"],
+                 sent_all=float(tot[0]), received_all=float(tot[1]), fronts=int(mine.sum()), ns=ns,
+                 above=int(((exec_ == rank) & (group != (np.uint64(1) << np.uint64(rank)))).sum()), full_matrix_bytes=8 * len(ja)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("world", [2, 4])
+def test_point_to_point_solver_protocol_on_gloo(world):
+    _shim_lib()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2p_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [out.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for r in res:
+        assert r["err"] < 1e-11, r  # the direct solution, on every rank
+        assert r["sent_all"] == r["received_all"] > 0  # every byte sent is received exactly once
+        assert 0 < r["fronts"] < r["ns"]
+    assert sum(r["fronts"] for r in res) == res[0]["ns"]  # every front executed by exactly one rank: nothing above the cut is repeated
+    assert sum(r["above"] for r in res) >= 1
