@@ -832,6 +832,32 @@ int ipcgpu_contact_energy(ipcgpu_ctx* c, double dHat, double kappa, double* E)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_contact_evaluate(ipcgpu_ctx* c, int n, const int* mmcvid_4n, double* val_n)
+{
+    return guarded([&] {
+        bind(c);
+        needArg(n >= 0 && (n == 0 || (mmcvid_4n && val_n)), "null argument");
+        for (int i = 0; i < 4 * n; ++i) {
+            const int v = mmcvid_4n[i] >= 0 ? mmcvid_4n[i] : ((i & 3) == 0 ? -mmcvid_4n[i] - 1 : 0); // [0] < 0 encodes a node; [2], [3] < 0 are flags / multiplicities
+            needArg(v < c->mesh->nV, "MMCVID node id out of range");
+        }
+        CT(c).evaluateTuples(c->mesh->d_x.p, n, mmcvid_4n, val_n);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_contact_jt_multiply(ipcgpu_ctx* c, int n, const int* mmcvid_4n, const double* input_n, double coef, double* out_3nV_inout)
+{
+    return guarded([&] {
+        bind(c);
+        needArg(n >= 0 && out_3nV_inout && (n == 0 || (mmcvid_4n && input_n)), "null argument");
+        for (int i = 0; i < 4 * n; ++i) {
+            const int v = mmcvid_4n[i] >= 0 ? mmcvid_4n[i] : ((i & 3) == 0 ? -mmcvid_4n[i] - 1 : 0);
+            needArg(v < c->mesh->nV, "MMCVID node id out of range");
+        }
+        CT(c).jtMultiplyTuples(c->mesh->d_x.p, c->mesh->nV, n, mmcvid_4n, input_n, coef, out_3nV_inout);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_contact_gradient_add(ipcgpu_ctx* c, double dHat, double kappa, int projectDBC, double* g)
 {
     return guarded([&] {

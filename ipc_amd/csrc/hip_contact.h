@@ -79,6 +79,12 @@ public:
         bool usePara = true, const unsigned char* need_dev = nullptr);
     void hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
         double* a_dev, const unsigned char* need_dev = nullptr);
+    // the reference's per-constraint interface on host arrays of MMCVID tuples (SelfCollisionHandler.cpp:37-148; ipcgpu_contact_evaluate / _jt_multiply):
+    // val[i] = squared distance of tuple i;  out += coef * multiplicity_i * input[i] * grad d_i
+    void evaluateTuples(const double* x_dev, int n, const int* tuples4, double* val);
+    void jtMultiplyTuples(const double* x_dev, int nV, int n, const int* tuples4, const double* input, double coef, double* out_3nV);
+    DevBuf<int> tupleBuf_;
+    DevBuf<double> tupleVal_, tupleOut_;
     void connectivity(std::vector<std::pair<int, int>>& pairs) const;
     bool patternCovers(const HipLinSysSolver& lin); // every node pair of the current sets has its block in lin's pattern (one small kernel)
     void candidateConnectivity(std::vector<std::pair<int, int>>& pairs) const; // appends; all node pairs of the candidate list

@@ -309,6 +309,31 @@ __global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, doub
         }
     }
 }
+// ---- the reference's per-constraint interface (round 5: what the compiled collision-handler adapter include/adapters/HipSelfCollisionHandler.hpp forwards to)
+// SelfCollisionHandler::evaluateConstraints (SelfCollisionHandler.cpp:37-81): the squared distance of every given MMCVID tuple
+__global__ __launch_bounds__(BLOCK) void k_evaluate_tuples(int n, const int* __restrict__ tuples, const double* __restrict__ x, double* __restrict__ val)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Stencil s = decode(tuples + 4 * (size_t)i);
+    double X[4][3];
+    gatherX(x, s.node, s.n, X);
+    val[i] = dist_only(s.kind, X);
+}
+// SelfCollisionHandler::leftMultiplyConstraintJacobianT (:84-148): out += coef * mult_i * input_i * grad d_i (mult = the multiplicity of a PP / PE tuple)
+__global__ __launch_bounds__(BLOCK) void k_jt_tuples(int n, const int* __restrict__ tuples, const double* __restrict__ x, const double* __restrict__ input, double coef,
+    double* __restrict__ out)
+{
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const Stencil s = decode(tuples + 4 * (size_t)i);
+    double X[4][3], g[12];
+    gatherX(x, s.node, s.n, X);
+    (void)stencil_distance(s.kind, X, g, nullptr);
+    const double w = coef * s.mult * input[i];
+    for (int k = 0; k < s.n; ++k)
+        for (int c = 0; c < 3; ++c) atomicAdd(&out[3 * (size_t)s.node[k] + c], w * g[3 * k + c]);
+}
 __global__ void k_zero_projected(int nV, const int* __restrict__ dbc, int projectDBC, double* __restrict__ grad)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2282,6 +2307,25 @@ double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf
     HIP_CHECK(hipMemcpyAsync(&out, scalar_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     return out;
+}
+
+void HipContact::evaluateTuples(const double* x_dev, int n, const int* tuples4, double* val)
+{
+    if (n <= 0) return;
+    tupleBuf_.upload(tuples4, 4 * (size_t)n, stream);
+    tupleVal_.alloc((size_t)n);
+    hipLaunchKernelGGL(k_evaluate_tuples, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, tupleBuf_.p, x_dev, tupleVal_.p);
+    tupleVal_.download(val, (size_t)n, stream);
+}
+
+void HipContact::jtMultiplyTuples(const double* x_dev, int nV, int n, const int* tuples4, const double* input, double coef, double* out_3nV)
+{
+    if (n <= 0) return;
+    tupleBuf_.upload(tuples4, 4 * (size_t)n, stream);
+    tupleVal_.upload(input, (size_t)n, stream);
+    tupleOut_.upload(out_3nV, 3 * (size_t)nV, stream);
+    hipLaunchKernelGGL(k_jt_tuples, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, tupleBuf_.p, x_dev, tupleVal_.p, coef, tupleOut_.p);
+    tupleOut_.download(out_3nV, 3 * (size_t)nV, stream);
 }
 
 void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev,

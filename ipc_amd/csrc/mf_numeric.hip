@@ -1044,68 +1044,65 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
     const int kb1 = (kb >= 0) ? kb + w : 0;
     const int w1 = (kb1 < nc) ? min(NB, nc - kb1) : 0;
     if (d.w >= 0) {
-        // ---- role A: F[i0.., j0..] -= P_kb[i0..] P_kb[j0..]^T behind the next panel, own columns (< nc) only
-        double(*As)[TS] = reinterpret_cast<double(*)[TS]>(sm);
-        double(*Bs)[TS] = reinterpret_cast<double(*)[TS]>(sm + NB * TS);
+        // ---- role A: F[i0.., j0..] -= P_kb[i0..] P_kb[j0..]^T behind the next panel, own columns (< nc) only.
+        // Round 5: on the matrix cores, one wave per 32 x 32 quadrant of the 64 x 64 tile, operands straight from the front -- the Schur kernel's inner
+        // product (schur_tile64_core) over the 32 columns of one panel.  As 4 x 4 register tiles fed from LDS (rounds 1-4) the update was bound by the LDS
+        // reads: eight ds_read_b64 per sixteen multiply-adds; the two forms have the same arithmetic peak on this chip, so the win is the operand traffic.  At
+        // 375 K nodes, where these tiles are most of what a step launch does, the step kernels ran at 12 % of the fp64 peak against 45 % for the Schur kernel
+        // (profiles/r05_mat433_kernel_stats.md).
         const int M0 = kb1 + w1;
-        const int i0 = M0 + TS * d.z, j0 = M0 + TS * d.w;
-        // All 16 panel loads and the 16 old values of this thread's 4 x 4 sub-tile are issued before anything waits on them.
-        // Written as loops of conditional loads / read-modify-writes, the compiler emitted load -> wait -> store chains: 32
-        // dependent memory round trips per workgroup, which made the trailing tiles as long as the pivot chain of role B.
-        constexpr int NLD = NB * TS / WGB;
-        double va[NLD], vb[NLD];
+        const int wv = tid >> 6, l = tid & 63, ar = l & 15, ak = l >> 4;
+        const int ia = M0 + TS * d.z + 32 * (wv & 1), ja = M0 + TS * d.w + 32 * (wv >> 1); // this wave's quadrant
+        const int colEnd = min(N, nc); // columns >= nc form the Schur complement: one pass at the end (k_big_schur*)
+        if (ia + 31 < ja || ia >= N || ja >= colEnd) return; // entirely above the diagonal, below the front or behind the own columns (no barrier follows)
+        const double* pa0 = F + min(ia + ar, N - 1);
+        const double* pa1 = F + min(ia + 16 + ar, N - 1);
+        const double* pb0 = F + min(ja + ar, N - 1);
+        const double* pb1 = F + min(ja + 16 + ar, N - 1);
+        // all 32 operand loads and the 16 old values of the quadrant are issued before anything waits on them
+        double x0[NB / 4], x1[NB / 4], y0[NB / 4], y1[NB / 4], old[2][2][4];
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + WGB * it;
-            const int k = e / TS, i = e - k * TS;
-            const long long colOff = (long long)N * (kb + min(k, w - 1)); // role A only exists behind a panel: w >= 1
-            va[it] = F[min(i0 + i, N - 1) + colOff];
-            vb[it] = F[min(j0 + i, N - 1) + colOff];
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const long long off = (long long)N * (kb + min(4 * ks + ak, w - 1)); // role A only exists behind a panel: w >= 1
+            x0[ks] = pa0[off];
+            x1[ks] = pa1[off];
+            y0[ks] = pb0[off];
+            y1[ks] = pb1[off];
         }
-        double old[4][4];
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
+        for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
-                old[ii][jj] = F[min(i0 + 4 * (tid & 15) + ii, N - 1) + (long long)N * min(j0 + 4 * (tid >> 4) + jj, N - 1)];
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = min(ia + 16 * mi + ar, N - 1);
 #pragma unroll
-        for (int it = 0; it < NLD; ++it) {
-            const int e = tid + WGB * it;
-            const int k = e / TS, i = e - k * TS;
-            const bool kin = k < w;
-            As[k][i] = (kin && i0 + i < N) ? va[it] : 0.0;
-            Bs[k][i] = (kin && j0 + i < N) ? vb[it] : 0.0;
-        }
-        __syncthreads();
-        const int ty = tid & 15, tx = tid >> 4;
-        double acc[4][4];
-#pragma unroll
-        for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-#pragma unroll 8
-        for (int k = 0; k < NB; ++k) {
-            double av[4], bv[4];
-#pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                av[ii] = As[k][4 * ty + ii];
-                bv[ii] = Bs[k][4 * tx + ii];
+                for (int r = 0; r < 4; ++r) old[nj][mi][r] = F[row + (long long)N * min(ja + 16 * nj + ak + 4 * r, N - 1)];
             }
+        __builtin_amdgcn_sched_barrier(0);
+        f64x4 acc[2][2]; // [nj][mi]: rows j of D, columns i (formed transposed: 16 lanes of an accumulator row hold 16 consecutive rows i of one column j)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii)
+        for (int a = 0; a < 2; ++a)
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+            for (int b = 0; b < 2; ++b) acc[a][b] = f64x4{ 0.0, 0.0, 0.0, 0.0 };
+#pragma unroll
+        for (int ks = 0; ks < NB / 4; ++ks) {
+            const bool in = 4 * ks + ak < w; // past the panel's width the clamped column was re-read: its products are masked
+            const double m0 = in ? y0[ks] : 0.0, m1 = in ? y1[ks] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x0[ks], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m0, x1[ks], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x0[ks], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(m1, x1[ks], acc[1][1], 0, 0, 0);
         }
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int col = j0 + 4 * tx + jj;
-            if (col >= nc) continue; // columns >= nc form the Schur complement: one pass at the end (k_big_schur)
+        for (int nj = 0; nj < 2; ++nj)
 #pragma unroll
-            for (int ii = 0; ii < 4; ++ii) {
-                const int row = i0 + 4 * ty + ii;
-                if (row < N && row >= col) F[row + (long long)N * col] = old[ii][jj] - acc[ii][jj];
+            for (int mi = 0; mi < 2; ++mi) {
+                const int row = ia + 16 * mi + ar;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = ja + 16 * nj + ak + 4 * r;
+                    if (col < colEnd && row < N && row >= col) F[row + (long long)N * col] = old[nj][mi][r] - acc[nj][mi][r];
+                }
             }
-        }
         return;
     }
     // ---- role B: bring panel kb1 up to date with panel kb, factor its pivot block, solve this workgroup's rows.

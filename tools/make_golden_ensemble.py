@@ -38,6 +38,9 @@ SCENES = [
     ("aligned_cubes", "paperExamples/supplementB/SQPBenchmark/12_alignedCubes.txt", "", 30),
     ("aligned_cubes_fric", "paperExamples/supplementB/SQPBenchmark/12_alignedCubes.txt", "\nselfFric 0.3\n", 40),
     ("attach", "tutorialExamples/advanced/2cubesFall_attach.txt", "", 22),
+    # BASELINE configs[4]'s chain: ten interlocked tori caught link after link, each from free fall onto the link above (--seeds 8: a run of the reference-compiled
+    # code takes a minute here)
+    ("chain10", "paperExamples/videoExamples/chain10.txt", "", 30),
 ]
 
 
