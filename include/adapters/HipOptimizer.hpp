@@ -26,6 +26,13 @@
 #include "Optimizer.hpp"
 #include "HalfSpace.hpp"
 #include "HipElasticEnergy.hpp"
+#ifndef IPCGPU_NO_HANDLER_REDIRECT
+#define IPCGPU_NO_HANDLER_REDIRECT // the registry and the class only: the name is redirected where Optimizer.cpp is compiled, not here
+#include "HipSelfCollisionHandler.hpp"
+#undef IPCGPU_NO_HANDLER_REDIRECT
+#else
+#include "HipSelfCollisionHandler.hpp"
+#endif
 #include <ipcgpu.h>
 #include <algorithm>
 #include <array>
@@ -151,6 +158,7 @@ class HipOptimizer : private HipOptimizerParts, public Optimizer<dim> {
 protected:
     int nSim = 0, nObst = 0; // nodes of Mesh<3>; nodes of the mesh collision objects riding along behind them
     bool uploaded = false, dragReleased = false;
+    bool contactOnDevice = false; // percall mode: the SelfCollisionHandler statics forward to this context (HipSelfCollisionHandler.hpp)
     int dragGroup = -1, pauseTurn = -1, pauseGroup[2] = { -1, -1 };
     std::vector<int> pauseIds[2];
     std::vector<std::array<double, 3>> plateVel; // DCOSquash / DCOSquash6: current velocity of every plate
@@ -172,6 +180,38 @@ public:
             hipUploadMesh(Parts::ctx, Base::result, Base::result.m_YM, Base::result.m_PR, Base::result.density);
             chk(ipcgpu_opt_init(Parts::ctx, Base::dt, p_animConfig.withGravity ? 1 : 0)); // work buffers of the element kernels; the time step itself stays the base class's
             mirrorDBC();
+            // self-contact on the device in this mode too (round 5): the statics of HipSelfCollisionHandler.hpp forward the constraint sets, the
+            // per-constraint distances / Jacobian products, the barrier Hessian, both CCD step bounds and the intersection test of the reference's own
+            // control flow to this context -- once it has the surface.  The mesh collision objects, the analytic planes, friction and the mollified
+            // pairs stay the reference's host code.  IPCGPU_PERCALL_CONTACT=host: everything on the host, as before round 5 (A/B).
+            const char* pc = std::getenv("IPCGPU_PERCALL_CONTACT");
+            const bool hostContact = pc && std::strcmp(pc, "host") == 0;
+            if (Base::solveIP && p_animConfig.isSelfCollision && !hostContact && p_animConfig.ccdMethod == ccd::CCDMethod::FLOATING_POINT_ROOT_FINDER) {
+                const Mesh<dim>& m = Base::result;
+                std::vector<int> ce(2 * (size_t)m.CE.rows());
+                for (int e = 0; e < (int)m.CE.rows(); ++e) {
+                    ce[2 * (size_t)e] = m.CE(e, 0);
+                    ce[2 * (size_t)e + 1] = m.CE(e, 1);
+                }
+                chk(ipcgpu_set_surface_codim(Parts::ctx, (int)m.SF.rows(), m.SF.data(), (int)m.CE.rows(), ce.empty() ? nullptr : ce.data()));
+#ifdef USE_PREDICATES
+                chk(ipcgpu_set_exact_predicates(Parts::ctx, 1));
+#endif
+                hipCollisionRegistry().ctx = Parts::ctx;
+                contactOnDevice = true;
+            }
+        }
+        std::fprintf(stderr, "HipOptimizer: %s mode%s\n", resident() ? "resident (whole time steps on the device)" : "percall (the reference's control flow)",
+            resident() ? "" : (contactOnDevice ? "; elasticity, Cholesky and self-contact on the device" : "; elasticity and Cholesky on the device, contact on the host"));
+    }
+    ~HipOptimizer() override
+    {
+        if (contactOnDevice) {
+            const HipCollisionRegistry& r = hipCollisionRegistry();
+            std::fprintf(stderr, "HipOptimizer: self-contact calls forwarded to the device: %lld constraint sets, %lld evaluations, %lld Jacobian products, %lld barrier "
+                                 "Hessians, %lld + %lld step bounds, %lld intersection tests (%lld Hessians fell back to the host)\n",
+                r.calls[0], r.calls[1], r.calls[2], r.calls[3], r.calls[4], r.calls[5], r.calls[6], r.hostFallbacks);
+            if (hipCollisionRegistry().ctx == Parts::ctx) hipCollisionRegistry().ctx = nullptr;
         }
     }
 

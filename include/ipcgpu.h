@@ -221,14 +221,14 @@ int ipcgpu_contact_get(ipcgpu_ctx*, int* active_4n, int* paraEE_4n, int* paraEEe
 int ipcgpu_contact_set(ipcgpu_ctx*, int nActive, const int* active_4n, int nParaEE, const int* paraEE_4n, const int* paraEEeIeJ_2n);
 /* kappa * (sum mult b(d) + sum e(c) b(d))  -- the barrier part of computeEnergyVal (Optimizer.cpp:3252-3353) */
 int ipcgpu_contact_energy(ipcgpu_ctx*, double dHat, double kappa, double* energy);
-/* grad += kappa J^T b'  (leftMultiplyConstraintJacobianT + augmentParaEEGradient, SelfCollisionHandler.cpp:84-148,
- * 2990-3036), then rows of projected Dirichlet nodes zeroed (Optimizer.cpp:3512-3516) */
 /* The reference's PER-CONSTRAINT interface, on caller-held MMCVID tuples at the positions of ipcgpu_set_positions (round 5: what the compiled collision-handler
  * adapter include/adapters/HipSelfCollisionHandler.hpp forwards to when the reference's own Optimizer.cpp drives the loop):
  * evaluateConstraints (SelfCollisionHandler.cpp:37-81): val[i] = squared distance of tuple i;
  * leftMultiplyConstraintJacobianT (:84-148): out += coef * multiplicity_i * input[i] * grad d_i (multiplicity = -MMCVID[3] of a PP / PE tuple, 1 otherwise). */
 int ipcgpu_contact_evaluate(ipcgpu_ctx*, int n, const int* mmcvid_4n, double* val_n);
 int ipcgpu_contact_jt_multiply(ipcgpu_ctx*, int n, const int* mmcvid_4n, const double* input_n, double coef, double* out_3nV_inout);
+/* grad += kappa J^T b'  (leftMultiplyConstraintJacobianT + augmentParaEEGradient, SelfCollisionHandler.cpp:84-148,
+ * 2990-3036), then rows of projected Dirichlet nodes zeroed (Optimizer.cpp:3512-3516) */
 int ipcgpu_contact_gradient_add(ipcgpu_ctx*, double dHat, double kappa, int projectDBC, double* grad_3nV_inout);
 /* a += PSD-projected barrier Hessians (augmentIPHessian + augmentParaEEHessian, SelfCollisionHandler.cpp:418-561,
  * 3039-3201).  The pattern must already contain the contact connectivity (ipcgpu_contact_connectivity ->

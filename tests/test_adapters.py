@@ -71,14 +71,18 @@ def build_main_hip():
     """tests/adapters/_build/ipc_main_hip: the reference's OWN main.cpp (compiled where it lies, tests/adapters/main_hook.hpp
     pre-included: the one `new Optimizer` of main.cpp:1397 becomes `new HipOptimizer`) + include/adapters/HipOptimizer.hpp +
     the reference's other compiled sources (the objects oracle/Makefile.ref built) + the factory line of
-    tests/adapters/main_hip_plug.cpp.  Build container only; the executable travels to the GPU box."""
+    tests/adapters/main_hip_plug.cpp.  Round 5: the reference's Optimizer.cpp is compiled once more for this executable, UNCHANGED, with
+    tests/adapters/optimizer_hook.hpp pre-included -- its 44 `SelfCollisionHandler<dim>::` call sites then reach the statics of
+    include/adapters/HipSelfCollisionHandler.hpp (device when HipOptimizer switched them on, the reference's own code otherwise).
+    Build container only; the executable travels to the GPU box."""
     from ipc_amd import build as b
     b.build()
     os.makedirs(BUILD, exist_ok=True)
     hook = os.path.join(ROOT, "tests", "adapters", "main_hook.hpp")
     plug = os.path.join(ROOT, "tests", "adapters", "main_hip_plug.cpp")
     ctcd = os.path.join(ROOT, "oracle", "ref_plug.cpp")
-    deps = [hook, plug, ctcd, LIB_REF, os.path.join(ROOT, "include", "ipcgpu.h"), os.path.join(REF_SRC, "main.cpp")]
+    opt_hook = os.path.join(ROOT, "tests", "adapters", "optimizer_hook.hpp")
+    deps = [hook, opt_hook, plug, ctcd, LIB_REF, os.path.join(ROOT, "include", "ipcgpu.h"), os.path.join(REF_SRC, "main.cpp"), os.path.join(REF_SRC, "TimeStepper", "Optimizer.cpp")]
     deps += [os.path.join(ROOT, "include", "adapters", f) for f in os.listdir(os.path.join(ROOT, "include", "adapters"))]
     if os.path.exists(MAIN_HIP) and all(os.path.getmtime(MAIN_HIP) >= os.path.getmtime(d) for d in deps):
         return MAIN_HIP
@@ -88,6 +92,7 @@ def build_main_hip():
              "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "include", "adapters")]
     objs = []
     jobs = [(os.path.join(REF_SRC, "main.cpp"), "main_hip.o", ["-Dmain=ipc_reference_main", "-include", hook]),
+            (os.path.join(REF_SRC, "TimeStepper", "Optimizer.cpp"), "optimizer_hip.o", ["-include", opt_hook]),
             (plug, "main_hip_plug.o", []), (ctcd, "ctcd_plug.o", ["-DIPCREF_PLUG_CTCD_ONLY"])]
     procs = []
     for src, name, extra in jobs:
@@ -98,7 +103,7 @@ def build_main_hip():
         out = pr.communicate()[0]
         assert pr.returncode == 0, out[-6000:]
     for dirpath, _d, files in os.walk(REF_OBJ):  # the reference's other translation units, as compiled for libipcref.so
-        objs += [os.path.join(dirpath, f) for f in files if f.endswith(".o") and f not in ("main.o", "ref_plug.o", "ref_api.o")]
+        objs += [os.path.join(dirpath, f) for f in files if f.endswith(".o") and f not in ("main.o", "ref_plug.o", "ref_api.o", "Optimizer.o")]
     cmd = ["g++", "-o", MAIN_HIP] + objs + ["-L" + os.path.join(ROOT, "ipc_amd"), "-lipcgpu", "-L" + os.path.join(ROOT, "oracle", "_build"), "-lorc",
            "-lstdc++fs", "-Wl,-rpath,$ORIGIN/../../../ipc_amd", "-Wl,-rpath,$ORIGIN/../../../oracle/_build", "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -131,7 +136,8 @@ def test_adapter_headers_use_only_the_public_c_abi():
         for line in txt.splitlines():
             if line.startswith("#include"):
                 inc = line.split()[1].strip('<>"')
-                assert inc in ("LinSysSolver.hpp", "Energy.hpp", "Optimizer.hpp", "HalfSpace.hpp", "HipLinSysSolver.hpp", "HipElasticEnergy.hpp", "ipcgpu.h",
+                assert inc in ("LinSysSolver.hpp", "Energy.hpp", "Optimizer.hpp", "HalfSpace.hpp", "SelfCollisionHandler.hpp", "HipLinSysSolver.hpp", "HipElasticEnergy.hpp",
+                               "HipSelfCollisionHandler.hpp", "ipcgpu.h",
                                "algorithm", "array", "cmath", "cstdio", "cstdlib", "cstring", "limits", "memory", "stdexcept", "string", "vector"), (f, inc)
         assert "oracle" not in txt and "hip/hip_runtime" not in txt
 

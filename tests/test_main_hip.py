@@ -59,11 +59,11 @@ def read_run(out_dir, steps):
     return pos, its
 
 
-def run_main_hip(S, meshes, tmp, steps, mode="resident"):
+def run_main_hip(S, meshes, tmp, steps, mode="resident", extra_env=None):
     script = export_scene(S, meshes, str(tmp), steps)
     out = os.path.join(str(tmp), "out_" + mode)
     os.makedirs(out, exist_ok=True)
-    env = dict(os.environ, IPCGPU_OPTIMIZER_MODE=mode)
+    env = dict(os.environ, IPCGPU_OPTIMIZER_MODE=mode, **(extra_env or {}))
     r = subprocess.run([MAIN_HIP, "100", script, "-o", out + "/", "--logLevel", "off"], cwd=str(tmp), env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, timeout=1500)
     log = r.stdout.decode(errors="replace")
@@ -161,12 +161,37 @@ def test_reference_main_bar_twist_percall(tmp_path):
 
 @pytest.mark.gpu
 @needs_exe
-def test_reference_main_two_cubes_fall_percall(tmp_path):
-    """percall mode with contact: the barrier terms, constraint sets and CCD are the reference's host code adding into the
-    HipLinSysSolver's pending host updates; elasticity and the factorisation run on the device."""
+def test_reference_main_two_cubes_fall_percall_contact_on_the_device(tmp_path):
+    """Round 5, percall mode with self-contact ON THE DEVICE: the reference's own solve() / fullyImplicit_IP() / solveSub_IP() / lineSearch() drive the
+    loop, and the 44 `SelfCollisionHandler<dim>::` call sites of its UNCHANGED Optimizer.cpp (compiled with tests/adapters/optimizer_hook.hpp pre-included)
+    reach the statics of include/adapters/HipSelfCollisionHandler.hpp: constraint sets, per-constraint distances and Jacobian products, the barrier Hessian
+    added in HBM, both CCD step bounds and the intersection test run through the C ABI; the ground plane, friction and the mollified pairs stay host code.
+    The run says which mode it is in and how many calls went to the device; it is held to the same criterion as the resident stepper (the envelope of the
+    reference's own one-ulp ensemble from the first touch-down on)."""
+    from test_oracle_vs_reference import check_envelope
     S, meshes = load_scene("two_cubes_fall")
     steps = 25
-    pos, its, _ = run_main_hip(S, meshes, tmp_path, steps, mode="percall")
+    pos, its, log = run_main_hip(S, meshes, tmp_path, steps, mode="percall")
+    assert "self-contact on the device" in log, log[-1500:]
+    import re
+    m = re.search(r"forwarded to the device: (\d+) constraint sets, (\d+) evaluations, (\d+) Jacobian products, (\d+) barrier Hessians, (\d+) \+ (\d+) step bounds, "
+                  r"(\d+) intersection tests \((\d+) Hessians fell back", log)
+    assert m, log[-1500:]
+    n = [int(x) for x in m.groups()]
+    assert min(n[0], n[1], n[2], n[3], n[4], n[6]) > 0 and n[7] == 0, n  # every kind of call reached the device (the full sweep n[5] only runs when a step leaves the CFL ball)
+    check_envelope("two_cubes_fall", S, pos, its)
+
+
+@pytest.mark.gpu
+@needs_exe
+def test_reference_main_two_cubes_fall_percall(tmp_path):
+    """percall mode with contact ON THE HOST (IPCGPU_PERCALL_CONTACT=host, the A/B of the test above and all there was before round 5): the barrier terms,
+    constraint sets and CCD are the reference's host code adding into the HipLinSysSolver's pending host updates; elasticity and the factorisation run on
+    the device."""
+    S, meshes = load_scene("two_cubes_fall")
+    steps = 25
+    pos, its, log = run_main_hip(S, meshes, tmp_path, steps, mode="percall", extra_env={"IPCGPU_PERCALL_CONTACT": "host"})
+    assert "contact on the host" in log, log[-1500:]
     free = 17
     for s in range(free):
         assert np.abs(pos[s] - S["positions"][s]).max() <= 1e-12

@@ -287,10 +287,10 @@ def load_ensemble(name):
     return np.load(os.path.join(GOLD, f"ref_ensemble_{name}.npz"))
 
 
-ENVELOPE_SCENES = ["two_cubes_fall", "dbc_time_range", "aligned_cubes", "aligned_cubes_fric", "attach"]
+ENVELOPE_SCENES = ["two_cubes_fall", "dbc_time_range", "aligned_cubes", "aligned_cubes_fric", "attach", "chain10"]
 
 
-def check_envelope(name, S, pos, its, exact_tol=1e-12):
+def check_envelope(name, S, pos, its, exact_tol=1e-12, positions=True):
     """The criterion for scenes whose contact begins from exact rest, where the REFERENCE ITSELF changes its Newton counts and end positions when its state
     is moved by one ulp (ENVELOPE_SCENES; up to 6 of 30 counts and 2.1e-2 of the scene's size for the aligned cubes, 16 of 40 counts with friction).
       * Before the first step in which the ensemble spreads (its deviation leaves round-off: > 1e-12): every count equal, positions to exact_tol.
@@ -314,7 +314,8 @@ def check_envelope(name, S, pos, its, exact_tol=1e-12):
     assert np.all(its[first:] >= lo[first:]) and np.all(its[first:] <= hi[first:]), report
     assert int((its != ref_its).sum()) <= int(E["ens_mismatches"].max()) + 1, report
     ahead = np.maximum(ens_dev, np.concatenate([ens_dev[1:], ens_dev[-1:]]))
-    assert np.all(dev[first:] <= 2.0 * ahead[first:] + exact_tol), report
+    if positions:  # (positions=False: the caller holds the positions to a criterion of its own)
+        assert np.all(dev[first:] <= 2.0 * ahead[first:] + exact_tol), report
     return dev
 
 
@@ -488,9 +489,11 @@ def test_shipped_scenes_against_the_reference(name, mism, tol):
 
 def check_chain(S, pos, its):
     """BASELINE configs[4]'s chain, videoExamples/chain10.txt as shipped (ten interlocked tori dropping onto a fixed torus ring given as a mesh
-    collision object, `size -1`, `script fallNoShift`), 30 steps run by the reference: EVERY Newton count equal while link after link is caught;
-    positions within the Newton tolerance of the touch-downs from exact rest."""
-    assert np.array_equal(its, S["iters"]), (its.tolist(), S["iters"].tolist())
+    collision object, `size -1`, `script fallNoShift`), 30 steps run by the reference: the Newton counts of the reference while link after link is caught --
+    inside the envelope of the reference's own one-ulp ensemble (round 5: continued from its own status1 with every coordinate moved by one ulp the reference
+    takes 4 instead of 6 iterations in step 4 and 8 instead of 7 in step 9, tools/make_golden_ensemble.py; rounds 3-4 asked for every count equal, which held
+    until the elimination order of the solver changed and step 4 took 7) --, positions within the Newton tolerance of the touch-downs from exact rest."""
+    check_envelope("chain10", S, pos, its, exact_tol=1e-13, positions=False)
     ref = S["positions"]
     n = min(pos.shape[1], ref.shape[1])
     assert np.abs(pos[:2, :n] - ref[:2, :n]).max() <= 1e-13 * np.abs(ref).max()
