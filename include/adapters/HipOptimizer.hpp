@@ -199,6 +199,11 @@ public:
 #endif
                 hipCollisionRegistry().ctx = Parts::ctx;
                 contactOnDevice = true;
+                static bool registered = false; // the reference's main() leaves through exit() without deleting its optimizer: the summary is printed from there
+                if (!registered) {
+                    std::atexit(reportForwardedCalls);
+                    registered = true;
+                }
             }
         }
         std::fprintf(stderr, "HipOptimizer: %s mode%s\n", resident() ? "resident (whole time steps on the device)" : "percall (the reference's control flow)",
@@ -206,13 +211,21 @@ public:
     }
     ~HipOptimizer() override
     {
-        if (contactOnDevice) {
-            const HipCollisionRegistry& r = hipCollisionRegistry();
-            std::fprintf(stderr, "HipOptimizer: self-contact calls forwarded to the device: %lld constraint sets, %lld evaluations, %lld Jacobian products, %lld barrier "
-                                 "Hessians, %lld + %lld step bounds, %lld intersection tests (%lld Hessians fell back to the host)\n",
-                r.calls[0], r.calls[1], r.calls[2], r.calls[3], r.calls[4], r.calls[5], r.calls[6], r.hostFallbacks);
-            if (hipCollisionRegistry().ctx == Parts::ctx) hipCollisionRegistry().ctx = nullptr;
+        if (contactOnDevice && hipCollisionRegistry().ctx == Parts::ctx) {
+            reportForwardedCalls();
+            hipCollisionRegistry().ctx = nullptr; // the context goes away with this object: the handler's statics are the reference's again
         }
+    }
+    // where the self-contact of a percall run was evaluated (stderr, once: from the destructor or, when the program leaves through exit(), from atexit)
+    static void reportForwardedCalls()
+    {
+        static bool done = false;
+        if (done) return;
+        done = true;
+        const HipCollisionRegistry& r = hipCollisionRegistry();
+        std::fprintf(stderr, "HipOptimizer: self-contact calls forwarded to the device: %lld constraint sets, %lld evaluations, %lld Jacobian products, %lld barrier "
+                             "Hessians, %lld + %lld step bounds, %lld intersection tests (%lld Hessians fell back to the host)\n",
+            r.calls[0], r.calls[1], r.calls[2], r.calls[3], r.calls[4], r.calls[5], r.calls[6], r.hostFallbacks);
     }
 
     ipcgpu_ctx* context() const { return Parts::ctx; }
