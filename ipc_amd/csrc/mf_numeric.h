@@ -172,9 +172,9 @@ private:
     std::vector<int> aPtrHost_; // front -> first entry (goes into the packed descriptors)
     DevBuf<int> bigFd_; // packed records of the other fronts (k_extend_add)
     DevBuf<int> fdesc_; // packed descriptors of the fused fronts (64 ints each, launch order)
-    DevBuf<int> bigASrc_; // entries of A of the other fronts, grouped by level: source index ...
+    DevBuf<int> bigASrc_; // entries of A of the other fronts, grouped by extend-add tile: source index ...
     DevBuf<long long> bigADst_; // ... and destination in the front buffer
-    std::vector<int> bigAOff_; // level -> first entry
+    DevBuf<int> eaAPtr_; // per extend-add tile: first of its entries in bigASrc_ / bigADst_ (the extend-add kernel adds them, round 5)
     DevBuf<int4> eaDesc_;
     DevBuf<int> smallList_, bigList_;
     DevBuf<int4> desc_; // all big-front step descriptors

@@ -87,14 +87,6 @@ __global__ void k_gather_a(int cnt, const int* __restrict__ src, const double* _
     if (k < cnt) aP[k] = a[src[k]];
 }
 
-// A entries of the fronts that go through the multi-workgroup path: F[dst] += a[src] after the extend-add of their level has
-// WRITTEN every lower-triangle entry (no memset of the front buffer: each entry that is ever read is written first)
-__global__ void k_scatter_big(int cnt, const int* __restrict__ src, const long long* __restrict__ dst, const double* __restrict__ a,
-    double* __restrict__ fronts)
-{
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k < cnt) fronts[dst[k]] += a[src[k]];
-}
 
 // desc = (record, ti, tj, 0): one 64 x 64 tile (ti >= tj) of a parent front.  `record` indexes a packed 64-int descriptor
 // (layout of the fused kernel: [0,1] front offset [2] N [8] #children in this record [9] next record or -1; child q at
@@ -103,8 +95,12 @@ __global__ void k_scatter_big(int cnt, const int* __restrict__ src, const long l
 // the tile are built once in LDS; lanes run along rows, which are (mostly) consecutive in the child as well, the four waves
 // split the 64 columns.  The gathers are unconditional (clamped address, value selected afterwards): all in flight together.
 // ownOnly: the level's Schur kernel gathers the children for the update block itself (k_big_schur64_ea): only columns < nc are written here
+// Round 5: the entries of A of the tile follow in the same launch (they used to be a launch of their own per level, k_scatter_big: 5 us on the chain of
+// every level).  aPtr[d.w] .. aPtr[d.w + 1]: the tile's entries in aSrc / aDst (sorted by tile on the host, MfNumeric::setup); every entry of A lands
+// in a column < nc, i.e. in a tile this kernel writes, and no two entries share a slot.
 __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc, const int* __restrict__ bigFd,
-    const int* __restrict__ invMap, double* __restrict__ fronts, int ownOnly)
+    const int* __restrict__ invMap, double* __restrict__ fronts, int ownOnly, const int* __restrict__ aPtr, const int* __restrict__ aSrc,
+    const long long* __restrict__ aDst, const double* __restrict__ a)
 {
     __shared__ __attribute__((aligned(16))) int fd[FD_STRIDE_EA];
     __shared__ int rmap[FUSED_MAX_KIDS_EA][TS], cmap[FUSED_MAX_KIDS_EA][TS];
@@ -161,6 +157,11 @@ __global__ __launch_bounds__(WG) void k_extend_add(const int4* __restrict__ desc
             const int J = j0 + 16 * wv + q;
             if (J <= I && (!ownOnly || J < ncOwn)) F[I + (long long)N * J] = sum[q]; // write, not accumulate: the fronts are never zero-filled
         }
+    }
+    const int aBeg = aPtr[d.w], aEnd = aPtr[d.w + 1];
+    if (aBeg < aEnd) { // (workgroup-uniform)
+        __syncthreads(); // the tile is written: the entries of A are added by whichever thread picks them up
+        for (int e = aBeg + tid; e < aEnd; e += WG) fronts[aDst[e]] += a[aSrc[e]];
     }
 }
 
@@ -527,64 +528,59 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
     // ---- the factor panel goes to HBM once (the solves read it)
     for (int J = wv; J < nc; J += NT / 64)
         for (int I = J + lane; I < N; I += 64) F[I + (long long)N * J] = P[J * N + I];
-    // ---- Schur complement: S = (children) - L21 L21^T, written once.  16 x 16 thread grid of 4 x 4 tiles: a thread column owns
-    // four consecutive rows, so that the 16 threads ty = 0..15 store 512 contiguous bytes per column.
+    // ---- Schur complement: S = (children) - L21 L21^T, written once.  Round 5: 16 x 16 tiles on the matrix cores, one tile per wave at a time, operands
+    // straight from the panel in LDS (a lane's A / B entry: 16 consecutive rows of one column of P -- conflict-free unless N is a multiple of 32).  As 4 x 4
+    // register tiles per thread (rounds 1-4) this block was bound by its LDS reads -- eight ds_read_b64 per sixteen multiply-adds: 18 us for a front of
+    // 250 rows and 60 columns, most of what a workgroup of the levels just below the batched ones took.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4] =
+    // L(j0 + (l & 15), k), B[l >> 4][l & 15] = L(i0 + (l & 15), k); D register r of lane l = S(i0 + (l & 15), j0 + (l >> 4) + 4 r): the 16 lanes of an
+    // accumulator row store 16 consecutive rows of one column, 128 contiguous bytes.
     {
         const int mt = N - nc;
-        const int ntile = (mt + 3) >> 2;
-        const int ty = tid & 15, tx = tid >> 4;
-        for (int tc = tx; tc < ntile; tc += NT / 16) {
-            for (int tr = ty; tr < ntile; tr += 16) {
-                if (tr < tc) continue;
-                const int i0 = nc + 4 * tr, j0 = nc + 4 * tc;
-                double acc[4][4];
+        const int nt16 = (mt + 15) >> 4;
+        const int lo = lane & 15, hi = lane >> 4;
+        const int ksteps = (nc + 3) >> 2;
+        for (int t = wv; t < nt16 * (nt16 + 1) / 2; t += NT / 64) {
+            int tr = 0; // tile (tr, tc), tc <= tr, number t of the lower triangle row by row
+            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
+            const int tc = t - tr * (tr + 1) / 2;
+            const int i0 = nc + 16 * tr, j0 = nc + 16 * tc;
+            const int row = i0 + lo;
+            // children first: their loads are in flight while the panel product runs
+            double ch[4] = { 0.0, 0.0, 0.0, 0.0 };
+            for (int q = 0; q < nk; ++q) {
+                const double* Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * q);
+                const long long Nc = fd[16 + 6 * q + 2];
+                const int* m = cm + q * N;
+                const int rr = (row < N) ? m[row] : -1;
 #pragma unroll
-                for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[ii][jj] = 0.0;
-                // children first: their loads are in flight while the panel product runs
-                for (int q = 0; q < nk; ++q) {
-                    const double* Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * q);
-                    const long long Nc = fd[16 + 6 * q + 2];
-                    const int* m = cm + q * N;
-                    int rr[4], cc[4];
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        rr[ii] = (i0 + ii < N) ? m[i0 + ii] : -1;
-                        cc[ii] = (j0 + ii < N) ? m[j0 + ii] : -1;
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                        for (int ii = 0; ii < 4; ++ii) {
-                            const bool ok = rr[ii] >= 0 && cc[jj] >= 0 && rr[ii] >= cc[jj];
-                            const double x = Fc[ok ? rr[ii] + Nc * cc[jj] : 0];
-                            acc[ii][jj] -= ok ? x : 0.0;
-                        }
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + hi + 4 * r;
+                    const int cc = (j < N) ? m[j] : -1;
+                    const bool ok = rr >= 0 && cc >= 0 && rr >= cc;
+                    const double x = Fc[ok ? rr + Nc * cc : 0];
+                    ch[r] += ok ? x : 0.0;
                 }
-#pragma unroll 4
-                for (int k = 0; k < nc; ++k) {
-                    const double* pk = P + (size_t)k * N;
-                    double av[4], bv[4];
+            }
+            f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
+            const double* pa = P + min(j0 + lo, N - 1); // rows past the end of the front are clamped: their products land in entries that are never written
+            const double* pb = P + min(row, N - 1);
+            for (int ks0 = 0; ks0 < ksteps; ks0 += 4) { // four k-steps at a time: their eight LDS reads are in flight before the first product
+                double av[4], bv[4];
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        av[ii] = pk[min(i0 + ii, N - 1)];
-                        bv[ii] = pk[min(j0 + ii, N - 1)];
-                    }
-#pragma unroll
-                    for (int ii = 0; ii < 4; ++ii)
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) acc[ii][jj] += av[ii] * bv[jj];
+                for (int u = 0; u < 4; ++u) {
+                    const int k = 4 * (ks0 + u) + hi;
+                    const size_t off = (size_t)min(k, nc - 1) * N;
+                    av[u] = pa[off];
+                    bv[u] = pb[off];
                 }
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int j = j0 + jj;
-                    if (j >= N) continue;
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((4 * (ks0 + u) + hi < nc) ? av[u] : 0.0, bv[u], acc, 0, 0, 0);
+            }
+            if (row < N) {
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int i = i0 + ii;
-                        if (i < N && i >= j) F[i + (long long)N * j] = -acc[ii][jj];
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const int j = j0 + hi + 4 * r;
+                    if (j < N && row >= j) F[row + (long long)N * j] = ch[r] - acc[r];
                 }
             }
         }
@@ -2037,24 +2033,60 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         nodeExec_.upload(ne, stream);
     }
     auto mine = [&](int s) { return world_ == 1 || exec_[s] == rank_; };
-    // entries of A grouped by owning front: (source index, offset inside the LDS panel) for the fused fronts,
-    // (source index, offset in the front buffer) per level for the others.  A parallel counting sort on a few host threads,
-    // written straight into pinned staging buffers (grow-only, like the device buffers they are copied to): this runs on
-    // every pattern change of a contact scene.
+    // The fronts of every level in the order the plans below use them (heaviest first, so that the tail of a level is made of short jobs), the levels whose
+    // Schur kernel gathers the update block itself (k_big_schur64_ea: their extend-add only writes own columns), and the numbering of the extend-add tiles
+    // (64 x 64, lower triangle, front after front): the entries of A are sorted by the tile they land in, because the extend-add kernel adds them (round 5).
+    std::vector<std::vector<int>> smallByLevel(nLevels_), bigByLevel(nLevels_);
+    std::vector<char> levelFuseEA(nLevels_, 0);
+    std::vector<int> eaTileBase(ns_, -1), eaColTiles(ns_, 0); // first tile of a front; tiles kept per tile row: min(ti + 1, eaColTiles)
+    int nEaTiles = 0;
+    for (int l = 0; l < nLevels_; ++l) {
+        std::vector<int>&small = smallByLevel[l], &big = bigByLevel[l];
+        for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
+            const int s = sym.levelFronts[i];
+            if (!mine(s)) continue; // factorised and solved by the rank that executes it
+            (isFused(s) ? small : big).push_back(s);
+        }
+        std::sort(small.begin(), small.end(), [&](int a, int b) { return sym.N(a) > sym.N(b) || (sym.N(a) == sym.N(b) && a < b); });
+        std::sort(big.begin(), big.end(), [&](int a, int b) { return sym.nc(a) > sym.nc(b) || (sym.nc(a) == sym.nc(b) && a < b); });
+        long long tiles32 = 0;
+        for (int s : big) {
+            const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
+            tiles32 += nt * (nt + 1) / 2;
+        }
+        levelFuseEA[l] = tiles32 >= schur64Min_;
+        for (int s : big) {
+            const int nt = (sym.N(s) + TS - 1) / TS;
+            eaColTiles[s] = levelFuseEA[l] ? (sym.nc(s) + TS - 1) / TS : nt;
+            eaTileBase[s] = nEaTiles;
+            for (int ti = 0; ti < nt; ++ti) nEaTiles += std::min(ti + 1, eaColTiles[s]);
+        }
+    }
+    auto eaTileOf = [&](int s, int ti, int tj) { // index of tile (ti, tj) of front s among the extend-add tiles
+        const int c = eaColTiles[s];
+        return eaTileBase[s] + (ti <= c ? ti * (ti + 1) / 2 : c * (c + 1) / 2 + (ti - c) * c) + tj;
+    };
+    // entries of A grouped by where they go: (source index, offset inside the LDS panel) for the fused fronts, per front; (source index, offset
+    // in the front buffer) for the others, per extend-add tile.  A parallel counting sort on a few host threads, written straight into pinned
+    // staging buffers (grow-only, like the device buffers they are copied to): this runs on every pattern change of a contact scene.
     {
         const size_t nnz = sym.aDst.size();
         std::vector<char> fused(ns_);
         for (int s = 0; s < ns_; ++s) fused[s] = isFused(s);
-        // bucket of an entry: fused front s -> s, other front of level l -> ns_ + l
-        const int nBuckets = ns_ + nLevels_ + 1;
+        // bucket of an entry: fused front s -> s, other front -> ns_ + its extend-add tile
+        const int nBuckets = ns_ + nEaTiles + 1;
         const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
         std::vector<std::vector<int>> cnt(nThreads, std::vector<int>(nBuckets, 0));
         auto range = [&](int t) { return std::make_pair(nnz * t / nThreads, nnz * (t + 1) / nThreads); };
-        const int skipBucket = ns_ + nLevels_; // entries of fronts another rank owns
+        const int skipBucket = ns_ + nEaTiles; // entries of fronts another rank executes
         auto bucketOf = [&](size_t k) {
             const int s = sym.aFront[k];
             if (!mine(s)) return skipBucket;
-            return fused[s] ? s : ns_ + sym.level[s];
+            if (fused[s]) return s;
+            const long long loc = sym.aDst[k] - sym.frontOff[s]; // row + N * column, column < nc, row >= column
+            const int N = sym.N(s);
+            const int J = (int)(loc / N), I = (int)(loc - (long long)J * N);
+            return ns_ + eaTileOf(s, I / TS, J / TS);
         };
         {
             std::vector<std::thread> pool;
@@ -2066,9 +2098,9 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 });
             for (auto& th : pool) th.join();
         }
-        // bucket starts: fused buckets share one index space (aSrc / aLoc), the level buckets another (bigASrc / bigADst)
+        // bucket starts: fused buckets share one index space (aSrc / aLoc), the tile buckets another (bigASrc / bigADst)
         std::vector<int> aPtr(ns_ + 1, 0);
-        std::vector<int> bigCnt(nLevels_ + 1, 0);
+        std::vector<int> bigCnt(nEaTiles + 1, 0);
         for (int bkt = 0; bkt < nBuckets; ++bkt) {
             int tot = 0;
             for (int t = 0; t < nThreads; ++t) {
@@ -2077,9 +2109,9 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 tot += c;
             }
             if (bkt < ns_) aPtr[bkt + 1] = aPtr[bkt] + tot;
-            else if (bkt < ns_ + nLevels_) bigCnt[bkt - ns_ + 1] = bigCnt[bkt - ns_] + tot;
+            else if (bkt < ns_ + nEaTiles) bigCnt[bkt - ns_ + 1] = bigCnt[bkt - ns_] + tot;
         }
-        const size_t nFused = (size_t)aPtr[ns_], nBig = (size_t)bigCnt[nLevels_];
+        const size_t nFused = (size_t)aPtr[ns_], nBig = (size_t)bigCnt[nEaTiles];
         auto growPinned = [](PinnedBuf<int>& b, size_t n) {
             if (b.n < n || !b.p) b.alloc(2 * n + 16); // pinned allocations cost ~5 ms each: room for the contact blocks a later pattern adds
         };
@@ -2106,8 +2138,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                             aLoc[q] = (int)(sym.aDst[k] - sym.frontOff[s]); // row + N * column, column < nc
                         }
                         else {
-                            const int l = sym.level[s];
-                            const int q = bigCnt[l] + off[ns_ + l]++;
+                            const int b = bucketOf(k) - ns_;
+                            const int q = bigCnt[b] + off[ns_ + b]++;
                             bSrc[q] = (int)k;
                             bDst[q] = sym.aDst[k];
                         }
@@ -2115,7 +2147,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 });
             for (auto& th : pool) th.join();
         }
-        bigAOff_.assign(bigCnt.begin(), bigCnt.end());
+        eaAPtr_.upload(bigCnt, stream); // per extend-add tile: its range in bigASrc_ / bigADst_
         aPtrHost_ = aPtr;
         nFusedA_ = (int)nFused;
         aPerm_.ensure(std::max<size_t>(nFused, 1));
@@ -2142,15 +2174,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
     size_t maxSmallLds = 0, maxSolveLds = 0, maxTriLds = 0, maxBwdLds = 0;
     for (int l = 0; l < nLevels_; ++l) {
         LevelPlan& P = plan_[l];
-        std::vector<int> small, big;
-        for (int i = sym.levelPtr[l]; i < sym.levelPtr[l + 1]; ++i) {
-            const int s = sym.levelFronts[i];
-            if (!mine(s)) continue; // factorised and solved by the rank that owns its subtree
-            (isFused(s) ? small : big).push_back(s);
-        }
-        // heaviest first so the tail of the level is made of short jobs
-        std::sort(small.begin(), small.end(), [&](int a, int b) { return sym.N(a) > sym.N(b); });
-        std::sort(big.begin(), big.end(), [&](int a, int b) { return sym.nc(a) > sym.nc(b); });
+        const std::vector<int>&small = smallByLevel[l], &big = bigByLevel[l];
         P.small.off = (int)smallList.size();
         P.small.cnt = (int)small.size();
         int maxN = 0, maxNc = 0;
@@ -2177,16 +2201,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         maxTriLds = std::max(maxTriLds, P.triLds);
         // extend-add descriptors: lower-triangular 64 x 64 tiles of the parent, each pointing at the parent's packed record
         P.ea.off = (int)ea.size();
-        // the extend-add of the update block is fused into the Schur kernel (k_big_schur64_ea) on the levels that take the 64 x 64 tiles: decided here
-        // because it thins out the extend-add's tiles
-        {
-            long long tiles32 = 0;
-            for (int s : big) {
-                const long long nt = (sym.N(s) - sym.nc(s) + TQ - 1) / TQ;
-                tiles32 += nt * (nt + 1) / 2;
-            }
-            P.schur64 = P.fuseEA = tiles32 >= schur64Min_;
-        }
+        P.schur64 = P.fuseEA = levelFuseEA[l] != 0; // (decided above: it thins out the extend-add's tiles and numbers them)
         for (int s : big) { // every lower-triangle tile is written (children sums or zeros): the fronts are never zero-filled
             const int first = (int)(bigFd.size() / FD_STRIDE);
             eaRecOf[s] = first;
@@ -2216,7 +2231,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
             for (int ti = 0; ti < nt; ++ti)
                 for (int tj = 0; tj <= ti; ++tj) {
                     if (P.fuseEA && TS * tj >= sym.nc(s)) continue; // a tile of the update block alone: the Schur kernel's
-                    ea.push_back(make_int4(first, ti, tj, 0));
+                    if ((int)ea.size() != eaTileOf(s, ti, tj)) throw StateError("internal: extend-add tiles are not numbered in emission order");
+                    ea.push_back(make_int4(first, ti, tj, eaTileOf(s, ti, tj)));
                 }
         }
         P.ea.cnt = (int)ea.size() - P.ea.off;
@@ -2634,11 +2650,8 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
                     dinv_.p, flag_.p);
         }
         if (P.ea.cnt) {
-            hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, bigFd_.p, inv_.p, fronts_.p, P.fuseEA ? 1 : 0);
-            const int na = bigAOff_[l + 1] - bigAOff_[l];
-            if (na)
-                hipLaunchKernelGGL(k_scatter_big, dim3((na + 255) / 256), dim3(256), 0, stream_, na, bigASrc_.p + bigAOff_[l],
-                    bigADst_.p + bigAOff_[l], a_dev, fronts_.p);
+            hipLaunchKernelGGL(k_extend_add, dim3(P.ea.cnt), dim3(WG), 0, stream_, eaDesc_.p + P.ea.off, bigFd_.p, inv_.p, fronts_.p, P.fuseEA ? 1 : 0, eaAPtr_.p,
+                bigASrc_.p, bigADst_.p, a_dev);
         }
         for (const Range& R : P.step) { // one launch per 32-column step, each with look-ahead (k_big_step)
             if (!R.cnt) continue;
