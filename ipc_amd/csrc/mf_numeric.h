@@ -174,6 +174,7 @@ private:
     DevBuf<int> fdesc_; // packed descriptors of the fused fronts (64 ints each, launch order)
     DevBuf<int> bigASrc_; // entries of A of the other fronts, grouped by extend-add tile: source index ...
     DevBuf<long long> bigADst_; // ... and destination in the front buffer
+    std::vector<int> bucketCache_; // per entry of A: its bucket in the set-up's counting sort
     DevBuf<int> eaAPtr_; // per extend-add tile: first of its entries in bigASrc_ / bigADst_ (the extend-add kernel adds them, round 5)
     DevBuf<int4> eaDesc_;
     DevBuf<int> smallList_, bigList_;

@@ -2077,6 +2077,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         const int nBuckets = ns_ + nEaTiles + 1;
         const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
         std::vector<std::vector<int>> cnt(nThreads, std::vector<int>(nBuckets, 0));
+        if (bucketCache_.size() < nnz) bucketCache_.resize(nnz + nnz / 2); // grow-only, like the pinned staging buffers
         auto range = [&](int t) { return std::make_pair(nnz * t / nThreads, nnz * (t + 1) / nThreads); };
         const int skipBucket = ns_ + nEaTiles; // entries of fronts another rank executes
         auto bucketOf = [&](size_t k) {
@@ -2094,7 +2095,11 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                 pool.emplace_back([&, t] {
                     const auto r = range(t);
                     int* c = cnt[t].data();
-                    for (size_t k = r.first; k < r.second; ++k) c[bucketOf(k)]++;
+                    for (size_t k = r.first; k < r.second; ++k) {
+                        const int b = bucketOf(k);
+                        bucketCache_[k] = b; // (the second pass reuses it: a bucket of a batched front costs a division)
+                        c[b]++;
+                    }
                 });
             for (auto& th : pool) th.join();
         }
@@ -2138,7 +2143,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
                             aLoc[q] = (int)(sym.aDst[k] - sym.frontOff[s]); // row + N * column, column < nc
                         }
                         else {
-                            const int b = bucketOf(k) - ns_;
+                            const int b = bucketCache_[k] - ns_;
                             const int q = bigCnt[b] + off[ns_ + b]++;
                             bSrc[q] = (int)k;
                             bDst[q] = sym.aDst[k];
