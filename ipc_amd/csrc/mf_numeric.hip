@@ -229,6 +229,9 @@ __device__ __forceinline__ double rcp_nr(double d)
 // blocks; X = C^-1 W with C the 2 x 2 Cholesky factors of the pivot blocks is the (unique) inverse of the Cholesky factor:
 //     X_k = W_k / l11,   X_k+1 = (W_k+1 - (l21 / l11) W_k) / l22,   l11 = sqrt(a), l21 = b / l11, l22 = sqrt(det / a).
 // Blocked 16 + 16 as above: T11 -= U01^T D0^-1 U01 and W10 = -(D0^-1 U01)^T W00 with D0 the block diagonal of pivot blocks.
+// the value of lane l ^ 16 (the partner row of a 2 x 2 pivot sits 16 lanes away): two ds_bpermute, in flight during the reciprocal chain.  (Round 5: gfx950's
+// v_permlane16_swap_b32 does the same exchange in the VALU -- probed, correct, and no faster: 422.0 against 421.3 it/s, profiles/r05_permlane_and_border_ab.txt --
+// the exchange is not what a pivot waits for.)
 __device__ __forceinline__ double lane_xor16(double v) { return __shfl_xor(v, 16, 64); }
 
 __device__ __forceinline__ bool wave_potrf_inv32_mfma(const double* blk, int ld, int w, int lane, double* Xs)
