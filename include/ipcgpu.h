@@ -166,6 +166,9 @@ int ipcgpu_linsys_exchange_stats(ipcgpu_ctx*, double* out4);
    such a context) sums the rows over the ranks first.  IPCGPU_NO_OWNER_COMPUTES=1 keeps the older all-reduce of the values. */
 int ipcgpu_opt_comm_stats(ipcgpu_ctx*, double* out6);
 int ipcgpu_opt_complete_matrix(ipcgpu_ctx*);
+/* diagnosis / tests (multifrontal solver, after analyze_pattern): for every entry k of the CSR pattern (ipcgpu_linsys_get_pattern order) the offset of its slot in
+ * the front buffer, as the device kernel of the set-up computed it -- the same numbers mf_entry_destinations (ipc_amd/csrc/mf_symbolic.cpp) computes on the host */
+int ipcgpu_linsys_entry_destinations(ipcgpu_ctx*, long long* dst_nnz);
 /* factor statistics: nnz(L), factorisation flops, number of supernodes / levels */
 int ipcgpu_linsys_stats(ipcgpu_ctx*, double* stats4);
 

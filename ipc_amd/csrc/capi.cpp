@@ -668,6 +668,16 @@ int ipcgpu_linsys_exchange_stats(ipcgpu_ctx* c, double* out4)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_linsys_entry_destinations(ipcgpu_ctx* c, long long* dst_nnz)
+{
+    return guarded([&] {
+        bind(c);
+        needArg(c && dst_nnz, "null argument");
+        need(L(c).solverType == IPCGPU_SOLVER_MULTIFRONTAL && L(c).analyzed(), "the multifrontal solver has not analysed a pattern yet");
+        L(c).entryDestinations(dst_nnz);
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_linsys_shard_stats(ipcgpu_ctx* c, double* out2)
 {
     return guarded([&] {

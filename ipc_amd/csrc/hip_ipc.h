@@ -100,6 +100,7 @@ public:
     void setExchangeHooks(MfNumeric::ExchangeFn fn, void* user, MfNumeric::ExchangeStreamFn sfn, void* streamUser) { num_.setExchangeHooks(fn, user, sfn, streamUser); }
     bool hasExchangeHook() const { return num_.hasExchangeHook(); }
     int solverWorld() const { return num_.world(); }
+    void entryDestinations(long long* out) const { num_.entryDestinations(out, ja.size()); }
     void nodeOwners(std::vector<int>& o) const { num_.nodeOwners(o); }
     long long exchangedBytes() const { return num_.exchangedBytes(); }
     long long exchangeCalls() const { return num_.exchangeCalls(); }

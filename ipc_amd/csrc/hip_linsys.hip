@@ -217,10 +217,11 @@ void HipLinSysSolver::analyze_pattern(const HipMesh* mesh)
     // 20: 398 it/s; mat433 42.9 -> 43.7; contact bench 10.98 -> 10.78 ms per iteration.
     int leaf = 12;
     if (const char* e = std::getenv("IPCGPU_ND_LEAF")) leaf = std::max(1, std::atoi(e));
-    mf_analyze(numRows, ia.data(), ja.data(), cptr, leaf, sym_);
+    // (the entries' destinations in the fronts are computed on the device by MfNumeric::setup; the rocSOLVER back end does not use them)
+    mf_analyze(numRows, ia.data(), ja.data(), cptr, leaf, sym_, /*withEntryDestinations=*/false);
     ++analysisVersion;
     if (solverType == 0) {
-        num_.setup(sym_, stream);
+        num_.setup(sym_, stream, d_ia.p, d_ja.p, (long long)ja.size());
     }
     else {
         rs_.reset(new RocsolverCsrrf);

@@ -13,7 +13,9 @@ public:
     MfNumeric(const MfNumeric&) = delete;
     MfNumeric& operator=(const MfNumeric&) = delete;
 
-    void setup(const MfSymbolic& sym, hipStream_t stream); // uploads maps, allocates fronts
+    // uploads maps, allocates fronts; ia_dev / ja_dev: the user's CSR pattern (0-based, symmetric upper) in HBM, nnzPattern entries -- the destinations of its
+    // entries in the fronts are computed on the device (sym.aDst / aFront are not read)
+    void setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_dev, const int* ja_dev, long long nnzPattern);
     // Multi-GPU (one process per GPU): the assembly tree is cut below its top separators, every rank factorises and solves the
     // subtrees it owns.  Round 5: a front above the cut is executed by ONE rank (the executor of its most expensive child, mf_assign_executors) instead
     // of being repeated by all of them, and what a parent on another rank needs -- the packed update matrix of a child in the factorisation, its update
@@ -77,6 +79,8 @@ public:
     bool lastPivotsOk() const { return pivotsOk(); }
     bool pivotsOk() const; // false: a non-positive pivot
     bool ready() const { return ns_ > 0; }
+    // diagnosis / tests: the slot of every entry of the user's matrix in the front buffer, as the set-up's device kernel computed it (nnz values)
+    void entryDestinations(long long* out, size_t nnz) const { entryDst_.download(out, nnz, stream_); }
     size_t front_bytes() const { return fronts_.n * sizeof(double); }
 
 private:
@@ -174,13 +178,14 @@ private:
     DevBuf<int> fdesc_; // packed descriptors of the fused fronts (64 ints each, launch order)
     DevBuf<int> bigASrc_; // entries of A of the other fronts, grouped by extend-add tile: source index ...
     DevBuf<long long> bigADst_; // ... and destination in the front buffer
-    std::vector<int> bucketCache_; // per entry of A: its bucket in the set-up's counting sort
+    DevBuf<long long> entryDst_; // set-up scratch: per entry of A its slot in the front buffer ...
+    DevBuf<int> entryBucket_, bucketHist_, bucketStart_, nodeFront_; // ... its bucket, the buckets' counts + tickets and starts, the front of every permuted node
+    DevBuf<int4> frontInfo_;
     DevBuf<int> eaAPtr_; // per extend-add tile: first of its entries in bigASrc_ / bigADst_ (the extend-add kernel adds them, round 5)
     DevBuf<int4> eaDesc_;
     DevBuf<int> smallList_, bigList_;
     DevBuf<int4> desc_; // all big-front step descriptors
     PinnedBuf<int> hflag_;
-    PinnedBuf<int> hSrc_, hLoc_, hBigSrc_, hBigDst_; // pinned staging of the A-entry lists (grow-only)
 };
 
 } // namespace ipcgpu

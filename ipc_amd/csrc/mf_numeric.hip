@@ -95,6 +95,102 @@ __global__ void k_gather_a(int cnt, const int* __restrict__ src, const double* _
 // the tile are built once in LDS; lanes run along rows, which are (mostly) consecutive in the child as well, the four waves
 // split the 64 columns.  The gathers are unconditional (clamped address, value selected afterwards): all in flight together.
 // ownOnly: the level's Schur kernel gathers the children for the update block itself (k_big_schur64_ea): only columns < nc are written here
+// ---- entries of A -> slots of the fronts, and their lists, on the device (round 5) --------------------------------------------------------------------
+// A pattern change of a contact scene used to spend 2.9 ms on the host computing, for every entry of the user's CSR matrix, the front that owns it and its
+// offset in that front (mf_entry_destinations, 16 threads) and 3.0 ms sorting the entries by destination (a counting sort into pinned staging buffers, then
+// four uploads).  Both are a few launches here, on the pattern that is in HBM anyway: k_entry_dst (a wave per row: permuted indices, owning front, row by
+// binary search in the front's sorted index list; bucket = the front for a single-workgroup front, the extend-add tile for a batched one; histogram),
+// k_scan_exclusive, k_entry_scatter (slot = bucket start + ticket).  The order inside a bucket is whatever the tickets give: every entry has a slot of its
+// own, so the assembled fronts do not depend on it.  tests/test_gpu_parity.py pins k_entry_dst on the host function, bit for bit.
+struct EntryView {
+    const int *ia, *ja;
+    int nRows, ns;
+    const int *newOf, *nodeFront, *firstNode, *idxPtr, *idx;
+    const long long* frontOff;
+    const int4* frontInfo; // per front: (kind: -1 another rank's, 0 single-workgroup, 1 batched; first extend-add tile; tile columns kept per tile row; 0)
+};
+__global__ __launch_bounds__(256) void k_entry_dst(EntryView v, long long* __restrict__ dst, int* __restrict__ bucket, int* __restrict__ hist)
+{
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= v.nRows) return;
+    const int pr = 3 * v.newOf[r / 3] + r % 3;
+    for (int k = v.ia[r] + lane; k < v.ia[r + 1]; k += 64) {
+        const int c = v.ja[k];
+        const int pc = 3 * v.newOf[c / 3] + c % 3;
+        const int i = max(pr, pc), j = min(pr, pc); // lower triangle of the permuted matrix: row i, column j
+        const int s = v.nodeFront[j / 3];
+        const int f = v.firstNode[s], l = v.firstNode[s + 1];
+        const int nIdx = v.idxPtr[s + 1] - v.idxPtr[s];
+        int lr;
+        if (i / 3 < l) lr = i - 3 * f;
+        else { // a row of the structure behind the own nodes: position of node i / 3 in the front's sorted index list
+            const int* b = v.idx + v.idxPtr[s] + (l - f);
+            int lo = 0, hi = nIdx - (l - f);
+            const int key = i / 3;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (b[mid] < key) lo = mid + 1;
+                else hi = mid;
+            }
+            lr = 3 * ((l - f) + lo) + i % 3;
+        }
+        const int lc = j - 3 * f;
+        dst[k] = v.frontOff[s] + lr + (long long)(3 * nIdx) * lc;
+        const int4 info = v.frontInfo[s];
+        int bkt = -1;
+        if (info.x == 0) bkt = s;
+        else if (info.x > 0) {
+            const int ti = lr / TS, tj = lc / TS, cT = info.z;
+            bkt = v.ns + info.y + (ti <= cT ? ti * (ti + 1) / 2 : cT * (cT + 1) / 2 + (ti - cT) * cT) + tj;
+        }
+        bucket[k] = bkt;
+        if (bkt >= 0) atomicAdd(&hist[bkt], 1);
+    }
+}
+// exclusive prefix sums of n counts by ONE workgroup of 1024 (n is a few hundred thousand at most); out[n] = the total
+__global__ __launch_bounds__(1024) void k_scan_exclusive(int n, const int* __restrict__ in, int* __restrict__ out)
+{
+    __shared__ int part[1024];
+    const int t = threadIdx.x;
+    const int chunk = (n + 1023) / 1024;
+    const int b = min(t * chunk, n), e = min(b + chunk, n);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += in[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // Hillis-Steele over the 1024 partial sums
+        const int x = (t >= off) ? part[t - off] : 0;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    int run = part[t] - sum; // exclusive prefix of this thread's chunk
+    for (int i = b; i < e; ++i) {
+        out[i] = run;
+        run += in[i];
+    }
+    if (t == 1023) out[n] = part[1023];
+}
+__global__ void k_entry_scatter(int nnz, int ns, const long long* __restrict__ dst, const int* __restrict__ bucket, const int* __restrict__ start,
+    int* __restrict__ cursor, const long long* __restrict__ frontOff, int* __restrict__ aSrc, int* __restrict__ aLoc, int* __restrict__ bigSrc,
+    long long* __restrict__ bigDst)
+{
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nnz) return;
+    const int b = bucket[k];
+    if (b < 0) return;
+    const int pos = start[b] + atomicAdd(&cursor[b], 1);
+    if (b < ns) {
+        aSrc[pos] = k;
+        aLoc[pos] = (int)(dst[k] - frontOff[b]); // row + N * column, column < nc
+    }
+    else {
+        const int q = pos - start[ns]; // the batched fronts' entries have an index space of their own
+        bigSrc[q] = k;
+        bigDst[q] = dst[k];
+    }
+}
+
 // Round 5: the entries of A of the tile follow in the same launch (they used to be a launch of their own per level, k_scatter_big: 5 us on the chain of
 // every level).  aPtr[d.w] .. aPtr[d.w + 1]: the tile's entries in aSrc / aDst (sorted by tile on the host, MfNumeric::setup); every entry of A lands
 // in a column < nc, i.e. in a tile this kernel writes, and no two entries share a slot.
@@ -1878,7 +1974,7 @@ __global__ __launch_bounds__(WG) void k_xinv_bwd(const int4* __restrict__ desc, 
 
 } // namespace
 
-void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
+void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_dev, const int* ja_dev, long long nnzPattern)
 {
     if (side_) HIP_CHECK(hipStreamSynchronize(side_)); // buffers are about to be replaced
     const bool timeIt = std::getenv("IPCGPU_MF_SETUP_TIMES") != nullptr;
@@ -2069,108 +2165,43 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream)
         const int c = eaColTiles[s];
         return eaTileBase[s] + (ti <= c ? ti * (ti + 1) / 2 : c * (c + 1) / 2 + (ti - c) * c) + tj;
     };
-    // entries of A grouped by where they go: (source index, offset inside the LDS panel) for the fused fronts, per front; (source index, offset
-    // in the front buffer) for the others, per extend-add tile.  A parallel counting sort on a few host threads, written straight into pinned
-    // staging buffers (grow-only, like the device buffers they are copied to): this runs on every pattern change of a contact scene.
+    // entries of A grouped by where they go: (source index, offset inside the LDS panel) for the single-workgroup fronts, per front; (source index, offset in
+    // the front buffer) for the others, per extend-add tile -- computed and sorted on the device from the pattern in HBM (k_entry_dst, k_scan_exclusive,
+    // k_entry_scatter above).  What comes back to the host: the bucket starts (the packed descriptors of the single-workgroup fronts carry their entry range).
     {
-        const size_t nnz = sym.aDst.size();
-        std::vector<char> fused(ns_);
-        for (int s = 0; s < ns_; ++s) fused[s] = isFused(s);
-        // bucket of an entry: fused front s -> s, other front -> ns_ + its extend-add tile
-        const int nBuckets = ns_ + nEaTiles + 1;
-        const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-        std::vector<std::vector<int>> cnt(nThreads, std::vector<int>(nBuckets, 0));
-        if (bucketCache_.size() < nnz) bucketCache_.resize(nnz + nnz / 2); // grow-only, like the pinned staging buffers
-        auto range = [&](int t) { return std::make_pair(nnz * t / nThreads, nnz * (t + 1) / nThreads); };
-        const int skipBucket = ns_ + nEaTiles; // entries of fronts another rank executes
-        auto bucketOf = [&](size_t k) {
-            const int s = sym.aFront[k];
-            if (!mine(s)) return skipBucket;
-            if (fused[s]) return s;
-            const long long loc = sym.aDst[k] - sym.frontOff[s]; // row + N * column, column < nc, row >= column
-            const int N = sym.N(s);
-            const int J = (int)(loc / N), I = (int)(loc - (long long)J * N);
-            return ns_ + eaTileOf(s, I / TS, J / TS);
-        };
-        {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nThreads; ++t)
-                pool.emplace_back([&, t] {
-                    const auto r = range(t);
-                    int* c = cnt[t].data();
-                    for (size_t k = r.first; k < r.second; ++k) {
-                        const int b = bucketOf(k);
-                        bucketCache_[k] = b; // (the second pass reuses it: a bucket of a batched front costs a division)
-                        c[b]++;
-                    }
-                });
-            for (auto& th : pool) th.join();
-        }
-        // bucket starts: fused buckets share one index space (aSrc / aLoc), the tile buckets another (bigASrc / bigADst)
-        std::vector<int> aPtr(ns_ + 1, 0);
-        std::vector<int> bigCnt(nEaTiles + 1, 0);
-        for (int bkt = 0; bkt < nBuckets; ++bkt) {
-            int tot = 0;
-            for (int t = 0; t < nThreads; ++t) {
-                const int c = cnt[t][bkt];
-                cnt[t][bkt] = tot; // offset of thread t inside the bucket
-                tot += c;
-            }
-            if (bkt < ns_) aPtr[bkt + 1] = aPtr[bkt] + tot;
-            else if (bkt < ns_ + nEaTiles) bigCnt[bkt - ns_ + 1] = bigCnt[bkt - ns_] + tot;
-        }
-        const size_t nFused = (size_t)aPtr[ns_], nBig = (size_t)bigCnt[nEaTiles];
-        auto growPinned = [](PinnedBuf<int>& b, size_t n) {
-            if (b.n < n || !b.p) b.alloc(2 * n + 16); // pinned allocations cost ~5 ms each: room for the contact blocks a later pattern adds
-        };
-        growPinned(hSrc_, nFused + 1);
-        growPinned(hLoc_, nFused + 1);
-        growPinned(hBigSrc_, nBig + 1);
-        growPinned(hBigDst_, 2 * (nBig + 1)); // 64-bit destinations
-        int* aSrc = hSrc_.p;
-        int* aLoc = hLoc_.p;
-        int* bSrc = hBigSrc_.p;
-        long long* bDst = reinterpret_cast<long long*>(hBigDst_.p);
-        {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nThreads; ++t)
-                pool.emplace_back([&, t] {
-                    const auto r = range(t);
-                    int* off = cnt[t].data();
-                    for (size_t k = r.first; k < r.second; ++k) {
-                        const int s = sym.aFront[k];
-                        if (!mine(s)) continue;
-                        if (fused[s]) {
-                            const int q = aPtr[s] + off[s]++;
-                            aSrc[q] = (int)k;
-                            aLoc[q] = (int)(sym.aDst[k] - sym.frontOff[s]); // row + N * column, column < nc
-                        }
-                        else {
-                            const int b = bucketCache_[k] - ns_;
-                            const int q = bigCnt[b] + off[ns_ + b]++;
-                            bSrc[q] = (int)k;
-                            bDst[q] = sym.aDst[k];
-                        }
-                    }
-                });
-            for (auto& th : pool) th.join();
-        }
-        eaAPtr_.upload(bigCnt, stream); // per extend-add tile: its range in bigASrc_ / bigADst_
-        aPtrHost_ = aPtr;
+        const size_t nnz = (size_t)nnzPattern;
+        const int nBuckets = ns_ + nEaTiles;
+        std::vector<int4> info(std::max(ns_, 1));
+        for (int s = 0; s < ns_; ++s) info[s] = make_int4(!mine(s) ? -1 : (isFused(s) ? 0 : 1), eaTileBase[s], eaColTiles[s], 0);
+        std::vector<int> nodeFront(std::max(sym.nn, 1));
+        for (int s = 0; s < ns_; ++s)
+            for (int v = sym.firstNode[s]; v < sym.firstNode[s + 1]; ++v) nodeFront[v] = s;
+        frontInfo_.upload(info.data(), info.size(), stream);
+        nodeFront_.upload(nodeFront, stream);
+        entryDst_.ensure(nnz + 1);
+        entryBucket_.ensure(nnz + 1);
+        bucketHist_.ensure(2 * (size_t)nBuckets + 2); // counts, then the tickets of the scatter
+        bucketStart_.ensure((size_t)nBuckets + 2);
+        bucketHist_.zeroN(2 * (size_t)nBuckets + 2, stream);
+        EntryView ev{ ia_dev, ja_dev, sym.n, ns_, newOf_.p, nodeFront_.p, firstNode_.p, idxPtr_.p, idx_.p, frontOff_.p, frontInfo_.p };
+        hipLaunchKernelGGL(k_entry_dst, dim3((sym.n + 3) / 4), dim3(256), 0, stream, ev, entryDst_.p, entryBucket_.p, bucketHist_.p);
+        hipLaunchKernelGGL(k_scan_exclusive, dim3(1), dim3(1024), 0, stream, nBuckets, bucketHist_.p, bucketStart_.p);
+        std::vector<int> start((size_t)nBuckets + 1);
+        bucketStart_.download(start.data(), start.size(), stream); // (synchronises)
+        const size_t nFused = (size_t)start[ns_], nBig = (size_t)(start[nBuckets] - start[ns_]);
+        aPtrHost_.assign(start.begin(), start.begin() + ns_ + 1);
         nFusedA_ = (int)nFused;
         aPerm_.ensure(std::max<size_t>(nFused, 1));
         aSrc_.ensure(nFused + 1);
         aLoc_.ensure(nFused + 1);
         bigASrc_.ensure(nBig + 1);
         bigADst_.ensure(nBig + 1);
-        if (nFused) {
-            HIP_CHECK(hipMemcpyAsync(aSrc_.p, aSrc, nFused * sizeof(int), hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(aLoc_.p, aLoc, nFused * sizeof(int), hipMemcpyHostToDevice, stream));
-        }
-        if (nBig) {
-            HIP_CHECK(hipMemcpyAsync(bigASrc_.p, bSrc, nBig * sizeof(int), hipMemcpyHostToDevice, stream));
-            HIP_CHECK(hipMemcpyAsync(bigADst_.p, bDst, nBig * sizeof(long long), hipMemcpyHostToDevice, stream));
-        }
+        if (nnz)
+            hipLaunchKernelGGL(k_entry_scatter, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, stream, (int)nnz, ns_, entryDst_.p, entryBucket_.p, bucketStart_.p,
+                bucketHist_.p + nBuckets + 1, frontOff_.p, aSrc_.p, aLoc_.p, bigASrc_.p, bigADst_.p);
+        std::vector<int> eaPtr((size_t)nEaTiles + 1);
+        for (int t = 0; t <= nEaTiles; ++t) eaPtr[t] = start[ns_ + t] - start[ns_];
+        eaAPtr_.upload(eaPtr, stream); // per extend-add tile: its range in bigASrc_ / bigADst_
     }
     lap("A-entry lists");
     plan_.assign(nLevels_, LevelPlan());

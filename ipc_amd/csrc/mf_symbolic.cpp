@@ -372,7 +372,85 @@ private:
 
 } // namespace
 
-void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int leafSize, MfSymbolic& o)
+// user-matrix entry -> front slot (lower triangle of the permuted matrix): aDst / aFront of `o` from its ordering and front structures.  The product computes
+// the same two arrays on the device (MfNumeric::setup, k_entry_dst: round 5); this host version is what mf_analyze(..., withEntryDestinations = true) fills in --
+// the tests of the analysis and the GPU test that pins the device kernel on it.
+void mf_entry_destinations(int n, const int* ia, const int* ja, MfSymbolic& o)
+{
+    std::vector<int> frontOfNode(o.nn);
+    for (int s = 0; s < o.ns; ++s)
+        for (int v = o.firstNode[s]; v < o.firstNode[s + 1]; ++v) frontOfNode[v] = s;
+    // room for the blocks a later (contact) pattern adds: growing inside the capacity faults in only the new pages, a reallocation all of them
+    if (o.aDst.capacity() < (size_t)ia[n]) {
+        o.aDst.reserve((size_t)ia[n] + (size_t)ia[n] / 2);
+        o.aFront.reserve((size_t)ia[n] + (size_t)ia[n] / 2);
+    }
+    o.aDst.resize(ia[n]);
+    o.aFront.resize(ia[n]);
+    auto slot = [&](int r, int c, int* owner = nullptr) -> int64_t {
+        const int pr = 3 * o.newOf[r / 3] + r % 3, pc = 3 * o.newOf[c / 3] + c % 3;
+        const int i = std::max(pr, pc), j = std::min(pr, pc);
+        const int s = frontOfNode[j / 3];
+        if (owner) *owner = s;
+        const int f = o.firstNode[s], l = o.firstNode[s + 1];
+        const int64_t N = o.N(s);
+        int64_t lr;
+        if (i / 3 < l) lr = i - 3 * f;
+        else {
+            const int* b = o.idx.data() + o.idxPtr[s] + (l - f);
+            const int* e = o.idx.data() + o.idxPtr[s + 1];
+            const int* it = std::lower_bound(b, e, i / 3);
+            if (it == e || *it != i / 3) throw std::logic_error("mf_analyze: matrix entry outside the symbolic structure");
+            lr = 3 * (int64_t)((l - f) + (it - b)) + i % 3;
+        }
+        return o.frontOff[s] + lr + N * (int64_t)(j - 3 * f);
+    };
+    if (block_structured(n, ia, ja)) {
+        // one lookup per 3 x 3 node block instead of one per scalar entry: inside a block the destination moves by 1 per
+        // row of the front and by N per column.  Node ranges are independent: a few host threads.
+        auto fillRange = [&](int u0, int u1) {
+        for (int u = u0; u < u1; ++u) {
+            const int base = ia[3 * u], L = ia[3 * u + 1] - base;
+            const int row1 = ia[3 * u + 1], row2 = ia[3 * u + 2];
+            // diagonal block: upper entries (a, b), a <= b, of node u -> lower entries (b, a) of its front
+            {
+                const int pu = o.newOf[u], s = frontOfNode[pu];
+                const int64_t N = o.N(s), d0 = o.frontOff[s] + 3 * (int64_t)(pu - o.firstNode[s]) * (N + 1);
+                o.aDst[base] = d0;
+                o.aDst[base + 1] = d0 + 1;
+                o.aDst[base + 2] = d0 + 2;
+                o.aDst[row1] = d0 + N + 1;
+                o.aDst[row1 + 1] = d0 + N + 2;
+                o.aDst[row2] = d0 + 2 * N + 2;
+                o.aFront[base] = o.aFront[base + 1] = o.aFront[base + 2] = o.aFront[row1] = o.aFront[row1 + 1] = o.aFront[row2] = s;
+            }
+            for (int q = 3; q < L; q += 3) {
+                const int w = ja[base + q] / 3;
+                const int pu = o.newOf[u], pw = o.newOf[w];
+                const int64_t d0 = slot(3 * u, 3 * w); // entry (row 0 of u, column 0 of w)
+                const int s = frontOfNode[std::min(pu, pw)];
+                const int64_t N = o.N(s);
+                // scalar (a of u, b of w): if u is the row node of the front (pu > pw) the row index follows a, the column b
+                const int64_t da = pu > pw ? 1 : N, db = pu > pw ? N : 1;
+                for (int b = 0; b < 3; ++b) {
+                    o.aDst[base + q + b] = d0 + db * b;
+                    o.aDst[row1 + q - 1 + b] = d0 + da + db * b;
+                    o.aDst[row2 + q - 2 + b] = d0 + 2 * da + db * b;
+                    o.aFront[base + q + b] = o.aFront[row1 + q - 1 + b] = o.aFront[row2 + q - 2 + b] = s;
+                }
+            }
+        }
+        };
+        const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
+        run_threads(nThreads, [&](int t) { fillRange((int)((int64_t)o.nn * t / nThreads), (int)((int64_t)o.nn * (t + 1) / nThreads)); });
+    }
+    else {
+        for (int r = 0; r < n; ++r)
+            for (int k = ia[r]; k < ia[r + 1]; ++k) o.aDst[k] = slot(r, ja[k], &o.aFront[k]);
+    }
+}
+
+void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int leafSize, MfSymbolic& o, bool withEntryDestinations)
 {
     if (n % 3 != 0) throw std::invalid_argument("mf_analyze: row count must be a multiple of 3 (3x3 node blocks)");
     // every vector below is re-assigned in full: keep the capacity of a previous analysis (tens of MB that would otherwise be
@@ -554,76 +632,14 @@ void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int l
         for (int s = 0; s < o.ns; ++s) o.levelFronts[pos[o.level[s]]++] = s;
     }
     lap("index + inverse maps, levels");
-    // user-matrix entry -> front slot (lower triangle of the permuted matrix)
-    // room for the blocks a later (contact) pattern adds: growing inside the capacity faults in only the new pages, a reallocation all of them
-    if (o.aDst.capacity() < (size_t)ia[n]) {
-        o.aDst.reserve((size_t)ia[n] + (size_t)ia[n] / 2);
-        o.aFront.reserve((size_t)ia[n] + (size_t)ia[n] / 2);
-    }
-    o.aDst.resize(ia[n]);
-    o.aFront.resize(ia[n]);
-    auto slot = [&](int r, int c, int* owner = nullptr) -> int64_t {
-        const int pr = 3 * o.newOf[r / 3] + r % 3, pc = 3 * o.newOf[c / 3] + c % 3;
-        const int i = std::max(pr, pc), j = std::min(pr, pc);
-        const int s = frontOfNode[j / 3];
-        if (owner) *owner = s;
-        const int f = o.firstNode[s], l = o.firstNode[s + 1];
-        const int64_t N = o.N(s);
-        int64_t lr;
-        if (i / 3 < l) lr = i - 3 * f;
-        else {
-            const int* b = o.idx.data() + o.idxPtr[s] + (l - f);
-            const int* e = o.idx.data() + o.idxPtr[s + 1];
-            const int* it = std::lower_bound(b, e, i / 3);
-            if (it == e || *it != i / 3) throw std::logic_error("mf_analyze: matrix entry outside the symbolic structure");
-            lr = 3 * (int64_t)((l - f) + (it - b)) + i % 3;
-        }
-        return o.frontOff[s] + lr + N * (int64_t)(j - 3 * f);
-    };
-    if (block_structured(n, ia, ja)) {
-        // one lookup per 3 x 3 node block instead of one per scalar entry: inside a block the destination moves by 1 per
-        // row of the front and by N per column.  Node ranges are independent: a few host threads.
-        auto fillRange = [&](int u0, int u1) {
-        for (int u = u0; u < u1; ++u) {
-            const int base = ia[3 * u], L = ia[3 * u + 1] - base;
-            const int row1 = ia[3 * u + 1], row2 = ia[3 * u + 2];
-            // diagonal block: upper entries (a, b), a <= b, of node u -> lower entries (b, a) of its front
-            {
-                const int pu = o.newOf[u], s = frontOfNode[pu];
-                const int64_t N = o.N(s), d0 = o.frontOff[s] + 3 * (int64_t)(pu - o.firstNode[s]) * (N + 1);
-                o.aDst[base] = d0;
-                o.aDst[base + 1] = d0 + 1;
-                o.aDst[base + 2] = d0 + 2;
-                o.aDst[row1] = d0 + N + 1;
-                o.aDst[row1 + 1] = d0 + N + 2;
-                o.aDst[row2] = d0 + 2 * N + 2;
-                o.aFront[base] = o.aFront[base + 1] = o.aFront[base + 2] = o.aFront[row1] = o.aFront[row1 + 1] = o.aFront[row2] = s;
-            }
-            for (int q = 3; q < L; q += 3) {
-                const int w = ja[base + q] / 3;
-                const int pu = o.newOf[u], pw = o.newOf[w];
-                const int64_t d0 = slot(3 * u, 3 * w); // entry (row 0 of u, column 0 of w)
-                const int s = frontOfNode[std::min(pu, pw)];
-                const int64_t N = o.N(s);
-                // scalar (a of u, b of w): if u is the row node of the front (pu > pw) the row index follows a, the column b
-                const int64_t da = pu > pw ? 1 : N, db = pu > pw ? N : 1;
-                for (int b = 0; b < 3; ++b) {
-                    o.aDst[base + q + b] = d0 + db * b;
-                    o.aDst[row1 + q - 1 + b] = d0 + da + db * b;
-                    o.aDst[row2 + q - 2 + b] = d0 + 2 * da + db * b;
-                    o.aFront[base + q + b] = o.aFront[row1 + q - 1 + b] = o.aFront[row2 + q - 2 + b] = s;
-                }
-            }
-        }
-        };
-        const int nThreads = std::max(1, std::min(16, (int)std::thread::hardware_concurrency()));
-        run_threads(nThreads, [&](int t) { fillRange((int)((int64_t)o.nn * t / nThreads), (int)((int64_t)o.nn * (t + 1) / nThreads)); });
+    if (withEntryDestinations) {
+        mf_entry_destinations(n, ia, ja, o);
+        lap("entry destinations");
     }
     else {
-        for (int r = 0; r < n; ++r)
-            for (int k = ia[r]; k < ia[r + 1]; ++k) o.aDst[k] = slot(r, ja[k], &o.aFront[k]);
+        o.aDst.clear();
+        o.aFront.clear();
     }
-    lap("entry destinations");
 }
 
 double mf_assign_owners(const MfSymbolic& sym, int world, std::vector<int>& owner)

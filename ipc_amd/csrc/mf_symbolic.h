@@ -36,7 +36,9 @@ struct MfSymbolic {
 
 // ia/ja: 0-based symmetric-upper CSR (scalar).  coords: optional nn x 3 row-major node coordinates used for
 // geometric bisection (rest positions); when null the bisection direction is a BFS level structure.
-void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int leafSize, MfSymbolic& out);
+// withEntryDestinations = false: aDst / aFront are left empty (the numeric phase computes them on the device from the pattern it is handed, MfNumeric::setup)
+void mf_analyze(int n, const int* ia, const int* ja, const double* coords, int leafSize, MfSymbolic& out, bool withEntryDestinations = true);
+void mf_entry_destinations(int n, const int* ia, const int* ja, MfSymbolic& sym);
 
 // Multi-GPU: cut the assembly tree below its top separators.  The most expensive subtree that still has children is opened until there are at least `world`
 // subtree roots; those go to the ranks greedily by factorisation cost (largest first, least-loaded rank), every front below a root inherits its rank,

@@ -205,6 +205,13 @@ class Context:
         self._chk(self._L.ipcgpu_linsys_exchange_stats(self.h, _dp(o)))
         return dict(sent_bytes=int(o[0]), received_bytes=int(o[1]), calls=int(o[2]))
 
+    def entry_destinations(self):
+        """per CSR entry its slot in the front buffer as the set-up's device kernel computed it (ipcgpu_linsys_entry_destinations)"""
+        rows, nnz = self.get_dims()
+        out = np.zeros(nnz, dtype=np.int64)
+        self._chk(self._L.ipcgpu_linsys_entry_destinations(self.h, out.ctypes.data_as(C.POINTER(C.c_longlong))))
+        return out
+
     def solver_shard_stats(self):
         o = np.zeros(2)
         self._chk(self._L.ipcgpu_linsys_shard_stats(self.h, _dp(o)))

@@ -279,3 +279,33 @@ def test_full_size_properties_mat150(gpu_lib):
     x = c.solve(b)
     assert np.linalg.norm(c.multiply(x) - b) <= 1e-9 * np.linalg.norm(b)
     c.close()
+
+
+def test_entry_destinations_on_the_device_equal_the_host_function(gpu_lib):
+    """Round 5: the slot of every entry of the user's matrix in the front buffer is computed by a device kernel in the solver's set-up (k_entry_dst,
+    ipc_amd/csrc/mf_numeric.hip) instead of on the host.  The host function it replaced, mf_entry_destinations (mf_symbolic.cpp, reached through the
+    test shim tests/mf_symbolic/shim.cpp and itself pinned on a Python restatement in tests/test_mf_symbolic.py), must give the same numbers, bit for
+    bit -- on a plain mesh pattern and on a pattern with contact pairs between two sheets."""
+    import ctypes as C
+    from test_mf_symbolic import analyze
+    from test_sharding_gloo import _shim_lib
+    shim = _shim_lib()
+    for contact in (False, True):
+        V, F, nA = scene.make_mat_stack(24, 2, gap=1.2e-3)
+        c = gpu_lib.Context(0)
+        c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+        c.opt_init(0.01, False)
+        if contact:
+            top = np.where((np.arange(V.shape[0]) < nA) & (V[:, 1] > V[:nA, 1].mean()))[0]
+            bot = np.where((np.arange(V.shape[0]) >= nA) & (V[:, 1] < V[nA:, 1].mean()))[0]
+            k = min(len(top), len(bot))
+            c.set_pattern(np.stack([top[:k], bot[:k]], 1).astype(np.int32))
+        else:
+            c.set_pattern()
+        c.analyze_pattern()
+        ia, ja = c.get_pattern()
+        got = c.entry_destinations()
+        o = analyze(shim, np.ascontiguousarray(ia, np.int32), np.ascontiguousarray(ja, np.int32), np.ascontiguousarray(V, np.float64), leaf=12)
+        assert got.shape == o["aDst"].shape and np.array_equal(got, o["aDst"]), int((got != o["aDst"]).sum())
+        assert len(np.unique(got)) == len(got)  # every entry has a slot of its own
+        c.close()
