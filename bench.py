@@ -75,7 +75,7 @@ def pmc_traffic(size):
     """HBM bytes per launch of the assembly kernel as measured with the PMC counters (same workload), or None."""
     here = os.path.dirname(os.path.abspath(__file__))
     path = None
-    for rnd in ("r04", "r03"):  # the newest measurement of this kernel (the patch size changed in round 4)
+    for rnd in ("r05", "r04", "r03"):  # the newest measurement of this kernel (the patch size changed in round 4; round 5 left the kernel alone and measured again)
         name = f"{rnd}_pmc_assembly_traffic.json" if size == 150 else f"{rnd}_pmc_assembly_traffic_mat{size}.json"
         if os.path.exists(os.path.join(here, "profiles", name)):
             path = os.path.join(here, "profiles", name)
@@ -288,9 +288,9 @@ def main():
                 "kernel": "k_assemble_patch<true> (fused NH gradient + PSD-projected Hessian + mass/DBC diagonal -> symmetric-upper CSR, atomic-free)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.size),
-                "traffic_source": "NOT a live counter: read from profiles/r04_pmc_assembly_traffic*.json (r03_* when absent), measured on this kernel with "
+                "traffic_source": "NOT a live counter: read from profiles/r05_pmc_assembly_traffic*.json (r04_*, r03_* when absent), measured on this kernel with "
                                   "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated in-run on a 1 GiB device copy "
-                                  "(tools/pmc_traffic.py, tools/gpu_round4.sh); bytes per launch",
+                                  "(tools/pmc_traffic.py, tools/gpu_round5.sh); bytes per launch",
                 "algorithmic_bytes": bytes_asm, "avg_launch_ms": ms_asm,
                 "measured_stream_copy_GBs": stream_gbs,
             },
