@@ -42,29 +42,97 @@ class DevPtr:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
 
-def gloo_exchange_hook(local_rank):
-    """--single-device-test only: the sharded solver's point-to-point group (ipcgpu_opt_set_exchange) over gloo through a host bounce -- plumbing, not a
-    data path (on real multi-GPU runs the RCCL binding enqueues ncclSend / ncclRecv on the context's stream, include/adapters/ipcgpu_rccl.cpp)."""
+def torch_hooks(local_rank, host_bounce):
+    """The two host-level hooks of the C ABI (ipcgpu_opt_set_allreduce / ipcgpu_opt_set_exchange) on torch.distributed.  The library drains its stream before it
+    calls them and expects the data in place when they return.  host_bounce = True: gloo through host tensors (--single-device-test, plumbing only);
+    False: the process group's RCCL communicator on the device buffers themselves (the fall-back transport of attach_transport)."""
     import torch
     import torch.distributed as dist
+    dev = f"cuda:{local_rank}"
 
-    def xhook(ops):
+    def allreduce(ptr, count, op):
+        t = torch.as_tensor(DevPtr(ptr, count), device=dev)
+        red = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN
+        if host_bounce:
+            h = t.cpu()
+            dist.all_reduce(h, op=red)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=red)
+        torch.cuda.synchronize()
+        return 0
+
+    def exchange(ops):
         reqs, recvs = [], []
         for ptr, count, peer, send in ops:
-            t = torch.as_tensor(DevPtr(ptr, count), device=f"cuda:{local_rank}")
+            t = torch.as_tensor(DevPtr(ptr, count), device=dev)
             if send:
-                reqs.append(dist.P2POp(dist.isend, t.cpu(), peer))
-            else:
+                reqs.append(dist.P2POp(dist.isend, t.cpu() if host_bounce else t, peer))
+            elif host_bounce:
                 h = torch.empty(count, dtype=torch.float64)
                 recvs.append((t, h))
                 reqs.append(dist.P2POp(dist.irecv, h, peer))
+            else:
+                reqs.append(dist.P2POp(dist.irecv, t, peer))
         for r in dist.batch_isend_irecv(reqs):
             r.wait()
         for t, h in recvs:
             t.copy_(h)
         torch.cuda.synchronize()
         return 0
-    return xhook
+    return allreduce, exchange
+
+
+def attach_transport(ctx, args, rank, world, local_rank):
+    """What carries the bytes between the ranks; returns its name (printed in the JSON line as `transport`).
+      * default: RCCL called from C on the context's own stream (include/ipcgpu_rccl.h, include/adapters/ipcgpu_rccl.cpp): rank 0 draws the unique id,
+        torch.distributed is only the bootstrap that carries its 128 bytes; no collective of the data path goes through Python after this.  A ring of
+        ncclSend / ncclRecv (ipcgpu_rccl_selftest_p2p) is pushed through the new communicator before the solver relies on it;
+      * if that fails on ANY rank (agreed by an all-reduce of a flag, so that all ranks take the same branch) and --transport is `auto`: the process group's own
+        RCCL communicator through the host-level hooks -- the same bytes, with a stream drain around every exchange;
+      * --single-device-test: gloo through a host bounce (plumbing check on a one-GPU box)."""
+    import torch
+    import torch.distributed as dist
+    import ipc_amd
+    if args.single_device_test:
+        ar, xc = torch_hooks(local_rank, host_bounce=True)
+        ctx.set_allreduce(ar)
+        ctx.set_exchange(xc)
+        return "gloo through a host bounce (plumbing test)"
+    dev = f"cuda:{local_rank}"
+    if args.transport in ("auto", "rccl"):
+        ok, why = 1, ""
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(ipc_amd.Context.rccl_unique_id()), dtype=torch.uint8))
+        except Exception as e:  # noqa: BLE001 -- the other ranks are waiting in the broadcast: take part in it, report afterwards
+            ok, why = 0, repr(e)
+            idt = torch.zeros(128, dtype=torch.uint8, device=dev)
+        dist.broadcast(idt, 0)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            try:
+                ctx.rccl_attach(rank, world, bytes(idt.cpu().numpy().tobytes()))
+                got = ctx.rccl_selftest_p2p(rank, world)
+                if got != float((rank + world - 1) % world + 1):
+                    raise RuntimeError(f"ring self-test: received {got} from rank {(rank + world - 1) % world}")
+            except Exception as e:  # noqa: BLE001
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return "RCCL from C on the context's stream (ncclAllReduce; ncclSend / ncclRecv groups)"
+        if why:
+            print(f"[bench] rank {rank}: RCCL binding not usable: {why}", file=sys.stderr, flush=True)
+        if args.transport == "rccl":
+            raise SystemExit("--transport rccl: the RCCL binding failed on at least one rank")
+        ctx.rccl_detach()
+    ar, xc = torch_hooks(local_rank, host_bounce=False)
+    ctx.set_allreduce(ar)
+    ctx.set_exchange(xc)
+    return "torch.distributed nccl backend through the host-level hooks (stream drained around every exchange)"
 
 
 # (rounds 2-3 switched the sharded assembly on only from 4 M tets: its partial matrices were summed by an all-reduce of the CSR values.  Round 4: with the solver
@@ -111,6 +179,9 @@ def main():
                     help="N > 1: subtree-sharded factorisation and solves (ipcgpu_linsys_set_shard); off = every rank repeats the whole solve")
     ap.add_argument("--single-device-test", action="store_true",
                     help="plumbing check on a one-GPU box: all ranks on cuda:0, collectives over gloo through a host bounce (numbers are meaningless)")
+    ap.add_argument("--transport", choices=["auto", "rccl", "torch"], default="auto",
+                    help="N > 1: rccl = RCCL called from C on the context's stream (include/ipcgpu_rccl.h); torch = the process group's communicator through the "
+                         "host-level hooks; auto = rccl, torch if the binding fails on any rank (attach_transport)")
     ap.add_argument("--shard", choices=["auto", "on", "off"], default="auto",
                     help="N > 1: shard the element assembly over the ranks (all-reduce of gradient + CSR values per iteration); "
                          "auto = only when the mesh is big enough for that to pay (see DESIGN.md section 6)")
@@ -143,30 +214,11 @@ def main():
     # the nodal gradient, scalars, and the solver's update matrices / vectors above its cut -- no CSR value.  --shard off / --solver-shard off are A/B switches.
     solver_sharded = distributed and args.solver_shard == "on"
     sharded = distributed and (args.shard == "on" or (args.shard == "auto" and solver_sharded))
+    transport = None
     if distributed:
-        def hook(ptr, count, op):
-            t = torch.as_tensor(DevPtr(ptr, count), device=f"cuda:{local_rank}")
-            if args.single_device_test:  # gloo works on host tensors
-                h = t.cpu()
-                dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
-                t.copy_(h)
-            else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
-            torch.cuda.synchronize()
-            return 0
         if sharded:
-            ctx.set_shard(rank, world)  # element assembly split over the ranks, gradient / CSR values all-reduced
-        if args.single_device_test:
-            ctx.set_allreduce(hook)  # gloo through a host bounce: plumbing only
-            ctx.set_exchange(gloo_exchange_hook(local_rank))
-        else:
-            # RCCL called from C on the context's own stream (include/ipcgpu_rccl.h): rank 0 draws the unique id, torch.distributed is
-            # only the bootstrap that carries its 128 bytes; no collective of the data path goes through Python after this
-            idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
-            if rank == 0:
-                idt.copy_(torch.frombuffer(bytearray(ipc_amd.Context.rccl_unique_id()), dtype=torch.uint8))
-            dist.broadcast(idt, 0)
-            ctx.rccl_attach(rank, world, bytes(idt.cpu().numpy().tobytes()))
+            ctx.set_shard(rank, world)  # elements and contact pairs by node ownership: a rank assembles the rows its fronts read
+        transport = attach_transport(ctx, args, rank, world, local_rank)
         if solver_sharded:
             # the direct solver is what an iteration consists of: the assembly tree is cut below its top separators, every rank
             # factorises / solves its own subtrees, a front above the cut is executed by ONE rank and fed point to point
@@ -270,6 +322,7 @@ def main():
                               "the pivot flag and the solution vector by all-reduce" if solver_sharded else "factorisation and solves repeated on every rank")),
                 "time_steps_completed": state["steps_done"],
             },
+            "transport": transport,
             "comm_per_iter": {"stepper_allreduce_bytes": (comm1["stepper_bytes"] - comm0["stepper_bytes"]) / K,
                               "stepper_allreduce_calls": (comm1["stepper_calls"] - comm0["stepper_calls"]) / K,
                               "solver_bytes_rank0": (comm1["solver_bytes"] - comm0["solver_bytes"]) / K,  # sent + received point to point + all-reduced buffers, this rank
@@ -416,22 +469,7 @@ def large_workload(args, rank, local_rank, world, torch, dist, ipc_amd):
     sharded = args.shard == "on" or (args.shard == "auto" and args.solver_shard == "on")
     if sharded:
         ctx.set_shard(rank, world)
-    if args.single_device_test:
-        def hook(ptr, count, op):
-            t = torch.as_tensor(DevPtr(ptr, count), device=f"cuda:{local_rank}")
-            h = t.cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MIN)
-            t.copy_(h)
-            torch.cuda.synchronize()
-            return 0
-        ctx.set_allreduce(hook)
-        ctx.set_exchange(gloo_exchange_hook(local_rank))
-    else:
-        idt = torch.zeros(128, dtype=torch.uint8, device=f"cuda:{local_rank}")
-        if rank == 0:
-            idt.copy_(torch.frombuffer(bytearray(ipc_amd.Context.rccl_unique_id()), dtype=torch.uint8))
-        dist.broadcast(idt, 0)
-        ctx.rccl_attach(rank, world, idt.cpu().numpy().tobytes())
+    attach_transport(ctx, args, rank, world, local_rank)
     if args.solver_shard == "on":
         ctx.set_solver_shard(rank, world)
     ctx.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)

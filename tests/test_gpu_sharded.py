@@ -356,3 +356,29 @@ def test_rccl_over_two_or_more_gpus():
         assert np.array_equal(a["iters"], b["iters"])
         assert np.abs(a["V"] - b["V"]).max() <= 1e-11 * np.abs(a["V"]).max()
         assert b["sent"].sum() == b["received"].sum() > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_at_two_ranks_on_one_device():
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per "GPU"), with --single-device-test so that a one-GPU box can run it:
+    both ranks on cuda:0, the hooks over gloo.  What this pins is everything of the N > 1 bench path except the wire itself: the launch contract (RANK /
+    LOCAL_RANK / WORLD_SIZE from the environment), attach_transport, the sharded set-up, the barrier-bracketed timing with the maximum over ranks, ONE JSON line
+    from rank 0 with the contract's keys, the communication record, and the second (>= 1 M-tet sized in the real run, small here) workload."""
+    import json
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29547",
+           os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--single-device-test", "--size", "60", "--large-size", "80"]
+    r = subprocess.run(cmd, cwd=repo, capture_output=True, text=True, timeout=600, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1e3) < 1e-6 * 1e3
+    assert "gloo" in d["transport"]
+    c = d["comm_per_iter"]
+    assert c["solver_p2p_sent_bytes_rank0"] + c["solver_p2p_received_bytes_rank0"] > 0  # the solver really was sharded: update matrices crossed ranks
+    assert 0.3 < c["rows_assembled_on_rank0"] < 0.8  # owner-computes rows: about half of the matrix each
+    lw = d["large_workload"]
+    assert lw["value"] > 0 and lw["solver_sharded"] and 0.0 < lw["shared_flop_fraction"] < 1.0

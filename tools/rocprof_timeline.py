@@ -14,7 +14,7 @@ def main():
     t0 = seq[0][1]
     prev_end = t0
     for name, st, en, gx, wx in seq:
-        n = name.split("(")[0].split("::")[-1].replace("void ", "")[:22]
+        n = name.replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1].replace("void ", "")[:22]  # kernels live in an anonymous namespace
         print(f"{n:22s} t={(st - t0) / 1e3:8.1f} gap={(st - prev_end) / 1e3:5.1f} dur={(en - st) / 1e3:6.1f} wgs={gx // max(wx, 1)}")
         prev_end = en
 
