@@ -17,9 +17,9 @@ LIB = os.path.join(HERE, "libipcgpu.so")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-SOURCES = ["nh_kernels.hip", "patch_assembly.hip", "hip_contact.hip", "hip_halfspace.hip", "mf_numeric.hip", "hip_linsys.hip", "mf_symbolic.cpp", "hip_mesh.cpp",
+SOURCES = ["nh_kernels.hip", "patch_assembly.hip", "hip_contact.hip", "hip_halfspace.hip", "mf_numeric.hip", "mf_sweeps.hip", "mf_exchange.hip", "hip_linsys.hip", "mf_symbolic.cpp", "hip_mesh.cpp",
            "hip_optimizer.cpp", "msh_io.cpp", "capi.cpp"]
-FMA_OK = {"nh_kernels.hip", "patch_assembly.hip", "mf_numeric.hip"}
+FMA_OK = {"nh_kernels.hip", "patch_assembly.hip", "mf_numeric.hip", "mf_sweeps.hip", "mf_exchange.hip"}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",
          "-Wall", "-Wno-unused-function", f"-I{ROCM}/include", f"-I{os.path.join(HERE, '..', 'include')}"]
 

@@ -133,6 +133,14 @@ private:
     DevBuf<int> nodeExec_; // per permuted node: executing rank
     void allreduceSum(double* dev, long long count);
     void exchange(const std::vector<P2POp>& ops);
+    // mf_exchange.hip: what crosses ranks, per level of the cut
+    void exchangeUpdateMatrices(int level);
+    void exchangeUpdateVectors(int level);
+    void reduceSolution();
+    void allreduceFlag();
+    // mf_sweeps.hip
+    void configureSweepKernels(size_t maxSolveLds, size_t maxBwdLds, size_t maxTriLds);
+    void enqueuePermuteRhs(const double* rhs_dev, hipStream_t st);
     const MfSymbolic* sym_ = nullptr;
     hipStream_t stream_ = nullptr;
     int ns_ = 0, nLevels_ = 0;
