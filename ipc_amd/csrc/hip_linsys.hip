@@ -263,10 +263,9 @@ void HipLinSysSolver::analyze_pattern(const HipMesh* mesh)
         // the analysis wants a numerically valid pair (M, T): use M = I-pattern values, T = identity factor
         hipLaunchKernelGGL(k_set_diag_one, dim3((numRows + 255) / 256), dim3(256), 0, stream, numRows, R.ptrT.p, R.indT.p, R.valT.p);
         hipLaunchKernelGGL(k_set_diag_one, dim3((numRows + 255) / 256), dim3(256), 0, stream, numRows, R.ptrA.p, R.indA.p, R.valA.p);
-        if (rocsolver_dcsrrf_analysis(R.handle, R.n, 1, R.nnzA, R.ptrA.p, R.indA.p, R.valA.p, R.nnzT, R.ptrT.p, R.indT.p, R.valT.p,
-                nullptr, R.pivQ.p, R.B.p, R.n, R.info)
-            != rocblas_status_success)
-            throw HipError("rocsolver_dcsrrf_analysis failed");
+        const rocblas_status st = rocsolver_dcsrrf_analysis(R.handle, R.n, 1, R.nnzA, R.ptrA.p, R.indA.p, R.valA.p, R.nnzT, R.ptrT.p, R.indT.p, R.valT.p,
+            nullptr, R.pivQ.p, R.B.p, R.n, R.info);
+        if (st != rocblas_status_success) throw HipError("rocsolver_dcsrrf_analysis failed (rocblas_status " + std::to_string((int)st) + ")");
         HIP_CHECK(hipStreamSynchronize(stream));
         R.analyzed = true;
     }
