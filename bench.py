@@ -365,11 +365,6 @@ def main():
                        "factor_ms": f_ms, "solve_ms": s_ms, "factor_gflops_per_s": st["flops"] / 1e9 / (f_ms * 1e-3),
                        "precompute_s": t_pre},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            progress("cpu_baseline (port, all host cores)")
-            out["cpu_baseline"] = cpu_baseline(V, F, left, right, args.cpu_iters)
-            progress("cpu_reference (the reference's sources, all host cores)")
-            out["cpu_reference"] = cpu_reference(V, F)
     ctx.close()
     if rank == 0 and world == 1 and not args.no_contact:
         # the contact half of the path, timed by the same process: two stacked mat100 sheets with self-collision on (barrier terms,
@@ -403,6 +398,14 @@ def main():
             out["roofline_large"] = large_single(args, ipc_amd)
         except Exception as e:  # noqa: BLE001
             out["roofline_large"] = {"value": None, "note": f"not measured: {e!r}"[:300]}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # The CPU baselines come LAST: their thread pools (OpenMP workers of the port, the std::thread pool behind the reference's parallel_for) stay alive in this
+        # process, and with them in the background the host side of the contact sub-record above measured 1.0 ms per iteration slower (symbolic analysis 1.11 -> 1.52,
+        # step bounds 0.63 -> 1.13 ms: profiles/r05_bench_line.json against r05_entry_lists_on_the_device_ab.txt).  Nothing on the GPU runs beside them.
+        progress("cpu_baseline (port, 16 host cores)")
+        out["cpu_baseline"] = cpu_baseline(V, F, left, right, args.cpu_iters)
+        progress("cpu_reference (the reference's sources, 16 threads)")
+        out["cpu_reference"] = cpu_reference(V, F)
     if distributed and args.large_size and args.size != args.large_size:
         # a second, >= 1 M-tet strong-scaling point for the curve (mat150's 2.9 ms iteration is mostly the dependent pivot chain of
         # its top separators, which does not shard): same script, same measurement, fewer steps
