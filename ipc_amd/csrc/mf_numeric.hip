@@ -408,6 +408,20 @@ constexpr int FUSED_MAX_KIDS = FUSED_MAX_KIDS_EA;
 //   [0,1] front offset  [2] N  [3] nc  [4,5] first dinv block  [6] aBeg  [7] aEnd  [8] #children
 //   child q at 16 + 6 q: [0,1] front offset  [2] N  [3] nc  [4] offset of its inverse map
 constexpr int FD_STRIDE = FD_STRIDE_EA;
+// Diagnosis build only (-DMF_FUSED_PROBE, tools/gpu_r5_call11.sh): thread 0 of every fused front stamps the phases of its workgroup with the 100 MHz wall clock;
+// MfNumeric::factorize prints the level averages once.  Expands to nothing in the product build.
+#ifndef MF_FUSED_SCHUR_GROUP
+#define MF_FUSED_SCHUR_GROUP 2 // Schur tiles a wave of the fused kernel gathers together (see the end of k_front_fused; 1 tile, 1 child at a time: 423.2, 2: 425.3, 4: 422.7 it/s)
+#endif
+#ifdef MF_FUSED_PROBE
+__device__ unsigned long long g_probe[16 << 16];
+__device__ const int* g_probeBase;
+#define MF_PROBE(slot) do { if (tid == 0) g_probe[16 * probeId + (slot)] = wall_clock64(); } while (0)
+#define MF_PROBE_ACC(var) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); var += now_ - probeLast; probeLast = now_; } } while (0)
+#else
+#define MF_PROBE(slot) do {} while (0)
+#define MF_PROBE_ACC(var) do {} while (0)
+#endif
 template <int NT>
 __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ fdesc, const int* __restrict__ invMap,
     const int* __restrict__ aLoc, const double* __restrict__ aP, double* __restrict__ fronts,
@@ -425,6 +439,16 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
     const int aBeg = fd[6], aEnd = fd[7];
     int* cm = reinterpret_cast<int*>(P + (size_t)nc * N);
     bool bad = false;
+#ifdef MF_FUSED_PROBE
+    const long long probeId = ((fdesc - g_probeBase) / FD_STRIDE + blockIdx.x) & 0xffff;
+    unsigned long long probeLast = 0, probePivot = 0, probeRows = 0, probeTrail = 0, probeGather = 0, probeTiles = 0;
+    if (tid == 0) {
+        g_probe[16 * probeId + 12] = N;
+        g_probe[16 * probeId + 13] = nc;
+        g_probe[16 * probeId + 14] = nk;
+    }
+#endif
+    MF_PROBE(0);
     // ---- index maps of the children
     for (int q = 0; q < nk; ++q) {
         const int* inv = invMap + fd[16 + 6 * q + 4];
@@ -436,6 +460,7 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
         }
     }
     __syncthreads();
+    MF_PROBE(1);
     // ---- own columns: children sums (lower triangle), zeros above the diagonal.  The loads are unconditional (clamped
     // address, value selected afterwards) so that all of them are in flight together.
     // Two columns per wave and round, the children two at a time: 16 loads in flight (one column and one child per round was a
@@ -477,6 +502,7 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
         }
     }
     __syncthreads();
+    MF_PROBE(2);
     // ---- entries of A (every destination is distinct)
     // aP: the values of A gathered into front order (k_gather_a); four (location, value) pairs requested per round
     for (int e0 = aBeg; e0 < aEnd; e0 += 4 * NT) {
@@ -493,6 +519,10 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
             if (e0 + u * NT + tid < aEnd) P[loc[u]] += av[u];
     }
     __syncthreads();
+    MF_PROBE(3);
+#ifdef MF_FUSED_PROBE
+    probeLast = wall_clock64();
+#endif
 
     // ---- factor the nc columns, 32 at a time, right-looking inside LDS
     for (int kb = 0; kb < nc; kb += NB, dblk += NB * NB) {
@@ -506,6 +536,7 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();
+        MF_PROBE_ACC(probePivot);
         for (int e = tid; e < NB * NB; e += NT) dblk[e] = Xs[(e >> 5) * LDX + (e & 31)]; // column-major, identity-padded
         // rows below the pivot block: L21 = A21 L11^-T, formed transposed per 16-row tile on the matrix cores, in place in LDS:
         //   D(n, m) = sum_k X(n, k) A21(m, k)     A[i = l & 15][kk = l >> 4] = X(n, k) (LDS), B[kk][j] = P[(kb + k) N + row m]
@@ -542,6 +573,7 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
             }
         }
         __syncthreads();
+        MF_PROBE_ACC(probeRows);
         // the own columns to the right of this panel (rows >= column): 4 x 4 register tiles, operands and result in LDS
         const int c0 = kb + w;
         if (c0 < nc) {
@@ -581,68 +613,136 @@ __global__ __launch_bounds__(NT, 3) void k_front_fused(const int* __restrict__ f
             }
             __syncthreads();
         }
+        MF_PROBE_ACC(probeTrail);
     }
+    MF_PROBE(4);
     // ---- the factor panel goes to HBM once (the solves read it)
     for (int J = wv; J < nc; J += NT / 64)
         for (int I = J + lane; I < N; I += 64) F[I + (long long)N * J] = P[J * N + I];
+    MF_PROBE(5);
     // ---- Schur complement: S = (children) - L21 L21^T, written once.  Round 5: 16 x 16 tiles on the matrix cores, one tile per wave at a time, operands
     // straight from the panel in LDS (a lane's A / B entry: 16 consecutive rows of one column of P -- conflict-free unless N is a multiple of 32).  As 4 x 4
     // register tiles per thread (rounds 1-4) this block was bound by its LDS reads -- eight ds_read_b64 per sixteen multiply-adds: 18 us for a front of
     // 250 rows and 60 columns, most of what a workgroup of the levels just below the batched ones took.  v_mfma_f64_16x16x4_f64: A[l & 15][l >> 4] =
     // L(j0 + (l & 15), k), B[l >> 4][l & 15] = L(i0 + (l & 15), k); D register r of lane l = S(i0 + (l & 15), j0 + (l >> 4) + 4 r): the 16 lanes of an
     // accumulator row store 16 consecutive rows of one column, 128 contiguous bytes.
+    // Tiles go through a wave SG at a time: the gathers of SG tiles and of two children are requested together, then summed child by child in the order they always
+    // were (bit-identical sums), then the SG products, then the stores.  Round 5, after the phase probe of the kernel (-DMF_FUSED_PROBE, profiles/r05_fused_front_phases.txt):
+    // the Schur block is 16-27 us of the 29-43 us a front of levels 1-3 takes, and 9-12 us of that are these gathers WHATEVER their grouping -- four times fewer dependent
+    // rounds took four times as long each: the phase is bound by what one CU can pull through its L1 (three fronts share it: ~27 KB of children per front, touched as
+    // partially used 128-byte lines), not by the latency of a round.  Groups of two are the measured optimum (fewer registers than four, fewer rounds than one).
     {
         const int mt = N - nc;
         const int nt16 = (mt + 15) >> 4;
+        const int nTiles = nt16 * (nt16 + 1) / 2;
         const int lo = lane & 15, hi = lane >> 4;
         const int ksteps = (nc + 3) >> 2;
-        for (int t = wv; t < nt16 * (nt16 + 1) / 2; t += NT / 64) {
-            int tr = 0; // tile (tr, tc), tc <= tr, number t of the lower triangle row by row
-            while ((tr + 1) * (tr + 2) / 2 <= t) ++tr;
-            const int tc = t - tr * (tr + 1) / 2;
-            const int i0 = nc + 16 * tr, j0 = nc + 16 * tc;
-            const int row = i0 + lo;
-            // children first: their loads are in flight while the panel product runs
-            double ch[4] = { 0.0, 0.0, 0.0, 0.0 };
-            for (int q = 0; q < nk; ++q) {
-                const double* Fc = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * q);
-                const long long Nc = fd[16 + 6 * q + 2];
-                const int* m = cm + q * N;
-                const int rr = (row < N) ? m[row] : -1;
+        constexpr int SG = MF_FUSED_SCHUR_GROUP, NW = NT / 64;
+        for (int tb = wv; tb < nTiles; tb += NW * SG) {
+            int i0[SG], j0[SG];
+            bool live[SG];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = j0 + hi + 4 * r;
-                    const int cc = (j < N) ? m[j] : -1;
-                    const bool ok = rr >= 0 && cc >= 0 && rr >= cc;
-                    const double x = Fc[ok ? rr + Nc * cc : 0];
-                    ch[r] += ok ? x : 0.0;
+            for (int u = 0; u < SG; ++u) {
+                const int t = tb + u * NW;
+                live[u] = t < nTiles;
+                const int tt = live[u] ? t : tb;
+                int tr = (int)((sqrtf(8.0f * (float)tt + 1.0f) - 1.0f) * 0.5f); // tile (tr, tc), tc <= tr, number tt of the lower triangle row by row
+                while (tr * (tr + 1) / 2 > tt) --tr;
+                while ((tr + 1) * (tr + 2) / 2 <= tt) ++tr;
+                const int tc = tt - tr * (tr + 1) / 2;
+                i0[u] = nc + 16 * tr;
+                j0[u] = nc + 16 * tc;
+            }
+#ifdef MF_FUSED_PROBE
+            probeLast = wall_clock64();
+#endif
+            double ch[SG][4];
+#pragma unroll
+            for (int u = 0; u < SG; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ch[u][r] = 0.0;
+            for (int q = 0; q < nk; q += 2) {
+                const bool two = q + 1 < nk;
+                const int qb = two ? q + 1 : q;
+                const double* Fa = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * q);
+                const double* Fb = fronts + *reinterpret_cast<const long long*>(fd + 16 + 6 * qb);
+                const long long Na = fd[16 + 6 * q + 2], Nb = fd[16 + 6 * qb + 2];
+                const int* ma = cm + q * N;
+                const int* mb = cm + qb * N;
+                double xa[SG][4], xb[SG][4];
+                bool oka[SG][4], okb[SG][4];
+#pragma unroll
+                for (int u = 0; u < SG; ++u) {
+                    const int row = i0[u] + lo;
+                    const int ra = (row < N) ? ma[row] : -1, rb = (row < N) ? mb[row] : -1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = j0[u] + hi + 4 * r;
+                        const int ca = (j < N) ? ma[j] : -1, cb = (j < N) ? mb[j] : -1;
+                        oka[u][r] = ra >= 0 && ca >= 0 && ra >= ca;
+                        okb[u][r] = two && rb >= 0 && cb >= 0 && rb >= cb;
+                        xa[u][r] = Fa[oka[u][r] ? ra + Na * ca : 0];
+                        xb[u][r] = Fb[okb[u][r] ? rb + Nb * cb : 0];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SG; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ch[u][r] += oka[u][r] ? xa[u][r] : 0.0;
+                        ch[u][r] += okb[u][r] ? xb[u][r] : 0.0;
+                    }
+            }
+#ifdef MF_FUSED_PROBE
+            if (tid == 0) { // the gathers are waited for here (in the product build they would be waited for inside the sums above)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long now_ = wall_clock64();
+                probeGather += now_ - probeLast;
+                probeLast = now_;
+            }
+#endif
+#pragma unroll
+            for (int u = 0; u < SG; ++u) {
+                if (!live[u]) continue; // wave-uniform
+                const int row = i0[u] + lo;
+                f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
+                const double* pa = P + min(j0[u] + lo, N - 1); // rows past the end of the front are clamped: their products land in entries that are never written
+                const double* pb = P + min(row, N - 1);
+                for (int ks0 = 0; ks0 < ksteps; ks0 += 4) { // four k-steps at a time: their eight LDS reads are in flight before the first product
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int k = 4 * (ks0 + v) + hi;
+                        const size_t off = (size_t)min(k, nc - 1) * N;
+                        av[v] = pa[off];
+                        bv[v] = pb[off];
+                    }
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((4 * (ks0 + v) + hi < nc) ? av[v] : 0.0, bv[v], acc, 0, 0, 0);
+                }
+                if (row < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = j0[u] + hi + 4 * r;
+                        if (j < N && row >= j) F[row + (long long)N * j] = ch[u][r] - acc[r];
+                    }
                 }
             }
-            f64x4 acc = { 0.0, 0.0, 0.0, 0.0 };
-            const double* pa = P + min(j0 + lo, N - 1); // rows past the end of the front are clamped: their products land in entries that are never written
-            const double* pb = P + min(row, N - 1);
-            for (int ks0 = 0; ks0 < ksteps; ks0 += 4) { // four k-steps at a time: their eight LDS reads are in flight before the first product
-                double av[4], bv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int k = 4 * (ks0 + u) + hi;
-                    const size_t off = (size_t)min(k, nc - 1) * N;
-                    av[u] = pa[off];
-                    bv[u] = pb[off];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64((4 * (ks0 + u) + hi < nc) ? av[u] : 0.0, bv[u], acc, 0, 0, 0);
-            }
-            if (row < N) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int j = j0 + hi + 4 * r;
-                    if (j < N && row >= j) F[row + (long long)N * j] = ch[r] - acc[r];
-                }
-            }
+            MF_PROBE_ACC(probeTiles);
         }
     }
     if (bad) atomicOr(flag, 1);
+#ifdef MF_FUSED_PROBE
+    __syncthreads();
+    MF_PROBE(6);
+    if (tid == 0) {
+        g_probe[16 * probeId + 8] = probePivot;
+        g_probe[16 * probeId + 9] = probeRows;
+        g_probe[16 * probeId + 10] = probeTrail;
+        g_probe[16 * probeId + 11] = probeGather;
+        g_probe[16 * probeId + 15] = probeTiles;
+    }
+#endif
 }
 
 // Schur complement of a big front in one pass: S(i, j) -= sum_{c < nc} L(i, c) L(j, c) for i, j >= nc.  Doing this per
@@ -2022,6 +2122,34 @@ bool MfNumeric::factorize(const double* a_dev)
     }
     hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(1), 0, stream_, flag_.p, hflag_.dev); // mapped pinned memory: no blit
     HIP_CHECK(hipStreamSynchronize(stream_));
+#ifdef MF_FUSED_PROBE
+    {
+        static int calls = 0;
+        if (++calls == 3) { // a warm one
+            std::vector<unsigned long long> h(16 << 16);
+            HIP_CHECK(hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_probe), h.size() * sizeof(unsigned long long)));
+            const char* names[7] = { "maps", "children", "A", "panels", "store", "schur", "total" };
+            for (int l = 0; l < nLevels_; ++l) {
+                const LevelPlan& P = plan_[l];
+                if (!P.small.cnt) continue;
+                double sum[16] = { 0 }, mx = 0;
+                for (int b = 0; b < P.small.cnt; ++b) {
+                    const unsigned long long* r = h.data() + 16 * (size_t)((P.small.off + b) & 0xffff);
+                    for (int k = 0; k < 6; ++k) sum[k] += (double)(r[k + 1] - r[k]);
+                    sum[6] += (double)(r[6] - r[0]);
+                    mx = std::max(mx, (double)(r[6] - r[0]));
+                    for (int k = 8; k < 16; ++k) sum[k] += (double)r[k];
+                }
+                const double c = 0.01 / P.small.cnt; // 100 MHz ticks -> us, averaged
+                std::fprintf(stderr, "[fused probe] level %d: %d fronts, %d threads, N %.0f nc %.0f kids %.1f |", l, P.small.cnt, P.smallThreads, sum[12] / P.small.cnt, sum[13] / P.small.cnt,
+                    sum[14] / P.small.cnt);
+                for (int k = 0; k < 7; ++k) std::fprintf(stderr, " %s %.2f", names[k], sum[k] * c);
+                std::fprintf(stderr, " us (max %.2f) | inside panels: pivot %.2f rows %.2f trailing %.2f | inside schur (wave 0): gathers %.2f products + stores %.2f\n", mx * 0.01, sum[8] * c, sum[9] * c,
+                    sum[10] * c, sum[11] * c, sum[15] * c);
+            }
+        }
+    }
+#endif
     return pivotsOk();
 }
 
@@ -2062,6 +2190,12 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
     if (sidePending_) HIP_CHECK(hipStreamWaitEvent(stream_, evSide_, 0)); // the side stream still reads the previous factor
     bool sideUsed = false;
     int fwdNext = 0; // first level not yet handed to the forward stream
+#ifdef MF_FUSED_PROBE
+    {
+        const int* base = fdesc_.p;
+        HIP_CHECK(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_probeBase), &base, sizeof(base), 0, hipMemcpyHostToDevice, stream_));
+    }
+#endif
     if (nFusedA_) hipLaunchKernelGGL(k_gather_a, dim3((nFusedA_ + 255) / 256), dim3(256), 0, stream_, nFusedA_, aSrc_.p, a_dev, aPerm_.p, flag_.p);
     else flag_.zero(stream_);
     for (int l = 0; l < nLevels_; ++l) {
