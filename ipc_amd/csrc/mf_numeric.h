@@ -96,6 +96,7 @@ private:
         Range ea; // extend-add descriptors
         Range bigFronts; // into bigList_
         std::vector<Range> step; // fused factor steps: launch 0 factors panel 0, launch j+1 applies panel j / factors j+1
+        std::vector<Range> bulk; // per step launch: the bulk updates of the wide fronts that follow it (k_big_bulk; empty ranges elsewhere)
         Range schur; // one-pass Schur complement tiles of the big fronts
         bool schur64 = false; // ... as 64 x 64 tiles (k_big_schur64) instead of 32 x 32 with the columns split over the waves
         bool stepTop = false; // the level's step launches carry role C, the explicit inverse growing by bordering (k_big_step<true>)
@@ -106,6 +107,8 @@ private:
     };
     int rank_ = 0, world_ = 1;
     long long schur64Min_ = 512;
+    double bulkMinMB_ = 48.0; // levels whose step launches read + write at least that many MB of own columns factor them in outer blocks (two-level blocking, k_big_bulk); IPCGPU_MF_BULK_MIN_MB
+    int bulkBlock_ = 256; // width of an outer block; IPCGPU_MF_BULK_BLOCK
     bool xinvBorder_ = true; // X = L11^-1 by bordering inside the step launches (IPCGPU_MF_XINV_BORDER=0: recursive doubling on the side stream)
     AllreduceFn allreduce_ = nullptr;
     AllreduceStreamFn allreduceStream_ = nullptr;

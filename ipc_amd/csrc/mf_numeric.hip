@@ -863,16 +863,17 @@ constexpr int TQ64 = 64;
 // LOAD_OLD = false: `old` arrives filled (the children's sums gathered by the caller: k_big_schur64_ea) and the tile is WRITTEN, not read-modify-written.
 // (Round 5: parking `old` in LDS over the product loop -- 32 registers less, a third wave per SIMD -- changed nothing, measured at 45 K and 375 K nodes:
 // the kernel is not occupancy-bound.  profiles/r05_solver_ab_xcd_occupancy.txt.)
+// orig: first row / column of tile (0, 0); colEnd: columns from here on are not this pass's (the Schur passes: orig = nc, colEnd = N; the bulk update of the wide
+// fronts' own columns, k_big_bulk: orig = the end of the outer block, colEnd = nc); [cLo, nc): the columns of L of this pass.
 template <bool LOAD_OLD>
-__device__ __forceinline__ void schur_tile64_core(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi,
-    double (&old)[2][2][4])
+__device__ __forceinline__ void schur_tile64_core(const int N, const int orig, const int colEnd, const int nc, double* __restrict__ F, const int ti, const int tj,
+    const int cLo, double (&old)[2][2][4])
 {
-    const int nc = min(ncAll, cHi);
     if (cLo >= nc) return;
     const int tid = threadIdx.x;
     const int wv = tid >> 6, l = tid & 63;
-    const int i0 = ncAll + TQ64 * ti + 32 * (wv & 1), j0 = ncAll + TQ64 * tj + 32 * (wv >> 1); // this wave's quadrant (behind ALL own columns; nc is the end of this pass)
-    if (i0 + 31 < j0 || i0 >= N || j0 >= N) return; // entirely above the diagonal (the upper right quadrant of a diagonal tile) or outside
+    const int i0 = orig + TQ64 * ti + 32 * (wv & 1), j0 = orig + TQ64 * tj + 32 * (wv >> 1); // this wave's quadrant
+    if (i0 + 31 < j0 || i0 >= N || j0 >= colEnd) return; // entirely above the diagonal (the upper right quadrant of a diagonal tile) or outside
     const int ar = l & 15, ak = l >> 4;
     if (LOAD_OLD) {
 #pragma unroll
@@ -938,20 +939,37 @@ __device__ __forceinline__ void schur_tile64_core(const int N, const int ncAll, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int col = j0 + 16 * nj + ak + 4 * r;
-                if (col < N && row < N && row >= col) F[row + (long long)N * col] = old[nj][mi][r] - acc[nj][mi][r];
+                if (col < colEnd && row < N && row >= col) F[row + (long long)N * col] = old[nj][mi][r] - acc[nj][mi][r];
             }
         }
 }
 __device__ __forceinline__ void schur_tile64(const int N, const int ncAll, double* __restrict__ F, const int ti, const int tj, const int cLo, const int cHi)
 {
     double old[2][2][4];
-    schur_tile64_core<true>(N, ncAll, F, ti, tj, cLo, cHi, old);
+    schur_tile64_core<true>(N, ncAll, N, min(ncAll, cHi), F, ti, tj, cLo, old);
 }
 __global__ __launch_bounds__(WG, MF_SCHUR_OCC) void k_big_schur64(const int4* __restrict__ desc, double* __restrict__ fronts)
 {
     const int4 d = desc[2 * blockIdx.x];
     const int4 d2 = desc[2 * blockIdx.x + 1];
     schur_tile64(d2.x, d2.y, fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z), d.y, d.z, 0, 1 << 30);
+}
+
+// Two-level blocking of the WIDE fronts (round 5; nc >= bulkMinNc_, the top separators of meshes beyond ~200 K nodes).  A step launch applies its panel as a rank-32
+// update -- 2.7 flops per byte of the trailing matrix it reads and writes -- and did so to ALL own columns behind the panel: at 375 K nodes the step launches ran at 12 %
+// of the fp64 peak and were half of the factorisation.  Here the own columns go in outer blocks of OBW: a step's rank-32 update stops at the end of its outer block
+// (role A records carry that end in place of nc), and when the block's last panel is final ONE launch of this kernel applies all OBW columns of the block to the own
+// columns behind it, rows down to N -- the Schur kernel's 64 x 64 tile product over a column range, eight times the flops per byte.  The panel that opens the next block
+// then has nothing left to apply (role B, kb <= -2).  desc = (OBW, cLo, ti, tj) + (N, nc, front offset): tile (ti, tj) counted from E = min(nc, cLo + OBW).
+// Which fronts: those of a level whose step launches move enough bytes for this to pay (setup(): bulkMinMB_), not the lone root of a small mesh -- there the
+// extra launches on the chain cost more than the traffic they save (45 K nodes: 1.84 -> 1.88 ms with the root's 900 columns in blocks).
+__global__ __launch_bounds__(WG, MF_SCHUR_OCC) void k_big_bulk(const int4* __restrict__ desc, double* __restrict__ fronts)
+{
+    const int4 d = desc[2 * blockIdx.x];
+    const int4 d2 = desc[2 * blockIdx.x + 1];
+    const int N = d2.x, nc = d2.y, E = min(nc, d.y + d.x);
+    double old[2][2][4];
+    schur_tile64_core<true>(N, E, nc, E, fronts + (((long long)(unsigned)d2.w << 32) | (unsigned)d2.z), d.z, d.w, d.y, old);
 }
 
 // The same with the EXTEND-ADD of the update block fused in (round 4): S = (children) - L21 L21^T written once.  The extend-add kernel of such a level
@@ -1024,7 +1042,7 @@ __global__ __launch_bounds__(WG) void k_big_schur64_ea(const int4* __restrict__ 
             }
         }
     }
-    if (active) schur_tile64_core<false>(N, nc, F, d.y, d.z, 0, 1 << 30, old);
+    if (active) schur_tile64_core<false>(N, nc, N, nc, F, d.y, d.z, 0, old);
 }
 
 
@@ -1186,9 +1204,9 @@ __device__ __forceinline__ void step_work(const int wg, const int4 d, const int4
         step_border<16, true>(d, d2, tv, xv, F, dinv, sm);
         return;
     }
-    const int kb = d.y;
+    const int kb = d.y; // >= 0: the panel to apply; -1: none, the next panel is the first; <= -2: none (the bulk update of its outer block did it), the next panel starts at -kb - 2
     const int w = (kb >= 0) ? min(NB, nc - kb) : 0;
-    const int kb1 = (kb >= 0) ? kb + w : 0;
+    const int kb1 = (kb >= 0) ? kb + w : (kb == -1 ? 0 : -kb - 2);
     const int w1 = (kb1 < nc) ? min(NB, nc - kb1) : 0;
     if (d.w >= 0) {
         // ---- role A: F[i0.., j0..] -= P_kb[i0..] P_kb[j0..]^T behind the next panel, own columns (< nc) only.
@@ -1589,6 +1607,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
     size_t fusedLds = 64 * 1024;
     schur64Min_ = 512; // levels with at least this many 32 x 32 Schur tiles take the 64 x 64 kernel (k_big_schur64); IPCGPU_MF_SCHUR64_MIN=0 always, huge never
     if (const char* e = std::getenv("IPCGPU_MF_SCHUR64_MIN")) schur64Min_ = std::atoll(e);
+    bulkMinMB_ = 48.0; // swept at 375 K nodes: 4, 16, 64 MB the same (factorisation 17.58 -> 16.9 ms); the contact stack's two top levels (11 and 17 MB) are better off without
+    bulkBlock_ = 256; // 128: the same, 512: half the gain (profiles/r05_two_level_blocking_ab.txt)
+    if (const char* e = std::getenv("IPCGPU_MF_BULK_MIN_MB")) bulkMinMB_ = std::atof(e); // (huge: every front updates all its own columns step by step, as before round 5)
+    if (const char* e = std::getenv("IPCGPU_MF_BULK_BLOCK")) bulkBlock_ = std::max(64, (std::atoi(e) / 32) * 32);
     if (const char* e = std::getenv("IPCGPU_MF_FUSED_KB")) fusedLds = (size_t)std::max(8, std::min(150, std::atoi(e))) * 1024;
     auto ldsOf = [&](int s) {
         const size_t kids = (size_t)(sym.childPtr[s + 1] - sym.childPtr[s]);
@@ -1819,6 +1841,12 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
         int steps = 0;
         for (int s : big) steps = std::max(steps, (sym.nc(s) + NB - 1) / NB);
         P.step.assign(big.empty() ? 0 : steps + 1, Range());
+        P.bulk.assign(P.step.size(), Range());
+        // two-level blocking (k_big_bulk) for the fronts of this level?  What a step launch's rank-32 update reads and writes: the own columns of every front, all rows
+        const int OBW = bulkBlock_;
+        double stepMB = 0.0;
+        for (int s : big) stepMB += 8.0e-6 * (double)sym.N(s) * sym.nc(s);
+        const bool levelWide = stepMB >= bulkMinMB_;
         for (int j = -1; j < steps && !big.empty(); ++j) {
             Range& R = P.step[j + 1];
             R.off = (int)desc.size();
@@ -1831,9 +1859,14 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
                 const int w1 = (kb1 < nc) ? std::min(NB, nc - kb1) : 0;
                 const long long foff = sym.frontOff[s];
                 const int4 rec2 = make_int4(N, nc, (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
+                // wide fronts (two-level blocking, k_big_bulk): E = the end of the outer block panel kb belongs to; when the next panel opens a new block, the
+                // bulk update launched in front of this step has applied panel kb already
+                const bool wide = levelWide && nc >= 2 * OBW;
+                const int E = (wide && j >= 0) ? std::min(nc, (kb / OBW + 1) * OBW) : nc;
+                const bool applied = wide && j >= 0 && kb1 >= E && kb1 < nc;
                 if (w1 > 0)
                     for (int r0 = 0; r0 < N - kb1; r0 += ROWS_B) {
-                        desc.push_back(make_int4((int)hDinvOff_[s], j >= 0 ? kb : -1, r0, -2));
+                        desc.push_back(make_int4((int)hDinvOff_[s], j < 0 ? -1 : (applied ? -2 - kb1 : kb), r0, -2));
                         desc.push_back(rec2);
                     }
                 if (j >= 0 && hasBorder(s)) { // role C: the rows of panel j of X = L11^-1, one workgroup per column tile up to the diagonal block
@@ -1844,18 +1877,37 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
                         desc.push_back(rec2);
                     }
                 }
-                if (j >= 0) {
-                    // trailing tiles inside the front's own columns; the Schur complement (columns >= nc) waits for k_big_schur
+                if (j >= 0 && !applied) {
+                    // trailing tiles inside the front's own columns (of a wide front: inside the panel's outer block -- the records carry E in place of nc, which is
+                    // all role A reads nc for); the Schur complement (columns >= nc) waits for k_big_schur
                     const int M0 = kb1 + w1;
-                    const int ntr = (N - M0 + TS - 1) / TS, ntc = (nc - M0 + TS - 1) / TS;
+                    const int ntr = (N - M0 + TS - 1) / TS, ntc = (E - M0 + TS - 1) / TS;
+                    const int4 recA = make_int4(N, E, rec2.z, rec2.w);
                     for (int ti = 0; ti < ntr; ++ti)
                         for (int tj = 0; tj <= ti && tj < ntc; ++tj) {
                             desc.push_back(make_int4((int)hDinvOff_[s], kb, ti, tj));
-                            desc.push_back(rec2);
+                            desc.push_back(recA);
                         }
                 }
             }
             R.cnt = ((int)desc.size() - R.off) / 2; // workgroups: two records each
+            // the bulk updates that have to run BEHIND this launch (it factored panel j + 1): of every wide front whose outer block ends with that panel
+            Range& U = P.bulk[j + 1];
+            U.off = (int)desc.size();
+            for (int s : big) {
+                const int N = sym.N(s), nc = sym.nc(s);
+                const int p0 = (j + 1) * NB, Eb = p0 + NB; // the panel just factored and its end
+                if (!levelWide || nc < 2 * OBW || Eb % OBW != 0 || Eb >= nc) continue;
+                const long long foff = sym.frontOff[s];
+                const int4 rec2 = make_int4(N, nc, (int)(unsigned)(foff & 0xffffffffll), (int)(unsigned)(foff >> 32));
+                const int ntr = (N - Eb + TQ64 - 1) / TQ64, ntc = (nc - Eb + TQ64 - 1) / TQ64;
+                for (int ti = 0; ti < ntr; ++ti)
+                    for (int tj = 0; tj <= ti && tj < ntc; ++tj) {
+                        desc.push_back(make_int4(OBW, Eb - OBW, ti, tj));
+                        desc.push_back(rec2);
+                    }
+            }
+            U.cnt = ((int)desc.size() - U.off) / 2;
         }
         // Schur complement: one pass behind the chain (k_big_schur / k_big_schur64 / k_big_schur64_ea).
         // XCD-aware order (round 5): workgroup b of a launch runs on XCD b % 8 (observed, MI355X_MICROARCH.md; a speed assumption only -- any placement is
@@ -2221,6 +2273,8 @@ void MfNumeric::enqueueFactor(const double* a_dev, bool overlapForward)
             if (!R.cnt) continue;
             if (P.stepTop) hipLaunchKernelGGL(k_big_step<true>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
             else hipLaunchKernelGGL(k_big_step<false>, dim3(R.cnt), dim3(WGB), 0, stream_, desc_.p + R.off, tv, fronts_.p, dinv_.p, flag_.p, xvF);
+            const Range& U = P.bulk[&R - P.step.data()]; // wide fronts: the outer block that ended with this launch's panel goes to the own columns behind it
+            if (U.cnt) hipLaunchKernelGGL(k_big_bulk, dim3(U.cnt), dim3(WG), 0, stream_, desc_.p + U.off, fronts_.p);
         }
         if (P.schur.cnt) {
             if (P.fuseEA) hipLaunchKernelGGL(k_big_schur64_ea, dim3(P.schur.cnt), dim3(WG), 0, stream_, desc_.p + P.schur.off, bigFd_.p, inv_.p, fronts_.p);
