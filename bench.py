@@ -312,14 +312,14 @@ def main():
                 "linear_solver": "gpu-multifrontal-llt" if args.solver == 0 else "rocsolver-csrrf",
                 "parallelism": "single GPU" if world == 1 else (
                     f"{world} GPUs: " + ("owner-computes assembly: a rank assembles the CSR rows of the nodes its subtrees eliminate + the separator rows above "
-                                         "the cut (elements and contact stencils on a cut evaluated by both sides), no matrix value crosses ranks; RCCL all-reduce "
+                                         "the cut (elements and contact stencils on a cut evaluated by both sides), no matrix value crosses ranks; all-reduce "
                                          "of the nodal gradient and of scalars" if sharded and solver_sharded else
                                          ("element-sharded assembly, partial matrices summed by an all-reduce of the CSR values" if sharded else
                                           "assembly repeated on every rank"))
                     + "; " + (f"subtree-sharded multifrontal factorisation and solves: {100 * ctx.solver_shard_stats()['shared_flop_fraction']:.0f} % of the "
                               "factorisation flops lie above the cut (each front there executed by one rank, the ranks below it waiting for its result); update "
-                              "matrices / vectors of children on other ranks and the separators' solution entries go point to point (ncclSend / ncclRecv groups), "
-                              "the pivot flag and the solution vector by all-reduce" if solver_sharded else "factorisation and solves repeated on every rank")),
+                              "matrices / vectors of children on other ranks and the separators' solution entries go point to point (one send / receive group per level of the cut), "
+                              "the pivot flag and the solution vector by all-reduce; what carries the bytes: see `transport`" if solver_sharded else "factorisation and solves repeated on every rank")),
                 "time_steps_completed": state["steps_done"],
             },
             "transport": transport,
