@@ -1090,7 +1090,7 @@ double HipOptimizer::filterStepSize(const double* p_dev, double stepSize)
     // Energy.cpp:565-581: min over elements of the root, applied only when 0 < min < stepSize
     if (mesh.energyType == 1) return stepSize; // :567 needElemInvSafeGuard
     launch_fill(d_scalar.p + 2, 1, 1e20, stream);
-    launch_inversion_step(view(), p_dev, 0.2, d_scalar.p + 2, stream);
+    launch_inversion_step(view(), p_dev, 0.2, stepSize, d_scalar.p + 2, stream);
     reduceMin(d_scalar.p + 2, 1);
     const double t = readScalar(d_scalar.p + 2);
     if (t > 0.0 && t < stepSize) stepSize = t;
@@ -1138,7 +1138,7 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
             // ten launches (fifteen before round 4: the resets, the copy + step-size + step and the two read-backs are one launch each now)
             launch_iter_reset(d_scalar.p, d_flag.p, stream);
             launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
-            if (mesh.energyType != 1) launch_inversion_step(view(), d_searchDir.p, 0.2, d_scalar.p + 2, stream);
+            if (mesh.energyType != 1) launch_inversion_step(view(), d_searchDir.p, 0.2, 1.0, d_scalar.p + 2, stream); // (the trial step starts at 1)
             launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
             launch_trial_step_fused(3 * mesh.nV, mesh.d_x.p, d_x0.p, d_searchDir.p, d_scalar.p + 2, mesh.energyType != 1, d_scalar.p + 6, stream);
             if (mesh.energyType != 1) launch_check_inversion(view(), d_flag.p, stream);
@@ -1185,7 +1185,7 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
         launch_fill(d_scalar.p + 3, 1, 0.0, stream);
         launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
         launch_fill(d_scalar.p + 2, 1, 1e20, stream);
-        if (mesh.energyType != 1) launch_inversion_step(view(), d_searchDir.p, 0.2, d_scalar.p + 2, stream);
+        if (mesh.energyType != 1) launch_inversion_step(view(), d_searchDir.p, 0.2, 1.0, d_scalar.p + 2, stream); // (the trial step starts at 1)
         launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
         launch_publish(d_scalar.p, h_scalar.dev, 8, stream); // 4 doubles = 8 words
         HIP_CHECK(hipStreamSynchronize(stream));

@@ -41,7 +41,8 @@ void launch_energy_per_elem(const ElemView& v, double* perElem, hipStream_t s);
 
 // inversion: flag[0] |= any det < 0 ; step bound: per-shard min written to *outMin (must be preset to +inf bits)
 void launch_check_inversion(const ElemView& v, int* flag, hipStream_t s);
-void launch_inversion_step(const ElemView& v, const double* p, double slackness, double* outMin, hipStream_t s);
+// tMax: roots from there on do not matter to the caller (elements that provably have none below it skip the closed form)
+void launch_inversion_step(const ElemView& v, const double* p, double slackness, double tMax, double* outMin, hipStream_t s);
 
 // nodal vector helpers
 void launch_step_forward(int n3, const double* x0, const double* p, double alpha, double* x, hipStream_t s);
