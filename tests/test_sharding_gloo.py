@@ -176,7 +176,7 @@ def _owner_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_owner_computes_protocol_on_gloo(world):
     _shim_lib()  # built once here, not by the ranks side by side
     ctx = mp.get_context("spawn")
@@ -373,7 +373,7 @@ def _p2p_worker(rank, world, port, out):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_point_to_point_solver_protocol_on_gloo(world):
     _shim_lib()
     ctx = mp.get_context("spawn")
