@@ -149,3 +149,55 @@ def test_analysis_is_reproducible(shim):
     b = analyze(shim, ia, ja, V)
     for k in a:
         assert np.array_equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("world", [2, 3, 5, 6, 8, 16, 64])
+def test_exchange_plans_of_all_ranks_fit_together(shim, world):
+    """The point-to-point plan of the sharded solver (mf_assign_owners -> mf_assign_executors -> mf_exchange_plan, ipc_amd/csrc/mf_symbolic.cpp), every rank's copy
+    side by side -- world sizes the multi-process tests do not reach, odd ones included:
+      * every front has exactly one executor, and it is a member of the front's group; a front below the cut is executed by its owner;
+      * level by level and pair of ranks by pair of ranks, what rank a sends to rank b is what rank b receives from rank a -- same fronts, IN THE SAME ORDER (RCCL
+        matches the sends and receives of a group between two ranks by their order), for the update matrices and for the solution segments;
+      * nobody sends to itself; a child's update travels exactly when its parent is executed elsewhere, and then exactly once."""
+    V, G, ia, ja = stacked_pattern(24, contact=True)
+    o = analyze(shim, ia, ja, V, leaf=12)
+    ns = o["ns"]
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    plans, execs = [], None
+    for rank in range(world):
+        exec_, group, level = np.zeros(ns, np.int32), np.zeros(ns, np.uint64), np.zeros(ns, np.int32)
+        cap = 8 * ns + 64
+        rec = np.zeros(7 * cap, np.int32)
+        n = shim.shim_exchange_plan(C.c_int(world), C.c_int(rank), p(exec_), p(group), p(level), p(rec), C.c_int(cap))
+        assert n >= 0
+        plans.append(rec[: 7 * n].reshape(n, 7).copy())
+        if execs is None:
+            execs, groups, levels = exec_.copy(), group.copy(), level.copy()
+        else:
+            assert np.array_equal(execs, exec_) and np.array_equal(groups, group)  # every rank derives the same assignment
+    owner, nodeOwner = np.zeros(ns, np.int32), np.zeros(o["nn"], np.int32)
+    shim.shim_owners.restype = C.c_double
+    shim.shim_owners(C.c_int(world), p(owner), p(nodeOwner))
+    assert ((execs >= 0) & (execs < world)).all()
+    assert all((int(groups[s]) >> int(execs[s])) & 1 for s in range(ns))
+    below = owner >= 0
+    assert np.array_equal(execs[below], owner[below])
+    parent = o["parent"]
+    # what has to travel: the update of a child whose parent another rank executes
+    must = {(int(s), int(execs[s]), int(execs[parent[s]])) for s in range(ns) if parent[s] >= 0 and execs[parent[s]] != execs[s]}
+    sent = set()
+    for a in range(world):
+        for b in range(world):
+            for ks, kr in ((0, 1), (2, 3)):
+                out = [(int(r[0]), int(r[2])) for r in plans[a] if r[1] == ks and r[6] == b]
+                inn = [(int(r[0]), int(r[2])) for r in plans[b] if r[1] == kr and r[6] == a]
+                assert out == inn, (a, b, ks, out[:5], inn[:5])
+                if a == b:
+                    assert not out
+                if ks == 0:
+                    for lvl, s in out:
+                        assert lvl == levels[s] and (s, a, b) in must and (s, a, b) not in sent
+                        sent.add((s, a, b))
+    assert sent == must
+    if world <= 16:
+        assert len(must) > 0  # the cut is not empty on this pattern
