@@ -7,7 +7,7 @@
 //   closest-feature typing dType_PT / dType_EE   :2160-2210, 2073-2158
 //   C2 clamped log barrier                        BarrierFunctions.hpp:56-83
 //   parallel-edge mollifier                       MeshCollisionUtils.hpp:2834-2866
-//   PSD projection of 6x6 / 9x9 / 12x12 blocks    IglUtils::makePD, IglUtils.hpp:119-137 (cyclic Jacobi)
+//   (the barrier HESSIAN of a stencil and its PSD projection: stencil_hessian_device.h, jacobi9_device.h)
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -389,225 +389,6 @@ __device__ inline double cross_sqnorm_derivs(const double (*X)[3], double* g, do
     const int coef[12] = { 0, 0, 0, 0, -1, 1, 0, 0, 0, 0, -1, 1 };
     expand(4, coef, gq, Hq, g, H);
     return q;
-}
-
-// strided view of a per-thread matrix that lives in LDS (element i of thread t at p[i * stride]: lanes hit distinct banks)
-struct Strided {
-    double* p;
-    int stride;
-    __device__ __forceinline__ double& operator[](int i) const { return p[i * stride]; }
-};
-
-// IglUtils::makePD for an n x n (n <= 12) symmetric matrix stored with leading dimension 12: cyclic Jacobi,
-// untouched when the smallest eigenvalue is >= 0.  Q, W: caller-provided scratch (144 doubles each) -- the two
-// matrices the sweeps iterate on.  In private memory they land in scratch (HBM round trips per access: 57 ms for
-// 28 K stencils); the Hessian kernel therefore hands in `Strided` views of LDS.
-template <class MQ, class MW>
-__device__ inline int make_pd(int n, double* A, MQ Q, MW W)
-{
-    int sweeps = 0;
-    for (int i = 0; i < 144; ++i) {
-        W[i] = A[i];
-        Q[i] = 0.0;
-    }
-    for (int i = 0; i < n; ++i) Q[i + 12 * i] = 1.0;
-    // Stop when the off-diagonal norm is 1e-14 of the diagonal norm: the projected block is compared at 1e-9, and the last
-    // two orders of magnitude cost cyclic Jacobi ~20 extra sweeps on these matrices (three exactly-zero translation modes).
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int j = 0; j < n; ++j)
-            for (int i = 0; i <= j; ++i) {
-                const double v = W[i + 12 * j];
-                if (i != j) off += 2.0 * v * v;
-                else dg += v * v;
-            }
-        if (off <= 1e-28 * dg || off == 0.0) break;
-        ++sweeps;
-        for (int p = 0; p < n - 1; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const double apq = W[p + 12 * q];
-                if (apq == 0.0) continue;
-                const double app = W[p + 12 * p], aqq = W[q + 12 * q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
-                // columns p and q of W and Q go through registers: 48 independent LDS reads in flight instead of a
-                // read-modify-write chain per element; W stays symmetric, so only rows / columns p, q are touched
-                double wp[12], wq[12], qp[12], qq[12];
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    wp[k] = W[k + 12 * p];
-                    wq[k] = W[k + 12 * q];
-                    qp[k] = Q[k + 12 * p];
-                    qq[k] = Q[k + 12 * q];
-                }
-#pragma unroll
-                for (int k = 0; k < 12; ++k) {
-                    const double nkp = c * wp[k] - s * wq[k], nkq = s * wp[k] + c * wq[k];
-                    if (k != p && k != q && k < n) {
-                        W[k + 12 * p] = nkp;
-                        W[p + 12 * k] = nkp;
-                        W[k + 12 * q] = nkq;
-                        W[q + 12 * k] = nkq;
-                    }
-                    Q[k + 12 * p] = c * qp[k] - s * qq[k];
-                    Q[k + 12 * q] = s * qp[k] + c * qq[k];
-                }
-                W[p + 12 * p] = app - t * apq;
-                W[q + 12 * q] = aqq + t * apq;
-                W[p + 12 * q] = 0.0;
-                W[q + 12 * p] = 0.0;
-            }
-    }
-    double wmin = W[0];
-    for (int i = 1; i < n; ++i) wmin = fmin(wmin, W[i + 12 * i]);
-    if (wmin >= 0.0) return sweeps;
-    for (int j = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) {
-            double s = 0.0;
-            for (int k = 0; k < n; ++k) {
-                const double wk = W[k + 12 * k];
-                if (wk > 0.0) s += Q[i + 12 * k] * wk * Q[j + 12 * k];
-            }
-            A[i + 12 * j] = s;
-        }
-    return sweeps;
-}
-
-// The same projection for the Hessian block of a contact stencil of nn = 2..4 nodes, carried out in the orthogonal complement
-// of the three rigid translations.  A stencil energy does not change when all its nodes move together, so B t = 0 for the three
-// translation vectors t and the projection leaves them alone: with R = H (x) I3, H the nn x (nn - 1) Helmert matrix (orthonormal
-// columns, orthogonal to (1, ..., 1)), B = R (R^T B R) R^T and makePD(B) = R makePD(R^T B R) R^T exactly.  The Jacobi sweeps then
-// run on a 3 (nn - 1) matrix -- 9 x 9 instead of 12 x 12: 36 rotations of length 9 per sweep instead of 66 of length 12 -- and
-// without the three exactly-zero eigenvalues that cost cyclic Jacobi most of its sweeps on these blocks.  Q, W: scratch views of 81
-// doubles each (LDS).  A: leading dimension 12, as above.  Returns the number of sweeps.
-template <class MQ, class MW>
-__device__ inline int make_pd_stencil(int nn, double* A, MQ Q, MW W)
-{
-    constexpr int LD = 9;
-    const int m = 3 * (nn - 1);
-    double h[3][4];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double sc = 1.0 / sqrt((double)((a + 1) * (a + 2)));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) h[a][k] = (a + 1 < nn && k < nn) ? (k <= a ? sc : (k == a + 1 ? -(a + 1) * sc : 0.0)) : 0.0;
-    }
-    // C = R^T A R, through D = R^T A (m x 3 nn, kept in Q row by row: only one block row of D is alive at a time)
-    for (int a = 0; a < nn - 1; ++a)
-        for (int i = 0; i < 3; ++i) {
-            double d[12]; // row (3 a + i) of R^T A
-#pragma unroll
-            for (int c = 0; c < 12; ++c) {
-                double v = 0.0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v += h[a][k] * A[(3 * k + i) + 12 * c];
-                d[c] = v;
-            }
-            for (int b = 0; b < nn - 1; ++b)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int l = 0; l < 4; ++l) v += h[b][l] * d[3 * l + j];
-                    W[(3 * a + i) + LD * (3 * b + j)] = v;
-                }
-        }
-    for (int j = 0; j < m; ++j)
-        for (int i = 0; i < m; ++i) Q[i + LD * j] = (i == j) ? 1.0 : 0.0;
-    // symmetrise (the two triangles of C differ by rounding): the sweeps below read and write both
-    for (int j = 0; j < m; ++j)
-        for (int i = 0; i < j; ++i) {
-            const double v = 0.5 * (W[i + LD * j] + W[j + LD * i]);
-            W[i + LD * j] = v;
-            W[j + LD * i] = v;
-        }
-    int sweeps = 0;
-    for (int sweep = 0; sweep < 60; ++sweep) {
-        double off = 0.0, dg = 0.0;
-        for (int j = 0; j < m; ++j)
-            for (int i = 0; i <= j; ++i) {
-                const double v = W[i + LD * j];
-                if (i != j) off += 2.0 * v * v;
-                else dg += v * v;
-            }
-        if (off <= 1e-28 * dg || off == 0.0) break;
-        ++sweeps;
-        for (int p = 0; p < m - 1; ++p)
-            for (int q = p + 1; q < m; ++q) {
-                const double apq = W[p + LD * q];
-                if (apq == 0.0) continue;
-                const double app = W[p + LD * p], aqq = W[q + LD * q];
-                const double theta = (aqq - app) / (2.0 * apq);
-                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
-                double wp[LD], wq[LD], qp[LD], qq[LD];
-#pragma unroll
-                for (int k = 0; k < LD; ++k) {
-                    wp[k] = W[k + LD * p];
-                    wq[k] = W[k + LD * q];
-                    qp[k] = Q[k + LD * p];
-                    qq[k] = Q[k + LD * q];
-                }
-#pragma unroll
-                for (int k = 0; k < LD; ++k) {
-                    if (k >= m) continue;
-                    const double nkp = c * wp[k] - sn * wq[k], nkq = sn * wp[k] + c * wq[k];
-                    if (k != p && k != q) {
-                        W[k + LD * p] = nkp;
-                        W[p + LD * k] = nkp;
-                        W[k + LD * q] = nkq;
-                        W[q + LD * k] = nkq;
-                    }
-                    Q[k + LD * p] = c * qp[k] - sn * qq[k];
-                    Q[k + LD * q] = sn * qp[k] + c * qq[k];
-                }
-                W[p + LD * p] = app - t * apq;
-                W[q + LD * q] = aqq + t * apq;
-                W[p + LD * q] = 0.0;
-                W[q + LD * p] = 0.0;
-            }
-    }
-    double ev[LD];
-    double wmin = W[0];
-#pragma unroll
-    for (int i = 0; i < LD; ++i) {
-        ev[i] = (i < m) ? W[i + LD * i] : 0.0;
-        if (i < m) wmin = fmin(wmin, ev[i]);
-    }
-    if (wmin >= 0.0) return sweeps;
-    // C+ = Q max(ev, 0) Q^T into W, then A = R C+ R^T
-    for (int j = 0; j < m; ++j)
-        for (int i = 0; i < m; ++i) {
-            double v = 0.0;
-#pragma unroll
-            for (int k = 0; k < LD; ++k)
-                if (k < m && ev[k] > 0.0) v += Q[i + LD * k] * ev[k] * Q[j + LD * k];
-            W[i + LD * j] = v;
-        }
-    for (int c = 0; c < 144; ++c) A[c] = 0.0;
-    for (int l = 0; l < nn; ++l)
-        for (int j = 0; j < 3; ++j) {
-            double d[LD]; // column (3 l + j) of C+ R^T: d[3 a + i] = sum_b C+[(3 a + i), (3 b + j)] h[b][l]
-#pragma unroll
-            for (int r = 0; r < LD; ++r) {
-                double v = 0.0;
-                if (r < m) {
-#pragma unroll
-                    for (int b = 0; b < 3; ++b) v += (b < nn - 1) ? W[r + LD * (3 * b + j)] * h[b][l] : 0.0;
-                }
-                d[r] = v;
-            }
-            for (int k = 0; k < nn; ++k)
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    double v = 0.0;
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) v += h[a][k] * d[3 * a + i];
-                    A[(3 * k + i) + 12 * (3 * l + j)] = v;
-                }
-        }
-    return sweeps;
 }
 
 } // namespace cdev

@@ -145,9 +145,9 @@ private:
     bool atomicScatter_ = false; // IPCGPU_CONTACT_ATOMICS=1: the fp64-atomic path of rounds 1-2 (A/B timing)
     DevBuf<double> detVals_;
     DevBuf<unsigned> detKey_, detKeyOut_;
-    DevBuf<int> detIota_, detPerm_, detRow_;
+    DevBuf<int> detIota_, detPerm_, detRow_, hessPerm_; // hessPerm_: the two lists' indices binned by stencil kind (k_bin_stencils)
     int detIotaN_ = 0;
-    void detBegin(size_t nSlots, int valsPerSlot, bool withRow);
+    void detBegin(size_t nSlots, int valsPerSlot, bool withRow, bool fillKeys = true);
     void detReduce3(size_t nSlots, int keyBits, double* grad_dev);
     void detReduceBlocks(size_t nSlots, int keyBits, const int* ia_dev, double* a_dev);
     void detSort(size_t nSlots, int keyBits);

@@ -2,7 +2,7 @@
 #include <climits>
 #include "hip_contact.h"
 #include "contact_device.h"
-#include "jacobi9_device.h"
+#include "stencil_hessian_device.h"
 #include "orient3d_exact.h"
 #include "hip_ipc.h"
 #include <hipcub/hipcub.hpp>
@@ -357,68 +357,6 @@ __device__ __forceinline__ int find_block(const CsrView& m, int rn, int cn)
     }
     return (lo < m.ia[3 * rn + 1] && m.ja[lo] == target) ? lo : -1;
 }
-// scatter the node-block Hessian H (12x12, ld 12) of `n` nodes into the symmetric-upper CSR, skipping projected nodes
-// slot0: first of the 16 slots (4 i + j) this stencil owns in the deterministic path
-__device__ inline void scatter_blocks(const CsrView& m, const BlockSink& sink, size_t slot0, const double* H, const int* node, int n, const int* dbc,
-    int projectDBC, int* err)
-{
-    double* a = sink.a;
-    if (sink.contrib) {
-        for (int i = 0; i < n; ++i) {
-            if (projected_dbc(dbc[node[i]], projectDBC)) continue;
-            for (int j = 0; j < n; ++j) {
-                const int vi = node[i], vj = node[j];
-                if (projected_dbc(dbc[vj], projectDBC) || vi > vj) continue;
-                if (vi == vj && j != i) continue; // (a stencil names a node once)
-                int p0 = m.ia[3 * vi];
-                if (vi != vj) {
-                    p0 = find_block(m, vi, vj);
-                    if (p0 < 0) {
-                        atomicOr(err, 1);
-                        continue;
-                    }
-                }
-                const size_t slot = slot0 + 4 * i + j;
-                sink.key[slot] = (unsigned)p0;
-                sink.rowNode[slot] = vi;
-                double* q = sink.contrib + 9 * slot;
-                for (int r = 0; r < 3; ++r)
-                    for (int c = 0; c < 3; ++c) q[r + 3 * c] = H[(3 * i + r) + 12 * (3 * j + c)];
-            }
-        }
-        return;
-    }
-    for (int i = 0; i < n; ++i) {
-        if (projected_dbc(dbc[node[i]], projectDBC)) continue;
-        for (int j = 0; j < n; ++j) {
-            if (projected_dbc(dbc[node[j]], projectDBC)) continue;
-            const int vi = node[i], vj = node[j];
-            if (vi > vj) continue; // lower-triangle writes are ignored (LinSysSolver.hpp:402-410)
-            const int L = m.ia[3 * vi + 1] - m.ia[3 * vi];
-            if (vi == vj) {
-                const int base = m.ia[3 * vi];
-                atomicAdd(&a[base + 0], H[(3 * i + 0) + 12 * (3 * j + 0)]);
-                atomicAdd(&a[base + 1], H[(3 * i + 0) + 12 * (3 * j + 1)]);
-                atomicAdd(&a[base + 2], H[(3 * i + 0) + 12 * (3 * j + 2)]);
-                atomicAdd(&a[base + L + 0], H[(3 * i + 1) + 12 * (3 * j + 1)]);
-                atomicAdd(&a[base + L + 1], H[(3 * i + 1) + 12 * (3 * j + 2)]);
-                atomicAdd(&a[base + 2 * L - 1], H[(3 * i + 2) + 12 * (3 * j + 2)]);
-            }
-            else {
-                const int p0 = find_block(m, vi, vj);
-                if (p0 < 0) {
-                    atomicOr(err, 1); // the pattern lacks this contact pair: set_pattern must include the connectivity
-                    continue;
-                }
-                for (int r = 0; r < 3; ++r) {
-                    const int rowOff = (r == 0) ? 0 : (r == 1 ? (L - 1) : (2 * L - 3));
-                    for (int c = 0; c < 3; ++c) atomicAdd(&a[p0 + rowOff + c], H[(3 * i + r) + 12 * (3 * j + c)]);
-                }
-            }
-        }
-    }
-}
-
 // does the CSR pattern hold a block for every node pair the barrier Hessian of the current sets will write?  (flag |= 1 if not)
 __global__ void k_pattern_check(ContactView cv, CsrView m, int* __restrict__ flag)
 {
@@ -442,94 +380,186 @@ __global__ void k_pattern_check(ContactView cv, CsrView m, int* __restrict__ fla
     if (miss) atomicOr(flag, 1);
 }
 
-// a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201)
-// HESS_T stencils per workgroup: the two 9 x 9 matrices the Jacobi sweeps iterate on (the block reduced by the three rigid
-// translations, see make_pd_stencil) sit in LDS (2 x 81 x 8 B per stencil)
-// REG: the Jacobi iterates live in registers (jacobi9_device.h; one wave per workgroup, no LDS) -- the default.  The LDS version is kept
-// behind IPCGPU_HESS_LDS for A/B runs.
-constexpr int HESS_T = 32;
-constexpr int HESS_R = 64;
-template <bool REG>
-__global__ __launch_bounds__(REG ? HESS_R : HESS_T) void k_contact_hessian(ContactView cv, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
-    double kappa, BlockSink sink, int* __restrict__ err, int probe)
+// ---- a += PSD-projected barrier Hessians (SelfCollisionHandler.cpp:418-561, 3039-3201) --------------------------------------------------------
+// Round 6 (stencil_hessian_device.h): the stencil kind is a compile-time constant of the code a wave runs.  k_bin_stencils sorts the indices of
+// the two lists into eight bins (active PP / PE / PT / EE, mollified with a PP / PE / PT / EE distance stencil); one workgroup = one wave of
+// k_contact_hessian takes 64 stencils of ONE bin (the workgroup finds its bin from the bin counts, which never leave the device), forms the
+// reduced block in the 9 x 9 frame, projects it (one instance of the Jacobi code for all bins: the rotations that only touch the zero rows of
+// a 3 x 3 or 6 x 6 block are skipped by the whole wave) and writes the <= 10 node-pair blocks into the stencil's own slots of the
+// deterministic scatter (HSLOTS per stencil, at HSLOTS * stencil index -- the order inside a bin does not matter).  Every slot of every
+// stencil is written, with KEY_NONE where there is nothing to add (fewer nodes, a projected Dirichlet node, a stencil of another rank): no
+// fill pass over the keys.  No scratch: every array index is a compile-time constant.
+constexpr int HESS_W = 64; // one wave per workgroup
+constexpr int HSLOTS = 10; // node pairs (k, l), k <= l, of a four-node stencil, in the order of pair_slot
+constexpr int NBINS = 8;
+struct HessBins {
+    const int* count; // NBINS
+    const int* perm; // NBINS x stride
+    int stride;
+};
+__host__ __device__ constexpr int pair_slot(int k, int l) { return l * (l + 1) / 2 + k; } // k <= l < 4
+
+__global__ __launch_bounds__(BLOCK) void k_bin_stencils(ContactView cv, int* __restrict__ count, int* __restrict__ perm, int stride)
 {
-    // probe (IPCGPU_HESS_PROBE, timing runs only -- the result is then wrong): 1 skips the projection, 2 also the scatter
-    constexpr int T = REG ? HESS_R : HESS_T;
-    __shared__ double jac[REG ? 1 : 2 * 81 * HESS_T];
-    const int i = blockIdx.x * T + threadIdx.x;
-    const Strided Qs{ jac + (REG ? 0 : threadIdx.x), T }, Ws{ jac + (REG ? 0 : 81 * T + threadIdx.x), T };
-    int sweepsDone = 0; // summed over the wave below: one atomic per wave instead of one per stencil
-    double H[144], B[144];
-    bool skip = false; // owner-computes sharding: none of the stencil's nodes has rows on this rank (no early return: the wave sums sweepsDone below)
-    if (cv.need) {
-        if (i < cv.nA) {
-            const Stencil q = decode(cv.active + 4 * (size_t)i);
-            skip = stencil_skipped(cv.need, q.node, q.n);
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    int bin = -1;
+    if (i < cv.nA) bin = decode(cv.active + 4 * (size_t)i).kind;
+    else if (i < cv.nA + cv.nP) bin = 4 + decode(cv.para + 4 * (size_t)(i - cv.nA)).kind;
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int b = 0; b < NBINS; ++b) {
+        const unsigned long long mask = __builtin_amdgcn_ballot_w64(bin == b);
+        if (!mask) continue;
+        int base = 0;
+        if (lane == __builtin_ctzll(mask)) base = atomicAdd(count + b, __builtin_popcountll(mask));
+        base = __shfl(base, __builtin_ctzll(mask), 64);
+        if (bin == b) perm[(size_t)b * stride + base + __builtin_popcountll(mask & ((1ull << lane) - 1))] = i;
+    }
+}
+
+struct HessOut {
+    CsrView m;
+    BlockSink sink;
+    int* err;
+};
+// one node-pair block of a projected stencil into its slot: rows from node K, columns from node L of the stencil (transposed when L's node
+// comes first in the matrix: the upper CSR holds (min, max))
+template <int NR, int K, int L>
+__device__ __forceinline__ void emit_pair(const HessOut& o, const double* C, size_t slot0, const int* node, const bool* proj)
+{
+    const size_t slot = slot0 + pair_slot(K, L);
+    if (proj[K] || proj[L]) {
+        o.sink.key[slot] = KEY_NONE;
+        return;
+    }
+    double A[9];
+    sh::pair_block<NR, K, L, 9>(C, A);
+    const int vk = node[K], vl = node[L];
+    const bool swap = vk > vl;
+    const int vi = swap ? vl : vk, vj = swap ? vk : vl;
+    int p0 = o.m.ia[3 * vi];
+    if (K != L) {
+        p0 = find_block(o.m, vi, vj);
+        if (p0 < 0) {
+            atomicOr(o.err, 1); // the pattern lacks this contact pair: set_pattern must include the connectivity
+            o.sink.key[slot] = KEY_NONE;
+            return;
         }
-        else if (i < cv.nA + cv.nP) {
-            int en[4];
-            paraNodes(cv, i - cv.nA, en);
-            skip = stencil_skipped(cv.need, en, 4);
-        }
     }
-    if (skip) {
+    o.sink.key[slot] = (unsigned)p0;
+    o.sink.rowNode[slot] = vi;
+    double* q = o.sink.contrib + 9 * slot;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) q[r + 3 * c] = swap ? A[c + 3 * r] : A[r + 3 * c];
+}
+template <int NN>
+__device__ __forceinline__ void emit_stencil(const HessOut& o, const double* C, size_t slot0, const int* node, const int* __restrict__ dbc, int projectDBC)
+{
+    constexpr int NR = NN - 1;
+    bool proj[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) proj[k] = k < NN ? projected_dbc(dbc[node[k]], projectDBC) : true;
+    emit_pair<NR, 0, 0>(o, C, slot0, node, proj);
+    emit_pair<NR, 0, 1>(o, C, slot0, node, proj);
+    emit_pair<NR, 1, 1>(o, C, slot0, node, proj);
+    if constexpr (NN >= 3) {
+        emit_pair<NR, 0, 2>(o, C, slot0, node, proj);
+        emit_pair<NR, 1, 2>(o, C, slot0, node, proj);
+        emit_pair<NR, 2, 2>(o, C, slot0, node, proj);
     }
-    else if (i < cv.nA) {
-        const Stencil s = decode(cv.active + 4 * (size_t)i);
-        double X[4][3], g[12], b, gb, Hb;
-        gatherX(cv.x, s.node, s.n, X);
-        const double d = stencil_distance(s.kind, X, g, H);
-        barrier(d, dHat, &b, &gb, &Hb);
-        const int n3 = 3 * s.n;
-        const double cf = kappa * s.mult;
-        for (int k = 0; k < 144; ++k) B[k] = 0.0;
-        for (int r = 0; r < n3; ++r)
-            for (int c = 0; c < n3; ++c) B[r + 12 * c] = ((cf * Hb) * g[r]) * g[c] + (cf * gb) * H[r + 12 * c];
-        if (probe < 1) sweepsDone = REG ? j9::make_pd_stencil_reg(s.n, B) : make_pd_stencil(s.n, B, Qs, Ws);
-        if (probe < 2) scatter_blocks(m, sink, 16 * (size_t)i, B, s.node, s.n, dbc, projectDBC, err);
-        else if (B[0] == 12345.678) err[0] = 1; // keeps the block alive
+    if constexpr (NN >= 4) {
+        emit_pair<NR, 0, 3>(o, C, slot0, node, proj);
+        emit_pair<NR, 1, 3>(o, C, slot0, node, proj);
+        emit_pair<NR, 2, 3>(o, C, slot0, node, proj);
+        emit_pair<NR, 3, 3>(o, C, slot0, node, proj);
     }
-    else if (i < cv.nA + cv.nP) {
-        const int j = i - cv.nA;
-        const Stencil s = decode(cv.para + 4 * (size_t)j);
-        double X[4][3], gS[12], b, gb, Hb;
-        gatherX(cv.x, s.node, s.n, X);
-        const double d = stencil_distance(s.kind, X, gS, H);
-        barrier(d, dHat, &b, &gb, &Hb);
-        int en[4];
-        paraNodes(cv, j, en);
-        double XE[4][3], cg[12], e, eg, eH;
-        double Q[144], W[144]; // Hessian of the cross norm, H_d on the edge nodes (used once each; the mollified set is small)
-        gatherX(cv.x, en, 4, XE);
-        const double c = cross_sqnorm_derivs(XE, cg, Q);
-        mollifier(c, eps_x_of(cv.xRest, en[0], en[1], en[2], en[3]), &e, &eg, &eH);
-        // distance derivatives mapped onto the four edge nodes (SelfCollisionHandler.cpp:3105-3160)
-        int imap[4] = { 0, 0, 0, 0 };
-        for (int k = 0; k < s.n; ++k)
-            for (int q = 0; q < 4; ++q)
-                if (en[q] == s.node[k]) imap[k] = q;
-        double gd[12];
-        for (int k = 0; k < 12; ++k) gd[k] = 0.0;
-        for (int k = 0; k < 144; ++k) W[k] = 0.0; // W = H_d on the edge nodes
-        for (int k = 0; k < s.n; ++k)
-            for (int cc = 0; cc < 3; ++cc) gd[3 * imap[k] + cc] = gS[3 * k + cc];
-        for (int k = 0; k < s.n; ++k)
-            for (int l = 0; l < s.n; ++l)
-                for (int r = 0; r < 3; ++r)
-                    for (int cc = 0; cc < 3; ++cc) W[(3 * imap[k] + r) + 12 * (3 * imap[l] + cc)] = H[(3 * k + r) + 12 * (3 * l + cc)];
-        for (int r = 0; r < 12; ++r)
-            for (int cc = 0; cc < 12; ++cc) {
-                const double e_g_r = eg * cg[r], e_g_c = eg * cg[cc];
-                const double e_H = eg * Q[r + 12 * cc] + eH * cg[r] * cg[cc];
-                B[r + 12 * cc] = (kappa * gb) * gd[r] * e_g_c + (kappa * gb) * gd[cc] * e_g_r + (kappa * b) * e_H + ((kappa * e * Hb) * gd[r]) * gd[cc]
-                    + (kappa * e * gb) * W[r + 12 * cc];
+#pragma unroll
+    for (int p = NN * (NN + 1) / 2; p < HSLOTS; ++p) o.sink.key[slot0 + p] = KEY_NONE;
+}
+template <int KIND>
+__device__ __forceinline__ void active_reduced(const ContactView& cv, const int* node, double mult, double dHat, double kappa, double (&C)[81])
+{
+    constexpr int NN = sh::NN_OF[KIND];
+    double X[4][3];
+#pragma unroll
+    for (int k = 0; k < NN; ++k)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) X[k][c] = cv.x[3 * (size_t)node[k] + c];
+    sh::active_block<KIND, 9>(X, dHat, kappa * mult, C);
+}
+template <int KIND>
+__device__ __forceinline__ void para_reduced(const ContactView& cv, const int* node, const int* en, double dHat, double kappa, double (&C)[81])
+{
+    constexpr int NN = sh::NN_OF[KIND];
+    double XE[4][3], sel[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) XE[q][c] = cv.x[3 * (size_t)en[q] + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sel[k][q] = (k < NN && en[q] == node[k]) ? 1.0 : 0.0; // the distance stencil's nodes are among the four (SelfCollisionHandler.cpp:3105-3160)
+    }
+    sh::para_block<KIND>(XE, sel, dHat, kappa, eps_x_of(cv.xRest, en[0], en[1], en[2], en[3]), C);
+}
+
+__global__ __launch_bounds__(HESS_W) void k_contact_hessian(ContactView cv, HessBins bins, CsrView m, const int* __restrict__ dbc, int projectDBC, double dHat,
+    double kappa, BlockSink sink, int* __restrict__ err)
+{
+    // this workgroup's bin and its 64 entries (uniform: the counts are read through the scalar path)
+    int bin = -1, first = 0, left = blockIdx.x, cnt = 0;
+#pragma unroll
+    for (int b = 0; b < NBINS; ++b) {
+        const int c = bins.count[b], nb = (c + HESS_W - 1) / HESS_W;
+        if (bin < 0) {
+            if (left < nb) {
+                bin = b;
+                first = left * HESS_W;
+                cnt = c;
             }
-        if (REG) j9::make_pd_stencil_reg(4, B);
-        else make_pd_stencil(4, B, Qs, Ws);
-        scatter_blocks(m, sink, 16 * (size_t)i, B, en, 4, dbc, projectDBC, err);
+            else left -= nb;
+        }
     }
-    // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it)
-    for (int o = 32; o; o >>= 1) sweepsDone += __shfl_xor(sweepsDone, o);
+    if (bin < 0) return;
+    const int t = first + (int)threadIdx.x;
+    const bool on = t < cnt;
+    const bool isPara = bin >= 4;
+    const int i = on ? bins.perm[(size_t)bin * bins.stride + t] : (isPara ? cv.nA : 0); // < nA: active list, else nA + index in the mollified list (a lane past the bin's end reads entry 0 of its list)
+    const Stencil s = decode((isPara ? cv.para + 4 * (size_t)(i - cv.nA) : cv.active + 4 * (size_t)i));
+    int en[4] = { s.node[0], s.node[1], s.node[2], s.node[3] }; // the nodes the block is scattered to
+    if (isPara && on) paraNodes(cv, i - cv.nA, en);
+    // owner-computes sharding: none of the stencil's nodes has rows on this rank (no early return: the wave votes in the Jacobi sweeps)
+    const bool skip = !on || stencil_skipped(cv.need, en, isPara ? 4 : s.n);
+    const HessOut o{ m, sink, err };
+    const size_t slot0 = (size_t)HSLOTS * (size_t)i;
+    double C[81];
+    switch (bin) { // uniform
+    case 0: active_reduced<K_PP>(cv, s.node, s.mult, dHat, kappa, C); break;
+    case 1: active_reduced<K_PE>(cv, s.node, s.mult, dHat, kappa, C); break;
+    case 2: active_reduced<K_PT>(cv, s.node, s.mult, dHat, kappa, C); break;
+    case 3: active_reduced<K_EE>(cv, s.node, s.mult, dHat, kappa, C); break;
+    case 4: para_reduced<K_PP>(cv, s.node, en, dHat, kappa, C); break;
+    case 5: para_reduced<K_PE>(cv, s.node, en, dHat, kappa, C); break;
+    case 6: para_reduced<K_PT>(cv, s.node, en, dHat, kappa, C); break;
+    default: para_reduced<K_EE>(cv, s.node, en, dHat, kappa, C); break;
+    }
+    if (skip) { // a lane without a stencil of its own iterates on the zero matrix: converged before the first sweep
+#pragma unroll
+        for (int e = 0; e < 81; ++e) C[e] = 0.0;
+    }
+    int sweepsDone = sh::project_psd<9>(C);
+    if (on) {
+        if (skip) {
+#pragma unroll
+            for (int p = 0; p < HSLOTS; ++p) sink.key[slot0 + p] = KEY_NONE;
+        }
+        else if (bin == 0) emit_stencil<2>(o, C, slot0, en, dbc, projectDBC);
+        else if (bin == 1) emit_stencil<3>(o, C, slot0, en, dbc, projectDBC);
+        else emit_stencil<4>(o, C, slot0, en, dbc, projectDBC);
+    }
+    // total sweep count: a cheap health indicator (IPCGPU_DEBUG prints it); one atomic per wave
+    for (int off = 32; off; off >>= 1) sweepsDone += __shfl_xor(sweepsDone, off);
     if ((threadIdx.x & 63) == 0 && sweepsDone) atomicAdd(err + 1, sweepsDone);
 }
 
@@ -1879,7 +1909,8 @@ __global__ void k_rec_keys(int n, const int* __restrict__ rec, int shift, unsign
     val[i] = i;
 }
 // category of a record: 0 direct active, 1 duplicate candidate (PP / PE), 2 mollified parallel edge pair.  Packed counters for
-// one 64-bit prefix sum: bits 0..20 direct, 21..41 duplicate, 42..62 parallel.
+// one 64-bit prefix sum: bits 0..31 direct, 32..63 duplicate; the parallel pairs in front of record j are the rest, j - direct - duplicate
+// (round 6: three 21-bit fields capped a set at 2 M candidate pairs -- the 1.1 M-tet stack has 1.2 M).
 __device__ __forceinline__ int rec_category(const int* r, bool isEE)
 {
     if (!isEE) return r[3] < 0 ? 1 : 0;
@@ -1894,7 +1925,8 @@ __global__ void k_classify(int nPT, int nEE, const int* __restrict__ recPT, cons
     const int* r = isEE ? recEE + 6 * (size_t)permEE[j - nPT] : recPT + 6 * (size_t)permPT[j];
     csPTEE[2 * (size_t)j] = isEE ? r[4] : -r[4] - 1;
     csPTEE[2 * (size_t)j + 1] = r[5];
-    flags[j] = 1ull << (21 * rec_category(r, isEE));
+    const int cat = rec_category(r, isEE);
+    flags[j] = cat == 0 ? 1ull : (cat == 1 ? 1ull << 32 : 0ull);
 }
 __device__ __forceinline__ unsigned bias(int v) { return (unsigned)v ^ 0x80000000u; } // signed order -> unsigned order
 __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict__ recPT, const int* __restrict__ permPT,
@@ -1908,7 +1940,8 @@ __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict
     const int* r = isEE ? recEE + 6 * (size_t)permEE[j - nPT] : recPT + 6 * (size_t)permPT[j];
     const unsigned long long p = pos[j];
     const int cat = rec_category(r, isEE);
-    const int q = (int)((p >> (21 * cat)) & 0x1fffff);
+    const int nd = (int)(p & 0xffffffffull), nu = (int)(p >> 32);
+    const int q = cat == 0 ? nd : (cat == 1 ? nu : j - nd - nu);
     if (cat == 0) {
         for (int k = 0; k < 4; ++k) active[4 * (size_t)q + k] = r[k];
     }
@@ -2157,7 +2190,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     };
     buildCells(nSF, 1, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
     buildCells(nSFE, 0, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
-    counters_.alloc(4);
+    counters_.alloc(16);
     int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
     int nPT = 0, nEE = 0;
     for (;;) {
@@ -2224,8 +2257,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     unsigned long long totals = 0;
     HIP_CHECK(hipMemcpyAsync(&totals, flagPos_.p + n, sizeof(totals), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
-    const int nDirect = (int)(totals & 0x1fffff), nDup = (int)((totals >> 21) & 0x1fffff), nPar = (int)((totals >> 42) & 0x1fffff);
-    if (n >= (1 << 21)) throw StateError("constraint-set build: more than 2 M candidate pairs in one set");
+    const int nDirect = (int)(totals & 0xffffffffull), nDup = (int)(totals >> 32), nPar = n - nDirect - nDup;
     d_active.ensure(4 * (size_t)std::max(nDirect + nDup, 1));
     d_para.ensure(4 * (size_t)std::max(nPar, 1));
     d_paraEIEJ.ensure(2 * (size_t)std::max(nPar, 1));
@@ -2354,22 +2386,17 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     if (!n) return;
     ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p, need_dev };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
-    counters_.alloc(4);
+    // counters: [0] pattern-miss flag, [1] Jacobi sweeps, [4 .. 11] the bin counts
+    counters_.alloc(16);
     counters_.zero(stream);
-    static const int probe = std::getenv("IPCGPU_HESS_PROBE") ? std::atoi(std::getenv("IPCGPU_HESS_PROBE")) : 0;
-    static const bool ldsJacobi = std::getenv("IPCGPU_HESS_LDS") != nullptr; // A/B: the Jacobi iterates in LDS (rounds 1-2)
-    auto launch = [&](const BlockSink& sink) {
-        if (ldsJacobi)
-            hipLaunchKernelGGL(k_contact_hessian<false>, dim3(nblk(n, HESS_T)), dim3(HESS_T), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, sink, counters_.p, probe);
-        else
-            hipLaunchKernelGGL(k_contact_hessian<true>, dim3(nblk(n, HESS_R)), dim3(HESS_R), 0, stream, cv, m, dbc_dev, projectDBC, dHat, kappa, sink, counters_.p, probe);
-    };
-    if (atomicScatter_) launch(BlockSink{ a_dev, nullptr, nullptr, nullptr });
-    else {
-        detBegin(16 * (size_t)n, 9, true);
-        launch(BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p });
-        detReduceBlocks(16 * (size_t)n, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
-    }
+    hessPerm_.ensure((size_t)NBINS * (size_t)n);
+    hipLaunchKernelGGL(k_bin_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, counters_.p + 4, hessPerm_.p, n);
+    const size_t nSlots = (size_t)HSLOTS * (size_t)n;
+    detBegin(nSlots, 9, true, /*fillKeys=*/false); // the kernel writes every key
+    const HessBins bins{ counters_.p + 4, hessPerm_.p, n };
+    hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_W) + NBINS), dim3(HESS_W), 0, stream, cv, bins, m, dbc_dev, projectDBC, dHat, kappa,
+        BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p }, counters_.p);
+    detReduceBlocks(nSlots, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
     int err[2];
     counters_.download(err, 2, stream);
     if (std::getenv("IPCGPU_DEBUG")) std::fprintf(stderr, "[ipcgpu] barrier Hessian: %d stencils, %.2f Jacobi sweeps on average\n", n, (double)err[1] / n);
@@ -2382,7 +2409,7 @@ bool HipContact::patternCovers(const HipLinSysSolver& lin)
     if (!n) return true;
     ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, nullptr, d_xRest.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
-    counters_.alloc(4);
+    counters_.alloc(16);
     counters_.zero(stream);
     hipLaunchKernelGGL(k_pattern_check, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, m, counters_.p);
     int miss = 0;
@@ -2434,7 +2461,7 @@ double HipContact::frictionEnergy(const double* x_dev, const double* xt_dev, dou
 }
 
 // ---- deterministic scatter, host side: slots + keys for one launch, then sort and sum the runs -------------------------------------------
-void HipContact::detBegin(size_t nSlots, int valsPerSlot, bool withRow)
+void HipContact::detBegin(size_t nSlots, int valsPerSlot, bool withRow, bool fillKeys)
 {
     detVals_.ensure(nSlots * (size_t)valsPerSlot);
     detKey_.ensure(nSlots);
@@ -2446,7 +2473,7 @@ void HipContact::detBegin(size_t nSlots, int valsPerSlot, bool withRow)
         detIotaN_ = (int)detIota_.n;
         hipLaunchKernelGGL(k_iota, dim3(nblk(detIotaN_)), dim3(BLOCK), 0, stream, detIotaN_, detIota_.p);
     }
-    HIP_CHECK(hipMemsetAsync(detKey_.p, 0xFF, nSlots * sizeof(unsigned), stream)); // KEY_NONE: slots nobody writes sort to the end
+    if (fillKeys) HIP_CHECK(hipMemsetAsync(detKey_.p, 0xFF, nSlots * sizeof(unsigned), stream)); // KEY_NONE: slots nobody writes sort to the end
 }
 void HipContact::detSort(size_t nSlots, int keyBits)
 {
@@ -2492,7 +2519,7 @@ void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, c
     if (!n) return;
     FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
-    counters_.alloc(4);
+    counters_.alloc(16);
     counters_.zero(stream);
     if (atomicScatter_)
         hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
@@ -2829,7 +2856,7 @@ double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const doubl
     ccdOut_.alloc(4);
     const unsigned long long init[2] = { ~0ull, ~0ull };
     HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init, sizeof(init), hipMemcpyHostToDevice, stream));
-    counters_.alloc(4);
+    counters_.alloc(16);
     counters_.zero(stream);
     CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
     for (int pass = 0; pass < 2; ++pass) {
@@ -2939,7 +2966,7 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
     build(nSFE, 2, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
     build(nSF, 3, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
     ccdOut_.alloc(4);
-    counters_.alloc(4);
+    counters_.alloc(16);
     // counters_: [0] queried pairs, [1] pairs that returned a time inside the step (the hit list)
     constexpr int HIT_CAP = 1 << 20;
     static const bool twoPass = std::getenv("IPCGPU_CCD_TWO_PASS") != nullptr; // A/B: find the limiting pair by a second run of the sweep (rounds 1-2)
@@ -2995,7 +3022,7 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
         g.dim[c] = gh.dim[c];
     }
     g.h = gh.h;
-    counters_.alloc(4);
+    counters_.alloc(16);
     counters_.zero(stream);
     if (exactPredicates)
         hipLaunchKernelGGL(k_intersect<true>, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p,
@@ -3029,7 +3056,7 @@ void HipContact::closeStencils(const double* x_dev, double dTol, std::vector<std
     for (;;) {
         closeIdx_.ensure((size_t)cap);
         closeVal_.ensure((size_t)cap);
-        counters_.alloc(4);
+        counters_.alloc(16);
         counters_.zero(stream);
         hipLaunchKernelGGL(k_close_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_active.p, x_dev, dTol, cap, closeIdx_.p, closeVal_.p, counters_.p);
         int cnt = 0;
