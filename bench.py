@@ -102,6 +102,25 @@ def attach_transport(ctx, args, rank, world, local_rank):
     dev = f"cuda:{local_rank}"
     if args.transport in ("auto", "rccl"):
         ok, why = 1, ""
+        # Preconditions are agreed BEFORE any collective of the binding: ncclCommInitRank inside rccl_attach and the ring self-test are collectives themselves, so
+        # a rank that cannot even load the binding must say so while the others can still hear it (an all-reduce of the process group, which is up).  What the
+        # `auto` fall-back covers are failures every rank sees or that are known up front; a rank that dies INSIDE ncclCommInitRank leaves the others waiting in
+        # RCCL until the launcher's own timeout ends the job (torch.distributed.run tears the group down when one rank exits).
+        try:
+            ipc_amd.Context.rccl_unique_id()
+        except Exception as e:  # noqa: BLE001
+            ok, why = 0, repr(e)
+        pre = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        if int(pre.item()) == 0:
+            if why:
+                print(f"[bench] rank {rank}: RCCL binding not loadable: {why}", file=sys.stderr, flush=True)
+            if args.transport == "rccl":
+                raise SystemExit("--transport rccl: the RCCL binding cannot be loaded on at least one rank")
+            ar, xc = torch_hooks(local_rank, host_bounce=False)
+            ctx.set_allreduce(ar)
+            ctx.set_exchange(xc)
+            return "torch.distributed nccl backend through the host-level hooks (stream drained around every exchange)"
         try:
             idt = torch.zeros(128, dtype=torch.uint8, device=dev)
             if rank == 0:

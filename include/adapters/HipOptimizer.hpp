@@ -26,13 +26,7 @@
 #include "Optimizer.hpp"
 #include "HalfSpace.hpp"
 #include "HipElasticEnergy.hpp"
-#ifndef IPCGPU_NO_HANDLER_REDIRECT
-#define IPCGPU_NO_HANDLER_REDIRECT // the registry and the class only: the name is redirected where Optimizer.cpp is compiled, not here
-#include "HipSelfCollisionHandler.hpp"
-#undef IPCGPU_NO_HANDLER_REDIRECT
-#else
-#include "HipSelfCollisionHandler.hpp"
-#endif
+#include "HipSelfCollisionHandler.hpp" // the registry and the class; the NAME is redirected where Optimizer.cpp is compiled (HipSelfCollisionHandlerRedirect.hpp), not here
 #include <ipcgpu.h>
 #include <algorithm>
 #include <array>

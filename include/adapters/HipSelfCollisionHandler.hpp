@@ -5,8 +5,9 @@
 // the C ABI (the constraint sets, the per-constraint distances and Jacobian-transpose products, the barrier Hessian, the two step bounds and the
 // intersection test run on the device); everything it does not define is inherited from the reference's class, so the rest of the handler --
 // the QP / SQP entry points, friction, the mollified-pair terms -- stays the reference's host code.  A maintainer makes Optimizer.cpp call it by
-// including this header in Optimizer.cpp; the last line below then redirects the name, exactly as tests/adapters/main_hook.hpp redirects
-// `new Optimizer` -- the test build pre-includes the header (g++ -include) in front of the UNCHANGED Optimizer.cpp.
+// including this header AND HipSelfCollisionHandlerRedirect.hpp (the one-line `#define` that redirects the name; a header of its own without an include
+// guard, so that it acts wherever it is included -- whatever was included before) behind the other includes of Optimizer.cpp, exactly as
+// tests/adapters/main_hook.hpp redirects `new Optimizer` -- the test build pre-includes both (g++ -include) in front of the UNCHANGED Optimizer.cpp.
 //
 // Who decides: hipCollisionRegistry().ctx.  Null (the default) = every call goes to the reference's implementation.  HipOptimizer sets it in
 // percall mode for scenes with `selfCollisionOn` (IPCGPU_PERCALL_CONTACT=host keeps the host code for A/B runs) after handing the surface to the
@@ -17,6 +18,7 @@
 // mesh between calls on the host.
 // Needs: the reference's SelfCollisionHandler.hpp, include/adapters/HipLinSysSolver.hpp, include/ipcgpu.h, -lipcgpu.
 #pragma once
+#define IPCGPU_HIP_SELF_COLLISION_HANDLER_DECLARED
 #include "SelfCollisionHandler.hpp"
 #include "HipLinSysSolver.hpp"
 #include <ipcgpu.h>
@@ -124,6 +126,18 @@ public:
         const std::vector<std::pair<int, int>>& constraintSet, std::vector<std::pair<int, int>>& candidates, double& stepSize)
     {
         if (!dev()) return Ref::largestFeasibleStepSize(mesh, sh, searchDir, slackness, constraintSet, candidates, stepSize);
+        // The library bounds the step over the candidate list IT kept at the last computeConstraintSet (getPTEE): that is the reference's call only when
+        // Optimizer.cpp passes MMActiveSet_CCD of that same build, i.e. in the CFL_FOR_CCD = 1 / 2 builds (Types.hpp:34; Optimizer.cpp:1891-1935).  With
+        // CFL_FOR_CCD == 0 the list is empty by construction and the reference's function of this name IS the full sweep: refuse to compile rather than
+        // hand back a partial bound.
+#if defined(CFL_FOR_CCD)
+        static_assert(CFL_FOR_CCD != 0, "HipSelfCollisionHandler::largestFeasibleStepSize forwards the PARTIAL CCD (CFL_FOR_CCD 1 or 2); a CFL_FOR_CCD == 0 build must forward to ipcgpu_ccd_full_reference");
+#endif
+        {
+            int counts[3] = { 0, 0, 0 };
+            chk(ipcgpu_contact_counts(dev(), counts));
+            if ((size_t)counts[2] != constraintSet.size()) throw std::runtime_error("HipSelfCollisionHandler::largestFeasibleStepSize: the candidate list handed in is not the one of the library's last computeConstraintSet (stale state)");
+        }
         hipCollisionRegistry().calls[4]++;
         sync(mesh);
         int pair[2] = { -1, -1 };
@@ -157,9 +171,3 @@ public:
 };
 
 } // namespace IPC
-
-// from here on `SelfCollisionHandler<dim>::f(...)` names the class above (and, for everything it does not define, the reference's class through it).
-// (HipOptimizer.hpp includes this header for the registry alone and asks for no redirect in its translation unit.)
-#ifndef IPCGPU_NO_HANDLER_REDIRECT
-#define SelfCollisionHandler HipSelfCollisionHandler
-#endif

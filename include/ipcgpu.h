@@ -219,6 +219,9 @@ int ipcgpu_set_codim_nodes(ipcgpu_ctx*, int n, const int* node_ids, const double
  * MMActiveSet (PP / PE duplicates merged, multiplicity in slot 3), paraEEMMCVIDSet + paraEEeIeJSet, and the
  * candidate list for the partial CCD.  counts3 = {nActive, nParaEE, nCandidates}. */
 int ipcgpu_contact_build(ipcgpu_ctx*, double dHat, int* counts3);
+/* the sizes of the sets the library holds since the last ipcgpu_contact_build / _set, counts3 as above (an adapter checks with it that the candidate list it is
+ * handed -- MMActiveSet_CCD of Optimizer.cpp:1926 -- is the one the library will sweep in ipcgpu_ccd_partial) */
+int ipcgpu_contact_counts(ipcgpu_ctx*, int* counts3);
 int ipcgpu_contact_get(ipcgpu_ctx*, int* active_4n, int* paraEE_4n, int* paraEEeIeJ_2n, int* csPTEE_2n /*nullable*/);
 /* hand an active set in (adapters that keep the reference's own constraint-set code; tests) */
 int ipcgpu_contact_set(ipcgpu_ctx*, int nActive, const int* active_4n, int nParaEE, const int* paraEE_4n, const int* paraEEeIeJ_2n);

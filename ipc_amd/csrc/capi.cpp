@@ -129,7 +129,6 @@ int ipcgpu_ctx_create(int device_id, ipcgpu_ctx** out)
             // workgroups are placed ahead of the bulk work the solver keeps on its own streams beside it (Schur passes, forward sweep)
             int lo = 0, hi = 0;
             HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            if (std::getenv("IPCGPU_NO_STREAM_PRIORITY")) hi = lo = 0;
             HIP_CHECK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
         }
         c->mesh.reset(new HipMesh);
@@ -832,6 +831,17 @@ int ipcgpu_contact_set(ipcgpu_ctx* c, int nA, const int* a4, int nP, const int* 
         return IPCGPU_OK;
     });
 }
+int ipcgpu_contact_counts(ipcgpu_ctx* c, int* counts3)
+{
+    return guarded([&] {
+        needArg(c != nullptr && counts3 != nullptr, "null argument");
+        HipContact& k = CT(c);
+        counts3[0] = k.nActive();
+        counts3[1] = k.nPara();
+        counts3[2] = k.nCand();
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_contact_energy(ipcgpu_ctx* c, double dHat, double kappa, double* E)
 {
     return guarded([&] {
@@ -842,15 +852,28 @@ int ipcgpu_contact_energy(ipcgpu_ctx* c, double dHat, double kappa, double* E)
         return IPCGPU_OK;
     });
 }
+// every node a kernel will read, checked per stencil kind exactly as the device decodes the tuple (hip_contact.hip decode()): c[0] >= 0: an edge-edge tuple, four
+// nodes; else -c[0] - 1 and c[1] are nodes, c[2] is one unless negative (point-point), c[3] is one when c[2] and c[3] are non-negative (point-triangle); a negative
+// c[3] behind a node c[2] is the multiplicity of a point-edge tuple
+static void checkTuples(ipcgpu_ctx* c, int n, const int* t)
+{
+    const int nV = c->mesh->nV;
+    auto node = [&](int v) { return v >= 0 && v < nV; };
+    for (int i = 0; i < n; ++i) {
+        const int* q = t + 4 * (size_t)i;
+        bool ok;
+        if (q[0] >= 0) ok = node(q[0]) && node(q[1]) && node(q[2]) && node(q[3]);
+        else ok = node(-q[0] - 1) && node(q[1]) && (q[2] < 0 || (node(q[2]) && (q[3] < 0 || node(q[3]))));
+        needArg(ok, "MMCVID node id out of range");
+    }
+}
 int ipcgpu_contact_evaluate(ipcgpu_ctx* c, int n, const int* mmcvid_4n, double* val_n)
 {
     return guarded([&] {
+        needArg(c != nullptr, "null context");
         bind(c);
         needArg(n >= 0 && (n == 0 || (mmcvid_4n && val_n)), "null argument");
-        for (int i = 0; i < 4 * n; ++i) {
-            const int v = mmcvid_4n[i] >= 0 ? mmcvid_4n[i] : ((i & 3) == 0 ? -mmcvid_4n[i] - 1 : 0); // [0] < 0 encodes a node; [2], [3] < 0 are flags / multiplicities
-            needArg(v < c->mesh->nV, "MMCVID node id out of range");
-        }
+        checkTuples(c, n, mmcvid_4n);
         CT(c).evaluateTuples(c->mesh->d_x.p, n, mmcvid_4n, val_n);
         return IPCGPU_OK;
     });
@@ -858,12 +881,10 @@ int ipcgpu_contact_evaluate(ipcgpu_ctx* c, int n, const int* mmcvid_4n, double* 
 int ipcgpu_contact_jt_multiply(ipcgpu_ctx* c, int n, const int* mmcvid_4n, const double* input_n, double coef, double* out_3nV_inout)
 {
     return guarded([&] {
+        needArg(c != nullptr, "null context");
         bind(c);
         needArg(n >= 0 && out_3nV_inout && (n == 0 || (mmcvid_4n && input_n)), "null argument");
-        for (int i = 0; i < 4 * n; ++i) {
-            const int v = mmcvid_4n[i] >= 0 ? mmcvid_4n[i] : ((i & 3) == 0 ? -mmcvid_4n[i] - 1 : 0);
-            needArg(v < c->mesh->nV, "MMCVID node id out of range");
-        }
+        checkTuples(c, n, mmcvid_4n);
         CT(c).jtMultiplyTuples(c->mesh->d_x.p, c->mesh->nV, n, mmcvid_4n, input_n, coef, out_3nV_inout);
         return IPCGPU_OK;
     });

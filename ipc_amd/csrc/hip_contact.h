@@ -24,8 +24,6 @@ class HipContact {
 public:
     explicit HipContact(hipStream_t s) : stream(s)
     {
-        if (const char* e = std::getenv("IPCGPU_CCD_MODE")) ccdMode = std::atoi(e) != 0 ? 1 : 0;
-        if (const char* e = std::getenv("IPCGPU_CONTACT_ATOMICS")) atomicScatter_ = std::atoi(e) != 0;
     }
     hipStream_t stream;
     // surface (Mesh::SF, SVI, SFEdges; Mesh.cpp:495-515, 890-930)

@@ -206,7 +206,7 @@ void HipLinSysSolver::analyze_pattern(const HipMesh* mesh)
     if (!numRows) throw StateError("analyze_pattern before set_pattern");
     std::vector<double> coords;
     const double* cptr = nullptr;
-    if (mesh && 3 * mesh->nV == numRows && !std::getenv("IPCGPU_ND_GRAPH")) {
+    if (mesh && 3 * mesh->nV == numRows) {
         coords.resize(3 * (size_t)mesh->nV);
         for (int v = 0; v < mesh->nV; ++v)
             for (int c = 0; c < 3; ++c) coords[3 * (size_t)v + c] = mesh->V_rest[v + (size_t)mesh->nV * c];
@@ -215,8 +215,7 @@ void HipLinSysSolver::analyze_pattern(const HipMesh* mesh)
     // leaf domains of at most 12 nodes (36 columns): one level less at the bottom of the tree than with 8 -- one launch less in the factorisation and in each sweep --
     // and still a single-workgroup front in 64 KB of LDS.  Measured (profiles/r04_nd_leaf_size_ab.txt): mat150 5: 382, 6: 384, 8: 393, 10: 396, 12: 406, 14: 406, 16: 394,
     // 20: 398 it/s; mat433 42.9 -> 43.7; contact bench 10.98 -> 10.78 ms per iteration.
-    int leaf = 12;
-    if (const char* e = std::getenv("IPCGPU_ND_LEAF")) leaf = std::max(1, std::atoi(e));
+    const int leaf = 12;
     // (the entries' destinations in the fronts are computed on the device by MfNumeric::setup; the rocSOLVER back end does not use them)
     mf_analyze(numRows, ia.data(), ja.data(), cptr, leaf, sym_, /*withEntryDestinations=*/false);
     ++analysisVersion;

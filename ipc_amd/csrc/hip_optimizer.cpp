@@ -486,7 +486,6 @@ void HipOptimizer::enableSelfCollision(HipContact* c, double eps)
     if (!planes.empty() && eps != dHatEps) throw ArgError("all collision objects of a context share one dHat (Config.cpp:41-45): got a different dHatEps");
     contact = c;
     selfCollision = true;
-    if (const char* e = std::getenv("IPCGPU_PATTERN_PAD")) patternPad = std::atof(e); // < 1: exact pattern, 1: full stencils of the current candidates, > 1: also look ahead in distance
     dHatEps = eps;
     dHat = eps * eps * lenScale2();
     dTol = dTolRel * dTolRel * lenScale2(); // dTolRel = tuning[3], 1e-9 by default (Optimizer.cpp:102-109)
@@ -727,8 +726,7 @@ bool HipOptimizer::ownerMode() const
 {
     // both halves sharded, and nothing in play that reads the WHOLE matrix every iteration (the lagged damping matrix is a second value array on the pattern
     // that enters energy and gradient through products with it: those runs keep the all-reduce of the values)
-    static const bool off = std::getenv("IPCGPU_NO_OWNER_COMPUTES") != nullptr; // A/B and tests of the older scheme
-    return !off && worldSize > 1 && lin.solverWorld() == worldSize && lin.solverType == 0 && lin.analyzed() && !(dampingStiff > 0.0); // (before the first analysis: the older scheme)
+    return worldSize > 1 && lin.solverWorld() == worldSize && lin.solverType == 0 && lin.analyzed() && !(dampingStiff > 0.0); // (before the first analysis: the older scheme)
 }
 
 void HipOptimizer::ensureOwnerPlan()
@@ -1104,9 +1102,8 @@ void HipOptimizer::stepForward(const double* x0_dev, double alpha)
 
 void HipOptimizer::speculativeAssembly()
 {
-    static const bool off = std::getenv("IPCGPU_NO_SPEC_ASSEMBLY") != nullptr;
     specAsmValid = false;
-    if (off || !specAsmOn || !fastPath() || !projDBC || lin.rowBase.empty()) return;
+    if (!specAsmOn || !fastPath() || !projDBC || lin.rowBase.empty()) return;
     ensurePatchPlan();
     d_aSpec.alloc(lin.d_a.n); // same capacity as the solver's value array: the two are swapped
     d_gradSpec.alloc(d_gradient.n);
@@ -1122,9 +1119,9 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
 {
     (void)projectDBC;
     bool ok;
-    static const bool twoCalls = std::getenv("IPCGPU_MF_NO_FWD_OVERLAP") != nullptr; // A/B: factorize(), then solve()
+    const bool twoCalls = false; // (factorize(), then solve(): the A/B of profiles/r03h_bench_line_*forward_overlap.json)
     launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
-    static const bool noSpec = std::getenv("IPCGPU_NO_TRIAL_AHEAD") != nullptr; // A/B: synchronise after the solve, again after the trial step
+    const bool noSpec = false; // (synchronise after the solve, again after the trial step: profiles/r03t_trial_ahead_ab.txt)
     cachedTrialValid = false;
     if (fastPath() && !twoCalls && !noSpec) {
         // ONE synchronisation per Newton iteration.  Behind factorisation + sweeps, on the same stream and without the host in between: |p|_inf
@@ -1198,8 +1195,7 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
 
 bool HipOptimizer::fastPath() const
 {
-    static const bool off = std::getenv("IPCGPU_NO_FASTPATH") != nullptr; // A/B: the one-scalar-per-synchronisation flow of rounds 1-2
-    return !off && worldSize == 1 && !ipOn() && nbcGroups.empty() && !(dampingStiff > 0.0) && !(rhoDBC && !tpIds.empty());
+    return worldSize == 1 && !ipOn() && nbcGroups.empty() && !(dampingStiff > 0.0) && !(rhoDBC && !tpIds.empty());
 }
 
 void HipOptimizer::resolveEventTimers()

@@ -107,9 +107,9 @@ private:
     };
     int rank_ = 0, world_ = 1;
     long long schur64Min_ = 512;
-    double bulkMinMB_ = 48.0; // levels whose step launches read + write at least that many MB of own columns factor them in outer blocks (two-level blocking, k_big_bulk); IPCGPU_MF_BULK_MIN_MB
-    int bulkBlock_ = 256; // width of an outer block; IPCGPU_MF_BULK_BLOCK
-    bool xinvBorder_ = true; // X = L11^-1 by bordering inside the step launches (IPCGPU_MF_XINV_BORDER=0: recursive doubling on the side stream)
+    double bulkMinMB_ = 48.0; // levels whose step launches read + write at least that many MB of own columns factor them in outer blocks (two-level blocking, k_big_bulk); ipcgpu_linsys_set_tuning "bulk_min_mb"
+    int bulkBlock_ = 256; // width of an outer block; ipcgpu_linsys_set_tuning "bulk_block"
+    bool xinvBorder_ = true; // X = L11^-1 by bordering inside the step launches (false: recursive doubling on the side stream, the round-4 scheme)
     AllreduceFn allreduce_ = nullptr;
     AllreduceStreamFn allreduceStream_ = nullptr;
     void* allreduceUser_ = nullptr;
@@ -162,8 +162,8 @@ private:
     };
     std::vector<XinvLevel> xinvLevel_;
     hipStream_t side_ = nullptr; // inverses are formed here, beside the chain of the upper levels
-    bool xcdOrder_ = true; // Schur tiles dealt to the XCDs front by front (IPCGPU_MF_XCD_ORDER=0: front after front over all XCDs, as before round 5)
-    int fwdStride_ = 4; // levels handed to the forward stream per event (IPCGPU_MF_FWD_STRIDE; 1 = every level, as before round 4)
+    bool xcdOrder_ = true; // Schur tiles dealt to the XCDs front by front (false: front after front over all XCDs, as before round 5; profiles/r05_solver_ab_xcd_occupancy.txt)
+    int fwdStride_ = 4; // levels handed to the forward stream per event (1 = every level, as before round 4; profiles/r05_knob_sweep.txt)
     bool fwdJoined_ = false; // the root's forward sweep went onto the main stream (factorizeSolve)
     // factorizeSolve(): the forward sweep of a level is enqueued on its own stream as soon as that level's factor kernels are, so that it
     // runs beside the latency-bound pivot chain of the levels above instead of behind the whole factorisation

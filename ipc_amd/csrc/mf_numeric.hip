@@ -22,6 +22,7 @@
 //                by one 512-thread workgroup per front (its only sequential part), the (N-nc) x nc rectangle is a
 //                row-parallel matrix-vector product in a second launch.
 // No vendor BLAS is involved: rocSOLVER's potrf / rocBLAS' trsm+syrk cost ~150 tiny launches per front.
+#include <climits>
 #include "mf_kernels.h"
 #include <algorithm>
 #include <chrono>
@@ -1581,9 +1582,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
         HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evSide_, hipEventDisableTiming));
     }
-    if (const char* e = std::getenv("IPCGPU_MF_FWD_STRIDE")) fwdStride_ = std::max(1, std::atoi(e));
-    if (const char* e = std::getenv("IPCGPU_MF_XCD_ORDER")) xcdOrder_ = std::atoi(e) != 0;
-    if (!fwd_ && !std::getenv("IPCGPU_MF_NO_FWD_OVERLAP")) {
+    if (!fwd_) {
         HIP_CHECK(hipStreamCreateWithFlags(&fwd_, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreateWithFlags(&evRhs_, hipEventDisableTiming));
         HIP_CHECK(hipEventCreateWithFlags(&evFwdDone_, hipEventDisableTiming));
@@ -1605,28 +1604,22 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
     // A front whose nc own columns (plus the index maps of its children) fit into LDS takes the fused single-workgroup path;
     // the others go through the level-batched multi-workgroup kernels.
     size_t fusedLds = 64 * 1024;
-    schur64Min_ = 512; // levels with at least this many 32 x 32 Schur tiles take the 64 x 64 kernel (k_big_schur64); IPCGPU_MF_SCHUR64_MIN=0 always, huge never
-    if (const char* e = std::getenv("IPCGPU_MF_SCHUR64_MIN")) schur64Min_ = std::atoll(e);
-    bulkMinMB_ = 48.0; // swept at 375 K nodes: 4, 16, 64 MB the same (factorisation 17.58 -> 16.9 ms); the contact stack's two top levels (11 and 17 MB) are better off without
-    bulkBlock_ = 256; // 128: the same, 512: half the gain (profiles/r05_two_level_blocking_ab.txt)
-    if (const char* e = std::getenv("IPCGPU_MF_BULK_MIN_MB")) bulkMinMB_ = std::atof(e); // (huge: every front updates all its own columns step by step, as before round 5)
-    if (const char* e = std::getenv("IPCGPU_MF_BULK_BLOCK")) bulkBlock_ = std::max(64, (std::atoi(e) / 32) * 32);
-    if (const char* e = std::getenv("IPCGPU_MF_FUSED_KB")) fusedLds = (size_t)std::max(8, std::min(150, std::atoi(e))) * 1024;
+    // Fixed since round 6 (each was an environment switch while it was being measured; the sweeps are profiles/r05_knob_sweep*.txt, r05_two_level_blocking_ab.txt,
+    // r03r_schur_tile_ab.txt, r04_nd_leaf_size_ab.txt): levels with >= 512 Schur tiles of 32 x 32 take the 64 x 64 kernel (schur64Min_); levels whose step launches
+    // move >= 48 MB of own columns factor them in outer blocks of 256 columns (bulkMinMB_, bulkBlock_: members with these defaults -- the only two a caller can set,
+    // ipcgpu_linsys_set_tuning, because no mesh of the test suite reaches 48 MB and the path has to be forced to be tested); 64 KB of LDS per fused front.
     auto ldsOf = [&](int s) {
         const size_t kids = (size_t)(sym.childPtr[s + 1] - sym.childPtr[s]);
         return ((size_t)sym.nc(s) * sym.N(s) + 64) * sizeof(double) + kids * sym.N(s) * sizeof(int);
     };
-    int ntSmallN = 0, ntBigN = 200;
-    if (const char* e = std::getenv("IPCGPU_MF_NT128_N")) ntSmallN = std::atoi(e);
-    if (const char* e = std::getenv("IPCGPU_MF_NT512_N")) ntBigN = std::atoi(e);
+    const int ntSmallN = 0, ntBigN = 200;
     // ... unless its level has fronts of the second kind anyway and only a few of the first (round 5): the single-workgroup kernel of such a level is a launch of
     // its own IN FRONT of the level's batched kernels -- 57 us for the 93 widest fused fronts of level 4 of a 45 K-node sheet, one workgroup each at the limit of
     // what LDS holds -- while as members of the batched launches the same fronts cost next to nothing (those launches are latency-bound and far from full).
-    // IPCGPU_MF_MIXED_LEVELS=1: every front that fits goes the fused way, as before round 5.
+    // (profiles/r05_mixed_levels_ab_and_p2p_bytes.txt)
     std::vector<char> fusedFront(ns_, 0);
     {
-        bool mixedOk = false;
-        if (const char* e = std::getenv("IPCGPU_MF_MIXED_LEVELS")) mixedOk = std::atoi(e) != 0;
+        const bool mixedOk = false;
         std::vector<int> nFit(nLevels_, 0), nBigL(nLevels_, 0);
         for (int s = 0; s < ns_; ++s) {
             fusedFront[s] = sym.childPtr[s + 1] - sym.childPtr[s] <= FUSED_MAX_KIDS && ldsOf(s) <= fusedLds;
@@ -1640,13 +1633,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
     }
     auto isFused = [&](int s) { return fusedFront[s] != 0; };
     // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
-    int xinvMin = 192;
-    if (const char* e = std::getenv("IPCGPU_MF_XINV_NC")) xinvMin = std::atoi(e) > 0 ? std::max(64, std::atoi(e)) : (1 << 30);
-    xinvBorder_ = true; // the inverse grows by bordering inside the step launches (step_border); 0: recursive doubling on the side stream, as before round 4
-    if (const char* e = std::getenv("IPCGPU_MF_XINV_BORDER")) xinvBorder_ = std::atoi(e) != 0;
-    int borderMaxNc = 1024; // wider separators (a root of 2 600 columns at 1.12 M tets) keep the recursive doubling: a bordering workgroup is as long as the
+    const int xinvMin = 192;
+    xinvBorder_ = true; // the inverse grows by bordering inside the step launches (step_border); false = recursive doubling on the side stream, as before round 4 (profiles/r05_permlane_and_border_ab.txt)
+    const int borderMaxNc = 1024; // wider separators (a root of 2 600 columns at 1.12 M tets) keep the recursive doubling: a bordering workgroup is as long as the
                             // front is wide, and at that width it stretches every step launch (measured at mat433: factorisation 20.0 -> 20.8 ms)
-    if (const char* e = std::getenv("IPCGPU_MF_BORDER_MAX_NC")) borderMaxNc = std::max(0, std::atoi(e));
     auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin; };
     auto hasBorder = [&](int s) { return xinvBorder_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; };
     // ---- multi-GPU: cut the assembly tree below its top separators (see mf_numeric.h)
@@ -1664,7 +1654,12 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
         xchg_.assign(nLevels_, Xchg());
         std::vector<int4> xd;
         long long maxCount = 1;
-        for (const MfExchangeLevel& E : plan) maxCount = std::max(maxCount, E.count + E.countW);
+        for (const MfExchangeLevel& E : plan) {
+            maxCount = std::max(maxCount, E.count + E.countW);
+            // the device descriptor of an update vector carries its offset (matrix area + offW) in ONE 32-bit word (k_xchg_w), the matrices' in two
+            if ((long long)E.count + (long long)E.countW > (long long)INT_MAX)
+                throw StateError("solver exchange: a level's staging area exceeds 2^31 doubles (the update-vector offsets are 32-bit)");
+        }
         xchgBuf_.ensure((size_t)maxCount + 1);
         for (int l = 0; l < nLevels_; ++l) {
             Xchg& X = xchg_[l];

@@ -514,7 +514,7 @@ void launch_assemble_patches(const ElemView& v, const PatchPlan& plan, int patch
         attrSet[wide] = lds;
     }
     const PatchView pv = plan.view();
-    static const int probe = std::getenv("IPCGPU_ASM_PROBE") ? std::atoi(std::getenv("IPCGPU_ASM_PROBE")) : 0; // profiling only
+    const int probe = 0;
     if (wide) {
         if (a)
             hipLaunchKernelGGL((k_assemble_patch<true, 512>), dim3(n), dim3(512), lds, s, v, pv, patchBegin, tcap, plan.maxNodes, coef, projectDBC, grad, a, probe, patchList);

@@ -14,6 +14,8 @@
 #include <cstring>
 #include <numeric>
 #include <queue>
+#include <random>
+#include <cstdlib>
 #include <vector>
 #include <omp.h>
 
@@ -145,9 +147,18 @@ struct ND {
 void analyze(Chol& c)
 {
     buildNodeGraph(c);
-    ND nd(c, 12);
+    // Two knobs for tools/make_golden_ensemble.py --orders (does the REFERENCE change its Newton counts when only the elimination order of its
+    // linear solver changes?): the leaf size of the dissection and a seeded shuffle of the node list it starts from (another BFS root, other
+    // separators).  Unset = the order every fixture under tests/golden/ was made with.
+    int leaf = 12;
+    if (const char* e = std::getenv("ORC_CHOL_LEAF")) leaf = std::max(1, std::atoi(e));
+    ND nd(c, leaf);
     std::vector<int> all(c.nn);
     std::iota(all.begin(), all.end(), 0);
+    if (const char* e = std::getenv("ORC_CHOL_SHUFFLE")) {
+        std::mt19937 gen((unsigned)std::atoi(e));
+        std::shuffle(all.begin(), all.end(), gen);
+    }
     nd.rec(all);
     c.ns = (int)nd.out.size();
     c.newOf.assign(c.nn, -1);

@@ -84,6 +84,36 @@ def test_errors_come_back_as_status_codes(gpu_lib, tmp_path):
     c.close()
 
 
+def test_malformed_mmcvid_tuples_are_refused(gpu_lib):
+    """ipcgpu_contact_evaluate / ipcgpu_contact_jt_multiply (SelfCollisionHandler.cpp:37-148 on caller-supplied tuples): every node id a kernel would read is
+    range-checked per stencil kind, exactly as the device decodes the tuple -- a negative id behind an edge-edge head or a node id past the mesh must come back
+    as an argument error, never reach the device."""
+    import ctypes as C
+    V, F = scene.make_box(2, 2, 2)
+    nV = V.shape[0]
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=1e5, PR=0.4, density=1000.0)
+    c.opt_init(0.01, False)
+    c.set_surface(scene.surface_tris(F))
+    L = c._L
+    L.ipcgpu_contact_evaluate.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.ipcgpu_contact_jt_multiply.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+
+    def both(t):
+        t = np.ascontiguousarray(t, dtype=np.int32).reshape(-1, 4)
+        val, inp, out = np.zeros(len(t)), np.ones(len(t)), np.zeros(3 * nV)
+        return (L.ipcgpu_contact_evaluate(c.h, len(t), t.ctypes.data, val.ctypes.data),
+                L.ipcgpu_contact_jt_multiply(c.h, len(t), t.ctypes.data, inp.ctypes.data, 1.0, out.ctypes.data), val, out)
+    good = [[0, 1, 25, 26], [-1, 26, -1, -2], [-1, 25, 26, -3], [-1, 24, 25, 26]]  # EE, PP x2, PE x3, PT
+    r0, r1, val, out = both(good)
+    assert r0 == 0 and r1 == 0 and np.all(val > 0) and np.abs(out).max() > 0
+    for bad in ([5, 6, 7, -3], [5, -2, 7, 8], [5, 6, -1, 8], [-4, -2, 1, 2], [-1, nV, -1, -1], [-nV - 1, 2, -1, -1], [-1, 2, nV, -1], [-1, 2, 3, nV], [0, 1, 2, nV]):
+        r0, r1, _, out = both(good + [bad])
+        assert r0 != 0 and r1 != 0, bad
+        assert np.all(out == 0.0)  # refused before anything was added
+    c.close()
+
+
 def test_a_setter_between_newton_iterations_discards_the_assembly_enqueued_ahead(orc, gpu_lib):
     """On the contact-free path the stepper enqueues the next iteration's assembly behind an accepted trial (HipOptimizer::speculativeAssembly).
     A caller that changes the constraints between two ipcgpu_opt_newton_iter calls must get an assembly of the NEW state: same iterates as the
