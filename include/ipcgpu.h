@@ -155,8 +155,14 @@ int ipcgpu_linsys_precondition_diag(ipcgpu_ctx*, const double* in, double* out);
    out2[0] = world size, out2[1] = the share of the factorisation flops that lies above the cut (executed once each, on the chain of the cut's levels). */
 int ipcgpu_linsys_set_shard(ipcgpu_ctx*, int rank, int world_size);
 int ipcgpu_linsys_shard_stats(ipcgpu_ctx*, double* out2);
-/* out4 = bytes THIS rank sent, bytes it received point to point through the solver's exchange hook so far, number of collective / group calls, 0 */
+/* out4 = bytes THIS rank sent, bytes it received point to point through the solver's exchange hook so far, number of collective / group calls, and the
+ * milliseconds this rank's stream spent inside those groups (HIP events around each: a rank that executes nothing at a level of the cut waits in its receive) */
 int ipcgpu_linsys_exchange_stats(ipcgpu_ctx*, double* out4);
+/* inputs of the strong-scaling model that bench.py prints beside its measured N-GPU value, after analyze_pattern: out5 = { dependent
+ * 32-column pivot steps on the critical path of the assembly tree (per level the widest front's steps, summed), the same over the fronts ABOVE the cut of
+ * ipcgpu_linsys_set_shard only, the largest rank's share of the flops below the cut (1 / world when balanced), levels, levels holding a front above the cut }.
+ * No counterpart in the reference: CHOLMOD (CHOLMODSolver.cpp:118-154) is single-process. */
+int ipcgpu_linsys_critical_path(ipcgpu_ctx*, double* out5);
 /* Owner-computes sharding (round 4; SURVEY.md 8e, the north star's "RCCL all-reduce of the shared-node gradient / Hessian rows"): a context that has BOTH
    ipcgpu_ctx_set_shard and ipcgpu_linsys_set_shard (same world) assembles, per rank, exactly the CSR rows its fronts read -- the rows of the nodes its
    subtrees eliminate plus the separator rows above the cut, which every rank repeats (elements and contact stencils on a cut are evaluated by both sides) --
@@ -169,6 +175,11 @@ int ipcgpu_opt_complete_matrix(ipcgpu_ctx*);
 /* diagnosis / tests (multifrontal solver, after analyze_pattern): for every entry k of the CSR pattern (ipcgpu_linsys_get_pattern order) the offset of its slot in
  * the front buffer, as the device kernel of the set-up computed it -- the same numbers mf_entry_destinations (ipc_amd/csrc/mf_symbolic.cpp) computes on the host */
 int ipcgpu_linsys_entry_destinations(ipcgpu_ctx*, long long* dst_nnz);
+/* The two parameters of the multifrontal factorisation a caller may set (every other one is fixed; their sweeps are under profiles/): levels of the assembly
+ * tree whose 32-column step launches move at least bulk_min_mb MB of own columns factor them in outer blocks of bulk_block columns (two-level blocking;
+ * defaults 48 MB / 256, reached by meshes beyond ~200 K nodes).  Takes effect at the next ipcgpu_linsys_analyze_pattern.  No counterpart in the reference
+ * (CHOLMOD's supernodal blocking is internal, CHOLMODSolver.cpp:118-131); exists so that tests can force the path at test sizes. */
+int ipcgpu_linsys_set_tuning(ipcgpu_ctx*, double bulk_min_mb, int bulk_block);
 /* factor statistics: nnz(L), factorisation flops, number of supernodes / levels */
 int ipcgpu_linsys_stats(ipcgpu_ctx*, double* stats4);
 

@@ -663,7 +663,7 @@ int ipcgpu_linsys_exchange_stats(ipcgpu_ctx* c, double* out4)
         out4[0] = (double)L(c).sentBytes();
         out4[1] = (double)L(c).receivedBytes();
         out4[2] = (double)L(c).exchangeCalls();
-        out4[3] = 0.0;
+        out4[3] = L(c).exchangeWaitMs();
         return IPCGPU_OK;
     });
 }
@@ -682,6 +682,23 @@ int ipcgpu_linsys_shard_stats(ipcgpu_ctx* c, double* out2)
     return guarded([&] {
         out2[0] = L(c).solverWorld();
         out2[1] = L(c).sharedFlopFraction();
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_set_tuning(ipcgpu_ctx* c, double bulk_min_mb, int bulk_block)
+{
+    return guarded([&] {
+        needArg(c != nullptr, "null context");
+        needArg(bulk_min_mb >= 0.0 && bulk_block >= 64 && bulk_block <= 4096, "set_tuning: bulk_min_mb >= 0, 64 <= bulk_block <= 4096");
+        L(c).setBulkTuning(bulk_min_mb, bulk_block);
+        return IPCGPU_OK;
+    });
+}
+int ipcgpu_linsys_critical_path(ipcgpu_ctx* c, double* out5)
+{
+    return guarded([&] {
+        needArg(c && out5, "null argument");
+        L(c).criticalPath(out5);
         return IPCGPU_OK;
     });
 }

@@ -140,7 +140,6 @@ private:
     DevBuf<double> closeVal_;
     DevBuf<char> scanTmp_;
     // deterministic scatter of the barrier / friction terms (hip_contact.hip "deterministic scatter"): per-stencil slots, keys, sort, run sums
-    bool atomicScatter_ = false; // IPCGPU_CONTACT_ATOMICS=1: the fp64-atomic path of rounds 1-2 (A/B timing)
     DevBuf<double> detVals_;
     DevBuf<unsigned> detKey_, detKeyOut_;
     DevBuf<int> detIota_, detPerm_, detRow_, hessPerm_; // hessPerm_: the two lists' indices binned by stencil kind (k_bin_stencils)

@@ -172,26 +172,21 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_scaled(const double* __restric
 // bits of g and a[] then depend on the order the atomics retire.  Now every stencil writes its contributions into its OWN slots of a
 // scratch array together with a key (the node, or the CSR position of the 3x3 block); the keys are radix-sorted (stable: equal keys
 // stay in slot order, i.e. stencil order) and one lane per run sums it front to back and adds the sum to the destination -- a fixed
-// summation order, bit-reproducible.  contrib == nullptr keeps the atomic path (IPCGPU_CONTACT_ATOMICS=1, for A/B timing).
+// summation order, bit-reproducible.  (The atomic path stayed behind an environment switch for A/B timing until round 6:
+// profiles/r03_contact_bench_atomic_scatter.json against r03_contact_bench_deterministic_scatter.json.)
 constexpr unsigned KEY_NONE = 0xFFFFFFFFu;
 struct GradSink {
-    double* grad; // atomic path
     double* contrib; // 3 doubles per slot
     unsigned* key; // node per slot (prefilled with KEY_NONE)
 };
 __device__ __forceinline__ void sink_add3(const GradSink& k, size_t slot, int node, const double v[3])
 {
-    if (k.contrib) {
-        k.key[slot] = (unsigned)node;
-        k.contrib[3 * slot] = v[0];
-        k.contrib[3 * slot + 1] = v[1];
-        k.contrib[3 * slot + 2] = v[2];
-    }
-    else
-        for (int c = 0; c < 3; ++c) atomicAdd(&k.grad[3 * (size_t)node + c], v[c]);
+    k.key[slot] = (unsigned)node;
+    k.contrib[3 * slot] = v[0];
+    k.contrib[3 * slot + 1] = v[1];
+    k.contrib[3 * slot + 2] = v[2];
 }
 struct BlockSink {
-    double* a; // atomic path
     double* contrib; // 9 doubles per slot, entry (r, c) at r + 3 c
     unsigned* key; // CSR index of the block's first entry (prefilled with KEY_NONE)
     int* rowNode; // row node of the block (the reducer derives row length and diagonal / off-diagonal from it)
@@ -733,7 +728,6 @@ __global__ __launch_bounds__(BLOCK) void k_friction_gradient(FrictionView fv, co
 __global__ __launch_bounds__(BLOCK) void k_friction_hessian(FrictionView fv, CsrView m, const double* __restrict__ x, const double* __restrict__ xt,
     const int* __restrict__ dbc, int projectDBC, double eps2, double coef, BlockSink sink, int* __restrict__ err)
 {
-    double* a = sink.a;
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= fv.n) return;
     const Stencil s = decode(fv.set + 4 * (size_t)i);
@@ -764,43 +758,20 @@ __global__ __launch_bounds__(BLOCK) void k_friction_hessian(FrictionView fv, Csr
             const int vj = s.node[l];
             if (projected_dbc(dbc[vj], projectDBC) || vi > vj) continue;
             const double w = wt[k] * wt[l];
-            const int L = m.ia[3 * vi + 1] - m.ia[3 * vi];
-            if (sink.contrib) { // deterministic path: the weighted block into this stencil's slot (4 k + l)
-                if (vi == vj && l != k) continue;
-                int p0 = m.ia[3 * vi];
-                if (vi != vj) {
-                    p0 = find_block(m, vi, vj);
-                    if (p0 < 0) {
-                        atomicOr(err, 1);
-                        continue;
-                    }
-                }
-                const size_t slot = 16 * (size_t)i + 4 * k + l;
-                sink.key[slot] = (unsigned)p0;
-                sink.rowNode[slot] = vi;
-                for (int q = 0; q < 9; ++q) sink.contrib[9 * slot + q] = w * BBt[q];
-                continue;
-            }
-            if (vi == vj) {
-                const int base = m.ia[3 * vi];
-                atomicAdd(&a[base + 0], w * BBt[0]);
-                atomicAdd(&a[base + 1], w * BBt[3]);
-                atomicAdd(&a[base + 2], w * BBt[6]);
-                atomicAdd(&a[base + L + 0], w * BBt[4]);
-                atomicAdd(&a[base + L + 1], w * BBt[7]);
-                atomicAdd(&a[base + 2 * L - 1], w * BBt[8]);
-            }
-            else {
-                const int p0 = find_block(m, vi, vj);
+            // the weighted block into this stencil's slot (4 k + l) of the deterministic scatter
+            if (vi == vj && l != k) continue;
+            int p0 = m.ia[3 * vi];
+            if (vi != vj) {
+                p0 = find_block(m, vi, vj);
                 if (p0 < 0) {
                     atomicOr(err, 1);
                     continue;
                 }
-                for (int r = 0; r < 3; ++r) {
-                    const int rowOff = (r == 0) ? 0 : (r == 1 ? (L - 1) : (2 * L - 3));
-                    for (int c = 0; c < 3; ++c) atomicAdd(&a[p0 + rowOff + c], w * BBt[r + 3 * c]);
-                }
             }
+            const size_t slot = 16 * (size_t)i + 4 * k + l;
+            sink.key[slot] = (unsigned)p0;
+            sink.rowNode[slot] = vi;
+            for (int q = 0; q < 9; ++q) sink.contrib[9 * slot + q] = w * BBt[q];
         }
     }
 }
@@ -2369,12 +2340,9 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
     const int n = nA + nP;
     if (n) {
         ContactView cv{ nA, nP, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p, need_dev };
-        if (atomicScatter_) hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ grad_dev, nullptr, nullptr });
-        else {
-            detBegin(8 * (size_t)n, 3, false);
-            hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ nullptr, detVals_.p, detKey_.p });
-            detReduce3(8 * (size_t)n, keyBitsFor((size_t)nV), grad_dev);
-        }
+        detBegin(8 * (size_t)n, 3, false);
+        hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ detVals_.p, detKey_.p });
+        detReduce3(8 * (size_t)n, keyBitsFor((size_t)nV), grad_dev);
     }
     hipLaunchKernelGGL(k_zero_projected, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, projectDBC, grad_dev);
 }
@@ -2395,7 +2363,7 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     detBegin(nSlots, 9, true, /*fillKeys=*/false); // the kernel writes every key
     const HessBins bins{ counters_.p + 4, hessPerm_.p, n };
     hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_W) + NBINS), dim3(HESS_W), 0, stream, cv, bins, m, dbc_dev, projectDBC, dHat, kappa,
-        BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p }, counters_.p);
+        BlockSink{ detVals_.p, detKey_.p, detRow_.p }, counters_.p);
     detReduceBlocks(nSlots, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
     int err[2];
     counters_.download(err, 2, stream);
@@ -2504,12 +2472,9 @@ void HipContact::frictionGradientAdd(const double* x_dev, const double* xt_dev, 
     const int n = (int)fricSet.size();
     if (!n) return;
     FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
-    if (atomicScatter_) hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, GradSink{ grad_dev, nullptr, nullptr });
-    else {
-        detBegin(8 * (size_t)n, 3, false);
-        hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, GradSink{ nullptr, detVals_.p, detKey_.p });
-        detReduce3(8 * (size_t)n, 32, grad_dev);
-    }
+    detBegin(8 * (size_t)n, 3, false);
+    hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, GradSink{ detVals_.p, detKey_.p });
+    detReduce3(8 * (size_t)n, 32, grad_dev);
 }
 
 void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, const int* dbc_dev, const HipLinSysSolver& lin, double eps2, double coef,
@@ -2521,15 +2486,10 @@ void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, c
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(16);
     counters_.zero(stream);
-    if (atomicScatter_)
-        hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
-            BlockSink{ a_dev, nullptr, nullptr, nullptr }, counters_.p);
-    else {
-        detBegin(16 * (size_t)n, 9, true);
-        hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
-            BlockSink{ nullptr, detVals_.p, detKey_.p, detRow_.p }, counters_.p);
-        detReduceBlocks(16 * (size_t)n, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
-    }
+    detBegin(16 * (size_t)n, 9, true);
+    hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
+        BlockSink{ detVals_.p, detKey_.p, detRow_.p }, counters_.p);
+    detReduceBlocks(16 * (size_t)n, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
     int err[2];
     counters_.download(err, 2, stream);
     if (err[0]) throw StateError("friction Hessian touches a node pair outside the CSR pattern: the pattern must contain the lagged set's connectivity");
@@ -2969,7 +2929,7 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
     counters_.alloc(16);
     // counters_: [0] queried pairs, [1] pairs that returned a time inside the step (the hit list)
     constexpr int HIT_CAP = 1 << 20;
-    static const bool twoPass = std::getenv("IPCGPU_CCD_TWO_PASS") != nullptr; // A/B: find the limiting pair by a second run of the sweep (rounds 1-2)
+    const bool twoPass = false; // (true: the limiting pair by a second run of the sweep, rounds 1-2; profiles/r03m_contact_bench_lds_jacobi_two_pass_ccd.json)
     if (!twoPass) ccdHits_.ensure(2 * (size_t)HIT_CAP);
     const unsigned long long init3[3] = { ~0ull, ~0ull, ~0ull };
     HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init3, sizeof(init3), hipMemcpyHostToDevice, stream));

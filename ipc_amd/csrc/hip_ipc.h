@@ -100,12 +100,15 @@ public:
     void setExchangeHooks(MfNumeric::ExchangeFn fn, void* user, MfNumeric::ExchangeStreamFn sfn, void* streamUser) { num_.setExchangeHooks(fn, user, sfn, streamUser); }
     bool hasExchangeHook() const { return num_.hasExchangeHook(); }
     int solverWorld() const { return num_.world(); }
+    void setBulkTuning(double minMB, int block) { num_.setBulkTuning(minMB, block); }
     void entryDestinations(long long* out) const { num_.entryDestinations(out, ja.size()); }
     void nodeOwners(std::vector<int>& o) const { num_.nodeOwners(o); }
     long long exchangedBytes() const { return num_.exchangedBytes(); }
     long long exchangeCalls() const { return num_.exchangeCalls(); }
     long long sentBytes() const { return num_.sentBytes(); }
     long long receivedBytes() const { return num_.receivedBytes(); }
+    double exchangeWaitMs() { return num_.exchangeWaitMs(); }
+    void criticalPath(double* out5) const { num_.criticalPath(out5); }
     int analysisVersion = 0; // bumped by every analyze_pattern (the owner-computes plan of the assembly follows the solver's cut)
     double sharedFlopFraction() const { return num_.sharedFlopFraction(); }
     bool analyzed() const { return analyzed_; }

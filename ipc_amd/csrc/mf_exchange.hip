@@ -1,5 +1,7 @@
 // GPU multifrontal Cholesky, multi-GPU: what crosses ranks (packed update matrices / vectors, solution segments, the pivot flag) and the hooks that carry it.
 // Split out of mf_numeric.hip in round 5.
+#include <chrono>
+#include <algorithm>
 #include "mf_kernels.h"
 
 namespace ipcgpu {
@@ -75,12 +77,73 @@ void MfNumeric::exchange(const std::vector<P2POp>& ops)
     }
     commCalls_++;
     if (exchangeStream_) { // stream-ordered (ncclSend / ncclRecv in one group on this stream): nothing to wait for on the host
+        if (waitPending_.size() >= 256) (void)exchangeWaitMs(); // (drains the stream once every 256 groups: the events are read in bulk)
+        std::pair<hipEvent_t, hipEvent_t> ev;
+        if (!waitFree_.empty()) {
+            ev = waitFree_.back();
+            waitFree_.pop_back();
+        }
+        else {
+            HIP_CHECK(hipEventCreate(&ev.first));
+            HIP_CHECK(hipEventCreate(&ev.second));
+        }
+        HIP_CHECK(hipEventRecord(ev.first, stream_));
         if (exchangeStream_(exchangeStreamUser_, (int)ops.size(), ops.data(), (void*)stream_) != 0) throw HipError("exchange hook failed");
+        HIP_CHECK(hipEventRecord(ev.second, stream_));
+        waitPending_.push_back(ev);
         return;
     }
     if (!exchange_) throw StateError("sharded solver without an exchange hook (ipcgpu_opt_set_exchange / ipcgpu_opt_set_exchange_stream)");
     HIP_CHECK(hipStreamSynchronize(stream_)); // the hook works on the caller's stream: ours has to be drained first
+    const auto t0 = std::chrono::steady_clock::now();
     if (exchange_(exchangeUser_, (int)ops.size(), ops.data()) != 0) throw HipError("exchange hook failed");
+    waitMs_ += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+double MfNumeric::exchangeWaitMs()
+{
+    for (auto& ev : waitPending_) {
+        HIP_CHECK(hipEventSynchronize(ev.second));
+        float ms = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms, ev.first, ev.second));
+        waitMs_ += (double)ms;
+        waitFree_.push_back(ev);
+    }
+    waitPending_.clear();
+    return waitMs_;
+}
+
+void MfNumeric::criticalPath(double* out5) const
+{
+    if (!sym_) throw StateError("critical path before analyze_pattern");
+    const MfSymbolic& sym = *sym_;
+    const int nLevels = (int)sym.levelPtr.size() - 1;
+    double steps = 0.0, above = 0.0, levelsAbove = 0.0;
+    std::vector<double> load(std::max(world_, 1), 0.0);
+    double below = 0.0;
+    for (int l = 0; l < nLevels; ++l) {
+        int widest = 0, widestAbove = 0;
+        for (int q = sym.levelPtr[l]; q < sym.levelPtr[l + 1]; ++q) {
+            const int s = sym.levelFronts[q], st = (sym.nc(s) + 31) / 32;
+            widest = std::max(widest, st);
+            const bool shared = world_ > 1 && owner_[s] < 0;
+            if (shared) widestAbove = std::max(widestAbove, st);
+            else {
+                const double N = sym.N(s), nc = sym.nc(s);
+                const double fl = nc * nc * nc / 3.0 + nc * nc * (N - nc) + nc * (N - nc) * (N - nc);
+                load[world_ > 1 ? owner_[s] : 0] += fl;
+                below += fl;
+            }
+        }
+        steps += widest;
+        above += widestAbove;
+        if (widestAbove) levelsAbove += 1.0;
+    }
+    out5[0] = steps;
+    out5[1] = above;
+    out5[2] = below > 0.0 ? *std::max_element(load.begin(), load.end()) / below : 1.0;
+    out5[3] = nLevels;
+    out5[4] = levelsAbove;
 }
 
 // update matrices of level l whose parent another rank executes: packed by the rank that computed them, sent point to point, unpacked into the same front on

@@ -40,6 +40,13 @@ public:
         world_ = world;
         setHooks(fn, user, sfn, streamUser);
     }
+    // the two parameters of the two-level blocking a caller may set (ipcgpu_linsys_set_tuning; read by the next setup()): no mesh of the test suite is big enough
+    // for the default threshold, so the tests force the path on through these
+    void setBulkTuning(double minMB, int block)
+    {
+        bulkMinMB_ = minMB;
+        bulkBlock_ = block < 64 ? 64 : (block / 32) * 32;
+    }
     void setExchangeHooks(ExchangeFn fn, void* user, ExchangeStreamFn sfn, void* streamUser)
     {
         exchange_ = fn;
@@ -65,6 +72,13 @@ public:
     long long exchangeCalls() const { return commCalls_; }
     long long sentBytes() const { return sentBytes_; }
     long long receivedBytes() const { return recvBytes_; }
+    // time this rank's stream spent inside the point-to-point groups so far (HIP events around every group: a rank that executes nothing at a level of the cut
+    // waits in its receive for the rank that does) -- the measured counterpart of `steps above the cut` in the strong-scaling model (bench.py expected_speedup_model)
+    double exchangeWaitMs();
+    // inputs of that model: out5 = { dependent 32-column pivot steps on the critical path of the tree (sum over the levels of the widest front's steps),
+    // the same over the fronts above the cut only, the largest rank's share of the flops below the cut (1 / world when balanced), levels, levels that
+    // hold a front above the cut }
+    void criticalPath(double* out5) const;
     double sharedFlopFraction() const { return sharedFlops_; } // share of the factorisation flops above the cut (executed once each since round 5, on the chain of the cut's levels)
     // a_dev: CSR values (device).  Returns false when a non-positive pivot was met.
     bool factorize(const double* a_dev);
@@ -106,7 +120,7 @@ private:
         Range xinvFwd, xinvBwd; // into xinvDesc_: row / column blocks of the fronts with an explicit inverse
     };
     int rank_ = 0, world_ = 1;
-    long long schur64Min_ = 512;
+    const long long schur64Min_ = 512; // levels with at least this many 32 x 32 Schur tiles take the 64 x 64 kernel (profiles/r03r_schur_tile_ab.txt)
     double bulkMinMB_ = 48.0; // levels whose step launches read + write at least that many MB of own columns factor them in outer blocks (two-level blocking, k_big_bulk); ipcgpu_linsys_set_tuning "bulk_min_mb"
     int bulkBlock_ = 256; // width of an outer block; ipcgpu_linsys_set_tuning "bulk_block"
     bool xinvBorder_ = true; // X = L11^-1 by bordering inside the step launches (false: recursive doubling on the side stream, the round-4 scheme)
@@ -123,6 +137,8 @@ private:
     std::vector<int> exec_; // per front: the rank that factorises and solves it (== owner_ below the cut)
     std::vector<unsigned long long> group_; // per front: ranks that execute a front of its subtree
     long long commBytes_ = 0, commCalls_ = 0, sentBytes_ = 0, recvBytes_ = 0;
+    double waitMs_ = 0.0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> waitPending_, waitFree_; // event pairs around exchange groups not yet read / free for reuse
     struct Xchg {
         Range pack; // into xchgDesc_: (front, staging offset lo, hi, offset of its update vector) of the fronts of this level this rank SENDS to their parent's rank
         Range unpack; // ... and of the children (of this level) of fronts this rank executes that it RECEIVES

@@ -1607,7 +1607,8 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
     // Fixed since round 6 (each was an environment switch while it was being measured; the sweeps are profiles/r05_knob_sweep*.txt, r05_two_level_blocking_ab.txt,
     // r03r_schur_tile_ab.txt, r04_nd_leaf_size_ab.txt): levels with >= 512 Schur tiles of 32 x 32 take the 64 x 64 kernel (schur64Min_); levels whose step launches
     // move >= 48 MB of own columns factor them in outer blocks of 256 columns (bulkMinMB_, bulkBlock_: members with these defaults -- the only two a caller can set,
-    // ipcgpu_linsys_set_tuning, because no mesh of the test suite reaches 48 MB and the path has to be forced to be tested); 64 KB of LDS per fused front.
+    // ipcgpu_linsys_set_tuning, because no mesh of the test suite reaches 48 MB and the path has to be forced to be tested; swept at 375 K nodes: 4, 16, 64 MB the
+    // same, factorisation 17.58 -> 16.9 ms; block 128 the same, 512 half the gain); 64 KB of LDS per fused front.
     auto ldsOf = [&](int s) {
         const size_t kids = (size_t)(sym.childPtr[s + 1] - sym.childPtr[s]);
         return ((size_t)sym.nc(s) * sym.N(s) + 64) * sizeof(double) + kids * sym.N(s) * sizeof(int);

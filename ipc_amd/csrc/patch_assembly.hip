@@ -253,8 +253,7 @@ void PatchPlan::build(const HipMesh& mesh, const HipLinSysSolver& lin, hipStream
     // elements per patch: 256 fills a 256-thread workgroup and has the least halo; a mesh that is only a round or two of resident workgroups (two per CU)
     // does better with 224 (mat150: 45.9 us against 47.8 -- more, shorter workgroups in the second round; mat433: 0.361 ms against 0.307,
     // profiles/r04_assembly_patch_size_ab.txt)
-    int tetCap = (nT < 300000) ? 224 : 256;
-    if (const char* e = std::getenv("IPCGPU_PATCH_TETS")) tetCap = std::max(32, std::min(BLOCK_MAX, std::atoi(e)));
+    const int tetCap = (nT < 300000) ? 224 : 256;
     std::vector<int> owner, localIdx; // filled with the patches (fresh topology only): who owns a node, and where in its patch
     const bool freshTopo = !(topo.mesh == (const void*)&mesh && topo.version == mesh.featuresVersion && topo.nV == nV && topo.nT == nT && topo.tetCap == tetCap);
     if (freshTopo) {

@@ -203,7 +203,14 @@ class Context:
         """bytes this rank sent / received point to point through the solver so far (ipcgpu_linsys_exchange_stats)"""
         o = np.zeros(4)
         self._chk(self._L.ipcgpu_linsys_exchange_stats(self.h, _dp(o)))
-        return dict(sent_bytes=int(o[0]), received_bytes=int(o[1]), calls=int(o[2]))
+        return dict(sent_bytes=int(o[0]), received_bytes=int(o[1]), calls=int(o[2]), wait_ms=float(o[3]))
+
+    def solver_critical_path(self):
+        """inputs of the strong-scaling model (ipcgpu_linsys_critical_path): dependent pivot steps of the assembly tree, those above the cut, the largest rank's share
+        of the flops below the cut, levels, levels with a front above the cut"""
+        o = np.zeros(5)
+        self._chk(self._L.ipcgpu_linsys_critical_path(self.h, _dp(o)))
+        return dict(steps=o[0], steps_above_cut=o[1], max_rank_share_below=o[2], levels=int(o[3]), levels_above_cut=int(o[4]))
 
     def entry_destinations(self):
         """per CSR entry its slot in the front buffer as the set-up's device kernel computed it (ipcgpu_linsys_entry_destinations)"""
@@ -414,6 +421,9 @@ class Context:
         out = np.zeros_like(v)
         self._chk(self._L.ipcgpu_linsys_precondition_diag(self.h, _dp(v), _dp(out)))
         return out
+
+    def set_solver_tuning(self, bulk_min_mb=48.0, bulk_block=256):
+        self._chk(self._L.ipcgpu_linsys_set_tuning(self.h, C.c_double(bulk_min_mb), C.c_int(bulk_block)))
 
     def linsys_stats(self):
         st = np.zeros(4)

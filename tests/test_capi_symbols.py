@@ -8,6 +8,8 @@ import pytest
 import ipc_amd
 from ipc_amd import lib as L
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def test_library_built_and_loads():
     assert os.path.exists(L.lib_path()), "libipcgpu.so missing: run __graft_entry__.build()"
@@ -53,3 +55,21 @@ def test_no_oracle_reference_in_product():
                 assert not pat.search(txt), (f, pat.search(txt).group(0))
     deps = os.popen(f"ldd {L.lib_path()}").read()
     assert "liborc" not in deps
+
+
+def test_the_product_reads_no_environment_switch_that_changes_results():
+    """every A/B switch whose loser is recorded under profiles/ is gone.  What the sources under ipc_amd/csrc may still read from the
+    environment only PRINTS (timings of a pattern change / of the solver's set-up, the barrier Hessian's sweep count); the two run-mode selectors of the
+    adapters (IPCGPU_OPTIMIZER_MODE, IPCGPU_PERCALL_CONTACT) choose WHICH implementation a reference build calls, not what it computes."""
+    import re
+    allowed = {"IPCGPU_DEBUG", "IPCGPU_MF_SETUP_TIMES", "IPCGPU_PATTERN_TIMES"}
+    found = set()
+    csrc = os.path.join(ROOT, "ipc_amd", "csrc")
+    for f in os.listdir(csrc):
+        found |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    assert found <= allowed, sorted(found - allowed)
+    adapters = os.path.join(ROOT, "include", "adapters")
+    found = set()
+    for f in os.listdir(adapters):
+        found |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(adapters, f)).read()))
+    assert found <= {"IPCGPU_OPTIMIZER_MODE", "IPCGPU_PERCALL_CONTACT", "IPCGPU_LINSYSSOLVER_TYPE"}, sorted(found)

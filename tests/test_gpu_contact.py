@@ -425,7 +425,7 @@ def test_mat_stack_sets_and_iterates_at_moderate_size(orc, gpu_lib):
 def test_contact_assembly_is_bit_reproducible(gpu_lib):
     """The barrier / friction forces and Hessian blocks are scattered by a sorted segmented reduction (hip_contact.hip "deterministic
     scatter"), not by fp64 atomics: evaluated twice at the same state they give the SAME BITS, and so does the elastic pass (gradient and
-    CSR values).  (IPCGPU_CONTACT_ATOMICS=1 brings the atomic path of rounds 1-2 back for A/B timing.)"""
+    CSR values)."""
     V, F, nA = scene.make_mat_stack(14, 2, gap=1.2e-3)
     Vs = scene.jitter(V, F, rel=2e-3)
     SF = scene.surface_tris(F)

@@ -296,3 +296,205 @@ def test_stack100_one_contact_newton_iteration(orc, gpu_lib, stack100):
     assert abs(sg["E"] - so["E"]) <= 1e-8 * abs(so["E"])
     assert relerr(sg["V"], so["V"]) < 1e-8
     c.close()
+
+
+# ---- contact_large: BASELINE configs[4] scale ("~1M tets: full pipeline"), SURVEY 8d item 5's stand-in --------------------------------------
+# Three mat250 sheets stacked with gaps < sqrt(dHat): 375 000 nodes / 1 116 018 tets / 749 988 surface triangles, 1.36 M active constraints + 0.25 M mollified
+# pairs out of 1.99 M candidate pairs at the first step.  The oracle's pieces (sets, barrier energy / gradient / Hessian, elastic energy) run at this size in seconds;
+# its time stepper does not (its symbolic analysis alone takes minutes on this pattern), so the Newton iterate is held to size-independent properties
+# evaluated WITH the oracle's pieces: the step solves the assembled system, the energy the stepper reports is the oracle's energy at the new state and has
+# not gone up, the new state is intersection-free, and the constraint set the stepper left behind is the oracle's set at the new state.
+@pytest.fixture(scope="module")
+def stack250(orc, gpu_lib):
+    V, F, nA = scene.make_mat_stack(250, 3, gap=1.2e-3)
+    Vs = scene.jitter(V, F, rel=2e-3)
+    SF = scene.surface_tris(F)
+    border = np.nonzero((np.abs(V[:nA, 0]) > 0.49) | (np.abs(V[:nA, 2]) > 0.49))[0].astype(np.int32)
+    m = orc.Mesh(V, F, YM=YM, PR=PR, density=RHO)
+    m.set_surface(SF)
+    m.set_dbc(border, 1)
+    m.set_V(Vs)
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=YM, PR=PR, density=RHO)
+    c.set_dbc(border, 1)
+    c.set_positions(Vs)
+    c.opt_init(0.01, True)
+    c.set_surface(SF)
+    dHat = 1e-6 * m.features()["bboxDiag2"]
+    yield dict(V=V, F=F, Vs=Vs, SF=SF, nA=nA, m=m, c=c, dHat=dHat, border=border)
+    c.close()
+
+
+def test_contact_large_constraint_sets_bit_exact(orc, stack250):
+    m, c, dHat = stack250["m"], stack250["c"], stack250["dHat"]
+    assert stack250["F"].shape[0] > 1100000
+    o = orc.Contacts().build(m, dHat)
+    g = c.contact_build(dHat)
+    assert len(o["active"]) > 1300000 and len(o["para"]) > 200000 and len(o["cs_ptee"]) > 1900000  # (three 21-bit counters once capped a set at 2 M candidates)
+    for k in ("active", "para", "para_eiej", "cs_ptee"):
+        assert np.array_equal(g[k], o[k]), k  # same tuples, same order, PP / PE multiplicities merged alike
+
+
+def test_contact_large_barrier_terms(orc, stack250):
+    m, c, dHat = stack250["m"], stack250["c"], stack250["dHat"]
+    cs = orc.Contacts()
+    cs.build(m, dHat)
+    c.contact_build(dHat)
+    kappa = 3.0e3
+    Eo = cs.energy(m, dHat, kappa)
+    assert abs(c.contact_energy(dHat, kappa) - Eo) <= 1e-10 * abs(Eo)
+    assert relerr(c.contact_gradient_add(dHat, kappa, True), cs.gradient(m, dHat, kappa, True)) < 1e-10
+    pairs = c.contact_connectivity()
+    assert np.array_equal(pairs, cs.connectivity(m))
+    c.set_pattern(pairs)
+    ia, ja = m.pattern(extra_edges=pairs)
+    ia_g, ja_g = c.get_pattern()
+    assert np.array_equal(ia_g, ia) and np.array_equal(ja_g, ja)
+    c.set_zero()
+    c.contact_hessian_add(dHat, kappa, True)
+    a_g = c.get_a()
+    a_o = cs.hessian(m, len(ja), dHat, kappa, True)
+    assert relerr(a_g, a_o) < 1e-9
+    assert np.array_equal(a_g == 0, a_o == 0)
+    c.set_pattern()
+
+
+def test_contact_large_newton_iterate_properties(orc, gpu_lib, stack250):
+    V, F, Vs, SF, nA, border = (stack250[k] for k in ("V", "F", "Vs", "SF", "nA", "border"))
+    dt = 0.01
+    vel = np.zeros_like(V)
+    vel[nA:, 1] = -0.05
+    c = gpu_lib.Context(0)
+    c.set_mesh(V, F, YM=YM, PR=PR, density=RHO)
+    c.set_dbc(border, 1)
+    c.set_positions(Vs)
+    c.opt_init(dt, True)
+    c.set_surface(SF)
+    c.enable_self_collision(1e-3)
+    c.set_velocity(vel)
+    c.precompute()
+    c.begin_timestep()
+    s0 = c.state()
+    m = orc.Mesh(V, F, YM=YM, PR=PR, density=RHO)
+    m.set_surface(SF)
+    m.set_dbc(border, 1)
+    mass = m.features()["mass"]
+    free = np.ones(V.shape[0], dtype=bool)
+    free[border] = False
+    xt = Vs + free[:, None] * (dt * vel + dt * dt * np.array([0.0, -9.80665, 0.0]))  # Optimizer.cpp:1236-1257
+
+    def oracle_energy(X, kappa, dHat):
+        m.set_V(X)
+        cs = orc.Contacts()
+        sets = cs.build(m, dHat)
+        E = m.elastic_energy(dt * dt) + 0.5 * float((mass * free * ((X - xt) ** 2).sum(1)).sum()) + cs.energy(m, dHat, kappa)
+        return E, sets
+    assert abs(s0["dHat"] - 1e-6 * m.features()["bboxDiag2"]) <= 1e-15 * s0["dHat"]
+    E0, sets0 = oracle_energy(s0["V"], s0["kappa"], s0["dHat"])
+    assert abs(s0["E"] - E0) <= 1e-9 * abs(E0)
+    assert c.contact_state()["nActive"] == len(sets0["active"]) > 1300000
+    assert not c.newton_iter()
+    s1 = c.state()
+    # the search direction solves the system the iterate assembled (elastic + inertia + 1.6 M PSD-projected barrier blocks on the contact pattern)
+    p, g = s1["searchDir"].reshape(-1), s1["gradient"].reshape(-1)
+    assert np.linalg.norm(c.multiply(p) + g) <= 1e-8 * np.linalg.norm(g)
+    assert 0.0 < s1["stepSize"] <= s1["alphaFeasible"] <= 1.0
+    assert relerr(s1["V"], s0["V"] + s1["stepSize"] * s1["searchDir"].reshape(-1, 3)) < 1e-14
+    # the energy the stepper accepted is the oracle's energy of the new state (kappa may have been doubled AFTER the line search: use the value it searched with)
+    E1, sets1 = oracle_energy(s1["V"], s0["kappa"], s1["dHat"])
+    assert abs(s1["E"] - E1) <= 1e-9 * abs(E1)
+    assert E1 <= E0
+    st = c.contact_state()
+    assert st["nActive"] == len(sets1["active"]) and st["nPara"] == len(sets1["para"])
+    assert not c.is_intersected() and not orc.is_intersected(m)
+    assert c.check_inversion()
+    c.close()
+
+
+# ---- matTwist AS SHIPPED: input/paperExamples/14_matTwist.txt:15 says `selfCollisionOn` (BASELINE configs[1] strips it) -------------------------
+def _twist_pair(orc, gpu_lib, status=None):
+    sys_path_tools()
+    import bench_mat_twist as bt
+    c, S = bt.make_context(150)
+    m = orc.Mesh(S["V"], S["F"], YM=YM, PR=PR, density=RHO)
+    m.set_surface(S["SF"])
+    o = orc.Optimizer(m, dt=DT, gravity=False, nthreads=16)
+    o.set_twist(S["left"], S["right"], 0.4 * np.pi)
+    orc.opt_enable_self_collision(o, 1e-3)
+    if status is not None:
+        c.load_status(status)
+        orc.opt_load_status(o, status)
+    o.precompute()
+    c.precompute()
+    return c, o
+
+
+def sys_path_tools():
+    import os
+    import sys
+    t = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if t not in sys.path:
+        sys.path.insert(0, t)
+
+
+def _track(o, c, iters, tol):
+    """one time step, iterate by iterate; returns the number of compared Newton iterations"""
+    o.begin_timestep()
+    c.begin_timestep()
+    done = 0
+    for it in range(iters):
+        co, cg = o.newton_iter(), c.newton_iter()
+        assert bool(co) == bool(cg), it
+        if co:
+            break
+        so, sg = o.state(), c.state()
+        cst_o, cst_g = orc_contact_state(o), c.contact_state()
+        assert cst_g["nActive"] == len(cst_o["active"]) and cst_g["nPara"] == len(cst_o["para"]) and cst_g["nCand"] == len(cst_o["cs_ptee"]), it
+        assert abs(sg["stepSize"] - so["stepSize"]) <= tol * so["stepSize"], it
+        assert abs(sg["kappa"] - so["kappa"]) <= tol * so["kappa"], it
+        assert abs(sg["E"] - so["E"]) <= tol * abs(so["E"]), it
+        assert relerr(sg["V"], so["V"]) < tol, it
+        done += 1
+    return done
+
+
+def orc_contact_state(o):
+    from oracle import orc as _o
+    return _o.opt_contact_state(o)
+
+
+def test_mat_twist_as_shipped_early_steps_track_the_oracle(orc, gpu_lib):
+    """The first time steps of the scene an IPC user runs: nothing is active yet, but every iteration builds the constraint sets, bounds the step by CCD and
+    checks for intersections (Optimizer.cpp:1884-2040, 2719-2744)."""
+    c, o = _twist_pair(orc, gpu_lib)
+    assert c.state()["dHat"] == o.state()["dHat"] > 0.0
+    n = 0
+    for step in range(2):
+        n += _track(o, c, 12, 1e-9)
+        o.end_timestep()
+        c.end_timestep()
+    assert n >= 5
+    assert c.contact_state()["nActive"] == 0
+    c.close()
+
+
+def test_mat_twist_as_shipped_wrapped_state_tracks_the_oracle(orc, gpu_lib, tmp_path):
+    """The same scene once the sheet has wrapped onto itself: the HIP stepper runs until its constraint set holds >= 1000 stencils (step 33 or so), writes the
+    reference's status file (Optimizer.cpp:2964-3011); a fresh context and the oracle both restart from it (`restart`, Optimizer.cpp:179-248) and take the next
+    step iterate by iterate: same set sizes, step sizes, kappa, energies, positions."""
+    sys_path_tools()
+    import bench_mat_twist as bt
+    c, S = bt.make_context(150)
+    c.precompute()
+    taken = bt.advance_to_contact(c, 1000, 80)
+    assert 20 <= taken < 80 and c.contact_state()["nActive"] >= 1000
+    assert not c.is_intersected()
+    status = str(tmp_path / "status_wrapped")
+    c.save_status(status)
+    c.close()
+    c2, o2 = _twist_pair(orc, gpu_lib, status)
+    assert c2.state()["timestep"] == o2.state()["timestep"] == taken
+    n = _track(o2, c2, 3, 1e-7)
+    assert n >= 3
+    assert c2.contact_state()["nActive"] >= 1000
+    c2.close()

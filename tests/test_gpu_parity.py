@@ -316,34 +316,23 @@ def test_two_level_blocking_of_wide_fronts(gpu_lib, block):
     """Round 5: the fronts of a level whose step launches move many bytes factor their own columns in outer blocks -- a step's rank-32 update stops at the end of its
     block, one bulk update per block (k_big_bulk, ipc_amd/csrc/mf_numeric.hip) brings the columns behind it up to date, the panel that opens the next block has nothing
     left to apply.  By default no mesh of the test suite is large enough to take that path (48 MB per step launch: meshes beyond ~200 K nodes), so it is forced on here
-    for every level (IPCGPU_MF_BULK_MIN_MB=0) with small blocks: the same matrix factorised both ways must give the same solution, and the residual of the CSR product
+    for every level (ipcgpu_linsys_set_tuning: bulk_min_mb 0) with small blocks: the same matrix factorised both ways must give the same solution, and the residual of the CSR product
     must be at round-off.  Not-PD detection included (the flag travels through the same step launches)."""
-    import os
     V, F = scene.make_mat(60)
     Vt = scene.twist_state(scene.jitter(V, F), 0.5)
     left, right = scene.border_verts(V, 0.01)
     xs = []
     for forced in (False, True):
-        old = {k: os.environ.get(k) for k in ("IPCGPU_MF_BULK_MIN_MB", "IPCGPU_MF_BULK_BLOCK")}
-        if forced:
-            os.environ["IPCGPU_MF_BULK_MIN_MB"], os.environ["IPCGPU_MF_BULK_BLOCK"] = "0", str(block)
-        else:
-            os.environ["IPCGPU_MF_BULK_MIN_MB"] = "1e9"
-        try:
+        if True:
             c = gpu_lib.Context(0)
+            c.set_solver_tuning(0.0, block) if forced else c.set_solver_tuning(1e9, 256)
             c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
             c.opt_init(0.04, False)
             c.set_dbc(np.concatenate([left, right]), 2)
             c.set_positions(Vt)
             c.set_pattern()
             c.assemble_newton(0.04 ** 2, True, with_gradient=False)
-            c.analyze_pattern()  # (the switches are read by the set-up of the numeric phase, here)
-        finally:
-            for k, v in old.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+            c.analyze_pattern()  # (the tuning is read by the set-up of the numeric phase, here)
         assert c.factorize()
         rows, _ = c.get_dims()
         b = np.random.default_rng(5).normal(size=rows)

@@ -386,3 +386,11 @@ def test_bench_line_at_two_ranks_on_one_device():
     assert 0.3 < c["rows_assembled_on_rank0"] < 0.8  # owner-computes rows: about half of the matrix each
     lw = d["large_workload"]
     assert lw["value"] > 0 and lw["solver_sharded"] and 0.0 < lw["shared_flop_fraction"] < 1.0
+    # round 6: the strong-scaling model of DESIGN.md section 6 evaluated beside the measured value, for both workloads, and the time a rank waits above the cut
+    for rec in (d, lw):
+        mdl = rec["expected_speedup_model"]
+        assert 0 < mdl["steps_above_cut"] < mdl["steps_on_critical_path"] and 0.4 < mdl["largest_rank_share_below_cut"] <= 1.0
+        assert 1.0 < mdl["expected_speedup"] < 2.0 and mdl["amdahl_bound_on_factorisation_flops"] <= 2.0
+        assert mdl["single_rank_measured_in_this_job"]["factor_ms"] > 0
+    assert c["rank_wait_ms"] >= 0.0 and lw["comm_per_iter_rank0"]["rank_wait_ms"] >= 0.0
+    assert len(d["ms_per_step_min_median_max"]) == 3 and d["ms_per_step_min_median_max"][0] <= d["ms_per_step_min_median_max"][2]

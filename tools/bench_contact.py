@@ -51,6 +51,10 @@ def run(n=60, layers=2, steps=3, max_iter=12, gap=1.2e-3, cpu_iters=0):
         counts.append(c.contact_state())
     wall = time.time() - t0
     tm = c.timers() - tm0
+    st = c.linsys_stats()  # of the pattern the last iteration factorised (mesh + contact pairs)
+    f_ms, s_ms = c.bench_factor_solve(1)
+    solver = {"nnzL": st["nnzL"], "factor_gflop": st["flops"] / 1e9, "fronts": st["fronts"], "levels": st["levels"], "factor_ms": f_ms, "solve_ms": s_ms,
+              "factor_tflops_per_s": st["flops"] / 1e12 / (f_ms * 1e-3), "frac_of_78.6_TFLOPs": st["flops"] / 1e12 / (f_ms * 1e-3) / 78.6}
     # timer buckets of the stepper (nested ones taken out of their parent, so that the entries add up to the wall time): bucket 0 is the whole
     # of computePrecondMtr and contains set_pattern (1) and the symbolic analysis (2) of a pattern change, plus the host-side connectivity work
     # of such a change; bucket 3 holds the numeric factorisation and -- overlapped with it -- both triangular sweeps (MfNumeric::factorizeSolve)
@@ -88,7 +92,7 @@ def run(n=60, layers=2, steps=3, max_iter=12, gap=1.2e-3, cpu_iters=0):
         "cpu_baseline": cpu,
         "scene": f"{args.layers} x mat{args.n} stack, gap {args.gap}, dHat 1e-3, self-collision on", "n_nodes": int(V.shape[0]), "n_tets": int(F.shape[0]),
         "n_surface_tris": int(SF.shape[0]), "newton_iterations": iters, "iters_per_s": iters / wall, "ms_per_iter_wall": 1e3 * wall / max(iters, 1),
-        "precompute_s": t_pre, "split_ms_per_iter": split, "contact_state_per_step": counts, "intersected_at_end": bool(c.is_intersected()),
+        "precompute_s": t_pre, "solver": solver, "split_ms_per_iter": split, "contact_state_per_step": counts, "intersected_at_end": bool(c.is_intersected()),
     }
 
 
