@@ -284,6 +284,12 @@ int ipcgpu_opt_set_twist(ipcgpu_ctx*, int nLeft, const int* left, int nRight, co
  * dHat = dHatEps^2 * bboxDiag^2 (`dHat` keyword, default 1e-3).  From then on the stepper builds constraint sets, adds the
  * barrier terms, adapts kappa and bounds every step by CCD exactly as fullyImplicit_IP / solveSub_IP do. */
 int ipcgpu_opt_enable_self_collision(ipcgpu_ctx*, double dHatEps);
+/* Look-ahead of the contact pattern (no counterpart in the reference, which rebuilds pattern + symbolic analysis whenever the contact graph changes,
+ * Optimizer.cpp:3570-3592; here the pattern only grows and a new analysis is needed when a pair shows up that the pattern lacks): on such a change the new
+ * pattern takes the full stencils of the candidate set at `pad` x dHat (squared distances), blocks of pairs that are not active yet hold explicit zeros.
+ * pad < 1: exactly the live pairs; 1: full stencils of the current candidates; > 1 (default 4 = twice the distance): fewer analyses, more fill in the factor.
+ * The Newton iterates do not depend on it (explicit zeros); what it trades is host-side analyses against factorisation flops. */
+int ipcgpu_opt_set_pattern_lookahead(ipcgpu_ctx*, double pad);
 /* analytic half-space obstacle (`ground` / `halfSpace` keywords, Config.cpp:306-345; HalfSpace.cpp:41-85): points with
  * normal.(x - origin) > 0 are free.  Needs ipcgpu_set_surface.  Returns its index in *id.  The stepper then builds its
  * vertex constraint set (CollisionObject.h:323-351), adds barrier energy / gradient / diagonal Hessian blocks

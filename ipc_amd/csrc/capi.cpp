@@ -1090,6 +1090,16 @@ int ipcgpu_opt_enable_self_collision(ipcgpu_ctx* c, double dHatEps)
         return IPCGPU_OK;
     });
 }
+int ipcgpu_opt_set_pattern_lookahead(ipcgpu_ctx* c, double pad)
+{
+    specChanged(c);
+    return guarded([&] {
+        HipOptimizer& o = O(c);
+        needArg(pad >= 0.0 && pad <= 100.0, "pattern look-ahead: 0 <= pad <= 100 (in units of dHat)");
+        o.patternPad = pad;
+        return IPCGPU_OK;
+    });
+}
 int ipcgpu_opt_add_half_space(ipcgpu_ctx* c, const double* origin, const double* normal, double dHatEps, int* id)
 {
     specChanged(c);

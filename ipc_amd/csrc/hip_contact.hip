@@ -1118,22 +1118,42 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restri
             }
     wg_list_flush(wl, &sBase, cap, out, counter);
 }
-// The same narrow phase CELL by cell (round 6).  The walk above visits, for every edge, every record of every cell its inflated box touches: ~300 records of
-// 32 B per edge, most of them the same neighbours met again in the next cell and once more from the other edge's side -- 1.2 GB through L2 for 1.2e5 edges,
-// 0.27 ms, the largest contact kernel for three rounds.  Here one WAVE takes one cell: lane b holds record b of the cell with its edge's nodes and positions
-// (loaded once), and the wave walks the cell's records a TOGETHER -- a uniform index, so the record, the nodes and the positions of edge a arrive through
-// the scalar cache, once per wave -- and lane b tests the pair (a, b) when a's edge has the smaller index.  Every record is read once per cell it lies in;
-// a pair is handled in the one cell that holds the low corner of the overlap of the two inflated boxes, exactly as above, by the same double-precision tests:
-// the SAME records come out (in another order; they are sorted by primitive pair afterwards).
+// The same narrow phase CELL by cell (round 6).  The walk above visits, for every edge, every record of every cell its inflated box touches (~300 records
+// of 32 B per edge, most of them the same neighbours met again in the next cell and once more from the other edge's side), and whenever one of the eight
+// lanes that share an edge finds a pair whose boxes overlap, it runs the typing + distance of that pair -- a few hundred fp64 instructions -- while the
+// other lanes of the wave wait: 0.27 ms for 1.2e5 edges, the largest contact kernel for three rounds.  Here:
+//   * one WAVE takes one cell.  Lane b holds record b of the cell with its edge's nodes and positions (loaded once); the wave walks the cell's records a
+//     TOGETHER -- a uniform index, so record, nodes and positions of edge a arrive through the scalar cache, once per wave -- and lane b tests the pair
+//     (a, b) when a's edge has the smaller index: outward-rounded float boxes, then the exact inflated boxes and the rule that a pair belongs to the one
+//     cell that holds the low corner of their overlap (exactly as above: the SAME pairs survive);
+//   * survivors are not typed where they are found: they go into a queue of the wave in LDS, and whenever 64 have gathered ALL lanes take one each --
+//     typing and distance run on full waves.
+// The same records come out (in another order; they are sorted by primitive pair afterwards).
+constexpr int EE_QUEUE = 128;
+__device__ __forceinline__ void narrow_ee_queued(int eI, int eJ, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
+    const int* __restrict__ dbc, int nE, double dHat, const WgList& wl, int cap, int* __restrict__ out, int* __restrict__ counter)
+{
+    const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1], b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
+    if ((dbc[a0] & 1) && (dbc[a1] & 1) && (dbc[b0] & 1) && (dbc[b1] & 1)) return; // SelfCollisionHandler.cpp:2294-2297
+    if (pair_filtered(dbc[a0], dbc[b0])) return;
+    const double pa0[3] = { x[3 * (size_t)a0], x[3 * (size_t)a0 + 1], x[3 * (size_t)a0 + 2] };
+    const double pa1[3] = { x[3 * (size_t)a1], x[3 * (size_t)a1 + 1], x[3 * (size_t)a1 + 2] };
+    const double pb0[3] = { x[3 * (size_t)b0], x[3 * (size_t)b0 + 1], x[3 * (size_t)b0 + 2] };
+    const double pb1[3] = { x[3 * (size_t)b1], x[3 * (size_t)b1 + 1], x[3 * (size_t)b1 + 2] };
+    narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
+}
 __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
     const int* __restrict__ dbc, Grid g, int nCells, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
     int* __restrict__ out, int* __restrict__ counter)
 {
     __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
+    __shared__ int2 sQueue[BLOCK / 64][EE_QUEUE];
     const WgList wl{ &sCount, sRecs };
     if (threadIdx.x == 0) sCount = 0;
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int2* q = sQueue[wv];
+    int qn = 0; // entries in the wave's queue (uniform)
     const int cell = blockIdx.x * (BLOCK / 64) + wv;
     int kBeg = 0, kEnd = 0;
     if (cell < nCells) {
@@ -1147,35 +1167,50 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __
             const BoxRec rb = load_box_rec(cellItems, vb ? kb0 + lane : kBeg);
             const int eJ = rb.id;
             const int b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
-            const double pb0[3] = { x[3 * (size_t)b0], x[3 * (size_t)b0 + 1], x[3 * (size_t)b0 + 2] };
-            const double pb1[3] = { x[3 * (size_t)b1], x[3 * (size_t)b1 + 1], x[3 * (size_t)b1 + 2] };
-            const bool bDbc = (dbc[b0] & 1) && (dbc[b1] & 1);
+            double jl[3], jh[3];
+            for (int c = 0; c < 3; ++c) {
+                const double p0 = x[3 * (size_t)b0 + c], p1 = x[3 * (size_t)b1 + c];
+                jl[c] = fmin(p0, p1) - infl;
+                jh[c] = fmax(p0, p1) + infl;
+            }
             for (int ka = kBeg; ka < kEnd; ++ka) {
                 const BoxRec ra = load_box_rec(cellItems, ka); // uniform over the wave
                 const int eI = ra.id;
-                const bool near = vb && eJ > eI
+                bool ok = vb && eJ > eI
                     && !(ra.lo[0] > rb.hi[0] || rb.lo[0] > ra.hi[0] || ra.lo[1] > rb.hi[1] || rb.lo[1] > ra.hi[1] || ra.lo[2] > rb.hi[2] || rb.lo[2] > ra.hi[2]);
-                if (!__any(near)) continue; // outward-rounded boxes apart for every lane: nothing of edge a is needed
+                if (!__any(ok)) continue; // outward-rounded boxes apart for every lane: nothing of edge a is needed
                 const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1];
-                const double pa0[3] = { x[3 * (size_t)a0], x[3 * (size_t)a0 + 1], x[3 * (size_t)a0 + 2] };
-                const double pa1[3] = { x[3 * (size_t)a1], x[3 * (size_t)a1 + 1], x[3 * (size_t)a1 + 2] };
-                if (!near) continue;
-                if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
+                ok = ok && !(a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1);
                 // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap
-                bool ok = true;
                 int canon[3];
                 for (int c = 0; c < 3; ++c) {
-                    const double il = fmin(pa0[c], pa1[c]) - infl, ih = fmax(pa0[c], pa1[c]) + infl;
-                    const double jl = fmin(pb0[c], pb1[c]) - infl, jh = fmax(pb0[c], pb1[c]) + infl;
-                    if (il > jh || jl > ih) ok = false;
-                    canon[c] = cell_of(g, fmax(il, jl), c);
+                    const double p0 = x[3 * (size_t)a0 + c], p1 = x[3 * (size_t)a1 + c];
+                    const double il = fmin(p0, p1) - infl, ih = fmax(p0, p1) + infl;
+                    if (il > jh[c] || jl[c] > ih) ok = false;
+                    canon[c] = cell_of(g, fmax(il, jl[c]), c);
                 }
-                if (!ok || canon[0] != cx || canon[1] != cy || canon[2] != cz) continue;
-                if (bDbc && (dbc[a0] & 1) && (dbc[a1] & 1)) continue; // SelfCollisionHandler.cpp:2294-2297
-                if (pair_filtered(dbc[a0], dbc[b0])) continue;
-                narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
+                ok = ok && canon[0] == cx && canon[1] == cy && canon[2] == cz;
+                const unsigned long long m = __ballot(ok);
+                if (!m) continue;
+                if (ok) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(eI, eJ);
+                qn += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) { // a full wave of pairs: type them, keep the rest
+                    const int2 pr = q[lane];
+                    const int rest = qn - 64;
+                    const int2 mv = q[64 + (lane < rest ? lane : 0)];
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < rest) q[lane] = mv;
+                    qn = rest;
+                    __builtin_amdgcn_wave_barrier();
+                    narrow_ee_queued(pr.x, pr.y, SFE, x, xRest, dbc, nE, dHat, wl, cap, out, counter);
+                }
             }
         }
+    if (lane < qn) {
+        const int2 pr = q[lane];
+        narrow_ee_queued(pr.x, pr.y, SFE, x, xRest, dbc, nE, dHat, wl, cap, out, counter);
+    }
     wg_list_flush(wl, &sBase, cap, out, counter);
 }
 // ---- conservative CCD (advancement on the unclassified distance until it meets the gap; contract in DESIGN.md) ---------------

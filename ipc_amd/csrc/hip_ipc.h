@@ -294,7 +294,7 @@ public:
     std::vector<std::array<int, 4>> closeID; // closeMConstraintID / Val (Optimizer.cpp:2396-2440)
     std::vector<double> closeVal;
     int lastCCDPair[2] = { 0, 0 }, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
-    double patternPad = 4.0; // look-ahead of the contact pattern in units of dHat (IPCGPU_PATTERN_PAD; 1 = exact pattern)
+    double patternPad = 4.0; // look-ahead of the contact pattern in units of dHat (ipcgpu_opt_set_pattern_lookahead; < 1 = exact pattern)
     // analytic half-space obstacles (animConfig.collisionObjects) and their close-constraint list (Optimizer.cpp:2364-2374)
     std::vector<std::unique_ptr<HipHalfSpace>> planes;
     std::vector<std::pair<int, int>> closeHS;

@@ -590,6 +590,9 @@ class Context:
     def enable_self_collision(self, dHatEps=1e-3):
         self._chk(self._L.ipcgpu_opt_enable_self_collision(self.h, C.c_double(dHatEps)))
 
+    def set_pattern_lookahead(self, pad=4.0):
+        self._chk(self._L.ipcgpu_opt_set_pattern_lookahead(self.h, C.c_double(pad)))
+
     def add_half_space(self, origin, normal, dHatEps=1e-3):
         o, n = _f64(np.asarray(origin)), _f64(np.asarray(normal))
         idx = C.c_int()

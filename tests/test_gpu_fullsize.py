@@ -449,7 +449,7 @@ def _track(o, c, iters, tol):
             break
         so, sg = o.state(), c.state()
         cst_o, cst_g = orc_contact_state(o), c.contact_state()
-        assert cst_g["nActive"] == len(cst_o["active"]) and cst_g["nPara"] == len(cst_o["para"]) and cst_g["nCand"] == len(cst_o["cs_ptee"]), it
+        assert cst_g["nActive"] == len(cst_o["active"]) and cst_g["nPara"] == len(cst_o["para"]) and cst_g["nCand"] == cst_o["n_candidates"], it
         assert abs(sg["stepSize"] - so["stepSize"]) <= tol * so["stepSize"], it
         assert abs(sg["kappa"] - so["kappa"]) <= tol * so["kappa"], it
         assert abs(sg["E"] - so["E"]) <= tol * abs(so["E"]), it

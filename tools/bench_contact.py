@@ -13,7 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ipc_amd import lib, scene  # noqa: E402
 
-def run(n=60, layers=2, steps=3, max_iter=12, gap=1.2e-3, cpu_iters=0):
+def run(n=60, layers=2, steps=3, max_iter=12, gap=1.2e-3, cpu_iters=0, pad=None):
     """One run of the contact scene on cuda:0; returns the record (dict) that the command line prints."""
     class A:
         pass
@@ -32,6 +32,8 @@ def run(n=60, layers=2, steps=3, max_iter=12, gap=1.2e-3, cpu_iters=0):
     border = low[(np.abs(V[:nA, 0]) > 0.49) | (np.abs(V[:nA, 2]) > 0.49)].astype(np.int32)
     c.set_dbc(border, 1)
     c.enable_self_collision(1e-3)
+    if pad is not None:
+        c.set_pattern_lookahead(pad)  # A/B of the look-ahead (ipcgpu_opt_set_pattern_lookahead); None = the library's default
     vel = np.zeros_like(V)
     vel[nA:, 1] = -0.05
     c.set_velocity(vel)
@@ -104,5 +106,6 @@ if __name__ == "__main__":
     ap.add_argument("--max-iter", type=int, default=12)
     ap.add_argument("--gap", type=float, default=1.2e-3)
     ap.add_argument("--cpu-iters", type=int, default=0, help="also time the CPU oracle on the first N Newton iterations of the same scene")
+    ap.add_argument("--pad", type=float, default=None, help="look-ahead of the contact pattern in units of dHat (default: the library's, 4)")
     args = ap.parse_args()
-    print(json.dumps(run(args.n, args.layers, args.steps, args.max_iter, args.gap, args.cpu_iters)))
+    print(json.dumps(run(args.n, args.layers, args.steps, args.max_iter, args.gap, args.cpu_iters, args.pad)))

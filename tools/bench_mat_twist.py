@@ -20,7 +20,7 @@ NAMES = {1: "pattern_change:set_pattern", 2: "pattern_change:symbolic_analysis",
          9: "energy_evals", 13: "step_bounds(inversion+CCD+CFL)", 14: "constraint_sets", 11: "timestep"}
 
 
-def make_context(n=150, ctx=None):
+def make_context(n=150, ctx=None, pad=None):
     """the bench scene of bench.py (mat N, twist handles, BE dt 0.04, no gravity) with `selfCollisionOn` (dHat 1e-3 of the bounding-box diagonal, Config.hpp)"""
     V, F = scene.make_mat(n)
     left, right = scene.border_verts(V, 0.01)
@@ -31,6 +31,8 @@ def make_context(n=150, ctx=None):
     c.set_surface(SF)
     c.set_twist(left, right, 0.4 * np.pi)
     c.enable_self_collision(1e-3)
+    if pad is not None:
+        c.set_pattern_lookahead(pad)
     return c, dict(V=V, F=F, SF=SF, left=left, right=right)
 
 
@@ -69,8 +71,8 @@ def advance_to_contact(c, min_active=1000, max_steps=200, max_iter=100):
     return taken
 
 
-def run(n=150, early_steps=5, contact_steps=5, min_active=1000, max_steps=200):
-    c, S = make_context(n)
+def run(n=150, early_steps=5, contact_steps=5, min_active=1000, max_steps=200, pad=None):
+    c, S = make_context(n, pad=pad)
     t0 = time.time()
     c.precompute()
     t_pre = time.time() - t0
@@ -98,5 +100,6 @@ if __name__ == "__main__":
     ap.add_argument("--contact-steps", type=int, default=5)
     ap.add_argument("--min-active", type=int, default=1000)
     ap.add_argument("--max-steps", type=int, default=200)
+    ap.add_argument("--pad", type=float, default=None, help="look-ahead of the contact pattern in units of dHat (default: the library's)")
     a = ap.parse_args()
-    print(json.dumps(run(a.n, a.early_steps, a.contact_steps, a.min_active, a.max_steps)))
+    print(json.dumps(run(a.n, a.early_steps, a.contact_steps, a.min_active, a.max_steps, a.pad)))
