@@ -131,6 +131,8 @@ private:
     DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
     DevBuf<int> d_v2sv, refVbox_, cellCountV_, cellStartV_, cellItemsV_; // reference-mode sweep: node -> surface index, index boxes, vertex cells
     DevBuf<double> bboxPartial_;
+    bool haveBox_ = false; // box_: the bounding box the last constraint-set build measured (the next build's grid is laid over it)
+    double box_[6] = { 0, 0, 0, 0, 0, 0 };
     DevBuf<int> gridCount_, gridStart_, gridItems_; // the narrow phase's grids, triangles and edges in one array of 2 nCells + 1 cells (k_grid_insert_both)
     // on-device assembly of the sets (buildConstraintSet)
     int nActive_ = 0, nPara_ = 0, nCand_ = 0;

@@ -825,6 +825,37 @@ __global__ __launch_bounds__(BLOCK) void k_bbox_partial(int nV, const double* __
         partial[6 * (size_t)blockIdx.x + threadIdx.x] = r;
     }
 }
+// the box of the current positions; *stale = 1 when it leaves the grid `g` the host laid over the previous build's box (the kernels of the build then return at
+// once and the host repeats the build on a fresh grid: with everything clamped into the border cells one cell would hold the whole surface)
+__global__ __launch_bounds__(BLOCK) void k_bbox_final(int nb, const double* __restrict__ partial, double* __restrict__ box6, Grid g, int check, int* __restrict__ stale)
+{
+    __shared__ double sm[6][BLOCK / 64];
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (int b = threadIdx.x; b < nb; b += BLOCK)
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fmin(lo[c], partial[6 * (size_t)b + c]);
+            hi[c] = fmax(hi[c], partial[6 * (size_t)b + 3 + c]);
+        }
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[c] = fmin(lo[c], __shfl_down(lo[c], off, 64));
+            hi[c] = fmax(hi[c], __shfl_down(hi[c], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sm[c][threadIdx.x >> 6] = lo[c];
+            sm[3 + c][threadIdx.x >> 6] = hi[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = sm[threadIdx.x][0];
+        for (int i = 1; i < BLOCK / 64; ++i) r = (threadIdx.x < 3) ? fmin(r, sm[threadIdx.x][i]) : fmax(r, sm[threadIdx.x][i]);
+        box6[threadIdx.x] = r;
+        const int c = threadIdx.x % 3;
+        if (check && (threadIdx.x < 3 ? r < g.lo[c] : r > g.lo[c] + g.h * g.dim[c])) atomicOr(stale, 1);
+    }
+}
 // Candidate walks (narrow phase, CCD sweeps, intersection test).  A surface has ~1e5 primitives and a primitive ~1e2 candidates behind a chain
 // of dependent loads (cell range -> item -> its nodes -> their positions): one lane per primitive leaves the machine two waves per SIMD, each
 // lane serialising its chains.  What the walks cost in round 2 (k_narrow_ee 0.57 ms, k_ref_sweep_edge 0.83 ms, k_ref_sweep_vertex 0.56 ms for
@@ -926,10 +957,11 @@ __global__ __launch_bounds__(BLOCK) void k_grid_insert(int nPrim, int isTri, con
 // into [nCells, 2 nCells).  mode 0 counts; mode 1 fills and takes its slots by counting the cells' counters back DOWN to zero -- no second fill pass, and the
 // array is zero again when the pass is over.
 __global__ __launch_bounds__(BLOCK) void k_grid_insert_both(int nTri, const int* __restrict__ tri, int nEdge, const int* __restrict__ edge, const double* __restrict__ x,
-    Grid g, int nCells, double infl, int mode, int* __restrict__ cellCount, const int* __restrict__ cellStart, int* __restrict__ cellItems)
+    Grid g, int nCells, double infl, int mode, int capItems, const int* __restrict__ stale, int* __restrict__ cellCount, const int* __restrict__ cellStart,
+    int* __restrict__ cellItems)
 {
     const int t = blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= nTri + nEdge) return;
+    if (t >= nTri + nEdge || *stale) return;
     const bool isTri = t < nTri;
     const int i = isTri ? t : t - nTri, nv = isTri ? 3 : 2, base = isTri ? 0 : nCells;
     const int* prim = isTri ? tri : edge;
@@ -954,6 +986,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_insert_both(int nTri, const int*
                 if (mode == 0) atomicAdd(&cellCount[cell], 1);
                 else {
                     const int slot = atomicSub(&cellCount[cell], 1) - 1;
+                    if (cellStart[cell] + slot >= capItems) continue; // (the host sees the total, grows the list and repeats the build)
                     int4* r = reinterpret_cast<int4*>(cellItems) + 2 * (size_t)(cellStart[cell] + slot);
                     r[0] = make_int4(i, __float_as_int(f_down(bl[0])), __float_as_int(f_down(bl[1])), __float_as_int(f_down(bl[2])));
                     r[1] = make_int4(__float_as_int(f_up(bh[0])), __float_as_int(f_up(bh[1])), __float_as_int(f_up(bh[2])), 0);
@@ -996,10 +1029,11 @@ __device__ __forceinline__ void wg_list_flush(const WgList& w, int* sBase, int c
 }
 __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __restrict__ SVI, const int* __restrict__ SF, const double* __restrict__ x,
     const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, int cap,
-    int* __restrict__ out, int* __restrict__ counter)
+    int* __restrict__ out, int* __restrict__ counter, int capItems, const int* __restrict__ stale)
 {
     __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
     const WgList wl{ &sCount, sRecs };
+    if (*stale) return; // (uniform: see k_bbox_final)
     if (threadIdx.x == 0) sCount = 0;
     __syncthreads();
     const int gi = blockIdx.x * BLOCK + threadIdx.x;
@@ -1009,7 +1043,7 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __rest
     const double p[3] = { x[3 * (size_t)vI], x[3 * (size_t)vI + 1], x[3 * (size_t)vI + 2] };
     const int cell = cell_of(g, p[0], 0) + g.dim[0] * (cell_of(g, p[1], 1) + g.dim[1] * cell_of(g, p[2], 2));
     const bool vDbc = (dbc[vI] & 1) != 0; // dbc: pair flags (bit 0 Dirichlet, bit 1 obstacle node, bit 2 obstacle-only filter on)
-    const int kEnd = valid ? cellStart[cell + 1] : 0;
+    const int kEnd = valid ? min(cellStart[cell + 1], capItems) : 0; // (capItems: a list the fill pass had to truncate -- the host repeats the build)
     for (int k = cellStart[cell] + sub; k < kEnd; k += COOP) {
         const BoxRec rec = load_box_rec(cellItems, k);
         // a point closer than sqrt(dHat) to the triangle lies inside the triangle's box inflated by that much
@@ -1142,71 +1176,95 @@ __device__ __forceinline__ void narrow_ee_queued(int eI, int eJ, const int* __re
     const double pb1[3] = { x[3 * (size_t)b1], x[3 * (size_t)b1 + 1], x[3 * (size_t)b1 + 2] };
     narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
 }
+struct EeTileRec { // one edge of a cell's list as the pair loop reads it from LDS: everything the box tests need, fetched ONCE per cell by the lane that owns the record
+    double lo[3], hi[3]; // the inflated box of the edge, exactly as the per-edge walk forms it
+    int id, n0, n1, pad;
+};
 __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
     const int* __restrict__ dbc, Grid g, int nCells, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
-    int* __restrict__ out, int* __restrict__ counter)
+    int* __restrict__ out, int* __restrict__ counter, int capItems, const int* __restrict__ stale)
 {
     __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
     __shared__ int2 sQueue[BLOCK / 64][EE_QUEUE];
+    __shared__ EeTileRec sTile[BLOCK / 64][64];
     const WgList wl{ &sCount, sRecs };
+    if (*stale) return; // (uniform: see k_bbox_final)
     if (threadIdx.x == 0) sCount = 0;
     __syncthreads();
     const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int2* q = sQueue[wv];
+    EeTileRec* tile = sTile[wv];
     int qn = 0; // entries in the wave's queue (uniform)
-    const int cell = blockIdx.x * (BLOCK / 64) + wv;
-    int kBeg = 0, kEnd = 0;
-    if (cell < nCells) {
-        kBeg = cellStart[cell];
-        kEnd = cellStart[cell + 1];
-    }
-    const int cx = cell % g.dim[0], cy = (cell / g.dim[0]) % g.dim[1], cz = cell / (g.dim[0] * g.dim[1]);
-    if (kEnd - kBeg >= 2)
+    const int nWaves = gridDim.x * (BLOCK / 64);
+    // a wave takes every nWaves-th cell: its queue fills across cells, so the typing below runs on full waves whatever a single cell yields
+    for (int cell = blockIdx.x * (BLOCK / 64) + wv; cell < nCells; cell += nWaves) {
+        const int kBeg = min(cellStart[cell], capItems), kEnd = min(cellStart[cell + 1], capItems); // (capItems: a truncated list -- the host repeats the build)
+        if (kEnd - kBeg < 2) continue;
+        const int cx = cell % g.dim[0], cy = (cell / g.dim[0]) % g.dim[1], cz = cell / (g.dim[0] * g.dim[1]);
         for (int kb0 = kBeg; kb0 < kEnd; kb0 += 64) {
+            // this lane's record of the cell (registers): lanes past the end hold a copy of the first one and never pair
             const bool vb = kb0 + lane < kEnd;
-            const BoxRec rb = load_box_rec(cellItems, vb ? kb0 + lane : kBeg);
-            const int eJ = rb.id;
-            const int b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
-            double jl[3], jh[3];
-            for (int c = 0; c < 3; ++c) {
-                const double p0 = x[3 * (size_t)b0 + c], p1 = x[3 * (size_t)b1 + c];
-                jl[c] = fmin(p0, p1) - infl;
-                jh[c] = fmax(p0, p1) + infl;
-            }
-            for (int ka = kBeg; ka < kEnd; ++ka) {
-                const BoxRec ra = load_box_rec(cellItems, ka); // uniform over the wave
-                const int eI = ra.id;
-                bool ok = vb && eJ > eI
-                    && !(ra.lo[0] > rb.hi[0] || rb.lo[0] > ra.hi[0] || ra.lo[1] > rb.hi[1] || rb.lo[1] > ra.hi[1] || ra.lo[2] > rb.hi[2] || rb.lo[2] > ra.hi[2]);
-                if (!__any(ok)) continue; // outward-rounded boxes apart for every lane: nothing of edge a is needed
-                const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1];
-                ok = ok && !(a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1);
-                // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap
-                int canon[3];
+            EeTileRec rb;
+            {
+                const int e = cellItems[(size_t)REC * (size_t)(vb ? kb0 + lane : kBeg)];
+                rb.id = e;
+                rb.n0 = SFE[2 * (size_t)e];
+                rb.n1 = SFE[2 * (size_t)e + 1];
                 for (int c = 0; c < 3; ++c) {
-                    const double p0 = x[3 * (size_t)a0 + c], p1 = x[3 * (size_t)a1 + c];
-                    const double il = fmin(p0, p1) - infl, ih = fmax(p0, p1) + infl;
-                    if (il > jh[c] || jl[c] > ih) ok = false;
-                    canon[c] = cell_of(g, fmax(il, jl[c]), c);
+                    const double p0 = x[3 * (size_t)rb.n0 + c], p1 = x[3 * (size_t)rb.n1 + c];
+                    rb.lo[c] = fmin(p0, p1) - infl;
+                    rb.hi[c] = fmax(p0, p1) + infl;
                 }
-                ok = ok && canon[0] == cx && canon[1] == cy && canon[2] == cz;
-                const unsigned long long m = __ballot(ok);
-                if (!m) continue;
-                if (ok) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(eI, eJ);
-                qn += __popcll(m);
+            }
+            for (int ka0 = kBeg; ka0 <= kb0; ka0 += 64) { // tiles of the cell's list in LDS; a pair (a, b) with id_a < id_b is met once: a's tile <= b's chunk or the reverse
+                const int nA = min(64, kEnd - ka0);
                 __builtin_amdgcn_wave_barrier();
-                if (qn >= 64) { // a full wave of pairs: type them, keep the rest
-                    const int2 pr = q[lane];
-                    const int rest = qn - 64;
-                    const int2 mv = q[64 + (lane < rest ? lane : 0)];
+                if (ka0 == kb0) tile[lane] = rb; // the same 64 records: no second fetch
+                else if (lane < nA) {
+                    EeTileRec ra;
+                    const int e = cellItems[(size_t)REC * (size_t)(ka0 + lane)];
+                    ra.id = e;
+                    ra.n0 = SFE[2 * (size_t)e];
+                    ra.n1 = SFE[2 * (size_t)e + 1];
+                    for (int c = 0; c < 3; ++c) {
+                        const double p0 = x[3 * (size_t)ra.n0 + c], p1 = x[3 * (size_t)ra.n1 + c];
+                        ra.lo[c] = fmin(p0, p1) - infl;
+                        ra.hi[c] = fmax(p0, p1) + infl;
+                    }
+                    tile[lane] = ra;
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (int ka = 0; ka < nA; ++ka) {
+                    const EeTileRec& ra = tile[ka]; // uniform address: a broadcast read
+                    // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap -- in either order of the two
+                    // (different tiles meet once, with a's tile first; inside one tile both orders of (ka, lane) come by and the smaller edge index decides)
+                    bool ok = vb && (ka0 == kb0 ? ra.id < rb.id : ra.id != rb.id);
+                    int canon[3];
+                    for (int c = 0; c < 3; ++c) {
+                        if (ra.lo[c] > rb.hi[c] || rb.lo[c] > ra.hi[c]) ok = false;
+                        canon[c] = cell_of(g, fmax(ra.lo[c], rb.lo[c]), c);
+                    }
+                    ok = ok && canon[0] == cx && canon[1] == cy && canon[2] == cz
+                        && !(ra.n0 == rb.n0 || ra.n0 == rb.n1 || ra.n1 == rb.n0 || ra.n1 == rb.n1);
+                    const unsigned long long m = __ballot(ok);
+                    if (!m) continue;
+                    if (ok) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(min(ra.id, rb.id), max(ra.id, rb.id));
+                    qn += __popcll(m);
                     __builtin_amdgcn_wave_barrier();
-                    if (lane < rest) q[lane] = mv;
-                    qn = rest;
-                    __builtin_amdgcn_wave_barrier();
-                    narrow_ee_queued(pr.x, pr.y, SFE, x, xRest, dbc, nE, dHat, wl, cap, out, counter);
+                    if (qn >= 64) { // a full wave of pairs: type them, keep the rest
+                        const int2 pr = q[lane];
+                        const int rest = qn - 64;
+                        const int2 mv = q[64 + (lane < rest ? lane : 0)];
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < rest) q[lane] = mv;
+                        qn = rest;
+                        __builtin_amdgcn_wave_barrier();
+                        narrow_ee_queued(pr.x, pr.y, SFE, x, xRest, dbc, nE, dHat, wl, cap, out, counter);
+                    }
                 }
             }
         }
+    }
     if (lane < qn) {
         const int2 pr = q[lane];
         narrow_ee_queued(pr.x, pr.y, SFE, x, xRest, dbc, nE, dHat, wl, cap, out, counter);
@@ -2197,6 +2255,7 @@ void HipContact::setSurface(const HipMesh& mesh, int nSF_, const int* SFc, int n
     d_xRest.upload(xr, stream);
     HIP_CHECK(hipStreamSynchronize(stream));
     surfaceSet = true;
+    haveBox_ = false;
     active.clear();
     nActive_ = nPara_ = nCand_ = 0;
     hostStale_ = false;
@@ -2266,74 +2325,83 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     const int nV = mesh.nV;
     const int* pf = pairFlags(nV, dbc_dev);
     const double infl = std::sqrt(dHat);
-    // bounding box of the current positions
+    // Bounding box -> grid.  cell_of() clamps, so a grid laid over an OLDER box is still a correct grid (whatever lies outside lands in the border cells, on both
+    // sides of every pair): the box of this build is measured on the device and read back with the narrow phase's counts, the grid uses the box the PREVIOUS
+    // build measured (padded by two cells).  Only the first build of a surface waits for its own box.  (Round 6: one synchronisation per build less; the second --
+    // the total number of cell entries -- went the same way: the fill pass writes into the capacity the last build needed and the total comes back with the counts.)
     const int nb = nblk(nV);
-    bboxPartial_.ensure(6 * (size_t)nb);
-    hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
-    std::vector<double> part(6 * (size_t)nb);
-    bboxPartial_.download(part.data(), part.size(), stream);
+    bboxPartial_.ensure(6 * (size_t)nb + 6);
+    double* box_dev = bboxPartial_.p + 6 * (size_t)nb;
+    counters_.alloc(16);
+    const int* stale = counters_.p + 2;
+    double boxNow[6];
+    if (!haveBox_) {
+        counters_.zero(stream);
+        hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
+        hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, stream, nb, bboxPartial_.p, box_dev, Grid{}, 0, counters_.p + 2);
+        HIP_CHECK(hipMemcpyAsync(boxNow, box_dev, sizeof(boxNow), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (int c = 0; c < 6; ++c) box_[c] = boxNow[c];
+        haveBox_ = true;
+    }
+    int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
+    const int nPrim = nSF + nSFE;
+    if (gridItems_.n < (size_t)REC * 16 * (size_t)nPrim) gridItems_.ensure((size_t)REC * 16 * (size_t)nPrim); // (a first guess: 16 cells per primitive)
+    int nPT = 0, nEE = 0;
     Grid g;
-    double hi[3];
-    for (int c = 0; c < 3; ++c) {
-        g.lo[c] = 1e300;
-        hi[c] = -1e300;
-    }
-    for (int b = 0; b < nb; ++b)
-        for (int c = 0; c < 3; ++c) {
-            g.lo[c] = std::min(g.lo[c], part[6 * (size_t)b + c]);
-            hi[c] = std::max(hi[c], part[6 * (size_t)b + 3 + c]);
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 8) throw StateError("constraint-set build: the grid does not settle");
+        g.h = std::max(mesh.avgEdgeLen, 2.0 * infl);
+        long long nCells;
+        for (;;) {
+            nCells = 1;
+            for (int c = 0; c < 3; ++c) {
+                g.lo[c] = box_[c] - 2.0 * g.h;
+                g.dim[c] = std::max(1, (int)std::floor((box_[3 + c] + 2.0 * g.h - g.lo[c]) / g.h) + 1);
+                nCells *= g.dim[c];
+            }
+            if (nCells <= (1LL << 26)) break;
+            g.h *= 1.5;
         }
-    g.h = std::max(mesh.avgEdgeLen, 2.0 * infl);
-    long long nCells;
-    for (;;) {
-        nCells = 1;
-        for (int c = 0; c < 3; ++c) {
-            g.dim[c] = std::max(1, (int)std::floor((hi[c] - g.lo[c]) / g.h) + 1);
-            nCells *= g.dim[c];
-        }
-        if (nCells <= (1LL << 26)) break;
-        g.h *= 1.5;
-    }
-    // both grids in one pass: counters [0, nCells) of the triangles, [nCells, 2 nCells) of the edges, one scan, one read-back (k_grid_insert_both)
-    const int* cellStartT = nullptr;
-    const int* cellStartE = nullptr;
-    {
         if (2 * nCells + 1 > (long long)INT_MAX) throw StateError("constraint-set build: grid too fine for 32-bit cell indices");
+        // both grids in one pass: counters [0, nCells) of the triangles, [nCells, 2 nCells) of the edges, one scan (k_grid_insert_both)
         const size_t nC2 = 2 * (size_t)nCells + 1;
         if (gridCount_.n < nC2) { // a fresh array is cleared once; every pass leaves it zero (the fill counts back down)
             gridCount_.ensure(nC2);
             gridCount_.zeroN(gridCount_.n, stream);
         }
         gridStart_.ensure(nC2);
-        const int nPrim = nSF + nSFE;
-        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 0, gridCount_.p,
-            (const int*)nullptr, (int*)nullptr);
+        const int* cellStartT = gridStart_.p;
+        const int* cellStartE = gridStart_.p + nCells;
+        outPT_.alloc(6 * (size_t)capPT);
+        outEE_.alloc(6 * (size_t)capEE);
+        const int capItems = (int)std::min<size_t>(gridItems_.n / REC, (size_t)INT_MAX);
+        counters_.zero(stream);
+        hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
+        hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, stream, nb, bboxPartial_.p, box_dev, g, 1, counters_.p + 2);
+        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 0, capItems, stale,
+            gridCount_.p, (const int*)nullptr, (int*)nullptr);
         size_t tmpBytes = 0;
         hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, gridCount_.p, gridStart_.p, (int)nC2, stream);
         if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes);
         hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, gridCount_.p, gridStart_.p, (int)nC2, stream);
-        int total = 0;
-        HIP_CHECK(hipMemcpyAsync(&total, gridStart_.p + (nC2 - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        gridItems_.ensure((size_t)REC * std::max(1, total));
-        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 1, gridCount_.p,
-            gridStart_.p, gridItems_.p);
-        cellStartT = gridStart_.p;
-        cellStartE = gridStart_.p + nCells;
-    }
-    counters_.alloc(16);
-    int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
-    int nPT = 0, nEE = 0;
-    for (;;) {
-        outPT_.alloc(6 * (size_t)capPT);
-        outEE_.alloc(6 * (size_t)capEE);
-        counters_.zero(stream);
+        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 1, capItems, stale,
+            gridCount_.p, gridStart_.p, gridItems_.p);
         hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(COOP * nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, pf, g, cellStartT, gridItems_.p,
-            dHat, capPT, outPT_.p, counters_.p);
-        hipLaunchKernelGGL(k_narrow_ee_cells, dim3(nblk(64 * nCells)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, (int)nCells, cellStartE,
-            gridItems_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1);
-        int cnt[2];
-        counters_.download(cnt, 2, stream);
+            dHat, capPT, outPT_.p, counters_.p, capItems, stale);
+        hipLaunchKernelGGL(k_narrow_ee_cells, dim3((int)std::min<long long>(nblk(64 * nCells), 4096)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, (int)nCells, cellStartE,
+            gridItems_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1, capItems, stale);
+        int cnt[3], total = 0;
+        HIP_CHECK(hipMemcpyAsync(cnt, counters_.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(&total, gridStart_.p + (nC2 - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipMemcpyAsync(boxNow, box_dev, sizeof(boxNow), hipMemcpyDeviceToHost, stream));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (int c = 0; c < 6; ++c) box_[c] = boxNow[c]; // the next grid
+        if (cnt[2]) continue; // the positions have left the old grid: nothing ran, once more on the fresh box
+        if (total > capItems) { // the cell lists did not fit (the narrow phase walked truncated lists): grow and redo
+            gridItems_.ensure((size_t)REC * ((size_t)total + (size_t)total / 4));
+            continue;
+        }
         if (cnt[0] > capPT || cnt[1] > capEE) { // overflow: grow and redo
             capPT = std::max(capPT, cnt[0] + cnt[0] / 4);
             capEE = std::max(capEE, cnt[1] + cnt[1] / 4);

@@ -449,13 +449,22 @@ def _track(o, c, iters, tol):
             break
         so, sg = o.state(), c.state()
         cst_o, cst_g = orc_contact_state(o), c.contact_state()
-        assert cst_g["nActive"] == len(cst_o["active"]) and cst_g["nPara"] == len(cst_o["para"]) and cst_g["nCand"] == cst_o["n_candidates"], it
-        assert abs(sg["stepSize"] - so["stepSize"]) <= tol * so["stepSize"], it
-        assert abs(sg["kappa"] - so["kappa"]) <= tol * so["kappa"], it
-        assert abs(sg["E"] - so["E"]) <= tol * abs(so["E"]), it
-        assert relerr(sg["V"], so["V"]) < tol, it
+        report = dict(it=it, nActive=(cst_g["nActive"], len(cst_o["active"])), nPara=(cst_g["nPara"], len(cst_o["para"])), nCand=(cst_g["nCand"], cst_o["n_candidates"]),
+                      step=(sg["stepSize"], so["stepSize"]), alphaFeasible=(sg["alphaFeasible"], so["alphaFeasible"]), kappa=(sg["kappa"], so["kappa"]), E=(sg["E"], so["E"]),
+                      dV=relerr(sg["V"], so["V"]), dP=relerr(sg["searchDir"], so["searchDir"]), dG=relerr(sg["gradient"], so["gradient"]),
+                      dbc=(c.dbc_state(), orc_dbc_state(o)))
+        assert cst_g["nActive"] == len(cst_o["active"]) and cst_g["nPara"] == len(cst_o["para"]) and cst_g["nCand"] == cst_o["n_candidates"], report
+        assert abs(sg["stepSize"] - so["stepSize"]) <= tol * so["stepSize"], report
+        assert abs(sg["kappa"] - so["kappa"]) <= tol * so["kappa"], report
+        assert relerr(sg["V"], so["V"]) < tol, report
+        assert abs(sg["E"] - so["E"]) <= tol * abs(so["E"]), report
         done += 1
     return done
+
+
+def orc_dbc_state(o):
+    from oracle import orc as _o
+    return _o.opt_dbc_state(o)
 
 
 def orc_contact_state(o):
