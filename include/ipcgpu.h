@@ -287,7 +287,8 @@ int ipcgpu_opt_enable_self_collision(ipcgpu_ctx*, double dHatEps);
 /* Look-ahead of the contact pattern (no counterpart in the reference, which rebuilds pattern + symbolic analysis whenever the contact graph changes,
  * Optimizer.cpp:3570-3592; here the pattern only grows and a new analysis is needed when a pair shows up that the pattern lacks): on such a change the new
  * pattern takes the full stencils of the candidate set at `pad` x dHat (squared distances), blocks of pairs that are not active yet hold explicit zeros.
- * pad < 1: exactly the live pairs; 1: full stencils of the current candidates; > 1 (default 4 = twice the distance): fewer analyses, more fill in the factor.
+ * pad < 1: exactly the live pairs; 1: full stencils of the current candidates; > 1: fewer analyses, more fill in the factor.  Default (never called): 4 (twice
+ * the distance) for meshes up to 150 K nodes, 2.25 beyond -- measured on the bench's contact workloads, profiles/r06_pattern_lookahead_ab.txt.
  * The Newton iterates do not depend on it (explicit zeros); what it trades is host-side analyses against factorisation flops. */
 int ipcgpu_opt_set_pattern_lookahead(ipcgpu_ctx*, double pad);
 /* analytic half-space obstacle (`ground` / `halfSpace` keywords, Config.cpp:306-345; HalfSpace.cpp:41-85): points with

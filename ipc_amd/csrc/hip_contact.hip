@@ -1001,9 +1001,11 @@ constexpr int WG_RECS = 512;
 struct WgList {
     int* count; // LDS
     int* recs; // LDS, 6 * WG_RECS
+    int* bucket; // global: records per first primitive (surface vertex | edge) -- the counting sort that orders the list afterwards starts here (k_bucket_fill)
 };
 __device__ __forceinline__ void wg_list_put(const WgList& w, const int* id, int i, int j, int cap, int* __restrict__ out, int* __restrict__ counter)
 {
+    atomicAdd(w.bucket + i, 1);
     int slot = atomicAdd(w.count, 1);
     int* o;
     if (slot < WG_RECS) o = w.recs + 6 * slot;
@@ -1029,10 +1031,10 @@ __device__ __forceinline__ void wg_list_flush(const WgList& w, int* sBase, int c
 }
 __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __restrict__ SVI, const int* __restrict__ SF, const double* __restrict__ x,
     const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, int cap,
-    int* __restrict__ out, int* __restrict__ counter, int capItems, const int* __restrict__ stale)
+    int* __restrict__ out, int* __restrict__ counter, int capItems, const int* __restrict__ stale, int* __restrict__ bucket)
 {
     __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
-    const WgList wl{ &sCount, sRecs };
+    const WgList wl{ &sCount, sRecs, bucket };
     if (*stale) return; // (uniform: see k_bbox_final)
     if (threadIdx.x == 0) sCount = 0;
     __syncthreads();
@@ -1097,69 +1099,14 @@ __device__ __forceinline__ void narrow_ee_pair(int eI, int eJ, int a0, int a1, i
     }
     if (d < dHat) wg_list_put(wl, id, eI, eJ, cap, out, counter);
 }
-__global__ __launch_bounds__(BLOCK) void k_narrow_ee(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
-    const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
-    int* __restrict__ out, int* __restrict__ counter)
-{
-    __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
-    const WgList wl{ &sCount, sRecs };
-    if (threadIdx.x == 0) sCount = 0;
-    __syncthreads();
-    const int gi = blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = gi / COOP < nE; // see k_narrow_pt
-    const int eI = valid ? gi / COOP : 0, sub = gi % COOP;
-    const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1];
-    const double pa0[3] = { x[3 * (size_t)a0], x[3 * (size_t)a0 + 1], x[3 * (size_t)a0 + 2] };
-    const double pa1[3] = { x[3 * (size_t)a1], x[3 * (size_t)a1 + 1], x[3 * (size_t)a1 + 2] };
-    double bl[3], bh[3];
-    int ca[3], cb[3];
-    for (int c = 0; c < 3; ++c) {
-        bl[c] = fmin(pa0[c], pa1[c]) - infl;
-        bh[c] = fmax(pa0[c], pa1[c]) + infl;
-        ca[c] = cell_of(g, bl[c], c);
-        cb[c] = cell_of(g, bh[c], c);
-    }
-    const bool aDbc = (dbc[a0] & 1) && (dbc[a1] & 1);
-    const float blF[3] = { f_down(bl[0]), f_down(bl[1]), f_down(bl[2]) }, bhF[3] = { f_up(bh[0]), f_up(bh[1]), f_up(bh[2]) };
-    for (int z = ca[2], zEnd = valid ? cb[2] : -1; z <= zEnd; ++z)
-        for (int y = ca[1]; y <= cb[1]; ++y)
-            for (int xx = ca[0]; xx <= cb[0]; ++xx) {
-                const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
-                const int kEnd = cellStart[cell + 1];
-                for (int k = cellStart[cell] + sub; k < kEnd; k += COOP) {
-                    const BoxRec rec = load_box_rec(cellItems, k);
-                    const int eJ = rec.id;
-                    if (eJ <= eI) continue;
-                    if (blF[0] > rec.hi[0] || rec.lo[0] > bhF[0] || blF[1] > rec.hi[1] || rec.lo[1] > bhF[1] || blF[2] > rec.hi[2] || rec.lo[2] > bhF[2])
-                        continue; // outward-rounded boxes apart: the exact ones below are too
-                    const int b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
-                    if (a0 == b0 || a0 == b1 || a1 == b0 || a1 == b1) continue;
-                    const double pb0[3] = { x[3 * (size_t)b0], x[3 * (size_t)b0 + 1], x[3 * (size_t)b0 + 2] };
-                    const double pb1[3] = { x[3 * (size_t)b1], x[3 * (size_t)b1 + 1], x[3 * (size_t)b1 + 2] };
-                    // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap
-                    bool ok = true;
-                    int canon[3];
-                    for (int c = 0; c < 3; ++c) {
-                        const double jl = fmin(pb0[c], pb1[c]) - infl, jh = fmax(pb0[c], pb1[c]) + infl;
-                        if (bl[c] > jh || jl > bh[c]) ok = false;
-                        canon[c] = cell_of(g, fmax(bl[c], jl), c);
-                    }
-                    if (!ok || canon[0] != xx || canon[1] != y || canon[2] != z) continue;
-                    if (aDbc && (dbc[b0] & 1) && (dbc[b1] & 1)) continue; // SelfCollisionHandler.cpp:2294-2297
-                    if (pair_filtered(dbc[a0], dbc[b0])) continue;
-                    narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
-                }
-            }
-    wg_list_flush(wl, &sBase, cap, out, counter);
-}
-// The same narrow phase CELL by cell (round 6).  The walk above visits, for every edge, every record of every cell its inflated box touches (~300 records
+// The edge-edge narrow phase CELL by cell (round 6).  The per-edge walk of rounds 2-5 (the shape k_narrow_pt still has) visited, for every edge, every record of every cell its inflated box touches (~300 records
 // of 32 B per edge, most of them the same neighbours met again in the next cell and once more from the other edge's side), and whenever one of the eight
 // lanes that share an edge finds a pair whose boxes overlap, it runs the typing + distance of that pair -- a few hundred fp64 instructions -- while the
 // other lanes of the wave wait: 0.27 ms for 1.2e5 edges, the largest contact kernel for three rounds.  Here:
 //   * one WAVE takes one cell.  Lane b holds record b of the cell with its edge's nodes and positions (loaded once); the wave walks the cell's records a
 //     TOGETHER -- a uniform index, so record, nodes and positions of edge a arrive through the scalar cache, once per wave -- and lane b tests the pair
 //     (a, b) when a's edge has the smaller index: outward-rounded float boxes, then the exact inflated boxes and the rule that a pair belongs to the one
-//     cell that holds the low corner of their overlap (exactly as above: the SAME pairs survive);
+//     cell that holds the low corner of their overlap (exactly as the per-edge walk had it: the SAME pairs survive);
 //   * survivors are not typed where they are found: they go into a queue of the wave in LDS, and whenever 64 have gathered ALL lanes take one each --
 //     typing and distance run on full waves.
 // The same records come out (in another order; they are sorted by primitive pair afterwards).
@@ -1167,6 +1114,10 @@ constexpr int EE_QUEUE = 128;
 __device__ __forceinline__ void narrow_ee_queued(int eI, int eJ, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
     const int* __restrict__ dbc, int nE, double dHat, const WgList& wl, int cap, int* __restrict__ out, int* __restrict__ counter)
 {
+#if defined(EE_PROBE) && EE_PROBE >= 1
+    if (eI == -12345) atomicAdd(counter, eJ); // probe 1: pairs are found and queued, never typed
+    return;
+#endif
     const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1], b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
     if ((dbc[a0] & 1) && (dbc[a1] & 1) && (dbc[b0] & 1) && (dbc[b1] & 1)) return; // SelfCollisionHandler.cpp:2294-2297
     if (pair_filtered(dbc[a0], dbc[b0])) return;
@@ -1182,12 +1133,12 @@ struct EeTileRec { // one edge of a cell's list as the pair loop reads it from L
 };
 __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
     const int* __restrict__ dbc, Grid g, int nCells, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
-    int* __restrict__ out, int* __restrict__ counter, int capItems, const int* __restrict__ stale)
+    int* __restrict__ out, int* __restrict__ counter, int capItems, const int* __restrict__ stale, int* __restrict__ bucket)
 {
     __shared__ int sCount, sBase, sRecs[6 * WG_RECS];
     __shared__ int2 sQueue[BLOCK / 64][EE_QUEUE];
     __shared__ EeTileRec sTile[BLOCK / 64][64];
-    const WgList wl{ &sCount, sRecs };
+    const WgList wl{ &sCount, sRecs, bucket };
     if (*stale) return; // (uniform: see k_bbox_final)
     if (threadIdx.x == 0) sCount = 0;
     __syncthreads();
@@ -1234,6 +1185,10 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __
                     tile[lane] = ra;
                 }
                 __builtin_amdgcn_wave_barrier();
+#if defined(EE_PROBE) && EE_PROBE >= 2
+                if (rb.id == -12345) atomicAdd(counter, 1); // probe 2: the cell's records are fetched, no pair loop
+                continue;
+#endif
                 for (int ka = 0; ka < nA; ++ka) {
                     const EeTileRec& ra = tile[ka]; // uniform address: a broadcast read
                     // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap -- in either order of the two

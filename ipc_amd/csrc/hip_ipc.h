@@ -294,7 +294,12 @@ public:
     std::vector<std::array<int, 4>> closeID; // closeMConstraintID / Val (Optimizer.cpp:2396-2440)
     std::vector<double> closeVal;
     int lastCCDPair[2] = { 0, 0 }, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
-    double patternPad = 4.0; // look-ahead of the contact pattern in units of dHat (ipcgpu_opt_set_pattern_lookahead; < 1 = exact pattern)
+    // look-ahead of the contact pattern in units of dHat (ipcgpu_opt_set_pattern_lookahead; < 1 = exact pattern).  Negative = by mesh size (lookahead()): what it
+    // trades is host-side analyses against fill in the factor, and the two scale differently -- measured (profiles/r06_pattern_lookahead_ab.txt): 40 K nodes, ms per
+    // Newton iteration at pad 1 / 2.25 / 4: 22.6 / 11.4 / 9.9 (27 / 7 / 4 analyses of ~14 ms); 375 K nodes: 461 / 258 / 357 (an analysis costs ~130 ms, but the
+    // factorisation 139 / 243 / 341 ms -- 3.7 / 7.2 / 10.7 TFLOP)
+    double patternPad = -1.0;
+    double lookahead() const { return patternPad >= 0.0 ? patternPad : (mesh.nV > 150000 ? 2.25 : 4.0); }
     // analytic half-space obstacles (animConfig.collisionObjects) and their close-constraint list (Optimizer.cpp:2364-2374)
     std::vector<std::unique_ptr<HipHalfSpace>> planes;
     std::vector<std::pair<int, int>> closeHS;

@@ -641,22 +641,19 @@ double HipOptimizer::kappaFloor() const
 
 void HipOptimizer::initKappa()
 {
-    // Optimizer.cpp:2236-2313: balance the barrier gradient of the active set against elasticity + inertia.  Once per time
-    // step, so the two gradients are dotted on the host in index order
+    // Optimizer.cpp:2236-2313: balance the barrier gradient of the active set against elasticity + inertia.  Once per time step; the two dot products are taken
+    // on the device (round 6: both gradients used to travel to the host, 2 x 24 nV bytes per time step, to be dotted there)
     if (!nConstraints()) return;
-    const size_t n3 = 3 * (size_t)mesh.nV;
-    std::vector<double> gE(n3), gc(n3);
+    const int n3 = 3 * mesh.nV;
     elasticInertiaGradient(true); // computeGradient with solveIP == false (:2243-2245)
     if (dampingStiff > 0.0) dampingGradientAdd(true, d_gradient.p); // still part of it (:3519-3540)
-    d_gradient.download(gE.data(), n3, stream);
     d_minusG.zero(stream);
     barrierGradientAdd(true, 1.0, true, d_minusG.p); // also clears the DBC rows (:2275-2277)
-    d_minusG.download(gc.data(), n3, stream);
-    double num = 0, den = 0;
-    for (size_t i = 0; i < n3; ++i) {
-        num += gc[i] * gE[i];
-        den += gc[i] * gc[i];
-    }
+    launch_dot_scaled(n3, d_minusG.p, d_gradient.p, 1.0, d_scalar.p + 6, stream);
+    launch_dot_scaled(n3, d_minusG.p, d_minusG.p, 1.0, d_scalar.p + 7, stream);
+    launch_publish(d_scalar.p + 6, h_scalar.dev, 4, stream); // two doubles = four words
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const double num = h_scalar.p[0], den = h_scalar.p[1];
     double minKappa = -num / den;
     if (minKappa > 0.0) kappa = minKappa;
     minKappa = kappaFloor();
@@ -912,15 +909,16 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         // union is dropped again once it has grown far beyond the live set.
         if (!std::includes(curExtra.begin(), curExtra.end(), fresh.begin(), fresh.end())) {
             // Look-ahead: contact spreads, so the next iterations bring pairs that are a little farther apart now.  The new
-            // pattern is built from the constraint set at a larger distance (patternPad * dHat, squared distances): its
+            // pattern is built from the constraint set at a larger distance (lookahead() * dHat, squared distances): its
             // blocks hold explicit zeros until the pairs become active, and pattern + symbolic analysis (tens of ms on the
             // host) are needed far less often.  Costs two extra constraint-set builds per analysis.
             std::vector<std::pair<int, int>> padded = fresh;
-            if (patternPad >= 1.0) {
+            const double pad = lookahead();
+            if (pad >= 1.0) {
                 std::vector<std::pair<int, int>> ahead;
-                if (patternPad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, patternPad * dHat);
+                if (pad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, pad * dHat);
                 contact->candidateConnectivitySorted(ahead); // full stencils: closest-feature changes need no new blocks; sorted, unique
-                if (patternPad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, dHat); // back to the real sets
+                if (pad > 1.0) contact->buildConstraintSet(mesh, mesh.d_x.p, mesh.d_dbc.p, dHat); // back to the real sets
                 std::vector<std::pair<int, int>> aheadNew;
                 aheadNew.reserve(ahead.size());
                 for (const auto& e : ahead) {

@@ -104,7 +104,7 @@ def test_malformed_mmcvid_tuples_are_refused(gpu_lib):
         val, inp, out = np.zeros(len(t)), np.ones(len(t)), np.zeros(3 * nV)
         return (L.ipcgpu_contact_evaluate(c.h, len(t), t.ctypes.data, val.ctypes.data),
                 L.ipcgpu_contact_jt_multiply(c.h, len(t), t.ctypes.data, inp.ctypes.data, 1.0, out.ctypes.data), val, out)
-    good = [[0, 1, 25, 26], [-1, 26, -1, -2], [-1, 25, 26, -3], [-1, 24, 25, 26]]  # EE, PP x2, PE x3, PT
+    good = [[0, 1, 22, 26], [-1, 26, -1, -2], [-1, 25, 26, -3], [-1, 22, 25, 26]]  # EE, PP x2, PE x3, PT (non-parallel edges, a proper triangle: the 0 / 0 of the degenerate ones is NaN here as in the reference)
     r0, r1, val, out = both(good)
     assert r0 == 0 and r1 == 0 and np.all(val > 0) and np.abs(out).max() > 0
     for bad in ([5, 6, 7, -3], [5, -2, 7, 8], [5, 6, -1, 8], [-4, -2, 1, 2], [-1, nV, -1, -1], [-nV - 1, 2, -1, -1], [-1, 2, nV, -1], [-1, 2, 3, nV], [0, 1, 2, nV]):

@@ -20,13 +20,15 @@ NAMES = {1: "pattern_change:set_pattern", 2: "pattern_change:symbolic_analysis",
          9: "energy_evals", 13: "step_bounds(inversion+CCD+CFL)", 14: "constraint_sets", 11: "timestep"}
 
 
-def make_context(n=150, ctx=None, pad=None):
+def make_context(n=150, ctx=None, pad=None, positions=None):
     """the bench scene of bench.py (mat N, twist handles, BE dt 0.04, no gravity) with `selfCollisionOn` (dHat 1e-3 of the bounding-box diagonal, Config.hpp)"""
     V, F = scene.make_mat(n)
     left, right = scene.border_verts(V, 0.01)
     SF = scene.surface_tris(F)
     c = ctx or lib.Context(0)
     c.set_mesh(V, F, YM=2e4, PR=0.4, density=1000.0)
+    if positions is not None:
+        c.set_positions(positions(V, F))  # tests: a generic (jittered, pre-twisted) start instead of exact rest, where the reference itself is round-off dependent
     c.opt_init(0.04, False)
     c.set_surface(SF)
     c.set_twist(left, right, 0.4 * np.pi)
