@@ -137,9 +137,12 @@ private:
     // on-device assembly of the sets (buildConstraintSet)
     int nActive_ = 0, nPara_ = 0, nCand_ = 0;
     mutable bool hostStale_ = false;
-    DevBuf<unsigned long long> sortKeyIn_, sortKeyOut_, flags_, flagPos_, dupHi_, dupHiOut_;
-    DevBuf<unsigned> dupLo_, dupLoOut_;
-    DevBuf<int> sortValIn_, permPT_, permEE_, dupTuple_, dupIdx_, dupIdx2_, head_, headPos_, closeIdx_;
+    DevBuf<unsigned long long> sortKeyIn_, sortKeyOut_, flags_, flagPos_;
+    DevBuf<int> permPT_, dupTuple_, closeIdx_;
+    // counting sorts of the record lists (by first primitive) and of the duplicate candidates (by vertex): counters, bucket starts, bucket contents, runs
+    DevBuf<int> bucketCount_, bucketStart_, bucketSeg_, dupCount_, dupStart_, runs_, runPos_;
+    bool countersDirty_ = false; // a build was left half-way (exception): the counters are cleared before the next one
+    PinnedBuf<unsigned long long> readback_; // BuildReadback: what the host reads between the stages of a build (mapped memory, written by the kernels)
     DevBuf<double> closeVal_;
     DevBuf<char> scanTmp_;
     // deterministic scatter of the barrier / friction terms (hip_contact.hip "deterministic scatter"): per-stencil slots, keys, sort, run sums

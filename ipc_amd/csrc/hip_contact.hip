@@ -2023,20 +2023,26 @@ __global__ __launch_bounds__(BLOCK) void k_eval_stencils(int n, const int* __res
 // ---- constraint-set assembly on the device (SelfCollisionHandler.cpp:2411-2476) ----------------------------------------------
 // The narrow phase appends candidate records through an atomic counter, in no particular order.  The reference emits them in
 // primitive order (vertex by vertex, edge by edge) and merges the point-point / point-edge duplicates in a std::map keyed by
-// the 4-tuple.  Same result here without the host: radix sort by the primitive pair, classification + stable compaction by a
-// prefix sum, a second radix sort of the duplicate candidates by tuple (signed lexicographic = the map's order), run lengths.
-// keys of BOTH record lists for one sort (round 6: one radix sort instead of two): (edge-edge flag, first primitive, second primitive); the value is the
-// record's index in its own list -- the point-triangle records sort to the front, so the sorted values ARE the two permutations, one behind the other
-__global__ void k_rec_keys(int nPT, int nEE, const int* __restrict__ recPT, const int* __restrict__ recEE, int shift, int flagBit, unsigned long long* __restrict__ key,
-    int* __restrict__ val)
+// the 4-tuple.  Same result here without the host, as two COUNTING sorts (round 6; rounds 2-5 ran radix sorts on 64-bit keys, which rocPRIM turns into a
+// merge sort of ~15 launches at these sizes -- 67 launches of ~5 us per Newton iteration):
+//   records by primitive pair: the narrow phase counts the records of every first primitive (WgList::bucket), one scan gives the buckets, k_bucket_fill
+//   drops every record into its bucket, k_bucket_sort_classify orders each bucket by the second primitive (a handful of entries) and classifies;
+//   duplicates by tuple: the bucket is the tuple's vertex (k_bucket_sort_classify counts, k_scatter_sets fills), k_dup_sort orders each bucket by the other
+//   two ids and counts its runs, one scan places the runs, k_dup_emit writes one tuple per run with its multiplicity.
+// Every counter array is counted up by one kernel and back down to zero by the one that fills the buckets: no clearing between builds.
+
+// one thread per record: its slot in the bucket of its first primitive (point-triangle buckets [0, nSVI), edge-edge buckets behind them)
+__global__ void k_bucket_fill(int nPT, int nEE, int nSVI, const int* __restrict__ recPT, const int* __restrict__ recEE, const int* __restrict__ start,
+    int* __restrict__ count, int2* __restrict__ seg)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nPT + nEE) return;
     const bool isEE = j >= nPT;
     const int i = isEE ? j - nPT : j;
     const int* r = (isEE ? recEE : recPT) + 6 * (size_t)i;
-    key[j] = ((unsigned long long)(isEE ? 1 : 0) << flagBit) | ((unsigned long long)(unsigned)r[4] << shift) | (unsigned)r[5];
-    val[j] = i;
+    const int b = isEE ? nSVI + r[4] : r[4];
+    const int slot = start[b] + atomicSub(count + b, 1) - 1;
+    seg[slot] = make_int2(r[5], i); // (second primitive, index in its own list)
 }
 // category of a record: 0 direct active, 1 duplicate candidate (PP / PE), 2 mollified parallel edge pair.  Packed counters for
 // one 64-bit prefix sum: bits 0..31 direct, 32..63 duplicate; the parallel pairs in front of record j are the rest, j - direct - duplicate
@@ -2046,24 +2052,41 @@ __device__ __forceinline__ int rec_category(const int* r, bool isEE)
     if (!isEE) return r[3] < 0 ? 1 : 0;
     return r[3] >= 0 ? 0 : (r[3] == -1 ? 1 : 2);
 }
-__global__ void k_classify(int nPT, int nEE, const int* __restrict__ recPT, const int* __restrict__ permPT, const int* __restrict__ recEE,
-    const int* __restrict__ permEE, int* __restrict__ csPTEE, unsigned long long* __restrict__ flags)
+// one thread per bucket: its records in the order of the second primitive (the pair is unique, the bucket a handful of entries: insertion sort in place) --
+// the bucket's range of the list IS its range in the serial enumeration, so the same thread writes the permutation (point-triangle records first, then the
+// edge-edge ones, each as an index into its own list), the candidate list, the category flags for the prefix sum, and counts the duplicate candidates per vertex
+__global__ void k_bucket_sort_classify(int nB, int nSVI, int n, int nV, const int* __restrict__ start, int2* __restrict__ seg, const int* __restrict__ recPT,
+    const int* __restrict__ recEE, int* __restrict__ perm, int* __restrict__ csPTEE, unsigned long long* __restrict__ flags, int* __restrict__ dupCount)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j == nPT + nEE) flags[j] = 0ull; // the scan runs over n + 1 entries: its last output is the totals
-    if (j >= nPT + nEE) return;
-    const bool isEE = j >= nPT;
-    const int* r = isEE ? recEE + 6 * (size_t)permEE[j - nPT] : recPT + 6 * (size_t)permPT[j];
-    csPTEE[2 * (size_t)j] = isEE ? r[4] : -r[4] - 1;
-    csPTEE[2 * (size_t)j + 1] = r[5];
-    const int cat = rec_category(r, isEE);
-    flags[j] = cat == 0 ? 1ull : (cat == 1 ? 1ull << 32 : 0ull);
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) flags[n] = 0ull; // the scan runs over n + 1 entries: its last output is the totals
+    if (b >= nB) return;
+    const int s0 = start[b], s1 = start[b + 1];
+    if (s0 == s1) return;
+    for (int a = s0 + 1; a < s1; ++a) {
+        const int2 v = seg[a];
+        int k = a - 1;
+        while (k >= s0 && seg[k].x > v.x) {
+            seg[k + 1] = seg[k];
+            --k;
+        }
+        seg[k + 1] = v;
+    }
+    const bool isEE = b >= nSVI;
+    for (int s = s0; s < s1; ++s) {
+        const int idx = seg[s].y;
+        perm[s] = idx;
+        const int* r = (isEE ? recEE : recPT) + 6 * (size_t)idx;
+        csPTEE[2 * (size_t)s] = isEE ? r[4] : -r[4] - 1;
+        csPTEE[2 * (size_t)s + 1] = r[5];
+        const int cat = rec_category(r, isEE);
+        flags[s] = cat == 0 ? 1ull : (cat == 1 ? 1ull << 32 : 0ull);
+        if (cat == 1) atomicAdd(dupCount + (r[0] + nV), 1); // id0 = -v - 1 in [-nV, -1]: buckets in ascending id0, the map's (signed) order
+    }
 }
-__device__ __forceinline__ unsigned bias(int v) { return (unsigned)v ^ 0x80000000u; } // signed order -> unsigned order
 __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict__ recPT, const int* __restrict__ permPT,
     const int* __restrict__ recEE, const int* __restrict__ permEE, const unsigned long long* __restrict__ pos, int* __restrict__ active,
-    int* __restrict__ dupTuple, unsigned long long* __restrict__ dupHi, unsigned* __restrict__ dupLo, int* __restrict__ dupIdx,
-    int* __restrict__ para, int* __restrict__ paraEIEJ, int nV, int packBits)
+    int* __restrict__ dupTuple, const int* __restrict__ dupStart, int* __restrict__ dupCount, int* __restrict__ para, int* __restrict__ paraEIEJ, int nV)
 {
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= nPT + nEE) return;
@@ -2072,21 +2095,16 @@ __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict
     const unsigned long long p = pos[j];
     const int cat = rec_category(r, isEE);
     const int nd = (int)(p & 0xffffffffull), nu = (int)(p >> 32);
-    const int q = cat == 0 ? nd : (cat == 1 ? nu : j - nd - nu);
     if (cat == 0) {
-        for (int k = 0; k < 4; ++k) active[4 * (size_t)q + k] = r[k];
+        for (int k = 0; k < 4; ++k) active[4 * (size_t)nd + k] = r[k];
     }
     else if (cat == 1) {
+        const int v = r[0] + nV;
+        const int q = dupStart[v] + atomicSub(dupCount + v, 1) - 1; // any slot of the vertex's bucket: k_dup_sort orders it
         for (int k = 0; k < 4; ++k) dupTuple[4 * (size_t)q + k] = r[k];
-        if (packBits) // (id0, id1, id2) in one 64-bit key, signed order kept: id0 in [-nV, -1], id1 in [0, nV), id2 in [-1, nV)
-            dupHi[q] = ((unsigned long long)(unsigned)(r[0] + nV) << (2 * packBits)) | ((unsigned long long)(unsigned)r[1] << packBits) | (unsigned)(r[2] + 1);
-        else {
-            dupHi[q] = ((unsigned long long)bias(r[0]) << 32) | bias(r[1]);
-            dupLo[q] = bias(r[2]); // r[3] == -1 for every duplicate candidate
-        }
-        dupIdx[q] = q;
     }
     else {
+        const int q = j - nd - nu;
         int* o = para + 4 * (size_t)q;
         o[0] = r[0]; o[1] = r[1]; o[2] = r[2];
         if (r[3] >= -nSFE - 1) {
@@ -2101,37 +2119,64 @@ __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict
         }
     }
 }
-__global__ void k_gather_u64(int n, const int* __restrict__ idx, const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst)
+// one thread per vertex: its duplicate candidates ordered by (id1, id2) (id2 = -1 of a point-point tuple sorts first, as in the map's signed order;
+// id3 = -1 for all of them) and the number of distinct tuples among them
+__global__ void k_dup_sort(int nV, const int* __restrict__ start, int4* __restrict__ tuple, int* __restrict__ runs)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[idx[i]];
-}
-// sorted duplicate candidates -> run heads
-__global__ void k_dup_heads(int n, const int* __restrict__ order, const int* __restrict__ tuple, int* __restrict__ head)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i == n) head[n] = 0; // (the scan's last output is the number of runs)
-    if (i >= n) return;
-    bool h = i == 0;
-    if (!h) {
-        const int* a = tuple + 4 * (size_t)order[i];
-        const int* b = tuple + 4 * (size_t)order[i - 1];
-        h = a[0] != b[0] || a[1] != b[1] || a[2] != b[2];
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == 0) runs[nV] = 0; // (the scan's last output is the number of runs)
+    if (v >= nV) return;
+    const int s0 = start[v], s1 = start[v + 1];
+    int nr = 0;
+    if (s1 > s0) {
+        for (int a = s0 + 1; a < s1; ++a) {
+            const int4 t = tuple[a];
+            int k = a - 1;
+            while (k >= s0 && (tuple[k].y > t.y || (tuple[k].y == t.y && tuple[k].z > t.z))) {
+                tuple[k + 1] = tuple[k];
+                --k;
+            }
+            tuple[k + 1] = t;
+        }
+        nr = 1;
+        for (int a = s0 + 1; a < s1; ++a) nr += (tuple[a].y != tuple[a - 1].y || tuple[a].z != tuple[a - 1].z) ? 1 : 0;
     }
-    head[i] = h ? 1 : 0;
+    runs[v] = nr;
 }
-// one thread per sorted duplicate: the head of a run writes (tuple, -multiplicity) behind the direct entries
-__global__ void k_dup_emit(int n, int nDirect, const int* __restrict__ order, const int* __restrict__ tuple, const int* __restrict__ head,
-    const int* __restrict__ headPos, int* __restrict__ active)
+// one thread per vertex: (tuple, -multiplicity) of each of its runs behind the direct entries
+__global__ void k_dup_emit(int nV, int nDirect, const int* __restrict__ start, const int4* __restrict__ tuple, const int* __restrict__ runPos,
+    int4* __restrict__ active)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || !head[i]) return;
-    int len = 1;
-    while (i + len < n && !head[i + len]) ++len; // runs are short (a vertex pair is seen from a handful of triangles)
-    const int* a = tuple + 4 * (size_t)order[i];
-    int* o = active + 4 * (size_t)(nDirect + headPos[i]);
-    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = -len;
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= nV) return;
+    const int s0 = start[v], s1 = start[v + 1];
+    if (s0 == s1) return;
+    int4* o = active + nDirect + runPos[v];
+    int a = s0;
+    while (a < s1) {
+        int len = 1;
+        while (a + len < s1 && tuple[a + len].y == tuple[a].y && tuple[a + len].z == tuple[a].z) ++len;
+        *o++ = make_int4(tuple[a].x, tuple[a].y, tuple[a].z, -len);
+        a += len;
+    }
 }
+// what the host needs between the stages of a build, written to mapped host memory by one thread (three blits of 12, 4 and 48 bytes before)
+struct BuildReadback {
+    int cnt[4]; // point-triangle records, edge-edge records, stale-grid flag, total number of cell entries
+    double box[6];
+    unsigned long long totals; // category totals of the candidate list (k_bucket_sort_classify's flags, scanned)
+    int nUnique, pad;
+};
+__global__ void k_publish_narrow(const int* __restrict__ counters, const int* __restrict__ gridTotal, const double* __restrict__ box, BuildReadback* __restrict__ out)
+{
+    out->cnt[0] = counters[0];
+    out->cnt[1] = counters[1];
+    out->cnt[2] = counters[2];
+    out->cnt[3] = gridTotal[0];
+    for (int c = 0; c < 6; ++c) out->box[c] = box[c];
+}
+__global__ void k_publish_u64(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = src[0]; }
+__global__ void k_publish_int(const int* __restrict__ src, int* __restrict__ dst) { dst[0] = src[0]; }
 // stencils of the active set closer than dTol (closeMConstraint bookkeeping, Optimizer.cpp:2365-2440): index + distance
 __global__ void k_close_stencils(int n, const int* __restrict__ ids, const double* __restrict__ x, double dTol, int cap, int* __restrict__ outIdx,
     double* __restrict__ outVal, int* __restrict__ counter)
@@ -2302,6 +2347,29 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     int capPT = std::max<int>(1 << 14, (int)outPT_.n / 6), capEE = std::max<int>(1 << 14, (int)outEE_.n / 6);
     const int nPrim = nSF + nSFE;
     if (gridItems_.n < (size_t)REC * 16 * (size_t)nPrim) gridItems_.ensure((size_t)REC * 16 * (size_t)nPrim); // (a first guess: 16 cells per primitive)
+    // counters of the counting sorts (see "constraint-set assembly on the device"): cleared when allocated and after a build that did not run to its end;
+    // a build that does leaves them zero
+    const int nB = nSVI + nSFE;
+    if (bucketCount_.n < (size_t)nB + 1 || dupCount_.n < (size_t)nV + 1 || countersDirty_) {
+        bucketCount_.ensure((size_t)nB + 1);
+        dupCount_.ensure((size_t)nV + 1);
+        bucketCount_.zero(stream);
+        dupCount_.zero(stream);
+    }
+    countersDirty_ = true;
+    bucketStart_.ensure((size_t)nB + 1);
+    dupStart_.ensure((size_t)nV + 1);
+    runs_.ensure((size_t)nV + 1);
+    runPos_.ensure((size_t)nV + 1);
+    if (!readback_.p) readback_.alloc((sizeof(BuildReadback) + 7) / 8);
+    BuildReadback* rb = reinterpret_cast<BuildReadback*>(readback_.p);
+    BuildReadback* rbDev = reinterpret_cast<BuildReadback*>(readback_.dev);
+    auto scan = [&](auto* in, auto* out, int count) { // exclusive prefix sum, temporary storage grown on demand
+        size_t bytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, count, stream);
+        if (scanTmp_.n < bytes) scanTmp_.alloc(bytes + bytes / 4);
+        hipcub::DeviceScan::ExclusiveSum((void*)scanTmp_.p, bytes, in, out, count, stream);
+    };
     int nPT = 0, nEE = 0;
     Grid g;
     for (int attempt = 0;; ++attempt) {
@@ -2336,122 +2404,80 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, stream, nb, bboxPartial_.p, box_dev, g, 1, counters_.p + 2);
         hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 0, capItems, stale,
             gridCount_.p, (const int*)nullptr, (int*)nullptr);
-        size_t tmpBytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, gridCount_.p, gridStart_.p, (int)nC2, stream);
-        if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes);
-        hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, gridCount_.p, gridStart_.p, (int)nC2, stream);
+        scan(gridCount_.p, gridStart_.p, (int)nC2);
         hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nSF, d_SF.p, nSFE, d_SFE.p, x_dev, g, (int)nCells, infl, 1, capItems, stale,
             gridCount_.p, gridStart_.p, gridItems_.p);
         hipLaunchKernelGGL(k_narrow_pt, dim3(nblk(COOP * nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, x_dev, pf, g, cellStartT, gridItems_.p,
-            dHat, capPT, outPT_.p, counters_.p, capItems, stale);
+            dHat, capPT, outPT_.p, counters_.p, capItems, stale, bucketCount_.p);
         hipLaunchKernelGGL(k_narrow_ee_cells, dim3((int)std::min<long long>(nblk(64 * nCells), 4096)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, d_xRest.p, pf, g, (int)nCells, cellStartE,
-            gridItems_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1, capItems, stale);
-        int cnt[3], total = 0;
-        HIP_CHECK(hipMemcpyAsync(cnt, counters_.p, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(&total, gridStart_.p + (nC2 - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipMemcpyAsync(boxNow, box_dev, sizeof(boxNow), hipMemcpyDeviceToHost, stream));
+            gridItems_.p, dHat, infl, capEE, outEE_.p, counters_.p + 1, capItems, stale, bucketCount_.p + nSVI);
+        // the buckets of the record sort: needed only when the build stands, enqueued before the host knows (one scan; the GPU would idle through the read-back)
+        scan(bucketCount_.p, bucketStart_.p, nB + 1);
+        hipLaunchKernelGGL(k_publish_narrow, dim3(1), dim3(1), 0, stream, counters_.p, gridStart_.p + (nC2 - 1), box_dev, rbDev);
         HIP_CHECK(hipStreamSynchronize(stream));
-        for (int c = 0; c < 6; ++c) box_[c] = boxNow[c]; // the next grid
-        if (cnt[2]) continue; // the positions have left the old grid: nothing ran, once more on the fresh box
+        const int total = rb->cnt[3];
+        for (int c = 0; c < 6; ++c) box_[c] = rb->box[c]; // the next grid
+        if (rb->cnt[2]) continue; // the positions have left the old grid: nothing ran, once more on the fresh box
         if (total > capItems) { // the cell lists did not fit (the narrow phase walked truncated lists): grow and redo
             gridItems_.ensure((size_t)REC * ((size_t)total + (size_t)total / 4));
+            bucketCount_.zero(stream);
             continue;
         }
-        if (cnt[0] > capPT || cnt[1] > capEE) { // overflow: grow and redo
-            capPT = std::max(capPT, cnt[0] + cnt[0] / 4);
-            capEE = std::max(capEE, cnt[1] + cnt[1] / 4);
+        if (rb->cnt[0] > capPT || rb->cnt[1] > capEE) { // overflow: grow and redo
+            capPT = std::max(capPT, rb->cnt[0] + rb->cnt[0] / 4);
+            capEE = std::max(capEE, rb->cnt[1] + rb->cnt[1] / 4);
+            bucketCount_.zero(stream);
             continue;
         }
-        nPT = cnt[0];
-        nEE = cnt[1];
+        nPT = rb->cnt[0];
+        nEE = rb->cnt[1];
         break;
     }
-    // ---- sets assembled on the device (kernels above); two scalar read-backs: the category totals, the number of merged tuples
+    // ---- sets assembled on the device (kernels above); two more scalar read-backs: the category totals, the number of merged tuples
     const int n = nPT + nEE;
     nCand_ = n;
     hostStale_ = true;
     d_csPTEE.ensure(2 * (size_t)std::max(n, 1));
     if (n == 0) {
         nActive_ = nPara_ = 0;
+        countersDirty_ = false;
         return 0;
     }
-    auto tmp = [&](size_t bytes) {
-        if (scanTmp_.n < bytes) scanTmp_.alloc(bytes + bytes / 4);
-        return (void*)scanTmp_.p;
-    };
-    auto bitsFor = [](long long v) {
-        int b = 1;
-        while ((1LL << b) <= v) ++b;
-        return b;
-    };
-    sortKeyIn_.ensure((size_t)n);
-    sortKeyOut_.ensure((size_t)n);
-    sortValIn_.ensure((size_t)n);
+    bucketSeg_.ensure(2 * (size_t)n);
     permPT_.ensure((size_t)n); // both permutations, the edge-edge one behind the point-triangle one
-    {
-        // by (svI, sfI) and (eI, eJ) -- the order a serial scan emits --, the point-triangle records first
-        const int shift = bitsFor(std::max(nSF, nSFE)), flagBit = shift + bitsFor(std::max(nSVI, nSFE)), endBit = flagBit + 1;
-        hipLaunchKernelGGL(k_rec_keys, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, outPT_.p, outEE_.p, shift, flagBit, sortKeyIn_.p, sortValIn_.p);
-        size_t bytes = 0;
-        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, permPT_.p, n, 0, endBit, stream);
-        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, sortKeyIn_.p, sortKeyOut_.p, sortValIn_.p, permPT_.p, n, 0, endBit, stream);
-    }
-    const int* permPT = permPT_.p;
-    const int* permEE = permPT_.p + nPT;
     flags_.ensure((size_t)n + 1);
     flagPos_.ensure((size_t)n + 1);
-    hipLaunchKernelGGL(k_classify, dim3(nblk(n + 1)), dim3(BLOCK), 0, stream, nPT, nEE, outPT_.p, permPT, outEE_.p, permEE, d_csPTEE.p, flags_.p);
-    {
-        size_t bytes = 0;
-        hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flags_.p, flagPos_.p, n + 1, stream);
-        hipcub::DeviceScan::ExclusiveSum(tmp(bytes), bytes, flags_.p, flagPos_.p, n + 1, stream);
-    }
-    unsigned long long totals = 0;
-    HIP_CHECK(hipMemcpyAsync(&totals, flagPos_.p + n, sizeof(totals), hipMemcpyDeviceToHost, stream));
+    // by (svI, sfI) and (eI, eJ) -- the order a serial scan emits --, the point-triangle records first
+    hipLaunchKernelGGL(k_bucket_fill, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSVI, outPT_.p, outEE_.p, bucketStart_.p, bucketCount_.p,
+        reinterpret_cast<int2*>(bucketSeg_.p));
+    hipLaunchKernelGGL(k_bucket_sort_classify, dim3(nblk(nB)), dim3(BLOCK), 0, stream, nB, nSVI, n, nV, bucketStart_.p, reinterpret_cast<int2*>(bucketSeg_.p),
+        outPT_.p, outEE_.p, permPT_.p, d_csPTEE.p, flags_.p, dupCount_.p);
+    const int* permPT = permPT_.p;
+    const int* permEE = permPT_.p + nPT;
+    scan(flags_.p, flagPos_.p, n + 1);
+    scan(dupCount_.p, dupStart_.p, nV + 1);
+    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, stream, flagPos_.p + n, &rbDev->totals);
     HIP_CHECK(hipStreamSynchronize(stream));
+    const unsigned long long totals = rb->totals;
     const int nDirect = (int)(totals & 0xffffffffull), nDup = (int)(totals >> 32), nPar = n - nDirect - nDup;
     d_active.ensure(4 * (size_t)std::max(nDirect + nDup, 1));
     d_para.ensure(4 * (size_t)std::max(nPar, 1));
     d_paraEIEJ.ensure(2 * (size_t)std::max(nPar, 1));
     dupTuple_.ensure(4 * (size_t)std::max(nDup, 1));
-    dupHi_.ensure((size_t)std::max(nDup, 1));
-    dupHiOut_.ensure((size_t)std::max(nDup, 1));
-    dupLo_.ensure((size_t)std::max(nDup, 1));
-    dupLoOut_.ensure((size_t)std::max(nDup, 1));
-    dupIdx_.ensure((size_t)std::max(nDup, 1));
-    dupIdx2_.ensure((size_t)std::max(nDup, 1));
-    // the duplicates' tuples as ONE 64-bit sort key when three node ids fit (meshes below 2 M nodes; round 6), else the two-pass sort of rounds 2-5
-    const int packBits = (3 * bitsFor(nV + 1) <= 64) ? bitsFor(nV + 1) : 0;
     hipLaunchKernelGGL(k_scatter_sets, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSFE, outPT_.p, permPT, outEE_.p, permEE, flagPos_.p,
-        d_active.p, dupTuple_.p, dupHi_.p, dupLo_.p, dupIdx_.p, d_para.p, d_paraEIEJ.p, nV, packBits);
+        d_active.p, dupTuple_.p, dupStart_.p, dupCount_.p, d_para.p, d_paraEIEJ.p, nV);
     int nUnique = 0;
     if (nDup) {
-        // lexicographic order of (id0, id1, id2): stable sort by the last component, then by the first two.  The second sort
-        // gathers its 64-bit keys through the order of the first.
-        size_t bytes = 0;
-        if (packBits) {
-            hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupHi_.p, dupHiOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 3 * packBits, stream);
-            hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupHi_.p, dupHiOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 3 * packBits, stream);
-            std::swap(dupIdx_.p, dupIdx2_.p); // dupIdx_ = order of the duplicates
-            std::swap(dupIdx_.n, dupIdx2_.n);
-        }
-        else {
-        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupLo_.p, dupLoOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 32, stream);
-        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupLo_.p, dupLoOut_.p, dupIdx_.p, dupIdx2_.p, nDup, 0, 32, stream);
-        hipLaunchKernelGGL(k_gather_u64, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, dupIdx2_.p, dupHi_.p, dupHiOut_.p);
-        hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dupHiOut_.p, dupHi_.p, dupIdx2_.p, dupIdx_.p, nDup, 0, 64, stream);
-        hipcub::DeviceRadixSort::SortPairs(tmp(bytes), bytes, dupHiOut_.p, dupHi_.p, dupIdx2_.p, dupIdx_.p, nDup, 0, 64, stream);
-        }
-        // dupIdx_ = order of the duplicates; run heads, their ranks, one tuple per run
-        head_.ensure((size_t)nDup + 1);
-        headPos_.ensure((size_t)nDup + 1);
-        hipLaunchKernelGGL(k_dup_heads, dim3(nblk(nDup + 1)), dim3(BLOCK), 0, stream, nDup, dupIdx_.p, dupTuple_.p, head_.p);
-        hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, head_.p, headPos_.p, nDup + 1, stream);
-        hipcub::DeviceScan::ExclusiveSum(tmp(bytes), bytes, head_.p, headPos_.p, nDup + 1, stream);
-        hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, nDirect, dupIdx_.p, dupTuple_.p, head_.p, headPos_.p, d_active.p);
-        HIP_CHECK(hipMemcpyAsync(&nUnique, headPos_.p + nDup, sizeof(int), hipMemcpyDeviceToHost, stream));
+        // lexicographic order of (id0, id1, id2) = the map's: buckets by id0, each ordered by (id1, id2); one tuple per run, its multiplicity in the last slot
+        hipLaunchKernelGGL(k_dup_sort, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dupStart_.p, reinterpret_cast<int4*>(dupTuple_.p), runs_.p);
+        scan(runs_.p, runPos_.p, nV + 1);
+        hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, nDirect, dupStart_.p, reinterpret_cast<const int4*>(dupTuple_.p), runPos_.p,
+            reinterpret_cast<int4*>(d_active.p));
+        hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, stream, runPos_.p + nV, &rbDev->nUnique);
         HIP_CHECK(hipStreamSynchronize(stream));
+        nUnique = rb->nUnique;
     }
+    countersDirty_ = false;
     nActive_ = nDirect + nUnique;
     nPara_ = nPar;
     return nActive_;
