@@ -72,6 +72,9 @@ public:
         e = (int)((long long)n * (shardRank + 1) / shardWorld);
     }
     double energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
+    // the same without the read-back: the value is left in *scalar_dev on the stream (false: empty sets, nothing enqueued, the value is 0) -- the time stepper
+    // reads it together with the elastic energy, one synchronisation for both
+    bool energyEnqueue(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
     // useActive / usePara: initKappa leaves the mollified set out (Optimizer.cpp:2262-2270)
     void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev, bool useActive = true,
         bool usePara = true, const unsigned char* need_dev = nullptr);
@@ -89,6 +92,9 @@ public:
     void candidateConnectivitySorted(std::vector<std::pair<int, int>>& pairs); // the same, sorted and unique, formed on the device
     // conservative CCD step bounds; pair2 receives the limiting pair ((-svI-1, sfI) or (eI, eJ)); returns the new bound
     double ccdPartial(const double* x_dev, const double* p_dev, double slackness, double stepSize, int* pair2);
+    // inversion filter (root already on the device, may be null) -> ccdPartial -> maxSurfaceSpeed with one synchronisation (the time stepper's step-size pipeline)
+    void stepBounds(const double* x_dev, const double* p_dev, double slackness, double stepSize, const double* filterDev, double* alphaOut, int* pair2,
+        double* pMaxOut);
     double ccdFull(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double stepSize, int* pair2,
         int* nCand);
     // the full sweep as the reference runs it (SelfCollisionHandler.cpp:982-1366 over SpatialHash.hpp:589-832): the hash first caps the step
@@ -138,22 +144,24 @@ private:
     int nActive_ = 0, nPara_ = 0, nCand_ = 0;
     mutable bool hostStale_ = false;
     DevBuf<unsigned long long> sortKeyIn_, sortKeyOut_, flags_, flagPos_;
-    DevBuf<int> permPT_, dupTuple_, closeIdx_;
+    DevBuf<int> permPT_, dupTuple_, dupSorted_, closeIdx_;
     // counting sorts of the record lists (by first primitive) and of the duplicate candidates (by vertex): counters, bucket starts, bucket contents, runs
     DevBuf<int> bucketCount_, bucketStart_, bucketSeg_, dupCount_, dupStart_, runs_, runPos_;
+    void readbackInit();
     bool countersDirty_ = false; // a build was left half-way (exception): the counters are cleared before the next one
     PinnedBuf<unsigned long long> readback_; // BuildReadback: what the host reads between the stages of a build (mapped memory, written by the kernels)
     DevBuf<double> closeVal_;
     DevBuf<char> scanTmp_;
-    // deterministic scatter of the barrier / friction terms (hip_contact.hip "deterministic scatter"): per-stencil slots, keys, sort, run sums
+    // deterministic scatter of the barrier / friction terms (hip_contact.hip "Deterministic scatter"): per-stencil slots, keys, bucket counters / starts /
+    // contents of the counting sort
     DevBuf<double> detVals_;
-    DevBuf<unsigned> detKey_, detKeyOut_;
-    DevBuf<int> detIota_, detPerm_, detRow_, hessPerm_; // hessPerm_: the two lists' indices binned by stencil kind (k_bin_stencils)
-    int detIotaN_ = 0;
-    void detBegin(size_t nSlots, int valsPerSlot, bool withRow, bool fillKeys = true);
-    void detReduce3(size_t nSlots, int keyBits, double* grad_dev);
-    void detReduceBlocks(size_t nSlots, int keyBits, const int* ia_dev, double* a_dev);
-    void detSort(size_t nSlots, int keyBits);
+    DevBuf<unsigned> detKey_;
+    DevBuf<int> detCount_, detStart_, detSeg_, detSorted_, detRow_, hessPerm_; // hessPerm_: the two lists' indices binned by stencil kind (k_bin_stencils)
+    bool detDirty_ = false; // a pass was left between its kernel and its fill (exception): the counters are cleared before the next one
+    void detBegin(size_t nSlots, int valsPerSlot, bool withRow, bool fillKeys, size_t nKeys);
+    void detBuckets(size_t nSlots, size_t nKeys, int div);
+    void detReduce3(size_t nSlots, size_t nKeys, double* grad_dev);
+    void detReduceBlocks(size_t nSlots, size_t nKeys, const int* ia_dev, double* a_dev);
 };
 
 } // namespace ipcgpu

@@ -19,14 +19,6 @@ namespace {
 using namespace cdev;
 constexpr int BLOCK = 256;
 
-// bit width of (largest real key + 1): see HipContact::detSort
-static int keyBitsFor(size_t nKeys)
-{
-    int b = 1;
-    while (b < 32 && ((size_t)1 << b) <= nKeys) ++b; // 2^b - 1 >= nKeys > every real key
-    return b;
-}
-
 struct ContactView {
     int nA, nP;
     const int* active; // int4 per entry
@@ -175,58 +167,97 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_scaled(const double* __restric
 // summation order, bit-reproducible.  (The atomic path stayed behind an environment switch for A/B timing until round 6:
 // profiles/r03_contact_bench_atomic_scatter.json against r03_contact_bench_deterministic_scatter.json.)
 constexpr unsigned KEY_NONE = 0xFFFFFFFFu;
+// Deterministic scatter (round 6: a counting sort; rounds 3-5 sorted the keys with rocPRIM's radix sort, which is a merge sort of ~16 launches at these sizes):
+// every contribution has a slot of its own (stencil index x slots per stencil), a key (the node, or the CSR position of the 3 x 3 block) and bumps the
+// counter of its key's bucket; one scan lays the buckets out, k_det_fill drops the slot indices into them (counting the counters back down to zero), k_det_rank puts every
+// bucket into ascending slot order, and one thread per bucket adds its contributions up in that order -- the order the stable sort produced, so the sums are bit for bit the same.
 struct GradSink {
     double* contrib; // 3 doubles per slot
-    unsigned* key; // node per slot (prefilled with KEY_NONE)
+    unsigned* key; // node per slot (KEY_NONE: nothing to add)
+    int* count; // contributions per node
 };
 __device__ __forceinline__ void sink_add3(const GradSink& k, size_t slot, int node, const double v[3])
 {
     k.key[slot] = (unsigned)node;
+    atomicAdd(k.count + node, 1);
     k.contrib[3 * slot] = v[0];
     k.contrib[3 * slot + 1] = v[1];
     k.contrib[3 * slot + 2] = v[2];
 }
 struct BlockSink {
     double* contrib; // 9 doubles per slot, entry (r, c) at r + 3 c
-    unsigned* key; // CSR index of the block's first entry (prefilled with KEY_NONE)
+    unsigned* key; // CSR index of the block's first entry (KEY_NONE: nothing to add)
     int* rowNode; // row node of the block (the reducer derives row length and diagonal / off-diagonal from it)
+    int* count; // contributions per block: bucket = key / 3 (the first entries of two blocks are at least three positions apart)
 };
-// one lane per sorted entry; the head of a run (first entry with its key) sums the run in order
-__global__ __launch_bounds__(BLOCK) void k_seg_sum3(int n, const unsigned* __restrict__ keys, const int* __restrict__ perm, const double* __restrict__ contrib,
+__device__ __forceinline__ void sink_key_block(const BlockSink& k, size_t slot, int p0, int rowNode)
+{
+    k.key[slot] = (unsigned)p0;
+    k.rowNode[slot] = rowNode;
+    atomicAdd(k.count + p0 / 3, 1);
+}
+// one thread per slot: its place in the bucket of its key
+__global__ __launch_bounds__(BLOCK) void k_det_fill(int n, const unsigned* __restrict__ keys, int div, const int* __restrict__ start, int* __restrict__ count,
+    int* __restrict__ seg)
+{
+    const int t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= n) return;
+    const unsigned key = keys[t];
+    if (key == KEY_NONE) return;
+    const int b = (int)(key / (unsigned)div);
+    seg[start[b] + atomicSub(count + b, 1) - 1] = t;
+}
+// one thread per bucket ENTRY: its rank among the slot indices of its bucket (a few tens of independent loads that hit the cache; one thread per bucket
+// insertion-sorting in place was a chain of dependent global loads -- 0.12 ms for the fullest nodes), the bucket in ascending slot order into `sorted`
+__global__ __launch_bounds__(BLOCK) void k_det_rank(int n, const unsigned* __restrict__ keys, int div, const int* __restrict__ start, int nKeys,
+    const int* __restrict__ seg, int* __restrict__ sorted)
+{
+    const int u = blockIdx.x * BLOCK + threadIdx.x;
+    if (u >= n || u >= start[nKeys]) return;
+    const int slot = seg[u];
+    const int b = (int)(keys[slot] / (unsigned)div);
+    const int s0 = start[b], s1 = start[b + 1];
+    int rank = 0;
+    for (int w = s0; w < s1; ++w) rank += seg[w] < slot ? 1 : 0;
+    sorted[s0 + rank] = slot;
+}
+// one thread per node: the node's contributions summed in slot order
+__global__ __launch_bounds__(BLOCK) void k_bucket_sum3(int nKeys, const int* __restrict__ start, const int* __restrict__ seg, const double* __restrict__ contrib,
     double* __restrict__ grad)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= n) return;
-    const unsigned key = keys[t];
-    if (key == KEY_NONE || (t > 0 && keys[t - 1] == key)) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int u = t; u < n && keys[u] == key; ++u) {
-        const double* q = contrib + 3 * (size_t)perm[u];
-        s0 += q[0];
-        s1 += q[1];
-        s2 += q[2];
+    const int v = blockIdx.x * BLOCK + threadIdx.x;
+    if (v >= nKeys) return;
+    const int s0 = start[v], s1 = start[v + 1];
+    if (s0 == s1) return;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+    for (int u = s0; u < s1; ++u) {
+        const double* q = contrib + 3 * (size_t)seg[u];
+        t0 += q[0];
+        t1 += q[1];
+        t2 += q[2];
     }
-    double* g = grad + 3 * (size_t)key;
-    g[0] += s0;
-    g[1] += s1;
-    g[2] += s2;
+    double* g = grad + 3 * (size_t)v;
+    g[0] += t0;
+    g[1] += t1;
+    g[2] += t2;
 }
-__global__ __launch_bounds__(BLOCK) void k_seg_sum_blocks(int n, const unsigned* __restrict__ keys, const int* __restrict__ perm, const double* __restrict__ contrib,
-    const int* __restrict__ rowNode, const int* __restrict__ ia, double* __restrict__ a)
+// one thread per bucket of CSR positions (at most one block's first entry falls into it)
+__global__ __launch_bounds__(BLOCK) void k_bucket_sum_blocks(int nKeys, const int* __restrict__ start, const int* __restrict__ seg, const unsigned* __restrict__ keys,
+    const double* __restrict__ contrib, const int* __restrict__ rowNode, const int* __restrict__ ia, double* __restrict__ a)
 {
-    const int t = blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= n) return;
-    const unsigned key = keys[t];
-    if (key == KEY_NONE || (t > 0 && keys[t - 1] == key)) return;
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= nKeys) return;
+    const int s0 = start[b], s1 = start[b + 1];
+    if (s0 == s1) return;
     double S[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) S[k] = 0.0;
-    for (int u = t; u < n && keys[u] == key; ++u) {
-        const double* q = contrib + 9 * (size_t)perm[u];
+    for (int u = s0; u < s1; ++u) {
+        const double* q = contrib + 9 * (size_t)seg[u];
 #pragma unroll
         for (int k = 0; k < 9; ++k) S[k] += q[k];
     }
-    const int vi = rowNode[perm[t]], p0 = (int)key;
+    const int vi = rowNode[seg[s0]], p0 = (int)keys[seg[s0]];
     const int base = ia[3 * vi], L = ia[3 * vi + 1] - base;
     if (p0 == base) { // the diagonal block: its upper triangle
         a[p0 + 0] += S[0];
@@ -244,11 +275,6 @@ __global__ __launch_bounds__(BLOCK) void k_seg_sum_blocks(int n, const unsigned*
             for (int c = 0; c < 3; ++c) a[p0 + rowOff + c] += S[r + 3 * c];
         }
     }
-}
-__global__ void k_iota(int n, int* __restrict__ v)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) v[i] = i;
 }
 
 // grad += kappa (mult b' grad d)  resp.  kappa (b e' grad c + e b' grad d)   (SelfCollisionHandler.cpp:84-148, 2990-3036)
@@ -446,8 +472,7 @@ __device__ __forceinline__ void emit_pair(const HessOut& o, const double* C, siz
             return;
         }
     }
-    o.sink.key[slot] = (unsigned)p0;
-    o.sink.rowNode[slot] = vi;
+    sink_key_block(o.sink, slot, p0, vi);
     double* q = o.sink.contrib + 9 * slot;
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -774,8 +799,7 @@ __global__ __launch_bounds__(BLOCK) void k_friction_hessian(FrictionView fv, Csr
                 }
             }
             const size_t slot = 16 * (size_t)i + 4 * k + l;
-            sink.key[slot] = (unsigned)p0;
-            sink.rowNode[slot] = vi;
+            sink_key_block(sink, slot, p0, vi);
             for (int q = 0; q < 9; ++q) sink.contrib[9 * slot + q] = w * BBt[q];
         }
     }
@@ -1324,10 +1348,12 @@ __global__ __launch_bounds__(BLOCK) void k_ccd_hits_arg(CcdOut o)
 
 // pass 0: minimum time; pass 1: first pair attaining it
 __global__ __launch_bounds__(BLOCK) void k_ccd_list(int nPairs, const int* __restrict__ pairs, const int* __restrict__ SVI, const int* __restrict__ SF,
-    const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ p, double slackness, double tmax, int pass, CcdOut o)
+    const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ p, double slackness, double tmax, int pass, CcdOut o,
+    const unsigned long long* __restrict__ tmaxDev)
 {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= nPairs) return;
+    if (tmaxDev) tmax = __longlong_as_double((long long)tmaxDev[0]); // the bound the inversion filter left on the device (HipContact::stepBounds)
     const int a = pairs[2 * (size_t)i], b = pairs[2 * (size_t)i + 1];
     int node[4], kind, ki, kj;
     if (a < 0) {
@@ -1926,7 +1952,7 @@ __device__ inline bool seg_tri_intersect(const double* ve0, const double* ve1, c
 // checkEdgeTriIntersectionIfAny (SelfCollisionHandler.cpp:3255-3300): one lane per surface triangle, edges from the grid
 template <bool exact>
 __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restrict__ SF, const int* __restrict__ SFE, const double* __restrict__ x,
-    const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, int* __restrict__ flag)
+    const int* __restrict__ dbc, Grid g, const int* __restrict__ cellStart, const int* __restrict__ cellItems, int* __restrict__ flag, int capItems)
 {
     const int gi = blockIdx.x * BLOCK + threadIdx.x;
     const int f = gi / COOP, sub = gi % COOP; // COOP lanes share a triangle and stride over the edges of each cell (see COOP)
@@ -1949,7 +1975,7 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
         for (int y = ca[1]; y <= cb[1]; ++y)
             for (int xx = ca[0]; xx <= cb[0]; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
-                for (int k = cellStart[cell] + sub, kEnd = cellStart[cell + 1]; k < kEnd; k += COOP) {
+                for (int k = cellStart[cell] + sub, kEnd = min(cellStart[cell + 1], capItems); k < kEnd; k += COOP) { // (capItems: a truncated list -- the host repeats)
                     const BoxRec rec = load_box_rec(cellItems, k);
                     if (rec.lo[0] > hiF[0] || rec.hi[0] < loF[0] || rec.lo[1] > hiF[1] || rec.hi[1] < loF[1] || rec.lo[2] > hiF[2] || rec.hi[2] < loF[2])
                         continue; // outward-rounded boxes apart: the exact test below would say the same
@@ -2026,9 +2052,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_stencils(int n, const int* __res
 // the 4-tuple.  Same result here without the host, as two COUNTING sorts (round 6; rounds 2-5 ran radix sorts on 64-bit keys, which rocPRIM turns into a
 // merge sort of ~15 launches at these sizes -- 67 launches of ~5 us per Newton iteration):
 //   records by primitive pair: the narrow phase counts the records of every first primitive (WgList::bucket), one scan gives the buckets, k_bucket_fill
-//   drops every record into its bucket, k_bucket_sort_classify orders each bucket by the second primitive (a handful of entries) and classifies;
-//   duplicates by tuple: the bucket is the tuple's vertex (k_bucket_sort_classify counts, k_scatter_sets fills), k_dup_sort orders each bucket by the other
-//   two ids and counts its runs, one scan places the runs, k_dup_emit writes one tuple per run with its multiplicity.
+//   drops every record into its bucket, k_bucket_rank_classify ranks each record inside its bucket by the second primitive (a handful of entries) and classifies;
+//   duplicates by tuple: the bucket is the tuple's vertex (k_bucket_rank_classify counts, k_scatter_sets fills), k_dup_rank orders each bucket by the other
+//   two ids, k_dup_runs counts its runs, one scan places the runs, k_dup_emit writes one tuple per run with its multiplicity.
 // Every counter array is counted up by one kernel and back down to zero by the one that fills the buckets: no clearing between builds.
 
 // one thread per record: its slot in the bucket of its first primitive (point-triangle buckets [0, nSVI), edge-edge buckets behind them)
@@ -2052,37 +2078,31 @@ __device__ __forceinline__ int rec_category(const int* r, bool isEE)
     if (!isEE) return r[3] < 0 ? 1 : 0;
     return r[3] >= 0 ? 0 : (r[3] == -1 ? 1 : 2);
 }
-// one thread per bucket: its records in the order of the second primitive (the pair is unique, the bucket a handful of entries: insertion sort in place) --
-// the bucket's range of the list IS its range in the serial enumeration, so the same thread writes the permutation (point-triangle records first, then the
-// edge-edge ones, each as an index into its own list), the candidate list, the category flags for the prefix sum, and counts the duplicate candidates per vertex
-__global__ void k_bucket_sort_classify(int nB, int nSVI, int n, int nV, const int* __restrict__ start, int2* __restrict__ seg, const int* __restrict__ recPT,
+// one thread per bucket ENTRY: the rank of its second primitive inside the bucket (the pair is unique, the bucket a handful of entries) gives the record's
+// place in the serial enumeration -- the bucket's range of the list IS its range there --, and the thread writes what belongs to that place: the permutation
+// (point-triangle records first, then the edge-edge ones, each as an index into its own list), the candidate list, the category flag for the prefix sum; it
+// also counts the duplicate candidates per vertex
+__global__ void k_bucket_rank_classify(int nPT, int nEE, int nSVI, int nV, const int* __restrict__ start, const int2* __restrict__ seg, const int* __restrict__ recPT,
     const int* __restrict__ recEE, int* __restrict__ perm, int* __restrict__ csPTEE, unsigned long long* __restrict__ flags, int* __restrict__ dupCount)
 {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b == 0) flags[n] = 0ull; // the scan runs over n + 1 entries: its last output is the totals
-    if (b >= nB) return;
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = nPT + nEE;
+    if (u == n) flags[n] = 0ull; // the scan runs over n + 1 entries: its last output is the totals
+    if (u >= n) return;
+    const bool isEE = u >= nPT;
+    const int2 e = seg[u];
+    const int* r = (isEE ? recEE : recPT) + 6 * (size_t)e.y;
+    const int b = isEE ? nSVI + r[4] : r[4];
     const int s0 = start[b], s1 = start[b + 1];
-    if (s0 == s1) return;
-    for (int a = s0 + 1; a < s1; ++a) {
-        const int2 v = seg[a];
-        int k = a - 1;
-        while (k >= s0 && seg[k].x > v.x) {
-            seg[k + 1] = seg[k];
-            --k;
-        }
-        seg[k + 1] = v;
-    }
-    const bool isEE = b >= nSVI;
-    for (int s = s0; s < s1; ++s) {
-        const int idx = seg[s].y;
-        perm[s] = idx;
-        const int* r = (isEE ? recEE : recPT) + 6 * (size_t)idx;
-        csPTEE[2 * (size_t)s] = isEE ? r[4] : -r[4] - 1;
-        csPTEE[2 * (size_t)s + 1] = r[5];
-        const int cat = rec_category(r, isEE);
-        flags[s] = cat == 0 ? 1ull : (cat == 1 ? 1ull << 32 : 0ull);
-        if (cat == 1) atomicAdd(dupCount + (r[0] + nV), 1); // id0 = -v - 1 in [-nV, -1]: buckets in ascending id0, the map's (signed) order
-    }
+    int rank = 0;
+    for (int w = s0; w < s1; ++w) rank += seg[w].x < e.x ? 1 : 0;
+    const int s = s0 + rank;
+    perm[s] = e.y;
+    csPTEE[2 * (size_t)s] = isEE ? r[4] : -r[4] - 1;
+    csPTEE[2 * (size_t)s + 1] = r[5];
+    const int cat = rec_category(r, isEE);
+    flags[s] = cat == 0 ? 1ull : (cat == 1 ? 1ull << 32 : 0ull);
+    if (cat == 1) atomicAdd(dupCount + (r[0] + nV), 1); // id0 = -v - 1 in [-nV, -1]: buckets in ascending id0, the map's (signed) order
 }
 __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict__ recPT, const int* __restrict__ permPT,
     const int* __restrict__ recEE, const int* __restrict__ permEE, const unsigned long long* __restrict__ pos, int* __restrict__ active,
@@ -2100,7 +2120,7 @@ __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict
     }
     else if (cat == 1) {
         const int v = r[0] + nV;
-        const int q = dupStart[v] + atomicSub(dupCount + v, 1) - 1; // any slot of the vertex's bucket: k_dup_sort orders it
+        const int q = dupStart[v] + atomicSub(dupCount + v, 1) - 1; // any slot of the vertex's bucket: k_dup_rank orders it
         for (int k = 0; k < 4; ++k) dupTuple[4 * (size_t)q + k] = r[k];
     }
     else {
@@ -2119,28 +2139,31 @@ __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict
         }
     }
 }
-// one thread per vertex: its duplicate candidates ordered by (id1, id2) (id2 = -1 of a point-point tuple sorts first, as in the map's signed order;
-// id3 = -1 for all of them) and the number of distinct tuples among them
-__global__ void k_dup_sort(int nV, const int* __restrict__ start, int4* __restrict__ tuple, int* __restrict__ runs)
+// one thread per duplicate candidate: its rank inside its vertex's bucket by (id1, id2) (id2 = -1 of a point-point tuple sorts first, as in the map's signed
+// order; id3 = -1 for all of them; equal tuples in the order they happen to lie in -- they are merged anyway)
+__global__ void k_dup_rank(int n, int nV, const int* __restrict__ start, const int4* __restrict__ tuple, int4* __restrict__ sorted)
+{
+    const int u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const int4 t = tuple[u];
+    const int v = t.x + nV;
+    const int s0 = start[v], s1 = start[v + 1];
+    int rank = 0;
+    for (int w = s0; w < s1; ++w) {
+        const int4 o = tuple[w];
+        rank += (o.y < t.y || (o.y == t.y && (o.z < t.z || (o.z == t.z && w < u)))) ? 1 : 0;
+    }
+    sorted[s0 + rank] = t;
+}
+// one thread per vertex: the number of distinct tuples among its (ordered) duplicate candidates
+__global__ void k_dup_runs(int nV, const int* __restrict__ start, const int4* __restrict__ tuple, int* __restrict__ runs)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
     if (v == 0) runs[nV] = 0; // (the scan's last output is the number of runs)
     if (v >= nV) return;
     const int s0 = start[v], s1 = start[v + 1];
-    int nr = 0;
-    if (s1 > s0) {
-        for (int a = s0 + 1; a < s1; ++a) {
-            const int4 t = tuple[a];
-            int k = a - 1;
-            while (k >= s0 && (tuple[k].y > t.y || (tuple[k].y == t.y && tuple[k].z > t.z))) {
-                tuple[k + 1] = tuple[k];
-                --k;
-            }
-            tuple[k + 1] = t;
-        }
-        nr = 1;
-        for (int a = s0 + 1; a < s1; ++a) nr += (tuple[a].y != tuple[a - 1].y || tuple[a].z != tuple[a - 1].z) ? 1 : 0;
-    }
+    int nr = s1 > s0 ? 1 : 0;
+    for (int a = s0 + 1; a < s1; ++a) nr += (tuple[a].y != tuple[a - 1].y || tuple[a].z != tuple[a - 1].z) ? 1 : 0;
     runs[v] = nr;
 }
 // one thread per vertex: (tuple, -multiplicity) of each of its runs behind the direct entries
@@ -2164,7 +2187,7 @@ __global__ void k_dup_emit(int nV, int nDirect, const int* __restrict__ start, c
 struct BuildReadback {
     int cnt[4]; // point-triangle records, edge-edge records, stale-grid flag, total number of cell entries
     double box[6];
-    unsigned long long totals; // category totals of the candidate list (k_bucket_sort_classify's flags, scanned)
+    unsigned long long totals; // category totals of the candidate list (k_bucket_rank_classify's flags, scanned)
     int nUnique, pad;
 };
 __global__ void k_publish_narrow(const int* __restrict__ counters, const int* __restrict__ gridTotal, const double* __restrict__ box, BuildReadback* __restrict__ out)
@@ -2176,6 +2199,19 @@ __global__ void k_publish_narrow(const int* __restrict__ counters, const int* __
     for (int c = 0; c < 6; ++c) out->box[c] = box[c];
 }
 __global__ void k_publish_u64(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) { dst[0] = src[0]; }
+__global__ void k_publish_u64x4(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst) { dst[threadIdx.x] = src[threadIdx.x]; }
+// ccdOut of HipContact::stepBounds: [0] minimum time, [1] its pair (both "none"), [2] largest surface speed, [3] the step the CCD is bounded by
+__global__ void k_step_bounds_init(double stepSize, const double* __restrict__ filterRoot, unsigned long long* __restrict__ out)
+{
+    out[0] = ~0ull;
+    out[1] = ~0ull;
+    out[2] = 0ull;
+    if (filterRoot) {
+        const double t = filterRoot[0];
+        if (t > 0.0 && t < stepSize) stepSize = t; // Energy.cpp:565-581
+    }
+    out[3] = (unsigned long long)__double_as_longlong(stepSize);
+}
 __global__ void k_publish_int(const int* __restrict__ src, int* __restrict__ dst) { dst[0] = src[0]; }
 // stencils of the active set closer than dTol (closeMConstraint bookkeeping, Optimizer.cpp:2365-2440): index + distance
 __global__ void k_close_stencils(int n, const int* __restrict__ ids, const double* __restrict__ x, double dTol, int cap, int* __restrict__ outIdx,
@@ -2319,6 +2355,12 @@ void HipContact::uploadSets()
     hostStale_ = false; // the host vectors are the source here
 }
 
+void HipContact::readbackInit()
+{
+    if (!readback_.p) readback_.alloc(16); // >= sizeof(BuildReadback) / 8
+    static_assert(sizeof(BuildReadback) <= 16 * sizeof(unsigned long long), "read-back block too small");
+}
+
 int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat)
 {
     if (!surfaceSet) throw StateError("contact_build before set_surface");
@@ -2361,7 +2403,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     dupStart_.ensure((size_t)nV + 1);
     runs_.ensure((size_t)nV + 1);
     runPos_.ensure((size_t)nV + 1);
-    if (!readback_.p) readback_.alloc((sizeof(BuildReadback) + 7) / 8);
+    readbackInit();
     BuildReadback* rb = reinterpret_cast<BuildReadback*>(readback_.p);
     BuildReadback* rbDev = reinterpret_cast<BuildReadback*>(readback_.dev);
     auto scan = [&](auto* in, auto* out, int count) { // exclusive prefix sum, temporary storage grown on demand
@@ -2450,8 +2492,8 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     // by (svI, sfI) and (eI, eJ) -- the order a serial scan emits --, the point-triangle records first
     hipLaunchKernelGGL(k_bucket_fill, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSVI, outPT_.p, outEE_.p, bucketStart_.p, bucketCount_.p,
         reinterpret_cast<int2*>(bucketSeg_.p));
-    hipLaunchKernelGGL(k_bucket_sort_classify, dim3(nblk(nB)), dim3(BLOCK), 0, stream, nB, nSVI, n, nV, bucketStart_.p, reinterpret_cast<int2*>(bucketSeg_.p),
-        outPT_.p, outEE_.p, permPT_.p, d_csPTEE.p, flags_.p, dupCount_.p);
+    hipLaunchKernelGGL(k_bucket_rank_classify, dim3(nblk(n + 1)), dim3(BLOCK), 0, stream, nPT, nEE, nSVI, nV, bucketStart_.p,
+        reinterpret_cast<const int2*>(bucketSeg_.p), outPT_.p, outEE_.p, permPT_.p, d_csPTEE.p, flags_.p, dupCount_.p);
     const int* permPT = permPT_.p;
     const int* permEE = permPT_.p + nPT;
     scan(flags_.p, flagPos_.p, n + 1);
@@ -2464,14 +2506,17 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     d_para.ensure(4 * (size_t)std::max(nPar, 1));
     d_paraEIEJ.ensure(2 * (size_t)std::max(nPar, 1));
     dupTuple_.ensure(4 * (size_t)std::max(nDup, 1));
+    dupSorted_.ensure(4 * (size_t)std::max(nDup, 1));
     hipLaunchKernelGGL(k_scatter_sets, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSFE, outPT_.p, permPT, outEE_.p, permEE, flagPos_.p,
         d_active.p, dupTuple_.p, dupStart_.p, dupCount_.p, d_para.p, d_paraEIEJ.p, nV);
     int nUnique = 0;
     if (nDup) {
         // lexicographic order of (id0, id1, id2) = the map's: buckets by id0, each ordered by (id1, id2); one tuple per run, its multiplicity in the last slot
-        hipLaunchKernelGGL(k_dup_sort, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dupStart_.p, reinterpret_cast<int4*>(dupTuple_.p), runs_.p);
+        hipLaunchKernelGGL(k_dup_rank, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, nV, dupStart_.p, reinterpret_cast<const int4*>(dupTuple_.p),
+            reinterpret_cast<int4*>(dupSorted_.p));
+        hipLaunchKernelGGL(k_dup_runs, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dupStart_.p, reinterpret_cast<const int4*>(dupSorted_.p), runs_.p);
         scan(runs_.p, runPos_.p, nV + 1);
-        hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, nDirect, dupStart_.p, reinterpret_cast<const int4*>(dupTuple_.p), runPos_.p,
+        hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, nDirect, dupStart_.p, reinterpret_cast<const int4*>(dupSorted_.p), runPos_.p,
             reinterpret_cast<int4*>(d_active.p));
         hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, stream, runPos_.p + nV, &rbDev->nUnique);
         HIP_CHECK(hipStreamSynchronize(stream));
@@ -2509,9 +2554,9 @@ void HipContact::syncHost() const
     self->hostStale_ = false;
 }
 
-double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
+bool HipContact::energyEnqueue(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
 {
-    if (nActive_ + nPara_ == 0) return 0.0;
+    if (nActive_ + nPara_ == 0) return false;
     int aB, aE, pB, pE; // this rank's share of the two lists
     shardRange(nActive_, aB, aE);
     shardRange(nPara_, pB, pE);
@@ -2522,9 +2567,16 @@ double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf
     if (n) hipLaunchKernelGGL(k_contact_energy, dim3(nb), dim3(BLOCK), 0, stream, cv, dHat, partial.p);
     hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, n ? nb : 0, kappa, scalar_dev);
     if (shardWorld > 1 && shardReduce) shardReduce(scalar_dev, 1);
-    double out = 0.0;
-    HIP_CHECK(hipMemcpyAsync(&out, scalar_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
+    return true;
+}
+double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
+{
+    if (!energyEnqueue(x_dev, dHat, kappa, partial, scalar_dev)) return 0.0;
+    readbackInit();
+    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, stream, reinterpret_cast<const unsigned long long*>(scalar_dev), readback_.dev);
     HIP_CHECK(hipStreamSynchronize(stream));
+    double out;
+    std::memcpy(&out, readback_.p, sizeof(out));
     return out;
 }
 
@@ -2556,9 +2608,9 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
     const int n = nA + nP;
     if (n) {
         ContactView cv{ nA, nP, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, x_dev, d_xRest.p, need_dev };
-        detBegin(8 * (size_t)n, 3, false, /*fillKeys=*/false); // the kernel writes every key
-        hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ detVals_.p, detKey_.p });
-        detReduce3(8 * (size_t)n, keyBitsFor((size_t)nV), grad_dev);
+        detBegin(8 * (size_t)n, 3, false, /*fillKeys=*/false, (size_t)nV); // the kernel writes every key
+        hipLaunchKernelGGL(k_contact_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, dHat, kappa, GradSink{ detVals_.p, detKey_.p, detCount_.p });
+        detReduce3(8 * (size_t)n, (size_t)nV, grad_dev);
     }
     hipLaunchKernelGGL(k_zero_projected, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dbc_dev, projectDBC, grad_dev);
 }
@@ -2576,11 +2628,12 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     hessPerm_.ensure((size_t)NBINS * (size_t)n);
     hipLaunchKernelGGL(k_bin_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, cv, counters_.p + 4, hessPerm_.p, n);
     const size_t nSlots = (size_t)HSLOTS * (size_t)n;
-    detBegin(nSlots, 9, true, /*fillKeys=*/false); // the kernel writes every key
+    const size_t nKeys = lin.ja.size() / 3 + 1; // buckets of the block positions
+    detBegin(nSlots, 9, true, /*fillKeys=*/false, nKeys); // the kernel writes every key
     const HessBins bins{ counters_.p + 4, hessPerm_.p, n };
     hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_W) + NBINS), dim3(HESS_W), 0, stream, cv, bins, m, dbc_dev, projectDBC, dHat, kappa,
-        BlockSink{ detVals_.p, detKey_.p, detRow_.p }, counters_.p);
-    detReduceBlocks(nSlots, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
+        BlockSink{ detVals_.p, detKey_.p, detRow_.p, detCount_.p }, counters_.p);
+    detReduceBlocks(nSlots, nKeys, lin.d_ia.p, a_dev);
     int err[2];
     counters_.download(err, 2, stream);
     if (std::getenv("IPCGPU_DEBUG")) std::fprintf(stderr, "[ipcgpu] barrier Hessian: %d stencils, %.2f Jacobi sweeps on average\n", n, (double)err[1] / n);
@@ -2644,43 +2697,43 @@ double HipContact::frictionEnergy(const double* x_dev, const double* xt_dev, dou
     return out;
 }
 
-// ---- deterministic scatter, host side: slots + keys for one launch, then sort and sum the runs -------------------------------------------
-void HipContact::detBegin(size_t nSlots, int valsPerSlot, bool withRow, bool fillKeys)
+// ---- deterministic scatter, host side: slots + keys + bucket counters for one launch, then scan, fill and sum the buckets --------------------
+void HipContact::detBegin(size_t nSlots, int valsPerSlot, bool withRow, bool fillKeys, size_t nKeys)
 {
+    if (nSlots > (size_t)INT_MAX || nKeys + 1 > (size_t)INT_MAX) throw StateError("too many contact contributions for one scatter pass");
     detVals_.ensure(nSlots * (size_t)valsPerSlot);
     detKey_.ensure(nSlots);
-    detKeyOut_.ensure(nSlots);
-    detPerm_.ensure(nSlots);
+    detSeg_.ensure(nSlots);
+    detSorted_.ensure(nSlots);
     if (withRow) detRow_.ensure(nSlots);
-    if (detIota_.n < nSlots || (size_t)detIotaN_ < nSlots) {
-        detIota_.ensure(nSlots);
-        detIotaN_ = (int)detIota_.n;
-        hipLaunchKernelGGL(k_iota, dim3(nblk(detIotaN_)), dim3(BLOCK), 0, stream, detIotaN_, detIota_.p);
+    if (detCount_.n < nKeys + 1 || detDirty_) { // the counters return to zero with every pass that runs to its end (k_det_fill)
+        detCount_.ensure(nKeys + 1);
+        detCount_.zero(stream);
     }
-    if (fillKeys) HIP_CHECK(hipMemsetAsync(detKey_.p, 0xFF, nSlots * sizeof(unsigned), stream)); // KEY_NONE: slots nobody writes sort to the end
+    detStart_.ensure(nKeys + 1);
+    detDirty_ = true;
+    if (fillKeys) HIP_CHECK(hipMemsetAsync(detKey_.p, 0xFF, nSlots * sizeof(unsigned), stream)); // KEY_NONE: slots the kernel does not write
 }
-void HipContact::detSort(size_t nSlots, int keyBits)
+void HipContact::detBuckets(size_t nSlots, size_t nKeys, int div)
 {
-    // Only the significant bits are sorted (round 4): keyBits = bit width of (largest real key + 1), so that no real key has all of them set; unused
-    // slots carry KEY_NONE = all ones and still sort behind every real key.  A node id has 16-19 bits, a CSR position 22-25: two or three digit passes of the
-    // radix sort instead of four.
-    if (nSlots > (size_t)INT_MAX) throw StateError("too many contact contributions for one scatter pass");
-    const int bits = std::max(1, std::min(32, keyBits));
     size_t bytes = 0;
-    hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, bits, stream);
+    hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, detCount_.p, detStart_.p, (int)nKeys + 1, stream);
     if (scanTmp_.n < bytes) scanTmp_.alloc(bytes + bytes / 4);
-    hipcub::DeviceRadixSort::SortPairs((void*)scanTmp_.p, bytes, detKey_.p, detKeyOut_.p, detIota_.p, detPerm_.p, (int)nSlots, 0, bits, stream);
+    hipcub::DeviceScan::ExclusiveSum((void*)scanTmp_.p, bytes, detCount_.p, detStart_.p, (int)nKeys + 1, stream);
+    hipLaunchKernelGGL(k_det_fill, dim3(nblk((int)nSlots)), dim3(BLOCK), 0, stream, (int)nSlots, detKey_.p, div, detStart_.p, detCount_.p, detSeg_.p);
+    hipLaunchKernelGGL(k_det_rank, dim3(nblk((int)nSlots)), dim3(BLOCK), 0, stream, (int)nSlots, detKey_.p, div, detStart_.p, (int)nKeys, detSeg_.p, detSorted_.p);
+    detDirty_ = false;
 }
-void HipContact::detReduce3(size_t nSlots, int keyBits, double* grad_dev)
+void HipContact::detReduce3(size_t nSlots, size_t nKeys, double* grad_dev)
 {
-    detSort(nSlots, keyBits);
-    hipLaunchKernelGGL(k_seg_sum3, dim3(nblk((int)nSlots)), dim3(BLOCK), 0, stream, (int)nSlots, detKeyOut_.p, detPerm_.p, detVals_.p, grad_dev);
+    detBuckets(nSlots, nKeys, 1);
+    hipLaunchKernelGGL(k_bucket_sum3, dim3(nblk((int)nKeys)), dim3(BLOCK), 0, stream, (int)nKeys, detStart_.p, detSorted_.p, detVals_.p, grad_dev);
 }
-void HipContact::detReduceBlocks(size_t nSlots, int keyBits, const int* ia_dev, double* a_dev)
+void HipContact::detReduceBlocks(size_t nSlots, size_t nKeys, const int* ia_dev, double* a_dev)
 {
-    detSort(nSlots, keyBits);
-    hipLaunchKernelGGL(k_seg_sum_blocks, dim3(nblk((int)nSlots)), dim3(BLOCK), 0, stream, (int)nSlots, detKeyOut_.p, detPerm_.p, detVals_.p, detRow_.p, ia_dev,
-        a_dev);
+    detBuckets(nSlots, nKeys, 3);
+    hipLaunchKernelGGL(k_bucket_sum_blocks, dim3(nblk((int)nKeys)), dim3(BLOCK), 0, stream, (int)nKeys, detStart_.p, detSorted_.p, detKey_.p, detVals_.p, detRow_.p,
+        ia_dev, a_dev);
 }
 
 void HipContact::frictionGradientAdd(const double* x_dev, const double* xt_dev, double eps2, double coef, double* grad_dev)
@@ -2688,9 +2741,9 @@ void HipContact::frictionGradientAdd(const double* x_dev, const double* xt_dev, 
     const int n = (int)fricSet.size();
     if (!n) return;
     FrictionView fv{ n, d_fricSet.p, d_fricLambda.p, d_fricCoord.p, d_fricBasis.p };
-    detBegin(8 * (size_t)n, 3, false);
-    hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, GradSink{ detVals_.p, detKey_.p });
-    detReduce3(8 * (size_t)n, 32, grad_dev);
+    detBegin(8 * (size_t)n, 3, false, true, d_xRest.n / 3); // (d_xRest: three rest coordinates per node)
+    hipLaunchKernelGGL(k_friction_gradient, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, coef, GradSink{ detVals_.p, detKey_.p, detCount_.p });
+    detReduce3(8 * (size_t)n, d_xRest.n / 3, grad_dev);
 }
 
 void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, const int* dbc_dev, const HipLinSysSolver& lin, double eps2, double coef,
@@ -2702,10 +2755,11 @@ void HipContact::frictionHessianAdd(const double* x_dev, const double* xt_dev, c
     CsrView m{ lin.d_ia.p, lin.d_ja.p };
     counters_.alloc(16);
     counters_.zero(stream);
-    detBegin(16 * (size_t)n, 9, true);
+    const size_t nKeys = lin.ja.size() / 3 + 1;
+    detBegin(16 * (size_t)n, 9, true, true, nKeys);
     hipLaunchKernelGGL(k_friction_hessian, dim3(nblk(n)), dim3(BLOCK), 0, stream, fv, m, x_dev, xt_dev, dbc_dev, projectDBC, eps2, coef,
-        BlockSink{ detVals_.p, detKey_.p, detRow_.p }, counters_.p);
-    detReduceBlocks(16 * (size_t)n, keyBitsFor(lin.ja.size()), lin.d_ia.p, a_dev);
+        BlockSink{ detVals_.p, detKey_.p, detRow_.p, detCount_.p }, counters_.p);
+    detReduceBlocks(16 * (size_t)n, nKeys, lin.d_ia.p, a_dev);
     int err[2];
     counters_.download(err, 2, stream);
     if (err[0]) throw StateError("friction Hessian touches a node pair outside the CSR pattern: the pattern must contain the lagged set's connectivity");
@@ -3006,13 +3060,37 @@ double HipContact::ccdPartial(const double* x_dev, const double* p_dev, double s
     CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
     for (int pass = 0; pass < 2; ++pass)
         hipLaunchKernelGGL(k_ccd_list, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_csPTEE.p, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, slackness, stepSize, pass,
-            o);
+            o, (const unsigned long long*)nullptr);
     unsigned long long h[2];
     HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     double out;
     decodeCcdOut(h, stepSize, &out, pair2);
     return out;
+}
+
+// The step bounds a Newton iteration of a contact scene asks for one after the other (Optimizer.cpp:1884-1953): the inversion filter's root (already on the
+// device, *filterDev, applied by the filter's rule -- Energy.cpp:565-581: only when 0 < root < step), the partial CCD over the candidates bounded by the
+// result, and the largest surface speed for the CFL test -- enqueued together and read back with ONE synchronisation (three before round 6).
+void HipContact::stepBounds(const double* x_dev, const double* p_dev, double slackness, double stepSize, const double* filterDev, double* alphaOut, int* pair2,
+    double* pMaxOut)
+{
+    ccdOut_.alloc(4);
+    readbackInit();
+    hipLaunchKernelGGL(k_step_bounds_init, dim3(1), dim3(1), 0, stream, stepSize, filterDev, ccdOut_.p);
+    const int n = nCand_;
+    CcdOut o{ ccdOut_.p, ccdOut_.p + 1 };
+    for (int pass = 0; pass < 2 && n; ++pass)
+        hipLaunchKernelGGL(k_ccd_list, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_csPTEE.p, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, slackness, stepSize, pass,
+            o, (const unsigned long long*)(ccdOut_.p + 3));
+    if (nSVI) hipLaunchKernelGGL(k_max_speed, dim3(nblk(nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, p_dev, ccdOut_.p + 2);
+    hipLaunchKernelGGL(k_publish_u64x4, dim3(1), dim3(4), 0, stream, (const unsigned long long*)ccdOut_.p, readback_.dev);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const unsigned long long* h = readback_.p;
+    double filtered;
+    std::memcpy(&filtered, &h[3], sizeof(filtered));
+    std::memcpy(pMaxOut, &h[2], sizeof(double));
+    decodeCcdOut(h, filtered, alphaOut, pair2);
 }
 
 double HipContact::ccdFull(const HipMesh& mesh, const double* x_dev, const double* p_dev, const int* dbc_dev, double slackness, double stepSize,
@@ -3190,6 +3268,77 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
 {
     if (!surfaceSet) throw StateError("is_intersected before set_surface");
     const int* pf = pairFlags(mesh.nV, dbc_dev);
+    auto pointsInTets = [&]() {
+        if (codimPoints.empty() || !mesh.nT) return;
+        const dim3 grid(nblk((long long)codimPoints.size() * mesh.nT));
+        if (exactPredicates)
+            hipLaunchKernelGGL(k_points_in_tets<true>, grid, dim3(BLOCK), 0, stream, (int)codimPoints.size(), d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev,
+                counters_.p);
+        else
+            hipLaunchKernelGGL(k_points_in_tets<false>, grid, dim3(BLOCK), 0, stream, (int)codimPoints.size(), d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev,
+                counters_.p);
+    };
+    // Round 6: the check runs once or twice per Newton iteration of a contact scene and used to wait for the host three times (bounding box, number of cell
+    // entries, result).  Like the constraint-set build it now lays its grid over the box the LAST build or check measured (a stale grid is detected on the
+    // device and nothing runs), fills the edge cells into the capacity the last pass needed, and reads flag + stale flag + total + the fresh box back at once.
+    for (int attempt = 0; haveBox_ && attempt < 3; ++attempt) {
+        const int nV = mesh.nV, nb = nblk(nV);
+        bboxPartial_.ensure(6 * (size_t)nb + 6);
+        double* box_dev = bboxPartial_.p + 6 * (size_t)nb;
+        counters_.alloc(16);
+        Grid g;
+        g.h = mesh.avgEdgeLen;
+        long long nCells;
+        for (;;) {
+            nCells = 1;
+            for (int c = 0; c < 3; ++c) {
+                g.lo[c] = box_[c] - 2.0 * g.h;
+                g.dim[c] = std::max(1, (int)std::floor((box_[3 + c] + 2.0 * g.h - g.lo[c]) / g.h) + 1);
+                nCells *= g.dim[c];
+            }
+            if (nCells <= (1LL << 26)) break;
+            g.h *= 1.5;
+        }
+        if (gridCount_.n < (size_t)nCells + 1) { // (cleared once: every pass counts its cells up and back down)
+            gridCount_.ensure((size_t)nCells + 1);
+            gridCount_.zeroN(gridCount_.n, stream);
+        }
+        gridStart_.ensure((size_t)nCells + 1);
+        if (gridItems_.n < (size_t)REC * 8 * (size_t)nSFE) gridItems_.ensure((size_t)REC * 8 * (size_t)nSFE);
+        const int capItems = (int)std::min<size_t>(gridItems_.n / REC, (size_t)INT_MAX);
+        const int* stale = counters_.p + 2;
+        readbackInit();
+        BuildReadback* rb = reinterpret_cast<BuildReadback*>(readback_.p);
+        counters_.zero(stream);
+        hipLaunchKernelGGL(k_bbox_partial, dim3(nb), dim3(BLOCK), 0, stream, nV, x_dev, bboxPartial_.p);
+        hipLaunchKernelGGL(k_bbox_final, dim3(1), dim3(BLOCK), 0, stream, nb, bboxPartial_.p, box_dev, g, 1, counters_.p + 2);
+        // (edges only, in cells [0, nCells): the kernel's offset of the edge cells is its nCells argument)
+        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, 0, (const int*)nullptr, nSFE, d_SFE.p, x_dev, g, 0, 0.0, 0, capItems, stale,
+            gridCount_.p, (const int*)nullptr, (int*)nullptr);
+        size_t tmpBytes = 0;
+        hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, gridCount_.p, gridStart_.p, (int)nCells + 1, stream);
+        if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes + tmpBytes / 4);
+        hipcub::DeviceScan::ExclusiveSum((void*)scanTmp_.p, tmpBytes, gridCount_.p, gridStart_.p, (int)nCells + 1, stream);
+        hipLaunchKernelGGL(k_grid_insert_both, dim3(nblk(nSFE)), dim3(BLOCK), 0, stream, 0, (const int*)nullptr, nSFE, d_SFE.p, x_dev, g, 0, 0.0, 1, capItems, stale,
+            gridCount_.p, gridStart_.p, gridItems_.p);
+        if (exactPredicates)
+            hipLaunchKernelGGL(k_intersect<true>, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, gridStart_.p,
+                gridItems_.p, counters_.p, capItems);
+        else
+            hipLaunchKernelGGL(k_intersect<false>, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, gridStart_.p,
+                gridItems_.p, counters_.p, capItems);
+        pointsInTets();
+        hipLaunchKernelGGL(k_publish_narrow, dim3(1), dim3(1), 0, stream, counters_.p, gridStart_.p + nCells, box_dev, reinterpret_cast<BuildReadback*>(readback_.dev));
+        HIP_CHECK(hipStreamSynchronize(stream));
+        for (int c = 0; c < 6; ++c) box_[c] = rb->box[c];
+        if (rb->cnt[2]) continue; // stale grid: nothing ran, once more over the fresh box
+        if (rb->cnt[3] > capItems) { // truncated cell lists: grow and repeat
+            gridItems_.ensure((size_t)REC * ((size_t)rb->cnt[3] + (size_t)rb->cnt[3] / 4));
+            continue;
+        }
+        return rb->cnt[0] != 0;
+    }
+    // the general path (first call on a surface, or a box that keeps moving): own bounding box, own cell arrays, three synchronisations
     const GridHost gh = makeGrid(mesh, x_dev, nullptr, 0.0, mesh.avgEdgeLen);
     buildCells(gh, nSFE, 2, d_SFE.p, x_dev, nullptr, 0.0, 0.0, cellCountE_, cellStartE_, cellItemsE_);
     Grid g;
@@ -3202,19 +3351,11 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
     counters_.zero(stream);
     if (exactPredicates)
         hipLaunchKernelGGL(k_intersect<true>, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p,
-            cellItemsE_.p, counters_.p);
+            cellItemsE_.p, counters_.p, INT_MAX);
     else
         hipLaunchKernelGGL(k_intersect<false>, dim3(nblk(COOP * (long long)nSF)), dim3(BLOCK), 0, stream, nSF, d_SF.p, d_SFE.p, x_dev, pf, g, cellStartE_.p,
-            cellItemsE_.p, counters_.p);
-    if (!codimPoints.empty() && mesh.nT) {
-        const dim3 grid(nblk((long long)codimPoints.size() * mesh.nT));
-        if (exactPredicates)
-            hipLaunchKernelGGL(k_points_in_tets<true>, grid, dim3(BLOCK), 0, stream, (int)codimPoints.size(), d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev,
-                counters_.p);
-        else
-            hipLaunchKernelGGL(k_points_in_tets<false>, grid, dim3(BLOCK), 0, stream, (int)codimPoints.size(), d_codimPoints.p, mesh.nT, mesh.d_tet.p, x_dev,
-                counters_.p);
-    }
+            cellItemsE_.p, counters_.p, INT_MAX);
+    pointsInTets();
     int f[2];
     counters_.download(f, 2, stream);
     return f[0] != 0;

@@ -293,11 +293,17 @@ double HipOptimizer::computeEnergyVal()
 {
     launch_energy(view(), elasticCoef(), true, rank == 0, d_partial.p, (int)d_partial.n, d_scalar.p, stream);
     reduceSum(d_scalar.p, 1);
-    double E = readScalar(d_scalar.p);
+    // the barrier energy of the self-contact sets is enqueued behind the elastic one and read back with it: one synchronisation instead of two (round 6; the
+    // reduction of the elastic partial sums is on the stream before the contact kernel reuses d_partial)
+    const bool contactQueued = selfCollision && contact->energyEnqueue(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4);
+    launch_publish(d_scalar.p, h_scalar.dev, 10, stream); // d_scalar[0 .. 4]
+    HIP_CHECK(hipStreamSynchronize(stream));
+    double E = h_scalar.p[0];
+    const double Econtact = contactQueued ? h_scalar.p[4] : 0.0;
     if (!nbcGroups.empty()) E += neumannEnergy();
     // barrier terms over the current constraint sets (Optimizer.cpp:3252-3353); replicated on every rank
     for (auto& h : planes) E += h->energy(mesh.d_x.p, dHat, kappa);
-    if (selfCollision) E += contact->energy(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4);
+    if (selfCollision) E += Econtact;
     if (fricDHat > 0.0) { // lagged friction (Optimizer.cpp:3357-3377)
         for (auto& h : planes)
             if (h->friction > 0.0) E += h->frictionEnergy(mesh.d_x.p, d_xPrev.p, fricDHat);
@@ -1541,11 +1547,13 @@ bool HipOptimizer::newtonIter()
     {
         Tic t(timers[13], stream);
         t.nosync = specAsmValid && cachedTrialValid; // nothing is enqueued in here on that path, and the stream carries the assembly enqueued ahead
+        // (one process, self-contact, no half-spaces between the filter and the CCD: the three bounds come back with one synchronisation, HipContact::stepBounds)
+        const bool batchedBounds = !cachedTrialValid && !cachedE0Valid && selfCollision && planes.empty() && worldSize == 1;
         if (cachedTrialValid) alpha = cachedAlpha; // decided on the device by the same rule, the trial step is already taken with it
         else if (cachedE0Valid) { // Optimizer.cpp:1887 with the value the solve's batch brought back
             if (mesh.energyType != 1 && cachedFilter > 0.0 && cachedFilter < alpha) alpha = cachedFilter;
         }
-        else
+        else if (!batchedBounds)
         alpha = filterStepSize(d_searchDir.p, alpha); // Optimizer.cpp:1887
         for (auto& h : planes) // slackness_a = 0.9 (:1886-1890)
             alpha = h->stepBound(contact->nSVI, contact->d_SVI.p, mesh.d_x.p, mesh.d_dbc.p, d_searchDir.p, 0.9, alpha);
@@ -1553,8 +1561,20 @@ bool HipOptimizer::newtonIter()
             // step-size pipeline of Optimizer.cpp:1884-2040: partial CCD over the candidates of the current
             // constraint set, CFL bound, full CCD only when the step leaves the CFL ball
             const double slackness_m = 0.8;
-            alpha = contact->ccdPartial(mesh.d_x.p, d_searchDir.p, slackness_m, alpha, lastCCDPair);
-            const double pMax = contact->maxSurfaceSpeed(d_searchDir.p);
+            double pMax;
+            if (batchedBounds) {
+                // inversion filter, partial CCD and surface speed in one batch: the filter's root stays on the device and bounds the CCD there
+                const bool filter = mesh.energyType != 1; // Energy.cpp:567 needElemInvSafeGuard
+                if (filter) {
+                    launch_fill(d_scalar.p + 2, 1, 1e20, stream);
+                    launch_inversion_step(view(), d_searchDir.p, 0.2, alpha, d_scalar.p + 2, stream);
+                }
+                contact->stepBounds(mesh.d_x.p, d_searchDir.p, slackness_m, alpha, filter ? d_scalar.p + 2 : nullptr, &alpha, lastCCDPair, &pMax);
+            }
+            else {
+                alpha = contact->ccdPartial(mesh.d_x.p, d_searchDir.p, slackness_m, alpha, lastCCDPair);
+                pMax = contact->maxSurfaceSpeed(d_searchDir.p);
+            }
             const double alpha_CFL = std::sqrt(dHat) / (pMax * 2.0);
             if ((!k && alpha > alpha_CFL) || alpha > 2.0 * alpha_CFL) {
                 alpha = fullCcd(slackness_m, alpha);

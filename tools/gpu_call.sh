@@ -17,7 +17,10 @@ prof() { # prof <tag> <cmd...>: kernel table of a command
   rm -rf /tmp/prof_$tag
   ( cd /tmp && timeout ${PROF_TIMEOUT:-600} rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o $tag -- "$@" > $GRAFT_REPO_ROOT/$out/${tag}_under_rocprof.json 2>> $GRAFT_REPO_ROOT/$out/err.log )
   db=$(find /tmp/prof_$tag -name "*.db" | head -1)
-  if [ -n "$db" ]; then python tools/rocprof_summary.py $db $out/${tag}_kernel_stats.md > /dev/null; fi
+  if [ -n "$db" ]; then
+    python tools/rocprof_summary.py $db $out/${tag}_kernel_stats.md > /dev/null
+    case $tag in contact*) python tools/contact_timeline.py $db ${TIMELINE_ITER:-20} > $out/${tag}_timeline.txt 2>&1;; esac
+  fi
 }
 if [ -n "$TESTS" ]; then
   t="$TESTS"; [ "$TESTS" = "all" ] && t="tests"
