@@ -78,8 +78,10 @@ public:
     // useActive / usePara: initKappa leaves the mollified set out (Optimizer.cpp:2262-2270)
     void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev, bool useActive = true,
         bool usePara = true, const unsigned char* need_dev = nullptr);
+    // deferCheck: the "pair outside the pattern" flag is not waited for; the caller calls takeHessianError() behind its next synchronisation of the stream
     void hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
-        double* a_dev, const unsigned char* need_dev = nullptr);
+        double* a_dev, const unsigned char* need_dev = nullptr, bool deferCheck = false);
+    void takeHessianError(); // throws what hessianAdd(..., deferCheck = true) would have thrown
     // the reference's per-constraint interface on host arrays of MMCVID tuples (SelfCollisionHandler.cpp:37-148; ipcgpu_contact_evaluate / _jt_multiply):
     // val[i] = squared distance of tuple i;  out += coef * multiplicity_i * input[i] * grad d_i
     void evaluateTuples(const double* x_dev, int n, const int* tuples4, double* val);
@@ -105,7 +107,10 @@ public:
     int ccdMode = 1; // 1: ccdFullReference in the time stepper; 0: the swept-box sweep of PT / EE pairs (ccdFull)
     bool isIntersected(const HipMesh& mesh, const double* x_dev, const int* dbc_dev);
     void evalStencils(const std::vector<std::array<int, 4>>& ids, const double* x_dev, std::vector<double>& d2);
-    void closeStencils(const double* x_dev, double dTol, std::vector<std::array<int, 4>>& ids, std::vector<double>& d2);
+    // lin != null: *covers = patternCovers(*lin), answered with the same synchronisation
+    void closeStencils(const double* x_dev, double dTol, std::vector<std::array<int, 4>>& ids, std::vector<double>& d2, const HipLinSysSolver* lin = nullptr,
+        int* covers = nullptr);
+    unsigned long long setsVersion = 0; // bumped whenever the sets change (buildConstraintSet, uploadSets): what a cached coverage answer is stamped with
     double maxSurfaceSpeed(const double* p_dev); // max_{v in SVI} |p_v|  (CFL bound, Optimizer.cpp:1947-1953)
     // lagged friction of the self-contact set: MMActiveSet_lastH, MMLambda_lastH, MMDistCoord, MMTanBasis
     std::vector<std::array<int, 4>> fricSet;
@@ -135,7 +140,7 @@ private:
     DevBuf<unsigned long long> ccdOut_, ccdHits_;
     DevBuf<int> d_codimPoints;
     DevBuf<int> cellCountT_, cellCountE_, cellStartT_, cellStartE_, cellItemsT_, cellItemsE_, outPT_, outEE_, counters_;
-    DevBuf<int> d_v2sv, refVbox_, cellCountV_, cellStartV_, cellItemsV_; // reference-mode sweep: node -> surface index, index boxes, vertex cells
+    DevBuf<int> d_v2sv, refVbox_, refCount_, refStart_, refItems_; // reference-mode sweep: node -> surface index, index boxes, the three cell structures in one
     DevBuf<double> bboxPartial_;
     bool haveBox_ = false; // box_: the bounding box the last constraint-set build measured (the next build's grid is laid over it)
     double box_[6] = { 0, 0, 0, 0, 0, 0 };
@@ -148,6 +153,7 @@ private:
     // counting sorts of the record lists (by first primitive) and of the duplicate candidates (by vertex): counters, bucket starts, bucket contents, runs
     DevBuf<int> bucketCount_, bucketStart_, bucketSeg_, dupCount_, dupStart_, runs_, runPos_;
     void readbackInit();
+    bool hessErrPending_ = false, refDirty_ = false;
     bool countersDirty_ = false; // a build was left half-way (exception): the counters are cleared before the next one
     PinnedBuf<unsigned long long> readback_; // BuildReadback: what the host reads between the stages of a build (mapped memory, written by the kernels)
     DevBuf<double> closeVal_;

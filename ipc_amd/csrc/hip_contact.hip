@@ -1631,8 +1631,9 @@ __global__ __launch_bounds__(BLOCK) void k_ref_insert(int nPrim, int nv, const i
         for (int y = b[1] / g.m; y <= b[4] / g.m; ++y)
             for (int xx = b[0] / g.m; xx <= b[3] / g.m; ++xx) {
                 const int cell = xx + g.dim[0] * (y + g.dim[1] * z);
-                const int slot = atomicAdd(&cellCount[cell], 1);
-                if (mode == 1) {
+                if (mode == 0) atomicAdd(&cellCount[cell], 1);
+                else { // the fill takes its slots by counting the cell back down: the counters are zero again afterwards, no clearing between sweeps
+                    const int slot = atomicSub(&cellCount[cell], 1) - 1;
                     int4* r = reinterpret_cast<int4*>(cellItems) + 2 * (size_t)(cellStart[cell] + slot);
                     r[0] = make_int4(i, b[0], b[1], b[2]);
                     r[1] = make_int4(b[3], b[4], b[5], 0);
@@ -2352,6 +2353,7 @@ void HipContact::uploadSets()
     HIP_CHECK(hipStreamSynchronize(stream));
     nActive_ = (int)active.size();
     nPara_ = (int)para.size();
+    ++setsVersion;
     hostStale_ = false; // the host vectors are the source here
 }
 
@@ -2364,6 +2366,7 @@ void HipContact::readbackInit()
 int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat)
 {
     if (!surfaceSet) throw StateError("contact_build before set_surface");
+    ++setsVersion;
     const int nV = mesh.nV;
     const int* pf = pairFlags(nV, dbc_dev);
     const double infl = std::sqrt(dHat);
@@ -2616,7 +2619,7 @@ void HipContact::gradientAdd(const double* x_dev, const int* dbc_dev, int nV, do
 }
 
 void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLinSysSolver& lin, double dHat, double kappa, int projectDBC,
-    double* a_dev, const unsigned char* need_dev)
+    double* a_dev, const unsigned char* need_dev, bool deferCheck)
 {
     const int n = nActive_ + nPara_; // the whole lists; need_dev (or null) says which stencils this rank evaluates: see gradientAdd
     if (!n) return;
@@ -2634,10 +2637,24 @@ void HipContact::hessianAdd(const double* x_dev, const int* dbc_dev, const HipLi
     hipLaunchKernelGGL(k_contact_hessian, dim3(nblk(n, HESS_W) + NBINS), dim3(HESS_W), 0, stream, cv, bins, m, dbc_dev, projectDBC, dHat, kappa,
         BlockSink{ detVals_.p, detKey_.p, detRow_.p, detCount_.p }, counters_.p);
     detReduceBlocks(nSlots, nKeys, lin.d_ia.p, a_dev);
+    if (deferCheck) { // the flag goes to mapped host memory behind the pass; the caller looks at it after its next synchronisation (takeHessianError)
+        readbackInit();
+        hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, stream, (const int*)counters_.p, reinterpret_cast<int*>(readback_.dev + 15));
+        hessErrPending_ = true;
+        return;
+    }
     int err[2];
     counters_.download(err, 2, stream);
     if (std::getenv("IPCGPU_DEBUG")) std::fprintf(stderr, "[ipcgpu] barrier Hessian: %d stencils, %.2f Jacobi sweeps on average\n", n, (double)err[1] / n);
     if (err[0]) throw StateError("barrier Hessian touches a node pair outside the CSR pattern: call set_pattern with the contact connectivity first");
+}
+
+void HipContact::takeHessianError()
+{
+    if (!hessErrPending_) return;
+    hessErrPending_ = false;
+    if (*reinterpret_cast<const volatile int*>(readback_.p + 15))
+        throw StateError("barrier Hessian touches a node pair outside the CSR pattern: call set_pattern with the contact connectivity first");
 }
 
 bool HipContact::patternCovers(const HipLinSysSolver& lin)
@@ -3199,37 +3216,49 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
     }
     refVbox_.ensure(6 * (size_t)nSVI);
     hipLaunchKernelGGL(k_ref_vbox, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, x_dev, p_dev, alpha, g, refVbox_.p);
-    auto build = [&](int nPrim, int nv, const int* prim, DevBuf<int>& cnt, DevBuf<int>& start, DevBuf<int>& items) {
-        cnt.ensure((size_t)nCells + 1);
-        start.ensure((size_t)nCells + 1);
-        cnt.zeroN((size_t)nCells + 1, stream);
-        hipLaunchKernelGGL(k_ref_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv, prim, d_v2sv.p, refVbox_.p, g, 0, cnt.p, (const int*)nullptr,
-            (int*)nullptr);
+    // The three cell structures (vertices, edges, triangles) in ONE counter array of 3 (nCells + 1) entries, one scan, one item list (round 6; three times
+    // clear - count - scan - read back - clear - fill before: the six clears of up to 32 MB each were ~0.3 ms of host time apiece, the whole sweep 3.3 ms of
+    // which the kernels took 0.9): the last entry of each third stays zero, the scan makes the offsets of the later thirds absolute, the fill counts the
+    // counters back down (k_ref_insert), and the host waits once, for the total.
+    const size_t nC1 = (size_t)nCells + 1;
+    if (refCount_.n < 3 * nC1 || refDirty_) { // (dirty: a sweep that was left between its count and its fill)
+        refCount_.ensure(3 * nC1);
+        refCount_.zero(stream);
+    }
+    refDirty_ = true;
+    refStart_.ensure(3 * nC1);
+    const int nPrims[3] = { nSVI, nSFE, nSF }, nvs[3] = { 1, 2, 3 };
+    const int* prims[3] = { d_SVI.p, d_SFE.p, d_SF.p };
+    for (int q = 0; q < 3; ++q)
+        if (nPrims[q])
+            hipLaunchKernelGGL(k_ref_insert, dim3(nblk(nPrims[q])), dim3(BLOCK), 0, stream, nPrims[q], nvs[q], prims[q], d_v2sv.p, refVbox_.p, g, 0,
+                refCount_.p + q * nC1, (const int*)nullptr, (int*)nullptr);
+    {
         size_t tmpBytes = 0;
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream));
-        if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes);
-        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, cnt.p, start.p, (int)nCells + 1, stream));
-        int total = 0;
-        HIP_CHECK(hipMemcpyAsync(&total, start.p + nCells, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_CHECK(hipStreamSynchronize(stream));
-        items.ensure((size_t)REC * std::max(1, total));
-        cnt.zeroN((size_t)nCells + 1, stream);
-        hipLaunchKernelGGL(k_ref_insert, dim3(nblk(nPrim)), dim3(BLOCK), 0, stream, nPrim, nv, prim, d_v2sv.p, refVbox_.p, g, 1, cnt.p, start.p, items.p);
-    };
-    build(nSVI, 1, d_SVI.p, cellCountV_, cellStartV_, cellItemsV_);
-    build(nSFE, 2, d_SFE.p, cellCountE_, cellStartE_, cellItemsE_);
-    build(nSF, 3, d_SF.p, cellCountT_, cellStartT_, cellItemsT_);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(nullptr, tmpBytes, refCount_.p, refStart_.p, (int)(3 * nC1), stream));
+        if (scanTmp_.n < tmpBytes) scanTmp_.alloc(tmpBytes + tmpBytes / 4);
+        HIP_CHECK(hipcub::DeviceScan::ExclusiveSum(scanTmp_.p, tmpBytes, refCount_.p, refStart_.p, (int)(3 * nC1), stream));
+    }
+    readbackInit();
+    hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, stream, (const int*)(refStart_.p + 3 * nC1 - 1), reinterpret_cast<int*>(readback_.dev));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const int totalItems = *reinterpret_cast<const int*>(readback_.p);
+    refItems_.ensure((size_t)REC * std::max(1, totalItems));
+    for (int q = 0; q < 3; ++q)
+        if (nPrims[q])
+            hipLaunchKernelGGL(k_ref_insert, dim3(nblk(nPrims[q])), dim3(BLOCK), 0, stream, nPrims[q], nvs[q], prims[q], d_v2sv.p, refVbox_.p, g, 1,
+                refCount_.p + q * nC1, (const int*)(refStart_.p + q * nC1), refItems_.p);
+    refDirty_ = false;
     ccdOut_.alloc(4);
     counters_.alloc(16);
     // counters_: [0] queried pairs, [1] pairs that returned a time inside the step (the hit list)
     constexpr int HIT_CAP = 1 << 20;
     const bool twoPass = false; // (true: the limiting pair by a second run of the sweep, rounds 1-2; profiles/r03m_contact_bench_lds_jacobi_two_pass_ccd.json)
     if (!twoPass) ccdHits_.ensure(2 * (size_t)HIT_CAP);
-    const unsigned long long init3[3] = { ~0ull, ~0ull, ~0ull };
-    HIP_CHECK(hipMemcpyAsync(ccdOut_.p, init3, sizeof(init3), hipMemcpyHostToDevice, stream));
+    HIP_CHECK(hipMemsetAsync(ccdOut_.p, 0xFF, 3 * sizeof(unsigned long long), stream)); // "no time yet" = all ones
     counters_.zero(stream);
     CcdOut o{ ccdOut_.p, ccdOut_.p + 1, twoPass ? nullptr : ccdHits_.p, counters_.p + 1, twoPass ? 0 : HIT_CAP };
-    const RefLists L{ cellStartV_.p, cellItemsV_.p, cellStartE_.p, cellItemsE_.p, cellStartT_.p, cellItemsT_.p };
+    const RefLists L{ refStart_.p, refItems_.p, refStart_.p + nC1, refItems_.p, refStart_.p + 2 * nC1, refItems_.p };
     auto sweep = [&](int pass) {
         hipLaunchKernelGGL(k_ref_sweep_vertex, dim3(nblk(SWEEP_COOP * (long long)nSVI)), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, d_SF.p, d_SFE.p, x_dev, p_dev, pf,
             d_v2sv.p, refVbox_.p, g, L, alpha, slackness, pass, o, counters_.p);
@@ -3237,15 +3266,20 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
         if (pass == 0) HIP_CHECK(hipMemcpyAsync(ccdOut_.p + 2, ccdOut_.p, sizeof(unsigned long long), hipMemcpyDeviceToDevice, stream));
         if (nSFE)
             hipLaunchKernelGGL(k_ref_sweep_edge, dim3(nblk(SWEEP_COOP * (long long)nSFE)), dim3(BLOCK), 0, stream, nSFE, d_SFE.p, x_dev, p_dev, pf, d_v2sv.p,
-                refVbox_.p, g, cellStartE_.p, cellItemsE_.p, alpha, ccdOut_.p + 2, slackness, pass, o, counters_.p);
+                refVbox_.p, g, L.startE, L.itemsE, alpha, ccdOut_.p + 2, slackness, pass, o, counters_.p);
     };
     sweep(0);
     if (twoPass) sweep(1);
     else hipLaunchKernelGGL(k_ccd_hits_arg, dim3(64), dim3(BLOCK), 0, stream, o);
     unsigned long long h[2];
     int cnt[2];
-    HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
-    counters_.download(cnt, 2, stream);
+    // minimum, pair and the two counters in one read-back through mapped memory
+    hipLaunchKernelGGL(k_publish_u64x4, dim3(1), dim3(2), 0, stream, (const unsigned long long*)ccdOut_.p, readback_.dev);
+    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, stream, reinterpret_cast<const unsigned long long*>(counters_.p), readback_.dev + 2);
+    HIP_CHECK(hipStreamSynchronize(stream));
+    h[0] = readback_.p[0];
+    h[1] = readback_.p[1];
+    std::memcpy(cnt, readback_.p + 2, sizeof(cnt));
     if (!twoPass && cnt[1] > HIT_CAP) { // more hits than the list holds (never seen): the limiting pair by the second run after all
         sweep(1);
         HIP_CHECK(hipMemcpyAsync(h, ccdOut_.p, sizeof(h), hipMemcpyDeviceToHost, stream));
@@ -3363,21 +3397,33 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
 
 // stencils of the current active set closer than dTol, in set order, with their squared distances: evaluated and
 // filtered on the device, only the (few) hits come back
-void HipContact::closeStencils(const double* x_dev, double dTol, std::vector<std::array<int, 4>>& ids, std::vector<double>& d2)
+void HipContact::closeStencils(const double* x_dev, double dTol, std::vector<std::array<int, 4>>& ids, std::vector<double>& d2, const HipLinSysSolver* lin,
+    int* covers)
 {
     ids.clear();
     d2.clear();
+    if (covers) *covers = 1;
     const int n = nActive_;
-    if (!n) return;
+    const int nCheck = lin ? nActive_ + nPara_ : 0; // the coverage test of patternCovers rides along (round 6): same sets, same synchronisation
+    if (!n && !nCheck) return;
     int cap = std::max<int>(1024, (int)closeIdx_.n);
+    readbackInit();
     for (;;) {
         closeIdx_.ensure((size_t)cap);
         closeVal_.ensure((size_t)cap);
         counters_.alloc(16);
         counters_.zero(stream);
-        hipLaunchKernelGGL(k_close_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_active.p, x_dev, dTol, cap, closeIdx_.p, closeVal_.p, counters_.p);
-        int cnt = 0;
-        counters_.download(&cnt, 1, stream);
+        if (n) hipLaunchKernelGGL(k_close_stencils, dim3(nblk(n)), dim3(BLOCK), 0, stream, n, d_active.p, x_dev, dTol, cap, closeIdx_.p, closeVal_.p, counters_.p);
+        if (nCheck) {
+            ContactView cv{ nActive_, nPara_, d_active.p, d_para.p, d_paraEIEJ.p, d_SFE.p, nullptr, d_xRest.p };
+            CsrView m{ lin->d_ia.p, lin->d_ja.p };
+            hipLaunchKernelGGL(k_pattern_check, dim3(nblk(nCheck)), dim3(BLOCK), 0, stream, cv, m, counters_.p + 2);
+        }
+        hipLaunchKernelGGL(k_publish_u64x4, dim3(1), dim3(2), 0, stream, reinterpret_cast<const unsigned long long*>(counters_.p), readback_.dev); // counters 0 .. 3
+        HIP_CHECK(hipStreamSynchronize(stream));
+        const int* h = reinterpret_cast<const int*>(readback_.p);
+        const int cnt = h[0];
+        if (covers) *covers = h[2] ? 0 : 1;
         if (cnt > cap) {
             cap = cnt + cnt / 4;
             continue;
@@ -3391,7 +3437,6 @@ void HipContact::closeStencils(const double* x_dev, double dTol, std::vector<std
         std::vector<int> order(cnt);
         for (int i = 0; i < cnt; ++i) order[i] = i;
         std::sort(order.begin(), order.end(), [&](int a, int b) { return idx[a] < idx[b]; }); // set order (the kernel appends atomically)
-        std::vector<int> tup(4 * (size_t)cnt);
         // the tuples of the hits: gather from the device set
         syncHost();
         for (int k : order) {

@@ -294,6 +294,10 @@ public:
     std::vector<std::array<int, 4>> closeID; // closeMConstraintID / Val (Optimizer.cpp:2396-2440)
     std::vector<double> closeVal;
     int lastCCDPair[2] = { 0, 0 }, nFullCCD = 0, nPatternChanges = 0, dbcIncomplete = 0;
+    // "does the pattern cover the contact sets" as answered at the end of the last iteration, stamped with the versions of sets and pattern it was asked for
+    unsigned long long coverSets = ~0ull;
+    int coverPattern = -1;
+    bool coverAnswer = false;
     // look-ahead of the contact pattern in units of dHat (ipcgpu_opt_set_pattern_lookahead; < 1 = exact pattern).  Negative = by mesh size (lookahead()): what it
     // trades is host-side analyses against fill in the factor, and the two scale differently -- measured (profiles/r06_pattern_lookahead_ab.txt): 40 K nodes, ms per
     // Newton iteration at pad 1 / 2.25 / 4: 22.6 / 11.4 / 9.9 (27 / 7 / 4 analyses of ~14 ms); 375 K nodes: 461 / 258 / 357 (an analysis costs ~130 ms, but the

@@ -716,7 +716,12 @@ void HipOptimizer::postLineSearch()
             }
     }
     if (!selfCollision) return;
-    contact->closeStencils(mesh.d_x.p, dTol, closeID, closeVal);
+    // ... and, in the same batch, whether the pattern holds every block of the sets the next assembly will use (computePrecondMtr asks first thing)
+    int cov = 1;
+    contact->closeStencils(mesh.d_x.p, dTol, closeID, closeVal, &lin, &cov);
+    coverSets = contact->setsVersion;
+    coverPattern = lin.patternVersion;
+    coverAnswer = cov != 0;
 }
 
 void HipOptimizer::ensurePatchPlan()
@@ -894,7 +899,9 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         fprintf(stderr, "pattern change: %-34s %.2f ms\n", what, std::chrono::duration<double, std::milli>(now - tLap).count());
         tLap = now;
     };
-    if (selfCollision && (frictionPairs || !contact->patternCovers(lin))) {
+    // (the coverage answer usually arrived with the close-stencil bookkeeping at the end of the last iteration, postLineSearch: same sets, same pattern)
+    const bool coverCached = selfCollision && coverSets == contact->setsVersion && coverPattern == lin.patternVersion;
+    if (selfCollision && (frictionPairs || !(coverCached ? coverAnswer : contact->patternCovers(lin)))) {
         lap("coverage check");
         // the pattern follows the contact connectivity (augmentConnectivity into vNeighbor_IP, Optimizer.cpp:3560-3612);
         // only pairs that are not mesh edges change it
@@ -998,7 +1005,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         launch_assemble_patches(view(), patch, 0, nOwnerPatches, elasticCoef(), projectDBC, withGradient ? d_gradient.p : nullptr, lin.d_a.p, stream,
             d_ownerPatches.p);
         matrixComplete = false;
-        if (ipOn() && selfCollision) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p, d_need.p);
+        if (ipOn() && selfCollision) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p, d_need.p, /*deferCheck=*/true);
         if (withGradient) {
             if (ipOn()) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p, 1);
             maskAndReduceGradient(d_gradient.p);
@@ -1041,7 +1048,7 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         if (withGradient) barrierGradientAdd(projectDBC, kappa, false, d_gradient.p);
         for (auto& h : planes)
             h->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin.d_rowBase.p, lin.d_rowLen.p, dHat, kappa, projectDBC, lin.d_a.p);
-        if (selfCollision && !contactSharded) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p);
+        if (selfCollision && !contactSharded) contact->hessianAdd(mesh.d_x.p, mesh.d_dbc.p, lin, dHat, kappa, projectDBC, lin.d_a.p, nullptr, /*deferCheck=*/true);
         if (fricDHat > 0.0) { // Optimizer.cpp:3677-3702
             for (auto& h : planes)
                 if (h->friction > 0.0)
@@ -1194,6 +1201,17 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
         cachedFilter = h_scalar.p[2];
         cachedDist = h_scalar.p[3];
         cachedDistValid = cachedE0Valid = true;
+    }
+    else {
+        // |p|_inf for the convergence test of the next pass (Optimizer.cpp:1869-1879) comes back behind the solve (round 6: newtonIter used to enqueue it and
+        // wait for it on its own), and with the same synchronisation the barrier Hessian's deferred "pair outside the pattern" flag
+        launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+        launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+        launch_publish(d_scalar.p + 3, h_scalar.dev + 3, 2, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        cachedDist = h_scalar.p[3];
+        cachedDistValid = true;
+        if (selfCollision) contact->takeHessianError();
     }
 }
 
@@ -1500,7 +1518,7 @@ bool HipOptimizer::newtonIter()
 {
     // convergence test (Optimizer.cpp:1869-1879) looks at the search direction of the previous pass
     double distToOpt_PN;
-    if (k && cachedDistValid && fastPath()) distToOpt_PN = cachedDist; // read back with the last solve
+    if (k && cachedDistValid) distToOpt_PN = cachedDist; // read back with the last solve
     else {
         launch_fill(d_scalar.p + 3, 1, 0.0, stream);
         launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
