@@ -1153,7 +1153,8 @@ __device__ __forceinline__ void narrow_ee_queued(int eI, int eJ, const int* __re
 }
 struct EeTileRec { // one edge of a cell's list as the pair loop reads it from LDS: everything the box tests need, fetched ONCE per cell by the lane that owns the record
     double lo[3], hi[3]; // the inflated box of the edge, exactly as the per-edge walk forms it
-    int id, n0, n1, pad;
+    int id, n0, n1;
+    int c[3]; // cell of the box's low corner: cell_of is monotone, so the cell of the low corner of an overlap is the larger of the two (no division per pair)
 };
 __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
     const int* __restrict__ dbc, Grid g, int nCells, const int* __restrict__ cellStart, const int* __restrict__ cellItems, double dHat, double infl, int cap,
@@ -1189,6 +1190,7 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __
                     const double p0 = x[3 * (size_t)rb.n0 + c], p1 = x[3 * (size_t)rb.n1 + c];
                     rb.lo[c] = fmin(p0, p1) - infl;
                     rb.hi[c] = fmax(p0, p1) + infl;
+                    rb.c[c] = cell_of(g, rb.lo[c], c);
                 }
             }
             for (int ka0 = kBeg; ka0 <= kb0; ka0 += 64) { // tiles of the cell's list in LDS; a pair (a, b) with id_a < id_b is met once: a's tile <= b's chunk or the reverse
@@ -1205,6 +1207,7 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __
                         const double p0 = x[3 * (size_t)ra.n0 + c], p1 = x[3 * (size_t)ra.n1 + c];
                         ra.lo[c] = fmin(p0, p1) - infl;
                         ra.hi[c] = fmax(p0, p1) + infl;
+                        ra.c[c] = cell_of(g, ra.lo[c], c);
                     }
                     tile[lane] = ra;
                 }
@@ -1218,12 +1221,9 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __
                     // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap -- in either order of the two
                     // (different tiles meet once, with a's tile first; inside one tile both orders of (ka, lane) come by and the smaller edge index decides)
                     bool ok = vb && (ka0 == kb0 ? ra.id < rb.id : ra.id != rb.id);
-                    int canon[3];
-                    for (int c = 0; c < 3; ++c) {
+                    for (int c = 0; c < 3; ++c)
                         if (ra.lo[c] > rb.hi[c] || rb.lo[c] > ra.hi[c]) ok = false;
-                        canon[c] = cell_of(g, fmax(ra.lo[c], rb.lo[c]), c);
-                    }
-                    ok = ok && canon[0] == cx && canon[1] == cy && canon[2] == cz
+                    ok = ok && max(ra.c[0], rb.c[0]) == cx && max(ra.c[1], rb.c[1]) == cy && max(ra.c[2], rb.c[2]) == cz
                         && !(ra.n0 == rb.n0 || ra.n0 == rb.n1 || ra.n1 == rb.n0 || ra.n1 == rb.n1);
                     const unsigned long long m = __ballot(ok);
                     if (!m) continue;

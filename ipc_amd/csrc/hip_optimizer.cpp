@@ -1134,6 +1134,7 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
     launch_negate(3 * mesh.nV, d_gradient.p, d_minusG.p, stream);
     const bool noSpec = false; // (synchronise after the solve, again after the trial step: profiles/r03t_trial_ahead_ab.txt)
     cachedTrialValid = false;
+    cachedDistValid = false; // (|p|_inf of the direction this call replaces)
     if (fastPath() && !twoCalls && !noSpec) {
         // ONE synchronisation per Newton iteration.  Behind factorisation + sweeps, on the same stream and without the host in between: |p|_inf
         // (convergence test of the next pass, Optimizer.cpp:1869-1879), the inversion step filter (:1887), E at the iterate (:2681), then the
@@ -1178,7 +1179,24 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
         // the right-hand side is known before the factorisation starts: the forward sweep of each level runs beside the pivot chain of
         // the levels above (MfNumeric::factorizeSolve); this bucket then holds factorisation + both sweeps
         Tic t(timers[3], stream);
-        ok = twoCalls ? lin.factorize() : lin.factorizeSolve(d_minusG.p, d_searchDir.p);
+        if (twoCalls) ok = lin.factorize();
+        else if (worldSize == 1) {
+            // one process: nothing waits inside the solver; |p|_inf for the convergence test of the next pass (Optimizer.cpp:1869-1879) is enqueued behind
+            // the sweeps and the pivot flag comes back with it -- one synchronisation (round 6; two before, and a third at the head of the next pass)
+            ok = lin.factorizeSolve(d_minusG.p, d_searchDir.p, /*wait=*/false);
+            if (ok) {
+                launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+                launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+                launch_publish(d_scalar.p + 3, h_scalar.dev + 3, 2, stream);
+                HIP_CHECK(hipStreamSynchronize(stream));
+                ok = lin.lastPivotsOk();
+                if (ok) {
+                    cachedDist = h_scalar.p[3];
+                    cachedDistValid = true;
+                }
+            }
+        }
+        else ok = lin.factorizeSolve(d_minusG.p, d_searchDir.p);
     }
     Tic t(timers[4], stream);
     if (!ok) {
@@ -1203,14 +1221,16 @@ void HipOptimizer::computeSearchDir(bool projectDBC)
         cachedDistValid = cachedE0Valid = true;
     }
     else {
-        // |p|_inf for the convergence test of the next pass (Optimizer.cpp:1869-1879) comes back behind the solve (round 6: newtonIter used to enqueue it and
-        // wait for it on its own), and with the same synchronisation the barrier Hessian's deferred "pair outside the pattern" flag
-        launch_fill(d_scalar.p + 3, 1, 0.0, stream);
-        launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
-        launch_publish(d_scalar.p + 3, h_scalar.dev + 3, 2, stream);
-        HIP_CHECK(hipStreamSynchronize(stream));
-        cachedDist = h_scalar.p[3];
-        cachedDistValid = true;
+        // the barrier Hessian's deferred "pair outside the pattern" flag has arrived with the solve's synchronisation; |p|_inf as above where it has not
+        // come back yet (several processes, or the diagonal fallback just replaced the direction)
+        if (!cachedDistValid) {
+            launch_fill(d_scalar.p + 3, 1, 0.0, stream);
+            launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
+            launch_publish(d_scalar.p + 3, h_scalar.dev + 3, 2, stream);
+            HIP_CHECK(hipStreamSynchronize(stream));
+            cachedDist = h_scalar.p[3];
+            cachedDistValid = true;
+        }
         if (selfCollision) contact->takeHessianError();
     }
 }

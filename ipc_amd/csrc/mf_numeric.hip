@@ -1636,7 +1636,10 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
     // explicit triangle inverses (see k_xinv_*): fronts of the multi-workgroup path with nc >= xinvMin
     const int xinvMin = 192;
     xinvBorder_ = true; // the inverse grows by bordering inside the step launches (step_border); false = recursive doubling on the side stream, as before round 4 (profiles/r05_permlane_and_border_ab.txt)
-    const int borderMaxNc = 1024; // wider separators (a root of 2 600 columns at 1.12 M tets) keep the recursive doubling: a bordering workgroup is as long as the
+#ifndef MF_BORDER_MAX_NC
+#define MF_BORDER_MAX_NC 1024
+#endif
+    const int borderMaxNc = MF_BORDER_MAX_NC; // wider separators (a root of 2 600 columns at 1.12 M tets) keep the recursive doubling: a bordering workgroup is as long as the
                             // front is wide, and at that width it stretches every step launch (measured at mat433: factorisation 20.0 -> 20.8 ms)
     auto hasXinv = [&](int s) { return !isFused(s) && sym.nc(s) >= xinvMin; };
     auto hasBorder = [&](int s) { return xinvBorder_ && hasXinv(s) && sym.nc(s) <= borderMaxNc; };
