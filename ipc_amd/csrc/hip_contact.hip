@@ -1068,7 +1068,8 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __rest
     const int vI = SVI[i];
     const double p[3] = { x[3 * (size_t)vI], x[3 * (size_t)vI + 1], x[3 * (size_t)vI + 2] };
     const int cell = cell_of(g, p[0], 0) + g.dim[0] * (cell_of(g, p[1], 1) + g.dim[1] * cell_of(g, p[2], 2));
-    const bool vDbc = (dbc[vI] & 1) != 0; // dbc: pair flags (bit 0 Dirichlet, bit 1 obstacle node, bit 2 obstacle-only filter on)
+    const int fI = dbc[vI]; // dbc: pair flags (bit 0 Dirichlet, bit 1 obstacle node, bit 2 obstacle-only filter on)
+    const bool vDbc = (fI & 1) != 0;
     const int kEnd = valid ? min(cellStart[cell + 1], capItems) : 0; // (capItems: a list the fill pass had to truncate -- the host repeats the build)
     for (int k = cellStart[cell] + sub; k < kEnd; k += COOP) {
         const BoxRec rec = load_box_rec(cellItems, k);
@@ -1076,12 +1077,13 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_pt(int nSVI, const int* __rest
         if (p[0] < rec.lo[0] || p[0] > rec.hi[0] || p[1] < rec.lo[1] || p[1] > rec.hi[1] || p[2] < rec.lo[2] || p[2] > rec.hi[2]) continue;
         const int f = rec.id;
         const int t0 = SF[3 * (size_t)f], t1 = SF[3 * (size_t)f + 1], t2 = SF[3 * (size_t)f + 2];
-        if (vI == t0 || vI == t1 || vI == t2) continue;
-        if (vDbc && (dbc[t0] & 1) && (dbc[t1] & 1) && (dbc[t2] & 1)) continue; // SelfCollisionHandler.cpp:2184-2187
-        if (pair_filtered(dbc[vI], dbc[t0])) continue;
+        // flags and positions requested together, filters without short-circuits (see narrow_ee_queued)
+        const int f0 = dbc[t0], f1 = dbc[t1], f2 = dbc[t2];
         const double a[3] = { x[3 * (size_t)t0], x[3 * (size_t)t0 + 1], x[3 * (size_t)t0 + 2] };
         const double b[3] = { x[3 * (size_t)t1], x[3 * (size_t)t1 + 1], x[3 * (size_t)t1 + 2] };
         const double c[3] = { x[3 * (size_t)t2], x[3 * (size_t)t2 + 1], x[3 * (size_t)t2 + 2] };
+        if ((vI == t0) | (vI == t1) | (vI == t2)) continue;
+        if ((vDbc & ((f0 & f1 & f2 & 1) != 0)) | pair_filtered(fI, f0)) continue; // SelfCollisionHandler.cpp:2184-2187; the obstacle-only filter
         double d;
         int id[4] = { -vI - 1, -1, -1, -1 };
         switch (dType_PT(p, a, b, c)) {
@@ -1143,12 +1145,14 @@ __device__ __forceinline__ void narrow_ee_queued(int eI, int eJ, const int* __re
     return;
 #endif
     const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1], b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
-    if ((dbc[a0] & 1) && (dbc[a1] & 1) && (dbc[b0] & 1) && (dbc[b1] & 1)) return; // SelfCollisionHandler.cpp:2294-2297
-    if (pair_filtered(dbc[a0], dbc[b0])) return;
+    // flags and positions of the four nodes are requested together and the filters evaluated without short-circuits: as `dbc[a0] && dbc[a1] && ...` each
+    // flag was a memory round trip of its own, in series, in front of the positions
+    const int fa0 = dbc[a0], fa1 = dbc[a1], fb0 = dbc[b0], fb1 = dbc[b1];
     const double pa0[3] = { x[3 * (size_t)a0], x[3 * (size_t)a0 + 1], x[3 * (size_t)a0 + 2] };
     const double pa1[3] = { x[3 * (size_t)a1], x[3 * (size_t)a1 + 1], x[3 * (size_t)a1 + 2] };
     const double pb0[3] = { x[3 * (size_t)b0], x[3 * (size_t)b0 + 1], x[3 * (size_t)b0 + 2] };
     const double pb1[3] = { x[3 * (size_t)b1], x[3 * (size_t)b1 + 1], x[3 * (size_t)b1 + 2] };
+    if (((fa0 & fa1 & fb0 & fb1 & 1) != 0) | pair_filtered(fa0, fb0)) return; // SelfCollisionHandler.cpp:2294-2297; the obstacle-only filter
     narrow_ee_pair(eI, eJ, a0, a1, b0, b1, pa0, pa1, pb0, pb1, xRest, nE, dHat, wl, cap, out, counter);
 }
 struct EeTileRec { // one edge of a cell's list as the pair loop reads it from LDS: everything the box tests need, fetched ONCE per cell by the lane that owns the record
@@ -1217,14 +1221,15 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __
                 continue;
 #endif
                 for (int ka = 0; ka < nA; ++ka) {
-                    const EeTileRec& ra = tile[ka]; // uniform address: a broadcast read
+                    const EeTileRec ra = tile[ka]; // uniform address: a broadcast read; by VALUE and tested without short-circuits below -- as a reference behind
+                                                   // && chains every field was its own LDS round trip (fourteen in a row per pair, ~1.5 k cycles: 0.16 ms of the kernel)
                     // inflated boxes must overlap, and the pair is handled only in the cell holding the low corner of the overlap -- in either order of the two
                     // (different tiles meet once, with a's tile first; inside one tile both orders of (ka, lane) come by and the smaller edge index decides)
-                    bool ok = vb && (ka0 == kb0 ? ra.id < rb.id : ra.id != rb.id);
-                    for (int c = 0; c < 3; ++c)
-                        if (ra.lo[c] > rb.hi[c] || rb.lo[c] > ra.hi[c]) ok = false;
-                    ok = ok && max(ra.c[0], rb.c[0]) == cx && max(ra.c[1], rb.c[1]) == cy && max(ra.c[2], rb.c[2]) == cz
-                        && !(ra.n0 == rb.n0 || ra.n0 == rb.n1 || ra.n1 == rb.n0 || ra.n1 == rb.n1);
+                    bool ok = vb & (ka0 == kb0 ? ra.id < rb.id : ra.id != rb.id);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) ok &= !(ra.lo[c] > rb.hi[c]) & !(rb.lo[c] > ra.hi[c]);
+                    ok &= (max(ra.c[0], rb.c[0]) == cx) & (max(ra.c[1], rb.c[1]) == cy) & (max(ra.c[2], rb.c[2]) == cz);
+                    ok &= (ra.n0 != rb.n0) & (ra.n0 != rb.n1) & (ra.n1 != rb.n0) & (ra.n1 != rb.n1);
                     const unsigned long long m = __ballot(ok);
                     if (!m) continue;
                     if (ok) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = make_int2(min(ra.id, rb.id), max(ra.id, rb.id));
@@ -1811,7 +1816,8 @@ __global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __r
         lo[c] = fmin(fmin(a0, b0), fmin(a1, b1));
         hi[c] = fmax(fmax(a0, b0), fmax(a1, b1));
     }
-    const bool aDbc = (pf[node[0]] & 1) && (pf[node[1]] & 1);
+    const int f0 = pf[node[0]];
+    const bool aDbc = (f0 & pf[node[1]] & 1) != 0;
     for (int z = bi[2] / g.m, zEnd = valid ? bi[5] / g.m : -1; z <= zEnd; ++z)
         for (int y = bi[1] / g.m; y <= bi[4] / g.m; ++y)
             for (int xx = bi[0] / g.m; xx <= bi[3] / g.m; ++xx) {
@@ -1824,17 +1830,17 @@ __global__ __launch_bounds__(BLOCK) void k_ref_sweep_edge(int nE, const int* __r
                     if (!ref_share(bi, bj) || !ref_canon(g, bi, bj, xx, y, z)) continue;
                     node[2] = SFE[2 * (size_t)eJ];
                     node[3] = SFE[2 * (size_t)eJ + 1];
-                    bool apart = false;
+                    // flags, positions and directions requested together, filters without short-circuits (see narrow_ee_queued)
+                    const int f2 = pf[node[2]], f3 = pf[node[3]];
+                    bool skip = (node[0] == node[2]) | (node[0] == node[3]) | (node[1] == node[2]) | (node[1] == node[3]);
                     for (int c = 0; c < 3; ++c) {
                         const double a0 = x[3 * (size_t)node[2] + c], a1 = x[3 * (size_t)node[3] + c];
                         const double b0 = swept_pos(a0, alphaEE, p[3 * (size_t)node[2] + c]), b1 = swept_pos(a1, alphaEE, p[3 * (size_t)node[3] + c]);
                         const double jl = fmin(fmin(a0, b0), fmin(a1, b1)), jh = fmax(fmax(a0, b0), fmax(a1, b1));
-                        if (jl - hi[c] > 0.0 || lo[c] - jh > 0.0) apart = true;
+                        skip |= (jl - hi[c] > 0.0) | (lo[c] - jh > 0.0);
                     }
-                    if (apart) continue;
-                    if (node[0] == node[2] || node[0] == node[3] || node[1] == node[2] || node[1] == node[3]) continue;
-                    if (aDbc && (pf[node[2]] & 1) && (pf[node[3]] & 1)) continue;
-                    if (pair_filtered(pf[node[0]], pf[node[2]])) continue;
+                    skip |= (aDbc & ((f2 & f3 & 1) != 0)) | pair_filtered(f0, f2);
+                    if (skip) continue;
                     ref_pair(K_EE, node, ref_key(1, eI, 0, eJ), x, p, slackness, alpha, pass, o, nQueried);
                 }
             }
@@ -1970,7 +1976,8 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
         ca[k] = cell_of(g, lo[k], k);
         cb[k] = cell_of(g, hi[k], k);
     }
-    const bool tDbc = (dbc[t0] & 1) && (dbc[t1] & 1) && (dbc[t2] & 1);
+    const int ft0 = dbc[t0];
+    const bool tDbc = (ft0 & dbc[t1] & dbc[t2] & 1) != 0;
     const float loF[3] = { f_down(lo[0]), f_down(lo[1]), f_down(lo[2]) }, hiF[3] = { f_up(hi[0]), f_up(hi[1]), f_up(hi[2]) };
     for (int z = ca[2]; z <= cb[2]; ++z)
         for (int y = ca[1]; y <= cb[1]; ++y)
@@ -1982,17 +1989,17 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
                         continue; // outward-rounded boxes apart: the exact test below would say the same
                     const int e = rec.id;
                     const int e0 = SFE[2 * (size_t)e], e1 = SFE[2 * (size_t)e + 1];
-                    if (e0 == t0 || e0 == t1 || e0 == t2 || e1 == t0 || e1 == t1 || e1 == t2) continue;
-                    if (tDbc && (dbc[e0] & 1) && (dbc[e1] & 1)) continue;
-                    if (pair_filtered(dbc[e0], dbc[t0])) continue;
+                    // flags and positions requested together, filters without short-circuits (see narrow_ee_queued)
+                    const int fe0 = dbc[e0], fe1 = dbc[e1];
                     double p0[3], p1[3];
-                    bool sep = false;
+                    bool skip = (e0 == t0) | (e0 == t1) | (e0 == t2) | (e1 == t0) | (e1 == t1) | (e1 == t2);
                     for (int q = 0; q < 3; ++q) {
                         p0[q] = x[3 * (size_t)e0 + q];
                         p1[q] = x[3 * (size_t)e1 + q];
-                        if (fmin(p0[q], p1[q]) > hi[q] || fmax(p0[q], p1[q]) < lo[q]) sep = true;
+                        skip |= (fmin(p0[q], p1[q]) > hi[q]) | (fmax(p0[q], p1[q]) < lo[q]);
                     }
-                    if (sep) continue;
+                    skip |= (tDbc & ((fe0 & fe1 & 1) != 0)) | pair_filtered(fe0, ft0);
+                    if (skip) continue;
                     if (seg_tri_intersect<exact>(p0, p1, a, b, c)) {
                         atomicOr(flag, 1);
                         return;
