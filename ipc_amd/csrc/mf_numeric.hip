@@ -1637,7 +1637,7 @@ void MfNumeric::setup(const MfSymbolic& sym, hipStream_t stream, const int* ia_d
     const int xinvMin = 192;
     xinvBorder_ = true; // the inverse grows by bordering inside the step launches (step_border); false = recursive doubling on the side stream, as before round 4 (profiles/r05_permlane_and_border_ab.txt)
 #ifndef MF_BORDER_MAX_NC
-#define MF_BORDER_MAX_NC 1024
+#define MF_BORDER_MAX_NC 1536 // (1024 until round 6: the 1 440-column root of the two-sheet contact stack keeps 0.17 ms of doubling rounds behind its factorisation, profiles/r06_border_max_nc_ab.txt)
 #endif
     const int borderMaxNc = MF_BORDER_MAX_NC; // wider separators (a root of 2 600 columns at 1.12 M tets) keep the recursive doubling: a bordering workgroup is as long as the
                             // front is wide, and at that width it stretches every step launch (measured at mat433: factorisation 20.0 -> 20.8 ms)
