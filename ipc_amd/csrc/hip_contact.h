@@ -74,7 +74,11 @@ public:
     double energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
     // the same without the read-back: the value is left in *scalar_dev on the stream (false: empty sets, nothing enqueued, the value is 0) -- the time stepper
     // reads it together with the elastic energy, one synchronisation for both
-    bool energyEnqueue(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev);
+    // pubWords > 0: the reduction's own launch also copies pubWords 32-bit words pubSrc -> pubDst (mapped host memory); publishedByEnergy() says whether it did
+    bool energyEnqueue(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev, const void* pubSrc = nullptr,
+        void* pubDst = nullptr, int pubWords = 0);
+    bool publishedByEnergy() const { return publishedByEnergy_; }
+    bool publishedByEnergy_ = false;
     // useActive / usePara: initKappa leaves the mollified set out (Optimizer.cpp:2262-2270)
     void gradientAdd(const double* x_dev, const int* dbc_dev, int nV, double dHat, double kappa, int projectDBC, double* grad_dev, bool useActive = true,
         bool usePara = true, const unsigned char* need_dev = nullptr);

@@ -150,13 +150,22 @@ __global__ __launch_bounds__(BLOCK) void k_contact_energy(ContactView cv, double
     const double r = block_sum(val, sm);
     if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
-__global__ __launch_bounds__(BLOCK) void k_reduce_scaled(const double* __restrict__ partial, int n, double scale, double* __restrict__ out)
+// pubWords > 0: the block also copies pubWords 32-bit words pubSrc -> pubDst (mapped host memory) once its own result is written -- the read-back of a batch
+// of scalars that ends with this reduction needs no launch of its own
+__global__ __launch_bounds__(BLOCK) void k_reduce_scaled(const double* __restrict__ partial, int n, double scale, double* __restrict__ out,
+    const unsigned* pubSrc, unsigned* pubDst, int pubWords)
 {
     __shared__ double sm[BLOCK / 64];
     double x = 0.0;
     for (int i = threadIdx.x; i < n; i += BLOCK) x += partial[i];
     const double r = block_sum(x, sm);
     if (threadIdx.x == 0) out[0] = scale * r;
+    if (pubWords > 0) {
+        __threadfence();
+        __syncthreads();
+        // (agent-scope loads: out[0] was written by this block a moment ago and must not come from a stale line of the vector cache)
+        if ((int)threadIdx.x < pubWords) pubDst[threadIdx.x] = __hip_atomic_load(pubSrc + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // ---- deterministic scatter ------------------------------------------------------------------------------------------------------------
@@ -2086,6 +2095,13 @@ __device__ __forceinline__ int rec_category(const int* r, bool isEE)
     if (!isEE) return r[3] < 0 ? 1 : 0;
     return r[3] >= 0 ? 0 : (r[3] == -1 ? 1 : 2);
 }
+// what the host needs between the stages of a build, written to mapped host memory by one thread (three blits of 12, 4 and 48 bytes before)
+struct BuildReadback {
+    int cnt[4]; // point-triangle records, edge-edge records, stale-grid flag, total number of cell entries
+    double box[6];
+    unsigned long long totals; // category totals of the candidate list (k_bucket_rank_classify's flags, scanned)
+    int nUnique, pad;
+};
 // one thread per bucket ENTRY: the rank of its second primitive inside the bucket (the pair is unique, the bucket a handful of entries) gives the record's
 // place in the serial enumeration -- the bucket's range of the list IS its range there --, and the thread writes what belongs to that place: the permutation
 // (point-triangle records first, then the edge-edge ones, each as an index into its own list), the candidate list, the category flag for the prefix sum; it
@@ -2149,10 +2165,11 @@ __global__ void k_scatter_sets(int nPT, int nEE, int nSFE, const int* __restrict
 }
 // one thread per duplicate candidate: its rank inside its vertex's bucket by (id1, id2) (id2 = -1 of a point-point tuple sorts first, as in the map's signed
 // order; id3 = -1 for all of them; equal tuples in the order they happen to lie in -- they are merged anyway)
-__global__ void k_dup_rank(int n, int nV, const int* __restrict__ start, const int4* __restrict__ tuple, int4* __restrict__ sorted)
+__global__ void k_dup_rank(const unsigned long long* __restrict__ totals, int nV, const int* __restrict__ start, const int4* __restrict__ tuple,
+    int4* __restrict__ sorted)
 {
     const int u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= n) return;
+    if (u >= (int)(totals[0] >> 32)) return; // the number of duplicate candidates never leaves the device before the build is complete
     const int4 t = tuple[u];
     const int v = t.x + nV;
     const int s0 = start[v], s1 = start[v + 1];
@@ -2175,11 +2192,16 @@ __global__ void k_dup_runs(int nV, const int* __restrict__ start, const int4* __
     runs[v] = nr;
 }
 // one thread per vertex: (tuple, -multiplicity) of each of its runs behind the direct entries
-__global__ void k_dup_emit(int nV, int nDirect, const int* __restrict__ start, const int4* __restrict__ tuple, const int* __restrict__ runPos,
-    int4* __restrict__ active)
+__global__ void k_dup_emit(int nV, const unsigned long long* __restrict__ totals, const int* __restrict__ start, const int4* __restrict__ tuple,
+    const int* __restrict__ runPos, int4* __restrict__ active, BuildReadback* __restrict__ out)
 {
     const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v == 0) { // what the host sizes the sets with (mapped memory): category totals and the number of merged tuples
+        out->totals = totals[0];
+        out->nUnique = runPos[nV];
+    }
     if (v >= nV) return;
+    const int nDirect = (int)(totals[0] & 0xffffffffull);
     const int s0 = start[v], s1 = start[v + 1];
     if (s0 == s1) return;
     int4* o = active + nDirect + runPos[v];
@@ -2191,13 +2213,6 @@ __global__ void k_dup_emit(int nV, int nDirect, const int* __restrict__ start, c
         a += len;
     }
 }
-// what the host needs between the stages of a build, written to mapped host memory by one thread (three blits of 12, 4 and 48 bytes before)
-struct BuildReadback {
-    int cnt[4]; // point-triangle records, edge-edge records, stale-grid flag, total number of cell entries
-    double box[6];
-    unsigned long long totals; // category totals of the candidate list (k_bucket_rank_classify's flags, scanned)
-    int nUnique, pad;
-};
 __global__ void k_publish_narrow(const int* __restrict__ counters, const int* __restrict__ gridTotal, const double* __restrict__ box, BuildReadback* __restrict__ out)
 {
     out->cnt[0] = counters[0];
@@ -2485,7 +2500,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
         nEE = rb->cnt[1];
         break;
     }
-    // ---- sets assembled on the device (kernels above); two more scalar read-backs: the category totals, the number of merged tuples
+    // ---- sets assembled on the device (kernels above); one more read-back: the category totals and the number of merged tuples
     const int n = nPT + nEE;
     nCand_ = n;
     hostStale_ = true;
@@ -2508,30 +2523,28 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     const int* permEE = permPT_.p + nPT;
     scan(flags_.p, flagPos_.p, n + 1);
     scan(dupCount_.p, dupStart_.p, nV + 1);
-    hipLaunchKernelGGL(k_publish_u64, dim3(1), dim3(1), 0, stream, flagPos_.p + n, &rbDev->totals);
+    // Everything below runs without the host knowing the category totals (round 6: two synchronisations per build less): the sets are sized for the
+    // worst case -- every candidate in one category --, the kernels read the totals where they need them (flagPos_[n]), and the counts come back at the end.
+    const unsigned long long* totalsDev = flagPos_.p + n;
+    d_active.ensure(4 * (size_t)n);
+    d_para.ensure(4 * (size_t)n);
+    d_paraEIEJ.ensure(2 * (size_t)n);
+    dupTuple_.ensure(4 * (size_t)n);
+    dupSorted_.ensure(4 * (size_t)n);
+    hipLaunchKernelGGL(k_scatter_sets, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSFE, outPT_.p, permPT, outEE_.p, permEE, flagPos_.p,
+        d_active.p, dupTuple_.p, dupStart_.p, dupCount_.p, d_para.p, d_paraEIEJ.p, nV);
+    // lexicographic order of (id0, id1, id2) = the map's: buckets by id0, each ordered by (id1, id2); one tuple per run, its multiplicity in the last slot
+    hipLaunchKernelGGL(k_dup_rank, dim3(nblk(n)), dim3(BLOCK), 0, stream, totalsDev, nV, dupStart_.p, reinterpret_cast<const int4*>(dupTuple_.p),
+        reinterpret_cast<int4*>(dupSorted_.p));
+    hipLaunchKernelGGL(k_dup_runs, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dupStart_.p, reinterpret_cast<const int4*>(dupSorted_.p), runs_.p);
+    scan(runs_.p, runPos_.p, nV + 1);
+    hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, totalsDev, dupStart_.p, reinterpret_cast<const int4*>(dupSorted_.p), runPos_.p,
+        reinterpret_cast<int4*>(d_active.p), rbDev);
     HIP_CHECK(hipStreamSynchronize(stream));
     const unsigned long long totals = rb->totals;
     const int nDirect = (int)(totals & 0xffffffffull), nDup = (int)(totals >> 32), nPar = n - nDirect - nDup;
-    d_active.ensure(4 * (size_t)std::max(nDirect + nDup, 1));
-    d_para.ensure(4 * (size_t)std::max(nPar, 1));
-    d_paraEIEJ.ensure(2 * (size_t)std::max(nPar, 1));
-    dupTuple_.ensure(4 * (size_t)std::max(nDup, 1));
-    dupSorted_.ensure(4 * (size_t)std::max(nDup, 1));
-    hipLaunchKernelGGL(k_scatter_sets, dim3(nblk(n)), dim3(BLOCK), 0, stream, nPT, nEE, nSFE, outPT_.p, permPT, outEE_.p, permEE, flagPos_.p,
-        d_active.p, dupTuple_.p, dupStart_.p, dupCount_.p, d_para.p, d_paraEIEJ.p, nV);
-    int nUnique = 0;
-    if (nDup) {
-        // lexicographic order of (id0, id1, id2) = the map's: buckets by id0, each ordered by (id1, id2); one tuple per run, its multiplicity in the last slot
-        hipLaunchKernelGGL(k_dup_rank, dim3(nblk(nDup)), dim3(BLOCK), 0, stream, nDup, nV, dupStart_.p, reinterpret_cast<const int4*>(dupTuple_.p),
-            reinterpret_cast<int4*>(dupSorted_.p));
-        hipLaunchKernelGGL(k_dup_runs, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, dupStart_.p, reinterpret_cast<const int4*>(dupSorted_.p), runs_.p);
-        scan(runs_.p, runPos_.p, nV + 1);
-        hipLaunchKernelGGL(k_dup_emit, dim3(nblk(nV)), dim3(BLOCK), 0, stream, nV, nDirect, dupStart_.p, reinterpret_cast<const int4*>(dupSorted_.p), runPos_.p,
-            reinterpret_cast<int4*>(d_active.p));
-        hipLaunchKernelGGL(k_publish_int, dim3(1), dim3(1), 0, stream, runPos_.p + nV, &rbDev->nUnique);
-        HIP_CHECK(hipStreamSynchronize(stream));
-        nUnique = rb->nUnique;
-    }
+    const int nUnique = rb->nUnique;
+    (void)nDup;
     countersDirty_ = false;
     nActive_ = nDirect + nUnique;
     nPara_ = nPar;
@@ -2564,7 +2577,8 @@ void HipContact::syncHost() const
     self->hostStale_ = false;
 }
 
-bool HipContact::energyEnqueue(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
+bool HipContact::energyEnqueue(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev, const void* pubSrc, void* pubDst,
+    int pubWords)
 {
     if (nActive_ + nPara_ == 0) return false;
     int aB, aE, pB, pE; // this rank's share of the two lists
@@ -2575,8 +2589,11 @@ bool HipContact::energyEnqueue(const double* x_dev, double dHat, double kappa, D
     const int nb = std::max(1, nblk(n));
     if (partial.n < (size_t)nb) partial.alloc(nb);
     if (n) hipLaunchKernelGGL(k_contact_energy, dim3(nb), dim3(BLOCK), 0, stream, cv, dHat, partial.p);
-    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, n ? nb : 0, kappa, scalar_dev);
+    const bool pub = pubWords > 0 && !(shardWorld > 1 && shardReduce); // (a sharded sum is complete only after the reduction below: the caller publishes)
+    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, n ? nb : 0, kappa, scalar_dev, pub ? (const unsigned*)pubSrc : nullptr,
+        pub ? (unsigned*)pubDst : nullptr, pub ? pubWords : 0);
     if (shardWorld > 1 && shardReduce) shardReduce(scalar_dev, 1);
+    publishedByEnergy_ = pub;
     return true;
 }
 double HipContact::energy(const double* x_dev, double dHat, double kappa, DevBuf<double>& partial, double* scalar_dev)
@@ -2714,7 +2731,7 @@ double HipContact::frictionEnergy(const double* x_dev, const double* xt_dev, dou
     const int nb = nblk(n);
     if (partial.n < (size_t)nb) partial.alloc(nb);
     hipLaunchKernelGGL(k_friction_energy, dim3(nb), dim3(BLOCK), 0, stream, fv, x_dev, xt_dev, eps2, partial.p);
-    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, nb, coef, scalar_dev);
+    hipLaunchKernelGGL(k_reduce_scaled, dim3(1), dim3(BLOCK), 0, stream, partial.p, nb, coef, scalar_dev, (const unsigned*)nullptr, (unsigned*)nullptr, 0);
     double out = 0.0;
     HIP_CHECK(hipMemcpyAsync(&out, scalar_dev, sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));

@@ -295,8 +295,8 @@ double HipOptimizer::computeEnergyVal()
     reduceSum(d_scalar.p, 1);
     // the barrier energy of the self-contact sets is enqueued behind the elastic one and read back with it: one synchronisation instead of two (round 6; the
     // reduction of the elastic partial sums is on the stream before the contact kernel reuses d_partial)
-    const bool contactQueued = selfCollision && contact->energyEnqueue(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4);
-    launch_publish(d_scalar.p, h_scalar.dev, 10, stream); // d_scalar[0 .. 4]
+    const bool contactQueued = selfCollision && contact->energyEnqueue(mesh.d_x.p, dHat, kappa, d_partial, d_scalar.p + 4, d_scalar.p, h_scalar.dev, 10);
+    if (!(contactQueued && contact->publishedByEnergy())) launch_publish(d_scalar.p, h_scalar.dev, 10, stream); // d_scalar[0 .. 4]
     HIP_CHECK(hipStreamSynchronize(stream));
     double E = h_scalar.p[0];
     const double Econtact = contactQueued ? h_scalar.p[4] : 0.0;
