@@ -132,6 +132,33 @@ def test_ccd_step_bounds_and_intersection_check(orc, pair):
     assert not c.is_intersected()
 
 
+def test_grid_over_the_last_measured_box_survives_a_mesh_that_moves_away(orc, pair):
+    """Constraint-set build and intersection check lay their grid over the bounding box the LAST build or check measured and read everything back with one
+    synchronisation (round 6).  A mesh that has left that box is noticed on the device (stale flag: nothing runs) and the pass repeats on the fresh box;
+    a state with many more cell entries than the last one grows the lists and repeats.  Same answers as the oracle either way."""
+    m, c, dHat, V = pair["m"], pair["c"], pair["dHat"], pair["V"]
+    nA = V.shape[0] // 2
+    assert len(c.contact_build(dHat)["active"]) > 30  # (measures the box at V)
+    for shift in ([7.0, -3.0, 11.0], [-40.0, 0.5, 0.25], [0.0, 0.0, 0.0]):  # far outside the last box, again, and back
+        X = V + np.asarray(shift)
+        c.set_positions(X)
+        m.set_V(X)
+        assert c.is_intersected() == orc.is_intersected(m) == False  # noqa: E712
+        got = c.contact_build(dHat)
+        want = orc.Contacts().build(m, dHat)
+        assert len(want["active"]) > 30
+        for k in ("active", "para", "para_eiej", "cs_ptee"):
+            assert np.array_equal(got[k], want[k]), (shift, k)
+        # pierced state at the shifted place: the upper slab pushed through the lower one
+        P = X.copy()
+        P[nA:, 1] -= 0.06
+        c.set_positions(P)
+        m.set_V(P)
+        assert c.is_intersected() == orc.is_intersected(m) == True  # noqa: E712
+    c.set_positions(V)
+    m.set_V(V)
+
+
 def drop_scene(orc, gpu_lib, n=2, gap=0.03, dHatEps=1e-2, dt=0.01, speed=-1.5, jitter=1e-2):
     """Two slabs, the upper one falling on the clamped lower one.  The start state is a jittered (pre-strained) copy of the
     rest shape: exactly at rest the reference's makePD2d is discontinuous (see test_gpu_parity), which would make an

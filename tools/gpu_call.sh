@@ -19,7 +19,10 @@ prof() { # prof <tag> <cmd...>: kernel table of a command
   db=$(find /tmp/prof_$tag -name "*.db" | head -1)
   if [ -n "$db" ]; then
     python tools/rocprof_summary.py $db $out/${tag}_kernel_stats.md > /dev/null
-    case $tag in contact*) python tools/contact_timeline.py $db ${TIMELINE_ITER:-20} > $out/${tag}_timeline.txt 2>&1;; esac
+    case $tag in
+      contact*) python tools/contact_timeline.py $db ${TIMELINE_ITER:-20} > $out/${tag}_timeline.txt 2>&1;;
+      bench) python tools/rocprof_timeline.py $db 30 > $out/${tag}_timeline.txt 2>&1;;
+    esac
   fi
 }
 if [ -n "$TESTS" ]; then
@@ -75,4 +78,4 @@ PY
   if [ -n "$BENCH_PROF" ]; then prof bench python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-contact --no-large $BENCH; fi
 fi
 if [ -n "$CMD" ]; then bash -c "$CMD" 2>&1 | filt | tail -${CMD_TAIL:-40}; fi
-tail -5 $out/err.log 2>/dev/null
+tail -5 $out/err.log 2>/dev/null || true
