@@ -256,6 +256,8 @@ public:
     void speculativeAssembly();
     hipEvent_t evAsm0 = nullptr, evAsm1 = nullptr, evTail = nullptr;
     bool evAsmPending = false;
+    int evAsmWeight = 1;
+    unsigned asmLaunches = 0;
     void resolveEventTimers();
     DevBuf<double> d_contactG; // this rank's share of the barrier forces before their all-reduce (contact-pair lists sharded)
     void* allreduceUser = nullptr;

@@ -1111,6 +1111,9 @@ void HipOptimizer::stepForward(const double* x0_dev, double alpha)
     launch_step_forward(3 * mesh.nV, x0_dev, d_searchDir.p, alpha, mesh.d_x.p, stream);
 }
 
+#ifndef ASM_TIME_EVERY
+#define ASM_TIME_EVERY 8
+#endif
 void HipOptimizer::speculativeAssembly()
 {
     specAsmValid = false;
@@ -1118,11 +1121,19 @@ void HipOptimizer::speculativeAssembly()
     ensurePatchPlan();
     d_aSpec.alloc(lin.d_a.n); // same capacity as the solver's value array: the two are swapped
     d_gradSpec.alloc(d_gradient.n);
-    resolveEventTimers(); // (this pass's own assembly: finished long ago)
-    HIP_CHECK(hipEventRecord(evAsm0, stream));
+    // The assembly bucket of the timers is fed by a pair of events around the launch -- on every ASM_TIME_EVERY-th launch only, counted ASM_TIME_EVERY times
+    // (round 6): a timing event is a barrier packet that drains the stream in front of the assembly and behind it, every iteration, for a bucket that holds 2 % of it
+    const bool timeIt = (asmLaunches++ % ASM_TIME_EVERY) == 0;
+    if (timeIt) {
+        resolveEventTimers(); // (the last timed assembly: finished long ago)
+        HIP_CHECK(hipEventRecord(evAsm0, stream));
+    }
     launch_assemble_patches(view(), patch, 0, patch.nPatches, elasticCoef(), 1, d_gradSpec.p, d_aSpec.p, stream); // what computePrecondMtr(true, true) launches on this path
-    HIP_CHECK(hipEventRecord(evAsm1, stream));
-    evAsmPending = true;
+    if (timeIt) {
+        HIP_CHECK(hipEventRecord(evAsm1, stream));
+        evAsmPending = true;
+        evAsmWeight = ASM_TIME_EVERY; // (this pair stands for ASM_TIME_EVERY launches)
+    }
     specAsmValid = true;
 }
 
@@ -1246,7 +1257,7 @@ void HipOptimizer::resolveEventTimers()
     HIP_CHECK(hipEventSynchronize(evAsm1));
     float ms = 0.0f;
     HIP_CHECK(hipEventElapsedTime(&ms, evAsm0, evAsm1));
-    timers[0] += 1.0e-3 * (double)ms;
+    timers[0] += 1.0e-3 * (double)ms * evAsmWeight;
     evAsmPending = false;
 }
 
@@ -1570,6 +1581,7 @@ bool HipOptimizer::newtonIter()
             computePrecondMtr(projDBC, true);
             HIP_CHECK(hipEventRecord(evAsm1, stream));
             evAsmPending = true;
+            evAsmWeight = 1; // (an assembly of its own: the first iteration of a time step, a rejected trial)
         }
         specAsmValid = false;
     }
