@@ -168,7 +168,13 @@ private:
     // to exactly one active subproblem, so key_ / seen_ are only touched by their owner; mark_ is also READ for neighbours
     // that may belong to another subproblem (where it holds that subproblem's tag, never ours) -- hence relaxed atomics; the tags
     // come from atomic counters and are unique.
-    static constexpr int PAR_DEPTH = 3;
+#ifndef MF_ND_PAR_DEPTH
+#define MF_ND_PAR_DEPTH 4 // (3 / 8192 until round 6: profiles/r06_nd_threads_ab.txt)
+#endif
+#ifndef MF_ND_PAR_MIN
+#define MF_ND_PAR_MIN 2048 // nodes below which a subproblem stays on its thread
+#endif
+    static constexpr int PAR_DEPTH = MF_ND_PAR_DEPTH;
     const Graph& g_;
     const double* xyz_;
     int leaf_;
@@ -340,7 +346,7 @@ private:
             (isLeftOf(v) ? left : right).push_back(v);
         }
         std::vector<int> sepCopy = sep;
-        if (depth < PAR_DEPTH && sorted.size() > 8192) {
+        if (depth < PAR_DEPTH && sorted.size() > MF_ND_PAR_MIN) {
             std::vector<std::vector<int>> gr;
             std::vector<int> grTask;
             std::exception_ptr err;
