@@ -3230,7 +3230,10 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
         nRef[c] = std::max(1, (int)std::floor((rt[c] - lb[c]) * g.oneDiv) + 1);
     }
     long long nCells;
-    for (g.m = 1;; ++g.m) {
+#ifndef REF_GRID_MIN_M
+#define REF_GRID_MIN_M 1
+#endif
+    for (g.m = REF_GRID_MIN_M;; ++g.m) {
         nCells = 1;
         for (int c = 0; c < 3; ++c) {
             g.dim[c] = (nRef[c] + g.m - 1) / g.m;
