@@ -3231,7 +3231,7 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
     }
     long long nCells;
 #ifndef REF_GRID_MIN_M
-#define REF_GRID_MIN_M 1
+#define REF_GRID_MIN_M 2 // search cells of 2 x 2 x 2 reference voxels (1 until round 6: profiles/r06_ref_grid_coarsening_ab.txt); pairs are accepted on the fine voxel indices either way
 #endif
     for (g.m = REF_GRID_MIN_M;; ++g.m) {
         nCells = 1;
