@@ -906,21 +906,28 @@ void HipOptimizer::computePrecondMtr(bool projectDBC, bool withGradient)
         // the pattern follows the contact connectivity (augmentConnectivity into vNeighbor_IP, Optimizer.cpp:3560-3612);
         // only pairs that are not mesh edges change it
         std::vector<std::pair<int, int>> extra, fresh;
-        if (contact->nActive() + contact->nPara()) contact->connectivity(extra);
-        if (fricDHat > 0.0 && selfFric > 0.0) contact->frictionConnectivity(extra); // lagged set (:3565-3566)
-        for (const auto& e : extra) {
-            const int* b = mesh.nb.data() + mesh.nbPtr[e.first];
-            const int* en = mesh.nb.data() + mesh.nbPtr[e.first + 1];
-            if (!std::binary_search(b, en, e.second)) fresh.push_back(e);
+        // The connectivity of the live sets on the host (read-back of the tuples, node pairs, filter, sort: 1-2 ms at 40 K nodes) is needed only for the lagged
+        // friction set and for a look-ahead below 1.  Otherwise (round 6) the device has already said that the pattern lacks a block of the live sets -- a new
+        // analysis is certain --, and the look-ahead list below, the FULL stencils of every candidate within lookahead() x dHat >= dHat, contains every node pair
+        // of the live sets: their stencils are sub-stencils of candidates, the mollified pairs' four nodes are their candidates' four nodes.
+        const bool liveOnHost = frictionPairs || lookahead() < 1.0;
+        if (liveOnHost) {
+            if (contact->nActive() + contact->nPara()) contact->connectivity(extra);
+            if (fricDHat > 0.0 && selfFric > 0.0) contact->frictionConnectivity(extra); // lagged set (:3565-3566)
+            for (const auto& e : extra) {
+                const int* b = mesh.nb.data() + mesh.nbPtr[e.first];
+                const int* en = mesh.nb.data() + mesh.nbPtr[e.first + 1];
+                if (!std::binary_search(b, en, e.second)) fresh.push_back(e);
+            }
+            std::sort(fresh.begin(), fresh.end());
+            fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
         }
-        std::sort(fresh.begin(), fresh.end());
-        fresh.erase(std::unique(fresh.begin(), fresh.end()), fresh.end());
         lap("connectivity of the live sets");
         // The reference rebuilds pattern + symbolic analysis whenever the contact graph changes (:3570-3592).  Here the pattern
         // only ever GROWS inside the stepper: pairs that left the constraint set keep their (zero) slots, so a new analysis is
         // needed only when a pair shows up that no earlier iteration had.  Same matrix, fewer host-side analyses; the
         // union is dropped again once it has grown far beyond the live set.
-        if (!std::includes(curExtra.begin(), curExtra.end(), fresh.begin(), fresh.end())) {
+        if (!liveOnHost || !std::includes(curExtra.begin(), curExtra.end(), fresh.begin(), fresh.end())) {
             // Look-ahead: contact spreads, so the next iterations bring pairs that are a little farther apart now.  The new
             // pattern is built from the constraint set at a larger distance (lookahead() * dHat, squared distances): its
             // blocks hold explicit zeros until the pairs become active, and pattern + symbolic analysis (tens of ms on the
