@@ -1,6 +1,8 @@
 // GPU multifrontal Cholesky: the triangular sweeps (forward level by level up the assembly tree, backward down it) on the factor mf_numeric.hip leaves in HBM.
 // Split out of mf_numeric.hip in round 5; the kernels and their launch order are unchanged.
 #include "mf_kernels.h"
+#include <string>
+#include <vector>
 #include <algorithm>
 
 namespace ipcgpu {
@@ -547,22 +549,52 @@ void MfNumeric::enqueueBackward(double* x_dev)
     TreeView tv{ frontOff_.p, idxPtr_.p, firstNode_.p, childPtr_.p, child_.p, invPtr_.p, inv_.p, idx_.p, dinvOff_.p };
     XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
     const int n3 = sym.n;
+#ifdef MF_BWD_PROBE // diagnosis build (-DMF_BWD_PROBE): timing events between the launches of the backward sweep, printed once (profiles/r06_backward_sweep_probe.txt)
+    static int probeCall = 0;
+    const bool probe = ++probeCall == 40;
+    std::vector<hipEvent_t> pe;
+    std::vector<std::string> pn;
+    auto mark = [&](const char* what, int l) {
+        if (!probe) return;
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreate(&e));
+        HIP_CHECK(hipEventRecord(e, stream_));
+        pe.push_back(e);
+        pn.push_back(std::string(what) + " L" + std::to_string(l));
+    };
+    mark("start", nLevels_);
+#else
+    auto mark = [](const char*, int) {};
+#endif
     for (int l = nLevels_ - 1; l >= 0; --l) {
         const LevelPlan& P = plan_[l];
         if (P.bwdInit.cnt)
             hipLaunchKernelGGL(k_big_bwd_init, dim3(P.bwdInit.cnt), dim3(WG), P.bwdLds, stream_, desc_.p + P.bwdInit.off, tv, fronts_.p, yperm_.p,
                 xsol_.p);
+        if (P.bwdInit.cnt) mark("bwd_init", l);
         if (P.bigTri.cnt)
             hipLaunchKernelGGL(k_big_bwd_tri, dim3(P.bigTri.cnt), dim3(WGT), P.triLds, stream_, triList_.p + P.bigTri.off, tv, fronts_.p,
                 dinv_.p, yperm_.p, xsol_.p);
+        if (P.bigTri.cnt) mark("bwd_tri", l);
         if (P.xinvBwd.cnt)
             hipLaunchKernelGGL(k_xinv_bwd, dim3(P.xinvBwd.cnt), dim3(WG), xinvLds_, stream_, xinvDesc_.p + P.xinvBwd.off, tv, xv, yperm_.p,
                 xsol_.p);
         if (P.small.cnt)
             hipLaunchKernelGGL(k_bwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
                 yperm_.p, xsol_.p);
+        if (P.xinvBwd.cnt || P.small.cnt) mark("xinv/small", l);
         if (world_ > 1) exchange(xchg_[l].opsX); // solution entries of this level's fronts above the cut -> the ranks that execute fronts below them
     }
+#ifdef MF_BWD_PROBE
+    if (probe) {
+        HIP_CHECK(hipStreamSynchronize(stream_));
+        for (size_t i = 1; i < pe.size(); ++i) {
+            float ms = 0;
+            HIP_CHECK(hipEventElapsedTime(&ms, pe[i - 1], pe[i]));
+            fprintf(stderr, "bwd probe: %-16s %7.1f us\n", pn[i].c_str(), 1e3 * ms);
+        }
+    }
+#endif
     if (world_ > 1) reduceSolution(); // every rank holds the solution of the fronts it executed: sum of the masked parts (mf_exchange.hip)
     hipLaunchKernelGGL(k_unpermute_x, dim3((n3 + 255) / 256), dim3(256), 0, stream_, sym.nn, newOf_.p, xsol_.p, x_dev);
 }
