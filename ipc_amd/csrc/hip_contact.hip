@@ -1149,10 +1149,6 @@ constexpr int EE_QUEUE = 128;
 __device__ __forceinline__ void narrow_ee_queued(int eI, int eJ, const int* __restrict__ SFE, const double* __restrict__ x, const double* __restrict__ xRest,
     const int* __restrict__ dbc, int nE, double dHat, const WgList& wl, int cap, int* __restrict__ out, int* __restrict__ counter)
 {
-#if defined(EE_PROBE) && EE_PROBE >= 1
-    if (eI == -12345) atomicAdd(counter, eJ); // probe 1: pairs are found and queued, never typed
-    return;
-#endif
     const int a0 = SFE[2 * (size_t)eI], a1 = SFE[2 * (size_t)eI + 1], b0 = SFE[2 * (size_t)eJ], b1 = SFE[2 * (size_t)eJ + 1];
     // flags and positions of the four nodes are requested together and the filters evaluated without short-circuits: as `dbc[a0] && dbc[a1] && ...` each
     // flag was a memory round trip of its own, in series, in front of the positions
@@ -1225,10 +1221,6 @@ __global__ __launch_bounds__(BLOCK) void k_narrow_ee_cells(int nE, const int* __
                     tile[lane] = ra;
                 }
                 __builtin_amdgcn_wave_barrier();
-#if defined(EE_PROBE) && EE_PROBE >= 2
-                if (rb.id == -12345) atomicAdd(counter, 1); // probe 2: the cell's records are fetched, no pair loop
-                continue;
-#endif
                 for (int ka = 0; ka < nA; ++ka) {
                     const EeTileRec ra = tile[ka]; // uniform address: a broadcast read; by VALUE and tested without short-circuits below -- as a reference behind
                                                    // && chains every field was its own LDS round trip (fourteen in a row per pair, ~1.5 k cycles: 0.16 ms of the kernel)
