@@ -3334,7 +3334,7 @@ bool HipContact::isIntersected(const HipMesh& mesh, const double* x_dev, const i
     // Round 6: the check runs once or twice per Newton iteration of a contact scene and used to wait for the host three times (bounding box, number of cell
     // entries, result).  Like the constraint-set build it now lays its grid over the box the LAST build or check measured (a stale grid is detected on the
     // device and nothing runs), fills the edge cells into the capacity the last pass needed, and reads flag + stale flag + total + the fresh box back at once.
-    for (int attempt = 0; haveBox_ && attempt < 3; ++attempt) {
+    for (int attempt = 0; haveBox_ && nSF > 0 && nSFE > 0 && attempt < 3; ++attempt) {
         const int nV = mesh.nV, nb = nblk(nV);
         bboxPartial_.ensure(6 * (size_t)nb + 6);
         double* box_dev = bboxPartial_.p + 6 * (size_t)nb;
