@@ -655,8 +655,7 @@ void HipOptimizer::initKappa()
     if (dampingStiff > 0.0) dampingGradientAdd(true, d_gradient.p); // still part of it (:3519-3540)
     d_minusG.zero(stream);
     barrierGradientAdd(true, 1.0, true, d_minusG.p); // also clears the DBC rows (:2275-2277)
-    launch_dot_scaled(n3, d_minusG.p, d_gradient.p, 1.0, d_scalar.p + 6, stream);
-    launch_dot_scaled(n3, d_minusG.p, d_minusG.p, 1.0, d_scalar.p + 7, stream);
+    launch_dot2(n3, d_minusG.p, d_gradient.p, d_partial.p, (int)d_partial.n, d_scalar.p + 6, stream);
     launch_publish(d_scalar.p + 6, h_scalar.dev, 4, stream); // two doubles = four words
     HIP_CHECK(hipStreamSynchronize(stream));
     const double num = h_scalar.p[0], den = h_scalar.p[1];

@@ -100,6 +100,8 @@ void launch_damp_dx(int nV, const int* dbc, int mode, int projectDBC, const doub
 void launch_damp_clear_diag(int nV, const int* dbc, const int* ia, double* d, hipStream_t s);
 void launch_axpy(long long n, double alpha, const double* x, double* y, hipStream_t s);
 void launch_dot_scaled(int n, const double* x, const double* y, double scale, double* out, hipStream_t s);
+// out2[0] = g . e, out2[1] = g . g (many workgroups, fixed order; partial: 2 x min(128, partialCap / 2) doubles of scratch)
+void launch_dot2(int n, const double* g, const double* e, double* partial, int partialCap, double* out2, hipStream_t s);
 void launch_mdbc_reduce(const MdbcView& m, const double* x, double rho, int mode /*0 energy, 1 |x - target|^2*/, double* out, hipStream_t s);
 void launch_mdbc_gradient(const MdbcView& m, const double* x, double rho, double* g, hipStream_t s);
 void launch_mdbc_hessian(const MdbcView& m, const int* ia, double rho, double* a, hipStream_t s);
