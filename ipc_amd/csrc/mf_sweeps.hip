@@ -5,6 +5,10 @@
 #include <vector>
 #include <algorithm>
 
+#ifndef BWD_NARROW_MAX_N
+#define BWD_NARROW_MAX_N 160 // levels whose fronts have at most this many rows sweep backward with two waves per workgroup (0 = never)
+#endif
+
 namespace ipcgpu {
 
 namespace {
@@ -256,9 +260,13 @@ __global__ __launch_bounds__(WG) void k_big_fwd_rect(const int4* __restrict__ de
     }
 }
 
-__global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, TreeView tv, const double* __restrict__ fronts,
+// NT = 256, or 128 on levels of narrow fronts (round 6: a leaf front has ~90 rows; with two waves per workgroup twice as many of the 2 176 leaves of mat150 are resident and
+// the level -- one latency-bound round of workgroups -- takes 22 instead of 36 us)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bwd_level(const int* __restrict__ list, TreeView tv, const double* __restrict__ fronts,
     const double* __restrict__ dinv, const double* __restrict__ yperm, double* __restrict__ xsol)
 {
+    constexpr int NW = NT / 64;
     extern __shared__ double x[];
     __shared__ double invs[NB * LDP];
     const int s = list[blockIdx.x];
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, 
     const int* idx = tv.idx + tv.idxPtr[s];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col0 = 3 * tv.firstNode[s];
-    for (int I = tid; I < N; I += WG) {
+    for (int I = tid; I < N; I += NT) {
         const int In = I / 3;
         x[I] = (I < nc) ? yperm[col0 + I] : xsol[3 * idx[In] + (I - 3 * In)];
     }
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, 
     // in flight; one column and one strip at a time this loop was nc / 4 x (N - nc) / 64 dependent round trips per wave)
     {
         const int m = N - nc;
-        for (int c0 = wave; c0 < nc; c0 += 16) {
+        for (int c0 = wave; c0 < nc; c0 += 4 * NW) {
             double acc[4] = { 0.0, 0.0, 0.0, 0.0 };
             for (int i0 = 0; i0 < m; i0 += 128) {
                 const int ia = i0 + lane, ib = i0 + 64 + lane;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, 
                 double va[4], vb[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const double* Lc = L + (long long)N * min(c0 + 4 * q, nc - 1) + nc;
+                    const double* Lc = L + (long long)N * min(c0 + NW * q, nc - 1) + nc;
                     va[q] = Lc[min(ia, m - 1)];
                     vb[q] = Lc[min(ib, m - 1)];
                 }
@@ -296,13 +304,13 @@ __global__ __launch_bounds__(WG) void k_bwd_level(const int* __restrict__ list, 
                 double t = acc[q];
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
-                if (lane == 0 && c0 + 4 * q < nc) x[c0 + 4 * q] -= t;
+                if (lane == 0 && c0 + NW * q < nc) x[c0 + NW * q] -= t;
             }
         }
     }
     __syncthreads();
-    bwd_triangle<WG>(L, N, nc, dinv + tv.dinvOff[s] * (NB * NB), x, invs, tid);
-    for (int I = tid; I < nc; I += WG) xsol[col0 + I] = x[I];
+    bwd_triangle<NT>(L, N, nc, dinv + tv.dinvOff[s] * (NB * NB), x, invs, tid);
+    for (int I = tid; I < nc; I += NT) xsol[col0 + I] = x[I];
 }
 
 // big fronts, backward prologue: y_c -= sum_{r >= nc} L(r, c) x_r  (x of the ancestors).  desc = (front, first column, 0, 0);
@@ -488,7 +496,8 @@ void MfNumeric::configureSweepKernels(size_t maxSolveLds, size_t maxBwdLds, size
     }
     if (maxSolveLds > 48 * 1024) {
         HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
     }
     if (maxBwdLds > 48 * 1024)
         HIP_CHECK(hipFuncSetAttribute((const void*)k_big_bwd_init, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxBwdLds));
@@ -579,9 +588,14 @@ void MfNumeric::enqueueBackward(double* x_dev)
         if (P.xinvBwd.cnt)
             hipLaunchKernelGGL(k_xinv_bwd, dim3(P.xinvBwd.cnt), dim3(WG), xinvLds_, stream_, xinvDesc_.p + P.xinvBwd.off, tv, xv, yperm_.p,
                 xsol_.p);
-        if (P.small.cnt)
-            hipLaunchKernelGGL(k_bwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
-                yperm_.p, xsol_.p);
+        if (P.small.cnt) {
+            if (P.solveLds <= BWD_NARROW_MAX_N * sizeof(double))
+                hipLaunchKernelGGL(k_bwd_level<128>, dim3(P.small.cnt), dim3(128), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
+                    yperm_.p, xsol_.p);
+            else
+                hipLaunchKernelGGL(k_bwd_level<256>, dim3(P.small.cnt), dim3(WG), P.solveLds, stream_, smallList_.p + P.small.off, tv, fronts_.p, dinv_.p,
+                    yperm_.p, xsol_.p);
+        }
         if (P.xinvBwd.cnt || P.small.cnt) mark("xinv/small", l);
         if (world_ > 1) exchange(xchg_[l].opsX); // solution entries of this level's fronts above the cut -> the ranks that execute fronts below them
     }
