@@ -211,9 +211,9 @@ public:
     std::vector<int> baseDbcType;
     double stepStartTime = 0, stepEndTime = 0; // AnimScripter.cpp:1406-1407
     // augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2150-2157, 2280-2350; Optimizer.cpp:1826-1828, 2168-2203)
-    std::vector<int> tpIds; // targetPos keys = the Dirichlet nodes, ascending
+    std::vector<int> tpIds, tpIdsOnDevice; // targetPos keys = the Dirichlet nodes, ascending (and the list d_tpIds currently holds)
     DevBuf<int> d_tpIds;
-    DevBuf<double> d_tpPos, d_tpLam;
+    DevBuf<double> d_tpPos, d_tpLam, d_tpStage;
     double dist2Tol = 0, completedStep = 1.0, lastMove = 1.0, rhoDBC = 0.0, CN_MBC = 0.0;
     bool projDBC = true; // m_projectDBC
     MdbcView mdbc() const { return MdbcView{ (int)tpIds.size(), d_tpIds.p, d_tpPos.p, d_tpLam.p, mesh.d_mass.p }; }

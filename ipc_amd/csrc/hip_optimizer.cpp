@@ -1500,24 +1500,23 @@ void HipOptimizer::buildTargetPositions()
     dist2Tol = 0.0;
     if (tpIds.empty()) return;
     const int n = (int)tpIds.size();
-    d_tpIds.uploadGrow(tpIds, stream);
+    if (tpIds != tpIdsOnDevice) { // (the same nodes step after step unless a Dirichlet group starts or ends)
+        d_tpIds.uploadGrow(tpIds, stream);
+        tpIdsOnDevice = tpIds;
+    }
     d_tpPos.ensure(3 * (size_t)n);
     d_tpLam.ensure(3 * (size_t)n);
+    d_tpStage.ensure(3 * (size_t)n);
     d_tpLam.zeroN(3 * (size_t)n, stream);
-    std::vector<double> x(3 * (size_t)n), p(3 * (size_t)n);
-    launch_gather3(n, d_tpIds.p, mesh.d_x.p, d_tpPos.p, stream);
-    HIP_CHECK(hipMemcpyAsync(x.data(), d_tpPos.p, x.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-    launch_gather3(n, d_tpIds.p, d_searchDir.p, d_tpPos.p, stream);
-    HIP_CHECK(hipMemcpyAsync(p.data(), d_tpPos.p, p.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
+    // targets x + p formed on the device (round 6: x and p of the scripted nodes used to travel to the host, their sum back); the host only needs p for the tolerance,
+    // summed there in index order as before
+    std::vector<double> p(3 * (size_t)n);
+    launch_target_positions(n, d_tpIds.p, mesh.d_x.p, d_searchDir.p, d_tpPos.p, d_tpStage.p, stream);
+    HIP_CHECK(hipMemcpyAsync(p.data(), d_tpStage.p, p.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     double sq = 0.0;
-    for (size_t i = 0; i < p.size(); ++i) {
-        sq += p[i] * p[i];
-        x[i] += p[i];
-    }
+    for (size_t i = 0; i < p.size(); ++i) sq += p[i] * p[i];
     dist2Tol = sq * 1.0e-6;
-    HIP_CHECK(hipMemcpyAsync(d_tpPos.p, x.data(), x.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
 }
 
 double HipOptimizer::computeCompletedStepSize()
@@ -1556,11 +1555,12 @@ bool HipOptimizer::newtonIter()
     // convergence test (Optimizer.cpp:1869-1879) looks at the search direction of the previous pass
     double distToOpt_PN;
     if (k && cachedDistValid) distToOpt_PN = cachedDist; // read back with the last solve
-    else {
+    else if (k) {
         launch_fill(d_scalar.p + 3, 1, 0.0, stream);
         launch_max_abs(3 * mesh.nV, d_searchDir.p, d_scalar.p + 3, stream);
-        distToOpt_PN = k ? readScalar(d_scalar.p + 3) : 0.0; // (the test needs k > 0)
+        distToOpt_PN = readScalar(d_scalar.p + 3);
     }
+    else distToOpt_PN = 0.0; // (the test needs k > 0: nothing to measure in the first pass of a time step)
     cachedDistValid = false;
     if (k && distToOpt_PN < targetGRes && completedStep > 1.0 - 1.0e-3) { // :1874-1879
         specAsmValid = false; // (the one assembly per time step that goes unused)

@@ -78,6 +78,7 @@ struct DbcMotion {
     double linDt[3];
 };
 void launch_gather3(int n, const int* ids, const double* x, double* out, hipStream_t s);
+void launch_target_positions(int n, const int* ids, const double* x, const double* p, double* pos, double* pOut, hipStream_t s);
 void launch_dbc_motion(int n, const int* ids, const DbcMotion& m, const double* x, double* p, hipStream_t s);
 void launch_dbc_targets(int n, const int* ids, const double* target_3n, const double* x, double* p, hipStream_t s);
 // Neumann boundary conditions (Mesh::NeumannBCs; Optimizer.cpp:3241-3250, 3452-3461): dtSqA3 = dt^2 * acceleration

@@ -495,6 +495,18 @@ __global__ void k_gather3(int n, const int* __restrict__ ids, const double* __re
     const int k = i / 3, c = i - 3 * k;
     out[i] = x[3 * (size_t)ids[k] + c];
 }
+// target positions of the scripted nodes (AnimScripter.cpp:2150-2157): pos = x + p at the listed nodes, and p at those nodes for the host's tolerance sum
+__global__ void k_target_positions(int n, const int* __restrict__ ids, const double* __restrict__ x, const double* __restrict__ p, double* __restrict__ pos,
+    double* __restrict__ pOut)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 3 * n) return;
+    const int k = i / 3, c = i - 3 * k;
+    const size_t j = 3 * (size_t)ids[k] + c;
+    const double pi = p[j];
+    pOut[i] = pi;
+    pos[i] = x[j] + pi; // (the same sum the host formed: x[i] += p[i])
+}
 // scripted Dirichlet motion (AnimScripter.cpp:1440-1462): p += R (x - c) + c + linVel dt - x
 __global__ void k_dbc_motion(int n, const int* __restrict__ ids, DbcMotion m, const double* __restrict__ x, double* __restrict__ p)
 {
@@ -851,6 +863,10 @@ void launch_mdbc_hessian(const MdbcView& m, const int* ia, double rho, double* a
 void launch_mdbc_lambda(const MdbcView& m, const double* x, double rho, hipStream_t s)
 {
     if (m.n) hipLaunchKernelGGL(k_mdbc_lambda, dim3(nblk(3LL * m.n)), dim3(BLOCK), 0, s, m.n, m.ids, m.pos, m.lam, m.mass, x, rho);
+}
+void launch_target_positions(int n, const int* ids, const double* x, const double* p, double* pos, double* pOut, hipStream_t s)
+{
+    if (n) hipLaunchKernelGGL(k_target_positions, dim3(nblk(3LL * n)), dim3(BLOCK), 0, s, n, ids, x, p, pos, pOut);
 }
 void launch_gather3(int n, const int* ids, const double* x, double* out, hipStream_t s)
 {
