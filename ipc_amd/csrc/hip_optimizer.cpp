@@ -18,6 +18,10 @@
 #include <cmath>
 #include <cstring>
 
+#ifndef BEGIN_BATCHED
+#define BEGIN_BATCHED 1 // 0: the time-step set-up of the contact-free twist question by question, as in rounds 1-5 (A/B: profiles/r06_begin_timestep_batch_ab.txt)
+#endif
+
 namespace ipcgpu {
 
 // The reference's Optimizer constructor calls setTime(10.0, 0.025) (Optimizer.cpp:116) and derives eps_v^2 h^2 (fricDHat0 / fricDHatTarget, :290-303)
@@ -89,9 +93,9 @@ void HipOptimizer::init(double dt_, bool withGravity)
     d_x0.alloc(n3);
     d_partial.alloc((size_t)std::max(mesh.nT, mesh.nV) / 256 + 2);
     d_scalar.alloc(8);
-    d_flag.alloc(1);
+    d_flag.alloc(2); // [0] the inversion flag of the stepper, [1] a second one for batches that test two states (beginTimestep)
     h_scalar.alloc(8);
-    h_flag.alloc(1);
+    h_flag.alloc(2);
     HIP_CHECK(hipMemcpyAsync(d_xPrev.p, mesh.d_x.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
     HIP_CHECK(hipMemcpyAsync(mesh.d_xTilde.p, mesh.d_x.p, n3 * sizeof(double), hipMemcpyDeviceToDevice, stream));
     for (int c = 0; c < 3; ++c) rotCenter[c] = 0.5 * (mesh.bboxLo[c] + mesh.bboxHi[c]);
@@ -1391,6 +1395,46 @@ void HipOptimizer::beginTimestep()
     if (!initialised) throw StateError("opt_begin_timestep before opt_init");
     if (!lin.analyzed()) throw StateError("opt_begin_timestep before opt_precompute");
     Tic t(timers[11], stream);
+    // The contact-free twist (BASELINE configs[1]; round 6): everything the set-up of a time step asks the device -- inverted before the motion? the filter's bound
+    // on the scripted step, the step, inverted after it? the energy there -- is enqueued as ONE batch and read back with one synchronisation (seven before: each
+    // question waited for its answer).  Any answer but the usual one ("no", "no") falls back to the general sequence below from the state it left off.
+    const bool batched = BEGIN_BATCHED && fastPath() && nHandles && dbcGroups.empty() && !selfCollision && planes.empty() && !(warmStart >= 1 && warmStart <= 5);
+    if (batched) {
+        const bool guard = mesh.energyType != 1; // Optimizer.cpp:252, 517: only under getNeedElemInvSafeGuard()
+        d_flag.zero(stream);
+        if (guard) launch_check_inversion(view(), d_flag.p, stream);
+        d_searchDir.zero(stream);
+        stepStartTime = stepEndTime; // AnimScripter.cpp:1406-1407
+        stepEndTime += dt;
+        setDBCVertices();
+        launch_twist_dir(nHandles, d_handleIds.p, d_handleAng.p, rotCenter[1], rotCenter[2], mesh.d_x.p, d_searchDir.p, stream);
+        buildTargetPositions(/*deferTolerance=*/true);
+        launch_fill(d_scalar.p + 2, 1, 1e20, stream);
+        if (guard) launch_inversion_step(view(), d_searchDir.p, 0.2, 1.0, d_scalar.p + 2, stream); // filterStepSize(p, 1.0) ...
+        launch_trial_step_fused(3 * mesh.nV, mesh.d_x.p, d_x0.p, d_searchDir.p, d_scalar.p + 2, guard, d_scalar.p + 6, stream); // ... applied by its rule; x0 = x, x += step p
+        if (guard) launch_check_inversion(view(), d_flag.p + 1, stream);
+        launch_energy(view(), elasticCoef(), true, true, d_partial.p, (int)d_partial.n, d_scalar.p, stream); // computeEnergyVal() of this configuration: elasticity + inertia
+        launch_publish2(d_flag.p, h_flag.dev, 2, d_scalar.p, h_scalar.dev, 14, stream);
+        HIP_CHECK(hipStreamSynchronize(stream));
+        if (h_flag.p[0]) throw StateError("element inversion before scripted motion (Optimizer.cpp:517-522)");
+        finishTolerance();
+        double stepSize = h_scalar.p[6];
+        bool energyKnown = true;
+        if (h_flag.p[1]) { // inverted behind the filtered step: the halving loop (AnimScripter.cpp:2172-2180) from here
+            energyKnown = false;
+            do {
+                stepSize /= 2.0;
+                stepForward(d_x0.p, stepSize);
+            } while (!checkInversion());
+        }
+        if (stepSize < 1.0) dbcIncomplete++;
+        completedStep = stepSize;
+        d_searchDir.zero(stream);
+        initSubProblem();
+        lastEnergyVal = energyKnown ? h_scalar.p[0] : computeEnergyVal(); // Optimizer.cpp:1609
+        k = 0;
+        return;
+    }
     if (!checkInversion()) throw StateError("element inversion before scripted motion (Optimizer.cpp:517-522)");
     d_searchDir.zero(stream);
     stepStartTime = stepEndTime; // AnimScripter.cpp:1406-1407
@@ -1492,12 +1536,13 @@ void HipOptimizer::initSubProblem()
 
 // targetPos / dist2Tol of stepAnimScript (AnimScripter.cpp:2150-2157).  Every scripted node is a Dirichlet node here (twist
 // handles, Dirichlet groups, scripted components), so the keys are the Dirichlet nodes.  Per time step, a few KB.
-void HipOptimizer::buildTargetPositions()
+void HipOptimizer::buildTargetPositions(bool deferTolerance)
 {
     tpIds.clear();
     for (int v = 0; v < mesh.nV; ++v)
         if (mesh.dbcType[v] != 0) tpIds.push_back(v);
     dist2Tol = 0.0;
+    tolPending = false;
     if (tpIds.empty()) return;
     const int n = (int)tpIds.size();
     if (tpIds != tpIdsOnDevice) { // (the same nodes step after step unless a Dirichlet group starts or ends)
@@ -1506,16 +1551,24 @@ void HipOptimizer::buildTargetPositions()
     }
     d_tpPos.ensure(3 * (size_t)n);
     d_tpLam.ensure(3 * (size_t)n);
-    d_tpStage.ensure(3 * (size_t)n);
     d_tpLam.zeroN(3 * (size_t)n, stream);
     // targets x + p formed on the device (round 6: x and p of the scripted nodes used to travel to the host, their sum back); the host only needs p for the tolerance,
-    // summed there in index order as before
-    std::vector<double> p(3 * (size_t)n);
-    launch_target_positions(n, d_tpIds.p, mesh.d_x.p, d_searchDir.p, d_tpPos.p, d_tpStage.p, stream);
-    HIP_CHECK(hipMemcpyAsync(p.data(), d_tpStage.p, p.size() * sizeof(double), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
+    // summed there in index order as before.  deferTolerance: p goes to mapped host memory and finishTolerance() sums it behind the caller's next synchronisation
+    if (h_tpStage.n < 3 * (size_t)n) h_tpStage.alloc(3 * (size_t)n + 3 * (size_t)n / 2 + 16);
+    launch_target_positions(n, d_tpIds.p, mesh.d_x.p, d_searchDir.p, d_tpPos.p, h_tpStage.dev, stream);
+    tolPending = true;
+    if (!deferTolerance) {
+        HIP_CHECK(hipStreamSynchronize(stream));
+        finishTolerance();
+    }
+}
+
+void HipOptimizer::finishTolerance()
+{
+    if (!tolPending) return;
+    tolPending = false;
     double sq = 0.0;
-    for (size_t i = 0; i < p.size(); ++i) sq += p[i] * p[i];
+    for (size_t i = 0, m = 3 * tpIds.size(); i < m; ++i) sq += h_tpStage.p[i] * h_tpStage.p[i];
     dist2Tol = sq * 1.0e-6;
 }
 
@@ -1565,6 +1618,7 @@ bool HipOptimizer::newtonIter()
     if (k && distToOpt_PN < targetGRes && completedStep > 1.0 - 1.0e-3) { // :1874-1879
         specAsmValid = false; // (the one assembly per time step that goes unused)
         Tic t(timers[12], stream);
+        t.nosync = fastPath(); // (nobody on the host waits for this gradient: whoever reads it synchronises)
         computeGradient(projDBC); // the reference leaves the gradient of the converged state behind (:1861)
         return true;
     }
@@ -1653,6 +1707,7 @@ void HipOptimizer::endTimestep()
 {
     specAsmValid = false;
     Tic t(timers[11], stream);
+    t.nosync = fastPath(); // (the update is one kernel on the stream; the next time step's batch synchronises)
     if (timeIntegration == 1)
         launch_nm_update(mesh.nV, mesh.d_dbc.p, mesh.d_x.p, d_xPrev.p, d_vel.p, d_acc.p, d_dxElastic.p, mesh.d_xTilde.p, dt, betaNM, gammaNM,
             gravity[0], gravity[1], gravity[2], stream);
