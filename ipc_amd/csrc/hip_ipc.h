@@ -213,12 +213,12 @@ public:
     // augmented-Lagrangian Dirichlet fallback (AnimScripter.cpp:2150-2157, 2280-2350; Optimizer.cpp:1826-1828, 2168-2203)
     std::vector<int> tpIds, tpIdsOnDevice; // targetPos keys = the Dirichlet nodes, ascending (and the list d_tpIds currently holds)
     DevBuf<int> d_tpIds;
-    DevBuf<double> d_tpPos, d_tpLam;
+    DevBuf<double> d_tpPos, d_tpLam, d_tpStage;
     double dist2Tol = 0, completedStep = 1.0, lastMove = 1.0, rhoDBC = 0.0, CN_MBC = 0.0;
     bool projDBC = true; // m_projectDBC
     MdbcView mdbc() const { return MdbcView{ (int)tpIds.size(), d_tpIds.p, d_tpPos.p, d_tpLam.p, mesh.d_mass.p }; }
     void buildTargetPositions(bool deferTolerance = false); // after the scripted search direction is known, before it is applied
-    void finishTolerance(); // dist2Tol from the scripted directions buildTargetPositions(true) left in mapped host memory (behind a synchronisation)
+    void finishTolerance(); // dist2Tol from the scripted directions buildTargetPositions(true) left in pinned host memory (behind a synchronisation)
     PinnedBuf<double> h_tpStage;
     bool tolPending = false;
     void initSubProblem(); // head of solveSub_IP (Optimizer.cpp:1826-1828)

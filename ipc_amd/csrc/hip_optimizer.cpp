@@ -1553,9 +1553,13 @@ void HipOptimizer::buildTargetPositions(bool deferTolerance)
     d_tpLam.ensure(3 * (size_t)n);
     d_tpLam.zeroN(3 * (size_t)n, stream);
     // targets x + p formed on the device (round 6: x and p of the scripted nodes used to travel to the host, their sum back); the host only needs p for the tolerance,
-    // summed there in index order as before.  deferTolerance: p goes to mapped host memory and finishTolerance() sums it behind the caller's next synchronisation
+    // summed there in index order as before.  deferTolerance: p goes to pinned host memory and finishTolerance() sums it behind the caller's next synchronisation
+    // (through a device buffer and ONE copy into pinned memory: thousands of 8-byte stores of a kernel into mapped host memory are thousands of bus transactions --
+    // 7 ms for the Dirichlet nodes of 4_rodsTwist when this was first written that way)
     if (h_tpStage.n < 3 * (size_t)n) h_tpStage.alloc(3 * (size_t)n + 3 * (size_t)n / 2 + 16);
-    launch_target_positions(n, d_tpIds.p, mesh.d_x.p, d_searchDir.p, d_tpPos.p, h_tpStage.dev, stream);
+    d_tpStage.ensure(3 * (size_t)n);
+    launch_target_positions(n, d_tpIds.p, mesh.d_x.p, d_searchDir.p, d_tpPos.p, d_tpStage.p, stream);
+    HIP_CHECK(hipMemcpyAsync(h_tpStage.p, d_tpStage.p, 3 * (size_t)n * sizeof(double), hipMemcpyDeviceToHost, stream));
     tolPending = true;
     if (!deferTolerance) {
         HIP_CHECK(hipStreamSynchronize(stream));
