@@ -171,10 +171,10 @@ __global__ __launch_bounds__(BLOCK) void k_reduce_scaled(const double* __restric
 // ---- deterministic scatter ------------------------------------------------------------------------------------------------------------
 // Barrier and friction terms add into nodes / CSR blocks that several stencils share.  Rounds 1-2 used hardware fp64 atomics: the last
 // bits of g and a[] then depend on the order the atomics retire.  Now every stencil writes its contributions into its OWN slots of a
-// scratch array together with a key (the node, or the CSR position of the 3x3 block); the keys are radix-sorted (stable: equal keys
-// stay in slot order, i.e. stencil order) and one lane per run sums it front to back and adds the sum to the destination -- a fixed
-// summation order, bit-reproducible.  (The atomic path stayed behind an environment switch for A/B timing until round 6:
-// profiles/r03_contact_bench_atomic_scatter.json against r03_contact_bench_deterministic_scatter.json.)
+// scratch array together with a key (the node, or the CSR position of the 3x3 block); the slots of a key are brought into slot order
+// (= stencil order) and summed front to back into the destination -- a fixed summation order, bit-reproducible.  (The atomic path stayed
+// behind an environment switch for A/B timing until round 6: profiles/r03_contact_bench_atomic_scatter.json against
+// r03_contact_bench_deterministic_scatter.json.)
 constexpr unsigned KEY_NONE = 0xFFFFFFFFu;
 // Deterministic scatter (round 6: a counting sort; rounds 3-5 sorted the keys with rocPRIM's radix sort, which is a merge sort of ~16 launches at these sizes):
 // every contribution has a slot of its own (stencil index x slots per stencil), a key (the node, or the CSR position of the 3 x 3 block) and bumps the
