@@ -5,6 +5,9 @@
 #include <vector>
 #include <algorithm>
 
+#ifndef FWD_NARROW
+#define FWD_NARROW 1 // the forward sweep of the narrow levels with two waves per workgroup as well (0: four)
+#endif
 #ifndef BWD_NARROW_MAX_N
 #define BWD_NARROW_MAX_N 160 // levels whose fronts have at most this many rows sweep backward with two waves per workgroup (0 = never)
 #endif
@@ -167,7 +170,9 @@ __device__ __forceinline__ void bwd_triangle(const double* __restrict__ L, int N
     }
 }
 
-__global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, TreeView tv, const long long* __restrict__ wOff,
+// (NT = 256, or 128 on levels of narrow fronts: see k_bwd_level)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fwd_level(const int* __restrict__ list, TreeView tv, const long long* __restrict__ wOff,
     const double* __restrict__ fronts, const double* __restrict__ dinv, double* __restrict__ wbuf, const double* __restrict__ bperm,
     double* __restrict__ yperm)
 {
@@ -177,11 +182,11 @@ __global__ __launch_bounds__(WG) void k_fwd_level(const int* __restrict__ list, 
     const double* L = fronts + tv.frontOff[s];
     const int tid = threadIdx.x;
     const int col0 = 3 * tv.firstNode[s];
-    for (int I = tid; I < N; I += WG) w[I] = gather_w(tv, wOff, wbuf, bperm, s, nc, I);
+    for (int I = tid; I < N; I += NT) w[I] = gather_w(tv, wOff, wbuf, bperm, s, nc, I);
     __syncthreads();
-    fwd_triangle<WG>(L, N, nc, N, dinv + tv.dinvOff[s] * (NB * NB), w, tid);
+    fwd_triangle<NT>(L, N, nc, N, dinv + tv.dinvOff[s] * (NB * NB), w, tid);
     double* wo = wbuf + wOff[s];
-    for (int I = tid; I < N; I += WG) {
+    for (int I = tid; I < N; I += NT) {
         wo[I] = w[I]; // rows >= nc carry (children contributions - L21 y) up to the parent
         if (I < nc) yperm[col0 + I] = w[I];
     }
@@ -495,7 +500,8 @@ void MfNumeric::configureSweepKernels(size_t maxSolveLds, size_t maxBwdLds, size
         HIP_CHECK(hipFuncSetAttribute((const void*)k_xinv_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)xinvLds_));
     }
     if (maxSolveLds > 48 * 1024) {
-        HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
+        HIP_CHECK(hipFuncSetAttribute((const void*)k_fwd_level<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
         HIP_CHECK(hipFuncSetAttribute((const void*)k_bwd_level<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)maxSolveLds));
     }
@@ -541,8 +547,14 @@ void MfNumeric::enqueueForwardLevel(int l, hipStream_t st)
     XinvView xv{ xinvOff_.p, xinvX_.p, xinvT_.p };
     const LevelPlan& P = plan_[l];
     if (P.small.cnt)
-        hipLaunchKernelGGL(k_fwd_level, dim3(P.small.cnt), dim3(WG), P.solveLds, st, smallList_.p + P.small.off, tv, wOff_.p, fronts_.p, dinv_.p, w_.p,
-            bperm_.p, yperm_.p);
+    {
+        if (FWD_NARROW && P.solveLds <= BWD_NARROW_MAX_N * sizeof(double))
+            hipLaunchKernelGGL(k_fwd_level<128>, dim3(P.small.cnt), dim3(128), P.solveLds, st, smallList_.p + P.small.off, tv, wOff_.p, fronts_.p, dinv_.p, w_.p,
+                bperm_.p, yperm_.p);
+        else
+            hipLaunchKernelGGL(k_fwd_level<256>, dim3(P.small.cnt), dim3(WG), P.solveLds, st, smallList_.p + P.small.off, tv, wOff_.p, fronts_.p, dinv_.p, w_.p,
+                bperm_.p, yperm_.p);
+    }
     if (P.bigTri.cnt)
         hipLaunchKernelGGL(k_big_fwd_tri, dim3(P.bigTri.cnt), dim3(WGT), P.triLds, st, triList_.p + P.bigTri.off, tv, wOff_.p, fronts_.p, dinv_.p, w_.p,
             bperm_.p, yperm_.p);
