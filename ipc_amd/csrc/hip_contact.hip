@@ -1560,10 +1560,28 @@ __global__ __launch_bounds__(BLOCK) void k_ref_abs_sum(int n, const int* __restr
     }
 }
 // bounding box of the surface nodes at x + alpha p, one partial per block (6 doubles: lo, hi)
-__global__ __launch_bounds__(BLOCK) void k_ref_bbox_swept(int n, const int* __restrict__ SVI, const double* __restrict__ x, const double* __restrict__ p,
-    double alpha, double* __restrict__ partial)
+// The prologue of the reference sweep on the device (round 6; three partial arrays used to travel to the host one after the other, each behind a synchronisation):
+// k_ref_cap adds the partial sums up in block order -- one thread, the same order as the host loop it replaces, so the cap is bit for bit the same -- and leaves the
+// capped step in out[0]; k_ref_bbox_swept_dev reads it from there; k_ref_box_final reduces the two families of partial boxes into out[1 .. 6] (corner, extent) and
+// publishes out[0 .. 6] to mapped host memory.
+__global__ void k_ref_cap(int nb, const double* __restrict__ partial, double alpha, double voxelSize, double* __restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    double pSize = 0.0, nOwn = 0.0;
+    for (int b = 0; b < nb; ++b) {
+        pSize += partial[b];
+        nOwn += partial[nb + b];
+    }
+    pSize /= fmax(nOwn, 1.0) * 3;
+    const double spanSize = alpha * pSize / voxelSize; // SpatialHash.hpp:603-618
+    if (spanSize > 1) alpha /= spanSize;
+    out[0] = alpha;
+}
+__global__ __launch_bounds__(BLOCK) void k_ref_bbox_swept_dev(int n, const int* __restrict__ SVI, const double* __restrict__ x, const double* __restrict__ p,
+    const double* __restrict__ alphaPtr, double* __restrict__ partial)
 {
     __shared__ double sm[6][BLOCK / 64];
+    const double alpha = alphaPtr[0];
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
     if (i < n) {
@@ -1587,6 +1605,39 @@ __global__ __launch_bounds__(BLOCK) void k_ref_bbox_swept(int n, const int* __re
         for (int k = 1; k < BLOCK / 64; ++k) r = (threadIdx.x < 3) ? fmin(r, sm[threadIdx.x][k]) : fmax(r, sm[threadIdx.x][k]);
         partial[6 * (size_t)blockIdx.x + threadIdx.x] = r;
     }
+}
+// min / max over nA + nB partial boxes (6 doubles each: lo[3], hi[3]) -> out[1 .. 6]; out[0 .. 6] -> mapped host memory
+__global__ __launch_bounds__(BLOCK) void k_ref_box_final(int nA, const double* __restrict__ partA, int nB, const double* __restrict__ partB, double* __restrict__ out,
+    double* __restrict__ mapped)
+{
+    __shared__ double sm[6][BLOCK / 64];
+    double lo[3] = { 1e300, 1e300, 1e300 }, hi[3] = { -1e300, -1e300, -1e300 };
+    for (int b = threadIdx.x; b < nA + nB; b += BLOCK) {
+        const double* q = b < nA ? partA + 6 * (size_t)b : partB + 6 * (size_t)(b - nA);
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = fmin(lo[c], q[c]);
+            hi[c] = fmax(hi[c], q[3 + c]);
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            lo[c] = fmin(lo[c], __shfl_down(lo[c], off, 64));
+            hi[c] = fmax(hi[c], __shfl_down(hi[c], off, 64));
+        }
+        if ((threadIdx.x & 63) == 0) {
+            sm[c][threadIdx.x >> 6] = lo[c];
+            sm[3 + c][threadIdx.x >> 6] = hi[c];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double r = sm[threadIdx.x][0];
+        for (int k = 1; k < BLOCK / 64; ++k) r = (threadIdx.x < 3) ? fmin(r, sm[threadIdx.x][k]) : fmax(r, sm[threadIdx.x][k]);
+        out[1 + threadIdx.x] = r;
+        mapped[1 + threadIdx.x] = r;
+    }
+    if (threadIdx.x == 6) mapped[0] = out[0];
 }
 // index box of every surface vertex: [min(now, then), max(now, then)] per axis (svMinVAI / svMaxVAI, SpatialHash.hpp:640-660)
 __global__ __launch_bounds__(BLOCK) void k_ref_vbox(int n, const int* __restrict__ SVI, const double* __restrict__ x, const double* __restrict__ p, double alpha,
@@ -3171,40 +3222,26 @@ double HipContact::ccdFullReference(const HipMesh& mesh, const double* x_dev, co
     if (alphaCapped) *alphaCapped = alpha;
     if (!nSVI) return alpha;
     const int* pf = pairFlags(mesh.nV, dbc_dev);
-    // the cap (SpatialHash.hpp:603-618): mean |component| of p over the surface nodes against the cell size
-    const int nbS = nblk(nSVI);
-    bboxPartial_.ensure(6 * (size_t)std::max(nbS, nblk(mesh.nV)));
-    hipLaunchKernelGGL(k_ref_abs_sum, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, hasObstacle ? (const int*)d_obst.p : (const int*)nullptr, p_dev,
-        bboxPartial_.p);
-    std::vector<double> part(6 * (size_t)std::max(nbS, nblk(mesh.nV)));
-    bboxPartial_.download(part.data(), 2 * (size_t)nbS, stream);
-    double pSize = 0.0, nOwn = 0.0;
-    for (int b = 0; b < nbS; ++b) {
-        pSize += part[(size_t)b];
-        nOwn += part[(size_t)nbS + b];
-    }
-    pSize /= std::max(nOwn, 1.0) * 3;
+    // the cap (SpatialHash.hpp:603-618): mean |component| of p over the surface nodes against the cell size; corner and extent (:620-634): all nodes now, the
+    // surface nodes at the capped step -- all on the device, ONE read-back (k_ref_cap, k_ref_bbox_swept_dev, k_ref_box_final)
+    const int nbS = nblk(nSVI), nbV = nblk(mesh.nV);
+    const size_t offAbs = 0, offBoxV = 2 * (size_t)nbS, offBoxS = offBoxV + 6 * (size_t)nbV, offOut = offBoxS + 6 * (size_t)nbS;
+    bboxPartial_.ensure(offOut + 8);
+    double* outDev = bboxPartial_.p + offOut;
     const double voxelSize = mesh.avgEdgeLen / 3.0;
-    const double spanSize = alpha * pSize / voxelSize;
-    if (spanSize > 1) alpha /= spanSize;
+    readbackInit();
+    hipLaunchKernelGGL(k_ref_abs_sum, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, hasObstacle ? (const int*)d_obst.p : (const int*)nullptr, p_dev,
+        bboxPartial_.p + offAbs);
+    hipLaunchKernelGGL(k_ref_cap, dim3(1), dim3(64), 0, stream, nbS, bboxPartial_.p + offAbs, alpha, voxelSize, outDev);
+    hipLaunchKernelGGL(k_bbox_partial, dim3(nbV), dim3(BLOCK), 0, stream, mesh.nV, x_dev, bboxPartial_.p + offBoxV);
+    hipLaunchKernelGGL(k_ref_bbox_swept_dev, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, x_dev, p_dev, (const double*)outDev, bboxPartial_.p + offBoxS);
+    hipLaunchKernelGGL(k_ref_box_final, dim3(1), dim3(BLOCK), 0, stream, nbV, bboxPartial_.p + offBoxV, nbS, bboxPartial_.p + offBoxS, outDev,
+        reinterpret_cast<double*>(readback_.dev));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    const double* hb = reinterpret_cast<const double*>(readback_.p);
+    alpha = hb[0];
     if (alphaCapped) *alphaCapped = alpha;
-    // corner and extent: all nodes now, the surface nodes at alpha (:620-634)
-    double lb[3] = { 1e300, 1e300, 1e300 }, rt[3] = { -1e300, -1e300, -1e300 };
-    const int nbV = nblk(mesh.nV);
-    hipLaunchKernelGGL(k_bbox_partial, dim3(nbV), dim3(BLOCK), 0, stream, mesh.nV, x_dev, bboxPartial_.p);
-    bboxPartial_.download(part.data(), 6 * (size_t)nbV, stream);
-    for (int b = 0; b < nbV; ++b)
-        for (int c = 0; c < 3; ++c) {
-            lb[c] = std::min(lb[c], part[6 * (size_t)b + c]);
-            rt[c] = std::max(rt[c], part[6 * (size_t)b + 3 + c]);
-        }
-    hipLaunchKernelGGL(k_ref_bbox_swept, dim3(nbS), dim3(BLOCK), 0, stream, nSVI, d_SVI.p, x_dev, p_dev, alpha, bboxPartial_.p);
-    bboxPartial_.download(part.data(), 6 * (size_t)nbS, stream);
-    for (int b = 0; b < nbS; ++b)
-        for (int c = 0; c < 3; ++c) {
-            lb[c] = std::min(lb[c], part[6 * (size_t)b + c]);
-            rt[c] = std::max(rt[c], part[6 * (size_t)b + 3 + c]);
-        }
+    double lb[3] = { hb[1], hb[2], hb[3] }, rt[3] = { hb[4], hb[5], hb[6] };
     RefGrid g;
     g.oneDiv = 1.0 / voxelSize;
     {
