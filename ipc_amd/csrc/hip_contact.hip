@@ -2428,6 +2428,9 @@ void HipContact::readbackInit()
     static_assert(sizeof(BuildReadback) <= 16 * sizeof(unsigned long long), "read-back block too small");
 }
 
+#ifndef GRID_H_SCALE
+#define GRID_H_SCALE 1.0 // cell size of the narrow phase's grid in mean edge lengths
+#endif
 int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, const int* dbc_dev, double dHat)
 {
     if (!surfaceSet) throw StateError("contact_build before set_surface");
@@ -2484,7 +2487,7 @@ int HipContact::buildConstraintSet(const HipMesh& mesh, const double* x_dev, con
     Grid g;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 8) throw StateError("constraint-set build: the grid does not settle");
-        g.h = std::max(mesh.avgEdgeLen, 2.0 * infl);
+        g.h = std::max(GRID_H_SCALE * mesh.avgEdgeLen, 2.0 * infl);
         long long nCells;
         for (;;) {
             nCells = 1;
