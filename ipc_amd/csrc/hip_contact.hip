@@ -2041,10 +2041,12 @@ __global__ __launch_bounds__(BLOCK) void k_intersect(int nSF, const int* __restr
                         continue; // outward-rounded boxes apart: the exact test below would say the same
                     const int e = rec.id;
                     const int e0 = SFE[2 * (size_t)e], e1 = SFE[2 * (size_t)e + 1];
-                    // flags and positions requested together, filters without short-circuits (see narrow_ee_queued)
+                    // most records that get here are the ~15 edges around the triangle's own nodes: they go before anything else is fetched; for the rest, flags and
+                    // positions are requested together and the filters evaluated without short-circuits (see narrow_ee_queued)
+                    if ((e0 == t0) | (e0 == t1) | (e0 == t2) | (e1 == t0) | (e1 == t1) | (e1 == t2)) continue;
                     const int fe0 = dbc[e0], fe1 = dbc[e1];
                     double p0[3], p1[3];
-                    bool skip = (e0 == t0) | (e0 == t1) | (e0 == t2) | (e1 == t0) | (e1 == t1) | (e1 == t2);
+                    bool skip = false;
                     for (int q = 0; q < 3; ++q) {
                         p0[q] = x[3 * (size_t)e0 + q];
                         p1[q] = x[3 * (size_t)e1 + q];
