@@ -1011,6 +1011,7 @@ int ipcgpu_assemble_newton(ipcgpu_ctx* c, double dtSq, int projectDBC, double* g
         o.dtSq = keep;
         if (grad) o.d_gradient.download(grad, 3 * (size_t)c->mesh->nV, c->stream);
         else HIP_CHECK(hipStreamSynchronize(c->stream));
+        if (o.selfCollision && o.contact) o.contact->takeHessianError(); // (the stepper leaves the barrier Hessian's "pair outside the pattern" flag to its next synchronisation: here)
         return IPCGPU_OK;
     });
 }
