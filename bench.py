@@ -376,9 +376,9 @@ def main():
                 "kernel": "k_assemble_patch<true> (fused NH gradient + PSD-projected Hessian + mass/DBC diagonal -> symmetric-upper CSR, atomic-free)",
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": pmc_traffic(args.size),
-                "traffic_source": "NOT a live counter: read from profiles/r05_pmc_assembly_traffic*.json (r04_*, r03_* when absent), measured on this kernel with "
+                "traffic_source": "NOT a live counter: read from profiles/r06_pmc_assembly_traffic*.json (r05_*, r04_*, r03_* when absent), measured on this kernel with "
                                   "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, calibrated in-run on a 1 GiB device copy "
-                                  "(tools/pmc_traffic.py, tools/gpu_round5.sh); bytes per launch",
+                                  "(tools/pmc_traffic.py, tools/gpu_pmc_traffic.sh); bytes per launch",
                 "algorithmic_bytes": bytes_asm, "avg_launch_ms": ms_asm,
                 "measured_stream_copy_GBs": stream_gbs,
             },
